@@ -1,0 +1,112 @@
+/*
+ * jpeg_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the JPEG arithmetic that sits behind the reference's
+ * hot path (reference call sites: /root/reference/src/compressor.rs:287-306 ->
+ * libcaesium 0.20.3 `compress_in_memory` -> mozjpeg-sys 2.2.1, pinned in
+ * /root/reference/Cargo.lock:892-913 and :1035-1044).  None of that third-party
+ * source is present under /root/reference, so this file restates the *published*
+ * algorithms (ITU-T T.81 + the libjpeg ISLOW integer pipeline) and is pinned by
+ *   (a) byte-for-byte agreement with libjpeg-turbo 3.1.4.1 (through Pillow), and
+ *   (b) byte-identical entropy round trips of the reference's own fixtures
+ *       samples/j0.JPG and samples/level_1_0/j1.jpg,
+ * see tests/test_oracle_*.py.  Parity with real mozjpeg's trellis quantiser,
+ * deringing and scan-script search is UNPINNED (DESIGN.md "Parity tiers").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * anything in oracle/.
+ */
+#ifndef CSO_JPEG_ORACLE_H
+#define CSO_JPEG_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSO_MAX_COMPS 4
+#define CSO_MAX_SCANS 64
+
+typedef struct {
+    int id, h, v, tq;          /* SOF: component id, sampling factors, quant table id */
+    int comp_w, comp_h;        /* real downsampled size in samples */
+    int real_bw, real_bh;      /* ceil(comp/8): block grid of non-interleaved scans */
+    int bw, bh;                /* MCU-padded block grid (interleaved scans) */
+    int16_t *coef;             /* [bh][bw][64], NATURAL order, quantised */
+} cso_comp;
+
+typedef struct {
+    int ncomp_in_scan;
+    int comp_idx[CSO_MAX_COMPS];
+    int Ss, Se, Ah, Al;
+} cso_scan;
+
+typedef struct {
+    int width, height, ncomp, precision;
+    int progressive;           /* SOF2 */
+    int hmax, vmax, mcus_x, mcus_y;
+    int restart_interval;
+    cso_comp comp[CSO_MAX_COMPS];
+    uint16_t qt[4][64];        /* natural order */
+    int qt_present[4];
+    int nscans;                /* scan script as found in the file */
+    cso_scan scans[CSO_MAX_SCANS];
+    /* marker segments kept for metadata carry-over: concatenated raw segments
+       (FF Mx len.. payload) of APPn/COM in file order */
+    uint8_t *meta; size_t meta_len;
+    int saw_jfif, adobe_transform;
+} cso_image;
+
+typedef struct {
+    int quality;               /* 0..100 (libjpeg scaling) */
+    int progressive;           /* 1: SOF2 + scan script; 0: sequential, one scan */
+    int subsampling;           /* 444, 422, 420; 0 = auto (420 for 3-comp, none for gray) */
+    int qtable_profile;        /* 3 = mozjpeg table #3 (JCP_MAX_COMPRESSION, pinned by j0.JPG);
+                                  0 = Annex K (stock libjpeg) */
+    int marker_style;          /* 1 = mozjpeg (merged DQT / merged DHT per scan), 0 = libjpeg */
+    int scan_script;           /* 0 = stock jpeg_simple_progression; 1 = the 8-scan script found in j0.JPG */
+    int keep_metadata;         /* copy APPn/COM (except the encoder's own JFIF) */
+    int force_baseline;        /* clamp quant entries to 255 */
+} cso_enc_params;
+
+/* ---- decode ---- */
+int  cso_decode(const uint8_t *data, size_t n, cso_image **out);   /* parse + entropy decode */
+void cso_image_free(cso_image *im);
+/* IDCT + upsample; out_color_space = jpeg_color_space (no colour conversion).
+   out: H*W*ncomp interleaved u8. */
+int  cso_decode_pixels(const cso_image *im, uint8_t *out);
+/* per-component decoded plane at component resolution (IDCT + range limit, cropped
+   to comp_w x comp_h).  out: comp_h*comp_w. */
+int  cso_decode_plane(const cso_image *im, int ci, uint8_t *out);
+
+/* ---- encode ---- */
+/* full-resolution interleaved samples (already in the JPEG colour space) -> new
+   coefficient image (edge expansion, downsample, jfdctint, plain quantiser, dummy blocks) */
+int  cso_forward(const uint8_t *pix, int w, int h, int ncomp,
+                 const cso_enc_params *p, const uint16_t *qt_override /* [2][64] natural or NULL */,
+                 cso_image **out);
+/* entropy-code a coefficient image (optimal Huffman tables) */
+int  cso_encode(const cso_image *im, const cso_enc_params *p,
+                const cso_scan *script, int nscans /* NULL/0 = per params */,
+                uint8_t **out, size_t *out_len);
+void cso_free(void *p);
+
+/* what libcaesium's jpeg::compress_in_memory does, plain profile:
+   lossless=0: decode -> pixels -> forward(quality) -> encode
+   lossless=1: decode -> encode (coefficients untouched) */
+int  cso_jpeg_compress(const uint8_t *in, size_t n, const cso_enc_params *p, int lossless,
+                       uint8_t **out, size_t *out_len);
+
+/* ---- pieces exported for stage-level parity tests ---- */
+void cso_quality_tables(int quality, int profile, int force_baseline, uint16_t out[2][64]);
+void cso_fdct_islow(const uint8_t *samples8x8 /* row stride 8 */, int32_t out[64]);
+void cso_idct_islow(const int16_t coef[64], const uint16_t qt[64], uint8_t out[64]);
+int  cso_stock_script(int ncomp, int which, cso_scan *out); /* returns nscans */
+/* optimal Huffman table: freq[257] -> bits[17], huffval[256]; returns #symbols */
+int  cso_gen_optimal_table(const long freq_in[257], uint8_t bits[17], uint8_t huffval[256]);
+const char *cso_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,203 @@
+"""ctypes binding of the CPU ORACLE (oracle/libcsoracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product path (caesium-clt_amd/) never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcsoracle.so")
+
+ZZ = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+               41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63], dtype=np.int64)
+
+
+class Comp(C.Structure):
+    _fields_ = [("id", C.c_int), ("h", C.c_int), ("v", C.c_int), ("tq", C.c_int),
+                ("comp_w", C.c_int), ("comp_h", C.c_int), ("real_bw", C.c_int), ("real_bh", C.c_int),
+                ("bw", C.c_int), ("bh", C.c_int), ("coef", C.POINTER(C.c_int16))]
+
+
+class Scan(C.Structure):
+    _fields_ = [("ncomp_in_scan", C.c_int), ("comp_idx", C.c_int * 4),
+                ("Ss", C.c_int), ("Se", C.c_int), ("Ah", C.c_int), ("Al", C.c_int)]
+
+    def astuple(self):
+        return (tuple(self.comp_idx[i] for i in range(self.ncomp_in_scan)), self.Ss, self.Se, self.Ah, self.Al)
+
+
+class Image(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("ncomp", C.c_int), ("precision", C.c_int),
+                ("progressive", C.c_int), ("hmax", C.c_int), ("vmax", C.c_int), ("mcus_x", C.c_int), ("mcus_y", C.c_int),
+                ("restart_interval", C.c_int), ("comp", Comp * 4), ("qt", (C.c_uint16 * 64) * 4), ("qt_present", C.c_int * 4),
+                ("nscans", C.c_int), ("scans", Scan * 64), ("meta", C.POINTER(C.c_uint8)), ("meta_len", C.c_size_t),
+                ("saw_jfif", C.c_int), ("adobe_transform", C.c_int)]
+
+
+class EncParams(C.Structure):
+    _fields_ = [("quality", C.c_int), ("progressive", C.c_int), ("subsampling", C.c_int), ("qtable_profile", C.c_int),
+                ("marker_style", C.c_int), ("scan_script", C.c_int), ("keep_metadata", C.c_int), ("force_baseline", C.c_int)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "jpeg_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.cso_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(Image))]
+        L.cso_image_free.argtypes = [C.POINTER(Image)]
+        L.cso_decode_pixels.argtypes = [C.POINTER(Image), C.c_void_p]
+        L.cso_decode_plane.argtypes = [C.POINTER(Image), C.c_int, C.c_void_p]
+        L.cso_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(EncParams), C.c_void_p, C.POINTER(C.POINTER(Image))]
+        L.cso_encode.argtypes = [C.POINTER(Image), C.POINTER(EncParams), C.POINTER(Scan), C.c_int,
+                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_jpeg_compress.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(EncParams), C.c_int,
+                                        C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_free.argtypes = [C.c_void_p]
+        L.cso_quality_tables.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.cso_fdct_islow.argtypes = [C.c_void_p, C.c_void_p]
+        L.cso_idct_islow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cso_stock_script.argtypes = [C.c_int, C.c_int, C.POINTER(Scan)]
+        L.cso_gen_optimal_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cso_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError(lib().cso_last_error().decode())
+
+
+def params(quality=80, progressive=1, subsampling=0, qtable_profile=3, marker_style=1, scan_script=0,
+           keep_metadata=0, force_baseline=0):
+    return EncParams(quality, progressive, subsampling, qtable_profile, marker_style, scan_script, keep_metadata, force_baseline)
+
+
+class CoefImage:
+    """Owns a cso_image*: quantised coefficients per component (natural order)."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().cso_image_free(self.ptr)
+            self.ptr = None
+
+    @property
+    def im(self):
+        return self.ptr.contents
+
+    def coefs(self, ci):
+        """[bh][bw][64] int16 natural order (copy)."""
+        k = self.im.comp[ci]
+        n = k.bw * k.bh * 64
+        return np.ctypeslib.as_array(k.coef, shape=(n,)).reshape(k.bh, k.bw, 64).copy()
+
+    def coefs_zigzag(self, ci):
+        return self.coefs(ci)[:, :, ZZ]
+
+    def qtable(self, tq):
+        return np.array(self.im.qt[tq], dtype=np.uint16)
+
+    def scans(self):
+        return [self.im.scans[i].astuple() for i in range(self.im.nscans)]
+
+    def pixels(self):
+        im = self.im
+        out = np.empty((im.height, im.width, im.ncomp), dtype=np.uint8)
+        _check(lib().cso_decode_pixels(self.ptr, out.ctypes.data))
+        return out
+
+    def plane(self, ci):
+        k = self.im.comp[ci]
+        out = np.empty((k.comp_h, k.comp_w), dtype=np.uint8)
+        _check(lib().cso_decode_plane(self.ptr, ci, out.ctypes.data))
+        return out
+
+    def encode(self, p, script=None):
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        if script is None:
+            _check(lib().cso_encode(self.ptr, C.byref(p), None, 0, C.byref(out), C.byref(n)))
+        else:
+            arr = (Scan * len(script))()
+            for i, (comps, ss, se, ah, al) in enumerate(script):
+                arr[i].ncomp_in_scan = len(comps)
+                for j, c in enumerate(comps):
+                    arr[i].comp_idx[j] = c
+                arr[i].Ss, arr[i].Se, arr[i].Ah, arr[i].Al = ss, se, ah, al
+            _check(lib().cso_encode(self.ptr, C.byref(p), arr, len(script), C.byref(out), C.byref(n)))
+        data = C.string_at(out, n.value)
+        lib().cso_free(out)
+        return data
+
+
+def decode(data):
+    ptr = C.POINTER(Image)()
+    _check(lib().cso_decode(data, len(data), C.byref(ptr)))
+    return CoefImage(ptr)
+
+
+def forward(pix, p, qtables=None):
+    """pix: HxWxC u8 in the JPEG colour space -> CoefImage (new quantised coefficients)."""
+    pix = np.ascontiguousarray(pix, dtype=np.uint8)
+    if pix.ndim == 2:
+        pix = pix[:, :, None]
+    h, w, c = pix.shape
+    qt = None
+    if qtables is not None:
+        qt = np.ascontiguousarray(qtables, dtype=np.uint16).reshape(2, 64)
+    ptr = C.POINTER(Image)()
+    _check(lib().cso_forward(pix.ctypes.data, w, h, c, C.byref(p), qt.ctypes.data if qt is not None else None, C.byref(ptr)))
+    return CoefImage(ptr)
+
+
+def jpeg_compress(data, p, lossless=False):
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    _check(lib().cso_jpeg_compress(data, len(data), C.byref(p), 1 if lossless else 0, C.byref(out), C.byref(n)))
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res
+
+
+def quality_tables(q, profile=3, force_baseline=0):
+    out = np.zeros((2, 64), dtype=np.uint16)
+    lib().cso_quality_tables(q, profile, force_baseline, out.ctypes.data)
+    return out
+
+
+def stock_script(ncomp, which=0):
+    arr = (Scan * 64)()
+    n = lib().cso_stock_script(ncomp, which, arr)
+    return [arr[i].astuple() for i in range(n)]
+
+
+def gen_optimal_table(freq):
+    f = np.zeros(257, dtype=np.int64)
+    f[:len(freq)] = freq
+    bits = np.zeros(17, dtype=np.uint8)
+    hv = np.zeros(256, dtype=np.uint8)
+    n = lib().cso_gen_optimal_table(f.ctypes.data, bits.ctypes.data, hv.ctypes.data)
+    return bits, hv[:n]
