@@ -1,0 +1,208 @@
+"""ctypes mirror of include/caesium_hip.h (same names, same argument meaning)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NPHASES = 8
+NKERNELS = 24
+PHASE_NAMES = ["decode", "pixel", "masks_flags_runs", "stats_tables", "sizes_scan", "pack", "stuff_assemble", "reserved"]
+
+
+class CCSParameters(C.Structure):
+    _fields_ = [("keep_metadata", C.c_bool), ("jpeg_quality", C.c_uint32), ("jpeg_chroma_subsampling", C.c_uint32),
+                ("jpeg_progressive", C.c_bool), ("jpeg_optimize", C.c_bool), ("jpeg_preserve_icc", C.c_bool),
+                ("png_quality", C.c_uint32), ("png_optimization_level", C.c_uint32), ("png_force_zopfli", C.c_bool),
+                ("png_optimize", C.c_bool), ("gif_quality", C.c_uint32), ("webp_quality", C.c_uint32), ("webp_lossless", C.c_bool),
+                ("tiff_compression", C.c_uint32), ("tiff_deflate_level", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class CCSResult(C.Structure):
+    _fields_ = [("success", C.c_bool), ("code", C.c_uint32), ("error_message", C.c_char_p)]
+
+
+class CByteArray(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("length", C.c_size_t)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("phase_ms", C.c_float * NPHASES), ("kernel_ms", C.c_float * NKERNELS), ("in_bytes", C.c_uint64), ("out_bytes", C.c_uint64),
+                ("pixels", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32)]
+
+
+class CaesiumError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libcaesium_hip.so")
+
+
+EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory",
+           "cs_batch_compress", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
+           "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_geometry", "csh_batch_read_coefs"]
+
+
+def _declare(L):
+    P = C.POINTER
+    L.cs_default_parameters.argtypes = [P(CCSParameters)]
+    L.cs_default_parameters.restype = None
+    L.cs_compress_in_memory.argtypes = [C.c_char_p, C.c_size_t, P(CCSParameters), P(CByteArray)]
+    L.cs_compress_in_memory.restype = CCSResult
+    L.cs_compress_to_size_in_memory.argtypes = [C.c_char_p, C.c_size_t, P(CCSParameters), C.c_size_t, C.c_bool, P(CByteArray)]
+    L.cs_compress_to_size_in_memory.restype = CCSResult
+    L.cs_convert_in_memory.argtypes = [C.c_char_p, C.c_size_t, P(CCSParameters), C.c_uint32, P(CByteArray)]
+    L.cs_convert_in_memory.restype = CCSResult
+    L.cs_batch_compress.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(CByteArray), P(CCSResult)]
+    L.cs_free_bytes.argtypes = [P(CByteArray)]
+    L.cs_free_bytes.restype = None
+    L.cs_free_result.argtypes = [P(CCSResult)]
+    L.cs_free_result.restype = None
+    L.csh_last_error.restype = C.c_char_p
+    L.csh_kernel_name.argtypes = [C.c_int]
+    L.csh_kernel_name.restype = C.c_char_p
+    L.csh_batch_create.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(C.c_void_p)]
+    L.csh_batch_run.argtypes = [C.c_void_p, P(Timing)]
+    L.csh_batch_fetch.argtypes = [C.c_void_p, P(CByteArray), P(CCSResult)]
+    L.csh_batch_destroy.argtypes = [C.c_void_p]
+    L.csh_batch_destroy.restype = None
+    L.csh_batch_geometry.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
+    L.csh_batch_read_coefs.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    return L
+
+
+def default_parameters(lib=None, **kw):
+    p = CCSParameters()
+    p.jpeg_quality = p.png_quality = p.webp_quality = p.gif_quality = 80
+    p.jpeg_progressive = True
+    p.jpeg_preserve_icc = True
+    p.png_optimization_level = 3
+    p.tiff_deflate_level = 6
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Batch:
+    """csh_batch: a group of input files resident in HBM."""
+
+    def __init__(self, api, blobs, params, device=0):
+        self.api = api
+        L = api.L
+        self.n = len(blobs)
+        self._keep = [C.create_string_buffer(b, len(b)) for b in blobs]
+        self._in = (CByteArray * self.n)()
+        for i, buf in enumerate(self._keep):
+            self._in[i].data = C.cast(buf, C.POINTER(C.c_uint8))
+            self._in[i].length = len(blobs[i])
+        self.h = C.c_void_p()
+        rc = L.csh_batch_create(self._in, self.n, C.byref(params), device, C.byref(self.h))
+        if rc:
+            raise CaesiumError(rc, L.csh_last_error().decode())
+
+    def run(self):
+        t = Timing()
+        rc = self.api.L.csh_batch_run(self.h, C.byref(t))
+        if rc:
+            raise CaesiumError(rc, self.api.L.csh_last_error().decode())
+        return t
+
+    def fetch(self):
+        """-> list of bytes (or CaesiumError instances for failed items), input order."""
+        L = self.api.L
+        outs = (CByteArray * self.n)()
+        res = (CCSResult * self.n)()
+        rc = L.csh_batch_fetch(self.h, outs, res)
+        if rc < 0:
+            raise CaesiumError(rc, L.csh_last_error().decode())
+        result = []
+        for i in range(self.n):
+            if res[i].success:
+                result.append(C.string_at(outs[i].data, outs[i].length))
+            else:
+                result.append(CaesiumError(res[i].code, (res[i].error_message or b"").decode()))
+            L.cs_free_bytes(C.byref(outs[i]))
+            L.cs_free_result(C.byref(res[i]))
+        return result
+
+    def coefs(self, image, comp, which):
+        """[bh][bw][64] int16, zig-zag order.  which: 0 decoded, 1 re-quantised."""
+        import numpy as np
+        L = self.api.L
+        bw, bh, rbw, rbh = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if L.csh_batch_geometry(self.h, image, comp, which, C.byref(bw), C.byref(bh), C.byref(rbw), C.byref(rbh)):
+            raise CaesiumError(-1, L.csh_last_error().decode())
+        a = np.empty((bh.value, bw.value, 64), dtype=np.int16)
+        if L.csh_batch_read_coefs(self.h, image, comp, which, a.ctypes.data):
+            raise CaesiumError(-1, L.csh_last_error().decode())
+        return a, (rbw.value, rbh.value)
+
+    def close(self):
+        if self.h:
+            self.api.L.csh_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CaesiumHip:
+    def __init__(self, path=None):
+        path = path or library_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        self.path = path
+        self.L = _declare(C.CDLL(path))
+
+    def kernel_names(self):
+        return [self.L.csh_kernel_name(i).decode() for i in range(NKERNELS)]
+
+    def device_count(self):
+        return self.L.csh_device_count()
+
+    def _call(self, fn, *args):
+        out = CByteArray()
+        r = fn(*args, C.byref(out))
+        try:
+            if not r.success:
+                raise CaesiumError(r.code, (r.error_message or b"").decode())
+            return C.string_at(out.data, out.length)
+        finally:
+            self.L.cs_free_bytes(C.byref(out))
+            self.L.cs_free_result(C.byref(r))
+
+    def compress_in_memory(self, data, params):
+        return self._call(self.L.cs_compress_in_memory, data, len(data), C.byref(params))
+
+    def compress_to_size_in_memory(self, data, params, max_output_size, return_smallest=True):
+        return self._call(self.L.cs_compress_to_size_in_memory, data, len(data), C.byref(params), max_output_size, return_smallest)
+
+    def convert_in_memory(self, data, params, fmt):
+        return self._call(self.L.cs_convert_in_memory, data, len(data), C.byref(params), fmt)
+
+    def batch(self, blobs, params, device=0):
+        return Batch(self, blobs, params, device)
+
+    def batch_compress(self, blobs, params, device=0):
+        b = self.batch(blobs, params, device)
+        try:
+            b.run()
+            return b.fetch()
+        finally:
+            b.close()
+
+
+_api = None
+
+
+def load():
+    global _api
+    if _api is None:
+        _api = CaesiumHip()
+    return _api

@@ -1,0 +1,98 @@
+// gpu_rt.h -- the one place that knows whether this translation unit is the product build
+// (hipcc, gfx950) or the CSH_EMUL logic-test build.
+//
+// Product build: plain HIP runtime.  Kernels are launched with CSH_LAUNCH on the batch's stream.
+//
+// CSH_EMUL build (g++, tests only -- see tests/emul/README.md): the SAME kernel sources are compiled
+// as ordinary C++ and a launch becomes a sequential loop over the grid.  It exists so the bit-level
+// kernel logic can be regression-tested in the GPU-less authoring container; it is never linked
+// into libcaesium_hip.so and the product library has no CPU fallback.  Kernels are written so that
+// this is legal: no thread reads what another thread of the same launch wrote (only atomics cross
+// threads), and no kernel needs a barrier.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#ifndef CSH_EMUL
+#include <hip/hip_runtime.h>
+#define CSH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+#define CSH_UNROLL _Pragma("unroll")
+#else
+// ------------------------------------------------------------------ emulation shims
+#include <algorithm>
+#include <chrono>
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+#define CSH_UNROLL
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+template <class F, class... A>
+static inline void csh_emul_launch(F kern, dim3 grid, dim3 block, A... args) {
+    gridDim = grid; blockDim = block;
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+        blockIdx = dim3(bx, by, bz);
+        for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned tx = 0; tx < block.x; tx++) {
+            threadIdx = dim3(tx, ty, tz);
+            kern(args...);
+        }
+    }
+}
+#define CSH_LAUNCH(kern, grid, block, stream, ...) csh_emul_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
+typedef int hipError_t;
+typedef int hipStream_t;
+struct csh_emul_event { std::chrono::steady_clock::time_point t; };
+typedef csh_emul_event *hipEvent_t;
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+static inline const char *hipGetErrorString(hipError_t) { return "emul"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 1; }
+static inline hipError_t hipFree(void *p) { free(p); return 0; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? 0 : 1; }
+static inline hipError_t hipHostFree(void *p) { free(p); return 0; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new csh_emul_event; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return 0;
+}
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+static inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __mul24(int a, int b) { return (int)((int64_t)((a << 8) >> 8) * ((b << 8) >> 8)); }
+using std::max;
+using std::min;
+#endif
+
+#define CSH_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) { csh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } \
+    } while (0)
+
+void csh_set_error(const char *fmt, ...);

@@ -1,0 +1,169 @@
+// k_assemble.hip -- phase 6: turn the packed scan bit strings into finished JPEG files in HBM:
+// 0xFF byte stuffing (T.81 F.1.2.3), DHT/SOS headers per scan (mozjpeg's merged-DHT marker style, as
+// /root/reference/samples/j0.JPG shows), EOI.  Replaces mozjpeg's jcmarker.c + the byte-level part of
+// jchuff/jcphuff for libcaesium's JPEG path (reference call site /root/reference/src/compressor.rs:305).
+// Every offset is computed on the device (exclusive scans), so the whole batch needs no host round trip
+// between entropy coding and the final D2H copy.
+#include "kernels.h"
+#ifndef CSH_EMUL
+#include <rocprim/rocprim.hpp>
+#endif
+
+namespace csh {
+
+// ------------------------------------------------------------------------------------------------
+#ifdef CSH_EMUL
+size_t exclusive_scan_tmp_bytes(uint64_t) { return 16; }
+void launch_exclusive_scan(hipStream_t, const uint32_t *in, uint64_t *out, uint64_t n, void *, size_t) {
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < n; i++) { out[i] = acc; acc += in[i]; }
+    out[n] = acc;
+}
+#else
+struct WidenU32 { __device__ uint64_t operator()(uint32_t v) const { return uint64_t(v); } };
+// in[] is allocated with one extra (zero) element so that an exclusive scan over n+1 inputs yields the total
+size_t exclusive_scan_tmp_bytes(uint64_t n) {
+    size_t bytes = 0;
+    auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, WidenU32());
+    (void)rocprim::exclusive_scan(nullptr, bytes, it, (uint64_t *)nullptr, uint64_t(0), size_t(n + 1), rocprim::plus<uint64_t>());
+    return bytes + 256;
+}
+void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, size_t tmp_bytes) {
+    auto it = rocprim::make_transform_iterator(in, WidenU32());
+    (void)rocprim::exclusive_scan(tmp, tmp_bytes, it, out, uint64_t(0), size_t(n + 1), rocprim::plus<uint64_t>(), st);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_scan_sizes(AsmCtx a) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.nwork) return;
+    ScanWork &w = a.work[j];
+    uint64_t bits = a.unit_off[w.unit_base + w.nunits] - a.unit_off[w.unit_base];
+    uint64_t bytes = (bits + 7) >> 3;
+    w.raw_bytes = uint32_t(bytes);
+    a.scan_pad_bytes[j] = uint32_t(((bytes + 63) & ~uint64_t(63)) + 64);  // +64: the packer may touch one word past the end
+}
+__global__ void k_scan_place(AsmCtx a) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.nwork) return;
+    a.work[j].raw_off = a.scan_raw_off[j];
+    if (j == a.nwork - 1 && a.scan_raw_off[a.nwork] > a.raw_chunks * 64) *a.overflow = 1;
+}
+
+__device__ __forceinline__ static int raw_byte(const uint32_t *raw, uint64_t byte_index) {
+    return int((raw[byte_index >> 2] >> (24 - 8 * int(byte_index & 3))) & 255u);
+}
+// which scan owns raw chunk c?  scan_raw_off is sorted; scans are 64-byte aligned
+__device__ static int owner_scan(const AsmCtx &a, uint64_t c) {
+    uint64_t byte = c * 64;
+    int lo = 0, hi = a.nwork;  // invariant: scan_raw_off[lo] <= byte < scan_raw_off[hi]
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (a.scan_raw_off[mid] <= byte) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) k_ff_count(AsmCtx a) {
+    uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= a.raw_chunks) return;
+    uint32_t n = 0;
+    uint64_t used = a.scan_raw_off[a.nwork];
+    if (c * 64 < used && used <= a.raw_chunks * 64) {
+        int j = owner_scan(a, c);
+        uint64_t rel = c * 64 - a.scan_raw_off[j];
+        uint64_t nbytes = a.work[j].raw_bytes;
+        for (int i = 0; i < 64; i++)
+            if (rel + i < nbytes && raw_byte(a.raw, c * 64 + i) == 0xFF) n++;
+    }
+    a.chunk_ff[c] = n;
+}
+
+// per image: where every scan lands in the file, and the file size
+__global__ void k_layout(AsmCtx a) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nimg) return;
+    const ImgDesc &im = a.imgs[i];
+    uint64_t pos = a.hdr_off[i + 1] - a.hdr_off[i];
+    for (int s = 0; s < im.nscans_out; s++) {
+        ScanWork &w = a.work[im.first_work + s];
+        const EncScan &sc = a.script[w.scan];
+        uint32_t hdr = 0;
+        if (sc.ntables) { hdr += 4; for (int t = 0; t < sc.ntables; t++) hdr += 17 + a.tables[w.table_base + t].nsym; }
+        hdr += 2 + 2 + 1 + 2 * sc.ncomp + 3;
+        uint64_t c0 = w.raw_off >> 6, c1 = (w.raw_off + ((uint64_t(w.raw_bytes) + 63) & ~uint64_t(63))) >> 6;
+        uint64_t ff = 0;
+        if (c1 <= a.raw_chunks) ff = a.chunk_ffoff[c1] - a.chunk_ffoff[c0];
+        w.out_off = uint32_t(pos);
+        w.hdr_bytes = hdr;
+        pos += hdr + w.raw_bytes + ff;
+    }
+    pos += 2;  // EOI
+    a.img_size[i] = uint32_t(pos);
+    a.img_size_pad[i] = uint32_t((pos + 15) & ~uint64_t(15));
+}
+
+// frame header copy + EOI (one lane per image) and DHT/SOS (one lane per scan)
+__global__ void k_emit_headers(AsmCtx a) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (*a.overflow) return;
+    if (a.img_off[a.nimg] > a.out_cap) { if (t == 0) *a.overflow = 2; return; }
+    if (t < a.nimg) {
+        uint8_t *o = a.out + a.img_off[t];
+        const uint8_t *h = a.hdr_pool + a.hdr_off[t];
+        uint32_t n = a.hdr_off[t + 1] - a.hdr_off[t];
+        for (uint32_t k = 0; k < n; k++) o[k] = h[k];
+        o[a.img_size[t] - 2] = 0xFF; o[a.img_size[t] - 1] = 0xD9;
+        return;
+    }
+    int j = t - a.nimg;
+    if (j >= a.nwork) return;
+    const ScanWork &w = a.work[j];
+    const EncScan &sc = a.script[w.scan];
+    const ImgDesc &im = a.imgs[w.image];
+    uint8_t *o = a.out + a.img_off[w.image] + w.out_off;
+    if (sc.ntables) {
+        int len = 2;
+        for (int k = 0; k < sc.ntables; k++) len += 17 + a.tables[w.table_base + k].nsym;
+        *o++ = 0xFF; *o++ = 0xC4; *o++ = uint8_t(len >> 8); *o++ = uint8_t(len);
+        for (int k = 0; k < sc.ntables; k++) {
+            const DevEncTable &T = a.tables[w.table_base + k];
+            *o++ = uint8_t(sc.dht_id[k]);
+            for (int l = 1; l <= 16; l++) *o++ = T.bits[l];
+            for (int v = 0; v < T.nsym; v++) *o++ = T.vals[v];
+        }
+    }
+    int len = 6 + 2 * sc.ncomp;
+    *o++ = 0xFF; *o++ = 0xDA; *o++ = uint8_t(len >> 8); *o++ = uint8_t(len); *o++ = uint8_t(sc.ncomp);
+    for (int k = 0; k < sc.ncomp; k++) { *o++ = uint8_t(im.comp_id[sc.comp[k]]); *o++ = uint8_t(sc.sos_tdta[k]); }
+    *o++ = uint8_t(sc.Ss); *o++ = uint8_t(sc.Se); *o++ = uint8_t((sc.Ah << 4) | sc.Al);
+}
+
+// stuffed copy: one lane per 64-byte raw chunk
+__global__ void __launch_bounds__(256) k_emit_data(AsmCtx a) {
+    uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= a.raw_chunks || *a.overflow) return;
+    uint64_t used = a.scan_raw_off[a.nwork];
+    if (c * 64 >= used) return;
+    int j = owner_scan(a, c);
+    const ScanWork &w = a.work[j];
+    uint64_t rel = c * 64 - w.raw_off;
+    if (rel >= w.raw_bytes) return;
+    uint64_t c0 = w.raw_off >> 6;
+    uint8_t *o = a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes + rel + (a.chunk_ffoff[c] - a.chunk_ffoff[c0]);
+    for (int i = 0; i < 64 && rel + i < w.raw_bytes; i++) {
+        int b = raw_byte(a.raw, c * 64 + i);
+        *o++ = uint8_t(b);
+        if (b == 0xFF) *o++ = 0;
+    }
+}
+
+void launch_scan_sizes(hipStream_t st, const AsmCtx &a) { if (a.nwork) CSH_LAUNCH(k_scan_sizes, dim3((a.nwork + 255) / 256), dim3(256), st, a); }
+void launch_scan_place(hipStream_t st, const AsmCtx &a) { if (a.nwork) CSH_LAUNCH(k_scan_place, dim3((a.nwork + 255) / 256), dim3(256), st, a); }
+void launch_ff_count(hipStream_t st, const AsmCtx &a) { if (a.raw_chunks) CSH_LAUNCH(k_ff_count, dim3(unsigned((a.raw_chunks + 255) / 256)), dim3(256), st, a); }
+void launch_layout(hipStream_t st, const AsmCtx &a) { if (a.nimg) CSH_LAUNCH(k_layout, dim3((a.nimg + 63) / 64), dim3(64), st, a); }
+void launch_emit(hipStream_t st, const AsmCtx &a) {
+    int n = a.nimg + a.nwork;
+    if (n) CSH_LAUNCH(k_emit_headers, dim3((n + 63) / 64), dim3(64), st, a);
+    if (a.raw_chunks) CSH_LAUNCH(k_emit_data, dim3(unsigned((a.raw_chunks + 255) / 256)), dim3(256), st, a);
+}
+
+}  // namespace csh

@@ -1,0 +1,390 @@
+// k_entropy.hip -- phases 2-5: progressive Huffman entropy ENCODE with optimal tables, on the device.
+//
+// Replaces mozjpeg's jcphuff.c (progressive scans, EOBRUN, correction bits) + jchuff.c
+// jpeg_gen_optimal_table for libcaesium's JPEG path (reference call site
+// /root/reference/src/compressor.rs:305).
+//
+// Formulation (DESIGN.md "Entropy encode"): one lane per block ("unit"), no bit-serial loop over the
+// 63 AC positions.  Per block three 64-bit significance masks (|c|>=1,2,4; bit = zig-zag index) turn the
+// coder's state machine into bit algebra:
+//   first pass  (Ah=0)     : coded positions NZ = M[Al] & band;  zero run = gap between set bits
+//   refinement  (Ah=Al+1)  : history H = M[Al+1] & band, newly significant N = M[Al] & ~M[Al+1] & band;
+//                            zero run = gap minus popcount(H in the gap); correction bits = bits of H
+//   block ends with EOB    : bit Se of NZ (resp. N) is clear
+// EOB runs span blocks; they are resolved from two per-scan bit vectors (has-symbol, ends-with-EOB):
+// the first block of every (sub-)run owns the EOBRUN symbol, so every block's output is one contiguous
+// bit string: [its symbols][EOBRUN symbol if it starts a (sub-)run][its trailing correction bits].
+// Passes: flags -> runs -> stats -> optimal tables -> sizes -> exclusive scan -> pack.
+#include "kernels.h"
+
+namespace csh {
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_masks(const int16_t *__restrict__ coef, uint64_t *__restrict__ masks, uint32_t ntiles) {
+    uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int16_t *p = coef + size_t(tile) * CSH_TILE_I16 + lane;
+    uint64_t m0 = 0, m1 = 0, m2 = 0;
+    CSH_UNROLL
+    for (int k = 0; k < 64; k++) {
+        int v = p[k << 6];
+        unsigned a = unsigned(v < 0 ? -v : v);
+        m0 |= uint64_t(a >= 1) << k;
+        m1 |= uint64_t(a >= 2) << k;
+        m2 |= uint64_t(a >= 4) << k;
+    }
+    uint64_t *o = masks + size_t(tile) * 192 + lane;
+    o[0] = m0; o[64] = m1; o[128] = m2;
+}
+void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t ntiles) {
+    if (ntiles) CSH_LAUNCH(k_masks, dim3((ntiles + 3) / 4), dim3(256), st, coef, masks, ntiles);
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ static uint64_t band_mask(int Ss, int Se) { return (~0ull >> (63 - Se)) & (~0ull << Ss); }
+__device__ __forceinline__ static int msb64(uint64_t v) { return 63 - __clzll(v); }
+__device__ __forceinline__ static int bitlen32(unsigned v) { return 32 - __clz(v); }
+
+// unit -> padded block index for a non-interleaved scan of component geometry g
+__device__ __forceinline__ static int unit_block(const CompGeom &g, uint32_t u) {
+    int by = int(u) / g.real_bw, bx = int(u) - by * g.real_bw;
+    return by * g.bw + bx;
+}
+__device__ __forceinline__ static uint64_t load_mask(const uint64_t *masks, const CompGeom &g, int b, int level) {
+    return masks[(size_t(g.tile_base) + size_t(b >> 6)) * 192 + size_t(level) * 64 + size_t(b & 63)];
+}
+__device__ __forceinline__ static bool get_bit(const uint64_t *w, uint32_t i) { return (w[i >> 6] >> (i & 63)) & 1; }
+
+struct AcMasks { uint64_t NZ, H, N; };  // first pass uses NZ; refinement uses H and N
+__device__ __forceinline__ static AcMasks ac_masks(const uint64_t *masks, const CompGeom &g, int b, const EncScan &sc) {
+    uint64_t band = band_mask(sc.Ss, sc.Se);
+    AcMasks m;
+    uint64_t lo = load_mask(masks, g, b, sc.Al);
+    if (sc.Ah == 0) { m.NZ = lo & band; m.H = 0; m.N = 0; }
+    else { uint64_t hi = load_mask(masks, g, b, sc.Al + 1); m.H = hi & band; m.N = lo & ~hi & band; m.NZ = 0; }
+    return m;
+}
+
+// ---- pass A: per-block flags of every AC scan
+__global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
+    const ScanWork w = c.work[blockIdx.y];
+    const EncScan sc = c.script[w.scan];
+    if (sc.Ss == 0) return;
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= w.nunits) return;
+    const CompGeom &g = c.imgs[w.image].out[sc.comp[0]];
+    AcMasks m = ac_masks(c.masks, g, unit_block(g, u), sc);
+    uint64_t S = sc.Ah == 0 ? m.NZ : m.N;
+    bool has_sym = S != 0;
+    bool ends_eob = !((S >> sc.Se) & 1);
+    int tail = 0;
+    if (sc.Ah) tail = S ? __popcll(m.H & ~((2ull << msb64(S)) - 1)) : __popcll(m.H);
+    if (has_sym) atomicOr(reinterpret_cast<unsigned long long *>(c.sym_bits + w.word_base + (u >> 6)), 1ull << (u & 63));
+    if (ends_eob) atomicOr(reinterpret_cast<unsigned long long *>(c.eob_bits + w.word_base + (u >> 6)), 1ull << (u & 63));
+    c.tail[w.unit_base + u] = uint8_t(tail);
+}
+
+// ---- pass B: EOB run structure -> EOBRUN value owned by the first block of each (sub-)run
+__global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
+    const ScanWork w = c.work[blockIdx.y];
+    const EncScan sc = c.script[w.scan];
+    if (sc.Ss == 0) return;
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= w.nunits) return;
+    const uint64_t *sym = c.sym_bits + w.word_base, *eob = c.eob_bits + w.word_base;
+    if (!get_bit(eob, u)) return;
+    bool start = get_bit(sym, u) || u == 0 || !get_bit(eob, u - 1);
+    if (!start) return;
+    // run = [u .. t], t = last block before the next block that carries a symbol
+    uint32_t t = w.nunits - 1;
+    {
+        uint32_t i = u + 1;
+        uint32_t nwords = (w.nunits + 63) >> 6;
+        while (i < w.nunits) {
+            uint32_t wi = i >> 6;
+            uint64_t bits = sym[wi] & (~0ull << (i & 63));
+            if (bits) { uint32_t p = (wi << 6) + uint32_t(__ffsll((unsigned long long)bits) - 1); if (p < w.nunits) t = p - 1; break; }
+            i = (wi + 1) << 6;
+            if (wi + 1 >= nwords) break;
+        }
+    }
+    uint16_t *er = c.eobrun + w.unit_base;
+    if (sc.Ah == 0) {
+        uint32_t L = t - u + 1, pos = u;
+        while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); pos += l; L -= l; }
+    } else {
+        // libjpeg also flushes when more than MAX_CORR_BITS-DCTSIZE2+1 = 937 correction bits are pending
+        const uint8_t *tl = c.tail + w.unit_base;
+        uint32_t cnt = 0, be = 0, s0 = u;
+        for (uint32_t j = u; j <= t; j++) {
+            cnt++; be += tl[j];
+            if (cnt == 0x7FFF || be > 937) { er[s0] = uint16_t(cnt); cnt = 0; be = 0; s0 = j + 1; }
+        }
+        if (cnt) er[s0] = uint16_t(cnt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the walker: visits exactly what the block emits, in stream order, and hands it to a sink
+//   sink.sym(t, s)    Huffman symbol s of table t (index inside the scan's table group)
+//   sink.raw(v, n)    n raw bits (n <= 16)
+struct StatsSink {
+    DevEncTable *tab;
+    static constexpr bool kValues = false;
+    __device__ __forceinline__ void sym(int t, int s) { atomicAdd(&tab[t].freq[s], 1u); }
+    __device__ __forceinline__ void syms(int t, int s, int n) { if (n) atomicAdd(&tab[t].freq[s], unsigned(n)); }
+    __device__ __forceinline__ void raw(unsigned, int) {}
+    __device__ __forceinline__ void rawcount(int) {}
+};
+struct SizeSink {
+    const DevEncTable *tab;
+    uint32_t bits;
+    static constexpr bool kValues = false;
+    __device__ __forceinline__ void sym(int t, int s) { bits += tab[t].size[s]; }
+    __device__ __forceinline__ void syms(int t, int s, int n) { bits += unsigned(n) * tab[t].size[s]; }
+    __device__ __forceinline__ void raw(unsigned, int n) { bits += n; }
+    __device__ __forceinline__ void rawcount(int n) { bits += n; }
+};
+struct PackSink {
+    const DevEncTable *tab;
+    uint32_t *raw_words;
+    uint64_t pos;  // absolute bit position in the raw pool
+    static constexpr bool kValues = true;
+    __device__ __forceinline__ void put(unsigned v, int n) {
+        if (n == 0) return;
+        v &= (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+        uint64_t w = pos >> 5;
+        int o = int(pos & 31);
+        uint64_t v64 = uint64_t(v) << (64 - o - n);
+        uint32_t hi = uint32_t(v64 >> 32), lo = uint32_t(v64);
+        if (hi) atomicOr(raw_words + w, hi);
+        if (lo) atomicOr(raw_words + w + 1, lo);
+        pos += n;
+    }
+    __device__ __forceinline__ void sym(int t, int s) { put(tab[t].code[s], tab[t].size[s]); }
+    __device__ __forceinline__ void syms(int t, int s, int n) { for (int i = 0; i < n; i++) sym(t, s); }
+    __device__ __forceinline__ void raw(unsigned v, int n) { put(v, n); }
+    __device__ __forceinline__ void rawcount(int) {}
+};
+
+template <class Sink>
+__device__ __forceinline__ static void emit_eobrun(Sink &sink, unsigned run) {
+    if (!run) return;
+    int nb = bitlen32(run) - 1;
+    sink.sym(0, nb << 4);
+    if (nb) sink.raw(run, nb);
+}
+
+template <class Sink>
+__device__ static void walk_ac_first(Sink &sink, const int16_t *blk, uint64_t NZ, const EncScan &sc, unsigned run) {
+    int prev = sc.Ss - 1;
+    while (NZ) {
+        int k = __ffsll((unsigned long long)NZ) - 1;
+        NZ &= NZ - 1;
+        int r = k - prev - 1;
+        prev = k;
+        sink.syms(0, 0xF0, r >> 4);
+        int v = blk[k << 6];
+        unsigned a = unsigned(v < 0 ? -v : v) >> sc.Al;
+        int nb = bitlen32(a);
+        sink.sym(0, ((r & 15) << 4) | nb);
+        sink.raw(v < 0 ? ~a : a, nb);
+    }
+    emit_eobrun(sink, run);
+}
+
+template <class Sink>
+__device__ static void walk_ac_refine(Sink &sink, const int16_t *blk, uint64_t H, uint64_t N, const EncScan &sc, unsigned run) {
+    if (!Sink::kValues) {
+        // symbols and bit counts only: zero run = gap - popcount(history in the gap)
+        int prev = sc.Ss - 1;
+        uint64_t n = N;
+        while (n) {
+            int k = __ffsll((unsigned long long)n) - 1;
+            n &= n - 1;
+            uint64_t between = (prev + 1 <= k - 1) ? band_mask(prev + 1, k - 1) : 0ull;
+            int z = (k - prev - 1) - __popcll(H & between);
+            prev = k;
+            sink.syms(0, 0xF0, z >> 4);
+            sink.sym(0, ((z & 15) << 4) | 1);
+            sink.rawcount(1);
+        }
+        sink.rawcount(__popcll(H));
+        emit_eobrun(sink, run);
+        return;
+    }
+    // exact stream order (jcphuff.c encode_mcu_AC_refine): correction bits ride behind the next symbol
+    int eobpos = N ? msb64(N) : -1;
+    uint64_t all = H | N;
+    int prev = sc.Ss - 1, r = 0;
+    uint64_t br = 0; int brn = 0;  // pending correction bits, oldest first in the high end
+    while (all) {
+        int k = __ffsll((unsigned long long)all) - 1;
+        all &= all - 1;
+        r += k - prev - 1;
+        prev = k;
+        if (k <= eobpos)
+            while (r > 15) {
+                sink.sym(0, 0xF0); r -= 16;
+                if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
+                if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
+                br = 0; brn = 0;
+            }
+        int v = blk[k << 6];
+        unsigned a = unsigned(v < 0 ? -v : v) >> sc.Al;
+        if ((H >> k) & 1) { br = (br << 1) | (a & 1); brn++; }
+        else {
+            sink.sym(0, (r << 4) | 1);
+            sink.raw(v < 0 ? 0u : 1u, 1);
+            if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
+            if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
+            br = 0; brn = 0; r = 0;
+        }
+    }
+    emit_eobrun(sink, run);
+    if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
+    if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
+}
+
+// DC scans: unit = MCU (interleaved) or block (single component)
+template <class Sink>
+__device__ static void walk_dc(Sink &sink, const EncCtx &c, const ImgDesc &im, const EncScan &sc, uint32_t u) {
+    for (int ci = 0; ci < sc.ncomp; ci++) {
+        const CompGeom &g = im.out[sc.comp[ci]];
+        int nb_x = sc.ncomp > 1 ? g.h : 1, nb_y = sc.ncomp > 1 ? g.v : 1;
+        int mx = 0, my = 0;
+        if (sc.ncomp > 1) { my = int(u) / im.omcus_x; mx = int(u) - my * im.omcus_x; }
+        int pred = 0;
+        bool have_pred = false;
+        for (int y = 0; y < nb_y; y++)
+            for (int x = 0; x < nb_x; x++) {
+                int b = sc.ncomp > 1 ? (my * g.v + y) * g.bw + mx * g.h + x : unit_block(g, u);
+                int dc = c.coef[coef_index(g.tile_base, b, 0)];
+                if (sc.Ah) { sink.raw(unsigned(dc >> sc.Al) & 1u, 1); continue; }
+                if (!have_pred) {
+                    // predictor = previous block of this component in scan order
+                    if (u == 0) pred = 0;
+                    else if (sc.ncomp > 1) {
+                        int pu = int(u) - 1, pmy = pu / im.omcus_x, pmx = pu - pmy * im.omcus_x;
+                        int pb = (pmy * g.v + g.v - 1) * g.bw + pmx * g.h + g.h - 1;
+                        pred = c.coef[coef_index(g.tile_base, pb, 0)] >> sc.Al;
+                    } else pred = c.coef[coef_index(g.tile_base, unit_block(g, u - 1), 0)] >> sc.Al;
+                    have_pred = true;
+                }
+                int t2 = dc >> sc.Al;
+                int t = t2 - pred;
+                pred = t2;
+                unsigned a = unsigned(t < 0 ? -t : t);
+                int nb = bitlen32(a);
+                sink.sym(sc.dc_tbl[ci], nb);
+                sink.raw(unsigned(t < 0 ? t - 1 : t), nb);
+            }
+    }
+}
+
+template <class Sink>
+__device__ __forceinline__ static void walk_unit(Sink &sink, const EncCtx &c, const ScanWork &w, const EncScan &sc, uint32_t u) {
+    const ImgDesc &im = c.imgs[w.image];
+    if (sc.Ss == 0) { walk_dc(sink, c, im, sc, u); return; }
+    const CompGeom &g = im.out[sc.comp[0]];
+    int b = unit_block(g, u);
+    AcMasks m = ac_masks(c.masks, g, b, sc);
+    const int16_t *blk = c.coef + coef_index(g.tile_base, b, 0);
+    unsigned run = c.eobrun[w.unit_base + u];
+    if (sc.Ah == 0) walk_ac_first(sink, blk, m.NZ, sc, run);
+    else walk_ac_refine(sink, blk, m.H, m.N, sc, run);
+}
+
+// ---- pass C: symbol statistics
+__global__ void __launch_bounds__(256) k_stats(EncCtx c) {
+    const ScanWork w = c.work[blockIdx.y];
+    const EncScan sc = c.script[w.scan];
+    if (sc.ntables == 0) return;
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= w.nunits) return;
+    StatsSink s; s.tab = c.tables + w.table_base;
+    walk_unit(s, c, w, sc, u);
+}
+
+// ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour), one lane per table
+__global__ void k_gen_tables(DevEncTable *tables, int ntables) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntables) return;
+    DevEncTable &T = tables[t];
+    int codesize[257], others[257];
+    uint32_t freq[257];
+    uint8_t bits[33];
+    for (int i = 0; i < 257; i++) { freq[i] = T.freq[i]; codesize[i] = 0; others[i] = -1; }
+    for (int i = 0; i < 33; i++) bits[i] = 0;
+    freq[256] = 1;
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        uint32_t v = 0xFFFFFFFFu;
+        for (int i = 0; i <= 256; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        v = 0xFFFFFFFFu;
+        for (int i = 0; i <= 256; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2]; freq[c2] = 0;
+        codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+        others[c1] = c2;
+        codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+    }
+    for (int i = 0; i <= 256; i++) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
+    for (int i = 32; i > 16; i--)
+        while (bits[i] > 0) {
+            int j = i - 2; while (bits[j] == 0) j--;
+            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+        }
+    int i = 16; while (i > 0 && bits[i] == 0) i--;
+    if (i > 0) bits[i]--;
+    for (int l = 0; l <= 16; l++) T.bits[l] = l ? bits[l] : 0;
+    int p = 0;
+    for (int l = 1; l <= 32; l++) for (int s = 0; s <= 255; s++) if (codesize[s] == l) T.vals[p++] = uint8_t(s);
+    T.nsym = p;
+    for (int s = 0; s < 256; s++) { T.size[s] = 0; T.code[s] = 0; }
+    int code = 0; p = 0;
+    for (int l = 1; l <= 16; l++) { for (int n = 0; n < T.bits[l]; n++, p++) { T.code[T.vals[p]] = uint16_t(code++); T.size[T.vals[p]] = uint8_t(l); } code <<= 1; }
+}
+void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
+    if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 63) / 64), dim3(64), st, tables, ntables);
+}
+
+// ---- pass E: size in bits of every unit's output
+__global__ void __launch_bounds__(256) k_sizes(EncCtx c) {
+    const ScanWork w = c.work[blockIdx.y];
+    const EncScan sc = c.script[w.scan];
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= w.nunits) return;
+    SizeSink s; s.tab = c.tables + w.table_base; s.bits = 0;
+    walk_unit(s, c, w, sc, u);
+    c.unit_bits[w.unit_base + u] = s.bits;
+}
+
+// ---- pass G: pack.  raw_off (bytes, multiple of 64) per scan comes from k_scan_layout.
+__global__ void __launch_bounds__(256) k_pack(EncCtx c) {
+    const ScanWork w = c.work[blockIdx.y];
+    const EncScan sc = c.script[w.scan];
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= w.nunits) return;
+    uint64_t base = c.unit_off[w.unit_base];
+    uint64_t total = c.unit_off[w.unit_base + w.nunits] - base;
+    uint64_t raw_bit0 = w.raw_off * 8;
+    if (raw_bit0 + total + 64 > c.raw_words * 32) { c.status[w.image] = 20200; return; }
+    PackSink s; s.tab = c.tables + w.table_base; s.raw_words = c.raw;
+    s.pos = raw_bit0 + (c.unit_off[w.unit_base + u] - base);
+    walk_unit(s, c, w, sc, u);
+    if (u == w.nunits - 1) {  // flush_bits: pad the last byte with 1-bits
+        int pad = int((8 - (total & 7)) & 7);
+        if (pad) s.put((1u << pad) - 1u, pad);
+    }
+}
+
+static dim3 unit_grid(const EncCtx &c) { return dim3((c.max_units + 255) / 256, c.nwork); }
+void launch_ac_flags(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_ac_flags, unit_grid(c), dim3(256), st, c); }
+void launch_ac_runs(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c); }
+void launch_stats(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_stats, unit_grid(c), dim3(256), st, c); }
+void launch_sizes(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_sizes, unit_grid(c), dim3(256), st, c); }
+void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_pack, unit_grid(c), dim3(256), st, c); }
+
+}  // namespace csh

@@ -1,0 +1,90 @@
+// kernels.h -- host-callable launchers of the device kernels (defined in k_*.hip).
+#pragma once
+#include "gpu_rt.h"
+#include "types.h"
+
+namespace csh {
+
+__host__ __device__ static inline size_t coef_index(uint32_t tile_base, int b, int k) {
+    return (size_t(tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t(k << 6) + size_t(b & 63);
+}
+
+// ---- phase 0: entropy decode (k_decode.hip)
+void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const DecScan *scans, const DevHuffSet *huffs,
+                       int16_t *coef, int nimg);
+
+// ---- phase 1: pixel-domain transcode (k_pixel.hip)
+// direct: dequant -> jidctint -> range limit -> jfdctint -> quantise, one block per lane
+void launch_xform_direct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                         const int16_t *coef_in, int16_t *coef_out);
+// subsampled components: IDCT to a u8 plane (edges replicated), then resample + FDCT + quantise
+void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                       const int16_t *coef_in, uint8_t *planes);
+void launch_resample_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                          const uint8_t *planes, int16_t *coef_out);
+void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
+
+// ---- phases 2-6: entropy encode (k_entropy.hip)
+void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t ntiles_total);
+
+struct EncCtx {  // device pointers + sizes every entropy kernel needs
+    const ImgDesc *imgs;
+    const EncScan *script;     // output script (CSH_MAX_SCANS)
+    const ScanWork *work;      // [nwork]
+    int nwork;
+    uint32_t max_units;        // max nunits over work items
+    const int16_t *coef;       // re-quantised coefficients (tiles)
+    const uint64_t *masks;     // [tile][3][64]
+    uint64_t *sym_bits;        // per AC scan: bit b set iff block b emits >=1 Huffman symbol in this scan
+    uint64_t *eob_bits;        // per AC scan: bit b set iff block b ends with a pending EOB
+    uint8_t *tail;             // per unit: # of correction bits left over at the end of the block (refine scans)
+    uint16_t *eobrun;          // per unit: EOBRUN value this block must emit after its symbols (0 = none)
+    uint32_t *unit_bits;       // per unit: size in bits of everything the unit emits
+    uint64_t *unit_off;        // exclusive scan of unit_bits over the whole batch
+    DevEncTable *tables;       // [ntables]
+    uint32_t *raw;             // unstuffed scan bytes as big-endian-logical u32 words, zero-initialised
+    uint64_t raw_words;        // capacity of raw in u32 words
+    uint32_t *status;          // per image
+};
+void launch_ac_flags(hipStream_t st, const EncCtx &c);
+void launch_ac_runs(hipStream_t st, const EncCtx &c);
+void launch_stats(hipStream_t st, const EncCtx &c);
+void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables);
+void launch_sizes(hipStream_t st, const EncCtx &c);
+void launch_pack(hipStream_t st, const EncCtx &c);
+
+// generic device primitive: out[i] = sum_{j<i} in[j] for i in [0, n]  (n+1 outputs; in[] has n entries)
+void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, size_t tmp_bytes);
+size_t exclusive_scan_tmp_bytes(uint64_t n);
+
+// ---- phase 6: byte stuffing + file assembly (k_assemble.hip)
+struct AsmCtx {
+    const ImgDesc *imgs;
+    const EncScan *script;
+    ScanWork *work;               // raw_off / raw_bytes / out_off / hdr_bytes are filled in here
+    int nwork, nimg, scans_per_image;
+    const DevEncTable *tables;
+    const uint64_t *unit_off;     // exclusive scan of unit_bits (+ trailing total)
+    uint32_t *scan_pad_bytes;     // [nwork] raw bytes per scan rounded up to 64 (+64 slack)
+    uint64_t *scan_raw_off;       // [nwork+1] exclusive scan of scan_pad_bytes
+    const uint32_t *raw;          // packed bits, big-endian-logical u32 words
+    uint64_t raw_chunks;          // capacity of raw in 64-byte chunks
+    uint32_t *chunk_ff;           // [raw_chunks] number of 0xFF bytes in the chunk
+    uint64_t *chunk_ffoff;        // [raw_chunks+1] exclusive scan of chunk_ff
+    const uint8_t *hdr_pool;      // per-image frame headers (host-built: SOI .. SOFn)
+    const uint32_t *hdr_off;      // [nimg+1]
+    uint32_t *img_size_pad;       // [nimg] file size rounded up to 16
+    uint32_t *img_size;           // [nimg] file size
+    uint64_t *img_off;            // [nimg+1] exclusive scan of img_size_pad
+    uint8_t *out;                 // output pool
+    uint64_t out_cap;
+    uint32_t *status;             // per image
+    uint32_t *overflow;           // [1] set when a pool is too small
+};
+void launch_scan_sizes(hipStream_t st, const AsmCtx &a);     // fills scan_pad_bytes + work[].raw_bytes
+void launch_scan_place(hipStream_t st, const AsmCtx &a);     // work[].raw_off from scan_raw_off
+void launch_ff_count(hipStream_t st, const AsmCtx &a);
+void launch_layout(hipStream_t st, const AsmCtx &a);         // per image: scan offsets, file size
+void launch_emit(hipStream_t st, const AsmCtx &a);           // headers, DHT/SOS, stuffed data, EOI
+
+}  // namespace csh

@@ -1,0 +1,608 @@
+// pipeline.cpp -- the device batch queue: what caesium-clt's rayon par_iter over files
+// (/root/reference/src/compressor.rs:74-101) becomes on an MI355X.  One csh_batch = one group of input
+// files resident in HBM; csh_batch_run pushes the whole group through
+//   entropy decode -> pixel-domain transcode -> masks/flags/runs -> stats/tables -> sizes/scan -> pack
+//   -> stuffing/assembly
+// on one stream with no host round trip (every size and offset is produced by device scans).
+// Host work is limited to container logic: marker parsing, table/script setup, descriptor building.
+#include <cmath>
+#include <cstdarg>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/caesium_hip.h"
+#include "jpeg_host.hpp"
+#include "kernels.h"
+
+static thread_local char g_err[512];
+void csh_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *csh_last_error(void) { return g_err; }
+
+#ifdef CSH_EMUL
+thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+#endif
+
+namespace csh {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        void *q = nullptr;
+        CSH_CHECK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+        p = static_cast<T *>(q);
+        return 0;
+    }
+    int upload(const std::vector<T> &v, hipStream_t st) {
+        if (alloc(v.size())) return -1;
+        if (!v.empty()) CSH_CHECK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    int zero(hipStream_t st) { if (n) CSH_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), st)); return 0; }
+};
+
+struct Item {
+    int code = 0;
+    std::string msg;
+    JpegInfo in;
+    JpegInfo out;     // output geometry (comp ids / sampling / tq)
+    int image = -1;   // index among the images that reached the device, or -1
+    size_t file_size = 0;
+};
+
+}  // namespace csh
+
+using namespace csh;
+
+struct csh_batch {
+    int device = 0;
+    hipStream_t stream = 0;
+    bool have_stream = false;
+    CCSParameters params;
+    std::vector<Item> items;
+    int nimg = 0;
+    bool lossless = false;
+
+    // host-side descriptor arrays
+    std::vector<ImgDesc> imgs;
+    std::vector<DecScan> dscans;
+    std::vector<DevHuffSet> hsets;
+    std::vector<DevQuant> quants;
+    std::vector<PlaneWork> pwork;
+    std::vector<EncScan> script;
+    std::vector<ScanWork> swork;
+    std::vector<uint8_t> bits_pool, hdr_pool;
+    std::vector<uint32_t> hdr_off;
+    uint32_t ntiles = 0, max_tiles = 0, max_units = 0, max_dummy = 0;
+    uint64_t total_units = 0, total_words = 0, plane_bytes = 0;
+    int ntables = 0;
+    uint64_t raw_bytes_cap = 0, out_cap = 0;
+
+    // device buffers
+    DevBuf<uint8_t> d_bits, d_planes, d_hdr, d_out, d_tail;
+    DevBuf<ImgDesc> d_imgs;
+    DevBuf<DecScan> d_dscans;
+    DevBuf<DevHuffSet> d_hsets;
+    DevBuf<DevQuant> d_quants;
+    DevBuf<PlaneWork> d_pwork;
+    DevBuf<EncScan> d_script;
+    DevBuf<ScanWork> d_swork;
+    DevBuf<int16_t> d_coef;
+    DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
+    DevBuf<uint16_t> d_eobrun;
+    DevBuf<uint32_t> d_unit_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
+    DevBuf<DevEncTable> d_tables;
+    DevBuf<uint8_t> d_scan_tmp;
+
+    std::vector<uint32_t> h_img_size;
+    std::vector<uint64_t> h_img_off;
+    std::vector<uint32_t> h_status;
+    bool ran = false;
+
+    ~csh_batch() { if (have_stream) (void)hipStreamDestroy(stream); }
+};
+
+// ------------------------------------------------------------------------------------------------
+static void build_dev_huff(const HuffSpec &h, DevHuff &d) {
+    memset(&d, 0, sizeof d);
+    for (int l = 0; l < 18; l++) d.maxcode[l] = -1;
+    if (!h.present) return;
+    int code = 0, p = 0;
+    for (int l = 1; l <= 16; l++) {
+        if (h.bits[l]) {
+            d.valptr[l] = p - code;
+            for (int i = 0; i < h.bits[l]; i++, p++, code++)
+                if (l <= 9) {
+                    int base = code << (9 - l);
+                    for (int k = 0; k < (1 << (9 - l)); k++) d.look[(base + k) & 511] = uint16_t((l << 8) | h.vals[p]);
+                }
+            d.maxcode[l] = code - 1;
+        }
+        code <<= 1;
+    }
+    d.maxcode[17] = 0x7FFFFFFF;
+    memcpy(d.vals, h.vals, 256);
+}
+
+static void make_quant(const uint16_t nat[64], DevQuant &q) {
+    for (int k = 0; k < 64; k++) {
+        q.q[k] = nat[kZigZag[k]];
+        q.div[k] = int32_t(q.q[k]) * 8;
+        q.rcp[k] = 1.0f / float(q.div[k]);
+    }
+}
+
+static void fill_geom(const JComp &c, CompGeom &g, uint32_t &ntiles) {
+    g.h = c.h; g.v = c.v; g.comp_w = c.comp_w; g.comp_h = c.comp_h;
+    g.real_bw = c.real_bw; g.real_bh = c.real_bh; g.bw = c.bw; g.bh = c.bh;
+    g.ntiles = (c.bw * c.bh + 63) / 64;
+    g.tile_base = ntiles;
+    ntiles += g.ntiles;
+}
+
+// output progressive script -> EncScan entries (libjpeg jpeg_simple_progression; Y uses tables 0, chroma tables 1)
+static void add_script(std::vector<EncScan> &v, int ncomp) {
+    for (const OutScan &o : output_script(ncomp, true)) {
+        EncScan e;
+        memset(&e, 0, sizeof e);
+        e.ncomp = o.ncomp; e.Ss = o.Ss; e.Se = o.Se; e.Ah = o.Ah; e.Al = o.Al;
+        for (int k = 0; k < o.ncomp; k++) e.comp[k] = o.comp[k];
+        if (o.Ss == 0) {
+            if (o.Ah == 0) {
+                e.ntables = 0;
+                for (int k = 0; k < o.ncomp; k++) {
+                    int id = o.comp[k] ? 1 : 0;
+                    int idx = -1;
+                    for (int t = 0; t < e.ntables; t++) if (e.dht_id[t] == id) idx = t;
+                    if (idx < 0) { idx = e.ntables; e.dht_id[e.ntables++] = id; }
+                    e.dc_tbl[k] = idx;
+                    e.sos_tdta[k] = id << 4;
+                }
+            }
+        } else {
+            int id = o.comp[0] ? 1 : 0;
+            e.ntables = 1; e.dht_id[0] = 0x10 | id; e.sos_tdta[0] = id;
+        }
+        v.push_back(e);
+    }
+}
+
+static bool is_jpeg(const uint8_t *d, size_t n) { return n >= 3 && d[0] == 0xFF && d[1] == 0xD8 && d[2] == 0xFF; }
+static int sniff_type(const uint8_t *d, size_t n) {
+    if (is_jpeg(d, n)) return CS_TYPE_JPEG;
+    if (n >= 8 && !memcmp(d, "\x89PNG\r\n\x1a\n", 8)) return CS_TYPE_PNG;
+    if (n >= 12 && !memcmp(d, "RIFF", 4) && !memcmp(d + 8, "WEBP", 4)) return CS_TYPE_WEBP;
+    if (n >= 6 && (!memcmp(d, "GIF87a", 6) || !memcmp(d, "GIF89a", 6))) return CS_TYPE_GIF;
+    if (n >= 4 && (!memcmp(d, "II*\0", 4) || !memcmp(d, "MM\0*", 4))) return CS_TYPE_TIFF;
+    return CS_TYPE_UNKN;
+}
+
+// decide the output frame for one parsed JPEG; returns 0 or an error code
+static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
+    const JpegInfo &in = it.in;
+    if (in.ncomp != 1 && in.ncomp != 3) { it.msg = "unsupported component count (CMYK/YCCK not on the device path yet)"; return CS_ERR_JPEG_FEATURE; }
+    if (in.ncomp == 3) {
+        bool rgb_ids = in.comp[0].id == 'R' && in.comp[1].id == 'G' && in.comp[2].id == 'B';
+        if (in.adobe_transform == 0 || rgb_ids) { it.msg = "RGB-colourspace JPEG not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
+    }
+    it.out = JpegInfo();
+    JpegInfo &o = it.out;
+    o.width = in.width; o.height = in.height; o.ncomp = in.ncomp;
+    if (lossless) {
+        for (int c = 0; c < in.ncomp; c++) o.comp[c] = in.comp[c];
+        jpeg_geometry(o);
+        return 0;
+    }
+    int ss = int(p.jpeg_chroma_subsampling);
+    if (ss == 0) ss = 420;
+    for (int c = 0; c < in.ncomp; c++) { o.comp[c].id = c + 1; o.comp[c].h = o.comp[c].v = 1; o.comp[c].tq = c ? 1 : 0; }
+    if (in.ncomp == 3) {
+        bool in444 = in.comp[0].h == 1 && in.comp[0].v == 1, in420 = in.comp[0].h == 2 && in.comp[0].v == 2;
+        bool chroma11 = in.comp[1].h == 1 && in.comp[1].v == 1 && in.comp[2].h == 1 && in.comp[2].v == 1;
+        if (!chroma11 || !(in444 || in420)) { it.msg = "input chroma sampling other than 4:4:4 / 4:2:0 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
+        if (ss == 420) { o.comp[0].h = 2; o.comp[0].v = 2; }
+        else if (ss == 444) { if (!in444) { it.msg = "4:2:0 -> 4:4:4 not on the device path yet"; return CS_ERR_JPEG_FEATURE; } }
+        else { it.msg = "output chroma subsampling 4:2:2 / 4:1:1 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
+    }
+    jpeg_geometry(o);
+    return 0;
+}
+
+extern "C" int csh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) {
+    *out = nullptr;
+    if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
+    std::unique_ptr<csh_batch> b(new csh_batch);
+    b->device = device;
+    b->params = *p;
+    b->lossless = p->jpeg_optimize;
+    if (!p->jpeg_progressive) { /* sequential output: handled per item below */ }
+    if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    b->have_stream = true;
+    b->items.resize(count);
+
+    uint16_t qout_nat[64];
+    quality_table(int(p->jpeg_quality), qout_nat);
+    DevQuant qo; make_quant(qout_nat, qo);
+    b->quants.push_back(qo);  // index 0: output table (luma == chroma in mozjpeg's profile 3)
+
+    add_script(b->script, 3);  // entries 0..9
+    add_script(b->script, 1);  // entries 10..15
+    const int script_base3 = 0, script_base1 = 10;
+
+    std::vector<std::pair<std::vector<uint8_t>, int>> hset_keys;
+    std::map<std::vector<uint16_t>, int> quant_index;
+    uint32_t plane_off = 0;
+
+    for (size_t n = 0; n < count; n++) {
+        Item &it = b->items[n];
+        const uint8_t *d = inputs[n].data;
+        size_t len = inputs[n].length;
+        it.file_size = len;
+        int type = sniff_type(d, len);
+        if (type == CS_TYPE_UNKN) { it.code = CS_ERR_UNKNOWN_TYPE; it.msg = "unknown file type"; continue; }
+        if (type != CS_TYPE_JPEG) { it.code = CS_ERR_UNSUPPORTED; it.msg = "only JPEG has a device path in this build"; continue; }
+        if (!p->jpeg_progressive) { it.code = CS_ERR_UNSUPPORTED; it.msg = "sequential (--jpeg-baseline) output not on the device path yet"; continue; }
+        it.code = parse_jpeg(d, len, it.in, it.msg);
+        if (it.code) continue;
+        it.code = plan_item(it, *p, b->lossless);
+        if (it.code) continue;
+
+        ImgDesc im;
+        memset(&im, 0, sizeof im);
+        const JpegInfo &in = it.in, &o = it.out;
+        im.width = in.width; im.height = in.height; im.ncomp = in.ncomp;
+        im.mcus_x = in.mcus_x; im.mcus_y = in.mcus_y;
+        im.progressive_in = in.progressive;
+        for (int c = 0; c < in.ncomp; c++) fill_geom(in.comp[c], im.in[c], b->ntiles);
+        for (int c = 0; c < in.ncomp; c++) {
+            if (b->lossless) im.out[c] = im.in[c];
+            else fill_geom(o.comp[c], im.out[c], b->ntiles);
+            im.comp_id[c] = o.comp[c].id;
+            std::vector<uint16_t> key(in.qt[in.comp[c].tq], in.qt[in.comp[c].tq] + 64);
+            auto f = quant_index.find(key);
+            if (f == quant_index.end()) {
+                DevQuant q; make_quant(key.data(), q);
+                f = quant_index.emplace(key, int(b->quants.size())).first;
+                b->quants.push_back(q);
+            }
+            im.qt_in[c] = f->second;
+            im.qt_out[c] = 0;
+            b->max_tiles = std::max<uint32_t>(b->max_tiles, std::max(im.in[c].ntiles, im.out[c].ntiles));
+            uint32_t nd = uint32_t(im.out[c].bw * im.out[c].bh - im.out[c].real_bw * im.out[c].real_bh);
+            b->max_dummy = std::max(b->max_dummy, nd);
+        }
+        im.omcus_x = o.mcus_x; im.omcus_y = o.mcus_y;
+        int img_index = int(b->imgs.size());
+        // entropy-coded scans
+        im.first_scan = int(b->dscans.size());
+        im.nscans_in = int(in.scans.size());
+        for (const JScan &js : in.scans) {
+            DecScan ds;
+            memset(&ds, 0, sizeof ds);
+            ds.bits_off = uint32_t(b->bits_pool.size());
+            ds.bits_len = uint32_t(js.data_len);
+            b->bits_pool.insert(b->bits_pool.end(), d + js.data_off, d + js.data_off + js.data_len);
+            b->bits_pool.resize((b->bits_pool.size() + 15) & ~size_t(15));
+            ds.ncomp = js.ncomp;
+            if (js.ncomp > CSH_MAX_COMPS) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "scan with more than 3 components"; break; }
+            for (int k = 0; k < js.ncomp; k++) { ds.comp[k] = js.comp_idx[k]; ds.td[k] = js.td[k]; ds.ta[k] = js.ta[k]; }
+            ds.Ss = js.Ss; ds.Se = js.Se; ds.Ah = js.Ah; ds.Al = js.Al;
+            ds.restart_interval = in.restart_interval;
+            // Huffman set, de-duplicated by content
+            std::vector<uint8_t> key;
+            for (int t = 0; t < 4; t++)
+                for (const HuffSpec *h : {&js.dc[t], &js.ac[t]}) {
+                    key.push_back(h->present);
+                    if (h->present) { key.insert(key.end(), h->bits, h->bits + 17); key.insert(key.end(), h->vals, h->vals + h->nvals); }
+                }
+            int found = -1;
+            for (auto &kv : hset_keys) if (kv.first == key) { found = kv.second; break; }
+            if (found < 0) {
+                found = int(b->hsets.size());
+                DevHuffSet hs;
+                for (int t = 0; t < 4; t++) { build_dev_huff(js.dc[t], hs.dc[t]); build_dev_huff(js.ac[t], hs.ac[t]); }
+                b->hsets.push_back(hs);
+                hset_keys.emplace_back(key, found);
+            }
+            ds.huff_set = found;
+            // tables the scan needs must exist
+            for (int k = 0; k < js.ncomp; k++) {
+                bool need_dc = in.progressive ? (js.Ss == 0 && js.Ah == 0) : true;
+                bool need_ac = in.progressive ? (js.Ss != 0) : true;
+                if ((need_dc && !js.dc[js.td[k]].present) || (need_ac && !js.ac[js.ta[k]].present)) { it.code = CS_ERR_BAD_JPEG; it.msg = "scan refers to a missing Huffman table"; }
+            }
+            b->dscans.push_back(ds);
+        }
+        if (it.code) { b->dscans.resize(im.first_scan); continue; }
+
+        // pixel work + planes
+        if (!b->lossless)
+            for (int c = 0; c < in.ncomp; c++) {
+                PlaneWork w; w.image = img_index; w.comp = c;
+                bool in_full = in.comp[c].h == in.hmax && in.comp[c].v == in.vmax;
+                bool out_full = o.comp[c].h == o.hmax && o.comp[c].v == o.vmax;
+                if (in_full && out_full) w.mode = 0;
+                else if (!in_full && !out_full) w.mode = 2;   // 4:2:0 chroma -> 4:2:0 chroma
+                else w.mode = 3;                               // full-res chroma -> h2v2 box
+                if (w.mode) {
+                    im.plane_off[c] = plane_off;
+                    plane_off += uint32_t(im.in[c].real_bw * 8 * im.in[c].real_bh * 8);
+                    plane_off = (plane_off + 63u) & ~63u;
+                }
+                b->pwork.push_back(w);
+            }
+
+        // output scans
+        int sb = in.ncomp == 3 ? script_base3 : script_base1;
+        int ns = in.ncomp == 3 ? 10 : 6;
+        im.first_work = int(b->swork.size());
+        im.nscans_out = ns;
+        for (int s = 0; s < ns; s++) {
+            const EncScan &e = b->script[sb + s];
+            ScanWork w;
+            memset(&w, 0, sizeof w);
+            w.image = img_index; w.scan = sb + s;
+            if (e.Ss == 0 && e.ncomp > 1) w.nunits = uint32_t(im.omcus_x * im.omcus_y);
+            else w.nunits = uint32_t(im.out[e.comp[0]].real_bw * im.out[e.comp[0]].real_bh);
+            w.unit_base = uint32_t(b->total_units);
+            b->total_units += w.nunits;
+            w.word_base = uint32_t(b->total_words);
+            if (e.Ss) b->total_words += (w.nunits + 63) / 64;
+            w.table_base = uint32_t(b->ntables);
+            b->ntables += e.ntables;
+            b->max_units = std::max(b->max_units, w.nunits);
+            b->swork.push_back(w);
+        }
+        if (b->total_units > 0xFFFFFFF0ull) { it.code = CS_ERR_POOL_OVERFLOW; it.msg = "batch too large"; }
+
+        // frame header (host-built): SOI, JFIF, [metadata], DQT, SOF
+        JpegInfo hdr = o;
+        if (b->lossless) memcpy(hdr.qt, in.qt, sizeof hdr.qt);           // coefficient transcode keeps the source tables
+        else { memcpy(hdr.qt[0], qout_nat, 128); memcpy(hdr.qt[1], qout_nat, 128); }
+        std::vector<uint8_t> fh = build_frame_header(hdr, true, p->keep_metadata ? &in.meta : nullptr);
+        b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
+        b->hdr_pool.insert(b->hdr_pool.end(), fh.begin(), fh.end());
+
+        it.image = img_index;
+        b->imgs.push_back(im);
+        b->raw_bytes_cap += 2 * len + 64 * 1024;
+    }
+    b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
+    b->nimg = int(b->imgs.size());
+    b->plane_bytes = plane_off;
+    b->out_cap = b->raw_bytes_cap;
+
+    // upload what never changes between runs
+    hipStream_t st = b->stream;
+    if (b->nimg) {
+        if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) ||
+            b->d_hsets.upload(b->hsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
+            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_hdr.upload(b->hdr_pool, st) ||
+            b->d_hdr_off.upload(b->hdr_off, st))
+            return CS_ERR_NO_DEVICE;
+        if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) ||
+            b->d_masks.alloc(size_t(b->ntiles) * 192) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
+            b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
+            b->d_unit_off.alloc(b->total_units + 2) || b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
+            b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
+            b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
+            return CS_ERR_NO_DEVICE;
+        if (hipStreamSynchronize(st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
+    }
+    *out = b.release();
+    return 0;
+}
+
+extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
+
+// kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
+static const char *const kKernelNames[CSH_NKERNELS] = {
+    "memset_coef", "k_decode_seq", "k_idct_plane", "k_xform_direct", "k_resample_fdct", "k_fix_dummy", "memset_enc", "k_masks",
+    "k_ac_flags", "k_ac_runs", "k_stats", "k_gen_tables", "k_sizes", "scan_units", "scan_layout", "k_pack",
+    "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", ""};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7};
+extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
+
+static int run_once(csh_batch *b, csh_timing *t) {
+    hipStream_t st = b->stream;
+    const int nimg = b->nimg;
+    uint64_t raw_chunks = (b->raw_bytes_cap + 63) / 64;
+    if (b->d_raw.n != raw_chunks * 16) {
+        if (b->d_raw.alloc(raw_chunks * 16) || b->d_chunk_ff.alloc(raw_chunks + 1) || b->d_chunk_ffoff.alloc(raw_chunks + 2) || b->d_out.alloc(b->out_cap + 64))
+            return -1;
+        size_t tmp = std::max(exclusive_scan_tmp_bytes(b->total_units), exclusive_scan_tmp_bytes(raw_chunks));
+        if (b->d_scan_tmp.alloc(tmp)) return -1;
+    }
+    hipEvent_t ev[CSH_NKERNELS + 1];
+    for (auto &e : ev) CSH_CHECK(hipEventCreate(&e));
+    int slot = 0;
+    // one event after every kernel, on the batch's own stream: kernel_ms[i] = ev[i+1] - ev[i]
+#define MARK() CSH_CHECK(hipEventRecord(ev[++slot], st))
+    CSH_CHECK(hipEventRecord(ev[0], st));
+    // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
+    if (b->d_coef.zero(st) || b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
+    MARK();
+    launch_decode_seq(st, b->d_bits.p, b->d_imgs.p, b->d_dscans.p, b->d_hsets.p, b->d_coef.p, nimg);
+    MARK();
+    // ---- phase 1: pixel-domain transcode
+    int nw = b->lossless ? 0 : int(b->pwork.size());
+    launch_idct_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_planes.p);
+    MARK();
+    launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p);
+    MARK();
+    launch_resample_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_planes.p, b->d_coef.p);
+    MARK();
+    if (!b->lossless) launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
+    MARK();
+    // ---- phase 2: masks, flags, EOB runs
+    EncCtx c;
+    memset(&c, 0, sizeof c);
+    c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size()); c.max_units = b->max_units;
+    c.coef = b->d_coef.p; c.masks = b->d_masks.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
+    c.eobrun = b->d_eobrun.p; c.unit_bits = b->d_unit_bits.p; c.unit_off = b->d_unit_off.p; c.tables = b->d_tables.p;
+    c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p;
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st)) return -1;
+    MARK();
+    launch_masks(st, b->d_coef.p, b->d_masks.p, b->ntiles);
+    MARK();
+    launch_ac_flags(st, c);
+    MARK();
+    launch_ac_runs(st, c);
+    MARK();
+    // ---- phase 3: statistics + optimal tables
+    launch_stats(st, c);
+    MARK();
+    launch_gen_tables(st, b->d_tables.p, b->ntables);
+    MARK();
+    // ---- phase 4: sizes + offsets
+    launch_sizes(st, c);
+    MARK();
+    launch_exclusive_scan(st, b->d_unit_bits.p, b->d_unit_off.p, b->total_units, b->d_scan_tmp.p, b->d_scan_tmp.n);
+    MARK();
+    AsmCtx a;
+    memset(&a, 0, sizeof a);
+    a.imgs = b->d_imgs.p; a.script = b->d_script.p; a.work = b->d_swork.p; a.nwork = c.nwork; a.nimg = nimg;
+    a.tables = b->d_tables.p; a.unit_off = b->d_unit_off.p; a.scan_pad_bytes = b->d_scan_pad.p; a.scan_raw_off = b->d_scan_raw_off.p;
+    a.raw = b->d_raw.p; a.raw_chunks = raw_chunks; a.chunk_ff = b->d_chunk_ff.p; a.chunk_ffoff = b->d_chunk_ffoff.p;
+    a.hdr_pool = b->d_hdr.p; a.hdr_off = b->d_hdr_off.p; a.img_size = b->d_img_size.p; a.img_size_pad = b->d_img_size_pad.p;
+    a.img_off = b->d_img_off.p; a.out = b->d_out.p; a.out_cap = b->out_cap; a.status = b->d_status.p; a.overflow = b->d_overflow.p;
+    launch_scan_sizes(st, a);
+    launch_exclusive_scan(st, b->d_scan_pad.p, b->d_scan_raw_off.p, uint64_t(a.nwork), b->d_scan_tmp.p, b->d_scan_tmp.n);
+    launch_scan_place(st, a);
+    MARK();
+    // ---- phase 5: pack
+    launch_pack(st, c);
+    MARK();
+    // ---- phase 6: stuffing + assembly
+    launch_ff_count(st, a);
+    MARK();
+    launch_exclusive_scan(st, b->d_chunk_ff.p, b->d_chunk_ffoff.p, raw_chunks, b->d_scan_tmp.p, b->d_scan_tmp.n);
+    MARK();
+    launch_layout(st, a);
+    MARK();
+    launch_exclusive_scan(st, b->d_img_size_pad.p, b->d_img_off.p, uint64_t(nimg), b->d_scan_tmp.p, b->d_scan_tmp.n);
+    MARK();
+    launch_emit(st, a);
+    MARK();
+#undef MARK
+    CSH_CHECK(hipStreamSynchronize(st));
+    CSH_CHECK(hipGetLastError());
+    if (t) {
+        for (int i = 0; i < CSH_NPHASES; i++) t->phase_ms[i] = 0;
+        for (int i = 0; i < CSH_NKERNELS; i++) t->kernel_ms[i] = 0;
+        for (int i = 0; i < slot; i++) {
+            CSH_CHECK(hipEventElapsedTime(&t->kernel_ms[i], ev[i], ev[i + 1]));
+            t->phase_ms[kKernelPhase[i]] += t->kernel_ms[i];
+        }
+        CSH_CHECK(hipEventElapsedTime(&t->total_ms, ev[0], ev[slot]));
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+extern "C" int csh_batch_run(csh_batch *b, csh_timing *t) {
+    if (t) memset(t, 0, sizeof *t);
+    if (!b->nimg) { b->ran = true; return 0; }
+    if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (run_once(b, t)) return CS_ERR_NO_DEVICE;
+        uint32_t ovf[4] = {0, 0, 0, 0};
+        if (hipMemcpy(ovf, b->d_overflow.p, sizeof ovf, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
+        b->h_status.resize(b->nimg);
+        if (hipMemcpy(b->h_status.data(), b->d_status.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
+        bool pool = ovf[0] != 0;
+        for (uint32_t s : b->h_status) if (s == CS_ERR_POOL_OVERFLOW) pool = true;
+        if (!pool) break;
+        if (attempt == 3) { csh_set_error("device pools overflowed after 3 retries"); return CS_ERR_POOL_OVERFLOW; }
+        b->raw_bytes_cap *= 4; b->out_cap = b->raw_bytes_cap;  // rare: output larger than 2x the input
+    }
+    b->h_img_size.resize(b->nimg);
+    b->h_img_off.resize(b->nimg + 1);
+    if (hipMemcpy(b->h_img_size.data(), b->d_img_size.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(b->h_img_off.data(), b->d_img_off.p, (b->nimg + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        csh_set_error("D2H of sizes failed"); return CS_ERR_NO_DEVICE;
+    }
+    if (t) {
+        t->n_images = uint32_t(b->nimg);
+        for (const Item &it : b->items) if (it.image < 0) t->n_failed++;
+        for (int i = 0; i < b->nimg; i++) { t->out_bytes += b->h_img_size[i]; t->pixels += uint64_t(b->imgs[i].width) * b->imgs[i].height; }
+        t->in_bytes = b->bits_pool.size();
+        uint64_t in_tiles = 0;
+        for (const ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) in_tiles += im.in[c].ntiles;
+        t->coef_bytes = in_tiles * CSH_TILE_I16 * 2;
+    }
+    b->ran = true;
+    return 0;
+}
+
+static void set_result(CCSResult *r, int code, const std::string &msg) {
+    r->success = code == 0;
+    r->code = uint32_t(code);
+    r->error_message = nullptr;
+    if (code) { char *m = (char *)malloc(msg.size() + 1); memcpy(m, msg.c_str(), msg.size() + 1); r->error_message = m; }
+}
+
+extern "C" int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results) {
+    if (!b->ran) { csh_set_error("csh_batch_fetch before csh_batch_run"); return -1; }
+    std::vector<uint8_t> host;
+    if (b->nimg) {
+        host.resize(b->h_img_off[b->nimg]);
+        if (!host.empty() && hipMemcpy(host.data(), b->d_out.p, host.size(), hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H of output failed"); return -1; }
+    }
+    int failed = 0;
+    for (size_t n = 0; n < b->items.size(); n++) {
+        Item &it = b->items[n];
+        outputs[n].data = nullptr; outputs[n].length = 0;
+        int code = it.code;
+        std::string msg = it.msg;
+        if (!code && it.image >= 0 && b->h_status[it.image]) { code = int(b->h_status[it.image]); msg = "device reported a malformed stream"; }
+        if (!code) {
+            size_t len = b->h_img_size[it.image];
+            outputs[n].data = (uint8_t *)malloc(len ? len : 1);
+            memcpy(outputs[n].data, host.data() + b->h_img_off[it.image], len);
+            outputs[n].length = len;
+        } else failed++;
+        if (results) set_result(&results[n], code, msg);
+    }
+    return failed;
+}
+
+extern "C" int csh_batch_geometry(csh_batch *b, size_t image, int comp, int which, int *bw, int *bh, int *real_bw, int *real_bh) {
+    if (image >= b->items.size() || b->items[image].image < 0) { csh_set_error("image not on the device"); return -1; }
+    const ImgDesc &im = b->imgs[b->items[image].image];
+    if (comp < 0 || comp >= im.ncomp) { csh_set_error("bad component"); return -1; }
+    const CompGeom &g = which ? im.out[comp] : im.in[comp];
+    *bw = g.bw; *bh = g.bh; *real_bw = g.real_bw; *real_bh = g.real_bh;
+    return 0;
+}
+
+extern "C" int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int which, int16_t *dst) {
+    int bw, bh, rbw, rbh;
+    if (csh_batch_geometry(b, image, comp, which, &bw, &bh, &rbw, &rbh)) return -1;
+    const ImgDesc &im = b->imgs[b->items[image].image];
+    const CompGeom &g = which ? im.out[comp] : im.in[comp];
+    std::vector<int16_t> tiles(size_t(g.ntiles) * CSH_TILE_I16);
+    if (hipMemcpy(tiles.data(), b->d_coef.p + size_t(g.tile_base) * CSH_TILE_I16, tiles.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return -1; }
+    for (int blk = 0; blk < bw * bh; blk++)
+        for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + (k << 6) + (blk & 63)];
+    return 0;
+}

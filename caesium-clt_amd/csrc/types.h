@@ -1,0 +1,111 @@
+// types.h -- descriptors shared by the host pipeline and the kernels.
+//
+// HBM data layout (DESIGN.md "Data layout"):
+//  * coefficient TILE = 64 consecutive blocks (padded raster order of one component of one image),
+//    stored k-major: int16 tile[64 /*zig-zag k*/][64 /*block in tile*/]  (8 KiB).  A wave owns a tile,
+//    lane = block: every access "coefficient k of my block" is one fully coalesced 128-byte row, and a
+//    band-limited progressive scan (Ss..Se) touches only rows Ss..Se.
+//  * per-block 64-bit significance masks M0/M1/M2 (bit k set iff |coef k| >= 1 / 2 / 4), SoA per tile:
+//    u64 mask[3][64 lanes].  The progressive coder's run/EOB logic is bit algebra on these.
+//  * u8 sample planes (subsampled components only), pitch = real_bw*8, rows = bh*8, edges replicated.
+#pragma once
+#include <cstdint>
+
+#define CSH_TILE_BLOCKS 64
+#define CSH_TILE_I16 4096  // int16 elements per tile
+#define CSH_MAX_COMPS 3
+#define CSH_MAX_SCANS 16
+
+namespace csh {
+
+struct CompGeom {
+    int h, v;              // sampling factors
+    int comp_w, comp_h;    // real size in samples
+    int real_bw, real_bh;  // ceil(comp/8)
+    int bw, bh;            // MCU-padded block grid
+    int ntiles;            // ceil(bw*bh/64)
+    uint32_t tile_base;    // first tile of this component in the coefficient pool
+};
+
+// decode LUT for one Huffman table (T.81 Annex C / F.2.2.3 with a 9-bit lookahead)
+struct DevHuff {
+    uint16_t look[512];   // (len<<8)|sym for codes of <= 9 bits, else 0
+    int32_t maxcode[18];  // per length, -1 if none
+    int32_t valptr[17];
+    uint8_t vals[256];
+};
+struct DevHuffSet { DevHuff dc[4], ac[4]; };
+
+// one entropy-coded scan of one input image
+struct DecScan {
+    uint32_t bits_off, bits_len;  // entropy segment in the bitstream pool
+    int huff_set;
+    int ncomp;                    // components in scan
+    int comp[CSH_MAX_COMPS], td[CSH_MAX_COMPS], ta[CSH_MAX_COMPS];
+    int Ss, Se, Ah, Al;
+    int restart_interval;
+};
+
+struct ImgDesc {
+    int width, height, ncomp;
+    int mcus_x, mcus_y;           // MCU grid of the INPUT frame (entropy decode)
+    int omcus_x, omcus_y;         // MCU grid of the OUTPUT frame (entropy encode)
+    int progressive_in;
+    CompGeom in[CSH_MAX_COMPS];   // decoded coefficient geometry
+    CompGeom out[CSH_MAX_COMPS];  // re-encoded geometry (== in for the lossless transcode)
+    int qt_in[CSH_MAX_COMPS];     // index into the quant pool (zig-zag u16[64] + divisors)
+    int qt_out[CSH_MAX_COMPS];
+    uint32_t plane_off[CSH_MAX_COMPS];  // byte offset of the u8 plane (subsampled comps)
+    int first_scan, nscans_in;    // range in the DecScan array
+    int comp_id[CSH_MAX_COMPS];   // component identifiers written to SOF/SOS
+    int first_work, nscans_out;   // this image's ScanWork range (output scans, in file order)
+    uint32_t status;              // 0 ok; set by kernels on malformed data
+};
+
+// quantisation table as the kernels want it: zig-zag order, with exact-division helpers
+struct DevQuant {
+    uint16_t q[64];      // table value, zig-zag order
+    int32_t div[64];     // q*8 (jfdctint output is scaled by 8)
+    float rcp[64];       // 1.0f/div, host-computed
+};
+
+// work item of the pixel kernels: one component of one image
+struct PlaneWork {
+    int image, comp;
+    int mode;  // 0 direct (IDCT->FDCT, 1:1), 1 idct-to-plane, 2 plane h2v2up+h2v2down (4:2:0 -> 4:2:0), 3 plane h2v2 box down (4:4:4 -> 4:2:0)
+};
+
+// one scan of the OUTPUT script (same for every image of the batch with equal ncomp)
+struct EncScan {
+    int ncomp, comp[CSH_MAX_COMPS];
+    int Ss, Se, Ah, Al;
+    int dc_tbl[CSH_MAX_COMPS];  // per scan component: index of its DC table inside this scan's table group
+    int ntables;                 // tables this scan defines (0 for DC refine)
+    int dht_id[2];               // (Tc<<4)|Th of each table of the group, in DHT emission order
+    int sos_tdta[CSH_MAX_COMPS]; // (Td<<4)|Ta byte of each scan component
+};
+
+// per (image, output scan) bookkeeping
+struct ScanWork {
+    int image, scan;
+    uint32_t nunits;       // lanes of work: blocks (AC, non-interleaved) or MCUs (interleaved DC)
+    uint32_t unit_base;    // offset of this scan in the flat per-unit arrays
+    uint32_t word_base;    // offset in the u64 bitmask arrays (AC scans), nwords = ceil(nunits/64)
+    uint32_t table_base;   // first of this scan's Huffman tables in the table pool
+    uint64_t raw_off;      // byte offset (multiple of 64) of the scan's unstuffed bytes in the raw pool (device-computed)
+    uint32_t raw_bytes;    // unstuffed length in bytes (device-computed)
+    uint32_t out_off;      // offset of this scan's DHT marker inside the image's output file (device-computed)
+    uint32_t hdr_bytes;    // DHT + SOS bytes in front of the entropy-coded data (device-computed)
+};
+
+// encoder-side Huffman table as generated on the device
+struct DevEncTable {
+    uint32_t freq[257];
+    uint8_t bits[17];
+    uint8_t vals[256];
+    uint16_t code[256];
+    uint8_t size[256];
+    int nsym;
+};
+
+}  // namespace csh

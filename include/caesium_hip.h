@@ -1,0 +1,135 @@
+/*
+ * caesium_hip.h -- C ABI of libcaesium_hip.so, the MI355X-native replacement for the three
+ * libcaesium entry points caesium-clt calls on its per-image hot path.
+ *
+ * Reference interface being replaced (Rust API, called from a rayon par_iter):
+ *   caesium::compress_in_memory          /root/reference/src/compressor.rs:305
+ *   caesium::compress_to_size_in_memory  /root/reference/src/compressor.rs:295,298
+ *   caesium::convert_in_memory           /root/reference/src/compressor.rs:289,300
+ *   parameter mapping (CSParameters)     /root/reference/src/compressor.rs:411-446, 503-536
+ *   SupportedFileTypes order             /root/reference/src/compressor.rs:589-598
+ *   the par_iter that becomes the batch  /root/reference/src/compressor.rs:74-101
+ * The struct layout mirrors libcaesium's own C interface (CCSParameters / CCSResult / CByteArray,
+ * SURVEY.md 2b) so a cgo/FFI binding written for libcaesium maps 1:1; INTEGRATION.md shows the
+ * Rust-side `extern "C"` block a maintainer would add.
+ *
+ * Conventions: nothing throws across this ABI; every call is thread-safe; inputs are borrowed for
+ * the duration of the call; outputs are callee-allocated and released with cs_free_bytes /
+ * cs_free_result.  The compute stages run on the GPU only: without a usable gfx950 device every
+ * compute entry point fails with code CS_ERR_NO_DEVICE -- there is no CPU fallback.
+ */
+#ifndef CAESIUM_HIP_H
+#define CAESIUM_HIP_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* caesium::SupportedFileTypes, in the order map_supported_formats() names them */
+enum { CS_TYPE_JPEG = 0, CS_TYPE_PNG = 1, CS_TYPE_GIF = 2, CS_TYPE_WEBP = 3, CS_TYPE_TIFF = 4, CS_TYPE_UNKN = 5 };
+
+/* error codes (CCSResult.code); 0 = success */
+enum {
+    CS_OK = 0,
+    CS_ERR_NO_DEVICE = 10001,      /* no gfx950 device / HIP runtime failure */
+    CS_ERR_UNKNOWN_TYPE = 10200,   /* magic bytes not recognised */
+    CS_ERR_UNSUPPORTED = 10201,    /* recognised, but this build has no device path for it yet */
+    CS_ERR_BAD_JPEG = 20100,       /* malformed / truncated JPEG */
+    CS_ERR_JPEG_FEATURE = 20101,   /* arithmetic coding, 12-bit, CMYK, unsupported sampling ... */
+    CS_ERR_POOL_OVERFLOW = 20200,  /* internal device pool too small even after retry */
+    CS_ERR_SAME_FORMAT = 10407,    /* convert_in_memory: source type == target type */
+    CS_ERR_TOO_BIG = 10500         /* compress_to_size: cannot reach max_output_size */
+};
+
+typedef struct {
+    bool keep_metadata;
+    uint32_t jpeg_quality;
+    uint32_t jpeg_chroma_subsampling; /* 444, 422, 420, 411, 0 = Auto */
+    bool jpeg_progressive;
+    bool jpeg_optimize;               /* true = lossless coefficient transcode (--lossless) */
+    bool jpeg_preserve_icc;
+    uint32_t png_quality;
+    uint32_t png_optimization_level;
+    bool png_force_zopfli;
+    bool png_optimize;
+    uint32_t gif_quality;
+    uint32_t webp_quality;
+    bool webp_lossless;
+    uint32_t tiff_compression;
+    uint32_t tiff_deflate_level;
+    uint32_t width;
+    uint32_t height;
+} CCSParameters;
+
+typedef struct {
+    bool success;
+    uint32_t code;
+    const char *error_message; /* callee-owned; release with cs_free_result */
+} CCSResult;
+
+typedef struct {
+    uint8_t *data; /* callee-allocated; release with cs_free_bytes */
+    size_t length;
+} CByteArray;
+
+/* CSParameters::new() defaults (quality 80, progressive, Auto subsampling, png level 3 ...) */
+void cs_default_parameters(CCSParameters *p);
+
+/* replaces caesium::compress_in_memory (compressor.rs:305) */
+CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, CByteArray *out);
+/* replaces caesium::compress_to_size_in_memory (compressor.rs:295,298); *p is in-out (quality fields
+   are overwritten while bisecting, as the reference's &mut CSParameters is) */
+CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size,
+                                        bool return_smallest, CByteArray *out);
+/* replaces caesium::convert_in_memory (compressor.rs:289,300) */
+CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out);
+
+/* start_compression's par_iter (compressor.rs:74-101) turned into a device batch queue:
+   results[i] / outputs[i] correspond to inputs[i] (order preserved, as compressor.rs:789-792 asserts).
+   device = HIP device ordinal.  Returns the number of failed items (per-item status in results). */
+int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device,
+                      CByteArray *outputs, CCSResult *results);
+
+void cs_free_bytes(CByteArray *b);
+void cs_free_result(CCSResult *r);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident batch interface: what bench.py times (inputs already in HBM) and what the stage
+ * parity tests poke at.  create = parse headers + upload entropy segments; run = the whole hot path
+ * on the device (entropy decode, pixel-domain transcode, entropy encode, byte assembly); fetch =
+ * copy the finished files back.
+ */
+typedef struct csh_batch csh_batch;
+
+enum { CSH_NPHASES = 8, CSH_NKERNELS = 24 };
+typedef struct {
+    float total_ms;               /* hipEvent time around the whole run, on the batch's stream */
+    float phase_ms[CSH_NPHASES];  /* 0 decode, 1 pixel transcode, 2 masks+flags+runs, 3 stats+tables,
+                                     4 size+scan, 5 pack, 6 stuff+assemble, 7 reserved */
+    float kernel_ms[CSH_NKERNELS];/* hipEvent time of every launch (names: csh_kernel_name) */
+    uint64_t in_bytes, out_bytes; /* entropy-coded bytes in, file bytes out */
+    uint64_t pixels;              /* source pixels processed */
+    uint64_t coef_bytes;          /* bytes of coefficient planes (one direction) */
+    uint32_t n_images, n_failed;
+} csh_timing;
+
+int csh_device_count(void);
+const char *csh_last_error(void);
+const char *csh_kernel_name(int slot);
+int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
+int csh_batch_run(csh_batch *b, csh_timing *t);
+int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results);
+void csh_batch_destroy(csh_batch *b);
+
+/* stage taps for the parity tests (copy device intermediates to host after csh_batch_run):
+   which = 0: decoded coefficients, 1: re-quantised coefficients.  dst receives the component's
+   [bh][bw][64] int16 blocks in ZIG-ZAG order.  Returns 0, or -1 (see csh_last_error). */
+int csh_batch_geometry(csh_batch *b, size_t image, int comp, int which, int *bw, int *bh, int *real_bw, int *real_bh);
+int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int which, int16_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

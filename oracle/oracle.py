@@ -114,6 +114,11 @@ class CoefImage:
         n = k.bw * k.bh * 64
         return np.ctypeslib.as_array(k.coef, shape=(n,)).reshape(k.bh, k.bw, 64).copy()
 
+    def coefs_view(self, ci):
+        """writable [bh][bw][64] view (natural order) of the oracle's own buffer -- for crafting test streams"""
+        k = self.im.comp[ci]
+        return np.ctypeslib.as_array(k.coef, shape=(k.bw * k.bh * 64,)).reshape(k.bh, k.bw, 64)
+
     def coefs_zigzag(self, ci):
         return self.coefs(ci)[:, :, ZZ]
 

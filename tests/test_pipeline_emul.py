@@ -1,0 +1,130 @@
+"""Kernel LOGIC tests on the CPU emulation build (tests/emul/README.md) + C-ABI surface checks.
+The parity tests proper are tests/test_pipeline_gpu.py (-m gpu)."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from _util import ROOT, emul_api, oracle_lossless, oracle_lossy, package
+from gen_synth import synth_jpeg, synth_rgb
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def params(**kw):
+    return package().default_parameters(**kw)
+
+
+@pytest.mark.parametrize("w,h,ss,tex", [(128, 96, 2, 45), (101, 67, 2, 0), (97, 61, 2, 80), (64, 48, 0, 30), (33, 31, 2, 60),
+                                         (8, 8, 2, 20), (1, 1, 2, 0), (17, 9, 0, 50), (250, 130, 2, 10), (16, 16, 0, 90)])
+def test_emul_bytes_equal_oracle(api, w, h, ss, tex):
+    src = synth_jpeg(7, w, h, subsampling=ss, texture=tex)
+    assert api.compress_in_memory(src, params()) == oracle_lossy(src)
+
+
+@pytest.mark.parametrize("q", [1, 25, 51, 95, 100])
+def test_emul_quality_sweep(api, q):
+    src = synth_jpeg(3, 120, 88, texture=35)
+    assert api.compress_in_memory(src, params(jpeg_quality=q)) == oracle_lossy(src, q)
+
+
+def test_emul_inputs_progressive_restart_gray_optimised(api):
+    from PIL import Image
+    srcs = [synth_jpeg(2, 104, 72, subsampling=2, progressive=True, texture=20), synth_jpeg(9, 160, 128, restart_rows=1, texture=15),
+            synth_jpeg(4, 150, 90, optimize=True, texture=40)]
+    g = Image.fromarray(synth_rgb(7, 203, 155, 20)).convert("L")
+    b = io.BytesIO(); g.save(b, format="JPEG", quality=90); srcs.append(b.getvalue())
+    for src, out in zip(srcs, api.batch_compress(srcs, params())):
+        assert out == oracle_lossy(src)
+
+
+def test_emul_lossless(api):
+    srcs = [synth_jpeg(21, 133, 122, texture=20), synth_jpeg(2, 104, 72, progressive=True, texture=30), synth_jpeg(8, 64, 64, subsampling=0)]
+    for src, out in zip(srcs, api.batch_compress(srcs, params(jpeg_optimize=True))):
+        assert out == oracle_lossless(src)
+
+
+def test_emul_long_eob_runs_and_flat_images(api):
+    """flat / near-flat images: EOB runs spanning thousands of blocks (incl. the 0x7FFF split at 520x512 luma blocks)"""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    imgs = [np.full((64, 64, 3), 128, np.uint8), np.full((4160, 4096, 3), 77, np.uint8)]
+    a = np.full((256, 256, 3), 90, np.uint8); a[100:108, 40:48] = rng.integers(0, 255, (8, 8, 3)); imgs.append(a)
+    for im in imgs:
+        b = io.BytesIO(); Image.fromarray(im).save(b, format="JPEG", quality=92, subsampling=2)
+        src = b.getvalue()
+        assert api.compress_in_memory(src, params()) == oracle_lossy(src)
+
+
+def crafted_corrbit_stream():
+    """every luma AC coefficient is +-2 or +-4 in a long stretch of blocks: at the last refinement scan each such block
+    carries 63 correction bits and no newly significant coefficient, so the pending-bits limit (937) forces EOBRUN flushes"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    base = O.forward(rng.integers(0, 255, (96, 256, 3), dtype=np.uint8), O.params(quality=90, subsampling=420))
+    y = base.coefs_view(0)
+    y[:, :, 1:] = rng.choice(np.array([-4, -2, 2, 4], dtype=np.int16), size=y[:, :, 1:].shape)
+    y[2, 5, 7] = 1      # one newly significant coefficient in the middle, and a few blocks with none at all
+    y[3, 0:4, 1:] = 0
+    return base.encode(O.params(progressive=1, marker_style=0))
+
+
+def test_emul_correction_bit_overflow_flush(api):
+    """refinement scans with > 937 pending correction bits force an early EOBRUN flush (jcphuff MAX_CORR_BITS)"""
+    blob = crafted_corrbit_stream()
+    assert api.compress_in_memory(blob, params(jpeg_optimize=True)) == oracle_lossless(blob)
+
+
+def test_emul_batch_order_and_errors(api):
+    good = [synth_jpeg(i, 80 + 8 * i, 64, texture=10 * i) for i in range(4)]
+    blobs = [good[0], b"not an image", good[1], good[2][:150], good[3], b"\x89PNG\r\n\x1a\n" + b"\0" * 32]
+    outs = api.batch_compress(blobs, params())
+    assert [isinstance(o, Exception) for o in outs] == [False, True, False, True, False, True]
+    assert outs[1].code == 10200 and outs[5].code == 10201
+    assert outs[0] == oracle_lossy(good[0]) and outs[4] == oracle_lossy(good[3])
+
+
+def test_emul_compress_to_size_and_convert(api):
+    src = synth_jpeg(12, 320, 200, texture=30)
+    p = params()
+    target = len(oracle_lossy(src, 60))
+    out = api.compress_to_size_in_memory(src, p, target)
+    assert len(out) <= target and len(out) > 0.9 * target
+    tiny = api.compress_to_size_in_memory(src, params(), 10, True)       # unreachable: smallest attempt comes back
+    assert tiny == oracle_lossy(src, tiny and 1)
+    with pytest.raises(package().CaesiumError) as e:
+        api.compress_to_size_in_memory(src, params(), 10, False)
+    assert e.value.code == 10500
+    with pytest.raises(package().CaesiumError) as e:
+        api.convert_in_memory(src, params(), 0)
+    assert e.value.code == 10407
+
+
+# ---- the product library: loads and exports everything include/caesium_hip.h declares (no compute without a GPU)
+def test_product_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "caesium_hip.h")).read()
+    declared = set(re.findall(r"\b(csh?_[a-z_0-9]+)\s*\(", hdr))
+    assert {"cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory", "cs_batch_compress"} <= declared
+    path = package().library_path()
+    assert os.path.exists(path), "libcaesium_hip.so not built (run __graft_entry__.build())"
+    lib = ctypes.CDLL(path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(package().binding.EXPORTS)
+
+
+def test_product_library_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    api = package().load()
+    assert api.device_count() == 0
+    with pytest.raises(package().CaesiumError) as e:
+        api.compress_in_memory(synth_jpeg(0, 64, 48), params())
+    assert e.value.code == 10001
