@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NPHASES = 8
-NKERNELS = 24
+NKERNELS = 32
 PHASE_NAMES = ["decode", "pixel", "masks_flags_runs", "stats_tables", "sizes_scan", "pack", "stuff_assemble", "reserved"]
 
 
@@ -26,7 +26,7 @@ class CByteArray(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("phase_ms", C.c_float * NPHASES), ("kernel_ms", C.c_float * NKERNELS), ("in_bytes", C.c_uint64), ("out_bytes", C.c_uint64),
-                ("pixels", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32)]
+                ("pixels", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32), ("n_seq_decoded", C.c_uint32), ("n_par_fallback", C.c_uint32)]
 
 
 class CaesiumError(RuntimeError):

@@ -37,13 +37,16 @@ struct dim3 {
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern int csh_emul_reverse;  // tests flip the (arbitrary) execution order to shake out order dependence
 template <class F, class... A>
 static inline void csh_emul_launch(F kern, dim3 grid, dim3 block, A... args) {
     gridDim = grid; blockDim = block;
-    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++) {
+    const bool rev = csh_emul_reverse != 0;
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bxi = 0; bxi < grid.x; bxi++) {
+        unsigned bx = rev ? grid.x - 1 - bxi : bxi;
         blockIdx = dim3(bx, by, bz);
-        for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned tx = 0; tx < block.x; tx++) {
-            threadIdx = dim3(tx, ty, tz);
+        for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned txi = 0; txi < block.x; txi++) {
+            threadIdx = dim3(rev ? block.x - 1 - txi : txi, ty, tz);
             kern(args...);
         }
     }

@@ -9,10 +9,6 @@
 
 namespace csh {
 
-__device__ static const uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-
 struct BitReader {
     const uint8_t *p, *end;
     uint64_t acc;
@@ -138,11 +134,17 @@ __device__ static void decode_block(BitReader &br, const DecScan &sc, bool progr
     }
 }
 
-__global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *scans, const DevHuffSet *huffs, int16_t *coef, int nimg) {
+__global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *scans, const DevHuffSet *huffs, int16_t *coef, int nimg,
+                             const uint32_t *need_seq) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nimg) return;
+    if (need_seq[i] == 0) return;  // the parallel decoder handled this image
     const ImgDesc &im = imgs[i];
-    (void)kZZ;
+    if (need_seq[i] == 2)          // the parallel decoder gave up half-way: start from clean tiles
+        for (int c = 0; c < im.ncomp; c++) {
+            int16_t *p = coef + size_t(im.in[c].tile_base) * CSH_TILE_I16;
+            for (size_t n = 0; n < size_t(im.in[c].ntiles) * CSH_TILE_I16; n++) p[n] = 0;
+        }
     for (int s = 0; s < im.nscans_in; s++) {
         const DecScan &sc = scans[im.first_scan + s];
         const DevHuffSet &hs = huffs[sc.huff_set];
@@ -176,8 +178,9 @@ __global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *
     }
 }
 
-void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const DecScan *scans, const DevHuffSet *huffs, int16_t *coef, int nimg) {
-    CSH_LAUNCH(k_decode_seq, dim3((nimg + 63) / 64), dim3(64), st, bits, imgs, scans, huffs, coef, nimg);
+void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const DecScan *scans, const DevHuffSet *huffs, int16_t *coef, int nimg,
+                       const uint32_t *need_seq) {
+    CSH_LAUNCH(k_decode_seq, dim3((nimg + 63) / 64), dim3(64), st, bits, imgs, scans, huffs, coef, nimg, need_seq);
 }
 
 }  // namespace csh

@@ -204,6 +204,15 @@ __device__ static int up_h2v2(const PlaneView &v, int r, int xx) {
     return (3 * cs + cn + ((xx & 1) ? 7 : 8)) >> 4;
 }
 
+// full-resolution sample (r, xx) of an h2v1-subsampled plane after fancy upsampling (jdsample h2v1_fancy_upsample;
+// its first/last-column special cases equal the replicate-clamped triangle filter)
+__device__ static int up_h2v1(const PlaneView &v, int r, int xx) {
+    int cx = xx >> 1;
+    if (v.cw <= 2) return pv(v, r, cx);
+    int nb = (xx & 1) ? cx + 1 : cx - 1;
+    return (3 * pv(v, r, cx) + pv(v, r, nb) + ((xx & 1) ? 2 : 1)) >> 2;
+}
+
 // generic (edge-block) path: out(y,x) = box of the four full-res samples under it, with libjpeg's clamps
 template <int MODE>
 __device__ static void resample_block_slow(const PlaneView &v, int W, int H, int out_ch, int by, int bx, int x[64]) {
@@ -217,7 +226,7 @@ __device__ static void resample_block_slow(const PlaneView &v, int W, int H, int
                     int r = 2 * ye + dy, xx = 2 * xo + dx;
                     r = r > H - 1 ? H - 1 : r;
                     xx = xx > W - 1 ? W - 1 : xx;
-                    sum += (MODE == 2) ? up_h2v2(v, r, xx) : pv(v, r, xx);
+                    sum += (MODE == 2) ? up_h2v2(v, r, xx) : (MODE == 4 ? up_h2v1(v, r, xx) : pv(v, r, xx));
                 }
             x[8 * Y + X] = (sum + ((xo & 1) ? 2 : 1)) >> 2;
         }
@@ -306,10 +315,10 @@ __global__ void __launch_bounds__(256) k_resample_fdct(const ImgDesc *imgs, cons
     if (w.mode == 2) {
         if (interior && gi.comp_w > 2) resample_block_420(v, gi.real_bh * 8, by, bx, x);
         else resample_block_slow<2>(v, W, H, go.comp_h, by, bx, x);
-    } else {
+    } else if (w.mode == 3) {
         if (interior && ((v.pitch & 15) == 0)) resample_block_box(v, by, bx, x);
         else resample_block_slow<3>(v, W, H, go.comp_h, by, bx, x);
-    }
+    } else resample_block_slow<4>(v, W, H, go.comp_h, by, bx, x);  // 4:2:2 source: generic path only (rare input)
     fdct_quant_store(x, quant[im.qt_out[w.comp]], dst);
 }
 

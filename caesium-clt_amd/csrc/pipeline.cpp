@@ -27,6 +27,8 @@ extern "C" const char *csh_last_error(void) { return g_err; }
 
 #ifdef CSH_EMUL
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+int csh_emul_reverse = 0;
+extern "C" void csh_emul_set_reverse(int r) { csh_emul_reverse = r; }
 #endif
 
 namespace csh {
@@ -81,6 +83,9 @@ struct csh_batch {
     std::vector<DevHuffSet> hsets;
     std::vector<DevQuant> quants;
     std::vector<PlaneWork> pwork;
+    std::vector<ParScan> pscans;
+    std::vector<uint32_t> need_seq_init;
+    uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
     std::vector<uint8_t> bits_pool, hdr_pool;
@@ -91,7 +96,11 @@ struct csh_batch {
     uint64_t raw_bytes_cap = 0, out_cap = 0;
 
     // device buffers
-    DevBuf<uint8_t> d_bits, d_planes, d_hdr, d_out, d_tail;
+    DevBuf<uint8_t> d_bits, d_clean, d_planes, d_hdr, d_out, d_tail;
+    DevBuf<ParScan> d_pscans;
+    DevBuf<uint64_t> d_pstate, d_relax_list[2], d_unstuff_off, d_blk_off, d_dc_off;
+    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt;
+    DevBuf<int32_t> d_dcdiff;
     DevBuf<ImgDesc> d_imgs;
     DevBuf<DecScan> d_dscans;
     DevBuf<DevHuffSet> d_hsets;
@@ -210,8 +219,9 @@ static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
     for (int c = 0; c < in.ncomp; c++) { o.comp[c].id = c + 1; o.comp[c].h = o.comp[c].v = 1; o.comp[c].tq = c ? 1 : 0; }
     if (in.ncomp == 3) {
         bool in444 = in.comp[0].h == 1 && in.comp[0].v == 1, in420 = in.comp[0].h == 2 && in.comp[0].v == 2;
+        bool in422 = in.comp[0].h == 2 && in.comp[0].v == 1;
         bool chroma11 = in.comp[1].h == 1 && in.comp[1].v == 1 && in.comp[2].h == 1 && in.comp[2].v == 1;
-        if (!chroma11 || !(in444 || in420)) { it.msg = "input chroma sampling other than 4:4:4 / 4:2:0 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
+        if (!chroma11 || !(in444 || in420 || in422)) { it.msg = "input chroma sampling other than 4:4:4 / 4:2:2 / 4:2:0 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
         if (ss == 420) { o.comp[0].h = 2; o.comp[0].v = 2; }
         else if (ss == 444) { if (!in444) { it.msg = "4:2:0 -> 4:4:4 not on the device path yet"; return CS_ERR_JPEG_FEATURE; } }
         else { it.msg = "output chroma subsampling 4:2:2 / 4:1:1 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
@@ -301,7 +311,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             ds.bits_off = uint32_t(b->bits_pool.size());
             ds.bits_len = uint32_t(js.data_len);
             b->bits_pool.insert(b->bits_pool.end(), d + js.data_off, d + js.data_off + js.data_len);
-            b->bits_pool.resize((b->bits_pool.size() + 15) & ~size_t(15));
+            b->bits_pool.resize((b->bits_pool.size() + 63) & ~size_t(63));
             ds.ncomp = js.ncomp;
             if (js.ncomp > CSH_MAX_COMPS) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "scan with more than 3 components"; break; }
             for (int k = 0; k < js.ncomp; k++) { ds.comp[k] = js.comp_idx[k]; ds.td[k] = js.td[k]; ds.ta[k] = js.ta[k]; }
@@ -334,6 +344,41 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         }
         if (it.code) { b->dscans.resize(im.first_scan); continue; }
 
+        // sequential-mode scans without restart markers go to the parallel self-synchronising decoder
+        bool par_ok = !in.progressive && in.restart_interval == 0;
+        for (const JScan &js : in.scans) if (js.data_len >= (1u << 28)) par_ok = false;
+        if (par_ok) {
+            for (size_t s = 0; s < in.scans.size(); s++) {
+                const JScan &js = in.scans[s];
+                const DecScan &ds = b->dscans[im.first_scan + s];
+                ParScan ps;
+                memset(&ps, 0, sizeof ps);
+                ps.bits_off = ds.bits_off; ps.bits_len = ds.bits_len; ps.huff_set = ds.huff_set; ps.image = img_index; ps.ncomp = js.ncomp;
+                int m = 0;
+                for (int k = 0; k < js.ncomp; k++) {
+                    const JComp &jc = in.comp[js.comp_idx[k]];
+                    int nh = js.ncomp > 1 ? jc.h : 1, nv = js.ncomp > 1 ? jc.v : 1;
+                    uint32_t nblocks = js.ncomp > 1 ? uint32_t(in.mcus_x * in.mcus_y * nh * nv) : uint32_t(jc.real_bw * jc.real_bh);
+                    for (int y = 0; y < nv; y++)
+                        for (int x = 0; x < nh; x++, m++) {
+                            if (m >= 10) break;
+                            ps.comp_of[m] = js.comp_idx[k]; ps.by_of[m] = y; ps.bx_of[m] = x; ps.dct[m] = js.td[k]; ps.act[m] = js.ta[k];
+                            ps.dc_base[m] = b->dc_total; ps.dc_per_mcu[m] = uint32_t(nh * nv); ps.dc_idx[m] = uint32_t(y * nh + x);
+                        }
+                    b->dc_total += nblocks;
+                    ps.total_blocks += nblocks;
+                }
+                ps.nb_mcu = m;
+                uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
+                ps.sub_base = b->total_sub; ps.par_index = uint32_t(b->pscans.size());
+                b->total_sub += nsub;
+                b->max_sub = std::max(b->max_sub, nsub);
+                b->max_par_blocks = std::max(b->max_par_blocks, ps.total_blocks);
+                b->pscans.push_back(ps);
+            }
+        }
+        b->need_seq_init.push_back(par_ok ? 0u : 1u);
+
         // pixel work + planes
         if (!b->lossless)
             for (int c = 0; c < in.ncomp; c++) {
@@ -341,7 +386,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 bool in_full = in.comp[c].h == in.hmax && in.comp[c].v == in.vmax;
                 bool out_full = o.comp[c].h == o.hmax && o.comp[c].v == o.vmax;
                 if (in_full && out_full) w.mode = 0;
-                else if (!in_full && !out_full) w.mode = 2;   // 4:2:0 chroma -> 4:2:0 chroma
+                else if (!in_full && !out_full) w.mode = (in.comp[c].v == in.vmax) ? 4 : 2;  // 4:2:2 / 4:2:0 chroma -> 4:2:0 chroma
                 else w.mode = 3;                               // full-res chroma -> h2v2 box
                 if (w.mode) {
                     im.plane_off[c] = plane_off;
@@ -397,8 +442,16 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_hdr.upload(b->hdr_pool, st) ||
-            b->d_hdr_off.upload(b->hdr_off, st))
+            b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
+        {
+            size_t nchunks = b->bits_pool.size() / 64 + 1, nst = size_t(b->total_sub) + b->pscans.size() + 1;
+            if (b->d_clean.alloc(b->bits_pool.size() + 64) || b->d_unstuff_cnt.alloc(nchunks + 1) || b->d_unstuff_off.alloc(nchunks + 2) ||
+                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(64) ||
+                b->d_nblk.alloc(size_t(b->total_sub) + 1) || b->d_blk_off.alloc(size_t(b->total_sub) + 2) || b->d_need_seq.alloc(b->nimg + 1) ||
+                b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2))
+                return CS_ERR_NO_DEVICE;
+        }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) ||
             b->d_masks.alloc(size_t(b->ntiles) * 192) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
             b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
@@ -416,10 +469,11 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
-    "memset_coef", "k_decode_seq", "k_idct_plane", "k_xform_direct", "k_resample_fdct", "k_fix_dummy", "memset_enc", "k_masks",
+    "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
+    "k_idct_plane", "k_xform_direct", "k_resample_fdct", "k_fix_dummy", "memset_enc", "k_masks",
     "k_ac_flags", "k_ac_runs", "k_stats", "k_gen_tables", "k_sizes", "scan_units", "scan_layout", "k_pack",
-    "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", ""};
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7};
+    "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", "", "", ""};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 
 static int run_once(csh_batch *b, csh_timing *t) {
@@ -429,7 +483,8 @@ static int run_once(csh_batch *b, csh_timing *t) {
     if (b->d_raw.n != raw_chunks * 16) {
         if (b->d_raw.alloc(raw_chunks * 16) || b->d_chunk_ff.alloc(raw_chunks + 1) || b->d_chunk_ffoff.alloc(raw_chunks + 2) || b->d_out.alloc(b->out_cap + 64))
             return -1;
-        size_t tmp = std::max(exclusive_scan_tmp_bytes(b->total_units), exclusive_scan_tmp_bytes(raw_chunks));
+        size_t tmp = std::max(std::max(exclusive_scan_tmp_bytes(b->total_units), exclusive_scan_tmp_bytes(raw_chunks)),
+                              std::max(exclusive_scan_tmp_bytes(b->dc_total), exclusive_scan_tmp_bytes(b->bits_pool.size() / 64 + 1)));
         if (b->d_scan_tmp.alloc(tmp)) return -1;
     }
     hipEvent_t ev[CSH_NKERNELS + 1];
@@ -440,8 +495,37 @@ static int run_once(csh_batch *b, csh_timing *t) {
     CSH_CHECK(hipEventRecord(ev[0], st));
     // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
     if (b->d_coef.zero(st) || b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
+    CSH_CHECK(hipMemcpyAsync(b->d_need_seq.p, b->d_need_seq_init.p, size_t(nimg) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     MARK();
-    launch_decode_seq(st, b->d_bits.p, b->d_imgs.p, b->d_dscans.p, b->d_hsets.p, b->d_coef.p, nimg);
+    {   // parallel self-synchronising decode of sequential-mode scans
+        int nps = int(b->pscans.size());
+        uint32_t nchunks = uint32_t(b->bits_pool.size() / 64);
+        if (nps) {
+            launch_unstuff_count(st, b->d_bits.p, b->d_pscans.p, nps, nchunks, b->d_unstuff_cnt.p);
+            launch_exclusive_scan(st, b->d_unstuff_cnt.p, b->d_unstuff_off.p, nchunks, b->d_scan_tmp.p, b->d_scan_tmp.n);
+            launch_unstuff_copy(st, b->d_bits.p, b->d_clean.p, b->d_pscans.p, nps, nchunks, b->d_unstuff_off.p);
+        }
+        MARK();
+        launch_dec_spec(st, b->d_clean.p, b->d_pscans.p, nps, b->max_sub, b->d_hsets.p, b->d_pstate.p);
+        MARK();
+        const int R = 20;  // list rounds after the dense one (each costs one near-empty launch once converged)
+        if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
+        launch_dec_relax_all(st, b->d_clean.p, b->d_pscans.p, nps, b->max_sub, b->d_hsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[0].p, b->d_relax_cnt.p);
+        MARK();
+        for (int it = 0; it < R && nps; it++)
+            launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, b->d_hsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
+                                  b->d_relax_cnt.p + it, b->d_relax_list[(it & 1) ^ 1].p, b->d_relax_cnt.p + it + 1);
+        if (nps) launch_dec_unconverged(st, b->d_pscans.p, b->total_sub, b->d_relax_list[R & 1].p, b->d_relax_cnt.p + R, b->d_need_seq.p);
+        MARK();
+        if (nps) launch_exclusive_scan(st, b->d_nblk.p, b->d_blk_off.p, b->total_sub, b->d_scan_tmp.p, b->d_scan_tmp.n);
+        launch_dec_write(st, b->d_clean.p, b->d_pscans.p, nps, b->max_sub, b->d_hsets.p, b->d_pstate.p, b->d_blk_off.p, b->d_imgs.p, b->d_coef.p,
+                         b->d_dcdiff.p, b->d_need_seq.p);
+        MARK();
+        if (nps) launch_exclusive_scan(st, reinterpret_cast<uint32_t *>(b->d_dcdiff.p), b->d_dc_off.p, b->dc_total, b->d_scan_tmp.p, b->d_scan_tmp.n);
+        launch_dc_scatter(st, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_dc_off.p, b->d_coef.p, b->d_need_seq.p);
+        MARK();
+    }
+    launch_decode_seq(st, b->d_bits.p, b->d_imgs.p, b->d_dscans.p, b->d_hsets.p, b->d_coef.p, nimg, b->d_need_seq.p);
     MARK();
     // ---- phase 1: pixel-domain transcode
     int nw = b->lossless ? 0 : int(b->pwork.size());
@@ -542,6 +626,9 @@ extern "C" int csh_batch_run(csh_batch *b, csh_timing *t) {
         csh_set_error("D2H of sizes failed"); return CS_ERR_NO_DEVICE;
     }
     if (t) {
+        std::vector<uint32_t> ns(b->nimg);
+        if (hipMemcpy(ns.data(), b->d_need_seq.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
+        for (uint32_t v : ns) { if (v) t->n_seq_decoded++; if (v == 2) t->n_par_fallback++; }
         t->n_images = uint32_t(b->nimg);
         for (const Item &it : b->items) if (it.image < 0) t->n_failed++;
         for (int i = 0; i < b->nimg; i++) { t->out_bytes += b->h_img_size[i]; t->pixels += uint64_t(b->imgs[i].width) * b->imgs[i].height; }

@@ -62,6 +62,20 @@ struct ImgDesc {
     uint32_t status;              // 0 ok; set by kernels on malformed data
 };
 
+// one sequential-mode scan handled by the parallel (self-synchronising) decoder, k_decode_par.hip
+#define CSH_SUBSEQ_BYTES 128
+struct ParScan {
+    uint32_t bits_off, bits_len;  // stuffed entropy segment in the bitstream pool (64-byte aligned)
+    uint32_t clean_len;           // unstuffed length (device-computed)
+    int huff_set, image, ncomp;
+    int nb_mcu;                   // blocks per MCU (1 for a non-interleaved scan)
+    int comp_of[10], by_of[10], bx_of[10], dct[10], act[10];
+    uint32_t total_blocks;        // blocks the scan must produce
+    uint32_t sub_base;            // first sub-sequence of this scan in the flat per-sub-sequence arrays
+    uint32_t par_index;           // index among ParScans (state arrays hold nsub+1 entries per scan)
+    uint32_t dc_base[10], dc_per_mcu[10], dc_idx[10];  // where block m's DC difference goes (scan order, per component)
+};
+
 // quantisation table as the kernels want it: zig-zag order, with exact-division helpers
 struct DevQuant {
     uint16_t q[64];      // table value, zig-zag order
@@ -72,7 +86,7 @@ struct DevQuant {
 // work item of the pixel kernels: one component of one image
 struct PlaneWork {
     int image, comp;
-    int mode;  // 0 direct (IDCT->FDCT, 1:1), 1 idct-to-plane, 2 plane h2v2up+h2v2down (4:2:0 -> 4:2:0), 3 plane h2v2 box down (4:4:4 -> 4:2:0)
+    int mode;  // 0 direct (IDCT->FDCT, 1:1), 1 idct-to-plane, 2 plane h2v2up+h2v2down (4:2:0 -> 4:2:0), 3 plane h2v2 box down (4:4:4 -> 4:2:0), 4 plane h2v1up+h2v2down (4:2:2 -> 4:2:0)
 };
 
 // one scan of the OUTPUT script (same for every image of the batch with equal ncomp)

@@ -103,7 +103,7 @@ void cs_free_result(CCSResult *r);
  */
 typedef struct csh_batch csh_batch;
 
-enum { CSH_NPHASES = 8, CSH_NKERNELS = 24 };
+enum { CSH_NPHASES = 8, CSH_NKERNELS = 32 };
 typedef struct {
     float total_ms;               /* hipEvent time around the whole run, on the batch's stream */
     float phase_ms[CSH_NPHASES];  /* 0 decode, 1 pixel transcode, 2 masks+flags+runs, 3 stats+tables,
@@ -113,6 +113,9 @@ typedef struct {
     uint64_t pixels;              /* source pixels processed */
     uint64_t coef_bytes;          /* bytes of coefficient planes (one direction) */
     uint32_t n_images, n_failed;
+    uint32_t n_seq_decoded;       /* images (re)done by the sequential decode kernel: progressive / DRI inputs, or
+                                     parallel-decoder fallbacks */
+    uint32_t n_par_fallback;      /* of those, images the parallel decoder started and gave up on */
 } csh_timing;
 
 int csh_device_count(void);

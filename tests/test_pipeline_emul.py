@@ -22,7 +22,7 @@ def params(**kw):
 
 
 @pytest.mark.parametrize("w,h,ss,tex", [(128, 96, 2, 45), (101, 67, 2, 0), (97, 61, 2, 80), (64, 48, 0, 30), (33, 31, 2, 60),
-                                         (8, 8, 2, 20), (1, 1, 2, 0), (17, 9, 0, 50), (250, 130, 2, 10), (16, 16, 0, 90)])
+                                         (8, 8, 2, 20), (1, 1, 2, 0), (17, 9, 0, 50), (250, 130, 2, 10), (16, 16, 0, 90), (104, 72, 1, 30), (33, 17, 1, 60), (3, 5, 1, 10)])
 def test_emul_bytes_equal_oracle(api, w, h, ss, tex):
     src = synth_jpeg(7, w, h, subsampling=ss, texture=tex)
     assert api.compress_in_memory(src, params()) == oracle_lossy(src)
@@ -42,6 +42,45 @@ def test_emul_inputs_progressive_restart_gray_optimised(api):
     b = io.BytesIO(); g.save(b, format="JPEG", quality=90); srcs.append(b.getvalue())
     for src, out in zip(srcs, api.batch_compress(srcs, params())):
         assert out == oracle_lossy(src)
+
+
+def test_emul_parallel_decoder_is_the_path_taken(api):
+    """baseline (sequential, no DRI) inputs go through the self-synchronising decoder without falling back"""
+    blobs = [synth_jpeg(i, 400, 300, texture=15 * i) for i in range(4)] + [synth_jpeg(9, 320, 240, optimize=True, texture=60)]
+    blobs += [synth_jpeg(2, 104, 72, progressive=True), synth_jpeg(9, 160, 128, restart_rows=1)]
+    b = api.batch(blobs, params())
+    t = b.run()
+    assert t.n_images == 7 and t.n_seq_decoded == 2 and t.n_par_fallback == 0
+    for src, out in zip(blobs, b.fetch()):
+        assert out == oracle_lossy(src)
+
+
+def test_emul_relaxation_is_order_independent(api):
+    """the emulation normally runs lanes in ascending order, which lets the in-place relaxation converge in its first
+    sweep; running every launch in DESCENDING order forces the work-list rounds a real GPU needs (and every atomics-based
+    kernel to cope with another arrival order).  Bytes must not change."""
+    import ctypes
+    blobs = [synth_jpeg(1, 640, 360, texture=25), synth_jpeg(4, 333, 222, subsampling=0, texture=50), synth_jpeg(2, 104, 72, progressive=True)]
+    api.L.csh_emul_set_reverse.argtypes = [ctypes.c_int]
+    api.L.csh_emul_set_reverse(1)
+    try:
+        b = api.batch(blobs, params())
+        t = b.run()
+        outs = b.fetch()
+    finally:
+        api.L.csh_emul_set_reverse(0)
+    assert t.n_par_fallback == 0 and t.n_seq_decoded == 1
+    for src, out in zip(blobs, outs):
+        assert out == oracle_lossy(src)
+
+
+def test_emul_truncated_stream_falls_back_and_matches_sequential_semantics(api):
+    src = synth_jpeg(3, 200, 150, texture=30)
+    cut = src[:len(src) * 2 // 3] + b"\xff\xd9"
+    b = api.batch([cut], params())
+    t = b.run()
+    assert t.n_par_fallback == 1
+    assert b.fetch()[0] == oracle_lossy(cut)
 
 
 def test_emul_lossless(api):

@@ -43,7 +43,7 @@ def test_golden_vectors_through_c_abi(api):
 
 
 @pytest.mark.parametrize("w,h,ss,tex", [(128, 96, 2, 45), (101, 67, 2, 0), (97, 61, 2, 80), (64, 48, 0, 30), (33, 31, 2, 60),
-                                         (8, 8, 2, 20), (1, 1, 2, 0), (17, 9, 0, 50), (640, 360, 2, 25), (250, 130, 2, 10)])
+                                         (8, 8, 2, 20), (1, 1, 2, 0), (17, 9, 0, 50), (640, 360, 2, 25), (250, 130, 2, 10), (104, 72, 1, 30), (33, 17, 1, 60)])
 def test_bytes_equal_oracle(api, w, h, ss, tex):
     src = synth_jpeg(7, w, h, subsampling=ss, texture=tex)
     assert api.compress_in_memory(src, params()) == oracle_lossy(src)
