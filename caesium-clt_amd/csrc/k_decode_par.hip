@@ -32,37 +32,51 @@ __device__ static int scan_of_byte(const ParScan *ps, int nps, uint32_t byte) {
     return lo;
 }
 
-__global__ void __launch_bounds__(256) k_unstuff_count(const uint8_t *__restrict__ raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt) {
+// a stuffed zero = 0x00 that follows 0xFF inside the scan (T.81 F.1.2.3).  One lane per 64-byte chunk; the chunk and the
+// byte in front of it are pulled into registers first, then a 64-bit "delete" mask drives both the count and the copy.
+__device__ __forceinline__ static uint64_t stuffed_mask(const uint8_t *raw, uint32_t b0, uint32_t lo, uint32_t end, uint8_t bytes[64]) {
+    uint64_t del = 0;
+    unsigned prev = (b0 > lo) ? raw[b0 - 1] : 0u;
+    for (int i = 0; i < 64; i++) {
+        unsigned v = (b0 + i < end) ? raw[b0 + i] : 0x55u;
+        bytes[i] = uint8_t(v);
+        if (b0 + i < end && prev == 0xFFu && v == 0u) del |= 1ull << i;
+        prev = v;
+    }
+    return del;
+}
+
+__global__ void __launch_bounds__(256) k_unstuff_count(const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     uint32_t n = 0, b0 = c * 64;
     if (nps) {
         const ParScan &s = ps[scan_of_byte(ps, nps, b0)];
         uint32_t end = s.bits_off + s.bits_len;
-        for (uint32_t j = b0; j < b0 + 64 && j < end; j++)
-            if (j > s.bits_off && raw[j] == 0 && raw[j - 1] == 0xFF) n++;
+        if (b0 < end) { uint8_t bytes[64]; n = uint32_t(__popcll(stuffed_mask(raw, b0, s.bits_off, end, bytes))); }
     }
     cnt[c] = n;
 }
 
-__global__ void __launch_bounds__(256) k_unstuff_copy(const uint8_t *__restrict__ raw, uint8_t *__restrict__ clean, ParScan *ps, int nps,
-                                                       uint32_t nchunks, const uint64_t *__restrict__ off) {
+__global__ void __launch_bounds__(256) k_unstuff_copy(const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks || !nps) return;
     uint32_t b0 = c * 64;
     int si = scan_of_byte(ps, nps, b0);
-    ParScan &s = ps[si];
-    uint32_t end = s.bits_off + s.bits_len;
+    const uint32_t lo = ps[si].bits_off, len = ps[si].bits_len, end = lo + len;
     if (b0 >= end) return;
-    uint32_t removed = uint32_t(off[c] - off[s.bits_off >> 6]);
-    uint8_t *o = clean + b0 - removed;
-    for (uint32_t j = b0; j < b0 + 64 && j < end; j++) {
-        if (j > s.bits_off && raw[j] == 0 && raw[j - 1] == 0xFF) continue;
-        *o++ = raw[j];
+    uint32_t removed = uint32_t(off[c] - off[lo >> 6]);
+    uint8_t bytes[64];
+    uint64_t del = stuffed_mask(raw, b0, lo, end, bytes);
+    uint32_t o = b0 - removed;
+    for (int i = 0; i < 64; i++) {
+        if (b0 + i >= end) break;
+        if ((del >> i) & 1) continue;
+        clean[o++] = bytes[i];
     }
     if (b0 + 64 >= end) {  // last chunk of the scan: publish the unstuffed length
         uint32_t last_chunk = (end + 63) >> 6;
-        s.clean_len = s.bits_len - uint32_t(off[last_chunk] - off[s.bits_off >> 6]);
+        ps[si].clean_len = len - uint32_t(off[last_chunk] - off[lo >> 6]);
     }
 }
 
