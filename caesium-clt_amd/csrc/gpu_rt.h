@@ -19,6 +19,15 @@
 #include <hip/hip_runtime.h>
 #define CSH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 #define CSH_UNROLL _Pragma("unroll")
+// Kernels that need workgroup barriers are written as a loop over "phases":
+//     CSH_SHARED int lds[...];
+//     CSH_PHASE_LOOP(3) { if (phase == 0) {...; continue;} ... }
+// On the GPU the loop's increment is the __syncthreads(), so `continue` is the only legal early exit of a phase
+// (never `return`: every lane must reach every barrier).  The emulation runs phase p for ALL lanes of a workgroup
+// before phase p+1, which is exactly the ordering the barrier gives.
+#define CSH_SHARED __shared__
+#define CSH_PHASE_LOOP(NPH) for (int phase = 0; phase < (NPH); ((phase + 1 < (NPH)) ? __syncthreads() : (void)0), phase++)
+#define CSH_LAUNCH_PHASED(kern, nph, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 #else
 // ------------------------------------------------------------------ emulation shims
 #include <algorithm>
@@ -52,6 +61,26 @@ static inline void csh_emul_launch(F kern, dim3 grid, dim3 block, A... args) {
     }
 }
 #define CSH_LAUNCH(kern, grid, block, stream, ...) csh_emul_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
+#define CSH_SHARED static
+extern thread_local int csh_emul_phase;
+#define CSH_PHASE_LOOP(NPH) for (int phase = csh_emul_phase, once_ = 1; once_; once_ = 0)
+template <class F, class... A>
+static inline void csh_emul_launch_phased(F kern, int nph, dim3 grid, dim3 block, A... args) {
+    gridDim = grid; blockDim = block;
+    const bool rev = csh_emul_reverse != 0;
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bxi = 0; bxi < grid.x; bxi++) {
+        blockIdx = dim3(rev ? grid.x - 1 - bxi : bxi, by, bz);
+        for (int ph = 0; ph < nph; ph++) {
+            csh_emul_phase = ph;
+            for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned txi = 0; txi < block.x; txi++) {
+                threadIdx = dim3(rev ? block.x - 1 - txi : txi, ty, tz);
+                kern(args...);
+            }
+        }
+    }
+    csh_emul_phase = 0;
+}
+#define CSH_LAUNCH_PHASED(kern, nph, grid, block, stream, ...) csh_emul_launch_phased(kern, nph, dim3(grid), dim3(block), __VA_ARGS__)
 typedef int hipError_t;
 typedef int hipStream_t;
 struct csh_emul_event { std::chrono::steady_clock::time_point t; };

@@ -99,12 +99,22 @@ struct PReader {
         for (int i = 0; i < 4; i++) v = (v << 8) | (b + i < len ? base[b + i] : 0u);
         return v;
     }
-    __device__ __forceinline__ uint32_t peek32(uint32_t pos) const {
-        uint32_t wi = pos >> 5, o = pos & 31;
-        uint64_t w = (uint64_t(word(wi)) << 32) | word(wi + 1);
-        return uint32_t((w << o) >> 32);
-    }
 };
+// the lane's slice of the stream staged in LDS: row[r] = big-endian word (w0 + r) for r < CSH_LROW_WORDS, global beyond
+#define CSH_LROW_WORDS 36   // 128-byte sub-sequence + 16 bytes of look-ahead
+#define CSH_LROW_STRIDE 37  // odd stride: lanes hit distinct banks
+struct LReader {
+    const uint32_t *row;
+    uint32_t w0;
+    PReader g;
+    __device__ __forceinline__ uint32_t word(uint32_t wi) const { uint32_t r = wi - w0; return r < CSH_LROW_WORDS ? row[r] : g.word(wi); }
+};
+template <class R>
+__device__ __forceinline__ static uint32_t peek32(const R &rd, uint32_t pos) {
+    uint32_t wi = pos >> 5, o = pos & 31;
+    uint64_t w = (uint64_t(rd.word(wi)) << 32) | rd.word(wi + 1);
+    return uint32_t((w << o) >> 32);
+}
 
 __device__ __forceinline__ static int huff_lookup(const DevHuff &h, uint32_t top16, int &len) {
     int e = h.look[top16 >> 7];
@@ -119,8 +129,8 @@ __device__ __forceinline__ static int huff_lookup(const DevHuff &h, uint32_t top
 __device__ __forceinline__ static int extend_p(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
 
 // decode from state `st` until st.pos >= stop_bit; returns #blocks completed.  WRITE: store coefficients.
-template <bool WRITE>
-__device__ static uint32_t decode_span(const PReader &rd, const DevHuffSet &hs, const ParScan &ps, PState &st, uint32_t stop_bit,
+template <bool WRITE, class R>
+__device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuffSet &hs, const ParScan &ps, PState &st, uint32_t stop_bit,
                                         uint32_t ordinal, const ImgDesc *im, int16_t *coef, int32_t *dcdiff) {
     uint32_t nblk = 0;
     int16_t *blk = nullptr;
@@ -138,13 +148,13 @@ __device__ static uint32_t decode_span(const PReader &rd, const DevHuffSet &hs, 
     };
     locate(ordinal);
     while (st.pos < stop_bit) {
-        uint32_t w = rd.peek32(st.pos);
+        uint32_t w = peek32(rd, st.pos);
         int len;
         if (st.k == 0) {
             int t = huff_lookup(hs.dc[ps.dct[st.m]], w >> 16, len);
             if (WRITE && ordinal + nblk < ps.total_blocks) {
                 int diff = 0;
-                if (t) { uint32_t w2 = rd.peek32(st.pos + len); diff = extend_p(int(w2 >> (32 - t)), t); }
+                if (t) { uint32_t w2 = peek32(rd, st.pos + len); diff = extend_p(int(w2 >> (32 - t)), t); }
                 dcdiff[ps.dc_base[st.m] + (ordinal + nblk) / uint32_t(ps.nb_mcu) * ps.dc_per_mcu[st.m] + ps.dc_idx[st.m]] = diff;
             }
             st.pos += len + t;
@@ -157,7 +167,7 @@ __device__ static uint32_t decode_span(const PReader &rd, const DevHuffSet &hs, 
                 st.k += r;
                 if (st.k > 63) st.k = 64;  // corrupt run: block ends (no extra bits consumed, as the sequential path)
                 else {
-                    if (WRITE && blk) { uint32_t w2 = rd.peek32(st.pos); blk[st.k << 6] = int16_t(extend_p(int(w2 >> (32 - n)), n)); }
+                    if (WRITE && blk) { uint32_t w2 = peek32(rd, st.pos); blk[st.k << 6] = int16_t(extend_p(int(w2 >> (32 - n)), n)); }
                     st.pos += n;
                     st.k++;
                 }
@@ -172,22 +182,6 @@ __device__ static uint32_t decode_span(const PReader &rd, const DevHuffSet &hs, 
         }
     }
     return nblk;
-}
-
-// pass A: speculative state at every cut
-__global__ void __launch_bounds__(256) k_dec_spec(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state) {
-    const ParScan &ps = pss[blockIdx.y];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
-    if (t >= nsub) return;
-    uint64_t *s = state + ps.sub_base + ps.par_index;  // nsub+1 entries per scan
-    PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = 0;
-    if (t == 0) s[0] = pack_state(st);
-    if (t * CSH_SUBSEQ_BYTES >= ps.clean_len) { s[t + 1] = 0; return; }  // sub-sequence lies in the slack the unstuffing freed
-    PReader rd; rd.base = clean + ps.bits_off; rd.len = ps.clean_len;
-    uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
-    decode_span<false>(rd, huffs[ps.huff_set], ps, st, stop, 0, nullptr, nullptr, nullptr);
-    s[t + 1] = pack_state(st);
 }
 
 // pass B: relaxation  s[t+1] = F_t(s[t]), in place.  Only the lane of sub-sequence t-1 ever writes s[t]; whenever it
@@ -208,16 +202,6 @@ __device__ __forceinline__ static void relax_one(const uint8_t *clean, const Par
     }
 }
 
-__global__ void __launch_bounds__(256) k_dec_relax_all(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
-                                                        uint64_t *list_out, uint32_t *cnt_out) {
-    const ParScan &ps = pss[blockIdx.y];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
-    if (t >= nsub) return;
-    if (t * CSH_SUBSEQ_BYTES >= ps.clean_len) { nblk[ps.sub_base + t] = 0; return; }
-    relax_one(clean, ps, huffs, state, nblk, t, list_out, cnt_out);
-}
-
 __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                                                          const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,23 +217,70 @@ __global__ void __launch_bounds__(256) k_dec_unconverged(const ParScan *pss, con
     need_seq[pss[uint32_t(list_in[j] >> 32)].image] = 2;
 }
 
-// pass W: decode from the true states and store
-__global__ void __launch_bounds__(256) k_dec_write(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, const uint64_t *state,
-                                                    const uint64_t *blk_off, const ImgDesc *imgs, int16_t *coef, int32_t *dcdiff, uint32_t *need_seq) {
-    const ParScan &ps = pss[blockIdx.y];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
-    if (t >= nsub) return;
-    if (need_seq[ps.image]) return;
-    PState st = unpack_state(state[ps.sub_base + ps.par_index + t]);
-    uint32_t ordinal = uint32_t(blk_off[ps.sub_base + t] - blk_off[ps.sub_base]);
-    if (t == nsub - 1) {  // the whole scan must have produced exactly its blocks
-        uint32_t total = uint32_t(blk_off[ps.sub_base + nsub] - blk_off[ps.sub_base]);
-        if (total < ps.total_blocks) need_seq[ps.image] = 2;
+// ---- dense passes (every sub-sequence of every scan): a workgroup = 256 consecutive sub-sequences of one scan.
+// Phase 0 stages what the lanes will hammer -- the scan's Huffman LUTs and the workgroup's 32 KiB slice of the stream --
+// into LDS with coalesced loads (global reads by 64 lanes at a 128-byte stride would cost 64 line requests per load);
+// phase 1 decodes out of LDS.  MODE 0: speculate from the guess state, 1: relax in place, 2: write coefficients.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
+    CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
+    CSH_SHARED DevHuffSet lhs;
+    const ParScan &ps = a.pss[blockIdx.y];
+    const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
+    const uint32_t t0 = blockIdx.x * 256, tid = threadIdx.x, t = t0 + tid;
+    const bool wg_live = t0 < nsub && t0 * CSH_SUBSEQ_BYTES < ps.clean_len && !(MODE == 2 && a.need_seq[ps.image] == 1);
+    PReader g; g.base = a.clean + ps.bits_off; g.len = ps.clean_len;
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) {
+            if (MODE == 1 && t < nsub && t * CSH_SUBSEQ_BYTES >= ps.clean_len) a.nblk[ps.sub_base + t] = 0;
+            if (!wg_live) continue;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.huffs[ps.huff_set]);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
+            for (uint32_t i = tid; i < sizeof(DevHuffSet) / 4; i += 256) dst[i] = src[i];
+            const uint32_t w_first = t0 * (CSH_SUBSEQ_BYTES / 4);
+            for (uint32_t i = 0; i < CSH_SUBSEQ_BYTES / 4 + 1; i++) {  // 33 x 256 words cover 256*32 + 4 look-ahead words
+                uint32_t d = i * 256 + tid;
+                if (d >= 256 * (CSH_SUBSEQ_BYTES / 4) + (CSH_LROW_WORDS - CSH_SUBSEQ_BYTES / 4)) break;
+                uint32_t v = g.word(w_first + d);
+                uint32_t lane = d / (CSH_SUBSEQ_BYTES / 4), off = d % (CSH_SUBSEQ_BYTES / 4);
+                if (lane < 256) lbits[lane * CSH_LROW_STRIDE + off] = v;
+                if (off < CSH_LROW_WORDS - CSH_SUBSEQ_BYTES / 4 && lane > 0) lbits[(lane - 1) * CSH_LROW_STRIDE + CSH_SUBSEQ_BYTES / 4 + off] = v;
+            }
+            continue;
+        }
+        if (!wg_live || t >= nsub) continue;
+        size_t base = ps.sub_base + ps.par_index;
+        const bool live = t * CSH_SUBSEQ_BYTES < ps.clean_len;
+        LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g = g;
+        const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+        if (MODE == 0) {
+            PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = 0;
+            if (t == 0) a.state[base] = pack_state(st);
+            if (!live) { a.state[base + t + 1] = 0; continue; }
+            decode_span<false>(rd, lhs, ps, st, stop, 0, nullptr, nullptr, nullptr);
+            a.state[base + t + 1] = pack_state(st);
+        } else if (MODE == 1) {
+            if (!live) continue;
+            PState st = unpack_state(a.state[base + t]);
+            uint32_t n = decode_span<false>(rd, lhs, ps, st, stop, 0, nullptr, nullptr, nullptr);
+            a.nblk[ps.sub_base + t] = n;
+            uint64_t e = pack_state(st);
+            if (e != a.state[base + t + 1]) {
+                a.state[base + t + 1] = e;
+                if ((t + 1) * CSH_SUBSEQ_BYTES < ps.clean_len) a.list_out[atomicAdd(a.cnt_out, 1u)] = (uint64_t(ps.par_index) << 32) | (t + 1);
+            }
+        } else {
+            if (a.need_seq[ps.image]) continue;
+            uint32_t ordinal = uint32_t(a.blk_off[ps.sub_base + t] - a.blk_off[ps.sub_base]);
+            if (t == nsub - 1 || (live && (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len)) {  // the scan must have produced all its blocks
+                uint32_t total = uint32_t(a.blk_off[ps.sub_base + nsub] - a.blk_off[ps.sub_base]);
+                if (total < ps.total_blocks) a.need_seq[ps.image] = 2;
+            }
+            if (!live || ordinal >= ps.total_blocks) continue;
+            PState st = unpack_state(a.state[base + t]);
+            decode_span<true>(rd, lhs, ps, st, stop, ordinal, &a.imgs[ps.image], a.coef, a.dcdiff);
+        }
     }
-    if (t * CSH_SUBSEQ_BYTES >= ps.clean_len || ordinal >= ps.total_blocks) return;
-    PReader rd; rd.base = clean + ps.bits_off; rd.len = ps.clean_len;
-    decode_span<true>(rd, huffs[ps.huff_set], ps, st, (t + 1) * CSH_SUBSEQ_BYTES * 8, ordinal, &imgs[ps.image], coef, dcdiff);
 }
 
 // DC: prefix sums of the differences (scan order) -> absolute DC at zig-zag row 0 of the tiles
@@ -277,12 +308,12 @@ void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps,
 void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off) {
     if (nchunks) CSH_LAUNCH(k_unstuff_copy, dim3((nchunks + 255) / 256), dim3(256), st, raw, clean, ps, nps, nchunks, off);
 }
-void launch_dec_spec(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_sub, const DevHuffSet *huffs, uint64_t *state) {
-    if (nps) CSH_LAUNCH(k_dec_spec, dim3((max_sub + 255) / 256, nps), dim3(256), st, clean, ps, huffs, state);
-}
-void launch_dec_relax_all(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_sub, const DevHuffSet *huffs, uint64_t *state,
-                          uint32_t *nblk, uint64_t *list_out, uint32_t *cnt_out) {
-    if (nps) CSH_LAUNCH(k_dec_relax_all, dim3((max_sub + 255) / 256, nps), dim3(256), st, clean, ps, huffs, state, nblk, list_out, cnt_out);
+void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const DenseArgs &a) {
+    if (!nps) return;
+    dim3 grid((max_sub + 255) / 256, nps);
+    if (mode == 0) CSH_LAUNCH_PHASED(k_dec_dense<0>, 2, grid, dim3(256), st, a);
+    else if (mode == 1) CSH_LAUNCH_PHASED(k_dec_dense<1>, 2, grid, dim3(256), st, a);
+    else CSH_LAUNCH_PHASED(k_dec_dense<2>, 2, grid, dim3(256), st, a);
 }
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
@@ -290,10 +321,6 @@ void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *
 }
 void launch_dec_unconverged(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *need_seq) {
     if (total_sub) CSH_LAUNCH(k_dec_unconverged, dim3((total_sub + 255) / 256), dim3(256), st, ps, list_in, cnt_in, need_seq);
-}
-void launch_dec_write(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_sub, const DevHuffSet *huffs, const uint64_t *state,
-                      const uint64_t *blk_off, const ImgDesc *imgs, int16_t *coef, int32_t *dcdiff, uint32_t *need_seq) {
-    if (nps) CSH_LAUNCH(k_dec_write, dim3((max_sub + 255) / 256, nps), dim3(256), st, clean, ps, huffs, state, blk_off, imgs, coef, dcdiff, need_seq);
 }
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq) {

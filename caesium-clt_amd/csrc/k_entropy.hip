@@ -66,23 +66,31 @@ __device__ __forceinline__ static AcMasks ac_masks(const uint64_t *masks, const 
     return m;
 }
 
-// ---- pass A: per-block flags of every AC scan
+// ---- pass A: per-block flags of every AC scan.  Lane = block, so a wave's 64 has-symbol / ends-with-EOB flags ARE one
+// word of the scan's bit vectors: one ballot, one 8-byte store, no atomics.
 __global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
     const ScanWork w = c.work[blockIdx.y];
     const EncScan sc = c.script[w.scan];
     if (sc.Ss == 0) return;
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= w.nunits) return;
-    const CompGeom &g = c.imgs[w.image].out[sc.comp[0]];
-    AcMasks m = ac_masks(c.masks, g, unit_block(g, u), sc);
-    uint64_t S = sc.Ah == 0 ? m.NZ : m.N;
-    bool has_sym = S != 0;
-    bool ends_eob = !((S >> sc.Se) & 1);
-    int tail = 0;
-    if (sc.Ah) tail = S ? __popcll(m.H & ~((2ull << msb64(S)) - 1)) : __popcll(m.H);
+    bool has_sym = false, ends_eob = false;
+    if (u < w.nunits) {
+        const CompGeom &g = c.imgs[w.image].out[sc.comp[0]];
+        AcMasks m = ac_masks(c.masks, g, unit_block(g, u), sc);
+        uint64_t S = sc.Ah == 0 ? m.NZ : m.N;
+        has_sym = S != 0;
+        ends_eob = !((S >> sc.Se) & 1);
+        int tail = 0;
+        if (sc.Ah) tail = S ? __popcll(m.H & ~((2ull << msb64(S)) - 1)) : __popcll(m.H);
+        c.tail[w.unit_base + u] = uint8_t(tail);
+    }
+#ifdef CSH_EMUL
     if (has_sym) atomicOr(reinterpret_cast<unsigned long long *>(c.sym_bits + w.word_base + (u >> 6)), 1ull << (u & 63));
     if (ends_eob) atomicOr(reinterpret_cast<unsigned long long *>(c.eob_bits + w.word_base + (u >> 6)), 1ull << (u & 63));
-    c.tail[w.unit_base + u] = uint8_t(tail);
+#else
+    uint64_t ms = __ballot(has_sym), me = __ballot(ends_eob);
+    if ((threadIdx.x & 63) == 0 && (u >> 6) < ((w.nunits + 63) >> 6)) { c.sym_bits[w.word_base + (u >> 6)] = ms; c.eob_bits[w.word_base + (u >> 6)] = me; }
+#endif
 }
 
 // ---- pass B: EOB run structure -> EOBRUN value owned by the first block of each (sub-)run
@@ -296,15 +304,37 @@ __device__ __forceinline__ static void walk_unit(Sink &sink, const EncCtx &c, co
     else walk_ac_refine(sink, blk, m.H, m.N, sc, run);
 }
 
-// ---- pass C: symbol statistics
+// ---- pass C: symbol statistics.  A workgroup walks CSH_STATS_CHUNK consecutive units of one scan into an LDS histogram
+// (ds_add), then flushes the non-zero bins with one global atomic each.
+#define CSH_STATS_CHUNK 2048
+struct LdsStatsSink {
+    uint32_t *hist;  // [2][257] in LDS
+    static constexpr bool kValues = false;
+    __device__ __forceinline__ void sym(int t, int s) { atomicAdd(&hist[t * 257 + s], 1u); }
+    __device__ __forceinline__ void syms(int t, int s, int n) { if (n) atomicAdd(&hist[t * 257 + s], unsigned(n)); }
+    __device__ __forceinline__ void raw(unsigned, int) {}
+    __device__ __forceinline__ void rawcount(int) {}
+};
 __global__ void __launch_bounds__(256) k_stats(EncCtx c) {
+    CSH_SHARED uint32_t hist[2 * 257];
     const ScanWork w = c.work[blockIdx.y];
     const EncScan sc = c.script[w.scan];
-    if (sc.ntables == 0) return;
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= w.nunits) return;
-    StatsSink s; s.tab = c.tables + w.table_base;
-    walk_unit(s, c, w, sc, u);
+    CSH_PHASE_LOOP(3) {
+        if (sc.ntables == 0 || blockIdx.x * CSH_STATS_CHUNK >= w.nunits) continue;
+        if (phase == 0) { for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) hist[i] = 0; continue; }
+        if (phase == 1) {
+            LdsStatsSink s; s.hist = hist;
+            for (uint32_t i = 0; i < CSH_STATS_CHUNK / 256; i++) {
+                uint32_t u = blockIdx.x * CSH_STATS_CHUNK + i * 256 + threadIdx.x;
+                if (u < w.nunits) walk_unit(s, c, w, sc, u);
+            }
+            continue;
+        }
+        for (int i = threadIdx.x; i < sc.ntables * 257; i += blockDim.x) {
+            uint32_t v = hist[i];
+            if (v) atomicAdd(&c.tables[w.table_base + i / 257].freq[i % 257], v);
+        }
+    }
 }
 
 // ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour), one lane per table
@@ -383,7 +413,9 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
 static dim3 unit_grid(const EncCtx &c) { return dim3((c.max_units + 255) / 256, c.nwork); }
 void launch_ac_flags(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_ac_flags, unit_grid(c), dim3(256), st, c); }
 void launch_ac_runs(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c); }
-void launch_stats(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_stats, unit_grid(c), dim3(256), st, c); }
+void launch_stats(hipStream_t st, const EncCtx &c) {
+    if (c.nwork) CSH_LAUNCH_PHASED(k_stats, 3, dim3((c.max_units + CSH_STATS_CHUNK - 1) / CSH_STATS_CHUNK, c.nwork), dim3(256), st, c);
+}
 void launch_sizes(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_sizes, unit_grid(c), dim3(256), st, c); }
 void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_pack, unit_grid(c), dim3(256), st, c); }
 

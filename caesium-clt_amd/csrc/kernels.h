@@ -16,14 +16,15 @@ void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const
 // parallel self-synchronising decoder (k_decode_par.hip); need_seq[image] != 0 -> the sequential kernel (re)does it
 void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt);
 void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off);
-void launch_dec_spec(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_sub, const DevHuffSet *huffs, uint64_t *state);
-void launch_dec_relax_all(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_sub, const DevHuffSet *huffs, uint64_t *state,
-                          uint32_t *nblk, uint64_t *list_out, uint32_t *cnt_out);
+struct DenseArgs {
+    const uint8_t *clean; const ParScan *pss; const DevHuffSet *huffs;
+    uint64_t *state; uint32_t *nblk; uint64_t *list_out; uint32_t *cnt_out;           // relax
+    const uint64_t *blk_off; const ImgDesc *imgs; int16_t *coef; int32_t *dcdiff; uint32_t *need_seq;  // write
+};
+void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out);
 void launch_dec_unconverged(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *need_seq);
-void launch_dec_write(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_sub, const DevHuffSet *huffs, const uint64_t *state,
-                      const uint64_t *blk_off, const ImgDesc *imgs, int16_t *coef, int32_t *dcdiff, uint32_t *need_seq);
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq);
 

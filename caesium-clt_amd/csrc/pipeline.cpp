@@ -28,6 +28,7 @@ extern "C" const char *csh_last_error(void) { return g_err; }
 #ifdef CSH_EMUL
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 int csh_emul_reverse = 0;
+thread_local int csh_emul_phase = 0;
 extern "C" void csh_emul_set_reverse(int r) { csh_emul_reverse = r; }
 #endif
 
@@ -506,11 +507,16 @@ static int run_once(csh_batch *b, csh_timing *t) {
             launch_unstuff_copy(st, b->d_bits.p, b->d_clean.p, b->d_pscans.p, nps, nchunks, b->d_unstuff_off.p);
         }
         MARK();
-        launch_dec_spec(st, b->d_clean.p, b->d_pscans.p, nps, b->max_sub, b->d_hsets.p, b->d_pstate.p);
+        DenseArgs da;
+        memset(&da, 0, sizeof da);
+        da.clean = b->d_clean.p; da.pss = b->d_pscans.p; da.huffs = b->d_hsets.p; da.state = b->d_pstate.p; da.nblk = b->d_nblk.p;
+        da.list_out = b->d_relax_list[0].p; da.cnt_out = b->d_relax_cnt.p; da.blk_off = b->d_blk_off.p; da.imgs = b->d_imgs.p;
+        da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p;
+        launch_dec_dense(st, 0, nps, b->max_sub, da);
         MARK();
         const int R = 20;  // list rounds after the dense one (each costs one near-empty launch once converged)
         if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
-        launch_dec_relax_all(st, b->d_clean.p, b->d_pscans.p, nps, b->max_sub, b->d_hsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[0].p, b->d_relax_cnt.p);
+        launch_dec_dense(st, 1, nps, b->max_sub, da);
         MARK();
         for (int it = 0; it < R && nps; it++)
             launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, b->d_hsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
@@ -518,8 +524,7 @@ static int run_once(csh_batch *b, csh_timing *t) {
         if (nps) launch_dec_unconverged(st, b->d_pscans.p, b->total_sub, b->d_relax_list[R & 1].p, b->d_relax_cnt.p + R, b->d_need_seq.p);
         MARK();
         if (nps) launch_exclusive_scan(st, b->d_nblk.p, b->d_blk_off.p, b->total_sub, b->d_scan_tmp.p, b->d_scan_tmp.n);
-        launch_dec_write(st, b->d_clean.p, b->d_pscans.p, nps, b->max_sub, b->d_hsets.p, b->d_pstate.p, b->d_blk_off.p, b->d_imgs.p, b->d_coef.p,
-                         b->d_dcdiff.p, b->d_need_seq.p);
+        launch_dec_dense(st, 2, nps, b->max_sub, da);
         MARK();
         if (nps) launch_exclusive_scan(st, reinterpret_cast<uint32_t *>(b->d_dcdiff.p), b->d_dc_off.p, b->dc_total, b->d_scan_tmp.p, b->d_scan_tmp.n);
         launch_dc_scatter(st, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_dc_off.p, b->d_coef.p, b->d_need_seq.p);
