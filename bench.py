@@ -31,7 +31,7 @@ def algorithmic_bytes(kernel, t, n):
         "k_decode_seq": t.in_bytes + coef,
         "k_xform_direct": 2 * y,
         "k_idct_plane": c + planes,
-        "k_resample_fdct": planes + c,
+        "k_resample+k_plane_fdct": 3 * planes + c,
         "k_masks": coef + coef * 24 // 128,
         "memset_coef": 2 * coef,
     }

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #define CSH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 #define CSH_UNROLL _Pragma("unroll")
+#define CSH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // keep the instruction scheduler from interleaving stages (register pressure)
 // Kernels that need workgroup barriers are written as a loop over "phases":
 //     CSH_SHARED int lds[...];
 //     CSH_PHASE_LOOP(3) { if (phase == 0) {...; continue;} ... }
@@ -39,6 +40,7 @@
 #define __restrict__
 #define __launch_bounds__(...)
 #define CSH_UNROLL
+#define CSH_SCHED_FENCE() ((void)0)
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}

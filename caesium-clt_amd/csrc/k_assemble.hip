@@ -51,6 +51,19 @@ __global__ void k_scan_place(AsmCtx a) {
     if (j == a.nwork - 1 && a.scan_raw_off[a.nwork] > a.raw_chunks * 64) *a.overflow = 1;
 }
 
+// byte sink that turns a lane's contiguous output run into aligned dword stores (single bytes only at the ragged ends)
+struct ByteRun {
+    uint8_t *p;
+    uint32_t acc; int n;
+    __device__ __forceinline__ void begin(uint8_t *dst) { p = dst; acc = 0; n = 0; }
+    __device__ __forceinline__ void push(uint32_t b) {
+        if (n == 0 && (reinterpret_cast<uintptr_t>(p) & 3)) { *p++ = uint8_t(b); return; }
+        acc |= b << (8 * n);
+        if (++n == 4) { *reinterpret_cast<uint32_t *>(p) = acc; p += 4; acc = 0; n = 0; }
+    }
+    __device__ __forceinline__ void finish() { for (int i = 0; i < n; i++) *p++ = uint8_t(acc >> (8 * i)); n = 0; }
+};
+
 __device__ __forceinline__ static int raw_byte(const uint32_t *raw, uint64_t byte_index) {
     return int((raw[byte_index >> 2] >> (24 - 8 * int(byte_index & 3))) & 255u);
 }
@@ -148,12 +161,20 @@ __global__ void __launch_bounds__(256) k_emit_data(AsmCtx a) {
     uint64_t rel = c * 64 - w.raw_off;
     if (rel >= w.raw_bytes) return;
     uint64_t c0 = w.raw_off >> 6;
-    uint8_t *o = a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes + rel + (a.chunk_ffoff[c] - a.chunk_ffoff[c0]);
-    for (int i = 0; i < 64 && rel + i < w.raw_bytes; i++) {
-        int b = raw_byte(a.raw, c * 64 + i);
-        *o++ = uint8_t(b);
-        if (b == 0xFF) *o++ = 0;
+    ByteRun o; o.begin(a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes + rel + (a.chunk_ffoff[c] - a.chunk_ffoff[c0]));
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.raw + c * 16);
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = src[q];
+        const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+        for (int j = 0; j < 4; j++)
+            for (int i = 0; i < 4; i++) {
+                if (rel + uint64_t(16 * q + 4 * j + i) >= w.raw_bytes) break;
+                uint32_t b = (ws[j] >> (24 - 8 * i)) & 255u;
+                o.push(b);
+                if (b == 0xFFu) o.push(0u);
+            }
     }
+    o.finish();
 }
 
 void launch_scan_sizes(hipStream_t st, const AsmCtx &a) { if (a.nwork) CSH_LAUNCH(k_scan_sizes, dim3((a.nwork + 255) / 256), dim3(256), st, a); }

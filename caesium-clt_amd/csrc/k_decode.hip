@@ -79,7 +79,7 @@ __device__ static void decode_block(BitReader &br, const DecScan &sc, bool progr
         for (int k = 1; k < 64;) {
             int rs = huff_decode(br, act);
             int r = rs >> 4, n = rs & 15;
-            if (n) { k += r; if (k > 63) break; blk.base[k << 6] = int16_t(extend(br_get(br, n), n)); k++; }
+            if (n) { k += r; if (k > 63) break; blk.base[coef_off(k)] = int16_t(extend(br_get(br, n), n)); k++; }
             else { if (r == 15) k += 16; else break; }
         }
         return;
@@ -98,7 +98,7 @@ __device__ static void decode_block(BitReader &br, const DecScan &sc, bool progr
         for (int k = sc.Ss; k <= sc.Se; k++) {
             int rs = huff_decode(br, act);
             int r = rs >> 4, n = rs & 15;
-            if (n) { k += r; if (k > 63) break; blk.base[k << 6] = int16_t(extend(br_get(br, n), n) * (1 << sc.Al)); }
+            if (n) { k += r; if (k > 63) break; blk.base[coef_off(k)] = int16_t(extend(br_get(br, n), n) * (1 << sc.Al)); }
             else {
                 if (r == 15) k += 15;
                 else { eobrun = 1 << r; if (r) eobrun += br_get(br, r); eobrun--; break; }
@@ -115,18 +115,18 @@ __device__ static void decode_block(BitReader &br, const DecScan &sc, bool progr
             if (n) val = br_get(br, 1) ? p1 : m1;
             else if (r != 15) { eobrun = 1 << r; if (r) eobrun += br_get(br, r); break; }
             do {
-                int16_t *c = &blk.base[k << 6];
+                int16_t *c = &blk.base[coef_off(k)];
                 int cv = *c;
                 if (cv != 0) { if (br_get(br, 1) && (cv & p1) == 0) *c = int16_t(cv >= 0 ? cv + p1 : cv + m1); }
                 else if (--r < 0) break;
                 k++;
             } while (k <= sc.Se);
-            if (val && k <= 63) blk.base[k << 6] = int16_t(val);
+            if (val && k <= 63) blk.base[coef_off(k)] = int16_t(val);
         }
     }
     if (eobrun > 0) {
         for (; k <= sc.Se; k++) {
-            int16_t *c = &blk.base[k << 6];
+            int16_t *c = &blk.base[coef_off(k)];
             int cv = *c;
             if (cv != 0 && br_get(br, 1) && (cv & p1) == 0) *c = int16_t(cv >= 0 ? cv + p1 : cv + m1);
         }

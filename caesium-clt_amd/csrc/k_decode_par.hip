@@ -32,51 +32,93 @@ __device__ static int scan_of_byte(const ParScan *ps, int nps, uint32_t byte) {
     return lo;
 }
 
-// a stuffed zero = 0x00 that follows 0xFF inside the scan (T.81 F.1.2.3).  One lane per 64-byte chunk; the chunk and the
-// byte in front of it are pulled into registers first, then a 64-bit "delete" mask drives both the count and the copy.
-__device__ __forceinline__ static uint64_t stuffed_mask(const uint8_t *raw, uint32_t b0, uint32_t lo, uint32_t end, uint8_t bytes[64]) {
-    uint64_t del = 0;
-    unsigned prev = (b0 > lo) ? raw[b0 - 1] : 0u;
-    for (int i = 0; i < 64; i++) {
-        unsigned v = (b0 + i < end) ? raw[b0 + i] : 0x55u;
-        bytes[i] = uint8_t(v);
-        if (b0 + i < end && prev == 0xFFu && v == 0u) del |= 1ull << i;
-        prev = v;
+// a stuffed zero = 0x00 that follows 0xFF inside the scan (T.81 F.1.2.3).  A workgroup owns 256 consecutive 64-byte chunks:
+// phase 0 pulls its 16 KiB (+ the dword in front) into LDS with coalesced loads, phase 1 lets each lane scan its own chunk
+// word-wise (zero-byte / 0xFF-byte bit tricks), so nothing is read from global memory byte by byte.
+#define CSH_US_STRIDE 17  // 16 data dwords per chunk + 1 pad: lanes start in distinct banks
+__device__ __forceinline__ static uint32_t zero_bytes(uint32_t w) { return ~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w | 0x7F7F7F7Fu); }  // 0x80 in every 0x00 byte
+__device__ __forceinline__ static void unstuff_stage(const uint8_t *raw, uint32_t c0, uint32_t nchunks, uint32_t *lw, uint32_t tid) {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(raw);
+    for (uint32_t i = 0; i < 16; i++) {
+        uint32_t d = i * 256 + tid, chunk = c0 + d / 16;
+        lw[(d / 16) * CSH_US_STRIDE + d % 16] = chunk < nchunks ? g[size_t(c0) * 16 + d] : 0u;
     }
-    return del;
+    if (tid == 0) lw[256 * CSH_US_STRIDE] = c0 ? g[size_t(c0) * 16 - 1] : 0u;  // dword in front of the first chunk
+}
+// per-lane: 16 "delete" nibble masks (bit 7 of byte i of del[j] set <=> byte 4j+i of the chunk is a stuffed zero)
+__device__ __forceinline__ static uint32_t unstuff_masks(const uint32_t *lw, uint32_t tid, uint32_t b0, uint32_t lo, uint32_t end, uint32_t del[16]) {
+    uint32_t prev = tid ? lw[(tid - 1) * CSH_US_STRIDE + 15] : lw[256 * CSH_US_STRIDE];
+    uint32_t carry = (b0 > lo) ? (zero_bytes(~prev) >> 24) : 0u;  // 0x80 if the byte in front is 0xFF and belongs to this scan
+    uint32_t n = 0;
+    for (int j = 0; j < 16; j++) {
+        uint32_t w = lw[tid * CSH_US_STRIDE + j];
+        uint32_t f = zero_bytes(~w), z = zero_bytes(w);
+        uint32_t d = z & ((f << 8) | carry);
+        carry = f >> 24;
+        // bytes outside [lo, end) never count
+        uint32_t pos = b0 + 4 * j;
+        if (pos + 4 > end) { uint32_t keep = pos >= end ? 0u : (0xFFFFFFFFu >> (8 * (pos + 4 - end))); d &= keep; }
+        del[j] = d;
+        n += __popc(d);
+    }
+    return n;
 }
 
 __global__ void __launch_bounds__(256) k_unstuff_count(const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks) return;
-    uint32_t n = 0, b0 = c * 64;
-    if (nps) {
-        const ParScan &s = ps[scan_of_byte(ps, nps, b0)];
-        uint32_t end = s.bits_off + s.bits_len;
-        if (b0 < end) { uint8_t bytes[64]; n = uint32_t(__popcll(stuffed_mask(raw, b0, s.bits_off, end, bytes))); }
+    CSH_SHARED uint32_t lw[256 * CSH_US_STRIDE + 1];
+    const uint32_t tid = threadIdx.x, c0 = blockIdx.x * 256, c = c0 + tid;
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) { unstuff_stage(raw, c0, nchunks, lw, tid); continue; }
+        if (c >= nchunks) continue;
+        uint32_t n = 0, b0 = c * 64;
+        if (nps) {
+            const ParScan &s = ps[scan_of_byte(ps, nps, b0)];
+            uint32_t end = s.bits_off + s.bits_len;
+            if (b0 < end) { uint32_t del[16]; n = unstuff_masks(lw, tid, b0, s.bits_off, end, del); }
+        }
+        cnt[c] = n;
     }
-    cnt[c] = n;
 }
 
-__global__ void __launch_bounds__(256) k_unstuff_copy(const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunks || !nps) return;
-    uint32_t b0 = c * 64;
-    int si = scan_of_byte(ps, nps, b0);
-    const uint32_t lo = ps[si].bits_off, len = ps[si].bits_len, end = lo + len;
-    if (b0 >= end) return;
-    uint32_t removed = uint32_t(off[c] - off[lo >> 6]);
-    uint8_t bytes[64];
-    uint64_t del = stuffed_mask(raw, b0, lo, end, bytes);
-    uint32_t o = b0 - removed;
-    for (int i = 0; i < 64; i++) {
-        if (b0 + i >= end) break;
-        if ((del >> i) & 1) continue;
-        clean[o++] = bytes[i];
+// byte sink that turns a lane's contiguous output run into aligned dword stores (single bytes only at the ragged ends)
+struct ByteRun {
+    uint8_t *p;
+    uint32_t acc; int n;
+    __device__ __forceinline__ void begin(uint8_t *dst) { p = dst; acc = 0; n = 0; }
+    __device__ __forceinline__ void push(uint32_t b) {
+        if (n == 0 && (reinterpret_cast<uintptr_t>(p) & 3)) { *p++ = uint8_t(b); return; }
+        acc |= b << (8 * n);
+        if (++n == 4) { *reinterpret_cast<uint32_t *>(p) = acc; p += 4; acc = 0; n = 0; }
     }
-    if (b0 + 64 >= end) {  // last chunk of the scan: publish the unstuffed length
-        uint32_t last_chunk = (end + 63) >> 6;
-        ps[si].clean_len = len - uint32_t(off[last_chunk] - off[lo >> 6]);
+    __device__ __forceinline__ void finish() { for (int i = 0; i < n; i++) *p++ = uint8_t(acc >> (8 * i)); n = 0; }
+};
+
+__global__ void __launch_bounds__(256) k_unstuff_copy(const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off) {
+    CSH_SHARED uint32_t lw[256 * CSH_US_STRIDE + 1];
+    const uint32_t tid = threadIdx.x, c0 = blockIdx.x * 256, c = c0 + tid;
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) { unstuff_stage(raw, c0, nchunks, lw, tid); continue; }
+        if (c >= nchunks || !nps) continue;
+        uint32_t b0 = c * 64;
+        int si = scan_of_byte(ps, nps, b0);
+        const uint32_t lo = ps[si].bits_off, len = ps[si].bits_len, end = lo + len;
+        if (b0 >= end) continue;
+        uint32_t removed = uint32_t(off[c] - off[lo >> 6]);
+        uint32_t del[16];
+        unstuff_masks(lw, tid, b0, lo, end, del);
+        ByteRun out; out.begin(clean + (b0 - removed));
+        for (int j = 0; j < 16; j++) {
+            uint32_t w = lw[tid * CSH_US_STRIDE + j], d = del[j];
+            for (int i = 0; i < 4; i++) {
+                if (b0 + 4 * j + i >= end) break;
+                if (!((d >> (8 * i + 7)) & 1)) out.push((w >> (8 * i)) & 255u);
+            }
+        }
+        out.finish();
+        if (b0 + 64 >= end) {  // last chunk of the scan: publish the unstuffed length
+            uint32_t last_chunk = (end + 63) >> 6;
+            ps[si].clean_len = len - uint32_t(off[last_chunk] - off[lo >> 6]);
+        }
     }
 }
 
@@ -167,7 +209,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuf
                 st.k += r;
                 if (st.k > 63) st.k = 64;  // corrupt run: block ends (no extra bits consumed, as the sequential path)
                 else {
-                    if (WRITE && blk) { uint32_t w2 = peek32(rd, st.pos); blk[st.k << 6] = int16_t(extend_p(int(w2 >> (32 - n)), n)); }
+                    if (WRITE && blk) { uint32_t w2 = peek32(rd, st.pos); blk[coef_off(st.k)] = int16_t(extend_p(int(w2 >> (32 - n)), n)); }
                     st.pos += n;
                     st.k++;
                 }
@@ -188,26 +230,56 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuf
 // changes s[t] it appends t to the next work list, so t is re-evaluated in a LATER launch with the newest s[t].  An empty
 // list therefore means s[t+1] == F_t(s[t]) for every t, i.e. the true state chain (s[0] is exact).  Reading a value that
 // a neighbour updates during the same launch is harmless: it only decides whether this evaluation is already final.
-__device__ __forceinline__ static void relax_one(const uint8_t *clean, const ParScan &ps, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
-                                                  uint32_t t, uint64_t *list_out, uint32_t *cnt_out) {
-    size_t base = ps.sub_base + ps.par_index;
-    PState st = unpack_state(state[base + t]);
-    PReader rd; rd.base = clean + ps.bits_off; rd.len = ps.clean_len;
-    uint32_t n = decode_span<false>(rd, huffs[ps.huff_set], ps, st, (t + 1) * CSH_SUBSEQ_BYTES * 8, 0, nullptr, nullptr, nullptr);
-    nblk[ps.sub_base + t] = n;
-    uint64_t e = pack_state(st);
-    if (e != state[base + t + 1]) {
-        state[base + t + 1] = e;
-        if ((t + 1) * CSH_SUBSEQ_BYTES < ps.clean_len) list_out[atomicAdd(cnt_out, 1u)] = (uint64_t(ps.par_index) << 32) | (t + 1);
-    }
-}
-
+// list rounds: the listed sub-sequences are scattered, so each wave stages its 64 lanes' 144-byte stream windows
+// cooperatively -- for lane r's window, lanes 0..35 fetch its 36 consecutive words in ONE coalesced access (a lane
+// reading its own window would cost 36 accesses x 64 cache lines per wave) -- then every lane decodes out of LDS.
 __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                                                          const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= *cnt_in) return;
-    uint64_t e = list_in[j];
-    relax_one(clean, pss[uint32_t(e >> 32)], huffs, state, nblk, uint32_t(e), list_out, cnt_out);
+    CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
+    CSH_SHARED DevHuffSet lhs;
+    CSH_SHARED uint32_t d_scan[256], d_t[256];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
+    const uint32_t tid = threadIdx.x, j = blockIdx.x * blockDim.x + tid, count = *cnt_in;
+    const uint32_t j0 = blockIdx.x * blockDim.x;
+    CSH_PHASE_LOOP(3) {
+        if (j0 >= count) continue;   // whole workgroup idle (uniform)
+        if (phase == 0) {
+            uint32_t si = 0xFFFFFFFFu, t = 0;
+            if (j < count) { uint64_t e = list_in[j]; si = uint32_t(e >> 32); t = uint32_t(e); }
+            d_scan[tid] = si; d_t[tid] = t;
+            // the first entry's Huffman set is staged; lanes with another set read theirs from global memory
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&huffs[pss[uint32_t(list_in[j0] >> 32)].huff_set]);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
+            for (uint32_t i = tid; i < sizeof(DevHuffSet) / 4; i += 256) dst[i] = src[i];
+            continue;
+        }
+        if (phase == 1) {
+            const uint32_t wave0 = tid & ~63u, lane = tid & 63u;
+            for (uint32_t r = 0; r < 64; r++) {
+                uint32_t si = d_scan[wave0 + r];
+                if (si == 0xFFFFFFFFu || lane >= CSH_LROW_WORDS) continue;
+                const ParScan &ps = pss[si];
+                PReader g; g.base = clean + ps.bits_off; g.len = ps.clean_len;
+                lbits[(wave0 + r) * CSH_LROW_STRIDE + lane] = g.word(d_t[wave0 + r] * (CSH_SUBSEQ_BYTES / 4) + lane);
+            }
+            continue;
+        }
+        if (j >= count) continue;
+        const ParScan &ps = pss[d_scan[tid]];
+        const uint32_t t = d_t[tid];
+        size_t base = ps.sub_base + ps.par_index;
+        PState st = unpack_state(state[base + t]);
+        LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g.base = clean + ps.bits_off; rd.g.len = ps.clean_len;
+        const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+        uint32_t n;
+        if (ps.huff_set == pss[d_scan[0]].huff_set) n = decode_span<false>(rd, lhs, ps, st, stop, 0, nullptr, nullptr, nullptr);
+        else n = decode_span<false>(rd, huffs[ps.huff_set], ps, st, stop, 0, nullptr, nullptr, nullptr);
+        nblk[ps.sub_base + t] = n;
+        uint64_t e = pack_state(st);
+        if (e != state[base + t + 1]) {
+            state[base + t + 1] = e;
+            if ((t + 1) * CSH_SUBSEQ_BYTES < ps.clean_len) list_out[atomicAdd(cnt_out, 1u)] = (uint64_t(ps.par_index) << 32) | (t + 1);
+        }
+    }
 }
 
 // whatever is still listed after the last launch has not reached the fixed point: sequential fallback for that image
@@ -303,10 +375,10 @@ __global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const Im
 }
 
 void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt) {
-    if (nchunks) CSH_LAUNCH(k_unstuff_count, dim3((nchunks + 255) / 256), dim3(256), st, raw, ps, nps, nchunks, cnt);
+    if (nchunks) CSH_LAUNCH_PHASED(k_unstuff_count, 2, dim3((nchunks + 255) / 256), dim3(256), st, raw, ps, nps, nchunks, cnt);
 }
 void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off) {
-    if (nchunks) CSH_LAUNCH(k_unstuff_copy, dim3((nchunks + 255) / 256), dim3(256), st, raw, clean, ps, nps, nchunks, off);
+    if (nchunks) CSH_LAUNCH_PHASED(k_unstuff_copy, 2, dim3((nchunks + 255) / 256), dim3(256), st, raw, clean, ps, nps, nchunks, off);
 }
 void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const DenseArgs &a) {
     if (!nps) return;
@@ -317,7 +389,7 @@ void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const
 }
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
-    if (total_sub) CSH_LAUNCH(k_dec_relax_list, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, huffs, state, nblk, list_in, cnt_in, list_out, cnt_out);
+    if (total_sub) CSH_LAUNCH_PHASED(k_dec_relax_list, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, huffs, state, nblk, list_in, cnt_in, list_out, cnt_out);
 }
 void launch_dec_unconverged(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *need_seq) {
     if (total_sub) CSH_LAUNCH(k_dec_unconverged, dim3((total_sub + 255) / 256), dim3(256), st, ps, list_in, cnt_in, need_seq);

@@ -20,25 +20,32 @@
 namespace csh {
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_masks(const int16_t *__restrict__ coef, uint64_t *__restrict__ masks, uint32_t ntiles) {
+__global__ void __launch_bounds__(256) k_masks(const int16_t *__restrict__ coef, uint64_t *__restrict__ masks, uint32_t first_tile, uint32_t ntiles) {
     uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
-    const int16_t *p = coef + size_t(tile) * CSH_TILE_I16 + lane;
+    tile += first_tile;
+    const int16_t *p = coef + size_t(tile) * CSH_TILE_I16 + lane * 8;
     uint64_t m0 = 0, m1 = 0, m2 = 0;
     CSH_UNROLL
-    for (int k = 0; k < 64; k++) {
-        int v = p[k << 6];
-        unsigned a = unsigned(v < 0 ? -v : v);
-        m0 |= uint64_t(a >= 1) << k;
-        m1 |= uint64_t(a >= 2) << k;
-        m2 |= uint64_t(a >= 4) << k;
+    for (int j = 0; j < 8; j++) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p + 512 * j);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        CSH_UNROLL
+        for (int i = 0; i < 8; i++) {
+            int v = (i & 1) ? (int(w[i >> 1]) >> 16) : (int(w[i >> 1] << 16) >> 16);
+            unsigned a = unsigned(v < 0 ? -v : v);
+            const int k = 8 * j + i;
+            m0 |= uint64_t(a >= 1) << k;
+            m1 |= uint64_t(a >= 2) << k;
+            m2 |= uint64_t(a >= 4) << k;
+        }
     }
     uint64_t *o = masks + size_t(tile) * 192 + lane;
     o[0] = m0; o[64] = m1; o[128] = m2;
 }
-void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t ntiles) {
-    if (ntiles) CSH_LAUNCH(k_masks, dim3((ntiles + 3) / 4), dim3(256), st, coef, masks, ntiles);
+void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t first_tile, uint32_t ntiles) {
+    if (ntiles) CSH_LAUNCH(k_masks, dim3((ntiles + 3) / 4), dim3(256), st, coef, masks, first_tile, ntiles);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -155,20 +162,38 @@ struct SizeSink {
     __device__ __forceinline__ void rawcount(int n) { bits += n; }
 };
 struct PackSink {
+    // Bits are gathered in a 64-bit accumulator and leave as whole big-endian-logical 32-bit words.  Only the first and the
+    // last word of a unit's bit string can be shared with a neighbouring unit, so only those two need an atomic OR; the
+    // words in between are exclusively this lane's and are stored plainly (the pool is zero-initialised).
     const DevEncTable *tab;
     uint32_t *raw_words;
-    uint64_t pos;  // absolute bit position in the raw pool
+    uint64_t pos;      // absolute bit position in the raw pool of the next bit to emit
+    uint64_t acc;      // pending bits, right-aligned
+    int nacc;          // number of pending bits (< 32 after every put)
+    bool first;        // the next word written is the unit's first (possibly shared) word
     static constexpr bool kValues = true;
+    __device__ __forceinline__ void begin(uint64_t p) { pos = p; nacc = int(p & 31); acc = 0; first = true; }
     __device__ __forceinline__ void put(unsigned v, int n) {
         if (n == 0) return;
         v &= (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
-        uint64_t w = pos >> 5;
-        int o = int(pos & 31);
-        uint64_t v64 = uint64_t(v) << (64 - o - n);
-        uint32_t hi = uint32_t(v64 >> 32), lo = uint32_t(v64);
-        if (hi) atomicOr(raw_words + w, hi);
-        if (lo) atomicOr(raw_words + w + 1, lo);
+        acc = (acc << n) | v;
+        nacc += n;
         pos += n;
+        if (nacc >= 32) {
+            uint32_t w = uint32_t(acc >> (nacc - 32));
+            uint64_t wi = (pos - uint64_t(nacc)) >> 5;   // word that holds the oldest pending bit
+            if (first) { if (w) atomicOr(raw_words + wi, w); first = false; }
+            else raw_words[wi] = w;
+            nacc -= 32;
+            acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (nacc == 0) return;
+        uint32_t w = uint32_t(acc << (32 - nacc));
+        uint64_t wi = (pos - uint64_t(nacc)) >> 5;
+        if (w) atomicOr(raw_words + wi, w);
+        nacc = 0;
     }
     __device__ __forceinline__ void sym(int t, int s) { put(tab[t].code[s], tab[t].size[s]); }
     __device__ __forceinline__ void syms(int t, int s, int n) { for (int i = 0; i < n; i++) sym(t, s); }
@@ -193,7 +218,7 @@ __device__ static void walk_ac_first(Sink &sink, const int16_t *blk, uint64_t NZ
         int r = k - prev - 1;
         prev = k;
         sink.syms(0, 0xF0, r >> 4);
-        int v = blk[k << 6];
+        int v = blk[coef_off(k)];
         unsigned a = unsigned(v < 0 ? -v : v) >> sc.Al;
         int nb = bitlen32(a);
         sink.sym(0, ((r & 15) << 4) | nb);
@@ -239,7 +264,7 @@ __device__ static void walk_ac_refine(Sink &sink, const int16_t *blk, uint64_t H
                 if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
                 br = 0; brn = 0;
             }
-        int v = blk[k << 6];
+        int v = blk[coef_off(k)];
         unsigned a = unsigned(v < 0 ? -v : v) >> sc.Al;
         if ((H >> k) & 1) { br = (br << 1) | (a & 1); brn++; }
         else {
@@ -337,30 +362,34 @@ __global__ void __launch_bounds__(256) k_stats(EncCtx c) {
     }
 }
 
-// ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour), one lane per table
+// ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour), one lane per table.
+// The merge loop runs over the COMPACTED list of used symbols (ascending symbol order, pseudo-symbol 256 last), which
+// preserves libjpeg's tie-breaking ("least frequency, ties to the larger symbol") while doing nnz^2 instead of 257*nnz work.
 __global__ void k_gen_tables(DevEncTable *tables, int ntables) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntables) return;
     DevEncTable &T = tables[t];
-    int codesize[257], others[257];
     uint32_t freq[257];
+    int16_t symof[257], codesize[257], others[257];
     uint8_t bits[33];
-    for (int i = 0; i < 257; i++) { freq[i] = T.freq[i]; codesize[i] = 0; others[i] = -1; }
+    int n = 0;
+    for (int i = 0; i < 256; i++) { uint32_t f = T.freq[i]; if (f) { freq[n] = f; symof[n] = int16_t(i); n++; } }
+    freq[n] = 1; symof[n] = 256; n++;   // reserved code point: guarantees no all-ones code
+    for (int i = 0; i < n; i++) { codesize[i] = 0; others[i] = -1; }
     for (int i = 0; i < 33; i++) bits[i] = 0;
-    freq[256] = 1;
     for (;;) {
         int c1 = -1, c2 = -1;
         uint32_t v = 0xFFFFFFFFu;
-        for (int i = 0; i <= 256; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        for (int i = 0; i < n; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
         v = 0xFFFFFFFFu;
-        for (int i = 0; i <= 256; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        for (int i = 0; i < n; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
         if (c2 < 0) break;
         freq[c1] += freq[c2]; freq[c2] = 0;
         codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
-        others[c1] = c2;
+        others[c1] = int16_t(c2);
         codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
     }
-    for (int i = 0; i <= 256; i++) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
+    for (int i = 0; i < n; i++) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
     for (int i = 32; i > 16; i--)
         while (bits[i] > 0) {
             int j = i - 2; while (bits[j] == 0) j--;
@@ -370,11 +399,11 @@ __global__ void k_gen_tables(DevEncTable *tables, int ntables) {
     if (i > 0) bits[i]--;
     for (int l = 0; l <= 16; l++) T.bits[l] = l ? bits[l] : 0;
     int p = 0;
-    for (int l = 1; l <= 32; l++) for (int s = 0; s <= 255; s++) if (codesize[s] == l) T.vals[p++] = uint8_t(s);
+    for (int l = 1; l <= 32; l++) for (int s = 0; s < n - 1; s++) if (codesize[s] == l) T.vals[p++] = uint8_t(symof[s]);
     T.nsym = p;
     for (int s = 0; s < 256; s++) { T.size[s] = 0; T.code[s] = 0; }
     int code = 0; p = 0;
-    for (int l = 1; l <= 16; l++) { for (int n = 0; n < T.bits[l]; n++, p++) { T.code[T.vals[p]] = uint16_t(code++); T.size[T.vals[p]] = uint8_t(l); } code <<= 1; }
+    for (int l = 1; l <= 16; l++) { for (int k2 = 0; k2 < T.bits[l]; k2++, p++) { T.code[T.vals[p]] = uint16_t(code++); T.size[T.vals[p]] = uint8_t(l); } code <<= 1; }
 }
 void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
     if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 63) / 64), dim3(64), st, tables, ntables);
@@ -402,12 +431,13 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     uint64_t raw_bit0 = w.raw_off * 8;
     if (raw_bit0 + total + 64 > c.raw_words * 32) { c.status[w.image] = 20200; return; }
     PackSink s; s.tab = c.tables + w.table_base; s.raw_words = c.raw;
-    s.pos = raw_bit0 + (c.unit_off[w.unit_base + u] - base);
+    s.begin(raw_bit0 + (c.unit_off[w.unit_base + u] - base));
     walk_unit(s, c, w, sc, u);
     if (u == w.nunits - 1) {  // flush_bits: pad the last byte with 1-bits
         int pad = int((8 - (total & 7)) & 7);
         if (pad) s.put((1u << pad) - 1u, pad);
     }
+    s.finish();
 }
 
 static dim3 unit_grid(const EncCtx &c) { return dim3((c.max_units + 255) / 256, c.nwork); }

@@ -2,22 +2,34 @@
 //
 // Replaces, for libcaesium's lossy JPEG path (reference call site /root/reference/src/compressor.rs:305;
 // SURVEY.md 8a rows J2,J3,J5,J6,J7 and Appendix B.2-B.6), mozjpeg's
-//   jidctint (dequantise + ISLOW IDCT + range limit), jdsample h2v2 fancy upsample,
+//   jidctint (dequantise + ISLOW IDCT + range limit), jdsample h2v2 / h2v1 fancy upsample,
 //   jcsample h2v2 downsample with edge expansion, jfdctint (ISLOW FDCT) and the scalar quantiser.
+// Full-resolution components go IDCT -> FDCT inside one lane (k_xform_direct); resampled components go
+// k_idct_plane -> k_resample_plane (per sample) -> k_plane_fdct.
 // All arithmetic is int32 exactly as the oracle's (oracle/jpeg_oracle.c); multiplies by the 13-bit DCT
 // constants use the full-rate 24-bit multiplier, which is exact whenever dequantised coefficients are
 // below 2^15 in magnitude (every stream made from 8-bit samples; libjpeg-turbo's SIMD IDCT has the same
-// domain).  Memory: tile rows are 128-byte coalesced (2 B per lane per row), planes are written/read in
-// row segments contiguous across the wave's adjacent blocks.  No LDS, no cross-lane traffic: the 2-D
-// transforms never leave the lane's registers, so zig-zag <-> natural reordering is free.
+// domain).  Memory: a block is 8 octets of 16 bytes; octet j of the wave's 64 blocks is one coalesced 1 KiB
+// access, so a tile moves in 8 vector loads / 8 vector stores per lane; planes are written/read in row segments
+// contiguous across the wave's adjacent blocks.  No LDS, no cross-lane traffic: the 2-D transforms never leave
+// the lane's registers, so zig-zag <-> natural reordering is free (compile-time register naming).
+#include <utility>
+
 #include "kernels.h"
 
 namespace csh {
 
-// natural index -> zig-zag index (inverse of T.81 Figure A.6)
-__device__ static const uint8_t kN2Z[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
-                                            41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
-                                            46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+// zig-zag index -> natural index, as a compile-time table: the block lives in 64 named VGPRs and every
+// reordering below must resolve at compile time (a run-time register index would spill the block to scratch)
+static constexpr uint8_t kZ2N[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+template <int I>
+__device__ __forceinline__ static int half_of(const uint4 &v) {  // sign-extended int16 element I of the octet
+    uint32_t w = (I / 2 == 0) ? v.x : (I / 2 == 1) ? v.y : (I / 2 == 2) ? v.z : v.w;
+    return (I & 1) ? (int(w) >> 16) : (int(w << 16) >> 16);
+}
+using Oct = std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>;
 
 #define FIX_0_298 2446
 #define FIX_0_390 3196
@@ -69,68 +81,94 @@ __device__ __forceinline__ static void fdct1d(int &d0, int &d1, int &d2, int &d3
     d3 = DESC(tmp6 + y2 + y3, SH); d1 = DESC(tmp7 + y1 + y4, SH);
 }
 
-// load + dequantise + 2-D IDCT + level shift + range limit; x[] natural order in, samples (0..255) out
+// load (8 x 16-byte octets) + dequantise + 2-D IDCT + level shift + range limit; samples (0..255) out, natural order
+template <int J, int... I>
+__device__ __forceinline__ static void dequant_octet(int x[64], const uint4 &v, const DevQuant &q, std::integer_sequence<int, I...>) {
+    ((x[kZ2N[8 * J + I]] = half_of<I>(v) * int(q.q[8 * J + I])), ...);
+}
+template <int... J>
+__device__ __forceinline__ static void load_dequant(const int16_t *__restrict__ blk, const DevQuant &q, int x[64], std::integer_sequence<int, J...>) {
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + 512 * J)...};  // all eight loads in flight before first use
+    (dequant_octet<J>(x, v[J], q, Oct()), ...);
+}
 __device__ __forceinline__ static void load_idct(const int16_t *__restrict__ blk, const DevQuant &q, int x[64]) {
-    CSH_UNROLL
-    for (int n = 0; n < 64; n++) { int k = kN2Z[n]; x[n] = int(blk[k << 6]) * int(q.q[k]); }
+    load_dequant(blk, q, x, Oct());
+    CSH_SCHED_FENCE();
     CSH_UNROLL
     for (int c = 0; c < 8; c++) idct1d(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c], 11);
+    CSH_SCHED_FENCE();
     CSH_UNROLL
-    for (int r = 0; r < 8; r++) idct1d(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7], 18);
-    CSH_UNROLL
-    for (int n = 0; n < 64; n++) { int v = x[n] + 128; x[n] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    for (int r = 0; r < 8; r++) {
+        idct1d(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7], 18);
+        CSH_UNROLL
+        for (int c = 0; c < 8; c++) { int v = x[8 * r + c] + 128; x[8 * r + c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    }
+    CSH_SCHED_FENCE();
 }
 
 // replicate the last valid column / row of an edge block (decoder crop + encoder edge expansion)
 __device__ __forceinline__ static void replicate_edges(int x[64], int vc, int vr) {
-    if (vc < 8) {
+    // propagate the last valid sample rightwards / downwards one step at a time: pure selects between neighbouring
+    // registers (a "pick column vc-1" formulation makes the compiler index the block dynamically = scratch)
+    CSH_UNROLL
+    for (int c = 1; c < 8; c++) {
+        const bool keep = c < vc;
         CSH_UNROLL
-        for (int r = 0; r < 8; r++) {
-            int last = x[8 * r];
-            CSH_UNROLL
-            for (int c = 1; c < 8; c++) last = (c < vc) ? x[8 * r + c] : last;
-            CSH_UNROLL
-            for (int c = 1; c < 8; c++) x[8 * r + c] = (c < vc) ? x[8 * r + c] : last;
-        }
+        for (int r = 0; r < 8; r++) x[8 * r + c] = keep ? x[8 * r + c] : x[8 * r + c - 1];
     }
-    if (vr < 8) {
+    CSH_UNROLL
+    for (int r = 1; r < 8; r++) {
+        const bool keep = r < vr;
         CSH_UNROLL
-        for (int c = 0; c < 8; c++) {
-            int last = x[c];
-            CSH_UNROLL
-            for (int r = 1; r < 8; r++) last = (r < vr) ? x[8 * r + c] : last;
-            CSH_UNROLL
-            for (int r = 1; r < 8; r++) x[8 * r + c] = (r < vr) ? x[8 * r + c] : last;
-        }
+        for (int c = 0; c < 8; c++) x[8 * r + c] = keep ? x[8 * r + c] : x[8 * (r - 1) + c];
     }
 }
 
-// samples (0..255, natural order) -> level shift -> 2-D FDCT -> scalar quantise -> store zig-zag rows
+// samples (0..255, natural order) -> level shift -> 2-D FDCT -> scalar quantise -> store as 8 x 16-byte octets
+template <int K>
+__device__ __forceinline__ static uint32_t quant_one(const int x[64], const DevQuant &q) {
+    int d = q.div[K];
+    int t = x[kZ2N[K]], a = t < 0 ? -t : t;
+    a += d >> 1;
+    // exact a/d: float estimate (a < 2^24) with one correction step
+    int qv = int(float(a) * q.rcp[K]);
+    int r = a - qv * d;
+    qv += (r >= d) ? 1 : 0;
+    qv -= (r < 0) ? 1 : 0;
+    return uint32_t(t < 0 ? -qv : qv) & 0xFFFFu;
+}
+template <int J>
+__device__ __forceinline__ static void quant_store_octet(const int x[64], const DevQuant &q, int16_t *__restrict__ blk) {
+    uint4 v;
+    v.x = quant_one<8 * J + 0>(x, q) | (quant_one<8 * J + 1>(x, q) << 16);
+    v.y = quant_one<8 * J + 2>(x, q) | (quant_one<8 * J + 3>(x, q) << 16);
+    v.z = quant_one<8 * J + 4>(x, q) | (quant_one<8 * J + 5>(x, q) << 16);
+    v.w = quant_one<8 * J + 6>(x, q) | (quant_one<8 * J + 7>(x, q) << 16);
+    *reinterpret_cast<uint4 *>(blk + 512 * J) = v;
+}
+template <int... J>
+__device__ __forceinline__ static void quant_store_all(const int x[64], const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
+    ((quant_store_octet<J>(x, q, blk), CSH_SCHED_FENCE()), ...);
+}
 __device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk) {
+    CSH_SCHED_FENCE();
     CSH_UNROLL
-    for (int n = 0; n < 64; n++) x[n] -= 128;
-    CSH_UNROLL
-    for (int r = 0; r < 8; r++) fdct1d<true>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
+    for (int r = 0; r < 8; r++) {
+        CSH_UNROLL
+        for (int c = 0; c < 8; c++) x[8 * r + c] -= 128;
+        fdct1d<true>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
+    }
+    CSH_SCHED_FENCE();
     CSH_UNROLL
     for (int c = 0; c < 8; c++) fdct1d<false>(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
-    CSH_UNROLL
-    for (int n = 0; n < 64; n++) {
-        int k = kN2Z[n];
-        int d = q.div[k];
-        int t = x[n], a = t < 0 ? -t : t;
-        a += d >> 1;
-        // exact a/d: float estimate (a < 2^24) with one correction step
-        int qv = int(float(a) * q.rcp[k]);
-        int r = a - qv * d;
-        qv += (r >= d) ? 1 : 0;
-        qv -= (r < 0) ? 1 : 0;
-        blk[k << 6] = int16_t(t < 0 ? -qv : qv);
-    }
+    CSH_SCHED_FENCE();
+    quant_store_all(x, q, blk, Oct());
 }
 
 __device__ __forceinline__ static void store_zero_block(int16_t *__restrict__ blk) {
+    uint4 z; z.x = z.y = z.z = z.w = 0;
     CSH_UNROLL
-    for (int k = 0; k < 64; k++) blk[k << 6] = 0;
+    for (int j = 0; j < 8; j++) *reinterpret_cast<uint4 *>(blk + 512 * j) = z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -213,92 +251,89 @@ __device__ static int up_h2v1(const PlaneView &v, int r, int xx) {
     return (3 * pv(v, r, cx) + pv(v, r, nb) + ((xx & 1) ? 2 : 1)) >> 2;
 }
 
-// generic (edge-block) path: out(y,x) = box of the four full-res samples under it, with libjpeg's clamps
+// one sample of the encoder-side plane: box of the four full-resolution samples under it, with libjpeg's clamps
+// (right edge: full-res columns replicate; bottom: rows below the last DOWNSAMPLED row replicate it -- SURVEY B.6)
 template <int MODE>
-__device__ static void resample_block_slow(const PlaneView &v, int W, int H, int out_ch, int by, int bx, int x[64]) {
-    for (int Y = 0; Y < 8; Y++) {
-        int y = by * 8 + Y;
-        int ye = y < out_ch - 1 ? y : out_ch - 1;  // rows below the last downsampled row replicate it
-        for (int X = 0; X < 8; X++) {
-            int xo = bx * 8 + X, sum = 0;
-            for (int dy = 0; dy < 2; dy++)
-                for (int dx = 0; dx < 2; dx++) {
-                    int r = 2 * ye + dy, xx = 2 * xo + dx;
-                    r = r > H - 1 ? H - 1 : r;
-                    xx = xx > W - 1 ? W - 1 : xx;
-                    sum += (MODE == 2) ? up_h2v2(v, r, xx) : (MODE == 4 ? up_h2v1(v, r, xx) : pv(v, r, xx));
-                }
-            x[8 * Y + X] = (sum + ((xo & 1) ? 2 : 1)) >> 2;
-        }
-    }
-}
-
-__device__ __forceinline__ static int byte_of(const uint4 &q, int i) {  // i compile-time after unrolling
-    uint32_t w = i < 4 ? q.x : (i < 8 ? q.y : (i < 12 ? q.z : q.w));
-    return int((w >> (8 * (i & 3))) & 255u);
-}
-
-// mode 2 interior path: 10x10 window of the subsampled plane -> composite fancy-up + box-down
-__device__ __forceinline__ static void resample_block_420(const PlaneView &v, int rows_alloc, int by, int bx, int x[64]) {
-    // window row j <-> plane row by*8-1+j ; window col i <-> plane col bx*8-1+i
-    int c0[10], c1[10], c2[10];  // three consecutive window rows
-    int cs0[10], cs1[10];
-    const int xoff = bx > 0 ? bx * 8 - 4 : 0;
-    const int sh = bx > 0 ? 3 : -1;  // window col i sits at byte (i + sh) of the 16-byte load
-    auto load_row = [&](int j, int out[10]) {
-        int y = by * 8 - 1 + j;
-        y = y < 0 ? 0 : (y > rows_alloc - 1 ? rows_alloc - 1 : y);
-        const uint8_t *rp = v.p + size_t(y) * v.pitch + xoff;
-        uint4 q;
-        q.x = reinterpret_cast<const uint32_t *>(rp)[0]; q.y = reinterpret_cast<const uint32_t *>(rp)[1];
-        q.z = reinterpret_cast<const uint32_t *>(rp)[2]; q.w = reinterpret_cast<const uint32_t *>(rp)[3];
-        if (bx > 0) {
-            CSH_UNROLL
-            for (int i = 0; i < 10; i++) out[i] = byte_of(q, i + 3);
-        } else {
-            out[0] = byte_of(q, 0);
-            CSH_UNROLL
-            for (int i = 1; i < 10; i++) out[i] = byte_of(q, i - 1);
-        }
-        if (bx * 8 + 8 > v.pitch - 1) out[9] = out[8];  // right neighbour outside the plane: replicate
-    };
-    (void)sh;
-    load_row(0, c0); load_row(1, c1);
+__device__ __forceinline__ static int resample_one(const PlaneView &v, int W, int H, int out_ch, int y, int xo) {
+    int ye = y < out_ch - 1 ? y : out_ch - 1;
+    int sum = 0;
     CSH_UNROLL
-    for (int Y = 0; Y < 8; Y++) {
-        load_row(Y + 2, c2);
+    for (int dy = 0; dy < 2; dy++) {
         CSH_UNROLL
-        for (int i = 0; i < 10; i++) { cs0[i] = 3 * c1[i] + c0[i]; cs1[i] = 3 * c1[i] + c2[i]; }
-        CSH_UNROLL
-        for (int X = 0; X < 8; X++) {
-            int i = X + 1;
-            int u00 = (3 * cs0[i] + cs0[i - 1] + 8) >> 4, u01 = (3 * cs0[i] + cs0[i + 1] + 7) >> 4;
-            int u10 = (3 * cs1[i] + cs1[i - 1] + 8) >> 4, u11 = (3 * cs1[i] + cs1[i + 1] + 7) >> 4;
-            x[8 * Y + X] = (u00 + u01 + u10 + u11 + ((X & 1) ? 2 : 1)) >> 2;
+        for (int dx = 0; dx < 2; dx++) {
+            int r = 2 * ye + dy, xx = 2 * xo + dx;
+            r = r > H - 1 ? H - 1 : r;
+            xx = xx > W - 1 ? W - 1 : xx;
+            sum += (MODE == 2) ? up_h2v2(v, r, xx) : (MODE == 4 ? up_h2v1(v, r, xx) : pv(v, r, xx));
         }
-        CSH_UNROLL
-        for (int i = 0; i < 10; i++) { c0[i] = c1[i]; c1[i] = c2[i]; }
     }
+    return (sum + ((xo & 1) ? 2 : 1)) >> 2;
 }
 
-// mode 3 interior path: 16x16 full-resolution samples -> h2v2 box
-__device__ __forceinline__ static void resample_block_box(const PlaneView &v, int by, int bx, int x[64]) {
+// decoded plane -> encoder-side plane, 4 samples per lane (one dword store).  Interior quads of the 4:2:0 -> 4:2:0 case
+// take a vector path (3 rows x 3 dwords in, composite triangle-up o box-down in registers); everything else goes through
+// the same clamped per-sample formula, so image borders, odd sizes and tiny planes need no special code.
+__device__ __forceinline__ static uint32_t resample_quad_420(const PlaneView &v, int rows_alloc, int y, int x0) {
+    // window columns x0-1 .. x0+4 of plane rows y-1, y, y+1 (row index clamped; columns all inside the plane)
+    int c[3][6];
     CSH_UNROLL
-    for (int Y = 0; Y < 8; Y++) {
-        const uint8_t *r0 = v.p + size_t(by * 16 + 2 * Y) * v.pitch + bx * 16;
-        uint4 a = *reinterpret_cast<const uint4 *>(r0), b = *reinterpret_cast<const uint4 *>(r0 + v.pitch);
-        CSH_UNROLL
-        for (int X = 0; X < 8; X++)
-            x[8 * Y + X] = (byte_of(a, 2 * X) + byte_of(a, 2 * X + 1) + byte_of(b, 2 * X) + byte_of(b, 2 * X + 1) + ((X & 1) ? 2 : 1)) >> 2;
+    for (int j = 0; j < 3; j++) {
+        int yy = y - 1 + j;
+        yy = yy < 0 ? 0 : (yy > rows_alloc - 1 ? rows_alloc - 1 : yy);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(v.p + size_t(yy) * v.pitch + x0);
+        uint32_t a = rp[-1], b = rp[0], d = rp[1];
+        c[j][0] = int(a >> 24);
+        c[j][1] = int(b & 255u); c[j][2] = int((b >> 8) & 255u); c[j][3] = int((b >> 16) & 255u); c[j][4] = int(b >> 24);
+        c[j][5] = int(d & 255u);
     }
+    int cs0[6], cs1[6];
+    CSH_UNROLL
+    for (int i = 0; i < 6; i++) { cs0[i] = 3 * c[1][i] + c[0][i]; cs1[i] = 3 * c[1][i] + c[2][i]; }
+    uint32_t out = 0;
+    CSH_UNROLL
+    for (int X = 0; X < 4; X++) {
+        int i = X + 1;
+        int u00 = (3 * cs0[i] + cs0[i - 1] + 8) >> 4, u01 = (3 * cs0[i] + cs0[i + 1] + 7) >> 4;
+        int u10 = (3 * cs1[i] + cs1[i - 1] + 8) >> 4, u11 = (3 * cs1[i] + cs1[i + 1] + 7) >> 4;
+        out |= uint32_t((u00 + u01 + u10 + u11 + ((X & 1) ? 2 : 1)) >> 2) << (8 * X);
+    }
+    return out;
 }
 
-__global__ void __launch_bounds__(256) k_resample_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant,
-                                                        const uint8_t *planes, int16_t *coef_out) {
+__global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, const PlaneWork *work, const uint8_t *planes, uint8_t *oplanes) {
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0) return;
     const ImgDesc &im = imgs[w.image];
     const CompGeom gi = im.in[w.comp], go = im.out[w.comp];
+    const int pitch_o = go.real_bw * 8, rows_o = go.real_bh * 8;
+    int q = blockIdx.x * blockDim.x + threadIdx.x;  // quad index
+    if (q >= (pitch_o >> 2) * rows_o) return;
+    int y = q / (pitch_o >> 2), x0 = (q - y * (pitch_o >> 2)) * 4;
+    PlaneView v;
+    v.p = planes + im.plane_off[w.comp]; v.pitch = gi.real_bw * 8; v.cw = gi.comp_w; v.ch = gi.comp_h;
+    uint32_t out = 0;
+    // vector path <=> no full-resolution clamp under the quad and its column neighbours lie inside the decoded plane
+    if (w.mode == 2 && x0 >= 4 && x0 + 8 <= v.pitch && 2 * (x0 + 3) + 1 <= im.width - 1 && 2 * y + 1 <= im.height - 1 && gi.comp_w > 2) {
+        out = resample_quad_420(v, gi.real_bh * 8, y, x0);
+    } else {
+        CSH_UNROLL
+        for (int i = 0; i < 4; i++) {
+            int s = w.mode == 2 ? resample_one<2>(v, im.width, im.height, go.comp_h, y, x0 + i)
+                  : w.mode == 3 ? resample_one<3>(v, im.width, im.height, go.comp_h, y, x0 + i)
+                                : resample_one<4>(v, im.width, im.height, go.comp_h, y, x0 + i);
+            out |= uint32_t(s) << (8 * i);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(oplanes + im.oplane_off[w.comp] + size_t(y) * pitch_o + x0) = out;
+}
+
+// encoder-side plane -> FDCT -> quantise, one block per lane
+__global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *oplanes,
+                                                     int16_t *coef_out) {
+    const PlaneWork w = work[blockIdx.y];
+    if (w.mode == 0) return;
+    const ImgDesc &im = imgs[w.image];
+    const CompGeom go = im.out[w.comp];
     int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     int b = tile * 64 + lane;
@@ -306,19 +341,15 @@ __global__ void __launch_bounds__(256) k_resample_fdct(const ImgDesc *imgs, cons
     int by = b / go.bw, bx = b - by * go.bw;
     int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
     if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); return; }
-    PlaneView v;
-    v.p = planes + im.plane_off[w.comp]; v.pitch = gi.real_bw * 8; v.cw = gi.comp_w; v.ch = gi.comp_h;
+    const int pitch = go.real_bw * 8;
+    const uint8_t *p = oplanes + im.oplane_off[w.comp] + size_t(by * 8) * pitch + bx * 8;
     int x[64];
-    const int W = im.width, H = im.height;
-    // interior <=> none of the 16x16 full-resolution samples under this block is clamped
-    bool interior = (16 * bx + 15 <= W - 1) && (16 * by + 15 <= H - 1);
-    if (w.mode == 2) {
-        if (interior && gi.comp_w > 2) resample_block_420(v, gi.real_bh * 8, by, bx, x);
-        else resample_block_slow<2>(v, W, H, go.comp_h, by, bx, x);
-    } else if (w.mode == 3) {
-        if (interior && ((v.pitch & 15) == 0)) resample_block_box(v, by, bx, x);
-        else resample_block_slow<3>(v, W, H, go.comp_h, by, bx, x);
-    } else resample_block_slow<4>(v, W, H, go.comp_h, by, bx, x);  // 4:2:2 source: generic path only (rare input)
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p + size_t(r) * pitch);
+        CSH_UNROLL
+        for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
+    }
     fdct_quant_store(x, quant[im.qt_out[w.comp]], dst);
 }
 
@@ -355,9 +386,12 @@ void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *wor
                        const int16_t *coef_in, uint8_t *planes) {
     if (nwork) CSH_LAUNCH(k_idct_plane, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, coef_in, planes);
 }
-void launch_resample_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                          const uint8_t *planes, int16_t *coef_out) {
-    if (nwork) CSH_LAUNCH(k_resample_fdct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, planes, coef_out);
+void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, uint32_t max_quads, const uint8_t *planes, uint8_t *oplanes) {
+    if (nwork && max_quads) CSH_LAUNCH(k_resample_plane, dim3((max_quads + 255) / 256, nwork), dim3(256), st, imgs, work, planes, oplanes);
+}
+void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                       const uint8_t *oplanes, int16_t *coef_out) {
+    if (nwork) CSH_LAUNCH(k_plane_fdct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out);
 }
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out) {
     if (nimg && max_blocks) CSH_LAUNCH(k_fix_dummy, dim3((max_blocks + 255) / 256, nimg), dim3(256), st, imgs, nimg, coef_out);

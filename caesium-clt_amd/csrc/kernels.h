@@ -5,8 +5,10 @@
 
 namespace csh {
 
+// coefficient tile addressing (types.h): element (block b, zig-zag k) of a component
+__host__ __device__ static inline int coef_off(int k) { return ((k >> 3) << 9) + (k & 7); }  // relative to the block's base
 __host__ __device__ static inline size_t coef_index(uint32_t tile_base, int b, int k) {
-    return (size_t(tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t(k << 6) + size_t(b & 63);
+    return (size_t(tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) << 3) + size_t(coef_off(k));
 }
 
 // ---- phase 0: entropy decode (k_decode.hip)
@@ -35,12 +37,13 @@ void launch_xform_direct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *w
 // subsampled components: IDCT to a u8 plane (edges replicated), then resample + FDCT + quantise
 void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
                        const int16_t *coef_in, uint8_t *planes);
-void launch_resample_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                          const uint8_t *planes, int16_t *coef_out);
+void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, uint32_t max_quads, const uint8_t *planes, uint8_t *oplanes);
+void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                       const uint8_t *oplanes, int16_t *coef_out);
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
 
 // ---- phases 2-6: entropy encode (k_entropy.hip)
-void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t ntiles_total);
+void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t first_tile, uint32_t ntiles);
 
 struct EncCtx {  // device pointers + sizes every entropy kernel needs
     const ImgDesc *imgs;

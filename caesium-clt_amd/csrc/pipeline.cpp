@@ -91,13 +91,14 @@ struct csh_batch {
     std::vector<ScanWork> swork;
     std::vector<uint8_t> bits_pool, hdr_pool;
     std::vector<uint32_t> hdr_off;
-    uint32_t ntiles = 0, max_tiles = 0, max_units = 0, max_dummy = 0;
-    uint64_t total_units = 0, total_words = 0, plane_bytes = 0;
+    uint32_t ntiles = 0, ntiles_in = 0, ntiles_out = 0, max_tiles = 0, max_units = 0, max_dummy = 0;
+    uint64_t total_units = 0, total_words = 0, plane_bytes = 0, oplane_bytes = 0;
+    uint32_t max_quads = 0;
     int ntables = 0;
     uint64_t raw_bytes_cap = 0, out_cap = 0;
 
     // device buffers
-    DevBuf<uint8_t> d_bits, d_clean, d_planes, d_hdr, d_out, d_tail;
+    DevBuf<uint8_t> d_bits, d_clean, d_planes, d_oplanes, d_hdr, d_out, d_tail;
     DevBuf<ParScan> d_pscans;
     DevBuf<uint64_t> d_pstate, d_relax_list[2], d_unstuff_off, d_blk_off, d_dc_off;
     DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt;
@@ -261,7 +262,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
 
     std::vector<std::pair<std::vector<uint8_t>, int>> hset_keys;
     std::map<std::vector<uint16_t>, int> quant_index;
-    uint32_t plane_off = 0;
+    uint32_t plane_off = 0, oplane_off = 0;
 
     for (size_t n = 0; n < count; n++) {
         Item &it = b->items[n];
@@ -283,10 +284,10 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         im.width = in.width; im.height = in.height; im.ncomp = in.ncomp;
         im.mcus_x = in.mcus_x; im.mcus_y = in.mcus_y;
         im.progressive_in = in.progressive;
-        for (int c = 0; c < in.ncomp; c++) fill_geom(in.comp[c], im.in[c], b->ntiles);
+        for (int c = 0; c < in.ncomp; c++) fill_geom(in.comp[c], im.in[c], b->ntiles_in);
         for (int c = 0; c < in.ncomp; c++) {
             if (b->lossless) im.out[c] = im.in[c];
-            else fill_geom(o.comp[c], im.out[c], b->ntiles);
+            else fill_geom(o.comp[c], im.out[c], b->ntiles_out);  // rebased behind all decoded tiles below
             im.comp_id[c] = o.comp[c].id;
             std::vector<uint16_t> key(in.qt[in.comp[c].tq], in.qt[in.comp[c].tq] + 64);
             auto f = quant_index.find(key);
@@ -393,6 +394,10 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                     im.plane_off[c] = plane_off;
                     plane_off += uint32_t(im.in[c].real_bw * 8 * im.in[c].real_bh * 8);
                     plane_off = (plane_off + 63u) & ~63u;
+                    im.oplane_off[c] = oplane_off;
+                    uint32_t osz = uint32_t(im.out[c].real_bw * 8 * im.out[c].real_bh * 8);
+                    oplane_off = (oplane_off + osz + 63u) & ~63u;
+                    b->max_quads = std::max(b->max_quads, osz / 4);
                 }
                 b->pwork.push_back(w);
             }
@@ -434,7 +439,12 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     }
     b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
     b->nimg = int(b->imgs.size());
+    // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
+    if (!b->lossless)
+        for (ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) im.out[c].tile_base += b->ntiles_in;
+    b->ntiles = b->ntiles_in + b->ntiles_out;
     b->plane_bytes = plane_off;
+    b->oplane_bytes = oplane_off;
     b->out_cap = b->raw_bytes_cap;
 
     // upload what never changes between runs
@@ -453,7 +463,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2))
                 return CS_ERR_NO_DEVICE;
         }
-        if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) ||
+        if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
             b->d_masks.alloc(size_t(b->ntiles) * 192) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
             b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
             b->d_unit_off.alloc(b->total_units + 2) || b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
@@ -471,7 +481,7 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
-    "k_idct_plane", "k_xform_direct", "k_resample_fdct", "k_fix_dummy", "memset_enc", "k_masks",
+    "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "k_masks",
     "k_ac_flags", "k_ac_runs", "k_stats", "k_gen_tables", "k_sizes", "scan_units", "scan_layout", "k_pack",
     "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", "", "", ""};
 static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7};
@@ -495,7 +505,8 @@ static int run_once(csh_batch *b, csh_timing *t) {
 #define MARK() CSH_CHECK(hipEventRecord(ev[++slot], st))
     CSH_CHECK(hipEventRecord(ev[0], st));
     // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
-    if (b->d_coef.zero(st) || b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
+    CSH_CHECK(hipMemsetAsync(b->d_coef.p, 0, size_t(b->ntiles_in) * CSH_TILE_I16 * sizeof(int16_t), st));
+    if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
     CSH_CHECK(hipMemcpyAsync(b->d_need_seq.p, b->d_need_seq_init.p, size_t(nimg) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     MARK();
     {   // parallel self-synchronising decode of sequential-mode scans
@@ -538,7 +549,8 @@ static int run_once(csh_batch *b, csh_timing *t) {
     MARK();
     launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p);
     MARK();
-    launch_resample_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_planes.p, b->d_coef.p);
+    launch_resample_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_quads, b->d_planes.p, b->d_oplanes.p);
+    launch_plane_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_oplanes.p, b->d_coef.p);
     MARK();
     if (!b->lossless) launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
     MARK();
@@ -551,7 +563,8 @@ static int run_once(csh_batch *b, csh_timing *t) {
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p;
     if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st)) return -1;
     MARK();
-    launch_masks(st, b->d_coef.p, b->d_masks.p, b->ntiles);
+    if (b->lossless) launch_masks(st, b->d_coef.p, b->d_masks.p, 0, b->ntiles_in);
+    else launch_masks(st, b->d_coef.p, b->d_masks.p, b->ntiles_in, b->ntiles_out);
     MARK();
     launch_ac_flags(st, c);
     MARK();
@@ -695,7 +708,7 @@ extern "C" int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int wh
     std::vector<int16_t> tiles(size_t(g.ntiles) * CSH_TILE_I16);
     if (hipMemcpy(tiles.data(), b->d_coef.p + size_t(g.tile_base) * CSH_TILE_I16, tiles.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return -1; }
     for (int blk = 0; blk < bw * bh; blk++)
-        for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + (k << 6) + (blk & 63)];
+        for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + ((blk & 63) << 3) + coef_off(k)];
     return 0;
 }
 

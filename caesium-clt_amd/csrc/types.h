@@ -1,10 +1,11 @@
 // types.h -- descriptors shared by the host pipeline and the kernels.
 //
 // HBM data layout (DESIGN.md "Data layout"):
-//  * coefficient TILE = 64 consecutive blocks (padded raster order of one component of one image),
-//    stored k-major: int16 tile[64 /*zig-zag k*/][64 /*block in tile*/]  (8 KiB).  A wave owns a tile,
-//    lane = block: every access "coefficient k of my block" is one fully coalesced 128-byte row, and a
-//    band-limited progressive scan (Ss..Se) touches only rows Ss..Se.
+//  * coefficient TILE = 64 consecutive blocks (padded raster order of one component of one image), 8 KiB,
+//    stored as 8 "octets": int16 tile[8 /*k>>3*/][64 /*block in tile*/][8 /*k&7*/].  A wave owns a tile,
+//    lane = block: octet j of every block is one 16-byte vector per lane = one fully coalesced 1 KiB access per
+//    wave (8 such loads/stores move a tile); a band-limited progressive scan (Ss..Se) touches only octets
+//    Ss>>3..Se>>3; a block's coefficients touch at most 8 cache lines (shared with 7 neighbour blocks).
 //  * per-block 64-bit significance masks M0/M1/M2 (bit k set iff |coef k| >= 1 / 2 / 4), SoA per tile:
 //    u64 mask[3][64 lanes].  The progressive coder's run/EOB logic is bit algebra on these.
 //  * u8 sample planes (subsampled components only), pitch = real_bw*8, rows = bh*8, edges replicated.
@@ -55,7 +56,8 @@ struct ImgDesc {
     CompGeom out[CSH_MAX_COMPS];  // re-encoded geometry (== in for the lossless transcode)
     int qt_in[CSH_MAX_COMPS];     // index into the quant pool (zig-zag u16[64] + divisors)
     int qt_out[CSH_MAX_COMPS];
-    uint32_t plane_off[CSH_MAX_COMPS];  // byte offset of the u8 plane (subsampled comps)
+    uint32_t plane_off[CSH_MAX_COMPS];  // byte offset of the decoded u8 plane (components that are resampled)
+    uint32_t oplane_off[CSH_MAX_COMPS]; // byte offset of the resampled u8 plane (encoder-side geometry)
     int first_scan, nscans_in;    // range in the DecScan array
     int comp_id[CSH_MAX_COMPS];   // component identifiers written to SOF/SOS
     int first_work, nscans_out;   // this image's ScanWork range (output scans, in file order)
