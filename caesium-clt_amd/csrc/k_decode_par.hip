@@ -171,45 +171,52 @@ __device__ __forceinline__ static int huff_lookup(const DevHuff &h, uint32_t top
 __device__ __forceinline__ static int extend_p(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
 
 // decode from state `st` until st.pos >= stop_bit; returns #blocks completed.  WRITE: store coefficients.
+// Everything that depends on the block-in-MCU index m (Huffman tables, component, DC slot, tile address) is refreshed
+// once per BLOCK, with the MCU coordinates advanced incrementally (no divisions in the loop); a coefficient's value bits
+// are taken from the same 32-bit window as its code (code <= 16 bits + value <= 16 bits).
 template <bool WRITE, class R>
 __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuffSet &hs, const ParScan &ps, PState &st, uint32_t stop_bit,
-                                        uint32_t ordinal, const ImgDesc *im, int16_t *coef, int32_t *dcdiff) {
+                                                        uint32_t ordinal, const ImgDesc *im, int16_t *coef, int32_t *dcdiff) {
     uint32_t nblk = 0;
     int16_t *blk = nullptr;
-    auto locate = [&](uint32_t ord) {
-        if (!WRITE) return;
-        blk = nullptr;
-        if (ord >= ps.total_blocks) return;
-        uint32_t mcu = ord / uint32_t(ps.nb_mcu);
-        int m = int(ord - mcu * uint32_t(ps.nb_mcu));
+    int32_t *dcp = nullptr;
+    const DevHuff *dct = &hs.dc[ps.dct[st.m]], *act = &hs.ac[ps.act[st.m]];
+    // WRITE-only bookkeeping: which block we are in
+    uint32_t mcu = 0; int mx = 0, my = 0, mcus_x = 1;
+    bool in_range = false;
+    auto locate = [&](int m) {
+        in_range = uint32_t(mcu) * uint32_t(ps.nb_mcu) + uint32_t(m) < ps.total_blocks;
+        if (!in_range) { blk = nullptr; dcp = nullptr; return; }
         const CompGeom &g = im->in[ps.comp_of[m]];
         int by, bx;
-        if (ps.ncomp > 1) { int my = int(mcu) / im->mcus_x, mx = int(mcu) - my * im->mcus_x; by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
-        else { by = int(mcu) / g.real_bw; bx = int(mcu) - by * g.real_bw; }
+        if (ps.ncomp > 1) { by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
+        else { by = my; bx = mx; }
         blk = coef + coef_index(g.tile_base, by * g.bw + bx, 0);
+        dcp = dcdiff + ps.dc_base[m] + mcu * ps.dc_per_mcu[m] + ps.dc_idx[m];
     };
-    locate(ordinal);
+    if (WRITE) {
+        mcu = ordinal / uint32_t(ps.nb_mcu);
+        mcus_x = ps.ncomp > 1 ? im->mcus_x : im->in[ps.comp_of[0]].real_bw;
+        my = int(mcu) / mcus_x; mx = int(mcu) - my * mcus_x;
+        locate(st.m);
+    }
     while (st.pos < stop_bit) {
         uint32_t w = peek32(rd, st.pos);
         int len;
         if (st.k == 0) {
-            int t = huff_lookup(hs.dc[ps.dct[st.m]], w >> 16, len);
-            if (WRITE && ordinal + nblk < ps.total_blocks) {
-                int diff = 0;
-                if (t) { uint32_t w2 = peek32(rd, st.pos + len); diff = extend_p(int(w2 >> (32 - t)), t); }
-                dcdiff[ps.dc_base[st.m] + (ordinal + nblk) / uint32_t(ps.nb_mcu) * ps.dc_per_mcu[st.m] + ps.dc_idx[st.m]] = diff;
-            }
+            int t = huff_lookup(*dct, w >> 16, len);
+            if (WRITE && in_range) *dcp = t ? extend_p(int((w << len) >> (32 - t)), t) : 0;
             st.pos += len + t;
             st.k = 1;
         } else {
-            int rs = huff_lookup(hs.ac[ps.act[st.m]], w >> 16, len);
+            int rs = huff_lookup(*act, w >> 16, len);
             int r = rs >> 4, n = rs & 15;
             st.pos += len;
             if (n) {
                 st.k += r;
                 if (st.k > 63) st.k = 64;  // corrupt run: block ends (no extra bits consumed, as the sequential path)
                 else {
-                    if (WRITE && blk) { uint32_t w2 = peek32(rd, st.pos); blk[coef_off(st.k)] = int16_t(extend_p(int(w2 >> (32 - n)), n)); }
+                    if (WRITE && in_range) blk[coef_off(st.k)] = int16_t(extend_p(int((w << len) >> (32 - n)), n));
                     st.pos += n;
                     st.k++;
                 }
@@ -218,9 +225,13 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuf
         }
         if (st.k >= 64) {
             st.k = 0;
-            st.m = st.m + 1 == ps.nb_mcu ? 0 : st.m + 1;
             nblk++;
-            locate(ordinal + nblk);
+            if (st.m + 1 == ps.nb_mcu) {
+                st.m = 0;
+                if (WRITE) { mcu++; if (++mx == mcus_x) { mx = 0; my++; } }
+            } else st.m++;
+            dct = &hs.dc[ps.dct[st.m]]; act = &hs.ac[ps.act[st.m]];
+            if (WRITE) locate(st.m);
         }
     }
     return nblk;
@@ -297,6 +308,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
     CSH_SHARED DevHuffSet lhs;
+    CSH_SHARED ParScan lps;   // the scan descriptor: its per-m arrays are indexed by every lane at every block
     const ParScan &ps = a.pss[blockIdx.y];
     const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     const uint32_t t0 = blockIdx.x * 256, tid = threadIdx.x, t = t0 + tid;
@@ -309,6 +321,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.huffs[ps.huff_set]);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
             for (uint32_t i = tid; i < sizeof(DevHuffSet) / 4; i += 256) dst[i] = src[i];
+            if (tid < sizeof(ParScan) / 4) reinterpret_cast<uint32_t *>(&lps)[tid] = reinterpret_cast<const uint32_t *>(&ps)[tid];
             const uint32_t w_first = t0 * (CSH_SUBSEQ_BYTES / 4);
             for (uint32_t i = 0; i < CSH_SUBSEQ_BYTES / 4 + 1; i++) {  // 33 x 256 words cover 256*32 + 4 look-ahead words
                 uint32_t d = i * 256 + tid;
@@ -329,12 +342,12 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = 0;
             if (t == 0) a.state[base] = pack_state(st);
             if (!live) { a.state[base + t + 1] = 0; continue; }
-            decode_span<false>(rd, lhs, ps, st, stop, 0, nullptr, nullptr, nullptr);
+            decode_span<false>(rd, lhs, lps, st, stop, 0, nullptr, nullptr, nullptr);
             a.state[base + t + 1] = pack_state(st);
         } else if (MODE == 1) {
             if (!live) continue;
             PState st = unpack_state(a.state[base + t]);
-            uint32_t n = decode_span<false>(rd, lhs, ps, st, stop, 0, nullptr, nullptr, nullptr);
+            uint32_t n = decode_span<false>(rd, lhs, lps, st, stop, 0, nullptr, nullptr, nullptr);
             a.nblk[ps.sub_base + t] = n;
             uint64_t e = pack_state(st);
             if (e != a.state[base + t + 1]) {
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             }
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            decode_span<true>(rd, lhs, ps, st, stop, ordinal, &a.imgs[ps.image], a.coef, a.dcdiff);
+            decode_span<true>(rd, lhs, lps, st, stop, ordinal, &a.imgs[ps.image], a.coef, a.dcdiff);
         }
     }
 }
