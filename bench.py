@@ -29,6 +29,9 @@ def algorithmic_bytes(kernel, t, n):
     planes = c // 2                # u8 chroma planes (1 B/sample vs 2 B/coefficient)
     table = {
         "k_decode_seq": t.in_bytes + coef,
+        "k_dec_spec": t.in_bytes, "k_dec_relax0": t.in_bytes,
+        "k_dec_write": t.in_bytes + coef,           # stream in, coefficient planes out (SURVEY 8d phase D)
+        "k_pack": coef + t.out_bytes, "k_stats": coef, "k_sizes": coef,
         "k_xform_direct": 2 * y,
         "k_idct_plane": c + planes,
         "k_resample+k_plane_fdct": 3 * planes + c,

@@ -23,19 +23,28 @@ static CCSResult make_result(int code, const char *msg) {
     return r;
 }
 
+// one device batch = at most CS_GROUP files: launch grids index (image, scan) pairs in gridDim.y (<= 65535), and a group
+// of 2048 1080p files already occupies ~40 GB of HBM and tens of thousands of workgroups per launch
+enum { CS_GROUP = 2048 };
 int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
-    csh_batch *b = nullptr;
-    int rc = csh_batch_create(inputs, count, p, device, &b);
-    if (rc == 0) rc = csh_batch_run(b, nullptr);
-    if (rc != 0) {
-        for (size_t i = 0; i < count; i++) if (results) results[i] = make_result(rc, csh_last_error());
+    int failed_total = 0;
+    for (size_t g0 = 0; g0 < count; g0 += CS_GROUP) {
+        size_t n = count - g0 < size_t(CS_GROUP) ? count - g0 : size_t(CS_GROUP);
+        csh_batch *b = nullptr;
+        int rc = csh_batch_create(inputs + g0, n, p, device, &b);
+        if (rc == 0) rc = csh_batch_run(b, nullptr);
+        if (rc != 0) {
+            for (size_t i = 0; i < n; i++) if (results) results[g0 + i] = make_result(rc, csh_last_error());
+            csh_batch_destroy(b);
+            failed_total += int(n);
+            continue;
+        }
+        int failed = csh_batch_fetch(b, outputs + g0, results ? results + g0 : nullptr);
         csh_batch_destroy(b);
-        return int(count);
+        failed_total += failed < 0 ? int(n) : failed;
     }
-    int failed = csh_batch_fetch(b, outputs, results);
-    csh_batch_destroy(b);
-    return failed < 0 ? int(count) : failed;
+    return failed_total;
 }
 
 CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, CByteArray *out) {

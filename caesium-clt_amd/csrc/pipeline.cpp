@@ -242,6 +242,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     *out = nullptr;
     if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
+    if (count > 6000) { csh_set_error("csh_batch_create: at most 6000 files per device batch (cs_batch_compress splits for you)"); return CS_ERR_POOL_OVERFLOW; }
     std::unique_ptr<csh_batch> b(new csh_batch);
     b->device = device;
     b->params = *p;

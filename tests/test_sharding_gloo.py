@@ -1,0 +1,44 @@
+"""N>1 host path: two processes (gloo, CPU) shard a file list round-robin, compress their shards (emulation build of the
+kernels), gather, and must reproduce the single-process result in input order."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from _util import ROOT
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, hashlib
+    sys.path[:0] = [r'{root}', r'{root}/tools', r'{root}/tests']
+    import torch.distributed as dist
+    from _util import emul_api, package, oracle_lossy
+    from gen_synth import synth_jpeg
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    pkg = package()
+    from caesium_clt_amd.sharding import compress_sharded, shard_indices
+    blobs = [synth_jpeg(i, 96 + 8 * i, 64 + 8 * (i % 3), texture=7 * i) for i in range(7)] + [b'garbage']
+    assert shard_indices(8, rank, world) == list(range(rank, 8, world))
+    res = compress_sharded(emul_api(), blobs, pkg.default_parameters(), rank, world)
+    assert len(res) == 8 and res[7][0] == 'ERR' and res[7][1] == 10200
+    for src, out in zip(blobs[:7], res[:7]):
+        assert out == oracle_lossy(src)
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+""")
+
+
+def test_two_rank_sharding_matches_oracle(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    from _util import emul_api
+    emul_api()  # build once before the ranks race to do it
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
