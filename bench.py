@@ -46,9 +46,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="1080p files per rank per step")
+    ap.add_argument("--batch", type=int, default=512, help="1080p files per rank per step")
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic images (cycled to --batch)")
-    ap.add_argument("--cpu-images", type=int, default=64, help="files timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-images", type=int, default=256, help="files timed through the CPU oracle (rank 0, N=1)")
     args = ap.parse_args()
 
     import torch
