@@ -161,12 +161,14 @@ __device__ __forceinline__ static uint32_t peek32(const R &rd, uint32_t pos) {
 __device__ __forceinline__ static int huff_lookup(const DevHuff &h, uint32_t top16, int &len) {
     int e = h.look[top16 >> 7];
     if (e) { len = e >> 8; return e & 255; }
-    for (int l = 10; l <= 16; l++) {
-        int c = int(top16 >> (16 - l));
-        if (c <= h.maxcode[l]) { len = l; return h.vals[(h.valptr[l] + c) & 255]; }
-    }
-    len = 16;
-    return 0;
+    // long code: with 64 lanes in flight some lane is almost always here, so this path must be short for the WHOLE
+    // wave: seven independent compares against left-aligned bounds instead of a 7-step dependent search
+    int l = 17;
+    CSH_UNROLL
+    for (int i = 6; i >= 0; i--) l = (top16 < h.limit[i]) ? 10 + i : l;
+    if (l == 17) { len = 16; return 0; }   // invalid code: consume 16 bits, symbol 0 (as the sequential path)
+    len = l;
+    return h.vals[(h.vbase[l - 10] + int(top16 >> (16 - l))) & 255];
 }
 __device__ __forceinline__ static int extend_p(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
 
@@ -200,40 +202,51 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuf
         my = int(mcu) / mcus_x; mx = int(mcu) - my * mcus_x;
         locate(st.m);
     }
-    while (st.pos < stop_bit) {
-        uint32_t w = peek32(rd, st.pos);
-        int len;
-        if (st.k == 0) {
+    // 64-bit bit buffer (MSB first), at least 32 valid bits after every refill: one stream word is fetched per ~32 bits
+    // consumed, so the only memory access on a symbol's critical path is its Huffman LUT entry
+    uint32_t pos = st.pos, wi = (pos >> 5) + 2;
+    int k = st.k, m = st.m;
+    uint64_t acc = ((uint64_t(rd.word(wi - 2)) << 32) | rd.word(wi - 1)) << (pos & 31);
+    int nb = 64 - int(pos & 31);
+    while (pos < stop_bit) {
+        const uint32_t w = uint32_t(acc >> 32);
+        int len, used;
+        if (k == 0) {
             int t = huff_lookup(*dct, w >> 16, len);
             if (WRITE && in_range) *dcp = t ? extend_p(int((w << len) >> (32 - t)), t) : 0;
-            st.pos += len + t;
-            st.k = 1;
+            used = len + t;
+            k = 1;
         } else {
             int rs = huff_lookup(*act, w >> 16, len);
             int r = rs >> 4, n = rs & 15;
-            st.pos += len;
+            used = len;
             if (n) {
-                st.k += r;
-                if (st.k > 63) st.k = 64;  // corrupt run: block ends (no extra bits consumed, as the sequential path)
+                k += r;
+                if (k > 63) k = 64;  // corrupt run: block ends (no extra bits consumed, as the sequential path)
                 else {
-                    if (WRITE && in_range) blk[coef_off(st.k)] = int16_t(extend_p(int((w << len) >> (32 - n)), n));
-                    st.pos += n;
-                    st.k++;
+                    if (WRITE && in_range) blk[coef_off(k)] = int16_t(extend_p(int((w << len) >> (32 - n)), n));
+                    used += n;
+                    k++;
                 }
-            } else if (r == 15) st.k += 16;
-            else st.k = 64;
+            } else if (r == 15) k += 16;
+            else k = 64;
         }
-        if (st.k >= 64) {
-            st.k = 0;
+        pos += used;
+        acc <<= used;
+        nb -= used;
+        if (nb < 32) { acc |= uint64_t(rd.word(wi++)) << (32 - nb); nb += 32; }
+        if (k >= 64) {
+            k = 0;
             nblk++;
-            if (st.m + 1 == ps.nb_mcu) {
-                st.m = 0;
+            if (m + 1 == ps.nb_mcu) {
+                m = 0;
                 if (WRITE) { mcu++; if (++mx == mcus_x) { mx = 0; my++; } }
-            } else st.m++;
-            dct = &hs.dc[ps.dct[st.m]]; act = &hs.ac[ps.act[st.m]];
-            if (WRITE) locate(st.m);
+            } else m++;
+            dct = &hs.dc[ps.dct[m]]; act = &hs.ac[ps.act[m]];
+            if (WRITE) locate(m);
         }
     }
+    st.pos = pos; st.k = k; st.m = m;
     return nblk;
 }
 

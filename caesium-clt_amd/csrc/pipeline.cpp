@@ -145,6 +145,11 @@ static void build_dev_huff(const HuffSpec &h, DevHuff &d) {
     }
     d.maxcode[17] = 0x7FFFFFFF;
     memcpy(d.vals, h.vals, 256);
+    uint32_t lim = 0;
+    for (int l = 1; l <= 16; l++) {
+        if (d.maxcode[l] >= 0) lim = uint32_t(d.maxcode[l] + 1) << (16 - l);
+        if (l >= 10) { d.limit[l - 10] = lim; d.vbase[l - 10] = d.valptr[l]; }
+    }
 }
 
 static void make_quant(const uint16_t nat[64], DevQuant &q) {

@@ -34,6 +34,10 @@ struct DevHuff {
     int32_t maxcode[18];  // per length, -1 if none
     int32_t valptr[17];
     uint8_t vals[256];
+    // branch-free long-code path (codes of 10..16 bits): limit[l-10] = left-aligned exclusive upper bound of the 16-bit
+    // window for length l (monotone in l), vbase[l-10] = valptr[l].  All 14 words are fetched at once.
+    uint32_t limit[7];
+    int32_t vbase[7];
 };
 struct DevHuffSet { DevHuff dc[4], ac[4]; };
 
