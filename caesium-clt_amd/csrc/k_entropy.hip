@@ -316,9 +316,59 @@ __device__ static void walk_dc(Sink &sink, const EncCtx &c, const ImgDesc &im, c
     }
 }
 
+// sequential-mode scan (jchuff.c encode_one_block behaviour): unit = MCU (interleaved) or block; per block DC difference,
+// then the AC coefficients straight off the |c|>=1 mask (zero run = gap between set bits), EOB unless position 63 is coded
+template <class Sink>
+__device__ static void walk_seq(Sink &sink, const EncCtx &c, const ImgDesc &im, const EncScan &sc, uint32_t u) {
+    for (int ci = 0; ci < sc.ncomp; ci++) {
+        const CompGeom &g = im.out[sc.comp[ci]];
+        int nb_x = sc.ncomp > 1 ? g.h : 1, nb_y = sc.ncomp > 1 ? g.v : 1;
+        int mx = 0, my = 0;
+        if (sc.ncomp > 1) { my = int(u) / im.omcus_x; mx = int(u) - my * im.omcus_x; }
+        int pred = 0;
+        bool have_pred = false;
+        for (int y = 0; y < nb_y; y++)
+            for (int x = 0; x < nb_x; x++) {
+                int b = sc.ncomp > 1 ? (my * g.v + y) * g.bw + mx * g.h + x : unit_block(g, u);
+                const int16_t *blk = c.coef + coef_index(g.tile_base, b, 0);
+                if (!have_pred) {
+                    if (u == 0) pred = 0;
+                    else if (sc.ncomp > 1) {
+                        int pu = int(u) - 1, pmy = pu / im.omcus_x, pmx = pu - pmy * im.omcus_x;
+                        pred = c.coef[coef_index(g.tile_base, (pmy * g.v + g.v - 1) * g.bw + pmx * g.h + g.h - 1, 0)];
+                    } else pred = c.coef[coef_index(g.tile_base, unit_block(g, u - 1), 0)];
+                    have_pred = true;
+                }
+                int dc = blk[0];
+                int t = dc - pred;
+                pred = dc;
+                unsigned a = unsigned(t < 0 ? -t : t);
+                int nb = bitlen32(a);
+                sink.sym(sc.dc_tbl[ci], nb);
+                sink.raw(unsigned(t < 0 ? t - 1 : t), nb);
+                uint64_t NZ = load_mask(c.masks, g, b, 0) & ~1ull;
+                int prev = 0;
+                while (NZ) {
+                    int k = __ffsll((unsigned long long)NZ) - 1;
+                    NZ &= NZ - 1;
+                    int r = k - prev - 1;
+                    prev = k;
+                    sink.syms(sc.ac_tbl[ci], 0xF0, r >> 4);
+                    int v = blk[coef_off(k)];
+                    unsigned av = unsigned(v < 0 ? -v : v);
+                    int nv = bitlen32(av);
+                    sink.sym(sc.ac_tbl[ci], ((r & 15) << 4) | nv);
+                    sink.raw(v < 0 ? ~av : av, nv);
+                }
+                if (prev < 63) sink.sym(sc.ac_tbl[ci], 0x00);
+            }
+    }
+}
+
 template <class Sink>
 __device__ __forceinline__ static void walk_unit(Sink &sink, const EncCtx &c, const ScanWork &w, const EncScan &sc, uint32_t u) {
     const ImgDesc &im = c.imgs[w.image];
+    if (sc.sequential) { walk_seq(sink, c, im, sc, u); return; }
     if (sc.Ss == 0) { walk_dc(sink, c, im, sc, u); return; }
     const CompGeom &g = im.out[sc.comp[0]];
     int b = unit_block(g, u);
@@ -333,7 +383,7 @@ __device__ __forceinline__ static void walk_unit(Sink &sink, const EncCtx &c, co
 // (ds_add), then flushes the non-zero bins with one global atomic each.
 #define CSH_STATS_CHUNK 2048
 struct LdsStatsSink {
-    uint32_t *hist;  // [2][257] in LDS
+    uint32_t *hist;  // [4][257] in LDS
     static constexpr bool kValues = false;
     __device__ __forceinline__ void sym(int t, int s) { atomicAdd(&hist[t * 257 + s], 1u); }
     __device__ __forceinline__ void syms(int t, int s, int n) { if (n) atomicAdd(&hist[t * 257 + s], unsigned(n)); }
@@ -341,12 +391,12 @@ struct LdsStatsSink {
     __device__ __forceinline__ void rawcount(int) {}
 };
 __global__ void __launch_bounds__(256) k_stats(EncCtx c) {
-    CSH_SHARED uint32_t hist[2 * 257];
+    CSH_SHARED uint32_t hist[4 * 257];
     const ScanWork w = c.work[blockIdx.y];
     const EncScan sc = c.script[w.scan];
     CSH_PHASE_LOOP(3) {
         if (sc.ntables == 0 || blockIdx.x * CSH_STATS_CHUNK >= w.nunits) continue;
-        if (phase == 0) { for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) hist[i] = 0; continue; }
+        if (phase == 0) { for (int i = threadIdx.x; i < 4 * 257; i += blockDim.x) hist[i] = 0; continue; }
         if (phase == 1) {
             LdsStatsSink s; s.hist = hist;
             for (uint32_t i = 0; i < CSH_STATS_CHUNK / 256; i++) {

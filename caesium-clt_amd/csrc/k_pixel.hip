@@ -251,23 +251,39 @@ __device__ static int up_h2v1(const PlaneView &v, int r, int xx) {
     return (3 * pv(v, r, cx) + pv(v, r, nb) + ((xx & 1) ? 2 : 1)) >> 2;
 }
 
-// one sample of the encoder-side plane: box of the four full-resolution samples under it, with libjpeg's clamps
-// (right edge: full-res columns replicate; bottom: rows below the last DOWNSAMPLED row replicate it -- SURVEY B.6)
-template <int MODE>
+// one sample of the encoder-side plane.  IN: how the decoded plane relates to full resolution (0 full, 1 h2v2 -> fancy
+// upsample, 2 h2v1 -> fancy upsample); OUT: the encoder's downsampling (0 none, 1 h2v2 box with bias 1,2,1,2.., 2 h2v1 box with
+// bias 0,1,0,1..).  libjpeg's edge rules: full-res columns beyond W replicate column W-1, full-res rows are
+// padded to the row group by replication, and rows below the last DOWNSAMPLED row replicate that row.
+template <int IN>
+__device__ __forceinline__ static int fullres_sample(const PlaneView &v, int r, int xx) {
+    return IN == 1 ? up_h2v2(v, r, xx) : (IN == 2 ? up_h2v1(v, r, xx) : pv(v, r, xx));
+}
+template <int IN, int OUT>
 __device__ __forceinline__ static int resample_one(const PlaneView &v, int W, int H, int out_ch, int y, int xo) {
     int ye = y < out_ch - 1 ? y : out_ch - 1;
+    const int HX = OUT ? 2 : 1, VX = OUT == 1 ? 2 : 1;
     int sum = 0;
     CSH_UNROLL
-    for (int dy = 0; dy < 2; dy++) {
+    for (int dy = 0; dy < VX; dy++) {
         CSH_UNROLL
-        for (int dx = 0; dx < 2; dx++) {
-            int r = 2 * ye + dy, xx = 2 * xo + dx;
+        for (int dx = 0; dx < HX; dx++) {
+            int r = VX * ye + dy, xx = HX * xo + dx;
             r = r > H - 1 ? H - 1 : r;
             xx = xx > W - 1 ? W - 1 : xx;
-            sum += (MODE == 2) ? up_h2v2(v, r, xx) : (MODE == 4 ? up_h2v1(v, r, xx) : pv(v, r, xx));
+            sum += fullres_sample<IN>(v, r, xx);
         }
     }
-    return (sum + ((xo & 1) ? 2 : 1)) >> 2;
+    if (OUT == 1) return (sum + ((xo & 1) ? 2 : 1)) >> 2;
+    if (OUT == 2) return (sum + (xo & 1)) >> 1;
+    return sum;
+}
+template <int IN, int OUT>
+__device__ __forceinline__ static uint32_t resample_quad(const PlaneView &v, int W, int H, int out_ch, int y, int x0) {
+    uint32_t out = 0;
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) out |= uint32_t(resample_one<IN, OUT>(v, W, H, out_ch, y, x0 + i)) << (8 * i);
+    return out;
 }
 
 // decoded plane -> encoder-side plane, 4 samples per lane (one dword store).  Interior quads of the 4:2:0 -> 4:2:0 case
@@ -313,15 +329,20 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
     v.p = planes + im.plane_off[w.comp]; v.pitch = gi.real_bw * 8; v.cw = gi.comp_w; v.ch = gi.comp_h;
     uint32_t out = 0;
     // vector path <=> no full-resolution clamp under the quad and its column neighbours lie inside the decoded plane
-    if (w.mode == 2 && x0 >= 4 && x0 + 8 <= v.pitch && 2 * (x0 + 3) + 1 <= im.width - 1 && 2 * y + 1 <= im.height - 1 && gi.comp_w > 2) {
+    const int W = im.width, H = im.height, och = go.comp_h;
+    const int in_kind = (w.mode - 1) / 3, out_kind = (w.mode - 1) % 3;   // PlaneWork.mode = 1 + 3*in + out
+    if (in_kind == 1 && out_kind == 1 && x0 >= 4 && x0 + 8 <= v.pitch && 2 * (x0 + 3) + 1 <= W - 1 && 2 * y + 1 <= H - 1 && gi.comp_w > 2) {
         out = resample_quad_420(v, gi.real_bh * 8, y, x0);
     } else {
-        CSH_UNROLL
-        for (int i = 0; i < 4; i++) {
-            int s = w.mode == 2 ? resample_one<2>(v, im.width, im.height, go.comp_h, y, x0 + i)
-                  : w.mode == 3 ? resample_one<3>(v, im.width, im.height, go.comp_h, y, x0 + i)
-                                : resample_one<4>(v, im.width, im.height, go.comp_h, y, x0 + i);
-            out |= uint32_t(s) << (8 * i);
+        switch (w.mode) {
+        case 2: out = resample_quad<0, 1>(v, W, H, och, y, x0); break;
+        case 3: out = resample_quad<0, 2>(v, W, H, och, y, x0); break;
+        case 4: out = resample_quad<1, 0>(v, W, H, och, y, x0); break;
+        case 5: out = resample_quad<1, 1>(v, W, H, och, y, x0); break;
+        case 6: out = resample_quad<1, 2>(v, W, H, och, y, x0); break;
+        case 7: out = resample_quad<2, 0>(v, W, H, och, y, x0); break;
+        case 8: out = resample_quad<2, 1>(v, W, H, och, y, x0); break;
+        default: out = resample_quad<2, 2>(v, W, H, och, y, x0); break;
         }
     }
     *reinterpret_cast<uint32_t *>(oplanes + im.oplane_off[w.comp] + size_t(y) * pitch_o + x0) = out;

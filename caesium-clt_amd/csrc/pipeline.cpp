@@ -168,14 +168,26 @@ static void fill_geom(const JComp &c, CompGeom &g, uint32_t &ntiles) {
     ntiles += g.ntiles;
 }
 
-// output progressive script -> EncScan entries (libjpeg jpeg_simple_progression; Y uses tables 0, chroma tables 1)
-static void add_script(std::vector<EncScan> &v, int ncomp) {
-    for (const OutScan &o : output_script(ncomp, true)) {
+// output script -> EncScan entries (progressive: libjpeg jpeg_simple_progression; sequential: one interleaved scan).
+// Y uses Huffman table ids 0, chroma ids 1.
+static void add_script(std::vector<EncScan> &v, int ncomp, bool progressive) {
+    for (const OutScan &o : output_script(ncomp, progressive)) {
         EncScan e;
         memset(&e, 0, sizeof e);
         e.ncomp = o.ncomp; e.Ss = o.Ss; e.Se = o.Se; e.Ah = o.Ah; e.Al = o.Al;
         for (int k = 0; k < o.ncomp; k++) e.comp[k] = o.comp[k];
-        if (o.Ss == 0) {
+        if (!progressive) {
+            e.sequential = 1;
+            for (int k = 0; k < o.ncomp; k++) {   // DHT order: per component DC then AC, each table once (libjpeg write_scan_header)
+                int id = o.comp[k] ? 1 : 0;
+                int di = -1, ai = -1;
+                for (int t = 0; t < e.ntables; t++) { if (e.dht_id[t] == id) di = t; if (e.dht_id[t] == (0x10 | id)) ai = t; }
+                if (di < 0) { di = e.ntables; e.dht_id[e.ntables++] = id; }
+                if (ai < 0) { ai = e.ntables; e.dht_id[e.ntables++] = 0x10 | id; }
+                e.dc_tbl[k] = di; e.ac_tbl[k] = ai;
+                e.sos_tdta[k] = (id << 4) | id;
+            }
+        } else if (o.Ss == 0) {
             if (o.Ah == 0) {
                 e.ntables = 0;
                 for (int k = 0; k < o.ncomp; k++) {
@@ -230,8 +242,8 @@ static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
         bool chroma11 = in.comp[1].h == 1 && in.comp[1].v == 1 && in.comp[2].h == 1 && in.comp[2].v == 1;
         if (!chroma11 || !(in444 || in420 || in422)) { it.msg = "input chroma sampling other than 4:4:4 / 4:2:2 / 4:2:0 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
         if (ss == 420) { o.comp[0].h = 2; o.comp[0].v = 2; }
-        else if (ss == 444) { if (!in444) { it.msg = "4:2:0 -> 4:4:4 not on the device path yet"; return CS_ERR_JPEG_FEATURE; } }
-        else { it.msg = "output chroma subsampling 4:2:2 / 4:1:1 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
+        else if (ss == 422) { o.comp[0].h = 2; o.comp[0].v = 1; }
+        else if (ss != 444) { it.msg = "output chroma subsampling 4:1:1 not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
     }
     jpeg_geometry(o);
     return 0;
@@ -252,7 +264,6 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     b->device = device;
     b->params = *p;
     b->lossless = p->jpeg_optimize;
-    if (!p->jpeg_progressive) { /* sequential output: handled per item below */ }
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     b->items.resize(count);
@@ -262,9 +273,12 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     DevQuant qo; make_quant(qout_nat, qo);
     b->quants.push_back(qo);  // index 0: output table (luma == chroma in mozjpeg's profile 3)
 
-    add_script(b->script, 3);  // entries 0..9
-    add_script(b->script, 1);  // entries 10..15
-    const int script_base3 = 0, script_base1 = 10;
+    const bool progressive = p->jpeg_progressive;
+    add_script(b->script, 3, true);   // entries 0..9
+    add_script(b->script, 1, true);   // entries 10..15
+    add_script(b->script, 3, false);  // entry 16
+    add_script(b->script, 1, false);  // entry 17
+    const int script_base3 = progressive ? 0 : 16, script_base1 = progressive ? 10 : 17;
 
     std::vector<std::pair<std::vector<uint8_t>, int>> hset_keys;
     std::map<std::vector<uint16_t>, int> quant_index;
@@ -278,7 +292,6 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         int type = sniff_type(d, len);
         if (type == CS_TYPE_UNKN) { it.code = CS_ERR_UNKNOWN_TYPE; it.msg = "unknown file type"; continue; }
         if (type != CS_TYPE_JPEG) { it.code = CS_ERR_UNSUPPORTED; it.msg = "only JPEG has a device path in this build"; continue; }
-        if (!p->jpeg_progressive) { it.code = CS_ERR_UNSUPPORTED; it.msg = "sequential (--jpeg-baseline) output not on the device path yet"; continue; }
         it.code = parse_jpeg(d, len, it.in, it.msg);
         if (it.code) continue;
         it.code = plan_item(it, *p, b->lossless);
@@ -393,9 +406,9 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 PlaneWork w; w.image = img_index; w.comp = c;
                 bool in_full = in.comp[c].h == in.hmax && in.comp[c].v == in.vmax;
                 bool out_full = o.comp[c].h == o.hmax && o.comp[c].v == o.vmax;
-                if (in_full && out_full) w.mode = 0;
-                else if (!in_full && !out_full) w.mode = (in.comp[c].v == in.vmax) ? 4 : 2;  // 4:2:2 / 4:2:0 chroma -> 4:2:0 chroma
-                else w.mode = 3;                               // full-res chroma -> h2v2 box
+                int in_kind = in_full ? 0 : (in.comp[c].v == in.vmax ? 2 : 1);    // 0 full, 1 h2v2, 2 h2v1
+                int out_kind = out_full ? 0 : (o.comp[c].v == o.vmax ? 2 : 1);
+                w.mode = (in_kind == 0 && out_kind == 0) ? 0 : 1 + 3 * in_kind + out_kind;
                 if (w.mode) {
                     im.plane_off[c] = plane_off;
                     plane_off += uint32_t(im.in[c].real_bw * 8 * im.in[c].real_bh * 8);
@@ -410,7 +423,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
 
         // output scans
         int sb = in.ncomp == 3 ? script_base3 : script_base1;
-        int ns = in.ncomp == 3 ? 10 : 6;
+        int ns = progressive ? (in.ncomp == 3 ? 10 : 6) : 1;
         im.first_work = int(b->swork.size());
         im.nscans_out = ns;
         for (int s = 0; s < ns; s++) {
@@ -435,7 +448,16 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         JpegInfo hdr = o;
         if (b->lossless) memcpy(hdr.qt, in.qt, sizeof hdr.qt);           // coefficient transcode keeps the source tables
         else { memcpy(hdr.qt[0], qout_nat, 128); memcpy(hdr.qt[1], qout_nat, 128); }
-        std::vector<uint8_t> fh = build_frame_header(hdr, true, p->keep_metadata ? &in.meta : nullptr);
+        // metadata carry-over (host logic): APPn/COM when keep_metadata (compressor.rs:431); ICC profile segments follow
+        // jpeg_preserve_icc = !--strip-icc (compressor.rs:425) independently of it
+        std::vector<uint8_t> meta;
+        for (size_t mo = 0; mo + 4 <= in.meta.size();) {
+            size_t L = (size_t(in.meta[mo + 2]) << 8) | in.meta[mo + 3];
+            bool is_icc = in.meta[mo + 1] == 0xE2 && L >= 14 && !memcmp(&in.meta[mo + 4], "ICC_PROFILE\0", 12);
+            if (is_icc ? p->jpeg_preserve_icc : p->keep_metadata) meta.insert(meta.end(), in.meta.begin() + mo, in.meta.begin() + mo + 2 + L);
+            mo += 2 + L;
+        }
+        std::vector<uint8_t> fh = build_frame_header(hdr, progressive, meta.empty() ? nullptr : &meta);
         b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
         b->hdr_pool.insert(b->hdr_pool.end(), fh.begin(), fh.end());
 

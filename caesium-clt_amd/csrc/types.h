@@ -15,7 +15,7 @@
 #define CSH_TILE_BLOCKS 64
 #define CSH_TILE_I16 4096  // int16 elements per tile
 #define CSH_MAX_COMPS 3
-#define CSH_MAX_SCANS 16
+#define CSH_MAX_SCANS 20
 
 namespace csh {
 
@@ -92,7 +92,7 @@ struct DevQuant {
 // work item of the pixel kernels: one component of one image
 struct PlaneWork {
     int image, comp;
-    int mode;  // 0 direct (IDCT->FDCT, 1:1), 1 idct-to-plane, 2 plane h2v2up+h2v2down (4:2:0 -> 4:2:0), 3 plane h2v2 box down (4:4:4 -> 4:2:0), 4 plane h2v1up+h2v2down (4:2:2 -> 4:2:0)
+    int mode;  // 0: full-res in and out (IDCT->FDCT in one lane); else 1 + 3*in_kind + out_kind with kinds 0 full, 1 h2v2, 2 h2v1
 };
 
 // one scan of the OUTPUT script (same for every image of the batch with equal ncomp)
@@ -100,8 +100,10 @@ struct EncScan {
     int ncomp, comp[CSH_MAX_COMPS];
     int Ss, Se, Ah, Al;
     int dc_tbl[CSH_MAX_COMPS];  // per scan component: index of its DC table inside this scan's table group
+    int ac_tbl[CSH_MAX_COMPS];  // sequential scans only: index of the component's AC table inside the group
+    int sequential;              // 1: sequential-mode scan (whole blocks, Huffman DC+AC+EOB; --jpeg-baseline)
     int ntables;                 // tables this scan defines (0 for DC refine)
-    int dht_id[2];               // (Tc<<4)|Th of each table of the group, in DHT emission order
+    int dht_id[4];               // (Tc<<4)|Th of each table of the group, in DHT emission order
     int sos_tdta[CSH_MAX_COMPS]; // (Td<<4)|Ta byte of each scan component
 };
 

@@ -927,7 +927,14 @@ int cso_encode(const cso_image *im, const cso_enc_params *p, const cso_scan *scr
         static const uint8_t jfif[] = {0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
         bv_write(&b, jfif, sizeof jfif);
     }
-    if (p->keep_metadata && im->meta_len) bv_write(&b, im->meta, im->meta_len);
+    /* metadata carry-over: APPn/COM when keep_metadata; ICC (APP2 "ICC_PROFILE\0") governed separately by preserve_icc */
+    for (size_t mo = 0; mo + 4 <= im->meta_len;) {
+        size_t L = ((size_t)im->meta[mo + 2] << 8) | im->meta[mo + 3];
+        int is_icc = im->meta[mo + 1] == 0xE2 && L >= 14 && !memcmp(im->meta + mo + 4, "ICC_PROFILE\0", 12);
+        int keep = is_icc ? p->preserve_icc : p->keep_metadata;
+        if (keep) bv_write(&b, im->meta + mo, 2 + L);
+        mo += 2 + L;
+    }
     write_dqt(&b, im, p->marker_style);
     int is_baseline = !p->progressive;
     for (int c = 0; c < im->ncomp; c++) for (int k = 0; k < 64; k++) if (im->qt[im->comp[c].tq][k] > 255) is_baseline = 0;

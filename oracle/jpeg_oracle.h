@@ -67,6 +67,8 @@ typedef struct {
     int scan_script;           /* 0 = stock jpeg_simple_progression; 1 = the 8-scan script found in j0.JPG */
     int keep_metadata;         /* copy APPn/COM (except the encoder's own JFIF) */
     int force_baseline;        /* clamp quant entries to 255 */
+    int preserve_icc;          /* keep APP2 "ICC_PROFILE" segments even when keep_metadata is 0; drop them when 0
+                                  (libcaesium jpeg.preserve_icc = !--strip-icc, compressor.rs:425) [UPSTREAM-RECALL] */
 } cso_enc_params;
 
 /* ---- decode ---- */

@@ -32,11 +32,12 @@ def emul_api():
     return package().CaesiumHip(so)
 
 
-def oracle_lossy(src, quality=80):
+def oracle_lossy(src, quality=80, progressive=1, subsampling=420, keep_metadata=0, preserve_icc=1):
     from oracle import oracle as O
-    return O.jpeg_compress(src, O.params(quality=quality, progressive=1, subsampling=420, qtable_profile=3, marker_style=1))
+    return O.jpeg_compress(src, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1,
+                                         keep_metadata=keep_metadata, preserve_icc=preserve_icc))
 
 
-def oracle_lossless(src):
+def oracle_lossless(src, progressive=1, keep_metadata=0, preserve_icc=1):
     from oracle import oracle as O
-    return O.jpeg_compress(src, O.params(progressive=1, marker_style=1), lossless=True)
+    return O.jpeg_compress(src, O.params(progressive=progressive, marker_style=1, keep_metadata=keep_metadata, preserve_icc=preserve_icc), lossless=True)

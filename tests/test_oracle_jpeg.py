@@ -58,8 +58,8 @@ def test_decode_pixels_equal_libjpeg_turbo(w, h, ss, prog):
 @pytest.mark.parametrize("ssn,ss", [(444, 0), (422, 1), (420, 2)])
 @pytest.mark.parametrize("prog", [1, 0])
 def test_transcode_bytes_equal_libjpeg_turbo(ssn, ss, prog):
-    for (w, h, q) in [(101, 67, 80), (320, 256, 30), (33, 31, 97), (16, 16, 51)]:
-        src = synth_jpeg(5, w, h, subsampling=0, texture=25)
+    for (w, h, q, src_ss) in [(101, 67, 80, 0), (320, 256, 30, 0), (33, 31, 97, 0), (16, 16, 51, 0), (99, 73, 80, 1), (99, 73, 60, 2), (17, 9, 90, 2), (18, 11, 75, 1)]:
+        src = synth_jpeg(5, w, h, subsampling=src_ss, texture=25)
         ref = pil_ycc(src)
         out = O.jpeg_compress(src, O.params(quality=q, progressive=prog, subsampling=ssn, marker_style=0, qtable_profile=0))
         b = io.BytesIO()

@@ -83,6 +83,48 @@ def test_emul_truncated_stream_falls_back_and_matches_sequential_semantics(api):
     assert b.fetch()[0] == oracle_lossy(cut)
 
 
+@pytest.mark.parametrize("ss_in", [0, 1, 2])
+@pytest.mark.parametrize("ss_out", [444, 422, 420])
+def test_emul_every_chroma_layout_combination(api, ss_in, ss_out):
+    """--jpeg-chroma-subsampling 4:4:4 / 4:2:2 / 4:2:0 from 4:4:4 / 4:2:2 / 4:2:0 sources (odd sizes: every edge rule)"""
+    for (w, h) in [(99, 73), (64, 48), (17, 9), (2, 3)]:
+        src = synth_jpeg(6, w, h, subsampling=ss_in, texture=35)
+        assert api.compress_in_memory(src, params(jpeg_chroma_subsampling=ss_out)) == oracle_lossy(src, subsampling=ss_out), (w, h)
+
+
+def test_emul_metadata_and_icc_policy(api):
+    """-e / --strip-icc: EXIF+COM copied only with keep_metadata, ICC (APP2 ICC_PROFILE) follows jpeg_preserve_icc"""
+    from PIL import Image
+    im = Image.fromarray(synth_rgb(3, 96, 64, 20))
+    exif = Image.Exif(); exif[0x010F] = "caesium-hip test"; exif[0x0112] = 6
+    b = io.BytesIO(); im.save(b, format="JPEG", quality=90, exif=exif.tobytes(), icc_profile=b"fake-icc-profile-bytes" * 40, comment=b"hello")
+    src = b.getvalue()
+    assert b"ICC_PROFILE" in src and b"Exif" in src
+    for keep in (0, 1):
+        for icc in (0, 1):
+            out = api.compress_in_memory(src, params(keep_metadata=bool(keep), jpeg_preserve_icc=bool(icc)))
+            assert out == oracle_lossy(src, keep_metadata=keep, preserve_icc=icc)
+            assert (b"ICC_PROFILE" in out) == bool(icc) and (b"Exif" in out) == bool(keep) and (b"hello" in out) == bool(keep)
+            out = api.compress_in_memory(src, params(keep_metadata=bool(keep), jpeg_preserve_icc=bool(icc), jpeg_optimize=True))
+            assert out == oracle_lossless(src, keep_metadata=keep, preserve_icc=icc)
+
+
+def test_emul_sequential_output(api):
+    """--jpeg-baseline: one interleaved sequential scan with optimal tables (DHT order DC0 AC0 DC1 AC1)"""
+    from PIL import Image
+    srcs = [synth_jpeg(3, 120, 88, texture=35), synth_jpeg(5, 97, 61, subsampling=0, texture=60), synth_jpeg(2, 104, 72, progressive=True, texture=20)]
+    g = Image.fromarray(synth_rgb(7, 83, 55, 20)).convert("L")
+    b = io.BytesIO(); g.save(b, format="JPEG", quality=90); srcs.append(b.getvalue())
+    for src, out in zip(srcs, api.batch_compress(srcs, params(jpeg_progressive=False))):
+        assert out == oracle_lossy(src, progressive=0)
+        assert b"\xff\xc0" in out[:700] and b"\xff\xc2" not in out[:700]
+    for src, out in zip(srcs, api.batch_compress(srcs, params(jpeg_progressive=False, jpeg_optimize=True))):
+        assert out == oracle_lossless(src, progressive=0)
+    # 16-bit quantisation entries (q=1) force SOF1
+    out = api.compress_in_memory(srcs[0], params(jpeg_progressive=False, jpeg_quality=1))
+    assert out == oracle_lossy(srcs[0], 1, progressive=0) and b"\xff\xc1" in out[:900]
+
+
 def test_emul_lossless(api):
     srcs = [synth_jpeg(21, 133, 122, texture=20), synth_jpeg(2, 104, 72, progressive=True, texture=30), synth_jpeg(8, 64, 64, subsampling=0)]
     for src, out in zip(srcs, api.batch_compress(srcs, params(jpeg_optimize=True))):

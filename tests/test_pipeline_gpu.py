@@ -130,3 +130,33 @@ def test_reference_fixture_lossless_if_present(api):
         pytest.skip("/root/reference not present on the GPU box")
     src = open(p, "rb").read()
     assert api.compress_in_memory(src, params(jpeg_optimize=True)) == oracle_lossless(src)
+
+
+# ---- the same behavioural cases the emulation suite runs, on the real library ----------------------------------------
+import test_pipeline_emul as E
+
+
+def test_sequential_output(api):
+    E.test_emul_sequential_output(api)
+
+
+@pytest.mark.parametrize("ss_in", [0, 1, 2])
+@pytest.mark.parametrize("ss_out", [444, 422, 420])
+def test_every_chroma_layout_combination(api, ss_in, ss_out):
+    E.test_emul_every_chroma_layout_combination(api, ss_in, ss_out)
+
+
+def test_metadata_and_icc_policy(api):
+    E.test_emul_metadata_and_icc_policy(api)
+
+
+def test_compress_to_size_and_convert(api):
+    E.test_emul_compress_to_size_and_convert(api)
+
+
+def test_parallel_decoder_is_the_path_taken(api):
+    E.test_emul_parallel_decoder_is_the_path_taken(api)
+
+
+def test_truncated_stream_falls_back(api):
+    E.test_emul_truncated_stream_falls_back_and_matches_sequential_semantics(api)
