@@ -140,7 +140,7 @@ __global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *
     if (i >= nimg) return;
     if (need_seq[i] == 0) return;  // the parallel decoder handled this image
     const ImgDesc &im = imgs[i];
-    if (need_seq[i] == 2)          // the parallel decoder gave up half-way: start from clean tiles
+    if (need_seq[i] >= 2)          // the parallel decoder gave up half-way (2: labels unresolved, 3: scan ended short): start from clean tiles
         for (int c = 0; c < im.ncomp; c++) {
             int16_t *p = coef + size_t(im.in[c].tile_base) * CSH_TILE_I16;
             for (size_t n = 0; n < size_t(im.in[c].ntiles) * CSH_TILE_I16; n++) p[n] = 0;

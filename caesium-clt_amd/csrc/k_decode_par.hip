@@ -257,8 +257,8 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuf
 // list rounds: the listed sub-sequences are scattered, so each wave stages its 64 lanes' 144-byte stream windows
 // cooperatively -- for lane r's window, lanes 0..35 fetch its 36 consecutive words in ONE coalesced access (a lane
 // reading its own window would cost 36 accesses x 64 cache lines per wave) -- then every lane decodes out of LDS.
-__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
-                                                         const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
+__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state, const uint64_t *state_rd,
+                                                         uint32_t *nblk, const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
     CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
     CSH_SHARED DevHuffSet lhs;
     CSH_SHARED uint32_t d_scan[256], d_t[256];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
         const ParScan &ps = pss[d_scan[tid]];
         const uint32_t t = d_t[tid];
         size_t base = ps.sub_base + ps.par_index;
-        PState st = unpack_state(state[base + t]);
+        PState st = unpack_state(state_rd[base + t]);
         LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g.base = clean + ps.bits_off; rd.g.len = ps.clean_len;
         const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
         uint32_t n;
@@ -306,17 +306,40 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
     }
 }
 
-// whatever is still listed after the last launch has not reached the fixed point: sequential fallback for that image
-__global__ void __launch_bounds__(256) k_dec_unconverged(const ParScan *pss, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *need_seq) {
+// Scans still listed after the list rounds are almost always stuck on the block-in-MCU LABEL m: with similar (optimised)
+// or identical luma/chroma tables a wrong m no longer derails the bit position, so it creeps forward one sub-sequence per
+// round.  For those scans only: k_dec_dense<3> decodes every sub-sequence once per possible entry label and records
+// (exit label, block count); k_dec_chain then walks the cuts of the scan composing those maps -- a few thousand table
+// look-ups -- which yields the exact labels and counts.  A hypothesis whose exit (position, zig-zag index) disagrees
+// with what the next cut settled on ends the walk: that image goes to the sequential kernel.
+__global__ void __launch_bounds__(256) k_dec_mark_pending(const ParScan *pss, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= *cnt_in) return;
-    need_seq[pss[uint32_t(list_in[j] >> 32)].image] = 2;
+    scan_pending[uint32_t(list_in[j] >> 32)] = 1;
+}
+__global__ void k_dec_chain(const ParScan *pss, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq) {
+    int si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nps || !scan_pending[si]) return;
+    const ParScan &ps = pss[si];
+    uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
+    size_t base = ps.sub_base + ps.par_index;
+    int m = 0;
+    for (uint32_t t = 0; t < nsub && t * CSH_SUBSEQ_BYTES < ps.clean_len; t++) {
+        PState st = unpack_state(state[base + t]);
+        st.m = m;
+        state[base + t] = pack_state(st);
+        uint16_t h = hyp[(size_t(ps.sub_base) + t) * 10 + m];
+        if (h == 0xFFFF) { need_seq[ps.image] = 2; return; }
+        nblk[ps.sub_base + t] = h & 4095u;
+        m = h >> 12;
+    }
 }
 
 // ---- dense passes (every sub-sequence of every scan): a workgroup = 256 consecutive sub-sequences of one scan.
 // Phase 0 stages what the lanes will hammer -- the scan's Huffman LUTs and the workgroup's 32 KiB slice of the stream --
 // into LDS with coalesced loads (global reads by 64 lanes at a 128-byte stride would cost 64 line requests per load);
-// phase 1 decodes out of LDS.  MODE 0: speculate from the guess state, 1: relax in place, 2: write coefficients.
+// phase 1 decodes out of LDS.  MODE 0: speculate from the guess state, 1: relax in place, 2: write coefficients,
+// 3: label hypotheses (see k_dec_chain).
 template <int MODE>
 __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
@@ -325,7 +348,8 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     const ParScan &ps = a.pss[blockIdx.y];
     const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     const uint32_t t0 = blockIdx.x * 256, tid = threadIdx.x, t = t0 + tid;
-    const bool wg_live = t0 < nsub && t0 * CSH_SUBSEQ_BYTES < ps.clean_len && !(MODE == 2 && a.need_seq[ps.image] == 1);
+    const bool wg_live = t0 < nsub && t0 * CSH_SUBSEQ_BYTES < ps.clean_len && !(MODE == 2 && a.need_seq[ps.image] == 1) &&
+                         !(MODE == 3 && a.scan_pending[ps.par_index] == 0);
     PReader g; g.base = a.clean + ps.bits_off; g.len = ps.clean_len;
     CSH_PHASE_LOOP(2) {
         if (phase == 0) {
@@ -367,12 +391,24 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
                 a.state[base + t + 1] = e;
                 if ((t + 1) * CSH_SUBSEQ_BYTES < ps.clean_len) a.list_out[atomicAdd(a.cnt_out, 1u)] = (uint64_t(ps.par_index) << 32) | (t + 1);
             }
+        } else if (MODE == 3) {
+            // exit label and block count for EVERY possible entry label, from the settled (position, zig-zag index)
+            if (!live) continue;
+            const PState s0 = unpack_state(a.state[base + t]);
+            const PState nx = unpack_state(a.state[base + t + 1]);
+            const bool last = (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len;
+            for (int m0 = 0; m0 < lps.nb_mcu && m0 < 10; m0++) {
+                PState st = s0; st.m = m0;
+                uint32_t n = decode_span<false>(rd, lhs, lps, st, stop, 0, nullptr, nullptr, nullptr);
+                const bool same = last || (st.pos == nx.pos && st.k == nx.k);
+                a.hyp[(size_t(ps.sub_base) + t) * 10 + m0] = same ? uint16_t((st.m << 12) | (n > 4095 ? 4095 : n)) : uint16_t(0xFFFF);
+            }
         } else {
             if (a.need_seq[ps.image]) continue;
             uint32_t ordinal = uint32_t(a.blk_off[ps.sub_base + t] - a.blk_off[ps.sub_base]);
             if (t == nsub - 1 || (live && (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len)) {  // the scan must have produced all its blocks
                 uint32_t total = uint32_t(a.blk_off[ps.sub_base + nsub] - a.blk_off[ps.sub_base]);
-                if (total < ps.total_blocks) a.need_seq[ps.image] = 2;
+                if (total < ps.total_blocks) a.need_seq[ps.image] = 3;
             }
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
@@ -411,14 +447,32 @@ void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const
     dim3 grid((max_sub + 255) / 256, nps);
     if (mode == 0) CSH_LAUNCH_PHASED(k_dec_dense<0>, 2, grid, dim3(256), st, a);
     else if (mode == 1) CSH_LAUNCH_PHASED(k_dec_dense<1>, 2, grid, dim3(256), st, a);
-    else CSH_LAUNCH_PHASED(k_dec_dense<2>, 2, grid, dim3(256), st, a);
+    else if (mode == 2) CSH_LAUNCH_PHASED(k_dec_dense<2>, 2, grid, dim3(256), st, a);
+    else CSH_LAUNCH_PHASED(k_dec_dense<3>, 2, grid, dim3(256), st, a);
 }
+#ifdef CSH_EMUL
+int csh_emul_jacobi = 0;  // tests: make a list round read the states as they were BEFORE the launch (what concurrent lanes see at worst)
+#endif
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
-                           const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
-    if (total_sub) CSH_LAUNCH_PHASED(k_dec_relax_list, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, huffs, state, nblk, list_in, cnt_in, list_out, cnt_out);
+                           const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate) {
+    if (!total_sub) return;
+    const uint64_t *state_rd = state;
+#ifdef CSH_EMUL
+    uint64_t *snap = nullptr;
+    if (csh_emul_jacobi) { snap = (uint64_t *)malloc(nstate * 8); memcpy(snap, state, nstate * 8); state_rd = snap; }
+#else
+    (void)nstate;
+#endif
+    CSH_LAUNCH_PHASED(k_dec_relax_list, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, huffs, state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
+#ifdef CSH_EMUL
+    free(snap);
+#endif
 }
-void launch_dec_unconverged(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *need_seq) {
-    if (total_sub) CSH_LAUNCH(k_dec_unconverged, dim3((total_sub + 255) / 256), dim3(256), st, ps, list_in, cnt_in, need_seq);
+void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending) {
+    if (total_sub) CSH_LAUNCH(k_dec_mark_pending, dim3((total_sub + 255) / 256), dim3(256), st, ps, list_in, cnt_in, scan_pending);
+}
+void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq) {
+    if (nps) CSH_LAUNCH(k_dec_chain, dim3((nps + 63) / 64), dim3(64), st, ps, nps, state, nblk, hyp, scan_pending, need_seq);
 }
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq) {

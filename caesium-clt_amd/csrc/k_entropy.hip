@@ -77,7 +77,7 @@ __device__ __forceinline__ static AcMasks ac_masks(const uint64_t *masks, const 
 // word of the scan's bit vectors: one ballot, one 8-byte store, no atomics.
 __global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
     const ScanWork w = c.work[blockIdx.y];
-    const EncScan sc = c.script[w.scan];
+    const EncScan &sc = c.script[w.scan];
     if (sc.Ss == 0) return;
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     bool has_sym = false, ends_eob = false;
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
 // ---- pass B: EOB run structure -> EOBRUN value owned by the first block of each (sub-)run
 __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
     const ScanWork w = c.work[blockIdx.y];
-    const EncScan sc = c.script[w.scan];
+    const EncScan &sc = c.script[w.scan];
     if (sc.Ss == 0) return;
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= w.nunits) return;
@@ -393,7 +393,7 @@ struct LdsStatsSink {
 __global__ void __launch_bounds__(256) k_stats(EncCtx c) {
     CSH_SHARED uint32_t hist[4 * 257];
     const ScanWork w = c.work[blockIdx.y];
-    const EncScan sc = c.script[w.scan];
+    const EncScan &sc = c.script[w.scan];
     CSH_PHASE_LOOP(3) {
         if (sc.ntables == 0 || blockIdx.x * CSH_STATS_CHUNK >= w.nunits) continue;
         if (phase == 0) { for (int i = threadIdx.x; i < 4 * 257; i += blockDim.x) hist[i] = 0; continue; }
@@ -462,7 +462,7 @@ void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
 // ---- pass E: size in bits of every unit's output
 __global__ void __launch_bounds__(256) k_sizes(EncCtx c) {
     const ScanWork w = c.work[blockIdx.y];
-    const EncScan sc = c.script[w.scan];
+    const EncScan &sc = c.script[w.scan];
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= w.nunits) return;
     SizeSink s; s.tab = c.tables + w.table_base; s.bits = 0;
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) k_sizes(EncCtx c) {
 // ---- pass G: pack.  raw_off (bytes, multiple of 64) per scan comes from k_scan_layout.
 __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     const ScanWork w = c.work[blockIdx.y];
-    const EncScan sc = c.script[w.scan];
+    const EncScan &sc = c.script[w.scan];
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= w.nunits) return;
     uint64_t base = c.unit_off[w.unit_base];

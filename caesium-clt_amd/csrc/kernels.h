@@ -21,12 +21,14 @@ void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, Par
 struct DenseArgs {
     const uint8_t *clean; const ParScan *pss; const DevHuffSet *huffs;
     uint64_t *state; uint32_t *nblk; uint64_t *list_out; uint32_t *cnt_out;           // relax
+    uint16_t *hyp; const uint32_t *scan_pending;                                       // label hypotheses (mode 3)
     const uint64_t *blk_off; const ImgDesc *imgs; int16_t *coef; int32_t *dcdiff; uint32_t *need_seq;  // write
 };
 void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
-                           const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out);
-void launch_dec_unconverged(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *need_seq);
+                           const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate);
+void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending);
+void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq);
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq);
 

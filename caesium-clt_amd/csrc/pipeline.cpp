@@ -30,6 +30,8 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 int csh_emul_reverse = 0;
 thread_local int csh_emul_phase = 0;
 extern "C" void csh_emul_set_reverse(int r) { csh_emul_reverse = r; }
+namespace csh { extern int csh_emul_jacobi; }
+extern "C" void csh_emul_set_jacobi(int j) { csh::csh_emul_jacobi = j; }
 #endif
 
 namespace csh {
@@ -101,7 +103,8 @@ struct csh_batch {
     DevBuf<uint8_t> d_bits, d_clean, d_planes, d_oplanes, d_hdr, d_out, d_tail;
     DevBuf<ParScan> d_pscans;
     DevBuf<uint64_t> d_pstate, d_relax_list[2], d_unstuff_off, d_blk_off, d_dc_off;
-    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt;
+    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt, d_scan_pending;
+    DevBuf<uint16_t> d_hyp;
     DevBuf<int32_t> d_dcdiff;
     DevBuf<ImgDesc> d_imgs;
     DevBuf<DecScan> d_dscans;
@@ -486,7 +489,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         {
             size_t nchunks = b->bits_pool.size() / 64 + 1, nst = size_t(b->total_sub) + b->pscans.size() + 1;
             if (b->d_clean.alloc(b->bits_pool.size() + 64) || b->d_unstuff_cnt.alloc(nchunks + 1) || b->d_unstuff_off.alloc(nchunks + 2) ||
-                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(64) ||
+                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(64) || b->d_scan_pending.alloc(b->pscans.size() + 1) || b->d_hyp.alloc((size_t(b->total_sub) + 1) * 10) ||
                 b->d_nblk.alloc(size_t(b->total_sub) + 1) || b->d_blk_off.alloc(size_t(b->total_sub) + 2) || b->d_need_seq.alloc(b->nimg + 1) ||
                 b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2))
                 return CS_ERR_NO_DEVICE;
@@ -553,14 +556,20 @@ static int run_once(csh_batch *b, csh_timing *t) {
         da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p;
         launch_dec_dense(st, 0, nps, b->max_sub, da);
         MARK();
-        const int R = 20;  // list rounds after the dense one (each costs one near-empty launch once converged)
+        const int R = 40;  // list rounds after the dense one (a converged round is a near-empty launch, ~5 us); similar luma/chroma tables need ~50
         if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
         launch_dec_dense(st, 1, nps, b->max_sub, da);
         MARK();
         for (int it = 0; it < R && nps; it++)
             launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, b->d_hsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
-                                  b->d_relax_cnt.p + it, b->d_relax_list[(it & 1) ^ 1].p, b->d_relax_cnt.p + it + 1);
-        if (nps) launch_dec_unconverged(st, b->d_pscans.p, b->total_sub, b->d_relax_list[R & 1].p, b->d_relax_cnt.p + R, b->d_need_seq.p);
+                                  b->d_relax_cnt.p + it, b->d_relax_list[(it & 1) ^ 1].p, b->d_relax_cnt.p + it + 1, b->d_pstate.n);
+        if (nps) {   // scans that are still listed: settle their block-in-MCU labels exactly (k_dec_chain), or hand the image to k_decode_seq
+            if (b->d_scan_pending.zero(st)) return -1;
+            launch_dec_mark_pending(st, b->d_pscans.p, b->total_sub, b->d_relax_list[R & 1].p, b->d_relax_cnt.p + R, b->d_scan_pending.p);
+            da.hyp = b->d_hyp.p; da.scan_pending = b->d_scan_pending.p;
+            launch_dec_dense(st, 3, nps, b->max_sub, da);
+            launch_dec_chain(st, b->d_pscans.p, nps, b->d_pstate.p, b->d_nblk.p, b->d_hyp.p, b->d_scan_pending.p, b->d_need_seq.p);
+        }
         MARK();
         if (nps) launch_exclusive_scan(st, b->d_nblk.p, b->d_blk_off.p, b->total_sub, b->d_scan_tmp.p, b->d_scan_tmp.n);
         launch_dec_dense(st, 2, nps, b->max_sub, da);
@@ -674,7 +683,7 @@ extern "C" int csh_batch_run(csh_batch *b, csh_timing *t) {
     if (t) {
         std::vector<uint32_t> ns(b->nimg);
         if (hipMemcpy(ns.data(), b->d_need_seq.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
-        for (uint32_t v : ns) { if (v) t->n_seq_decoded++; if (v == 2) t->n_par_fallback++; }
+        for (uint32_t v : ns) { if (v) t->n_seq_decoded++; if (v >= 2) t->n_par_fallback++; if (v == 3) t->n_par_short++; }
         t->n_images = uint32_t(b->nimg);
         for (const Item &it : b->items) if (it.image < 0) t->n_failed++;
         for (int i = 0; i < b->nimg; i++) { t->out_bytes += b->h_img_size[i]; t->pixels += uint64_t(b->imgs[i].width) * b->imgs[i].height; }
@@ -751,6 +760,8 @@ extern "C" long csh_batch_debug_read(csh_batch *b, int which, void *dst, size_t 
     case 4: src = b->d_pscans.p; n = b->d_pscans.n * sizeof(ParScan); break;
     case 5: src = b->d_unstuff_off.p; n = b->d_unstuff_off.n * 8; break;
     case 6: src = b->d_bits.p; n = b->d_bits.n; break;
+    case 7: src = b->d_need_seq.p; n = b->d_need_seq.n * 4; break;
+    case 8: src = b->d_relax_cnt.p; n = b->d_relax_cnt.n * 4; break;
     default: return -1;
     }
     if (n > max_bytes) n = max_bytes;

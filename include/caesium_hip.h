@@ -116,6 +116,7 @@ typedef struct {
     uint32_t n_seq_decoded;       /* images (re)done by the sequential decode kernel: progressive / DRI inputs, or
                                      parallel-decoder fallbacks */
     uint32_t n_par_fallback;      /* of those, images the parallel decoder started and gave up on */
+    uint32_t n_par_short;         /* of those, because the scan produced fewer blocks than the frame needs (truncated data) */
 } csh_timing;
 
 int csh_device_count(void);

@@ -74,6 +74,28 @@ def test_emul_relaxation_is_order_independent(api):
         assert out == oracle_lossy(src)
 
 
+def test_emul_worst_case_concurrency_and_shared_tables(api):
+    """GPU lanes of one list round may all read the states from BEFORE the round (pure Jacobi).  With similar (optimised)
+    or identical luma/chroma Huffman tables a wrong block-in-MCU label then creeps one sub-sequence per round; the
+    prefix-sum re-labelling must settle it.  The emulation's jacobi mode reproduces exactly that schedule."""
+    import ctypes
+    from PIL import Image
+    from oracle import oracle as O
+    # one Huffman table set shared by every component: craft with the oracle (sequential, standard luma tables for all)
+    blobs = [synth_jpeg(9, 320, 240, optimize=True, texture=60), synth_jpeg(3, 640, 480, optimize=True, texture=25)]
+    api.L.csh_emul_set_jacobi.argtypes = [ctypes.c_int]
+    api.L.csh_emul_set_jacobi(1)
+    try:
+        b = api.batch(blobs, params())
+        t = b.run()
+        outs = b.fetch()
+    finally:
+        api.L.csh_emul_set_jacobi(0)
+    assert t.n_par_fallback == 0, "parallel decoder fell back"
+    for src, out in zip(blobs, outs):
+        assert out == oracle_lossy(src)
+
+
 def test_emul_truncated_stream_falls_back_and_matches_sequential_semantics(api):
     src = synth_jpeg(3, 200, 150, texture=30)
     cut = src[:len(src) * 2 // 3] + b"\xff\xd9"
