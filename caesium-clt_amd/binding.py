@@ -41,7 +41,7 @@ def library_path():
 
 EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory",
            "cs_batch_compress", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
-           "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_geometry", "csh_batch_read_coefs"]
+           "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs"]
 
 
 def _declare(L):
@@ -65,6 +65,10 @@ def _declare(L):
     L.csh_batch_create.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(C.c_void_p)]
     L.csh_batch_run.argtypes = [C.c_void_p, P(Timing)]
     L.csh_batch_fetch.argtypes = [C.c_void_p, P(CByteArray), P(CCSResult)]
+    L.csh_batch_retain_dct.argtypes = [C.c_void_p, C.c_int]
+    L.csh_batch_set_quality.argtypes = [C.c_void_p, P(C.c_uint32)]
+    L.csh_batch_rerun_encode.argtypes = [C.c_void_p, P(Timing)]
+    L.cs_batch_compress_to_size.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_size_t, C.c_bool, C.c_int, P(CByteArray), P(CCSResult)]
     L.csh_batch_destroy.argtypes = [C.c_void_p]
     L.csh_batch_destroy.restype = None
     L.csh_batch_geometry.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
@@ -108,6 +112,21 @@ class Batch:
         rc = self.api.L.csh_batch_run(self.h, C.byref(t))
         if rc:
             raise CaesiumError(rc, self.api.L.csh_last_error().decode())
+        return t
+
+    def retain_dct(self, on=True):
+        if self.api.L.csh_batch_retain_dct(self.h, 1 if on else 0):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+
+    def set_quality(self, qualities):
+        arr = (C.c_uint32 * self.n)(*qualities)
+        if self.api.L.csh_batch_set_quality(self.h, arr):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+
+    def rerun_encode(self):
+        t = Timing()
+        if self.api.L.csh_batch_rerun_encode(self.h, C.byref(t)):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
         return t
 
     def fetch(self):
@@ -185,6 +204,20 @@ class CaesiumHip:
 
     def convert_in_memory(self, data, params, fmt):
         return self._call(self.L.cs_convert_in_memory, data, len(data), C.byref(params), fmt)
+
+    def batch_compress_to_size(self, blobs, params, max_output_size, return_smallest=True, device=0):
+        n = len(blobs)
+        keep = [C.create_string_buffer(x, len(x)) for x in blobs]
+        ins = (CByteArray * n)()
+        for i, buf in enumerate(keep):
+            ins[i].data = C.cast(buf, C.POINTER(C.c_uint8)); ins[i].length = len(blobs[i])
+        outs = (CByteArray * n)(); res = (CCSResult * n)()
+        self.L.cs_batch_compress_to_size(ins, n, C.byref(params), max_output_size, return_smallest, device, outs, res)
+        result = []
+        for i in range(n):
+            result.append(C.string_at(outs[i].data, outs[i].length) if res[i].success else CaesiumError(res[i].code, (res[i].error_message or b"").decode()))
+            self.L.cs_free_bytes(C.byref(outs[i])); self.L.cs_free_result(C.byref(res[i]))
+        return result
 
     def batch(self, blobs, params, device=0):
         return Batch(self, blobs, params, device)

@@ -55,41 +55,84 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
     return r;
 }
 
-// libcaesium's size-targeting: bisection on quality, start 80, bounds (1,101), tolerance 2 % of the target,
-// at most 10 tries, return the smallest attempt when the target is unreachable and return_smallest is set
-// (call sites compressor.rs:295,298 always pass true).
-CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size, bool return_smallest, CByteArray *out) {
-    out->data = nullptr; out->length = 0;
+// libcaesium's size-targeting (compress_to_size_in_memory; SURVEY.md 2b [UPSTREAM-RECALL], corroborated by
+// /root/reference/samples/j0.JPG whose quantiser scale is the q=51 this walk reaches: 80,40,60,50,55,52,51):
+// bisection on quality from 80 inside (1,101); stop when the result fits and is within 2 % of the target, or when the
+// midpoint stops moving (the file of that last try is returned, fitting or not); a walk that bottoms out at q=1 still
+// too large returns that smallest file only if return_smallest; more than 10 tries is an error.
+// Device form: the whole group is decoded and transformed ONCE (unquantised DCT retained in HBM); every round re-quantises
+// and re-codes with each file's current quality, and files leave the search as they finish.
+struct SizeWalk { int quality = 80, last_less = 1, last_high = 101, tries = 0; bool done = false; };
+
+int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
+                              CByteArray *outputs, CCSResult *results) {
+    for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; results[i] = make_result(0, nullptr); }
     const size_t tolerance = max_output_size * 2 / 100;
-    int lo = 1, hi = 101, q = 80;
-    CByteArray best = {nullptr, 0};    // largest result that fits
-    CByteArray smallest = {nullptr, 0};
-    CCSResult last = make_result(0, nullptr);
-    for (int tries = 0; tries < 10; tries++) {
-        p->jpeg_quality = p->png_quality = p->webp_quality = uint32_t(q);
-        CByteArray cur = {nullptr, 0};
-        cs_free_result(&last);
-        last = cs_compress_in_memory(in, n, p, &cur);
-        if (!last.success) { cs_free_bytes(&best); cs_free_bytes(&smallest); return last; }
-        if (!smallest.data || cur.length < smallest.length) {
-            cs_free_bytes(&smallest);
-            smallest.data = (uint8_t *)malloc(cur.length ? cur.length : 1); memcpy(smallest.data, cur.data, cur.length); smallest.length = cur.length;
+    int failed_total = 0;
+    for (size_t g0 = 0; g0 < count; g0 += CS_GROUP) {
+        const size_t n = count - g0 < size_t(CS_GROUP) ? count - g0 : size_t(CS_GROUP);
+        p->jpeg_quality = p->png_quality = p->webp_quality = 80;
+        csh_batch *b = nullptr;
+        int rc = csh_batch_create(inputs + g0, n, p, device, &b);
+        if (rc == 0 && !p->jpeg_optimize) rc = csh_batch_retain_dct(b, 1) ? CS_ERR_NO_DEVICE : 0;
+        std::vector<SizeWalk> walk(n);
+        std::vector<uint32_t> q(n, 0);
+        std::vector<CByteArray> cur(n);
+        std::vector<CCSResult> res(n);
+        for (int round = 0; rc == 0; round++) {
+            rc = round == 0 ? csh_batch_run(b, nullptr) : csh_batch_rerun_encode(b, nullptr);
+            if (rc) break;
+            if (csh_batch_fetch(b, cur.data(), res.data()) < 0) { rc = CS_ERR_NO_DEVICE; break; }
+            bool any = false;
+            for (size_t i = 0; i < n; i++) {
+                SizeWalk &w = walk[i];
+                q[i] = 0;
+                if (w.done) { cs_free_bytes(&cur[i]); cs_free_result(&res[i]); continue; }
+                auto finish = [&](bool keep_file, int code, const char *msg) {
+                    w.done = true;
+                    if (keep_file) outputs[g0 + i] = cur[i]; else cs_free_bytes(&cur[i]);
+                    cs_free_result(&results[g0 + i]);
+                    if (code) { results[g0 + i] = make_result(code, msg); cs_free_result(&res[i]); failed_total++; }
+                    else results[g0 + i] = res[i];
+                };
+                if (!res[i].success) { w.done = true; results[g0 + i] = res[i]; failed_total++; continue; }
+                if (p->jpeg_optimize) { finish(true, 0, nullptr); continue; }   // lossless: quality does not apply, one try
+                const size_t len = cur[i].length;
+                if (len <= max_output_size && max_output_size - len < tolerance) { finish(true, 0, nullptr); continue; }
+                if (len <= max_output_size) w.last_less = w.quality; else w.last_high = w.quality;
+                int nq = (w.last_high + w.last_less) / 2;
+                nq = nq < 1 ? 1 : (nq > 100 ? 100 : nq);
+                if (nq == w.quality) {
+                    if (nq == 1 && w.last_high == 1 && !return_smallest) finish(false, CS_ERR_TOO_BIG, "cannot compress to the requested size");
+                    else finish(true, 0, nullptr);
+                    continue;
+                }
+                if (++w.tries >= 10) { finish(false, CS_ERR_TOO_BIG, "max tries reached while compressing to size"); continue; }
+                w.quality = nq;
+                q[i] = uint32_t(nq);
+                any = true;
+                cs_free_bytes(&cur[i]); cs_free_result(&res[i]);
+            }
+            if (!any) break;
+            if (csh_batch_set_quality(b, q.data())) { rc = CS_ERR_NO_DEVICE; break; }
         }
-        if (cur.length <= max_output_size) {
-            if (!best.data || cur.length > best.length) { cs_free_bytes(&best); best = cur; cur.data = nullptr; }
-            if (max_output_size - best.length < tolerance) { cs_free_bytes(&cur); break; }
-            lo = q;
-        } else hi = q;
-        cs_free_bytes(&cur);
-        int nq = (lo + hi) / 2;
-        if (nq == q) break;
-        q = nq;
+        if (rc)
+            for (size_t i = 0; i < n; i++)
+                if (!walk[i].done) { cs_free_result(&results[g0 + i]); results[g0 + i] = make_result(rc, csh_last_error()); failed_total++; }
+        // the reference leaves the quality of the last try in its &mut CSParameters; with many files that is per file, so a
+        // batch reports the first file's
+        if (g0 == 0 && n) p->jpeg_quality = p->png_quality = p->webp_quality = uint32_t(walk[0].quality);
+        csh_batch_destroy(b);
     }
-    if (best.data) { *out = best; cs_free_bytes(&smallest); return last; }
-    if (return_smallest && smallest.data) { *out = smallest; return last; }
-    cs_free_bytes(&smallest);
-    cs_free_result(&last);
-    return make_result(CS_ERR_TOO_BIG, "cannot compress to the requested size");
+    return failed_total;
+}
+
+CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size, bool return_smallest, CByteArray *out) {
+    CByteArray input; input.data = const_cast<uint8_t *>(in); input.length = n;
+    CCSResult r = make_result(0, nullptr);
+    out->data = nullptr; out->length = 0;
+    cs_batch_compress_to_size(&input, 1, p, max_output_size, return_smallest, 0, out, &r);
+    return r;
 }
 
 static int sniff(const uint8_t *d, size_t n) {

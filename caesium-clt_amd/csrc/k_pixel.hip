@@ -150,7 +150,20 @@ template <int... J>
 __device__ __forceinline__ static void quant_store_all(const int x[64], const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
     ((quant_store_octet<J>(x, q, blk), CSH_SCHED_FENCE()), ...);
 }
-__device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk) {
+template <int J>
+__device__ __forceinline__ static void raw_store_octet(const int x[64], int16_t *__restrict__ raw) {
+    uint4 v;
+    v.x = (uint32_t(x[kZ2N[8 * J + 0]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 1]]) << 16);
+    v.y = (uint32_t(x[kZ2N[8 * J + 2]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 3]]) << 16);
+    v.z = (uint32_t(x[kZ2N[8 * J + 4]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 5]]) << 16);
+    v.w = (uint32_t(x[kZ2N[8 * J + 6]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 7]]) << 16);
+    *reinterpret_cast<uint4 *>(raw + 512 * J) = v;
+}
+template <int... J>
+__device__ __forceinline__ static void raw_store_all(const int x[64], int16_t *__restrict__ raw, std::integer_sequence<int, J...>) {
+    (raw_store_octet<J>(x, raw), ...);
+}
+__device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw = nullptr) {
     CSH_SCHED_FENCE();
     CSH_UNROLL
     for (int r = 0; r < 8; r++) {
@@ -162,6 +175,20 @@ __device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuan
     CSH_UNROLL
     for (int c = 0; c < 8; c++) fdct1d<false>(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
     CSH_SCHED_FENCE();
+    if (raw) raw_store_all(x, raw, Oct());   // size-targeting keeps the unquantised DCT so later tries only re-quantise
+    quant_store_all(x, q, blk, Oct());
+}
+
+// re-quantise a retained DCT block with another table (k_requant)
+template <int J, int... I>
+__device__ __forceinline__ static void raw_to_nat(int x[64], const uint4 &v, std::integer_sequence<int, I...>) {
+    ((x[kZ2N[8 * J + I]] = half_of<I>(v)), ...);
+}
+template <int... J>
+__device__ __forceinline__ static void requant_block(const int16_t *__restrict__ raw, const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(raw + 512 * J)...};
+    int x[64];
+    (raw_to_nat<J>(x, v[J], Oct()), ...);
     quant_store_all(x, q, blk, Oct());
 }
 
@@ -174,7 +201,7 @@ __device__ __forceinline__ static void store_zero_block(int16_t *__restrict__ bl
 // ------------------------------------------------------------------------------------------------
 // mode 0: full-resolution component, IDCT -> (crop + edge expand) -> FDCT -> quantise
 __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant,
-                                                       const int16_t *coef_in, int16_t *coef_out) {
+                                                       const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 0) return;
     const ImgDesc &im = imgs[w.image];
@@ -190,7 +217,7 @@ __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const
     load_idct(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
     int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
     if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
-    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst);
+    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
 }
 
 // mode 1 producer: subsampled component, IDCT -> u8 plane (pitch real_bw*8, rows real_bh*8, edges replicated)
@@ -350,7 +377,7 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
 
 // encoder-side plane -> FDCT -> quantise, one block per lane
 __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *oplanes,
-                                                     int16_t *coef_out) {
+                                                     int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0) return;
     const ImgDesc &im = imgs[w.image];
@@ -371,7 +398,22 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
         CSH_UNROLL
         for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
     }
-    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst);
+    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
+}
+
+// size-targeting: re-quantise every retained DCT block with the image's CURRENT output table (one block per lane)
+__global__ void __launch_bounds__(256) k_requant(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const int16_t *dct_raw, uint32_t raw_tile0,
+                                                  int16_t *coef_out) {
+    const PlaneWork w = work[blockIdx.y];
+    const ImgDesc &im = imgs[w.image];
+    const CompGeom go = im.out[w.comp];
+    int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int b = tile * 64 + lane;
+    if (b >= go.bw * go.bh) return;
+    int by = b / go.bw, bx = b - by * go.bw;
+    if (by >= go.real_bh || bx >= go.real_bw) return;   // dummy blocks: k_fix_dummy
+    requant_block(dct_raw + coef_index(go.tile_base - raw_tile0, b, 0), quant[im.qt_out[w.comp]], coef_out + coef_index(go.tile_base, b, 0), Oct());
 }
 
 // dummy blocks (exist only to complete an MCU): zero AC, DC copied per libjpeg's jccoefct rule
@@ -400,8 +442,8 @@ __global__ void k_fix_dummy(const ImgDesc *imgs, int nimg, int16_t *coef_out) {
 static dim3 tile_grid(int max_tiles, int nwork) { return dim3((max_tiles + 3) / 4, nwork); }
 
 void launch_xform_direct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                         const int16_t *coef_in, int16_t *coef_out) {
-    if (nwork) CSH_LAUNCH(k_xform_direct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, coef_in, coef_out);
+                         const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    if (nwork) CSH_LAUNCH(k_xform_direct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, coef_in, coef_out, dct_raw, raw_tile0);
 }
 void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
                        const int16_t *coef_in, uint8_t *planes) {
@@ -411,8 +453,12 @@ void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork 
     if (nwork && max_quads) CSH_LAUNCH(k_resample_plane, dim3((max_quads + 255) / 256, nwork), dim3(256), st, imgs, work, planes, oplanes);
 }
 void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                       const uint8_t *oplanes, int16_t *coef_out) {
-    if (nwork) CSH_LAUNCH(k_plane_fdct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out);
+                       const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    if (nwork) CSH_LAUNCH(k_plane_fdct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out, dct_raw, raw_tile0);
+}
+void launch_requant(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant, const int16_t *dct_raw,
+                    uint32_t raw_tile0, int16_t *coef_out) {
+    if (nwork) CSH_LAUNCH(k_requant, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, dct_raw, raw_tile0, coef_out);
 }
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out) {
     if (nimg && max_blocks) CSH_LAUNCH(k_fix_dummy, dim3((max_blocks + 255) / 256, nimg), dim3(256), st, imgs, nimg, coef_out);

@@ -34,14 +34,17 @@ void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_
 
 // ---- phase 1: pixel-domain transcode (k_pixel.hip)
 // direct: dequant -> jidctint -> range limit -> jfdctint -> quantise, one block per lane
+// dct_raw != nullptr: also keep the unquantised DCT (tile index relative to raw_tile0) for launch_requant
 void launch_xform_direct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                         const int16_t *coef_in, int16_t *coef_out);
+                         const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
+void launch_requant(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant, const int16_t *dct_raw,
+                    uint32_t raw_tile0, int16_t *coef_out);
 // subsampled components: IDCT to a u8 plane (edges replicated), then resample + FDCT + quantise
 void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
                        const int16_t *coef_in, uint8_t *planes);
 void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, uint32_t max_quads, const uint8_t *planes, uint8_t *oplanes);
 void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                       const uint8_t *oplanes, int16_t *coef_out);
+                       const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
 
 // ---- phases 2-6: entropy encode (k_entropy.hip)

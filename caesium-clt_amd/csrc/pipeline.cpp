@@ -65,6 +65,7 @@ struct Item {
     JpegInfo out;     // output geometry (comp ids / sampling / tq)
     int image = -1;   // index among the images that reached the device, or -1
     size_t file_size = 0;
+    std::vector<uint8_t> meta_out;  // APPn/COM segments that survive the metadata/ICC policy (frame header rebuilds)
 };
 
 }  // namespace csh
@@ -79,6 +80,10 @@ struct csh_batch {
     std::vector<Item> items;
     int nimg = 0;
     bool lossless = false;
+    bool progressive = true;
+    bool retain_dct = false;       // size targeting: keep the unquantised DCT so that another quality only re-quantises
+    bool have_dct = false;
+    int q_base = 0;                // quants[q_base + q] = output table for quality q (1..100)
 
     // host-side descriptor arrays
     std::vector<ImgDesc> imgs;
@@ -113,7 +118,7 @@ struct csh_batch {
     DevBuf<PlaneWork> d_pwork;
     DevBuf<EncScan> d_script;
     DevBuf<ScanWork> d_swork;
-    DevBuf<int16_t> d_coef;
+    DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
     DevBuf<uint16_t> d_eobrun;
     DevBuf<uint32_t> d_unit_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
@@ -267,6 +272,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     b->device = device;
     b->params = *p;
     b->lossless = p->jpeg_optimize;
+    const bool progressive = p->jpeg_progressive;
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     b->items.resize(count);
@@ -275,8 +281,10 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     quality_table(int(p->jpeg_quality), qout_nat);
     DevQuant qo; make_quant(qout_nat, qo);
     b->quants.push_back(qo);  // index 0: output table (luma == chroma in mozjpeg's profile 3)
+    b->q_base = int(b->quants.size()) - 1;   // then one table per quality 1..100 (size targeting re-targets per image)
+    for (int q = 1; q <= 100; q++) { uint16_t tq[64]; quality_table(q, tq); DevQuant dq; make_quant(tq, dq); b->quants.push_back(dq); }
+    b->progressive = progressive;
 
-    const bool progressive = p->jpeg_progressive;
     add_script(b->script, 3, true);   // entries 0..9
     add_script(b->script, 1, true);   // entries 10..15
     add_script(b->script, 3, false);  // entry 16
@@ -460,6 +468,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             if (is_icc ? p->jpeg_preserve_icc : p->keep_metadata) meta.insert(meta.end(), in.meta.begin() + mo, in.meta.begin() + mo + 2 + L);
             mo += 2 + L;
         }
+        it.meta_out = meta;
         std::vector<uint8_t> fh = build_frame_header(hdr, progressive, meta.empty() ? nullptr : &meta);
         b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
         b->hdr_pool.insert(b->hdr_pool.end(), fh.begin(), fh.end());
@@ -518,7 +527,7 @@ static const char *const kKernelNames[CSH_NKERNELS] = {
 static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 
-static int run_once(csh_batch *b, csh_timing *t) {
+static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     hipStream_t st = b->stream;
     const int nimg = b->nimg;
     uint64_t raw_chunks = (b->raw_bytes_cap + 63) / 64;
@@ -535,6 +544,13 @@ static int run_once(csh_batch *b, csh_timing *t) {
     // one event after every kernel, on the batch's own stream: kernel_ms[i] = ev[i+1] - ev[i]
 #define MARK() CSH_CHECK(hipEventRecord(ev[++slot], st))
     CSH_CHECK(hipEventRecord(ev[0], st));
+    if (requant_only) {
+        if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
+        launch_requant(st, b->d_imgs.p, b->d_pwork.p, int(b->pwork.size()), b->max_tiles, b->d_quants.p, b->d_dct_raw.p, b->ntiles_in, b->d_coef.p);
+        launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
+        slot = 12;   // kernel_ms slots of the decode + pixel phases: only the first carries time (k_requant + k_fix_dummy)
+        for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
+    } else {
     // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
     CSH_CHECK(hipMemsetAsync(b->d_coef.p, 0, size_t(b->ntiles_in) * CSH_TILE_I16 * sizeof(int16_t), st));
     if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
@@ -584,13 +600,15 @@ static int run_once(csh_batch *b, csh_timing *t) {
     int nw = b->lossless ? 0 : int(b->pwork.size());
     launch_idct_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_planes.p);
     MARK();
-    launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p);
+    int16_t *rawp = (b->retain_dct && !b->lossless) ? b->d_dct_raw.p : nullptr;
+    launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p, rawp, b->ntiles_in);
     MARK();
     launch_resample_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_quads, b->d_planes.p, b->d_oplanes.p);
-    launch_plane_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_oplanes.p, b->d_coef.p);
+    launch_plane_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_oplanes.p, b->d_coef.p, rawp, b->ntiles_in);
     MARK();
     if (!b->lossless) launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
     MARK();
+    }  // !requant_only
     // ---- phase 2: masks, flags, EOB runs
     EncCtx c;
     memset(&c, 0, sizeof c);
@@ -658,12 +676,56 @@ static int run_once(csh_batch *b, csh_timing *t) {
     return 0;
 }
 
-extern "C" int csh_batch_run(csh_batch *b, csh_timing *t) {
+static int batch_run(csh_batch *b, csh_timing *t, bool requant_only);
+extern "C" int csh_batch_run(csh_batch *b, csh_timing *t) { return batch_run(b, t, false); }
+
+// size targeting (caesium::compress_to_size_in_memory, compressor.rs:295,298): keep the unquantised DCT of the first run ...
+extern "C" int csh_batch_retain_dct(csh_batch *b, int on) {
+    if (b->lossless) { csh_set_error("retain_dct: a coefficient transcode has no quality to re-target"); return -1; }
+    b->retain_dct = on != 0;
+    if (b->retain_dct && b->nimg && b->d_dct_raw.n == 0 && b->d_dct_raw.alloc(size_t(b->ntiles_out) * CSH_TILE_I16)) return -1;
+    return 0;
+}
+// ... give some images another quality (quality[i] == 0: unchanged; indexed like the inputs) ...
+extern "C" int csh_batch_set_quality(csh_batch *b, const uint32_t *quality) {
+    if (b->lossless) { csh_set_error("set_quality on a lossless batch"); return -1; }
+    b->hdr_pool.clear(); b->hdr_off.clear();
+    for (size_t n = 0; n < b->items.size(); n++) {
+        Item &it = b->items[n];
+        if (it.image < 0) continue;
+        ImgDesc &im = b->imgs[it.image];
+        if (quality[n]) {
+            int q = int(quality[n]) < 1 ? 1 : (quality[n] > 100 ? 100 : int(quality[n]));
+            for (int c = 0; c < im.ncomp; c++) im.qt_out[c] = b->q_base + q;
+        }
+        JpegInfo hdr = it.out;
+        int qidx = im.qt_out[0];
+        uint16_t nat[64];
+        for (int k = 0; k < 64; k++) nat[kZigZag[k]] = b->quants[qidx].q[k];
+        memcpy(hdr.qt[0], nat, 128); memcpy(hdr.qt[1], nat, 128);
+        std::vector<uint8_t> fh = build_frame_header(hdr, b->progressive, it.meta_out.empty() ? nullptr : &it.meta_out);
+        b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
+        b->hdr_pool.insert(b->hdr_pool.end(), fh.begin(), fh.end());
+    }
+    b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
+    if (!b->nimg) return 0;
+    if (hipSetDevice(b->device) != hipSuccess) return -1;
+    if (b->d_imgs.upload(b->imgs, b->stream) || b->d_hdr.upload(b->hdr_pool, b->stream) || b->d_hdr_off.upload(b->hdr_off, b->stream)) return -1;
+    CSH_CHECK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+// ... and re-run only re-quantisation + entropy coding + assembly.
+extern "C" int csh_batch_rerun_encode(csh_batch *b, csh_timing *t) {
+    if (!b->have_dct) { csh_set_error("rerun_encode needs a completed csh_batch_run after csh_batch_retain_dct(1)"); return -1; }
+    return batch_run(b, t, true);
+}
+
+static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
     if (t) memset(t, 0, sizeof *t);
     if (!b->nimg) { b->ran = true; return 0; }
     if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
     for (int attempt = 0; attempt < 4; attempt++) {
-        if (run_once(b, t)) return CS_ERR_NO_DEVICE;
+        if (run_once(b, t, requant_only)) return CS_ERR_NO_DEVICE;
         uint32_t ovf[4] = {0, 0, 0, 0};
         if (hipMemcpy(ovf, b->d_overflow.p, sizeof ovf, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
         b->h_status.resize(b->nimg);
@@ -693,6 +755,7 @@ extern "C" int csh_batch_run(csh_batch *b, csh_timing *t) {
         t->coef_bytes = in_tiles * CSH_TILE_I16 * 2;
     }
     b->ran = true;
+    if (!requant_only) b->have_dct = b->retain_dct && !b->lossless;
     return 0;
 }
 

@@ -91,6 +91,10 @@ CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters 
    device = HIP device ordinal.  Returns the number of failed items (per-item status in results). */
 int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device,
                       CByteArray *outputs, CCSResult *results);
+/* the same for --max-size (compressor.rs:297-299): every file runs libcaesium's quality bisection; the batch is decoded
+   and transformed once, each round only re-quantises and re-codes the files still searching */
+int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest,
+                              int device, CByteArray *outputs, CCSResult *results);
 
 void cs_free_bytes(CByteArray *b);
 void cs_free_result(CCSResult *r);
@@ -126,6 +130,13 @@ int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters
 int csh_batch_run(csh_batch *b, csh_timing *t);
 int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results);
 void csh_batch_destroy(csh_batch *b);
+
+/* size targeting on the device (what compress_to_size_in_memory's bisection needs per try): retain the unquantised DCT
+   of a full run, re-target the quality of individual images (quality[i] == 0 keeps it; same indexing as the inputs), and
+   re-run only re-quantisation + entropy coding + assembly.  Results are identical to a full run at that quality. */
+int csh_batch_retain_dct(csh_batch *b, int on);
+int csh_batch_set_quality(csh_batch *b, const uint32_t *quality);
+int csh_batch_rerun_encode(csh_batch *b, csh_timing *t);
 
 /* stage taps for the parity tests (copy device intermediates to host after csh_batch_run):
    which = 0: decoded coefficients, 1: re-quantised coefficients.  dst receives the component's

@@ -193,20 +193,69 @@ def test_emul_batch_order_and_errors(api):
     assert outs[0] == oracle_lossy(good[0]) and outs[4] == oracle_lossy(good[3])
 
 
+def reference_size_walk(src, max_size, return_smallest=True):
+    """libcaesium's bisection restated: -> (quality sequence, bytes or None)"""
+    tol = max_size * 2 // 100
+    q, less, high, seq = 80, 1, 101, []
+    for _ in range(10):
+        seq.append(q)
+        out = oracle_lossy(src, q)
+        if len(out) <= max_size and max_size - len(out) < tol:
+            return seq, out
+        if len(out) <= max_size:
+            less = q
+        else:
+            high = q
+        nq = min(max((high + less) // 2, 1), 100)
+        if nq == q:
+            if q == 1 and high == 1 and not return_smallest:
+                return seq, None
+            return seq, out
+        q = nq
+    return seq, None
+
+
 def test_emul_compress_to_size_and_convert(api):
     src = synth_jpeg(12, 320, 200, texture=30)
-    p = params()
-    target = len(oracle_lossy(src, 60))
-    out = api.compress_to_size_in_memory(src, p, target)
-    assert len(out) <= target and len(out) > 0.9 * target
-    tiny = api.compress_to_size_in_memory(src, params(), 10, True)       # unreachable: smallest attempt comes back
-    assert tiny == oracle_lossy(src, tiny and 1)
+    for target in (len(oracle_lossy(src, 60)), len(oracle_lossy(src, 93)) + 3, len(src) * 4, 2000):
+        p = params()
+        seq, want = reference_size_walk(src, target)
+        assert want is not None
+        assert api.compress_to_size_in_memory(src, p, target) == want
+        assert p.jpeg_quality == seq[-1]          # &mut CSParameters: the quality fields are left at the last try
+    # the j0.JPG walk of SURVEY 2b: 80,40,60,50,55,52,51
+    seq, _ = reference_size_walk(src, len(oracle_lossy(src, 51)) + 1)
+    assert seq[:2] == [80, 40]
+    tiny = api.compress_to_size_in_memory(src, params(), 10, True)       # unreachable: the q=1 file comes back
+    assert tiny == oracle_lossy(src, 1)
     with pytest.raises(package().CaesiumError) as e:
         api.compress_to_size_in_memory(src, params(), 10, False)
     assert e.value.code == 10500
     with pytest.raises(package().CaesiumError) as e:
         api.convert_in_memory(src, params(), 0)
     assert e.value.code == 10407
+
+
+def test_emul_batch_size_targeting_and_requant_equivalence(api):
+    """--max-size over a batch: one decode + DCT, then only re-quantise/re-code per round; every file's result equals the
+    restated libcaesium walk, and a re-quantised run at quality q equals a full run at q"""
+    srcs = [synth_jpeg(i, 160 + 16 * i, 120, subsampling=(0, 2, 1)[i % 3], texture=10 + 9 * i) for i in range(5)] + [b"junk"]
+    target = 5000
+    outs = api.batch_compress_to_size(srcs, params(), target)
+    assert isinstance(outs[5], Exception) and outs[5].code == 10200
+    for src, out in zip(srcs[:5], outs[:5]):
+        assert out == reference_size_walk(src, target)[1]
+    b = api.batch(srcs[:5], params())
+    b.retain_dct()
+    b.run()
+    for qs in ([33, 0, 97, 5, 61], [80, 80, 1, 100, 0]):
+        b.set_quality(qs)
+        b.rerun_encode()
+        now = [q or prev for q, prev in zip(qs, getattr(test_emul_batch_size_targeting_and_requant_equivalence, "_last", [80] * 5))]
+        test_emul_batch_size_targeting_and_requant_equivalence._last = now
+        for src, out, q in zip(srcs[:5], b.fetch(), now):
+            assert out == oracle_lossy(src, q), q
+    del test_emul_batch_size_targeting_and_requant_equivalence._last
 
 
 # ---- the product library: loads and exports everything include/caesium_hip.h declares (no compute without a GPU)
