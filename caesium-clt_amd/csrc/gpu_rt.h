@@ -118,6 +118,8 @@ static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) 
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline float __fmul_rn(float a, float b) { return a * b; }   // the emulation is built with -ffp-contract=off
+static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline int __mul24(int a, int b) { return (int)((int64_t)((a << 8) >> 8) * ((b << 8) >> 8)); }
 using std::max;
 using std::min;

@@ -347,21 +347,22 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0) return;
     const ImgDesc &im = imgs[w.image];
-    const CompGeom gi = im.in[w.comp], go = im.out[w.comp];
+    const CompGeom gi = im.src[w.comp], go = im.out[w.comp];
     const int pitch_o = go.real_bw * 8, rows_o = go.real_bh * 8;
     int q = blockIdx.x * blockDim.x + threadIdx.x;  // quad index
     if (q >= (pitch_o >> 2) * rows_o) return;
     int y = q / (pitch_o >> 2), x0 = (q - y * (pitch_o >> 2)) * 4;
     PlaneView v;
-    v.p = planes + im.plane_off[w.comp]; v.pitch = gi.real_bw * 8; v.cw = gi.comp_w; v.ch = gi.comp_h;
+    v.p = planes + im.splane_off[w.comp]; v.pitch = gi.real_bw * 8; v.cw = gi.comp_w; v.ch = gi.comp_h;
     uint32_t out = 0;
     // vector path <=> no full-resolution clamp under the quad and its column neighbours lie inside the decoded plane
-    const int W = im.width, H = im.height, och = go.comp_h;
+    const int W = im.enc_w, H = im.enc_h, och = go.comp_h;
     const int in_kind = (w.mode - 1) / 3, out_kind = (w.mode - 1) % 3;   // PlaneWork.mode = 1 + 3*in + out
     if (in_kind == 1 && out_kind == 1 && x0 >= 4 && x0 + 8 <= v.pitch && 2 * (x0 + 3) + 1 <= W - 1 && 2 * y + 1 <= H - 1 && gi.comp_w > 2) {
         out = resample_quad_420(v, gi.real_bh * 8, y, x0);
     } else {
         switch (w.mode) {
+        case 1: out = resample_quad<0, 0>(v, W, H, och, y, x0); break;   // resize path: full-resolution plane, edge expansion only
         case 2: out = resample_quad<0, 1>(v, W, H, och, y, x0); break;
         case 3: out = resample_quad<0, 2>(v, W, H, och, y, x0); break;
         case 4: out = resample_quad<1, 0>(v, W, H, och, y, x0); break;

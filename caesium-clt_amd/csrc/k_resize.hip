@@ -1,0 +1,123 @@
+// k_resize.hip -- the resize branch of libcaesium's JPEG path (width/height set: reference parameter mapping
+// /root/reference/src/compressor.rs:503-536; engine: image 0.25.9 `resize_exact(.., Lanczos3)`, SURVEY.md 8a row R1 + J4).
+//   k_planes_to_rgb   decoded component planes -> interleaved RGB (jdsample fancy upsample + jdcolor, both libjpeg integer)
+//   k_lanczos_v / _h  image-rs's separable resample: vertical pass to an f32 image, horizontal pass back to u8.
+//                     Weights (sinc(x)sinc(x/3), normalised, all f32) are computed on the HOST with the same libm calls the
+//                     oracle uses; the kernels only multiply and add -- with __fmul_rn/__fadd_rn so nothing is contracted
+//                     into an FMA -- in image-rs's left-to-right order, so the result is bit-identical to the oracle.
+//   k_rgb_to_planes   RGB -> full-resolution Y/Cb/Cr planes (jccolor fixed point) for the encoder-side kernels of k_pixel.hip.
+// One lane per sample (vertical pass: per output sample column-wise coalesced; horizontal pass: per output sample).
+#include "kernels.h"
+
+namespace csh {
+
+__device__ __forceinline__ static int rv(const uint8_t *p, int pitch, int cw, int ch, int y, int x) {
+    y = y < 0 ? 0 : (y > ch - 1 ? ch - 1 : y);
+    x = x < 0 ? 0 : (x > cw - 1 ? cw - 1 : x);
+    return p[size_t(y) * pitch + x];
+}
+// full-resolution chroma sample: kind 0 full plane, 1 h2v2 fancy, 2 h2v1 fancy (same formulas as k_pixel.hip / jdsample.c)
+__device__ static int chroma_at(const uint8_t *p, int pitch, int cw, int ch, int kind, int r, int xx) {
+    if (kind == 0) return rv(p, pitch, cw, ch, r, xx);
+    int cx = xx >> 1;
+    if (kind == 2) {
+        if (cw <= 2) return rv(p, pitch, cw, ch, r, cx);
+        int nb = (xx & 1) ? cx + 1 : cx - 1;
+        return (3 * rv(p, pitch, cw, ch, r, cx) + rv(p, pitch, cw, ch, r, nb) + ((xx & 1) ? 2 : 1)) >> 2;
+    }
+    int cy = r >> 1;
+    if (cw <= 2) return rv(p, pitch, cw, ch, cy, cx);
+    int fy = (r & 1) ? cy + 1 : cy - 1, nb = (xx & 1) ? cx + 1 : cx - 1;
+    int cs = 3 * rv(p, pitch, cw, ch, cy, cx) + rv(p, pitch, cw, ch, fy, cx);
+    int cn = 3 * rv(p, pitch, cw, ch, cy, nb) + rv(p, pitch, cw, ch, fy, nb);
+    return (3 * cs + cn + ((xx & 1) ? 7 : 8)) >> 4;
+}
+
+__global__ void __launch_bounds__(256) k_planes_to_rgb(const ImgDesc *imgs, const ResizeWork *work, const uint8_t *planes, uint8_t *rgb) {
+    const ResizeWork w = work[blockIdx.y];
+    const ImgDesc &im = imgs[w.image];
+    const int W = im.width, H = im.height;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    int y = i / W, x = i - y * W;
+    const CompGeom &g0 = im.in[0];
+    int Y = planes[im.plane_off[0] + size_t(y) * (g0.real_bw * 8) + x];
+    uint8_t *o = rgb + w.rgb_src_off + size_t(i) * im.ncomp;
+    if (im.ncomp == 1) { o[0] = uint8_t(Y); return; }
+    int cc[2];
+    for (int c = 1; c < 3; c++) {
+        const CompGeom &g = im.in[c];
+        cc[c - 1] = chroma_at(planes + im.plane_off[c], g.real_bw * 8, g.comp_w, g.comp_h, w.in_kind, y, x) - 128;
+    }
+    // jdcolor.c ycc_rgb_convert, SCALEBITS 16
+    int r = Y + ((91881 * cc[1] + 32768) >> 16);
+    int b = Y + ((116130 * cc[0] + 32768) >> 16);
+    int g = Y + ((-22554 * cc[0] + (-46802 * cc[1] + 32768)) >> 16);
+    o[0] = uint8_t(r < 0 ? 0 : r > 255 ? 255 : r);
+    o[1] = uint8_t(g < 0 ? 0 : g > 255 ? 255 : g);
+    o[2] = uint8_t(b < 0 ? 0 : b > 255 ? 255 : b);
+}
+
+// vertical pass: tmp[oy][x][c] = sum_i src[left+i][x][c] * w[i]      (f32, no clamp)
+__global__ void __launch_bounds__(256) k_lanczos_v(const ImgDesc *imgs, const ResizeWork *work, const ResizeTap *taps, const float *weights,
+                                                    const uint8_t *rgb, float *tmp) {
+    const ResizeWork w = work[blockIdx.y];
+    const ImgDesc &im = imgs[w.image];
+    const int rowlen = im.width * im.ncomp;   // samples per source row
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(w.nh) * rowlen) return;
+    int oy = int(i / rowlen), xc = int(i - size_t(oy) * rowlen);
+    const ResizeTap t = taps[w.vtap_base + oy];
+    const float *ws = weights + t.woff;
+    const uint8_t *s = rgb + w.rgb_src_off + size_t(t.left) * rowlen + xc;
+    float acc = 0.0f;
+    for (int k = 0; k < t.n; k++) acc = __fadd_rn(acc, __fmul_rn(float(s[size_t(k) * rowlen]), ws[k]));
+    tmp[w.tmp_off + i] = acc;
+}
+
+// horizontal pass: dst[y][ox][c] = round(clamp(sum_i tmp[y][left+i][c] * w[i]))
+__global__ void __launch_bounds__(256) k_lanczos_h(const ImgDesc *imgs, const ResizeWork *work, const ResizeTap *taps, const float *weights,
+                                                    const float *tmp, uint8_t *rgb) {
+    const ResizeWork w = work[blockIdx.y];
+    const ImgDesc &im = imgs[w.image];
+    const int nc = im.ncomp, rowlen_in = im.width * nc, rowlen_out = w.nw * nc;
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= size_t(w.nh) * rowlen_out) return;
+    int y = int(i / rowlen_out), r = int(i - size_t(y) * rowlen_out), ox = r / nc, c = r - ox * nc;
+    const ResizeTap t = taps[w.htap_base + ox];
+    const float *ws = weights + t.woff;
+    const float *s = tmp + w.tmp_off + size_t(y) * rowlen_in + size_t(t.left) * nc + c;
+    float acc = 0.0f;
+    for (int k = 0; k < t.n; k++) acc = __fadd_rn(acc, __fmul_rn(s[size_t(k) * nc], ws[k]));
+    acc = acc < 0.0f ? 0.0f : (acc > 255.0f ? 255.0f : acc);
+    int q = int(acc);                                     // round half away from zero (acc >= 0), without the
+    q += (acc - float(q) >= 0.5f) ? 1 : 0;                // double rounding of int(acc + 0.5f)
+    rgb[w.rgb_dst_off + i] = uint8_t(q);
+}
+
+// RGB -> full-resolution component planes (jccolor.c rgb_ycc_convert); pitch = the luma plane's padded width
+__global__ void __launch_bounds__(256) k_rgb_to_planes(const ImgDesc *imgs, const ResizeWork *work, const uint8_t *rgb, uint8_t *planes) {
+    const ResizeWork w = work[blockIdx.y];
+    const ImgDesc &im = imgs[w.image];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w.nw * w.nh) return;
+    int y = i / w.nw, x = i - y * w.nw;
+    const uint8_t *s = rgb + w.rgb_dst_off + size_t(i) * im.ncomp;
+    const int pitch = im.src[0].real_bw * 8;
+    if (im.ncomp == 1) { planes[im.splane_off[0] + size_t(y) * pitch + x] = s[0]; return; }
+    int r = s[0], g = s[1], b = s[2];
+    planes[im.splane_off[0] + size_t(y) * pitch + x] = uint8_t((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+    planes[im.splane_off[1] + size_t(y) * pitch + x] = uint8_t((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16);
+    planes[im.splane_off[2] + size_t(y) * pitch + x] = uint8_t((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16);
+}
+
+void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, int nwork, const ResizeTap *taps, const float *weights,
+                   uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst) {
+    if (!nwork) return;
+    CSH_LAUNCH(k_planes_to_rgb, dim3((max_src_px + 255) / 256, nwork), dim3(256), st, imgs, work, planes, rgb);
+    CSH_LAUNCH(k_lanczos_v, dim3(unsigned((max_tmp + 255) / 256), nwork), dim3(256), st, imgs, work, taps, weights, rgb, tmp);
+    CSH_LAUNCH(k_lanczos_h, dim3(unsigned((max_dst + 255) / 256), nwork), dim3(256), st, imgs, work, taps, weights, tmp, rgb);
+    CSH_LAUNCH(k_rgb_to_planes, dim3(unsigned((max_dst + 255) / 256), nwork), dim3(256), st, imgs, work, rgb, planes);
+}
+
+}  // namespace csh

@@ -47,6 +47,10 @@ void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *wor
                        const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
 
+// resize branch (k_resize.hip): decoded planes -> RGB -> Lanczos3 (f32, image-rs order) -> full-resolution YCbCr planes
+void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, int nwork, const ResizeTap *taps, const float *weights,
+                   uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst);
+
 // ---- phases 2-6: entropy encode (k_entropy.hip)
 void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t first_tile, uint32_t ntiles);
 

@@ -91,6 +91,11 @@ struct csh_batch {
     std::vector<DevHuffSet> hsets;
     std::vector<DevQuant> quants;
     std::vector<PlaneWork> pwork;
+    std::vector<ResizeWork> rwork;
+    std::vector<ResizeTap> rtaps;
+    std::vector<float> rweights;
+    uint64_t rgb_bytes = 0, tmp_floats = 0, max_tmp = 0, max_dst = 0;
+    uint32_t max_src_px = 0;
     std::vector<ParScan> pscans;
     std::vector<uint32_t> need_seq_init;
     uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
@@ -116,6 +121,10 @@ struct csh_batch {
     DevBuf<DevHuffSet> d_hsets;
     DevBuf<DevQuant> d_quants;
     DevBuf<PlaneWork> d_pwork;
+    DevBuf<ResizeWork> d_rwork;
+    DevBuf<ResizeTap> d_rtaps;
+    DevBuf<float> d_rweights, d_rtmp;
+    DevBuf<uint8_t> d_rgb;
     DevBuf<EncScan> d_script;
     DevBuf<ScanWork> d_swork;
     DevBuf<int16_t> d_coef, d_dct_raw;
@@ -226,6 +235,40 @@ static int sniff_type(const uint8_t *d, size_t n) {
 }
 
 // decide the output frame for one parsed JPEG; returns 0 or an error code
+// image-rs Lanczos3 taps of one axis (imageops::sample) -- host side, same libm calls as the oracle
+static float sincf_(float t) { float a = t * 3.14159265358979323846f; return t == 0.0f ? 1.0f : sinf(a) / a; }
+static float lanczos3f(float x) { return fabsf(x) < 3.0f ? sincf_(x) * sincf_(x / 3.0f) : 0.0f; }
+static void lanczos_axis(int in_size, int out_size, bool identity, std::vector<ResizeTap> &taps, std::vector<float> &weights) {
+    for (int o = 0; o < out_size; o++) {
+        ResizeTap t;
+        t.woff = uint32_t(weights.size());
+        if (identity) { t.left = o; t.n = 1; weights.push_back(1.0f); taps.push_back(t); continue; }
+        float ratio = float(in_size) / float(out_size);
+        float sratio = ratio < 1.0f ? 1.0f : ratio;
+        float support = 3.0f * sratio;
+        float center = (float(o) + 0.5f) * ratio;
+        long left = long(floorf(center - support)); if (left < 0) left = 0; if (left > in_size - 1) left = in_size - 1;
+        long right = long(ceilf(center + support)); if (right < left + 1) right = left + 1; if (right > in_size) right = in_size;
+        center = center - 0.5f;
+        float sum = 0.0f;
+        for (long i = left; i < right; i++) { float w = lanczos3f((float(i) - center) / sratio); weights.push_back(w); sum += w; }
+        for (size_t i = t.woff; i < weights.size(); i++) weights[i] /= sum;
+        t.left = int(left); t.n = int(right - left);
+        taps.push_back(t);
+    }
+}
+// libcaesium resize.rs compute_dimensions [UPSTREAM-RECALL]: both given -> exact; one given -> keep aspect, f32, round half away
+static void compute_dimensions(int ow, int oh, int dw, int dh, int &nw, int &nh) {
+    if (dw > 0 && dh > 0) { nw = dw; nh = dh; }
+    else {
+        float ratio = float(ow) / float(oh);
+        if (dw > 0) { nw = dw; nh = int(roundf(float(dw) / ratio)); }
+        else { nh = dh; nw = int(roundf(float(dh) * ratio)); }
+    }
+    if (nw < 1) nw = 1;
+    if (nh < 1) nh = 1;
+}
+
 static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
     const JpegInfo &in = it.in;
     if (in.ncomp != 1 && in.ncomp != 3) { it.msg = "unsupported component count (CMYK/YCCK not on the device path yet)"; return CS_ERR_JPEG_FEATURE; }
@@ -236,6 +279,11 @@ static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
     it.out = JpegInfo();
     JpegInfo &o = it.out;
     o.width = in.width; o.height = in.height; o.ncomp = in.ncomp;
+    if (p.width || p.height) {
+        if (lossless) { it.msg = "resize + lossless transcode not on the device path"; return CS_ERR_UNSUPPORTED; }
+        compute_dimensions(in.width, in.height, int(p.width), int(p.height), o.width, o.height);
+        if (o.width > 65500 || o.height > 65500) { it.msg = "resize target too large for JPEG"; return CS_ERR_JPEG_FEATURE; }
+    }
     if (lossless) {
         for (int c = 0; c < in.ncomp; c++) o.comp[c] = in.comp[c];
         jpeg_geometry(o);
@@ -333,6 +381,9 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             b->max_dummy = std::max(b->max_dummy, nd);
         }
         im.omcus_x = o.mcus_x; im.omcus_y = o.mcus_y;
+        const bool resized = (p->width || p->height) && !b->lossless;
+        im.enc_w = o.width; im.enc_h = o.height;
+        for (int c = 0; c < in.ncomp; c++) im.src[c] = im.in[c];
         int img_index = int(b->imgs.size());
         // entropy-coded scans
         im.first_scan = int(b->dscans.size());
@@ -420,10 +471,20 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 int in_kind = in_full ? 0 : (in.comp[c].v == in.vmax ? 2 : 1);    // 0 full, 1 h2v2, 2 h2v1
                 int out_kind = out_full ? 0 : (o.comp[c].v == o.vmax ? 2 : 1);
                 w.mode = (in_kind == 0 && out_kind == 0) ? 0 : 1 + 3 * in_kind + out_kind;
+                if (resized) w.mode = 1 + out_kind;   // encoder side is fed full-resolution planes of the resized image (k_resize.hip)
                 if (w.mode) {
                     im.plane_off[c] = plane_off;
                     plane_off += uint32_t(im.in[c].real_bw * 8 * im.in[c].real_bh * 8);
                     plane_off = (plane_off + 63u) & ~63u;
+                    im.splane_off[c] = im.plane_off[c];
+                    if (resized) {   // full-resolution plane of the resized image, pitch = luma's padded width
+                        JComp full; full.h = full.v = 1;
+                        JpegInfo tmpj; tmpj.width = o.width; tmpj.height = o.height; tmpj.ncomp = 1; tmpj.comp[0] = full; jpeg_geometry(tmpj);
+                        uint32_t dummy = 0; fill_geom(tmpj.comp[0], im.src[c], dummy);
+                        im.splane_off[c] = plane_off;
+                        plane_off += uint32_t(im.src[c].real_bw * 8 * im.src[c].real_bh * 8);
+                        plane_off = (plane_off + 63u) & ~63u;
+                    }
                     im.oplane_off[c] = oplane_off;
                     uint32_t osz = uint32_t(im.out[c].real_bw * 8 * im.out[c].real_bh * 8);
                     oplane_off = (oplane_off + osz + 63u) & ~63u;
@@ -431,6 +492,25 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 }
                 b->pwork.push_back(w);
             }
+
+        if (resized) {
+            ResizeWork rw;
+            memset(&rw, 0, sizeof rw);
+            rw.image = img_index; rw.nw = o.width; rw.nh = o.height;
+            rw.in_kind = in.ncomp == 1 ? 0 : ((in.comp[1].h == in.hmax && in.comp[1].v == in.vmax) ? 0 : (in.comp[1].v == in.vmax ? 2 : 1));
+            const uint64_t src_bytes = uint64_t(in.width) * in.height * in.ncomp, dst_bytes = uint64_t(o.width) * o.height * in.ncomp;
+            rw.rgb_src_off = b->rgb_bytes; b->rgb_bytes += (src_bytes + 63) & ~uint64_t(63);
+            rw.rgb_dst_off = b->rgb_bytes; b->rgb_bytes += (dst_bytes + 63) & ~uint64_t(63);
+            const uint64_t tmpn = uint64_t(o.height) * in.width * in.ncomp;
+            rw.tmp_off = b->tmp_floats; b->tmp_floats += tmpn;
+            const bool same = o.width == in.width && o.height == in.height;   // image-rs copies instead of resampling
+            rw.vtap_base = uint32_t(b->rtaps.size()); lanczos_axis(in.height, o.height, same, b->rtaps, b->rweights);
+            rw.htap_base = uint32_t(b->rtaps.size()); lanczos_axis(in.width, o.width, same, b->rtaps, b->rweights);
+            b->max_src_px = std::max<uint32_t>(b->max_src_px, uint32_t(in.width) * in.height);
+            b->max_tmp = std::max(b->max_tmp, tmpn);
+            b->max_dst = std::max(b->max_dst, dst_bytes);
+            b->rwork.push_back(rw);
+        }
 
         // output scans
         int sb = in.ncomp == 3 ? script_base3 : script_base1;
@@ -493,7 +573,8 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_hdr.upload(b->hdr_pool, st) ||
-            b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_need_seq_init.upload(b->need_seq_init, st))
+            b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
+            b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
         {
             size_t nchunks = b->bits_pool.size() / 64 + 1, nst = size_t(b->total_sub) + b->pscans.size() + 1;
@@ -600,6 +681,8 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     int nw = b->lossless ? 0 : int(b->pwork.size());
     launch_idct_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_planes.p);
     MARK();
+    launch_resize(st, b->d_imgs.p, b->d_rwork.p, int(b->rwork.size()), b->d_rtaps.p, b->d_rweights.p, b->d_planes.p, b->d_rgb.p, b->d_rtmp.p,
+                  b->max_src_px, b->max_tmp, b->max_dst);
     int16_t *rawp = (b->retain_dct && !b->lossless) ? b->d_dct_raw.p : nullptr;
     launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p, rawp, b->ntiles_in);
     MARK();

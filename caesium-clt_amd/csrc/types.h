@@ -62,6 +62,11 @@ struct ImgDesc {
     int qt_out[CSH_MAX_COMPS];
     uint32_t plane_off[CSH_MAX_COMPS];  // byte offset of the decoded u8 plane (components that are resampled)
     uint32_t oplane_off[CSH_MAX_COMPS]; // byte offset of the resampled u8 plane (encoder-side geometry)
+    // planes that FEED the encoder-side resample: the decoded planes (src == in, enc == image size), or -- resize path --
+    // full-resolution planes of the resized image (k_resize.hip)
+    CompGeom src[CSH_MAX_COMPS];
+    uint32_t splane_off[CSH_MAX_COMPS];
+    int enc_w, enc_h;
     int first_scan, nscans_in;    // range in the DecScan array
     int comp_id[CSH_MAX_COMPS];   // component identifiers written to SOF/SOS
     int first_work, nscans_out;   // this image's ScanWork range (output scans, in file order)
@@ -94,6 +99,16 @@ struct PlaneWork {
     int image, comp;
     int mode;  // 0: full-res in and out (IDCT->FDCT in one lane); else 1 + 3*in_kind + out_kind with kinds 0 full, 1 h2v2, 2 h2v1
 };
+
+// resize path work item (k_resize.hip): one image
+struct ResizeWork {
+    int image, in_kind;            // in_kind: how the decoded chroma planes relate to full resolution (0 full, 1 h2v2, 2 h2v1)
+    int nw, nh;                    // new size
+    uint64_t rgb_src_off, rgb_dst_off;  // byte offsets in the RGB pool (W*H*nc source, nw*nh*nc resized)
+    uint64_t tmp_off;              // float offset in the f32 pool (nh*W*nc)
+    uint32_t vtap_base, htap_base; // first ResizeTap of the vertical (nh entries) / horizontal (nw entries) pass
+};
+struct ResizeTap { int left, n; uint32_t woff; };  // output coordinate -> first source index, #taps, offset of its weights
 
 // one scan of the OUTPUT script (same for every image of the batch with equal ncomp)
 struct EncScan {

@@ -14,6 +14,7 @@
  * restated (unpinned -- see DESIGN.md).
  */
 #include "jpeg_oracle.h"
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -996,5 +997,100 @@ int cso_jpeg_compress(const uint8_t *in, size_t n, const cso_enc_params *p, int 
         dst->meta = NULL; dst->meta_len = 0;
     }
     free(pix); cso_image_free(src); cso_image_free(dst);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* resize path -- see jpeg_oracle.h.  Compile with -ffp-contract=off: image-rs does not fuse. */
+void cso_compute_dimensions(int ow, int oh, int dw, int dh, int *nw, int *nh) {
+    if (dw > 0 && dh > 0) { *nw = dw; *nh = dh; return; }
+    float ratio = (float)ow / (float)oh;
+    if (dw > 0) { *nw = dw; *nh = (int)roundf((float)dw / ratio); }
+    else if (dh > 0) { *nh = dh; *nw = (int)roundf((float)dh * ratio); }
+    else { *nw = ow; *nh = oh; }
+    if (*nw < 1) *nw = 1;
+    if (*nh < 1) *nh = 1;
+}
+static float sincf_(float t) { float a = t * 3.14159265358979323846f; return t == 0.0f ? 1.0f : sinf(a) / a; }
+static float lanczos3f(float x) { return fabsf(x) < 3.0f ? sincf_(x) * sincf_(x / 3.0f) : 0.0f; }
+/* weights of one output coordinate (image-rs horizontal_sample / vertical_sample) */
+static int lanczos_taps(int in_size, int out_size, int o, int *left_out, float *ws) {
+    float ratio = (float)in_size / (float)out_size;
+    float sratio = ratio < 1.0f ? 1.0f : ratio;
+    float support = 3.0f * sratio;
+    float center = ((float)o + 0.5f) * ratio;
+    long left = (long)floorf(center - support); if (left < 0) left = 0; if (left > in_size - 1) left = in_size - 1;
+    long right = (long)ceilf(center + support); if (right < left + 1) right = left + 1; if (right > in_size) right = in_size;
+    center = center - 0.5f;
+    float sum = 0.0f; int n = 0;
+    for (long i = left; i < right; i++) { float w = lanczos3f(((float)i - center) / sratio); ws[n++] = w; sum += w; }
+    for (int i = 0; i < n; i++) ws[i] /= sum;
+    *left_out = (int)left;
+    return n;
+}
+void cso_lanczos3_resize(const uint8_t *src, int w, int h, int nch, int nw, int nh, uint8_t *dst) {
+    if (nw == w && nh == h) { memcpy(dst, src, (size_t)w * h * nch); return; }
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)w * nh * nch);
+    float *ws = (float *)malloc(sizeof(float) * (size_t)((h > w ? h : w) + 8));
+    for (int oy = 0; oy < nh; oy++) {               /* vertical pass -> f32 */
+        int left, n = lanczos_taps(h, nh, oy, &left, ws);
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < nch; c++) {
+                float t = 0.0f;
+                for (int i = 0; i < n; i++) t += (float)src[((size_t)(left + i) * w + x) * nch + c] * ws[i];
+                tmp[((size_t)oy * w + x) * nch + c] = t;
+            }
+    }
+    for (int ox = 0; ox < nw; ox++) {               /* horizontal pass -> u8 */
+        int left, n = lanczos_taps(w, nw, ox, &left, ws);
+        for (int y = 0; y < nh; y++)
+            for (int c = 0; c < nch; c++) {
+                float t = 0.0f;
+                for (int i = 0; i < n; i++) t += tmp[((size_t)y * w + left + i) * nch + c] * ws[i];
+                t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);
+                dst[((size_t)y * nw + ox) * nch + c] = (uint8_t)roundf(t);
+            }
+    }
+    free(tmp); free(ws);
+}
+/* libjpeg jdcolor.c ycc_rgb_convert: SCALEBITS 16, Cr=>R 1.40200, Cb=>B 1.77200, Cr=>G -0.71414, Cb=>G -0.34414 */
+void cso_ycc_to_rgb(const uint8_t *ycc, size_t npix, uint8_t *rgb) {
+    for (size_t i = 0; i < npix; i++) {
+        int y = ycc[3 * i], cb = ycc[3 * i + 1] - 128, cr = ycc[3 * i + 2] - 128;
+        int r = y + ((91881 * cr + 32768) >> 16);
+        int b = y + ((116130 * cb + 32768) >> 16);
+        int g = y + ((-22554 * cb + (-46802 * cr + 32768)) >> 16);
+        rgb[3 * i] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        rgb[3 * i + 1] = (uint8_t)(g < 0 ? 0 : g > 255 ? 255 : g);
+        rgb[3 * i + 2] = (uint8_t)(b < 0 ? 0 : b > 255 ? 255 : b);
+    }
+}
+/* libjpeg jccolor.c rgb_ycc_convert */
+void cso_rgb_to_ycc(const uint8_t *rgb, size_t npix, uint8_t *ycc) {
+    for (size_t i = 0; i < npix; i++) {
+        int r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        ycc[3 * i] = (uint8_t)((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+        ycc[3 * i + 1] = (uint8_t)((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16);
+        ycc[3 * i + 2] = (uint8_t)((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16);
+    }
+}
+int cso_jpeg_compress_resized(const uint8_t *in, size_t n, const cso_enc_params *p, int width, int height, uint8_t **out, size_t *out_len) {
+    cso_image *src = NULL, *dst = NULL;
+    if (cso_decode(in, n, &src)) return -1;
+    if (src->ncomp != 1 && src->ncomp != 3) { cso_image_free(src); FAIL("unsupported component count %d", src->ncomp); }
+    int W = src->width, H = src->height, nc = src->ncomp, nw, nh, rc = -1;
+    cso_compute_dimensions(W, H, width, height, &nw, &nh);
+    uint8_t *pix = (uint8_t *)malloc((size_t)W * H * nc), *rs = (uint8_t *)malloc((size_t)nw * nh * nc);
+    if (cso_decode_pixels(src, pix) == 0) {
+        if (nc == 3) cso_ycc_to_rgb(pix, (size_t)W * H, pix);
+        cso_lanczos3_resize(pix, W, H, nc, nw, nh, rs);
+        if (nc == 3) cso_rgb_to_ycc(rs, (size_t)nw * nh, rs);
+        if (cso_forward(rs, nw, nh, nc, p, NULL, &dst) == 0) {
+            dst->meta = src->meta; dst->meta_len = src->meta_len;
+            rc = cso_encode(dst, p, NULL, 0, out, out_len);
+            dst->meta = NULL; dst->meta_len = 0;
+        }
+    }
+    free(pix); free(rs); cso_image_free(src); cso_image_free(dst);
     return rc;
 }

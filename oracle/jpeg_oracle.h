@@ -99,6 +99,22 @@ void cso_free(void *p);
 int  cso_jpeg_compress(const uint8_t *in, size_t n, const cso_enc_params *p, int lossless,
                        uint8_t **out, size_t *out_len);
 
+/* resize path (libcaesium: decode -> image-rs resize_exact(Lanczos3) -> re-encode; reference parameter mapping
+   /root/reference/src/compressor.rs:503-536).  Restated pieces, all [UPSTREAM-RECALL] (image 0.25.9 imageops::sample,
+   SURVEY.md B.11) -- parity with the real crate is UNPINNED:
+     cso_compute_dimensions  libcaesium resize.rs compute_dimensions (f32 ratio, round half away)
+     cso_lanczos3_resize     vertical_sample -> f32 image -> horizontal_sample, weights sinc(x)sinc(x/3) normalised in f32,
+                             separate multiply and add (no FMA), clamp [0,255], round half away
+     cso_ycc_to_rgb / cso_rgb_to_ycc   libjpeg jdcolor.c / jccolor.c 16-bit fixed point
+   cso_jpeg_compress_resized = decode -> YCbCr->RGB -> Lanczos3 -> RGB->YCbCr -> forward(quality) -> encode.
+   (the real chain decodes with zune-jpeg and re-encodes once more with image-rs before mozjpeg sees it) */
+void cso_compute_dimensions(int ow, int oh, int dw, int dh, int *nw, int *nh);
+void cso_lanczos3_resize(const uint8_t *src, int w, int h, int nch, int nw, int nh, uint8_t *dst);
+void cso_ycc_to_rgb(const uint8_t *ycc, size_t npix, uint8_t *rgb);
+void cso_rgb_to_ycc(const uint8_t *rgb, size_t npix, uint8_t *ycc);
+int  cso_jpeg_compress_resized(const uint8_t *in, size_t n, const cso_enc_params *p, int width, int height,
+                               uint8_t **out, size_t *out_len);
+
 /* ---- pieces exported for stage-level parity tests ---- */
 void cso_quality_tables(int quality, int profile, int force_baseline, uint16_t out[2][64]);
 void cso_fdct_islow(const uint8_t *samples8x8 /* row stride 8 */, int32_t out[64]);

@@ -74,6 +74,12 @@ def lib():
         L.cso_idct_islow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cso_stock_script.argtypes = [C.c_int, C.c_int, C.POINTER(Scan)]
         L.cso_gen_optimal_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cso_compute_dimensions.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.cso_lanczos3_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.cso_ycc_to_rgb.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cso_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cso_jpeg_compress_resized.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(EncParams), C.c_int, C.c_int,
+                                                C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -206,3 +212,40 @@ def gen_optimal_table(freq):
     hv = np.zeros(256, dtype=np.uint8)
     n = lib().cso_gen_optimal_table(f.ctypes.data, bits.ctypes.data, hv.ctypes.data)
     return bits, hv[:n]
+
+
+def compute_dimensions(ow, oh, dw, dh):
+    nw, nh = C.c_int(), C.c_int()
+    lib().cso_compute_dimensions(ow, oh, dw, dh, C.byref(nw), C.byref(nh))
+    return nw.value, nh.value
+
+
+def lanczos3_resize(img, nw, nh):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    h, w, c = img.shape
+    out = np.empty((nh, nw, c), dtype=np.uint8)
+    lib().cso_lanczos3_resize(img.ctypes.data, w, h, c, nw, nh, out.ctypes.data)
+    return out
+
+
+def ycc_to_rgb(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8); out = np.empty_like(a)
+    lib().cso_ycc_to_rgb(a.ctypes.data, a.size // 3, out.ctypes.data)
+    return out
+
+
+def rgb_to_ycc(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8); out = np.empty_like(a)
+    lib().cso_rgb_to_ycc(a.ctypes.data, a.size // 3, out.ctypes.data)
+    return out
+
+
+def jpeg_compress_resized(data, p, width, height):
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    _check(lib().cso_jpeg_compress_resized(data, len(data), C.byref(p), width, height, C.byref(out), C.byref(n)))
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res

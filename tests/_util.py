@@ -41,3 +41,8 @@ def oracle_lossy(src, quality=80, progressive=1, subsampling=420, keep_metadata=
 def oracle_lossless(src, progressive=1, keep_metadata=0, preserve_icc=1):
     from oracle import oracle as O
     return O.jpeg_compress(src, O.params(progressive=progressive, marker_style=1, keep_metadata=keep_metadata, preserve_icc=preserve_icc), lossless=True)
+
+
+def oracle_resized(src, width, height, quality=80, subsampling=420):
+    from oracle import oracle as O
+    return O.jpeg_compress_resized(src, O.params(quality=quality, progressive=1, subsampling=subsampling, qtable_profile=3, marker_style=1), width, height)

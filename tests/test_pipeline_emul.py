@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from _util import ROOT, emul_api, oracle_lossless, oracle_lossy, package
+from _util import ROOT, emul_api, oracle_lossless, oracle_lossy, oracle_resized, package
 from gen_synth import synth_jpeg, synth_rgb
 
 
@@ -129,6 +129,26 @@ def test_emul_metadata_and_icc_policy(api):
             assert (b"ICC_PROFILE" in out) == bool(icc) and (b"Exif" in out) == bool(keep) and (b"hello" in out) == bool(keep)
             out = api.compress_in_memory(src, params(keep_metadata=bool(keep), jpeg_preserve_icc=bool(icc), jpeg_optimize=True))
             assert out == oracle_lossless(src, keep_metadata=keep, preserve_icc=icc)
+
+
+@pytest.mark.parametrize("ss", [0, 1, 2])
+def test_emul_resize_lanczos3(api, ss):
+    """--width/--height/--long-edge: decode -> RGB (jdcolor) -> image-rs Lanczos3 (f32, vertical then horizontal) -> YCbCr
+    (jccolor) -> encode.  Bit-exact against the oracle's restatement (0 ULP, so the 1-ULP bar of the north star holds)."""
+    src = synth_jpeg(4, 200, 140, subsampling=ss, texture=30)
+    for (w, h) in [(150, 0), (0, 35), (97, 201), (200, 140), (333, 0), (1, 1), (0, 1000)]:
+        out = api.compress_in_memory(src, params(width=w, height=h))
+        assert out == oracle_resized(src, w, h), (w, h)
+    from PIL import Image
+    g = Image.fromarray(synth_rgb(7, 83, 55, 20)).convert("L")
+    b = io.BytesIO(); g.save(b, format="JPEG", quality=90)
+    assert api.compress_in_memory(b.getvalue(), params(width=40, jpeg_chroma_subsampling=444)) == oracle_resized(b.getvalue(), 40, 0, subsampling=444)
+    # a batch mixing resized geometry classes keeps order; lossless + resize is refused per item
+    outs = api.batch_compress([src, src[:100], src], params(height=70))
+    assert outs[0] == outs[2] == oracle_resized(src, 0, 70) and isinstance(outs[1], Exception)
+    with pytest.raises(package().CaesiumError) as e:
+        api.compress_in_memory(src, params(width=50, jpeg_optimize=True))
+    assert e.value.code == 10201
 
 
 def test_emul_sequential_output(api):

@@ -164,3 +164,18 @@ def test_truncated_stream_falls_back(api):
 
 def test_batch_size_targeting_and_requant_equivalence(api):
     E.test_emul_batch_size_targeting_and_requant_equivalence(api)
+
+
+@pytest.mark.parametrize("ss", [0, 1, 2])
+def test_resize_lanczos3(api, ss):
+    E.test_emul_resize_lanczos3(api, ss)
+
+
+def test_resize_1080p_to_long_edge_1500(api):
+    """BASELINE config 4's geometry: 1920x1080 --long-edge 1500 -> 1500x844"""
+    from _util import oracle_resized
+    src = synth_jpeg(0)
+    out = api.compress_in_memory(src, params(width=1500, jpeg_quality=85))
+    assert out == oracle_resized(src, 1500, 0, quality=85)
+    from PIL import Image
+    assert Image.open(io.BytesIO(out)).size == (1500, 844)
