@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #define CSH_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 #define CSH_UNROLL _Pragma("unroll")
+// pin a 32-bit value in a VGPR here: a load feeding it cannot be sunk into a later branch
+#define CSH_PIN(x) asm volatile("" : "+v"(x))
 #define CSH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  // keep the instruction scheduler from interleaving stages (register pressure)
 // Kernels that need workgroup barriers are written as a loop over "phases":
 //     CSH_SHARED int lds[...];
@@ -40,6 +42,7 @@
 #define __restrict__
 #define __launch_bounds__(...)
 #define CSH_UNROLL
+#define CSH_PIN(x) ((void)0)
 #define CSH_SCHED_FENCE() ((void)0)
 struct dim3 {
     unsigned x, y, z;
@@ -121,6 +124,7 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline float __fmul_rn(float a, float b) { return a * b; }   // the emulation is built with -ffp-contract=off
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline int __mul24(int a, int b) { return (int)((int64_t)((a << 8) >> 8) * ((b << 8) >> 8)); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 using std::max;
 using std::min;
 #endif

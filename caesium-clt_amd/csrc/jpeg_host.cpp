@@ -113,6 +113,7 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
                 int code = 0;
                 for (int l = 1; l <= 16; l++) { code = (code + h.bits[l]) << 1; if (code > (2 << l)) BAD(CS_ERR_BAD_JPEG, "oversubscribed DHT"); }
                 memcpy(h.vals, s + p, cnt);
+                if (!tc) for (int i = 0; i < cnt; i++) if (h.vals[i] > 15) BAD(CS_ERR_BAD_JPEG, "DC Huffman symbol out of range");   // libjpeg JERR_BAD_HUFF_TABLE
                 h.nvals = cnt;
                 h.present = true;
                 p += cnt;

@@ -158,92 +158,113 @@ __device__ __forceinline__ static uint32_t peek32(const R &rd, uint32_t pos) {
     return uint32_t((w << o) >> 32);
 }
 
-__device__ __forceinline__ static int huff_lookup(const DevHuff &h, uint32_t top16, int &len) {
-    int e = h.look[top16 >> 7];
-    if (e) { len = e >> 8; return e & 255; }
-    // long code: with 64 lanes in flight some lane is almost always here, so this path must be short for the WHOLE
-    // wave: seven independent compares against left-aligned bounds instead of a 7-step dependent search
-    int l = 17;
-    CSH_UNROLL
-    for (int i = 6; i >= 0; i--) l = (top16 < h.limit[i]) ? 10 + i : l;
-    if (l == 17) { len = 16; return 0; }   // invalid code: consume 16 bits, symbol 0 (as the sequential path)
-    len = l;
-    return h.vals[(h.vbase[l - 10] + int(top16 >> (16 - l))) & 255];
-}
 __device__ __forceinline__ static int extend_p(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
 
+// what the loop needs from the scan descriptor, in registers
+struct ParCtx {
+    uint64_t sel;          // ParScan::sel
+    int nb_mcu;
+    uint32_t total_blocks;
+    int mcus_x;            // MCUs per row (write pass)
+};
+__device__ __forceinline__ static ParCtx make_ctx(const ParScan &ps, const ImgDesc *im) {
+    ParCtx c; c.sel = ps.sel; c.nb_mcu = ps.nb_mcu; c.total_blocks = ps.total_blocks;
+    c.mcus_x = im ? (ps.ncomp > 1 ? im->mcus_x : im->in[ps.comp_of[0]].real_bw) : 1;
+    return c;
+}
+// per-m placement table of the write pass (LDS): a non-interleaved scan walks its component block by block (h = v = 1)
+__device__ __forceinline__ static void make_block_info(const ParScan &ps, const ImgDesc &im, int m, ParBlockInfo &o) {
+    const CompGeom &g = im.in[ps.comp_of[m]];
+    o.tile_base = g.tile_base; o.bw = g.bw;
+    if (ps.ncomp > 1) { o.h = g.h; o.v = g.v; o.by0 = ps.by_of[m]; o.bx0 = ps.bx_of[m]; }
+    else { o.h = 1; o.v = 1; o.by0 = 0; o.bx0 = 0; }
+    o.dc_base = ps.dc_base[m]; o.dc_per_mcu = ps.dc_per_mcu[m]; o.dc_idx = ps.dc_idx[m];
+}
+
 // decode from state `st` until st.pos >= stop_bit; returns #blocks completed.  WRITE: store coefficients.
-// Everything that depends on the block-in-MCU index m (Huffman tables, component, DC slot, tile address) is refreshed
-// once per BLOCK, with the MCU coordinates advanced incrementally (no divisions in the loop); a coefficient's value bits
-// are taken from the same 32-bit window as its code (code <= 16 bits + value <= 16 bits).
-template <bool WRITE, class R>
-__device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuffSet &hs, const ParScan &ps, PState &st, uint32_t stop_bit,
-                                                        uint32_t ordinal, const ImgDesc *im, int16_t *coef, int32_t *dcdiff) {
+// The loop is INSTRUCTION-ISSUE bound (64 unrelated serial bit streams per wave: every divergent path is executed by the
+// whole wave), so it is written to be short and straight:
+//   * DC and AC symbols share one code path -- the table is selected by (k == 0), not branched on;
+//   * two-level tables (ParHuffSet): a code of >= 10 bits costs one more LDS read, not a search; a coefficient's value bits
+//     come from the same 32-bit window as its code;
+//   * the stream is read from the lane's LDS window only (36 words cover every reachable position: a lane enters at most
+//     31 bits past its cut and a symbol is at most 31 bits), the next word is fetched one refill ahead;
+//   * table selectors for every block-in-MCU index sit in a register (ParCtx::sel); the write pass takes its per-block
+//     placement from a small LDS table (ParBlockInfo).
+template <bool WRITE>
+__device__ __forceinline__ static uint32_t decode_span(const uint32_t *row, uint32_t w0, const ParHuffSet &hs, const ParCtx &cx, PState &st, uint32_t stop_bit,
+                                                        uint32_t ordinal, const ParBlockInfo *bi, int16_t *coef, int32_t *dcdiff) {
     uint32_t nblk = 0;
     int16_t *blk = nullptr;
     int32_t *dcp = nullptr;
-    const DevHuff *dct = &hs.dc[ps.dct[st.m]], *act = &hs.ac[ps.act[st.m]];
-    // WRITE-only bookkeeping: which block we are in
-    uint32_t mcu = 0; int mx = 0, my = 0, mcus_x = 1;
+    const uint8_t *hb = reinterpret_cast<const uint8_t *>(&hs);
+    const uint16_t *sub = hs.sub;
+    uint32_t mcu = 0; int mx = 0, my = 0;
     bool in_range = false;
-    auto locate = [&](int m) {
-        in_range = uint32_t(mcu) * uint32_t(ps.nb_mcu) + uint32_t(m) < ps.total_blocks;
-        if (!in_range) { blk = nullptr; dcp = nullptr; return; }
-        const CompGeom &g = im->in[ps.comp_of[m]];
-        int by, bx;
-        if (ps.ncomp > 1) { by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
-        else { by = my; bx = mx; }
-        blk = coef + coef_index(g.tile_base, by * g.bw + bx, 0);
-        dcp = dcdiff + ps.dc_base[m] + mcu * ps.dc_per_mcu[m] + ps.dc_idx[m];
+    auto word = [&](uint32_t wi) -> uint32_t {
+        uint32_t r = wi - w0;
+#ifdef CSH_EMUL
+        if (r >= CSH_LROW_WORDS) { fprintf(stderr, "decode_span: stream window exceeded (%u)\n", r); abort(); }
+#endif
+        return row[r];
     };
-    if (WRITE) {
-        mcu = ordinal / uint32_t(ps.nb_mcu);
-        mcus_x = ps.ncomp > 1 ? im->mcus_x : im->in[ps.comp_of[0]].real_bw;
-        my = int(mcu) / mcus_x; mx = int(mcu) - my * mcus_x;
-        locate(st.m);
-    }
-    // 64-bit bit buffer (MSB first), at least 32 valid bits after every refill: one stream word is fetched per ~32 bits
-    // consumed, so the only memory access on a symbol's critical path is its Huffman LUT entry
+    auto locate = [&](int m) {
+        in_range = mcu * uint32_t(cx.nb_mcu) + uint32_t(m) < cx.total_blocks;
+        const ParBlockInfo g = bi[m];
+        int by = my * g.v + g.by0, bx = mx * g.h + g.bx0;
+        blk = coef + coef_index(g.tile_base, by * g.bw + bx, 0);
+        dcp = dcdiff + g.dc_base + mcu * g.dc_per_mcu + g.dc_idx;
+    };
     uint32_t pos = st.pos, wi = (pos >> 5) + 2;
     int k = st.k, m = st.m;
-    uint64_t acc = ((uint64_t(rd.word(wi - 2)) << 32) | rd.word(wi - 1)) << (pos & 31);
+    if (WRITE) {
+        mcu = ordinal / uint32_t(cx.nb_mcu);
+        my = int(mcu) / cx.mcus_x; mx = int(mcu) - my * cx.mcus_x;
+        locate(m);
+    }
+    uint32_t dco, aco;   // byte offsets of the current DC / AC root tables
+    auto tables = [&](int mm) { uint32_t x = uint32_t(cx.sel >> (6 * mm)); dco = (x & 7u) << 10; aco = (x & 56u) << 7; };
+    tables(m);
+    // 64-bit bit buffer (MSB first), at least 32 valid bits after every refill
+    uint64_t acc = ((uint64_t(word(wi - 2)) << 32) | word(wi - 1)) << (pos & 31);
     int nb = 64 - int(pos & 31);
+    uint32_t nxt = word(wi);
     while (pos < stop_bit) {
-        const uint32_t w = uint32_t(acc >> 32);
-        int len, used;
-        if (k == 0) {
-            int t = huff_lookup(*dct, w >> 16, len);
-            if (WRITE && in_range) *dcp = t ? extend_p(int((w << len) >> (32 - t)), t) : 0;
-            used = len + t;
-            k = 1;
-        } else {
-            int rs = huff_lookup(*act, w >> 16, len);
-            int r = rs >> 4, n = rs & 15;
-            used = len;
-            if (n) {
-                k += r;
-                if (k > 63) k = 64;  // corrupt run: block ends (no extra bits consumed, as the sequential path)
-                else {
-                    if (WRITE && in_range) blk[coef_off(k)] = int16_t(extend_p(int((w << len) >> (32 - n)), n));
-                    used += n;
-                    k++;
-                }
-            } else if (r == 15) k += 16;
-            else k = 64;
+        const uint32_t w = uint32_t(acc >> 32), top16 = w >> 16;
+        const bool isdc = k == 0;
+        uint32_t e = *reinterpret_cast<const uint16_t *>(hb + (isdc ? dco : aco) + ((top16 >> 7) << 1));
+        if (e & 0x8000u) e = sub[(e & 0xFFFu) + ((top16 & 127u) >> (7u - ((e >> 12) & 7u)))];
+        const int len = e ? int(e >> 8) : 16;      // no such code: consume 16 bits, symbol 0 (as the sequential path)
+        const int sym = int(e & 255u);
+        // one symbol: DC -> (run 0, size sym); AC -> (run sym>>4, size sym&15)
+        const int n = sym & 15, r = isdc ? 0 : (sym >> 4);
+        const int kn = k + r;
+        const bool val = n != 0 && kn <= 63;                           // kn > 63: corrupt run, block ends, no value bits consumed
+        int v = int((w << len) >> ((32 - n) & 31));
+        v = v < int(1u << ((n - 1) & 31)) ? v - (1 << n) + 1 : v;   // EXTEND (T.81 F.2.2.1); n == 0 is masked below
+        v = val ? v : 0;
+        if (WRITE && in_range) {
+            if (isdc) *dcp = v;
+            else if (val) blk[coef_off(kn)] = int16_t(v);
         }
-        pos += used;
+        const int used = len + (val ? n : 0);
+        const bool eob = !isdc && n == 0 && r != 15;
+        const int kc = kn > 63 ? 63 : kn;
+        k = eob ? 64 : kc + 1;                                           // ZRL: k + 16; coefficient / DC: kn + 1
+        pos += uint32_t(used);
         acc <<= used;
         nb -= used;
-        if (nb < 32) { acc |= uint64_t(rd.word(wi++)) << (32 - nb); nb += 32; }
+        if (nb < 32) { acc |= uint64_t(nxt) << (32 - nb); nb += 32; wi++; nxt = word(wi); }
         if (k >= 64) {
             k = 0;
             nblk++;
-            if (m + 1 == ps.nb_mcu) {
-                m = 0;
-                if (WRITE) { mcu++; if (++mx == mcus_x) { mx = 0; my++; } }
-            } else m++;
-            dct = &hs.dc[ps.dct[m]]; act = &hs.ac[ps.act[m]];
-            if (WRITE) locate(m);
+            const bool wrap = m + 1 == cx.nb_mcu;
+            m = wrap ? 0 : m + 1;
+            tables(m);
+            if (WRITE) {
+                if (wrap) { mcu++; if (++mx == cx.mcus_x) { mx = 0; my++; } }
+                locate(m);
+            }
         }
     }
     st.pos = pos; st.k = k; st.m = m;
@@ -257,10 +278,10 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, const DevHuf
 // list rounds: the listed sub-sequences are scattered, so each wave stages its 64 lanes' 144-byte stream windows
 // cooperatively -- for lane r's window, lanes 0..35 fetch its 36 consecutive words in ONE coalesced access (a lane
 // reading its own window would cost 36 accesses x 64 cache lines per wave) -- then every lane decodes out of LDS.
-__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const DevHuffSet *huffs, uint64_t *state, const uint64_t *state_rd,
+__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, uint64_t *state, const uint64_t *state_rd,
                                                          uint32_t *nblk, const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
     CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
-    CSH_SHARED DevHuffSet lhs;
+    CSH_SHARED ParHuffSet lhs;
     CSH_SHARED uint32_t d_scan[256], d_t[256];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
     const uint32_t tid = threadIdx.x, j = blockIdx.x * blockDim.x + tid, count = *cnt_in;
     const uint32_t j0 = blockIdx.x * blockDim.x;
@@ -273,7 +294,7 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
             // the first entry's Huffman set is staged; lanes with another set read theirs from global memory
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&huffs[pss[uint32_t(list_in[j0] >> 32)].huff_set]);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
-            for (uint32_t i = tid; i < sizeof(DevHuffSet) / 4; i += 256) dst[i] = src[i];
+            for (uint32_t i = tid; i < sizeof(ParHuffSet) / 4; i += 256) dst[i] = src[i];
             continue;
         }
         if (phase == 1) {
@@ -295,8 +316,9 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
         LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g.base = clean + ps.bits_off; rd.g.len = ps.clean_len;
         const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
         uint32_t n;
-        if (ps.huff_set == pss[d_scan[0]].huff_set) n = decode_span<false>(rd, lhs, ps, st, stop, 0, nullptr, nullptr, nullptr);
-        else n = decode_span<false>(rd, huffs[ps.huff_set], ps, st, stop, 0, nullptr, nullptr, nullptr);
+        const ParCtx cx = make_ctx(ps, nullptr);
+        if (ps.huff_set == pss[d_scan[0]].huff_set) n = decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
+        else n = decode_span<false>(rd.row, rd.w0, huffs[ps.huff_set], cx, st, stop, 0, nullptr, nullptr, nullptr);
         nblk[ps.sub_base + t] = n;
         uint64_t e = pack_state(st);
         if (e != state[base + t + 1]) {
@@ -343,8 +365,8 @@ __global__ void k_dec_chain(const ParScan *pss, int nps, uint64_t *state, uint32
 template <int MODE>
 __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
-    CSH_SHARED DevHuffSet lhs;
-    CSH_SHARED ParScan lps;   // the scan descriptor: its per-m arrays are indexed by every lane at every block
+    CSH_SHARED ParHuffSet lhs;
+    CSH_SHARED ParBlockInfo lbi[10];   // write pass: where block m of an MCU goes
     const ParScan &ps = a.pss[blockIdx.y];
     const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     const uint32_t t0 = blockIdx.x * 256, tid = threadIdx.x, t = t0 + tid;
@@ -357,8 +379,8 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             if (!wg_live) continue;
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.huffs[ps.huff_set]);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
-            for (uint32_t i = tid; i < sizeof(DevHuffSet) / 4; i += 256) dst[i] = src[i];
-            if (tid < sizeof(ParScan) / 4) reinterpret_cast<uint32_t *>(&lps)[tid] = reinterpret_cast<const uint32_t *>(&ps)[tid];
+            for (uint32_t i = tid; i < sizeof(ParHuffSet) / 4; i += 256) dst[i] = src[i];
+            if (MODE == 2 && int(tid) < ps.nb_mcu && tid < 10) make_block_info(ps, a.imgs[ps.image], int(tid), lbi[tid]);
             const uint32_t w_first = t0 * (CSH_SUBSEQ_BYTES / 4);
             for (uint32_t i = 0; i < CSH_SUBSEQ_BYTES / 4 + 1; i++) {  // 33 x 256 words cover 256*32 + 4 look-ahead words
                 uint32_t d = i * 256 + tid;
@@ -375,16 +397,17 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
         const bool live = t * CSH_SUBSEQ_BYTES < ps.clean_len;
         LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g = g;
         const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+        const ParCtx cx = make_ctx(ps, MODE == 2 ? &a.imgs[ps.image] : nullptr);
         if (MODE == 0) {
             PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = 0;
             if (t == 0) a.state[base] = pack_state(st);
             if (!live) { a.state[base + t + 1] = 0; continue; }
-            decode_span<false>(rd, lhs, lps, st, stop, 0, nullptr, nullptr, nullptr);
+            decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
             a.state[base + t + 1] = pack_state(st);
         } else if (MODE == 1) {
             if (!live) continue;
             PState st = unpack_state(a.state[base + t]);
-            uint32_t n = decode_span<false>(rd, lhs, lps, st, stop, 0, nullptr, nullptr, nullptr);
+            uint32_t n = decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
             a.nblk[ps.sub_base + t] = n;
             uint64_t e = pack_state(st);
             if (e != a.state[base + t + 1]) {
@@ -397,9 +420,9 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             const PState s0 = unpack_state(a.state[base + t]);
             const PState nx = unpack_state(a.state[base + t + 1]);
             const bool last = (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len;
-            for (int m0 = 0; m0 < lps.nb_mcu && m0 < 10; m0++) {
+            for (int m0 = 0; m0 < ps.nb_mcu && m0 < 10; m0++) {
                 PState st = s0; st.m = m0;
-                uint32_t n = decode_span<false>(rd, lhs, lps, st, stop, 0, nullptr, nullptr, nullptr);
+                uint32_t n = decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
                 const bool same = last || (st.pos == nx.pos && st.k == nx.k);
                 a.hyp[(size_t(ps.sub_base) + t) * 10 + m0] = same ? uint16_t((st.m << 12) | (n > 4095 ? 4095 : n)) : uint16_t(0xFFFF);
             }
@@ -412,7 +435,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             }
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            decode_span<true>(rd, lhs, lps, st, stop, ordinal, &a.imgs[ps.image], a.coef, a.dcdiff);
+            decode_span<true>(rd.row, rd.w0, lhs, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
         }
     }
 }
@@ -453,7 +476,7 @@ void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const
 #ifdef CSH_EMUL
 int csh_emul_jacobi = 0;  // tests: make a list round read the states as they were BEFORE the launch (what concurrent lanes see at worst)
 #endif
-void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
+void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const ParHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate) {
     if (!total_sub) return;
     const uint64_t *state_rd = state;

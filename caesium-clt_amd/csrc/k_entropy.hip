@@ -25,11 +25,11 @@ __global__ void __launch_bounds__(256) k_masks(const int16_t *__restrict__ coef,
     int lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
     tile += first_tile;
-    const int16_t *p = coef + size_t(tile) * CSH_TILE_I16 + lane * 8;
+    const int16_t *p = coef + size_t(tile) * CSH_TILE_I16 + lane * CSH_BLK_STRIDE;
     uint64_t m0 = 0, m1 = 0, m2 = 0;
     CSH_UNROLL
     for (int j = 0; j < 8; j++) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(p + 512 * j);
+        const uint4 q = *reinterpret_cast<const uint4 *>(p + CSH_OCT_STRIDE * j);
         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
         CSH_UNROLL
         for (int i = 0; i < 8; i++) {

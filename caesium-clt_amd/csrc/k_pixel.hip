@@ -88,7 +88,7 @@ __device__ __forceinline__ static void dequant_octet(int x[64], const uint4 &v, 
 }
 template <int... J>
 __device__ __forceinline__ static void load_dequant(const int16_t *__restrict__ blk, const DevQuant &q, int x[64], std::integer_sequence<int, J...>) {
-    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + 512 * J)...};  // all eight loads in flight before first use
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_OCT_STRIDE * J)...};  // all eight loads in flight before first use
     (dequant_octet<J>(x, v[J], q, Oct()), ...);
 }
 __device__ __forceinline__ static void load_idct(const int16_t *__restrict__ blk, const DevQuant &q, int x[64]) {
@@ -144,7 +144,7 @@ __device__ __forceinline__ static void quant_store_octet(const int x[64], const 
     v.y = quant_one<8 * J + 2>(x, q) | (quant_one<8 * J + 3>(x, q) << 16);
     v.z = quant_one<8 * J + 4>(x, q) | (quant_one<8 * J + 5>(x, q) << 16);
     v.w = quant_one<8 * J + 6>(x, q) | (quant_one<8 * J + 7>(x, q) << 16);
-    *reinterpret_cast<uint4 *>(blk + 512 * J) = v;
+    *reinterpret_cast<uint4 *>(blk + CSH_OCT_STRIDE * J) = v;
 }
 template <int... J>
 __device__ __forceinline__ static void quant_store_all(const int x[64], const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
@@ -157,7 +157,7 @@ __device__ __forceinline__ static void raw_store_octet(const int x[64], int16_t 
     v.y = (uint32_t(x[kZ2N[8 * J + 2]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 3]]) << 16);
     v.z = (uint32_t(x[kZ2N[8 * J + 4]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 5]]) << 16);
     v.w = (uint32_t(x[kZ2N[8 * J + 6]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 7]]) << 16);
-    *reinterpret_cast<uint4 *>(raw + 512 * J) = v;
+    *reinterpret_cast<uint4 *>(raw + CSH_OCT_STRIDE * J) = v;
 }
 template <int... J>
 __device__ __forceinline__ static void raw_store_all(const int x[64], int16_t *__restrict__ raw, std::integer_sequence<int, J...>) {
@@ -186,7 +186,7 @@ __device__ __forceinline__ static void raw_to_nat(int x[64], const uint4 &v, std
 }
 template <int... J>
 __device__ __forceinline__ static void requant_block(const int16_t *__restrict__ raw, const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
-    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(raw + 512 * J)...};
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(raw + CSH_OCT_STRIDE * J)...};
     int x[64];
     (raw_to_nat<J>(x, v[J], Oct()), ...);
     quant_store_all(x, q, blk, Oct());
@@ -195,7 +195,7 @@ __device__ __forceinline__ static void requant_block(const int16_t *__restrict__
 __device__ __forceinline__ static void store_zero_block(int16_t *__restrict__ blk) {
     uint4 z; z.x = z.y = z.z = z.w = 0;
     CSH_UNROLL
-    for (int j = 0; j < 8; j++) *reinterpret_cast<uint4 *>(blk + 512 * j) = z;
+    for (int j = 0; j < 8; j++) *reinterpret_cast<uint4 *>(blk + CSH_OCT_STRIDE * j) = z;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,9 +6,9 @@
 namespace csh {
 
 // coefficient tile addressing (types.h): element (block b, zig-zag k) of a component
-__host__ __device__ static inline int coef_off(int k) { return ((k >> 3) << 9) + (k & 7); }  // relative to the block's base
+__host__ __device__ static inline int coef_off(int k) { return (k >> 3) * CSH_OCT_STRIDE + (k & 7); }  // relative to the block's base
 __host__ __device__ static inline size_t coef_index(uint32_t tile_base, int b, int k) {
-    return (size_t(tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) << 3) + size_t(coef_off(k));
+    return (size_t(tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE) + size_t(coef_off(k));
 }
 
 // ---- phase 0: entropy decode (k_decode.hip)
@@ -19,13 +19,13 @@ void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const
 void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt);
 void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off);
 struct DenseArgs {
-    const uint8_t *clean; const ParScan *pss; const DevHuffSet *huffs;
+    const uint8_t *clean; const ParScan *pss; const ParHuffSet *huffs;
     uint64_t *state; uint32_t *nblk; uint64_t *list_out; uint32_t *cnt_out;           // relax
     uint16_t *hyp; const uint32_t *scan_pending;                                       // label hypotheses (mode 3)
     const uint64_t *blk_off; const ImgDesc *imgs; int16_t *coef; int32_t *dcdiff; uint32_t *need_seq;  // write
 };
 void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
-void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const DevHuffSet *huffs, uint64_t *state, uint32_t *nblk,
+void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const ParHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate);
 void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending);
 void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq);

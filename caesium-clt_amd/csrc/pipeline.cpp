@@ -89,6 +89,8 @@ struct csh_batch {
     std::vector<ImgDesc> imgs;
     std::vector<DecScan> dscans;
     std::vector<DevHuffSet> hsets;
+    std::vector<ParHuffSet> phsets;   // the same sets in the parallel decoder's LDS form
+    std::vector<char> phset_fits;     // 0: sub-table pool overflow -> sequential decoder
     std::vector<DevQuant> quants;
     std::vector<PlaneWork> pwork;
     std::vector<ResizeWork> rwork;
@@ -119,6 +121,7 @@ struct csh_batch {
     DevBuf<ImgDesc> d_imgs;
     DevBuf<DecScan> d_dscans;
     DevBuf<DevHuffSet> d_hsets;
+    DevBuf<ParHuffSet> d_phsets;
     DevBuf<DevQuant> d_quants;
     DevBuf<PlaneWork> d_pwork;
     DevBuf<ResizeWork> d_rwork;
@@ -162,11 +165,42 @@ static void build_dev_huff(const HuffSpec &h, DevHuff &d) {
     }
     d.maxcode[17] = 0x7FFFFFFF;
     memcpy(d.vals, h.vals, 256);
-    uint32_t lim = 0;
+}
+// two-level table of the parallel decoder; returns false when the shared sub-table pool is exhausted
+static bool build_par_huff(const HuffSpec &h, uint16_t root[512], uint16_t *sub, int &sub_used) {
+    memset(root, 0, 512 * sizeof(uint16_t));
+    if (!h.present) return true;
+    // canonical codes, left-aligned to 16 bits
+    struct Code { uint16_t first; uint8_t len, sym; };
+    std::vector<Code> longc;
+    int code = 0, p = 0;
     for (int l = 1; l <= 16; l++) {
-        if (d.maxcode[l] >= 0) lim = uint32_t(d.maxcode[l] + 1) << (16 - l);
-        if (l >= 10) { d.limit[l - 10] = lim; d.vbase[l - 10] = d.valptr[l]; }
+        for (int i = 0; i < h.bits[l]; i++, p++, code++) {
+            if (l <= 9) {
+                int base = code << (9 - l);
+                for (int k = 0; k < (1 << (9 - l)); k++) root[(base + k) & 511] = uint16_t((l << 8) | h.vals[p]);
+            } else longc.push_back({uint16_t(code << (16 - l)), uint8_t(l), h.vals[p]});
+        }
+        code <<= 1;
     }
+    for (size_t i = 0; i < longc.size();) {
+        const int prefix = longc[i].first >> 7;
+        size_t j = i;
+        int maxlen = 0;
+        while (j < longc.size() && (longc[j].first >> 7) == prefix) { maxlen = std::max<int>(maxlen, longc[j].len); j++; }
+        const int nbits = maxlen - 9, n = 1 << nbits;
+        if (sub_used + n > CSH_PAR_SUB) return false;
+        uint16_t *t = sub + sub_used;
+        memset(t, 0, n * sizeof(uint16_t));
+        for (size_t c = i; c < j; c++) {
+            int lo = (longc[c].first & 127) >> (7 - nbits), span = 1 << (maxlen - longc[c].len);
+            for (int k = 0; k < span; k++) t[lo + k] = uint16_t((longc[c].len << 8) | longc[c].sym);
+        }
+        root[prefix & 511] = uint16_t(0x8000 | (nbits << 12) | sub_used);
+        sub_used += n;
+        i = j;
+    }
+    return true;
 }
 
 static void make_quant(const uint16_t nat[64], DevQuant &q) {
@@ -414,6 +448,13 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 DevHuffSet hs;
                 for (int t = 0; t < 4; t++) { build_dev_huff(js.dc[t], hs.dc[t]); build_dev_huff(js.ac[t], hs.ac[t]); }
                 b->hsets.push_back(hs);
+                ParHuffSet phs;
+                memset(&phs, 0, sizeof phs);
+                int sub_used = 0;
+                bool fits = true;
+                for (int t = 0; t < 4; t++) fits = fits && build_par_huff(js.dc[t], phs.root[t], phs.sub, sub_used) && build_par_huff(js.ac[t], phs.root[4 + t], phs.sub, sub_used);
+                b->phsets.push_back(phs);
+                b->phset_fits.push_back(fits ? 1 : 0);
                 hset_keys.emplace_back(key, found);
             }
             ds.huff_set = found;
@@ -429,6 +470,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
 
         // sequential-mode scans without restart markers go to the parallel self-synchronising decoder
         bool par_ok = !in.progressive && in.restart_interval == 0;
+        for (size_t s = 0; s < in.scans.size(); s++) if (!b->phset_fits[b->dscans[im.first_scan + s].huff_set]) par_ok = false;
         for (const JScan &js : in.scans) if (js.data_len >= (1u << 28)) par_ok = false;
         if (par_ok) {
             for (size_t s = 0; s < in.scans.size(); s++) {
@@ -447,6 +489,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                             if (m >= 10) break;
                             ps.comp_of[m] = js.comp_idx[k]; ps.by_of[m] = y; ps.bx_of[m] = x; ps.dct[m] = js.td[k]; ps.act[m] = js.ta[k];
                             ps.dc_base[m] = b->dc_total; ps.dc_per_mcu[m] = uint32_t(nh * nv); ps.dc_idx[m] = uint32_t(y * nh + x);
+                            ps.sel |= uint64_t((js.td[k] & 3) | ((4 + (js.ta[k] & 3)) << 3)) << (6 * m);
                         }
                     b->dc_total += nblocks;
                     ps.total_blocks += nblocks;
@@ -571,7 +614,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     hipStream_t st = b->stream;
     if (b->nimg) {
         if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) ||
-            b->d_hsets.upload(b->hsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
+            b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
             b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
@@ -648,7 +691,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         MARK();
         DenseArgs da;
         memset(&da, 0, sizeof da);
-        da.clean = b->d_clean.p; da.pss = b->d_pscans.p; da.huffs = b->d_hsets.p; da.state = b->d_pstate.p; da.nblk = b->d_nblk.p;
+        da.clean = b->d_clean.p; da.pss = b->d_pscans.p; da.huffs = b->d_phsets.p; da.state = b->d_pstate.p; da.nblk = b->d_nblk.p;
         da.list_out = b->d_relax_list[0].p; da.cnt_out = b->d_relax_cnt.p; da.blk_off = b->d_blk_off.p; da.imgs = b->d_imgs.p;
         da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p;
         launch_dec_dense(st, 0, nps, b->max_sub, da);
@@ -658,7 +701,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         launch_dec_dense(st, 1, nps, b->max_sub, da);
         MARK();
         for (int it = 0; it < R && nps; it++)
-            launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, b->d_hsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
+            launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, b->d_phsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
                                   b->d_relax_cnt.p + it, b->d_relax_list[(it & 1) ^ 1].p, b->d_relax_cnt.p + it + 1, b->d_pstate.n);
         if (nps) {   // scans that are still listed: settle their block-in-MCU labels exactly (k_dec_chain), or hand the image to k_decode_seq
             if (b->d_scan_pending.zero(st)) return -1;
@@ -891,7 +934,7 @@ extern "C" int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int wh
     std::vector<int16_t> tiles(size_t(g.ntiles) * CSH_TILE_I16);
     if (hipMemcpy(tiles.data(), b->d_coef.p + size_t(g.tile_base) * CSH_TILE_I16, tiles.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return -1; }
     for (int blk = 0; blk < bw * bh; blk++)
-        for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + ((blk & 63) << 3) + coef_off(k)];
+        for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + (blk & 63) * CSH_BLK_STRIDE + coef_off(k)];
     return 0;
 }
 

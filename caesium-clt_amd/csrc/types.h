@@ -14,6 +14,17 @@
 
 #define CSH_TILE_BLOCKS 64
 #define CSH_TILE_I16 4096  // int16 elements per tile
+// position of coefficient k (zig-zag) of block `lane` inside a tile: lane*CSH_BLK_STRIDE + (k>>3)*CSH_OCT_STRIDE + (k&7)
+#ifndef CSH_BLOCK_MAJOR
+#define CSH_BLOCK_MAJOR 0
+#endif
+#if CSH_BLOCK_MAJOR      // int16 tile[64 blocks][64 k]: one block = one 128-byte line
+#define CSH_OCT_STRIDE 8
+#define CSH_BLK_STRIDE 64
+#else                    // int16 tile[8 k>>3][64 blocks][8 k&7]: a wave's octet loads are contiguous
+#define CSH_OCT_STRIDE 512
+#define CSH_BLK_STRIDE 8
+#endif
 #define CSH_MAX_COMPS 3
 #define CSH_MAX_SCANS 20
 
@@ -34,12 +45,21 @@ struct DevHuff {
     int32_t maxcode[18];  // per length, -1 if none
     int32_t valptr[17];
     uint8_t vals[256];
-    // branch-free long-code path (codes of 10..16 bits): limit[l-10] = left-aligned exclusive upper bound of the 16-bit
-    // window for length l (monotone in l), vbase[l-10] = valptr[l].  All 14 words are fetched at once.
-    uint32_t limit[7];
-    int32_t vbase[7];
 };
 struct DevHuffSet { DevHuff dc[4], ac[4]; };
+
+// the same tables as the parallel decoder wants them in LDS (k_decode_par.hip): two-level look-up.
+// root[t][top 9 bits]: (len<<8)|sym for a code of <= 9 bits; 0x8000 | nbits<<12 | offset for a 9-bit prefix shared by longer
+// codes -- then sub[offset + next nbits bits] holds (len<<8)|sym (len 10..16); 0 = no such code.  The sub-tables of all
+// eight tables share one pool; a set that does not fit (possible only with pathological tables) sends its images to the
+// sequential decoder.
+#define CSH_PAR_SUB 2048
+struct ParHuffSet {
+    uint16_t root[8][512];   // 0..3 DC tables, 4..7 AC tables
+    uint16_t sub[CSH_PAR_SUB];
+};
+// where block m of an MCU goes (write pass), one entry per block-in-MCU index
+struct ParBlockInfo { uint32_t tile_base; int bw, h, v, by0, bx0; uint32_t dc_base, dc_per_mcu, dc_idx; };
 
 // one entropy-coded scan of one input image
 struct DecScan {
@@ -85,6 +105,7 @@ struct ParScan {
     uint32_t sub_base;            // first sub-sequence of this scan in the flat per-sub-sequence arrays
     uint32_t par_index;           // index among ParScans (state arrays hold nsub+1 entries per scan)
     uint32_t dc_base[10], dc_per_mcu[10], dc_idx[10];  // where block m's DC difference goes (scan order, per component)
+    uint64_t sel;                 // table selectors, 6 bits per block-in-MCU index m: dct[m] | (4 + act[m]) << 3
 };
 
 // quantisation table as the kernels want it: zig-zag order, with exact-division helpers

@@ -354,6 +354,7 @@ int cso_decode(const uint8_t *d, size_t n, cso_image **out) {
                 j += 17;
                 if (cnt > 256 || j + cnt > sl) { snprintf(g_err, sizeof g_err, "bad DHT"); goto done; }
                 memcpy(h->huffval, s + j, cnt); j += cnt;
+                if (!tc) for (int i = 0; i < cnt; i++) if (h->huffval[i] > 15) { snprintf(g_err, sizeof g_err, "bad DHT (DC symbol > 15)"); goto done; }  /* libjpeg JERR_BAD_HUFF_TABLE */
                 if (build_dhuff(h)) goto done;
                 h->present = 1;
             }
