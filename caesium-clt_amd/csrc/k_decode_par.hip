@@ -175,10 +175,10 @@ __device__ __forceinline__ static ParCtx make_ctx(const ParScan &ps, const ImgDe
 // per-m placement table of the write pass (LDS): a non-interleaved scan walks its component block by block (h = v = 1)
 __device__ __forceinline__ static void make_block_info(const ParScan &ps, const ImgDesc &im, int m, ParBlockInfo &o) {
     const CompGeom &g = im.in[ps.comp_of[m]];
-    o.tile_base = g.tile_base; o.bw = g.bw;
-    if (ps.ncomp > 1) { o.h = g.h; o.v = g.v; o.by0 = ps.by_of[m]; o.bx0 = ps.bx_of[m]; }
-    else { o.h = 1; o.v = 1; o.by0 = 0; o.bx0 = 0; }
-    o.dc_base = ps.dc_base[m]; o.dc_per_mcu = ps.dc_per_mcu[m]; o.dc_idx = ps.dc_idx[m];
+    o.tile_base = g.tile_base;
+    if (ps.ncomp > 1) { o.row_step = g.v * g.bw; o.col_step = g.h; o.first = ps.by_of[m] * g.bw + ps.bx_of[m]; }
+    else { o.row_step = g.bw; o.col_step = 1; o.first = 0; }
+    o.dc_first = ps.dc_base[m] + ps.dc_idx[m]; o.dc_per_mcu = ps.dc_per_mcu[m];
 }
 
 // decode from state `st` until st.pos >= stop_bit; returns #blocks completed.  WRITE: store coefficients.
@@ -209,11 +209,11 @@ __device__ __forceinline__ static uint32_t decode_span(const uint32_t *row, uint
         return row[r];
     };
     auto locate = [&](int m) {
-        in_range = mcu * uint32_t(cx.nb_mcu) + uint32_t(m) < cx.total_blocks;
+        // 24-bit multiplies: the host sends scans of >= 2^24 blocks to the sequential decoder
+        in_range = __umul24(mcu, uint32_t(cx.nb_mcu)) + uint32_t(m) < cx.total_blocks;
         const ParBlockInfo g = bi[m];
-        int by = my * g.v + g.by0, bx = mx * g.h + g.bx0;
-        blk = coef + coef_index(g.tile_base, by * g.bw + bx, 0);
-        dcp = dcdiff + g.dc_base + mcu * g.dc_per_mcu + g.dc_idx;
+        blk = coef + coef_index(g.tile_base, __mul24(my, g.row_step) + __mul24(mx, g.col_step) + g.first, 0);
+        dcp = dcdiff + (__umul24(mcu, g.dc_per_mcu) + g.dc_first);
     };
     uint32_t pos = st.pos, wi = (pos >> 5) + 2;
     int k = st.k, m = st.m;
@@ -223,7 +223,7 @@ __device__ __forceinline__ static uint32_t decode_span(const uint32_t *row, uint
         locate(m);
     }
     uint32_t dco, aco;   // byte offsets of the current DC / AC root tables
-    auto tables = [&](int mm) { uint32_t x = uint32_t(cx.sel >> (6 * mm)); dco = (x & 7u) << 10; aco = (x & 56u) << 7; };
+    auto tables = [&](int mm) { uint32_t x = uint32_t(cx.sel >> __umul24(uint32_t(mm), 6u)); dco = (x & 7u) << 10; aco = (x & 56u) << 7; };
     tables(m);
     // 64-bit bit buffer (MSB first), at least 32 valid bits after every refill
     uint64_t acc = ((uint64_t(word(wi - 2)) << 32) | word(wi - 1)) << (pos & 31);

@@ -472,6 +472,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         bool par_ok = !in.progressive && in.restart_interval == 0;
         for (size_t s = 0; s < in.scans.size(); s++) if (!b->phset_fits[b->dscans[im.first_scan + s].huff_set]) par_ok = false;
         for (const JScan &js : in.scans) if (js.data_len >= (1u << 28)) par_ok = false;
+        if (uint64_t(in.mcus_x) * uint64_t(in.mcus_y) * 10 >= (1u << 24)) par_ok = false;   // k_decode_par.hip uses 24-bit multiplies on block counts
         if (par_ok) {
             for (size_t s = 0; s < in.scans.size(); s++) {
                 const JScan &js = in.scans[s];

@@ -59,7 +59,8 @@ struct ParHuffSet {
     uint16_t sub[CSH_PAR_SUB];
 };
 // where block m of an MCU goes (write pass), one entry per block-in-MCU index
-struct ParBlockInfo { uint32_t tile_base; int bw, h, v, by0, bx0; uint32_t dc_base, dc_per_mcu, dc_idx; };
+// block index in the component = my*row_step + mx*col_step + first; DC difference slot = mcu*dc_per_mcu + dc_first
+struct ParBlockInfo { uint32_t tile_base; int row_step, col_step, first; uint32_t dc_first, dc_per_mcu; };
 
 // one entropy-coded scan of one input image
 struct DecScan {
