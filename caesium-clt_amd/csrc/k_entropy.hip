@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) k_masks(const int16_t *__restrict__ coef,
     if (tile >= ntiles) return;
     tile += first_tile;
     const int16_t *p = coef + size_t(tile) * CSH_TILE_I16 + lane * CSH_BLK_STRIDE;
-    uint64_t m0 = 0, m1 = 0, m2 = 0;
+    uint64_t m0 = 0, m1 = 0, m2 = 0, b0 = 0, b1 = 0, sg = 0;
     CSH_UNROLL
     for (int j = 0; j < 8; j++) {
         const uint4 q = *reinterpret_cast<const uint4 *>(p + CSH_OCT_STRIDE * j);
@@ -39,10 +39,13 @@ __global__ void __launch_bounds__(256) k_masks(const int16_t *__restrict__ coef,
             m0 |= uint64_t(a >= 1) << k;
             m1 |= uint64_t(a >= 2) << k;
             m2 |= uint64_t(a >= 4) << k;
+            b0 |= uint64_t(a & 1u) << k;
+            b1 |= uint64_t((a >> 1) & 1u) << k;
+            sg |= uint64_t(v < 0) << k;
         }
     }
-    uint64_t *o = masks + size_t(tile) * 192 + lane;
-    o[0] = m0; o[64] = m1; o[128] = m2;
+    uint64_t *o = masks + size_t(tile) * CSH_MASK_TILE + lane;
+    o[0] = m0; o[64] = m1; o[128] = m2; o[192] = b0; o[256] = b1; o[320] = sg;
 }
 void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t first_tile, uint32_t ntiles) {
     if (ntiles) CSH_LAUNCH(k_masks, dim3((ntiles + 3) / 4), dim3(256), st, coef, masks, first_tile, ntiles);
@@ -59,17 +62,22 @@ __device__ __forceinline__ static int unit_block(const CompGeom &g, uint32_t u) 
     return by * g.bw + bx;
 }
 __device__ __forceinline__ static uint64_t load_mask(const uint64_t *masks, const CompGeom &g, int b, int level) {
-    return masks[(size_t(g.tile_base) + size_t(b >> 6)) * 192 + size_t(level) * 64 + size_t(b & 63)];
+    return masks[(size_t(g.tile_base) + size_t(b >> 6)) * CSH_MASK_TILE + size_t(level) * 64 + size_t(b & 63)];
 }
 __device__ __forceinline__ static bool get_bit(const uint64_t *w, uint32_t i) { return (w[i >> 6] >> (i & 63)) & 1; }
 
-struct AcMasks { uint64_t NZ, H, N; };  // first pass uses NZ; refinement uses H and N
+struct AcMasks { uint64_t NZ, H, N, C, S; };  // first pass uses NZ; refinement uses H and N (+ C: correction-bit plane, S: signs when packing)
+template <bool VALUES = false>
 __device__ __forceinline__ static AcMasks ac_masks(const uint64_t *masks, const CompGeom &g, int b, const EncScan &sc) {
     uint64_t band = band_mask(sc.Ss, sc.Se);
     AcMasks m;
     uint64_t lo = load_mask(masks, g, b, sc.Al);
+    m.C = 0; m.S = 0;
     if (sc.Ah == 0) { m.NZ = lo & band; m.H = 0; m.N = 0; }
-    else { uint64_t hi = load_mask(masks, g, b, sc.Al + 1); m.H = hi & band; m.N = lo & ~hi & band; m.NZ = 0; }
+    else {
+        uint64_t hi = load_mask(masks, g, b, sc.Al + 1); m.H = hi & band; m.N = lo & ~hi & band; m.NZ = 0;
+        if (VALUES) { m.C = load_mask(masks, g, b, 3 + sc.Al); m.S = load_mask(masks, g, b, 5); }   // Al <= 1 whenever Ah != 0 (three significance planes)
+    }
     return m;
 }
 
@@ -152,6 +160,11 @@ struct StatsSink {
     __device__ __forceinline__ void raw(unsigned, int) {}
     __device__ __forceinline__ void rawcount(int) {}
 };
+// k_pack reads the scan's tables from LDS: ltab[t * 256 + s] = size << 16 | code (staged once per workgroup; for k_sizes,
+// which only needs one byte per symbol, the staging barrier costs more than it saves -- measured)
+__device__ __forceinline__ static void stage_enc_tables(uint32_t *ltab, const DevEncTable *tab, int ntables) {
+    for (int i = threadIdx.x; i < ntables * 256; i += blockDim.x) { const DevEncTable &T = tab[i >> 8]; ltab[i] = (uint32_t(T.size[i & 255]) << 16) | T.code[i & 255]; }
+}
 struct SizeSink {
     const DevEncTable *tab;
     uint32_t bits;
@@ -165,7 +178,7 @@ struct PackSink {
     // Bits are gathered in a 64-bit accumulator and leave as whole big-endian-logical 32-bit words.  Only the first and the
     // last word of a unit's bit string can be shared with a neighbouring unit, so only those two need an atomic OR; the
     // words in between are exclusively this lane's and are stored plainly (the pool is zero-initialised).
-    const DevEncTable *tab;
+    const uint32_t *tab;
     uint32_t *raw_words;
     uint64_t pos;      // absolute bit position in the raw pool of the next bit to emit
     uint64_t acc;      // pending bits, right-aligned
@@ -195,7 +208,7 @@ struct PackSink {
         if (w) atomicOr(raw_words + wi, w);
         nacc = 0;
     }
-    __device__ __forceinline__ void sym(int t, int s) { put(tab[t].code[s], tab[t].size[s]); }
+    __device__ __forceinline__ void sym(int t, int s) { uint32_t e = tab[t * 256 + s]; put(e & 0xFFFFu, int(e >> 16)); }
     __device__ __forceinline__ void syms(int t, int s, int n) { for (int i = 0; i < n; i++) sym(t, s); }
     __device__ __forceinline__ void raw(unsigned v, int n) { put(v, n); }
     __device__ __forceinline__ void rawcount(int) {}
@@ -228,7 +241,7 @@ __device__ static void walk_ac_first(Sink &sink, const int16_t *blk, uint64_t NZ
 }
 
 template <class Sink>
-__device__ static void walk_ac_refine(Sink &sink, const int16_t *blk, uint64_t H, uint64_t N, const EncScan &sc, unsigned run) {
+__device__ static void walk_ac_refine(Sink &sink, uint64_t H, uint64_t N, uint64_t C, uint64_t S, const EncScan &sc, unsigned run) {
     if (!Sink::kValues) {
         // symbols and bit counts only: zero run = gap - popcount(history in the gap)
         int prev = sc.Ss - 1;
@@ -264,12 +277,11 @@ __device__ static void walk_ac_refine(Sink &sink, const int16_t *blk, uint64_t H
                 if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
                 br = 0; brn = 0;
             }
-        int v = blk[coef_off(k)];
-        unsigned a = unsigned(v < 0 ? -v : v) >> sc.Al;
-        if ((H >> k) & 1) { br = (br << 1) | (a & 1); brn++; }
+        // no coefficient is read: the correction bit and the sign come from the bit planes
+        if ((H >> k) & 1) { br = (br << 1) | ((C >> k) & 1); brn++; }
         else {
             sink.sym(0, (r << 4) | 1);
-            sink.raw(v < 0 ? 0u : 1u, 1);
+            sink.raw(unsigned((~S >> k) & 1), 1);
             if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
             if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
             br = 0; brn = 0; r = 0;
@@ -372,11 +384,11 @@ __device__ __forceinline__ static void walk_unit(Sink &sink, const EncCtx &c, co
     if (sc.Ss == 0) { walk_dc(sink, c, im, sc, u); return; }
     const CompGeom &g = im.out[sc.comp[0]];
     int b = unit_block(g, u);
-    AcMasks m = ac_masks(c.masks, g, b, sc);
+    AcMasks m = ac_masks<Sink::kValues>(c.masks, g, b, sc);
     const int16_t *blk = c.coef + coef_index(g.tile_base, b, 0);
     unsigned run = c.eobrun[w.unit_base + u];
     if (sc.Ah == 0) walk_ac_first(sink, blk, m.NZ, sc, run);
-    else walk_ac_refine(sink, blk, m.H, m.N, sc, run);
+    else walk_ac_refine(sink, m.H, m.N, m.C, m.S, sc, run);
 }
 
 // ---- pass C: symbol statistics.  A workgroup walks CSH_STATS_CHUNK consecutive units of one scan into an LDS histogram
@@ -474,20 +486,25 @@ __global__ void __launch_bounds__(256) k_sizes(EncCtx c) {
 __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     const ScanWork w = c.work[blockIdx.y];
     const EncScan &sc = c.script[w.scan];
+    CSH_SHARED uint32_t ltab[4 * 256];
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= w.nunits) return;
-    uint64_t base = c.unit_off[w.unit_base];
-    uint64_t total = c.unit_off[w.unit_base + w.nunits] - base;
-    uint64_t raw_bit0 = w.raw_off * 8;
-    if (raw_bit0 + total + 64 > c.raw_words * 32) { c.status[w.image] = 20200; return; }
-    PackSink s; s.tab = c.tables + w.table_base; s.raw_words = c.raw;
-    s.begin(raw_bit0 + (c.unit_off[w.unit_base + u] - base));
-    walk_unit(s, c, w, sc, u);
-    if (u == w.nunits - 1) {  // flush_bits: pad the last byte with 1-bits
-        int pad = int((8 - (total & 7)) & 7);
-        if (pad) s.put((1u << pad) - 1u, pad);
+    CSH_PHASE_LOOP(2) {
+        if (blockIdx.x * blockDim.x >= w.nunits) continue;   // whole workgroup idle (uniform)
+        if (phase == 0) { stage_enc_tables(ltab, c.tables + w.table_base, sc.ntables); continue; }
+        if (u >= w.nunits) continue;
+        uint64_t base = c.unit_off[w.unit_base];
+        uint64_t total = c.unit_off[w.unit_base + w.nunits] - base;
+        uint64_t raw_bit0 = w.raw_off * 8;
+        if (raw_bit0 + total + 64 > c.raw_words * 32) { c.status[w.image] = 20200; continue; }
+        PackSink s; s.tab = ltab; s.raw_words = c.raw;
+        s.begin(raw_bit0 + (c.unit_off[w.unit_base + u] - base));
+        walk_unit(s, c, w, sc, u);
+        if (u == w.nunits - 1) {  // flush_bits: pad the last byte with 1-bits
+            int pad = int((8 - (total & 7)) & 7);
+            if (pad) s.put((1u << pad) - 1u, pad);
+        }
+        s.finish();
     }
-    s.finish();
 }
 
 static dim3 unit_grid(const EncCtx &c) { return dim3((c.max_units + 255) / 256, c.nwork); }
@@ -497,6 +514,6 @@ void launch_stats(hipStream_t st, const EncCtx &c) {
     if (c.nwork) CSH_LAUNCH_PHASED(k_stats, 3, dim3((c.max_units + CSH_STATS_CHUNK - 1) / CSH_STATS_CHUNK, c.nwork), dim3(256), st, c);
 }
 void launch_sizes(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_sizes, unit_grid(c), dim3(256), st, c); }
-void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_pack, unit_grid(c), dim3(256), st, c); }
+void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH_PHASED(k_pack, 2, unit_grid(c), dim3(256), st, c); }
 
 }  // namespace csh

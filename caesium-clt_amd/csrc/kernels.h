@@ -61,7 +61,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     int nwork;
     uint32_t max_units;        // max nunits over work items
     const int16_t *coef;       // re-quantised coefficients (tiles)
-    const uint64_t *masks;     // [tile][3][64]
+    const uint64_t *masks;     // [tile][CSH_MASK_PLANES][64]
     uint64_t *sym_bits;        // per AC scan: bit b set iff block b emits >=1 Huffman symbol in this scan
     uint64_t *eob_bits;        // per AC scan: bit b set iff block b ends with a pending EOB
     uint8_t *tail;             // per unit: # of correction bits left over at the end of the block (refine scans)

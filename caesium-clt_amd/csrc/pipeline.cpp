@@ -629,7 +629,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 return CS_ERR_NO_DEVICE;
         }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
-            b->d_masks.alloc(size_t(b->ntiles) * 192) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
+            b->d_masks.alloc(size_t(b->ntiles) * CSH_MASK_TILE) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
             b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
             b->d_unit_off.alloc(b->total_units + 2) || b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||

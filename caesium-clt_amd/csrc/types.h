@@ -26,6 +26,10 @@
 #define CSH_BLK_STRIDE 8
 #endif
 #define CSH_MAX_COMPS 3
+// per-block 64-bit planes (bit = zig-zag index), SoA per tile u64[CSH_MASK_PLANES][64]:
+// 0..2 significance |c| >= 1, 2, 4;  3, 4 = bit 0, bit 1 of |c|;  5 = sign.  Refinement scans are coded from these alone.
+#define CSH_MASK_PLANES 6
+#define CSH_MASK_TILE (CSH_MASK_PLANES * 64)
 #define CSH_MAX_SCANS 20
 
 namespace csh {
