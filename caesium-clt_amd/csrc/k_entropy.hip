@@ -424,9 +424,11 @@ __global__ void __launch_bounds__(256) k_stats(EncCtx c) {
     }
 }
 
-// ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour), one lane per table.
+// ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour).
 // The merge loop runs over the COMPACTED list of used symbols (ascending symbol order, pseudo-symbol 256 last), which
 // preserves libjpeg's tie-breaking ("least frequency, ties to the larger symbol") while doing nnz^2 instead of 257*nnz work.
+#ifdef CSH_EMUL
+// emulation build: the plain serial form, one lane per table (the statement of the algorithm the wave kernel must match)
 __global__ void k_gen_tables(DevEncTable *tables, int ntables) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntables) return;
@@ -467,8 +469,131 @@ __global__ void k_gen_tables(DevEncTable *tables, int ntables) {
     int code = 0; p = 0;
     for (int l = 1; l <= 16; l++) { for (int k2 = 0; k2 < T.bits[l]; k2++, p++) { T.code[T.vals[p]] = uint16_t(code++); T.size[T.vals[p]] = uint8_t(l); } code <<= 1; }
 }
+#else
+// product build: one WAVE per table.  Entry e of the compacted list lives in lane e & 63, slot e >> 6 (registers).  A merge
+// is two wave-wide arg-min reductions (key = freq << 32 | ~index: least frequency, ties to the larger index) and one
+// data-parallel update: instead of walking libjpeg's `others` chain, every entry carries the id of the tree it belongs to
+// and all entries of the two merged trees bump their code size at once -- the same code sizes, without the serial chain.
+#define CSH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+__device__ __forceinline__ static uint64_t wave_min_u64(uint64_t v) {
+    CSH_UNROLL
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(v)), o, 64)), hi = uint32_t(__shfl_xor(int(uint32_t(v >> 32)), o, 64));
+        uint64_t x = (uint64_t(hi) << 32) | lo;
+        v = x < v ? x : v;
+    }
+    return v;
+}
+__global__ void __launch_bounds__(256) k_gen_tables(DevEncTable *tables, int ntables) {
+    __shared__ uint32_t s_freq[4][260];
+    __shared__ uint16_t s_sym[4][260], s_grp[4][260], s_cs[4][260], s_code[4][256];
+    __shared__ uint8_t s_size[4][256], s_vals[4][256];
+    __shared__ uint32_t s_bits[4][34];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= ntables) return;   // whole wave: only wave-level synchronisation is used below
+    DevEncTable &T = tables[t];
+    uint32_t *freq0 = s_freq[wv]; uint16_t *symof = s_sym[wv], *grp = s_grp[wv], *csz = s_cs[wv], *ocode = s_code[wv];
+    uint8_t *osize = s_size[wv], *ovals = s_vals[wv];
+    uint32_t *bits = s_bits[wv];
+    const uint64_t lt = (1ull << lane) - 1ull;
+    // compact the used symbols, ascending
+    int n = 0;
+    CSH_UNROLL
+    for (int j = 0; j < 4; j++) {
+        uint32_t f = T.freq[lane + 64 * j];
+        uint64_t m = __ballot(f != 0);
+        if (f) { int pos = n + __popcll(m & lt); freq0[pos] = f; symof[pos] = uint16_t(lane + 64 * j); }
+        n += __popcll(m);
+    }
+    if (lane == 0) { freq0[n] = 1; symof[n] = 256; }   // reserved code point: guarantees no all-ones code
+    n++;
+    if (lane < 34) bits[lane] = 0;
+    for (int i = lane; i < 256; i += 64) { ocode[i] = 0; osize[i] = 0; ovals[i] = 0; }
+    CSH_WAVE_SYNC();
+    uint32_t f[5]; int cs[5], g[5];
+    CSH_UNROLL
+    for (int j = 0; j < 5; j++) { int e = lane + 64 * j; f[j] = e < n ? freq0[e] : 0u; cs[j] = 0; g[j] = e; if (e < n) grp[e] = uint16_t(e); }
+    CSH_WAVE_SYNC();
+    for (;;) {
+        uint64_t k1 = ~0ull;
+        CSH_UNROLL
+        for (int j = 0; j < 5; j++) { uint64_t k = (uint64_t(f[j]) << 32) | uint32_t(~uint32_t(lane + 64 * j)); if (f[j] && k < k1) k1 = k; }
+        k1 = wave_min_u64(k1);
+        const int c1 = int(~uint32_t(k1));
+        uint64_t k2 = ~0ull;
+        CSH_UNROLL
+        for (int j = 0; j < 5; j++) { uint64_t k = (uint64_t(f[j]) << 32) | uint32_t(~uint32_t(lane + 64 * j)); if (f[j] && lane + 64 * j != c1 && k < k2) k2 = k; }
+        k2 = wave_min_u64(k2);
+        if (k2 == ~0ull) break;
+        const int c2 = int(~uint32_t(k2));
+        const uint32_t f2 = uint32_t(k2 >> 32);
+        const int g1 = grp[c1], g2 = grp[c2];
+        CSH_WAVE_SYNC();   // everyone has read the tree ids before they are rewritten
+        CSH_UNROLL
+        for (int j = 0; j < 5; j++) {
+            const int e = lane + 64 * j;
+            if (e == c1) f[j] += f2;
+            if (e == c2) f[j] = 0;
+            if (e < n && (g[j] == g1 || g[j] == g2)) { cs[j]++; if (g[j] != g1) { g[j] = g1; grp[e] = uint16_t(g1); } }
+        }
+        CSH_WAVE_SYNC();
+    }
+    // code-length counts (of every entry, the reserved one included), then libjpeg's length limiting
+    CSH_UNROLL
+    for (int j = 0; j < 5; j++) {
+        const int e = lane + 64 * j;
+        if (e < n) {
+            csz[e] = uint16_t(cs[j]);
+            if (cs[j]) atomicAdd(&bits[cs[j] > 32 ? 32 : cs[j]], 1u);
+            if (e < n - 1 && cs[j] >= 1 && cs[j] <= 32) atomicAdd(&bits[33], 1u);   // listed symbols
+        }
+    }
+    CSH_WAVE_SYNC();
+    // order of the symbols: by code size, then by symbol (the reserved entry n-1 is not listed); sizes above 32 are not coded
+    {
+        int before[5] = {0, 0, 0, 0, 0};
+        for (int q = 0; q < n - 1; q++) {
+            const int cq = csz[q];
+            CSH_UNROLL
+            for (int j = 0; j < 5; j++) before[j] += (cq >= 1 && cq <= 32 && (cq < cs[j] || (cq == cs[j] && q < lane + 64 * j))) ? 1 : 0;
+        }
+        CSH_UNROLL
+        for (int j = 0; j < 5; j++) { const int e = lane + 64 * j; if (e < n - 1 && cs[j] >= 1 && cs[j] <= 32) ovals[before[j]] = uint8_t(symof[e]); }
+    }
+    if (lane == 0) {
+        for (int i = 32; i > 16; i--)
+            while (bits[i] > 0) {
+                int j = i - 2; while (bits[j] == 0) j--;
+                bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+            }
+        int i = 16; while (i > 0 && bits[i] == 0) i--;
+        if (i > 0) bits[i]--;
+    }
+    CSH_WAVE_SYNC();
+    const int nsym = int(bits[33]);
+    // canonical codes for the listed symbols: position p has the length l with start[l] <= p < start[l] + bits[l]
+    for (int p = lane; p < nsym; p += 64) {
+        int code = 0, st = 0, len = 0, mine = 0;
+        for (int l = 1; l <= 16; l++) {
+            const int bl = int(bits[l]);
+            if (!len && p < st + bl) { len = l; mine = code + (p - st); }
+            code = (code + bl) << 1; st += bl;
+        }
+        if (len) { ocode[ovals[p]] = uint16_t(mine); osize[ovals[p]] = uint8_t(len); }
+    }
+    CSH_WAVE_SYNC();
+    if (lane <= 16) T.bits[lane] = lane ? uint8_t(bits[lane]) : 0;
+    if (lane == 0) T.nsym = nsym;
+    for (int i = lane; i < 256; i += 64) { T.vals[i] = ovals[i]; T.code[i] = ocode[i]; T.size[i] = osize[i]; }
+}
+#endif
 void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
+#ifdef CSH_EMUL
     if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 63) / 64), dim3(64), st, tables, ntables);
+#else
+    if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 3) / 4), dim3(256), st, tables, ntables);
+#endif
 }
 
 // ---- pass E: size in bits of every unit's output
