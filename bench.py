@@ -41,6 +41,32 @@ def algorithmic_bytes(kernel, t, n):
     return table.get(kernel)
 
 
+# hipEvent kernel slot -> substring of the rocprofv3 kernel name (profiles/*.csv)
+ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2>", "k_dec_spec": "k_dec_dense<0>", "k_dec_relax0": "k_dec_dense<1>", "k_dec_relax1_4": "k_dec_relax_list",
+                "k_resample+k_plane_fdct": "k_resample_plane", "unstuff": "k_unstuff_copy", "k_emit": "k_emit_data"}
+
+
+def pmc_traffic(kernel, batch):
+    """HBM bytes of ONE launch of `kernel` from the committed PMC passes (profiles/r01_pmc_{FETCH,WRITE}_SIZE_batch512.csv:
+    separate rocprofv3 --pmc runs of this same command at --batch 512 --steps 1; raw counter unit KiB; FETCH_SIZE doubled
+    per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is -- it reads exactly 2*coef bytes on the pool memset).
+    None when the batch differs from the profiled one or the files are absent."""
+    import csv
+    if batch != 512:
+        return None
+    key = ROCPROF_NAME.get(kernel, kernel)
+    tot = 0.0
+    for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(ROOT, "profiles", f"r01_pmc_{counter}_batch512.csv")
+        if not os.path.exists(path):
+            return None
+        hit = [r for r in csv.reader(open(path)) if len(r) == 3 and key in r[0]]
+        if not hit:
+            return None
+        tot += sum(float(r[2]) / max(1, int(r[1])) for r in hit) * 1024.0 * scale
+    return int(tot)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,7 +134,7 @@ def main():
         kms = [sum(tm.kernel_ms[i] for tm in timings) / len(timings) for i in range(len(names))]
         dom = max(range(len(names)), key=lambda i: kms[i])
         ab = algorithmic_bytes(names[dom], t, args.batch)
-        roof = {"bound": "hbm", "kernel": names[dom], "avg_ms": round(kms[dom], 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        roof = {"bound": "hbm", "kernel": names[dom], "avg_ms": round(kms[dom], 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": pmc_traffic(names[dom], args.batch)}
         if ab is not None:
             ach = ab / (kms[dom] * 1e-3) / 1e9
             roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(ab)})
