@@ -938,23 +938,3 @@ extern "C" int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int wh
         for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + (blk & 63) * CSH_BLK_STRIDE + coef_off(k)];
     return 0;
 }
-
-// debug tap (tests / bring-up only): raw copies of internal device buffers
-extern "C" long csh_batch_debug_read(csh_batch *b, int which, void *dst, size_t max_bytes) {
-    const void *src = nullptr; size_t n = 0;
-    switch (which) {
-    case 0: src = b->d_clean.p; n = b->d_clean.n; break;
-    case 1: src = b->d_pstate.p; n = b->d_pstate.n * 8; break;
-    case 2: src = b->d_nblk.p; n = b->d_nblk.n * 4; break;
-    case 3: src = b->d_blk_off.p; n = b->d_blk_off.n * 8; break;
-    case 4: src = b->d_pscans.p; n = b->d_pscans.n * sizeof(ParScan); break;
-    case 5: src = b->d_unstuff_off.p; n = b->d_unstuff_off.n * 8; break;
-    case 6: src = b->d_bits.p; n = b->d_bits.n; break;
-    case 7: src = b->d_need_seq.p; n = b->d_need_seq.n * 4; break;
-    case 8: src = b->d_relax_cnt.p; n = b->d_relax_cnt.n * 4; break;
-    default: return -1;
-    }
-    if (n > max_bytes) n = max_bytes;
-    if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return long(n);
-}
