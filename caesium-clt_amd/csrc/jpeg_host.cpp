@@ -150,11 +150,13 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
             size_t b = i + 2 + L, e = b;
             while (e + 1 < n) {
                 if (d[e] == 0xFF && d[e + 1] != 0x00 && d[e + 1] != 0xFF && !(d[e + 1] >= 0xD0 && d[e + 1] <= 0xD7)) break;
+                if (d[e] == 0xFF && d[e + 1] != 0x00) sc.has_marker = true;
                 e++;
             }
             if (e + 1 >= n) e = n;
             sc.data_off = b;
             sc.data_len = e - b;
+            if (e > b && d[e - 1] == 0xFF) sc.has_marker = true;   // a dangling 0xFF at the end of the data
             j.scans.push_back(sc);
             i = e;
             continue;

@@ -24,6 +24,7 @@ struct JScan {
     int comp_idx[4] = {0}, td[4] = {0}, ta[4] = {0};
     int Ss = 0, Se = 63, Ah = 0, Al = 0;
     size_t data_off = 0, data_len = 0;  // entropy-coded segment inside the file
+    bool has_marker = false;            // an 0xFF followed by anything but 0x00 lies inside the segment (RSTn, or garbage)
     HuffSpec dc[4], ac[4];              // tables in force at SOS
 };
 

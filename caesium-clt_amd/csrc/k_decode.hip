@@ -138,7 +138,7 @@ __global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *
                              const uint32_t *need_seq) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nimg) return;
-    if (need_seq[i] == 0) return;  // the parallel decoder handled this image
+    if (need_seq[i] == 0 || need_seq[i] == 4) return;  // the parallel decoder / the progressive wave decoder handled this image
     const ImgDesc &im = imgs[i];
     if (need_seq[i] >= 2)          // the parallel decoder gave up half-way (2: labels unresolved, 3: scan ended short): start from clean tiles
         for (int c = 0; c < im.ncomp; c++) {

@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) k_dec_mark_pending(const ParScan *pss, co
 }
 __global__ void k_dec_chain(const ParScan *pss, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq) {
     int si = blockIdx.x * blockDim.x + threadIdx.x;
-    if (si >= nps || !scan_pending[si]) return;
+    if (si >= nps || !scan_pending[si] || pss[si].kind) return;
     const ParScan &ps = pss[si];
     uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     size_t base = ps.sub_base + ps.par_index;
@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     CSH_SHARED ParHuffSet lhs;
     CSH_SHARED ParBlockInfo lbi[10];   // write pass: where block m of an MCU goes
     const ParScan &ps = a.pss[blockIdx.y];
+    if (ps.kind) return;   // progressive scan: listed for the unstuffing pass only (uniform for the workgroup, before any barrier)
     const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     const uint32_t t0 = blockIdx.x * 256, tid = threadIdx.x, t = t0 + tid;
     const bool wg_live = t0 < nsub && t0 * CSH_SUBSEQ_BYTES < ps.clean_len && !(MODE == 2 && a.need_seq[ps.image] == 1) &&
@@ -466,7 +467,7 @@ void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, Par
     if (nchunks) CSH_LAUNCH_PHASED(k_unstuff_copy, 2, dim3((nchunks + 255) / 256), dim3(256), st, raw, clean, ps, nps, nchunks, off);
 }
 void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const DenseArgs &a) {
-    if (!nps) return;
+    if (!nps || !max_sub) return;   // max_sub == 0: only progressive scans are listed (a zero-sized grid is a launch error)
     dim3 grid((max_sub + 255) / 256, nps);
     if (mode == 0) CSH_LAUNCH_PHASED(k_dec_dense<0>, 2, grid, dim3(256), st, a);
     else if (mode == 1) CSH_LAUNCH_PHASED(k_dec_dense<1>, 2, grid, dim3(256), st, a);
@@ -499,7 +500,7 @@ void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *stat
 }
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq) {
-    if (nps) CSH_LAUNCH(k_dc_scatter, dim3((max_blocks + 255) / 256, nps), dim3(256), st, ps, imgs, dc_off, coef, need_seq);
+    if (nps && max_blocks) CSH_LAUNCH(k_dc_scatter, dim3((max_blocks + 255) / 256, nps), dim3(256), st, ps, imgs, dc_off, coef, need_seq);
 }
 
 }  // namespace csh

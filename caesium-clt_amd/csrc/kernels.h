@@ -27,6 +27,9 @@ struct DenseArgs {
 void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const ParHuffSet *huffs, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate);
+// progressive inputs: one wave per chain of scans (k_decode_prog.hip); images with need_seq == 4
+void launch_decode_prog(hipStream_t st, const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,
+                        const int *chain_scans, int nchains, const ImgDesc *imgs, int16_t *coef, uint32_t *need_seq);
 void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending);
 void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq);
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,

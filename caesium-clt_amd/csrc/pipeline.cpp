@@ -100,6 +100,8 @@ struct csh_batch {
     uint32_t max_src_px = 0;
     std::vector<ParScan> pscans;
     std::vector<uint32_t> need_seq_init;
+    std::vector<ProgChain> chains;        // progressive inputs (k_decode_prog.hip)
+    std::vector<int> chain_scans;
     uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
@@ -120,6 +122,8 @@ struct csh_batch {
     DevBuf<int32_t> d_dcdiff;
     DevBuf<ImgDesc> d_imgs;
     DevBuf<DecScan> d_dscans;
+    DevBuf<ProgChain> d_chains;
+    DevBuf<int> d_chain_scans;
     DevBuf<DevHuffSet> d_hsets;
     DevBuf<ParHuffSet> d_phsets;
     DevBuf<DevQuant> d_quants;
@@ -434,6 +438,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             for (int k = 0; k < js.ncomp; k++) { ds.comp[k] = js.comp_idx[k]; ds.td[k] = js.td[k]; ds.ta[k] = js.ta[k]; }
             ds.Ss = js.Ss; ds.Se = js.Se; ds.Ah = js.Ah; ds.Al = js.Al;
             ds.restart_interval = in.restart_interval;
+            ds.par_index = -1;
             // Huffman set, de-duplicated by content
             std::vector<uint8_t> key;
             for (int t = 0; t < 4; t++)
@@ -504,7 +509,35 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 b->pscans.push_back(ps);
             }
         }
-        b->need_seq_init.push_back(par_ok ? 0u : 1u);
+        // progressive scans without restart markers: one wave per chain (k_decode_prog.hip); the scans are listed as ParScans
+        // of kind 1 so that the unstuffing pre-pass covers them
+        bool prog_ok = in.progressive && in.restart_interval == 0;
+        for (size_t s = 0; s < in.scans.size(); s++) {
+            const JScan &js = in.scans[s];
+            if (js.has_marker || js.data_len >= (1u << 28) || !b->phset_fits[b->dscans[im.first_scan + s].huff_set]) prog_ok = false;
+        }
+        if (prog_ok) {
+            for (size_t s = 0; s < in.scans.size(); s++) {
+                DecScan &ds = b->dscans[im.first_scan + s];
+                ParScan ps;
+                memset(&ps, 0, sizeof ps);
+                ps.kind = 1;
+                ps.bits_off = ds.bits_off; ps.bits_len = ds.bits_len; ps.huff_set = ds.huff_set; ps.image = img_index; ps.ncomp = ds.ncomp; ps.nb_mcu = 1;
+                ps.sub_base = b->total_sub; ps.par_index = uint32_t(b->pscans.size());
+                ds.par_index = int(b->pscans.size());
+                b->pscans.push_back(ps);
+            }
+            for (int chain = 0; chain <= in.ncomp; chain++) {   // 0: DC scans; c + 1: AC scans of component c
+                ProgChain pc; pc.image = img_index; pc.first = int(b->chain_scans.size()); pc.count = 0;
+                for (size_t s = 0; s < in.scans.size(); s++) {
+                    const JScan &js = in.scans[s];
+                    bool mine = chain == 0 ? js.Ss == 0 : (js.Ss != 0 && js.comp_idx[0] == chain - 1);
+                    if (mine) { b->chain_scans.push_back(im.first_scan + int(s)); pc.count++; }
+                }
+                if (pc.count) b->chains.push_back(pc);
+            }
+        }
+        b->need_seq_init.push_back(par_ok ? 0u : (prog_ok ? 4u : 1u));
 
         // pixel work + planes
         if (!b->lossless)
@@ -614,7 +647,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     // upload what never changes between runs
     hipStream_t st = b->stream;
     if (b->nimg) {
-        if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) ||
+        if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
@@ -719,6 +752,8 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         launch_dc_scatter(st, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_dc_off.p, b->d_coef.p, b->d_need_seq.p);
         MARK();
     }
+    launch_decode_prog(st, b->d_clean.p, b->d_pscans.p, b->d_phsets.p, b->d_dscans.p, b->d_chains.p, b->d_chain_scans.p, int(b->chains.size()), b->d_imgs.p,
+                       b->d_coef.p, b->d_need_seq.p);
     launch_decode_seq(st, b->d_bits.p, b->d_imgs.p, b->d_dscans.p, b->d_hsets.p, b->d_coef.p, nimg, b->d_need_seq.p);
     MARK();
     // ---- phase 1: pixel-domain transcode
@@ -872,7 +907,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
     if (t) {
         std::vector<uint32_t> ns(b->nimg);
         if (hipMemcpy(ns.data(), b->d_need_seq.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
-        for (uint32_t v : ns) { if (v) t->n_seq_decoded++; if (v >= 2) t->n_par_fallback++; if (v == 3) t->n_par_short++; }
+        for (uint32_t v : ns) { if (v == 4) { t->n_prog_decoded++; continue; } if (v) t->n_seq_decoded++; if (v == 2 || v == 3) t->n_par_fallback++; if (v == 3) t->n_par_short++; }
         t->n_images = uint32_t(b->nimg);
         for (const Item &it : b->items) if (it.image < 0) t->n_failed++;
         for (int i = 0; i < b->nimg; i++) { t->out_bytes += b->h_img_size[i]; t->pixels += uint64_t(b->imgs[i].width) * b->imgs[i].height; }

@@ -58,7 +58,7 @@ struct DevHuffSet { DevHuff dc[4], ac[4]; };
 // eight tables share one pool; a set that does not fit (possible only with pathological tables) sends its images to the
 // sequential decoder.
 #define CSH_PAR_SUB 2048
-struct ParHuffSet {
+struct alignas(16) ParHuffSet {
     uint16_t root[8][512];   // 0..3 DC tables, 4..7 AC tables
     uint16_t sub[CSH_PAR_SUB];
 };
@@ -74,7 +74,12 @@ struct DecScan {
     int comp[CSH_MAX_COMPS], td[CSH_MAX_COMPS], ta[CSH_MAX_COMPS];
     int Ss, Se, Ah, Al;
     int restart_interval;
+    int par_index;                // index of this scan's ParScan (unstuffed copy of the segment), -1 if none
 };
+
+// progressive input: a chain = the scans of one image that must run in file order because they touch the same
+// coefficients -- all DC scans, or all AC scans of one component.  Chains of an image are independent of each other.
+struct ProgChain { int image, first, count; };   // chain_scans[first .. first+count) = DecScan indices
 
 struct ImgDesc {
     int width, height, ncomp;
@@ -111,6 +116,7 @@ struct ParScan {
     uint32_t par_index;           // index among ParScans (state arrays hold nsub+1 entries per scan)
     uint32_t dc_base[10], dc_per_mcu[10], dc_idx[10];  // where block m's DC difference goes (scan order, per component)
     uint64_t sel;                 // table selectors, 6 bits per block-in-MCU index m: dct[m] | (4 + act[m]) << 3
+    int kind;                     // 0: sequential-mode scan for the self-synchronising decoder; 1: progressive scan, listed only to be unstuffed
 };
 
 // quantisation table as the kernels want it: zig-zag order, with exact-division helpers

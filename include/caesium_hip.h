@@ -121,6 +121,7 @@ typedef struct {
                                      parallel-decoder fallbacks */
     uint32_t n_par_fallback;      /* of those, images the parallel decoder started and gave up on */
     uint32_t n_par_short;         /* of those, because the scan produced fewer blocks than the frame needs (truncated data) */
+    uint32_t n_prog_decoded;      /* progressive inputs decoded by the wave-per-chain kernel (not counted in n_seq_decoded) */
 } csh_timing;
 
 int csh_device_count(void);

@@ -50,7 +50,7 @@ def test_emul_parallel_decoder_is_the_path_taken(api):
     blobs += [synth_jpeg(2, 104, 72, progressive=True), synth_jpeg(9, 160, 128, restart_rows=1)]
     b = api.batch(blobs, params())
     t = b.run()
-    assert t.n_images == 7 and t.n_seq_decoded == 2 and t.n_par_fallback == 0
+    assert t.n_images == 7 and t.n_seq_decoded == 1 and t.n_prog_decoded == 1 and t.n_par_fallback == 0   # DRI -> sequential kernel, progressive -> wave-per-chain kernel
     for src, out in zip(blobs, b.fetch()):
         assert out == oracle_lossy(src)
 
@@ -69,7 +69,7 @@ def test_emul_relaxation_is_order_independent(api):
         outs = b.fetch()
     finally:
         api.L.csh_emul_set_reverse(0)
-    assert t.n_par_fallback == 0 and t.n_seq_decoded == 1
+    assert t.n_par_fallback == 0 and t.n_seq_decoded == 0 and t.n_prog_decoded == 1
     for src, out in zip(blobs, outs):
         assert out == oracle_lossy(src)
 
