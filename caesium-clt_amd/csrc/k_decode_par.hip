@@ -166,10 +166,12 @@ struct ParCtx {
     int nb_mcu;
     uint32_t total_blocks;
     int mcus_x;            // MCUs per row (write pass)
+    uint32_t first_mcu;    // where in the scan this segment starts (restart intervals)
 };
 __device__ __forceinline__ static ParCtx make_ctx(const ParScan &ps, const ImgDesc *im) {
     ParCtx c; c.sel = ps.sel; c.nb_mcu = ps.nb_mcu; c.total_blocks = ps.total_blocks;
     c.mcus_x = im ? (ps.ncomp > 1 ? im->mcus_x : im->in[ps.comp_of[0]].real_bw) : 1;
+    c.first_mcu = ps.first_mcu;
     return c;
 }
 // per-m placement table of the write pass (LDS): a non-interleaved scan walks its component block by block (h = v = 1)
@@ -219,7 +221,7 @@ __device__ __forceinline__ static uint32_t decode_span(const uint32_t *row, uint
     int k = st.k, m = st.m;
     if (WRITE) {
         mcu = ordinal / uint32_t(cx.nb_mcu);
-        my = int(mcu) / cx.mcus_x; mx = int(mcu) - my * cx.mcus_x;
+        my = int(mcu + cx.first_mcu) / cx.mcus_x; mx = int(mcu + cx.first_mcu) - my * cx.mcus_x;   // mcu itself stays relative to the segment
         locate(m);
     }
     uint32_t dco, aco;   // byte offsets of the current DC / AC root tables
@@ -452,8 +454,9 @@ __global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const Im
     int m = int(j - mcu * uint32_t(ps.nb_mcu));
     const CompGeom &g = im.in[ps.comp_of[m]];
     int by, bx;
-    if (ps.ncomp > 1) { int my = int(mcu) / im.mcus_x, mx = int(mcu) - my * im.mcus_x; by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
-    else { by = int(mcu) / g.real_bw; bx = int(mcu) - by * g.real_bw; }
+    const int amcu = int(mcu + ps.first_mcu);   // position in the scan; `mcu` is relative to the segment (restart interval)
+    if (ps.ncomp > 1) { int my = amcu / im.mcus_x, mx = amcu - my * im.mcus_x; by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
+    else { by = amcu / g.real_bw; bx = amcu - by * g.real_bw; }
     uint32_t idx = ps.dc_base[m] + mcu * ps.dc_per_mcu[m] + ps.dc_idx[m];
     // inclusive prefix over this component's differences (two's-complement wrap-around is harmless)
     uint32_t v = uint32_t(dc_off[idx + 1] - dc_off[ps.dc_base[m]]);

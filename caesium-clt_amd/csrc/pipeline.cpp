@@ -473,40 +473,80 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         }
         if (it.code) { b->dscans.resize(im.first_scan); continue; }
 
-        // sequential-mode scans without restart markers go to the parallel self-synchronising decoder
-        bool par_ok = !in.progressive && in.restart_interval == 0;
+        // sequential-mode scans go to the parallel self-synchronising decoder: a scan without restart markers as one
+        // ParScan, a scan with them as one ParScan per restart interval (each interval is an independent stream whose DC
+        // prediction starts at zero -- exactly what a ParScan is); the intervals are copied into the pool once more, each
+        // 64-byte aligned, because the unstuffing pass works on aligned segments
+        bool par_ok = !in.progressive;
         for (size_t s = 0; s < in.scans.size(); s++) if (!b->phset_fits[b->dscans[im.first_scan + s].huff_set]) par_ok = false;
         for (const JScan &js : in.scans) if (js.data_len >= (1u << 28)) par_ok = false;
         if (uint64_t(in.mcus_x) * uint64_t(in.mcus_y) * 10 >= (1u << 24)) par_ok = false;   // k_decode_par.hip uses 24-bit multiplies on block counts
+        struct Piece { size_t off, len; uint32_t first_mcu, nmcus; };
+        std::vector<std::vector<Piece>> pieces(in.scans.size());
+        for (size_t s = 0; s < in.scans.size() && par_ok; s++) {
+            const JScan &js = in.scans[s];
+            const uint32_t units = js.ncomp > 1 ? uint32_t(in.mcus_x * in.mcus_y)
+                                                : uint32_t(in.comp[js.comp_idx[0]].real_bw * in.comp[js.comp_idx[0]].real_bh);
+            if (in.restart_interval == 0) {
+                if (js.has_marker) par_ok = false;   // marker bytes inside the data: leave it to the sequential kernel's libjpeg-like handling
+                else pieces[s].push_back({js.data_off, js.data_len, 0u, units});
+                continue;
+            }
+            // restart intervals: RSTm markers must come in order, one after every `restart_interval` MCUs, none missing
+            const uint32_t ri = uint32_t(in.restart_interval), want = (units + ri - 1) / ri;
+            size_t pos = js.data_off, end = js.data_off + js.data_len, start = pos;
+            uint32_t idx = 0;
+            bool ok = true;
+            while (pos + 1 < end) {
+                if (d[pos] == 0xFF && d[pos + 1] != 0x00) {
+                    if (d[pos + 1] != 0xD0 + (idx & 7)) { ok = false; break; }
+                    pieces[s].push_back({start, pos - start, idx * ri, std::min(ri, units - idx * ri)});
+                    idx++;
+                    if (idx >= want) { ok = false; break; }
+                    pos += 2; start = pos;
+                } else pos++;
+            }
+            if (ok && end > start && d[end - 1] == 0xFF) ok = false;
+            if (ok) pieces[s].push_back({start, end - start, idx * ri, std::min(ri, units - idx * ri)});
+            if (!ok || pieces[s].size() != want) par_ok = false;
+        }
         if (par_ok) {
             for (size_t s = 0; s < in.scans.size(); s++) {
                 const JScan &js = in.scans[s];
                 const DecScan &ds = b->dscans[im.first_scan + s];
-                ParScan ps;
-                memset(&ps, 0, sizeof ps);
-                ps.bits_off = ds.bits_off; ps.bits_len = ds.bits_len; ps.huff_set = ds.huff_set; ps.image = img_index; ps.ncomp = js.ncomp;
-                int m = 0;
-                for (int k = 0; k < js.ncomp; k++) {
-                    const JComp &jc = in.comp[js.comp_idx[k]];
-                    int nh = js.ncomp > 1 ? jc.h : 1, nv = js.ncomp > 1 ? jc.v : 1;
-                    uint32_t nblocks = js.ncomp > 1 ? uint32_t(in.mcus_x * in.mcus_y * nh * nv) : uint32_t(jc.real_bw * jc.real_bh);
-                    for (int y = 0; y < nv; y++)
-                        for (int x = 0; x < nh; x++, m++) {
-                            if (m >= 10) break;
-                            ps.comp_of[m] = js.comp_idx[k]; ps.by_of[m] = y; ps.bx_of[m] = x; ps.dct[m] = js.td[k]; ps.act[m] = js.ta[k];
-                            ps.dc_base[m] = b->dc_total; ps.dc_per_mcu[m] = uint32_t(nh * nv); ps.dc_idx[m] = uint32_t(y * nh + x);
-                            ps.sel |= uint64_t((js.td[k] & 3) | ((4 + (js.ta[k] & 3)) << 3)) << (6 * m);
-                        }
-                    b->dc_total += nblocks;
-                    ps.total_blocks += nblocks;
+                for (const Piece &pc : pieces[s]) {
+                    ParScan ps;
+                    memset(&ps, 0, sizeof ps);
+                    if (in.restart_interval == 0) { ps.bits_off = ds.bits_off; ps.bits_len = ds.bits_len; }
+                    else {
+                        ps.bits_off = uint32_t(b->bits_pool.size()); ps.bits_len = uint32_t(pc.len);
+                        b->bits_pool.insert(b->bits_pool.end(), d + pc.off, d + pc.off + pc.len);
+                        b->bits_pool.resize((b->bits_pool.size() + 63) & ~size_t(63));
+                    }
+                    ps.huff_set = ds.huff_set; ps.image = img_index; ps.ncomp = js.ncomp; ps.first_mcu = pc.first_mcu;
+                    int m = 0;
+                    for (int k = 0; k < js.ncomp; k++) {
+                        const JComp &jc = in.comp[js.comp_idx[k]];
+                        int nh = js.ncomp > 1 ? jc.h : 1, nv = js.ncomp > 1 ? jc.v : 1;
+                        uint32_t nblocks = pc.nmcus * uint32_t(nh * nv);
+                        for (int y = 0; y < nv; y++)
+                            for (int x = 0; x < nh; x++, m++) {
+                                if (m >= 10) break;
+                                ps.comp_of[m] = js.comp_idx[k]; ps.by_of[m] = y; ps.bx_of[m] = x; ps.dct[m] = js.td[k]; ps.act[m] = js.ta[k];
+                                ps.dc_base[m] = b->dc_total; ps.dc_per_mcu[m] = uint32_t(nh * nv); ps.dc_idx[m] = uint32_t(y * nh + x);
+                                ps.sel |= uint64_t((js.td[k] & 3) | ((4 + (js.ta[k] & 3)) << 3)) << (6 * m);
+                            }
+                        b->dc_total += nblocks;
+                        ps.total_blocks += nblocks;
+                    }
+                    ps.nb_mcu = m;
+                    uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
+                    ps.sub_base = b->total_sub; ps.par_index = uint32_t(b->pscans.size());
+                    b->total_sub += nsub;
+                    b->max_sub = std::max(b->max_sub, nsub);
+                    b->max_par_blocks = std::max(b->max_par_blocks, ps.total_blocks);
+                    b->pscans.push_back(ps);
                 }
-                ps.nb_mcu = m;
-                uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
-                ps.sub_base = b->total_sub; ps.par_index = uint32_t(b->pscans.size());
-                b->total_sub += nsub;
-                b->max_sub = std::max(b->max_sub, nsub);
-                b->max_par_blocks = std::max(b->max_par_blocks, ps.total_blocks);
-                b->pscans.push_back(ps);
             }
         }
         // progressive scans without restart markers: one wave per chain (k_decode_prog.hip); the scans are listed as ParScans

@@ -116,6 +116,7 @@ struct ParScan {
     uint32_t par_index;           // index among ParScans (state arrays hold nsub+1 entries per scan)
     uint32_t dc_base[10], dc_per_mcu[10], dc_idx[10];  // where block m's DC difference goes (scan order, per component)
     uint64_t sel;                 // table selectors, 6 bits per block-in-MCU index m: dct[m] | (4 + act[m]) << 3
+    uint32_t first_mcu;           // restart interval: MCU (or block, non-interleaved) of the scan this segment starts at
     int kind;                     // 0: sequential-mode scan for the self-synchronising decoder; 1: progressive scan, listed only to be unstuffed
 };
 

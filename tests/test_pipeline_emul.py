@@ -50,9 +50,39 @@ def test_emul_parallel_decoder_is_the_path_taken(api):
     blobs += [synth_jpeg(2, 104, 72, progressive=True), synth_jpeg(9, 160, 128, restart_rows=1)]
     b = api.batch(blobs, params())
     t = b.run()
-    assert t.n_images == 7 and t.n_seq_decoded == 1 and t.n_prog_decoded == 1 and t.n_par_fallback == 0   # DRI -> sequential kernel, progressive -> wave-per-chain kernel
+    assert t.n_images == 7 and t.n_seq_decoded == 0 and t.n_prog_decoded == 1 and t.n_par_fallback == 0   # restart intervals -> parallel decoder too, progressive -> wave-per-chain kernel
     for src, out in zip(blobs, b.fetch()):
         assert out == oracle_lossy(src)
+
+
+def restart_cases():
+    """restart-interval sources: intervals of rows and of odd block counts, every layout, grayscale, more than 8 intervals
+    (the RSTm index wraps), and two broken ones (a marker out of order, a marker missing)"""
+    from PIL import Image
+    out = []
+    for i, (w, h, ss, kw) in enumerate([(160, 128, 2, {"restart_marker_rows": 1}), (200, 168, 2, {"restart_marker_blocks": 7}), (99, 73, 0, {"restart_marker_blocks": 3}),
+                                         (104, 72, 1, {"restart_marker_rows": 2}), (333, 222, 2, {"restart_marker_blocks": 1}), (64, 64, 2, {"restart_marker_blocks": 1000})]):
+        b = io.BytesIO(); Image.fromarray(synth_rgb(20 + i, w, h, 25)).save(b, format="JPEG", quality=88, subsampling=ss, **kw)
+        out.append(b.getvalue())
+    g = Image.fromarray(synth_rgb(7, 203, 155, 20)).convert("L")
+    b = io.BytesIO(); g.save(b, format="JPEG", quality=90, restart_marker_blocks=5); out.append(b.getvalue())
+    good = out[1]
+    i0 = good.index(b"\xff\xd1")
+    out.append(good[:i0] + b"\xff\xd3" + good[i0 + 2:])            # RST1 replaced by RST3
+    i1 = good.index(b"\xff\xd2")
+    out.append(good[:i1] + good[i1 + 2:])                            # RST2 missing
+    return out
+
+
+def test_emul_restart_intervals_decode_in_parallel(api):
+    blobs = restart_cases()
+    b = api.batch(blobs, params())
+    t = b.run()
+    assert t.n_seq_decoded == 2 and t.n_par_fallback == 0      # only the two broken files leave the parallel decoder
+    for i, (src, out) in enumerate(zip(blobs, b.fetch())):
+        assert out == oracle_lossy(src), i
+    for src, out in zip(blobs[:4], api.batch_compress(blobs[:4], params(jpeg_optimize=True))):
+        assert out == oracle_lossless(src)
 
 
 def test_emul_relaxation_is_order_independent(api):

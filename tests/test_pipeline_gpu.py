@@ -92,6 +92,10 @@ def test_lossless_transcode(api):
             assert np.array_equal(a.coefs(c), b.coefs(c))
 
 
+def test_restart_intervals_decode_in_parallel(api):
+    E.test_emul_restart_intervals_decode_in_parallel(api)
+
+
 def test_correction_bit_overflow_flush(api):
     from test_pipeline_emul import crafted_corrbit_stream
     blob = crafted_corrbit_stream()
