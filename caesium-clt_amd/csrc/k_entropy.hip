@@ -84,10 +84,10 @@ __device__ __forceinline__ static AcMasks ac_masks(const uint64_t *masks, const 
 // ---- pass A: per-block flags of every AC scan.  Lane = block, so a wave's 64 has-symbol / ends-with-EOB flags ARE one
 // word of the scan's bit vectors: one ballot, one 8-byte store, no atomics.
 __global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
-    const ScanWork w = c.work[blockIdx.y];
+    const ScanWork w = c.work[c.chunk_work[blockIdx.x]];
     const EncScan &sc = c.script[w.scan];
     if (sc.Ss == 0) return;
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
     bool has_sym = false, ends_eob = false;
     if (u < w.nunits) {
         const CompGeom &g = c.imgs[w.image].out[sc.comp[0]];
@@ -110,10 +110,10 @@ __global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
 
 // ---- pass B: EOB run structure -> EOBRUN value owned by the first block of each (sub-)run
 __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
-    const ScanWork w = c.work[blockIdx.y];
+    const ScanWork w = c.work[c.chunk_work[blockIdx.x]];
     const EncScan &sc = c.script[w.scan];
     if (sc.Ss == 0) return;
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
     if (u >= w.nunits) return;
     const uint64_t *sym = c.sym_bits + w.word_base, *eob = c.eob_bits + w.word_base;
     if (!get_bit(eob, u)) return;
@@ -598,9 +598,9 @@ void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
 
 // ---- pass E: size in bits of every unit's output
 __global__ void __launch_bounds__(256) k_sizes(EncCtx c) {
-    const ScanWork w = c.work[blockIdx.y];
+    const ScanWork w = c.work[c.chunk_work[blockIdx.x]];
     const EncScan &sc = c.script[w.scan];
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
     if (u >= w.nunits) return;
     SizeSink s; s.tab = c.tables + w.table_base; s.bits = 0;
     walk_unit(s, c, w, sc, u);
@@ -609,12 +609,11 @@ __global__ void __launch_bounds__(256) k_sizes(EncCtx c) {
 
 // ---- pass G: pack.  raw_off (bytes, multiple of 64) per scan comes from k_scan_layout.
 __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
-    const ScanWork w = c.work[blockIdx.y];
+    const ScanWork w = c.work[c.chunk_work[blockIdx.x]];
     const EncScan &sc = c.script[w.scan];
     CSH_SHARED uint32_t ltab[4 * 256];
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
     CSH_PHASE_LOOP(2) {
-        if (blockIdx.x * blockDim.x >= w.nunits) continue;   // whole workgroup idle (uniform)
         if (phase == 0) { stage_enc_tables(ltab, c.tables + w.table_base, sc.ntables); continue; }
         if (u >= w.nunits) continue;
         uint64_t base = c.unit_off[w.unit_base];
@@ -632,13 +631,13 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     }
 }
 
-static dim3 unit_grid(const EncCtx &c) { return dim3((c.max_units + 255) / 256, c.nwork); }
-void launch_ac_flags(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_ac_flags, unit_grid(c), dim3(256), st, c); }
-void launch_ac_runs(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c); }
+static dim3 unit_grid(const EncCtx &c) { return dim3(c.nchunks); }   // flat: one workgroup per 256-unit chunk that exists
+void launch_ac_flags(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_ac_flags, unit_grid(c), dim3(256), st, c); }
+void launch_ac_runs(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c); }
 void launch_stats(hipStream_t st, const EncCtx &c) {
     if (c.nwork) CSH_LAUNCH_PHASED(k_stats, 3, dim3((c.max_units + CSH_STATS_CHUNK - 1) / CSH_STATS_CHUNK, c.nwork), dim3(256), st, c);
 }
-void launch_sizes(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH(k_sizes, unit_grid(c), dim3(256), st, c); }
-void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nwork) CSH_LAUNCH_PHASED(k_pack, 2, unit_grid(c), dim3(256), st, c); }
+void launch_sizes(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_sizes, unit_grid(c), dim3(256), st, c); }
+void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH_PHASED(k_pack, 2, unit_grid(c), dim3(256), st, c); }
 
 }  // namespace csh

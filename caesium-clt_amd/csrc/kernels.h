@@ -63,6 +63,8 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     const ScanWork *work;      // [nwork]
     int nwork;
     uint32_t max_units;        // max nunits over work items
+    const uint32_t *chunk_work; // per 256-unit chunk: its work item (a flat grid: no workgroup is launched for nothing)
+    uint32_t nchunks;
     const int16_t *coef;       // re-quantised coefficients (tiles)
     const uint64_t *masks;     // [tile][CSH_MASK_PLANES][64]
     uint64_t *sym_bits;        // per AC scan: bit b set iff block b emits >=1 Huffman symbol in this scan

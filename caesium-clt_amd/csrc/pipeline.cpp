@@ -105,6 +105,7 @@ struct csh_batch {
     uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
+    std::vector<uint32_t> chunk_work;
     std::vector<uint8_t> bits_pool, hdr_pool;
     std::vector<uint32_t> hdr_off;
     uint32_t ntiles = 0, ntiles_in = 0, ntiles_out = 0, max_tiles = 0, max_units = 0, max_dummy = 0;
@@ -134,6 +135,7 @@ struct csh_batch {
     DevBuf<uint8_t> d_rgb;
     DevBuf<EncScan> d_script;
     DevBuf<ScanWork> d_swork;
+    DevBuf<uint32_t> d_chunk_work;
     DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
     DevBuf<uint16_t> d_eobrun;
@@ -648,6 +650,8 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             w.table_base = uint32_t(b->ntables);
             b->ntables += e.ntables;
             b->max_units = std::max(b->max_units, w.nunits);
+            w.first_chunk = uint32_t(b->chunk_work.size());
+            b->chunk_work.insert(b->chunk_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
             b->swork.push_back(w);
         }
         if (b->total_units > 0xFFFFFFF0ull) { it.code = CS_ERR_POOL_OVERFLOW; it.msg = "batch too large"; }
@@ -689,7 +693,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     if (b->nimg) {
         if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
-            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_hdr.upload(b->hdr_pool, st) ||
+            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_chunk_work.upload(b->chunk_work, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
             b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
@@ -814,7 +818,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     // ---- phase 2: masks, flags, EOB runs
     EncCtx c;
     memset(&c, 0, sizeof c);
-    c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size()); c.max_units = b->max_units;
+    c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size()); c.max_units = b->max_units; c.chunk_work = b->d_chunk_work.p; c.nchunks = uint32_t(b->chunk_work.size());
     c.coef = b->d_coef.p; c.masks = b->d_masks.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
     c.eobrun = b->d_eobrun.p; c.unit_bits = b->d_unit_bits.p; c.unit_off = b->d_unit_off.p; c.tables = b->d_tables.p;
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p;

@@ -160,6 +160,7 @@ struct ScanWork {
     int image, scan;
     uint32_t nunits;       // lanes of work: blocks (AC, non-interleaved) or MCUs (interleaved DC)
     uint32_t unit_base;    // offset of this scan in the flat per-unit arrays
+    uint32_t first_chunk;  // first 256-unit chunk of this scan in the flat chunk list (EncCtx::chunk_work)
     uint32_t word_base;    // offset in the u64 bitmask arrays (AC scans), nwords = ceil(nunits/64)
     uint32_t table_base;   // first of this scan's Huffman tables in the table pool
     uint64_t raw_off;      // byte offset (multiple of 64) of the scan's unstuffed bytes in the raw pool (device-computed)
