@@ -48,6 +48,7 @@ __global__ void k_scan_place(AsmCtx a) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.nwork) return;
     a.work[j].raw_off = a.scan_raw_off[j];
+    a.work[j].no_room = a.scan_raw_off[j + 1] > a.raw_chunks * 64 ? 1u : 0u;
     if (j == a.nwork - 1 && a.scan_raw_off[a.nwork] > a.raw_chunks * 64) *a.overflow = 1;
 }
 

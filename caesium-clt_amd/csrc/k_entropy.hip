@@ -616,10 +616,10 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     CSH_PHASE_LOOP(2) {
         if (phase == 0) { stage_enc_tables(ltab, c.tables + w.table_base, sc.ntables); continue; }
         if (u >= w.nunits) continue;
+        if (w.no_room) { c.status[w.image] = 20200; continue; }   // decided per scan by k_scan_place: no data-dependent branch in front of the loads
         uint64_t base = c.unit_off[w.unit_base];
         uint64_t total = c.unit_off[w.unit_base + w.nunits] - base;
         uint64_t raw_bit0 = w.raw_off * 8;
-        if (raw_bit0 + total + 64 > c.raw_words * 32) { c.status[w.image] = 20200; continue; }
         PackSink s; s.tab = ltab; s.raw_words = c.raw;
         s.begin(raw_bit0 + (c.unit_off[w.unit_base + u] - base));
         walk_unit(s, c, w, sc, u);

@@ -167,6 +167,7 @@ struct ScanWork {
     uint32_t raw_bytes;    // unstuffed length in bytes (device-computed)
     uint32_t out_off;      // offset of this scan's DHT marker inside the image's output file (device-computed)
     uint32_t hdr_bytes;    // DHT + SOS bytes in front of the entropy-coded data (device-computed)
+    uint32_t no_room;      // the raw pool cannot hold this scan (device-computed): the packer skips it, the batch is re-run with a larger pool
 };
 
 // encoder-side Huffman table as generated on the device
