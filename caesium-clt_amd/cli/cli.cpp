@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -439,7 +440,7 @@ struct Job {
     std::vector<uint8_t> data;
     CCSParameters params{};
     bool engine = false;  // reached the engine stage
-    std::vector<uint8_t> result;
+    CByteArray result{nullptr, 0};   // owned: the engine's output buffer, released after the write (no copy)
     bool ok = false;
     std::string engine_msg;
 };
@@ -500,9 +501,14 @@ int run(const Options &o) {
     const bool quiet = o.quiet || o.verbose == 0;
     const int verbose = quiet ? 0 : o.verbose;
     const size_t threads = parallelism_count(o.threads, std::max(1u, std::thread::hardware_concurrency()));
+    const bool trace = getenv("CSH_TRACE") != nullptr;   // wall-clock of the stages, on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_start = now();
     std::optional<fs::path> base;
     std::vector<fs::path> files;
     scan_files(o.files, o.recursive, o.check_extension_only, base, files);
+    const auto t_scan = now();
     if (!base) {
         const char *m = "Unable to compute the base path for the files.";
         if (o.json) printf("%s\n", build_json({}, o.dry_run, m).c_str()); else fprintf(stderr, "%s\n", m);
@@ -541,6 +547,7 @@ int run(const Options &o) {
         j.engine = true;
     });
 
+    const auto t_read = now();
     // ---- stage 2 (device): the engine calls of compressor.rs:287-306, batched.  Files that share a parameter set form one
     // batch per device; groups go round-robin over --gpus devices, one host thread per device.
     if (!o.dry_run) {
@@ -550,8 +557,12 @@ int run(const Options &o) {
         const size_t kBatch = 1024;
         for (auto &g : groups) for (size_t k = 0; k < g.second.size(); k += kBatch) batches.emplace_back(g.second.begin() + k, g.second.begin() + std::min(k + kBatch, g.second.size()));
         int ndev = std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
-        parallel_for(size_t(ndev), size_t(ndev), [&](size_t dev) {
-            for (size_t bi = dev; bi < batches.size(); bi += size_t(ndev)) {
+        // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being
+        // parsed and uploaded (separate streams; the boundary call is thread-safe)
+        const size_t nworkers = size_t(ndev) * 2;
+        parallel_for(nworkers, nworkers, [&](size_t worker) {
+            const size_t dev = worker % size_t(ndev);
+            for (size_t bi = worker; bi < batches.size(); bi += nworkers) {
                 const std::vector<size_t> &idx = batches[bi];
                 std::vector<CByteArray> in(idx.size()), out(idx.size());
                 std::vector<CCSResult> res(idx.size());
@@ -578,21 +589,26 @@ int run(const Options &o) {
                 for (size_t k = 0; k < idx.size(); k++) {
                     Job &j = jobs[idx[k]];
                     j.ok = res[k].success;
-                    if (j.ok) j.result.assign(out[k].data, out[k].data + out[k].length);
-                    else if (!silent[k]) j.engine_msg = std::string("Error compressing file: ") + (res[k].error_message ? res[k].error_message : "");
-                    cs_free_bytes(&out[k]); cs_free_result(&res[k]);
+                    if (j.ok) j.result = out[k];
+                    else {
+                        if (!silent[k]) j.engine_msg = std::string("Error compressing file: ") + (res[k].error_message ? res[k].error_message : "");
+                        cs_free_bytes(&out[k]);
+                    }
+                    cs_free_result(&res[k]);
                 }
             }
         });
     }
 
+    const auto t_engine = now();
     // ---- stage 3 (host, parallel): the rest of perform_compression
     parallel_for(files.size(), threads, [&](size_t i) {
         Job &j = jobs[i];
         Result &r = results[i];
         if (!j.engine) return;
         if (!j.ok) { r.message = j.engine_msg; return; }
-        const uint64_t orig = r.original_size, outsz = j.result.size();
+        const uint64_t orig = r.original_size, outsz = j.result.length;
+        struct Release { CByteArray *b; ~Release() { cs_free_bytes(b); } } release{&j.result};
         if (o.min_savings && orig != 0) {
             uint64_t saved = orig > outsz ? orig - outsz : 0;
             char b[160];
@@ -613,7 +629,7 @@ int run(const Options &o) {
         }
         FILE *f = fopen(j.output.c_str(), "wb");
         if (!f) { r.message = "Error creating output file"; return; }
-        bool wrote = fwrite(j.result.data(), 1, j.result.size(), f) == j.result.size();
+        bool wrote = fwrite(j.result.data, 1, j.result.length, f) == j.result.length;
         if (wrote && o.keep_dates) {
             fflush(f);
             struct timespec ts[2] = {j.st.st_atim, j.st.st_mtim};
@@ -625,6 +641,8 @@ int run(const Options &o) {
         r.compressed_size = outsz;
     });
 
+    if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms, engine %.0f ms, policy+write %.0f ms\n", files.size(), ms(t_start, t_scan),
+                       ms(t_scan, t_read), ms(t_read, t_engine), ms(t_engine, now()));
     if (o.json) printf("%s\n", build_json(results, o.dry_run, nullptr).c_str());
     else fputs(build_recap(results, verbose, isatty(1)).c_str(), stdout);
     return 0;

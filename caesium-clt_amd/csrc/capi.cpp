@@ -1,5 +1,6 @@
 // capi.cpp -- the libcaesium-shaped entry points on top of the device batch queue.
 // Reference semantics: /root/reference/src/compressor.rs:287-306 (call shapes), :411-446 (parameters).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -32,8 +33,12 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
     for (size_t g0 = 0; g0 < count; g0 += CS_GROUP) {
         size_t n = count - g0 < size_t(CS_GROUP) ? count - g0 : size_t(CS_GROUP);
         csh_batch *b = nullptr;
+        const bool trace = getenv("CSH_TRACE") != nullptr;   // host-side phase times of the boundary call, on stderr
+        auto t0 = std::chrono::steady_clock::now();
         int rc = csh_batch_create(inputs + g0, n, p, device, &b);
+        auto t1 = std::chrono::steady_clock::now();
         if (rc == 0) rc = csh_batch_run(b, nullptr);
+        auto t2 = std::chrono::steady_clock::now();
         if (rc != 0) {
             for (size_t i = 0; i < n; i++) if (results) results[g0 + i] = make_result(rc, csh_last_error());
             csh_batch_destroy(b);
@@ -41,7 +46,13 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
             continue;
         }
         int failed = csh_batch_fetch(b, outputs + g0, results ? results + g0 : nullptr);
+        auto t3 = std::chrono::steady_clock::now();
         csh_batch_destroy(b);
+        if (trace) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[csh] %zu files on device %d: create %.1f ms, run %.1f ms, fetch %.1f ms, destroy %.1f ms\n", n, device, ms(t0, t1), ms(t1, t2), ms(t2, t3),
+                    ms(t3, std::chrono::steady_clock::now()));
+        }
         failed_total += failed < 0 ? int(n) : failed;
     }
     return failed_total;

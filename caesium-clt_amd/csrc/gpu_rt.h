@@ -66,7 +66,7 @@ static inline void csh_emul_launch(F kern, dim3 grid, dim3 block, A... args) {
     }
 }
 #define CSH_LAUNCH(kern, grid, block, stream, ...) csh_emul_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
-#define CSH_SHARED static
+#define CSH_SHARED static thread_local   // one copy per host thread: the emulated kernels of concurrent batches must not share "LDS"
 extern thread_local int csh_emul_phase;
 #define CSH_PHASE_LOOP(NPH) for (int phase = csh_emul_phase, once_ = 1; once_; once_ = 0)
 template <class F, class... A>
@@ -94,6 +94,7 @@ enum { hipSuccess = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hip
 static inline const char *hipGetErrorString(hipError_t) { return "emul"; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 1; }
 static inline hipError_t hipFree(void *p) { free(p); return 0; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? 0 : 1; }

@@ -148,9 +148,12 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
             }
             for (int t = 0; t < 4; t++) { sc.dc[t] = dc[t]; sc.ac[t] = ac[t]; }
             size_t b = i + 2 + L, e = b;
-            while (e + 1 < n) {
-                if (d[e] == 0xFF && d[e + 1] != 0x00 && d[e + 1] != 0xFF && !(d[e + 1] >= 0xD0 && d[e + 1] <= 0xD7)) break;
-                if (d[e] == 0xFF && d[e + 1] != 0x00) sc.has_marker = true;
+            while (e + 1 < n) {   // hop from 0xFF to 0xFF (memchr), the data in between cannot end the scan
+                const void *f = memchr(d + e, 0xFF, n - 1 - e);
+                if (!f) { e = n; break; }
+                e = size_t(static_cast<const uint8_t *>(f) - d);
+                if (d[e + 1] != 0x00 && d[e + 1] != 0xFF && !(d[e + 1] >= 0xD0 && d[e + 1] <= 0xD7)) break;
+                if (d[e + 1] != 0x00) sc.has_marker = true;
                 e++;
             }
             if (e + 1 >= n) e = n;

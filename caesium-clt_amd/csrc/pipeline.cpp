@@ -5,10 +5,14 @@
 //   -> stuffing/assembly
 // on one stream with no host round trip (every size and offset is produced by device scans).
 // Host work is limited to container logic: marker parsing, table/script setup, descriptor building.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -36,17 +40,73 @@ extern "C" void csh_emul_set_jacobi(int j) { csh::csh_emul_jacobi = j; }
 
 namespace csh {
 
+// ---- memory caches.  A batch of the same shape follows almost every batch (the CLI feeds groups of 1024 files), and
+// hipMalloc / hipFree of ~20 GB of pools plus the pageable-memory copies cost ten times what the kernels do.  Freed device
+// blocks and pinned host blocks are therefore kept (per device / process-wide) and handed to the next batch that fits.
+struct BlockCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;   // capacity -> block
+    size_t cached = 0, limit;
+    bool pinned;
+    explicit BlockCache(size_t lim, bool pin) : limit(lim), pinned(pin) {}
+    static size_t round_up(size_t bytes) { size_t g = bytes < (1u << 20) ? 4096 : (2u << 20); return (bytes + g - 1) / g * g; }
+    void *get(size_t bytes, size_t &cap) {
+        bytes = round_up(bytes ? bytes : 1);
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto it = free_blocks.lower_bound(bytes);
+            if (it != free_blocks.end() && it->first <= 2 * bytes + (64u << 20)) {
+                void *q = it->second; cap = it->first; cached -= cap; free_blocks.erase(it);
+                return q;
+            }
+        }
+        void *q = nullptr;
+        hipError_t e = pinned ? hipHostMalloc(&q, bytes) : hipMalloc(&q, bytes);
+        if (e != hipSuccess) {   // out of memory: drop everything cached and try once more
+            trim(0);
+            e = pinned ? hipHostMalloc(&q, bytes) : hipMalloc(&q, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        cap = bytes;
+        return q;
+    }
+    void put(void *q, size_t cap) {
+        std::lock_guard<std::mutex> l(mu);
+        free_blocks.emplace(cap, q); cached += cap;
+        if (cached > limit) trim_locked(limit / 2);
+    }
+    void trim(size_t keep) { std::lock_guard<std::mutex> l(mu); trim_locked(keep); }
+    void trim_locked(size_t keep) {
+        while (cached > keep && !free_blocks.empty()) {
+            auto it = std::prev(free_blocks.end());
+            if (pinned) (void)hipHostFree(it->second); else (void)hipFree(it->second);
+            cached -= it->first; free_blocks.erase(it);
+        }
+    }
+};
+static BlockCache &device_cache(int dev) {
+    static BlockCache *caches[64] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> l(mu);
+    dev = dev < 0 ? 0 : dev & 63;
+    if (!caches[dev]) caches[dev] = new BlockCache(size_t(160) << 30, false);   // of the 288 GB of HBM
+    return *caches[dev];
+}
+static BlockCache &pinned_cache() { static BlockCache c(size_t(16) << 30, true); return c; }
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0, cap = 0;
+    int dev = 0;
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) device_cache(dev).put(p, cap); p = nullptr; n = 0; cap = 0; }
     int alloc(size_t count) {
         release();
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        void *q = device_cache(dev).get((count ? count : 1) * sizeof(T), cap);
+        if (!q) { csh_set_error("out of device memory"); return -1; }
         n = count;
-        void *q = nullptr;
-        CSH_CHECK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
         p = static_cast<T *>(q);
         return 0;
     }
@@ -56,6 +116,50 @@ struct DevBuf {
         return 0;
     }
     int zero(hipStream_t st) { if (n) CSH_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), st)); return 0; }
+};
+
+// growable byte pool in pinned host memory (the entropy-coded segments of a batch: uploaded by DMA straight from here)
+struct PinnedBytes {
+    uint8_t *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~PinnedBytes() { if (p) pinned_cache().put(p, cap); }
+    size_t size() const { return n; }
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        size_t ncap = 0;
+        void *q = pinned_cache().get(std::max(want, cap * 2), ncap);
+        if (!q) return false;
+        if (p) pinned_cache().put(p, cap);   // nothing to move: the data is copied in by flush_copies()
+        p = static_cast<uint8_t *>(q); cap = ncap;
+        return true;
+    }
+    // data, then zero padding to a multiple of 64.  The bytes are copied later, by flush_copies(): the pool of a batch is
+    // ~0.6 MB per file and one thread's memcpy would be most of the batch set-up time
+    struct Copy { size_t dst; const uint8_t *src; size_t len, pad; };
+    std::vector<Copy> pending;
+    bool append_aligned(const uint8_t *src, size_t len) {
+        size_t end = (n + len + 63) & ~size_t(63);
+        if (!reserve(end)) return false;
+        pending.push_back({n, src, len, end - n - len});
+        n = end;
+        return true;
+    }
+    void flush_copies() {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next++) < pending.size();) {
+                const Copy &c = pending[i];
+                memcpy(p + c.dst, c.src, c.len);
+                memset(p + c.dst + c.len, 0, c.pad);
+            }
+        };
+        size_t bytes = n, nthreads = std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), bytes / (8u << 20) + 1);
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+        pending.clear();
+    }
 };
 
 struct Item {
@@ -106,7 +210,8 @@ struct csh_batch {
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
     std::vector<uint32_t> chunk_work;
-    std::vector<uint8_t> bits_pool, hdr_pool;
+    PinnedBytes bits_pool;
+    std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
     uint32_t ntiles = 0, ntiles_in = 0, ntiles_out = 0, max_tiles = 0, max_units = 0, max_dummy = 0;
     uint64_t total_units = 0, total_words = 0, plane_bytes = 0, oplane_bytes = 0;
@@ -383,15 +488,32 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     std::map<std::vector<uint16_t>, int> quant_index;
     uint32_t plane_off = 0, oplane_off = 0;
 
+    {   // marker parsing is per file and touches every byte of it once (the hunt for the end of each scan): all cores
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t n; (n = next++) < count;) {
+                Item &it = b->items[n];
+                it.file_size = inputs[n].length;
+                int type = sniff_type(inputs[n].data, inputs[n].length);
+                if (type == CS_TYPE_UNKN) { it.code = CS_ERR_UNKNOWN_TYPE; it.msg = "unknown file type"; }
+                else if (type != CS_TYPE_JPEG) { it.code = CS_ERR_UNSUPPORTED; it.msg = "only JPEG has a device path in this build"; }
+                else it.code = parse_jpeg(inputs[n].data, inputs[n].length, it.in, it.msg);
+            }
+        };
+        size_t nthreads = std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), (count + 15) / 16);
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
+    {
+        size_t total = 0;
+        for (size_t n = 0; n < count; n++) total += inputs[n].length;
+        if (!b->bits_pool.reserve(total + total / 16 + (64u << 10))) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
+    }
     for (size_t n = 0; n < count; n++) {
         Item &it = b->items[n];
         const uint8_t *d = inputs[n].data;
-        size_t len = inputs[n].length;
-        it.file_size = len;
-        int type = sniff_type(d, len);
-        if (type == CS_TYPE_UNKN) { it.code = CS_ERR_UNKNOWN_TYPE; it.msg = "unknown file type"; continue; }
-        if (type != CS_TYPE_JPEG) { it.code = CS_ERR_UNSUPPORTED; it.msg = "only JPEG has a device path in this build"; continue; }
-        it.code = parse_jpeg(d, len, it.in, it.msg);
         if (it.code) continue;
         it.code = plan_item(it, *p, b->lossless);
         if (it.code) continue;
@@ -433,8 +555,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             memset(&ds, 0, sizeof ds);
             ds.bits_off = uint32_t(b->bits_pool.size());
             ds.bits_len = uint32_t(js.data_len);
-            b->bits_pool.insert(b->bits_pool.end(), d + js.data_off, d + js.data_off + js.data_len);
-            b->bits_pool.resize((b->bits_pool.size() + 63) & ~size_t(63));
+            if (!b->bits_pool.append_aligned(d + js.data_off, js.data_len)) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
             ds.ncomp = js.ncomp;
             if (js.ncomp > CSH_MAX_COMPS) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "scan with more than 3 components"; break; }
             for (int k = 0; k < js.ncomp; k++) { ds.comp[k] = js.comp_idx[k]; ds.td[k] = js.td[k]; ds.ta[k] = js.ta[k]; }
@@ -500,7 +621,10 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             uint32_t idx = 0;
             bool ok = true;
             while (pos + 1 < end) {
-                if (d[pos] == 0xFF && d[pos + 1] != 0x00) {
+                const void *f = memchr(d + pos, 0xFF, end - 1 - pos);
+                if (!f) break;
+                pos = size_t(static_cast<const uint8_t *>(f) - d);
+                if (d[pos + 1] != 0x00) {
                     if (d[pos + 1] != 0xD0 + (idx & 7)) { ok = false; break; }
                     pieces[s].push_back({start, pos - start, idx * ri, std::min(ri, units - idx * ri)});
                     idx++;
@@ -522,8 +646,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                     if (in.restart_interval == 0) { ps.bits_off = ds.bits_off; ps.bits_len = ds.bits_len; }
                     else {
                         ps.bits_off = uint32_t(b->bits_pool.size()); ps.bits_len = uint32_t(pc.len);
-                        b->bits_pool.insert(b->bits_pool.end(), d + pc.off, d + pc.off + pc.len);
-                        b->bits_pool.resize((b->bits_pool.size() + 63) & ~size_t(63));
+                        if (!b->bits_pool.append_aligned(d + pc.off, pc.len)) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
                     }
                     ps.huff_set = ds.huff_set; ps.image = img_index; ps.ncomp = js.ncomp; ps.first_mcu = pc.first_mcu;
                     int m = 0;
@@ -676,7 +799,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
 
         it.image = img_index;
         b->imgs.push_back(im);
-        b->raw_bytes_cap += 2 * len + 64 * 1024;
+        b->raw_bytes_cap += 2 * inputs[n].length + 64 * 1024;
     }
     b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
     b->nimg = int(b->imgs.size());
@@ -691,7 +814,9 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     // upload what never changes between runs
     hipStream_t st = b->stream;
     if (b->nimg) {
-        if (b->d_bits.upload(b->bits_pool, st) || b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
+        b->bits_pool.flush_copies();
+        if (b->d_bits.alloc(b->bits_pool.size()) || (b->bits_pool.size() && hipMemcpyAsync(b->d_bits.p, b->bits_pool.p, b->bits_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
+            b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_chunk_work.upload(b->chunk_work, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
@@ -974,27 +1099,36 @@ static void set_result(CCSResult *r, int code, const std::string &msg) {
 
 extern "C" int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results) {
     if (!b->ran) { csh_set_error("csh_batch_fetch before csh_batch_run"); return -1; }
-    std::vector<uint8_t> host;
-    if (b->nimg) {
-        host.resize(b->h_img_off[b->nimg]);
-        if (!host.empty() && hipMemcpy(host.data(), b->d_out.p, host.size(), hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H of output failed"); return -1; }
+    struct PinnedOut { uint8_t *p = nullptr; size_t cap = 0; ~PinnedOut() { if (p) pinned_cache().put(p, cap); } uint8_t *data() const { return p; } } host;
+    if (b->nimg && b->h_img_off[b->nimg]) {
+        host.p = static_cast<uint8_t *>(pinned_cache().get(b->h_img_off[b->nimg], host.cap));
+        if (!host.p) { csh_set_error("out of pinned host memory"); return -1; }
+        if (hipMemcpy(host.p, b->d_out.p, b->h_img_off[b->nimg], hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H of output failed"); return -1; }
     }
-    int failed = 0;
-    for (size_t n = 0; n < b->items.size(); n++) {
-        Item &it = b->items[n];
-        outputs[n].data = nullptr; outputs[n].length = 0;
-        int code = it.code;
-        std::string msg = it.msg;
-        if (!code && it.image >= 0 && b->h_status[it.image]) { code = int(b->h_status[it.image]); msg = "device reported a malformed stream"; }
-        if (!code) {
-            size_t len = b->h_img_size[it.image];
-            outputs[n].data = (uint8_t *)malloc(len ? len : 1);
-            memcpy(outputs[n].data, host.data() + b->h_img_off[it.image], len);
-            outputs[n].length = len;
-        } else failed++;
-        if (results) set_result(&results[n], code, msg);
-    }
-    return failed;
+    std::atomic<int> failed{0};
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (size_t n; (n = next++) < b->items.size();) {
+            Item &it = b->items[n];
+            outputs[n].data = nullptr; outputs[n].length = 0;
+            int code = it.code;
+            std::string msg = it.msg;
+            if (!code && it.image >= 0 && b->h_status[it.image]) { code = int(b->h_status[it.image]); msg = "device reported a malformed stream"; }
+            if (!code) {
+                size_t len = b->h_img_size[it.image];
+                outputs[n].data = (uint8_t *)malloc(len ? len : 1);
+                memcpy(outputs[n].data, host.data() + b->h_img_off[it.image], len);
+                outputs[n].length = len;
+            } else failed++;
+            if (results) set_result(&results[n], code, msg);
+        }
+    };
+    size_t nthreads = std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), b->items.size() / 64 + 1);
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    return failed.load();
 }
 
 extern "C" int csh_batch_geometry(csh_batch *b, size_t image, int comp, int which, int *bw, int *bh, int *real_bw, int *real_bh) {
