@@ -47,17 +47,15 @@ ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2>", "k_dec_spec": "k_dec_dense<0>",
 
 
 def pmc_traffic(kernel, batch):
-    """HBM bytes of ONE launch of `kernel` from the committed PMC passes (profiles/r01_pmc_{FETCH,WRITE}_SIZE_batch512.csv:
-    separate rocprofv3 --pmc runs of this same command at --batch 512 --steps 1; raw counter unit KiB; FETCH_SIZE doubled
+    """HBM bytes of ONE launch of `kernel` from the committed PMC passes (profiles/r01_pmc_{FETCH,WRITE}_SIZE_batch<B>.csv:
+    separate rocprofv3 --pmc runs of this same command at the same --batch, --steps 1; raw counter unit KiB; FETCH_SIZE doubled
     per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is -- it reads exactly 2*coef bytes on the pool memset).
     None when the batch differs from the profiled one or the files are absent."""
     import csv
-    if batch != 512:
-        return None
     key = ROCPROF_NAME.get(kernel, kernel)
     tot = 0.0
     for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(ROOT, "profiles", f"r01_pmc_{counter}_batch512.csv")
+        path = os.path.join(ROOT, "profiles", f"r01_pmc_{counter}_batch{batch}.csv")
         if not os.path.exists(path):
             return None
         hit = [r for r in csv.reader(open(path)) if len(r) == 3 and key in r[0]]
@@ -72,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="1080p files per rank per step")
+    ap.add_argument("--batch", type=int, default=2048, help="1080p files per rank per step (2048 x ~21 MB of device pools = 44 GB of the 288 GB)")
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic images (cycled to --batch)")
     ap.add_argument("--cpu-images", type=int, default=256, help="files timed through the CPU oracle (rank 0, N=1)")
     args = ap.parse_args()

@@ -142,21 +142,36 @@ struct PReader {
         return v;
     }
 };
-// the lane's slice of the stream staged in LDS: row[r] = big-endian word (w0 + r) for r < CSH_LROW_WORDS, global beyond
-#define CSH_LROW_WORDS 36   // 128-byte sub-sequence + 16 bytes of look-ahead
-#define CSH_LROW_STRIDE 37  // odd stride: lanes hit distinct banks
-struct LReader {
+// A lane reads words 0..34 relative to its sub-sequence (32 of its own + 3 of look-ahead: it enters at most 31 bits past
+// its cut, a symbol is at most 31 bits, and the reader fetches one word ahead).  Two LDS layouts:
+//   RowReader  (list rounds, scattered sub-sequences): a private row per lane, odd stride so lanes hit distinct banks;
+//   SwzReader  (dense passes, 256 consecutive sub-sequences): the workgroup's 32 KiB of stream stored ONCE -- the look-ahead
+//              of lane t is simply the row of lane t+1 -- with the word index rotated by the row number so that lanes
+//              reading the same relative word hit 32 distinct banks.  No padding, no duplicated look-ahead: 32.1 KiB
+//              instead of 37 KiB, which (with the compact table sets) is the difference between 3 and 4 workgroups per CU.
+#define CSH_LROW_WORDS 35
+#define CSH_LROW_STRIDE 35
+struct RowReader {
     const uint32_t *row;
-    uint32_t w0;
-    PReader g;
-    __device__ __forceinline__ uint32_t word(uint32_t wi) const { uint32_t r = wi - w0; return r < CSH_LROW_WORDS ? row[r] : g.word(wi); }
+    __device__ __forceinline__ uint32_t word(uint32_t r) const {
+#ifdef CSH_EMUL
+        if (r >= CSH_LROW_WORDS) { fprintf(stderr, "decode_span: stream window exceeded (%u)\n", r); abort(); }
+#endif
+        return row[r];
+    }
 };
-template <class R>
-__device__ __forceinline__ static uint32_t peek32(const R &rd, uint32_t pos) {
-    uint32_t wi = pos >> 5, o = pos & 31;
-    uint64_t w = (uint64_t(rd.word(wi)) << 32) | rd.word(wi + 1);
-    return uint32_t((w << o) >> 32);
-}
+#define CSH_SWZ_WORDS (257 * 32)   // 256 rows + the look-ahead row of the last lane
+struct SwzReader {
+    const uint32_t *lds;
+    uint32_t tl;   // lane's row
+    __device__ __forceinline__ static uint32_t index(uint32_t row, uint32_t r) { return (row << 5) + ((r + row) & 31u); }
+    __device__ __forceinline__ uint32_t word(uint32_t r) const {
+#ifdef CSH_EMUL
+        if (r >= CSH_LROW_WORDS) { fprintf(stderr, "decode_span: stream window exceeded (%u)\n", r); abort(); }
+#endif
+        return lds[index(tl + (r >> 5), r & 31u)];
+    }
+};
 
 __device__ __forceinline__ static int extend_p(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
 
@@ -193,23 +208,16 @@ __device__ __forceinline__ static void make_block_info(const ParScan &ps, const 
 //     31 bits past its cut and a symbol is at most 31 bits), the next word is fetched one refill ahead;
 //   * table selectors for every block-in-MCU index sit in a register (ParCtx::sel); the write pass takes its per-block
 //     placement from a small LDS table (ParBlockInfo).
-template <bool WRITE>
-__device__ __forceinline__ static uint32_t decode_span(const uint32_t *row, uint32_t w0, const ParHuffSet &hs, const ParCtx &cx, PState &st, uint32_t stop_bit,
+template <bool WRITE, class R>
+__device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0, const uint8_t *hb, uint32_t sub_off, const ParCtx &cx, PState &st, uint32_t stop_bit,
                                                         uint32_t ordinal, const ParBlockInfo *bi, int16_t *coef, int32_t *dcdiff) {
     uint32_t nblk = 0;
     int16_t *blk = nullptr;
     int32_t *dcp = nullptr;
-    const uint8_t *hb = reinterpret_cast<const uint8_t *>(&hs);
-    const uint16_t *sub = hs.sub;
+    const uint16_t *sub = reinterpret_cast<const uint16_t *>(hb + sub_off);
     uint32_t mcu = 0; int mx = 0, my = 0;
     bool in_range = false;
-    auto word = [&](uint32_t wi) -> uint32_t {
-        uint32_t r = wi - w0;
-#ifdef CSH_EMUL
-        if (r >= CSH_LROW_WORDS) { fprintf(stderr, "decode_span: stream window exceeded (%u)\n", r); abort(); }
-#endif
-        return row[r];
-    };
+    auto word = [&](uint32_t wi) -> uint32_t { return rd.word(wi - w0); };
     auto locate = [&](int m) {
         // 24-bit multiplies: the host sends scans of >= 2^24 blocks to the sequential decoder
         in_range = __umul24(mcu, uint32_t(cx.nb_mcu)) + uint32_t(m) < cx.total_blocks;
@@ -280,10 +288,11 @@ __device__ __forceinline__ static uint32_t decode_span(const uint32_t *row, uint
 // list rounds: the listed sub-sequences are scattered, so each wave stages its 64 lanes' 144-byte stream windows
 // cooperatively -- for lane r's window, lanes 0..35 fetch its 36 consecutive words in ONE coalesced access (a lane
 // reading its own window would cost 36 accesses x 64 cache lines per wave) -- then every lane decodes out of LDS.
-__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, uint64_t *state, const uint64_t *state_rd,
+template <class SET>
+__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const SET *huffs, uint64_t *state, const uint64_t *state_rd,
                                                          uint32_t *nblk, const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
     CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
-    CSH_SHARED ParHuffSet lhs;
+    CSH_SHARED SET lhs;
     CSH_SHARED uint32_t d_scan[256], d_t[256];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
     const uint32_t tid = threadIdx.x, j = blockIdx.x * blockDim.x + tid, count = *cnt_in;
     const uint32_t j0 = blockIdx.x * blockDim.x;
@@ -296,7 +305,7 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
             // the first entry's Huffman set is staged; lanes with another set read theirs from global memory
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&huffs[pss[uint32_t(list_in[j0] >> 32)].huff_set]);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
-            for (uint32_t i = tid; i < sizeof(ParHuffSet) / 4; i += 256) dst[i] = src[i];
+            for (uint32_t i = tid; i < sizeof(SET) / 4; i += 256) dst[i] = src[i];
             continue;
         }
         if (phase == 1) {
@@ -315,12 +324,12 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
         const uint32_t t = d_t[tid];
         size_t base = ps.sub_base + ps.par_index;
         PState st = unpack_state(state_rd[base + t]);
-        LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g.base = clean + ps.bits_off; rd.g.len = ps.clean_len;
-        const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+        RowReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE;
+        const uint32_t w0 = t * (CSH_SUBSEQ_BYTES / 4), stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
         uint32_t n;
         const ParCtx cx = make_ctx(ps, nullptr);
-        if (ps.huff_set == pss[d_scan[0]].huff_set) n = decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
-        else n = decode_span<false>(rd.row, rd.w0, huffs[ps.huff_set], cx, st, stop, 0, nullptr, nullptr, nullptr);
+        const uint8_t *hb = ps.huff_set == pss[d_scan[0]].huff_set ? reinterpret_cast<const uint8_t *>(&lhs) : reinterpret_cast<const uint8_t *>(&huffs[ps.huff_set]);
+        n = decode_span<false>(rd, w0, hb, uint32_t(sizeof(SET::root)), cx, st, stop, 0, nullptr, nullptr, nullptr);
         nblk[ps.sub_base + t] = n;
         uint64_t e = pack_state(st);
         if (e != state[base + t + 1]) {
@@ -364,10 +373,10 @@ __global__ void k_dec_chain(const ParScan *pss, int nps, uint64_t *state, uint32
 // into LDS with coalesced loads (global reads by 64 lanes at a 128-byte stride would cost 64 line requests per load);
 // phase 1 decodes out of LDS.  MODE 0: speculate from the guess state, 1: relax in place, 2: write coefficients,
 // 3: label hypotheses (see k_dec_chain).
-template <int MODE>
+template <int MODE, class SET>
 __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
-    CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
-    CSH_SHARED ParHuffSet lhs;
+    CSH_SHARED uint32_t lbits[CSH_SWZ_WORDS];
+    CSH_SHARED SET lhs;
     CSH_SHARED ParBlockInfo lbi[10];   // write pass: where block m of an MCU goes
     const ParScan &ps = a.pss[blockIdx.y];
     if (ps.kind) return;   // progressive scan: listed for the unstuffing pass only (uniform for the workgroup, before any barrier)
@@ -380,37 +389,36 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
         if (phase == 0) {
             if (MODE == 1 && t < nsub && t * CSH_SUBSEQ_BYTES >= ps.clean_len) a.nblk[ps.sub_base + t] = 0;
             if (!wg_live) continue;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(&a.huffs[ps.huff_set]);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&static_cast<const SET *>(a.huffs)[ps.huff_set]);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
-            for (uint32_t i = tid; i < sizeof(ParHuffSet) / 4; i += 256) dst[i] = src[i];
+            for (uint32_t i = tid; i < sizeof(SET) / 4; i += 256) dst[i] = src[i];
             if (MODE == 2 && int(tid) < ps.nb_mcu && tid < 10) make_block_info(ps, a.imgs[ps.image], int(tid), lbi[tid]);
             const uint32_t w_first = t0 * (CSH_SUBSEQ_BYTES / 4);
-            for (uint32_t i = 0; i < CSH_SUBSEQ_BYTES / 4 + 1; i++) {  // 33 x 256 words cover 256*32 + 4 look-ahead words
+            for (uint32_t i = 0; i < CSH_SUBSEQ_BYTES / 4 + 1; i++) {  // 33 x 256 words cover the 256 rows + the look-ahead words of the last one
                 uint32_t d = i * 256 + tid;
                 if (d >= 256 * (CSH_SUBSEQ_BYTES / 4) + (CSH_LROW_WORDS - CSH_SUBSEQ_BYTES / 4)) break;
-                uint32_t v = g.word(w_first + d);
-                uint32_t lane = d / (CSH_SUBSEQ_BYTES / 4), off = d % (CSH_SUBSEQ_BYTES / 4);
-                if (lane < 256) lbits[lane * CSH_LROW_STRIDE + off] = v;
-                if (off < CSH_LROW_WORDS - CSH_SUBSEQ_BYTES / 4 && lane > 0) lbits[(lane - 1) * CSH_LROW_STRIDE + CSH_SUBSEQ_BYTES / 4 + off] = v;
+                lbits[SwzReader::index(d >> 5, d & 31u)] = g.word(w_first + d);
             }
             continue;
         }
         if (!wg_live || t >= nsub) continue;
         size_t base = ps.sub_base + ps.par_index;
         const bool live = t * CSH_SUBSEQ_BYTES < ps.clean_len;
-        LReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE; rd.w0 = t * (CSH_SUBSEQ_BYTES / 4); rd.g = g;
-        const uint32_t stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+        SwzReader rd; rd.lds = lbits; rd.tl = tid;
+        const uint32_t w0 = t * (CSH_SUBSEQ_BYTES / 4), stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+        const uint8_t *hb = reinterpret_cast<const uint8_t *>(&lhs);
+        const uint32_t sub_off = uint32_t(sizeof(SET::root));
         const ParCtx cx = make_ctx(ps, MODE == 2 ? &a.imgs[ps.image] : nullptr);
         if (MODE == 0) {
             PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = 0;
             if (t == 0) a.state[base] = pack_state(st);
             if (!live) { a.state[base + t + 1] = 0; continue; }
-            decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
+            decode_span<false>(rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
             a.state[base + t + 1] = pack_state(st);
         } else if (MODE == 1) {
             if (!live) continue;
             PState st = unpack_state(a.state[base + t]);
-            uint32_t n = decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
+            uint32_t n = decode_span<false>(rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
             a.nblk[ps.sub_base + t] = n;
             uint64_t e = pack_state(st);
             if (e != a.state[base + t + 1]) {
@@ -425,7 +433,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             const bool last = (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len;
             for (int m0 = 0; m0 < ps.nb_mcu && m0 < 10; m0++) {
                 PState st = s0; st.m = m0;
-                uint32_t n = decode_span<false>(rd.row, rd.w0, lhs, cx, st, stop, 0, nullptr, nullptr, nullptr);
+                uint32_t n = decode_span<false>(rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
                 const bool same = last || (st.pos == nx.pos && st.k == nx.k);
                 a.hyp[(size_t(ps.sub_base) + t) * 10 + m0] = same ? uint16_t((st.m << 12) | (n > 4095 ? 4095 : n)) : uint16_t(0xFFFF);
             }
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             }
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            decode_span<true>(rd.row, rd.w0, lhs, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
+            decode_span<true>(rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
         }
     }
 }
@@ -472,15 +480,18 @@ void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, Par
 void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const DenseArgs &a) {
     if (!nps || !max_sub) return;   // max_sub == 0: only progressive scans are listed (a zero-sized grid is a launch error)
     dim3 grid((max_sub + 255) / 256, nps);
-    if (mode == 0) CSH_LAUNCH_PHASED(k_dec_dense<0>, 2, grid, dim3(256), st, a);
-    else if (mode == 1) CSH_LAUNCH_PHASED(k_dec_dense<1>, 2, grid, dim3(256), st, a);
-    else if (mode == 2) CSH_LAUNCH_PHASED(k_dec_dense<2>, 2, grid, dim3(256), st, a);
-    else CSH_LAUNCH_PHASED(k_dec_dense<3>, 2, grid, dim3(256), st, a);
+#define CSH_DENSE(M) do { if (a.compact) CSH_LAUNCH_PHASED((k_dec_dense<M, ParHuffSet4>), 2, grid, dim3(256), st, a); \
+                          else CSH_LAUNCH_PHASED((k_dec_dense<M, ParHuffSet>), 2, grid, dim3(256), st, a); } while (0)
+    if (mode == 0) CSH_DENSE(0);
+    else if (mode == 1) CSH_DENSE(1);
+    else if (mode == 2) CSH_DENSE(2);
+    else CSH_DENSE(3);
+#undef CSH_DENSE
 }
 #ifdef CSH_EMUL
 int csh_emul_jacobi = 0;  // tests: make a list round read the states as they were BEFORE the launch (what concurrent lanes see at worst)
 #endif
-void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const ParHuffSet *huffs, uint64_t *state, uint32_t *nblk,
+void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const void *huffs, int compact, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate) {
     if (!total_sub) return;
     const uint64_t *state_rd = state;
@@ -490,7 +501,8 @@ void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *
 #else
     (void)nstate;
 #endif
-    CSH_LAUNCH_PHASED(k_dec_relax_list, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, huffs, state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
+    if (compact) CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet4>, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, static_cast<const ParHuffSet4 *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
+    else CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet>, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, static_cast<const ParHuffSet *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
 #ifdef CSH_EMUL
     free(snap);
 #endif

@@ -19,13 +19,13 @@ void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const
 void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt);
 void launch_unstuff_copy(hipStream_t st, const uint8_t *raw, uint8_t *clean, ParScan *ps, int nps, uint32_t nchunks, const uint64_t *off);
 struct DenseArgs {
-    const uint8_t *clean; const ParScan *pss; const ParHuffSet *huffs;
+    const uint8_t *clean; const ParScan *pss; const void *huffs; int compact;   // huffs: ParHuffSet4[] if compact, else ParHuffSet[]
     uint64_t *state; uint32_t *nblk; uint64_t *list_out; uint32_t *cnt_out;           // relax
     uint16_t *hyp; const uint32_t *scan_pending;                                       // label hypotheses (mode 3)
     const uint64_t *blk_off; const ImgDesc *imgs; int16_t *coef; int32_t *dcdiff; uint32_t *need_seq;  // write
 };
 void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
-void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const ParHuffSet *huffs, uint64_t *state, uint32_t *nblk,
+void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const void *huffs, int compact, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate);
 // progressive inputs: one wave per chain of scans (k_decode_prog.hip); images with need_seq == 4
 void launch_decode_prog(hipStream_t st, const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,

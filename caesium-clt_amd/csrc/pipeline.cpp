@@ -6,6 +6,7 @@
 // on one stream with no host round trip (every size and offset is produced by device scans).
 // Host work is limited to container logic: marker parsing, table/script setup, descriptor building.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <map>
@@ -195,6 +196,9 @@ struct csh_batch {
     std::vector<DevHuffSet> hsets;
     std::vector<ParHuffSet> phsets;   // the same sets in the parallel decoder's LDS form
     std::vector<char> phset_fits;     // 0: sub-table pool overflow -> sequential decoder
+    std::vector<ParHuffSet4> phsets4; // compact form (types.h); slot4[set][0..3 DC, 4..7 AC] = slot or -1
+    std::vector<std::array<int8_t, 8>> slot4;
+    bool use4 = true;                 // every table set of the batch fits the compact form
     std::vector<DevQuant> quants;
     std::vector<PlaneWork> pwork;
     std::vector<ResizeWork> rwork;
@@ -232,6 +236,7 @@ struct csh_batch {
     DevBuf<int> d_chain_scans;
     DevBuf<DevHuffSet> d_hsets;
     DevBuf<ParHuffSet> d_phsets;
+    DevBuf<ParHuffSet4> d_phsets4;
     DevBuf<DevQuant> d_quants;
     DevBuf<PlaneWork> d_pwork;
     DevBuf<ResizeWork> d_rwork;
@@ -583,6 +588,27 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                 for (int t = 0; t < 4; t++) fits = fits && build_par_huff(js.dc[t], phs.root[t], phs.sub, sub_used) && build_par_huff(js.ac[t], phs.root[4 + t], phs.sub, sub_used);
                 b->phsets.push_back(phs);
                 b->phset_fits.push_back(fits ? 1 : 0);
+                ParHuffSet4 ph4;
+                memset(&ph4, 0, sizeof ph4);
+                std::array<int8_t, 8> slots;
+                slots.fill(-1);
+                int nslot = 0, sub4 = 0;
+                bool fits4 = true;
+                for (int t = 0; t < 8 && fits4; t++) {
+                    const HuffSpec &h = t < 4 ? js.dc[t] : js.ac[t - 4];
+                    if (!h.present) continue;
+                    if (nslot == 4) { fits4 = false; break; }
+                    uint16_t tmp_sub[CSH_PAR_SUB];
+                    int used = 0;
+                    if (!build_par_huff(h, ph4.root[nslot], tmp_sub, used) || sub4 + used > CSH_PAR_SUB4) { fits4 = false; break; }
+                    for (int e = 0; e < 512; e++) if (ph4.root[nslot][e] & 0x8000u) ph4.root[nslot][e] = uint16_t(ph4.root[nslot][e] + sub4);   // rebase the sub-table offsets
+                    memcpy(ph4.sub + sub4, tmp_sub, used * sizeof(uint16_t));
+                    sub4 += used;
+                    slots[t] = int8_t(nslot++);
+                }
+                if (!fits4) b->use4 = false;
+                b->phsets4.push_back(ph4);
+                b->slot4.push_back(slots);
                 hset_keys.emplace_back(key, found);
             }
             ds.huff_set = found;
@@ -659,7 +685,6 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
                                 if (m >= 10) break;
                                 ps.comp_of[m] = js.comp_idx[k]; ps.by_of[m] = y; ps.bx_of[m] = x; ps.dct[m] = js.td[k]; ps.act[m] = js.ta[k];
                                 ps.dc_base[m] = b->dc_total; ps.dc_per_mcu[m] = uint32_t(nh * nv); ps.dc_idx[m] = uint32_t(y * nh + x);
-                                ps.sel |= uint64_t((js.td[k] & 3) | ((4 + (js.ta[k] & 3)) << 3)) << (6 * m);
                             }
                         b->dc_total += nblocks;
                         ps.total_blocks += nblocks;
@@ -806,6 +831,12 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
     if (!b->lossless)
         for (ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) im.out[c].tile_base += b->ntiles_in;
+    for (ParScan &ps : b->pscans)   // table selectors: slot numbers of the table-set form the batch uses
+        for (int m = 0; m < ps.nb_mcu && m < 10; m++) {
+            int dcs = ps.dct[m] & 3, acs = 4 + (ps.act[m] & 3);
+            if (b->use4) { dcs = std::max<int>(0, b->slot4[ps.huff_set][dcs]); acs = std::max<int>(0, b->slot4[ps.huff_set][acs]); }
+            ps.sel |= uint64_t(dcs | (acs << 3)) << (6 * m);
+        }
     b->ntiles = b->ntiles_in + b->ntiles_out;
     b->plane_bytes = plane_off;
     b->oplane_bytes = oplane_off;
@@ -817,7 +848,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         b->bits_pool.flush_copies();
         if (b->d_bits.alloc(b->bits_pool.size()) || (b->bits_pool.size() && hipMemcpyAsync(b->d_bits.p, b->bits_pool.p, b->bits_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
             b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
-            b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
+            b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || (b->use4 && b->d_phsets4.upload(b->phsets4, st)) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_chunk_work.upload(b->chunk_work, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
             b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
@@ -894,7 +925,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         MARK();
         DenseArgs da;
         memset(&da, 0, sizeof da);
-        da.clean = b->d_clean.p; da.pss = b->d_pscans.p; da.huffs = b->d_phsets.p; da.state = b->d_pstate.p; da.nblk = b->d_nblk.p;
+        da.clean = b->d_clean.p; da.pss = b->d_pscans.p; da.huffs = b->use4 ? static_cast<const void *>(b->d_phsets4.p) : static_cast<const void *>(b->d_phsets.p); da.compact = b->use4 ? 1 : 0; da.state = b->d_pstate.p; da.nblk = b->d_nblk.p;
         da.list_out = b->d_relax_list[0].p; da.cnt_out = b->d_relax_cnt.p; da.blk_off = b->d_blk_off.p; da.imgs = b->d_imgs.p;
         da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p;
         launch_dec_dense(st, 0, nps, b->max_sub, da);
@@ -904,7 +935,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         launch_dec_dense(st, 1, nps, b->max_sub, da);
         MARK();
         for (int it = 0; it < R && nps; it++)
-            launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, b->d_phsets.p, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
+            launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, da.huffs, da.compact, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
                                   b->d_relax_cnt.p + it, b->d_relax_list[(it & 1) ^ 1].p, b->d_relax_cnt.p + it + 1, b->d_pstate.n);
         if (nps) {   // scans that are still listed: settle their block-in-MCU labels exactly (k_dec_chain), or hand the image to k_decode_seq
             if (b->d_scan_pending.zero(st)) return -1;

@@ -60,7 +60,15 @@ struct DevHuffSet { DevHuff dc[4], ac[4]; };
 #define CSH_PAR_SUB 2048
 struct alignas(16) ParHuffSet {
     uint16_t root[8][512];   // 0..3 DC tables, 4..7 AC tables
-    uint16_t sub[CSH_PAR_SUB];
+    uint16_t sub[CSH_PAR_SUB];   // directly behind root (the kernels address it as sizeof(root))
+};
+// compact form for the self-synchronising decoder: almost every file defines four tables (two DC, two AC), and 6 KB instead
+// of 12 KB of LDS is what lets a fourth workgroup onto each CU.  Slots are assigned per table set in order of presence;
+// ParScan::sel holds slot numbers.  A batch uses this form when ALL its table sets fit it.
+#define CSH_PAR_SUB4 1024
+struct alignas(16) ParHuffSet4 {
+    uint16_t root[4][512];
+    uint16_t sub[CSH_PAR_SUB4];
 };
 // where block m of an MCU goes (write pass), one entry per block-in-MCU index
 // block index in the component = my*row_step + mx*col_step + first; DC difference slot = mcu*dc_per_mcu + dc_first

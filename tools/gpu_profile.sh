@@ -1,16 +1,16 @@
-R=$(pwd); cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01 -- python $R/bench.py --steps 5 --warmup 1 --batch 512 > $R/gpurun_out/prof_r01_bench.json 2> $R/gpurun_out/prof_r01.err
-cd $R; find gpurun_out/prof_r01 -name "*kernel_stats.csv" -exec cp {} gpurun_out/r01_kernel_stats_batch512.csv \;
+B=${1:-2048}; R=$(pwd); cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r01 -- python $R/bench.py --steps 5 --warmup 1 --batch $B > $R/gpurun_out/prof_r01_bench.json 2> $R/gpurun_out/prof_r01.err
+cd $R; find gpurun_out/prof_r01 -name "*kernel_stats.csv" -exec cp {} gpurun_out/r01_kernel_stats_batch$B.csv \;
 rm -rf gpurun_out/prof_r01
 for c in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp; rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python $R/bench.py --steps 1 --warmup 0 --batch 512 --cpu-images 0 > $R/gpurun_out/pmc_$c.log 2>&1; cd $R
+  cd /tmp; rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python $R/bench.py --steps 1 --warmup 0 --batch $B --cpu-images 0 > $R/gpurun_out/pmc_$c.log 2>&1; cd $R
   python - <<PY
 import csv,glob,collections
 agg=collections.defaultdict(float); n=collections.Counter()
 for fn in glob.glob("gpurun_out/pmc_$c/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(fn)):
         k=r["Kernel_Name"]; agg[k]+=float(r["Counter_Value"]); n[k]+=1
-w=csv.writer(open("gpurun_out/r01_pmc_$c.csv","w")); w.writerow(["kernel","dispatches","$c"+"_sum_KiB_raw"])
+w=csv.writer(open("gpurun_out/r01_pmc_${c}_batch$B.csv","w")); w.writerow(["kernel","dispatches","$c"+"_sum_KiB_raw"])
 for k,v in sorted(agg.items(), key=lambda kv:-kv[1]): w.writerow([k,n[k],int(v)])
 PY
   rm -rf gpurun_out/pmc_$c
