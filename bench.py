@@ -42,7 +42,7 @@ def algorithmic_bytes(kernel, t, n):
 
 
 # hipEvent kernel slot -> substring of the rocprofv3 kernel name (profiles/*.csv)
-ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2>", "k_dec_spec": "k_dec_dense<0>", "k_dec_relax0": "k_dec_dense<1>", "k_dec_relax1_4": "k_dec_relax_list",
+ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2", "k_dec_spec": "k_dec_dense<0", "k_dec_relax0": "k_dec_dense<1", "k_dec_relax1_4": "k_dec_relax_list",
                 "k_resample+k_plane_fdct": "k_resample_plane", "unstuff": "k_unstuff_copy", "k_emit": "k_emit_data"}
 
 
