@@ -55,6 +55,20 @@ def test_emul_parallel_decoder_is_the_path_taken(api):
         assert out == oracle_lossy(src)
 
 
+def test_emul_non_interleaved_sequential_scans(api):
+    """a sequential-mode file whose components come in three separate scans (legal, rare): each scan is its own segment of the
+    parallel decoder, the block grid of a non-interleaved scan is the component's real one (no MCU padding blocks)"""
+    from oracle import oracle as O
+    for (w, h, ss) in [(203, 155, 2), (64, 48, 0), (99, 73, 1)]:
+        ci = O.decode(synth_jpeg(5, w, h, subsampling=ss, texture=30))
+        src = ci.encode(O.params(progressive=0, marker_style=0), script=[((0,), 0, 63, 0, 0), ((1,), 0, 63, 0, 0), ((2,), 0, 63, 0, 0)])
+        b = api.batch([src], params())
+        t = b.run()
+        assert t.n_seq_decoded == 0 and t.n_par_fallback == 0
+        assert b.fetch()[0] == oracle_lossy(src)
+        assert api.compress_in_memory(src, params(jpeg_optimize=True)) == oracle_lossless(src)
+
+
 def restart_cases():
     """restart-interval sources: intervals of rows and of odd block counts, every layout, grayscale, more than 8 intervals
     (the RSTm index wraps), and two broken ones (a marker out of order, a marker missing)"""

@@ -1,5 +1,7 @@
 import sys, time, os
-sys.path.insert(0, 'tests'); sys.path.insert(0, 'tools')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 from _util import package
 from gen_synth import synth_jpeg
 pkg = package(); api = pkg.load()
