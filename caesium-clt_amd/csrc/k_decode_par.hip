@@ -227,6 +227,22 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     };
     uint32_t pos = st.pos, wi = (pos >> 5) + 2;
     int k = st.k, m = st.m;
+    // WRITE: the coefficients of one octet (8 zig-zag positions = 16 contiguous bytes of the tile) are gathered in two
+    // registers and leave as ONE 16-byte store when the block moves on to another octet or ends -- a 2-byte store per
+    // coefficient cost the memory system a 32-byte sector write each (2.4x the planes in HBM write traffic).  An octet that
+    // this lane may share with a neighbouring lane (the block it entered half-way: the octet of its entry position; the block
+    // it leaves unfinished: the octet still pending at the exit) is written coefficient by coefficient instead.
+    int cur_oct = -1, shared_oct = k > 0 ? (k >> 3) : -1;
+    uint64_t olo = 0, ohi = 0;
+    auto flush = [&](bool piecewise) {
+        int16_t *dst = blk + cur_oct * CSH_OCT_STRIDE;
+        if (!piecewise) *reinterpret_cast<uint4 *>(dst) = uint4{uint32_t(olo), uint32_t(olo >> 32), uint32_t(ohi), uint32_t(ohi >> 32)};
+        else {
+            CSH_UNROLL
+            for (int i = 0; i < 8; i++) { const uint32_t c = uint32_t(((i & 4) ? ohi : olo) >> (16 * (i & 3))) & 0xFFFFu; if (c) dst[i] = int16_t(c); }
+        }
+        cur_oct = -1; olo = 0; ohi = 0;
+    };
     if (WRITE) {
         mcu = ordinal / uint32_t(cx.nb_mcu);
         my = int(mcu + cx.first_mcu) / cx.mcus_x; mx = int(mcu + cx.first_mcu) - my * cx.mcus_x;   // mcu itself stays relative to the segment
@@ -255,7 +271,12 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
         v = val ? v : 0;
         if (WRITE && in_range) {
             if (isdc) *dcp = v;
-            else if (val) blk[coef_off(kn)] = int16_t(v);
+            else if (val) {
+                const int oct = kn >> 3;
+                if (oct != cur_oct) { if (cur_oct >= 0) flush(cur_oct == shared_oct); cur_oct = oct; }
+                const uint64_t piece = uint64_t(uint32_t(v) & 0xFFFFu) << (16 * (kn & 3));
+                if (kn & 4) ohi |= piece; else olo |= piece;
+            }
         }
         const int used = len + (val ? n : 0);
         const bool eob = !isdc && n == 0 && r != 15;
@@ -266,6 +287,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
         nb -= used;
         if (nb < 32) { acc |= uint64_t(nxt) << (32 - nb); nb += 32; wi++; nxt = word(wi); }
         if (k >= 64) {
+            if (WRITE) { if (cur_oct >= 0) flush(cur_oct == shared_oct); shared_oct = -1; }
             k = 0;
             nblk++;
             const bool wrap = m + 1 == cx.nb_mcu;
@@ -277,6 +299,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
             }
         }
     }
+    if (WRITE && cur_oct >= 0) flush(true);   // unfinished block: the next lane may add to this octet
     st.pos = pos; st.k = k; st.m = m;
     return nblk;
 }
