@@ -163,17 +163,22 @@ __global__ void __launch_bounds__(256) k_emit_data(AsmCtx a) {
     if (rel >= w.raw_bytes) return;
     uint64_t c0 = w.raw_off >> 6;
     ByteRun o; o.begin(a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes + rel + (a.chunk_ffoff[c] - a.chunk_ffoff[c0]));
+    // the whole chunk first (four loads in flight at once), then the stores back to back: stores of one lane that are spread
+    // over several memory round trips reach HBM as separate 32-byte sector writes instead of merging in the L2
     const uint4 *src = reinterpret_cast<const uint4 *>(a.raw + c * 16);
-    for (int q = 0; q < 4; q++) {
-        const uint4 v = src[q];
-        const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
-        for (int j = 0; j < 4; j++)
-            for (int i = 0; i < 4; i++) {
-                if (rel + uint64_t(16 * q + 4 * j + i) >= w.raw_bytes) break;
+    const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+    const uint32_t ws[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    const uint32_t nbytes = w.raw_bytes - rel < 64 ? uint32_t(w.raw_bytes - rel) : 64u;
+    CSH_UNROLL
+    for (int j = 0; j < 16; j++) {
+        CSH_UNROLL
+        for (int i = 0; i < 4; i++) {
+            if (uint32_t(4 * j + i) < nbytes) {
                 uint32_t b = (ws[j] >> (24 - 8 * i)) & 255u;
                 o.push(b);
                 if (b == 0xFFu) o.push(0u);
             }
+        }
     }
     o.finish();
 }
