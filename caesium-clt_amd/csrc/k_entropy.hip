@@ -184,8 +184,10 @@ struct PackSink {
     uint64_t acc;      // pending bits, right-aligned
     int nacc;          // number of pending bits (< 32 after every put)
     bool first;        // the next word written is the unit's first (possibly shared) word
+    uint32_t fw; uint64_t fwi;   // that first word, held back: both atomics of a unit are issued together at the end, when the
+                                 // wave has reconverged -- neighbouring lanes' atomics then travel in the same instruction
     static constexpr bool kValues = true;
-    __device__ __forceinline__ void begin(uint64_t p) { pos = p; nacc = int(p & 31); acc = 0; first = true; }
+    __device__ __forceinline__ void begin(uint64_t p) { pos = p; nacc = int(p & 31); acc = 0; first = true; fw = 0; fwi = 0; }
     __device__ __forceinline__ void put(unsigned v, int n) {
         if (n == 0) return;
         v &= (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
@@ -195,13 +197,14 @@ struct PackSink {
         if (nacc >= 32) {
             uint32_t w = uint32_t(acc >> (nacc - 32));
             uint64_t wi = (pos - uint64_t(nacc)) >> 5;   // word that holds the oldest pending bit
-            if (first) { if (w) atomicOr(raw_words + wi, w); first = false; }
+            if (first) { fw = w; fwi = wi; first = false; }
             else raw_words[wi] = w;
             nacc -= 32;
             acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
         }
     }
     __device__ __forceinline__ void finish() {
+        if (fw) atomicOr(raw_words + fwi, fw);
         if (nacc == 0) return;
         uint32_t w = uint32_t(acc << (32 - nacc));
         uint64_t wi = (pos - uint64_t(nacc)) >> 5;
