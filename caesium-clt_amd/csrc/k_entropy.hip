@@ -140,10 +140,19 @@ __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
         // libjpeg also flushes when more than MAX_CORR_BITS-DCTSIZE2+1 = 937 correction bits are pending
         const uint8_t *tl = c.tail + w.unit_base;
         uint32_t cnt = 0, be = 0, s0 = u;
-        for (uint32_t j = u; j <= t; j++) {
-            cnt++; be += tl[j];
+        auto step = [&](uint32_t j, uint32_t tail_bits) {
+            cnt++; be += tail_bits;
             if (cnt == 0x7FFF || be > 937) { er[s0] = uint16_t(cnt); cnt = 0; be = 0; s0 = j + 1; }
+        };
+        // runs of a refinement scan can be thousands of blocks long: the tail counts are read eight at a time
+        uint32_t j = u;
+        while (j <= t && (reinterpret_cast<uintptr_t>(tl + j) & 7)) { step(j, tl[j]); j++; }
+        for (; j + 7 <= t; j += 8) {
+            const uint64_t v = *reinterpret_cast<const uint64_t *>(tl + j);
+            CSH_UNROLL
+            for (int i = 0; i < 8; i++) step(j + i, uint32_t(v >> (8 * i)) & 255u);
         }
+        for (; j <= t; j++) step(j, tl[j]);
         if (cnt) er[s0] = uint16_t(cnt);
     }
 }
