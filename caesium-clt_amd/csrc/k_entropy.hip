@@ -403,9 +403,9 @@ __device__ __forceinline__ static void walk_unit(Sink &sink, const EncCtx &c, co
     else walk_ac_refine(sink, m.H, m.N, m.C, m.S, sc, run);
 }
 
-// ---- pass C: symbol statistics.  A workgroup walks CSH_STATS_CHUNK consecutive units of one scan into an LDS histogram
-// (ds_add), then flushes the non-zero bins with one global atomic each.
-#define CSH_STATS_CHUNK 2048
+// ---- pass C: symbol statistics.  A workgroup walks its 256 consecutive units of one scan into an LDS histogram (ds_add),
+// then flushes the non-zero bins with one global atomic each.  (One unit per lane: with eight units per lane the kernel was
+// 40 % slower -- a lane's walks ran one after the other, each with its own round trips to memory.)
 struct LdsStatsSink {
     uint32_t *hist;  // [4][257] in LDS
     static constexpr bool kValues = false;
@@ -416,17 +416,15 @@ struct LdsStatsSink {
 };
 __global__ void __launch_bounds__(256) k_stats(EncCtx c) {
     CSH_SHARED uint32_t hist[4 * 257];
-    const ScanWork w = c.work[blockIdx.y];
+    const ScanWork w = c.work[c.chunk_work[blockIdx.x]];
     const EncScan &sc = c.script[w.scan];
     CSH_PHASE_LOOP(3) {
-        if (sc.ntables == 0 || blockIdx.x * CSH_STATS_CHUNK >= w.nunits) continue;
+        if (sc.ntables == 0) continue;
         if (phase == 0) { for (int i = threadIdx.x; i < 4 * 257; i += blockDim.x) hist[i] = 0; continue; }
         if (phase == 1) {
             LdsStatsSink s; s.hist = hist;
-            for (uint32_t i = 0; i < CSH_STATS_CHUNK / 256; i++) {
-                uint32_t u = blockIdx.x * CSH_STATS_CHUNK + i * 256 + threadIdx.x;
-                if (u < w.nunits) walk_unit(s, c, w, sc, u);
-            }
+            uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
+            if (u < w.nunits) walk_unit(s, c, w, sc, u);
             continue;
         }
         for (int i = threadIdx.x; i < sc.ntables * 257; i += blockDim.x) {
@@ -647,7 +645,7 @@ static dim3 unit_grid(const EncCtx &c) { return dim3(c.nchunks); }   // flat: on
 void launch_ac_flags(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_ac_flags, unit_grid(c), dim3(256), st, c); }
 void launch_ac_runs(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c); }
 void launch_stats(hipStream_t st, const EncCtx &c) {
-    if (c.nwork) CSH_LAUNCH_PHASED(k_stats, 3, dim3((c.max_units + CSH_STATS_CHUNK - 1) / CSH_STATS_CHUNK, c.nwork), dim3(256), st, c);
+    if (c.nchunks) CSH_LAUNCH_PHASED(k_stats, 3, unit_grid(c), dim3(256), st, c);
 }
 void launch_sizes(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_sizes, unit_grid(c), dim3(256), st, c); }
 void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH_PHASED(k_pack, 2, unit_grid(c), dim3(256), st, c); }
