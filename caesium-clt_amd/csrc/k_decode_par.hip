@@ -311,12 +311,15 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
 // list rounds: the listed sub-sequences are scattered, so each wave stages its 64 lanes' 144-byte stream windows
 // cooperatively -- for lane r's window, lanes 0..35 fetch its 36 consecutive words in ONE coalesced access (a lane
 // reading its own window would cost 36 accesses x 64 cache lines per wave) -- then every lane decodes out of LDS.
+// 512 lanes per workgroup: 70 KiB of windows + the table set + 4 KiB of lane descriptors = two workgroups = 16 waves per CU
+// (with 256 lanes the table set is paid twice as often and only 12 waves fit)
+#define CSH_LIST_LANES 512
 template <class SET>
-__global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const SET *huffs, uint64_t *state, const uint64_t *state_rd,
+__global__ void __launch_bounds__(CSH_LIST_LANES) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const SET *huffs, uint64_t *state, const uint64_t *state_rd,
                                                          uint32_t *nblk, const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
-    CSH_SHARED uint32_t lbits[256 * CSH_LROW_STRIDE];
+    CSH_SHARED uint32_t lbits[CSH_LIST_LANES * CSH_LROW_STRIDE];
     CSH_SHARED SET lhs;
-    CSH_SHARED uint32_t d_scan[256], d_t[256];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
+    CSH_SHARED uint32_t d_scan[CSH_LIST_LANES], d_t[CSH_LIST_LANES];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
     const uint32_t tid = threadIdx.x, j = blockIdx.x * blockDim.x + tid, count = *cnt_in;
     const uint32_t j0 = blockIdx.x * blockDim.x;
     CSH_PHASE_LOOP(3) {
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(256) k_dec_relax_list(const uint8_t *clean, co
             // the first entry's Huffman set is staged; lanes with another set read theirs from global memory
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&huffs[pss[uint32_t(list_in[j0] >> 32)].huff_set]);
             uint32_t *dst = reinterpret_cast<uint32_t *>(&lhs);
-            for (uint32_t i = tid; i < sizeof(SET) / 4; i += 256) dst[i] = src[i];
+            for (uint32_t i = tid; i < sizeof(SET) / 4; i += CSH_LIST_LANES) dst[i] = src[i];
             continue;
         }
         if (phase == 1) {
@@ -524,8 +527,8 @@ void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *
 #else
     (void)nstate;
 #endif
-    if (compact) CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet4>, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, static_cast<const ParHuffSet4 *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
-    else CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet>, 3, dim3((total_sub + 255) / 256), dim3(256), st, clean, ps, static_cast<const ParHuffSet *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
+    if (compact) CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet4>, 3, dim3((total_sub + CSH_LIST_LANES - 1) / CSH_LIST_LANES), dim3(CSH_LIST_LANES), st, clean, ps, static_cast<const ParHuffSet4 *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
+    else CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet>, 3, dim3((total_sub + CSH_LIST_LANES - 1) / CSH_LIST_LANES), dim3(CSH_LIST_LANES), st, clean, ps, static_cast<const ParHuffSet *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
 #ifdef CSH_EMUL
     free(snap);
 #endif

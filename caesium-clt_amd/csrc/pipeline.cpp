@@ -930,7 +930,9 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p;
         launch_dec_dense(st, 0, nps, b->max_sub, da);
         MARK();
-        const int R = 40;  // list rounds after the dense one (a converged round is a near-empty launch, ~5 us); similar luma/chroma tables need ~50
+        const int R = 40;  // list rounds after the dense one.  Stock tables settle in ~9 (a converged round is a near-empty launch, ~6 us), but with
+                           // similar luma/chroma tables positions keep moving for 30+ rounds before only the label creeps (the hypothesis chain
+                           // below needs settled positions): 20 rounds sent such a file to the sequential kernel
         if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
         launch_dec_dense(st, 1, nps, b->max_sub, da);
         MARK();
