@@ -317,30 +317,34 @@ __device__ __forceinline__ static uint32_t resample_quad(const PlaneView &v, int
 // take a vector path (3 rows x 3 dwords in, composite triangle-up o box-down in registers); everything else goes through
 // the same clamped per-sample formula, so image borders, odd sizes and tiny planes need no special code.
 __device__ __forceinline__ static uint32_t resample_quad_420(const PlaneView &v, int rows_alloc, int y, int x0) {
-    // window columns x0-1 .. x0+4 of plane rows y-1, y, y+1 (row index clamped; columns all inside the plane)
-    int c[3][6];
+    // window columns x0-1 .. x0+4 of plane rows y-1, y, y+1 (row index clamped; columns all inside the plane).
+    // Two samples per 32-bit register (16-bit fields; every intermediate is < 4096, nothing carries across):
+    //   E = columns (0, 2), O = (1, 3) of the quad, L = (-1, 1), R = (2, 4): even outputs have centre E, neighbours L and O,
+    //   odd outputs have centre O, neighbours E and R -- so the bias pattern of both filters is constant per register.
+    uint32_t E[3], O[3], L[3], R[3];
     CSH_UNROLL
     for (int j = 0; j < 3; j++) {
         int yy = y - 1 + j;
         yy = yy < 0 ? 0 : (yy > rows_alloc - 1 ? rows_alloc - 1 : yy);
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(v.p + size_t(yy) * v.pitch + x0);
-        uint32_t a = rp[-1], b = rp[0], d = rp[1];
-        c[j][0] = int(a >> 24);
-        c[j][1] = int(b & 255u); c[j][2] = int((b >> 8) & 255u); c[j][3] = int((b >> 16) & 255u); c[j][4] = int(b >> 24);
-        c[j][5] = int(d & 255u);
+        const uint32_t a = rp[-1], b = rp[0], d = rp[1];
+        E[j] = b & 0x00FF00FFu;
+        O[j] = (b >> 8) & 0x00FF00FFu;
+        L[j] = (a >> 24) | (O[j] << 16);
+        R[j] = (E[j] >> 16) | ((d & 0xFFu) << 16);
     }
-    int cs0[6], cs1[6];
-    CSH_UNROLL
-    for (int i = 0; i < 6; i++) { cs0[i] = 3 * c[1][i] + c[0][i]; cs1[i] = 3 * c[1][i] + c[2][i]; }
-    uint32_t out = 0;
-    CSH_UNROLL
-    for (int X = 0; X < 4; X++) {
-        int i = X + 1;
-        int u00 = (3 * cs0[i] + cs0[i - 1] + 8) >> 4, u01 = (3 * cs0[i] + cs0[i + 1] + 7) >> 4;
-        int u10 = (3 * cs1[i] + cs1[i - 1] + 8) >> 4, u11 = (3 * cs1[i] + cs1[i + 1] + 7) >> 4;
-        out |= uint32_t((u00 + u01 + u10 + u11 + ((X & 1) ? 2 : 1)) >> 2) << (8 * X);
-    }
-    return out;
+    // vertical step of the triangle filter (jdsample h2v2_fancy_upsample): 3 * nearer row + further row, for the two output
+    // rows 2y (further = y-1) and 2y+1 (further = y+1)
+    uint32_t e0 = 3u * E[1] + E[0], e1 = 3u * E[1] + E[2], o0 = 3u * O[1] + O[0], o1 = 3u * O[1] + O[2];
+    uint32_t l0 = 3u * L[1] + L[0], l1 = 3u * L[1] + L[2], r0 = 3u * R[1] + R[0], r1 = 3u * R[1] + R[2];
+    const uint32_t M = 0x00FF00FFu;
+    // horizontal step: (3 * centre + left + 8) >> 4 and (3 * centre + right + 7) >> 4; then jcsample's box: (sum + {1,2}) >> 2
+    auto up = [&](uint32_t c, uint32_t nb, uint32_t bias) { return ((3u * c + nb + bias) >> 4) & M; };
+    uint32_t even = up(e0, l0, 0x00080008u) + up(e0, o0, 0x00070007u) + up(e1, l1, 0x00080008u) + up(e1, o1, 0x00070007u);
+    uint32_t odd = up(o0, e0, 0x00080008u) + up(o0, r0, 0x00070007u) + up(o1, e1, 0x00080008u) + up(o1, r1, 0x00070007u);
+    even = ((even + 0x00010001u) >> 2) & M;   // outputs 0 and 2: bias 1
+    odd = ((odd + 0x00020002u) >> 2) & M;     // outputs 1 and 3: bias 2
+    return even | (odd << 8);
 }
 
 __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, const PlaneWork *work, const uint8_t *planes, uint8_t *oplanes) {
