@@ -69,6 +69,38 @@ def test_emul_non_interleaved_sequential_scans(api):
         assert api.compress_in_memory(src, params(jpeg_optimize=True)) == oracle_lossless(src)
 
 
+def six_tables(src):
+    """give Cr its own (identical) Huffman tables, ids 2/2: the file then defines six tables, more than the compact table-set
+    form of the parallel decoder holds, so the whole batch runs the 8-slot variant of its kernels"""
+    out = bytearray(src[:2]); i = 2; dht = {}
+    while i < len(src):
+        m, L = src[i + 1], int.from_bytes(src[i + 2:i + 4], "big")
+        seg = src[i:i + 2 + L]
+        if m == 0xC4:
+            p = 4
+            while p < len(seg):
+                n = sum(seg[p + 1:p + 17]); dht[seg[p]] = bytes(seg[p + 1:p + 17 + n]); p += 17 + n
+        if m == 0xDA:
+            for cls in (0, 1):
+                body = bytes([cls << 4 | 2]) + dht[cls << 4 | 1]
+                out += b"\xff\xc4" + (2 + len(body)).to_bytes(2, "big") + body
+            sos = bytearray(seg)
+            sos[5 + 2 * (sos[4] - 1) + 1] = 0x22
+            return bytes(out + sos + src[i + 2 + L:])
+        out += seg; i += 2 + L
+    raise AssertionError("no SOS")
+
+
+def test_emul_six_huffman_tables(api):
+    srcs = [six_tables(synth_jpeg(3, 203, 155, texture=30)), synth_jpeg(5, 160, 120, texture=20), six_tables(synth_jpeg(8, 333, 222, restart_rows=1, texture=25))]
+    assert oracle_lossy(srcs[0]) == oracle_lossy(synth_jpeg(3, 203, 155, texture=30))
+    b = api.batch(srcs, params())
+    t = b.run()
+    assert t.n_seq_decoded == 0 and t.n_par_fallback == 0
+    for src, out in zip(srcs, b.fetch()):
+        assert out == oracle_lossy(src)
+
+
 def restart_cases():
     """restart-interval sources: intervals of rows and of odd block counts, every layout, grayscale, more than 8 intervals
     (the RSTm index wraps), and two broken ones (a marker out of order, a marker missing)"""

@@ -96,6 +96,10 @@ def test_non_interleaved_sequential_scans(api):
     E.test_emul_non_interleaved_sequential_scans(api)
 
 
+def test_six_huffman_tables(api):
+    E.test_emul_six_huffman_tables(api)
+
+
 def test_restart_intervals_decode_in_parallel(api):
     E.test_emul_restart_intervals_decode_in_parallel(api)
 
