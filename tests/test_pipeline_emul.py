@@ -101,6 +101,63 @@ def test_emul_six_huffman_tables(api):
         assert out == oracle_lossy(src)
 
 
+def long_block_jpeg(w=48, h=32, seed=3):
+    """grayscale baseline JPEG, standard Huffman tables, quantiser 1, every AC coefficient +-512..1023: each block codes to
+    ~205 bytes, i.e. spans two or three 128-byte sub-sequences of the parallel decoder"""
+    from PIL import Image
+    b = io.BytesIO(); Image.new("L", (w, h), 128).save(b, format="JPEG", quality=100, optimize=False); ref = b.getvalue()
+    segs = {}; i = 2
+    while ref[i + 1] != 0xDA:
+        L = int.from_bytes(ref[i + 2:i + 4], "big"); segs.setdefault(ref[i + 1], []).append(ref[i:i + 2 + L]); i += 2 + L
+    sos = ref[i:i + 2 + int.from_bytes(ref[i + 2:i + 4], "big")]
+    tabs = {}
+    for seg in segs[0xC4]:
+        p = 4
+        while p < len(seg):
+            bits = seg[p + 1:p + 17]; n = sum(bits); vals = seg[p + 17:p + 17 + n]
+            code, k, enc = 0, 0, {}
+            for l in range(1, 17):
+                for _ in range(bits[l - 1]): enc[vals[k]] = (code, l); code += 1; k += 1
+                code <<= 1
+            tabs[seg[p]] = enc; p += 17 + n
+    rng = np.random.default_rng(seed)
+    out = []; acc = 0; nb = 0
+    def put(v, n):
+        nonlocal acc, nb
+        acc = (acc << n) | (v & ((1 << n) - 1)); nb += n
+        while nb >= 8:
+            byte = (acc >> (nb - 8)) & 255; out.append(byte)
+            if byte == 255: out.append(0)
+            nb -= 8
+    def coef(table, run, v):
+        a = abs(v); s = a.bit_length()
+        c, l = table[(run << 4) | s]; put(c, l)
+        if s: put(v if v > 0 else v - 1, s)
+    pred = 0
+    for _ in range(((w + 7) // 8) * ((h + 7) // 8)):
+        dc = int(rng.integers(-200, 200)); coef(tabs[0x00], 0, dc - pred); pred = dc
+        for k in range(1, 64): coef(tabs[0x10], 0, int(rng.integers(512, 1024)) * int(rng.choice([-1, 1])))
+    if nb: put((1 << (8 - nb)) - 1, 8 - nb)
+    dqt = b"\xff\xdb\x00\x43\x00" + bytes([1] * 64)
+    head = ref[:2] + b"".join(s for m in (0xE0,) for s in segs.get(m, [])) + dqt + segs[0xC0][0] + b"".join(segs[0xC4])
+    return head + sos + bytes(out) + b"\xff\xd9"
+
+
+def test_emul_blocks_longer_than_a_subsequence(api):
+    """a block of ~205 coded bytes is decoded by two or three lanes: the first stores the octets it completes, the others
+    what follows, and the octet a cut falls into is written coefficient by coefficient from both sides"""
+    srcs = [long_block_jpeg(16, 8, 4), long_block_jpeg(32, 16, 6), long_block_jpeg(48, 32, 3), long_block_jpeg(200, 120, 5)]
+    for lossless in (True, False):
+        b = api.batch(srcs, params(jpeg_optimize=lossless))
+        t = b.run()
+        # such a stream hardly self-synchronises (no block boundary inside most sub-sequences), so on a GPU the states settle
+        # about one cut per round: the two small files are through well inside the 40 rounds, the large one may be handed to
+        # the sequential kernel -- either way the bytes are the oracle's
+        assert t.n_seq_decoded <= 2
+        for src, out in zip(srcs, b.fetch()):
+            assert out == (oracle_lossless(src) if lossless else oracle_lossy(src))
+
+
 def restart_cases():
     """restart-interval sources: intervals of rows and of odd block counts, every layout, grayscale, more than 8 intervals
     (the RSTm index wraps), and two broken ones (a marker out of order, a marker missing)"""

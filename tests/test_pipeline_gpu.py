@@ -100,6 +100,10 @@ def test_six_huffman_tables(api):
     E.test_emul_six_huffman_tables(api)
 
 
+def test_blocks_longer_than_a_subsequence(api):
+    E.test_emul_blocks_longer_than_a_subsequence(api)
+
+
 def test_restart_intervals_decode_in_parallel(api):
     E.test_emul_restart_intervals_decode_in_parallel(api)
 
