@@ -14,6 +14,9 @@ struct BitReader {
     uint64_t acc;
     int nbits;
     int marker;  // first marker byte met (0 = none); zeros are fed from then on, as libjpeg does
+    // libjpeg jdhuff.c `insufficient_data`: once more bits have been CONSUMED than the segment holds, the current MCU is
+    // finished on zero bits and every later MCU up to the next restart is skipped (left as it is).  real = file bits in acc.
+    int real, insufficient;
 };
 
 __device__ static inline void br_fill(BitReader &b) {
@@ -26,13 +29,14 @@ __device__ static inline void br_fill(BitReader &b) {
                 if (c2 == 0) b.p += 2;
                 else { b.marker = c2; c = 0; }
             } else b.p++;
+            if (!b.marker) b.real += 8;
         }
         b.acc |= uint64_t(c) << (56 - b.nbits);
         b.nbits += 8;
     }
 }
 __device__ static inline int br_peek16(BitReader &b) { if (b.nbits < 16) br_fill(b); return int(b.acc >> 48); }
-__device__ static inline void br_skip(BitReader &b, int n) { b.acc <<= n; b.nbits -= n; }
+__device__ static inline void br_skip(BitReader &b, int n) { b.acc <<= n; b.nbits -= n; if (n > b.real) { b.insufficient = 1; b.real = 0; } else b.real -= n; }
 __device__ static inline int br_get(BitReader &b, int n) {
     if (n == 0) return 0;
     if (b.nbits < n) br_fill(b);
@@ -54,11 +58,11 @@ __device__ static inline int huff_decode(BitReader &b, const DevHuff &h) {
 __device__ static inline int extend(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
 
 __device__ static inline void restart(BitReader &b) {
-    b.acc = 0; b.nbits = 0;
-    if (b.marker >= 0xD0 && b.marker <= 0xD7) { b.p += 2; b.marker = 0; }
+    b.acc = 0; b.nbits = 0; b.real = 0;
+    if (b.marker >= 0xD0 && b.marker <= 0xD7) { b.p += 2; b.marker = 0; b.insufficient = 0; }
     else {
         while (b.p + 1 < b.end && !(b.p[0] == 0xFF && b.p[1] >= 0xD0 && b.p[1] <= 0xD7)) b.p++;
-        if (b.p + 1 < b.end) b.p += 2;
+        if (b.p + 1 < b.end) { b.p += 2; b.insufficient = 0; }
     }
 }
 
@@ -149,7 +153,7 @@ __global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *
         const DecScan &sc = scans[im.first_scan + s];
         const DevHuffSet &hs = huffs[sc.huff_set];
         BitReader br;
-        br.p = bits + sc.bits_off; br.end = br.p + sc.bits_len; br.acc = 0; br.nbits = 0; br.marker = 0;
+        br.p = bits + sc.bits_off; br.end = br.p + sc.bits_len; br.acc = 0; br.nbits = 0; br.marker = 0; br.real = 0; br.insufficient = 0;
         int pred[CSH_MAX_COMPS] = {0, 0, 0};
         int eobrun = 0;
         int ri = sc.restart_interval, todo = ri;
@@ -160,12 +164,14 @@ __global__ void k_decode_seq(const uint8_t *bits, ImgDesc *imgs, const DecScan *
             for (int by = 0; by < g.real_bh; by++)
                 for (int bx = 0; bx < g.real_bw; bx++) {
                     if (ri) { if (todo == 0) { restart(br); pred[0] = pred[1] = pred[2] = 0; eobrun = 0; todo = ri; } todo--; }
+                    if (br.insufficient) continue;
                     decode_block(br, sc, prog, dct, act, pred[0], eobrun, block_ref(coef, g, by, bx));
                 }
         } else {
             for (int my = 0; my < im.mcus_y; my++)
                 for (int mx = 0; mx < im.mcus_x; mx++) {
                     if (ri) { if (todo == 0) { restart(br); pred[0] = pred[1] = pred[2] = 0; eobrun = 0; todo = ri; } todo--; }
+                    if (br.insufficient) continue;
                     for (int c = 0; c < sc.ncomp; c++) {
                         const CompGeom &g = im.in[sc.comp[c]];
                         const DevHuff &dct = hs.dc[sc.td[c] & 3], &act = hs.ac[sc.ta[c] & 3];

@@ -182,11 +182,13 @@ struct ParCtx {
     uint32_t total_blocks;
     int mcus_x;            // MCUs per row (write pass)
     uint32_t first_mcu;    // where in the scan this segment starts (restart intervals)
+    uint32_t real_bits;    // unstuffed length of the segment in bits
 };
 __device__ __forceinline__ static ParCtx make_ctx(const ParScan &ps, const ImgDesc *im) {
     ParCtx c; c.sel = ps.sel; c.nb_mcu = ps.nb_mcu; c.total_blocks = ps.total_blocks;
     c.mcus_x = im ? (ps.ncomp > 1 ? im->mcus_x : im->in[ps.comp_of[0]].real_bw) : 1;
     c.first_mcu = ps.first_mcu;
+    c.real_bits = ps.clean_len * 8u;
     return c;
 }
 // per-m placement table of the write pass (LDS): a non-interleaved scan walks its component block by block (h = v = 1)
@@ -232,6 +234,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     // coefficient cost the memory system a 32-byte sector write each (2.4x the planes in HBM write traffic).  An octet that
     // this lane may share with a neighbouring lane (the block it entered half-way: the octet of its entry position; the block
     // it leaves unfinished: the octet still pending at the exit) is written coefficient by coefficient instead.
+    uint32_t ok_blk = 0;
     int cur_oct = -1, shared_oct = k > 0 ? (k >> 3) : -1;
     uint64_t olo = 0, ohi = 0;
     auto flush = [&](bool piecewise) {
@@ -290,6 +293,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
             if (WRITE) { if (cur_oct >= 0) flush(cur_oct == shared_oct); shared_oct = -1; }
             k = 0;
             nblk++;
+            if (WRITE) ok_blk = pos <= cx.real_bits ? nblk : ok_blk;   // blocks finished on bits the file really holds
             const bool wrap = m + 1 == cx.nb_mcu;
             m = wrap ? 0 : m + 1;
             tables(m);
@@ -301,7 +305,10 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     }
     if (WRITE && cur_oct >= 0) flush(true);   // unfinished block: the next lane may add to this octet
     st.pos = pos; st.k = k; st.m = m;
-    return nblk;
+    // WRITE: did a block the frame needs take bits from beyond the data?  (the first block not finished on real bits is block
+    // ordinal + ok_blk.)  libjpeg's insufficient-data rule then decides what the following MCUs hold, and only the sequential
+    // kernel implements it -- the caller hands the image over.
+    return WRITE ? uint32_t(pos > cx.real_bits && ordinal + ok_blk < cx.total_blocks) : nblk;
 }
 
 // pass B: relaxation  s[t+1] = F_t(s[t]), in place.  Only the lane of sub-sequence t-1 ever writes s[t]; whenever it
@@ -472,7 +479,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             }
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            decode_span<true>(rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
+            if (decode_span<true>(rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff)) a.need_seq[ps.image] = 3;
         }
     }
 }

@@ -59,6 +59,9 @@ struct WaveReader {
     uint64_t acc;
     int nb;
     uint32_t wi;        // next word to append
+    uint64_t consumed;  // bits taken so far; past len*8 the rest of the MCU runs on zero bits and every later MCU is skipped
+                        // (libjpeg jdphuff.c `insufficient_data`)
+    __device__ __forceinline__ bool insufficient() const { return consumed > uint64_t(len) * 8u; }
     __device__ __forceinline__ uint32_t loadw(uint32_t w) const {
         uint32_t b = w * 4;
         if (b + 4 <= len) {
@@ -87,11 +90,11 @@ struct WaveReader {
         for (int l = 0; l < 64; l++) { win[l] = loadw(l); nxt[l] = loadw(64 + l); }
 #endif
         acc = (uint64_t(word(0)) << 32) | word(1);
-        nb = 64; wi = 2;
+        nb = 64; wi = 2; consumed = 0;
     }
     __device__ __forceinline__ uint32_t peek16() const { return uint32_t(acc >> 48); }
     __device__ __forceinline__ void skip(int n) {   // n <= 32
-        acc <<= n; nb -= n;
+        acc <<= n; nb -= n; consumed += uint32_t(n);
         if (nb < 32) { acc |= uint64_t(word(wi)) << (32 - nb); wi++; nb += 32; }
     }
     __device__ __forceinline__ uint32_t get(int n) {   // n <= 32
@@ -161,14 +164,16 @@ __device__ static void scan_dc_first(const ScanCtx &x, WaveReader &rd) {
     };
     if (sc.ncomp == 1) {
         const CompGeom &g = im.in[sc.comp[0]];
-        for (int by = 0; by < g.real_bh; by++) for (int bx = 0; bx < g.real_bw; bx++) one(0, by, bx);
+        for (int by = 0; by < g.real_bh; by++) for (int bx = 0; bx < g.real_bw; bx++) { if (rd.insufficient()) return; one(0, by, bx); }
     } else {
         for (int my = 0; my < im.mcus_y; my++)
-            for (int mx = 0; mx < im.mcus_x; mx++)
+            for (int mx = 0; mx < im.mcus_x; mx++) {
+                if (rd.insufficient()) return;
                 for (int ci = 0; ci < sc.ncomp; ci++) {
                     const CompGeom &g = im.in[sc.comp[ci]];
                     for (int y = 0; y < g.v; y++) for (int xx = 0; xx < g.h; xx++) one(ci, my * g.v + y, mx * g.h + xx);
                 }
+            }
     }
 }
 
@@ -213,6 +218,7 @@ __device__ static void scan_ac_first(const ScanCtx &x, WaveReader &rd) {
     uint32_t o = 0;
     int by = 0, bx = 0;
     while (o < total) {
+        if (rd.insufficient()) return;
         if (eobrun) {   // blocks inside an EOB run carry no bits in a first pass: jump over them
             uint32_t skip = eobrun < total - o ? eobrun : total - o;
             eobrun -= skip; o += skip;
@@ -253,6 +259,7 @@ __device__ static void scan_ac_refine(const ScanCtx &x, WaveReader &rd) {
     if (g.real_bw > 0 && g.real_bh > 0) load_block(ahead, x.coef + coef_index(g.tile_base, 0, 0));
     for (int by = 0; by < g.real_bh; by++)
         for (int bx = 0; bx < g.real_bw; bx++) {
+            if (rd.insufficient()) return;
             int16_t *blk = x.coef + coef_index(g.tile_base, by * g.bw + bx, 0);
             c = ahead;
             {   // fetch the next block of the scan while this one is decoded

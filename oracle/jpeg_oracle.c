@@ -119,6 +119,10 @@ typedef struct {
     const uint8_t *p, *end;
     uint64_t acc; int nbits;
     int hit_marker; /* marker code seen (0 = none) */
+    /* libjpeg jdhuff.c "insufficient_data": once the decoder has CONSUMED more bits than the segment holds (zeros are fed
+       for the rest of that MCU), every following MCU up to the next restart is skipped, i.e. left as it is (zero blocks
+       in a sequential or first scan).  `real` = bits of acc that came from the file. */
+    int real, insufficient;
 } breader;
 
 static void br_fill(breader *b) {
@@ -133,13 +137,14 @@ static void br_fill(breader *b) {
                     c = 0;
                 }
             } else b->p++;
+            if (!b->hit_marker) b->real += 8;
         }
         b->acc |= (uint64_t)c << (56 - b->nbits);
         b->nbits += 8;
     }
 }
 static inline int br_peek(breader *b, int n) { if (b->nbits < n) br_fill(b); return (int)(b->acc >> (64 - n)); }
-static inline void br_skip(breader *b, int n) { b->acc <<= n; b->nbits -= n; }
+static inline void br_skip(breader *b, int n) { b->acc <<= n; b->nbits -= n; if (n > b->real) { b->insufficient = 1; b->real = 0; } else b->real -= n; }
 static inline int br_get(breader *b, int n) { if (n == 0) return 0; int v = br_peek(b, n); br_skip(b, n); return v; }
 static inline int hdecode(breader *b, const dhuff *h) {
     int v = br_peek(b, 16);
@@ -238,12 +243,12 @@ static void dec_block_ac_refine(sdec *s, int16_t *blk) {
 static void dec_restart(sdec *s) {
     breader *b = &s->br;
     /* discard partial byte + any fill, then consume RSTn */
-    b->acc = 0; b->nbits = 0;
-    if (b->hit_marker >= 0xD0 && b->hit_marker <= 0xD7) { b->p += 2; b->hit_marker = 0; }
+    b->acc = 0; b->nbits = 0; b->real = 0;
+    if (b->hit_marker >= 0xD0 && b->hit_marker <= 0xD7) { b->p += 2; b->hit_marker = 0; b->insufficient = 0; }
     else {
         /* bit reader may not have touched the marker yet: scan forward */
         while (b->p + 1 < b->end && !(b->p[0] == 0xFF && b->p[1] >= 0xD0 && b->p[1] <= 0xD7)) b->p++;
-        if (b->p + 1 < b->end) b->p += 2;
+        if (b->p + 1 < b->end) { b->p += 2; b->insufficient = 0; }
     }
     for (int i = 0; i < CSO_MAX_COMPS; i++) s->pred[i] = 0;
     s->eobrun = 0;
@@ -271,6 +276,7 @@ static int decode_scan(cso_image *im, const cso_scan *sc, dhuff dctab[4], dhuff 
         for (int by = 0; by < k->real_bh; by++)
             for (int bx = 0; bx < k->real_bw; bx++) {
                 if (ri) { if (todo == 0) { dec_restart(&s); todo = ri; } todo--; }
+                if (s.br.insufficient) continue;
                 int16_t *blk = k->coef + ((size_t)by * k->bw + bx) * 64;
                 if (!im->progressive) dec_block_seq(&s, 0, blk);
                 else if (dc_scan) { if (sc->Ah == 0) dec_block_dc_first(&s, 0, blk); else dec_block_dc_refine(&s, blk); }
@@ -280,6 +286,7 @@ static int decode_scan(cso_image *im, const cso_scan *sc, dhuff dctab[4], dhuff 
         for (int my = 0; my < im->mcus_y; my++)
             for (int mx = 0; mx < im->mcus_x; mx++) {
                 if (ri) { if (todo == 0) { dec_restart(&s); todo = ri; } todo--; }
+                if (s.br.insufficient) continue;
                 for (int i = 0; i < sc->ncomp_in_scan; i++) {
                     cso_comp *k = &im->comp[sc->comp_idx[i]];
                     for (int y = 0; y < k->v; y++)

@@ -100,6 +100,23 @@ def test_lossless_transcode_invariants():
     assert np.array_equal(a.pixels(), b.pixels())
 
 
+def test_truncated_sequential_streams_equal_libjpeg_turbo():
+    """libjpeg's insufficient-data rule (jdhuff.c): the MCU in which the data runs out is finished on zero bits, every later
+    MCU up to the next restart marker stays zero.  (Progressive files cut short are NOT pinned: libjpeg then also applies
+    inter-block smoothing, which this oracle does not restate.)"""
+    from PIL import ImageFile
+    old = ImageFile.LOAD_TRUNCATED_IMAGES
+    ImageFile.LOAD_TRUNCATED_IMAGES = True
+    try:
+        for kw in ({}, {"restart_rows": 1}, {"subsampling": 0}, {"subsampling": 1}, {"optimize": True}):
+            src = synth_jpeg(3, 200, 150, texture=30, **kw)
+            for frac in (0.3, 0.5, 0.66, 0.9, 0.99):
+                cut = src[:int(len(src) * frac)] + b"\xff\xd9"
+                assert np.array_equal(O.decode(cut).pixels(), pil_ycc(cut)), (kw, frac)
+    finally:
+        ImageFile.LOAD_TRUNCATED_IMAGES = old
+
+
 def test_bad_inputs_fail_cleanly():
     with pytest.raises(O.OracleError):
         O.decode(b"")

@@ -229,6 +229,23 @@ def test_emul_worst_case_concurrency_and_shared_tables(api):
         assert out == oracle_lossy(src)
 
 
+def test_emul_streams_cut_short(api):
+    """files cut at many points, sequential / restart-interval / progressive: whatever path takes them (parallel decoder with
+    hand-over, wave-per-chain, sequential kernel) the bytes are the oracle's, which follows libjpeg's insufficient-data rule"""
+    blobs = []
+    for kw in ({}, {"restart_rows": 1}, {"progressive": True}, {"subsampling": 0, "optimize": True}):
+        src = synth_jpeg(6, 160, 120, texture=30, **kw)
+        start = src.index(b"\xff\xda") + 14
+        for frac in (0.02, 0.31, 0.5, 0.77, 0.97):
+            n = start + int((len(src) - start) * frac)
+            blobs += [src[:n] + b"\xff\xd9", src[:n + 1]]
+    for lossless in (False, True):
+        outs = api.batch_compress(blobs, params(jpeg_optimize=lossless))
+        for i, (src, out) in enumerate(zip(blobs, outs)):
+            assert not isinstance(out, Exception), (i, out)
+            assert out == (oracle_lossless(src) if lossless else oracle_lossy(src)), i
+
+
 def test_emul_truncated_stream_falls_back_and_matches_sequential_semantics(api):
     src = synth_jpeg(3, 200, 150, texture=30)
     cut = src[:len(src) * 2 // 3] + b"\xff\xd9"

@@ -104,6 +104,10 @@ def test_blocks_longer_than_a_subsequence(api):
     E.test_emul_blocks_longer_than_a_subsequence(api)
 
 
+def test_streams_cut_short(api):
+    E.test_emul_streams_cut_short(api)
+
+
 def test_restart_intervals_decode_in_parallel(api):
     E.test_emul_restart_intervals_decode_in_parallel(api)
 
