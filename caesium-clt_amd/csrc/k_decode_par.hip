@@ -219,10 +219,17 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     const uint16_t *sub = reinterpret_cast<const uint16_t *>(hb + sub_off);
     uint32_t mcu = 0; int mx = 0, my = 0;
     bool in_range = false;
-    auto word = [&](uint32_t wi) -> uint32_t { return rd.word(wi - w0); };
+    // (write pass: a lane finishing the MCU in which the data ran out may walk past its window; everything there is zero bits)
+    auto word = [&](uint32_t wi) -> uint32_t { const uint32_t r = wi - w0; return (WRITE && r >= CSH_LROW_WORDS) ? 0u : rd.word(r); };
+    // libjpeg's insufficient-data rule (jdhuff.c): the MCU in which the data runs out is finished on zero bits (the LDS window
+    // holds zeros past the end), every later MCU of the segment stays zero.  cut_mcu = that MCU, once a block has ended past
+    // the last real bit; blocks of later MCUs are decoded (to keep walking) but not stored.  The lane in which the data runs out
+    // finishes that MCU even past its own cut (the loop condition below); a lane that STARTS past the data stores nothing.
+    uint32_t cut_mcu = 0xFFFFFFFFu;
+    const bool dead = WRITE && st.pos > cx.real_bits;
     auto locate = [&](int m) {
         // 24-bit multiplies: the host sends scans of >= 2^24 blocks to the sequential decoder
-        in_range = __umul24(mcu, uint32_t(cx.nb_mcu)) + uint32_t(m) < cx.total_blocks;
+        in_range = __umul24(mcu, uint32_t(cx.nb_mcu)) + uint32_t(m) < cx.total_blocks && mcu <= cut_mcu && !dead;
         const ParBlockInfo g = bi[m];
         blk = coef + coef_index(g.tile_base, __mul24(my, g.row_step) + __mul24(mx, g.col_step) + g.first, 0);
         dcp = dcdiff + (__umul24(mcu, g.dc_per_mcu) + g.dc_first);
@@ -234,7 +241,6 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     // coefficient cost the memory system a 32-byte sector write each (2.4x the planes in HBM write traffic).  An octet that
     // this lane may share with a neighbouring lane (the block it entered half-way: the octet of its entry position; the block
     // it leaves unfinished: the octet still pending at the exit) is written coefficient by coefficient instead.
-    uint32_t ok_blk = 0;
     int cur_oct = -1, shared_oct = k > 0 ? (k >> 3) : -1;
     uint64_t olo = 0, ohi = 0;
     auto flush = [&](bool piecewise) {
@@ -258,7 +264,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     uint64_t acc = ((uint64_t(word(wi - 2)) << 32) | word(wi - 1)) << (pos & 31);
     int nb = 64 - int(pos & 31);
     uint32_t nxt = word(wi);
-    while (pos < stop_bit) {
+    auto step = [&]() {
         const uint32_t w = uint32_t(acc >> 32), top16 = w >> 16;
         const bool isdc = k == 0;
         uint32_t e = *reinterpret_cast<const uint16_t *>(hb + (isdc ? dco : aco) + ((top16 >> 7) << 1));
@@ -293,7 +299,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
             if (WRITE) { if (cur_oct >= 0) flush(cur_oct == shared_oct); shared_oct = -1; }
             k = 0;
             nblk++;
-            if (WRITE) ok_blk = pos <= cx.real_bits ? nblk : ok_blk;   // blocks finished on bits the file really holds
+            if (WRITE) cut_mcu = (pos > cx.real_bits && mcu < cut_mcu) ? mcu : cut_mcu;
             const bool wrap = m + 1 == cx.nb_mcu;
             m = wrap ? 0 : m + 1;
             tables(m);
@@ -302,13 +308,16 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
                 locate(m);
             }
         }
-    }
+    };
+    while (pos < stop_bit) step();
+    // the lane in which the data ran out finishes that MCU (if the frame needs it) past its own cut: nobody else will, the
+    // next lanes are beyond the data.  (A separate loop: this condition inside the hot loop doubled the kernel's time.)
+    if (WRITE && !dead)
+        while (pos > cx.real_bits && (k != 0 || m != 0) && __umul24(mcu, uint32_t(cx.nb_mcu)) < cx.total_blocks) step();
     if (WRITE && cur_oct >= 0) flush(true);   // unfinished block: the next lane may add to this octet
     st.pos = pos; st.k = k; st.m = m;
-    // WRITE: did a block the frame needs take bits from beyond the data?  (the first block not finished on real bits is block
-    // ordinal + ok_blk.)  libjpeg's insufficient-data rule then decides what the following MCUs hold, and only the sequential
-    // kernel implements it -- the caller hands the image over.
-    return WRITE ? uint32_t(pos > cx.real_bits && ordinal + ok_blk < cx.total_blocks) : nblk;
+    // WRITE: first block ordinal (relative to the segment) that stays zero because the data ran out, or 0xFFFFFFFF
+    return WRITE ? ((cut_mcu == 0xFFFFFFFFu || dead) ? 0xFFFFFFFFu : (cut_mcu + 1u) * uint32_t(cx.nb_mcu)) : nblk;
 }
 
 // pass B: relaxation  s[t+1] = F_t(s[t]), in place.  Only the lane of sub-sequence t-1 ever writes s[t]; whenever it
@@ -473,19 +482,19 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
         } else {
             if (a.need_seq[ps.image]) continue;
             uint32_t ordinal = uint32_t(a.blk_off[ps.sub_base + t] - a.blk_off[ps.sub_base]);
-            if (t == nsub - 1 || (live && (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len)) {  // the scan must have produced all its blocks
-                uint32_t total = uint32_t(a.blk_off[ps.sub_base + nsub] - a.blk_off[ps.sub_base]);
-                if (total < ps.total_blocks) a.need_seq[ps.image] = 3;
-            }
+            // a segment that yields fewer blocks than the frame needs has run out of data: its remaining blocks stay zero
+            // (cut_block, set by the lane that crossed the end; k_dc_scatter gives those blocks a zero DC as well)
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            if (decode_span<true>(rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff)) a.need_seq[ps.image] = 3;
+            const uint32_t cut = decode_span<true>(rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
+            if (cut != 0xFFFFFFFFu) atomicMin(&a.cut_block[ps.par_index], cut);
         }
     }
 }
 
 // DC: prefix sums of the differences (scan order) -> absolute DC at zig-zag row 0 of the tiles
-__global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef, const uint32_t *need_seq) {
+__global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef, const uint32_t *need_seq,
+                                                     const uint32_t *cut_block) {
     const ParScan &ps = pss[blockIdx.y];
     if (need_seq[ps.image]) return;
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;  // block ordinal in scan order
@@ -501,6 +510,7 @@ __global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const Im
     uint32_t idx = ps.dc_base[m] + mcu * ps.dc_per_mcu[m] + ps.dc_idx[m];
     // inclusive prefix over this component's differences (two's-complement wrap-around is harmless)
     uint32_t v = uint32_t(dc_off[idx + 1] - dc_off[ps.dc_base[m]]);
+    if (j >= cut_block[blockIdx.y]) v = 0;   // MCUs after the one in which the data ran out hold zeros, DC included
     coef[coef_index(g.tile_base, by * g.bw + bx, 0)] = int16_t(int32_t(v));
 }
 
@@ -547,8 +557,8 @@ void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *stat
     if (nps) CSH_LAUNCH(k_dec_chain, dim3((nps + 63) / 64), dim3(64), st, ps, nps, state, nblk, hyp, scan_pending, need_seq);
 }
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
-                       const uint32_t *need_seq) {
-    if (nps && max_blocks) CSH_LAUNCH(k_dc_scatter, dim3((max_blocks + 255) / 256, nps), dim3(256), st, ps, imgs, dc_off, coef, need_seq);
+                       const uint32_t *need_seq, const uint32_t *cut_block) {
+    if (nps && max_blocks) CSH_LAUNCH(k_dc_scatter, dim3((max_blocks + 255) / 256, nps), dim3(256), st, ps, imgs, dc_off, coef, need_seq, cut_block);
 }
 
 }  // namespace csh

@@ -23,6 +23,7 @@ struct DenseArgs {
     uint64_t *state; uint32_t *nblk; uint64_t *list_out; uint32_t *cnt_out;           // relax
     uint16_t *hyp; const uint32_t *scan_pending;                                       // label hypotheses (mode 3)
     const uint64_t *blk_off; const ImgDesc *imgs; int16_t *coef; int32_t *dcdiff; uint32_t *need_seq;  // write
+    uint32_t *cut_block;   // per segment: first block that stays zero because the data ran out (0xFFFFFFFF: none), write pass -> k_dc_scatter
 };
 void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const void *huffs, int compact, uint64_t *state, uint32_t *nblk,
@@ -33,7 +34,7 @@ void launch_decode_prog(hipStream_t st, const uint8_t *clean, const ParScan *pss
 void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending);
 void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq);
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
-                       const uint32_t *need_seq);
+                       const uint32_t *need_seq, const uint32_t *cut_block);
 
 // ---- phase 1: pixel-domain transcode (k_pixel.hip)
 // direct: dequant -> jidctint -> range limit -> jfdctint -> quantise, one block per lane

@@ -227,7 +227,7 @@ struct csh_batch {
     DevBuf<uint8_t> d_bits, d_clean, d_planes, d_oplanes, d_hdr, d_out, d_tail;
     DevBuf<ParScan> d_pscans;
     DevBuf<uint64_t> d_pstate, d_relax_list[2], d_unstuff_off, d_blk_off, d_dc_off;
-    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt, d_scan_pending;
+    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt, d_scan_pending, d_cut_block;
     DevBuf<uint16_t> d_hyp;
     DevBuf<int32_t> d_dcdiff;
     DevBuf<ImgDesc> d_imgs;
@@ -856,7 +856,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         {
             size_t nchunks = b->bits_pool.size() / 64 + 1, nst = size_t(b->total_sub) + b->pscans.size() + 1;
             if (b->d_clean.alloc(b->bits_pool.size() + 64) || b->d_unstuff_cnt.alloc(nchunks + 1) || b->d_unstuff_off.alloc(nchunks + 2) ||
-                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(64) || b->d_scan_pending.alloc(b->pscans.size() + 1) || b->d_hyp.alloc((size_t(b->total_sub) + 1) * 10) ||
+                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(64) || b->d_scan_pending.alloc(b->pscans.size() + 1) || b->d_cut_block.alloc(b->pscans.size() + 1) || b->d_hyp.alloc((size_t(b->total_sub) + 1) * 10) ||
                 b->d_nblk.alloc(size_t(b->total_sub) + 1) || b->d_blk_off.alloc(size_t(b->total_sub) + 2) || b->d_need_seq.alloc(b->nimg + 1) ||
                 b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2))
                 return CS_ERR_NO_DEVICE;
@@ -927,7 +927,8 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         memset(&da, 0, sizeof da);
         da.clean = b->d_clean.p; da.pss = b->d_pscans.p; da.huffs = b->use4 ? static_cast<const void *>(b->d_phsets4.p) : static_cast<const void *>(b->d_phsets.p); da.compact = b->use4 ? 1 : 0; da.state = b->d_pstate.p; da.nblk = b->d_nblk.p;
         da.list_out = b->d_relax_list[0].p; da.cnt_out = b->d_relax_cnt.p; da.blk_off = b->d_blk_off.p; da.imgs = b->d_imgs.p;
-        da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p;
+        da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p; da.cut_block = b->d_cut_block.p;
+        CSH_CHECK(hipMemsetAsync(b->d_cut_block.p, 0xFF, b->d_cut_block.n * sizeof(uint32_t), st));
         launch_dec_dense(st, 0, nps, b->max_sub, da);
         MARK();
         const int R = 40;  // list rounds after the dense one.  Stock tables settle in ~9 (a converged round is a near-empty launch, ~6 us), but with
@@ -951,7 +952,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         launch_dec_dense(st, 2, nps, b->max_sub, da);
         MARK();
         if (nps) launch_exclusive_scan(st, reinterpret_cast<uint32_t *>(b->d_dcdiff.p), b->d_dc_off.p, b->dc_total, b->d_scan_tmp.p, b->d_scan_tmp.n);
-        launch_dc_scatter(st, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_dc_off.p, b->d_coef.p, b->d_need_seq.p);
+        launch_dc_scatter(st, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_dc_off.p, b->d_coef.p, b->d_need_seq.p, b->d_cut_block.p);
         MARK();
     }
     launch_decode_prog(st, b->d_clean.p, b->d_pscans.p, b->d_phsets.p, b->d_dscans.p, b->d_chains.p, b->d_chain_scans.p, int(b->chains.size()), b->d_imgs.p,

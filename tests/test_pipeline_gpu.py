@@ -178,8 +178,8 @@ def test_parallel_decoder_is_the_path_taken(api):
     E.test_emul_parallel_decoder_is_the_path_taken(api)
 
 
-def test_truncated_stream_falls_back(api):
-    E.test_emul_truncated_stream_falls_back_and_matches_sequential_semantics(api)
+def test_truncated_stream_stays_on_the_parallel_decoder(api):
+    E.test_emul_truncated_stream_stays_on_the_parallel_decoder(api)
 
 
 def test_batch_size_targeting_and_requant_equivalence(api):
