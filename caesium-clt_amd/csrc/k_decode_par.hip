@@ -330,9 +330,20 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
 // 512 lanes per workgroup: 70 KiB of windows + the table set + 4 KiB of lane descriptors = two workgroups = 16 waves per CU
 // (with 256 lanes the table set is paid twice as often and only 12 waves fit)
 #define CSH_LIST_LANES 512
+// A lane whose result changes s[t+1] does not just list t+1 for the next launch: it walks on into t+1 itself (up to
+// CSH_LIST_WALK sub-sequences), because with long blocks (high-quality sources: 50+ bytes per block) a wrong state survives
+// ~90 % of the sub-sequences it crosses and one cut per launch would need a hundred launches.  claim[t] = number of the
+// launch in which somebody took sub-sequence t: whoever exchanges it first evaluates t in this launch -- a listed lane that
+// finds it taken stands down (the walker that took it carries the newest s[t]), a walker that finds it taken lists it for
+// the next launch as before (the owner may have read s[t] before it changed).  So each s[t+1] still has one writer per launch
+// and every change of s[t] is followed by a fresh evaluation of t: the fixed-point argument above is untouched.
+// Walking only starts once the list is short or old (count < walk_below, see the launcher): in the first rounds nearly every
+// wave would have a walker and wait for it (measured: the list rounds of the bench workload took twice as long).
+#define CSH_LIST_WALK 8
 template <class SET>
 __global__ void __launch_bounds__(CSH_LIST_LANES) k_dec_relax_list(const uint8_t *clean, const ParScan *pss, const SET *huffs, uint64_t *state, const uint64_t *state_rd,
-                                                         uint32_t *nblk, const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out) {
+                                                         uint32_t *nblk, const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out,
+                                                         uint32_t *claim, uint32_t epoch, uint32_t walk_below) {
     CSH_SHARED uint32_t lbits[CSH_LIST_LANES * CSH_LROW_STRIDE];
     CSH_SHARED SET lhs;
     CSH_SHARED uint32_t d_scan[CSH_LIST_LANES], d_t[CSH_LIST_LANES];   // per lane: ParScan index (0xFFFFFFFF = idle), sub-sequence
@@ -342,7 +353,10 @@ __global__ void __launch_bounds__(CSH_LIST_LANES) k_dec_relax_list(const uint8_t
         if (j0 >= count) continue;   // whole workgroup idle (uniform)
         if (phase == 0) {
             uint32_t si = 0xFFFFFFFFu, t = 0;
-            if (j < count) { uint64_t e = list_in[j]; si = uint32_t(e >> 32); t = uint32_t(e); }
+            if (j < count) {
+                uint64_t e = list_in[j]; si = uint32_t(e >> 32); t = uint32_t(e);
+                if (atomicExch(&claim[pss[si].sub_base + t], epoch) == epoch) si = 0xFFFFFFFFu;   // a walker of this launch already has it
+            }
             d_scan[tid] = si; d_t[tid] = t;
             // the first entry's Huffman set is staged; lanes with another set read theirs from global memory
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&huffs[pss[uint32_t(list_in[j0] >> 32)].huff_set]);
@@ -361,22 +375,32 @@ __global__ void __launch_bounds__(CSH_LIST_LANES) k_dec_relax_list(const uint8_t
             }
             continue;
         }
-        if (j >= count) continue;
+        if (j >= count || d_scan[tid] == 0xFFFFFFFFu) continue;
         const ParScan &ps = pss[d_scan[tid]];
-        const uint32_t t = d_t[tid];
-        size_t base = ps.sub_base + ps.par_index;
+        uint32_t t = d_t[tid];
+        const size_t base = ps.sub_base + ps.par_index;
         PState st = unpack_state(state_rd[base + t]);
-        RowReader rd; rd.row = lbits + tid * CSH_LROW_STRIDE;
-        const uint32_t w0 = t * (CSH_SUBSEQ_BYTES / 4), stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
-        uint32_t n;
+        uint32_t *row = lbits + tid * CSH_LROW_STRIDE;
+        RowReader rd; rd.row = row;
         const ParCtx cx = make_ctx(ps, nullptr);
-        const uint8_t *hb = ps.huff_set == pss[d_scan[0]].huff_set ? reinterpret_cast<const uint8_t *>(&lhs) : reinterpret_cast<const uint8_t *>(&huffs[ps.huff_set]);
-        n = decode_span<false>(rd, w0, hb, uint32_t(sizeof(SET::root)), cx, st, stop, 0, nullptr, nullptr, nullptr);
-        nblk[ps.sub_base + t] = n;
-        uint64_t e = pack_state(st);
-        if (e != state[base + t + 1]) {
+        const int staged_set = pss[uint32_t(list_in[j0] >> 32)].huff_set;
+        const uint8_t *hb = ps.huff_set == staged_set ? reinterpret_cast<const uint8_t *>(&lhs) : reinterpret_cast<const uint8_t *>(&huffs[ps.huff_set]);
+        PReader g; g.base = clean + ps.bits_off; g.len = ps.clean_len;
+        for (int step = 0;; step++) {
+            const uint32_t w0 = t * (CSH_SUBSEQ_BYTES / 4), stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
+            const uint32_t n = decode_span<false>(rd, w0, hb, uint32_t(sizeof(SET::root)), cx, st, stop, 0, nullptr, nullptr, nullptr);
+            nblk[ps.sub_base + t] = n;
+            const uint64_t e = pack_state(st);
+            if (e == state[base + t + 1]) break;                            // in step with what is recorded: nothing downstream changes
             state[base + t + 1] = e;
-            if ((t + 1) * CSH_SUBSEQ_BYTES < ps.clean_len) list_out[atomicAdd(cnt_out, 1u)] = (uint64_t(ps.par_index) << 32) | (t + 1);
+            if ((t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len) break;          // past the data
+            if (count < walk_below && step + 1 < CSH_LIST_WALK && atomicExch(&claim[ps.sub_base + t + 1], epoch) != epoch) {
+                t++;                                                         // walk on: this lane's own row is refilled by the lane itself
+                for (uint32_t i = 0; i < CSH_LROW_WORDS; i++) row[i] = g.word(t * (CSH_SUBSEQ_BYTES / 4) + i);
+                continue;
+            }
+            list_out[atomicAdd(cnt_out, 1u)] = (uint64_t(ps.par_index) << 32) | (t + 1);
+            break;
         }
     }
 }
@@ -535,7 +559,11 @@ void launch_dec_dense(hipStream_t st, int mode, int nps, uint32_t max_sub, const
 int csh_emul_jacobi = 0;  // tests: make a list round read the states as they were BEFORE the launch (what concurrent lanes see at worst)
 #endif
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const void *huffs, int compact, uint64_t *state, uint32_t *nblk,
-                           const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate) {
+                           const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate, uint32_t *claim, uint32_t epoch) {
+    // walking starts when the list is down to 0.1 % of the sub-sequences, or after ten launches whatever its size: files of
+    // ordinary quality are through by then (their lists shrink by 60 % a launch and walking would only make their waves wait
+    // for the walkers), what is left is slow-to-synchronise data that needs it
+    const uint32_t walk_below = epoch > 10 ? 0xFFFFFFFFu : total_sub / 1024 + 1;
     if (!total_sub) return;
     const uint64_t *state_rd = state;
 #ifdef CSH_EMUL
@@ -544,8 +572,8 @@ void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *
 #else
     (void)nstate;
 #endif
-    if (compact) CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet4>, 3, dim3((total_sub + CSH_LIST_LANES - 1) / CSH_LIST_LANES), dim3(CSH_LIST_LANES), st, clean, ps, static_cast<const ParHuffSet4 *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
-    else CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet>, 3, dim3((total_sub + CSH_LIST_LANES - 1) / CSH_LIST_LANES), dim3(CSH_LIST_LANES), st, clean, ps, static_cast<const ParHuffSet *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out);
+    if (compact) CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet4>, 3, dim3((total_sub + CSH_LIST_LANES - 1) / CSH_LIST_LANES), dim3(CSH_LIST_LANES), st, clean, ps, static_cast<const ParHuffSet4 *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out, claim, epoch, walk_below);
+    else CSH_LAUNCH_PHASED(k_dec_relax_list<ParHuffSet>, 3, dim3((total_sub + CSH_LIST_LANES - 1) / CSH_LIST_LANES), dim3(CSH_LIST_LANES), st, clean, ps, static_cast<const ParHuffSet *>(huffs), state, state_rd, nblk, list_in, cnt_in, list_out, cnt_out, claim, epoch, walk_below);
 #ifdef CSH_EMUL
     free(snap);
 #endif

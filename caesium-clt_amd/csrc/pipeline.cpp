@@ -227,7 +227,7 @@ struct csh_batch {
     DevBuf<uint8_t> d_bits, d_clean, d_planes, d_oplanes, d_hdr, d_out, d_tail;
     DevBuf<ParScan> d_pscans;
     DevBuf<uint64_t> d_pstate, d_relax_list[2], d_unstuff_off, d_blk_off, d_dc_off;
-    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt, d_scan_pending, d_cut_block;
+    DevBuf<uint32_t> d_unstuff_cnt, d_nblk, d_need_seq, d_need_seq_init, d_relax_cnt, d_scan_pending, d_cut_block, d_claim;
     DevBuf<uint16_t> d_hyp;
     DevBuf<int32_t> d_dcdiff;
     DevBuf<ImgDesc> d_imgs;
@@ -856,7 +856,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         {
             size_t nchunks = b->bits_pool.size() / 64 + 1, nst = size_t(b->total_sub) + b->pscans.size() + 1;
             if (b->d_clean.alloc(b->bits_pool.size() + 64) || b->d_unstuff_cnt.alloc(nchunks + 1) || b->d_unstuff_off.alloc(nchunks + 2) ||
-                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(64) || b->d_scan_pending.alloc(b->pscans.size() + 1) || b->d_cut_block.alloc(b->pscans.size() + 1) || b->d_hyp.alloc((size_t(b->total_sub) + 1) * 10) ||
+                b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(512) || b->d_scan_pending.alloc(b->pscans.size() + 1) || b->d_cut_block.alloc(b->pscans.size() + 1) || b->d_claim.alloc(size_t(b->total_sub) + 1) || b->d_hyp.alloc((size_t(b->total_sub) + 1) * 10) ||
                 b->d_nblk.alloc(size_t(b->total_sub) + 1) || b->d_blk_off.alloc(size_t(b->total_sub) + 2) || b->d_need_seq.alloc(b->nimg + 1) ||
                 b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2))
                 return CS_ERR_NO_DEVICE;
@@ -931,15 +931,26 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         CSH_CHECK(hipMemsetAsync(b->d_cut_block.p, 0xFF, b->d_cut_block.n * sizeof(uint32_t), st));
         launch_dec_dense(st, 0, nps, b->max_sub, da);
         MARK();
-        const int R = 40;  // list rounds after the dense one.  Stock tables settle in ~9 (a converged round is a near-empty launch, ~6 us), but with
-                           // similar luma/chroma tables positions keep moving for 30+ rounds before only the label creeps (the hypothesis chain
-                           // below needs settled positions): 20 rounds sent such a file to the sequential kernel
         if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
+        if (nps && b->d_claim.zero(st)) return -1;
         launch_dec_dense(st, 1, nps, b->max_sub, da);
         MARK();
-        for (int it = 0; it < R && nps; it++)
-            launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, da.huffs, da.compact, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[it & 1].p,
-                                  b->d_relax_cnt.p + it, b->d_relax_list[(it & 1) ^ 1].p, b->d_relax_cnt.p + it + 1, b->d_pstate.n);
+        // list rounds until the list is empty.  How many that takes depends on the data: stock tables at ordinary quality settle
+        // in ~8 (the list shrinks by 60 % a round), 50 bytes per block in ~30, 85 bytes per block in more than a hundred (a
+        // wrong state then survives most of the cuts it crosses) -- so the host looks at the list length after 12 rounds and
+        // then after every 8 (a 4-byte read-back; an empty round is a ~6 us launch), up to kMaxRounds.  What is still listed
+        // after that goes through the label chain below or to the sequential kernel.
+        const int kMaxRounds = int(b->d_relax_cnt.n) - 2;
+        int R = 0;
+        for (int group = 12; nps && R < kMaxRounds; group = 8) {
+            for (int g = 0; g < group && R < kMaxRounds; g++, R++)
+                launch_dec_relax_list(st, b->d_clean.p, b->d_pscans.p, b->total_sub, da.huffs, da.compact, b->d_pstate.p, b->d_nblk.p, b->d_relax_list[R & 1].p,
+                                      b->d_relax_cnt.p + R, b->d_relax_list[(R & 1) ^ 1].p, b->d_relax_cnt.p + R + 1, b->d_pstate.n, b->d_claim.p, uint32_t(R + 1));
+            uint32_t left = 0;
+            CSH_CHECK(hipMemcpyAsync(&left, b->d_relax_cnt.p + R, sizeof left, hipMemcpyDeviceToHost, st));
+            CSH_CHECK(hipStreamSynchronize(st));
+            if (!left) break;
+        }
         if (nps) {   // scans that are still listed: settle their block-in-MCU labels exactly (k_dec_chain), or hand the image to k_decode_seq
             if (b->d_scan_pending.zero(st)) return -1;
             launch_dec_mark_pending(st, b->d_pscans.p, b->total_sub, b->d_relax_list[R & 1].p, b->d_relax_cnt.p + R, b->d_scan_pending.p);
@@ -1110,6 +1121,14 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
     if (t) {
         std::vector<uint32_t> ns(b->nimg);
         if (hipMemcpy(ns.data(), b->d_need_seq.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
+        if (getenv("CSH_TRACE") && b->d_relax_cnt.n) {   // sub-sequences re-listed after each relaxation round
+            std::vector<uint32_t> rc(b->d_relax_cnt.n);
+            if (hipMemcpy(rc.data(), b->d_relax_cnt.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[csh] relax list sizes (of %u sub-sequences):", b->total_sub);
+                for (size_t i = 0; i < rc.size() && (i < 16 || rc[i]); i++) fprintf(stderr, " %u", rc[i]);
+                fprintf(stderr, "\n");
+            }
+        }
         for (uint32_t v : ns) { if (v == 4) { t->n_prog_decoded++; continue; } if (v) t->n_seq_decoded++; if (v == 2 || v == 3) t->n_par_fallback++; if (v == 3) t->n_par_short++; }
         t->n_images = uint32_t(b->nimg);
         for (const Item &it : b->items) if (it.image < 0) t->n_failed++;
