@@ -109,8 +109,51 @@ __global__ void __launch_bounds__(256) k_ac_flags(EncCtx c) {
 }
 
 // ---- pass B: EOB run structure -> EOBRUN value owned by the first block of each (sub-)run
+// A run [u .. t] is cut into sub-runs as jcphuff.c does: after 0x7FFF blocks, and (refinement) as soon as more than
+// MAX_CORR_BITS - DCTSIZE2 + 1 = 937 correction bits are pending.  Serial form (short runs, and the emulation build):
+__device__ static void eob_run_serial(const EncCtx &c, const ScanWork &w, const EncScan &sc, uint32_t u, uint32_t t) {
+    uint16_t *er = c.eobrun + w.unit_base;
+    if (sc.Ah == 0) {
+        uint32_t L = t - u + 1, pos = u;
+        while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); pos += l; L -= l; }
+        return;
+    }
+    const uint8_t *tl = c.tail + w.unit_base;
+    uint32_t cnt = 0, be = 0, s0 = u;
+    auto step = [&](uint32_t j, uint32_t tail_bits) {
+        cnt++; be += tail_bits;
+        if (cnt == 0x7FFF || be > 937) { er[s0] = uint16_t(cnt); cnt = 0; be = 0; s0 = j + 1; }
+    };
+    uint32_t j = u;
+    while (j <= t && (reinterpret_cast<uintptr_t>(tl + j) & 7)) { step(j, tl[j]); j++; }
+    for (; j + 7 <= t; j += 8) {
+        const uint64_t v = *reinterpret_cast<const uint64_t *>(tl + j);
+        CSH_UNROLL
+        for (int i = 0; i < 8; i++) step(j + i, uint32_t(v >> (8 * i)) & 255u);
+    }
+    for (; j <= t; j++) step(j, tl[j]);
+    if (cnt) er[s0] = uint16_t(cnt);
+}
+// last block of the run that starts at u: the block before the next one that carries a symbol.  Looks at most `max_words`
+// words of the has-symbol vector ahead; returns false if the end lies further on.
+__device__ static bool eob_run_end(const uint64_t *sym, uint32_t nunits, uint32_t u, uint32_t max_words, uint32_t &t) {
+    t = nunits - 1;
+    uint32_t i = u + 1;
+    const uint32_t nwords = (nunits + 63) >> 6;
+    for (uint32_t n = 0; i < nunits; n++) {
+        if (n == max_words) return false;
+        uint32_t wi = i >> 6;
+        uint64_t bits = sym[wi] & (~0ull << (i & 63));
+        if (bits) { uint32_t p = (wi << 6) + uint32_t(__ffsll((unsigned long long)bits) - 1); if (p < nunits) t = p - 1; return true; }
+        i = (wi + 1) << 6;
+        if (wi + 1 >= nwords) break;
+    }
+    return true;
+}
+#define CSH_LONG_RUN_WORDS 8   // a run whose end is not within 8 words (512 blocks) goes to k_ac_runs_long: one WAVE per run
 __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
-    const ScanWork w = c.work[c.chunk_work[blockIdx.x]];
+    const uint32_t wi = c.chunk_work[blockIdx.x];
+    const ScanWork w = c.work[wi];
     const EncScan &sc = c.script[w.scan];
     if (sc.Ss == 0) return;
     uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
@@ -119,41 +162,65 @@ __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
     if (!get_bit(eob, u)) return;
     bool start = get_bit(sym, u) || u == 0 || !get_bit(eob, u - 1);
     if (!start) return;
-    // run = [u .. t], t = last block before the next block that carries a symbol
-    uint32_t t = w.nunits - 1;
-    {
-        uint32_t i = u + 1;
-        uint32_t nwords = (w.nunits + 63) >> 6;
-        while (i < w.nunits) {
-            uint32_t wi = i >> 6;
-            uint64_t bits = sym[wi] & (~0ull << (i & 63));
-            if (bits) { uint32_t p = (wi << 6) + uint32_t(__ffsll((unsigned long long)bits) - 1); if (p < w.nunits) t = p - 1; break; }
-            i = (wi + 1) << 6;
-            if (wi + 1 >= nwords) break;
+    uint32_t t;
+    if (eob_run_end(sym, w.nunits, u, CSH_LONG_RUN_WORDS, t)) eob_run_serial(c, w, sc, u, t);
+    else { uint32_t e = atomicAdd(c.long_cnt, 1u); c.long_runs[2 * e] = wi; c.long_runs[2 * e + 1] = u; }
+}
+// long runs (flat regions, low-quality sources: a run can span a whole scan of 32 k blocks, and a single lane walking it held
+// the kernel for a millisecond): the 64 lanes look for the end 4096 blocks at a time and cut the run 64 blocks at a time
+// (wave prefix sum of the pending correction bits; the first lane over a limit ends the sub-run).
+__global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
+    const uint32_t n = *c.long_cnt;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const ScanWork w = c.work[c.long_runs[2 * e]];
+        const EncScan &sc = c.script[w.scan];
+        const uint32_t u = c.long_runs[2 * e + 1];
+        const uint64_t *sym = c.sym_bits + w.word_base;
+#ifdef CSH_EMUL
+        uint32_t t;
+        eob_run_end(sym, w.nunits, u, 0xFFFFFFFFu, t);
+        eob_run_serial(c, w, sc, u, t);
+#else
+        const uint32_t lane = threadIdx.x, nwords = (w.nunits + 63) >> 6;
+        uint32_t t = w.nunits - 1;
+        for (uint32_t w0 = (u + 1) >> 6; w0 < nwords; w0 += 64) {   // 64 words = 4096 blocks per step
+            uint64_t bits = w0 + lane < nwords ? sym[w0 + lane] : 0ull;
+            if (w0 + lane == ((u + 1) >> 6)) bits &= ~0ull << ((u + 1) & 63);
+            const uint64_t hit = __ballot(bits != 0);
+            if (hit) {
+                const int l0 = __ffsll((unsigned long long)hit) - 1;
+                const uint32_t lo = uint32_t(__shfl(int(uint32_t(bits)), l0, 64)), hi = uint32_t(__shfl(int(uint32_t(bits >> 32)), l0, 64));
+                const uint64_t b = (uint64_t(hi) << 32) | lo;
+                const uint32_t p = ((w0 + uint32_t(l0)) << 6) + uint32_t(__ffsll((unsigned long long)b) - 1);
+                if (p < w.nunits) t = p - 1;
+                break;
+            }
         }
-    }
-    uint16_t *er = c.eobrun + w.unit_base;
-    if (sc.Ah == 0) {
-        uint32_t L = t - u + 1, pos = u;
-        while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); pos += l; L -= l; }
-    } else {
-        // libjpeg also flushes when more than MAX_CORR_BITS-DCTSIZE2+1 = 937 correction bits are pending
+        uint16_t *er = c.eobrun + w.unit_base;
+        if (sc.Ah == 0) {
+            if (lane == 0) { uint32_t L = t - u + 1, pos = u; while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); pos += l; L -= l; } }
+            continue;
+        }
         const uint8_t *tl = c.tail + w.unit_base;
-        uint32_t cnt = 0, be = 0, s0 = u;
-        auto step = [&](uint32_t j, uint32_t tail_bits) {
-            cnt++; be += tail_bits;
-            if (cnt == 0x7FFF || be > 937) { er[s0] = uint16_t(cnt); cnt = 0; be = 0; s0 = j + 1; }
-        };
-        // runs of a refinement scan can be thousands of blocks long: the tail counts are read eight at a time
-        uint32_t j = u;
-        while (j <= t && (reinterpret_cast<uintptr_t>(tl + j) & 7)) { step(j, tl[j]); j++; }
-        for (; j + 7 <= t; j += 8) {
-            const uint64_t v = *reinterpret_cast<const uint64_t *>(tl + j);
+        uint32_t cnt = 0, be = 0, s0 = u, pos = u;
+        while (pos <= t) {
+            const uint32_t here = pos + lane <= t ? uint32_t(tl[pos + lane]) : 0u;
+            uint32_t incl = here;
             CSH_UNROLL
-            for (int i = 0; i < 8; i++) step(j + i, uint32_t(v >> (8 * i)) & 255u);
+            for (int o = 1; o < 64; o <<= 1) { uint32_t v = uint32_t(__shfl_up(int(incl), o, 64)); if (int(lane) >= o) incl += v; }
+            const bool over = pos + lane <= t && (be + incl > 937 || cnt + lane + 1 == 0x7FFF);
+            const uint64_t om = __ballot(over);
+            if (om) {
+                const uint32_t l0 = uint32_t(__ffsll((unsigned long long)om) - 1);
+                if (lane == 0) er[s0] = uint16_t(cnt + l0 + 1);
+                s0 = pos + l0 + 1; pos = s0; cnt = 0; be = 0;
+            } else {
+                const uint32_t len = t - pos + 1 < 64 ? t - pos + 1 : 64;
+                be += uint32_t(__shfl(int(incl), 63, 64)); cnt += len; pos += len;
+            }
         }
-        for (; j <= t; j++) step(j, tl[j]);
-        if (cnt) er[s0] = uint16_t(cnt);
+        if (cnt && lane == 0) er[s0] = uint16_t(cnt);
+#endif
     }
 }
 
@@ -643,7 +710,15 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
 
 static dim3 unit_grid(const EncCtx &c) { return dim3(c.nchunks); }   // flat: one workgroup per 256-unit chunk that exists
 void launch_ac_flags(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_ac_flags, unit_grid(c), dim3(256), st, c); }
-void launch_ac_runs(hipStream_t st, const EncCtx &c) { if (c.nchunks) CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c); }
+void launch_ac_runs(hipStream_t st, const EncCtx &c) {
+    if (!c.nchunks) return;
+    CSH_LAUNCH(k_ac_runs, unit_grid(c), dim3(256), st, c);
+#ifdef CSH_EMUL
+    CSH_LAUNCH(k_ac_runs_long, dim3(64), dim3(1), st, c);
+#else
+    CSH_LAUNCH(k_ac_runs_long, dim3(4096), dim3(64), st, c);
+#endif
+}
 void launch_stats(hipStream_t st, const EncCtx &c) {
     if (c.nchunks) CSH_LAUNCH_PHASED(k_stats, 3, unit_grid(c), dim3(256), st, c);
 }

@@ -72,6 +72,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint64_t *eob_bits;        // per AC scan: bit b set iff block b ends with a pending EOB
     uint8_t *tail;             // per unit: # of correction bits left over at the end of the block (refine scans)
     uint16_t *eobrun;          // per unit: EOBRUN value this block must emit after its symbols (0 = none)
+    uint32_t *long_runs, *long_cnt;   // runs longer than 512 blocks: (work item, first block) pairs for k_ac_runs_long
     uint32_t *unit_bits;       // per unit: size in bits of everything the unit emits
     uint64_t *unit_off;        // exclusive scan of unit_bits over the whole batch
     DevEncTable *tables;       // [ntables]

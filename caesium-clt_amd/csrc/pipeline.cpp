@@ -249,7 +249,7 @@ struct csh_batch {
     DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
     DevBuf<uint16_t> d_eobrun;
-    DevBuf<uint32_t> d_unit_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
+    DevBuf<uint32_t> d_long_runs, d_long_cnt, d_unit_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
 
@@ -863,7 +863,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
             b->d_masks.alloc(size_t(b->ntiles) * CSH_MASK_TILE) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
-            b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
+            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
             b->d_unit_off.alloc(b->total_units + 2) || b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
@@ -990,9 +990,9 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     memset(&c, 0, sizeof c);
     c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size()); c.max_units = b->max_units; c.chunk_work = b->d_chunk_work.p; c.nchunks = uint32_t(b->chunk_work.size());
     c.coef = b->d_coef.p; c.masks = b->d_masks.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
-    c.eobrun = b->d_eobrun.p; c.unit_bits = b->d_unit_bits.p; c.unit_off = b->d_unit_off.p; c.tables = b->d_tables.p;
+    c.eobrun = b->d_eobrun.p; c.long_runs = b->d_long_runs.p; c.long_cnt = b->d_long_cnt.p; c.unit_bits = b->d_unit_bits.p; c.unit_off = b->d_unit_off.p; c.tables = b->d_tables.p;
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p;
-    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st)) return -1;
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_long_cnt.zero(st)) return -1;
     MARK();
     if (b->lossless) launch_masks(st, b->d_coef.p, b->d_masks.p, 0, b->ntiles_in);
     else launch_masks(st, b->d_coef.p, b->d_masks.p, b->ntiles_in, b->ntiles_out);

@@ -337,12 +337,12 @@ def test_emul_long_eob_runs_and_flat_images(api):
         assert api.compress_in_memory(src, params()) == oracle_lossy(src)
 
 
-def crafted_corrbit_stream():
+def crafted_corrbit_stream(h=96, w=256):
     """every luma AC coefficient is +-2 or +-4 in a long stretch of blocks: at the last refinement scan each such block
     carries 63 correction bits and no newly significant coefficient, so the pending-bits limit (937) forces EOBRUN flushes"""
     from oracle import oracle as O
     rng = np.random.default_rng(1)
-    base = O.forward(rng.integers(0, 255, (96, 256, 3), dtype=np.uint8), O.params(quality=90, subsampling=420))
+    base = O.forward(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), O.params(quality=90, subsampling=420))
     y = base.coefs_view(0)
     y[:, :, 1:] = rng.choice(np.array([-4, -2, 2, 4], dtype=np.int16), size=y[:, :, 1:].shape)
     y[2, 5, 7] = 1      # one newly significant coefficient in the middle, and a few blocks with none at all
@@ -354,6 +354,8 @@ def test_emul_correction_bit_overflow_flush(api):
     """refinement scans with > 937 pending correction bits force an early EOBRUN flush (jcphuff MAX_CORR_BITS)"""
     blob = crafted_corrbit_stream()
     assert api.compress_in_memory(blob, params(jpeg_optimize=True)) == oracle_lossless(blob)
+    big = crafted_corrbit_stream(384, 640)   # 1920 luma blocks in one run: the wave-per-run kernel (k_ac_runs_long) cuts it
+    assert api.compress_in_memory(big, params(jpeg_optimize=True)) == oracle_lossless(big)
 
 
 def test_emul_batch_order_and_errors(api):

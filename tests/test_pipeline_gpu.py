@@ -116,6 +116,8 @@ def test_correction_bit_overflow_flush(api):
     from test_pipeline_emul import crafted_corrbit_stream
     blob = crafted_corrbit_stream()
     assert api.compress_in_memory(blob, params(jpeg_optimize=True)) == oracle_lossless(blob)
+    big = crafted_corrbit_stream(384, 640)   # 1920 luma blocks in one run: the wave-per-run kernel (k_ac_runs_long) cuts it
+    assert api.compress_in_memory(big, params(jpeg_optimize=True)) == oracle_lossless(big)
 
 
 def test_long_eob_runs_and_flat_images(api):
