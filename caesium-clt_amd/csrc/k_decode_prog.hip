@@ -119,6 +119,20 @@ __device__ __forceinline__ static int prog_huff(WaveReader &rd, const ParHuffSet
     return int(e & 255u);
 }
 __device__ __forceinline__ static int prog_extend(int r, int n) { return r < (1 << (n - 1)) ? r - (1 << n) + 1 : r; }
+// one Huffman symbol AND the raw bits that follow it (at most 15 + 16 <= 31 bits together) out of the same 32-bit window:
+// one trip through the bit reader per symbol instead of two or three.  extra(sym) = number of raw bits that belong to it.
+template <class F>
+__device__ __forceinline__ static int prog_huff_with_bits(WaveReader &rd, const ParHuffSet &hs, int tbl, F extra, uint32_t &bits) {
+    const uint32_t w = uint32_t(rd.acc >> 32), top16 = w >> 16;
+    uint32_t e = hs.root[tbl][top16 >> 7];
+    if (e & 0x8000u) e = hs.sub[(e & 0xFFFu) + ((top16 & 127u) >> (7u - ((e >> 12) & 7u)))];
+    e = uniform32(e);
+    const int len = e ? int(e >> 8) : 16, sym = int(e & 255u);
+    const int n = extra(sym);
+    bits = n ? (w << len) >> (32 - n) : 0u;
+    rd.skip(len + n);
+    return sym;
+}
 
 // ---- block <-> lanes
 __device__ __forceinline__ static void load_block(Vec64 &c, const int16_t *blk) { VFOR(j) VAT(c, j) = blk[coef_off(j)]; }
@@ -155,8 +169,9 @@ __device__ static void scan_dc_first(const ScanCtx &x, WaveReader &rd) {
     int pred[CSH_MAX_COMPS] = {0, 0, 0};
     auto one = [&](int ci, int by, int bx) {
         const CompGeom &g = im.in[sc.comp[ci]];
-        int t = prog_huff(rd, *x.hs, sc.td[ci] & 3);
-        int diff = t ? prog_extend(int(rd.get(t)), t) : 0;
+        uint32_t raw;
+        int t = prog_huff_with_bits(rd, *x.hs, sc.td[ci] & 3, [](int s) { return s & 15; }, raw) & 15;   // DC categories are <= 15 (host-checked)
+        int diff = t ? prog_extend(int(raw), t) : 0;
         pred[ci] += diff;
         int16_t *blk = x.coef + coef_index(g.tile_base, by * g.bw + bx, 0);
         const int v = pred[ci] * (1 << sc.Al);
@@ -230,17 +245,21 @@ __device__ static void scan_ac_first(const ScanCtx &x, WaveReader &rd) {
         VFOR(j) { (void)j; VAT(c, j) = 0; }
         uint64_t placed = 0;
         for (int k = sc.Ss; k <= sc.Se; k++) {
-            int rs = prog_huff(rd, *x.hs, tbl);
+            uint32_t raw;
+            // raw bits of a symbol: the coefficient's n value bits -- unless the run overflows the block (no bits are read then,
+            // k_decode.hip) -- or the r low bits of an EOB run length
+            const int kk = k;
+            int rs = prog_huff_with_bits(rd, *x.hs, tbl, [kk](int s) { int r = s >> 4, n = s & 15; return n ? (kk + r > 63 ? 0 : n) : (r == 15 ? 0 : r); }, raw);
             int r = rs >> 4, n = rs & 15;
             if (n) {
                 k += r;
                 if (k > 63) break;
-                const int v = prog_extend(int(rd.get(n)), n) * (1 << sc.Al);
+                const int v = prog_extend(int(raw), n) * (1 << sc.Al);
                 VFOR(j) if (j == k) VAT(c, j) = v;
                 placed |= 1ull << k;
             } else {
                 if (r == 15) k += 15;
-                else { eobrun = 1u << r; if (r) eobrun += rd.get(r); eobrun--; break; }
+                else { eobrun = (1u << r) + raw - 1u; break; }
             }
         }
         if (placed) store_lanes(c, x.coef + coef_index(g.tile_base, by * g.bw + bx, 0), placed);
@@ -272,10 +291,11 @@ __device__ static void scan_ac_refine(const ScanCtx &x, WaveReader &rd) {
             int k = sc.Ss;
             if (eobrun == 0) {
                 while (k <= Se) {
-                    int rs = prog_huff(rd, *x.hs, tbl);
+                    uint32_t raw;
+                    int rs = prog_huff_with_bits(rd, *x.hs, tbl, [](int s) { int r = s >> 4, n = s & 15; return n ? 1 : (r == 15 ? 0 : r); }, raw);   // sign bit, or EOB run bits
                     int r = rs >> 4, n = rs & 15, val = 0;
-                    if (n) val = rd.get(1) ? p1 : m1;
-                    else if (r != 15) { eobrun = 1u << r; if (r) eobrun += rd.get(r); break; }
+                    if (n) val = raw ? p1 : m1;
+                    else if (r != 15) { eobrun = (1u << r) + raw; break; }
                     // pass over coefficients until r zero-history positions are skipped and the next one is reached; every
                     // non-zero-history position on the way takes a correction bit
                     const uint64_t Z = ~H & span(k, Se);
