@@ -66,7 +66,6 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
                 for (int k = 0; k < 64; k++) {
                     int v = pq ? ((s[p] << 8) | s[p + 1]) : s[p];
                     p += pq ? 2 : 1;
-                    if (v == 0) BAD(CS_ERR_BAD_JPEG, "zero quantiser in DQT");
                     j.qt[tq][kZigZag[k]] = uint16_t(v);
                 }
                 j.qt_present[tq] = true;
@@ -133,10 +132,10 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
                 int cid = s[1 + 2 * k], ci = -1;
                 for (int c = 0; c < j.ncomp; c++) if (j.comp[c].id == cid) ci = c;
                 if (ci < 0) BAD(CS_ERR_BAD_JPEG, "SOS names an unknown component");
+                for (int q = 0; q < k; q++) if (sc.comp_idx[q] == ci) BAD(CS_ERR_BAD_JPEG, "SOS names a component twice");   // libjpeg JERR_BAD_COMPONENT_ID
                 sc.comp_idx[k] = ci;
                 sc.td[k] = s[2 + 2 * k] >> 4;
                 sc.ta[k] = s[2 + 2 * k] & 15;
-                if (sc.td[k] > 3 || sc.ta[k] > 3) BAD(CS_ERR_BAD_JPEG, "SOS table id out of range");
             }
             sc.Ss = s[1 + 2 * ns]; sc.Se = s[2 + 2 * ns];
             sc.Ah = s[3 + 2 * ns] >> 4; sc.Al = s[3 + 2 * ns] & 15;
@@ -145,6 +144,11 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
                 if (sc.Ss > sc.Se || sc.Se > 63 || sc.Al > 13 || sc.Ah > 13) BAD(CS_ERR_BAD_JPEG, "bad progressive parameters");
                 if (sc.Ss == 0 && sc.Se != 0) BAD(CS_ERR_BAD_JPEG, "bad progressive DC scan");
                 if (sc.Ss != 0 && ns != 1) BAD(CS_ERR_BAD_JPEG, "interleaved progressive AC scan");
+            }
+            for (int k = 0; k < ns; k++) {   // only the selectors the scan uses are checked (libjpeg: jpeg_make_d_derived_tbl on use)
+                const bool need_dc = j.progressive ? (sc.Ss == 0 && sc.Ah == 0) : true, need_ac = j.progressive ? sc.Ss != 0 : true;
+                if ((need_dc && sc.td[k] > 3) || (need_ac && sc.ta[k] > 3)) BAD(CS_ERR_BAD_JPEG, "SOS table id out of range");
+                sc.td[k] &= 3; sc.ta[k] &= 3;
             }
             for (int t = 0; t < 4; t++) { sc.dc[t] = dc[t]; sc.ac[t] = ac[t]; }
             size_t b = i + 2 + L, e = b;

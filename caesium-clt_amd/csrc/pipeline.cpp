@@ -630,6 +630,11 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
         for (size_t s = 0; s < in.scans.size(); s++) if (!b->phset_fits[b->dscans[im.first_scan + s].huff_set]) par_ok = false;
         for (const JScan &js : in.scans) if (js.data_len >= (1u << 28)) par_ok = false;
         if (uint64_t(in.mcus_x) * uint64_t(in.mcus_y) * 10 >= (1u << 24)) par_ok = false;   // k_decode_par.hip uses 24-bit multiplies on block counts
+        {   // a component coded by two scans (malformed, but libjpeg decodes it: the later scan wins) must not be written by two
+            // segments at once: leave the order to the sequential kernel
+            int seen[4] = {0, 0, 0, 0};
+            for (const JScan &js : in.scans) for (int k = 0; k < js.ncomp; k++) if (seen[js.comp_idx[k] & 3]++) par_ok = false;
+        }
         struct Piece { size_t off, len; uint32_t first_mcu, nmcus; };
         std::vector<std::vector<Piece>> pieces(in.scans.size());
         for (size_t s = 0; s < in.scans.size() && par_ok; s++) {

@@ -379,6 +379,7 @@ int cso_decode(const uint8_t *d, size_t n, cso_image **out) {
                 int cid = s[1 + 2 * k], ci = -1;
                 for (int c = 0; c < im->ncomp; c++) if (im->comp[c].id == cid) ci = c;
                 if (ci < 0) { snprintf(g_err, sizeof g_err, "SOS names unknown component"); goto done; }
+                for (int q = 0; q < k; q++) if (sc->comp_idx[q] == ci) { snprintf(g_err, sizeof g_err, "SOS names a component twice"); goto done; }  /* libjpeg JERR_BAD_COMPONENT_ID */
                 sc->comp_idx[k] = ci; td[k] = (s[2 + 2 * k] >> 4) & 3; ta[k] = s[2 + 2 * k] & 3;
             }
             sc->Ss = s[1 + 2 * ns]; sc->Se = s[2 + 2 * ns]; sc->Ah = s[3 + 2 * ns] >> 4; sc->Al = s[3 + 2 * ns] & 15;
@@ -401,6 +402,8 @@ int cso_decode(const uint8_t *d, size_t n, cso_image **out) {
         i += 2 + L;
     }
     if (!have_sof || im->nscans == 0) { snprintf(g_err, sizeof g_err, "no image data"); goto done; }
+    for (int c = 0; c < im->ncomp; c++)   /* libjpeg JERR_NO_QUANT_TABLE: at decompression start, and at emit_dqt when transcoding */
+        if (im->comp[c].tq < 0 || im->comp[c].tq > 3 || !im->qt_present[im->comp[c].tq]) { snprintf(g_err, sizeof g_err, "missing quantisation table"); goto done; }
     im->meta = meta.p; im->meta_len = meta.n; meta.p = NULL;
     rc = 0;
 done:

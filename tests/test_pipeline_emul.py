@@ -358,6 +358,42 @@ def test_emul_correction_bit_overflow_flush(api):
     assert api.compress_in_memory(big, params(jpeg_optimize=True)) == oracle_lossless(big)
 
 
+def fuzzed_blobs(seed, count, whole_file):
+    """bit flips, byte overwrites and deletions in the entropy-coded data (or anywhere in the file) of four kinds of source"""
+    rng = np.random.default_rng(seed)
+    srcs = [synth_jpeg(3, 120, 88, texture=30), synth_jpeg(4, 96, 64, progressive=True, texture=20), synth_jpeg(5, 104, 72, restart_rows=1, texture=25),
+            synth_jpeg(6, 64, 48, subsampling=0, optimize=True)]
+    blobs = []
+    for k in range(count):
+        s = bytearray(srcs[k % 4])
+        start = 2 if whole_file else s.index(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 4))):
+            i = int(rng.integers(start, len(s) - 2))
+            mode = int(rng.integers(0, 3))
+            if mode == 0: s[i] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1: s[i] = int(rng.integers(0, 256))
+            else: del s[i:i + int(rng.integers(1, 6))]
+        blobs.append(bytes(s))
+    return blobs
+
+
+def test_emul_fuzzed_streams_agree_with_the_oracle(api):
+    """damaged files: the device path and the oracle either both refuse a file or produce the same bytes (the decoders
+    share libjpeg's rules for bad codes, overlong runs, data that ends early, markers in the data)"""
+    for lossless in (True, False):
+        for whole_file in (False, True):
+            blobs = fuzzed_blobs(7 + 2 * lossless + whole_file, 48, whole_file)
+            outs = api.batch_compress(blobs, params(jpeg_optimize=lossless))
+            for i, (src, out) in enumerate(zip(blobs, outs)):
+                try:
+                    want = oracle_lossless(src) if lossless else oracle_lossy(src)
+                except Exception as e:   # noqa: BLE001 - the oracle refuses the file
+                    want = e
+                assert isinstance(want, Exception) == isinstance(out, Exception), (lossless, whole_file, i, out, want)
+                if not isinstance(out, Exception):
+                    assert out == want, (lossless, whole_file, i)
+
+
 def test_emul_batch_order_and_errors(api):
     good = [synth_jpeg(i, 80 + 8 * i, 64, texture=10 * i) for i in range(4)]
     blobs = [good[0], b"not an image", good[1], good[2][:150], good[3], b"\x89PNG\r\n\x1a\n" + b"\0" * 32]

@@ -108,6 +108,10 @@ def test_streams_cut_short(api):
     E.test_emul_streams_cut_short(api)
 
 
+def test_fuzzed_streams_agree_with_the_oracle(api):
+    E.test_emul_fuzzed_streams_agree_with_the_oracle(api)
+
+
 def test_restart_intervals_decode_in_parallel(api):
     E.test_emul_restart_intervals_decode_in_parallel(api)
 
