@@ -358,11 +358,12 @@ def test_emul_correction_bit_overflow_flush(api):
     assert api.compress_in_memory(big, params(jpeg_optimize=True)) == oracle_lossless(big)
 
 
-def fuzzed_blobs(seed, count, whole_file):
+def fuzzed_blobs(seed, count, whole_file, scale=1):
     """bit flips, byte overwrites and deletions in the entropy-coded data (or anywhere in the file) of four kinds of source"""
     rng = np.random.default_rng(seed)
-    srcs = [synth_jpeg(3, 120, 88, texture=30), synth_jpeg(4, 96, 64, progressive=True, texture=20), synth_jpeg(5, 104, 72, restart_rows=1, texture=25),
-            synth_jpeg(6, 64, 48, subsampling=0, optimize=True)]
+    k = scale
+    srcs = [synth_jpeg(3, 120 * k, 88 * k, texture=30), synth_jpeg(4, 96 * k, 64 * k, progressive=True, texture=20), synth_jpeg(5, 104 * k, 72 * k, restart_rows=1, texture=25),
+            synth_jpeg(6, 64 * k, 48 * k, subsampling=0, optimize=True, texture=10 * (k - 1))]
     blobs = []
     for k in range(count):
         s = bytearray(srcs[k % 4])
