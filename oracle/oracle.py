@@ -44,9 +44,15 @@ class EncParams(C.Structure):
                 ("marker_style", C.c_int), ("scan_script", C.c_int), ("keep_metadata", C.c_int), ("force_baseline", C.c_int), ("preserve_icc", C.c_int)]
 
 
+class Png(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_int), ("ctype", C.c_int), ("interlace", C.c_int),
+                ("channels", C.c_int), ("bpp", C.c_int), ("nplte", C.c_int), ("rowbytes", C.c_size_t),
+                ("pix", C.POINTER(C.c_uint8)), ("chunks", C.POINTER(C.c_uint8)), ("chunks_len", C.c_size_t), ("idat_at", C.c_size_t)]
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "jpeg_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -81,6 +87,17 @@ def lib():
         L.cso_jpeg_compress_resized.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(EncParams), C.c_int, C.c_int,
                                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_last_error.restype = C.c_char_p
+        L.cso_crc32.restype = C.c_uint32
+        L.cso_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
+        L.cso_adler32.restype = C.c_uint32
+        L.cso_adler32.argtypes = [C.c_char_p, C.c_size_t]
+        L.cso_inflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.cso_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(Png))]
+        L.cso_png_free.argtypes = [C.POINTER(Png)]
+        L.cso_png_filter.argtypes = [C.POINTER(Png), C.c_int, C.c_void_p, C.c_void_p]
+        L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_png_trials.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.cso_png_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -249,3 +266,86 @@ def jpeg_compress_resized(data, p, width, height):
     res = C.string_at(out, n.value)
     lib().cso_free(out)
     return res
+
+
+# ---------------------------------------------------------------- lossless PNG row (png_oracle.c; parity unpinned, see its header)
+class PngError(OracleError):
+    def __init__(self, code):
+        super().__init__("png oracle: code %d" % code)
+        self.code = code
+
+
+class PngImage:
+    """Owns a cso_png*: the unfiltered rows and the chunks that are carried over."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().cso_png_free(self.ptr)
+            self.ptr = None
+
+    @property
+    def im(self):
+        return self.ptr.contents
+
+    def rows(self):
+        im = self.im
+        return np.ctypeslib.as_array(im.pix, shape=(im.height * im.rowbytes,)).reshape(im.height, im.rowbytes).copy()
+
+    def filtered(self, strategy):
+        """(stream of height*(1+rowbytes) bytes, per-row filter choice)"""
+        im = self.im
+        out = np.empty(im.height * (1 + im.rowbytes), dtype=np.uint8)
+        choice = np.empty(im.height, dtype=np.uint8)
+        rc = lib().cso_png_filter(self.ptr, strategy, out.ctypes.data, choice.ctypes.data)
+        if rc:
+            raise PngError(rc)
+        return out, choice
+
+
+def png_decode(data, keep_metadata=False):
+    ptr = C.POINTER(Png)()
+    rc = lib().cso_png_decode(data, len(data), 1 if keep_metadata else 0, C.byref(ptr))
+    if rc:
+        raise PngError(rc)
+    return PngImage(ptr)
+
+
+def deflate_zlib(data):
+    data = bytes(data)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    lib().cso_deflate_zlib(data, len(data), C.byref(out), C.byref(n))
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res
+
+
+def inflate_zlib(data, cap):
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().cso_inflate_zlib(data, len(data), out.ctypes.data, cap, C.byref(n))
+    if rc:
+        raise PngError(rc)
+    return out[:n.value].tobytes()
+
+
+def png_trials(level):
+    arr = (C.c_int * 10)()
+    n = lib().cso_png_trials(level, arr)
+    return [arr[i] for i in range(n)]
+
+
+def png_optimize(data, level=3, keep_metadata=False):
+    """-> (file bytes, winning strategy or -1 when the input is returned unchanged)"""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    chosen = C.c_int()
+    rc = lib().cso_png_optimize(data, len(data), level, 1 if keep_metadata else 0, C.byref(out), C.byref(n), C.byref(chosen))
+    if rc:
+        raise PngError(rc)
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res, chosen.value

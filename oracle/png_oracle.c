@@ -1,0 +1,661 @@
+/*
+ * png_oracle.c -- CPU ORACLE for the lossless PNG row of the hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), tools/): nothing under caesium-clt_amd/ links or calls this.
+ *
+ * PARITY UNPINNED.  The reference reaches this path through `caesium::compress_in_memory` with `png.optimize = true`
+ * (/root/reference/src/compressor.rs:305, parameters :427-429, level :64 of src/options.rs), which runs oxipng 9.1.5 +
+ * libdeflate 1.25.2 (Cargo.lock:1161, :917-932).  Neither is in /root/reference nor in this image, and the reference's
+ * tests hold no PNG golden bytes, so byte parity with the real tool cannot be established here.  What this
+ * file pins instead:
+ *   - decode (chunk walk, RFC 1950/1951 inflate, PNG unfilter): pixel-exact against libpng via Pillow
+ *     (tests/test_oracle_png.py), on every colour type / bit depth Pillow can write;
+ *   - the output is a valid PNG whose pixels equal the input's (Pillow decodes both), and a valid zlib stream (zlib
+ *     inflates it);
+ *   - the row-filter strategies follow the numbering oxipng documents (0-4 fixed, 5 MinSum, 6 Entropy, 7 Bigrams,
+ *     8 BigEnt, 9 Brute) and the trial sets of its presets (-o3: filters 0,7,8,9) [UPSTREAM-RECALL]; their scoring is
+ *     restated from the published heuristics (LodePNG's, which oxipng adopted): see filter_scores();
+ *   - the DEFLATE coder is THIS PROJECT'S OWN (a chunk-parallel LZ77 + dynamic Huffman coder laid out for the GPU,
+ *     deflate_chunk()), not libdeflate's near-optimal parser: sizes differ from the reference's by a few percent, the
+ *     decoded pixels do not.  The device path (k_png_*.hip) must equal this file byte for byte.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "png_oracle.h"
+
+/* ------------------------------------------------------------------------------------------------ checksums */
+static uint32_t crc_table[256];
+static void crc_init(void) {
+    if (crc_table[1]) return;
+    for (uint32_t n = 0; n < 256; n++) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        crc_table[n] = c;
+    }
+}
+uint32_t cso_crc32(uint32_t crc, const uint8_t *p, size_t n) {
+    crc_init();
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) crc = crc_table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    return ~crc;
+}
+uint32_t cso_adler32(const uint8_t *p, size_t n) {
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < n; i++) { a = (a + p[i]) % 65521u; b = (b + a) % 65521u; }
+    return (b << 16) | a;
+}
+static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static void put_be32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+
+/* ------------------------------------------------------------------------------------------------ inflate (RFC 1951) */
+typedef struct { const uint8_t *in; size_t n, pos; uint32_t bitbuf; int bitcnt; int err; } ibits;
+static uint32_t need(ibits *s, int n) {
+    uint32_t v = s->bitbuf;
+    while (s->bitcnt < n) {
+        if (s->pos >= s->n) { s->err = 1; return 0; }
+        v |= (uint32_t)s->in[s->pos++] << s->bitcnt;
+        s->bitcnt += 8;
+    }
+    s->bitbuf = n < 32 ? v >> n : 0;
+    s->bitcnt -= n;
+    return v & ((n < 32 ? (1u << n) : 0u) - 1u);
+}
+typedef struct { uint16_t count[16], symbol[288]; } hcode;
+/* canonical code from lengths; returns 0 complete, >0 incomplete, <0 over-subscribed */
+static int hbuild(hcode *h, const uint8_t *len, int n) {
+    uint16_t offs[16];
+    memset(h->count, 0, sizeof h->count);
+    for (int i = 0; i < n; i++) h->count[len[i]]++;
+    if (h->count[0] == n) return 0;
+    int left = 1;
+    for (int l = 1; l < 16; l++) { left <<= 1; left -= h->count[l]; if (left < 0) return left; }
+    offs[1] = 0;
+    for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + h->count[l];
+    for (int i = 0; i < n; i++) if (len[i]) h->symbol[offs[len[i]]++] = (uint16_t)i;
+    return left;
+}
+static int hdecode(ibits *s, const hcode *h) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; l++) {
+        code |= (int)need(s, 1);
+        if (s->err) return -1;
+        int count = h->count[l];
+        if (code - count < first) return h->symbol[index + (code - first)];
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+/* raw deflate -> out (capacity cap).  Stops at the final block, or as soon as cap bytes exist (a PNG decoder needs no
+   more: libpng's "too much image data" is a warning).  Returns 0, or a negative error. */
+static int inflate_raw(ibits *s, uint8_t *out, size_t cap, size_t *produced) {
+    size_t o = 0;
+    int last;
+    do {
+        last = (int)need(s, 1);
+        int type = (int)need(s, 2);
+        if (s->err) return -1;
+        if (type == 0) {
+            s->bitbuf = 0; s->bitcnt = 0;
+            if (s->pos + 4 > s->n) return -1;
+            unsigned len = s->in[s->pos] | (s->in[s->pos + 1] << 8), nlen = s->in[s->pos + 2] | (s->in[s->pos + 3] << 8);
+            s->pos += 4;
+            if ((len ^ 0xFFFFu) != nlen) return -2;
+            if (s->pos + len > s->n) return -1;
+            size_t take = len; if (take > cap - o) take = cap - o;
+            memcpy(out + o, s->in + s->pos, take);
+            o += take; s->pos += len;
+            if (o >= cap) break;
+            continue;
+        }
+        if (type == 3) return -3;
+        hcode lc, dc;
+        uint8_t lens[320];
+        if (type == 1) {
+            int i = 0;
+            for (; i < 144; i++) lens[i] = 8;
+            for (; i < 256; i++) lens[i] = 9;
+            for (; i < 280; i++) lens[i] = 7;
+            for (; i < 288; i++) lens[i] = 8;
+            hbuild(&lc, lens, 288);
+            for (i = 0; i < 30; i++) lens[i] = 5;
+            hbuild(&dc, lens, 30);
+        } else {
+            int nlen = (int)need(s, 5) + 257, ndist = (int)need(s, 5) + 1, ncode = (int)need(s, 4) + 4;
+            if (s->err) return -1;
+            if (nlen > 286 || ndist > 30) return -4;
+            uint8_t cl[19]; memset(cl, 0, sizeof cl);
+            for (int i = 0; i < ncode; i++) cl[CL_ORDER[i]] = (uint8_t)need(s, 3);
+            if (s->err) return -1;
+            hcode cc;
+            if (hbuild(&cc, cl, 19) != 0) return -5;   /* zlib: the code-length code must be complete */
+            int idx = 0;
+            while (idx < nlen + ndist) {
+                int sym = hdecode(s, &cc);
+                if (sym < 0) return -6;
+                if (sym < 16) lens[idx++] = (uint8_t)sym;
+                else {
+                    int rep, val = 0;
+                    if (sym == 16) { if (idx == 0) return -7; val = lens[idx - 1]; rep = 3 + (int)need(s, 2); }
+                    else if (sym == 17) rep = 3 + (int)need(s, 3);
+                    else rep = 11 + (int)need(s, 7);
+                    if (s->err) return -1;
+                    if (idx + rep > nlen + ndist) return -8;
+                    while (rep--) lens[idx++] = (uint8_t)val;
+                }
+            }
+            if (lens[256] == 0) return -9;
+            int r = hbuild(&lc, lens, nlen);
+            if (r < 0 || (r > 0 && nlen - lc.count[0] != 1)) return -10;
+            r = hbuild(&dc, lens + nlen, ndist);
+            if (r < 0 || (r > 0 && ndist - dc.count[0] != 1)) return -11;
+        }
+        for (;;) {
+            int sym = hdecode(s, &lc);
+            if (sym < 0) return -12;
+            if (sym < 256) { if (o < cap) out[o] = (uint8_t)sym; o++; if (o >= cap) break; continue; }
+            if (sym == 256) break;
+            sym -= 257;
+            if (sym >= 29) return -13;
+            unsigned len = LEN_BASE[sym] + need(s, LEN_EXTRA[sym]);
+            int ds = hdecode(s, &dc);
+            if (ds < 0 || ds >= 30) return -14;
+            unsigned dist = DIST_BASE[ds] + need(s, DIST_EXTRA[ds]);
+            if (s->err) return -1;
+            if (dist > o) return -15;
+            while (len-- && o < cap) { out[o] = out[o - dist]; o++; }
+            if (o >= cap) break;
+        }
+        if (o >= cap) break;
+    } while (!last);
+    *produced = o;
+    return 0;
+}
+int cso_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced) {
+    if (n < 2) return -20;
+    unsigned cmf = in[0], flg = in[1];
+    if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 || (flg & 0x20)) return -21;
+    ibits s; memset(&s, 0, sizeof s);
+    s.in = in; s.n = n; s.pos = 2;
+    *produced = 0;
+    return inflate_raw(&s, out, cap, produced);
+}
+
+/* ------------------------------------------------------------------------------------------------ PNG parse + unfilter */
+static const uint8_t PNG_SIG[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+static int kept_when_stripping(const uint8_t *type) {   /* oxipng StripChunks::Safe keeps these ancillary chunks [UPSTREAM-RECALL] */
+    static const char *keep[] = {"cICP", "iCCP", "sRGB", "pHYs", "tRNS"};   /* tRNS is image data, never stripped */
+    for (size_t i = 0; i < sizeof keep / sizeof *keep; i++) if (!memcmp(type, keep[i], 4)) return 1;
+    return 0;
+}
+static int paeth(int a, int b, int c) {
+    int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+void cso_png_free(cso_png *p) {
+    if (!p) return;
+    free(p->pix); free(p->chunks); free(p);
+}
+int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out) {
+    *out = NULL;
+    if (n < 8 + 25 || memcmp(in, PNG_SIG, 8)) return CSO_PNG_BAD;
+    cso_png *P = (cso_png *)calloc(1, sizeof *P);
+    uint8_t *idat = (uint8_t *)malloc(n);
+    size_t nidat = 0, pos = 8;
+    int seen_ihdr = 0, seen_idat = 0, seen_iend = 0, rc = 0;
+    P->chunks = (uint8_t *)malloc(n); P->chunks_len = 0; P->idat_at = (size_t)-1;
+    while (pos + 12 <= n && !seen_iend) {
+        uint32_t len = be32(in + pos);
+        const uint8_t *type = in + pos + 4;
+        if (len > 0x7FFFFFFFu || pos + 12 + (size_t)len > n) { rc = CSO_PNG_BAD; break; }
+        const uint8_t *d = in + pos + 8;
+        if (!seen_ihdr) {
+            if (memcmp(type, "IHDR", 4) || len != 13) { rc = CSO_PNG_BAD; break; }
+            if (cso_crc32(0, type, 4 + 13) != be32(d + 13)) { rc = CSO_PNG_BAD; break; }
+            P->width = be32(d); P->height = be32(d + 4); P->depth = d[8]; P->ctype = d[9]; P->interlace = d[12];
+            if (!P->width || !P->height || P->width > 0x7FFFFFFFu || P->height > 0x7FFFFFFFu || d[10] || d[11] || d[12] > 1) { rc = CSO_PNG_BAD; break; }
+            static const int chans[7] = {1, 0, 3, 1, 2, 0, 4};
+            int okd = 0;
+            switch (P->ctype) {
+            case 0: okd = P->depth == 1 || P->depth == 2 || P->depth == 4 || P->depth == 8 || P->depth == 16; break;
+            case 3: okd = P->depth == 1 || P->depth == 2 || P->depth == 4 || P->depth == 8; break;
+            case 2: case 4: case 6: okd = P->depth == 8 || P->depth == 16; break;
+            }
+            if (!okd) { rc = CSO_PNG_BAD; break; }
+            P->channels = chans[P->ctype];
+            int bits = P->channels * P->depth;
+            P->bpp = bits >= 8 ? bits / 8 : 1;
+            P->rowbytes = ((size_t)P->width * (size_t)bits + 7) / 8;
+            seen_ihdr = 1;
+        } else if (!memcmp(type, "IDAT", 4)) {
+            if (P->idat_at == (size_t)-1) P->idat_at = P->chunks_len;
+            memcpy(idat + nidat, d, len); nidat += len; seen_idat = 1;
+        } else if (!memcmp(type, "IEND", 4)) {
+            seen_iend = 1;
+        } else {
+            if (!memcmp(type, "acTL", 4)) { rc = CSO_PNG_UNSUPPORTED; break; }   /* animated PNG */
+            if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) { rc = CSO_PNG_BAD; break; } P->nplte = (int)(len / 3); }
+            int critical = !(type[0] & 0x20);
+            if (critical || keep_metadata || kept_when_stripping(type)) {
+                memcpy(P->chunks + P->chunks_len, in + pos, 12 + (size_t)len);
+                P->chunks_len += 12 + (size_t)len;
+            }
+        }
+        pos += 12 + (size_t)len;
+    }
+    if (!rc && (!seen_ihdr || !seen_idat || !seen_iend)) rc = CSO_PNG_BAD;
+    if (!rc && P->ctype == 3 && !P->nplte) rc = CSO_PNG_BAD;
+    if (!rc && P->interlace) rc = CSO_PNG_UNSUPPORTED;   /* Adam7: not on this path yet */
+    if (rc) { free(idat); cso_png_free(P); return rc; }
+    size_t stride = 1 + P->rowbytes, raw_len = stride * P->height, got = 0;
+    uint8_t *raw = (uint8_t *)malloc(raw_len);
+    rc = cso_inflate_zlib(idat, nidat, raw, raw_len, &got);
+    free(idat);
+    if (rc || got < raw_len) { free(raw); cso_png_free(P); return CSO_PNG_BAD; }
+    P->pix = (uint8_t *)malloc(P->rowbytes * P->height);
+    const int bpp = P->bpp;
+    for (uint32_t y = 0; y < P->height && !rc; y++) {
+        const uint8_t *f = raw + y * stride;
+        uint8_t *cur = P->pix + y * P->rowbytes;
+        const uint8_t *up = y ? cur - P->rowbytes : NULL;
+        int ft = f[0];
+        if (ft > 4) { rc = CSO_PNG_BAD; break; }
+        for (size_t x = 0; x < P->rowbytes; x++) {
+            int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0, v = f[1 + x];
+            switch (ft) {
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) >> 1; break;
+            case 4: v += paeth(a, b, c); break;
+            }
+            cur[x] = (uint8_t)v;
+        }
+    }
+    free(raw);
+    if (rc) { cso_png_free(P); return rc; }
+    *out = P;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ row filters */
+static void filter_row(int ft, const uint8_t *cur, const uint8_t *up, size_t n, int bpp, uint8_t *dst) {
+    dst[0] = (uint8_t)ft;
+    for (size_t x = 0; x < n; x++) {
+        int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0, v = cur[x];
+        switch (ft) {
+        case 1: v -= a; break;
+        case 2: v -= b; break;
+        case 3: v -= (a + b) >> 1; break;
+        case 4: v -= paeth(a, b, c); break;
+        }
+        dst[1 + x] = (uint8_t)v;
+    }
+}
+/* i * log2(i) in integers: LodePNG's ilog2i (floor(log2) plus a linear fraction) */
+static uint64_t ilog2i(uint64_t i) {
+    if (!i) return 0;
+    int l = 63 - __builtin_clzll(i);
+    return i * (uint64_t)l + ((i - (1ull << l)) << 1);
+}
+static uint64_t fixed_cost_row(const uint8_t *row, size_t n, int bpp);
+/* scores of one candidate row (type byte + n filtered bytes):
+     [0] MinSum: sum of |signed byte| over the data bytes            (least wins)
+     [1] Entropy: sum ilog2i(count) over the byte histogram, type byte included   (most wins)
+     [2] Bigrams: number of distinct byte pairs, type byte included  (least wins)
+     [3] BigEnt: sum ilog2i(count) over the pair histogram           (most wins)
+     [4] Brute: estimated bits of the row under this project's tokenizer and a code of its own (least wins).  oxipng's
+         Brute deflates the candidate together with the previously chosen rows at a fast libdeflate level, which makes the
+         rows depend on each other; this statement scores every row on its own so that all rows are independent. */
+static void filter_scores(const uint8_t *row, size_t n, int bpp, uint64_t sc[5]) {
+    uint64_t ms = 0;
+    uint32_t cnt[256]; memset(cnt, 0, sizeof cnt);
+    for (size_t i = 1; i <= n; i++) { uint8_t b = row[i]; ms += b < 128 ? b : 256 - b; }
+    for (size_t i = 0; i <= n; i++) cnt[row[i]]++;
+    uint64_t ent = 0;
+    for (int i = 0; i < 256; i++) ent += ilog2i(cnt[i]);
+    static uint32_t pc[65536];
+    uint64_t distinct = 0, bent = 0;
+    for (size_t i = 0; i < n; i++) { uint32_t k = ((uint32_t)row[i] << 8) | row[i + 1]; if (!pc[k]++) distinct++; }
+    for (size_t i = 0; i < n; i++) { uint32_t k = ((uint32_t)row[i] << 8) | row[i + 1]; if (pc[k]) { bent += ilog2i(pc[k]); pc[k] = 0; } }
+    sc[0] = ms; sc[1] = ent; sc[2] = distinct; sc[3] = bent;
+    sc[4] = fixed_cost_row(row, n + 1, bpp);
+}
+/* strategy 0..4: that filter on every row; 5..9: per row, the candidate with the best score (ties: the lower filter) */
+int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice) {
+    if (strategy < 0 || strategy > 9) return -1;
+    const size_t n = P->rowbytes, stride = 1 + n;
+    uint8_t *cand = (uint8_t *)malloc(stride * 5);
+    for (uint32_t y = 0; y < P->height; y++) {
+        const uint8_t *cur = P->pix + (size_t)y * n, *up = y ? cur - n : NULL;
+        int pick = strategy;
+        if (strategy >= 5) {
+            uint64_t best = 0;
+            pick = 0;
+            for (int f = 0; f < 5; f++) {
+                uint64_t sc[5];
+                filter_row(f, cur, up, n, P->bpp, cand + f * stride);
+                filter_scores(cand + f * stride, n, P->bpp, sc);
+                uint64_t v = sc[strategy - 5];
+                int more_wins = strategy == 6 || strategy == 8;
+                if (f == 0 || (more_wins ? v > best : v < best)) { best = v; pick = f; }
+            }
+            memcpy(out + (size_t)y * stride, cand + pick * stride, stride);
+        } else
+            filter_row(pick, cur, up, n, P->bpp, out + (size_t)y * stride);
+        if (choice) choice[y] = (uint8_t)pick;
+    }
+    free(cand);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ deflate (this project's coder)
+ * The stream is cut into CHUNKs of 32 KiB of input; every chunk becomes one dynamic-Huffman block followed -- except
+ * after the last one -- by an empty stored block, which byte-aligns it (the "sync flush" pigz uses for the same
+ * purpose), so chunks are coded independently and concatenated as bytes.
+ * Tokenizer, per TILE of 64 consecutive positions (one GPU wave takes a tile per step):
+ *   candidates of position p:  (a) up to four earlier positions q < tile start whose 4 bytes hash like p's: a table of
+ *   2048 buckets x 4 entries, seeded with the 32 KiB in front of the chunk and refreshed after each tile (per hash, the
+ *   tile's last position is pushed in);  (b) the fixed distances 1,2,3,4,6,8 (pixel strides of filtered PNG data), of
+ *   which the one with the longest match inside the first 8 bytes (ties: the smaller distance) is extended if all 8
+ *   agree.  The longest wins (ties: (b), then the nearer); length 3 is only taken at distance <= 8.  Matches end at the
+ *   chunk end; their sources may lie in front of the chunk (the deflate window spans blocks).
+ *   parse: greedy with one step of lazy evaluation inside a tile (a match at p yields to a longer one at p+1 unless p is
+ *   the last position of its tile).
+ * Code lengths: Huffman by repeated merge of the two least frequent (ties: the larger index first), limited to 15 (7 for
+ * the code-length code) by the bit-count adjustment of T.81 K.2 / libjpeg; at least two symbols are coded in every
+ * alphabet (zlib's rule, which keeps every code complete).
+ */
+#define CHUNK 32768u
+#define HASH_BITS 11
+#define WAYS 4
+static int len_code(int len) { int c = 28; while (LEN_BASE[c] > len) c--; return c; }
+static int dist_code(int d) { int c = 29; while (DIST_BASE[c] > d) c--; return c; }
+static size_t lcp(const uint8_t *a, const uint8_t *b, size_t max) { size_t l = 0; while (l < max && a[l] == b[l]) l++; return l; }
+static const int FIXED_DIST[6] = {1, 2, 3, 4, 6, 8};
+static uint32_t hash4(const uint8_t *d) {
+    uint32_t v = d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24);
+    return (v * 0x9E3779B1u) >> (32 - HASH_BITS);
+}
+/* after a tile: of the tile's positions with one hash only the LAST enters the bucket, pushing the older entries back */
+static void insert_tile(uint16_t (*table)[WAYS], const uint8_t *data, size_t total, size_t base_rel, size_t t0, size_t t1) {
+    /* positions are stored as 16-bit offsets from (chunk start - 32768): rel = p + base_rel */
+    size_t lastpos[1 << HASH_BITS];   /* only the slots of this tile's hashes are read */
+    for (size_t p = t0; p < t1 && p + 4 <= total; p++) lastpos[hash4(data + p)] = p;
+    for (size_t p = t0; p < t1 && p + 4 <= total; p++) {
+        uint32_t h = hash4(data + p);
+        size_t rel = p + base_rel;
+        if (lastpos[h] != p || rel == 0xFFFF) continue;
+        for (int w = WAYS - 1; w > 0; w--) table[h][w] = table[h][w - 1];
+        table[h][0] = (uint16_t)rel;
+    }
+}
+
+typedef struct { uint16_t len, dist; } token;   /* len 0: literal */
+/* tokens of data[start, end) (one chunk of a stream of `total` bytes; tiles are aligned to multiples of 64 of the stream).
+   tok[i] describes position start+i; taken[i] = the parse visits it. */
+static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end, token *tok, uint8_t *taken) {
+    uint16_t table[1 << HASH_BITS][WAYS];
+    memset(table, 0xFF, sizeof table);
+    const size_t seed0 = start > 32768 ? start - 32768 : 0;
+    const size_t base_rel = 32768 - start;   /* modulo 2^64: rel = p - start + 32768 */
+    for (size_t t0 = seed0; t0 < start; t0 += 64) insert_tile(table, data, total, base_rel, t0, t0 + 64);
+    size_t carry = start;   /* next position the parse visits */
+    for (size_t t0 = start; t0 < end; t0 += 64) {
+        size_t t1 = t0 + 64 < end ? t0 + 64 : end;
+        for (size_t p = t0; p < t1; p++) {
+            size_t maxlen = end - p < 258 ? end - p : 258;
+            size_t bl = 0, bd = 0;
+            size_t l8best = 0, dbest = 0;
+            for (int k = 0; k < 6; k++) {
+                size_t d = (size_t)FIXED_DIST[k];
+                if (d > p) continue;
+                size_t l8 = lcp(data + p, data + p - d, maxlen < 8 ? maxlen : 8);
+                if (l8 > l8best) { l8best = l8; dbest = d; }
+            }
+            if (l8best) { bl = l8best; bd = dbest; if (l8best == 8 && maxlen > 8) bl = lcp(data + p, data + p - dbest, maxlen); }
+            if (p + 4 <= total) {
+                uint32_t h = hash4(data + p);
+                for (int w = 0; w < WAYS; w++) {   /* most recent first; a longer match wins, a tie keeps the nearer */
+                    if (table[h][w] == 0xFFFF) break;
+                    size_t d = (p + base_rel) - table[h][w];
+                    if (d > 32768) break;
+                    size_t l = lcp(data + p, data + p - d, maxlen);
+                    if (l > bl) { bl = l; bd = d; }
+                }
+            }
+            if (bl < 3 || (bl == 3 && bd > 8)) { bl = 0; bd = 0; }
+            tok[p - start].len = (uint16_t)bl; tok[p - start].dist = (uint16_t)bd;
+        }
+        insert_tile(table, data, total, base_rel, t0, t1);
+        for (size_t p = t0; p < t1; p++) {
+            size_t i = p - start;
+            taken[i] = 0;
+            if (p != carry) continue;
+            taken[i] = 1;
+            int lazy = tok[i].len && p + 1 < t1 && tok[i + 1].len > tok[i].len;
+            if (lazy) tok[i].len = 0;
+            carry = p + (tok[i].len ? tok[i].len : 1);
+        }
+    }
+}
+/* code lengths for freq[0..n): Huffman, then limited to `limit` bits */
+static void code_lengths(const uint32_t *freq_in, int n, int limit, uint8_t *len_out) {
+    uint32_t freq[288]; int codesize[288], others[288], idx[288], m = 0;
+    uint32_t f2[288];
+    memcpy(f2, freq_in, sizeof(uint32_t) * (size_t)n);
+    int used = 0;
+    for (int i = 0; i < n; i++) used += f2[i] != 0;
+    for (int i = 0; i < n && used < 2; i++) if (!f2[i]) { f2[i] = 1; used++; }   /* zlib: force at least two codes */
+    for (int i = 0; i < n; i++) { len_out[i] = 0; if (f2[i]) { freq[m] = f2[i]; idx[m] = i; codesize[m] = 0; others[m] = -1; m++; } }
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        uint64_t v = ~0ull;
+        for (int i = 0; i < m; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        v = ~0ull;
+        for (int i = 0; i < m; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2]; freq[c2] = 0;
+        codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+        others[c1] = c2;
+        codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+    }
+    int bits[64]; memset(bits, 0, sizeof bits);
+    for (int i = 0; i < m; i++) bits[codesize[i] > 63 ? 63 : codesize[i]]++;
+    for (int i = 63; i > limit; i--)
+        while (bits[i] > 0) {
+            int j = i - 2; while (bits[j] == 0) j--;
+            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+        }
+    /* symbols in order of (unlimited) code size, then of symbol, take the limited lengths shortest first */
+    int l = 1;
+    for (int cs = 1; cs < 64; cs++)
+        for (int i = 0; i < m; i++)
+            if ((codesize[i] > 63 ? 63 : codesize[i]) == cs) { while (bits[l] == 0) l++; bits[l]--; len_out[idx[i]] = (uint8_t)l; }
+}
+static void canonical(const uint8_t *len, int n, uint16_t *code) {   /* bit-reversed canonical codes, as deflate packs them */
+    int count[16] = {0}, next[16];
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    count[0] = 0;
+    int c = 0;
+    for (int l = 1; l < 16; l++) { c = (c + count[l - 1]) << 1; next[l] = c; }
+    for (int i = 0; i < n; i++) {
+        code[i] = 0;
+        if (!len[i]) continue;
+        int v = next[len[i]]++, r = 0;
+        for (int b = 0; b < len[i]; b++) r |= ((v >> b) & 1) << (len[i] - 1 - b);
+        code[i] = (uint16_t)r;
+    }
+}
+typedef struct { uint8_t *p; size_t n, cap; uint64_t acc; int nb; } obits;
+static void put(obits *o, uint32_t v, int n) {
+    o->acc |= (uint64_t)v << o->nb; o->nb += n;
+    while (o->nb >= 8) {
+        if (o->n == o->cap) { o->cap = o->cap * 2 + 64; o->p = (uint8_t *)realloc(o->p, o->cap); }
+        o->p[o->n++] = (uint8_t)o->acc; o->acc >>= 8; o->nb -= 8;
+    }
+}
+static void align(obits *o) { if (o->nb) put(o, 0, 8 - o->nb); }
+
+/* the code-length sequence of a block header: run-length symbols over the concatenated litlen + dist lengths */
+static int header_symbols(const uint8_t *seq, int n, uint8_t *sym, uint8_t *extra) {
+    int m = 0;
+    for (int i = 0; i < n;) {
+        int v = seq[i], r = 1;
+        while (i + r < n && seq[i + r] == v) r++;
+        i += r;
+        if (v == 0) {
+            while (r >= 11) { int t = r > 138 ? 138 : r; sym[m] = 18; extra[m++] = (uint8_t)(t - 11); r -= t; }
+            if (r >= 3) { sym[m] = 17; extra[m++] = (uint8_t)(r - 3); r = 0; }
+            while (r--) { sym[m] = 0; extra[m++] = 0; }
+        } else {
+            sym[m] = (uint8_t)v; extra[m++] = 0; r--;
+            while (r >= 3) { int t = r > 6 ? 6 : r; sym[m] = 16; extra[m++] = (uint8_t)(t - 3); r -= t; }
+            while (r--) { sym[m] = (uint8_t)v; extra[m++] = 0; }
+        }
+    }
+    return m;
+}
+static void deflate_chunk(const uint8_t *data, size_t total, size_t start, size_t end, int last, obits *o) {
+    size_t n = end - start;
+    token *tok = (token *)malloc(sizeof(token) * n);
+    uint8_t *taken = (uint8_t *)malloc(n);
+    tokenize(data, total, start, end, tok, taken);
+    uint32_t lf[286], df[30];
+    memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
+    for (size_t i = 0; i < n; i++) {
+        if (!taken[i]) continue;
+        if (tok[i].len) { lf[257 + len_code(tok[i].len)]++; df[dist_code(tok[i].dist)]++; } else lf[data[start + i]]++;
+    }
+    lf[256] = 1;
+    uint8_t ll[286], dl[30];
+    uint16_t lc[286], dc[30];
+    code_lengths(lf, 286, 15, ll);
+    code_lengths(df, 30, 15, dl);
+    canonical(ll, 286, lc); canonical(dl, 30, dc);
+    int nl = 286, nd = 30;
+    while (nl > 257 && !ll[nl - 1]) nl--;
+    while (nd > 1 && !dl[nd - 1]) nd--;
+    uint8_t seq[316], sym[316], extra[316];
+    memcpy(seq, ll, (size_t)nl); memcpy(seq + nl, dl, (size_t)nd);
+    int m = header_symbols(seq, nl + nd, sym, extra);
+    uint32_t cf[19]; memset(cf, 0, sizeof cf);
+    for (int i = 0; i < m; i++) cf[sym[i]]++;
+    uint8_t cl[19]; uint16_t cc[19];
+    code_lengths(cf, 19, 7, cl);
+    canonical(cl, 19, cc);
+    int ncl = 19;
+    while (ncl > 4 && !cl[CL_ORDER[ncl - 1]]) ncl--;
+    put(o, last ? 1 : 0, 1); put(o, 2, 2);
+    put(o, (uint32_t)(nl - 257), 5); put(o, (uint32_t)(nd - 1), 5); put(o, (uint32_t)(ncl - 4), 4);
+    for (int i = 0; i < ncl; i++) put(o, cl[CL_ORDER[i]], 3);
+    for (int i = 0; i < m; i++) {
+        put(o, cc[sym[i]], cl[sym[i]]);
+        if (sym[i] == 16) put(o, extra[i], 2); else if (sym[i] == 17) put(o, extra[i], 3); else if (sym[i] == 18) put(o, extra[i], 7);
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (!taken[i]) continue;
+        if (tok[i].len) {
+            int c = len_code(tok[i].len), d = dist_code(tok[i].dist);
+            put(o, lc[257 + c], ll[257 + c]); put(o, (uint32_t)(tok[i].len - LEN_BASE[c]), LEN_EXTRA[c]);
+            put(o, dc[d], dl[d]); put(o, (uint32_t)(tok[i].dist - DIST_BASE[d]), DIST_EXTRA[d]);
+        } else
+            put(o, lc[data[start + i]], ll[data[start + i]]);
+    }
+    put(o, lc[256], ll[256]);
+    if (last) align(o);
+    else { put(o, 0, 3); align(o); put(o, 0, 16); put(o, 0xFFFF, 16); }
+    free(tok); free(taken);
+}
+/* Brute score: estimated bits of one candidate row (type byte first) coded as a chunk of its own with a dynamic code:
+   n*log2(n) - sum c*log2(c) over the literal/length and the distance histograms of its tokens (ilog2i), plus the extra
+   bits.  Rows longer than a chunk are scored on their first CHUNK bytes. */
+static uint64_t fixed_cost_row(const uint8_t *row, size_t n, int bpp) {
+    (void)bpp;
+    if (n > CHUNK) n = CHUNK;
+    token *tok = (token *)malloc(sizeof(token) * n);
+    uint8_t *taken = (uint8_t *)malloc(n);
+    tokenize(row, n, 0, n, tok, taken);
+    uint32_t lf[286], df[30];
+    memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
+    uint64_t extra = 0, nl = 0, nd = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!taken[i]) continue;
+        nl++;
+        if (tok[i].len) { int c = len_code(tok[i].len), d = dist_code(tok[i].dist); lf[257 + c]++; df[d]++; nd++; extra += (uint64_t)(LEN_EXTRA[c] + DIST_EXTRA[d]); }
+        else lf[row[i]]++;
+    }
+    uint64_t bits = ilog2i(nl) + ilog2i(nd) + extra, sub = 0;
+    for (int i = 0; i < 286; i++) sub += ilog2i(lf[i]);
+    for (int i = 0; i < 30; i++) sub += ilog2i(df[i]);
+    free(tok); free(taken);
+    return bits - sub;
+}
+int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len) {
+    obits o; memset(&o, 0, sizeof o);
+    put(&o, 0x78, 8); put(&o, 0xDA, 8);
+    if (n == 0) { put(&o, 1, 1); put(&o, 1, 2); put(&o, 0, 7); align(&o); }
+    for (size_t s = 0; s < n; s += CHUNK) {
+        size_t e = s + CHUNK < n ? s + CHUNK : n;
+        deflate_chunk(data, n, s, e, e == n, &o);
+    }
+    uint32_t ad = cso_adler32(data, n);
+    put(&o, ad >> 24, 8); put(&o, (ad >> 16) & 255, 8); put(&o, (ad >> 8) & 255, 8); put(&o, ad & 255, 8);
+    *out = o.p; *out_len = o.n;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ the whole row: optimise
+ * trial sets per --png-opt-level, after oxipng's presets [UPSTREAM-RECALL]: 0,1 -> {5}; 2 -> {0,1,6,7}; 3,4 -> {0,7,8,9};
+ * 5 -> {0,1,2,5,6,7,8,9}; 6 -> {0..9}.  (The presets' libdeflate levels have no counterpart: one coder here.)  The
+ * smallest stream wins (ties: the earlier trial); when the new file is not smaller than the input, the input is
+ * returned unchanged (oxipng: "file already optimized"). */
+int cso_png_trials(int level, int *set) {
+    static const int s01[] = {5}, s2[] = {0, 1, 6, 7}, s34[] = {0, 7, 8, 9}, s5[] = {0, 1, 2, 5, 6, 7, 8, 9}, s6[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+    const int *s; int n;
+    if (level <= 1) { s = s01; n = 1; } else if (level == 2) { s = s2; n = 4; } else if (level <= 4) { s = s34; n = 4; } else if (level == 5) { s = s5; n = 8; } else { s = s6; n = 10; }
+    memcpy(set, s, sizeof(int) * (size_t)n);
+    return n;
+}
+int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen) {
+    cso_png *P = NULL;
+    int rc = cso_png_decode(in, n, keep_metadata, &P);
+    if (rc) return rc;
+    size_t raw_len = (1 + P->rowbytes) * (size_t)P->height;
+    uint8_t *filt = (uint8_t *)malloc(raw_len), *best = NULL;
+    size_t best_len = 0;
+    int set[10], ns = cso_png_trials(level, set), best_s = -1;
+    for (int t = 0; t < ns; t++) {
+        uint8_t *z; size_t zl;
+        cso_png_filter(P, set[t], filt, NULL);
+        cso_deflate_zlib(filt, raw_len, &z, &zl);
+        if (!best || zl < best_len) { free(best); best = z; best_len = zl; best_s = set[t]; } else free(z);
+    }
+    free(filt);
+    /* signature, IHDR, the kept chunks in their order with the one new IDAT where the first IDAT stood, IEND */
+    size_t cap = 8 + 25 + P->chunks_len + 12 + best_len + 12;
+    uint8_t *o = (uint8_t *)malloc(cap), *w = o;
+    memcpy(w, PNG_SIG, 8); w += 8;
+    put_be32(w, 13); memcpy(w + 4, "IHDR", 4); put_be32(w + 8, P->width); put_be32(w + 12, P->height);
+    w[16] = (uint8_t)P->depth; w[17] = (uint8_t)P->ctype; w[18] = 0; w[19] = 0; w[20] = 0;
+    put_be32(w + 21, cso_crc32(0, w + 4, 17)); w += 25;
+    memcpy(w, P->chunks, P->idat_at); w += P->idat_at;
+    put_be32(w, (uint32_t)best_len); memcpy(w + 4, "IDAT", 4); memcpy(w + 8, best, best_len);
+    put_be32(w + 8 + best_len, cso_crc32(0, w + 4, 4 + best_len)); w += 12 + best_len;
+    memcpy(w, P->chunks + P->idat_at, P->chunks_len - P->idat_at); w += P->chunks_len - P->idat_at;
+    put_be32(w, 0); memcpy(w + 4, "IEND", 4); put_be32(w + 8, 0xAE426082u); w += 12;
+    size_t total = (size_t)(w - o);
+    free(best);
+    cso_png_free(P);
+    if (chosen) *chosen = best_s;
+    if (total >= n) { free(o); o = (uint8_t *)malloc(n); memcpy(o, in, n); total = n; if (chosen) *chosen = -1; }
+    *out = o; *out_len = total;
+    return 0;
+}

@@ -1,0 +1,24 @@
+/* png_oracle.h -- CPU oracle of the lossless PNG row (TEST INFRASTRUCTURE ONLY; see png_oracle.c) */
+#ifndef PNG_ORACLE_H
+#define PNG_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+enum { CSO_PNG_BAD = 30100, CSO_PNG_UNSUPPORTED = 10201 };
+typedef struct {
+    uint32_t width, height;
+    int depth, ctype, interlace, channels, bpp, nplte;
+    size_t rowbytes;
+    uint8_t *pix;            /* height * rowbytes, unfiltered */
+    uint8_t *chunks;         /* the chunks that are carried over (whole: length, type, data, crc), in file order */
+    size_t chunks_len, idat_at; /* idat_at: offset in `chunks` where the first IDAT stood */
+} cso_png;
+uint32_t cso_crc32(uint32_t crc, const uint8_t *p, size_t n);
+uint32_t cso_adler32(const uint8_t *p, size_t n);
+int cso_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced);
+int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out);
+void cso_png_free(cso_png *p);
+int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice);
+int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len);
+int cso_png_trials(int level, int *set);
+int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen);
+#endif

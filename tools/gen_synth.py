@@ -43,3 +43,26 @@ def synth_jpeg(i, w=1920, h=1080, quality=92, subsampling=2, progressive=False, 
     Image.fromarray(synth_rgb(i, w, h, texture), "RGB").save(b, format="JPEG", quality=quality, subsampling=subsampling,
                                                     progressive=progressive, optimize=optimize, **kw)
     return b.getvalue()
+
+
+def synth_png(seed, width, height, mode="RGB", compress_level=6, **save_kw):
+    """PNG of the SURVEY 8d synthetic picture in a Pillow mode ("RGB", "RGBA", "L", "LA", "P", "1", "I;16"), written by
+    Pillow/libpng (adaptive filtering, zlib `compress_level`)."""
+    import io
+
+    from PIL import Image
+    im = Image.fromarray(synth_rgb(seed, width, height), "RGB")
+    if mode == "I;16":
+        rng = np.random.default_rng(seed)
+        a = np.asarray(im.convert("L")).astype(np.uint16) * 256 + rng.integers(0, 256, (height, width), dtype=np.uint16)
+        im = Image.frombytes("I;16", (width, height), a.astype("<u2").tobytes())
+    elif mode == "RGBA":
+        im = im.convert("RGBA")
+        a = np.asarray(im).copy()
+        a[height // 4: height // 2, width // 4: width // 2, 3] = 128
+        im = Image.fromarray(a, "RGBA")
+    elif mode != "RGB":
+        im = im.convert(mode)
+    b = io.BytesIO()
+    im.save(b, "PNG", compress_level=compress_level, **save_kw)
+    return b.getvalue()
