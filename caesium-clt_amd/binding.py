@@ -29,6 +29,11 @@ class Timing(C.Structure):
                 ("pixels", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32), ("n_seq_decoded", C.c_uint32), ("n_par_fallback", C.c_uint32), ("n_par_short", C.c_uint32), ("n_prog_decoded", C.c_uint32)]
 
 
+class PngTiming(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("kernel_ms", C.c_float * 16), ("in_bytes", C.c_uint64), ("out_bytes", C.c_uint64), ("pixels", C.c_uint64),
+                ("raw_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32), ("n_trials", C.c_uint32)]
+
+
 class CaesiumError(RuntimeError):
     def __init__(self, code, message):
         super().__init__(f"[{code}] {message}")
@@ -41,7 +46,9 @@ def library_path():
 
 EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory",
            "cs_batch_compress", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
-           "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs"]
+           "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
+           "csp_kernel_name", "csp_batch_create", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
+           "csp_batch_trials", "csp_batch_read_scores"]
 
 
 def _declare(L):
@@ -73,6 +80,18 @@ def _declare(L):
     L.csh_batch_destroy.restype = None
     L.csh_batch_geometry.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
     L.csh_batch_read_coefs.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    L.csp_kernel_name.argtypes = [C.c_int]
+    L.csp_kernel_name.restype = C.c_char_p
+    L.csp_batch_create.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(C.c_void_p)]
+    L.csp_batch_run.argtypes = [C.c_void_p, P(PngTiming)]
+    L.csp_batch_fetch.argtypes = [C.c_void_p, P(CByteArray), P(CCSResult)]
+    L.csp_batch_destroy.argtypes = [C.c_void_p]
+    L.csp_batch_destroy.restype = None
+    L.csp_batch_geometry.argtypes = [C.c_void_p, C.c_size_t, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]
+    L.csp_batch_read_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.csp_batch_read_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.csp_batch_read_scores.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, P(C.c_int)]
+    L.csp_batch_trials.argtypes = [C.c_void_p, C.c_size_t, P(C.c_int), P(C.c_uint64), P(C.c_int), P(C.c_int)]
     return L
 
 
@@ -171,6 +190,93 @@ class Batch:
             pass
 
 
+class PngBatch:
+    """csp_batch: a group of PNG files resident in HBM (the lossless PNG row)."""
+
+    def __init__(self, api, blobs, params, device=0):
+        self.api = api
+        L = api.L
+        self.n = len(blobs)
+        self._keep = [C.create_string_buffer(b, len(b)) for b in blobs]
+        self._in = (CByteArray * self.n)()
+        for i, buf in enumerate(self._keep):
+            self._in[i].data = C.cast(buf, C.POINTER(C.c_uint8))
+            self._in[i].length = len(blobs[i])
+        self.h = C.c_void_p()
+        rc = L.csp_batch_create(self._in, self.n, C.byref(params), device, C.byref(self.h))
+        if rc:
+            raise CaesiumError(rc, L.csh_last_error().decode())
+
+    def run(self):
+        t = PngTiming()
+        rc = self.api.L.csp_batch_run(self.h, C.byref(t))
+        if rc:
+            raise CaesiumError(rc, self.api.L.csh_last_error().decode())
+        return t
+
+    def fetch(self):
+        L = self.api.L
+        outs = (CByteArray * self.n)()
+        res = (CCSResult * self.n)()
+        if L.csp_batch_fetch(self.h, outs, res) < 0:
+            raise CaesiumError(-1, L.csh_last_error().decode())
+        result = []
+        for i in range(self.n):
+            result.append(C.string_at(outs[i].data, outs[i].length) if res[i].success else CaesiumError(res[i].code, (res[i].error_message or b"").decode()))
+            L.cs_free_bytes(C.byref(outs[i])); L.cs_free_result(C.byref(res[i]))
+        return result
+
+    def geometry(self, image):
+        w, h, rb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        if self.api.L.csp_batch_geometry(self.h, image, C.byref(w), C.byref(h), C.byref(rb)):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+        return w.value, h.value, rb.value
+
+    def rows(self, image):
+        import numpy as np
+        w, h, rb = self.geometry(image)
+        out = np.empty((h, rb), dtype=np.uint8)
+        if self.api.L.csp_batch_read_rows(self.h, image, out.ctypes.data):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+        return out
+
+    def stream(self, image, strategy):
+        import numpy as np
+        w, h, rb = self.geometry(image)
+        out = np.empty(h * (rb + 1), dtype=np.uint8)
+        if self.api.L.csp_batch_read_stream(self.h, image, strategy, out.ctypes.data):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+        return out
+
+    def scores(self, image):
+        """-> ([height][5][5] scores, bit mask of the score columns this plan computed)"""
+        import numpy as np
+        w, h, rb = self.geometry(image)
+        out = np.zeros((h, 5, 5), dtype=np.uint64)
+        have = C.c_int()
+        if self.api.L.csp_batch_read_scores(self.h, image, out.ctypes.data, C.byref(have)):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+        return out, have.value
+
+    def trials(self, image):
+        """-> ([(strategy, zlib bytes)], index of the winner)"""
+        st = (C.c_int * 10)(); zb = (C.c_uint64 * 10)(); n = C.c_int(); w = C.c_int()
+        if self.api.L.csp_batch_trials(self.h, image, st, zb, C.byref(n), C.byref(w)):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+        return [(st[i], zb[i]) for i in range(n.value)], w.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.api.L.csp_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CaesiumHip:
     def __init__(self, path=None):
         path = path or library_path()
@@ -221,6 +327,27 @@ class CaesiumHip:
 
     def batch(self, blobs, params, device=0):
         return Batch(self, blobs, params, device)
+
+    def png_batch(self, blobs, params, device=0):
+        return PngBatch(self, blobs, params, device)
+
+    def png_kernel_names(self):
+        return [self.L.csp_kernel_name(i).decode() for i in range(16)]
+
+    def cs_batch_compress(self, blobs, params, device=0):
+        """the C entry point itself: mixed inputs, routed per file type"""
+        n = len(blobs)
+        keep = [C.create_string_buffer(x, len(x)) for x in blobs]
+        ins = (CByteArray * n)()
+        for i, buf in enumerate(keep):
+            ins[i].data = C.cast(buf, C.POINTER(C.c_uint8)); ins[i].length = len(blobs[i])
+        outs = (CByteArray * n)(); res = (CCSResult * n)()
+        self.L.cs_batch_compress(ins, n, C.byref(params), device, outs, res)
+        result = []
+        for i in range(n):
+            result.append(C.string_at(outs[i].data, outs[i].length) if res[i].success else CaesiumError(res[i].code, (res[i].error_message or b"").decode()))
+            self.L.cs_free_bytes(C.byref(outs[i])); self.L.cs_free_result(C.byref(res[i]))
+        return result
 
     def batch_compress(self, blobs, params, device=0):
         b = self.batch(blobs, params, device)

@@ -27,7 +27,7 @@ static CCSResult make_result(int code, const char *msg) {
 // one device batch = at most CS_GROUP files: launch grids index (image, scan) pairs in gridDim.y (<= 65535), and a group
 // of 2048 1080p files already occupies ~40 GB of HBM and tens of thousands of workgroups per launch
 enum { CS_GROUP = 2048 };
-int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
     int failed_total = 0;
     for (size_t g0 = 0; g0 < count; g0 += CS_GROUP) {
@@ -56,6 +56,71 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
         failed_total += failed < 0 ? int(n) : failed;
     }
     return failed_total;
+}
+
+static int sniff(const uint8_t *d, size_t n);
+// lossless PNG (png.optimize): groups sized by what they occupy in HBM -- per file the inflated stream, the pixels, one
+// filtered stream per trial slot (up to 10) and the output region, ~13 x the raw size
+static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+    int failed_total = 0;
+    const uint64_t budget = uint64_t(96) << 30;
+    for (size_t g0 = 0; g0 < count;) {
+        uint64_t bytes = 0;
+        size_t n = 0;
+        while (g0 + n < count && n < 4096) {
+            const uint8_t *d = inputs[g0 + n].data;
+            uint64_t est = 1 << 20;
+            if (inputs[g0 + n].length >= 33) {
+                const uint64_t w = (uint64_t(d[16]) << 24) | (d[17] << 16) | (d[18] << 8) | d[19], h = (uint64_t(d[20]) << 24) | (d[21] << 16) | (d[22] << 8) | d[23];
+                est += w * h * 8 * 14;   // at most 8 bytes per pixel
+            }
+            if (n && bytes + est > budget) break;
+            bytes += est; n++;
+        }
+        csp_batch *b = nullptr;
+        const bool trace = getenv("CSH_TRACE") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = csp_batch_create(inputs + g0, n, p, device, &b);
+        auto t1 = std::chrono::steady_clock::now();
+        if (rc == 0) rc = csp_batch_run(b, nullptr);
+        auto t2 = std::chrono::steady_clock::now();
+        if (rc != 0) {
+            for (size_t i = 0; i < n; i++) { outputs[g0 + i].data = nullptr; outputs[g0 + i].length = 0; if (results) results[g0 + i] = make_result(rc, csh_last_error()); }
+            failed_total += int(n);
+        } else {
+            int failed = csp_batch_fetch(b, outputs + g0, results ? results + g0 : nullptr);
+            failed_total += failed < 0 ? int(n) : failed;
+        }
+        csp_batch_destroy(b);
+        if (trace) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[csh] %zu PNG files on device %d: create %.1f ms, run %.1f ms, fetch+destroy %.1f ms\n", n, device, ms(t0, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
+        }
+        g0 += n;
+    }
+    return failed_total;
+}
+
+// one call, mixed inputs: PNG files under png.optimize go to the PNG pipeline, everything else to the JPEG pipeline (which
+// answers per file for what it has no device path for); results keep the order of the inputs
+int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+    std::vector<size_t> png;
+    if (p->png_optimize) for (size_t i = 0; i < count; i++) if (sniff(inputs[i].data, inputs[i].length) == CS_TYPE_PNG) png.push_back(i);
+    if (png.empty()) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
+    std::vector<size_t> other;
+    { size_t k = 0; for (size_t i = 0; i < count; i++) { if (k < png.size() && png[k] == i) k++; else other.push_back(i); } }
+    int failed = 0;
+    auto run = [&](const std::vector<size_t> &idx, bool is_png) {
+        if (idx.empty()) return;
+        std::vector<CByteArray> in(idx.size()), out(idx.size());
+        std::vector<CCSResult> res(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) in[k] = inputs[idx[k]];
+        failed += is_png ? png_batch_compress(in.data(), in.size(), p, device, out.data(), res.data()) : jpeg_batch_compress(in.data(), in.size(), p, device, out.data(), res.data());
+        for (size_t k = 0; k < idx.size(); k++) { outputs[idx[k]] = out[k]; if (results) results[idx[k]] = res[k]; else cs_free_result(&res[k]); }
+    };
+    run(png, true);
+    run(other, false);
+    return failed;
 }
 
 CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, CByteArray *out) {

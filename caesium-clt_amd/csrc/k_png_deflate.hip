@@ -1,0 +1,432 @@
+// k_png_deflate.hip -- row P4 of SURVEY.md 8a: DEFLATE of the filtered streams (statement: oracle/png_oracle.c
+// deflate_chunk() / cso_deflate_zlib() / cso_png_optimize()).
+// The reference spends >90 % of this path in libdeflate's serial optimal parser, once per filter trial.  Here a stream
+// is cut into 32 KiB chunks that are coded independently -- one dynamic-Huffman block each, byte-aligned by an empty
+// stored block (the sync marker pigz uses) -- so the unit of parallelism is (image, trial, chunk):
+//   hist   one wave per (trial, chunk): tokenizer (png_lz.h), symbol counts into LDS
+//   codes  one lane per (trial, chunk): code lengths, canonical codes, header run-lengths, exact block size
+//   choose one lane per image: stream size of every trial, the winner, byte offset of each of its chunks
+//   emit   one wave per chunk of the winner: tokenizer again, bits through an LDS window straight to their final place
+//   finish Adler-32, CRC-32, IDAT framing, carried chunks
+// Only sizes decide the winner, so the losing trials are never packed.
+#include "png_kernels.h"
+#include "png_lz.h"
+
+namespace csp {
+
+__device__ static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ static PngChunk &chunk_rec(const DeflateCtx &c, const PngImg &im, int slot, uint32_t ci) {
+    return c.chunks[uint64_t(im.chunk_base) + uint64_t(slot) * im.nchunks + ci];
+}
+
+// ------------------------------------------------------------------------------------------------ hist
+struct HistLds { LzLds lz; uint32_t hist[CSP_NSYM]; };
+struct HistSink {
+    uint32_t *hist;
+    LV<uint32_t> extra;
+    __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t taken, const LV<uint32_t> &mlen, const LV<uint32_t> &mdist, const LV<uint32_t> &lit) {
+        LFOR(l) if ((taken >> l) & 1) {
+            if (mlen[l]) {
+                const uint32_t lc = len_code_of(mlen[l]), dc = dist_code_of(mdist[l]);
+                atomicAdd(&hist[257 + lc], 1u); atomicAdd(&hist[CSP_NLIT + dc], 1u);
+                extra[l] += len_extra_of(lc) + dist_extra_of(dc);
+            } else
+                atomicAdd(&hist[lit[l]], 1u);
+        }
+    }
+};
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_hist(DeflateCtx c) {
+    CSH_SHARED HistLds S;
+    const uint32_t bc = blockIdx.x, trial = blockIdx.y;
+    const uint32_t image = c.chunk_image[bc];
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint32_t ci = bc - c.chunk_first[image];
+    const int slot = c.plan.trial_slot[trial];
+    const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
+    const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
+    LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.hist[i] = 0;
+    HistSink sink; sink.hist = S.hist;
+    LFOR(l) sink.extra[l] = 0;
+    CSP_WAVE_SYNC();
+    lz_chunk(data, im.raw_len, start, end, S.lz, sink);
+    CSP_WAVE_SYNC();
+    PngChunk &rec = chunk_rec(c, im, slot, ci);
+    LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) rec.freq[i] = i == 256 ? 1u : S.hist[i];
+    LV<uint64_t> e;
+    LFOR(l) e[l] = sink.extra[l];
+    const uint64_t extra = lsum(e);
+    LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+}
+
+// ------------------------------------------------------------------------------------------------ codes
+// Huffman by repeated merge of the two least frequent (ties: the larger index first), limited by the bit-count adjustment
+// of T.81 K.2; at least two symbols are coded (zlib's rule).  One lane does one code: the arrays live in scratch.
+__device__ static void code_lengths(const uint32_t *freq_in, int n, int limit, uint8_t *len_out) {
+    uint32_t freq[288];
+    int16_t codesize[288], others[288], idx[288];
+    int used = 0, m = 0;
+    for (int i = 0; i < n; i++) used += freq_in[i] != 0;
+    int forced = 2 - used;   // zero-frequency symbols that get a code anyway, lowest first
+    for (int i = 0; i < n; i++) {
+        uint32_t f = freq_in[i];
+        if (!f && forced > 0) { f = 1; forced--; }
+        len_out[i] = 0;
+        if (f) { freq[m] = f; idx[m] = int16_t(i); codesize[m] = 0; others[m] = -1; m++; }
+    }
+    for (;;) {
+        int c1 = -1, c2 = -1;
+        uint64_t v = ~0ull;
+        for (int i = 0; i < m; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
+        v = ~0ull;
+        for (int i = 0; i < m; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
+        if (c2 < 0) break;
+        freq[c1] += freq[c2]; freq[c2] = 0;
+        codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
+        others[c1] = int16_t(c2);
+        codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
+    }
+    int bits[64];
+    for (int i = 0; i < 64; i++) bits[i] = 0;
+    for (int i = 0; i < m; i++) bits[codesize[i] > 63 ? 63 : codesize[i]]++;
+    for (int i = 63; i > limit; i--)
+        while (bits[i] > 0) {
+            int j = i - 2; while (bits[j] == 0) j--;
+            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
+        }
+    int l = 1;
+    for (int cs = 1; cs < 64; cs++)
+        for (int i = 0; i < m; i++)
+            if ((codesize[i] > 63 ? 63 : codesize[i]) == cs) { while (bits[l] == 0) l++; bits[l]--; len_out[idx[i]] = uint8_t(l); }
+}
+__device__ static void canonical(const uint8_t *len, int n, uint16_t *code) {   // bit-reversed, as deflate packs Huffman codes
+    int count[16], next[16];
+    for (int i = 0; i < 16; i++) count[i] = 0;
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    count[0] = 0;
+    int cd = 0;
+    next[0] = 0;
+    for (int l = 1; l < 16; l++) { cd = (cd + count[l - 1]) << 1; next[l] = cd; }
+    for (int i = 0; i < n; i++) {
+        code[i] = 0;
+        if (!len[i]) continue;
+        const int v = next[len[i]]++;
+        int r = 0;
+        for (int b = 0; b < len[i]; b++) r |= ((v >> b) & 1) << (len[i] - 1 - b);
+        code[i] = uint16_t(r);
+    }
+}
+__global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c) {
+    const uint32_t bc = blockIdx.x * blockDim.x + threadIdx.x, trial = blockIdx.y;
+    if (bc >= c.total_chunks) return;
+    const uint32_t image = c.chunk_image[bc];
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint32_t ci = bc - c.chunk_first[image];
+    PngChunk &rec = chunk_rec(c, im, c.plan.trial_slot[trial], ci);
+    code_lengths(rec.freq, CSP_NLIT, 15, rec.len);
+    code_lengths(rec.freq + CSP_NLIT, CSP_NDIST, 15, rec.len + CSP_NLIT);
+    canonical(rec.len, CSP_NLIT, rec.code);
+    canonical(rec.len + CSP_NLIT, CSP_NDIST, rec.code + CSP_NLIT);
+    int nl = CSP_NLIT, nd = CSP_NDIST;
+    while (nl > 257 && !rec.len[nl - 1]) nl--;
+    while (nd > 1 && !rec.len[CSP_NLIT + nd - 1]) nd--;
+    // run-length symbols over the concatenated lengths (runs may cross from one alphabet into the other)
+    int m = 0;
+    const int total = nl + nd;
+    auto at = [&](int i) -> int { return i < nl ? rec.len[i] : rec.len[CSP_NLIT + (i - nl)]; };
+    for (int i = 0; i < total;) {
+        const int v = at(i);
+        int r = 1;
+        while (i + r < total && at(i + r) == v) r++;
+        i += r;
+        if (v == 0) {
+            while (r >= 11) { const int t = r > 138 ? 138 : r; rec.hdr_sym[m] = 18; rec.hdr_extra[m++] = uint8_t(t - 11); r -= t; }
+            if (r >= 3) { rec.hdr_sym[m] = 17; rec.hdr_extra[m++] = uint8_t(r - 3); r = 0; }
+            while (r--) { rec.hdr_sym[m] = 0; rec.hdr_extra[m++] = 0; }
+        } else {
+            rec.hdr_sym[m] = uint8_t(v); rec.hdr_extra[m++] = 0; r--;
+            while (r >= 3) { const int t = r > 6 ? 6 : r; rec.hdr_sym[m] = 16; rec.hdr_extra[m++] = uint8_t(t - 3); r -= t; }
+            while (r--) { rec.hdr_sym[m] = uint8_t(v); rec.hdr_extra[m++] = 0; }
+        }
+    }
+    uint32_t cf[CSP_NCL];
+    for (int i = 0; i < int(CSP_NCL); i++) cf[i] = 0;
+    for (int i = 0; i < m; i++) cf[rec.hdr_sym[i]]++;
+    code_lengths(cf, CSP_NCL, 7, rec.cl_len);
+    canonical(rec.cl_len, CSP_NCL, rec.cl_code);
+    int ncl = CSP_NCL;
+    while (ncl > 4 && !rec.cl_len[kClOrder[ncl - 1]]) ncl--;
+    rec.hlit = uint16_t(nl); rec.hdist = uint16_t(nd); rec.hclen = uint16_t(ncl); rec.nhdr = uint16_t(m);
+    uint64_t bits = 3 + 5 + 5 + 4 + 3 * uint64_t(ncl);
+    for (int i = 0; i < m; i++) { const int s = rec.hdr_sym[i]; bits += rec.cl_len[s] + (s == 16 ? 2 : s == 17 ? 3 : s == 18 ? 7 : 0); }
+    for (int i = 0; i < int(CSP_NSYM); i++) bits += uint64_t(rec.freq[i]) * rec.len[i];
+    bits += rec.extra_bits;
+    rec.bits = bits;
+    const bool last = ci + 1 == im.nchunks;
+    rec.bytes = last ? uint32_t((bits + 7) >> 3) : uint32_t((bits + 3 + 7) >> 3) + 4u;
+}
+
+// ------------------------------------------------------------------------------------------------ choose
+__global__ void __launch_bounds__(64) k_png_choose(DeflateCtx c) {
+    const int image = blockIdx.x * blockDim.x + threadIdx.x;
+    if (image >= c.nimg || c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    int best = 0;
+    uint64_t best_bytes = ~0ull;
+    for (int t = 0; t < c.plan.ntrials; t++) {
+        uint64_t bytes = 2 + 4;
+        for (uint32_t ci = 0; ci < im.nchunks; ci++) bytes += chunk_rec(c, im, c.plan.trial_slot[t], ci).bytes;
+        c.trial_bytes[uint64_t(image) * CSP_MAX_STREAMS + t] = bytes;
+        if (bytes < best_bytes) { best_bytes = bytes; best = t; }
+    }
+    c.winner[image] = best;
+    const uint64_t file_len = uint64_t(im.prefix_len) + 12 + best_bytes + im.suffix_len;
+    if (file_len > im.out_cap) { c.status[image] = CSP_ERR_POOL; return; }
+    c.file_len[image] = uint32_t(file_len);
+}
+
+// ------------------------------------------------------------------------------------------------ emit
+// bits are OR-ed into a window of LDS words; complete words leave for HBM after every tile
+struct EmitLds { LzLds lz; uint32_t code[CSP_NSYM]; uint32_t win[160]; };
+struct BitOut {
+    uint32_t *win;       // window: word 0 = output word `wbase`
+    uint8_t *out;        // chunk's first byte
+    uint64_t bitpos;     // bits written so far
+    uint32_t wbase;
+    // every lane appends nbits[l] (<= 48) bits of val[l], lane order
+    __device__ void put(const LV<uint64_t> &val, const LV<uint32_t> &nbits) {
+        uint32_t total;
+        const LV<uint32_t> off = lscan(nbits, total);
+        if (!total) return;
+        LFOR(l) if (nbits[l]) {
+            const uint64_t at = bitpos + off[l] - uint64_t(wbase) * 32u;
+            const uint32_t w = uint32_t(at >> 5), sh = uint32_t(at & 31u);
+            const uint64_t v = val[l] & ((1ull << nbits[l]) - 1ull);
+            atomicOr(&win[w], uint32_t(v << sh));
+            if (sh + nbits[l] > 32) atomicOr(&win[w + 1], uint32_t(v >> (32 - sh)));
+            if (sh + nbits[l] > 64) atomicOr(&win[w + 2], uint32_t(v >> (64 - sh)));
+        }
+        bitpos += total;
+        CSP_WAVE_SYNC();
+        const uint32_t full = uint32_t(bitpos >> 5) - wbase;   // complete words
+        if (full) {
+            for (uint32_t w0 = 0; w0 < full; w0 += 64) LFOR(l) {
+                const uint32_t w = w0 + uint32_t(l);
+                if (w < full) { const uint32_t v = win[w]; uint8_t *o = out + uint64_t(wbase + w) * 4u; o[0] = uint8_t(v); o[1] = uint8_t(v >> 8); o[2] = uint8_t(v >> 16); o[3] = uint8_t(v >> 24); }
+            }
+            CSP_WAVE_SYNC();
+            const uint32_t carry = win[full];
+            CSP_WAVE_SYNC();
+            LFOR(l) for (uint32_t w = uint32_t(l); w <= full; w += 64) win[w] = w == 0 ? carry : 0u;
+            wbase += full;
+            CSP_WAVE_SYNC();
+        }
+    }
+    // the last partial word, byte by byte, up to the byte that holds bit bitpos-1
+    __device__ void finish() {
+        const uint32_t nbytes = uint32_t(((bitpos + 7) >> 3) - uint64_t(wbase) * 4u);
+        LFOR(l) if (uint32_t(l) < nbytes) out[uint64_t(wbase) * 4u + uint32_t(l)] = uint8_t(win[0] >> (8 * l));
+    }
+};
+struct EmitSink {
+    const uint32_t *code;   // code | length << 16, litlen then distance
+    BitOut *bo;
+    __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t taken, const LV<uint32_t> &mlen, const LV<uint32_t> &mdist, const LV<uint32_t> &lit) {
+        LV<uint64_t> val; LV<uint32_t> nb;
+        LFOR(l) {
+            val[l] = 0; nb[l] = 0;
+            if ((taken >> l) & 1) {
+                if (mlen[l]) {
+                    const uint32_t lc = len_code_of(mlen[l]), dc = dist_code_of(mdist[l]);
+                    const uint32_t cl = code[257 + lc], cd = code[CSP_NLIT + dc];
+                    uint64_t v = cl & 0xFFFFu; uint32_t n = cl >> 16;
+                    v |= uint64_t(mlen[l] - len_base_of(lc)) << n; n += len_extra_of(lc);
+                    v |= uint64_t(cd & 0xFFFFu) << n; n += cd >> 16;
+                    v |= uint64_t(mdist[l] - dist_base_of(dc)) << n; n += dist_extra_of(dc);
+                    val[l] = v; nb[l] = n;
+                } else { const uint32_t cl = code[lit[l]]; val[l] = cl & 0xFFFFu; nb[l] = cl >> 16; }
+            }
+        }
+        bo->put(val, nb);
+    }
+};
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_emit(DeflateCtx c) {
+    CSH_SHARED EmitLds S;
+    const uint32_t bc = blockIdx.x;
+    const uint32_t image = c.chunk_image[bc];
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint32_t ci = bc - c.chunk_first[image];
+    const int slot = c.plan.trial_slot[c.winner[image]];
+    const PngChunk &rec = chunk_rec(c, im, slot, ci);
+    const bool last = ci + 1 == im.nchunks;
+    // where this chunk's bytes go: after the zlib header and the chunks in front of it
+    uint64_t at = uint64_t(im.prefix_len) + 8 + 2;
+    {
+        LV<uint64_t> part;
+        LFOR(l) { uint64_t s = 0; for (uint32_t k = uint32_t(l); k < ci; k += 64) s += chunk_rec(c, im, slot, k).bytes; part[l] = s; }
+        at += lsum(part);
+    }
+    LFOR(l) {
+        for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.code[i] = uint32_t(rec.code[i]) | (uint32_t(rec.len[i]) << 16);
+        for (uint32_t i = uint32_t(l); i < 160; i += 64) S.win[i] = 0;
+    }
+    CSP_WAVE_SYNC();
+    BitOut bo; bo.win = S.win; bo.out = c.out + im.out_off + at; bo.bitpos = 0; bo.wbase = 0;
+    LV<uint64_t> val; LV<uint32_t> nb;
+    // block header: BFINAL, BTYPE=2, HLIT, HDIST, HCLEN (lane 0), the code-length code's lengths (lanes 1..)
+    LFOR(l) {
+        val[l] = 0; nb[l] = 0;
+        if (l == 0) { val[l] = (last ? 1u : 0u) | (2u << 1) | (uint64_t(rec.hlit - 257) << 3) | (uint64_t(rec.hdist - 1) << 8) | (uint64_t(rec.hclen - 4) << 13); nb[l] = 17; }
+        else if (l <= int(rec.hclen)) { val[l] = rec.cl_len[kClOrder[l - 1]]; nb[l] = 3; }
+    }
+    bo.put(val, nb);
+    for (uint32_t h0 = 0; h0 < rec.nhdr; h0 += 64) {
+        LFOR(l) {
+            val[l] = 0; nb[l] = 0;
+            const uint32_t h = h0 + uint32_t(l);
+            if (h < rec.nhdr) {
+                const uint32_t s = rec.hdr_sym[h], n = rec.cl_len[s];
+                val[l] = uint64_t(rec.cl_code[s]) | (uint64_t(rec.hdr_extra[h]) << n);
+                nb[l] = n + (s == 16 ? 2u : s == 17 ? 3u : s == 18 ? 7u : 0u);
+            }
+        }
+        bo.put(val, nb);
+    }
+    EmitSink sink; sink.code = S.code; sink.bo = &bo;
+    const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
+    const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
+    lz_chunk(data, im.raw_len, start, end, S.lz, sink);
+    // end of block; then the sync marker (empty stored block) that byte-aligns every chunk but the last
+    LFOR(l) {
+        val[l] = 0; nb[l] = 0;
+        if (l == 0) { val[l] = S.code[256] & 0xFFFFu; nb[l] = S.code[256] >> 16; }
+        if (l == 1 && !last) nb[l] = 3;
+    }
+    bo.put(val, nb);
+    if (!last) {
+        const uint32_t pad = uint32_t((8 - (bo.bitpos & 7)) & 7);
+        LFOR(l) { val[l] = 0; nb[l] = 0; if (l == 0) nb[l] = pad; if (l == 1) nb[l] = 16; if (l == 2) { val[l] = 0xFFFF; nb[l] = 16; } }
+        bo.put(val, nb);
+    }
+    CSP_WAVE_SYNC();
+    bo.finish();
+    if (bo.bitpos != (last ? rec.bits : ((rec.bits + 3 + 7) & ~7ull) + 32)) LFOR(l) if (l == 0) c.status[image] = CSP_ERR_POOL;   // the size pass and the emit pass disagree: never ship it
+}
+
+// ------------------------------------------------------------------------------------------------ finish
+// Adler-32 parts of the winner's chunks: (sum of bytes, sum of (n - i) * byte) per chunk, modulo 65521
+__global__ void __launch_bounds__(256) k_png_adler(DeflateCtx c) {
+    CSH_SHARED unsigned long long acc[2];
+    const uint32_t bc = blockIdx.x;
+    const uint32_t image = c.chunk_image[bc];
+    const PngImg &im = c.imgs[image];
+    const uint32_t ci = bc - c.chunk_first[image];
+    const bool dead = c.status[image] != 0;
+    CSH_PHASE_LOOP(3) {
+        if (phase == 0) { if (threadIdx.x == 0) { acc[0] = 0; acc[1] = 0; } continue; }
+        if (dead) continue;
+        if (phase == 1) {
+            const int slot = c.plan.trial_slot[c.winner[image]];
+            const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
+            const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
+            const uint32_t n = uint32_t(end - start);
+            unsigned long long s1 = 0, s2 = 0;
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { const uint32_t b = data[start + i]; s1 += b; s2 += uint64_t(n - i) * b; }
+            if (s1) { atomicAdd(&acc[0], s1); atomicAdd(&acc[1], s2); }
+            continue;
+        }
+        if (threadIdx.x == 0) { c.adler_parts[2 * uint64_t(bc)] = uint32_t(acc[0] % 65521u); c.adler_parts[2 * uint64_t(bc) + 1] = uint32_t(acc[1] % 65521u); }
+    }
+}
+// CRC-32 of the IDAT chunk in KiB pieces (type field + zlib stream), one lane per piece; the pieces are folded by k_png_finish
+enum { CRC_PIECE = 1024 };
+__device__ __forceinline__ static uint32_t crc_byte_table(uint32_t n) { uint32_t v = n; for (int k = 0; k < 8; k++) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1; return v; }
+__device__ static uint32_t gf2_mul(uint32_t a, uint32_t b) {   // a * b modulo the CRC polynomial (zlib multmodp)
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+__device__ static uint32_t gf2_x_pow_bytes(uint64_t nbytes) {   // x^(8 * nbytes)
+    uint32_t sq = 1u << 30;   // x^1
+    for (int k = 0; k < 3; k++) sq = gf2_mul(sq, sq);   // x^8
+    uint32_t p = 1u << 31;    // x^0
+    while (nbytes) { if (nbytes & 1) p = gf2_mul(sq, p); sq = gf2_mul(sq, sq); nbytes >>= 1; }
+    return p;
+}
+__global__ void __launch_bounds__(256) k_png_crc_pieces(DeflateCtx c, uint32_t max_pieces) {
+    CSH_SHARED uint32_t table[256];
+    const int image = blockIdx.y;
+    const PngImg &im = c.imgs[image];
+    const bool dead = c.status[image] != 0;
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) { table[threadIdx.x] = crc_byte_table(threadIdx.x); continue; }
+        if (dead) continue;
+        const uint64_t n = uint64_t(c.file_len[image]) - im.prefix_len - im.suffix_len - 8;   // "IDAT" + stream
+        const uint32_t piece = blockIdx.x * blockDim.x + threadIdx.x;
+        if (uint64_t(piece) * CRC_PIECE >= n) continue;
+        const uint8_t *p = c.out + im.out_off + im.prefix_len + 4 + uint64_t(piece) * CRC_PIECE;
+        const uint32_t m = n - uint64_t(piece) * CRC_PIECE < CRC_PIECE ? uint32_t(n - uint64_t(piece) * CRC_PIECE) : uint32_t(CRC_PIECE);
+        uint32_t crc = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < m; i++) crc = table[(crc ^ p[i]) & 255u] ^ (crc >> 8);
+        c.crc_parts[uint64_t(image) * max_pieces + piece] = ~crc;
+    }
+}
+// per image: zlib header and Adler-32, IDAT length / type / CRC, the carried chunks in front and behind
+__global__ void __launch_bounds__(64) k_png_frame(DeflateCtx c) {
+    const int image = blockIdx.x;
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    uint8_t *o = c.out + im.out_off;
+    const uint32_t flen = c.file_len[image];
+    const uint64_t zlen = uint64_t(flen) - im.prefix_len - im.suffix_len - 12;
+    for (uint32_t i = threadIdx.x; i < im.prefix_len; i += blockDim.x) o[i] = c.fixed[im.fix_off + i];
+    for (uint32_t i = threadIdx.x; i < im.suffix_len; i += blockDim.x) o[flen - im.suffix_len + i] = c.fixed[im.fix_off + im.prefix_len + i];
+    if (threadIdx.x == 0) {
+        uint8_t *d = o + im.prefix_len;
+        d[0] = uint8_t(zlen >> 24); d[1] = uint8_t(zlen >> 16); d[2] = uint8_t(zlen >> 8); d[3] = uint8_t(zlen);
+        d[4] = 'I'; d[5] = 'D'; d[6] = 'A'; d[7] = 'T';
+        d[8] = 0x78; d[9] = 0xDA;
+        uint64_t a = 1, b = 0;
+        const uint32_t first = c.chunk_first[image];
+        for (uint32_t ci = 0; ci < im.nchunks; ci++) {
+            const uint64_t start = uint64_t(ci) * CSP_CHUNK, n = (start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len) - start;
+            b = (b + n % 65521u * a + c.adler_parts[2 * uint64_t(first + ci) + 1]) % 65521u;
+            a = (a + c.adler_parts[2 * uint64_t(first + ci)]) % 65521u;
+        }
+        uint8_t *t = d + 8 + zlen - 4;
+        t[0] = uint8_t(b >> 8); t[1] = uint8_t(b); t[2] = uint8_t(a >> 8); t[3] = uint8_t(a);
+    }
+}
+__global__ void __launch_bounds__(64) k_png_crc_fold(DeflateCtx c, uint32_t max_pieces) {
+    const int image = blockIdx.x * blockDim.x + threadIdx.x;
+    if (image >= c.nimg || c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint64_t n = uint64_t(c.file_len[image]) - im.prefix_len - im.suffix_len - 8;
+    const uint32_t pieces = uint32_t((n + CRC_PIECE - 1) / CRC_PIECE);
+    const uint32_t op = gf2_x_pow_bytes(CRC_PIECE), op_last = gf2_x_pow_bytes(n - uint64_t(pieces - 1) * CRC_PIECE);
+    uint32_t crc = 0;
+    for (uint32_t p = 0; p < pieces; p++) crc = gf2_mul(p + 1 == pieces ? op_last : op, crc) ^ c.crc_parts[uint64_t(image) * max_pieces + p];
+    uint8_t *t = c.out + im.out_off + im.prefix_len + 4 + n;
+    t[0] = uint8_t(crc >> 24); t[1] = uint8_t(crc >> 16); t[2] = uint8_t(crc >> 8); t[3] = uint8_t(crc);
+}
+
+void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_hist, dim3(c.total_chunks, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_codes(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_codes, dim3((c.total_chunks + 63) / 64, c.plan.ntrials), dim3(64), st, c); }
+void launch_png_choose(hipStream_t st, const DeflateCtx &c) { if (c.nimg) CSH_LAUNCH(k_png_choose, dim3((c.nimg + 63) / 64), dim3(64), st, c); }
+void launch_png_emit(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_emit, dim3(c.total_chunks), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces) {
+    if (!c.nimg) return;
+    CSH_LAUNCH_PHASED(k_png_adler, 3, dim3(c.total_chunks), dim3(256), st, c);
+    CSH_LAUNCH(k_png_frame, dim3(c.nimg), dim3(64), st, c);
+    CSH_LAUNCH_PHASED(k_png_crc_pieces, 2, dim3((max_pieces + 255) / 256, c.nimg), dim3(256), st, c, max_pieces);
+    CSH_LAUNCH(k_png_crc_fold, dim3((c.nimg + 63) / 64), dim3(64), st, c, max_pieces);
+}
+
+}  // namespace csp

@@ -1,0 +1,175 @@
+// k_png_filter.hip -- row P3 of SURVEY.md 8a: the PNG row-filter search (oxipng's RowFilter 0-9 as restated in
+// oracle/png_oracle.c filter_row() / filter_scores() / cso_png_filter()).
+// Filtering reads RAW neighbours only, so every row is independent: the five fixed-filter streams are produced in one
+// pass (slots 0..4), every (row, filter) candidate is scored from them, and the adaptive strategies (5 MinSum, 6 Entropy,
+// 7 Bigrams, 8 BigEnt, 9 Brute) pick per row and gather their stream out of the five.
+#include "png_kernels.h"
+#include "png_lz.h"
+
+namespace csp {
+
+__device__ __forceinline__ static int paeth_f(int a, int b, int c) {
+    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+__device__ __forceinline__ static uint64_t ilog2i(uint64_t i) {   // i * log2(i) in integers (LodePNG)
+    if (!i) return 0;
+    const int l = 63 - __clzll((unsigned long long)i);
+    return i * uint64_t(l) + ((i - (1ull << l)) << 1);
+}
+
+// one workgroup per batch row: all five filtered versions of the row
+__global__ void __launch_bounds__(256) k_png_filter5(FilterCtx c) {
+    const uint32_t row = blockIdx.x;
+    const uint32_t image = c.row_image[row];
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint32_t y = row - im.row_base, W = im.rowbytes, bpp = im.bpp;
+    const uint8_t *cur = c.pix + im.pix_off + uint64_t(y) * W, *up = y ? cur - W : nullptr;
+    uint8_t *dst = c.streams + im.stream_off + uint64_t(y) * (W + 1);
+    if (threadIdx.x < 5) dst[uint64_t(threadIdx.x) * im.stream_stride] = uint8_t(threadIdx.x);
+    for (uint32_t x = threadIdx.x; x < W; x += blockDim.x) {
+        const int v = cur[x], a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, cc = (up && x >= bpp) ? up[x - bpp] : 0;
+        uint8_t *o = dst + 1 + x;
+        o[0] = uint8_t(v);
+        o[im.stream_stride] = uint8_t(v - a);
+        o[2 * im.stream_stride] = uint8_t(v - b);
+        o[3 * im.stream_stride] = uint8_t(v - ((a + b) >> 1));
+        o[4 * im.stream_stride] = uint8_t(v - paeth_f(a, b, cc));
+    }
+}
+
+// one workgroup per batch row; per filter seven barrier-separated steps (byte histogram, entropy, pair counts in two halves
+// of the key space: 32768 32-bit counters fill 128 KiB of LDS).  An exchange-with-zero pass reads every distinct pair
+// once and leaves the table clean for the next use.
+enum { SCORE_STEPS = 7, SCORE_THREADS = 1024 };
+struct ScoreLds {
+    uint32_t pair[32768];
+    uint32_t hist[256];
+    unsigned long long minsum, entropy, distinct, bigent;
+};
+__global__ void __launch_bounds__(SCORE_THREADS) k_png_scores(FilterCtx c) {
+    CSH_SHARED ScoreLds S;
+    const uint32_t row = blockIdx.x;
+    const uint32_t image = c.row_image[row];
+    const PngImg &im = c.imgs[image];
+    const uint32_t y = row - im.row_base, W = im.rowbytes, n = W + 1;   // n bytes: type byte + data
+    const bool dead = c.status[image] != 0;
+    CSH_PHASE_LOOP(1 + 5 * SCORE_STEPS) {
+        if (phase == 0) {
+            for (uint32_t i = threadIdx.x; i < 32768; i += blockDim.x) S.pair[i] = 0;
+            if (threadIdx.x < 256) S.hist[threadIdx.x] = 0;
+            if (threadIdx.x == 0) { S.minsum = 0; S.entropy = 0; S.distinct = 0; S.bigent = 0; }
+            continue;
+        }
+        if (dead) continue;
+        const int f = (phase - 1) / SCORE_STEPS, step = (phase - 1) % SCORE_STEPS;
+        const uint8_t *r = c.streams + im.stream_off + uint64_t(f) * im.stream_stride + uint64_t(y) * n;
+        if (step == 0) {
+            unsigned long long ms = 0;
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t b = r[i];
+                atomicAdd(&S.hist[b], 1u);
+                if (i) ms += b < 128 ? b : 256 - b;
+            }
+            if (ms) atomicAdd(&S.minsum, ms);
+        } else if (step == 1) {
+            if (threadIdx.x < 256) { const uint32_t h = S.hist[threadIdx.x]; S.hist[threadIdx.x] = 0; if (h) atomicAdd(&S.entropy, (unsigned long long)ilog2i(h)); }
+        } else if (step == 2 || step == 4) {
+            const uint32_t half = step == 2 ? 0u : 1u;
+            for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) {
+                const uint32_t k = (uint32_t(r[i]) << 8) | r[i + 1];
+                if ((k >> 15) == half) atomicAdd(&S.pair[k & 32767u], 1u);
+            }
+        } else if (step == 3 || step == 5) {
+            const uint32_t half = step == 3 ? 0u : 1u;
+            unsigned long long d = 0, e = 0;
+            for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) {
+                const uint32_t k = (uint32_t(r[i]) << 8) | r[i + 1];
+                if ((k >> 15) == half) { const uint32_t cnt = atomicExch(&S.pair[k & 32767u], 0u); if (cnt) { d++; e += ilog2i(cnt); } }
+            }
+            if (d) { atomicAdd(&S.distinct, d); atomicAdd(&S.bigent, e); }
+        } else if (threadIdx.x == 0) {
+            uint64_t *sc = c.scores + (uint64_t(row) * 5 + uint32_t(f)) * 5;
+            sc[0] = S.minsum; sc[1] = S.entropy; sc[2] = S.distinct; sc[3] = S.bigent;
+            S.minsum = 0; S.entropy = 0; S.distinct = 0; S.bigent = 0;
+        }
+    }
+}
+
+// Brute score (strategy 9): one wave per (row, filter) tokenizes the candidate row as a chunk of its own and estimates
+// its size under a code of its own: n log n - sum c log c over both alphabets, plus the extra bits.
+struct BruteLds { LzLds lz; uint32_t hist[CSP_NSYM]; };
+struct BruteSink {
+    uint32_t *hist;
+    LV<uint32_t> extra, nl, nd;
+    __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t taken, const LV<uint32_t> &mlen, const LV<uint32_t> &mdist, const LV<uint32_t> &lit) {
+        LFOR(l) if ((taken >> l) & 1) {
+            nl[l]++;
+            if (mlen[l]) {
+                const uint32_t lc = len_code_of(mlen[l]), dc = dist_code_of(mdist[l]);
+                atomicAdd(&hist[257 + lc], 1u); atomicAdd(&hist[CSP_NLIT + dc], 1u);
+                extra[l] += len_extra_of(lc) + dist_extra_of(dc); nd[l]++;
+            } else
+                atomicAdd(&hist[lit[l]], 1u);
+        }
+    }
+};
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_brute(FilterCtx c) {
+    CSH_SHARED BruteLds S;
+    const uint32_t row = blockIdx.x, f = blockIdx.y;
+    const uint32_t image = c.row_image[row];
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint32_t y = row - im.row_base;
+    uint64_t n = uint64_t(im.rowbytes) + 1;
+    const uint8_t *r = c.streams + im.stream_off + uint64_t(f) * im.stream_stride + uint64_t(y) * n;
+    if (n > CSP_CHUNK) n = CSP_CHUNK;
+    LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.hist[i] = 0;
+    BruteSink sink; sink.hist = S.hist;
+    LFOR(l) { sink.extra[l] = 0; sink.nl[l] = 0; sink.nd[l] = 0; }
+    CSP_WAVE_SYNC();
+    lz_chunk(r, n, 0, n, S.lz, sink);
+    CSP_WAVE_SYNC();
+    LV<uint64_t> part;
+    LFOR(l) { uint64_t s = 0; for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) s += ilog2i(S.hist[i]); part[l] = s; }
+    const uint64_t sub = lsum(part);
+    LFOR(l) part[l] = sink.extra[l];
+    const uint64_t extra = lsum(part);
+    LFOR(l) part[l] = sink.nl[l];
+    const uint64_t nl = lsum(part);
+    LFOR(l) part[l] = sink.nd[l];
+    const uint64_t nd = lsum(part);
+    LFOR(l) if (l == 0) c.scores[(uint64_t(row) * 5 + f) * 5 + 4] = ilog2i(nl) + ilog2i(nd) + extra - sub;
+    if (c.plan.need_brute == 2) LFOR(l) if (l == 0) { uint64_t *d = c.scores + (uint64_t(row) * 5 + f) * 5; d[0] = nl; d[1] = nd; d[2] = extra; d[3] = sub; }
+}
+
+// per row: the adaptive strategies' choices (ties: the lower filter), and their streams gathered out of the fixed five
+__global__ void __launch_bounds__(256) k_png_pick(FilterCtx c) {
+    const uint32_t row = blockIdx.x;
+    const uint32_t image = c.row_image[row];
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint32_t y = row - im.row_base, n = im.rowbytes + 1;
+    const uint64_t *sc = c.scores + uint64_t(row) * 25;
+    for (int a = 0; a < c.plan.nadaptive; a++) {
+        const int s = c.plan.adaptive_strategy[a], k = s - 5;
+        const bool more_wins = s == 6 || s == 8;
+        int pick = 0;
+        uint64_t best = sc[k];
+        for (int f = 1; f < 5; f++) { const uint64_t v = sc[f * 5 + k]; if (more_wins ? v > best : v < best) { best = v; pick = f; } }
+        if (threadIdx.x == 0) c.choice[uint64_t(a) * c.total_rows + row] = uint8_t(pick);
+        const uint8_t *src = c.streams + im.stream_off + uint64_t(pick) * im.stream_stride + uint64_t(y) * n;
+        uint8_t *dst = c.streams + im.stream_off + uint64_t(5 + a) * im.stream_stride + uint64_t(y) * n;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+void launch_png_filter5(hipStream_t st, const FilterCtx &c) { if (c.total_rows) CSH_LAUNCH(k_png_filter5, dim3(c.total_rows), dim3(256), st, c); }
+void launch_png_scores(hipStream_t st, const FilterCtx &c) {
+    if (c.total_rows) CSH_LAUNCH_PHASED(k_png_scores, 1 + 5 * SCORE_STEPS, dim3(c.total_rows), dim3(SCORE_THREADS), st, c);
+}
+void launch_png_brute(hipStream_t st, const FilterCtx &c) { if (c.total_rows) CSH_LAUNCH(k_png_brute, dim3(c.total_rows, 5), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_pick(hipStream_t st, const FilterCtx &c) { if (c.total_rows && c.plan.nadaptive) CSH_LAUNCH(k_png_pick, dim3(c.total_rows), dim3(256), st, c); }
+
+}  // namespace csp

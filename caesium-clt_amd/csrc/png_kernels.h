@@ -1,0 +1,55 @@
+// png_kernels.h -- host-callable launchers of the PNG kernels (k_png_*.hip)
+#pragma once
+#include "gpu_rt.h"
+#include "png_types.h"
+
+namespace csp {
+
+// P1: IDAT zlib stream -> filtered rows -> pixels (k_png_inflate.hip)
+void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint32_t *status);
+void launch_png_unfilter(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *raw, uint8_t *pix, uint32_t *status);
+
+// P3: row-filter search (k_png_filter.hip)
+struct FilterCtx {
+    const PngImg *imgs;
+    int nimg;
+    uint32_t total_rows;          // rows of the whole batch
+    const uint32_t *row_image;    // [total_rows] image of a batch row
+    const uint8_t *pix;
+    uint8_t *streams;
+    uint64_t *scores;             // [total_rows][5 filters][5 scores]: MinSum, Entropy, Bigrams, BigEnt, Brute
+    uint8_t *choice;              // [5 strategies][total_rows]
+    PngPlan plan;
+    const uint32_t *status;
+};
+void launch_png_filter5(hipStream_t st, const FilterCtx &c);   // the five fixed-filter streams (slots 0..4)
+void launch_png_scores(hipStream_t st, const FilterCtx &c);    // scores 0..3 of every (row, filter)
+void launch_png_brute(hipStream_t st, const FilterCtx &c);     // score 4
+void launch_png_pick(hipStream_t st, const FilterCtx &c);      // per strategy and row: best filter; gathers the adaptive streams (slots 5..)
+
+// P4: deflate (k_png_deflate.hip)
+struct DeflateCtx {
+    const PngImg *imgs;
+    int nimg;
+    uint32_t total_chunks;        // chunks of one stream slot over the whole batch
+    const uint32_t *chunk_image;  // [total_chunks] image of a batch chunk; its index inside the image = chunk - imgs[image].chunk0
+    const uint32_t *chunk_first;  // [nimg] first batch chunk of the image
+    const uint8_t *streams;
+    PngChunk *chunks;             // [(image chunk_base) + slot * nchunks + c]
+    PngPlan plan;
+    uint64_t *trial_bytes;        // [nimg][CSP_MAX_STREAMS] zlib stream size per trial
+    int32_t *winner;              // [nimg] winning trial
+    uint32_t *adler_parts;        // [total_chunks][2]
+    uint8_t *out;
+    const uint8_t *fixed;         // prefix/suffix bytes
+    uint32_t *file_len;           // [nimg]
+    uint32_t *crc_parts;          // per KiB piece of the IDAT chunk
+    uint32_t *status;
+};
+void launch_png_hist(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 1: symbol counts of every (trial, chunk)
+void launch_png_codes(hipStream_t st, const DeflateCtx &c);    // code lengths, codes, header, block size
+void launch_png_choose(hipStream_t st, const DeflateCtx &c);   // per image: stream sizes, the winner, chunk byte offsets
+void launch_png_emit(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 2 on the winner: the blocks, in place
+void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces);   // max_pieces: KiB pieces of the largest IDAT chunk; crc_parts holds nimg * max_pieces   // zlib header + Adler-32, IDAT framing + CRC-32, carried chunks
+
+}  // namespace csp

@@ -1,0 +1,162 @@
+// png_lz.h -- the LZ77 tokenizer of the deflate coder, one wave per chunk (statement: oracle/png_oracle.c tokenize()).
+// Per step the wave takes a TILE of 64 consecutive positions, one per lane:
+//   * candidates: up to four earlier positions from a 2048-bucket x 4-entry hash table in LDS (entries are positions
+//     in front of the tile, so every lane can look up before anyone inserts), plus the fixed distances 1,2,3,4,6,8 checked
+//     against a 16-byte window held in registers;
+//   * after the lookups the tile inserts, per hash, its LAST position (found by a max-by-retry write to a byte map);
+//   * parse: lazy flags by a lane shift, then a uniform walk that only stops at matches (ballot + count-trailing-zeros).
+// The caller's sink sees, per tile, which lanes are visited and their (length, distance) or literal.
+#pragma once
+#include "png_types.h"
+#include "png_wave.h"
+
+namespace csp {
+
+struct LzLds {
+    uint64_t bucket[1u << CSP_HASH_BITS];   // four 16-bit positions, most recent in the low bits; position = offset from (chunk start - 32768)
+    uint8_t lastlane[1u << CSP_HASH_BITS];
+};
+
+__device__ __forceinline__ static uint64_t load64u(const uint8_t *p) {
+#ifdef CSH_EMUL
+    uint64_t v; memcpy(&v, p, 8); return v;
+#else
+    return *reinterpret_cast<const uint64_t *>(p);   // unaligned global loads are legal on gfx9
+#endif
+}
+__device__ __forceinline__ static uint32_t lz_hash(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - CSP_HASH_BITS); }
+__device__ __forceinline__ static uint32_t ctz64(uint64_t x) { return uint32_t(__ffsll((unsigned long long)x) - 1); }
+// common prefix of data[p..] and data[p-d..], at most maxlen, given that the first `from` bytes are known to agree
+__device__ __forceinline__ static uint32_t lz_lcp(const uint8_t *data, uint64_t p, uint32_t d, uint32_t maxlen, uint32_t from) {
+    uint32_t k = from;
+    while (k < maxlen) {
+        const uint64_t x = load64u(data + p + k) ^ load64u(data + p - d + k);
+        if (x) { k += ctz64(x) >> 3; break; }
+        k += 8;
+    }
+    return k < maxlen ? k : maxlen;
+}
+__device__ __forceinline__ static uint32_t len_code_of(uint32_t len) {   // 0..28
+    if (len < 11) return len - 3;
+    if (len == 258) return 28;
+    const uint32_t x = len - 3, eb = (31u - uint32_t(__clz(x))) - 2u;
+    return 4u * eb + 4u + ((x >> eb) & 3u);
+}
+__device__ __forceinline__ static uint32_t len_extra_of(uint32_t code) { return code < 8 || code == 28 ? 0u : (code >> 2) - 1u; }
+__device__ __forceinline__ static uint32_t len_base_of(uint32_t code) { return code < 8 ? 3u + code : code == 28 ? 258u : ((4u | (code & 3u)) << ((code >> 2) - 1u)) + 3u; }
+__device__ __forceinline__ static uint32_t dist_code_of(uint32_t dist) {   // 0..29
+    if (dist < 5) return dist - 1;
+    const uint32_t x = dist - 1, eb = (31u - uint32_t(__clz(x))) - 1u;
+    return 2u * eb + 2u + ((x >> eb) & 1u);
+}
+__device__ __forceinline__ static uint32_t dist_extra_of(uint32_t code) { return code < 4 ? 0u : (code >> 1) - 1u; }
+__device__ __forceinline__ static uint32_t dist_base_of(uint32_t code) { return code < 4 ? code + 1u : ((2u | (code & 1u)) << ((code >> 1) - 1u)) + 1u; }
+
+// insert the tile [t0, t1) into the table: per hash its last position
+__device__ __forceinline__ static void lz_insert(LzLds &L, const LV<uint32_t> &hash, const LV<uint32_t> &hashable, const LV<uint32_t> &rel) {
+    LFOR(l) if (hashable[l]) L.lastlane[hash[l]] = uint8_t(l);
+    CSP_WAVE_SYNC();
+    for (;;) {
+        const uint64_t lose = lballot([&](int l) { return hashable[l] && int(L.lastlane[hash[l]]) < l; });
+        if (!lose) break;
+        LFOR(l) if ((lose >> l) & 1) L.lastlane[hash[l]] = uint8_t(l);
+        CSP_WAVE_SYNC();
+    }
+    LFOR(l) if (hashable[l] && int(L.lastlane[hash[l]]) == l && rel[l] != 0xFFFFu) L.bucket[hash[l]] = (L.bucket[hash[l]] << 16) | rel[l];
+    CSP_WAVE_SYNC();
+}
+
+// Tokenize data[start, end), a chunk of a stream of `total` bytes whose tiles are aligned to multiples of 64 of the
+// stream.  sink.tile(t0, count, taken, len, dist, lit) is called once per tile: lane l describes position t0 + l; bit l
+// of `taken` says the parse visits it; len 0 = literal `lit`.
+template <class Sink>
+__device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, LzLds &L, Sink &sink) {
+    LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH_BITS); i += 64) L.bucket[i] = ~0ull;
+    CSP_WAVE_SYNC();
+    const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
+    for (uint64_t t0 = seed0; t0 < start; t0 += 64) {
+        LV<uint32_t> hash, hashable, rel;
+        LFOR(l) {
+            const uint64_t p = t0 + uint32_t(l);
+            hashable[l] = p + 4 <= total ? 1u : 0u;
+            hash[l] = hashable[l] ? lz_hash(uint32_t(load64u(data + p))) : 0u;
+            rel[l] = uint32_t(p + 32768 - start);
+        }
+        lz_insert(L, hash, hashable, rel);
+    }
+    uint64_t carry = start;
+    for (uint64_t t0 = start; t0 < end; t0 += 64) {
+        const uint32_t count = end - t0 < 64 ? uint32_t(end - t0) : 64u;
+        LV<uint32_t> hash, hashable, rel, mlen, mdist, lit;
+        LFOR(l) {
+            const uint64_t p = t0 + uint32_t(l);
+            mlen[l] = 0; mdist[l] = 0; lit[l] = 0; hashable[l] = 0; hash[l] = 0; rel[l] = uint32_t(p + 32768 - start);
+            if (uint32_t(l) < count) {
+                const uint32_t maxlen = end - p < 258 ? uint32_t(end - p) : 258u;
+                const uint64_t hi = load64u(data + p);
+                lit[l] = uint32_t(hi & 255u);
+                // the six fixed distances against the 8 bytes in front of p
+                uint32_t bl = 0, bd = 0;
+                {
+                    const uint64_t lo = load64u(data + p - 8);   // bytes p-8..p-1; in front of the data (p < 8) whatever the pool holds there: guarded by d <= p
+                    const uint32_t cap8 = maxlen < 8 ? maxlen : 8u;
+                    uint32_t l8best = 0, dbest = 0;
+                    CSH_UNROLL
+                    for (int k = 0; k < 6; k++) {
+                        const uint32_t d = k < 4 ? uint32_t(k + 1) : (k == 4 ? 6u : 8u);
+                        if (uint64_t(d) > p) continue;
+                        const uint64_t shifted = d == 8 ? lo : ((hi << (8 * d)) | (lo >> (64 - 8 * d)));   // bytes p-d .. p-d+7
+                        const uint64_t x = hi ^ shifted;
+                        uint32_t l8 = x ? ctz64(x) >> 3 : 8u;
+                        if (l8 > cap8) l8 = cap8;
+                        if (l8 > l8best) { l8best = l8; dbest = d; }
+                    }
+                    if (l8best) { bl = l8best; bd = dbest; if (l8best == 8 && maxlen > 8) bl = lz_lcp(data, p, dbest, maxlen, 8); }
+                }
+                if (p + 4 <= total) {
+                    hashable[l] = 1;
+                    hash[l] = lz_hash(uint32_t(hi));
+                    const uint64_t b = L.bucket[hash[l]];
+                    for (int w = 0; w < int(CSP_WAYS); w++) {
+                        const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;
+                        if (r == 0xFFFFu) break;
+                        const uint32_t d = rel[l] - r;
+                        if (d > 32768u) break;
+                        const uint32_t ln = lz_lcp(data, p, d, maxlen, 0);
+                        if (ln > bl) { bl = ln; bd = d; }
+                    }
+                }
+                if (bl < 3 || (bl == 3 && bd > 8)) { bl = 0; bd = 0; }
+                mlen[l] = bl; mdist[l] = bd;
+            }
+        }
+        CSP_WAVE_SYNC();
+        lz_insert(L, hash, hashable, rel);
+        // lazy evaluation inside the tile, then the walk
+        LV<uint32_t> nextlen;
+#ifdef CSH_EMUL
+        for (int l = 0; l < 64; l++) nextlen.v[l] = l < 63 ? mlen.v[l + 1] : 0u;
+#else
+        nextlen.v = uint32_t(__shfl_down(int(mlen.v), 1, 64));
+#endif
+        LFOR(l) if (mlen[l] && uint32_t(l) + 1 < count && nextlen[l] > mlen[l]) mlen[l] = 0;
+        const uint64_t matches = lballot([&](int l) { return mlen[l] != 0; });
+        uint64_t taken = 0;
+        uint32_t cur = carry > t0 ? uint32_t(carry - t0) : 0u;
+        while (cur < count) {
+            const uint64_t ahead = matches & ~lanes_below(int(cur));
+            if (!ahead) { taken |= (count == 64 ? ~0ull : lanes_below(int(count))) & ~lanes_below(int(cur)); cur = count; break; }
+            const uint32_t m = ctz64(ahead);
+            taken |= (m == 63 ? ~0ull : lanes_below(int(m) + 1)) & ~lanes_below(int(cur));
+#ifdef CSH_EMUL
+            cur = m + mlen.v[m];
+#else
+            cur = m + uint32_t(__builtin_amdgcn_readlane(int(mlen.v), int(m)));
+#endif
+        }
+        carry = t0 + cur;
+        sink.tile(t0, count, taken, mlen, mdist, lit);
+    }
+}
+
+}  // namespace csp

@@ -1,0 +1,388 @@
+// png_pipeline.cpp -- the device batch queue of the lossless PNG row: what `caesium::compress_in_memory` does for a PNG
+// with png.optimize set (/root/reference/src/compressor.rs:305, parameters :411-446) -- oxipng's decode, row-filter
+// trials and DEFLATE -- for a whole group of files at once.  Host work is container logic only: the chunk walk, the
+// carried-chunk policy, descriptors.  Statement of every stage: oracle/png_oracle.c.
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/caesium_hip.h"
+#include "devmem.hpp"
+#include "png_kernels.h"
+
+using namespace csp;
+using csh::DevBuf;
+using csh::PinnedBytes;
+
+namespace {
+
+uint32_t be32(const uint8_t *p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+void put_be32(uint8_t *p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); }
+uint32_t crc32_host(const uint8_t *p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    uint32_t crc = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    return ~crc;
+}
+const uint8_t kSig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+
+struct PngItem {
+    int code = 0;
+    std::string msg;
+    int image = -1;
+    size_t file_size = 0;
+    uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0;
+    std::vector<std::pair<size_t, size_t>> idat;   // (offset, length) of every IDAT payload in the input
+    size_t idat_len = 0;
+    std::vector<uint8_t> prefix, suffix;            // output bytes in front of / behind the IDAT chunk
+};
+
+// oxipng StripChunks::Safe keeps these ancillary chunks [UPSTREAM-RECALL]; tRNS is image data
+bool kept_when_stripping(const uint8_t *type) {
+    static const char *keep[] = {"cICP", "iCCP", "sRGB", "pHYs", "tRNS"};
+    for (const char *k : keep) if (!memcmp(type, k, 4)) return true;
+    return false;
+}
+
+// the chunk walk (oracle: cso_png_decode, first half)
+void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
+    auto fail = [&](int code, const char *msg) { it.code = code; it.msg = msg; };
+    it.file_size = n;
+    if (n < 8 + 25 || memcmp(in, kSig, 8)) return fail(CS_ERR_BAD_PNG, "not a PNG");
+    size_t pos = 8;
+    bool seen_ihdr = false, seen_idat = false, seen_iend = false;
+    int depth = 0, ctype = 0, nplte = 0;
+    while (pos + 12 <= n && !seen_iend) {
+        const uint32_t len = be32(in + pos);
+        const uint8_t *type = in + pos + 4, *d = in + pos + 8;
+        if (len > 0x7FFFFFFFu || pos + 12 + size_t(len) > n) return fail(CS_ERR_BAD_PNG, "truncated PNG chunk");
+        if (!seen_ihdr) {
+            if (memcmp(type, "IHDR", 4) || len != 13) return fail(CS_ERR_BAD_PNG, "PNG does not start with IHDR");
+            if (crc32_host(type, 17) != be32(d + 13)) return fail(CS_ERR_BAD_PNG, "IHDR checksum");
+            it.width = be32(d); it.height = be32(d + 4); depth = d[8]; ctype = d[9];
+            if (!it.width || !it.height || it.width > 0x7FFFFFFFu || it.height > 0x7FFFFFFFu || d[10] || d[11] || d[12] > 1) return fail(CS_ERR_BAD_PNG, "bad IHDR");
+            static const int chans[7] = {1, 0, 3, 1, 2, 0, 4};
+            bool ok = false;
+            switch (ctype) {
+            case 0: ok = depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16; break;
+            case 3: ok = depth == 1 || depth == 2 || depth == 4 || depth == 8; break;
+            case 2: case 4: case 6: ok = depth == 8 || depth == 16; break;
+            }
+            if (!ok) return fail(CS_ERR_BAD_PNG, "bad colour type / bit depth");
+            if (d[12]) return fail(CS_ERR_UNSUPPORTED, "interlaced PNG has no device path in this build");
+            const uint64_t bits = uint64_t(chans[ctype]) * uint64_t(depth);
+            it.bpp = bits >= 8 ? uint32_t(bits / 8) : 1u;
+            const uint64_t rb = (uint64_t(it.width) * bits + 7) / 8;
+            if (rb > 0x7FFFFFF0u) return fail(CS_ERR_UNSUPPORTED, "PNG row too long");
+            it.rowbytes = uint32_t(rb);
+            it.prefix.assign(kSig, kSig + 8);
+            it.prefix.insert(it.prefix.end(), in + pos, in + pos + 25);
+            it.prefix[8 + 8 + 12] = 0;   // interlace method of the output
+            put_be32(&it.prefix[8 + 8 + 13], crc32_host(&it.prefix[8 + 4], 17));
+            seen_ihdr = true;
+        } else if (!memcmp(type, "IDAT", 4)) {
+            it.idat.emplace_back(pos + 8, size_t(len)); it.idat_len += len; seen_idat = true;
+        } else if (!memcmp(type, "IEND", 4)) {
+            seen_iend = true;
+        } else {
+            if (!memcmp(type, "acTL", 4)) return fail(CS_ERR_UNSUPPORTED, "animated PNG has no device path in this build");
+            if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); }
+            const bool critical = !(type[0] & 0x20);
+            if (critical || keep_metadata || kept_when_stripping(type)) {
+                std::vector<uint8_t> &dst = seen_idat ? it.suffix : it.prefix;
+                dst.insert(dst.end(), in + pos, in + pos + 12 + size_t(len));
+            }
+        }
+        pos += 12 + size_t(len);
+    }
+    if (!seen_ihdr || !seen_idat || !seen_iend) return fail(CS_ERR_BAD_PNG, "PNG without IHDR / IDAT / IEND");
+    if (ctype == 3 && !nplte) return fail(CS_ERR_BAD_PNG, "palette PNG without PLTE");
+    static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+    it.suffix.insert(it.suffix.end(), iend, iend + 12);
+    // the two zlib header bytes (oracle: cso_inflate_zlib)
+    uint8_t z[2]; size_t got = 0;
+    for (auto &r : it.idat) for (size_t k = 0; k < r.second && got < 2; k++) z[got++] = in[r.first + k];
+    if (got < 2 || (z[0] & 15) != 8 || (z[0] >> 4) > 7 || ((unsigned(z[0]) << 8) | z[1]) % 31 || (z[1] & 0x20)) return fail(CS_ERR_BAD_PNG, "bad zlib header in IDAT");
+    if (it.idat_len > 0xFFFFFFF0u) return fail(CS_ERR_UNSUPPORTED, "IDAT stream too long");
+}
+
+// oxipng's presets [UPSTREAM-RECALL]: filters tried per --png-opt-level (oracle: cso_png_trials)
+int trial_set(int level, int *set) {
+    static const int s01[] = {5}, s2[] = {0, 1, 6, 7}, s34[] = {0, 7, 8, 9}, s5[] = {0, 1, 2, 5, 6, 7, 8, 9}, s6[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+    const int *s; int n;
+    if (level <= 1) { s = s01; n = 1; } else if (level == 2) { s = s2; n = 4; } else if (level <= 4) { s = s34; n = 4; } else if (level == 5) { s = s5; n = 8; } else { s = s6; n = 10; }
+    memcpy(set, s, sizeof(int) * size_t(n));
+    return n;
+}
+
+const char *kPngKernelNames[CSP_NKERNELS] = {"k_png_inflate", "k_png_unfilter", "k_png_filter5", "k_png_scores", "k_png_brute", "k_png_pick",
+                                             "k_png_hist", "k_png_codes", "k_png_choose", "k_png_emit", "k_png_finish", "", "", "", "", ""};
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct csp_batch {
+    int device = 0;
+    hipStream_t stream{};
+    bool have_stream = false;
+    std::vector<PngItem> items;
+    std::vector<const uint8_t *> inputs;
+    std::vector<PngImg> imgs;
+    PngPlan plan{};
+    int slot_of_strategy[10];
+    uint32_t total_rows = 0, total_chunks = 0, max_pieces = 0;
+    uint64_t raw_total = 0, pixels = 0;
+    DevBuf<PngImg> d_imgs;
+    DevBuf<uint8_t> d_idat, d_raw, d_pix, d_streams, d_out, d_fixed, d_choice;
+    DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_status, d_file_len, d_adler, d_crc;
+    DevBuf<uint64_t> d_scores, d_trial_bytes;
+    DevBuf<int32_t> d_winner;
+    DevBuf<PngChunk> d_chunks;
+    hipEvent_t ev[CSP_NKERNELS + 1]{};
+    bool have_events = false, ran = false;
+    ~csp_batch() {
+        if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
+        if (have_stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" const char *csp_kernel_name(int i) { return (i >= 0 && i < CSP_NKERNELS) ? kPngKernelNames[i] : ""; }
+extern "C" void csp_batch_destroy(csp_batch *b) { delete b; }
+
+extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { csh_set_error("no HIP device: libcaesium_hip has no CPU path"); return CS_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { csh_set_error("device %d out of range (%d visible)", device, ndev); return CS_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
+    std::unique_ptr<csp_batch> b(new csp_batch);
+    b->device = device;
+    if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    b->have_stream = true;
+    for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) { csh_set_error("hipEventCreate failed"); return CS_ERR_NO_DEVICE; }
+    b->have_events = true;
+    hipStream_t st = b->stream;
+
+    // trial plan: the five fixed streams always exist (the adaptive ones are gathered out of them)
+    int set[10];
+    PngPlan &plan = b->plan;
+    plan.ntrials = trial_set(int(p->png_optimization_level), set);
+    for (int s = 0; s < 10; s++) b->slot_of_strategy[s] = s < 5 ? s : -1;
+    for (int t = 0; t < plan.ntrials; t++) {
+        const int s = set[t];
+        if (s >= 5 && b->slot_of_strategy[s] < 0) { b->slot_of_strategy[s] = 5 + plan.nadaptive; plan.adaptive_strategy[plan.nadaptive++] = s; if (s == 9) plan.need_brute = 1; }
+        plan.trial_slot[t] = b->slot_of_strategy[s]; plan.trial_strategy[t] = s;
+    }
+    if (plan.need_brute && getenv("CSP_BRUTE_DEBUG")) plan.need_brute = 2;
+    const int nslots = 5 + plan.nadaptive;
+
+    b->items.resize(count);
+    b->inputs.resize(count);
+    PinnedBytes idat_pool;
+    std::vector<uint8_t> fixed;
+    size_t raw_bytes = 0, pix_bytes = 0, stream_bytes = 256, out_bytes = 0;   // the tokenizer reads up to 8 bytes in front of a stream
+    uint64_t nchunk_recs = 0;
+    for (size_t i = 0; i < count; i++) {
+        PngItem &it = b->items[i];
+        b->inputs[i] = inputs[i].data;
+        parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
+        if (it.code) continue;
+        PngImg im{};
+        im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
+        im.raw_len = uint64_t(it.height) * (uint64_t(it.rowbytes) + 1);
+        if (im.raw_len > (uint64_t(1) << 36) || uint64_t(b->total_rows) + it.height > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
+        im.idat_off = idat_pool.size(); im.idat_len = uint32_t(it.idat_len);
+        {   // the IDAT payloads back to back (a stream may be cut anywhere, even inside the zlib header)
+            size_t at = idat_pool.size(), end = align_up(at + it.idat_len + 8, 256);
+            if (!idat_pool.reserve(end)) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
+            for (auto &r : it.idat) { idat_pool.pending.push_back({at, inputs[i].data + r.first, r.second, 0}); at += r.second; }
+            idat_pool.pending.push_back({at, inputs[i].data, 0, end - at});
+            idat_pool.n = end;
+        }
+        im.raw_off = raw_bytes; raw_bytes += align_up(im.raw_len + CSP_RAW_SLACK, 256);
+        im.pix_off = pix_bytes; pix_bytes += align_up(uint64_t(it.height) * it.rowbytes + 64, 256);
+        im.stream_stride = align_up(im.raw_len + 64, 256);
+        im.stream_off = stream_bytes; stream_bytes += im.stream_stride * size_t(nslots);
+        im.row_base = b->total_rows; b->total_rows += it.height;
+        im.nchunks = uint32_t((im.raw_len + CSP_CHUNK - 1) / CSP_CHUNK);
+        im.chunk_base = uint32_t(nchunk_recs); nchunk_recs += uint64_t(im.nchunks) * nslots;
+        if (nchunk_recs > 0x7FFFFFFFu) { csh_set_error("PNG batch too large"); return CS_ERR_POOL_OVERFLOW; }
+        im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
+        im.fix_off = fixed.size();
+        fixed.insert(fixed.end(), it.prefix.begin(), it.prefix.end());
+        fixed.insert(fixed.end(), it.suffix.begin(), it.suffix.end());
+        im.out_cap = uint64_t(im.prefix_len) + 12 + im.suffix_len + 6 + uint64_t(im.nchunks) * (CSP_CHUNK + CSP_CHUNK / 8 + 1024);
+        if (im.out_cap > 0xFFFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
+        im.out_off = out_bytes; out_bytes += align_up(im.out_cap + 16, 256);
+        const uint32_t pieces = uint32_t((im.out_cap + 1023) / 1024);
+        if (pieces > b->max_pieces) b->max_pieces = pieces;
+        it.image = int(b->imgs.size());
+        b->imgs.push_back(im);
+        b->total_chunks += im.nchunks;
+        b->raw_total += im.raw_len; b->pixels += uint64_t(it.width) * it.height;
+    }
+    idat_pool.flush_copies();
+    const int nimg = int(b->imgs.size());
+    std::vector<uint32_t> row_image(b->total_rows), chunk_image(b->total_chunks), chunk_first(size_t(nimg) + 1);
+    {
+        uint32_t r = 0, c = 0;
+        for (int i = 0; i < nimg; i++) {
+            chunk_first[i] = c;
+            for (uint32_t y = 0; y < b->imgs[i].height; y++) row_image[r++] = uint32_t(i);
+            for (uint32_t k = 0; k < b->imgs[i].nchunks; k++) chunk_image[c++] = uint32_t(i);
+        }
+        chunk_first[nimg] = c;
+    }
+    if (b->d_imgs.upload(b->imgs, st) || b->d_row_image.upload(row_image, st) || b->d_chunk_image.upload(chunk_image, st) || b->d_chunk_first.upload(chunk_first, st) ||
+        b->d_fixed.upload(fixed, st))
+        return CS_ERR_NO_DEVICE;
+    if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_raw.alloc(raw_bytes + 256) || b->d_pix.alloc(pix_bytes + 256) || b->d_streams.alloc(stream_bytes + 256) ||
+        b->d_out.alloc(out_bytes + 256) || b->d_choice.alloc(size_t(5) * b->total_rows + 1) || b->d_status.alloc(size_t(nimg) + 1) || b->d_file_len.alloc(size_t(nimg) + 1) ||
+        b->d_adler.alloc(2 * size_t(b->total_chunks) + 2) || b->d_crc.alloc(size_t(nimg) * b->max_pieces + 1) || b->d_scores.alloc(size_t(b->total_rows) * 25 + 1) ||
+        b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
+        return CS_ERR_NO_DEVICE;
+    if (idat_pool.size()) {
+        if (hipMemcpyAsync(b->d_idat.p, idat_pool.p, idat_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }   // the pinned pool goes back to the cache
+    *out = b.release();
+    return 0;
+}
+
+extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
+    if (!b) return CS_ERR_NO_DEVICE;
+    if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
+    hipStream_t st = b->stream;
+    const int nimg = int(b->imgs.size());
+    if (b->d_status.zero(st)) return CS_ERR_NO_DEVICE;
+    FilterCtx f{};
+    f.imgs = b->d_imgs.p; f.nimg = nimg; f.total_rows = b->total_rows; f.row_image = b->d_row_image.p; f.pix = b->d_pix.p; f.streams = b->d_streams.p;
+    f.scores = b->d_scores.p; f.choice = b->d_choice.p; f.plan = b->plan; f.status = b->d_status.p;
+    DeflateCtx d{};
+    d.imgs = b->d_imgs.p; d.nimg = nimg; d.total_chunks = b->total_chunks; d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p;
+    d.streams = b->d_streams.p; d.chunks = b->d_chunks.p; d.plan = b->plan; d.trial_bytes = b->d_trial_bytes.p; d.winner = b->d_winner.p;
+    d.adler_parts = b->d_adler.p; d.out = b->d_out.p; d.fixed = b->d_fixed.p; d.file_len = b->d_file_len.p; d.crc_parts = b->d_crc.p; d.status = b->d_status.p;
+    bool need_scores = false;
+    for (int a = 0; a < b->plan.nadaptive; a++) if (b->plan.adaptive_strategy[a] != 9) need_scores = true;
+    int k = 0;
+    auto mark = [&]() { (void)hipEventRecord(b->ev[k++], st); };
+    mark(); launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_raw.p, b->d_status.p);
+    mark(); launch_png_unfilter(st, b->d_imgs.p, nimg, b->d_raw.p, b->d_pix.p, b->d_status.p);
+    mark(); launch_png_filter5(st, f);
+    mark(); if (need_scores && b->plan.need_brute != 2) launch_png_scores(st, f);
+    mark(); if (b->plan.need_brute) launch_png_brute(st, f);
+    mark(); launch_png_pick(st, f);
+    mark(); launch_png_hist(st, d);
+    mark(); launch_png_codes(st, d);
+    mark(); launch_png_choose(st, d);
+    mark(); launch_png_emit(st, d);
+    mark(); launch_png_finish(st, d, b->max_pieces);
+    mark();
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG kernels failed"); return CS_ERR_NO_DEVICE; }
+    b->ran = true;
+    if (t) {
+        memset(t, 0, sizeof *t);
+        (void)hipEventElapsedTime(&t->total_ms, b->ev[0], b->ev[k - 1]);
+        for (int i = 0; i + 1 < k; i++) (void)hipEventElapsedTime(&t->kernel_ms[i], b->ev[i], b->ev[i + 1]);
+        std::vector<uint32_t> status(size_t(nimg) + 1), flen(size_t(nimg) + 1);
+        if (nimg) {
+            (void)hipMemcpy(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost);
+        }
+        for (auto &it : b->items) {
+            if (it.image < 0) { t->n_failed++; continue; }
+            if (status[it.image]) { t->n_failed++; continue; }
+            t->in_bytes += it.idat_len; t->out_bytes += flen[it.image];
+        }
+        t->pixels = b->pixels; t->raw_bytes = b->raw_total; t->n_images = uint32_t(nimg); t->n_trials = uint32_t(b->plan.ntrials);
+    }
+    return 0;
+}
+
+static CCSResult png_result(int code, const char *msg) {
+    CCSResult r;
+    r.success = code == 0; r.code = uint32_t(code); r.error_message = nullptr;
+    if (code && msg) { size_t n = strlen(msg); char *m = (char *)malloc(n + 1); memcpy(m, msg, n + 1); r.error_message = m; }
+    return r;
+}
+
+extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results) {
+    if (!b || !b->ran) { csh_set_error("csp_batch_fetch before csp_batch_run"); return -1; }
+    if (hipSetDevice(b->device) != hipSuccess) return -1;
+    const int nimg = int(b->imgs.size());
+    std::vector<uint32_t> status(size_t(nimg) + 1), flen(size_t(nimg) + 1);
+    if (nimg) {
+        if (hipMemcpy(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return -1; }
+    }
+    int failed = 0;
+    for (size_t i = 0; i < b->items.size(); i++) {
+        PngItem &it = b->items[i];
+        outputs[i].data = nullptr; outputs[i].length = 0;
+        int code = it.code;
+        const char *msg = it.msg.c_str();
+        if (!code && status[it.image]) { code = int(status[it.image]); msg = code == int(CSP_ERR_POOL) ? "internal device pool too small" : "malformed PNG data"; }
+        if (code) { failed++; if (results) results[i] = png_result(code, msg); continue; }
+        const size_t n = flen[it.image];
+        if (n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
+            outputs[i].data = (uint8_t *)malloc(it.file_size ? it.file_size : 1);
+            memcpy(outputs[i].data, b->inputs[i], it.file_size);
+            outputs[i].length = it.file_size;
+        } else {
+            outputs[i].data = (uint8_t *)malloc(n ? n : 1);
+            if (hipMemcpy(outputs[i].data, b->d_out.p + b->imgs[it.image].out_off, n, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return -1; }
+            outputs[i].length = n;
+        }
+        if (results) results[i] = png_result(0, nullptr);
+    }
+    return failed;
+}
+
+// ---- stage taps
+static const PngImg *tap_image(csp_batch *b, size_t image) {
+    if (!b || !b->ran || image >= b->items.size() || b->items[image].image < 0) { csh_set_error("no such decoded PNG in the batch"); return nullptr; }
+    return &b->imgs[b->items[image].image];
+}
+extern "C" int csp_batch_geometry(csp_batch *b, size_t image, uint32_t *width, uint32_t *height, uint32_t *rowbytes) {
+    const PngImg *im = tap_image(b, image);
+    if (!im) return -1;
+    *width = im->width; *height = im->height; *rowbytes = im->rowbytes;
+    return 0;
+}
+extern "C" int csp_batch_read_rows(csp_batch *b, size_t image, uint8_t *dst) {
+    const PngImg *im = tap_image(b, image);
+    if (!im) return -1;
+    return hipMemcpy(dst, b->d_pix.p + im->pix_off, size_t(im->height) * im->rowbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+extern "C" int csp_batch_read_stream(csp_batch *b, size_t image, int strategy, uint8_t *dst) {
+    const PngImg *im = tap_image(b, image);
+    if (!im) return -1;
+    if (strategy < 0 || strategy > 9 || b->slot_of_strategy[strategy] < 0) { csh_set_error("strategy %d is not part of this level's plan", strategy); return -1; }
+    return hipMemcpy(dst, b->d_streams.p + im->stream_off + uint64_t(b->slot_of_strategy[strategy]) * im->stream_stride, im->raw_len, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+extern "C" int csp_batch_read_scores(csp_batch *b, size_t image, uint64_t *dst, int *have) {
+    const PngImg *im = tap_image(b, image);
+    if (!im) return -1;
+    *have = 0;
+    for (int a = 0; a < b->plan.nadaptive; a++) *have |= b->plan.adaptive_strategy[a] == 9 ? 16 : 15;
+    return hipMemcpy(dst, b->d_scores.p + size_t(im->row_base) * 25, sizeof(uint64_t) * 25 * im->height, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+extern "C" int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uint64_t *zlib_bytes, int *ntrials, int *winner) {
+    const PngImg *im = tap_image(b, image);
+    if (!im) return -1;
+    const int idx = b->items[image].image;
+    *ntrials = b->plan.ntrials;
+    for (int t = 0; t < b->plan.ntrials; t++) strategies[t] = b->plan.trial_strategy[t];
+    int32_t w = 0;
+    if (hipMemcpy(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * b->plan.ntrials, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&w, b->d_winner.p + idx, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    *winner = w;
+    return 0;
+}

@@ -39,6 +39,7 @@ enum {
     CS_ERR_BAD_JPEG = 20100,       /* malformed / truncated JPEG */
     CS_ERR_JPEG_FEATURE = 20101,   /* arithmetic coding, 12-bit, CMYK, unsupported sampling ... */
     CS_ERR_POOL_OVERFLOW = 20200,  /* internal device pool too small even after retry */
+    CS_ERR_BAD_PNG = 30100,        /* malformed / truncated PNG (chunk walk, zlib stream, filter bytes) */
     CS_ERR_SAME_FORMAT = 10407,    /* convert_in_memory: source type == target type */
     CS_ERR_TOO_BIG = 10500         /* compress_to_size: cannot reach max_output_size */
 };
@@ -144,6 +145,38 @@ int csh_batch_rerun_encode(csh_batch *b, csh_timing *t);
    [bh][bw][64] int16 blocks in ZIG-ZAG order.  Returns 0, or -1 (see csh_last_error). */
 int csh_batch_geometry(csh_batch *b, size_t image, int comp, int which, int *bw, int *bh, int *real_bw, int *real_bh);
 int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int which, int16_t *dst);
+
+/* ------------------------------------------------------------------------------------------------
+ * Lossless PNG row (png.optimize = true, the `--lossless` flag: compressor.rs:427-429; level = --png-opt-level,
+ * src/options.rs:63-65): the device-resident batch interface of the PNG pipeline.  create = chunk walk + upload of the IDAT
+ * streams; run = inflate, unfilter, row-filter search, deflate trials, assembly, all on the device; fetch = copy the
+ * finished files back (a file that did not get smaller comes back unchanged, as oxipng does).  cs_batch_compress routes
+ * PNG inputs here.
+ */
+typedef struct csp_batch csp_batch;
+enum { CSP_NKERNELS = 16 };
+typedef struct {
+    float total_ms;
+    float kernel_ms[CSP_NKERNELS];   /* names: csp_kernel_name */
+    uint64_t in_bytes, out_bytes;    /* IDAT bytes in, file bytes out (device result, before the "not smaller" rule) */
+    uint64_t pixels, raw_bytes;      /* pixels; bytes of one filtered stream per image, summed */
+    uint32_t n_images, n_failed, n_trials;
+} csp_timing;
+const char *csp_kernel_name(int slot);
+int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
+int csp_batch_run(csp_batch *b, csp_timing *t);
+int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results);
+void csp_batch_destroy(csp_batch *b);
+/* stage taps for the parity tests (after csp_batch_run): the unfiltered rows (height * rowbytes), the filtered stream of
+   one oxipng strategy 0..9 (height * (1 + rowbytes); only strategies the level needs exist), and per trial the size of
+   its zlib stream with the winner */
+int csp_batch_geometry(csp_batch *b, size_t image, uint32_t *width, uint32_t *height, uint32_t *rowbytes);
+int csp_batch_read_rows(csp_batch *b, size_t image, uint8_t *dst);
+int csp_batch_read_stream(csp_batch *b, size_t image, int strategy, uint8_t *dst);
+/* scores of every (row, filter) candidate: dst[height][5 filters][5: MinSum, Entropy, Bigrams, BigEnt, Brute]; *have = bit k
+   set when score k was computed for this level's plan */
+int csp_batch_read_scores(csp_batch *b, size_t image, uint64_t *dst, int *have);
+int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uint64_t *zlib_bytes, int *ntrials, int *winner);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,7 @@ def lib():
         L.cso_inflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.cso_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(Png))]
         L.cso_png_free.argtypes = [C.POINTER(Png)]
+        L.cso_png_scores.argtypes = [C.POINTER(Png), C.c_void_p]
         L.cso_png_filter.argtypes = [C.POINTER(Png), C.c_int, C.c_void_p, C.c_void_p]
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_trials.argtypes = [C.c_int, C.POINTER(C.c_int)]
@@ -293,6 +294,12 @@ class PngImage:
     def rows(self):
         im = self.im
         return np.ctypeslib.as_array(im.pix, shape=(im.height * im.rowbytes,)).reshape(im.height, im.rowbytes).copy()
+
+    def scores(self):
+        """[height][5 filters][5 scores: MinSum, Entropy, Bigrams, BigEnt, Brute]"""
+        out = np.empty((self.im.height, 5, 5), dtype=np.uint64)
+        lib().cso_png_scores(self.ptr, out.ctypes.data)
+        return out
 
     def filtered(self, strategy):
         """(stream of height*(1+rowbytes) bytes, per-row filter choice)"""

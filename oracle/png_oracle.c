@@ -328,6 +328,17 @@ static void filter_scores(const uint8_t *row, size_t n, int bpp, uint64_t sc[5])
     sc[0] = ms; sc[1] = ent; sc[2] = distinct; sc[3] = bent;
     sc[4] = fixed_cost_row(row, n + 1, bpp);
 }
+/* scores of every (row, filter): out[height][5][5] */
+int cso_png_scores(const cso_png *P, uint64_t *out) {
+    const size_t n = P->rowbytes, stride = 1 + n;
+    uint8_t *cand = (uint8_t *)malloc(stride);
+    for (uint32_t y = 0; y < P->height; y++) {
+        const uint8_t *cur = P->pix + (size_t)y * n, *up = y ? cur - n : NULL;
+        for (int f = 0; f < 5; f++) { filter_row(f, cur, up, n, P->bpp, cand); filter_scores(cand, n, P->bpp, out + ((size_t)y * 5 + f) * 5); }
+    }
+    free(cand);
+    return 0;
+}
 /* strategy 0..4: that filter on every row; 5..9: per row, the candidate with the best score (ties: the lower filter) */
 int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice) {
     if (strategy < 0 || strategy > 9) return -1;
@@ -596,6 +607,7 @@ static uint64_t fixed_cost_row(const uint8_t *row, size_t n, int bpp) {
     for (int i = 0; i < 286; i++) sub += ilog2i(lf[i]);
     for (int i = 0; i < 30; i++) sub += ilog2i(df[i]);
     free(tok); free(taken);
+    if (getenv("CSP_BRUTE_DEBUG")) fprintf(stderr, "BRUTE n=%zu nl=%llu nd=%llu extra=%llu sub=%llu\n", n, (unsigned long long)nl, (unsigned long long)nd, (unsigned long long)extra, (unsigned long long)sub);
     return bits - sub;
 }
 int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len) {

@@ -17,6 +17,7 @@ uint32_t cso_adler32(const uint8_t *p, size_t n);
 int cso_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *produced);
 int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out);
 void cso_png_free(cso_png *p);
+int cso_png_scores(const cso_png *P, uint64_t *out);
 int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice);
 int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len);
 int cso_png_trials(int level, int *set);

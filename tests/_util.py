@@ -46,3 +46,40 @@ def oracle_lossless(src, progressive=1, keep_metadata=0, preserve_icc=1):
 def oracle_resized(src, width, height, quality=80, subsampling=420):
     from oracle import oracle as O
     return O.jpeg_compress_resized(src, O.params(quality=quality, progressive=1, subsampling=subsampling, qtable_profile=3, marker_style=1), width, height)
+
+
+# ---------------------------------------------------------------- lossless PNG row
+def png_cases(small=True):
+    """(name, file bytes) inputs of the PNG parity tests: every Pillow mode, one chunk and several, stored / fixed / dynamic
+    deflate blocks in the input, carried and stripped ancillary chunks."""
+    import io
+
+    from PIL import Image, PngImagePlugin
+
+    from gen_synth import synth_png
+    cases = []
+    for k, mode in enumerate(["RGB", "RGBA", "L", "LA", "P", "1", "I;16"]):
+        cases.append((f"{mode}_97x61", synth_png(10 + k, 97, 61, mode, texture=2.0 + k)))
+    cases.append(("RGB_flat_64x48", synth_png(3, 64, 48, "RGB", texture=0.0)))              # long matches, runs
+    cases.append(("RGB_200x150_3chunks", synth_png(20, 200, 150, "RGB", texture=6.0)))     # 90 KB of stream: three blocks, window seeding
+    cases.append(("RGB_stored_input", synth_png(21, 80, 60, "RGB", compress_level=0)))     # stored blocks in the input
+    cases.append(("L_level1_input", synth_png(22, 33, 21, "L", compress_level=1)))
+    cases.append(("RGB_1x1", synth_png(23, 1, 1, "RGB")))
+    cases.append(("L_1x300", synth_png(24, 1, 300, "L")))
+    cases.append(("RGBA_300x2", synth_png(25, 300, 2, "RGBA")))
+    im = Image.open(io.BytesIO(synth_png(26, 60, 40, "RGB")))
+    info = PngImagePlugin.PngInfo()
+    info.add_text("Comment", "carried only with keep_metadata")
+    b = io.BytesIO()
+    im.save(b, "PNG", pnginfo=info, dpi=(300, 300), compress_level=1)
+    cases.append(("RGB_with_text_and_phys", b.getvalue()))
+    if not small:
+        cases.append(("RGB_640x480", synth_png(30, 640, 480, "RGB", texture=4.0)))
+        cases.append(("RGBA_511x300", synth_png(31, 511, 300, "RGBA", texture=1.0)))
+        cases.append(("I16_400x300", synth_png(32, 400, 300, "I;16")))
+    return cases
+
+
+def oracle_png(src, level=3, keep_metadata=False):
+    from oracle import oracle as O
+    return O.png_optimize(src, level, keep_metadata)[0]

@@ -1,0 +1,106 @@
+"""Lossless PNG row: the kernel sources compiled for the CPU (emulation build, tests only) against the oracle, stage by
+stage and file bytes.  The same cases run on the device in test_png_gpu.py."""
+import numpy as np
+import pytest
+
+from _util import emul_api, oracle_png, package, png_cases
+from oracle import oracle as O
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def check_batch(api, cases, level, keep_metadata=False, stages=True):
+    pkg = package()
+    p = pkg.default_parameters(png_optimize=True, png_optimization_level=level, keep_metadata=keep_metadata)
+    blobs = [c[1] for c in cases]
+    b = api.png_batch(blobs, p)
+    try:
+        b.run()
+        outs = b.fetch()
+        for i, (name, blob) in enumerate(cases):
+            assert not isinstance(outs[i], Exception), (name, outs[i])
+            ref, chosen = O.png_optimize(blob, level, keep_metadata)
+            if stages:
+                P = O.png_decode(blob)
+                assert np.array_equal(b.rows(i), P.rows()), name
+                got, have = b.scores(i)
+                want = P.scores()
+                for k in range(5):
+                    if have >> k & 1:
+                        bad = np.argwhere(got[:, :, k] != want[:, :, k])
+                        assert not len(bad), (name, "score", k, "row/filter", bad[0].tolist(), int(got[tuple(bad[0])][k]), int(want[tuple(bad[0])][k]))
+                trials, winner = b.trials(i)
+                for s, zbytes in trials:
+                    f, _ = P.filtered(s)
+                    assert np.array_equal(b.stream(i, s), f), (name, s)
+                    assert zbytes == len(O.deflate_zlib(f)), (name, s)
+                if chosen >= 0:
+                    assert trials[winner][0] == chosen, name
+            assert outs[i] == ref, name
+    finally:
+        b.close()
+
+
+def test_level3_stage_by_stage(api):
+    check_batch(api, png_cases(), 3)
+
+
+@pytest.mark.parametrize("level", [1, 2, 6])
+def test_other_levels(api, level):
+    cases = [c for c in png_cases() if c[0] in ("RGB_97x61", "LA_97x61", "RGB_flat_64x48", "I;16_97x61")]
+    check_batch(api, cases, level)
+
+
+def test_keep_metadata(api):
+    cases = [c for c in png_cases() if c[0] == "RGB_with_text_and_phys"]
+    check_batch(api, cases, 3, keep_metadata=True, stages=False)
+    check_batch(api, cases, 3, keep_metadata=False, stages=False)
+
+
+def test_refusals_and_mixed_batch(api):
+    pkg = package()
+    good = dict(png_cases())["RGB_97x61"]
+    adam7 = bytearray(good); adam7[28] = 1
+    import zlib
+    adam7[29:33] = zlib.crc32(bytes(adam7[12:29])).to_bytes(4, "big")
+    cut = good[:len(good) // 2]
+    # damage inside the zlib stream: flip bits in the middle of the IDAT payload
+    i0 = good.index(b"IDAT") + 4
+    bad = bytearray(good); bad[i0 + 40] ^= 0xFF; bad[i0 + 41] ^= 0xFF
+    short = bytearray(good)   # a valid stream that ends early: re-deflate half of the rows
+    blobs = [good, bytes(adam7), cut, bytes(bad), b"\x89PNG\r\n\x1a\n" + b"\0" * 40, good]
+    p = pkg.default_parameters(png_optimize=True)
+    outs = api.cs_batch_compress(blobs, p)
+    assert outs[0] == oracle_png(good) and outs[5] == outs[0]
+    assert isinstance(outs[1], Exception) and outs[1].code == 10201
+    assert isinstance(outs[2], Exception) and outs[2].code == 30100
+    assert isinstance(outs[4], Exception) and outs[4].code == 30100
+    # the damaged stream either fails in the oracle too, or both produce the same file
+    try:
+        ref = oracle_png(bytes(bad))
+    except O.PngError:
+        ref = None
+    if ref is None:
+        assert isinstance(outs[3], Exception) and outs[3].code == 30100
+    else:
+        assert outs[3] == ref
+
+
+def test_jpeg_and_png_in_one_call(api):
+    from _util import oracle_lossless
+    from gen_synth import synth_jpeg
+    pkg = package()
+    png = dict(png_cases())["L_97x61"]
+    jpg = synth_jpeg(1, 64, 48)
+    p = pkg.default_parameters(png_optimize=True, jpeg_optimize=True)
+    outs = api.cs_batch_compress([jpg, png, jpg], p)
+    assert outs[1] == oracle_png(png)
+    assert outs[0] == oracle_lossless(jpg) and outs[2] == outs[0]
+    # without png.optimize a PNG has no device path (lossy PNG is not built)
+    outs = api.cs_batch_compress([png], pkg.default_parameters())
+    assert isinstance(outs[0], Exception) and outs[0].code == 10201

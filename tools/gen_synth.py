@@ -45,13 +45,14 @@ def synth_jpeg(i, w=1920, h=1080, quality=92, subsampling=2, progressive=False, 
     return b.getvalue()
 
 
-def synth_png(seed, width, height, mode="RGB", compress_level=6, **save_kw):
+def synth_png(seed, width, height, mode="RGB", compress_level=6, texture=3.0, **save_kw):
     """PNG of the SURVEY 8d synthetic picture in a Pillow mode ("RGB", "RGBA", "L", "LA", "P", "1", "I;16"), written by
     Pillow/libpng (adaptive filtering, zlib `compress_level`)."""
     import io
 
     from PIL import Image
-    im = Image.fromarray(synth_rgb(seed, width, height), "RGB")
+    # cut out of a larger picture: the recipe's solid rectangles (40-400 px) would otherwise cover a small one completely
+    im = Image.fromarray(np.ascontiguousarray(synth_rgb(seed, width + 400, height + 300, texture=texture)[150:150 + height, 200:200 + width]), "RGB")
     if mode == "I;16":
         rng = np.random.default_rng(seed)
         a = np.asarray(im.convert("L")).astype(np.uint16) * 256 + rng.integers(0, 256, (height, width), dtype=np.uint16)
