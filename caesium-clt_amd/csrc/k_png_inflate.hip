@@ -18,7 +18,7 @@ namespace csp {
 enum { LROOT = 10, DROOT = 8, RING = 32768, RING_NEAR = RING - 258 };   // the ring covers (almost) the whole deflate window: 40 KB of LDS per stream, four streams per CU
 
 struct InflateLds {
-    uint32_t lcount[16], dcount[16], ccount[16];
+    uint32_t lcount[16], dcount[16], ccount[16], offs[16];
     uint16_t lsorted[288], dsorted[32], csorted[20];
     uint16_t lroot[1 << LROOT], droot[1 << DROOT];
     uint8_t lens[320];
@@ -37,7 +37,7 @@ __device__ __forceinline__ static uint32_t canon_walk(uint32_t bits, int maxlen,
     return 0;
 }
 // counts, canonical symbol order and the root table of one code; returns "left" (0 complete, >0 incomplete, <0 over-subscribed)
-__device__ static int build_code(const uint8_t *lens, int n, uint32_t *count, uint16_t *sorted, uint16_t *root, int rootbits) {
+__device__ static int build_code(const uint8_t *lens, int n, uint32_t *count, uint32_t *offs, uint16_t *sorted, uint16_t *root, int rootbits) {
     LFOR(l) if (l < 16) count[l] = 0;
     CSP_WAVE_SYNC();
     LFOR(l) for (int i = l; i < n; i += 64) atomicAdd(&count[lens[i]], 1u);
@@ -46,13 +46,13 @@ __device__ static int build_code(const uint8_t *lens, int n, uint32_t *count, ui
     for (int l = 1; l < 16; l++) { left <<= 1; left -= int(count[l]); if (left < 0) return left; }
     if (int(count[0]) == n) left = 0;
     LFOR(l) if (l == 0) {   // symbols in order of (length, symbol)
-        uint32_t offs[16];
         offs[1] = 0;
         for (int k = 1; k < 15; k++) offs[k + 1] = offs[k] + count[k];
         for (int i = 0; i < n; i++) { const int k = lens[i]; if (k) sorted[offs[k]++] = uint16_t(i); }
     }
     CSP_WAVE_SYNC();
-    if (root) LFOR(l) for (int e = l; e < (1 << rootbits); e += 64) root[e] = uint16_t(canon_walk(uint32_t(e), rootbits, count, sorted));
+    // root entries: (symbol << 4) | length, bit 15 set for everything that is not a literal; 0 = longer than the root
+    if (root) LFOR(l) for (int e = l; e < (1 << rootbits); e += 64) { const uint32_t v = canon_walk(uint32_t(e), rootbits, count, sorted); root[e] = uint16_t(v | ((v >> 4) >= 256u ? 0x8000u : 0u)); }
     CSP_WAVE_SYNC();
     return left;
 }
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
                 LFOR(l) if (l == 0) S.lens[order[i]] = uint8_t(v);
             }
             CSP_WAVE_SYNC();
-            if (build_code(S.lens, 19, S.ccount, S.csorted, nullptr, 0) != 0) { err = CSP_ERR_BAD_PNG; break; }   // zlib: must be complete
+            if (build_code(S.lens, 19, S.ccount, S.offs, S.csorted, nullptr, 0) != 0) { err = CSP_ERR_BAD_PNG; break; }   // zlib: must be complete
             // the code lengths of the two alphabets, as one run-length coded sequence
             int idx = 0;
             uint32_t prev = 0;
@@ -192,9 +192,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
             if (S.lens[256] == 0) { err = CSP_ERR_BAD_PNG; break; }
         }
         {
-            int r = build_code(S.lens, nlen, S.lcount, S.lsorted, S.lroot, LROOT);
+            int r = build_code(S.lens, nlen, S.lcount, S.offs, S.lsorted, S.lroot, LROOT);
             if (type == 2 && (r < 0 || (r > 0 && nlen - int(S.lcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }
-            r = build_code(S.lens + 288, ndist, S.dcount, S.dsorted, S.droot, DROOT);
+            r = build_code(S.lens + 288, ndist, S.dcount, S.offs, S.dsorted, S.droot, DROOT);
             if (type == 2 && (r < 0 || (r > 0 && ndist - int(S.dcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }   // the fixed distance code is incomplete by definition
         }
         // The symbols.  One pass = one window: EVERY lane looks up the two root tables for "a code starting at bit bp + lane"
@@ -206,7 +206,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
             if (rd.overrun()) { err = CSP_ERR_BAD_PNG; break; }
             LV<uint32_t> E, D, pend;
             LFOR(l) { const uint32_t b = rd.at(uint32_t(l)); E[l] = S.lroot[b & ((1u << LROOT) - 1u)]; D[l] = S.droot[b & ((1u << DROOT) - 1u)]; pend[l] = 0; }
-            uint32_t off = 0, npend = 0;
+            uint32_t off = 0;
+            uint64_t lits = 0;   // bit o set: a literal whose code starts at window offset o waits in lane o of `pend`
             auto lane_of = [&](const LV<uint32_t> &v, uint32_t i) -> uint32_t {
 #ifdef CSH_EMUL
                 return v.v[i];
@@ -214,27 +215,40 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
                 return uint32_t(__builtin_amdgcn_readlane(int(v.v), int(i)));
 #endif
             };
-            auto spill = [&]() {   // pending literals -> ring
-                if (!npend) return;
-                LFOR(l) if (uint32_t(l) < npend) S.ring[(uint32_t(pos) + uint32_t(l)) & (RING - 1)] = uint8_t(pend[l]);
-                pos += npend; npend = 0;
+            auto spill = [&]() {   // pending literals -> ring, in offset order
+                if (!lits) return;
+                LFOR(l) if ((lits >> l) & 1) S.ring[(uint32_t(pos) + uint32_t(__popcll(lits & lanes_below(l)))) & (RING - 1)] = uint8_t(pend[l]);
+                pos += uint32_t(__popcll(lits)); lits = 0;
                 if ((pos >> 10) != (flushed >> 10)) flush();
             };
-            while (off < 44) {
+            // close to the end of the image a window is one symbol long, so that nothing is decoded past the last byte
+            uint32_t wlimit = cap - pos < 512 ? 1u : 44u;
+            while (off < wlimit) {
                 uint32_t e = lane_of(E, off);
+                // a run of literals out of the root table: the common case, a loop of its own with nothing else in it
+                while ((e - 1u) < 0x7FFFu) {
+#ifdef CSH_EMUL
+                    pend.v[off] = e >> 4;
+#else
+                    pend.v = (threadIdx.x & 63u) == off ? e >> 4 : pend.v;
+#endif
+                    lits |= 1ull << off; off += e & 15u;
+                    if (off >= wlimit) break;
+                    e = lane_of(E, off);
+                }
+                if (off >= wlimit) break;
                 if (!e) { e = uni(canon_walk(rd.peek(off, 15), 15, S.lcount, S.lsorted)); if (!e) { err = CSP_ERR_BAD_PNG; break; } }
-                off += e & 15u;
-                const uint32_t sym = e >> 4;
+                const uint32_t sym = (e >> 4) & 0x1FFu;
                 if (sym < 256) {
 #ifdef CSH_EMUL
-                    pend.v[npend] = sym;
+                    pend.v[off] = sym;
 #else
-                    pend.v = (threadIdx.x & 63u) == npend ? sym : pend.v;
+                    pend.v = (threadIdx.x & 63u) == off ? sym : pend.v;
 #endif
-                    npend++;
-                    if (pos + npend >= cap) break;
+                    lits |= 1ull << off; off += e & 15u;
                     continue;
                 }
+                off += e & 15u;
                 spill();
                 if (sym == 256) { block_done = true; break; }
                 const uint32_t li = sym - 257;
@@ -265,6 +279,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
                 pos += len;
                 if ((pos >> 10) != (flushed >> 10)) flush();
                 if (pos >= cap) break;
+                if (cap - pos < 512) wlimit = 1;
             }
             if (err) break;
             spill();

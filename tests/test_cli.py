@@ -306,6 +306,27 @@ def end_to_end(binary, tree, tmp_path):
     assert j["files"][0]["status"] == "error" and j["files"][0]["message"].startswith("Error compressing file: ") and j["files"][0]["output_path"].endswith("j1.png")
 
 
+    # 10. PNG: --lossless runs the device PNG pipeline (mixed with JPEG in one run, order kept); -q on a PNG (lossy PNG) has no
+    # device path and fails per file
+    from _util import oracle_png
+    from gen_synth import synth_png
+    mixed = tmp_path / "mixed"
+    mixed.mkdir()
+    pngs = {"a.png": synth_png(60, 120, 80, "RGB", compress_level=1), "c.png": synth_png(61, 64, 64, "LA", compress_level=1)}
+    for name, data in pngs.items():
+        (mixed / name).write_bytes(data)
+    (mixed / "b.jpg").write_bytes(files["level_1_0/j1.jpg"])
+    j = json.loads(run_cli(binary, "--lossless", "-o", tmp_path / "mx", "--json", "--png-opt-level", 2, mixed).stdout)
+    assert [os.path.basename(f["original_path"]) for f in j["files"]] == ["a.png", "b.jpg", "c.png"]
+    assert [f["status"] for f in j["files"]] == ["success"] * 3
+    for f in j["files"]:
+        name = os.path.basename(f["original_path"])
+        want = oracle_png(pngs[name], 2) if name in pngs else oracle_lossless(files["level_1_0/j1.jpg"])
+        assert open(f["output_path"], "rb").read() == want, name
+    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "mq", "--json", mixed / "a.png").stdout)
+    assert j["files"][0]["status"] == "error" and j["files"][0]["message"].startswith("Error compressing file: ")
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
 
