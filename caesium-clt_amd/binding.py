@@ -48,7 +48,7 @@ EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_siz
            "cs_batch_compress", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
-           "csp_batch_trials", "csp_batch_read_scores"]
+           "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits"]
 
 
 def _declare(L):
@@ -91,6 +91,7 @@ def _declare(L):
     L.csp_batch_read_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.csp_batch_read_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.csp_batch_read_scores.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, P(C.c_int)]
+    L.csp_batch_chunk_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, P(C.c_uint64), C.c_size_t, P(C.c_size_t)]
     L.csp_batch_trials.argtypes = [C.c_void_p, C.c_size_t, P(C.c_int), P(C.c_uint64), P(C.c_int), P(C.c_int)]
     return L
 
@@ -257,6 +258,12 @@ class PngBatch:
         if self.api.L.csp_batch_read_scores(self.h, image, out.ctypes.data, C.byref(have)):
             raise CaesiumError(-1, self.api.L.csh_last_error().decode())
         return out, have.value
+
+    def chunk_bits(self, image, trial):
+        arr = (C.c_uint64 * 65536)(); n = C.c_size_t()
+        if self.api.L.csp_batch_chunk_bits(self.h, image, trial, arr, 65536, C.byref(n)):
+            raise CaesiumError(-1, self.api.L.csh_last_error().decode())
+        return [arr[i] for i in range(n.value + (317 if os.environ.get('CSP_DEBUG_CHUNK') else 0))]
 
     def trials(self, image):
         """-> ([(strategy, zlib bytes)], index of the winner)"""

@@ -38,26 +38,29 @@ struct HistSink {
 };
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_hist(DeflateCtx c) {
     CSH_SHARED HistLds S;
-    const uint32_t bc = blockIdx.x, trial = blockIdx.y;
-    const uint32_t image = c.chunk_image[bc];
+    const uint32_t bg = blockIdx.x, trial = blockIdx.y;
+    const uint32_t image = c.group_image[bg];
     if (c.status[image]) return;
     const PngImg &im = c.imgs[image];
-    const uint32_t ci = bc - c.chunk_first[image];
+    const uint32_t c0 = (bg - c.group_first[image]) * CSP_GROUP, c1 = c0 + CSP_GROUP < im.nchunks ? c0 + CSP_GROUP : im.nchunks;
     const int slot = c.plan.trial_slot[trial];
     const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
-    const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
-    LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.hist[i] = 0;
-    HistSink sink; sink.hist = S.hist;
-    LFOR(l) sink.extra[l] = 0;
-    CSP_WAVE_SYNC();
-    lz_chunk(data, im.raw_len, start, end, S.lz, sink);
-    CSP_WAVE_SYNC();
-    PngChunk &rec = chunk_rec(c, im, slot, ci);
-    LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) rec.freq[i] = i == 256 ? 1u : S.hist[i];
-    LV<uint64_t> e;
-    LFOR(l) e[l] = sink.extra[l];
-    const uint64_t extra = lsum(e);
-    LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+    for (uint32_t ci = c0; ci < c1; ci++) {
+        const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
+        LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.hist[i] = 0;
+        HistSink sink; sink.hist = S.hist;
+        LFOR(l) sink.extra[l] = 0;
+        CSP_WAVE_SYNC();
+        lz_chunk(data, im.raw_len, start, end, S.lz, sink);
+        CSP_WAVE_SYNC();
+        PngChunk &rec = chunk_rec(c, im, slot, ci);
+        LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) rec.freq[i] = i == 256 ? 1u : S.hist[i];
+        LV<uint64_t> e;
+        LFOR(l) e[l] = sink.extra[l];
+        const uint64_t extra = lsum(e);
+        LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+        CSP_WAVE_SYNC();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ codes
@@ -254,66 +257,72 @@ struct EmitSink {
 };
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_emit(DeflateCtx c) {
     CSH_SHARED EmitLds S;
-    const uint32_t bc = blockIdx.x;
-    const uint32_t image = c.chunk_image[bc];
+    const uint32_t bg = blockIdx.x;
+    const uint32_t image = c.group_image[bg];
     if (c.status[image]) return;
     const PngImg &im = c.imgs[image];
-    const uint32_t ci = bc - c.chunk_first[image];
+    const uint32_t c0 = (bg - c.group_first[image]) * CSP_GROUP, c1 = c0 + CSP_GROUP < im.nchunks ? c0 + CSP_GROUP : im.nchunks;
     const int slot = c.plan.trial_slot[c.winner[image]];
-    const PngChunk &rec = chunk_rec(c, im, slot, ci);
-    const bool last = ci + 1 == im.nchunks;
-    // where this chunk's bytes go: after the zlib header and the chunks in front of it
+    const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
+    // where the group's first chunk goes: after the zlib header and the chunks in front of it
     uint64_t at = uint64_t(im.prefix_len) + 8 + 2;
     {
         LV<uint64_t> part;
-        LFOR(l) { uint64_t s = 0; for (uint32_t k = uint32_t(l); k < ci; k += 64) s += chunk_rec(c, im, slot, k).bytes; part[l] = s; }
+        LFOR(l) { uint64_t s = 0; for (uint32_t k = uint32_t(l); k < c0; k += 64) s += chunk_rec(c, im, slot, k).bytes; part[l] = s; }
         at += lsum(part);
     }
-    LFOR(l) {
-        for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.code[i] = uint32_t(rec.code[i]) | (uint32_t(rec.len[i]) << 16);
-        for (uint32_t i = uint32_t(l); i < 160; i += 64) S.win[i] = 0;
-    }
-    CSP_WAVE_SYNC();
-    BitOut bo; bo.win = S.win; bo.out = c.out + im.out_off + at; bo.bitpos = 0; bo.wbase = 0;
-    LV<uint64_t> val; LV<uint32_t> nb;
-    // block header: BFINAL, BTYPE=2, HLIT, HDIST, HCLEN (lane 0), the code-length code's lengths (lanes 1..)
-    LFOR(l) {
-        val[l] = 0; nb[l] = 0;
-        if (l == 0) { val[l] = (last ? 1u : 0u) | (2u << 1) | (uint64_t(rec.hlit - 257) << 3) | (uint64_t(rec.hdist - 1) << 8) | (uint64_t(rec.hclen - 4) << 13); nb[l] = 17; }
-        else if (l <= int(rec.hclen)) { val[l] = rec.cl_len[kClOrder[l - 1]]; nb[l] = 3; }
-    }
-    bo.put(val, nb);
-    for (uint32_t h0 = 0; h0 < rec.nhdr; h0 += 64) {
+    bool ok = true;
+    for (uint32_t ci = c0; ci < c1; ci++) {
+        const PngChunk &rec = chunk_rec(c, im, slot, ci);
+        const bool last = ci + 1 == im.nchunks;
+        LFOR(l) {
+            for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.code[i] = uint32_t(rec.code[i]) | (uint32_t(rec.len[i]) << 16);
+            for (uint32_t i = uint32_t(l); i < 160; i += 64) S.win[i] = 0;
+        }
+        CSP_WAVE_SYNC();
+        BitOut bo; bo.win = S.win; bo.out = c.out + im.out_off + at; bo.bitpos = 0; bo.wbase = 0;
+        LV<uint64_t> val; LV<uint32_t> nb;
+        // block header: BFINAL, BTYPE=2, HLIT, HDIST, HCLEN (lane 0), the code-length code's lengths (lanes 1..)
         LFOR(l) {
             val[l] = 0; nb[l] = 0;
-            const uint32_t h = h0 + uint32_t(l);
-            if (h < rec.nhdr) {
-                const uint32_t s = rec.hdr_sym[h], n = rec.cl_len[s];
-                val[l] = uint64_t(rec.cl_code[s]) | (uint64_t(rec.hdr_extra[h]) << n);
-                nb[l] = n + (s == 16 ? 2u : s == 17 ? 3u : s == 18 ? 7u : 0u);
-            }
+            if (l == 0) { val[l] = (last ? 1u : 0u) | (2u << 1) | (uint64_t(rec.hlit - 257) << 3) | (uint64_t(rec.hdist - 1) << 8) | (uint64_t(rec.hclen - 4) << 13); nb[l] = 17; }
+            else if (l <= int(rec.hclen)) { val[l] = rec.cl_len[kClOrder[l - 1]]; nb[l] = 3; }
         }
         bo.put(val, nb);
-    }
-    EmitSink sink; sink.code = S.code; sink.bo = &bo;
-    const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
-    const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
-    lz_chunk(data, im.raw_len, start, end, S.lz, sink);
-    // end of block; then the sync marker (empty stored block) that byte-aligns every chunk but the last
-    LFOR(l) {
-        val[l] = 0; nb[l] = 0;
-        if (l == 0) { val[l] = S.code[256] & 0xFFFFu; nb[l] = S.code[256] >> 16; }
-        if (l == 1 && !last) nb[l] = 3;
-    }
-    bo.put(val, nb);
-    if (!last) {
-        const uint32_t pad = uint32_t((8 - (bo.bitpos & 7)) & 7);
-        LFOR(l) { val[l] = 0; nb[l] = 0; if (l == 0) nb[l] = pad; if (l == 1) nb[l] = 16; if (l == 2) { val[l] = 0xFFFF; nb[l] = 16; } }
+        for (uint32_t h0 = 0; h0 < rec.nhdr; h0 += 64) {
+            LFOR(l) {
+                val[l] = 0; nb[l] = 0;
+                const uint32_t h = h0 + uint32_t(l);
+                if (h < rec.nhdr) {
+                    const uint32_t s = rec.hdr_sym[h], n = rec.cl_len[s];
+                    val[l] = uint64_t(rec.cl_code[s]) | (uint64_t(rec.hdr_extra[h]) << n);
+                    nb[l] = n + (s == 16 ? 2u : s == 17 ? 3u : s == 18 ? 7u : 0u);
+                }
+            }
+            bo.put(val, nb);
+        }
+        EmitSink sink; sink.code = S.code; sink.bo = &bo;
+        const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
+        lz_chunk(data, im.raw_len, start, end, S.lz, sink);
+        // end of block; then the sync marker (empty stored block) that byte-aligns every chunk but the last
+        LFOR(l) {
+            val[l] = 0; nb[l] = 0;
+            if (l == 0) { val[l] = S.code[256] & 0xFFFFu; nb[l] = S.code[256] >> 16; }
+            if (l == 1 && !last) nb[l] = 3;
+        }
         bo.put(val, nb);
+        if (!last) {
+            const uint32_t pad = uint32_t((8 - (bo.bitpos & 7)) & 7);
+            LFOR(l) { val[l] = 0; nb[l] = 0; if (l == 0) nb[l] = pad; if (l == 1) nb[l] = 16; if (l == 2) { val[l] = 0xFFFF; nb[l] = 16; } }
+            bo.put(val, nb);
+        }
+        CSP_WAVE_SYNC();
+        bo.finish();
+        if (bo.bitpos != (last ? rec.bits : ((rec.bits + 3 + 7) & ~7ull) + 32)) { if (ok) LFOR(l) if (l == 0) { uint64_t *dbg = c.trial_bytes + uint64_t(image) * CSP_MAX_STREAMS; dbg[7] = ci; dbg[8] = bo.bitpos; dbg[9] = rec.bits; } ok = false; }   // the size pass and the emit pass disagree: never ship it
+        at += rec.bytes;
+        CSP_WAVE_SYNC();
     }
-    CSP_WAVE_SYNC();
-    bo.finish();
-    if (bo.bitpos != (last ? rec.bits : ((rec.bits + 3 + 7) & ~7ull) + 32)) LFOR(l) if (l == 0) c.status[image] = CSP_ERR_POOL;   // the size pass and the emit pass disagree: never ship it
+    if (!ok) LFOR(l) if (l == 0) c.status[image] = CSP_ERR_POOL;
 }
 
 // ------------------------------------------------------------------------------------------------ finish
@@ -404,29 +413,47 @@ __global__ void __launch_bounds__(64) k_png_frame(DeflateCtx c) {
         t[0] = uint8_t(b >> 8); t[1] = uint8_t(b); t[2] = uint8_t(a >> 8); t[3] = uint8_t(a);
     }
 }
-__global__ void __launch_bounds__(64) k_png_crc_fold(DeflateCtx c, uint32_t max_pieces) {
+// fold the piece CRCs: crc(A || B) = x^(8 |B|) * crc(A) + crc(B).  First 64 pieces (64 KiB) per lane, in place; then the
+// groups of an image by one lane.
+__global__ void __launch_bounds__(64) k_png_crc_fold1(DeflateCtx c, uint32_t max_pieces) {
+    const int image = blockIdx.y;
+    if (c.status[image]) return;
+    const PngImg &im = c.imgs[image];
+    const uint64_t n = uint64_t(c.file_len[image]) - im.prefix_len - im.suffix_len - 8;
+    const uint32_t pieces = uint32_t((n + CRC_PIECE - 1) / CRC_PIECE), g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (uint64_t(g) * 64 >= pieces) return;
+    const uint32_t p0 = g * 64, p1 = p0 + 64 < pieces ? p0 + 64 : pieces;
+    const uint32_t op = gf2_x_pow_bytes(CRC_PIECE);
+    uint32_t *parts = c.crc_parts + uint64_t(image) * max_pieces;
+    uint32_t crc = parts[p0];
+    for (uint32_t p = p0 + 1; p < p1; p++) crc = gf2_mul(p + 1 == pieces ? gf2_x_pow_bytes(n - uint64_t(pieces - 1) * CRC_PIECE) : op, crc) ^ parts[p];
+    parts[p0] = crc;
+}
+__global__ void __launch_bounds__(64) k_png_crc_fold2(DeflateCtx c, uint32_t max_pieces) {
     const int image = blockIdx.x * blockDim.x + threadIdx.x;
     if (image >= c.nimg || c.status[image]) return;
     const PngImg &im = c.imgs[image];
     const uint64_t n = uint64_t(c.file_len[image]) - im.prefix_len - im.suffix_len - 8;
-    const uint32_t pieces = uint32_t((n + CRC_PIECE - 1) / CRC_PIECE);
-    const uint32_t op = gf2_x_pow_bytes(CRC_PIECE), op_last = gf2_x_pow_bytes(n - uint64_t(pieces - 1) * CRC_PIECE);
+    const uint32_t pieces = uint32_t((n + CRC_PIECE - 1) / CRC_PIECE), groups = (pieces + 63) / 64;
+    const uint32_t op = gf2_x_pow_bytes(uint64_t(CRC_PIECE) * 64);
+    const uint32_t *parts = c.crc_parts + uint64_t(image) * max_pieces;
     uint32_t crc = 0;
-    for (uint32_t p = 0; p < pieces; p++) crc = gf2_mul(p + 1 == pieces ? op_last : op, crc) ^ c.crc_parts[uint64_t(image) * max_pieces + p];
+    for (uint32_t g = 0; g < groups; g++) crc = gf2_mul(g + 1 == groups ? gf2_x_pow_bytes(n - uint64_t(g) * 64 * CRC_PIECE) : op, crc) ^ parts[uint64_t(g) * 64];
     uint8_t *t = c.out + im.out_off + im.prefix_len + 4 + n;
     t[0] = uint8_t(crc >> 24); t[1] = uint8_t(crc >> 16); t[2] = uint8_t(crc >> 8); t[3] = uint8_t(crc);
 }
 
-void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_hist, dim3(c.total_chunks, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) CSH_LAUNCH(k_png_hist, dim3(c.total_groups, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); }
 void launch_png_codes(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_codes, dim3((c.total_chunks + 63) / 64, c.plan.ntrials), dim3(64), st, c); }
 void launch_png_choose(hipStream_t st, const DeflateCtx &c) { if (c.nimg) CSH_LAUNCH(k_png_choose, dim3((c.nimg + 63) / 64), dim3(64), st, c); }
-void launch_png_emit(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_emit, dim3(c.total_chunks), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_emit(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) CSH_LAUNCH(k_png_emit, dim3(c.total_groups), dim3(CSP_WAVE_THREADS), st, c); }
 void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces) {
     if (!c.nimg) return;
     CSH_LAUNCH_PHASED(k_png_adler, 3, dim3(c.total_chunks), dim3(256), st, c);
     CSH_LAUNCH(k_png_frame, dim3(c.nimg), dim3(64), st, c);
     CSH_LAUNCH_PHASED(k_png_crc_pieces, 2, dim3((max_pieces + 255) / 256, c.nimg), dim3(256), st, c, max_pieces);
-    CSH_LAUNCH(k_png_crc_fold, dim3((c.nimg + 63) / 64), dim3(64), st, c, max_pieces);
+    CSH_LAUNCH(k_png_crc_fold1, dim3((max_pieces / 64 + 64) / 64, c.nimg), dim3(64), st, c, max_pieces);
+    CSH_LAUNCH(k_png_crc_fold2, dim3((c.nimg + 63) / 64), dim3(64), st, c, max_pieces);
 }
 
 }  // namespace csp

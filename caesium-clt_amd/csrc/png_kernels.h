@@ -34,6 +34,9 @@ struct DeflateCtx {
     uint32_t total_chunks;        // chunks of one stream slot over the whole batch
     const uint32_t *chunk_image;  // [total_chunks] image of a batch chunk; its index inside the image = chunk - imgs[image].chunk0
     const uint32_t *chunk_first;  // [nimg] first batch chunk of the image
+    uint32_t total_groups;        // the tokenizer passes take CSP_GROUP consecutive chunks per wave
+    const uint32_t *group_image;  // [total_groups]
+    const uint32_t *group_first;  // [nimg] first batch group of the image
     const uint8_t *streams;
     PngChunk *chunks;             // [(image chunk_base) + slot * nchunks + c]
     PngPlan plan;

@@ -71,18 +71,21 @@ __device__ __forceinline__ static void lz_insert(LzLds &L, const LV<uint32_t> &h
 // of `taken` says the parse visits it; len 0 = literal `lit`.
 template <class Sink>
 __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, LzLds &L, Sink &sink) {
-    LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH_BITS); i += 64) L.bucket[i] = ~0ull;
-    CSP_WAVE_SYNC();
-    const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
-    for (uint64_t t0 = seed0; t0 < start; t0 += 64) {
-        LV<uint32_t> hash, hashable, rel;
-        LFOR(l) {
-            const uint64_t p = t0 + uint32_t(l);
-            hashable[l] = p + 4 <= total ? 1u : 0u;
-            hash[l] = hashable[l] ? lz_hash(uint32_t(load64u(data + p))) : 0u;
-            rel[l] = uint32_t(p + 32768 - start);
+    {
+        // a table of its own: empty, then seeded with the 32 KiB in front of the chunk
+        LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH_BITS); i += 64) L.bucket[i] = ~0ull;
+        CSP_WAVE_SYNC();
+        const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
+        for (uint64_t t0 = seed0; t0 < start; t0 += 64) {
+            LV<uint32_t> hash, hashable, rel;
+            LFOR(l) {
+                const uint64_t p = t0 + uint32_t(l);
+                hashable[l] = p + 4 <= total ? 1u : 0u;
+                hash[l] = hashable[l] ? lz_hash(uint32_t(load64u(data + p))) : 0u;
+                rel[l] = uint32_t(p + 32768 - start);
+            }
+            lz_insert(L, hash, hashable, rel);
         }
-        lz_insert(L, hash, hashable, rel);
     }
     uint64_t carry = start;
     for (uint64_t t0 = start; t0 < end; t0 += 64) {

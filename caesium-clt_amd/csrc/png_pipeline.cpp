@@ -137,11 +137,11 @@ struct csp_batch {
     std::vector<PngImg> imgs;
     PngPlan plan{};
     int slot_of_strategy[10];
-    uint32_t total_rows = 0, total_chunks = 0, max_pieces = 0;
+    uint32_t total_rows = 0, total_chunks = 0, total_groups = 0, max_pieces = 0;
     uint64_t raw_total = 0, pixels = 0;
     DevBuf<PngImg> d_imgs;
     DevBuf<uint8_t> d_idat, d_raw, d_pix, d_streams, d_out, d_fixed, d_choice;
-    DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_status, d_file_len, d_adler, d_crc;
+    DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_file_len, d_adler, d_crc;
     DevBuf<uint64_t> d_scores, d_trial_bytes;
     DevBuf<int32_t> d_winner;
     DevBuf<PngChunk> d_chunks;
@@ -240,6 +240,15 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         }
         chunk_first[nimg] = c;
     }
+    std::vector<uint32_t> group_image, group_first(size_t(nimg) + 1);
+    for (int i = 0; i < nimg; i++) {
+        group_first[i] = uint32_t(group_image.size());
+        for (uint32_t g = 0; g < (b->imgs[i].nchunks + CSP_GROUP - 1) / CSP_GROUP; g++) group_image.push_back(uint32_t(i));
+    }
+    group_first[nimg] = uint32_t(group_image.size());
+    b->total_groups = uint32_t(group_image.size());
+    group_image.push_back(0);
+    if (b->d_group_image.upload(group_image, st) || b->d_group_first.upload(group_first, st)) return CS_ERR_NO_DEVICE;
     if (b->d_imgs.upload(b->imgs, st) || b->d_row_image.upload(row_image, st) || b->d_chunk_image.upload(chunk_image, st) || b->d_chunk_first.upload(chunk_first, st) ||
         b->d_fixed.upload(fixed, st))
         return CS_ERR_NO_DEVICE;
@@ -267,6 +276,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     f.scores = b->d_scores.p; f.choice = b->d_choice.p; f.plan = b->plan; f.status = b->d_status.p;
     DeflateCtx d{};
     d.imgs = b->d_imgs.p; d.nimg = nimg; d.total_chunks = b->total_chunks; d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p;
+    d.total_groups = b->total_groups; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;
     d.streams = b->d_streams.p; d.chunks = b->d_chunks.p; d.plan = b->plan; d.trial_bytes = b->d_trial_bytes.p; d.winner = b->d_winner.p;
     d.adler_parts = b->d_adler.p; d.out = b->d_out.p; d.fixed = b->d_fixed.p; d.file_len = b->d_file_len.p; d.crc_parts = b->d_crc.p; d.status = b->d_status.p;
     bool need_scores = false;
@@ -381,8 +391,18 @@ extern "C" int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uin
     *ntrials = b->plan.ntrials;
     for (int t = 0; t < b->plan.ntrials; t++) strategies[t] = b->plan.trial_strategy[t];
     int32_t w = 0;
-    if (hipMemcpy(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * b->plan.ntrials, hipMemcpyDeviceToHost) != hipSuccess ||
+    if (hipMemcpy(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * (getenv("CSP_DEBUG_SLOTS") ? 10 : b->plan.ntrials), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&w, b->d_winner.p + idx, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *winner = w;
+    return 0;
+}
+extern "C" int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, size_t cap, size_t *nchunks) {
+    const PngImg *im = tap_image(b, image);
+    if (!im || trial < 0 || trial >= b->plan.ntrials) return -1;
+    *nchunks = im->nchunks;
+    std::vector<PngChunk> recs(im->nchunks);
+    if (hipMemcpy(recs.data(), b->d_chunks.p + size_t(im->chunk_base) + size_t(b->plan.trial_slot[trial]) * im->nchunks, sizeof(PngChunk) * im->nchunks, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (size_t i = 0; i < im->nchunks && i < cap; i++) dst[i] = recs[i].bits;
+    if (const char *e = getenv("CSP_DEBUG_CHUNK")) { const int ci = atoi(e); if (ci < int(im->nchunks) && cap >= im->nchunks + 317) { for (int k = 0; k < 316; k++) dst[im->nchunks + k] = recs[ci].freq[k]; dst[im->nchunks + 316] = recs[ci].extra_bits; } }
     return 0;
 }

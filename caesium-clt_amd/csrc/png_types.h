@@ -10,6 +10,8 @@ enum : uint32_t {
     CSP_CHUNK = 32768,        // bytes of filtered stream per deflate block (one wave codes one chunk)
     CSP_HASH_BITS = 11,       // match finder: 2048 buckets x 4 positions (16 KiB of LDS per wave)
     CSP_WAYS = 4,
+    CSP_GROUP = 1,            // consecutive chunks one wave codes in a row (every chunk seeds its own match finder: carrying the
+                              // table from chunk to chunk was measured at -3 % on the tokenizer passes, not worth its complexity)
     CSP_NLIT = 286, CSP_NDIST = 30, CSP_NSYM = 316, CSP_NCL = 19,
     CSP_RAW_SLACK = 4096,     // the inflate kernel flushes whole KiB and a last match may overshoot the expected size
     CSP_MAX_STREAMS = 10,     // 5 fixed filters + up to 5 adaptive strategies

@@ -177,6 +177,8 @@ int csp_batch_read_stream(csp_batch *b, size_t image, int strategy, uint8_t *dst
    set when score k was computed for this level's plan */
 int csp_batch_read_scores(csp_batch *b, size_t image, uint64_t *dst, int *have);
 int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uint64_t *zlib_bytes, int *ntrials, int *winner);
+/* size in bits of every deflate block of one trial (dst[*nchunks]; capacity `cap` entries) */
+int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, size_t cap, size_t *nchunks);
 
 #ifdef __cplusplus
 }
