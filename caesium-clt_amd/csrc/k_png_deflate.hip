@@ -17,7 +17,7 @@ namespace csp {
 __device__ static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ static PngChunk &chunk_rec(const DeflateCtx &c, const PngImg &im, int slot, uint32_t ci) {
-    return c.chunks[uint64_t(im.chunk_base) + uint64_t(slot) * im.nchunks + ci];
+    return c.chunks[uint64_t(im.chunk_base) + uint64_t(slot) * im.chunk_stride + ci];
 }
 
 // ------------------------------------------------------------------------------------------------ hist

@@ -18,6 +18,49 @@ __device__ __forceinline__ static uint64_t ilog2i(uint64_t i) {   // i * log2(i)
     return i * uint64_t(l) + ((i - (1ull << l)) << 1);
 }
 
+// ---- P2: reductions (oracle: cso_png_reduce)
+__global__ void __launch_bounds__(256) k_png_analyze(const PngImg *imgs, const uint32_t *row_image, const uint8_t *pix, uint32_t *flags, const uint32_t *status) {
+    const uint32_t row = blockIdx.x, image = row_image[row];
+    if (status[image]) return;
+    const PngImg &im = imgs[image];
+    const uint32_t ch = im.channels, bps = im.bps;
+    if (!bps) return;
+    uint32_t keep = flags[image];   // only ever cleared: a stale read costs work, not correctness
+    if (!keep) return;
+    const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
+    for (uint32_t x = threadIdx.x; x < im.width && keep; x += blockDim.x) {
+        const uint8_t *px = r + uint64_t(x) * ch * bps;
+        if (keep & 1u) for (uint32_t k = 0; k < ch; k++) if (px[2 * k] != px[2 * k + 1]) keep &= ~1u;
+        if (keep & 2u) for (uint32_t b = 0; b < bps; b++) if (px[(ch - 1) * bps + b] != 0xFF) keep &= ~2u;
+        if (keep & 4u) for (uint32_t b = 0; b < bps; b++) if (px[b] != px[bps + b] || px[b] != px[2 * bps + b]) keep &= ~4u;
+    }
+    if (keep != 7u) atomicAnd(&flags[image], keep);
+}
+__global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const ReduceJob *jobs, const uint8_t *src, uint8_t *dst) {
+    const ReduceJob j = jobs[blockIdx.y];
+    const PngImg &im = imgs[j.image];   // already the new geometry
+    const uint32_t y = blockIdx.x;
+    if (y >= im.height) return;
+    const uint32_t nbps = im.bps, nk = im.channels;
+    const bool opaque = j.mask & 2u, grey = j.mask & 4u;
+    const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
+    uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
+    for (uint32_t x = threadIdx.x; x < im.width; x += blockDim.x) {
+        uint32_t k2 = 0;
+        for (uint32_t k = 0; k < j.old_channels; k++) {
+            if ((opaque && k == j.old_channels - 1) || (grey && (k == 1 || k == 2))) continue;
+            for (uint32_t b = 0; b < nbps; b++) d[(uint64_t(x) * nk + k2) * nbps + b] = s[(uint64_t(x) * j.old_channels + k) * j.old_bps + b];
+            k2++;
+        }
+    }
+}
+void launch_png_analyze(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, uint32_t *flags, const uint32_t *status) {
+    if (total_rows) CSH_LAUNCH(k_png_analyze, dim3(total_rows), dim3(256), st, imgs, row_image, pix, flags, status);
+}
+void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst) {
+    if (njobs) CSH_LAUNCH(k_png_repack, dim3(max_height, njobs), dim3(256), st, imgs, jobs, src, dst);
+}
+
 // one workgroup per batch row: all five filtered versions of the row
 __global__ void __launch_bounds__(256) k_png_filter5(FilterCtx c) {
     const uint32_t row = blockIdx.x;

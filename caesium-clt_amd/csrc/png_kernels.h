@@ -9,6 +9,13 @@ namespace csp {
 void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint32_t *status);
 void launch_png_unfilter(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *raw, uint8_t *pix, uint32_t *status);
 
+// P2: reductions (k_png_filter.hip).  flags[image] starts as the reductions the format allows (1: 16 -> 8 bits, 2: drop an
+// opaque alpha channel, 4: colour -> grey); the analysis clears what a pixel contradicts; the host decides and rewrites the
+// descriptor; the repack moves the surviving bytes (from `src` at the old geometry to `dst` at the new one).
+struct ReduceJob { uint32_t image, mask, old_rowbytes, old_channels, old_bps; uint64_t src_off, dst_off; };
+void launch_png_analyze(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, uint32_t *flags, const uint32_t *status);
+void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst);
+
 // P3: row-filter search (k_png_filter.hip)
 struct FilterCtx {
     const PngImg *imgs;

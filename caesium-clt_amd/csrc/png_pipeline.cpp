@@ -38,7 +38,8 @@ struct PngItem {
     std::string msg;
     int image = -1;
     size_t file_size = 0;
-    uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0;
+    uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0, channels = 0, depth = 0, ctype = 0;
+    bool no_reduce = false;   // a carried chunk is tied to the colour type (tRNS, bKGD, sBIT)
     std::vector<std::pair<size_t, size_t>> idat;   // (offset, length) of every IDAT payload in the input
     size_t idat_len = 0;
     std::vector<uint8_t> prefix, suffix;            // output bytes in front of / behind the IDAT chunk
@@ -79,6 +80,7 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
             if (d[12]) return fail(CS_ERR_UNSUPPORTED, "interlaced PNG has no device path in this build");
             const uint64_t bits = uint64_t(chans[ctype]) * uint64_t(depth);
             it.bpp = bits >= 8 ? uint32_t(bits / 8) : 1u;
+            it.channels = uint32_t(chans[ctype]); it.depth = uint32_t(depth); it.ctype = uint32_t(ctype);
             const uint64_t rb = (uint64_t(it.width) * bits + 7) / 8;
             if (rb > 0x7FFFFFF0u) return fail(CS_ERR_UNSUPPORTED, "PNG row too long");
             it.rowbytes = uint32_t(rb);
@@ -96,6 +98,7 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
             if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); }
             const bool critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
+                if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) it.no_reduce = true;
                 std::vector<uint8_t> &dst = seen_idat ? it.suffix : it.prefix;
                 dst.insert(dst.end(), in + pos, in + pos + 12 + size_t(len));
             }
@@ -122,8 +125,8 @@ int trial_set(int level, int *set) {
     return n;
 }
 
-const char *kPngKernelNames[CSP_NKERNELS] = {"k_png_inflate", "k_png_unfilter", "k_png_filter5", "k_png_scores", "k_png_brute", "k_png_pick",
-                                             "k_png_hist", "k_png_codes", "k_png_choose", "k_png_emit", "k_png_finish", "", "", "", "", ""};
+const char *kPngKernelNames[CSP_NKERNELS] = {"k_png_inflate", "k_png_unfilter", "k_png_reduce", "k_png_filter5", "k_png_scores", "k_png_brute", "k_png_pick",
+                                             "k_png_hist", "k_png_codes", "k_png_choose", "k_png_emit", "k_png_finish", "", "", "", ""};
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -135,12 +138,18 @@ struct csp_batch {
     std::vector<PngItem> items;
     std::vector<const uint8_t *> inputs;
     std::vector<PngImg> imgs;
+    std::vector<uint8_t> fixed;
+    std::vector<uint32_t> flags0;   // reductions each image's format allows
+    bool reduced = false;
+    uint32_t n_reduced = 0;
     PngPlan plan{};
     int slot_of_strategy[10];
     uint32_t total_rows = 0, total_chunks = 0, total_groups = 0, max_pieces = 0;
     uint64_t raw_total = 0, pixels = 0;
     DevBuf<PngImg> d_imgs;
-    DevBuf<uint8_t> d_idat, d_raw, d_pix, d_streams, d_out, d_fixed, d_choice;
+    DevBuf<uint8_t> d_idat, d_work, d_streams, d_out, d_fixed, d_choice;   // d_work: inflated streams, then pixels (one buffer: a reduction swaps the two regions of an image)
+    DevBuf<ReduceJob> d_jobs;
+    DevBuf<uint32_t> d_flags;
     DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_file_len, d_adler, d_crc;
     DevBuf<uint64_t> d_scores, d_trial_bytes;
     DevBuf<int32_t> d_winner;
@@ -155,6 +164,24 @@ struct csp_batch {
 
 extern "C" const char *csp_kernel_name(int i) { return (i >= 0 && i < CSP_NKERNELS) ? kPngKernelNames[i] : ""; }
 extern "C" void csp_batch_destroy(csp_batch *b) { delete b; }
+
+// (re)build the per-chunk / per-group index arrays from the current geometry of the images
+static int upload_chunk_index(csp_batch *b) {
+    const int nimg = int(b->imgs.size());
+    std::vector<uint32_t> chunk_image, chunk_first(size_t(nimg) + 1), group_image, group_first(size_t(nimg) + 1);
+    for (int i = 0; i < nimg; i++) {
+        chunk_first[i] = uint32_t(chunk_image.size()); group_first[i] = uint32_t(group_image.size());
+        for (uint32_t k = 0; k < b->imgs[i].nchunks; k++) chunk_image.push_back(uint32_t(i));
+        for (uint32_t g = 0; g < (b->imgs[i].nchunks + CSP_GROUP - 1) / CSP_GROUP; g++) group_image.push_back(uint32_t(i));
+    }
+    chunk_first[nimg] = uint32_t(chunk_image.size()); group_first[nimg] = uint32_t(group_image.size());
+    b->total_chunks = uint32_t(chunk_image.size()); b->total_groups = uint32_t(group_image.size());
+    chunk_image.push_back(0); group_image.push_back(0);
+    if (b->d_chunk_image.upload(chunk_image, b->stream) || b->d_chunk_first.upload(chunk_first, b->stream) || b->d_group_image.upload(group_image, b->stream) ||
+        b->d_group_first.upload(group_first, b->stream))
+        return -1;
+    return hipStreamSynchronize(b->stream) == hipSuccess ? 0 : -1;   // the host vectors go out of scope
+}
 
 extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
     *out = nullptr;
@@ -186,7 +213,7 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
     b->items.resize(count);
     b->inputs.resize(count);
     PinnedBytes idat_pool;
-    std::vector<uint8_t> fixed;
+    std::vector<uint8_t> &fixed = b->fixed;
     size_t raw_bytes = 0, pix_bytes = 0, stream_bytes = 256, out_bytes = 0;   // the tokenizer reads up to 8 bytes in front of a stream
     uint64_t nchunk_recs = 0;
     for (size_t i = 0; i < count; i++) {
@@ -213,6 +240,9 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         im.row_base = b->total_rows; b->total_rows += it.height;
         im.nchunks = uint32_t((im.raw_len + CSP_CHUNK - 1) / CSP_CHUNK);
         im.chunk_base = uint32_t(nchunk_recs); nchunk_recs += uint64_t(im.nchunks) * nslots;
+        im.chunk_stride = im.nchunks;
+        im.channels = it.channels; im.bps = (it.ctype != 3 && it.depth >= 8) ? it.depth / 8 : 0;
+        b->flags0.push_back((it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u)));
         if (nchunk_recs > 0x7FFFFFFFu) { csh_set_error("PNG batch too large"); return CS_ERR_POOL_OVERFLOW; }
         im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
         im.fix_off = fixed.size();
@@ -225,34 +255,20 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         if (pieces > b->max_pieces) b->max_pieces = pieces;
         it.image = int(b->imgs.size());
         b->imgs.push_back(im);
-        b->total_chunks += im.nchunks;
         b->raw_total += im.raw_len; b->pixels += uint64_t(it.width) * it.height;
     }
     idat_pool.flush_copies();
     const int nimg = int(b->imgs.size());
-    std::vector<uint32_t> row_image(b->total_rows), chunk_image(b->total_chunks), chunk_first(size_t(nimg) + 1);
+    std::vector<uint32_t> row_image(b->total_rows);
     {
-        uint32_t r = 0, c = 0;
-        for (int i = 0; i < nimg; i++) {
-            chunk_first[i] = c;
-            for (uint32_t y = 0; y < b->imgs[i].height; y++) row_image[r++] = uint32_t(i);
-            for (uint32_t k = 0; k < b->imgs[i].nchunks; k++) chunk_image[c++] = uint32_t(i);
-        }
-        chunk_first[nimg] = c;
+        uint32_t r = 0;
+        for (int i = 0; i < nimg; i++) for (uint32_t y = 0; y < b->imgs[i].height; y++) row_image[r++] = uint32_t(i);
     }
-    std::vector<uint32_t> group_image, group_first(size_t(nimg) + 1);
-    for (int i = 0; i < nimg; i++) {
-        group_first[i] = uint32_t(group_image.size());
-        for (uint32_t g = 0; g < (b->imgs[i].nchunks + CSP_GROUP - 1) / CSP_GROUP; g++) group_image.push_back(uint32_t(i));
-    }
-    group_first[nimg] = uint32_t(group_image.size());
-    b->total_groups = uint32_t(group_image.size());
-    group_image.push_back(0);
-    if (b->d_group_image.upload(group_image, st) || b->d_group_first.upload(group_first, st)) return CS_ERR_NO_DEVICE;
-    if (b->d_imgs.upload(b->imgs, st) || b->d_row_image.upload(row_image, st) || b->d_chunk_image.upload(chunk_image, st) || b->d_chunk_first.upload(chunk_first, st) ||
-        b->d_fixed.upload(fixed, st))
+    for (int i = 0; i < nimg; i++) b->imgs[i].pix_off += raw_bytes;   // pixels live behind the inflated streams in one buffer
+    if (upload_chunk_index(b.get())) return CS_ERR_NO_DEVICE;
+    if (b->d_imgs.upload(b->imgs, st) || b->d_row_image.upload(row_image, st) || b->d_fixed.upload(fixed, st) || b->d_flags.alloc(size_t(nimg) + 1) || b->d_jobs.alloc(size_t(nimg) + 1))
         return CS_ERR_NO_DEVICE;
-    if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_raw.alloc(raw_bytes + 256) || b->d_pix.alloc(pix_bytes + 256) || b->d_streams.alloc(stream_bytes + 256) ||
+    if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_work.alloc(raw_bytes + pix_bytes + 256) || b->d_streams.alloc(stream_bytes + 256) ||
         b->d_out.alloc(out_bytes + 256) || b->d_choice.alloc(size_t(5) * b->total_rows + 1) || b->d_status.alloc(size_t(nimg) + 1) || b->d_file_len.alloc(size_t(nimg) + 1) ||
         b->d_adler.alloc(2 * size_t(b->total_chunks) + 2) || b->d_crc.alloc(size_t(nimg) * b->max_pieces + 1) || b->d_scores.alloc(size_t(b->total_rows) * 25 + 1) ||
         b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
@@ -265,14 +281,63 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
     return 0;
 }
 
+// P2: which reductions the pixels allow (device), the new geometry and IHDR (host), the repack (device).  One host round trip
+// per batch; afterwards every later stage sees the reduced image as if it had come in that way.
+static int reduce_step(csp_batch *b) {
+    hipStream_t st = b->stream;
+    const int nimg = int(b->imgs.size());
+    b->reduced = true;
+    bool any = false;
+    for (uint32_t f : b->flags0) any |= f != 0;
+    if (!any || !nimg) return 0;
+    if (hipMemcpyAsync(b->d_flags.p, b->flags0.data(), sizeof(uint32_t) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    launch_png_analyze(st, b->d_imgs.p, b->total_rows, b->d_row_image.p, b->d_work.p, b->d_flags.p, b->d_status.p);
+    std::vector<uint32_t> flags(nimg), status(nimg);
+    if (hipMemcpyAsync(flags.data(), b->d_flags.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        csh_set_error("PNG analysis failed");
+        return -1;
+    }
+    std::vector<ReduceJob> jobs;
+    uint32_t max_height = 0;
+    for (int i = 0; i < nimg; i++) {
+        if (!flags[i] || status[i]) continue;
+        PngImg &im = b->imgs[i];
+        const bool narrow = flags[i] & 1u, opaque = flags[i] & 2u, grey = flags[i] & 4u;
+        ReduceJob j{};
+        j.image = uint32_t(i); j.mask = flags[i]; j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps;
+        j.src_off = im.pix_off; j.dst_off = im.raw_off;   // the inflated stream is not needed any more: its region takes the new pixels
+        const uint32_t nk = im.channels - (opaque ? 1u : 0u) - (grey ? 2u : 0u), nbps = narrow ? 1u : im.bps;
+        im.channels = nk; im.bps = nbps; im.bpp = nk * nbps; im.rowbytes = im.width * nk * nbps;
+        im.raw_len = uint64_t(im.height) * (uint64_t(im.rowbytes) + 1);
+        im.nchunks = uint32_t((im.raw_len + CSP_CHUNK - 1) / CSP_CHUNK);
+        std::swap(im.pix_off, im.raw_off);
+        // the new IHDR: depth, colour type, checksum (prefix = signature, IHDR, carried chunks)
+        uint8_t *ihdr = &b->fixed[im.fix_off + 8];
+        ihdr[8 + 8] = uint8_t(nbps * 8); ihdr[8 + 9] = uint8_t(nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6);
+        put_be32(ihdr + 8 + 13, crc32_host(ihdr + 4, 17));
+        if (im.height > max_height) max_height = im.height;
+        jobs.push_back(j);
+    }
+    if (jobs.empty()) return 0;
+    b->n_reduced = uint32_t(jobs.size());
+    b->raw_total = 0;
+    for (auto &im : b->imgs) b->raw_total += im.raw_len;
+    if (hipMemcpyAsync(b->d_imgs.p, b->imgs.data(), sizeof(PngImg) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(b->d_jobs.p, jobs.data(), sizeof(ReduceJob) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(b->d_fixed.p, b->fixed.data(), b->fixed.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("PNG reduction upload failed"); return -1; }
+    launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()), max_height, b->d_work.p, b->d_work.p);
+    return upload_chunk_index(b);   // synchronises: jobs may go out of scope
+}
+
 extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     if (!b) return CS_ERR_NO_DEVICE;
     if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
     hipStream_t st = b->stream;
     const int nimg = int(b->imgs.size());
-    if (b->d_status.zero(st)) return CS_ERR_NO_DEVICE;
+    if (!b->reduced && b->d_status.zero(st)) return CS_ERR_NO_DEVICE;
     FilterCtx f{};
-    f.imgs = b->d_imgs.p; f.nimg = nimg; f.total_rows = b->total_rows; f.row_image = b->d_row_image.p; f.pix = b->d_pix.p; f.streams = b->d_streams.p;
+    f.imgs = b->d_imgs.p; f.nimg = nimg; f.total_rows = b->total_rows; f.row_image = b->d_row_image.p; f.pix = b->d_work.p; f.streams = b->d_streams.p;
     f.scores = b->d_scores.p; f.choice = b->d_choice.p; f.plan = b->plan; f.status = b->d_status.p;
     DeflateCtx d{};
     d.imgs = b->d_imgs.p; d.nimg = nimg; d.total_chunks = b->total_chunks; d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p;
@@ -283,8 +348,11 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     for (int a = 0; a < b->plan.nadaptive; a++) if (b->plan.adaptive_strategy[a] != 9) need_scores = true;
     int k = 0;
     auto mark = [&]() { (void)hipEventRecord(b->ev[k++], st); };
-    mark(); launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_raw.p, b->d_status.p);
-    mark(); launch_png_unfilter(st, b->d_imgs.p, nimg, b->d_raw.p, b->d_pix.p, b->d_status.p);
+    mark(); if (!b->reduced) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, b->d_status.p);
+    mark(); if (!b->reduced) launch_png_unfilter(st, b->d_imgs.p, nimg, b->d_work.p, b->d_work.p, b->d_status.p);
+    mark(); if (!b->reduced && reduce_step(b)) return CS_ERR_NO_DEVICE;
+    d.total_chunks = b->total_chunks; d.total_groups = b->total_groups;
+    d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;
     mark(); launch_png_filter5(st, f);
     mark(); if (need_scores && b->plan.need_brute != 2) launch_png_scores(st, f);
     mark(); if (b->plan.need_brute) launch_png_brute(st, f);
@@ -369,7 +437,7 @@ extern "C" int csp_batch_geometry(csp_batch *b, size_t image, uint32_t *width, u
 extern "C" int csp_batch_read_rows(csp_batch *b, size_t image, uint8_t *dst) {
     const PngImg *im = tap_image(b, image);
     if (!im) return -1;
-    return hipMemcpy(dst, b->d_pix.p + im->pix_off, size_t(im->height) * im->rowbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return hipMemcpy(dst, b->d_work.p + im->pix_off, size_t(im->height) * im->rowbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 extern "C" int csp_batch_read_stream(csp_batch *b, size_t image, int strategy, uint8_t *dst) {
     const PngImg *im = tap_image(b, image);

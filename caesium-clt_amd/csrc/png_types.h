@@ -31,7 +31,9 @@ struct PngImg {
     uint64_t stream_stride;
     uint32_t row_base;        // first row of the image in the per-row arrays
     uint32_t nchunks;         // ceil(raw_len / CSP_CHUNK)
-    uint32_t chunk_base;      // chunk record of (slot s, chunk c): chunk_base + s * nchunks + c
+    uint32_t chunk_base;      // chunk record of (slot s, chunk c): chunk_base + s * chunk_stride + c
+    uint32_t chunk_stride;    // records reserved per slot (nchunks of the image as it came in; a reduction only shrinks it)
+    uint32_t channels, bps;   // samples per pixel, bytes per sample (0 for palette / sub-byte images: no reductions)
     uint32_t prefix_len;      // bytes in front of the IDAT chunk in the output file (signature, IHDR, carried chunks)
     uint32_t suffix_len;      // bytes after it (carried chunks, IEND)
     uint64_t fix_off;         // prefix bytes then suffix bytes in the `fixed` pool

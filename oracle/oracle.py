@@ -47,7 +47,7 @@ class EncParams(C.Structure):
 class Png(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_int), ("ctype", C.c_int), ("interlace", C.c_int),
                 ("channels", C.c_int), ("bpp", C.c_int), ("nplte", C.c_int), ("rowbytes", C.c_size_t),
-                ("pix", C.POINTER(C.c_uint8)), ("chunks", C.POINTER(C.c_uint8)), ("chunks_len", C.c_size_t), ("idat_at", C.c_size_t)]
+                ("pix", C.POINTER(C.c_uint8)), ("chunks", C.POINTER(C.c_uint8)), ("chunks_len", C.c_size_t), ("idat_at", C.c_size_t), ("no_reduce", C.c_int)]
 
 
 def build(force=False):
@@ -94,6 +94,7 @@ def lib():
         L.cso_inflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.cso_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(Png))]
         L.cso_png_free.argtypes = [C.POINTER(Png)]
+        L.cso_png_reduce.argtypes = [C.POINTER(Png)]
         L.cso_png_scores.argtypes = [C.POINTER(Png), C.c_void_p]
         L.cso_png_filter.argtypes = [C.POINTER(Png), C.c_int, C.c_void_p, C.c_void_p]
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
@@ -294,6 +295,10 @@ class PngImage:
     def rows(self):
         im = self.im
         return np.ctypeslib.as_array(im.pix, shape=(im.height * im.rowbytes,)).reshape(im.height, im.rowbytes).copy()
+
+    def reduce(self):
+        """P2 reductions in place; -> bit mask of what was applied"""
+        return lib().cso_png_reduce(self.ptr)
 
     def scores(self):
         """[height][5 filters][5 scores: MinSum, Entropy, Bigrams, BigEnt, Brute]"""

@@ -245,6 +245,7 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
             if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) { rc = CSO_PNG_BAD; break; } P->nplte = (int)(len / 3); }
             int critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
+                if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) P->no_reduce = 1;
                 memcpy(P->chunks + P->chunks_len, in + pos, 12 + (size_t)len);
                 P->chunks_len += 12 + (size_t)len;
             }
@@ -283,6 +284,47 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
     if (rc) { cso_png_free(P); return rc; }
     *out = P;
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ P2: reductions
+ * The subset of oxipng's reductions that needs no palette: 16 -> 8 bits when every sample's two bytes are equal; alpha
+ * dropped when every pixel is opaque; colour -> grey when r == g == b everywhere.  Applied in that order, always (oxipng
+ * evaluates both variants and keeps the smaller; for these three the reduced image practically always wins), and never
+ * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Palette / sub-byte depth reductions: not built. */
+int cso_png_reduce(cso_png *P) {
+    if (P->no_reduce || P->ctype == 3 || P->depth < 8) return 0;
+    const int bps = P->depth / 8, ch = P->channels;
+    const size_t npx = (size_t)P->width * P->height;
+    int narrow = bps == 2, opaque = (ch == 2 || ch == 4), grey = ch >= 3;
+    for (uint32_t y = 0; y < P->height; y++) {
+        const uint8_t *r = P->pix + (size_t)y * P->rowbytes;
+        for (uint32_t x = 0; x < P->width; x++) {
+            const uint8_t *px = r + (size_t)x * ch * bps;
+            if (narrow) for (int k = 0; k < ch; k++) if (px[2 * k] != px[2 * k + 1]) narrow = 0;
+            if (opaque) for (int b = 0; b < bps; b++) if (px[(ch - 1) * bps + b] != 0xFF) opaque = 0;
+            if (grey) for (int b = 0; b < bps; b++) if (px[b] != px[bps + b] || px[b] != px[2 * bps + b]) grey = 0;
+        }
+    }
+    (void)npx;
+    if (!narrow && !opaque && !grey) return 0;
+    const int nbps = narrow ? 1 : bps;
+    int keep[4], nk = 0;   /* source channels that survive */
+    for (int k = 0; k < ch; k++) {
+        if (opaque && k == ch - 1) continue;
+        if (grey && (k == 1 || k == 2)) continue;
+        keep[nk++] = k;
+    }
+    const size_t nrow = (size_t)P->width * nk * nbps;
+    uint8_t *np = (uint8_t *)malloc(nrow * P->height);
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++)
+            for (int k = 0; k < nk; k++)
+                for (int b = 0; b < nbps; b++)
+                    np[(size_t)y * nrow + ((size_t)x * nk + k) * nbps + b] = P->pix[(size_t)y * P->rowbytes + ((size_t)x * ch + keep[k]) * bps + b];
+    free(P->pix);
+    P->pix = np; P->rowbytes = nrow; P->channels = nk; P->depth = nbps * 8; P->bpp = nk * nbps;
+    P->ctype = nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6;
+    return (narrow ? 1 : 0) | (opaque ? 2 : 0) | (grey ? 4 : 0);
 }
 
 /* ------------------------------------------------------------------------------------------------ row filters */
@@ -640,6 +682,7 @@ int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, 
     cso_png *P = NULL;
     int rc = cso_png_decode(in, n, keep_metadata, &P);
     if (rc) return rc;
+    cso_png_reduce(P);
     size_t raw_len = (1 + P->rowbytes) * (size_t)P->height;
     uint8_t *filt = (uint8_t *)malloc(raw_len), *best = NULL;
     size_t best_len = 0;

@@ -73,6 +73,27 @@ def png_cases(small=True):
     b = io.BytesIO()
     im.save(b, "PNG", pnginfo=info, dpi=(300, 300), compress_level=1)
     cases.append(("RGB_with_text_and_phys", b.getvalue()))
+    # P2 reductions: opaque alpha, grey stored as colour, 16-bit samples with equal bytes -- and images that only nearly qualify
+    import numpy as np
+
+    from gen_synth import synth_rgb
+
+    def save(im, **kw):
+        b = io.BytesIO()
+        im.save(b, "PNG", **kw)
+        return b.getvalue()
+    a = np.ascontiguousarray(synth_rgb(27, 560, 420, texture=3.0)[150:270, 200:360])
+    full = np.full(a.shape[:2], 255, np.uint8)
+    cases.append(("reduce_rgba_opaque", save(Image.fromarray(np.dstack([a, full]), "RGBA"))))
+    cases.append(("reduce_rgb_grey", save(Image.fromarray(np.dstack([a[:, :, 0]] * 3), "RGB"))))
+    cases.append(("reduce_rgba_grey_opaque", save(Image.fromarray(np.dstack([a[:, :, 0]] * 3 + [full]), "RGBA"))))
+    cases.append(("reduce_la_opaque", save(Image.fromarray(np.dstack([a[:, :, 0], full]), "LA"))))
+    cases.append(("reduce_i16_narrow", save(Image.frombytes("I;16", (160, 120), (a[:, :, 0].astype("<u2") * 257).tobytes()))))
+    nearly = full.copy(); nearly[119, 159] = 254
+    cases.append(("reduce_rgba_nearly_opaque", save(Image.fromarray(np.dstack([a, nearly]), "RGBA"))))
+    g = np.dstack([a[:, :, 0]] * 3); g[60, 80, 2] ^= 1
+    cases.append(("reduce_rgb_nearly_grey", save(Image.fromarray(g, "RGB"))))
+    cases.append(("reduce_blocked_by_trns", save(Image.fromarray(np.dstack([a[:, :, 0]] * 3), "RGB"), transparency=(1, 2, 3))))
     if not small:
         cases.append(("RGB_640x480", synth_png(30, 640, 480, "RGB", texture=4.0)))
         cases.append(("RGBA_511x300", synth_png(31, 511, 300, "RGBA", texture=1.0)))

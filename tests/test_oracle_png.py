@@ -74,7 +74,11 @@ def test_optimised_file_keeps_the_pixels(mode):
     for level in (1, 3, 6):
         out, chosen = O.png_optimize(data, level)
         assert len(out) <= len(data)
-        assert pil_pixels(out)[0] == pil_pixels(data)[0] and np.array_equal(pil_pixels(out)[1], pil_pixels(data)[1])
+        a, b = PIL.open(io.BytesIO(data)), PIL.open(io.BytesIO(out))
+        if mode == "I;16":
+            assert a.mode == b.mode and np.array_equal(np.asarray(a), np.asarray(b))
+        else:   # a reduction (P2) may change the colour type, never what the pixels mean
+            assert np.array_equal(np.asarray(a.convert("RGBA")), np.asarray(b.convert("RGBA")))
         if chosen < 0:
             assert out == data
         else:
@@ -110,6 +114,24 @@ def test_metadata_policy():
     assert b"tEXt" not in stripped and b"pHYs" in stripped
     assert b"tEXt" in kept and b"pHYs" in kept
     assert PIL.open(io.BytesIO(kept)).info.get("Comment") == "hello"
+
+
+def test_reductions_keep_what_the_pixels_mean():
+    from _util import png_cases
+    want = {"reduce_rgba_opaque": ("RGB", 2), "reduce_rgb_grey": ("L", 4), "reduce_rgba_grey_opaque": ("L", 6), "reduce_la_opaque": ("L", 2), "reduce_i16_narrow": ("L", 1),
+            "reduce_rgba_nearly_opaque": ("RGBA", 0), "reduce_rgb_nearly_grey": ("RGB", 0), "reduce_blocked_by_trns": ("RGB", 0)}
+    for name, data in png_cases():
+        if name not in want:
+            continue
+        P = O.png_decode(data)
+        assert P.reduce() == want[name][1], name
+        out, _ = O.png_optimize(data, 2)
+        a, b = PIL.open(io.BytesIO(data)), PIL.open(io.BytesIO(out))
+        assert b.mode == want[name][0], name
+        if a.mode == "I;16":
+            assert np.array_equal(np.asarray(a) >> 8, np.asarray(b))
+        else:
+            assert np.array_equal(np.asarray(a.convert("RGBA")), np.asarray(b.convert("RGBA"))), name
 
 
 def test_refusals():

@@ -26,7 +26,8 @@ def check_batch(api, cases, level, keep_metadata=False, stages=True):
             assert not isinstance(outs[i], Exception), (name, outs[i])
             ref, chosen = O.png_optimize(blob, level, keep_metadata)
             if stages:
-                P = O.png_decode(blob)
+                P = O.png_decode(blob, keep_metadata)
+                P.reduce()   # P2: the device works on the reduced image from here on
                 assert np.array_equal(b.rows(i), P.rows()), name
                 got, have = b.scores(i)
                 want = P.scores()
