@@ -51,7 +51,7 @@ class Png(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h", "webp_oracle.c", "webp_oracle.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -100,6 +100,10 @@ def lib():
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_trials.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.cso_png_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.cso_webp_rgb_to_yuv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cso_webp_quality_to_qi.argtypes = [C.c_int]
+        L.cso_webp_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cso_webp_encode_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -361,3 +365,41 @@ def png_optimize(data, level=3, keep_metadata=False):
     res = C.string_at(out, n.value)
     lib().cso_free(out)
     return res, chosen.value
+
+
+# ---------------------------------------------------------------- lossy WebP row (webp_oracle.c; a minimal VP8 encoder, parity unpinned)
+def webp_rgb_to_yuv(rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    mbw, mbh = (w + 15) // 16, (h + 15) // 16
+    y = np.empty((mbh * 16, mbw * 16), np.uint8); u = np.empty((mbh * 8, mbw * 8), np.uint8); v = np.empty_like(u)
+    lib().cso_webp_rgb_to_yuv(rgb.ctypes.data, w, h, y.ctypes.data, u.ctypes.data, v.ctypes.data)
+    return y, u, v
+
+
+def webp_encode_yuv(y, u, v, width, height, qi):
+    """-> (file bytes, the encoder's own reconstruction (y, u, v))"""
+    ry, ru, rv = np.zeros_like(y), np.zeros_like(u), np.zeros_like(v)
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    rc = lib().cso_webp_encode_yuv(y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, qi, C.byref(out), C.byref(n), ry.ctypes.data, ru.ctypes.data, rv.ctypes.data)
+    if rc:
+        raise OracleError("webp oracle: %d" % rc)
+    data = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return data, (ry, ru, rv)
+
+
+def webp_encode_rgb(rgb, quality):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    rc = lib().cso_webp_encode_rgb(rgb.ctypes.data, w, h, quality, C.byref(out), C.byref(n))
+    if rc:
+        raise OracleError("webp oracle: %d" % rc)
+    data = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return data
+
+
+def webp_quality_to_qi(q):
+    return lib().cso_webp_quality_to_qi(q)

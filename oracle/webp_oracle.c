@@ -1,0 +1,321 @@
+/*
+ * webp_oracle.c -- CPU ORACLE of the lossy WebP row: RGB -> YUV 4:2:0 -> VP8 key frame -> RIFF.
+ *
+ * TEST INFRASTRUCTURE ONLY (tests/, tools/): nothing under caesium-clt_amd/ links or calls this.
+ *
+ * PARITY UNPINNED, AND THE ENCODER IS NOT libwebp's.  The reference reaches this path through
+ * `caesium::convert_in_memory(.., SupportedFileTypes::WebP)` (/root/reference/src/compressor.rs:289, :300), i.e. libwebp
+ * (libwebp-sys 0.9.5, Cargo.lock:956) at its default method 4: analysis, segments, intra-mode RD search (i16 / i4 / uv),
+ * trellis, loop-filter strength search.  None of that source is available.  This file is a first, MINIMAL conformant VP8
+ * encoder laid out for the GPU: every macroblock is coded i16x16 DC_PRED + chroma DC_PRED with one quantiser index, no
+ * segments, no loop filter, the default coefficient probabilities, one token partition.  What is pinned:
+ *   - the bitstream is valid: libwebp (through Pillow) decodes every output;
+ *   - the decoder-side arithmetic (dequantisation, inverse WHT / DCT, DC prediction, RFC 6386) is restated exactly, which
+ *     the tests check by comparing this file's own reconstruction with libwebp's decoded YUV -> the encoder and any
+ *     decoder stay in step;
+ *   - quality: PSNR against the source is asserted in the tests; size is larger than libwebp's at equal quality (no mode
+ *     search) -- stated, not hidden.
+ * The device path (k_webp.hip) must equal this file byte for byte.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/vp8_tables.h"
+#include "webp_oracle.h"
+
+/* ------------------------------------------------------------------------------------------------ W1: RGB -> YUV 4:2:0
+ * BT.601 limited range in 16-bit fixed point (libwebp's coefficients); chroma from the plain sum of the 2x2 block
+ * (libwebp averages in gamma-linear space: not restated), edges replicated.  Planes are padded to whole macroblocks by
+ * replicating the last sample. */
+static int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+void cso_webp_rgb_to_yuv(const uint8_t *rgb, int w, int h, uint8_t *yp, uint8_t *up, uint8_t *vp) {
+    const int mbw = (w + 15) >> 4, mbh = (h + 15) >> 4, ys = mbw * 16, cs = mbw * 8;
+    for (int y = 0; y < mbh * 16; y++)
+        for (int x = 0; x < ys; x++) {
+            const uint8_t *p = rgb + ((size_t)(y < h ? y : h - 1) * w + (x < w ? x : w - 1)) * 3;
+            yp[(size_t)y * ys + x] = (uint8_t)((16839 * p[0] + 33059 * p[1] + 6420 * p[2] + (16 << 16) + (1 << 15)) >> 16);
+        }
+    for (int y = 0; y < mbh * 8; y++)
+        for (int x = 0; x < cs; x++) {
+            int r = 0, g = 0, b = 0;
+            for (int dy = 0; dy < 2; dy++)
+                for (int dx = 0; dx < 2; dx++) {
+                    int yy = 2 * y + dy, xx = 2 * x + dx;
+                    const uint8_t *p = rgb + ((size_t)(yy < h ? yy : h - 1) * w + (xx < w ? xx : w - 1)) * 3;
+                    r += p[0]; g += p[1]; b += p[2];
+                }
+            up[(size_t)y * cs + x] = (uint8_t)clip8((-9719 * r - 19081 * g + 28800 * b + (128 << 18) + (1 << 17)) >> 18);
+            vp[(size_t)y * cs + x] = (uint8_t)clip8((28800 * r - 24116 * g - 4684 * b + (128 << 18) + (1 << 17)) >> 18);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------ transforms */
+/* forward 4x4 DCT of (src - pred), libwebp's integer form; forward transforms are the encoder's choice */
+static void fdct4(const uint8_t *src, int sstride, const uint8_t *ref, int rstride, int16_t *out) {
+    int tmp[16];
+    for (int i = 0; i < 4; i++, src += sstride, ref += rstride) {
+        int d0 = src[0] - ref[0], d1 = src[1] - ref[1], d2 = src[2] - ref[2], d3 = src[3] - ref[3];
+        int a0 = d0 + d3, a1 = d1 + d2, a2 = d1 - d2, a3 = d0 - d3;
+        tmp[0 + i * 4] = (a0 + a1) * 8;
+        tmp[1 + i * 4] = (a2 * 2217 + a3 * 5352 + 1812) >> 9;
+        tmp[2 + i * 4] = (a0 - a1) * 8;
+        tmp[3 + i * 4] = (a3 * 2217 - a2 * 5352 + 937) >> 9;
+    }
+    for (int i = 0; i < 4; i++) {
+        int a0 = tmp[0 + i] + tmp[12 + i], a1 = tmp[4 + i] + tmp[8 + i], a2 = tmp[4 + i] - tmp[8 + i], a3 = tmp[0 + i] - tmp[12 + i];
+        out[0 + i] = (int16_t)((a0 + a1 + 7) >> 4);
+        out[4 + i] = (int16_t)(((a2 * 2217 + a3 * 5352 + 12000) >> 16) + (a3 != 0));
+        out[8 + i] = (int16_t)((a0 - a1 + 7) >> 4);
+        out[12 + i] = (int16_t)((a3 * 2217 - a2 * 5352 + 51000) >> 16);
+    }
+}
+static void fwht(const int16_t *dc16, int16_t *out) {   /* the 16 luma DCs (raster order of the 4x4 blocks) */
+    int tmp[16];
+    for (int i = 0; i < 4; i++) {
+        int a0 = dc16[i * 4 + 0] + dc16[i * 4 + 2], a1 = dc16[i * 4 + 1] + dc16[i * 4 + 3], a2 = dc16[i * 4 + 1] - dc16[i * 4 + 3], a3 = dc16[i * 4 + 0] - dc16[i * 4 + 2];
+        tmp[0 + i * 4] = a0 + a1; tmp[1 + i * 4] = a3 + a2; tmp[2 + i * 4] = a3 - a2; tmp[3 + i * 4] = a0 - a1;
+    }
+    for (int i = 0; i < 4; i++) {
+        int a0 = tmp[0 + i] + tmp[8 + i], a1 = tmp[4 + i] + tmp[12 + i], a2 = tmp[4 + i] - tmp[12 + i], a3 = tmp[0 + i] - tmp[8 + i];
+        out[0 + i] = (int16_t)((a0 + a1) >> 1); out[4 + i] = (int16_t)((a3 + a2) >> 1); out[8 + i] = (int16_t)((a3 - a2) >> 1); out[12 + i] = (int16_t)((a0 - a1) >> 1);
+    }
+}
+/* inverse transforms: RFC 6386 section 14.3 / 14.4, what every decoder does */
+static void iwht(const int16_t *in, int16_t *dc16) {
+    int tmp[16];
+    for (int i = 0; i < 4; i++) {
+        int a0 = in[0 + i] + in[12 + i], a1 = in[4 + i] + in[8 + i], a2 = in[4 + i] - in[8 + i], a3 = in[0 + i] - in[12 + i];
+        tmp[0 + i] = a0 + a1; tmp[8 + i] = a0 - a1; tmp[4 + i] = a3 + a2; tmp[12 + i] = a3 - a2;
+    }
+    for (int i = 0; i < 4; i++) {
+        int dc = tmp[0 + i * 4] + 3, a0 = dc + tmp[3 + i * 4], a1 = tmp[1 + i * 4] + tmp[2 + i * 4], a2 = tmp[1 + i * 4] - tmp[2 + i * 4], a3 = dc - tmp[3 + i * 4];
+        dc16[i * 4 + 0] = (int16_t)((a0 + a1) >> 3); dc16[i * 4 + 1] = (int16_t)((a3 + a2) >> 3); dc16[i * 4 + 2] = (int16_t)((a0 - a1) >> 3); dc16[i * 4 + 3] = (int16_t)((a3 - a2) >> 3);
+    }
+}
+#define MUL1(a) ((((a) * 20091) >> 16) + (a))
+#define MUL2(a) (((a) * 35468) >> 16)
+static void idct4_add(const int16_t *in, const uint8_t *pred, int pstride, uint8_t *dst, int dstride) {
+    int tmp[16];
+    for (int i = 0; i < 4; i++) {   /* vertical pass */
+        int a = in[0 + i] + in[8 + i], b = in[0 + i] - in[8 + i];
+        int c = MUL2(in[4 + i]) - MUL1(in[12 + i]), d = MUL1(in[4 + i]) + MUL2(in[12 + i]);
+        tmp[0 + i * 4] = a + d; tmp[1 + i * 4] = b + c; tmp[2 + i * 4] = b - c; tmp[3 + i * 4] = a - d;
+    }
+    for (int i = 0; i < 4; i++) {   /* horizontal pass: output row i... the transposed walk of libwebp's TransformOne */
+        int dc = tmp[0 + i] + 4, a = dc + tmp[8 + i], b = dc - tmp[8 + i];
+        int c = MUL2(tmp[4 + i]) - MUL1(tmp[12 + i]), d = MUL1(tmp[4 + i]) + MUL2(tmp[12 + i]);
+        dst[i * dstride + 0] = (uint8_t)clip8(pred[i * pstride + 0] + ((a + d) >> 3));
+        dst[i * dstride + 1] = (uint8_t)clip8(pred[i * pstride + 1] + ((b + c) >> 3));
+        dst[i * dstride + 2] = (uint8_t)clip8(pred[i * pstride + 2] + ((b - c) >> 3));
+        dst[i * dstride + 3] = (uint8_t)clip8(pred[i * pstride + 3] + ((a - d) >> 3));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ boolean entropy coder (RFC 6386 section 7.3) */
+typedef struct { uint8_t *buf; size_t pos, cap; uint32_t range, bottom; int bit_count; } boolenc;
+static void be_init(boolenc *e) { e->buf = NULL; e->pos = 0; e->cap = 0; e->range = 255; e->bottom = 0; e->bit_count = 24; }
+static void be_byte(boolenc *e, uint8_t b) {
+    if (e->pos == e->cap) { e->cap = e->cap * 2 + 256; e->buf = (uint8_t *)realloc(e->buf, e->cap); }
+    e->buf[e->pos++] = b;
+}
+static void be_carry(boolenc *e) { size_t p = e->pos; while (p && e->buf[p - 1] == 255) e->buf[--p] = 0; if (p) e->buf[p - 1]++; }
+static void be_put(boolenc *e, int bit, int prob) {
+    uint32_t split = 1 + (((e->range - 1) * (uint32_t)prob) >> 8);
+    if (bit) { e->bottom += split; e->range -= split; } else e->range = split;
+    while (e->range < 128) {
+        e->range <<= 1;
+        if (e->bottom & 0x80000000u) be_carry(e);
+        e->bottom <<= 1;
+        if (!--e->bit_count) { be_byte(e, (uint8_t)(e->bottom >> 24)); e->bottom &= 0xFFFFFFu; e->bit_count = 8; }
+    }
+}
+static void be_bits(boolenc *e, uint32_t v, int n) { while (n--) be_put(e, (v >> n) & 1, 128); }
+static void be_flush(boolenc *e) {
+    int c = e->bit_count;
+    uint32_t v = e->bottom;
+    if (v & (1u << (32 - c))) be_carry(e);
+    v <<= c & 7; c >>= 3;
+    while (--c >= 0) v <<= 8;
+    c = 4;
+    while (--c >= 0) { be_byte(e, (uint8_t)(v >> 24)); v <<= 8; }
+}
+
+/* ------------------------------------------------------------------------------------------------ tokens (RFC 6386 section 13) */
+/* one block: coefficient levels in scan order, first = 1 for i16 luma blocks (their DC travels in the Y2 block) */
+static int put_coeffs(boolenc *e, int type, int ctx, const int16_t *lv, int first) {
+    int last = -1;
+    for (int i = first; i < 16; i++) if (lv[i]) last = i;
+    int n = first;
+    const uint8_t *p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
+    if (last < 0) { be_put(e, 0, p[0]); return 0; }
+    be_put(e, 1, p[0]);
+    while (n < 16) {
+        const int c = lv[n++];
+        const int sign = c < 0;
+        int v = sign ? -c : c;
+        if (!v) { be_put(e, 0, p[1]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
+        be_put(e, 1, p[1]);
+        if (v == 1) { be_put(e, 0, p[2]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
+        else {
+            be_put(e, 1, p[2]);
+            if (v <= 4) { be_put(e, 0, p[3]); if (v == 2) be_put(e, 0, p[4]); else { be_put(e, 1, p[4]); be_put(e, v == 4, p[5]); } }
+            else if (v <= 10) {
+                be_put(e, 1, p[3]); be_put(e, 0, p[6]);
+                if (v <= 6) { be_put(e, 0, p[7]); be_put(e, v == 6, 159); }
+                else { be_put(e, 1, p[7]); be_put(e, v >= 9, 165); be_put(e, !(v & 1), 145); }
+            } else {
+                int mask; const uint8_t *tab;
+                be_put(e, 1, p[3]); be_put(e, 1, p[6]);
+                if (v < 3 + (8 << 1)) { be_put(e, 0, p[8]); be_put(e, 0, p[9]); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
+                else if (v < 3 + (8 << 2)) { be_put(e, 0, p[8]); be_put(e, 1, p[9]); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
+                else if (v < 3 + (8 << 3)) { be_put(e, 1, p[8]); be_put(e, 0, p[10]); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
+                else { be_put(e, 1, p[8]); be_put(e, 1, p[10]); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
+                while (mask) { be_put(e, !!(v & mask), *tab++); mask >>= 1; }
+            }
+            p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
+        }
+        be_put(e, sign, 128);
+        if (n == 16) return 1;
+        if (n > last) { be_put(e, 0, p[0]); return 1; }
+        be_put(e, 1, p[0]);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ the frame */
+/* quality 0..100 -> quantiser index 0..127: libwebp's quality-to-compression curve without its segment / SNS adjustments */
+int cso_webp_quality_to_qi(int quality) {
+    double c = (quality < 0 ? 0 : quality > 100 ? 100 : quality) / 100.0;
+    double lin = c < 0.75 ? c * (2.0 / 3.0) : 2.0 * c - 1.0;
+    /* cube root by Newton steps on integers would do; this runs on the host only */
+    double v = 0.0;
+    if (lin > 0) { v = lin; for (int i = 0; i < 60; i++) v = v - (v * v * v - lin) / (3 * v * v); }
+    int qi = (int)(127.0 * (1.0 - v) + 0.5);
+    return qi < 0 ? 0 : qi > 127 ? 127 : qi;
+}
+static int quant(int c, int q) { int a = c < 0 ? -c : c; a = (a + (q >> 1)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
+
+/* levels: per macroblock 25 blocks x 16 (Y2, 16 luma, 4 U, 4 V), scan order.  recon planes come back for the tests. */
+int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp, int width, int height, int qi, uint8_t **out, size_t *out_len,
+                        uint8_t *ry, uint8_t *ru, uint8_t *rv) {
+    const int mbw = (width + 15) >> 4, mbh = (height + 15) >> 4, ys = mbw * 16, cs = mbw * 8;
+    if (width < 1 || height < 1 || width > 16383 || height > 16383) return -1;
+    const int y1dc = kVp8DcQ[qi], y1ac = kVp8AcQ[qi], y2dc = kVp8DcQ[qi] * 2;
+    int y2ac = kVp8AcQ[qi] * 155 / 100; if (y2ac < 8) y2ac = 8;
+    int uvdc = kVp8DcQ[qi]; if (uvdc > 132) uvdc = 132;
+    const int uvac = kVp8AcQ[qi];
+    int own = 0;
+    if (!ry) { own = 1; ry = (uint8_t *)malloc((size_t)ys * mbh * 16); ru = (uint8_t *)malloc((size_t)cs * mbh * 8); rv = (uint8_t *)malloc((size_t)cs * mbh * 8); }
+    int16_t *levels = (int16_t *)calloc((size_t)mbw * mbh * 400, sizeof(int16_t));
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
+            /* luma: DC prediction from the reconstructed row above and column to the left */
+            {
+                uint8_t *r = ry + (size_t)my * 16 * ys + mx * 16;
+                const uint8_t *s = yp + (size_t)my * 16 * ys + mx * 16;
+                int dc = 128;
+                if (mx || my) {
+                    int sum = 0, n = 0;
+                    if (my) { for (int i = 0; i < 16; i++) sum += r[i - ys]; n += 16; }
+                    if (mx) { for (int i = 0; i < 16; i++) sum += r[i * ys - 1]; n += 16; }
+                    dc = n == 32 ? (sum + 16) >> 5 : (sum + 8) >> 4;
+                }
+                uint8_t pred[16]; memset(pred, dc, 16);   /* a flat block: one row serves as every row (stride 0) */
+                int16_t coef[16][16], dcs[16], y2[16], dq[16];
+                for (int b = 0; b < 16; b++) { fdct4(s + (b >> 2) * 4 * ys + (b & 3) * 4, ys, pred, 0, coef[b]); dcs[b] = coef[b][0]; }
+                fwht(dcs, y2);
+                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc); dq[k] = (int16_t)(L[n] * (k ? y2ac : y2dc)); }
+                iwht(dq, dcs);
+                for (int b = 0; b < 16; b++) {
+                    int16_t c[16];
+                    c[0] = dcs[b];
+                    L[16 + b * 16] = 0;
+                    for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; L[16 + b * 16 + n] = (int16_t)quant(coef[b][k], y1ac); c[k] = (int16_t)(L[16 + b * 16 + n] * y1ac); }
+                    (void)y1dc;
+                    idct4_add(c, pred, 0, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
+                }
+            }
+            for (int pl = 0; pl < 2; pl++) {
+                uint8_t *r = (pl ? rv : ru) + (size_t)my * 8 * cs + mx * 8;
+                const uint8_t *s = (pl ? vp : up) + (size_t)my * 8 * cs + mx * 8;
+                int dc = 128;
+                if (mx || my) {
+                    int sum = 0, n = 0;
+                    if (my) { for (int i = 0; i < 8; i++) sum += r[i - cs]; n += 8; }
+                    if (mx) { for (int i = 0; i < 8; i++) sum += r[i * cs - 1]; n += 8; }
+                    dc = n == 16 ? (sum + 8) >> 4 : (sum + 4) >> 3;
+                }
+                uint8_t pred[8]; memset(pred, dc, 8);
+                for (int b = 0; b < 4; b++) {
+                    int16_t coef[16], c[16], *lv = L + (17 + pl * 4 + b) * 16;
+                    fdct4(s + (b >> 1) * 4 * cs + (b & 1) * 4, cs, pred, 0, coef);
+                    for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = (int16_t)quant(coef[k], k ? uvac : uvdc); c[k] = (int16_t)(lv[n] * (k ? uvac : uvdc)); }
+                    idct4_add(c, pred, 0, r + (b >> 1) * 4 * cs + (b & 1) * 4, cs);
+                }
+            }
+        }
+    /* partition 0: frame header + per-macroblock modes; partition 1: tokens */
+    boolenc h, t;
+    be_init(&h); be_init(&t);
+    be_bits(&h, 0, 1);            /* colour space */
+    be_bits(&h, 0, 1);            /* clamping required */
+    be_bits(&h, 0, 1);            /* no segmentation */
+    be_bits(&h, 1, 1);            /* simple filter ... */
+    be_bits(&h, 0, 6);            /* ... at level 0: off */
+    be_bits(&h, 0, 3);            /* sharpness */
+    be_bits(&h, 0, 1);            /* no filter deltas */
+    be_bits(&h, 0, 2);            /* one token partition */
+    be_bits(&h, (uint32_t)qi, 7);
+    for (int i = 0; i < 5; i++) be_bits(&h, 0, 1);   /* no quantiser deltas */
+    be_bits(&h, 0, 1);            /* refresh_entropy_probs */
+    for (int i = 0; i < 4 * 8 * 3 * 11; i++) be_put(&h, 0, kVp8CoefUpdateProbs[i]);   /* keep the default coefficient probabilities */
+    be_bits(&h, 0, 1);            /* no skip flags */
+    for (int i = 0; i < mbw * mbh; i++) {
+        be_put(&h, 1, 145); be_put(&h, 0, 156); be_put(&h, 0, 163);   /* i16x16, DC_PRED */
+        be_put(&h, 0, 142);                                          /* chroma DC_PRED */
+    }
+    be_flush(&h);
+    uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
+    for (int my = 0; my < mbh; my++) {
+        uint8_t left[9]; memset(left, 0, 9);
+        for (int mx = 0; mx < mbw; mx++) {
+            const int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
+            uint8_t *tp = top + (size_t)mx * 9;
+            tp[8] = left[8] = (uint8_t)put_coeffs(&t, 1, tp[8] + left[8], L, 0);
+            for (int by = 0; by < 4; by++)
+                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(&t, 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1);
+            for (int pl = 0; pl < 2; pl++)
+                for (int by = 0; by < 2; by++)
+                    for (int bx = 0; bx < 2; bx++)
+                        tp[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = (uint8_t)put_coeffs(&t, 2, tp[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0);
+        }
+    }
+    be_flush(&t);
+    free(top); free(levels);
+    if (own) { free(ry); free(ru); free(rv); }
+    /* RIFF / WEBP / "VP8 " : frame tag, start code, dimensions, partition 0, partition 1 */
+    const size_t vp8 = 10 + h.pos + t.pos, padded = vp8 + (vp8 & 1), total = 12 + 8 + padded;
+    uint8_t *o = (uint8_t *)calloc(total, 1), *w = o;
+    memcpy(w, "RIFF", 4); w[4] = (uint8_t)(total - 8); w[5] = (uint8_t)((total - 8) >> 8); w[6] = (uint8_t)((total - 8) >> 16); w[7] = (uint8_t)((total - 8) >> 24);
+    memcpy(w + 8, "WEBPVP8 ", 8); w[16] = (uint8_t)vp8; w[17] = (uint8_t)(vp8 >> 8); w[18] = (uint8_t)(vp8 >> 16); w[19] = (uint8_t)(vp8 >> 24);
+    w += 20;
+    const uint32_t tag = ((uint32_t)h.pos << 5) | (1u << 4) | (0u << 1) | 0u;   /* key frame, version 0, shown */
+    w[0] = (uint8_t)tag; w[1] = (uint8_t)(tag >> 8); w[2] = (uint8_t)(tag >> 16);
+    w[3] = 0x9D; w[4] = 0x01; w[5] = 0x2A;
+    w[6] = (uint8_t)width; w[7] = (uint8_t)(width >> 8); w[8] = (uint8_t)height; w[9] = (uint8_t)(height >> 8);
+    memcpy(w + 10, h.buf, h.pos); memcpy(w + 10 + h.pos, t.buf, t.pos);
+    free(h.buf); free(t.buf);
+    *out = o; *out_len = total;
+    return 0;
+}
+int cso_webp_encode_rgb(const uint8_t *rgb, int width, int height, int quality, uint8_t **out, size_t *out_len) {
+    const int mbw = (width + 15) >> 4, mbh = (height + 15) >> 4;
+    uint8_t *yp = (uint8_t *)malloc((size_t)mbw * mbh * 256), *up = (uint8_t *)malloc((size_t)mbw * mbh * 64), *vp = (uint8_t *)malloc((size_t)mbw * mbh * 64);
+    cso_webp_rgb_to_yuv(rgb, width, height, yp, up, vp);
+    int rc = cso_webp_encode_yuv(yp, up, vp, width, height, cso_webp_quality_to_qi(quality), out, out_len, NULL, NULL, NULL);
+    free(yp); free(up); free(vp);
+    return rc;
+}
