@@ -113,33 +113,41 @@ static void idct4_add(const int16_t *in, const uint8_t *pred, int pstride, uint8
     }
 }
 
-/* ------------------------------------------------------------------------------------------------ boolean entropy coder (RFC 6386 section 7.3) */
-typedef struct { uint8_t *buf; size_t pos, cap; uint32_t range, bottom; int bit_count; } boolenc;
-static void be_init(boolenc *e) { e->buf = NULL; e->pos = 0; e->cap = 0; e->range = 255; e->bottom = 0; e->bit_count = 24; }
-static void be_byte(boolenc *e, uint8_t b) {
-    if (e->pos == e->cap) { e->cap = e->cap * 2 + 256; e->buf = (uint8_t *)realloc(e->buf, e->cap); }
-    e->buf[e->pos++] = b;
+/* ------------------------------------------------------------------------------------------------ boolean entropy coder
+ * RFC 6386 section 7 arithmetic in the carry-deferring form (a run counter for 0xFF bytes instead of walking back over the
+ * output), so that a writer never reads what it wrote except the one byte in front of it. */
+typedef struct { uint8_t *buf; size_t pos, cap; int32_t range, value; int run, nb_bits; } boolenc;
+static void be_init(boolenc *e) { e->buf = NULL; e->pos = 0; e->cap = 0; e->range = 255 - 1; e->value = 0; e->run = 0; e->nb_bits = -8; }
+static void be_room(boolenc *e, size_t n) { if (e->pos + n > e->cap) { e->cap = (e->pos + n) * 2 + 256; e->buf = (uint8_t *)realloc(e->buf, e->cap); } }
+static void be_flush_bits(boolenc *e) {
+    const int s = 8 + e->nb_bits;
+    const int32_t bits = e->value >> s;
+    e->value -= bits << s;
+    e->nb_bits -= 8;
+    if ((bits & 0xff) != 0xff) {
+        be_room(e, (size_t)e->run + 1);
+        if ((bits & 0x100) && e->pos > 0) e->buf[e->pos - 1]++;   /* the carry; the byte in front is never 0xff */
+        if (e->run > 0) { const uint8_t v = (bits & 0x100) ? 0x00 : 0xff; for (; e->run > 0; --e->run) e->buf[e->pos++] = v; }
+        e->buf[e->pos++] = (uint8_t)(bits & 0xff);
+    } else
+        e->run++;
 }
-static void be_carry(boolenc *e) { size_t p = e->pos; while (p && e->buf[p - 1] == 255) e->buf[--p] = 0; if (p) e->buf[p - 1]++; }
 static void be_put(boolenc *e, int bit, int prob) {
-    uint32_t split = 1 + (((e->range - 1) * (uint32_t)prob) >> 8);
-    if (bit) { e->bottom += split; e->range -= split; } else e->range = split;
-    while (e->range < 128) {
-        e->range <<= 1;
-        if (e->bottom & 0x80000000u) be_carry(e);
-        e->bottom <<= 1;
-        if (!--e->bit_count) { be_byte(e, (uint8_t)(e->bottom >> 24)); e->bottom &= 0xFFFFFFu; e->bit_count = 8; }
+    const int32_t split = (e->range * prob) >> 8;
+    if (bit) { e->value += split + 1; e->range -= split + 1; } else e->range = split;
+    if (e->range < 127) {
+        const int shift = __builtin_clz((unsigned)(e->range + 1)) - 24;   /* (range + 1) << shift lands in [128, 255] */
+        e->range = ((e->range + 1) << shift) - 1;
+        e->value <<= shift;
+        e->nb_bits += shift;
+        if (e->nb_bits > 0) be_flush_bits(e);
     }
 }
 static void be_bits(boolenc *e, uint32_t v, int n) { while (n--) be_put(e, (v >> n) & 1, 128); }
 static void be_flush(boolenc *e) {
-    int c = e->bit_count;
-    uint32_t v = e->bottom;
-    if (v & (1u << (32 - c))) be_carry(e);
-    v <<= c & 7; c >>= 3;
-    while (--c >= 0) v <<= 8;
-    c = 4;
-    while (--c >= 0) { be_byte(e, (uint8_t)(v >> 24)); v <<= 8; }
+    be_bits(e, 0, 9 - e->nb_bits);
+    e->nb_bits = 0;
+    be_flush_bits(e);
 }
 
 /* ------------------------------------------------------------------------------------------------ tokens (RFC 6386 section 13) */
