@@ -48,7 +48,7 @@ EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_siz
            "cs_batch_compress", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
-           "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits"]
+           "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert"]
 
 
 def _declare(L):
@@ -80,6 +80,8 @@ def _declare(L):
     L.csh_batch_destroy.restype = None
     L.csh_batch_geometry.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
     L.csh_batch_read_coefs.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    L.csh_batch_create_webp.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(C.c_void_p)]
+    L.cs_batch_convert.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_uint32, C.c_int, P(CByteArray), P(CCSResult)]
     L.csp_kernel_name.argtypes = [C.c_int]
     L.csp_kernel_name.restype = C.c_char_p
     L.csp_batch_create.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(C.c_void_p)]
@@ -334,6 +336,21 @@ class CaesiumHip:
 
     def batch(self, blobs, params, device=0):
         return Batch(self, blobs, params, device)
+
+    def batch_convert(self, blobs, params, fmt, device=0):
+        """cs_batch_convert: -> list of bytes / CaesiumError, input order"""
+        n = len(blobs)
+        keep = [C.create_string_buffer(x, len(x)) for x in blobs]
+        ins = (CByteArray * n)()
+        for i, buf in enumerate(keep):
+            ins[i].data = C.cast(buf, C.POINTER(C.c_uint8)); ins[i].length = len(blobs[i])
+        outs = (CByteArray * n)(); res = (CCSResult * n)()
+        self.L.cs_batch_convert(ins, n, C.byref(params), fmt, device, outs, res)
+        result = []
+        for i in range(n):
+            result.append(C.string_at(outs[i].data, outs[i].length) if res[i].success else CaesiumError(res[i].code, (res[i].error_message or b"").decode()))
+            self.L.cs_free_bytes(C.byref(outs[i])); self.L.cs_free_result(C.byref(res[i]))
+        return result
 
     def png_batch(self, blobs, params, device=0):
         return PngBatch(self, blobs, params, device)

@@ -220,13 +220,45 @@ static int sniff(const uint8_t *d, size_t n) {
     return CS_TYPE_UNKN;
 }
 
+// convert: JPEG -> WebP runs on the device (same decode and resize as the JPEG path, then the VP8 encoder); every other pair
+// of formats has no device path
+int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
+    int failed_total = 0;
+    std::vector<size_t> ok;
+    for (size_t i = 0; i < count; i++) {
+        outputs[i].data = nullptr; outputs[i].length = 0;
+        const int src = sniff(inputs[i].data, inputs[i].length);
+        int code = 0; const char *msg = nullptr;
+        if (src == CS_TYPE_UNKN) { code = CS_ERR_UNKNOWN_TYPE; msg = "unknown file type"; }
+        else if (uint32_t(src) == format) { code = CS_ERR_SAME_FORMAT; msg = "cannot convert to the same format"; }
+        else if (src != CS_TYPE_JPEG || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP)"; }
+        else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
+        if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else ok.push_back(i);
+    }
+    for (size_t g0 = 0; g0 < ok.size(); g0 += 1024) {
+        const size_t n = ok.size() - g0 < 1024 ? ok.size() - g0 : 1024;
+        std::vector<CByteArray> in(n), out(n);
+        std::vector<CCSResult> res(n);
+        for (size_t k = 0; k < n; k++) in[k] = inputs[ok[g0 + k]];
+        csh_batch *b = nullptr;
+        int rc = csh_batch_create_webp(in.data(), n, p, device, &b);
+        if (rc == 0) rc = csh_batch_run(b, nullptr);
+        int failed = rc ? int(n) : csh_batch_fetch(b, out.data(), res.data());
+        for (size_t k = 0; k < n; k++) {
+            if (rc || failed < 0) { if (results) results[ok[g0 + k]] = make_result(rc ? rc : CS_ERR_NO_DEVICE, csh_last_error()); }
+            else { outputs[ok[g0 + k]] = out[k]; if (results) results[ok[g0 + k]] = res[k]; else cs_free_result(&res[k]); }
+        }
+        csh_batch_destroy(b);
+        failed_total += failed < 0 ? int(n) : failed;
+    }
+    return failed_total;
+}
 CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out) {
-    (void)p;
+    CByteArray input; input.data = const_cast<uint8_t *>(in); input.length = n;
+    CCSResult r; r.success = false; r.code = 0; r.error_message = nullptr;
     out->data = nullptr; out->length = 0;
-    int src = sniff(in, n);
-    if (src == CS_TYPE_UNKN) return make_result(CS_ERR_UNKNOWN_TYPE, "unknown file type");
-    if (uint32_t(src) == format) return make_result(CS_ERR_SAME_FORMAT, "cannot convert to the same format");
-    return make_result(CS_ERR_UNSUPPORTED, "format conversion has no device path in this build");
+    cs_batch_convert(&input, 1, p, format, 0, out, &r);
+    return r;
 }
 
 void cs_free_bytes(CByteArray *b) { if (b && b->data) { free(b->data); b->data = nullptr; b->length = 0; } }

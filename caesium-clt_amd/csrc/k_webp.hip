@@ -1,0 +1,377 @@
+// k_webp.hip -- the lossy WebP row on the device; statement: oracle/webp_oracle.c.
+//   k_webp_yuv   W1: RGB -> YUV 4:2:0 planes padded to whole macroblocks, one lane per sample
+//   k_webp_mb    W2: prediction, transforms, quantisation, reconstruction.  DC prediction needs the reconstructed
+//                neighbours, so the macroblocks of an image form a chain: ONE WAVE PER IMAGE walks them in raster order and
+//                its lanes are the blocks of the macroblock (0..15 luma, 16..19 U, 20..23 V); the 16 luma DCs meet by
+//                v_readlane for the Walsh-Hadamard transform, which every lane repeats for itself
+//   k_webp_code  W3: the boolean entropy coder is one serial chain per partition: one wave per image runs it on its uniform
+//                side (lane 0 stores), header partition first, tokens behind it, then the RIFF / frame headers
+// Parallelism is across the files of the batch, as in the reference's par_iter; what one wave does is a latency.
+#include "../../include/vp8_tables.h"
+#include "png_wave.h"
+#include "webp_kernels.h"
+
+namespace csw {
+using namespace csp;   // LFOR / LV / lsum / coherent_load (png_wave.h)
+
+__device__ __forceinline__ static int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+__global__ void __launch_bounds__(256) k_webp_yuv(const WebpImg *imgs, const uint8_t *rgb, uint8_t *work) {
+    const WebpImg &im = imgs[blockIdx.y];
+    const int w = int(im.width), h = int(im.height), ys = int(im.mbw) * 16, cs = int(im.mbw) * 8, nc = int(im.ncomp);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint8_t *src = rgb + im.rgb_off;
+    auto px = [&](int yy, int xx, int &r, int &g, int &b) {
+        const uint8_t *p = src + (size_t(yy < h ? yy : h - 1) * w + (xx < w ? xx : w - 1)) * nc;
+        r = p[0]; g = nc == 3 ? p[1] : p[0]; b = nc == 3 ? p[2] : p[0];
+    };
+    if (i < uint32_t(ys) * im.mbh * 16) {
+        const int y = int(i / uint32_t(ys)), x = int(i - uint32_t(y) * ys);
+        int r, g, b;
+        px(y, x, r, g, b);
+        work[im.y_off + i] = uint8_t((16839 * r + 33059 * g + 6420 * b + (16 << 16) + (1 << 15)) >> 16);
+    }
+    if (i < uint32_t(cs) * im.mbh * 8) {
+        const int y = int(i / uint32_t(cs)), x = int(i - uint32_t(y) * cs);
+        int r = 0, g = 0, b = 0;
+        for (int dy = 0; dy < 2; dy++)
+            for (int dx = 0; dx < 2; dx++) { int r1, g1, b1; px(2 * y + dy, 2 * x + dx, r1, g1, b1); r += r1; g += g1; b += b1; }
+        work[im.u_off + i] = uint8_t(clip8((-9719 * r - 19081 * g + 28800 * b + (128 << 18) + (1 << 17)) >> 18));
+        work[im.v_off + i] = uint8_t(clip8((28800 * r - 24116 * g - 4684 * b + (128 << 18) + (1 << 17)) >> 18));
+    }
+}
+
+// ---- transforms (oracle: fdct4 / fwht / iwht / idct4_add)
+__device__ __forceinline__ static void fdct4(const int (&d)[16], int (&out)[16]) {   // d = src - pred, row-major
+    int tmp[16];
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int a0 = d[4 * i] + d[4 * i + 3], a1 = d[4 * i + 1] + d[4 * i + 2], a2 = d[4 * i + 1] - d[4 * i + 2], a3 = d[4 * i] - d[4 * i + 3];
+        tmp[0 + i * 4] = (a0 + a1) * 8;
+        tmp[1 + i * 4] = (a2 * 2217 + a3 * 5352 + 1812) >> 9;
+        tmp[2 + i * 4] = (a0 - a1) * 8;
+        tmp[3 + i * 4] = (a3 * 2217 - a2 * 5352 + 937) >> 9;
+    }
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int a0 = tmp[0 + i] + tmp[12 + i], a1 = tmp[4 + i] + tmp[8 + i], a2 = tmp[4 + i] - tmp[8 + i], a3 = tmp[0 + i] - tmp[12 + i];
+        out[0 + i] = (a0 + a1 + 7) >> 4;
+        out[4 + i] = ((a2 * 2217 + a3 * 5352 + 12000) >> 16) + (a3 != 0);
+        out[8 + i] = (a0 - a1 + 7) >> 4;
+        out[12 + i] = (a3 * 2217 - a2 * 5352 + 51000) >> 16;
+    }
+}
+__device__ __forceinline__ static void fwht(const int (&dc)[16], int (&out)[16]) {
+    int tmp[16];
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int a0 = dc[i * 4 + 0] + dc[i * 4 + 2], a1 = dc[i * 4 + 1] + dc[i * 4 + 3], a2 = dc[i * 4 + 1] - dc[i * 4 + 3], a3 = dc[i * 4 + 0] - dc[i * 4 + 2];
+        tmp[0 + i * 4] = a0 + a1; tmp[1 + i * 4] = a3 + a2; tmp[2 + i * 4] = a3 - a2; tmp[3 + i * 4] = a0 - a1;
+    }
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int a0 = tmp[0 + i] + tmp[8 + i], a1 = tmp[4 + i] + tmp[12 + i], a2 = tmp[4 + i] - tmp[12 + i], a3 = tmp[0 + i] - tmp[8 + i];
+        out[0 + i] = (a0 + a1) >> 1; out[4 + i] = (a3 + a2) >> 1; out[8 + i] = (a3 - a2) >> 1; out[12 + i] = (a0 - a1) >> 1;
+    }
+}
+__device__ __forceinline__ static void iwht(const int (&in)[16], int (&dc)[16]) {
+    int tmp[16];
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int a0 = in[0 + i] + in[12 + i], a1 = in[4 + i] + in[8 + i], a2 = in[4 + i] - in[8 + i], a3 = in[0 + i] - in[12 + i];
+        tmp[0 + i] = a0 + a1; tmp[8 + i] = a0 - a1; tmp[4 + i] = a3 + a2; tmp[12 + i] = a3 - a2;
+    }
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int d = tmp[0 + i * 4] + 3, a0 = d + tmp[3 + i * 4], a1 = tmp[1 + i * 4] + tmp[2 + i * 4], a2 = tmp[1 + i * 4] - tmp[2 + i * 4], a3 = d - tmp[3 + i * 4];
+        dc[i * 4 + 0] = (a0 + a1) >> 3; dc[i * 4 + 1] = (a3 + a2) >> 3; dc[i * 4 + 2] = (a0 - a1) >> 3; dc[i * 4 + 3] = (a3 - a2) >> 3;
+    }
+}
+__device__ __forceinline__ static int mul1(int a) { return ((a * 20091) >> 16) + a; }
+__device__ __forceinline__ static int mul2(int a) { return (a * 35468) >> 16; }
+__device__ __forceinline__ static void idct4_add(const int (&in)[16], int pred, int (&px)[16]) {   // px: reconstructed 4x4, row-major
+    int tmp[16];
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int a = in[0 + i] + in[8 + i], b = in[0 + i] - in[8 + i];
+        const int c = mul2(in[4 + i]) - mul1(in[12 + i]), d = mul1(in[4 + i]) + mul2(in[12 + i]);
+        tmp[0 + i * 4] = a + d; tmp[1 + i * 4] = b + c; tmp[2 + i * 4] = b - c; tmp[3 + i * 4] = a - d;
+    }
+    CSH_UNROLL
+    for (int i = 0; i < 4; i++) {
+        const int dc = tmp[0 + i] + 4, a = dc + tmp[8 + i], b = dc - tmp[8 + i];
+        const int c = mul2(tmp[4 + i]) - mul1(tmp[12 + i]), d = mul1(tmp[4 + i]) + mul2(tmp[12 + i]);
+        px[i * 4 + 0] = clip8(pred + ((a + d) >> 3)); px[i * 4 + 1] = clip8(pred + ((b + c) >> 3));
+        px[i * 4 + 2] = clip8(pred + ((b - c) >> 3)); px[i * 4 + 3] = clip8(pred + ((a - d) >> 3));
+    }
+}
+__device__ __forceinline__ static int quant(int c, int q) { int a = c < 0 ? -c : c; a = (a + (q >> 1)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
+
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *imgs, uint8_t *work, int16_t *levels) {
+    const WebpImg im = imgs[blockIdx.x];
+    const int mbw = int(im.mbw), mbh = int(im.mbh), ys = mbw * 16, cs = mbw * 8, qi = im.qi;
+    const int y1ac = kVp8AcQ[qi], y2dc = kVp8DcQ[qi] * 2, uvac = kVp8AcQ[qi];
+    int y2ac = kVp8AcQ[qi] * 155 / 100; if (y2ac < 8) y2ac = 8;
+    int uvdc = kVp8DcQ[qi]; if (uvdc > 132) uvdc = 132;
+    const uint8_t *sy = work + im.y_off, *su = work + im.u_off, *sv = work + im.v_off;
+    uint8_t *ry = work + im.ry_off, *ru = work + im.ru_off, *rv = work + im.rv_off;
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            // the three DC predictions: lanes 0..31 gather the luma edge, 32..47 the U edge, 48..63 the V edge; one packed sum
+            LV<uint64_t> edge;
+            LFOR(l) {
+                uint64_t v = 0;
+                if (l < 16) { if (my) v = coherent_load(ry + size_t(my * 16 - 1) * ys + mx * 16 + l); }
+                else if (l < 32) { if (mx) v = coherent_load(ry + size_t(my * 16 + (l - 16)) * ys + mx * 16 - 1); }
+                else {
+                    const uint8_t *r = l < 48 ? ru : rv;
+                    const int k = (l - 32) & 15;
+                    if (k < 8) { if (my) v = coherent_load(r + size_t(my * 8 - 1) * cs + mx * 8 + k); }
+                    else if (mx) v = coherent_load(r + size_t(my * 8 + (k - 8)) * cs + mx * 8 - 1);
+                    v <<= l < 48 ? 16 : 32;
+                }
+                edge[l] = v;
+            }
+            const uint64_t sums = lsum(edge);
+            const int both = (mx && my) ? 1 : 0, any = (mx || my) ? 1 : 0;
+            const int sY = int(sums & 0xFFFFu), sU = int((sums >> 16) & 0xFFFFu), sV = int((sums >> 32) & 0xFFFFu);
+            const int dcY = !any ? 128 : both ? (sY + 16) >> 5 : (sY + 8) >> 4;
+            const int dcU = !any ? 128 : both ? (sU + 8) >> 4 : (sU + 4) >> 3;
+            const int dcV = !any ? 128 : both ? (sV + 8) >> 4 : (sV + 4) >> 3;
+            // every block lane: residual and forward DCT
+            LV<int> dc0;
+            int coef[16];   // this lane's block (emulation: re-derived per lane below)
+#ifdef CSH_EMUL
+            int coefs[24][16];
+#endif
+            LFOR(l) {
+                dc0[l] = 0;
+                if (l < 24) {
+                    const bool luma = l < 16;
+                    const int b = luma ? l : (l - 16) & 3;
+                    const uint8_t *s = luma ? sy + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4
+                                            : (l < 20 ? su : sv) + size_t(my * 8 + (b >> 1) * 4) * cs + mx * 8 + (b & 1) * 4;
+                    const int stride = luma ? ys : cs, pred = luma ? dcY : (l < 20 ? dcU : dcV);
+                    int d[16];
+                    CSH_UNROLL
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t w4 = *reinterpret_cast<const uint32_t *>(s + size_t(r) * stride);
+                        CSH_UNROLL
+                        for (int c = 0; c < 4; c++) d[r * 4 + c] = int((w4 >> (8 * c)) & 255u) - pred;
+                    }
+                    fdct4(d, coef);
+                    dc0[l] = coef[0];
+#ifdef CSH_EMUL
+                    for (int k = 0; k < 16; k++) coefs[l][k] = coef[k];
+#endif
+                }
+            }
+            // the 16 luma DCs to everyone; Walsh-Hadamard, quantise, and back: each luma lane takes its own DC out of the result
+            int dcs[16], y2[16], dq[16], lv2[16];
+            CSH_UNROLL
+            for (int k = 0; k < 16; k++) {
+#ifdef CSH_EMUL
+                dcs[k] = dc0.v[k];
+#else
+                dcs[k] = __builtin_amdgcn_readlane(dc0.v, k);
+#endif
+            }
+            fwht(dcs, y2);
+            CSH_UNROLL
+            for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? y2ac : y2dc; lv2[n] = quant(y2[k], q); dq[k] = lv2[n] * q; }
+            iwht(dq, dcs);
+            int16_t *L = levels + im.lev_off + (size_t(my) * mbw + mx) * 400;
+            LFOR(l) {
+                if (l == 0) { CSH_UNROLL for (int n = 0; n < 16; n++) L[n] = int16_t(lv2[n]); }
+                if (l < 24) {
+#ifdef CSH_EMUL
+                    for (int k = 0; k < 16; k++) coef[k] = coefs[l][k];
+#endif
+                    const bool luma = l < 16;
+                    const int b = luma ? l : (l - 16) & 3;
+                    int c[16], px[16], lv[16];
+                    if (luma) {
+                        int mine = 0;
+                        CSH_UNROLL
+                        for (int k = 0; k < 16; k++) mine = b == k ? dcs[k] : mine;
+                        c[0] = mine; lv[0] = 0;
+                        CSH_UNROLL
+                        for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = quant(coef[k], y1ac); c[k] = lv[n] * y1ac; }
+                    } else {
+                        CSH_UNROLL
+                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? uvac : uvdc; lv[n] = quant(coef[k], q); c[k] = lv[n] * q; }
+                    }
+                    idct4_add(c, luma ? dcY : (l < 20 ? dcU : dcV), px);
+                    uint8_t *r = luma ? ry + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4
+                                      : (l < 20 ? ru : rv) + size_t(my * 8 + (b >> 1) * 4) * cs + mx * 8 + (b & 1) * 4;
+                    const int stride = luma ? ys : cs;
+                    CSH_UNROLL
+                    for (int rr = 0; rr < 4; rr++)
+                        *reinterpret_cast<uint32_t *>(r + size_t(rr) * stride) = uint32_t(px[rr * 4]) | (uint32_t(px[rr * 4 + 1]) << 8) | (uint32_t(px[rr * 4 + 2]) << 16) | (uint32_t(px[rr * 4 + 3]) << 24);
+                    int16_t *o = L + (luma ? 1 + b : 17 + (l - 16)) * 16;
+                    CSH_UNROLL
+                    for (int n = 0; n < 16; n++) o[n] = int16_t(lv[n]);
+                }
+            }
+            CSP_MEM_FENCE();   // the next macroblock predicts from these pixels
+        }
+}
+
+// ---- W3: boolean entropy coder (oracle: boolenc) and the token walk (oracle: put_coeffs)
+#ifdef CSH_EMUL
+#define LANE0 if (true)
+#else
+#define LANE0 if ((threadIdx.x & 63u) == 0)
+#endif
+struct BoolEnc {
+    uint8_t *buf;
+    uint32_t pos, cap;
+    int32_t range, value;
+    int run, nb_bits;
+    bool overflow;
+    __device__ __forceinline__ void init(uint8_t *b, uint32_t c) { buf = b; pos = 0; cap = c; range = 254; value = 0; run = 0; nb_bits = -8; overflow = false; }
+    __device__ __forceinline__ void flush_bits() {
+        const int s = 8 + nb_bits;
+        const int32_t bits = value >> s;
+        value -= bits << s;
+        nb_bits -= 8;
+        if ((bits & 0xff) != 0xff) {
+            if (pos + uint32_t(run) + 1 > cap) { overflow = true; run = 0; return; }
+            LANE0 {
+                if ((bits & 0x100) && pos > 0) buf[pos - 1]++;
+                const uint8_t v = (bits & 0x100) ? 0x00 : 0xff;
+                for (int k = 0; k < run; k++) buf[pos + uint32_t(k)] = v;
+                buf[pos + uint32_t(run)] = uint8_t(bits & 0xff);
+            }
+            pos += uint32_t(run) + 1; run = 0;
+        } else
+            run++;
+    }
+    __device__ __forceinline__ void put(int bit, int prob) {
+        const int32_t split = (range * prob) >> 8;
+        if (bit) { value += split + 1; range -= split + 1; } else range = split;
+        if (range < 127) {
+            const int shift = __clz(uint32_t(range + 1)) - 24;
+            range = ((range + 1) << shift) - 1;
+            value <<= shift;
+            nb_bits += shift;
+            if (nb_bits > 0) flush_bits();
+        }
+    }
+    __device__ __forceinline__ void bits(uint32_t v, int n) { while (n--) put(int((v >> n) & 1u), 128); }
+    __device__ __forceinline__ void finish() { bits(0, 9 - nb_bits); nb_bits = 0; flush_bits(); }
+};
+__device__ static int put_coeffs(BoolEnc &e, int type, int ctx, const int16_t *lv, int first) {
+    int last = -1;
+    for (int i = first; i < 16; i++) if (lv[i]) last = i;
+    int n = first;
+    const uint8_t *p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
+    if (last < 0) { e.put(0, p[0]); return 0; }
+    e.put(1, p[0]);
+    while (n < 16) {
+        const int c = lv[n++];
+        const int sign = c < 0;
+        int v = sign ? -c : c;
+        if (!v) { e.put(0, p[1]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
+        e.put(1, p[1]);
+        if (v == 1) { e.put(0, p[2]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
+        else {
+            e.put(1, p[2]);
+            if (v <= 4) { e.put(0, p[3]); if (v == 2) e.put(0, p[4]); else { e.put(1, p[4]); e.put(v == 4, p[5]); } }
+            else if (v <= 10) {
+                e.put(1, p[3]); e.put(0, p[6]);
+                if (v <= 6) { e.put(0, p[7]); e.put(v == 6, 159); }
+                else { e.put(1, p[7]); e.put(v >= 9, 165); e.put(!(v & 1), 145); }
+            } else {
+                int mask; const uint8_t *tab;
+                e.put(1, p[3]); e.put(1, p[6]);
+                if (v < 3 + (8 << 1)) { e.put(0, p[8]); e.put(0, p[9]); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
+                else if (v < 3 + (8 << 2)) { e.put(0, p[8]); e.put(1, p[9]); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
+                else if (v < 3 + (8 << 3)) { e.put(1, p[8]); e.put(0, p[10]); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
+                else { e.put(1, p[8]); e.put(1, p[10]); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
+                while (mask) { e.put(!!(v & mask), *tab++); mask >>= 1; }
+            }
+            p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
+        }
+        e.put(sign, 128);
+        if (n == 16) return 1;
+        if (n > last) { e.put(0, p[0]); return 1; }
+        e.put(1, p[0]);
+    }
+    return 1;
+}
+
+enum { WEBP_MAX_MBW = 1024 };   // 16383 pixels
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, uint8_t *out, uint32_t *img_size, uint32_t *status) {
+    CSH_SHARED uint8_t top[WEBP_MAX_MBW * 9];   // per macroblock column: non-zero flags of 4 luma, 2 U, 2 V blocks and the Y2 block above
+    const WebpImg im = imgs[blockIdx.x];
+    if (status[im.image]) return;
+    const int mbw = int(im.mbw), mbh = int(im.mbh);
+    uint8_t *o = out + im.out_off;
+    if (im.out_cap < 64) { LANE0 status[im.image] = 20200; return; }
+    // partition 0: frame header fields, then the modes of every macroblock (all i16x16 DC_PRED + chroma DC_PRED)
+    BoolEnc h;
+    h.init(o + 30, im.out_cap - 32);
+    h.bits(0, 1); h.bits(0, 1); h.bits(0, 1);           // colour space, clamping, no segmentation
+    h.bits(1, 1); h.bits(0, 6); h.bits(0, 3);           // simple filter at level 0 (off), sharpness
+    h.bits(0, 1); h.bits(0, 2);                         // no filter deltas, one token partition
+    h.bits(uint32_t(im.qi), 7);
+    for (int i = 0; i < 5; i++) h.bits(0, 1);           // no quantiser deltas
+    h.bits(0, 1);                                       // refresh_entropy_probs
+    for (int i = 0; i < 4 * 8 * 3 * 11; i++) h.put(0, kVp8CoefUpdateProbs[i]);   // keep the default coefficient probabilities
+    h.bits(0, 1);                                       // no skip flags
+    for (int i = 0; i < mbw * mbh; i++) { h.put(1, 145); h.put(0, 156); h.put(0, 163); h.put(0, 142); }
+    h.finish();
+    const uint32_t p0 = h.pos;
+    // partition 1: tokens, right behind it
+    BoolEnc t;
+    t.init(o + 30 + p0, h.overflow ? 0u : im.out_cap - 32 - p0);
+    LFOR(l) for (int i = l; i < mbw * 9; i += 64) top[i] = 0;
+    CSP_WAVE_SYNC();
+    const int16_t *lev = levels + im.lev_off;
+    for (int my = 0; my < mbh && !t.overflow; my++) {
+        uint8_t left[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int mx = 0; mx < mbw; mx++) {
+            const int16_t *L = lev + (size_t(my) * mbw + mx) * 400;
+            uint8_t *tp = top + mx * 9;
+            uint8_t nz[9];
+            for (int k = 0; k < 9; k++) nz[k] = tp[k];
+            nz[8] = left[8] = uint8_t(put_coeffs(t, 1, nz[8] + left[8], L, 0));
+            for (int by = 0; by < 4; by++)
+                for (int bx = 0; bx < 4; bx++) nz[bx] = left[by] = uint8_t(put_coeffs(t, 0, nz[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1));
+            for (int pl = 0; pl < 2; pl++)
+                for (int by = 0; by < 2; by++)
+                    for (int bx = 0; bx < 2; bx++)
+                        nz[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = uint8_t(put_coeffs(t, 2, nz[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0));
+            LANE0 for (int k = 0; k < 9; k++) tp[k] = nz[k];
+            CSP_WAVE_SYNC();
+        }
+    }
+    t.finish();
+    if (h.overflow || t.overflow) { LANE0 status[im.image] = 20200; return; }
+    // RIFF / WEBP / "VP8 ": frame tag, start code, dimensions
+    const uint32_t vp8 = 10 + p0 + t.pos, padded = vp8 + (vp8 & 1u), total = 20 + padded;
+    LANE0 {
+        const uint8_t hdr[20] = {'R', 'I', 'F', 'F', uint8_t(total - 8), uint8_t((total - 8) >> 8), uint8_t((total - 8) >> 16), uint8_t((total - 8) >> 24), 'W', 'E', 'B', 'P',
+                                 'V', 'P', '8', ' ', uint8_t(vp8), uint8_t(vp8 >> 8), uint8_t(vp8 >> 16), uint8_t(vp8 >> 24)};
+        for (int k = 0; k < 20; k++) o[k] = hdr[k];
+        const uint32_t tag = (p0 << 5) | (1u << 4);   // key frame, version 0, shown
+        o[20] = uint8_t(tag); o[21] = uint8_t(tag >> 8); o[22] = uint8_t(tag >> 16);
+        o[23] = 0x9D; o[24] = 0x01; o[25] = 0x2A;
+        o[26] = uint8_t(im.width); o[27] = uint8_t(im.width >> 8); o[28] = uint8_t(im.height); o[29] = uint8_t(im.height >> 8);
+        if (vp8 & 1u) o[20 + vp8] = 0;
+        img_size[im.image] = total;
+    }
+}
+
+void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work) {
+    if (nimg && max_luma) CSH_LAUNCH(k_webp_yuv, dim3((max_luma + 255) / 256, nimg), dim3(256), st, imgs, rgb, work);
+}
+void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work, int16_t *levels) {
+    if (nimg) CSH_LAUNCH(k_webp_mb, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, work, levels);
+}
+void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, const int16_t *levels, uint8_t *out, uint32_t *img_size, uint32_t *status) {
+    if (nimg) CSH_LAUNCH(k_webp_code, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, out, img_size, status);
+}
+
+}  // namespace csw

@@ -21,6 +21,7 @@
 #include "devmem.hpp"
 #include "jpeg_host.hpp"
 #include "kernels.h"
+#include "webp_kernels.h"
 
 static thread_local char g_err[512];
 void csh_set_error(const char *fmt, ...) {
@@ -64,6 +65,11 @@ struct csh_batch {
     std::vector<Item> items;
     int nimg = 0;
     bool lossless = false;
+    bool webp = false;             // target container: the decoded (and resized) RGB goes to the VP8 encoder instead of the JPEG one
+    uint32_t webp_mb_bytes = 768;  // output bytes reserved per macroblock (grows on overflow)
+    std::vector<csw::WebpImg> wimgs;
+    uint64_t wwork_bytes = 0, wlevels = 0;
+    uint32_t wmax_luma = 0;
     bool progressive = true;
     bool retain_dct = false;       // size targeting: keep the unquantised DCT so that another quality only re-quantises
     bool have_dct = false;
@@ -126,6 +132,9 @@ struct csh_batch {
     DevBuf<ScanWork> d_swork;
     DevBuf<uint32_t> d_chunk_work;
     DevBuf<int16_t> d_coef, d_dct_raw;
+    DevBuf<csw::WebpImg> d_wimgs;
+    DevBuf<uint8_t> d_wwork;
+    DevBuf<int16_t> d_wlevels;
     DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
     DevBuf<uint16_t> d_eobrun;
     DevBuf<uint32_t> d_long_runs, d_long_cnt, d_unit_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
@@ -340,7 +349,11 @@ extern "C" int csh_device_count(void) {
     return n;
 }
 
-extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) {
+static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out);
+extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, false, out); }
+// JPEG in, WebP out (caesium::convert_in_memory to SupportedFileTypes::WebP, compressor.rs:289,300): same decode and resize, then the VP8 encoder
+extern "C" int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, true, out); }
+static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out) {
     *out = nullptr;
     if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
@@ -348,7 +361,8 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
     std::unique_ptr<csh_batch> b(new csh_batch);
     b->device = device;
     b->params = *p;
-    b->lossless = p->jpeg_optimize;
+    b->lossless = p->jpeg_optimize && !webp;
+    b->webp = webp;
     const bool progressive = p->jpeg_progressive;
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
@@ -427,7 +441,7 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             b->max_dummy = std::max(b->max_dummy, nd);
         }
         im.omcus_x = o.mcus_x; im.omcus_y = o.mcus_y;
-        const bool resized = (p->width || p->height) && !b->lossless;
+        const bool resized = ((p->width || p->height) && !b->lossless) || b->webp;   // the WebP encoder takes the RGB the resize branch produces (a plain copy at equal size)
         im.enc_w = o.width; im.enc_h = o.height;
         for (int c = 0; c < in.ncomp; c++) im.src[c] = im.in[c];
         int img_index = int(b->imgs.size());
@@ -661,6 +675,18 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
             b->max_tmp = std::max(b->max_tmp, tmpn);
             b->max_dst = std::max(b->max_dst, dst_bytes);
             b->rwork.push_back(rw);
+            if (b->webp) {
+                csw::WebpImg wi;
+                memset(&wi, 0, sizeof wi);
+                wi.width = uint32_t(o.width); wi.height = uint32_t(o.height); wi.mbw = (wi.width + 15) / 16; wi.mbh = (wi.height + 15) / 16; wi.ncomp = uint32_t(in.ncomp);
+                wi.rgb_off = rw.rgb_dst_off; wi.image = uint32_t(img_index);
+                const uint64_t ly = uint64_t(wi.mbw) * wi.mbh * 256, lc = uint64_t(wi.mbw) * wi.mbh * 64;
+                auto take = [&](uint64_t n) { uint64_t at = b->wwork_bytes; b->wwork_bytes += (n + 63) & ~uint64_t(63); return at; };
+                wi.y_off = take(ly); wi.u_off = take(lc); wi.v_off = take(lc); wi.ry_off = take(ly); wi.ru_off = take(lc); wi.rv_off = take(lc);
+                wi.lev_off = b->wlevels; b->wlevels += uint64_t(wi.mbw) * wi.mbh * 400;
+                b->wmax_luma = std::max<uint32_t>(b->wmax_luma, uint32_t(ly));
+                b->wimgs.push_back(wi);
+            }
         }
 
         // output scans
@@ -769,6 +795,47 @@ static const char *const kKernelNames[CSH_NKERNELS] = {
 static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 
+// the WebP tail of a run: RGB (resize branch) -> YUV 4:2:0 -> macroblocks -> tokens; files land in the batch's output pool at
+// fixed offsets (capacity per macroblock grows on overflow, like the JPEG pools)
+static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
+    hipStream_t st = b->stream;
+    const int nimg = int(b->wimgs.size());
+    uint64_t out_bytes = 0;
+    std::vector<uint64_t> off(size_t(b->nimg) + 1, 0);
+    for (auto &wi : b->wimgs) {
+        const uint64_t cap = 256 + uint64_t(wi.mbw) * wi.mbh * (b->webp_mb_bytes + 2);
+        wi.out_cap = uint32_t(std::min<uint64_t>(cap, 0xFFFFFF00u)); wi.out_off = out_bytes;
+        off[wi.image] = out_bytes;
+        out_bytes += (wi.out_cap + 63) & ~uint64_t(63);
+        const int q = int(b->params.webp_quality);
+        // libwebp's quality -> quantiser curve without its segment / SNS adjustments (oracle: cso_webp_quality_to_qi)
+        double c = (q < 0 ? 0 : q > 100 ? 100 : q) / 100.0, lin = c < 0.75 ? c * (2.0 / 3.0) : 2.0 * c - 1.0, v = 0.0;
+        if (lin > 0) { v = lin; for (int i = 0; i < 60; i++) v = v - (v * v * v - lin) / (3 * v * v); }
+        int qi = int(127.0 * (1.0 - v) + 0.5);
+        wi.qi = qi < 0 ? 0 : qi > 127 ? 127 : qi;
+    }
+    off[b->nimg] = out_bytes;
+    if (b->d_out.n < out_bytes + 64 && b->d_out.alloc(out_bytes + 64)) return -1;
+    if (b->d_wimgs.upload(b->wimgs, st) || (b->d_wwork.n < b->wwork_bytes + 64 && b->d_wwork.alloc(b->wwork_bytes + 64)) ||
+        (b->d_wlevels.n < b->wlevels + 64 && b->d_wlevels.alloc(b->wlevels + 64)))
+        return -1;
+    CSH_CHECK(hipMemcpyAsync(b->d_img_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    if (b->d_img_size.zero(st)) return -1;
+    csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
+    csw::launch_webp_mb(st, b->d_wimgs.p, nimg, b->d_wwork.p, b->d_wlevels.p);
+    csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->d_wlevels.p, b->d_out.p, b->d_img_size.p, b->d_status.p);
+    CSH_CHECK(hipEventRecord(ev[++slot], st));
+    CSH_CHECK(hipStreamSynchronize(st));
+    CSH_CHECK(hipGetLastError());
+    if (t) {
+        for (int i = 0; i < slot; i++) CSH_CHECK(hipEventElapsedTime(&t->kernel_ms[i], ev[i], ev[i + 1]));
+        CSH_CHECK(hipEventElapsedTime(&t->total_ms, ev[0], ev[slot]));
+        t->n_images = uint32_t(b->nimg);
+    }
+    for (int i = 0; i <= CSH_NKERNELS; i++) (void)hipEventDestroy(ev[i]);
+    return 0;
+}
+
 static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     hipStream_t st = b->stream;
     const int nimg = b->nimg;
@@ -860,6 +927,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     MARK();
     launch_resize(st, b->d_imgs.p, b->d_rwork.p, int(b->rwork.size()), b->d_rtaps.p, b->d_rweights.p, b->d_planes.p, b->d_rgb.p, b->d_rtmp.p,
                   b->max_src_px, b->max_tmp, b->max_dst);
+    if (b->webp) return run_webp(b, t, ev, slot);
     int16_t *rawp = (b->retain_dct && !b->lossless) ? b->d_dct_raw.p : nullptr;
     launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p, rawp, b->ntiles_in);
     MARK();
@@ -995,6 +1063,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
         if (!pool) break;
         if (attempt == 3) { csh_set_error("device pools overflowed after 3 retries"); return CS_ERR_POOL_OVERFLOW; }
         b->raw_bytes_cap *= 4; b->out_cap = b->raw_bytes_cap;  // rare: output larger than 2x the input
+        b->webp_mb_bytes *= 4;
     }
     b->h_img_size.resize(b->nimg);
     b->h_img_off.resize(b->nimg + 1);

@@ -1,0 +1,24 @@
+// webp_kernels.h -- the lossy WebP row on the device: descriptors and launchers (k_webp.hip).
+// Statement: oracle/webp_oracle.c (a minimal conformant VP8 key-frame encoder; see its header for what is and is not pinned).
+#pragma once
+#include "gpu_rt.h"
+
+namespace csw {
+
+struct WebpImg {
+    uint32_t width, height, mbw, mbh, ncomp;   // ncomp: 3 = interleaved RGB input, 1 = grey
+    int32_t qi;                                // quantiser index 0..127
+    uint64_t rgb_off;                          // input pixels in the RGB pool
+    uint64_t y_off, u_off, v_off;              // source planes, padded to whole macroblocks (work pool)
+    uint64_t ry_off, ru_off, rv_off;           // the encoder's reconstruction (what a decoder will see)
+    uint64_t lev_off;                          // quantised levels: per macroblock 25 blocks x 16 int16, scan order (int16 index)
+    uint64_t out_off;                          // output file region
+    uint32_t out_cap;
+    uint32_t image;                            // index of the image in the batch's status / size arrays
+};
+
+void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work);
+void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work, int16_t *levels);
+void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, const int16_t *levels, uint8_t *out, uint32_t *img_size, uint32_t *status);
+
+}  // namespace csw

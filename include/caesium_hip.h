@@ -84,8 +84,11 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
    are overwritten while bisecting, as the reference's &mut CSParameters is) */
 CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size,
                                         bool return_smallest, CByteArray *out);
-/* replaces caesium::convert_in_memory (compressor.rs:289,300) */
+/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP (lossy); every other pair answers
+   CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
 CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out);
+/* the batch form of it: results[i] / outputs[i] correspond to inputs[i] */
+int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results);
 
 /* start_compression's par_iter (compressor.rs:74-101) turned into a device batch queue:
    results[i] / outputs[i] correspond to inputs[i] (order preserved, as compressor.rs:789-792 asserts).
@@ -129,6 +132,9 @@ int csh_device_count(void);
 const char *csh_last_error(void);
 const char *csh_kernel_name(int slot);
 int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
+/* the same batch with WebP as the target container (convert_in_memory to WebP, compressor.rs:289,300): decode, optional
+   resize, then the VP8 encoder; run / fetch / destroy as for any csh_batch */
+int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
 int csh_batch_run(csh_batch *b, csh_timing *t);
 int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results);
 void csh_batch_destroy(csh_batch *b);

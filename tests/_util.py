@@ -104,3 +104,31 @@ def png_cases(small=True):
 def oracle_png(src, level=3, keep_metadata=False):
     from oracle import oracle as O
     return O.png_optimize(src, level, keep_metadata)[0]
+
+
+# ---------------------------------------------------------------- lossy WebP row (JPEG in, WebP out)
+def oracle_jpeg_to_webp(src, quality=80, width=0, height=0):
+    """the oracle's statement of convert_in_memory(JPEG -> WebP): libjpeg decode to RGB (oracle), image-rs Lanczos3 when a size
+    is given (oracle), then the minimal VP8 encoder (oracle/webp_oracle.c)"""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+    img = O.decode(src)
+    pix = img.pixels()
+    h, w, nc = pix.shape
+    rgb = np.empty_like(pix)
+    if nc == 3:
+        O.lib().cso_ycc_to_rgb(pix.ctypes.data, w * h, rgb.ctypes.data)
+    else:
+        rgb = pix
+    if width or height:
+        nw, nh = C.c_int(), C.c_int()
+        O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
+        out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
+        O.lib().cso_lanczos3_resize(np.ascontiguousarray(rgb).ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+        rgb = out
+    if nc == 1:
+        rgb = np.repeat(rgb, 3, axis=2)
+    return O.webp_encode_rgb(rgb, quality)

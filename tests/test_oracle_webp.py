@@ -1,0 +1,67 @@
+"""Pins the CPU oracle of the lossy WebP row (oracle/webp_oracle.c) to what exists here: libwebp's DECODER.  Every stream
+must decode, and the encoder's own reconstruction must equal what libwebp decodes (so the prediction chain of the encoder and
+of any decoder stay in step).  Byte parity with libwebp's ENCODER is neither possible nor claimed: see the oracle's header."""
+import ctypes as C
+import ctypes.util
+import io
+
+import numpy as np
+import pytest
+
+from gen_synth import synth_rgb
+from oracle import oracle as O
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def crop(seed, w, h, texture=4.0):
+    return np.ascontiguousarray(synth_rgb(seed, w + 400, h + 300, texture=texture)[150:150 + h, 200:200 + w])
+
+
+def libwebp_decode_yuv(data):
+    name = ctypes.util.find_library("webp")
+    if not name:
+        pytest.skip("no system libwebp for the YUV-level comparison")
+    W = C.CDLL(name)
+    W.WebPDecodeYUV.restype = C.POINTER(C.c_uint8)
+    w, h, s, us = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    u, v = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)()
+    y = W.WebPDecodeYUV(data, len(data), C.byref(w), C.byref(h), C.byref(u), C.byref(v), C.byref(s), C.byref(us))
+    assert y, "libwebp refuses the stream"
+    cw, ch = (w.value + 1) // 2, (h.value + 1) // 2
+    Y = np.ctypeslib.as_array(y, shape=(h.value, s.value))[:, :w.value].copy()
+    U = np.ctypeslib.as_array(u, shape=(ch, us.value))[:, :cw].copy()
+    V = np.ctypeslib.as_array(v, shape=(ch, us.value))[:, :cw].copy()
+    return Y, U, V
+
+
+CASES = [(64, 48, 85), (100, 75, 85), (161, 97, 50), (320, 240, 95), (17, 9, 75), (300, 200, 10), (1, 1, 50), (16, 16, 100), (33, 250, 0)]
+
+
+@pytest.mark.parametrize("w,h,q", CASES)
+def test_reconstruction_equals_libwebp_decoder(w, h, q):
+    rgb = crop(3, w, h)
+    y, u, v = O.webp_rgb_to_yuv(rgb)
+    data, (ry, ru, rv) = O.webp_encode_yuv(y, u, v, w, h, O.webp_quality_to_qi(q))
+    assert data[:4] == b"RIFF" and data[8:16] == b"WEBPVP8 " and int.from_bytes(data[4:8], "little") == len(data) - 8
+    Y, U, V = libwebp_decode_yuv(data)
+    assert np.array_equal(Y, ry[:h, :w]) and np.array_equal(U, ru[:(h + 1) // 2, :(w + 1) // 2]) and np.array_equal(V, rv[:(h + 1) // 2, :(w + 1) // 2])
+
+
+def test_quality_against_libwebp_at_the_same_setting():
+    rgb = crop(5, 320, 240, texture=6.0)
+    for q in (50, 85):
+        ours = O.webp_encode_rgb(rgb, q)
+        b = io.BytesIO()
+        PIL.fromarray(rgb).save(b, "WEBP", quality=q)
+
+        def psnr(data):
+            a = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(np.float64)
+            return 10 * np.log10(255.0 ** 2 / ((a - rgb) ** 2).mean())
+        # no mode search: about the same fidelity as libwebp at this quality, more bytes
+        assert psnr(ours) > psnr(b.getvalue()) - 1.0
+        assert len(ours) < 4 * len(b.getvalue())
+
+
+def test_quality_curve():
+    assert [O.webp_quality_to_qi(q) for q in (0, 50, 75, 85, 100)] == [127, 39, 26, 14, 0]

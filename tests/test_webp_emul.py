@@ -1,0 +1,71 @@
+"""JPEG in, WebP out (convert_in_memory to WebP): the kernel sources compiled for the CPU against the oracle; the same cases
+run on the device in test_webp_gpu.py."""
+import io
+
+import numpy as np
+import pytest
+
+from _util import emul_api, oracle_jpeg_to_webp, package, png_cases
+from gen_synth import synth_jpeg
+
+PIL = pytest.importorskip("PIL.Image")
+WEBP, JPEG, PNG = 3, 0, 1
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def webp_cases(big=False):
+    cases = [("420_160x96", synth_jpeg(1, 160, 96, texture=10)), ("444_97x61", synth_jpeg(2, 97, 61, subsampling=0, texture=5)), ("flat_64x48", synth_jpeg(3, 64, 48)),
+             ("422_50x34", synth_jpeg(4, 50, 34, subsampling=1, texture=8)), ("prog_104x72", synth_jpeg(5, 104, 72, progressive=True, texture=6)), ("tiny_9x5", synth_jpeg(6, 9, 5, texture=3))]
+    import io as _io
+    g = PIL.open(_io.BytesIO(synth_jpeg(7, 80, 60, texture=6))).convert("L")
+    b = _io.BytesIO(); g.save(b, "JPEG", quality=90)
+    cases.append(("grey_80x60", b.getvalue()))
+    if big:
+        cases.append(("420_1920x1080", synth_jpeg(8, 1920, 1080)))
+    return cases
+
+
+def check(api, cases, quality, width=0, height=0):
+    pkg = package()
+    p = pkg.default_parameters(webp_quality=quality, jpeg_quality=quality, width=width, height=height)
+    outs = api.batch_convert([c[1] for c in cases], p, WEBP)
+    for (name, src), out in zip(cases, outs):
+        assert not isinstance(out, Exception), (name, out)
+        assert out == oracle_jpeg_to_webp(src, quality, width, height), name
+        im = PIL.open(io.BytesIO(out))
+        im.load()
+        assert im.format == "WEBP"
+
+
+def test_convert_equals_oracle(api):
+    check(api, webp_cases(), 85)
+    check(api, webp_cases()[:3], 30)
+
+
+def test_convert_with_resize(api):
+    check(api, webp_cases()[:2], 85, width=60)
+    check(api, webp_cases()[1:3], 75, height=40)
+
+
+def test_entry_point_and_refusals(api):
+    pkg = package()
+    src = webp_cases()[0][1]
+    p = pkg.default_parameters(webp_quality=85)
+    assert api.convert_in_memory(src, p, WEBP) == oracle_jpeg_to_webp(src, 85)
+    png = png_cases()[0][1]
+    outs = api.batch_convert([src, png, b"junk", src], p, WEBP)
+    assert outs[0] == oracle_jpeg_to_webp(src, 85) and outs[3] == outs[0]
+    assert [getattr(o, "code", 0) for o in outs] == [0, 10201, 10200, 0]
+    with pytest.raises(Exception) as e:
+        api.convert_in_memory(src, p, JPEG)
+    assert e.value.code == 10407
+    with pytest.raises(Exception) as e:
+        api.convert_in_memory(src, p, PNG)
+    assert e.value.code == 10201
+    with pytest.raises(Exception) as e:
+        api.convert_in_memory(src, pkg.default_parameters(webp_quality=85, webp_lossless=True), WEBP)
+    assert e.value.code == 10201
