@@ -115,7 +115,7 @@ def default_parameters(lib=None, **kw):
 class Batch:
     """csh_batch: a group of input files resident in HBM."""
 
-    def __init__(self, api, blobs, params, device=0):
+    def __init__(self, api, blobs, params, device=0, webp=False):
         self.api = api
         L = api.L
         self.n = len(blobs)
@@ -125,7 +125,7 @@ class Batch:
             self._in[i].data = C.cast(buf, C.POINTER(C.c_uint8))
             self._in[i].length = len(blobs[i])
         self.h = C.c_void_p()
-        rc = L.csh_batch_create(self._in, self.n, C.byref(params), device, C.byref(self.h))
+        rc = (L.csh_batch_create_webp if webp else L.csh_batch_create)(self._in, self.n, C.byref(params), device, C.byref(self.h))
         if rc:
             raise CaesiumError(rc, L.csh_last_error().decode())
 
@@ -336,6 +336,10 @@ class CaesiumHip:
 
     def batch(self, blobs, params, device=0):
         return Batch(self, blobs, params, device)
+
+    def webp_batch(self, blobs, params, device=0):
+        """JPEG in, WebP out: the same batch object with the VP8 encoder as its tail"""
+        return Batch(self, blobs, params, device, webp=True)
 
     def batch_convert(self, blobs, params, fmt, device=0):
         """cs_batch_convert: -> list of bytes / CaesiumError, input order"""

@@ -569,8 +569,10 @@ int run(const Options &o) {
                 std::vector<char> silent(idx.size(), 0);
                 for (size_t k = 0; k < idx.size(); k++) { in[k].data = jobs[idx[k]].data.data(); in[k].length = jobs[idx[k]].data.size(); }
                 CCSParameters p = jobs[idx[0]].params;
-                if (o.format != Format::Original) {
-                    // convert (+ optional size targeting): one engine call per file, as the reference does
+                if (o.format != Format::Original && !o.max_size) {
+                    cs_batch_convert(in.data(), in.size(), &p, map_format(o.format), int(dev), out.data(), res.data());   // the whole group in one device batch
+                } else if (o.format != Format::Original) {
+                    // convert + size targeting: one engine call per file, as the reference does
                     for (size_t k = 0; k < idx.size(); k++) {
                         res[k] = cs_convert_in_memory(in[k].data, in[k].length, &p, map_format(o.format), &out[k]);
                         if (o.max_size && res[k].success) {

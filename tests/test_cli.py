@@ -306,6 +306,12 @@ def end_to_end(binary, tree, tmp_path):
     assert j["files"][0]["status"] == "error" and j["files"][0]["message"].startswith("Error compressing file: ") and j["files"][0]["output_path"].endswith("j1.png")
 
 
+    # 9b. JPEG -> WebP is built (configs[3] shape: convert + long edge): bytes equal the oracle's
+    from _util import oracle_jpeg_to_webp
+    j = json.loads(run_cli(binary, "-q", 85, "-o", tmp_path / "wp", "--json", "--format", "webp", "--long-edge", 90, root / "level_1_0" / "j1.jpg", root / "j0.JPG").stdout)
+    assert [f["status"] for f in j["files"]] == ["success"] * 2 and j["files"][0]["output_path"].endswith("j1.webp")
+    assert open(j["files"][0]["output_path"], "rb").read() == oracle_jpeg_to_webp(files["level_1_0/j1.jpg"], 85, 0, 90)
+    assert open(j["files"][1]["output_path"], "rb").read() == oracle_jpeg_to_webp(files["j0.JPG"], 85, 90, 0)
     # 10. PNG: --lossless runs the device PNG pipeline (mixed with JPEG in one run, order kept); -q on a PNG (lossy PNG) has no
     # device path and fails per file
     from _util import oracle_png
