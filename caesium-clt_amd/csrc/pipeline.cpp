@@ -384,7 +384,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
 
     std::vector<std::pair<std::vector<uint8_t>, int>> hset_keys;
     std::map<std::vector<uint16_t>, int> quant_index;
-    uint32_t plane_off = 0, oplane_off = 0;
+    uint64_t plane_off = 0, oplane_off = 0;   // 64-bit: a resize batch of 1024 1080p files has 7 GB of planes
 
     {   // marker parsing is per file and touches every byte of it once (the hunt for the end of each scan): all cores
         std::atomic<size_t> next{0};
@@ -639,20 +639,20 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 if (resized) w.mode = 1 + out_kind;   // encoder side is fed full-resolution planes of the resized image (k_resize.hip)
                 if (w.mode) {
                     im.plane_off[c] = plane_off;
-                    plane_off += uint32_t(im.in[c].real_bw * 8 * im.in[c].real_bh * 8);
-                    plane_off = (plane_off + 63u) & ~63u;
+                    plane_off += uint64_t(im.in[c].real_bw * 8) * uint64_t(im.in[c].real_bh * 8);
+                    plane_off = (plane_off + 63u) & ~uint64_t(63);
                     im.splane_off[c] = im.plane_off[c];
                     if (resized) {   // full-resolution plane of the resized image, pitch = luma's padded width
                         JComp full; full.h = full.v = 1;
                         JpegInfo tmpj; tmpj.width = o.width; tmpj.height = o.height; tmpj.ncomp = 1; tmpj.comp[0] = full; jpeg_geometry(tmpj);
                         uint32_t dummy = 0; fill_geom(tmpj.comp[0], im.src[c], dummy);
                         im.splane_off[c] = plane_off;
-                        plane_off += uint32_t(im.src[c].real_bw * 8 * im.src[c].real_bh * 8);
-                        plane_off = (plane_off + 63u) & ~63u;
+                        plane_off += uint64_t(im.src[c].real_bw * 8) * uint64_t(im.src[c].real_bh * 8);
+                        plane_off = (plane_off + 63u) & ~uint64_t(63);
                     }
                     im.oplane_off[c] = oplane_off;
                     uint32_t osz = uint32_t(im.out[c].real_bw * 8 * im.out[c].real_bh * 8);
-                    oplane_off = (oplane_off + osz + 63u) & ~63u;
+                    oplane_off = (oplane_off + osz + 63u) & ~uint64_t(63);
                     b->max_quads = std::max(b->max_quads, osz / 4);
                 }
                 b->pwork.push_back(w);

@@ -98,12 +98,12 @@ struct ImgDesc {
     CompGeom out[CSH_MAX_COMPS];  // re-encoded geometry (== in for the lossless transcode)
     int qt_in[CSH_MAX_COMPS];     // index into the quant pool (zig-zag u16[64] + divisors)
     int qt_out[CSH_MAX_COMPS];
-    uint32_t plane_off[CSH_MAX_COMPS];  // byte offset of the decoded u8 plane (components that are resampled)
-    uint32_t oplane_off[CSH_MAX_COMPS]; // byte offset of the resampled u8 plane (encoder-side geometry)
+    uint64_t plane_off[CSH_MAX_COMPS];  // byte offset of the decoded u8 plane (components that are resampled)
+    uint64_t oplane_off[CSH_MAX_COMPS]; // byte offset of the resampled u8 plane (encoder-side geometry)
     // planes that FEED the encoder-side resample: the decoded planes (src == in, enc == image size), or -- resize path --
     // full-resolution planes of the resized image (k_resize.hip)
     CompGeom src[CSH_MAX_COMPS];
-    uint32_t splane_off[CSH_MAX_COMPS];
+    uint64_t splane_off[CSH_MAX_COMPS];
     int enc_w, enc_h;
     int first_scan, nscans_in;    // range in the DecScan array
     int comp_id[CSH_MAX_COMPS];   // component identifiers written to SOF/SOS
