@@ -89,7 +89,7 @@ __device__ __forceinline__ static void iwht(const int (&in)[16], int (&dc)[16]) 
 }
 __device__ __forceinline__ static int mul1(int a) { return ((a * 20091) >> 16) + a; }
 __device__ __forceinline__ static int mul2(int a) { return (a * 35468) >> 16; }
-__device__ __forceinline__ static void idct4_add(const int (&in)[16], int pred, int (&px)[16]) {   // px: reconstructed 4x4, row-major
+__device__ __forceinline__ static void idct4_add(const int (&in)[16], const int (&pred)[16], int (&px)[16]) {   // px: reconstructed 4x4, row-major
     int tmp[16];
     CSH_UNROLL
     for (int i = 0; i < 4; i++) {
@@ -101,8 +101,8 @@ __device__ __forceinline__ static void idct4_add(const int (&in)[16], int pred, 
     for (int i = 0; i < 4; i++) {
         const int dc = tmp[0 + i] + 4, a = dc + tmp[8 + i], b = dc - tmp[8 + i];
         const int c = mul2(tmp[4 + i]) - mul1(tmp[12 + i]), d = mul1(tmp[4 + i]) + mul2(tmp[12 + i]);
-        px[i * 4 + 0] = clip8(pred + ((a + d) >> 3)); px[i * 4 + 1] = clip8(pred + ((b + c) >> 3));
-        px[i * 4 + 2] = clip8(pred + ((b - c) >> 3)); px[i * 4 + 3] = clip8(pred + ((a - d) >> 3));
+        px[i * 4 + 0] = clip8(pred[i * 4 + 0] + ((a + d) >> 3)); px[i * 4 + 1] = clip8(pred[i * 4 + 1] + ((b + c) >> 3));
+        px[i * 4 + 2] = clip8(pred[i * 4 + 2] + ((b - c) >> 3)); px[i * 4 + 3] = clip8(pred[i * 4 + 3] + ((a - d) >> 3));
     }
 }
 __device__ __forceinline__ static int quant(int c, int q) { int a = c < 0 ? -c : c; a = (a + (q >> 1)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
@@ -138,31 +138,97 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
             const int dcY = !any ? 128 : both ? (sY + 16) >> 5 : (sY + 8) >> 4;
             const int dcU = !any ? 128 : both ? (sU + 8) >> 4 : (sU + 4) >> 3;
             const int dcV = !any ? 128 : both ? (sV + 8) >> 4 : (sV + 4) >> 3;
-            // every block lane: residual and forward DCT
+            // every block lane: its 4x4 source samples and, when both neighbours exist, the macroblock edge it predicts from
             LV<int> dc0;
-            int coef[16];   // this lane's block (emulation: re-derived per lane below)
+            int coef[16];   // this lane's block (emulation: kept per lane in coefs[])
+            int pred[16];   // its prediction (emulation: preds[])
 #ifdef CSH_EMUL
-            int coefs[24][16];
+            int coefs[24][16], preds[24][16], srcs[24][16], tops[24][4], lefts[24][4], corners[24];
 #endif
+            int src16[16], top4[4], left4[4], corner = 0;
+            const int nmodes = (mx && my) ? 4 : 1;
+            LFOR(l) if (l < 24) {
+                const bool luma = l < 16;
+                const int b = luma ? l : (l - 16) & 3, bx = luma ? b & 3 : b & 1, by = luma ? b >> 2 : b >> 1;
+                const int stride = luma ? ys : cs, n0 = luma ? 16 : 8;
+                const uint8_t *s = (luma ? sy : (l < 20 ? su : sv)) + size_t(my * n0 + by * 4) * stride + mx * n0 + bx * 4;
+                const uint8_t *r = (luma ? ry : (l < 20 ? ru : rv)) + size_t(my * n0) * stride + mx * n0;   // the macroblock's corner in the reconstruction
+                CSH_UNROLL
+                for (int rr = 0; rr < 4; rr++) {
+                    const uint32_t w4 = *reinterpret_cast<const uint32_t *>(s + size_t(rr) * stride);
+                    CSH_UNROLL
+                    for (int c = 0; c < 4; c++) src16[rr * 4 + c] = int((w4 >> (8 * c)) & 255u);
+                }
+                CSH_UNROLL
+                for (int k = 0; k < 4; k++) { top4[k] = 0; left4[k] = 0; }
+                corner = 0;
+                if (nmodes == 4) {
+                    const uint32_t t4 = coherent_load(reinterpret_cast<const uint32_t *>(r - stride + bx * 4));
+                    CSH_UNROLL
+                    for (int k = 0; k < 4; k++) { top4[k] = int((t4 >> (8 * k)) & 255u); left4[k] = coherent_load(r + size_t(by * 4 + k) * stride - 1); }
+                    corner = coherent_load(r - stride - 1);
+                }
+#ifdef CSH_EMUL
+                for (int k = 0; k < 16; k++) srcs[l][k] = src16[k];
+                for (int k = 0; k < 4; k++) { tops[l][k] = top4[k]; lefts[l][k] = left4[k]; }
+                corners[l] = corner;
+#endif
+            }
+            // the mode of the luma block and the shared mode of the two chroma blocks: least sum of |DCT coefficients| of the residual
+            int ymode = 0, cmode = 0;
+            if (nmodes == 4) {
+                uint64_t best_y = ~0ull, best_c = ~0ull;
+                for (int m = 0; m < 4; m++) {
+                    LV<uint64_t> cost;
+                    LFOR(l) {
+                        cost[l] = 0;
+                        if (l < 24) {
+#ifdef CSH_EMUL
+                            for (int k = 0; k < 16; k++) src16[k] = srcs[l][k];
+                            for (int k = 0; k < 4; k++) { top4[k] = tops[l][k]; left4[k] = lefts[l][k]; }
+                            corner = corners[l];
+#endif
+                            const int flat = l < 16 ? dcY : (l < 20 ? dcU : dcV);
+                            int d[16], c[16];
+                            CSH_UNROLL
+                            for (int k = 0; k < 16; k++) {
+                                const int x = k & 3, y = k >> 2;
+                                const int pv = m == 0 ? flat : m == 1 ? top4[x] : m == 2 ? left4[y] : clip8(top4[x] + left4[y] - corner);
+                                d[k] = src16[k] - pv;
+                            }
+                            fdct4(d, c);
+                            uint64_t sum = 0;
+                            CSH_UNROLL
+                            for (int k = 0; k < 16; k++) sum += uint64_t(c[k] < 0 ? -c[k] : c[k]);
+                            cost[l] = l < 16 ? sum : sum << 32;
+                        }
+                    }
+                    const uint64_t tot = lsum(cost), cy = tot & 0xFFFFFFFFull, cc = tot >> 32;
+                    if (cy < best_y) { best_y = cy; ymode = m; }
+                    if (cc < best_c) { best_c = cc; cmode = m; }
+                }
+            }
+            // residual against the chosen prediction, forward DCT
             LFOR(l) {
                 dc0[l] = 0;
                 if (l < 24) {
-                    const bool luma = l < 16;
-                    const int b = luma ? l : (l - 16) & 3;
-                    const uint8_t *s = luma ? sy + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4
-                                            : (l < 20 ? su : sv) + size_t(my * 8 + (b >> 1) * 4) * cs + mx * 8 + (b & 1) * 4;
-                    const int stride = luma ? ys : cs, pred = luma ? dcY : (l < 20 ? dcU : dcV);
+#ifdef CSH_EMUL
+                    for (int k = 0; k < 16; k++) src16[k] = srcs[l][k];
+                    for (int k = 0; k < 4; k++) { top4[k] = tops[l][k]; left4[k] = lefts[l][k]; }
+                    corner = corners[l];
+#endif
+                    const int m = l < 16 ? ymode : cmode, flat = l < 16 ? dcY : (l < 20 ? dcU : dcV);
                     int d[16];
                     CSH_UNROLL
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t w4 = *reinterpret_cast<const uint32_t *>(s + size_t(r) * stride);
-                        CSH_UNROLL
-                        for (int c = 0; c < 4; c++) d[r * 4 + c] = int((w4 >> (8 * c)) & 255u) - pred;
+                    for (int k = 0; k < 16; k++) {
+                        const int x = k & 3, y = k >> 2;
+                        pred[k] = m == 0 ? flat : m == 1 ? top4[x] : m == 2 ? left4[y] : clip8(top4[x] + left4[y] - corner);
+                        d[k] = src16[k] - pred[k];
                     }
                     fdct4(d, coef);
                     dc0[l] = coef[0];
 #ifdef CSH_EMUL
-                    for (int k = 0; k < 16; k++) coefs[l][k] = coef[k];
+                    for (int k = 0; k < 16; k++) { coefs[l][k] = coef[k]; preds[l][k] = pred[k]; }
 #endif
                 }
             }
@@ -185,7 +251,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
                 if (l == 0) { CSH_UNROLL for (int n = 0; n < 16; n++) L[n] = int16_t(lv2[n]); }
                 if (l < 24) {
 #ifdef CSH_EMUL
-                    for (int k = 0; k < 16; k++) coef[k] = coefs[l][k];
+                    for (int k = 0; k < 16; k++) { coef[k] = coefs[l][k]; pred[k] = preds[l][k]; }
 #endif
                     const bool luma = l < 16;
                     const int b = luma ? l : (l - 16) & 3;
@@ -194,14 +260,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
                         int mine = 0;
                         CSH_UNROLL
                         for (int k = 0; k < 16; k++) mine = b == k ? dcs[k] : mine;
-                        c[0] = mine; lv[0] = 0;
+                        c[0] = mine; lv[0] = b == 0 ? ymode : b == 1 ? cmode : 0;   // the unused DC slots of luma blocks 0 and 1 carry the modes to k_webp_code
                         CSH_UNROLL
                         for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = quant(coef[k], y1ac); c[k] = lv[n] * y1ac; }
                     } else {
                         CSH_UNROLL
                         for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? uvac : uvdc; lv[n] = quant(coef[k], q); c[k] = lv[n] * q; }
                     }
-                    idct4_add(c, luma ? dcY : (l < 20 ? dcU : dcV), px);
+                    idct4_add(c, pred, px);
                     uint8_t *r = luma ? ry + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4
                                       : (l < 20 ? ru : rv) + size_t(my * 8 + (b >> 1) * 4) * cs + mx * 8 + (b & 1) * 4;
                     const int stride = luma ? ys : cs;
@@ -309,7 +375,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
     const int mbw = int(im.mbw), mbh = int(im.mbh);
     uint8_t *o = out + im.out_off;
     if (im.out_cap < 64) { LANE0 status[im.image] = 20200; return; }
-    // partition 0: frame header fields, then the modes of every macroblock (all i16x16 DC_PRED + chroma DC_PRED)
+    // partition 0: frame header fields, then the modes of every macroblock (i16x16 with the luma / chroma modes k_webp_mb chose)
     BoolEnc h;
     h.init(o + 30, im.out_cap - 32);
     h.bits(0, 1); h.bits(0, 1); h.bits(0, 1);           // colour space, clamping, no segmentation
@@ -320,7 +386,13 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
     h.bits(0, 1);                                       // refresh_entropy_probs
     for (int i = 0; i < 4 * 8 * 3 * 11; i++) h.put(0, kVp8CoefUpdateProbs[i]);   // keep the default coefficient probabilities
     h.bits(0, 1);                                       // no skip flags
-    for (int i = 0; i < mbw * mbh; i++) { h.put(1, 145); h.put(0, 156); h.put(0, 163); h.put(0, 142); }
+    for (int i = 0; i < mbw * mbh; i++) {
+        const int16_t *L = levels + im.lev_off + size_t(i) * 400;
+        const int ym = L[16], cm = L[32];
+        h.put(1, 145);                                                                        // i16x16
+        if (ym >= 2) { h.put(1, 156); h.put(ym == 3, 128); } else { h.put(0, 156); h.put(ym == 1, 163); }   // (H | TM) : (DC | V)
+        if (!cm) h.put(0, 142); else { h.put(1, 142); if (cm == 1) h.put(0, 114); else { h.put(1, 114); h.put(cm == 3, 183); } }
+    }
     h.finish();
     const uint32_t p0 = h.pos;
     // partition 1: tokens, right behind it

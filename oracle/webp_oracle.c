@@ -7,8 +7,9 @@
  * `caesium::convert_in_memory(.., SupportedFileTypes::WebP)` (/root/reference/src/compressor.rs:289, :300), i.e. libwebp
  * (libwebp-sys 0.9.5, Cargo.lock:956) at its default method 4: analysis, segments, intra-mode RD search (i16 / i4 / uv),
  * trellis, loop-filter strength search.  None of that source is available.  This file is a first, MINIMAL conformant VP8
- * encoder laid out for the GPU: every macroblock is coded i16x16 DC_PRED + chroma DC_PRED with one quantiser index, no
- * segments, no loop filter, the default coefficient probabilities, one token partition.  What is pinned:
+ * encoder laid out for the GPU: every macroblock is coded i16x16 (DC / V / H / TM by least transformed residual) + one chroma
+ * mode chosen the same way, one quantiser index, no i4x4, no segments, no loop filter, the default coefficient
+ * probabilities, one token partition.  What is pinned:
  *   - the bitstream is valid: libwebp (through Pillow) decodes every output;
  *   - the decoder-side arithmetic (dequantisation, inverse WHT / DCT, DC prediction, RFC 6386) is restated exactly, which
  *     the tests check by comparing this file's own reconstruction with libwebp's decoded YUV -> the encoder and any
@@ -205,6 +206,51 @@ int cso_webp_quality_to_qi(int quality) {
 }
 static int quant(int c, int q) { int a = c < 0 ? -c : c; a = (a + (q >> 1)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
 
+/* One N x N intra prediction (N = 16 luma, 8 chroma) from the reconstruction around it (RFC 6386 section 12.2).  Modes: 0 DC,
+   1 V (the row above), 2 H (the column to the left), 3 TM (above + left - corner, clipped).  Returns the chosen mode and its
+   prediction in pred (stride N); for chroma the two planes share one mode and pred holds U then V (64 samples each). */
+static void fill_pred(int mode, const uint8_t *r, int rs, int N, int mx, int my, uint8_t *pred) {
+    if (mode == 0) {
+        int dc = 128;
+        if (mx || my) {
+            int sum = 0, n = 0;
+            if (my) { for (int i = 0; i < N; i++) sum += r[i - rs]; n += N; }
+            if (mx) { for (int i = 0; i < N; i++) sum += r[i * rs - 1]; n += N; }
+            dc = n == 2 * N ? (sum + N) / (2 * N) : (sum + N / 2) / N;
+        }
+        memset(pred, dc, (size_t)N * N);
+        return;
+    }
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++)
+            pred[y * N + x] = (uint8_t)(mode == 1 ? r[x - rs] : mode == 2 ? r[y * rs - 1] : clip8(r[x - rs] + r[y * rs - 1] - r[-rs - 1]));
+}
+static int predict(const uint8_t *r, int rs, int N, const uint8_t *s, int ss, int mx, int my, const uint8_t *r2, const uint8_t *s2, int two, uint8_t *pred, int pstride) {
+    (void)pstride;
+    int best = 0;
+    uint64_t best_err = ~0ull;
+    const int nmodes = (mx && my) ? 4 : 1;
+    uint8_t tmp[2][256];
+    for (int m = 0; m < nmodes; m++) {
+        uint64_t err = 0;
+        for (int pl = 0; pl <= two; pl++) {
+            fill_pred(m, pl ? r2 : r, rs, N, mx, my, tmp[pl]);
+            const uint8_t *src = pl ? s2 : s;
+            /* cost of a mode: the sum of the magnitudes of the transformed residual (what the entropy coder will have to
+               spend bits on), not the squared error -- on noisy texture the flat DC prediction is the cheaper one */
+            for (int by = 0; by < N / 4; by++)
+                for (int bx = 0; bx < N / 4; bx++) {
+                    int16_t c[16];
+                    fdct4(src + by * 4 * ss + bx * 4, ss, tmp[pl] + by * 4 * N + bx * 4, N, c);
+                    for (int k = 0; k < 16; k++) err += (uint64_t)(c[k] < 0 ? -c[k] : c[k]);
+                }
+        }
+        if (err < best_err) { best_err = err; best = m; }
+    }
+    for (int pl = 0; pl <= two; pl++) fill_pred(best, pl ? r2 : r, rs, N, mx, my, pred + pl * N * N);
+    return best;
+}
+
 /* levels: per macroblock 25 blocks x 16 (Y2, 16 luma, 4 U, 4 V), scan order.  recon planes come back for the tests. */
 int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp, int width, int height, int qi, uint8_t **out, size_t *out_len,
                         uint8_t *ry, uint8_t *ru, uint8_t *rv) {
@@ -217,23 +263,21 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     int own = 0;
     if (!ry) { own = 1; ry = (uint8_t *)malloc((size_t)ys * mbh * 16); ru = (uint8_t *)malloc((size_t)cs * mbh * 8); rv = (uint8_t *)malloc((size_t)cs * mbh * 8); }
     int16_t *levels = (int16_t *)calloc((size_t)mbw * mbh * 400, sizeof(int16_t));
+    uint8_t *modes = (uint8_t *)calloc((size_t)mbw * mbh, 2);   /* per macroblock: luma mode, chroma mode */
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) {
             int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
-            /* luma: DC prediction from the reconstructed row above and column to the left */
+            /* the intra mode of the 16x16 luma block and of the two 8x8 chroma blocks: DC_PRED, or -- where both the row above
+               and the column to the left exist, so that no edge rule of the decoder is involved -- V_PRED / H_PRED / TM_PRED
+               when that leaves the smaller transformed residual (sum of |DCT coefficients|; ties: the earlier in this order) */
+            uint8_t *M = modes + ((size_t)my * mbw + mx) * 2;
             {
                 uint8_t *r = ry + (size_t)my * 16 * ys + mx * 16;
                 const uint8_t *s = yp + (size_t)my * 16 * ys + mx * 16;
-                int dc = 128;
-                if (mx || my) {
-                    int sum = 0, n = 0;
-                    if (my) { for (int i = 0; i < 16; i++) sum += r[i - ys]; n += 16; }
-                    if (mx) { for (int i = 0; i < 16; i++) sum += r[i * ys - 1]; n += 16; }
-                    dc = n == 32 ? (sum + 16) >> 5 : (sum + 8) >> 4;
-                }
-                uint8_t pred[16]; memset(pred, dc, 16);   /* a flat block: one row serves as every row (stride 0) */
+                uint8_t pred[256];
+                M[0] = (uint8_t)predict(r, ys, 16, s, ys, mx, my, NULL, NULL, 0, pred, 16);
                 int16_t coef[16][16], dcs[16], y2[16], dq[16];
-                for (int b = 0; b < 16; b++) { fdct4(s + (b >> 2) * 4 * ys + (b & 3) * 4, ys, pred, 0, coef[b]); dcs[b] = coef[b][0]; }
+                for (int b = 0; b < 16; b++) { fdct4(s + (b >> 2) * 4 * ys + (b & 3) * 4, ys, pred + (b >> 2) * 64 + (b & 3) * 4, 16, coef[b]); dcs[b] = coef[b][0]; }
                 fwht(dcs, y2);
                 for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc); dq[k] = (int16_t)(L[n] * (k ? y2ac : y2dc)); }
                 iwht(dq, dcs);
@@ -243,25 +287,23 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
                     L[16 + b * 16] = 0;
                     for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; L[16 + b * 16 + n] = (int16_t)quant(coef[b][k], y1ac); c[k] = (int16_t)(L[16 + b * 16 + n] * y1ac); }
                     (void)y1dc;
-                    idct4_add(c, pred, 0, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
+                    idct4_add(c, pred + (b >> 2) * 64 + (b & 3) * 4, 16, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
                 }
             }
-            for (int pl = 0; pl < 2; pl++) {
-                uint8_t *r = (pl ? rv : ru) + (size_t)my * 8 * cs + mx * 8;
-                const uint8_t *s = (pl ? vp : up) + (size_t)my * 8 * cs + mx * 8;
-                int dc = 128;
-                if (mx || my) {
-                    int sum = 0, n = 0;
-                    if (my) { for (int i = 0; i < 8; i++) sum += r[i - cs]; n += 8; }
-                    if (mx) { for (int i = 0; i < 8; i++) sum += r[i * cs - 1]; n += 8; }
-                    dc = n == 16 ? (sum + 8) >> 4 : (sum + 4) >> 3;
-                }
-                uint8_t pred[8]; memset(pred, dc, 8);
-                for (int b = 0; b < 4; b++) {
-                    int16_t coef[16], c[16], *lv = L + (17 + pl * 4 + b) * 16;
-                    fdct4(s + (b >> 1) * 4 * cs + (b & 1) * 4, cs, pred, 0, coef);
-                    for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = (int16_t)quant(coef[k], k ? uvac : uvdc); c[k] = (int16_t)(lv[n] * (k ? uvac : uvdc)); }
-                    idct4_add(c, pred, 0, r + (b >> 1) * 4 * cs + (b & 1) * 4, cs);
+            {
+                uint8_t *r0 = ru + (size_t)my * 8 * cs + mx * 8, *r1 = rv + (size_t)my * 8 * cs + mx * 8;
+                const uint8_t *s0 = up + (size_t)my * 8 * cs + mx * 8, *s1 = vp + (size_t)my * 8 * cs + mx * 8;
+                uint8_t pred[2][64];
+                M[1] = (uint8_t)predict(r0, cs, 8, s0, cs, mx, my, r1, s1, 1, pred[0], 8);
+                for (int pl = 0; pl < 2; pl++) {
+                    uint8_t *r = pl ? r1 : r0;
+                    const uint8_t *s = pl ? s1 : s0;
+                    for (int b = 0; b < 4; b++) {
+                        int16_t coef[16], c[16], *lv = L + (17 + pl * 4 + b) * 16;
+                        fdct4(s + (b >> 1) * 4 * cs + (b & 1) * 4, cs, pred[pl] + (b >> 1) * 32 + (b & 1) * 4, 8, coef);
+                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = (int16_t)quant(coef[k], k ? uvac : uvdc); c[k] = (int16_t)(lv[n] * (k ? uvac : uvdc)); }
+                        idct4_add(c, pred[pl] + (b >> 1) * 32 + (b & 1) * 4, 8, r + (b >> 1) * 4 * cs + (b & 1) * 4, cs);
+                    }
                 }
             }
         }
@@ -282,8 +324,10 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     for (int i = 0; i < 4 * 8 * 3 * 11; i++) be_put(&h, 0, kVp8CoefUpdateProbs[i]);   /* keep the default coefficient probabilities */
     be_bits(&h, 0, 1);            /* no skip flags */
     for (int i = 0; i < mbw * mbh; i++) {
-        be_put(&h, 1, 145); be_put(&h, 0, 156); be_put(&h, 0, 163);   /* i16x16, DC_PRED */
-        be_put(&h, 0, 142);                                          /* chroma DC_PRED */
+        const int ym = modes[2 * i], cm = modes[2 * i + 1];
+        be_put(&h, 1, 145);                                                               /* i16x16 */
+        if (ym >= 2) { be_put(&h, 1, 156); be_put(&h, ym == 3, 128); } else { be_put(&h, 0, 156); be_put(&h, ym == 1, 163); }   /* (H | TM) : (DC | V) */
+        if (!cm) be_put(&h, 0, 142); else { be_put(&h, 1, 142); if (cm == 1) be_put(&h, 0, 114); else { be_put(&h, 1, 114); be_put(&h, cm == 3, 183); } }
     }
     be_flush(&h);
     uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
@@ -302,7 +346,7 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
         }
     }
     be_flush(&t);
-    free(top); free(levels);
+    free(top); free(levels); free(modes);
     if (own) { free(ry); free(ru); free(rv); }
     /* RIFF / WEBP / "VP8 " : frame tag, start code, dimensions, partition 0, partition 1 */
     const size_t vp8 = 10 + h.pos + t.pos, padded = vp8 + (vp8 & 1), total = 12 + 8 + padded;
