@@ -4,8 +4,10 @@
 //                neighbours, so the macroblocks of an image form a chain: ONE WAVE PER IMAGE walks them in raster order and
 //                its lanes are the blocks of the macroblock (0..15 luma, 16..19 U, 20..23 V); the 16 luma DCs meet by
 //                v_readlane for the Walsh-Hadamard transform, which every lane repeats for itself
-//   k_webp_code  W3: the boolean entropy coder is one serial chain per partition: one wave per image runs it on its uniform
-//                side (lane 0 stores), header partition first, tokens behind it, then the RIFF / frame headers
+//   k_webp_code  W3: the boolean entropy coder is one serial chain per partition: one wave per (image, partition) runs it on
+//                its uniform side (lane 0 stores) -- the header partition and up to eight token partitions (macroblock rows
+//                interleaved), independent of each other because their contexts come from masks stored with the levels;
+//                k_webp_assemble puts the pieces and the RIFF / frame headers in place
 // Parallelism is across the files of the batch, as in the reference's par_iter; what one wave does is a latency.
 #include "../../include/vp8_tables.h"
 #include "png_wave.h"
@@ -247,7 +249,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
             for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? y2ac : y2dc; lv2[n] = quant(y2[k], q); dq[k] = lv2[n] * q; }
             iwht(dq, dcs);
             int16_t *L = levels + im.lev_off + (size_t(my) * mbw + mx) * 400;
+            LV<int> nzl;
             LFOR(l) {
+                nzl[l] = 0;
                 if (l == 0) { CSH_UNROLL for (int n = 0; n < 16; n++) L[n] = int16_t(lv2[n]); }
                 if (l < 24) {
 #ifdef CSH_EMUL
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
                         int mine = 0;
                         CSH_UNROLL
                         for (int k = 0; k < 16; k++) mine = b == k ? dcs[k] : mine;
-                        c[0] = mine; lv[0] = b == 0 ? ymode : b == 1 ? cmode : 0;   // the unused DC slots of luma blocks 0 and 1 carry the modes to k_webp_code
+                        c[0] = mine; lv[0] = b == 0 ? ymode : b == 1 ? cmode : 0;   // the unused DC slots of luma blocks 0 and 1 carry the modes to k_webp_code (2 and 3: see below)
                         CSH_UNROLL
                         for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = quant(coef[k], y1ac); c[k] = lv[n] * y1ac; }
                     } else {
@@ -277,7 +281,22 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
                     int16_t *o = L + (luma ? 1 + b : 17 + (l - 16)) * 16;
                     CSH_UNROLL
                     for (int n = 0; n < 16; n++) o[n] = int16_t(lv[n]);
+                    int any = 0;
+                    CSH_UNROLL
+                    for (int n = 1; n < 16; n++) any |= lv[n];
+                    if (!luma) any |= lv[0];
+                    nzl[l] = any != 0;
                 }
+            }
+            // which blocks have anything to code: bit 0 the Y2 block, 1..16 luma, 17..24 chroma -- the token coder's contexts, kept in
+            // the unused DC slots of luma blocks 2 and 3 so that every token partition can look them up without a serial pass
+            {
+                int y2any = 0;
+                CSH_UNROLL
+                for (int n = 0; n < 16; n++) y2any |= lv2[n];
+                const uint64_t bal = lballot([&](int l) { return l < 24 && nzl[l] != 0; });
+                const uint32_t mask = (uint32_t(bal & 0xFFFFFFu) << 1) | (y2any ? 1u : 0u);
+                LFOR(l) if (l == 0) { L[48] = int16_t(mask & 0xFFFFu); L[64] = int16_t(mask >> 16); }
             }
             CSP_MEM_FENCE();   // the next macroblock predicts from these pixels
         }
@@ -367,63 +386,81 @@ __device__ static int put_coeffs(BoolEnc &e, int type, int ctx, const int16_t *l
     return 1;
 }
 
-enum { WEBP_MAX_MBW = 1024 };   // 16383 pixels
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, uint8_t *out, uint32_t *img_size, uint32_t *status) {
-    CSH_SHARED uint8_t top[WEBP_MAX_MBW * 9];   // per macroblock column: non-zero flags of 4 luma, 2 U, 2 V blocks and the Y2 block above
+// One wave per (image, partition): y = 0 the header partition (frame header fields and the macroblock modes), y = 1..8 the
+// token partitions (macroblock row r belongs to partition r mod P).  Contexts come from the non-zero masks k_webp_mb left
+// with the levels, so no partition waits for another.  Every partition goes to its own slice of a scratch region; the
+// sizes decide where k_webp_assemble puts them.
+__device__ __forceinline__ static uint32_t nz_mask(const int16_t *L) { return uint32_t(uint16_t(L[48])) | (uint32_t(uint16_t(L[64])) << 16); }
+__device__ __forceinline__ static int webp_parts(int mbh) { return mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1; }
+__device__ __forceinline__ static uint32_t webp_hdr_cap(const WebpImg &im) { return 2048u + im.mbw * im.mbh; }
+__device__ __forceinline__ static uint32_t webp_part_cap(const WebpImg &im) { return (im.out_cap - 128u - webp_hdr_cap(im)) / uint32_t(webp_parts(int(im.mbh))); }
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, uint8_t *scratch, uint32_t *part_size, const uint32_t *status) {
     const WebpImg im = imgs[blockIdx.x];
     if (status[im.image]) return;
-    const int mbw = int(im.mbw), mbh = int(im.mbh);
-    uint8_t *o = out + im.out_off;
-    if (im.out_cap < 64) { LANE0 status[im.image] = 20200; return; }
-    // partition 0: frame header fields, then the modes of every macroblock (i16x16 with the luma / chroma modes k_webp_mb chose)
-    BoolEnc h;
-    h.init(o + 30, im.out_cap - 32);
-    h.bits(0, 1); h.bits(0, 1); h.bits(0, 1);           // colour space, clamping, no segmentation
-    h.bits(1, 1); h.bits(0, 6); h.bits(0, 3);           // simple filter at level 0 (off), sharpness
-    h.bits(0, 1); h.bits(0, 2);                         // no filter deltas, one token partition
-    h.bits(uint32_t(im.qi), 7);
-    for (int i = 0; i < 5; i++) h.bits(0, 1);           // no quantiser deltas
-    h.bits(0, 1);                                       // refresh_entropy_probs
-    for (int i = 0; i < 4 * 8 * 3 * 11; i++) h.put(0, kVp8CoefUpdateProbs[i]);   // keep the default coefficient probabilities
-    h.bits(0, 1);                                       // no skip flags
-    for (int i = 0; i < mbw * mbh; i++) {
-        const int16_t *L = levels + im.lev_off + size_t(i) * 400;
-        const int ym = L[16], cm = L[32];
-        h.put(1, 145);                                                                        // i16x16
-        if (ym >= 2) { h.put(1, 156); h.put(ym == 3, 128); } else { h.put(0, 156); h.put(ym == 1, 163); }   // (H | TM) : (DC | V)
-        if (!cm) h.put(0, 142); else { h.put(1, 142); if (cm == 1) h.put(0, 114); else { h.put(1, 114); h.put(cm == 3, 183); } }
-    }
-    h.finish();
-    const uint32_t p0 = h.pos;
-    // partition 1: tokens, right behind it
-    BoolEnc t;
-    t.init(o + 30 + p0, h.overflow ? 0u : im.out_cap - 32 - p0);
-    LFOR(l) for (int i = l; i < mbw * 9; i += 64) top[i] = 0;
-    CSP_WAVE_SYNC();
+    const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh), part = int(blockIdx.y) - 1;
+    if (part >= nparts) return;
     const int16_t *lev = levels + im.lev_off;
-    for (int my = 0; my < mbh && !t.overflow; my++) {
-        uint8_t left[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int mx = 0; mx < mbw; mx++) {
-            const int16_t *L = lev + (size_t(my) * mbw + mx) * 400;
-            uint8_t *tp = top + mx * 9;
-            uint8_t nz[9];
-            for (int k = 0; k < 9; k++) nz[k] = tp[k];
-            nz[8] = left[8] = uint8_t(put_coeffs(t, 1, nz[8] + left[8], L, 0));
-            for (int by = 0; by < 4; by++)
-                for (int bx = 0; bx < 4; bx++) nz[bx] = left[by] = uint8_t(put_coeffs(t, 0, nz[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1));
-            for (int pl = 0; pl < 2; pl++)
-                for (int by = 0; by < 2; by++)
-                    for (int bx = 0; bx < 2; bx++)
-                        nz[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = uint8_t(put_coeffs(t, 2, nz[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0));
-            LANE0 for (int k = 0; k < 9; k++) tp[k] = nz[k];
-            CSP_WAVE_SYNC();
+    uint8_t *base = scratch + im.out_off;
+    BoolEnc e;
+    if (part < 0) {
+        e.init(base, webp_hdr_cap(im));
+        e.bits(0, 1); e.bits(0, 1); e.bits(0, 1);           // colour space, clamping, no segmentation
+        e.bits(1, 1); e.bits(0, 6); e.bits(0, 3);           // simple filter at level 0 (off), sharpness
+        e.bits(0, 1);                                       // no filter deltas
+        e.bits(uint32_t(nparts == 8 ? 3 : nparts == 4 ? 2 : nparts == 2 ? 1 : 0), 2);
+        e.bits(uint32_t(im.qi), 7);
+        for (int i = 0; i < 5; i++) e.bits(0, 1);           // no quantiser deltas
+        e.bits(0, 1);                                       // refresh_entropy_probs
+        for (int i = 0; i < 4 * 8 * 3 * 11; i++) e.put(0, kVp8CoefUpdateProbs[i]);   // keep the default coefficient probabilities
+        e.bits(0, 1);                                       // no skip flags
+        for (int i = 0; i < mbw * mbh; i++) {
+            const int16_t *L = lev + size_t(i) * 400;
+            const int ym = L[16], cm = L[32];
+            e.put(1, 145);                                                                        // i16x16
+            if (ym >= 2) { e.put(1, 156); e.put(ym == 3, 128); } else { e.put(0, 156); e.put(ym == 1, 163); }   // (H | TM) : (DC | V)
+            if (!cm) e.put(0, 142); else { e.put(1, 142); if (cm == 1) e.put(0, 114); else { e.put(1, 114); e.put(cm == 3, 183); } }
         }
+    } else {
+        e.init(base + webp_hdr_cap(im) + uint32_t(part) * webp_part_cap(im), webp_part_cap(im));
+        for (int my = part; my < mbh && !e.overflow; my += nparts)
+            for (int mx = 0; mx < mbw; mx++) {
+                const int16_t *L = lev + (size_t(my) * mbw + mx) * 400;
+                const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * 400) : 0u, left = mx ? nz_mask(L - 400) : 0u;
+                put_coeffs(e, 1, int((top & 1u) + (left & 1u)), L, 0);
+                for (int by = 0; by < 4; by++)
+                    for (int bx = 0; bx < 4; bx++) {
+                        const uint32_t t1 = by ? (cur >> (1 + (by - 1) * 4 + bx)) & 1u : (top >> (13 + bx)) & 1u;
+                        const uint32_t l1 = bx ? (cur >> (by * 4 + bx)) & 1u : (left >> (4 + by * 4)) & 1u;
+                        put_coeffs(e, 0, int(t1 + l1), L + (1 + by * 4 + bx) * 16, 1);
+                    }
+                for (int pl = 0; pl < 2; pl++)
+                    for (int by = 0; by < 2; by++)
+                        for (int bx = 0; bx < 2; bx++) {
+                            const int b0 = 17 + pl * 4;
+                            const uint32_t t1 = by ? (cur >> (b0 + bx)) & 1u : (top >> (b0 + 2 + bx)) & 1u;
+                            const uint32_t l1 = bx ? (cur >> (b0 + by * 2)) & 1u : (left >> (b0 + by * 2 + 1)) & 1u;
+                            put_coeffs(e, 2, int(t1 + l1), L + (b0 + by * 2 + bx) * 16, 0);
+                        }
+            }
     }
-    t.finish();
-    if (h.overflow || t.overflow) { LANE0 status[im.image] = 20200; return; }
-    // RIFF / WEBP / "VP8 ": frame tag, start code, dimensions
-    const uint32_t vp8 = 10 + p0 + t.pos, padded = vp8 + (vp8 & 1u), total = 20 + padded;
-    LANE0 {
+    e.finish();
+    LANE0 part_size[size_t(im.image) * 9 + blockIdx.y] = e.overflow ? 0xFFFFFFFFu : e.pos;
+}
+// the file: RIFF / WEBP / "VP8 " headers, frame tag, start code, dimensions, header partition, the sizes of all token partitions
+// but the last, the partitions
+__global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, const uint8_t *scratch, const uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
+    const WebpImg im = imgs[blockIdx.x];
+    if (status[im.image]) return;
+    const int nparts = webp_parts(int(im.mbh));
+    const uint32_t *ps = part_size + size_t(im.image) * 9;
+    bool bad = false;
+    uint32_t tok = 0;
+    for (int k = 0; k <= nparts; k++) { if (ps[k] == 0xFFFFFFFFu) bad = true; else if (k) tok += ps[k]; }
+    const uint32_t p0 = ps[0], vp8 = 10u + p0 + 3u * uint32_t(nparts - 1) + tok, total = 20u + vp8 + (vp8 & 1u);
+    if (bad || total > im.out_cap) { if (threadIdx.x == 0) status[im.image] = 20200; return; }
+    uint8_t *o = out + im.out_off;
+    const uint8_t *base = scratch + im.out_off;
+    if (threadIdx.x == 0) {
         const uint8_t hdr[20] = {'R', 'I', 'F', 'F', uint8_t(total - 8), uint8_t((total - 8) >> 8), uint8_t((total - 8) >> 16), uint8_t((total - 8) >> 24), 'W', 'E', 'B', 'P',
                                  'V', 'P', '8', ' ', uint8_t(vp8), uint8_t(vp8 >> 8), uint8_t(vp8 >> 16), uint8_t(vp8 >> 24)};
         for (int k = 0; k < 20; k++) o[k] = hdr[k];
@@ -431,8 +468,16 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
         o[20] = uint8_t(tag); o[21] = uint8_t(tag >> 8); o[22] = uint8_t(tag >> 16);
         o[23] = 0x9D; o[24] = 0x01; o[25] = 0x2A;
         o[26] = uint8_t(im.width); o[27] = uint8_t(im.width >> 8); o[28] = uint8_t(im.height); o[29] = uint8_t(im.height >> 8);
+        for (int p = 0; p + 1 < nparts; p++) { uint8_t *z = o + 30 + p0 + 3 * p; z[0] = uint8_t(ps[1 + p]); z[1] = uint8_t(ps[1 + p] >> 8); z[2] = uint8_t(ps[1 + p] >> 16); }
         if (vp8 & 1u) o[20 + vp8] = 0;
         img_size[im.image] = total;
+    }
+    for (uint32_t i = threadIdx.x; i < p0; i += blockDim.x) o[30 + i] = base[i];
+    uint32_t at = 30u + p0 + 3u * uint32_t(nparts - 1);
+    for (int p = 0; p < nparts; p++) {
+        const uint8_t *src = base + webp_hdr_cap(im) + uint32_t(p) * webp_part_cap(im);
+        for (uint32_t i = threadIdx.x; i < ps[1 + p]; i += blockDim.x) o[at + i] = src[i];
+        at += ps[1 + p];
     }
 }
 
@@ -442,8 +487,10 @@ void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max
 void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work, int16_t *levels) {
     if (nimg) CSH_LAUNCH(k_webp_mb, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, work, levels);
 }
-void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, const int16_t *levels, uint8_t *out, uint32_t *img_size, uint32_t *status) {
-    if (nimg) CSH_LAUNCH(k_webp_code, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, out, img_size, status);
+void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, const int16_t *levels, uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
+    if (!nimg) return;
+    CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, scratch, part_size, status);
+    CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
 }
 
 }  // namespace csw

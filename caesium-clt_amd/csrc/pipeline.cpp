@@ -133,7 +133,8 @@ struct csh_batch {
     DevBuf<uint32_t> d_chunk_work;
     DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<csw::WebpImg> d_wimgs;
-    DevBuf<uint8_t> d_wwork;
+    DevBuf<uint8_t> d_wwork, d_wscratch;
+    DevBuf<uint32_t> d_wpart;
     DevBuf<int16_t> d_wlevels;
     DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
     DevBuf<uint16_t> d_eobrun;
@@ -803,7 +804,7 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     uint64_t out_bytes = 0;
     std::vector<uint64_t> off(size_t(b->nimg) + 1, 0);
     for (auto &wi : b->wimgs) {
-        const uint64_t cap = 256 + uint64_t(wi.mbw) * wi.mbh * (b->webp_mb_bytes + 2);
+        const uint64_t cap = 4096 + uint64_t(wi.mbw) * wi.mbh * (b->webp_mb_bytes + 2);
         wi.out_cap = uint32_t(std::min<uint64_t>(cap, 0xFFFFFF00u)); wi.out_off = out_bytes;
         off[wi.image] = out_bytes;
         out_bytes += (wi.out_cap + 63) & ~uint64_t(63);
@@ -816,6 +817,7 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     }
     off[b->nimg] = out_bytes;
     if (b->d_out.n < out_bytes + 64 && b->d_out.alloc(out_bytes + 64)) return -1;
+    if ((b->d_wscratch.n < out_bytes + 64 && b->d_wscratch.alloc(out_bytes + 64)) || (b->d_wpart.n < size_t(b->nimg) * 9 + 9 && b->d_wpart.alloc(size_t(b->nimg) * 9 + 9))) return -1;
     if (b->d_wimgs.upload(b->wimgs, st) || (b->d_wwork.n < b->wwork_bytes + 64 && b->d_wwork.alloc(b->wwork_bytes + 64)) ||
         (b->d_wlevels.n < b->wlevels + 64 && b->d_wlevels.alloc(b->wlevels + 64)))
         return -1;
@@ -823,7 +825,7 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     if (b->d_img_size.zero(st)) return -1;
     csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
     csw::launch_webp_mb(st, b->d_wimgs.p, nimg, b->d_wwork.p, b->d_wlevels.p);
-    csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->d_wlevels.p, b->d_out.p, b->d_img_size.p, b->d_status.p);
+    csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->d_wlevels.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_img_size.p, b->d_status.p);
     CSH_CHECK(hipEventRecord(ev[++slot], st));
     CSH_CHECK(hipStreamSynchronize(st));
     CSH_CHECK(hipGetLastError());

@@ -9,7 +9,7 @@
  * trellis, loop-filter strength search.  None of that source is available.  This file is a first, MINIMAL conformant VP8
  * encoder laid out for the GPU: every macroblock is coded i16x16 (DC / V / H / TM by least transformed residual) + one chroma
  * mode chosen the same way, one quantiser index, no i4x4, no segments, no loop filter, the default coefficient
- * probabilities, one token partition.  What is pinned:
+ * probabilities, up to eight token partitions (rows interleaved).  What is pinned:
  *   - the bitstream is valid: libwebp (through Pillow) decodes every output;
  *   - the decoder-side arithmetic (dequantisation, inverse WHT / DCT, DC prediction, RFC 6386) is restated exactly, which
  *     the tests check by comparing this file's own reconstruction with libwebp's decoded YUV -> the encoder and any
@@ -308,8 +308,8 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
             }
         }
     /* partition 0: frame header + per-macroblock modes; partition 1: tokens */
-    boolenc h, t;
-    be_init(&h); be_init(&t);
+    boolenc h;
+    be_init(&h);
     be_bits(&h, 0, 1);            /* colour space */
     be_bits(&h, 0, 1);            /* clamping required */
     be_bits(&h, 0, 1);            /* no segmentation */
@@ -317,7 +317,7 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     be_bits(&h, 0, 6);            /* ... at level 0: off */
     be_bits(&h, 0, 3);            /* sharpness */
     be_bits(&h, 0, 1);            /* no filter deltas */
-    be_bits(&h, 0, 2);            /* one token partition */
+    be_bits(&h, (uint32_t)(mbh >= 8 ? 3 : mbh >= 4 ? 2 : mbh >= 2 ? 1 : 0), 2);   /* log2 of the number of token partitions */
     be_bits(&h, (uint32_t)qi, 7);
     for (int i = 0; i < 5; i++) be_bits(&h, 0, 1);   /* no quantiser deltas */
     be_bits(&h, 0, 1);            /* refresh_entropy_probs */
@@ -330,26 +330,34 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
         if (!cm) be_put(&h, 0, 142); else { be_put(&h, 1, 142); if (cm == 1) be_put(&h, 0, 114); else { be_put(&h, 1, 114); be_put(&h, cm == 3, 183); } }
     }
     be_flush(&h);
+    /* token partitions: macroblock row r goes to partition r mod P, P = 8 / 4 / 2 / 1 by the number of rows.  The contexts
+       (is the block above / to the left non-zero?) carry over from row to row whatever the partition, and depend on the
+       levels only -- so the partitions are independent chains once the levels exist. */
+    const int nparts = mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1;
+    boolenc t[8];
+    for (int p = 0; p < nparts; p++) be_init(&t[p]);
     uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
     for (int my = 0; my < mbh; my++) {
         uint8_t left[9]; memset(left, 0, 9);
+        boolenc *e = &t[my & (nparts - 1)];
         for (int mx = 0; mx < mbw; mx++) {
             const int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
             uint8_t *tp = top + (size_t)mx * 9;
-            tp[8] = left[8] = (uint8_t)put_coeffs(&t, 1, tp[8] + left[8], L, 0);
+            tp[8] = left[8] = (uint8_t)put_coeffs(e, 1, tp[8] + left[8], L, 0);
             for (int by = 0; by < 4; by++)
-                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(&t, 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1);
+                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(e, 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1);
             for (int pl = 0; pl < 2; pl++)
                 for (int by = 0; by < 2; by++)
                     for (int bx = 0; bx < 2; bx++)
-                        tp[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = (uint8_t)put_coeffs(&t, 2, tp[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0);
+                        tp[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = (uint8_t)put_coeffs(e, 2, tp[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0);
         }
     }
-    be_flush(&t);
+    size_t tok = 0;
+    for (int p = 0; p < nparts; p++) { be_flush(&t[p]); tok += t[p].pos; }
     free(top); free(levels); free(modes);
     if (own) { free(ry); free(ru); free(rv); }
-    /* RIFF / WEBP / "VP8 " : frame tag, start code, dimensions, partition 0, partition 1 */
-    const size_t vp8 = 10 + h.pos + t.pos, padded = vp8 + (vp8 & 1), total = 12 + 8 + padded;
+    /* RIFF / WEBP / "VP8 " : frame tag, start code, dimensions, partition 0, the sizes of all token partitions but the last, the partitions */
+    const size_t vp8 = 10 + h.pos + 3 * (size_t)(nparts - 1) + tok, padded = vp8 + (vp8 & 1), total = 12 + 8 + padded;
     uint8_t *o = (uint8_t *)calloc(total, 1), *w = o;
     memcpy(w, "RIFF", 4); w[4] = (uint8_t)(total - 8); w[5] = (uint8_t)((total - 8) >> 8); w[6] = (uint8_t)((total - 8) >> 16); w[7] = (uint8_t)((total - 8) >> 24);
     memcpy(w + 8, "WEBPVP8 ", 8); w[16] = (uint8_t)vp8; w[17] = (uint8_t)(vp8 >> 8); w[18] = (uint8_t)(vp8 >> 16); w[19] = (uint8_t)(vp8 >> 24);
@@ -358,8 +366,10 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     w[0] = (uint8_t)tag; w[1] = (uint8_t)(tag >> 8); w[2] = (uint8_t)(tag >> 16);
     w[3] = 0x9D; w[4] = 0x01; w[5] = 0x2A;
     w[6] = (uint8_t)width; w[7] = (uint8_t)(width >> 8); w[8] = (uint8_t)height; w[9] = (uint8_t)(height >> 8);
-    memcpy(w + 10, h.buf, h.pos); memcpy(w + 10 + h.pos, t.buf, t.pos);
-    free(h.buf); free(t.buf);
+    memcpy(w + 10, h.buf, h.pos); w += 10 + h.pos;
+    for (int p = 0; p + 1 < nparts; p++) { w[0] = (uint8_t)t[p].pos; w[1] = (uint8_t)(t[p].pos >> 8); w[2] = (uint8_t)(t[p].pos >> 16); w += 3; }
+    for (int p = 0; p < nparts; p++) { memcpy(w, t[p].buf, t[p].pos); w += t[p].pos; free(t[p].buf); }
+    free(h.buf);
     *out = o; *out_len = total;
     return 0;
 }
