@@ -107,7 +107,7 @@ __device__ __forceinline__ static void idct4_add(const int (&in)[16], const int 
         px[i * 4 + 2] = clip8(pred[i * 4 + 2] + ((b - c) >> 3)); px[i * 4 + 3] = clip8(pred[i * 4 + 3] + ((a - d) >> 3));
     }
 }
-__device__ __forceinline__ static int quant(int c, int q) { int a = c < 0 ? -c : c; a = (a + (q >> 1)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
+__device__ __forceinline__ static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }   // bias / 256 of a step: libwebp's rounding offsets
 
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *imgs, uint8_t *work, int16_t *levels) {
     const WebpImg im = imgs[blockIdx.x];
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
             }
             fwht(dcs, y2);
             CSH_UNROLL
-            for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? y2ac : y2dc; lv2[n] = quant(y2[k], q); dq[k] = lv2[n] * q; }
+            for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? y2ac : y2dc; lv2[n] = quant(y2[k], q, k ? 108 : 96); dq[k] = lv2[n] * q; }
             iwht(dq, dcs);
             int16_t *L = levels + im.lev_off + (size_t(my) * mbw + mx) * 400;
             LV<int> nzl;
@@ -266,10 +266,10 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
                         for (int k = 0; k < 16; k++) mine = b == k ? dcs[k] : mine;
                         c[0] = mine; lv[0] = b == 0 ? ymode : b == 1 ? cmode : 0;   // the unused DC slots of luma blocks 0 and 1 carry the modes to k_webp_code (2 and 3: see below)
                         CSH_UNROLL
-                        for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = quant(coef[k], y1ac); c[k] = lv[n] * y1ac; }
+                        for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = quant(coef[k], y1ac, 110); c[k] = lv[n] * y1ac; }
                     } else {
                         CSH_UNROLL
-                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? uvac : uvdc; lv[n] = quant(coef[k], q); c[k] = lv[n] * q; }
+                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? uvac : uvdc; lv[n] = quant(coef[k], q, k ? 115 : 110); c[k] = lv[n] * q; }
                     }
                     idct4_add(c, pred, px);
                     uint8_t *r = luma ? ry + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4

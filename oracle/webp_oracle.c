@@ -204,7 +204,9 @@ int cso_webp_quality_to_qi(int quality) {
     int qi = (int)(127.0 * (1.0 - v) + 0.5);
     return qi < 0 ? 0 : qi > 127 ? 127 : qi;
 }
-static int quant(int c, int q) { int a = c < 0 ? -c : c; a = (a + (q >> 1)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
+/* scalar quantiser with libwebp's rounding offsets (bias / 256 of a step instead of one half: luma AC 110, Y2 DC 96 / AC 108,
+   chroma DC 110 / AC 115 -- its kBiasMatrices), levels capped at 2047 */
+static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
 
 /* One N x N intra prediction (N = 16 luma, 8 chroma) from the reconstruction around it (RFC 6386 section 12.2).  Modes: 0 DC,
    1 V (the row above), 2 H (the column to the left), 3 TM (above + left - corner, clipped).  Returns the chosen mode and its
@@ -279,13 +281,13 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
                 int16_t coef[16][16], dcs[16], y2[16], dq[16];
                 for (int b = 0; b < 16; b++) { fdct4(s + (b >> 2) * 4 * ys + (b & 3) * 4, ys, pred + (b >> 2) * 64 + (b & 3) * 4, 16, coef[b]); dcs[b] = coef[b][0]; }
                 fwht(dcs, y2);
-                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc); dq[k] = (int16_t)(L[n] * (k ? y2ac : y2dc)); }
+                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc, k ? 108 : 96); dq[k] = (int16_t)(L[n] * (k ? y2ac : y2dc)); }
                 iwht(dq, dcs);
                 for (int b = 0; b < 16; b++) {
                     int16_t c[16];
                     c[0] = dcs[b];
                     L[16 + b * 16] = 0;
-                    for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; L[16 + b * 16 + n] = (int16_t)quant(coef[b][k], y1ac); c[k] = (int16_t)(L[16 + b * 16 + n] * y1ac); }
+                    for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; L[16 + b * 16 + n] = (int16_t)quant(coef[b][k], y1ac, 110); c[k] = (int16_t)(L[16 + b * 16 + n] * y1ac); }
                     (void)y1dc;
                     idct4_add(c, pred + (b >> 2) * 64 + (b & 3) * 4, 16, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
                 }
@@ -301,7 +303,7 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
                     for (int b = 0; b < 4; b++) {
                         int16_t coef[16], c[16], *lv = L + (17 + pl * 4 + b) * 16;
                         fdct4(s + (b >> 1) * 4 * cs + (b & 1) * 4, cs, pred[pl] + (b >> 1) * 32 + (b & 1) * 4, 8, coef);
-                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = (int16_t)quant(coef[k], k ? uvac : uvdc); c[k] = (int16_t)(lv[n] * (k ? uvac : uvdc)); }
+                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = (int16_t)quant(coef[k], k ? uvac : uvdc, k ? 115 : 110); c[k] = (int16_t)(lv[n] * (k ? uvac : uvdc)); }
                         idct4_add(c, pred[pl] + (b >> 1) * 32 + (b & 1) * 4, 8, r + (b >> 1) * 4 * cs + (b & 1) * 4, cs);
                     }
                 }
