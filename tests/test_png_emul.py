@@ -105,3 +105,47 @@ def test_jpeg_and_png_in_one_call(api):
     # without png.optimize a PNG has no device path (lossy PNG is not built)
     outs = api.cs_batch_compress([png], pkg.default_parameters())
     assert isinstance(outs[0], Exception) and outs[0].code == 10201
+
+
+def damaged_pngs(seed, count):
+    """valid PNGs with one random injury each: a flipped bit anywhere, a zeroed run, a cut, a chunk length off by a little"""
+    rng = np.random.default_rng(seed)
+    base = [c[1] for c in png_cases() if c[0] in ("L_level1_input", "RGB_stored_input", "P_97x61", "RGBA_300x2")]
+    out = []
+    for k in range(count):
+        b = bytearray(base[k % len(base)])
+        kind = int(rng.integers(0, 4))
+        at = int(rng.integers(8, len(b)))
+        if kind == 0:
+            b[at] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            n = int(rng.integers(1, 9))
+            b[at:at + n] = bytes(len(b[at:at + n]))
+        elif kind == 2:
+            del b[at:]
+        else:
+            i = bytes(b).find(b"IDAT") - 4
+            b[i + 3] = (b[i + 3] + int(rng.integers(1, 5))) & 255
+        out.append(bytes(b))
+    return out
+
+
+def agree_with_oracle(api, blobs, level=1):
+    pkg = package()
+    outs = api.cs_batch_compress(blobs, pkg.default_parameters(png_optimize=True, png_optimization_level=level))
+    bad = 0
+    for b, o in zip(blobs, outs):
+        try:
+            ref = O.png_optimize(b, level)[0]
+        except O.PngError as e:
+            ref = e
+        if isinstance(ref, Exception):
+            if not (isinstance(o, Exception) and o.code == ref.code):
+                bad += 1
+        elif o != ref:
+            bad += 1
+    return bad
+
+
+def test_damaged_files_are_refused_or_decoded_like_the_oracle(api):
+    assert agree_with_oracle(api, damaged_pngs(1, 160)) == 0

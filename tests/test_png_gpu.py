@@ -95,3 +95,8 @@ def test_full_size_batch_by_properties(api):
         a, b = PIL.open(io.BytesIO(src)), PIL.open(io.BytesIO(out))
         assert a.mode == b.mode and np.array_equal(np.asarray(a), np.asarray(b))
     assert outs[3] == oracle_png(blobs[3])
+
+
+def test_damaged_files_are_refused_or_decoded_like_the_oracle(api):
+    from test_png_emul import agree_with_oracle, damaged_pngs
+    assert agree_with_oracle(api, damaged_pngs(2, 640)) == 0
