@@ -4,6 +4,9 @@
 //                neighbours, so the macroblocks of an image form a chain: ONE WAVE PER IMAGE walks them in raster order and
 //                its lanes are the blocks of the macroblock (0..15 luma, 16..19 U, 20..23 V); the 16 luma DCs meet by
 //                v_readlane for the Walsh-Hadamard transform, which every lane repeats for itself
+//   k_webp_stats / k_webp_probs   the frame's coefficient probabilities: every adaptive decision of the token walk is
+//                counted first (all blocks of all macroblocks in parallel: contexts come from masks), and an entry of the
+//                probability table is replaced when coding with the counted frequency pays for announcing it
 //   k_webp_code  W3: the boolean entropy coder is one serial chain per partition: one wave per (image, partition) runs it on
 //                its uniform side (lane 0 stores) -- the header partition and up to eight token partitions (macroblock rows
 //                interleaved), independent of each other because their contexts come from masks stored with the levels;
@@ -346,42 +349,56 @@ struct BoolEnc {
     __device__ __forceinline__ void bits(uint32_t v, int n) { while (n--) put(int((v >> n) & 1u), 128); }
     __device__ __forceinline__ void finish() { bits(0, 9 - nb_bits); nb_bits = 0; flush_bits(); }
 };
-__device__ static int put_coeffs(BoolEnc &e, int type, int ctx, const int16_t *lv, int first) {
+// the token walk of one block, either coding (CodeSink: the frame's probabilities) or only counting what it would code
+// (StatSink), which is how the frame's probabilities are chosen (oracle: put_coeffs / tsink)
+struct CodeSink {
+    BoolEnc &e;
+    const uint8_t *probs;
+    __device__ __forceinline__ void ad(int bit, int idx) { e.put(bit, probs[idx]); }
+    __device__ __forceinline__ void fx(int bit, int prob) { e.put(bit, prob); }
+};
+struct StatSink {
+    uint32_t *cnt;   // [1056][2] in LDS
+    __device__ __forceinline__ void ad(int bit, int idx) { atomicAdd(&cnt[2 * idx + (bit ? 1 : 0)], 1u); }
+    __device__ __forceinline__ void fx(int, int) {}
+};
+template <class S>
+__device__ static int put_coeffs(S &e, int type, int ctx, const int16_t *lv, int first) {
     int last = -1;
     for (int i = first; i < 16; i++) if (lv[i]) last = i;
     int n = first;
-    const uint8_t *p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
-    if (last < 0) { e.put(0, p[0]); return 0; }
-    e.put(1, p[0]);
+    int p = ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
+    if (last < 0) { e.ad(0, p + 0); return 0; }
+    e.ad(1, p + 0);
     while (n < 16) {
         const int c = lv[n++];
         const int sign = c < 0;
         int v = sign ? -c : c;
-        if (!v) { e.put(0, p[1]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
-        e.put(1, p[1]);
-        if (v == 1) { e.put(0, p[2]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
+        if (!v) { e.ad(0, p + 1); p = ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
+        e.ad(1, p + 1);
+        if (v == 1) { e.ad(0, p + 2); p = ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
         else {
-            e.put(1, p[2]);
-            if (v <= 4) { e.put(0, p[3]); if (v == 2) e.put(0, p[4]); else { e.put(1, p[4]); e.put(v == 4, p[5]); } }
+            e.ad(1, p + 2);
+            if (v <= 4) { e.ad(0, p + 3); if (v == 2) e.ad(0, p + 4); else { e.ad(1, p + 4); e.ad(v == 4, p + 5); } }
             else if (v <= 10) {
-                e.put(1, p[3]); e.put(0, p[6]);
-                if (v <= 6) { e.put(0, p[7]); e.put(v == 6, 159); }
-                else { e.put(1, p[7]); e.put(v >= 9, 165); e.put(!(v & 1), 145); }
+                e.ad(1, p + 3); e.ad(0, p + 6);
+                if (v <= 6) { e.ad(0, p + 7); e.fx(v == 6, 159); }
+                else { e.ad(1, p + 7); e.fx(v >= 9, 165); e.fx(!(v & 1), 145); }
             } else {
                 int mask; const uint8_t *tab;
-                e.put(1, p[3]); e.put(1, p[6]);
-                if (v < 3 + (8 << 1)) { e.put(0, p[8]); e.put(0, p[9]); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
-                else if (v < 3 + (8 << 2)) { e.put(0, p[8]); e.put(1, p[9]); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
-                else if (v < 3 + (8 << 3)) { e.put(1, p[8]); e.put(0, p[10]); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
-                else { e.put(1, p[8]); e.put(1, p[10]); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
-                while (mask) { e.put(!!(v & mask), *tab++); mask >>= 1; }
+                e.ad(1, p + 3); e.ad(1, p + 6);
+                if (v < 3 + (8 << 1)) { e.ad(0, p + 8); e.ad(0, p + 9); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
+                else if (v < 3 + (8 << 2)) { e.ad(0, p + 8); e.ad(1, p + 9); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
+                else if (v < 3 + (8 << 3)) { e.ad(1, p + 8); e.ad(0, p + 10); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
+                else { e.ad(1, p + 8); e.ad(1, p + 10); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
+                while (mask) { e.fx(!!(v & mask), *tab++); mask >>= 1; }
             }
-            p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
+            p = ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
         }
-        e.put(sign, 128);
+        e.fx(sign, 128);
         if (n == 16) return 1;
-        if (n > last) { e.put(0, p[0]); return 1; }
-        e.put(1, p[0]);
+        if (n > last) { e.ad(0, p + 0); return 1; }
+        e.ad(1, p + 0);
     }
     return 1;
 }
@@ -394,12 +411,76 @@ __device__ __forceinline__ static uint32_t nz_mask(const int16_t *L) { return ui
 __device__ __forceinline__ static int webp_parts(int mbh) { return mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1; }
 __device__ __forceinline__ static uint32_t webp_hdr_cap(const WebpImg &im) { return 2048u + im.mbw * im.mbh; }
 __device__ __forceinline__ static uint32_t webp_part_cap(const WebpImg &im) { return (im.out_cap - 128u - webp_hdr_cap(im)) / uint32_t(webp_parts(int(im.mbh))); }
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, uint8_t *scratch, uint32_t *part_size, const uint32_t *status) {
+// block k of a macroblock (0 the Y2 block, 1..16 luma, 17..24 chroma): coefficient type, first coded position, and the context
+// "how many of the blocks above / to the left have something to code" out of the three masks
+__device__ __forceinline__ static void block_info(int k, uint32_t cur, uint32_t top, uint32_t left, int &type, int &first, int &ctx) {
+    if (k == 0) { type = 1; first = 0; ctx = int((top & 1u) + (left & 1u)); return; }
+    if (k <= 16) {
+        const int b = k - 1, bx = b & 3, by = b >> 2;
+        const uint32_t t1 = by ? (cur >> (1 + (by - 1) * 4 + bx)) & 1u : (top >> (13 + bx)) & 1u;
+        const uint32_t l1 = bx ? (cur >> (by * 4 + bx)) & 1u : (left >> (4 + by * 4)) & 1u;
+        type = 0; first = 1; ctx = int(t1 + l1);
+        return;
+    }
+    const int b = k - 17, pl = b >> 2, bx = b & 1, by = (b >> 1) & 1, b0 = 17 + pl * 4;
+    const uint32_t t1 = by ? (cur >> (b0 + bx)) & 1u : (top >> (b0 + 2 + bx)) & 1u;
+    const uint32_t l1 = bx ? (cur >> (b0 + by * 2)) & 1u : (left >> (b0 + by * 2 + 1)) & 1u;
+    type = 2; first = 0; ctx = int(t1 + l1);
+}
+// counts of every adaptive decision of the token walk: one wave per macroblock row, lanes 0..24 = the blocks of one macroblock
+// at a time (the contexts come from the masks, so all blocks of all macroblocks are independent); LDS counters, then one
+// atomic per non-zero counter into the image's totals
+enum { WEBP_NPROB = 4 * 8 * 3 * 11 };
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *imgs, const int16_t *levels, uint32_t *stats) {
+    CSH_SHARED uint32_t cnt[2 * WEBP_NPROB];
+    const WebpImg im = imgs[blockIdx.y];
+    const int mbw = int(im.mbw), my = int(blockIdx.x);
+    if (my >= int(im.mbh)) return;
+    LFOR(l) for (int i = l; i < 2 * WEBP_NPROB; i += 64) cnt[i] = 0;
+    CSP_WAVE_SYNC();
+    const int16_t *row = levels + im.lev_off + size_t(my) * mbw * 400;
+    for (int mx = 0; mx < mbw; mx++) {
+        const int16_t *L = row + size_t(mx) * 400;
+        const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * 400) : 0u, left = mx ? nz_mask(L - 400) : 0u;
+        LFOR(l) if (l < 25) {
+            int type, first, ctx;
+            block_info(l, cur, top, left, type, first, ctx);
+            StatSink sink{cnt};
+            put_coeffs(sink, type, ctx, L + l * 16, first);
+        }
+    }
+    CSP_WAVE_SYNC();
+    uint32_t *dst = stats + size_t(im.image) * 2 * WEBP_NPROB;
+    LFOR(l) for (int i = l; i < 2 * WEBP_NPROB; i += 64) if (cnt[i]) atomicAdd(&dst[i], cnt[i]);
+}
+// the frame's coefficient probabilities (oracle: bool_cost / choose_probs): one lane per entry
+__device__ __forceinline__ static uint32_t bool_cost(int p) {
+    const int l = 31 - __clz(uint32_t(p));
+    return uint32_t(256 * (8 - l)) - (((uint32_t(p) << 8) >> l) - 256u);
+}
+__global__ void __launch_bounds__(256) k_webp_probs(const WebpImg *imgs, const uint32_t *stats, uint8_t *probs, uint8_t *update) {
+    const WebpImg &im = imgs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= WEBP_NPROB) return;
+    const uint64_t n0 = stats[(size_t(im.image) * WEBP_NPROB + i) * 2], n1 = stats[(size_t(im.image) * WEBP_NPROB + i) * 2 + 1], total = n0 + n1;
+    const int oldp = kVp8CoefProbs[i], up = kVp8CoefUpdateProbs[i];
+    int np = total ? int(255 - n1 * 255 / total) : 255;
+    if (np < 1) np = 1;
+    const uint64_t old_cost = n0 * bool_cost(oldp) + n1 * bool_cost(256 - oldp) + bool_cost(up);
+    const uint64_t new_cost = n0 * bool_cost(np) + n1 * bool_cost(256 - np) + bool_cost(256 - up) + 8 * 256;
+    const bool use = new_cost < old_cost;
+    update[size_t(im.image) * WEBP_NPROB + i] = use ? 1 : 0;
+    probs[size_t(im.image) * WEBP_NPROB + i] = uint8_t(use ? np : oldp);
+}
+
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, const uint8_t *probs_all, const uint8_t *update_all, uint8_t *scratch,
+                                                                 uint32_t *part_size, const uint32_t *status) {
     const WebpImg im = imgs[blockIdx.x];
     if (status[im.image]) return;
     const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh), part = int(blockIdx.y) - 1;
     if (part >= nparts) return;
     const int16_t *lev = levels + im.lev_off;
+    const uint8_t *probs = probs_all + size_t(im.image) * WEBP_NPROB, *update = update_all + size_t(im.image) * WEBP_NPROB;
     uint8_t *base = scratch + im.out_off;
     BoolEnc e;
     if (part < 0) {
@@ -411,7 +492,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
         e.bits(uint32_t(im.qi), 7);
         for (int i = 0; i < 5; i++) e.bits(0, 1);           // no quantiser deltas
         e.bits(0, 1);                                       // refresh_entropy_probs
-        for (int i = 0; i < 4 * 8 * 3 * 11; i++) e.put(0, kVp8CoefUpdateProbs[i]);   // keep the default coefficient probabilities
+        for (int i = 0; i < WEBP_NPROB; i++) { e.put(update[i], kVp8CoefUpdateProbs[i]); if (update[i]) e.bits(probs[i], 8); }   // the frame's coefficient probabilities
         e.bits(0, 1);                                       // no skip flags
         for (int i = 0; i < mbw * mbh; i++) {
             const int16_t *L = lev + size_t(i) * 400;
@@ -426,21 +507,12 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
             for (int mx = 0; mx < mbw; mx++) {
                 const int16_t *L = lev + (size_t(my) * mbw + mx) * 400;
                 const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * 400) : 0u, left = mx ? nz_mask(L - 400) : 0u;
-                put_coeffs(e, 1, int((top & 1u) + (left & 1u)), L, 0);
-                for (int by = 0; by < 4; by++)
-                    for (int bx = 0; bx < 4; bx++) {
-                        const uint32_t t1 = by ? (cur >> (1 + (by - 1) * 4 + bx)) & 1u : (top >> (13 + bx)) & 1u;
-                        const uint32_t l1 = bx ? (cur >> (by * 4 + bx)) & 1u : (left >> (4 + by * 4)) & 1u;
-                        put_coeffs(e, 0, int(t1 + l1), L + (1 + by * 4 + bx) * 16, 1);
-                    }
-                for (int pl = 0; pl < 2; pl++)
-                    for (int by = 0; by < 2; by++)
-                        for (int bx = 0; bx < 2; bx++) {
-                            const int b0 = 17 + pl * 4;
-                            const uint32_t t1 = by ? (cur >> (b0 + bx)) & 1u : (top >> (b0 + 2 + bx)) & 1u;
-                            const uint32_t l1 = bx ? (cur >> (b0 + by * 2)) & 1u : (left >> (b0 + by * 2 + 1)) & 1u;
-                            put_coeffs(e, 2, int(t1 + l1), L + (b0 + by * 2 + bx) * 16, 0);
-                        }
+                CodeSink sink{e, probs};
+                for (int k = 0; k < 25; k++) {
+                    int type, first, ctx;
+                    block_info(k, cur, top, left, type, first, ctx);
+                    put_coeffs(sink, type, ctx, L + k * 16, first);
+                }
             }
     }
     e.finish();
@@ -487,9 +559,12 @@ void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max
 void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work, int16_t *levels) {
     if (nimg) CSH_LAUNCH(k_webp_mb, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, work, levels);
 }
-void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, const int16_t *levels, uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
+void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
+                      uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
     if (!nimg) return;
-    CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, scratch, part_size, status);
+    CSH_LAUNCH(k_webp_stats, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, stats);
+    CSH_LAUNCH(k_webp_probs, dim3((WEBP_NPROB + 255) / 256, nimg), dim3(256), st, imgs, stats, probs, update);
+    CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
     CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
 }
 

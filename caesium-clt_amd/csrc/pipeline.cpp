@@ -134,7 +134,9 @@ struct csh_batch {
     DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<csw::WebpImg> d_wimgs;
     DevBuf<uint8_t> d_wwork, d_wscratch;
-    DevBuf<uint32_t> d_wpart;
+    DevBuf<uint32_t> d_wpart, d_wstats;
+    DevBuf<uint8_t> d_wprobs, d_wupdate;
+    uint32_t wmax_mbh = 0;
     DevBuf<int16_t> d_wlevels;
     DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
     DevBuf<uint16_t> d_eobrun;
@@ -686,6 +688,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 wi.y_off = take(ly); wi.u_off = take(lc); wi.v_off = take(lc); wi.ry_off = take(ly); wi.ru_off = take(lc); wi.rv_off = take(lc);
                 wi.lev_off = b->wlevels; b->wlevels += uint64_t(wi.mbw) * wi.mbh * 400;
                 b->wmax_luma = std::max<uint32_t>(b->wmax_luma, uint32_t(ly));
+                b->wmax_mbh = std::max(b->wmax_mbh, wi.mbh);
                 b->wimgs.push_back(wi);
             }
         }
@@ -817,7 +820,10 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     }
     off[b->nimg] = out_bytes;
     if (b->d_out.n < out_bytes + 64 && b->d_out.alloc(out_bytes + 64)) return -1;
-    if ((b->d_wscratch.n < out_bytes + 64 && b->d_wscratch.alloc(out_bytes + 64)) || (b->d_wpart.n < size_t(b->nimg) * 9 + 9 && b->d_wpart.alloc(size_t(b->nimg) * 9 + 9))) return -1;
+    if ((b->d_wscratch.n < out_bytes + 64 && b->d_wscratch.alloc(out_bytes + 64)) || (b->d_wpart.n < size_t(b->nimg) * 9 + 9 && b->d_wpart.alloc(size_t(b->nimg) * 9 + 9)) ||
+        (b->d_wstats.n < size_t(b->nimg) * 2112 + 8 && (b->d_wstats.alloc(size_t(b->nimg) * 2112 + 8) || b->d_wprobs.alloc(size_t(b->nimg) * 1056 + 8) || b->d_wupdate.alloc(size_t(b->nimg) * 1056 + 8))))
+        return -1;
+    if (b->d_wstats.zero(st)) return -1;
     if (b->d_wimgs.upload(b->wimgs, st) || (b->d_wwork.n < b->wwork_bytes + 64 && b->d_wwork.alloc(b->wwork_bytes + 64)) ||
         (b->d_wlevels.n < b->wlevels + 64 && b->d_wlevels.alloc(b->wlevels + 64)))
         return -1;
@@ -825,7 +831,8 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     if (b->d_img_size.zero(st)) return -1;
     csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
     csw::launch_webp_mb(st, b->d_wimgs.p, nimg, b->d_wwork.p, b->d_wlevels.p);
-    csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->d_wlevels.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_img_size.p, b->d_status.p);
+    csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p,
+                          b->d_img_size.p, b->d_status.p);
     CSH_CHECK(hipEventRecord(ev[++slot], st));
     CSH_CHECK(hipStreamSynchronize(st));
     CSH_CHECK(hipGetLastError());

@@ -8,8 +8,8 @@
  * (libwebp-sys 0.9.5, Cargo.lock:956) at its default method 4: analysis, segments, intra-mode RD search (i16 / i4 / uv),
  * trellis, loop-filter strength search.  None of that source is available.  This file is a first, MINIMAL conformant VP8
  * encoder laid out for the GPU: every macroblock is coded i16x16 (DC / V / H / TM by least transformed residual) + one chroma
- * mode chosen the same way, one quantiser index, no i4x4, no segments, no loop filter, the default coefficient
- * probabilities, up to eight token partitions (rows interleaved).  What is pinned:
+ * mode chosen the same way, one quantiser index, no i4x4, no segments, no loop filter, coefficient probabilities
+ * chosen from the frame's own token counts, up to eight token partitions (rows interleaved).  What is pinned:
  *   - the bitstream is valid: libwebp (through Pillow) decodes every output;
  *   - the decoder-side arithmetic (dequantisation, inverse WHT / DCT, DC prediction, RFC 6386) is restated exactly, which
  *     the tests check by comparing this file's own reconstruction with libwebp's decoded YUV -> the encoder and any
@@ -152,45 +152,70 @@ static void be_flush(boolenc *e) {
 }
 
 /* ------------------------------------------------------------------------------------------------ tokens (RFC 6386 section 13) */
-/* one block: coefficient levels in scan order, first = 1 for i16 luma blocks (their DC travels in the Y2 block) */
-static int put_coeffs(boolenc *e, int type, int ctx, const int16_t *lv, int first) {
+/* one block: coefficient levels in scan order, first = 1 for i16 luma blocks (their DC travels in the Y2 block).  The walk
+   either codes (e != NULL, with the frame's probabilities) or only counts what it would code (stats[2 * index + bit]), which is
+   how the frame's probabilities are chosen. */
+typedef struct { boolenc *e; const uint8_t *probs; uint32_t *stats; } tsink;
+static void ad(tsink *s, int bit, int idx) { if (s->stats) s->stats[2 * idx + (bit ? 1 : 0)]++; else be_put(s->e, bit, s->probs[idx]); }
+static void fx(tsink *s, int bit, int prob) { if (!s->stats) be_put(s->e, bit, prob); }
+static int put_coeffs(tsink *e, int type, int ctx, const int16_t *lv, int first) {
     int last = -1;
     for (int i = first; i < 16; i++) if (lv[i]) last = i;
     int n = first;
-    const uint8_t *p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
-    if (last < 0) { be_put(e, 0, p[0]); return 0; }
-    be_put(e, 1, p[0]);
+    int p = ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
+    if (last < 0) { ad(e, 0, p + 0); return 0; }
+    ad(e, 1, p + 0);
     while (n < 16) {
         const int c = lv[n++];
         const int sign = c < 0;
         int v = sign ? -c : c;
-        if (!v) { be_put(e, 0, p[1]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
-        be_put(e, 1, p[1]);
-        if (v == 1) { be_put(e, 0, p[2]); p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
+        if (!v) { ad(e, 0, p + 1); p = ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
+        ad(e, 1, p + 1);
+        if (v == 1) { ad(e, 0, p + 2); p = ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
         else {
-            be_put(e, 1, p[2]);
-            if (v <= 4) { be_put(e, 0, p[3]); if (v == 2) be_put(e, 0, p[4]); else { be_put(e, 1, p[4]); be_put(e, v == 4, p[5]); } }
+            ad(e, 1, p + 2);
+            if (v <= 4) { ad(e, 0, p + 3); if (v == 2) ad(e, 0, p + 4); else { ad(e, 1, p + 4); ad(e, v == 4, p + 5); } }
             else if (v <= 10) {
-                be_put(e, 1, p[3]); be_put(e, 0, p[6]);
-                if (v <= 6) { be_put(e, 0, p[7]); be_put(e, v == 6, 159); }
-                else { be_put(e, 1, p[7]); be_put(e, v >= 9, 165); be_put(e, !(v & 1), 145); }
+                ad(e, 1, p + 3); ad(e, 0, p + 6);
+                if (v <= 6) { ad(e, 0, p + 7); fx(e, v == 6, 159); }
+                else { ad(e, 1, p + 7); fx(e, v >= 9, 165); fx(e, !(v & 1), 145); }
             } else {
                 int mask; const uint8_t *tab;
-                be_put(e, 1, p[3]); be_put(e, 1, p[6]);
-                if (v < 3 + (8 << 1)) { be_put(e, 0, p[8]); be_put(e, 0, p[9]); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
-                else if (v < 3 + (8 << 2)) { be_put(e, 0, p[8]); be_put(e, 1, p[9]); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
-                else if (v < 3 + (8 << 3)) { be_put(e, 1, p[8]); be_put(e, 0, p[10]); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
-                else { be_put(e, 1, p[8]); be_put(e, 1, p[10]); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
-                while (mask) { be_put(e, !!(v & mask), *tab++); mask >>= 1; }
+                ad(e, 1, p + 3); ad(e, 1, p + 6);
+                if (v < 3 + (8 << 1)) { ad(e, 0, p + 8); ad(e, 0, p + 9); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
+                else if (v < 3 + (8 << 2)) { ad(e, 0, p + 8); ad(e, 1, p + 9); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
+                else if (v < 3 + (8 << 3)) { ad(e, 1, p + 8); ad(e, 0, p + 10); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
+                else { ad(e, 1, p + 8); ad(e, 1, p + 10); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
+                while (mask) { fx(e, !!(v & mask), *tab++); mask >>= 1; }
             }
-            p = kVp8CoefProbs + ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
+            p = ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
         }
-        be_put(e, sign, 128);
+        fx(e, sign, 128);
         if (n == 16) return 1;
-        if (n > last) { be_put(e, 0, p[0]); return 1; }
-        be_put(e, 1, p[0]);
+        if (n > last) { ad(e, 0, p + 0); return 1; }
+        ad(e, 1, p + 0);
     }
     return 1;
+}
+/* cost of a boolean with probability p / 256 in 1/256 bit: 256 * (8 - log2 p), log2 by its integer part and a linear
+   fraction -- integers only, so that every build decides alike */
+static uint32_t bool_cost(int p) {
+    int l = 31 - __builtin_clz((unsigned)p);
+    return (uint32_t)(256 * (8 - l) - ((((unsigned)p << 8) >> l) - 256));
+}
+/* the frame's coefficient probabilities: for each of the 1056 entries the probability the counts ask for, taken when coding
+   with it (plus the 8 bits and the flag that announce it) is cheaper than keeping the default */
+static void choose_probs(const uint32_t *stats, uint8_t *probs, uint8_t *update) {
+    for (int i = 0; i < 4 * 8 * 3 * 11; i++) {
+        const uint64_t n0 = stats[2 * i], n1 = stats[2 * i + 1], total = n0 + n1;
+        const int oldp = kVp8CoefProbs[i], up = kVp8CoefUpdateProbs[i];
+        int np = total ? (int)(255 - n1 * 255 / total) : 255;
+        if (np < 1) np = 1;
+        const uint64_t old_cost = n0 * bool_cost(oldp) + n1 * bool_cost(256 - oldp) + bool_cost(up);
+        const uint64_t new_cost = n0 * bool_cost(np) + n1 * bool_cost(256 - np) + bool_cost(256 - up) + 8 * 256;
+        update[i] = (uint8_t)(new_cost < old_cost);
+        probs[i] = (uint8_t)(update[i] ? np : oldp);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ the frame */
@@ -207,6 +232,27 @@ int cso_webp_quality_to_qi(int quality) {
 /* scalar quantiser with libwebp's rounding offsets (bias / 256 of a step instead of one half: luma AC 110, Y2 DC 96 / AC 108,
    chroma DC 110 / AC 115 -- its kBiasMatrices), levels capped at 2047 */
 static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
+
+/* every macroblock's blocks in coding order; row r goes to sink[r mod nsinks] (one = a single sink for all rows) */
+static void token_walk(tsink *one, tsink *sinks, int nsinks, const int16_t *levels, int mbw, int mbh) {
+    uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
+    for (int my = 0; my < mbh; my++) {
+        uint8_t left[9]; memset(left, 0, 9);
+        tsink *e = one ? one : &sinks[my & (nsinks - 1)];
+        for (int mx = 0; mx < mbw; mx++) {
+            const int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
+            uint8_t *tp = top + (size_t)mx * 9;
+            tp[8] = left[8] = (uint8_t)put_coeffs(e, 1, tp[8] + left[8], L, 0);
+            for (int by = 0; by < 4; by++)
+                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(e, 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1);
+            for (int pl = 0; pl < 2; pl++)
+                for (int by = 0; by < 2; by++)
+                    for (int bx = 0; bx < 2; bx++)
+                        tp[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = (uint8_t)put_coeffs(e, 2, tp[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0);
+        }
+    }
+    free(top);
+}
 
 /* One N x N intra prediction (N = 16 luma, 8 chroma) from the reconstruction around it (RFC 6386 section 12.2).  Modes: 0 DC,
    1 V (the row above), 2 H (the column to the left), 3 TM (above + left - corner, clipped).  Returns the chosen mode and its
@@ -309,6 +355,15 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
                 }
             }
         }
+    /* what the token walk will code, counted first: the frame's coefficient probabilities come from it */
+    uint8_t probs[4 * 8 * 3 * 11], update[4 * 8 * 3 * 11];
+    {
+        uint32_t *stats = (uint32_t *)calloc(2 * 4 * 8 * 3 * 11, sizeof(uint32_t));
+        tsink cnt = {NULL, NULL, stats};
+        token_walk(&cnt, NULL, 1, levels, mbw, mbh);
+        choose_probs(stats, probs, update);
+        free(stats);
+    }
     /* partition 0: frame header + per-macroblock modes; partition 1: tokens */
     boolenc h;
     be_init(&h);
@@ -323,7 +378,7 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     be_bits(&h, (uint32_t)qi, 7);
     for (int i = 0; i < 5; i++) be_bits(&h, 0, 1);   /* no quantiser deltas */
     be_bits(&h, 0, 1);            /* refresh_entropy_probs */
-    for (int i = 0; i < 4 * 8 * 3 * 11; i++) be_put(&h, 0, kVp8CoefUpdateProbs[i]);   /* keep the default coefficient probabilities */
+    for (int i = 0; i < 4 * 8 * 3 * 11; i++) { be_put(&h, update[i], kVp8CoefUpdateProbs[i]); if (update[i]) be_bits(&h, probs[i], 8); }   /* the frame's coefficient probabilities */
     be_bits(&h, 0, 1);            /* no skip flags */
     for (int i = 0; i < mbw * mbh; i++) {
         const int ym = modes[2 * i], cm = modes[2 * i + 1];
@@ -338,25 +393,14 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     const int nparts = mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1;
     boolenc t[8];
     for (int p = 0; p < nparts; p++) be_init(&t[p]);
-    uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
-    for (int my = 0; my < mbh; my++) {
-        uint8_t left[9]; memset(left, 0, 9);
-        boolenc *e = &t[my & (nparts - 1)];
-        for (int mx = 0; mx < mbw; mx++) {
-            const int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
-            uint8_t *tp = top + (size_t)mx * 9;
-            tp[8] = left[8] = (uint8_t)put_coeffs(e, 1, tp[8] + left[8], L, 0);
-            for (int by = 0; by < 4; by++)
-                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(e, 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1);
-            for (int pl = 0; pl < 2; pl++)
-                for (int by = 0; by < 2; by++)
-                    for (int bx = 0; bx < 2; bx++)
-                        tp[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = (uint8_t)put_coeffs(e, 2, tp[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0);
-        }
+    {
+        tsink code[8];
+        for (int p = 0; p < nparts; p++) { code[p].e = &t[p]; code[p].probs = probs; code[p].stats = NULL; }
+        token_walk(NULL, code, nparts, levels, mbw, mbh);
     }
     size_t tok = 0;
     for (int p = 0; p < nparts; p++) { be_flush(&t[p]); tok += t[p].pos; }
-    free(top); free(levels); free(modes);
+    free(levels); free(modes);
     if (own) { free(ry); free(ru); free(rv); }
     /* RIFF / WEBP / "VP8 " : frame tag, start code, dimensions, partition 0, the sizes of all token partitions but the last, the partitions */
     const size_t vp8 = 10 + h.pos + 3 * (size_t)(nparts - 1) + tok, padded = vp8 + (vp8 & 1), total = 12 + 8 + padded;
