@@ -69,3 +69,23 @@ def test_entry_point_and_refusals(api):
     with pytest.raises(Exception) as e:
         api.convert_in_memory(src, pkg.default_parameters(webp_quality=85, webp_lossless=True), WEBP)
     assert e.value.code == 10201
+
+
+def test_damaged_jpegs_convert_like_the_oracle_or_fail(api):
+    """the JPEG side of a conversion sees the same damaged inputs as the JPEG path: whatever decodes must give the oracle's WebP"""
+    from test_pipeline_emul import fuzzed_blobs
+    pkg = package()
+    blobs = fuzzed_blobs(11, 24, True)
+    outs = api.batch_convert(blobs, pkg.default_parameters(webp_quality=75), WEBP)
+    decoded = 0
+    for b, o in zip(blobs, outs):
+        try:
+            want = oracle_jpeg_to_webp(b, 75)
+        except Exception:
+            want = None
+        if want is None:
+            assert isinstance(o, Exception)
+        else:
+            assert o == want
+            decoded += 1
+    assert decoded >= 4
