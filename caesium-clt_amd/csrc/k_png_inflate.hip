@@ -9,6 +9,8 @@
 //   * match copies: up to 258 bytes move 64 per step, out of a 32 KiB ring in LDS that holds the most recent output (only a
 //     match further back than the ring -- the last 258 bytes of the window -- reads the flushed copy in HBM);
 //   * the flush itself: whole KiB leave the ring as 64 x 16-byte stores.
+// Adam7 inputs: the stream holds seven reduced images; each is reconstructed as a job of its own, then k_png_deinterlace
+// gathers the pixels into place (the output is never interlaced).
 // Codes longer than the root width take the bit-serial canonical walk (rare symbols by construction).
 #include "png_kernels.h"
 #include "png_wave.h"
@@ -114,8 +116,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
     const int image = blockIdx.x;
     if (image >= nimg || status[image]) return;
     const PngImg im = imgs[image];
-    uint8_t *out = raw + im.raw_off;
-    const uint64_t cap = im.raw_len;
+    uint8_t *out = raw + im.inflate_off;
+    const uint64_t cap = im.inflate_len;
     PosReader rd;
     rd.begin(idat + im.idat_off, im.idat_len, 16);   // the host checked the two zlib header bytes
     uint64_t pos = 0, flushed = 0;
@@ -302,13 +304,14 @@ __device__ __forceinline__ static int paeth(int a, int b, int c) {
     const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngImg *imgs, int nimg, const uint8_t *raw, uint8_t *pix, uint32_t *status) {
-    const int image = blockIdx.x;
-    if (image >= nimg || status[image]) return;
-    const PngImg im = imgs[image];
-    const uint8_t *src = raw + im.raw_off;
-    uint8_t *dst = pix + im.pix_off;
-    const uint32_t W = im.rowbytes, bpp = im.bpp, npx = W / bpp, H = im.height;
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass *jobs, int njobs, uint8_t *work, uint32_t *status) {
+    if (int(blockIdx.x) >= njobs) return;
+    const PngPass job = jobs[blockIdx.x];
+    const int image = int(job.image);
+    if (status[image]) return;
+    const uint8_t *src = work + job.src_off;
+    uint8_t *dst = work + job.dst_off;
+    const uint32_t W = job.rowbytes, bpp = job.bpp, npx = W / bpp, H = job.height;
     bool bad = false;
     for (uint32_t y0 = 0; y0 < H; y0 += 64) {
         LV<uint32_t> ft;
@@ -358,8 +361,51 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngImg 
 void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint32_t *status) {
     if (nimg) CSH_LAUNCH(k_png_inflate, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, idat, raw, status);
 }
-void launch_png_unfilter(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *raw, uint8_t *pix, uint32_t *status) {
-    if (nimg) CSH_LAUNCH(k_png_unfilter, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, raw, pix, status);
+void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint8_t *work, uint32_t *status) {
+    if (njobs) CSH_LAUNCH(k_png_unfilter, dim3(njobs), dim3(CSP_WAVE_THREADS), st, jobs, njobs, work, status);
+}
+
+// ---- Adam7: every pixel of the image gathers itself out of the pass it belongs to (no scatter, so sub-byte samples need no
+// atomics): one lane per pixel for whole-byte pixels, one lane per byte of the row otherwise
+__device__ __forceinline__ static int adam7_pass(uint32_t ox, uint32_t oy) {
+    return (oy & 1u) ? 6 : (ox & 1u) ? 5 : (oy & 2u) ? 4 : (ox & 2u) ? 3 : (oy & 4u) ? 2 : (ox & 4u) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_png_deinterlace(const PngImg *imgs, const PngAdam7 *jobs, uint8_t *work, const uint32_t *status) {
+    const PngAdam7 &a = jobs[blockIdx.y];
+    if (status[a.image]) return;
+    const PngImg &im = imgs[a.image];
+    const uint32_t XS[7] = {0, 4, 0, 2, 0, 1, 0}, YS[7] = {0, 0, 4, 0, 2, 0, 1}, DXs[7] = {3, 3, 2, 2, 1, 1, 0}, DYs[7] = {3, 3, 3, 2, 2, 1, 1};   // steps as shifts
+    const uint32_t bits = a.bits;
+    uint8_t *dst = work + im.pix_off;
+    if (bits >= 8) {
+        const uint32_t bytes = bits >> 3;
+        const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+        if (i >= uint64_t(im.width) * im.height) return;
+        const uint32_t oy = uint32_t(i / im.width), ox = uint32_t(i - uint64_t(oy) * im.width);
+        const int p = adam7_pass(ox, oy);
+        const uint32_t x = (ox - XS[p]) >> DXs[p], y = (oy - YS[p]) >> DYs[p];
+        const uint8_t *s = work + a.base[p] + uint64_t(y) * a.prb[p] + uint64_t(x) * bytes;
+        uint8_t *d = dst + uint64_t(oy) * im.rowbytes + uint64_t(ox) * bytes;
+        for (uint32_t k = 0; k < bytes; k++) d[k] = s[k];
+    } else {
+        const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+        if (i >= uint64_t(im.rowbytes) * im.height) return;
+        const uint32_t oy = uint32_t(i / im.rowbytes), bx = uint32_t(i - uint64_t(oy) * im.rowbytes), per = 8u / bits;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t ox = bx * per + k;
+            if (ox >= im.width) break;
+            const int p = adam7_pass(ox, oy);
+            const uint32_t x = (ox - XS[p]) >> DXs[p], y = (oy - YS[p]) >> DYs[p];
+            const uint64_t sb = uint64_t(x) * bits;
+            const uint32_t sample = (uint32_t(work[a.base[p] + uint64_t(y) * a.prb[p] + (sb >> 3)]) >> (8u - bits - uint32_t(sb & 7u))) & ((1u << bits) - 1u);
+            v |= sample << (8u - bits - k * bits);
+        }
+        dst[i] = uint8_t(v);
+    }
+}
+void launch_png_deinterlace(hipStream_t st, const PngImg *imgs, const PngAdam7 *jobs, int njobs, uint64_t max_items, uint8_t *work, const uint32_t *status) {
+    if (njobs && max_items) CSH_LAUNCH(k_png_deinterlace, dim3(unsigned((max_items + 255) / 256), njobs), dim3(256), st, imgs, jobs, work, status);
 }
 
 }  // namespace csp

@@ -40,6 +40,7 @@ struct PngItem {
     size_t file_size = 0;
     uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0, channels = 0, depth = 0, ctype = 0;
     bool no_reduce = false;   // a carried chunk is tied to the colour type (tRNS, bKGD, sBIT)
+    bool interlace = false;   // Adam7 input (the output never is)
     std::vector<std::pair<size_t, size_t>> idat;   // (offset, length) of every IDAT payload in the input
     size_t idat_len = 0;
     std::vector<uint8_t> prefix, suffix;            // output bytes in front of / behind the IDAT chunk
@@ -77,7 +78,7 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
             case 2: case 4: case 6: ok = depth == 8 || depth == 16; break;
             }
             if (!ok) return fail(CS_ERR_BAD_PNG, "bad colour type / bit depth");
-            if (d[12]) return fail(CS_ERR_UNSUPPORTED, "interlaced PNG has no device path in this build");
+            it.interlace = d[12] != 0;
             const uint64_t bits = uint64_t(chans[ctype]) * uint64_t(depth);
             it.bpp = bits >= 8 ? uint32_t(bits / 8) : 1u;
             it.channels = uint32_t(chans[ctype]); it.depth = uint32_t(depth); it.ctype = uint32_t(ctype);
@@ -140,6 +141,9 @@ struct csp_batch {
     std::vector<PngImg> imgs;
     std::vector<uint8_t> fixed;
     std::vector<uint32_t> flags0;   // reductions each image's format allows
+    std::vector<PngPass> passes;    // reconstruction jobs: one per image, seven per Adam7 image
+    std::vector<PngAdam7> adam7;
+    uint64_t adam7_items = 0;
     bool reduced = false;
     uint32_t n_reduced = 0;
     PngPlan plan{};
@@ -149,6 +153,8 @@ struct csp_batch {
     DevBuf<PngImg> d_imgs;
     DevBuf<uint8_t> d_idat, d_work, d_streams, d_out, d_fixed, d_choice;   // d_work: inflated streams, then pixels (one buffer: a reduction swaps the two regions of an image)
     DevBuf<ReduceJob> d_jobs;
+    DevBuf<PngPass> d_passes;
+    DevBuf<PngAdam7> d_adam7;
     DevBuf<uint32_t> d_flags;
     DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_file_len, d_adler, d_crc;
     DevBuf<uint64_t> d_scores, d_trial_bytes;
@@ -214,7 +220,7 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
     b->inputs.resize(count);
     PinnedBytes idat_pool;
     std::vector<uint8_t> &fixed = b->fixed;
-    size_t raw_bytes = 0, pix_bytes = 0, stream_bytes = 256, out_bytes = 0;   // the tokenizer reads up to 8 bytes in front of a stream
+    size_t work_bytes = 0, stream_bytes = 256, out_bytes = 0;   // the tokenizer reads up to 8 bytes in front of a stream
     uint64_t nchunk_recs = 0;
     for (size_t i = 0; i < count; i++) {
         PngItem &it = b->items[i];
@@ -233,8 +239,40 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
             idat_pool.pending.push_back({at, inputs[i].data, 0, end - at});
             idat_pool.n = end;
         }
-        im.raw_off = raw_bytes; raw_bytes += align_up(im.raw_len + CSP_RAW_SLACK, 256);
-        im.pix_off = pix_bytes; pix_bytes += align_up(uint64_t(it.height) * it.rowbytes + 64, 256);
+        {   // two regions of the work buffer per image.  Plain image: A takes the inflated stream, B the pixels.  Adam7: A takes the
+            // seven passes' streams, B their reconstructed rows, and the gather puts the image back into A
+            static const uint32_t XS[7] = {0, 4, 0, 2, 0, 1, 0}, YS[7] = {0, 0, 4, 0, 2, 0, 1}, DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+            const uint64_t bits = uint64_t(it.channels) * it.depth, image_bytes = uint64_t(it.height) * it.rowbytes;
+            uint64_t pass_stream = 0, pass_pixels = 0;
+            uint32_t pw[7], ph[7], prb[7];
+            for (int p = 0; p < 7; p++) {
+                pw[p] = (it.width + DX[p] - 1 - XS[p]) / DX[p]; ph[p] = (it.height + DY[p] - 1 - YS[p]) / DY[p];
+                prb[p] = (pw[p] && ph[p]) ? uint32_t((uint64_t(pw[p]) * bits + 7) / 8) : 0u;
+                if (prb[p]) { pass_stream += uint64_t(ph[p]) * (1 + prb[p]); pass_pixels += uint64_t(ph[p]) * prb[p]; }
+            }
+            im.inflate_len = it.interlace ? pass_stream : im.raw_len;
+            const uint64_t A = work_bytes; work_bytes += align_up(std::max(im.inflate_len, image_bytes) + CSP_RAW_SLACK, 256);
+            const uint64_t B = work_bytes; work_bytes += align_up(std::max(image_bytes, it.interlace ? pass_pixels : 0) + 64, 256);
+            im.inflate_off = A;
+            const uint32_t image_index = uint32_t(b->imgs.size());
+            if (!it.interlace) {
+                im.raw_off = A; im.pix_off = B;
+                b->passes.push_back(PngPass{image_index, it.rowbytes, it.height, it.bpp, A, B});
+            } else {
+                im.pix_off = A; im.raw_off = B;
+                PngAdam7 a{};
+                a.image = image_index; a.bits = uint32_t(bits);
+                uint64_t so = A, po = B;
+                for (int p = 0; p < 7; p++) {
+                    a.base[p] = po; a.prb[p] = prb[p];
+                    if (!prb[p]) continue;
+                    b->passes.push_back(PngPass{image_index, prb[p], ph[p], it.bpp, so, po});
+                    so += uint64_t(ph[p]) * (1 + prb[p]); po += uint64_t(ph[p]) * prb[p];
+                }
+                b->adam7.push_back(a);
+                b->adam7_items = std::max<uint64_t>(b->adam7_items, bits >= 8 ? uint64_t(it.width) * it.height : image_bytes);
+            }
+        }
         im.stream_stride = align_up(im.raw_len + 64, 256);
         im.stream_off = stream_bytes; stream_bytes += im.stream_stride * size_t(nslots);
         im.row_base = b->total_rows; b->total_rows += it.height;
@@ -264,11 +302,10 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         uint32_t r = 0;
         for (int i = 0; i < nimg; i++) for (uint32_t y = 0; y < b->imgs[i].height; y++) row_image[r++] = uint32_t(i);
     }
-    for (int i = 0; i < nimg; i++) b->imgs[i].pix_off += raw_bytes;   // pixels live behind the inflated streams in one buffer
     if (upload_chunk_index(b.get())) return CS_ERR_NO_DEVICE;
     if (b->d_imgs.upload(b->imgs, st) || b->d_row_image.upload(row_image, st) || b->d_fixed.upload(fixed, st) || b->d_flags.alloc(size_t(nimg) + 1) || b->d_jobs.alloc(size_t(nimg) + 1))
         return CS_ERR_NO_DEVICE;
-    if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_work.alloc(raw_bytes + pix_bytes + 256) || b->d_streams.alloc(stream_bytes + 256) ||
+    if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_work.alloc(work_bytes + 256) || b->d_passes.upload(b->passes, st) || b->d_adam7.upload(b->adam7, st) || b->d_streams.alloc(stream_bytes + 256) ||
         b->d_out.alloc(out_bytes + 256) || b->d_choice.alloc(size_t(5) * b->total_rows + 1) || b->d_status.alloc(size_t(nimg) + 1) || b->d_file_len.alloc(size_t(nimg) + 1) ||
         b->d_adler.alloc(2 * size_t(b->total_chunks) + 2) || b->d_crc.alloc(size_t(nimg) * b->max_pieces + 1) || b->d_scores.alloc(size_t(b->total_rows) * 25 + 1) ||
         b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
@@ -349,7 +386,10 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     int k = 0;
     auto mark = [&]() { (void)hipEventRecord(b->ev[k++], st); };
     mark(); if (!b->reduced) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, b->d_status.p);
-    mark(); if (!b->reduced) launch_png_unfilter(st, b->d_imgs.p, nimg, b->d_work.p, b->d_work.p, b->d_status.p);
+    mark(); if (!b->reduced) {
+        launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), b->d_work.p, b->d_status.p);
+        launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);
+    }
     mark(); if (!b->reduced && reduce_step(b)) return CS_ERR_NO_DEVICE;
     d.total_chunks = b->total_chunks; d.total_groups = b->total_groups;
     d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;

@@ -25,7 +25,10 @@ struct PngImg {
     uint32_t idat_len;
     uint32_t width, height, rowbytes, bpp;   // bpp: filter unit in bytes (1..8)
     uint64_t raw_len;         // height * (1 + rowbytes): bytes of a filtered stream
-    uint64_t raw_off;         // inflate output (the input's own filtered stream), raw_len + CSP_RAW_SLACK bytes
+    uint64_t inflate_off;     // inflate output: the input's own filtered stream (Adam7: the seven passes back to back)
+    uint64_t inflate_len;     // its length in bytes
+    uint64_t raw_off;         // a second region of the image's size (plain images: the inflate output's; Adam7: the pass buffers'): the
+                              // reductions repack into it
     uint64_t pix_off;         // unfiltered rows, height * rowbytes
     uint64_t stream_off;      // stream slot s of this image: stream_off + s * stream_stride
     uint64_t stream_stride;
@@ -39,6 +42,18 @@ struct PngImg {
     uint64_t fix_off;         // prefix bytes then suffix bytes in the `fixed` pool
     uint64_t out_off;         // output file region
     uint64_t out_cap;
+};
+
+// one reconstruction job of k_png_unfilter: a plain image, or one pass of an Adam7 image (PNG spec 8.2)
+struct PngPass {
+    uint32_t image, rowbytes, height, bpp;
+    uint64_t src_off, dst_off;   // filtered rows (1 + rowbytes each) -> pixel rows (rowbytes each), both in the work buffer
+};
+// an Adam7 image: where its seven reconstructed passes are, for the gather that puts the pixels in place
+struct PngAdam7 {
+    uint32_t image, bits;        // bits per pixel
+    uint64_t base[7];            // pass pixel rows in the work buffer
+    uint32_t prb[7];             // their row lengths in bytes (0: the pass is empty)
 };
 
 // per (image, stream slot, chunk): what the coder knows about one deflate block

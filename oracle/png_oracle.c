@@ -254,30 +254,58 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
     }
     if (!rc && (!seen_ihdr || !seen_idat || !seen_iend)) rc = CSO_PNG_BAD;
     if (!rc && P->ctype == 3 && !P->nplte) rc = CSO_PNG_BAD;
-    if (!rc && P->interlace) rc = CSO_PNG_UNSUPPORTED;   /* Adam7: not on this path yet */
     if (rc) { free(idat); cso_png_free(P); return rc; }
-    size_t stride = 1 + P->rowbytes, raw_len = stride * P->height, got = 0;
+    /* the passes of the stream: one for a plain image, up to seven reduced images for Adam7 (PNG spec section 8.2); every pass is
+       filtered on its own; the output is never interlaced */
+    static const int XS[7] = {0, 4, 0, 2, 0, 1, 0}, YS[7] = {0, 0, 4, 0, 2, 0, 1}, DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int bits = P->channels * P->depth, npass = P->interlace ? 7 : 1;
+    size_t raw_len = 0;
+    for (int p = 0; p < npass; p++) {
+        const uint32_t pw = P->interlace ? (P->width + DX[p] - 1 - XS[p]) / DX[p] : P->width, ph = P->interlace ? (P->height + DY[p] - 1 - YS[p]) / DY[p] : P->height;
+        if (pw && ph) raw_len += (size_t)ph * (1 + ((size_t)pw * bits + 7) / 8);
+    }
+    size_t got = 0;
     uint8_t *raw = (uint8_t *)malloc(raw_len);
     rc = cso_inflate_zlib(idat, nidat, raw, raw_len, &got);
     free(idat);
     if (rc || got < raw_len) { free(raw); cso_png_free(P); return CSO_PNG_BAD; }
-    P->pix = (uint8_t *)malloc(P->rowbytes * P->height);
+    P->pix = (uint8_t *)calloc(P->rowbytes, P->height);
     const int bpp = P->bpp;
-    for (uint32_t y = 0; y < P->height && !rc; y++) {
-        const uint8_t *f = raw + y * stride;
-        uint8_t *cur = P->pix + y * P->rowbytes;
-        const uint8_t *up = y ? cur - P->rowbytes : NULL;
-        int ft = f[0];
-        if (ft > 4) { rc = CSO_PNG_BAD; break; }
-        for (size_t x = 0; x < P->rowbytes; x++) {
-            int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0, v = f[1 + x];
-            switch (ft) {
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
+    const uint8_t *f = raw;
+    for (int p = 0; p < npass && !rc; p++) {
+        const uint32_t pw = P->interlace ? (P->width + DX[p] - 1 - XS[p]) / DX[p] : P->width, ph = P->interlace ? (P->height + DY[p] - 1 - YS[p]) / DY[p] : P->height;
+        if (!pw || !ph) continue;
+        const size_t prb = ((size_t)pw * bits + 7) / 8;
+        uint8_t *tmp = P->interlace ? (uint8_t *)malloc(prb * ph) : P->pix;
+        for (uint32_t y = 0; y < ph && !rc; y++, f += 1 + prb) {
+            uint8_t *cur = tmp + y * prb;
+            const uint8_t *up = y ? cur - prb : NULL;
+            int ft = f[0];
+            if (ft > 4) { rc = CSO_PNG_BAD; break; }
+            for (size_t x = 0; x < prb; x++) {
+                int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0, v = f[1 + x];
+                switch (ft) {
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                }
+                cur[x] = (uint8_t)v;
             }
-            cur[x] = (uint8_t)v;
+        }
+        if (P->interlace) {
+            if (!rc)
+                for (uint32_t y = 0; y < ph; y++)
+                    for (uint32_t x = 0; x < pw; x++) {
+                        const uint32_t oy = YS[p] + y * DY[p], ox = XS[p] + x * DX[p];
+                        if (bits >= 8) memcpy(P->pix + (size_t)oy * P->rowbytes + (size_t)ox * (bits / 8), tmp + (size_t)y * prb + (size_t)x * (bits / 8), (size_t)bits / 8);
+                        else {   /* sub-byte samples: most significant bits first */
+                            const size_t sb = (size_t)x * bits, db = (size_t)ox * bits;
+                            const int v = (tmp[(size_t)y * prb + sb / 8] >> (8 - bits - (sb & 7))) & ((1 << bits) - 1);
+                            P->pix[(size_t)oy * P->rowbytes + db / 8] |= (uint8_t)(v << (8 - bits - (db & 7)));
+                        }
+                    }
+            free(tmp);
         }
     }
     free(raw);

@@ -94,11 +94,52 @@ def png_cases(small=True):
     g = np.dstack([a[:, :, 0]] * 3); g[60, 80, 2] ^= 1
     cases.append(("reduce_rgb_nearly_grey", save(Image.fromarray(g, "RGB"))))
     cases.append(("reduce_blocked_by_trns", save(Image.fromarray(np.dstack([a[:, :, 0]] * 3), "RGB"), transparency=(1, 2, 3))))
+    # Adam7 inputs: every kind of pixel, sizes around the 8x8 pattern (empty passes included)
+    for k, (mode, w, h) in enumerate([("RGB", 33, 21), ("RGBA", 9, 9), ("L", 5, 3), ("P", 40, 17), ("1", 37, 11), ("I;16", 12, 20), ("LA", 2, 1), ("RGB", 1, 1), ("L", 8, 8)]):
+        cases.append((f"adam7_{mode}_{w}x{h}", adam7_png(synth_png(40 + k, w, h, mode))))
     if not small:
+        cases.append(("adam7_RGB_300x200", adam7_png(synth_png(49, 300, 200, "RGB", texture=4.0))))
         cases.append(("RGB_640x480", synth_png(30, 640, 480, "RGB", texture=4.0)))
         cases.append(("RGBA_511x300", synth_png(31, 511, 300, "RGBA", texture=1.0)))
         cases.append(("I16_400x300", synth_png(32, 400, 300, "I;16")))
     return cases
+
+
+def adam7_png(data):
+    """the same image as an Adam7-interlaced PNG (Pillow cannot write one): the pixels split into the seven passes, filter 0, zlib;
+    PLTE / tRNS carried over"""
+    import io
+    import zlib
+
+    import numpy as np
+    from PIL import Image
+
+    from oracle import oracle as O
+    im = Image.open(io.BytesIO(data))
+    P = O.png_decode(data)
+    rows = P.rows()
+    w, h = im.size
+    bits = P.im.channels * P.im.depth
+    XS, YS, DX, DY = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    allbits = np.unpackbits(rows, axis=1)[:, :w * bits].reshape(h, w, bits)
+    raw = b""
+    for p in range(7):
+        sub = allbits[YS[p]::DY[p], XS[p]::DX[p]]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        for r in np.packbits(sub.reshape(sub.shape[0], -1), axis=1):
+            raw += bytes([0]) + r.tobytes()
+    ihdr = bytearray(data[8:33])
+    ihdr[8 + 12] = 1
+    ihdr[21:25] = zlib.crc32(bytes(ihdr[4:21])).to_bytes(4, "big")
+    z = zlib.compress(raw, 6)
+    pos, extra = 33, b""
+    while pos < len(data):
+        ln = int.from_bytes(data[pos:pos + 4], "big")
+        if data[pos + 4:pos + 8] in (b"PLTE", b"tRNS"):
+            extra += data[pos:pos + 12 + ln]
+        pos += 12 + ln
+    return data[:8] + bytes(ihdr) + extra + len(z).to_bytes(4, "big") + b"IDAT" + z + zlib.crc32(b"IDAT" + z).to_bytes(4, "big") + b"\0\0\0\0IEND\xaeB`\x82"
 
 
 def oracle_png(src, level=3, keep_metadata=False):

@@ -141,9 +141,24 @@ def test_refusals():
     bad = bytearray(data); bad[20] ^= 1   # IHDR crc
     with pytest.raises(O.PngError):
         O.png_optimize(bytes(bad), 3)
-    # Adam7 input: recognised, refused (not on this path yet)
-    adam7 = bytearray(data); adam7[28] = 1
-    adam7[29:33] = zlib.crc32(bytes(adam7[12:29])).to_bytes(4, "big")
+    # an animated PNG: recognised, refused (not on this path)
+    apng = data[:33] + (8).to_bytes(4, "big") + b"acTL" + bytes(8) + zlib.crc32(b"acTL" + bytes(8)).to_bytes(4, "big") + data[33:]
     with pytest.raises(O.PngError) as e:
-        O.png_optimize(bytes(adam7), 3)
+        O.png_optimize(apng, 3)
     assert e.value.code == 10201
+
+
+def test_adam7_inputs_decode_like_libpng():
+    from _util import adam7_png
+    for mode, w, h in [("RGB", 33, 21), ("RGBA", 9, 9), ("L", 5, 3), ("P", 40, 17), ("1", 37, 11), ("I;16", 12, 20), ("LA", 2, 1), ("RGB", 1, 1)]:
+        plain = synth_png(9, w, h, mode)
+        inter = adam7_png(plain)
+        ref = PIL.open(io.BytesIO(inter))
+        ref.load()   # libpng accepts the hand-made interlaced file
+        assert ref.info.get("interlace") == 1
+        assert np.array_equal(O.png_decode(inter).rows(), O.png_decode(plain).rows()), (mode, w, h)
+        out, _ = O.png_optimize(inter, 2)
+        got = PIL.open(io.BytesIO(out))
+        assert out == inter or not got.info.get("interlace")   # a tiny file may come back unchanged ("already optimised")
+        if mode != "I;16":
+            assert np.array_equal(np.asarray(got.convert("RGBA")), np.asarray(ref.convert("RGBA")))

@@ -66,9 +66,8 @@ def test_keep_metadata(api):
 def test_refusals_and_mixed_batch(api):
     pkg = package()
     good = dict(png_cases())["RGB_97x61"]
-    adam7 = bytearray(good); adam7[28] = 1
     import zlib
-    adam7[29:33] = zlib.crc32(bytes(adam7[12:29])).to_bytes(4, "big")
+    adam7 = good[:33] + (8).to_bytes(4, "big") + b"acTL" + bytes(8) + zlib.crc32(b"acTL" + bytes(8)).to_bytes(4, "big") + good[33:]   # animated: refused
     cut = good[:len(good) // 2]
     # damage inside the zlib stream: flip bits in the middle of the IDAT payload
     i0 = good.index(b"IDAT") + 4

@@ -44,8 +44,7 @@ def test_entry_points_and_refusals(api):
     good = dict(png_cases())["RGB_97x61"]
     p = pkg.default_parameters(png_optimize=True)
     assert api.compress_in_memory(good, p) == oracle_png(good)
-    adam7 = bytearray(good); adam7[28] = 1
-    adam7[29:33] = zlib.crc32(bytes(adam7[12:29])).to_bytes(4, "big")
+    adam7 = good[:33] + (8).to_bytes(4, "big") + b"acTL" + bytes(8) + zlib.crc32(b"acTL" + bytes(8)).to_bytes(4, "big") + good[33:]   # animated: refused
     i0 = good.index(b"IDAT") + 4
     outs = api.cs_batch_compress([good, bytes(adam7), good[:len(good) // 2], b"\x89PNG\r\n\x1a\n" + b"\0" * 40, good], p)
     assert outs[0] == oracle_png(good) and outs[4] == outs[0]
