@@ -265,7 +265,7 @@ class PngBatch:
         arr = (C.c_uint64 * 65536)(); n = C.c_size_t()
         if self.api.L.csp_batch_chunk_bits(self.h, image, trial, arr, 65536, C.byref(n)):
             raise CaesiumError(-1, self.api.L.csh_last_error().decode())
-        return [arr[i] for i in range(n.value + (317 if os.environ.get('CSP_DEBUG_CHUNK') else 0))]
+        return [arr[i] for i in range(n.value)]
 
     def trials(self, image):
         """-> ([(strategy, zlib bytes)], index of the winner)"""

@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_emit(DeflateCtx c) {
         }
         CSP_WAVE_SYNC();
         bo.finish();
-        if (bo.bitpos != (last ? rec.bits : ((rec.bits + 3 + 7) & ~7ull) + 32)) { if (ok) LFOR(l) if (l == 0) { uint64_t *dbg = c.trial_bytes + uint64_t(image) * CSP_MAX_STREAMS; dbg[7] = ci; dbg[8] = bo.bitpos; dbg[9] = rec.bits; } ok = false; }   // the size pass and the emit pass disagree: never ship it
+        if (bo.bitpos != (last ? rec.bits : ((rec.bits + 3 + 7) & ~7ull) + 32)) ok = false;   // the size pass and the emit pass disagree: never ship it
         at += rec.bytes;
         CSP_WAVE_SYNC();
     }

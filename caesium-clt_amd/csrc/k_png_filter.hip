@@ -184,7 +184,6 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_brute(FilterCtx c) {
     LFOR(l) part[l] = sink.nd[l];
     const uint64_t nd = lsum(part);
     LFOR(l) if (l == 0) c.scores[(uint64_t(row) * 5 + f) * 5 + 4] = ilog2i(nl) + ilog2i(nd) + extra - sub;
-    if (c.plan.need_brute == 2) LFOR(l) if (l == 0) { uint64_t *d = c.scores + (uint64_t(row) * 5 + f) * 5; d[0] = nl; d[1] = nd; d[2] = extra; d[3] = sub; }
 }
 
 // per row: the adaptive strategies' choices (ties: the lower filter), and their streams gathered out of the fixed five

@@ -213,7 +213,6 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         if (s >= 5 && b->slot_of_strategy[s] < 0) { b->slot_of_strategy[s] = 5 + plan.nadaptive; plan.adaptive_strategy[plan.nadaptive++] = s; if (s == 9) plan.need_brute = 1; }
         plan.trial_slot[t] = b->slot_of_strategy[s]; plan.trial_strategy[t] = s;
     }
-    if (plan.need_brute && getenv("CSP_BRUTE_DEBUG")) plan.need_brute = 2;
     const int nslots = 5 + plan.nadaptive;
 
     b->items.resize(count);
@@ -394,7 +393,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     d.total_chunks = b->total_chunks; d.total_groups = b->total_groups;
     d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;
     mark(); launch_png_filter5(st, f);
-    mark(); if (need_scores && b->plan.need_brute != 2) launch_png_scores(st, f);
+    mark(); if (need_scores) launch_png_scores(st, f);
     mark(); if (b->plan.need_brute) launch_png_brute(st, f);
     mark(); launch_png_pick(st, f);
     mark(); launch_png_hist(st, d);
@@ -499,7 +498,7 @@ extern "C" int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uin
     *ntrials = b->plan.ntrials;
     for (int t = 0; t < b->plan.ntrials; t++) strategies[t] = b->plan.trial_strategy[t];
     int32_t w = 0;
-    if (hipMemcpy(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * (getenv("CSP_DEBUG_SLOTS") ? 10 : b->plan.ntrials), hipMemcpyDeviceToHost) != hipSuccess ||
+    if (hipMemcpy(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * b->plan.ntrials, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(&w, b->d_winner.p + idx, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *winner = w;
     return 0;
@@ -511,6 +510,5 @@ extern "C" int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint6
     std::vector<PngChunk> recs(im->nchunks);
     if (hipMemcpy(recs.data(), b->d_chunks.p + size_t(im->chunk_base) + size_t(b->plan.trial_slot[trial]) * im->nchunks, sizeof(PngChunk) * im->nchunks, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     for (size_t i = 0; i < im->nchunks && i < cap; i++) dst[i] = recs[i].bits;
-    if (const char *e = getenv("CSP_DEBUG_CHUNK")) { const int ci = atoi(e); if (ci < int(im->nchunks) && cap >= im->nchunks + 317) { for (int k = 0; k < 316; k++) dst[im->nchunks + k] = recs[ci].freq[k]; dst[im->nchunks + 316] = recs[ci].extra_bits; } }
     return 0;
 }

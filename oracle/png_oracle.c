@@ -677,7 +677,6 @@ static uint64_t fixed_cost_row(const uint8_t *row, size_t n, int bpp) {
     for (int i = 0; i < 286; i++) sub += ilog2i(lf[i]);
     for (int i = 0; i < 30; i++) sub += ilog2i(df[i]);
     free(tok); free(taken);
-    if (getenv("CSP_BRUTE_DEBUG")) fprintf(stderr, "BRUTE n=%zu nl=%llu nd=%llu extra=%llu sub=%llu\n", n, (unsigned long long)nl, (unsigned long long)nd, (unsigned long long)extra, (unsigned long long)sub);
     return bits - sub;
 }
 int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len) {
