@@ -10,10 +10,17 @@ def shard_indices(n_files, rank, world):
     return list(range(rank, n_files, world))
 
 
-def compress_sharded(api, blobs, params, rank, world, device=0, group=None):
-    """every rank passes the same `blobs`; returns the full result list (input order) on every rank"""
+def compress_sharded(api, blobs, params, rank, world, device=0, group=None, fmt=None):
+    """every rank passes the same `blobs`; returns the full result list (input order) on every rank.  The shard goes through the C
+    entry point itself (`cs_batch_compress`: JPEG and, under png_optimize, PNG files in one call) or, with `fmt`, through
+    `cs_batch_convert`"""
     mine = shard_indices(len(blobs), rank, world)
-    outs = api.batch_compress([blobs[i] for i in mine], params, device) if mine else []
+    if not mine:
+        outs = []
+    elif fmt is None:
+        outs = api.cs_batch_compress([blobs[i] for i in mine], params, device)
+    else:
+        outs = api.batch_convert([blobs[i] for i in mine], params, fmt, device)
     if world == 1:
         return outs
     import torch.distributed as dist

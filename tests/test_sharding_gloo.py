@@ -24,6 +24,15 @@ WORKER = textwrap.dedent("""
     assert len(res) == 8 and res[7][0] == 'ERR' and res[7][1] == 10200
     for src, out in zip(blobs[:7], res[:7]):
         assert out == oracle_lossy(src)
+    # a mixed --lossless shard (JPEG + PNG in one call per rank) and a conversion shard
+    from _util import oracle_lossless, oracle_png, oracle_jpeg_to_webp
+    from gen_synth import synth_png
+    mixed = [blobs[0], synth_png(1, 40, 30, 'RGB', compress_level=1), blobs[1], synth_png(2, 33, 21, 'L', compress_level=1), synth_png(3, 20, 20, 'RGBA')]
+    res = compress_sharded(emul_api(), mixed, pkg.default_parameters(jpeg_optimize=True, png_optimize=True, png_optimization_level=2), rank, world)
+    want = [oracle_lossless(mixed[0]), oracle_png(mixed[1], 2), oracle_lossless(mixed[2]), oracle_png(mixed[3], 2), oracle_png(mixed[4], 2)]
+    assert res == want
+    res = compress_sharded(emul_api(), blobs[:5], pkg.default_parameters(webp_quality=70), rank, world, fmt=3)
+    assert res == [oracle_jpeg_to_webp(b, 70) for b in blobs[:5]]
     dist.barrier()
     dist.destroy_process_group()
     print('rank', rank, 'ok')
