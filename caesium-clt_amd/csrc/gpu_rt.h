@@ -120,6 +120,7 @@ template <class T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; 
 template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <class T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 static inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
 static inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }

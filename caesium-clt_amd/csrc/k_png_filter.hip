@@ -61,6 +61,68 @@ void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs
     if (njobs) CSH_LAUNCH(k_png_repack, dim3(max_height, njobs), dim3(256), st, imgs, jobs, src, dst);
 }
 
+// ---- colour -> palette
+__device__ __forceinline__ static uint32_t pixel_key(const uint8_t *px, uint32_t ch, uint32_t bps) {   // alpha, red, green, blue (high bytes)
+    return (uint32_t(ch == 4 ? px[3 * bps] : 255u) << 24) | (uint32_t(px[0]) << 16) | (uint32_t(px[bps]) << 8) | px[2 * bps];
+}
+__device__ __forceinline__ static uint32_t key_slot(uint32_t key) { return (key * 0x9E3779B1u) >> 22; }
+__global__ void __launch_bounds__(256) k_png_colors(const PngImg *imgs, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys, uint32_t *counts,
+                                                    const uint32_t *status) {
+    const uint32_t row = blockIdx.x, image = row_image[row];
+    const uint32_t ch = cand[image];
+    if (!ch || status[image]) return;
+    const PngImg &im = imgs[image];
+    const uint32_t bps = im.bps;
+    const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
+    unsigned long long *tab = keys + uint64_t(image) * CSP_PAL_SLOTS;
+    uint32_t prev = 0;
+    bool have_prev = false;
+    for (uint32_t x = threadIdx.x; x < im.width; x += blockDim.x) {
+        if (counts[image] > 256u) return;   // already too many colours (a stale read only costs work)
+        const uint32_t key = pixel_key(r + uint64_t(x) * ch * bps, ch, bps);
+        if (have_prev && key == prev) continue;
+        prev = key; have_prev = true;
+        uint32_t h = key_slot(key);
+        for (int probe = 0; probe < int(CSP_PAL_SLOTS); probe++, h = (h + 1) & (CSP_PAL_SLOTS - 1)) {
+            const unsigned long long seen = atomicCAS(&tab[h], ~0ull, (unsigned long long)key);
+            if (seen == ~0ull) { atomicAdd(&counts[image], 1u); break; }
+            if (seen == (unsigned long long)key) break;
+        }
+    }
+}
+// one lane per byte of the indexed row
+__global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const PaletteJob *jobs, const unsigned long long *keys, const uint16_t *slot_index, const uint8_t *src, uint8_t *dst) {
+    const PaletteJob j = jobs[blockIdx.y];
+    const PngImg &im = imgs[j.image];   // already the new geometry
+    const uint32_t y = blockIdx.x;
+    if (y >= im.height) return;
+    const unsigned long long *tab = keys + uint64_t(j.table) * CSP_PAL_SLOTS;
+    const uint16_t *idx = slot_index + uint64_t(j.table) * CSP_PAL_SLOTS;
+    const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
+    uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
+    const uint32_t per = 8u / j.depth;
+    for (uint32_t bx = threadIdx.x; bx < im.rowbytes; bx += blockDim.x) {
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t x = bx * per + k;
+            if (x >= im.width) break;
+            const uint32_t key = pixel_key(s + uint64_t(x) * j.old_channels * j.old_bps, j.old_channels, j.old_bps);
+            uint32_t h = key_slot(key);
+            while (tab[h] != (unsigned long long)key) h = (h + 1) & (CSP_PAL_SLOTS - 1);   // every pixel's colour is in the table
+            v |= uint32_t(idx[h]) << (8u - j.depth - k * j.depth);
+        }
+        d[bx] = uint8_t(v);
+    }
+}
+void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys,
+                       uint32_t *counts, const uint32_t *status) {
+    if (total_rows) CSH_LAUNCH(k_png_colors, dim3(total_rows), dim3(256), st, imgs, row_image, pix, cand, keys, counts, status);
+}
+void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
+                        const uint8_t *src, uint8_t *dst) {
+    if (njobs) CSH_LAUNCH(k_png_indexed, dim3(max_height, njobs), dim3(256), st, imgs, jobs, keys, slot_index, src, dst);
+}
+
 // one workgroup per batch row: all five filtered versions of the row
 __global__ void __launch_bounds__(256) k_png_filter5(FilterCtx c) {
     const uint32_t row = blockIdx.x;

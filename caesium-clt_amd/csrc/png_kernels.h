@@ -17,6 +17,17 @@ struct ReduceJob { uint32_t image, mask, old_rowbytes, old_channels, old_bps; ui
 void launch_png_analyze(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, uint32_t *flags, const uint32_t *status);
 void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst);
 
+// colour -> palette (oracle: to_palette).  cand[image] = channels (3 / 4) of an 8- or 16-bit truecolour image that may become indexed,
+// else 0.  The distinct pixels (alpha, red, green, blue of the high bytes in one 32-bit key) are collected in a 1024-slot open
+// hash table per image; counts above 256 mean "not a palette image".  The host sorts the palette and sends back, per slot, the
+// index of its colour; the conversion packs the indices (depth 1, 2, 4 or 8).
+enum { CSP_PAL_SLOTS = 1024 };
+struct PaletteJob { uint32_t image, old_rowbytes, old_channels, old_bps, depth, table; uint64_t src_off, dst_off; };   // table: the image's slot in the tables
+void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys,
+                       uint32_t *counts, const uint32_t *status);
+void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
+                        const uint8_t *src, uint8_t *dst);
+
 // P3: row-filter search (k_png_filter.hip)
 struct FilterCtx {
     const PngImg *imgs;

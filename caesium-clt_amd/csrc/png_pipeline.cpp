@@ -41,6 +41,7 @@ struct PngItem {
     uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0, channels = 0, depth = 0, ctype = 0;
     bool no_reduce = false;   // a carried chunk is tied to the colour type (tRNS, bKGD, sBIT)
     bool interlace = false;   // Adam7 input (the output never is)
+    bool has_plte = false;
     std::vector<std::pair<size_t, size_t>> idat;   // (offset, length) of every IDAT payload in the input
     size_t idat_len = 0;
     std::vector<uint8_t> prefix, suffix;            // output bytes in front of / behind the IDAT chunk
@@ -96,7 +97,7 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
             seen_iend = true;
         } else {
             if (!memcmp(type, "acTL", 4)) return fail(CS_ERR_UNSUPPORTED, "animated PNG has no device path in this build");
-            if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); }
+            if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); it.has_plte = true; }
             const bool critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
                 if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) it.no_reduce = true;
@@ -141,6 +142,7 @@ struct csp_batch {
     std::vector<PngImg> imgs;
     std::vector<uint8_t> fixed;
     std::vector<uint32_t> flags0;   // reductions each image's format allows
+    std::vector<uint32_t> cand0;    // channels of an image that may become indexed (8- or 16-bit truecolour, no PLTE, nothing tied to the colour type), else 0
     std::vector<PngPass> passes;    // reconstruction jobs: one per image, seven per Adam7 image
     std::vector<PngAdam7> adam7;
     uint64_t adam7_items = 0;
@@ -154,6 +156,10 @@ struct csp_batch {
     DevBuf<uint8_t> d_idat, d_work, d_streams, d_out, d_fixed, d_choice;   // d_work: inflated streams, then pixels (one buffer: a reduction swaps the two regions of an image)
     DevBuf<ReduceJob> d_jobs;
     DevBuf<PngPass> d_passes;
+    DevBuf<PaletteJob> d_pjobs;
+    DevBuf<unsigned long long> d_keys;
+    DevBuf<uint16_t> d_slot_index;
+    DevBuf<uint32_t> d_counts, d_cand;
     DevBuf<PngAdam7> d_adam7;
     DevBuf<uint32_t> d_flags;
     DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_file_len, d_adler, d_crc;
@@ -279,13 +285,14 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         im.chunk_base = uint32_t(nchunk_recs); nchunk_recs += uint64_t(im.nchunks) * nslots;
         im.chunk_stride = im.nchunks;
         im.channels = it.channels; im.bps = (it.ctype != 3 && it.depth >= 8) ? it.depth / 8 : 0;
+        b->cand0.push_back((!it.no_reduce && !it.has_plte && im.bps && (im.channels == 3 || im.channels == 4)) ? im.channels : 0u);
         b->flags0.push_back((it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u)));
         if (nchunk_recs > 0x7FFFFFFFu) { csh_set_error("PNG batch too large"); return CS_ERR_POOL_OVERFLOW; }
         im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
         im.fix_off = fixed.size();
         fixed.insert(fixed.end(), it.prefix.begin(), it.prefix.end());
         fixed.insert(fixed.end(), it.suffix.begin(), it.suffix.end());
-        im.out_cap = uint64_t(im.prefix_len) + 12 + im.suffix_len + 6 + uint64_t(im.nchunks) * (CSP_CHUNK + CSP_CHUNK / 8 + 1024);
+        im.out_cap = uint64_t(im.prefix_len) + 1100 /* a PLTE and a tRNS chunk a reduction may add */ + 12 + im.suffix_len + 6 + uint64_t(im.nchunks) * (CSP_CHUNK + CSP_CHUNK / 8 + 1024);
         if (im.out_cap > 0xFFFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
         im.out_off = out_bytes; out_bytes += align_up(im.out_cap + 16, 256);
         const uint32_t pieces = uint32_t((im.out_cap + 1023) / 1024);
@@ -324,46 +331,107 @@ static int reduce_step(csp_batch *b) {
     const int nimg = int(b->imgs.size());
     b->reduced = true;
     bool any = false;
-    for (uint32_t f : b->flags0) any |= f != 0;
+    for (int i = 0; i < nimg; i++) any |= b->flags0[i] != 0 || b->cand0[i] != 0;
     if (!any || !nimg) return 0;
-    if (hipMemcpyAsync(b->d_flags.p, b->flags0.data(), sizeof(uint32_t) * nimg, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (b->d_keys.alloc(size_t(nimg) * CSP_PAL_SLOTS) || b->d_slot_index.alloc(size_t(nimg) * CSP_PAL_SLOTS) || b->d_counts.alloc(size_t(nimg) + 1) || b->d_cand.upload(b->cand0, st)) return -1;
+    if (hipMemcpyAsync(b->d_flags.p, b->flags0.data(), sizeof(uint32_t) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(b->d_keys.p, 0xFF, sizeof(unsigned long long) * size_t(nimg) * CSP_PAL_SLOTS, st) != hipSuccess || b->d_counts.zero(st)) return -1;
     launch_png_analyze(st, b->d_imgs.p, b->total_rows, b->d_row_image.p, b->d_work.p, b->d_flags.p, b->d_status.p);
-    std::vector<uint32_t> flags(nimg), status(nimg);
+    launch_png_colors(st, b->d_imgs.p, b->total_rows, b->d_row_image.p, b->d_work.p, b->d_cand.p, b->d_keys.p, b->d_counts.p, b->d_status.p);
+    std::vector<uint32_t> flags(nimg), status(nimg), counts(nimg);
     if (hipMemcpyAsync(flags.data(), b->d_flags.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(counts.data(), b->d_counts.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         csh_set_error("PNG analysis failed");
         return -1;
     }
+    std::vector<size_t> item_of(nimg, 0);
+    for (size_t n = 0; n < b->items.size(); n++) if (b->items[n].image >= 0) item_of[b->items[n].image] = n;
     std::vector<ReduceJob> jobs;
+    std::vector<PaletteJob> pjobs;
+    std::vector<uint16_t> slot_index(size_t(nimg) * CSP_PAL_SLOTS, 0);
     uint32_t max_height = 0;
+    bool changed = false;
     for (int i = 0; i < nimg; i++) {
-        if (!flags[i] || status[i]) continue;
+        if (status[i]) continue;
         PngImg &im = b->imgs[i];
+        PngItem &it = b->items[item_of[i]];
         const bool narrow = flags[i] & 1u, opaque = flags[i] & 2u, grey = flags[i] & 4u;
-        ReduceJob j{};
-        j.image = uint32_t(i); j.mask = flags[i]; j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps;
-        j.src_off = im.pix_off; j.dst_off = im.raw_off;   // the inflated stream is not needed any more: its region takes the new pixels
         const uint32_t nk = im.channels - (opaque ? 1u : 0u) - (grey ? 2u : 0u), nbps = narrow ? 1u : im.bps;
-        im.channels = nk; im.bps = nbps; im.bpp = nk * nbps; im.rowbytes = im.width * nk * nbps;
+        // colour -> palette (oracle: to_palette): at most 256 distinct pixels, and smaller rows even with the PLTE / tRNS chunks
+        std::vector<uint32_t> pal;
+        std::vector<unsigned long long> tab;
+        uint32_t depth = 0, ntr = 0;
+        if (b->cand0[i] && !grey && nbps == 1 && (nk == 3 || nk == 4) && counts[i] <= 256) {
+            tab.resize(CSP_PAL_SLOTS);
+            if (hipMemcpy(tab.data(), b->d_keys.p + size_t(i) * CSP_PAL_SLOTS, sizeof(unsigned long long) * CSP_PAL_SLOTS, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            for (auto k : tab) if (k != ~0ull) pal.push_back(uint32_t(k));
+            std::sort(pal.begin(), pal.end());
+            const uint32_t n = uint32_t(pal.size());
+            for (uint32_t k = 0; k < n; k++) if ((pal[k] >> 24) != 255) ntr = k + 1;
+            depth = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
+            const uint64_t nrb = (uint64_t(im.width) * depth + 7) / 8, extra = 12 + 3 * uint64_t(n) + (ntr ? 12 + ntr : 0);
+            if (uint64_t(im.height) * (1 + nrb) + extra >= uint64_t(im.height) * (1 + uint64_t(im.width) * nk)) depth = 0;
+        }
+        if (!depth && !flags[i]) continue;
+        changed = true;
+        uint8_t *ihdr = &it.prefix[8];   // the new IHDR: depth, colour type, checksum
+        if (depth) {
+            PaletteJob j{};
+            j.image = uint32_t(i); j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps; j.depth = depth; j.table = uint32_t(i);
+            j.src_off = im.pix_off; j.dst_off = im.raw_off;
+            for (uint32_t sl = 0; sl < CSP_PAL_SLOTS; sl++)
+                if (tab[sl] != ~0ull) slot_index[size_t(i) * CSP_PAL_SLOTS + sl] = uint16_t(std::lower_bound(pal.begin(), pal.end(), uint32_t(tab[sl])) - pal.begin());
+            im.channels = 1; im.bps = 0; im.bpp = 1; im.rowbytes = uint32_t((uint64_t(im.width) * depth + 7) / 8);
+            ihdr[8 + 8] = uint8_t(depth); ihdr[8 + 9] = 3;
+            const uint32_t n = uint32_t(pal.size());
+            std::vector<uint8_t> ch(12 + 3 * n);
+            put_be32(ch.data(), 3 * n); memcpy(&ch[4], "PLTE", 4);
+            for (uint32_t k = 0; k < n; k++) { ch[8 + 3 * k] = uint8_t(pal[k] >> 16); ch[9 + 3 * k] = uint8_t(pal[k] >> 8); ch[10 + 3 * k] = uint8_t(pal[k]); }
+            put_be32(&ch[8 + 3 * n], crc32_host(&ch[4], 4 + 3 * n));
+            it.prefix.insert(it.prefix.end(), ch.begin(), ch.end());
+            if (ntr) {
+                std::vector<uint8_t> tr(12 + ntr);
+                put_be32(tr.data(), ntr); memcpy(&tr[4], "tRNS", 4);
+                for (uint32_t k = 0; k < ntr; k++) tr[8 + k] = uint8_t(pal[k] >> 24);
+                put_be32(&tr[8 + ntr], crc32_host(&tr[4], 4 + ntr));
+                it.prefix.insert(it.prefix.end(), tr.begin(), tr.end());
+            }
+            pjobs.push_back(j);
+        } else {
+            ReduceJob j{};
+            j.image = uint32_t(i); j.mask = flags[i]; j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps;
+            j.src_off = im.pix_off; j.dst_off = im.raw_off;   // the second region of the image takes the new pixels
+            im.channels = nk; im.bps = nbps; im.bpp = nk * nbps; im.rowbytes = im.width * nk * nbps;
+            ihdr[8 + 8] = uint8_t(nbps * 8); ihdr[8 + 9] = uint8_t(nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6);
+            jobs.push_back(j);
+        }
+        ihdr = &it.prefix[8];
+        put_be32(ihdr + 8 + 13, crc32_host(ihdr + 4, 17));
         im.raw_len = uint64_t(im.height) * (uint64_t(im.rowbytes) + 1);
         im.nchunks = uint32_t((im.raw_len + CSP_CHUNK - 1) / CSP_CHUNK);
         std::swap(im.pix_off, im.raw_off);
-        // the new IHDR: depth, colour type, checksum (prefix = signature, IHDR, carried chunks)
-        uint8_t *ihdr = &b->fixed[im.fix_off + 8];
-        ihdr[8 + 8] = uint8_t(nbps * 8); ihdr[8 + 9] = uint8_t(nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6);
-        put_be32(ihdr + 8 + 13, crc32_host(ihdr + 4, 17));
         if (im.height > max_height) max_height = im.height;
-        jobs.push_back(j);
     }
-    if (jobs.empty()) return 0;
-    b->n_reduced = uint32_t(jobs.size());
+    if (!changed) return 0;
+    b->n_reduced = uint32_t(jobs.size() + pjobs.size());
     b->raw_total = 0;
-    for (auto &im : b->imgs) b->raw_total += im.raw_len;
-    if (hipMemcpyAsync(b->d_imgs.p, b->imgs.data(), sizeof(PngImg) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(b->d_jobs.p, jobs.data(), sizeof(ReduceJob) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(b->d_fixed.p, b->fixed.data(), b->fixed.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("PNG reduction upload failed"); return -1; }
-    launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()), max_height, b->d_work.p, b->d_work.p);
-    return upload_chunk_index(b);   // synchronises: jobs may go out of scope
+    b->fixed.clear();   // prefixes changed (IHDR, perhaps PLTE / tRNS): lay the carried bytes out again
+    for (int i = 0; i < nimg; i++) {
+        PngImg &im = b->imgs[i];
+        const PngItem &it = b->items[item_of[i]];
+        b->raw_total += im.raw_len;
+        im.fix_off = b->fixed.size(); im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
+        b->fixed.insert(b->fixed.end(), it.prefix.begin(), it.prefix.end());
+        b->fixed.insert(b->fixed.end(), it.suffix.begin(), it.suffix.end());
+    }
+    jobs.push_back(ReduceJob{}); pjobs.push_back(PaletteJob{});   // never empty uploads
+    if (b->d_fixed.upload(b->fixed, st) || b->d_pjobs.upload(pjobs, st) || b->d_slot_index.upload(slot_index, st) ||
+        hipMemcpyAsync(b->d_imgs.p, b->imgs.data(), sizeof(PngImg) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(b->d_jobs.p, jobs.data(), sizeof(ReduceJob) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("PNG reduction upload failed"); return -1; }
+    launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()) - 1, max_height, b->d_work.p, b->d_work.p);
+    launch_png_indexed(st, b->d_imgs.p, b->d_pjobs.p, int(pjobs.size()) - 1, max_height, b->d_keys.p, b->d_slot_index.p, b->d_work.p, b->d_work.p);
+    return upload_chunk_index(b);   // synchronises: the job vectors may go out of scope
 }
 
 extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {

@@ -318,7 +318,63 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
  * The subset of oxipng's reductions that needs no palette: 16 -> 8 bits when every sample's two bytes are equal; alpha
  * dropped when every pixel is opaque; colour -> grey when r == g == b everywhere.  Applied in that order, always (oxipng
  * evaluates both variants and keeps the smaller; for these three the reduced image practically always wins), and never
- * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Palette / sub-byte depth reductions: not built. */
+ * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Then colour -> palette (to_palette).  Depth reductions of
+ * grey / palette images: not built. */
+/* colour -> palette: an 8-bit RGB / RGBA image with at most 256 distinct pixels becomes an indexed one (entries sorted by
+   alpha, then red, green, blue, so that the translucent ones come first and tRNS stops at the last of them; index depth 1, 2, 4
+   or 8 by their number) when the indexed rows plus the PLTE / tRNS chunks are smaller than the rows were.  Returns 8 or 0. */
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+static int to_palette(cso_png *P) {
+    if (P->depth != 8 || (P->ctype != 2 && P->ctype != 6) || P->nplte) return 0;
+    const int ch = P->channels;
+    uint32_t pal[257];
+    int n = 0;
+    for (uint32_t y = 0; y < P->height && n <= 256; y++) {
+        const uint8_t *r = P->pix + (size_t)y * P->rowbytes;
+        for (uint32_t x = 0; x < P->width && n <= 256; x++) {
+            const uint8_t *px = r + (size_t)x * ch;
+            const uint32_t key = ((uint32_t)(ch == 4 ? px[3] : 255) << 24) | ((uint32_t)px[0] << 16) | ((uint32_t)px[1] << 8) | px[2];
+            int k = 0;
+            while (k < n && pal[k] != key) k++;
+            if (k == n) pal[n++] = key;
+        }
+    }
+    if (n > 256) return 0;
+    qsort(pal, (size_t)n, sizeof pal[0], cmp_u32);
+    int ntr = 0;
+    for (int k = 0; k < n; k++) if ((pal[k] >> 24) != 255) ntr = k + 1;
+    const int d = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
+    const size_t nrb = ((size_t)P->width * d + 7) / 8;
+    const size_t extra = 12 + 3 * (size_t)n + (ntr ? 12 + (size_t)ntr : 0);
+    if ((size_t)P->height * (1 + nrb) + extra >= (size_t)P->height * (1 + P->rowbytes)) return 0;
+    uint8_t *np = (uint8_t *)calloc(nrb, P->height);
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) {
+            const uint8_t *px = P->pix + (size_t)y * P->rowbytes + (size_t)x * ch;
+            const uint32_t key = ((uint32_t)(ch == 4 ? px[3] : 255) << 24) | ((uint32_t)px[0] << 16) | ((uint32_t)px[1] << 8) | px[2];
+            int k = 0;
+            while (pal[k] != key) k++;
+            const size_t bit = (size_t)x * d;
+            np[(size_t)y * nrb + bit / 8] |= (uint8_t)(k << (8 - d - (bit & 7)));
+        }
+    free(P->pix);
+    P->pix = np; P->rowbytes = nrb; P->channels = 1; P->depth = d; P->bpp = 1; P->ctype = 3; P->nplte = n;
+    /* PLTE and tRNS go in front of where the first IDAT stood */
+    uint8_t *ins = (uint8_t *)malloc(extra), *w = ins;
+    put_be32(w, (uint32_t)(3 * n)); memcpy(w + 4, "PLTE", 4);
+    for (int k = 0; k < n; k++) { w[8 + 3 * k] = (uint8_t)(pal[k] >> 16); w[9 + 3 * k] = (uint8_t)(pal[k] >> 8); w[10 + 3 * k] = (uint8_t)pal[k]; }
+    put_be32(w + 8 + 3 * n, cso_crc32(0, w + 4, 4 + 3 * (size_t)n)); w += 12 + 3 * n;
+    if (ntr) {
+        put_be32(w, (uint32_t)ntr); memcpy(w + 4, "tRNS", 4);
+        for (int k = 0; k < ntr; k++) w[8 + k] = (uint8_t)(pal[k] >> 24);
+        put_be32(w + 8 + ntr, cso_crc32(0, w + 4, 4 + (size_t)ntr)); w += 12 + ntr;
+    }
+    uint8_t *nc = (uint8_t *)malloc(P->chunks_len + extra);
+    memcpy(nc, P->chunks, P->idat_at); memcpy(nc + P->idat_at, ins, extra); memcpy(nc + P->idat_at + extra, P->chunks + P->idat_at, P->chunks_len - P->idat_at);
+    free(P->chunks); free(ins);
+    P->chunks = nc; P->chunks_len += extra; P->idat_at += extra;
+    return 8;
+}
 int cso_png_reduce(cso_png *P) {
     if (P->no_reduce || P->ctype == 3 || P->depth < 8) return 0;
     const int bps = P->depth / 8, ch = P->channels;
@@ -334,7 +390,7 @@ int cso_png_reduce(cso_png *P) {
         }
     }
     (void)npx;
-    if (!narrow && !opaque && !grey) return 0;
+    if (!narrow && !opaque && !grey) return to_palette(P);
     const int nbps = narrow ? 1 : bps;
     int keep[4], nk = 0;   /* source channels that survive */
     for (int k = 0; k < ch; k++) {
@@ -352,7 +408,7 @@ int cso_png_reduce(cso_png *P) {
     free(P->pix);
     P->pix = np; P->rowbytes = nrow; P->channels = nk; P->depth = nbps * 8; P->bpp = nk * nbps;
     P->ctype = nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6;
-    return (narrow ? 1 : 0) | (opaque ? 2 : 0) | (grey ? 4 : 0);
+    return (narrow ? 1 : 0) | (opaque ? 2 : 0) | (grey ? 4 : 0) | to_palette(P);
 }
 
 /* ------------------------------------------------------------------------------------------------ row filters */

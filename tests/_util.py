@@ -94,6 +94,21 @@ def png_cases(small=True):
     g = np.dstack([a[:, :, 0]] * 3); g[60, 80, 2] ^= 1
     cases.append(("reduce_rgb_nearly_grey", save(Image.fromarray(g, "RGB"))))
     cases.append(("reduce_blocked_by_trns", save(Image.fromarray(np.dstack([a[:, :, 0]] * 3), "RGB"), transparency=(1, 2, 3))))
+    # colour -> palette: few distinct colours (opaque / with translucent entries / two colours -> 1 bit / 17 -> 8 bit), and 257 colours
+    from PIL import ImageDraw
+    rng = np.random.default_rng(4)
+    flat = Image.new("RGB", (200, 120), (250, 250, 250))
+    d = ImageDraw.Draw(flat)
+    for _ in range(30):
+        x0, y0 = int(rng.integers(0, 180)), int(rng.integers(0, 100))
+        d.rectangle([x0, y0, x0 + int(rng.integers(5, 60)), y0 + int(rng.integers(5, 40))], fill=tuple(int(v) for v in rng.integers(0, 255, 3)))
+    cases.append(("palette_rgb_few", save(flat)))
+    fa = np.asarray(flat.convert("RGBA")).copy(); fa[20:60, 40:120, 3] = 100; fa[70:90, :, 3] = 0
+    cases.append(("palette_rgba_translucent", save(Image.fromarray(fa, "RGBA"))))
+    two = np.where(np.asarray(flat)[:, :, :1] > 128, np.array([200, 10, 30], np.uint8), np.array([10, 200, 90], np.uint8))
+    cases.append(("palette_two_colours", save(Image.fromarray(two, "RGB"))))
+    many = np.zeros((20, 300, 3), np.uint8); many[:, :, 0] = np.arange(300)[None, :] % 257 % 256; many[:, 256:, 1] = 7   # 257 distinct colours
+    cases.append(("palette_257_colours", save(Image.fromarray(many, "RGB"))))
     # Adam7 inputs: every kind of pixel, sizes around the 8x8 pattern (empty passes included)
     for k, (mode, w, h) in enumerate([("RGB", 33, 21), ("RGBA", 9, 9), ("L", 5, 3), ("P", 40, 17), ("1", 37, 11), ("I;16", 12, 20), ("LA", 2, 1), ("RGB", 1, 1), ("L", 8, 8)]):
         cases.append((f"adam7_{mode}_{w}x{h}", adam7_png(synth_png(40 + k, w, h, mode))))
