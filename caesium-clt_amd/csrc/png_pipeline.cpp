@@ -458,7 +458,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
         launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);
     }
     mark(); if (!b->reduced && reduce_step(b)) return CS_ERR_NO_DEVICE;
-    d.total_chunks = b->total_chunks; d.total_groups = b->total_groups;
+    d.total_chunks = b->total_chunks; d.total_groups = b->total_groups; d.fixed = b->d_fixed.p;   // the reduction step may have re-laid these out
     d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;
     mark(); launch_png_filter5(st, f);
     mark(); if (need_scores) launch_png_scores(st, f);
