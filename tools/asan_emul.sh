@@ -1,0 +1,29 @@
+#!/bin/bash
+# The emulation build of every kernel + the host pipelines under AddressSanitizer / UBSan (shift checks off: the emulation's
+# __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip"
+CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp"
+(cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
+    $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
+cat > $O/run.py <<PY
+import sys
+sys.path[:0] = ['$R', '$R/tools', '$R/tests']
+import _util
+pkg = _util.package()
+api = pkg.CaesiumHip('$O/libcaesium_emul.so')
+import test_png_emul as T, test_webp_emul as W, test_pipeline_emul as PE
+from gen_synth import synth_jpeg
+T.check_batch(api, _util.png_cases(), 3)
+T.check_batch(api, [c for c in _util.png_cases() if c[0] in ("RGB_97x61", "palette_rgba_translucent", "adam7_1_37x11", "reduce_i16_narrow")], 6)
+assert T.agree_with_oracle(api, T.damaged_pngs(1, 80)) == 0
+W.check(api, W.webp_cases(), 85); W.check(api, W.webp_cases()[:2], 60, width=50)
+srcs = [synth_jpeg(1, 160, 96, texture=10), synth_jpeg(2, 97, 61, subsampling=0, texture=5), synth_jpeg(5, 104, 72, progressive=True, texture=6), synth_jpeg(6, 120, 88, restart_rows=1, texture=9)]
+for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_quality=80))): assert o == _util.oracle_lossy(s)
+for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_optimize=True))): assert o == _util.oracle_lossless(s)
+for s, o in zip(srcs, api.batch_compress(srcs[:2], pkg.default_parameters(jpeg_quality=70, width=60))): assert o == _util.oracle_resized(s, 60, 0, quality=70)
+api.batch_compress(PE.fuzzed_blobs(3, 24, True), pkg.default_parameters(jpeg_quality=80))
+print('asan run: all cases equal the oracle')
+PY
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
