@@ -101,11 +101,11 @@ static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSP
     return failed_total;
 }
 
-// one call, mixed inputs: PNG files under png.optimize go to the PNG pipeline, everything else to the JPEG pipeline (which
+// one call, mixed inputs: PNG files go to the PNG pipeline, everything else to the JPEG pipeline (which
 // answers per file for what it has no device path for); results keep the order of the inputs
 int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
-    std::vector<size_t> png;
-    if (p->png_optimize) for (size_t i = 0; i < count; i++) if (sniff(inputs[i].data, inputs[i].length) == CS_TYPE_PNG) png.push_back(i);
+    std::vector<size_t> png;   // PNG files: lossless under png.optimize, else the lossy (quantising) form of the same pipeline
+    for (size_t i = 0; i < count; i++) if (sniff(inputs[i].data, inputs[i].length) == CS_TYPE_PNG) png.push_back(i);
     if (png.empty()) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
     std::vector<size_t> other;
     { size_t k = 0; for (size_t i = 0; i < count; i++) { if (k < png.size() && png[k] == i) k++; else other.push_back(i); } }

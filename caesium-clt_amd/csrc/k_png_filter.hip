@@ -90,37 +90,86 @@ __global__ void __launch_bounds__(256) k_png_colors(const PngImg *imgs, const ui
         }
     }
 }
-// one lane per byte of the indexed row
-__global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const PaletteJob *jobs, const unsigned long long *keys, const uint16_t *slot_index, const uint8_t *src, uint8_t *dst) {
+// one lane per byte of the indexed row: the index of every pixel by hash look-up (exact palette) or by nearest entry (lossy)
+__global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const PaletteJob *jobs, const unsigned long long *keys, const uint16_t *slot_index, const uint32_t *palettes,
+                                                     const uint8_t *src, uint8_t *dst) {
+    CSH_SHARED uint32_t pal[256];
     const PaletteJob j = jobs[blockIdx.y];
     const PngImg &im = imgs[j.image];   // already the new geometry
     const uint32_t y = blockIdx.x;
-    if (y >= im.height) return;
-    const unsigned long long *tab = keys + uint64_t(j.table) * CSP_PAL_SLOTS;
-    const uint16_t *idx = slot_index + uint64_t(j.table) * CSP_PAL_SLOTS;
-    const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
-    uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
-    const uint32_t per = 8u / j.depth;
-    for (uint32_t bx = threadIdx.x; bx < im.rowbytes; bx += blockDim.x) {
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < per; k++) {
-            const uint32_t x = bx * per + k;
-            if (x >= im.width) break;
-            const uint32_t key = pixel_key(s + uint64_t(x) * j.old_channels * j.old_bps, j.old_channels, j.old_bps);
-            uint32_t h = key_slot(key);
-            while (tab[h] != (unsigned long long)key) h = (h + 1) & (CSP_PAL_SLOTS - 1);   // every pixel's colour is in the table
-            v |= uint32_t(idx[h]) << (8u - j.depth - k * j.depth);
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) { if (j.nearest && threadIdx.x < j.npal) pal[threadIdx.x] = palettes[j.pal_off + threadIdx.x]; continue; }
+        if (y >= im.height) continue;
+        const unsigned long long *tab = keys + uint64_t(j.table) * CSP_PAL_SLOTS;
+        const uint16_t *idx = slot_index + uint64_t(j.table) * CSP_PAL_SLOTS;
+        const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
+        uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
+        const uint32_t per = 8u / j.depth;
+        for (uint32_t bx = threadIdx.x; bx < im.rowbytes; bx += blockDim.x) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < per; k++) {
+                const uint32_t x = bx * per + k;
+                if (x >= im.width) break;
+                const uint32_t key = pixel_key(s + uint64_t(x) * j.old_channels * j.old_bps, j.old_channels, j.old_bps);
+                uint32_t index;
+                if (j.nearest) {   // squared distance over a, r, g, b; ties: the lower index
+                    const int a = int(key >> 24), r = int((key >> 16) & 255u), g = int((key >> 8) & 255u), b = int(key & 255u);
+                    uint32_t bd = ~0u;
+                    index = 0;
+                    for (uint32_t q = 0; q < j.npal; q++) {
+                        const uint32_t pq = pal[q];
+                        const int dr = r - int((pq >> 16) & 255u), dg = g - int((pq >> 8) & 255u), db = b - int(pq & 255u), da = a - int(pq >> 24);
+                        const uint32_t dist = uint32_t(dr * dr + dg * dg + db * db + da * da);
+                        if (dist < bd) { bd = dist; index = q; }
+                    }
+                } else {
+                    uint32_t h = key_slot(key);
+                    while (tab[h] != (unsigned long long)key) h = (h + 1) & (CSP_PAL_SLOTS - 1);   // every pixel's colour is in the table
+                    index = idx[h];
+                }
+                v |= index << (8u - j.depth - k * j.depth);
+            }
+            d[bx] = uint8_t(v);
         }
-        d[bx] = uint8_t(v);
     }
+}
+// ---- lossy PNG: colour bins
+__global__ void __launch_bounds__(256) k_png_qhist(const QuantJob *jobs, const uint8_t *work, uint32_t *bins) {
+    const QuantJob j = jobs[blockIdx.y];
+    const uint32_t y = blockIdx.x;
+    if (y >= j.height) return;
+    const uint8_t *r = work + j.src_off + uint64_t(y) * j.rowbytes;
+    uint32_t *b = bins + j.bins_off;
+    for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
+        const uint32_t key = pixel_key(r + uint64_t(x) * j.channels * j.bps, j.channels, j.bps);
+        const uint32_t a = key >> 24, rr = (key >> 16) & 255u, g = (key >> 8) & 255u, bb = key & 255u;
+        uint32_t *q = b + uint64_t(((a >> 4) << 15) | ((rr >> 3) << 10) | ((g >> 3) << 5) | (bb >> 3)) * 5;
+        atomicAdd(&q[0], 1u); atomicAdd(&q[1], rr); atomicAdd(&q[2], g); atomicAdd(&q[3], bb); atomicAdd(&q[4], a);
+    }
+}
+__global__ void __launch_bounds__(256) k_png_qcompact(const QuantJob *jobs, const uint32_t *bins, QBin *list, uint32_t *nlist) {
+    const QuantJob j = jobs[blockIdx.y];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CSP_QBINS) return;
+    const uint32_t *q = bins + j.bins_off + uint64_t(i) * 5;
+    if (!q[0]) return;
+    const uint32_t slot = atomicAdd(&nlist[blockIdx.y], 1u);
+    QBin o; o.id = i; o.cnt = q[0]; o.s[0] = q[1]; o.s[1] = q[2]; o.s[2] = q[3]; o.s[3] = q[4];
+    list[j.list_off + slot] = o;
 }
 void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys,
                        uint32_t *counts, const uint32_t *status) {
     if (total_rows) CSH_LAUNCH(k_png_colors, dim3(total_rows), dim3(256), st, imgs, row_image, pix, cand, keys, counts, status);
 }
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
-                        const uint8_t *src, uint8_t *dst) {
-    if (njobs) CSH_LAUNCH(k_png_indexed, dim3(max_height, njobs), dim3(256), st, imgs, jobs, keys, slot_index, src, dst);
+                        const uint32_t *palettes, const uint8_t *src, uint8_t *dst) {
+    if (njobs) CSH_LAUNCH_PHASED(k_png_indexed, 2, dim3(max_height, njobs), dim3(256), st, imgs, jobs, keys, slot_index, palettes, src, dst);
+}
+void launch_png_qhist(hipStream_t st, const QuantJob *jobs, int njobs, uint32_t max_height, const uint8_t *work, uint32_t *bins) {
+    if (njobs) CSH_LAUNCH(k_png_qhist, dim3(max_height, njobs), dim3(256), st, jobs, work, bins);
+}
+void launch_png_qcompact(hipStream_t st, const QuantJob *jobs, int njobs, const uint32_t *bins, QBin *list, uint32_t *nlist) {
+    if (njobs) CSH_LAUNCH(k_png_qcompact, dim3(CSP_QBINS / 256, njobs), dim3(256), st, jobs, bins, list, nlist);
 }
 
 // one workgroup per batch row: all five filtered versions of the row

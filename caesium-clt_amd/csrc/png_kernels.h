@@ -22,11 +22,23 @@ void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs
 // hash table per image; counts above 256 mean "not a palette image".  The host sorts the palette and sends back, per slot, the
 // index of its colour; the conversion packs the indices (depth 1, 2, 4 or 8).
 enum { CSP_PAL_SLOTS = 1024 };
-struct PaletteJob { uint32_t image, old_rowbytes, old_channels, old_bps, depth, table; uint64_t src_off, dst_off; };   // table: the image's slot in the tables
+struct PaletteJob {
+    uint32_t image, old_rowbytes, old_channels, old_bps, depth, table;   // table: the image's slot in the hash tables (exact) ...
+    uint32_t nearest, npal, pal_off;                                      // ... or, lossy: nearest entry of palette[pal_off, pal_off + npal)
+    uint64_t src_off, dst_off;
+};
 void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys,
                        uint32_t *counts, const uint32_t *status);
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
-                        const uint8_t *src, uint8_t *dst);
+                        const uint32_t *palettes, const uint8_t *src, uint8_t *dst);
+
+// lossy PNG (oracle: quantize): colour bins of 4 + 5 + 5 + 5 bits (a, r, g, b) with count and channel sums, compacted to a list the
+// host runs the median cut on
+enum { CSP_QBINS = 1 << 19 };
+struct QBin { uint32_t id, cnt, s[4]; };
+struct QuantJob { uint32_t image, channels, bps, rowbytes, width, height; uint64_t src_off, bins_off, list_off; };   // bins_off: in uint32 units (5 per bin); list_off: in QBin units
+void launch_png_qhist(hipStream_t st, const QuantJob *jobs, int njobs, uint32_t max_height, const uint8_t *work, uint32_t *bins);
+void launch_png_qcompact(hipStream_t st, const QuantJob *jobs, int njobs, const uint32_t *bins, QBin *list, uint32_t *nlist);
 
 // P3: row-filter search (k_png_filter.hip)
 struct FilterCtx {

@@ -4,6 +4,7 @@
 // carried-chunk policy, descriptors.  Statement of every stage: oracle/png_oracle.c.
 #include <cstdarg>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -147,6 +148,7 @@ struct csp_batch {
     std::vector<PngAdam7> adam7;
     uint64_t adam7_items = 0;
     bool reduced = false;
+    bool lossy = false;             // png.optimize not set: truecolour images with more than 256 colours are quantised (oracle: quantize)
     uint32_t n_reduced = 0;
     PngPlan plan{};
     int slot_of_strategy[10];
@@ -159,7 +161,9 @@ struct csp_batch {
     DevBuf<PaletteJob> d_pjobs;
     DevBuf<unsigned long long> d_keys;
     DevBuf<uint16_t> d_slot_index;
-    DevBuf<uint32_t> d_counts, d_cand;
+    DevBuf<uint32_t> d_counts, d_cand, d_qbins, d_qn, d_qpal;
+    DevBuf<QuantJob> d_qjobs;
+    DevBuf<QBin> d_qlist;
     DevBuf<PngAdam7> d_adam7;
     DevBuf<uint32_t> d_flags;
     DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_file_len, d_adler, d_crc;
@@ -176,6 +180,52 @@ struct csp_batch {
 
 extern "C" const char *csp_kernel_name(int i) { return (i >= 0 && i < CSP_NKERNELS) ? kPngKernelNames[i] : ""; }
 extern "C" void csp_batch_destroy(csp_batch *b) { delete b; }
+
+// lossy PNG: the median cut over the colour bins of one image (oracle: median_cut).  bins must be sorted by id.  Returns the palette
+// (keys a, r, g, b; sorted, duplicates merged).
+static std::vector<uint32_t> median_cut(const std::vector<QBin> &bins) {
+    const int nbins = int(bins.size());
+    std::vector<int> ord(nbins);
+    for (int i = 0; i < nbins; i++) ord[i] = i;
+    struct Box { int lo, hi; uint64_t cnt; bool dead; };
+    std::vector<Box> box;
+    uint64_t total = 0;
+    for (auto &q : bins) total += q.cnt;
+    box.push_back(Box{0, nbins, total, false});
+    auto mean = [&](int bin, int c) { return int(bins[bin].s[c] / bins[bin].cnt); };
+    while (box.size() < 256) {
+        int pick = -1;
+        for (int k = 0; k < int(box.size()); k++) if (!box[k].dead && box[k].hi - box[k].lo > 1 && (pick < 0 || box[k].cnt > box[pick].cnt)) pick = k;
+        if (pick < 0) break;
+        int axis = 0, range = -1;
+        for (int c = 0; c < 4; c++) {
+            int mn = 255, mx = 0;
+            for (int i = box[pick].lo; i < box[pick].hi; i++) { const int m = mean(ord[i], c); mn = std::min(mn, m); mx = std::max(mx, m); }
+            if (mx - mn > range) { range = mx - mn; axis = c; }
+        }
+        if (range == 0) { box[pick].dead = true; continue; }
+        std::sort(ord.begin() + box[pick].lo, ord.begin() + box[pick].hi, [&](int x, int y) {
+            const int mx = mean(x, axis), my = mean(y, axis);
+            return mx != my ? mx < my : bins[x].id < bins[y].id;
+        });
+        uint64_t cum = 0;
+        int sp = box[pick].lo;
+        while (sp < box[pick].hi - 1) { cum += bins[ord[sp]].cnt; sp++; if (2 * cum >= box[pick].cnt) break; }
+        box.push_back(Box{sp, box[pick].hi, box[pick].cnt - cum, false});
+        box[pick].hi = sp; box[pick].cnt = cum;
+    }
+    std::vector<uint32_t> pal;
+    for (auto &bx : box) {
+        uint64_t sum[4] = {0, 0, 0, 0}, cnt = 0;
+        for (int i = bx.lo; i < bx.hi; i++) { const QBin &q = bins[ord[i]]; cnt += q.cnt; for (int c = 0; c < 4; c++) sum[c] += q.s[c]; }
+        uint32_t v[4];
+        for (int c = 0; c < 4; c++) v[c] = uint32_t((2 * sum[c] + cnt) / (2 * cnt));
+        pal.push_back((v[3] << 24) | (v[0] << 16) | (v[1] << 8) | v[2]);
+    }
+    std::sort(pal.begin(), pal.end());
+    pal.erase(std::unique(pal.begin(), pal.end()), pal.end());
+    return pal;
+}
 
 // (re)build the per-chunk / per-group index arrays from the current geometry of the images
 static int upload_chunk_index(csp_batch *b) {
@@ -203,6 +253,7 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
     std::unique_ptr<csp_batch> b(new csp_batch);
     b->device = device;
+    b->lossy = !p->png_optimize;
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) { csh_set_error("hipEventCreate failed"); return CS_ERR_NO_DEVICE; }
@@ -347,8 +398,45 @@ static int reduce_step(csp_batch *b) {
     }
     std::vector<size_t> item_of(nimg, 0);
     for (size_t n = 0; n < b->items.size(); n++) if (b->items[n].image >= 0) item_of[b->items[n].image] = n;
+    // lossy: truecolour images that keep more than 256 colours after the lossless reductions get their colour bins counted, and the
+    // host runs the median cut on the non-empty bins (a second round trip, only for such images)
+    std::map<int, std::vector<uint32_t>> qpal;
+    if (b->lossy) {
+        std::vector<QuantJob> qjobs;
+        uint64_t list_total = 0;
+        uint32_t qmax_h = 0;
+        for (int i = 0; i < nimg; i++) {
+            if (status[i] || !b->cand0[i] || (flags[i] & 4u) || counts[i] <= 256) continue;
+            const PngImg &im = b->imgs[i];
+            QuantJob q{};
+            q.image = uint32_t(i); q.channels = im.channels; q.bps = im.bps; q.rowbytes = im.rowbytes; q.width = im.width; q.height = im.height; q.src_off = im.pix_off;
+            q.bins_off = uint64_t(qjobs.size()) * CSP_QBINS * 5; q.list_off = list_total;
+            list_total += std::min<uint64_t>(uint64_t(im.width) * im.height, CSP_QBINS);
+            qmax_h = std::max(qmax_h, im.height);
+            qjobs.push_back(q);
+        }
+        // a few images at a time: 10 MB of bins each
+        for (size_t g0 = 0; g0 < qjobs.size(); g0 += 64) {
+            const size_t gn = std::min<size_t>(64, qjobs.size() - g0);
+            std::vector<QuantJob> part(qjobs.begin() + g0, qjobs.begin() + g0 + gn);
+            uint64_t lt = 0;
+            for (size_t k = 0; k < gn; k++) { part[k].bins_off = uint64_t(k) * CSP_QBINS * 5; part[k].list_off = lt; lt += std::min<uint64_t>(uint64_t(part[k].width) * part[k].height, CSP_QBINS); }
+            if (b->d_qbins.alloc(gn * size_t(CSP_QBINS) * 5) || b->d_qbins.zero(st) || b->d_qlist.alloc(lt + 1) || b->d_qn.alloc(gn + 1) || b->d_qn.zero(st) || b->d_qjobs.upload(part, st)) return -1;
+            launch_png_qhist(st, b->d_qjobs.p, int(gn), qmax_h, b->d_work.p, b->d_qbins.p);
+            launch_png_qcompact(st, b->d_qjobs.p, int(gn), b->d_qbins.p, b->d_qlist.p, b->d_qn.p);
+            std::vector<uint32_t> qn(gn);
+            if (hipMemcpyAsync(qn.data(), b->d_qn.p, sizeof(uint32_t) * gn, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+            for (size_t k = 0; k < gn; k++) {
+                std::vector<QBin> bins(qn[k]);
+                if (qn[k] && hipMemcpy(bins.data(), b->d_qlist.p + part[k].list_off, sizeof(QBin) * qn[k], hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                std::sort(bins.begin(), bins.end(), [](const QBin &x, const QBin &y) { return x.id < y.id; });
+                qpal[int(part[k].image)] = median_cut(bins);
+            }
+        }
+    }
     std::vector<ReduceJob> jobs;
     std::vector<PaletteJob> pjobs;
+    std::vector<uint32_t> palettes;
     std::vector<uint16_t> slot_index(size_t(nimg) * CSP_PAL_SLOTS, 0);
     uint32_t max_height = 0;
     bool changed = false;
@@ -362,6 +450,7 @@ static int reduce_step(csp_batch *b) {
         std::vector<uint32_t> pal;
         std::vector<unsigned long long> tab;
         uint32_t depth = 0, ntr = 0;
+        bool nearest = false;
         if (b->cand0[i] && !grey && nbps == 1 && (nk == 3 || nk == 4) && counts[i] <= 256) {
             tab.resize(CSP_PAL_SLOTS);
             if (hipMemcpy(tab.data(), b->d_keys.p + size_t(i) * CSP_PAL_SLOTS, sizeof(unsigned long long) * CSP_PAL_SLOTS, hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -373,6 +462,15 @@ static int reduce_step(csp_batch *b) {
             const uint64_t nrb = (uint64_t(im.width) * depth + 7) / 8, extra = 12 + 3 * uint64_t(n) + (ntr ? 12 + ntr : 0);
             if (uint64_t(im.height) * (1 + nrb) + extra >= uint64_t(im.height) * (1 + uint64_t(im.width) * nk)) depth = 0;
         }
+        // lossy: what is still truecolour is quantised (oracle: quantize) -- the palette was made by the median cut above this loop
+        if (!depth && qpal.count(i)) {
+            pal = qpal[i];
+            const uint32_t n = uint32_t(pal.size());
+            ntr = 0;
+            for (uint32_t k = 0; k < n; k++) if ((pal[k] >> 24) != 255) ntr = k + 1;
+            depth = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
+            nearest = true;
+        }
         if (!depth && !flags[i]) continue;
         changed = true;
         uint8_t *ihdr = &it.prefix[8];   // the new IHDR: depth, colour type, checksum
@@ -380,7 +478,9 @@ static int reduce_step(csp_batch *b) {
             PaletteJob j{};
             j.image = uint32_t(i); j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps; j.depth = depth; j.table = uint32_t(i);
             j.src_off = im.pix_off; j.dst_off = im.raw_off;
-            for (uint32_t sl = 0; sl < CSP_PAL_SLOTS; sl++)
+            j.nearest = nearest ? 1u : 0u; j.npal = uint32_t(pal.size()); j.pal_off = uint32_t(palettes.size());
+            if (nearest) palettes.insert(palettes.end(), pal.begin(), pal.end());
+            for (uint32_t sl = 0; sl < CSP_PAL_SLOTS && !nearest; sl++)
                 if (tab[sl] != ~0ull) slot_index[size_t(i) * CSP_PAL_SLOTS + sl] = uint16_t(std::lower_bound(pal.begin(), pal.end(), uint32_t(tab[sl])) - pal.begin());
             im.channels = 1; im.bps = 0; im.bpp = 1; im.rowbytes = uint32_t((uint64_t(im.width) * depth + 7) / 8);
             ihdr[8 + 8] = uint8_t(depth); ihdr[8 + 9] = 3;
@@ -426,11 +526,12 @@ static int reduce_step(csp_batch *b) {
         b->fixed.insert(b->fixed.end(), it.suffix.begin(), it.suffix.end());
     }
     jobs.push_back(ReduceJob{}); pjobs.push_back(PaletteJob{});   // never empty uploads
-    if (b->d_fixed.upload(b->fixed, st) || b->d_pjobs.upload(pjobs, st) || b->d_slot_index.upload(slot_index, st) ||
+    palettes.push_back(0);
+    if (b->d_fixed.upload(b->fixed, st) || b->d_pjobs.upload(pjobs, st) || b->d_slot_index.upload(slot_index, st) || b->d_qpal.upload(palettes, st) ||
         hipMemcpyAsync(b->d_imgs.p, b->imgs.data(), sizeof(PngImg) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(b->d_jobs.p, jobs.data(), sizeof(ReduceJob) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("PNG reduction upload failed"); return -1; }
     launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()) - 1, max_height, b->d_work.p, b->d_work.p);
-    launch_png_indexed(st, b->d_imgs.p, b->d_pjobs.p, int(pjobs.size()) - 1, max_height, b->d_keys.p, b->d_slot_index.p, b->d_work.p, b->d_work.p);
+    launch_png_indexed(st, b->d_imgs.p, b->d_pjobs.p, int(pjobs.size()) - 1, max_height, b->d_keys.p, b->d_slot_index.p, b->d_qpal.p, b->d_work.p, b->d_work.p);
     return upload_chunk_index(b);   // synchronises: the job vectors may go out of scope
 }
 
@@ -516,7 +617,7 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
         if (!code && status[it.image]) { code = int(status[it.image]); msg = code == int(CSP_ERR_POOL) ? "internal device pool too small" : "malformed PNG data"; }
         if (code) { failed++; if (results) results[i] = png_result(code, msg); continue; }
         const size_t n = flen[it.image];
-        if (n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
+        if (!b->lossy && n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
             outputs[i].data = (uint8_t *)malloc(it.file_size ? it.file_size : 1);
             memcpy(outputs[i].data, b->inputs[i], it.file_size);
             outputs[i].length = it.file_size;

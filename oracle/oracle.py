@@ -95,6 +95,8 @@ def lib():
         L.cso_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(Png))]
         L.cso_png_free.argtypes = [C.POINTER(Png)]
         L.cso_png_reduce.argtypes = [C.POINTER(Png)]
+        L.cso_png_quantize.argtypes = [C.POINTER(Png)]
+        L.cso_png_lossy.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_scores.argtypes = [C.POINTER(Png), C.c_void_p]
         L.cso_png_filter.argtypes = [C.POINTER(Png), C.c_int, C.c_void_p, C.c_void_p]
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
@@ -304,6 +306,10 @@ class PngImage:
         """P2 reductions in place; -> bit mask of what was applied"""
         return lib().cso_png_reduce(self.ptr)
 
+    def quantize(self):
+        """lossy: median cut to at most 256 colours, in place; -> 16 when applied"""
+        return lib().cso_png_quantize(self.ptr)
+
     def scores(self):
         """[height][5 filters][5 scores: MinSum, Entropy, Bigrams, BigEnt, Brute]"""
         out = np.empty((self.im.height, 5, 5), dtype=np.uint64)
@@ -403,3 +409,14 @@ def webp_encode_rgb(rgb, quality):
 
 def webp_quality_to_qi(q):
     return lib().cso_webp_quality_to_qi(q)
+
+
+def png_lossy(data, level=3, keep_metadata=False):
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    rc = lib().cso_png_lossy(data, len(data), level, 1 if keep_metadata else 0, C.byref(out), C.byref(n))
+    if rc:
+        raise PngError(rc)
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res

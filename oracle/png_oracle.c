@@ -411,6 +411,144 @@ int cso_png_reduce(cso_png *P) {
     return (narrow ? 1 : 0) | (opaque ? 2 : 0) | (grey ? 4 : 0) | to_palette(P);
 }
 
+/* ------------------------------------------------------------------------------------------------ lossy PNG: colour quantisation
+ * `-q` on a PNG (png.optimize = false): libcaesium quantises with imagequant 4.4.1 (dithering 1.0) and writes a palette PNG with
+ * lodepng (Cargo.lock:735, :972).  Neither is available and their output cannot be pinned; this is a plain, deterministic,
+ * integer MEDIAN CUT laid out for the GPU, without dithering -- coarser than imagequant on gradients, stated as such:
+ *   1. pixels -> (a, r, g, b) of 8 bits (high bytes of 16-bit samples); bins of 4 + 5 + 5 + 5 bits hold count and channel sums;
+ *   2. boxes over the non-empty bins (ascending bin id): the most populous splittable box is cut along the channel with the
+ *      largest spread of bin means (ties: r, g, b, a) at the weighted median, until 256 boxes;
+ *   3. palette = rounded mean of each box, sorted by (a, r, g, b), duplicates merged; every pixel takes the nearest entry
+ *      (squared distance over the four channels; ties: the lower index).
+ * Applied to truecolour images that still have more than 256 colours after the lossless reductions; everything else (grey,
+ * indexed, few colours) goes through unchanged, which is already exact. */
+typedef struct { uint32_t id, cnt, s[4]; } qbin;   /* s: sums of r, g, b, a */
+typedef struct { int lo, hi; uint64_t cnt; } qbox;  /* bins ord[lo, hi) */
+static const qbin *g_bins; static int g_axis;
+static int bin_mean(const qbin *b, int c) { return (int)(b->s[c] / b->cnt); }
+static int cmp_axis(const void *x, const void *y) {
+    const qbin *a = g_bins + *(const int *)x, *b = g_bins + *(const int *)y;
+    int ma = bin_mean(a, g_axis), mb = bin_mean(b, g_axis);
+    if (ma != mb) return ma < mb ? -1 : 1;
+    return a->id < b->id ? -1 : a->id > b->id;
+}
+static int box_axis(const qbin *bins, const int *ord, const qbox *bx, int *range) {
+    int best = 0, br = -1;
+    for (int c = 0; c < 4; c++) {
+        int mn = 255, mx = 0;
+        for (int i = bx->lo; i < bx->hi; i++) { int m = bin_mean(bins + ord[i], c); if (m < mn) mn = m; if (m > mx) mx = m; }
+        if (mx - mn > br) { br = mx - mn; best = c; }
+    }
+    *range = br;
+    return best;
+}
+static int median_cut(const qbin *bins, int nbins, uint32_t *pal) {
+    int *ord = (int *)malloc(sizeof(int) * (size_t)nbins);
+    for (int i = 0; i < nbins; i++) ord[i] = i;
+    qbox box[256];
+    int nbox = 1;
+    box[0].lo = 0; box[0].hi = nbins; box[0].cnt = 0;
+    for (int i = 0; i < nbins; i++) box[0].cnt += bins[i].cnt;
+    uint8_t dead[256]; memset(dead, 0, sizeof dead);
+    while (nbox < 256) {
+        int pick = -1;
+        for (int k = 0; k < nbox; k++) if (!dead[k] && box[k].hi - box[k].lo > 1 && (pick < 0 || box[k].cnt > box[pick].cnt)) pick = k;
+        if (pick < 0) break;
+        int range, axis = box_axis(bins, ord, &box[pick], &range);
+        if (range == 0) { dead[pick] = 1; continue; }
+        g_bins = bins; g_axis = axis;
+        qsort(ord + box[pick].lo, (size_t)(box[pick].hi - box[pick].lo), sizeof(int), cmp_axis);
+        uint64_t cum = 0;
+        int s = box[pick].lo;
+        while (s < box[pick].hi - 1) { cum += bins[ord[s]].cnt; s++; if (2 * cum >= box[pick].cnt) break; }
+        box[nbox].lo = s; box[nbox].hi = box[pick].hi; box[nbox].cnt = box[pick].cnt - cum;
+        box[pick].hi = s; box[pick].cnt = cum;
+        nbox++;
+    }
+    int n = 0;
+    for (int k = 0; k < nbox; k++) {
+        uint64_t sum[4] = {0, 0, 0, 0}, cnt = 0;
+        for (int i = box[k].lo; i < box[k].hi; i++) { const qbin *b = bins + ord[i]; cnt += b->cnt; for (int c = 0; c < 4; c++) sum[c] += b->s[c]; }
+        uint32_t v[4];
+        for (int c = 0; c < 4; c++) v[c] = (uint32_t)((2 * sum[c] + cnt) / (2 * cnt));
+        pal[n++] = (v[3] << 24) | (v[0] << 16) | (v[1] << 8) | v[2];
+    }
+    free(ord);
+    qsort(pal, (size_t)n, sizeof pal[0], cmp_u32);
+    int m = 0;
+    for (int k = 0; k < n; k++) if (!m || pal[k] != pal[m - 1]) pal[m++] = pal[k];
+    return m;
+}
+/* truecolour (8 or 16 bit) with more than 256 colours -> an 8-bit indexed image; returns 16 when applied */
+static int quantize(cso_png *P) {
+    if (P->no_reduce || (P->ctype != 2 && P->ctype != 6) || P->nplte) return 0;
+    const int ch = P->channels, bps = P->depth / 8;
+    const size_t npx = (size_t)P->width * P->height;
+    {   /* at most 256 distinct pixels (high bytes): nothing to quantise, the image stays as the lossless reductions left it */
+        uint32_t seen[257];
+        int ns = 0;
+        for (uint32_t y = 0; y < P->height && ns <= 256; y++)
+            for (uint32_t x = 0; x < P->width && ns <= 256; x++) {
+                const uint8_t *px = P->pix + (size_t)y * P->rowbytes + (size_t)x * ch * bps;
+                const uint32_t key = ((uint32_t)(ch == 4 ? px[3 * bps] : 255) << 24) | ((uint32_t)px[0] << 16) | ((uint32_t)px[bps] << 8) | px[2 * bps];
+                int k = 0;
+                while (k < ns && seen[k] != key) k++;
+                if (k == ns) seen[ns++] = key;
+            }
+        if (ns <= 256) return 0;
+    }
+    qbin *all = (qbin *)calloc(1u << 19, sizeof(qbin));
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) {
+            const uint8_t *px = P->pix + (size_t)y * P->rowbytes + (size_t)x * ch * bps;
+            const uint32_t r = px[0], g = px[bps], b = px[2 * bps], a = ch == 4 ? px[3 * bps] : 255u;
+            qbin *q = all + (((a >> 4) << 15) | ((r >> 3) << 10) | ((g >> 3) << 5) | (b >> 3));
+            q->cnt++; q->s[0] += r; q->s[1] += g; q->s[2] += b; q->s[3] += a;
+        }
+    int nbins = 0;
+    for (uint32_t i = 0; i < (1u << 19); i++) if (all[i].cnt) { all[nbins] = all[i]; all[nbins].id = i; nbins++; }
+    uint32_t pal[256];
+    const int n = median_cut(all, nbins, pal);
+    free(all);
+    (void)npx;
+    int ntr = 0;
+    for (int k = 0; k < n; k++) if ((pal[k] >> 24) != 255) ntr = k + 1;
+    const int d = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
+    const size_t nrb = ((size_t)P->width * d + 7) / 8;
+    uint8_t *np = (uint8_t *)calloc(nrb, P->height);
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) {
+            const uint8_t *px = P->pix + (size_t)y * P->rowbytes + (size_t)x * ch * bps;
+            const int r = px[0], g = px[bps], b = px[2 * bps], a = ch == 4 ? px[3 * bps] : 255;
+            int best = 0; uint32_t bd = ~0u;
+            for (int k = 0; k < n; k++) {
+                const int dr = r - (int)((pal[k] >> 16) & 255), dg = g - (int)((pal[k] >> 8) & 255), db = b - (int)(pal[k] & 255), da = a - (int)(pal[k] >> 24);
+                const uint32_t dist = (uint32_t)(dr * dr + dg * dg + db * db + da * da);
+                if (dist < bd) { bd = dist; best = k; }
+            }
+            const size_t bit = (size_t)x * d;
+            np[(size_t)y * nrb + bit / 8] |= (uint8_t)(best << (8 - d - (bit & 7)));
+        }
+    free(P->pix);
+    P->pix = np; P->rowbytes = nrb; P->channels = 1; P->depth = d; P->bpp = 1; P->ctype = 3; P->nplte = n;
+    const size_t extra = 12 + 3 * (size_t)n + (ntr ? 12 + (size_t)ntr : 0);
+    uint8_t *ins = (uint8_t *)malloc(extra), *w = ins;
+    put_be32(w, (uint32_t)(3 * n)); memcpy(w + 4, "PLTE", 4);
+    for (int k = 0; k < n; k++) { w[8 + 3 * k] = (uint8_t)(pal[k] >> 16); w[9 + 3 * k] = (uint8_t)(pal[k] >> 8); w[10 + 3 * k] = (uint8_t)pal[k]; }
+    put_be32(w + 8 + 3 * n, cso_crc32(0, w + 4, 4 + 3 * (size_t)n)); w += 12 + 3 * n;
+    if (ntr) {
+        put_be32(w, (uint32_t)ntr); memcpy(w + 4, "tRNS", 4);
+        for (int k = 0; k < ntr; k++) w[8 + k] = (uint8_t)(pal[k] >> 24);
+        put_be32(w + 8 + ntr, cso_crc32(0, w + 4, 4 + (size_t)ntr)); w += 12 + ntr;
+    }
+    uint8_t *nc = (uint8_t *)malloc(P->chunks_len + extra);
+    memcpy(nc, P->chunks, P->idat_at); memcpy(nc + P->idat_at, ins, extra); memcpy(nc + P->idat_at + extra, P->chunks + P->idat_at, P->chunks_len - P->idat_at);
+    free(P->chunks); free(ins);
+    P->chunks = nc; P->chunks_len += extra; P->idat_at += extra;
+    return 16;
+}
+int cso_png_quantize(cso_png *P) { return quantize(P); }
+
 /* ------------------------------------------------------------------------------------------------ row filters */
 static void filter_row(int ft, const uint8_t *cur, const uint8_t *up, size_t n, int bpp, uint8_t *dst) {
     dst[0] = (uint8_t)ft;
@@ -761,11 +899,12 @@ int cso_png_trials(int level, int *set) {
     memcpy(set, s, sizeof(int) * (size_t)n);
     return n;
 }
-int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen) {
+static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata, int lossy, uint8_t **out, size_t *out_len, int *chosen) {
     cso_png *P = NULL;
     int rc = cso_png_decode(in, n, keep_metadata, &P);
     if (rc) return rc;
     cso_png_reduce(P);
+    if (lossy) quantize(P);
     size_t raw_len = (1 + P->rowbytes) * (size_t)P->height;
     uint8_t *filt = (uint8_t *)malloc(raw_len), *best = NULL;
     size_t best_len = 0;
@@ -793,7 +932,14 @@ int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, 
     free(best);
     cso_png_free(P);
     if (chosen) *chosen = best_s;
-    if (total >= n) { free(o); o = (uint8_t *)malloc(n); memcpy(o, in, n); total = n; if (chosen) *chosen = -1; }
+    if (!lossy && total >= n) { free(o); o = (uint8_t *)malloc(n); memcpy(o, in, n); total = n; if (chosen) *chosen = -1; }   /* oxipng: "already optimised" */
     *out = o; *out_len = total;
     return 0;
+}
+int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen) {
+    return png_recode(in, n, level, keep_metadata, 0, out, out_len, chosen);
+}
+/* `-q` on a PNG: the reductions, the quantiser, then the same filter trials and coder; the result is returned whatever its size */
+int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len) {
+    return png_recode(in, n, level, keep_metadata, 1, out, out_len, NULL);
 }

@@ -188,3 +188,8 @@ def oracle_jpeg_to_webp(src, quality=80, width=0, height=0):
     if nc == 1:
         rgb = np.repeat(rgb, 3, axis=2)
     return O.webp_encode_rgb(rgb, quality)
+
+
+def oracle_png_lossy(src, level=3, keep_metadata=False):
+    from oracle import oracle as O
+    return O.png_lossy(src, level, keep_metadata)

@@ -312,8 +312,7 @@ def end_to_end(binary, tree, tmp_path):
     assert [f["status"] for f in j["files"]] == ["success"] * 2 and j["files"][0]["output_path"].endswith("j1.webp")
     assert open(j["files"][0]["output_path"], "rb").read() == oracle_jpeg_to_webp(files["level_1_0/j1.jpg"], 85, 0, 90)
     assert open(j["files"][1]["output_path"], "rb").read() == oracle_jpeg_to_webp(files["j0.JPG"], 85, 90, 0)
-    # 10. PNG: --lossless runs the device PNG pipeline (mixed with JPEG in one run, order kept); -q on a PNG (lossy PNG) has no
-    # device path and fails per file
+    # 10. PNG: --lossless runs the device PNG pipeline (mixed with JPEG in one run, order kept)
     from _util import oracle_png
     from gen_synth import synth_png
     mixed = tmp_path / "mixed"
@@ -329,12 +328,23 @@ def end_to_end(binary, tree, tmp_path):
         name = os.path.basename(f["original_path"])
         want = oracle_png(pngs[name], 2) if name in pngs else oracle_lossless(files["level_1_0/j1.jpg"])
         assert open(f["output_path"], "rb").read() == want, name
-    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "mq", "--json", mixed / "a.png").stdout)
-    assert j["files"][0]["status"] == "error" and j["files"][0]["message"].startswith("Error compressing file: ")
+
+
+def lossy_png_step(binary, tmp_path):
+    """-q on a PNG: the lossy (quantising) form of the PNG pipeline.  Its own step: on the device it runs from tests/test_zz_png_lossy_gpu.py"""
+    from _util import oracle_png_lossy
+    from gen_synth import synth_png
+    d = tmp_path / "lossy_in"
+    d.mkdir()
+    png = synth_png(60, 120, 80, "RGB", compress_level=1)
+    (d / "a.png").write_bytes(png)
+    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "mq", "--json", d / "a.png").stdout)
+    assert j["files"][0]["status"] == "success" and open(j["files"][0]["output_path"], "rb").read() == oracle_png_lossy(png)
 
 
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
+    lossy_png_step(EMUL_CLI, tmp_path)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,52 @@
+"""`-q` on a PNG (png.optimize not set): the reductions, the median-cut quantiser and the same filter trials / coder, emulated
+kernels against the oracle; the device run is tests/test_zz_png_lossy_gpu.py.  What the quantiser is and is not: oracle/png_oracle.c."""
+import io
+
+import numpy as np
+import pytest
+
+from _util import emul_api, oracle_png_lossy, package, png_cases
+from gen_synth import synth_png
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def lossy_cases(big=False):
+    names = ("RGB_97x61", "RGBA_97x61", "L_97x61", "P_97x61", "I;16_97x61", "RGB_200x150_3chunks", "reduce_rgba_opaque", "reduce_rgb_grey", "palette_rgb_few", "palette_rgba_translucent",
+             "palette_257_colours", "adam7_RGB_33x21", "RGB_1x1", "RGBA_300x2")
+    cases = [c for c in png_cases() if c[0] in names]
+    cases.append(("RGBA_soft_alpha", synth_png(71, 120, 90, "RGBA", texture=5.0)))
+    if big:
+        cases.append(("RGB_640x480", synth_png(72, 640, 480, "RGB", texture=2.0)))
+    return cases
+
+
+def check_lossy(api, cases, level=2):
+    pkg = package()
+    outs = api.cs_batch_compress([c[1] for c in cases], pkg.default_parameters(png_optimize=False, png_optimization_level=level))
+    for (name, src), out in zip(cases, outs):
+        assert not isinstance(out, Exception), (name, out)
+        assert out == oracle_png_lossy(src, level), name
+        a, b = PIL.open(io.BytesIO(src)), PIL.open(io.BytesIO(out))
+        assert a.size == b.size
+        if a.mode != "I;16":
+            x, y = np.asarray(a.convert("RGBA")).astype(np.float64), np.asarray(b.convert("RGBA")).astype(np.float64)
+            mse = ((x - y) ** 2).mean()
+            assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) > 30, name   # at most 256 colours, no dithering: still close
+
+
+def test_lossy_equals_oracle(api):
+    check_lossy(api, lossy_cases())
+
+
+def test_quantised_files_are_indexed(api):
+    pkg = package()
+    src = dict(lossy_cases())["RGB_200x150_3chunks"]
+    out = api.cs_batch_compress([src], pkg.default_parameters(png_optimize=False))[0]
+    im = PIL.open(io.BytesIO(out))
+    assert im.mode == "P" and len(out) < len(src)

@@ -1,0 +1,28 @@
+"""`-q` on a PNG on the device, through the C ABI, against the oracle (file bytes).  Last in the alphabet on purpose: this path was
+written after the round's GPU budget was spent and has only been validated in the emulation build."""
+import pytest
+
+from _util import product_api
+from test_png_lossy_emul import check_lossy, lossy_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    a = product_api()
+    assert a.device_count() >= 1, "no HIP device: libcaesium_hip has no CPU path"
+    return a
+
+
+def test_lossy_equals_oracle(api):
+    check_lossy(api, lossy_cases(big=True))
+    check_lossy(api, lossy_cases()[:4], level=0)
+
+
+def test_cli_lossy_png_on_device(tmp_path):
+    import os
+
+    from test_cli import PRODUCT_CLI, lossy_png_step
+    assert os.path.exists(PRODUCT_CLI)
+    lossy_png_step(PRODUCT_CLI, tmp_path)
