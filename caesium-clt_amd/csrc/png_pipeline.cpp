@@ -426,12 +426,25 @@ static int reduce_step(csp_batch *b) {
             launch_png_qcompact(st, b->d_qjobs.p, int(gn), b->d_qbins.p, b->d_qlist.p, b->d_qn.p);
             std::vector<uint32_t> qn(gn);
             if (hipMemcpyAsync(qn.data(), b->d_qn.p, sizeof(uint32_t) * gn, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+            std::vector<std::vector<QBin>> lists(gn);
             for (size_t k = 0; k < gn; k++) {
-                std::vector<QBin> bins(qn[k]);
-                if (qn[k] && hipMemcpy(bins.data(), b->d_qlist.p + part[k].list_off, sizeof(QBin) * qn[k], hipMemcpyDeviceToHost) != hipSuccess) return -1;
-                std::sort(bins.begin(), bins.end(), [](const QBin &x, const QBin &y) { return x.id < y.id; });
-                qpal[int(part[k].image)] = median_cut(bins);
+                lists[k].resize(qn[k]);
+                if (qn[k] && hipMemcpy(lists[k].data(), b->d_qlist.p + part[k].list_off, sizeof(QBin) * qn[k], hipMemcpyDeviceToHost) != hipSuccess) return -1;
             }
+            // the cuts of different images are independent: host threads (a 4K photograph has ~10^5 bins, tens of milliseconds each)
+            std::vector<std::vector<uint32_t>> cut(gn);
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t k; (k = next++) < gn;) {
+                    std::sort(lists[k].begin(), lists[k].end(), [](const QBin &x, const QBin &y) { return x.id < y.id; });
+                    cut[k] = median_cut(lists[k]);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < std::min<size_t>(gn, std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()))); t++) pool.emplace_back(worker);
+            worker();
+            for (auto &t : pool) t.join();
+            for (size_t k = 0; k < gn; k++) qpal[int(part[k].image)] = std::move(cut[k]);
         }
     }
     std::vector<ReduceJob> jobs;
