@@ -27,14 +27,19 @@ __global__ void __launch_bounds__(256) k_png_analyze(const PngImg *imgs, const u
     if (!bps) return;
     uint32_t keep = flags[image];   // only ever cleared: a stale read costs work, not correctness
     if (!keep) return;
+    const uint32_t start = keep;
     const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
     for (uint32_t x = threadIdx.x; x < im.width && keep; x += blockDim.x) {
         const uint8_t *px = r + uint64_t(x) * ch * bps;
         if (keep & 1u) for (uint32_t k = 0; k < ch; k++) if (px[2 * k] != px[2 * k + 1]) keep &= ~1u;
         if (keep & 2u) for (uint32_t b = 0; b < bps; b++) if (px[(ch - 1) * bps + b] != 0xFF) keep &= ~2u;
         if (keep & 4u) for (uint32_t b = 0; b < bps; b++) if (px[b] != px[bps + b] || px[b] != px[2 * bps + b]) keep &= ~4u;
+        const uint32_t v = px[0];   // the grey level, if the image turns out grey (high byte of a 16-bit sample)
+        if ((keep & 8u) && v % 17u) keep &= ~8u;
+        if ((keep & 16u) && v % 85u) keep &= ~16u;
+        if ((keep & 32u) && v % 255u) keep &= ~32u;
     }
-    if (keep != 7u) atomicAnd(&flags[image], keep);
+    if (keep != start) atomicAnd(&flags[image], keep);
 }
 __global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const ReduceJob *jobs, const uint8_t *src, uint8_t *dst) {
     const ReduceJob j = jobs[blockIdx.y];
@@ -45,6 +50,19 @@ __global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const Re
     const bool opaque = j.mask & 2u, grey = j.mask & 4u;
     const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
     uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
+    if (j.gdepth) {   // an 8-bit grey result packed to 4, 2 or 1 bit: one lane per byte of the new row
+        const uint32_t per = 8u / j.gdepth, div = 255u / ((1u << j.gdepth) - 1u);
+        for (uint32_t bx = threadIdx.x; bx < im.rowbytes; bx += blockDim.x) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < per; k++) {
+                const uint32_t x = bx * per + k;
+                if (x >= im.width) break;
+                v |= (uint32_t(s[uint64_t(x) * j.old_channels * j.old_bps]) / div) << (8u - j.gdepth - k * j.gdepth);
+            }
+            d[bx] = uint8_t(v);
+        }
+        return;
+    }
     for (uint32_t x = threadIdx.x; x < im.width; x += blockDim.x) {
         uint32_t k2 = 0;
         for (uint32_t k = 0; k < j.old_channels; k++) {

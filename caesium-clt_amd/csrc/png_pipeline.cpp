@@ -337,7 +337,7 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         im.chunk_stride = im.nchunks;
         im.channels = it.channels; im.bps = (it.ctype != 3 && it.depth >= 8) ? it.depth / 8 : 0;
         b->cand0.push_back((!it.no_reduce && !it.has_plte && im.bps && (im.channels == 3 || im.channels == 4)) ? im.channels : 0u);
-        b->flags0.push_back((it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u)));
+        b->flags0.push_back((it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u) | 56u));
         if (nchunk_recs > 0x7FFFFFFFu) { csh_set_error("PNG batch too large"); return CS_ERR_POOL_OVERFLOW; }
         im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
         im.fix_off = fixed.size();
@@ -484,7 +484,10 @@ static int reduce_step(csp_batch *b) {
             depth = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
             nearest = true;
         }
-        if (!depth && !flags[i]) continue;
+        // 8-bit grey -> 4 / 2 / 1 bit (oracle: grey_depth): the result is a single 8-bit channel whose every level fits
+        uint32_t gdepth = 0;
+        if (!depth && nk == 1 && nbps == 1) gdepth = (flags[i] & 32u) ? 1u : (flags[i] & 16u) ? 2u : (flags[i] & 8u) ? 4u : 0u;
+        if (!depth && !(flags[i] & 7u) && !gdepth) continue;
         changed = true;
         uint8_t *ihdr = &it.prefix[8];   // the new IHDR: depth, colour type, checksum
         if (depth) {
@@ -513,10 +516,12 @@ static int reduce_step(csp_batch *b) {
             pjobs.push_back(j);
         } else {
             ReduceJob j{};
-            j.image = uint32_t(i); j.mask = flags[i]; j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps;
+            j.image = uint32_t(i); j.mask = flags[i] & 7u; j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps;
             j.src_off = im.pix_off; j.dst_off = im.raw_off;   // the second region of the image takes the new pixels
+            j.gdepth = gdepth;
             im.channels = nk; im.bps = nbps; im.bpp = nk * nbps; im.rowbytes = im.width * nk * nbps;
-            ihdr[8 + 8] = uint8_t(nbps * 8); ihdr[8 + 9] = uint8_t(nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6);
+            if (gdepth) { im.bps = 0; im.bpp = 1; im.rowbytes = uint32_t((uint64_t(im.width) * gdepth + 7) / 8); }
+            ihdr[8 + 8] = uint8_t(gdepth ? gdepth : nbps * 8); ihdr[8 + 9] = uint8_t(nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6);
             jobs.push_back(j);
         }
         ihdr = &it.prefix[8];

@@ -318,8 +318,8 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
  * The subset of oxipng's reductions that needs no palette: 16 -> 8 bits when every sample's two bytes are equal; alpha
  * dropped when every pixel is opaque; colour -> grey when r == g == b everywhere.  Applied in that order, always (oxipng
  * evaluates both variants and keeps the smaller; for these three the reduced image practically always wins), and never
- * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Then colour -> palette (to_palette).  Depth reductions of
- * grey / palette images: not built. */
+ * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Then colour -> palette (to_palette) and 8-bit grey -> 4 / 2 / 1 bit
+ * (grey_depth).  Depth reductions of images that come in indexed: not built. */
 /* colour -> palette: an 8-bit RGB / RGBA image with at most 256 distinct pixels becomes an indexed one (entries sorted by
    alpha, then red, green, blue, so that the translucent ones come first and tRNS stops at the last of them; index depth 1, 2, 4
    or 8 by their number) when the indexed rows plus the PLTE / tRNS chunks are smaller than the rows were.  Returns 8 or 0. */
@@ -375,6 +375,31 @@ static int to_palette(cso_png *P) {
     P->chunks = nc; P->chunks_len += extra; P->idat_at += extra;
     return 8;
 }
+/* 8-bit grey -> 4, 2 or 1 bit when every sample is a multiple of 17, 85 or 255 (the values those depths can express).  Returns 32 or 0. */
+static int grey_depth(cso_png *P) {
+    if (P->ctype != 0 || P->depth != 8) return 0;
+    int ok4 = 1, ok2 = 1, ok1 = 1;
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) {
+            const int v = P->pix[(size_t)y * P->rowbytes + x];
+            if (v % 17) ok4 = 0;
+            if (v % 85) ok2 = 0;
+            if (v % 255) ok1 = 0;
+        }
+    const int d = ok1 ? 1 : ok2 ? 2 : ok4 ? 4 : 0;
+    if (!d) return 0;
+    const size_t nrb = ((size_t)P->width * d + 7) / 8;
+    uint8_t *np = (uint8_t *)calloc(nrb, P->height);
+    const int div = 255 / ((1 << d) - 1);
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) {
+            const size_t bit = (size_t)x * d;
+            np[(size_t)y * nrb + bit / 8] |= (uint8_t)((P->pix[(size_t)y * P->rowbytes + x] / div) << (8 - d - (bit & 7)));
+        }
+    free(P->pix);
+    P->pix = np; P->rowbytes = nrb; P->depth = d; P->bpp = 1;
+    return 32;
+}
 int cso_png_reduce(cso_png *P) {
     if (P->no_reduce || P->ctype == 3 || P->depth < 8) return 0;
     const int bps = P->depth / 8, ch = P->channels;
@@ -390,7 +415,7 @@ int cso_png_reduce(cso_png *P) {
         }
     }
     (void)npx;
-    if (!narrow && !opaque && !grey) return to_palette(P);
+    if (!narrow && !opaque && !grey) return to_palette(P) | grey_depth(P);
     const int nbps = narrow ? 1 : bps;
     int keep[4], nk = 0;   /* source channels that survive */
     for (int k = 0; k < ch; k++) {
@@ -408,7 +433,7 @@ int cso_png_reduce(cso_png *P) {
     free(P->pix);
     P->pix = np; P->rowbytes = nrow; P->channels = nk; P->depth = nbps * 8; P->bpp = nk * nbps;
     P->ctype = nk == 1 ? 0 : nk == 2 ? 4 : nk == 3 ? 2 : 6;
-    return (narrow ? 1 : 0) | (opaque ? 2 : 0) | (grey ? 4 : 0) | to_palette(P);
+    return (narrow ? 1 : 0) | (opaque ? 2 : 0) | (grey ? 4 : 0) | to_palette(P) | grey_depth(P);
 }
 
 /* ------------------------------------------------------------------------------------------------ lossy PNG: colour quantisation

@@ -109,6 +109,13 @@ def png_cases(small=True):
     cases.append(("palette_two_colours", save(Image.fromarray(two, "RGB"))))
     many = np.zeros((20, 300, 3), np.uint8); many[:, :, 0] = np.arange(300)[None, :] % 257 % 256; many[:, 256:, 1] = 7   # 257 distinct colours
     cases.append(("palette_257_colours", save(Image.fromarray(many, "RGB"))))
+    # grey depth: black-and-white stored as 8-bit grey / as RGB, 16 levels, 4 levels behind an opaque alpha, and noise that stays 8-bit
+    bw = (rng.random((60, 83)) > 0.5).astype(np.uint8) * 255
+    cases.append(("greydepth_bw_L", save(Image.fromarray(bw, "L"))))
+    cases.append(("greydepth_bw_RGB", save(Image.fromarray(np.dstack([bw] * 3), "RGB"))))
+    cases.append(("greydepth_16_levels", save(Image.fromarray((rng.integers(0, 16, (60, 83)) * 17).astype(np.uint8), "L"))))
+    g2 = (rng.integers(0, 4, (60, 83)) * 85).astype(np.uint8)
+    cases.append(("greydepth_4_levels_RGBA", save(Image.fromarray(np.dstack([g2] * 3 + [np.full_like(g2, 255)]), "RGBA"))))
     # Adam7 inputs: every kind of pixel, sizes around the 8x8 pattern (empty passes included)
     for k, (mode, w, h) in enumerate([("RGB", 33, 21), ("RGBA", 9, 9), ("L", 5, 3), ("P", 40, 17), ("1", 37, 11), ("I;16", 12, 20), ("LA", 2, 1), ("RGB", 1, 1), ("L", 8, 8)]):
         cases.append((f"adam7_{mode}_{w}x{h}", adam7_png(synth_png(40 + k, w, h, mode))))

@@ -120,6 +120,7 @@ def test_reductions_keep_what_the_pixels_mean():
     from _util import png_cases
     want = {"reduce_rgba_opaque": ("RGB", 2), "reduce_rgb_grey": ("L", 4), "reduce_rgba_grey_opaque": ("L", 6), "reduce_la_opaque": ("L", 2), "reduce_i16_narrow": ("L", 1),
             "reduce_rgba_nearly_opaque": ("RGBA", 0), "reduce_rgb_nearly_grey": ("P", 8),   # not grey, but at most 256 distinct pixels: indexed
+            "greydepth_bw_L": ("1", 32), "greydepth_bw_RGB": ("1", 36), "greydepth_16_levels": ("L", 32), "greydepth_4_levels_RGBA": ("L", 38),
             "palette_rgb_few": ("P", 8), "palette_rgba_translucent": ("P", 8), "palette_two_colours": ("P", 8), "palette_257_colours": ("RGB", 0), "reduce_blocked_by_trns": ("RGB", 0)}
     for name, data in png_cases():
         if name not in want:
