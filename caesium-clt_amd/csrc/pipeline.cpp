@@ -397,7 +397,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 it.file_size = inputs[n].length;
                 int type = sniff_type(inputs[n].data, inputs[n].length);
                 if (type == CS_TYPE_UNKN) { it.code = CS_ERR_UNKNOWN_TYPE; it.msg = "unknown file type"; }
-                else if (type != CS_TYPE_JPEG) { it.code = CS_ERR_UNSUPPORTED; it.msg = "only JPEG has a device path in this build"; }
+                else if (type != CS_TYPE_JPEG) { it.code = CS_ERR_UNSUPPORTED; it.msg = "this input format has no device path in this build (built: JPEG, PNG)"; }
                 else it.code = parse_jpeg(inputs[n].data, inputs[n].length, it.in, it.msg);
             }
         };
