@@ -22,14 +22,13 @@ namespace {
 uint32_t be32(const uint8_t *p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
 void put_be32(uint8_t *p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); }
 uint32_t crc32_host(const uint8_t *p, size_t n) {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
-        init = true;
-    }
+    struct Table {   // built once, thread-safe (the boundary is called from several host threads)
+        uint32_t t[256];
+        Table() { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; t[i] = c; } }
+    };
+    static const Table table;
     uint32_t crc = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    for (size_t i = 0; i < n; i++) crc = table.t[(crc ^ p[i]) & 255] ^ (crc >> 8);
     return ~crc;
 }
 const uint8_t kSig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
