@@ -61,7 +61,7 @@ static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCS
 static int sniff(const uint8_t *d, size_t n);
 // lossless PNG (png.optimize): groups sized by what they occupy in HBM -- per file the inflated stream, the pixels, one
 // filtered stream per trial slot (up to 10) and the output region, ~13 x the raw size
-static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results, bool to_webp = false) {
     int failed_total = 0;
     const uint64_t budget = uint64_t(96) << 30;
     for (size_t g0 = 0; g0 < count;) {
@@ -80,7 +80,7 @@ static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSP
         csp_batch *b = nullptr;
         const bool trace = getenv("CSH_TRACE") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
-        int rc = csp_batch_create(inputs + g0, n, p, device, &b);
+        int rc = to_webp ? csp_batch_create_webp(inputs + g0, n, p, device, &b) : csp_batch_create(inputs + g0, n, p, device, &b);
         auto t1 = std::chrono::steady_clock::now();
         if (rc == 0) rc = csp_batch_run(b, nullptr);
         auto t2 = std::chrono::steady_clock::now();
@@ -220,20 +220,20 @@ static int sniff(const uint8_t *d, size_t n) {
     return CS_TYPE_UNKN;
 }
 
-// convert: JPEG -> WebP runs on the device (same decode and resize as the JPEG path, then the VP8 encoder); every other pair
-// of formats has no device path
+// convert: JPEG -> WebP (the JPEG path's decode and resize, then the VP8 encoder) and opaque PNG -> WebP (the PNG path's decode, then
+// the same encoder) run on the device; every other pair of formats has no device path
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
-    std::vector<size_t> ok;
+    std::vector<size_t> ok, okpng;
     for (size_t i = 0; i < count; i++) {
         outputs[i].data = nullptr; outputs[i].length = 0;
         const int src = sniff(inputs[i].data, inputs[i].length);
         int code = 0; const char *msg = nullptr;
         if (src == CS_TYPE_UNKN) { code = CS_ERR_UNKNOWN_TYPE; msg = "unknown file type"; }
         else if (uint32_t(src) == format) { code = CS_ERR_SAME_FORMAT; msg = "cannot convert to the same format"; }
-        else if (src != CS_TYPE_JPEG || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP)"; }
+        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP, PNG -> WebP)"; }
         else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
-        if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else ok.push_back(i);
+        if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
     for (size_t g0 = 0; g0 < ok.size(); g0 += 1024) {
         const size_t n = ok.size() - g0 < 1024 ? ok.size() - g0 : 1024;
@@ -250,6 +250,14 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         }
         csh_batch_destroy(b);
         failed_total += failed < 0 ? int(n) : failed;
+    }
+    if (!okpng.empty()) {
+        const size_t n = okpng.size();
+        std::vector<CByteArray> in(n), out(n);
+        std::vector<CCSResult> res(n);
+        for (size_t k = 0; k < n; k++) in[k] = inputs[okpng[k]];
+        failed_total += png_batch_compress(in.data(), n, p, device, out.data(), res.data(), true);
+        for (size_t k = 0; k < n; k++) { outputs[okpng[k]] = out[k]; if (results) results[okpng[k]] = res[k]; else cs_free_result(&res[k]); }
     }
     return failed_total;
 }

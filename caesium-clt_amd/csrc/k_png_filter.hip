@@ -151,6 +151,39 @@ __global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const P
         }
     }
 }
+// ---- PNG -> WebP: one lane per pixel, any opaque PNG format to the 8-bit samples the VP8 encoder imports.  16-bit samples round as
+// image-rs converts them ((v + 128) / 257 [UPSTREAM-RECALL]); sub-byte grey scales to the full range; a palette index past the
+// PLTE decodes as black
+__global__ void __launch_bounds__(256) k_png_rgb(const RgbJob *jobs, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status) {
+    const RgbJob j = jobs[blockIdx.y];
+    const uint32_t y = blockIdx.x;
+    if (y >= j.height || status[j.image]) return;
+    const uint8_t *r = work + j.src_off + uint64_t(y) * j.rowbytes;
+    const uint8_t *pal = plte + j.plte_off;
+    const uint32_t nc = j.ctype == 0 ? 1u : 3u;
+    uint8_t *d = rgb + j.dst_off + uint64_t(y) * j.width * nc;
+    auto narrow = [](const uint8_t *p) { return uint8_t((((uint32_t(p[0]) << 8) | p[1]) + 128u) / 257u); };
+    for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
+        if (j.ctype == 2) {
+            uint8_t *o = d + uint64_t(x) * 3;
+            if (j.depth == 16) { const uint8_t *p = r + uint64_t(x) * 6; o[0] = narrow(p); o[1] = narrow(p + 2); o[2] = narrow(p + 4); }
+            else { const uint8_t *p = r + uint64_t(x) * 3; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+            continue;
+        }
+        uint32_t v;
+        if (j.depth == 16) v = narrow(r + uint64_t(x) * 2);
+        else if (j.depth == 8) v = r[x];
+        else {
+            const uint32_t per = 8u / j.depth, k = x % per;
+            v = (uint32_t(r[x / per]) >> (8u - j.depth - k * j.depth)) & ((1u << j.depth) - 1u);
+            if (j.ctype == 0) v *= 255u / ((1u << j.depth) - 1u);
+        }
+        if (j.ctype == 3) {
+            uint8_t *o = d + uint64_t(x) * 3;
+            if (v < j.npal) { o[0] = pal[3 * v]; o[1] = pal[3 * v + 1]; o[2] = pal[3 * v + 2]; } else { o[0] = 0; o[1] = 0; o[2] = 0; }
+        } else d[x] = uint8_t(v);
+    }
+}
 // ---- lossy PNG: colour bins
 __global__ void __launch_bounds__(256) k_png_qhist(const QuantJob *jobs, const uint8_t *work, uint32_t *bins) {
     const QuantJob j = jobs[blockIdx.y];
@@ -182,6 +215,9 @@ void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, 
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
                         const uint32_t *palettes, const uint8_t *src, uint8_t *dst) {
     if (njobs) CSH_LAUNCH_PHASED(k_png_indexed, 2, dim3(max_height, njobs), dim3(256), st, imgs, jobs, keys, slot_index, palettes, src, dst);
+}
+void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_height, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status) {
+    if (njobs) CSH_LAUNCH(k_png_rgb, dim3(max_height, njobs), dim3(256), st, jobs, plte, work, rgb, status);
 }
 void launch_png_qhist(hipStream_t st, const QuantJob *jobs, int njobs, uint32_t max_height, const uint8_t *work, uint32_t *bins) {
     if (njobs) CSH_LAUNCH(k_png_qhist, dim3(max_height, njobs), dim3(256), st, jobs, work, bins);

@@ -33,6 +33,10 @@ void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, 
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
                         const uint32_t *palettes, const uint8_t *src, uint8_t *dst);
 
+// conversion to WebP: the decoded pixels of any opaque PNG format as 8-bit RGB (grey stays one channel) for k_webp_yuv
+struct RgbJob { uint32_t image, width, height, rowbytes, ctype, depth, plte_off, npal; uint64_t src_off, dst_off; };
+void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_height, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status);
+
 // lossy PNG (oracle: quantize): colour bins of 4 + 5 + 5 + 5 bits (a, r, g, b) with count and channel sums, compacted to a list the
 // host runs the median cut on
 enum { CSP_QBINS = 1 << 19 };

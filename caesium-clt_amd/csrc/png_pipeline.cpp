@@ -12,6 +12,7 @@
 #include "../../include/caesium_hip.h"
 #include "devmem.hpp"
 #include "png_kernels.h"
+#include "webp_kernels.h"
 
 using namespace csp;
 using csh::DevBuf;
@@ -41,7 +42,8 @@ struct PngItem {
     uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0, channels = 0, depth = 0, ctype = 0;
     bool no_reduce = false;   // a carried chunk is tied to the colour type (tRNS, bKGD, sBIT)
     bool interlace = false;   // Adam7 input (the output never is)
-    bool has_plte = false;
+    bool has_plte = false, has_trns = false;
+    std::vector<uint8_t> plte;                      // PLTE payload (conversion to WebP reads it)
     std::vector<std::pair<size_t, size_t>> idat;   // (offset, length) of every IDAT payload in the input
     size_t idat_len = 0;
     std::vector<uint8_t> prefix, suffix;            // output bytes in front of / behind the IDAT chunk
@@ -97,7 +99,8 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
             seen_iend = true;
         } else {
             if (!memcmp(type, "acTL", 4)) return fail(CS_ERR_UNSUPPORTED, "animated PNG has no device path in this build");
-            if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); it.has_plte = true; }
+            if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); it.has_plte = true; it.plte.assign(d, d + len); }
+            if (!memcmp(type, "tRNS", 4)) it.has_trns = true;
             const bool critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
                 if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) it.no_reduce = true;
@@ -147,6 +150,19 @@ struct csp_batch {
     std::vector<PngAdam7> adam7;
     uint64_t adam7_items = 0;
     bool reduced = false;
+    bool to_webp = false;           // csp_batch_create_webp: the decoded pixels go to the VP8 encoder
+    int webp_quality = 0;
+    uint32_t webp_mb_bytes = 768, wmax_luma = 0, wmax_mbh = 0, rgb_max_h = 0;
+    uint64_t wwork_bytes = 0, wlevels = 0, rgb_bytes = 0;
+    std::vector<csw::WebpImg> wimgs;
+    std::vector<RgbJob> rgbjobs;
+    std::vector<uint8_t> plte;
+    std::vector<uint32_t> h_wstatus;
+    DevBuf<csw::WebpImg> d_wimgs;
+    DevBuf<RgbJob> d_rgbjobs;
+    DevBuf<uint8_t> d_plte, d_rgb, d_wwork, d_wscratch, d_wprobs, d_wupdate;
+    DevBuf<int16_t> d_wlevels;
+    DevBuf<uint32_t> d_wstats, d_wpart, d_wstatus;
     bool lossy = false;             // png.optimize not set: truecolour images with more than 256 colours are quantised (oracle: quantize)
     uint32_t n_reduced = 0;
     PngPlan plan{};
@@ -244,7 +260,10 @@ static int upload_chunk_index(csp_batch *b) {
     return hipStreamSynchronize(b->stream) == hipSuccess ? 0 : -1;   // the host vectors go out of scope
 }
 
-extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
+static int png_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out);
+extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, count, p, device, false, out); }
+extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, count, p, device, true, out); }
+static int png_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { csh_set_error("no HIP device: libcaesium_hip has no CPU path"); return CS_ERR_NO_DEVICE; }
@@ -253,6 +272,7 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
     std::unique_ptr<csp_batch> b(new csp_batch);
     b->device = device;
     b->lossy = !p->png_optimize;
+    b->to_webp = to_webp; b->webp_quality = int(p->webp_quality);
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) { csh_set_error("hipEventCreate failed"); return CS_ERR_NO_DEVICE; }
@@ -269,7 +289,7 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         if (s >= 5 && b->slot_of_strategy[s] < 0) { b->slot_of_strategy[s] = 5 + plan.nadaptive; plan.adaptive_strategy[plan.nadaptive++] = s; if (s == 9) plan.need_brute = 1; }
         plan.trial_slot[t] = b->slot_of_strategy[s]; plan.trial_strategy[t] = s;
     }
-    const int nslots = 5 + plan.nadaptive;
+    const int nslots = to_webp ? 0 : 5 + plan.nadaptive;   // a conversion has no filtered streams
 
     b->items.resize(count);
     b->inputs.resize(count);
@@ -282,6 +302,9 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         b->inputs[i] = inputs[i].data;
         parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
         if (it.code) continue;
+        if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
+        if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
+        if (to_webp && (p->width || p->height)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a PNG source has no device path in this build"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
         im.raw_len = uint64_t(it.height) * (uint64_t(it.rowbytes) + 1);
@@ -344,10 +367,32 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         fixed.insert(fixed.end(), it.suffix.begin(), it.suffix.end());
         im.out_cap = uint64_t(im.prefix_len) + 1100 /* a PLTE and a tRNS chunk a reduction may add */ + 12 + im.suffix_len + 6 + uint64_t(im.nchunks) * (CSP_CHUNK + CSP_CHUNK / 8 + 1024);
         if (im.out_cap > 0xFFFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        im.out_off = out_bytes; out_bytes += align_up(im.out_cap + 16, 256);
+        im.out_off = out_bytes;
+        if (!to_webp) out_bytes += align_up(im.out_cap + 16, 256);
         const uint32_t pieces = uint32_t((im.out_cap + 1023) / 1024);
         if (pieces > b->max_pieces) b->max_pieces = pieces;
         it.image = int(b->imgs.size());
+        if (to_webp) {
+            RgbJob j{};
+            j.image = uint32_t(it.image); j.width = it.width; j.height = it.height; j.rowbytes = it.rowbytes; j.ctype = it.ctype; j.depth = it.depth;
+            j.plte_off = uint32_t(b->plte.size()); j.npal = uint32_t(it.plte.size() / 3);
+            b->plte.insert(b->plte.end(), it.plte.begin(), it.plte.end());
+            j.src_off = im.pix_off; j.dst_off = b->rgb_bytes;
+            const uint32_t nc = it.ctype == 0 ? 1u : 3u;
+            b->rgb_bytes += align_up(uint64_t(it.width) * it.height * nc + 64, 256);
+            b->rgb_max_h = std::max(b->rgb_max_h, it.height);
+            b->rgbjobs.push_back(j);
+            csw::WebpImg wi{};
+            wi.width = it.width; wi.height = it.height; wi.mbw = (it.width + 15) / 16; wi.mbh = (it.height + 15) / 16; wi.ncomp = nc;
+            wi.rgb_off = j.dst_off; wi.image = uint32_t(it.image);
+            const uint64_t ly = uint64_t(wi.mbw) * wi.mbh * 256, lc = uint64_t(wi.mbw) * wi.mbh * 64;
+            auto take = [&](uint64_t n) { uint64_t at = b->wwork_bytes; b->wwork_bytes += (n + 63) & ~uint64_t(63); return at; };
+            wi.y_off = take(ly); wi.u_off = take(lc); wi.v_off = take(lc); wi.ry_off = take(ly); wi.ru_off = take(lc); wi.rv_off = take(lc);
+            wi.lev_off = b->wlevels; b->wlevels += uint64_t(wi.mbw) * wi.mbh * 400;
+            b->wmax_luma = std::max<uint32_t>(b->wmax_luma, uint32_t(ly));
+            b->wmax_mbh = std::max(b->wmax_mbh, wi.mbh);
+            b->wimgs.push_back(wi);
+        }
         b->imgs.push_back(im);
         b->raw_total += im.raw_len; b->pixels += uint64_t(it.width) * it.height;
     }
@@ -365,6 +410,10 @@ extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CC
         b->d_out.alloc(out_bytes + 256) || b->d_choice.alloc(size_t(5) * b->total_rows + 1) || b->d_status.alloc(size_t(nimg) + 1) || b->d_file_len.alloc(size_t(nimg) + 1) ||
         b->d_adler.alloc(2 * size_t(b->total_chunks) + 2) || b->d_crc.alloc(size_t(nimg) * b->max_pieces + 1) || b->d_scores.alloc(size_t(b->total_rows) * 25 + 1) ||
         b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
+        return CS_ERR_NO_DEVICE;
+    if (to_webp && (b->d_rgbjobs.upload(b->rgbjobs, st) || b->d_plte.upload(b->plte, st) || b->d_rgb.alloc(b->rgb_bytes + 256) || b->d_wwork.alloc(b->wwork_bytes + 64) ||
+                    b->d_wlevels.alloc(b->wlevels + 64) || b->d_wstats.alloc(size_t(nimg) * 2112 + 8) || b->d_wprobs.alloc(size_t(nimg) * 1056 + 8) || b->d_wupdate.alloc(size_t(nimg) * 1056 + 8) ||
+                    b->d_wpart.alloc(size_t(nimg) * 9 + 9) || b->d_wstatus.alloc(size_t(nimg) + 1)))
         return CS_ERR_NO_DEVICE;
     if (idat_pool.size()) {
         if (hipMemcpyAsync(b->d_idat.p, idat_pool.p, idat_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
@@ -552,6 +601,44 @@ static int reduce_step(csp_batch *b) {
     return upload_chunk_index(b);   // synchronises: the job vectors may go out of scope
 }
 
+// conversion to WebP: pixels -> 8-bit RGB -> the VP8 encoder of webp_kernels.h (statement: oracle/webp_oracle.c).  The output pool is
+// sized per macroblock and grows when a file overflows it, as in the JPEG -> WebP path (pipeline.cpp: run_webp)
+static int run_to_webp(csp_batch *b) {
+    hipStream_t st = b->stream;
+    const int nimg = int(b->wimgs.size());
+    if (!nimg) return 0;
+    launch_png_rgb(st, b->d_rgbjobs.p, nimg, b->rgb_max_h, b->d_plte.p, b->d_work.p, b->d_rgb.p, b->d_status.p);
+    // libwebp's quality -> quantiser curve without its segment / SNS adjustments (oracle: cso_webp_quality_to_qi)
+    const int q = b->webp_quality;
+    double c = (q < 0 ? 0 : q > 100 ? 100 : q) / 100.0, lin = c < 0.75 ? c * (2.0 / 3.0) : 2.0 * c - 1.0, v = 0.0;
+    if (lin > 0) { v = lin; for (int i = 0; i < 60; i++) v = v - (v * v * v - lin) / (3 * v * v); }
+    int qi = int(127.0 * (1.0 - v) + 0.5);
+    qi = qi < 0 ? 0 : qi > 127 ? 127 : qi;
+    b->h_wstatus.assign(size_t(nimg), 0);
+    for (int attempt = 0; attempt < 4; attempt++) {
+        uint64_t out_bytes = 0;
+        for (auto &wi : b->wimgs) {
+            const uint64_t cap = 4096 + uint64_t(wi.mbw) * wi.mbh * (b->webp_mb_bytes + 2);
+            wi.out_cap = uint32_t(std::min<uint64_t>(cap, 0xFFFFFF00u)); wi.out_off = out_bytes; wi.qi = qi;
+            b->imgs[wi.image].out_off = out_bytes;
+            out_bytes += (wi.out_cap + 63) & ~uint64_t(63);
+        }
+        if (b->d_out.alloc(out_bytes + 64) || b->d_wscratch.alloc(out_bytes + 64) || b->d_wimgs.upload(b->wimgs, st) || b->d_wstats.zero(st) || b->d_wstatus.zero(st) || b->d_file_len.zero(st)) return CS_ERR_NO_DEVICE;
+        csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
+        csw::launch_webp_mb(st, b->d_wimgs.p, nimg, b->d_wwork.p, b->d_wlevels.p);
+        csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_file_len.p,
+                              b->d_wstatus.p);
+        if (hipMemcpyAsync(b->h_wstatus.data(), b->d_wstatus.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+            hipGetLastError() != hipSuccess) { csh_set_error("WebP kernels failed"); return CS_ERR_NO_DEVICE; }
+        bool pool = false;
+        for (uint32_t s : b->h_wstatus) if (s == CS_ERR_POOL_OVERFLOW) pool = true;
+        if (!pool) break;
+        if (attempt == 3) { csh_set_error("device pools overflowed after 3 retries"); return CS_ERR_POOL_OVERFLOW; }
+        b->webp_mb_bytes *= 4;
+    }
+    return 0;
+}
+
 extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     if (!b) return CS_ERR_NO_DEVICE;
     if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
@@ -574,6 +661,20 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     mark(); if (!b->reduced) {
         launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), b->d_work.p, b->d_status.p);
         launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);
+    }
+    if (b->to_webp) {
+        mark();
+        const int rc = run_to_webp(b);
+        if (rc) return rc;
+        mark();
+        b->ran = true;
+        if (t) {
+            memset(t, 0, sizeof *t);
+            (void)hipEventElapsedTime(&t->total_ms, b->ev[0], b->ev[k - 1]);
+            for (int i = 0; i + 1 < k; i++) (void)hipEventElapsedTime(&t->kernel_ms[i], b->ev[i], b->ev[i + 1]);
+            t->pixels = b->pixels; t->raw_bytes = b->raw_total; t->n_images = uint32_t(nimg);
+        }
+        return 0;
     }
     mark(); if (!b->reduced && reduce_step(b)) return CS_ERR_NO_DEVICE;
     d.total_chunks = b->total_chunks; d.total_groups = b->total_groups; d.fixed = b->d_fixed.p;   // the reduction step may have re-laid these out
@@ -631,10 +732,11 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
         outputs[i].data = nullptr; outputs[i].length = 0;
         int code = it.code;
         const char *msg = it.msg.c_str();
-        if (!code && status[it.image]) { code = int(status[it.image]); msg = code == int(CSP_ERR_POOL) ? "internal device pool too small" : "malformed PNG data"; }
+        if (!code && !status[it.image] && b->to_webp && b->h_wstatus[it.image]) { code = int(b->h_wstatus[it.image]); msg = "WebP encoder failed"; }
+        else if (!code && status[it.image]) { code = int(status[it.image]); msg = code == int(CSP_ERR_POOL) ? "internal device pool too small" : "malformed PNG data"; }
         if (code) { failed++; if (results) results[i] = png_result(code, msg); continue; }
         const size_t n = flen[it.image];
-        if (!b->lossy && n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
+        if (!b->lossy && !b->to_webp && n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
             outputs[i].data = (uint8_t *)malloc(it.file_size ? it.file_size : 1);
             memcpy(outputs[i].data, b->inputs[i], it.file_size);
             outputs[i].length = it.file_size;

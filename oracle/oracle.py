@@ -97,6 +97,7 @@ def lib():
         L.cso_png_reduce.argtypes = [C.POINTER(Png)]
         L.cso_png_quantize.argtypes = [C.POINTER(Png)]
         L.cso_png_lossy.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_png_to_webp.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_scores.argtypes = [C.POINTER(Png), C.c_void_p]
         L.cso_png_filter.argtypes = [C.POINTER(Png), C.c_int, C.c_void_p, C.c_void_p]
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
@@ -409,6 +410,16 @@ def webp_encode_rgb(rgb, quality):
 
 def webp_quality_to_qi(q):
     return lib().cso_webp_quality_to_qi(q)
+
+
+def png_to_webp(data, quality):
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    rc = lib().cso_png_to_webp(data, len(data), quality, C.byref(out), C.byref(n))
+    if rc:
+        raise PngError(rc)
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res
 
 
 def png_lossy(data, level=3, keep_metadata=False):

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include "png_oracle.h"
+#include "webp_oracle.h"
 
 /* ------------------------------------------------------------------------------------------------ checksums */
 static uint32_t crc_table[256];
@@ -967,4 +968,53 @@ int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, 
 /* `-q` on a PNG: the reductions, the quantiser, then the same filter trials and coder; the result is returned whatever its size */
 int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len) {
     return png_recode(in, n, level, keep_metadata, 1, out, out_len, NULL);
+}
+
+/* ---- PNG -> WebP (caesium::convert_in_memory with a PNG source, /root/reference/src/compressor.rs:289-299): the decoded pixels as the
+   8-bit RGB the VP8 encoder imports.  Opaque formats only (the device build refuses transparency).  16-bit samples round as
+   image-rs converts them, (v + 128) / 257 [UPSTREAM-RECALL]; sub-byte grey scales to the full range; an index past the PLTE is black */
+int cso_png_to_rgb(const cso_png *P, uint8_t *rgb) {
+    const uint8_t *plte = NULL;
+    int npal = 0;
+    for (size_t pos = 0; pos + 12 <= P->chunks_len;) {
+        const uint32_t len = be32(P->chunks + pos);
+        if (!memcmp(P->chunks + pos + 4, "PLTE", 4)) { plte = P->chunks + pos + 8; npal = (int)(len / 3); }
+        if (!memcmp(P->chunks + pos + 4, "tRNS", 4)) return CSO_PNG_UNSUPPORTED;
+        pos += 12 + (size_t)len;
+    }
+    if (P->ctype == 4 || P->ctype == 6) return CSO_PNG_UNSUPPORTED;
+    for (uint32_t y = 0; y < P->height; y++) {
+        const uint8_t *r = P->pix + (size_t)y * P->rowbytes;
+        uint8_t *o = rgb + (size_t)y * P->width * 3;
+        for (uint32_t x = 0; x < P->width; x++, o += 3) {
+            if (P->ctype == 2) {
+                for (int c = 0; c < 3; c++)
+                    o[c] = P->depth == 16 ? (uint8_t)(((((uint32_t)r[6 * (size_t)x + 2 * c] << 8) | r[6 * (size_t)x + 2 * c + 1]) + 128u) / 257u) : r[3 * (size_t)x + c];
+                continue;
+            }
+            uint32_t v;
+            if (P->depth == 16) v = ((((uint32_t)r[2 * (size_t)x] << 8) | r[2 * (size_t)x + 1]) + 128u) / 257u;
+            else if (P->depth == 8) v = r[x];
+            else {
+                const uint32_t per = 8u / (uint32_t)P->depth, k = x % per;
+                v = ((uint32_t)r[x / per] >> (8u - (uint32_t)P->depth - k * (uint32_t)P->depth)) & ((1u << P->depth) - 1u);
+                if (P->ctype == 0) v *= 255u / ((1u << P->depth) - 1u);
+            }
+            if (P->ctype == 3) {
+                if ((int)v < npal) { o[0] = plte[3 * v]; o[1] = plte[3 * v + 1]; o[2] = plte[3 * v + 2]; } else { o[0] = o[1] = o[2] = 0; }
+            } else o[0] = o[1] = o[2] = (uint8_t)v;
+        }
+    }
+    return 0;
+}
+int cso_png_to_webp(const uint8_t *in, size_t n, int quality, uint8_t **out, size_t *out_len) {
+    cso_png *P = NULL;
+    int rc = cso_png_decode(in, n, 0, &P);
+    if (rc) return rc;
+    uint8_t *rgb = (uint8_t *)malloc((size_t)P->width * P->height * 3 + 1);
+    rc = cso_png_to_rgb(P, rgb);
+    if (!rc && cso_webp_encode_rgb(rgb, (int)P->width, (int)P->height, quality, out, out_len)) rc = CSO_PNG_UNSUPPORTED;
+    free(rgb);
+    cso_png_free(P);
+    return rc;
 }

@@ -342,9 +342,27 @@ def lossy_png_step(binary, tmp_path):
     assert j["files"][0]["status"] == "success" and open(j["files"][0]["output_path"], "rb").read() == oracle_png_lossy(png)
 
 
+def png_to_webp_step(binary, tmp_path):
+    """--format webp over PNG and JPEG sources in one run.  Its own step: on the device it runs from tests/test_zzz_png_webp_gpu.py"""
+    from _util import oracle_jpeg_to_webp
+    from gen_synth import synth_jpeg, synth_png
+    from oracle import oracle as O
+    d = tmp_path / "pw_in"
+    d.mkdir()
+    png, grey, rgba, jpg = synth_png(61, 100, 70, "RGB"), synth_png(62, 33, 50, "L"), synth_png(63, 40, 30, "RGBA"), synth_jpeg(64, 96, 64, texture=5)
+    for name, data in (("a.png", png), ("b.png", grey), ("c.png", rgba), ("d.jpg", jpg)):
+        (d / name).write_bytes(data)
+    j = json.loads(run_cli(binary, "-q", 70, "-o", tmp_path / "pw", "--json", "--format", "webp", d / "a.png", d / "b.png", d / "c.png", d / "d.jpg").stdout)
+    assert [f["status"] for f in j["files"]] == ["success", "success", "error", "success"]
+    got = [open(f["output_path"], "rb").read() for f in j["files"] if f["status"] == "success"]
+    assert got == [O.png_to_webp(png, 70), O.png_to_webp(grey, 70), oracle_jpeg_to_webp(jpg, 70)]
+    assert j["files"][0]["output_path"].endswith("a.webp")
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
+    png_to_webp_step(EMUL_CLI, tmp_path)
 
 
 @pytest.mark.gpu

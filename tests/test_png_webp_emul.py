@@ -1,0 +1,119 @@
+"""PNG in, WebP out (convert_in_memory to WebP with a PNG source): the PNG decode stages feeding the VP8 encoder, kernel sources compiled
+for the CPU, against the oracle's statement (cso_png_to_webp); the same cases run on the device in test_zz_png_webp_gpu.py."""
+import io
+
+import pytest
+
+from _util import emul_api, package, png_cases
+
+PIL = pytest.importorskip("PIL.Image")
+WEBP = 3
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def make_png(w, h, depth, ctype, pixels, extra=()):
+    """a PNG file from raw rows (filter 0 on every row)"""
+    import zlib
+
+    def chunk(t, d):
+        return len(d).to_bytes(4, "big") + t + d + zlib.crc32(t + d).to_bytes(4, "big")
+    rb = len(pixels) // h
+    raw = b"".join(b"\0" + pixels[y * rb:(y + 1) * rb] for y in range(h))
+    ihdr = w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([depth, ctype, 0, 0, 0])
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + b"".join(chunk(t, d) for t, d in extra) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+def extra_cases():
+    """formats png_cases has no opaque example of: 16-bit truecolour, 2- and 4-bit grey, a short palette"""
+    import numpy as np
+
+    from gen_synth import synth_rgb
+    rgb = synth_rgb(61, 70, 45, texture=4.0)
+    wide = (rgb.astype(">u2") * 251 + 77)
+    cases = [("rgb16_70x45", make_png(70, 45, 16, 2, wide.tobytes()))]
+    g = rgb[:, :, 1]
+    for depth in (2, 4):
+        per = 8 // depth
+        rows = []
+        for y in range(45):
+            v = (g[y] >> (8 - depth)).astype(np.uint32)
+            v = np.concatenate([v, np.zeros((-len(v)) % per, np.uint32)]).reshape(-1, per)
+            rows.append(bytes(int(sum(int(v[i, k]) << (8 - depth - k * depth) for k in range(per))) for i in range(v.shape[0])))
+        cases.append((f"grey{depth}_70x45", make_png(70, 45, depth, 0, b"".join(rows))))
+    idx = (g >> 5).astype(np.uint8)   # indices 0..7 with a five-entry PLTE: 5, 6, 7 decode as black
+    plte = bytes(range(40, 55))
+    cases.append(("short_plte_70x45", make_png(70, 45, 8, 3, idx.tobytes(), extra=[(b"PLTE", plte)])))
+    return cases
+
+
+def check(api, cases, quality):
+    from oracle import oracle as O
+    p = package().default_parameters(webp_quality=quality)
+    outs = api.batch_convert([c[1] for c in cases], p, WEBP)
+    done = 0
+    for (name, src), out in zip(cases, outs):
+        try:
+            want = O.png_to_webp(src, quality)
+        except O.PngError as e:
+            assert isinstance(out, Exception) and out.code == e.code, (name, out, e.code)
+            continue
+        assert not isinstance(out, Exception), (name, out)
+        assert out == want, name
+        im = PIL.open(io.BytesIO(out))
+        im.load()
+        assert im.format == "WEBP" and im.size == PIL.open(io.BytesIO(src)).size
+        done += 1
+    return done
+
+
+def test_png_sources_equal_oracle(api):
+    cases = png_cases()
+    assert check(api, cases, 85) >= len(cases) // 2
+    assert check(api, extra_cases(), 60) == 4
+
+
+def test_transparency_and_resize_are_refused(api):
+    cases = dict(png_cases())
+    p = package().default_parameters(webp_quality=80)
+    outs = api.batch_convert([cases["RGBA_97x61"], cases["LA_97x61"], cases["reduce_blocked_by_trns"], cases["RGB_97x61"]], p, WEBP)
+    assert [getattr(o, "code", 0) for o in outs] == [10201, 10201, 10201, 0]
+    outs = api.batch_convert([cases["RGB_97x61"]], package().default_parameters(webp_quality=80, width=40), WEBP)
+    assert outs[0].code == 10201 and "resiz" in str(outs[0])
+
+
+def test_mixed_sources_keep_their_order(api):
+    from _util import oracle_jpeg_to_webp
+    from gen_synth import synth_jpeg
+    from oracle import oracle as O
+    cases = dict(png_cases())
+    jpg = synth_jpeg(5, 88, 56, texture=6)
+    blobs = [cases["L_97x61"], jpg, b"junk", cases["P_97x61"], jpg, cases["adam7_RGB_53x37"] if "adam7_RGB_53x37" in cases else cases["RGB_1x1"]]
+    outs = api.batch_convert(blobs, package().default_parameters(webp_quality=70), WEBP)
+    assert outs[0] == O.png_to_webp(blobs[0], 70) and outs[3] == O.png_to_webp(blobs[3], 70) and outs[5] == O.png_to_webp(blobs[5], 70)
+    assert outs[1] == oracle_jpeg_to_webp(jpg, 70) and outs[4] == outs[1]
+    assert outs[2].code == 10200
+
+
+def test_damaged_pngs_convert_like_the_oracle_or_fail(api):
+    """the PNG side of a conversion sees the same damaged inputs as the PNG path: what the oracle decodes gives the oracle's WebP, what it
+    refuses is refused"""
+    from oracle import oracle as O
+    from test_png_emul import damaged_pngs
+    blobs = damaged_pngs(23, 40)
+    outs = api.batch_convert(blobs, package().default_parameters(webp_quality=75), WEBP)
+    decoded = 0
+    for k, (b, o) in enumerate(zip(blobs, outs)):
+        try:
+            want = O.png_to_webp(b, 75)
+        except O.PngError:
+            want = None
+        if want is None:
+            assert isinstance(o, Exception), k
+        else:
+            assert o == want, k
+            decoded += 1
+    assert decoded >= 4
