@@ -220,18 +220,63 @@ static int sniff(const uint8_t *d, size_t n) {
     return CS_TYPE_UNKN;
 }
 
-// convert: JPEG -> WebP (the JPEG path's decode and resize, then the VP8 encoder) and opaque PNG -> WebP (the PNG path's decode, then
-// the same encoder) run on the device; every other pair of formats has no device path
+// JPEG -> PNG: the JPEG path's decode and resize leave the pixels in device memory, the PNG coder takes them from there (lossless under
+// png.optimize, quantising otherwise -- what png::compress does to the intermediate file libcaesium makes)
+static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+    int failed_total = 0;
+    for (size_t g0 = 0, n = 0; g0 < count; g0 += n) {
+        // the PNG coder keeps about 14 bytes per sample in flight: groups of at most 512 files and 400 MB of JPEG (some 5 GB of pixels)
+        uint64_t bytes = 0;
+        for (n = 0; g0 + n < count && n < 512 && (!n || bytes + inputs[g0 + n].length <= (uint64_t(400) << 20)); n++) bytes += inputs[g0 + n].length;
+        for (size_t k = 0; k < n; k++) { outputs[g0 + k].data = nullptr; outputs[g0 + k].length = 0; }
+        csh_batch *jb = nullptr;
+        int rc = csh_batch_create_pixels(inputs + g0, n, p, device, &jb);
+        if (rc == 0) rc = csh_batch_run(jb, nullptr);
+        std::vector<csp_pixels> px;
+        std::vector<size_t> at;
+        for (size_t k = 0; k < n && rc == 0; k++) {
+            csp_pixels s; const char *msg = "";
+            const int code = csh_batch_pixels(jb, k, &s.device_pixels, &s.width, &s.height, &s.channels, &msg);
+            if (code) { results[g0 + k] = make_result(code, msg); failed_total++; } else { px.push_back(s); at.push_back(g0 + k); }
+        }
+        csp_batch *pb = nullptr;
+        if (rc == 0 && !px.empty()) {
+            rc = csp_batch_create_pixels(px.data(), px.size(), p, device, &pb);
+            if (rc == 0) rc = csp_batch_run(pb, nullptr);
+            if (rc == 0) {
+                std::vector<CByteArray> out(px.size());
+                std::vector<CCSResult> res(px.size());
+                const int failed = csp_batch_fetch(pb, out.data(), res.data());
+                if (failed < 0) rc = CS_ERR_NO_DEVICE;
+                else {
+                    failed_total += failed;
+                    for (size_t k = 0; k < px.size(); k++) { outputs[at[k]] = out[k]; results[at[k]] = res[k]; }
+                }
+            }
+            if (rc) { for (size_t k = 0; k < px.size(); k++) results[at[k]] = make_result(rc, csh_last_error()); failed_total += int(px.size()); rc = 0; }
+        } else if (rc) {
+            for (size_t k = 0; k < n; k++) results[g0 + k] = make_result(rc, csh_last_error());
+            failed_total += int(n);
+        }
+        csp_batch_destroy(pb);
+        csh_batch_destroy(jb);
+    }
+    return failed_total;
+}
+
+// convert: JPEG -> WebP (the JPEG path's decode and resize, then the VP8 encoder), opaque PNG -> WebP (the PNG path's decode, then
+// the same encoder) and JPEG -> PNG run on the device; every other pair of formats has no device path
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
-    std::vector<size_t> ok, okpng;
+    std::vector<size_t> ok, okpng, topng;
     for (size_t i = 0; i < count; i++) {
         outputs[i].data = nullptr; outputs[i].length = 0;
         const int src = sniff(inputs[i].data, inputs[i].length);
         int code = 0; const char *msg = nullptr;
         if (src == CS_TYPE_UNKN) { code = CS_ERR_UNKNOWN_TYPE; msg = "unknown file type"; }
         else if (uint32_t(src) == format) { code = CS_ERR_SAME_FORMAT; msg = "cannot convert to the same format"; }
-        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP, PNG -> WebP)"; }
+        else if (src == CS_TYPE_JPEG && format == CS_TYPE_PNG) { topng.push_back(i); continue; }
+        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP, PNG -> WebP, JPEG -> PNG)"; }
         else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
         if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
@@ -250,6 +295,14 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         }
         csh_batch_destroy(b);
         failed_total += failed < 0 ? int(n) : failed;
+    }
+    if (!topng.empty()) {
+        const size_t n = topng.size();
+        std::vector<CByteArray> in(n), out(n);
+        std::vector<CCSResult> res(n);
+        for (size_t k = 0; k < n; k++) in[k] = inputs[topng[k]];
+        failed_total += jpeg_to_png(in.data(), n, p, device, out.data(), res.data());
+        for (size_t k = 0; k < n; k++) { outputs[topng[k]] = out[k]; if (results) results[topng[k]] = res[k]; else cs_free_result(&res[k]); }
     }
     if (!okpng.empty()) {
         const size_t n = okpng.size();

@@ -65,6 +65,7 @@ struct csh_batch {
     std::vector<Item> items;
     int nimg = 0;
     bool lossless = false;
+    bool rgb_out = false;          // csh_batch_create_pixels: stop after the resize branch's RGB
     bool webp = false;             // target container: the decoded (and resized) RGB goes to the VP8 encoder instead of the JPEG one
     uint32_t webp_mb_bytes = 768;  // output bytes reserved per macroblock (grows on overflow)
     std::vector<csw::WebpImg> wimgs;
@@ -352,11 +353,13 @@ extern "C" int csh_device_count(void) {
     return n;
 }
 
-static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out);
+static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out = false);
 extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, false, out); }
+// JPEG in, pixels out (the front half of convert_in_memory to PNG): decode and resize only; the RGB stays in device memory (csh_batch_pixels)
+extern "C" int csh_batch_create_pixels(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, false, out, true); }
 // JPEG in, WebP out (caesium::convert_in_memory to SupportedFileTypes::WebP, compressor.rs:289,300): same decode and resize, then the VP8 encoder
 extern "C" int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, true, out); }
-static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out) {
+static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out) {
     *out = nullptr;
     if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
@@ -364,8 +367,8 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     std::unique_ptr<csh_batch> b(new csh_batch);
     b->device = device;
     b->params = *p;
-    b->lossless = p->jpeg_optimize && !webp;
-    b->webp = webp;
+    b->lossless = p->jpeg_optimize && !webp && !rgb_out;
+    b->webp = webp; b->rgb_out = rgb_out;
     const bool progressive = p->jpeg_progressive;
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
@@ -444,7 +447,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->max_dummy = std::max(b->max_dummy, nd);
         }
         im.omcus_x = o.mcus_x; im.omcus_y = o.mcus_y;
-        const bool resized = ((p->width || p->height) && !b->lossless) || b->webp;   // the WebP encoder takes the RGB the resize branch produces (a plain copy at equal size)
+        const bool resized = ((p->width || p->height) && !b->lossless) || b->webp || b->rgb_out;   // the WebP encoder takes the RGB the resize branch produces (a plain copy at equal size)
         im.enc_w = o.width; im.enc_h = o.height;
         for (int c = 0; c < in.ncomp; c++) im.src[c] = im.in[c];
         int img_index = int(b->imgs.size());
@@ -845,6 +848,21 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     return 0;
 }
 
+// csh_batch_create_pixels: nothing behind the resize branch
+static int run_rgb_only(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
+    hipStream_t st = b->stream;
+    CSH_CHECK(hipEventRecord(ev[++slot], st));
+    CSH_CHECK(hipStreamSynchronize(st));
+    CSH_CHECK(hipGetLastError());
+    if (t) {
+        for (int i = 0; i < slot; i++) CSH_CHECK(hipEventElapsedTime(&t->kernel_ms[i], ev[i], ev[i + 1]));
+        CSH_CHECK(hipEventElapsedTime(&t->total_ms, ev[0], ev[slot]));
+        t->n_images = uint32_t(b->nimg);
+    }
+    for (int i = 0; i <= CSH_NKERNELS; i++) (void)hipEventDestroy(ev[i]);
+    return 0;
+}
+
 static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     hipStream_t st = b->stream;
     const int nimg = b->nimg;
@@ -937,6 +955,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     launch_resize(st, b->d_imgs.p, b->d_rwork.p, int(b->rwork.size()), b->d_rtaps.p, b->d_rweights.p, b->d_planes.p, b->d_rgb.p, b->d_rtmp.p,
                   b->max_src_px, b->max_tmp, b->max_dst);
     if (b->webp) return run_webp(b, t, ev, slot);
+    if (b->rgb_out) return run_rgb_only(b, t, ev, slot);
     int16_t *rawp = (b->retain_dct && !b->lossless) ? b->d_dct_raw.p : nullptr;
     launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p, rawp, b->ntiles_in);
     MARK();
@@ -1112,8 +1131,27 @@ static void set_result(CCSResult *r, int code, const std::string &msg) {
     if (code) { char *m = (char *)malloc(msg.size() + 1); memcpy(m, msg.c_str(), msg.size() + 1); r->error_message = m; }
 }
 
+// the decoded (and resized) image of a csh_batch_create_pixels batch, still in device memory: interleaved 8-bit samples, 1 or 3 per pixel.
+// Returns the file's CCSResult code (0: the pointers are set; they live as long as the batch)
+extern "C" int csh_batch_pixels(csh_batch *b, size_t image, const uint8_t **device_pixels, uint32_t *width, uint32_t *height, uint32_t *channels, const char **message) {
+    *device_pixels = nullptr; *width = *height = *channels = 0;
+    if (message) *message = "";
+    if (!b || !b->ran || !b->rgb_out || image >= b->items.size()) { csh_set_error("csh_batch_pixels: not a pixel batch that has run"); if (message) *message = "not a pixel batch that has run"; return CS_ERR_NO_DEVICE; }
+    const Item &it = b->items[image];
+    if (it.code) { if (message) *message = it.msg.c_str(); return it.code; }
+    if (b->h_status[it.image]) { if (message) *message = "device reported a malformed stream"; return int(b->h_status[it.image]); }
+    for (const ResizeWork &rw : b->rwork) {
+        if (rw.image != it.image) continue;
+        *device_pixels = b->d_rgb.p + rw.rgb_dst_off; *width = uint32_t(rw.nw); *height = uint32_t(rw.nh); *channels = uint32_t(b->imgs[it.image].ncomp);
+        return 0;
+    }
+    if (message) *message = "image has no pixel output";
+    return CS_ERR_NO_DEVICE;
+}
+
 extern "C" int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results) {
     if (!b->ran) { csh_set_error("csh_batch_fetch before csh_batch_run"); return -1; }
+    if (b->rgb_out) { csh_set_error("csh_batch_fetch: a pixel batch has no files (csh_batch_pixels)"); return -1; }
     struct PinnedOut { uint8_t *p = nullptr; size_t cap = 0; ~PinnedOut() { if (p) pinned_cache().put(p, cap); } uint8_t *data() const { return p; } } host;
     if (b->nimg && b->h_img_off[b->nimg]) {
         host.p = static_cast<uint8_t *>(pinned_cache().get(b->h_img_off[b->nimg], host.cap));

@@ -150,6 +150,7 @@ struct csp_batch {
     std::vector<PngAdam7> adam7;
     uint64_t adam7_items = 0;
     bool reduced = false;
+    bool from_pixels = false;       // csp_batch_create_pixels: no file to decode
     bool to_webp = false;           // csp_batch_create_webp: the decoded pixels go to the VP8 encoder
     int webp_quality = 0;
     uint32_t webp_mb_bytes = 768, wmax_luma = 0, wmax_mbh = 0, rgb_max_h = 0;
@@ -260,10 +261,28 @@ static int upload_chunk_index(csp_batch *b) {
     return hipStreamSynchronize(b->stream) == hipSuccess ? 0 : -1;   // the host vectors go out of scope
 }
 
-static int png_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out);
-extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, count, p, device, false, out); }
-extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, count, p, device, true, out); }
-static int png_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out) {
+static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out);
+extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, nullptr, count, p, device, false, out); }
+extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, nullptr, count, p, device, true, out); }
+extern "C" int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(nullptr, sources, count, p, device, false, out); }
+
+// a source that is pixels already (csp_batch_create_pixels): the item a PNG file of that image would parse to
+static void pixels_item(const csp_pixels &src, PngItem &it) {
+    static const uint8_t ctype_of[5] = {0, 0, 4, 2, 6};
+    if (!src.device_pixels || !src.width || !src.height || src.channels < 1 || src.channels > 4 || src.width > 0x7FFFFFFFu || src.height > 0x7FFFFFFFu ||
+        uint64_t(src.width) * src.channels > 0x7FFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "bad pixel source"; return; }
+    it.width = src.width; it.height = src.height; it.depth = 8; it.ctype = ctype_of[src.channels]; it.channels = src.channels; it.bpp = src.channels;
+    it.rowbytes = src.width * src.channels;
+    uint8_t ihdr[25] = {0, 0, 0, 13, 'I', 'H', 'D', 'R'};
+    put_be32(ihdr + 8, src.width); put_be32(ihdr + 12, src.height); ihdr[16] = 8; ihdr[17] = ctype_of[src.channels];
+    put_be32(ihdr + 21, crc32_host(ihdr + 4, 17));
+    it.prefix.assign(kSig, kSig + 8);
+    it.prefix.insert(it.prefix.end(), ihdr, ihdr + 25);
+    static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+    it.suffix.assign(iend, iend + 12);
+}
+
+static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { csh_set_error("no HIP device: libcaesium_hip has no CPU path"); return CS_ERR_NO_DEVICE; }
@@ -272,6 +291,7 @@ static int png_create(const CByteArray *inputs, size_t count, const CCSParameter
     std::unique_ptr<csp_batch> b(new csp_batch);
     b->device = device;
     b->lossy = !p->png_optimize;
+    b->from_pixels = px != nullptr;
     b->to_webp = to_webp; b->webp_quality = int(p->webp_quality);
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
@@ -299,8 +319,9 @@ static int png_create(const CByteArray *inputs, size_t count, const CCSParameter
     uint64_t nchunk_recs = 0;
     for (size_t i = 0; i < count; i++) {
         PngItem &it = b->items[i];
-        b->inputs[i] = inputs[i].data;
-        parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
+        b->inputs[i] = px ? nullptr : inputs[i].data;
+        if (px) pixels_item(px[i], it);
+        else parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
         if (it.code) continue;
         if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
@@ -310,7 +331,7 @@ static int png_create(const CByteArray *inputs, size_t count, const CCSParameter
         im.raw_len = uint64_t(it.height) * (uint64_t(it.rowbytes) + 1);
         if (im.raw_len > (uint64_t(1) << 36) || uint64_t(b->total_rows) + it.height > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
         im.idat_off = idat_pool.size(); im.idat_len = uint32_t(it.idat_len);
-        {   // the IDAT payloads back to back (a stream may be cut anywhere, even inside the zlib header)
+        if (!px) {   // the IDAT payloads back to back (a stream may be cut anywhere, even inside the zlib header)
             size_t at = idat_pool.size(), end = align_up(at + it.idat_len + 8, 256);
             if (!idat_pool.reserve(end)) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
             for (auto &r : it.idat) { idat_pool.pending.push_back({at, inputs[i].data + r.first, r.second, 0}); at += r.second; }
@@ -417,6 +438,11 @@ static int png_create(const CByteArray *inputs, size_t count, const CCSParameter
         return CS_ERR_NO_DEVICE;
     if (idat_pool.size()) {
         if (hipMemcpyAsync(b->d_idat.p, idat_pool.p, idat_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
+    }
+    for (size_t i = 0; px && i < count; i++) {
+        const PngItem &it = b->items[i];
+        if (it.image < 0) continue;
+        if (hipMemcpyAsync(b->d_work.p + b->imgs[it.image].pix_off, px[i].device_pixels, size_t(it.height) * it.rowbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
     }
     if (hipStreamSynchronize(st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }   // the pinned pool goes back to the cache
     *out = b.release();
@@ -657,8 +683,8 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     for (int a = 0; a < b->plan.nadaptive; a++) if (b->plan.adaptive_strategy[a] != 9) need_scores = true;
     int k = 0;
     auto mark = [&]() { (void)hipEventRecord(b->ev[k++], st); };
-    mark(); if (!b->reduced) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, b->d_status.p);
-    mark(); if (!b->reduced) {
+    mark(); if (!b->reduced && !b->from_pixels) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, b->d_status.p);
+    mark(); if (!b->reduced && !b->from_pixels) {
         launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), b->d_work.p, b->d_status.p);
         launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);
     }
@@ -736,7 +762,7 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
         else if (!code && status[it.image]) { code = int(status[it.image]); msg = code == int(CSP_ERR_POOL) ? "internal device pool too small" : "malformed PNG data"; }
         if (code) { failed++; if (results) results[i] = png_result(code, msg); continue; }
         const size_t n = flen[it.image];
-        if (!b->lossy && !b->to_webp && n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
+        if (!b->lossy && !b->to_webp && !b->from_pixels && n >= it.file_size) {   // oxipng: "file already optimized" -- the input comes back unchanged
             outputs[i].data = (uint8_t *)malloc(it.file_size ? it.file_size : 1);
             memcpy(outputs[i].data, b->inputs[i], it.file_size);
             outputs[i].length = it.file_size;

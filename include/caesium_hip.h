@@ -85,7 +85,7 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
 CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size,
                                         bool return_smallest, CByteArray *out);
 /* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and opaque PNG -> WebP (lossy; a PNG source
-   takes no resize); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
+   takes no resize), JPEG -> PNG (png_optimize: lossless trials, else the quantiser); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
 CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out);
 /* the batch form of it: results[i] / outputs[i] correspond to inputs[i] */
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results);
@@ -135,6 +135,11 @@ int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters
 /* the same batch with WebP as the target container (convert_in_memory to WebP, compressor.rs:289,300): decode, optional
    resize, then the VP8 encoder; run / fetch / destroy as for any csh_batch */
 int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
+/* the same decode and resize with nothing behind them (the front half of convert_in_memory to PNG): after csh_batch_run the image
+   of input i is in device memory -- interleaved 8-bit samples, 1 (grey) or 3 (RGB) per pixel, rows back to back -- until the batch is
+   destroyed.  csh_batch_pixels returns the CCSResult code of that file (0: pointers set); csh_batch_fetch does not apply */
+int csh_batch_create_pixels(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
+int csh_batch_pixels(csh_batch *b, size_t image, const uint8_t **device_pixels, uint32_t *width, uint32_t *height, uint32_t *channels, const char **message);
 int csh_batch_run(csh_batch *b, csh_timing *t);
 int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results);
 void csh_batch_destroy(csh_batch *b);
@@ -174,6 +179,12 @@ int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters
    /root/reference/src/compressor.rs:289-299): opaque PNGs only, no resize; p->webp_quality applies.  run / fetch / destroy as above;
    the stage taps of the PNG coder do not exist for such a batch */
 int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
+/* the PNG coder over pixels that are already in device memory (caesium::convert_in_memory to PNG: the decoded source goes through
+   png::compress, /root/reference/src/compressor.rs:289-305): 8-bit samples, rows of width * channels bytes back to back, channels 1
+   (grey), 2 (grey + alpha), 3 (RGB) or 4 (RGBA).  The pixels are copied at creation (device to device; the source must be complete:
+   synchronise the stream that produced it first).  p selects the lossless (png_optimize) or the quantising form, as for a PNG file */
+typedef struct { const uint8_t *device_pixels; uint32_t width, height, channels; } csp_pixels;
+int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out);
 int csp_batch_run(csp_batch *b, csp_timing *t);
 int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results);
 void csp_batch_destroy(csp_batch *b);

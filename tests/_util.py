@@ -197,6 +197,44 @@ def oracle_jpeg_to_webp(src, quality=80, width=0, height=0):
     return O.webp_encode_rgb(rgb, quality)
 
 
+def oracle_jpeg_to_png(src, lossless, level=3, width=0, height=0):
+    """the oracle's statement of convert_in_memory(JPEG -> PNG): libjpeg decode to RGB (oracle), image-rs Lanczos3 when a size is given
+    (oracle), any valid PNG file of those pixels, then the PNG path over that file (oracle/png_oracle.c) -- whose result depends on the
+    pixels only, not on how the intermediate file was coded"""
+    import ctypes as C
+    import zlib
+
+    import numpy as np
+
+    from oracle import oracle as O
+    img = O.decode(src)
+    pix = img.pixels()
+    h, w, nc = pix.shape
+    rgb = np.empty_like(pix)
+    if nc == 3:
+        O.lib().cso_ycc_to_rgb(pix.ctypes.data, w * h, rgb.ctypes.data)
+    else:
+        rgb = pix
+    if width or height:
+        nw, nh = C.c_int(), C.c_int()
+        O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
+        out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
+        O.lib().cso_lanczos3_resize(np.ascontiguousarray(rgb).ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+        rgb = out
+    h, w, nc = rgb.shape
+
+    def chunk(t, d):
+        return len(d).to_bytes(4, "big") + t + d + zlib.crc32(t + d).to_bytes(4, "big")
+    raw = b"".join(b"\0" + np.ascontiguousarray(rgb[y]).tobytes() for y in range(h))
+    ihdr = w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([8, 2 if nc == 3 else 0, 0, 0, 0])
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(raw, 0)) + chunk(b"IEND", b"")
+    if lossless:
+        out, chosen = O.png_optimize(png, level)   # the intermediate is stored, not compressed: the "not smaller" rule never keeps it
+        assert chosen >= 0
+        return out
+    return O.png_lossy(png, level)
+
+
 def oracle_png_lossy(src, level=3, keep_metadata=False):
     from oracle import oracle as O
     return O.png_lossy(src, level, keep_metadata)

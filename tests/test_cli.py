@@ -302,8 +302,8 @@ def end_to_end(binary, tree, tmp_path):
     assert r.stdout.rstrip().split("\n")[-2] == "Compressed 2 files (1 success, 0 skipped, 1 errors)"
     assert (root / "j0.min.JPG").read_bytes() == oracle_lossy(files["j0.JPG"], 80)
     # 9. formats without a device path fail per file, not the run
-    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "cv", "--json", "--format", "png", root / "level_1_0" / "j1.jpg").stdout)
-    assert j["files"][0]["status"] == "error" and j["files"][0]["message"].startswith("Error compressing file: ") and j["files"][0]["output_path"].endswith("j1.png")
+    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "cv", "--json", "--format", "tiff", root / "level_1_0" / "j1.jpg").stdout)
+    assert j["files"][0]["status"] == "error" and j["files"][0]["message"].startswith("Error compressing file: ") and j["files"][0]["output_path"].endswith("j1.tiff")
 
 
     # 9b. JPEG -> WebP is built (configs[3] shape: convert + long edge): bytes equal the oracle's
@@ -359,10 +359,28 @@ def png_to_webp_step(binary, tmp_path):
     assert j["files"][0]["output_path"].endswith("a.webp")
 
 
+def jpeg_to_png_step(binary, tmp_path):
+    """--format png over JPEG sources: lossless target, quantising target, with a resize.  Its own step: on the device it runs from
+    tests/test_zzz_jpeg_png_gpu.py"""
+    from _util import oracle_jpeg_to_png
+    from gen_synth import synth_jpeg
+    d = tmp_path / "jp_in"
+    d.mkdir()
+    a, b = synth_jpeg(71, 120, 80, texture=6), synth_jpeg(72, 64, 96, subsampling=0, texture=3)
+    (d / "a.jpg").write_bytes(a); (d / "b.jpg").write_bytes(b)
+    j = json.loads(run_cli(binary, "--lossless", "-o", tmp_path / "jp1", "--json", "--format", "png", d / "a.jpg", d / "b.jpg").stdout)
+    assert [f["status"] for f in j["files"]] == ["success"] * 2 and j["files"][0]["output_path"].endswith("a.png")
+    assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_jpeg_to_png(a, True), oracle_jpeg_to_png(b, True)]
+    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "jp2", "--json", "--format", "png", "--long-edge", 60, d / "a.jpg", d / "b.jpg").stdout)
+    assert [f["status"] for f in j["files"]] == ["success"] * 2
+    assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_jpeg_to_png(a, False, 3, 60, 0), oracle_jpeg_to_png(b, False, 3, 0, 60)]
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
     png_to_webp_step(EMUL_CLI, tmp_path)
+    jpeg_to_png_step(EMUL_CLI, tmp_path)
 
 
 @pytest.mark.gpu

@@ -9,7 +9,7 @@ from _util import emul_api, oracle_jpeg_to_webp, package, png_cases
 from gen_synth import synth_jpeg
 
 PIL = pytest.importorskip("PIL.Image")
-WEBP, JPEG, PNG = 3, 0, 1
+WEBP, JPEG, PNG, TIFF = 3, 0, 1, 4
 
 
 @pytest.fixture(scope="module")
@@ -64,7 +64,7 @@ def test_entry_point_and_refusals(api):
         api.convert_in_memory(src, p, JPEG)
     assert e.value.code == 10407
     with pytest.raises(Exception) as e:
-        api.convert_in_memory(src, p, PNG)
+        api.convert_in_memory(src, p, TIFF)   # JPEG -> PNG is built: test_jpeg_png_emul.py
     assert e.value.code == 10201
     with pytest.raises(Exception) as e:
         api.convert_in_memory(src, pkg.default_parameters(webp_quality=85, webp_lossless=True), WEBP)
