@@ -24,6 +24,9 @@ for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_quali
 for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_optimize=True))): assert o == _util.oracle_lossless(s)
 for s, o in zip(srcs, api.batch_compress(srcs[:2], pkg.default_parameters(jpeg_quality=70, width=60))): assert o == _util.oracle_resized(s, 60, 0, quality=70)
 api.batch_compress(PE.fuzzed_blobs(3, 24, True), pkg.default_parameters(jpeg_quality=80))
+import test_png_webp_emul as PW, test_jpeg_png_emul as JP
+PW.check(api, _util.png_cases(), 85); PW.check(api, PW.extra_cases(), 60); PW.test_damaged_pngs_convert_like_the_oracle_or_fail(api)
+JP.check(api, W.webp_cases(), True); JP.check(api, W.webp_cases()[:3], False, width=50); JP.test_mixed_batch_and_failures(api); JP.test_damaged_jpegs_convert_like_the_oracle_or_fail(api)
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
