@@ -33,6 +33,13 @@ WORKER = textwrap.dedent("""
     assert res == want
     res = compress_sharded(emul_api(), blobs[:5], pkg.default_parameters(webp_quality=70), rank, world, fmt=3)
     assert res == [oracle_jpeg_to_webp(b, 70) for b in blobs[:5]]
+    # conversions whose sources are of both kinds (to WebP), and JPEG -> PNG
+    from _util import oracle_jpeg_to_png
+    from oracle import oracle as O
+    res = compress_sharded(emul_api(), mixed[:4], pkg.default_parameters(webp_quality=60), rank, world, fmt=3)
+    assert res == [oracle_jpeg_to_webp(mixed[0], 60), O.png_to_webp(mixed[1], 60), oracle_jpeg_to_webp(mixed[2], 60), O.png_to_webp(mixed[3], 60)]
+    res = compress_sharded(emul_api(), blobs[:3], pkg.default_parameters(png_optimize=True, png_optimization_level=1), rank, world, fmt=1)
+    assert res == [oracle_jpeg_to_png(b, True, 1) for b in blobs[:3]]
     dist.barrier()
     dist.destroy_process_group()
     print('rank', rank, 'ok')
