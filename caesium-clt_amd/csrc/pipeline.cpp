@@ -22,6 +22,7 @@
 #include "jpeg_host.hpp"
 #include "kernels.h"
 #include "webp_kernels.h"
+#include "resize_host.h"
 
 static thread_local char g_err[512];
 void csh_set_error(const char *fmt, ...) {
@@ -280,7 +281,7 @@ static int sniff_type(const uint8_t *d, size_t n) {
 // image-rs Lanczos3 taps of one axis (imageops::sample) -- host side, same libm calls as the oracle
 static float sincf_(float t) { float a = t * 3.14159265358979323846f; return t == 0.0f ? 1.0f : sinf(a) / a; }
 static float lanczos3f(float x) { return fabsf(x) < 3.0f ? sincf_(x) * sincf_(x / 3.0f) : 0.0f; }
-static void lanczos_axis(int in_size, int out_size, bool identity, std::vector<ResizeTap> &taps, std::vector<float> &weights) {
+void csh_lanczos_axis(int in_size, int out_size, bool identity, std::vector<ResizeTap> &taps, std::vector<float> &weights) {   // also used by png_pipeline.cpp (resize_host.h)
     for (int o = 0; o < out_size; o++) {
         ResizeTap t;
         t.woff = uint32_t(weights.size());
@@ -300,7 +301,7 @@ static void lanczos_axis(int in_size, int out_size, bool identity, std::vector<R
     }
 }
 // libcaesium resize.rs compute_dimensions [UPSTREAM-RECALL]: both given -> exact; one given -> keep aspect, f32, round half away
-static void compute_dimensions(int ow, int oh, int dw, int dh, int &nw, int &nh) {
+void csh_compute_dimensions(int ow, int oh, int dw, int dh, int &nw, int &nh) {
     if (dw > 0 && dh > 0) { nw = dw; nh = dh; }
     else {
         float ratio = float(ow) / float(oh);
@@ -323,7 +324,7 @@ static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
     o.width = in.width; o.height = in.height; o.ncomp = in.ncomp;
     if (p.width || p.height) {
         if (lossless) { it.msg = "resize + lossless transcode not on the device path"; return CS_ERR_UNSUPPORTED; }
-        compute_dimensions(in.width, in.height, int(p.width), int(p.height), o.width, o.height);
+        csh_compute_dimensions(in.width, in.height, int(p.width), int(p.height), o.width, o.height);
         if (o.width > 65500 || o.height > 65500) { it.msg = "resize target too large for JPEG"; return CS_ERR_JPEG_FEATURE; }
     }
     if (lossless) {
@@ -675,8 +676,8 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             const uint64_t tmpn = uint64_t(o.height) * in.width * in.ncomp;
             rw.tmp_off = b->tmp_floats; b->tmp_floats += tmpn;
             const bool same = o.width == in.width && o.height == in.height;   // image-rs copies instead of resampling
-            rw.vtap_base = uint32_t(b->rtaps.size()); lanczos_axis(in.height, o.height, same, b->rtaps, b->rweights);
-            rw.htap_base = uint32_t(b->rtaps.size()); lanczos_axis(in.width, o.width, same, b->rtaps, b->rweights);
+            rw.vtap_base = uint32_t(b->rtaps.size()); csh_lanczos_axis(in.height, o.height, same, b->rtaps, b->rweights);
+            rw.htap_base = uint32_t(b->rtaps.size()); csh_lanczos_axis(in.width, o.width, same, b->rtaps, b->rweights);
             b->max_src_px = std::max<uint32_t>(b->max_src_px, uint32_t(in.width) * in.height);
             b->max_tmp = std::max(b->max_tmp, tmpn);
             b->max_dst = std::max(b->max_dst, dst_bytes);

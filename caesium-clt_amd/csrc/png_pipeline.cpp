@@ -13,6 +13,7 @@
 #include "devmem.hpp"
 #include "png_kernels.h"
 #include "webp_kernels.h"
+#include "resize_host.h"
 
 using namespace csp;
 using csh::DevBuf;
@@ -151,6 +152,7 @@ struct csp_batch {
     uint64_t adam7_items = 0;
     bool reduced = false;
     bool from_pixels = false;       // csp_batch_create_pixels: no file to decode
+    bool decode_only = false;       // the front half of a resize: stop at the pixels (decoded_image)
     bool to_webp = false;           // csp_batch_create_webp: the decoded pixels go to the VP8 encoder
     int webp_quality = 0;
     uint32_t webp_mb_bytes = 768, wmax_luma = 0, wmax_mbh = 0, rgb_max_h = 0;
@@ -261,10 +263,15 @@ static int upload_chunk_index(csp_batch *b) {
     return hipStreamSynchronize(b->stream) == hipSuccess ? 0 : -1;   // the host vectors go out of scope
 }
 
-static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out);
-extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, nullptr, count, p, device, false, out); }
-extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, nullptr, count, p, device, true, out); }
-extern "C" int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(nullptr, sources, count, p, device, false, out); }
+enum { MODE_PNG = 0, MODE_WEBP = 1, MODE_DECODE = 2 };
+struct PreFail { int code; std::string msg; };
+static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre = nullptr);
+static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
+extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
+    return (p->width || p->height) ? png_create_resized(inputs, count, p, device, out) : png_create(inputs, nullptr, count, p, device, MODE_PNG, out);
+}
+extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, nullptr, count, p, device, MODE_WEBP, out); }
+extern "C" int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(nullptr, sources, count, p, device, MODE_PNG, out); }
 
 // a source that is pixels already (csp_batch_create_pixels): the item a PNG file of that image would parse to
 static void pixels_item(const csp_pixels &src, PngItem &it) {
@@ -282,8 +289,9 @@ static void pixels_item(const csp_pixels &src, PngItem &it) {
     it.suffix.assign(iend, iend + 12);
 }
 
-static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, bool to_webp, csp_batch **out) {
+static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre) {
     *out = nullptr;
+    const bool to_webp = mode == MODE_WEBP, decode_only = mode == MODE_DECODE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { csh_set_error("no HIP device: libcaesium_hip has no CPU path"); return CS_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { csh_set_error("device %d out of range (%d visible)", device, ndev); return CS_ERR_NO_DEVICE; }
@@ -292,6 +300,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     b->device = device;
     b->lossy = !p->png_optimize;
     b->from_pixels = px != nullptr;
+    b->decode_only = decode_only;
     b->to_webp = to_webp; b->webp_quality = int(p->webp_quality);
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
@@ -309,7 +318,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         if (s >= 5 && b->slot_of_strategy[s] < 0) { b->slot_of_strategy[s] = 5 + plan.nadaptive; plan.adaptive_strategy[plan.nadaptive++] = s; if (s == 9) plan.need_brute = 1; }
         plan.trial_slot[t] = b->slot_of_strategy[s]; plan.trial_strategy[t] = s;
     }
-    const int nslots = to_webp ? 0 : 5 + plan.nadaptive;   // a conversion has no filtered streams
+    const int nslots = (to_webp || decode_only) ? 0 : 5 + plan.nadaptive;   // a conversion has no filtered streams
 
     b->items.resize(count);
     b->inputs.resize(count);
@@ -320,12 +329,14 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     for (size_t i = 0; i < count; i++) {
         PngItem &it = b->items[i];
         b->inputs[i] = px ? nullptr : inputs[i].data;
-        if (px) pixels_item(px[i], it);
+        if (pre && (*pre)[i].code) { it.code = (*pre)[i].code; it.msg = (*pre)[i].msg; }
+        else if (px) pixels_item(px[i], it);
         else parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
         if (it.code) continue;
         if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        if (to_webp && (p->width || p->height)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a PNG source has no device path in this build"; continue; }
+        if (to_webp && (p->width || p->height)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a PNG source on the way to WebP has no device path in this build"; continue; }
+        if (decode_only && (it.depth != 8 || it.ctype == 3 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing this PNG format has no device path in this build (built: 8-bit grey / RGB, with or without alpha)"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
         im.raw_len = uint64_t(it.height) * (uint64_t(it.rowbytes) + 1);
@@ -389,7 +400,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         im.out_cap = uint64_t(im.prefix_len) + 1100 /* a PLTE and a tRNS chunk a reduction may add */ + 12 + im.suffix_len + 6 + uint64_t(im.nchunks) * (CSP_CHUNK + CSP_CHUNK / 8 + 1024);
         if (im.out_cap > 0xFFFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
         im.out_off = out_bytes;
-        if (!to_webp) out_bytes += align_up(im.out_cap + 16, 256);
+        if (!to_webp && !decode_only) out_bytes += align_up(im.out_cap + 16, 256);
         const uint32_t pieces = uint32_t((im.out_cap + 1023) / 1024);
         if (pieces > b->max_pieces) b->max_pieces = pieces;
         it.image = int(b->imgs.size());
@@ -688,6 +699,13 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
         launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), b->d_work.p, b->d_status.p);
         launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);
     }
+    if (b->decode_only) {
+        mark();
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG kernels failed"); return CS_ERR_NO_DEVICE; }
+        b->ran = true;
+        if (t) memset(t, 0, sizeof *t);
+        return 0;
+    }
     if (b->to_webp) {
         mark();
         const int rc = run_to_webp(b);
@@ -736,6 +754,63 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     return 0;
 }
 
+// width / height on PNG sources (libcaesium png::compress with a size: decode, image-rs resize_exact Lanczos3, encode): a decode-only
+// batch, the two Lanczos passes over its pixels, then the coder over the resized pixels (device to device, as for JPEG -> PNG).
+// What a decoder-side transformation would have to expand first (palette, sub-byte, 16-bit, tRNS) is refused per file.
+static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
+    *out = nullptr;
+    csp_batch *raw = nullptr;
+    int rc = png_create(inputs, nullptr, count, p, device, MODE_DECODE, &raw);
+    std::unique_ptr<csp_batch> a(raw);
+    if (rc == 0) rc = csp_batch_run(a.get(), nullptr);
+    if (rc) return rc;
+    hipStream_t st = a->stream;
+    const int nimg = int(a->imgs.size());
+    std::vector<uint32_t> status(size_t(nimg) + 1, 0);
+    if (nimg && hipMemcpy(status.data(), a->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return CS_ERR_NO_DEVICE; }
+    std::vector<PreFail> pre(count);
+    std::vector<csp_pixels> px(count);
+    std::vector<PngResize> jobs;
+    std::vector<size_t> job_item;
+    std::vector<csh::ResizeTap> taps;
+    std::vector<float> weights;
+    uint64_t tmp_floats = 0, dst_bytes = 0, max_tmp = 0, max_dst = 0;
+    for (size_t i = 0; i < count; i++) {
+        const PngItem &it = a->items[i];
+        px[i] = csp_pixels{nullptr, 0, 0, 0};
+        if (it.code) { pre[i] = PreFail{it.code, it.msg}; continue; }
+        if (status[it.image]) { pre[i] = PreFail{int(status[it.image]), "malformed PNG data"}; continue; }
+        int nw = 0, nh = 0;
+        csh_compute_dimensions(int(it.width), int(it.height), int(p->width), int(p->height), nw, nh);
+        const uint64_t tmpn = uint64_t(nh) * it.width * it.channels, dstn = uint64_t(nw) * nh * it.channels;
+        if (uint64_t(nw) * it.channels > 0x7FFFFFF0u || tmpn > (uint64_t(1) << 40)) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }
+        PngResize j{};
+        j.width = it.width; j.height = it.height; j.nc = it.channels; j.nw = uint32_t(nw); j.nh = uint32_t(nh);
+        j.src_off = a->imgs[it.image].pix_off; j.tmp_off = tmp_floats; j.dst_off = dst_bytes;
+        const bool same = uint32_t(nw) == it.width && uint32_t(nh) == it.height;   // image-rs copies instead of resampling
+        j.vtap_base = uint32_t(taps.size()); csh_lanczos_axis(int(it.height), nh, same, taps, weights);
+        j.htap_base = uint32_t(taps.size()); csh_lanczos_axis(int(it.width), nw, same, taps, weights);
+        tmp_floats += (tmpn + 63) & ~uint64_t(63); dst_bytes += (dstn + 255) & ~uint64_t(255);
+        max_tmp = std::max(max_tmp, tmpn); max_dst = std::max(max_dst, dstn);
+        px[i].width = uint32_t(nw); px[i].height = uint32_t(nh); px[i].channels = it.channels;
+        jobs.push_back(j); job_item.push_back(i);
+    }
+    DevBuf<PngResize> d_jobs;
+    DevBuf<csh::ResizeTap> d_taps;
+    DevBuf<float> d_weights, d_tmp;
+    DevBuf<uint8_t> d_dst;
+    if (!jobs.empty()) {
+        if (max_tmp / 256 > 0x7FFFFFF0u || max_dst / 256 > 0x7FFFFFF0u) { csh_set_error("PNG resize too large"); return CS_ERR_POOL_OVERFLOW; }
+        if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256)) return CS_ERR_NO_DEVICE;
+        launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, a->d_work.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG resize kernels failed"); return CS_ERR_NO_DEVICE; }
+        for (size_t k = 0; k < jobs.size(); k++) px[job_item[k]].device_pixels = d_dst.p + jobs[k].dst_off;
+    }
+    CCSParameters q = *p;
+    q.width = 0; q.height = 0;
+    return png_create(nullptr, px.data(), count, &q, device, MODE_PNG, out, &pre);   // copies the pixels before d_dst goes out of scope
+}
+
 static CCSResult png_result(int code, const char *msg) {
     CCSResult r;
     r.success = code == 0; r.code = uint32_t(code); r.error_message = nullptr;
@@ -744,7 +819,7 @@ static CCSResult png_result(int code, const char *msg) {
 }
 
 extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results) {
-    if (!b || !b->ran) { csh_set_error("csp_batch_fetch before csp_batch_run"); return -1; }
+    if (!b || !b->ran || b->decode_only) { csh_set_error("csp_batch_fetch before csp_batch_run"); return -1; }
     if (hipSetDevice(b->device) != hipSuccess) return -1;
     const int nimg = int(b->imgs.size());
     std::vector<uint32_t> status(size_t(nimg) + 1), flen(size_t(nimg) + 1);

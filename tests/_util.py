@@ -202,7 +202,6 @@ def oracle_jpeg_to_png(src, lossless, level=3, width=0, height=0):
     (oracle), any valid PNG file of those pixels, then the PNG path over that file (oracle/png_oracle.c) -- whose result depends on the
     pixels only, not on how the intermediate file was coded"""
     import ctypes as C
-    import zlib
 
     import numpy as np
 
@@ -221,17 +220,59 @@ def oracle_jpeg_to_png(src, lossless, level=3, width=0, height=0):
         out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
         O.lib().cso_lanczos3_resize(np.ascontiguousarray(rgb).ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
         rgb = out
-    h, w, nc = rgb.shape
+    nc = rgb.shape[2]
+    png = raw_png(rgb, 2 if nc == 3 else 0)
+    if lossless:
+        out, chosen = O.png_optimize(png, level)   # the intermediate is padded (raw_png): the "not smaller" rule never keeps it
+        assert chosen >= 0
+        return out
+    return O.png_lossy(png, level)
+
+
+def raw_png(pixels, ctype, depth=8, level=0, pad=True):
+    """a PNG file of an (h, w, channels) uint8 array: filter 0 on every row, stored deflate by default.  pad: a text chunk as large as
+    the pixels in front of them (stripped by the PNG path), so the "not smaller than the input" rule never returns this file"""
+    import zlib
+
+    import numpy as np
 
     def chunk(t, d):
         return len(d).to_bytes(4, "big") + t + d + zlib.crc32(t + d).to_bytes(4, "big")
-    raw = b"".join(b"\0" + np.ascontiguousarray(rgb[y]).tobytes() for y in range(h))
-    ihdr = w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([8, 2 if nc == 3 else 0, 0, 0, 0])
-    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(raw, 0)) + chunk(b"IEND", b"")
+    h, w = pixels.shape[:2]
+    raw = b"".join(b"\0" + np.ascontiguousarray(pixels[y]).tobytes() for y in range(h))
+    ihdr = w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([depth, ctype, 0, 0, 0])
+    text = chunk(b"tEXt", b"Comment\0" + b"x" * (len(raw) + 4096)) if pad else b""
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + text + chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b"")
+
+
+def oracle_png_resized(src, lossless, level=3, width=0, height=0):
+    """the oracle's statement of compress_in_memory on a PNG with a size: decode (oracle), image-rs Lanczos3 over the decoded samples
+    (oracle), a PNG file of the result, then the PNG path over that file.  8-bit grey / RGB with or without alpha; anything else
+    raises (the device refuses it)"""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+    P = O.png_decode(src)
+    im = P.im
+    chunks, pos, trns = C.string_at(im.chunks, im.chunks_len), 0, False
+    while pos + 12 <= len(chunks):
+        trns |= chunks[pos + 4:pos + 8] == b"tRNS"
+        pos += 12 + int.from_bytes(chunks[pos:pos + 4], "big")
+    if im.depth != 8 or im.ctype == 3 or trns:
+        raise O.PngError(10201)
+    w, h, nc = im.width, im.height, im.channels
+    pix = P.rows().reshape(h, w, nc)
+    nw, nh = C.c_int(), C.c_int()
+    O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
+    out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
+    O.lib().cso_lanczos3_resize(np.ascontiguousarray(pix).ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+    png = raw_png(out, im.ctype)
     if lossless:
-        out, chosen = O.png_optimize(png, level)   # the intermediate is stored, not compressed: the "not smaller" rule never keeps it
+        res, chosen = O.png_optimize(png, level)
         assert chosen >= 0
-        return out
+        return res
     return O.png_lossy(png, level)
 
 

@@ -376,11 +376,31 @@ def jpeg_to_png_step(binary, tmp_path):
     assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_jpeg_to_png(a, False, 3, 60, 0), oracle_jpeg_to_png(b, False, 3, 0, 60)]
 
 
+def png_resize_step(binary, tmp_path):
+    """--long-edge over PNG and JPEG sources in one run (one parameter group per orientation).  Its own step: on the device it runs from
+    tests/test_zzz_png_resize_gpu.py"""
+    from _util import oracle_png_resized, oracle_resized
+    from gen_synth import synth_jpeg, synth_png
+    d = tmp_path / "pr_in"
+    d.mkdir()
+    wide, tall, pal, jpg = synth_png(81, 120, 70, "RGB"), synth_png(82, 50, 90, "RGBA"), synth_png(83, 60, 40, "P"), synth_jpeg(84, 100, 60, texture=4)
+    for name, data in (("a.png", wide), ("b.png", tall), ("c.png", pal), ("d.jpg", jpg)):
+        (d / name).write_bytes(data)
+    j = json.loads(run_cli(binary, "--lossless", "--png-opt-level", 2, "-o", tmp_path / "pr", "--json", "--long-edge", 45, d / "a.png", d / "b.png", d / "c.png").stdout)
+    assert [f["status"] for f in j["files"]] == ["success", "success", "error"]
+    got = [open(f["output_path"], "rb").read() for f in j["files"][:2]]
+    assert got == [oracle_png_resized(wide, True, 2, 45, 0), oracle_png_resized(tall, True, 2, 0, 45)]
+    j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "pr2", "--json", "--width", 40, d / "a.png", d / "d.jpg").stdout)
+    assert [f["status"] for f in j["files"]] == ["success", "success"]
+    assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_png_resized(wide, False, 3, 40, 0), oracle_resized(jpg, 40, 0)]
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
     png_to_webp_step(EMUL_CLI, tmp_path)
     jpeg_to_png_step(EMUL_CLI, tmp_path)
+    png_resize_step(EMUL_CLI, tmp_path)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,84 @@
+"""PNG sources with --width / --height: decode, Lanczos3 over the decoded samples, the PNG coder over the result.  Kernel sources compiled
+for the CPU, against the oracle's statement; the same cases run on the device in test_zzz_png_resize_gpu.py."""
+import io
+
+import numpy as np
+import pytest
+
+from _util import emul_api, oracle_png_resized, package, png_cases
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def check(api, cases, lossless, level=3, width=0, height=0):
+    from oracle import oracle as O
+    p = package().default_parameters(png_optimize=lossless, png_optimization_level=level, width=width, height=height)
+    outs = api.cs_batch_compress([c[1] for c in cases], p)
+    done = 0
+    for (name, src), out in zip(cases, outs):
+        try:
+            want = oracle_png_resized(src, lossless, level, width, height)
+        except O.PngError as e:
+            assert isinstance(out, Exception) and out.code == e.code, (name, out, e.code)
+            continue
+        assert not isinstance(out, Exception), (name, out)
+        assert out == want, name
+        im = PIL.open(io.BytesIO(out))
+        im.load()
+        done += 1
+    return done
+
+
+def test_every_case_resizes_like_the_oracle_or_is_refused(api):
+    cases = png_cases()
+    assert check(api, cases, True, level=1, height=30) >= 12   # L_1x300 becomes 1x30, RGBA_300x2 4500x30
+    assert check(api, cases[:6], False, width=25) >= 4
+
+
+def test_sizes_and_shapes(api):
+    cases = dict(png_cases())
+    pick = [(k, cases[k]) for k in ("RGB_97x61", "RGBA_97x61", "L_97x61", "LA_97x61", "RGB_200x150_3chunks")]
+    assert check(api, pick, True, level=2, width=150) == 5            # enlarging
+    assert check(api, pick, True, level=2, width=33, height=77) == 5  # both given: exact, aspect not kept
+    assert check(api, pick[:2], True, level=2, width=97) == 2         # same size: a copy
+    out = api.cs_batch_compress([pick[1][1]], package().default_parameters(png_optimize=True, width=50))[0]
+    assert PIL.open(io.BytesIO(out)).size == (50, 31)
+
+
+def test_result_is_close_to_pillows_lanczos(api):
+    """a semantic anchor outside the oracle: Pillow's own Lanczos resize of the same image (different arithmetic, same filter)"""
+    cases = dict(png_cases())
+    src = cases["RGB_200x150_3chunks"]
+    out = api.cs_batch_compress([src], package().default_parameters(png_optimize=True, png_optimization_level=1, width=100))[0]
+    a = np.asarray(PIL.open(io.BytesIO(out)).convert("RGB")).astype(int)
+    b = np.asarray(PIL.open(io.BytesIO(src)).convert("RGB").resize((100, 75), PIL.LANCZOS)).astype(int)
+    assert a.shape == b.shape and np.abs(a - b).mean() < 1.0
+
+
+def test_mixed_batch_with_jpegs_and_damage(api):
+    from _util import oracle_resized
+    from gen_synth import synth_jpeg
+    from test_png_emul import damaged_pngs
+    cases = dict(png_cases())
+    jpg = synth_jpeg(3, 120, 90, texture=5)
+    blobs = [cases["RGB_97x61"], jpg, cases["P_97x61"], b"junk"] + damaged_pngs(5, 12)
+    p = package().default_parameters(png_optimize=True, png_optimization_level=1, jpeg_quality=80, width=48)
+    outs = api.cs_batch_compress(blobs, p)
+    assert outs[0] == oracle_png_resized(blobs[0], True, 1, 48, 0)
+    assert outs[1] == oracle_resized(jpg, 48, 0)
+    assert outs[2].code == 10201 and outs[3].code == 10200
+    from oracle import oracle as O
+    for b, o in zip(blobs[4:], outs[4:]):
+        try:
+            want = oracle_png_resized(b, True, 1, 48, 0)
+        except O.PngError:
+            want = None
+        if want is None:
+            assert isinstance(o, Exception)
+        else:
+            assert o == want

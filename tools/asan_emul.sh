@@ -3,7 +3,7 @@
 # __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
-HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip"
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip"
 CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
     $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
@@ -27,6 +27,8 @@ api.batch_compress(PE.fuzzed_blobs(3, 24, True), pkg.default_parameters(jpeg_qua
 import test_png_webp_emul as PW, test_jpeg_png_emul as JP
 PW.check(api, _util.png_cases(), 85); PW.check(api, PW.extra_cases(), 60); PW.test_damaged_pngs_convert_like_the_oracle_or_fail(api)
 JP.check(api, W.webp_cases(), True); JP.check(api, W.webp_cases()[:3], False, width=50); JP.test_mixed_batch_and_failures(api); JP.test_damaged_jpegs_convert_like_the_oracle_or_fail(api)
+import test_png_resize_emul as PR
+PR.test_every_case_resizes_like_the_oracle_or_is_refused(api); PR.test_sizes_and_shapes(api); PR.test_mixed_batch_with_jpegs_and_damage(api)
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
