@@ -266,11 +266,13 @@ static int upload_chunk_index(csp_batch *b) {
 enum { MODE_PNG = 0, MODE_WEBP = 1, MODE_DECODE = 2 };
 struct PreFail { int code; std::string msg; };
 static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre = nullptr);
-static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
+static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out);
 extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
-    return (p->width || p->height) ? png_create_resized(inputs, count, p, device, out) : png_create(inputs, nullptr, count, p, device, MODE_PNG, out);
+    return (p->width || p->height) ? png_create_resized(inputs, count, p, device, MODE_PNG, out) : png_create(inputs, nullptr, count, p, device, MODE_PNG, out);
 }
-extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(inputs, nullptr, count, p, device, MODE_WEBP, out); }
+extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
+    return (p->width || p->height) ? png_create_resized(inputs, count, p, device, MODE_WEBP, out) : png_create(inputs, nullptr, count, p, device, MODE_WEBP, out);
+}
 extern "C" int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(nullptr, sources, count, p, device, MODE_PNG, out); }
 
 // a source that is pixels already (csp_batch_create_pixels): the item a PNG file of that image would parse to
@@ -335,7 +337,6 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         if (it.code) continue;
         if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        if (to_webp && (p->width || p->height)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a PNG source on the way to WebP has no device path in this build"; continue; }
         if (decode_only && (it.depth != 8 || it.ctype == 3 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing this PNG format has no device path in this build (built: 8-bit grey / RGB, with or without alpha)"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
@@ -755,9 +756,10 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
 }
 
 // width / height on PNG sources (libcaesium png::compress with a size: decode, image-rs resize_exact Lanczos3, encode): a decode-only
-// batch, the two Lanczos passes over its pixels, then the coder over the resized pixels (device to device, as for JPEG -> PNG).
+// batch, the two Lanczos passes over its pixels, then the coder -- or, on the way to WebP, the VP8 encoder -- over the resized pixels
+// (device to device, as for JPEG -> PNG).
 // What a decoder-side transformation would have to expand first (palette, sub-byte, 16-bit, tRNS) is refused per file.
-static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
+static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out) {
     *out = nullptr;
     csp_batch *raw = nullptr;
     int rc = png_create(inputs, nullptr, count, p, device, MODE_DECODE, &raw);
@@ -808,7 +810,7 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
     }
     CCSParameters q = *p;
     q.width = 0; q.height = 0;
-    return png_create(nullptr, px.data(), count, &q, device, MODE_PNG, out, &pre);   // copies the pixels before d_dst goes out of scope
+    return png_create(nullptr, px.data(), count, &q, device, mode, out, &pre);   // copies the pixels before d_dst goes out of scope
 }
 
 static CCSResult png_result(int code, const char *msg) {

@@ -84,8 +84,7 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
    are overwritten while bisecting, as the reference's &mut CSParameters is) */
 CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size,
                                         bool return_smallest, CByteArray *out);
-/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and opaque PNG -> WebP (lossy; a PNG source
-   takes no resize), JPEG -> PNG (png_optimize: lossless trials, else the quantiser); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
+/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and opaque PNG -> WebP (lossy), JPEG -> PNG (png_optimize: lossless trials, else the quantiser); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
 CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out);
 /* the batch form of it: results[i] / outputs[i] correspond to inputs[i] */
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results);
@@ -176,7 +175,7 @@ typedef struct {
 const char *csp_kernel_name(int slot);
 int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
 /* the same decode stages feeding the VP8 encoder (caesium::convert_in_memory with a PNG source and SupportedFileTypes::WebP,
-   /root/reference/src/compressor.rs:289-299): opaque PNGs only, no resize; p->webp_quality applies.  run / fetch / destroy as above;
+   /root/reference/src/compressor.rs:289-299): opaque PNGs only (with a size: 8-bit grey / RGB only); p->webp_quality applies.  run / fetch / destroy as above;
    the stage taps of the PNG coder do not exist for such a batch */
 int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
 /* the PNG coder over pixels that are already in device memory (caesium::convert_in_memory to PNG: the decoded source goes through

@@ -276,6 +276,33 @@ def oracle_png_resized(src, lossless, level=3, width=0, height=0):
     return O.png_lossy(png, level)
 
 
+def oracle_png_to_webp(src, quality, width=0, height=0):
+    """convert_in_memory(PNG -> WebP): without a size the oracle's cso_png_to_webp; with one, decode, Lanczos3 (8-bit grey / RGB
+    only, as the device), then the VP8 encoder"""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+    if not (width or height):
+        return O.png_to_webp(src, quality)
+    P = O.png_decode(src)
+    im = P.im
+    chunks, pos, trns = C.string_at(im.chunks, im.chunks_len), 0, False
+    while pos + 12 <= len(chunks):
+        trns |= chunks[pos + 4:pos + 8] == b"tRNS"
+        pos += 12 + int.from_bytes(chunks[pos:pos + 4], "big")
+    if im.depth != 8 or im.ctype not in (0, 2) or trns:
+        raise O.PngError(10201)
+    w, h, nc = im.width, im.height, im.channels
+    nw, nh = C.c_int(), C.c_int()
+    O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
+    out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
+    pix = np.ascontiguousarray(P.rows().reshape(h, w, nc))   # named: the C call needs it alive
+    O.lib().cso_lanczos3_resize(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+    return O.webp_encode_rgb(np.repeat(out, 3, axis=2) if nc == 1 else out, quality)
+
+
 def oracle_png_lossy(src, level=3, keep_metadata=False):
     from oracle import oracle as O
     return O.png_lossy(src, level, keep_metadata)

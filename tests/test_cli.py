@@ -357,6 +357,10 @@ def png_to_webp_step(binary, tmp_path):
     got = [open(f["output_path"], "rb").read() for f in j["files"] if f["status"] == "success"]
     assert got == [O.png_to_webp(png, 70), O.png_to_webp(grey, 70), oracle_jpeg_to_webp(jpg, 70)]
     assert j["files"][0]["output_path"].endswith("a.webp")
+    from _util import oracle_png_to_webp
+    j = json.loads(run_cli(binary, "-q", 70, "-o", tmp_path / "pw2", "--json", "--format", "webp", "--long-edge", 60, d / "a.png", d / "d.jpg").stdout)
+    assert [f["status"] for f in j["files"]] == ["success", "success"]
+    assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_png_to_webp(png, 70, 60, 0), oracle_jpeg_to_webp(jpg, 70, 60, 0)]
 
 
 def jpeg_to_png_step(binary, tmp_path):

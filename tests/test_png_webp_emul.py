@@ -50,14 +50,15 @@ def extra_cases():
     return cases
 
 
-def check(api, cases, quality):
+def check(api, cases, quality, width=0, height=0):
+    from _util import oracle_png_to_webp
     from oracle import oracle as O
-    p = package().default_parameters(webp_quality=quality)
+    p = package().default_parameters(webp_quality=quality, width=width, height=height)
     outs = api.batch_convert([c[1] for c in cases], p, WEBP)
     done = 0
     for (name, src), out in zip(cases, outs):
         try:
-            want = O.png_to_webp(src, quality)
+            want = oracle_png_to_webp(src, quality, width, height)
         except O.PngError as e:
             assert isinstance(out, Exception) and out.code == e.code, (name, out, e.code)
             continue
@@ -65,7 +66,7 @@ def check(api, cases, quality):
         assert out == want, name
         im = PIL.open(io.BytesIO(out))
         im.load()
-        assert im.format == "WEBP" and im.size == PIL.open(io.BytesIO(src)).size
+        assert im.format == "WEBP" and (width or height or im.size == PIL.open(io.BytesIO(src)).size)
         done += 1
     return done
 
@@ -76,12 +77,20 @@ def test_png_sources_equal_oracle(api):
     assert check(api, extra_cases(), 60) == 4
 
 
-def test_transparency_and_resize_are_refused(api):
+def test_transparency_is_refused(api):
     cases = dict(png_cases())
     p = package().default_parameters(webp_quality=80)
     outs = api.batch_convert([cases["RGBA_97x61"], cases["LA_97x61"], cases["reduce_blocked_by_trns"], cases["RGB_97x61"]], p, WEBP)
     assert [getattr(o, "code", 0) for o in outs] == [10201, 10201, 10201, 0]
-    outs = api.batch_convert([cases["RGB_97x61"]], package().default_parameters(webp_quality=80, width=40), WEBP)
+
+
+def test_resize_in_front(api):
+    """--format webp --long-edge N over PNG sources (configs[3] shape): 8-bit grey / RGB resize, everything else is refused"""
+    cases = png_cases()
+    assert check(api, cases, 85, width=50) >= 8
+    pick = [c for c in cases if c[0] in ("RGB_97x61", "L_97x61", "RGB_200x150_3chunks")]
+    assert check(api, pick, 70, height=100) == 3
+    outs = api.batch_convert([dict(cases)["P_97x61"]], package().default_parameters(webp_quality=80, width=40), WEBP)
     assert outs[0].code == 10201 and "resiz" in str(outs[0])
 
 
