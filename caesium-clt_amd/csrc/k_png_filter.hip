@@ -151,37 +151,43 @@ __global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const P
         }
     }
 }
-// ---- PNG -> WebP: one lane per pixel, any opaque PNG format to the 8-bit samples the VP8 encoder imports.  16-bit samples round as
-// image-rs converts them ((v + 128) / 257 [UPSTREAM-RECALL]); sub-byte grey scales to the full range; a palette index past the
-// PLTE decodes as black
+// ---- one lane per pixel: any PNG format to interleaved 8-bit samples (RgbJob).  16-bit samples round as image-rs converts them
+// ((v + 128) / 257 [UPSTREAM-RECALL]); sub-byte grey scales to the full range; a palette index past the PLTE decodes as black
 __global__ void __launch_bounds__(256) k_png_rgb(const RgbJob *jobs, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status) {
     const RgbJob j = jobs[blockIdx.y];
     const uint32_t y = blockIdx.x;
     if (y >= j.height || status[j.image]) return;
     const uint8_t *r = work + j.src_off + uint64_t(y) * j.rowbytes;
-    const uint8_t *pal = plte + j.plte_off;
-    const uint32_t nc = j.ctype == 0 ? 1u : 3u;
+    const uint8_t *pal = plte + j.plte_off, *trns = plte + j.trns_off;
+    const uint32_t nc = j.out_nc, in_nc = j.ctype == 2 ? 3u : j.ctype == 4 ? 2u : j.ctype == 6 ? 4u : 1u, bps = j.depth == 16 ? 2u : 1u;
+    const bool alpha_out = nc == 2 || nc == 4;
     uint8_t *d = rgb + j.dst_off + uint64_t(y) * j.width * nc;
-    auto narrow = [](const uint8_t *p) { return uint8_t((((uint32_t(p[0]) << 8) | p[1]) + 128u) / 257u); };
+    auto sample = [&](const uint8_t *p) { return bps == 2 ? uint32_t(((((uint32_t(p[0]) << 8) | p[1]) + 128u) / 257u)) : uint32_t(p[0]); };
+    auto raw16 = [&](const uint8_t *p) { return bps == 2 ? ((uint32_t(p[0]) << 8) | p[1]) : uint32_t(p[0]); };
+    auto key = [&](int c) { return (uint32_t(trns[2 * c]) << 8) | trns[2 * c + 1]; };
     for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
-        if (j.ctype == 2) {
-            uint8_t *o = d + uint64_t(x) * 3;
-            if (j.depth == 16) { const uint8_t *p = r + uint64_t(x) * 6; o[0] = narrow(p); o[1] = narrow(p + 2); o[2] = narrow(p + 4); }
-            else { const uint8_t *p = r + uint64_t(x) * 3; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+        uint8_t *o = d + uint64_t(x) * nc;
+        if (j.ctype == 2 || j.ctype == 6 || j.ctype == 4 || (j.ctype == 0 && j.depth >= 8)) {
+            const uint8_t *p = r + uint64_t(x) * in_nc * bps;
+            const uint32_t colour = j.ctype == 2 || j.ctype == 6 ? 3u : 1u;
+            for (uint32_t c = 0; c < colour; c++) o[c] = uint8_t(sample(p + c * bps));
+            if (in_nc > colour) { if (alpha_out) o[colour] = uint8_t(sample(p + colour * bps)); }
+            else if (alpha_out) {
+                bool hit = j.ntrns != 0;
+                for (uint32_t c = 0; c < colour && hit; c++) hit = raw16(p + c * bps) == key(int(c));
+                o[colour] = hit ? 0 : 255;
+            }
             continue;
         }
-        uint32_t v;
-        if (j.depth == 16) v = narrow(r + uint64_t(x) * 2);
-        else if (j.depth == 8) v = r[x];
-        else {
-            const uint32_t per = 8u / j.depth, k = x % per;
-            v = (uint32_t(r[x / per]) >> (8u - j.depth - k * j.depth)) & ((1u << j.depth) - 1u);
-            if (j.ctype == 0) v *= 255u / ((1u << j.depth) - 1u);
-        }
+        const uint32_t per = 8u / j.depth, k = x % per;
+        const uint32_t v = (uint32_t(r[x / per]) >> (8u - j.depth - k * j.depth)) & ((1u << j.depth) - 1u);   // depth 8 too: per = 1
         if (j.ctype == 3) {
-            uint8_t *o = d + uint64_t(x) * 3;
             if (v < j.npal) { o[0] = pal[3 * v]; o[1] = pal[3 * v + 1]; o[2] = pal[3 * v + 2]; } else { o[0] = 0; o[1] = 0; o[2] = 0; }
-        } else d[x] = uint8_t(v);
+            if (alpha_out) o[3] = v < j.ntrns ? trns[v] : 255;
+        } else {
+            o[0] = uint8_t(v * (255u / ((1u << j.depth) - 1u)));
+            if (alpha_out) o[1] = (j.ntrns && v == key(0)) ? 0 : 255;
+        }
     }
 }
 // ---- lossy PNG: colour bins

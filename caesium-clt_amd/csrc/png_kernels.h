@@ -39,8 +39,11 @@ struct PngResize { uint32_t width, height, nc, nw, nh, vtap_base, htap_base, pad
 void launch_png_resize(hipStream_t st, const PngResize *jobs, int njobs, const csh::ResizeTap *taps, const float *weights, const uint8_t *src, float *tmp, uint8_t *dst,
                        uint64_t max_tmp, uint64_t max_dst);
 
-// conversion to WebP: the decoded pixels of any opaque PNG format as 8-bit RGB (grey stays one channel) for k_webp_yuv
-struct RgbJob { uint32_t image, width, height, rowbytes, ctype, depth, plte_off, npal; uint64_t src_off, dst_off; };
+// the decoded pixels of an 8-bit-or-less PNG format (16-bit: narrowed) as interleaved 8-bit samples.  out_nc 1 / 3: grey or RGB for
+// k_webp_yuv (opaque sources).  out_nc 2 / 4 (or 1 / 3 with no tRNS): what the png crate's EXPAND transformation gives image-rs before
+// a resize -- palette entries looked up, sub-byte grey scaled, tRNS turned into an alpha channel (trns: per-index alpha for a palette,
+// else the transparent sample value(s) as 16-bit big-endian numbers)
+struct RgbJob { uint32_t image, width, height, rowbytes, ctype, depth, plte_off, npal, out_nc, trns_off, ntrns, pad_; uint64_t src_off, dst_off; };
 void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_height, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status);
 
 // lossy PNG (oracle: quantize): colour bins of 4 + 5 + 5 + 5 bits (a, r, g, b) with count and channel sums, compacted to a list the

@@ -44,7 +44,7 @@ struct PngItem {
     bool no_reduce = false;   // a carried chunk is tied to the colour type (tRNS, bKGD, sBIT)
     bool interlace = false;   // Adam7 input (the output never is)
     bool has_plte = false, has_trns = false;
-    std::vector<uint8_t> plte;                      // PLTE payload (conversion to WebP reads it)
+    std::vector<uint8_t> plte, trns;                // PLTE / tRNS payloads (conversion to WebP and the resize read them)
     std::vector<std::pair<size_t, size_t>> idat;   // (offset, length) of every IDAT payload in the input
     size_t idat_len = 0;
     std::vector<uint8_t> prefix, suffix;            // output bytes in front of / behind the IDAT chunk
@@ -101,7 +101,7 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
         } else {
             if (!memcmp(type, "acTL", 4)) return fail(CS_ERR_UNSUPPORTED, "animated PNG has no device path in this build");
             if (!memcmp(type, "PLTE", 4)) { if (len % 3 || len > 768) return fail(CS_ERR_BAD_PNG, "bad PLTE"); nplte = int(len / 3); it.has_plte = true; it.plte.assign(d, d + len); }
-            if (!memcmp(type, "tRNS", 4)) it.has_trns = true;
+            if (!memcmp(type, "tRNS", 4)) { it.has_trns = true; it.trns.assign(d, d + len); }
             const bool critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
                 if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) it.no_reduce = true;
@@ -337,7 +337,8 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         if (it.code) continue;
         if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        if (decode_only && (it.depth != 8 || it.ctype == 3 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing this PNG format has no device path in this build (built: 8-bit grey / RGB, with or without alpha)"; continue; }
+        if (decode_only && it.depth == 16) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG has no device path in this build"; continue; }
+        if (decode_only && it.has_trns && it.trns.size() != (it.ctype == 3 ? it.trns.size() : it.ctype == 0 ? 2u : it.ctype == 2 ? 6u : ~size_t(0))) { it.code = CS_ERR_BAD_PNG; it.msg = "bad tRNS"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
         im.raw_len = uint64_t(it.height) * (uint64_t(it.rowbytes) + 1);
@@ -412,6 +413,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
             b->plte.insert(b->plte.end(), it.plte.begin(), it.plte.end());
             j.src_off = im.pix_off; j.dst_off = b->rgb_bytes;
             const uint32_t nc = it.ctype == 0 ? 1u : 3u;
+            j.out_nc = nc;
             b->rgb_bytes += align_up(uint64_t(it.width) * it.height * nc + 64, 256);
             b->rgb_max_h = std::max(b->rgb_max_h, it.height);
             b->rgbjobs.push_back(j);
@@ -758,7 +760,8 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
 // width / height on PNG sources (libcaesium png::compress with a size: decode, image-rs resize_exact Lanczos3, encode): a decode-only
 // batch, the two Lanczos passes over its pixels, then the coder -- or, on the way to WebP, the VP8 encoder -- over the resized pixels
 // (device to device, as for JPEG -> PNG).
-// What a decoder-side transformation would have to expand first (palette, sub-byte, 16-bit, tRNS) is refused per file.
+// The pixels are expanded first as the png crate does for image-rs (palette looked up, sub-byte grey scaled, tRNS as an alpha channel:
+// k_png_rgb); 16-bit sources are refused per file.
 static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out) {
     *out = nullptr;
     csp_batch *raw = nullptr;
@@ -773,38 +776,56 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
     std::vector<PreFail> pre(count);
     std::vector<csp_pixels> px(count);
     std::vector<PngResize> jobs;
+    std::vector<RgbJob> ejobs;
+    std::vector<uint8_t> tables(1, 0);   // PLTE and tRNS payloads
     std::vector<size_t> job_item;
     std::vector<csh::ResizeTap> taps;
     std::vector<float> weights;
-    uint64_t tmp_floats = 0, dst_bytes = 0, max_tmp = 0, max_dst = 0;
+    uint64_t tmp_floats = 0, dst_bytes = 0, max_tmp = 0, max_dst = 0, src_bytes = 0;
+    uint32_t max_h = 0;
     for (size_t i = 0; i < count; i++) {
         const PngItem &it = a->items[i];
         px[i] = csp_pixels{nullptr, 0, 0, 0};
         if (it.code) { pre[i] = PreFail{it.code, it.msg}; continue; }
         if (status[it.image]) { pre[i] = PreFail{int(status[it.image]), "malformed PNG data"}; continue; }
+        // what the png crate's EXPAND transformation hands image-rs: 8-bit samples, palette looked up, tRNS as an alpha channel
+        const uint32_t colour = (it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u, nc = colour + ((it.ctype == 4 || it.ctype == 6 || it.has_trns) ? 1u : 0u);
         int nw = 0, nh = 0;
         csh_compute_dimensions(int(it.width), int(it.height), int(p->width), int(p->height), nw, nh);
-        const uint64_t tmpn = uint64_t(nh) * it.width * it.channels, dstn = uint64_t(nw) * nh * it.channels;
-        if (uint64_t(nw) * it.channels > 0x7FFFFFF0u || tmpn > (uint64_t(1) << 40)) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }
+        const uint64_t tmpn = uint64_t(nh) * it.width * nc, dstn = uint64_t(nw) * nh * nc;
+        if (uint64_t(nw) * nc > 0x7FFFFFF0u || uint64_t(it.width) * nc > 0x7FFFFFF0u || tmpn > (uint64_t(1) << 40)) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }
+        RgbJob e{};
+        e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth; e.out_nc = nc;
+        e.plte_off = uint32_t(tables.size()); e.npal = uint32_t(it.plte.size() / 3);
+        tables.insert(tables.end(), it.plte.begin(), it.plte.end());
+        e.trns_off = uint32_t(tables.size()); e.ntrns = uint32_t(it.trns.size());
+        tables.insert(tables.end(), it.trns.begin(), it.trns.end());
+        e.src_off = a->imgs[it.image].pix_off; e.dst_off = src_bytes;
+        src_bytes += (uint64_t(it.width) * it.height * nc + 255) & ~uint64_t(255);
+        max_h = std::max(max_h, it.height);
+        ejobs.push_back(e);
         PngResize j{};
-        j.width = it.width; j.height = it.height; j.nc = it.channels; j.nw = uint32_t(nw); j.nh = uint32_t(nh);
-        j.src_off = a->imgs[it.image].pix_off; j.tmp_off = tmp_floats; j.dst_off = dst_bytes;
+        j.width = it.width; j.height = it.height; j.nc = nc; j.nw = uint32_t(nw); j.nh = uint32_t(nh);
+        j.src_off = e.dst_off; j.tmp_off = tmp_floats; j.dst_off = dst_bytes;
         const bool same = uint32_t(nw) == it.width && uint32_t(nh) == it.height;   // image-rs copies instead of resampling
         j.vtap_base = uint32_t(taps.size()); csh_lanczos_axis(int(it.height), nh, same, taps, weights);
         j.htap_base = uint32_t(taps.size()); csh_lanczos_axis(int(it.width), nw, same, taps, weights);
         tmp_floats += (tmpn + 63) & ~uint64_t(63); dst_bytes += (dstn + 255) & ~uint64_t(255);
         max_tmp = std::max(max_tmp, tmpn); max_dst = std::max(max_dst, dstn);
-        px[i].width = uint32_t(nw); px[i].height = uint32_t(nh); px[i].channels = it.channels;
+        px[i].width = uint32_t(nw); px[i].height = uint32_t(nh); px[i].channels = nc;
         jobs.push_back(j); job_item.push_back(i);
     }
     DevBuf<PngResize> d_jobs;
     DevBuf<csh::ResizeTap> d_taps;
     DevBuf<float> d_weights, d_tmp;
-    DevBuf<uint8_t> d_dst;
+    DevBuf<uint8_t> d_dst, d_src, d_tables;
+    DevBuf<RgbJob> d_ejobs;
     if (!jobs.empty()) {
         if (max_tmp / 256 > 0x7FFFFFF0u || max_dst / 256 > 0x7FFFFFF0u) { csh_set_error("PNG resize too large"); return CS_ERR_POOL_OVERFLOW; }
-        if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256)) return CS_ERR_NO_DEVICE;
-        launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, a->d_work.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
+        if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256) ||
+            d_ejobs.upload(ejobs, st) || d_tables.upload(tables, st) || d_src.alloc(src_bytes + 256)) return CS_ERR_NO_DEVICE;
+        launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
+        launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG resize kernels failed"); return CS_ERR_NO_DEVICE; }
         for (size_t k = 0; k < jobs.size(); k++) px[job_item[k]].device_pixels = d_dst.p + jobs[k].dst_off;
     }

@@ -245,30 +245,74 @@ def raw_png(pixels, ctype, depth=8, level=0, pad=True):
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + text + chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b"")
 
 
+def png_expand8(P):
+    """what the png crate's EXPAND transformation hands image-rs, restated with numpy over the oracle's decode: 8-bit samples, palette
+    looked up (an index past the PLTE is black), sub-byte grey scaled to the full range, tRNS as an alpha channel.  -> ((h, w, nc)
+    array, colour type of that layout).  16-bit images raise (the device refuses to resize them)"""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+    im = P.im
+    chunks, pos, trns, plte = C.string_at(im.chunks, im.chunks_len), 0, None, b""
+    while pos + 12 <= len(chunks):
+        ln = int.from_bytes(chunks[pos:pos + 4], "big")
+        if chunks[pos + 4:pos + 8] == b"tRNS":
+            trns = chunks[pos + 8:pos + 8 + ln]
+        if chunks[pos + 4:pos + 8] == b"PLTE":
+            plte = chunks[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    if im.depth == 16:
+        raise O.PngError(10201)
+    if trns is not None and im.ctype != 3 and len(trns) != {0: 2, 2: 6}.get(im.ctype, -1):
+        raise O.PngError(30100)
+    w, h, rows = im.width, im.height, P.rows()
+    if im.ctype in (4, 6):
+        return rows.reshape(h, w, im.channels), im.ctype
+    if im.ctype == 2:
+        rgb = rows.reshape(h, w, 3)
+        if trns is None:
+            return rgb, 2
+        key = np.array([int.from_bytes(trns[2 * c:2 * c + 2], "big") for c in range(3)])
+        alpha = np.where((rgb == key).all(axis=2), 0, 255).astype(np.uint8)
+        return np.dstack([rgb, alpha]), 6
+    v = rows if im.depth == 8 else np.packbits(np.pad(np.unpackbits(rows, axis=1)[:, :w * im.depth].reshape(h, w, im.depth), ((0, 0), (0, 0), (8 - im.depth, 0))), axis=2)[:, :, 0]
+    v = v.reshape(h, w)
+    if im.ctype == 3:
+        pal = np.zeros((256, 3), np.uint8)
+        pal[:len(plte) // 3] = np.frombuffer(plte, np.uint8).reshape(-1, 3)
+        rgb = pal[v]
+        if trns is None:
+            return rgb, 2
+        al = np.full(256, 255, np.uint8)
+        al[:len(trns)] = np.frombuffer(trns, np.uint8)
+        return np.dstack([rgb, al[v]]), 6
+    g = (v.astype(np.uint32) * (255 // ((1 << im.depth) - 1))).astype(np.uint8)
+    if trns is None:
+        return g.reshape(h, w, 1), 0
+    alpha = np.where(v == int.from_bytes(trns[:2], "big"), 0, 255).astype(np.uint8)
+    return np.dstack([g, alpha]), 4
+
+
 def oracle_png_resized(src, lossless, level=3, width=0, height=0):
     """the oracle's statement of compress_in_memory on a PNG with a size: decode (oracle), image-rs Lanczos3 over the decoded samples
-    (oracle), a PNG file of the result, then the PNG path over that file.  8-bit grey / RGB with or without alpha; anything else
-    raises (the device refuses it)"""
+    (oracle; after png_expand8), a PNG file of the result, then the PNG path over that file.  16-bit images raise (the device refuses
+    them)"""
     import ctypes as C
 
     import numpy as np
 
     from oracle import oracle as O
     P = O.png_decode(src)
-    im = P.im
-    chunks, pos, trns = C.string_at(im.chunks, im.chunks_len), 0, False
-    while pos + 12 <= len(chunks):
-        trns |= chunks[pos + 4:pos + 8] == b"tRNS"
-        pos += 12 + int.from_bytes(chunks[pos:pos + 4], "big")
-    if im.depth != 8 or im.ctype == 3 or trns:
-        raise O.PngError(10201)
-    w, h, nc = im.width, im.height, im.channels
-    pix = P.rows().reshape(h, w, nc)
+    pix, ctype = png_expand8(P)
+    pix = np.ascontiguousarray(pix)
+    h, w, nc = pix.shape
     nw, nh = C.c_int(), C.c_int()
     O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
     out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
-    O.lib().cso_lanczos3_resize(np.ascontiguousarray(pix).ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
-    png = raw_png(out, im.ctype)
+    O.lib().cso_lanczos3_resize(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+    png = raw_png(out, ctype)
     if lossless:
         res, chosen = O.png_optimize(png, level)
         assert chosen >= 0
@@ -277,8 +321,8 @@ def oracle_png_resized(src, lossless, level=3, width=0, height=0):
 
 
 def oracle_png_to_webp(src, quality, width=0, height=0):
-    """convert_in_memory(PNG -> WebP): without a size the oracle's cso_png_to_webp; with one, decode, Lanczos3 (8-bit grey / RGB
-    only, as the device), then the VP8 encoder"""
+    """convert_in_memory(PNG -> WebP): without a size the oracle's cso_png_to_webp; with one, decode, png_expand8, Lanczos3, then the VP8
+    encoder (transparency and 16-bit images raise, as the device refuses them)"""
     import ctypes as C
 
     import numpy as np
@@ -287,18 +331,14 @@ def oracle_png_to_webp(src, quality, width=0, height=0):
     if not (width or height):
         return O.png_to_webp(src, quality)
     P = O.png_decode(src)
-    im = P.im
-    chunks, pos, trns = C.string_at(im.chunks, im.chunks_len), 0, False
-    while pos + 12 <= len(chunks):
-        trns |= chunks[pos + 4:pos + 8] == b"tRNS"
-        pos += 12 + int.from_bytes(chunks[pos:pos + 4], "big")
-    if im.depth != 8 or im.ctype not in (0, 2) or trns:
+    pix, ctype = png_expand8(P)
+    if ctype in (4, 6):
         raise O.PngError(10201)
-    w, h, nc = im.width, im.height, im.channels
+    pix = np.ascontiguousarray(pix)   # named: the C call needs it alive
+    h, w, nc = pix.shape
     nw, nh = C.c_int(), C.c_int()
     O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
     out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
-    pix = np.ascontiguousarray(P.rows().reshape(h, w, nc))   # named: the C call needs it alive
     O.lib().cso_lanczos3_resize(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
     return O.webp_encode_rgb(np.repeat(out, 3, axis=2) if nc == 1 else out, quality)
 

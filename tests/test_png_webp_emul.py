@@ -85,12 +85,12 @@ def test_transparency_is_refused(api):
 
 
 def test_resize_in_front(api):
-    """--format webp --long-edge N over PNG sources (configs[3] shape): 8-bit grey / RGB resize, everything else is refused"""
+    """--format webp --long-edge N over PNG sources (configs[3] shape): everything opaque that is not 16-bit resizes"""
     cases = png_cases()
     assert check(api, cases, 85, width=50) >= 8
     pick = [c for c in cases if c[0] in ("RGB_97x61", "L_97x61", "RGB_200x150_3chunks")]
     assert check(api, pick, 70, height=100) == 3
-    outs = api.batch_convert([dict(cases)["P_97x61"]], package().default_parameters(webp_quality=80, width=40), WEBP)
+    outs = api.batch_convert([dict(cases)["I;16_97x61"]], package().default_parameters(webp_quality=80, width=40), WEBP)
     assert outs[0].code == 10201 and "resiz" in str(outs[0])
 
 
