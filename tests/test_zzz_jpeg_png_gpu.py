@@ -6,7 +6,8 @@ from _util import oracle_jpeg_to_png, package, product_api
 from test_jpeg_png_emul import check
 from test_webp_emul import webp_cases
 
-pytestmark = pytest.mark.gpu
+# a wedged kernel must end the run, not hold the box (these files are last, so ending the process loses nothing after them)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 
 @pytest.fixture(scope="module")

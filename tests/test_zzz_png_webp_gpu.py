@@ -5,7 +5,8 @@ import pytest
 from _util import package, product_api
 from test_png_webp_emul import check, extra_cases
 
-pytestmark = pytest.mark.gpu
+# a wedged kernel must end the run, not hold the box (these files are last, so ending the process loses nothing after them)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 
 @pytest.fixture(scope="module")
