@@ -15,12 +15,14 @@ jpegs = [synth_jpeg(i, 96 + 8 * i, 64, texture=5 * i) for i in range(3)]
 pngs = [c[1] for c in _util.png_cases() if c[0] in ("RGB_97x61", "palette_rgb_few", "adam7_P_40x17")]
 def w(k):
     for rep in range(2):
-        wh = (k + rep) % 4
+        wh = (k + rep) % 6
         if wh == 0: api.cs_batch_compress(jpegs, pkg.default_parameters())
         elif wh == 1: api.cs_batch_compress(pngs, pkg.default_parameters(png_optimize=True, png_optimization_level=1))
         elif wh == 2: api.cs_batch_compress(pngs, pkg.default_parameters(png_optimization_level=1))
-        else: api.batch_convert(jpegs, pkg.default_parameters(webp_quality=75), 3)
-ts = [threading.Thread(target=w, args=(k,)) for k in range(4)]
+        elif wh == 3: api.batch_convert(jpegs, pkg.default_parameters(webp_quality=75), 3)
+        elif wh == 4: api.batch_convert(jpegs[:2], pkg.default_parameters(png_optimize=True, png_optimization_level=1), 1); api.batch_convert(pngs[:2], pkg.default_parameters(webp_quality=60), 3)
+        else: api.cs_batch_compress(pngs, pkg.default_parameters(png_optimize=True, png_optimization_level=1, width=40))
+ts = [threading.Thread(target=w, args=(k,)) for k in range(6)]
 [t.start() for t in ts]; [t.join() for t in ts]
 print('tsan run done')
 PY
