@@ -220,6 +220,8 @@ static int sniff(const uint8_t *d, size_t n) {
     return CS_TYPE_UNKN;
 }
 
+static uint32_t rd_be32(const uint8_t *d) { return (uint32_t(d[0]) << 24) | (uint32_t(d[1]) << 16) | (uint32_t(d[2]) << 8) | d[3]; }
+
 // JPEG -> PNG: the JPEG path's decode and resize leave the pixels in device memory, the PNG coder takes them from there (lossless under
 // png.optimize, quantising otherwise -- what png::compress does to the intermediate file libcaesium makes)
 static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
@@ -265,10 +267,10 @@ static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParamete
 }
 
 // convert: JPEG -> WebP (the JPEG path's decode and resize, then the VP8 encoder), opaque PNG -> WebP (the PNG path's decode, then
-// the same encoder) and JPEG -> PNG run on the device; every other pair of formats has no device path
+// the same encoder), JPEG -> PNG and PNG -> JPEG (csp_png_to_jpeg) run on the device; every other pair of formats has no device path
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
-    std::vector<size_t> ok, okpng, topng;
+    std::vector<size_t> ok, okpng, topng, tojpeg;
     for (size_t i = 0; i < count; i++) {
         outputs[i].data = nullptr; outputs[i].length = 0;
         const int src = sniff(inputs[i].data, inputs[i].length);
@@ -276,7 +278,8 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         if (src == CS_TYPE_UNKN) { code = CS_ERR_UNKNOWN_TYPE; msg = "unknown file type"; }
         else if (uint32_t(src) == format) { code = CS_ERR_SAME_FORMAT; msg = "cannot convert to the same format"; }
         else if (src == CS_TYPE_JPEG && format == CS_TYPE_PNG) { topng.push_back(i); continue; }
-        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP, PNG -> WebP, JPEG -> PNG)"; }
+        else if (src == CS_TYPE_PNG && format == CS_TYPE_JPEG) { tojpeg.push_back(i); continue; }
+        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP, PNG -> WebP, JPEG -> PNG, PNG -> JPEG)"; }
         else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
         if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
@@ -303,6 +306,21 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         for (size_t k = 0; k < n; k++) in[k] = inputs[topng[k]];
         failed_total += jpeg_to_png(in.data(), n, p, device, out.data(), res.data());
         for (size_t k = 0; k < n; k++) { outputs[topng[k]] = out[k]; if (results) results[topng[k]] = res[k]; else cs_free_result(&res[k]); }
+    }
+    for (size_t g0 = 0, n = 0; g0 < tojpeg.size(); g0 += n) {   // groups of at most 256 files and 96 GB of decode buffers (8 bytes per pixel at most, three regions)
+        uint64_t bytes = 0;
+        for (n = 0; g0 + n < tojpeg.size() && n < 256; n++) {
+            const CByteArray &f = inputs[tojpeg[g0 + n]];
+            uint64_t est = 1 << 20;
+            if (f.length >= 33) est += (uint64_t(rd_be32(f.data + 16)) * rd_be32(f.data + 20)) * 24;
+            if (n && bytes + est > (uint64_t(96) << 30)) break;
+            bytes += est;
+        }
+        std::vector<CByteArray> in(n), out(n);
+        std::vector<CCSResult> res(n);
+        for (size_t k = 0; k < n; k++) in[k] = inputs[tojpeg[g0 + k]];
+        failed_total += csp_png_to_jpeg(in.data(), n, p, device, out.data(), res.data());
+        for (size_t k = 0; k < n; k++) { outputs[tojpeg[g0 + k]] = out[k]; if (results) results[tojpeg[g0 + k]] = res[k]; else cs_free_result(&res[k]); }
     }
     if (!okpng.empty()) {
         const size_t n = okpng.size();

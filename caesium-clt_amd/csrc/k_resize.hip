@@ -35,6 +35,7 @@ __device__ static int chroma_at(const uint8_t *p, int pitch, int cw, int ch, int
 
 __global__ void __launch_bounds__(256) k_planes_to_rgb(const ImgDesc *imgs, const ResizeWork *work, const uint8_t *planes, uint8_t *rgb) {
     const ResizeWork w = work[blockIdx.y];
+    if (w.in_kind < 0) return;   // a pixel source: its RGB was copied in when the batch was made
     const ImgDesc &im = imgs[w.image];
     const int W = im.width, H = im.height;
     int i = blockIdx.x * blockDim.x + threadIdx.x;

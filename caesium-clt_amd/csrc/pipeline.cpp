@@ -354,13 +354,13 @@ extern "C" int csh_device_count(void) {
     return n;
 }
 
-static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out = false);
+static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out = false, const csp_pixels *px = nullptr);
 extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, false, out); }
 // JPEG in, pixels out (the front half of convert_in_memory to PNG): decode and resize only; the RGB stays in device memory (csh_batch_pixels)
 extern "C" int csh_batch_create_pixels(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, false, out, true); }
 // JPEG in, WebP out (caesium::convert_in_memory to SupportedFileTypes::WebP, compressor.rs:289,300): same decode and resize, then the VP8 encoder
 extern "C" int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, true, out); }
-static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out) {
+static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out, const csp_pixels *px) {
     *out = nullptr;
     if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
@@ -368,7 +368,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     std::unique_ptr<csh_batch> b(new csh_batch);
     b->device = device;
     b->params = *p;
-    b->lossless = p->jpeg_optimize && !webp && !rgb_out;
+    b->lossless = p->jpeg_optimize && !webp && !rgb_out && !px;
     b->webp = webp; b->rgb_out = rgb_out;
     const bool progressive = p->jpeg_progressive;
     if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
@@ -448,7 +448,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->max_dummy = std::max(b->max_dummy, nd);
         }
         im.omcus_x = o.mcus_x; im.omcus_y = o.mcus_y;
-        const bool resized = ((p->width || p->height) && !b->lossless) || b->webp || b->rgb_out;   // the WebP encoder takes the RGB the resize branch produces (a plain copy at equal size)
+        const bool resized = ((p->width || p->height) && !b->lossless) || b->webp || b->rgb_out || px;   // the WebP encoder takes the RGB the resize branch produces (a plain copy at equal size)
         im.enc_w = o.width; im.enc_h = o.height;
         for (int c = 0; c < in.ncomp; c++) im.src[c] = im.in[c];
         int img_index = int(b->imgs.size());
@@ -670,6 +670,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             memset(&rw, 0, sizeof rw);
             rw.image = img_index; rw.nw = o.width; rw.nh = o.height;
             rw.in_kind = in.ncomp == 1 ? 0 : ((in.comp[1].h == in.hmax && in.comp[1].v == in.vmax) ? 0 : (in.comp[1].v == in.vmax ? 2 : 1));
+            if (px) rw.in_kind = -1;   // the RGB of this image is not made from decoded planes: it is copied in below (csh_batch_create_from_pixels)
             const uint64_t src_bytes = uint64_t(in.width) * in.height * in.ncomp, dst_bytes = uint64_t(o.width) * o.height * in.ncomp;
             rw.rgb_src_off = b->rgb_bytes; b->rgb_bytes += (src_bytes + 63) & ~uint64_t(63);
             rw.rgb_dst_off = b->rgb_bytes; b->rgb_bytes += (dst_bytes + 63) & ~uint64_t(63);
@@ -786,10 +787,56 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
             return CS_ERR_NO_DEVICE;
+        for (size_t n = 0; px && n < count; n++) {
+            const Item &it = b->items[n];
+            if (it.image < 0) continue;
+            for (const ResizeWork &rw : b->rwork)
+                if (rw.image == it.image) {
+                    if (hipMemcpyAsync(b->d_rgb.p + rw.rgb_src_off, px[n].device_pixels, size_t(px[n].width) * px[n].height * px[n].channels, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
+                    break;
+                }
+        }
         if (hipStreamSynchronize(st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
     }
     *out = b.release();
     return 0;
+}
+
+// Pixels in, JPEG out (the back half of convert_in_memory to JPEG): the batch object derives every descriptor from a parsed JPEG, so a
+// pixel source presents itself as one -- a baseline 4:4:4 (or grey) file of its size whose every block is empty (two bits per block:
+// DC difference 0, end of block) -- and its RGB is copied over what those planes would have given, in front of the resize branch.
+// The decode of the stand-in costs a few bits per block and one IDCT over zeros; everything behind the RGB is the resize path as is.
+static std::vector<uint8_t> standin_jpeg(uint32_t w, uint32_t h, uint32_t nc) {
+    std::vector<uint8_t> f = {0xFF, 0xD8, 0xFF, 0xDB, 0x00, 0x43, 0x00};
+    f.insert(f.end(), 64, 1);                                                                    // DQT 0: all ones
+    const uint8_t sof[] = {0xFF, 0xC0, 0x00, uint8_t(8 + 3 * nc), 8, uint8_t(h >> 8), uint8_t(h), uint8_t(w >> 8), uint8_t(w), uint8_t(nc)};
+    f.insert(f.end(), sof, sof + sizeof sof);
+    for (uint32_t c = 0; c < nc; c++) { f.push_back(uint8_t(c + 1)); f.push_back(0x11); f.push_back(0); }
+    for (int cls = 0; cls < 2; cls++) {                                                          // DHT: one 1-bit code, symbol 0 (DC category 0 / AC end of block)
+        const uint8_t dht[] = {0xFF, 0xC4, 0x00, 0x14, uint8_t(cls << 4), 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x00};
+        f.insert(f.end(), dht, dht + sizeof dht);
+    }
+    const uint8_t sos[] = {0xFF, 0xDA, 0x00, uint8_t(6 + 2 * nc), uint8_t(nc)};
+    f.insert(f.end(), sos, sos + sizeof sos);
+    for (uint32_t c = 0; c < nc; c++) { f.push_back(uint8_t(c + 1)); f.push_back(0x00); }
+    f.push_back(0); f.push_back(63); f.push_back(0);
+    const uint64_t bits = uint64_t((w + 7) / 8) * ((h + 7) / 8) * nc * 2;
+    f.insert(f.end(), size_t(bits / 8), 0x00);
+    if (bits % 8) f.push_back(uint8_t(0xFF >> (bits % 8)));                                      // the last byte is padded with one-bits
+    f.push_back(0xFF); f.push_back(0xD9);
+    return f;
+}
+extern "C" int csh_batch_create_from_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csh_batch **out) {
+    *out = nullptr;
+    std::vector<std::vector<uint8_t>> files(count);
+    std::vector<CByteArray> in(count);
+    for (size_t i = 0; i < count; i++) {
+        const csp_pixels &s = sources[i];
+        if (!s.device_pixels || !s.width || !s.height || s.width > 65535 || s.height > 65535 || (s.channels != 1 && s.channels != 3)) files[i] = {'?'};   // answered per file: unknown type
+        else files[i] = standin_jpeg(s.width, s.height, s.channels);
+        in[i].data = files[i].data(); in[i].length = files[i].size();
+    }
+    return batch_create(in.data(), count, p, device, false, out, false, sources);
 }
 
 extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }

@@ -263,7 +263,7 @@ static int upload_chunk_index(csp_batch *b) {
     return hipStreamSynchronize(b->stream) == hipSuccess ? 0 : -1;   // the host vectors go out of scope
 }
 
-enum { MODE_PNG = 0, MODE_WEBP = 1, MODE_DECODE = 2 };
+enum { MODE_PNG = 0, MODE_WEBP = 1, MODE_DECODE = 2, MODE_DECODE_ANY = 3 };   // DECODE: the front half of a resize (no 16-bit); DECODE_ANY: of a conversion to JPEG
 struct PreFail { int code; std::string msg; };
 static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre = nullptr);
 static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out);
@@ -293,7 +293,7 @@ static void pixels_item(const csp_pixels &src, PngItem &it) {
 
 static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre) {
     *out = nullptr;
-    const bool to_webp = mode == MODE_WEBP, decode_only = mode == MODE_DECODE;
+    const bool to_webp = mode == MODE_WEBP, decode_only = mode == MODE_DECODE || mode == MODE_DECODE_ANY;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { csh_set_error("no HIP device: libcaesium_hip has no CPU path"); return CS_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) { csh_set_error("device %d out of range (%d visible)", device, ndev); return CS_ERR_NO_DEVICE; }
@@ -337,7 +337,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         if (it.code) continue;
         if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        if (decode_only && it.depth == 16) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG has no device path in this build"; continue; }
+        if (mode == MODE_DECODE && it.depth == 16) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG has no device path in this build"; continue; }
         if (decode_only && it.has_trns && it.trns.size() != (it.ctype == 3 ? it.trns.size() : it.ctype == 0 ? 2u : it.ctype == 2 ? 6u : ~size_t(0))) { it.code = CS_ERR_BAD_PNG; it.msg = "bad tRNS"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
@@ -840,6 +840,73 @@ static CCSResult png_result(int code, const char *msg) {
     if (code && msg) { size_t n = strlen(msg); char *m = (char *)malloc(n + 1); memcpy(m, msg, n + 1); r.error_message = m; }
     return r;
 }
+
+// PNG -> JPEG (convert_in_memory to JPEG, /root/reference/src/compressor.rs:289-299): a decode-only batch, the pixels as 8-bit grey or
+// RGB (k_png_rgb: palette looked up, 16-bit narrowed, sub-byte grey scaled; an alpha channel or tRNS is dropped, as image-rs's JPEG
+// encoder does [UPSTREAM-RECALL]), then the JPEG batch object from those pixels (csh_batch_create_from_pixels: its resize honours
+// width / height, its encoder p's JPEG parameters).  Device to device; results in input order.
+extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+    for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
+    auto fail_all = [&](int rc) { for (size_t i = 0; i < count; i++) if (results) results[i] = png_result(rc, csh_last_error()); return int(count); };
+    CCSParameters q = *p;
+    q.width = 0; q.height = 0;
+    csp_batch *raw = nullptr;
+    int rc = png_create(inputs, nullptr, count, &q, device, MODE_DECODE_ANY, &raw);
+    std::unique_ptr<csp_batch> a(raw);
+    if (rc == 0) rc = csp_batch_run(a.get(), nullptr);
+    if (rc) return fail_all(rc);
+    hipStream_t st = a->stream;
+    const int nimg = int(a->imgs.size());
+    std::vector<uint32_t> status(size_t(nimg) + 1, 0);
+    if (nimg && hipMemcpy(status.data(), a->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return fail_all(CS_ERR_NO_DEVICE); }
+    std::vector<RgbJob> ejobs;
+    std::vector<uint8_t> tables(1, 0);
+    std::vector<size_t> at;
+    std::vector<csp_pixels> px;
+    uint64_t src_bytes = 0;
+    uint32_t max_h = 0;
+    int failed = 0;
+    for (size_t i = 0; i < count; i++) {
+        const PngItem &it = a->items[i];
+        int code = it.code;
+        const char *msg = it.msg.c_str();
+        if (!code && status[it.image]) { code = int(status[it.image]); msg = "malformed PNG data"; }
+        if (!code && (it.width > 65535 || it.height > 65535)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a JPEG"; }
+        if (code) { if (results) results[i] = png_result(code, msg); failed++; continue; }
+        RgbJob e{};
+        e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth;
+        e.out_nc = (it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u;
+        e.plte_off = uint32_t(tables.size()); e.npal = uint32_t(it.plte.size() / 3);
+        tables.insert(tables.end(), it.plte.begin(), it.plte.end());
+        e.src_off = a->imgs[it.image].pix_off; e.dst_off = src_bytes;
+        src_bytes += (uint64_t(it.width) * it.height * e.out_nc + 255) & ~uint64_t(255);
+        max_h = std::max(max_h, it.height);
+        px.push_back(csp_pixels{reinterpret_cast<const uint8_t *>(uintptr_t(e.dst_off)), it.width, it.height, e.out_nc});   // offset for now
+        ejobs.push_back(e); at.push_back(i);
+    }
+    if (px.empty()) return failed;
+    auto fail_rest = [&](int code) { for (size_t k : at) if (results) results[k] = png_result(code, csh_last_error()); return failed + int(at.size()); };   // the files that were still good
+    DevBuf<RgbJob> d_ejobs;
+    DevBuf<uint8_t> d_tables, d_src;
+    if (d_ejobs.upload(ejobs, st) || d_tables.upload(tables, st) || d_src.alloc(src_bytes + 256)) return fail_rest(CS_ERR_NO_DEVICE);
+    launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG kernels failed"); return fail_rest(CS_ERR_NO_DEVICE); }
+    for (auto &s : px) s.device_pixels = d_src.p + uintptr_t(s.device_pixels);
+    csh_batch *jb = nullptr;
+    rc = csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
+    if (rc == 0) rc = csh_batch_run(jb, nullptr);
+    std::vector<CByteArray> out(px.size());
+    std::vector<CCSResult> res(px.size());
+    int jf = rc ? -1 : csh_batch_fetch(jb, out.data(), res.data());
+    for (size_t k = 0; k < px.size(); k++) {
+        if (jf < 0) { if (results) results[at[k]] = png_result(rc ? rc : CS_ERR_NO_DEVICE, csh_last_error()); continue; }
+        outputs[at[k]] = out[k];
+        if (results) results[at[k]] = res[k]; else cs_free_result(&res[k]);
+    }
+    csh_batch_destroy(jb);
+    return failed + (jf < 0 ? int(px.size()) : jf);
+}
+
 
 extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results) {
     if (!b || !b->ran || b->decode_only) { csh_set_error("csp_batch_fetch before csp_batch_run"); return -1; }

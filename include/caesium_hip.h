@@ -84,7 +84,7 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
    are overwritten while bisecting, as the reference's &mut CSParameters is) */
 CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size,
                                         bool return_smallest, CByteArray *out);
-/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and opaque PNG -> WebP (lossy), JPEG -> PNG (png_optimize: lossless trials, else the quantiser); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
+/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and opaque PNG -> WebP (lossy), JPEG -> PNG (png_optimize: lossless trials, else the quantiser), PNG -> JPEG (alpha dropped); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
 CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out);
 /* the batch form of it: results[i] / outputs[i] correspond to inputs[i] */
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results);
@@ -139,6 +139,11 @@ int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParam
    destroyed.  csh_batch_pixels returns the CCSResult code of that file (0: pointers set); csh_batch_fetch does not apply */
 int csh_batch_create_pixels(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
 int csh_batch_pixels(csh_batch *b, size_t image, const uint8_t **device_pixels, uint32_t *width, uint32_t *height, uint32_t *channels, const char **message);
+/* pixels in, JPEG out (the back half of convert_in_memory to JPEG): 8-bit grey or RGB in device memory (csp_pixels below; copied at
+   creation), then the resize and the encoder of the JPEG path with p's quality / progressive / chroma parameters.  A side of more than
+   65535 pixels or another channel count is answered per file */
+struct csp_pixels_s;
+int csh_batch_create_from_pixels(const struct csp_pixels_s *sources, size_t count, const CCSParameters *p, int device, csh_batch **out);
 int csh_batch_run(csh_batch *b, csh_timing *t);
 int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *results);
 void csh_batch_destroy(csh_batch *b);
@@ -182,8 +187,12 @@ int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParam
    png::compress, /root/reference/src/compressor.rs:289-305): 8-bit samples, rows of width * channels bytes back to back, channels 1
    (grey), 2 (grey + alpha), 3 (RGB) or 4 (RGBA).  The pixels are copied at creation (device to device; the source must be complete:
    synchronise the stream that produced it first).  p selects the lossless (png_optimize) or the quantising form, as for a PNG file */
-typedef struct { const uint8_t *device_pixels; uint32_t width, height, channels; } csp_pixels;
+typedef struct csp_pixels_s { const uint8_t *device_pixels; uint32_t width, height, channels; } csp_pixels;
 int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out);
+/* PNG in, JPEG out in one call (what cs_batch_convert does for such files; convert_in_memory to JPEG, compressor.rs:289-299): the PNG
+   decode stages, the pixels as 8-bit grey / RGB (alpha dropped), then the JPEG resize + encoder with p's parameters.  Returns the
+   number of failed files; outputs / results in input order */
+int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results);
 int csp_batch_run(csp_batch *b, csp_timing *t);
 int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results);
 void csp_batch_destroy(csp_batch *b);

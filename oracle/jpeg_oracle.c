@@ -1085,6 +1085,20 @@ void cso_rgb_to_ycc(const uint8_t *rgb, size_t npix, uint8_t *ycc) {
         ycc[3 * i + 2] = (uint8_t)((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16);
     }
 }
+/* pixels in, JPEG out (the back half of convert_in_memory to JPEG): 8-bit grey (nc 1) or RGB (nc 3) -> optional image-rs Lanczos3 ->
+   jccolor -> the same forward path and encoder as a resized JPEG; no metadata */
+int cso_pixels_to_jpeg(const uint8_t *pix, int W, int H, int nc, const cso_enc_params *p, int width, int height, uint8_t **out, size_t *out_len) {
+    if (nc != 1 && nc != 3) FAIL("unsupported channel count %d", nc);
+    int nw = W, nh = H, rc = -1;
+    if (width || height) cso_compute_dimensions(W, H, width, height, &nw, &nh);
+    cso_image *dst = NULL;
+    uint8_t *rs = (uint8_t *)malloc((size_t)nw * nh * nc);
+    cso_lanczos3_resize(pix, W, H, nc, nw, nh, rs);
+    if (nc == 3) cso_rgb_to_ycc(rs, (size_t)nw * nh, rs);
+    if (cso_forward(rs, nw, nh, nc, p, NULL, &dst) == 0) rc = cso_encode(dst, p, NULL, 0, out, out_len);
+    free(rs); cso_image_free(dst);
+    return rc;
+}
 int cso_jpeg_compress_resized(const uint8_t *in, size_t n, const cso_enc_params *p, int width, int height, uint8_t **out, size_t *out_len) {
     cso_image *src = NULL, *dst = NULL;
     if (cso_decode(in, n, &src)) return -1;

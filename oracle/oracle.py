@@ -84,6 +84,7 @@ def lib():
         L.cso_lanczos3_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cso_ycc_to_rgb.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.cso_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cso_pixels_to_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(EncParams), C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_jpeg_compress_resized.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(EncParams), C.c_int, C.c_int,
                                                 C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_last_error.restype = C.c_char_p
@@ -272,6 +273,18 @@ def jpeg_compress_resized(data, p, width, height):
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t()
     _check(lib().cso_jpeg_compress_resized(data, len(data), C.byref(p), width, height, C.byref(out), C.byref(n)))
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res
+
+
+def pixels_to_jpeg(pix, p, width=0, height=0):
+    """(h, w, 1 or 3) uint8 -> JPEG file bytes"""
+    pix = np.ascontiguousarray(pix, dtype=np.uint8)
+    h, w, nc = pix.shape
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    _check(lib().cso_pixels_to_jpeg(pix.ctypes.data, w, h, nc, C.byref(p), width, height, C.byref(out), C.byref(n)))
     res = C.string_at(out, n.value)
     lib().cso_free(out)
     return res

@@ -245,7 +245,7 @@ def raw_png(pixels, ctype, depth=8, level=0, pad=True):
     return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + text + chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b"")
 
 
-def png_expand8(P):
+def png_expand8(P, ignore_trns=False):
     """what the png crate's EXPAND transformation hands image-rs, restated with numpy over the oracle's decode: 8-bit samples, palette
     looked up (an index past the PLTE is black), sub-byte grey scaled to the full range, tRNS as an alpha channel.  -> ((h, w, nc)
     array, colour type of that layout).  16-bit images raise (the device refuses to resize them)"""
@@ -258,7 +258,7 @@ def png_expand8(P):
     chunks, pos, trns, plte = C.string_at(im.chunks, im.chunks_len), 0, None, b""
     while pos + 12 <= len(chunks):
         ln = int.from_bytes(chunks[pos:pos + 4], "big")
-        if chunks[pos + 4:pos + 8] == b"tRNS":
+        if chunks[pos + 4:pos + 8] == b"tRNS" and not ignore_trns:
             trns = chunks[pos + 8:pos + 8 + ln]
         if chunks[pos + 4:pos + 8] == b"PLTE":
             plte = chunks[pos + 8:pos + 8 + ln]
@@ -341,6 +341,29 @@ def oracle_png_to_webp(src, quality, width=0, height=0):
     out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
     O.lib().cso_lanczos3_resize(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
     return O.webp_encode_rgb(np.repeat(out, 3, axis=2) if nc == 1 else out, quality)
+
+
+def oracle_png_to_jpeg(src, quality=80, width=0, height=0, subsampling=420, progressive=1):
+    """convert_in_memory(PNG -> JPEG): decode (oracle), the pixels as 8-bit grey / RGB (alpha and tRNS dropped, 16-bit narrowed as
+    image-rs does), then the oracle's pixels-to-JPEG path (Lanczos3 when a size is given, jccolor, forward DCT, encoder)"""
+    import numpy as np
+
+    from oracle import oracle as O
+    P = O.png_decode(src)
+    im = P.im
+    if im.width > 65535 or im.height > 65535:
+        raise O.PngError(10201)
+    h, w = im.height, im.width
+    if im.depth == 16:
+        v = P.rows().reshape(h, w, im.channels, 2).astype(np.uint32)
+        pix = (((v[..., 0] << 8) | v[..., 1]) + 128) // 257
+        pix = pix.astype(np.uint8)
+        ctype = im.ctype
+    else:
+        pix, ctype = png_expand8(P, ignore_trns=True)   # a tRNS chunk makes no alpha channel here
+    if ctype in (4, 6):
+        pix = pix[:, :, :-1]
+    return O.pixels_to_jpeg(pix, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1), width, height)
 
 
 def oracle_png_lossy(src, level=3, keep_metadata=False):

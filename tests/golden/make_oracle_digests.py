@@ -36,6 +36,7 @@ def digests():
             put(f"png_to_webp/{name}/q80", O.png_to_webp(src, 80))
         except O.PngError as e:
             out[f"png_to_webp/{name}/q80"] = f"refused {e.code}"
+        put(f"png_to_jpeg/{name}/q80", U.oracle_png_to_jpeg(src, 80))
         try:
             put(f"png_resized/{name}/w40", U.oracle_png_resized(src, True, 2, 40, 0))
         except O.PngError as e:

@@ -399,12 +399,32 @@ def png_resize_step(binary, tmp_path):
     assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_png_resized(wide, False, 3, 40, 0), oracle_resized(jpg, 40, 0)]
 
 
+def png_to_jpeg_step(binary, tmp_path):
+    """--format jpeg over PNG sources, with and without a resize.  Its own step: on the device it runs from tests/test_zzzz_png_jpeg_gpu.py"""
+    from _util import oracle_png_to_jpeg
+    from gen_synth import synth_png
+    d = tmp_path / "pj_in"
+    d.mkdir()
+    rgb, rgba, pal = synth_png(91, 120, 70, "RGB"), synth_png(92, 50, 90, "RGBA"), synth_png(93, 60, 40, "P")
+    for name, data in (("a.png", rgb), ("b.png", rgba), ("c.png", pal)):
+        (d / name).write_bytes(data)
+    j = json.loads(run_cli(binary, "-q", 70, "-o", tmp_path / "pj", "--json", "--format", "jpeg", d / "a.png", d / "b.png", d / "c.png").stdout)
+    assert [f["status"] for f in j["files"]] == ["success"] * 3 and j["files"][0]["output_path"].endswith("a.jpg")
+    assert [open(f["output_path"], "rb").read() for f in j["files"]] == [oracle_png_to_jpeg(s, 70) for s in (rgb, rgba, pal)]
+    j = json.loads(run_cli(binary, "-q", 85, "-o", tmp_path / "pj2", "--json", "--format", "jpeg", "--long-edge", 48, "--jpeg-baseline", "--jpeg-chroma-subsampling", "4:4:4",
+                           d / "a.png", d / "b.png").stdout)
+    assert [f["status"] for f in j["files"]] == ["success"] * 2
+    want = [oracle_png_to_jpeg(rgb, 85, 48, 0, 444, 0), oracle_png_to_jpeg(rgba, 85, 0, 48, 444, 0)]
+    assert [open(f["output_path"], "rb").read() for f in j["files"]] == want
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
     png_to_webp_step(EMUL_CLI, tmp_path)
     jpeg_to_png_step(EMUL_CLI, tmp_path)
     png_resize_step(EMUL_CLI, tmp_path)
+    png_to_jpeg_step(EMUL_CLI, tmp_path)
 
 
 @pytest.mark.gpu

@@ -27,7 +27,8 @@ api.batch_compress(PE.fuzzed_blobs(3, 24, True), pkg.default_parameters(jpeg_qua
 import test_png_webp_emul as PW, test_jpeg_png_emul as JP
 PW.check(api, _util.png_cases(), 85); PW.check(api, PW.extra_cases(), 60); PW.test_damaged_pngs_convert_like_the_oracle_or_fail(api)
 JP.check(api, W.webp_cases(), True); JP.check(api, W.webp_cases()[:3], False, width=50); JP.test_mixed_batch_and_failures(api); JP.test_damaged_jpegs_convert_like_the_oracle_or_fail(api)
-import test_png_resize_emul as PR
+import test_png_resize_emul as PR, test_png_jpeg_emul as PJ
+PJ.test_every_png_format_converts_like_the_oracle(api); PJ.test_resize_in_front(api); PJ.test_mixed_batch_and_failures(api)
 PR.test_every_case_resizes_like_the_oracle_or_is_refused(api); PR.test_sizes_and_shapes(api); PR.test_mixed_batch_with_jpegs_and_damage(api)
 print('asan run: all cases equal the oracle')
 PY
