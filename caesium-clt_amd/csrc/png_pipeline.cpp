@@ -793,7 +793,7 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
         int nw = 0, nh = 0;
         csh_compute_dimensions(int(it.width), int(it.height), int(p->width), int(p->height), nw, nh);
         const uint64_t tmpn = uint64_t(nh) * it.width * nc, dstn = uint64_t(nw) * nh * nc;
-        if (uint64_t(nw) * nc > 0x7FFFFFF0u || uint64_t(it.width) * nc > 0x7FFFFFF0u || tmpn > (uint64_t(1) << 40)) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }
+        if (uint64_t(nw) * nc > 0x7FFFFFF0u || uint64_t(it.width) * nc > 0x7FFFFFF0u || tmpn > 0xFFFFFF00u || dstn > 0xFFFFFF00u) {   // one lane per sample: a launch holds 2^32 of them pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }
         RgbJob e{};
         e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth; e.out_nc = nc;
         e.plte_off = uint32_t(tables.size()); e.npal = uint32_t(it.plte.size() / 3);
@@ -821,7 +821,6 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
     DevBuf<uint8_t> d_dst, d_src, d_tables;
     DevBuf<RgbJob> d_ejobs;
     if (!jobs.empty()) {
-        if (max_tmp / 256 > 0x7FFFFFF0u || max_dst / 256 > 0x7FFFFFF0u) { csh_set_error("PNG resize too large"); return CS_ERR_POOL_OVERFLOW; }
         if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256) ||
             d_ejobs.upload(ejobs, st) || d_tables.upload(tables, st) || d_src.alloc(src_bytes + 256)) return CS_ERR_NO_DEVICE;
         launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
