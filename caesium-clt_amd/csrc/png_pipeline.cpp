@@ -793,7 +793,7 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
         int nw = 0, nh = 0;
         csh_compute_dimensions(int(it.width), int(it.height), int(p->width), int(p->height), nw, nh);
         const uint64_t tmpn = uint64_t(nh) * it.width * nc, dstn = uint64_t(nw) * nh * nc;
-        if (uint64_t(nw) * nc > 0x7FFFFFF0u || uint64_t(it.width) * nc > 0x7FFFFFF0u || tmpn > 0xFFFFFF00u || dstn > 0xFFFFFF00u) {   // one lane per sample: a launch holds 2^32 of them pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }
+        if (uint64_t(nw) * nc > 0x7FFFFFF0u || uint64_t(it.width) * nc > 0x7FFFFFF0u || tmpn > 0xFFFFFF00u || dstn > 0xFFFFFF00u) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }   // one lane per sample: a launch holds 2^32 of them
         RgbJob e{};
         e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth; e.out_nc = nc;
         e.plte_off = uint32_t(tables.size()); e.npal = uint32_t(it.plte.size() / 3);
