@@ -790,11 +790,9 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         for (size_t n = 0; px && n < count; n++) {
             const Item &it = b->items[n];
             if (it.image < 0) continue;
-            for (const ResizeWork &rw : b->rwork)
-                if (rw.image == it.image) {
-                    if (hipMemcpyAsync(b->d_rgb.p + rw.rgb_src_off, px[n].device_pixels, size_t(px[n].width) * px[n].height * px[n].channels, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
-                    break;
-                }
+            const ResizeWork &rw = b->rwork[size_t(it.image)];   // every image of such a batch has its resize work item, in image order
+            if (rw.image != it.image) { csh_set_error("internal: resize work out of order"); return CS_ERR_NO_DEVICE; }
+            if (hipMemcpyAsync(b->d_rgb.p + rw.rgb_src_off, px[n].device_pixels, size_t(px[n].width) * px[n].height * px[n].channels, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
         }
         if (hipStreamSynchronize(st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
     }
@@ -1188,8 +1186,8 @@ extern "C" int csh_batch_pixels(csh_batch *b, size_t image, const uint8_t **devi
     const Item &it = b->items[image];
     if (it.code) { if (message) *message = it.msg.c_str(); return it.code; }
     if (b->h_status[it.image]) { if (message) *message = "device reported a malformed stream"; return int(b->h_status[it.image]); }
-    for (const ResizeWork &rw : b->rwork) {
-        if (rw.image != it.image) continue;
+    if (size_t(it.image) < b->rwork.size() && b->rwork[size_t(it.image)].image == it.image) {   // every image of a pixel batch has its resize work item, in image order
+        const ResizeWork &rw = b->rwork[size_t(it.image)];
         *device_pixels = b->d_rgb.p + rw.rgb_dst_off; *width = uint32_t(rw.nw); *height = uint32_t(rw.nh); *channels = uint32_t(b->imgs[it.image].ncomp);
         return 0;
     }
