@@ -34,8 +34,9 @@ void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, 
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
                         const uint32_t *palettes, const uint8_t *src, uint8_t *dst);
 
-// resize of a PNG source (k_png_resize.hip): interleaved 8-bit samples, nc per pixel; src / dst are byte offsets, tmp a float offset
-struct PngResize { uint32_t width, height, nc, nw, nh, vtap_base, htap_base, pad_; uint64_t src_off, tmp_off, dst_off; };
+// resize of a PNG source (k_png_resize.hip): interleaved samples of bps bytes (1, or 2 big-endian), nc per pixel; src / dst are byte
+// offsets, tmp a float offset
+struct PngResize { uint32_t width, height, nc, nw, nh, vtap_base, htap_base, bps; uint64_t src_off, tmp_off, dst_off; };
 void launch_png_resize(hipStream_t st, const PngResize *jobs, int njobs, const csh::ResizeTap *taps, const float *weights, const uint8_t *src, float *tmp, uint8_t *dst,
                        uint64_t max_tmp, uint64_t max_dst);
 

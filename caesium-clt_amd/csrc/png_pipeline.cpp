@@ -265,7 +265,8 @@ static int upload_chunk_index(csp_batch *b) {
 
 enum { MODE_PNG = 0, MODE_WEBP = 1, MODE_DECODE = 2, MODE_DECODE_ANY = 3 };   // DECODE: the front half of a resize (no 16-bit); DECODE_ANY: of a conversion to JPEG
 struct PreFail { int code; std::string msg; };
-static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre = nullptr);
+static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre = nullptr,
+                      const std::vector<uint8_t> *px_bits = nullptr);   // px_bits: 8 or 16 per pixel source (default 8)
 static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out);
 extern "C" int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out) {
     return (p->width || p->height) ? png_create_resized(inputs, count, p, device, MODE_PNG, out) : png_create(inputs, nullptr, count, p, device, MODE_PNG, out);
@@ -276,14 +277,15 @@ extern "C" int csp_batch_create_webp(const CByteArray *inputs, size_t count, con
 extern "C" int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csp_batch **out) { return png_create(nullptr, sources, count, p, device, MODE_PNG, out); }
 
 // a source that is pixels already (csp_batch_create_pixels): the item a PNG file of that image would parse to
-static void pixels_item(const csp_pixels &src, PngItem &it) {
+static void pixels_item(const csp_pixels &src, uint32_t bits, PngItem &it) {
+    const uint32_t bps = bits / 8;
     static const uint8_t ctype_of[5] = {0, 0, 4, 2, 6};
     if (!src.device_pixels || !src.width || !src.height || src.channels < 1 || src.channels > 4 || src.width > 0x7FFFFFFFu || src.height > 0x7FFFFFFFu ||
-        uint64_t(src.width) * src.channels > 0x7FFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "bad pixel source"; return; }
-    it.width = src.width; it.height = src.height; it.depth = 8; it.ctype = ctype_of[src.channels]; it.channels = src.channels; it.bpp = src.channels;
-    it.rowbytes = src.width * src.channels;
+        uint64_t(src.width) * src.channels * bps > 0x7FFFFFF0u) { it.code = CS_ERR_UNSUPPORTED; it.msg = "bad pixel source"; return; }
+    it.width = src.width; it.height = src.height; it.depth = bits; it.ctype = ctype_of[src.channels]; it.channels = src.channels; it.bpp = src.channels * bps;
+    it.rowbytes = src.width * src.channels * bps;
     uint8_t ihdr[25] = {0, 0, 0, 13, 'I', 'H', 'D', 'R'};
-    put_be32(ihdr + 8, src.width); put_be32(ihdr + 12, src.height); ihdr[16] = 8; ihdr[17] = ctype_of[src.channels];
+    put_be32(ihdr + 8, src.width); put_be32(ihdr + 12, src.height); ihdr[16] = uint8_t(bits); ihdr[17] = ctype_of[src.channels];
     put_be32(ihdr + 21, crc32_host(ihdr + 4, 17));
     it.prefix.assign(kSig, kSig + 8);
     it.prefix.insert(it.prefix.end(), ihdr, ihdr + 25);
@@ -291,7 +293,8 @@ static void pixels_item(const csp_pixels &src, PngItem &it) {
     it.suffix.assign(iend, iend + 12);
 }
 
-static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre) {
+static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out, const std::vector<PreFail> *pre,
+                      const std::vector<uint8_t> *px_bits) {
     *out = nullptr;
     const bool to_webp = mode == MODE_WEBP, decode_only = mode == MODE_DECODE || mode == MODE_DECODE_ANY;
     int ndev = 0;
@@ -332,12 +335,12 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         PngItem &it = b->items[i];
         b->inputs[i] = px ? nullptr : inputs[i].data;
         if (pre && (*pre)[i].code) { it.code = (*pre)[i].code; it.msg = (*pre)[i].msg; }
-        else if (px) pixels_item(px[i], it);
+        else if (px) pixels_item(px[i], px_bits ? (*px_bits)[i] : 8, it);
         else parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
         if (it.code) continue;
         if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        if (mode == MODE_DECODE && it.depth == 16) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG has no device path in this build"; continue; }
+        if (mode == MODE_DECODE && it.depth == 16 && it.has_trns) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG with a tRNS chunk has no device path in this build"; continue; }
         if (decode_only && it.has_trns && it.trns.size() != (it.ctype == 3 ? it.trns.size() : it.ctype == 0 ? 2u : it.ctype == 2 ? 6u : ~size_t(0))) { it.code = CS_ERR_BAD_PNG; it.msg = "bad tRNS"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
@@ -761,7 +764,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
 // batch, the two Lanczos passes over its pixels, then the coder -- or, on the way to WebP, the VP8 encoder -- over the resized pixels
 // (device to device, as for JPEG -> PNG).
 // The pixels are expanded first as the png crate does for image-rs (palette looked up, sub-byte grey scaled, tRNS as an alpha channel:
-// k_png_rgb); 16-bit sources are refused per file.
+// k_png_rgb); 16-bit sources keep their 16 bits (refused only with a tRNS chunk).
 static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out) {
     *out = nullptr;
     csp_batch *raw = nullptr;
@@ -783,17 +786,22 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
     std::vector<float> weights;
     uint64_t tmp_floats = 0, dst_bytes = 0, max_tmp = 0, max_dst = 0, src_bytes = 0;
     uint32_t max_h = 0;
+    struct RawCopy { uint64_t dst, src, bytes; };
+    std::vector<RawCopy> copies;
+    std::vector<uint8_t> bits(count, 8);
     for (size_t i = 0; i < count; i++) {
         const PngItem &it = a->items[i];
         px[i] = csp_pixels{nullptr, 0, 0, 0};
         if (it.code) { pre[i] = PreFail{it.code, it.msg}; continue; }
         if (status[it.image]) { pre[i] = PreFail{int(status[it.image]), "malformed PNG data"}; continue; }
         // what the png crate's EXPAND transformation hands image-rs: 8-bit samples, palette looked up, tRNS as an alpha channel
-        const uint32_t colour = (it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u, nc = colour + ((it.ctype == 4 || it.ctype == 6 || it.has_trns) ? 1u : 0u);
+        // (16-bit images stay as they are: image-rs resamples L16 / La16 / Rgb16 / Rgba16 at 16 bits)
+        const bool wide = it.depth == 16;
+        const uint32_t colour = (it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u, nc = colour + ((it.ctype == 4 || it.ctype == 6 || it.has_trns) ? 1u : 0u), bps = wide ? 2u : 1u;
         int nw = 0, nh = 0;
         csh_compute_dimensions(int(it.width), int(it.height), int(p->width), int(p->height), nw, nh);
         const uint64_t tmpn = uint64_t(nh) * it.width * nc, dstn = uint64_t(nw) * nh * nc;
-        if (uint64_t(nw) * nc > 0x7FFFFFF0u || uint64_t(it.width) * nc > 0x7FFFFFF0u || tmpn > 0xFFFFFF00u || dstn > 0xFFFFFF00u) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }   // one lane per sample: a launch holds 2^32 of them
+        if (uint64_t(nw) * nc * bps > 0x7FFFFFF0u || uint64_t(it.width) * nc * bps > 0x7FFFFFF0u || tmpn > 0xFFFFFF00u || dstn > 0xFFFFFF00u / bps) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resized PNG too large for one device batch"}; continue; }   // one lane per sample: a launch holds 2^32 of them
         RgbJob e{};
         e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth; e.out_nc = nc;
         e.plte_off = uint32_t(tables.size()); e.npal = uint32_t(it.plte.size() / 3);
@@ -801,16 +809,17 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
         e.trns_off = uint32_t(tables.size()); e.ntrns = uint32_t(it.trns.size());
         tables.insert(tables.end(), it.trns.begin(), it.trns.end());
         e.src_off = a->imgs[it.image].pix_off; e.dst_off = src_bytes;
-        src_bytes += (uint64_t(it.width) * it.height * nc + 255) & ~uint64_t(255);
-        max_h = std::max(max_h, it.height);
-        ejobs.push_back(e);
+        src_bytes += (uint64_t(it.width) * it.height * nc * bps + 255) & ~uint64_t(255);
+        if (wide) copies.push_back(RawCopy{e.dst_off, e.src_off, uint64_t(it.height) * it.rowbytes});   // nothing to expand
+        else { max_h = std::max(max_h, it.height); ejobs.push_back(e); }
+        bits[i] = uint8_t(8 * bps);
         PngResize j{};
-        j.width = it.width; j.height = it.height; j.nc = nc; j.nw = uint32_t(nw); j.nh = uint32_t(nh);
+        j.width = it.width; j.height = it.height; j.nc = nc; j.nw = uint32_t(nw); j.nh = uint32_t(nh); j.bps = bps;
         j.src_off = e.dst_off; j.tmp_off = tmp_floats; j.dst_off = dst_bytes;
         const bool same = uint32_t(nw) == it.width && uint32_t(nh) == it.height;   // image-rs copies instead of resampling
         j.vtap_base = uint32_t(taps.size()); csh_lanczos_axis(int(it.height), nh, same, taps, weights);
         j.htap_base = uint32_t(taps.size()); csh_lanczos_axis(int(it.width), nw, same, taps, weights);
-        tmp_floats += (tmpn + 63) & ~uint64_t(63); dst_bytes += (dstn + 255) & ~uint64_t(255);
+        tmp_floats += (tmpn + 63) & ~uint64_t(63); dst_bytes += (dstn * bps + 255) & ~uint64_t(255);
         max_tmp = std::max(max_tmp, tmpn); max_dst = std::max(max_dst, dstn);
         px[i].width = uint32_t(nw); px[i].height = uint32_t(nh); px[i].channels = nc;
         jobs.push_back(j); job_item.push_back(i);
@@ -824,13 +833,15 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
         if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256) ||
             d_ejobs.upload(ejobs, st) || d_tables.upload(tables, st) || d_src.alloc(src_bytes + 256)) return CS_ERR_NO_DEVICE;
         launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
+        for (const RawCopy &c : copies)
+            if (hipMemcpyAsync(d_src.p + c.dst, a->d_work.p + c.src, c.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
         launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG resize kernels failed"); return CS_ERR_NO_DEVICE; }
         for (size_t k = 0; k < jobs.size(); k++) px[job_item[k]].device_pixels = d_dst.p + jobs[k].dst_off;
     }
     CCSParameters q = *p;
     q.width = 0; q.height = 0;
-    return png_create(nullptr, px.data(), count, &q, device, mode, out, &pre);   // copies the pixels before d_dst goes out of scope
+    return png_create(nullptr, px.data(), count, &q, device, mode, out, &pre, &bits);   // copies the pixels before d_dst goes out of scope
 }
 
 static CCSResult png_result(int code, const char *msg) {

@@ -180,7 +180,7 @@ typedef struct {
 const char *csp_kernel_name(int slot);
 int csp_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
 /* the same decode stages feeding the VP8 encoder (caesium::convert_in_memory with a PNG source and SupportedFileTypes::WebP,
-   /root/reference/src/compressor.rs:289-299): opaque PNGs only (with a size: not 16-bit); p->webp_quality applies.  run / fetch / destroy as above;
+   /root/reference/src/compressor.rs:289-299): opaque PNGs only; p->webp_quality applies.  run / fetch / destroy as above;
    the stage taps of the PNG coder do not exist for such a batch */
 int csp_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csp_batch **out);
 /* the PNG coder over pixels that are already in device memory (caesium::convert_in_memory to PNG: the decoded source goes through

@@ -1064,6 +1064,32 @@ void cso_lanczos3_resize(const uint8_t *src, int w, int h, int nch, int nw, int 
     }
     free(tmp); free(ws);
 }
+/* the same resample over 16-bit samples (image-rs keeps L16 / La16 / Rgb16 / Rgba16 images at 16 bits: clamp to 0..65535) */
+void cso_lanczos3_resize16(const uint16_t *src, int w, int h, int nch, int nw, int nh, uint16_t *dst) {
+    if (nw == w && nh == h) { memcpy(dst, src, (size_t)w * h * nch * 2); return; }
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)w * nh * nch);
+    float *ws = (float *)malloc(sizeof(float) * (size_t)((h > w ? h : w) + 8));
+    for (int oy = 0; oy < nh; oy++) {
+        int left, n = lanczos_taps(h, nh, oy, &left, ws);
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < nch; c++) {
+                float t = 0.0f;
+                for (int i = 0; i < n; i++) t += (float)src[((size_t)(left + i) * w + x) * nch + c] * ws[i];
+                tmp[((size_t)oy * w + x) * nch + c] = t;
+            }
+    }
+    for (int ox = 0; ox < nw; ox++) {
+        int left, n = lanczos_taps(w, nw, ox, &left, ws);
+        for (int y = 0; y < nh; y++)
+            for (int c = 0; c < nch; c++) {
+                float t = 0.0f;
+                for (int i = 0; i < n; i++) t += tmp[((size_t)y * w + left + i) * nch + c] * ws[i];
+                t = t < 0.0f ? 0.0f : (t > 65535.0f ? 65535.0f : t);
+                dst[((size_t)y * nw + ox) * nch + c] = (uint16_t)roundf(t);
+            }
+    }
+    free(tmp); free(ws);
+}
 /* libjpeg jdcolor.c ycc_rgb_convert: SCALEBITS 16, Cr=>R 1.40200, Cb=>B 1.77200, Cr=>G -0.71414, Cb=>G -0.34414 */
 void cso_ycc_to_rgb(const uint8_t *ycc, size_t npix, uint8_t *rgb) {
     for (size_t i = 0; i < npix; i++) {

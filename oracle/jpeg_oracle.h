@@ -109,6 +109,7 @@ int  cso_jpeg_compress(const uint8_t *in, size_t n, const cso_enc_params *p, int
    cso_jpeg_compress_resized = decode -> YCbCr->RGB -> Lanczos3 -> RGB->YCbCr -> forward(quality) -> encode.
    (the real chain decodes with zune-jpeg and re-encodes once more with image-rs before mozjpeg sees it) */
 void cso_compute_dimensions(int ow, int oh, int dw, int dh, int *nw, int *nh);
+void cso_lanczos3_resize16(const uint16_t *src, int w, int h, int nch, int nw, int nh, uint16_t *dst);
 int cso_pixels_to_jpeg(const uint8_t *pix, int W, int H, int nc, const cso_enc_params *p, int width, int height, uint8_t **out, size_t *out_len);
 void cso_lanczos3_resize(const uint8_t *src, int w, int h, int nch, int nw, int nh, uint8_t *dst);
 void cso_ycc_to_rgb(const uint8_t *ycc, size_t npix, uint8_t *rgb);

@@ -82,6 +82,7 @@ def lib():
         L.cso_gen_optimal_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cso_compute_dimensions.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.cso_lanczos3_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.cso_lanczos3_resize16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cso_ycc_to_rgb.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.cso_rgb_to_ycc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.cso_pixels_to_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(EncParams), C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]

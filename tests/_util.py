@@ -295,24 +295,46 @@ def png_expand8(P, ignore_trns=False):
     return np.dstack([g, alpha]), 4
 
 
-def oracle_png_resized(src, lossless, level=3, width=0, height=0):
-    """the oracle's statement of compress_in_memory on a PNG with a size: decode (oracle), image-rs Lanczos3 over the decoded samples
-    (oracle; after png_expand8), a PNG file of the result, then the PNG path over that file.  16-bit images raise (the device refuses
-    them)"""
+def png_resized_pixels(P, width, height):
+    """decode -> what image-rs resamples (png_expand8, or the 16-bit samples as they are) -> Lanczos3.  -> (array, colour type, depth)"""
     import ctypes as C
 
     import numpy as np
 
     from oracle import oracle as O
-    P = O.png_decode(src)
+    im = P.im
+    nw, nh = C.c_int(), C.c_int()
+    O.lib().cso_compute_dimensions(im.width, im.height, width, height, C.byref(nw), C.byref(nh))
+    if im.depth == 16:
+        chunks, pos = C.string_at(im.chunks, im.chunks_len), 0
+        while pos + 12 <= len(chunks):
+            if chunks[pos + 4:pos + 8] == b"tRNS":
+                raise O.PngError(10201)
+            pos += 12 + int.from_bytes(chunks[pos:pos + 4], "big")
+        h, w, nc = im.height, im.width, im.channels
+        pix = np.ascontiguousarray(P.rows().view(">u2").astype(np.uint16).reshape(h, w, nc))
+        out = np.empty((nh.value, nw.value, nc), dtype=np.uint16)
+        O.lib().cso_lanczos3_resize16(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+        return out, im.ctype, 16
     pix, ctype = png_expand8(P)
     pix = np.ascontiguousarray(pix)
     h, w, nc = pix.shape
-    nw, nh = C.c_int(), C.c_int()
-    O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
     out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
     O.lib().cso_lanczos3_resize(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
-    png = raw_png(out, ctype)
+    return out, ctype, 8
+
+
+def oracle_png_resized(src, lossless, level=3, width=0, height=0):
+    """the oracle's statement of compress_in_memory on a PNG with a size: decode (oracle), image-rs Lanczos3 over the decoded samples
+    (oracle; after png_expand8), a PNG file of the result, then the PNG path over that file.  16-bit images are resampled at 16 bits (with a tRNS chunk they raise: the
+    device refuses them)"""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import oracle as O
+    out, ctype, depth = png_resized_pixels(O.png_decode(src), width, height)
+    png = raw_png(out.astype(">u2").view(np.uint8) if depth == 16 else out, ctype, depth)
     if lossless:
         res, chosen = O.png_optimize(png, level)
         assert chosen >= 0
@@ -330,16 +352,12 @@ def oracle_png_to_webp(src, quality, width=0, height=0):
     from oracle import oracle as O
     if not (width or height):
         return O.png_to_webp(src, quality)
-    P = O.png_decode(src)
-    pix, ctype = png_expand8(P)
+    out, ctype, depth = png_resized_pixels(O.png_decode(src), width, height)
     if ctype in (4, 6):
         raise O.PngError(10201)
-    pix = np.ascontiguousarray(pix)   # named: the C call needs it alive
-    h, w, nc = pix.shape
-    nw, nh = C.c_int(), C.c_int()
-    O.lib().cso_compute_dimensions(w, h, width, height, C.byref(nw), C.byref(nh))
-    out = np.empty((nh.value, nw.value, nc), dtype=np.uint8)
-    O.lib().cso_lanczos3_resize(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
+    if depth == 16:
+        out = ((out.astype(np.uint32) + 128) // 257).astype(np.uint8)
+    nc = out.shape[2]
     return O.webp_encode_rgb(np.repeat(out, 3, axis=2) if nc == 1 else out, quality)
 
 

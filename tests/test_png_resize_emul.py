@@ -36,7 +36,7 @@ def check(api, cases, lossless, level=3, width=0, height=0):
 
 def test_every_case_resizes_like_the_oracle_or_is_refused(api):
     cases = png_cases()
-    assert check(api, cases, True, level=1, height=30) >= len(cases) - 8   # everything but the 16-bit images; L_1x300 becomes 1x30, RGBA_300x2 4500x30
+    assert check(api, cases, True, level=1, height=30) == len(cases)   # every format; L_1x300 becomes 1x30, RGBA_300x2 4500x30
     assert check(api, cases[:6], False, width=25) >= 4
 
 
@@ -57,6 +57,20 @@ def test_expansion_before_the_resize(api):
     assert check(api, pick, True, level=2, width=31) == len(pick)
     out = api.cs_batch_compress([pick[-2][1]], package().default_parameters(png_optimize=True, width=31))[0]
     assert PIL.open(io.BytesIO(out)).mode in ("RGBA", "LA", "P")   # grey 120 was transparent: the result carries alpha
+
+
+def test_sixteen_bit_images_stay_sixteen_bit(api):
+    """image-rs resamples L16 / Rgb16 at 16 bits; the coder may then narrow what fits 8 bits (reduce_i16_narrow does, noise does not)"""
+    from test_png_webp_emul import make_png
+    rng = np.random.default_rng(8)
+    rgb16 = make_png(37, 29, 16, 2, rng.integers(0, 65536, (29, 37, 3)).astype(">u2").tobytes())
+    la16 = make_png(21, 33, 16, 4, rng.integers(0, 65536, (33, 21, 2)).astype(">u2").tobytes())
+    cases = dict(png_cases())
+    pick = [("rgb16_noise", rgb16), ("la16_noise", la16), ("I;16_97x61", cases["I;16_97x61"]), ("reduce_i16_narrow", cases["reduce_i16_narrow"]), ("adam7_I;16_12x20", cases["adam7_I;16_12x20"])]
+    assert check(api, pick, True, level=2, width=19) == 5
+    assert check(api, pick, True, level=1, width=60, height=50) == 5
+    out = api.cs_batch_compress([rgb16], package().default_parameters(png_optimize=True, width=19))[0]
+    assert out[24] == 16   # IHDR bit depth
 
 
 def test_sizes_and_shapes(api):
@@ -85,15 +99,17 @@ def test_mixed_batch_with_jpegs_and_damage(api):
     from test_png_emul import damaged_pngs
     cases = dict(png_cases())
     jpg = synth_jpeg(3, 120, 90, texture=5)
-    blobs = [cases["RGB_97x61"], jpg, cases["I;16_97x61"], b"junk", cases["P_97x61"]] + damaged_pngs(5, 12)
+    from test_png_webp_emul import make_png
+    wide_trns = make_png(20, 10, 16, 0, bytes(range(200)) * 2, extra=[(b"tRNS", b"\0\7")])   # 16-bit grey with a transparent level: refused
+    blobs = [cases["RGB_97x61"], jpg, wide_trns, b"junk", cases["P_97x61"], cases["I;16_97x61"]] + damaged_pngs(5, 12)
     p = package().default_parameters(png_optimize=True, png_optimization_level=1, jpeg_quality=80, width=48)
     outs = api.cs_batch_compress(blobs, p)
     assert outs[0] == oracle_png_resized(blobs[0], True, 1, 48, 0)
     assert outs[1] == oracle_resized(jpg, 48, 0)
     assert outs[2].code == 10201 and "16-bit" in str(outs[2]) and outs[3].code == 10200
-    assert outs[4] == oracle_png_resized(blobs[4], True, 1, 48, 0)
+    assert outs[4] == oracle_png_resized(blobs[4], True, 1, 48, 0) and outs[5] == oracle_png_resized(blobs[5], True, 1, 48, 0)
     from oracle import oracle as O
-    for b, o in zip(blobs[5:], outs[5:]):
+    for b, o in zip(blobs[6:], outs[6:]):
         try:
             want = oracle_png_resized(b, True, 1, 48, 0)
         except O.PngError:
