@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/caesium_hip.h"
+#include "../../include/png_quality_table.h"
 #include "devmem.hpp"
 #include "png_kernels.h"
 #include "webp_kernels.h"
@@ -166,6 +167,7 @@ struct csp_batch {
     DevBuf<uint8_t> d_plte, d_rgb, d_wwork, d_wscratch, d_wprobs, d_wupdate;
     DevBuf<int16_t> d_wlevels;
     DevBuf<uint32_t> d_wstats, d_wpart, d_wstatus;
+    int png_quality = 80;
     bool lossy = false;             // png.optimize not set: truecolour images with more than 256 colours are quantised (oracle: quantize)
     uint32_t n_reduced = 0;
     PngPlan plan{};
@@ -201,7 +203,7 @@ extern "C" void csp_batch_destroy(csp_batch *b) { delete b; }
 
 // lossy PNG: the median cut over the colour bins of one image (oracle: median_cut).  bins must be sorted by id.  Returns the palette
 // (keys a, r, g, b; sorted, duplicates merged).
-static std::vector<uint32_t> median_cut(const std::vector<QBin> &bins) {
+static std::vector<uint32_t> median_cut(const std::vector<QBin> &bins, int quality) {
     const int nbins = int(bins.size());
     std::vector<int> ord(nbins);
     for (int i = 0; i < nbins; i++) ord[i] = i;
@@ -211,7 +213,22 @@ static std::vector<uint32_t> median_cut(const std::vector<QBin> &bins) {
     for (auto &q : bins) total += q.cnt;
     box.push_back(Box{0, nbins, total, false});
     auto mean = [&](int bin, int c) { return int(bins[bin].s[c] / bins[bin].cnt); };
+    // error of the palette entry a box would give: every bin mean against the rounded box mean (oracle: box_error)
+    auto box_error = [&](const Box &bx) {
+        uint64_t sum[4] = {0, 0, 0, 0}, cnt = 0, err = 0;
+        for (int i = bx.lo; i < bx.hi; i++) { const QBin &q = bins[ord[i]]; cnt += q.cnt; for (int c = 0; c < 4; c++) sum[c] += q.s[c]; }
+        for (int i = bx.lo; i < bx.hi; i++) {
+            uint64_t d2 = 0;
+            for (int c = 0; c < 4; c++) { const int64_t d = int64_t(mean(ord[i], c)) - int64_t((2 * sum[c] + cnt) / (2 * cnt)); d2 += uint64_t(d * d); }
+            err += d2 * bins[ord[i]].cnt;
+        }
+        return err;
+    };
+    std::vector<uint64_t> berr(1, nbins ? box_error(box[0]) : 0);
+    uint64_t total_err = berr[0];
+    quality = quality < 0 ? 0 : quality > 100 ? 100 : quality;
     while (box.size() < 256) {
+        if (box.size() >= 2 && (quality == 0 || total_err * 1024 <= kQualityBound[quality] * total)) break;   // good enough for this -q
         int pick = -1;
         for (int k = 0; k < int(box.size()); k++) if (!box[k].dead && box[k].hi - box[k].lo > 1 && (pick < 0 || box[k].cnt > box[pick].cnt)) pick = k;
         if (pick < 0) break;
@@ -231,6 +248,9 @@ static std::vector<uint32_t> median_cut(const std::vector<QBin> &bins) {
         while (sp < box[pick].hi - 1) { cum += bins[ord[sp]].cnt; sp++; if (2 * cum >= box[pick].cnt) break; }
         box.push_back(Box{sp, box[pick].hi, box[pick].cnt - cum, false});
         box[pick].hi = sp; box[pick].cnt = cum;
+        total_err -= berr[pick];
+        berr[pick] = box_error(box[pick]); berr.push_back(box_error(box.back()));
+        total_err += berr[pick] + berr.back();
     }
     std::vector<uint32_t> pal;
     for (auto &bx : box) {
@@ -303,7 +323,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
     std::unique_ptr<csp_batch> b(new csp_batch);
     b->device = device;
-    b->lossy = !p->png_optimize;
+    b->lossy = !p->png_optimize; b->png_quality = int(p->png_quality);
     b->from_pixels = px != nullptr;
     b->decode_only = decode_only;
     b->to_webp = to_webp; b->webp_quality = int(p->webp_quality);
@@ -528,7 +548,7 @@ static int reduce_step(csp_batch *b) {
             auto worker = [&]() {
                 for (size_t k; (k = next++) < gn;) {
                     std::sort(lists[k].begin(), lists[k].end(), [](const QBin &x, const QBin &y) { return x.id < y.id; });
-                    cut[k] = median_cut(lists[k]);
+                    cut[k] = median_cut(lists[k], b->png_quality);
                 }
             };
             std::vector<std::thread> pool;

@@ -51,7 +51,7 @@ class Png(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h", "webp_oracle.c", "webp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h", "webp_oracle.c", "webp_oracle.h")] + [os.path.join(_HERE, "..", "include", f) for f in ("png_quality_table.h", "vp8_tables.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -97,8 +97,8 @@ def lib():
         L.cso_png_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(Png))]
         L.cso_png_free.argtypes = [C.POINTER(Png)]
         L.cso_png_reduce.argtypes = [C.POINTER(Png)]
-        L.cso_png_quantize.argtypes = [C.POINTER(Png)]
-        L.cso_png_lossy.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_png_quantize.argtypes = [C.POINTER(Png), C.c_int]
+        L.cso_png_lossy.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_to_webp.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_scores.argtypes = [C.POINTER(Png), C.c_void_p]
         L.cso_png_filter.argtypes = [C.POINTER(Png), C.c_int, C.c_void_p, C.c_void_p]
@@ -321,9 +321,9 @@ class PngImage:
         """P2 reductions in place; -> bit mask of what was applied"""
         return lib().cso_png_reduce(self.ptr)
 
-    def quantize(self):
-        """lossy: median cut to at most 256 colours, in place; -> 16 when applied"""
-        return lib().cso_png_quantize(self.ptr)
+    def quantize(self, quality=80):
+        """lossy: median cut to at most 256 colours (fewer when the quality allows), in place; -> 16 when applied"""
+        return lib().cso_png_quantize(self.ptr, quality)
 
     def scores(self):
         """[height][5 filters][5 scores: MinSum, Entropy, Bigrams, BigEnt, Brute]"""
@@ -436,10 +436,10 @@ def png_to_webp(data, quality):
     return res
 
 
-def png_lossy(data, level=3, keep_metadata=False):
+def png_lossy(data, level=3, keep_metadata=False, quality=80):
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t()
-    rc = lib().cso_png_lossy(data, len(data), level, 1 if keep_metadata else 0, C.byref(out), C.byref(n))
+    rc = lib().cso_png_lossy(data, len(data), level, 1 if keep_metadata else 0, quality, C.byref(out), C.byref(n))
     if rc:
         raise PngError(rc)
     res = C.string_at(out, n.value)

@@ -26,6 +26,7 @@
 
 #include "png_oracle.h"
 #include "webp_oracle.h"
+#include "../include/png_quality_table.h"
 
 /* ------------------------------------------------------------------------------------------------ checksums */
 static uint32_t crc_table[256];
@@ -443,7 +444,8 @@ int cso_png_reduce(cso_png *P) {
  * integer MEDIAN CUT laid out for the GPU, without dithering -- coarser than imagequant on gradients, stated as such:
  *   1. pixels -> (a, r, g, b) of 8 bits (high bytes of 16-bit samples); bins of 4 + 5 + 5 + 5 bits hold count and channel sums;
  *   2. boxes over the non-empty bins (ascending bin id): the most populous splittable box is cut along the channel with the
- *      largest spread of bin means (ties: r, g, b, a) at the weighted median, until 256 boxes;
+ *      largest spread of bin means (ties: r, g, b, a) at the weighted median, until 256 boxes -- or, from two boxes on, until the
+ *      palette is good enough for the quality asked for (png_quality_table.h);
  *   3. palette = rounded mean of each box, sorted by (a, r, g, b), duplicates merged; every pixel takes the nearest entry
  *      (squared distance over the four channels; ties: the lower index).
  * Applied to truecolour images that still have more than 256 colours after the lossless reductions; everything else (grey,
@@ -468,7 +470,19 @@ static int box_axis(const qbin *bins, const int *ord, const qbox *bx, int *range
     *range = br;
     return best;
 }
-static int median_cut(const qbin *bins, int nbins, uint32_t *pal) {
+/* error of the palette entry box k would give: every bin mean against the rounded box mean */
+static uint64_t box_error(const qbin *bins, const int *ord, const qbox *bx) {
+    uint64_t sum[4] = {0, 0, 0, 0}, cnt = 0, err = 0;
+    for (int i = bx->lo; i < bx->hi; i++) { const qbin *b = bins + ord[i]; cnt += b->cnt; for (int c = 0; c < 4; c++) sum[c] += b->s[c]; }
+    for (int i = bx->lo; i < bx->hi; i++) {
+        const qbin *b = bins + ord[i];
+        uint64_t d2 = 0;
+        for (int c = 0; c < 4; c++) { const int64_t d = (int64_t)bin_mean(b, c) - (int64_t)((2 * sum[c] + cnt) / (2 * cnt)); d2 += (uint64_t)(d * d); }
+        err += d2 * b->cnt;
+    }
+    return err;
+}
+static int median_cut(const qbin *bins, int nbins, int quality, uint32_t *pal) {
     int *ord = (int *)malloc(sizeof(int) * (size_t)nbins);
     for (int i = 0; i < nbins; i++) ord[i] = i;
     qbox box[256];
@@ -476,7 +490,12 @@ static int median_cut(const qbin *bins, int nbins, uint32_t *pal) {
     box[0].lo = 0; box[0].hi = nbins; box[0].cnt = 0;
     for (int i = 0; i < nbins; i++) box[0].cnt += bins[i].cnt;
     uint8_t dead[256]; memset(dead, 0, sizeof dead);
+    const uint64_t pixels = box[0].cnt;
+    uint64_t berr[256], total_err;
+    berr[0] = total_err = box_error(bins, ord, &box[0]);
+    quality = quality < 0 ? 0 : quality > 100 ? 100 : quality;
     while (nbox < 256) {
+        if (nbox >= 2 && (quality == 0 || total_err * 1024 <= kQualityBound[quality] * pixels)) break;   /* good enough for this -q */
         int pick = -1;
         for (int k = 0; k < nbox; k++) if (!dead[k] && box[k].hi - box[k].lo > 1 && (pick < 0 || box[k].cnt > box[pick].cnt)) pick = k;
         if (pick < 0) break;
@@ -489,6 +508,9 @@ static int median_cut(const qbin *bins, int nbins, uint32_t *pal) {
         while (s < box[pick].hi - 1) { cum += bins[ord[s]].cnt; s++; if (2 * cum >= box[pick].cnt) break; }
         box[nbox].lo = s; box[nbox].hi = box[pick].hi; box[nbox].cnt = box[pick].cnt - cum;
         box[pick].hi = s; box[pick].cnt = cum;
+        total_err -= berr[pick];
+        berr[pick] = box_error(bins, ord, &box[pick]); berr[nbox] = box_error(bins, ord, &box[nbox]);
+        total_err += berr[pick] + berr[nbox];
         nbox++;
     }
     int n = 0;
@@ -506,7 +528,7 @@ static int median_cut(const qbin *bins, int nbins, uint32_t *pal) {
     return m;
 }
 /* truecolour (8 or 16 bit) with more than 256 colours -> an 8-bit indexed image; returns 16 when applied */
-static int quantize(cso_png *P) {
+static int quantize(cso_png *P, int quality) {
     if (P->no_reduce || (P->ctype != 2 && P->ctype != 6) || P->nplte) return 0;
     const int ch = P->channels, bps = P->depth / 8;
     const size_t npx = (size_t)P->width * P->height;
@@ -534,7 +556,7 @@ static int quantize(cso_png *P) {
     int nbins = 0;
     for (uint32_t i = 0; i < (1u << 19); i++) if (all[i].cnt) { all[nbins] = all[i]; all[nbins].id = i; nbins++; }
     uint32_t pal[256];
-    const int n = median_cut(all, nbins, pal);
+    const int n = median_cut(all, nbins, quality, pal);
     free(all);
     (void)npx;
     int ntr = 0;
@@ -573,7 +595,7 @@ static int quantize(cso_png *P) {
     P->chunks = nc; P->chunks_len += extra; P->idat_at += extra;
     return 16;
 }
-int cso_png_quantize(cso_png *P) { return quantize(P); }
+int cso_png_quantize(cso_png *P, int quality) { return quantize(P, quality); }
 
 /* ------------------------------------------------------------------------------------------------ row filters */
 static void filter_row(int ft, const uint8_t *cur, const uint8_t *up, size_t n, int bpp, uint8_t *dst) {
@@ -925,12 +947,12 @@ int cso_png_trials(int level, int *set) {
     memcpy(set, s, sizeof(int) * (size_t)n);
     return n;
 }
-static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata, int lossy, uint8_t **out, size_t *out_len, int *chosen) {
+static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata, int lossy, int quality, uint8_t **out, size_t *out_len, int *chosen) {
     cso_png *P = NULL;
     int rc = cso_png_decode(in, n, keep_metadata, &P);
     if (rc) return rc;
     cso_png_reduce(P);
-    if (lossy) quantize(P);
+    if (lossy) quantize(P, quality);
     size_t raw_len = (1 + P->rowbytes) * (size_t)P->height;
     uint8_t *filt = (uint8_t *)malloc(raw_len), *best = NULL;
     size_t best_len = 0;
@@ -963,11 +985,11 @@ static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata,
     return 0;
 }
 int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen) {
-    return png_recode(in, n, level, keep_metadata, 0, out, out_len, chosen);
+    return png_recode(in, n, level, keep_metadata, 0, 0, out, out_len, chosen);
 }
 /* `-q` on a PNG: the reductions, the quantiser, then the same filter trials and coder; the result is returned whatever its size */
-int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len) {
-    return png_recode(in, n, level, keep_metadata, 1, out, out_len, NULL);
+int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, int quality, uint8_t **out, size_t *out_len) {
+    return png_recode(in, n, level, keep_metadata, 1, quality, out, out_len, NULL);
 }
 
 /* ---- PNG -> WebP (caesium::convert_in_memory with a PNG source, /root/reference/src/compressor.rs:289-299): the decoded pixels as the

@@ -20,8 +20,8 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
 void cso_png_free(cso_png *p);
 int cso_png_scores(const cso_png *P, uint64_t *out);
 int cso_png_reduce(cso_png *P);   /* P2: returns a bit mask of what was applied (1: 16->8 bits, 2: alpha dropped, 4: colour->grey, 8: colour->palette, 32: grey depth) */
-int cso_png_quantize(cso_png *P);   /* lossy: truecolour with more than 256 colours -> indexed (median cut); returns 16 when applied */
-int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len);
+int cso_png_quantize(cso_png *P, int quality);   /* lossy: truecolour with more than 256 colours -> indexed (median cut); returns 16 when applied */
+int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, int quality, uint8_t **out, size_t *out_len);
 int cso_png_to_rgb(const cso_png *P, uint8_t *rgb);   /* width * height * 3 bytes; CSO_PNG_UNSUPPORTED for an image with transparency */
 int cso_png_to_webp(const uint8_t *in, size_t n, int quality, uint8_t **out, size_t *out_len);
 int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice);

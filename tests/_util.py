@@ -384,6 +384,6 @@ def oracle_png_to_jpeg(src, quality=80, width=0, height=0, subsampling=420, prog
     return O.pixels_to_jpeg(pix, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1), width, height)
 
 
-def oracle_png_lossy(src, level=3, keep_metadata=False):
+def oracle_png_lossy(src, level=3, keep_metadata=False, quality=80):
     from oracle import oracle as O
-    return O.png_lossy(src, level, keep_metadata)
+    return O.png_lossy(src, level, keep_metadata, quality)

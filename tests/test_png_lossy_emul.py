@@ -26,22 +26,37 @@ def lossy_cases(big=False):
     return cases
 
 
-def check_lossy(api, cases, level=2):
+def check_lossy(api, cases, level=2, quality=80):
     pkg = package()
-    outs = api.cs_batch_compress([c[1] for c in cases], pkg.default_parameters(png_optimize=False, png_optimization_level=level))
+    outs = api.cs_batch_compress([c[1] for c in cases], pkg.default_parameters(png_optimize=False, png_optimization_level=level, png_quality=quality))
+    floor = 30 if quality >= 80 else 12   # dB: what is asked of the result depends on what was asked of the quantiser
     for (name, src), out in zip(cases, outs):
         assert not isinstance(out, Exception), (name, out)
-        assert out == oracle_png_lossy(src, level), name
+        assert out == oracle_png_lossy(src, level, quality=quality), name
         a, b = PIL.open(io.BytesIO(src)), PIL.open(io.BytesIO(out))
         assert a.size == b.size
         if a.mode != "I;16":
             x, y = np.asarray(a.convert("RGBA")).astype(np.float64), np.asarray(b.convert("RGBA")).astype(np.float64)
             mse = ((x - y) ** 2).mean()
-            assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) > 30, name   # at most 256 colours, no dithering: still close
+            assert mse == 0 or 10 * np.log10(255.0 ** 2 / mse) > floor, name   # no dithering: still close
 
 
 def test_lossy_equals_oracle(api):
     check_lossy(api, lossy_cases())
+
+
+def test_quality_sets_the_palette_size(api):
+    """-q is imagequant's quality: the fewest colours whose error is within the bound of that quality; lower -q, fewer colours, smaller file"""
+    cases = [c for c in lossy_cases() if c[0] in ("RGB_200x150_3chunks", "RGBA_soft_alpha", "RGB_97x61")]
+    for q in (0, 10, 50, 100):
+        check_lossy(api, cases, level=1, quality=q)
+    src = dict(cases)["RGB_200x150_3chunks"]
+    sizes, colours = [], []
+    for q in (0, 10, 40, 70, 90, 100):
+        out = api.cs_batch_compress([src], package().default_parameters(png_optimize=False, png_optimization_level=1, png_quality=q))[0]
+        sizes.append(len(out)); colours.append(len(PIL.open(io.BytesIO(out)).getcolors(1 << 20)))
+    assert colours == sorted(colours) and colours[0] == 2 and colours[-1] > 200 and colours[1] < colours[4]
+    assert sizes[0] < sizes[2] < sizes[-1]
 
 
 def test_quantised_files_are_indexed(api):

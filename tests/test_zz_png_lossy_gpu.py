@@ -17,6 +17,7 @@ def api():
 def test_lossy_equals_oracle(api):
     check_lossy(api, lossy_cases(big=True))
     check_lossy(api, lossy_cases()[:4], level=0)
+    check_lossy(api, lossy_cases()[:6], level=1, quality=30)   # fewer colours: the cut stops at the bound of that quality (host decision)
 
 
 def test_cli_lossy_png_on_device(tmp_path):
