@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/caesium_hip.h"
@@ -140,8 +141,82 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
 // and re-codes with each file's current quality, and files leave the search as they finish.
 struct SizeWalk { int quality = 80, last_less = 1, last_high = 101, tries = 0; bool done = false; };
 
+// PNG files under --max-size: the same walk over png.quality (the quantiser's palette size follows it).  Every try is a full run of the
+// PNG pipeline for the files still searching, grouped by the quality they are at (the first round is one batch, later rounds a few);
+// under png.optimize the quality does not apply and one try is all there is
+static int png_compress_to_size(const CByteArray *inputs, size_t count, const CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
+                                CByteArray *outputs, CCSResult *results) {
+    const size_t tolerance = max_output_size * 2 / 100;
+    int failed_total = 0;
+    std::vector<SizeWalk> walk(count);
+    for (;;) {   // rounds: at most ten per file (SizeWalk::tries)
+        std::map<int, std::vector<size_t>> by_quality;
+        for (size_t i = 0; i < count; i++) if (!walk[i].done) by_quality[walk[i].quality].push_back(i);
+        if (by_quality.empty()) break;
+        for (auto &g : by_quality) {
+            const std::vector<size_t> &idx = g.second;
+            std::vector<CByteArray> in(idx.size()), cur(idx.size());
+            std::vector<CCSResult> res(idx.size());
+            for (size_t k = 0; k < idx.size(); k++) in[k] = inputs[idx[k]];
+            CCSParameters q = *p;
+            q.png_quality = uint32_t(g.first);
+            png_batch_compress(in.data(), in.size(), &q, device, cur.data(), res.data());
+            for (size_t k = 0; k < idx.size(); k++) {
+                const size_t i = idx[k];
+                SizeWalk &w = walk[i];
+                auto finish = [&](bool keep_file, int code, const char *msg) {
+                    w.done = true;
+                    if (keep_file) outputs[i] = cur[k]; else cs_free_bytes(&cur[k]);
+                    cs_free_result(&results[i]);
+                    if (code) { results[i] = make_result(code, msg); cs_free_result(&res[k]); failed_total++; }
+                    else results[i] = res[k];
+                };
+                if (!res[k].success) { w.done = true; cs_free_result(&results[i]); results[i] = res[k]; failed_total++; continue; }
+                if (p->png_optimize) { finish(true, 0, nullptr); continue; }
+                const size_t len = cur[k].length;
+                if (len <= max_output_size && max_output_size - len < tolerance) { finish(true, 0, nullptr); continue; }
+                if (len <= max_output_size) w.last_less = w.quality; else w.last_high = w.quality;
+                int nq = (w.last_high + w.last_less) / 2;
+                nq = nq < 1 ? 1 : (nq > 100 ? 100 : nq);
+                if (nq == w.quality) {
+                    if (nq == 1 && w.last_high == 1 && !return_smallest) finish(false, CS_ERR_TOO_BIG, "cannot compress to the requested size");
+                    else finish(true, 0, nullptr);
+                    continue;
+                }
+                if (++w.tries >= 10) { finish(false, CS_ERR_TOO_BIG, "max tries reached while compressing to size"); continue; }
+                w.quality = nq;
+                cs_free_bytes(&cur[k]); cs_free_result(&res[k]);
+            }
+        }
+    }
+    return failed_total;
+}
+
+static int jpeg_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
+                                       CByteArray *outputs, CCSResult *results);
 int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
                               CByteArray *outputs, CCSResult *results) {
+    std::vector<size_t> png, other;
+    for (size_t i = 0; i < count; i++) (sniff(inputs[i].data, inputs[i].length) == CS_TYPE_PNG ? png : other).push_back(i);
+    if (png.empty()) return jpeg_batch_compress_to_size(inputs, count, p, max_output_size, return_smallest, device, outputs, results);
+    int failed = 0;
+    auto run = [&](const std::vector<size_t> &idx, bool is_png) {
+        if (idx.empty()) return;
+        std::vector<CByteArray> in(idx.size()), out(idx.size());
+        std::vector<CCSResult> res(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) { in[k] = inputs[idx[k]]; out[k].data = nullptr; out[k].length = 0; res[k] = make_result(0, nullptr); }
+        CCSParameters q = *p;
+        failed += is_png ? png_compress_to_size(in.data(), in.size(), &q, max_output_size, return_smallest, device, out.data(), res.data())
+                         : jpeg_batch_compress_to_size(in.data(), in.size(), &q, max_output_size, return_smallest, device, out.data(), res.data());
+        if (!is_png) *p = q;   // the JPEG walk leaves its last quality in the caller's parameters, as the reference's &mut does
+        for (size_t k = 0; k < idx.size(); k++) { outputs[idx[k]] = out[k]; results[idx[k]] = res[k]; }
+    };
+    run(other, false);
+    run(png, true);
+    return failed;
+}
+static int jpeg_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
+                                       CByteArray *outputs, CCSResult *results) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; results[i] = make_result(0, nullptr); }
     const size_t tolerance = max_output_size * 2 / 100;
     int failed_total = 0;

@@ -404,8 +404,9 @@ def test_emul_batch_order_and_errors(api):
     assert outs[0] == oracle_lossy(good[0]) and outs[4] == oracle_lossy(good[3])
 
 
-def reference_size_walk(src, max_size, return_smallest=True):
-    """libcaesium's bisection restated: -> (quality sequence, bytes or None)"""
+def reference_size_walk(src, max_size, return_smallest=True, encode=None):
+    """libcaesium's bisection restated: -> (quality sequence, bytes or None).  encode(src, q): the one-try engine (JPEG lossy by default)"""
+    oracle_lossy = encode or globals()["oracle_lossy"]
     tol = max_size * 2 // 100
     q, less, high, seq = 80, 1, 101, []
     for _ in range(10):

@@ -59,6 +59,37 @@ def test_quality_sets_the_palette_size(api):
     assert sizes[0] < sizes[2] < sizes[-1]
 
 
+def test_max_size_walks_the_quality(api):
+    """--max-size on PNG files: libcaesium's bisection over png.quality, every try a run of the lossy pipeline; mixed with JPEGs in one call"""
+    from gen_synth import synth_jpeg
+    from test_pipeline_emul import reference_size_walk
+    pkg = package()
+    cases = dict(lossy_cases())
+    a, b = cases["RGB_200x150_3chunks"], cases["RGBA_soft_alpha"]
+
+    def enc(src, q):
+        return oracle_png_lossy(src, 1, quality=q)
+    sizes = {q: len(enc(a, q)) for q in (1, 30, 80)}
+    assert sizes[1] < sizes[30] < sizes[80]
+    jpg = synth_jpeg(12, 160, 120, texture=20)
+    for target in (sizes[30] + 40, sizes[80] * 2, sizes[1] + 10):
+        p = pkg.default_parameters(png_optimization_level=1)
+        outs = api.batch_compress_to_size([a, jpg, b, b"junk"], p, target)
+        assert outs[0] == reference_size_walk(a, target, encode=enc)[1]
+        assert outs[2] == reference_size_walk(b, target, encode=enc)[1]
+        assert outs[1] == reference_size_walk(jpg, target)[1] and outs[3].code == 10200
+    seq, _ = reference_size_walk(a, sizes[30] + 40, encode=enc)
+    assert seq[:2] == [80, 40] and len(seq) >= 3
+    # unreachable target: the q = 1 file comes back, or the error when the caller does not want it
+    assert api.compress_to_size_in_memory(a, pkg.default_parameters(png_optimization_level=1), 50, True) == enc(a, 1)
+    with pytest.raises(pkg.CaesiumError) as e:
+        api.compress_to_size_in_memory(a, pkg.default_parameters(png_optimization_level=1), 50, False)
+    assert e.value.code == 10500
+    # png.optimize: one lossless try, whatever the target
+    from _util import oracle_png
+    assert api.compress_to_size_in_memory(a, pkg.default_parameters(png_optimize=True, png_optimization_level=1), 50, True) == oracle_png(a, 1)
+
+
 def test_quantised_files_are_indexed(api):
     pkg = package()
     src = dict(lossy_cases())["RGB_200x150_3chunks"]
