@@ -340,6 +340,12 @@ def lossy_png_step(binary, tmp_path):
     (d / "a.png").write_bytes(png)
     j = json.loads(run_cli(binary, "-q", 80, "-o", tmp_path / "mq", "--json", d / "a.png").stdout)
     assert j["files"][0]["status"] == "success" and open(j["files"][0]["output_path"], "rb").read() == oracle_png_lossy(png)
+    # --max-size on a PNG: the bisection over png.quality
+    from test_pipeline_emul import reference_size_walk
+    target = len(oracle_png_lossy(png, quality=30)) + 30
+    j = json.loads(run_cli(binary, "--max-size", target, "-o", tmp_path / "mq2", "--json", d / "a.png").stdout)
+    want = reference_size_walk(png, target, encode=lambda s, q: oracle_png_lossy(s, quality=q))[1]
+    assert j["files"][0]["status"] == "success" and open(j["files"][0]["output_path"], "rb").read() == want and len(want) <= target
 
 
 def png_to_webp_step(binary, tmp_path):

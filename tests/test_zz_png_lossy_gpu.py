@@ -20,6 +20,11 @@ def test_lossy_equals_oracle(api):
     check_lossy(api, lossy_cases()[:6], level=1, quality=30)   # fewer colours: the cut stops at the bound of that quality (host decision)
 
 
+def test_max_size_on_png_files(api):
+    from test_png_lossy_emul import test_max_size_walks_the_quality
+    test_max_size_walks_the_quality(api)
+
+
 def test_cli_lossy_png_on_device(tmp_path):
     import os
 
