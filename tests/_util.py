@@ -197,7 +197,7 @@ def oracle_jpeg_to_webp(src, quality=80, width=0, height=0):
     return O.webp_encode_rgb(rgb, quality)
 
 
-def oracle_jpeg_to_png(src, lossless, level=3, width=0, height=0):
+def oracle_jpeg_to_png(src, lossless, level=3, width=0, height=0, quality=80):
     """the oracle's statement of convert_in_memory(JPEG -> PNG): libjpeg decode to RGB (oracle), image-rs Lanczos3 when a size is given
     (oracle), any valid PNG file of those pixels, then the PNG path over that file (oracle/png_oracle.c) -- whose result depends on the
     pixels only, not on how the intermediate file was coded"""
@@ -226,7 +226,7 @@ def oracle_jpeg_to_png(src, lossless, level=3, width=0, height=0):
         out, chosen = O.png_optimize(png, level)   # the intermediate is padded (raw_png): the "not smaller" rule never keeps it
         assert chosen >= 0
         return out
-    return O.png_lossy(png, level)
+    return O.png_lossy(png, level, False, quality)
 
 
 def raw_png(pixels, ctype, depth=8, level=0, pad=True):
@@ -324,7 +324,7 @@ def png_resized_pixels(P, width, height):
     return out, ctype, 8
 
 
-def oracle_png_resized(src, lossless, level=3, width=0, height=0):
+def oracle_png_resized(src, lossless, level=3, width=0, height=0, quality=80):
     """the oracle's statement of compress_in_memory on a PNG with a size: decode (oracle), image-rs Lanczos3 over the decoded samples
     (oracle; after png_expand8), a PNG file of the result, then the PNG path over that file.  16-bit images are resampled at 16 bits (with a tRNS chunk they raise: the
     device refuses them)"""
@@ -339,7 +339,7 @@ def oracle_png_resized(src, lossless, level=3, width=0, height=0):
         res, chosen = O.png_optimize(png, level)
         assert chosen >= 0
         return res
-    return O.png_lossy(png, level)
+    return O.png_lossy(png, level, False, quality)
 
 
 def oracle_png_to_webp(src, quality, width=0, height=0):

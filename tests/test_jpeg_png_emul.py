@@ -35,6 +35,12 @@ def test_lossless_target_equals_oracle(api):
 
 def test_quantising_target_equals_oracle(api):
     check(api, webp_cases(), False)
+    # -q reaches the quantiser of the target
+    cases = webp_cases()[:2]
+    p = package().default_parameters(png_optimize=False, png_optimization_level=1, png_quality=25)
+    outs = api.batch_convert([c[1] for c in cases], p, PNG)
+    assert outs == [oracle_jpeg_to_png(c[1], False, 1, quality=25) for c in cases]
+    assert all(len(o) < len(oracle_jpeg_to_png(c[1], False, 1)) for o, c in zip(outs, cases))
 
 
 def test_pixels_survive_a_lossless_target(api):
