@@ -30,6 +30,17 @@ JP.check(api, W.webp_cases(), True); JP.check(api, W.webp_cases()[:3], False, wi
 import test_png_resize_emul as PR, test_png_jpeg_emul as PJ
 PJ.test_every_png_format_converts_like_the_oracle(api); PJ.test_resize_in_front(api); PJ.test_mixed_batch_and_failures(api)
 PR.test_every_case_resizes_like_the_oracle_or_is_refused(api); PR.test_sizes_and_shapes(api); PR.test_mixed_batch_with_jpegs_and_damage(api)
+# damaged PNGs through the composed paths: device and oracle must agree on refusal or on the bytes
+blobs = T.damaged_pngs(77, 240)
+def agree(outs, want):
+    for b, o in zip(blobs, outs):
+        try: w = want(b)
+        except Exception: w = None
+        assert isinstance(o, Exception) if w is None else o == w
+agree(api.batch_convert(blobs, pkg.default_parameters(jpeg_quality=70), 0), lambda b: _util.oracle_png_to_jpeg(b, 70))
+agree(api.batch_convert(blobs, pkg.default_parameters(webp_quality=70, width=30), 3), lambda b: _util.oracle_png_to_webp(b, 70, 30, 0))
+agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimize=True, png_optimization_level=1, height=20)), lambda b: _util.oracle_png_resized(b, True, 1, 0, 20))
+agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimization_level=1, png_quality=20)), lambda b: _util.oracle_png_lossy(b, 1, quality=20))
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
