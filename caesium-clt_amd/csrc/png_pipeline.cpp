@@ -911,7 +911,7 @@ extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCS
         e.src_off = a->imgs[it.image].pix_off; e.dst_off = src_bytes;
         src_bytes += (uint64_t(it.width) * it.height * e.out_nc + 255) & ~uint64_t(255);
         max_h = std::max(max_h, it.height);
-        px.push_back(csp_pixels{reinterpret_cast<const uint8_t *>(uintptr_t(e.dst_off)), it.width, it.height, e.out_nc});   // offset for now
+        px.push_back(csp_pixels{nullptr, it.width, it.height, e.out_nc});   // the pointer is known once the buffer is
         ejobs.push_back(e); at.push_back(i);
     }
     if (px.empty()) return failed;
@@ -921,7 +921,7 @@ extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCS
     if (d_ejobs.upload(ejobs, st) || d_tables.upload(tables, st) || d_src.alloc(src_bytes + 256)) return fail_rest(CS_ERR_NO_DEVICE);
     launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG kernels failed"); return fail_rest(CS_ERR_NO_DEVICE); }
-    for (auto &s : px) s.device_pixels = d_src.p + uintptr_t(s.device_pixels);
+    for (size_t k = 0; k < px.size(); k++) px[k].device_pixels = d_src.p + ejobs[k].dst_off;
     csh_batch *jb = nullptr;
     rc = csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
     if (rc == 0) rc = csh_batch_run(jb, nullptr);
