@@ -65,15 +65,87 @@ def pmc_traffic(kernel, batch):
     return int(tot)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def pillow_proxy(src):
+    """libjpeg-turbo through Pillow doing the plain-profile job: decode without colour conversion, re-encode with the q80 table #3,
+    4:2:0, progressive, optimised Huffman (what tests/test_oracle_jpeg.py pins the oracle to)"""
+    import io
+
+    from PIL import Image
+    im = Image.open(io.BytesIO(src))
+    im.draft("YCbCr", im.size)
+    im.load()
+    b = io.BytesIO()
+    im.save(b, format="JPEG", qtables=[Q80_TABLE3, Q80_TABLE3], subsampling=2, progressive=True, optimize=True)
+    return b.getvalue()
+
+
+# mozjpeg base table #3 at libjpeg scale 40 (= -q 80), natural order (SURVEY.md 8c-1, pinned by samples/j0.JPG's DQT at scale 98)
+_BASE3 = [16, 16, 16, 18, 25, 37, 56, 85, 16, 17, 20, 27, 34, 40, 53, 75, 16, 20, 24, 31, 43, 62, 91, 135, 18, 27, 31, 40, 53, 74, 106, 156,
+          25, 34, 43, 53, 69, 94, 131, 189, 37, 40, 62, 74, 94, 124, 169, 238, 56, 53, 91, 106, 131, 169, 226, 311, 85, 75, 135, 156, 189, 238, 311, 418]
+Q80_TABLE3 = [max(1, min(32767, (v * 40 + 50) // 100)) for v in _BASE3]
+
+
+def _one_input(i):
+    from gen_synth import synth_jpeg
+    return synth_jpeg(i)
+
+
+def make_inputs(first, count):
+    """`count` distinct 1080p q92 4:2:0 baseline JPEGs (SURVEY 8d recipe, seeds first..), made on all host cores (~1.2 s of numpy each)"""
+    if count <= 4:
+        return [_one_input(first + i) for i in range(count)]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(count, os.cpu_count() or 1, 64)) as pool:
+        return pool.map(_one_input, range(first, first + count), chunksize=1)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* as
+    torch.distributed.run would set them), pass rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench ranks exited with {rcs}")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=2048, help="1080p files per rank per step (2048 x ~21 MB of device pools = 44 GB of the 288 GB)")
-    ap.add_argument("--unique", type=int, default=16, help="distinct synthetic images (cycled to --batch)")
-    ap.add_argument("--cpu-images", type=int, default=256, help="files timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic images per rank (cycled to --batch); generated on all host cores")
+    ap.add_argument("--cpu-images", type=int, default=128, help="files timed through the single-thread CPU oracle (rank 0, N=1); the all-core and Pillow lines scale from it")
+    ap.add_argument("--boundary-files", type=int, default=512, help="files of the cs_batch_compress (host buffers in, host buffers out) measurement; 0 = skip")
+    ap.add_argument("--no-extras", action="store_true", help="skip the boundary / CPU / other-config records (profiling runs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)   # python bench.py --gpus N by itself: one process per GPU, this process only relays rank 0's line
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +166,7 @@ def main():
         raise SystemExit("no HIP device: libcaesium_hip has no CPU path")
 
     # config 2 inputs: Pillow/libjpeg-turbo q92 4:2:0 baseline JPEGs of the SURVEY 8d synthetic images
-    uniq = [synth_jpeg(rank * args.unique + i) for i in range(args.unique)]
+    uniq = make_inputs(rank * args.unique, args.unique)
     blobs = [uniq[i % args.unique] for i in range(args.batch)]
     params = pkg.default_parameters(jpeg_quality=80)
     batch = api.batch(blobs, params, device=local)   # parse + upload: inputs now resident in HBM
@@ -138,8 +210,9 @@ def main():
             roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(ab)})
         else:
             roof.update({"achieved": None, "frac": None})
-        cpu = None
-        if world == 1 and args.cpu_images > 0:
+        cpu = cpu_all = cpu_pillow = boundary = None
+        extras = world == 1 and not args.no_extras
+        if extras and args.cpu_images > 0:
             n = args.cpu_images
             c0 = time.perf_counter()
             for i in range(n):
@@ -147,6 +220,32 @@ def main():
             cdt = time.perf_counter() - c0
             cpu = {"value": round(n * 2.0736 / cdt, 2), "unit": "MP/s", "cores": 1, "kind": "port",
                    "sample": f"{n} of the same 1080p files through oracle/jpeg_oracle.c (decode+IDCT+FDCT+quant+progressive optimal-Huffman), 1 thread, {cdt:.1f} s"}
+            # the same port on every host core (the reference's rayon par_iter shape), and the libjpeg-turbo proxy (Pillow: decode to YCbCr,
+            # re-encode q80 4:2:0 progressive + optimised tables -- the plain profile the oracle is pinned to) on every core
+            from concurrent.futures import ThreadPoolExecutor
+            cores = os.cpu_count() or 1
+            m = min(max(cores * 8, n), 16 * n)
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(lambda i: len(oracle_lossy(blobs[i % len(blobs)])), range(m)))   # ctypes releases the GIL inside the oracle
+            cdt = time.perf_counter() - c0
+            cpu_all = {"value": round(m * 2.0736 / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port", "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(lambda i: len(pillow_proxy(blobs[i % len(blobs)])), range(m)))
+            cdt = time.perf_counter() - c0
+            cpu_pillow = {"value": round(m * 2.0736 / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "libjpeg-turbo proxy (Pillow), not libcaesium",
+                          "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+        if extras and args.boundary_files > 0:
+            # the boundary itself: cs_batch_compress, host buffers in -> host buffers out (marker parse, pinned upload, kernels, download);
+            # PCIe and the host side are inside this number and never inside `value`
+            nb = min(args.boundary_files, len(blobs))
+            api.cs_batch_compress(blobs[:min(nb, 64)], params, device=local)     # warm the block caches as a long-running caller would have
+            tm = []
+            res = api.cs_batch_compress(blobs[:nb], params, device=local, timing=tm)
+            ok = sum(1 for r in res if isinstance(r, bytes))
+            boundary = {"entry": "cs_batch_compress", "files": nb, "ok": ok, "seconds": round(tm[0], 4), "files_per_s": round(nb / tm[0], 1),
+                        "value": round(nb * 2.0736 / tm[0], 1), "unit": "MP/s", "note": "host buffers in and out, one call, second call of the process"}
         out = {
             "metric": "megapixels/sec JPEG q=80 1920x1080 batch", "value": round(value, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
@@ -156,7 +255,8 @@ def main():
             "parity_spot_check": bool(parity),
             "device_ms_per_step": round(sum(tm.total_ms for tm in timings) / len(timings), 3),
             "kernel_ms": {names[i]: round(kms[i], 4) for i in range(len(names)) if names[i]},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow, "boundary": boundary,
+            "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
             "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},
         }
         print(json.dumps(out))

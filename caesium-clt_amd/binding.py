@@ -45,7 +45,7 @@ def library_path():
 
 
 EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory",
-           "cs_batch_compress", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
+           "cs_batch_compress", "cs_batch_extent", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_create_webp", "csp_batch_create_pixels", "csh_batch_create_pixels", "csh_batch_pixels", "csh_batch_create_from_pixels", "csp_png_to_jpeg", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
            "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert"]
@@ -62,6 +62,8 @@ def _declare(L):
     L.cs_convert_in_memory.argtypes = [C.c_char_p, C.c_size_t, P(CCSParameters), C.c_uint32, P(CByteArray)]
     L.cs_convert_in_memory.restype = CCSResult
     L.cs_batch_compress.argtypes = [P(CByteArray), C.c_size_t, P(CCSParameters), C.c_int, P(CByteArray), P(CCSResult)]
+    L.cs_batch_extent.argtypes = [P(CByteArray), C.c_size_t]
+    L.cs_batch_extent.restype = C.c_size_t
     L.cs_free_bytes.argtypes = [P(CByteArray)]
     L.cs_free_bytes.restype = None
     L.cs_free_result.argtypes = [P(CCSResult)]
@@ -297,6 +299,16 @@ class CaesiumHip:
     def kernel_names(self):
         return [self.L.csh_kernel_name(i).decode() for i in range(NKERNELS)]
 
+    def batch_extent(self, sizes_and_heads):
+        """cs_batch_extent over inputs described as (declared length, header bytes): the header bytes are what the probe reads; the
+        declared length may exceed them (the probe never reads past the header of a well-formed file)"""
+        n = len(sizes_and_heads)
+        keep = [C.create_string_buffer(h, len(h)) for _, h in sizes_and_heads]
+        ins = (CByteArray * n)()
+        for i, (length, _) in enumerate(sizes_and_heads):
+            ins[i].data = C.cast(keep[i], C.POINTER(C.c_uint8)); ins[i].length = length
+        return self.L.cs_batch_extent(ins, n)
+
     def device_count(self):
         return self.L.csh_device_count()
 
@@ -362,15 +374,20 @@ class CaesiumHip:
     def png_kernel_names(self):
         return [self.L.csp_kernel_name(i).decode() for i in range(16)]
 
-    def cs_batch_compress(self, blobs, params, device=0):
-        """the C entry point itself: mixed inputs, routed per file type"""
+    def cs_batch_compress(self, blobs, params, device=0, timing=None):
+        """the C entry point itself: mixed inputs, routed per file type.  timing: a list that receives the seconds spent inside the C call
+        (host buffers in -> host buffers out: parse, upload, kernels, download), without this wrapper's own copies"""
+        import time
         n = len(blobs)
         keep = [C.create_string_buffer(x, len(x)) for x in blobs]
         ins = (CByteArray * n)()
         for i, buf in enumerate(keep):
             ins[i].data = C.cast(buf, C.POINTER(C.c_uint8)); ins[i].length = len(blobs[i])
         outs = (CByteArray * n)(); res = (CCSResult * n)()
+        t0 = time.perf_counter()
         self.L.cs_batch_compress(ins, n, C.byref(params), device, outs, res)
+        if timing is not None:
+            timing.append(time.perf_counter() - t0)
         result = []
         for i in range(n):
             result.append(C.string_at(outs[i].data, outs[i].length) if res[i].success else CaesiumError(res[i].code, (res[i].error_message or b"").decode()))

@@ -107,7 +107,30 @@ std::string usage() {
            "  -h, --help  -V, --version\n";
 }
 
-bool parse_args(const std::vector<std::string> &a, Options &o, std::string &err) {
+// clap's short-option forms: clusters (-RS, -Rd), attached values (-q80, -q=80, -Oall, -o=dir), a value-taking flag inside a cluster
+// takes the rest of the token (-RSq80); a bare '-' and everything behind '--' are positionals
+static std::vector<std::string> expand_short_options(const std::vector<std::string> &in) {
+    std::vector<std::string> out;
+    for (size_t i = 0; i < in.size(); i++) {
+        const std::string &t = in[i];
+        if (t == "--") { out.insert(out.end(), in.begin() + i, in.end()); break; }
+        if (t.size() < 3 || t[0] != '-' || t[1] == '-') { out.push_back(t); continue; }
+        for (size_t k = 1; k < t.size(); k++) {
+            const char c = t[k];
+            out.push_back(std::string("-") + c);
+            if (c == 'q' || c == 'o' || c == 'O') {   // takes a value: the rest of the token is it
+                std::string rest = t.substr(k + 1);
+                if (!rest.empty() && rest[0] == '=') rest.erase(0, 1);
+                if (!rest.empty() || (k + 1 < t.size())) out.push_back(rest);
+                break;
+            }
+        }
+    }
+    return out;
+}
+
+bool parse_args(const std::vector<std::string> &args_in, Options &o, std::string &err) {
+    const std::vector<std::string> a = expand_short_options(args_in);
     bool verbose_set = false;
     auto need = [&](size_t &i, const std::string &flag, std::string &val) {
         size_t eq = a[i].find('=');
@@ -322,9 +345,9 @@ bool probe_dimensions(const std::vector<uint8_t> &b, bool keep_metadata, size_t 
                 bool le = t[0] == 'I';
                 if (tl >= 8 && (le || t[0] == 'M')) {
                     uint32_t ifd = rd32(t + 4, le);
-                    if (ifd + 2 <= tl) {
+                    if (uint64_t(ifd) + 2 <= tl) {   // 64-bit bounds: an offset near 2^32 must not wrap back into range
                         uint32_t cnt = rd16(t + ifd, le);
-                        for (uint32_t k = 0; k < cnt && ifd + 2 + 12 * (k + 1) <= tl; k++) {
+                        for (uint32_t k = 0; k < cnt && uint64_t(ifd) + 2 + 12ull * (k + 1) <= tl; k++) {
                             const uint8_t *e = t + ifd + 2 + 12 * k;
                             if (rd16(e, le) == 0x0112) orientation = int(rd16(e + 8, le));
                         }
@@ -554,8 +577,15 @@ int run(const Options &o) {
         std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;   // resize target -> job indices (the only per-file parameter)
         for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].engine) groups[{jobs[i].params.width, jobs[i].params.height}].push_back(i);
         std::vector<std::vector<size_t>> batches;
-        const size_t kBatch = 1024;
-        for (auto &g : groups) for (size_t k = 0; k < g.second.size(); k += kBatch) batches.emplace_back(g.second.begin() + k, g.second.begin() + std::min(k + kBatch, g.second.size()));
+        const size_t kBatch = 1024;   // and never more than one device batch takes by bytes / declared pixels (cs_batch_extent)
+        for (auto &g : groups) {
+            std::vector<CByteArray> gin(g.second.size());
+            for (size_t k = 0; k < gin.size(); k++) { gin[k].data = jobs[g.second[k]].data.data(); gin[k].length = jobs[g.second[k]].data.size(); }
+            for (size_t k = 0, n = 0; k < g.second.size(); k += n) {
+                n = std::max<size_t>(1, cs_batch_extent(gin.data() + k, std::min(kBatch, g.second.size() - k)));
+                batches.emplace_back(g.second.begin() + k, g.second.begin() + k + n);
+            }
+        }
         int ndev = std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
         // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being
         // parsed and uploaded (separate streams; the boundary call is thread-safe)

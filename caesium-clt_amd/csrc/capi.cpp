@@ -1,5 +1,6 @@
 // capi.cpp -- the libcaesium-shaped entry points on top of the device batch queue.
 // Reference semantics: /root/reference/src/compressor.rs:287-306 (call shapes), :411-446 (parameters).
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -28,11 +29,47 @@ static CCSResult make_result(int code, const char *msg) {
 // one device batch = at most CS_GROUP files: launch grids index (image, scan) pairs in gridDim.y (<= 65535), and a group
 // of 2048 1080p files already occupies ~40 GB of HBM and tens of thousands of workgroups per launch
 enum { CS_GROUP = 2048 };
+// declared pixel count of a JPEG / PNG (0 when the header does not say): what a file will occupy on the device is known before
+// anything is decoded
+static uint64_t declared_pixels(const uint8_t *d, size_t n) {
+    if (n >= 24 && !memcmp(d, "\x89PNG\r\n\x1a\n", 8)) {
+        const uint64_t w = (uint64_t(d[16]) << 24) | (d[17] << 16) | (d[18] << 8) | d[19], h = (uint64_t(d[20]) << 24) | (d[21] << 16) | (d[22] << 8) | d[23];
+        return w * h;
+    }
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return 0;
+    for (size_t i = 2; i + 4 <= n;) {
+        if (d[i] != 0xFF) { i++; continue; }
+        const int m = d[i + 1];
+        if (m == 0xFF) { i++; continue; }
+        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) { i += 2; continue; }
+        const size_t L = (size_t(d[i + 2]) << 8) | d[i + 3];
+        if (L < 2 || i + 2 + L > n) break;
+        if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC && L >= 7) return (uint64_t((d[i + 5] << 8) | d[i + 6])) * uint64_t((d[i + 7] << 8) | d[i + 8]);
+        if (m == 0xDA) break;
+        i += 2 + L;
+    }
+    return 0;
+}
+size_t cs_batch_extent(const CByteArray *inputs, size_t count) {
+    const uint64_t byte_cap = uint64_t(2) << 30, pool_cap = uint64_t(96) << 30;
+    uint64_t bytes = 0, pools = 0;
+    size_t n = 0;
+    while (n < count && n < size_t(CS_GROUP)) {
+        const uint64_t len = inputs[n].length;
+        // ~25 bytes of pools per pixel on the JPEG path (coefficients both ways, planes, per-unit arrays), 4 x the file for the streams
+        const uint64_t est = declared_pixels(inputs[n].data, inputs[n].length) * 25 + 4 * len + (1u << 20);
+        if (n && (bytes + len > byte_cap || pools + est > pool_cap)) break;
+        bytes += len; pools += est; n++;
+    }
+    return n;
+}
 static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
     int failed_total = 0;
-    for (size_t g0 = 0; g0 < count; g0 += CS_GROUP) {
-        size_t n = count - g0 < size_t(CS_GROUP) ? count - g0 : size_t(CS_GROUP);
+    size_t limit = CS_GROUP;   // halved when a whole group fails for want of memory: one oversized neighbour must not fail 2047 others
+    for (size_t g0 = 0; g0 < count;) {
+        size_t n = cs_batch_extent(inputs + g0, count - g0);
+        if (n > limit) n = limit;
         csh_batch *b = nullptr;
         const bool trace = getenv("CSH_TRACE") != nullptr;   // host-side phase times of the boundary call, on stderr
         auto t0 = std::chrono::steady_clock::now();
@@ -41,9 +78,11 @@ static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCS
         if (rc == 0) rc = csh_batch_run(b, nullptr);
         auto t2 = std::chrono::steady_clock::now();
         if (rc != 0) {
-            for (size_t i = 0; i < n; i++) if (results) results[g0 + i] = make_result(rc, csh_last_error());
             csh_batch_destroy(b);
+            if (n > 1 && (rc == CS_ERR_NO_DEVICE || rc == CS_ERR_POOL_OVERFLOW) && csh_device_count() > device) { limit = (n + 1) / 2; continue; }   // same files again, in smaller groups
+            for (size_t i = 0; i < n; i++) if (results) results[g0 + i] = make_result(rc, csh_last_error());
             failed_total += int(n);
+            g0 += n;
             continue;
         }
         int failed = csh_batch_fetch(b, outputs + g0, results ? results + g0 : nullptr);
@@ -55,6 +94,7 @@ static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCS
                     ms(t3, std::chrono::steady_clock::now()));
         }
         failed_total += failed < 0 ? int(n) : failed;
+        g0 += n;
     }
     return failed_total;
 }
@@ -220,8 +260,8 @@ static int jpeg_batch_compress_to_size(const CByteArray *inputs, size_t count, C
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; results[i] = make_result(0, nullptr); }
     const size_t tolerance = max_output_size * 2 / 100;
     int failed_total = 0;
-    for (size_t g0 = 0; g0 < count; g0 += CS_GROUP) {
-        const size_t n = count - g0 < size_t(CS_GROUP) ? count - g0 : size_t(CS_GROUP);
+    for (size_t g0 = 0, n = 0; g0 < count; g0 += n) {
+        n = cs_batch_extent(inputs + g0, count - g0);
         p->jpeg_quality = p->png_quality = p->webp_quality = 80;
         csh_batch *b = nullptr;
         int rc = csh_batch_create(inputs + g0, n, p, device, &b);
@@ -358,11 +398,12 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
         if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
-    for (size_t g0 = 0; g0 < ok.size(); g0 += 1024) {
-        const size_t n = ok.size() - g0 < 1024 ? ok.size() - g0 : 1024;
-        std::vector<CByteArray> in(n), out(n);
+    std::vector<CByteArray> ok_in(ok.size());
+    for (size_t k = 0; k < ok.size(); k++) ok_in[k] = inputs[ok[k]];
+    for (size_t g0 = 0, n = 0; g0 < ok.size(); g0 += n) {
+        n = cs_batch_extent(ok_in.data() + g0, std::min<size_t>(ok.size() - g0, 1024));
+        std::vector<CByteArray> in(ok_in.begin() + g0, ok_in.begin() + g0 + n), out(n);
         std::vector<CCSResult> res(n);
-        for (size_t k = 0; k < n; k++) in[k] = inputs[ok[g0 + k]];
         csh_batch *b = nullptr;
         int rc = csh_batch_create_webp(in.data(), n, p, device, &b);
         if (rc == 0) rc = csh_batch_run(b, nullptr);

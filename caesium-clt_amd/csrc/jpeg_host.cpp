@@ -124,6 +124,7 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
             break;
         case 0xDA: {
             if (!have_sof) BAD(CS_ERR_BAD_JPEG, "SOS before SOF");
+            if (sl < 6) BAD(CS_ERR_BAD_JPEG, "malformed SOS");   // before s[0] is read: a two-byte segment at the very end of the file has no body
             int ns = s[0];
             if (ns < 1 || ns > 4 || sl < size_t(1 + 2 * ns + 3)) BAD(CS_ERR_BAD_JPEG, "malformed SOS");
             JScan sc;

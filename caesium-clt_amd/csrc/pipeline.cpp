@@ -319,13 +319,16 @@ static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
         bool rgb_ids = in.comp[0].id == 'R' && in.comp[1].id == 'G' && in.comp[2].id == 'B';
         if (in.adobe_transform == 0 || rgb_ids) { it.msg = "RGB-colourspace JPEG not on the device path yet"; return CS_ERR_JPEG_FEATURE; }
     }
+    // one image's planes, tiles and unit arrays are indexed with 32 bits and take ~25 bytes per pixel of HBM: a header that declares
+    // more than 2^28 pixels (16384 x 16384) fails here, by itself, instead of sizing the whole batch's pools
+    if (uint64_t(in.width) * uint64_t(in.height) > (1ull << 28)) { it.msg = "image dimensions too large for the device path"; return CS_ERR_JPEG_FEATURE; }
     it.out = JpegInfo();
     JpegInfo &o = it.out;
     o.width = in.width; o.height = in.height; o.ncomp = in.ncomp;
     if (p.width || p.height) {
         if (lossless) { it.msg = "resize + lossless transcode not on the device path"; return CS_ERR_UNSUPPORTED; }
         csh_compute_dimensions(in.width, in.height, int(p.width), int(p.height), o.width, o.height);
-        if (o.width > 65500 || o.height > 65500) { it.msg = "resize target too large for JPEG"; return CS_ERR_JPEG_FEATURE; }
+        if (o.width > 65500 || o.height > 65500 || uint64_t(o.width) * uint64_t(o.height) > (1ull << 28)) { it.msg = "resize target too large for JPEG"; return CS_ERR_JPEG_FEATURE; }
     }
     if (lossless) {
         for (int c = 0; c < in.ncomp; c++) o.comp[c] = in.comp[c];
@@ -414,6 +417,9 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     {
         size_t total = 0;
         for (size_t n = 0; n < count; n++) total += inputs[n].length;
+        // DecScan / ParScan address the pool with 32 bits (types.h): a group whose entropy data (plus the per-restart-interval copies)
+        // could pass 4 GiB is refused as a whole -- cs_batch_extent() sizes groups well below this, so only a direct caller sees it
+        if (total + total / 16 + (64u << 10) >= 0xF0000000ull) { csh_set_error("csh_batch_create: more than 3.75 GiB of input in one device batch (cs_batch_extent sizes groups)"); return CS_ERR_POOL_OVERFLOW; }
         if (!b->bits_pool.reserve(total + total / 16 + (64u << 10))) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
     }
     for (size_t n = 0; n < count; n++) {
@@ -658,9 +664,9 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                         plane_off = (plane_off + 63u) & ~uint64_t(63);
                     }
                     im.oplane_off[c] = oplane_off;
-                    uint32_t osz = uint32_t(im.out[c].real_bw * 8 * im.out[c].real_bh * 8);
+                    const uint64_t osz = uint64_t(im.out[c].real_bw) * 8 * uint64_t(im.out[c].real_bh) * 8;   // <= 2^28 + edge blocks (plan_item)
                     oplane_off = (oplane_off + osz + 63u) & ~uint64_t(63);
-                    b->max_quads = std::max(b->max_quads, osz / 4);
+                    b->max_quads = std::max(b->max_quads, uint32_t(osz / 4));
                 }
                 b->pwork.push_back(w);
             }

@@ -99,6 +99,11 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
 int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest,
                               int device, CByteArray *outputs, CCSResult *results);
 
+/* how many of the leading `count` inputs one device batch takes: at most 2048 files, 2 GiB of input bytes (scan offsets are 32-bit)
+   and ~96 GiB of estimated device pools (from each file's declared size: a header probe, no decode).  Always >= 1 when count >= 1.
+   cs_batch_* use it themselves; it is exported for callers that drive csh_batch_create directly (the CLI, bench.py) */
+size_t cs_batch_extent(const CByteArray *inputs, size_t count);
+
 void cs_free_bytes(CByteArray *b);
 void cs_free_result(CCSResult *r);
 

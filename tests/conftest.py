@@ -13,11 +13,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-REFERENCE_SAMPLES = "/root/reference/samples"
+# the reference's own sample files, copied under tests/golden/ so that they travel to the GPU box (tests/golden/reference_samples/README.md)
+REFERENCE_SAMPLES = os.path.join(ROOT, "tests", "golden", "reference_samples")
 
 
 @pytest.fixture(scope="session")
 def reference_samples():
-    if not os.path.isdir(REFERENCE_SAMPLES):
-        pytest.skip("/root/reference not present (GPU box)")
+    assert os.path.isdir(REFERENCE_SAMPLES), "tests/golden/reference_samples is part of the repository"
     return REFERENCE_SAMPLES

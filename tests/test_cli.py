@@ -58,6 +58,33 @@ def tree(tmp_path):
     return root, files
 
 
+def test_exif_ifd_offset_near_4gib_does_not_wrap(tmp_path):
+    """an APP1 whose IFD offset is 0xFFFFFFFE passed the 32-bit bounds check and read 4 GB past the buffer"""
+    src = synth_jpeg(7, 64, 48)
+    tiff = b"II*\x00" + (0xFFFFFFFE).to_bytes(4, "little") + b"\x00" * 16
+    app1 = b"\xff\xe1" + (2 + 6 + len(tiff)).to_bytes(2, "big") + b"Exif\x00\x00" + tiff
+    f = tmp_path / "wrap.jpg"
+    f.write_bytes(src[:2] + app1 + src[2:])
+    assert probe("dims", f, 1) == "64 48"
+
+
+# ------------------------------------------------------------------------------------------------ clap short-option forms
+def test_short_option_clusters_and_attached_values():
+    """clap accepts -RS, -Rd, -q80, -q=80, -Oall, -o=dir, -RSq 80 and a bare '-' positional; each parses to what
+    the spelled-out form gives"""
+    ref, _ = parsed("-q", "80", "-o", "out", "-R", "-S", "-d", "-O", "all", "x.jpg")
+    for form in (("-q80", "-oout", "-RSd", "-Oall", "x.jpg"), ("-q=80", "-o=out", "-RS", "-d", "-O=all", "x.jpg"),
+                 ("-RSdq", "80", "-o", "out", "-O", "all", "x.jpg"), ("-dRSq80", "-Oall", "-oout", "x.jpg")):
+        got, err = parsed(*form)
+        assert err is None and got == ref, (form, got, err)
+    got, err = parsed("--lossless", "-o", "out", "-eQ", "-")
+    assert err is None and got["exif"] == "1" and got["quiet"] == "1" and got["files"] == "1"
+    _, err = parsed("-q80", "-oout", "-RZ", "x.jpg")
+    assert err == "unexpected argument '-Z' found"
+    got, err = parsed("-q", "80", "-o", "out", "--", "-RS")     # behind '--' everything is a file
+    assert err is None and got["recursive"] == "0" and got["files"] == "1"
+
+
 # ------------------------------------------------------------------------------------------------ validators
 def test_validators_max_size():
     want = {"10000": 10000, "1000000": 1000000, "1KB": 1000, "1KiB": 1024, "1MB": 1_000_000, "1MiB": 1_048_576, "0.3GB": 300_000_000, "0.5GiB": 536_870_912}

@@ -404,6 +404,36 @@ def test_emul_batch_order_and_errors(api):
     assert outs[0] == oracle_lossy(good[0]) and outs[4] == oracle_lossy(good[3])
 
 
+def _with_declared_size(src, w, h):
+    """the same JPEG with another size in its SOF0"""
+    i = src.index(b"\xff\xc0")
+    return src[:i + 5] + bytes([h >> 8, h & 255, w >> 8, w & 255]) + src[i + 9:]
+
+
+def test_emul_oversized_header_fails_alone(api):
+    """a ~1 KB file that declares 65535 x 65535 must fail by itself (it used to size -- and overflow -- the whole batch's
+    pools), and a two-byte SOS at the very end of a file must not be read past"""
+    good = [synth_jpeg(i, 96, 64, texture=15) for i in range(3)]
+    huge = _with_declared_size(good[0], 65535, 65535)
+    i = good[1].index(b"\xff\xda")
+    short_sos = good[1][:i] + b"\xff\xda\x00\x02"
+    outs = api.batch_compress([good[0], huge, good[1], short_sos, good[2]], params())
+    assert [isinstance(o, Exception) for o in outs] == [False, True, False, True, False]
+    assert "too large" in str(outs[1]) and "SOS" in str(outs[3])
+    assert outs[0] == oracle_lossy(good[0]) and outs[4] == oracle_lossy(good[2])
+
+
+def test_emul_batch_extent_splits_by_bytes_and_declared_pixels(api):
+    """scan offsets are 32-bit, so a device batch is cut by input bytes (2 GiB) and by the pools its headers announce (96 GiB),
+    not by file count alone"""
+    head = synth_jpeg(0, 64, 48)[:700]
+    assert api.batch_extent([(len(head), head)] * 5000) == 2048                      # count cap
+    assert api.batch_extent([(5 << 20, head)] * 1024) == 409                         # 2 GiB / 5 MiB, before the sum passes the cap
+    big = _with_declared_size(head, 16000, 16000)                                    # 256 MP -> ~6.4 GB of pools each
+    assert api.batch_extent([(len(big), big)] * 100) == 16
+    assert api.batch_extent([(3 << 30, head)] * 3) == 1                              # a single file always goes through, alone
+
+
 def reference_size_walk(src, max_size, return_smallest=True, encode=None):
     """libcaesium's bisection restated: -> (quality sequence, bytes or None).  encode(src, q): the one-try engine (JPEG lossy by default)"""
     oracle_lossy = encode or globals()["oracle_lossy"]

@@ -149,12 +149,11 @@ def test_1080p_full_size(api):
         assert out == oracle_lossy(src)
 
 
-def test_reference_fixture_lossless_if_present(api):
-    """BASELINE config 1 (samples/j0.JPG --lossless): only where /root/reference exists."""
-    p = "/root/reference/samples/j0.JPG"
-    if not os.path.exists(p):
-        pytest.skip("/root/reference not present on the GPU box")
-    src = open(p, "rb").read()
+@pytest.mark.parametrize("rel", ["j0.JPG", "level_1_0/j1.jpg"])
+def test_reference_fixture_lossless(api, reference_samples, rel):
+    """BASELINE configs[0] (samples/j0.JPG --lossless) and the reference's other JPEG sample through the HIP path: both are progressive
+    inputs (k_decode_prog), 2000x3000 and 1600x1200-class frames; device == oracle byte for byte (the fixtures travel in tests/golden)."""
+    src = open(os.path.join(reference_samples, rel), "rb").read()
     assert api.compress_in_memory(src, params(jpeg_optimize=True)) == oracle_lossless(src)
 
 

@@ -5,11 +5,7 @@ import pytest
 from _util import oracle_png_resized, package, product_api
 
 # a wedged kernel must end the run, not hold the box (these files are last, so ending the process loses nothing after them)
-pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread"),
-              # bit-exact on the emulation build; written after the round's GPU minutes were spent, so its first device run is the driver's.
-              # Non-strict: a pass shows as XPASS, a mismatch as XFAIL with the diff, and neither hides the suites that have run before.
-              # Remove this mark with the first green device run.
-              pytest.mark.xfail(strict=False, reason="first device run pending (validated on the emulation build only)")]
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]   # green on the MI355X since round 1 (GPUTEST_r01)
 
 
 @pytest.fixture(scope="module")
