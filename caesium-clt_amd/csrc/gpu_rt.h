@@ -29,6 +29,10 @@
 // (never `return`: every lane must reach every barrier).  The emulation runs phase p for ALL lanes of a workgroup
 // before phase p+1, which is exactly the ordering the barrier gives.
 #define CSH_SHARED __shared__
+// per-lane state that lives across the phases of a phased kernel: plain registers here (the phase loop is one function body); the
+// emulation re-enters the kernel once per phase and lane, so there it is a per-thread array indexed by the lane.  Declare it in front
+// of CSH_PHASE_LOOP.
+#define CSH_PERSIST(T, name, N) T name[N]
 #define CSH_PHASE_LOOP(NPH) for (int phase = 0; phase < (NPH); ((phase + 1 < (NPH)) ? __syncthreads() : (void)0), phase++)
 #define CSH_LAUNCH_PHASED(kern, nph, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 #else
@@ -67,6 +71,7 @@ static inline void csh_emul_launch(F kern, dim3 grid, dim3 block, A... args) {
 }
 #define CSH_LAUNCH(kern, grid, block, stream, ...) csh_emul_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
 #define CSH_SHARED static thread_local   // one copy per host thread: the emulated kernels of concurrent batches must not share "LDS"
+#define CSH_PERSIST(T, name, N) static thread_local T name##_lanes_[1024][N]; T (&name)[N] = name##_lanes_[threadIdx.x]
 extern thread_local int csh_emul_phase;
 #define CSH_PHASE_LOOP(NPH) for (int phase = csh_emul_phase, once_ = 1; once_; once_ = 0)
 template <class F, class... A>

@@ -39,7 +39,7 @@ __global__ void k_scan_sizes(AsmCtx a) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.nwork) return;
     ScanWork &w = a.work[j];
-    uint64_t bits = a.unit_off[w.unit_base + w.nunits] - a.unit_off[w.unit_base];
+    uint64_t bits = a.chunk_off[w.first_chunk + (w.nunits + 255) / 256] - a.chunk_off[w.first_chunk];
     uint64_t bytes = (bits + 7) >> 3;
     w.raw_bytes = uint32_t(bytes);
     a.scan_pad_bytes[j] = uint32_t(((bytes + 63) & ~uint64_t(63)) + 64);  // +64: the packer may touch one word past the end

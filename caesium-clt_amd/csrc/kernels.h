@@ -55,36 +55,42 @@ void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blo
 void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, int nwork, const ResizeTap *taps, const float *weights,
                    uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst);
 
-// ---- phases 2-6: entropy encode (k_entropy.hip)
-void launch_masks(hipStream_t st, const int16_t *coef, uint64_t *masks, uint32_t first_tile, uint32_t ntiles);
-
+// ---- phases 2-5: entropy encode (k_entropy.hip)
+// tokens -> runs -> tables -> chunk sizes -> (scan) -> pack.  A token is one u32 (k_entropy.hip); the tokens of one (scan, 256-unit
+// chunk) are contiguous in the token pool, unit after unit.
 struct EncCtx {  // device pointers + sizes every entropy kernel needs
     const ImgDesc *imgs;
-    const EncScan *script;     // output script (CSH_MAX_SCANS)
+    const EncScan *script;     // output scripts
     const ScanWork *work;      // [nwork]
     int nwork;
-    uint32_t max_units;        // max nunits over work items
-    const uint32_t *chunk_work; // per 256-unit chunk: its work item (a flat grid: no workgroup is launched for nothing)
-    uint32_t nchunks;
-    const int16_t *coef;       // re-quantised coefficients (tiles)
-    const uint64_t *masks;     // [tile][CSH_MASK_PLANES][64]
+    const EChunk *echunks;     // the token kernel's grid
+    uint32_t nechunks;
+    const uint32_t *slot_work; // per slot (work item, 256-unit chunk): its work item -- the grid of the per-scan kernels
+    uint32_t nslots;
+    const int16_t *coef;       // coefficients to code (tiles)
     uint64_t *sym_bits;        // per AC scan: bit b set iff block b emits >=1 Huffman symbol in this scan
     uint64_t *eob_bits;        // per AC scan: bit b set iff block b ends with a pending EOB
     uint8_t *tail;             // per unit: # of correction bits left over at the end of the block (refine scans)
-    uint16_t *eobrun;          // per unit: EOBRUN value this block must emit after its symbols (0 = none)
+    uint16_t *eobrun;          // per unit: EOBRUN value this block must emit at its EOB token (0 = none)
     uint32_t *long_runs, *long_cnt;   // runs longer than 512 blocks: (work item, first block) pairs for k_ac_runs_long
-    uint32_t *unit_bits;       // per unit: size in bits of everything the unit emits
-    uint64_t *unit_off;        // exclusive scan of unit_bits over the whole batch
+    uint16_t *unit_ntok;       // per unit: number of tokens
+    uint32_t *tokens;          // token pool
+    uint64_t tok_cap;          // its capacity in tokens
+    unsigned long long *tok_cursor;   // [1] bump allocator of the pool
+    uint64_t *tok_off;         // per slot: first token
+    uint32_t *chunk_ntok;      // per slot: number of tokens
+    uint32_t *chunk_bits;      // per slot: size in bits of everything the chunk emits
+    const uint64_t *chunk_off; // exclusive scan of chunk_bits over the whole batch
     DevEncTable *tables;       // [ntables]
     uint32_t *raw;             // unstuffed scan bytes as big-endian-logical u32 words, zero-initialised
     uint64_t raw_words;        // capacity of raw in u32 words
     uint32_t *status;          // per image
+    uint32_t *overflow;        // [4]: [1] = the token pool was too small
 };
-void launch_ac_flags(hipStream_t st, const EncCtx &c);
+void launch_tokens(hipStream_t st, const EncCtx &c);
 void launch_ac_runs(hipStream_t st, const EncCtx &c);
-void launch_stats(hipStream_t st, const EncCtx &c);
 void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables);
-void launch_sizes(hipStream_t st, const EncCtx &c);
+void launch_chunk_sizes(hipStream_t st, const EncCtx &c);
 void launch_pack(hipStream_t st, const EncCtx &c);
 
 // generic device primitive: out[i] = sum_{j<i} in[j] for i in [0, n]  (n+1 outputs; in[] has n entries)
@@ -98,7 +104,7 @@ struct AsmCtx {
     ScanWork *work;               // raw_off / raw_bytes / out_off / hdr_bytes are filled in here
     int nwork, nimg, scans_per_image;
     const DevEncTable *tables;
-    const uint64_t *unit_off;     // exclusive scan of unit_bits (+ trailing total)
+    const uint64_t *chunk_off;    // exclusive scan of the chunks' bit sizes (+ trailing total)
     uint32_t *scan_pad_bytes;     // [nwork] raw bytes per scan rounded up to 64 (+64 slack)
     uint64_t *scan_raw_off;       // [nwork+1] exclusive scan of scan_pad_bytes
     const uint32_t *raw;          // packed bits, big-endian-logical u32 words

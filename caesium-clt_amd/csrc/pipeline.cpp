@@ -100,7 +100,9 @@ struct csh_batch {
     uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
-    std::vector<uint32_t> chunk_work;
+    std::vector<uint32_t> slot_work;      // per (work item, 256-unit chunk) slot: its work item
+    std::vector<EChunk> echunks;          // the token kernel's workgroups
+    uint64_t tok_cap = 0;                 // token pool capacity (grows on overflow)
     PinnedBytes bits_pool;
     std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
@@ -132,7 +134,8 @@ struct csh_batch {
     DevBuf<uint8_t> d_rgb;
     DevBuf<EncScan> d_script;
     DevBuf<ScanWork> d_swork;
-    DevBuf<uint32_t> d_chunk_work;
+    DevBuf<uint32_t> d_slot_work;
+    DevBuf<EChunk> d_echunks;
     DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<csw::WebpImg> d_wimgs;
     DevBuf<uint8_t> d_wwork, d_wscratch;
@@ -140,9 +143,10 @@ struct csh_batch {
     DevBuf<uint8_t> d_wprobs, d_wupdate;
     uint32_t wmax_mbh = 0;
     DevBuf<int16_t> d_wlevels;
-    DevBuf<uint64_t> d_masks, d_symbits, d_eobbits, d_unit_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
-    DevBuf<uint16_t> d_eobrun;
-    DevBuf<uint32_t> d_long_runs, d_long_cnt, d_unit_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
+    DevBuf<uint64_t> d_symbits, d_eobbits, d_tok_off, d_chunk_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
+    DevBuf<unsigned long long> d_tok_cursor;
+    DevBuf<uint16_t> d_eobrun, d_unit_ntok;
+    DevBuf<uint32_t> d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
 
@@ -723,10 +727,20 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             w.table_base = uint32_t(b->ntables);
             b->ntables += e.ntables;
             b->max_units = std::max(b->max_units, w.nunits);
-            w.first_chunk = uint32_t(b->chunk_work.size());
-            b->chunk_work.insert(b->chunk_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
+            w.first_chunk = uint32_t(b->slot_work.size());
+            b->slot_work.insert(b->slot_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
+            if (e.Ss == 0 || e.sequential)   // DC scans and sequential-mode scans: one token workgroup per (scan, 256 units)
+                for (uint32_t j = 0; j < (w.nunits + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(b->swork.size()), 0, 1, j});
             b->swork.push_back(w);
         }
+        if (progressive)   // the AC scans of a component share one pass over its blocks
+            for (int c = 0; c < in.ncomp; c++) {
+                int nac = 0;
+                for (int s = 0; s < ns; s++) { const EncScan &e = b->script[sb + s]; if (e.Ss > 0 && e.comp[0] == c) { nac++; if (e.Al > (e.Ah ? 3 : 4)) nac = 99; } }
+                if (nac > CSH_TK_MAXSLOT) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "internal: output scan script outside what the token kernel carries"; }
+                const uint32_t nu = uint32_t(im.out[c].real_bw * im.out[c].real_bh);
+                if (nac) for (uint32_t j = 0; j < (nu + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(img_index), uint16_t(c), 0, j});
+            }
         if (b->total_units > 0xFFFFFFF0ull) { it.code = CS_ERR_POOL_OVERFLOW; it.msg = "batch too large"; }
 
         // frame header (host-built): SOI, JFIF, [metadata], DQT, SOF
@@ -766,6 +780,8 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     b->plane_bytes = plane_off;
     b->oplane_bytes = oplane_off;
     b->out_cap = b->raw_bytes_cap;
+    // token pool (k_entropy.hip): ordinary files need about half a token per byte of input; the pool grows on overflow like the others
+    b->tok_cap = b->bits_pool.size() + uint64_t(16384) * b->imgs.size() + 65536;
 
     // upload what never changes between runs
     hipStream_t st = b->stream;
@@ -774,7 +790,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         if (b->d_bits.alloc(b->bits_pool.size()) || (b->bits_pool.size() && hipMemcpyAsync(b->d_bits.p, b->bits_pool.p, b->bits_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
             b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || (b->use4 && b->d_phsets4.upload(b->phsets4, st)) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
-            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_chunk_work.upload(b->chunk_work, st) || b->d_hdr.upload(b->hdr_pool, st) ||
+            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_slot_work.upload(b->slot_work, st) || b->d_echunks.upload(b->echunks, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
             b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
@@ -787,9 +803,10 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 return CS_ERR_NO_DEVICE;
         }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
-            b->d_masks.alloc(size_t(b->ntiles) * CSH_MASK_TILE) || b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
-            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_bits.alloc(b->total_units + 1) ||
-            b->d_unit_off.alloc(b->total_units + 2) || b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
+            b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
+            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_ntok.alloc(b->total_units + 1) ||
+            b->d_tok_off.alloc(b->slot_work.size() + 1) || b->d_chunk_ntok.alloc(b->slot_work.size() + 1) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(2) ||
+            b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
             return CS_ERR_NO_DEVICE;
@@ -848,10 +865,10 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
-    "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "k_masks",
-    "k_ac_flags", "k_ac_runs", "k_stats", "k_gen_tables", "k_sizes", "scan_units", "scan_layout", "k_pack",
-    "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", "", "", ""};
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7};
+    "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "k_tokens",
+    "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack",
+    "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", "", "", "", "", ""};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 
 // the WebP tail of a run: RGB (resize branch) -> YUV 4:2:0 -> macroblocks -> tokens; files land in the batch's output pool at
@@ -922,10 +939,11 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     if (b->d_raw.n != raw_chunks * 16) {
         if (b->d_raw.alloc(raw_chunks * 16) || b->d_chunk_ff.alloc(raw_chunks + 1) || b->d_chunk_ffoff.alloc(raw_chunks + 2) || b->d_out.alloc(b->out_cap + 64))
             return -1;
-        size_t tmp = std::max(std::max(exclusive_scan_tmp_bytes(b->total_units), exclusive_scan_tmp_bytes(raw_chunks)),
+        size_t tmp = std::max(std::max(exclusive_scan_tmp_bytes(b->slot_work.size() + 1), exclusive_scan_tmp_bytes(raw_chunks)),
                               std::max(exclusive_scan_tmp_bytes(b->dc_total), exclusive_scan_tmp_bytes(b->bits_pool.size() / 64 + 1)));
         if (b->d_scan_tmp.alloc(tmp)) return -1;
     }
+    if (b->d_tokens.n < b->tok_cap && b->d_tokens.alloc(b->tok_cap)) return -1;
     hipEvent_t ev[CSH_NKERNELS + 1];
     for (auto &e : ev) CSH_CHECK(hipEventCreate(&e));
     int slot = 0;
@@ -1017,36 +1035,34 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     if (!b->lossless) launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
     MARK();
     }  // !requant_only
-    // ---- phase 2: masks, flags, EOB runs
+    // ---- phase 2: tokens (+ flags + statistics), EOB runs
     EncCtx c;
     memset(&c, 0, sizeof c);
-    c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size()); c.max_units = b->max_units; c.chunk_work = b->d_chunk_work.p; c.nchunks = uint32_t(b->chunk_work.size());
-    c.coef = b->d_coef.p; c.masks = b->d_masks.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
-    c.eobrun = b->d_eobrun.p; c.long_runs = b->d_long_runs.p; c.long_cnt = b->d_long_cnt.p; c.unit_bits = b->d_unit_bits.p; c.unit_off = b->d_unit_off.p; c.tables = b->d_tables.p;
-    c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p;
-    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_long_cnt.zero(st)) return -1;
+    c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size());
+    c.echunks = b->d_echunks.p; c.nechunks = uint32_t(b->echunks.size()); c.slot_work = b->d_slot_work.p; c.nslots = uint32_t(b->slot_work.size());
+    c.coef = b->d_coef.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
+    c.eobrun = b->d_eobrun.p; c.long_runs = b->d_long_runs.p; c.long_cnt = b->d_long_cnt.p; c.unit_ntok = b->d_unit_ntok.p;
+    c.tokens = b->d_tokens.p; c.tok_cap = b->tok_cap; c.tok_cursor = b->d_tok_cursor.p; c.tok_off = b->d_tok_off.p; c.chunk_ntok = b->d_chunk_ntok.p;
+    c.chunk_bits = b->d_chunk_bits.p; c.chunk_off = b->d_chunk_off.p; c.tables = b->d_tables.p;
+    c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p; c.overflow = b->d_overflow.p;
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_long_cnt.zero(st) || b->d_tok_cursor.zero(st)) return -1;
     MARK();
-    if (b->lossless) launch_masks(st, b->d_coef.p, b->d_masks.p, 0, b->ntiles_in);
-    else launch_masks(st, b->d_coef.p, b->d_masks.p, b->ntiles_in, b->ntiles_out);
-    MARK();
-    launch_ac_flags(st, c);
+    launch_tokens(st, c);
     MARK();
     launch_ac_runs(st, c);
     MARK();
-    // ---- phase 3: statistics + optimal tables
-    launch_stats(st, c);
-    MARK();
+    // ---- phase 3: optimal tables
     launch_gen_tables(st, b->d_tables.p, b->ntables);
     MARK();
     // ---- phase 4: sizes + offsets
-    launch_sizes(st, c);
+    launch_chunk_sizes(st, c);
     MARK();
-    launch_exclusive_scan(st, b->d_unit_bits.p, b->d_unit_off.p, b->total_units, b->d_scan_tmp.p, b->d_scan_tmp.n);
+    launch_exclusive_scan(st, b->d_chunk_bits.p, b->d_chunk_off.p, b->slot_work.size(), b->d_scan_tmp.p, b->d_scan_tmp.n);
     MARK();
     AsmCtx a;
     memset(&a, 0, sizeof a);
     a.imgs = b->d_imgs.p; a.script = b->d_script.p; a.work = b->d_swork.p; a.nwork = c.nwork; a.nimg = nimg;
-    a.tables = b->d_tables.p; a.unit_off = b->d_unit_off.p; a.scan_pad_bytes = b->d_scan_pad.p; a.scan_raw_off = b->d_scan_raw_off.p;
+    a.tables = b->d_tables.p; a.chunk_off = b->d_chunk_off.p; a.scan_pad_bytes = b->d_scan_pad.p; a.scan_raw_off = b->d_scan_raw_off.p;
     a.raw = b->d_raw.p; a.raw_chunks = raw_chunks; a.chunk_ff = b->d_chunk_ff.p; a.chunk_ffoff = b->d_chunk_ffoff.p;
     a.hdr_pool = b->d_hdr.p; a.hdr_off = b->d_hdr_off.p; a.img_size = b->d_img_size.p; a.img_size_pad = b->d_img_size_pad.p;
     a.img_off = b->d_img_off.p; a.out = b->d_out.p; a.out_cap = b->out_cap; a.status = b->d_status.p; a.overflow = b->d_overflow.p;
@@ -1139,6 +1155,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
         b->h_status.resize(b->nimg);
         if (hipMemcpy(b->h_status.data(), b->d_status.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
         bool pool = ovf[0] != 0;
+        if (ovf[1]) { pool = true; b->tok_cap *= 4; }   // token pool (k_tokens)
         for (uint32_t s : b->h_status) if (s == CS_ERR_POOL_OVERFLOW) pool = true;
         if (!pool) break;
         if (attempt == 3) { csh_set_error("device pools overflowed after 3 retries"); return CS_ERR_POOL_OVERFLOW; }

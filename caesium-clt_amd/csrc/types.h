@@ -6,8 +6,8 @@
 //    lane = block: octet j of every block is one 16-byte vector per lane = one fully coalesced 1 KiB access per
 //    wave (8 such loads/stores move a tile); a band-limited progressive scan (Ss..Se) touches only octets
 //    Ss>>3..Se>>3; a block's coefficients touch at most 8 cache lines (shared with 7 neighbour blocks).
-//  * per-block 64-bit significance masks M0/M1/M2 (bit k set iff |coef k| >= 1 / 2 / 4), SoA per tile:
-//    u64 mask[3][64 lanes].  The progressive coder's run/EOB logic is bit algebra on these.
+//  * per-block 64-bit planes (bit k: |coef k| >= 2^l, bit l of |coef k|, sign) exist only in registers (k_entropy.hip): the
+//    progressive coder's run/EOB logic is bit algebra on them.
 //  * u8 sample planes (subsampled components only), pitch = real_bw*8, rows = bh*8, edges replicated.
 #pragma once
 #include <cstdint>
@@ -177,6 +177,13 @@ struct ScanWork {
     uint32_t hdr_bytes;    // DHT + SOS bytes in front of the entropy-coded data (device-computed)
     uint32_t no_room;      // the raw pool cannot hold this scan (device-computed): the packer skips it, the batch is re-run with a larger pool
 };
+
+// one workgroup of the token kernel (k_tokens): 256 consecutive units, [256 j, 256 j + 256)
+//   kind 0: ALL progressive AC scans of component `comp` of image `a` (the block's coefficients are read once for all of them)
+//   kind 1: the one scan of work item `a` (DC scans: unit = MCU or block; sequential-mode scans)
+// Whatever the kind, the tokens of (work item w, chunk j) belong to slot w.first_chunk + j of the per-chunk arrays.
+struct EChunk { uint32_t a; uint16_t comp, kind; uint32_t j; };
+#define CSH_TK_MAXSLOT 8   // AC scans of one component that a kind-0 chunk can carry
 
 // encoder-side Huffman table as generated on the device
 struct DevEncTable {
