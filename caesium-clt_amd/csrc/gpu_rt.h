@@ -35,6 +35,11 @@
 #define CSH_PERSIST(T, name, N) T name[N]
 #define CSH_PHASE_LOOP(NPH) for (int phase = 0; phase < (NPH); ((phase + 1 < (NPH)) ? __syncthreads() : (void)0), phase++)
 #define CSH_LAUNCH_PHASED(kern, nph, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+// the same loop where some phase ends only synchronise a wave with itself: bit p of WAVE_MASK set = after phase p the lanes of a wave
+// see each other's LDS writes (no s_barrier -- the kernel's waves must then not exchange data at that point)
+#define CSH_PHASE_LOOP_MIXED(NPH, WAVE_MASK)                                                                                              \
+    for (int phase = 0; phase < (NPH);                                                                                                    \
+         ((phase + 1 < (NPH)) ? ((((WAVE_MASK) >> phase) & 1u) ? (__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"), __builtin_amdgcn_wave_barrier()) : __syncthreads()) : (void)0), phase++)
 #else
 // ------------------------------------------------------------------ emulation shims
 #include <algorithm>
@@ -74,6 +79,7 @@ static inline void csh_emul_launch(F kern, dim3 grid, dim3 block, A... args) {
 #define CSH_PERSIST(T, name, N) static thread_local T name##_lanes_[1024][N]; T (&name)[N] = name##_lanes_[threadIdx.x]
 extern thread_local int csh_emul_phase;
 #define CSH_PHASE_LOOP(NPH) for (int phase = csh_emul_phase, once_ = 1; once_; once_ = 0)
+#define CSH_PHASE_LOOP_MIXED(NPH, WAVE_MASK) CSH_PHASE_LOOP(NPH)
 template <class F, class... A>
 static inline void csh_emul_launch_phased(F kern, int nph, dim3 grid, dim3 block, A... args) {
     gridDim = grid; blockDim = block;

@@ -23,14 +23,16 @@
 namespace csh {
 
 // ------------------------------------------------------------------------------------------------ tokens
-//  kind (bits 0-1)
-//   SYM  Huffman symbol + raw bits behind it:  [9:2] symbol  [11:10] table of the scan's group  [15:12] n raw bits (0..15)  [30:16] the bits
-//   RAW  raw bits only:                        [15:12] n (1..15)  [30:16] the bits
-//   ACF  first-pass AC coefficient:            [7:2] zero run in front of it (0..62; every 16 cost one ZRL)  [11:8] size  [27:12] its bits
-//   EOB  the block ends with an EOB here: the packer emits the unit's EOBRUN symbol (eobrun[unit], if it owns one)
-enum : uint32_t { TK_SYM = 0u, TK_RAW = 1u, TK_ACF = 2u, TK_EOB = 3u };
-#define CSH_TK_STAGE 4096   // tokens a workgroup stages in LDS (16 KB); larger chunks go to / come from HBM directly
-#define CSH_PK_WORDS 2048   // bit buffer of the packer in LDS (64 Kbit); larger chunks are packed into HBM directly
+//  kind (bits 0-2)
+//   SYM  Huffman symbol + raw bits behind it:  [10:3] symbol  [12:11] table of the scan's group  [16:13] n raw bits (0..15)  [31:17] the bits
+//   RAW  raw bits only:                        [16:13] n (0..15; 0 = a token that emits nothing)  [31:17] the bits
+//   ACF  first-pass AC coefficient:            [8:3] zero run in front of it (0..62; every 16 cost one ZRL)  [12:9] size  [28:13] its bits
+//   REF  refinement-scan event:                [10:3] unit inside the chunk  [14:11] zero run  [15] sign bit  [21:16] n correction bits behind it
+//                                              [27:22] where they start in the unit's correction word  [28] 1 = the event is a ZRL (no sign bit)
+//   EOB  the block ends with an EOB here:      [10:3] unit inside the chunk  [21:16] / [27:22] its trailing correction bits, as in REF;
+//                                              the packer emits the unit's EOBRUN symbol in front of them (eobrun[unit], if it owns one)
+enum : uint32_t { TK_SYM = 0u, TK_RAW = 1u, TK_ACF = 2u, TK_REF = 3u, TK_EOB = 4u };
+#define CSH_PK_WORDS 1024   // the packer's window of the bit stream, per wave, in LDS words (a step of 256 tokens adds at most 768)
 
 __device__ __forceinline__ static uint64_t band_mask(int Ss, int Se) { return (~0ull >> (63 - Se)) & (~0ull << Ss); }
 __device__ __forceinline__ static int msb64(uint64_t v) { return 63 - __clzll(v); }
@@ -44,6 +46,19 @@ __device__ __forceinline__ static int unit_block(const CompGeom &g, uint32_t u) 
 }
 __device__ __forceinline__ static bool get_bit(const uint64_t *w, uint32_t i) { return (w[i >> 6] >> (i & 63)) & 1; }
 
+// OR over the 64 lanes of a wave, in a scalar register pair (the emulation, where a lane cannot see the others, answers "all ones":
+// callers use it only to skip work no lane has)
+__device__ __forceinline__ static uint64_t wave_or64(uint64_t v) {
+#ifdef CSH_EMUL
+    (void)v;
+    return ~0ull;
+#else
+    uint32_t lo = uint32_t(v), hi = uint32_t(v >> 32);
+    CSH_UNROLL
+    for (int o = 32; o >= 1; o >>= 1) { lo |= uint32_t(__shfl_xor(int(lo), o, 64)); hi |= uint32_t(__shfl_xor(int(hi), o, 64)); }
+    return (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(hi)))) << 32) | uint32_t(__builtin_amdgcn_readfirstlane(int(lo)));
+#endif
+}
 // inclusive scan over the 64 lanes of a wave of the values in[0..63] (LDS, written in an earlier phase), for lane `lane`
 __device__ __forceinline__ static uint32_t wave_incl_scan(const uint32_t *in, int lane) {
 #ifdef CSH_EMUL
@@ -58,12 +73,12 @@ __device__ __forceinline__ static uint32_t wave_incl_scan(const uint32_t *in, in
 #endif
 }
 
-// where a lane's tokens go: the workgroup's LDS stage, or (chunks with more tokens than the stage holds) the pool itself
+// where a lane's tokens go: straight into its stretch of the pool
 struct TokOut {
-    uint32_t *stage, *pool;
-    bool staged;
-    uint32_t pos;   // next token, relative to the chunk's first
-    __device__ __forceinline__ void put(uint32_t t) { if (staged) stage[pos] = t; else pool[pos] = t; pos++; }
+    uint32_t *pool;
+    uint32_t pos;   // next token, relative to pool
+    bool dry;
+    __device__ __forceinline__ void put(uint32_t t) { if (!dry) pool[pos] = t; pos++; }
 };
 
 // the sink of the walkers below.  EMIT = false only counts tokens (the same merge rules, so the count is what EMIT = true writes);
@@ -76,63 +91,86 @@ struct TokSink {
     TokOut out;
     uint32_t *hist;     // [h0 + table][257] in LDS
     int h0;
+    uint32_t rawbits;   // raw bits emitted (EMIT)
     static constexpr bool kValues = true;
     __device__ __forceinline__ void begin() { n = 0; pend = 0; has_pend = false; }
     __device__ __forceinline__ void flush() { if (has_pend) { if (EMIT) out.put(pend); n++; has_pend = false; } }
     __device__ __forceinline__ void sym(int t, int s) {
         flush();
-        pend = TK_SYM | (uint32_t(s) << 2) | (uint32_t(t) << 10); has_pend = true;
+        pend = TK_SYM | (uint32_t(s) << 3) | (uint32_t(t) << 11); has_pend = true;
         if (EMIT) atomicAdd(&hist[(h0 + t) * 257 + s], 1u);
     }
     __device__ __forceinline__ void syms(int t, int s, int cnt) { for (int i = 0; i < cnt; i++) sym(t, s); }
     __device__ __forceinline__ void raw(unsigned v, int nb) {   // the nb low bits of v, most significant first
+        if (EMIT) rawbits += uint32_t(nb);
         while (nb > 0) {
-            int have = has_pend ? int((pend >> 12) & 15u) : 0;
+            int have = has_pend ? int((pend >> 13) & 15u) : 0;
             if (has_pend && have == 15) { flush(); have = 0; }
             if (!has_pend) { pend = TK_RAW; has_pend = true; }
             const int take = nb < 15 - have ? nb : 15 - have;
             const uint32_t piece = (v >> (nb - take)) & ((1u << take) - 1u);
-            const uint32_t val = (((pend >> 16) << take) | piece) & 0x7FFFu;
-            pend = (pend & 0xFFFu) | (uint32_t(have + take) << 12) | (val << 16);
+            const uint32_t val = (((pend >> 17) << take) | piece) & 0x7FFFu;
+            pend = (pend & 0x1FFFu) | (uint32_t(have + take) << 13) | (val << 17);
             nb -= take;
         }
     }
-    __device__ __forceinline__ void eob() { flush(); if (EMIT) out.put(TK_EOB); n++; }
     __device__ __forceinline__ void finish() { flush(); }
 };
 
-// refinement scan of one block (jcphuff.c encode_mcu_AC_refine order: correction bits ride behind the next symbol); no coefficient
-// is read: the correction bit and the sign come from the bit planes
-template <class Sink>
-__device__ static void walk_ac_refine(Sink &sink, uint64_t H, uint64_t N, uint64_t C, uint64_t S, int Ss, bool ends_eob) {
-    int eobpos = N ? msb64(N) : -1;
-    uint64_t all = H | N;
-    int prev = Ss - 1, r = 0;
-    uint64_t br = 0; int brn = 0;  // pending correction bits, oldest first in the high end
-    while (all) {
-        int k = __ffsll((unsigned long long)all) - 1;
-        all &= all - 1;
-        r += k - prev - 1;
-        prev = k;
-        if (k <= eobpos)
-            while (r > 15) {
-                sink.sym(0, 0xF0); r -= 16;
-                if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
-                if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
-                br = 0; brn = 0;
+// refinement scan of one block (jcphuff.c encode_mcu_AC_refine order: correction bits ride behind the next symbol).  No coefficient is
+// read: H = positions with history, N = newly significant ones, C = their correction bits, S = signs.  One token per event (a newly
+// significant coefficient, a ZRL, the EOB); the correction bits are not in the tokens: they sit, in stream order and left-aligned, in
+// one 64-bit word per unit (at most 63 of them), and every token says which stretch of that word follows it.
+// Tokens written: at most `room` (the closed-form count of the caller: popcount(N) + zeros/16 + EOB); the rest is filled with empty ones.
+__device__ __forceinline__ static uint32_t refine_room(uint64_t H, uint64_t N, int Ss, bool ends_eob) {
+    if (!N) return ends_eob ? 1u : 0u;
+    const int eobpos = msb64(N);
+    const int zeros = (eobpos - Ss + 1) - __popcll((H | N) & band_mask(Ss, eobpos));
+    return uint32_t(__popcll(N)) + uint32_t(zeros >> 4) + (ends_eob ? 1u : 0u);
+}
+__device__ __forceinline__ static uint64_t correction_word(uint64_t H, uint64_t C) {
+    uint64_t corr = 0;
+    int i = 63;
+    while (H) { const int k = __ffsll((unsigned long long)H) - 1; H &= H - 1; corr |= ((C >> k) & 1ull) << i; i--; }
+    return corr;
+}
+__device__ static void emit_ac_refine(TokOut &out, uint32_t *hist, uint32_t unit, uint64_t H, uint64_t N, uint64_t S, int Ss, bool ends_eob, uint32_t room) {
+    const uint32_t pos0 = out.pos;
+    uint32_t cursor = 0;
+    int prev = Ss - 1;
+    uint64_t n = N;
+    while (n) {
+        const int k = __ffsll((unsigned long long)n) - 1;
+        n &= n - 1;
+        const uint64_t gap = (prev + 1 <= k - 1) ? band_mask(prev + 1, k - 1) : 0ull;
+        uint32_t hc = uint32_t(__popcll(H & gap));
+        int z = (k - prev - 1) - int(hc);
+        if (z > 15) {
+            // rare: ZRLs inside the gap.  Each is emitted at the first non-zero position after 16 more zeros and takes the correction bits
+            // seen up to there
+            int r = 0, p = prev;
+            uint32_t pending = 0;
+            uint64_t hm = (H & gap) | (1ull << k);
+            while (hm) {
+                const int q = __ffsll((unsigned long long)hm) - 1;
+                hm &= hm - 1;
+                r += q - p - 1; p = q;
+                while (r > 15) {
+                    out.put(TK_REF | (unit << 3) | (pending << 16) | (cursor << 22) | (1u << 28));
+                    atomicAdd(&hist[0xF0], 1u);
+                    cursor += pending; pending = 0; r -= 16;
+                }
+                if (q != k) pending++;
             }
-        if ((H >> k) & 1) { br = (br << 1) | ((C >> k) & 1); brn++; }
-        else {
-            sink.sym(0, (r << 4) | 1);
-            sink.raw(unsigned((~S >> k) & 1), 1);
-            if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
-            if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
-            br = 0; brn = 0; r = 0;
+            z = r; hc = pending;
         }
+        out.put(TK_REF | (unit << 3) | (uint32_t(z) << 11) | (uint32_t((~S >> k) & 1ull) << 15) | (hc << 16) | (cursor << 22));
+        atomicAdd(&hist[(z << 4) | 1], 1u);
+        cursor += hc;
+        prev = k;
     }
-    if (ends_eob) sink.eob();
-    if (brn > 32) { sink.raw(unsigned(br >> 32), brn - 32); }
-    if (brn) sink.raw(unsigned(br), brn > 32 ? 32 : brn);
+    if (ends_eob) out.put(TK_EOB | (unit << 3) | ((uint32_t(__popcll(H)) - cursor) << 16) | (cursor << 22));
+    while (out.pos - pos0 < room) out.put(TK_RAW);
 }
 
 // DC scans: unit = MCU (interleaved) or block (single component)
@@ -272,40 +310,60 @@ __device__ __forceinline__ static uint64_t pick_bit(const uint64_t *s, int l) { 
 __device__ __forceinline__ static bool ac_scan_of(const EncScan &sc, int comp) { return sc.Ss > 0 && !sc.sequential && sc.comp[0] == comp; }
 
 // ---- pass A: tokens, flags, statistics
-// state of a lane across the phases: the planes.  The coefficients themselves are loaded again where the first-pass scans are coded
-// (from the L2: the workgroup read the same lines a few microseconds earlier) -- 32 registers per lane held across the barriers cost
-// more in occupancy than the second load does.
-__global__ void __launch_bounds__(256, 4) k_tokens(EncCtx c) {
+// A workgroup is four independent waves of 64 units that share only the histogram: between the phases below a wave synchronises
+// with itself alone (no s_barrier: a wave that waits for its memory does not hold the other three), except after the histogram is
+// cleared and before it is flushed.  Each wave gets its own stretch of the token pool per slot ("segment": slot x 4 + wave).
+// State of a lane across the phases: the planes.  The coefficients themselves are loaded again where the first-pass scans are coded
+// (from the L2: the wave read the same lines a few microseconds earlier) -- 32 registers per lane held across the phases cost more
+// in occupancy than the second load does.
+__global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
     CSH_SHARED uint32_t hist[CSH_TK_MAXSLOT * 257];
-    CSH_SHARED uint32_t cnt[CSH_TK_MAXSLOT][256];   // tokens per (slot, lane); after the scan: exclusive offsets inside the slot
-    CSH_SHARED uint32_t stage[CSH_TK_STAGE];
-    CSH_SHARED uint32_t s_tot[CSH_TK_MAXSLOT], s_base[CSH_TK_MAXSLOT + 1], s_tbase[CSH_TK_MAXSLOT], s_nh, s_flags;
-    CSH_SHARED unsigned long long s_gbase;
+    CSH_SHARED uint32_t cnt[CSH_TK_MAXSLOT][256];   // tokens per (slot, lane)
+    CSH_SHARED uint32_t off[CSH_TK_MAXSLOT][256];   // exclusive scan of them inside the lane's wave
+    CSH_SHARED uint32_t s_wtot[4][CSH_TK_MAXSLOT];  // per wave: tokens of the slot
+    CSH_SHARED unsigned long long s_wbase[4][CSH_TK_MAXSLOT];   // per wave: first token of its segment in the pool (~0: no room)
+    CSH_SHARED uint32_t s_raw[CSH_TK_MAXSLOT];      // raw (non-Huffman) bits of the slot, EOBRUN bits excluded
+    CSH_SHARED TokPlan s_plan;                      // kind 0: the component's geometry and AC scans
     CSH_PERSIST(uint64_t, pl, 10);     // bit k of: |c_k| >= 1, 2, 4, 8, 16; bit 0..3 of |c_k|; c_k < 0
     const EChunk ch = c.echunks[blockIdx.x];
     const int tid = int(threadIdx.x), lane = lane_id(), wv = tid >> 6;
-    const ImgDesc &im = c.imgs[ch.kind == 0 ? ch.a : c.work[ch.a].image];
     const uint32_t u = ch.j * 256u + uint32_t(tid);
+    const TokPlan &P = s_plan;
 
-    CSH_PHASE_LOOP(5) {
+    CSH_PHASE_LOOP_MIXED(6, 0x0Eu) {   // after phases 1, 2, 3 only the wave synchronises
+        if ((c.debug & 1024u) && ch.kind == 1) continue;
+        if ((c.debug & 2048u) && ch.kind == 0) continue;
         if (phase == 0) {
-            // ---------------------------------------------------------------- load, planes, counts, flags
             for (int i = tid; i < CSH_TK_MAXSLOT * 257; i += 256) hist[i] = 0;
+            if (tid < CSH_TK_MAXSLOT) s_raw[tid] = 0;
+            if (ch.kind == 0 && tid < int(sizeof(TokPlan) / 4)) reinterpret_cast<uint32_t *>(&s_plan)[tid] = reinterpret_cast<const uint32_t *>(c.plans + ch.plan)[tid];
+            continue;
+        }
+        if (phase == 1) {
+            // ---------------------------------------------------------------- load, planes, counts, flags
             if (ch.kind == 1) {
                 const ScanWork &w = c.work[ch.a];
                 const EncScan &sc = c.script[w.scan];
-                TokSink<false> s; s.begin();
-                if (u < w.nunits) { if (sc.sequential) walk_seq(s, c, im, sc, u); else walk_dc(s, c, im, sc, u); s.finish(); }
-                cnt[0][tid] = s.n;
+                const ImgDesc &im = c.imgs[w.image];
+                uint32_t n = 0;
+                if (u < w.nunits) {
+                    if (sc.sequential) { TokSink<false> s; s.begin(); walk_seq(s, c, im, sc, u); s.finish(); n = s.n; }
+                    else {   // DC scans: one SYM token per block (the difference's bits ride in it), or one bit per block, fifteen to a token
+                        uint32_t nb = 0;
+                        for (int ci = 0; ci < sc.ncomp; ci++) nb += sc.ncomp > 1 ? uint32_t(im.out[sc.comp[ci]].h * im.out[sc.comp[ci]].v) : 1u;
+                        n = sc.Ah ? (nb + 14u) / 15u : nb;
+                    }
+                }
+                cnt[0][tid] = n;
+                for (int slot = 1; slot < CSH_TK_MAXSLOT; slot++) cnt[slot][tid] = 0;
                 continue;
             }
-            const CompGeom &g = im.out[ch.comp];
-            const bool valid = u < uint32_t(g.real_bw * g.real_bh);
+            const bool valid = u < P.nunits;
             CSH_UNROLL
             for (int i = 0; i < 10; i++) pl[i] = 0;
             if (valid) {
-                const int b = unit_block(g, u);
-                const int16_t *p = c.coef + (size_t(g.tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE);
+                const int by = int(u) / P.real_bw, b = by * P.bw + (int(u) - by * P.real_bw);
+                const int16_t *p = c.coef + (size_t(P.tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE);
                 uint32_t sm[32];   // sign-and-magnitude halves: bits 0-14 |c|, bit 15 the sign
                 CSH_UNROLL
                 for (int j = 0; j < 8; j++) {
@@ -324,7 +382,7 @@ __global__ void __launch_bounds__(256, 4) k_tokens(EncCtx c) {
                     m[2 * t + 1] = (sm[t] >> 16) | (sm[t + 16] & 0xFFFF0000u);
                 }
                 CSH_SCHED_FENCE();
-                transpose32(m);
+                if (!(c.debug & 512u)) transpose32(m);
                 CSH_SCHED_FENCE();
                 uint64_t acc = 0;
                 CSH_UNROLL
@@ -337,119 +395,98 @@ __global__ void __launch_bounds__(256, 4) k_tokens(EncCtx c) {
                 pl[9] = uint64_t(m[15]) | (uint64_t(m[31]) << 32);
                 CSH_SCHED_FENCE();
             }
-            const uint64_t sgn = pl[9];
-            int slot = 0;
-            for (int sl = 0; sl < im.nscans_out && slot < CSH_TK_MAXSLOT; sl++) {
-                const ScanWork &w = c.work[im.first_work + sl];
-                const EncScan &sc = c.script[w.scan];
-                if (!ac_scan_of(sc, ch.comp)) continue;
-                const uint64_t band = band_mask(sc.Ss, sc.Se);
-                const uint64_t lo = pick_sig(pl, sc.Al);
+            for (int slot = 0; slot < CSH_TK_MAXSLOT; slot++) {
+                if (slot >= int(P.nslot)) { cnt[slot][tid] = 0; continue; }
+                const AcSlot &a = P.s[slot];
+                const uint64_t band = band_mask(a.Ss, a.Se);
+                const uint64_t lo = pick_sig(pl, a.Al);
                 bool has_sym = false, ends_eob = false;
                 uint32_t n = 0; int tail = 0;
                 if (valid) {
-                    if (sc.Ah == 0) {
+                    if (a.Ah == 0) {
                         const uint64_t NZ = lo & band;
-                        has_sym = NZ != 0; ends_eob = !((NZ >> sc.Se) & 1);
+                        has_sym = NZ != 0; ends_eob = !((NZ >> a.Se) & 1);
                         n = uint32_t(__popcll(NZ)) + (ends_eob ? 1u : 0u);
                     } else {
-                        const uint64_t hi = pick_sig(pl, sc.Al + 1), H = hi & band, N = lo & ~hi & band;
-                        has_sym = N != 0; ends_eob = !((N >> sc.Se) & 1);
+                        const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
+                        has_sym = N != 0; ends_eob = !((N >> a.Se) & 1);
                         tail = N ? __popcll(H & ~((2ull << msb64(N)) - 1)) : __popcll(H);
-                        TokSink<false> s; s.begin();
-                        walk_ac_refine(s, H, N, pick_bit(pl + 5, sc.Al), sgn, sc.Ss, ends_eob);
-                        s.finish();
-                        n = s.n;
+                        n = refine_room(H, N, a.Ss, ends_eob);
+                        if (!(c.debug & 256u)) c.corr[a.unit_base + u] = correction_word(H, pick_bit(pl + 5, a.Al));
                     }
-                    c.tail[w.unit_base + u] = uint8_t(tail);
+                    c.tail[a.unit_base + u] = uint8_t(tail);
                 }
                 cnt[slot][tid] = n;
 #ifdef CSH_EMUL
-                if (has_sym) atomicOr(reinterpret_cast<unsigned long long *>(c.sym_bits + w.word_base + (u >> 6)), 1ull << (u & 63));
-                if (ends_eob) atomicOr(reinterpret_cast<unsigned long long *>(c.eob_bits + w.word_base + (u >> 6)), 1ull << (u & 63));
+                if (has_sym) atomicOr(reinterpret_cast<unsigned long long *>(c.sym_bits + a.word_base + (u >> 6)), 1ull << (u & 63));
+                if (ends_eob) atomicOr(reinterpret_cast<unsigned long long *>(c.eob_bits + a.word_base + (u >> 6)), 1ull << (u & 63));
 #else
                 // lane = block, so a wave's 64 flags ARE one word of the scan's bit vectors: one ballot, one 8-byte store
                 const uint64_t ms = __ballot(has_sym), me = __ballot(ends_eob);
-                if (lane == 0 && (u >> 6) < ((w.nunits + 63) >> 6)) { c.sym_bits[w.word_base + (u >> 6)] = ms; c.eob_bits[w.word_base + (u >> 6)] = me; }
-#endif
-                slot++;
-            }
-            continue;
-        }
-        if (phase == 1) {
-            // ---------------------------------------------------------------- exclusive scan of the counts, slot by slot (wave w: slots w, w + 4)
-            for (int slot = wv; slot < CSH_TK_MAXSLOT; slot += 4) {
-#ifdef CSH_EMUL
-                if (lane == 0) { uint32_t acc = 0; for (int i = 0; i < 256; i++) { uint32_t v = cnt[slot][i]; cnt[slot][i] = acc; acc += v; } s_tot[slot] = acc; }
-#else
-                uint32_t carry = 0;
-                CSH_UNROLL
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t v = cnt[slot][64 * q + lane];
-                    const uint32_t incl = wave_incl_scan(&cnt[slot][64 * q], lane);
-                    cnt[slot][64 * q + lane] = carry + incl - v;
-                    carry += uint32_t(__shfl(int(incl), 63, 64));
-                }
-                if (lane == 0) s_tot[slot] = carry;
+                if (lane == 0 && (u >> 6) < ((a.nunits_work + 63) >> 6)) { c.sym_bits[a.word_base + (u >> 6)] = ms; c.eob_bits[a.word_base + (u >> 6)] = me; }
 #endif
             }
             continue;
         }
         if (phase == 2) {
-            // ---------------------------------------------------------------- one lane: room in the pool for the whole chunk, slot by slot
-            if (tid != 0) continue;
-            uint32_t total = 0;
-            int nslot = 0;
-            if (ch.kind == 1) { nslot = 1; s_base[0] = 0; total = s_tot[0]; }
-            else
-                for (int sl = 0; sl < im.nscans_out && nslot < CSH_TK_MAXSLOT; sl++)
-                    if (ac_scan_of(c.script[c.work[im.first_work + sl].scan], ch.comp)) { s_base[nslot] = total; total += s_tot[nslot]; nslot++; }
-            s_base[nslot] = total;
-            const unsigned long long gb = atomicAdd(c.tok_cursor, (unsigned long long)total);
-            const bool ok = gb + total <= c.tok_cap;
-            if (!ok) c.overflow[1] = 1;
-            s_gbase = gb;
-            s_flags = (ok ? 1u : 0u) | (total <= CSH_TK_STAGE ? 2u : 0u);
-            if (ch.kind == 1) {
-                const ScanWork &w = c.work[ch.a];
-                const EncScan &sc = c.script[w.scan];
-                c.tok_off[w.first_chunk + ch.j] = gb; c.chunk_ntok[w.first_chunk + ch.j] = ok ? total : 0u;
-                s_nh = uint32_t(sc.ntables);
-                for (int t = 0; t < sc.ntables; t++) s_tbase[t] = w.table_base + uint32_t(t);
-            } else {
-                int slot = 0;
-                for (int sl = 0; sl < im.nscans_out && slot < CSH_TK_MAXSLOT; sl++) {
-                    const ScanWork &w = c.work[im.first_work + sl];
-                    if (!ac_scan_of(c.script[w.scan], ch.comp)) continue;
-                    c.tok_off[w.first_chunk + ch.j] = gb + s_base[slot]; c.chunk_ntok[w.first_chunk + ch.j] = ok ? s_tot[slot] : 0u;
-                    s_tbase[slot] = w.table_base;
-                    slot++;
-                }
-                s_nh = uint32_t(slot);
+            // ---------------------------------------------------------------- exclusive scan of the counts inside the wave, slot by slot
+            CSH_UNROLL
+            for (int slot = 0; slot < CSH_TK_MAXSLOT; slot++) {
+                const uint32_t incl = wave_incl_scan(&cnt[slot][64 * wv], lane);
+                off[slot][tid] = incl - cnt[slot][tid];
+                if (lane == 63) s_wtot[wv][slot] = incl;
             }
             continue;
         }
         if (phase == 3) {
+            // ---------------------------------------------------------------- one lane per wave: room in the pool for the wave's segments
+            if (lane != 0) continue;
+            uint32_t total = 0;
+            CSH_UNROLL
+            for (int slot = 0; slot < CSH_TK_MAXSLOT; slot++) total += s_wtot[wv][slot];
+            const TokRegion rg = c.regions[ch.region];
+            const uint32_t rel = atomicAdd(&c.tok_cursor[ch.region], total);
+            const bool ok = uint64_t(rel) + total <= rg.cap;
+            const unsigned long long gb = rg.base + rel;
+            if (!ok) c.overflow[1] = 1;
+            unsigned long long at = gb;
+            if (ch.kind == 1) {
+                const ScanWork &w = c.work[ch.a];
+                const uint32_t seg = (w.first_chunk + ch.j) * 4u + uint32_t(wv);
+                c.tok_off[seg] = gb; c.chunk_ntok[seg] = ok ? total : 0u;
+                s_wbase[wv][0] = ok ? gb : ~0ull;
+            } else {
+                for (int slot = 0; slot < int(P.nslot); slot++) {
+                    const uint32_t seg = (P.s[slot].first_chunk + ch.j) * 4u + uint32_t(wv);
+                    c.tok_off[seg] = at; c.chunk_ntok[seg] = ok ? s_wtot[wv][slot] : 0u;
+                    s_wbase[wv][slot] = ok ? at : ~0ull;
+                    at += s_wtot[wv][slot];
+                }
+            }
+            continue;
+        }
+        if (phase == 4) {
             // ---------------------------------------------------------------- tokens + histograms
-            if (!(s_flags & 1u)) continue;
-            TokOut out; out.stage = stage; out.pool = c.tokens + s_gbase; out.staged = (s_flags & 2u) != 0;
+            if (s_wbase[wv][0] == ~0ull) continue;
+            if (c.debug & 1u) continue;
+            TokOut out; out.pool = c.tokens; out.dry = (c.debug & 4u) != 0;
             if (ch.kind == 1) {
                 const ScanWork &w = c.work[ch.a];
                 const EncScan &sc = c.script[w.scan];
                 if (u >= w.nunits) continue;
-                TokSink<true> s; s.begin(); s.out = out; s.out.pos = cnt[0][tid]; s.hist = hist; s.h0 = 0;
-                if (sc.sequential) walk_seq(s, c, im, sc, u); else walk_dc(s, c, im, sc, u);
+                TokSink<true> s; s.begin(); s.out = out; s.out.pool = c.tokens + s_wbase[wv][0] + off[0][tid]; s.out.pos = 0; s.hist = hist; s.h0 = 0; s.rawbits = 0;
+                if (sc.sequential) walk_seq(s, c, c.imgs[w.image], sc, u); else walk_dc(s, c, c.imgs[w.image], sc, u);
                 s.finish();
-                c.unit_ntok[w.unit_base + u] = uint16_t(s.n);
+                while (s.out.pos < cnt[0][tid]) s.out.put(TK_RAW);
+                if (s.rawbits) atomicAdd(&s_raw[0], s.rawbits);
                 continue;
             }
-            const CompGeom &g = im.out[ch.comp];
-            if (u >= uint32_t(g.real_bw * g.real_bh)) continue;
+            if (u >= P.nunits) continue;
             const uint64_t sgn = pl[9];
             uint32_t aw[32];   // |c_k|: k = 2 i in the low half of word i, k = 2 i + 1 in the high half
             {
-                const int b = unit_block(g, u);
-                const int16_t *p = c.coef + (size_t(g.tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE);
+                const int by = int(u) / P.real_bw, b = by * P.bw + (int(u) - by * P.real_bw);
+                const int16_t *p = c.coef + (size_t(P.tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE);
                 CSH_UNROLL
                 for (int j = 0; j < 8; j++) {
                     const uint4 q = *reinterpret_cast<const uint4 *>(p + CSH_OCT_STRIDE * j);
@@ -457,61 +494,75 @@ __global__ void __launch_bounds__(256, 4) k_tokens(EncCtx c) {
                 }
                 CSH_SCHED_FENCE();
             }
-            int slot = 0;
-            for (int sl = 0; sl < im.nscans_out && slot < CSH_TK_MAXSLOT; sl++) {
-                const ScanWork &w = c.work[im.first_work + sl];
-                const EncScan &sc = c.script[w.scan];
-                if (!ac_scan_of(sc, ch.comp)) continue;
-                const uint64_t band = band_mask(sc.Ss, sc.Se);
-                const uint64_t lo = pick_sig(pl, sc.Al);
-                out.pos = s_base[slot] + cnt[slot][tid];
-                const uint32_t pos0 = out.pos;
-                if (sc.Ah == 0) {
+            for (int slot = 0; slot < int(P.nslot); slot++) {
+                const AcSlot &a = P.s[slot];
+                const uint64_t band = band_mask(a.Ss, a.Se);
+                const uint64_t lo = pick_sig(pl, a.Al);
+                out.pool = c.tokens + s_wbase[wv][slot] + off[slot][tid];
+                out.pos = 0;
+                uint32_t rawbits = 0;
+                if (a.Ah == 0) {
+                    if (c.debug & 16u) continue;
                     // first pass: one token per coded coefficient; the 63 positions are a static sweep, so that |c_k| is a register
                     CSH_UNROLL
                     for (int i = 0; i < 32; i++) CSH_PIN(aw[i]);   // what the steps derive from loop-invariant registers (the unpacked halves, the sign
                     uint32_t sg_lo = uint32_t(sgn), sg_hi = uint32_t(sgn >> 32);   // bits) is not to be hoisted out of the loop over the scans: 64 + 63 live registers
                     CSH_PIN(sg_lo); CSH_PIN(sg_hi);
                     const uint64_t NZ = lo & band;
+                    const uint64_t any = wave_or64(NZ);   // positions no lane of the wave codes cost two scalar instructions
                     uint32_t *h = hist + slot * 257;
-                    int prev = sc.Ss - 1;
+                    const int Al = a.Al;
+                    int prev = int(a.Ss) - 1;
                     CSH_UNROLL
                     for (int k = 1; k < 64; k++) {
                         CSH_SCHED_FENCE();
+                        if (!((any >> k) & 1)) continue;
                         if ((NZ >> k) & 1) {
-                            const uint32_t a = ((k & 1) ? (aw[k >> 1] >> 16) : (aw[k >> 1] & 0xFFFFu)) >> sc.Al;
-                            const int nb = bitlen32(a);
+                            const uint32_t av = ((k & 1) ? (aw[k >> 1] >> 16) : (aw[k >> 1] & 0xFFFFu)) >> Al;
+                            const int nb = bitlen32(av);
                             const int r = k - prev - 1;
                             prev = k;
-                            const uint32_t val = ((((k < 32 ? sg_lo >> (k & 31) : sg_hi >> (k & 31)) & 1u) ? ~a : a)) & ((1u << nb) - 1u);
-                            out.put(TK_ACF | (uint32_t(r) << 2) | (uint32_t(nb) << 8) | (val << 12));
+                            const uint32_t val = ((((k < 32 ? sg_lo >> (k & 31) : sg_hi >> (k & 31)) & 1u) ? ~av : av)) & ((1u << nb) - 1u);
+                            out.put(TK_ACF | (uint32_t(r) << 3) | (uint32_t(nb) << 9) | (val << 13));
+                            if (!(c.debug & 2u)) {
                             if (r >> 4) atomicAdd(&h[0xF0], uint32_t(r >> 4));
                             atomicAdd(&h[((r & 15) << 4) | nb], 1u);
+                            }
+                            rawbits += uint32_t(nb);
                         }
                     }
-                    if (!((NZ >> sc.Se) & 1)) out.put(TK_EOB);
+                    if (!((NZ >> a.Se) & 1)) out.put(TK_EOB | (uint32_t(tid) << 3));
                 } else {
-                    const uint64_t hi = pick_sig(pl, sc.Al + 1), H = hi & band, N = lo & ~hi & band;
-                    TokSink<true> s; s.begin(); s.out = out; s.hist = hist; s.h0 = slot;
-                    walk_ac_refine(s, H, N, pick_bit(pl + 5, sc.Al), sgn, sc.Ss, !((N >> sc.Se) & 1));
-                    s.finish();
-                    out.pos = s.out.pos;
+                    const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
+                    if (c.debug & 8u) continue;
+                    emit_ac_refine(out, hist + slot * 257, uint32_t(tid), H, N, sgn, a.Ss, !((N >> a.Se) & 1), cnt[slot][tid]);
+                    rawbits = uint32_t(__popcll(N) + __popcll(H));   // a sign bit per new coefficient, a correction bit per old one
                 }
-                c.unit_ntok[w.unit_base + u] = uint16_t(out.pos - pos0);
-                slot++;
+                if (rawbits) atomicAdd(&s_raw[slot], rawbits);
             }
             continue;
         }
-        // -------------------------------------------------------------------- stage -> pool (coalesced), histograms -> tables
-        if (!(s_flags & 1u)) continue;
-        if (s_flags & 2u) {
-            uint32_t *dst = c.tokens + s_gbase;
-            const uint32_t total = s_base[ch.kind == 1 ? 1 : int(s_nh)];
-            for (uint32_t i = uint32_t(tid); i < total; i += 256) dst[i] = stage[i];
-        }
-        for (uint32_t i = uint32_t(tid); i < s_nh * 257u; i += 256) {
-            const uint32_t v = hist[i];
-            if (v) atomicAdd(&c.tables[s_tbase[i / 257u]].freq[i % 257u], v);
+        // -------------------------------------------------------------------- histograms -> tables, and per slot for k_chunk_sizes
+        if (c.debug & 32u) continue;
+        if (ch.kind == 1) {
+            const ScanWork &w = c.work[ch.a];
+            const EncScan &sc = c.script[w.scan];
+            const SlotRec &r = c.slots[w.first_chunk + ch.j];
+            for (uint32_t i = uint32_t(tid); i < uint32_t(sc.ntables) * 256u; i += 256) {
+                const uint32_t v = hist[(i >> 8) * 257u + (i & 255u)];
+                c.slot_hist[size_t(r.hist_row) * 256u + i] = uint16_t(v);
+                if (v) atomicAdd(&c.tables[w.table_base + (i >> 8)].freq[i & 255u], v);
+            }
+            if (tid == 0) c.slot_raw[w.first_chunk + ch.j] = s_raw[0];
+        } else {
+            for (int slot = 0; slot < int(P.nslot); slot++) {
+                const AcSlot &a = P.s[slot];
+                const uint32_t cs = a.first_chunk + ch.j;
+                const uint32_t v = hist[slot * 257 + tid];
+                if (!(c.debug & 64u)) c.slot_hist[size_t(c.slots[cs].hist_row) * 256u + uint32_t(tid)] = uint16_t(v);
+                if (v && !(c.debug & 128u)) atomicAdd(&c.tables[a.table_base].freq[tid], v);
+                if (tid == 0) c.slot_raw[cs] = s_raw[slot];
+            }
         }
     }
 }
@@ -520,20 +571,20 @@ __global__ void __launch_bounds__(256, 4) k_tokens(EncCtx c) {
 // ---- pass B: EOB run structure -> EOBRUN value owned by the first block of each (sub-)run, and those symbols' statistics
 // A run [u .. t] is cut into sub-runs as jcphuff.c does: after 0x7FFF blocks, and (refinement) as soon as more than
 // MAX_CORR_BITS - DCTSIZE2 + 1 = 937 correction bits are pending.  Serial form (short runs, and the emulation build):
-// `h` = histogram of the EOBn symbols (index = n), LDS or the scan's table
+// count(run, owner): called for every EOBRUN symbol, with the block that emits it
 template <class Count>
 __device__ static void eob_run_serial(const EncCtx &c, const ScanWork &w, const EncScan &sc, uint32_t u, uint32_t t, Count count) {
     uint16_t *er = c.eobrun + w.unit_base;
     if (sc.Ah == 0) {
         uint32_t L = t - u + 1, pos = u;
-        while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); count(l); pos += l; L -= l; }
+        while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); count(l, pos); pos += l; L -= l; }
         return;
     }
     const uint8_t *tl = c.tail + w.unit_base;
     uint32_t cnt = 0, be = 0, s0 = u;
     auto step = [&](uint32_t j, uint32_t tail_bits) {
         cnt++; be += tail_bits;
-        if (cnt == 0x7FFF || be > 937) { er[s0] = uint16_t(cnt); count(cnt); cnt = 0; be = 0; s0 = j + 1; }
+        if (cnt == 0x7FFF || be > 937) { er[s0] = uint16_t(cnt); count(cnt, s0); cnt = 0; be = 0; s0 = j + 1; }
     };
     uint32_t j = u;
     while (j <= t && (reinterpret_cast<uintptr_t>(tl + j) & 7)) { step(j, tl[j]); j++; }
@@ -543,7 +594,7 @@ __device__ static void eob_run_serial(const EncCtx &c, const ScanWork &w, const 
         for (int i = 0; i < 8; i++) step(j + i, uint32_t(v >> (8 * i)) & 255u);
     }
     for (; j <= t; j++) step(j, tl[j]);
-    if (cnt) { er[s0] = uint16_t(cnt); count(cnt); }
+    if (cnt) { er[s0] = uint16_t(cnt); count(cnt, s0); }
 }
 // last block of the run that starts at u: the block before the next one that carries a symbol.  Looks at most `max_words`
 // words of the has-symbol vector ahead; returns false if the end lies further on.
@@ -562,24 +613,70 @@ __device__ static bool eob_run_end(const uint64_t *sym, uint32_t nunits, uint32_
     return true;
 }
 #define CSH_LONG_RUN_WORDS 8   // a run whose end is not within 8 words (512 blocks) goes to k_ac_runs_long: one WAVE per run
+// Four slots (1024 blocks) per workgroup, one block per lane and slot.  The common case needs no loop and no further load: the block
+// starts a run (it ends with an EOB and has symbols, or its predecessor does not end with one), the next block with a symbol lies in
+// this or the next word of the has-symbol vector, and the run is at most 14 blocks long -- then no correction-bit limit can cut it
+// (14 x 63 <= 937) and its EOBRUN is its length.  Everything else takes the general path (eob_run_end / eob_run_serial).
 __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
-    CSH_SHARED uint32_t eh[16];
-    const uint32_t wi = c.slot_work[blockIdx.x];
-    const ScanWork w = c.work[wi];
-    const EncScan &sc = c.script[w.scan];
-    CSH_PHASE_LOOP(3) {
-        if (sc.Ss == 0 || sc.sequential) continue;
-        if (phase == 0) { if (threadIdx.x < 16) eh[threadIdx.x] = 0; continue; }
-        if (phase == 2) { if (threadIdx.x < 15 && eh[threadIdx.x]) atomicAdd(&c.tables[w.table_base].freq[threadIdx.x << 4], eh[threadIdx.x]); continue; }
-        uint32_t u = (blockIdx.x - w.first_chunk) * blockDim.x + threadIdx.x;
-        if (u >= w.nunits) continue;
-        const uint64_t *sym = c.sym_bits + w.word_base, *eob = c.eob_bits + w.word_base;
-        if (!get_bit(eob, u)) continue;
-        bool start = get_bit(sym, u) || u == 0 || !get_bit(eob, u - 1);
-        if (!start) continue;
-        uint32_t t;
-        if (eob_run_end(sym, w.nunits, u, CSH_LONG_RUN_WORDS, t)) eob_run_serial(c, w, sc, u, t, [&](uint32_t run) { atomicAdd(&eh[bitlen32(run) - 1], 1u); });
-        else { uint32_t e = atomicAdd(c.long_cnt, 1u); c.long_runs[2 * e] = wi; c.long_runs[2 * e + 1] = u; }
+    const int lane = lane_id();
+    (void)lane;
+    CSH_UNROLL
+    for (int q = 0; q < 4; q++) {
+        const uint32_t cs = blockIdx.x * 4u + uint32_t(q);
+        if (cs >= c.nslots) break;
+        const SlotRec r = c.slots[cs];
+        if (!(r.flags & 1u)) continue;
+        const uint32_t u = r.j * 256u + threadIdx.x, nunits = r.nunits_work;
+        uint32_t *freq = c.tables[r.table_base].freq;
+        const uint64_t *sym = c.sym_bits + r.word_base, *eob = c.eob_bits + r.word_base;
+        int my_nb = -1;
+        if (u < nunits) {
+            const uint32_t w0 = u >> 6, nwords = (nunits + 63) >> 6;
+            const int bit = int(u & 63);
+            const uint64_t s0 = sym[w0], e0 = eob[w0];
+            const uint64_t s1 = w0 + 1 < nwords ? sym[w0 + 1] : ~0ull;   // behind the scan's last block: a block "with a symbol" ends the run there
+            const bool prev_eob = u == 0 ? false : (bit ? ((e0 >> (bit - 1)) & 1) != 0 : ((eob[w0 - 1] >> 63) & 1) != 0);
+            const bool start = ((e0 >> bit) & 1) && (((s0 >> bit) & 1) || !prev_eob);
+            if (start) {
+                // next block with a symbol, looking at this word and the next one
+                const uint64_t a0 = bit == 63 ? 0ull : (s0 & (~0ull << (bit + 1)));
+                uint32_t next = 0xFFFFFFFFu;
+                if (a0) next = (w0 << 6) + uint32_t(__ffsll((unsigned long long)a0) - 1);
+                else if (s1) next = ((w0 + 1) << 6) + uint32_t(__ffsll((unsigned long long)s1) - 1);
+                if (next != 0xFFFFFFFFu && next > nunits) next = nunits;
+                const uint32_t len = next == 0xFFFFFFFFu ? 0xFFFFFFFFu : next - u;
+                if (len <= 14u || (len < 0x7FFFu && r.Ah == 0)) {
+                    c.eobrun[r.unit_base + u] = uint16_t(len);
+                    my_nb = bitlen32(len) - 1;
+                } else {
+                    ScanWork w; w.unit_base = r.unit_base; w.word_base = r.word_base; w.nunits = nunits; w.first_chunk = r.first_chunk; w.table_base = r.table_base;
+                    EncScan sc; sc.Ss = r.Ss; sc.Se = r.Se; sc.Ah = r.Ah; sc.Al = r.Al;
+                    uint32_t t;
+                    if (eob_run_end(sym, nunits, u, CSH_LONG_RUN_WORDS, t))
+                        eob_run_serial(c, w, sc, u, t, [&](uint32_t run, uint32_t owner) {   // a run cut into sub-runs, or a long one: counted one by one
+                            const int nb = bitlen32(run) - 1;
+                            atomicAdd(&freq[nb << 4], 1u); atomicAdd(&c.slot_eobh[size_t(r.first_chunk + (owner >> 8)) * 16u + uint32_t(nb)], 1u);   // the symbol belongs to the chunk of the block that emits it
+                        });
+                    else { uint32_t e = atomicAdd(c.long_cnt, 1u); c.long_runs[2 * e] = r.work; c.long_runs[2 * e + 1] = u; }
+                }
+            }
+        }
+        // the EOBn symbol of an ordinary run (one per lane at most) is counted wave-wide: a ballot per class instead of 64 atomics on a few counters
+#ifdef CSH_EMUL
+        if (my_nb >= 0) { atomicAdd(&freq[my_nb << 4], 1u); atomicAdd(&c.slot_eobh[cs * 16u + uint32_t(my_nb)], 1u); }
+#else
+        CSH_UNROLL
+        for (int nb = 0; nb < 4; nb++) {   // runs of up to 14 blocks: EOB0 .. EOB3; longer first-pass runs below
+            const uint64_t m = __ballot(my_nb == nb);
+            if (m && lane == nb) { atomicAdd(&freq[nb << 4], uint32_t(__popcll(m))); atomicAdd(&c.slot_eobh[cs * 16u + uint32_t(nb)], uint32_t(__popcll(m))); }
+        }
+        if (__ballot(my_nb >= 4)) {
+            for (int nb = 4; nb < 15; nb++) {
+                const uint64_t m = __ballot(my_nb == nb);
+                if (m && lane == nb) { atomicAdd(&freq[nb << 4], uint32_t(__popcll(m))); atomicAdd(&c.slot_eobh[cs * 16u + uint32_t(nb)], uint32_t(__popcll(m))); }
+            }
+        }
+#endif
     }
 }
 // long runs (flat regions, low-quality sources: a run can span a whole scan of 32 k blocks, and a single lane walking it held
@@ -593,7 +690,10 @@ __global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
         const uint32_t u = c.long_runs[2 * e + 1];
         const uint64_t *sym = c.sym_bits + w.word_base;
         uint32_t *freq = c.tables[w.table_base].freq;
-        auto count = [&](uint32_t run) { atomicAdd(&freq[(bitlen32(run) - 1) << 4], 1u); };
+        auto count = [&](uint32_t run, uint32_t owner) {   // the symbol belongs to the chunk of the block that emits it
+            const int nb = bitlen32(run) - 1;
+            atomicAdd(&freq[nb << 4], 1u); atomicAdd(&c.slot_eobh[size_t(w.first_chunk + (owner >> 8)) * 16u + uint32_t(nb)], 1u);
+        };
 #ifdef CSH_EMUL
         uint32_t t;
         eob_run_end(sym, w.nunits, u, 0xFFFFFFFFu, t);
@@ -616,7 +716,7 @@ __global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
         }
         uint16_t *er = c.eobrun + w.unit_base;
         if (sc.Ah == 0) {
-            if (lane == 0) { uint32_t L = t - u + 1, pos = u; while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); count(l); pos += l; L -= l; } }
+            if (lane == 0) { uint32_t L = t - u + 1, pos = u; while (L > 0) { uint32_t l = L < 0x7FFF ? L : 0x7FFF; er[pos] = uint16_t(l); count(l, pos); pos += l; L -= l; } }
             continue;
         }
         const uint8_t *tl = c.tail + w.unit_base;
@@ -630,14 +730,14 @@ __global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
             const uint64_t om = __ballot(over);
             if (om) {
                 const uint32_t l0 = uint32_t(__ffsll((unsigned long long)om) - 1);
-                if (lane == 0) { er[s0] = uint16_t(cnt + l0 + 1); count(cnt + l0 + 1); }
+                if (lane == 0) { er[s0] = uint16_t(cnt + l0 + 1); count(cnt + l0 + 1, s0); }
                 s0 = pos + l0 + 1; pos = s0; cnt = 0; be = 0;
             } else {
                 const uint32_t len = t - pos + 1 < 64 ? t - pos + 1 : 64;
                 be += uint32_t(__shfl(int(incl), 63, 64)); cnt += len; pos += len;
             }
         }
-        if (cnt && lane == 0) { er[s0] = uint16_t(cnt); count(cnt); }
+        if (cnt && lane == 0) { er[s0] = uint16_t(cnt); count(cnt, s0); }
 #endif
     }
 }
@@ -686,6 +786,7 @@ __global__ void k_gen_tables(DevEncTable *tables, int ntables) {
     for (int s = 0; s < 256; s++) { T.size[s] = 0; T.code[s] = 0; }
     int code = 0; p = 0;
     for (int l = 1; l <= 16; l++) { for (int k2 = 0; k2 < T.bits[l]; k2++, p++) { T.code[T.vals[p]] = uint16_t(code++); T.size[T.vals[p]] = uint8_t(l); } code <<= 1; }
+    for (int s = 0; s < 256; s++) T.lut[s] = (uint32_t(T.size[s]) << 16) | T.code[s];
 }
 #else
 // product build: one WAVE per table.  Entry e of the compacted list lives in lane e & 63, slot e >> 6 (registers).  A merge
@@ -803,7 +904,7 @@ __global__ void __launch_bounds__(256) k_gen_tables(DevEncTable *tables, int nta
     CSH_WAVE_SYNC();
     if (lane <= 16) T.bits[lane] = lane ? uint8_t(bits[lane]) : 0;
     if (lane == 0) T.nsym = nsym;
-    for (int i = lane; i < 256; i += 64) { T.vals[i] = ovals[i]; T.code[i] = ocode[i]; T.size[i] = osize[i]; }
+    for (int i = lane; i < 256; i += 64) { T.vals[i] = ovals[i]; T.code[i] = ocode[i]; T.size[i] = osize[i]; T.lut[i] = (uint32_t(osize[i]) << 16) | ocode[i]; }
 }
 #endif
 void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
@@ -815,193 +916,246 @@ void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
 }
 
 // ------------------------------------------------------------------------------------------------ tokens -> bits
-// the scan's tables in LDS: ltab[t * 256 + s] = size << 16 | code
-__device__ __forceinline__ static void stage_enc_tables(uint32_t *ltab, const DevEncTable *tab, int ntables) {
-    for (int i = threadIdx.x; i < ntables * 256; i += blockDim.x) { const DevEncTable &T = tab[i >> 8]; ltab[i] = (uint32_t(T.size[i & 255]) << 16) | T.code[i & 255]; }
+// What one token puts into the stream: at most three pieces of at most 32 bits, in order (piece i: the n[i] low bits of v[i]).
+struct Pieces { uint32_t v[3], n[3]; };
+struct TokenCtx {                 // what the packer kernels know about the slot their tokens belong to
+    const uint32_t *lut;          // the scan's tables: lut[t * lut_stride + s] = size << 16 | code   (DevEncTable::lut in HBM, or its copy in LDS)
+    uint32_t lut_stride;
+    const uint16_t *eobrun;       // of the chunk's units
+    const uint64_t *corr;         // of the chunk's units (refinement scans)
+};
+#define CSH_LUT_STRIDE uint32_t(sizeof(DevEncTable) / 4)
+__device__ __forceinline__ static void corr_pieces(Pieces &p, uint64_t corr, uint32_t t) {
+    const uint32_t cnt = (t >> 16) & 63u, cur = (t >> 22) & 63u;
+    if (!cnt) return;
+    const uint64_t bits = (corr << cur) >> (64u - cnt);   // cnt >= 1, cur + cnt <= 63
+    if (cnt > 32) { p.v[1] = uint32_t(bits >> 32); p.n[1] = cnt - 32; p.v[2] = uint32_t(bits); p.n[2] = 32; }
+    else { p.v[2] = uint32_t(bits); p.n[2] = cnt; }
 }
-// one token through a bit sink (put(value, n bits)); `run` = the unit's EOBRUN (0: it owns none)
-template <class Sink>
-__device__ __forceinline__ static void token_bits(Sink &s, uint32_t t, const uint32_t *ltab, unsigned run) {
-    const uint32_t kind = t & 3u;
+// MODE names what the scan's tokens can be, so that a wave does not walk through the code of kinds it cannot meet:
+// 0 anything, 1 first-pass AC scan (ACF, EOB), 2 refinement scan (REF, EOB, empty RAW), 3 DC or sequential-mode scan (SYM, RAW)
+template <int MODE = 0>
+__device__ __forceinline__ static Pieces token_pieces(uint32_t t, const TokenCtx &x) {
+    Pieces p;
+    p.v[0] = p.v[1] = p.v[2] = 0; p.n[0] = p.n[1] = p.n[2] = 0;
+    uint32_t kind = t & 7u;
+    if (MODE == 1) { if (kind == TK_RAW) return p; kind = kind == TK_ACF ? uint32_t(TK_ACF) : uint32_t(TK_EOB); }   // RAW: the empty token behind a segment's end
+    if (MODE == 2) { if (kind == TK_RAW) return p; kind = kind == TK_REF ? uint32_t(TK_REF) : uint32_t(TK_EOB); }
+    if (MODE == 3) kind = kind == TK_SYM ? uint32_t(TK_SYM) : uint32_t(TK_RAW);
     if (kind == TK_SYM) {
-        const uint32_t e = ltab[((t >> 10) & 3u) * 256u + ((t >> 2) & 255u)];
-        s.put(e & 0xFFFFu, int(e >> 16));
-        s.put(t >> 16, int((t >> 12) & 15u));
-    } else if (kind == TK_RAW) s.put(t >> 16, int((t >> 12) & 15u));
+        const uint32_t e = x.lut[((t >> 11) & 3u) * x.lut_stride + ((t >> 3) & 255u)], nr = (t >> 13) & 15u;
+        p.v[0] = ((e & 0xFFFFu) << nr) | (t >> 17); p.n[0] = (e >> 16) + nr;            // <= 16 + 15 bits
+    } else if (kind == TK_RAW) { p.v[0] = t >> 17; p.n[0] = (t >> 13) & 15u; }
     else if (kind == TK_ACF) {
-        const uint32_t r = (t >> 2) & 63u, nb = (t >> 8) & 15u;
-        if (r >> 4) { const uint32_t z = ltab[0xF0]; for (uint32_t i = 0; i < (r >> 4); i++) s.put(z & 0xFFFFu, int(z >> 16)); }
-        const uint32_t e = ltab[((r & 15u) << 4) | nb];
-        s.put(e & 0xFFFFu, int(e >> 16));
-        s.put((t >> 12) & 0xFFFFu, int(nb));
-    } else if (run) {
-        const int nb = bitlen32(run) - 1;
-        const uint32_t e = ltab[nb << 4];
-        s.put(e & 0xFFFFu, int(e >> 16));
-        s.put(run & ((1u << nb) - 1u), nb);
+        const uint32_t r = (t >> 3) & 63u, nb = (t >> 9) & 15u, zr = r >> 4;
+        if (zr) {
+            const uint32_t z = x.lut[0xF0], zc = z & 0xFFFFu, zl = z >> 16;
+            p.v[0] = zc; p.n[0] = zl;
+            if (zr > 1) { p.v[0] = (zc << zl) | zc; p.n[0] = 2 * zl; }
+            if (zr > 2) { p.v[1] = zc; p.n[1] = zl; }
+        }
+        const uint32_t e = x.lut[((r & 15u) << 4) | nb];
+        p.v[2] = ((e & 0xFFFFu) << nb) | ((t >> 13) & 0xFFFFu); p.n[2] = (e >> 16) + nb;   // <= 16 + 15 bits
+    } else if (kind == TK_REF) {
+        const uint32_t unit = (t >> 3) & 255u;
+        if (t & (1u << 28)) { const uint32_t e = x.lut[0xF0]; p.v[0] = e & 0xFFFFu; p.n[0] = e >> 16; }
+        else { const uint32_t e = x.lut[(((t >> 11) & 15u) << 4) | 1u]; p.v[0] = ((e & 0xFFFFu) << 1) | ((t >> 15) & 1u); p.n[0] = (e >> 16) + 1; }
+        if ((t >> 16) & 63u) corr_pieces(p, x.corr[unit], t);
+    } else {   // TK_EOB
+        const uint32_t unit = (t >> 3) & 255u;
+        const uint32_t run = x.eobrun[unit];
+        if (run) {
+            const int nb = bitlen32(run) - 1;
+            const uint32_t e = x.lut[nb << 4];
+            p.v[0] = ((e & 0xFFFFu) << nb) | (run & ((1u << nb) - 1u)); p.n[0] = (e >> 16) + uint32_t(nb);   // <= 16 + 14 bits
+        }
+        if ((t >> 16) & 63u) corr_pieces(p, x.corr[unit], t);
     }
+    return p;
 }
-struct BitCount {
-    uint32_t bits;
-    __device__ __forceinline__ void put(unsigned, int n) { bits += uint32_t(n); }
-};
+__device__ __forceinline__ static TokenCtx token_ctx(const EncCtx &c, const SlotRec &r) {
+    TokenCtx x;
+    x.lut = c.tables[r.table_base].lut; x.lut_stride = CSH_LUT_STRIDE;
+    x.eobrun = c.eobrun + r.unit0;
+    x.corr = c.corr + r.unit0;
+    return x;
+}
+// four consecutive tokens of the chunk, starting at i (one 16-byte load where all four exist: the pool is 16-byte aligned per chunk only
+// by chance, so the load is of single words)
+__device__ __forceinline__ static void load4(const uint32_t *tk, uint32_t i, uint32_t n, uint32_t (&t)[4]) {
+    CSH_UNROLL
+    for (int q = 0; q < 4; q++) t[q] = i + uint32_t(q) < n ? tk[i + uint32_t(q)] : uint32_t(TK_RAW);
+}
 
-// ---- pass E: size in bits of every chunk.  Flat over the chunk's tokens (coalesced), plus the EOBRUN symbols its units own.
+// ---- pass E: size in bits of every chunk: ONE WAVE per (scan, chunk) slot.  No token is read: the chunk's symbol counts (k_tokens kept
+// them per slot), the code lengths, the raw bits k_tokens counted, and the EOBRUN symbols k_ac_runs counted per slot.
 __global__ void __launch_bounds__(256) k_chunk_sizes(EncCtx c) {
-    CSH_SHARED uint32_t ltab[4 * 256];
-    CSH_SHARED uint32_t s_sum;
-    const uint32_t cs = blockIdx.x;
-    const ScanWork w = c.work[c.slot_work[cs]];
-    const EncScan &sc = c.script[w.scan];
-    CSH_PHASE_LOOP(3) {
-        if (phase == 0) { stage_enc_tables(ltab, c.tables + w.table_base, sc.ntables); if (threadIdx.x == 0) s_sum = 0; continue; }
-        if (phase == 2) { if (threadIdx.x == 0) c.chunk_bits[cs] = s_sum; continue; }
-        BitCount b; b.bits = 0;
-        const uint32_t n = c.chunk_ntok[cs];
-        const uint32_t *tk = c.tokens + c.tok_off[cs];
-        for (uint32_t i = threadIdx.x; i < n; i += 256) token_bits(b, tk[i], ltab, 0u);
-        const uint32_t u = (cs - w.first_chunk) * 256u + threadIdx.x;
-        if (sc.Ss > 0 && !sc.sequential && u < w.nunits) {
-            const unsigned run = c.eobrun[w.unit_base + u];
-            if (run) { const int nb = bitlen32(run) - 1; b.bits += (ltab[nb << 4] >> 16) + uint32_t(nb); }
-        }
-        if (b.bits) atomicAdd(&s_sum, b.bits);
+    const uint32_t cs = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = lane_id();
+    if (cs >= c.nslots) return;
+    const SlotRec r = c.slots[cs];
+#ifdef CSH_EMUL
+    if (lane) return;
+    uint32_t bits = c.slot_raw[cs];
+    for (uint32_t t = 0; t < r.ntables; t++)
+        for (uint32_t sy = 0; sy < 256; sy++) bits += uint32_t(c.slot_hist[size_t(r.hist_row + t) * 256u + sy]) * c.tables[r.table_base + t].size[sy];
+    if (r.flags & 1u) for (uint32_t nb = 0; nb < 15; nb++) bits += c.slot_eobh[cs * 16u + nb] * (uint32_t(c.tables[r.table_base].size[nb << 4]) + nb);
+    c.chunk_bits[cs] = bits;
+#else
+    uint32_t bits = lane == 0 ? c.slot_raw[cs] : 0u;
+    for (uint32_t t = 0; t < r.ntables; t++) {
+        const uint2 h = reinterpret_cast<const uint2 *>(c.slot_hist + size_t(r.hist_row + t) * 256u)[lane];          // symbols 4 lane .. 4 lane + 3
+        const uint32_t z = reinterpret_cast<const uint32_t *>(c.tables[r.table_base + t].size)[lane];
+        bits += (h.x & 0xFFFFu) * (z & 255u) + (h.x >> 16) * ((z >> 8) & 255u) + (h.y & 0xFFFFu) * ((z >> 16) & 255u) + (h.y >> 16) * (z >> 24);
     }
+    if ((r.flags & 1u) && lane < 15) bits += c.slot_eobh[cs * 16u + uint32_t(lane)] * (uint32_t(c.tables[r.table_base].size[lane << 4]) + uint32_t(lane));
+    CSH_UNROLL
+    for (int o = 32; o >= 1; o >>= 1) bits += uint32_t(__shfl_xor(int(bits), o, 64));
+    if (lane == 0) c.chunk_bits[cs] = bits;
+#endif
 }
 
-// ---- pass G: pack.  Bits are gathered in a 64-bit accumulator and leave as whole big-endian-logical 32-bit words.  Only the first
-// and the last word of a unit's bit string can be shared with a neighbouring unit, so only those two need an atomic OR; the words in
-// between are exclusively this lane's and are stored plainly (the target is zero-initialised).  The target is the workgroup's LDS bit
-// buffer, or -- chunks too large for it -- the raw pool itself.
-struct PackSink {
-    uint32_t *words;
-    uint64_t pos;      // bit position (relative to words) of the next bit to emit
-    uint64_t acc;      // pending bits, right-aligned
-    int nacc;          // number of pending bits (< 32 after every put)
-    bool first;        // the next word written is the unit's first (possibly shared) word
-    __device__ __forceinline__ void begin(uint32_t *w, uint64_t p) { words = w; pos = p; nacc = int(p & 31); acc = 0; first = true; }
-    __device__ __forceinline__ void put(unsigned v, int n) {
-        if (n == 0) return;
-        v &= (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
-        acc = (acc << n) | v;
-        nacc += n;
-        pos += n;
-        if (nacc >= 32) {
-            uint32_t w = uint32_t(acc >> (nacc - 32));
-            uint64_t wi = (pos - uint64_t(nacc)) >> 5;   // word that holds the oldest pending bit
-            if (first) { if (w) atomicOr(words + wi, w); first = false; }
-            else words[wi] = w;
-            nacc -= 32;
-            acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
+// ---- pass G: pack: ONE WAVE per slot.  256 tokens at a time, four per lane: their pieces, a wave scan of the lengths, every lane ORs
+// its pieces into the wave's LDS window of the bit stream (the window is word-aligned with the raw pool, so flushing it is a plain
+// copy: only the chunk's first and last word can be shared with a neighbouring chunk and need an atomic OR; the pool is
+// zero-initialised).  The scan's tables, the units' EOBRUNs and correction words are staged in LDS first: everything a token needs
+// is then one LDS read away.
+__device__ __forceinline__ static void or_bits(uint32_t *words, uint64_t pos, uint32_t v, uint32_t n) {   // n in 1..32, at bit `pos` of a big-endian-logical word array
+    v &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    const uint64_t t = uint64_t(v) << (64u - n - uint32_t(pos & 31u));
+    const uint32_t hi = uint32_t(t >> 32), lo = uint32_t(t);
+    if (hi) atomicOr(words + (pos >> 5), hi);
+    if (lo) atomicOr(words + (pos >> 5) + 1, lo);
+}
+#define CSH_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#ifndef CSH_EMUL
+struct PackState { uint32_t *buf, *out; uint64_t pos; uint32_t ww; bool first_flush; };
+template <int MODE>
+__device__ __forceinline__ static void pack_segments(const EncCtx &c, const TokenCtx &x, PackState &S, uint32_t cs, uint32_t pad, int lane) {
+    uint32_t *buf = S.buf, *out = S.out;
+    uint64_t pos = S.pos;
+    uint32_t ww = S.ww;
+    bool first_flush = S.first_flush;
+    const uint32_t seg_n = lane < 4 ? c.chunk_ntok[cs * 4u + uint32_t(lane)] : 0u;              // the slot's four segments (one per wave of k_tokens)
+    const unsigned long long seg_o = lane < 4 ? c.tok_off[cs * 4u + uint32_t(lane)] : 0ull;
+    for (int seg = 0; seg < 4; seg++) {
+    const uint32_t n = uint32_t(__shfl(int(seg_n), seg, 64));
+    const uint32_t *tk = c.tokens + ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o)), seg, 64)) | ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o >> 32)), seg, 64)) << 32));
+    const uint32_t n_ext = n + ((pad && seg == 3) ? 1u : 0u);      // the byte fill of the scan's last chunk rides as one more token
+    for (uint32_t i0 = 0; i0 < n_ext; i0 += 256) {
+        const uint32_t i = i0 + 4u * uint32_t(lane);
+        uint32_t t[4];
+        load4(tk, i, n, t);
+        Pieces p[4];
+        uint32_t len = 0;
+        CSH_UNROLL
+        for (int q = 0; q < 4; q++) {
+            p[q] = token_pieces<MODE>(t[q], x);
+            if (pad && seg == 3 && i + uint32_t(q) == n) { p[q].v[0] = (1u << pad) - 1u; p[q].n[0] = pad; }
+            len += p[q].n[0] + p[q].n[1] + p[q].n[2];
         }
-    }
-    __device__ __forceinline__ void finish() {
-        if (nacc == 0) return;
-        uint32_t w = uint32_t(acc << (32 - nacc));
-        uint64_t wi = (pos - uint64_t(nacc)) >> 5;
-        if (w) atomicOr(words + wi, w);
-        nacc = 0;
-    }
-};
-
-__global__ void __launch_bounds__(256) k_pack(EncCtx c) {
-    CSH_SHARED uint32_t ltab[4 * 256];
-    CSH_SHARED uint32_t tstage[CSH_TK_STAGE];
-    CSH_SHARED uint32_t bitbuf[CSH_PK_WORDS + 2];
-    CSH_SHARED uint32_t a_cnt[256], a_first[256], a_size[256], a_off[256], w_tok[4], w_bit[4];
-    const uint32_t cs = blockIdx.x;
-    const ScanWork w = c.work[c.slot_work[cs]];
-    const EncScan &sc = c.script[w.scan];
-    const int tid = int(threadIdx.x), lane = lane_id(), wv = tid >> 6;
-    const uint32_t nch = (w.nunits + 255u) / 256u, j = cs - w.first_chunk;
-    const uint32_t u = j * 256u + uint32_t(tid);
-    const bool valid = u < w.nunits;
-    const uint32_t ntok_chunk = c.chunk_ntok[cs];
-    const bool staged = ntok_chunk <= CSH_TK_STAGE;
-    const uint32_t *tk = staged ? tstage : c.tokens + c.tok_off[cs];
-    // the chunk's place: bits [raw_bit0, raw_bit0 + nbits) of the raw pool; the scan's last chunk also carries the 1-bits that fill the last byte
-    const uint64_t scan0 = c.chunk_off[w.first_chunk];
-    const uint64_t raw_bit0 = w.raw_off * 8 + (c.chunk_off[cs] - scan0);
-    uint32_t nbits = c.chunk_bits[cs];
-    int pad = 0;
-    if (j == nch - 1) { const uint64_t total = c.chunk_off[w.first_chunk + nch] - scan0; pad = int((8 - (total & 7)) & 7); nbits += uint32_t(pad); }
-    const bool in_lds = nbits <= CSH_PK_WORDS * 32u;
-    const bool is_ac = sc.Ss > 0 && !sc.sequential;
-    CSH_PHASE_LOOP(6) {
-        if (w.no_room) { if (phase == 0 && tid == 0) c.status[w.image] = 20200; continue; }   // decided per scan by k_scan_place
-        if (phase == 0) {
-            stage_enc_tables(ltab, c.tables + w.table_base, sc.ntables);
-            a_cnt[tid] = valid ? uint32_t(c.unit_ntok[w.unit_base + u]) : 0u;
-            if (staged) { const uint32_t *src = c.tokens + c.tok_off[cs]; for (uint32_t i = uint32_t(tid); i < ntok_chunk; i += 256) tstage[i] = src[i]; }
-            if (in_lds) for (uint32_t i = uint32_t(tid); i < (nbits + 31u) / 32u + 2u; i += 256) bitbuf[i] = 0;
-            continue;
+        uint32_t incl = len;
+        CSH_UNROLL
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = uint32_t(__shfl_up(int(incl), o, 64)); if (lane >= o) incl += tt; }
+        uint64_t at = pos + incl - len - uint64_t(ww) * 32u;    // bit position inside the window
+        CSH_UNROLL
+        for (int q = 0; q < 4; q++) {
+            CSH_UNROLL
+            for (int k = 0; k < 3; k++) if (p[q].n[k]) { or_bits(buf, at, p[q].v[k], p[q].n[k]); at += p[q].n[k]; }
         }
-        if (phase == 1) {   // first token of every unit: scan of the counts inside each wave ...
-            const uint32_t incl = wave_incl_scan(a_cnt + 64 * wv, lane);
-            a_first[tid] = incl - a_cnt[tid];
-            if (lane == 63) w_tok[wv] = incl;
-            continue;
-        }
-        if (phase == 2) {   // ... and across the waves; then the size of every unit
-            uint32_t first = a_first[tid];
-            for (int q = 0; q < wv; q++) first += w_tok[q];
-            const bool sane = w_tok[0] + w_tok[1] + w_tok[2] + w_tok[3] == ntok_chunk;   // a pool that overflowed leaves stale counts behind: nothing is read then
-            BitCount b; b.bits = 0;
-            if (valid && sane) {
-                const unsigned run = is_ac ? unsigned(c.eobrun[w.unit_base + u]) : 0u;
-                const uint32_t n = a_cnt[tid];
-                for (uint32_t i = 0; i < n; i++) token_bits(b, tk[first + i], ltab, run);
-                if (u == w.nunits - 1) b.bits += uint32_t(pad);
+        pos += uint32_t(__shfl(int(incl), 63, 64));
+        // slide the window when another 256 tokens' worth of bits (256 x 96) might not fit any more
+        const uint32_t done = uint32_t(pos >> 5) - ww;   // complete words in the window
+        if (done > CSH_PK_WORDS - 770) {
+            CSH_WAVE_FENCE();
+            for (uint32_t q = uint32_t(lane); q < done; q += 64) {
+                const uint32_t v = buf[q];
+                if (first_flush && q == 0) { if (v) atomicOr(out + ww, v); } else out[ww + q] = v;
             }
-            a_first[tid] = sane ? first : 0xFFFFFFFFu;
-            a_size[tid] = b.bits;
-            continue;
-        }
-        if (phase == 3) {   // bit offsets: the same two steps
-            const uint32_t incl = wave_incl_scan(a_size + 64 * wv, lane);
-            a_off[tid] = incl - a_size[tid];
-            if (lane == 63) w_bit[wv] = incl;
-            continue;
-        }
-        if (phase == 4) {   // pack
-            uint32_t off = a_off[tid];
-            for (int q = 0; q < wv; q++) off += w_bit[q];
-            const uint32_t first = a_first[tid];
-            if (!valid || first == 0xFFFFFFFFu) continue;
-            const uint32_t n = a_cnt[tid];
-            const unsigned run = is_ac ? unsigned(c.eobrun[w.unit_base + u]) : 0u;
-            PackSink s;
-            if (in_lds) s.begin(bitbuf, uint64_t(off)); else s.begin(c.raw, raw_bit0 + off);
-            for (uint32_t i = 0; i < n; i++) token_bits(s, tk[first + i], ltab, run);
-            if (u == w.nunits - 1 && pad) s.put((1u << pad) - 1u, pad);
-            s.finish();
-            continue;
-        }
-        // phase 5: the LDS bit buffer moves to its place, shifted by the chunk's bit offset inside its first word
-        if (!in_lds || nbits == 0) continue;
-        const uint32_t sh = uint32_t(raw_bit0 & 31u);
-        const uint64_t w0 = raw_bit0 >> 5;
-        const uint32_t nout = (sh + nbits + 31u) >> 5;
-        for (uint32_t i = uint32_t(tid); i < nout; i += 256) {
-            const uint32_t lo = bitbuf[i], hi = i ? bitbuf[i - 1] : 0u;   // the buffer is zero behind the chunk's last word
-            const uint32_t v = sh ? ((hi << (32u - sh)) | (lo >> sh)) : lo;
-            if (i == 0 || i == nout - 1) { if (v) atomicOr(c.raw + w0 + i, v); }
-            else c.raw[w0 + i] = v;
+            const uint32_t partial = buf[done];
+            CSH_WAVE_FENCE();
+            for (int q = lane; q < CSH_PK_WORDS; q += 64) buf[q] = (q == 0) ? partial : 0u;
+            CSH_WAVE_FENCE();
+            ww += done; first_flush = false;
         }
     }
+    }
+    S.pos = pos; S.ww = ww; S.first_flush = first_flush;
+}
+#endif
+__global__ void __launch_bounds__(256) k_pack(EncCtx c) {
+    const int wv = int(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t cs = blockIdx.x * 4u + uint32_t(wv);
+    if (cs >= c.nslots) return;
+    const SlotRec r = c.slots[cs];
+    const ScanWork &w = c.work[r.work];
+    if (w.no_room) { if (lane == 0) c.status[w.image] = 20200; return; }   // decided per scan by k_scan_place
+    TokenCtx x = token_ctx(c, r);
+    // the chunk's place: bits [raw_bit0, raw_bit0 + nbits) of the raw pool; the scan's last chunk also carries the 1-bits that fill the last byte
+    const uint64_t scan0 = c.chunk_off[r.first_chunk];
+    const uint64_t raw_bit0 = w.raw_off * 8 + (c.chunk_off[cs] - scan0);
+    uint32_t pad = 0;
+    if (r.j == r.nch - 1) { const uint64_t total = c.chunk_off[r.first_chunk + r.nch] - scan0; pad = uint32_t((8 - (total & 7)) & 7); }
+#ifdef CSH_EMUL
+    // the same pieces, one after the other, straight into the pool
+    if (lane) return;
+    uint64_t pos = raw_bit0;
+    for (uint32_t seg = 0; seg < 4; seg++) {
+        const uint32_t n = c.chunk_ntok[cs * 4u + seg];
+        const uint32_t *tk = c.tokens + c.tok_off[cs * 4u + seg];
+        for (uint32_t i = 0; i < n; i++) {
+            const Pieces p = token_pieces(tk[i], x);
+            for (int q = 0; q < 3; q++) if (p.n[q]) { or_bits(c.raw, pos, p.v[q], p.n[q]); pos += p.n[q]; }
+        }
+    }
+    if (pad) or_bits(c.raw, pos, (1u << pad) - 1u, pad);
+#else
+    __shared__ uint32_t win[4][CSH_PK_WORDS];
+    __shared__ uint32_t s_lut[4][2][256];
+    __shared__ uint16_t s_eob[4][256];
+    __shared__ uint64_t s_corr[4][256];
+    uint32_t *buf = win[wv];
+    // stage (uniform branches: one scan per wave)
+    if (r.ntables <= 2) {
+        for (int i = lane; i < int(r.ntables) * 256; i += 64) s_lut[wv][i >> 8][i & 255] = x.lut[(i >> 8) * CSH_LUT_STRIDE + (i & 255)];
+        x.lut = &s_lut[wv][0][0]; x.lut_stride = 256;
+    }
+    if (r.flags & 1u) {
+        for (int i = lane; i < 256; i += 64) s_eob[wv][i] = uint32_t(i) < r.nun ? x.eobrun[i] : uint16_t(0);
+        x.eobrun = s_eob[wv];
+        if (r.flags & 2u) { for (int i = lane; i < 256; i += 64) s_corr[wv][i] = uint32_t(i) < r.nun ? x.corr[i] : 0ull; x.corr = s_corr[wv]; }
+    }
+    for (int i = lane; i < CSH_PK_WORDS; i += 64) buf[i] = 0;
+    uint32_t *out = c.raw + (raw_bit0 >> 5);        // word 0 of the frame below
+    uint64_t pos = raw_bit0 & 31u;                   // next bit, in the frame whose word 0 is the chunk's first word in the pool
+    uint32_t ww = 0;                                 // first word of the window
+    bool first_flush = true;
+    CSH_WAVE_FENCE();
+    PackState S; S.buf = buf; S.out = out; S.pos = pos; S.ww = ww; S.first_flush = first_flush;
+    if (!(r.flags & 1u)) pack_segments<3>(c, x, S, cs, pad, lane);
+    else if (r.flags & 2u) pack_segments<2>(c, x, S, cs, pad, lane);
+    else pack_segments<1>(c, x, S, cs, pad, lane);
+    pos = S.pos; ww = S.ww; first_flush = S.first_flush;
+    CSH_WAVE_FENCE();
+    const uint32_t last = uint32_t((pos + 31) >> 5) - ww;   // words in the window that carry bits
+    for (uint32_t q = uint32_t(lane); q < last; q += 64) {
+        const uint32_t v = buf[q];
+        if ((first_flush && q == 0) || q == last - 1) { if (v) atomicOr(out + ww + q, v); } else out[ww + q] = v;
+    }
+#endif
 }
 
-void launch_tokens(hipStream_t st, const EncCtx &c) { if (c.nechunks) CSH_LAUNCH_PHASED(k_tokens, 5, dim3(c.nechunks), dim3(256), st, c); }
+void launch_tokens(hipStream_t st, const EncCtx &c) { if (c.nechunks) CSH_LAUNCH_PHASED(k_tokens, 6, dim3(c.nechunks), dim3(256), st, c); }
 void launch_ac_runs(hipStream_t st, const EncCtx &c) {
     if (!c.nslots) return;
-    CSH_LAUNCH_PHASED(k_ac_runs, 3, dim3(c.nslots), dim3(256), st, c);
+    CSH_LAUNCH(k_ac_runs, dim3((c.nslots + 3) / 4), dim3(256), st, c);
 #ifdef CSH_EMUL
     CSH_LAUNCH(k_ac_runs_long, dim3(64), dim3(1), st, c);
 #else
     CSH_LAUNCH(k_ac_runs_long, dim3(4096), dim3(64), st, c);
 #endif
 }
-void launch_chunk_sizes(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH_PHASED(k_chunk_sizes, 3, dim3(c.nslots), dim3(256), st, c); }
-void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH_PHASED(k_pack, 6, dim3(c.nslots), dim3(256), st, c); }
+void launch_chunk_sizes(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH(k_chunk_sizes, dim3((c.nslots + 3) / 4), dim3(256), st, c); }
+void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH(k_pack, dim3((c.nslots + 3) / 4), dim3(256), st, c); }
 
 }  // namespace csh

@@ -65,7 +65,9 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     int nwork;
     const EChunk *echunks;     // the token kernel's grid
     uint32_t nechunks;
+    const TokPlan *plans;      // what its kind-0 chunks need, per (image, component)
     const uint32_t *slot_work; // per slot (work item, 256-unit chunk): its work item -- the grid of the per-scan kernels
+    const SlotRec *slots;      // the same slots, with what the packer kernels need of them
     uint32_t nslots;
     const int16_t *coef;       // coefficients to code (tiles)
     uint64_t *sym_bits;        // per AC scan: bit b set iff block b emits >=1 Huffman symbol in this scan
@@ -73,12 +75,15 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint8_t *tail;             // per unit: # of correction bits left over at the end of the block (refine scans)
     uint16_t *eobrun;          // per unit: EOBRUN value this block must emit at its EOB token (0 = none)
     uint32_t *long_runs, *long_cnt;   // runs longer than 512 blocks: (work item, first block) pairs for k_ac_runs_long
-    uint16_t *unit_ntok;       // per unit: number of tokens
+    uint64_t *corr;            // per unit (refinement scans): its correction bits in stream order, left-aligned
     uint32_t *tokens;          // token pool
-    uint64_t tok_cap;          // its capacity in tokens
-    unsigned long long *tok_cursor;   // [1] bump allocator of the pool
-    uint64_t *tok_off;         // per slot: first token
-    uint32_t *chunk_ntok;      // per slot: number of tokens
+    const TokRegion *regions;  // its regions (EChunk::region)
+    uint32_t *tok_cursor;      // per region: tokens handed out
+    uint64_t *tok_off;         // per segment (slot x 4 + wave of k_tokens): first token
+    uint32_t *chunk_ntok;      // per segment: number of tokens
+    uint16_t *slot_hist;       // per slot: ntables rows of 256 symbol counts (EOBRUN symbols excluded)
+    uint32_t *slot_raw;        // per slot: raw bits (EOBRUN bits excluded)
+    uint32_t *slot_eobh;       // per slot: [16] EOBn symbols owned by its units
     uint32_t *chunk_bits;      // per slot: size in bits of everything the chunk emits
     const uint64_t *chunk_off; // exclusive scan of chunk_bits over the whole batch
     DevEncTable *tables;       // [ntables]
@@ -86,6 +91,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint64_t raw_words;        // capacity of raw in u32 words
     uint32_t *status;          // per image
     uint32_t *overflow;        // [4]: [1] = the token pool was too small
+    uint32_t debug;            // CSH_DEBUG: performance experiments (parts of k_tokens switched off; output is then garbage)
 };
 void launch_tokens(hipStream_t st, const EncCtx &c);
 void launch_ac_runs(hipStream_t st, const EncCtx &c);

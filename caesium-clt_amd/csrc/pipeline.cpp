@@ -101,8 +101,15 @@ struct csh_batch {
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
     std::vector<uint32_t> slot_work;      // per (work item, 256-unit chunk) slot: its work item
+    std::vector<SlotRec> slots;
+    std::vector<TokPlan> plans;
+    std::vector<int> plan_comp, plan_image;
     std::vector<EChunk> echunks;          // the token kernel's workgroups
-    uint64_t tok_cap = 0;                 // token pool capacity (grows on overflow)
+    uint64_t tok_cap = 0;                 // token pool capacity: the sum of the regions
+    uint32_t tok_scale = 1;               // grows on overflow
+    std::vector<TokRegion> regions;       // one per TokPlan, then one per DC / sequential work item
+    std::vector<uint32_t> region_est;     // estimated tokens of each (x tok_scale = its capacity)
+    uint32_t hist_rows = 0;               // rows of 256 symbol counts over all slots
     PinnedBytes bits_pool;
     std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
@@ -136,6 +143,8 @@ struct csh_batch {
     DevBuf<ScanWork> d_swork;
     DevBuf<uint32_t> d_slot_work;
     DevBuf<EChunk> d_echunks;
+    DevBuf<SlotRec> d_slots;
+    DevBuf<TokPlan> d_plans;
     DevBuf<int16_t> d_coef, d_dct_raw;
     DevBuf<csw::WebpImg> d_wimgs;
     DevBuf<uint8_t> d_wwork, d_wscratch;
@@ -143,10 +152,11 @@ struct csh_batch {
     DevBuf<uint8_t> d_wprobs, d_wupdate;
     uint32_t wmax_mbh = 0;
     DevBuf<int16_t> d_wlevels;
-    DevBuf<uint64_t> d_symbits, d_eobbits, d_tok_off, d_chunk_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
-    DevBuf<unsigned long long> d_tok_cursor;
-    DevBuf<uint16_t> d_eobrun, d_unit_ntok;
-    DevBuf<uint32_t> d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
+    DevBuf<uint64_t> d_corr, d_symbits, d_eobbits, d_tok_off, d_chunk_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
+    DevBuf<uint32_t> d_tok_cursor;
+    DevBuf<TokRegion> d_regions;
+    DevBuf<uint16_t> d_eobrun, d_slot_hist;
+    DevBuf<uint32_t> d_slot_raw, d_slot_eobh, d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
 
@@ -367,6 +377,17 @@ extern "C" int csh_batch_create(const CByteArray *inputs, size_t count, const CC
 extern "C" int csh_batch_create_pixels(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, false, out, true); }
 // JPEG in, WebP out (caesium::convert_in_memory to SupportedFileTypes::WebP, compressor.rs:289,300): same decode and resize, then the VP8 encoder
 extern "C" int csh_batch_create_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out) { return batch_create(inputs, count, p, device, true, out); }
+// token pool (k_entropy.hip): every region gets its estimate x tok_scale (the scale grows on overflow, like the other pools)
+static void layout_token_pool(csh_batch *b) {
+    b->regions.resize(b->region_est.size());
+    uint64_t at = 0;
+    for (size_t i = 0; i < b->regions.size(); i++) {
+        const uint64_t cap = std::min<uint64_t>(uint64_t(b->region_est[i]) * b->tok_scale, 0xFFFFFFF0ull);
+        b->regions[i].base = at; b->regions[i].cap = uint32_t(cap); b->regions[i].pad = 0;
+        at += (cap + 3) & ~uint64_t(3);
+    }
+    b->tok_cap = at + 64;
+}
 static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out, const csp_pixels *px) {
     *out = nullptr;
     if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
@@ -729,8 +750,25 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->max_units = std::max(b->max_units, w.nunits);
             w.first_chunk = uint32_t(b->slot_work.size());
             b->slot_work.insert(b->slot_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
+            for (uint32_t j = 0, nch = (w.nunits + 255) / 256; j < nch; j++) {
+                SlotRec r;
+                r.work = uint32_t(b->swork.size()); r.j = j; r.nch = nch; r.first_chunk = w.first_chunk; r.unit0 = w.unit_base + 256 * j;
+                r.nun = std::min<uint32_t>(256, w.nunits - 256 * j); r.table_base = w.table_base; r.ntables = uint16_t(e.ntables);
+                r.flags = uint16_t((e.Ss > 0 && !e.sequential ? 1 : 0) | (e.Ss > 0 && !e.sequential && e.Ah ? 2 : 0));
+                r.hist_row = b->hist_rows; b->hist_rows += uint32_t(e.ntables);
+                r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
+                r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                b->slots.push_back(r);
+            }
             if (e.Ss == 0 || e.sequential)   // DC scans and sequential-mode scans: one token workgroup per (scan, 256 units)
-                for (uint32_t j = 0; j < (w.nunits + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(b->swork.size()), 0, 1, j});
+            {
+                // tokens of a DC scan are known exactly (one per block, or one per fifteen blocks' bits); a sequential-mode block has at most 64 + 3
+                uint32_t blocks = 0;
+                for (int k = 0; k < e.ncomp; k++) blocks += e.ncomp > 1 ? uint32_t(o.comp[e.comp[k]].h * o.comp[e.comp[k]].v) : 1u;
+                const uint32_t per_unit = e.sequential ? blocks * 20u : (e.Ah ? (blocks + 14u) / 15u : blocks);
+                for (uint32_t j = 0; j < (w.nunits + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(b->swork.size()), 0, 1, j, 0, uint32_t(b->region_est.size())});
+                b->region_est.push_back(w.nunits * per_unit + 64);
+            }
             b->swork.push_back(w);
         }
         if (progressive)   // the AC scans of a component share one pass over its blocks
@@ -739,7 +777,27 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 for (int s = 0; s < ns; s++) { const EncScan &e = b->script[sb + s]; if (e.Ss > 0 && e.comp[0] == c) { nac++; if (e.Al > (e.Ah ? 3 : 4)) nac = 99; } }
                 if (nac > CSH_TK_MAXSLOT) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "internal: output scan script outside what the token kernel carries"; }
                 const uint32_t nu = uint32_t(im.out[c].real_bw * im.out[c].real_bh);
-                if (nac) for (uint32_t j = 0; j < (nu + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(img_index), uint16_t(c), 0, j});
+                if (!nac || nac > CSH_TK_MAXSLOT) continue;
+                TokPlan P;
+                memset(&P, 0, sizeof P);
+                P.nunits = nu; P.real_bw = im.out[c].real_bw; P.bw = im.out[c].bw; P.tile_base = im.out[c].tile_base;   // tile_base of re-quantised tiles is rebased below
+                for (int s = 0; s < ns; s++) {
+                    const EncScan &e = b->script[sb + s];
+                    if (!(e.Ss > 0 && e.comp[0] == c)) continue;
+                    const ScanWork &w = b->swork[size_t(im.first_work) + s];
+                    AcSlot &a = P.s[P.nslot++];
+                    a.unit_base = w.unit_base; a.word_base = w.word_base; a.first_chunk = w.first_chunk; a.table_base = w.table_base; a.nunits_work = w.nunits;
+                    a.Ss = uint8_t(e.Ss); a.Se = uint8_t(e.Se); a.Ah = uint8_t(e.Ah); a.Al = uint8_t(e.Al);
+                }
+                {   // every non-zero coefficient becomes a token in exactly one scan (~5 bits of a source file each), plus an EOB per block and scan
+                    uint64_t blocks_all = 0;
+                    for (int k = 0; k < in.ncomp; k++) blocks_all += uint64_t(im.out[k].real_bw) * im.out[k].real_bh;
+                    const uint64_t est = uint64_t(inputs[n].length) * 3 * nu / std::max<uint64_t>(1, blocks_all) + uint64_t(nu) * nac + 1024;
+                    for (uint32_t j = 0; j < (nu + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(img_index), uint16_t(c), 0, j, uint32_t(b->plans.size()), uint32_t(b->region_est.size())});
+                    b->region_est.push_back(uint32_t(std::min<uint64_t>(est, 0x3FFFFFFFu)));
+                }
+                b->plan_comp.push_back(c); b->plan_image.push_back(img_index);
+                b->plans.push_back(P);
             }
         if (b->total_units > 0xFFFFFFF0ull) { it.code = CS_ERR_POOL_OVERFLOW; it.msg = "batch too large"; }
 
@@ -770,6 +828,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
     if (!b->lossless)
         for (ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) im.out[c].tile_base += b->ntiles_in;
+    for (size_t i = 0; i < b->plans.size(); i++) b->plans[i].tile_base = b->imgs[size_t(b->plan_image[i])].out[b->plan_comp[i]].tile_base;
     for (ParScan &ps : b->pscans)   // table selectors: slot numbers of the table-set form the batch uses
         for (int m = 0; m < ps.nb_mcu && m < 10; m++) {
             int dcs = ps.dct[m] & 3, acs = 4 + (ps.act[m] & 3);
@@ -780,8 +839,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     b->plane_bytes = plane_off;
     b->oplane_bytes = oplane_off;
     b->out_cap = b->raw_bytes_cap;
-    // token pool (k_entropy.hip): ordinary files need about half a token per byte of input; the pool grows on overflow like the others
-    b->tok_cap = b->bits_pool.size() + uint64_t(16384) * b->imgs.size() + 65536;
+    layout_token_pool(b.get());
 
     // upload what never changes between runs
     hipStream_t st = b->stream;
@@ -790,7 +848,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         if (b->d_bits.alloc(b->bits_pool.size()) || (b->bits_pool.size() && hipMemcpyAsync(b->d_bits.p, b->bits_pool.p, b->bits_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
             b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || (b->use4 && b->d_phsets4.upload(b->phsets4, st)) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
-            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_slot_work.upload(b->slot_work, st) || b->d_echunks.upload(b->echunks, st) || b->d_hdr.upload(b->hdr_pool, st) ||
+            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_slot_work.upload(b->slot_work, st) || b->d_slots.upload(b->slots, st) || b->d_plans.upload(b->plans, st) || b->d_echunks.upload(b->echunks, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
             b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
@@ -804,8 +862,9 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
             b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
-            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_unit_ntok.alloc(b->total_units + 1) ||
-            b->d_tok_off.alloc(b->slot_work.size() + 1) || b->d_chunk_ntok.alloc(b->slot_work.size() + 1) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(2) ||
+            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_corr.alloc(b->total_units + 1) ||
+            b->d_tok_off.alloc(4 * b->slot_work.size() + 4) || b->d_chunk_ntok.alloc(4 * b->slot_work.size() + 4) || b->d_slot_hist.alloc(size_t(b->hist_rows) * 256 + 256) ||
+            b->d_slot_raw.alloc(b->slot_work.size() + 1) || b->d_slot_eobh.alloc(16 * b->slot_work.size() + 16) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
             b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
@@ -1039,13 +1098,14 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     EncCtx c;
     memset(&c, 0, sizeof c);
     c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size());
-    c.echunks = b->d_echunks.p; c.nechunks = uint32_t(b->echunks.size()); c.slot_work = b->d_slot_work.p; c.nslots = uint32_t(b->slot_work.size());
+    c.echunks = b->d_echunks.p; c.plans = b->d_plans.p; c.nechunks = uint32_t(b->echunks.size()); c.slot_work = b->d_slot_work.p; c.slots = b->d_slots.p; c.nslots = uint32_t(b->slot_work.size());
     c.coef = b->d_coef.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
-    c.eobrun = b->d_eobrun.p; c.long_runs = b->d_long_runs.p; c.long_cnt = b->d_long_cnt.p; c.unit_ntok = b->d_unit_ntok.p;
-    c.tokens = b->d_tokens.p; c.tok_cap = b->tok_cap; c.tok_cursor = b->d_tok_cursor.p; c.tok_off = b->d_tok_off.p; c.chunk_ntok = b->d_chunk_ntok.p;
+    c.eobrun = b->d_eobrun.p; c.long_runs = b->d_long_runs.p; c.long_cnt = b->d_long_cnt.p; c.corr = b->d_corr.p;
+    c.tokens = b->d_tokens.p; c.regions = b->d_regions.p; c.tok_cursor = b->d_tok_cursor.p; c.tok_off = b->d_tok_off.p; c.chunk_ntok = b->d_chunk_ntok.p; c.slot_hist = b->d_slot_hist.p; c.slot_raw = b->d_slot_raw.p; c.slot_eobh = b->d_slot_eobh.p;
     c.chunk_bits = b->d_chunk_bits.p; c.chunk_off = b->d_chunk_off.p; c.tables = b->d_tables.p;
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p; c.overflow = b->d_overflow.p;
-    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_long_cnt.zero(st) || b->d_tok_cursor.zero(st)) return -1;
+    c.debug = getenv("CSH_DEBUG") ? uint32_t(atoi(getenv("CSH_DEBUG"))) : 0u;
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_long_cnt.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st)) return -1;
     MARK();
     launch_tokens(st, c);
     MARK();
@@ -1155,7 +1215,11 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
         b->h_status.resize(b->nimg);
         if (hipMemcpy(b->h_status.data(), b->d_status.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
         bool pool = ovf[0] != 0;
-        if (ovf[1]) { pool = true; b->tok_cap *= 4; }   // token pool (k_tokens)
+        if (ovf[1]) {   // token pool (k_tokens)
+            pool = true; b->tok_scale *= 4;
+            layout_token_pool(b);
+            if (b->d_regions.upload(b->regions, b->stream) || hipStreamSynchronize(b->stream) != hipSuccess) return CS_ERR_NO_DEVICE;
+        }
         for (uint32_t s : b->h_status) if (s == CS_ERR_POOL_OVERFLOW) pool = true;
         if (!pool) break;
         if (attempt == 3) { csh_set_error("device pools overflowed after 3 retries"); return CS_ERR_POOL_OVERFLOW; }

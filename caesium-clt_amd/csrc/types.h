@@ -182,8 +182,31 @@ struct ScanWork {
 //   kind 0: ALL progressive AC scans of component `comp` of image `a` (the block's coefficients are read once for all of them)
 //   kind 1: the one scan of work item `a` (DC scans: unit = MCU or block; sequential-mode scans)
 // Whatever the kind, the tokens of (work item w, chunk j) belong to slot w.first_chunk + j of the per-chunk arrays.
-struct EChunk { uint32_t a; uint16_t comp, kind; uint32_t j; };
+struct EChunk { uint32_t a; uint16_t comp, kind; uint32_t j; uint32_t plan; uint32_t region; };
+// the token pool is cut into regions with a bump cursor each -- one per (image, component) and one per DC / sequential scan: a single
+// cursor for the whole batch would be one L2 address taking a million atomics, one after the other
+struct TokRegion { uint64_t base; uint32_t cap, pad; };
 #define CSH_TK_MAXSLOT 8   // AC scans of one component that a kind-0 chunk can carry
+// what a kind-0 chunk needs of its image, component and scans, in one piece (host-built per (image, component); the workgroup copies it
+// to LDS with one coalesced load instead of chasing ImgDesc -> ScanWork -> EncScan through dependent scalar loads, scan after scan)
+struct AcSlot { uint32_t unit_base, word_base, first_chunk, table_base, nunits_work; uint8_t Ss, Se, Ah, Al; uint32_t pad[2]; };   // 32 bytes
+struct TokPlan {
+    uint32_t nslot, nunits;        // AC scans of the component; its blocks
+    int32_t real_bw, bw;           // block grid: real and MCU-padded width
+    uint32_t tile_base, pad[3];
+    AcSlot s[CSH_TK_MAXSLOT];
+};
+// what the per-slot kernels need of (work item, chunk j), in one 32-byte load (host-built; slot = work.first_chunk + j)
+struct SlotRec {
+    uint32_t work, j, nch;       // work item, chunk number, chunks of the work item
+    uint32_t first_chunk;        // the work item's first slot
+    uint32_t unit0, nun;         // first unit (index into the per-unit arrays) and number of units of the chunk
+    uint32_t table_base;
+    uint16_t ntables, flags;     // flags: 1 progressive AC scan (EOB tokens), 2 refinement (correction words)
+    uint32_t hist_row;           // first of the slot's ntables rows of 256 symbol counts (EncCtx::slot_hist)
+    uint32_t word_base, unit_base, nunits_work;   // of the work item (k_ac_runs)
+    uint8_t Ss, Se, Ah, Al; uint32_t pad[3];
+};
 
 // encoder-side Huffman table as generated on the device
 struct DevEncTable {
@@ -193,6 +216,7 @@ struct DevEncTable {
     uint16_t code[256];
     uint8_t size[256];
     int nsym;
+    uint32_t lut[256];   // size << 16 | code, what the packer gathers
 };
 
 }  // namespace csh

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/gpu_pmc.sh <tag> "<counters>"   -- one PMC pass of one bench step, per-kernel sums -> gpurun_out/pmc_<tag>.txt
 R=$(pwd); cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc $2 --output-format csv -d $R/gpurun_out/pmc_$1 -- python $R/bench.py --steps 1 --warmup 0 --cpu-images 0 > $R/gpurun_out/pmc_$1.log 2>&1
+rocprofv3 --pmc $2 --output-format csv -d $R/gpurun_out/pmc_$1 -- python $R/bench.py --steps 1 --warmup 0 --no-extras --unique 16 --batch ${B:-1024} > $R/gpurun_out/pmc_$1.log 2>&1
 python - <<PY
 import csv,glob,collections
 f=glob.glob("$R/gpurun_out/pmc_$1/**/*counter_collection.csv",recursive=True)
