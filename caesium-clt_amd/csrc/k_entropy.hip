@@ -289,8 +289,10 @@ __device__ __forceinline__ static void transpose32(uint32_t (&A)[32]) {
         CSH_UNROLL
         for (int k = 0; k < 32; k++)
             if (!(k & j)) {
-                const uint32_t t = ((A[k] >> j) ^ A[k + j]) & msk;
-                A[k + j] ^= t; A[k] ^= t << j;
+                // exchange the high-column half of row k with the low-column half of row k + j: two bit-field inserts
+                const uint32_t a = A[k], b = A[k + j];
+                A[k] = (a & msk) | ((b << j) & ~msk);
+                A[k + j] = ((a >> j) & msk) | (b & ~msk);
             }
         msk ^= msk << (j >> 1);
         CSH_SCHED_FENCE();
@@ -324,6 +326,9 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
     CSH_SHARED unsigned long long s_wbase[4][CSH_TK_MAXSLOT];   // per wave: first token of its segment in the pool (~0: no room)
     CSH_SHARED uint32_t s_raw[CSH_TK_MAXSLOT];      // raw (non-Huffman) bits of the slot, EOBRUN bits excluded
     CSH_SHARED TokPlan s_plan;                      // kind 0: the component's geometry and AC scans
+    CSH_SHARED ScanWork s_w;                        // kind 1: the work item, its scan and its image (copied once: the walkers read them
+    CSH_SHARED EncScan s_sc;                        //         field by field, and every read from HBM is a dependent scalar load)
+    CSH_SHARED ImgDesc s_im;
     CSH_PERSIST(uint64_t, pl, 10);     // bit k of: |c_k| >= 1, 2, 4, 8, 16; bit 0..3 of |c_k|; c_k < 0
     const EChunk ch = c.echunks[blockIdx.x];
     const int tid = int(threadIdx.x), lane = lane_id(), wv = tid >> 6;
@@ -337,14 +342,20 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             for (int i = tid; i < CSH_TK_MAXSLOT * 257; i += 256) hist[i] = 0;
             if (tid < CSH_TK_MAXSLOT) s_raw[tid] = 0;
             if (ch.kind == 0 && tid < int(sizeof(TokPlan) / 4)) reinterpret_cast<uint32_t *>(&s_plan)[tid] = reinterpret_cast<const uint32_t *>(c.plans + ch.plan)[tid];
+            if (ch.kind == 1) {
+                const ScanWork &gw = c.work[ch.a];
+                if (tid < int(sizeof(ScanWork) / 4)) reinterpret_cast<uint32_t *>(&s_w)[tid] = reinterpret_cast<const uint32_t *>(&gw)[tid];
+                if (tid < int(sizeof(EncScan) / 4)) reinterpret_cast<uint32_t *>(&s_sc)[tid] = reinterpret_cast<const uint32_t *>(c.script + gw.scan)[tid];
+                if (tid < int(sizeof(ImgDesc) / 4)) reinterpret_cast<uint32_t *>(&s_im)[tid] = reinterpret_cast<const uint32_t *>(c.imgs + gw.image)[tid];
+            }
             continue;
         }
         if (phase == 1) {
             // ---------------------------------------------------------------- load, planes, counts, flags
             if (ch.kind == 1) {
-                const ScanWork &w = c.work[ch.a];
-                const EncScan &sc = c.script[w.scan];
-                const ImgDesc &im = c.imgs[w.image];
+                const ScanWork &w = s_w;
+                const EncScan &sc = s_sc;
+                const ImgDesc &im = s_im;
                 uint32_t n = 0;
                 if (u < w.nunits) {
                     if (sc.sequential) { TokSink<false> s; s.begin(); walk_seq(s, c, im, sc, u); s.finish(); n = s.n; }
@@ -451,7 +462,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             if (!ok) c.overflow[1] = 1;
             unsigned long long at = gb;
             if (ch.kind == 1) {
-                const ScanWork &w = c.work[ch.a];
+                const ScanWork &w = s_w;
                 const uint32_t seg = (w.first_chunk + ch.j) * 4u + uint32_t(wv);
                 c.tok_off[seg] = gb; c.chunk_ntok[seg] = ok ? total : 0u;
                 s_wbase[wv][0] = ok ? gb : ~0ull;
@@ -471,11 +482,11 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             if (c.debug & 1u) continue;
             TokOut out; out.pool = c.tokens; out.dry = (c.debug & 4u) != 0;
             if (ch.kind == 1) {
-                const ScanWork &w = c.work[ch.a];
-                const EncScan &sc = c.script[w.scan];
+                const ScanWork &w = s_w;
+                const EncScan &sc = s_sc;
                 if (u >= w.nunits) continue;
                 TokSink<true> s; s.begin(); s.out = out; s.out.pool = c.tokens + s_wbase[wv][0] + off[0][tid]; s.out.pos = 0; s.hist = hist; s.h0 = 0; s.rawbits = 0;
-                if (sc.sequential) walk_seq(s, c, c.imgs[w.image], sc, u); else walk_dc(s, c, c.imgs[w.image], sc, u);
+                if (sc.sequential) walk_seq(s, c, s_im, sc, u); else walk_dc(s, c, s_im, sc, u);
                 s.finish();
                 while (s.out.pos < cnt[0][tid]) s.out.put(TK_RAW);
                 if (s.rawbits) atomicAdd(&s_raw[0], s.rawbits);
@@ -545,8 +556,8 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
         // -------------------------------------------------------------------- histograms -> tables, and per slot for k_chunk_sizes
         if (c.debug & 32u) continue;
         if (ch.kind == 1) {
-            const ScanWork &w = c.work[ch.a];
-            const EncScan &sc = c.script[w.scan];
+            const ScanWork &w = s_w;
+            const EncScan &sc = s_sc;
             const SlotRec &r = c.slots[w.first_chunk + ch.j];
             for (uint32_t i = uint32_t(tid); i < uint32_t(sc.ntables) * 256u; i += 256) {
                 const uint32_t v = hist[(i >> 8) * 257u + (i & 255u)];
@@ -1038,20 +1049,14 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
     bool first_flush = S.first_flush;
     const uint32_t seg_n = lane < 4 ? c.chunk_ntok[cs * 4u + uint32_t(lane)] : 0u;              // the slot's four segments (one per wave of k_tokens)
     const unsigned long long seg_o = lane < 4 ? c.tok_off[cs * 4u + uint32_t(lane)] : 0ull;
-    for (int seg = 0; seg < 4; seg++) {
-    const uint32_t n = uint32_t(__shfl(int(seg_n), seg, 64));
-    const uint32_t *tk = c.tokens + ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o)), seg, 64)) | ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o >> 32)), seg, 64)) << 32));
-    const uint32_t n_ext = n + ((pad && seg == 3) ? 1u : 0u);      // the byte fill of the scan's last chunk rides as one more token
-    for (uint32_t i0 = 0; i0 < n_ext; i0 += 256) {
-        const uint32_t i = i0 + 4u * uint32_t(lane);
-        uint32_t t[4];
-        load4(tk, i, n, t);
+    // 256 tokens, four per lane: pieces, wave scan of the lengths, OR into the window, slide the window when it fills
+    auto step = [&](const uint32_t (&t)[4], uint32_t i, uint32_t n, bool last_seg) {
         Pieces p[4];
         uint32_t len = 0;
         CSH_UNROLL
         for (int q = 0; q < 4; q++) {
             p[q] = token_pieces<MODE>(t[q], x);
-            if (pad && seg == 3 && i + uint32_t(q) == n) { p[q].v[0] = (1u << pad) - 1u; p[q].n[0] = pad; }
+            if (pad && last_seg && i + uint32_t(q) == n) { p[q].v[0] = (1u << pad) - 1u; p[q].n[0] = pad; }   // the byte fill of the scan's last chunk rides as one more token
             len += p[q].n[0] + p[q].n[1] + p[q].n[2];
         }
         uint32_t incl = len;
@@ -1078,7 +1083,26 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
             CSH_WAVE_FENCE();
             ww += done; first_flush = false;
         }
+    };
+    // the four segments are walked as ONE list (most are far shorter than a step: a step per segment would run with three quarters
+    // of the lanes idle): token g of the list lies in segment (g >= b1) + (g >= b2) + (g >= b3)
+    uint32_t n[4]; const uint32_t *tk[4];
+    CSH_UNROLL
+    for (int seg = 0; seg < 4; seg++) {
+        n[seg] = uint32_t(__shfl(int(seg_n), seg, 64));
+        tk[seg] = c.tokens + ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o)), seg, 64)) | ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o >> 32)), seg, 64)) << 32));
     }
+    const uint32_t b1 = n[0], b2 = b1 + n[1], b3 = b2 + n[2], total = b3 + n[3];
+    const uint32_t n_ext = total + (pad ? 1u : 0u);
+    for (uint32_t g0 = 0; g0 < n_ext; g0 += 256) {
+        uint32_t t[4];
+        CSH_UNROLL
+        for (int q = 0; q < 4; q++) {
+            const uint32_t g = g0 + 4u * uint32_t(lane) + uint32_t(q);
+            const uint32_t *src = g >= b3 ? tk[3] + (g - b3) : g >= b2 ? tk[2] + (g - b2) : g >= b1 ? tk[1] + (g - b1) : tk[0] + g;
+            t[q] = g < total ? *src : uint32_t(TK_RAW);
+        }
+        step(t, g0 + 4u * uint32_t(lane), total, true);
     }
     S.pos = pos; S.ww = ww; S.first_flush = first_flush;
 }
@@ -1115,16 +1139,16 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     __shared__ uint16_t s_eob[4][256];
     __shared__ uint64_t s_corr[4][256];
     uint32_t *buf = win[wv];
-    // stage (uniform branches: one scan per wave)
-    if (r.ntables <= 2) {
+    // stage (uniform branches: one scan per wave).  A scan with more than two tables (sequential mode) keeps its look-ups in HBM; the two
+    // cases are separate instantiations below so that every look-up has ONE address space (a pointer that may be either makes them flat loads)
+    const bool in_lds = r.ntables <= 2;
+    if (in_lds) {
         for (int i = lane; i < int(r.ntables) * 256; i += 64) s_lut[wv][i >> 8][i & 255] = x.lut[(i >> 8) * CSH_LUT_STRIDE + (i & 255)];
-        x.lut = &s_lut[wv][0][0]; x.lut_stride = 256;
+        if (r.flags & 1u) for (int i = lane; i < 256; i += 64) s_eob[wv][i] = uint32_t(i) < r.nun ? x.eobrun[i] : uint16_t(0);
+        if (r.flags & 2u) for (int i = lane; i < 256; i += 64) s_corr[wv][i] = uint32_t(i) < r.nun ? x.corr[i] : 0ull;
     }
-    if (r.flags & 1u) {
-        for (int i = lane; i < 256; i += 64) s_eob[wv][i] = uint32_t(i) < r.nun ? x.eobrun[i] : uint16_t(0);
-        x.eobrun = s_eob[wv];
-        if (r.flags & 2u) { for (int i = lane; i < 256; i += 64) s_corr[wv][i] = uint32_t(i) < r.nun ? x.corr[i] : 0ull; x.corr = s_corr[wv]; }
-    }
+    TokenCtx xl;   // the same, out of LDS
+    xl.lut = &s_lut[wv][0][0]; xl.lut_stride = 256; xl.eobrun = &s_eob[wv][0]; xl.corr = &s_corr[wv][0];
     for (int i = lane; i < CSH_PK_WORDS; i += 64) buf[i] = 0;
     uint32_t *out = c.raw + (raw_bit0 >> 5);        // word 0 of the frame below
     uint64_t pos = raw_bit0 & 31u;                   // next bit, in the frame whose word 0 is the chunk's first word in the pool
@@ -1132,9 +1156,10 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     bool first_flush = true;
     CSH_WAVE_FENCE();
     PackState S; S.buf = buf; S.out = out; S.pos = pos; S.ww = ww; S.first_flush = first_flush;
-    if (!(r.flags & 1u)) pack_segments<3>(c, x, S, cs, pad, lane);
-    else if (r.flags & 2u) pack_segments<2>(c, x, S, cs, pad, lane);
-    else pack_segments<1>(c, x, S, cs, pad, lane);
+    if (!in_lds) pack_segments<3>(c, x, S, cs, pad, lane);
+    else if (!(r.flags & 1u)) pack_segments<3>(c, xl, S, cs, pad, lane);
+    else if (r.flags & 2u) pack_segments<2>(c, xl, S, cs, pad, lane);
+    else pack_segments<1>(c, xl, S, cs, pad, lane);
     pos = S.pos; ww = S.ww; first_flush = S.first_flush;
     CSH_WAVE_FENCE();
     const uint32_t last = uint32_t((pos + 31) >> 5) - ww;   // words in the window that carry bits
