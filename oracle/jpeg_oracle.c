@@ -924,41 +924,17 @@ static void write_dht_group(bvec *b, ehuff *const tabs[], const int cls_id[], in
     }
 }
 
-int cso_encode(const cso_image *im, const cso_enc_params *p, const cso_scan *script, int nscans, uint8_t **out, size_t *out_len) {
-    cso_scan local[CSO_MAX_SCANS];
-    cso_image hdr = *im; /* shallow: only flags differ */
-    hdr.progressive = p->progressive;
-    if (!script || !nscans) {
-        if (p->progressive) { nscans = cso_stock_script(im->ncomp, p->scan_script, local); script = local; }
-        else { local[0].ncomp_in_scan = im->ncomp; for (int c = 0; c < im->ncomp; c++) local[0].comp_idx[c] = c; local[0].Ss = 0; local[0].Se = 63; local[0].Ah = local[0].Al = 0; nscans = 1; script = local; }
-    }
-    bvec b = {0};
-    put_marker(&b, 0xD8);
-    /* libjpeg write_file_header: JFIF APP0 for YCbCr / grayscale */
-    if (im->ncomp == 1 || im->ncomp == 3) {
-        static const uint8_t jfif[] = {0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
-        bv_write(&b, jfif, sizeof jfif);
-    }
-    /* metadata carry-over: APPn/COM when keep_metadata; ICC (APP2 "ICC_PROFILE\0") governed separately by preserve_icc */
-    for (size_t mo = 0; mo + 4 <= im->meta_len;) {
-        size_t L = ((size_t)im->meta[mo + 2] << 8) | im->meta[mo + 3];
-        int is_icc = im->meta[mo + 1] == 0xE2 && L >= 14 && !memcmp(im->meta + mo + 4, "ICC_PROFILE\0", 12);
-        int keep = is_icc ? p->preserve_icc : p->keep_metadata;
-        if (keep) bv_write(&b, im->meta + mo, 2 + L);
-        mo += 2 + L;
-    }
-    write_dqt(&b, im, p->marker_style);
-    int is_baseline = !p->progressive;
-    for (int c = 0; c < im->ncomp; c++) for (int k = 0; k < 64; k++) if (im->qt[im->comp[c].tq][k] > 255) is_baseline = 0;
-    put_marker(&b, p->progressive ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));
-    bv_put2(&b, 8 + 3 * im->ncomp); bv_put(&b, 8); bv_put2(&b, im->height); bv_put2(&b, im->width); bv_put(&b, im->ncomp);
-    for (int c = 0; c < im->ncomp; c++) { bv_put(&b, im->comp[c].id); bv_put(&b, (im->comp[c].h << 4) | im->comp[c].v); bv_put(&b, im->comp[c].tq); }
-
-    tvec tv = {0};
-    for (int s = 0; s < nscans; s++) {
-        const cso_scan *sc = &script[s];
+static int cso_search_progression(const cso_image *hdr, const cso_enc_params *p, cso_scan *out);
+/* one scan as it goes into the file: DHT group, SOS, entropy-coded data (optimal tables, byte stuffing, final byte padded with 1-bits).
+   mozjpeg's scan search measures exactly these bytes per candidate (jcmaster.c: every candidate scan is written, header included, into
+   its own memory buffer; scan_size[] is that buffer's length) */
+static void encode_one_scan(bvec *bp, const cso_image *hdr, const cso_enc_params *p, const cso_scan *sc, tvec *tvp) {
+    bvec b = *bp;
+    tvec tv = *tvp;
+    const cso_image *im = hdr;
+    {
         tv.n = 0;
-        tokenize_scan(&hdr, sc, &tv);
+        tokenize_scan(hdr, sc, &tv);
         long freq[8][257]; memset(freq, 0, sizeof freq);
         for (size_t i = 0; i < tv.n; i++) if (tv.t[i].tbl != 255) freq[tv.t[i].tbl][tv.t[i].sym]++;
         ehuff tabs[8]; memset(tabs, 0, sizeof tabs);
@@ -989,10 +965,165 @@ int cso_encode(const cso_image *im, const cso_enc_params *p, const cso_scan *scr
         }
         if (nb > 0) { int c = (int)(((acc << (8 - nb)) | ((1u << (8 - nb)) - 1)) & 255); bv_put(&b, c); if (c == 255) bv_put(&b, 0); }
     }
+    *bp = b; *tvp = tv;
+}
+
+int cso_encode(const cso_image *im, const cso_enc_params *p, const cso_scan *script, int nscans, uint8_t **out, size_t *out_len) {
+    cso_scan local[CSO_MAX_SCANS];
+    cso_image hdr = *im; /* shallow: only flags differ */
+    hdr.progressive = p->progressive;
+    if (!script || !nscans) {
+        if (p->progressive) { nscans = cso_stock_script(im->ncomp, p->scan_script, local); script = local; }
+        else { local[0].ncomp_in_scan = im->ncomp; for (int c = 0; c < im->ncomp; c++) local[0].comp_idx[c] = c; local[0].Ss = 0; local[0].Se = 63; local[0].Ah = local[0].Al = 0; nscans = 1; script = local; }
+    }
+    bvec b = {0};
+    put_marker(&b, 0xD8);
+    /* libjpeg write_file_header: JFIF APP0 for YCbCr / grayscale */
+    if (im->ncomp == 1 || im->ncomp == 3) {
+        static const uint8_t jfif[] = {0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+        bv_write(&b, jfif, sizeof jfif);
+    }
+    /* metadata carry-over: APPn/COM when keep_metadata; ICC (APP2 "ICC_PROFILE\0") governed separately by preserve_icc */
+    for (size_t mo = 0; mo + 4 <= im->meta_len;) {
+        size_t L = ((size_t)im->meta[mo + 2] << 8) | im->meta[mo + 3];
+        int is_icc = im->meta[mo + 1] == 0xE2 && L >= 14 && !memcmp(im->meta + mo + 4, "ICC_PROFILE\0", 12);
+        int keep = is_icc ? p->preserve_icc : p->keep_metadata;
+        if (keep) bv_write(&b, im->meta + mo, 2 + L);
+        mo += 2 + L;
+    }
+    write_dqt(&b, im, p->marker_style);
+    int is_baseline = !p->progressive;
+    for (int c = 0; c < im->ncomp; c++) for (int k = 0; k < 64; k++) if (im->qt[im->comp[c].tq][k] > 255) is_baseline = 0;
+    put_marker(&b, p->progressive ? 0xC2 : (is_baseline ? 0xC0 : 0xC1));
+    bv_put2(&b, 8 + 3 * im->ncomp); bv_put(&b, 8); bv_put2(&b, im->height); bv_put2(&b, im->width); bv_put(&b, im->ncomp);
+    for (int c = 0; c < im->ncomp; c++) { bv_put(&b, im->comp[c].id); bv_put(&b, (im->comp[c].h << 4) | im->comp[c].v); bv_put(&b, im->comp[c].tq); }
+
+    cso_scan chosen[CSO_MAX_SCANS];
+    if (p->progressive && p->scan_script == 2 && (script == local)) { nscans = cso_search_progression(&hdr, p, chosen); script = chosen; }
+    tvec tv = {0};
+    for (int s = 0; s < nscans; s++) encode_one_scan(&b, &hdr, p, &script[s], &tv);
     free(tv.t);
     put_marker(&b, 0xD9);
     *out = b.p; *out_len = b.n;
     return 0;
+}
+
+/* ---- mozjpeg's scan-script search (optimize_scans; reached through jpeg_simple_progression under the JCP_MAX_COMPRESSION profile,
+   which libcaesium uses on both its lossy and its lossless JPEG path: /root/reference/src/compressor.rs:415,434 -> Cargo.lock:1035-1044).
+   [UPSTREAM-RECALL] of jcparam.c jpeg_search_progression (the candidate list) and jcmaster.c select_scans (the decisions), with
+   dc_scan_opt_mode = 0 (one DC scan for all components: what the reference's own output samples/j0.JPG shows).  PINNED by that file:
+   run on j0's coefficients it must come back with j0's 8-scan script (tests/test_oracle_jpeg.py).
+   Candidates (index: scan), YCbCr -- grey images have the first 23 only:
+     0 DC of every component | 1, 2 Y 1-8 / 9-63 at Al 0 | for Al = 0, 1, 2: 3+3Al Y 1-63 refinement Ah=Al+1 -> Al, then Y 1-8 / 9-63 at Al+1
+     12 Y 1-63 | 13.. five splits {2, 8, 5, 12, 18}: Y 1-s, Y s+1-63 (12..22 at the Al chosen for luma)
+     23-25 chroma DC variants (written by mozjpeg, never used in this mode) | 26-29 Cb 1-8, 9-63, Cr 1-8, 9-63 at Al 0
+     for Al = 0, 1: 30+6Al Cb, Cr refinements, then the four band scans at Al+1 | 42, 43 Cb, Cr 1-63 | 44.. five splits x (Cb lo, Cb hi, Cr lo, Cr hi)
+   A candidate's cost is the size of everything it puts into the file: DHT, SOS and the stuffed entropy-coded bytes. */
+static size_t scan_cost(const cso_image *hdr, const cso_enc_params *p, const cso_scan *sc, tvec *tv) {
+    bvec b = {0};
+    encode_one_scan(&b, hdr, p, sc, tv);
+    size_t n = b.n;
+    free(b.p);
+    return n;
+}
+static int cso_search_progression(const cso_image *hdr, const cso_enc_params *p, cso_scan *out) {
+    static const int split[5] = {2, 8, 5, 12, 18};
+    const int ncomp = hdr->ncomp;
+    if (ncomp != 1 && ncomp != 3) return cso_stock_script(ncomp, 0, out);
+    cso_scan L[64];
+    int n = 0;
+#define S1(c, ss, se, ah, al) do { L[n].ncomp_in_scan = 1; L[n].comp_idx[0] = c; L[n].Ss = ss; L[n].Se = se; L[n].Ah = ah; L[n].Al = al; n++; } while (0)
+    L[n].ncomp_in_scan = ncomp; for (int c = 0; c < ncomp; c++) L[n].comp_idx[c] = c; L[n].Ss = L[n].Se = L[n].Ah = L[n].Al = 0; n++;
+    S1(0, 1, 8, 0, 0); S1(0, 9, 63, 0, 0);
+    for (int Al = 0; Al < 3; Al++) { S1(0, 1, 63, Al + 1, Al); S1(0, 1, 8, 0, Al + 1); S1(0, 9, 63, 0, Al + 1); }
+    S1(0, 1, 63, 0, 0);
+    for (int i = 0; i < 5; i++) { S1(0, 1, split[i], 0, 0); S1(0, split[i] + 1, 63, 0, 0); }
+    const int nluma = n;   /* 23 */
+    if (ncomp == 3) {
+        L[n].ncomp_in_scan = 2; L[n].comp_idx[0] = 1; L[n].comp_idx[1] = 2; L[n].Ss = L[n].Se = L[n].Ah = L[n].Al = 0; n++;
+        S1(1, 0, 0, 0, 0); S1(2, 0, 0, 0, 0);
+        S1(1, 1, 8, 0, 0); S1(1, 9, 63, 0, 0); S1(2, 1, 8, 0, 0); S1(2, 9, 63, 0, 0);
+        for (int Al = 0; Al < 2; Al++) { S1(1, 1, 63, Al + 1, Al); S1(2, 1, 63, Al + 1, Al); S1(1, 1, 8, 0, Al + 1); S1(1, 9, 63, 0, Al + 1); S1(2, 1, 8, 0, Al + 1); S1(2, 9, 63, 0, Al + 1); }
+        S1(1, 1, 63, 0, 0); S1(2, 1, 63, 0, 0);
+        for (int i = 0; i < 5; i++) { S1(1, 1, split[i], 0, 0); S1(1, split[i] + 1, 63, 0, 0); S1(2, 1, split[i], 0, 0); S1(2, split[i] + 1, 63, 0, 0); }
+    }
+#undef S1
+    const int nscans = n, luma_split0 = 12, chroma_dc = 3, chroma_base = nluma + chroma_dc, chroma_split0 = nluma + chroma_dc + 16;
+    size_t size[64];
+    memset(size, 0, sizeof size);
+    tvec tv = {0};
+    int best_Al_luma = 0, best_Al_chroma = 0, best_split_luma = 0, best_split_chroma = 0;
+    size_t best_cost = 0;
+    for (int sn = 0; sn < nscans;) {
+        cso_scan sc = L[sn];
+        if (sn >= luma_split0 && sn < nluma) sc.Al = best_Al_luma;                 /* the frequency-split candidates are coded at the Al chosen before */
+        if (sn >= chroma_split0) sc.Al = best_Al_chroma;
+        L[sn] = sc;
+        if (!(sn >= nluma && sn < chroma_base)) size[sn] = scan_cost(hdr, p, &sc, &tv);   /* the chroma DC variants play no part with one DC scan for all */
+        const int next = sn + 1;   /* scans done */
+        int jump = -1;
+        if (next > 1 && next <= luma_split0) {
+            if ((next - 1) % 3 == 2) {
+                const int Al = (next - 1) / 3;
+                size_t cost = size[next - 2] + size[next - 1];
+                for (int i = 0; i < Al; i++) cost += size[3 + 3 * i];
+                if (Al == 0 || cost < best_cost) { best_cost = cost; best_Al_luma = Al; }
+                else jump = luma_split0;
+            }
+        } else if (next > luma_split0 && next <= nluma) {
+            if (next == luma_split0 + 1) { best_split_luma = 0; best_cost = size[next - 1]; }
+            else if ((next - luma_split0) % 2 == 1) {
+                const int idx = (next - luma_split0) >> 1;
+                const size_t cost = size[next - 2] + size[next - 1];
+                if (cost < best_cost) { best_cost = cost; best_split_luma = idx; }
+                if ((idx == 2 && best_split_luma == 0) || (idx == 3 && best_split_luma != 2) || (idx == 4 && best_split_luma != 4)) jump = nluma;
+            }
+        } else if (nscans > nluma) {
+            if (next > chroma_base && next <= chroma_split0) {
+                if ((next - chroma_base) % 6 == 4) {
+                    const int Al = (next - chroma_base) / 6;
+                    size_t cost = size[next - 4] + size[next - 3] + size[next - 2] + size[next - 1];
+                    for (int i = 0; i < Al; i++) cost += size[chroma_base + 4 + 6 * i] + size[chroma_base + 5 + 6 * i];
+                    if (Al == 0 || cost < best_cost) { best_cost = cost; best_Al_chroma = Al; }
+                    else jump = chroma_split0;
+                }
+            } else if (next > chroma_split0 && next <= nscans) {
+                if (next == chroma_split0 + 2) { best_split_chroma = 0; best_cost = size[next - 2] + size[next - 1]; }
+                else if ((next - chroma_split0) % 4 == 2) {
+                    const int idx = (next - chroma_split0) >> 2;
+                    const size_t cost = size[next - 4] + size[next - 3] + size[next - 2] + size[next - 1];
+                    if (cost < best_cost) { best_cost = cost; best_split_chroma = idx; }
+                    if ((idx == 2 && best_split_chroma == 0) || (idx == 3 && best_split_chroma != 2) || (idx == 4 && best_split_chroma != 4)) jump = nscans;
+                }
+            }
+        }
+        sn = jump >= 0 ? jump : sn + 1;
+    }
+    free(tv.t);
+    /* the file: DC, luma bands, luma refinements down to the Al both share, chroma bands, chroma refinements down to it, then the
+       shared refinements luma first */
+    int m = 0;
+    const int min_Al = ncomp == 3 ? (best_Al_luma < best_Al_chroma ? best_Al_luma : best_Al_chroma) : best_Al_luma;
+    out[m++] = L[0];
+    if (best_split_luma == 0) out[m++] = L[luma_split0];
+    else { out[m++] = L[luma_split0 + 2 * (best_split_luma - 1) + 1]; out[m++] = L[luma_split0 + 2 * (best_split_luma - 1) + 2]; }
+    for (int Al = best_Al_luma - 1; Al >= min_Al; Al--) out[m++] = L[3 + 3 * Al];
+    if (ncomp == 3) {
+        if (best_split_chroma == 0) { out[m++] = L[chroma_split0]; out[m++] = L[chroma_split0 + 1]; }
+        else for (int i = 2; i <= 5; i++) out[m++] = L[chroma_split0 + 4 * (best_split_chroma - 1) + i];
+        for (int Al = best_Al_chroma - 1; Al >= min_Al; Al--) { out[m++] = L[chroma_base + 6 * Al + 4]; out[m++] = L[chroma_base + 6 * Al + 5]; }
+    }
+    for (int Al = min_Al - 1; Al >= 0; Al--) {
+        out[m++] = L[3 + 3 * Al];
+        if (ncomp == 3) { out[m++] = L[chroma_base + 6 * Al + 4]; out[m++] = L[chroma_base + 6 * Al + 5]; }
+    }
+    return m;
+}
+/* the script the search picks for an image's coefficients (tests; the device's choice is compared with it) */
+int cso_search_script(const cso_image *im, const cso_enc_params *p, cso_scan *out) {
+    cso_image hdr = *im;
+    hdr.progressive = 1;
+    return cso_search_progression(&hdr, p, out);
 }
 
 int cso_jpeg_compress(const uint8_t *in, size_t n, const cso_enc_params *p, int lossless, uint8_t **out, size_t *out_len) {

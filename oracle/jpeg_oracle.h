@@ -64,7 +64,8 @@ typedef struct {
     int qtable_profile;        /* 3 = mozjpeg table #3 (JCP_MAX_COMPRESSION, pinned by j0.JPG);
                                   0 = Annex K (stock libjpeg) */
     int marker_style;          /* 1 = mozjpeg (merged DQT / merged DHT per scan), 0 = libjpeg */
-    int scan_script;           /* 0 = stock jpeg_simple_progression; 1 = the 8-scan script found in j0.JPG */
+    int scan_script;           /* 0 = stock jpeg_simple_progression; 1 = the 8-scan script found in j0.JPG;
+                                  2 = mozjpeg's scan search (optimize_scans): the script is chosen per image from the sizes of its candidate scans */
     int keep_metadata;         /* copy APPn/COM (except the encoder's own JFIF) */
     int force_baseline;        /* clamp quant entries to 255 */
     int preserve_icc;          /* keep APP2 "ICC_PROFILE" segments even when keep_metadata is 0; drop them when 0
@@ -92,6 +93,8 @@ int  cso_encode(const cso_image *im, const cso_enc_params *p,
                 const cso_scan *script, int nscans /* NULL/0 = per params */,
                 uint8_t **out, size_t *out_len);
 void cso_free(void *p);
+/* the scan script mozjpeg's optimize_scans search picks for these coefficients ([UPSTREAM-RECALL], pinned by samples/j0.JPG) */
+int  cso_search_script(const cso_image *im, const cso_enc_params *p, cso_scan *out);
 
 /* what libcaesium's jpeg::compress_in_memory does, plain profile:
    lossless=0: decode -> pixels -> forward(quality) -> encode

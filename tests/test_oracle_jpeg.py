@@ -146,3 +146,35 @@ def test_reference_fixture_entropy_roundtrip(reference_samples, rel, style):
         assert ci.scans() == O.stock_script(3, 1)
     else:
         assert ci.scans() == O.stock_script(3, 0)
+
+
+def test_scan_search_is_pinned_by_the_reference_fixture(reference_samples):
+    """mozjpeg's optimize_scans search, restated from recall (oracle/jpeg_oracle.c cso_search_progression), run on the coefficients of the
+    reference's own mozjpeg-made sample: it must pick j0's script WITHOUT being given it, and the lossless transcode that libcaesium does
+    with --lossless (BASELINE configs[0]) then reproduces j0's own DQT..EOI byte for byte (SURVEY 8c-4 iii).  On j1 (made by plain
+    libjpeg: stock script) the search picks another script and the file gets smaller."""
+    d = open(os.path.join(reference_samples, "j0.JPG"), "rb").read()
+    out = O.jpeg_compress(d, O.params(progressive=1, marker_style=1, scan_script=2), lossless=True)
+    assert O.decode(out).scans() == O.stock_script(3, 1) == O.decode(d).scans()
+    assert out[out.index(b"\xff\xdb"):] == d[d.index(b"\xff\xdb"):]
+    d1 = open(os.path.join(reference_samples, "level_1_0", "j1.jpg"), "rb").read()
+    out1 = O.jpeg_compress(d1, O.params(progressive=1, marker_style=1, scan_script=2), lossless=True)
+    stock1 = O.jpeg_compress(d1, O.params(progressive=1, marker_style=1, scan_script=0), lossless=True)
+    assert len(out1) < len(stock1)
+    assert O.decode(out1).scans() != O.stock_script(3, 0)
+    a, b = O.decode(out1), O.decode(d1)
+    assert np.array_equal(a.pixels(), b.pixels())
+
+
+def test_scan_search_grey_and_small_images():
+    """the search's grey list (23 candidates) and its early exits on tiny images: the result decodes to the same coefficients"""
+    for i, (w, h, ss) in enumerate([(64, 48, 0), (101, 67, 2), (320, 240, 2)]):
+        src = synth_jpeg(10 + i, w, h, subsampling=ss, texture=10.0 * i)
+        a = O.jpeg_compress(src, O.params(quality=80, scan_script=2))
+        b = O.jpeg_compress(src, O.params(quality=80, scan_script=0))
+        assert np.array_equal(O.decode(a).pixels(), O.decode(b).pixels())
+    from PIL import Image
+    im = Image.open(io.BytesIO(synth_jpeg(3, 160, 120))).convert("L")
+    bb = io.BytesIO(); im.save(bb, format="JPEG", quality=90)
+    g = O.jpeg_compress(bb.getvalue(), O.params(quality=80, scan_script=2))
+    assert O.decode(g).im.ncomp == 1 and np.array_equal(O.decode(g).pixels(), O.decode(O.jpeg_compress(bb.getvalue(), O.params(quality=80))).pixels())
