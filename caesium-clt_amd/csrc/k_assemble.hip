@@ -36,8 +36,8 @@ void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, ui
 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_scan_sizes(AsmCtx a) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= a.nwork) return;
+    int j = a.work0 + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= a.work0 + a.nwork_run) return;
     ScanWork &w = a.work[j];
     uint64_t bits = a.chunk_off[w.first_chunk + (w.nunits + 255) / 256] - a.chunk_off[w.first_chunk];
     uint64_t bytes = (bits + 7) >> 3;
@@ -45,11 +45,27 @@ __global__ void k_scan_sizes(AsmCtx a) {
     a.scan_pad_bytes[j] = uint32_t(((bytes + 63) & ~uint64_t(63)) + 64);  // +64: the packer may touch one word past the end
 }
 __global__ void k_scan_place(AsmCtx a) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= a.nwork) return;
+    int j = a.work0 + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= a.work0 + a.nwork_run) return;
     a.work[j].raw_off = a.scan_raw_off[j];
     a.work[j].no_room = a.scan_raw_off[j + 1] > a.raw_chunks * 64 ? 1u : 0u;
-    if (j == a.nwork - 1 && a.scan_raw_off[a.nwork] > a.raw_chunks * 64) *a.overflow = 1;
+    a.work[j].out_off = 0xFFFFFFFFu;   // not part of a file until k_layout says so
+    if (j == a.work0 + a.nwork_run - 1 && a.scan_raw_off[j + 1] > a.raw_chunks * 64) *a.overflow = 1;
+}
+__device__ static uint32_t scan_header_bytes(const AsmCtx &a, const ScanWork &w, const EncScan &sc) {
+    uint32_t hdr = 0;
+    if (sc.ntables) { hdr += 4; for (int t = 0; t < sc.ntables; t++) hdr += 17 + a.tables[w.table_base + t].nsym; }
+    return hdr + 2 + 2 + 1 + 2 * sc.ncomp + 3;
+}
+__device__ static uint64_t scan_stuffing(const AsmCtx &a, const ScanWork &w) {
+    uint64_t c0 = w.raw_off >> 6, c1 = (w.raw_off + ((uint64_t(w.raw_bytes) + 63) & ~uint64_t(63))) >> 6;
+    return c1 <= a.raw_chunks ? a.chunk_ffoff[c1] - a.chunk_ffoff[c0] : 0;
+}
+__global__ void k_scan_cost(AsmCtx a) {
+    int j = a.work0 + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= a.work0 + a.nwork_run) return;
+    const ScanWork &w = a.work[j];
+    a.scan_cost[j] = scan_header_bytes(a, w, a.script[w.scan]) + w.raw_bytes + uint32_t(scan_stuffing(a, w));
 }
 
 // byte sink that turns a lane's contiguous output run into aligned dword stores (single bytes only at the ragged ends)
@@ -95,20 +111,14 @@ __global__ void __launch_bounds__(256) k_ff_count(AsmCtx a) {
 __global__ void k_layout(AsmCtx a) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.nimg) return;
-    const ImgDesc &im = a.imgs[i];
     uint64_t pos = a.hdr_off[i + 1] - a.hdr_off[i];
-    for (int s = 0; s < im.nscans_out; s++) {
-        ScanWork &w = a.work[im.first_work + s];
-        const EncScan &sc = a.script[w.scan];
-        uint32_t hdr = 0;
-        if (sc.ntables) { hdr += 4; for (int t = 0; t < sc.ntables; t++) hdr += 17 + a.tables[w.table_base + t].nsym; }
-        hdr += 2 + 2 + 1 + 2 * sc.ncomp + 3;
-        uint64_t c0 = w.raw_off >> 6, c1 = (w.raw_off + ((uint64_t(w.raw_bytes) + 63) & ~uint64_t(63))) >> 6;
-        uint64_t ff = 0;
-        if (c1 <= a.raw_chunks) ff = a.chunk_ffoff[c1] - a.chunk_ffoff[c0];
+    const uint32_t n = a.img_nlist[i];
+    for (uint32_t s = 0; s < n; s++) {
+        ScanWork &w = a.work[a.img_list[size_t(i) * CSH_LIST_MAX + s]];
+        const uint32_t hdr = scan_header_bytes(a, w, a.script[w.scan]);
         w.out_off = uint32_t(pos);
         w.hdr_bytes = hdr;
-        pos += hdr + w.raw_bytes + ff;
+        pos += hdr + w.raw_bytes + scan_stuffing(a, w);
     }
     pos += 2;  // EOI
     a.img_size[i] = uint32_t(pos);
@@ -131,6 +141,7 @@ __global__ void k_emit_headers(AsmCtx a) {
     int j = t - a.nimg;
     if (j >= a.nwork) return;
     const ScanWork &w = a.work[j];
+    if (w.out_off == 0xFFFFFFFFu) return;   // a candidate of the scan search that did not make it into the file
     const EncScan &sc = a.script[w.scan];
     const ImgDesc &im = a.imgs[w.image];
     uint8_t *o = a.out + a.img_off[w.image] + w.out_off;
@@ -160,7 +171,7 @@ __global__ void __launch_bounds__(256) k_emit_data(AsmCtx a) {
     int j = owner_scan(a, c);
     const ScanWork &w = a.work[j];
     uint64_t rel = c * 64 - w.raw_off;
-    if (rel >= w.raw_bytes) return;
+    if (rel >= w.raw_bytes || w.out_off == 0xFFFFFFFFu) return;
     uint64_t c0 = w.raw_off >> 6;
     ByteRun o; o.begin(a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes + rel + (a.chunk_ffoff[c] - a.chunk_ffoff[c0]));
     // the whole chunk first (four loads in flight at once), then the stores back to back: stores of one lane that are spread
@@ -183,8 +194,9 @@ __global__ void __launch_bounds__(256) k_emit_data(AsmCtx a) {
     o.finish();
 }
 
-void launch_scan_sizes(hipStream_t st, const AsmCtx &a) { if (a.nwork) CSH_LAUNCH(k_scan_sizes, dim3((a.nwork + 255) / 256), dim3(256), st, a); }
-void launch_scan_place(hipStream_t st, const AsmCtx &a) { if (a.nwork) CSH_LAUNCH(k_scan_place, dim3((a.nwork + 255) / 256), dim3(256), st, a); }
+void launch_scan_sizes(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH(k_scan_sizes, dim3((a.nwork_run + 255) / 256), dim3(256), st, a); }
+void launch_scan_place(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH(k_scan_place, dim3((a.nwork_run + 255) / 256), dim3(256), st, a); }
+void launch_scan_cost(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH(k_scan_cost, dim3((a.nwork_run + 255) / 256), dim3(256), st, a); }
 void launch_ff_count(hipStream_t st, const AsmCtx &a) { if (a.raw_chunks) CSH_LAUNCH(k_ff_count, dim3(unsigned((a.raw_chunks + 255) / 256)), dim3(256), st, a); }
 void launch_layout(hipStream_t st, const AsmCtx &a) { if (a.nimg) CSH_LAUNCH(k_layout, dim3((a.nimg + 63) / 64), dim3(64), st, a); }
 void launch_emit(hipStream_t st, const AsmCtx &a) {

@@ -633,8 +633,8 @@ __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
     (void)lane;
     CSH_UNROLL
     for (int q = 0; q < 4; q++) {
-        const uint32_t cs = blockIdx.x * 4u + uint32_t(q);
-        if (cs >= c.nslots) break;
+        const uint32_t cs = c.slot0 + blockIdx.x * 4u + uint32_t(q);
+        if (cs >= c.slot0 + c.nslots) break;
         const SlotRec r = c.slots[cs];
         if (!(r.flags & 1u)) continue;
         const uint32_t u = r.j * 256u + threadIdx.x, nunits = r.nunits_work;
@@ -1001,9 +1001,9 @@ __device__ __forceinline__ static void load4(const uint32_t *tk, uint32_t i, uin
 // ---- pass E: size in bits of every chunk: ONE WAVE per (scan, chunk) slot.  No token is read: the chunk's symbol counts (k_tokens kept
 // them per slot), the code lengths, the raw bits k_tokens counted, and the EOBRUN symbols k_ac_runs counted per slot.
 __global__ void __launch_bounds__(256) k_chunk_sizes(EncCtx c) {
-    const uint32_t cs = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t cs = c.slot0 + blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = lane_id();
-    if (cs >= c.nslots) return;
+    if (cs >= c.slot0 + c.nslots) return;
     const SlotRec r = c.slots[cs];
 #ifdef CSH_EMUL
     if (lane) return;
@@ -1109,8 +1109,8 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
 #endif
 __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     const int wv = int(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t cs = blockIdx.x * 4u + uint32_t(wv);
-    if (cs >= c.nslots) return;
+    const uint32_t cs = c.slot0 + blockIdx.x * 4u + uint32_t(wv);
+    if (cs >= c.slot0 + c.nslots) return;
     const SlotRec r = c.slots[cs];
     const ScanWork &w = c.work[r.work];
     if (w.no_room) { if (lane == 0) c.status[w.image] = 20200; return; }   // decided per scan by k_scan_place

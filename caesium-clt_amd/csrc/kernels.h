@@ -68,7 +68,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     const TokPlan *plans;      // what its kind-0 chunks need, per (image, component)
     const uint32_t *slot_work; // per slot (work item, 256-unit chunk): its work item -- the grid of the per-scan kernels
     const SlotRec *slots;      // the same slots, with what the packer kernels need of them
-    uint32_t nslots;
+    uint32_t slot0, nslots;    // the slots this run of the kernels covers: [slot0, slot0 + nslots)
     const int16_t *coef;       // coefficients to code (tiles)
     uint64_t *sym_bits;        // per AC scan: bit b set iff block b emits >=1 Huffman symbol in this scan
     uint64_t *eob_bits;        // per AC scan: bit b set iff block b ends with a pending EOB
@@ -109,6 +109,10 @@ struct AsmCtx {
     const EncScan *script;
     ScanWork *work;               // raw_off / raw_bytes / out_off / hdr_bytes are filled in here
     int nwork, nimg, scans_per_image;
+    int work0, nwork_run;         // the work items this run of the per-scan kernels covers (a stage of the scan search; everything otherwise)
+    const uint32_t *img_list;     // [nimg][CSH_LIST_MAX] the work items that make up each file, in file order
+    const uint32_t *img_nlist;    // [nimg]
+    uint32_t *scan_cost;          // [nwork] bytes a scan puts into a file: DHT + SOS + stuffed data (what mozjpeg's scan search compares)
     const DevEncTable *tables;
     const uint64_t *chunk_off;    // exclusive scan of the chunks' bit sizes (+ trailing total)
     uint32_t *scan_pad_bytes;     // [nwork] raw bytes per scan rounded up to 64 (+64 slack)
@@ -127,6 +131,7 @@ struct AsmCtx {
     uint32_t *status;             // per image
     uint32_t *overflow;           // [1] set when a pool is too small
 };
+void launch_scan_cost(hipStream_t st, const AsmCtx &a);      // scan_cost of the run's work items (after launch_ff_count + its scan)
 void launch_scan_sizes(hipStream_t st, const AsmCtx &a);     // fills scan_pad_bytes + work[].raw_bytes
 void launch_scan_place(hipStream_t st, const AsmCtx &a);     // work[].raw_off from scan_raw_off
 void launch_ff_count(hipStream_t st, const AsmCtx &a);

@@ -110,6 +110,15 @@ struct csh_batch {
     std::vector<TokRegion> regions;       // one per TokPlan, then one per DC / sequential work item
     std::vector<uint32_t> region_est;     // estimated tokens of each (x tok_scale = its capacity)
     uint32_t hist_rows = 0;               // rows of 256 symbol counts over all slots
+    // mozjpeg's scan search (the default profile; CSH_PROFILE=plain keeps the stock script): the candidate scans are coded in two
+    // stages -- work items, slots, token chunks and tables of stage 1 first, of stage 2 behind them -- and the host replays
+    // jcmaster.c select_scans on their sizes in between
+    bool search = false;
+    struct Stage { uint32_t work0 = 0, nwork = 0, slot0 = 0, nslots = 0, ech0 = 0, nech = 0, table0 = 0, ntables = 0, plan0 = 0, nplans = 0; } stage[2];
+    struct SearchImg { int cand_work[64]; int ncand; int Al_luma = 0, Al_chroma = 0; };   // candidate number -> work item (-1: not coded)
+    std::vector<SearchImg> simg;
+    std::vector<uint32_t> img_list, img_nlist, h_cost;
+    std::map<std::array<int, 5>, int> cand_script;   // (component, Ss, Se, Ah, Al) -> EncScan index
     PinnedBytes bits_pool;
     std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
@@ -156,7 +165,7 @@ struct csh_batch {
     DevBuf<uint32_t> d_tok_cursor;
     DevBuf<TokRegion> d_regions;
     DevBuf<uint16_t> d_eobrun, d_slot_hist;
-    DevBuf<uint32_t> d_slot_raw, d_slot_eobh, d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
+    DevBuf<uint32_t> d_img_list, d_img_nlist, d_scan_cost, d_slot_raw, d_slot_eobh, d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
 
@@ -416,6 +425,107 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     add_script(b->script, 3, false);  // entry 16
     add_script(b->script, 1, false);  // entry 17
     const int script_base3 = progressive ? 0 : 16, script_base1 = progressive ? 10 : 17;
+    b->search = progressive && !webp && !rgb_out && !(getenv("CSH_PROFILE") && !strcmp(getenv("CSH_PROFILE"), "plain"));
+    // EncScan entries of the search's candidates, made on first use
+    auto cand_index = [&](int comp, int Ss, int Se, int Ah, int Al) -> int {
+        const std::array<int, 5> key = {comp, Ss, Se, Ah, Al};
+        auto f = b->cand_script.find(key);
+        if (f != b->cand_script.end()) return f->second;
+        EncScan e;
+        memset(&e, 0, sizeof e);
+        const int id = comp ? 1 : 0;
+        e.ncomp = 1; e.comp[0] = comp; e.Ss = Ss; e.Se = Se; e.Ah = Ah; e.Al = Al;
+        e.ntables = 1; e.dht_id[0] = 0x10 | id; e.sos_tdta[0] = id;
+        b->script.push_back(e);
+        return b->cand_script[key] = int(b->script.size()) - 1;
+    };
+    auto dc_scan_index = [&](int ncomp) -> int {   // first DC scan of all components at Al = 0 (dc_scan_opt_mode 0)
+        const std::array<int, 5> key = {-ncomp, 0, 0, 0, 0};
+        auto f = b->cand_script.find(key);
+        if (f != b->cand_script.end()) return f->second;
+        EncScan e;
+        memset(&e, 0, sizeof e);
+        e.ncomp = ncomp;
+        for (int k = 0; k < ncomp; k++) {
+            e.comp[k] = k;
+            const int id = k ? 1 : 0;
+            int idx = -1;
+            for (int t = 0; t < e.ntables; t++) if (e.dht_id[t] == id) idx = t;
+            if (idx < 0) { idx = e.ntables; e.dht_id[e.ntables++] = id; }
+            e.dc_tbl[k] = idx; e.sos_tdta[k] = id << 4;
+        }
+        b->script.push_back(e);
+        return b->cand_script[key] = int(b->script.size()) - 1;
+    };
+    // work items, slots, token chunks and plans of one image for a list of scans (EncScan indices), in list order
+    auto add_works = [&](Item &it, ImgDesc &im, int img_index, const std::vector<int> &list, size_t in_len, const JpegInfo &o) {
+        const int w_first = int(b->swork.size());
+        for (int sidx : list) {
+            const EncScan &e = b->script[sidx];
+            ScanWork w;
+            memset(&w, 0, sizeof w);
+            w.image = img_index; w.scan = sidx;
+            if (e.Ss == 0 && e.ncomp > 1) w.nunits = uint32_t(im.omcus_x * im.omcus_y);
+            else w.nunits = uint32_t(im.out[e.comp[0]].real_bw * im.out[e.comp[0]].real_bh);
+            w.unit_base = uint32_t(b->total_units);
+            b->total_units += w.nunits;
+            w.word_base = uint32_t(b->total_words);
+            if (e.Ss) b->total_words += (w.nunits + 63) / 64;
+            w.table_base = uint32_t(b->ntables);
+            b->ntables += e.ntables;
+            b->max_units = std::max(b->max_units, w.nunits);
+            w.first_chunk = uint32_t(b->slot_work.size());
+            b->slot_work.insert(b->slot_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
+            for (uint32_t j = 0, nch = (w.nunits + 255) / 256; j < nch; j++) {
+                SlotRec r;
+                r.work = uint32_t(b->swork.size()); r.j = j; r.nch = nch; r.first_chunk = w.first_chunk; r.unit0 = w.unit_base + 256 * j;
+                r.nun = std::min<uint32_t>(256, w.nunits - 256 * j); r.table_base = w.table_base; r.ntables = uint16_t(e.ntables);
+                r.flags = uint16_t((e.Ss > 0 && !e.sequential ? 1 : 0) | (e.Ss > 0 && !e.sequential && e.Ah ? 2 : 0));
+                r.hist_row = b->hist_rows; b->hist_rows += uint32_t(e.ntables);
+                r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
+                r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                b->slots.push_back(r);
+            }
+            if (e.Ss == 0 || e.sequential) {   // DC scans and sequential-mode scans: one token workgroup per (scan, 256 units)
+                // tokens of a DC scan are known exactly (one per block, or one per fifteen blocks' bits); a sequential-mode block has at most 64 + 3
+                uint32_t blocks = 0;
+                for (int k = 0; k < e.ncomp; k++) blocks += e.ncomp > 1 ? uint32_t(o.comp[e.comp[k]].h * o.comp[e.comp[k]].v) : 1u;
+                const uint32_t per_unit = e.sequential ? blocks * 20u : (e.Ah ? (blocks + 14u) / 15u : blocks);
+                for (uint32_t j = 0; j < (w.nunits + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(b->swork.size()), 0, 1, j, 0, uint32_t(b->region_est.size())});
+                b->region_est.push_back(w.nunits * per_unit + 64);
+            }
+            b->swork.push_back(w);
+        }
+        // the progressive AC scans of a component share one pass over its blocks
+        for (int c = 0; c < im.ncomp; c++) {
+            int nac = 0;
+            for (int sidx : list) { const EncScan &e = b->script[sidx]; if (e.Ss > 0 && !e.sequential && e.comp[0] == c) { nac++; if (e.Al > (e.Ah ? 3 : 4)) nac = 99; } }
+            if (nac > CSH_TK_MAXSLOT) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "internal: output scan script outside what the token kernel carries"; }
+            const uint32_t nu = uint32_t(im.out[c].real_bw * im.out[c].real_bh);
+            if (!nac || nac > CSH_TK_MAXSLOT) continue;
+            TokPlan P;
+            memset(&P, 0, sizeof P);
+            P.nunits = nu; P.real_bw = im.out[c].real_bw; P.bw = im.out[c].bw; P.tile_base = im.out[c].tile_base;   // tile_base of re-quantised tiles is rebased below
+            for (size_t k = 0; k < list.size(); k++) {
+                const EncScan &e = b->script[list[k]];
+                if (!(e.Ss > 0 && !e.sequential && e.comp[0] == c)) continue;
+                const ScanWork &w = b->swork[size_t(w_first) + k];
+                AcSlot &a = P.s[P.nslot++];
+                a.unit_base = w.unit_base; a.word_base = w.word_base; a.first_chunk = w.first_chunk; a.table_base = w.table_base; a.nunits_work = w.nunits;
+                a.Ss = uint8_t(e.Ss); a.Se = uint8_t(e.Se); a.Ah = uint8_t(e.Ah); a.Al = uint8_t(e.Al);
+            }
+            // every non-zero coefficient becomes a token in exactly one scan of a script (~5 bits of a source file each), plus an EOB per
+            // block and scan; the search's lists hold several scripts' worth
+            uint64_t blocks_all = 0;
+            for (int k = 0; k < im.ncomp; k++) blocks_all += uint64_t(im.out[k].real_bw) * im.out[k].real_bh;
+            const uint64_t scripts = b->search ? uint64_t(nac + 1) / 2 : 1;
+            const uint64_t est = uint64_t(in_len) * 3 * scripts * nu / std::max<uint64_t>(1, blocks_all) + uint64_t(nu) * nac + 1024;
+            for (uint32_t j = 0; j < (nu + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(img_index), uint16_t(c), 0, j, uint32_t(b->plans.size()), uint32_t(b->region_est.size())});
+            b->region_est.push_back(uint32_t(std::min<uint64_t>(est, 0x3FFFFFFFu)));
+            b->plan_comp.push_back(c); b->plan_image.push_back(img_index);
+            b->plans.push_back(P);
+        }
+    };
 
     std::vector<std::pair<std::vector<uint8_t>, int>> hset_keys;
     std::map<std::vector<uint16_t>, int> quant_index;
@@ -730,75 +840,40 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         }
 
         // output scans
-        int sb = in.ncomp == 3 ? script_base3 : script_base1;
-        int ns = progressive ? (in.ncomp == 3 ? 10 : 6) : 1;
         im.first_work = int(b->swork.size());
-        im.nscans_out = ns;
-        for (int s = 0; s < ns; s++) {
-            const EncScan &e = b->script[sb + s];
-            ScanWork w;
-            memset(&w, 0, sizeof w);
-            w.image = img_index; w.scan = sb + s;
-            if (e.Ss == 0 && e.ncomp > 1) w.nunits = uint32_t(im.omcus_x * im.omcus_y);
-            else w.nunits = uint32_t(im.out[e.comp[0]].real_bw * im.out[e.comp[0]].real_bh);
-            w.unit_base = uint32_t(b->total_units);
-            b->total_units += w.nunits;
-            w.word_base = uint32_t(b->total_words);
-            if (e.Ss) b->total_words += (w.nunits + 63) / 64;
-            w.table_base = uint32_t(b->ntables);
-            b->ntables += e.ntables;
-            b->max_units = std::max(b->max_units, w.nunits);
-            w.first_chunk = uint32_t(b->slot_work.size());
-            b->slot_work.insert(b->slot_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
-            for (uint32_t j = 0, nch = (w.nunits + 255) / 256; j < nch; j++) {
-                SlotRec r;
-                r.work = uint32_t(b->swork.size()); r.j = j; r.nch = nch; r.first_chunk = w.first_chunk; r.unit0 = w.unit_base + 256 * j;
-                r.nun = std::min<uint32_t>(256, w.nunits - 256 * j); r.table_base = w.table_base; r.ntables = uint16_t(e.ntables);
-                r.flags = uint16_t((e.Ss > 0 && !e.sequential ? 1 : 0) | (e.Ss > 0 && !e.sequential && e.Ah ? 2 : 0));
-                r.hist_row = b->hist_rows; b->hist_rows += uint32_t(e.ntables);
-                r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
-                r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
-                b->slots.push_back(r);
+        if (!b->search) {
+            int sb = in.ncomp == 3 ? script_base3 : script_base1;
+            int ns = progressive ? (in.ncomp == 3 ? 10 : 6) : 1;
+            std::vector<int> list;
+            for (int s = 0; s < ns; s++) list.push_back(sb + s);
+            add_works(it, im, img_index, list, inputs[n].length, o);
+            for (int s = 0; s < ns; s++) b->img_list.push_back(uint32_t(im.first_work + s));
+            b->img_list.resize(size_t(img_index + 1) * CSH_LIST_MAX, 0u);
+            b->img_nlist.push_back(uint32_t(ns));
+        } else {
+            // stage 1 of the search: the DC scan and every candidate whose Al is fixed (oracle/jpeg_oracle.c cso_search_progression)
+            csh_batch::SearchImg si;
+            for (int &cw : si.cand_work) cw = -1;
+            std::vector<int> list, cands;
+            auto add = [&](int cand, int idx) { cands.push_back(cand); list.push_back(idx); };
+            add(0, dc_scan_index(in.ncomp));
+            add(1, cand_index(0, 1, 8, 0, 0)); add(2, cand_index(0, 9, 63, 0, 0));
+            for (int Al = 0; Al < 3; Al++) { add(3 + 3 * Al, cand_index(0, 1, 63, Al + 1, Al)); add(4 + 3 * Al, cand_index(0, 1, 8, 0, Al + 1)); add(5 + 3 * Al, cand_index(0, 9, 63, 0, Al + 1)); }
+            if (in.ncomp == 3) {
+                add(26, cand_index(1, 1, 8, 0, 0)); add(27, cand_index(1, 9, 63, 0, 0)); add(28, cand_index(2, 1, 8, 0, 0)); add(29, cand_index(2, 9, 63, 0, 0));
+                for (int Al = 0; Al < 2; Al++) {
+                    add(30 + 6 * Al, cand_index(1, 1, 63, Al + 1, Al)); add(31 + 6 * Al, cand_index(2, 1, 63, Al + 1, Al));
+                    add(32 + 6 * Al, cand_index(1, 1, 8, 0, Al + 1)); add(33 + 6 * Al, cand_index(1, 9, 63, 0, Al + 1));
+                    add(34 + 6 * Al, cand_index(2, 1, 8, 0, Al + 1)); add(35 + 6 * Al, cand_index(2, 9, 63, 0, Al + 1));
+                }
             }
-            if (e.Ss == 0 || e.sequential)   // DC scans and sequential-mode scans: one token workgroup per (scan, 256 units)
-            {
-                // tokens of a DC scan are known exactly (one per block, or one per fifteen blocks' bits); a sequential-mode block has at most 64 + 3
-                uint32_t blocks = 0;
-                for (int k = 0; k < e.ncomp; k++) blocks += e.ncomp > 1 ? uint32_t(o.comp[e.comp[k]].h * o.comp[e.comp[k]].v) : 1u;
-                const uint32_t per_unit = e.sequential ? blocks * 20u : (e.Ah ? (blocks + 14u) / 15u : blocks);
-                for (uint32_t j = 0; j < (w.nunits + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(b->swork.size()), 0, 1, j, 0, uint32_t(b->region_est.size())});
-                b->region_est.push_back(w.nunits * per_unit + 64);
-            }
-            b->swork.push_back(w);
+            add_works(it, im, img_index, list, inputs[n].length, o);
+            for (size_t k = 0; k < cands.size(); k++) si.cand_work[cands[k]] = im.first_work + int(k);
+            si.ncand = in.ncomp == 3 ? 64 : 23;
+            b->simg.push_back(si);
+            b->img_list.resize(size_t(img_index + 1) * CSH_LIST_MAX, 0u);
+            b->img_nlist.push_back(0u);
         }
-        if (progressive)   // the AC scans of a component share one pass over its blocks
-            for (int c = 0; c < in.ncomp; c++) {
-                int nac = 0;
-                for (int s = 0; s < ns; s++) { const EncScan &e = b->script[sb + s]; if (e.Ss > 0 && e.comp[0] == c) { nac++; if (e.Al > (e.Ah ? 3 : 4)) nac = 99; } }
-                if (nac > CSH_TK_MAXSLOT) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "internal: output scan script outside what the token kernel carries"; }
-                const uint32_t nu = uint32_t(im.out[c].real_bw * im.out[c].real_bh);
-                if (!nac || nac > CSH_TK_MAXSLOT) continue;
-                TokPlan P;
-                memset(&P, 0, sizeof P);
-                P.nunits = nu; P.real_bw = im.out[c].real_bw; P.bw = im.out[c].bw; P.tile_base = im.out[c].tile_base;   // tile_base of re-quantised tiles is rebased below
-                for (int s = 0; s < ns; s++) {
-                    const EncScan &e = b->script[sb + s];
-                    if (!(e.Ss > 0 && e.comp[0] == c)) continue;
-                    const ScanWork &w = b->swork[size_t(im.first_work) + s];
-                    AcSlot &a = P.s[P.nslot++];
-                    a.unit_base = w.unit_base; a.word_base = w.word_base; a.first_chunk = w.first_chunk; a.table_base = w.table_base; a.nunits_work = w.nunits;
-                    a.Ss = uint8_t(e.Ss); a.Se = uint8_t(e.Se); a.Ah = uint8_t(e.Ah); a.Al = uint8_t(e.Al);
-                }
-                {   // every non-zero coefficient becomes a token in exactly one scan (~5 bits of a source file each), plus an EOB per block and scan
-                    uint64_t blocks_all = 0;
-                    for (int k = 0; k < in.ncomp; k++) blocks_all += uint64_t(im.out[k].real_bw) * im.out[k].real_bh;
-                    const uint64_t est = uint64_t(inputs[n].length) * 3 * nu / std::max<uint64_t>(1, blocks_all) + uint64_t(nu) * nac + 1024;
-                    for (uint32_t j = 0; j < (nu + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(img_index), uint16_t(c), 0, j, uint32_t(b->plans.size()), uint32_t(b->region_est.size())});
-                    b->region_est.push_back(uint32_t(std::min<uint64_t>(est, 0x3FFFFFFFu)));
-                }
-                b->plan_comp.push_back(c); b->plan_image.push_back(img_index);
-                b->plans.push_back(P);
-            }
         if (b->total_units > 0xFFFFFFF0ull) { it.code = CS_ERR_POOL_OVERFLOW; it.msg = "batch too large"; }
 
         // frame header (host-built): SOI, JFIF, [metadata], DQT, SOF
@@ -821,10 +896,48 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
 
         it.image = img_index;
         b->imgs.push_back(im);
-        b->raw_bytes_cap += 2 * inputs[n].length + 64 * 1024;
+        b->raw_bytes_cap += (b->search ? 12 : 2) * inputs[n].length + 64 * 1024;   // the search's candidates are ten scripts' worth of scans
     }
     b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
     b->nimg = int(b->imgs.size());
+    // stage boundary: everything made so far is stage 1 (without the search: all there is)
+    b->stage[0].nwork = uint32_t(b->swork.size()); b->stage[0].nslots = uint32_t(b->slot_work.size()); b->stage[0].nech = uint32_t(b->echunks.size());
+    b->stage[0].ntables = uint32_t(b->ntables); b->stage[0].nplans = uint32_t(b->plans.size());
+    if (b->search) {
+        // one unused slot between the stages: each stage's exclusive scan of chunk sizes writes one entry past its slots
+        { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
+        b->stage[1].work0 = uint32_t(b->swork.size()); b->stage[1].slot0 = uint32_t(b->slot_work.size()); b->stage[1].ech0 = uint32_t(b->echunks.size());
+        b->stage[1].table0 = uint32_t(b->ntables); b->stage[1].plan0 = uint32_t(b->plans.size());
+        static const int split[5] = {2, 8, 5, 12, 18};
+        for (size_t n = 0; n < count; n++) {
+            Item &it = b->items[n];
+            if (it.image < 0) continue;
+            ImgDesc &im = b->imgs[size_t(it.image)];
+            csh_batch::SearchImg &si = b->simg[size_t(it.image)];
+            // stage 2: the frequency-split candidates; their Al is the one stage 1 chooses (entered as 0 here, patched before the stage runs)
+            std::vector<int> list, cands;
+            auto add = [&](int cand, int idx) { cands.push_back(cand); list.push_back(idx); };
+            add(12, cand_index(0, 1, 63, 0, 0));
+            for (int i = 0; i < 5; i++) { add(13 + 2 * i, cand_index(0, 1, split[i], 0, 0)); add(14 + 2 * i, cand_index(0, split[i] + 1, 63, 0, 0)); }
+            if (im.ncomp == 3) {
+                add(42, cand_index(1, 1, 63, 0, 0)); add(43, cand_index(2, 1, 63, 0, 0));
+                for (int i = 0; i < 5; i++) {
+                    add(44 + 4 * i, cand_index(1, 1, split[i], 0, 0)); add(45 + 4 * i, cand_index(1, split[i] + 1, 63, 0, 0));
+                    add(46 + 4 * i, cand_index(2, 1, split[i], 0, 0)); add(47 + 4 * i, cand_index(2, split[i] + 1, 63, 0, 0));
+                }
+            }
+            for (int c = 0; c < im.ncomp; c++) for (int i = -1; i < 5; i++) for (int Al = 1; Al <= (c ? 2 : 3); Al++) {   // the variants the patch may pick
+                if (i < 0) cand_index(c, 1, 63, 0, Al); else { cand_index(c, 1, split[i], 0, Al); cand_index(c, split[i] + 1, 63, 0, Al); }
+            }
+            const int first2 = int(b->swork.size());
+            add_works(it, im, it.image, list, inputs[n].length, it.out);
+            for (size_t k = 0; k < cands.size(); k++) si.cand_work[cands[k]] = first2 + int(k);
+        }
+        b->stage[1].nwork = uint32_t(b->swork.size()) - b->stage[1].work0; b->stage[1].nslots = uint32_t(b->slot_work.size()) - b->stage[1].slot0;
+        b->stage[1].nech = uint32_t(b->echunks.size()) - b->stage[1].ech0; b->stage[1].ntables = uint32_t(b->ntables) - b->stage[1].table0;
+        b->stage[1].nplans = uint32_t(b->plans.size()) - b->stage[1].plan0;
+        if (b->total_units > 0xFFFFFFF0ull) { csh_set_error("csh_batch_create: batch too large for the scan search's candidate lists (fewer files per batch)"); return CS_ERR_POOL_OVERFLOW; }
+    }
     // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
     if (!b->lossless)
         for (ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) im.out[c].tile_base += b->ntiles_in;
@@ -864,7 +977,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
             b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_corr.alloc(b->total_units + 1) ||
             b->d_tok_off.alloc(4 * b->slot_work.size() + 4) || b->d_chunk_ntok.alloc(4 * b->slot_work.size() + 4) || b->d_slot_hist.alloc(size_t(b->hist_rows) * 256 + 256) ||
-            b->d_slot_raw.alloc(b->slot_work.size() + 1) || b->d_slot_eobh.alloc(16 * b->slot_work.size() + 16) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
+            b->d_slot_raw.alloc(b->slot_work.size() + 1) || b->d_img_list.upload(b->img_list, st) || b->d_img_nlist.upload(b->img_nlist, st) || b->d_scan_cost.alloc(b->swork.size() + 1) || b->d_slot_eobh.alloc(16 * b->slot_work.size() + 16) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
             b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
@@ -926,8 +1039,8 @@ static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
     "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "k_tokens",
     "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack",
-    "k_ff_count", "scan_chunks", "k_layout", "scan_images", "k_emit", "", "", "", "", "", "", ""};
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 4, 4, 4, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7};
+    "k_ff_count", "scan_chunks", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", "", "", "", ""};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 4, 4, 4, 5, 6, 6, 7, 6, 6, 6, 7, 7, 7, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 
 // the WebP tail of a run: RGB (resize branch) -> YUV 4:2:0 -> macroblocks -> tokens; files land in the batch's output pool at
@@ -988,6 +1101,105 @@ static int run_rgb_only(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
         t->n_images = uint32_t(b->nimg);
     }
     for (int i = 0; i <= CSH_NKERNELS; i++) (void)hipEventDestroy(ev[i]);
+    return 0;
+}
+
+// The host side of mozjpeg's scan search (jcmaster.c select_scans [UPSTREAM-RECALL]; the statement the oracle is pinned with:
+// oracle/jpeg_oracle.c cso_search_progression).  The device has coded a stage's candidate scans; their sizes (DHT + SOS + stuffed data)
+// come back, the decisions are replayed per image, and what they decide goes to the device: after stage 1 the Al of the stage-2
+// candidates (their work items' scan and their plans), after stage 2 every file's list of scans.
+static int search_select(csh_batch *b, AsmCtx &a, int stage) {
+    hipStream_t st = b->stream;
+    const csh_batch::Stage &sg = b->stage[stage];
+    a.work0 = int(sg.work0); a.nwork_run = int(sg.nwork);
+    launch_scan_cost(st, a);
+    b->h_cost.resize(b->swork.size());
+    CSH_CHECK(hipMemcpyAsync(b->h_cost.data() + sg.work0, b->d_scan_cost.p + sg.work0, size_t(sg.nwork) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    CSH_CHECK(hipStreamSynchronize(st));
+    static const int split[5] = {2, 8, 5, 12, 18};
+    const int luma_split0 = 12, nluma = 23, chroma_base = 26, chroma_split0 = 42;
+    for (int i = 0; i < b->nimg; i++) {
+        csh_batch::SearchImg &si = b->simg[size_t(i)];
+        const ImgDesc &im = b->imgs[size_t(i)];
+        auto size = [&](int cand) -> uint64_t { return b->h_cost[size_t(si.cand_work[cand])]; };
+        if (stage == 0) {
+            uint64_t best = 0;
+            si.Al_luma = 0; si.Al_chroma = 0;
+            for (int Al = 0; Al <= 3; Al++) {   // after candidates 2, 5, 8, 11: the two band scans at Al plus the refinements that bring it back to 0
+                uint64_t cost = size(1 + 3 * Al) + size(2 + 3 * Al);
+                for (int k = 0; k < Al; k++) cost += size(3 + 3 * k);
+                if (Al == 0 || cost < best) { best = cost; si.Al_luma = Al; } else break;
+            }
+            if (im.ncomp == 3)
+                for (int Al = 0; Al <= 2; Al++) {
+                    uint64_t cost = 0;
+                    for (int k = 0; k < 4; k++) cost += size(chroma_base + 6 * Al + k);
+                    for (int k = 0; k < Al; k++) cost += size(chroma_base + 4 + 6 * k) + size(chroma_base + 5 + 6 * k);
+                    if (Al == 0 || cost < best) { best = cost; si.Al_chroma = Al; } else break;
+                }
+            // stage 2 of this image is coded at these Al
+            for (int cand = luma_split0; cand < (im.ncomp == 3 ? 64 : nluma); cand++) {
+                if (cand >= nluma && cand < chroma_split0) continue;
+                const int wi = si.cand_work[cand];
+                if (wi < 0) continue;
+                ScanWork &w = b->swork[size_t(wi)];
+                const EncScan e = b->script[size_t(w.scan)];
+                const int Al = e.comp[0] == 0 ? si.Al_luma : si.Al_chroma;
+                w.scan = b->cand_script.at({e.comp[0], e.Ss, e.Se, 0, Al});
+            }
+        } else {
+            int split_luma = 0, split_chroma = 0;
+            uint64_t best = size(luma_split0);
+            for (int idx = 1; idx <= 5; idx++) {
+                const uint64_t cost = size(luma_split0 + 2 * idx - 1) + size(luma_split0 + 2 * idx);
+                if (cost < best) { best = cost; split_luma = idx; }
+                if ((idx == 2 && split_luma == 0) || (idx == 3 && split_luma != 2) || (idx == 4 && split_luma != 4)) break;
+            }
+            if (im.ncomp == 3) {
+                best = size(chroma_split0) + size(chroma_split0 + 1);
+                for (int idx = 1; idx <= 5; idx++) {
+                    uint64_t cost = 0;
+                    for (int k = 2; k <= 5; k++) cost += size(chroma_split0 + 4 * (idx - 1) + k);
+                    if (cost < best) { best = cost; split_chroma = idx; }
+                    if ((idx == 2 && split_chroma == 0) || (idx == 3 && split_chroma != 2) || (idx == 4 && split_chroma != 4)) break;
+                }
+            }
+            // the file: DC, luma bands, luma refinements down to the Al both share, chroma bands, chroma refinements down to it, then the
+            // shared refinements, luma first
+            uint32_t *list = b->img_list.data() + size_t(i) * CSH_LIST_MAX;
+            uint32_t m = 0;
+            auto put = [&](int cand) { list[m++] = uint32_t(si.cand_work[cand]); };
+            const int min_Al = im.ncomp == 3 ? std::min(si.Al_luma, si.Al_chroma) : si.Al_luma;
+            put(0);
+            if (split_luma == 0) put(luma_split0); else { put(luma_split0 + 2 * split_luma - 1); put(luma_split0 + 2 * split_luma); }
+            for (int Al = si.Al_luma - 1; Al >= min_Al; Al--) put(3 + 3 * Al);
+            if (im.ncomp == 3) {
+                if (split_chroma == 0) { put(chroma_split0); put(chroma_split0 + 1); }
+                else for (int k = 2; k <= 5; k++) put(chroma_split0 + 4 * (split_chroma - 1) + k);
+                for (int Al = si.Al_chroma - 1; Al >= min_Al; Al--) { put(chroma_base + 6 * Al + 4); put(chroma_base + 6 * Al + 5); }
+            }
+            for (int Al = min_Al - 1; Al >= 0; Al--) {
+                put(3 + 3 * Al);
+                if (im.ncomp == 3) { put(chroma_base + 6 * Al + 4); put(chroma_base + 6 * Al + 5); }
+            }
+            b->img_nlist[size_t(i)] = m;
+        }
+    }
+    (void)split;
+    if (stage == 0) {
+        // patch the device's view of stage 2: the work items' scans, and the Al in the token plans
+        const csh_batch::Stage &s2 = b->stage[1];
+        for (uint32_t pi = s2.plan0; pi < s2.plan0 + s2.nplans; pi++) {
+            TokPlan &P = b->plans[pi];
+            const csh_batch::SearchImg &si = b->simg[size_t(b->plan_image[pi])];
+            for (uint32_t k = 0; k < P.nslot; k++) P.s[k].Al = uint8_t(b->plan_comp[pi] == 0 ? si.Al_luma : si.Al_chroma);
+        }
+        CSH_CHECK(hipMemcpyAsync(b->d_swork.p + s2.work0, b->swork.data() + s2.work0, size_t(s2.nwork) * sizeof(ScanWork), hipMemcpyHostToDevice, st));
+        CSH_CHECK(hipMemcpyAsync(b->d_plans.p + s2.plan0, b->plans.data() + s2.plan0, size_t(s2.nplans) * sizeof(TokPlan), hipMemcpyHostToDevice, st));
+    } else {
+        CSH_CHECK(hipMemcpyAsync(b->d_img_list.p, b->img_list.data(), b->img_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        CSH_CHECK(hipMemcpyAsync(b->d_img_nlist.p, b->img_nlist.data(), b->img_nlist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
     return 0;
 }
 
@@ -1105,19 +1317,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     c.chunk_bits = b->d_chunk_bits.p; c.chunk_off = b->d_chunk_off.p; c.tables = b->d_tables.p;
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p; c.overflow = b->d_overflow.p;
     c.debug = getenv("CSH_DEBUG") ? uint32_t(atoi(getenv("CSH_DEBUG"))) : 0u;
-    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_long_cnt.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st)) return -1;
-    MARK();
-    launch_tokens(st, c);
-    MARK();
-    launch_ac_runs(st, c);
-    MARK();
-    // ---- phase 3: optimal tables
-    launch_gen_tables(st, b->d_tables.p, b->ntables);
-    MARK();
-    // ---- phase 4: sizes + offsets
-    launch_chunk_sizes(st, c);
-    MARK();
-    launch_exclusive_scan(st, b->d_chunk_bits.p, b->d_chunk_off.p, b->slot_work.size(), b->d_scan_tmp.p, b->d_scan_tmp.n);
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st) || b->d_scan_pad.zero(st)) return -1;
     MARK();
     AsmCtx a;
     memset(&a, 0, sizeof a);
@@ -1126,17 +1326,43 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     a.raw = b->d_raw.p; a.raw_chunks = raw_chunks; a.chunk_ff = b->d_chunk_ff.p; a.chunk_ffoff = b->d_chunk_ffoff.p;
     a.hdr_pool = b->d_hdr.p; a.hdr_off = b->d_hdr_off.p; a.img_size = b->d_img_size.p; a.img_size_pad = b->d_img_size_pad.p;
     a.img_off = b->d_img_off.p; a.out = b->d_out.p; a.out_cap = b->out_cap; a.status = b->d_status.p; a.overflow = b->d_overflow.p;
-    launch_scan_sizes(st, a);
-    launch_exclusive_scan(st, b->d_scan_pad.p, b->d_scan_raw_off.p, uint64_t(a.nwork), b->d_scan_tmp.p, b->d_scan_tmp.n);
-    launch_scan_place(st, a);
-    MARK();
-    // ---- phase 5: pack
-    launch_pack(st, c);
-    MARK();
-    // ---- phase 6: stuffing + assembly
-    launch_ff_count(st, a);
-    MARK();
-    launch_exclusive_scan(st, b->d_chunk_ff.p, b->d_chunk_ffoff.p, raw_chunks, b->d_scan_tmp.p, b->d_scan_tmp.n);
+    a.img_list = b->d_img_list.p; a.img_nlist = b->d_img_nlist.p; a.scan_cost = b->d_scan_cost.p;
+    // one stage = tokens -> runs -> tables -> chunk sizes -> offsets -> pack -> stuffing counts, over a contiguous range of work items
+    // (without the scan search: one stage, everything).  mark: timing slots are recorded for stage 1 only, stage 2 gets one slot.
+    auto run_stage = [&](const csh_batch::Stage &sg, bool mark) -> int {
+#define SMARK() do { if (mark) MARK(); } while (0)
+        c.echunks = b->d_echunks.p + sg.ech0; c.nechunks = sg.nech; c.slot0 = sg.slot0; c.nslots = sg.nslots;
+        a.work0 = int(sg.work0); a.nwork_run = int(sg.nwork);
+        if (b->d_long_cnt.zero(st)) return -1;
+        launch_tokens(st, c);
+        SMARK();
+        launch_ac_runs(st, c);
+        SMARK();
+        launch_gen_tables(st, b->d_tables.p + sg.table0, int(sg.ntables));
+        SMARK();
+        launch_chunk_sizes(st, c);
+        SMARK();
+        launch_exclusive_scan(st, b->d_chunk_bits.p + sg.slot0, b->d_chunk_off.p + sg.slot0, sg.nslots, b->d_scan_tmp.p, b->d_scan_tmp.n);
+        SMARK();
+        launch_scan_sizes(st, a);
+        launch_exclusive_scan(st, b->d_scan_pad.p, b->d_scan_raw_off.p, uint64_t(a.nwork), b->d_scan_tmp.p, b->d_scan_tmp.n);   // all work items: those of a later stage still count zero
+        launch_scan_place(st, a);
+        SMARK();
+        launch_pack(st, c);
+        SMARK();
+        launch_ff_count(st, a);
+        SMARK();
+        launch_exclusive_scan(st, b->d_chunk_ff.p, b->d_chunk_ffoff.p, raw_chunks, b->d_scan_tmp.p, b->d_scan_tmp.n);
+        SMARK();
+#undef SMARK
+        return 0;
+    };
+    if (run_stage(b->stage[0], true)) return -1;
+    if (b->search) {
+        if (search_select(b, a, 0)) return -1;           // sizes of the stage-1 candidates -> Al of luma and chroma, per image; stage 2 patched
+        if (run_stage(b->stage[1], false)) return -1;
+        if (search_select(b, a, 1)) return -1;           // sizes of the stage-2 candidates -> frequency splits; the files' scan lists
+    }
     MARK();
     launch_layout(st, a);
     MARK();

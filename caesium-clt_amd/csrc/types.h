@@ -31,6 +31,7 @@
 #define CSH_MASK_PLANES 6
 #define CSH_MASK_TILE (CSH_MASK_PLANES * 64)
 #define CSH_MAX_SCANS 20
+#define CSH_LIST_MAX 16   // scans of one output file (the scan search ends with at most 14)
 
 namespace csh {
 
@@ -107,7 +108,7 @@ struct ImgDesc {
     int enc_w, enc_h;
     int first_scan, nscans_in;    // range in the DecScan array
     int comp_id[CSH_MAX_COMPS];   // component identifiers written to SOF/SOS
-    int first_work, nscans_out;   // this image's ScanWork range (output scans, in file order)
+    int first_work, nscans_out;   // host bookkeeping: the image's first work item and the number of them (the file's scans are EncCtx-independent: AsmCtx::img_list)
     uint32_t status;              // 0 ok; set by kernels on malformed data
 };
 
@@ -186,7 +187,7 @@ struct EChunk { uint32_t a; uint16_t comp, kind; uint32_t j; uint32_t plan; uint
 // the token pool is cut into regions with a bump cursor each -- one per (image, component) and one per DC / sequential scan: a single
 // cursor for the whole batch would be one L2 address taking a million atomics, one after the other
 struct TokRegion { uint64_t base; uint32_t cap, pad; };
-#define CSH_TK_MAXSLOT 8   // AC scans of one component that a kind-0 chunk can carry
+#define CSH_TK_MAXSLOT 12  // AC scans of one component that a kind-0 chunk can carry (a stage of the scan search has 11)
 // what a kind-0 chunk needs of its image, component and scans, in one piece (host-built per (image, component); the workgroup copies it
 // to LDS with one coalesced load instead of chasing ImgDesc -> ScanWork -> EncScan through dependent scalar loads, scan after scan)
 struct AcSlot { uint32_t unit_base, word_base, first_chunk, table_base, nunits_work; uint8_t Ss, Se, Ah, Al; uint32_t pad[2]; };   // 32 bytes

@@ -32,20 +32,26 @@ def emul_api():
     return package().CaesiumHip(so)
 
 
+def device_scan_script():
+    """the oracle's scan_script for what the device library does by default: mozjpeg's scan search (2); the stock jpeg_simple_progression
+    script (0) under CSH_PROFILE=plain"""
+    return 0 if os.environ.get("CSH_PROFILE") == "plain" else 2
+
+
 def oracle_lossy(src, quality=80, progressive=1, subsampling=420, keep_metadata=0, preserve_icc=1):
     from oracle import oracle as O
-    return O.jpeg_compress(src, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1,
+    return O.jpeg_compress(src, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script(),
                                          keep_metadata=keep_metadata, preserve_icc=preserve_icc))
 
 
 def oracle_lossless(src, progressive=1, keep_metadata=0, preserve_icc=1):
     from oracle import oracle as O
-    return O.jpeg_compress(src, O.params(progressive=progressive, marker_style=1, keep_metadata=keep_metadata, preserve_icc=preserve_icc), lossless=True)
+    return O.jpeg_compress(src, O.params(progressive=progressive, marker_style=1, scan_script=device_scan_script(), keep_metadata=keep_metadata, preserve_icc=preserve_icc), lossless=True)
 
 
 def oracle_resized(src, width, height, quality=80, subsampling=420):
     from oracle import oracle as O
-    return O.jpeg_compress_resized(src, O.params(quality=quality, progressive=1, subsampling=subsampling, qtable_profile=3, marker_style=1), width, height)
+    return O.jpeg_compress_resized(src, O.params(quality=quality, progressive=1, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), width, height)
 
 
 # ---------------------------------------------------------------- lossless PNG row
@@ -381,7 +387,7 @@ def oracle_png_to_jpeg(src, quality=80, width=0, height=0, subsampling=420, prog
         pix, ctype = png_expand8(P, ignore_trns=True)   # a tRNS chunk makes no alpha channel here
     if ctype in (4, 6):
         pix = pix[:, :, :-1]
-    return O.pixels_to_jpeg(pix, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1), width, height)
+    return O.pixels_to_jpeg(pix, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), width, height)
 
 
 def oracle_png_lossy(src, level=3, keep_metadata=False, quality=80):

@@ -325,6 +325,30 @@ def test_emul_lossless(api):
         assert out == oracle_lossless(src)
 
 
+def test_emul_scan_search_reproduces_reference_fixture(api, reference_samples):
+    """BASELINE configs[0], through the kernels: `--lossless` on the reference's own mozjpeg-made sample runs the scan search on j0's
+    coefficients (64 candidate scans coded in two stages, the decisions replayed on the host in between) and comes back with j0's own
+    DQT..EOI -- the 8-scan script is not given, it is found.  j1 (stock script in) leaves with a searched script and fewer bytes."""
+    d = open(os.path.join(reference_samples, "j0.JPG"), "rb").read()
+    out = api.compress_in_memory(d, params(jpeg_optimize=True))
+    assert out[out.index(b"\xff\xdb"):] == d[d.index(b"\xff\xdb"):]
+    d1 = open(os.path.join(reference_samples, "level_1_0", "j1.jpg"), "rb").read()
+    out1 = api.compress_in_memory(d1, params(jpeg_optimize=True))
+    assert out1 == oracle_lossless(d1) and len(out1) < len(d1)
+
+
+def test_emul_plain_profile_keeps_the_stock_script(api, monkeypatch):
+    """CSH_PROFILE=plain: jpeg_simple_progression's ten scans, the profile that is pinned to libjpeg-turbo's bytes"""
+    from oracle import oracle as O
+    monkeypatch.setenv("CSH_PROFILE", "plain")
+    src = synth_jpeg(5, 128, 96, texture=45)
+    out = api.compress_in_memory(src, params())
+    assert out == O.jpeg_compress(src, O.params(quality=80, scan_script=0)) == oracle_lossy(src)
+    assert O.decode(out).scans() == O.stock_script(3, 0)
+    monkeypatch.delenv("CSH_PROFILE")
+    assert api.compress_in_memory(src, params()) == O.jpeg_compress(src, O.params(quality=80, scan_script=2))
+
+
 def test_emul_long_eob_runs_and_flat_images(api):
     """flat / near-flat images: EOB runs spanning thousands of blocks (incl. the 0x7FFF split at 520x512 luma blocks)"""
     from PIL import Image

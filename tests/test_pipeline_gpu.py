@@ -161,6 +161,16 @@ def test_reference_fixture_lossless(api, reference_samples, rel):
 import test_pipeline_emul as E
 
 
+def test_scan_search_reproduces_reference_fixture(api, reference_samples):
+    E.test_emul_scan_search_reproduces_reference_fixture(api, reference_samples)
+
+
+def test_plain_profile_keeps_the_stock_script(api, monkeypatch):
+    E.test_emul_plain_profile_keeps_the_stock_script(api, monkeypatch)
+
+
+
+
 def test_sequential_output(api):
     E.test_emul_sequential_output(api)
 
