@@ -48,7 +48,8 @@ EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_siz
            "cs_batch_compress", "cs_batch_extent", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_batch_create",
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_create_webp", "csp_batch_create_pixels", "csh_batch_create_pixels", "csh_batch_pixels", "csh_batch_create_from_pixels", "csp_png_to_jpeg", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
-           "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert"]
+           "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert",
+           "cswd_batch_create", "cswd_batch_run", "cswd_batch_pixels", "cswd_batch_read_pixels", "cswd_batch_destroy", "csh_batch_create_webp_from_pixels", "csh_batch_create_from_pixels_rgb"]
 
 
 def _declare(L):
@@ -97,6 +98,12 @@ def _declare(L):
     L.csp_batch_read_scores.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, P(C.c_int)]
     L.csp_batch_chunk_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, P(C.c_uint64), C.c_size_t, P(C.c_size_t)]
     L.csp_batch_trials.argtypes = [C.c_void_p, C.c_size_t, P(C.c_int), P(C.c_uint64), P(C.c_int), P(C.c_int)]
+    L.cswd_batch_create.argtypes = [P(CByteArray), C.c_size_t, C.c_int, P(C.c_void_p)]
+    L.cswd_batch_run.argtypes = [C.c_void_p]
+    L.cswd_batch_pixels.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32), P(C.c_char_p)]
+    L.cswd_batch_read_pixels.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cswd_batch_destroy.argtypes = [C.c_void_p]
+    L.cswd_batch_destroy.restype = None
     return L
 
 
@@ -348,6 +355,38 @@ class CaesiumHip:
 
     def batch(self, blobs, params, device=0):
         return Batch(self, blobs, params, device)
+
+    def webp_decode(self, blobs, device=0):
+        """cswd_batch: lossy WebP files -> [H][W][3] uint8 arrays (or CaesiumError per file), decoded on the device"""
+        import numpy as np
+        L = self.L
+        n = len(blobs)
+        keep = [C.create_string_buffer(x, len(x)) for x in blobs]
+        ins = (CByteArray * n)()
+        for i, buf in enumerate(keep):
+            ins[i].data = C.cast(buf, C.POINTER(C.c_uint8)); ins[i].length = len(blobs[i])
+        h = C.c_void_p()
+        rc = L.cswd_batch_create(ins, n, device, C.byref(h))
+        if rc:
+            raise CaesiumError(rc, L.csh_last_error().decode())
+        try:
+            rc = L.cswd_batch_run(h)
+            if rc:
+                raise CaesiumError(rc, L.csh_last_error().decode())
+            out = []
+            for i in range(n):
+                p = C.c_void_p(); w = C.c_uint32(); hh = C.c_uint32(); ch = C.c_uint32(); msg = C.c_char_p()
+                rc = L.cswd_batch_pixels(h, i, C.byref(p), C.byref(w), C.byref(hh), C.byref(ch), C.byref(msg))
+                if rc:
+                    out.append(CaesiumError(rc, (msg.value or b"").decode()))
+                    continue
+                a = np.empty((hh.value, w.value, 3), dtype=np.uint8)
+                if L.cswd_batch_read_pixels(h, i, a.ctypes.data):
+                    raise CaesiumError(-1, L.csh_last_error().decode())
+                out.append(a)
+            return out
+        finally:
+            L.cswd_batch_destroy(h)
 
     def webp_batch(self, blobs, params, device=0):
         """JPEG in, WebP out: the same batch object with the VP8 encoder as its tail"""

@@ -604,29 +604,7 @@ int run(const Options &o) {
                 } else if (o.format != Format::Original) {
                     // convert + size targeting: one engine call per file, as the reference does
                     for (size_t k = 0; k < idx.size(); k++) {
-                        if (o.format == Format::Webp) {
-                            // the reference converts, then bisects the quality by re-encoding the WebP it made; this build has no WebP decoder, so the
-                            // same walk (start 80, bounds 1..101, 2 % tolerance, ten tries) runs over the conversion itself, from the source
-                            const size_t target = *o.max_size, tol = target * 2 / 100;
-                            int q = 80, less = 1, high = 101;
-                            for (int tries = 0;; tries++) {
-                                CCSParameters pk = p;
-                                pk.webp_quality = uint32_t(q);
-                                res[k] = cs_convert_in_memory(in[k].data, in[k].length, &pk, CS_TYPE_WEBP, &out[k]);
-                                if (!res[k].success) break;
-                                const size_t len = out[k].length;
-                                if (len <= target && target - len < tol) break;
-                                if (len <= target) less = q; else high = q;
-                                int nq = (high + less) / 2;
-                                nq = nq < 1 ? 1 : nq > 100 ? 100 : nq;
-                                if (nq == q) break;                     // the walk stopped moving: this file is the answer (the smallest one if even q = 1 is too big)
-                                if (tries + 1 >= 10) { cs_free_bytes(&out[k]); cs_free_result(&res[k]); res[k].success = false; res[k].code = CS_ERR_TOO_BIG; res[k].error_message = nullptr; silent[k] = 1; break; }
-                                q = nq;
-                                cs_free_bytes(&out[k]); cs_free_result(&res[k]);
-                            }
-                            if (!res[k].success && !silent[k]) { cs_free_result(&res[k]); res[k].success = false; res[k].error_message = nullptr; silent[k] = 1; }   // `.ok()?`: the text is dropped
-                            continue;
-                        }
+                        // convert, then walk the quality over the converted file (a WebP made here is decoded again on the device, as the reference does with libwebp)
                         res[k] = cs_convert_in_memory(in[k].data, in[k].length, &p, map_format(o.format), &out[k]);
                         if (o.max_size && res[k].success) {
                             CByteArray conv = out[k];

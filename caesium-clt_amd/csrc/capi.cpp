@@ -142,28 +142,88 @@ static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSP
     return failed_total;
 }
 
+// WebP inputs (libcaesium: libwebp decodes, then webp::compress / convert_in_memory, compressor.rs:289-305): the device decodes the
+// key frame (cswd_batch), the RGB stays in HBM and goes to the encoder of the target: the WebP encoder at webp.quality (`compress`
+// on a WebP file), the JPEG or the PNG row (conversions).  A size, if given, is applied by the JPEG row's Lanczos branch on the way.
+static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t target, int device, CByteArray *outputs, CCSResult *results) {
+    int failed_total = 0;
+    for (size_t g0 = 0, n = 0; g0 < count; g0 += n) {
+        uint64_t bytes = 0;
+        for (n = 0; g0 + n < count && n < 512 && (!n || bytes + inputs[g0 + n].length <= (uint64_t(256) << 20)); n++) bytes += inputs[g0 + n].length;
+        for (size_t k = 0; k < n; k++) { outputs[g0 + k].data = nullptr; outputs[g0 + k].length = 0; }
+        cswd_batch *wb = nullptr;
+        int rc = cswd_batch_create(inputs + g0, n, device, &wb);
+        if (rc == 0) rc = cswd_batch_run(wb);
+        std::vector<csp_pixels> px;
+        std::vector<size_t> at;
+        for (size_t k = 0; k < n && rc == 0; k++) {
+            csp_pixels s; const char *msg = "";
+            const int code = cswd_batch_pixels(wb, k, &s.device_pixels, &s.width, &s.height, &s.channels, &msg);
+            if (code) { if (results) results[g0 + k] = make_result(code, msg); failed_total++; } else { px.push_back(s); at.push_back(g0 + k); }
+        }
+        if (rc) { for (size_t k = 0; k < n; k++) if (results) results[g0 + k] = make_result(rc, csh_last_error()); failed_total += int(n); cswd_batch_destroy(wb); continue; }
+        if (!px.empty()) {
+            std::vector<CByteArray> out(px.size());
+            std::vector<CCSResult> res(px.size());
+            int failed = -1;
+            csh_batch *jb = nullptr, *rb = nullptr;
+            csp_batch *pb = nullptr;
+            if (target == CS_TYPE_PNG) {
+                std::vector<csp_pixels> src = px;
+                if (p->width || p->height) {   // resized pixels first: the JPEG row's resize branch, stopped behind its RGB
+                    rc = csh_batch_create_from_pixels_rgb(px.data(), px.size(), p, device, &rb);
+                    if (rc == 0) rc = csh_batch_run(rb, nullptr);
+                    for (size_t k = 0; k < px.size() && rc == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) rc = CS_ERR_NO_DEVICE; }
+                }
+                if (rc == 0) rc = csp_batch_create_pixels(src.data(), src.size(), p, device, &pb);
+                if (rc == 0) rc = csp_batch_run(pb, nullptr);
+                if (rc == 0) failed = csp_batch_fetch(pb, out.data(), res.data());
+            } else {
+                rc = target == CS_TYPE_WEBP ? csh_batch_create_webp_from_pixels(px.data(), px.size(), p, device, &jb) : csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
+                if (rc == 0) rc = csh_batch_run(jb, nullptr);
+                if (rc == 0) failed = csh_batch_fetch(jb, out.data(), res.data());
+            }
+            if (rc || failed < 0) { for (size_t k = 0; k < px.size(); k++) if (results) results[at[k]] = make_result(rc ? rc : CS_ERR_NO_DEVICE, csh_last_error()); failed_total += int(px.size()); }
+            else {
+                failed_total += failed;
+                for (size_t k = 0; k < px.size(); k++) { outputs[at[k]] = out[k]; if (results) results[at[k]] = res[k]; else cs_free_result(&res[k]); }
+            }
+            csp_batch_destroy(pb); csh_batch_destroy(jb); csh_batch_destroy(rb);
+        }
+        cswd_batch_destroy(wb);
+    }
+    return failed_total;
+}
+
 // one call, mixed inputs: PNG files go to the PNG pipeline, everything else to the JPEG pipeline (which
 // answers per file for what it has no device path for); results keep the order of the inputs
 int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
-    std::vector<size_t> png;   // PNG files: lossless under png.optimize, else the lossy (quantising) form of the same pipeline
-    for (size_t i = 0; i < count; i++) if (sniff(inputs[i].data, inputs[i].length) == CS_TYPE_PNG) png.push_back(i);
-    if (png.empty()) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
-    std::vector<size_t> other;
-    { size_t k = 0; for (size_t i = 0; i < count; i++) { if (k < png.size() && png[k] == i) k++; else other.push_back(i); } }
+    std::vector<size_t> png, webp, other;   // PNG files: lossless under png.optimize, else the lossy (quantising) form of the same pipeline
+    for (size_t i = 0; i < count; i++) {
+        const int t = sniff(inputs[i].data, inputs[i].length);
+        (t == CS_TYPE_PNG ? png : t == CS_TYPE_WEBP ? webp : other).push_back(i);
+    }
+    if (png.empty() && webp.empty()) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
     int failed = 0;
-    auto run = [&](const std::vector<size_t> &idx, bool is_png) {
+    auto run = [&](const std::vector<size_t> &idx, int kind) {
         if (idx.empty()) return;
         std::vector<CByteArray> in(idx.size()), out(idx.size());
         std::vector<CCSResult> res(idx.size());
-        for (size_t k = 0; k < idx.size(); k++) in[k] = inputs[idx[k]];
-        failed += is_png ? png_batch_compress(in.data(), in.size(), p, device, out.data(), res.data()) : jpeg_batch_compress(in.data(), in.size(), p, device, out.data(), res.data());
+        for (size_t k = 0; k < idx.size(); k++) { in[k] = inputs[idx[k]]; res[k] = make_result(0, nullptr); out[k].data = nullptr; out[k].length = 0; }
+        if (kind == 2 && p->webp_lossless) {
+            for (size_t k = 0; k < idx.size(); k++) res[k] = make_result(CS_ERR_UNSUPPORTED, "lossless WebP has no device path in this build");
+            failed += int(idx.size());
+        } else
+            failed += kind == 1 ? png_batch_compress(in.data(), in.size(), p, device, out.data(), res.data())
+                    : kind == 2 ? webp_inputs(in.data(), in.size(), p, CS_TYPE_WEBP, device, out.data(), res.data())
+                                : jpeg_batch_compress(in.data(), in.size(), p, device, out.data(), res.data());
         for (size_t k = 0; k < idx.size(); k++) { outputs[idx[k]] = out[k]; if (results) results[idx[k]] = res[k]; else cs_free_result(&res[k]); }
     };
-    run(png, true);
-    run(other, false);
+    run(png, 1);
+    run(webp, 2);
+    run(other, 0);
     return failed;
 }
-
 CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, CByteArray *out) {
     CByteArray input; input.data = const_cast<uint8_t *>(in); input.length = n;
     CCSResult r; r.success = false; r.code = 0; r.error_message = nullptr;
@@ -185,7 +245,7 @@ struct SizeWalk { int quality = 80, last_less = 1, last_high = 101, tries = 0; b
 // PNG pipeline for the files still searching, grouped by the quality they are at (the first round is one batch, later rounds a few);
 // under png.optimize the quality does not apply and one try is all there is
 static int png_compress_to_size(const CByteArray *inputs, size_t count, const CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
-                                CByteArray *outputs, CCSResult *results) {
+                                CByteArray *outputs, CCSResult *results, bool webp) {
     const size_t tolerance = max_output_size * 2 / 100;
     int failed_total = 0;
     std::vector<SizeWalk> walk(count);
@@ -199,8 +259,10 @@ static int png_compress_to_size(const CByteArray *inputs, size_t count, const CC
             std::vector<CCSResult> res(idx.size());
             for (size_t k = 0; k < idx.size(); k++) in[k] = inputs[idx[k]];
             CCSParameters q = *p;
-            q.png_quality = uint32_t(g.first);
-            png_batch_compress(in.data(), in.size(), &q, device, cur.data(), res.data());
+            q.png_quality = q.webp_quality = uint32_t(g.first);
+            // WebP files: the same walk over webp.quality, every try a decode + encode of the files still searching (libcaesium's webp::compress per try)
+            if (webp) { for (size_t k = 0; k < idx.size(); k++) res[k] = make_result(0, nullptr); webp_inputs(in.data(), in.size(), &q, CS_TYPE_WEBP, device, cur.data(), res.data()); }
+            else png_batch_compress(in.data(), in.size(), &q, device, cur.data(), res.data());
             for (size_t k = 0; k < idx.size(); k++) {
                 const size_t i = idx[k];
                 SizeWalk &w = walk[i];
@@ -212,7 +274,7 @@ static int png_compress_to_size(const CByteArray *inputs, size_t count, const CC
                     else results[i] = res[k];
                 };
                 if (!res[k].success) { w.done = true; cs_free_result(&results[i]); results[i] = res[k]; failed_total++; continue; }
-                if (p->png_optimize) { finish(true, 0, nullptr); continue; }
+                if (!webp && p->png_optimize) { finish(true, 0, nullptr); continue; }
                 const size_t len = cur[k].length;
                 if (len <= max_output_size && max_output_size - len < tolerance) { finish(true, 0, nullptr); continue; }
                 if (len <= max_output_size) w.last_less = w.quality; else w.last_high = w.quality;
@@ -236,23 +298,27 @@ static int jpeg_batch_compress_to_size(const CByteArray *inputs, size_t count, C
                                        CByteArray *outputs, CCSResult *results);
 int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
                               CByteArray *outputs, CCSResult *results) {
-    std::vector<size_t> png, other;
-    for (size_t i = 0; i < count; i++) (sniff(inputs[i].data, inputs[i].length) == CS_TYPE_PNG ? png : other).push_back(i);
-    if (png.empty()) return jpeg_batch_compress_to_size(inputs, count, p, max_output_size, return_smallest, device, outputs, results);
+    std::vector<size_t> png, webp, other;
+    for (size_t i = 0; i < count; i++) {
+        const int t = sniff(inputs[i].data, inputs[i].length);
+        (t == CS_TYPE_PNG ? png : t == CS_TYPE_WEBP ? webp : other).push_back(i);
+    }
+    if (png.empty() && webp.empty()) return jpeg_batch_compress_to_size(inputs, count, p, max_output_size, return_smallest, device, outputs, results);
     int failed = 0;
-    auto run = [&](const std::vector<size_t> &idx, bool is_png) {
+    auto run = [&](const std::vector<size_t> &idx, int kind) {
         if (idx.empty()) return;
         std::vector<CByteArray> in(idx.size()), out(idx.size());
         std::vector<CCSResult> res(idx.size());
         for (size_t k = 0; k < idx.size(); k++) { in[k] = inputs[idx[k]]; out[k].data = nullptr; out[k].length = 0; res[k] = make_result(0, nullptr); }
         CCSParameters q = *p;
-        failed += is_png ? png_compress_to_size(in.data(), in.size(), &q, max_output_size, return_smallest, device, out.data(), res.data())
-                         : jpeg_batch_compress_to_size(in.data(), in.size(), &q, max_output_size, return_smallest, device, out.data(), res.data());
-        if (!is_png) *p = q;   // the JPEG walk leaves its last quality in the caller's parameters, as the reference's &mut does
+        failed += kind ? png_compress_to_size(in.data(), in.size(), &q, max_output_size, return_smallest, device, out.data(), res.data(), kind == 2)
+                       : jpeg_batch_compress_to_size(in.data(), in.size(), &q, max_output_size, return_smallest, device, out.data(), res.data());
+        if (!kind) *p = q;   // the JPEG walk leaves its last quality in the caller's parameters, as the reference's &mut does
         for (size_t k = 0; k < idx.size(); k++) { outputs[idx[k]] = out[k]; results[idx[k]] = res[k]; }
     };
-    run(other, false);
-    run(png, true);
+    run(other, 0);
+    run(png, 1);
+    run(webp, 2);
     return failed;
 }
 static int jpeg_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
@@ -385,7 +451,7 @@ static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParamete
 // the same encoder), JPEG -> PNG and PNG -> JPEG (csp_png_to_jpeg) run on the device; every other pair of formats has no device path
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
-    std::vector<size_t> ok, okpng, topng, tojpeg;
+    std::vector<size_t> ok, okpng, topng, tojpeg, fromwebp;
     for (size_t i = 0; i < count; i++) {
         outputs[i].data = nullptr; outputs[i].length = 0;
         const int src = sniff(inputs[i].data, inputs[i].length);
@@ -394,7 +460,8 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         else if (uint32_t(src) == format) { code = CS_ERR_SAME_FORMAT; msg = "cannot convert to the same format"; }
         else if (src == CS_TYPE_JPEG && format == CS_TYPE_PNG) { topng.push_back(i); continue; }
         else if (src == CS_TYPE_PNG && format == CS_TYPE_JPEG) { tojpeg.push_back(i); continue; }
-        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG -> WebP, PNG -> WebP, JPEG -> PNG, PNG -> JPEG)"; }
+        else if (src == CS_TYPE_WEBP && (format == CS_TYPE_JPEG || format == CS_TYPE_PNG)) { fromwebp.push_back(i); continue; }
+        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG / PNG -> WebP, JPEG <-> PNG, lossy WebP -> JPEG / PNG)"; }
         else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
         if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
@@ -414,6 +481,14 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         }
         csh_batch_destroy(b);
         failed_total += failed < 0 ? int(n) : failed;
+    }
+    if (!fromwebp.empty()) {
+        const size_t n = fromwebp.size();
+        std::vector<CByteArray> in(n), out(n);
+        std::vector<CCSResult> res(n);
+        for (size_t k = 0; k < n; k++) { in[k] = inputs[fromwebp[k]]; res[k] = make_result(0, nullptr); }
+        failed_total += webp_inputs(in.data(), n, p, format, device, out.data(), res.data());
+        for (size_t k = 0; k < n; k++) { outputs[fromwebp[k]] = out[k]; if (results) results[fromwebp[k]] = res[k]; else cs_free_result(&res[k]); }
     }
     if (!topng.empty()) {
         const size_t n = topng.size();

@@ -1032,6 +1032,32 @@ extern "C" int csh_batch_create_from_pixels(const csp_pixels *sources, size_t co
     return batch_create(in.data(), count, p, device, false, out, false, sources);
 }
 
+// pixels in, (resized) pixels out: the resize branch alone, for WebP -> PNG with a size
+extern "C" int csh_batch_create_from_pixels_rgb(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csh_batch **out) {
+    *out = nullptr;
+    std::vector<std::vector<uint8_t>> files(count);
+    std::vector<CByteArray> in(count);
+    for (size_t i = 0; i < count; i++) {
+        const csp_pixels &s = sources[i];
+        if (!s.device_pixels || !s.width || !s.height || s.width > 65535 || s.height > 65535 || (s.channels != 1 && s.channels != 3)) files[i] = {'?'};
+        else files[i] = standin_jpeg(s.width, s.height, s.channels);
+        in[i].data = files[i].data(); in[i].length = files[i].size();
+    }
+    return batch_create(in.data(), count, p, device, false, out, true, sources);
+}
+extern "C" int csh_batch_create_webp_from_pixels(const csp_pixels *sources, size_t count, const CCSParameters *p, int device, csh_batch **out) {
+    *out = nullptr;
+    std::vector<std::vector<uint8_t>> files(count);
+    std::vector<CByteArray> in(count);
+    for (size_t i = 0; i < count; i++) {
+        const csp_pixels &s = sources[i];
+        if (!s.device_pixels || !s.width || !s.height || s.width > 16383 || s.height > 16383 || (s.channels != 1 && s.channels != 3)) files[i] = {'?'};
+        else files[i] = standin_jpeg(s.width, s.height, s.channels);
+        in[i].data = files[i].data(); in[i].length = files[i].size();
+    }
+    return batch_create(in.data(), count, p, device, true, out, false, sources);
+}
+
 extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()

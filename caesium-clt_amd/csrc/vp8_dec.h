@@ -1,0 +1,505 @@
+// vp8_dec.h -- VP8 key-frame decoder (RFC 6386), the lossy WebP inputs of libcaesium's webp::compress / convert paths
+// (/root/reference/src/compressor.rs:289-305, 589-598 name WebP among the inputs; libcaesium decodes them with libwebp).  One image is
+// decoded by ONE lane, start to end (boolean decoder, intra prediction, inverse transforms, loop filter, then libwebp's "fancy"
+// chroma upsampling and its fixed-point YCbCr -> RGB): the format is a serial chain per partition and the pictures of a batch are the
+// parallel axis.  Pixel-exact against libwebp (through Pillow) in tests/test_webp_decode*.py.
+// Everything here is host + device code: the emulation build compiles it as plain C++.
+#pragma once
+#include <cstdint>
+#include "../../include/vp8_tables.h"
+
+namespace csw {
+
+struct Vp8In {              // one input file, host-parsed container
+    uint64_t data_off;      // VP8 chunk payload in the input pool
+    uint32_t data_len;
+    uint32_t width, height, mbw, mbh;
+    uint64_t work_off;      // per-image work area in the work pool (layout below)
+    uint64_t rgb_off;       // width * height * 3 bytes in the pixel pool
+    uint32_t status;        // device: 0 ok, else an error code
+};
+// work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts
+__host__ __device__ static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t mbh) {
+    const uint64_t ly = uint64_t(mbw) * 16 * mbh * 16, lc = uint64_t(mbw) * 8 * mbh * 8;
+    return ly + 2 * lc + uint64_t(mbw) * mbh * 4 + uint64_t(mbw) * 16 + 256;
+}
+
+struct BoolDec {
+    const uint8_t *p, *end;
+    uint32_t value, range;
+    int bits;   // bits consumed of the current low byte
+    bool eof;
+    __host__ __device__ void init(const uint8_t *d, size_t n) {
+        p = d; end = d + n; eof = false;
+        value = 0;
+        for (int i = 0; i < 2; i++) value = (value << 8) | (p < end ? *p++ : 0u);
+        range = 255; bits = 0;
+    }
+    __host__ __device__ int get(int prob) {
+        const uint32_t split = 1u + (((range - 1u) * uint32_t(prob)) >> 8);
+        const uint32_t big = split << 8;
+        int r;
+        if (value >= big) { r = 1; range -= split; value -= big; } else { r = 0; range = split; }
+        while (range < 128u) {
+            value <<= 1; range <<= 1;
+            if (++bits == 8) { bits = 0; if (p < end) value |= *p++; else eof = true; }
+        }
+        return r;
+    }
+    __host__ __device__ uint32_t lit(int n) { uint32_t v = 0; while (n-- > 0) v = (v << 1) | uint32_t(get(128)); return v; }
+    __host__ __device__ int slit(int n) { const int v = int(lit(n)); return get(128) ? -v : v; }
+};
+
+__host__ __device__ static inline int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+__host__ __device__ static inline int clipq(int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; }
+
+// inverse DCT of one 4x4 block, added to the prediction in dst (libwebp TransformOne: the two multipliers of RFC 6386 14.3)
+__host__ __device__ static inline void vp8_idct_add(const int16_t *in, uint8_t *dst, int stride) {
+    int tmp[16];
+    for (int i = 0; i < 4; i++) {
+        const int a = in[i] + in[8 + i], b = in[i] - in[8 + i];
+        const int c = ((in[4 + i] * 35468) >> 16) - (((in[12 + i] * 20091) >> 16) + in[12 + i]);
+        const int d = (((in[4 + i] * 20091) >> 16) + in[4 + i]) + ((in[12 + i] * 35468) >> 16);
+        tmp[4 * i] = a + d; tmp[4 * i + 1] = b + c; tmp[4 * i + 2] = b - c; tmp[4 * i + 3] = a - d;
+    }
+    for (int i = 0; i < 4; i++) {
+        const int dc = tmp[i] + 4;
+        const int a = dc + tmp[8 + i], b = dc - tmp[8 + i];
+        const int c = ((tmp[4 + i] * 35468) >> 16) - (((tmp[12 + i] * 20091) >> 16) + tmp[12 + i]);
+        const int d = (((tmp[4 + i] * 20091) >> 16) + tmp[4 + i]) + ((tmp[12 + i] * 35468) >> 16);
+        uint8_t *o = dst + i * stride;
+        o[0] = uint8_t(clip8(o[0] + ((a + d) >> 3))); o[1] = uint8_t(clip8(o[1] + ((b + c) >> 3)));
+        o[2] = uint8_t(clip8(o[2] + ((b - c) >> 3))); o[3] = uint8_t(clip8(o[3] + ((a - d) >> 3)));
+    }
+}
+// inverse Walsh-Hadamard of the 16 luma DCs (libwebp TransformWHT); out[k * 16] = DC of block k
+__host__ __device__ static inline void vp8_iwht(const int16_t *in, int16_t *out) {
+    int tmp[16];
+    for (int i = 0; i < 4; i++) {
+        const int a0 = in[i] + in[12 + i], a1 = in[4 + i] + in[8 + i], a2 = in[4 + i] - in[8 + i], a3 = in[i] - in[12 + i];
+        tmp[i] = a0 + a1; tmp[8 + i] = a0 - a1; tmp[4 + i] = a3 + a2; tmp[12 + i] = a3 - a2;
+    }
+    for (int i = 0; i < 4; i++) {
+        const int dc = tmp[4 * i] + 3;
+        const int a0 = dc + tmp[4 * i + 3], a1 = tmp[4 * i + 1] + tmp[4 * i + 2], a2 = tmp[4 * i + 1] - tmp[4 * i + 2], a3 = dc - tmp[4 * i + 3];
+        out[(4 * i) * 16] = int16_t((a0 + a1) >> 3); out[(4 * i + 1) * 16] = int16_t((a3 + a2) >> 3);
+        out[(4 * i + 2) * 16] = int16_t((a0 - a1) >> 3); out[(4 * i + 3) * 16] = int16_t((a3 - a2) >> 3);
+    }
+}
+
+// ---- intra prediction.  `d` points at the block's top-left sample in a plane with `s` bytes per row whose row above and column to the
+// left hold the neighbours (frame edges: 127 above, 129 to the left, as libwebp initialises them)
+__host__ __device__ static inline void pred_fill(uint8_t *d, int s, int n, int v) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) d[y * s + x] = uint8_t(v); }
+__host__ __device__ static inline void pred_tm(uint8_t *d, int s, int n) {
+    const int tl = d[-s - 1];
+    for (int y = 0; y < n; y++) { const int l = d[y * s - 1]; for (int x = 0; x < n; x++) d[y * s + x] = uint8_t(clip8(l + d[-s + x] - tl)); }
+}
+__host__ __device__ static inline void pred_v(uint8_t *d, int s, int n) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) d[y * s + x] = d[-s + x]; }
+__host__ __device__ static inline void pred_h(uint8_t *d, int s, int n) { for (int y = 0; y < n; y++) { const uint8_t l = d[y * s - 1]; for (int x = 0; x < n; x++) d[y * s + x] = l; } }
+// DC of an n x n block (n = 16 or 8): has_top / has_left say which neighbours exist
+__host__ __device__ static inline void pred_dc(uint8_t *d, int s, int n, bool has_top, bool has_left) {
+    int sum = 0, cnt = 0;
+    if (has_top) { for (int x = 0; x < n; x++) sum += d[-s + x]; cnt += n; }
+    if (has_left) { for (int y = 0; y < n; y++) sum += d[y * s - 1]; cnt += n; }
+    const int v = cnt ? (sum + (cnt >> 1)) / cnt : 128;
+    pred_fill(d, s, n, v);
+}
+#define AVG3(a, b, c) uint8_t(((a) + 2 * (b) + (c) + 2) >> 2)
+#define AVG2(a, b) uint8_t(((a) + (b) + 1) >> 1)
+// the ten 4x4 modes (RFC 6386 12.3); tr = the four samples above and to the right
+__host__ __device__ static inline void pred4(uint8_t *d, int s, int mode, const uint8_t *tr) {
+    const int A = d[-s], B = d[-s + 1], C = d[-s + 2], D = d[-s + 3], E = tr[0], F = tr[1], G = tr[2], H = tr[3];
+    const int I = d[-1], J = d[s - 1], K = d[2 * s - 1], L = d[3 * s - 1], X = d[-s - 1];
+#define P(x, y) d[(y) * s + (x)]
+    switch (mode) {
+    case 0: { const int v = (A + B + C + D + I + J + K + L + 4) >> 3; pred_fill(d, s, 4, v); break; }          // B_DC_PRED
+    case 1: pred_tm(d, s, 4); break;                                                                                // B_TM_PRED
+    case 2: { const uint8_t v[4] = {AVG3(X, A, B), AVG3(A, B, C), AVG3(B, C, D), AVG3(C, D, E)};                   // B_VE_PRED
+              for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) P(x, y) = v[x]; break; }
+    case 3: { const uint8_t v[4] = {AVG3(X, I, J), AVG3(I, J, K), AVG3(J, K, L), AVG3(K, L, L)};                   // B_HE_PRED
+              for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) P(x, y) = v[y]; break; }
+    case 4:                                                                                                         // B_RD_PRED
+        P(0, 3) = AVG3(J, K, L); P(1, 3) = P(0, 2) = AVG3(I, J, K); P(2, 3) = P(1, 2) = P(0, 1) = AVG3(X, I, J);
+        P(3, 3) = P(2, 2) = P(1, 1) = P(0, 0) = AVG3(A, X, I); P(3, 2) = P(2, 1) = P(1, 0) = AVG3(B, A, X);
+        P(3, 1) = P(2, 0) = AVG3(C, B, A); P(3, 0) = AVG3(D, C, B); break;
+    case 5:                                                                                                         // B_VR_PRED
+        P(0, 0) = P(1, 2) = AVG2(X, A); P(1, 0) = P(2, 2) = AVG2(A, B); P(2, 0) = P(3, 2) = AVG2(B, C); P(3, 0) = AVG2(C, D);
+        P(0, 3) = AVG3(K, J, I); P(0, 2) = AVG3(J, I, X); P(0, 1) = P(1, 3) = AVG3(I, X, A); P(1, 1) = P(2, 3) = AVG3(X, A, B);
+        P(2, 1) = P(3, 3) = AVG3(A, B, C); P(3, 1) = AVG3(B, C, D); break;
+    case 6:                                                                                                         // B_LD_PRED
+        P(0, 0) = AVG3(A, B, C); P(1, 0) = P(0, 1) = AVG3(B, C, D); P(2, 0) = P(1, 1) = P(0, 2) = AVG3(C, D, E);
+        P(3, 0) = P(2, 1) = P(1, 2) = P(0, 3) = AVG3(D, E, F); P(3, 1) = P(2, 2) = P(1, 3) = AVG3(E, F, G);
+        P(3, 2) = P(2, 3) = AVG3(F, G, H); P(3, 3) = AVG3(G, H, H); break;
+    case 7:                                                                                                         // B_VL_PRED
+        P(0, 0) = AVG2(A, B); P(1, 0) = P(0, 2) = AVG2(B, C); P(2, 0) = P(1, 2) = AVG2(C, D); P(3, 0) = P(2, 2) = AVG2(D, E);
+        P(0, 1) = AVG3(A, B, C); P(1, 1) = P(0, 3) = AVG3(B, C, D); P(2, 1) = P(1, 3) = AVG3(C, D, E); P(3, 1) = P(2, 3) = AVG3(D, E, F);
+        P(3, 2) = AVG3(E, F, G); P(3, 3) = AVG3(F, G, H); break;
+    case 8:                                                                                                         // B_HD_PRED
+        P(0, 0) = P(2, 1) = AVG2(I, X); P(0, 1) = P(2, 2) = AVG2(J, I); P(0, 2) = P(2, 3) = AVG2(K, J); P(0, 3) = AVG2(L, K);
+        P(3, 0) = AVG3(A, B, C); P(2, 0) = AVG3(X, A, B); P(1, 0) = P(3, 1) = AVG3(I, X, A); P(1, 1) = P(3, 2) = AVG3(J, I, X);
+        P(1, 2) = P(3, 3) = AVG3(K, J, I); P(1, 3) = AVG3(L, K, J); break;
+    default:                                                                                                        // B_HU_PRED
+        P(0, 0) = AVG2(I, J); P(2, 0) = P(0, 1) = AVG2(J, K); P(2, 1) = P(0, 2) = AVG2(K, L);
+        P(1, 0) = AVG3(I, J, K); P(3, 0) = P(1, 1) = AVG3(J, K, L); P(3, 1) = P(1, 2) = AVG3(K, L, L);
+        P(3, 2) = P(2, 2) = P(0, 3) = P(1, 3) = P(2, 3) = P(3, 3) = uint8_t(L); break;
+    }
+#undef P
+}
+
+// ---- loop filter (RFC 6386 section 15, libwebp's arithmetic)
+__host__ __device__ static inline int sclip1(int v) { return v < -128 ? -128 : v > 127 ? 127 : v; }
+__host__ __device__ static inline int sclip2(int v) { return v < -16 ? -16 : v > 15 ? 15 : v; }
+__host__ __device__ static inline int iabs(int v) { return v < 0 ? -v : v; }
+__host__ __device__ static inline void lf2(uint8_t *p, int st) {
+    const int p1 = p[-2 * st], p0 = p[-st], q0 = p[0], q1 = p[st];
+    const int a = 3 * (q0 - p0) + sclip1(p1 - q1);
+    const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3);
+    p[-st] = uint8_t(clip8(p0 + a2)); p[0] = uint8_t(clip8(q0 - a1));
+}
+__host__ __device__ static inline void lf4(uint8_t *p, int st) {
+    const int p1 = p[-2 * st], p0 = p[-st], q0 = p[0], q1 = p[st];
+    const int a = 3 * (q0 - p0);
+    const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3), a3 = (a1 + 1) >> 1;
+    p[-2 * st] = uint8_t(clip8(p1 + a3)); p[-st] = uint8_t(clip8(p0 + a2)); p[0] = uint8_t(clip8(q0 - a1)); p[st] = uint8_t(clip8(q1 - a3));
+}
+__host__ __device__ static inline void lf6(uint8_t *p, int st) {
+    const int p2 = p[-3 * st], p1 = p[-2 * st], p0 = p[-st], q0 = p[0], q1 = p[st], q2 = p[2 * st];
+    const int a = sclip1(3 * (q0 - p0) + sclip1(p1 - q1));
+    const int a1 = (27 * a + 63) >> 7, a2 = (18 * a + 63) >> 7, a3 = (9 * a + 63) >> 7;
+    p[-3 * st] = uint8_t(clip8(p2 + a3)); p[-2 * st] = uint8_t(clip8(p1 + a2)); p[-st] = uint8_t(clip8(p0 + a1));
+    p[0] = uint8_t(clip8(q0 - a1)); p[st] = uint8_t(clip8(q1 - a2)); p[2 * st] = uint8_t(clip8(q2 - a3));
+}
+__host__ __device__ static inline bool lf_hev(const uint8_t *p, int st, int t) { return iabs(p[-2 * st] - p[-st]) > t || iabs(p[st] - p[0]) > t; }
+__host__ __device__ static inline bool lf_needs(const uint8_t *p, int st, int t) { return 4 * iabs(p[-st] - p[0]) + iabs(p[-2 * st] - p[st]) <= t; }
+__host__ __device__ static inline bool lf_needs2(const uint8_t *p, int st, int t, int it) {
+    if (4 * iabs(p[-st] - p[0]) + iabs(p[-2 * st] - p[st]) > t) return false;
+    return iabs(p[-4 * st] - p[-3 * st]) <= it && iabs(p[-3 * st] - p[-2 * st]) <= it && iabs(p[-2 * st] - p[-st]) <= it &&
+           iabs(p[3 * st] - p[2 * st]) <= it && iabs(p[2 * st] - p[st]) <= it && iabs(p[st] - p[0]) <= it;
+}
+// an edge of `size` samples: hs = step across the edge, vs = step along it
+__host__ __device__ static inline void lf_simple(uint8_t *p, int hs, int vs, int size, int thresh) {
+    const int t2 = 2 * thresh + 1;
+    for (int i = 0; i < size; i++, p += vs) if (lf_needs(p, hs, t2)) lf2(p, hs);
+}
+__host__ __device__ static inline void lf_edge(uint8_t *p, int hs, int vs, int size, int thresh, int ithresh, int hev, bool mb_edge) {
+    const int t2 = 2 * thresh + 1;
+    for (int i = 0; i < size; i++, p += vs)
+        if (lf_needs2(p, hs, t2, ithresh)) { if (lf_hev(p, hs, hev)) lf2(p, hs); else if (mb_edge) lf6(p, hs); else lf4(p, hs); }
+}
+
+// libwebp yuv.h: 14-bit fixed point with the rounding folded into the constants
+__host__ __device__ static inline int yuv_clip(int v) { return (v & ~16383) == 0 ? (v >> 6) : (v < 0 ? 0 : 255); }
+__host__ __device__ static inline void yuv_rgb(int y, int u, int v, uint8_t *o) {
+    const int yy = (y * 19077) >> 8;
+    o[0] = uint8_t(yuv_clip(yy + ((v * 26149) >> 8) - 14234));
+    o[1] = uint8_t(yuv_clip(yy - ((u * 6419) >> 8) - ((v * 13320) >> 8) + 8708));
+    o[2] = uint8_t(yuv_clip(yy + ((u * 33050) >> 8) - 17685));
+}
+
+struct Vp8Seg { int y1[2], y2[2], uv[2]; };
+struct Vp8FInfo { uint8_t limit, ilevel, inner, hev; };
+
+// the whole key frame.  Returns 0 or an error code (CS_ERR_* numbers are the caller's: 1 = malformed, 2 = unsupported feature)
+__host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *rgb) {
+    if (n < 10) return 1;
+    const uint32_t tag = data[0] | (data[1] << 8) | (data[2] << 16);
+    if (tag & 1) return 2;                                   // not a key frame
+    const uint32_t part0_len = tag >> 5;
+    if (data[3] != 0x9D || data[4] != 0x01 || data[5] != 0x2A) return 1;
+    const uint32_t fw = (data[6] | (data[7] << 8)) & 0x3FFF, fh = (data[8] | (data[9] << 8)) & 0x3FFF;
+    if (fw != W || fh != H || !W || !H) return 1;
+    if (10 + size_t(part0_len) > n) return 1;
+    const uint32_t mbw = (W + 15) >> 4, mbh = (H + 15) >> 4;
+    const int ys = int(mbw * 16), cs = int(mbw * 8);
+    uint8_t *Y = work, *U = Y + size_t(ys) * mbh * 16, *V = U + size_t(cs) * mbh * 8;
+    Vp8FInfo *finfo = reinterpret_cast<Vp8FInfo *>(V + size_t(cs) * mbh * 8);
+    uint8_t *ctx = reinterpret_cast<uint8_t *>(finfo + size_t(mbw) * mbh);   // per macroblock column: [0..3] sub-block modes above, [4..12] non-zero flags above (4 y, 2 u, 2 v, 1 y2)
+    BoolDec br; br.init(data + 10, part0_len);
+    br.get(128); br.get(128);                                // colour space, clamping type: no effect on decoding
+    // segments
+    bool use_seg = br.get(128) != 0, update_map = false, seg_abs = true;
+    int seg_q[4] = {0, 0, 0, 0}, seg_lf[4] = {0, 0, 0, 0}, seg_prob[3] = {255, 255, 255};
+    if (use_seg) {
+        update_map = br.get(128) != 0;
+        if (br.get(128)) {
+            seg_abs = br.get(128) != 0;
+            for (int i = 0; i < 4; i++) seg_q[i] = br.get(128) ? br.slit(7) : 0;
+            for (int i = 0; i < 4; i++) seg_lf[i] = br.get(128) ? br.slit(6) : 0;
+        }
+        if (update_map) for (int i = 0; i < 3; i++) seg_prob[i] = br.get(128) ? int(br.lit(8)) : 255;
+    }
+    // filter
+    const bool simple = br.get(128) != 0;
+    const int level = int(br.lit(6)), sharp = int(br.lit(3));
+    const bool use_delta = br.get(128) != 0;
+    int ref_delta[4] = {0, 0, 0, 0}, mode_delta[4] = {0, 0, 0, 0};
+    if (use_delta && br.get(128)) {
+        for (int i = 0; i < 4; i++) if (br.get(128)) ref_delta[i] = br.slit(6);
+        for (int i = 0; i < 4; i++) if (br.get(128)) mode_delta[i] = br.slit(6);
+    }
+    // token partitions
+    const int nparts = 1 << br.lit(2);
+    const uint8_t *psz = data + 10 + part0_len;
+    if (size_t(psz - data) + 3 * size_t(nparts - 1) > n) return 1;
+    const uint8_t *pstart = psz + 3 * (nparts - 1);
+    BoolDec tok[8];
+    {
+        const uint8_t *q = pstart;
+        for (int i = 0; i < nparts; i++) {
+            size_t len = i + 1 < nparts ? size_t(psz[3 * i] | (psz[3 * i + 1] << 8) | (psz[3 * i + 2] << 16)) : size_t(data + n - q);
+            if (q > data + n) return 1;
+            if (len > size_t(data + n - q)) len = size_t(data + n - q);
+            tok[i].init(q, len);
+            q += len;
+        }
+    }
+    // quantisers
+    const int base_q = int(br.lit(7));
+    int dq[5];
+    for (int i = 0; i < 5; i++) dq[i] = br.get(128) ? br.slit(4) : 0;   // y1 dc, y2 dc, y2 ac, uv dc, uv ac
+    Vp8Seg seg[4];
+    for (int i = 0; i < 4; i++) {
+        int q = base_q;
+        if (use_seg) q = seg_abs ? seg_q[i] : q + seg_q[i];
+        seg[i].y1[0] = kVp8DcQ[clipq(q + dq[0], 127)]; seg[i].y1[1] = kVp8AcQ[clipq(q, 127)];
+        seg[i].y2[0] = kVp8DcQ[clipq(q + dq[1], 127)] * 2; seg[i].y2[1] = (kVp8AcQ[clipq(q + dq[2], 127)] * 101581) >> 16;
+        if (seg[i].y2[1] < 8) seg[i].y2[1] = 8;
+        seg[i].uv[0] = kVp8DcQ[clipq(q + dq[3], 117)]; seg[i].uv[1] = kVp8AcQ[clipq(q + dq[4], 127)];
+    }
+    br.get(128);                                             // refresh_entropy_probs: a single frame
+    // coefficient probabilities
+    uint8_t probs_local[4 * 8 * 3 * 11];                     // [4 types][8 bands][3 contexts][11 nodes]
+    for (int i = 0; i < 4 * 8 * 3 * 11; i++) probs_local[i] = br.get(kVp8CoefUpdateProbs[i]) ? uint8_t(br.lit(8)) : kVp8CoefProbs[i];
+    const bool use_skip = br.get(128) != 0;
+    const int skip_p = use_skip ? int(br.lit(8)) : 0;
+    // filter strengths per segment and block type
+    Vp8FInfo fstr[4][2];
+    for (int s = 0; s < 4; s++)
+        for (int i4 = 0; i4 < 2; i4++) {
+            int base = level;
+            if (use_seg) base = seg_abs ? seg_lf[s] : base + seg_lf[s];
+            int lv = base;
+            if (use_delta) { lv += ref_delta[0]; if (i4) lv += mode_delta[0]; }
+            lv = clipq(lv, 63);
+            Vp8FInfo f = {0, 0, uint8_t(i4), 0};
+            if (lv > 0) {
+                int il = lv;
+                if (sharp > 0) { il >>= (sharp > 4) ? 2 : 1; if (il > 9 - sharp) il = 9 - sharp; }
+                if (il < 1) il = 1;
+                f.ilevel = uint8_t(il); f.limit = uint8_t(2 * lv + il); f.hev = uint8_t(lv >= 40 ? 2 : lv >= 15 ? 1 : 0);
+            }
+            fstr[s][i4] = f;
+        }
+    const bool filtering = level != 0;   // libwebp: a frame-level 0 switches the filter off whatever the segments say
+
+    for (uint32_t i = 0; i < mbw * 16; i++) ctx[i] = 0;
+    // ---- macroblocks
+    for (uint32_t my = 0; my < mbh; my++) {
+        BoolDec &tb = tok[my & uint32_t(nparts - 1)];
+        uint8_t left_modes[4] = {0, 0, 0, 0};
+        uint8_t lnz[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // non-zero flags to the left: 4 y, 2 u, 2 v, y2
+        for (uint32_t mx = 0; mx < mbw; mx++) {
+            uint8_t *top_modes = ctx + size_t(mx) * 16, *tnz = top_modes + 4;
+            // modes (first partition)
+            int segment = 0;
+            if (update_map) segment = !br.get(seg_prob[0]) ? br.get(seg_prob[1]) : br.get(seg_prob[2]) + 2;
+            const bool skip_flag = use_skip ? br.get(skip_p) != 0 : false;
+            const bool i4 = !br.get(145);
+            uint8_t bmodes[16];
+            int ymode = 0;
+            if (!i4) {
+                ymode = br.get(156) ? (br.get(128) ? 1 : 3) : (br.get(163) ? 2 : 0);   // B_ order: 0 DC, 1 TM, 2 V, 3 H
+                for (int k = 0; k < 4; k++) { top_modes[k] = uint8_t(ymode); left_modes[k] = uint8_t(ymode); }
+            } else {
+                for (int y = 0; y < 4; y++) {
+                    int lm = left_modes[y];
+                    for (int x = 0; x < 4; x++) {
+                        const uint8_t *pr = kVp8BModeProbs + (size_t(top_modes[x]) * 10 + size_t(lm)) * 9;
+                        int m;
+                        if (!br.get(pr[0])) m = 0;
+                        else if (!br.get(pr[1])) m = 1;
+                        else if (!br.get(pr[2])) m = 2;
+                        else if (!br.get(pr[3])) { if (!br.get(pr[4])) m = 3; else m = !br.get(pr[5]) ? 4 : 5; }
+                        else if (!br.get(pr[6])) m = 6;
+                        else if (!br.get(pr[7])) m = 7;
+                        else m = !br.get(pr[8]) ? 8 : 9;
+                        bmodes[4 * y + x] = uint8_t(m); top_modes[x] = uint8_t(m); lm = m;
+                    }
+                    left_modes[y] = uint8_t(lm);
+                }
+            }
+            const int uvmode = !br.get(142) ? 0 : !br.get(114) ? 2 : br.get(183) ? 1 : 3;
+            // residuals (token partition of this macroblock row)
+            int16_t coef[25 * 16];
+            for (int k = 0; k < 25 * 16; k++) coef[k] = 0;
+            bool any = false;
+            uint32_t nzmask = 0;   // blocks with coefficients: bit b (0..15 y, 16..19 u, 20..23 v)
+            const Vp8Seg &sq = seg[segment];
+            auto get_coeffs = [&](int type, int ctx0, const int *q2, int first, int16_t *out) -> int {
+                const uint8_t *bp = probs_local + size_t(type) * 8 * 33;
+                int nn = first;
+                const uint8_t *p = bp + size_t(kVp8Bands[nn]) * 33 + size_t(ctx0) * 11;
+                for (; nn < 16; nn++) {
+                    if (!tb.get(p[0])) return nn;
+                    while (!tb.get(p[1])) { p = bp + size_t(kVp8Bands[++nn]) * 33; if (nn == 16) return 16; }
+                    const uint8_t *pn = bp + size_t(kVp8Bands[nn + 1]) * 33;
+                    int v;
+                    if (!tb.get(p[2])) { v = 1; p = pn + 11; }
+                    else {
+                        if (!tb.get(p[3])) { v = !tb.get(p[4]) ? 2 : 3 + tb.get(p[5]); }
+                        else if (!tb.get(p[6])) {
+                            if (!tb.get(p[7])) v = 5 + tb.get(159);
+                            else { v = 7 + 2 * tb.get(165); v += tb.get(145); }
+                        } else {
+                            const int b1 = tb.get(p[8]), b0 = tb.get(p[9 + b1]), cat = 2 * b1 + b0;
+                            const uint8_t *tab = cat == 0 ? kVp8Cat3 : cat == 1 ? kVp8Cat4 : cat == 2 ? kVp8Cat5 : kVp8Cat6;
+                            v = 0;
+                            for (; *tab; ++tab) v += v + tb.get(*tab);
+                            v += 3 + (8 << cat);
+                        }
+                        p = pn + 22;
+                    }
+                    out[kVp8Zigzag[nn]] = int16_t((tb.get(128) ? -v : v) * q2[nn > 0]);
+                }
+                return 16;
+            };
+            if (!skip_flag) {
+                int first = 0, ytype = 3;
+                if (!i4) {
+                    int16_t dc[16];
+                    for (int k = 0; k < 16; k++) dc[k] = 0;
+                    const int nz = get_coeffs(1, tnz[8] + lnz[8], sq.y2, 0, dc);
+                    tnz[8] = lnz[8] = uint8_t(nz > 0);
+                    if (nz > 0) any = true;
+                    vp8_iwht(dc, coef);
+                    for (int k = 0; k < 16; k++) if (coef[16 * k]) nzmask |= 1u << k;
+                    first = 1; ytype = 0;
+                }
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++) {
+                        const int nz = get_coeffs(ytype, tnz[x] + lnz[y], sq.y1, first, coef + (4 * y + x) * 16);
+                        tnz[x] = lnz[y] = uint8_t(nz > first);
+                        if (nz > first) { any = true; nzmask |= 1u << (4 * y + x); }
+                    }
+                for (int ch = 0; ch < 2; ch++)
+                    for (int y = 0; y < 2; y++)
+                        for (int x = 0; x < 2; x++) {
+                            const int nz = get_coeffs(2, tnz[4 + 2 * ch + x] + lnz[4 + 2 * ch + y], sq.uv, 0, coef + (16 + 4 * ch + 2 * y + x) * 16);
+                            tnz[4 + 2 * ch + x] = lnz[4 + 2 * ch + y] = uint8_t(nz > 0);
+                            if (nz > 0) { any = true; nzmask |= 1u << (16 + 4 * ch + 2 * y + x); }
+                        }
+            } else {
+                for (int k = 0; k < 8; k++) { tnz[k] = 0; lnz[k] = 0; }
+                if (!i4) { tnz[8] = 0; lnz[8] = 0; }
+            }
+            if (filtering) { Vp8FInfo f = fstr[segment][i4 ? 1 : 0]; f.inner |= uint8_t((skip_flag || !any) ? 0 : 1); finfo[size_t(my) * mbw + mx] = f; }
+            // ---- reconstruction (prediction from UNFILTERED neighbours: the loop filter runs over the finished frame below)
+            uint8_t *yd = Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = V + size_t(my) * 8 * cs + size_t(mx) * 8;
+            // borders live in small local arrays copied around the block: the planes have no margin, so predict into a 21 x 17 scratch
+            uint8_t sy[(16 + 1) * 32], su[(8 + 1) * 16], sv[(8 + 1) * 16];
+            const int S = 32, SC = 16;
+            uint8_t *py = sy + S + 1, *pu = su + SC + 1, *pv = sv + SC + 1;
+            for (int x = -1; x < 20; x++) {
+                int v = 127;
+                if (my > 0) {
+                    if (x < 0) v = mx > 0 ? yd[-ys - 1] : 129;
+                    else if (x < 16) v = yd[-ys + x];
+                    else v = mx + 1 < mbw ? yd[-ys + x] : yd[-ys + 15];
+                }
+                py[-S + x] = uint8_t(v);
+            }
+            for (int y = 0; y < 16; y++) py[y * S - 1] = mx > 0 ? yd[y * ys - 1] : uint8_t(129);
+            for (int x = -1; x < 8; x++) {
+                int a = 127, b = 127;
+                if (my > 0) { if (x < 0) { a = mx > 0 ? ud[-cs - 1] : 129; b = mx > 0 ? vd[-cs - 1] : 129; } else { a = ud[-cs + x]; b = vd[-cs + x]; } }
+                pu[-SC + x] = uint8_t(a); pv[-SC + x] = uint8_t(b);
+            }
+            for (int y = 0; y < 8; y++) { pu[y * SC - 1] = mx > 0 ? ud[y * cs - 1] : uint8_t(129); pv[y * SC - 1] = mx > 0 ? vd[y * cs - 1] : uint8_t(129); }
+            if (!i4) {
+                switch (ymode) {
+                case 0: pred_dc(py, S, 16, my > 0, mx > 0); break;
+                case 1: pred_tm(py, S, 16); break;
+                case 2: pred_v(py, S, 16); break;
+                default: pred_h(py, S, 16); break;
+                }
+                for (int k = 0; k < 16; k++) if (nzmask & (1u << k)) vp8_idct_add(coef + 16 * k, py + (k >> 2) * 4 * S + (k & 3) * 4, S);
+            } else {
+                for (int k = 0; k < 16; k++) {
+                    uint8_t *d = py + (k >> 2) * 4 * S + (k & 3) * 4;
+                    uint8_t tr[4];
+                    if ((k & 3) == 3) { for (int q = 0; q < 4; q++) tr[q] = py[-S + 16 + q]; }    // right column: the four samples above and right of the MACROBLOCK, whatever the row
+                    else for (int q = 0; q < 4; q++) tr[q] = d[-S + 4 + q];
+                    pred4(d, S, bmodes[k], tr);
+                    if (nzmask & (1u << k)) vp8_idct_add(coef + 16 * k, d, S);
+                }
+            }
+            for (int ch = 0; ch < 2; ch++) {
+                uint8_t *pc = ch ? pv : pu;
+                switch (uvmode) {
+                case 0: pred_dc(pc, SC, 8, my > 0, mx > 0); break;
+                case 1: pred_tm(pc, SC, 8); break;
+                case 2: pred_v(pc, SC, 8); break;
+                default: pred_h(pc, SC, 8); break;
+                }
+                for (int k = 0; k < 4; k++) if (nzmask & (1u << (16 + 4 * ch + k))) vp8_idct_add(coef + (16 + 4 * ch + k) * 16, pc + (k >> 1) * 4 * SC + (k & 1) * 4, SC);
+            }
+            for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) yd[y * ys + x] = py[y * S + x];
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { ud[y * cs + x] = pu[y * SC + x]; vd[y * cs + x] = pv[y * SC + x]; }
+        }
+        if (br.eof) return 1;
+    }
+    // ---- loop filter, macroblock by macroblock in raster order
+    if (filtering)
+        for (uint32_t my = 0; my < mbh; my++)
+            for (uint32_t mx = 0; mx < mbw; mx++) {
+                const Vp8FInfo f = finfo[size_t(my) * mbw + mx];
+                if (!f.limit) continue;
+                uint8_t *yd = Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = V + size_t(my) * 8 * cs + size_t(mx) * 8;
+                if (simple) {
+                    if (mx > 0) lf_simple(yd, 1, ys, 16, f.limit + 4);
+                    if (f.inner) for (int k = 4; k < 16; k += 4) lf_simple(yd + k, 1, ys, 16, f.limit);
+                    if (my > 0) lf_simple(yd, ys, 1, 16, f.limit + 4);
+                    if (f.inner) for (int k = 4; k < 16; k += 4) lf_simple(yd + k * ys, ys, 1, 16, f.limit);
+                } else {
+                    if (mx > 0) { lf_edge(yd, 1, ys, 16, f.limit + 4, f.ilevel, f.hev, true); lf_edge(ud, 1, cs, 8, f.limit + 4, f.ilevel, f.hev, true); lf_edge(vd, 1, cs, 8, f.limit + 4, f.ilevel, f.hev, true); }
+                    if (f.inner) {
+                        for (int k = 4; k < 16; k += 4) lf_edge(yd + k, 1, ys, 16, f.limit, f.ilevel, f.hev, false);
+                        lf_edge(ud + 4, 1, cs, 8, f.limit, f.ilevel, f.hev, false); lf_edge(vd + 4, 1, cs, 8, f.limit, f.ilevel, f.hev, false);
+                    }
+                    if (my > 0) { lf_edge(yd, ys, 1, 16, f.limit + 4, f.ilevel, f.hev, true); lf_edge(ud, cs, 1, 8, f.limit + 4, f.ilevel, f.hev, true); lf_edge(vd, cs, 1, 8, f.limit + 4, f.ilevel, f.hev, true); }
+                    if (f.inner) {
+                        for (int k = 4; k < 16; k += 4) lf_edge(yd + k * ys, ys, 1, 16, f.limit, f.ilevel, f.hev, false);
+                        lf_edge(ud + 4 * cs, cs, 1, 8, f.limit, f.ilevel, f.hev, false); lf_edge(vd + 4 * cs, cs, 1, 8, f.limit, f.ilevel, f.hev, false);
+                    }
+                }
+            }
+    // ---- libwebp's fancy upsampler (chroma at 9:3:3:1 of the four nearest samples, computed on u | v << 16 pairs) + YCbCr -> RGB
+    const int cw = int((W + 1) >> 1), chh = int((H + 1) >> 1);
+    auto uvp = [&](int cx, int cy) -> uint32_t { return uint32_t(U[size_t(cy) * cs + cx]) | (uint32_t(V[size_t(cy) * cs + cx]) << 16); };
+    auto line_pair = [&](int ytop, int ybot, int ctop, int ccur) {   // ytop / ybot: luma rows (-1: none); chroma rows above / current
+        auto emit = [&](int yrow, int x, uint32_t uv) { yuv_rgb(Y[size_t(yrow) * ys + x], int(uv & 0xFF), int(uv >> 16), rgb + (size_t(yrow) * W + x) * 3); };
+        const int last_pair = (int(W) - 1) >> 1;
+        uint32_t tl = uvp(0, ctop), l = uvp(0, ccur);
+        if (ytop >= 0) emit(ytop, 0, (3 * tl + l + 0x00020002u) >> 2);
+        if (ybot >= 0) emit(ybot, 0, (3 * l + tl + 0x00020002u) >> 2);
+        for (int x = 1; x <= last_pair; x++) {
+            const uint32_t t = uvp(x, ctop), c = uvp(x, ccur);
+            const uint32_t avg = tl + t + l + c + 0x00080008u;
+            const uint32_t d12 = (avg + 2 * (t + l)) >> 3, d03 = (avg + 2 * (tl + c)) >> 3;
+            if (ytop >= 0) { emit(ytop, 2 * x - 1, (d12 + tl) >> 1); emit(ytop, 2 * x, (d03 + t) >> 1); }
+            if (ybot >= 0) { emit(ybot, 2 * x - 1, (d03 + l) >> 1); emit(ybot, 2 * x, (d12 + c) >> 1); }
+            tl = t; l = c;
+        }
+        if (!(W & 1)) {
+            if (ytop >= 0) emit(ytop, int(W) - 1, (3 * tl + l + 0x00020002u) >> 2);
+            if (ybot >= 0) emit(ybot, int(W) - 1, (3 * l + tl + 0x00020002u) >> 2);
+        }
+    };
+    (void)cw;
+    line_pair(0, -1, 0, 0);                                             // first row: its chroma row on both sides
+    for (int k = 1; k < chh; k++) line_pair(2 * k - 1, 2 * k, k - 1, k); // rows 2k-1 and 2k between chroma rows k-1 and k
+    if (!(H & 1)) line_pair(int(H) - 1, -1, chh - 1, chh - 1);          // even height: the last row again on its own
+    return 0;
+}
+
+}  // namespace csw

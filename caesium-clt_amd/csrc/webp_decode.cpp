@@ -1,0 +1,124 @@
+// webp_decode.cpp -- WebP INPUTS of the batch queue: container parsing on the host (RIFF / VP8 / VP8X chunk walk), the key frame on the
+// device (k_webp_dec.hip), the decoded RGB stays in HBM and is handed to the encoders as csp_pixels -- what libcaesium's
+// webp::compress and convert_in_memory do with libwebp's decoder in front (/root/reference/src/compressor.rs:289-305).
+// Built: lossy (VP8) still pictures.  Lossless (VP8L), alpha (ALPH) and animation answer CS_ERR_UNSUPPORTED per file.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/caesium_hip.h"
+#include "devmem.hpp"
+#include "webp_kernels.h"
+#include "vp8_dec.h"
+
+using namespace csh;
+
+struct cswd_batch {
+    int device = 0;
+    hipStream_t stream = 0;
+    bool have_stream = false;
+    struct Item { int code = 0; std::string msg; int image = -1; };
+    std::vector<Item> items;
+    std::vector<csw::Vp8In> imgs;
+    std::vector<uint8_t> pool;
+    DevBuf<uint8_t> d_pool, d_work, d_rgb;
+    DevBuf<csw::Vp8In> d_imgs;
+    uint64_t work_bytes = 0, rgb_bytes = 0;
+    bool ran = false;
+    ~cswd_batch() { if (have_stream) (void)hipStreamDestroy(stream); }
+};
+
+static uint32_t rd32le(const uint8_t *d) { return uint32_t(d[0]) | (uint32_t(d[1]) << 8) | (uint32_t(d[2]) << 16) | (uint32_t(d[3]) << 24); }
+
+// RIFF walk: where the VP8 key frame lies; refuses what this build does not decode
+static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint32_t &w, uint32_t &h, std::string &msg) {
+    if (n < 20 || memcmp(d, "RIFF", 4) || memcmp(d + 8, "WEBP", 4)) { msg = "not a WebP file"; return CS_ERR_UNKNOWN_TYPE; }
+    size_t end = size_t(rd32le(d + 4)) + 8;
+    if (end > n) end = n;   // libwebp tolerates a RIFF size past the file's end as long as the chunks are there
+    bool found = false;
+    for (size_t i = 12; i + 8 <= end;) {
+        const size_t cl = rd32le(d + i + 4);
+        if (i + 8 + cl > n) { msg = "truncated WebP chunk"; return CS_ERR_BAD_WEBP; }
+        if (!memcmp(d + i, "VP8 ", 4)) { if (!found) { off = i + 8; len = cl; found = true; } }
+        else if (!memcmp(d + i, "VP8L", 4)) { msg = "lossless WebP (VP8L) input has no device path in this build"; return CS_ERR_UNSUPPORTED; }
+        else if (!memcmp(d + i, "ALPH", 4)) { msg = "WebP input with an alpha plane has no device path in this build"; return CS_ERR_UNSUPPORTED; }
+        else if (!memcmp(d + i, "ANIM", 4) || !memcmp(d + i, "ANMF", 4)) { msg = "animated WebP input has no device path in this build"; return CS_ERR_UNSUPPORTED; }
+        i += 8 + cl + (cl & 1);
+    }
+    if (!found || len < 10) { msg = "no VP8 frame in the WebP file"; return CS_ERR_BAD_WEBP; }
+    const uint8_t *f = d + off;
+    if ((f[0] & 1) || f[3] != 0x9D || f[4] != 0x01 || f[5] != 0x2A) { msg = "malformed VP8 frame header"; return CS_ERR_BAD_WEBP; }
+    w = (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFF; h = (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFF;
+    if (!w || !h) { msg = "empty VP8 frame"; return CS_ERR_BAD_WEBP; }
+    return 0;
+}
+
+extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int device, cswd_batch **out) {
+    *out = nullptr;
+    if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
+    std::unique_ptr<cswd_batch> b(new cswd_batch);
+    b->device = device;
+    if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    b->have_stream = true;
+    b->items.resize(count);
+    for (size_t n = 0; n < count; n++) {
+        cswd_batch::Item &it = b->items[n];
+        size_t off = 0, len = 0;
+        uint32_t w = 0, h = 0;
+        it.code = parse_webp(inputs[n].data, inputs[n].length, off, len, w, h, it.msg);
+        if (it.code) continue;
+        csw::Vp8In im;
+        memset(&im, 0, sizeof im);
+        im.data_off = b->pool.size(); im.data_len = uint32_t(len);
+        b->pool.insert(b->pool.end(), inputs[n].data + off, inputs[n].data + off + len);
+        b->pool.resize((b->pool.size() + 15) & ~size_t(15));
+        im.width = w; im.height = h; im.mbw = (w + 15) / 16; im.mbh = (h + 15) / 16;
+        im.work_off = b->work_bytes; b->work_bytes += (csw::vp8_work_bytes(im.mbw, im.mbh) + 63) & ~uint64_t(63);
+        im.rgb_off = b->rgb_bytes; b->rgb_bytes += (uint64_t(w) * h * 3 + 63) & ~uint64_t(63);
+        it.image = int(b->imgs.size());
+        b->imgs.push_back(im);
+    }
+    if (!b->imgs.empty()) {
+        if (b->d_pool.upload(b->pool, b->stream) || b->d_imgs.upload(b->imgs, b->stream) || b->d_work.alloc(b->work_bytes + 64) || b->d_rgb.alloc(b->rgb_bytes + 64)) return CS_ERR_NO_DEVICE;
+        if (hipStreamSynchronize(b->stream) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
+    }
+    *out = b.release();
+    return 0;
+}
+
+extern "C" int cswd_batch_run(cswd_batch *b) {
+    if (b->imgs.empty()) { b->ran = true; return 0; }
+    if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
+    csw::launch_vp8_decode(b->stream, b->d_pool.p, b->d_imgs.p, int(b->imgs.size()), b->d_work.p, b->d_rgb.p);
+    if (hipMemcpyAsync(b->imgs.data(), b->d_imgs.p, b->imgs.size() * sizeof(csw::Vp8In), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+        hipStreamSynchronize(b->stream) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("VP8 decode failed on the device"); return CS_ERR_NO_DEVICE; }
+    for (cswd_batch::Item &it : b->items)
+        if (it.image >= 0 && b->imgs[size_t(it.image)].status) {
+            it.code = b->imgs[size_t(it.image)].status == 2 ? CS_ERR_UNSUPPORTED : CS_ERR_BAD_WEBP;
+            it.msg = b->imgs[size_t(it.image)].status == 2 ? "VP8 frame type not supported" : "malformed VP8 stream";
+        }
+    b->ran = true;
+    return 0;
+}
+
+extern "C" int cswd_batch_pixels(cswd_batch *b, size_t image, const uint8_t **device_pixels, uint32_t *width, uint32_t *height, uint32_t *channels, const char **message) {
+    if (!b->ran || image >= b->items.size()) { csh_set_error("cswd_batch_pixels: batch not run / index out of range"); return -1; }
+    const cswd_batch::Item &it = b->items[image];
+    if (message) *message = it.msg.c_str();
+    if (it.code) return it.code;
+    const csw::Vp8In &im = b->imgs[size_t(it.image)];
+    *device_pixels = b->d_rgb.p + im.rgb_off; *width = im.width; *height = im.height; *channels = 3;
+    return 0;
+}
+
+extern "C" int cswd_batch_read_pixels(cswd_batch *b, size_t image, uint8_t *dst) {
+    const uint8_t *p; uint32_t w, h, c; const char *m;
+    int rc = cswd_batch_pixels(b, image, &p, &w, &h, &c, &m);
+    if (rc) return rc;
+    if (hipMemcpy(dst, p, size_t(w) * h * c, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
+    return 0;
+}
+
+extern "C" void cswd_batch_destroy(cswd_batch *b) { delete b; }

@@ -24,4 +24,8 @@ void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
                       uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
 
+struct Vp8In;
+// lossy WebP inputs (k_webp_dec.hip): every image's VP8 key frame -> RGB in the pixel pool; imgs[i].status = 0 or an error
+void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb);
+
 }  // namespace csw

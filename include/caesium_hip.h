@@ -40,6 +40,7 @@ enum {
     CS_ERR_JPEG_FEATURE = 20101,   /* arithmetic coding, 12-bit, CMYK, unsupported sampling ... */
     CS_ERR_POOL_OVERFLOW = 20200,  /* internal device pool too small even after retry */
     CS_ERR_BAD_PNG = 30100,        /* malformed / truncated PNG (chunk walk, zlib stream, filter bytes) */
+    CS_ERR_BAD_WEBP = 40100,       /* malformed / truncated WebP (RIFF chunk walk, VP8 frame header, bool-coded data running out) */
     CS_ERR_SAME_FORMAT = 10407,    /* convert_in_memory: source type == target type */
     CS_ERR_TOO_BIG = 10500         /* compress_to_size: cannot reach max_output_size */
 };
@@ -213,6 +214,23 @@ int csp_batch_read_scores(csp_batch *b, size_t image, uint64_t *dst, int *have);
 int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uint64_t *zlib_bytes, int *ntrials, int *winner);
 /* size in bits of every deflate block of one trial (dst[*nchunks]; capacity `cap` entries) */
 int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, size_t cap, size_t *nchunks);
+
+/* ------------------------------------------------------------------------------------------------
+ * WebP INPUTS (libcaesium decodes them with libwebp before webp::compress / convert_in_memory, compressor.rs:289-305): the RIFF
+ * container is walked on the host, the VP8 key frame is decoded on the device (k_webp_dec.hip), the RGB stays in HBM
+ * (cswd_batch_pixels: the csp_pixels the encoders take).  Built: lossy still pictures; VP8L / ALPH / animation answer
+ * CS_ERR_UNSUPPORTED per file.  cs_batch_compress and cs_batch_convert route WebP files here themselves.
+ */
+typedef struct cswd_batch cswd_batch;
+int cswd_batch_create(const CByteArray *inputs, size_t count, int device, cswd_batch **out);
+int cswd_batch_run(cswd_batch *b);
+int cswd_batch_pixels(cswd_batch *b, size_t image, const uint8_t **device_pixels, uint32_t *width, uint32_t *height, uint32_t *channels, const char **message);
+int cswd_batch_read_pixels(cswd_batch *b, size_t image, uint8_t *dst /* width * height * 3 */);
+void cswd_batch_destroy(cswd_batch *b);
+/* pixels in, WebP out: the lossy WebP encoder behind the same stand-in as csh_batch_create_from_pixels */
+int csh_batch_create_webp_from_pixels(const struct csp_pixels_s *sources, size_t count, const CCSParameters *p, int device, csh_batch **out);
+/* pixels in, resized pixels out (csh_batch_pixels): the Lanczos branch alone */
+int csh_batch_create_from_pixels_rgb(const struct csp_pixels_s *sources, size_t count, const CCSParameters *p, int device, csh_batch **out);
 
 #ifdef __cplusplus
 }

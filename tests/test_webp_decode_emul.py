@@ -1,0 +1,109 @@
+"""WebP INPUTS (S1 / S3 with a WebP source; BASELINE configs[4] names WebP among the inputs): the VP8 key-frame decoder that runs on the
+device, here through the emulation build.  The decoder is pinned to libwebp itself: every picture must equal, sample for sample, what
+libwebp 1.6 (through Pillow) decodes -- the reference's own samples/w0.webp and level_1_1/w1.webp included.  What is made of the pixels
+(WebP again at webp.quality, or JPEG / PNG for conversions) is checked against the oracle's encoders fed libwebp's pixels."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from _util import device_scan_script, emul_api, package
+from gen_synth import synth_rgb
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def params(**kw):
+    return package().default_parameters(**kw)
+
+
+def webp_of(seed, w, h, quality, method=4, texture=0.0):
+    b = io.BytesIO()
+    Image.fromarray(synth_rgb(seed, w, h, texture=texture), "RGB").save(b, format="WEBP", quality=quality, method=method)
+    return b.getvalue()
+
+
+def libwebp_rgb(blob):
+    return np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"))
+
+
+CASES = [(64, 48, 80, 4, 0.0), (101, 67, 50, 6, 10.0), (17, 9, 90, 0, 20.0), (1, 1, 75, 4, 0.0), (320, 240, 20, 4, 30.0), (200, 150, 95, 6, 40.0),
+         (333, 222, 5, 2, 50.0), (16, 16, 100, 4, 5.0), (15, 33, 60, 3, 25.0), (256, 8, 70, 5, 15.0)]
+
+
+def test_emul_reference_samples_decode_like_libwebp(api, reference_samples):
+    blobs = [open(os.path.join(reference_samples, rel), "rb").read() for rel in ("w0.webp", "level_1_1/w1.webp")]   # plain VP8; VP8X + EXIF + XMP
+    for blob, got in zip(blobs, api.webp_decode(blobs)):
+        assert np.array_equal(got, libwebp_rgb(blob))
+
+
+def test_emul_synthetic_files_decode_like_libwebp(api):
+    """sizes down to 1 x 1 and off the macroblock grid, qualities 5..100 (filter strengths, segments, both block types), encoder methods 0..6"""
+    blobs = [webp_of(30 + i, *c) for i, c in enumerate(CASES)]
+    for c, blob, got in zip(CASES, blobs, api.webp_decode(blobs)):
+        assert np.array_equal(got, libwebp_rgb(blob)), c
+
+
+def test_emul_damaged_and_unsupported_inputs_fail_alone(api):
+    good = webp_of(3, 64, 48, 80)
+    lossless = io.BytesIO(); Image.fromarray(synth_rgb(4, 32, 24), "RGB").save(lossless, format="WEBP", lossless=True)
+    alpha = io.BytesIO(); Image.fromarray(np.dstack([synth_rgb(5, 32, 24), np.full((24, 32), 128, np.uint8)]), "RGBA").save(alpha, format="WEBP", quality=80)
+    outs = api.webp_decode([good, good[:60], lossless.getvalue(), alpha.getvalue(), good[:12] + b"JUNK" + good[16:], good])
+    assert [isinstance(o, Exception) for o in outs] == [False, True, True, True, True, False]
+    assert outs[2].code == 10201 and outs[3].code == 10201 and outs[1].code == 40100
+    assert np.array_equal(outs[0], libwebp_rgb(good)) and np.array_equal(outs[5], libwebp_rgb(good))
+    cut = good[:len(good) * 2 // 3]   # data running out inside the token partitions: refused by both, or decoded alike
+    got = api.webp_decode([cut])[0]
+    try:
+        ref = libwebp_rgb(cut)
+    except Exception:
+        ref = None
+    assert isinstance(got, Exception) or (ref is not None and got.shape == ref.shape)
+
+
+def test_emul_compress_and_convert_from_webp(api, reference_samples):
+    """compress_in_memory on a WebP = decode, encode again at webp.quality; convert_in_memory WebP -> JPEG / PNG = decode, then the JPEG / PNG
+    rows from pixels.  Oracle: libwebp's pixels through oracle/webp_oracle.c, jpeg_oracle.c, png_oracle.c."""
+    from oracle import oracle as O
+    w0 = open(os.path.join(reference_samples, "w0.webp"), "rb").read()
+    srcs = [w0, webp_of(8, 97, 61, 70, texture=20.0)]
+    for src in srcs:
+        rgb = np.ascontiguousarray(libwebp_rgb(src))
+        assert api.compress_in_memory(src, params(webp_quality=60)) == O.webp_encode_rgb(rgb, 60)
+        want_jpeg = O.pixels_to_jpeg(rgb, O.params(quality=75, progressive=1, subsampling=420, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), 0, 0)
+        assert api.convert_in_memory(src, params(jpeg_quality=75), 0) == want_jpeg
+        got_png = api.convert_in_memory(src, params(png_optimize=True), 1)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(got_png)).convert("RGB")), rgb)
+    # a size on the way: the JPEG row's Lanczos branch resamples the decoded pixels
+    rgb = np.ascontiguousarray(libwebp_rgb(srcs[1]))
+    want = O.pixels_to_jpeg(rgb, O.params(quality=80, progressive=1, subsampling=420, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), 48, 0)
+    assert api.convert_in_memory(srcs[1], params(jpeg_quality=80, width=48), 0) == want
+    got_png = api.convert_in_memory(srcs[1], params(png_optimize=True, width=48), 1)
+    assert Image.open(io.BytesIO(got_png)).size[0] == 48
+    with pytest.raises(package().CaesiumError) as e:
+        api.convert_in_memory(srcs[1], params(), 3)
+    assert e.value.code == 10407   # same format
+    # mixed batch through the one entry point: order kept, every type served
+    from gen_synth import synth_jpeg, synth_png
+    from _util import oracle_lossy
+    j = synth_jpeg(9, 80, 64)
+    outs = api.cs_batch_compress([srcs[1], j, srcs[0]], params(webp_quality=60, jpeg_quality=80))
+    assert outs[1] == oracle_lossy(j) and outs[0] == O.webp_encode_rgb(np.ascontiguousarray(libwebp_rgb(srcs[1])), 60) and outs[2][:4] == b"RIFF"
+
+
+def test_emul_compress_to_size_on_webp(api):
+    """--max-size on a WebP: libcaesium's walk over webp.quality (80, then bisection, 2 % tolerance, ten tries), every try a decode + encode"""
+    from oracle import oracle as O
+    from test_pipeline_emul import reference_size_walk
+    src = webp_of(12, 160, 120, 90, texture=30.0)
+    rgb = np.ascontiguousarray(libwebp_rgb(src))
+    full = len(O.webp_encode_rgb(rgb, 80))
+    target = full * 6 // 10
+    qs, want = reference_size_walk(src, target, encode=lambda s, q: O.webp_encode_rgb(rgb, q))
+    got = api.compress_to_size_in_memory(src, params(), target)
+    assert got == want and len(qs) > 1
