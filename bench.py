@@ -270,6 +270,41 @@ def main():
             cdt = time.perf_counter() - c0
             cpu_pillow = {"value": round(m * 2.0736 / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "libjpeg-turbo proxy (Pillow), not libcaesium",
                           "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+        other = None
+        if extras:
+            # the other single-GPU configurations of BASELINE.json, as sub-records (device time of the whole path, inputs resident in HBM):
+            # configs[2] 3840x2160 RGB8 PNGs --lossless --png-opt-level 3; configs[3] the same 1080p JPEGs -> WebP q85 at long edge 1500
+            other = {}
+            try:
+                from gen_synth import synth_png
+                import multiprocessing as mp
+                with mp.get_context("fork").Pool(4) as pool:
+                    pngs = pool.starmap(synth_png, [(100 + k, 3840, 2160, "RGB") for k in range(4)])
+                pb = api.png_batch([pngs[k % 4] for k in range(16)], pkg.default_parameters(png_optimize=True, png_optimization_level=3), device=local)
+                pb.run()
+                ptm = pb.run()
+                pouts = pb.fetch()
+                pn = api.png_kernel_names()
+                pdom = max(range(len(pn)), key=lambda i: ptm.kernel_ms[i])
+                other["configs[2] 4K PNG --lossless -o3"] = {
+                    "files": 16, "value": round(16 * 3840 * 2160 / 1e6 / (ptm.total_ms / 1e3), 1), "unit": "MP/s", "device_ms": round(ptm.total_ms, 1),
+                    "in_bytes": sum(len(pngs[k % 4]) for k in range(16)), "out_bytes": sum(len(o) for o in pouts if isinstance(o, bytes)),
+                    "dominant_kernel": pn[pdom], "dominant_ms": round(ptm.kernel_ms[pdom], 1),
+                    "note": "k_png_inflate is one wave per zlib stream: a latency (the same for 16 or 1000 files), not a throughput"}
+                pb.close()
+            except Exception as e:   # a sub-record must not take the headline down
+                other["configs[2] 4K PNG --lossless -o3"] = {"error": str(e)[:200]}
+            try:
+                wb = api.webp_batch(blobs[:256], pkg.default_parameters(webp_quality=85, width=1500), device=local)
+                wb.run()
+                wtm = wb.run()
+                wdom = max(range(len(names)), key=lambda i: wtm.kernel_ms[i])
+                other["configs[3] JPEG -> WebP q85 long edge 1500"] = {
+                    "files": 256, "value": round(256 * 2.0736 / (wtm.total_ms / 1e3), 1), "unit": "source MP/s", "device_ms": round(wtm.total_ms, 1), "out_bytes": int(wtm.out_bytes),
+                    "dominant_slot": names[wdom] or "webp tail", "dominant_ms": round(wtm.kernel_ms[wdom], 1)}
+                wb.close()
+            except Exception as e:
+                other["configs[3] JPEG -> WebP q85 long edge 1500"] = {"error": str(e)[:200]}
         if extras and args.boundary_files > 0:
             # the boundary itself: cs_batch_compress, host buffers in -> host buffers out (marker parse, pinned upload, kernels, download);
             # PCIe and the host side are inside this number and never inside `value`
@@ -290,7 +325,7 @@ def main():
             "parity_spot_check": bool(parity),
             "device_ms_per_step": round(sum(tm.total_ms for tm in timings) / len(timings), 3),
             "kernel_ms": {names[i]: round(kms[i], 4) for i in range(len(names)) if names[i]},
-            "roofline": roof, "phases": phases, "plain_profile": plain, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow, "boundary": boundary,
+            "roofline": roof, "phases": phases, "plain_profile": plain, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow, "boundary": boundary, "other_configs": other,
             "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
             "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},
         }
