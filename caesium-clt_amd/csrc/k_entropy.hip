@@ -1039,6 +1039,46 @@ __device__ __forceinline__ static void or_bits(uint32_t *words, uint64_t pos, ui
     if (lo) atomicOr(words + (pos >> 5) + 1, lo);
 }
 #define CSH_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// the common case of token_pieces: everything a token emits fits ONE piece of at most 32 bits (no ZRL in front of a first-pass coefficient,
+// symbol + sign + correction bits of a refinement event within 32 bits).  Returns false when it does not: the caller then takes the
+// three-piece form for the whole step.
+template <int MODE>
+__device__ __forceinline__ static bool token_main(uint32_t t, const TokenCtx &x, uint32_t &v, uint32_t &n) {
+    v = 0; n = 0;
+    const uint32_t kind = t & 7u;
+    if (kind == TK_RAW) { v = t >> 17; n = (t >> 13) & 15u; return true; }
+    if (MODE == 3) {   // SYM
+        const uint32_t e = x.lut[((t >> 11) & 3u) * x.lut_stride + ((t >> 3) & 255u)], nr = (t >> 13) & 15u;
+        v = ((e & 0xFFFFu) << nr) | (t >> 17); n = (e >> 16) + nr;
+        return true;
+    }
+    if (MODE == 1 && kind == TK_ACF) {
+        const uint32_t r = (t >> 3) & 63u, nb = (t >> 9) & 15u;
+        if (r >> 4) return false;
+        const uint32_t e = x.lut[(r << 4) | nb];
+        v = ((e & 0xFFFFu) << nb) | ((t >> 13) & 0xFFFFu); n = (e >> 16) + nb;
+        return true;
+    }
+    const uint32_t unit = (t >> 3) & 255u, cnt = (t >> 16) & 63u, cur = (t >> 22) & 63u;
+    if (MODE == 2 && kind == TK_REF) {
+        if (t & (1u << 28)) { const uint32_t e = x.lut[0xF0]; v = e & 0xFFFFu; n = e >> 16; }
+        else { const uint32_t e = x.lut[(((t >> 11) & 15u) << 4) | 1u]; v = ((e & 0xFFFFu) << 1) | ((t >> 15) & 1u); n = (e >> 16) + 1; }
+    } else {   // EOB
+        const uint32_t run = x.eobrun[unit];
+        if (run) {
+            const int nb = bitlen32(run) - 1;
+            const uint32_t e = x.lut[nb << 4];
+            v = ((e & 0xFFFFu) << nb) | (run & ((1u << nb) - 1u)); n = (e >> 16) + uint32_t(nb);
+        }
+    }
+    if (MODE == 2 && cnt) {
+        if (n + cnt > 32) return false;
+        const uint32_t bits = uint32_t((x.corr[unit] << cur) >> (64u - cnt));
+        v = (n ? (v << cnt) : 0u) | bits; n += cnt;
+    }
+    return true;
+}
+
 #ifndef CSH_EMUL
 struct PackState { uint32_t *buf, *out; uint64_t pos; uint32_t ww; bool first_flush; };
 template <int MODE>
@@ -1051,6 +1091,28 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
     const unsigned long long seg_o = lane < 4 ? c.tok_off[cs * 4u + uint32_t(lane)] : 0ull;
     // 256 tokens, four per lane: pieces, wave scan of the lengths, OR into the window, slide the window when it fills
     auto step = [&](const uint32_t (&t)[4], uint32_t i, uint32_t n, bool last_seg) {
+        // the one-piece form first: most steps have nothing else
+        {
+            uint32_t v4[4], n4[4];
+            bool slow = false;
+            CSH_UNROLL
+            for (int q = 0; q < 4; q++) {
+                slow |= !token_main<MODE>(t[q], x, v4[q], n4[q]);
+                if (pad && last_seg && i + uint32_t(q) == n) { v4[q] = (1u << pad) - 1u; n4[q] = pad; }
+            }
+            if (!__ballot(slow) && !(c.debug & 4096u)) {
+                const uint32_t len1 = n4[0] + n4[1] + n4[2] + n4[3];
+                uint32_t incl1 = len1;
+                CSH_UNROLL
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = uint32_t(__shfl_up(int(incl1), o, 64)); if (lane >= o) incl1 += tt; }
+                uint64_t at1 = pos + incl1 - len1 - uint64_t(ww) * 32u;
+                CSH_UNROLL
+                for (int q = 0; q < 4; q++) if (n4[q]) { or_bits(buf, at1, v4[q], n4[q]); at1 += n4[q]; }
+                pos += uint32_t(__shfl(int(incl1), 63, 64));
+                goto slide;
+            }
+        }
+        {
         Pieces p[4];
         uint32_t len = 0;
         CSH_UNROLL
@@ -1069,6 +1131,8 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
             for (int k = 0; k < 3; k++) if (p[q].n[k]) { or_bits(buf, at, p[q].v[k], p[q].n[k]); at += p[q].n[k]; }
         }
         pos += uint32_t(__shfl(int(incl), 63, 64));
+        }
+    slide:
         // slide the window when another 256 tokens' worth of bits (256 x 96) might not fit any more
         const uint32_t done = uint32_t(pos >> 5) - ww;   // complete words in the window
         if (done > CSH_PK_WORDS - 770) {
@@ -1170,6 +1234,24 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
 #endif
 }
 
+// ---- before the pack: the words two chunks may share -- every chunk's first and last -- are the only ones that are ORed into, so they
+// are the only ones that must start at zero (the pool itself is not cleared: under the scan search it is ten files' worth per file)
+__global__ void __launch_bounds__(256) k_zero_edges(EncCtx c) {
+    const uint32_t cs = c.slot0 + blockIdx.x * 256u + threadIdx.x;
+    if (cs >= c.slot0 + c.nslots) return;
+    const SlotRec r = c.slots[cs];
+    const ScanWork &w = c.work[r.work];
+    if (w.no_room) return;
+    const uint64_t scan0 = c.chunk_off[r.first_chunk];
+    const uint64_t bit0 = w.raw_off * 8 + (c.chunk_off[cs] - scan0);
+    const uint64_t nbits = c.chunk_bits[cs];
+    c.raw[bit0 >> 5] = 0;
+    // the chunk's last word (ORed by the packer even when the chunk ends on a word boundary) and the first one behind it; the scan's
+    // last chunk also carries up to 7 bits of byte fill
+    const uint64_t lo = nbits ? (bit0 + nbits - 1) >> 5 : bit0 >> 5, hi = (bit0 + nbits + (r.j == r.nch - 1 ? 8 : 0)) >> 5;
+    for (uint64_t wi = lo; wi <= hi; wi++) c.raw[wi] = 0;
+}
+void launch_zero_edges(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH(k_zero_edges, dim3((c.nslots + 255) / 256), dim3(256), st, c); }
 void launch_tokens(hipStream_t st, const EncCtx &c) { if (c.nechunks) CSH_LAUNCH_PHASED(k_tokens, 6, dim3(c.nechunks), dim3(256), st, c); }
 void launch_ac_runs(hipStream_t st, const EncCtx &c) {
     if (!c.nslots) return;

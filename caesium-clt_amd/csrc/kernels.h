@@ -97,6 +97,7 @@ void launch_tokens(hipStream_t st, const EncCtx &c);
 void launch_ac_runs(hipStream_t st, const EncCtx &c);
 void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables);
 void launch_chunk_sizes(hipStream_t st, const EncCtx &c);
+void launch_zero_edges(hipStream_t st, const EncCtx &c);   // between the scans' placement and the pack
 void launch_pack(hipStream_t st, const EncCtx &c);
 
 // generic device primitive: out[i] = sum_{j<i} in[j] for i in [0, n]  (n+1 outputs; in[] has n entries)

@@ -896,7 +896,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
 
         it.image = img_index;
         b->imgs.push_back(im);
-        b->raw_bytes_cap += (b->search ? 12 : 2) * inputs[n].length + 64 * 1024;   // the search's candidates are ten scripts' worth of scans
+        b->raw_bytes_cap += (b->search ? 8 : 2) * inputs[n].length + (b->search ? 256 : 64) * 1024;   // the search's candidates are ten scripts' worth of scans (of the OUTPUT's size)
     }
     b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
     b->nimg = int(b->imgs.size());
@@ -1343,7 +1343,12 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     c.chunk_bits = b->d_chunk_bits.p; c.chunk_off = b->d_chunk_off.p; c.tables = b->d_tables.p;
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p; c.overflow = b->d_overflow.p;
     c.debug = getenv("CSH_DEBUG") ? uint32_t(atoi(getenv("CSH_DEBUG"))) : 0u;
-    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_raw.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st) || b->d_scan_pad.zero(st)) return -1;
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st) || b->d_scan_pad.zero(st)) return -1;
+#ifdef CSH_EMUL
+    if (b->d_raw.zero(st)) return -1;   // the emulation's packer ORs every word into the pool (no LDS window there)
+#else
+    if ((c.debug & 8192u) && b->d_raw.zero(st)) return -1;
+#endif
     MARK();
     AsmCtx a;
     memset(&a, 0, sizeof a);
@@ -1373,6 +1378,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         launch_scan_sizes(st, a);
         launch_exclusive_scan(st, b->d_scan_pad.p, b->d_scan_raw_off.p, uint64_t(a.nwork), b->d_scan_tmp.p, b->d_scan_tmp.n);   // all work items: those of a later stage still count zero
         launch_scan_place(st, a);
+        launch_zero_edges(st, c);
         SMARK();
         launch_pack(st, c);
         SMARK();
