@@ -313,43 +313,63 @@ __device__ __forceinline__ static uint32_t resample_quad(const PlaneView &v, int
     return out;
 }
 
+// Two samples per 32-bit register (16-bit fields; every intermediate is < 4096, nothing carries across).  Of a quad of output
+// columns: E = plane columns (0, 2), O = (1, 3), L = (-1, 1), R = (2, 4): even outputs have centre E and neighbours L and O, odd
+// outputs have centre O and neighbours E and R -- so the bias pattern of both filters is constant per register.
+struct Quad420 { uint32_t E, O, L, R; };
+__device__ __forceinline__ static Quad420 quad420_fields(uint32_t a, uint32_t b, uint32_t d) {   // dwords at columns -4, 0, +4
+    Quad420 f;
+    f.E = b & 0x00FF00FFu;
+    f.O = (b >> 8) & 0x00FF00FFu;
+    f.L = (a >> 24) | (f.O << 16);
+    f.R = (f.E >> 16) | ((d & 0xFFu) << 16);
+    return f;
+}
+// sums over the two full-resolution rows 2y, 2y+1 of the upsampled samples under a quad of outputs: A = full-resolution columns
+// 2x (x = 0, 2), B = columns 2x+1 (x = 0, 2), C = columns 2x (x = 1, 3), D = columns 2x+1 (x = 1, 3)
+struct Sums420 { uint32_t A, B, C, D; };
+__device__ __forceinline__ static Sums420 quad420_sums(const Quad420 &p, const Quad420 &c, const Quad420 &n) {
+    // vertical step of the triangle filter (jdsample h2v2_fancy_upsample): 3 * nearer row + further row, for the two output
+    // rows 2y (further = y-1) and 2y+1 (further = y+1)
+    const uint32_t e0 = 3u * c.E + p.E, e1 = 3u * c.E + n.E, o0 = 3u * c.O + p.O, o1 = 3u * c.O + n.O;
+    const uint32_t l0 = 3u * c.L + p.L, l1 = 3u * c.L + n.L, r0 = 3u * c.R + p.R, r1 = 3u * c.R + n.R;
+    const uint32_t M = 0x00FF00FFu;
+    // horizontal step: (3 * centre + left + 8) >> 4 and (3 * centre + right + 7) >> 4
+    auto up = [&](uint32_t ce, uint32_t nb, uint32_t bias) { return ((3u * ce + nb + bias) >> 4) & M; };
+    Sums420 s;
+    s.A = up(e0, l0, 0x00080008u) + up(e1, l1, 0x00080008u);
+    s.B = up(e0, o0, 0x00070007u) + up(e1, o1, 0x00070007u);
+    s.C = up(o0, e0, 0x00080008u) + up(o1, e1, 0x00080008u);
+    s.D = up(o0, r0, 0x00070007u) + up(o1, r1, 0x00070007u);
+    return s;
+}
+// jcsample's h2v2 box: (sum of four + {1, 2, 1, 2 ..}) >> 2; even = outputs (0, 2), odd = outputs (1, 3), 16-bit fields
+__device__ __forceinline__ static void quad420_finish(const Sums420 &s, uint32_t &even, uint32_t &odd) {
+    even = ((s.A + s.B + 0x00010001u) >> 2) & 0x00FF00FFu;
+    odd = ((s.C + s.D + 0x00020002u) >> 2) & 0x00FF00FFu;
+}
+
 // decoded plane -> encoder-side plane, 4 samples per lane (one dword store).  Interior quads of the 4:2:0 -> 4:2:0 case
 // take a vector path (3 rows x 3 dwords in, composite triangle-up o box-down in registers); everything else goes through
 // the same clamped per-sample formula, so image borders, odd sizes and tiny planes need no special code.
 __device__ __forceinline__ static uint32_t resample_quad_420(const PlaneView &v, int rows_alloc, int y, int x0) {
-    // window columns x0-1 .. x0+4 of plane rows y-1, y, y+1 (row index clamped; columns all inside the plane).
-    // Two samples per 32-bit register (16-bit fields; every intermediate is < 4096, nothing carries across):
-    //   E = columns (0, 2), O = (1, 3) of the quad, L = (-1, 1), R = (2, 4): even outputs have centre E, neighbours L and O,
-    //   odd outputs have centre O, neighbours E and R -- so the bias pattern of both filters is constant per register.
-    uint32_t E[3], O[3], L[3], R[3];
+    // window columns x0-1 .. x0+4 of plane rows y-1, y, y+1 (row index clamped; columns all inside the plane)
+    Quad420 f[3];
     CSH_UNROLL
     for (int j = 0; j < 3; j++) {
         int yy = y - 1 + j;
         yy = yy < 0 ? 0 : (yy > rows_alloc - 1 ? rows_alloc - 1 : yy);
         const uint32_t *rp = reinterpret_cast<const uint32_t *>(v.p + size_t(yy) * v.pitch + x0);
-        const uint32_t a = rp[-1], b = rp[0], d = rp[1];
-        E[j] = b & 0x00FF00FFu;
-        O[j] = (b >> 8) & 0x00FF00FFu;
-        L[j] = (a >> 24) | (O[j] << 16);
-        R[j] = (E[j] >> 16) | ((d & 0xFFu) << 16);
+        f[j] = quad420_fields(rp[-1], rp[0], rp[1]);
     }
-    // vertical step of the triangle filter (jdsample h2v2_fancy_upsample): 3 * nearer row + further row, for the two output
-    // rows 2y (further = y-1) and 2y+1 (further = y+1)
-    uint32_t e0 = 3u * E[1] + E[0], e1 = 3u * E[1] + E[2], o0 = 3u * O[1] + O[0], o1 = 3u * O[1] + O[2];
-    uint32_t l0 = 3u * L[1] + L[0], l1 = 3u * L[1] + L[2], r0 = 3u * R[1] + R[0], r1 = 3u * R[1] + R[2];
-    const uint32_t M = 0x00FF00FFu;
-    // horizontal step: (3 * centre + left + 8) >> 4 and (3 * centre + right + 7) >> 4; then jcsample's box: (sum + {1,2}) >> 2
-    auto up = [&](uint32_t c, uint32_t nb, uint32_t bias) { return ((3u * c + nb + bias) >> 4) & M; };
-    uint32_t even = up(e0, l0, 0x00080008u) + up(e0, o0, 0x00070007u) + up(e1, l1, 0x00080008u) + up(e1, o1, 0x00070007u);
-    uint32_t odd = up(o0, e0, 0x00080008u) + up(o0, r0, 0x00070007u) + up(o1, e1, 0x00080008u) + up(o1, r1, 0x00070007u);
-    even = ((even + 0x00010001u) >> 2) & M;   // outputs 0 and 2: bias 1
-    odd = ((odd + 0x00020002u) >> 2) & M;     // outputs 1 and 3: bias 2
+    uint32_t even, odd;
+    quad420_finish(quad420_sums(f[0], f[1], f[2]), even, odd);
     return even | (odd << 8);
 }
 
 __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, const PlaneWork *work, const uint8_t *planes, uint8_t *oplanes) {
     const PlaneWork w = work[blockIdx.y];
-    if (w.mode == 0) return;
+    if (w.mode == 0 || w.mode == 10) return;
     const ImgDesc &im = imgs[w.image];
     const CompGeom gi = im.src[w.comp], go = im.out[w.comp];
     const int pitch_o = go.real_bw * 8, rows_o = go.real_bh * 8;
@@ -384,7 +404,7 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
 __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *oplanes,
                                                      int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
     const PlaneWork w = work[blockIdx.y];
-    if (w.mode == 0) return;
+    if (w.mode == 0 || w.mode == 10) return;
     const ImgDesc &im = imgs[w.image];
     const CompGeom go = im.out[w.comp];
     int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -402,6 +422,97 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
         const uint2 v = *reinterpret_cast<const uint2 *>(p + size_t(r) * pitch);
         CSH_UNROLL
         for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
+    }
+    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
+}
+
+// The camera case in one pass: 4:2:0 in, 4:2:0 out, no resize (PlaneWork.mode 10).  One lane per OUTPUT block: a 10 x 10 window of
+// the decoded plane (4 dwords x 10 rows) -> fancy upsample o box downsample in packed registers -> FDCT -> quantise.  The
+// encoder-side plane is never written.  libjpeg's edge rules are applied where they bite:
+//   rows:    an odd H makes full-resolution row 2y+1 of the last output row a copy of row 2y -- the window row below it is
+//            loaded from plane row y-1 instead; output rows below the last one replicate it;
+//   columns: full-resolution columns beyond W-1 replicate column W-1 -- the per-column sums are patched in the block that
+//            holds plane column (W-1)/2 (always the last block column).
+__global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *planes,
+                                                            int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    const PlaneWork w = work[blockIdx.y];
+    if (w.mode != 10) return;
+    const ImgDesc &im = imgs[w.image];
+    const CompGeom gi = im.src[w.comp], go = im.out[w.comp];
+    int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    int b = tile * 64 + lane;
+    if (b >= go.bw * go.bh) return;
+    int by = b / go.bw, bx = b - by * go.bw;
+    int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
+    if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); return; }
+    const int pitch = gi.real_bw * 8, rows_alloc = gi.real_bh * 8;
+    const uint8_t *pl = planes + im.splane_off[w.comp];
+    const int x0 = bx * 8, y0 = by * 8, W = im.enc_w, H = im.enc_h, och = go.comp_h;
+    const bool first = bx == 0, last = x0 + 12 > pitch, hodd = (H & 1) != 0;
+    const int kt = ((W - 1) >> 1) - x0;        // block-relative plane column that holds full-resolution column W-1 (< 8: patch)
+    // which 16-bit fields of A/B/C/D are beyond W-1, per quad (lo field = outputs 0 / 1, hi field = outputs 2 / 3)
+    uint32_t mA[2], mB[2], mC[2], mD[2];
+    const bool wodd = (W & 1) != 0;
+    CSH_UNROLL
+    for (int q = 0; q < 2; q++) {
+        auto even_gone = [&](int k) { return k > kt ? 0xFFFFu : 0u; };                  // 2k > W-1
+        auto odd_gone = [&](int k) { return (k > kt || (wodd && k == kt)) ? 0xFFFFu : 0u; };   // 2k+1 > W-1
+        mA[q] = even_gone(4 * q) | (even_gone(4 * q + 2) << 16);
+        mB[q] = odd_gone(4 * q) | (odd_gone(4 * q + 2) << 16);
+        mC[q] = even_gone(4 * q + 1) | (even_gone(4 * q + 3) << 16);
+        mD[q] = odd_gone(4 * q + 1) | (odd_gone(4 * q + 3) << 16);
+    }
+    int x[64];
+    Quad420 win[3][2];
+    auto load_row = [&](int j, Quad420 out[2]) {
+        int yy = y0 - 1 + j;
+        if (hodd && yy == och) yy = och - 2;
+        yy = yy < 0 ? 0 : (yy > rows_alloc - 1 ? rows_alloc - 1 : yy);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(pl + size_t(yy) * pitch + x0);
+        const uint32_t bq = rp[0], cq = rp[1];
+        const uint32_t aq = first ? bq << 24 : rp[-1];     // plane column -1 = column 0
+        const uint32_t dq = last ? cq >> 24 : rp[2];       // plane column `pitch` = column pitch-1
+        out[0] = quad420_fields(aq, bq, cq);
+        out[1] = quad420_fields(bq, cq, dq);
+    };
+    load_row(0, win[0]);
+    load_row(1, win[1]);
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++) {
+        Quad420 *p = win[r % 3], *c = win[(r + 1) % 3], *n = win[(r + 2) % 3];
+        load_row(r + 2, n);
+        Sums420 s[2] = {quad420_sums(p[0], c[0], n[0]), quad420_sums(p[1], c[1], n[1])};
+        if (kt < 8) {
+            // the sum at full-resolution column W-1: plane column kt, the 2x+1 sample when W is even
+            const int q = kt >> 2, odd_col = kt & 1;
+            uint32_t sl = wodd ? (odd_col ? s[q].C : s[q].A) : (odd_col ? s[q].D : s[q].B);
+            sl = (kt & 2) ? sl >> 16 : sl & 0xFFFFu;
+            sl |= sl << 16;
+            CSH_UNROLL
+            for (int qq = 0; qq < 2; qq++) {
+                s[qq].A = (s[qq].A & ~mA[qq]) | (sl & mA[qq]);
+                s[qq].B = (s[qq].B & ~mB[qq]) | (sl & mB[qq]);
+                s[qq].C = (s[qq].C & ~mC[qq]) | (sl & mC[qq]);
+                s[qq].D = (s[qq].D & ~mD[qq]) | (sl & mD[qq]);
+            }
+        }
+        CSH_UNROLL
+        for (int q = 0; q < 2; q++) {
+            uint32_t even, odd;
+            quad420_finish(s[q], even, odd);
+            x[8 * r + 4 * q] = int(even & 0xFFFFu); x[8 * r + 4 * q + 2] = int(even >> 16);
+            x[8 * r + 4 * q + 1] = int(odd & 0xFFFFu); x[8 * r + 4 * q + 3] = int(odd >> 16);
+        }
+    }
+    const int ylast = och - 1 - y0;   // rows below the last downsampled row replicate it
+    if (ylast < 7) {
+        CSH_UNROLL
+        for (int r = 1; r < 8; r++)
+            if (r > ylast) {
+                CSH_UNROLL
+                for (int cc = 0; cc < 8; cc++) x[8 * r + cc] = x[8 * (r - 1) + cc];
+            }
     }
     fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
 }
@@ -460,6 +571,10 @@ void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork 
 void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
                        const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
     if (nwork) CSH_LAUNCH(k_plane_fdct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out, dct_raw, raw_tile0);
+}
+void launch_resample_fdct_420(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                              const uint8_t *planes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    if (nwork) CSH_LAUNCH(k_resample_fdct_420, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, planes, coef_out, dct_raw, raw_tile0);
 }
 void launch_requant(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant, const int16_t *dct_raw,
                     uint32_t raw_tile0, int16_t *coef_out) {

@@ -49,6 +49,8 @@ void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *wor
 void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, uint32_t max_quads, const uint8_t *planes, uint8_t *oplanes);
 void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
                        const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
+void launch_resample_fdct_420(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
+                              const uint8_t *planes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
 
 // resize branch (k_resize.hip): decoded planes -> RGB -> Lanczos3 (f32, image-rs order) -> full-resolution YCbCr planes

@@ -785,6 +785,10 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 int out_kind = out_full ? 0 : (o.comp[c].v == o.vmax ? 2 : 1);
                 w.mode = (in_kind == 0 && out_kind == 0) ? 0 : 1 + 3 * in_kind + out_kind;
                 if (resized) w.mode = 1 + out_kind;   // encoder side is fed full-resolution planes of the resized image (k_resize.hip)
+                // the camera case (4:2:0 kept, no resize) goes through k_resample_fdct_420 and has no encoder-side plane
+                const bool fused = w.mode == 5 && !resized && im.in[c].comp_w > 2 && im.in[c].real_bw == im.out[c].real_bw && im.in[c].real_bh == im.out[c].real_bh &&
+                                   im.in[c].comp_w == im.out[c].comp_w && im.in[c].comp_h == im.out[c].comp_h && !getenv("CSH_NO_FUSED_420");
+                if (fused) w.mode = 10;
                 if (w.mode) {
                     im.plane_off[c] = plane_off;
                     plane_off += uint64_t(im.in[c].real_bw * 8) * uint64_t(im.in[c].real_bh * 8);
@@ -799,7 +803,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                         plane_off = (plane_off + 63u) & ~uint64_t(63);
                     }
                     im.oplane_off[c] = oplane_off;
-                    const uint64_t osz = uint64_t(im.out[c].real_bw) * 8 * uint64_t(im.out[c].real_bh) * 8;   // <= 2^28 + edge blocks (plan_item)
+                    const uint64_t osz = fused ? 0 : uint64_t(im.out[c].real_bw) * 8 * uint64_t(im.out[c].real_bh) * 8;   // <= 2^28 + edge blocks (plan_item)
                     oplane_off = (oplane_off + osz + 63u) & ~uint64_t(63);
                     b->max_quads = std::max(b->max_quads, uint32_t(osz / 4));
                 }
@@ -1328,6 +1332,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     MARK();
     launch_resample_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_quads, b->d_planes.p, b->d_oplanes.p);
     launch_plane_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_oplanes.p, b->d_coef.p, rawp, b->ntiles_in);
+    launch_resample_fdct_420(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_planes.p, b->d_coef.p, rawp, b->ntiles_in);
     MARK();
     if (!b->lossless) launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
     MARK();

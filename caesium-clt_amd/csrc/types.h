@@ -139,7 +139,7 @@ struct DevQuant {
 // work item of the pixel kernels: one component of one image
 struct PlaneWork {
     int image, comp;
-    int mode;  // 0: full-res in and out (IDCT->FDCT in one lane); else 1 + 3*in_kind + out_kind with kinds 0 full, 1 h2v2, 2 h2v1
+    int mode;  // 0: full-res in and out (IDCT->FDCT in one lane); 10: h2v2 kept, no resize (k_resample_fdct_420); else 1 + 3*in_kind + out_kind with kinds 0 full, 1 h2v2, 2 h2v1
 };
 
 // resize path work item (k_resize.hip): one image

@@ -266,6 +266,23 @@ def test_emul_every_chroma_layout_combination(api, ss_in, ss_out):
         assert api.compress_in_memory(src, params(jpeg_chroma_subsampling=ss_out)) == oracle_lossy(src, subsampling=ss_out), (w, h)
 
 
+def test_emul_fused_420_edge_rules(api, monkeypatch):
+    """k_resample_fdct_420 (4:2:0 kept, no resize): every combination of odd / even width and height around block and MCU
+    boundaries, checked against the oracle and against the three-kernel chain it replaces"""
+    sizes = [(w, h) for w in (5, 6, 15, 16, 17, 18, 31, 32, 33, 34, 47, 49) for h in (5, 6, 15, 16, 17, 18, 33, 34)]
+    srcs = [synth_jpeg(11 + i, w, h, subsampling=2, texture=40 + (i % 5) * 10) for i, (w, h) in enumerate(sizes)]
+    want = [oracle_lossy(s) for s in srcs]
+    b = api.batch(srcs, params())
+    b.run()
+    got = b.fetch()
+    bad = [sizes[i] for i in range(len(sizes)) if got[i] != want[i]]
+    assert not bad, bad
+    monkeypatch.setenv("CSH_NO_FUSED_420", "1")
+    b = api.batch(srcs, params())
+    b.run()
+    assert b.fetch() == want
+
+
 def test_emul_metadata_and_icc_policy(api):
     """-e / --strip-icc: EXIF+COM copied only with keep_metadata, ICC (APP2 ICC_PROFILE) follows jpeg_preserve_icc"""
     from PIL import Image

@@ -181,6 +181,10 @@ def test_every_chroma_layout_combination(api, ss_in, ss_out):
     E.test_emul_every_chroma_layout_combination(api, ss_in, ss_out)
 
 
+def test_fused_420_edge_rules(api, monkeypatch):
+    E.test_emul_fused_420_edge_rules(api, monkeypatch)
+
+
 def test_metadata_and_icc_policy(api):
     E.test_emul_metadata_and_icc_policy(api)
 
