@@ -46,6 +46,26 @@ __device__ __forceinline__ static int unit_block(const CompGeom &g, uint32_t u) 
 }
 __device__ __forceinline__ static bool get_bit(const uint64_t *w, uint32_t i) { return (w[i >> 6] >> (i & 63)) & 1; }
 
+#ifndef CSH_EMUL
+// inclusive scan over the 64 lanes of a wave with the cross-lane data path of the VALU (DPP: row shifts inside the rows of 16, then
+// the two row broadcasts) -- six dependent VALU instructions, where a __shfl_up ladder is six LDS round trips.  Op: + or |
+// (identity 0: lanes a step does not reach take `old` = 0).
+template <class Op>
+__device__ __forceinline__ static uint32_t wave_scan_dpp(uint32_t v, Op op) {
+    v = op(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false)));   // row_shr:1
+    v = op(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false)));   // row_shr:2
+    v = op(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false)));   // row_shr:4
+    v = op(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false)));   // row_shr:8
+    v = op(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false)));   // row_bcast:15 into rows 1 and 3
+    v = op(v, uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false)));   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ static uint32_t wave_incl_sum(uint32_t v) { return wave_scan_dpp(v, [](uint32_t a, uint32_t b) { return a + b; }); }
+// value of the last ACTIVE lane: the scan's total when the active lanes are lanes 0 .. m (a DPP step leaves a lane alone whose
+// source lane is switched off, so a scan is valid exactly over such a prefix)
+__device__ __forceinline__ static uint32_t wave_last(uint32_t v) { return uint32_t(__builtin_amdgcn_readlane(int(v), 63 - __clzll((unsigned long long)__ballot(1)))); }
+#endif
+
 // OR over the 64 lanes of a wave, in a scalar register pair (the emulation, where a lane cannot see the others, answers "all ones":
 // callers use it only to skip work no lane has)
 __device__ __forceinline__ static uint64_t wave_or64(uint64_t v) {
@@ -53,10 +73,9 @@ __device__ __forceinline__ static uint64_t wave_or64(uint64_t v) {
     (void)v;
     return ~0ull;
 #else
-    uint32_t lo = uint32_t(v), hi = uint32_t(v >> 32);
-    CSH_UNROLL
-    for (int o = 32; o >= 1; o >>= 1) { lo |= uint32_t(__shfl_xor(int(lo), o, 64)); hi |= uint32_t(__shfl_xor(int(hi), o, 64)); }
-    return (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(hi)))) << 32) | uint32_t(__builtin_amdgcn_readfirstlane(int(lo)));
+    auto bor = [](uint32_t a, uint32_t b) { return a | b; };
+    const uint32_t lo = wave_last(wave_scan_dpp(uint32_t(v), bor)), hi = wave_last(wave_scan_dpp(uint32_t(v >> 32), bor));
+    return (uint64_t(hi) << 32) | lo;
 #endif
 }
 // inclusive scan over the 64 lanes of a wave of the values in[0..63] (LDS, written in an earlier phase), for lane `lane`
@@ -66,10 +85,7 @@ __device__ __forceinline__ static uint32_t wave_incl_scan(const uint32_t *in, in
     for (int i = 0; i <= lane; i++) s += in[i];
     return s;
 #else
-    uint32_t v = in[lane];
-    CSH_UNROLL
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = uint32_t(__shfl_up(int(v), o, 64)); if (lane >= o) v += t; }
-    return v;
+    return wave_incl_sum(in[lane]);
 #endif
 }
 
@@ -366,7 +382,6 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                     }
                 }
                 cnt[0][tid] = n;
-                for (int slot = 1; slot < CSH_TK_MAXSLOT; slot++) cnt[slot][tid] = 0;
                 continue;
             }
             const bool valid = u < P.nunits;
@@ -406,8 +421,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                 pl[9] = uint64_t(m[15]) | (uint64_t(m[31]) << 32);
                 CSH_SCHED_FENCE();
             }
-            for (int slot = 0; slot < CSH_TK_MAXSLOT; slot++) {
-                if (slot >= int(P.nslot)) { cnt[slot][tid] = 0; continue; }
+            for (int slot = 0; slot < int(P.nslot); slot++) {
                 const AcSlot &a = P.s[slot];
                 const uint64_t band = band_mask(a.Ss, a.Se);
                 const uint64_t lo = pick_sig(pl, a.Al);
@@ -441,8 +455,8 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
         }
         if (phase == 2) {
             // ---------------------------------------------------------------- exclusive scan of the counts inside the wave, slot by slot
-            CSH_UNROLL
-            for (int slot = 0; slot < CSH_TK_MAXSLOT; slot++) {
+            const int nslot = ch.kind == 1 ? 1 : int(P.nslot);   // the slots above hold nothing (and are not read below)
+            for (int slot = 0; slot < nslot; slot++) {
                 const uint32_t incl = wave_incl_scan(&cnt[slot][64 * wv], lane);
                 off[slot][tid] = incl - cnt[slot][tid];
                 if (lane == 63) s_wtot[wv][slot] = incl;
@@ -453,10 +467,14 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             // ---------------------------------------------------------------- one lane per wave: room in the pool for the wave's segments
             if (lane != 0) continue;
             uint32_t total = 0;
-            CSH_UNROLL
-            for (int slot = 0; slot < CSH_TK_MAXSLOT; slot++) total += s_wtot[wv][slot];
+            const int nslot = ch.kind == 1 ? 1 : int(P.nslot);
+            for (int slot = 0; slot < nslot; slot++) total += s_wtot[wv][slot];
             const TokRegion rg = c.regions[ch.region];
-            const uint32_t rel = atomicAdd(&c.tok_cursor[ch.region], total);
+            uint32_t rel;
+            if (c.debug & 16384u) {   // timing experiment: a static share of the region instead of the cursor (tokens may collide)
+                const uint32_t nch = ((ch.kind == 1 ? s_w.nunits : P.nunits) + 255u) >> 8;
+                rel = (ch.j * 4u + uint32_t(wv)) * (rg.cap / (nch * 4u));
+            } else rel = atomicAdd(&c.tok_cursor[ch.region], total);
             const bool ok = uint64_t(rel) + total <= rg.cap;
             const unsigned long long gb = rg.base + rel;
             if (!ok) c.overflow[1] = 1;
@@ -734,9 +752,7 @@ __global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
         uint32_t cnt = 0, be = 0, s0 = u, pos = u;
         while (pos <= t) {
             const uint32_t here = pos + lane <= t ? uint32_t(tl[pos + lane]) : 0u;
-            uint32_t incl = here;
-            CSH_UNROLL
-            for (int o = 1; o < 64; o <<= 1) { uint32_t v = uint32_t(__shfl_up(int(incl), o, 64)); if (int(lane) >= o) incl += v; }
+            const uint32_t incl = wave_incl_sum(here);
             const bool over = pos + lane <= t && (be + incl > 937 || cnt + lane + 1 == 0x7FFF);
             const uint64_t om = __ballot(over);
             if (om) {
@@ -745,7 +761,7 @@ __global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
                 s0 = pos + l0 + 1; pos = s0; cnt = 0; be = 0;
             } else {
                 const uint32_t len = t - pos + 1 < 64 ? t - pos + 1 : 64;
-                be += uint32_t(__shfl(int(incl), 63, 64)); cnt += len; pos += len;
+                be += wave_last(incl); cnt += len; pos += len;
             }
         }
         if (cnt && lane == 0) { er[s0] = uint16_t(cnt); count(cnt, s0); }
@@ -1102,13 +1118,11 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
             }
             if (!__ballot(slow) && !(c.debug & 4096u)) {
                 const uint32_t len1 = n4[0] + n4[1] + n4[2] + n4[3];
-                uint32_t incl1 = len1;
-                CSH_UNROLL
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = uint32_t(__shfl_up(int(incl1), o, 64)); if (lane >= o) incl1 += tt; }
+                const uint32_t incl1 = wave_incl_sum(len1);
                 uint64_t at1 = pos + incl1 - len1 - uint64_t(ww) * 32u;
                 CSH_UNROLL
                 for (int q = 0; q < 4; q++) if (n4[q]) { or_bits(buf, at1, v4[q], n4[q]); at1 += n4[q]; }
-                pos += uint32_t(__shfl(int(incl1), 63, 64));
+                pos += wave_last(incl1);
                 goto slide;
             }
         }
@@ -1121,16 +1135,14 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
             if (pad && last_seg && i + uint32_t(q) == n) { p[q].v[0] = (1u << pad) - 1u; p[q].n[0] = pad; }   // the byte fill of the scan's last chunk rides as one more token
             len += p[q].n[0] + p[q].n[1] + p[q].n[2];
         }
-        uint32_t incl = len;
-        CSH_UNROLL
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = uint32_t(__shfl_up(int(incl), o, 64)); if (lane >= o) incl += tt; }
+        const uint32_t incl = wave_incl_sum(len);
         uint64_t at = pos + incl - len - uint64_t(ww) * 32u;    // bit position inside the window
         CSH_UNROLL
         for (int q = 0; q < 4; q++) {
             CSH_UNROLL
             for (int k = 0; k < 3; k++) if (p[q].n[k]) { or_bits(buf, at, p[q].v[k], p[q].n[k]); at += p[q].n[k]; }
         }
-        pos += uint32_t(__shfl(int(incl), 63, 64));
+        pos += wave_last(incl);
         }
     slide:
         // slide the window when another 256 tokens' worth of bits (256 x 96) might not fit any more
@@ -1153,8 +1165,8 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
     uint32_t n[4]; const uint32_t *tk[4];
     CSH_UNROLL
     for (int seg = 0; seg < 4; seg++) {
-        n[seg] = uint32_t(__shfl(int(seg_n), seg, 64));
-        tk[seg] = c.tokens + ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o)), seg, 64)) | ((unsigned long long)uint32_t(__shfl(int(uint32_t(seg_o >> 32)), seg, 64)) << 32));
+        n[seg] = uint32_t(__builtin_amdgcn_readlane(int(seg_n), seg));
+        tk[seg] = c.tokens + ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(int(uint32_t(seg_o)), seg)) | ((unsigned long long)uint32_t(__builtin_amdgcn_readlane(int(uint32_t(seg_o >> 32)), seg)) << 32));
     }
     const uint32_t b1 = n[0], b2 = b1 + n[1], b3 = b2 + n[2], total = b3 + n[3];
     const uint32_t n_ext = total + (pad ? 1u : 0u);
