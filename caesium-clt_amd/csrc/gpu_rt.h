@@ -33,6 +33,8 @@
 // emulation re-enters the kernel once per phase and lane, so there it is a per-thread array indexed by the lane.  Declare it in front
 // of CSH_PHASE_LOOP.
 #define CSH_PERSIST(T, name, N) T name[N]
+// a value every lane of the wave holds alike, moved to a scalar register (and so waited for HERE, not lazily inside a later branch)
+#define CSH_UNIFORM(x) __builtin_amdgcn_readfirstlane(int(x))
 #define CSH_PHASE_LOOP(NPH) for (int phase = 0; phase < (NPH); ((phase + 1 < (NPH)) ? __syncthreads() : (void)0), phase++)
 #define CSH_LAUNCH_PHASED(kern, nph, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 // the same loop where some phase ends only synchronise a wave with itself: bit p of WAVE_MASK set = after phase p the lanes of a wave
@@ -52,6 +54,7 @@
 #define __launch_bounds__(...)
 #define CSH_UNROLL
 #define CSH_PIN(x) ((void)0)
+#define CSH_UNIFORM(x) int(x)
 #define CSH_SCHED_FENCE() ((void)0)
 struct dim3 {
     unsigned x, y, z;

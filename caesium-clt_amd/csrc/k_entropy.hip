@@ -540,8 +540,8 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                     const uint64_t NZ = lo & band;
                     const uint64_t any = wave_or64(NZ);   // positions no lane of the wave codes cost two scalar instructions
                     uint32_t *h = hist + slot * 257;
-                    const int Al = a.Al;
-                    int prev = int(a.Ss) - 1;
+                    const int Al = CSH_UNIFORM(a.Al), Se = CSH_UNIFORM(a.Se);   // read from LDS here: the steps below then wait for nothing
+                    int prev = CSH_UNIFORM(a.Ss) - 1;
                     CSH_UNROLL
                     for (int k = 1; k < 64; k++) {
                         CSH_SCHED_FENCE();
@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                             rawbits += uint32_t(nb);
                         }
                     }
-                    if (!((NZ >> a.Se) & 1)) out.put(TK_EOB | (uint32_t(tid) << 3));
+                    if (!((NZ >> Se) & 1)) out.put(TK_EOB | (uint32_t(tid) << 3));
                 } else {
                     const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
                     if (c.debug & 8u) continue;
