@@ -17,6 +17,7 @@ struct Vp8In {              // one input file, host-parsed container
     uint64_t work_off;      // per-image work area in the work pool (layout below)
     uint64_t rgb_off;       // width * height * 3 bytes in the pixel pool
     uint32_t status;        // device: 0 ok, else an error code
+    uint32_t lossless;      // 1: the payload is a VP8L stream (vp8l_dec.h), work area sized by vp8l_work_bytes
 };
 // work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts
 __host__ __device__ static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t mbh) {

@@ -1,0 +1,418 @@
+// vp8l_dec.h -- WebP lossless (VP8L) decoder, the lossless WebP inputs of libcaesium's webp::compress / convert paths
+// (/root/reference/src/compressor.rs:289-305, 589-598 name WebP among the inputs; libcaesium decodes them with libwebp).
+// Statement followed: the WebP Lossless Bitstream Specification (prefix codes over an LSB-first bit reader, the colour cache, LZ77
+// with the 120-entry neighbourhood distance map, meta prefix image, and the four transforms: predictor (14 modes), cross-colour,
+// subtract-green, colour indexing), with libwebp's behaviour where the text leaves room (a code with a single used symbol costs no
+// bits; every pixel enters the colour cache, copied and looked-up ones included; incomplete codes are an error).
+// One image is decoded by ONE lane, start to end: the entropy layer is a serial chain and the pictures of a batch are the parallel
+// axis.  Pixel-exact against libwebp (through Pillow) in tests/test_webp_decode*.py.  Host + device code: the emulation build compiles
+// it as plain C++.
+#pragma once
+#include <cstdint>
+
+namespace csw {
+
+// work area of one image (bytes): two ARGB frames (the decoded -- possibly pixel-packed -- picture and the one colour indexing expands
+// into), three sub-images (predictor modes, cross-colour elements, meta prefix groups: at most a quarter of the picture's side each,
+// as their block side is >= 4), the palette, the colour cache, and the prefix-code arena
+__host__ __device__ static inline uint64_t vp8l_arena_bytes(uint64_t file_bytes) { return 4ull * 1024 * 1024 + 16ull * file_bytes; }
+__host__ __device__ static inline uint64_t vp8l_sub_pixels(uint32_t w, uint32_t h) { return uint64_t((w + 3) / 4) * ((h + 3) / 4) + 16; }
+__host__ __device__ static inline uint64_t vp8l_work_bytes(uint32_t w, uint32_t h, uint64_t file_bytes) {
+    return 2ull * 4 * w * h + 3ull * 4 * vp8l_sub_pixels(w, h) + 4ull * 256 + 4ull * 2048 + vp8l_arena_bytes(file_bytes) + 256;
+}
+
+struct LBits {   // LSB-first bit reader
+    const uint8_t *p, *end;
+    uint64_t val;
+    int nbits;
+    bool eos;
+    __host__ __device__ void init(const uint8_t *d, size_t n) { p = d; end = d + n; val = 0; nbits = 0; eos = false; }
+    __host__ __device__ void fill() { while (nbits <= 56 && p < end) { val |= uint64_t(*p++) << nbits; nbits += 8; } }
+    __host__ __device__ uint32_t peek(int n) { if (nbits < n) fill(); return uint32_t(val) & ((1u << n) - 1u); }   // n <= 16
+    __host__ __device__ void drop(int n) { if (nbits < n) { eos = true; val = 0; nbits = 0; return; } val >>= n; nbits -= n; }
+    __host__ __device__ uint32_t read(int n) { if (!n) return 0; const uint32_t v = peek(n); drop(n); return v; }
+};
+
+// one prefix code: canonical, decoded length by length; codes of up to 8 bits also through a 256-entry table (when the arena had room)
+struct LCode {
+    uint16_t first_code[16], first_idx[16], count[16];
+    uint32_t syms;       // sorted symbols: u16 index into the arena
+    uint32_t lut;        // 256 x u16 (symbol | length << 12; 0: longer than 8 bits), or 0xFFFFFFFF
+    uint16_t single;     // the only symbol, when nsym == 1 (costs no bits)
+    uint16_t nsym;
+};
+struct LGroup { LCode c[5]; };   // green + length prefixes + cache indices, red, blue, alpha, distance
+
+struct LArena { uint16_t *base; uint64_t cap, used; };   // in u16 units
+
+__host__ __device__ static inline int lsym(LBits &br, const LCode &c, const uint16_t *arena) {
+    if (c.nsym <= 1) return c.single;
+    if (c.lut != 0xFFFFFFFFu) {
+        const uint16_t e = arena[c.lut + br.peek(8)];
+        if (e) { br.drop(e >> 12); return e & 0xFFF; }
+    }
+    uint32_t code = 0;
+    for (int len = 1; len <= 15; len++) {
+        code = (code << 1) | br.read(1);
+        const uint32_t d = code - c.first_code[len];
+        if (d < c.count[len]) return arena[c.syms + c.first_idx[len] + d];
+    }
+    br.eos = true;   // cannot happen with a complete code
+    return 0;
+}
+
+// lengths[0..n) -> code.  false: not a complete prefix code (or no room for its symbols)
+__host__ __device__ static inline bool lbuild(const uint8_t *lengths, int n, LCode &c, LArena &ar, bool want_lut) {
+    for (int l = 0; l < 16; l++) c.count[l] = 0;
+    int used = 0, last = 0;
+    for (int s = 0; s < n; s++) if (lengths[s]) { c.count[lengths[s]]++; used++; last = s; }
+    c.nsym = uint16_t(used > 0xFFFF ? 0xFFFF : used); c.single = uint16_t(last); c.lut = 0xFFFFFFFFu; c.syms = 0;
+    if (used == 0) return false;
+    if (used == 1) { c.nsym = 1; return true; }
+    uint32_t code = 0, idx = 0, left = 1;
+    for (int l = 1; l <= 15; l++) {
+        left <<= 1;
+        if (c.count[l] > left) return false;
+        left -= c.count[l];
+        c.first_code[l] = uint16_t(code); c.first_idx[l] = uint16_t(idx);
+        code = (code + c.count[l]) << 1; idx += c.count[l];
+    }
+    if (left) return false;
+    if (ar.used + uint64_t(used) > ar.cap) return false;
+    c.syms = uint32_t(ar.used); ar.used += uint64_t(used);
+    uint16_t next[16];
+    for (int l = 1; l <= 15; l++) next[l] = c.first_idx[l];
+    for (int s = 0; s < n; s++) if (lengths[s]) ar.base[c.syms + next[lengths[s]]++] = uint16_t(s);
+    if (want_lut && ar.used + 256 <= ar.cap) {
+        c.lut = uint32_t(ar.used); ar.used += 256;
+        uint16_t *t = ar.base + c.lut;
+        for (int i = 0; i < 256; i++) t[i] = 0;
+        for (int l = 1; l <= 8; l++)
+            for (uint32_t k = 0; k < c.count[l]; k++) {
+                const uint32_t cd = c.first_code[l] + k;
+                uint32_t rev = 0;
+                for (int b = 0; b < l; b++) rev |= ((cd >> b) & 1u) << (l - 1 - b);
+                const uint16_t e = uint16_t(ar.base[c.syms + c.first_idx[l] + k] | (l << 12));
+                for (uint32_t i = rev; i < 256; i += 1u << l) t[i] = e;
+            }
+    }
+    return true;
+}
+
+// reads one prefix code of `alphabet` symbols (lengths: scratch of >= alphabet bytes)
+__host__ __device__ static inline bool lread_code(LBits &br, int alphabet, LCode &c, LArena &ar, uint8_t *lengths, bool want_lut) {
+    for (int i = 0; i < alphabet; i++) lengths[i] = 0;
+    if (br.read(1)) {   // simple code: one or two symbols
+        const int nsym = int(br.read(1)) + 1;
+        const int s0 = int(br.read(br.read(1) ? 8 : 1));
+        if (s0 >= alphabet) return false;
+        lengths[s0] = 1;
+        if (nsym == 2) { const int s1 = int(br.read(8)); if (s1 >= alphabet) return false; lengths[s1] = 1; }
+    } else {
+        const uint8_t order[19] = {17, 18, 0, 1, 2, 3, 4, 5, 16, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+        uint8_t cl[19];
+        for (int i = 0; i < 19; i++) cl[i] = 0;
+        const int ncl = 4 + int(br.read(4));
+        for (int i = 0; i < ncl; i++) cl[order[i]] = uint8_t(br.read(3));
+        // the code of the code lengths: 19 symbols, lengths up to 7 -- decoded length by length from a small local description
+        LCode cc;
+        uint16_t cc_syms[19];
+        LArena la; la.base = cc_syms; la.cap = 19; la.used = 0;
+        if (!lbuild(cl, 19, cc, la, false)) return false;
+        int max_symbol = alphabet;
+        if (br.read(1)) {
+            const int nb = 2 + 2 * int(br.read(3));
+            max_symbol = 2 + int(br.read(nb));
+            if (max_symbol > alphabet) return false;
+        }
+        int s = 0, prev = 8;
+        while (s < alphabet) {
+            if (max_symbol-- == 0) break;
+            const int v = lsym(br, cc, cc_syms);
+            if (v < 16) { lengths[s++] = uint8_t(v); if (v) prev = v; }
+            else {
+                const int extra = v == 16 ? 2 : (v == 17 ? 3 : 7), base = v == 18 ? 11 : 3;
+                const int rep = int(br.read(extra)) + base;
+                if (s + rep > alphabet) return false;
+                const uint8_t fill = v == 16 ? uint8_t(prev) : uint8_t(0);
+                for (int i = 0; i < rep; i++) lengths[s++] = fill;
+            }
+        }
+    }
+    if (br.eos) return false;
+    return lbuild(lengths, alphabet, c, ar, want_lut);
+}
+
+// LZ77 prefix value (length or distance code): the prefix symbol, then its extra bits
+__host__ __device__ static inline uint32_t lprefix_value(LBits &br, int sym) {
+    if (sym < 4) return uint32_t(sym) + 1;
+    const int extra = (sym - 2) >> 1;
+    const uint32_t off = uint32_t(2 + (sym & 1)) << extra;
+    return off + br.read(extra) + 1;
+}
+// distance code 1..120 -> pixel distance through the neighbourhood map: the 120 positions (dx, dy), dy in 0..7, dx in -7..8 (dy = 0: dx > 0),
+// ordered by dx^2 + dy^2, then |dx|, then dx > 0 first (the specification's table, generated instead of spelled out); kept packed as
+// (dy << 4) | (8 - dx)
+__host__ __device__ static inline void lplane_table(uint8_t t[120]) {
+    int n = 0;
+    for (int d2 = 1; d2 <= 113 && n < 120; d2++)
+        for (int ax = 0; ax <= 8; ax++)
+            for (int sgn = 0; sgn < 2; sgn++) {
+                const int dx = sgn ? -ax : ax;
+                if (sgn && ax == 0) continue;
+                const int r = d2 - ax * ax;
+                if (r < 0) continue;
+                int dy = 0;
+                while (dy * dy < r) dy++;
+                if (dy * dy != r || dy > 7) continue;
+                if (dx < -7 || dx > 8) continue;
+                if (dy == 0 && dx <= 0) continue;
+                t[n++] = uint8_t((dy << 4) | (8 - dx));
+            }
+}
+
+__host__ __device__ static inline uint32_t ladd(uint32_t a, uint32_t b) { return (((a & 0xFF00FF00u) + (b & 0xFF00FF00u)) & 0xFF00FF00u) | (((a & 0x00FF00FFu) + (b & 0x00FF00FFu)) & 0x00FF00FFu); }
+__host__ __device__ static inline uint32_t lavg(uint32_t a, uint32_t b) { return (((a ^ b) & 0xFEFEFEFEu) >> 1) + (a & b); }
+__host__ __device__ static inline int labs(int v) { return v < 0 ? -v : v; }
+__host__ __device__ static inline uint32_t lclip(int v) { return v < 0 ? 0u : v > 255 ? 255u : uint32_t(v); }
+__host__ __device__ static inline uint32_t lselect(uint32_t L, uint32_t T, uint32_t TL) {
+    int pl = 0, pt = 0;   // distance of the gradient estimate L + T - TL to L and to T
+    for (int s = 0; s < 32; s += 8) { const int l = int((L >> s) & 255u), t = int((T >> s) & 255u), tl = int((TL >> s) & 255u); pl += labs(t - tl); pt += labs(l - tl); }
+    return pl < pt ? L : T;
+}
+__host__ __device__ static inline uint32_t lclamp_full(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r = 0;
+    for (int s = 0; s < 32; s += 8) r |= lclip(int((a >> s) & 255u) + int((b >> s) & 255u) - int((c >> s) & 255u)) << s;
+    return r;
+}
+__host__ __device__ static inline uint32_t lclamp_half(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+    for (int s = 0; s < 32; s += 8) { const int x = int((a >> s) & 255u), y = int((b >> s) & 255u); r |= lclip(x + (x - y) / 2) << s; }
+    return r;
+}
+__host__ __device__ static inline uint32_t lpredict(int mode, const uint32_t *px, int w) {   // px: the pixel being decoded, in a frame of width w
+    const uint32_t L = px[-1], T = px[-w], TR = px[-w + 1], TL = px[-w - 1];
+    switch (mode) {
+    case 0: return 0xFF000000u;
+    case 1: return L;
+    case 2: return T;
+    case 3: return TR;
+    case 4: return TL;
+    case 5: return lavg(lavg(L, TR), T);
+    case 6: return lavg(L, TL);
+    case 7: return lavg(L, T);
+    case 8: return lavg(TL, T);
+    case 9: return lavg(T, TR);
+    case 10: return lavg(lavg(L, TL), lavg(T, TR));
+    case 11: return lselect(L, T, TL);
+    case 12: return lclamp_full(L, T, TL);
+    case 13: return lclamp_half(lavg(L, T), TL);
+    default: return 0xFF000000u;   // modes 14, 15: libwebp treats them as "black"
+    }
+}
+
+struct LTransform { int type, bits; uint32_t xsize; uint32_t *data; uint32_t ncolors; };
+
+struct LDec {
+    LBits br;
+    LArena ar;
+    uint32_t *cache;      // 2048 entries
+    uint8_t *lengths;     // scratch: 2328 bytes
+    uint8_t plane[120];
+};
+
+// entropy-coded ARGB image of xs x ys pixels into out.  level0: the meta prefix image may be present (meta_buf holds it).
+template <bool level0>
+__host__ __device__ static inline int ldecode_pixels(LDec &d, uint32_t xs, uint32_t ys, uint32_t *out, uint32_t *meta_buf, uint64_t meta_cap) {
+    LBits &br = d.br;
+    int cache_bits = 0;
+    if (br.read(1)) { cache_bits = int(br.read(4)); if (cache_bits < 1 || cache_bits > 11) return 1; }
+    int prec = 0; uint32_t mw = 0; uint32_t ngroups = 1;
+    if (level0 && br.read(1)) {
+        const uint64_t arena_mark = d.ar.used;
+        prec = int(br.read(3)) + 2;
+        mw = (xs + (1u << prec) - 1) >> prec;
+        const uint32_t mh = (ys + (1u << prec) - 1) >> prec;
+        if (uint64_t(mw) * mh > meta_cap) return 1;
+        const int rc = ldecode_pixels<false>(d, mw, mh, meta_buf, nullptr, 0);
+        d.ar.used = arena_mark;   // the meta image's codes are done with
+        if (rc) return rc;
+        uint32_t mx = 0;
+        for (uint64_t i = 0; i < uint64_t(mw) * mh; i++) { meta_buf[i] = (meta_buf[i] >> 8) & 0xFFFFu; if (meta_buf[i] > mx) mx = meta_buf[i]; }
+        ngroups = mx + 1;
+    }
+    // the groups' descriptions live in the arena too (u16 units)
+    const uint64_t gwords = (sizeof(LGroup) + 1) / 2;
+    d.ar.used = (d.ar.used + 3) & ~uint64_t(3);   // 8-byte alignment
+    if (d.ar.used + gwords * ngroups > d.ar.cap) return 2;
+    LGroup *groups = reinterpret_cast<LGroup *>(d.ar.base + d.ar.used);
+    d.ar.used += gwords * ngroups;
+    const int cache_size = cache_bits ? 1 << cache_bits : 0;
+    // tables of 256 entries for every code while a quarter of the arena is free; beyond that the codes are decoded length by length
+    for (uint32_t g = 0; g < ngroups; g++) {
+        const int alpha[5] = {256 + 24 + cache_size, 256, 256, 256, 40};
+        for (int k = 0; k < 5; k++) {
+            const bool want_lut = d.ar.used + 4096 < d.ar.cap - d.ar.cap / 4;
+            if (!lread_code(br, alpha[k], groups[g].c[k], d.ar, d.lengths, want_lut)) return br.eos ? 1 : (d.ar.used + 4096 >= d.ar.cap ? 2 : 1);
+        }
+    }
+    if (cache_bits) for (int i = 0; i < cache_size; i++) d.cache[i] = 0;
+    const uint64_t total = uint64_t(xs) * ys;
+    uint64_t pos = 0;
+    uint32_t x = 0, y = 0;
+    const uint32_t pmask = prec ? (1u << prec) - 1 : 0xFFFFFFFFu;
+    const LGroup *grp = &groups[0];
+    auto pick = [&]() { if (prec) grp = &groups[meta_buf[uint64_t(y >> prec) * mw + (x >> prec)]]; };
+    auto put_cache = [&](uint32_t v) { if (cache_bits) d.cache[(0x1E35A7BDu * v) >> (32 - cache_bits)] = v; };
+    pick();
+    const uint16_t *A = d.ar.base;
+    while (pos < total) {
+        if ((x & pmask) == 0) pick();
+        const int code = lsym(br, grp->c[0], A);
+        if (code < 256) {
+            const uint32_t r = uint32_t(lsym(br, grp->c[1], A)), b = uint32_t(lsym(br, grp->c[2], A)), a = uint32_t(lsym(br, grp->c[3], A));
+            const uint32_t v = (a << 24) | (r << 16) | (uint32_t(code) << 8) | b;
+            out[pos++] = v; put_cache(v);
+            if (++x == xs) { x = 0; y++; }
+        } else if (code < 256 + 24) {
+            const uint32_t len = lprefix_value(br, code - 256);
+            const int ds = lsym(br, grp->c[4], A);
+            const uint32_t dcode = lprefix_value(br, ds);
+            uint64_t dist;
+            if (dcode > 120) dist = dcode - 120;
+            else {
+                const uint8_t e = d.plane[dcode - 1];
+                const int64_t dd = int64_t(e >> 4) * xs + (8 - int(e & 15));
+                dist = dd < 1 ? 1 : uint64_t(dd);
+            }
+            if (dist > pos || pos + len > total) return 1;
+            for (uint32_t i = 0; i < len; i++) { const uint32_t v = out[pos - dist]; out[pos++] = v; put_cache(v); }
+            x += len;
+            while (x >= xs) { x -= xs; y++; }
+            if (pos < total && prec) pick();
+        } else {
+            const int idx = code - (256 + 24);
+            if (idx >= cache_size) return 1;
+            const uint32_t v = d.cache[idx];
+            out[pos++] = v; put_cache(v);
+            if (++x == xs) { x = 0; y++; }
+        }
+        if (br.eos) return 1;
+    }
+    return 0;
+}
+
+// 0 ok, 1 malformed, 2 beyond this build (work area exhausted), 3 the picture is not opaque
+__host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *rgb, uint64_t file_bytes) {
+    LDec d;
+    d.br.init(data, n);
+    LBits &br = d.br;
+    if (br.read(8) != 0x2F) return 1;
+    const uint32_t w = br.read(14) + 1, h = br.read(14) + 1;
+    br.read(1);   // alpha_is_used: a hint; the pixels decide
+    if (br.read(3) != 0 || w != W || h != H) return 1;
+    const uint64_t npx = uint64_t(W) * H, sub = vp8l_sub_pixels(W, H);
+    uint32_t *frame0 = reinterpret_cast<uint32_t *>(work), *frame1 = frame0 + npx;
+    uint32_t *subimg[3] = {frame1 + npx, frame1 + npx + sub, frame1 + npx + 2 * sub};
+    uint32_t *palette = subimg[2] + sub;
+    d.cache = palette + 256;
+    d.ar.base = reinterpret_cast<uint16_t *>(d.cache + 2048);
+    d.ar.cap = vp8l_arena_bytes(file_bytes) / 2 - 2328 / 2 - 8; d.ar.used = 0;
+    d.lengths = reinterpret_cast<uint8_t *>(d.ar.base + d.ar.cap);
+    lplane_table(d.plane);
+    // ---- transforms, in the order they are undone LAST to FIRST
+    LTransform tr[4];
+    int ntr = 0, seen = 0;
+    uint32_t xs = W;
+    while (br.read(1)) {
+        const int type = int(br.read(2));
+        if (seen & (1 << type)) return 1;
+        seen |= 1 << type;
+        LTransform &t = tr[ntr++];
+        t.type = type; t.bits = 0; t.xsize = xs; t.data = nullptr; t.ncolors = 0;
+        if (type == 0 || type == 1) {
+            t.bits = int(br.read(3)) + 2;
+            const uint32_t bw = (xs + (1u << t.bits) - 1) >> t.bits, bh = (H + (1u << t.bits) - 1) >> t.bits;
+            if (uint64_t(bw) * bh > sub) return 1;
+            t.data = subimg[type];
+            const uint64_t keep = d.ar.used;
+            const int rc = ldecode_pixels<false>(d, bw, bh, t.data, nullptr, 0);
+            d.ar.used = keep;   // the sub-image's codes are done with
+            if (rc) return rc;
+        } else if (type == 3) {
+            t.ncolors = br.read(8) + 1;
+            t.bits = t.ncolors > 16 ? 0 : t.ncolors > 4 ? 1 : t.ncolors > 2 ? 2 : 3;
+            t.data = palette;
+            const uint64_t keep = d.ar.used;
+            const int rc = ldecode_pixels<false>(d, t.ncolors, 1, palette, nullptr, 0);
+            d.ar.used = keep;
+            if (rc) return rc;
+            for (uint32_t i = 1; i < t.ncolors; i++) palette[i] = ladd(palette[i], palette[i - 1]);
+            for (uint32_t i = t.ncolors; i < 256; i++) palette[i] = 0;
+            xs = (xs + (1u << t.bits) - 1) >> t.bits;
+        }
+        if (br.eos) return 1;
+    }
+    // ---- the picture itself
+    {
+        const int rc = ldecode_pixels<true>(d, xs, H, frame0, subimg[2], sub);
+        if (rc) return rc;
+    }
+    // ---- inverse transforms
+    uint32_t *cur = frame0, *other = frame1;
+    for (int k = ntr - 1; k >= 0; k--) {
+        const LTransform &t = tr[k];
+        const uint32_t tw = t.xsize;
+        if (t.type == 2) {
+            const uint64_t cnt = uint64_t(tw) * H;
+            for (uint64_t i = 0; i < cnt; i++) { const uint32_t v = cur[i], g = (v >> 8) & 255u; cur[i] = (v & 0xFF00FF00u) | ((((v & 0x00FF00FFu) + ((g << 16) | g))) & 0x00FF00FFu); }
+        } else if (t.type == 1) {
+            const uint32_t bw = (tw + (1u << t.bits) - 1) >> t.bits;
+            for (uint32_t y = 0; y < H; y++)
+                for (uint32_t x = 0; x < tw; x++) {
+                    const uint32_t m = t.data[uint64_t(y >> t.bits) * bw + (x >> t.bits)];
+                    const int8_t g2r = int8_t(m & 255u), g2b = int8_t((m >> 8) & 255u), r2b = int8_t((m >> 16) & 255u);
+                    uint32_t &p = cur[uint64_t(y) * tw + x];
+                    const int8_t green = int8_t((p >> 8) & 255u);
+                    int nr = int((p >> 16) & 255u), nb = int(p & 255u);
+                    nr = (nr + ((int(g2r) * int(green)) >> 5)) & 255;
+                    nb = (nb + ((int(g2b) * int(green)) >> 5) + ((int(r2b) * int(int8_t(nr))) >> 5)) & 255;
+                    p = (p & 0xFF00FF00u) | (uint32_t(nr) << 16) | uint32_t(nb);
+                }
+        } else if (t.type == 0) {
+            const uint32_t bw = (tw + (1u << t.bits) - 1) >> t.bits;
+            cur[0] = ladd(cur[0], 0xFF000000u);
+            for (uint32_t x = 1; x < tw; x++) cur[x] = ladd(cur[x], cur[x - 1]);
+            for (uint32_t y = 1; y < H; y++) {
+                uint32_t *row = cur + uint64_t(y) * tw;
+                row[0] = ladd(row[0], row[-int64_t(tw)]);
+                for (uint32_t x = 1; x < tw; x++) {
+                    const int mode = int((t.data[uint64_t(y >> t.bits) * bw + (x >> t.bits)] >> 8) & 15u);
+                    row[x] = ladd(row[x], lpredict(mode, row + x, int(tw)));
+                }
+            }
+        } else {
+            // colour indexing: the frame holds 1 << bits indices per pixel (bits > 0), the low ones first
+            const uint32_t pw = (tw + (1u << t.bits) - 1) >> t.bits;
+            const int per = 1 << t.bits, nb = 8 >> t.bits;
+            for (uint32_t y = 0; y < H; y++)
+                for (uint32_t x = 0; x < tw; x++) {
+                    const uint32_t packed = (cur[uint64_t(y) * pw + (x >> t.bits)] >> 8) & 255u;
+                    const uint32_t idx = t.bits ? (packed >> (nb * int(x & uint32_t(per - 1)))) & ((1u << nb) - 1u) : packed;
+                    other[uint64_t(y) * tw + x] = idx < t.ncolors ? t.data[idx] : 0u;
+                }
+            uint32_t *sw = cur; cur = other; other = sw;
+            xs = tw;
+        }
+    }
+    // ---- ARGB -> RGB (an input that is not opaque has no path through the three-channel encoders behind this)
+    uint32_t amin = 255;
+    for (uint64_t i = 0; i < npx; i++) {
+        const uint32_t v = cur[i];
+        rgb[3 * i] = uint8_t(v >> 16); rgb[3 * i + 1] = uint8_t(v >> 8); rgb[3 * i + 2] = uint8_t(v);
+        if ((v >> 24) < amin) amin = v >> 24;
+    }
+    return amin == 255 ? 0 : 3;
+}
+
+}  // namespace csw

@@ -1,7 +1,8 @@
 // webp_decode.cpp -- WebP INPUTS of the batch queue: container parsing on the host (RIFF / VP8 / VP8X chunk walk), the key frame on the
 // device (k_webp_dec.hip), the decoded RGB stays in HBM and is handed to the encoders as csp_pixels -- what libcaesium's
 // webp::compress and convert_in_memory do with libwebp's decoder in front (/root/reference/src/compressor.rs:289-305).
-// Built: lossy (VP8) still pictures.  Lossless (VP8L), alpha (ALPH) and animation answer CS_ERR_UNSUPPORTED per file.
+// Built: lossy (VP8) and lossless (VP8L) still pictures without transparency.  Alpha (an ALPH chunk, or a VP8L picture that is not
+// opaque) and animation answer CS_ERR_UNSUPPORTED per file: the encoders behind this take three channels.
 #include <cstring>
 #include <memory>
 #include <string>
@@ -11,6 +12,7 @@
 #include "devmem.hpp"
 #include "webp_kernels.h"
 #include "vp8_dec.h"
+#include "vp8l_dec.h"
 
 using namespace csh;
 
@@ -32,7 +34,8 @@ struct cswd_batch {
 static uint32_t rd32le(const uint8_t *d) { return uint32_t(d[0]) | (uint32_t(d[1]) << 8) | (uint32_t(d[2]) << 16) | (uint32_t(d[3]) << 24); }
 
 // RIFF walk: where the VP8 key frame lies; refuses what this build does not decode
-static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint32_t &w, uint32_t &h, std::string &msg) {
+static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint32_t &w, uint32_t &h, bool &lossless, std::string &msg) {
+    lossless = false;
     if (n < 20 || memcmp(d, "RIFF", 4) || memcmp(d + 8, "WEBP", 4)) { msg = "not a WebP file"; return CS_ERR_UNKNOWN_TYPE; }
     size_t end = size_t(rd32le(d + 4)) + 8;
     if (end > n) end = n;   // libwebp tolerates a RIFF size past the file's end as long as the chunks are there
@@ -41,13 +44,19 @@ static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint
         const size_t cl = rd32le(d + i + 4);
         if (i + 8 + cl > n) { msg = "truncated WebP chunk"; return CS_ERR_BAD_WEBP; }
         if (!memcmp(d + i, "VP8 ", 4)) { if (!found) { off = i + 8; len = cl; found = true; } }
-        else if (!memcmp(d + i, "VP8L", 4)) { msg = "lossless WebP (VP8L) input has no device path in this build"; return CS_ERR_UNSUPPORTED; }
+        else if (!memcmp(d + i, "VP8L", 4)) { if (!found) { off = i + 8; len = cl; found = true; lossless = true; } }
         else if (!memcmp(d + i, "ALPH", 4)) { msg = "WebP input with an alpha plane has no device path in this build"; return CS_ERR_UNSUPPORTED; }
         else if (!memcmp(d + i, "ANIM", 4) || !memcmp(d + i, "ANMF", 4)) { msg = "animated WebP input has no device path in this build"; return CS_ERR_UNSUPPORTED; }
         i += 8 + cl + (cl & 1);
     }
-    if (!found || len < 10) { msg = "no VP8 frame in the WebP file"; return CS_ERR_BAD_WEBP; }
+    if (!found || len < (lossless ? 5u : 10u)) { msg = "no VP8 frame in the WebP file"; return CS_ERR_BAD_WEBP; }
     const uint8_t *f = d + off;
+    if (lossless) {   // signature, 14 + 14 bits of size minus one, alpha hint, version
+        const uint32_t bits = rd32le(f + 1);
+        if (f[0] != 0x2F || (bits >> 29) != 0) { msg = "malformed VP8L header"; return CS_ERR_BAD_WEBP; }
+        w = (bits & 0x3FFFu) + 1; h = ((bits >> 14) & 0x3FFFu) + 1;
+        return 0;
+    }
     if ((f[0] & 1) || f[3] != 0x9D || f[4] != 0x01 || f[5] != 0x2A) { msg = "malformed VP8 frame header"; return CS_ERR_BAD_WEBP; }
     w = (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFF; h = (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFF;
     if (!w || !h) { msg = "empty VP8 frame"; return CS_ERR_BAD_WEBP; }
@@ -67,7 +76,8 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
         cswd_batch::Item &it = b->items[n];
         size_t off = 0, len = 0;
         uint32_t w = 0, h = 0;
-        it.code = parse_webp(inputs[n].data, inputs[n].length, off, len, w, h, it.msg);
+        bool lossless = false;
+        it.code = parse_webp(inputs[n].data, inputs[n].length, off, len, w, h, lossless, it.msg);
         if (it.code) continue;
         csw::Vp8In im;
         memset(&im, 0, sizeof im);
@@ -75,7 +85,8 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
         b->pool.insert(b->pool.end(), inputs[n].data + off, inputs[n].data + off + len);
         b->pool.resize((b->pool.size() + 15) & ~size_t(15));
         im.width = w; im.height = h; im.mbw = (w + 15) / 16; im.mbh = (h + 15) / 16;
-        im.work_off = b->work_bytes; b->work_bytes += (csw::vp8_work_bytes(im.mbw, im.mbh) + 63) & ~uint64_t(63);
+        im.lossless = lossless ? 1u : 0u;
+        im.work_off = b->work_bytes; b->work_bytes += ((lossless ? csw::vp8l_work_bytes(w, h, len) : csw::vp8_work_bytes(im.mbw, im.mbh)) + 63) & ~uint64_t(63);
         im.rgb_off = b->rgb_bytes; b->rgb_bytes += (uint64_t(w) * h * 3 + 63) & ~uint64_t(63);
         it.image = int(b->imgs.size());
         b->imgs.push_back(im);
@@ -96,8 +107,9 @@ extern "C" int cswd_batch_run(cswd_batch *b) {
         hipStreamSynchronize(b->stream) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("VP8 decode failed on the device"); return CS_ERR_NO_DEVICE; }
     for (cswd_batch::Item &it : b->items)
         if (it.image >= 0 && b->imgs[size_t(it.image)].status) {
-            it.code = b->imgs[size_t(it.image)].status == 2 ? CS_ERR_UNSUPPORTED : CS_ERR_BAD_WEBP;
-            it.msg = b->imgs[size_t(it.image)].status == 2 ? "VP8 frame type not supported" : "malformed VP8 stream";
+            const uint32_t st = b->imgs[size_t(it.image)].status;
+            it.code = st >= 2 ? CS_ERR_UNSUPPORTED : CS_ERR_BAD_WEBP;
+            it.msg = st == 3 ? "WebP input with transparency has no device path in this build" : st == 2 ? "WebP frame beyond this build (frame type / prefix-code work area)" : "malformed WebP stream";
         }
     b->ran = true;
     return 0;

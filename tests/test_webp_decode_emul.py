@@ -49,9 +49,68 @@ def test_emul_synthetic_files_decode_like_libwebp(api):
         assert np.array_equal(got, libwebp_rgb(blob)), c
 
 
+def lossless_of(arr, mode="RGB", **kw):
+    b = io.BytesIO()
+    Image.fromarray(arr, mode).save(b, format="WEBP", lossless=True, **kw)
+    return b.getvalue()
+
+
+def lossless_cases():
+    """every tool of the VP8L format: photographic content (predictor + cross-colour + subtract-green, colour cache, LZ77 with near and far
+    distances, meta prefix image on the larger ones), palettes of 2 / 3 / 5 / 17 / 200 colours (colour indexing with 8 / 4 / 2 / 1 pixels per
+    sample), flat and tiny pictures (codes with a single symbol), encoder efforts 0..6, an opaque RGBA source"""
+    rng = np.random.default_rng(77)
+    out = []
+    for i, (w, h, tex, method, q) in enumerate([(64, 48, 0.0, 4, 75), (101, 67, 20.0, 6, 100), (17, 9, 40.0, 0, 0), (1, 1, 0.0, 4, 75), (320, 240, 30.0, 4, 75),
+                                                (333, 222, 50.0, 2, 50), (16, 16, 5.0, 3, 75), (15, 33, 25.0, 5, 90), (256, 8, 15.0, 1, 20), (640, 480, 10.0, 6, 100)]):
+        out.append(("photo%d" % i, lossless_of(synth_rgb(60 + i, w, h, texture=tex), method=method, quality=q)))
+    for ncol in (2, 3, 5, 17, 200):
+        pal = rng.integers(0, 256, (ncol, 3), dtype=np.uint8)
+        idx = rng.integers(0, ncol, (37, 53))
+        idx[10:30, 5:40] = idx[10, 5]   # a flat patch: runs for the LZ77 layer
+        out.append(("palette%d" % ncol, lossless_of(pal[idx])))
+    out.append(("flat", lossless_of(np.full((40, 30, 3), 77, np.uint8))))
+    g = np.zeros((64, 200, 3), np.uint8); g[..., 0] = np.arange(200)[None, :]; g[..., 1] = np.arange(64)[:, None] * 3; g[..., 2] = 255 - g[..., 0]
+    out.append(("gradient", lossless_of(g)))
+    out.append(("opaque_rgba", lossless_of(np.dstack([synth_rgb(90, 48, 40, texture=20.0), np.full((40, 48), 255, np.uint8)]), "RGBA")))
+    noise = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    out.append(("noise", lossless_of(noise, method=6, quality=100)))
+    return out
+
+
+def test_emul_lossless_files_decode_like_libwebp(api):
+    cases = lossless_cases()
+    outs = api.webp_decode([b for _, b in cases])
+    for (name, blob), got in zip(cases, outs):
+        assert not isinstance(got, Exception), (name, got)
+        assert np.array_equal(got, libwebp_rgb(blob)), name
+
+
+def test_emul_damaged_lossless_streams_fail_alone(api):
+    """truncated and bit-flipped VP8L streams: refused (or decoded to a picture of the declared size), never a crash, and the good file
+    next to them is untouched"""
+    rng = np.random.default_rng(5)
+    cases = dict(lossless_cases())
+    good = cases["photo4"]
+    bad = []
+    for name in ("photo4", "palette5", "photo1", "gradient"):
+        blob = cases[name]
+        for cut in (len(blob) // 3, len(blob) * 2 // 3, len(blob) - 3, 40):
+            bad.append(blob[:cut])
+        for _ in range(12):
+            b = bytearray(blob)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(20, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            bad.append(bytes(b))
+    outs = api.webp_decode([good] + bad + [good])
+    assert np.array_equal(outs[0], libwebp_rgb(good)) and np.array_equal(outs[-1], libwebp_rgb(good))
+    for blob, o in zip(bad, outs[1:-1]):
+        assert isinstance(o, Exception) or o.ndim == 3
+
+
 def test_emul_damaged_and_unsupported_inputs_fail_alone(api):
     good = webp_of(3, 64, 48, 80)
-    lossless = io.BytesIO(); Image.fromarray(synth_rgb(4, 32, 24), "RGB").save(lossless, format="WEBP", lossless=True)
+    lossless = io.BytesIO(); Image.fromarray(np.dstack([synth_rgb(4, 32, 24), np.full((24, 32), 128, np.uint8)]), "RGBA").save(lossless, format="WEBP", lossless=True)   # VP8L, not opaque
     alpha = io.BytesIO(); Image.fromarray(np.dstack([synth_rgb(5, 32, 24), np.full((24, 32), 128, np.uint8)]), "RGBA").save(alpha, format="WEBP", quality=80)
     outs = api.webp_decode([good, good[:60], lossless.getvalue(), alpha.getvalue(), good[:12] + b"JUNK" + good[16:], good])
     assert [isinstance(o, Exception) for o in outs] == [False, True, True, True, True, False]
@@ -71,7 +130,7 @@ def test_emul_compress_and_convert_from_webp(api, reference_samples):
     rows from pixels.  Oracle: libwebp's pixels through oracle/webp_oracle.c, jpeg_oracle.c, png_oracle.c."""
     from oracle import oracle as O
     w0 = open(os.path.join(reference_samples, "w0.webp"), "rb").read()
-    srcs = [w0, webp_of(8, 97, 61, 70, texture=20.0)]
+    srcs = [w0, webp_of(8, 97, 61, 70, texture=20.0), lossless_of(synth_rgb(9, 83, 59, texture=15.0))]   # lossy (VP8) and lossless (VP8L) sources
     for src in srcs:
         rgb = np.ascontiguousarray(libwebp_rgb(src))
         assert api.compress_in_memory(src, params(webp_quality=60)) == O.webp_encode_rgb(rgb, 60)

@@ -22,6 +22,14 @@ def test_synthetic_files_decode_like_libwebp(api):
     E.test_emul_synthetic_files_decode_like_libwebp(api)
 
 
+def test_lossless_files_decode_like_libwebp(api):
+    E.test_emul_lossless_files_decode_like_libwebp(api)
+
+
+def test_damaged_lossless_streams_fail_alone(api):
+    E.test_emul_damaged_lossless_streams_fail_alone(api)
+
+
 def test_damaged_and_unsupported_inputs_fail_alone(api):
     E.test_emul_damaged_and_unsupported_inputs_fail_alone(api)
 

@@ -3,8 +3,8 @@
 # __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
-HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip"
-CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp"
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip"
+CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
     $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
 cat > $O/run.py <<PY
@@ -41,6 +41,8 @@ agree(api.batch_convert(blobs, pkg.default_parameters(jpeg_quality=70), 0), lamb
 agree(api.batch_convert(blobs, pkg.default_parameters(webp_quality=70, width=30), 3), lambda b: _util.oracle_png_to_webp(b, 70, 30, 0))
 agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimize=True, png_optimization_level=1, height=20)), lambda b: _util.oracle_png_resized(b, True, 1, 0, 20))
 agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimization_level=1, png_quality=20)), lambda b: _util.oracle_png_lossy(b, 1, quality=20))
+import test_webp_decode_emul as WD
+WD.test_emul_synthetic_files_decode_like_libwebp(api); WD.test_emul_lossless_files_decode_like_libwebp(api); WD.test_emul_damaged_lossless_streams_fail_alone(api); WD.test_emul_damaged_and_unsupported_inputs_fail_alone(api)
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
