@@ -145,6 +145,50 @@ static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSP
 // WebP inputs (libcaesium: libwebp decodes, then webp::compress / convert_in_memory, compressor.rs:289-305): the device decodes the
 // key frame (cswd_batch), the RGB stays in HBM and goes to the encoder of the target: the WebP encoder at webp.quality (`compress`
 // on a WebP file), the JPEG or the PNG row (conversions).  A size, if given, is applied by the JPEG row's Lanczos branch on the way.
+// keep_metadata on WebP -> WebP (libcaesium's webp::compress: ICC profile and EXIF of the SOURCE read with img-parts and set on the encoded
+// file, which turns it into the extended format): RIFF { VP8X(flags, canvas), ICCP?, VP8, EXIF? }.  XMP is not carried (img-parts' API
+// sets profile and EXIF only).  The chunk walk is the container's: host work, like the JPEG row's marker copy.
+static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
+    auto rd32 = [](const uint8_t *d) { return uint32_t(d[0]) | (uint32_t(d[1]) << 8) | (uint32_t(d[2]) << 16) | (uint32_t(d[3]) << 24); };
+    const uint8_t *d = src.data;
+    const size_t n = src.length;
+    if (n < 20 || !out.data || out.length < 30 || memcmp(out.data + 12, "VP8 ", 4)) return;
+    const uint8_t *icc = nullptr, *exif = nullptr;
+    size_t icc_len = 0, exif_len = 0;
+    for (size_t i = 12; i + 8 <= n;) {
+        const size_t cl = rd32(d + i + 4);
+        if (i + 8 + cl > n) break;
+        if (!memcmp(d + i, "ICCP", 4) && !icc) { icc = d + i + 8; icc_len = cl; }
+        if (!memcmp(d + i, "EXIF", 4) && !exif) { exif = d + i + 8; exif_len = cl; }
+        i += 8 + cl + (cl & 1);
+    }
+    if (!icc && !exif) return;
+    const uint8_t *f = out.data + 20;   // VP8 frame header: tag (3), start code (3), 14-bit width and height
+    const uint32_t w = (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFFu, h = (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFFu;
+    const size_t body = out.length - 12;   // the "VP8 " chunk with its header and padding
+    const size_t total = 12 + 18 + (icc ? 8 + icc_len + (icc_len & 1) : 0) + body + (exif ? 8 + exif_len + (exif_len & 1) : 0);
+    uint8_t *o = static_cast<uint8_t *>(malloc(total));
+    if (!o) return;
+    auto wr32 = [](uint8_t *q, uint32_t v) { q[0] = uint8_t(v); q[1] = uint8_t(v >> 8); q[2] = uint8_t(v >> 16); q[3] = uint8_t(v >> 24); };
+    size_t at = 0;
+    memcpy(o, "RIFF", 4); wr32(o + 4, uint32_t(total - 8)); memcpy(o + 8, "WEBP", 4); at = 12;
+    memcpy(o + at, "VP8X", 4); wr32(o + at + 4, 10);
+    o[at + 8] = uint8_t((icc ? 0x20 : 0) | (exif ? 0x08 : 0)); o[at + 9] = o[at + 10] = o[at + 11] = 0;
+    const uint32_t cw = w - 1, chh = h - 1;
+    o[at + 12] = uint8_t(cw); o[at + 13] = uint8_t(cw >> 8); o[at + 14] = uint8_t(cw >> 16);
+    o[at + 15] = uint8_t(chh); o[at + 16] = uint8_t(chh >> 8); o[at + 17] = uint8_t(chh >> 16);
+    at += 18;
+    auto chunk = [&](const char *id, const uint8_t *pl, size_t len) {
+        memcpy(o + at, id, 4); wr32(o + at + 4, uint32_t(len)); memcpy(o + at + 8, pl, len); at += 8 + len;
+        if (len & 1) o[at++] = 0;
+    };
+    if (icc) chunk("ICCP", icc, icc_len);
+    memcpy(o + at, out.data + 12, body); at += body;
+    if (exif) chunk("EXIF", exif, exif_len);
+    free(out.data);
+    out.data = o; out.length = total;
+}
+
 static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t target, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
     for (size_t g0 = 0, n = 0; g0 < count; g0 += n) {
@@ -186,7 +230,10 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
             if (rc || failed < 0) { for (size_t k = 0; k < px.size(); k++) if (results) results[at[k]] = make_result(rc ? rc : CS_ERR_NO_DEVICE, csh_last_error()); failed_total += int(px.size()); }
             else {
                 failed_total += failed;
-                for (size_t k = 0; k < px.size(); k++) { outputs[at[k]] = out[k]; if (results) results[at[k]] = res[k]; else cs_free_result(&res[k]); }
+                for (size_t k = 0; k < px.size(); k++) {
+                    if (target == CS_TYPE_WEBP && p->keep_metadata && out[k].data) webp_carry_metadata(inputs[at[k]], out[k]);
+                    outputs[at[k]] = out[k]; if (results) results[at[k]] = res[k]; else cs_free_result(&res[k]);
+                }
             }
             csp_batch_destroy(pb); csh_batch_destroy(jb); csh_batch_destroy(rb);
         }

@@ -166,3 +166,28 @@ def test_emul_compress_to_size_on_webp(api):
     qs, want = reference_size_walk(src, target, encode=lambda s, q: O.webp_encode_rgb(rgb, q))
     got = api.compress_to_size_in_memory(src, params(), target)
     assert got == want and len(qs) > 1
+
+
+def test_emul_webp_metadata_carried_over(api, reference_samples):
+    """-e on WebP -> WebP: the source's ICC profile and EXIF ride in an extended-format file (VP8X flags, ICCP in front of the frame, EXIF
+    behind it), the frame itself is the one written without -e; no metadata in the source, or no -e: the simple format"""
+    b = io.BytesIO()
+    icc = bytes(range(256)) * 2 + b"x"     # odd length: chunk padding
+    exif = b"Exif\x00\x00MM\x00*\x00\x00\x00\x08\x00\x00"
+    Image.fromarray(synth_rgb(12, 75, 49, texture=10.0), "RGB").save(b, format="WEBP", quality=70, icc_profile=icc, exif=exif)
+    src = b.getvalue()
+    plain = api.compress_in_memory(src, params(webp_quality=60))
+    kept = api.compress_in_memory(src, params(webp_quality=60, keep_metadata=True))
+    assert plain[12:16] == b"VP8 " and kept[12:16] == b"VP8X" and kept[20] == 0x28
+    assert int.from_bytes(kept[4:8], "little") == len(kept) - 8
+    assert int.from_bytes(kept[24:27], "little") == 74 and int.from_bytes(kept[27:30], "little") == 48
+    im = Image.open(io.BytesIO(kept)); im.load()
+    assert im.info["icc_profile"] == icc and im.info["exif"] == Image.open(io.BytesIO(src)).info["exif"] and len(im.info["exif"]) >= 10
+    assert np.array_equal(np.asarray(im.convert("RGB")), libwebp_rgb(plain))
+    assert plain[12:] in kept   # the VP8 chunk is carried whole
+    w1 = open(os.path.join(reference_samples, "level_1_1/w1.webp"), "rb").read()   # VP8X + EXIF + XMP
+    kept = api.compress_in_memory(w1, params(webp_quality=60, keep_metadata=True))
+    im = Image.open(io.BytesIO(kept)); im.load()
+    assert kept[20] == 0x08 and im.info["exif"] == Image.open(io.BytesIO(w1)).info["exif"] and b"XMP " not in kept
+    w0 = open(os.path.join(reference_samples, "w0.webp"), "rb").read()
+    assert api.compress_in_memory(w0, params(webp_quality=60, keep_metadata=True)) == api.compress_in_memory(w0, params(webp_quality=60))

@@ -40,3 +40,7 @@ def test_compress_and_convert_from_webp(api, reference_samples):
 
 def test_compress_to_size_on_webp(api):
     E.test_emul_compress_to_size_on_webp(api)
+
+
+def test_webp_metadata_carried_over(api, reference_samples):
+    E.test_emul_webp_metadata_carried_over(api, reference_samples)
