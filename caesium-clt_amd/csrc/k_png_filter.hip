@@ -5,6 +5,7 @@
 // 7 Bigrams, 8 BigEnt, 9 Brute) pick per row and gather their stream out of the five.
 #include "png_kernels.h"
 #include "png_lz.h"
+#include "png_wave.h"
 
 namespace csp {
 
@@ -93,18 +94,23 @@ __global__ void __launch_bounds__(256) k_png_colors(const PngImg *imgs, const ui
     const uint32_t bps = im.bps;
     const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
     unsigned long long *tab = keys + uint64_t(image) * CSP_PAL_SLOTS;
+    // Too many colours is the common answer (every photograph): the rows of such an image must learn it at once -- a row that keeps
+    // inserting fills the table, and a full table costs every later key a walk over all of its slots.  So the count is read afresh
+    // (not from a register the compiler kept) on entry, with every new key, and every few probes.
+    auto too_many = [&]() { return coherent_load(&counts[image]) > 256u; };
+    if (too_many()) return;
     uint32_t prev = 0;
     bool have_prev = false;
     for (uint32_t x = threadIdx.x; x < im.width; x += blockDim.x) {
-        if (counts[image] > 256u) return;   // already too many colours (a stale read only costs work)
         const uint32_t key = pixel_key(r + uint64_t(x) * ch * bps, ch, bps);
         if (have_prev && key == prev) continue;
         prev = key; have_prev = true;
         uint32_t h = key_slot(key);
         for (int probe = 0; probe < int(CSP_PAL_SLOTS); probe++, h = (h + 1) & (CSP_PAL_SLOTS - 1)) {
             const unsigned long long seen = atomicCAS(&tab[h], ~0ull, (unsigned long long)key);
-            if (seen == ~0ull) { atomicAdd(&counts[image], 1u); break; }
+            if (seen == ~0ull) { if (atomicAdd(&counts[image], 1u) >= 256u) return; break; }
             if (seen == (unsigned long long)key) break;
+            if ((probe & 7) == 7 && too_many()) return;
         }
     }
 }

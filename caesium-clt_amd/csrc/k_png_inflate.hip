@@ -1,14 +1,18 @@
 // k_png_inflate.hip -- row P1 of SURVEY.md 8a on the device: the IDAT zlib stream back to filtered rows (RFC 1951), then
 // the PNG reconstruction filters back to pixels.  Statement: oracle/png_oracle.c inflate_raw() / cso_png_decode().
 //
-// A deflate stream is one serial chain (every symbol's position depends on all symbols before it), so the parallelism is
-// across the files of the batch: ONE WAVE PER STREAM.  Control flow is wave-uniform; what the 64 lanes add is
-//   * the stream window: 64 words per load, handed to the uniform bit reader by v_readlane (png_wave.h LeReader);
-//   * table construction: every lane decodes its own root-table indices with the canonical (count/first) walk, so the
-//     1024-entry table is filled without a scatter;
-//   * match copies: up to 258 bytes move 64 per step, out of a 32 KiB ring in LDS that holds the most recent output (only a
-//     match further back than the ring -- the last 258 bytes of the window -- reads the flushed copy in HBM);
-//   * the flush itself: whole KiB leave the ring as 64 x 16-byte stores.
+// A deflate stream is one serial chain of prefix codes, so the parallelism of the CODE WALK is across the files of the batch: one
+// wave per stream (k_png_huff).  What makes a stream slow, though, is not the walk but waiting for every match copy before the next
+// symbol; the two are therefore separate kernels:
+//   k_png_huff   walks the codes and nothing else.  Control flow is wave-uniform; the 64 lanes give it the stream window (64 words
+//                per load, handed to the uniform bit reader by v_readlane), the table construction (every lane decodes its own root
+//                entries with the canonical walk: no scatter), and the root-table answers for 64 bit offsets at a time.  Literals go
+//                straight to their final place in the output (their position is known: the walk keeps the byte count); a match becomes
+//                an 8-byte record (position, length, distance) in a list.
+//   k_png_lz77   resolves the matches, 16 KiB of output at a time, in LDS: the bytes of a match whose source lies in front of the piece
+//                are copied from the 48 KiB of history the ring holds; the others get a pointer to their source and the pointers are
+//                doubled (p <- p[p]) until every byte points at a byte that is final -- a run of 258 bytes at distance 1 takes 9 rounds,
+//                not 258 steps -- then gathered.  No step waits for a single copy.
 // Adam7 inputs: the stream holds seven reduced images; each is reconstructed as a job of its own, then k_png_deinterlace
 // gathers the pixels into place (the output is never interlaced).
 // Codes longer than the root width take the bit-serial canonical walk (rare symbols by construction).
@@ -17,14 +21,13 @@
 
 namespace csp {
 
-enum { LROOT = 10, DROOT = 8, RING = 32768, RING_NEAR = RING - 258 };   // the ring covers (almost) the whole deflate window: 40 KB of LDS per stream, four streams per CU
+enum { LROOT = 10, DROOT = 8, LZ_RING = 65536, LZ_PIECE = 16384 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
     uint16_t lsorted[288], dsorted[32], csorted[20];
     uint16_t lroot[1 << LROOT], droot[1 << DROOT];
     uint8_t lens[320];
-    alignas(16) uint8_t ring[RING];
 };
 
 // canonical walk over the low bits of `bits` (LSB first), at most maxlen of them: (sym << 4) | len, or 0
@@ -66,7 +69,8 @@ struct PosReader {
     uint32_t len, wbase;     // wbase: multiple of 32 words; the window is words [wbase, wbase + 64)
     LV<uint32_t> win, nxt;   // nxt: lane l holds word wbase + 64 + (l & 31)
     uint64_t bp;             // current bit
-    uint32_t w0, w1, w2, w3; // the four words from bp's word on (96+ bits in front of bp)
+    uint32_t w0, w1, w2, w3, w4; // the five words from bp's word on (128+ bits in front of bp)
+    uint32_t u0, u1, u2, u3;     // the 128 bits that start AT bp (the same words, shifted once, uniformly)
     __device__ __forceinline__ uint32_t loadw(uint32_t w) const {
         const uint64_t b = uint64_t(w) * 4u;
         if (b + 4 <= len) return *reinterpret_cast<const uint32_t *>(base + b);
@@ -93,7 +97,10 @@ struct PosReader {
             LFOR(l) { win[l] = l < 32 ? up[l] : nxt[l]; nxt[l] = loadw(wbase + 64 + (uint32_t(l) & 31u)); }
         }
         const uint32_t q = uint32_t(bp >> 5);
-        w0 = lane_word(q); w1 = lane_word(q + 1); w2 = lane_word(q + 2); w3 = lane_word(q + 3);
+        w0 = lane_word(q); w1 = lane_word(q + 1); w2 = lane_word(q + 2); w3 = lane_word(q + 3); w4 = lane_word(q + 4);
+        const uint32_t sh = uint32_t(bp & 31u);
+        u0 = uint32_t((uint64_t(w0) | (uint64_t(w1) << 32)) >> sh); u1 = uint32_t((uint64_t(w1) | (uint64_t(w2) << 32)) >> sh);
+        u2 = uint32_t((uint64_t(w2) | (uint64_t(w3) << 32)) >> sh); u3 = uint32_t((uint64_t(w3) | (uint64_t(w4) << 32)) >> sh);
     }
     __device__ __forceinline__ void begin(const uint8_t *p, uint32_t n, uint64_t bit) {
         base = p; len = n; bp = bit; wbase = uint32_t(bit >> 5) & ~31u;
@@ -106,30 +113,35 @@ struct PosReader {
         const uint64_t lo = uint64_t(w0) | (uint64_t(w1) << 32), mid = uint64_t(w1) | (uint64_t(w2) << 32), hi = uint64_t(w2) | (uint64_t(w3) << 32);
         return s < 32 ? uint32_t(lo >> s) : s < 64 ? uint32_t(mid >> (s - 32)) : uint32_t(hi >> (s - 64));
     }
+    // 64 bits starting `lane` bits after bp (lane <= 63): what a whole token needs (15 + 5 + 15 + 13 bits at most).  Which words a lane
+    // takes depends on the lane alone (u0.. start at bp), so this is two-way selects on a lane constant and two shifts
+    __device__ __forceinline__ uint64_t at64(uint32_t lane) const {
+        const bool hi = lane >= 32u;
+        const uint32_t r = lane & 31u;
+        const uint32_t a = hi ? u1 : u0, b = hi ? u2 : u1, c = hi ? u3 : u2;
+        const uint64_t lo = (uint64_t(a) | (uint64_t(b) << 32)) >> r;
+        return r ? lo | (uint64_t(c) << (64u - r)) : lo;
+    }
     __device__ __forceinline__ uint32_t peek(uint32_t off, int n) const { return n ? at(off) & (0xFFFFFFFFu >> (32 - n)) : 0u; }   // n <= 32
     __device__ __forceinline__ uint32_t get(int n) { const uint32_t v = peek(0, n); bp += uint32_t(n); refresh(); return v; }
     __device__ __forceinline__ bool overrun() const { return bp > uint64_t(len) * 8u; }
 };
 
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint32_t *status) {
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status) {
     CSH_SHARED InflateLds S;
     const int image = blockIdx.x;
-    if (image >= nimg || status[image]) return;
+    if (image >= nimg) return;
+    LFOR(l) if (l == 0) nmatch[image] = 0;
+    if (status[image]) return;
     const PngImg im = imgs[image];
     uint8_t *out = raw + im.inflate_off;
+    uint64_t *mlist = matches + im.match_off;
     const uint64_t cap = im.inflate_len;
     PosReader rd;
     rd.begin(idat + im.idat_off, im.idat_len, 16);   // the host checked the two zlib header bytes
-    uint64_t pos = 0, flushed = 0;
+    uint64_t pos = 0;
     uint32_t err = 0;
-    auto flush = [&]() {   // whole KiB that are complete leave the ring
-        CSP_WAVE_SYNC();
-        while (flushed + 1024 <= pos) {
-            LFOR(l) *reinterpret_cast<uint4 *>(out + flushed + uint32_t(l) * 16u) = *reinterpret_cast<const uint4 *>(S.ring + ((uint32_t(flushed) + uint32_t(l) * 16u) & (RING - 1)));
-            flushed += 1024;
-        }
-        CSP_MEM_FENCE();
-    };
+    uint32_t mtotal = 0;   // matches so far: record k of the stream is mlist[k]
     bool last = false;
     while (!last && !err && pos < cap) {
         last = rd.get(1) != 0;
@@ -142,10 +154,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
             if (uint64_t(at) + len > rd.len) { err = CSP_ERR_BAD_PNG; break; }
             for (uint32_t r0 = 0; r0 < len && pos < cap; r0 += 64) {
                 const uint32_t m = len - r0 < 64u ? len - r0 : 64u;
-                LFOR(l) if (uint32_t(l) < m) S.ring[(uint32_t(pos) + uint32_t(l)) & (RING - 1)] = rd.base[at + r0 + uint32_t(l)];
-                CSP_WAVE_SYNC();
+                LFOR(l) if (uint32_t(l) < m && pos + uint32_t(l) < cap) out[pos + uint32_t(l)] = rd.base[at + r0 + uint32_t(l)];
                 pos += m;
-                if ((pos >> 10) != (flushed >> 10)) flush();
             }
             rd.bp += uint64_t(len) * 8u;
             rd.refresh();
@@ -199,102 +209,234 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_inflate(const PngImg *
             r = build_code(S.lens + 288, ndist, S.dcount, S.offs, S.dsorted, S.droot, DROOT);
             if (type == 2 && (r < 0 || (r > 0 && ndist - int(S.dcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }   // the fixed distance code is incomplete by definition
         }
-        // The symbols.  One pass = one window: EVERY lane looks up the two root tables for "a code starting at bit bp + lane"
-        // (two LDS reads for the whole wave), then the uniform side walks from code to code through those answers with
-        // v_readlane -- the LDS round trip is paid once per ~44 bits instead of once per symbol.  Literals collect in a
-        // vector register (one lane each) and reach the ring with one store when a match or the end of the window comes.
+        // The symbols.  One pass = one window of 64 bit offsets: EVERY lane decodes the complete token that would start at bit bp + lane
+        // (literal / end of block / length with its extra bits, distance code and distance extra bits: two LDS look-ups and arithmetic,
+        // all in the vector domain) and so knows where the next token would start.  The only serial work is following those links from
+        // offset 0 -- one v_readlane per token.  The tokens on the chain then place themselves: a prefix sum of their output lengths
+        // gives every literal its byte in the output and every match its record.  A token the root tables do not hold ends the window
+        // and is decoded by the uniform bit-serial walk below.
+        enum { K_LIT = 0, K_MATCH = 1, K_EOB = 2, K_SLOW = 3 };
+        auto lane_of = [&](const LV<uint32_t> &v, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+#ifdef CSH_EMUL
+            return v.v[i];
+#else
+            return uint32_t(__builtin_amdgcn_readlane(int(v.v), int(i)));
+#endif
+        };
+        auto put_match = [&](uint64_t at, uint32_t len, uint32_t dist) __attribute__((always_inline)) {   // uniform: one record from the slow path
+            LFOR(l) if (l == 0) mlist[mtotal] = (at & 0xFFFFFFFFull) | (uint64_t(len) << 32) | (uint64_t(dist) << 48);
+            mtotal++;
+        };
+        auto slow_symbol = [&](bool &block_done) __attribute__((always_inline)) {   // one symbol at bp, by the canonical walk over up to 15 bits
+            const uint32_t e = uni(canon_walk(rd.peek(0, 15), 15, S.lcount, S.lsorted));
+            if (!e) { err = CSP_ERR_BAD_PNG; return; }
+            uint32_t off = e & 15u;
+            const uint32_t sym = e >> 4;
+            if (sym < 256) { LFOR(l) if (l == 0 && pos < cap) out[pos] = uint8_t(sym); pos++; }
+            else if (sym == 256) block_done = true;
+            else {
+                const uint32_t li = sym - 257;
+                if (li >= 29) { err = CSP_ERR_BAD_PNG; return; }
+                uint32_t len;
+                if (li < 8) len = 3 + li; else if (li == 28) len = 258; else { const int eb = int(li >> 2) - 1; len = ((4u | (li & 3u)) << eb) + 3u + rd.peek(off, eb); off += uint32_t(eb); }
+                const uint32_t d = uni(canon_walk(rd.peek(off, 15), 15, S.dcount, S.dsorted));
+                if (!d) { err = CSP_ERR_BAD_PNG; return; }
+                off += d & 15u;
+                const uint32_t ds = d >> 4;
+                if (ds >= 30) { err = CSP_ERR_BAD_PNG; return; }
+                uint32_t dist;
+                if (ds < 4) dist = ds + 1; else { const int eb = int(ds >> 1) - 1; dist = ((2u | (ds & 1u)) << eb) + 1u + rd.peek(off, eb); off += uint32_t(eb); }
+                if (uint64_t(dist) > pos || rd.bp + off > uint64_t(rd.len) * 8u) { err = CSP_ERR_BAD_PNG; return; }
+                put_match(pos, len, dist);
+                pos += len;
+            }
+            rd.bp += off;
+            rd.refresh();
+        };
         bool block_done = false;
         while (!block_done && !err && pos < cap) {
             if (rd.overrun()) { err = CSP_ERR_BAD_PNG; break; }
-            LV<uint32_t> E, D, pend;
-            LFOR(l) { const uint32_t b = rd.at(uint32_t(l)); E[l] = S.lroot[b & ((1u << LROOT) - 1u)]; D[l] = S.droot[b & ((1u << DROOT) - 1u)]; pend[l] = 0; }
-            uint32_t off = 0;
-            uint64_t lits = 0;   // bit o set: a literal whose code starts at window offset o waits in lane o of `pend`
-            auto lane_of = [&](const LV<uint32_t> &v, uint32_t i) -> uint32_t {
-#ifdef CSH_EMUL
-                return v.v[i];
-#else
-                return uint32_t(__builtin_amdgcn_readlane(int(v.v), int(i)));
-#endif
-            };
-            auto spill = [&]() {   // pending literals -> ring, in offset order
-                if (!lits) return;
-                LFOR(l) if ((lits >> l) & 1) S.ring[(uint32_t(pos) + uint32_t(__popcll(lits & lanes_below(l)))) & (RING - 1)] = uint8_t(pend[l]);
-                pos += uint32_t(__popcll(lits)); lits = 0;
-                if ((pos >> 10) != (flushed >> 10)) flush();
-            };
-            // close to the end of the image a window is one symbol long, so that nothing is decoded past the last byte
-            uint32_t wlimit = cap - pos < 512 ? 1u : 44u;
-            while (off < wlimit) {
-                uint32_t e = lane_of(E, off);
-                // a run of literals out of the root table: the common case, a loop of its own with nothing else in it
-                while ((e - 1u) < 0x7FFFu) {
-#ifdef CSH_EMUL
-                    pend.v[off] = e >> 4;
-#else
-                    pend.v = (threadIdx.x & 63u) == off ? e >> 4 : pend.v;
-#endif
-                    lits |= 1ull << off; off += e & 15u;
-                    if (off >= wlimit) break;
-                    e = lane_of(E, off);
-                }
-                if (off >= wlimit) break;
-                if (!e) { e = uni(canon_walk(rd.peek(off, 15), 15, S.lcount, S.lsorted)); if (!e) { err = CSP_ERR_BAD_PNG; break; } }
+            LV<uint32_t> NX, OL, VAL;   // next offset | kind << 8; bytes the token produces; the literal, or length | distance << 16
+            LFOR(l) {
+                const uint64_t b = rd.at64(uint32_t(l));
+                const uint32_t e = S.lroot[uint32_t(b) & ((1u << LROOT) - 1u)];
                 const uint32_t sym = (e >> 4) & 0x1FFu;
-                if (sym < 256) {
-#ifdef CSH_EMUL
-                    pend.v[off] = sym;
-#else
-                    pend.v = (threadIdx.x & 63u) == off ? sym : pend.v;
-#endif
-                    lits |= 1ull << off; off += e & 15u;
-                    continue;
-                }
-                off += e & 15u;
-                spill();
-                if (sym == 256) { block_done = true; break; }
-                const uint32_t li = sym - 257;
-                if (li >= 29) { err = CSP_ERR_BAD_PNG; break; }
-                uint32_t len;
-                if (li < 8) len = 3 + li; else if (li == 28) len = 258; else { const int eb = int(li >> 2) - 1; len = ((4u | (li & 3u)) << eb) + 3u + rd.peek(off, eb); off += uint32_t(eb); }
-                uint32_t d = lane_of(D, off);   // off <= 43 + 15 + 5
-                if (!d) { d = uni(canon_walk(rd.peek(off, 15), 15, S.dcount, S.dsorted)); if (!d) { err = CSP_ERR_BAD_PNG; break; } }
-                off += d & 15u;
-                const uint32_t ds = d >> 4;
-                if (ds >= 30) { err = CSP_ERR_BAD_PNG; break; }
-                uint32_t dist;
-                if (ds < 4) dist = ds + 1; else { const int eb = int(ds >> 1) - 1; dist = ((2u | (ds & 1u)) << eb) + 1u + rd.peek(off, eb); off += uint32_t(eb); }
-                if (uint64_t(dist) > pos || rd.bp + off > uint64_t(rd.len) * 8u) { err = CSP_ERR_BAD_PNG; break; }
-                // byte pos+i is byte pos-dist+(i mod dist): every source lies in front of pos, so all lanes copy at once
-                CSP_WAVE_SYNC();
-                for (uint32_t r0 = 0; r0 < len; r0 += 64) {
-                    LFOR(l) {
-                        const uint32_t i = r0 + uint32_t(l);
-                        if (i < len) {
-                            const uint32_t back = dist - (dist >= len ? i : i % dist);   // source = pos - back
-                            const uint8_t b = dist <= RING_NEAR ? S.ring[(uint32_t(pos) - back) & (RING - 1)] : coherent_load(out + (pos - back));
-                            S.ring[(uint32_t(pos) + i) & (RING - 1)] = b;
+                uint32_t kind = K_LIT, tl = e & 15u, ol = 1, val = sym;
+                if (!e) kind = K_SLOW;
+                else if (sym == 256) { kind = K_EOB; ol = 0; }
+                else if (sym > 256) {
+                    const uint32_t li = sym - 257;
+                    kind = K_SLOW;   // until the whole token is known (an invalid one is reported by the slow path)
+                    if (li < 29) {
+                        const uint32_t eb = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
+                        const uint32_t len = (li < 8 ? 3u + li : li == 28 ? 258u : ((4u | (li & 3u)) << eb) + 3u) + (uint32_t(b >> tl) & ((1u << eb) - 1u));
+                        tl += eb;
+                        const uint32_t d = S.droot[uint32_t(b >> tl) & ((1u << DROOT) - 1u)];
+                        const uint32_t ds = (d >> 4) & 0x7FFu;
+                        if (d && ds < 30) {
+                            const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
+                            tl += d & 15u;
+                            const uint32_t dist = (ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(b >> tl) & ((1u << deb) - 1u));
+                            tl += deb;
+                            kind = K_MATCH; ol = len; val = len | (dist << 16);
                         }
                     }
                 }
-                CSP_WAVE_SYNC();
-                pos += len;
-                if ((pos >> 10) != (flushed >> 10)) flush();
-                if (pos >= cap) break;
-                if (cap - pos < 512) wlimit = 1;
+                // the link the chase follows: the next token's offset; a token that ends the chase (end of block, slow path) carries bit 7
+                // or 8, so "offset < 64" is the one test of the loop
+                NX[l] = kind == K_SLOW ? (0x100u | uint32_t(l)) : kind == K_EOB ? (0x80u | (uint32_t(l) + tl)) : (uint32_t(l) + tl) | (kind << 16);
+                OL[l] = ol; VAL[l] = val;
             }
-            if (err) break;
-            spill();
-            rd.bp += off;
+            uint64_t real = 0;
+            uint32_t s0 = 0, stop = 0;   // stop: 0 the window is used up, 1 end of block, 2 a token for the slow path at s0, 3 the image is complete
+            {
+                uint32_t v;
+                do { v = lane_of(NX, s0) & 0xFFFFu; real |= 1ull << s0; if (v >= 64u) break; s0 = v; } while (true);
+                if (v & 0x100u) { stop = 2; real &= ~(1ull << s0); }      // s0 stays at the slow token
+                else if (v & 0x80u) { stop = 1; s0 = v & 0x7Fu; }        // behind the end-of-block code (< 64 + 15)
+                else s0 = v;
+            }
+            LV<uint32_t> mine;
+            LFOR(l) mine[l] = ((real >> l) & 1) ? OL[l] : 0u;
+            uint32_t total = 0;
+            const LV<uint32_t> before = lscan(mine, total);
+            // nothing is decoded past the image's last byte: the first token that would start there ends the stream
+            const uint64_t beyond = lballot([&](int l) { return ((real >> l) & 1) && pos + before[l] >= cap; });
+            if (beyond) { const int fb = __builtin_ctzll(beyond); real &= lanes_below(fb); total = lane_of(before, uint32_t(fb)); stop = 3; }
+            const uint64_t mm = lballot([&](int l) { return ((real >> l) & 1) && (NX[l] >> 16) == uint32_t(K_MATCH); });
+            if (lballot([&](int l) { return ((mm >> l) & 1) && (uint64_t(VAL[l] >> 16) > pos + before[l] || rd.bp + (NX[l] & 0x7Fu) > uint64_t(rd.len) * 8u); })) { err = CSP_ERR_BAD_PNG; break; }
+            LFOR(l) if ((real >> l) & 1) {
+                const uint64_t at = pos + before[l];
+                if ((mm >> l) & 1) mlist[mtotal + uint32_t(__popcll(mm & lanes_below(l)))] = (at & 0xFFFFFFFFull) | (uint64_t(VAL[l] & 0xFFFFu) << 32) | (uint64_t(VAL[l] >> 16) << 48);
+                else if (OL[l]) out[at] = uint8_t(VAL[l]);
+            }
+            mtotal += uint32_t(__popcll(mm));
+            pos += total;
+            if (stop == 3) break;
+            rd.bp += s0;
             rd.refresh();
+            if (stop == 1) block_done = true;
+            else if (stop == 2) slow_symbol(block_done);
         }
     }
     if (!err && rd.overrun()) err = CSP_ERR_BAD_PNG;
     if (!err && pos < cap) err = CSP_ERR_BAD_PNG;   // libpng: "not enough image data"
     if (err) { LFOR(l) if (l == 0) status[image] = err; return; }
-    // the tail: bytes [flushed, cap) are still only in the ring
-    CSP_WAVE_SYNC();
-    LFOR(l) for (uint64_t i = flushed + uint32_t(l); i < cap; i += 64) out[i] = S.ring[uint32_t(i) & (RING - 1)];
+    LFOR(l) if (l == 0) nmatch[image] = mtotal;
+}
+
+// ---- the matches of one stream, resolved piece by piece (header of this file).  One wave per stream.
+struct Lz77Lds {
+    alignas(16) uint8_t ring[LZ_RING];      // byte at absolute position p: ring[p & 65535]
+    alignas(16) uint16_t ptr[LZ_PIECE];     // for the bytes of the piece: ring index of a byte this one equals (itself: final)
+};
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *imgs, int nimg, uint8_t *raw, const uint64_t *matches, const uint32_t *nmatch, const uint32_t *status) {
+    CSH_SHARED Lz77Lds S;
+    const int image = blockIdx.x;
+    if (image >= nimg || status[image]) return;
+    const PngImg im = imgs[image];
+    uint8_t *out = raw + im.inflate_off;
+    const uint64_t *mlist = matches + im.match_off;
+    const uint64_t cap = im.inflate_len;
+    const uint32_t nm = nmatch[image];
+    uint32_t mi = 0;   // first match that may still have bytes at or behind the piece's start
+    for (uint64_t c0 = 0; c0 < cap; c0 += LZ_PIECE) {
+        const uint64_t c1 = c0 + LZ_PIECE < cap ? c0 + LZ_PIECE : cap;
+        const uint32_t n = uint32_t(c1 - c0);
+        // the piece as k_png_huff left it (literals in place, match bytes undefined), every byte its own source
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+            LFOR(l) {
+                const uint32_t i = i0 + uint32_t(l) * 16u;
+                if (i < n) {
+                    uint4 v;
+                    if (i + 16 <= n) v = *reinterpret_cast<const uint4 *>(out + c0 + i);
+                    else { uint8_t t[16]; for (int k = 0; k < 16; k++) t[k] = i + uint32_t(k) < n ? out[c0 + i + uint32_t(k)] : uint8_t(0); v = *reinterpret_cast<const uint4 *>(t); }
+                    *reinterpret_cast<uint4 *>(S.ring + ((uint32_t(c0) + i) & (LZ_RING - 1))) = v;
+                }
+            }
+        }
+        for (uint32_t i0 = 0; i0 < LZ_PIECE; i0 += 256) {
+            LFOR(l) {
+                const uint32_t i = i0 + uint32_t(l) * 4u, r = (uint32_t(c0) + i) & (LZ_RING - 1);
+                uint2 v; v.x = r | ((r + 1) << 16); v.y = (r + 2) | ((r + 3) << 16);
+                *reinterpret_cast<uint2 *>(&S.ptr[i]) = v;
+            }
+        }
+        CSP_WAVE_SYNC();
+        // the matches that reach into the piece, 64 at a time.  A byte whose source lies in front of the piece takes its value now (that
+        // part of the ring is final); one whose source is in the piece points at it.
+        for (bool more = mi < nm; more;) {
+            LV<uint32_t> done;
+            LFOR(l) {
+                done[l] = 0;
+                const uint32_t k = mi + uint32_t(l);
+                if (k < nm) {
+                    const uint64_t rec = mlist[k];
+                    const uint64_t mpos = rec & 0xFFFFFFFFull;   // streams are shorter than 4 GiB (plan: at most 2^28 pixels of at most 8 bytes)
+                    const uint32_t len = uint32_t(rec >> 32) & 0xFFFFu, dist = uint32_t(rec >> 48);
+                    if (mpos < c1) {
+                        const uint64_t e = mpos + len < c1 ? mpos + len : c1;
+                        for (uint64_t p = mpos > c0 ? mpos : c0; p < e; p++) {
+                            const uint64_t src = p - dist;
+                            if (src < c0) S.ring[uint32_t(p) & (LZ_RING - 1)] = S.ring[uint32_t(src) & (LZ_RING - 1)];
+                            else S.ptr[uint32_t(p - c0)] = uint16_t(uint32_t(src) & (LZ_RING - 1));
+                        }
+                        done[l] = mpos + len <= c1 ? 1u : 0u;
+                    }
+                }
+            }
+            // records are in stream order: the finished ones are a prefix of the 64; stop at the first that goes on into the next piece
+            const uint64_t fin = lballot([&](int l) { return done[l] != 0u; });
+            const uint32_t nfin = fin == ~0ull ? 64u : uint32_t(__builtin_ctzll(~fin));
+            mi += nfin;
+            more = nfin == 64u && mi < nm;
+        }
+        CSP_WAVE_SYNC();
+        // pointer doubling, four bytes per lane and step: p <- ptr[p].  A final byte points at itself, so the step needs no test; the
+        // piece starts on a multiple of its size, so a ring index's low 14 bits are the byte's index in the piece.  Entries behind the
+        // stream's last byte point at themselves.
+        for (int round = 0; round < 15; round++) {
+            bool changed = false;
+            for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+                LV<uint32_t> moved;
+                LFOR(l) {
+                    moved[l] = 0;
+                    const uint32_t i = i0 + uint32_t(l) * 4u;
+                    if (i < n) {
+                        const uint2 v = *reinterpret_cast<const uint2 *>(&S.ptr[i]);
+                        uint2 w;
+                        w.x = uint32_t(S.ptr[v.x & (LZ_PIECE - 1)]) | (uint32_t(S.ptr[(v.x >> 16) & (LZ_PIECE - 1)]) << 16);
+                        w.y = uint32_t(S.ptr[v.y & (LZ_PIECE - 1)]) | (uint32_t(S.ptr[(v.y >> 16) & (LZ_PIECE - 1)]) << 16);
+                        if (w.x != v.x || w.y != v.y) { *reinterpret_cast<uint2 *>(&S.ptr[i]) = w; moved[l] = 1; }
+                    }
+                }
+                if (lballot([&](int l) { return moved[l] != 0u; })) changed = true;
+            }
+            CSP_WAVE_SYNC();
+            if (!changed) break;
+        }
+        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+            LFOR(l) {
+                const uint32_t i = i0 + uint32_t(l) * 4u;
+                if (i < n) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(&S.ptr[i]);
+                    const uint32_t bytes = uint32_t(S.ring[v.x & 0xFFFFu]) | (uint32_t(S.ring[v.x >> 16]) << 8) | (uint32_t(S.ring[v.y & 0xFFFFu]) << 16) | (uint32_t(S.ring[v.y >> 16]) << 24);
+                    *reinterpret_cast<uint32_t *>(S.ring + ((uint32_t(c0) + i) & (LZ_RING - 1))) = bytes;
+                }
+            }
+        }
+        CSP_WAVE_SYNC();
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+            LFOR(l) {
+                const uint32_t i = i0 + uint32_t(l) * 16u;
+                if (i < n) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(S.ring + ((uint32_t(c0) + i) & (LZ_RING - 1)));
+                    if (i + 16 <= n) *reinterpret_cast<uint4 *>(out + c0 + i) = v;
+                    else { const uint8_t *t = reinterpret_cast<const uint8_t *>(&v); for (uint32_t k = 0; i + k < n; k++) out[c0 + i + k] = t[k]; }
+                }
+            }
+        }
+    }
 }
 
 // ---- reconstruction filters: pixel (i, y) needs (i-1, y), (i, y-1), (i-1, y-1) -> an anti-diagonal front.  One wave per
@@ -358,8 +500,10 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
     if (bad) LFOR(l) if (l == 0) status[image] = CSP_ERR_BAD_PNG;
 }
 
-void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint32_t *status) {
-    if (nimg) CSH_LAUNCH(k_png_inflate, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, idat, raw, status);
+void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status) {
+    if (!nimg) return;
+    CSH_LAUNCH(k_png_huff, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, idat, raw, matches, nmatch, status);
+    CSH_LAUNCH(k_png_lz77, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, raw, matches, nmatch, status);
 }
 void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint8_t *work, uint32_t *status) {
     if (njobs) CSH_LAUNCH(k_png_unfilter, dim3(njobs), dim3(CSP_WAVE_THREADS), st, jobs, njobs, work, status);

@@ -186,7 +186,7 @@ struct csp_batch {
     DevBuf<QBin> d_qlist;
     DevBuf<PngAdam7> d_adam7;
     DevBuf<uint32_t> d_flags;
-    DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_file_len, d_adler, d_crc;
+    DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_nmatch, d_file_len, d_adler, d_crc;
     DevBuf<uint64_t> d_scores, d_trial_bytes;
     DevBuf<int32_t> d_winner;
     DevBuf<PngChunk> d_chunks;
@@ -409,7 +409,8 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
             }
         }
         im.stream_stride = align_up(im.raw_len + 64, 256);
-        im.stream_off = stream_bytes; stream_bytes += im.stream_stride * size_t(nslots);
+        im.stream_off = stream_bytes; im.match_off = stream_bytes / 8;   // a match is at least three bytes long
+        stream_bytes += std::max<uint64_t>(im.stream_stride * uint64_t(nslots), align_up((im.inflate_len / 3 + 128) * 8, 256));
         im.row_base = b->total_rows; b->total_rows += it.height;
         im.nchunks = uint32_t((im.raw_len + CSP_CHUNK - 1) / CSP_CHUNK);
         im.chunk_base = uint32_t(nchunk_recs); nchunk_recs += uint64_t(im.nchunks) * nslots;
@@ -467,7 +468,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_work.alloc(work_bytes + 256) || b->d_passes.upload(b->passes, st) || b->d_adam7.upload(b->adam7, st) || b->d_streams.alloc(stream_bytes + 256) ||
         b->d_out.alloc(out_bytes + 256) || b->d_choice.alloc(size_t(5) * b->total_rows + 1) || b->d_status.alloc(size_t(nimg) + 1) || b->d_file_len.alloc(size_t(nimg) + 1) ||
         b->d_adler.alloc(2 * size_t(b->total_chunks) + 2) || b->d_crc.alloc(size_t(nimg) * b->max_pieces + 1) || b->d_scores.alloc(size_t(b->total_rows) * 25 + 1) ||
-        b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
+        b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_nmatch.alloc(size_t(nimg) + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
         return CS_ERR_NO_DEVICE;
     if (to_webp && (b->d_rgbjobs.upload(b->rgbjobs, st) || b->d_plte.upload(b->plte, st) || b->d_rgb.alloc(b->rgb_bytes + 256) || b->d_wwork.alloc(b->wwork_bytes + 64) ||
                     b->d_wlevels.alloc(b->wlevels + 64) || b->d_wstats.alloc(size_t(nimg) * 2112 + 8) || b->d_wprobs.alloc(size_t(nimg) * 1056 + 8) || b->d_wupdate.alloc(size_t(nimg) * 1056 + 8) ||
@@ -720,7 +721,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     for (int a = 0; a < b->plan.nadaptive; a++) if (b->plan.adaptive_strategy[a] != 9) need_scores = true;
     int k = 0;
     auto mark = [&]() { (void)hipEventRecord(b->ev[k++], st); };
-    mark(); if (!b->reduced && !b->from_pixels) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, b->d_status.p);
+    mark(); if (!b->reduced && !b->from_pixels) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, reinterpret_cast<uint64_t *>(b->d_streams.p), b->d_nmatch.p, b->d_status.p);
     mark(); if (!b->reduced && !b->from_pixels) {
         launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), b->d_work.p, b->d_status.p);
         launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);

@@ -32,6 +32,7 @@ struct PngImg {
     uint64_t pix_off;         // unfiltered rows, height * rowbytes
     uint64_t stream_off;      // stream slot s of this image: stream_off + s * stream_stride
     uint64_t stream_stride;
+    uint64_t match_off;       // k_png_huff's match records of this image (8-byte units, in the stream pool: the slots are free until the first trial)
     uint32_t row_base;        // first row of the image in the per-row arrays
     uint32_t nchunks;         // ceil(raw_len / CSP_CHUNK)
     uint32_t chunk_base;      // chunk record of (slot s, chunk c): chunk_base + s * chunk_stride + c

@@ -63,11 +63,15 @@ __device__ __forceinline__ static LV<uint32_t> lscan(const LV<uint32_t> &x, uint
     for (int j = 0; j < 64; j++) { r.v[j] = s; s += x.v[j]; }
     sum = s;
 #else
-    const int lane = int(threadIdx.x & 63u);
+    // inclusive scan on the VALU's cross-lane path (row shifts, then the two row broadcasts): no LDS round trips
     uint32_t v = x.v;
-    CSH_UNROLL
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = uint32_t(__shfl_up(int(v), o, 64)); if (lane >= o) v += t; }
-    sum = uint32_t(__shfl(int(v), 63, 64));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));
+    v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));
+    sum = uint32_t(__builtin_amdgcn_readlane(int(v), 63));   // callers run it with all 64 lanes active
     r.v = v - x.v;
 #endif
     return r;
