@@ -222,6 +222,14 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
                 if (rc == 0) rc = csp_batch_create_pixels(src.data(), src.size(), p, device, &pb);
                 if (rc == 0) rc = csp_batch_run(pb, nullptr);
                 if (rc == 0) failed = csp_batch_fetch(pb, out.data(), res.data());
+            } else if (target == CS_TYPE_WEBP && p->webp_lossless) {   // webp.lossless: the VP8L coder over the (resized) pixels
+                std::vector<csp_pixels> src = px;
+                if (p->width || p->height) {
+                    rc = csh_batch_create_from_pixels_rgb(px.data(), px.size(), p, device, &rb);
+                    if (rc == 0) rc = csh_batch_run(rb, nullptr);
+                    for (size_t k = 0; k < px.size() && rc == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) rc = CS_ERR_NO_DEVICE; }
+                }
+                if (rc == 0) failed = csl_encode_pixels(src.data(), src.size(), device, out.data(), res.data());
             } else {
                 rc = target == CS_TYPE_WEBP ? csh_batch_create_webp_from_pixels(px.data(), px.size(), p, device, &jb) : csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
                 if (rc == 0) rc = csh_batch_run(jb, nullptr);
@@ -257,11 +265,7 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
         std::vector<CByteArray> in(idx.size()), out(idx.size());
         std::vector<CCSResult> res(idx.size());
         for (size_t k = 0; k < idx.size(); k++) { in[k] = inputs[idx[k]]; res[k] = make_result(0, nullptr); out[k].data = nullptr; out[k].length = 0; }
-        if (kind == 2 && p->webp_lossless) {
-            for (size_t k = 0; k < idx.size(); k++) res[k] = make_result(CS_ERR_UNSUPPORTED, "lossless WebP has no device path in this build");
-            failed += int(idx.size());
-        } else
-            failed += kind == 1 ? png_batch_compress(in.data(), in.size(), p, device, out.data(), res.data())
+        failed += kind == 1 ? png_batch_compress(in.data(), in.size(), p, device, out.data(), res.data())
                     : kind == 2 ? webp_inputs(in.data(), in.size(), p, CS_TYPE_WEBP, device, out.data(), res.data())
                                 : jpeg_batch_compress(in.data(), in.size(), p, device, out.data(), res.data());
         for (size_t k = 0; k < idx.size(); k++) { outputs[idx[k]] = out[k]; if (results) results[idx[k]] = res[k]; else cs_free_result(&res[k]); }
@@ -452,7 +456,7 @@ static uint32_t rd_be32(const uint8_t *d) { return (uint32_t(d[0]) << 24) | (uin
 
 // JPEG -> PNG: the JPEG path's decode and resize leave the pixels in device memory, the PNG coder takes them from there (lossless under
 // png.optimize, quantising otherwise -- what png::compress does to the intermediate file libcaesium makes)
-static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results, bool lossless_webp = false) {
     int failed_total = 0;
     for (size_t g0 = 0, n = 0; g0 < count; g0 += n) {
         // the PNG coder keeps about 14 bytes per sample in flight: groups of at most 512 files and 400 MB of JPEG (some 5 GB of pixels)
@@ -470,7 +474,12 @@ static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParamete
             if (code) { results[g0 + k] = make_result(code, msg); failed_total++; } else { px.push_back(s); at.push_back(g0 + k); }
         }
         csp_batch *pb = nullptr;
-        if (rc == 0 && !px.empty()) {
+        if (rc == 0 && !px.empty() && lossless_webp) {   // the same decoded (and resized) pixels into the VP8L coder
+            std::vector<CByteArray> out(px.size());
+            std::vector<CCSResult> res(px.size());
+            failed_total += csl_encode_pixels(px.data(), px.size(), device, out.data(), res.data());
+            for (size_t k = 0; k < px.size(); k++) { outputs[at[k]] = out[k]; results[at[k]] = res[k]; }
+        } else if (rc == 0 && !px.empty()) {
             rc = csp_batch_create_pixels(px.data(), px.size(), p, device, &pb);
             if (rc == 0) rc = csp_batch_run(pb, nullptr);
             if (rc == 0) {
@@ -498,7 +507,7 @@ static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParamete
 // the same encoder), JPEG -> PNG and PNG -> JPEG (csp_png_to_jpeg) run on the device; every other pair of formats has no device path
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
-    std::vector<size_t> ok, okpng, topng, tojpeg, fromwebp;
+    std::vector<size_t> ok, okpng, topng, tojpeg, fromwebp, tolossless;
     for (size_t i = 0; i < count; i++) {
         outputs[i].data = nullptr; outputs[i].length = 0;
         const int src = sniff(inputs[i].data, inputs[i].length);
@@ -508,8 +517,9 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         else if (src == CS_TYPE_JPEG && format == CS_TYPE_PNG) { topng.push_back(i); continue; }
         else if (src == CS_TYPE_PNG && format == CS_TYPE_JPEG) { tojpeg.push_back(i); continue; }
         else if (src == CS_TYPE_WEBP && (format == CS_TYPE_JPEG || format == CS_TYPE_PNG)) { fromwebp.push_back(i); continue; }
-        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG / PNG -> WebP, JPEG <-> PNG, lossy WebP -> JPEG / PNG)"; }
-        else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "lossless WebP has no device path in this build"; }
+        else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG / PNG -> WebP, JPEG <-> PNG, WebP -> JPEG / PNG)"; }
+        else if (p->webp_lossless && src == CS_TYPE_JPEG) { tolossless.push_back(i); continue; }
+        else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "PNG -> lossless WebP has no device path in this build"; }
         if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
     std::vector<CByteArray> ok_in(ok.size());
@@ -536,6 +546,14 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         for (size_t k = 0; k < n; k++) { in[k] = inputs[fromwebp[k]]; res[k] = make_result(0, nullptr); }
         failed_total += webp_inputs(in.data(), n, p, format, device, out.data(), res.data());
         for (size_t k = 0; k < n; k++) { outputs[fromwebp[k]] = out[k]; if (results) results[fromwebp[k]] = res[k]; else cs_free_result(&res[k]); }
+    }
+    if (!tolossless.empty()) {
+        const size_t n = tolossless.size();
+        std::vector<CByteArray> in(n), out(n);
+        std::vector<CCSResult> res(n);
+        for (size_t k = 0; k < n; k++) { in[k] = inputs[tolossless[k]]; res[k] = make_result(0, nullptr); }
+        failed_total += jpeg_to_png(in.data(), n, p, device, out.data(), res.data(), true);
+        for (size_t k = 0; k < n; k++) { outputs[tolossless[k]] = out[k]; if (results) results[tolossless[k]] = res[k]; else cs_free_result(&res[k]); }
     }
     if (!topng.empty()) {
         const size_t n = topng.size();

@@ -11,6 +11,7 @@
 // Only sizes decide the winner, so the losing trials are never packed.
 #include "png_kernels.h"
 #include "png_lz.h"
+#include "png_codes.h"
 
 namespace csp {
 
@@ -64,62 +65,6 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_hist(DeflateCtx c) {
 }
 
 // ------------------------------------------------------------------------------------------------ codes
-// Huffman by repeated merge of the two least frequent (ties: the larger index first), limited by the bit-count adjustment
-// of T.81 K.2; at least two symbols are coded (zlib's rule).  One lane does one code: the arrays live in scratch.
-__device__ static void code_lengths(const uint32_t *freq_in, int n, int limit, uint8_t *len_out) {
-    uint32_t freq[288];
-    int16_t codesize[288], others[288], idx[288];
-    int used = 0, m = 0;
-    for (int i = 0; i < n; i++) used += freq_in[i] != 0;
-    int forced = 2 - used;   // zero-frequency symbols that get a code anyway, lowest first
-    for (int i = 0; i < n; i++) {
-        uint32_t f = freq_in[i];
-        if (!f && forced > 0) { f = 1; forced--; }
-        len_out[i] = 0;
-        if (f) { freq[m] = f; idx[m] = int16_t(i); codesize[m] = 0; others[m] = -1; m++; }
-    }
-    for (;;) {
-        int c1 = -1, c2 = -1;
-        uint64_t v = ~0ull;
-        for (int i = 0; i < m; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
-        v = ~0ull;
-        for (int i = 0; i < m; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
-        if (c2 < 0) break;
-        freq[c1] += freq[c2]; freq[c2] = 0;
-        codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
-        others[c1] = int16_t(c2);
-        codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
-    }
-    int bits[64];
-    for (int i = 0; i < 64; i++) bits[i] = 0;
-    for (int i = 0; i < m; i++) bits[codesize[i] > 63 ? 63 : codesize[i]]++;
-    for (int i = 63; i > limit; i--)
-        while (bits[i] > 0) {
-            int j = i - 2; while (bits[j] == 0) j--;
-            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
-        }
-    int l = 1;
-    for (int cs = 1; cs < 64; cs++)
-        for (int i = 0; i < m; i++)
-            if ((codesize[i] > 63 ? 63 : codesize[i]) == cs) { while (bits[l] == 0) l++; bits[l]--; len_out[idx[i]] = uint8_t(l); }
-}
-__device__ static void canonical(const uint8_t *len, int n, uint16_t *code) {   // bit-reversed, as deflate packs Huffman codes
-    int count[16], next[16];
-    for (int i = 0; i < 16; i++) count[i] = 0;
-    for (int i = 0; i < n; i++) count[len[i]]++;
-    count[0] = 0;
-    int cd = 0;
-    next[0] = 0;
-    for (int l = 1; l < 16; l++) { cd = (cd + count[l - 1]) << 1; next[l] = cd; }
-    for (int i = 0; i < n; i++) {
-        code[i] = 0;
-        if (!len[i]) continue;
-        const int v = next[len[i]]++;
-        int r = 0;
-        for (int b = 0; b < len[i]; b++) r |= ((v >> b) & 1) << (len[i] - 1 - b);
-        code[i] = uint16_t(r);
-    }
-}
 __global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c) {
     const uint32_t bc = blockIdx.x * blockDim.x + threadIdx.x, trial = blockIdx.y;
     if (bc >= c.total_chunks) return;
@@ -193,46 +138,6 @@ __global__ void __launch_bounds__(64) k_png_choose(DeflateCtx c) {
 // ------------------------------------------------------------------------------------------------ emit
 // bits are OR-ed into a window of LDS words; complete words leave for HBM after every tile
 struct EmitLds { LzLds lz; uint32_t code[CSP_NSYM]; uint32_t win[160]; };
-struct BitOut {
-    uint32_t *win;       // window: word 0 = output word `wbase`
-    uint8_t *out;        // chunk's first byte
-    uint64_t bitpos;     // bits written so far
-    uint32_t wbase;
-    // every lane appends nbits[l] (<= 48) bits of val[l], lane order
-    __device__ void put(const LV<uint64_t> &val, const LV<uint32_t> &nbits) {
-        uint32_t total;
-        const LV<uint32_t> off = lscan(nbits, total);
-        if (!total) return;
-        LFOR(l) if (nbits[l]) {
-            const uint64_t at = bitpos + off[l] - uint64_t(wbase) * 32u;
-            const uint32_t w = uint32_t(at >> 5), sh = uint32_t(at & 31u);
-            const uint64_t v = val[l] & ((1ull << nbits[l]) - 1ull);
-            atomicOr(&win[w], uint32_t(v << sh));
-            if (sh + nbits[l] > 32) atomicOr(&win[w + 1], uint32_t(v >> (32 - sh)));
-            if (sh + nbits[l] > 64) atomicOr(&win[w + 2], uint32_t(v >> (64 - sh)));
-        }
-        bitpos += total;
-        CSP_WAVE_SYNC();
-        const uint32_t full = uint32_t(bitpos >> 5) - wbase;   // complete words
-        if (full) {
-            for (uint32_t w0 = 0; w0 < full; w0 += 64) LFOR(l) {
-                const uint32_t w = w0 + uint32_t(l);
-                if (w < full) { const uint32_t v = win[w]; uint8_t *o = out + uint64_t(wbase + w) * 4u; o[0] = uint8_t(v); o[1] = uint8_t(v >> 8); o[2] = uint8_t(v >> 16); o[3] = uint8_t(v >> 24); }
-            }
-            CSP_WAVE_SYNC();
-            const uint32_t carry = win[full];
-            CSP_WAVE_SYNC();
-            LFOR(l) for (uint32_t w = uint32_t(l); w <= full; w += 64) win[w] = w == 0 ? carry : 0u;
-            wbase += full;
-            CSP_WAVE_SYNC();
-        }
-    }
-    // the last partial word, byte by byte, up to the byte that holds bit bitpos-1
-    __device__ void finish() {
-        const uint32_t nbytes = uint32_t(((bitpos + 7) >> 3) - uint64_t(wbase) * 4u);
-        LFOR(l) if (uint32_t(l) < nbytes) out[uint64_t(wbase) * 4u + uint32_t(l)] = uint8_t(win[0] >> (8 * l));
-    }
-};
 struct EmitSink {
     const uint32_t *code;   // code | length << 16, litlen then distance
     BitOut *bo;

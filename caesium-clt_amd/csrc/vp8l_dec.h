@@ -190,8 +190,7 @@ __host__ __device__ static inline uint32_t lclamp_half(uint32_t a, uint32_t b) {
     for (int s = 0; s < 32; s += 8) { const int x = int((a >> s) & 255u), y = int((b >> s) & 255u); r |= lclip(x + (x - y) / 2) << s; }
     return r;
 }
-__host__ __device__ static inline uint32_t lpredict(int mode, const uint32_t *px, int w) {   // px: the pixel being decoded, in a frame of width w
-    const uint32_t L = px[-1], T = px[-w], TR = px[-w + 1], TL = px[-w - 1];
+__host__ __device__ static inline uint32_t lpredict_vals(int mode, uint32_t L, uint32_t T, uint32_t TR, uint32_t TL) {
     switch (mode) {
     case 0: return 0xFF000000u;
     case 1: return L;
@@ -209,6 +208,9 @@ __host__ __device__ static inline uint32_t lpredict(int mode, const uint32_t *px
     case 13: return lclamp_half(lavg(L, T), TL);
     default: return 0xFF000000u;   // modes 14, 15: libwebp treats them as "black"
     }
+}
+__host__ __device__ static inline uint32_t lpredict(int mode, const uint32_t *px, int w) {   // px: the pixel being decoded, in a frame of width w
+    return lpredict_vals(mode, px[-1], px[-w], px[-w + 1], px[-w - 1]);
 }
 
 struct LTransform { int type, bits; uint32_t xsize; uint32_t *data; uint32_t ncolors; };

@@ -1,0 +1,76 @@
+// vp8l_encode.cpp -- lossless WebP OUTPUT of the batch queue (webp.lossless; libcaesium's webp::compress with libwebp's lossless coder,
+// /root/reference/src/compressor.rs:427-429 and 289-305): pixels that are already in device memory -> one VP8L file each
+// (k_vp8l_enc.hip).  Sources are the decoders of this library (WebP inputs: webp_decode.cpp; JPEG inputs: the pixel tap of the JPEG row).
+#include <cstring>
+#include <vector>
+
+#include "../../include/caesium_hip.h"
+#include "devmem.hpp"
+#include "webp_kernels.h"
+
+using namespace csh;
+
+static CCSResult make_res(uint32_t code, const char *msg) {
+    CCSResult r; r.success = code == 0; r.code = code; r.error_message = nullptr;
+    if (code && msg) { size_t n = strlen(msg); char *m = static_cast<char *>(malloc(n + 1)); memcpy(m, msg, n + 1); r.error_message = m; }
+    return r;
+}
+
+extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device, CByteArray *outputs, CCSResult *results) {
+    for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
+    if (csh_device_count() <= device || hipSetDevice(device) != hipSuccess) {
+        for (size_t i = 0; i < count; i++) results[i] = make_res(CS_ERR_NO_DEVICE, "no HIP device available (libcaesium_hip has no CPU path)");
+        return int(count);
+    }
+    int failed = 0;
+    std::vector<csw::Vp8lImg> imgs;
+    std::vector<size_t> at;
+    uint64_t work = 0, modes = 0, out = 0, max_px = 0;
+    uint32_t max_blocks = 0;
+    for (size_t i = 0; i < count; i++) {
+        if ((px[i].channels != 3 && px[i].channels != 1) || !px[i].width || !px[i].height || px[i].width > 16384 || px[i].height > 16384) {
+            results[i] = make_res(CS_ERR_UNSUPPORTED, "lossless WebP output takes opaque 8-bit RGB or grey pictures of at most 16384 x 16384"); failed++; continue;
+        }
+        csw::Vp8lImg im;
+        memset(&im, 0, sizeof im);
+        im.rgb = px[i].device_pixels; im.width = px[i].width; im.height = px[i].height; im.channels = px[i].channels;
+        im.bw = (im.width + 15) / 16; im.bh = (im.height + 15) / 16;
+        const uint64_t npx = uint64_t(im.width) * im.height;
+        im.res_off = work; work += (npx + 63) & ~uint64_t(63);
+        im.mode_off = modes; modes += (uint64_t(im.bw) * im.bh + 63) & ~uint64_t(63);
+        const uint64_t cap = 6 * npx + 2 * uint64_t(im.bw) * im.bh + 8192;   // three codes of at most 15 bits per pixel, the mode image, the code descriptions
+        if (cap > 0xFFFFFFF0ull) { results[i] = make_res(CS_ERR_UNSUPPORTED, "picture too large for one lossless WebP batch item"); failed++; continue; }
+        im.out_off = out; im.out_cap = uint32_t(cap); out += (cap + 255) & ~uint64_t(255);
+        max_px = std::max(max_px, npx); max_blocks = std::max(max_blocks, im.bw * im.bh);
+        imgs.push_back(im); at.push_back(i);
+    }
+    if (imgs.empty()) return failed;
+    hipStream_t st = 0;
+    bool have_st = false;
+    DevBuf<csw::Vp8lImg> d_imgs;
+    DevBuf<uint32_t> d_work, d_hist, d_len, d_status;
+    DevBuf<uint8_t> d_modes, d_out;
+    std::vector<uint32_t> len(imgs.size()), status(imgs.size());
+    bool ok = hipStreamCreate(&st) == hipSuccess;
+    have_st = ok;
+    ok = ok && !d_imgs.upload(imgs, st) && !d_work.alloc(work + 64) && !d_hist.alloc(imgs.size() * 768 + 8) && !d_hist.zero(st) && !d_len.alloc(imgs.size() + 1) && !d_status.alloc(imgs.size() + 1) &&
+         !d_modes.alloc(modes + 64) && !d_out.alloc(out + 256);
+    if (ok) {
+        csw::launch_vp8l_encode(st, d_imgs.p, int(imgs.size()), max_blocks, max_px, d_work.p, d_modes.p, d_hist.p, d_out.p, d_len.p, d_status.p);
+        ok = hipMemcpyAsync(len.data(), d_len.p, len.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+    }
+    for (size_t k = 0; k < imgs.size(); k++) {
+        const size_t i = at[k];
+        if (!ok) { results[i] = make_res(CS_ERR_NO_DEVICE, "lossless WebP coding failed on the device"); failed++; continue; }
+        if (status[k] || !len[k]) { results[i] = make_res(CS_ERR_POOL_OVERFLOW, "lossless WebP output larger than its region"); failed++; continue; }
+        outputs[i].data = static_cast<uint8_t *>(malloc(len[k]));
+        if (!outputs[i].data || hipMemcpy(outputs[i].data, d_out.p + imgs[k].out_off, len[k], hipMemcpyDeviceToHost) != hipSuccess) {
+            free(outputs[i].data); outputs[i].data = nullptr; results[i] = make_res(CS_ERR_NO_DEVICE, "D2H failed"); failed++; continue;
+        }
+        outputs[i].length = len[k];
+        results[i] = make_res(0, nullptr);
+    }
+    if (have_st) (void)hipStreamDestroy(st);
+    return failed;
+}

@@ -24,6 +24,18 @@ void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
                       uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
 
+// lossless WebP output (k_vp8l_enc.hip): one picture of 8-bit RGB (channels 3) or grey (1) pixels in device memory
+struct Vp8lImg {
+    const uint8_t *rgb;
+    uint32_t width, height, channels, bw, bh;   // bw x bh blocks of 16 x 16 pixels
+    uint64_t res_off;      // residual ARGB, one u32 per pixel (u32 index into the work pool)
+    uint64_t mode_off;     // predictor mode of every block (byte index)
+    uint64_t out_off;      // output file region
+    uint32_t out_cap;
+};
+void launch_vp8l_encode(hipStream_t st, const Vp8lImg *imgs, int nimg, uint32_t max_blocks, uint64_t max_pixels, uint32_t *work, uint8_t *modes, uint32_t *hist, uint8_t *out, uint32_t *file_len,
+                        uint32_t *status);
+
 struct Vp8In;
 // lossy WebP inputs (k_webp_dec.hip): every image's VP8 key frame -> RGB in the pixel pool; imgs[i].status = 0 or an error
 void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb);

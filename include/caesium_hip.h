@@ -218,9 +218,15 @@ int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, s
 /* ------------------------------------------------------------------------------------------------
  * WebP INPUTS (libcaesium decodes them with libwebp before webp::compress / convert_in_memory, compressor.rs:289-305): the RIFF
  * container is walked on the host, the VP8 key frame is decoded on the device (k_webp_dec.hip), the RGB stays in HBM
- * (cswd_batch_pixels: the csp_pixels the encoders take).  Built: lossy still pictures; VP8L / ALPH / animation answer
- * CS_ERR_UNSUPPORTED per file.  cs_batch_compress and cs_batch_convert route WebP files here themselves.
+ * (cswd_batch_pixels: the csp_pixels the encoders take).  Built: lossy (VP8) and lossless (VP8L) still pictures that are opaque; ALPH /
+ * transparency / animation answer CS_ERR_UNSUPPORTED per file.  cs_batch_compress and cs_batch_convert route WebP files here themselves.
  */
+/* lossless WebP OUTPUT (webp.lossless; libcaesium: webp::compress with libwebp's lossless coder, compressor.rs:427-429, 289-305):
+ * 8-bit RGB (channels 3) or grey (1) pictures that are in device memory -> one VP8L file each (k_vp8l_enc.hip).  outputs / results as
+ * cs_batch_compress; returns the number of failed items.  cs_batch_compress (WebP sources) and cs_batch_convert (JPEG sources) call it
+ * when p->webp_lossless is set. */
+int csl_encode_pixels(const struct csp_pixels_s *sources, size_t count, int device, CByteArray *outputs, CCSResult *results);
+
 typedef struct cswd_batch cswd_batch;
 int cswd_batch_create(const CByteArray *inputs, size_t count, int device, cswd_batch **out);
 int cswd_batch_run(cswd_batch *b);

@@ -544,7 +544,7 @@ def test_emul_batch_size_targeting_and_requant_equivalence(api):
 # ---- the product library: loads and exports everything include/caesium_hip.h declares (no compute without a GPU)
 def test_product_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "caesium_hip.h")).read()
-    declared = set(re.findall(r"\b(cs(?:h|p|wd)?_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(cs(?:h|p|wd|l)?_[a-z_0-9]+)\s*\(", hdr))
     assert {"cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory", "cs_batch_compress"} <= declared
     path = package().library_path()
     assert os.path.exists(path), "libcaesium_hip.so not built (run __graft_entry__.build())"

@@ -1,0 +1,81 @@
+"""Lossless WebP OUTPUT (webp.lossless / --lossless on WebP files, and JPEG -> WebP conversions with it): the device's VP8L coder.  Its bytes
+are not libwebp's (parity unpinned: libwebp's lossless coder is a serial search); what is pinned is the format's own invariant, checked with
+libwebp itself (through Pillow): the file decodes to EXACTLY the pixels that went in -- and this repo's VP8L decoder agrees."""
+import io
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from _util import emul_api, package
+from gen_synth import synth_jpeg, synth_rgb
+import test_webp_decode_emul as D
+
+
+@pytest.fixture(scope="module")
+def api():
+    return emul_api()
+
+
+def params(**kw):
+    return package().default_parameters(**kw)
+
+
+def check_vp8l(blob, want_rgb):
+    assert blob[:4] == b"RIFF" and blob[8:16] == b"WEBPVP8L" and int.from_bytes(blob[4:8], "little") == len(blob) - 8 and len(blob) % 2 == 0
+    im = Image.open(io.BytesIO(blob))
+    got = np.asarray(im.convert("RGB"))
+    assert got.shape == want_rgb.shape and np.array_equal(got, want_rgb)
+
+
+def sources():
+    """lossless and lossy WebP sources: photographic, flat, tiny, off the 16 x 16 block grid, one pixel wide / high"""
+    out = []
+    for i, (w, h, tex) in enumerate([(64, 48, 0.0), (101, 67, 20.0), (17, 9, 40.0), (1, 1, 0.0), (320, 240, 30.0), (1, 37, 5.0), (53, 1, 5.0), (16, 16, 10.0), (33, 31, 60.0)]):
+        out.append(D.lossless_of(synth_rgb(200 + i, w, h, texture=tex)))
+    out.append(D.lossless_of(np.full((40, 30, 3), 77, np.uint8)))
+    out.append(D.webp_of(7, 97, 61, 70, texture=20.0))
+    return out
+
+
+def test_emul_lossless_webp_round_trips_through_libwebp(api, reference_samples):
+    srcs = sources() + [open(os.path.join(reference_samples, "w0.webp"), "rb").read()]
+    outs = api.cs_batch_compress(srcs, params(webp_lossless=True))
+    for src, out in zip(srcs, outs):
+        assert isinstance(out, bytes), out
+        check_vp8l(out, D.libwebp_rgb(src))
+    # and this repo's own decoder reads them back
+    for src, got in zip(srcs, api.webp_decode(list(outs))):
+        assert np.array_equal(got, D.libwebp_rgb(src))
+
+
+def test_emul_lossless_webp_sizes_are_sane(api):
+    """no search for backward references: somewhat larger than libwebp's file, far smaller than the pixels"""
+    rgb = synth_rgb(31, 320, 240, texture=5.0)   # measured: 8 % over libwebp on noisy content, 13 % at texture 2; smooth synthetic gradients (where
+    src = D.lossless_of(rgb)                     # libwebp's backward references and colour cache pay) come out up to three times libwebp's size
+    out = api.compress_in_memory(src, params(webp_lossless=True))
+    assert len(out) < rgb.size * 0.7 and len(out) < len(src) * 1.25
+
+
+def test_emul_jpeg_to_lossless_webp_and_resize(api):
+    from oracle import oracle as O
+    src = synth_jpeg(4, 120, 88, texture=30)
+    out = api.convert_in_memory(src, params(webp_lossless=True), 3)
+    want = np.asarray(Image.open(io.BytesIO(api.convert_in_memory(src, params(png_optimize=True), 1))).convert("RGB"))   # the same decode, through the PNG row
+    check_vp8l(out, want)
+    small = api.convert_in_memory(src, params(webp_lossless=True, width=60), 3)
+    want = np.asarray(Image.open(io.BytesIO(api.convert_in_memory(src, params(png_optimize=True, width=60), 1))).convert("RGB"))
+    check_vp8l(small, want)
+    lossless_src = D.lossless_of(synth_rgb(5, 90, 70, texture=10.0))
+    resized = api.compress_in_memory(lossless_src, params(webp_lossless=True, height=35))
+    im = Image.open(io.BytesIO(resized))
+    assert im.size == (45, 35)
+
+
+def test_emul_lossless_webp_failures_stay_per_file(api):
+    good = D.lossless_of(synth_rgb(6, 40, 30, texture=20.0))
+    alpha = D.lossless_of(np.dstack([synth_rgb(7, 32, 24), np.full((24, 32), 128, np.uint8)]), "RGBA")
+    outs = api.cs_batch_compress([good, good[:50], alpha, good], params(webp_lossless=True))
+    assert [isinstance(o, Exception) for o in outs] == [False, True, True, False]
+    check_vp8l(outs[0], D.libwebp_rgb(good)); check_vp8l(outs[3], D.libwebp_rgb(good))

@@ -3,8 +3,8 @@
 # __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
-HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip"
-CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp"
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip"
+CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp vp8l_encode.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
     $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
 cat > $O/run.py <<PY
@@ -43,6 +43,8 @@ agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimize=True, png
 agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimization_level=1, png_quality=20)), lambda b: _util.oracle_png_lossy(b, 1, quality=20))
 import test_webp_decode_emul as WD
 WD.test_emul_synthetic_files_decode_like_libwebp(api); WD.test_emul_lossless_files_decode_like_libwebp(api); WD.test_emul_damaged_lossless_streams_fail_alone(api); WD.test_emul_damaged_and_unsupported_inputs_fail_alone(api)
+import test_webp_lossless_emul as WL
+WL.test_emul_lossless_webp_round_trips_through_libwebp(api, '$R/tests/golden/reference_samples'); WL.test_emul_jpeg_to_lossless_webp_and_resize(api); WL.test_emul_lossless_webp_failures_stay_per_file(api)
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
