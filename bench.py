@@ -215,8 +215,7 @@ def main():
             ach = ab / (kms[dom] * 1e-3) / 1e9
             roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(ab)})
         if names[dom] == "k_tokens":
-            roof["note"] = ("integer bit work, bound by VALU issue, not by HBM: 2.27 G wave-instructions per 1024 files at 4 cycles each on 1024 SIMDs = 3.7 ms of the "
-                            "9.2 ms launch (profiles/r02_pmc_sq_*.txt); the scan search launches it twice per step (stage 1 timed here, stage 2 inside scan_search_stage2)")
+            roof["note"] = ("integer bit work, bound by instruction issue, not by HBM: 1.04 M waves of 4.3 k issue slots per 1024 files, stalled 61 % of their life at 3 waves per SIMD (profiles/r02_pmc_sq_*_batch1024.txt); the scan search launches it twice per step (stage 1 timed here, stage 2 inside scan_search_stage2)")
         else:
             roof.update({"achieved": None, "frac": None})
         cpu = cpu_all = cpu_pillow = boundary = plain = None
