@@ -343,7 +343,7 @@ int cso_decode(const uint8_t *d, size_t n, cso_image **out) {
                 snprintf(g_err, sizeof g_err, "unsupported SOF"); goto done; }
             for (int c = 0; c < im->ncomp; c++) {
                 im->comp[c].id = s[6 + 3 * c]; im->comp[c].h = s[7 + 3 * c] >> 4; im->comp[c].v = s[7 + 3 * c] & 15;
-                im->comp[c].tq = s[8 + 3 * c] & 3;
+                im->comp[c].tq = s[8 + 3 * c];   /* libjpeg keeps the byte and fails on a table number >= 4 when the table is needed (JERR_NO_QUANT_TABLE) */
             }
             if (setup_geometry(im)) goto done;
             have_sof = 1;
