@@ -142,7 +142,7 @@ int parse_jpeg(const uint8_t *d, size_t n, JpegInfo &j, std::string &msg) {
             sc.Ah = s[3 + 2 * ns] >> 4; sc.Al = s[3 + 2 * ns] & 15;
             if (!j.progressive) { sc.Ss = 0; sc.Se = 63; sc.Ah = sc.Al = 0; }
             else {
-                if (sc.Ss > sc.Se || sc.Se > 63 || sc.Al > 13 || sc.Ah > 13) BAD(CS_ERR_BAD_JPEG, "bad progressive parameters");
+                if (sc.Ss > sc.Se || sc.Se > 63 || sc.Al > 13 || (sc.Ah != 0 && sc.Al != sc.Ah - 1)) BAD(CS_ERR_BAD_JPEG, "bad progressive parameters");   // libjpeg jdphuff.c: JERR_BAD_PROGRESSION
                 if (sc.Ss == 0 && sc.Se != 0) BAD(CS_ERR_BAD_JPEG, "bad progressive DC scan");
                 if (sc.Ss != 0 && ns != 1) BAD(CS_ERR_BAD_JPEG, "interleaved progressive AC scan");
             }

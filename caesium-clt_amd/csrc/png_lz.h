@@ -15,7 +15,10 @@ namespace csp {
 struct LzLds {
     uint64_t bucket[1u << CSP_HASH_BITS];   // four 16-bit positions, most recent in the low bits; position = offset from (chunk start - 32768)
     uint8_t lastlane[1u << CSP_HASH_BITS];
+    uint32_t cnt[256];      // byte counts of the chunk
+    uint16_t cost16[256];   // what a literal costs in this chunk, in 1/16 bit (oracle/png_oracle.c literal_costs)
 };
+enum { CSP_MATCH_BASE16 = 320, CSP_MATCH_RULE_MAXLEN = 8 };
 
 __device__ __forceinline__ static uint64_t load64u(const uint8_t *p) {
 #ifdef CSH_EMUL
@@ -87,6 +90,26 @@ __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t st
             lz_insert(L, hash, hashable, rel);
         }
     }
+    {
+        // literal costs of this chunk: log2(total / count) in integer arithmetic (exponent + four mantissa bits), 1 .. 15 bits.  A match
+        // of up to eight bytes is taken only if the literals it replaces cost more than it does (a code pair + the distance's extra bits)
+        LFOR(l) for (uint32_t i = uint32_t(l); i < 256; i += 64) L.cnt[i] = 0;
+        CSP_WAVE_SYNC();
+        for (uint64_t p0 = start; p0 < end; p0 += 64) LFOR(l) { const uint64_t p = p0 + uint32_t(l); if (p < end) atomicAdd(&L.cnt[data[p]], 1u); }
+        CSP_WAVE_SYNC();
+        const uint32_t total = uint32_t(end - start);
+        LFOR(l) for (uint32_t i = uint32_t(l); i < 256; i += 64) {
+            uint32_t c = 240;
+            if (L.cnt[i]) {
+                const uint32_t q = (total << 8) / L.cnt[i];   // >= 256; total <= 32768
+                const uint32_t e = 31u - uint32_t(__clz(q));
+                c = 16u * (e - 8u) + (((q << 4) >> e) & 15u);
+                c = c < 16u ? 16u : c > 240u ? 240u : c;
+            }
+            L.cost16[i] = uint16_t(c);
+        }
+        CSP_WAVE_SYNC();
+    }
     uint64_t carry = start;
     for (uint64_t t0 = start; t0 < end; t0 += 64) {
         const uint32_t count = end - t0 < 64 ? uint32_t(end - t0) : 64u;
@@ -130,6 +153,11 @@ __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t st
                     }
                 }
                 if (bl < 3 || (bl == 3 && bd > 8)) { bl = 0; bd = 0; }
+                if (bl && bl <= uint32_t(CSP_MATCH_RULE_MAXLEN)) {   // the bytes are the low ones of `hi`; lengths 3..8 have no extra bits
+                    uint32_t litc = 0;
+                    for (uint32_t k = 0; k < bl; k++) litc += L.cost16[uint32_t(hi >> (8 * k)) & 255u];
+                    if (litc < uint32_t(CSP_MATCH_BASE16) + 16u * dist_extra_of(dist_code_of(bd))) { bl = 0; bd = 0; }
+                }
                 mlen[l] = bl; mdist[l] = bd;
             }
         }

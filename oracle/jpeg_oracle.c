@@ -260,15 +260,17 @@ static int decode_scan(cso_image *im, const cso_scan *sc, dhuff dctab[4], dhuff 
     s.im = im; s.sc = sc; s.br.p = p; s.br.end = end;
     int dc_scan = sc->Ss == 0;
     for (int i = 0; i < sc->ncomp_in_scan; i++) {
-        s.dc[i] = &dctab[td[i]]; s.ac[i] = &actab[ta[i]];
         int need_dc = im->progressive ? (dc_scan && sc->Ah == 0) : 1;
         int need_ac = im->progressive ? (!dc_scan) : 1;
+        if ((need_dc && td[i] > 3) || (need_ac && ta[i] > 3)) FAIL("SOS table id out of range");
+        s.dc[i] = &dctab[td[i] & 3]; s.ac[i] = &actab[ta[i] & 3];
         if (need_dc && !s.dc[i]->present) FAIL("missing DC Huffman table %d", td[i]);
         if (need_ac && !s.ac[i]->present) FAIL("missing AC Huffman table %d", ta[i]);
     }
-    if (im->progressive) {
+    if (im->progressive) {   /* libjpeg jdphuff.c start_pass_phuff_decoder: JERR_BAD_PROGRESSION */
         if (dc_scan) { if (sc->Se != 0) FAIL("bad progressive DC scan"); }
         else if (sc->ncomp_in_scan != 1 || sc->Se < sc->Ss || sc->Se > 63) FAIL("bad progressive AC scan");
+        if ((sc->Ah != 0 && sc->Al != sc->Ah - 1) || sc->Al > 13) FAIL("bad progressive parameters");
     }
     int ri = im->restart_interval, todo = ri;
     if (sc->ncomp_in_scan == 1) {
@@ -306,7 +308,7 @@ static int decode_scan(cso_image *im, const cso_scan *sc, dhuff dctab[4], dhuff 
 /* marker parser (T.81 Annex B)                                                               */
 int cso_decode(const uint8_t *d, size_t n, cso_image **out) {
     *out = NULL;
-    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) FAIL("not a JPEG (no SOI)");
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8 || d[2] != 0xFF) FAIL("not a JPEG (no SOI + marker: libcaesium sniffs FF D8 FF)");
     cso_image *im = (cso_image *)calloc(1, sizeof *im);
     dhuff *dctab = (dhuff *)calloc(4, sizeof(dhuff)), *actab = (dhuff *)calloc(4, sizeof(dhuff));
     bvec meta = {0};
@@ -380,7 +382,7 @@ int cso_decode(const uint8_t *d, size_t n, cso_image **out) {
                 for (int c = 0; c < im->ncomp; c++) if (im->comp[c].id == cid) ci = c;
                 if (ci < 0) { snprintf(g_err, sizeof g_err, "SOS names unknown component"); goto done; }
                 for (int q = 0; q < k; q++) if (sc->comp_idx[q] == ci) { snprintf(g_err, sizeof g_err, "SOS names a component twice"); goto done; }  /* libjpeg JERR_BAD_COMPONENT_ID */
-                sc->comp_idx[k] = ci; td[k] = (s[2 + 2 * k] >> 4) & 3; ta[k] = s[2 + 2 * k] & 3;
+                sc->comp_idx[k] = ci; td[k] = s[2 + 2 * k] >> 4; ta[k] = s[2 + 2 * k] & 15;   /* a number >= 4 fails when the table is needed (libjpeg: JERR_NO_HUFF_TABLE) */
             }
             sc->Ss = s[1 + 2 * ns]; sc->Se = s[2 + 2 * ns]; sc->Ah = s[3 + 2 * ns] >> 4; sc->Al = s[3 + 2 * ns] & 15;
             if (!im->progressive) { sc->Ss = 0; sc->Se = 63; sc->Ah = sc->Al = 0; }

@@ -721,6 +721,29 @@ static void insert_tile(uint16_t (*table)[WAYS], const uint8_t *data, size_t tot
     }
 }
 
+/* What a literal costs in this chunk, in 1/16 bit: log2(total / count) in integer arithmetic (exponent + the top four bits of the
+   mantissa, i.e. a piecewise-linear log2), at least one bit, at most fifteen.  A short match is taken only if the literals it replaces
+   cost more than it does: on filtered photographic data a byte costs 5-6 bits, and a three-byte match at a row's distance (a length
+   code, a distance code and 11 extra bits) is a loss -- zlib and a greedy parse take it anyway, an optimal parser (libdeflate, zopfli)
+   does not. */
+static void literal_costs(const uint8_t *data, size_t start, size_t end, uint16_t cost16[256]) {
+    uint32_t cnt[256];
+    memset(cnt, 0, sizeof cnt);
+    for (size_t p = start; p < end; p++) cnt[data[p]]++;
+    const uint64_t total = end - start;
+    for (int b = 0; b < 256; b++) {
+        uint32_t c = 240;
+        if (cnt[b]) {
+            const uint64_t q = (total << 8) / cnt[b];   /* >= 256 */
+            int e = 63; while (!((q >> e) & 1)) e--;
+            c = 16u * (uint32_t)(e - 8) + (uint32_t)(((q << 4) >> e) & 15u);
+            if (c < 16) c = 16; if (c > 240) c = 240;
+        }
+        cost16[b] = (uint16_t)c;
+    }
+}
+#define MATCH_BASE16 320   /* what the two symbols of a match cost before their extra bits, in 1/16 bit (tuned on the synthetic set) */
+#define MATCH_RULE_MAXLEN 8   /* longer matches always pay */
 typedef struct { uint16_t len, dist; } token;   /* len 0: literal */
 /* tokens of data[start, end) (one chunk of a stream of `total` bytes; tiles are aligned to multiples of 64 of the stream).
    tok[i] describes position start+i; taken[i] = the parse visits it. */
@@ -731,6 +754,8 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
     const size_t base_rel = 32768 - start;   /* modulo 2^64: rel = p - start + 32768 */
     for (size_t t0 = seed0; t0 < start; t0 += 64) insert_tile(table, data, total, base_rel, t0, t0 + 64);
     size_t carry = start;   /* next position the parse visits */
+    uint16_t cost16[256];
+    literal_costs(data, start, end, cost16);
     for (size_t t0 = start; t0 < end; t0 += 64) {
         size_t t1 = t0 + 64 < end ? t0 + 64 : end;
         for (size_t p = t0; p < t1; p++) {
@@ -755,6 +780,11 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
                 }
             }
             if (bl < 3 || (bl == 3 && bd > 8)) { bl = 0; bd = 0; }
+            if (bl && bl <= MATCH_RULE_MAXLEN) {   /* lengths 3..8 have no extra bits */
+                uint32_t lit = 0;
+                for (size_t k = 0; k < bl; k++) lit += cost16[data[p + k]];
+                if (lit < MATCH_BASE16 + 16u * (uint32_t)DIST_EXTRA[dist_code((int)bd)]) { bl = 0; bd = 0; }
+            }
             tok[p - start].len = (uint16_t)bl; tok[p - start].dist = (uint16_t)bd;
         }
         insert_tile(table, data, total, base_rel, t0, t1);
