@@ -112,16 +112,22 @@ __device__ __forceinline__ static void idct4_add(const int (&in)[16], const int 
 }
 __device__ __forceinline__ static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }   // bias / 256 of a step: libwebp's rounding offsets
 
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *imgs, uint8_t *work, int16_t *levels) {
-    const WebpImg im = imgs[blockIdx.x];
+// One wave per macroblock; one launch per anti-diagonal of the macroblock grid (mx + my = diag): a macroblock predicts from the
+// reconstruction of its left, upper and upper-left neighbours only (16 x 16 and 8 x 8 modes have no upper-right dependency), so the
+// macroblocks of a diagonal -- of every picture of the batch -- are independent.  (The first version walked a picture's macroblocks in
+// raster order with one wave: 16.7 us each, 83 ms for 256 pictures whatever else the chip had to do.)
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *imgs, uint8_t *work, int16_t *levels, int diag) {
+    const WebpImg im = imgs[blockIdx.y];
     const int mbw = int(im.mbw), mbh = int(im.mbh), ys = mbw * 16, cs = mbw * 8, qi = im.qi;
     const int y1ac = kVp8AcQ[qi], y2dc = kVp8DcQ[qi] * 2, uvac = kVp8AcQ[qi];
     int y2ac = kVp8AcQ[qi] * 155 / 100; if (y2ac < 8) y2ac = 8;
     int uvdc = kVp8DcQ[qi]; if (uvdc > 132) uvdc = 132;
     const uint8_t *sy = work + im.y_off, *su = work + im.u_off, *sv = work + im.v_off;
     uint8_t *ry = work + im.ry_off, *ru = work + im.ru_off, *rv = work + im.rv_off;
-    for (int my = 0; my < mbh; my++)
-        for (int mx = 0; mx < mbw; mx++) {
+    {
+        {
+            const int my = int(blockIdx.x), mx = diag - my;
+            if (my >= mbh || mx < 0 || mx >= mbw) return;
             // the three DC predictions: lanes 0..31 gather the luma edge, 32..47 the U edge, 48..63 the V edge; one packed sum
             LV<uint64_t> edge;
             LFOR(l) {
@@ -301,8 +307,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
                 const uint32_t mask = (uint32_t(bal & 0xFFFFFFu) << 1) | (y2any ? 1u : 0u);
                 LFOR(l) if (l == 0) { L[48] = int16_t(mask & 0xFFFFu); L[64] = int16_t(mask >> 16); }
             }
-            CSP_MEM_FENCE();   // the next macroblock predicts from these pixels
         }
+    }
 }
 
 // ---- W3: boolean entropy coder (oracle: boolenc) and the token walk (oracle: put_coeffs)
@@ -317,12 +323,13 @@ struct BoolEnc {
     int32_t range, value;
     int run, nb_bits;
     bool overflow;
+    __device__ __forceinline__ static int32_t u(int32_t v) { return int32_t(csp::uni(uint32_t(v))); }   // the coder's state is wave-uniform: keep it in scalar registers
     __device__ __forceinline__ void init(uint8_t *b, uint32_t c) { buf = b; pos = 0; cap = c; range = 254; value = 0; run = 0; nb_bits = -8; overflow = false; }
     __device__ __forceinline__ void flush_bits() {
         const int s = 8 + nb_bits;
-        const int32_t bits = value >> s;
-        value -= bits << s;
-        nb_bits -= 8;
+        const int32_t bits = u(value >> s);
+        value = u(value - (bits << s));
+        nb_bits = u(nb_bits - 8);
         if ((bits & 0xff) != 0xff) {
             if (pos + uint32_t(run) + 1 > cap) { overflow = true; run = 0; return; }
             LANE0 {
@@ -331,18 +338,20 @@ struct BoolEnc {
                 for (int k = 0; k < run; k++) buf[pos + uint32_t(k)] = v;
                 buf[pos + uint32_t(run)] = uint8_t(bits & 0xff);
             }
-            pos += uint32_t(run) + 1; run = 0;
+            pos = uint32_t(u(int32_t(pos + uint32_t(run) + 1))); run = 0;
         } else
-            run++;
+            run = u(run + 1);
     }
     __device__ __forceinline__ void put(int bit, int prob) {
+        bit = u(bit); prob = u(prob);
         const int32_t split = (range * prob) >> 8;
         if (bit) { value += split + 1; range -= split + 1; } else range = split;
+        range = u(range); value = u(value);
         if (range < 127) {
             const int shift = __clz(uint32_t(range + 1)) - 24;
-            range = ((range + 1) << shift) - 1;
-            value <<= shift;
-            nb_bits += shift;
+            range = u(((range + 1) << shift) - 1);
+            value = u(value << shift);
+            nb_bits = u(nb_bits + shift);
             if (nb_bits > 0) flush_bits();
         }
     }
@@ -351,27 +360,45 @@ struct BoolEnc {
 };
 // the token walk of one block, either coding (CodeSink: the frame's probabilities) or only counting what it would code
 // (StatSink), which is how the frame's probabilities are chosen (oracle: put_coeffs / tsink)
+// the coder's wave is one serial chain, and what makes it slow is waiting for memory once per decision: the frame's probabilities
+// therefore sit in LDS, and a block's sixteen levels arrive with ONE load (lane n holds level n; the walk reads them with v_readlane)
 struct CodeSink {
     BoolEnc &e;
-    const uint8_t *probs;
+    const uint8_t *probs;   // LDS
+    LV<int> lvl;
+    __device__ __forceinline__ void begin(const int16_t *lv) { LFOR(l) lvl[l] = l < 16 ? int(lv[l]) : 0; }
+    __device__ __forceinline__ int lev(const int16_t *, int i) const {
+#ifdef CSH_EMUL
+        return lvl.v[i];
+#else
+        return __builtin_amdgcn_readlane(lvl.v, i);
+#endif
+    }
+    __device__ __forceinline__ int last_nonzero(const int16_t *, int first) const {
+        const uint64_t nz = lballot([&](int l) { return l >= first && l < 16 && lvl[l] != 0; });
+        return nz ? 63 - __builtin_clzll(nz) : -1;
+    }
     __device__ __forceinline__ void ad(int bit, int idx) { e.put(bit, probs[idx]); }
     __device__ __forceinline__ void fx(int bit, int prob) { e.put(bit, prob); }
 };
 struct StatSink {
     uint32_t *cnt;   // [1056][2] in LDS
+    __device__ __forceinline__ void begin(const int16_t *) {}
+    __device__ __forceinline__ int lev(const int16_t *lv, int i) const { return lv[i]; }   // lanes = blocks here: every lane reads its own block
+    __device__ __forceinline__ int last_nonzero(const int16_t *lv, int first) const { int last = -1; for (int i = first; i < 16; i++) if (lv[i]) last = i; return last; }
     __device__ __forceinline__ void ad(int bit, int idx) { atomicAdd(&cnt[2 * idx + (bit ? 1 : 0)], 1u); }
     __device__ __forceinline__ void fx(int, int) {}
 };
 template <class S>
 __device__ static int put_coeffs(S &e, int type, int ctx, const int16_t *lv, int first) {
-    int last = -1;
-    for (int i = first; i < 16; i++) if (lv[i]) last = i;
+    e.begin(lv);
+    const int last = e.last_nonzero(lv, first);
     int n = first;
     int p = ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
     if (last < 0) { e.ad(0, p + 0); return 0; }
     e.ad(1, p + 0);
     while (n < 16) {
-        const int c = lv[n++];
+        const int c = e.lev(lv, n++);
         const int sign = c < 0;
         int v = sign ? -c : c;
         if (!v) { e.ad(0, p + 1); p = ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
@@ -480,7 +507,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
     const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh), part = int(blockIdx.y) - 1;
     if (part >= nparts) return;
     const int16_t *lev = levels + im.lev_off;
-    const uint8_t *probs = probs_all + size_t(im.image) * WEBP_NPROB, *update = update_all + size_t(im.image) * WEBP_NPROB;
+    const uint8_t *probs_g = probs_all + size_t(im.image) * WEBP_NPROB, *update = update_all + size_t(im.image) * WEBP_NPROB;
+    CSH_SHARED uint8_t s_probs[WEBP_NPROB];
+    LFOR(l) for (int i = l; i < WEBP_NPROB; i += 64) s_probs[i] = probs_g[i];
+    CSP_WAVE_SYNC();
+    const uint8_t *probs = s_probs;
     uint8_t *base = scratch + im.out_off;
     BoolEnc e;
     if (part < 0) {
@@ -507,7 +538,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
             for (int mx = 0; mx < mbw; mx++) {
                 const int16_t *L = lev + (size_t(my) * mbw + mx) * 400;
                 const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * 400) : 0u, left = mx ? nz_mask(L - 400) : 0u;
-                CodeSink sink{e, probs};
+                CodeSink sink{e, probs, {}};
                 for (int k = 0; k < 25; k++) {
                     int type, first, ctx;
                     block_info(k, cur, top, left, type, first, ctx);
@@ -556,8 +587,9 @@ __global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, cons
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work) {
     if (nimg && max_luma) CSH_LAUNCH(k_webp_yuv, dim3((max_luma + 255) / 256, nimg), dim3(256), st, imgs, rgb, work);
 }
-void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work, int16_t *levels) {
-    if (nimg) CSH_LAUNCH(k_webp_mb, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, work, levels);
+void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels) {
+    if (!nimg || !max_mbw || !max_mbh) return;
+    for (uint32_t d = 0; d + 1 < max_mbw + max_mbh; d++) CSH_LAUNCH(k_webp_mb, dim3(max_mbh, unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, imgs, work, levels, int(d));
 }
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
                       uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {

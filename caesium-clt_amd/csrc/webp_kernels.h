@@ -18,7 +18,7 @@ struct WebpImg {
 };
 
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work);
-void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint8_t *work, int16_t *levels);
+void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels);   // one launch per anti-diagonal
 // stats: nimg x 1056 x 2 counters (zeroed by the caller); probs / update: nimg x 1056 bytes; scratch: a second region laid out like the
 // output pool (every partition is coded into its own slice of it); part_size: nimg x 9
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
