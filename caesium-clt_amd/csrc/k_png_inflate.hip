@@ -21,13 +21,14 @@
 
 namespace csp {
 
-enum { LROOT = 10, DROOT = 8, LZ_RING = 65536, LZ_PIECE = 16384 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
+enum { LROOT = 10, DROOT = 8, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 256, HUFF_STAGE_WORDS = HUFF_SUB * 64 / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
     uint16_t lsorted[288], dsorted[32], csorted[20];
     uint16_t lroot[1 << LROOT], droot[1 << DROOT];
     uint8_t lens[320];
+    uint32_t stage[HUFF_STAGE_WORDS];   // k_png_huff: the round's stretch of the stream
 };
 
 // canonical walk over the low bits of `bits` (LSB first), at most maxlen of them: (sym << 4) | len, or 0
@@ -209,13 +210,13 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
             r = build_code(S.lens + 288, ndist, S.dcount, S.offs, S.dsorted, S.droot, DROOT);
             if (type == 2 && (r < 0 || (r > 0 && ndist - int(S.dcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }   // the fixed distance code is incomplete by definition
         }
-        // The symbols.  One pass = one window of 64 bit offsets: EVERY lane decodes the complete token that would start at bit bp + lane
-        // (literal / end of block / length with its extra bits, distance code and distance extra bits: two LDS look-ups and arithmetic,
-        // all in the vector domain) and so knows where the next token would start.  The only serial work is following those links from
-        // offset 0 -- one v_readlane per token.  The tokens on the chain then place themselves: a prefix sum of their output lengths
-        // gives every literal its byte in the output and every match its record.  A token the root tables do not hold ends the window
-        // and is decoded by the uniform bit-serial walk below.
-        enum { K_LIT = 0, K_MATCH = 1, K_EOB = 2, K_SLOW = 3 };
+        // The symbols, SUB bits per lane and round.  Where a prefix-coded stream is entered matters only for a few tokens: a walk that starts
+        // at a wrong bit falls into step with the true one after a handful of codes.  So every lane walks its own stretch of the block --
+        // lane l the tokens that start in [base + l SUB, base + (l + 1) SUB) -- first from the stretch's first bit (a guess; lane 0's is
+        // the truth), then from where its left neighbour's walk actually left off, again and again until no lane's entry moves (two or
+        // three passes; each only for the lanes whose entry moved).  Then the walks are the block's token sequence cut in 64: a prefix sum
+        // of what each produces gives every lane its place in the output and in the match list, and a last pass writes.  The stretches of
+        // a round come from an LDS copy of the stream (one coalesced load per round instead of one dependent load per token).
         auto lane_of = [&](const LV<uint32_t> &v, uint32_t i) __attribute__((always_inline)) -> uint32_t {
 #ifdef CSH_EMUL
             return v.v[i];
@@ -223,100 +224,148 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
             return uint32_t(__builtin_amdgcn_readlane(int(v.v), int(i)));
 #endif
         };
-        auto put_match = [&](uint64_t at, uint32_t len, uint32_t dist) __attribute__((always_inline)) {   // uniform: one record from the slow path
-            LFOR(l) if (l == 0) mlist[mtotal] = (at & 0xFFFFFFFFull) | (uint64_t(len) << 32) | (uint64_t(dist) << 48);
-            mtotal++;
-        };
-        auto slow_symbol = [&](bool &block_done) __attribute__((always_inline)) {   // one symbol at bp, by the canonical walk over up to 15 bits
-            const uint32_t e = uni(canon_walk(rd.peek(0, 15), 15, S.lcount, S.lsorted));
-            if (!e) { err = CSP_ERR_BAD_PNG; return; }
-            uint32_t off = e & 15u;
-            const uint32_t sym = e >> 4;
-            if (sym < 256) { LFOR(l) if (l == 0 && pos < cap) out[pos] = uint8_t(sym); pos++; }
-            else if (sym == 256) block_done = true;
-            else {
-                const uint32_t li = sym - 257;
-                if (li >= 29) { err = CSP_ERR_BAD_PNG; return; }
-                uint32_t len;
-                if (li < 8) len = 3 + li; else if (li == 28) len = 258; else { const int eb = int(li >> 2) - 1; len = ((4u | (li & 3u)) << eb) + 3u + rd.peek(off, eb); off += uint32_t(eb); }
-                const uint32_t d = uni(canon_walk(rd.peek(off, 15), 15, S.dcount, S.dsorted));
-                if (!d) { err = CSP_ERR_BAD_PNG; return; }
-                off += d & 15u;
-                const uint32_t ds = d >> 4;
-                if (ds >= 30) { err = CSP_ERR_BAD_PNG; return; }
-                uint32_t dist;
-                if (ds < 4) dist = ds + 1; else { const int eb = int(ds >> 1) - 1; dist = ((2u | (ds & 1u)) << eb) + 1u + rd.peek(off, eb); off += uint32_t(eb); }
-                if (uint64_t(dist) > pos || rd.bp + off > uint64_t(rd.len) * 8u) { err = CSP_ERR_BAD_PNG; return; }
-                put_match(pos, len, dist);
-                pos += len;
-            }
-            rd.bp += off;
-            rd.refresh();
+        auto lane_of64 = [&](const LV<uint64_t> &v, uint32_t i) __attribute__((always_inline)) -> uint64_t {
+#ifdef CSH_EMUL
+            return v.v[i];
+#else
+            return (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v.v >> 32)), int(i)))) << 32) | uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v.v)), int(i)));
+#endif
         };
         bool block_done = false;
         while (!block_done && !err && pos < cap) {
             if (rd.overrun()) { err = CSP_ERR_BAD_PNG; break; }
-            LV<uint32_t> NX, OL, VAL;   // next offset | kind << 8; bytes the token produces; the literal, or length | distance << 16
-            LFOR(l) {
-                const uint64_t b = rd.at64(uint32_t(l));
-                const uint32_t e = S.lroot[uint32_t(b) & ((1u << LROOT) - 1u)];
-                const uint32_t sym = (e >> 4) & 0x1FFu;
-                uint32_t kind = K_LIT, tl = e & 15u, ol = 1, val = sym;
-                if (!e) kind = K_SLOW;
-                else if (sym == 256) { kind = K_EOB; ol = 0; }
-                else if (sym > 256) {
-                    const uint32_t li = sym - 257;
-                    kind = K_SLOW;   // until the whole token is known (an invalid one is reported by the slow path)
-                    if (li < 29) {
-                        const uint32_t eb = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
-                        const uint32_t len = (li < 8 ? 3u + li : li == 28 ? 258u : ((4u | (li & 3u)) << eb) + 3u) + (uint32_t(b >> tl) & ((1u << eb) - 1u));
-                        tl += eb;
-                        const uint32_t d = S.droot[uint32_t(b >> tl) & ((1u << DROOT) - 1u)];
-                        const uint32_t ds = (d >> 4) & 0x7FFu;
-                        if (d && ds < 30) {
-                            const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
-                            tl += d & 15u;
-                            const uint32_t dist = (ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(b >> tl) & ((1u << deb) - 1u));
-                            tl += deb;
-                            kind = K_MATCH; ol = len; val = len | (dist << 16);
-                        }
-                    }
+            const uint64_t base = rd.bp, limit = uint64_t(rd.len) * 8u;
+            {   // bytes [base / 8 rounded down to a word, + SUB * 64 / 8 + slack) -> LDS, zero behind the stream's end
+                const uint64_t b0 = (base >> 5) << 2;
+                LFOR(l) for (uint32_t i = uint32_t(l); i < HUFF_STAGE_WORDS; i += 64) {
+                    const uint64_t at = b0 + uint64_t(i) * 4u;
+                    uint32_t w = 0;
+                    if (at + 4 <= rd.len) w = *reinterpret_cast<const uint32_t *>(rd.base + at);
+                    else for (int k = 0; k < 4; k++) if (at + uint32_t(k) < rd.len) w |= uint32_t(rd.base[at + uint32_t(k)]) << (8 * k);
+                    S.stage[i] = w;
                 }
-                // the link the chase follows: the next token's offset; a token that ends the chase (end of block, slow path) carries bit 7
-                // or 8, so "offset < 64" is the one test of the loop
-                NX[l] = kind == K_SLOW ? (0x100u | uint32_t(l)) : kind == K_EOB ? (0x80u | (uint32_t(l) + tl)) : (uint32_t(l) + tl) | (kind << 16);
-                OL[l] = ol; VAL[l] = val;
+                CSP_WAVE_SYNC();
             }
-            uint64_t real = 0;
-            uint32_t s0 = 0, stop = 0;   // stop: 0 the window is used up, 1 end of block, 2 a token for the slow path at s0, 3 the image is complete
+            const uint64_t stage_bit0 = (base >> 5) << 5;
+            // 64 bits of the stream from bit p on (p inside the staged range: at most SUB * 64 + 48 bits behind base)
+            auto bits_at = [&](uint64_t p) __attribute__((always_inline)) -> uint64_t {
+                const uint32_t r = uint32_t(p - stage_bit0), w = r >> 5, sh = r & 31u;
+                const uint64_t lo = (uint64_t(S.stage[w]) | (uint64_t(S.stage[w + 1]) << 32)) >> sh;
+                return sh ? lo | (uint64_t(S.stage[w + 2]) << (64u - sh)) : lo;
+            };
+            // one token at bit p: kind 0 literal, 1 match, 2 end of block, 3 not a token (error if it is on the true walk)
+            auto token = [&](uint64_t p, uint32_t &kind, uint32_t &tl, uint32_t &val) __attribute__((always_inline)) {
+                const uint64_t b = bits_at(p);
+                uint32_t e = S.lroot[uint32_t(b) & ((1u << LROOT) - 1u)];
+                if (!e) e = canon_walk(uint32_t(b) & 0x7FFFu, 15, S.lcount, S.lsorted);
+                kind = 3; tl = 1; val = 0;
+                if (!e) return;
+                const uint32_t sym = (e >> 4) & 0x1FFu;
+                tl = e & 15u;
+                if (sym < 256) { kind = 0; val = sym; return; }
+                if (sym == 256) { kind = 2; return; }
+                const uint32_t li = sym - 257;
+                if (li >= 29) return;
+                const uint32_t eb = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
+                const uint32_t len = (li < 8 ? 3u + li : li == 28 ? 258u : ((4u | (li & 3u)) << eb) + 3u) + (uint32_t(b >> tl) & ((1u << eb) - 1u));
+                tl += eb;
+                uint32_t d = S.droot[uint32_t(b >> tl) & ((1u << DROOT) - 1u)];
+                if (!d) d = canon_walk(uint32_t(b >> tl) & 0x7FFFu, 15, S.dcount, S.dsorted);
+                const uint32_t ds = (d >> 4) & 0x7FFu;
+                if (!d || ds >= 30) return;
+                const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
+                tl += d & 15u;
+                const uint32_t dist = (ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(b >> tl) & ((1u << deb) - 1u));
+                tl += deb;
+                kind = 1; val = len | (dist << 16);
+            };
+            LV<uint64_t> entry, leave;      // where the lane's walk starts / where the token behind its last one starts
+            LV<uint32_t> nout, nmat, stopk; // bytes and matches its walk produces; how it ended: 0 ran out of its stretch, 2 end of block, 3 not a token
+            LV<uint32_t> redo;
+            LFOR(l) { entry[l] = base + uint64_t(HUFF_SUB) * uint32_t(l); redo[l] = 1; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }
+            for (int pass = 0; pass < 66; pass++) {
+                LFOR(l) if (redo[l]) {
+                    const uint64_t end = base + uint64_t(HUFF_SUB) * (uint32_t(l) + 1u);
+                    uint64_t p = entry[l];
+                    uint32_t no = 0, nm = 0, sk = 0;
+                    if (p != ~0ull) {
+                        while (p < end) {
+                            uint32_t kind, tl, val;
+                            token(p, kind, tl, val);
+                            if (kind == 3) { sk = 3; break; }
+                            p += tl;
+                            if (kind == 2) { sk = 2; break; }
+                            if (kind == 1) { no += val & 0xFFFFu; nm++; } else no++;
+                        }
+                    } else sk = 3;   // no entry: the walk in front of it ended the block (or was no walk)
+                    leave[l] = p; nout[l] = no; nmat[l] = nm; stopk[l] = sk;
+                }
+                // everyone's new entry: where the left neighbour left off (nowhere, if it stopped)
+                LV<uint64_t> from;
+#ifdef CSH_EMUL
+                for (int l = 63; l >= 1; l--) from.v[l] = stopk.v[l - 1] ? ~0ull : leave.v[l - 1];
+                from.v[0] = base;
+#else
+                {
+                    const uint64_t mine = stopk.v ? ~0ull : leave.v;
+                    const uint32_t lo = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(mine)), 0x138, 0xf, 0xf, false)), hi = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(mine >> 32)), 0x138, 0xf, 0xf, false));   // wave_shr:1
+                    from.v = (threadIdx.x & 63u) ? (uint64_t(hi) << 32) | lo : base;
+                }
+#endif
+                LFOR(l) { redo[l] = from[l] != entry[l] ? 1u : 0u; entry[l] = from[l]; }
+                if (!lballot([&](int l) { return redo[l] != 0u; })) break;
+            }
+            // the lanes of the true walk: up to and including the first that stopped
+            const uint64_t stopped = lballot([&](int l) { return stopk[l] != 0u; });
+            const int nlanes = stopped ? __builtin_ctzll(stopped) + 1 : 64;
+            const uint32_t how = stopped ? lane_of(stopk, uint32_t(nlanes - 1)) : 0u;
+            LV<uint32_t> mo, mm;
+            LFOR(l) { mo[l] = l < nlanes ? nout[l] : 0u; mm[l] = l < nlanes ? nmat[l] : 0u; }
+            uint32_t tot_out = 0, tot_mat = 0;
+            const LV<uint32_t> before = lscan(mo, tot_out);
+            const LV<uint32_t> mbefore = lscan(mm, tot_mat);
+            // the last pass: literals to their bytes, matches to their records.  Nothing is decoded past the image's last byte: a walk stops
+            // in front of the first token that would start there, and what it finds wrong behind that point does not count
+            LV<uint32_t> bad, wrote;
+            LV<uint64_t> pfin;
+            LFOR(l) {
+                bad[l] = 0; wrote[l] = 0; pfin[l] = 0;
+                if (l < nlanes && entry[l] != ~0ull && pos + before[l] < cap) {
+                    const uint64_t end = base + uint64_t(HUFF_SUB) * (uint32_t(l) + 1u);
+                    uint64_t p = entry[l], at = pos + before[l];
+                    uint32_t mi = mtotal + mbefore[l];
+                    while (p < end && at < cap) {
+                        uint32_t kind, tl, val;
+                        token(p, kind, tl, val);
+                        if (kind == 3) { bad[l] = 1; break; }
+                        if (kind == 2) break;
+                        if (kind == 1) {
+                            const uint32_t len = val & 0xFFFFu, dist = val >> 16;
+                            if (uint64_t(dist) > at || p + tl > limit) { bad[l] = 1; break; }
+                            mlist[mi++] = (at & 0xFFFFFFFFull) | (uint64_t(len) << 32) | (uint64_t(dist) << 48);
+                            at += len;
+                        } else out[at++] = uint8_t(val);
+                        p += tl;
+                    }
+                    wrote[l] = mi - (mtotal + mbefore[l]); pfin[l] = p;
+                }
+            }
+            if (lballot([&](int l) { return bad[l] != 0u; })) { err = CSP_ERR_BAD_PNG; break; }
             {
-                uint32_t v;
-                do { v = lane_of(NX, s0) & 0xFFFFu; real |= 1ull << s0; if (v >= 64u) break; s0 = v; } while (true);
-                if (v & 0x100u) { stop = 2; real &= ~(1ull << s0); }      // s0 stays at the slow token
-                else if (v & 0x80u) { stop = 1; s0 = v & 0x7Fu; }        // behind the end-of-block code (< 64 + 15)
-                else s0 = v;
+                uint32_t nw = 0;
+                (void)lscan(wrote, nw);
+                mtotal += nw;   // == tot_mat unless the image's last byte came first
             }
-            LV<uint32_t> mine;
-            LFOR(l) mine[l] = ((real >> l) & 1) ? OL[l] : 0u;
-            uint32_t total = 0;
-            const LV<uint32_t> before = lscan(mine, total);
-            // nothing is decoded past the image's last byte: the first token that would start there ends the stream
-            const uint64_t beyond = lballot([&](int l) { return ((real >> l) & 1) && pos + before[l] >= cap; });
-            if (beyond) { const int fb = __builtin_ctzll(beyond); real &= lanes_below(fb); total = lane_of(before, uint32_t(fb)); stop = 3; }
-            const uint64_t mm = lballot([&](int l) { return ((real >> l) & 1) && (NX[l] >> 16) == uint32_t(K_MATCH); });
-            if (lballot([&](int l) { return ((mm >> l) & 1) && (uint64_t(VAL[l] >> 16) > pos + before[l] || rd.bp + (NX[l] & 0x7Fu) > uint64_t(rd.len) * 8u); })) { err = CSP_ERR_BAD_PNG; break; }
-            LFOR(l) if ((real >> l) & 1) {
-                const uint64_t at = pos + before[l];
-                if ((mm >> l) & 1) mlist[mtotal + uint32_t(__popcll(mm & lanes_below(l)))] = (at & 0xFFFFFFFFull) | (uint64_t(VAL[l] & 0xFFFFu) << 32) | (uint64_t(VAL[l] >> 16) << 48);
-                else if (OL[l]) out[at] = uint8_t(VAL[l]);
+            pos += tot_out;
+            if (pos >= cap) {   // complete: the stream position is where the last walk that wrote anything stopped
+                const uint64_t started = lballot([&](int l) { return l < nlanes && entry[l] != ~0ull && pos - tot_out + before[l] < cap; });
+                if (started) { rd.bp = lane_of64(pfin, uint32_t(63 - __builtin_clzll(started))); rd.refresh(); }
+                break;
             }
-            mtotal += uint32_t(__popcll(mm));
-            pos += total;
-            if (stop == 3) break;
-            rd.bp += s0;
+            if (how == 3) { err = CSP_ERR_BAD_PNG; break; }   // the true walk met something that is no token
+            rd.bp = lane_of64(leave, uint32_t(nlanes - 1));
             rd.refresh();
-            if (stop == 1) block_done = true;
-            else if (stop == 2) slow_symbol(block_done);
+            if (how == 2) block_done = true;
         }
     }
     if (!err && rd.overrun()) err = CSP_ERR_BAD_PNG;
