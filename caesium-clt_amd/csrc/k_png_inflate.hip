@@ -21,7 +21,7 @@
 
 namespace csp {
 
-enum { LROOT = 10, DROOT = 8, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 256, HUFF_STAGE_WORDS = HUFF_SUB * 64 / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
+enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_STAGE_WORDS = HUFF_SUB * 64 / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
