@@ -29,6 +29,7 @@ struct InflateLds {
     uint16_t lroot[1 << LROOT], droot[1 << DROOT];
     uint8_t lens[320];
     uint32_t stage[HUFF_STAGE_WORDS];   // k_png_huff: the round's stretch of the stream
+    uint32_t lresume[2], dresume[2];    // canon_resume's starting point for codes longer than the root tables
 };
 
 // canonical walk over the low bits of `bits` (LSB first), at most maxlen of them: (sym << 4) | len, or 0
@@ -42,8 +43,26 @@ __device__ __forceinline__ static uint32_t canon_walk(uint32_t bits, int maxlen,
     }
     return 0;
 }
+// the same walk for a code that is known to be longer than `root` bits: it starts where the walk stands behind length `root` (first /
+// index there depend on the counts alone: `resume`, made by build_code), with the first `root` bits as the code so far
+__device__ __forceinline__ static uint32_t canon_resume(uint32_t bits, int root, const uint32_t *count, const uint16_t *sorted, const uint32_t *resume) {
+#ifdef CSH_EMUL
+    uint32_t rev = 0;
+    for (int k = 0; k < root; k++) rev |= ((bits >> k) & 1u) << (root - 1 - k);
+#else
+    const uint32_t rev = __brev(bits & ((1u << root) - 1u)) >> (32 - root);
+#endif
+    int code = int(rev << 1), first = int(resume[0]), index = int(resume[1]);
+    for (int l = root + 1; l <= 15; l++) {
+        code |= int((bits >> (l - 1)) & 1u);
+        const int cnt = int(count[l]);
+        if (code - cnt < first) return (uint32_t(sorted[index + (code - first)]) << 4) | uint32_t(l);
+        index += cnt; first += cnt; first <<= 1; code <<= 1;
+    }
+    return 0;
+}
 // counts, canonical symbol order and the root table of one code; returns "left" (0 complete, >0 incomplete, <0 over-subscribed)
-__device__ static int build_code(const uint8_t *lens, int n, uint32_t *count, uint32_t *offs, uint16_t *sorted, uint16_t *root, int rootbits) {
+__device__ static int build_code(const uint8_t *lens, int n, uint32_t *count, uint32_t *offs, uint16_t *sorted, uint16_t *root, int rootbits, uint32_t *resume = nullptr) {
     LFOR(l) if (l < 16) count[l] = 0;
     CSP_WAVE_SYNC();
     LFOR(l) for (int i = l; i < n; i += 64) atomicAdd(&count[lens[i]], 1u);
@@ -55,6 +74,11 @@ __device__ static int build_code(const uint8_t *lens, int n, uint32_t *count, ui
         offs[1] = 0;
         for (int k = 1; k < 15; k++) offs[k + 1] = offs[k] + count[k];
         for (int i = 0; i < n; i++) { const int k = lens[i]; if (k) sorted[offs[k]++] = uint16_t(i); }
+        if (resume) {   // where canon_walk stands behind length `rootbits`
+            int first = 0, index = 0;
+            for (int k = 1; k <= rootbits; k++) { const int cnt = int(count[k]); index += cnt; first += cnt; first <<= 1; }
+            resume[0] = uint32_t(first); resume[1] = uint32_t(index);
+        }
     }
     CSP_WAVE_SYNC();
     // root entries: (symbol << 4) | length, bit 15 set for everything that is not a literal; 0 = longer than the root
@@ -205,9 +229,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
             if (S.lens[256] == 0) { err = CSP_ERR_BAD_PNG; break; }
         }
         {
-            int r = build_code(S.lens, nlen, S.lcount, S.offs, S.lsorted, S.lroot, LROOT);
+            int r = build_code(S.lens, nlen, S.lcount, S.offs, S.lsorted, S.lroot, LROOT, S.lresume);
             if (type == 2 && (r < 0 || (r > 0 && nlen - int(S.lcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }
-            r = build_code(S.lens + 288, ndist, S.dcount, S.offs, S.dsorted, S.droot, DROOT);
+            r = build_code(S.lens + 288, ndist, S.dcount, S.offs, S.dsorted, S.droot, DROOT, S.dresume);
             if (type == 2 && (r < 0 || (r > 0 && ndist - int(S.dcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }   // the fixed distance code is incomplete by definition
         }
         // The symbols, SUB bits per lane and round.  Where a prefix-coded stream is entered matters only for a few tokens: a walk that starts
@@ -247,17 +271,19 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
                 CSP_WAVE_SYNC();
             }
             const uint64_t stage_bit0 = (base >> 5) << 5;
-            // 64 bits of the stream from bit p on (p inside the staged range: at most SUB * 64 + 48 bits behind base)
-            auto bits_at = [&](uint64_t p) __attribute__((always_inline)) -> uint64_t {
-                const uint32_t r = uint32_t(p - stage_bit0), w = r >> 5, sh = r & 31u;
-                const uint64_t lo = (uint64_t(S.stage[w]) | (uint64_t(S.stage[w + 1]) << 32)) >> sh;
-                return sh ? lo | (uint64_t(S.stage[w + 2]) << (64u - sh)) : lo;
+            const uint32_t rbase = uint32_t(base - stage_bit0);   // positions below are relative to the staged copy's first bit (< 2^15)
+            // at least 33 bits of the stream from relative bit r on: enough for a literal / length code with its extra bits and the root
+            // look-up of the distance code behind it
+            auto bits_at = [&](uint32_t r) __attribute__((always_inline)) -> uint64_t {
+                const uint32_t w = r >> 5;
+                return (uint64_t(S.stage[w]) | (uint64_t(S.stage[w + 1]) << 32)) >> (r & 31u);
             };
-            // one token at bit p: kind 0 literal, 1 match, 2 end of block, 3 not a token (error if it is on the true walk)
-            auto token = [&](uint64_t p, uint32_t &kind, uint32_t &tl, uint32_t &val) __attribute__((always_inline)) {
-                const uint64_t b = bits_at(p);
+            // one token at relative bit r: kind 0 literal, 1 match, 2 end of block, 3 not a token (an error if it is on the true walk).
+            // tl: its bits; val: the literal, or the match length (VALUES: length | distance << 16)
+            auto token = [&](uint32_t r, bool values, uint32_t &kind, uint32_t &tl, uint32_t &val) __attribute__((always_inline)) {
+                const uint64_t b = bits_at(r);
                 uint32_t e = S.lroot[uint32_t(b) & ((1u << LROOT) - 1u)];
-                if (!e) e = canon_walk(uint32_t(b) & 0x7FFFu, 15, S.lcount, S.lsorted);
+                if (!e) e = canon_resume(uint32_t(b) & 0x7FFFu, LROOT, S.lcount, S.lsorted, S.lresume);
                 kind = 3; tl = 1; val = 0;
                 if (!e) return;
                 const uint32_t sym = (e >> 4) & 0x1FFu;
@@ -268,48 +294,48 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
                 if (li >= 29) return;
                 const uint32_t eb = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
                 const uint32_t len = (li < 8 ? 3u + li : li == 28 ? 258u : ((4u | (li & 3u)) << eb) + 3u) + (uint32_t(b >> tl) & ((1u << eb) - 1u));
-                tl += eb;
+                tl += eb;   // <= 20
                 uint32_t d = S.droot[uint32_t(b >> tl) & ((1u << DROOT) - 1u)];
-                if (!d) d = canon_walk(uint32_t(b >> tl) & 0x7FFFu, 15, S.dcount, S.dsorted);
+                if (!d) d = canon_resume(uint32_t(bits_at(r + tl)) & 0x7FFFu, DROOT, S.dcount, S.dsorted, S.dresume);
                 const uint32_t ds = (d >> 4) & 0x7FFu;
                 if (!d || ds >= 30) return;
                 const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
                 tl += d & 15u;
-                const uint32_t dist = (ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(b >> tl) & ((1u << deb) - 1u));
+                val = len;
+                if (values) val |= ((ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(bits_at(r + tl)) & ((1u << deb) - 1u))) << 16;
                 tl += deb;
-                kind = 1; val = len | (dist << 16);
+                kind = 1;
             };
-            LV<uint64_t> entry, leave;      // where the lane's walk starts / where the token behind its last one starts
+            LV<uint32_t> entry, leave;      // where the lane's walk starts / where the token behind its last one starts (relative; ~0: nowhere)
             LV<uint32_t> nout, nmat, stopk; // bytes and matches its walk produces; how it ended: 0 ran out of its stretch, 2 end of block, 3 not a token
             LV<uint32_t> redo;
-            LFOR(l) { entry[l] = base + uint64_t(HUFF_SUB) * uint32_t(l); redo[l] = 1; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }
+            LFOR(l) { entry[l] = rbase + uint32_t(HUFF_SUB) * uint32_t(l); redo[l] = 1; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }
             for (int pass = 0; pass < 66; pass++) {
                 LFOR(l) if (redo[l]) {
-                    const uint64_t end = base + uint64_t(HUFF_SUB) * (uint32_t(l) + 1u);
-                    uint64_t p = entry[l];
-                    uint32_t no = 0, nm = 0, sk = 0;
-                    if (p != ~0ull) {
+                    const uint32_t end = rbase + uint32_t(HUFF_SUB) * (uint32_t(l) + 1u);
+                    uint32_t p = entry[l], no = 0, nm = 0, sk = 0;
+                    if (p != ~0u) {
                         while (p < end) {
                             uint32_t kind, tl, val;
-                            token(p, kind, tl, val);
+                            token(p, false, kind, tl, val);
                             if (kind == 3) { sk = 3; break; }
                             p += tl;
                             if (kind == 2) { sk = 2; break; }
-                            if (kind == 1) { no += val & 0xFFFFu; nm++; } else no++;
+                            if (kind == 1) { no += val; nm++; } else no++;
                         }
                     } else sk = 3;   // no entry: the walk in front of it ended the block (or was no walk)
                     leave[l] = p; nout[l] = no; nmat[l] = nm; stopk[l] = sk;
                 }
                 // everyone's new entry: where the left neighbour left off (nowhere, if it stopped)
-                LV<uint64_t> from;
+                LV<uint32_t> from;
 #ifdef CSH_EMUL
-                for (int l = 63; l >= 1; l--) from.v[l] = stopk.v[l - 1] ? ~0ull : leave.v[l - 1];
-                from.v[0] = base;
+                for (int l = 63; l >= 1; l--) from.v[l] = stopk.v[l - 1] ? ~0u : leave.v[l - 1];
+                from.v[0] = rbase;
 #else
                 {
-                    const uint64_t mine = stopk.v ? ~0ull : leave.v;
-                    const uint32_t lo = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(mine)), 0x138, 0xf, 0xf, false)), hi = uint32_t(__builtin_amdgcn_update_dpp(0, int(uint32_t(mine >> 32)), 0x138, 0xf, 0xf, false));   // wave_shr:1
-                    from.v = (threadIdx.x & 63u) ? (uint64_t(hi) << 32) | lo : base;
+                    const uint32_t mine = stopk.v ? ~0u : leave.v;
+                    const uint32_t prev = uint32_t(__builtin_amdgcn_update_dpp(0, int(mine), 0x138, 0xf, 0xf, false));   // wave_shr:1
+                    from.v = (threadIdx.x & 63u) ? prev : rbase;
                 }
 #endif
                 LFOR(l) { redo[l] = from[l] != entry[l] ? 1u : 0u; entry[l] = from[l]; }
@@ -324,24 +350,25 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
             uint32_t tot_out = 0, tot_mat = 0;
             const LV<uint32_t> before = lscan(mo, tot_out);
             const LV<uint32_t> mbefore = lscan(mm, tot_mat);
+            (void)tot_mat;
             // the last pass: literals to their bytes, matches to their records.  Nothing is decoded past the image's last byte: a walk stops
             // in front of the first token that would start there, and what it finds wrong behind that point does not count
-            LV<uint32_t> bad, wrote;
-            LV<uint64_t> pfin;
+            LV<uint32_t> bad, wrote, pfin;
             LFOR(l) {
                 bad[l] = 0; wrote[l] = 0; pfin[l] = 0;
-                if (l < nlanes && entry[l] != ~0ull && pos + before[l] < cap) {
-                    const uint64_t end = base + uint64_t(HUFF_SUB) * (uint32_t(l) + 1u);
-                    uint64_t p = entry[l], at = pos + before[l];
+                if (l < nlanes && entry[l] != ~0u && pos + before[l] < cap) {
+                    const uint32_t end = rbase + uint32_t(HUFF_SUB) * (uint32_t(l) + 1u);
+                    uint32_t p = entry[l];
+                    uint64_t at = pos + before[l];
                     uint32_t mi = mtotal + mbefore[l];
                     while (p < end && at < cap) {
                         uint32_t kind, tl, val;
-                        token(p, kind, tl, val);
+                        token(p, true, kind, tl, val);
                         if (kind == 3) { bad[l] = 1; break; }
                         if (kind == 2) break;
                         if (kind == 1) {
                             const uint32_t len = val & 0xFFFFu, dist = val >> 16;
-                            if (uint64_t(dist) > at || p + tl > limit) { bad[l] = 1; break; }
+                            if (uint64_t(dist) > at || stage_bit0 + p + tl > limit) { bad[l] = 1; break; }
                             mlist[mi++] = (at & 0xFFFFFFFFull) | (uint64_t(len) << 32) | (uint64_t(dist) << 48);
                             at += len;
                         } else out[at++] = uint8_t(val);
@@ -358,12 +385,12 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
             }
             pos += tot_out;
             if (pos >= cap) {   // complete: the stream position is where the last walk that wrote anything stopped
-                const uint64_t started = lballot([&](int l) { return l < nlanes && entry[l] != ~0ull && pos - tot_out + before[l] < cap; });
-                if (started) { rd.bp = lane_of64(pfin, uint32_t(63 - __builtin_clzll(started))); rd.refresh(); }
+                const uint64_t started = lballot([&](int l) { return l < nlanes && entry[l] != ~0u && pos - tot_out + before[l] < cap; });
+                if (started) { rd.bp = stage_bit0 + lane_of(pfin, uint32_t(63 - __builtin_clzll(started))); rd.refresh(); }
                 break;
             }
             if (how == 3) { err = CSP_ERR_BAD_PNG; break; }   // the true walk met something that is no token
-            rd.bp = lane_of64(leave, uint32_t(nlanes - 1));
+            rd.bp = stage_bit0 + lane_of(leave, uint32_t(nlanes - 1));
             rd.refresh();
             if (how == 2) block_done = true;
         }
