@@ -522,21 +522,36 @@ __device__ __forceinline__ static int paeth(int a, int b, int c) {
     const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
+// A row filtered with None or Sub does not look at the row above it, so the rows of an image fall into independent runs that start at
+// such rows (and at row 0).  Wave k of a job takes the runs that START in rows [64 k, 64 k + 64): from the first such row there up to the
+// first one at or behind row 64 (k + 1).  An image written with adaptive filters has hundreds of runs; one filtered with Paeth throughout
+// has one, and wave 0 walks it alone as before.
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass *jobs, int njobs, uint8_t *work, uint32_t *status) {
-    if (int(blockIdx.x) >= njobs) return;
-    const PngPass job = jobs[blockIdx.x];
+    if (int(blockIdx.y) >= njobs) return;
+    const PngPass job = jobs[blockIdx.y];
     const int image = int(job.image);
     if (status[image]) return;
     const uint8_t *src = work + job.src_off;
     uint8_t *dst = work + job.dst_off;
     const uint32_t W = job.rowbytes, bpp = job.bpp, npx = W / bpp, H = job.height;
+    const uint32_t band0 = blockIdx.x * 64u;
+    if (band0 >= H) return;
+    // first row of a run in this wave's band; first row of a run at or behind the band's end
+    auto run_start_in = [&](uint32_t r0) __attribute__((always_inline)) -> uint32_t {   // first y in [r0, r0 + 64) that starts a run, or ~0
+        const uint64_t m = lballot([&](int l) { const uint32_t y = r0 + uint32_t(l); return y < H && (y == 0 || src[uint64_t(y) * (W + 1)] <= 1u); });
+        return m ? r0 + uint32_t(__builtin_ctzll(m)) : ~0u;
+    };
+    const uint32_t ys = run_start_in(band0);
+    if (ys == ~0u) return;
+    uint32_t ye = H;
+    for (uint32_t r0 = band0 + 64u; r0 < H; r0 += 64) { const uint32_t f = run_start_in(r0); if (f != ~0u) { ye = f; break; } }
     bool bad = false;
-    for (uint32_t y0 = 0; y0 < H; y0 += 64) {
+    for (uint32_t y0 = ys; y0 < ye; y0 += 64) {
         LV<uint32_t> ft;
         LV<uint64_t> a, c, mine;   // left, upper-left, this row's latest pixel (bytes packed little-endian)
-        LFOR(l) { const uint32_t y = y0 + uint32_t(l); ft[l] = y < H ? src[uint64_t(y) * (W + 1)] : 0u; a[l] = 0; c[l] = 0; mine[l] = 0; }
+        LFOR(l) { const uint32_t y = y0 + uint32_t(l); ft[l] = y < ye ? src[uint64_t(y) * (W + 1)] : 0u; a[l] = 0; c[l] = 0; mine[l] = 0; }
         if (lballot([&](int l) { return ft[l] > 4u; })) { bad = true; break; }
-        if (y0) CSP_MEM_FENCE();   // the band above was written by this wave
+        if (y0 > ys) CSP_MEM_FENCE();   // the band above was written by this wave
         for (uint32_t t = 0; t < npx + 63; t++) {
             // what the row above produced one step ago is the pixel above this lane's current pixel
             LV<uint64_t> up;
@@ -551,9 +566,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
 #endif
             LFOR(l) {
                 const uint32_t y = y0 + uint32_t(l), i = t - uint32_t(l);
-                if (y < H && t >= uint32_t(l) && i < npx) {
+                if (y < ye && t >= uint32_t(l) && i < npx) {
                     uint64_t b = up[l];
-                    if (l == 0 && y0) { b = 0; for (uint32_t k = 0; k < bpp; k++) b |= uint64_t(coherent_load(dst + uint64_t(y - 1) * W + uint64_t(i) * bpp + k)) << (8 * k); }
+                    if (l == 0 && y0 > ys) { b = 0; for (uint32_t k = 0; k < bpp; k++) b |= uint64_t(coherent_load(dst + uint64_t(y - 1) * W + uint64_t(i) * bpp + k)) << (8 * k); }
                     const uint8_t *f = src + uint64_t(y) * (W + 1) + 1 + uint64_t(i) * bpp;
                     uint64_t o = 0;
                     for (uint32_t k = 0; k < bpp; k++) {
@@ -581,8 +596,8 @@ void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint
     CSH_LAUNCH(k_png_huff, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, idat, raw, matches, nmatch, status);
     CSH_LAUNCH(k_png_lz77, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, raw, matches, nmatch, status);
 }
-void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint8_t *work, uint32_t *status) {
-    if (njobs) CSH_LAUNCH(k_png_unfilter, dim3(njobs), dim3(CSP_WAVE_THREADS), st, jobs, njobs, work, status);
+void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint32_t max_height, uint8_t *work, uint32_t *status) {
+    if (njobs && max_height) CSH_LAUNCH(k_png_unfilter, dim3((max_height + 63) / 64, unsigned(njobs)), dim3(CSP_WAVE_THREADS), st, jobs, njobs, work, status);
 }
 
 // ---- Adam7: every pixel of the image gathers itself out of the pass it belongs to (no scatter, so sub-byte samples need no

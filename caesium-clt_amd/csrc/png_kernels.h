@@ -8,7 +8,7 @@ namespace csp {
 
 // P1: IDAT zlib stream -> filtered rows -> pixels (k_png_inflate.hip)
 void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status);
-void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint8_t *work, uint32_t *status);   // one job per image, seven per Adam7 image
+void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint32_t max_height, uint8_t *work, uint32_t *status);   // one job per image, seven per Adam7 image
 void launch_png_deinterlace(hipStream_t st, const PngImg *imgs, const PngAdam7 *jobs, int njobs, uint64_t max_items, uint8_t *work, const uint32_t *status);
 
 // P2: reductions (k_png_filter.hip).  flags[image] starts as the reductions the format allows (1: 16 -> 8 bits, 2: drop an

@@ -723,7 +723,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     auto mark = [&]() { (void)hipEventRecord(b->ev[k++], st); };
     mark(); if (!b->reduced && !b->from_pixels) launch_png_inflate(st, b->d_imgs.p, nimg, b->d_idat.p, b->d_work.p, reinterpret_cast<uint64_t *>(b->d_streams.p), b->d_nmatch.p, b->d_status.p);
     mark(); if (!b->reduced && !b->from_pixels) {
-        launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), b->d_work.p, b->d_status.p);
+        { uint32_t mh = 0; for (const PngPass &pp : b->passes) mh = std::max(mh, pp.height); launch_png_unfilter(st, b->d_passes.p, int(b->passes.size()), mh, b->d_work.p, b->d_status.p); }
         launch_png_deinterlace(st, b->d_imgs.p, b->d_adam7.p, int(b->adam7.size()), b->adam7_items, b->d_work.p, b->d_status.p);
     }
     if (b->decode_only) {
