@@ -304,7 +304,7 @@ def main():
                 wdom = max(range(len(names)), key=lambda i: wtm.kernel_ms[i])
                 other["configs[3] JPEG -> WebP q85 long edge 1500"] = {
                     "files": nweb, "value": round(nweb * 2.0736 / (wtm.total_ms / 1e3), 1), "unit": "source MP/s", "device_ms": round(wtm.total_ms, 1), "out_bytes": int(wtm.out_bytes),
-                    "dominant_slot": "WebP tail (Lanczos, RGB -> YUV, k_webp_mb, k_webp_stats, k_webp_code: one timing slot; split in profiles/r02_webp_kernel_stats_batch256.csv)",
+                    "dominant_slot": "WebP tail (Lanczos, RGB -> YUV, k_webp_mb, k_webp_stats, k_webp_code: one timing slot; split in profiles/r02_webp_kernel_stats_batch1024.csv)",
                     "dominant_ms": round(wtm.kernel_ms[wdom], 1)}
                 wb.close()
             except Exception as e:
