@@ -59,32 +59,48 @@ __global__ void __launch_bounds__(256) k_planes_to_rgb(const ImgDesc *imgs, cons
     o[2] = uint8_t(b < 0 ? 0 : b > 255 ? 255 : b);
 }
 
-// vertical pass: tmp[oy][x][c] = sum_i src[left+i][x][c] * w[i]      (f32, no clamp)
+// vertical pass: tmp[oy][x][c] = sum_i src[left+i][x][c] * w[i]      (f32, no clamp).  A workgroup is a piece of ONE output row, so the
+// row's taps and weights are scalar loads; a lane takes four consecutive samples (one dword load per tap, four accumulators in the
+// order image-rs adds them)
 __global__ void __launch_bounds__(256) k_lanczos_v(const ImgDesc *imgs, const ResizeWork *work, const ResizeTap *taps, const float *weights,
                                                     const uint8_t *rgb, float *tmp) {
-    const ResizeWork w = work[blockIdx.y];
+    const ResizeWork w = work[blockIdx.z];
     const ImgDesc &im = imgs[w.image];
-    const int rowlen = im.width * im.ncomp;   // samples per source row
-    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= size_t(w.nh) * rowlen) return;
-    int oy = int(i / rowlen), xc = int(i - size_t(oy) * rowlen);
+    const uint32_t rowlen = uint32_t(im.width) * uint32_t(im.ncomp);   // samples per source row
+    const uint32_t oy = blockIdx.y, xc = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (oy >= uint32_t(w.nh) || xc >= rowlen) return;
     const ResizeTap t = taps[w.vtap_base + oy];
     const float *ws = weights + t.woff;
     const uint8_t *s = rgb + w.rgb_src_off + size_t(t.left) * rowlen + xc;
-    float acc = 0.0f;
-    for (int k = 0; k < t.n; k++) acc = __fadd_rn(acc, __fmul_rn(float(s[size_t(k) * rowlen]), ws[k]));
-    tmp[w.tmp_off + i] = acc;
+    float *o = tmp + w.tmp_off + size_t(oy) * rowlen + xc;
+    if (xc + 4 <= rowlen) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        for (int k = 0; k < t.n; k++) {
+            uint32_t v;
+            memcpy(&v, s + size_t(k) * rowlen, 4);   // a row need not start on a word
+            const float wk = ws[k];
+            a0 = __fadd_rn(a0, __fmul_rn(float(v & 255u), wk)); a1 = __fadd_rn(a1, __fmul_rn(float((v >> 8) & 255u), wk));
+            a2 = __fadd_rn(a2, __fmul_rn(float((v >> 16) & 255u), wk)); a3 = __fadd_rn(a3, __fmul_rn(float(v >> 24), wk));
+        }
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+    } else {
+        for (uint32_t j = 0; xc + j < rowlen; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < t.n; k++) acc = __fadd_rn(acc, __fmul_rn(float(s[size_t(k) * rowlen + j]), ws[k]));
+            o[j] = acc;
+        }
+    }
 }
 
-// horizontal pass: dst[y][ox][c] = round(clamp(sum_i tmp[y][left+i][c] * w[i]))
+// horizontal pass: dst[y][ox][c] = round(clamp(sum_i tmp[y][left+i][c] * w[i])); a workgroup is a piece of one row
 __global__ void __launch_bounds__(256) k_lanczos_h(const ImgDesc *imgs, const ResizeWork *work, const ResizeTap *taps, const float *weights,
                                                     const float *tmp, uint8_t *rgb) {
-    const ResizeWork w = work[blockIdx.y];
+    const ResizeWork w = work[blockIdx.z];
     const ImgDesc &im = imgs[w.image];
-    const int nc = im.ncomp, rowlen_in = im.width * nc, rowlen_out = w.nw * nc;
-    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= size_t(w.nh) * rowlen_out) return;
-    int y = int(i / rowlen_out), r = int(i - size_t(y) * rowlen_out), ox = r / nc, c = r - ox * nc;
+    const uint32_t nc = uint32_t(im.ncomp), rowlen_in = uint32_t(im.width) * nc, rowlen_out = uint32_t(w.nw) * nc;
+    const uint32_t y = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= uint32_t(w.nh) || r >= rowlen_out) return;
+    const uint32_t ox = nc == 3 ? r / 3u : nc == 1 ? r : r / nc, c = r - ox * nc;
     const ResizeTap t = taps[w.htap_base + ox];
     const float *ws = weights + t.woff;
     const float *s = tmp + w.tmp_off + size_t(y) * rowlen_in + size_t(t.left) * nc + c;
@@ -93,7 +109,7 @@ __global__ void __launch_bounds__(256) k_lanczos_h(const ImgDesc *imgs, const Re
     acc = acc < 0.0f ? 0.0f : (acc > 255.0f ? 255.0f : acc);
     int q = int(acc);                                     // round half away from zero (acc >= 0), without the
     q += (acc - float(q) >= 0.5f) ? 1 : 0;                // double rounding of int(acc + 0.5f)
-    rgb[w.rgb_dst_off + i] = uint8_t(q);
+    rgb[w.rgb_dst_off + size_t(y) * rowlen_out + r] = uint8_t(q);
 }
 
 // RGB -> full-resolution component planes (jccolor.c rgb_ycc_convert); pitch = the luma plane's padded width
@@ -113,11 +129,12 @@ __global__ void __launch_bounds__(256) k_rgb_to_planes(const ImgDesc *imgs, cons
 }
 
 void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, int nwork, const ResizeTap *taps, const float *weights,
-                   uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst) {
+                   uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst, uint32_t max_row_in, uint32_t max_row_out, uint32_t max_nh) {
+    (void)max_tmp;
     if (!nwork) return;
     CSH_LAUNCH(k_planes_to_rgb, dim3((max_src_px + 255) / 256, nwork), dim3(256), st, imgs, work, planes, rgb);
-    CSH_LAUNCH(k_lanczos_v, dim3(unsigned((max_tmp + 255) / 256), nwork), dim3(256), st, imgs, work, taps, weights, rgb, tmp);
-    CSH_LAUNCH(k_lanczos_h, dim3(unsigned((max_dst + 255) / 256), nwork), dim3(256), st, imgs, work, taps, weights, tmp, rgb);
+    CSH_LAUNCH(k_lanczos_v, dim3((max_row_in + 1023) / 1024, max_nh, nwork), dim3(256), st, imgs, work, taps, weights, rgb, tmp);
+    CSH_LAUNCH(k_lanczos_h, dim3((max_row_out + 255) / 256, max_nh, nwork), dim3(256), st, imgs, work, taps, weights, tmp, rgb);
     CSH_LAUNCH(k_rgb_to_planes, dim3(unsigned((max_dst + 255) / 256), nwork), dim3(256), st, imgs, work, rgb, planes);
 }
 
