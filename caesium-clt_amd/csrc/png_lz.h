@@ -95,7 +95,11 @@ __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t st
         // of up to eight bytes is taken only if the literals it replaces cost more than it does (a code pair + the distance's extra bits)
         LFOR(l) for (uint32_t i = uint32_t(l); i < 256; i += 64) L.cnt[i] = 0;
         CSP_WAVE_SYNC();
-        for (uint64_t p0 = start; p0 < end; p0 += 64) LFOR(l) { const uint64_t p = p0 + uint32_t(l); if (p < end) atomicAdd(&L.cnt[data[p]], 1u); }
+        for (uint64_t p0 = start; p0 < end; p0 += 512) LFOR(l) {   // eight bytes per lane and step
+            const uint64_t p = p0 + uint32_t(l) * 8u;
+            if (p + 8 <= end) { const uint64_t v = load64u(data + p); CSH_UNROLL for (int k = 0; k < 8; k++) atomicAdd(&L.cnt[uint32_t(v >> (8 * k)) & 255u], 1u); }
+            else for (uint64_t q = p; q < end; q++) atomicAdd(&L.cnt[data[q]], 1u);
+        }
         CSP_WAVE_SYNC();
         const uint32_t total = uint32_t(end - start);
         LFOR(l) for (uint32_t i = uint32_t(l); i < 256; i += 64) {
@@ -143,13 +147,26 @@ __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t st
                     hashable[l] = 1;
                     hash[l] = lz_hash(uint32_t(hi));
                     const uint64_t b = L.bucket[hash[l]];
+                    // the candidates' first eight bytes are fetched together (independent loads, one round trip to the L2 instead of one
+                    // per candidate); the order of evaluation, and with it every tie, stays the serial statement's
+                    uint32_t dw[CSP_WAYS];
+                    uint64_t xw[CSP_WAYS];
+                    int nw = 0;
                     for (int w = 0; w < int(CSP_WAYS); w++) {
                         const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;
                         if (r == 0xFFFFu) break;
                         const uint32_t d = rel[l] - r;
                         if (d > 32768u) break;
-                        const uint32_t ln = lz_lcp(data, p, d, maxlen, 0);
-                        if (ln > bl) { bl = ln; bd = d; }
+                        dw[nw++] = d;
+                    }
+                    CSH_UNROLL
+                    for (int w = 0; w < int(CSP_WAYS); w++) xw[w] = w < nw ? hi ^ load64u(data + p - dw[w]) : 0ull;
+                    CSH_UNROLL
+                    for (int w = 0; w < int(CSP_WAYS); w++) if (w < nw) {
+                        uint32_t ln;
+                        if (xw[w]) { ln = ctz64(xw[w]) >> 3; if (ln > maxlen) ln = maxlen; }
+                        else ln = maxlen > 8 ? lz_lcp(data, p, dw[w], maxlen, 8) : maxlen;
+                        if (ln > bl) { bl = ln; bd = dw[w]; }
                     }
                 }
                 if (bl < 3 || (bl == 3 && bd > 8)) { bl = 0; bd = 0; }
