@@ -164,3 +164,17 @@ def test_adam7_inputs_decode_like_libpng():
         assert out == inter or not got.info.get("interlace")   # a tiny file may come back unchanged ("already optimised")
         if mode != "I;16":
             assert np.array_equal(np.asarray(got.convert("RGBA")), np.asarray(ref.convert("RGBA")))
+
+
+@pytest.mark.parametrize("rel", ["p0.png", "level_1_0/level_2_0/p2.png"])
+def test_reference_samples_decode_like_libpng_and_recode_losslessly(reference_samples, rel):
+    """the reference's own PNG samples (tests/golden/reference_samples): the oracle decodes them to libpng's rows, and what it writes for
+    them under --lossless decodes, in libpng, to the same pixels -- never larger than the input"""
+    import os
+    data = open(os.path.join(reference_samples, rel), "rb").read()
+    im = PIL.open(io.BytesIO(data)); im.load()
+    assert np.array_equal(O.png_decode(data).rows(), np.asarray(im).reshape(im.size[1], -1))
+    for level in (1, 3):
+        out = O.png_optimize(data, level, False)[0]
+        back = PIL.open(io.BytesIO(out)); back.load()
+        assert len(out) <= len(data) and np.array_equal(np.asarray(back.convert(im.mode)), np.asarray(im))

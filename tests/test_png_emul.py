@@ -149,3 +149,25 @@ def agree_with_oracle(api, blobs, level=1):
 
 def test_damaged_files_are_refused_or_decoded_like_the_oracle(api):
     assert agree_with_oracle(api, damaged_pngs(1, 160)) == 0
+
+
+def test_emul_reference_sample_pngs(api, reference_samples):
+    """samples/p0.png and level_2_0/p2.png through the device pipeline: the oracle's bytes, libpng's pixels"""
+    import io, os
+    import numpy as np
+    from PIL import Image
+    from _util import oracle_png, package
+    for rel in ("p0.png", "level_1_0/level_2_0/p2.png"):
+        data = open(os.path.join(reference_samples, rel), "rb").read()
+        out = api.compress_in_memory(data, package().default_parameters(png_optimize=True, png_optimization_level=3))
+        assert out == oracle_png(data, 3)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(out)).convert("RGB")), np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+
+
+def test_emul_zopfli_is_refused_loudly(api):
+    from _util import package, png_cases
+    png = dict(png_cases())["RGB_97x61"]
+    with pytest.raises(Exception) as e:
+        api.compress_in_memory(png, package().default_parameters(png_optimize=True, png_force_zopfli=True))
+    assert e.value.code == 10201 and "zopfli" in str(e.value)
+    assert isinstance(api.compress_in_memory(png, package().default_parameters(png_optimize=True)), bytes)

@@ -98,3 +98,8 @@ def test_full_size_batch_by_properties(api):
 def test_damaged_files_are_refused_or_decoded_like_the_oracle(api):
     from test_png_emul import agree_with_oracle, damaged_pngs
     assert agree_with_oracle(api, damaged_pngs(2, 640)) == 0
+
+
+def test_reference_sample_pngs(api, reference_samples):
+    import test_png_emul as E
+    E.test_emul_reference_sample_pngs(api, reference_samples)
