@@ -21,7 +21,14 @@
 
 namespace csp {
 
-enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_STAGE_WORDS = HUFF_SUB * 64 / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
+#ifdef CSH_EMUL
+enum { HUFF_WAVES = 1 };   // the emulation plays one wave: the same code, the hand-overs between waves degenerate
+#define HUFF_BARRIER() ((void)0)
+#else
+enum { HUFF_WAVES = 4 };
+#define HUFF_BARRIER() __syncthreads()
+#endif
+enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
@@ -30,6 +37,13 @@ struct InflateLds {
     uint8_t lens[320];
     uint32_t stage[HUFF_STAGE_WORDS];   // k_png_huff: the round's stretch of the stream
     uint32_t lresume[2], dresume[2];    // canon_resume's starting point for codes longer than the root tables
+    // k_png_huff, between its waves (the first wave decides, all waves act: see the kernel)
+    uint32_t cmd, any, nlanes, bad;
+    uint32_t rbase;                      // the round's first bit, relative to the staged copy
+    uint64_t stage_bit0, pos, limit;     // the staged copy's first bit in the stream; bytes produced in front of the round; the stream's bits
+    uint32_t mtotal;
+    uint32_t leave[HUFF_LANES], stopk[HUFF_LANES];
+    uint32_t wfirst[HUFF_WAVES], wout[HUFF_WAVES], wmat[HUFF_WAVES], woff[HUFF_WAVES], wmoff[HUFF_WAVES], wwrote[HUFF_WAVES], wlast[HUFF_WAVES], wpfin[HUFF_WAVES];
 };
 
 // canonical walk over the low bits of `bits` (LSB first), at most maxlen of them: (sym << 4) | len, or 0
@@ -152,16 +166,170 @@ struct PosReader {
     __device__ __forceinline__ bool overrun() const { return bp > uint64_t(len) * 8u; }
 };
 
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status) {
+__global__ void __launch_bounds__(CSP_WAVE_THREADS * HUFF_WAVES) k_png_huff(const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status) {
     CSH_SHARED InflateLds S;
     const int image = blockIdx.x;
     if (image >= nimg) return;
-    LFOR(l) if (l == 0) nmatch[image] = 0;
+#ifdef CSH_EMUL
+    const uint32_t wv = 0;
+#else
+    const uint32_t wv = threadIdx.x >> 6;
+#endif
+    if (wv == 0) LFOR(l) if (l == 0) nmatch[image] = 0;
     if (status[image]) return;
     const PngImg im = imgs[image];
     uint8_t *out = raw + im.inflate_off;
     uint64_t *mlist = matches + im.match_off;
     const uint64_t cap = im.inflate_len;
+    const uint8_t *sbase = idat + im.idat_off;
+    const uint32_t slen = im.idat_len;
+    // ---- what every wave does when told to (HUFF_LANES lanes walk HUFF_LANES stretches; lane g = 64 wv + l)
+    LV<uint32_t> entry, leave, nout, nmat, stopk, redo, before, mbefore;   // a lane's state over the passes of a round
+    LFOR(l) { entry[l] = 0; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; redo[l] = 0; before[l] = 0; mbefore[l] = 0; }
+    enum { CMD_EXIT = 0, CMD_STAGE, CMD_WALK, CMD_LINK, CMD_STOP, CMD_SUM, CMD_WRITE };
+    auto lane_of = [&](const LV<uint32_t> &v, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+#ifdef CSH_EMUL
+        return v.v[i];
+#else
+        return uint32_t(__builtin_amdgcn_readlane(int(v.v), int(i)));
+#endif
+    };
+    // at least 33 bits of the stream from relative bit r on
+    auto bits_at = [&](uint32_t r) __attribute__((always_inline)) -> uint64_t {
+        const uint32_t w = r >> 5;
+        return (uint64_t(S.stage[w]) | (uint64_t(S.stage[w + 1]) << 32)) >> (r & 31u);
+    };
+    // one token at relative bit r: kind 0 literal, 1 match, 2 end of block, 3 not a token (an error if it is on the true walk).
+    // tl: its bits; val: the literal, or the match length (VALUES: length | distance << 16)
+    auto token = [&](uint32_t r, bool values, uint32_t &kind, uint32_t &tl, uint32_t &val) __attribute__((always_inline)) {
+        const uint64_t b = bits_at(r);
+        uint32_t e = S.lroot[uint32_t(b) & ((1u << LROOT) - 1u)];
+        if (!e) e = canon_resume(uint32_t(b) & 0x7FFFu, LROOT, S.lcount, S.lsorted, S.lresume);
+        kind = 3; tl = 1; val = 0;
+        if (!e) return;
+        const uint32_t sym = (e >> 4) & 0x1FFu;
+        tl = e & 15u;
+        if (sym < 256) { kind = 0; val = sym; return; }
+        if (sym == 256) { kind = 2; return; }
+        const uint32_t li = sym - 257;
+        if (li >= 29) return;
+        const uint32_t eb = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
+        const uint32_t len = (li < 8 ? 3u + li : li == 28 ? 258u : ((4u | (li & 3u)) << eb) + 3u) + (uint32_t(b >> tl) & ((1u << eb) - 1u));
+        tl += eb;   // <= 20
+        uint32_t d = S.droot[uint32_t(b >> tl) & ((1u << DROOT) - 1u)];
+        if (!d) d = canon_resume(uint32_t(bits_at(r + tl)) & 0x7FFFu, DROOT, S.dcount, S.dsorted, S.dresume);
+        const uint32_t ds = (d >> 4) & 0x7FFu;
+        if (!d || ds >= 30) return;
+        const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
+        tl += d & 15u;
+        val = len;
+        if (values) val |= ((ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(bits_at(r + tl)) & ((1u << deb) - 1u))) << 16;
+        tl += deb;
+        kind = 1;
+    };
+    auto act = [&](uint32_t cmd) __attribute__((always_inline)) {
+        const uint32_t rbase = S.rbase;
+        if (cmd == CMD_STAGE) {   // the round's stretch of the stream -> LDS (zero behind the stream's end); every lane's first guess
+            const uint64_t b0 = S.stage_bit0 >> 3;
+            LFOR(l) for (uint32_t i = 64u * wv + uint32_t(l); i < uint32_t(HUFF_STAGE_WORDS); i += uint32_t(HUFF_LANES)) {
+                const uint64_t at = b0 + uint64_t(i) * 4u;
+                uint32_t w = 0;
+                if (at + 4 <= slen) w = *reinterpret_cast<const uint32_t *>(sbase + at);
+                else for (int k = 0; k < 4; k++) if (at + uint32_t(k) < slen) w |= uint32_t(sbase[at + uint32_t(k)]) << (8 * k);
+                S.stage[i] = w;
+            }
+            LFOR(l) { entry[l] = rbase + uint32_t(HUFF_SUB) * (64u * wv + uint32_t(l)); redo[l] = 1; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }
+        } else if (cmd == CMD_WALK) {   // the lanes whose entry moved walk their stretch; everyone publishes where its walk left off
+            LFOR(l) {
+                if (redo[l]) {
+                    const uint32_t end = rbase + uint32_t(HUFF_SUB) * (64u * wv + uint32_t(l) + 1u);
+                    uint32_t p = entry[l], no = 0, nm = 0, sk = 0;
+                    if (p != ~0u) {
+                        while (p < end) {
+                            uint32_t kind, tl, val;
+                            token(p, false, kind, tl, val);
+                            if (kind == 3) { sk = 3; break; }
+                            p += tl;
+                            if (kind == 2) { sk = 2; break; }
+                            if (kind == 1) { no += val; nm++; } else no++;
+                        }
+                    } else sk = 3;   // no entry: the walk in front of it ended the block (or was no walk)
+                    leave[l] = p; nout[l] = no; nmat[l] = nm; stopk[l] = sk;
+                }
+                S.leave[64u * wv + uint32_t(l)] = stopk[l] ? ~0u : leave[l];
+            }
+        } else if (cmd == CMD_LINK) {   // everyone's new entry: where the left neighbour left off (nowhere, if it stopped)
+            LFOR(l) {
+                const uint32_t g = 64u * wv + uint32_t(l);
+                const uint32_t from = g ? S.leave[g - 1] : rbase;
+                redo[l] = from != entry[l] ? 1u : 0u;
+                entry[l] = from;
+            }
+            if (lballot([&](int l) { return redo[l] != 0u; })) LFOR(l) if (l == 0) S.any = 1;
+        } else if (cmd == CMD_STOP) {   // the first lane of this wave whose walk stopped (64: none)
+            const uint64_t st = lballot([&](int l) { return stopk[l] != 0u; });
+            LFOR(l) { S.stopk[64u * wv + uint32_t(l)] = stopk[l]; S.leave[64u * wv + uint32_t(l)] = leave[l]; if (l == 0) S.wfirst[wv] = st ? uint32_t(__builtin_ctzll(st)) : 64u; }   // leave: as it is, the stopped walks' too
+        } else if (cmd == CMD_SUM) {   // bytes and matches of the lanes on the true walk: scans inside the wave, totals for the first wave to add up
+            const uint32_t nl = S.nlanes;
+            LV<uint32_t> mo, mm;
+            LFOR(l) { const bool on = 64u * wv + uint32_t(l) < nl; mo[l] = on ? nout[l] : 0u; mm[l] = on ? nmat[l] : 0u; }
+            uint32_t to = 0, tm = 0;
+            before = lscan(mo, to);
+            mbefore = lscan(mm, tm);
+            LFOR(l) if (l == 0) { S.wout[wv] = to; S.wmat[wv] = tm; }
+        } else if (cmd == CMD_WRITE) {   // literals to their bytes, matches to their records.  Nothing is decoded past the image's last byte
+            const uint32_t nl = S.nlanes, mt = S.mtotal + S.wmoff[wv];
+            const uint64_t p0 = S.pos + S.woff[wv], limit = S.limit, sb0 = S.stage_bit0;
+            LV<uint32_t> badl, wrote, pfin, started;
+            LFOR(l) {
+                badl[l] = 0; wrote[l] = 0; pfin[l] = 0; started[l] = 0;
+                const uint32_t g = 64u * wv + uint32_t(l);
+                if (g < nl && entry[l] != ~0u && p0 + before[l] < cap) {
+                    started[l] = 1;
+                    const uint32_t end = rbase + uint32_t(HUFF_SUB) * (g + 1u);
+                    uint32_t p = entry[l];
+                    uint64_t at = p0 + before[l];
+                    uint32_t mi = mt + mbefore[l];
+                    while (p < end && at < cap) {
+                        uint32_t kind, tl, val;
+                        token(p, true, kind, tl, val);
+                        if (kind == 3) { badl[l] = 1; break; }
+                        if (kind == 2) break;
+                        if (kind == 1) {
+                            const uint32_t len = val & 0xFFFFu, dist = val >> 16;
+                            if (uint64_t(dist) > at || sb0 + p + tl > limit) { badl[l] = 1; break; }
+                            mlist[mi++] = (at & 0xFFFFFFFFull) | (uint64_t(len) << 32) | (uint64_t(dist) << 48);
+                            at += len;
+                        } else out[at++] = uint8_t(val);
+                        p += tl;
+                    }
+                    wrote[l] = mi - (mt + mbefore[l]); pfin[l] = p;
+                }
+            }
+            if (lballot([&](int l) { return badl[l] != 0u; })) LFOR(l) if (l == 0) S.bad = 1;
+            uint32_t nw = 0;
+            (void)lscan(wrote, nw);
+            const uint64_t sm = lballot([&](int l) { return started[l] != 0u; });
+            const uint32_t lastl = sm ? uint32_t(63 - __builtin_clzll(sm)) : 64u;
+            const uint32_t pf = sm ? lane_of(pfin, lastl) : 0u;
+            LFOR(l) if (l == 0) { S.wwrote[wv] = nw; S.wlast[wv] = lastl; S.wpfin[wv] = pf; }
+        }
+    };
+    if (wv != 0) {   // the other waves: told what to do between two barriers, until told to leave
+        for (;;) {
+            HUFF_BARRIER();
+            const uint32_t cmd = uni(S.cmd);
+            if (cmd == CMD_EXIT) return;
+            act(cmd);
+            HUFF_BARRIER();
+        }
+    }
+    auto run = [&](uint32_t cmd) __attribute__((always_inline)) {   // first wave: publish the command, act on it with everyone, meet again
+        LFOR(l) if (l == 0) S.cmd = cmd;
+        HUFF_BARRIER();
+        act(cmd);
+        HUFF_BARRIER();
+    };
     PosReader rd;
     rd.begin(idat + im.idat_off, im.idat_len, 16);   // the host checked the two zlib header bytes
     uint64_t pos = 0;
@@ -234,167 +402,52 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_huff(const PngImg *img
             r = build_code(S.lens + 288, ndist, S.dcount, S.offs, S.dsorted, S.droot, DROOT, S.dresume);
             if (type == 2 && (r < 0 || (r > 0 && ndist - int(S.dcount[0]) != 1))) { err = CSP_ERR_BAD_PNG; break; }   // the fixed distance code is incomplete by definition
         }
-        // The symbols, SUB bits per lane and round.  Where a prefix-coded stream is entered matters only for a few tokens: a walk that starts
-        // at a wrong bit falls into step with the true one after a handful of codes.  So every lane walks its own stretch of the block --
-        // lane l the tokens that start in [base + l SUB, base + (l + 1) SUB) -- first from the stretch's first bit (a guess; lane 0's is
-        // the truth), then from where its left neighbour's walk actually left off, again and again until no lane's entry moves (two or
-        // three passes; each only for the lanes whose entry moved).  Then the walks are the block's token sequence cut in 64: a prefix sum
-        // of what each produces gives every lane its place in the output and in the match list, and a last pass writes.  The stretches of
-        // a round come from an LDS copy of the stream (one coalesced load per round instead of one dependent load per token).
-        auto lane_of = [&](const LV<uint32_t> &v, uint32_t i) __attribute__((always_inline)) -> uint32_t {
-#ifdef CSH_EMUL
-            return v.v[i];
-#else
-            return uint32_t(__builtin_amdgcn_readlane(int(v.v), int(i)));
-#endif
-        };
-        auto lane_of64 = [&](const LV<uint64_t> &v, uint32_t i) __attribute__((always_inline)) -> uint64_t {
-#ifdef CSH_EMUL
-            return v.v[i];
-#else
-            return (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v.v >> 32)), int(i)))) << 32) | uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v.v)), int(i)));
-#endif
-        };
+        // The symbols, HUFF_SUB bits per lane and round.  Where a prefix-coded stream is entered matters only for a few tokens: a walk that
+        // starts at a wrong bit falls into step with the true one after a handful of codes.  So every lane of every wave walks its own
+        // stretch of the block -- lane g the tokens that start in [base + g SUB, base + (g + 1) SUB) -- first from the stretch's first bit
+        // (a guess; lane 0's is the truth), then from where its left neighbour's walk actually left off, again and again until no lane's
+        // entry moves (a handful of passes; each only for the lanes whose entry moved).  Then the walks are the block's token sequence cut
+        // in HUFF_LANES: prefix sums of what each produces give every lane its place in the output and in the match list, and a last
+        // pass writes.  This wave decides and does the serial parts (headers, tables, sums over the waves); act() is what all waves do.
         bool block_done = false;
         while (!block_done && !err && pos < cap) {
             if (rd.overrun()) { err = CSP_ERR_BAD_PNG; break; }
-            const uint64_t base = rd.bp, limit = uint64_t(rd.len) * 8u;
-            {   // bytes [base / 8 rounded down to a word, + SUB * 64 / 8 + slack) -> LDS, zero behind the stream's end
-                const uint64_t b0 = (base >> 5) << 2;
-                LFOR(l) for (uint32_t i = uint32_t(l); i < HUFF_STAGE_WORDS; i += 64) {
-                    const uint64_t at = b0 + uint64_t(i) * 4u;
-                    uint32_t w = 0;
-                    if (at + 4 <= rd.len) w = *reinterpret_cast<const uint32_t *>(rd.base + at);
-                    else for (int k = 0; k < 4; k++) if (at + uint32_t(k) < rd.len) w |= uint32_t(rd.base[at + uint32_t(k)]) << (8 * k);
-                    S.stage[i] = w;
-                }
-                CSP_WAVE_SYNC();
+            const uint64_t base = rd.bp, stage_bit0 = (base >> 5) << 5;
+            LFOR(l) if (l == 0) { S.rbase = uint32_t(base - stage_bit0); S.stage_bit0 = stage_bit0; S.pos = pos; S.mtotal = mtotal; S.limit = uint64_t(rd.len) * 8u; S.bad = 0; }
+            run(CMD_STAGE);
+            for (int pass = 0; pass < HUFF_LANES + 2; pass++) {
+                run(CMD_WALK);
+                LFOR(l) if (l == 0) S.any = 0;
+                run(CMD_LINK);
+                if (!uni(S.any)) break;
             }
-            const uint64_t stage_bit0 = (base >> 5) << 5;
-            const uint32_t rbase = uint32_t(base - stage_bit0);   // positions below are relative to the staged copy's first bit (< 2^15)
-            // at least 33 bits of the stream from relative bit r on: enough for a literal / length code with its extra bits and the root
-            // look-up of the distance code behind it
-            auto bits_at = [&](uint32_t r) __attribute__((always_inline)) -> uint64_t {
-                const uint32_t w = r >> 5;
-                return (uint64_t(S.stage[w]) | (uint64_t(S.stage[w + 1]) << 32)) >> (r & 31u);
-            };
-            // one token at relative bit r: kind 0 literal, 1 match, 2 end of block, 3 not a token (an error if it is on the true walk).
-            // tl: its bits; val: the literal, or the match length (VALUES: length | distance << 16)
-            auto token = [&](uint32_t r, bool values, uint32_t &kind, uint32_t &tl, uint32_t &val) __attribute__((always_inline)) {
-                const uint64_t b = bits_at(r);
-                uint32_t e = S.lroot[uint32_t(b) & ((1u << LROOT) - 1u)];
-                if (!e) e = canon_resume(uint32_t(b) & 0x7FFFu, LROOT, S.lcount, S.lsorted, S.lresume);
-                kind = 3; tl = 1; val = 0;
-                if (!e) return;
-                const uint32_t sym = (e >> 4) & 0x1FFu;
-                tl = e & 15u;
-                if (sym < 256) { kind = 0; val = sym; return; }
-                if (sym == 256) { kind = 2; return; }
-                const uint32_t li = sym - 257;
-                if (li >= 29) return;
-                const uint32_t eb = (li < 8 || li == 28) ? 0u : (li >> 2) - 1u;
-                const uint32_t len = (li < 8 ? 3u + li : li == 28 ? 258u : ((4u | (li & 3u)) << eb) + 3u) + (uint32_t(b >> tl) & ((1u << eb) - 1u));
-                tl += eb;   // <= 20
-                uint32_t d = S.droot[uint32_t(b >> tl) & ((1u << DROOT) - 1u)];
-                if (!d) d = canon_resume(uint32_t(bits_at(r + tl)) & 0x7FFFu, DROOT, S.dcount, S.dsorted, S.dresume);
-                const uint32_t ds = (d >> 4) & 0x7FFu;
-                if (!d || ds >= 30) return;
-                const uint32_t deb = ds < 4 ? 0u : (ds >> 1) - 1u;
-                tl += d & 15u;
-                val = len;
-                if (values) val |= ((ds < 4 ? ds + 1u : ((2u | (ds & 1u)) << deb) + 1u) + (uint32_t(bits_at(r + tl)) & ((1u << deb) - 1u))) << 16;
-                tl += deb;
-                kind = 1;
-            };
-            LV<uint32_t> entry, leave;      // where the lane's walk starts / where the token behind its last one starts (relative; ~0: nowhere)
-            LV<uint32_t> nout, nmat, stopk; // bytes and matches its walk produces; how it ended: 0 ran out of its stretch, 2 end of block, 3 not a token
-            LV<uint32_t> redo;
-            LFOR(l) { entry[l] = rbase + uint32_t(HUFF_SUB) * uint32_t(l); redo[l] = 1; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }
-            for (int pass = 0; pass < 66; pass++) {
-                LFOR(l) if (redo[l]) {
-                    const uint32_t end = rbase + uint32_t(HUFF_SUB) * (uint32_t(l) + 1u);
-                    uint32_t p = entry[l], no = 0, nm = 0, sk = 0;
-                    if (p != ~0u) {
-                        while (p < end) {
-                            uint32_t kind, tl, val;
-                            token(p, false, kind, tl, val);
-                            if (kind == 3) { sk = 3; break; }
-                            p += tl;
-                            if (kind == 2) { sk = 2; break; }
-                            if (kind == 1) { no += val; nm++; } else no++;
-                        }
-                    } else sk = 3;   // no entry: the walk in front of it ended the block (or was no walk)
-                    leave[l] = p; nout[l] = no; nmat[l] = nm; stopk[l] = sk;
-                }
-                // everyone's new entry: where the left neighbour left off (nowhere, if it stopped)
-                LV<uint32_t> from;
-#ifdef CSH_EMUL
-                for (int l = 63; l >= 1; l--) from.v[l] = stopk.v[l - 1] ? ~0u : leave.v[l - 1];
-                from.v[0] = rbase;
-#else
-                {
-                    const uint32_t mine = stopk.v ? ~0u : leave.v;
-                    const uint32_t prev = uint32_t(__builtin_amdgcn_update_dpp(0, int(mine), 0x138, 0xf, 0xf, false));   // wave_shr:1
-                    from.v = (threadIdx.x & 63u) ? prev : rbase;
-                }
-#endif
-                LFOR(l) { redo[l] = from[l] != entry[l] ? 1u : 0u; entry[l] = from[l]; }
-                if (!lballot([&](int l) { return redo[l] != 0u; })) break;
-            }
+            run(CMD_STOP);
             // the lanes of the true walk: up to and including the first that stopped
-            const uint64_t stopped = lballot([&](int l) { return stopk[l] != 0u; });
-            const int nlanes = stopped ? __builtin_ctzll(stopped) + 1 : 64;
-            const uint32_t how = stopped ? lane_of(stopk, uint32_t(nlanes - 1)) : 0u;
-            LV<uint32_t> mo, mm;
-            LFOR(l) { mo[l] = l < nlanes ? nout[l] : 0u; mm[l] = l < nlanes ? nmat[l] : 0u; }
+            uint32_t nlanes = uint32_t(HUFF_LANES), how = 0;
+            for (uint32_t w = 0; w < uint32_t(HUFF_WAVES); w++) { const uint32_t f = uni(S.wfirst[w]); if (f < 64u) { nlanes = 64u * w + f + 1u; how = uni(S.stopk[64u * w + f]); break; } }
+            LFOR(l) if (l == 0) S.nlanes = nlanes;
+            run(CMD_SUM);
             uint32_t tot_out = 0, tot_mat = 0;
-            const LV<uint32_t> before = lscan(mo, tot_out);
-            const LV<uint32_t> mbefore = lscan(mm, tot_mat);
+            for (uint32_t w = 0; w < uint32_t(HUFF_WAVES); w++) { LFOR(l) if (l == 0) { S.woff[w] = tot_out; S.wmoff[w] = tot_mat; } tot_out += uni(S.wout[w]); tot_mat += uni(S.wmat[w]); }
+            run(CMD_WRITE);
+            if (uni(S.bad)) { err = CSP_ERR_BAD_PNG; break; }
+            uint32_t nw = 0, lastw = ~0u;
+            for (uint32_t w = 0; w < uint32_t(HUFF_WAVES); w++) { nw += uni(S.wwrote[w]); if (uni(S.wlast[w]) < 64u) lastw = w; }
+            mtotal += nw;   // == tot_mat unless the image's last byte came first
             (void)tot_mat;
-            // the last pass: literals to their bytes, matches to their records.  Nothing is decoded past the image's last byte: a walk stops
-            // in front of the first token that would start there, and what it finds wrong behind that point does not count
-            LV<uint32_t> bad, wrote, pfin;
-            LFOR(l) {
-                bad[l] = 0; wrote[l] = 0; pfin[l] = 0;
-                if (l < nlanes && entry[l] != ~0u && pos + before[l] < cap) {
-                    const uint32_t end = rbase + uint32_t(HUFF_SUB) * (uint32_t(l) + 1u);
-                    uint32_t p = entry[l];
-                    uint64_t at = pos + before[l];
-                    uint32_t mi = mtotal + mbefore[l];
-                    while (p < end && at < cap) {
-                        uint32_t kind, tl, val;
-                        token(p, true, kind, tl, val);
-                        if (kind == 3) { bad[l] = 1; break; }
-                        if (kind == 2) break;
-                        if (kind == 1) {
-                            const uint32_t len = val & 0xFFFFu, dist = val >> 16;
-                            if (uint64_t(dist) > at || stage_bit0 + p + tl > limit) { bad[l] = 1; break; }
-                            mlist[mi++] = (at & 0xFFFFFFFFull) | (uint64_t(len) << 32) | (uint64_t(dist) << 48);
-                            at += len;
-                        } else out[at++] = uint8_t(val);
-                        p += tl;
-                    }
-                    wrote[l] = mi - (mtotal + mbefore[l]); pfin[l] = p;
-                }
-            }
-            if (lballot([&](int l) { return bad[l] != 0u; })) { err = CSP_ERR_BAD_PNG; break; }
-            {
-                uint32_t nw = 0;
-                (void)lscan(wrote, nw);
-                mtotal += nw;   // == tot_mat unless the image's last byte came first
-            }
             pos += tot_out;
             if (pos >= cap) {   // complete: the stream position is where the last walk that wrote anything stopped
-                const uint64_t started = lballot([&](int l) { return l < nlanes && entry[l] != ~0u && pos - tot_out + before[l] < cap; });
-                if (started) { rd.bp = stage_bit0 + lane_of(pfin, uint32_t(63 - __builtin_clzll(started))); rd.refresh(); }
+                if (lastw != ~0u) { rd.bp = stage_bit0 + uni(S.wpfin[lastw]); rd.refresh(); }
                 break;
             }
             if (how == 3) { err = CSP_ERR_BAD_PNG; break; }   // the true walk met something that is no token
-            rd.bp = stage_bit0 + lane_of(leave, uint32_t(nlanes - 1));
+            rd.bp = stage_bit0 + uni(S.leave[nlanes - 1]);
             rd.refresh();
             if (how == 2) block_done = true;
         }
     }
+    LFOR(l) if (l == 0) S.cmd = CMD_EXIT;
+    HUFF_BARRIER();   // the other waves leave
     if (!err && rd.overrun()) err = CSP_ERR_BAD_PNG;
     if (!err && pos < cap) err = CSP_ERR_BAD_PNG;   // libpng: "not enough image data"
     if (err) { LFOR(l) if (l == 0) status[image] = err; return; }
@@ -593,7 +646,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
 
 void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status) {
     if (!nimg) return;
-    CSH_LAUNCH(k_png_huff, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, idat, raw, matches, nmatch, status);
+    CSH_LAUNCH(k_png_huff, dim3(nimg), dim3(CSP_WAVE_THREADS * HUFF_WAVES), st, imgs, nimg, idat, raw, matches, nmatch, status);
     CSH_LAUNCH(k_png_lz77, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, raw, matches, nmatch, status);
 }
 void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint32_t max_height, uint8_t *work, uint32_t *status) {
