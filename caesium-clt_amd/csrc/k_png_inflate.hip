@@ -1,21 +1,22 @@
 // k_png_inflate.hip -- row P1 of SURVEY.md 8a on the device: the IDAT zlib stream back to filtered rows (RFC 1951), then
 // the PNG reconstruction filters back to pixels.  Statement: oracle/png_oracle.c inflate_raw() / cso_png_decode().
 //
-// A deflate stream is one serial chain of prefix codes, so the parallelism of the CODE WALK is across the files of the batch: one
-// wave per stream (k_png_huff).  What makes a stream slow, though, is not the walk but waiting for every match copy before the next
-// symbol; the two are therefore separate kernels:
-//   k_png_huff   walks the codes and nothing else.  Control flow is wave-uniform; the 64 lanes give it the stream window (64 words
-//                per load, handed to the uniform bit reader by v_readlane), the table construction (every lane decodes its own root
-//                entries with the canonical walk: no scatter), and the root-table answers for 64 bit offsets at a time.  Literals go
-//                straight to their final place in the output (their position is known: the walk keeps the byte count); a match becomes
-//                an 8-byte record (position, length, distance) in a list.
+// A deflate stream is one serial chain of prefix codes, and the files of a batch are the obvious parallel axis (one workgroup per
+// stream).  Two things make a stream slow when it is walked token by token: waiting for every match copy before the next symbol, and
+// the walk itself being one dependent chain.  Both are taken apart:
+//   k_png_huff   walks the codes and nothing else, speculatively: where a prefix-coded stream is entered matters only for a few tokens,
+//                so every lane of the workgroup's four waves walks its own 288-bit stretch of the block from a guessed entry, then from
+//                where its left neighbour's walk really left off, until no entry moves; prefix sums of what the walks produce place
+//                every literal (stored directly: its position is known) and every match (an 8-byte record: position, length,
+//                distance).  The first wave also parses the block headers and builds the tables (every lane decodes its own root
+//                entries with the canonical walk: no scatter); the other waves act on its commands between two barriers.
 //   k_png_lz77   resolves the matches, 16 KiB of output at a time, in LDS: the bytes of a match whose source lies in front of the piece
 //                are copied from the 48 KiB of history the ring holds; the others get a pointer to their source and the pointers are
 //                doubled (p <- p[p]) until every byte points at a byte that is final -- a run of 258 bytes at distance 1 takes 9 rounds,
 //                not 258 steps -- then gathered.  No step waits for a single copy.
 // Adam7 inputs: the stream holds seven reduced images; each is reconstructed as a job of its own, then k_png_deinterlace
 // gathers the pixels into place (the output is never interlaced).
-// Codes longer than the root width take the bit-serial canonical walk (rare symbols by construction).
+// Codes longer than the root tables (13 / 10 bits) resume the canonical walk behind the root width (rare symbols by construction).
 #include "png_kernels.h"
 #include "png_wave.h"
 
