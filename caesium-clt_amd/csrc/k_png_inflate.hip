@@ -29,7 +29,7 @@ enum { HUFF_WAVES = 1 };   // the emulation plays one wave: the same code, the h
 enum { HUFF_WAVES = 4 };
 #define HUFF_BARRIER() __syncthreads()
 #endif
-enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
+enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_PRE = 96, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
@@ -239,11 +239,24 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS * HUFF_WAVES) k_png_huff(cons
                 else for (int k = 0; k < 4; k++) if (at + uint32_t(k) < slen) w |= uint32_t(sbase[at + uint32_t(k)]) << (8 * k);
                 S.stage[i] = w;
             }
-            LFOR(l) { entry[l] = rbase + uint32_t(HUFF_SUB) * (64u * wv + uint32_t(l)); redo[l] = 1; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }
+            LFOR(l) { entry[l] = rbase + uint32_t(HUFF_SUB) * (64u * wv + uint32_t(l)); redo[l] = 2; leave[l] = 0; nout[l] = 0; nmat[l] = 0; stopk[l] = 0; }   // redo 2: first walk
         } else if (cmd == CMD_WALK) {   // the lanes whose entry moved walk their stretch; everyone publishes where its walk left off
             LFOR(l) {
                 if (redo[l]) {
                     const uint32_t end = rbase + uint32_t(HUFF_SUB) * (64u * wv + uint32_t(l) + 1u);
+                    if (redo[l] == 2 && (wv || l)) {
+                        // a better first guess than the stretch's first bit: a walk that comes in from HUFF_PRE bits in front of it has
+                        // usually fallen into step by the time it arrives, so most lanes start their first pass at a true token
+                        const uint32_t s0 = entry[l];
+                        uint32_t q = s0 - uint32_t(HUFF_PRE);
+                        while (q < s0) {
+                            uint32_t kind, tl, val;
+                            token(q, false, kind, tl, val);
+                            if (kind >= 2) { q = s0; break; }   // no token, or an end of block, on a walk that may be nobody's: the plain guess
+                            q += tl;
+                        }
+                        entry[l] = q;
+                    }
                     uint32_t p = entry[l], no = 0, nm = 0, sk = 0;
                     if (p != ~0u) {
                         while (p < end) {
