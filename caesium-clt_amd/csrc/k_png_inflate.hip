@@ -29,7 +29,7 @@ enum { HUFF_WAVES = 1 };   // the emulation plays one wave: the same code, the h
 enum { HUFF_WAVES = 4 };
 #define HUFF_BARRIER() __syncthreads()
 #endif
-enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_PRE = 96, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
+enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_PRE = 192, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
