@@ -468,28 +468,40 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS * HUFF_WAVES) k_png_huff(cons
     LFOR(l) if (l == 0) nmatch[image] = mtotal;
 }
 
-// ---- the matches of one stream, resolved piece by piece (header of this file).  One wave per stream.
+// ---- the matches of one stream, resolved piece by piece (header of this file).  One workgroup of HUFF_WAVES waves per stream: every
+// step of a piece is a loop over its bytes or its matches shared out over all lanes, with a barrier behind it; what decides the control
+// flow (are there more matches for this piece? did a pointer move?) is read by all waves from LDS behind a barrier, so they agree.
 struct Lz77Lds {
     alignas(16) uint8_t ring[LZ_RING];      // byte at absolute position p: ring[p & 65535]
     alignas(16) uint16_t ptr[LZ_PIECE];     // for the bytes of the piece: ring index of a byte this one equals (itself: final)
+    uint32_t wfin[HUFF_WAVES];              // matches a wave finished in this step (64: all of its 64)
+    uint32_t moved[3];                      // "a pointer moved" of the doubling rounds, three in rotation
 };
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *imgs, int nimg, uint8_t *raw, const uint64_t *matches, const uint32_t *nmatch, const uint32_t *status) {
+__global__ void __launch_bounds__(CSP_WAVE_THREADS * HUFF_WAVES) k_png_lz77(const PngImg *imgs, int nimg, uint8_t *raw, const uint64_t *matches, const uint32_t *nmatch, const uint32_t *status) {
     CSH_SHARED Lz77Lds S;
     const int image = blockIdx.x;
     if (image >= nimg || status[image]) return;
+#ifdef CSH_EMUL
+    const uint32_t wv = 0;
+#else
+    const uint32_t wv = threadIdx.x >> 6;
+#endif
+    const uint32_t NL = uint32_t(HUFF_LANES);
     const PngImg im = imgs[image];
     uint8_t *out = raw + im.inflate_off;
     const uint64_t *mlist = matches + im.match_off;
     const uint64_t cap = im.inflate_len;
     const uint32_t nm = nmatch[image];
-    uint32_t mi = 0;   // first match that may still have bytes at or behind the piece's start
+    uint32_t mi = 0;   // first match that may still have bytes at or behind the piece's start (the same in every wave)
+    if (wv == 0) LFOR(l) if (l < 3) S.moved[l] = 0;
+    HUFF_BARRIER();
     for (uint64_t c0 = 0; c0 < cap; c0 += LZ_PIECE) {
         const uint64_t c1 = c0 + LZ_PIECE < cap ? c0 + LZ_PIECE : cap;
         const uint32_t n = uint32_t(c1 - c0);
         // the piece as k_png_huff left it (literals in place, match bytes undefined), every byte its own source
-        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        for (uint32_t i0 = 0; i0 < n; i0 += 16u * NL) {
             LFOR(l) {
-                const uint32_t i = i0 + uint32_t(l) * 16u;
+                const uint32_t i = i0 + (64u * wv + uint32_t(l)) * 16u;
                 if (i < n) {
                     uint4 v;
                     if (i + 16 <= n) v = *reinterpret_cast<const uint4 *>(out + c0 + i);
@@ -498,21 +510,23 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *img
                 }
             }
         }
-        for (uint32_t i0 = 0; i0 < LZ_PIECE; i0 += 256) {
+        for (uint32_t i0 = 0; i0 < LZ_PIECE; i0 += 4u * NL) {
             LFOR(l) {
-                const uint32_t i = i0 + uint32_t(l) * 4u, r = (uint32_t(c0) + i) & (LZ_RING - 1);
+                const uint32_t i = i0 + (64u * wv + uint32_t(l)) * 4u, r = (uint32_t(c0) + i) & (LZ_RING - 1);
                 uint2 v; v.x = r | ((r + 1) << 16); v.y = (r + 2) | ((r + 3) << 16);
                 *reinterpret_cast<uint2 *>(&S.ptr[i]) = v;
             }
         }
+        if (wv == 0) LFOR(l) if (l < 3) S.moved[l] = 0;
         CSP_WAVE_SYNC();
-        // the matches that reach into the piece, 64 at a time.  A byte whose source lies in front of the piece takes its value now (that
-        // part of the ring is final); one whose source is in the piece points at it.
+        HUFF_BARRIER();
+        // the matches that reach into the piece, one per lane and step.  A byte whose source lies in front of the piece takes its value
+        // now (that part of the ring is final); one whose source is in the piece points at it.
         for (bool more = mi < nm; more;) {
             LV<uint32_t> done;
             LFOR(l) {
                 done[l] = 0;
-                const uint32_t k = mi + uint32_t(l);
+                const uint32_t k = mi + 64u * wv + uint32_t(l);
                 if (k < nm) {
                     const uint64_t rec = mlist[k];
                     const uint64_t mpos = rec & 0xFFFFFFFFull;   // streams are shorter than 4 GiB (plan: at most 2^28 pixels of at most 8 bytes)
@@ -528,23 +542,28 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *img
                     }
                 }
             }
-            // records are in stream order: the finished ones are a prefix of the 64; stop at the first that goes on into the next piece
+            // records are in stream order: the finished ones are a prefix of the step's; stop at the first that goes on into the next piece
             const uint64_t fin = lballot([&](int l) { return done[l] != 0u; });
-            const uint32_t nfin = fin == ~0ull ? 64u : uint32_t(__builtin_ctzll(~fin));
-            mi += nfin;
-            more = nfin == 64u && mi < nm;
+            LFOR(l) if (l == 0) S.wfin[wv] = fin == ~0ull ? 64u : uint32_t(__builtin_ctzll(~fin));
+            CSP_WAVE_SYNC();
+            HUFF_BARRIER();
+            uint32_t total = 0;
+            bool all = true;
+            for (uint32_t w = 0; w < uint32_t(HUFF_WAVES) && all; w++) { const uint32_t f = uni(S.wfin[w]); total += f; all = f == 64u; }
+            mi += total;
+            more = all && mi < nm;
+            HUFF_BARRIER();   // wfin is read by all before the next step writes it
         }
-        CSP_WAVE_SYNC();
         // pointer doubling, four bytes per lane and step: p <- ptr[p].  A final byte points at itself, so the step needs no test; the
         // piece starts on a multiple of its size, so a ring index's low 14 bits are the byte's index in the piece.  Entries behind the
         // stream's last byte point at themselves.
         for (int round = 0; round < 15; round++) {
             bool changed = false;
-            for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+            for (uint32_t i0 = 0; i0 < n; i0 += 4u * NL) {
                 LV<uint32_t> moved;
                 LFOR(l) {
                     moved[l] = 0;
-                    const uint32_t i = i0 + uint32_t(l) * 4u;
+                    const uint32_t i = i0 + (64u * wv + uint32_t(l)) * 4u;
                     if (i < n) {
                         const uint2 v = *reinterpret_cast<const uint2 *>(&S.ptr[i]);
                         uint2 w;
@@ -555,12 +574,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *img
                 }
                 if (lballot([&](int l) { return moved[l] != 0u; })) changed = true;
             }
+            LFOR(l) if (l == 0) { if (changed) S.moved[round % 3] = 1; if (wv == 0) S.moved[(round + 1) % 3] = 0; }
             CSP_WAVE_SYNC();
-            if (!changed) break;
+            HUFF_BARRIER();
+            if (!uni(S.moved[round % 3])) break;
         }
-        for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        for (uint32_t i0 = 0; i0 < n; i0 += 4u * NL) {
             LFOR(l) {
-                const uint32_t i = i0 + uint32_t(l) * 4u;
+                const uint32_t i = i0 + (64u * wv + uint32_t(l)) * 4u;
                 if (i < n) {
                     const uint2 v = *reinterpret_cast<const uint2 *>(&S.ptr[i]);
                     const uint32_t bytes = uint32_t(S.ring[v.x & 0xFFFFu]) | (uint32_t(S.ring[v.x >> 16]) << 8) | (uint32_t(S.ring[v.y & 0xFFFFu]) << 16) | (uint32_t(S.ring[v.y >> 16]) << 24);
@@ -569,9 +590,10 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *img
             }
         }
         CSP_WAVE_SYNC();
-        for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        HUFF_BARRIER();
+        for (uint32_t i0 = 0; i0 < n; i0 += 16u * NL) {
             LFOR(l) {
-                const uint32_t i = i0 + uint32_t(l) * 16u;
+                const uint32_t i = i0 + (64u * wv + uint32_t(l)) * 16u;
                 if (i < n) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(S.ring + ((uint32_t(c0) + i) & (LZ_RING - 1)));
                     if (i + 16 <= n) *reinterpret_cast<uint4 *>(out + c0 + i) = v;
@@ -579,6 +601,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_lz77(const PngImg *img
                 }
             }
         }
+        HUFF_BARRIER();   // the next piece rewrites ptr and a quarter of the ring
     }
 }
 
@@ -661,7 +684,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
 void launch_png_inflate(hipStream_t st, const PngImg *imgs, int nimg, const uint8_t *idat, uint8_t *raw, uint64_t *matches, uint32_t *nmatch, uint32_t *status) {
     if (!nimg) return;
     CSH_LAUNCH(k_png_huff, dim3(nimg), dim3(CSP_WAVE_THREADS * HUFF_WAVES), st, imgs, nimg, idat, raw, matches, nmatch, status);
-    CSH_LAUNCH(k_png_lz77, dim3(nimg), dim3(CSP_WAVE_THREADS), st, imgs, nimg, raw, matches, nmatch, status);
+    CSH_LAUNCH(k_png_lz77, dim3(nimg), dim3(CSP_WAVE_THREADS * HUFF_WAVES), st, imgs, nimg, raw, matches, nmatch, status);
 }
 void launch_png_unfilter(hipStream_t st, const PngPass *jobs, int njobs, uint32_t max_height, uint8_t *work, uint32_t *status) {
     if (njobs && max_height) CSH_LAUNCH(k_png_unfilter, dim3((max_height + 63) / 64, unsigned(njobs)), dim3(CSP_WAVE_THREADS), st, jobs, njobs, work, status);
