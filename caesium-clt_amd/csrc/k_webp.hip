@@ -110,203 +110,374 @@ __device__ __forceinline__ static void idct4_add(const int (&in)[16], const int 
         px[i * 4 + 2] = clip8(pred[i * 4 + 2] + ((b - c) >> 3)); px[i * 4 + 3] = clip8(pred[i * 4 + 3] + ((a - d) >> 3));
     }
 }
-__device__ __forceinline__ static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }   // bias / 256 of a step: libwebp's rounding offsets
+// bias / 256 of a step: libwebp's rounding offsets.  The division is a multiplication: numerators stay below 2^16 (|coefficient| < 2^15 for every
+// transform here) and steps below 2^9, where (n * (2^32 / q + 1)) >> 32 is exactly n / q
+__device__ __forceinline__ static uint32_t quant_recip(int q) { return uint32_t(0xFFFFFFFFu / uint32_t(q)) + 1u; }   // q >= 4, never a power-of-two edge case: 2^32 / q rounds down either way
+__device__ __forceinline__ static int quant(int c, int q, int bias, uint32_t recip) {
+    int a = c < 0 ? -c : c;
+    a = int((uint64_t(uint32_t(a + ((q * bias) >> 8))) * recip) >> 32);
+    if (a > 2047) a = 2047;
+    return c < 0 ? -a : a;
+}
 
-// One wave per macroblock; one launch per anti-diagonal of the macroblock grid (mx + my = diag): a macroblock predicts from the
-// reconstruction of its left, upper and upper-left neighbours only (16 x 16 and 8 x 8 modes have no upper-right dependency), so the
-// macroblocks of a diagonal -- of every picture of the batch -- are independent.  (The first version walked a picture's macroblocks in
-// raster order with one wave: 16.7 us each, 83 ms for 256 pictures whatever else the chip had to do.)
+// ---- the macroblock record: 25 blocks x 16 levels (Y2, 16 luma, 4 U, 4 V; scan order) + an info block
+//   I[0], I[1]  which blocks have anything to code: bit 0 the Y2 flag as the macroblock to the RIGHT sees it, 1..16 luma, 17..24 chroma, bit 25 the
+//               Y2 flag as the macroblock BELOW sees it (an i4x4 macroblock has no Y2 block and hands its neighbours' flags on: the two differ)
+//   I[2] luma mode (0 DC, 1 V, 2 H, 3 TM; 4 = i4x4), I[3] chroma mode, I[4..19] the sixteen sub-block modes (i16: what the mode counts as in its
+//   neighbours' sub-block contexts) -- the token coder's contexts and the header's modes, looked up without a serial pass
+enum { MB_INFO = 400 };
+static_assert(WEBP_MB_REC >= MB_INFO + 20, "macroblock record");
+__device__ __forceinline__ static uint32_t nz_mask(const int16_t *L) { return uint32_t(uint16_t(L[MB_INFO])) | (uint32_t(uint16_t(L[MB_INFO + 1])) << 16); }
+
+// minimum of a key over each row of 16 lanes, in every lane of the row
+__device__ __forceinline__ static LV<uint32_t> lrowmin(const LV<uint32_t> &x) {
+    LV<uint32_t> r;
+#ifdef CSH_EMUL
+    for (int g = 0; g < 4; g++) {
+        uint32_t m = 0xFFFFFFFFu;
+        for (int k = 0; k < 16; k++) m = x.v[g * 16 + k] < m ? x.v[g * 16 + k] : m;
+        for (int k = 0; k < 16; k++) r.v[g * 16 + k] = m;
+    }
+#else
+    uint32_t v = x.v, o;
+    o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0xB1, 0xf, 0xf, false)); v = o < v ? o : v;    // quad_perm [1,0,3,2]
+    o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x4E, 0xf, 0xf, false)); v = o < v ? o : v;    // quad_perm [2,3,0,1]
+    o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x141, 0xf, 0xf, false)); v = o < v ? o : v;   // row_half_mirror
+    o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x140, 0xf, 0xf, false)); v = o < v ? o : v;   // row_mirror
+    r.v = v;
+#endif
+    return r;
+}
+
+// One wave per macroblock; one launch per skewed diagonal of the macroblock grid (mx + 2 my = diag): a macroblock predicts from the
+// reconstruction of its left, upper, upper-left and -- the 4 x 4 modes of its right column -- upper-RIGHT neighbours, which all lie on earlier
+// diagonals; the macroblocks of a diagonal -- of every picture of the batch -- are independent.  (The first version walked a picture's
+// macroblocks in raster order with one wave: 16.7 us each, 83 ms for 256 pictures whatever else the chip had to do.)
+// Luma (oracle: cso_webp_encode_yuv): i16x16 first; when that leaves AC levels to code the macroblock is coded i4x4 instead -- sixteen
+// sub-blocks, each predicted from the reconstruction so far, ten modes tried by ten lanes (two sub-blocks at a time: sub-block (bx, by) only
+// needs (bx - 1, by), (bx, by - 1) and (bx + 1, by - 1), so bx + 2 by = step walks the sixteen in ten steps).
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *imgs, uint8_t *work, int16_t *levels, int diag) {
+    CSH_SHARED uint32_t s_cbw[17 * 8];      // the macroblock's luma with its edges: 17 rows of 32 bytes; row 0 = the row above, byte 3 = the column
+                                            // to the left, bytes 4..19 the macroblock, 20..23 the four samples above-right
+    CSH_SHARED uint32_t s_srcw[64];         // luma source, 16 x 16
+    CSH_SHARED uint16_t s_taps[128];
+    CSH_SHARED uint8_t s_bm[16], s_nz[16], s_tm[4], s_lm[4], s_e[32];   // s_e: the edge line L K J I X A B C D E F G H of the (up to) two sub-blocks of a step
+    uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_cbw), *s_src = reinterpret_cast<uint8_t *>(s_srcw);
     const WebpImg im = imgs[blockIdx.y];
     const int mbw = int(im.mbw), mbh = int(im.mbh), ys = mbw * 16, cs = mbw * 8, qi = im.qi;
-    const int y1ac = kVp8AcQ[qi], y2dc = kVp8DcQ[qi] * 2, uvac = kVp8AcQ[qi];
+    const int y1dc = kVp8DcQ[qi], y1ac = kVp8AcQ[qi], y2dc = kVp8DcQ[qi] * 2, uvac = kVp8AcQ[qi];
     int y2ac = kVp8AcQ[qi] * 155 / 100; if (y2ac < 8) y2ac = 8;
     int uvdc = kVp8DcQ[qi]; if (uvdc > 132) uvdc = 132;
+    const uint32_t r_y1dc = quant_recip(y1dc), r_y1ac = quant_recip(y1ac), r_y2dc = quant_recip(y2dc), r_y2ac = quant_recip(y2ac), r_uvdc = quant_recip(uvdc), r_uvac = quant_recip(uvac);
     const uint8_t *sy = work + im.y_off, *su = work + im.u_off, *sv = work + im.v_off;
     uint8_t *ry = work + im.ry_off, *ru = work + im.ru_off, *rv = work + im.rv_off;
-    {
-        {
-            const int my = int(blockIdx.x), mx = diag - my;
-            if (my >= mbh || mx < 0 || mx >= mbw) return;
-            // the three DC predictions: lanes 0..31 gather the luma edge, 32..47 the U edge, 48..63 the V edge; one packed sum
-            LV<uint64_t> edge;
+    const int my = int(blockIdx.x), mx = diag - 2 * my;
+    if (my >= mbh || mx < 0 || mx >= mbw) return;
+    int16_t *L = levels + im.lev_off + (size_t(my) * mbw + mx) * WEBP_MB_REC, *I = L + MB_INFO;
+    const int16_t *Ltop = L - size_t(mbw) * WEBP_MB_REC, *Lleft = L - WEBP_MB_REC;
+    // the three DC predictions: lanes 0..31 gather the luma edge, 32..47 the U edge, 48..63 the V edge; one packed sum
+    LV<uint64_t> edge;
+    LFOR(l) {
+        uint64_t v = 0;
+        if (l < 16) { if (my) v = coherent_load(ry + size_t(my * 16 - 1) * ys + mx * 16 + l); }
+        else if (l < 32) { if (mx) v = coherent_load(ry + size_t(my * 16 + (l - 16)) * ys + mx * 16 - 1); }
+        else {
+            const uint8_t *r = l < 48 ? ru : rv;
+            const int k = (l - 32) & 15;
+            if (k < 8) { if (my) v = coherent_load(r + size_t(my * 8 - 1) * cs + mx * 8 + k); }
+            else if (mx) v = coherent_load(r + size_t(my * 8 + (k - 8)) * cs + mx * 8 - 1);
+            v <<= l < 48 ? 16 : 32;
+        }
+        edge[l] = v;
+        s_taps[l] = kVp8Pred4Taps[l]; s_taps[64 + l] = kVp8Pred4Taps[64 + l];
+    }
+    const uint64_t sums = lsum(edge);
+    const int both = (mx && my) ? 1 : 0, any = (mx || my) ? 1 : 0;
+    const int sY = int(sums & 0xFFFFu), sU = int((sums >> 16) & 0xFFFFu), sV = int((sums >> 32) & 0xFFFFu);
+    const int dcY = !any ? 128 : both ? (sY + 16) >> 5 : (sY + 8) >> 4;
+    const int dcU = !any ? 128 : both ? (sU + 8) >> 4 : (sU + 4) >> 3;
+    const int dcV = !any ? 128 : both ? (sV + 8) >> 4 : (sV + 4) >> 3;
+    // every block lane: its 4x4 source samples and, when both neighbours exist, the macroblock edge it predicts from
+    LV<int> dc0;
+    int coef[16];   // this lane's block (emulation: kept per lane in coefs[])
+    int pred[16];   // its prediction (emulation: preds[])
+#ifdef CSH_EMUL
+    int coefs[24][16], preds[24][16], srcs[24][16], tops[24][4], lefts[24][4], corners[24];
+#endif
+    int src16[16], top4[4], left4[4], corner = 0;
+    const int nmodes = (mx && my) ? 4 : 1;
+    LFOR(l) if (l < 24) {
+        const bool luma = l < 16;
+        const int b = luma ? l : (l - 16) & 3, bx = luma ? b & 3 : b & 1, by = luma ? b >> 2 : b >> 1;
+        const int stride = luma ? ys : cs, n0 = luma ? 16 : 8;
+        const uint8_t *s = (luma ? sy : (l < 20 ? su : sv)) + size_t(my * n0 + by * 4) * stride + mx * n0 + bx * 4;
+        const uint8_t *r = (luma ? ry : (l < 20 ? ru : rv)) + size_t(my * n0) * stride + mx * n0;   // the macroblock's corner in the reconstruction
+        CSH_UNROLL
+        for (int rr = 0; rr < 4; rr++) {
+            const uint32_t w4 = *reinterpret_cast<const uint32_t *>(s + size_t(rr) * stride);
+            if (luma) s_srcw[(by * 4 + rr) * 4 + bx] = w4;
+            CSH_UNROLL
+            for (int c = 0; c < 4; c++) src16[rr * 4 + c] = int((w4 >> (8 * c)) & 255u);
+        }
+        CSH_UNROLL
+        for (int k = 0; k < 4; k++) { top4[k] = 0; left4[k] = 0; }
+        corner = 0;
+        if (nmodes == 4) {
+            const uint32_t t4 = coherent_load(reinterpret_cast<const uint32_t *>(r - stride + bx * 4));
+            CSH_UNROLL
+            for (int k = 0; k < 4; k++) { top4[k] = int((t4 >> (8 * k)) & 255u); left4[k] = coherent_load(r + size_t(by * 4 + k) * stride - 1); }
+            corner = coherent_load(r - stride - 1);
+        }
+#ifdef CSH_EMUL
+        for (int k = 0; k < 16; k++) srcs[l][k] = src16[k];
+        for (int k = 0; k < 4; k++) { tops[l][k] = top4[k]; lefts[l][k] = left4[k]; }
+        corners[l] = corner;
+#endif
+    }
+    // the mode of the luma block and the shared mode of the two chroma blocks: least sum of |DCT coefficients| of the residual
+    int ymode = 0, cmode = 0;
+    if (nmodes == 4) {
+        uint64_t best_y = ~0ull, best_c = ~0ull;
+        for (int m = 0; m < 4; m++) {
+            LV<uint64_t> cost;
             LFOR(l) {
-                uint64_t v = 0;
-                if (l < 16) { if (my) v = coherent_load(ry + size_t(my * 16 - 1) * ys + mx * 16 + l); }
-                else if (l < 32) { if (mx) v = coherent_load(ry + size_t(my * 16 + (l - 16)) * ys + mx * 16 - 1); }
-                else {
-                    const uint8_t *r = l < 48 ? ru : rv;
-                    const int k = (l - 32) & 15;
-                    if (k < 8) { if (my) v = coherent_load(r + size_t(my * 8 - 1) * cs + mx * 8 + k); }
-                    else if (mx) v = coherent_load(r + size_t(my * 8 + (k - 8)) * cs + mx * 8 - 1);
-                    v <<= l < 48 ? 16 : 32;
-                }
-                edge[l] = v;
-            }
-            const uint64_t sums = lsum(edge);
-            const int both = (mx && my) ? 1 : 0, any = (mx || my) ? 1 : 0;
-            const int sY = int(sums & 0xFFFFu), sU = int((sums >> 16) & 0xFFFFu), sV = int((sums >> 32) & 0xFFFFu);
-            const int dcY = !any ? 128 : both ? (sY + 16) >> 5 : (sY + 8) >> 4;
-            const int dcU = !any ? 128 : both ? (sU + 8) >> 4 : (sU + 4) >> 3;
-            const int dcV = !any ? 128 : both ? (sV + 8) >> 4 : (sV + 4) >> 3;
-            // every block lane: its 4x4 source samples and, when both neighbours exist, the macroblock edge it predicts from
-            LV<int> dc0;
-            int coef[16];   // this lane's block (emulation: kept per lane in coefs[])
-            int pred[16];   // its prediction (emulation: preds[])
-#ifdef CSH_EMUL
-            int coefs[24][16], preds[24][16], srcs[24][16], tops[24][4], lefts[24][4], corners[24];
-#endif
-            int src16[16], top4[4], left4[4], corner = 0;
-            const int nmodes = (mx && my) ? 4 : 1;
-            LFOR(l) if (l < 24) {
-                const bool luma = l < 16;
-                const int b = luma ? l : (l - 16) & 3, bx = luma ? b & 3 : b & 1, by = luma ? b >> 2 : b >> 1;
-                const int stride = luma ? ys : cs, n0 = luma ? 16 : 8;
-                const uint8_t *s = (luma ? sy : (l < 20 ? su : sv)) + size_t(my * n0 + by * 4) * stride + mx * n0 + bx * 4;
-                const uint8_t *r = (luma ? ry : (l < 20 ? ru : rv)) + size_t(my * n0) * stride + mx * n0;   // the macroblock's corner in the reconstruction
-                CSH_UNROLL
-                for (int rr = 0; rr < 4; rr++) {
-                    const uint32_t w4 = *reinterpret_cast<const uint32_t *>(s + size_t(rr) * stride);
-                    CSH_UNROLL
-                    for (int c = 0; c < 4; c++) src16[rr * 4 + c] = int((w4 >> (8 * c)) & 255u);
-                }
-                CSH_UNROLL
-                for (int k = 0; k < 4; k++) { top4[k] = 0; left4[k] = 0; }
-                corner = 0;
-                if (nmodes == 4) {
-                    const uint32_t t4 = coherent_load(reinterpret_cast<const uint32_t *>(r - stride + bx * 4));
-                    CSH_UNROLL
-                    for (int k = 0; k < 4; k++) { top4[k] = int((t4 >> (8 * k)) & 255u); left4[k] = coherent_load(r + size_t(by * 4 + k) * stride - 1); }
-                    corner = coherent_load(r - stride - 1);
-                }
-#ifdef CSH_EMUL
-                for (int k = 0; k < 16; k++) srcs[l][k] = src16[k];
-                for (int k = 0; k < 4; k++) { tops[l][k] = top4[k]; lefts[l][k] = left4[k]; }
-                corners[l] = corner;
-#endif
-            }
-            // the mode of the luma block and the shared mode of the two chroma blocks: least sum of |DCT coefficients| of the residual
-            int ymode = 0, cmode = 0;
-            if (nmodes == 4) {
-                uint64_t best_y = ~0ull, best_c = ~0ull;
-                for (int m = 0; m < 4; m++) {
-                    LV<uint64_t> cost;
-                    LFOR(l) {
-                        cost[l] = 0;
-                        if (l < 24) {
-#ifdef CSH_EMUL
-                            for (int k = 0; k < 16; k++) src16[k] = srcs[l][k];
-                            for (int k = 0; k < 4; k++) { top4[k] = tops[l][k]; left4[k] = lefts[l][k]; }
-                            corner = corners[l];
-#endif
-                            const int flat = l < 16 ? dcY : (l < 20 ? dcU : dcV);
-                            int d[16], c[16];
-                            CSH_UNROLL
-                            for (int k = 0; k < 16; k++) {
-                                const int x = k & 3, y = k >> 2;
-                                const int pv = m == 0 ? flat : m == 1 ? top4[x] : m == 2 ? left4[y] : clip8(top4[x] + left4[y] - corner);
-                                d[k] = src16[k] - pv;
-                            }
-                            fdct4(d, c);
-                            uint64_t sum = 0;
-                            CSH_UNROLL
-                            for (int k = 0; k < 16; k++) sum += uint64_t(c[k] < 0 ? -c[k] : c[k]);
-                            cost[l] = l < 16 ? sum : sum << 32;
-                        }
-                    }
-                    const uint64_t tot = lsum(cost), cy = tot & 0xFFFFFFFFull, cc = tot >> 32;
-                    if (cy < best_y) { best_y = cy; ymode = m; }
-                    if (cc < best_c) { best_c = cc; cmode = m; }
-                }
-            }
-            // residual against the chosen prediction, forward DCT
-            LFOR(l) {
-                dc0[l] = 0;
+                cost[l] = 0;
                 if (l < 24) {
 #ifdef CSH_EMUL
                     for (int k = 0; k < 16; k++) src16[k] = srcs[l][k];
                     for (int k = 0; k < 4; k++) { top4[k] = tops[l][k]; left4[k] = lefts[l][k]; }
                     corner = corners[l];
 #endif
-                    const int m = l < 16 ? ymode : cmode, flat = l < 16 ? dcY : (l < 20 ? dcU : dcV);
-                    int d[16];
+                    const int flat = l < 16 ? dcY : (l < 20 ? dcU : dcV);
+                    int d[16], c[16];
                     CSH_UNROLL
                     for (int k = 0; k < 16; k++) {
                         const int x = k & 3, y = k >> 2;
-                        pred[k] = m == 0 ? flat : m == 1 ? top4[x] : m == 2 ? left4[y] : clip8(top4[x] + left4[y] - corner);
-                        d[k] = src16[k] - pred[k];
+                        const int pv = m == 0 ? flat : m == 1 ? top4[x] : m == 2 ? left4[y] : clip8(top4[x] + left4[y] - corner);
+                        d[k] = src16[k] - pv;
                     }
-                    fdct4(d, coef);
-                    dc0[l] = coef[0];
-#ifdef CSH_EMUL
-                    for (int k = 0; k < 16; k++) { coefs[l][k] = coef[k]; preds[l][k] = pred[k]; }
-#endif
+                    fdct4(d, c);
+                    uint64_t sum = 0;
+                    CSH_UNROLL
+                    for (int k = 0; k < 16; k++) sum += uint64_t(c[k] < 0 ? -c[k] : c[k]);
+                    cost[l] = l < 16 ? sum : sum << 32;
                 }
             }
-            // the 16 luma DCs to everyone; Walsh-Hadamard, quantise, and back: each luma lane takes its own DC out of the result
-            int dcs[16], y2[16], dq[16], lv2[16];
+            const uint64_t tot = lsum(cost), cy = tot & 0xFFFFFFFFull, cc = tot >> 32;
+            if (cy < best_y) { best_y = cy; ymode = m; }
+            if (cc < best_c) { best_c = cc; cmode = m; }
+        }
+    }
+    // residual against the chosen prediction, forward DCT; does any luma AC coefficient survive the quantiser?
+    LV<int> acl;
+    LFOR(l) {
+        dc0[l] = 0; acl[l] = 0;
+        if (l < 24) {
+#ifdef CSH_EMUL
+            for (int k = 0; k < 16; k++) src16[k] = srcs[l][k];
+            for (int k = 0; k < 4; k++) { top4[k] = tops[l][k]; left4[k] = lefts[l][k]; }
+            corner = corners[l];
+#endif
+            const int m = l < 16 ? ymode : cmode, flat = l < 16 ? dcY : (l < 20 ? dcU : dcV);
+            int d[16];
             CSH_UNROLL
             for (int k = 0; k < 16; k++) {
-#ifdef CSH_EMUL
-                dcs[k] = dc0.v[k];
-#else
-                dcs[k] = __builtin_amdgcn_readlane(dc0.v, k);
-#endif
+                const int x = k & 3, y = k >> 2;
+                pred[k] = m == 0 ? flat : m == 1 ? top4[x] : m == 2 ? left4[y] : clip8(top4[x] + left4[y] - corner);
+                d[k] = src16[k] - pred[k];
             }
-            fwht(dcs, y2);
-            CSH_UNROLL
-            for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? y2ac : y2dc; lv2[n] = quant(y2[k], q, k ? 108 : 96); dq[k] = lv2[n] * q; }
-            iwht(dq, dcs);
-            int16_t *L = levels + im.lev_off + (size_t(my) * mbw + mx) * 400;
-            LV<int> nzl;
-            LFOR(l) {
-                nzl[l] = 0;
-                if (l == 0) { CSH_UNROLL for (int n = 0; n < 16; n++) L[n] = int16_t(lv2[n]); }
-                if (l < 24) {
+            fdct4(d, coef);
+            dc0[l] = coef[0];
+            if (l < 16) {
+                int big = 0;
+                CSH_UNROLL
+                for (int k = 1; k < 16; k++) big |= ((coef[k] < 0 ? -coef[k] : coef[k]) + ((y1ac * 110) >> 8) >= y1ac) ? 1 : 0;   // <=> its level is not 0
+                acl[l] = big;
+            }
 #ifdef CSH_EMUL
-                    for (int k = 0; k < 16; k++) { coef[k] = coefs[l][k]; pred[k] = preds[l][k]; }
+            for (int k = 0; k < 16; k++) { coefs[l][k] = coef[k]; preds[l][k] = pred[k]; }
 #endif
-                    const bool luma = l < 16;
-                    const int b = luma ? l : (l - 16) & 3;
-                    int c[16], px[16], lv[16];
-                    if (luma) {
-                        int mine = 0;
-                        CSH_UNROLL
-                        for (int k = 0; k < 16; k++) mine = b == k ? dcs[k] : mine;
-                        c[0] = mine; lv[0] = b == 0 ? ymode : b == 1 ? cmode : 0;   // the unused DC slots of luma blocks 0 and 1 carry the modes to k_webp_code (2 and 3: see below)
-                        CSH_UNROLL
-                        for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = quant(coef[k], y1ac, 110); c[k] = lv[n] * y1ac; }
-                    } else {
-                        CSH_UNROLL
-                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? uvac : uvdc; lv[n] = quant(coef[k], q, k ? 115 : 110); c[k] = lv[n] * q; }
-                    }
-                    idct4_add(c, pred, px);
-                    uint8_t *r = luma ? ry + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4
-                                      : (l < 20 ? ru : rv) + size_t(my * 8 + (b >> 1) * 4) * cs + mx * 8 + (b & 1) * 4;
-                    const int stride = luma ? ys : cs;
-                    CSH_UNROLL
-                    for (int rr = 0; rr < 4; rr++)
-                        *reinterpret_cast<uint32_t *>(r + size_t(rr) * stride) = uint32_t(px[rr * 4]) | (uint32_t(px[rr * 4 + 1]) << 8) | (uint32_t(px[rr * 4 + 2]) << 16) | (uint32_t(px[rr * 4 + 3]) << 24);
-                    int16_t *o = L + (luma ? 1 + b : 17 + (l - 16)) * 16;
-                    CSH_UNROLL
-                    for (int n = 0; n < 16; n++) o[n] = int16_t(lv[n]);
-                    int any = 0;
-                    CSH_UNROLL
-                    for (int n = 1; n < 16; n++) any |= lv[n];
-                    if (!luma) any |= lv[0];
-                    nzl[l] = any != 0;
+        }
+    }
+    const bool use4 = lballot([&](int l) { return acl[l] != 0; }) != 0;
+    // the 16 luma DCs to everyone; Walsh-Hadamard, quantise, and back: each luma lane takes its own DC out of the result
+    int dcs[16], y2[16], dq[16], lv2[16];
+    CSH_UNROLL
+    for (int k = 0; k < 16; k++) {
+#ifdef CSH_EMUL
+        dcs[k] = dc0.v[k];
+#else
+        dcs[k] = __builtin_amdgcn_readlane(dc0.v, k);
+#endif
+    }
+    int y2any = 0;
+    if (!use4) {
+        fwht(dcs, y2);
+        CSH_UNROLL
+        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? y2ac : y2dc; lv2[n] = quant(y2[k], q, k ? 108 : 96, k ? r_y2ac : r_y2dc); dq[k] = lv2[n] * q; y2any |= lv2[n]; }
+        iwht(dq, dcs);
+    } else {
+        CSH_UNROLL
+        for (int n = 0; n < 16; n++) lv2[n] = 0;
+    }
+    LV<int> nzl;
+    LFOR(l) {
+        nzl[l] = 0;
+        if (l == 0) { CSH_UNROLL for (int n = 0; n < 16; n++) L[n] = int16_t(lv2[n]); }
+        if (l < 24 && !(use4 && l < 16)) {
+#ifdef CSH_EMUL
+            for (int k = 0; k < 16; k++) { coef[k] = coefs[l][k]; pred[k] = preds[l][k]; }
+#endif
+            const bool luma = l < 16;
+            const int b = luma ? l : (l - 16) & 3;
+            int c[16], px[16], lv[16];
+            if (luma) {   // only when every AC level is 0: the block is its share of the Y2 block
+                int mine = 0;
+                CSH_UNROLL
+                for (int k = 0; k < 16; k++) mine = b == k ? dcs[k] : mine;
+                CSH_UNROLL
+                for (int n = 0; n < 16; n++) { lv[n] = 0; c[n] = 0; }
+                c[0] = mine;
+            } else {
+                CSH_UNROLL
+                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n], q = k ? uvac : uvdc; lv[n] = quant(coef[k], q, k ? 115 : 110, k ? r_uvac : r_uvdc); c[k] = lv[n] * q; }
+            }
+            idct4_add(c, pred, px);
+            uint8_t *r = luma ? ry + size_t(my * 16 + (b >> 2) * 4) * ys + mx * 16 + (b & 3) * 4
+                              : (l < 20 ? ru : rv) + size_t(my * 8 + (b >> 1) * 4) * cs + mx * 8 + (b & 1) * 4;
+            const int stride = luma ? ys : cs;
+            CSH_UNROLL
+            for (int rr = 0; rr < 4; rr++)
+                *reinterpret_cast<uint32_t *>(r + size_t(rr) * stride) = uint32_t(px[rr * 4]) | (uint32_t(px[rr * 4 + 1]) << 8) | (uint32_t(px[rr * 4 + 2]) << 16) | (uint32_t(px[rr * 4 + 3]) << 24);
+            int16_t *o = L + (luma ? 1 + b : 17 + (l - 16)) * 16;
+            CSH_UNROLL
+            for (int n = 0; n < 16; n++) o[n] = int16_t(lv[n]);
+            int any = 0;
+            CSH_UNROLL
+            for (int n = 0; n < 16; n++) any |= lv[n];
+            nzl[l] = any != 0;
+        }
+    }
+    uint32_t luma_nz = 0;
+    if (use4) {
+        // ---- i4x4.  The luma context: the row above (127 above the frame; its corner 129 on the left frame edge below the first row; the four
+        // samples above-right come from the next macroblock of the row above, or repeat the last one at the right frame edge) and the column
+        // to the left (129 outside) -- the decoder's rules
+        LFOR(l) {
+            if (l < 24) {
+                const int x = l - 4;   // byte l of row 0 is sample x of the row above
+                int v = 127;
+                if (x >= -1 && my > 0) {
+                    const uint8_t *top = ry + size_t(my * 16 - 1) * ys + mx * 16;
+                    if (x < 0) v = mx > 0 ? int(coherent_load(top - 1)) : 129;
+                    else if (x < 16) v = coherent_load(top + x);
+                    else v = mx + 1 < mbw ? int(coherent_load(top + x)) : int(coherent_load(top + 15));
+                }
+                s_cb[l] = uint8_t(v);
+            } else if (l >= 32 && l < 48) {
+                const int y = l - 32;
+                s_cb[(y + 1) * 32 + 3] = mx > 0 ? coherent_load(ry + size_t(my * 16 + y) * ys + mx * 16 - 1) : uint8_t(129);
+            } else if (l >= 48 && l < 52) {
+                s_tm[l - 48] = my > 0 ? uint8_t(Ltop[MB_INFO + 4 + 12 + (l - 48)]) : uint8_t(0);
+            } else if (l >= 52 && l < 56) {
+                s_lm[l - 52] = mx > 0 ? uint8_t(Lleft[MB_INFO + 4 + (l - 52) * 4 + 3]) : uint8_t(0);
+            }
+        }
+        CSP_WAVE_SYNC();
+        for (int t = 0; t < 10; t++) {
+            const int by0 = t <= 3 ? 0 : (t - 2) >> 1;
+            LV<uint32_t> key;
+            int px[16], lv[16];
+#ifdef CSH_EMUL
+            int pxs[64][16], lvs[64][16];
+#endif
+            LFOR(l) {
+                const int grp = l >> 4, i = l & 15, by = by0 + grp, bx = t - 2 * by;
+                if (grp < 2 && i < 13 && by <= 3 && bx >= 0 && bx <= 3) {
+                    const uint8_t *d = s_cb + (by * 4 + 1) * 32 + 4 + bx * 4;   // the sub-block's first sample
+                    s_e[grp * 16 + i] = i < 4 ? d[(3 - i) * 32 - 1] : i == 4 ? d[-32 - 1] : i < 9 ? d[-32 + (i - 5)] : bx == 3 ? s_cb[20 + (i - 9)] : d[-32 + 4 + (i - 9)];
                 }
             }
-            // which blocks have anything to code: bit 0 the Y2 block, 1..16 luma, 17..24 chroma -- the token coder's contexts, kept in
-            // the unused DC slots of luma blocks 2 and 3 so that every token partition can look them up without a serial pass
-            {
-                int y2any = 0;
-                CSH_UNROLL
-                for (int n = 0; n < 16; n++) y2any |= lv2[n];
-                const uint64_t bal = lballot([&](int l) { return l < 24 && nzl[l] != 0; });
-                const uint32_t mask = (uint32_t(bal & 0xFFFFFFu) << 1) | (y2any ? 1u : 0u);
-                LFOR(l) if (l == 0) { L[48] = int16_t(mask & 0xFFFFu); L[64] = int16_t(mask >> 16); }
+            CSP_WAVE_SYNC();
+            LFOR(l) {
+                key[l] = 0xFFFFFFFFu;
+                const int grp = l >> 4, m = l & 15, by = by0 + grp, bx = t - 2 * by;
+                if (grp < 2 && m < 10 && by <= 3 && bx >= 0 && bx <= 3) {
+                    const int k = by * 4 + bx;
+                    const uint8_t *e = s_e + grp * 16;
+                    const int tmode = by ? s_bm[k - 4] : s_tm[bx], lmode = bx ? s_bm[k - 1] : s_lm[by];
+                    int p4[16], dd[16], c[16];
+                    if (m == 0) {
+                        const int v = (e[5] + e[6] + e[7] + e[8] + e[3] + e[2] + e[1] + e[0] + 4) >> 3;
+                        CSH_UNROLL
+                        for (int i = 0; i < 16; i++) p4[i] = v;
+                    } else if (m == 1) {
+                        int ee[9];
+                        CSH_UNROLL
+                        for (int i = 0; i < 9; i++) ee[i] = e[i];
+                        CSH_UNROLL
+                        for (int i = 0; i < 16; i++) p4[i] = clip8(ee[3 - (i >> 2)] + ee[5 + (i & 3)] - ee[4]);
+                    } else {
+                        // the directional modes: four taps per sample out of the edge line (vp8_tables.h)
+                        CSH_UNROLL
+                        for (int i = 0; i < 16; i++) {
+                            const uint32_t tp = s_taps[(m - 2) * 16 + i];
+                            p4[i] = (int(e[tp & 15u]) + int(e[(tp >> 4) & 15u]) + int(e[(tp >> 8) & 15u]) + int(e[tp >> 12]) + 2) >> 2;
+                        }
+                    }
+                    CSH_UNROLL
+                    for (int i = 0; i < 16; i++) dd[i] = int(s_src[(by * 4 + (i >> 2)) * 16 + bx * 4 + (i & 3)]) - p4[i];
+                    fdct4(dd, c);
+                    uint32_t satd = 0;
+                    CSH_UNROLL
+                    for (int i = 0; i < 16; i++) satd += uint32_t(c[i] < 0 ? -c[i] : c[i]);
+                    const uint32_t sc = satd * 16u + ((4u * uint32_t(y1ac) * uint32_t(kVp8BModeCost[(tmode * 10 + lmode) * 10 + m])) >> 8);
+                    key[l] = (sc << 4) | uint32_t(m);
+                    // every candidate goes on to its levels and reconstruction: the lanes run together anyway, and the winner has them at hand
+                    int cq[16];
+                    CSH_UNROLL
+                    for (int n = 0; n < 16; n++) { const int z = kVp8Zigzag[n], q = z ? y1ac : y1dc; lv[n] = quant(c[z], q, z ? 110 : 96, z ? r_y1ac : r_y1dc); cq[z] = lv[n] * q; }
+                    idct4_add(cq, p4, px);
+#ifdef CSH_EMUL
+                    for (int i = 0; i < 16; i++) { pxs[l][i] = px[i]; lvs[l][i] = lv[i]; }
+#endif
+                }
             }
+            const LV<uint32_t> best = lrowmin(key);
+            LFOR(l) {
+                const int grp = l >> 4, m = l & 15, by = by0 + grp, bx = t - 2 * by;
+                if (key[l] != 0xFFFFFFFFu && key[l] == best[l]) {
+#ifdef CSH_EMUL
+                    for (int i = 0; i < 16; i++) { px[i] = pxs[l][i]; lv[i] = lvs[l][i]; }
+#endif
+                    const int k = by * 4 + bx;
+                    CSH_UNROLL
+                    for (int rr = 0; rr < 4; rr++)
+                        s_cbw[(by * 4 + rr + 1) * 8 + 1 + bx] = uint32_t(px[rr * 4]) | (uint32_t(px[rr * 4 + 1]) << 8) | (uint32_t(px[rr * 4 + 2]) << 16) | (uint32_t(px[rr * 4 + 3]) << 24);
+                    int16_t *o = L + (1 + k) * 16;
+                    int any = 0;
+                    CSH_UNROLL
+                    for (int n = 0; n < 16; n++) { o[n] = int16_t(lv[n]); any |= lv[n]; }
+                    s_bm[k] = uint8_t(m);
+                    s_nz[k] = any ? 1 : 0;
+                }
+            }
+            CSP_WAVE_SYNC();
+        }
+        // the macroblock's reconstruction to the plane, a word per lane
+        LFOR(l) *reinterpret_cast<uint32_t *>(ry + size_t(my * 16 + (l >> 2)) * ys + mx * 16 + (l & 3) * 4) = s_cbw[((l >> 2) + 1) * 8 + 1 + (l & 3)];
+        luma_nz = uint32_t(lballot([&](int l) { return l < 16 && s_nz[l] != 0; }));
+    } else
+        luma_nz = uint32_t(lballot([&](int l) { return l < 16 && nzl[l] != 0; }));
+    // the info block
+    {
+        const uint32_t chroma_nz = uint32_t(lballot([&](int l) { return l >= 16 && l < 24 && nzl[l] != 0; }) >> 16);
+        const uint32_t left_y2 = mx > 0 ? nz_mask(Lleft) & 1u : 0u, top_y2 = my > 0 ? (nz_mask(Ltop) >> 25) & 1u : 0u;
+        const uint32_t mask = (use4 ? left_y2 : (y2any ? 1u : 0u)) | ((luma_nz & 0xFFFFu) << 1) | ((chroma_nz & 0xFFu) << 17) | ((use4 ? top_y2 : (y2any ? 1u : 0u)) << 25);
+        const int as_b = ymode == 0 ? 0 : ymode == 1 ? 2 : ymode == 2 ? 3 : 1;
+        LFOR(l) {
+            if (l == 0) { I[0] = int16_t(mask & 0xFFFFu); I[1] = int16_t(mask >> 16); I[2] = int16_t(use4 ? 4 : ymode); I[3] = int16_t(cmode); }
+            if (l < 16) I[4 + l] = int16_t(use4 ? int(s_bm[l]) : as_b);
         }
     }
 }
@@ -434,19 +605,18 @@ __device__ static int put_coeffs(S &e, int type, int ctx, const int16_t *lv, int
 // token partitions (macroblock row r belongs to partition r mod P).  Contexts come from the non-zero masks k_webp_mb left
 // with the levels, so no partition waits for another.  Every partition goes to its own slice of a scratch region; the
 // sizes decide where k_webp_assemble puts them.
-__device__ __forceinline__ static uint32_t nz_mask(const int16_t *L) { return uint32_t(uint16_t(L[48])) | (uint32_t(uint16_t(L[64])) << 16); }
 __device__ __forceinline__ static int webp_parts(int mbh) { return mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1; }
-__device__ __forceinline__ static uint32_t webp_hdr_cap(const WebpImg &im) { return 2048u + im.mbw * im.mbh; }
+__device__ __forceinline__ static uint32_t webp_hdr_cap(const WebpImg &im) { return 2048u + ((im.out_cap - 4096u) >> 4); }   // a sixteenth of the file's room (48 bytes per macroblock to begin with): the frame header and the modes, sixteen of them in an i4x4 macroblock; grows with out_cap when a run is repeated
 __device__ __forceinline__ static uint32_t webp_part_cap(const WebpImg &im) { return (im.out_cap - 128u - webp_hdr_cap(im)) / uint32_t(webp_parts(int(im.mbh))); }
 // block k of a macroblock (0 the Y2 block, 1..16 luma, 17..24 chroma): coefficient type, first coded position, and the context
 // "how many of the blocks above / to the left have something to code" out of the three masks
-__device__ __forceinline__ static void block_info(int k, uint32_t cur, uint32_t top, uint32_t left, int &type, int &first, int &ctx) {
-    if (k == 0) { type = 1; first = 0; ctx = int((top & 1u) + (left & 1u)); return; }
+__device__ __forceinline__ static void block_info(int k, uint32_t cur, uint32_t top, uint32_t left, bool i4, int &type, int &first, int &ctx) {
+    if (k == 0) { type = 1; first = 0; ctx = int(((top >> 25) & 1u) + (left & 1u)); return; }
     if (k <= 16) {
         const int b = k - 1, bx = b & 3, by = b >> 2;
         const uint32_t t1 = by ? (cur >> (1 + (by - 1) * 4 + bx)) & 1u : (top >> (13 + bx)) & 1u;
         const uint32_t l1 = bx ? (cur >> (by * 4 + bx)) & 1u : (left >> (4 + by * 4)) & 1u;
-        type = 0; first = 1; ctx = int(t1 + l1);
+        type = i4 ? 3 : 0; first = i4 ? 0 : 1; ctx = int(t1 + l1);   // an i4x4 macroblock's luma blocks carry their own DC
         return;
     }
     const int b = k - 17, pl = b >> 2, bx = b & 1, by = (b >> 1) & 1, b0 = 17 + pl * 4;
@@ -465,13 +635,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *
     if (my >= int(im.mbh)) return;
     LFOR(l) for (int i = l; i < 2 * WEBP_NPROB; i += 64) cnt[i] = 0;
     CSP_WAVE_SYNC();
-    const int16_t *row = levels + im.lev_off + size_t(my) * mbw * 400;
+    const int16_t *row = levels + im.lev_off + size_t(my) * mbw * WEBP_MB_REC;
     for (int mx = 0; mx < mbw; mx++) {
-        const int16_t *L = row + size_t(mx) * 400;
-        const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * 400) : 0u, left = mx ? nz_mask(L - 400) : 0u;
-        LFOR(l) if (l < 25) {
+        const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
+        const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
+        const bool i4 = L[MB_INFO + 2] == 4;
+        LFOR(l) if (l < 25 && !(i4 && l == 0)) {   // no Y2 block in an i4x4 macroblock
             int type, first, ctx;
-            block_info(l, cur, top, left, type, first, ctx);
+            block_info(l, cur, top, left, i4, type, first, ctx);
             StatSink sink{cnt};
             put_coeffs(sink, type, ctx, L + l * 16, first);
         }
@@ -525,23 +696,49 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
         e.bits(0, 1);                                       // refresh_entropy_probs
         for (int i = 0; i < WEBP_NPROB; i++) { e.put(update[i], kVp8CoefUpdateProbs[i]); if (update[i]) e.bits(probs[i], 8); }   // the frame's coefficient probabilities
         e.bits(0, 1);                                       // no skip flags
-        for (int i = 0; i < mbw * mbh; i++) {
-            const int16_t *L = lev + size_t(i) * 400;
-            const int ym = L[16], cm = L[32];
-            e.put(1, 145);                                                                        // i16x16
-            if (ym >= 2) { e.put(1, 156); e.put(ym == 3, 128); } else { e.put(0, 156); e.put(ym == 1, 163); }   // (H | TM) : (DC | V)
-            if (!cm) e.put(0, 142); else { e.put(1, 142); if (cm == 1) e.put(0, 114); else { e.put(1, 114); e.put(cm == 3, 183); } }
-        }
+        for (int my = 0; my < mbh; my++)
+            for (int mx = 0; mx < mbw; mx++) {
+                const int16_t *I = lev + (size_t(my) * mbw + mx) * WEBP_MB_REC + MB_INFO, *It = I - size_t(mbw) * WEBP_MB_REC, *Il = I - WEBP_MB_REC;
+                const int ym = I[2], cm = I[3];
+                if (ym == 4) {
+                    e.put(0, 145);                                                                    // i4x4: sixteen sub-block modes, each after the modes above and to the left
+                    for (int k = 0; k < 16; k++) {
+                        const int bx = k & 3, by = k >> 2, m = I[4 + k];
+                        const int tmode = by ? I[4 + k - 4] : (my ? It[4 + 12 + bx] : 0), lmode = bx ? I[4 + k - 1] : (mx ? Il[4 + by * 4 + 3] : 0);
+                        const uint8_t *pr = kVp8BModeProbs + (tmode * 10 + lmode) * 9;
+                        // the key-frame sub-block mode tree (RFC 6386 11.2; oracle: bmode_path)
+                        if (m == 0) e.put(0, pr[0]);
+                        else {
+                            e.put(1, pr[0]);
+                            if (m == 1) e.put(0, pr[1]);
+                            else {
+                                e.put(1, pr[1]);
+                                if (m == 2) e.put(0, pr[2]);
+                                else {
+                                    e.put(1, pr[2]);
+                                    if (m <= 5) { e.put(0, pr[3]); if (m == 3) e.put(0, pr[4]); else { e.put(1, pr[4]); e.put(m == 5, pr[5]); } }
+                                    else { e.put(1, pr[3]); if (m == 6) e.put(0, pr[6]); else { e.put(1, pr[6]); if (m == 7) e.put(0, pr[7]); else { e.put(1, pr[7]); e.put(m == 9, pr[8]); } } }
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    e.put(1, 145);                                                                    // i16x16
+                    if (ym >= 2) { e.put(1, 156); e.put(ym == 3, 128); } else { e.put(0, 156); e.put(ym == 1, 163); }   // (H | TM) : (DC | V)
+                }
+                if (!cm) e.put(0, 142); else { e.put(1, 142); if (cm == 1) e.put(0, 114); else { e.put(1, 114); e.put(cm == 3, 183); } }
+            }
     } else {
         e.init(base + webp_hdr_cap(im) + uint32_t(part) * webp_part_cap(im), webp_part_cap(im));
         for (int my = part; my < mbh && !e.overflow; my += nparts)
             for (int mx = 0; mx < mbw; mx++) {
-                const int16_t *L = lev + (size_t(my) * mbw + mx) * 400;
-                const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * 400) : 0u, left = mx ? nz_mask(L - 400) : 0u;
+                const int16_t *L = lev + (size_t(my) * mbw + mx) * WEBP_MB_REC;
+                const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
+                const bool i4 = L[MB_INFO + 2] == 4;
                 CodeSink sink{e, probs, {}};
-                for (int k = 0; k < 25; k++) {
+                for (int k = i4 ? 1 : 0; k < 25; k++) {
                     int type, first, ctx;
-                    block_info(k, cur, top, left, type, first, ctx);
+                    block_info(k, cur, top, left, i4, type, first, ctx);
                     put_coeffs(sink, type, ctx, L + k * 16, first);
                 }
             }
@@ -587,9 +784,9 @@ __global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, cons
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work) {
     if (nimg && max_luma) CSH_LAUNCH(k_webp_yuv, dim3((max_luma + 255) / 256, nimg), dim3(256), st, imgs, rgb, work);
 }
-void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels) {
+void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels) {   // one launch per skewed diagonal mx + 2 my
     if (!nimg || !max_mbw || !max_mbh) return;
-    for (uint32_t d = 0; d + 1 < max_mbw + max_mbh; d++) CSH_LAUNCH(k_webp_mb, dim3(max_mbh, unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, imgs, work, levels, int(d));
+    for (uint32_t d = 0; d + 2 < max_mbw + 2 * max_mbh; d++) CSH_LAUNCH(k_webp_mb, dim3(max_mbh, unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, imgs, work, levels, int(d));
 }
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
                       uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {

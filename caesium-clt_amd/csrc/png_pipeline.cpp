@@ -447,7 +447,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
             const uint64_t ly = uint64_t(wi.mbw) * wi.mbh * 256, lc = uint64_t(wi.mbw) * wi.mbh * 64;
             auto take = [&](uint64_t n) { uint64_t at = b->wwork_bytes; b->wwork_bytes += (n + 63) & ~uint64_t(63); return at; };
             wi.y_off = take(ly); wi.u_off = take(lc); wi.v_off = take(lc); wi.ry_off = take(ly); wi.ru_off = take(lc); wi.rv_off = take(lc);
-            wi.lev_off = b->wlevels; b->wlevels += uint64_t(wi.mbw) * wi.mbh * 400;
+            wi.lev_off = b->wlevels; b->wlevels += uint64_t(wi.mbw) * wi.mbh * csw::WEBP_MB_REC;
             b->wmax_luma = std::max<uint32_t>(b->wmax_luma, uint32_t(ly));
             b->wmax_mbh = std::max(b->wmax_mbh, wi.mbh);
             b->wimgs.push_back(wi);

@@ -5,20 +5,22 @@
 
 namespace csw {
 
+enum { WEBP_MB_REC = 432 };   // int16 per macroblock in the level pool: 25 blocks x 16 levels + the info block (k_webp.hip)
+
 struct WebpImg {
     uint32_t width, height, mbw, mbh, ncomp;   // ncomp: 3 = interleaved RGB input, 1 = grey
     int32_t qi;                                // quantiser index 0..127
     uint64_t rgb_off;                          // input pixels in the RGB pool
     uint64_t y_off, u_off, v_off;              // source planes, padded to whole macroblocks (work pool)
     uint64_t ry_off, ru_off, rv_off;           // the encoder's reconstruction (what a decoder will see)
-    uint64_t lev_off;                          // quantised levels: per macroblock 25 blocks x 16 int16, scan order (int16 index)
+    uint64_t lev_off;                          // quantised levels: WEBP_MB_REC int16 per macroblock (int16 index)
     uint64_t out_off;                          // output file region
     uint32_t out_cap;
     uint32_t image;                            // index of the image in the batch's status / size arrays
 };
 
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work);
-void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels);   // one launch per anti-diagonal
+void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels);   // one launch per skewed diagonal of macroblocks
 // stats: nimg x 1056 x 2 counters (zeroed by the caller); probs / update: nimg x 1056 bytes; scratch: a second region laid out like the
 // output pool (every partition is coded into its own slice of it); part_size: nimg x 9
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,

@@ -233,8 +233,9 @@ int cso_webp_quality_to_qi(int quality) {
    chroma DC 110 / AC 115 -- its kBiasMatrices), levels capped at 2047 */
 static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
 
+enum { MODE_REC = 18 };   /* per macroblock: luma mode (0 DC, 1 V, 2 H, 3 TM; 4 = i4x4), chroma mode, the sixteen sub-block modes */
 /* every macroblock's blocks in coding order; row r goes to sink[r mod nsinks] (one = a single sink for all rows) */
-static void token_walk(tsink *one, tsink *sinks, int nsinks, const int16_t *levels, int mbw, int mbh) {
+static void token_walk(tsink *one, tsink *sinks, int nsinks, const int16_t *levels, const uint8_t *modes, int mbw, int mbh) {
     uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
     for (int my = 0; my < mbh; my++) {
         uint8_t left[9]; memset(left, 0, 9);
@@ -242,9 +243,11 @@ static void token_walk(tsink *one, tsink *sinks, int nsinks, const int16_t *leve
         for (int mx = 0; mx < mbw; mx++) {
             const int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
             uint8_t *tp = top + (size_t)mx * 9;
-            tp[8] = left[8] = (uint8_t)put_coeffs(e, 1, tp[8] + left[8], L, 0);
+            const int i4 = modes[((size_t)my * mbw + mx) * MODE_REC] == 4;
+            /* an i4x4 macroblock has no Y2 block (its luma blocks are of type 3 and carry their own DC); the Y2 context flags pass through it untouched */
+            if (!i4) tp[8] = left[8] = (uint8_t)put_coeffs(e, 1, tp[8] + left[8], L, 0);
             for (int by = 0; by < 4; by++)
-                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(e, 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, 1);
+                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(e, i4 ? 3 : 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, i4 ? 0 : 1);
             for (int pl = 0; pl < 2; pl++)
                 for (int by = 0; by < 2; by++)
                     for (int bx = 0; bx < 2; bx++)
@@ -299,6 +302,45 @@ static int predict(const uint8_t *r, int rs, int N, const uint8_t *s, int ss, in
     return best;
 }
 
+/* ---- i4x4: the ten sub-block predictors from the thirteen edge samples e[] = L K J I X A B C D E F G H (vp8_tables.h) */
+static void pred4(int mode, const uint8_t *e, uint8_t *out) {
+    if (mode == 0) { const int v = (e[5] + e[6] + e[7] + e[8] + e[3] + e[2] + e[1] + e[0] + 4) >> 3; memset(out, v, 16); return; }
+    for (int k = 0; k < 16; k++) {
+        if (mode == 1) out[k] = (uint8_t)clip8(e[3 - (k >> 2)] + e[5 + (k & 3)] - e[4]);
+        else { const unsigned t = kVp8Pred4Taps[(mode - 2) * 16 + k]; out[k] = (uint8_t)((e[t & 15] + e[(t >> 4) & 15] + e[(t >> 8) & 15] + e[t >> 12] + 2) >> 2); }
+    }
+}
+/* cost (1/256 bit) of coding sub-block mode m after the modes above and to the left (the fixed key-frame tree, RFC 6386 11.2) */
+static void bmode_path(int m, int *node, int *bit, int *n) {
+    static const signed char path[10][4][2] = {   /* (node, bit) steps of the tree, -1 ends */
+        {{0, 0}, {-1, 0}, {-1, 0}, {-1, 0}}, {{0, 1}, {1, 0}, {-1, 0}, {-1, 0}}, {{0, 1}, {1, 1}, {2, 0}, {-1, 0}},
+        {{3, 0}, {4, 0}, {-1, 0}, {-1, 0}}, {{3, 0}, {4, 1}, {5, 0}, {-1, 0}}, {{3, 0}, {4, 1}, {5, 1}, {-1, 0}},
+        {{3, 1}, {6, 0}, {-1, 0}, {-1, 0}}, {{3, 1}, {6, 1}, {7, 0}, {-1, 0}}, {{3, 1}, {6, 1}, {7, 1}, {8, 0}}, {{3, 1}, {6, 1}, {7, 1}, {8, 1}}};
+    *n = 0;
+    if (m >= 3) { node[0] = 0; bit[0] = 1; node[1] = 1; bit[1] = 1; node[2] = 2; bit[2] = 1; *n = 3; }   /* modes 3..9 sit behind three 1-branches */
+    for (int k = 0; k < 4 && path[m][k][0] >= 0; k++) { node[*n] = path[m][k][0]; bit[*n] = path[m][k][1]; (*n)++; }
+}
+static uint32_t bmode_cost(int m, int top, int left) {
+    const uint8_t *pr = kVp8BModeProbs + (top * 10 + left) * 9;
+    int node[8], bit[8], n;
+    uint32_t c = 0;
+    bmode_path(m, node, bit, &n);
+    for (int k = 0; k < n; k++) c += bool_cost(bit[k] ? 256 - pr[node[k]] : pr[node[k]]);
+    return c;
+}
+/* for the tests: the formula above against the table the device reads (vp8_tables.h) */
+int cso_webp_bmode_cost(int m, int top, int left, int from_table) { return from_table ? kVp8BModeCost[(top * 10 + left) * 10 + m] : (int)bmode_cost(m, top, left); }
+static void put_bmode(boolenc *e, int m, int top, int left) {
+    const uint8_t *pr = kVp8BModeProbs + (top * 10 + left) * 9;
+    int node[8], bit[8], n;
+    bmode_path(m, node, bit, &n);
+    for (int k = 0; k < n; k++) be_put(e, bit[k], pr[node[k]]);
+}
+static const uint8_t kI16AsBMode[4] = {0, 2, 3, 1};   /* what an i16 macroblock (DC, V, H, TM) counts as in its neighbours' sub-block mode contexts */
+/* the sub-block mode choice weighs the transformed residual against the mode's cost: BM_SATD * sum|DCT| + (BM_LAMBDA * q * cost in 1/256 bit) >> BM_SHIFT,
+   q = the luma AC step (weights found on the 1500 px set; tools/webp_rd_eval.py) */
+enum { BM_SATD = 16, BM_LAMBDA = 4, BM_SHIFT = 8 };
+
 /* levels: per macroblock 25 blocks x 16 (Y2, 16 luma, 4 U, 4 V), scan order.  recon planes come back for the tests. */
 int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp, int width, int height, int qi, uint8_t **out, size_t *out_len,
                         uint8_t *ry, uint8_t *ru, uint8_t *rv) {
@@ -311,31 +353,86 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     int own = 0;
     if (!ry) { own = 1; ry = (uint8_t *)malloc((size_t)ys * mbh * 16); ru = (uint8_t *)malloc((size_t)cs * mbh * 8); rv = (uint8_t *)malloc((size_t)cs * mbh * 8); }
     int16_t *levels = (int16_t *)calloc((size_t)mbw * mbh * 400, sizeof(int16_t));
-    uint8_t *modes = (uint8_t *)calloc((size_t)mbw * mbh, 2);   /* per macroblock: luma mode, chroma mode */
-    for (int my = 0; my < mbh; my++)
+    uint8_t *modes = (uint8_t *)calloc((size_t)mbw * mbh, MODE_REC);
+    uint8_t *tmodes = (uint8_t *)calloc((size_t)mbw, 4);       /* sub-block modes of the row above, per column */
+    for (int my = 0; my < mbh; my++) {
+        uint8_t lmodes[4] = {0, 0, 0, 0};
         for (int mx = 0; mx < mbw; mx++) {
             int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
-            /* the intra mode of the 16x16 luma block and of the two 8x8 chroma blocks: DC_PRED, or -- where both the row above
-               and the column to the left exist, so that no edge rule of the decoder is involved -- V_PRED / H_PRED / TM_PRED
-               when that leaves the smaller transformed residual (sum of |DCT coefficients|; ties: the earlier in this order) */
-            uint8_t *M = modes + ((size_t)my * mbw + mx) * 2;
+            uint8_t *M = modes + ((size_t)my * mbw + mx) * MODE_REC;
+            uint8_t *tm = tmodes + (size_t)mx * 4;
             {
                 uint8_t *r = ry + (size_t)my * 16 * ys + mx * 16;
                 const uint8_t *s = yp + (size_t)my * 16 * ys + mx * 16;
+                /* --- i16x16 first: DC_PRED, or -- where both the row above and the column to the left exist -- V / H / TM when that leaves
+                   the smaller transformed residual (sum of |DCT coefficients|; ties: the earlier in this order) */
                 uint8_t pred[256];
-                M[0] = (uint8_t)predict(r, ys, 16, s, ys, mx, my, NULL, NULL, 0, pred, 16);
+                int16_t L16[17 * 16];
+                const int ym = predict(r, ys, 16, s, ys, mx, my, NULL, NULL, 0, pred, 16);
                 int16_t coef[16][16], dcs[16], y2[16], dq[16];
                 for (int b = 0; b < 16; b++) { fdct4(s + (b >> 2) * 4 * ys + (b & 3) * 4, ys, pred + (b >> 2) * 64 + (b & 3) * 4, 16, coef[b]); dcs[b] = coef[b][0]; }
                 fwht(dcs, y2);
-                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc, k ? 108 : 96); dq[k] = (int16_t)(L[n] * (k ? y2ac : y2dc)); }
+                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L16[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc, k ? 108 : 96); dq[k] = (int16_t)(L16[n] * (k ? y2ac : y2dc)); }
                 iwht(dq, dcs);
+                int any16 = 0;
                 for (int b = 0; b < 16; b++) {
-                    int16_t c[16];
-                    c[0] = dcs[b];
-                    L[16 + b * 16] = 0;
-                    for (int n = 1; n < 16; n++) { const int k = kVp8Zigzag[n]; L[16 + b * 16 + n] = (int16_t)quant(coef[b][k], y1ac, 110); c[k] = (int16_t)(L[16 + b * 16 + n] * y1ac); }
-                    (void)y1dc;
-                    idct4_add(c, pred + (b >> 2) * 64 + (b & 3) * 4, 16, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
+                    L16[16 + b * 16] = 0;
+                    for (int n = 1; n < 16; n++) { L16[16 + b * 16 + n] = (int16_t)quant(coef[b][kVp8Zigzag[n]], y1ac, 110); any16 |= L16[16 + b * 16 + n]; }
+                }
+                if (!any16) {
+                    /* nothing but the sixteen DCs (the Y2 block) to code: the macroblock stays i16x16 */
+                    M[0] = (uint8_t)ym;
+                    memcpy(L, L16, sizeof L16);
+                    for (int b = 0; b < 16; b++) {
+                        int16_t c[16];
+                        memset(c, 0, sizeof c);
+                        c[0] = dcs[b];
+                        idct4_add(c, pred + (b >> 2) * 64 + (b & 3) * 4, 16, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
+                    }
+                    for (int k = 0; k < 4; k++) tm[k] = lmodes[k] = kI16AsBMode[ym];
+                } else {
+                    /* --- otherwise i4x4 (on the 1500 px set a rate-distortion comparison of the two codings picked i4x4 for all but a few
+                       of these macroblocks and bought 0.25 %: not worth a second reconstruction on the device).  Sub-blocks in raster order,
+                       each predicted from the reconstruction so far with the decoder's frame-edge rules (127 above the frame, 129 to its
+                       left; the four samples above-right of the MACROBLOCK serve the whole right column of sub-blocks); its mode is the one
+                       with the least BM_SATD * sum|DCT of the residual| + (BM_LAMBDA * q * mode cost) >> BM_SHIFT, ties to the lower mode */
+                    enum { CB = 32 };
+                    uint8_t cbuf[17 * CB], *cb = cbuf + CB + 1;
+                    for (int x = -1; x < 20; x++) {
+                        int v = 127;
+                        if (my > 0) {
+                            if (x < 0) v = mx > 0 ? r[-ys - 1] : 129;
+                            else if (x < 16) v = r[-ys + x];
+                            else v = mx + 1 < mbw ? r[-ys + x] : r[-ys + 15];
+                        }
+                        cb[-CB + x] = (uint8_t)v;
+                    }
+                    for (int y = 0; y < 16; y++) cb[y * CB - 1] = mx > 0 ? r[y * ys - 1] : (uint8_t)129;
+                    M[0] = 4;
+                    memset(L, 0, 16 * sizeof(int16_t));
+                    for (int k = 0; k < 16; k++) {
+                        const int bx = k & 3, by = k >> 2;
+                        uint8_t *d = cb + by * 4 * CB + bx * 4, e[13], best_pred[16];
+                        for (int i = 0; i < 4; i++) { e[i] = d[(3 - i) * CB - 1]; e[5 + i] = d[-CB + i]; e[9 + i] = bx == 3 ? cb[-CB + 16 + i] : d[-CB + 4 + i]; }
+                        e[4] = d[-CB - 1];
+                        uint64_t best = ~0ull;
+                        int bmode = 0;
+                        int16_t bc[16], c[16];
+                        for (int m = 0; m < 10; m++) {
+                            uint8_t p4[16];
+                            pred4(m, e, p4);
+                            fdct4(s + by * 4 * ys + bx * 4, ys, p4, 4, c);
+                            uint64_t sc = 0;
+                            for (int i = 0; i < 16; i++) sc += (uint64_t)(c[i] < 0 ? -c[i] : c[i]);
+                            sc = sc * BM_SATD + (((uint64_t)BM_LAMBDA * y1ac * bmode_cost(m, tm[bx], lmodes[by])) >> BM_SHIFT);
+                            if (sc < best) { best = sc; bmode = m; memcpy(bc, c, sizeof bc); memcpy(best_pred, p4, 16); }
+                        }
+                        M[2 + k] = tm[bx] = lmodes[by] = (uint8_t)bmode;
+                        int16_t *lv = L + 16 + k * 16;
+                        for (int n = 0; n < 16; n++) { const int z = kVp8Zigzag[n], q = z ? y1ac : y1dc; lv[n] = (int16_t)quant(bc[z], q, z ? 110 : 96); c[z] = (int16_t)(lv[n] * q); }
+                        idct4_add(c, best_pred, 4, d, CB);
+                    }
+                    for (int y = 0; y < 16; y++) memcpy(r + (size_t)y * ys, cb + y * CB, 16);
                 }
             }
             {
@@ -355,12 +452,14 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
                 }
             }
         }
+    }
+    free(tmodes);
     /* what the token walk will code, counted first: the frame's coefficient probabilities come from it */
     uint8_t probs[4 * 8 * 3 * 11], update[4 * 8 * 3 * 11];
     {
         uint32_t *stats = (uint32_t *)calloc(2 * 4 * 8 * 3 * 11, sizeof(uint32_t));
         tsink cnt = {NULL, NULL, stats};
-        token_walk(&cnt, NULL, 1, levels, mbw, mbh);
+        token_walk(&cnt, NULL, 1, levels, modes, mbw, mbh);
         choose_probs(stats, probs, update);
         free(stats);
     }
@@ -380,11 +479,26 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     be_bits(&h, 0, 1);            /* refresh_entropy_probs */
     for (int i = 0; i < 4 * 8 * 3 * 11; i++) { be_put(&h, update[i], kVp8CoefUpdateProbs[i]); if (update[i]) be_bits(&h, probs[i], 8); }   /* the frame's coefficient probabilities */
     be_bits(&h, 0, 1);            /* no skip flags */
-    for (int i = 0; i < mbw * mbh; i++) {
-        const int ym = modes[2 * i], cm = modes[2 * i + 1];
-        be_put(&h, 1, 145);                                                               /* i16x16 */
-        if (ym >= 2) { be_put(&h, 1, 156); be_put(&h, ym == 3, 128); } else { be_put(&h, 0, 156); be_put(&h, ym == 1, 163); }   /* (H | TM) : (DC | V) */
-        if (!cm) be_put(&h, 0, 142); else { be_put(&h, 1, 142); if (cm == 1) be_put(&h, 0, 114); else { be_put(&h, 1, 114); be_put(&h, cm == 3, 183); } }
+    {
+        uint8_t *tmo = (uint8_t *)calloc((size_t)mbw, 4);
+        for (int my = 0; my < mbh; my++) {
+            uint8_t lmo[4] = {0, 0, 0, 0};
+            for (int mx = 0; mx < mbw; mx++) {
+                const uint8_t *M = modes + ((size_t)my * mbw + mx) * MODE_REC;
+                const int ym = M[0], cm = M[1];
+                uint8_t *tm = tmo + (size_t)mx * 4;
+                if (ym == 4) {
+                    be_put(&h, 0, 145);                                                       /* i4x4: sixteen sub-block modes, each after its neighbours' */
+                    for (int k = 0; k < 16; k++) { put_bmode(&h, M[2 + k], tm[k & 3], lmo[k >> 2]); tm[k & 3] = lmo[k >> 2] = M[2 + k]; }
+                } else {
+                    be_put(&h, 1, 145);                                                       /* i16x16 */
+                    if (ym >= 2) { be_put(&h, 1, 156); be_put(&h, ym == 3, 128); } else { be_put(&h, 0, 156); be_put(&h, ym == 1, 163); }   /* (H | TM) : (DC | V) */
+                    for (int k = 0; k < 4; k++) tm[k] = lmo[k] = kI16AsBMode[ym];
+                }
+                if (!cm) be_put(&h, 0, 142); else { be_put(&h, 1, 142); if (cm == 1) be_put(&h, 0, 114); else { be_put(&h, 1, 114); be_put(&h, cm == 3, 183); } }
+            }
+        }
+        free(tmo);
     }
     be_flush(&h);
     /* token partitions: macroblock row r goes to partition r mod P, P = 8 / 4 / 2 / 1 by the number of rows.  The contexts
@@ -396,7 +510,7 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     {
         tsink code[8];
         for (int p = 0; p < nparts; p++) { code[p].e = &t[p]; code[p].probs = probs; code[p].stats = NULL; }
-        token_walk(NULL, code, nparts, levels, mbw, mbh);
+        token_walk(NULL, code, nparts, levels, modes, mbw, mbh);
     }
     size_t tok = 0;
     for (int p = 0; p < nparts; p++) { be_flush(&t[p]); tok += t[p].pos; }

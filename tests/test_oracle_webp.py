@@ -65,3 +65,27 @@ def test_quality_against_libwebp_at_the_same_setting():
 
 def test_quality_curve():
     assert [O.webp_quality_to_qi(q) for q in (0, 50, 75, 85, 100)] == [127, 39, 26, 14, 0]
+
+
+def test_sub_block_mode_cost_table_is_the_formula():
+    L = O.lib()
+    for top in range(10):
+        for left in range(10):
+            for m in range(10):
+                assert L.cso_webp_bmode_cost(m, top, left, 1) == L.cso_webp_bmode_cost(m, top, left, 0)
+
+
+@pytest.mark.parametrize("w,h,q,texture", [(97, 61, 85, 8.0), (48, 48, 92, 12.0), (200, 120, 60, 6.0), (16, 200, 85, 9.0), (250, 16, 85, 9.0), (129, 130, 100, 10.0)])
+def test_i4x4_macroblocks_reconstruct_like_libwebp(w, h, q, texture):
+    """Textured pictures make most macroblocks i4x4 (sub-block modes at the frame edges, along the right column where the samples above-right
+    come from the next macroblock, on one-macroblock-wide and -high pictures): the encoder's reconstruction must be the decoder's."""
+    rgb = crop(11, w, h, texture=texture)
+    y, u, v = O.webp_rgb_to_yuv(rgb)
+    data, (ry, ru, rv) = O.webp_encode_yuv(y, u, v, w, h, O.webp_quality_to_qi(q))
+    Y, U, V = libwebp_decode_yuv(data)
+    assert np.array_equal(Y, ry[:h, :w]) and np.array_equal(U, ru[:(h + 1) // 2, :(w + 1) // 2]) and np.array_equal(V, rv[:(h + 1) // 2, :(w + 1) // 2])
+    # the i4x4 flag of the first macroblock's header is not visible from here; what is: such pictures must now be smaller than libwebp's
+    # i16-only coding would allow -- checked loosely against libwebp itself at the same quality
+    b = io.BytesIO()
+    PIL.fromarray(rgb).save(b, "WEBP", quality=q)
+    assert len(data) < 1.35 * len(b.getvalue()) + 200
