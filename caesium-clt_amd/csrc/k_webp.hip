@@ -671,21 +671,11 @@ __global__ void __launch_bounds__(256) k_webp_probs(const WebpImg *imgs, const u
     probs[size_t(im.image) * WEBP_NPROB + i] = uint8_t(use ? np : oldp);
 }
 
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, const uint8_t *probs_all, const uint8_t *update_all, uint8_t *scratch,
-                                                                 uint32_t *part_size, const uint32_t *status) {
-    const WebpImg im = imgs[blockIdx.x];
-    if (status[im.image]) return;
-    const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh), part = int(blockIdx.y) - 1;
-    if (part >= nparts) return;
-    const int16_t *lev = levels + im.lev_off;
-    const uint8_t *probs_g = probs_all + size_t(im.image) * WEBP_NPROB, *update = update_all + size_t(im.image) * WEBP_NPROB;
-    CSH_SHARED uint8_t s_probs[WEBP_NPROB];
-    LFOR(l) for (int i = l; i < WEBP_NPROB; i += 64) s_probs[i] = probs_g[i];
-    CSP_WAVE_SYNC();
-    const uint8_t *probs = s_probs;
-    uint8_t *base = scratch + im.out_off;
+// the header partition (frame header, the frame's coefficient probabilities, every macroblock's modes) is a function of its own, not inlined: next to it
+// in one body the token walk's coder state no longer fitted the scalar registers, and the eight token waves of a picture ran 3.4 x slower
+__device__ __attribute__((noinline)) static void code_header(const WebpImg &im, const int16_t *lev, const uint8_t *probs, const uint8_t *update, const uint8_t *s_bmp, uint8_t *base, uint32_t *size_out) {
+    const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh);
     BoolEnc e;
-    if (part < 0) {
         e.init(base, webp_hdr_cap(im));
         e.bits(0, 1); e.bits(0, 1); e.bits(0, 1);           // colour space, clamping, no segmentation
         e.bits(1, 1); e.bits(0, 6); e.bits(0, 3);           // simple filter at level 0 (off), sharpness
@@ -696,39 +686,85 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
         e.bits(0, 1);                                       // refresh_entropy_probs
         for (int i = 0; i < WEBP_NPROB; i++) { e.put(update[i], kVp8CoefUpdateProbs[i]); if (update[i]) e.bits(probs[i], 8); }   // the frame's coefficient probabilities
         e.bits(0, 1);                                       // no skip flags
-        for (int my = 0; my < mbh; my++)
-            for (int mx = 0; mx < mbw; mx++) {
-                const int16_t *I = lev + (size_t(my) * mbw + mx) * WEBP_MB_REC + MB_INFO, *It = I - size_t(mbw) * WEBP_MB_REC, *Il = I - WEBP_MB_REC;
-                const int ym = I[2], cm = I[3];
-                if (ym == 4) {
-                    e.put(0, 145);                                                                    // i4x4: sixteen sub-block modes, each after the modes above and to the left
-                    for (int k = 0; k < 16; k++) {
-                        const int bx = k & 3, by = k >> 2, m = I[4 + k];
-                        const int tmode = by ? I[4 + k - 4] : (my ? It[4 + 12 + bx] : 0), lmode = bx ? I[4 + k - 1] : (mx ? Il[4 + by * 4 + 3] : 0);
-                        const uint8_t *pr = kVp8BModeProbs + (tmode * 10 + lmode) * 9;
-                        // the key-frame sub-block mode tree (RFC 6386 11.2; oracle: bmode_path)
-                        if (m == 0) e.put(0, pr[0]);
+        // the modes: this wave is one serial chain over every macroblock of the picture, so nothing in it may wait for HBM per decision.  A macroblock's
+        // info block and the neighbours' modes it needs arrive with one load, a macroblock ahead (lanes 0..19 its info, 32..35 the sub-block modes above,
+        // 40..43 those to the left); the sub-block mode probabilities sit in LDS and come a row (nine) at a time
+        auto info_of = [&](int i) {
+            LV<int> v;
+            const int my = i / mbw, mx = i - my * mbw;
+            const int16_t *I = lev + size_t(i) * WEBP_MB_REC + MB_INFO, *It = I - size_t(mbw) * WEBP_MB_REC, *Il = I - WEBP_MB_REC;
+            LFOR(l) {
+                int x = 0;
+                if (i < mbw * mbh) {
+                    if (l < 20) x = I[l];
+                    else if (l >= 32 && l < 36) x = my ? int(It[4 + 12 + (l - 32)]) : 0;
+                    else if (l >= 40 && l < 44) x = mx ? int(Il[4 + (l - 40) * 4 + 3]) : 0;
+                }
+                v[l] = x;
+            }
+            return v;
+        };
+        auto rd = [](const LV<int> &v, int i) {
+#ifdef CSH_EMUL
+            return v.v[i];
+#else
+            return __builtin_amdgcn_readlane(v.v, i);
+#endif
+        };
+        LV<int> inf = info_of(0);
+        for (int i = 0; i < mbw * mbh; i++) {
+            const LV<int> nxt = info_of(i + 1);
+            const int ym = rd(inf, 2), cm = rd(inf, 3);
+            if (ym == 4) {
+                e.put(0, 145);                                                                    // i4x4: sixteen sub-block modes, each after the modes above and to the left
+                for (int k = 0; k < 16; k++) {
+                    const int bx = k & 3, by = k >> 2, m = rd(inf, 4 + k);
+                    const int tmode = by ? rd(inf, 4 + k - 4) : rd(inf, 32 + bx), lmode = bx ? rd(inf, 4 + k - 1) : rd(inf, 40 + by);
+                    LV<int> prv;
+                    LFOR(l) prv[l] = l < 9 ? int(s_bmp[(tmode * 10 + lmode) * 9 + l]) : 0;
+                    // the key-frame sub-block mode tree (RFC 6386 11.2; oracle: bmode_path)
+                    if (m == 0) e.put(0, rd(prv, 0));
+                    else {
+                        e.put(1, rd(prv, 0));
+                        if (m == 1) e.put(0, rd(prv, 1));
                         else {
-                            e.put(1, pr[0]);
-                            if (m == 1) e.put(0, pr[1]);
+                            e.put(1, rd(prv, 1));
+                            if (m == 2) e.put(0, rd(prv, 2));
                             else {
-                                e.put(1, pr[1]);
-                                if (m == 2) e.put(0, pr[2]);
-                                else {
-                                    e.put(1, pr[2]);
-                                    if (m <= 5) { e.put(0, pr[3]); if (m == 3) e.put(0, pr[4]); else { e.put(1, pr[4]); e.put(m == 5, pr[5]); } }
-                                    else { e.put(1, pr[3]); if (m == 6) e.put(0, pr[6]); else { e.put(1, pr[6]); if (m == 7) e.put(0, pr[7]); else { e.put(1, pr[7]); e.put(m == 9, pr[8]); } } }
-                                }
+                                e.put(1, rd(prv, 2));
+                                if (m <= 5) { e.put(0, rd(prv, 3)); if (m == 3) e.put(0, rd(prv, 4)); else { e.put(1, rd(prv, 4)); e.put(m == 5, rd(prv, 5)); } }
+                                else { e.put(1, rd(prv, 3)); if (m == 6) e.put(0, rd(prv, 6)); else { e.put(1, rd(prv, 6)); if (m == 7) e.put(0, rd(prv, 7)); else { e.put(1, rd(prv, 7)); e.put(m == 9, rd(prv, 8)); } } }
                             }
                         }
                     }
-                } else {
-                    e.put(1, 145);                                                                    // i16x16
-                    if (ym >= 2) { e.put(1, 156); e.put(ym == 3, 128); } else { e.put(0, 156); e.put(ym == 1, 163); }   // (H | TM) : (DC | V)
                 }
-                if (!cm) e.put(0, 142); else { e.put(1, 142); if (cm == 1) e.put(0, 114); else { e.put(1, 114); e.put(cm == 3, 183); } }
+            } else {
+                e.put(1, 145);                                                                    // i16x16
+                if (ym >= 2) { e.put(1, 156); e.put(ym == 3, 128); } else { e.put(0, 156); e.put(ym == 1, 163); }   // (H | TM) : (DC | V)
             }
-    } else {
+            if (!cm) e.put(0, 142); else { e.put(1, 142); if (cm == 1) e.put(0, 114); else { e.put(1, 114); e.put(cm == 3, 183); } }
+            inf = nxt;
+        }
+    e.finish();
+    LANE0 *size_out = e.overflow ? 0xFFFFFFFFu : e.pos;
+}
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *imgs, const int16_t *levels, const uint8_t *probs_all, const uint8_t *update_all, uint8_t *scratch,
+                                                                 uint32_t *part_size, const uint32_t *status) {
+    const WebpImg im = imgs[blockIdx.x];
+    if (status[im.image]) return;
+    const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh), part = int(blockIdx.y) - 1;
+    if (part >= nparts) return;
+    const int16_t *lev = levels + im.lev_off;
+    const uint8_t *probs_g = probs_all + size_t(im.image) * WEBP_NPROB, *update = update_all + size_t(im.image) * WEBP_NPROB;
+    CSH_SHARED uint8_t s_probs[WEBP_NPROB], s_bmp[900];
+    LFOR(l) for (int i = l; i < WEBP_NPROB; i += 64) s_probs[i] = probs_g[i];
+    if (part < 0) { LFOR(l) for (int i = l; i < 900; i += 64) s_bmp[i] = kVp8BModeProbs[i]; }
+    CSP_WAVE_SYNC();
+    const uint8_t *probs = s_probs;
+    uint8_t *base = scratch + im.out_off;
+    if (part < 0) { code_header(im, lev, probs, update, s_bmp, base, &part_size[size_t(im.image) * 9]); return; }
+    BoolEnc e;
+    {
         e.init(base + webp_hdr_cap(im) + uint32_t(part) * webp_part_cap(im), webp_part_cap(im));
         for (int my = part; my < mbh && !e.overflow; my += nparts)
             for (int mx = 0; mx < mbw; mx++) {
