@@ -514,7 +514,7 @@ static int jpeg_to_png(const CByteArray *inputs, size_t count, const CCSParamete
 // the same encoder), JPEG -> PNG and PNG -> JPEG (csp_png_to_jpeg) run on the device; every other pair of formats has no device path
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
-    std::vector<size_t> ok, okpng, topng, tojpeg, fromwebp, tolossless;
+    std::vector<size_t> ok, okpng, topng, tojpeg_, fromwebp, tolossless, pnglossless;
     for (size_t i = 0; i < count; i++) {
         outputs[i].data = nullptr; outputs[i].length = 0;
         const int src = sniff(inputs[i].data, inputs[i].length);
@@ -522,11 +522,11 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         if (src == CS_TYPE_UNKN) { code = CS_ERR_UNKNOWN_TYPE; msg = "unknown file type"; }
         else if (uint32_t(src) == format) { code = CS_ERR_SAME_FORMAT; msg = "cannot convert to the same format"; }
         else if (src == CS_TYPE_JPEG && format == CS_TYPE_PNG) { topng.push_back(i); continue; }
-        else if (src == CS_TYPE_PNG && format == CS_TYPE_JPEG) { tojpeg.push_back(i); continue; }
+        else if (src == CS_TYPE_PNG && format == CS_TYPE_JPEG) { tojpeg_.push_back(i); continue; }
         else if (src == CS_TYPE_WEBP && (format == CS_TYPE_JPEG || format == CS_TYPE_PNG)) { fromwebp.push_back(i); continue; }
         else if ((src != CS_TYPE_JPEG && src != CS_TYPE_PNG) || format != CS_TYPE_WEBP) { code = CS_ERR_UNSUPPORTED; msg = "this format conversion has no device path in this build (built: JPEG / PNG -> WebP, JPEG <-> PNG, WebP -> JPEG / PNG)"; }
         else if (p->webp_lossless && src == CS_TYPE_JPEG) { tolossless.push_back(i); continue; }
-        else if (p->webp_lossless) { code = CS_ERR_UNSUPPORTED; msg = "PNG -> lossless WebP has no device path in this build"; }
+        else if (p->webp_lossless) { pnglossless.push_back(i); continue; }
         if (code) { if (results) results[i] = make_result(code, msg); failed_total++; } else (src == CS_TYPE_PNG ? okpng : ok).push_back(i);
     }
     std::vector<CByteArray> ok_in(ok.size());
@@ -570,6 +570,8 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         failed_total += jpeg_to_png(in.data(), n, p, device, out.data(), res.data());
         for (size_t k = 0; k < n; k++) { outputs[topng[k]] = out[k]; if (results) results[topng[k]] = res[k]; else cs_free_result(&res[k]); }
     }
+    for (int pass = 0; pass < 2; pass++) {
+    const std::vector<size_t> &tojpeg = pass ? pnglossless : tojpeg_;   // PNG -> lossless WebP: the same decode, the VP8L coder behind it
     for (size_t g0 = 0, n = 0; g0 < tojpeg.size(); g0 += n) {   // groups of at most 256 files and 96 GB of decode buffers (8 bytes per pixel at most, three regions)
         uint64_t bytes = 0;
         for (n = 0; g0 + n < tojpeg.size() && n < 256; n++) {
@@ -582,8 +584,9 @@ int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters
         std::vector<CByteArray> in(n), out(n);
         std::vector<CCSResult> res(n);
         for (size_t k = 0; k < n; k++) in[k] = inputs[tojpeg[g0 + k]];
-        failed_total += csp_png_to_jpeg(in.data(), n, p, device, out.data(), res.data());
+        failed_total += pass ? csp_png_to_lossless_webp(in.data(), n, p, device, out.data(), res.data()) : csp_png_to_jpeg(in.data(), n, p, device, out.data(), res.data());
         for (size_t k = 0; k < n; k++) { outputs[tojpeg[g0 + k]] = out[k]; if (results) results[tojpeg[g0 + k]] = res[k]; else cs_free_result(&res[k]); }
+    }
     }
     if (!okpng.empty()) {
         const size_t n = okpng.size();

@@ -876,7 +876,10 @@ static CCSResult png_result(int code, const char *msg) {
 // RGB (k_png_rgb: palette looked up, 16-bit narrowed, sub-byte grey scaled; an alpha channel or tRNS is dropped, as image-rs's JPEG
 // encoder does [UPSTREAM-RECALL]), then the JPEG batch object from those pixels (csh_batch_create_from_pixels: its resize honours
 // width / height, its encoder p's JPEG parameters).  Device to device; results in input order.
-extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+// PNG -> JPEG and PNG -> lossless WebP share everything up to the pixels: decode (any PNG format), 8-bit grey / RGB in device memory.  The lossless
+// WebP target refuses pictures with transparency (dropping it would not be lossless) and sends the pixels -- resized first when a size is given,
+// through the JPEG row's resize branch stopped behind its RGB -- to the VP8L coder (csl_encode_pixels).
+static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results, bool lossless_webp) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
     auto fail_all = [&](int rc) { for (size_t i = 0; i < count; i++) if (results) results[i] = png_result(rc, csh_last_error()); return int(count); };
     CCSParameters q = *p;
@@ -902,7 +905,9 @@ extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCS
         int code = it.code;
         const char *msg = it.msg.c_str();
         if (!code && status[it.image]) { code = int(status[it.image]); msg = "malformed PNG data"; }
-        if (!code && (it.width > 65535 || it.height > 65535)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a JPEG"; }
+        if (!code && !lossless_webp && (it.width > 65535 || it.height > 65535)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a JPEG"; }
+        if (!code && lossless_webp && (it.width > 16384 || it.height > 16384)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a WebP"; }
+        if (!code && lossless_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { code = CS_ERR_UNSUPPORTED; msg = "PNG -> lossless WebP with transparency has no device path in this build"; }
         if (code) { if (results) results[i] = png_result(code, msg); failed++; continue; }
         RgbJob e{};
         e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth;
@@ -923,6 +928,25 @@ extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCS
     launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG kernels failed"); return fail_rest(CS_ERR_NO_DEVICE); }
     for (size_t k = 0; k < px.size(); k++) px[k].device_pixels = d_src.p + ejobs[k].dst_off;
+    if (lossless_webp) {
+        std::vector<csp_pixels> src = px;
+        csh_batch *rb = nullptr;
+        if (p->width || p->height) {
+            rc = csh_batch_create_from_pixels_rgb(px.data(), px.size(), p, device, &rb);
+            if (rc == 0) rc = csh_batch_run(rb, nullptr);
+            for (size_t k = 0; k < px.size() && rc == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) rc = CS_ERR_NO_DEVICE; }
+        }
+        std::vector<CByteArray> out(px.size());
+        std::vector<CCSResult> res(px.size());
+        const int lf = rc ? -1 : csl_encode_pixels(src.data(), src.size(), device, out.data(), res.data());
+        for (size_t k = 0; k < px.size(); k++) {
+            if (lf < 0) { if (results) results[at[k]] = png_result(rc ? rc : CS_ERR_NO_DEVICE, csh_last_error()); continue; }
+            outputs[at[k]] = out[k];
+            if (results) results[at[k]] = res[k]; else cs_free_result(&res[k]);
+        }
+        csh_batch_destroy(rb);
+        return failed + (lf < 0 ? int(px.size()) : lf);
+    }
     csh_batch *jb = nullptr;
     rc = csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
     if (rc == 0) rc = csh_batch_run(jb, nullptr);
@@ -936,6 +960,12 @@ extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCS
     }
     csh_batch_destroy(jb);
     return failed + (jf < 0 ? int(px.size()) : jf);
+}
+extern "C" int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+    return png_to_pixels_then(inputs, count, p, device, outputs, results, false);
+}
+extern "C" int csp_png_to_lossless_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
+    return png_to_pixels_then(inputs, count, p, device, outputs, results, true);
 }
 
 

@@ -199,6 +199,9 @@ int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSPa
    decode stages, the pixels as 8-bit grey / RGB (alpha dropped), then the JPEG resize + encoder with p's parameters.  Returns the
    number of failed files; outputs / results in input order */
 int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results);
+/* PNG -> lossless WebP (`--format webp --lossless` on a PNG; compressor.rs:289-305 with webp.lossless): the same decode, the VP8L coder behind it;
+   pictures with an alpha channel or a tRNS chunk answer CS_ERR_UNSUPPORTED per file */
+int csp_png_to_lossless_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results);
 int csp_batch_run(csp_batch *b, csp_timing *t);
 int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results);
 void csp_batch_destroy(csp_batch *b);

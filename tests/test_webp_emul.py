@@ -68,8 +68,10 @@ def test_entry_point_and_refusals(api):
     assert e.value.code == 10201
     out = api.convert_in_memory(src, pkg.default_parameters(webp_quality=85, webp_lossless=True), WEBP)   # lossless WebP from a JPEG: tests/test_webp_lossless_emul.py
     assert out[8:16] == b"WEBPVP8L"
+    out = api.convert_in_memory(dict(png_cases())["RGB_97x61"], pkg.default_parameters(webp_lossless=True), WEBP)   # and from an opaque PNG
+    assert out[8:16] == b"WEBPVP8L"
     with pytest.raises(Exception) as e:
-        api.convert_in_memory(dict(png_cases())["RGB_97x61"], pkg.default_parameters(webp_lossless=True), WEBP)   # from a PNG: not built
+        api.convert_in_memory(dict(png_cases())["RGBA_97x61"], pkg.default_parameters(webp_lossless=True), WEBP)   # transparency: not built
     assert e.value.code == 10201
 
 

@@ -79,3 +79,27 @@ def test_emul_lossless_webp_failures_stay_per_file(api):
     outs = api.cs_batch_compress([good, good[:50], alpha, good], params(webp_lossless=True))
     assert [isinstance(o, Exception) for o in outs] == [False, True, True, False]
     check_vp8l(outs[0], D.libwebp_rgb(good)); check_vp8l(outs[3], D.libwebp_rgb(good))
+
+
+def test_emul_png_to_lossless_webp(api):
+    """--format webp --lossless over PNG sources: the PNG row's decode, the VP8L coder behind it.  8-bit and palette / low-depth opaque pictures must
+    come back as exactly the pixels libpng (Pillow) reads; transparency is refused per file; a size resizes first."""
+    from _util import png_cases
+    from test_png_webp_emul import extra_cases
+    cases = dict(png_cases())
+    cases.update(dict(extra_cases()))
+    exact = ["RGB_97x61", "L_97x61", "P_97x61", "1_97x61", "RGB_flat_64x48", "RGB_200x150_3chunks", "RGB_stored_input", "L_level1_input", "RGB_1x1", "L_1x300",
+             "grey2_70x45", "grey4_70x45", "short_plte_70x45"]
+    refused = ["RGBA_97x61", "LA_97x61", "RGBA_300x2", "reduce_blocked_by_trns"]
+    outs = api.batch_convert([cases[n] for n in exact + refused + ["I;16_97x61", "rgb16_70x45"]], params(webp_lossless=True), 3)
+    for name, out in zip(exact, outs):
+        assert isinstance(out, bytes), (name, out)
+        check_vp8l(out, np.asarray(Image.open(io.BytesIO(cases[name])).convert("RGB")))
+    for name, out in zip(refused, outs[len(exact):]):
+        assert getattr(out, "code", 0) == 10201, (name, out)
+    for name, out in zip(["I;16_97x61", "rgb16_70x45"], outs[len(exact) + len(refused):]):   # 16-bit samples are narrowed (the lossy PNG -> WebP path pins the rule)
+        assert isinstance(out, bytes) and Image.open(io.BytesIO(out)).size == Image.open(io.BytesIO(cases[name])).size, name
+    # the same pixels as the lossy conversion's source: a JPEG made from the PNG at 4:4:4 q100 is not exact, so compare with PNG -> PNG resize instead
+    small = api.convert_in_memory(cases["RGB_200x150_3chunks"], params(webp_lossless=True, width=80), 3)
+    assert Image.open(io.BytesIO(small)).size == (80, 60)
+    assert api.convert_in_memory(cases["RGB_97x61"], params(webp_lossless=True), 3) == outs[0]

@@ -37,3 +37,7 @@ def test_emulation_and_device_write_the_same_bytes(api):
     src = D.lossless_of(synth_rgb(9, 150, 90, texture=20.0))
     p = E.params(webp_lossless=True)
     assert api.compress_in_memory(src, p) == emul_api().compress_in_memory(src, p)
+
+
+def test_png_to_lossless_webp(api):
+    E.test_emul_png_to_lossless_webp(api)
