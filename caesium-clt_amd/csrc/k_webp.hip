@@ -1,5 +1,5 @@
 // k_webp.hip -- the lossy WebP row on the device; statement: oracle/webp_oracle.c.
-//   k_webp_yuv   W1: RGB -> YUV 4:2:0 planes padded to whole macroblocks, one lane per sample
+//   k_webp_yuv   W1: RGB -> YUV 4:2:0 planes padded to whole macroblocks, one lane per sample; libwebp's import (chroma averaged in gamma-0.80 linear light)
 //   k_webp_mb    W2: prediction, transforms, quantisation, reconstruction.  DC prediction needs the reconstructed
 //                neighbours, so the macroblocks of an image form a chain: ONE WAVE PER IMAGE walks them in raster order and
 //                its lanes are the blocks of the macroblock (0..15 luma, 16..19 U, 20..23 V); the 16 luma DCs meet by
@@ -21,9 +21,10 @@ using namespace csp;   // LFOR / LV / lsum / coherent_load (png_wave.h)
 
 __device__ __forceinline__ static int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 
+// libwebp's import (oracle: cso_webp_rgb_to_yuv, pinned against WebPPictureImportRGB): chroma from the 2x2 block's mean in gamma-0.80 linear light
 __global__ void __launch_bounds__(256) k_webp_yuv(const WebpImg *imgs, const uint8_t *rgb, uint8_t *work) {
     const WebpImg &im = imgs[blockIdx.y];
-    const int w = int(im.width), h = int(im.height), ys = int(im.mbw) * 16, cs = int(im.mbw) * 8, nc = int(im.ncomp);
+    const int w = int(im.width), h = int(im.height), ys = int(im.mbw) * 16, cs = int(im.mbw) * 8, nc = int(im.ncomp), cw = (w + 1) >> 1, ch = (h + 1) >> 1;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint8_t *src = rgb + im.rgb_off;
     auto px = [&](int yy, int xx, int &r, int &g, int &b) {
@@ -38,9 +39,13 @@ __global__ void __launch_bounds__(256) k_webp_yuv(const WebpImg *imgs, const uin
     }
     if (i < uint32_t(cs) * im.mbh * 8) {
         const int y = int(i / uint32_t(cs)), x = int(i - uint32_t(y) * cs);
+        const int cx = x < cw ? x : cw - 1, cy = y < ch ? y : ch - 1;   // beyond the picture: the plane's last sample again
+        // the two tables (578 bytes) stay in the first-level cache; twelve gathers per chroma sample next to twelve bytes from HBM
         int r = 0, g = 0, b = 0;
         for (int dy = 0; dy < 2; dy++)
-            for (int dx = 0; dx < 2; dx++) { int r1, g1, b1; px(2 * y + dy, 2 * x + dx, r1, g1, b1); r += r1; g += g1; b += b1; }
+            for (int dx = 0; dx < 2; dx++) { int r1, g1, b1; px(2 * cy + dy, 2 * cx + dx, r1, g1, b1); r += kVp8GammaToLinear[r1]; g += kVp8GammaToLinear[g1]; b += kVp8GammaToLinear[b1]; }
+        auto back = [&](int s) { const int pos = s >> 9, f = s & 511; return (int(kVp8LinearToGamma[pos + 1]) * f + int(kVp8LinearToGamma[pos]) * (512 - f) + 64) >> 7; };
+        r = back(r); g = back(g); b = back(b);
         work[im.u_off + i] = uint8_t(clip8((-9719 * r - 19081 * g + 28800 * b + (128 << 18) + (1 << 17)) >> 18));
         work[im.v_off + i] = uint8_t(clip8((28800 * r - 24116 * g - 4684 * b + (128 << 18) + (1 << 17)) >> 18));
     }

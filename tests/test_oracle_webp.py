@@ -89,3 +89,51 @@ def test_i4x4_macroblocks_reconstruct_like_libwebp(w, h, q, texture):
     b = io.BytesIO()
     PIL.fromarray(rgb).save(b, "WEBP", quality=q)
     assert len(data) < 1.35 * len(b.getvalue()) + 200
+
+
+def libwebp_import_rgb(rgb):
+    """libwebp's own RGB -> YUV 4:2:0 (WebPPictureImportRGB on a picture with use_argb = 0), read out of its WebPPicture: use_argb, colorspace, width, height
+    (4 x int32), y / u / v pointers, y_stride, uv_stride -- the head of the struct in webp/encode.h since libwebp 0.5"""
+    name = ctypes.util.find_library("webp")
+    if not name:
+        pytest.skip("no system libwebp")
+    W = C.CDLL(name)
+    if not hasattr(W, "WebPPictureImportRGB"):
+        pytest.skip("libwebp without the encoder API")
+    h, w, _ = rgb.shape
+    buf = (C.c_uint8 * 1024)()
+    assert W.WebPPictureInitInternal(buf, 0x020f)
+    ints = C.cast(buf, C.POINTER(C.c_int32))
+    assert ints[0] == 0
+    ints[2], ints[3] = w, h
+    rgb = np.ascontiguousarray(rgb)
+    W.WebPPictureImportRGB.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert W.WebPPictureImportRGB(buf, rgb.ctypes.data, w * 3)
+    ptrs = C.cast(buf, C.POINTER(C.c_void_p))
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    planes = []
+    for k, (rows, cols, stride) in enumerate([(h, w, ints[10]), (ch, cw, ints[11]), (ch, cw, ints[11])]):
+        planes.append(np.ctypeslib.as_array(C.cast(ptrs[2 + k], C.POINTER(C.c_uint8)), shape=(rows, stride))[:, :cols].copy())
+    W.WebPPictureFree(buf)
+    return planes
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (33, 17), (1, 1), (2, 5), (255, 3), (16, 16), (161, 97)])
+def test_rgb_to_yuv_is_libwebp_s_import(w, h):
+    """W1 pinned to the library: luma and the gamma-weighted chroma of WebPPictureImportRGB, bit for bit, odd sizes included; the macroblock padding
+    repeats each plane's last sample"""
+    rng = np.random.default_rng(w * 1000 + h)
+    for rgb in (rng.integers(0, 256, (h, w, 3), dtype=np.uint8), crop(w + h, w, h, texture=5.0)):
+        y, u, v = O.webp_rgb_to_yuv(rgb)
+        Y, U, V = libwebp_import_rgb(rgb)
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        assert np.array_equal(y[:h, :w], Y) and np.array_equal(u[:ch, :cw], U) and np.array_equal(v[:ch, :cw], V)
+        assert (y[:, w:] == y[:, w - 1:w]).all() and (y[h:] == y[h - 1]).all() and (u[:, cw:] == u[:, cw - 1:cw]).all() and (v[ch:] == v[ch - 1]).all()
+
+
+def test_gamma_tables_cover_every_sample_value():
+    v = np.arange(256, dtype=np.uint8)
+    rgb = np.repeat(np.repeat(np.stack([v, v[::-1], np.roll(v, 77)], -1)[None], 2, 0), 2, 1).reshape(2, 512, 3)
+    y, u, vv = O.webp_rgb_to_yuv(rgb)
+    Y, U, V = libwebp_import_rgb(rgb)
+    assert np.array_equal(y[:2, :512], Y) and np.array_equal(u[:1, :256], U) and np.array_equal(vv[:1, :256], V)
