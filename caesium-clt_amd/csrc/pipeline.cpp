@@ -22,6 +22,7 @@
 #include "jpeg_host.hpp"
 #include "kernels.h"
 #include "webp_kernels.h"
+#include "../../include/vp8_tables.h"
 #include "resize_host.h"
 
 static thread_local char g_err[512];
@@ -1089,11 +1090,7 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
         off[wi.image] = out_bytes;
         out_bytes += (wi.out_cap + 63) & ~uint64_t(63);
         const int q = int(b->params.webp_quality);
-        // libwebp's quality -> quantiser curve without its segment / SNS adjustments (oracle: cso_webp_quality_to_qi)
-        double c = (q < 0 ? 0 : q > 100 ? 100 : q) / 100.0, lin = c < 0.75 ? c * (2.0 / 3.0) : 2.0 * c - 1.0, v = 0.0;
-        if (lin > 0) { v = lin; for (int i = 0; i < 60; i++) v = v - (v * v * v - lin) / (3 * v * v); }
-        int qi = int(127.0 * (1.0 - v) + 0.5);
-        wi.qi = qi < 0 ? 0 : qi > 127 ? 127 : qi;
+        wi.qi = kVp8QualityToQi[q < 0 ? 0 : q > 100 ? 100 : q];   // libwebp's quality -> quantiser curve for one segment, no SNS (vp8_tables.h; oracle: cso_webp_quality_to_qi)
     }
     off[b->nimg] = out_bytes;
     if (b->d_out.n < out_bytes + 64 && b->d_out.alloc(out_bytes + 64)) return -1;

@@ -14,6 +14,7 @@
 #include "devmem.hpp"
 #include "png_kernels.h"
 #include "webp_kernels.h"
+#include "../../include/vp8_tables.h"
 #include "resize_host.h"
 
 using namespace csp;
@@ -672,12 +673,7 @@ static int run_to_webp(csp_batch *b) {
     const int nimg = int(b->wimgs.size());
     if (!nimg) return 0;
     launch_png_rgb(st, b->d_rgbjobs.p, nimg, b->rgb_max_h, b->d_plte.p, b->d_work.p, b->d_rgb.p, b->d_status.p);
-    // libwebp's quality -> quantiser curve without its segment / SNS adjustments (oracle: cso_webp_quality_to_qi)
-    const int q = b->webp_quality;
-    double c = (q < 0 ? 0 : q > 100 ? 100 : q) / 100.0, lin = c < 0.75 ? c * (2.0 / 3.0) : 2.0 * c - 1.0, v = 0.0;
-    if (lin > 0) { v = lin; for (int i = 0; i < 60; i++) v = v - (v * v * v - lin) / (3 * v * v); }
-    int qi = int(127.0 * (1.0 - v) + 0.5);
-    qi = qi < 0 ? 0 : qi > 127 ? 127 : qi;
+    const int q = b->webp_quality, qi = kVp8QualityToQi[q < 0 ? 0 : q > 100 ? 100 : q];   // libwebp's quality -> quantiser curve for one segment, no SNS (vp8_tables.h)
     b->h_wstatus.assign(size_t(nimg), 0);
     for (int attempt = 0; attempt < 4; attempt++) {
         uint64_t out_bytes = 0;

@@ -226,16 +226,8 @@ static void choose_probs(const uint32_t *stats, uint8_t *probs, uint8_t *update)
 }
 
 /* ------------------------------------------------------------------------------------------------ the frame */
-/* quality 0..100 -> quantiser index 0..127: libwebp's quality-to-compression curve without its segment / SNS adjustments */
-int cso_webp_quality_to_qi(int quality) {
-    double c = (quality < 0 ? 0 : quality > 100 ? 100 : quality) / 100.0;
-    double lin = c < 0.75 ? c * (2.0 / 3.0) : 2.0 * c - 1.0;
-    /* cube root by Newton steps on integers would do; this runs on the host only */
-    double v = 0.0;
-    if (lin > 0) { v = lin; for (int i = 0; i < 60; i++) v = v - (v * v * v - lin) / (3 * v * v); }
-    int qi = (int)(127.0 * (1.0 - v) + 0.5);
-    return qi < 0 ? 0 : qi > 127 ? 127 : qi;
-}
+/* quality 0..100 -> quantiser index 0..127: libwebp's curve for one segment without SNS modulation (vp8_tables.h; pinned to streams libwebp made) */
+int cso_webp_quality_to_qi(int quality) { return kVp8QualityToQi[quality < 0 ? 0 : quality > 100 ? 100 : quality]; }
 /* scalar quantiser with libwebp's rounding offsets (bias / 256 of a step instead of one half: luma AC 110, Y2 DC 96 / AC 108,
    chroma DC 110 / AC 115 -- its kBiasMatrices), levels capped at 2047 */
 static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }

@@ -64,7 +64,95 @@ def test_quality_against_libwebp_at_the_same_setting():
 
 
 def test_quality_curve():
-    assert [O.webp_quality_to_qi(q) for q in (0, 50, 75, 85, 100)] == [127, 39, 26, 14, 0]
+    assert [O.webp_quality_to_qi(q) for q in (0, 50, 75, 85, 100)] == [127, 38, 26, 14, 0]
+
+
+class _BoolDecoder:
+    """RFC 6386 section 7, enough of it to read a frame header"""
+    def __init__(self, d):
+        self.d, self.pos, self.value, self.range, self.bits = d, 2, (d[0] << 8) | d[1], 255, 0
+
+    def get(self, p):
+        split = 1 + (((self.range - 1) * p) >> 8)
+        big = split << 8
+        if self.value >= big:
+            bit, self.range, self.value = 1, self.range - split, self.value - big
+        else:
+            bit, self.range = 0, split
+        while self.range < 128:
+            self.value <<= 1
+            self.range <<= 1
+            self.bits += 1
+            if self.bits == 8:
+                self.bits = 0
+                self.value |= self.d[self.pos] if self.pos < len(self.d) else 0
+                self.pos += 1
+        return bit
+
+    def lit(self, n):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | self.get(128)
+        return v
+
+
+def frame_quantiser_index(webp):
+    assert webp[12:16] == b"VP8 "
+    b = _BoolDecoder(webp[30:])
+    b.lit(2)
+    assert b.lit(1) == 0, "segments"
+    b.lit(10)
+    if b.lit(1) and b.lit(1):
+        for _ in range(8):
+            if b.lit(1):
+                b.lit(7)
+    b.lit(2)
+    return b.lit(7)
+
+
+def libwebp_encode(rgb, quality, segments=1, sns=0, filt=0, method=4):
+    """libwebp's own encoder through ctypes (WebPConfig: 4-byte fields, [2] method, [6] segments, [7] sns_strength, [8] filter_strength; WebPPicture: writer and
+    custom_ptr at bytes 96 / 104) -- here with everything this repo's encoder does not have switched off"""
+    name = ctypes.util.find_library("webp")
+    if not name:
+        pytest.skip("no system libwebp")
+    W = C.CDLL(name)
+    if not hasattr(W, "WebPEncode"):
+        pytest.skip("libwebp without the encoder API")
+    h, w, _ = rgb.shape
+    cfg = (C.c_int32 * 64)()
+    W.WebPConfigInitInternal.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
+    assert W.WebPConfigInitInternal(cfg, 0, float(quality), 0x020f)
+    cfg[2], cfg[6], cfg[7], cfg[8] = method, segments, sns, filt
+    pic = (C.c_uint8 * 1024)()
+    assert W.WebPPictureInitInternal(pic, 0x020f)
+    ints = C.cast(pic, C.POINTER(C.c_int32))
+    ints[2], ints[3] = w, h
+    rgb = np.ascontiguousarray(rgb)
+    W.WebPPictureImportRGB.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert W.WebPPictureImportRGB(pic, rgb.ctypes.data, w * 3)
+    wr = (C.c_uint8 * 64)()
+    W.WebPMemoryWriterInit.argtypes = [C.c_void_p]
+    W.WebPMemoryWriterInit(wr)
+    ptrs = C.cast(pic, C.POINTER(C.c_void_p))
+    ptrs[12] = C.cast(W.WebPMemoryWrite, C.c_void_p).value
+    ptrs[13] = C.addressof(wr)
+    W.WebPEncode.argtypes = [C.c_void_p, C.c_void_p]
+    assert W.WebPEncode(cfg, pic)
+    data = C.string_at(C.cast(wr, C.POINTER(C.c_void_p))[0], C.cast(wr, C.POINTER(C.c_size_t))[1])
+    W.WebPPictureFree(pic)
+    return data
+
+
+def test_quality_to_quantiser_index_is_libwebp_s():
+    """the base quantiser index libwebp itself writes into its frame header (one segment, no SNS) for every quality 0..100, and the one this repo's streams carry"""
+    rgb = np.random.default_rng(0).integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    for q in range(101):
+        want = frame_quantiser_index(libwebp_encode(rgb, q))
+        assert O.webp_quality_to_qi(q) == want, q
+        if q % 10 == 0:
+            assert frame_quantiser_index(O.webp_encode_rgb(rgb, q)) == want
+
 
 
 def test_sub_block_mode_cost_table_is_the_formula():
