@@ -55,7 +55,7 @@ void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blo
 
 // resize branch (k_resize.hip): decoded planes -> RGB -> Lanczos3 (f32, image-rs order) -> full-resolution YCbCr planes
 void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, int nwork, const ResizeTap *taps, const float *weights,
-                   uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst, uint32_t max_row_in, uint32_t max_row_out, uint32_t max_nh);
+                   uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst, uint32_t max_row_in, uint32_t max_out_w, uint32_t max_nh, bool to_planes);
 
 // ---- phases 2-5: entropy encode (k_entropy.hip)
 // tokens -> runs -> tables -> chunk sizes -> (scan) -> pack.  A token is one u32 (k_entropy.hip); the tokens of one (scan, 256-unit

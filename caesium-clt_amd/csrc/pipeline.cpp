@@ -93,7 +93,7 @@ struct csh_batch {
     std::vector<ResizeTap> rtaps;
     std::vector<float> rweights;
     uint64_t rgb_bytes = 0, tmp_floats = 0, max_tmp = 0, max_dst = 0;
-    uint32_t max_row_in = 0, max_row_out = 0, max_nh = 0;   // resize launches: samples per source / resized row, resized rows
+    uint32_t max_row_in = 0, max_out_w = 0, max_nh = 0;   // resize launches: samples per source row, pixels per resized row, resized rows
     uint32_t max_src_px = 0;
     std::vector<ParScan> pscans;
     std::vector<uint32_t> need_seq_init;
@@ -828,7 +828,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             rw.htap_base = uint32_t(b->rtaps.size()); csh_lanczos_axis(in.width, o.width, same, b->rtaps, b->rweights);
             b->max_src_px = std::max<uint32_t>(b->max_src_px, uint32_t(in.width) * in.height);
             b->max_tmp = std::max(b->max_tmp, tmpn);
-            b->max_row_in = std::max(b->max_row_in, uint32_t(in.width) * uint32_t(in.ncomp)); b->max_row_out = std::max(b->max_row_out, uint32_t(o.width) * uint32_t(in.ncomp));
+            b->max_row_in = std::max(b->max_row_in, uint32_t(in.width) * uint32_t(in.ncomp)); b->max_out_w = std::max(b->max_out_w, uint32_t(o.width));
             b->max_nh = std::max(b->max_nh, uint32_t(o.height));
             b->max_dst = std::max(b->max_dst, dst_bytes);
             b->rwork.push_back(rw);
@@ -1324,7 +1324,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     launch_idct_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_planes.p);
     MARK();
     launch_resize(st, b->d_imgs.p, b->d_rwork.p, int(b->rwork.size()), b->d_rtaps.p, b->d_rweights.p, b->d_planes.p, b->d_rgb.p, b->d_rtmp.p,
-                  b->max_src_px, b->max_tmp, b->max_dst, b->max_row_in, b->max_row_out, b->max_nh);
+                  b->max_src_px, b->max_tmp, b->max_dst, b->max_row_in, b->max_out_w, b->max_nh, !(b->webp || b->rgb_out));
     if (b->webp) return run_webp(b, t, ev, slot);
     if (b->rgb_out) return run_rgb_only(b, t, ev, slot);
     int16_t *rawp = (b->retain_dct && !b->lossless) ? b->d_dct_raw.p : nullptr;
