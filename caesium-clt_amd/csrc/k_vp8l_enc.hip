@@ -7,7 +7,7 @@
 // ("parity unpinned"), the invariant that is pinned is the format's: libwebp decodes the file to exactly the source pixels
 // (tests/test_webp_lossless*.py), and so does this repo's own decoder (vp8l_dec.h).
 //   k_vp8l_residuals  one workgroup per block: mode choice, residual ARGB
-//   k_vp8l_hist       symbol counts of the three coded channels (alpha is constant: opaque sources only)
+//   k_vp8l_hist       symbol counts of the four channels (an opaque source's alpha residuals are all one value: a code without bits)
 //   k_vp8l_pack       one wave per picture: code lengths, canonical codes, the headers, then every pixel's three codes through the LDS
 //                     bit window straight to their place, RIFF framing
 #include "webp_kernels.h"
@@ -19,10 +19,14 @@ namespace csw {
 using csp::LV;
 
 __device__ __forceinline__ static uint32_t sg_pixel(const Vp8lImg &im, uint32_t x, uint32_t y) {   // ARGB after subtract-green
-    const uint8_t *p = im.rgb + (uint64_t(y) * im.width + x) * im.channels;
-    if (im.channels == 1) return 0xFF000000u | (uint32_t(p[0]) << 8);   // grey: red - green = blue - green = 0
+    // channels: 1 grey, 2 grey + alpha, 3 RGB, 4 RGBA; VP8L_ALPHA_OF + 2 / + 4: the ALPHA sample of such a picture taken as a grey picture (the ALPH
+    // chunk of a lossy file is a VP8L stream whose green channel is the alpha plane)
+    const uint32_t pick = im.channels >= VP8L_ALPHA_OF ? im.channels - VP8L_ALPHA_OF : 0u, nc = pick ? pick : im.channels;
+    const uint8_t *p = im.rgb + (uint64_t(y) * im.width + x) * nc;
+    if (pick) return 0xFF000000u | (uint32_t(p[nc - 1]) << 8);
+    if (nc <= 2) return (nc == 2 ? uint32_t(p[1]) << 24 : 0xFF000000u) | (uint32_t(p[0]) << 8);   // grey: red - green = blue - green = 0
     const uint32_t r = p[0], g = p[1], b = p[2];
-    return 0xFF000000u | (((r - g) & 255u) << 16) | (g << 8) | ((b - g) & 255u);
+    return (nc == 4 ? uint32_t(p[3]) << 24 : 0xFF000000u) | (((r - g) & 255u) << 16) | (g << 8) | ((b - g) & 255u);
 }
 __device__ __forceinline__ static uint32_t lsub(uint32_t a, uint32_t b) {   // per-channel a - b mod 256
     return (((a | 0x00FF00FFu) - (b & 0xFF00FF00u)) & 0xFF00FF00u) | (((a | 0xFF00FF00u) - (b & 0x00FF00FFu)) & 0x00FF00FFu);
@@ -76,33 +80,33 @@ __global__ void __launch_bounds__(256) k_vp8l_residuals(const Vp8lImg *imgs, uin
 }
 
 __global__ void __launch_bounds__(256) k_vp8l_hist(const Vp8lImg *imgs, const uint32_t *work, uint32_t *hist) {
-    CSH_SHARED uint32_t h[3 * 256];
+    CSH_SHARED uint32_t h[4 * 256];
     const Vp8lImg &im = imgs[blockIdx.y];
     const uint64_t npx = uint64_t(im.width) * im.height, i0 = uint64_t(blockIdx.x) * 4096u;
     CSH_PHASE_LOOP(3) {
         if (i0 >= npx) continue;
-        if (phase == 0) { for (uint32_t i = threadIdx.x; i < 768; i += 256) h[i] = 0; continue; }
+        if (phase == 0) { for (uint32_t i = threadIdx.x; i < 1024; i += 256) h[i] = 0; continue; }
         if (phase == 1) {
             for (uint32_t k = threadIdx.x; k < 4096; k += 256) {
                 const uint64_t i = i0 + k;
                 if (i >= npx) break;
                 const uint32_t v = work[im.res_off + i];
-                atomicAdd(&h[(v >> 8) & 255u], 1u); atomicAdd(&h[256 + ((v >> 16) & 255u)], 1u); atomicAdd(&h[512 + (v & 255u)], 1u);
+                atomicAdd(&h[(v >> 8) & 255u], 1u); atomicAdd(&h[256 + ((v >> 16) & 255u)], 1u); atomicAdd(&h[512 + (v & 255u)], 1u); atomicAdd(&h[768 + (v >> 24)], 1u);
             }
             continue;
         }
-        for (uint32_t i = threadIdx.x; i < 768; i += 256) if (h[i]) atomicAdd(&hist[uint64_t(blockIdx.y) * 768u + i], h[i]);
+        for (uint32_t i = threadIdx.x; i < 1024; i += 256) if (h[i]) atomicAdd(&hist[uint64_t(blockIdx.y) * 1024u + i], h[i]);
     }
 }
 
 // ---- one wave per picture
 struct PackLds {
-    uint8_t len[4][288];       // green (alphabet 280), red, blue, modes (alphabet 280)
-    uint16_t code[4][288];
+    uint8_t len[5][288];       // green (alphabet 280), red, blue, modes (alphabet 280), alpha
+    uint16_t code[5][288];
     uint32_t mh[288];          // histogram of the modes, as a green alphabet
     uint32_t gh[288];          // the green histogram widened to its alphabet (256 literals + 24 length prefixes that are never used)
     uint32_t win[160];
-    uint32_t nused[4], sym0[4], sym1[4], last[4];   // per code: symbols with a non-zero count, the first two of them, the highest
+    uint32_t nused[5], sym0[5], sym1[5], last[5];   // per code: symbols with a non-zero count, the first two of them, the highest
 };
 __device__ __forceinline__ static uint32_t rev4(uint32_t v) { return ((v & 1u) << 3) | ((v & 2u) << 1) | ((v & 4u) >> 1) | ((v & 8u) >> 3); }
 
@@ -113,17 +117,17 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8l_pack(const Vp8lImg *i
     if (image >= nimg) return;
     const Vp8lImg im = imgs[image];
     uint8_t *file = outp + im.out_off;
-    const uint32_t *hh = hist + uint64_t(image) * 768u;
+    const uint32_t *hh = hist + uint64_t(image) * 1024u;
     const uint32_t nblk = im.bw * im.bh;
     LFOR(l) for (int i = l; i < 288; i += 64) { S.mh[i] = 0; S.gh[i] = i < 256 ? hh[i] : 0u; }
     LFOR(l) for (int i = l; i < 160; i += 64) S.win[i] = 0;
     CSP_WAVE_SYNC();
     for (uint32_t b0 = 0; b0 < nblk; b0 += 64) LFOR(l) if (b0 + uint32_t(l) < nblk) atomicAdd(&S.mh[modes[im.mode_off + b0 + uint32_t(l)]], 1u);
     CSP_WAVE_SYNC();
-    // four codes, one lane each (the arrays of code_lengths live in scratch)
-    LFOR(l) if (l < 4) {
+    // five codes, one lane each (the arrays of code_lengths live in scratch)
+    LFOR(l) if (l < 5) {
         const int n = (l == 0 || l == 3) ? 280 : 256;
-        const uint32_t *f = l == 0 ? S.gh : l == 3 ? S.mh : hh + 256u * uint32_t(l);
+        const uint32_t *f = l == 0 ? S.gh : l == 3 ? S.mh : l == 4 ? hh + 768u : hh + 256u * uint32_t(l);
         csp::code_lengths(f, n, 15, S.len[l]);
         uint32_t used = 0, s0 = 0, s1 = 0, hi = 0;
         for (int i = 0; i < n; i++) if (f[i]) { if (used == 0) s0 = uint32_t(i); else if (used == 1) s1 = uint32_t(i); used++; hi = uint32_t(i); }
@@ -144,8 +148,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8l_pack(const Vp8lImg *i
     auto put_code = [&](int t) __attribute__((always_inline)) {
         const uint32_t used = S.nused[t];
         if (used <= 2) {
-            const uint64_t two = used == 2 ? 1 : 0;
-            put1(1ull | (two << 1) | (1ull << 2) | (uint64_t(S.sym0[t]) << 3) | (two ? uint64_t(S.sym1[t]) << 11 : 0ull), two ? 19 : 11);
+            const uint64_t two = used == 2 ? 1 : 0, wide = S.sym0[t] > 1 ? 1 : 0;   // the first symbol's field is one bit wide when that is enough
+            const uint32_t w0 = wide ? 8u : 1u;
+            put1(1ull | (two << 1) | (wide << 2) | (uint64_t(S.sym0[t]) << 3) | (two ? uint64_t(S.sym1[t]) << (3 + w0) : 0ull), 3 + w0 + (two ? 8u : 0u));
             return;
         }
         put1(0, 1);          // not a simple code
@@ -162,7 +167,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8l_pack(const Vp8lImg *i
     };
     auto put_single = [&]() __attribute__((always_inline)) { put1(1 | (0 << 1) | (0 << 2) | (0 << 3), 4); };   // simple code, one symbol, 1-bit symbol field, symbol 0
     put1(0x2F, 8);
-    put1(uint64_t(im.width - 1) | (uint64_t(im.height - 1) << 14) | (0ull << 28) | (0ull << 29), 32);   // sizes, no alpha, version 0
+    const bool has_alpha = im.channels == 2 || im.channels == 4;
+    put1(uint64_t(im.width - 1) | (uint64_t(im.height - 1) << 14) | (uint64_t(has_alpha ? 1 : 0) << 28) | (0ull << 29), 32);   // sizes, alpha_is_used (a hint), version 0
     put1(1 | (2u << 1), 3);                      // a transform follows: subtract green
     put1(1 | (0u << 1) | (2u << 3), 6);          // a transform follows: predictor, block side 1 << (2 + 2)
     put1(0, 1);                                   // the mode image: no colour cache
@@ -179,17 +185,17 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8l_pack(const Vp8lImg *i
     put1(0, 1);                                   // no further transform
     put1(0, 1);                                   // the picture: no colour cache
     put1(0, 1);                                   // no meta prefix image
-    put_code(0); put_code(1); put_code(2); put_single(); put_single();
+    put_code(0); put_code(1); put_code(2); put_code(4); put_single();   // green, red, blue, alpha (one symbol, no bits, in an opaque picture), distance
     const uint64_t npx = uint64_t(im.width) * im.height;
     for (uint64_t i0 = 0; i0 < npx; i0 += 64) {
         LV<uint64_t> val; LV<uint32_t> nb;
         LFOR(l) {
             const uint64_t i = i0 + uint32_t(l);
             const uint32_t v = i < npx ? work[im.res_off + i] : 0u;
-            const uint32_t g = (v >> 8) & 255u, r = (v >> 16) & 255u, b = v & 255u;
-            const uint32_t lg = S.len[0][g], lr = S.len[1][r], lb = S.len[2][b];
-            nb[l] = i < npx ? lg + lr + lb : 0u;
-            val[l] = uint64_t(S.code[0][g]) | (uint64_t(S.code[1][r]) << lg) | (uint64_t(S.code[2][b]) << (lg + lr));
+            const uint32_t g = (v >> 8) & 255u, r = (v >> 16) & 255u, b = v & 255u, a = v >> 24;
+            const uint32_t lg = S.len[0][g], lr = S.len[1][r], lb = S.len[2][b], la = S.len[4][a];
+            nb[l] = i < npx ? lg + lr + lb + la : 0u;
+            val[l] = uint64_t(S.code[0][g]) | (uint64_t(S.code[1][r]) << lg) | (uint64_t(S.code[2][b]) << (lg + lr)) | (uint64_t(S.code[4][a]) << (lg + lr + lb));
         }
         bo.put(val, nb);
     }

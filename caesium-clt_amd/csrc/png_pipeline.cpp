@@ -873,7 +873,7 @@ static CCSResult png_result(int code, const char *msg) {
 // encoder does [UPSTREAM-RECALL]), then the JPEG batch object from those pixels (csh_batch_create_from_pixels: its resize honours
 // width / height, its encoder p's JPEG parameters).  Device to device; results in input order.
 // PNG -> JPEG and PNG -> lossless WebP share everything up to the pixels: decode (any PNG format), 8-bit grey / RGB in device memory.  The lossless
-// WebP target refuses pictures with transparency (dropping it would not be lossless) and sends the pixels -- resized first when a size is given,
+// WebP target keeps an alpha channel / tRNS chunk as the picture's alpha (grey + alpha / RGBA pixels) and sends the pixels -- resized first when a size is given,
 // through the JPEG row's resize branch stopped behind its RGB -- to the VP8L coder (csl_encode_pixels).
 static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results, bool lossless_webp) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
@@ -903,13 +903,16 @@ static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSP
         if (!code && status[it.image]) { code = int(status[it.image]); msg = "malformed PNG data"; }
         if (!code && !lossless_webp && (it.width > 65535 || it.height > 65535)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a JPEG"; }
         if (!code && lossless_webp && (it.width > 16384 || it.height > 16384)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a WebP"; }
-        if (!code && lossless_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { code = CS_ERR_UNSUPPORTED; msg = "PNG -> lossless WebP with transparency has no device path in this build"; }
+        const bool transparent = it.ctype == 4 || it.ctype == 6 || it.has_trns;
+        if (!code && lossless_webp && transparent && (p->width || p->height)) { code = CS_ERR_UNSUPPORTED; msg = "PNG -> lossless WebP: a transparent picture cannot be resized on this path in this build"; }
         if (code) { if (results) results[i] = png_result(code, msg); failed++; continue; }
         RgbJob e{};
         e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth;
-        e.out_nc = (it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u;
+        e.out_nc = ((it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u) + ((lossless_webp && transparent) ? 1u : 0u);   // a JPEG drops the alpha; a lossless WebP keeps it
         e.plte_off = uint32_t(tables.size()); e.npal = uint32_t(it.plte.size() / 3);
         tables.insert(tables.end(), it.plte.begin(), it.plte.end());
+        e.trns_off = uint32_t(tables.size()); e.ntrns = uint32_t(it.trns.size());
+        tables.insert(tables.end(), it.trns.begin(), it.trns.end());
         e.src_off = a->imgs[it.image].pix_off; e.dst_off = src_bytes;
         src_bytes += (uint64_t(it.width) * it.height * e.out_nc + 255) & ~uint64_t(255);
         max_h = std::max(max_h, it.height);

@@ -28,8 +28,9 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
     uint64_t work = 0, modes = 0, out = 0, max_px = 0;
     uint32_t max_blocks = 0;
     for (size_t i = 0; i < count; i++) {
-        if ((px[i].channels != 3 && px[i].channels != 1) || !px[i].width || !px[i].height || px[i].width > 16384 || px[i].height > 16384) {
-            results[i] = make_res(CS_ERR_UNSUPPORTED, "lossless WebP output takes opaque 8-bit RGB or grey pictures of at most 16384 x 16384"); failed++; continue;
+        const uint32_t ch = px[i].channels;
+        if (!((ch >= 1 && ch <= 4) || ch == csw::VP8L_ALPHA_OF + 2 || ch == csw::VP8L_ALPHA_OF + 4) || !px[i].width || !px[i].height || px[i].width > 16384 || px[i].height > 16384) {
+            results[i] = make_res(CS_ERR_UNSUPPORTED, "lossless WebP output takes 8-bit grey / RGB pictures, with or without alpha, of at most 16384 x 16384"); failed++; continue;
         }
         csw::Vp8lImg im;
         memset(&im, 0, sizeof im);
@@ -38,7 +39,7 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
         const uint64_t npx = uint64_t(im.width) * im.height;
         im.res_off = work; work += (npx + 63) & ~uint64_t(63);
         im.mode_off = modes; modes += (uint64_t(im.bw) * im.bh + 63) & ~uint64_t(63);
-        const uint64_t cap = 6 * npx + 2 * uint64_t(im.bw) * im.bh + 8192;   // three codes of at most 15 bits per pixel, the mode image, the code descriptions
+        const uint64_t cap = 8 * npx + 2 * uint64_t(im.bw) * im.bh + 8192;   // four codes of at most 15 bits per pixel, the mode image, the code descriptions
         if (cap > 0xFFFFFFF0ull) { results[i] = make_res(CS_ERR_UNSUPPORTED, "picture too large for one lossless WebP batch item"); failed++; continue; }
         im.out_off = out; im.out_cap = uint32_t(cap); out += (cap + 255) & ~uint64_t(255);
         max_px = std::max(max_px, npx); max_blocks = std::max(max_blocks, im.bw * im.bh);
@@ -53,7 +54,7 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
     std::vector<uint32_t> len(imgs.size()), status(imgs.size());
     bool ok = hipStreamCreate(&st) == hipSuccess;
     have_st = ok;
-    ok = ok && !d_imgs.upload(imgs, st) && !d_work.alloc(work + 64) && !d_hist.alloc(imgs.size() * 768 + 8) && !d_hist.zero(st) && !d_len.alloc(imgs.size() + 1) && !d_status.alloc(imgs.size() + 1) &&
+    ok = ok && !d_imgs.upload(imgs, st) && !d_work.alloc(work + 64) && !d_hist.alloc(imgs.size() * 1024 + 8) && !d_hist.zero(st) && !d_len.alloc(imgs.size() + 1) && !d_status.alloc(imgs.size() + 1) &&
          !d_modes.alloc(modes + 64) && !d_out.alloc(out + 256);
     if (ok) {
         csw::launch_vp8l_encode(st, d_imgs.p, int(imgs.size()), max_blocks, max_px, d_work.p, d_modes.p, d_hist.p, d_out.p, d_len.p, d_status.p);

@@ -26,7 +26,8 @@ void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_
 void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
                       uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
 
-// lossless WebP output (k_vp8l_enc.hip): one picture of 8-bit RGB (channels 3) or grey (1) pixels in device memory
+enum { VP8L_ALPHA_OF = 16 };   // Vp8lImg::channels = VP8L_ALPHA_OF + 2 / + 4: code the alpha sample of a grey + alpha / RGBA picture as a grey picture
+// lossless WebP output (k_vp8l_enc.hip): one picture of 8-bit grey (channels 1), grey + alpha (2), RGB (3) or RGBA (4) pixels in device memory
 struct Vp8lImg {
     const uint8_t *rgb;
     uint32_t width, height, channels, bw, bh;   // bw x bh blocks of 16 x 16 pixels

@@ -83,23 +83,29 @@ def test_emul_lossless_webp_failures_stay_per_file(api):
 
 def test_emul_png_to_lossless_webp(api):
     """--format webp --lossless over PNG sources: the PNG row's decode, the VP8L coder behind it.  8-bit and palette / low-depth opaque pictures must
-    come back as exactly the pixels libpng (Pillow) reads; transparency is refused per file; a size resizes first."""
+    come back as exactly the pixels libpng (Pillow) reads, alpha channel / tRNS included (RGBA in libwebp's reading); a size resizes opaque pictures first."""
     from _util import png_cases
     from test_png_webp_emul import extra_cases
     cases = dict(png_cases())
     cases.update(dict(extra_cases()))
     exact = ["RGB_97x61", "L_97x61", "P_97x61", "1_97x61", "RGB_flat_64x48", "RGB_200x150_3chunks", "RGB_stored_input", "L_level1_input", "RGB_1x1", "L_1x300",
              "grey2_70x45", "grey4_70x45", "short_plte_70x45"]
-    refused = ["RGBA_97x61", "LA_97x61", "RGBA_300x2", "reduce_blocked_by_trns"]
-    outs = api.batch_convert([cases[n] for n in exact + refused + ["I;16_97x61", "rgb16_70x45"]], params(webp_lossless=True), 3)
+    alpha = ["RGBA_97x61", "LA_97x61", "RGBA_300x2", "reduce_blocked_by_trns"]   # an alpha channel or a tRNS chunk: kept, as the picture's alpha
+    outs = api.batch_convert([cases[n] for n in exact + alpha + ["I;16_97x61", "rgb16_70x45"]], params(webp_lossless=True), 3)
     for name, out in zip(exact, outs):
         assert isinstance(out, bytes), (name, out)
         check_vp8l(out, np.asarray(Image.open(io.BytesIO(cases[name])).convert("RGB")))
-    for name, out in zip(refused, outs[len(exact):]):
-        assert getattr(out, "code", 0) == 10201, (name, out)
-    for name, out in zip(["I;16_97x61", "rgb16_70x45"], outs[len(exact) + len(refused):]):   # 16-bit samples are narrowed (the lossy PNG -> WebP path pins the rule)
+    for name, out in zip(alpha, outs[len(exact):]):
+        assert isinstance(out, bytes) and out[8:16] == b"WEBPVP8L", (name, out)
+        got = Image.open(io.BytesIO(out))
+        assert got.mode == "RGBA", name
+        assert np.array_equal(np.asarray(got), np.asarray(Image.open(io.BytesIO(cases[name])).convert("RGBA"))), name
+    for name, out in zip(["I;16_97x61", "rgb16_70x45"], outs[len(exact) + len(alpha):]):   # 16-bit samples are narrowed (the lossy PNG -> WebP path pins the rule)
         assert isinstance(out, bytes) and Image.open(io.BytesIO(out)).size == Image.open(io.BytesIO(cases[name])).size, name
     # the same pixels as the lossy conversion's source: a JPEG made from the PNG at 4:4:4 q100 is not exact, so compare with PNG -> PNG resize instead
     small = api.convert_in_memory(cases["RGB_200x150_3chunks"], params(webp_lossless=True, width=80), 3)
     assert Image.open(io.BytesIO(small)).size == (80, 60)
     assert api.convert_in_memory(cases["RGB_97x61"], params(webp_lossless=True), 3) == outs[0]
+    with pytest.raises(Exception) as e:   # the resize in front takes opaque pixels only
+        api.convert_in_memory(cases["RGBA_97x61"], params(webp_lossless=True, width=40), 3)
+    assert e.value.code == 10201
