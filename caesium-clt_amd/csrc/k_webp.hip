@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) k_webp_yuv(const WebpImg *imgs, const uin
     const uint8_t *src = rgb + im.rgb_off;
     auto px = [&](int yy, int xx, int &r, int &g, int &b) {
         const uint8_t *p = src + (size_t(yy < h ? yy : h - 1) * w + (xx < w ? xx : w - 1)) * nc;
-        r = p[0]; g = nc == 3 ? p[1] : p[0]; b = nc == 3 ? p[2] : p[0];
+        r = p[0]; g = nc >= 3 ? p[1] : p[0]; b = nc >= 3 ? p[2] : p[0];   // nc 2 / 4: the last sample is alpha, which the ALPH chunk carries (png_pipeline.cpp)
     };
     if (i < uint32_t(ys) * im.mbh * 16) {
         const int y = int(i / uint32_t(ys)), x = int(i - uint32_t(y) * ys);

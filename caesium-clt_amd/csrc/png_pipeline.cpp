@@ -163,6 +163,7 @@ struct csp_batch {
     std::vector<RgbJob> rgbjobs;
     std::vector<uint8_t> plte;
     std::vector<uint32_t> h_wstatus;
+    std::vector<uint8_t> walpha;    // per image: 0, or the samples per pixel (2 / 4) of a picture whose last sample is alpha
     DevBuf<csw::WebpImg> d_wimgs;
     DevBuf<RgbJob> d_rgbjobs;
     DevBuf<uint8_t> d_plte, d_rgb, d_wwork, d_wscratch, d_wprobs, d_wupdate;
@@ -359,7 +360,6 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         else if (px) pixels_item(px[i], px_bits ? (*px_bits)[i] : 8, it);
         else parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
         if (it.code) continue;
-        if (to_webp && (it.ctype == 4 || it.ctype == 6 || it.has_trns)) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG with transparency to WebP has no device path in this build"; continue; }
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
         if (mode == MODE_DECODE && it.depth == 16 && it.has_trns) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG with a tRNS chunk has no device path in this build"; continue; }
         if (decode_only && it.has_trns && it.trns.size() != (it.ctype == 3 ? it.trns.size() : it.ctype == 0 ? 2u : it.ctype == 2 ? 6u : ~size_t(0))) { it.code = CS_ERR_BAD_PNG; it.msg = "bad tRNS"; continue; }
@@ -436,9 +436,16 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
             j.image = uint32_t(it.image); j.width = it.width; j.height = it.height; j.rowbytes = it.rowbytes; j.ctype = it.ctype; j.depth = it.depth;
             j.plte_off = uint32_t(b->plte.size()); j.npal = uint32_t(it.plte.size() / 3);
             b->plte.insert(b->plte.end(), it.plte.begin(), it.plte.end());
+            j.trns_off = uint32_t(b->plte.size()); j.ntrns = uint32_t(it.trns.size());
+            b->plte.insert(b->plte.end(), it.trns.begin(), it.trns.end());
             j.src_off = im.pix_off; j.dst_off = b->rgb_bytes;
-            const uint32_t nc = it.ctype == 0 ? 1u : 3u;
+            // 8-bit grey / RGB for the VP8 encoder; an alpha channel or a tRNS chunk rides along as a fourth (second) sample: the encoder skips it, the
+            // VP8L coder makes the file's ALPH chunk of it when the results are fetched
+            const bool transparent = it.ctype == 4 || it.ctype == 6 || it.has_trns;
+            const uint32_t nc = ((it.ctype == 0 || it.ctype == 4) ? 1u : 3u) + (transparent ? 1u : 0u);
             j.out_nc = nc;
+            b->walpha.resize(b->imgs.size() + 1, 0);
+            b->walpha[b->imgs.size()] = transparent ? uint8_t(nc) : uint8_t(0);
             b->rgb_bytes += align_up(uint64_t(it.width) * it.height * nc + 64, 256);
             b->rgb_max_h = std::max(b->rgb_max_h, it.height);
             b->rgbjobs.push_back(j);
@@ -872,6 +879,7 @@ static CCSResult png_result(int code, const char *msg) {
 // RGB (k_png_rgb: palette looked up, 16-bit narrowed, sub-byte grey scaled; an alpha channel or tRNS is dropped, as image-rs's JPEG
 // encoder does [UPSTREAM-RECALL]), then the JPEG batch object from those pixels (csh_batch_create_from_pixels: its resize honours
 // width / height, its encoder p's JPEG parameters).  Device to device; results in input order.
+static void put_le32(uint8_t *p, uint32_t v) { p[0] = uint8_t(v); p[1] = uint8_t(v >> 8); p[2] = uint8_t(v >> 16); p[3] = uint8_t(v >> 24); }
 // PNG -> JPEG and PNG -> lossless WebP share everything up to the pixels: decode (any PNG format), 8-bit grey / RGB in device memory.  The lossless
 // WebP target keeps an alpha channel / tRNS chunk as the picture's alpha (grey + alpha / RGBA pixels) and sends the pixels -- resized first when a size is given,
 // through the JPEG row's resize branch stopped behind its RGB -- to the VP8L coder (csl_encode_pixels).
@@ -978,11 +986,32 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
             hipMemcpy(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return -1; }
     }
     int failed = 0;
+    // pictures with transparency going to WebP: their alpha plane through the VP8L coder now (the pixels are still in d_rgb), one call for all of them
+    std::vector<CByteArray> alpha_out;
+    std::vector<CCSResult> alpha_res;
+    std::vector<int> alpha_at(b->items.size(), -1);
+    if (b->to_webp) {
+        std::vector<csp_pixels> apx;
+        for (size_t i = 0; i < b->items.size(); i++) {
+            const PngItem &it = b->items[i];
+            if (it.code || it.image < 0 || status[it.image] || b->h_wstatus[it.image] || size_t(it.image) >= b->walpha.size() || !b->walpha[it.image]) continue;
+            const csw::WebpImg *wi = nullptr;
+            for (const csw::WebpImg &w : b->wimgs) if (int(w.image) == it.image) { wi = &w; break; }
+            if (!wi) continue;
+            alpha_at[i] = int(apx.size());
+            apx.push_back(csp_pixels{b->d_rgb.p + wi->rgb_off, wi->width, wi->height, uint32_t(csw::VP8L_ALPHA_OF) + b->walpha[it.image]});
+        }
+        if (!apx.empty()) {
+            alpha_out.resize(apx.size()); alpha_res.resize(apx.size());
+            csl_encode_pixels(apx.data(), apx.size(), b->device, alpha_out.data(), alpha_res.data());
+        }
+    }
     for (size_t i = 0; i < b->items.size(); i++) {
         PngItem &it = b->items[i];
         outputs[i].data = nullptr; outputs[i].length = 0;
         int code = it.code;
         const char *msg = it.msg.c_str();
+        if (!code && alpha_at[i] >= 0 && !alpha_out[size_t(alpha_at[i])].data) { code = int(alpha_res[size_t(alpha_at[i])].code ? alpha_res[size_t(alpha_at[i])].code : CS_ERR_NO_DEVICE); msg = "alpha plane coder failed"; }
         if (!code && !status[it.image] && b->to_webp && b->h_wstatus[it.image]) { code = int(b->h_wstatus[it.image]); msg = "WebP encoder failed"; }
         else if (!code && status[it.image]) { code = int(status[it.image]); msg = code == int(CSP_ERR_POOL) ? "internal device pool too small" : "malformed PNG data"; }
         if (code) { failed++; if (results) results[i] = png_result(code, msg); continue; }
@@ -996,8 +1025,29 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
             if (hipMemcpy(outputs[i].data, b->d_out.p + b->imgs[it.image].out_off, n, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return -1; }
             outputs[i].length = n;
         }
+        if (alpha_at[i] >= 0) {
+            // extended format: VP8X (alpha flag, canvas size), ALPH (one header byte: lossless compression, no filter, no pre-processing; then the VP8L
+            // stream of the alpha plane without its five header bytes -- signature and sizes, which ALPH implies), the VP8 frame
+            CByteArray &a = alpha_out[size_t(alpha_at[i])];
+            const uint8_t *lossy = outputs[i].data;
+            const size_t vp8 = outputs[i].length - 12;
+            const size_t apay = (size_t(a.data[16]) | (size_t(a.data[17]) << 8) | (size_t(a.data[18]) << 16) | (size_t(a.data[19]) << 24)) - 5;   // the VP8L chunk's payload less its header
+            const size_t alph = 1 + apay, total = 12 + 18 + 8 + alph + (alph & 1) + vp8;
+            uint8_t *o = (uint8_t *)malloc(total), *w = o;
+            memcpy(w, "RIFF", 4); put_le32(w + 4, uint32_t(total - 8)); memcpy(w + 8, "WEBPVP8X", 8); put_le32(w + 16, 10);
+            w[20] = 0x10; w[21] = w[22] = w[23] = 0;
+            const uint32_t cw = it.width - 1, chh = it.height - 1;
+            w[24] = uint8_t(cw); w[25] = uint8_t(cw >> 8); w[26] = uint8_t(cw >> 16); w[27] = uint8_t(chh); w[28] = uint8_t(chh >> 8); w[29] = uint8_t(chh >> 16);
+            w += 30;
+            memcpy(w, "ALPH", 4); put_le32(w + 4, uint32_t(alph)); w[8] = 0x01; memcpy(w + 9, a.data + 25, apay); w += 8 + alph;
+            if (alph & 1) *w++ = 0;
+            memcpy(w, lossy + 12, vp8);
+            free(outputs[i].data); cs_free_bytes(&a);
+            outputs[i].data = o; outputs[i].length = total;
+        }
         if (results) results[i] = png_result(0, nullptr);
     }
+    for (size_t k = 0; k < alpha_out.size(); k++) { cs_free_bytes(&alpha_out[k]); cs_free_result(&alpha_res[k]); }
     return failed;
 }
 

@@ -8,7 +8,7 @@ namespace csw {
 enum { WEBP_MB_REC = 432 };   // int16 per macroblock in the level pool: 25 blocks x 16 levels + the info block (k_webp.hip)
 
 struct WebpImg {
-    uint32_t width, height, mbw, mbh, ncomp;   // ncomp: 3 = interleaved RGB input, 1 = grey
+    uint32_t width, height, mbw, mbh, ncomp;   // ncomp: samples per input pixel: 3 = interleaved RGB, 1 = grey, 4 / 2 = the same with an alpha sample behind (skipped here)
     int32_t qi;                                // quantiser index 0..127
     uint64_t rgb_off;                          // input pixels in the RGB pool
     uint64_t y_off, u_off, v_off;              // source planes, padded to whole macroblocks (work pool)

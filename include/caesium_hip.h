@@ -85,7 +85,7 @@ CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters
    are overwritten while bisecting, as the reference's &mut CSParameters is) */
 CCSResult cs_compress_to_size_in_memory(const uint8_t *in, size_t n, CCSParameters *p, size_t max_output_size,
                                         bool return_smallest, CByteArray *out);
-/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and opaque PNG -> WebP (lossy), JPEG -> PNG (png_optimize: lossless trials, else the quantiser), PNG -> JPEG (alpha dropped); every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
+/* replaces caesium::convert_in_memory (compressor.rs:289,300).  Built: JPEG -> WebP and PNG -> WebP (lossy, or lossless with webp_lossless; a PNG's transparency is kept: an ALPH chunk / ARGB), JPEG -> PNG (png_optimize: lossless trials, else the quantiser), PNG -> JPEG (alpha dropped), WebP -> JPEG / PNG; every other pair answers CS_ERR_UNSUPPORTED (or CS_ERR_SAME_FORMAT) */
 CCSResult cs_convert_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, uint32_t format, CByteArray *out);
 /* the batch form of it: results[i] / outputs[i] correspond to inputs[i] */
 int cs_batch_convert(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t format, int device, CByteArray *outputs, CCSResult *results);
@@ -200,7 +200,7 @@ int csp_batch_create_pixels(const csp_pixels *sources, size_t count, const CCSPa
    number of failed files; outputs / results in input order */
 int csp_png_to_jpeg(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results);
 /* PNG -> lossless WebP (`--format webp --lossless` on a PNG; compressor.rs:289-305 with webp.lossless): the same decode, the VP8L coder behind it;
-   pictures with an alpha channel or a tRNS chunk answer CS_ERR_UNSUPPORTED per file */
+   an alpha channel or a tRNS chunk stays (grey + alpha / RGBA pixels into the coder); such a picture with p->width / height answers CS_ERR_UNSUPPORTED */
 int csp_png_to_lossless_webp(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results);
 int csp_batch_run(csp_batch *b, csp_timing *t);
 int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *results);
@@ -225,9 +225,10 @@ int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, s
  * transparency / animation answer CS_ERR_UNSUPPORTED per file.  cs_batch_compress and cs_batch_convert route WebP files here themselves.
  */
 /* lossless WebP OUTPUT (webp.lossless; libcaesium: webp::compress with libwebp's lossless coder, compressor.rs:427-429, 289-305):
- * 8-bit RGB (channels 3) or grey (1) pictures that are in device memory -> one VP8L file each (k_vp8l_enc.hip).  outputs / results as
- * cs_batch_compress; returns the number of failed items.  cs_batch_compress (WebP sources) and cs_batch_convert (JPEG sources) call it
- * when p->webp_lossless is set. */
+ * 8-bit grey (channels 1), grey + alpha (2), RGB (3) or RGBA (4) pictures that are in device memory -> one VP8L file each (k_vp8l_enc.hip).
+ * outputs / results as cs_batch_compress; returns the number of failed items.  cs_batch_compress (WebP sources) and cs_batch_convert (JPEG and PNG
+ * sources) call it when p->webp_lossless is set; the lossy PNG -> WebP path calls it for the ALPH chunk of a transparent picture (channels 16 + n: the
+ * last of n samples per pixel coded as a grey picture). */
 int csl_encode_pixels(const struct csp_pixels_s *sources, size_t count, int device, CByteArray *outputs, CCSResult *results);
 
 typedef struct cswd_batch cswd_batch;

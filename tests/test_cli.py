@@ -386,9 +386,10 @@ def png_to_webp_step(binary, tmp_path):
     for name, data in (("a.png", png), ("b.png", grey), ("c.png", rgba), ("d.jpg", jpg)):
         (d / name).write_bytes(data)
     j = json.loads(run_cli(binary, "-q", 70, "-o", tmp_path / "pw", "--json", "--format", "webp", d / "a.png", d / "b.png", d / "c.png", d / "d.jpg").stdout)
-    assert [f["status"] for f in j["files"]] == ["success", "success", "error", "success"]
-    got = [open(f["output_path"], "rb").read() for f in j["files"] if f["status"] == "success"]
-    assert got == [O.png_to_webp(png, 70), O.png_to_webp(grey, 70), oracle_jpeg_to_webp(jpg, 70)]
+    assert [f["status"] for f in j["files"]] == ["success", "success", "success", "success"]
+    got = [open(f["output_path"], "rb").read() for f in j["files"]]
+    assert [got[0], got[1], got[3]] == [O.png_to_webp(png, 70), O.png_to_webp(grey, 70), oracle_jpeg_to_webp(jpg, 70)]
+    assert got[2][12:16] == b"VP8X" and b"ALPH" in got[2][:64]   # the RGBA picture keeps its alpha (tests/test_png_webp_emul.py checks the chunk)
     assert j["files"][0]["output_path"].endswith("a.webp")
     from _util import oracle_png_to_webp
     j = json.loads(run_cli(binary, "-q", 70, "-o", tmp_path / "pw2", "--json", "--format", "webp", "--long-edge", 60, d / "a.png", d / "d.jpg").stdout)

@@ -56,10 +56,10 @@ def test_entry_point_and_refusals(api):
     src = webp_cases()[0][1]
     p = pkg.default_parameters(webp_quality=85)
     assert api.convert_in_memory(src, p, WEBP) == oracle_jpeg_to_webp(src, 85)
-    png = dict(png_cases())["RGBA_97x61"]   # transparency: no device path (opaque PNG sources: test_png_webp_emul.py)
+    png = dict(png_cases())["RGBA_97x61"]   # transparency: an extended file with an ALPH chunk (test_png_webp_emul.py)
     outs = api.batch_convert([src, png, b"junk", src], p, WEBP)
     assert outs[0] == oracle_jpeg_to_webp(src, 85) and outs[3] == outs[0]
-    assert [getattr(o, "code", 0) for o in outs] == [0, 10201, 10200, 0]
+    assert [getattr(o, "code", 0) for o in outs] == [0, 0, 10200, 0] and outs[1][12:16] == b"VP8X"
     with pytest.raises(Exception) as e:
         api.convert_in_memory(src, p, JPEG)
     assert e.value.code == 10407

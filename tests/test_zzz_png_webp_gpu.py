@@ -26,7 +26,7 @@ def test_png_sources_equal_oracle(api):
 
 def test_refusals_mixed_and_damaged(api):
     import test_png_webp_emul as T
-    T.test_transparency_is_refused(api)
+    T.test_transparency_becomes_an_alph_chunk(api)
     T.test_resize_in_front(api)
     T.test_mixed_sources_keep_their_order(api)
     T.test_damaged_pngs_convert_like_the_oracle_or_fail(api)
