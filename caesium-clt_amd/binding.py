@@ -49,7 +49,7 @@ EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_siz
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_create_webp", "csp_batch_create_pixels", "csh_batch_create_pixels", "csh_batch_pixels", "csh_batch_create_from_pixels", "csp_png_to_jpeg", "csp_png_to_lossless_webp", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
            "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert",
-           "cswd_batch_create", "cswd_batch_run", "cswd_batch_pixels", "cswd_batch_read_pixels", "cswd_batch_destroy", "csh_batch_create_webp_from_pixels", "csh_batch_create_from_pixels_rgb", "csl_encode_pixels"]
+           "cswd_batch_create", "cswd_batch_run", "cswd_batch_pixels", "cswd_batch_read_pixels", "cswd_batch_alpha", "cswd_batch_read_rgba", "cswd_batch_destroy", "csh_batch_create_webp_from_pixels", "csh_batch_create_from_pixels_rgb", "csl_encode_pixels", "csl_attach_alpha"]
 
 
 def _declare(L):
@@ -102,6 +102,8 @@ def _declare(L):
     L.cswd_batch_run.argtypes = [C.c_void_p]
     L.cswd_batch_pixels.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p), P(C.c_uint32), P(C.c_uint32), P(C.c_uint32), P(C.c_char_p)]
     L.cswd_batch_read_pixels.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cswd_batch_alpha.argtypes = [C.c_void_p, C.c_size_t, P(C.c_void_p), P(C.c_void_p)]
+    L.cswd_batch_read_rgba.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.cswd_batch_destroy.argtypes = [C.c_void_p]
     L.cswd_batch_destroy.restype = None
     return L
@@ -357,7 +359,7 @@ class CaesiumHip:
         return Batch(self, blobs, params, device)
 
     def webp_decode(self, blobs, device=0):
-        """cswd_batch: lossy WebP files -> [H][W][3] uint8 arrays (or CaesiumError per file), decoded on the device"""
+        """cswd_batch: WebP files -> [H][W][3] uint8 arrays ([H][W][4] for a picture with transparency; CaesiumError per file), decoded on the device"""
         import numpy as np
         L = self.L
         n = len(blobs)
@@ -380,8 +382,10 @@ class CaesiumHip:
                 if rc:
                     out.append(CaesiumError(rc, (msg.value or b"").decode()))
                     continue
-                a = np.empty((hh.value, w.value, 3), dtype=np.uint8)
-                if L.cswd_batch_read_pixels(h, i, a.ctypes.data):
+                rgba, plane = C.c_void_p(), C.c_void_p()
+                L.cswd_batch_alpha(h, i, C.byref(rgba), C.byref(plane))
+                a = np.empty((hh.value, w.value, 4 if rgba.value else 3), dtype=np.uint8)   # a picture with transparency comes back as RGBA
+                if (L.cswd_batch_read_rgba if rgba.value else L.cswd_batch_read_pixels)(h, i, a.ctypes.data):
                     raise CaesiumError(-1, L.csh_last_error().decode())
                 out.append(a)
             return out

@@ -159,7 +159,8 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
     auto rd32 = [](const uint8_t *d) { return uint32_t(d[0]) | (uint32_t(d[1]) << 8) | (uint32_t(d[2]) << 16) | (uint32_t(d[3]) << 24); };
     const uint8_t *d = src.data;
     const size_t n = src.length;
-    if (n < 20 || !out.data || out.length < 30 || memcmp(out.data + 12, "VP8 ", 4)) return;
+    const bool extended = out.data && out.length >= 38 && !memcmp(out.data + 12, "VP8X", 4);   // made here: VP8X, ALPH, VP8 (a picture with transparency)
+    if (n < 20 || !out.data || out.length < 30 || (memcmp(out.data + 12, "VP8 ", 4) && !extended)) return;
     const uint8_t *icc = nullptr, *exif = nullptr;
     size_t icc_len = 0, exif_len = 0;
     for (size_t i = 12; i + 8 <= n;) {
@@ -170,9 +171,11 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
         i += 8 + cl + (cl & 1);
     }
     if (!icc && !exif) return;
-    const uint8_t *f = out.data + 20;   // VP8 frame header: tag (3), start code (3), 14-bit width and height
-    const uint32_t w = (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFFu, h = (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFFu;
-    const size_t body = out.length - 12;   // the "VP8 " chunk with its header and padding
+    const uint8_t *f = out.data + 20;   // VP8 frame header: tag (3), start code (3), 14-bit width and height -- or the VP8X chunk's flags and canvas size
+    const uint32_t w = extended ? (uint32_t(f[4]) | (uint32_t(f[5]) << 8) | (uint32_t(f[6]) << 16)) + 1 : (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFFu;
+    const uint32_t h = extended ? (uint32_t(f[7]) | (uint32_t(f[8]) << 8) | (uint32_t(f[9]) << 16)) + 1 : (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFFu;
+    const uint8_t flags0 = extended ? f[0] : 0;
+    const size_t body0 = extended ? 30 : 12, body = out.length - body0;   // the chunks behind the file header (and behind VP8X), with their padding
     const size_t total = 12 + 18 + (icc ? 8 + icc_len + (icc_len & 1) : 0) + body + (exif ? 8 + exif_len + (exif_len & 1) : 0);
     uint8_t *o = static_cast<uint8_t *>(malloc(total));
     if (!o) return;
@@ -180,7 +183,7 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
     size_t at = 0;
     memcpy(o, "RIFF", 4); wr32(o + 4, uint32_t(total - 8)); memcpy(o + 8, "WEBP", 4); at = 12;
     memcpy(o + at, "VP8X", 4); wr32(o + at + 4, 10);
-    o[at + 8] = uint8_t((icc ? 0x20 : 0) | (exif ? 0x08 : 0)); o[at + 9] = o[at + 10] = o[at + 11] = 0;
+    o[at + 8] = uint8_t(flags0 | (icc ? 0x20 : 0) | (exif ? 0x08 : 0)); o[at + 9] = o[at + 10] = o[at + 11] = 0;
     const uint32_t cw = w - 1, chh = h - 1;
     o[at + 12] = uint8_t(cw); o[at + 13] = uint8_t(cw >> 8); o[at + 14] = uint8_t(cw >> 16);
     o[at + 15] = uint8_t(chh); o[at + 16] = uint8_t(chh >> 8); o[at + 17] = uint8_t(chh >> 16);
@@ -190,7 +193,7 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
         if (len & 1) o[at++] = 0;
     };
     if (icc) chunk("ICCP", icc, icc_len);
-    memcpy(o + at, out.data + 12, body); at += body;
+    memcpy(o + at, out.data + body0, body); at += body;
     if (exif) chunk("EXIF", exif, exif_len);
     free(out.data);
     out.data = o; out.length = total;
@@ -206,11 +209,19 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
         int rc = cswd_batch_create(inputs + g0, n, device, &wb);
         if (rc == 0) rc = cswd_batch_run(wb);
         std::vector<csp_pixels> px;
+        std::vector<const uint8_t *> aplane;   // per picture: its alpha plane in device memory, or null (opaque)
         std::vector<size_t> at;
         for (size_t k = 0; k < n && rc == 0; k++) {
             csp_pixels s; const char *msg = "";
-            const int code = cswd_batch_pixels(wb, k, &s.device_pixels, &s.width, &s.height, &s.channels, &msg);
-            if (code) { if (results) results[g0 + k] = make_result(code, msg); failed_total++; } else { px.push_back(s); at.push_back(g0 + k); }
+            int code = cswd_batch_pixels(wb, k, &s.device_pixels, &s.width, &s.height, &s.channels, &msg);
+            const uint8_t *rgba = nullptr, *plane = nullptr;
+            if (!code) cswd_batch_alpha(wb, k, &rgba, &plane);
+            if (!code && plane && (p->width || p->height)) { code = CS_ERR_UNSUPPORTED; msg = "resizing a WebP picture with transparency has no device path in this build"; }
+            if (code) { if (results) results[g0 + k] = make_result(code, msg); failed_total++; continue; }
+            // a picture with transparency: the PNG coder and the lossless WebP coder take its RGBA; the lossy WebP encoder its RGB, the plane becomes the
+            // ALPH chunk afterwards; a JPEG drops the plane (as image-rs does)
+            if (plane && (target == CS_TYPE_PNG || (target == CS_TYPE_WEBP && p->webp_lossless))) { s.device_pixels = rgba; s.channels = 4; }
+            px.push_back(s); aplane.push_back((plane && target == CS_TYPE_WEBP && !p->webp_lossless) ? plane : nullptr); at.push_back(g0 + k);
         }
         if (rc) { for (size_t k = 0; k < n; k++) if (results) results[g0 + k] = make_result(rc, csh_last_error()); failed_total += int(n); cswd_batch_destroy(wb); continue; }
         if (!px.empty()) {
@@ -241,6 +252,24 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
                 rc = target == CS_TYPE_WEBP ? csh_batch_create_webp_from_pixels(px.data(), px.size(), p, device, &jb) : csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
                 if (rc == 0) rc = csh_batch_run(jb, nullptr);
                 if (rc == 0) failed = csh_batch_fetch(jb, out.data(), res.data());
+                // the alpha planes of the pictures that have one: the VP8L coder over each plane as a grey picture, then VP8X + ALPH + VP8
+                std::vector<csp_pixels> apx;
+                std::vector<size_t> aat;
+                for (size_t k = 0; k < px.size() && rc == 0 && failed >= 0; k++)
+                    if (aplane[k] && out[k].data) { apx.push_back(csp_pixels{aplane[k], px[k].width, px[k].height, 1}); aat.push_back(k); }
+                if (!apx.empty()) {
+                    std::vector<CByteArray> aout(apx.size());
+                    std::vector<CCSResult> ares(apx.size());
+                    csl_encode_pixels(apx.data(), apx.size(), device, aout.data(), ares.data());
+                    for (size_t j = 0; j < apx.size(); j++) {
+                        const size_t k = aat[j];
+                        if (!aout[j].data || csl_attach_alpha(&out[k], &aout[j], apx[j].width, apx[j].height)) {
+                            cs_free_bytes(&out[k]); cs_free_result(&res[k]);
+                            res[k] = make_result(ares[j].code ? ares[j].code : CS_ERR_NO_DEVICE, "alpha plane coder failed"); failed++;
+                        }
+                        cs_free_bytes(&aout[j]); cs_free_result(&ares[j]);
+                    }
+                }
             }
             if (rc || failed < 0) { for (size_t k = 0; k < px.size(); k++) if (results) results[at[k]] = make_result(rc ? rc : CS_ERR_NO_DEVICE, csh_last_error()); failed_total += int(px.size()); }
             else {

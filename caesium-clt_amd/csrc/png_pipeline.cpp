@@ -990,20 +990,20 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
     std::vector<CByteArray> alpha_out;
     std::vector<CCSResult> alpha_res;
     std::vector<int> alpha_at(b->items.size(), -1);
+    std::vector<csp_pixels> alpha_px;
     if (b->to_webp) {
-        std::vector<csp_pixels> apx;
         for (size_t i = 0; i < b->items.size(); i++) {
             const PngItem &it = b->items[i];
             if (it.code || it.image < 0 || status[it.image] || b->h_wstatus[it.image] || size_t(it.image) >= b->walpha.size() || !b->walpha[it.image]) continue;
             const csw::WebpImg *wi = nullptr;
             for (const csw::WebpImg &w : b->wimgs) if (int(w.image) == it.image) { wi = &w; break; }
             if (!wi) continue;
-            alpha_at[i] = int(apx.size());
-            apx.push_back(csp_pixels{b->d_rgb.p + wi->rgb_off, wi->width, wi->height, uint32_t(csw::VP8L_ALPHA_OF) + b->walpha[it.image]});
+            alpha_at[i] = int(alpha_px.size());
+            alpha_px.push_back(csp_pixels{b->d_rgb.p + wi->rgb_off, wi->width, wi->height, uint32_t(csw::VP8L_ALPHA_OF) + b->walpha[it.image]});
         }
-        if (!apx.empty()) {
-            alpha_out.resize(apx.size()); alpha_res.resize(apx.size());
-            csl_encode_pixels(apx.data(), apx.size(), b->device, alpha_out.data(), alpha_res.data());
+        if (!alpha_px.empty()) {
+            alpha_out.resize(alpha_px.size()); alpha_res.resize(alpha_px.size());
+            csl_encode_pixels(alpha_px.data(), alpha_px.size(), b->device, alpha_out.data(), alpha_res.data());
         }
     }
     for (size_t i = 0; i < b->items.size(); i++) {
@@ -1026,24 +1026,12 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
             outputs[i].length = n;
         }
         if (alpha_at[i] >= 0) {
-            // extended format: VP8X (alpha flag, canvas size), ALPH (one header byte: lossless compression, no filter, no pre-processing; then the VP8L
-            // stream of the alpha plane without its five header bytes -- signature and sizes, which ALPH implies), the VP8 frame
-            CByteArray &a = alpha_out[size_t(alpha_at[i])];
-            const uint8_t *lossy = outputs[i].data;
-            const size_t vp8 = outputs[i].length - 12;
-            const size_t apay = (size_t(a.data[16]) | (size_t(a.data[17]) << 8) | (size_t(a.data[18]) << 16) | (size_t(a.data[19]) << 24)) - 5;   // the VP8L chunk's payload less its header
-            const size_t alph = 1 + apay, total = 12 + 18 + 8 + alph + (alph & 1) + vp8;
-            uint8_t *o = (uint8_t *)malloc(total), *w = o;
-            memcpy(w, "RIFF", 4); put_le32(w + 4, uint32_t(total - 8)); memcpy(w + 8, "WEBPVP8X", 8); put_le32(w + 16, 10);
-            w[20] = 0x10; w[21] = w[22] = w[23] = 0;
-            const uint32_t cw = it.width - 1, chh = it.height - 1;
-            w[24] = uint8_t(cw); w[25] = uint8_t(cw >> 8); w[26] = uint8_t(cw >> 16); w[27] = uint8_t(chh); w[28] = uint8_t(chh >> 8); w[29] = uint8_t(chh >> 16);
-            w += 30;
-            memcpy(w, "ALPH", 4); put_le32(w + 4, uint32_t(alph)); w[8] = 0x01; memcpy(w + 9, a.data + 25, apay); w += 8 + alph;
-            if (alph & 1) *w++ = 0;
-            memcpy(w, lossy + 12, vp8);
-            free(outputs[i].data); cs_free_bytes(&a);
-            outputs[i].data = o; outputs[i].length = total;
+            const csp_pixels &ap = alpha_px[size_t(alpha_at[i])];
+            if (csl_attach_alpha(&outputs[i], &alpha_out[size_t(alpha_at[i])], ap.width, ap.height)) {
+                cs_free_bytes(&outputs[i]); failed++;
+                if (results) results[i] = png_result(CS_ERR_NO_DEVICE, "could not assemble the WebP file with its alpha plane");
+                continue;
+            }
         }
         if (results) results[i] = png_result(0, nullptr);
     }

@@ -18,6 +18,10 @@ struct Vp8In {              // one input file, host-parsed container
     uint64_t rgb_off;       // width * height * 3 bytes in the pixel pool
     uint32_t status;        // device: 0 ok, else an error code
     uint32_t lossless;      // 1: the payload is a VP8L stream (vp8l_dec.h), work area sized by vp8l_work_bytes
+    uint32_t has_alpha;     // device: 1 when the picture is not opaque -- then rgba_off / a_off hold it as RGBA and its alpha plane as well
+    uint64_t alph_off;      // lossy files: the ALPH chunk's payload in the input pool (alph_len 0: none)
+    uint32_t alph_len, pad_;
+    uint64_t rgba_off, a_off;   // width * height * 4 and width * height bytes in the pixel pool (~0: not reserved)
 };
 // work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts
 __host__ __device__ static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t mbh) {

@@ -304,15 +304,20 @@ __host__ __device__ static inline int ldecode_pixels(LDec &d, uint32_t xs, uint3
     return 0;
 }
 
-// 0 ok, 1 malformed, 2 beyond this build (work area exhausted), 3 the picture is not opaque
-__host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *rgb, uint64_t file_bytes) {
+// 0 ok, 1 malformed, 2 beyond this build (work area exhausted), 3 the picture is not opaque and the caller gave no room for its alpha.
+// headerless: the stream of an ALPH chunk -- no signature, no sizes (W x H are the picture's); its green channel is the alpha plane and goes to aplane.
+// Otherwise rgb gets the colour; a picture that is not opaque also fills rgba (interleaved) and aplane and sets *has_alpha.
+__host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *rgb, uint64_t file_bytes, bool headerless = false,
+                                                        uint8_t *rgba = nullptr, uint8_t *aplane = nullptr, uint32_t *has_alpha = nullptr) {
     LDec d;
     d.br.init(data, n);
     LBits &br = d.br;
-    if (br.read(8) != 0x2F) return 1;
-    const uint32_t w = br.read(14) + 1, h = br.read(14) + 1;
-    br.read(1);   // alpha_is_used: a hint; the pixels decide
-    if (br.read(3) != 0 || w != W || h != H) return 1;
+    if (!headerless) {
+        if (br.read(8) != 0x2F) return 1;
+        const uint32_t w = br.read(14) + 1, h = br.read(14) + 1;
+        br.read(1);   // alpha_is_used: a hint; the pixels decide
+        if (br.read(3) != 0 || w != W || h != H) return 1;
+    }
     const uint64_t npx = uint64_t(W) * H, sub = vp8l_sub_pixels(W, H);
     uint32_t *frame0 = reinterpret_cast<uint32_t *>(work), *frame1 = frame0 + npx;
     uint32_t *subimg[3] = {frame1 + npx, frame1 + npx + sub, frame1 + npx + 2 * sub};
@@ -407,14 +412,65 @@ __host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, siz
             xs = tw;
         }
     }
-    // ---- ARGB -> RGB (an input that is not opaque has no path through the three-channel encoders behind this)
+    if (headerless) {   // an alpha plane travelling in the green channel
+        for (uint64_t i = 0; i < npx; i++) aplane[i] = uint8_t(cur[i] >> 8);
+        return 0;
+    }
+    // ---- ARGB -> RGB for the three-channel encoders; a picture that is not opaque leaves RGBA and its alpha plane as well
     uint32_t amin = 255;
     for (uint64_t i = 0; i < npx; i++) {
         const uint32_t v = cur[i];
         rgb[3 * i] = uint8_t(v >> 16); rgb[3 * i + 1] = uint8_t(v >> 8); rgb[3 * i + 2] = uint8_t(v);
         if ((v >> 24) < amin) amin = v >> 24;
     }
-    return amin == 255 ? 0 : 3;
+    if (amin == 255) return 0;
+    if (!rgba || !aplane) return 3;
+    for (uint64_t i = 0; i < npx; i++) {
+        const uint32_t v = cur[i];
+        rgba[4 * i] = uint8_t(v >> 16); rgba[4 * i + 1] = uint8_t(v >> 8); rgba[4 * i + 2] = uint8_t(v); rgba[4 * i + 3] = uint8_t(v >> 24);
+        aplane[i] = uint8_t(v >> 24);
+    }
+    if (has_alpha) *has_alpha = 1;
+    return 0;
+}
+
+// The ALPH chunk of a lossy file (WebP container specification): a header byte -- compression in bits 0-1 (0 raw, 1 a headerless VP8L stream), filter in bits
+// 2-3 (none, horizontal, vertical, gradient), pre-processing in bits 4-5 (nothing to undo) -- then the plane; the filters predict a sample from its left /
+// upper neighbours as libwebp's unfilters do (first row: from the left, first sample 0; first sample of a later row: from the one above).  0 ok, else as above.
+__host__ __device__ static inline int alph_decode(const uint8_t *d, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *aplane) {
+    if (n < 1) return 1;
+    const int method = d[0] & 3, filter = (d[0] >> 2) & 3, pre = (d[0] >> 4) & 3, rsrv = (d[0] >> 6) & 3;
+    const uint64_t npx = uint64_t(W) * H;
+    if (method > 1 || pre > 1 || rsrv > 1) return 1;
+    if (method == 0) {
+        if (uint64_t(n - 1) < npx) return 1;
+        for (uint64_t i = 0; i < npx; i++) aplane[i] = d[1 + i];
+    } else {
+        const int rc = vp8l_decode_frame(d + 1, n - 1, W, H, work, nullptr, n - 1, true, nullptr, aplane, nullptr);
+        if (rc) return rc;
+    }
+    if (filter == 0) return 0;
+    for (uint32_t y = 0; y < H; y++) {
+        uint8_t *row = aplane + uint64_t(y) * W;
+        const uint8_t *prev = y ? row - W : nullptr;
+        if (!prev || filter == 1) {   // horizontal (and every filter's first row)
+            uint32_t pred = prev ? prev[0] : 0u;
+            for (uint32_t x = 0; x < W; x++) { pred = (pred + row[x]) & 255u; row[x] = uint8_t(pred); }
+        } else if (filter == 2) {
+            for (uint32_t x = 0; x < W; x++) row[x] = uint8_t(row[x] + prev[x]);
+        } else {
+            int top = prev[0], top_left = top, left = top;
+            for (uint32_t x = 0; x < W; x++) {
+                top = prev[x];
+                int g = left + top - top_left;
+                g = g < 0 ? 0 : g > 255 ? 255 : g;
+                left = (int(row[x]) + g) & 255;
+                top_left = top;
+                row[x] = uint8_t(left);
+            }
+        }
+    }
+    return 0;
 }
 
 }  // namespace csw

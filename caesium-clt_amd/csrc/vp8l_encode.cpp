@@ -75,3 +75,28 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
     if (have_st) (void)hipStreamDestroy(st);
     return failed;
 }
+
+// A lossy file and its alpha plane as a VP8L file (csl_encode_pixels over the plane as a grey picture) -> the extended-format file libwebp writes for a picture with
+// transparency: VP8X (alpha flag, canvas size), ALPH (one header byte: lossless compression, no filter, no pre-processing; then the VP8L stream without its five
+// header bytes -- signature and sizes, which ALPH implies; its green channel is the alpha), the VP8 frame.  lossy is replaced; 0 ok.
+extern "C" int csl_attach_alpha(CByteArray *lossy, const CByteArray *alpha_vp8l, uint32_t width, uint32_t height) {
+    if (!lossy || !lossy->data || lossy->length < 30 || memcmp(lossy->data + 12, "VP8 ", 4) || !alpha_vp8l || !alpha_vp8l->data || alpha_vp8l->length < 26 || memcmp(alpha_vp8l->data + 12, "VP8L", 4)) return -1;
+    const uint8_t *a = alpha_vp8l->data;
+    const size_t pl = size_t(a[16]) | (size_t(a[17]) << 8) | (size_t(a[18]) << 16) | (size_t(a[19]) << 24);
+    if (pl < 5 || 20 + pl > alpha_vp8l->length) return -1;
+    const size_t vp8 = lossy->length - 12, apay = pl - 5, alph = 1 + apay, total = 12 + 18 + 8 + alph + (alph & 1) + vp8;
+    uint8_t *o = static_cast<uint8_t *>(malloc(total)), *w = o;
+    if (!o) return -1;
+    auto le32 = [](uint8_t *q, uint32_t v) { q[0] = uint8_t(v); q[1] = uint8_t(v >> 8); q[2] = uint8_t(v >> 16); q[3] = uint8_t(v >> 24); };
+    memcpy(w, "RIFF", 4); le32(w + 4, uint32_t(total - 8)); memcpy(w + 8, "WEBPVP8X", 8); le32(w + 16, 10);
+    w[20] = 0x10; w[21] = w[22] = w[23] = 0;
+    const uint32_t cw = width - 1, ch = height - 1;
+    w[24] = uint8_t(cw); w[25] = uint8_t(cw >> 8); w[26] = uint8_t(cw >> 16); w[27] = uint8_t(ch); w[28] = uint8_t(ch >> 8); w[29] = uint8_t(ch >> 16);
+    w += 30;
+    memcpy(w, "ALPH", 4); le32(w + 4, uint32_t(alph)); w[8] = 0x01; memcpy(w + 9, a + 25, apay); w += 8 + alph;
+    if (alph & 1) *w++ = 0;
+    memcpy(w, lossy->data + 12, vp8);
+    free(lossy->data);
+    lossy->data = o; lossy->length = total;
+    return 0;
+}

@@ -1,8 +1,10 @@
 // webp_decode.cpp -- WebP INPUTS of the batch queue: container parsing on the host (RIFF / VP8 / VP8X chunk walk), the key frame on the
 // device (k_webp_dec.hip), the decoded RGB stays in HBM and is handed to the encoders as csp_pixels -- what libcaesium's
 // webp::compress and convert_in_memory do with libwebp's decoder in front (/root/reference/src/compressor.rs:289-305).
-// Built: lossy (VP8) and lossless (VP8L) still pictures without transparency.  Alpha (an ALPH chunk, or a VP8L picture that is not
-// opaque) and animation answer CS_ERR_UNSUPPORTED per file: the encoders behind this take three channels.
+// Built: lossy (VP8) and lossless (VP8L) still pictures, with or without transparency (an ALPH chunk next to the VP8 frame, or a VP8L picture that is
+// not opaque): such a picture leaves its RGB, its RGBA and its alpha plane in HBM (cswd_batch_alpha), and the caller picks what its encoder takes.
+// Animation answers CS_ERR_UNSUPPORTED per file.
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -34,8 +36,8 @@ struct cswd_batch {
 static uint32_t rd32le(const uint8_t *d) { return uint32_t(d[0]) | (uint32_t(d[1]) << 8) | (uint32_t(d[2]) << 16) | (uint32_t(d[3]) << 24); }
 
 // RIFF walk: where the VP8 key frame lies; refuses what this build does not decode
-static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint32_t &w, uint32_t &h, bool &lossless, std::string &msg) {
-    lossless = false;
+static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint32_t &w, uint32_t &h, bool &lossless, size_t &alph_off, size_t &alph_len, std::string &msg) {
+    lossless = false; alph_off = 0; alph_len = 0;
     if (n < 20 || memcmp(d, "RIFF", 4) || memcmp(d + 8, "WEBP", 4)) { msg = "not a WebP file"; return CS_ERR_UNKNOWN_TYPE; }
     size_t end = size_t(rd32le(d + 4)) + 8;
     if (end > n) end = n;   // libwebp tolerates a RIFF size past the file's end as long as the chunks are there
@@ -45,12 +47,13 @@ static int parse_webp(const uint8_t *d, size_t n, size_t &off, size_t &len, uint
         if (i + 8 + cl > n) { msg = "truncated WebP chunk"; return CS_ERR_BAD_WEBP; }
         if (!memcmp(d + i, "VP8 ", 4)) { if (!found) { off = i + 8; len = cl; found = true; } }
         else if (!memcmp(d + i, "VP8L", 4)) { if (!found) { off = i + 8; len = cl; found = true; lossless = true; } }
-        else if (!memcmp(d + i, "ALPH", 4)) { msg = "WebP input with an alpha plane has no device path in this build"; return CS_ERR_UNSUPPORTED; }
+        else if (!memcmp(d + i, "ALPH", 4)) { if (!found && !alph_len) { alph_off = i + 8; alph_len = cl; } }   // the alpha plane of the VP8 frame that follows
         else if (!memcmp(d + i, "ANIM", 4) || !memcmp(d + i, "ANMF", 4)) { msg = "animated WebP input has no device path in this build"; return CS_ERR_UNSUPPORTED; }
         i += 8 + cl + (cl & 1);
     }
     if (!found || len < (lossless ? 5u : 10u)) { msg = "no VP8 frame in the WebP file"; return CS_ERR_BAD_WEBP; }
     const uint8_t *f = d + off;
+    if (lossless) alph_len = 0;
     if (lossless) {   // signature, 14 + 14 bits of size minus one, alpha hint, version
         const uint32_t bits = rd32le(f + 1);
         if (f[0] != 0x2F || (bits >> 29) != 0) { msg = "malformed VP8L header"; return CS_ERR_BAD_WEBP; }
@@ -77,7 +80,8 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
         size_t off = 0, len = 0;
         uint32_t w = 0, h = 0;
         bool lossless = false;
-        it.code = parse_webp(inputs[n].data, inputs[n].length, off, len, w, h, lossless, it.msg);
+        size_t alph_off = 0, alph_len = 0;
+        it.code = parse_webp(inputs[n].data, inputs[n].length, off, len, w, h, lossless, alph_off, alph_len, it.msg);
         if (it.code) continue;
         csw::Vp8In im;
         memset(&im, 0, sizeof im);
@@ -86,8 +90,20 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
         b->pool.resize((b->pool.size() + 15) & ~size_t(15));
         im.width = w; im.height = h; im.mbw = (w + 15) / 16; im.mbh = (h + 15) / 16;
         im.lossless = lossless ? 1u : 0u;
-        im.work_off = b->work_bytes; b->work_bytes += ((lossless ? csw::vp8l_work_bytes(w, h, len) : csw::vp8_work_bytes(im.mbw, im.mbh)) + 63) & ~uint64_t(63);
+        uint64_t work = lossless ? csw::vp8l_work_bytes(w, h, len) : csw::vp8_work_bytes(im.mbw, im.mbh);
+        if (alph_len) {
+            im.alph_off = b->pool.size(); im.alph_len = uint32_t(alph_len);
+            b->pool.insert(b->pool.end(), inputs[n].data + alph_off, inputs[n].data + alph_off + alph_len);
+            b->pool.resize((b->pool.size() + 15) & ~size_t(15));
+            work = std::max(work, csw::vp8l_work_bytes(w, h, alph_len));   // the plane's VP8L stream is decoded in the frame's work area, after the frame
+        }
+        im.work_off = b->work_bytes; b->work_bytes += (work + 63) & ~uint64_t(63);
         im.rgb_off = b->rgb_bytes; b->rgb_bytes += (uint64_t(w) * h * 3 + 63) & ~uint64_t(63);
+        im.rgba_off = im.a_off = ~0ull;
+        if (lossless || alph_len) {   // a picture that may turn out not to be opaque: room for its RGBA and its alpha plane
+            im.rgba_off = b->rgb_bytes; b->rgb_bytes += (uint64_t(w) * h * 4 + 63) & ~uint64_t(63);
+            im.a_off = b->rgb_bytes; b->rgb_bytes += (uint64_t(w) * h + 63) & ~uint64_t(63);
+        }
         it.image = int(b->imgs.size());
         b->imgs.push_back(im);
     }
@@ -109,7 +125,7 @@ extern "C" int cswd_batch_run(cswd_batch *b) {
         if (it.image >= 0 && b->imgs[size_t(it.image)].status) {
             const uint32_t st = b->imgs[size_t(it.image)].status;
             it.code = st >= 2 ? CS_ERR_UNSUPPORTED : CS_ERR_BAD_WEBP;
-            it.msg = st == 3 ? "WebP input with transparency has no device path in this build" : st == 2 ? "WebP frame beyond this build (frame type / prefix-code work area)" : "malformed WebP stream";
+            it.msg = st == 3 ? "WebP input with transparency: no room was reserved for its alpha" : st == 2 ? "WebP frame beyond this build (frame type / prefix-code work area)" : "malformed WebP stream";
         }
     b->ran = true;
     return 0;
@@ -125,11 +141,32 @@ extern "C" int cswd_batch_pixels(cswd_batch *b, size_t image, const uint8_t **de
     return 0;
 }
 
+// a picture that is not opaque: its RGBA (width * height * 4) and its alpha plane (width * height) in device memory; both null for an opaque one
+extern "C" int cswd_batch_alpha(cswd_batch *b, size_t image, const uint8_t **device_rgba, const uint8_t **device_alpha) {
+    *device_rgba = nullptr; *device_alpha = nullptr;
+    if (!b->ran || image >= b->items.size()) { csh_set_error("cswd_batch_alpha: batch not run / index out of range"); return -1; }
+    const cswd_batch::Item &it = b->items[image];
+    if (it.code) return it.code;
+    const csw::Vp8In &im = b->imgs[size_t(it.image)];
+    if (im.has_alpha) { *device_rgba = b->d_rgb.p + im.rgba_off; *device_alpha = b->d_rgb.p + im.a_off; }
+    return 0;
+}
+
 extern "C" int cswd_batch_read_pixels(cswd_batch *b, size_t image, uint8_t *dst) {
     const uint8_t *p; uint32_t w, h, c; const char *m;
     int rc = cswd_batch_pixels(b, image, &p, &w, &h, &c, &m);
     if (rc) return rc;
     if (hipMemcpy(dst, p, size_t(w) * h * c, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
+    return 0;
+}
+
+extern "C" int cswd_batch_read_rgba(cswd_batch *b, size_t image, uint8_t *dst) {   // width * height * 4 bytes of a picture that is not opaque; 1 for an opaque one
+    const uint8_t *rgba, *a;
+    const int rc = cswd_batch_alpha(b, image, &rgba, &a);
+    if (rc) return rc;
+    if (!rgba) return 1;
+    const csw::Vp8In &im = b->imgs[size_t(b->items[image].image)];
+    if (hipMemcpy(dst, rgba, size_t(im.width) * im.height * 4, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
     return 0;
 }
 

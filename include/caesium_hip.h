@@ -221,8 +221,8 @@ int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, s
 /* ------------------------------------------------------------------------------------------------
  * WebP INPUTS (libcaesium decodes them with libwebp before webp::compress / convert_in_memory, compressor.rs:289-305): the RIFF
  * container is walked on the host, the VP8 key frame is decoded on the device (k_webp_dec.hip), the RGB stays in HBM
- * (cswd_batch_pixels: the csp_pixels the encoders take).  Built: lossy (VP8) and lossless (VP8L) still pictures that are opaque; ALPH /
- * transparency / animation answer CS_ERR_UNSUPPORTED per file.  cs_batch_compress and cs_batch_convert route WebP files here themselves.
+ * (cswd_batch_pixels: the csp_pixels the encoders take).  Built: lossy (VP8) and lossless (VP8L) still pictures, transparency (ALPH chunk, non-opaque
+ * VP8L) included -- cswd_batch_alpha; animation answers CS_ERR_UNSUPPORTED per file.  cs_batch_compress and cs_batch_convert route WebP files here themselves.
  */
 /* lossless WebP OUTPUT (webp.lossless; libcaesium: webp::compress with libwebp's lossless coder, compressor.rs:427-429, 289-305):
  * 8-bit grey (channels 1), grey + alpha (2), RGB (3) or RGBA (4) pictures that are in device memory -> one VP8L file each (k_vp8l_enc.hip).
@@ -230,12 +230,19 @@ int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint64_t *dst, s
  * sources) call it when p->webp_lossless is set; the lossy PNG -> WebP path calls it for the ALPH chunk of a transparent picture (channels 16 + n: the
  * last of n samples per pixel coded as a grey picture). */
 int csl_encode_pixels(const struct csp_pixels_s *sources, size_t count, int device, CByteArray *outputs, CCSResult *results);
+/* a lossy WebP file + its alpha plane coded by csl_encode_pixels (as a grey picture) -> the extended-format file with an ALPH chunk (VP8X, ALPH, VP8);
+   lossy is replaced in place.  0 ok. */
+int csl_attach_alpha(CByteArray *lossy, const CByteArray *alpha_vp8l, uint32_t width, uint32_t height);
 
 typedef struct cswd_batch cswd_batch;
 int cswd_batch_create(const CByteArray *inputs, size_t count, int device, cswd_batch **out);
 int cswd_batch_run(cswd_batch *b);
 int cswd_batch_pixels(cswd_batch *b, size_t image, const uint8_t **device_pixels, uint32_t *width, uint32_t *height, uint32_t *channels, const char **message);
 int cswd_batch_read_pixels(cswd_batch *b, size_t image, uint8_t *dst /* width * height * 3 */);
+/* a picture with transparency (ALPH chunk / a VP8L picture that is not opaque): its RGBA (4 bytes per pixel) and its alpha plane in device memory; both
+   NULL for an opaque picture.  cswd_batch_pixels keeps handing out the RGB of either kind. */
+int cswd_batch_alpha(cswd_batch *b, size_t image, const uint8_t **device_rgba, const uint8_t **device_alpha);
+int cswd_batch_read_rgba(cswd_batch *b, size_t image, uint8_t *dst /* width * height * 4; returns 1 for an opaque picture */);
 void cswd_batch_destroy(cswd_batch *b);
 /* pixels in, WebP out: the lossy WebP encoder behind the same stand-in as csh_batch_create_from_pixels */
 int csh_batch_create_webp_from_pixels(const struct csp_pixels_s *sources, size_t count, const CCSParameters *p, int device, csh_batch **out);

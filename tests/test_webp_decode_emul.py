@@ -113,8 +113,8 @@ def test_emul_damaged_and_unsupported_inputs_fail_alone(api):
     lossless = io.BytesIO(); Image.fromarray(np.dstack([synth_rgb(4, 32, 24), np.full((24, 32), 128, np.uint8)]), "RGBA").save(lossless, format="WEBP", lossless=True)   # VP8L, not opaque
     alpha = io.BytesIO(); Image.fromarray(np.dstack([synth_rgb(5, 32, 24), np.full((24, 32), 128, np.uint8)]), "RGBA").save(alpha, format="WEBP", quality=80)
     outs = api.webp_decode([good, good[:60], lossless.getvalue(), alpha.getvalue(), good[:12] + b"JUNK" + good[16:], good])
-    assert [isinstance(o, Exception) for o in outs] == [False, True, True, True, True, False]
-    assert outs[2].code == 10201 and outs[3].code == 10201 and outs[1].code == 40100
+    assert [isinstance(o, Exception) for o in outs] == [False, True, False, False, True, False]
+    assert outs[2].shape == (24, 32, 4) and outs[3].shape == (24, 32, 4) and outs[1].code == 40100   # transparency: RGBA (test_emul_transparent_files_decode_like_libwebp)
     assert np.array_equal(outs[0], libwebp_rgb(good)) and np.array_equal(outs[5], libwebp_rgb(good))
     cut = good[:len(good) * 2 // 3]   # data running out inside the token partitions: refused by both, or decoded alike
     got = api.webp_decode([cut])[0]
@@ -191,3 +191,89 @@ def test_emul_webp_metadata_carried_over(api, reference_samples):
     assert kept[20] == 0x08 and im.info["exif"] == Image.open(io.BytesIO(w1)).info["exif"] and b"XMP " not in kept
     w0 = open(os.path.join(reference_samples, "w0.webp"), "rb").read()
     assert api.compress_in_memory(w0, params(webp_quality=60, keep_metadata=True)) == api.compress_in_memory(w0, params(webp_quality=60))
+
+
+def transparent_files():
+    """WebP files with transparency as libwebp writes them: lossy frames with an ALPH chunk (lossless alpha with libwebp's choice of filter; alpha_quality
+    below 100 adds its level reduction, which needs no undoing), lossless pictures with an alpha channel; smooth, noisy, binary and constant alpha"""
+    out = []
+    rng = np.random.default_rng(5)
+    for k, (w, h) in enumerate([(64, 48), (97, 61), (33, 17), (1, 1), (16, 16), (130, 5)]):
+        rgb = synth_rgb(300 + k, w, h, texture=10.0)
+        yy, xx = np.mgrid[0:h, 0:w]
+        alphas = {"ramp": ((xx * 255) // max(1, w - 1)).astype(np.uint8), "noise": rng.integers(0, 256, (h, w), dtype=np.uint8),
+                  "mask": np.where((xx // 5 + yy // 3) % 2 == 0, 0, 255).astype(np.uint8), "half": np.full((h, w), 128, np.uint8)}
+        for name, a in alphas.items():
+            im = Image.fromarray(np.dstack([rgb, a]), "RGBA")
+            for label, kw in (("lossy", dict(quality=80)), ("lossy_aq50", dict(quality=60, alpha_quality=50)), ("lossy_m6", dict(quality=90, method=6)), ("lossless", dict(lossless=True))):
+                if k > 1 and label in ("lossy_aq50", "lossy_m6"):
+                    continue
+                b = io.BytesIO()
+                im.save(b, format="WEBP", **kw)
+                out.append(("%s_%s_%dx%d" % (label, name, w, h), b.getvalue()))
+    return out
+
+
+def test_emul_transparent_files_decode_like_libwebp(api):
+    files = transparent_files()
+    outs = api.webp_decode([f[1] for f in files])
+    filters = set()
+    for (name, blob), got in zip(files, outs):
+        assert not isinstance(got, Exception), (name, got)
+        ref = Image.open(io.BytesIO(blob))
+        want = np.asarray(ref.convert("RGBA"))
+        if (want[:, :, 3] == 255).all():   # libwebp found the plane opaque after its level reduction: an RGB picture for both
+            assert got.shape[2] == 3 and np.array_equal(got, want[:, :, :3]), name
+            continue
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        at = blob.find(b"ALPH")
+        if at > 0:
+            filters.add((blob[at + 8] >> 2) & 3)
+    assert len(filters) >= 2, filters   # the files between them use more than one of the alpha filters
+
+
+def test_emul_transparent_sources_keep_their_alpha(api):
+    """-q / --lossless / --format png / --format jpeg on WebP files with transparency: the alpha plane survives exactly (it is coded losslessly either way), the
+    colour goes through the same encoders as an opaque picture's"""
+    from _util import package
+    pkg = package()
+    rgb = synth_rgb(41, 80, 56, texture=12.0)
+    yy, xx = np.mgrid[0:56, 0:80]
+    a = np.where((xx - 40) ** 2 + (yy - 28) ** 2 < 500, 255, ((xx * 3) % 256)).astype(np.uint8)
+    files = {}
+    for label, kw in (("lossy", dict(quality=85)), ("lossless", dict(lossless=True))):
+        b = io.BytesIO()
+        Image.fromarray(np.dstack([rgb, a]), "RGBA").save(b, format="WEBP", **kw)
+        files[label] = b.getvalue()
+    opaque = webp_of(3, 64, 48, 80)
+    for label, src in files.items():
+        src_rgba = np.asarray(Image.open(io.BytesIO(src)).convert("RGBA"))
+        # lossy again: VP8X + ALPH + VP8, alpha exact, colour = what the opaque path makes of the same RGB
+        outs = api.cs_batch_compress([opaque, src, opaque], pkg.default_parameters(webp_quality=70))
+        assert outs[0] == outs[2] and outs[0][12:16] == b"VP8 "
+        out = outs[1]
+        assert out[12:16] == b"VP8X" and out[30:34] == b"ALPH", label
+        got = np.asarray(Image.open(io.BytesIO(out)).convert("RGBA"))
+        assert np.array_equal(got[:, :, 3], src_rgba[:, :, 3]), label
+        plain = io.BytesIO()
+        Image.fromarray(src_rgba[:, :, :3], "RGB").save(plain, format="WEBP", lossless=True)
+        want = api.compress_in_memory(plain.getvalue(), pkg.default_parameters(webp_quality=70))
+        assert np.array_equal(got[:, :, :3], np.asarray(Image.open(io.BytesIO(want)).convert("RGB"))), label
+        # losslessly: exactly the RGBA
+        out = api.compress_in_memory(src, pkg.default_parameters(webp_lossless=True))
+        assert out[8:16] == b"WEBPVP8L" and np.array_equal(np.asarray(Image.open(io.BytesIO(out)).convert("RGBA")), src_rgba), label
+        # to PNG (lossless trials): exactly the RGBA; to JPEG: the plane is dropped
+        out = api.convert_in_memory(src, pkg.default_parameters(png_optimize=True), 1)
+        im = Image.open(io.BytesIO(out))
+        assert im.format == "PNG" and np.array_equal(np.asarray(im.convert("RGBA")), src_rgba), label
+        out = api.convert_in_memory(src, pkg.default_parameters(jpeg_quality=90), 0)
+        assert Image.open(io.BytesIO(out)).mode == "RGB"
+        # a resize of such a picture is refused, per file
+        outs = api.cs_batch_compress([src, opaque], pkg.default_parameters(webp_quality=70, width=40))
+        assert getattr(outs[0], "code", 0) == 10201 and isinstance(outs[1], bytes)
+    # metadata travels with the alpha: ICCP in front of ALPH, EXIF behind the frame
+    meta = io.BytesIO()
+    Image.fromarray(np.dstack([rgb, a]), "RGBA").save(meta, format="WEBP", quality=85, exif=b"Exif\0\0MM\0*\0\0\0\x08\0\0", icc_profile=b"fake profile bytes")
+    out = api.compress_in_memory(meta.getvalue(), pkg.default_parameters(webp_quality=70, keep_metadata=True))
+    im = Image.open(io.BytesIO(out))
+    assert im.mode == "RGBA" and im.info.get("icc_profile") == b"fake profile bytes" and out[20] & 0x38 == 0x38

@@ -44,3 +44,11 @@ def test_compress_to_size_on_webp(api):
 
 def test_webp_metadata_carried_over(api, reference_samples):
     E.test_emul_webp_metadata_carried_over(api, reference_samples)
+
+
+def test_transparent_files_decode_like_libwebp(api):
+    E.test_emul_transparent_files_decode_like_libwebp(api)
+
+
+def test_transparent_sources_keep_their_alpha(api):
+    E.test_emul_transparent_sources_keep_their_alpha(api)
