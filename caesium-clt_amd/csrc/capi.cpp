@@ -216,7 +216,9 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
             int code = cswd_batch_pixels(wb, k, &s.device_pixels, &s.width, &s.height, &s.channels, &msg);
             const uint8_t *rgba = nullptr, *plane = nullptr;
             if (!code) cswd_batch_alpha(wb, k, &rgba, &plane);
-            if (!code && plane && (p->width || p->height)) { code = CS_ERR_UNSUPPORTED; msg = "resizing a WebP picture with transparency has no device path in this build"; }
+            if (!code && plane && (p->width || p->height) && !(target == CS_TYPE_WEBP && !p->webp_lossless) && target != CS_TYPE_JPEG) {   // the RGBA consumers take no resize here
+                code = CS_ERR_UNSUPPORTED; msg = "resizing a WebP picture with transparency into a PNG / lossless WebP has no device path in this build";
+            }
             if (code) { if (results) results[g0 + k] = make_result(code, msg); failed_total++; continue; }
             // a picture with transparency: the PNG coder and the lossless WebP coder take its RGBA; the lossy WebP encoder its RGB, the plane becomes the
             // ALPH chunk afterwards; a JPEG drops the plane (as image-rs does)
@@ -257,7 +259,12 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
                 std::vector<size_t> aat;
                 for (size_t k = 0; k < px.size() && rc == 0 && failed >= 0; k++)
                     if (aplane[k] && out[k].data) { apx.push_back(csp_pixels{aplane[k], px[k].width, px[k].height, 1}); aat.push_back(k); }
-                if (!apx.empty()) {
+                if (!apx.empty() && (p->width || p->height)) {   // the planes through the same Lanczos branch as the colour, as grey pictures (image-rs resamples the four channels alike)
+                    rc = csh_batch_create_from_pixels_rgb(apx.data(), apx.size(), p, device, &rb);
+                    if (rc == 0) rc = csh_batch_run(rb, nullptr);
+                    for (size_t j = 0; j < apx.size() && rc == 0; j++) { const char *m = ""; if (csh_batch_pixels(rb, j, &apx[j].device_pixels, &apx[j].width, &apx[j].height, &apx[j].channels, &m)) rc = CS_ERR_NO_DEVICE; }
+                }
+                if (!apx.empty() && rc == 0) {
                     std::vector<CByteArray> aout(apx.size());
                     std::vector<CCSResult> ares(apx.size());
                     csl_encode_pixels(apx.data(), apx.size(), device, aout.data(), ares.data());

@@ -268,8 +268,15 @@ def test_emul_transparent_sources_keep_their_alpha(api):
         assert im.format == "PNG" and np.array_equal(np.asarray(im.convert("RGBA")), src_rgba), label
         out = api.convert_in_memory(src, pkg.default_parameters(jpeg_quality=90), 0)
         assert Image.open(io.BytesIO(out)).mode == "RGB"
-        # a resize of such a picture is refused, per file
+        # with a resize: colour and plane through the same Lanczos branch (the plane as a grey picture); the RGBA consumers refuse it, per file
         outs = api.cs_batch_compress([src, opaque], pkg.default_parameters(webp_quality=70, width=40))
+        small = Image.open(io.BytesIO(outs[0]))
+        assert small.mode == "RGBA" and small.size == (40, 28) and isinstance(outs[1], bytes), label
+        plane = io.BytesIO()
+        Image.fromarray(np.repeat(src_rgba[:, :, 3:4], 3, axis=2), "RGB").save(plane, format="WEBP", lossless=True)   # the plane as a grey picture, resized the same way
+        want = np.asarray(Image.open(io.BytesIO(api.compress_in_memory(plane.getvalue(), pkg.default_parameters(webp_lossless=True, width=40)))).convert("RGB"))[:, :, 0]
+        assert np.array_equal(np.asarray(small)[:, :, 3], want), label
+        outs = api.cs_batch_compress([src, opaque], pkg.default_parameters(webp_lossless=True, width=40))
         assert getattr(outs[0], "code", 0) == 10201 and isinstance(outs[1], bytes)
     # metadata travels with the alpha: ICCP in front of ALPH, EXIF behind the frame
     meta = io.BytesIO()
