@@ -493,18 +493,35 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_mb(const WebpImg *img
 #else
 #define LANE0 if ((threadIdx.x & 63u) == 0)
 #endif
-struct BoolEnc {
+// The coder's state is wave-uniform.  VEC = false keeps it in scalar registers; VEC = true keeps range and value in VECTOR registers (every lane the same
+// numbers): with eight token waves per picture and a thousand pictures the token kernel runs at three quarters of the chip's SCALAR issue rate (12 k scalar
+// instructions per macroblock against 1.7 k vector ones, profiles/r02_pmc_sq_webp_batch256.txt), so the arithmetic of a decision -- split, the two updates, the
+// renormalisation, which needs no branch: the shift is 0 when none is due -- moves to the idle vector unit and only the bit count and the byte output stay scalar.
+template <bool VEC>
+struct BoolEncT {
     uint8_t *buf;
     uint32_t pos, cap;
     int32_t range, value;
     int run, nb_bits;
     bool overflow;
-    __device__ __forceinline__ static int32_t u(int32_t v) { return int32_t(csp::uni(uint32_t(v))); }   // the coder's state is wave-uniform: keep it in scalar registers
-    __device__ __forceinline__ void init(uint8_t *b, uint32_t c) { buf = b; pos = 0; cap = c; range = 254; value = 0; run = 0; nb_bits = -8; overflow = false; }
+    __device__ __forceinline__ static int32_t u(int32_t v) { return int32_t(csp::uni(uint32_t(v))); }
+    __device__ __forceinline__ static int32_t vzero() {   // a zero the compiler takes for a per-lane value
+#ifdef CSH_EMUL
+        return 0;
+#else
+        int32_t z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        return z;
+#endif
+    }
+    __device__ __forceinline__ void init(uint8_t *b, uint32_t c) {
+        buf = b; pos = 0; cap = c; run = 0; nb_bits = -8; overflow = false;
+        if (VEC) { range = 254 + vzero(); value = vzero(); } else { range = 254; value = 0; }
+    }
     __device__ __forceinline__ void flush_bits() {
         const int s = 8 + nb_bits;
         const int32_t bits = u(value >> s);
-        value = u(value - (bits << s));
+        value = VEC ? value - (bits << s) : u(value - (bits << s));
         nb_bits = u(nb_bits - 8);
         if ((bits & 0xff) != 0xff) {
             if (pos + uint32_t(run) + 1 > cap) { overflow = true; run = 0; return; }
@@ -520,6 +537,17 @@ struct BoolEnc {
     }
     __device__ __forceinline__ void put(int bit, int prob) {
         bit = u(bit); prob = u(prob);
+        if (VEC) {
+            const int32_t split = (range * prob) >> 8, m = -int32_t(bit != 0);
+            value += (split + 1) & m;
+            range = split + ((range - 2 * split - 1) & m);               // bit ? range - split - 1 : split
+            const int shift = __clz(uint32_t(range + 1)) - 24;          // 0 for range >= 127: no renormalisation due
+            range = ((range + 1) << shift) - 1;
+            value <<= shift;
+            nb_bits = u(nb_bits + u(shift));
+            if (nb_bits > 0) flush_bits();
+            return;
+        }
         const int32_t split = (range * prob) >> 8;
         if (bit) { value += split + 1; range -= split + 1; } else range = split;
         range = u(range); value = u(value);
@@ -534,12 +562,14 @@ struct BoolEnc {
     __device__ __forceinline__ void bits(uint32_t v, int n) { while (n--) put(int((v >> n) & 1u), 128); }
     __device__ __forceinline__ void finish() { bits(0, 9 - nb_bits); nb_bits = 0; flush_bits(); }
 };
+typedef BoolEncT<false> BoolEnc;      // the header partition
+typedef BoolEncT<true> BoolEncTok;    // the token partitions
 // the token walk of one block, either coding (CodeSink: the frame's probabilities) or only counting what it would code
 // (StatSink), which is how the frame's probabilities are chosen (oracle: put_coeffs / tsink)
 // the coder's wave is one serial chain, and what makes it slow is waiting for memory once per decision: the frame's probabilities
 // therefore sit in LDS, and a block's sixteen levels arrive with ONE load (lane n holds level n; the walk reads them with v_readlane)
 struct CodeSink {
-    BoolEnc &e;
+    BoolEncTok &e;
     const uint8_t *probs;   // LDS
     LV<int> lvl;
     __device__ __forceinline__ void begin(const int16_t *lv) { LFOR(l) lvl[l] = l < 16 ? int(lv[l]) : 0; }
@@ -768,7 +798,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_code(const WebpImg *i
     const uint8_t *probs = s_probs;
     uint8_t *base = scratch + im.out_off;
     if (part < 0) { code_header(im, lev, probs, update, s_bmp, base, &part_size[size_t(im.image) * 9]); return; }
-    BoolEnc e;
+    BoolEncTok e;
     {
         e.init(base + webp_hdr_cap(im) + uint32_t(part) * webp_part_cap(im), webp_part_cap(im));
         for (int my = part; my < mbh && !e.overflow; my += nparts)
