@@ -504,3 +504,33 @@ def test_product_binary_fails_loudly_without_gpu(tree, tmp_path):
     root, _ = tree
     j = json.loads(run_cli(PRODUCT_CLI, "-q", 80, "-o", tmp_path / "o", "--json", root).stdout)
     assert j["files"] and all(f["status"] == "error" and "device" in f["message"].lower() for f in j["files"])
+
+
+def test_transparency_through_the_cli(tmp_path):
+    """WebP files with transparency (an ALPH chunk / a VP8L picture that is not opaque) and a transparent PNG through the whole program on the emulation build:
+    -q with a resize keeps the alpha (the VP8X canvas size is what the resize parameters are computed from), --format webp on the PNG as well"""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from gen_synth import synth_rgb
+    d = tmp_path / "alpha_in"
+    d.mkdir()
+    rgb = synth_rgb(1, 80, 56, texture=10.0)
+    a = np.tile((np.arange(80) * 3).astype(np.uint8), (56, 1))
+    for name, kw in (("a.webp", dict(quality=80)), ("b.webp", dict(lossless=True))):
+        Image.fromarray(np.dstack([rgb, a]), "RGBA").save(d / name, format="WEBP", **kw)
+    Image.fromarray(np.dstack([rgb, a]), "RGBA").save(d / "c.png")
+    j = json.loads(run_cli(EMUL_CLI, "-q", 70, "--long-edge", 40, "-o", tmp_path / "alpha_out", "--json", d / "a.webp", d / "b.webp", d / "c.png").stdout)
+    assert [f["status"] for f in j["files"]] == ["success"] * 3
+    for f in j["files"][:2]:
+        im = Image.open(f["output_path"])
+        assert (im.format, im.mode, im.size) == ("WEBP", "RGBA", (40, 28))
+    j = json.loads(run_cli(EMUL_CLI, "-q", 70, "--format", "webp", "-o", tmp_path / "alpha_out2", "--json", d / "c.png").stdout)
+    assert j["files"][0]["status"] == "success"
+    im = Image.open(j["files"][0]["output_path"])
+    assert (im.format, im.mode, im.size) == ("WEBP", "RGBA", (80, 56)) and np.array_equal(np.asarray(im)[:, :, 3], a)
+    j = json.loads(run_cli(EMUL_CLI, "--lossless", "-o", tmp_path / "alpha_out3", "--json", d / "b.webp").stdout)
+    assert j["files"][0]["status"] == "success"
+    assert np.array_equal(np.asarray(Image.open(j["files"][0]["output_path"])), np.asarray(Image.open(d / "b.webp")))   # (libwebp itself cleared the colour under alpha 0 when it made b.webp)

@@ -284,3 +284,34 @@ def test_emul_transparent_sources_keep_their_alpha(api):
     out = api.compress_in_memory(meta.getvalue(), pkg.default_parameters(webp_quality=70, keep_metadata=True))
     im = Image.open(io.BytesIO(out))
     assert im.mode == "RGBA" and im.info.get("icc_profile") == b"fake profile bytes" and out[20] & 0x38 == 0x38
+
+
+def test_emul_damaged_transparent_files_fail_alone(api):
+    """bit flips inside the ALPH chunk and in non-opaque VP8L streams, truncated chunks, a plane shorter than the picture: refused per file or decoded to a
+    picture of the right shape, never past a buffer (tools/asan_emul.sh runs this under the sanitizers)"""
+    rng = np.random.default_rng(11)
+    files = [f for f in transparent_files() if "64x48" in f[0] or "33x17" in f[0]]
+    good = webp_of(3, 64, 48, 80)
+    bad = []
+    for name, blob in files:
+        at = blob.find(b"ALPH")
+        lo, hi = (at + 8, at + 8 + int.from_bytes(blob[at + 4:at + 8], "little")) if at > 0 else (20, len(blob))
+        for _ in range(3):
+            b = bytearray(blob)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
+            bad.append(bytes(b))
+        if at > 0:   # the chunk cut short (its size field and the RIFF size adjusted), and a raw plane that is too small
+            n = int.from_bytes(blob[at + 4:at + 8], "little")
+            keep = max(1, n // 2)
+            cut = blob[:at + 4] + keep.to_bytes(4, "little") + blob[at + 8:at + 8 + keep] + (b"\0" if keep & 1 else b"") + blob[at + 8 + n + (n & 1):]
+            bad.append(cut[:4] + (len(cut) - 8).to_bytes(4, "little") + cut[8:])
+            raw = blob[:at + 4] + (5).to_bytes(4, "little") + b"\0abcd\0" + blob[at + 8 + n + (n & 1):]
+            bad.append(raw[:4] + (len(raw) - 8).to_bytes(4, "little") + raw[8:])
+    outs = api.webp_decode([good] + bad + [good])
+    assert np.array_equal(outs[0], libwebp_rgb(good)) and np.array_equal(outs[-1], libwebp_rgb(good))
+    refused = 0
+    for o in outs[1:-1]:
+        assert isinstance(o, Exception) or (o.ndim == 3 and o.shape[2] in (3, 4))
+        refused += isinstance(o, Exception)
+    assert refused >= 3

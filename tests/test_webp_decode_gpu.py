@@ -52,3 +52,7 @@ def test_transparent_files_decode_like_libwebp(api):
 
 def test_transparent_sources_keep_their_alpha(api):
     E.test_emul_transparent_sources_keep_their_alpha(api)
+
+
+def test_damaged_transparent_files_fail_alone(api):
+    E.test_emul_damaged_transparent_files_fail_alone(api)

@@ -45,8 +45,10 @@ agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimize=True, png
 agree(api.cs_batch_compress(blobs, pkg.default_parameters(png_optimization_level=1, png_quality=20)), lambda b: _util.oracle_png_lossy(b, 1, quality=20))
 import test_webp_decode_emul as WD
 WD.test_emul_synthetic_files_decode_like_libwebp(api); WD.test_emul_lossless_files_decode_like_libwebp(api); WD.test_emul_damaged_lossless_streams_fail_alone(api); WD.test_emul_damaged_and_unsupported_inputs_fail_alone(api)
+WD.test_emul_transparent_files_decode_like_libwebp(api); WD.test_emul_damaged_transparent_files_fail_alone(api); WD.test_emul_transparent_sources_keep_their_alpha(api)
 import test_webp_lossless_emul as WL
-WL.test_emul_lossless_webp_round_trips_through_libwebp(api, '$R/tests/golden/reference_samples'); WL.test_emul_jpeg_to_lossless_webp_and_resize(api); WL.test_emul_lossless_webp_failures_stay_per_file(api)
+WL.test_emul_lossless_webp_round_trips_through_libwebp(api, '$R/tests/golden/reference_samples'); WL.test_emul_jpeg_to_lossless_webp_and_resize(api); WL.test_emul_lossless_webp_failures_stay_per_file(api); WL.test_emul_png_to_lossless_webp(api)
+PW.test_transparency_becomes_an_alph_chunk(api)
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
