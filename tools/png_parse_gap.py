@@ -1,6 +1,6 @@
 """How far the device's DEFLATE parse is from libdeflate's (what oxipng -o3 links, level 11 / 12): the IDAT stream of this repo's -o3 output (the oracle's
 bytes = the device's) is inflated and packed again by the system libdeflate at levels 6, 9, 11, 12 and by zlib 6 / 9 -- same filtered bytes, so only the
-parse differs.  `python tools/png_parse_gap.py [width height]`"""
+parse differs.  `python tools/png_parse_gap.py [width height] [--zopfli]`"""
 import ctypes as C
 import ctypes.util
 import io
@@ -40,7 +40,8 @@ def idat(png):
     return out
 
 
-w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720)
+nums = [a for a in sys.argv[1:] if a.isdigit()]
+w, h = (int(nums[0]), int(nums[1])) if len(nums) > 1 else (1280, 720)
 for k, (mode, tex) in enumerate([("RGB", 3.0), ("RGB", 0.5), ("RGBA", 3.0), ("L", 3.0)]):
     src = synth_png(40 + k, w, h, mode, texture=tex)
     out, _ = O.png_optimize(src, 3)
@@ -49,4 +50,12 @@ for k, (mode, tex) in enumerate([("RGB", 3.0), ("RGB", 0.5), ("RGBA", 3.0), ("L"
     line = ["%s tex %.1f: in %d out %d | idat %d" % (mode, tex, len(src), len(out), len(z))]
     line.append("zlib6 %.3f zlib9 %.3f" % (len(zlib.compress(raw, 6)) / len(z), len(zlib.compress(raw, 9)) / len(z)))
     line.append(" ".join("ld%d %.3f" % (lv, libdeflate(raw, lv) / len(z)) for lv in (6, 9, 11, 12)))
+    zopfli = next((c for c in ("/opt/conda/bin/zopfli", "/usr/bin/zopfli") if os.path.exists(c)), None)
+    if zopfli and "--zopfli" in sys.argv:   # what --zopfli (refused by this build) would have bought: slow, so only on request
+        import subprocess
+        import tempfile
+        f = os.path.join(tempfile.mkdtemp(), "raw.bin")
+        open(f, "wb").write(raw)
+        subprocess.run([zopfli, "--zlib", "--i15", f], check=True)
+        line.append("zopfli-i15 %.3f" % (os.path.getsize(f + ".zlib") / len(z)))
     print(" | ".join(line))
