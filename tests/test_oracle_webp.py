@@ -241,3 +241,16 @@ def test_bytes_and_fidelity_against_libwebp_at_the_same_quantiser():
         assert frame_quantiser_index(ours) == frame_quantiser_index(lib4)
         assert len(ours) <= 1.04 * len(lib4) and psnr(ours) >= psnr(lib4) - 0.6, (q, len(ours), len(lib4), psnr(ours), psnr(lib4))
         assert len(ours) < 0.9 * len(lib0), (q, len(ours), len(lib0))
+
+
+def test_random_sizes_and_qualities_reconstruct_like_libwebp():
+    """forty random pictures (1 .. 70 pixels a side, any quality, flat to very noisy): every combination of frame-edge rule, sub-block mode and macroblock
+    type the encoder can reach must leave exactly the picture libwebp's decoder makes of the stream"""
+    rng = np.random.default_rng(2024)
+    for k in range(40):
+        w, h, q = int(rng.integers(1, 71)), int(rng.integers(1, 71)), int(rng.integers(0, 101))
+        rgb = crop(100 + k, w, h, texture=float(rng.choice([0.0, 1.0, 4.0, 12.0, 40.0])))
+        y, u, v = O.webp_rgb_to_yuv(rgb)
+        data, (ry, ru, rv) = O.webp_encode_yuv(y, u, v, w, h, O.webp_quality_to_qi(q))
+        Y, U, V = libwebp_decode_yuv(data)
+        assert np.array_equal(Y, ry[:h, :w]) and np.array_equal(U, ru[:(h + 1) // 2, :(w + 1) // 2]) and np.array_equal(V, rv[:(h + 1) // 2, :(w + 1) // 2]), (k, w, h, q)
