@@ -468,6 +468,10 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             if (lane != 0) continue;
             uint32_t total = 0;
             const int nslot = ch.kind == 1 ? 1 : int(P.nslot);
+            if (c.stats_only) {   // the trellis stage's statistics scans: nothing is written to the pool (phase 4 runs dry)
+                for (int slot = 0; slot < nslot; slot++) s_wbase[wv][slot] = 0ull;
+                continue;
+            }
             for (int slot = 0; slot < nslot; slot++) total += s_wtot[wv][slot];
             const TokRegion rg = c.regions[ch.region];
             uint32_t rel;
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             // ---------------------------------------------------------------- tokens + histograms
             if (s_wbase[wv][0] == ~0ull) continue;
             if (c.debug & 1u) continue;
-            TokOut out; out.pool = c.tokens; out.dry = (c.debug & 4u) != 0;
+            TokOut out; out.pool = c.tokens; out.dry = (c.debug & 4u) != 0 || c.stats_only != 0;
             if (ch.kind == 1) {
                 const ScanWork &w = s_w;
                 const EncScan &sc = s_sc;

@@ -13,6 +13,7 @@
 // access, so a tile moves in 8 vector loads / 8 vector stores per lane; planes are written/read in row segments
 // contiguous across the wave's adjacent blocks.  No LDS, no cross-lane traffic: the 2-D transforms never leave
 // the lane's registers, so zig-zag <-> natural reordering is free (compile-time register naming).
+#include <cmath>
 #include <utility>
 
 #include "kernels.h"
@@ -163,14 +164,84 @@ template <int... J>
 __device__ __forceinline__ static void raw_store_all(const int x[64], int16_t *__restrict__ raw, std::integer_sequence<int, J...>) {
     (raw_store_octet<J>(x, raw), ...);
 }
-__device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw = nullptr) {
+// mozjpeg's overshoot deringing (jcdctmgr.c preprocess_deringing + catmull_rom; on in the JCP_MAX_COMPRESSION profile libcaesium's -q runs,
+// /root/reference/src/compressor.rs:415,427; [UPSTREAM-RECALL], the statement checked against: oracle/jpeg_oracle.c cso_dering_block).
+// On the level-shifted samples, walked in zig-zag order as one line: every run of samples at the top of the range (>= 127) becomes a
+// Catmull-Rom arc through the slopes either side of it, overshooting by at most min(31, 2 * DC quantiser, the block's headroom).
+// Few blocks have such samples (and not all 64 of them): a wave whose lanes have none pays the count only; otherwise the lanes that
+// need it put their block into a column of LDS and walk it there (the walk indexes the samples with run-time positions, which
+// registers cannot), the others wait.  float arithmetic in the C source's order; the steps 1 / (length + 1) come from a table so that
+// no device division is involved.
+#define CSH_DERING_LDS int16_t (*dr_col)[256]
+__device__ static const uint8_t kZ2Nrt[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+__device__ static const float kDeringStep[65] = {
+    0.f, 1.f / 1.f, 1.f / 2.f, 1.f / 3.f, 1.f / 4.f, 1.f / 5.f, 1.f / 6.f, 1.f / 7.f, 1.f / 8.f, 1.f / 9.f, 1.f / 10.f, 1.f / 11.f, 1.f / 12.f, 1.f / 13.f, 1.f / 14.f,
+    1.f / 15.f, 1.f / 16.f, 1.f / 17.f, 1.f / 18.f, 1.f / 19.f, 1.f / 20.f, 1.f / 21.f, 1.f / 22.f, 1.f / 23.f, 1.f / 24.f, 1.f / 25.f, 1.f / 26.f, 1.f / 27.f, 1.f / 28.f,
+    1.f / 29.f, 1.f / 30.f, 1.f / 31.f, 1.f / 32.f, 1.f / 33.f, 1.f / 34.f, 1.f / 35.f, 1.f / 36.f, 1.f / 37.f, 1.f / 38.f, 1.f / 39.f, 1.f / 40.f, 1.f / 41.f, 1.f / 42.f,
+    1.f / 43.f, 1.f / 44.f, 1.f / 45.f, 1.f / 46.f, 1.f / 47.f, 1.f / 48.f, 1.f / 49.f, 1.f / 50.f, 1.f / 51.f, 1.f / 52.f, 1.f / 53.f, 1.f / 54.f, 1.f / 55.f, 1.f / 56.f,
+    1.f / 57.f, 1.f / 58.f, 1.f / 59.f, 1.f / 60.f, 1.f / 61.f, 1.f / 62.f, 1.f / 63.f, 1.f / 64.f};
+__device__ static float dering_catmull_rom(int value1, int value2, int value3, int value4, float t, int size) {
+    const int tan1 = (value3 - value1) * size, tan2 = (value4 - value2) * size;
+    const float t2 = t * t, t3 = t2 * t;
+    const float f1 = 2.f * t3 - 3.f * t2 + 1.f, f2 = -2.f * t3 + 3.f * t2, f3 = t3 - 2.f * t2 + t, f4 = t3 - t2;
+    return float(value2) * f1 + float(tan1) * f3 + float(value3) * f2 + float(tan2) * f4;
+}
+__device__ static void dering_walk(int16_t *col /* sample n (natural order) at col[n * 256] */, int dc_quant, int cnt, int sum) {
+    const int maxsample = 127, size = 64;
+    const int over = 2 * dc_quant < 31 ? 2 * dc_quant : 31, room = (maxsample * size - sum) / cnt;
+    const int maxovershoot = maxsample + (over < room ? over : room);
+    auto at = [&](int n) -> int16_t & { return col[int(kZ2Nrt[n]) * 256]; };
+    int n = 0;
+    do {
+        if (at(n) < maxsample) { n++; continue; }
+        const int start = n;
+        while (++n < size && at(n) >= maxsample) {}
+        const int end = n;
+        const float f1 = float(at(start >= 1 ? start - 1 : 0)), f2 = float(at(start >= 2 ? start - 2 : 0));
+        const float l1 = float(at(end < size - 1 ? end : size - 1)), l2 = float(at(end < size - 2 ? end + 1 : size - 1));
+        float fslope = f1 - f2 > float(maxsample) - f1 ? f1 - f2 : float(maxsample) - f1;
+        float lslope = l1 - l2 > float(maxsample) - l1 ? l1 - l2 : float(maxsample) - l1;
+        if (start == 0) fslope = lslope;
+        if (end == size) lslope = fslope;
+        const int length = end - start;
+        const float step = kDeringStep[length + 1];
+        float position = step;
+        for (int i = start; i < end; i++, position += step) {
+            const int tmp = int(ceilf(dering_catmull_rom(int(float(maxsample) - fslope), maxsample, maxsample, int(float(maxsample) - lslope), position, length)));
+            at(i) = int16_t(tmp < maxovershoot ? tmp : maxovershoot);
+        }
+        n++;
+    } while (n < size);
+}
+__device__ __forceinline__ static void dering_block(int x[64] /* level-shifted, natural order */, int dc_quant, CSH_DERING_LDS) {
+    int cnt = 0, sum = 0;
+    CSH_UNROLL
+    for (int i = 0; i < 64; i++) { sum += x[i]; cnt += x[i] >= 127 ? 1 : 0; }
+    const bool need = cnt != 0 && cnt != 64;
+#ifdef CSH_EMUL
+    if (!need) return;
+#else
+    if (!__ballot(need)) return;
+#endif
+    int16_t *col = &dr_col[0][threadIdx.x];
+    if (need) {
+        CSH_UNROLL
+        for (int i = 0; i < 64; i++) col[i * 256] = int16_t(x[i]);
+        dering_walk(col, dc_quant, cnt, sum);
+        CSH_UNROLL
+        for (int i = 0; i < 64; i++) x[i] = col[i * 256];
+    }
+}
+template <bool DERING>
+__device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw, CSH_DERING_LDS) {
     CSH_SCHED_FENCE();
     CSH_UNROLL
-    for (int r = 0; r < 8; r++) {
-        CSH_UNROLL
-        for (int c = 0; c < 8; c++) x[8 * r + c] -= 128;
-        fdct1d<true>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
-    }
+    for (int i = 0; i < 64; i++) x[i] -= 128;
+    if (DERING) { dering_block(x, int(q.q[0]), dr_col); CSH_SCHED_FENCE(); }
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++) fdct1d<true>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
     CSH_SCHED_FENCE();
     CSH_UNROLL
     for (int c = 0; c < 8; c++) fdct1d<false>(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
@@ -200,8 +271,10 @@ __device__ __forceinline__ static void store_zero_block(int16_t *__restrict__ bl
 
 // ------------------------------------------------------------------------------------------------
 // mode 0: full-resolution component, IDCT -> (crop + edge expand) -> FDCT -> quantise
+template <bool DERING>
 __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant,
                                                        const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    CSH_SHARED int16_t s_dr[DERING ? 64 : 1][256];
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 0) return;
     const ImgDesc &im = imgs[w.image];
@@ -217,7 +290,7 @@ __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const
     load_idct(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
     int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
     if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
-    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
+    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
 }
 
 // mode 1 producer: subsampled component, IDCT -> u8 plane (pitch real_bw*8, rows real_bh*8, edges replicated)
@@ -401,8 +474,10 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
 }
 
 // encoder-side plane -> FDCT -> quantise, one block per lane
+template <bool DERING>
 __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *oplanes,
                                                      int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    CSH_SHARED int16_t s_dr[DERING ? 64 : 1][256];
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0 || w.mode == 10) return;
     const ImgDesc &im = imgs[w.image];
@@ -423,7 +498,7 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
         CSH_UNROLL
         for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
     }
-    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
+    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
 }
 
 // The camera case in one pass: 4:2:0 in, 4:2:0 out, no resize (PlaneWork.mode 10).  One lane per OUTPUT block: a 10 x 10 window of
@@ -433,8 +508,10 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
 //            loaded from plane row y-1 instead; output rows below the last one replicate it;
 //   columns: full-resolution columns beyond W-1 replicate column W-1 -- the per-column sums are patched in the block that
 //            holds plane column (W-1)/2 (always the last block column).
+template <bool DERING>
 __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *planes,
                                                             int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+    CSH_SHARED int16_t s_dr[DERING ? 64 : 1][256];
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 10) return;
     const ImgDesc &im = imgs[w.image];
@@ -514,7 +591,7 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, 
                 for (int cc = 0; cc < 8; cc++) x[8 * r + cc] = x[8 * (r - 1) + cc];
             }
     }
-    fdct_quant_store(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr);
+    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
 }
 
 // size-targeting: re-quantise every retained DCT block with the image's CURRENT output table (one block per lane)
@@ -558,8 +635,10 @@ __global__ void k_fix_dummy(const ImgDesc *imgs, int nimg, int16_t *coef_out) {
 static dim3 tile_grid(int max_tiles, int nwork) { return dim3((max_tiles + 3) / 4, nwork); }
 
 void launch_xform_direct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                         const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
-    if (nwork) CSH_LAUNCH(k_xform_direct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, coef_in, coef_out, dct_raw, raw_tile0);
+                         const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0, bool dering) {
+    if (!nwork) return;
+    if (dering) CSH_LAUNCH(k_xform_direct<true>, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, coef_in, coef_out, dct_raw, raw_tile0);
+    else CSH_LAUNCH(k_xform_direct<false>, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, coef_in, coef_out, dct_raw, raw_tile0);
 }
 void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
                        const int16_t *coef_in, uint8_t *planes) {
@@ -569,12 +648,16 @@ void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork 
     if (nwork && max_quads) CSH_LAUNCH(k_resample_plane, dim3((max_quads + 255) / 256, nwork), dim3(256), st, imgs, work, planes, oplanes);
 }
 void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                       const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
-    if (nwork) CSH_LAUNCH(k_plane_fdct, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out, dct_raw, raw_tile0);
+                       const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0, bool dering) {
+    if (!nwork) return;
+    if (dering) CSH_LAUNCH(k_plane_fdct<true>, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out, dct_raw, raw_tile0);
+    else CSH_LAUNCH(k_plane_fdct<false>, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, oplanes, coef_out, dct_raw, raw_tile0);
 }
 void launch_resample_fdct_420(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                              const uint8_t *planes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
-    if (nwork) CSH_LAUNCH(k_resample_fdct_420, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, planes, coef_out, dct_raw, raw_tile0);
+                              const uint8_t *planes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0, bool dering) {
+    if (!nwork) return;
+    if (dering) CSH_LAUNCH(k_resample_fdct_420<true>, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, planes, coef_out, dct_raw, raw_tile0);
+    else CSH_LAUNCH(k_resample_fdct_420<false>, tile_grid(max_tiles, nwork), dim3(256), st, imgs, work, quant, planes, coef_out, dct_raw, raw_tile0);
 }
 void launch_requant(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant, const int16_t *dct_raw,
                     uint32_t raw_tile0, int16_t *coef_out) {

@@ -1,0 +1,342 @@
+// k_trellis.hip -- mozjpeg's trellis quantiser on the device (CSH_PROFILE=mozjpeg).
+//
+// Replaces mozjpeg's jcdctmgr.c quantize_trellis as jccoefct.c compress_trellis_pass drives it for libcaesium's `-q N` path
+// (reference call sites /root/reference/src/compressor.rs:415,427 -> libcaesium 0.20.3 -> mozjpeg-sys 2.2.1,
+// /root/reference/Cargo.lock:1035-1044; the source is not under /root/reference -- the statement these kernels are checked against,
+// bit for bit, is oracle/jpeg_oracle.c quantize_trellis_row, [UPSTREAM-RECALL], parity with the real crate UNPINNED).
+//
+// Per component: a statistics scan over the scalar-quantised coefficients (k_tokens in its stats-only form + k_ac_runs + k_gen_tables)
+// has left the optimal AC table's code lengths; then
+//   k_trellis_ac   lane = block.  The block's unquantised DCT (retained by the pixel kernels) is swept once, in zig-zag order, in
+//                  registers: lambda from the block's AC energy, the running sum Z of "distortion if dropped", and one LIST ENTRY per
+//                  coefficient whose scalar level is not zero (the only positions the dynamic programme can keep).  The programme then
+//                  runs over list entries, not positions: step t gives entry t its cheapest (predecessor entry, candidate level) --
+//                  the t-th entry has exactly t + 1 possible predecessors whatever the block, so the inner loop bound is the same for
+//                  all 64 lanes of a wave and only the candidate count (1 + log2 level) differs.  Lists live in LDS, entry-major
+//                  ([entry][lane]: every access of a step is one conflict-free row); entries past CSH_TR_CAP spill to a per-workgroup
+//                  stretch of HBM (dense blocks: high qualities).  Then the cheapest last coefficient, the path back, the block.
+//   k_trellis_dc   lane = one iMCU row of a component: the Viterbi path over up to 9 DC levels per block along each row of blocks
+//                  (81 transitions per block, all in registers), back-pointers in a side array, the path written back.
+// All cost arithmetic is float in mozjpeg's order of operations (no contraction: the Makefile passes -ffp-contract=off); lambda is
+// double arithmetic rounded once, as in the C source.  No MFMA: the programme is a data-dependent minimisation, not a contraction.
+#include <utility>
+
+#include "kernels.h"
+
+namespace csh {
+
+#define CSH_TR_CAP 16                      // list entries per block that live in LDS (48 KiB per workgroup of 256 blocks)
+#define CSH_TR_SPILL (63 - CSH_TR_CAP)     // the rest, in HBM
+#define CSH_TR_MAXWG 2048                  // workgroups of the AC kernel (each loops over its share of the chunks)
+size_t trellis_spill_words() { return size_t(CSH_TR_MAXWG) * CSH_TR_SPILL * 3u * 256u; }
+
+#ifdef CSH_EMUL
+#define CSH_ANY(p) (p)                     // a lane cannot see the others there: its own loop bounds
+#else
+#define CSH_ANY(p) (__ballot(p) != 0ull)   // wave-uniform loop conditions
+#endif
+
+using Oct8 = std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>;
+// natural index -> zig-zag index (the energy sum runs in natural order, as the C source's loop over the JBLOCK does)
+static constexpr uint8_t kN2Z[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                                     41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                                     46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+template <int I>
+__device__ __forceinline__ static int tr_half(const uint4 &v) {
+    uint32_t w = (I / 2 == 0) ? v.x : (I / 2 == 1) ? v.y : (I / 2 == 2) ? v.z : v.w;
+    return (I & 1) ? (int(w) >> 16) : (int(w << 16) >> 16);
+}
+template <int J, int... I>
+__device__ __forceinline__ static void tr_unpack(int r[64], const uint4 &v, std::integer_sequence<int, I...>) { ((r[8 * J + I] = tr_half<I>(v)), ...); }
+template <int... J>
+__device__ __forceinline__ static void tr_load(const int16_t *__restrict__ blk, int r[64], std::integer_sequence<int, J...>) {   // zig-zag order
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_OCT_STRIDE * J)...};
+    (tr_unpack<J>(r, v[J], Oct8()), ...);
+}
+// exact (x + d / 2) / d for 0 <= x < 2^16, d = 8 q: float estimate + one correction (the pixel kernels' quantiser)
+__device__ __forceinline__ static int tr_level(int x, int d, float rcp) {
+    const int a = x + (d >> 1);
+    int qv = int(float(a) * rcp);
+    const int rem = a - qv * d;
+    qv += (rem >= d) ? 1 : 0;
+    qv -= (rem < 0) ? 1 : 0;
+    return qv;
+}
+__device__ __forceinline__ static int tr_bitlen(unsigned v) { return 32 - __clz(v); }
+__device__ __forceinline__ static float tr_bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+__device__ __forceinline__ static uint32_t tr_f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+#define TRELLIS_LAMBDA_C1 0x1.ae89f995ad3adp+14   // pow(2.0, lambda_log_scale1 = 14.75)
+#define TRELLIS_LAMBDA_C2 0x1.6a09e667f3bcdp+16   // pow(2.0, lambda_log_scale2 = 16.5)
+#define TRELLIS_MAX_LEVEL 1023                    // (1 << MAX_COEF_BITS) - 1
+
+struct TrLds {
+    float (*A)[256];      // [entry][lane]: cost of the cheapest path that ends with this entry
+    float (*Z)[256];      // before the entry's step: Z just in front of its position; after it: Z at its position
+    uint32_t (*P)[256];   // before: |DCT| (15) | position << 15 (6) | scalar level << 21 (10) | sign << 31;  after: predecessor entry + 1 (6) | position << 15 | chosen level << 21 | sign << 31
+    const uint8_t *len;   // AC code lengths of the statistics pass (0 = symbol unused)
+    const int32_t *q8;    // 8 q, zig-zag order
+    const float *lt;      // 1 / q^2
+};
+
+// tables of the chunk's component -> LDS (all 256 lanes)
+__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, uint8_t *s_len, int32_t *s_q8, float *s_lt) {
+    const TrellisWork &w = c.work[c.chunks[chi].work];
+    const ImgDesc &im = c.imgs[w.image];
+    const DevQuant &Q = c.quant[im.qt_out[w.comp]];
+    const int tid = int(threadIdx.x);
+    s_len[tid] = c.tables[w.table_ac].size[tid];
+    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_lt[tid] = Q.lt[tid]; }
+}
+
+__device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32_t chi, uint32_t wg_slot, const TrLds &L) {
+    const TrellisChunk ch = c.chunks[chi];
+    const TrellisWork &w = c.work[ch.work];
+    const ImgDesc &im = c.imgs[w.image];
+    const CompGeom g = im.out[w.comp];
+    const DevQuant &Q = c.quant[im.qt_out[w.comp]];
+    const int tid = int(threadIdx.x);
+    const uint32_t u = ch.j * 256u + uint32_t(tid);
+    if (u >= w.nunits) return;
+    const int by = int(u) / g.real_bw, b = by * g.bw + (int(u) - by * g.real_bw);
+    uint32_t *sp = c.spill + size_t(wg_slot) * (CSH_TR_SPILL * 3u * 256u) + uint32_t(tid);   // entry e >= CAP: sp[((e - CAP) * 3 + {0 A, 1 Z, 2 P}) * 256]
+
+    int r[64];
+    tr_load(c.raw + coef_index(g.tile_base - c.raw_tile0, b, 0), r, Oct8());
+    CSH_SCHED_FENCE();
+    // lambda: the block's mean squared AC value (float accumulation in natural order), two roundings from double as in the C source
+    float norm = 0.0f;
+    CSH_UNROLL
+    for (int n = 1; n < 64; n++) { const int v = r[kN2Z[n]]; norm = norm + float(v * v); }
+    norm = float(double(norm) / 63.0);
+    const float lambda = float(TRELLIS_LAMBDA_C1 / (TRELLIS_LAMBDA_C2 + double(norm)));
+    c.lambda[w.unit_base + u] = lambda;
+    CSH_SCHED_FENCE();
+
+    // ---- sweep: Z, the list of positions whose scalar level is not zero
+    uint32_t ne = 0;
+    float Zrun = 0.0f;
+    CSH_UNROLL
+    for (int k = 1; k < 64; k++) {
+        const int v = r[k], x = v < 0 ? -v : v;
+        int qv = tr_level(x, Q.div[k], Q.rcp[k]);
+        qv = qv > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : qv;
+        if (qv) {
+            const uint32_t P = uint32_t(x) | (uint32_t(k) << 15) | (uint32_t(qv) << 21) | (v < 0 ? 0x80000000u : 0u);
+            if (ne < CSH_TR_CAP) { L.Z[ne][tid] = Zrun; L.P[ne][tid] = P; }
+            else { sp[((ne - CSH_TR_CAP) * 3u + 1u) * 256u] = tr_f_bits(Zrun); sp[((ne - CSH_TR_CAP) * 3u + 2u) * 256u] = P; }
+            ne++;
+        }
+        Zrun = (float(x * x) * lambda) * Q.lt[k] + Zrun;
+    }
+    const float Z63 = Zrun;
+    const int dc_level = tr_level(r[0] < 0 ? -r[0] : r[0], Q.div[0], Q.rcp[0]);   // scalar DC: k_trellis_dc replaces it
+    const int dc_signed = r[0] < 0 ? -dc_level : dc_level;
+    CSH_SCHED_FENCE();
+
+    // ---- the programme over list entries
+    const int lenZRL = L.len[0xF0], lenEOB = L.len[0x00];
+    for (uint32_t t = 0; CSH_ANY(t < ne); t++) {
+        const bool on = t < ne;
+        float Zp; uint32_t P;
+        if (t < CSH_TR_CAP) { Zp = L.Z[t][tid]; P = L.P[t][tid]; }
+        else { Zp = tr_bits_f(sp[((t - CSH_TR_CAP) * 3u + 1u) * 256u]); P = sp[((t - CSH_TR_CAP) * 3u + 2u) * 256u]; }
+        if (!on) { Zp = 0.0f; P = 0u; }
+        const int x = int(P & 0x7FFFu), kpos = int((P >> 15) & 63u), qval = int((P >> 21) & 1023u);
+        const int q8 = L.q8[kpos];
+        const float ltk = L.lt[kpos];
+        const int ncand = on ? tr_bitlen(unsigned(qval)) : 0;
+        float dist[10];
+        CSH_UNROLL
+        for (int kc = 0; kc < 10; kc++) {
+            if (!CSH_ANY(kc < ncand)) break;
+            const int cand = kc < ncand - 1 ? (2 << kc) - 1 : qval;
+            const int delta = cand * q8 - x;
+            dist[kc] = (float(delta * delta) * lambda) * ltk;
+        }
+        float bestc = 1e38f;
+        uint32_t bestsel = 0;   // (predecessor entry + 1) << 4 | candidate
+        for (int jj = -1; jj < int(t); jj++) {
+            float Aj = 0.0f, Zj = 0.0f;
+            int posj = 0;
+            if (jj >= 0) {
+                if (jj < CSH_TR_CAP) { Aj = L.A[jj][tid]; Zj = L.Z[jj][tid]; posj = int((L.P[jj][tid] >> 15) & 63u); }
+                else { const uint32_t *q = sp + (uint32_t(jj - CSH_TR_CAP) * 3u) * 256u; Aj = tr_bits_f(q[0]); Zj = tr_bits_f(q[256]); posj = int((q[512] >> 15) & 63u); }
+            }
+            const int zr = kpos - 1 - posj;
+            const bool okrun = on && !((zr >> 4) != 0 && lenZRL == 0);
+            const int run_bits = (zr >> 4) * lenZRL;
+            const int base = 16 * (zr & 15) + 1;
+            const float tj = (Zp - Zj) + Aj;
+            CSH_UNROLL
+            for (int kc = 0; kc < 10; kc++) {
+                if (!CSH_ANY(kc < ncand)) break;
+                const int cb = on ? int(L.len[base + kc]) : 0;
+                const float cost = (float(cb + (kc + 1) + run_bits) + dist[kc]) + tj;
+                const bool better = okrun && kc < ncand && cb != 0 && cost < bestc;
+                bestc = better ? cost : bestc;
+                bestsel = better ? ((uint32_t(jj + 1) << 4) | uint32_t(kc)) : bestsel;
+            }
+        }
+        if (on) {
+            const int bk = int(bestsel & 15u);
+            const uint32_t level = uint32_t(bk < ncand - 1 ? (2 << bk) - 1 : qval);
+            const float Zi = (float(x * x) * lambda) * ltk + Zp;
+            const uint32_t P2 = (bestsel >> 4) | (uint32_t(kpos) << 15) | (level << 21) | (P & 0x80000000u);
+            if (t < CSH_TR_CAP) { L.A[t][tid] = bestc; L.Z[t][tid] = Zi; L.P[t][tid] = P2; }
+            else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * 256u; q[0] = tr_f_bits(bestc); q[256] = tr_f_bits(Zi); q[512] = P2; }
+        }
+    }
+
+    // ---- the cheapest last coefficient
+    float best = Z63 + float(lenEOB);
+    int last = -1;
+    for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
+        float Ae, Ze; uint32_t Pe;
+        if (e < CSH_TR_CAP) { Ae = L.A[e][tid]; Ze = L.Z[e][tid]; Pe = L.P[e][tid]; }
+        else { const uint32_t *q = sp + ((e - CSH_TR_CAP) * 3u) * 256u; Ae = tr_bits_f(q[0]); Ze = tr_bits_f(q[256]); Pe = q[512]; }
+        float cost = (Ae + Z63) - Ze;
+        if (int((Pe >> 15) & 63u) < 63) cost = cost + float(lenEOB);
+        if (e < ne && cost < best) { best = cost; last = int(e); }
+    }
+
+    // ---- the block: zeros, the scalar DC, the levels on the path back from the last coefficient
+    int16_t *dst = c.coef + coef_index(g.tile_base, b, 0);
+    {
+        uint4 z; z.x = z.y = z.z = z.w = 0;
+        CSH_UNROLL
+        for (int j = 0; j < 8; j++) *reinterpret_cast<uint4 *>(dst + CSH_OCT_STRIDE * j) = z;
+    }
+    dst[0] = int16_t(dc_signed);
+    for (int e = last; CSH_ANY(e >= 0);) {
+        if (e >= 0) {
+            const uint32_t Pe = e < CSH_TR_CAP ? L.P[e][tid] : sp[(uint32_t(e - CSH_TR_CAP) * 3u + 2u) * 256u];
+            const int pos = int((Pe >> 15) & 63u), level = int((Pe >> 21) & 1023u);
+            dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
+            e = int(Pe & 63u) - 1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_trellis_ac(TrellisCtx c) {
+    CSH_SHARED float s_A[CSH_TR_CAP][256];
+    CSH_SHARED float s_Z[CSH_TR_CAP][256];
+    CSH_SHARED uint32_t s_P[CSH_TR_CAP][256];
+    CSH_SHARED uint8_t s_len[256];
+    CSH_SHARED int32_t s_q8[64];
+    CSH_SHARED float s_lt[64];
+    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.len = s_len; L.q8 = s_q8; L.lt = s_lt;
+#ifdef CSH_EMUL
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) { trellis_stage(c, blockIdx.x, s_len, s_q8, s_lt); continue; }
+        trellis_block(c, blockIdx.x, 0u, L);
+    }
+#else
+    for (uint32_t chi = blockIdx.x; chi < c.nchunks; chi += gridDim.x) {
+        trellis_stage(c, chi, s_len, s_q8, s_lt);
+        __syncthreads();
+        trellis_block(c, chi, blockIdx.x, L);
+        __syncthreads();
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ DC
+// T.81 Tables K.3 / K.4 code lengths (what jpeg_set_defaults installs): in progressive mode no DC statistics exist when the trellis
+// passes run, so the DC path is priced with these
+__device__ static const uint8_t kStdDcLen[2][12] = {{2, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9}, {2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}};
+
+__global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
+    const TrellisWork w = c.work[blockIdx.y];
+    const ImgDesc &im = c.imgs[w.image];
+    const CompGeom g = im.out[w.comp];
+    const DevQuant &Q = c.quant[im.qt_out[w.comp]];
+    const int row = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (row >= (g.real_bh + g.v - 1) / g.v) return;
+    int ncand = (2 + 60 / int(Q.q[0])) | 1;
+    ncand = ncand > 9 ? 9 : ncand;
+    uint64_t lens = 0;   // code length of difference category 0..11, 5 bits each
+    for (int i = 0; i < 12; i++) lens |= uint64_t(w.table_dc < 0 ? kStdDcLen[w.comp ? 1 : 0][i] : c.tables[w.table_dc].size[i]) << (5 * i);
+    const int q = Q.div[0];
+    const float rcp = Q.rcp[0], lt0 = Q.lt[0];
+    const int half = ncand / 2;
+    int last_dc = 0;   // compress_trellis_pass: 0 at the start of every iMCU row, then the last DC of the row before
+    const int by1 = (row + 1) * g.v < g.real_bh ? (row + 1) * g.v : g.real_bh;
+    for (int by = row * g.v; by < by1; by++) {
+        float acc[9];
+        int cprev[9];
+        CSH_UNROLL
+        for (int k = 0; k < 9; k++) { acc[k] = 0.0f; cprev[k] = 0; }
+        for (int bi = 0; bi < g.real_bw; bi++) {
+            const uint32_t u = uint32_t(by * g.real_bw + bi);
+            const int raw0 = c.raw[coef_index(g.tile_base - c.raw_tile0, by * g.bw + bi, 0)];
+            const float lambda_dc = c.lambda[w.unit_base + u] * lt0;
+            const int x = raw0 < 0 ? -raw0 : raw0;
+            const int qval = tr_level(x, q, rcp);
+            uint64_t bt = 0;
+            float nacc[9];
+            int ccur[9];
+            CSH_UNROLL
+            for (int k = 0; k < 9; k++) {
+                nacc[k] = 0.0f; ccur[k] = 0;
+                if (k < ncand) {
+                    int cand = qval - half + k;
+                    cand = cand > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : cand;
+                    cand = cand < -TRELLIS_MAX_LEVEL ? -TRELLIS_MAX_LEVEL : cand;
+                    const int delta = cand * q - x;
+                    const float dist = float(delta * delta) * lambda_dc;
+                    cand = raw0 < 0 ? -cand : cand;
+                    ccur[k] = cand;
+                    if (bi == 0) {
+                        const int d = cand - last_dc, bits = tr_bitlen(unsigned(d < 0 ? -d : d));
+                        nacc[k] = float(bits + int((lens >> (5 * bits)) & 31u)) + dist;
+                    } else {
+                        float bc = 0.0f;
+                        uint32_t bl = 0;
+                        CSH_UNROLL
+                        for (int l = 0; l < 9; l++) {
+                            if (l < ncand) {
+                                const int d = cand - cprev[l], bits = tr_bitlen(unsigned(d < 0 ? -d : d));
+                                const float cost = (float(bits + int((lens >> (5 * bits)) & 31u)) + dist) + acc[l];
+                                if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
+                            }
+                        }
+                        nacc[k] = bc;
+                        bt |= uint64_t(bl) << (4 * k);
+                    }
+                }
+            }
+            CSH_UNROLL
+            for (int k = 0; k < 9; k++) { acc[k] = nacc[k]; cprev[k] = ccur[k]; }
+            c.dcbt[w.unit_base + u] = bt | (uint64_t(uint32_t(qval)) << 36) | (uint64_t(raw0 < 0 ? 1u : 0u) << 47);
+        }
+        float bv = acc[0];
+        uint32_t j = 0;
+        CSH_UNROLL
+        for (int i = 1; i < 9; i++) if (i < ncand && acc[i] < bv) { bv = acc[i]; j = uint32_t(i); }
+        for (int bi = g.real_bw - 1; bi >= 0; bi--) {
+            const uint64_t rec = c.dcbt[w.unit_base + uint32_t(by * g.real_bw + bi)];
+            int cand = int((rec >> 36) & 2047u) - half + int(j);
+            cand = cand > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : cand;
+            cand = cand < -TRELLIS_MAX_LEVEL ? -TRELLIS_MAX_LEVEL : cand;
+            cand = ((rec >> 47) & 1u) ? -cand : cand;
+            c.coef[coef_index(g.tile_base, by * g.bw + bi, 0)] = int16_t(cand);
+            if (bi == g.real_bw - 1) last_dc = cand;
+            j = uint32_t((rec >> (4 * j)) & 15u);
+        }
+    }
+}
+
+void launch_trellis_ac(hipStream_t st, const TrellisCtx &c) {
+    if (!c.nchunks) return;
+#ifdef CSH_EMUL
+    CSH_LAUNCH_PHASED(k_trellis_ac, 2, dim3(c.nchunks), dim3(256), st, c);
+#else
+    CSH_LAUNCH(k_trellis_ac, dim3(c.nchunks < CSH_TR_MAXWG ? c.nchunks : CSH_TR_MAXWG), dim3(256), st, c);
+#endif
+}
+void launch_trellis_dc(hipStream_t st, const TrellisCtx &c) {
+    if (c.nwork && c.max_rows) CSH_LAUNCH(k_trellis_dc, dim3((c.max_rows + 63) / 64, c.nwork), dim3(64), st, c);
+}
+
+}  // namespace csh

@@ -39,8 +39,9 @@ void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_
 // ---- phase 1: pixel-domain transcode (k_pixel.hip)
 // direct: dequant -> jidctint -> range limit -> jfdctint -> quantise, one block per lane
 // dct_raw != nullptr: also keep the unquantised DCT (tile index relative to raw_tile0) for launch_requant
+// dering: mozjpeg's overshoot deringing on the level-shifted samples in front of every forward DCT (CSH_PROFILE=mozjpeg)
 void launch_xform_direct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                         const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
+                         const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0, bool dering);
 void launch_requant(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant, const int16_t *dct_raw,
                     uint32_t raw_tile0, int16_t *coef_out);
 // subsampled components: IDCT to a u8 plane (edges replicated), then resample + FDCT + quantise
@@ -48,9 +49,9 @@ void launch_idct_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *wor
                        const int16_t *coef_in, uint8_t *planes);
 void launch_resample_plane(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, uint32_t max_quads, const uint8_t *planes, uint8_t *oplanes);
 void launch_plane_fdct(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                       const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
+                       const uint8_t *oplanes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0, bool dering);
 void launch_resample_fdct_420(hipStream_t st, const ImgDesc *imgs, const PlaneWork *work, int nwork, int max_tiles, const DevQuant *quant,
-                              const uint8_t *planes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0);
+                              const uint8_t *planes, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0, bool dering);
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
 
 // resize branch (k_resize.hip): decoded planes -> RGB -> Lanczos3 (f32, image-rs order) -> full-resolution YCbCr planes
@@ -94,6 +95,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint32_t *status;          // per image
     uint32_t *overflow;        // [4]: [1] = the token pool was too small
     uint32_t debug;            // CSH_DEBUG: performance experiments (parts of k_tokens switched off; output is then garbage)
+    uint32_t stats_only;       // the trellis stage's statistics scans: histograms, flags and EOB runs only -- no token is written
 };
 void launch_tokens(hipStream_t st, const EncCtx &c);
 void launch_ac_runs(hipStream_t st, const EncCtx &c);
@@ -101,6 +103,28 @@ void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables);
 void launch_chunk_sizes(hipStream_t st, const EncCtx &c);
 void launch_zero_edges(hipStream_t st, const EncCtx &c);   // between the scans' placement and the pack
 void launch_pack(hipStream_t st, const EncCtx &c);
+
+// ---- mozjpeg's trellis quantiser (k_trellis.hip): re-quantise every block from the retained DCT with the statistics pass's code
+// lengths as rates -- AC coefficients per block (k_trellis_ac), DC coefficients along each row of blocks (k_trellis_dc)
+struct TrellisCtx {
+    const ImgDesc *imgs;
+    const DevQuant *quant;
+    const TrellisWork *work;
+    int nwork;
+    const TrellisChunk *chunks;
+    uint32_t nchunks;
+    const DevEncTable *tables;
+    const int16_t *raw;        // unquantised jfdctint output, tiles (index relative to raw_tile0)
+    uint32_t raw_tile0;
+    int16_t *coef;             // re-quantised coefficients (tiles)
+    float *lambda;             // per real block: the block's lambda (AC kernel -> DC kernel)
+    uint64_t *dcbt;            // per real block: back-pointers of the DC path (9 x 4 bits) | rounded DC level << 36 | sign << 47
+    uint32_t *spill;           // per workgroup of the AC kernel: entries of the block lists that do not fit LDS
+    uint32_t max_rows;         // DC kernel: most iMCU rows of a component
+};
+void launch_trellis_ac(hipStream_t st, const TrellisCtx &c);
+void launch_trellis_dc(hipStream_t st, const TrellisCtx &c);
+size_t trellis_spill_words();   // size of TrellisCtx::spill in u32
 
 // generic device primitive: out[i] = sum_{j<i} in[j] for i in [0, n]  (n+1 outputs; in[] has n entries)
 void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, size_t tmp_bytes);

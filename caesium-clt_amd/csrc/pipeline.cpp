@@ -121,6 +121,13 @@ struct csh_batch {
     std::vector<SearchImg> simg;
     std::vector<uint32_t> img_list, img_nlist, h_cost;
     std::map<std::array<int, 5>, int> cand_script;   // (component, Ss, Se, Ah, Al) -> EncScan index
+    // mozjpeg's quantiser half (CSH_PROFILE=mozjpeg): overshoot deringing in front of every forward DCT; trellis quantisation behind it --
+    // a third stage of work items (one statistics scan per component, coded for its histogram only) and the two k_trellis kernels
+    bool trellis = false, dering = false;
+    Stage tstage;
+    std::vector<TrellisWork> twork;
+    std::vector<TrellisChunk> tchunks;
+    uint32_t t_units = 0, t_max_rows = 0;
     PinnedBytes bits_pool;
     std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
@@ -170,6 +177,11 @@ struct csh_batch {
     DevBuf<uint32_t> d_img_list, d_img_nlist, d_scan_cost, d_slot_raw, d_slot_eobh, d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
+    DevBuf<TrellisWork> d_twork;
+    DevBuf<TrellisChunk> d_tchunks;
+    DevBuf<float> d_tlambda;
+    DevBuf<uint64_t> d_tdcbt;
+    DevBuf<uint32_t> d_tspill;
 
     std::vector<uint32_t> h_img_size;
     std::vector<uint64_t> h_img_off;
@@ -242,6 +254,7 @@ static void make_quant(const uint16_t nat[64], DevQuant &q) {
         q.q[k] = nat[kZigZag[k]];
         q.div[k] = int32_t(q.q[k]) * 8;
         q.rcp[k] = 1.0f / float(q.div[k]);
+        q.lt[k] = float(1.0 / double(int(q.q[k]) * int(q.q[k])));   // mozjpeg quantize_trellis, mode 1: lambda_table[i] = 1.0 / (q * q)
     }
 }
 
@@ -427,7 +440,13 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     add_script(b->script, 3, false);  // entry 16
     add_script(b->script, 1, false);  // entry 17
     const int script_base3 = progressive ? 0 : 16, script_base1 = progressive ? 10 : 17;
-    b->search = progressive && !webp && !rgb_out && !(getenv("CSH_PROFILE") && !strcmp(getenv("CSH_PROFILE"), "plain"));
+    const char *profile = getenv("CSH_PROFILE");
+    b->search = progressive && !webp && !rgb_out && !(profile && !strcmp(profile, "plain"));
+    // CSH_PROFILE=mozjpeg: the whole JCP_MAX_COMPRESSION profile libcaesium's -q runs (scan search + trellis quantisation + overshoot
+    // deringing; UNPINNED); mozjpeg-trellis / mozjpeg-dering switch the two halves on separately (scan search kept)
+    const bool lossy_jpeg = !b->lossless && !webp && !rgb_out;
+    b->trellis = lossy_jpeg && profile && (!strcmp(profile, "mozjpeg") || !strcmp(profile, "mozjpeg-trellis"));
+    b->dering = lossy_jpeg && profile && (!strcmp(profile, "mozjpeg") || !strcmp(profile, "mozjpeg-dering"));
     // EncScan entries of the search's candidates, made on first use
     auto cand_index = [&](int comp, int Ss, int Se, int Ah, int Al) -> int {
         const std::array<int, 5> key = {comp, Ss, Se, Ah, Al};
@@ -460,7 +479,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         return b->cand_script[key] = int(b->script.size()) - 1;
     };
     // work items, slots, token chunks and plans of one image for a list of scans (EncScan indices), in list order
-    auto add_works = [&](Item &it, ImgDesc &im, int img_index, const std::vector<int> &list, size_t in_len, const JpegInfo &o) {
+    auto add_works = [&](Item &it, ImgDesc &im, int img_index, const std::vector<int> &list, size_t in_len, const JpegInfo &o, bool stats_only = false) {
         const int w_first = int(b->swork.size());
         for (int sidx : list) {
             const EncScan &e = b->script[sidx];
@@ -494,7 +513,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 for (int k = 0; k < e.ncomp; k++) blocks += e.ncomp > 1 ? uint32_t(o.comp[e.comp[k]].h * o.comp[e.comp[k]].v) : 1u;
                 const uint32_t per_unit = e.sequential ? blocks * 20u : (e.Ah ? (blocks + 14u) / 15u : blocks);
                 for (uint32_t j = 0; j < (w.nunits + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(b->swork.size()), 0, 1, j, 0, uint32_t(b->region_est.size())});
-                b->region_est.push_back(w.nunits * per_unit + 64);
+                b->region_est.push_back(stats_only ? 64u : w.nunits * per_unit + 64);
             }
             b->swork.push_back(w);
         }
@@ -523,7 +542,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             const uint64_t scripts = b->search ? uint64_t(nac + 1) / 2 : 1;
             const uint64_t est = uint64_t(in_len) * 3 * scripts * nu / std::max<uint64_t>(1, blocks_all) + uint64_t(nu) * nac + 1024;
             for (uint32_t j = 0; j < (nu + 255) / 256; j++) b->echunks.push_back(EChunk{uint32_t(img_index), uint16_t(c), 0, j, uint32_t(b->plans.size()), uint32_t(b->region_est.size())});
-            b->region_est.push_back(uint32_t(std::min<uint64_t>(est, 0x3FFFFFFFu)));
+            b->region_est.push_back(stats_only ? 64u : uint32_t(std::min<uint64_t>(est, 0x3FFFFFFFu)));
             b->plan_comp.push_back(c); b->plan_image.push_back(img_index);
             b->plans.push_back(P);
         }
@@ -946,6 +965,52 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         b->stage[1].nplans = uint32_t(b->plans.size()) - b->stage[1].plan0;
         if (b->total_units > 0xFFFFFFF0ull) { csh_set_error("csh_batch_create: batch too large for the scan search's candidate lists (fewer files per batch)"); return CS_ERR_POOL_OVERFLOW; }
     }
+    if (b->trellis) {
+        // the trellis stage: per component one statistics scan in the output mode's entropy coder -- progressive: the component alone,
+        // 1-63 at Al 0 (EOBRUN symbols included); sequential: a one-component sequential scan (DC and AC tables) -- coded for its
+        // histograms only (mozjpeg jcmaster.c: the huff_opt pass in front of every trellis pass; oracle: cso_trellis_tables)
+        { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
+        csh_batch::Stage &tg = b->tstage;
+        tg.work0 = uint32_t(b->swork.size()); tg.slot0 = uint32_t(b->slot_work.size()); tg.ech0 = uint32_t(b->echunks.size());
+        tg.table0 = uint32_t(b->ntables); tg.plan0 = uint32_t(b->plans.size());
+        auto seq1_index = [&](int comp) -> int {
+            const std::array<int, 5> key = {comp, 0, 63, -1, -1};
+            auto f = b->cand_script.find(key);
+            if (f != b->cand_script.end()) return f->second;
+            EncScan e;
+            memset(&e, 0, sizeof e);
+            const int id = comp ? 1 : 0;
+            e.ncomp = 1; e.comp[0] = comp; e.Ss = 0; e.Se = 63; e.sequential = 1;
+            e.ntables = 2; e.dht_id[0] = id; e.dht_id[1] = 0x10 | id; e.dc_tbl[0] = 0; e.ac_tbl[0] = 1; e.sos_tdta[0] = (id << 4) | id;
+            b->script.push_back(e);
+            return b->cand_script[key] = int(b->script.size()) - 1;
+        };
+        for (size_t n = 0; n < count; n++) {
+            Item &it = b->items[n];
+            if (it.image < 0) continue;
+            ImgDesc &im = b->imgs[size_t(it.image)];
+            std::vector<int> list;
+            for (int c = 0; c < im.ncomp; c++) list.push_back(progressive ? cand_index(c, 1, 63, 0, 0) : seq1_index(c));
+            const size_t first = b->swork.size();
+            add_works(it, im, it.image, list, inputs[n].length, it.out, true);
+            for (int c = 0; c < im.ncomp; c++) {
+                const ScanWork &sw = b->swork[first + size_t(c)];
+                TrellisWork tw;
+                memset(&tw, 0, sizeof tw);
+                tw.image = it.image; tw.comp = c;
+                tw.table_ac = sw.table_base + (progressive ? 0u : 1u);
+                tw.table_dc = progressive ? -1 : int32_t(sw.table_base);
+                tw.nunits = sw.nunits; tw.unit_base = b->t_units;
+                b->t_units += sw.nunits;
+                for (uint32_t j = 0; j < (sw.nunits + 255) / 256; j++) b->tchunks.push_back(TrellisChunk{uint32_t(b->twork.size()), j});
+                b->t_max_rows = std::max<uint32_t>(b->t_max_rows, uint32_t((im.out[c].real_bh + im.out[c].v - 1) / im.out[c].v));
+                b->twork.push_back(tw);
+            }
+        }
+        tg.nwork = uint32_t(b->swork.size()) - tg.work0; tg.nslots = uint32_t(b->slot_work.size()) - tg.slot0;
+        tg.nech = uint32_t(b->echunks.size()) - tg.ech0; tg.ntables = uint32_t(b->ntables) - tg.table0; tg.nplans = uint32_t(b->plans.size()) - tg.plan0;
+        if (b->total_units > 0xFFFFFFF0ull) { csh_set_error("csh_batch_create: batch too large (fewer files per batch)"); return CS_ERR_POOL_OVERFLOW; }
+    }
     // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
     if (!b->lossless)
         for (ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) im.out[c].tile_base += b->ntiles_in;
@@ -989,6 +1054,9 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
+            return CS_ERR_NO_DEVICE;
+        if (b->trellis && (b->d_twork.upload(b->twork, st) || b->d_tchunks.upload(b->tchunks, st) || b->d_tlambda.alloc(size_t(b->t_units) + 1) || b->d_tdcbt.alloc(size_t(b->t_units) + 1) ||
+                           b->d_tspill.alloc(trellis_spill_words()) || b->d_dct_raw.alloc(size_t(b->ntiles_out) * CSH_TILE_I16)))
             return CS_ERR_NO_DEVICE;
         for (size_t n = 0; px && n < count; n++) {
             const Item &it = b->items[n];
@@ -1071,10 +1139,12 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
-    "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "k_tokens",
+    "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc", "k_tokens",
     "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack",
-    "k_ff_count", "scan_chunks", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", "", "", "", ""};
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 3, 4, 4, 4, 5, 6, 6, 7, 6, 6, 6, 7, 7, 7, 7, 7, 7};
+    "k_ff_count", "scan_chunks", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", ""};
+// the trellis slots (statistics scan = k_tokens without tokens + k_ac_runs + k_gen_tables; the two k_trellis kernels + k_fix_dummy) count
+// as phase 1: they are the quantiser; zero unless CSH_PROFILE=mozjpeg
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 3, 4, 4, 4, 5, 6, 6, 7, 6, 6, 6, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 
 // the WebP tail of a run: RGB (resize branch) -> YUV 4:2:0 -> macroblocks -> tokens; files land in the batch's output pool at
@@ -1327,12 +1397,12 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
                   b->max_src_px, b->max_tmp, b->max_dst, b->max_row_in, b->max_out_w, b->max_nh, !(b->webp || b->rgb_out));
     if (b->webp) return run_webp(b, t, ev, slot);
     if (b->rgb_out) return run_rgb_only(b, t, ev, slot);
-    int16_t *rawp = (b->retain_dct && !b->lossless) ? b->d_dct_raw.p : nullptr;
-    launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p, rawp, b->ntiles_in);
+    int16_t *rawp = ((b->retain_dct || b->trellis) && !b->lossless) ? b->d_dct_raw.p : nullptr;   // the trellis quantiser works from the unquantised DCT
+    launch_xform_direct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_coef.p, rawp, b->ntiles_in, b->dering);
     MARK();
     launch_resample_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_quads, b->d_planes.p, b->d_oplanes.p);
-    launch_plane_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_oplanes.p, b->d_coef.p, rawp, b->ntiles_in);
-    launch_resample_fdct_420(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_planes.p, b->d_coef.p, rawp, b->ntiles_in);
+    launch_plane_fdct(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_oplanes.p, b->d_coef.p, rawp, b->ntiles_in, b->dering);
+    launch_resample_fdct_420(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_planes.p, b->d_coef.p, rawp, b->ntiles_in, b->dering);
     MARK();
     if (!b->lossless) launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
     MARK();
@@ -1355,9 +1425,32 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     if ((c.debug & 8192u) && b->d_raw.zero(st)) return -1;
 #endif
     MARK();
+    // ---- mozjpeg's trellis quantiser (CSH_PROFILE=mozjpeg): per component a statistics scan over the scalar-quantised coefficients
+    // (tokens without tokens: histograms, flags, EOB runs -> optimal tables), then every block re-quantised from the retained DCT
+    if (b->trellis) {
+        const csh_batch::Stage &tg = b->tstage;
+        c.echunks = b->d_echunks.p + tg.ech0; c.nechunks = tg.nech; c.slot0 = tg.slot0; c.nslots = tg.nslots; c.stats_only = 1;
+        if (b->d_long_cnt.zero(st)) return -1;
+        launch_tokens(st, c);
+        launch_ac_runs(st, c);
+        launch_gen_tables(st, b->d_tables.p + tg.table0, int(tg.ntables));
+        c.stats_only = 0;
+        MARK();
+        TrellisCtx tc;
+        memset(&tc, 0, sizeof tc);
+        tc.imgs = b->d_imgs.p; tc.quant = b->d_quants.p; tc.work = b->d_twork.p; tc.nwork = int(b->twork.size()); tc.chunks = b->d_tchunks.p; tc.nchunks = uint32_t(b->tchunks.size());
+        tc.tables = b->d_tables.p; tc.raw = b->d_dct_raw.p; tc.raw_tile0 = b->ntiles_in; tc.coef = b->d_coef.p; tc.lambda = b->d_tlambda.p; tc.dcbt = b->d_tdcbt.p;
+        tc.spill = b->d_tspill.p; tc.max_rows = b->t_max_rows;
+        launch_trellis_ac(st, tc);
+        MARK();
+        launch_trellis_dc(st, tc);
+        launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);   // the dummy blocks copy DC values the trellis has just changed
+        MARK();
+    } else { MARK(); MARK(); MARK(); }
     AsmCtx a;
     memset(&a, 0, sizeof a);
-    a.imgs = b->d_imgs.p; a.script = b->d_script.p; a.work = b->d_swork.p; a.nwork = c.nwork; a.nimg = nimg;
+    a.imgs = b->d_imgs.p; a.script = b->d_script.p; a.work = b->d_swork.p; a.nimg = nimg;
+    a.nwork = b->trellis ? int(b->tstage.work0) : c.nwork;   // the trellis stage's statistics scans (the last work items) put nothing into a file
     a.tables = b->d_tables.p; a.chunk_off = b->d_chunk_off.p; a.scan_pad_bytes = b->d_scan_pad.p; a.scan_raw_off = b->d_scan_raw_off.p;
     a.raw = b->d_raw.p; a.raw_chunks = raw_chunks; a.chunk_ff = b->d_chunk_ff.p; a.chunk_ffoff = b->d_chunk_ffoff.p;
     a.hdr_pool = b->d_hdr.p; a.hdr_off = b->d_hdr_off.p; a.img_size = b->d_img_size.p; a.img_size_pad = b->d_img_size_pad.p;
@@ -1516,7 +1609,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
         t->coef_bytes = in_tiles * CSH_TILE_I16 * 2;
     }
     b->ran = true;
-    if (!requant_only) b->have_dct = b->retain_dct && !b->lossless;
+    if (!requant_only) b->have_dct = (b->retain_dct || b->trellis) && !b->lossless;
     return 0;
 }
 

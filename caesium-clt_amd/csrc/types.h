@@ -134,6 +134,7 @@ struct DevQuant {
     uint16_t q[64];      // table value, zig-zag order
     int32_t div[64];     // q*8 (jfdctint output is scaled by 8)
     float rcp[64];       // 1.0f/div, host-computed
+    float lt[64];        // 1 / q^2 as float(1.0 / double(q * q)): the distortion weight of mozjpeg's trellis (k_trellis.hip), host-computed
 };
 
 // work item of the pixel kernels: one component of one image
@@ -208,6 +209,18 @@ struct SlotRec {
     uint32_t word_base, unit_base, nunits_work;   // of the work item (k_ac_runs)
     uint8_t Ss, Se, Ah, Al; uint32_t pad[3];
 };
+
+// mozjpeg's trellis quantiser (k_trellis.hip; CSH_PROFILE=mozjpeg): one work item per (image, component) -- the component's statistics
+// scan (a ScanWork of the trellis stage) supplies the rate tables -- and one chunk of the AC kernel per 256 of its blocks
+struct TrellisWork {
+    int image, comp;
+    uint32_t table_ac;       // DevEncTable of the statistics pass: code lengths of the AC symbols
+    int32_t table_dc;        // sequential output: the optimal DC table of the same pass; -1: the Annex K table of the component (progressive)
+    uint32_t nunits;         // real blocks of the component
+    uint32_t unit_base;      // first entry of the component in the per-block side arrays (lambda, DC back-pointers)
+    uint32_t pad[2];
+};
+struct TrellisChunk { uint32_t work, j; };
 
 // encoder-side Huffman table as generated on the device
 struct DevEncTable {

@@ -9,9 +9,10 @@
  * SURVEY.md Appendix B) and is pinned by tests/test_oracle_*.py against libjpeg-turbo 3.1.4.1
  * (via Pillow) and against the reference's own fixtures samples/j0.JPG, samples/level_1_0/j1.jpg.
  *
- * Profile implemented: "plain" = ISLOW integer DCTs, scalar quantiser, optimal Huffman tables,
- * stock progression (or a supplied script).  mozjpeg's trellis / deringing / scan search are not
- * restated (unpinned -- see DESIGN.md).
+ * Profiles: "plain" = ISLOW integer DCTs, scalar quantiser, optimal Huffman tables, stock progression
+ * (or a supplied script) -- byte-pinned to libjpeg-turbo; + mozjpeg's scan search (scan_script 2, pinned by
+ * samples/j0.JPG); + mozjpeg's trellis quantiser and overshoot deringing (cso_enc_params.trellis /
+ * .deringing: restated from recall of mozjpeg 4.1's jcdctmgr.c, PARITY UNPINNED -- DESIGN.md).
  */
 #include "jpeg_oracle.h"
 #include <math.h>
@@ -473,12 +474,12 @@ void cso_idct_islow(const int16_t coef[64], const uint16_t qt[64], uint8_t out[6
     }
 }
 
-/* libjpeg jfdctint.c behaviour (ISLOW forward DCT, rows then columns; output scaled by 8).
-   Level shift (-128) is part of the sample-conversion step and is folded in here. */
-void cso_fdct_islow(const uint8_t *s, int32_t d[64]) {
+/* libjpeg jfdctint.c behaviour (ISLOW forward DCT, rows then columns; output scaled by 8), on level-shifted samples
+   (the -128 belongs to the sample-conversion step in front: mozjpeg's deringing sits between the two). */
+static void fdct_islow_ls(const int32_t *s, int32_t d[64]) {
     for (int r = 0; r < 8; r++) {
-        const uint8_t *p = s + 8 * r; int32_t *o = d + 8 * r;
-        int32_t d0 = p[0] - 128, d1 = p[1] - 128, d2 = p[2] - 128, d3 = p[3] - 128, d4 = p[4] - 128, d5 = p[5] - 128, d6 = p[6] - 128, d7 = p[7] - 128;
+        const int32_t *p = s + 8 * r; int32_t *o = d + 8 * r;
+        int32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4], d5 = p[5], d6 = p[6], d7 = p[7];
         int32_t tmp0 = d0 + d7, tmp7 = d0 - d7, tmp1 = d1 + d6, tmp6 = d1 - d6, tmp2 = d2 + d5, tmp5 = d2 - d5, tmp3 = d3 + d4, tmp4 = d3 - d4;
         int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         o[0] = (tmp10 + tmp11) * (1 << PASS1_BITS); o[4] = (tmp10 - tmp11) * (1 << PASS1_BITS);
@@ -506,6 +507,52 @@ void cso_fdct_islow(const uint8_t *s, int32_t d[64]) {
         o[56] = DESCALE(tmp4 + y1 + y3, CONST_BITS + PASS1_BITS); o[40] = DESCALE(tmp5 + y2 + y4, CONST_BITS + PASS1_BITS);
         o[24] = DESCALE(tmp6 + y2 + y3, CONST_BITS + PASS1_BITS); o[8] = DESCALE(tmp7 + y1 + y4, CONST_BITS + PASS1_BITS);
     }
+}
+void cso_fdct_islow(const uint8_t *s, int32_t d[64]) {
+    int32_t ls[64];
+    for (int i = 0; i < 64; i++) ls[i] = (int32_t)s[i] - 128;
+    fdct_islow_ls(ls, d);
+}
+
+/* mozjpeg jcdctmgr.c preprocess_deringing + catmull_rom ("overshoot deringing", on by default in the JCP_MAX_COMPRESSION profile)
+   [UPSTREAM-RECALL, UNPINNED].  On the level-shifted samples of one block, walked in zig-zag order as one line: every run of samples at
+   the top of the range (>= 127) is replaced by a Catmull-Rom arc through the slopes either side of it, so that the clipped plateau
+   overshoots (by at most min(31, 2 * DC quantiser, the headroom the block's mean leaves)) instead of ringing.  float arithmetic, no
+   contraction (x86-64 build of the crate), DCTELEM truncation where the C source passes a float to a DCTELEM parameter. */
+static float dering_catmull_rom(int value1, int value2, int value3, int value4, float t, int size) {
+    const int tan1 = (value3 - value1) * size, tan2 = (value4 - value2) * size;
+    const float t2 = t * t, t3 = t2 * t;
+    const float f1 = 2.f * t3 - 3.f * t2 + 1.f, f2 = -2.f * t3 + 3.f * t2, f3 = t3 - 2.f * t2 + t, f4 = t3 - t2;
+    return value2 * f1 + tan1 * f3 + value3 * f2 + tan2 * f4;
+}
+void cso_dering_block(int32_t data[64], int dc_quant) {
+    const int maxsample = 255 - 128, size = 64;
+    int sum = 0, cnt = 0;
+    for (int i = 0; i < size; i++) { sum += data[i]; if (data[i] >= maxsample) cnt++; }
+    if (!cnt || cnt == size) return;
+    int over = 2 * dc_quant < 31 ? 2 * dc_quant : 31, room = (maxsample * size - sum) / cnt;
+    const int maxovershoot = maxsample + (over < room ? over : room);
+    int n = 0;
+    do {
+        if (data[ZZ[n]] < maxsample) { n++; continue; }
+        const int start = n;
+        while (++n < size && data[ZZ[n]] >= maxsample) {}
+        const int end = n;
+        const float f1 = (float)data[ZZ[start >= 1 ? start - 1 : 0]], f2 = (float)data[ZZ[start >= 2 ? start - 2 : 0]];
+        const float l1 = (float)data[ZZ[end < size - 1 ? end : size - 1]], l2 = (float)data[ZZ[end < size - 2 ? end + 1 : size - 1]];
+        float fslope = f1 - f2 > maxsample - f1 ? f1 - f2 : maxsample - f1;
+        float lslope = l1 - l2 > maxsample - l1 ? l1 - l2 : maxsample - l1;
+        if (start == 0) fslope = lslope;
+        if (end == size) lslope = fslope;
+        const int length = end - start;
+        const float step = 1.f / (float)(length + 1);
+        float position = step;
+        for (int i = start; i < end; i++, position += step) {
+            const int tmp = (int)ceilf(dering_catmull_rom((int)(maxsample - fslope), maxsample, maxsample, (int)(maxsample - lslope), position, length));
+            data[ZZ[i]] = tmp < maxovershoot ? tmp : maxovershoot;
+        }
+        n++;
+    } while (n < size);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -616,7 +663,22 @@ void cso_quality_tables(int q, int profile, int force_baseline, uint16_t out[2][
 
 /* ------------------------------------------------------------------------------------------ */
 /* forward path: libjpeg jcprepct/jcsample/jcdctmgr/jccoefct behaviour   */
-static void forward_component(const uint8_t *full, int W, int H, cso_image *im, int ci) {
+/* blocks that exist only to complete an MCU (jccoefct.c): zero AC, DC of the last real block in the row (right edge) / of block
+   (h-1) of the MCU in the row above (bottom) */
+static void make_dummy_blocks(cso_image *im, int ci) {
+    cso_comp *k = &im->comp[ci];
+    for (int by = 0; by < k->real_bh; by++)
+        for (int bx = k->real_bw; bx < k->bw; bx++) {
+            int16_t *o = k->coef + ((size_t)by * k->bw + bx) * 64;
+            memset(o, 0, 128); o[0] = o[-64];
+        }
+    for (int by = k->real_bh; by < k->bh; by++)
+        for (int m = 0; m < im->mcus_x; m++) {
+            int16_t last = k->coef[((size_t)(by - 1) * k->bw + m * k->h + k->h - 1) * 64];
+            for (int x = 0; x < k->h; x++) { int16_t *o = k->coef + ((size_t)by * k->bw + m * k->h + x) * 64; memset(o, 0, 128); o[0] = last; }
+        }
+}
+static void forward_component(const uint8_t *full, int W, int H, cso_image *im, int ci, int deringing, int16_t *raw /* unquantised DCT per padded block, or NULL */) {
     cso_comp *k = &im->comp[ci];
     int hx = im->hmax / k->h, vx = im->vmax / k->v;
     int pw = k->real_bw * 8, ph = k->bh * 8;         /* sample plane fed to the DCT */
@@ -649,12 +711,14 @@ static void forward_component(const uint8_t *full, int W, int H, cso_image *im, 
     free(r0); free(r1);
 
     const uint16_t *qt = im->qt[k->tq];
-    uint8_t s[64]; int32_t d[64];
+    int32_t s[64], d[64];
     for (int by = 0; by < k->real_bh; by++) {
         for (int bx = 0; bx < k->real_bw; bx++) {
-            for (int y = 0; y < 8; y++) memcpy(s + 8 * y, pl + (size_t)(by * 8 + y) * pw + bx * 8, 8);
-            cso_fdct_islow(s, d);
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) s[8 * y + x] = (int32_t)pl[(size_t)(by * 8 + y) * pw + bx * 8 + x] - 128;
+            if (deringing) cso_dering_block(s, qt[0]);
+            fdct_islow_ls(s, d);
             int16_t *o = k->coef + ((size_t)by * k->bw + bx) * 64;
+            if (raw) for (int i = 0; i < 64; i++) raw[((size_t)by * k->bw + bx) * 64 + i] = (int16_t)d[i];
             for (int i = 0; i < 64; i++) {
                 int32_t qv = (int32_t)qt[i] << 3, t = d[i];
                 if (t < 0) { t = -t; t += qv >> 1; t = t >= qv ? t / qv : 0; t = -t; }
@@ -662,21 +726,12 @@ static void forward_component(const uint8_t *full, int W, int H, cso_image *im, 
                 o[i] = (int16_t)t;
             }
         }
-        /* dummy blocks at the right edge: zero AC, DC of the last real block in the row */
-        for (int bx = k->real_bw; bx < k->bw; bx++) {
-            int16_t *o = k->coef + ((size_t)by * k->bw + bx) * 64;
-            memset(o, 0, 128); o[0] = o[-64];
-        }
     }
-    /* dummy block rows at the bottom: zero AC, DC of block (h-1) of the MCU in the row above */
-    for (int by = k->real_bh; by < k->bh; by++)
-        for (int m = 0; m < im->mcus_x; m++) {
-            int16_t last = k->coef[((size_t)(by - 1) * k->bw + m * k->h + k->h - 1) * 64];
-            for (int x = 0; x < k->h; x++) { int16_t *o = k->coef + ((size_t)by * k->bw + m * k->h + x) * 64; memset(o, 0, 128); o[0] = last; }
-        }
+    make_dummy_blocks(im, ci);
     free(pl);
 }
 
+static void trellis_image(cso_image *im, int16_t *const raw[], const cso_enc_params *p);
 int cso_forward(const uint8_t *pix, int w, int h, int ncomp, const cso_enc_params *p, const uint16_t *qto, cso_image **out) {
     *out = NULL;
     if (ncomp != 1 && ncomp != 3) FAIL("forward: only 1 or 3 components");
@@ -695,11 +750,14 @@ int cso_forward(const uint8_t *pix, int w, int h, int ncomp, const cso_enc_param
     if (qto) memcpy(t, qto, sizeof t); else cso_quality_tables(p->quality, p->qtable_profile, p->force_baseline, t);
     memcpy(im->qt[0], t[0], 128); memcpy(im->qt[1], t[1], 128); im->qt_present[0] = 1; im->qt_present[1] = ncomp > 1;
     uint8_t *full = (uint8_t *)malloc((size_t)w * h);
+    int16_t *raw[CSO_MAX_COMPS] = {0};
     for (int c = 0; c < ncomp; c++) {
         for (size_t i = 0; i < (size_t)w * h; i++) full[i] = pix[i * ncomp + c];
-        forward_component(full, w, h, im, c);
+        if (p->trellis) raw[c] = (int16_t *)calloc((size_t)im->comp[c].bw * im->comp[c].bh * 64, sizeof(int16_t));
+        forward_component(full, w, h, im, c, p->deringing, raw[c]);
     }
     free(full);
+    if (p->trellis) { trellis_image(im, raw, p); for (int c = 0; c < ncomp; c++) free(raw[c]); }
     *out = im;
     return 0;
 }
@@ -868,6 +926,185 @@ static void derive_ehuff(ehuff *h) {
     int p = 0, code = 0;
     memset(h->size, 0, sizeof h->size);
     for (int l = 1; l <= 16; l++) { for (int i = 0; i < h->bits[l]; i++, p++) { h->code[h->huffval[p]] = (uint16_t)code++; h->size[h->huffval[p]] = (uint8_t)l; } code <<= 1; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* mozjpeg's trellis quantiser (jcdctmgr.c quantize_trellis, driven by jccoefct.c compress_trellis_pass and the pass sequence of
+   jcmaster.c) [UPSTREAM-RECALL of mozjpeg 4.1.x as pinned by mozjpeg-sys 2.2.1, /root/reference/Cargo.lock:1035-1044; UNPINNED].
+   Profile constants (jcparam.c, JCP_MAX_COMPRESSION): trellis_quant, trellis_quant_dc on; trellis_eob_opt, trellis_q_opt,
+   use_scans_in_trellis off; trellis_num_loops 1; lambda_log_scale1 14.75, lambda_log_scale2 16.5; trellis_delta_dc_weight 0.
+   What the pass sequence amounts to (optimize_coding on): per component, in order,
+     (1) a statistics pass over its scalar-quantised coefficients with the entropy coder of the output mode -- progressive: ONE scan
+         of the component alone, Ss 1, Se 63, Ah = Al = 0 (EOBRUN symbols included), which yields the optimal AC table; sequential
+         (--jpeg-baseline): a one-component sequential scan, which yields optimal DC and AC tables;
+     (2) the trellis pass: every row of blocks is re-quantised from the unquantised DCT with that table's code lengths as rates.  The DC
+         table in progressive mode is still the Annex K table jpeg_set_defaults installed (no DC statistics exist yet).
+   Inside quantize_trellis (`mode = 1` is hard-wired there, so the CSF weight table is overridden by 1 / q^2 and lambda_base is 1):
+     norm   = mean of the block's 63 squared AC DCT values (float accumulation, natural order)
+     lambda = 2^14.75 / (2^16.5 + norm)                                      (double arithmetic, stored as float)
+     AC:  dynamic programme over zig-zag positions; a non-zero scalar level v offers the candidates 1, 3, 7, ... (2^k - 1 < v) and v;
+          cost = bits of the (run, size) symbol + size + ZRL bits + squared error * lambda / q^2 (+ the squared values of the zeros skipped);
+          then the cheapest last coefficient (an EOB costs the length of symbol 0x00), everything behind it zero
+     DC:  per row of blocks a Viterbi path over up to 9 levels around the rounded one (min(9, (2 + 60 / q_dc) | 1)), rate = size +
+          the DC code of the difference to the previous block's candidate; the predictor of a row's first block is the last DC of
+          the row before it inside the same iMCU row, 0 for the first row of an iMCU row
+   All cost arithmetic is float in the order written below (gcc, x86-64, no contraction). */
+#define TRELLIS_MAX_COEF_BITS 10
+#define TRELLIS_DC_MAX_CAND 9
+static const uint8_t STD_DC_LEN[2][12] = {{2, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9}, {2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}};   /* T.81 Tables K.3, K.4 */
+#define TRELLIS_LAMBDA_C1 0x1.ae89f995ad3adp+14   /* pow(2.0, 14.75) */
+#define TRELLIS_LAMBDA_C2 0x1.6a09e667f3bcdp+16   /* pow(2.0, 16.5) */
+
+static void quantize_trellis_row(const uint8_t dclen[17], const uint8_t aclen[256], int16_t *coef_blocks, const int16_t *src, int num_blocks,
+                                 const uint16_t *qt /* natural order */, int trellis_dc, int16_t *last_dc_val) {
+    float accumulated_zero_dist[64], accumulated_cost[64];
+    int run_start[64] = {0};
+    float lambda_table[64];
+    const int Ss = 1, Se = 63;
+    int dcn = 2 + 60 / qt[0]; dcn |= 1; if (dcn > TRELLIS_DC_MAX_CAND) dcn = TRELLIS_DC_MAX_CAND;
+    const int dc_trellis_candidates = dcn;
+    float *accumulated_dc_cost[TRELLIS_DC_MAX_CAND]; int *dc_cost_backtrack[TRELLIS_DC_MAX_CAND]; int16_t *dc_candidate[TRELLIS_DC_MAX_CAND];
+    for (int i = 0; i < TRELLIS_DC_MAX_CAND; i++) {
+        accumulated_dc_cost[i] = (float *)malloc(sizeof(float) * (size_t)num_blocks);
+        dc_cost_backtrack[i] = (int *)malloc(sizeof(int) * (size_t)num_blocks);
+        dc_candidate[i] = (int16_t *)malloc(sizeof(int16_t) * (size_t)num_blocks);
+    }
+    for (int i = 0; i < 64; i++) lambda_table[i] = (float)(1.0 / (double)((int)qt[i] * (int)qt[i]));
+    for (int bi = 0; bi < num_blocks; bi++) {
+        const int16_t *sb = src + (size_t)bi * 64;
+        int16_t *cb = coef_blocks + (size_t)bi * 64;
+        float norm = 0.0f;
+        for (int i = 1; i < 64; i++) norm += (float)((int)sb[i] * (int)sb[i]);
+        norm = (float)((double)norm / 63.0);
+        const float lambda = (float)(TRELLIS_LAMBDA_C1 * 1.0 / (TRELLIS_LAMBDA_C2 + (double)norm));
+        const float lambda_dc = lambda * lambda_table[0];
+        accumulated_zero_dist[Ss - 1] = 0.0f;
+        accumulated_cost[Ss - 1] = 0.0f;
+        if (trellis_dc) {
+            const int sign = sb[0] >> 31, x = abs(sb[0]), q = 8 * qt[0];
+            const int qval = (x + q / 2) / q;
+            for (int k = 0; k < dc_trellis_candidates; k++) {
+                int cand = qval - dc_trellis_candidates / 2 + k;
+                if (cand >= (1 << TRELLIS_MAX_COEF_BITS)) cand = (1 << TRELLIS_MAX_COEF_BITS) - 1;
+                if (cand <= -(1 << TRELLIS_MAX_COEF_BITS)) cand = -(1 << TRELLIS_MAX_COEF_BITS) + 1;
+                const int delta = cand * q - x;
+                const float dc_candidate_dist = (float)(delta * delta) * lambda_dc;
+                cand *= 1 + 2 * sign;
+                dc_candidate[k][bi] = (int16_t)cand;
+                if (bi == 0) {
+                    int dc_delta = abs(cand - *last_dc_val), bits = 0;
+                    while (dc_delta) { dc_delta >>= 1; bits++; }
+                    const float cost = (float)(bits + dclen[bits]) + dc_candidate_dist;
+                    accumulated_dc_cost[k][0] = cost;
+                    dc_cost_backtrack[k][0] = -1;
+                } else {
+                    for (int l = 0; l < dc_trellis_candidates; l++) {
+                        int dc_delta = abs(cand - dc_candidate[l][bi - 1]), bits = 0;
+                        while (dc_delta) { dc_delta >>= 1; bits++; }
+                        const float cost = (float)(bits + dclen[bits]) + dc_candidate_dist + accumulated_dc_cost[l][bi - 1];
+                        if (l == 0 || cost < accumulated_dc_cost[k][bi]) { accumulated_dc_cost[k][bi] = cost; dc_cost_backtrack[k][bi] = l; }
+                    }
+                }
+            }
+        }
+        for (int i = Ss; i <= Se; i++) {
+            const int z = ZZ[i];
+            const int sign = sb[z] >> 31, x = abs(sb[z]), q = 8 * qt[z];
+            int candidate[16], candidate_bits[16];
+            float candidate_dist[16];
+            accumulated_zero_dist[i] = (float)(x * x) * lambda * lambda_table[z] + accumulated_zero_dist[i - 1];
+            int qval = (x + q / 2) / q;
+            if (qval == 0) { cb[z] = 0; accumulated_cost[i] = 1e38f; continue; }
+            if (qval >= (1 << TRELLIS_MAX_COEF_BITS)) qval = (1 << TRELLIS_MAX_COEF_BITS) - 1;
+            const int num_candidates = bitlen((unsigned)qval);
+            for (int k = 0; k < num_candidates; k++) {
+                candidate[k] = (k < num_candidates - 1) ? (2 << k) - 1 : qval;
+                const int delta = candidate[k] * q - x;
+                candidate_bits[k] = k + 1;
+                candidate_dist[k] = (float)(delta * delta) * lambda * lambda_table[z];
+            }
+            accumulated_cost[i] = 1e38f;
+            for (int j = Ss - 1; j < i; j++) {
+                if (j != Ss - 1 && cb[ZZ[j]] == 0) continue;
+                int zero_run = i - 1 - j;
+                if ((zero_run >> 4) && aclen[0xF0] == 0) continue;
+                const int run_bits = (zero_run >> 4) * aclen[0xF0];
+                zero_run &= 15;
+                for (int k = 0; k < num_candidates; k++) {
+                    const int coef_bits = aclen[16 * zero_run + candidate_bits[k]];
+                    if (coef_bits == 0) continue;
+                    const int rate = coef_bits + candidate_bits[k] + run_bits;
+                    float cost = (float)rate + candidate_dist[k];
+                    cost += accumulated_zero_dist[i - 1] - accumulated_zero_dist[j] + accumulated_cost[j];
+                    if (cost < accumulated_cost[i]) {
+                        cb[z] = (int16_t)((candidate[k] ^ sign) - sign);
+                        accumulated_cost[i] = cost;
+                        run_start[i] = j;
+                    }
+                }
+            }
+        }
+        int last_coeff_idx = Ss - 1;
+        float best_cost = accumulated_zero_dist[Se] + (float)aclen[0];
+        for (int i = Ss; i <= Se; i++) {
+            if (cb[ZZ[i]] != 0) {
+                float cost = accumulated_cost[i] + accumulated_zero_dist[Se] - accumulated_zero_dist[i];
+                if (i < Se) cost += (float)aclen[0];
+                if (cost < best_cost) { best_cost = cost; last_coeff_idx = i; }
+            }
+        }
+        /* zero out coefficients that are part of runs */
+        for (int i = Se; i >= Ss;) {
+            while (i > last_coeff_idx) { cb[ZZ[i]] = 0; i--; }
+            last_coeff_idx = run_start[i];
+            i--;
+        }
+    }
+    if (trellis_dc) {
+        int j = 0;
+        for (int i = 1; i < dc_trellis_candidates; i++)
+            if (accumulated_dc_cost[i][num_blocks - 1] < accumulated_dc_cost[j][num_blocks - 1]) j = i;
+        for (int bi = num_blocks - 1; bi >= 0; bi--) { coef_blocks[(size_t)bi * 64] = dc_candidate[j][bi]; j = dc_cost_backtrack[j][bi]; }
+        *last_dc_val = coef_blocks[(size_t)(num_blocks - 1) * 64];
+    }
+    for (int i = 0; i < TRELLIS_DC_MAX_CAND; i++) { free(accumulated_dc_cost[i]); free(dc_cost_backtrack[i]); free(dc_candidate[i]); }
+}
+
+/* code lengths (0 = symbol unused) of the optimal table for these counts */
+static void optimal_lengths(const long freq[257], uint8_t len[256]) {
+    ehuff h; memset(&h, 0, sizeof h);
+    h.nsym = cso_gen_optimal_table(freq, h.bits, h.huffval);
+    derive_ehuff(&h);
+    memcpy(len, h.size, 256);
+}
+/* the rate tables one component's trellis pass works with (exported for the stage-level device tests): aclen[256], dclen[17] */
+void cso_trellis_tables(const cso_image *im, int ci, uint8_t aclen[256], uint8_t dclen[17]) {
+    cso_scan sc; memset(&sc, 0, sizeof sc);
+    sc.ncomp_in_scan = 1; sc.comp_idx[0] = ci; sc.Ss = im->progressive ? 1 : 0; sc.Se = 63;
+    tvec tv = {0};
+    tokenize_scan(im, &sc, &tv);
+    long freq[8][257]; memset(freq, 0, sizeof freq);
+    for (size_t i = 0; i < tv.n; i++) if (tv.t[i].tbl != 255) freq[tv.t[i].tbl][tv.t[i].sym]++;
+    free(tv.t);
+    const int id = ci ? 1 : 0;
+    optimal_lengths(freq[4 + id], aclen);
+    memset(dclen, 0, 17);
+    if (im->progressive) memcpy(dclen, STD_DC_LEN[id], 12);
+    else { uint8_t l[256]; optimal_lengths(freq[id], l); memcpy(dclen, l, 17); }
+}
+static void trellis_image(cso_image *im, int16_t *const raw[], const cso_enc_params *p) {
+    (void)p;
+    for (int ci = 0; ci < im->ncomp; ci++) {
+        cso_comp *k = &im->comp[ci];
+        uint8_t aclen[256], dclen[17];
+        cso_trellis_tables(im, ci, aclen, dclen);
+        int16_t last_dc = 0;
+        for (int by = 0; by < k->real_bh; by++) {
+            if (by % k->v == 0) last_dc = 0;   /* compress_trellis_pass: the predictor starts at 0 in every iMCU row */
+            quantize_trellis_row(dclen, aclen, k->coef + (size_t)by * k->bw * 64, raw[ci] + (size_t)by * k->bw * 64, k->real_bw, im->qt[k->tq], 1, &last_dc);
+        }
+        make_dummy_blocks(im, ci);
+    }
 }
 
 /* stock progression scripts: libjpeg jcparam.c jpeg_simple_progression behaviour;

@@ -10,8 +10,9 @@
  *   (a) byte-for-byte agreement with libjpeg-turbo 3.1.4.1 (through Pillow), and
  *   (b) byte-identical entropy round trips of the reference's own fixtures
  *       samples/j0.JPG and samples/level_1_0/j1.jpg,
- * see tests/test_oracle_*.py.  Parity with real mozjpeg's trellis quantiser,
- * deringing and scan-script search is UNPINNED (DESIGN.md "Parity tiers").
+ * see tests/test_oracle_*.py.  The scan-script search is pinned by j0.JPG; parity with real
+ * mozjpeg's trellis quantiser and deringing (cso_enc_params.trellis / .deringing) is UNPINNED
+ * (DESIGN.md "Parity tiers").
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * anything in oracle/.
@@ -70,6 +71,12 @@ typedef struct {
     int force_baseline;        /* clamp quant entries to 255 */
     int preserve_icc;          /* keep APP2 "ICC_PROFILE" segments even when keep_metadata is 0; drop them when 0
                                   (libcaesium jpeg.preserve_icc = !--strip-icc, compressor.rs:425) [UPSTREAM-RECALL] */
+    /* the quantiser half of mozjpeg's JCP_MAX_COMPRESSION profile -- what `-q N` runs in libcaesium (compressor.rs:415,427 ->
+       jpeg_set_defaults).  [UPSTREAM-RECALL] of mozjpeg-sys 2.2.1 (mozjpeg 4.1) jcdctmgr.c / jccoefct.c / jcmaster.c, UNPINNED: no
+       golden bytes exist in the reference and the crate cannot be built here (tests/golden/make_reference_goldens.sh is the recipe). */
+    int trellis;               /* 1: trellis quantisation of the AC coefficients (quantize_trellis) and, as mozjpeg's default couples it, of the DC
+                                  coefficients (trellis_quant_dc); rates from the optimal Huffman table of a statistics pass over the scalar result */
+    int deringing;             /* 1: overshoot deringing (preprocess_deringing) on the level-shifted samples in front of the forward DCT */
 } cso_enc_params;
 
 /* ---- decode ---- */
@@ -123,6 +130,8 @@ int  cso_jpeg_compress_resized(const uint8_t *in, size_t n, const cso_enc_params
 /* ---- pieces exported for stage-level parity tests ---- */
 void cso_quality_tables(int quality, int profile, int force_baseline, uint16_t out[2][64]);
 void cso_fdct_islow(const uint8_t *samples8x8 /* row stride 8 */, int32_t out[64]);
+void cso_dering_block(int32_t level_shifted[64] /* natural order, in place */, int dc_quant);   /* mozjpeg preprocess_deringing [UPSTREAM-RECALL] */
+void cso_trellis_tables(const cso_image *im, int ci, uint8_t aclen[256], uint8_t dclen[17]);   /* rate tables of component ci's trellis pass */
 void cso_idct_islow(const int16_t coef[64], const uint16_t qt[64], uint8_t out[64]);
 int  cso_stock_script(int ncomp, int which, cso_scan *out); /* returns nscans */
 /* optimal Huffman table: freq[257] -> bits[17], huffval[256]; returns #symbols */

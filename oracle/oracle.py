@@ -41,7 +41,8 @@ class Image(C.Structure):
 
 class EncParams(C.Structure):
     _fields_ = [("quality", C.c_int), ("progressive", C.c_int), ("subsampling", C.c_int), ("qtable_profile", C.c_int),
-                ("marker_style", C.c_int), ("scan_script", C.c_int), ("keep_metadata", C.c_int), ("force_baseline", C.c_int), ("preserve_icc", C.c_int)]
+                ("marker_style", C.c_int), ("scan_script", C.c_int), ("keep_metadata", C.c_int), ("force_baseline", C.c_int), ("preserve_icc", C.c_int),
+                ("trellis", C.c_int), ("deringing", C.c_int)]
 
 
 class Png(C.Structure):
@@ -123,8 +124,8 @@ def _check(rc):
 
 
 def params(quality=80, progressive=1, subsampling=0, qtable_profile=3, marker_style=1, scan_script=0,
-           keep_metadata=0, force_baseline=0, preserve_icc=1):
-    return EncParams(quality, progressive, subsampling, qtable_profile, marker_style, scan_script, keep_metadata, force_baseline, preserve_icc)
+           keep_metadata=0, force_baseline=0, preserve_icc=1, trellis=0, deringing=0):
+    return EncParams(quality, progressive, subsampling, qtable_profile, marker_style, scan_script, keep_metadata, force_baseline, preserve_icc, trellis, deringing)
 
 
 class CoefImage:
