@@ -38,10 +38,17 @@ def device_scan_script():
     return 0 if os.environ.get("CSH_PROFILE") == "plain" else 2
 
 
+def device_quantiser():
+    """the oracle's trellis / deringing switches for the profile the device library is in: both under CSH_PROFILE=mozjpeg (the whole
+    JCP_MAX_COMPRESSION profile libcaesium's -q runs), one each under mozjpeg-trellis / mozjpeg-dering, neither by default"""
+    prof = os.environ.get("CSH_PROFILE", "")
+    return dict(trellis=int(prof in ("mozjpeg", "mozjpeg-trellis")), deringing=int(prof in ("mozjpeg", "mozjpeg-dering")))
+
+
 def oracle_lossy(src, quality=80, progressive=1, subsampling=420, keep_metadata=0, preserve_icc=1):
     from oracle import oracle as O
     return O.jpeg_compress(src, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script(),
-                                         keep_metadata=keep_metadata, preserve_icc=preserve_icc))
+                                         keep_metadata=keep_metadata, preserve_icc=preserve_icc, **device_quantiser()))
 
 
 def oracle_lossless(src, progressive=1, keep_metadata=0, preserve_icc=1):
@@ -51,7 +58,7 @@ def oracle_lossless(src, progressive=1, keep_metadata=0, preserve_icc=1):
 
 def oracle_resized(src, width, height, quality=80, subsampling=420):
     from oracle import oracle as O
-    return O.jpeg_compress_resized(src, O.params(quality=quality, progressive=1, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), width, height)
+    return O.jpeg_compress_resized(src, O.params(quality=quality, progressive=1, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script(), **device_quantiser()), width, height)
 
 
 # ---------------------------------------------------------------- lossless PNG row
@@ -387,7 +394,7 @@ def oracle_png_to_jpeg(src, quality=80, width=0, height=0, subsampling=420, prog
         pix, ctype = png_expand8(P, ignore_trns=True)   # a tRNS chunk makes no alpha channel here
     if ctype in (4, 6):
         pix = pix[:, :, :-1]
-    return O.pixels_to_jpeg(pix, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), width, height)
+    return O.pixels_to_jpeg(pix, O.params(quality=quality, progressive=progressive, subsampling=subsampling, qtable_profile=3, marker_style=1, scan_script=device_scan_script(), **device_quantiser()), width, height)
 
 
 def oracle_png_lossy(src, level=3, keep_metadata=False, quality=80):
