@@ -44,3 +44,22 @@ def test_1080p_full_size_and_a_wide_batch(api, monkeypatch):
     for i in (0, 1, 2, 13, 25):
         assert outs[i] == oracle_lossy(srcs[i]), i
     assert all(isinstance(o, bytes) and o[:2] == b"\xff\xd8" for o in outs)
+
+
+# ---- parity tier P1 on the device: the HIP path against the REAL caesiumclt 1.4.0 (activates when tests/golden/libcaesium/ exists;
+# tests/golden/make_reference_goldens.sh makes it; tests/test_reference_goldens.py is the oracle's twin of this test)
+import os
+
+import test_reference_goldens as G
+
+DEVICE_RECIPES = {"jpeg_q80": dict(jpeg_quality=80), "jpeg_q51": dict(jpeg_quality=51), "jpeg_q95": dict(jpeg_quality=95),
+                  "jpeg_q80_baseline": dict(jpeg_quality=80, jpeg_progressive=False), "jpeg_q80_444": dict(jpeg_quality=80, jpeg_chroma_subsampling=444),
+                  "jpeg_q80_422": dict(jpeg_quality=80, jpeg_chroma_subsampling=422), "jpeg_lossless": dict(jpeg_optimize=True),
+                  "jpeg_q80_exif": dict(jpeg_quality=80, keep_metadata=True), "jpeg_q80_width100": dict(jpeg_quality=80, width=100)}
+
+
+@pytest.mark.parametrize("recipe,name", [c for c in G._cases() if c.values[0] in DEVICE_RECIPES])
+def test_device_reproduces_caesiumclt(api, monkeypatch, recipe, name):
+    monkeypatch.setenv("CSH_PROFILE", "mozjpeg")
+    want = open(os.path.join(G.TREE, recipe, name), "rb").read()
+    G._report(api.compress_in_memory(G._source(name), E.params(**DEVICE_RECIPES[recipe])), want, G.RECIPES[recipe][0])
