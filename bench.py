@@ -5,11 +5,21 @@ A step = one pass of the whole hot path (entropy decode -> pixel-domain transcod
 assembly) over one batch of synthetic 1080p JPEGs whose bytes are already resident in HBM.  One process per
 GPU; files shard per rank with no collective on the data path (weak scaling: every rank gets --batch files).
 Prints ONE JSON line on rank 0.
+
+Beside the headline (`value`: the default profile = mozjpeg's scan search over the scalar quantiser, the profile whose pieces are pinned)
+the line carries, measured in the same run: `plain_profile` and `mozjpeg_profile` (CSH_PROFILE=mozjpeg: scan search + trellis quantisation
++ overshoot deringing -- what libcaesium's -q runs; unpinned), `roofline` for the dominant kernel with `traffic` from two rocprofv3 --pmc
+passes this script starts itself (FETCH_SIZE, WRITE_SIZE; separate passes, no trace domain), `cpu_baseline` (the oracle on the host),
+`boundary` (cs_batch_compress from host buffers), `cli_end_to_end` (the caesiumclt binary, files in -> files out), `other_configs`
+(configs[2], configs[3], configs[4]) each with its own roofline and CPU lines.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -18,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MP_1080P = 1920 * 1080 / 1e6
 
 
 def algorithmic_bytes(kernel, t, n):
@@ -38,32 +49,57 @@ def algorithmic_bytes(kernel, t, n):
         "k_idct_plane": c + planes,
         "k_resample+k_plane_fdct": 3 * planes + c,
         "memset_coef": 2 * coef,
+        # the trellis quantiser reads the retained DCT once and writes the coefficients once (J7 inside phase X)
+        "k_trellis_ac": 2 * coef, "trellis_stats": coef,
     }
     return table.get(kernel)
 
 
-# hipEvent kernel slot -> substring of the rocprofv3 kernel name (profiles/*.csv)
+# hipEvent kernel slot -> substring of the rocprofv3 kernel name
 ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2", "k_dec_spec": "k_dec_dense<0", "k_dec_relax0": "k_dec_dense<1", "k_dec_relax1_4": "k_dec_relax_list",
-                "k_resample+k_plane_fdct": "k_resample_plane", "unstuff": "k_unstuff_copy", "k_emit": "k_emit_data"}
+                "k_resample+k_plane_fdct": "k_resample_fdct_420", "unstuff": "k_unstuff_copy", "k_emit": "k_emit_data", "trellis_stats": "k_tokens",
+                "scan_search_stage2": "k_tokens"}
 
 
-def pmc_traffic(kernel, batch):
-    """HBM bytes of ONE launch of `kernel` from the committed PMC passes (profiles/r02_pmc_{FETCH,WRITE}_SIZE_batch<B>.csv:
-    separate rocprofv3 --pmc runs of this same command at the same --batch, --steps 1; raw counter unit KiB; FETCH_SIZE doubled
-    per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is -- it reads exactly 2*coef bytes on the pool memset).
-    None when the batch differs from the profiled one or the files are absent."""
+def live_pmc(kernel, batch, profile, timeout=240):
+    """HBM bytes of ONE launch of `kernel`, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass,
+    MI355X_MICROARCH.md "rocprofv3 PMC slots"; no trace domain next to them) over one step of this same workload in a child process
+    (`--pmc-child`).  Counter unit KiB; FETCH_SIZE doubled (the gfx950 note of the same guide: wide coalesced reads are tallied at half their
+    bytes), WRITE_SIZE as is (it reads exactly the bytes of the coefficient-pool memset).  Returns (bytes per launch or None, detail dict)."""
     import csv
+    import glob
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, {"error": "rocprofv3 not on PATH"}
     key = ROCPROF_NAME.get(kernel, kernel)
-    tot = 0.0
+    detail = {"kernel_regex": key, "method": "rocprofv3 --pmc <counter> --kernel-include-regex, one step, child process of this run"}
+    total = 0.0
     for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(ROOT, "profiles", f"r02_pmc_{counter}_batch{batch}.csv")
-        if not os.path.exists(path):
-            return None
-        hit = [r for r in csv.reader(open(path)) if len(r) == 3 and key in r[0]]
-        if not hit:
-            return None
-        tot += sum(float(r[2]) / max(1, int(r[1])) for r in hit) * 1024.0 * scale
-    return int(tot)
+        d = tempfile.mkdtemp(prefix="csh_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        if profile:
+            env["CSH_PROFILE"] = profile
+        else:
+            env.pop("CSH_PROFILE", None)
+        cmd = [exe, "--pmc", counter, "--kernel-include-regex", key.replace("<", "."), "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(batch)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            vals = []
+            for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(fn)):
+                    if r.get("Counter_Name") == counter and key in r.get("Kernel_Name", ""):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, dict(detail, error=f"no {counter} rows for {key}")
+            per_launch = sum(vals) / len(vals) * 1024.0 * scale
+            detail[counter] = {"dispatches": len(vals), "bytes_per_launch": int(per_launch), "scale": scale}
+            total += per_launch
+        except Exception as e:   # a profiler problem must not take the headline down
+            return None, dict(detail, error=f"{counter}: {str(e)[:160]}")
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(total), detail
 
 
 def cpu_model():
@@ -90,6 +126,29 @@ def pillow_proxy(src):
     return b.getvalue()
 
 
+def pillow_png_proxy(src):
+    """libpng through Pillow: decode, re-encode at zlib level 9 with adaptive filtering (BASELINE.md section 3's PNG proxy; not oxipng)"""
+    import io
+
+    from PIL import Image
+    b = io.BytesIO()
+    Image.open(io.BytesIO(src)).save(b, format="PNG", compress_level=9)
+    return b.getvalue()
+
+
+def pillow_webp_proxy(src):
+    """libjpeg-turbo + Pillow's Lanczos + libwebp method 4 through Pillow: JPEG -> long edge 1500 -> WebP q85 (BASELINE.md section 3's proxy)"""
+    import io
+
+    from PIL import Image
+    im = Image.open(io.BytesIO(src)).convert("RGB")
+    w, h = im.size
+    nw, nh = (1500, round(h * 1500 / w)) if w >= h else (round(w * 1500 / h), 1500)
+    b = io.BytesIO()
+    im.resize((nw, nh), Image.LANCZOS).save(b, format="WEBP", quality=85, method=4)
+    return b.getvalue()
+
+
 # mozjpeg base table #3 at libjpeg scale 40 (= -q 80), natural order (SURVEY.md 8c-1, pinned by samples/j0.JPG's DQT at scale 98)
 _BASE3 = [16, 16, 16, 18, 25, 37, 56, 85, 16, 17, 20, 27, 34, 40, 53, 75, 16, 20, 24, 31, 43, 62, 91, 135, 18, 27, 31, 40, 53, 74, 106, 156,
           25, 34, 43, 53, 69, 94, 131, 189, 37, 40, 62, 74, 94, 124, 169, 238, 56, 53, 91, 106, 131, 169, 226, 311, 85, 75, 135, 156, 189, 238, 311, 418]
@@ -101,20 +160,40 @@ def _one_input(i):
     return synth_jpeg(i)
 
 
+def _one_png_1080(i):
+    from gen_synth import synth_png
+    return synth_png(i, 1920, 1080, "RGB")
+
+
+def _one_webp_1080(i):
+    import io
+
+    from PIL import Image
+
+    from gen_synth import synth_rgb
+    b = io.BytesIO()
+    Image.fromarray(synth_rgb(i), "RGB").save(b, format="WEBP", quality=90, method=2)
+    return b.getvalue()
+
+
+def pool_map(fn, items):
+    items = list(items)
+    if len(items) <= 4:
+        return [fn(i) for i in items]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(len(items), os.cpu_count() or 1, 192)) as pool:
+        return pool.map(fn, items, chunksize=1)
+
+
 def make_inputs(first, count):
     """`count` distinct 1080p q92 4:2:0 baseline JPEGs (SURVEY 8d recipe, seeds first..), made on all host cores (~1.2 s of numpy each)"""
-    if count <= 4:
-        return [_one_input(first + i) for i in range(count)]
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(min(count, os.cpu_count() or 1, 64)) as pool:
-        return pool.map(_one_input, range(first, first + count), chunksize=1)
+    return pool_map(_one_input, range(first, first + count))
 
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this script (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* as
     torch.distributed.run would set them), pass rank 0's JSON line through, fail if any rank fails."""
     import socket
-    import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -133,17 +212,87 @@ def spawn_ranks(n):
     return None
 
 
+def set_profile(profile):
+    if profile:
+        os.environ["CSH_PROFILE"] = profile
+    else:
+        os.environ.pop("CSH_PROFILE", None)
+
+
+def profile_record(api, pkg, blobs, params, local, profile, steps, names, note, parity_idx):
+    """the same batch under another CSH_PROFILE: value, per-kernel times, output bytes, and a byte check of a few files against the oracle
+    restated for that profile"""
+    import torch
+
+    from _util import oracle_lossy
+    before = os.environ.get("CSH_PROFILE")
+    set_profile(profile)
+    try:
+        pb = api.batch(blobs, params, device=local)
+        pb.run()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        ptm = [pb.run() for _ in range(steps)]
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - p0) / len(ptm)
+        outs = pb.fetch()
+        parity = all(outs[i] == oracle_lossy(blobs[i]) for i in parity_idx)
+        rec = {"value": round(ptm[-1].pixels / 1e6 / pdt, 1), "unit": "MP/s", "ms_per_step": round(pdt * 1e3, 3), "out_bytes": int(ptm[-1].out_bytes),
+               "parity_spot_check": bool(parity),
+               "kernel_ms": {names[i]: round(sum(x.kernel_ms[i] for x in ptm) / len(ptm), 3) for i in range(len(names)) if names[i] and ptm[-1].kernel_ms[i] > 0.05},
+               "note": note}
+        del outs
+        pb.close()
+        return rec, ptm
+    finally:
+        set_profile(before)
+
+
+def timed_threads(fn, items, cores):
+    from concurrent.futures import ThreadPoolExecutor
+    c0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(fn, items))
+    return time.perf_counter() - c0
+
+
+def run_cli(args_list, env=None):
+    exe = os.path.join(ROOT, "caesium-clt_amd", "bin", "caesiumclt")
+    c0 = time.perf_counter()
+    r = subprocess.run([exe] + args_list, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    return time.perf_counter() - c0, r
+
+
+def scratch_dir():
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    return tempfile.mkdtemp(prefix="csh_bench_", dir=base)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=2048, help="1080p files per rank per step (2048 x ~21 MB of device pools = 44 GB of the 288 GB)")
-    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic images per rank (cycled to --batch); generated on all host cores")
-    ap.add_argument("--cpu-images", type=int, default=64, help="files timed through the single-thread CPU oracle (rank 0, N=1); the all-core and Pillow lines scale from it")
+    ap.add_argument("--unique", type=int, default=1000, help="distinct synthetic images per rank (cycled to --batch): SURVEY 8d's 1 000 unique images; generated on all host cores")
+    ap.add_argument("--cpu-images", type=int, default=48, help="files timed through the single-thread CPU oracle (rank 0, N=1); the all-core and Pillow lines scale from it")
     ap.add_argument("--boundary-files", type=int, default=512, help="files of the cs_batch_compress (host buffers in, host buffers out) measurement; 0 = skip")
+    ap.add_argument("--cli-files", type=int, default=2048, help="files of the caesiumclt end-to-end measurement (files in -> files out); 0 = skip")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / CPU / other-config records (profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.pmc_child:
+        # one step of the same workload for the counter passes (live_pmc): no torch, no records
+        from _util import package
+        pkg = package()
+        api = pkg.load()
+        uniq = make_inputs(0, 64)
+        b = api.batch([uniq[i % 64] for i in range(args.batch)], pkg.default_parameters(jpeg_quality=80))
+        b.run()
+        b.close()
+        return None
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)   # python bench.py --gpus N by itself: one process per GPU, this process only relays rank 0's line
@@ -160,15 +309,15 @@ def main():
     torch.cuda.set_device(local)
 
     from _util import package
-    from gen_synth import synth_jpeg
     pkg = package()
     api = pkg.load()
     if api.device_count() < 1:
         raise SystemExit("no HIP device: libcaesium_hip has no CPU path")
 
     # config 2 inputs: Pillow/libjpeg-turbo q92 4:2:0 baseline JPEGs of the SURVEY 8d synthetic images
-    uniq = make_inputs(rank * args.unique, args.unique)
-    blobs = [uniq[i % args.unique] for i in range(args.batch)]
+    nuniq = max(1, min(args.unique, args.batch))
+    uniq = make_inputs(rank * nuniq, nuniq)
+    blobs = [uniq[i % nuniq] for i in range(args.batch)]
     params = pkg.default_parameters(jpeg_quality=80)
     batch = api.batch(blobs, params, device=local)   # parse + upload: inputs now resident in HBM
 
@@ -191,15 +340,18 @@ def main():
 
     t = timings[-1]
     assert t.n_images == args.batch and t.n_failed == 0
-    profile = "plain (stock jpeg_simple_progression script)" if os.environ.get("CSH_PROFILE") == "plain" else \
-        "mozjpeg scan search (optimize_scans: 64 candidate scans coded per file, pinned by samples/j0.JPG)"
+    prof_env = os.environ.get("CSH_PROFILE", "")
+    profile = {"plain": "plain (stock jpeg_simple_progression script)",
+               "mozjpeg": "mozjpeg JCP_MAX_COMPRESSION (scan search + trellis quantisation + overshoot deringing; parity with the real crate unpinned)"}.get(
+        prof_env, "mozjpeg scan search (optimize_scans: 64 candidate scans coded per file, pinned by samples/j0.JPG) over the scalar quantiser")
     mp_per_step = t.pixels / 1e6 * world
     value = mp_per_step * args.steps / dt
 
-    # spot-check parity on this very batch (outside the timed region)
+    # spot-check parity on this very batch (outside the timed region): files spread over the distinct images
     outs = batch.fetch()
     from _util import oracle_lossy
-    parity = all(outs[i] == oracle_lossy(blobs[i]) for i in range(min(2, args.unique)))
+    parity_idx = sorted({0, nuniq // 3, (2 * nuniq) // 3, nuniq - 1})
+    parity = all(outs[i] == oracle_lossy(blobs[i]) for i in parity_idx)
     del outs
     batch.close()   # its pools go back to the block cache: the records below make batches of their own
 
@@ -207,108 +359,77 @@ def main():
     if rank == 0:
         names = api.kernel_names()
         kms = [sum(tm.kernel_ms[i] for tm in timings) / len(timings) for i in range(len(names))]
-        lumps = {"scan_search_stage2", "memset_coef", "memset_enc"}   # several launches under one timing slot / not a kernel of ours
+        lumps = {"scan_search_stage2", "memset_coef", "memset_enc", "trellis_stats"}   # several launches under one timing slot / not a kernel of ours
         dom = max((i for i in range(len(names)) if names[i] not in lumps), key=lambda i: kms[i])
         ab = algorithmic_bytes(names[dom], t, args.batch)
-        roof = {"bound": "hbm", "kernel": names[dom], "avg_ms": round(kms[dom], 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": pmc_traffic(names[dom], args.batch)}
+        roof = {"bound": "hbm", "kernel": names[dom], "avg_ms": round(kms[dom], 4), "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
         if ab is not None:
             ach = ab / (kms[dom] * 1e-3) / 1e9
             roof.update({"achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(ab)})
-        if names[dom] == "k_tokens":
-            roof["note"] = ("integer bit work, bound by instruction issue, not by HBM: 1.04 M waves of 4.3 k issue slots per 1024 files, stalled 61 % of their life at 3 waves per SIMD (profiles/r02_pmc_sq_*_batch1024.txt); the scan search launches it twice per step (stage 1 timed here, stage 2 inside scan_search_stage2)")
         else:
             roof.update({"achieved": None, "frac": None})
-        cpu = cpu_all = cpu_pillow = boundary = plain = None
         extras = world == 1 and not args.no_extras
+        if world == 1 and not args.no_pmc:
+            traffic, detail = live_pmc(names[dom], args.batch, prof_env)
+            roof["traffic"] = traffic
+            roof["traffic_detail"] = detail
+            if traffic and ab:
+                roof["traffic_over_algorithmic"] = round(traffic / ab, 3)
+        cpu = cpu_all = cpu_pillow = cpu_moz = boundary = plain = moz = cli = None
         # the three phases of the path against SURVEY 8d's algorithmic bytes (D: stream in + planes out, X: planes in + out, E: planes in + files out)
         ph = [sum(tm.phase_ms[i] for tm in timings) / len(timings) for i in range(8)]
         coefb = t.coef_bytes
+
         def phase(ms, nbytes):
             return {"ms": round(ms, 3), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                     "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
         phases = {"D_entropy_decode": phase(ph[0], t.in_bytes + coefb), "X_pixel_transcode": phase(ph[1], 2 * coefb),
                   "X_read_only": phase(ph[1], coefb), "E_entropy_encode": phase(sum(ph[2:8]), coefb + t.out_bytes)}
-        if extras and os.environ.get("CSH_PROFILE") != "plain":
-            # the same batch under the plain profile (stock 10-scan script: the output that is byte-identical to libjpeg-turbo's)
-            os.environ["CSH_PROFILE"] = "plain"
-            try:
-                pb = api.batch(blobs, params, device=local)
-                pb.run()
-                torch.cuda.synchronize()
-                p0 = time.perf_counter()
-                ptm = [pb.run() for _ in range(max(2, args.steps // 2))]
-                torch.cuda.synchronize()
-                pdt = (time.perf_counter() - p0) / len(ptm)
-                plain = {"value": round(t.pixels / 1e6 / pdt, 1), "unit": "MP/s", "ms_per_step": round(pdt * 1e3, 3), "out_bytes": int(ptm[-1].out_bytes),
-                         "kernel_ms": {names[i]: round(sum(x.kernel_ms[i] for x in ptm) / len(ptm), 3) for i in range(len(names)) if names[i] and ptm[-1].kernel_ms[i] > 0.05},
-                         "note": "CSH_PROFILE=plain: jpeg_simple_progression, no scan search; byte-identical to libjpeg-turbo (tests/test_oracle_jpeg.py)"}
-                pb.close()
-            finally:
-                del os.environ["CSH_PROFILE"]
+        sub_steps = max(2, args.steps // 2)
+        if extras and prof_env != "plain":
+            plain, _ = profile_record(api, pkg, blobs, params, local, "plain", sub_steps, names,
+                                      "CSH_PROFILE=plain: jpeg_simple_progression, no scan search; byte-identical to libjpeg-turbo (tests/test_oracle_jpeg.py)", parity_idx[:2])
+        if extras and prof_env != "mozjpeg":
+            moz, mtm = profile_record(api, pkg, blobs, params, local, "mozjpeg", sub_steps, names,
+                                      "CSH_PROFILE=mozjpeg: the whole JCP_MAX_COMPRESSION profile libcaesium's -q runs -- scan search + trellis quantisation (k_trellis_ac / k_trellis_dc "
+                                      "after a statistics scan) + overshoot deringing; device == oracle byte for byte, oracle restated from recall of mozjpeg 4.1 (UNPINNED: "
+                                      "tests/golden/make_reference_goldens.sh is the recipe that pins it)", parity_idx[:2])
+            i_tr = names.index("k_trellis_ac")
+            tr_ms = sum(x.kernel_ms[i_tr] for x in mtm) / len(mtm)
+            moz["roofline_k_trellis_ac"] = {"bound": "hbm", "avg_ms": round(tr_ms, 3), "algorithmic_bytes": int(2 * coefb), "achieved": round(2 * coefb / (tr_ms * 1e-3) / 1e9, 1),
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(2 * coefb / (tr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "note": "a per-block dynamic programme (float cost minimisation over list entries): bound by instruction issue and LDS latency, not by HBM"}
         if extras and args.cpu_images > 0:
             n = args.cpu_images
             c0 = time.perf_counter()
             for i in range(n):
                 oracle_lossy(blobs[i % len(blobs)])
             cdt = time.perf_counter() - c0
-            cpu = {"value": round(n * 2.0736 / cdt, 2), "unit": "MP/s", "cores": 1, "kind": "port",
-                   "sample": f"{n} of the same 1080p files through oracle/jpeg_oracle.c (decode+IDCT+FDCT+quant+progressive optimal-Huffman), 1 thread, {cdt:.1f} s"}
+            cpu = {"value": round(n * MP_1080P / cdt, 2), "unit": "MP/s", "cores": 1, "kind": "port",
+                   "sample": f"{n} of the same 1080p files through oracle/jpeg_oracle.c (decode+IDCT+FDCT+quant+scan search+progressive optimal-Huffman: the default profile), 1 thread, {cdt:.1f} s"}
             # the same port on every host core (the reference's rayon par_iter shape), and the libjpeg-turbo proxy (Pillow: decode to YCbCr,
             # re-encode q80 4:2:0 progressive + optimised tables -- the plain profile the oracle is pinned to) on every core
-            from concurrent.futures import ThreadPoolExecutor
             cores = os.cpu_count() or 1
-            m = min(max(cores * 8, n), 16 * n)
-            c0 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(lambda i: len(oracle_lossy(blobs[i % len(blobs)])), range(m)))   # ctypes releases the GIL inside the oracle
-            cdt = time.perf_counter() - c0
-            cpu_all = {"value": round(m * 2.0736 / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port", "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
-            c0 = time.perf_counter()
-            with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(lambda i: len(pillow_proxy(blobs[i % len(blobs)])), range(m)))
-            cdt = time.perf_counter() - c0
-            cpu_pillow = {"value": round(m * 2.0736 / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "libjpeg-turbo proxy (Pillow), not libcaesium",
+            m = min(max(cores * 6, n), 16 * n)
+            cdt = timed_threads(lambda i: len(oracle_lossy(blobs[i % len(blobs)])), range(m), cores)   # ctypes releases the GIL inside the oracle
+            cpu_all = {"value": round(m * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port", "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+            cdt = timed_threads(lambda i: len(pillow_proxy(blobs[i % len(blobs)])), range(m), cores)
+            cpu_pillow = {"value": round(m * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "libjpeg-turbo proxy (Pillow), not libcaesium",
                           "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+            # the oracle doing what libcaesium's -q does (trellis + deringing + scan search): what the mozjpeg_profile record is to be read against
+            set_profile("mozjpeg")
+            try:
+                mm = min(m, cores * 4)
+                cdt = timed_threads(lambda i: len(oracle_lossy(blobs[i % len(blobs)])), range(mm), cores)
+                cpu_moz = {"value": round(mm * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
+                           "sample": f"{mm} files through the oracle with trellis + deringing + scan search, {cores} threads, {cdt:.1f} s"}
+            finally:
+                set_profile(prof_env)
+            if moz is not None:
+                moz["cpu_baseline_all_cores"] = cpu_moz
         other = None
         if extras:
-            # the other single-GPU configurations of BASELINE.json, as sub-records (device time of the whole path, inputs resident in HBM):
-            # configs[2] 3840x2160 RGB8 PNGs --lossless --png-opt-level 3; configs[3] the same 1080p JPEGs -> WebP q85 at long edge 1500
-            other = {}
-            try:
-                from gen_synth import synth_png
-                import multiprocessing as mp
-                with mp.get_context("fork").Pool(4) as pool:
-                    pngs = pool.starmap(synth_png, [(100 + k, 3840, 2160, "RGB") for k in range(4)])
-                npng = 128   # k_png_huff is one wave per zlib stream (a latency of ~2.3 s for a 4K file, whatever the count): the batch must be wide
-                pp = pkg.default_parameters(png_optimize=True, png_optimization_level=3)
-                warm = api.png_batch(pngs[:2], pp, device=local); warm.run(); warm.close()     # code objects and allocator warm; the timed batch is new
-                pb = api.png_batch([pngs[k % 4] for k in range(npng)], pp, device=local)
-                ptm = pb.run()                                                                  # its FIRST run: a second one would find the files already inflated
-                pouts = pb.fetch()
-                pn = api.png_kernel_names()
-                pdom = max(range(len(pn)), key=lambda i: ptm.kernel_ms[i])
-                other["configs[2] 4K PNG --lossless -o3"] = {
-                    "files": npng, "value": round(npng * 3840 * 2160 / 1e6 / (ptm.total_ms / 1e3), 1), "unit": "MP/s", "device_ms": round(ptm.total_ms, 1),
-                    "in_bytes": sum(len(pngs[k % 4]) for k in range(npng)), "out_bytes": sum(len(o) for o in pouts if isinstance(o, bytes)),
-                    "dominant_kernel": pn[pdom], "dominant_ms": round(ptm.kernel_ms[pdom], 1),
-                    "kernel_ms": {pn[i]: round(ptm.kernel_ms[i], 1) for i in range(len(pn)) if pn[i] and ptm.kernel_ms[i] >= 0.05},
-                    "note": "the k_png_inflate slot (k_png_huff + k_png_lz77) is one wave per zlib stream: a latency, the same for 16 or 500 files; the other kernels scale with the file count"}
-                pb.close()
-            except Exception as e:   # a sub-record must not take the headline down
-                other["configs[2] 4K PNG --lossless -o3"] = {"error": str(e)[:200]}
-            try:
-                nweb = 1024   # the macroblock and boolean-coder kernels are one wave per (picture, partition): 256 files leave the chip half empty
-                wb = api.webp_batch([blobs[k % len(blobs)] for k in range(nweb)], pkg.default_parameters(webp_quality=85, width=1500), device=local)
-                wb.run()
-                wtm = wb.run()
-                wdom = max(range(len(names)), key=lambda i: wtm.kernel_ms[i])
-                other["configs[3] JPEG -> WebP q85 long edge 1500"] = {
-                    "files": nweb, "value": round(nweb * 2.0736 / (wtm.total_ms / 1e3), 1), "unit": "source MP/s", "device_ms": round(wtm.total_ms, 1), "out_bytes": int(wtm.out_bytes),
-                    "dominant_slot": "WebP tail (Lanczos, RGB -> YUV, k_webp_mb, k_webp_stats, k_webp_code: one timing slot; split in profiles/r02_webp_kernel_stats_batch1024.csv)",
-                    "dominant_ms": round(wtm.kernel_ms[wdom], 1)}
-                wb.close()
-            except Exception as e:
-                other["configs[3] JPEG -> WebP q85 long edge 1500"] = {"error": str(e)[:200]}
+            other = other_configs(api, pkg, blobs, local)
         if extras and args.boundary_files > 0:
             # the boundary itself: cs_batch_compress, host buffers in -> host buffers out (marker parse, pinned upload, kernels, download);
             # PCIe and the host side are inside this number and never inside `value`
@@ -318,18 +439,21 @@ def main():
             res = api.cs_batch_compress(blobs[:nb], params, device=local, timing=tm)
             ok = sum(1 for r in res if isinstance(r, bytes))
             boundary = {"entry": "cs_batch_compress", "files": nb, "ok": ok, "seconds": round(tm[0], 4), "files_per_s": round(nb / tm[0], 1),
-                        "value": round(nb * 2.0736 / tm[0], 1), "unit": "MP/s", "note": "host buffers in and out, one call, second call of the process"}
+                        "value": round(nb * MP_1080P / tm[0], 1), "unit": "MP/s", "note": "host buffers in and out, one call, second call of the process"}
+        if extras and args.cli_files > 0:
+            cli = cli_end_to_end(blobs, min(args.cli_files, 4096))
         out = {
             "metric": "megapixels/sec JPEG q=80 1920x1080 batch", "value": round(value, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 1920x1080 q92 4:2:0 baseline JPEGs -> -q 80 progressive, inputs resident in HBM",
-                       "files_per_gpu_per_step": args.batch, "unique_images": args.unique, "sharding": f"files/{world} ranks, no collective",
+                       "files_per_gpu_per_step": args.batch, "unique_images": nuniq, "sharding": f"files/{world} ranks, no collective",
                        "profile": profile},
-            "parity_spot_check": bool(parity),
+            "parity_spot_check": bool(parity), "parity_files_checked": len(parity_idx),
             "device_ms_per_step": round(sum(tm.total_ms for tm in timings) / len(timings), 3),
             "kernel_ms": {names[i]: round(kms[i], 4) for i in range(len(names)) if names[i]},
-            "roofline": roof, "phases": phases, "plain_profile": plain, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow, "boundary": boundary, "other_configs": other,
+            "roofline": roof, "phases": phases, "plain_profile": plain, "mozjpeg_profile": moz, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow,
+            "boundary": boundary, "cli_end_to_end": cli, "other_configs": other,
             "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
             "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},
         }
@@ -337,6 +461,153 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     return out
+
+
+def cli_end_to_end(blobs, n):
+    """the drop-in binary, files in -> files out: caesiumclt -q 80 over n 1080p files in a directory (tmpfs when there is one), the
+    reference's own shape of a run (/root/reference/src/main.rs:43-113); wall clock of the whole process, second run of two"""
+    d = scratch_dir()
+    try:
+        os.makedirs(os.path.join(d, "in"))
+        for k in range(n):
+            with open(os.path.join(d, "in", f"f{k:05d}.jpg"), "wb") as f:
+                f.write(blobs[k % len(blobs)])
+        best = None
+        for _ in range(2):
+            shutil.rmtree(os.path.join(d, "out"), ignore_errors=True)
+            secs, r = run_cli(["-q", "80", "--quiet", "-o", os.path.join(d, "out"), os.path.join(d, "in")])
+            if r.returncode != 0:
+                return {"error": f"caesiumclt exited {r.returncode}: {r.stderr.decode()[-200:]}"}
+            best = secs
+        nout = len(os.listdir(os.path.join(d, "out")))
+        return {"command": "caesiumclt -q 80 --quiet -o out/ in/", "files": n, "files_written": nout, "seconds": round(best, 3), "files_per_s": round(n / best, 1),
+                "value": round(n * MP_1080P / best, 1), "unit": "MP/s", "where": os.path.dirname(d),
+                "note": "process start, directory scan, reads, parse, upload, kernels, download and writes all inside the number; second run of two"}
+    except Exception as e:
+        return {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def other_configs(api, pkg, blobs, local):
+    """the other single-GPU configurations of BASELINE.json as sub-records (device time of the whole path, inputs resident in HBM), each with
+    the roofline of its dominant kernel (SURVEY 8d's algorithmic bytes) and CPU lines timed on this host:
+    configs[2] 3840x2160 RGB8 PNGs --lossless --png-opt-level 3; configs[3] the same 1080p JPEGs -> WebP q85 at long edge 1500;
+    configs[4] a mixed JPEG / PNG / WebP tree through the caesiumclt binary (-R -S -q 80), files in -> files out"""
+    other = {}
+    cores = os.cpu_count() or 1
+    try:
+        from gen_synth import synth_png
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(4) as pool:
+            pngs = pool.starmap(synth_png, [(100 + k, 3840, 2160, "RGB") for k in range(4)])
+        npng = 128   # k_png_huff is one wave per zlib stream (a latency of ~0.4 s for a 4K file, whatever the count): the batch must be wide
+        pp = pkg.default_parameters(png_optimize=True, png_optimization_level=3)
+        warm = api.png_batch(pngs[:2], pp, device=local); warm.run(); warm.close()     # code objects and allocator warm; the timed batch is new
+        pb = api.png_batch([pngs[k % 4] for k in range(npng)], pp, device=local)
+        ptm = pb.run()                                                                  # its FIRST run: a second one would find the files already inflated
+        pouts = pb.fetch()
+        pn = api.png_kernel_names()
+        pdom = max(range(len(pn)), key=lambda i: ptm.kernel_ms[i])
+        raw_bytes = 2160 * (1 + 3840 * 3)   # filtered stream of one file: 24 885 360 B (SURVEY 8d)
+        # algorithmic bytes per launch, per file: inflate R idat + W raw; a tokenizer / filter pass over the four trial streams of -o3: R 4 x raw
+        per_file = {"k_png_inflate": 13_000_000 + raw_bytes, "k_png_hist": 4 * raw_bytes, "k_png_brute": 5 * raw_bytes, "k_png_scores": 5 * raw_bytes,
+                    "k_png_emit": raw_bytes, "k_png_unfilter": 2 * raw_bytes, "k_png_filter5": 6 * raw_bytes}
+        abp = per_file.get(pn[pdom], raw_bytes) * npng
+        rec = {"files": npng, "value": round(npng * 3840 * 2160 / 1e6 / (ptm.total_ms / 1e3), 1), "unit": "MP/s", "device_ms": round(ptm.total_ms, 1),
+               "in_bytes": sum(len(pngs[k % 4]) for k in range(npng)), "out_bytes": sum(len(o) for o in pouts if isinstance(o, bytes)),
+               "dominant_kernel": pn[pdom], "dominant_ms": round(ptm.kernel_ms[pdom], 1),
+               "kernel_ms": {pn[i]: round(ptm.kernel_ms[i], 1) for i in range(len(pn)) if pn[i] and ptm.kernel_ms[i] >= 0.05},
+               "roofline": {"bound": "hbm", "kernel": pn[pdom], "avg_ms": round(ptm.kernel_ms[pdom], 1), "algorithmic_bytes": int(abp), "achieved": round(abp / (ptm.kernel_ms[pdom] * 1e-3) / 1e9, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(abp / (ptm.kernel_ms[pdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "note": "latency-bound stream work (one workgroup per zlib stream / dependent match loads), not bandwidth-bound"},
+               "note": "the k_png_inflate slot (k_png_huff + k_png_lz77) is one workgroup per zlib stream: a latency, the same for 16 or 500 files; the other kernels scale with the file count"}
+        pb.close()
+        # CPU lines: libpng / zlib level 9 through Pillow on every core (BASELINE.md section 3's proxy), and the oracle (1 thread, a 1080p file: the 4K one takes a minute)
+        m = min(cores, 128)
+        cdt = timed_threads(lambda i: len(pillow_png_proxy(pngs[i % 4])), range(m), cores)
+        rec["cpu_proxy_pillow"] = {"value": round(m * 3840 * 2160 / 1e6 / cdt, 2), "unit": "MP/s", "cores": min(cores, m), "kind": "libpng + zlib-9 proxy (Pillow), not oxipng",
+                                   "sample": f"{m} of the same 4K files, decode + re-encode compress_level 9, {cdt:.1f} s"}
+        from _util import oracle_png
+        small = _one_png_1080(100)
+        c0 = time.perf_counter()
+        oracle_png(small, 3)
+        cdt = time.perf_counter() - c0
+        rec["cpu_baseline"] = {"value": round(MP_1080P / cdt, 3), "unit": "MP/s", "cores": 1, "kind": "port",
+                               "sample": f"one 1920x1080 RGB8 file of the same recipe through oracle/png_oracle.c at -o3 (4 trials), 1 thread, {cdt:.1f} s"}
+        other["configs[2] 4K PNG --lossless -o3"] = rec
+    except Exception as e:   # a sub-record must not take the headline down
+        other["configs[2] 4K PNG --lossless -o3"] = {"error": str(e)[:200]}
+    try:
+        nweb = 1024   # the macroblock and boolean-coder kernels are one wave per (picture, partition): 256 files leave the chip half empty
+        wb = api.webp_batch([blobs[k % len(blobs)] for k in range(nweb)], pkg.default_parameters(webp_quality=85, width=1500), device=local)
+        wb.run()
+        wtm = wb.run()
+        wn = api.webp_kernel_names()
+        wdom = max(range(len(wn)), key=lambda i: wtm.kernel_ms[i])
+        # SURVEY 8d: Lanczos R 6 220 800 / W 3 798 000 per file; the VP8 tail reads the 1500 x 844 YUV 4:2:0 (1 899 000 B) and writes levels + the file
+        per_file = {"resize": 6_220_800 + 3_798_000, "k_webp_yuv": 3_798_000 + 1_899_000, "k_webp_mb": 2 * 1_899_000, "k_webp_stats+probs+code+assemble": 1_899_000 + int(wtm.out_bytes) // nweb}
+        abw = per_file.get(wn[wdom], 1_899_000) * nweb
+        rec = {"files": nweb, "value": round(nweb * MP_1080P / (wtm.total_ms / 1e3), 1), "unit": "source MP/s", "device_ms": round(wtm.total_ms, 1), "out_bytes": int(wtm.out_bytes),
+               "dominant_kernel": wn[wdom], "dominant_ms": round(wtm.kernel_ms[wdom], 1),
+               "kernel_ms": {wn[i]: round(wtm.kernel_ms[i], 1) for i in range(len(wn)) if wn[i] and wtm.kernel_ms[i] >= 0.05},
+               "roofline": {"bound": "hbm", "kernel": wn[wdom], "avg_ms": round(wtm.kernel_ms[wdom], 1), "algorithmic_bytes": int(abw), "achieved": round(abw / (wtm.kernel_ms[wdom] * 1e-3) / 1e9, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(abw / (wtm.kernel_ms[wdom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "note": "serial chains per picture / partition (intra prediction from reconstructed neighbours, the boolean coder): issue- and latency-bound"}}
+        wb.close()
+        m = min(cores * 2, 512)
+        cdt = timed_threads(lambda i: len(pillow_webp_proxy(blobs[i % len(blobs)])), range(m), cores)
+        rec["cpu_proxy_pillow"] = {"value": round(m * MP_1080P / cdt, 2), "unit": "source MP/s", "cores": cores, "kind": "libjpeg-turbo + Pillow Lanczos + libwebp method 4 proxy, not libcaesium",
+                                   "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+        from _util import oracle_jpeg_to_webp
+        c0 = time.perf_counter()
+        for i in range(2):
+            oracle_jpeg_to_webp(blobs[i], 85, 1500, 0)
+        cdt = time.perf_counter() - c0
+        rec["cpu_baseline"] = {"value": round(2 * MP_1080P / cdt, 2), "unit": "source MP/s", "cores": 1, "kind": "port",
+                               "sample": f"2 of the same files through the oracle (libjpeg decode, Lanczos3, oracle/webp_oracle.c), 1 thread, {cdt:.1f} s"}
+        other["configs[3] JPEG -> WebP q85 long edge 1500"] = rec
+    except Exception as e:
+        other["configs[3] JPEG -> WebP q85 long edge 1500"] = {"error": str(e)[:200]}
+    try:
+        other["configs[4] mixed JPEG/PNG/WebP tree, caesiumclt -R -S -q 80"] = mixed_tree(blobs)
+    except Exception as e:
+        other["configs[4] mixed JPEG/PNG/WebP tree, caesiumclt -R -S -q 80"] = {"error": str(e)[:200]}
+    return other
+
+
+def mixed_tree(blobs, per_type=96):
+    """configs[4] on ONE device (the driver shards it over 8 with --gpus; SURVEY 8d cfg 5): a directory tree of the cfg-2 JPEGs and 1080p PNGs
+    and WebPs of the same recipe, 1:1:1, through the binary: caesiumclt -q 80 -R -S -o out tree/ -- files in -> files out, wall clock"""
+    d = scratch_dir()
+    try:
+        pngs = pool_map(_one_png_1080, range(200, 200 + 8))
+        webps = pool_map(_one_webp_1080, range(300, 300 + 8))
+        layout = {"a": ("jpg", lambda k: blobs[k % len(blobs)]), os.path.join("b", "c"): ("png", lambda k: pngs[k % 8]), os.path.join("d", "e", "f"): ("webp", lambda k: webps[k % 8])}
+        nbytes = 0
+        for sub, (ext, get) in layout.items():
+            os.makedirs(os.path.join(d, "tree", sub))
+            for k in range(per_type):
+                data = get(k)
+                nbytes += len(data)
+                with open(os.path.join(d, "tree", sub, f"m{k:04d}.{ext}"), "wb") as f:
+                    f.write(data)
+        secs, r = run_cli(["-q", "80", "-R", "-S", "--json", "-o", os.path.join(d, "out"), os.path.join(d, "tree")])
+        if r.returncode != 0:
+            return {"error": f"caesiumclt exited {r.returncode}: {r.stderr.decode()[-200:]}"}
+        res = json.loads(r.stdout.decode())
+        files = res.get("files", [])
+        ok = sum(1 for f in files if str(f.get("status", "")).lower() == "success")
+        by_status = {}
+        for f in files:
+            by_status[str(f.get("status"))] = by_status.get(str(f.get("status")), 0) + 1
+        nout = sum(len(fs) for _, _, fs in os.walk(os.path.join(d, "out")))
+        n = 3 * per_type
+        return {"command": "caesiumclt -q 80 -R -S --json -o out/ tree/", "files": n, "per_type": per_type, "status": by_status, "success": ok, "files_written": nout,
+                "in_bytes": nbytes, "seconds": round(secs, 3), "files_per_s": round(n / secs, 1), "value": round(n * MP_1080P / secs, 1), "unit": "MP/s",
+                "note": "one device, first run of the process, everything inside (scan, reads, three codec rows, writes); PNG -q goes through the lossy PNG row, WebP inputs through the VP8 decoder"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -1139,13 +1139,17 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
-    "k_idct_plane", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc", "k_tokens",
+    "k_idct_plane", "resize", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc", "k_tokens",
     "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack",
-    "k_ff_count", "scan_chunks", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", ""};
+    "k_ff_count", "scan_chunks", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", ""};
+// a WebP batch (csh_batch_create_webp) leaves the JPEG path behind the resize slot: its next three slots are these
+static const char *const kWebpTailNames[3] = {"k_webp_yuv", "k_webp_mb", "k_webp_stats+probs+code+assemble"};
+
 // the trellis slots (statistics scan = k_tokens without tokens + k_ac_runs + k_gen_tables; the two k_trellis kernels + k_fix_dummy) count
 // as phase 1: they are the quantiser; zero unless CSH_PROFILE=mozjpeg
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 3, 4, 4, 4, 5, 6, 6, 7, 6, 6, 6, 7, 7, 7};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 3, 4, 4, 4, 5, 6, 6, 7, 6, 6, 6, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
+extern "C" const char *csh_kernel_name_webp(int i) { return (i >= 10 && i < 13) ? kWebpTailNames[i - 10] : csh_kernel_name(i); }
 
 // the WebP tail of a run: RGB (resize branch) -> YUV 4:2:0 -> macroblocks -> tokens; files land in the batch's output pool at
 // fixed offsets (capacity per macroblock grows on overflow, like the JPEG pools)
@@ -1174,7 +1178,9 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     CSH_CHECK(hipMemcpyAsync(b->d_img_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     if (b->d_img_size.zero(st)) return -1;
     csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
+    CSH_CHECK(hipEventRecord(ev[++slot], st));
     { uint32_t mw = 0, mh = 0; for (const csw::WebpImg &wi : b->wimgs) { mw = std::max(mw, wi.mbw); mh = std::max(mh, wi.mbh); } csw::launch_webp_mb(st, b->d_wimgs.p, nimg, mw, mh, b->d_wwork.p, b->d_wlevels.p); }
+    CSH_CHECK(hipEventRecord(ev[++slot], st));
     csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p,
                           b->d_img_size.p, b->d_status.p);
     CSH_CHECK(hipEventRecord(ev[++slot], st));
@@ -1325,7 +1331,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
         launch_requant(st, b->d_imgs.p, b->d_pwork.p, int(b->pwork.size()), b->max_tiles, b->d_quants.p, b->d_dct_raw.p, b->ntiles_in, b->d_coef.p);
         launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
-        slot = 12;   // kernel_ms slots of the decode + pixel phases: only the first carries time (k_requant + k_fix_dummy)
+        slot = 13;   // kernel_ms slots of the decode + pixel phases: only the first carries time (k_requant + k_fix_dummy)
         for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
     } else {
     // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
@@ -1395,6 +1401,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     MARK();
     launch_resize(st, b->d_imgs.p, b->d_rwork.p, int(b->rwork.size()), b->d_rtaps.p, b->d_rweights.p, b->d_planes.p, b->d_rgb.p, b->d_rtmp.p,
                   b->max_src_px, b->max_tmp, b->max_dst, b->max_row_in, b->max_out_w, b->max_nh, !(b->webp || b->rgb_out));
+    MARK();
     if (b->webp) return run_webp(b, t, ev, slot);
     if (b->rgb_out) return run_rgb_only(b, t, ev, slot);
     int16_t *rawp = ((b->retain_dct || b->trellis) && !b->lossless) ? b->d_dct_raw.p : nullptr;   // the trellis quantiser works from the unquantised DCT

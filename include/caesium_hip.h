@@ -136,6 +136,7 @@ typedef struct {
 int csh_device_count(void);
 const char *csh_last_error(void);
 const char *csh_kernel_name(int slot);
+const char *csh_kernel_name_webp(int slot);   /* the same for a csh_batch_create_webp batch: behind the resize slot come the VP8 tail's kernels */
 int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
 /* the same batch with WebP as the target container (convert_in_memory to WebP, compressor.rs:289,300): decode, optional
    resize, then the VP8 encoder; run / fetch / destroy as for any csh_batch */
