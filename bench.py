@@ -84,7 +84,9 @@ def live_pmc(kernel, batch, profile, timeout=240):
         cmd = [exe, "--pmc", counter, "--kernel-include-regex", key.replace("<", "."), "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(batch)]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            if r.returncode != 0:
+                return None, dict(detail, error=f"{counter}: rocprofv3 exited {r.returncode}: ...{r.stderr.decode(errors='replace')[-300:]}")
             vals = []
             for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(fn)):
@@ -96,7 +98,7 @@ def live_pmc(kernel, batch, profile, timeout=240):
             detail[counter] = {"dispatches": len(vals), "bytes_per_launch": int(per_launch), "scale": scale}
             total += per_launch
         except Exception as e:   # a profiler problem must not take the headline down
-            return None, dict(detail, error=f"{counter}: {str(e)[:160]}")
+            return None, dict(detail, error=f"{counter}: {type(e).__name__}: {str(e)[-200:]}")
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return int(total), detail
@@ -472,17 +474,21 @@ def cli_end_to_end(blobs, n):
         for k in range(n):
             with open(os.path.join(d, "in", f"f{k:05d}.jpg"), "wb") as f:
                 f.write(blobs[k % len(blobs)])
-        best = None
+        runs, traces = [], []
         for _ in range(2):
             shutil.rmtree(os.path.join(d, "out"), ignore_errors=True)
-            secs, r = run_cli(["-q", "80", "--quiet", "-o", os.path.join(d, "out"), os.path.join(d, "in")])
+            secs, r = run_cli(["-q", "80", "--quiet", "-o", os.path.join(d, "out"), os.path.join(d, "in")], env=dict(os.environ, CSH_TRACE="1"))
             if r.returncode != 0:
                 return {"error": f"caesiumclt exited {r.returncode}: {r.stderr.decode()[-200:]}"}
-            best = secs
+            runs.append(round(secs, 3))
+            traces.append([ln for ln in r.stderr.decode(errors="replace").splitlines() if ln.startswith("[cli]")][-1:])
+        best = min(runs)
         nout = len(os.listdir(os.path.join(d, "out")))
-        return {"command": "caesiumclt -q 80 --quiet -o out/ in/", "files": n, "files_written": nout, "seconds": round(best, 3), "files_per_s": round(n / best, 1),
-                "value": round(n * MP_1080P / best, 1), "unit": "MP/s", "where": os.path.dirname(d),
-                "note": "process start, directory scan, reads, parse, upload, kernels, download and writes all inside the number; second run of two"}
+        return {"command": "caesiumclt -q 80 --quiet -o out/ in/", "files": n, "files_written": nout, "seconds": best, "seconds_each_run": runs, "files_per_s": round(n / best, 1),
+                "value": round(n * MP_1080P / best, 1), "unit": "MP/s", "where": os.path.dirname(d), "stages": traces,
+                "note": "one process per run, as the reference tool: process start, HIP initialisation and first-launch code loading, directory scan, reads, parse, device pool "
+                        "allocation, upload, kernels, download and writes all inside the number; the faster of two runs (a run right behind another process's exit waits for the "
+                        "driver to hand its VRAM back: `stages` shows where the time went)"}
     except Exception as e:
         return {"error": str(e)[:200]}
     finally:

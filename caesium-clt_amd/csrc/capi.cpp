@@ -31,7 +31,18 @@ static CCSResult make_result(int code, const char *msg) {
 enum { CS_GROUP = 2048 };
 // declared pixel count of a JPEG / PNG (0 when the header does not say): what a file will occupy on the device is known before
 // anything is decoded
+// canvas of a WebP file from its first chunk: VP8X (24-bit width-1 / height-1), a bare VP8 key frame (14-bit sizes behind the start
+// code) or a bare VP8L stream (14 + 14 bits behind the signature); 0 when the header does not say
+static uint64_t webp_declared_pixels(const uint8_t *d, size_t n) {
+    if (n < 30 || memcmp(d, "RIFF", 4) || memcmp(d + 8, "WEBP", 4)) return 0;
+    const uint8_t *f = d + 20;
+    if (!memcmp(d + 12, "VP8X", 4)) return (uint64_t(f[4] | (f[5] << 8) | (f[6] << 16)) + 1) * (uint64_t(f[7] | (f[8] << 8) | (f[9] << 16)) + 1);
+    if (!memcmp(d + 12, "VP8 ", 4)) return (f[3] == 0x9D && f[4] == 0x01 && f[5] == 0x2A) ? uint64_t((f[6] | (f[7] << 8)) & 0x3FFF) * uint64_t((f[8] | (f[9] << 8)) & 0x3FFF) : 0;
+    if (!memcmp(d + 12, "VP8L", 4) && f[0] == 0x2F) { const uint32_t b = uint32_t(f[1]) | (uint32_t(f[2]) << 8) | (uint32_t(f[3]) << 16) | (uint32_t(f[4]) << 24); return uint64_t((b & 0x3FFF) + 1) * uint64_t(((b >> 14) & 0x3FFF) + 1); }
+    return 0;
+}
 static uint64_t declared_pixels(const uint8_t *d, size_t n) {
+    if (n >= 30 && !memcmp(d, "RIFF", 4)) return webp_declared_pixels(d, n);
     if (n >= 24 && !memcmp(d, "\x89PNG\r\n\x1a\n", 8)) {
         const uint64_t w = (uint64_t(d[16]) << 24) | (d[17] << 16) | (d[18] << 8) | d[19], h = (uint64_t(d[20]) << 24) | (d[21] << 16) | (d[22] << 8) | d[23];
         return w * h;
@@ -66,8 +77,8 @@ size_t cs_batch_extent(const CByteArray *inputs, size_t count) {
 static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
     for (size_t i = 0; i < count; i++) { outputs[i].data = nullptr; outputs[i].length = 0; }
     int failed_total = 0;
-    size_t limit = CS_GROUP;   // halved when a whole group fails for want of memory: one oversized neighbour must not fail 2047 others
-    for (size_t g0 = 0; g0 < count;) {
+    size_t limit = CS_GROUP;   // halved when a whole group fails for want of memory: one oversized neighbour must not fail 2047 others;
+    for (size_t g0 = 0; g0 < count;) {   // back to the full group once a group has gone through (the shortage belonged to those files)
         size_t n = cs_batch_extent(inputs + g0, count - g0);
         if (n > limit) n = limit;
         csh_batch *b = nullptr;
@@ -95,6 +106,7 @@ static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCS
         }
         failed_total += failed < 0 ? int(n) : failed;
         g0 += n;
+        limit = CS_GROUP;
     }
     return failed_total;
 }
@@ -160,7 +172,8 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
     const uint8_t *d = src.data;
     const size_t n = src.length;
     const bool extended = out.data && out.length >= 38 && !memcmp(out.data + 12, "VP8X", 4);   // made here: VP8X, ALPH, VP8 (a picture with transparency)
-    if (n < 20 || !out.data || out.length < 30 || (memcmp(out.data + 12, "VP8 ", 4) && !extended)) return;
+    const bool lossless = out.data && out.length >= 26 && !memcmp(out.data + 12, "VP8L", 4) && out.data[20] == 0x2F;   // webp.lossless: a bare VP8L stream
+    if (n < 20 || !out.data || out.length < 26 || (memcmp(out.data + 12, "VP8 ", 4) && !extended && !lossless)) return;
     const uint8_t *icc = nullptr, *exif = nullptr;
     size_t icc_len = 0, exif_len = 0;
     for (size_t i = 12; i + 8 <= n;) {
@@ -172,9 +185,11 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
     }
     if (!icc && !exif) return;
     const uint8_t *f = out.data + 20;   // VP8 frame header: tag (3), start code (3), 14-bit width and height -- or the VP8X chunk's flags and canvas size
-    const uint32_t w = extended ? (uint32_t(f[4]) | (uint32_t(f[5]) << 8) | (uint32_t(f[6]) << 16)) + 1 : (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFFu;
-    const uint32_t h = extended ? (uint32_t(f[7]) | (uint32_t(f[8]) << 8) | (uint32_t(f[9]) << 16)) + 1 : (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFFu;
-    const uint8_t flags0 = extended ? f[0] : 0;
+    // a VP8L stream says its size (14 + 14 bits, each minus one) and whether its alpha is in use right behind the signature byte
+    const uint32_t lbits = lossless ? uint32_t(f[1]) | (uint32_t(f[2]) << 8) | (uint32_t(f[3]) << 16) | (uint32_t(f[4]) << 24) : 0u;
+    const uint32_t w = lossless ? (lbits & 0x3FFFu) + 1 : extended ? (uint32_t(f[4]) | (uint32_t(f[5]) << 8) | (uint32_t(f[6]) << 16)) + 1 : (uint32_t(f[6]) | (uint32_t(f[7]) << 8)) & 0x3FFFu;
+    const uint32_t h = lossless ? ((lbits >> 14) & 0x3FFFu) + 1 : extended ? (uint32_t(f[7]) | (uint32_t(f[8]) << 8) | (uint32_t(f[9]) << 16)) + 1 : (uint32_t(f[8]) | (uint32_t(f[9]) << 8)) & 0x3FFFu;
+    const uint8_t flags0 = lossless ? uint8_t(((lbits >> 28) & 1u) ? 0x10 : 0) : extended ? f[0] : 0;   // VP8X alpha flag from the stream's alpha_is_used bit
     const size_t body0 = extended ? 30 : 12, body = out.length - body0;   // the chunks behind the file header (and behind VP8X), with their padding
     const size_t total = 12 + 18 + (icc ? 8 + icc_len + (icc_len & 1) : 0) + body + (exif ? 8 + exif_len + (exif_len & 1) : 0);
     uint8_t *o = static_cast<uint8_t *>(malloc(total));
@@ -201,13 +216,28 @@ static void webp_carry_metadata(const CByteArray &src, CByteArray &out) {
 
 static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParameters *p, uint32_t target, int device, CByteArray *outputs, CCSResult *results) {
     int failed_total = 0;
+    // groups by what the decoder reserves, not by file bytes: per declared pixel 3 B of RGB, 5 B of alpha room and 8 B of VP8L work area
+    // (+ 4 MiB + 16 x the file), so ~20 B per pixel of the canvas the header declares -- a tiny file may declare 16383 x 16383.  A group
+    // that still fails for want of memory is halved and tried again (as the JPEG row does), so that one oversized header fails alone.
+    const uint64_t pool_cap = uint64_t(64) << 30;
+    size_t limit = 512;
     for (size_t g0 = 0, n = 0; g0 < count; g0 += n) {
-        uint64_t bytes = 0;
-        for (n = 0; g0 + n < count && n < 512 && (!n || bytes + inputs[g0 + n].length <= (uint64_t(256) << 20)); n++) bytes += inputs[g0 + n].length;
+        uint64_t bytes = 0, pools = 0;
+        for (n = 0; g0 + n < count && n < limit; n++) {
+            const uint64_t est = webp_declared_pixels(inputs[g0 + n].data, inputs[g0 + n].length) * 20 + 16 * uint64_t(inputs[g0 + n].length) + (uint64_t(4) << 20);
+            if (n && (bytes + inputs[g0 + n].length > (uint64_t(256) << 20) || pools + est > pool_cap)) break;
+            bytes += inputs[g0 + n].length; pools += est;
+        }
         for (size_t k = 0; k < n; k++) { outputs[g0 + k].data = nullptr; outputs[g0 + k].length = 0; }
         cswd_batch *wb = nullptr;
         int rc = cswd_batch_create(inputs + g0, n, device, &wb);
         if (rc == 0) rc = cswd_batch_run(wb);
+        if (rc != 0 && n > 1 && (rc == CS_ERR_NO_DEVICE || rc == CS_ERR_POOL_OVERFLOW) && csh_device_count() > device) {   // same files again, in smaller groups
+            cswd_batch_destroy(wb);
+            limit = (n + 1) / 2; n = 0;
+            continue;
+        }
+        limit = 512;
         std::vector<csp_pixels> px;
         std::vector<const uint8_t *> aplane;   // per picture: its alpha plane in device memory, or null (opaque)
         std::vector<size_t> at;

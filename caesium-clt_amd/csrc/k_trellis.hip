@@ -74,19 +74,22 @@ struct TrLds {
     float (*A)[256];      // [entry][lane]: cost of the cheapest path that ends with this entry
     float (*Z)[256];      // before the entry's step: Z just in front of its position; after it: Z at its position
     uint32_t (*P)[256];   // before: |DCT| (15) | position << 15 (6) | scalar level << 21 (10) | sign << 31;  after: predecessor entry + 1 (6) | position << 15 | chosen level << 21 | sign << 31
-    const uint8_t *len;   // AC code lengths of the statistics pass (0 = symbol unused)
+    const uint8_t *len;   // AC symbol costs of the statistics pass: code length + size bits (the symbol's low nibble); 0 = symbol unused
     const int32_t *q8;    // 8 q, zig-zag order
+    const float *rcp;     // 1 / (8 q)
     const float *lt;      // 1 / q^2
 };
 
 // tables of the chunk's component -> LDS (all 256 lanes)
-__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, uint8_t *s_len, int32_t *s_q8, float *s_lt) {
+// (the sweep reads the quantiser's three values per position from here: as loads from HBM they were 189 dependent round trips per wave)
+__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, uint8_t *s_len, int32_t *s_q8, float *s_rcp, float *s_lt) {
     const TrellisWork &w = c.work[c.chunks[chi].work];
     const ImgDesc &im = c.imgs[w.image];
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
     const int tid = int(threadIdx.x);
-    s_len[tid] = c.tables[w.table_ac].size[tid];
-    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_lt[tid] = Q.lt[tid]; }
+    const int l = c.tables[w.table_ac].size[tid];
+    s_len[tid] = uint8_t((tid == 0xF0 || tid == 0x00) ? l : (l ? l + (tid & 15) : 0));   // ZRL and EOB keep their plain lengths (their low nibble is no size)
+    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_rcp[tid] = Q.rcp[tid]; s_lt[tid] = Q.lt[tid]; }
 }
 
 __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32_t chi, uint32_t wg_slot, const TrLds &L) {
@@ -94,7 +97,6 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     const TrellisWork &w = c.work[ch.work];
     const ImgDesc &im = c.imgs[w.image];
     const CompGeom g = im.out[w.comp];
-    const DevQuant &Q = c.quant[im.qt_out[w.comp]];
     const int tid = int(threadIdx.x);
     const uint32_t u = ch.j * 256u + uint32_t(tid);
     if (u >= w.nunits) return;
@@ -119,7 +121,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     CSH_UNROLL
     for (int k = 1; k < 64; k++) {
         const int v = r[k], x = v < 0 ? -v : v;
-        int qv = tr_level(x, Q.div[k], Q.rcp[k]);
+        int qv = tr_level(x, L.q8[k], L.rcp[k]);
         qv = qv > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : qv;
         if (qv) {
             const uint32_t P = uint32_t(x) | (uint32_t(k) << 15) | (uint32_t(qv) << 21) | (v < 0 ? 0x80000000u : 0u);
@@ -127,10 +129,10 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             else { sp[((ne - CSH_TR_CAP) * 3u + 1u) * 256u] = tr_f_bits(Zrun); sp[((ne - CSH_TR_CAP) * 3u + 2u) * 256u] = P; }
             ne++;
         }
-        Zrun = (float(x * x) * lambda) * Q.lt[k] + Zrun;
+        Zrun = (float(x * x) * lambda) * L.lt[k] + Zrun;
     }
     const float Z63 = Zrun;
-    const int dc_level = tr_level(r[0] < 0 ? -r[0] : r[0], Q.div[0], Q.rcp[0]);   // scalar DC: k_trellis_dc replaces it
+    const int dc_level = tr_level(r[0] < 0 ? -r[0] : r[0], L.q8[0], L.rcp[0]);   // scalar DC: k_trellis_dc replaces it
     const int dc_signed = r[0] < 0 ? -dc_level : dc_level;
     CSH_SCHED_FENCE();
 
@@ -171,8 +173,8 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             CSH_UNROLL
             for (int kc = 0; kc < 10; kc++) {
                 if (!CSH_ANY(kc < ncand)) break;
-                const int cb = on ? int(L.len[base + kc]) : 0;
-                const float cost = (float(cb + (kc + 1) + run_bits) + dist[kc]) + tj;
+                const int cb = on ? int(L.len[base + kc]) : 0;   // code length + size bits
+                const float cost = (float(cb + run_bits) + dist[kc]) + tj;
                 const bool better = okrun && kc < ncand && cb != 0 && cost < bestc;
                 bestc = better ? cost : bestc;
                 bestsel = better ? ((uint32_t(jj + 1) << 4) | uint32_t(kc)) : bestsel;
@@ -224,16 +226,17 @@ __global__ void __launch_bounds__(256) k_trellis_ac(TrellisCtx c) {
     CSH_SHARED uint32_t s_P[CSH_TR_CAP][256];
     CSH_SHARED uint8_t s_len[256];
     CSH_SHARED int32_t s_q8[64];
+    CSH_SHARED float s_rcp[64];
     CSH_SHARED float s_lt[64];
-    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.len = s_len; L.q8 = s_q8; L.lt = s_lt;
+    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.len = s_len; L.q8 = s_q8; L.rcp = s_rcp; L.lt = s_lt;
 #ifdef CSH_EMUL
     CSH_PHASE_LOOP(2) {
-        if (phase == 0) { trellis_stage(c, blockIdx.x, s_len, s_q8, s_lt); continue; }
+        if (phase == 0) { trellis_stage(c, blockIdx.x, s_len, s_q8, s_rcp, s_lt); continue; }
         trellis_block(c, blockIdx.x, 0u, L);
     }
 #else
     for (uint32_t chi = blockIdx.x; chi < c.nchunks; chi += gridDim.x) {
-        trellis_stage(c, chi, s_len, s_q8, s_lt);
+        trellis_stage(c, chi, s_len, s_q8, s_rcp, s_lt);
         __syncthreads();
         trellis_block(c, chi, blockIdx.x, L);
         __syncthreads();
@@ -255,8 +258,10 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
     if (row >= (g.real_bh + g.v - 1) / g.v) return;
     int ncand = (2 + 60 / int(Q.q[0])) | 1;
     ncand = ncand > 9 ? 9 : ncand;
-    uint64_t lens = 0;   // code length of difference category 0..11, 5 bits each
-    for (int i = 0; i < 12; i++) lens |= uint64_t(w.table_dc < 0 ? kStdDcLen[w.comp ? 1 : 0][i] : c.tables[w.table_dc].size[i]) << (5 * i);
+    // what a DC difference of category 0..11 costs: its code length + that many raw bits, as the float the C source converts it to.  Every
+    // lane writes the (same) twelve values and reads them back itself: no barrier
+    CSH_SHARED float s_cost[16];
+    for (int i = 0; i < 12; i++) s_cost[i] = float(i + int(w.table_dc < 0 ? kStdDcLen[w.comp ? 1 : 0][i] : c.tables[w.table_dc].size[i]));
     const int q = Q.div[0];
     const float rcp = Q.rcp[0], lt0 = Q.lt[0];
     const int half = ncand / 2;
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
                     ccur[k] = cand;
                     if (bi == 0) {
                         const int d = cand - last_dc, bits = tr_bitlen(unsigned(d < 0 ? -d : d));
-                        nacc[k] = float(bits + int((lens >> (5 * bits)) & 31u)) + dist;
+                        nacc[k] = s_cost[bits] + dist;
                     } else {
                         float bc = 0.0f;
                         uint32_t bl = 0;
@@ -297,7 +302,7 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
                         for (int l = 0; l < 9; l++) {
                             if (l < ncand) {
                                 const int d = cand - cprev[l], bits = tr_bitlen(unsigned(d < 0 ? -d : d));
-                                const float cost = (float(bits + int((lens >> (5 * bits)) & 31u)) + dist) + acc[l];
+                                const float cost = (s_cost[bits] + dist) + acc[l];
                                 if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
                             }
                         }

@@ -337,7 +337,6 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
             // residuals (token partition of this macroblock row)
             int16_t coef[25 * 16];
             for (int k = 0; k < 25 * 16; k++) coef[k] = 0;
-            bool any = false;
             uint32_t nzmask = 0;   // blocks with coefficients: bit b (0..15 y, 16..19 u, 20..23 v)
             const Vp8Seg &sq = seg[segment];
             auto get_coeffs = [&](int type, int ctx0, const int *q2, int first, int16_t *out) -> int {
@@ -375,7 +374,6 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
                     for (int k = 0; k < 16; k++) dc[k] = 0;
                     const int nz = get_coeffs(1, tnz[8] + lnz[8], sq.y2, 0, dc);
                     tnz[8] = lnz[8] = uint8_t(nz > 0);
-                    if (nz > 0) any = true;
                     vp8_iwht(dc, coef);
                     for (int k = 0; k < 16; k++) if (coef[16 * k]) nzmask |= 1u << k;
                     first = 1; ytype = 0;
@@ -384,20 +382,21 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
                     for (int x = 0; x < 4; x++) {
                         const int nz = get_coeffs(ytype, tnz[x] + lnz[y], sq.y1, first, coef + (4 * y + x) * 16);
                         tnz[x] = lnz[y] = uint8_t(nz > first);
-                        if (nz > first) { any = true; nzmask |= 1u << (4 * y + x); }
+                        if (nz > first) nzmask |= 1u << (4 * y + x);
                     }
                 for (int ch = 0; ch < 2; ch++)
                     for (int y = 0; y < 2; y++)
                         for (int x = 0; x < 2; x++) {
                             const int nz = get_coeffs(2, tnz[4 + 2 * ch + x] + lnz[4 + 2 * ch + y], sq.uv, 0, coef + (16 + 4 * ch + 2 * y + x) * 16);
                             tnz[4 + 2 * ch + x] = lnz[4 + 2 * ch + y] = uint8_t(nz > 0);
-                            if (nz > 0) { any = true; nzmask |= 1u << (16 + 4 * ch + 2 * y + x); }
+                            if (nz > 0) nzmask |= 1u << (16 + 4 * ch + 2 * y + x);
                         }
             } else {
                 for (int k = 0; k < 8; k++) { tnz[k] = 0; lnz[k] = 0; }
                 if (!i4) { tnz[8] = 0; lnz[8] = 0; }
             }
-            if (filtering) { Vp8FInfo f = fstr[segment][i4 ? 1 : 0]; f.inner |= uint8_t((skip_flag || !any) ? 0 : 1); finfo[size_t(my) * mbw + mx] = f; }
+            // libwebp: f_inner |= !skip with skip = !(non_zero_y | non_zero_uv), the bits AFTER the inverse WHT -- a Y2 block whose transform comes out all zero does not count
+            if (filtering) { Vp8FInfo f = fstr[segment][i4 ? 1 : 0]; f.inner |= uint8_t((skip_flag || nzmask == 0) ? 0 : 1); finfo[size_t(my) * mbw + mx] = f; }
             // ---- reconstruction (prediction from UNFILTERED neighbours: the loop filter runs over the finished frame below)
             uint8_t *yd = Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = V + size_t(my) * 8 * cs + size_t(mx) * 8;
             // borders live in small local arrays copied around the block: the planes have no margin, so predict into a 21 x 17 scratch

@@ -473,6 +473,12 @@ def test_emul_batch_extent_splits_by_bytes_and_declared_pixels(api):
     big = _with_declared_size(head, 16000, 16000)                                    # 256 MP -> ~6.4 GB of pools each
     assert api.batch_extent([(len(big), big)] * 100) == 16
     assert api.batch_extent([(3 << 30, head)] * 3) == 1                              # a single file always goes through, alone
+    # a WebP header's canvas counts too (VP8L: 14 + 14 bits behind the signature; VP8X: 24-bit sizes) -- a tiny file may declare 16383 x 16383
+    bits = (16383 - 1) | ((16383 - 1) << 14)
+    vp8l = b"RIFF" + (26).to_bytes(4, "little") + b"WEBPVP8L" + (14).to_bytes(4, "little") + b"\x2f" + bits.to_bytes(4, "little") + bytes(9)
+    assert api.batch_extent([(len(vp8l), vp8l)] * 100) == 15
+    vp8x = b"RIFF" + (30).to_bytes(4, "little") + b"WEBPVP8X" + (10).to_bytes(4, "little") + bytes(4) + (15999).to_bytes(3, "little") + (15999).to_bytes(3, "little") + bytes(8)
+    assert api.batch_extent([(len(vp8x), vp8x)] * 100) == 16
 
 
 def reference_size_walk(src, max_size, return_smallest=True, encode=None):

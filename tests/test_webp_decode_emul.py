@@ -191,6 +191,22 @@ def test_emul_webp_metadata_carried_over(api, reference_samples):
     assert kept[20] == 0x08 and im.info["exif"] == Image.open(io.BytesIO(w1)).info["exif"] and b"XMP " not in kept
     w0 = open(os.path.join(reference_samples, "w0.webp"), "rb").read()
     assert api.compress_in_memory(w0, params(webp_quality=60, keep_metadata=True)) == api.compress_in_memory(w0, params(webp_quality=60))
+    # --lossless -e: the VP8L coder's file carries them as well (libcaesium's webp::compress sets ICC / EXIF whatever the coder); the canvas
+    # comes from the VP8L header, the VP8X alpha flag from its alpha_is_used bit
+    plain_l = api.compress_in_memory(src, params(webp_lossless=True))
+    kept_l = api.compress_in_memory(src, params(webp_lossless=True, keep_metadata=True))
+    assert plain_l[12:16] == b"VP8L" and kept_l[12:16] == b"VP8X" and kept_l[20] == 0x28 and plain_l[12:] in kept_l
+    assert int.from_bytes(kept_l[24:27], "little") == 74 and int.from_bytes(kept_l[27:30], "little") == 48 and int.from_bytes(kept_l[4:8], "little") == len(kept_l) - 8
+    im = Image.open(io.BytesIO(kept_l)); im.load()
+    assert im.info["icc_profile"] == icc and im.info["exif"] == Image.open(io.BytesIO(src)).info["exif"]
+    assert np.array_equal(np.asarray(im.convert("RGB")), np.asarray(Image.open(io.BytesIO(plain_l)).convert("RGB")))
+    rgba = synth_rgb(13, 40, 30, texture=5.0)
+    a4 = np.dstack([rgba, np.where(np.arange(40)[None, :] < 20, 255, 90).astype(np.uint8).repeat(30, 0).reshape(30, 40)])
+    bb = io.BytesIO(); Image.fromarray(a4, "RGBA").save(bb, format="WEBP", lossless=True, exif=exif)
+    kept_a = api.compress_in_memory(bb.getvalue(), params(webp_lossless=True, keep_metadata=True))
+    assert kept_a[12:16] == b"VP8X" and kept_a[20] == 0x18          # EXIF + alpha
+    im = Image.open(io.BytesIO(kept_a)); im.load()
+    assert im.mode == "RGBA" and np.array_equal(np.asarray(im), a4)
 
 
 def transparent_files():
