@@ -351,7 +351,10 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
     const uint32_t u = ch.j * 256u + uint32_t(tid);
     const TokPlan &P = s_plan;
 
+    // a conditional stage of the scan search codes only the images whose search asks for it: the others' workgroups have nothing to do
+    const bool skipped = c.work_active && !c.work_active[ch.kind == 1 ? ch.a : c.plans[ch.plan].work0];
     CSH_PHASE_LOOP_MIXED(6, 0x0Eu) {   // after phases 1, 2, 3 only the wave synchronises
+        if (skipped) continue;
         if ((c.debug & 1024u) && ch.kind == 1) continue;
         if ((c.debug & 2048u) && ch.kind == 0) continue;
         if (phase == 0) {
@@ -659,6 +662,7 @@ __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
         if (cs >= c.slot0 + c.nslots) break;
         const SlotRec r = c.slots[cs];
         if (!(r.flags & 1u)) continue;
+        if (c.work_active && !c.work_active[r.work]) continue;
         const uint32_t u = r.j * 256u + threadIdx.x, nunits = r.nunits_work;
         uint32_t *freq = c.tables[r.table_base].freq;
         const uint64_t *sym = c.sym_bits + r.word_base, *eob = c.eob_bits + r.word_base;
@@ -1025,6 +1029,7 @@ __global__ void __launch_bounds__(256) k_chunk_sizes(EncCtx c) {
     const int lane = lane_id();
     if (cs >= c.slot0 + c.nslots) return;
     const SlotRec r = c.slots[cs];
+    if (c.work_active && !c.work_active[r.work]) { if (lane == 0) c.chunk_bits[cs] = 0; return; }   // a skipped scan has no bits
 #ifdef CSH_EMUL
     if (lane) return;
     uint32_t bits = c.slot_raw[cs];
@@ -1193,6 +1198,7 @@ __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     if (cs >= c.slot0 + c.nslots) return;
     const SlotRec r = c.slots[cs];
     const ScanWork &w = c.work[r.work];
+    if (c.work_active && !c.work_active[r.work]) return;
     if (w.no_room) { if (lane == 0) c.status[w.image] = 20200; return; }   // decided per scan by k_scan_place
     TokenCtx x = token_ctx(c, r);
     // the chunk's place: bits [raw_bit0, raw_bit0 + nbits) of the raw pool; the scan's last chunk also carries the 1-bits that fill the last byte
@@ -1257,7 +1263,7 @@ __global__ void __launch_bounds__(256) k_zero_edges(EncCtx c) {
     if (cs >= c.slot0 + c.nslots) return;
     const SlotRec r = c.slots[cs];
     const ScanWork &w = c.work[r.work];
-    if (w.no_room) return;
+    if (w.no_room || (c.work_active && !c.work_active[r.work])) return;
     const uint64_t scan0 = c.chunk_off[r.first_chunk];
     const uint64_t bit0 = w.raw_off * 8 + (c.chunk_off[cs] - scan0);
     const uint64_t nbits = c.chunk_bits[cs];

@@ -32,8 +32,15 @@ size_t trellis_spill_words() { return size_t(CSH_TR_MAXWG) * CSH_TR_SPILL * 3u *
 
 #ifdef CSH_EMUL
 #define CSH_ANY(p) (p)                     // a lane cannot see the others there: its own loop bounds
+#define CSH_SPILL_LD(ptr) (*(ptr))
+#define CSH_SPILL_ST(ptr, v) (*(ptr) = (v))
 #else
 #define CSH_ANY(p) (__ballot(p) != 0ull)   // wave-uniform loop conditions
+// the spilled entries are read and written as streaming accesses: besides the hint, that keeps them from being merged with the LDS
+// accesses of the other branch into one generic-address (flat) access -- which is what the compiler made of `e < CAP ? lds : hbm`,
+// three flat loads with a full wait per predecessor
+#define CSH_SPILL_LD(ptr) __builtin_nontemporal_load(ptr)
+#define CSH_SPILL_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #endif
 
 using Oct8 = std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>;
@@ -126,7 +133,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         if (qv) {
             const uint32_t P = uint32_t(x) | (uint32_t(k) << 15) | (uint32_t(qv) << 21) | (v < 0 ? 0x80000000u : 0u);
             if (ne < CSH_TR_CAP) { L.Z[ne][tid] = Zrun; L.P[ne][tid] = P; }
-            else { sp[((ne - CSH_TR_CAP) * 3u + 1u) * 256u] = tr_f_bits(Zrun); sp[((ne - CSH_TR_CAP) * 3u + 2u) * 256u] = P; }
+            else { CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 1u) * 256u, tr_f_bits(Zrun)); CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 2u) * 256u, P); }
             ne++;
         }
         Zrun = (float(x * x) * lambda) * L.lt[k] + Zrun;
@@ -142,43 +149,48 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         const bool on = t < ne;
         float Zp; uint32_t P;
         if (t < CSH_TR_CAP) { Zp = L.Z[t][tid]; P = L.P[t][tid]; }
-        else { Zp = tr_bits_f(sp[((t - CSH_TR_CAP) * 3u + 1u) * 256u]); P = sp[((t - CSH_TR_CAP) * 3u + 2u) * 256u]; }
+        else { Zp = tr_bits_f(CSH_SPILL_LD(sp + ((t - CSH_TR_CAP) * 3u + 1u) * 256u)); P = CSH_SPILL_LD(sp + ((t - CSH_TR_CAP) * 3u + 2u) * 256u); }
         if (!on) { Zp = 0.0f; P = 0u; }
         const int x = int(P & 0x7FFFu), kpos = int((P >> 15) & 63u), qval = int((P >> 21) & 1023u);
         const int q8 = L.q8[kpos];
         const float ltk = L.lt[kpos];
         const int ncand = on ? tr_bitlen(unsigned(qval)) : 0;
+        int ncmax = 0;   // most candidates any lane of the wave has at this step: the (uniform) bound of the candidate loops
+        CSH_UNROLL
+        for (int kc = 0; kc < 10; kc++) ncmax = CSH_ANY(kc < ncand) ? kc + 1 : ncmax;
         float dist[10];
         CSH_UNROLL
         for (int kc = 0; kc < 10; kc++) {
-            if (!CSH_ANY(kc < ncand)) break;
+            if (kc >= ncmax) break;
             const int cand = kc < ncand - 1 ? (2 << kc) - 1 : qval;
             const int delta = cand * q8 - x;
             dist[kc] = (float(delta * delta) * lambda) * ltk;
         }
         float bestc = 1e38f;
         uint32_t bestsel = 0;   // (predecessor entry + 1) << 4 | candidate
-        for (int jj = -1; jj < int(t); jj++) {
-            float Aj = 0.0f, Zj = 0.0f;
-            int posj = 0;
-            if (jj >= 0) {
-                if (jj < CSH_TR_CAP) { Aj = L.A[jj][tid]; Zj = L.Z[jj][tid]; posj = int((L.P[jj][tid] >> 15) & 63u); }
-                else { const uint32_t *q = sp + (uint32_t(jj - CSH_TR_CAP) * 3u) * 256u; Aj = tr_bits_f(q[0]); Zj = tr_bits_f(q[256]); posj = int((q[512] >> 15) & 63u); }
-            }
+        // one predecessor: entry jj (position posj, path cost Aj, Z at its position Zj), or jj = -1: the start of the block
+        auto from = [&](int jj, int posj, float Aj, float Zj) {
             const int zr = kpos - 1 - posj;
             const bool okrun = on && !((zr >> 4) != 0 && lenZRL == 0);
             const int run_bits = (zr >> 4) * lenZRL;
-            const int base = 16 * (zr & 15) + 1;
+            const int base = 16 * (zr & 15) + 1;   // in 1..241 whatever zr is: a lane that is not `on` reads a valid, unused byte
             const float tj = (Zp - Zj) + Aj;
             CSH_UNROLL
             for (int kc = 0; kc < 10; kc++) {
-                if (!CSH_ANY(kc < ncand)) break;
-                const int cb = on ? int(L.len[base + kc]) : 0;   // code length + size bits
+                if (kc >= ncmax) break;
+                const int cb = int(L.len[base + kc]);   // code length + size bits
                 const float cost = (float(cb + run_bits) + dist[kc]) + tj;
                 const bool better = okrun && kc < ncand && cb != 0 && cost < bestc;
                 bestc = better ? cost : bestc;
                 bestsel = better ? ((uint32_t(jj + 1) << 4) | uint32_t(kc)) : bestsel;
             }
+        };
+        from(-1, 0, 0.0f, 0.0f);
+        const int t_lds = int(t) < CSH_TR_CAP ? int(t) : CSH_TR_CAP;
+        for (int jj = 0; jj < t_lds; jj++) from(jj, int((L.P[jj][tid] >> 15) & 63u), L.A[jj][tid], L.Z[jj][tid]);
+        for (int jj = CSH_TR_CAP; jj < int(t); jj++) {
+            const uint32_t *q = sp + (uint32_t(jj - CSH_TR_CAP) * 3u) * 256u;
+            from(jj, int((CSH_SPILL_LD(q + 512) >> 15) & 63u), tr_bits_f(CSH_SPILL_LD(q)), tr_bits_f(CSH_SPILL_LD(q + 256)));
         }
         if (on) {
             const int bk = int(bestsel & 15u);
@@ -186,7 +198,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             const float Zi = (float(x * x) * lambda) * ltk + Zp;
             const uint32_t P2 = (bestsel >> 4) | (uint32_t(kpos) << 15) | (level << 21) | (P & 0x80000000u);
             if (t < CSH_TR_CAP) { L.A[t][tid] = bestc; L.Z[t][tid] = Zi; L.P[t][tid] = P2; }
-            else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * 256u; q[0] = tr_f_bits(bestc); q[256] = tr_f_bits(Zi); q[512] = P2; }
+            else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * 256u; CSH_SPILL_ST(q, tr_f_bits(bestc)); CSH_SPILL_ST(q + 256, tr_f_bits(Zi)); CSH_SPILL_ST(q + 512, P2); }
         }
     }
 
@@ -196,7 +208,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
         float Ae, Ze; uint32_t Pe;
         if (e < CSH_TR_CAP) { Ae = L.A[e][tid]; Ze = L.Z[e][tid]; Pe = L.P[e][tid]; }
-        else { const uint32_t *q = sp + ((e - CSH_TR_CAP) * 3u) * 256u; Ae = tr_bits_f(q[0]); Ze = tr_bits_f(q[256]); Pe = q[512]; }
+        else { const uint32_t *q = sp + ((e - CSH_TR_CAP) * 3u) * 256u; Ae = tr_bits_f(CSH_SPILL_LD(q)); Ze = tr_bits_f(CSH_SPILL_LD(q + 256)); Pe = CSH_SPILL_LD(q + 512); }
         float cost = (Ae + Z63) - Ze;
         if (int((Pe >> 15) & 63u) < 63) cost = cost + float(lenEOB);
         if (e < ne && cost < best) { best = cost; last = int(e); }
@@ -212,7 +224,8 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     dst[0] = int16_t(dc_signed);
     for (int e = last; CSH_ANY(e >= 0);) {
         if (e >= 0) {
-            const uint32_t Pe = e < CSH_TR_CAP ? L.P[e][tid] : sp[(uint32_t(e - CSH_TR_CAP) * 3u + 2u) * 256u];
+            uint32_t Pe;
+            if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + (uint32_t(e - CSH_TR_CAP) * 3u + 2u) * 256u);
             const int pos = int((Pe >> 15) & 63u), level = int((Pe >> 21) & 1023u);
             dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
             e = int(Pe & 63u) - 1;

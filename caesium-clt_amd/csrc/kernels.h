@@ -96,6 +96,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint32_t *overflow;        // [4]: [1] = the token pool was too small
     uint32_t debug;            // CSH_DEBUG: performance experiments (parts of k_tokens switched off; output is then garbage)
     uint32_t stats_only;       // the trellis stage's statistics scans: histograms, flags and EOB runs only -- no token is written
+    const uint8_t *work_active;// null: every work item of the run is coded; else per work item 1 = coded, 0 = skipped (conditional stages of the scan search)
 };
 void launch_tokens(hipStream_t st, const EncCtx &c);
 void launch_ac_runs(hipStream_t st, const EncCtx &c);

@@ -112,13 +112,25 @@ struct csh_batch {
     std::vector<TokRegion> regions;       // one per TokPlan, then one per DC / sequential work item
     std::vector<uint32_t> region_est;     // estimated tokens of each (x tok_scale = its capacity)
     uint32_t hist_rows = 0;               // rows of 256 symbol counts over all slots
-    // mozjpeg's scan search (the default profile; CSH_PROFILE=plain keeps the stock script): the candidate scans are coded in two
-    // stages -- work items, slots, token chunks and tables of stage 1 first, of stage 2 behind them -- and the host replays
-    // jcmaster.c select_scans on their sizes in between
+    // mozjpeg's scan search (the default profile; CSH_PROFILE=plain keeps the stock script): the candidate scans are coded in stages
+    // -- work items, slots, token chunks and tables of one stage behind those of the stage before -- and the host replays
+    // jcmaster.c select_scans on their sizes in between.  mozjpeg codes its candidates one after the other and skips ahead as soon as
+    // a decision is made; the stages follow that order: what every image needs (ST_1, ST_2), and what only an image whose search runs
+    // on needs (ST_1B: luma at Al 3; ST_2B / ST_2C: the fourth and fifth frequency split) -- those stages run only when some image
+    // asks for them, and then only over the work items of those images (EncCtx::work_active).
     bool search = false;
-    struct Stage { uint32_t work0 = 0, nwork = 0, slot0 = 0, nslots = 0, ech0 = 0, nech = 0, table0 = 0, ntables = 0, plan0 = 0, nplans = 0; } stage[2];
-    struct SearchImg { int cand_work[64]; int ncand; int Al_luma = 0, Al_chroma = 0; };   // candidate number -> work item (-1: not coded)
+    enum { ST_1 = 0, ST_1B = 1, ST_2 = 2, ST_2B = 3, ST_2C = 4, ST_N = 5 };
+    struct Stage { uint32_t work0 = 0, nwork = 0, slot0 = 0, nslots = 0, ech0 = 0, nech = 0, table0 = 0, ntables = 0, plan0 = 0, nplans = 0; } stage[ST_N];
+    struct SearchImg {
+        int cand_work[64]; int ncand;       // candidate number -> work item (-1: not coded by itself -- see search_work)
+        int Al_luma = 0, Al_chroma = 0;
+        uint64_t best_luma = 0, best_chroma = 0;   // running minimum of the decision in progress
+        int split_luma = 0, split_chroma = 0;
+        bool luma_on = false, chroma_on = false;    // the decision in progress needs the next stage's candidates
+    };
     std::vector<SearchImg> simg;
+    std::vector<uint8_t> work_active;               // per work item: coded in the (gated) stage about to run
+    uint32_t n_gated_runs = 0;                      // how many of the conditional stages the last run needed (csh_timing.n_search_extra)
     std::vector<uint32_t> img_list, img_nlist, h_cost;
     std::map<std::array<int, 5>, int> cand_script;   // (component, Ss, Se, Ah, Al) -> EncScan index
     // mozjpeg's quantiser half (CSH_PROFILE=mozjpeg): overshoot deringing in front of every forward DCT; trellis quantisation behind it --
@@ -177,6 +189,7 @@ struct csh_batch {
     DevBuf<uint32_t> d_img_list, d_img_nlist, d_scan_cost, d_slot_raw, d_slot_eobh, d_long_runs, d_long_cnt, d_tokens, d_chunk_ntok, d_chunk_bits, d_raw, d_scan_pad, d_chunk_ff, d_hdr_off, d_img_size, d_img_size_pad, d_status, d_overflow;
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
+    DevBuf<uint8_t> d_work_active;
     DevBuf<TrellisWork> d_twork;
     DevBuf<TrellisChunk> d_tchunks;
     DevBuf<float> d_tlambda;
@@ -486,6 +499,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             ScanWork w;
             memset(&w, 0, sizeof w);
             w.image = img_index; w.scan = sidx;
+            w.out_off = 0xFFFFFFFFu;   // not part of a file until k_layout says so (a conditional stage of the scan search may never run)
             if (e.Ss == 0 && e.ncomp > 1) w.nunits = uint32_t(im.omcus_x * im.omcus_y);
             else w.nunits = uint32_t(im.out[e.comp[0]].real_bw * im.out[e.comp[0]].real_bh);
             w.unit_base = uint32_t(b->total_units);
@@ -527,10 +541,12 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             TokPlan P;
             memset(&P, 0, sizeof P);
             P.nunits = nu; P.real_bw = im.out[c].real_bw; P.bw = im.out[c].bw; P.tile_base = im.out[c].tile_base;   // tile_base of re-quantised tiles is rebased below
+            P.work0 = 0xFFFFFFFFu;
             for (size_t k = 0; k < list.size(); k++) {
                 const EncScan &e = b->script[list[k]];
                 if (!(e.Ss > 0 && !e.sequential && e.comp[0] == c)) continue;
                 const ScanWork &w = b->swork[size_t(w_first) + k];
+                if (P.work0 == 0xFFFFFFFFu) P.work0 = uint32_t(w_first) + uint32_t(k);   // the plan's scans are coded or skipped together: the first stands for all
                 AcSlot &a = P.s[P.nslot++];
                 a.unit_base = w.unit_base; a.word_base = w.word_base; a.first_chunk = w.first_chunk; a.table_base = w.table_base; a.nunits_work = w.nunits;
                 a.Ss = uint8_t(e.Ss); a.Se = uint8_t(e.Se); a.Ah = uint8_t(e.Ah); a.Al = uint8_t(e.Al);
@@ -885,7 +901,8 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             auto add = [&](int cand, int idx) { cands.push_back(cand); list.push_back(idx); };
             add(0, dc_scan_index(in.ncomp));
             add(1, cand_index(0, 1, 8, 0, 0)); add(2, cand_index(0, 9, 63, 0, 0));
-            for (int Al = 0; Al < 3; Al++) { add(3 + 3 * Al, cand_index(0, 1, 63, Al + 1, Al)); add(4 + 3 * Al, cand_index(0, 1, 8, 0, Al + 1)); add(5 + 3 * Al, cand_index(0, 9, 63, 0, Al + 1)); }
+            // luma at Al 1 and 2 (mozjpeg tries Al 3 only when Al 2 beat Al 1: candidates 9-11 are stage ST_1B)
+            for (int Al = 0; Al < 2; Al++) { add(3 + 3 * Al, cand_index(0, 1, 63, Al + 1, Al)); add(4 + 3 * Al, cand_index(0, 1, 8, 0, Al + 1)); add(5 + 3 * Al, cand_index(0, 9, 63, 0, Al + 1)); }
             if (in.ncomp == 3) {
                 add(26, cand_index(1, 1, 8, 0, 0)); add(27, cand_index(1, 9, 63, 0, 0)); add(28, cand_index(2, 1, 8, 0, 0)); add(29, cand_index(2, 9, 63, 0, 0));
                 for (int Al = 0; Al < 2; Al++) {
@@ -931,38 +948,52 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     b->stage[0].nwork = uint32_t(b->swork.size()); b->stage[0].nslots = uint32_t(b->slot_work.size()); b->stage[0].nech = uint32_t(b->echunks.size());
     b->stage[0].ntables = uint32_t(b->ntables); b->stage[0].nplans = uint32_t(b->plans.size());
     if (b->search) {
-        // one unused slot between the stages: each stage's exclusive scan of chunk sizes writes one entry past its slots
-        { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
-        b->stage[1].work0 = uint32_t(b->swork.size()); b->stage[1].slot0 = uint32_t(b->slot_work.size()); b->stage[1].ech0 = uint32_t(b->echunks.size());
-        b->stage[1].table0 = uint32_t(b->ntables); b->stage[1].plan0 = uint32_t(b->plans.size());
         static const int split[5] = {2, 8, 5, 12, 18};
-        for (size_t n = 0; n < count; n++) {
-            Item &it = b->items[n];
-            if (it.image < 0) continue;
-            ImgDesc &im = b->imgs[size_t(it.image)];
-            csh_batch::SearchImg &si = b->simg[size_t(it.image)];
-            // stage 2: the frequency-split candidates; their Al is the one stage 1 chooses (entered as 0 here, patched before the stage runs)
-            std::vector<int> list, cands;
-            auto add = [&](int cand, int idx) { cands.push_back(cand); list.push_back(idx); };
-            add(12, cand_index(0, 1, 63, 0, 0));
-            for (int i = 0; i < 5; i++) { add(13 + 2 * i, cand_index(0, 1, split[i], 0, 0)); add(14 + 2 * i, cand_index(0, split[i] + 1, 63, 0, 0)); }
+        // the later stages, each contiguous: make(image, add) lists the stage's candidates of one image
+        auto add_stage = [&](int sid, auto make) -> int {
+            // one unused slot between the stages: each stage's exclusive scan of chunk sizes writes one entry past its slots
+            { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
+            csh_batch::Stage &sg = b->stage[sid];
+            sg.work0 = uint32_t(b->swork.size()); sg.slot0 = uint32_t(b->slot_work.size()); sg.ech0 = uint32_t(b->echunks.size());
+            sg.table0 = uint32_t(b->ntables); sg.plan0 = uint32_t(b->plans.size());
+            for (size_t n = 0; n < count; n++) {
+                Item &it = b->items[n];
+                if (it.image < 0) continue;
+                ImgDesc &im = b->imgs[size_t(it.image)];
+                csh_batch::SearchImg &si = b->simg[size_t(it.image)];
+                std::vector<int> list, cands;
+                auto add = [&](int cand, int idx) { cands.push_back(cand); list.push_back(idx); };
+                make(im, add);
+                const int first = int(b->swork.size());
+                add_works(it, im, it.image, list, inputs[n].length, it.out);
+                for (size_t k = 0; k < cands.size(); k++) si.cand_work[cands[k]] = first + int(k);
+            }
+            sg.nwork = uint32_t(b->swork.size()) - sg.work0; sg.nslots = uint32_t(b->slot_work.size()) - sg.slot0;
+            sg.nech = uint32_t(b->echunks.size()) - sg.ech0; sg.ntables = uint32_t(b->ntables) - sg.table0; sg.nplans = uint32_t(b->plans.size()) - sg.plan0;
+            return 0;
+        };
+        // ST_1B: luma at Al 3 -- the refinement that brings it back to 2 and the two band scans
+        add_stage(csh_batch::ST_1B, [&](const ImgDesc &, auto &add) { add(9, cand_index(0, 1, 63, 3, 2)); add(10, cand_index(0, 1, 8, 0, 3)); add(11, cand_index(0, 9, 63, 0, 3)); });
+        // ST_2: the frequency-split candidates every search looks at: the whole band, the splits at 2 and at 5 (the split at 8 IS stage 1's
+        // pair of band scans at the chosen Al: nothing is coded for it).  Their Al is the one stage 1 chooses: entered as 0, patched before the stage runs
+        auto splits = [&](const ImgDesc &im, auto &add, int i0, int i1, bool whole) {
+            if (whole) add(12, cand_index(0, 1, 63, 0, 0));
+            for (int i = i0; i <= i1; i++) if (i != 1) { add(13 + 2 * i, cand_index(0, 1, split[i], 0, 0)); add(14 + 2 * i, cand_index(0, split[i] + 1, 63, 0, 0)); }
             if (im.ncomp == 3) {
-                add(42, cand_index(1, 1, 63, 0, 0)); add(43, cand_index(2, 1, 63, 0, 0));
-                for (int i = 0; i < 5; i++) {
+                if (whole) { add(42, cand_index(1, 1, 63, 0, 0)); add(43, cand_index(2, 1, 63, 0, 0)); }
+                for (int i = i0; i <= i1; i++) if (i != 1) {
                     add(44 + 4 * i, cand_index(1, 1, split[i], 0, 0)); add(45 + 4 * i, cand_index(1, split[i] + 1, 63, 0, 0));
                     add(46 + 4 * i, cand_index(2, 1, split[i], 0, 0)); add(47 + 4 * i, cand_index(2, split[i] + 1, 63, 0, 0));
                 }
             }
-            for (int c = 0; c < im.ncomp; c++) for (int i = -1; i < 5; i++) for (int Al = 1; Al <= (c ? 2 : 3); Al++) {   // the variants the patch may pick
-                if (i < 0) cand_index(c, 1, 63, 0, Al); else { cand_index(c, 1, split[i], 0, Al); cand_index(c, split[i] + 1, 63, 0, Al); }
-            }
-            const int first2 = int(b->swork.size());
-            add_works(it, im, it.image, list, inputs[n].length, it.out);
-            for (size_t k = 0; k < cands.size(); k++) si.cand_work[cands[k]] = first2 + int(k);
+        };
+        add_stage(csh_batch::ST_2, [&](const ImgDesc &im, auto &add) { splits(im, add, 0, 2, true); });
+        add_stage(csh_batch::ST_2B, [&](const ImgDesc &im, auto &add) { splits(im, add, 3, 3, false); });   // the split at 12: only if the split at 8 leads after the third
+        add_stage(csh_batch::ST_2C, [&](const ImgDesc &im, auto &add) { splits(im, add, 4, 4, false); });   // the split at 18: only if the split at 12 leads after the fourth
+        for (int c = 0; c < 3; c++) for (int i = -1; i < 5; i++) for (int Al = 1; Al <= (c ? 2 : 3); Al++) {   // the variants the Al patch may pick
+            if (i < 0) cand_index(c, 1, 63, 0, Al); else { cand_index(c, 1, split[i], 0, Al); cand_index(c, split[i] + 1, 63, 0, Al); }
         }
-        b->stage[1].nwork = uint32_t(b->swork.size()) - b->stage[1].work0; b->stage[1].nslots = uint32_t(b->slot_work.size()) - b->stage[1].slot0;
-        b->stage[1].nech = uint32_t(b->echunks.size()) - b->stage[1].ech0; b->stage[1].ntables = uint32_t(b->ntables) - b->stage[1].table0;
-        b->stage[1].nplans = uint32_t(b->plans.size()) - b->stage[1].plan0;
+        b->work_active.assign(b->swork.size(), 0);
         if (b->total_units > 0xFFFFFFF0ull) { csh_set_error("csh_batch_create: batch too large for the scan search's candidate lists (fewer files per batch)"); return CS_ERR_POOL_OVERFLOW; }
     }
     if (b->trellis) {
@@ -1212,9 +1243,25 @@ static int run_rgb_only(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
 
 // The host side of mozjpeg's scan search (jcmaster.c select_scans [UPSTREAM-RECALL]; the statement the oracle is pinned with:
 // oracle/jpeg_oracle.c cso_search_progression).  The device has coded a stage's candidate scans; their sizes (DHT + SOS + stuffed data)
-// come back, the decisions are replayed per image, and what they decide goes to the device: after stage 1 the Al of the stage-2
-// candidates (their work items' scan and their plans), after stage 2 every file's list of scans.
-static int search_select(csh_batch *b, AsmCtx &a, int stage) {
+// come back and the decisions are replayed per image in mozjpeg's own order -- which is also what decides whether an image needs a
+// conditional stage at all:
+//   after ST_1   luma Al 0, 1, 2 in turn (stop at the first that is not cheaper); chroma Al 0, 1, 2 likewise.  Al 2 cheaper than Al 1:
+//                the image wants luma at Al 3 tried (ST_1B)
+//   after ST_1B  luma Al 3.  Then the Al of the frequency-split candidates is known: their work items and token plans are patched
+//   after ST_2   whole band, split at 2, split at 8 (= stage 1's band pair at the chosen Al: search_work), [stop if the whole band still
+//                leads], split at 5, [stop unless the split at 8 leads]: luma and chroma apart.  Not stopped: the split at 12 (ST_2B)
+//   after ST_2B  split at 12, [stop unless it leads].  Not stopped: the split at 18 (ST_2C)
+//   after ST_2C  split at 18.  Then every file's list of scans.
+// Candidate numbering: cso_search_progression's.
+static const int kSplit[5] = {2, 8, 5, 12, 18};
+enum { kLumaSplit0 = 12, kNLuma = 23, kChromaBase = 26, kChromaSplit0 = 42 };
+// the work item that holds candidate `cand` of an image: its own, or -- the split at 8 -- stage 1's band scans at the chosen Al
+static int search_work(const csh_batch::SearchImg &si, int cand) {
+    if (cand == kLumaSplit0 + 3 || cand == kLumaSplit0 + 4) return si.cand_work[1 + 3 * si.Al_luma + (cand - (kLumaSplit0 + 3))];
+    if (cand >= kChromaSplit0 + 6 && cand <= kChromaSplit0 + 9) return si.cand_work[kChromaBase + 6 * si.Al_chroma + (cand - (kChromaSplit0 + 6))];
+    return si.cand_work[cand];
+}
+static int search_costs(csh_batch *b, AsmCtx &a, int stage) {
     hipStream_t st = b->stream;
     const csh_batch::Stage &sg = b->stage[stage];
     a.work0 = int(sg.work0); a.nwork_run = int(sg.nwork);
@@ -1222,90 +1269,124 @@ static int search_select(csh_batch *b, AsmCtx &a, int stage) {
     b->h_cost.resize(b->swork.size());
     CSH_CHECK(hipMemcpyAsync(b->h_cost.data() + sg.work0, b->d_scan_cost.p + sg.work0, size_t(sg.nwork) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     CSH_CHECK(hipStreamSynchronize(st));
-    static const int split[5] = {2, 8, 5, 12, 18};
-    const int luma_split0 = 12, nluma = 23, chroma_base = 26, chroma_split0 = 42;
+    return 0;
+}
+// marks the work items of `stage` of every image for which want(image) holds; returns how many images that is
+template <class F>
+static uint32_t search_gate(csh_batch *b, int stage, F want) {
+    const csh_batch::Stage &sg = b->stage[stage];
+    b->work_active.resize(b->swork.size());
+    uint32_t nimg = 0;
+    std::vector<char> on(size_t(b->nimg), 0);
+    for (int i = 0; i < b->nimg; i++) { const int m = want(i); on[size_t(i)] = char(m); if (m) nimg++; }
+    for (uint32_t wi = sg.work0; wi < sg.work0 + sg.nwork; wi++) {
+        const ScanWork &w = b->swork[wi];
+        const int comp = b->script[size_t(w.scan)].comp[0];
+        b->work_active[wi] = uint8_t((on[size_t(w.image)] & (comp == 0 ? 1 : 2)) ? 1 : 0);   // want: bit 0 luma, bit 1 chroma
+    }
+    return nimg;
+}
+static int search_decide(csh_batch *b, int stage) {
+    hipStream_t st = b->stream;
     for (int i = 0; i < b->nimg; i++) {
         csh_batch::SearchImg &si = b->simg[size_t(i)];
         const ImgDesc &im = b->imgs[size_t(i)];
-        auto size = [&](int cand) -> uint64_t { return b->h_cost[size_t(si.cand_work[cand])]; };
-        if (stage == 0) {
-            uint64_t best = 0;
-            si.Al_luma = 0; si.Al_chroma = 0;
-            for (int Al = 0; Al <= 3; Al++) {   // after candidates 2, 5, 8, 11: the two band scans at Al plus the refinements that bring it back to 0
+        auto size = [&](int cand) -> uint64_t { return b->h_cost[size_t(search_work(si, cand))]; };
+        auto luma_split = [&](int idx) { return idx == 0 ? size(kLumaSplit0) : size(kLumaSplit0 + 2 * idx - 1) + size(kLumaSplit0 + 2 * idx); };
+        auto chroma_split = [&](int idx) {
+            if (idx == 0) return size(kChromaSplit0) + size(kChromaSplit0 + 1);
+            uint64_t cost = 0;
+            for (int k = 2; k <= 5; k++) cost += size(kChromaSplit0 + 4 * (idx - 1) + k);
+            return cost;
+        };
+        // one step of the split loop (jcmaster.c): returns true when the search goes on to idx + 1
+        auto split_step = [&](int idx, uint64_t cost, uint64_t &best, int &choice) {
+            if (idx == 0) { best = cost; choice = 0; return true; }
+            if (cost < best) { best = cost; choice = idx; }
+            return !((idx == 2 && choice == 0) || (idx == 3 && choice != 2) || (idx == 4 && choice != 4) || idx == 5);
+        };
+        if (stage == csh_batch::ST_1) {
+            si.Al_luma = 0; si.Al_chroma = 0; si.luma_on = true; si.chroma_on = false;
+            for (int Al = 0; Al <= 2 && si.luma_on; Al++) {   // candidates 1+3Al, 2+3Al: the two band scans at Al; 3+3k: the refinements that bring it back to 0
                 uint64_t cost = size(1 + 3 * Al) + size(2 + 3 * Al);
                 for (int k = 0; k < Al; k++) cost += size(3 + 3 * k);
-                if (Al == 0 || cost < best) { best = cost; si.Al_luma = Al; } else break;
+                if (Al == 0 || cost < si.best_luma) { si.best_luma = cost; si.Al_luma = Al; } else si.luma_on = false;
             }
             if (im.ncomp == 3)
                 for (int Al = 0; Al <= 2; Al++) {
                     uint64_t cost = 0;
-                    for (int k = 0; k < 4; k++) cost += size(chroma_base + 6 * Al + k);
-                    for (int k = 0; k < Al; k++) cost += size(chroma_base + 4 + 6 * k) + size(chroma_base + 5 + 6 * k);
-                    if (Al == 0 || cost < best) { best = cost; si.Al_chroma = Al; } else break;
+                    for (int k = 0; k < 4; k++) cost += size(kChromaBase + 6 * Al + k);
+                    for (int k = 0; k < Al; k++) cost += size(kChromaBase + 4 + 6 * k) + size(kChromaBase + 5 + 6 * k);
+                    if (Al == 0 || cost < si.best_chroma) { si.best_chroma = cost; si.Al_chroma = Al; } else break;
                 }
-            // stage 2 of this image is coded at these Al
-            for (int cand = luma_split0; cand < (im.ncomp == 3 ? 64 : nluma); cand++) {
-                if (cand >= nluma && cand < chroma_split0) continue;
-                const int wi = si.cand_work[cand];
-                if (wi < 0) continue;
-                ScanWork &w = b->swork[size_t(wi)];
-                const EncScan e = b->script[size_t(w.scan)];
-                const int Al = e.comp[0] == 0 ? si.Al_luma : si.Al_chroma;
-                w.scan = b->cand_script.at({e.comp[0], e.Ss, e.Se, 0, Al});
+        } else if (stage == csh_batch::ST_1B) {
+            if (si.luma_on) {
+                const uint64_t cost = size(10) + size(11) + size(3) + size(6) + size(9);
+                if (cost < si.best_luma) { si.best_luma = cost; si.Al_luma = 3; }
+                si.luma_on = false;
             }
+        } else if (stage == csh_batch::ST_2) {
+            si.luma_on = true;
+            for (int idx = 0; idx <= 3 && si.luma_on; idx++) si.luma_on = split_step(idx, luma_split(idx), si.best_luma, si.split_luma);
+            si.chroma_on = im.ncomp == 3;
+            for (int idx = 0; idx <= 3 && si.chroma_on; idx++) si.chroma_on = split_step(idx, chroma_split(idx), si.best_chroma, si.split_chroma);
         } else {
-            int split_luma = 0, split_chroma = 0;
-            uint64_t best = size(luma_split0);
-            for (int idx = 1; idx <= 5; idx++) {
-                const uint64_t cost = size(luma_split0 + 2 * idx - 1) + size(luma_split0 + 2 * idx);
-                if (cost < best) { best = cost; split_luma = idx; }
-                if ((idx == 2 && split_luma == 0) || (idx == 3 && split_luma != 2) || (idx == 4 && split_luma != 4)) break;
-            }
-            if (im.ncomp == 3) {
-                best = size(chroma_split0) + size(chroma_split0 + 1);
-                for (int idx = 1; idx <= 5; idx++) {
-                    uint64_t cost = 0;
-                    for (int k = 2; k <= 5; k++) cost += size(chroma_split0 + 4 * (idx - 1) + k);
-                    if (cost < best) { best = cost; split_chroma = idx; }
-                    if ((idx == 2 && split_chroma == 0) || (idx == 3 && split_chroma != 2) || (idx == 4 && split_chroma != 4)) break;
-                }
-            }
-            // the file: DC, luma bands, luma refinements down to the Al both share, chroma bands, chroma refinements down to it, then the
-            // shared refinements, luma first
-            uint32_t *list = b->img_list.data() + size_t(i) * CSH_LIST_MAX;
-            uint32_t m = 0;
-            auto put = [&](int cand) { list[m++] = uint32_t(si.cand_work[cand]); };
-            const int min_Al = im.ncomp == 3 ? std::min(si.Al_luma, si.Al_chroma) : si.Al_luma;
-            put(0);
-            if (split_luma == 0) put(luma_split0); else { put(luma_split0 + 2 * split_luma - 1); put(luma_split0 + 2 * split_luma); }
-            for (int Al = si.Al_luma - 1; Al >= min_Al; Al--) put(3 + 3 * Al);
-            if (im.ncomp == 3) {
-                if (split_chroma == 0) { put(chroma_split0); put(chroma_split0 + 1); }
-                else for (int k = 2; k <= 5; k++) put(chroma_split0 + 4 * (split_chroma - 1) + k);
-                for (int Al = si.Al_chroma - 1; Al >= min_Al; Al--) { put(chroma_base + 6 * Al + 4); put(chroma_base + 6 * Al + 5); }
-            }
-            for (int Al = min_Al - 1; Al >= 0; Al--) {
-                put(3 + 3 * Al);
-                if (im.ncomp == 3) { put(chroma_base + 6 * Al + 4); put(chroma_base + 6 * Al + 5); }
-            }
-            b->img_nlist[size_t(i)] = m;
+            const int idx = stage == csh_batch::ST_2B ? 4 : 5;
+            if (si.luma_on) si.luma_on = split_step(idx, luma_split(idx), si.best_luma, si.split_luma);
+            if (si.chroma_on) si.chroma_on = split_step(idx, chroma_split(idx), si.best_chroma, si.split_chroma);
         }
     }
-    (void)split;
-    if (stage == 0) {
-        // patch the device's view of stage 2: the work items' scans, and the Al in the token plans
-        const csh_batch::Stage &s2 = b->stage[1];
-        for (uint32_t pi = s2.plan0; pi < s2.plan0 + s2.nplans; pi++) {
-            TokPlan &P = b->plans[pi];
-            const csh_batch::SearchImg &si = b->simg[size_t(b->plan_image[pi])];
-            for (uint32_t k = 0; k < P.nslot; k++) P.s[k].Al = uint8_t(b->plan_comp[pi] == 0 ? si.Al_luma : si.Al_chroma);
+    if (stage == csh_batch::ST_1 || stage == csh_batch::ST_1B) {
+        // once no image waits for ST_1B: the frequency-split stages are coded at the chosen Al -- their work items' scans, and the Al in their token plans
+        bool pending = false;
+        for (int i = 0; i < b->nimg && stage == csh_batch::ST_1; i++) pending = pending || b->simg[size_t(i)].luma_on;
+        if (pending) return 0;
+        for (int sid : {int(csh_batch::ST_2), int(csh_batch::ST_2B), int(csh_batch::ST_2C)}) {
+            const csh_batch::Stage &sg = b->stage[sid];
+            for (uint32_t wi = sg.work0; wi < sg.work0 + sg.nwork; wi++) {
+                ScanWork &w = b->swork[wi];
+                const EncScan e = b->script[size_t(w.scan)];
+                const csh_batch::SearchImg &si = b->simg[size_t(w.image)];
+                w.scan = b->cand_script.at({e.comp[0], e.Ss, e.Se, 0, e.comp[0] == 0 ? si.Al_luma : si.Al_chroma});
+            }
+            for (uint32_t pi = sg.plan0; pi < sg.plan0 + sg.nplans; pi++) {
+                TokPlan &P = b->plans[pi];
+                const csh_batch::SearchImg &si = b->simg[size_t(b->plan_image[pi])];
+                for (uint32_t k = 0; k < P.nslot; k++) P.s[k].Al = uint8_t(b->plan_comp[pi] == 0 ? si.Al_luma : si.Al_chroma);
+            }
+            if (sg.nwork) CSH_CHECK(hipMemcpyAsync(b->d_swork.p + sg.work0, b->swork.data() + sg.work0, size_t(sg.nwork) * sizeof(ScanWork), hipMemcpyHostToDevice, st));
+            if (sg.nplans) CSH_CHECK(hipMemcpyAsync(b->d_plans.p + sg.plan0, b->plans.data() + sg.plan0, size_t(sg.nplans) * sizeof(TokPlan), hipMemcpyHostToDevice, st));
         }
-        CSH_CHECK(hipMemcpyAsync(b->d_swork.p + s2.work0, b->swork.data() + s2.work0, size_t(s2.nwork) * sizeof(ScanWork), hipMemcpyHostToDevice, st));
-        CSH_CHECK(hipMemcpyAsync(b->d_plans.p + s2.plan0, b->plans.data() + s2.plan0, size_t(s2.nplans) * sizeof(TokPlan), hipMemcpyHostToDevice, st));
-    } else {
-        CSH_CHECK(hipMemcpyAsync(b->d_img_list.p, b->img_list.data(), b->img_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        CSH_CHECK(hipMemcpyAsync(b->d_img_nlist.p, b->img_nlist.data(), b->img_nlist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     }
+    return 0;
+}
+// every file's list of scans: DC, luma bands, luma refinements down to the Al both share, chroma bands, chroma refinements down to it, then the
+// shared refinements, luma first
+static int search_lists(csh_batch *b) {
+    hipStream_t st = b->stream;
+    for (int i = 0; i < b->nimg; i++) {
+        const csh_batch::SearchImg &si = b->simg[size_t(i)];
+        const ImgDesc &im = b->imgs[size_t(i)];
+        uint32_t *list = b->img_list.data() + size_t(i) * CSH_LIST_MAX;
+        uint32_t m = 0;
+        auto put = [&](int cand) { list[m++] = uint32_t(search_work(si, cand)); };
+        const int min_Al = im.ncomp == 3 ? std::min(si.Al_luma, si.Al_chroma) : si.Al_luma;
+        put(0);
+        if (si.split_luma == 0) put(kLumaSplit0); else { put(kLumaSplit0 + 2 * si.split_luma - 1); put(kLumaSplit0 + 2 * si.split_luma); }
+        for (int Al = si.Al_luma - 1; Al >= min_Al; Al--) put(3 + 3 * Al);
+        if (im.ncomp == 3) {
+            if (si.split_chroma == 0) { put(kChromaSplit0); put(kChromaSplit0 + 1); }
+            else for (int k = 2; k <= 5; k++) put(kChromaSplit0 + 4 * (si.split_chroma - 1) + k);
+            for (int Al = si.Al_chroma - 1; Al >= min_Al; Al--) { put(kChromaBase + 6 * Al + 4); put(kChromaBase + 6 * Al + 5); }
+        }
+        for (int Al = min_Al - 1; Al >= 0; Al--) {
+            put(3 + 3 * Al);
+            if (im.ncomp == 3) { put(kChromaBase + 6 * Al + 4); put(kChromaBase + 6 * Al + 5); }
+        }
+        b->img_nlist[size_t(i)] = m;
+    }
+    CSH_CHECK(hipMemcpyAsync(b->d_img_list.p, b->img_list.data(), b->img_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    CSH_CHECK(hipMemcpyAsync(b->d_img_nlist.p, b->img_nlist.data(), b->img_nlist.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     return 0;
 }
 
@@ -1465,9 +1546,10 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     a.img_list = b->d_img_list.p; a.img_nlist = b->d_img_nlist.p; a.scan_cost = b->d_scan_cost.p;
     // one stage = tokens -> runs -> tables -> chunk sizes -> offsets -> pack -> stuffing counts, over a contiguous range of work items
     // (without the scan search: one stage, everything).  mark: timing slots are recorded for stage 1 only, stage 2 gets one slot.
-    auto run_stage = [&](const csh_batch::Stage &sg, bool mark) -> int {
+    auto run_stage = [&](const csh_batch::Stage &sg, bool mark, bool gate) -> int {
 #define SMARK() do { if (mark) MARK(); } while (0)
         c.echunks = b->d_echunks.p + sg.ech0; c.nechunks = sg.nech; c.slot0 = sg.slot0; c.nslots = sg.nslots;
+        c.work_active = gate ? b->d_work_active.p : nullptr;
         a.work0 = int(sg.work0); a.nwork_run = int(sg.nwork);
         if (b->d_long_cnt.zero(st)) return -1;
         launch_tokens(st, c);
@@ -1494,11 +1576,24 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
 #undef SMARK
         return 0;
     };
-    if (run_stage(b->stage[0], true)) return -1;
+    if (run_stage(b->stage[0], true, false)) return -1;
     if (b->search) {
-        if (search_select(b, a, 0)) return -1;           // sizes of the stage-1 candidates -> Al of luma and chroma, per image; stage 2 patched
-        if (run_stage(b->stage[1], false)) return -1;
-        if (search_select(b, a, 1)) return -1;           // sizes of the stage-2 candidates -> frequency splits; the files' scan lists
+        b->n_gated_runs = 0;
+        // a conditional stage: coded only if some image's search asks for it, and then only for those images (work_active)
+        auto gated = [&](int sid, auto want) -> int {
+            if (!search_gate(b, sid, want)) return 0;
+            b->n_gated_runs++;
+            if (b->d_work_active.upload(b->work_active, st)) return -1;
+            if (run_stage(b->stage[sid], false, true) || search_costs(b, a, sid)) return -1;
+            return search_decide(b, sid);
+        };
+        if (search_costs(b, a, csh_batch::ST_1) || search_decide(b, csh_batch::ST_1)) return -1;      // Al of luma (unless Al 3 is still to be tried) and of chroma
+        if (gated(csh_batch::ST_1B, [&](int i) { return b->simg[size_t(i)].luma_on ? 1 : 0; })) return -1;
+        if (run_stage(b->stage[csh_batch::ST_2], false, false)) return -1;
+        if (search_costs(b, a, csh_batch::ST_2) || search_decide(b, csh_batch::ST_2)) return -1;      // the splits up to the third
+        for (int sid : {int(csh_batch::ST_2B), int(csh_batch::ST_2C)})
+            if (gated(sid, [&](int i) { return (b->simg[size_t(i)].luma_on ? 1 : 0) | (b->simg[size_t(i)].chroma_on ? 2 : 0); })) return -1;
+        if (search_lists(b)) return -1;
     }
     MARK();
     launch_layout(st, a);
@@ -1608,6 +1703,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
         }
         for (uint32_t v : ns) { if (v == 4) { t->n_prog_decoded++; continue; } if (v) t->n_seq_decoded++; if (v == 2 || v == 3) t->n_par_fallback++; if (v == 3) t->n_par_short++; }
         t->n_images = uint32_t(b->nimg);
+        t->n_search_extra = b->search ? b->n_gated_runs : 0u;
         for (const Item &it : b->items) if (it.image < 0) t->n_failed++;
         for (int i = 0; i < b->nimg; i++) { t->out_bytes += b->h_img_size[i]; t->pixels += uint64_t(b->imgs[i].width) * b->imgs[i].height; }
         t->in_bytes = b->bits_pool.size();

@@ -195,7 +195,9 @@ struct AcSlot { uint32_t unit_base, word_base, first_chunk, table_base, nunits_w
 struct TokPlan {
     uint32_t nslot, nunits;        // AC scans of the component; its blocks
     int32_t real_bw, bw;           // block grid: real and MCU-padded width
-    uint32_t tile_base, pad[3];
+    uint32_t tile_base;
+    uint32_t work0;                // first work item of these scans (EncCtx::work_active: a gated stage codes or skips a plan's scans together)
+    uint32_t pad[2];
     AcSlot s[CSH_TK_MAXSLOT];
 };
 // what the per-slot kernels need of (work item, chunk j), in one 32-byte load (host-built; slot = work.first_chunk + j)

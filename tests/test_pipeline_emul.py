@@ -28,6 +28,31 @@ def test_emul_bytes_equal_oracle(api, w, h, ss, tex):
     assert api.compress_in_memory(src, params()) == oracle_lossy(src)
 
 
+def test_emul_scan_search_conditional_stages(api):
+    """mozjpeg's search looks at luma Al 3 only when Al 2 beat Al 1, and at the splits at 12 / 18 only while the search runs on: those
+    candidates are coded in stages of their own, for the images that ask for them only.  A batch that mixes such images with ones whose
+    search stops early takes all three extra stages and every file still equals the oracle's; a batch of calm pictures takes none."""
+    from oracle import oracle as O
+    rich = [(0, 90, 80), (2, 40, 95), (0, 10, 80), (4, 90, 80), (1, 90, 80)]    # (seed, texture, quality): luma Al 2, splits at 12 and at 18 (luma and chroma)
+    calm = [(0, 0, 30), (3, 0, 30)]
+    for q in (80, 95, 30):
+        srcs = [synth_jpeg(sd, 160, 120, texture=tx) for sd, tx, qq in rich + calm if qq == q]
+        if not srcs:
+            continue
+        b = api.batch(srcs, params(jpeg_quality=q))
+        t = b.run()
+        outs = b.fetch()
+        for src, out in zip(srcs, outs):
+            assert out == oracle_lossy(src, q)
+        if q == 80:
+            assert t.n_search_extra == 3
+            scripts = [O.decode(o).scans() for o in outs]
+            assert any(s[1][4] == 2 for s in scripts)                                      # a luma band scan at Al 2: Al 3 was tried
+            assert any((0,) == s[1][0] and s[1][2] in (12, 18) for s in scripts)           # a late split won
+        if q == 30:
+            assert t.n_search_extra == 0
+
+
 @pytest.mark.parametrize("q", [1, 25, 51, 95, 100])
 def test_emul_quality_sweep(api, q):
     src = synth_jpeg(3, 120, 88, texture=35)

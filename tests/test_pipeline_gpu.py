@@ -92,6 +92,10 @@ def test_lossless_transcode(api):
             assert np.array_equal(a.coefs(c), b.coefs(c))
 
 
+def test_scan_search_conditional_stages(api):
+    E.test_emul_scan_search_conditional_stages(api)
+
+
 def test_non_interleaved_sequential_scans(api):
     E.test_emul_non_interleaved_sequential_scans(api)
 
