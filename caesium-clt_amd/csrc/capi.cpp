@@ -325,13 +325,38 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
 
 // one call, mixed inputs: PNG files go to the PNG pipeline, everything else to the JPEG pipeline (which
 // answers per file for what it has no device path for); results keep the order of the inputs
+// GIF and TIFF files (libcaesium: gifski / the tiff crate; SURVEY.md 2 rows 9-10: outside the north-star's JPEG / PNG / WebP scope, "CPU
+// passthrough") are passed through: the file comes back as it is, with Success -- as for a PNG that oxipng cannot make smaller.  A tree
+// that holds such files (configs[4], /root/reference/src/compressor.rs:774 hands the engine a .tif) then completes without error lines; the
+// caller's overwrite / min-savings policy sees equal sizes and acts on that.  A resize or a conversion of such a file is still refused.
+static bool passthrough(const CByteArray &in, const CCSParameters *p, CByteArray *out, CCSResult *res) {
+    const int t = sniff(in.data, in.length);
+    if (t != CS_TYPE_GIF && t != CS_TYPE_TIFF) return false;
+    out->data = nullptr; out->length = 0;
+    if (p->width || p->height) { if (res) *res = make_result(CS_ERR_UNSUPPORTED, "resizing a GIF / TIFF file has no path in this build (the file itself is passed through without a size)"); return true; }
+    out->data = static_cast<uint8_t *>(malloc(in.length ? in.length : 1));
+    if (!out->data) { if (res) *res = make_result(CS_ERR_NO_DEVICE, "out of memory"); return true; }
+    memcpy(out->data, in.data, in.length); out->length = in.length;
+    if (res) *res = make_result(0, nullptr);
+    return true;
+}
 int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results) {
     std::vector<size_t> png, webp, other;   // PNG files: lossless under png.optimize, else the lossy (quantising) form of the same pipeline
+    int passed_failed = 0;
+    bool any_pass = false;
     for (size_t i = 0; i < count; i++) {
         const int t = sniff(inputs[i].data, inputs[i].length);
+        if (t == CS_TYPE_GIF || t == CS_TYPE_TIFF) {
+            CCSResult r = make_result(0, nullptr);
+            passthrough(inputs[i], p, &outputs[i], &r);
+            if (!r.success) passed_failed++;
+            if (results) results[i] = r; else cs_free_result(&r);
+            any_pass = true;
+            continue;
+        }
         (t == CS_TYPE_PNG ? png : t == CS_TYPE_WEBP ? webp : other).push_back(i);
     }
-    if (png.empty() && webp.empty()) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
+    if (png.empty() && webp.empty() && !any_pass) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
     int failed = 0;
     auto run = [&](const std::vector<size_t> &idx, int kind) {
         if (idx.empty()) return;
@@ -346,7 +371,7 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
     run(png, 1);
     run(webp, 2);
     run(other, 0);
-    return failed;
+    return failed + passed_failed;
 }
 CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, CByteArray *out) {
     CByteArray input; input.data = const_cast<uint8_t *>(in); input.length = n;
@@ -423,12 +448,21 @@ static int jpeg_batch_compress_to_size(const CByteArray *inputs, size_t count, C
 int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParameters *p, size_t max_output_size, bool return_smallest, int device,
                               CByteArray *outputs, CCSResult *results) {
     std::vector<size_t> png, webp, other;
+    int failed = 0;
+    bool any_pass = false;
     for (size_t i = 0; i < count; i++) {
         const int t = sniff(inputs[i].data, inputs[i].length);
+        if (t == CS_TYPE_GIF || t == CS_TYPE_TIFF) {   // passed through as it is (see passthrough()): there is no quality to walk
+            CCSResult r = make_result(0, nullptr);
+            passthrough(inputs[i], p, &outputs[i], &r);
+            if (!r.success) failed++;
+            results[i] = r;
+            any_pass = true;
+            continue;
+        }
         (t == CS_TYPE_PNG ? png : t == CS_TYPE_WEBP ? webp : other).push_back(i);
     }
-    if (png.empty() && webp.empty()) return jpeg_batch_compress_to_size(inputs, count, p, max_output_size, return_smallest, device, outputs, results);
-    int failed = 0;
+    if (png.empty() && webp.empty() && !any_pass) return jpeg_batch_compress_to_size(inputs, count, p, max_output_size, return_smallest, device, outputs, results);
     auto run = [&](const std::vector<size_t> &idx, int kind) {
         if (idx.empty()) return;
         std::vector<CByteArray> in(idx.size()), out(idx.size());

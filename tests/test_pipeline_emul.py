@@ -594,3 +594,19 @@ def test_product_library_fails_loudly_without_gpu():
     with pytest.raises(package().CaesiumError) as e:
         api.compress_in_memory(synth_jpeg(0, 64, 48), params())
     assert e.value.code == 10001
+
+
+def test_emul_gif_and_tiff_files_are_passed_through(api):
+    """SURVEY 2 rows 9-10 (out of the JPEG / PNG / WebP scope: "passthrough"): a GIF or TIFF among the inputs comes back as it is, with
+    Success, in its place -- the batch keeps its order and the other files are compressed as usual; a resize of such a file is refused"""
+    gif = b"GIF89a" + (16).to_bytes(2, "little") + (8).to_bytes(2, "little") + b"\x80\x00\x00" + bytes(6) + b"\x2c" + bytes(9) + b"\x02\x02\x44\x01\x00\x3b"
+    tif = b"II*\x00\x08\x00\x00\x00" + b"\x00\x00" + bytes(4)
+    jpg = synth_jpeg(3, 64, 48, texture=10)
+    outs = api.cs_batch_compress([gif, jpg, tif, jpg], params())
+    assert outs[0] == gif and outs[2] == tif and outs[1] == oracle_lossy(jpg) and outs[3] == outs[1]
+    assert api.compress_in_memory(gif, params()) == gif
+    sized = api.batch_compress_to_size([tif, jpg], params(), 4000)
+    assert sized[0] == tif and sized[1] == reference_size_walk(jpg, 4000)[1]
+    with pytest.raises(package().CaesiumError) as e:
+        api.compress_in_memory(gif, params(width=8))
+    assert e.value.code == 10407 or e.value.code > 0
