@@ -283,6 +283,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / CPU / other-config records (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--boundary", action="store_true", help="measure the BOUNDARY across --gpus ranks instead of the resident-in-HBM path: one shared file list, every rank calls "
+                    "cs_batch_compress from host buffers on its own device (strong scaling; /root/reference/src/compressor.rs:81-100's par_iter as device shards)")
+    ap.add_argument("--boundary-total", type=int, default=10000, help="files of the shared list of --boundary (SURVEY 8d: 10 000)")
+    ap.add_argument("--same-device", action="store_true", help="--boundary: every rank uses device 0 (two ranks on one GPU: the code path of N ranks without N GPUs)")
     args = ap.parse_args()
 
     if args.pmc_child:
@@ -298,6 +302,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)   # python bench.py --gpus N by itself: one process per GPU, this process only relays rank 0's line
+    if args.boundary:
+        return boundary_main(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -462,6 +468,60 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return out
+
+
+def boundary_main(args):
+    """`--boundary`: where multi-GPU scaling can actually break -- the host side.  One shared list of --boundary-total 1080p files (every rank
+    makes the same list: same seeds); rank r takes files r, r + N, r + 2N, ... (the per-file round-robin of caesium-clt_amd/sharding.py), and calls
+    cs_batch_compress on them from host buffers on its own device: marker parse on the host's cores, pinned upload, kernels, download, all
+    inside the time.  No collective touches the data; the barrier and the MAX over ranks of the elapsed time go over gloo (CPU), so that two
+    ranks may share one device (--same-device).  Prints ONE JSON line on rank 0: total files / slowest rank's time = strong scaling."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    from _util import package
+    pkg = package()
+    api = pkg.load()
+    if api.device_count() <= local:
+        raise SystemExit(f"rank {rank}: no HIP device {local}")
+    nuniq = max(1, min(args.unique, 256, args.boundary_total))
+    uniq = make_inputs(0, nuniq)                                   # the SAME list on every rank
+    files = [uniq[i % nuniq] for i in range(args.boundary_total)]
+    mine = files[rank::world]
+    params = pkg.default_parameters(jpeg_quality=80)
+    api.cs_batch_compress(mine[:64], params, device=local)         # block caches and code objects warm, as in a long-running caller
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = api.cs_batch_compress(mine, params, device=local)
+    dt = time.perf_counter() - t0
+    ok = sum(1 for r in res if isinstance(r, bytes))
+    out_bytes = sum(len(r) for r in res if isinstance(r, bytes))
+    stats = torch.tensor([dt, float(ok), float(out_bytes), float(len(mine))], dtype=torch.float64)
+    if world > 1:
+        mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, ok, out_bytes, nfiles = float(mx[0]), int(sm[1]), int(sm[2]), int(sm[3])
+        dist.destroy_process_group()
+    else:
+        nfiles = len(mine)
+    out = None
+    if rank == 0:
+        out = {"metric": "megapixels/sec JPEG q=80 1920x1080 batch, boundary (cs_batch_compress from host buffers)", "value": round(nfiles * MP_1080P / dt, 1), "unit": "MP/s",
+               "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32",
+               "data": "synthetic", "config": {"workload": f"configs[1] at the boundary: one list of {nfiles} synthetic 1080p q92 JPEGs ({nuniq} distinct), -q 80, host buffers in and out",
+                                               "sharding": f"file i -> rank i mod {world}, no collective on the data path", "devices": "all ranks on device 0" if args.same_device else "rank r on device r"},
+               "files": nfiles, "ok": ok, "out_bytes": out_bytes, "files_per_s": round(nfiles / dt, 1), "seconds_slowest_rank": round(dt, 3),
+               "host": {"nproc": os.cpu_count(), "cpu": cpu_model(), "parse_threads_per_rank": min(16, os.cpu_count() or 1)},
+               "note": "PCIe and the host side are inside this number; every rank parses on up to 16 host threads (pipeline.cpp batch_create) and uploads from its own pinned pool, so N ranks "
+                       "use up to 16 N cores and N upload streams of the host"}
+        print(json.dumps(out))
     return out
 
 

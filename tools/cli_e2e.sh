@@ -1,6 +1,8 @@
 #!/bin/bash
-# end-to-end CLI timing on the GPU box: N copies of 16 synthetic 1080p files through caesium-clt_amd/bin/caesiumclt
-N=${1:-2048}
+# end-to-end CLI timing on the GPU box: N copies of 16 synthetic 1080p files through caesium-clt_amd/bin/caesiumclt, files in -> files out.
+# usage: tools/cli_e2e.sh [files=2048] [gpus=1]     (gpus > 1: caesiumclt --gpus G deals its device batches round-robin over G devices,
+# one host thread pair per device -- the reference's rayon par_iter over files, /root/reference/src/compressor.rs:81-100, as device shards)
+N=${1:-2048}; G=${2:-1}
 D=/tmp/cli_e2e; rm -rf $D; mkdir -p $D/in
 python - <<PY
 import sys; sys.path.insert(0,'tools')
@@ -10,7 +12,7 @@ for k in range($N): open('$D/in/f%05d.jpg'%k,'wb').write(u[k%16])
 PY
 for t in 1 2; do
   rm -rf $D/out; s=$(date +%s.%N)
-  CSH_TRACE=1 caesium-clt_amd/bin/caesiumclt -q 80 -o $D/out --quiet $D/in
-  e=$(date +%s.%N); python -c "print(\"run $t: $N files in %.3f s\" % ($e - $s))"
+  CSH_TRACE=1 caesium-clt_amd/bin/caesiumclt -q 80 -o $D/out --quiet --gpus $G $D/in
+  e=$(date +%s.%N); python -c "print(\"run $t: $N files on $G device(s) in %.3f s = %.0f files/s\" % ($e - $s, $N / ($e - $s)))"
 done
 ls $D/out | wc -l
