@@ -86,7 +86,8 @@ def live_pmc(kernel, batch, profile, timeout=240):
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
             if r.returncode != 0:
-                return None, dict(detail, error=f"{counter}: rocprofv3 exited {r.returncode}: ...{r.stderr.decode(errors='replace')[-300:]}")
+                err = "\n".join(ln for ln in r.stderr.decode(errors="replace").splitlines() if not (ln[:1] in "WEI" and ln[1:5].isdigit()))   # the child's own words, not the profiler's log lines
+                return None, dict(detail, error=f"{counter}: rocprofv3 exited {r.returncode}: ...{err[-400:]}")
             vals = []
             for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(fn)):
@@ -378,6 +379,7 @@ def main():
             roof.update({"achieved": None, "frac": None})
         extras = world == 1 and not args.no_extras
         if world == 1 and not args.no_pmc:
+            api.release_cached_memory()   # the closed batch's pools sit in this process's block cache: the child needs the same 100 GB
             traffic, detail = live_pmc(names[dom], args.batch, prof_env)
             roof["traffic"] = traffic
             roof["traffic_detail"] = detail
@@ -449,6 +451,7 @@ def main():
             boundary = {"entry": "cs_batch_compress", "files": nb, "ok": ok, "seconds": round(tm[0], 4), "files_per_s": round(nb / tm[0], 1),
                         "value": round(nb * MP_1080P / tm[0], 1), "unit": "MP/s", "note": "host buffers in and out, one call, second call of the process"}
         if extras and args.cli_files > 0:
+            api.release_cached_memory()   # another process is about to use the device
             cli = cli_end_to_end(blobs, min(args.cli_files, 4096))
         out = {
             "metric": "megapixels/sec JPEG q=80 1920x1080 batch", "value": round(value, 1), "unit": "MP/s", "n_gpus": world,
@@ -636,6 +639,7 @@ def other_configs(api, pkg, blobs, local):
     except Exception as e:
         other["configs[3] JPEG -> WebP q85 long edge 1500"] = {"error": str(e)[:200]}
     try:
+        api.release_cached_memory()
         other["configs[4] mixed JPEG/PNG/WebP tree, caesiumclt -R -S -q 80"] = mixed_tree(blobs)
     except Exception as e:
         other["configs[4] mixed JPEG/PNG/WebP tree, caesiumclt -R -S -q 80"] = {"error": str(e)[:200]}

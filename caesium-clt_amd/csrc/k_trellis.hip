@@ -81,7 +81,10 @@ struct TrLds {
     float (*A)[256];      // [entry][lane]: cost of the cheapest path that ends with this entry
     float (*Z)[256];      // before the entry's step: Z just in front of its position; after it: Z at its position
     uint32_t (*P)[256];   // before: |DCT| (15) | position << 15 (6) | scalar level << 21 (10) | sign << 31;  after: predecessor entry + 1 (6) | position << 15 | chosen level << 21 | sign << 31
-    const uint8_t *len;   // AC symbol costs of the statistics pass: code length + size bits (the symbol's low nibble); 0 = symbol unused
+    const float *lenf;    // what an AC symbol costs, as the float the C source converts the rate to: code length + size bits (the symbol's low nibble);
+                          // 1e38 for a symbol the statistics pass never saw (its code length is 0: mozjpeg skips such candidates -- at that cost none can win)
+    const float *runf;    // [4] what 0..3 ZRLs in front of a symbol cost; 1e38 where ZRL has no code
+    int lenEOB;           // plain code length of the end-of-block symbol
     const int32_t *q8;    // 8 q, zig-zag order
     const float *rcp;     // 1 / (8 q)
     const float *lt;      // 1 / q^2
@@ -89,13 +92,16 @@ struct TrLds {
 
 // tables of the chunk's component -> LDS (all 256 lanes)
 // (the sweep reads the quantiser's three values per position from here: as loads from HBM they were 189 dependent round trips per wave)
-__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, uint8_t *s_len, int32_t *s_q8, float *s_rcp, float *s_lt) {
+__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, float *s_lenf, float *s_runf, int *s_eob, int32_t *s_q8, float *s_rcp, float *s_lt) {
     const TrellisWork &w = c.work[c.chunks[chi].work];
     const ImgDesc &im = c.imgs[w.image];
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
     const int tid = int(threadIdx.x);
-    const int l = c.tables[w.table_ac].size[tid];
-    s_len[tid] = uint8_t((tid == 0xF0 || tid == 0x00) ? l : (l ? l + (tid & 15) : 0));   // ZRL and EOB keep their plain lengths (their low nibble is no size)
+    const uint8_t *size = c.tables[w.table_ac].size;
+    const int l = size[tid];
+    s_lenf[tid] = l ? float(l + (tid & 15)) : 1e38f;
+    if (tid < 4) s_runf[tid] = tid == 0 ? 0.0f : (size[0xF0] ? float(tid * int(size[0xF0])) : 1e38f);
+    if (tid == 0) *s_eob = size[0x00];
     if (tid < 64) { s_q8[tid] = Q.div[tid]; s_rcp[tid] = Q.rcp[tid]; s_lt[tid] = Q.lt[tid]; }
 }
 
@@ -121,6 +127,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     const float lambda = float(TRELLIS_LAMBDA_C1 / (TRELLIS_LAMBDA_C2 + double(norm)));
     c.lambda[w.unit_base + u] = lambda;
     CSH_SCHED_FENCE();
+    if (c.debug & 1u) return;
 
     // ---- sweep: Z, the list of positions whose scalar level is not zero
     uint32_t ne = 0;
@@ -143,8 +150,12 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     const int dc_signed = r[0] < 0 ? -dc_level : dc_level;
     CSH_SCHED_FENCE();
 
-    // ---- the programme over list entries
-    const int lenZRL = L.len[0xF0], lenEOB = L.len[0x00];
+    // ---- the programme over list entries.  Every candidate's cost is the C source's float expression, operation for operation:
+    // (float(rate) + dist) + ((Z in front - Z at the predecessor) + the predecessor's path cost), rate = symbol bits + size + ZRL bits --
+    // float(rate) as the sum of two small exact floats (symbol cost, ZRL cost).  What mozjpeg skips (a symbol or a ZRL without a code, a
+    // candidate the level does not offer) is priced at 1e38 instead: such a sum is never below the running minimum, which starts at 1e38.
+    const float lenEOBf = float(L.lenEOB);
+    if (c.debug & 2u) ne = 0;
     for (uint32_t t = 0; CSH_ANY(t < ne); t++) {
         const bool on = t < ne;
         float Zp; uint32_t P;
@@ -161,28 +172,26 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         float dist[10];
         CSH_UNROLL
         for (int kc = 0; kc < 10; kc++) {
-            if (kc >= ncmax) break;
             const int cand = kc < ncand - 1 ? (2 << kc) - 1 : qval;
             const int delta = cand * q8 - x;
-            dist[kc] = (float(delta * delta) * lambda) * ltk;
+            dist[kc] = kc < ncand ? (float(delta * delta) * lambda) * ltk : 1e38f;
         }
         float bestc = 1e38f;
         uint32_t bestsel = 0;   // (predecessor entry + 1) << 4 | candidate
         // one predecessor: entry jj (position posj, path cost Aj, Z at its position Zj), or jj = -1: the start of the block
         auto from = [&](int jj, int posj, float Aj, float Zj) {
             const int zr = kpos - 1 - posj;
-            const bool okrun = on && !((zr >> 4) != 0 && lenZRL == 0);
-            const int run_bits = (zr >> 4) * lenZRL;
-            const int base = 16 * (zr & 15) + 1;   // in 1..241 whatever zr is: a lane that is not `on` reads a valid, unused byte
+            const float runf = L.runf[(zr >> 4) & 3];
+            const float *lf = L.lenf + (16 * (zr & 15) + 1);   // symbols (zr & 15) << 4 | 1 .. : in range whatever zr is (a lane that is not `on` reads valid, unused floats)
             const float tj = (Zp - Zj) + Aj;
+            const uint32_t sel0 = uint32_t(jj + 1) << 4;
             CSH_UNROLL
             for (int kc = 0; kc < 10; kc++) {
                 if (kc >= ncmax) break;
-                const int cb = int(L.len[base + kc]);   // code length + size bits
-                const float cost = (float(cb + run_bits) + dist[kc]) + tj;
-                const bool better = okrun && kc < ncand && cb != 0 && cost < bestc;
+                const float cost = ((lf[kc] + runf) + dist[kc]) + tj;
+                const bool better = cost < bestc;
                 bestc = better ? cost : bestc;
-                bestsel = better ? ((uint32_t(jj + 1) << 4) | uint32_t(kc)) : bestsel;
+                bestsel = better ? (sel0 | uint32_t(kc)) : bestsel;
             }
         };
         from(-1, 0, 0.0f, 0.0f);
@@ -203,17 +212,18 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     }
 
     // ---- the cheapest last coefficient
-    float best = Z63 + float(lenEOB);
+    float best = Z63 + lenEOBf;
     int last = -1;
     for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
         float Ae, Ze; uint32_t Pe;
         if (e < CSH_TR_CAP) { Ae = L.A[e][tid]; Ze = L.Z[e][tid]; Pe = L.P[e][tid]; }
         else { const uint32_t *q = sp + ((e - CSH_TR_CAP) * 3u) * 256u; Ae = tr_bits_f(CSH_SPILL_LD(q)); Ze = tr_bits_f(CSH_SPILL_LD(q + 256)); Pe = CSH_SPILL_LD(q + 512); }
         float cost = (Ae + Z63) - Ze;
-        if (int((Pe >> 15) & 63u) < 63) cost = cost + float(lenEOB);
+        if (int((Pe >> 15) & 63u) < 63) cost = cost + lenEOBf;
         if (e < ne && cost < best) { best = cost; last = int(e); }
     }
 
+    if (c.debug & 4u) return;
     // ---- the block: zeros, the scalar DC, the levels on the path back from the last coefficient
     int16_t *dst = c.coef + coef_index(g.tile_base, b, 0);
     {
@@ -237,20 +247,24 @@ __global__ void __launch_bounds__(256) k_trellis_ac(TrellisCtx c) {
     CSH_SHARED float s_A[CSH_TR_CAP][256];
     CSH_SHARED float s_Z[CSH_TR_CAP][256];
     CSH_SHARED uint32_t s_P[CSH_TR_CAP][256];
-    CSH_SHARED uint8_t s_len[256];
+    CSH_SHARED float s_lenf[256 + 16];   // + 16: the candidate loop's reads behind symbol 0xFA of a lane that is not coding stay inside
+    CSH_SHARED float s_runf[4];
+    CSH_SHARED int s_eob;
     CSH_SHARED int32_t s_q8[64];
     CSH_SHARED float s_rcp[64];
     CSH_SHARED float s_lt[64];
-    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.len = s_len; L.q8 = s_q8; L.rcp = s_rcp; L.lt = s_lt;
+    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.lenf = s_lenf; L.runf = s_runf; L.q8 = s_q8; L.rcp = s_rcp; L.lt = s_lt;
 #ifdef CSH_EMUL
     CSH_PHASE_LOOP(2) {
-        if (phase == 0) { trellis_stage(c, blockIdx.x, s_len, s_q8, s_rcp, s_lt); continue; }
+        if (phase == 0) { trellis_stage(c, blockIdx.x, s_lenf, s_runf, &s_eob, s_q8, s_rcp, s_lt); continue; }
+        L.lenEOB = s_eob;
         trellis_block(c, blockIdx.x, 0u, L);
     }
 #else
     for (uint32_t chi = blockIdx.x; chi < c.nchunks; chi += gridDim.x) {
-        trellis_stage(c, chi, s_len, s_q8, s_rcp, s_lt);
+        trellis_stage(c, chi, s_lenf, s_runf, &s_eob, s_q8, s_rcp, s_lt);
         __syncthreads();
+        L.lenEOB = s_eob;
         trellis_block(c, chi, blockIdx.x, L);
         __syncthreads();
     }

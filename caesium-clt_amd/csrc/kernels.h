@@ -122,6 +122,7 @@ struct TrellisCtx {
     uint64_t *dcbt;            // per real block: back-pointers of the DC path (9 x 4 bits) | rounded DC level << 36 | sign << 47
     uint32_t *spill;           // per workgroup of the AC kernel: entries of the block lists that do not fit LDS
     uint32_t max_rows;         // DC kernel: most iMCU rows of a component
+    uint32_t debug;            // CSH_TR_DEBUG: timing experiments (parts of k_trellis_ac switched off; the output is then garbage)
 };
 void launch_trellis_ac(hipStream_t st, const TrellisCtx &c);
 void launch_trellis_dc(hipStream_t st, const TrellisCtx &c);

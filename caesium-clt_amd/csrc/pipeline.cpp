@@ -402,6 +402,14 @@ static int plan_item(Item &it, const CCSParameters &p, bool lossless) {
     return 0;
 }
 
+// Device pools and pinned blocks of finished batches stay in per-device / process-wide caches (devmem.hpp: hipMalloc / hipFree cost more than
+// the kernels); a caller that wants the memory back -- another process is about to use the device -- says so here.
+extern "C" void csh_release_cached_memory(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    for (int d = 0; d < n && d < 64; d++) device_cache(d).trim(0);
+    pinned_cache().trim(0);
+}
 extern "C" int csh_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1529,6 +1537,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         tc.imgs = b->d_imgs.p; tc.quant = b->d_quants.p; tc.work = b->d_twork.p; tc.nwork = int(b->twork.size()); tc.chunks = b->d_tchunks.p; tc.nchunks = uint32_t(b->tchunks.size());
         tc.tables = b->d_tables.p; tc.raw = b->d_dct_raw.p; tc.raw_tile0 = b->ntiles_in; tc.coef = b->d_coef.p; tc.lambda = b->d_tlambda.p; tc.dcbt = b->d_tdcbt.p;
         tc.spill = b->d_tspill.p; tc.max_rows = b->t_max_rows;
+        tc.debug = getenv("CSH_TR_DEBUG") ? uint32_t(atoi(getenv("CSH_TR_DEBUG"))) : 0u;
         launch_trellis_ac(st, tc);
         MARK();
         launch_trellis_dc(st, tc);

@@ -136,6 +136,7 @@ typedef struct {
 
 int csh_device_count(void);
 const char *csh_last_error(void);
+void csh_release_cached_memory(void);   /* hand the cached device pools and pinned blocks of finished batches back to the driver (they are kept for the next batch otherwise) */
 const char *csh_kernel_name(int slot);
 const char *csh_kernel_name_webp(int slot);   /* the same for a csh_batch_create_webp batch: behind the resize slot come the VP8 tail's kernels */
 int csh_batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, csh_batch **out);
