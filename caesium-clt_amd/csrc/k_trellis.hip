@@ -299,37 +299,74 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
         int cprev[9];
         CSH_UNROLL
         for (int k = 0; k < 9; k++) { acc[k] = 0.0f; cprev[k] = 0; }
+        int qprev = 0, sprev = 0;   // the block before: its rounded level and sign
+        bool cprev_clamped = false;
         for (int bi = 0; bi < g.real_bw; bi++) {
             const uint32_t u = uint32_t(by * g.real_bw + bi);
             const int raw0 = c.raw[coef_index(g.tile_base - c.raw_tile0, by * g.bw + bi, 0)];
             const float lambda_dc = c.lambda[w.unit_base + u] * lt0;
             const int x = raw0 < 0 ? -raw0 : raw0;
             const int qval = tr_level(x, q, rcp);
+            const int sgn = raw0 < 0 ? 1 : 0;
+            const bool clamped = qval + half > TRELLIS_MAX_LEVEL;   // a candidate is cut off at the largest level: the closed form below does not hold
             uint64_t bt = 0;
             float nacc[9];
             int ccur[9];
+            float dist[9];
             CSH_UNROLL
             for (int k = 0; k < 9; k++) {
-                nacc[k] = 0.0f; ccur[k] = 0;
+                nacc[k] = 0.0f; ccur[k] = 0; dist[k] = 0.0f;
                 if (k < ncand) {
                     int cand = qval - half + k;
                     cand = cand > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : cand;
                     cand = cand < -TRELLIS_MAX_LEVEL ? -TRELLIS_MAX_LEVEL : cand;
                     const int delta = cand * q - x;
-                    const float dist = float(delta * delta) * lambda_dc;
-                    cand = raw0 < 0 ? -cand : cand;
-                    ccur[k] = cand;
-                    if (bi == 0) {
-                        const int d = cand - last_dc, bits = tr_bitlen(unsigned(d < 0 ? -d : d));
-                        nacc[k] = s_cost[bits] + dist;
-                    } else {
+                    dist[k] = float(delta * delta) * lambda_dc;
+                    ccur[k] = sgn ? -cand : cand;
+                }
+            }
+            if (bi == 0) {
+                CSH_UNROLL
+                for (int k = 0; k < 9; k++)
+                    if (k < ncand) { const int d = ccur[k] - last_dc, bits = tr_bitlen(unsigned(d < 0 ? -d : d)); nacc[k] = s_cost[bits] + dist[k]; }
+            } else if (clamped || cprev_clamped) {
+                // the general statement: every pair of levels by itself
+                CSH_UNROLL
+                for (int k = 0; k < 9; k++) {
+                    if (k < ncand) {
                         float bc = 0.0f;
                         uint32_t bl = 0;
                         CSH_UNROLL
                         for (int l = 0; l < 9; l++) {
                             if (l < ncand) {
-                                const int d = cand - cprev[l], bits = tr_bitlen(unsigned(d < 0 ? -d : d));
-                                const float cost = (s_cost[bits] + dist) + acc[l];
+                                const int d = ccur[k] - cprev[l], bits = tr_bitlen(unsigned(d < 0 ? -d : d));
+                                const float cost = (s_cost[bits] + dist[k]) + acc[l];
+                                if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
+                            }
+                        }
+                        nacc[k] = bc;
+                        bt |= uint64_t(bl) << (4 * k);
+                    }
+                }
+            } else {
+                // the levels of a block are consecutive integers, so the difference of level k to the previous block's level l depends on
+                // k - l (equal signs: |qval - qprev + k - l|) or on k + l (opposite signs: |qval + qprev - 2 half + k + l|) alone: 17 + 17
+                // category look-ups instead of 81
+                const bool same = sgn == sprev;
+                const int base = same ? qval - qprev : qval + qprev - 2 * half;
+                float cd[17];
+                CSH_UNROLL
+                for (int i = 0; i < 17; i++) { const int d = base + (i - 8); const int dd = same ? d : d + 8; cd[i] = s_cost[tr_bitlen(unsigned(dd < 0 ? -dd : dd))]; }   // same: index k - l + 8; opposite: index k + l
+                CSH_UNROLL
+                for (int k = 0; k < 9; k++) {
+                    if (k < ncand) {
+                        float bc = 0.0f;
+                        uint32_t bl = 0;
+                        CSH_UNROLL
+                        for (int l = 0; l < 9; l++) {
+                            if (l < ncand) {
+                                const float cbits = same ? cd[k - l + 8] : cd[k + l];
+                                const float cost = (cbits + dist[k]) + acc[l];
                                 if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
                             }
                         }
@@ -340,6 +377,7 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
             }
             CSH_UNROLL
             for (int k = 0; k < 9; k++) { acc[k] = nacc[k]; cprev[k] = ccur[k]; }
+            qprev = qval; sprev = sgn; cprev_clamped = clamped;
             c.dcbt[w.unit_base + u] = bt | (uint64_t(uint32_t(qval)) << 36) | (uint64_t(raw0 < 0 ? 1u : 0u) << 47);
         }
         float bv = acc[0];
