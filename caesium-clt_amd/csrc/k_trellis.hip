@@ -125,7 +125,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     for (int n = 1; n < 64; n++) { const int v = r[kN2Z[n]]; norm = norm + float(v * v); }
     norm = float(double(norm) / 63.0);
     const float lambda = float(TRELLIS_LAMBDA_C1 / (TRELLIS_LAMBDA_C2 + double(norm)));
-    c.lambda[w.unit_base + u] = lambda;
+    c.dcrec[w.unit_base + u] = (uint64_t(tr_f_bits(lambda)) << 32) | (uint32_t(r[0]) & 0xFFFFu);   // what the DC kernel needs of this block, in one load
     CSH_SCHED_FENCE();
     if (c.debug & 1u) return;
 
@@ -301,10 +301,15 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
         for (int k = 0; k < 9; k++) { acc[k] = 0.0f; cprev[k] = 0; }
         int qprev = 0, sprev = 0;   // the block before: its rounded level and sign
         bool cprev_clamped = false;
+        // a lane walks its row block by block and every step needs that block's record: the next one is fetched a step ahead (the walk
+        // was bound by the latency of these loads: 6 waves per SIMD, two dependent loads per block)
+        uint64_t rec_next = c.dcrec[w.unit_base + uint32_t(by * g.real_bw)];
         for (int bi = 0; bi < g.real_bw; bi++) {
             const uint32_t u = uint32_t(by * g.real_bw + bi);
-            const int raw0 = c.raw[coef_index(g.tile_base - c.raw_tile0, by * g.bw + bi, 0)];
-            const float lambda_dc = c.lambda[w.unit_base + u] * lt0;
+            const uint64_t rec = rec_next;
+            if (bi + 1 < g.real_bw) rec_next = c.dcrec[w.unit_base + u + 1u];
+            const int raw0 = int(int16_t(uint16_t(rec & 0xFFFFu)));
+            const float lambda_dc = tr_bits_f(uint32_t(rec >> 32)) * lt0;
             const int x = raw0 < 0 ? -raw0 : raw0;
             const int qval = tr_level(x, q, rcp);
             const int sgn = raw0 < 0 ? 1 : 0;
@@ -384,8 +389,10 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
         uint32_t j = 0;
         CSH_UNROLL
         for (int i = 1; i < 9; i++) if (i < ncand && acc[i] < bv) { bv = acc[i]; j = uint32_t(i); }
+        uint64_t bt_next = c.dcbt[w.unit_base + uint32_t(by * g.real_bw + g.real_bw - 1)];
         for (int bi = g.real_bw - 1; bi >= 0; bi--) {
-            const uint64_t rec = c.dcbt[w.unit_base + uint32_t(by * g.real_bw + bi)];
+            const uint64_t rec = bt_next;
+            if (bi > 0) bt_next = c.dcbt[w.unit_base + uint32_t(by * g.real_bw + bi - 1)];
             int cand = int((rec >> 36) & 2047u) - half + int(j);
             cand = cand > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : cand;
             cand = cand < -TRELLIS_MAX_LEVEL ? -TRELLIS_MAX_LEVEL : cand;

@@ -118,7 +118,7 @@ struct TrellisCtx {
     const int16_t *raw;        // unquantised jfdctint output, tiles (index relative to raw_tile0)
     uint32_t raw_tile0;
     int16_t *coef;             // re-quantised coefficients (tiles)
-    float *lambda;             // per real block: the block's lambda (AC kernel -> DC kernel)
+    uint64_t *dcrec;           // per real block: lambda (float bits) << 32 | the unquantised DC & 0xFFFF (AC kernel -> DC kernel)
     uint64_t *dcbt;            // per real block: back-pointers of the DC path (9 x 4 bits) | rounded DC level << 36 | sign << 47
     uint32_t *spill;           // per workgroup of the AC kernel: entries of the block lists that do not fit LDS
     uint32_t max_rows;         // DC kernel: most iMCU rows of a component

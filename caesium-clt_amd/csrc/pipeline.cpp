@@ -192,7 +192,7 @@ struct csh_batch {
     DevBuf<uint8_t> d_work_active;
     DevBuf<TrellisWork> d_twork;
     DevBuf<TrellisChunk> d_tchunks;
-    DevBuf<float> d_tlambda;
+    DevBuf<uint64_t> d_tlambda;
     DevBuf<uint64_t> d_tdcbt;
     DevBuf<uint32_t> d_tspill;
 
@@ -1535,7 +1535,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         TrellisCtx tc;
         memset(&tc, 0, sizeof tc);
         tc.imgs = b->d_imgs.p; tc.quant = b->d_quants.p; tc.work = b->d_twork.p; tc.nwork = int(b->twork.size()); tc.chunks = b->d_tchunks.p; tc.nchunks = uint32_t(b->tchunks.size());
-        tc.tables = b->d_tables.p; tc.raw = b->d_dct_raw.p; tc.raw_tile0 = b->ntiles_in; tc.coef = b->d_coef.p; tc.lambda = b->d_tlambda.p; tc.dcbt = b->d_tdcbt.p;
+        tc.tables = b->d_tables.p; tc.raw = b->d_dct_raw.p; tc.raw_tile0 = b->ntiles_in; tc.coef = b->d_coef.p; tc.dcrec = b->d_tlambda.p; tc.dcbt = b->d_tdcbt.p;
         tc.spill = b->d_tspill.p; tc.max_rows = b->t_max_rows;
         tc.debug = getenv("CSH_TR_DEBUG") ? uint32_t(atoi(getenv("CSH_TR_DEBUG"))) : 0u;
         launch_trellis_ac(st, tc);
