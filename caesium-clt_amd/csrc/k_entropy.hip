@@ -340,9 +340,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
     CSH_SHARED uint32_t off[CSH_TK_MAXSLOT][256];   // exclusive scan of them inside the lane's wave
     CSH_SHARED uint32_t s_wtot[4][CSH_TK_MAXSLOT];  // per wave: tokens of the slot
     CSH_SHARED unsigned long long s_wbase[4][CSH_TK_MAXSLOT];   // per wave: first token of its segment in the pool (~0: no room)
-    CSH_SHARED uint32_t s_raw[CSH_TK_MAXSLOT];      // raw (non-Huffman) bits of the slot (the bits behind the EOBRUN symbols of runs resolved here included)
-    CSH_SHARED unsigned long long s_symw[CSH_TK_MAXSLOT][4];   // per slot and wave: bit b set iff block b of the wave emits a symbol / ends with a pending EOB
-    CSH_SHARED unsigned long long s_eobw[CSH_TK_MAXSLOT][4];   // (the same words that go to c.sym_bits / c.eob_bits: phase 5 resolves the chunk's own EOB runs from them)
+    CSH_SHARED uint32_t s_raw[CSH_TK_MAXSLOT];      // raw (non-Huffman) bits of the slot, EOBRUN bits excluded
     CSH_SHARED TokPlan s_plan;                      // kind 0: the component's geometry and AC scans
     CSH_SHARED ScanWork s_w;                        // kind 1: the work item, its scan and its image (copied once: the walkers read them
     CSH_SHARED EncScan s_sc;                        //         field by field, and every read from HBM is a dependent scalar load)
@@ -355,14 +353,13 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
 
     // a conditional stage of the scan search codes only the images whose search asks for it: the others' workgroups have nothing to do
     const bool skipped = c.work_active && !c.work_active[ch.kind == 1 ? ch.a : c.plans[ch.plan].work0];
-    CSH_PHASE_LOOP_MIXED(7, 0x0Eu) {   // after phases 1, 2, 3 only the wave synchronises
+    CSH_PHASE_LOOP_MIXED(6, 0x0Eu) {   // after phases 1, 2, 3 only the wave synchronises
         if (skipped) continue;
         if ((c.debug & 1024u) && ch.kind == 1) continue;
         if ((c.debug & 2048u) && ch.kind == 0) continue;
         if (phase == 0) {
             for (int i = tid; i < CSH_TK_MAXSLOT * 257; i += 256) hist[i] = 0;
             if (tid < CSH_TK_MAXSLOT) s_raw[tid] = 0;
-            if (tid < CSH_TK_MAXSLOT * 4) { s_symw[tid >> 2][tid & 3] = 0ull; s_eobw[tid >> 2][tid & 3] = 0ull; }
             if (ch.kind == 0 && tid < int(sizeof(TokPlan) / 4)) reinterpret_cast<uint32_t *>(&s_plan)[tid] = reinterpret_cast<const uint32_t *>(c.plans + ch.plan)[tid];
             if (ch.kind == 1) {
                 const ScanWork &gw = c.work[ch.a];
@@ -449,12 +446,11 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                 }
                 cnt[slot][tid] = n;
 #ifdef CSH_EMUL
-                if (has_sym) { atomicOr(reinterpret_cast<unsigned long long *>(c.sym_bits + a.word_base + (u >> 6)), 1ull << (u & 63)); atomicOr(&s_symw[slot][wv], 1ull << (u & 63)); }
-                if (ends_eob) { atomicOr(reinterpret_cast<unsigned long long *>(c.eob_bits + a.word_base + (u >> 6)), 1ull << (u & 63)); atomicOr(&s_eobw[slot][wv], 1ull << (u & 63)); }
+                if (has_sym) atomicOr(reinterpret_cast<unsigned long long *>(c.sym_bits + a.word_base + (u >> 6)), 1ull << (u & 63));
+                if (ends_eob) atomicOr(reinterpret_cast<unsigned long long *>(c.eob_bits + a.word_base + (u >> 6)), 1ull << (u & 63));
 #else
                 // lane = block, so a wave's 64 flags ARE one word of the scan's bit vectors: one ballot, one 8-byte store
                 const uint64_t ms = __ballot(has_sym), me = __ballot(ends_eob);
-                if (lane == 0) { s_symw[slot][wv] = ms; s_eobw[slot][wv] = me; }
                 if (lane == 0 && (u >> 6) < ((a.nunits_work + 63) >> 6)) { c.sym_bits[a.word_base + (u >> 6)] = ms; c.eob_bits[a.word_base + (u >> 6)] = me; }
 #endif
             }
@@ -582,50 +578,6 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             }
             continue;
         }
-        if (phase == 5) {
-            // ---------------------------------------------------------------- EOB runs that begin and end inside this chunk (all but one or two per scan
-            // and chunk): the first block of a run owns its EOBRUN symbol (jcphuff.c emits it in front of the next symbol; here it rides at the
-            // owner's EOB token).  A run starts at a block that ends with an EOB and either has symbols of its own or follows a block that does
-            // not end with one; it ends in front of the next block with a symbol.  Resolved here: runs of at most 14 blocks (no correction-bit
-            // limit can cut them: 14 x 63 <= 937) and first-pass runs shorter than 0x7FFF whose end lies in this chunk (or at the scan's end).
-            // Everything else -- the chunk's first block when it may continue a run of the chunk before, a run that leaves the chunk, a long
-            // refinement run -- is marked 0xFFFF for k_ac_runs, which settles it from the scan's bit vectors.
-            if (ch.kind != 0) continue;
-            for (int slot = 0; slot < int(P.nslot); slot++) {
-                const AcSlot &a = P.s[slot];
-                if (u >= a.nunits_work) continue;
-                const int w0 = tid >> 6, bit = tid & 63;
-                const unsigned long long s0 = s_symw[slot][w0], e0 = s_eobw[slot][w0];
-                if (!((e0 >> bit) & 1ull)) continue;                                   // does not end with an EOB: owns nothing
-                const bool has = ((s0 >> bit) & 1ull) != 0;
-                bool defer = false, start = has;
-                if (!has) {
-                    if (tid == 0) { if (ch.j == 0) start = true; else defer = true; }   // the chunk before knows whether its last block ends with an EOB
-                    else start = !((tid & 63) ? ((e0 >> (bit - 1)) & 1ull) : ((s_eobw[slot][w0 - 1] >> 63) & 1ull));
-                }
-                if (!start && !defer) continue;
-                uint32_t len = 0;
-                if (!defer) {
-                    // the next block with a symbol: behind this bit in this wave's word, then in the following waves' words
-                    int next = -1;
-                    unsigned long long m = bit == 63 ? 0ull : (s0 & (~0ull << (bit + 1)));
-                    int wq = w0;
-                    while (!m && ++wq < 4) m = s_symw[slot][wq];
-                    if (m) next = (wq << 6) + __ffsll(m) - 1;
-                    const uint32_t in_chunk = a.nunits_work - ch.j * 256u < 256u ? a.nunits_work - ch.j * 256u : 256u;   // units of this chunk
-                    if (next >= 0 && uint32_t(next) < in_chunk) len = uint32_t(next - tid);
-                    else if (ch.j * 256u + in_chunk == a.nunits_work) len = in_chunk - uint32_t(tid);                  // the run ends with the scan
-                    else defer = true;
-                    if (!defer && !(len <= 14u || (len < 0x7FFFu && a.Ah == 0))) defer = true;
-                }
-                if (defer) { c.eobrun[a.unit_base + u] = 0xFFFFu; continue; }
-                c.eobrun[a.unit_base + u] = uint16_t(len);
-                const int nb = bitlen32(len) - 1;
-                atomicAdd(&hist[slot * 257 + (nb << 4)], 1u);
-                if (nb) atomicAdd(&s_raw[slot], uint32_t(nb));
-            }
-            continue;
-        }
         // -------------------------------------------------------------------- histograms -> tables, and per slot for k_chunk_sizes
         if (c.debug & 32u) continue;
         if (ch.kind == 1) {
@@ -715,9 +667,7 @@ __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
         uint32_t *freq = c.tables[r.table_base].freq;
         const uint64_t *sym = c.sym_bits + r.word_base, *eob = c.eob_bits + r.word_base;
         int my_nb = -1;
-        // k_tokens has settled every run that begins and ends inside its chunk; what it left is marked 0xFFFF
-        if (u < nunits && c.eobrun[r.unit_base + u] == 0xFFFFu) {
-            c.eobrun[r.unit_base + u] = 0;
+        if (u < nunits) {
             const uint32_t w0 = u >> 6, nwords = (nunits + 63) >> 6;
             const int bit = int(u & 63);
             const uint64_t s0 = sym[w0], e0 = eob[w0];
@@ -1324,7 +1274,7 @@ __global__ void __launch_bounds__(256) k_zero_edges(EncCtx c) {
     for (uint64_t wi = lo; wi <= hi; wi++) c.raw[wi] = 0;
 }
 void launch_zero_edges(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH(k_zero_edges, dim3((c.nslots + 255) / 256), dim3(256), st, c); }
-void launch_tokens(hipStream_t st, const EncCtx &c) { if (c.nechunks) CSH_LAUNCH_PHASED(k_tokens, 7, dim3(c.nechunks), dim3(256), st, c); }
+void launch_tokens(hipStream_t st, const EncCtx &c) { if (c.nechunks) CSH_LAUNCH_PHASED(k_tokens, 6, dim3(c.nechunks), dim3(256), st, c); }
 void launch_ac_runs(hipStream_t st, const EncCtx &c) {
     if (!c.nslots) return;
     CSH_LAUNCH(k_ac_runs, dim3((c.nslots + 3) / 4), dim3(256), st, c);

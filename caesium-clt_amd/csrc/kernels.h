@@ -84,7 +84,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint32_t *tok_cursor;      // per region: tokens handed out
     uint64_t *tok_off;         // per segment (slot x 4 + wave of k_tokens): first token
     uint32_t *chunk_ntok;      // per segment: number of tokens
-    uint16_t *slot_hist;       // per slot: ntables rows of 256 symbol counts (with the EOBRUN symbols of the runs k_tokens settles itself; those k_ac_runs settles are in slot_eobh)
+    uint16_t *slot_hist;       // per slot: ntables rows of 256 symbol counts (EOBRUN symbols excluded)
     uint32_t *slot_raw;        // per slot: raw bits (EOBRUN bits excluded)
     uint32_t *slot_eobh;       // per slot: [16] EOBn symbols owned by its units
     uint32_t *chunk_bits;      // per slot: size in bits of everything the chunk emits
