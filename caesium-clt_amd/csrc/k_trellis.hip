@@ -25,10 +25,11 @@
 
 namespace csh {
 
-#define CSH_TR_CAP 16                      // list entries per block that live in LDS (48 KiB per workgroup of 256 blocks)
+#define CSH_TR_CAP 16                      // list entries per block that live in LDS (192 bytes per block)
+#define CSH_TR_WGU uint32_t(CSH_TR_WG)     // blocks (= lanes) per workgroup of the AC kernel: kernels.h
 #define CSH_TR_SPILL (63 - CSH_TR_CAP)     // the rest, in HBM
 #define CSH_TR_MAXWG 2048                  // workgroups of the AC kernel (each loops over its share of the chunks)
-size_t trellis_spill_words() { return size_t(CSH_TR_MAXWG) * CSH_TR_SPILL * 3u * 256u; }
+size_t trellis_spill_words() { return size_t(CSH_TR_MAXWG) * CSH_TR_SPILL * 3u * CSH_TR_WGU; }
 
 #ifdef CSH_EMUL
 #define CSH_ANY(p) (p)                     // a lane cannot see the others there: its own loop bounds
@@ -78,9 +79,9 @@ __device__ __forceinline__ static uint32_t tr_f_bits(float f) { uint32_t u; memc
 #define TRELLIS_MAX_LEVEL 1023                    // (1 << MAX_COEF_BITS) - 1
 
 struct TrLds {
-    float (*A)[256];      // [entry][lane]: cost of the cheapest path that ends with this entry
-    float (*Z)[256];      // before the entry's step: Z just in front of its position; after it: Z at its position
-    uint32_t (*P)[256];   // before: |DCT| (15) | position << 15 (6) | scalar level << 21 (10) | sign << 31;  after: predecessor entry + 1 (6) | position << 15 | chosen level << 21 | sign << 31
+    float (*A)[CSH_TR_WG];      // [entry][lane]: cost of the cheapest path that ends with this entry
+    float (*Z)[CSH_TR_WG];      // before the entry's step: Z just in front of its position; after it: Z at its position
+    uint32_t (*P)[CSH_TR_WG];   // before: |DCT| (15) | position << 15 (6) | scalar level << 21 (10) | sign << 31;  after: predecessor entry + 1 (6) | position << 15 | chosen level << 21 | sign << 31
     const float *lenf;    // what an AC symbol costs, as the float the C source converts the rate to: code length + size bits (the symbol's low nibble);
                           // 1e38 for a symbol the statistics pass never saw (its code length is 0: mozjpeg skips such candidates -- at that cost none can win)
     const float *runf;    // [4] what 0..3 ZRLs in front of a symbol cost; 1e38 where ZRL has no code
@@ -98,8 +99,7 @@ __device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
     const int tid = int(threadIdx.x);
     const uint8_t *size = c.tables[w.table_ac].size;
-    const int l = size[tid];
-    s_lenf[tid] = l ? float(l + (tid & 15)) : 1e38f;
+    for (int i = tid; i < 256; i += CSH_TR_WG) { const int l = size[i]; s_lenf[i] = l ? float(l + (i & 15)) : 1e38f; }
     if (tid < 4) s_runf[tid] = tid == 0 ? 0.0f : (size[0xF0] ? float(tid * int(size[0xF0])) : 1e38f);
     if (tid == 0) *s_eob = size[0x00];
     if (tid < 64) { s_q8[tid] = Q.div[tid]; s_rcp[tid] = Q.rcp[tid]; s_lt[tid] = Q.lt[tid]; }
@@ -111,10 +111,10 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     const ImgDesc &im = c.imgs[w.image];
     const CompGeom g = im.out[w.comp];
     const int tid = int(threadIdx.x);
-    const uint32_t u = ch.j * 256u + uint32_t(tid);
+    const uint32_t u = ch.j * CSH_TR_WGU + uint32_t(tid);
     if (u >= w.nunits) return;
     const int by = int(u) / g.real_bw, b = by * g.bw + (int(u) - by * g.real_bw);
-    uint32_t *sp = c.spill + size_t(wg_slot) * (CSH_TR_SPILL * 3u * 256u) + uint32_t(tid);   // entry e >= CAP: sp[((e - CAP) * 3 + {0 A, 1 Z, 2 P}) * 256]
+    uint32_t *sp = c.spill + size_t(wg_slot) * (CSH_TR_SPILL * 3u * CSH_TR_WGU) + uint32_t(tid);   // entry e >= CAP: sp[((e - CAP) * 3 + {0 A, 1 Z, 2 P}) * WG]
 
     int r[64];
     tr_load(c.raw + coef_index(g.tile_base - c.raw_tile0, b, 0), r, Oct8());
@@ -140,7 +140,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         if (qv) {
             const uint32_t P = uint32_t(x) | (uint32_t(k) << 15) | (uint32_t(qv) << 21) | (v < 0 ? 0x80000000u : 0u);
             if (ne < CSH_TR_CAP) { L.Z[ne][tid] = Zrun; L.P[ne][tid] = P; }
-            else { CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 1u) * 256u, tr_f_bits(Zrun)); CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 2u) * 256u, P); }
+            else { CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 1u) * CSH_TR_WGU, tr_f_bits(Zrun)); CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU, P); }
             ne++;
         }
         Zrun = (float(x * x) * lambda) * L.lt[k] + Zrun;
@@ -160,7 +160,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         const bool on = t < ne;
         float Zp; uint32_t P;
         if (t < CSH_TR_CAP) { Zp = L.Z[t][tid]; P = L.P[t][tid]; }
-        else { Zp = tr_bits_f(CSH_SPILL_LD(sp + ((t - CSH_TR_CAP) * 3u + 1u) * 256u)); P = CSH_SPILL_LD(sp + ((t - CSH_TR_CAP) * 3u + 2u) * 256u); }
+        else { Zp = tr_bits_f(CSH_SPILL_LD(sp + ((t - CSH_TR_CAP) * 3u + 1u) * CSH_TR_WGU)); P = CSH_SPILL_LD(sp + ((t - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU); }
         if (!on) { Zp = 0.0f; P = 0u; }
         const int x = int(P & 0x7FFFu), kpos = int((P >> 15) & 63u), qval = int((P >> 21) & 1023u);
         const int q8 = L.q8[kpos];
@@ -198,8 +198,8 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         const int t_lds = int(t) < CSH_TR_CAP ? int(t) : CSH_TR_CAP;
         for (int jj = 0; jj < t_lds; jj++) from(jj, int((L.P[jj][tid] >> 15) & 63u), L.A[jj][tid], L.Z[jj][tid]);
         for (int jj = CSH_TR_CAP; jj < int(t); jj++) {
-            const uint32_t *q = sp + (uint32_t(jj - CSH_TR_CAP) * 3u) * 256u;
-            from(jj, int((CSH_SPILL_LD(q + 512) >> 15) & 63u), tr_bits_f(CSH_SPILL_LD(q)), tr_bits_f(CSH_SPILL_LD(q + 256)));
+            const uint32_t *q = sp + (uint32_t(jj - CSH_TR_CAP) * 3u) * CSH_TR_WGU;
+            from(jj, int((CSH_SPILL_LD(q + 2 * CSH_TR_WG) >> 15) & 63u), tr_bits_f(CSH_SPILL_LD(q)), tr_bits_f(CSH_SPILL_LD(q + CSH_TR_WG)));
         }
         if (on) {
             const int bk = int(bestsel & 15u);
@@ -207,7 +207,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             const float Zi = (float(x * x) * lambda) * ltk + Zp;
             const uint32_t P2 = (bestsel >> 4) | (uint32_t(kpos) << 15) | (level << 21) | (P & 0x80000000u);
             if (t < CSH_TR_CAP) { L.A[t][tid] = bestc; L.Z[t][tid] = Zi; L.P[t][tid] = P2; }
-            else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * 256u; CSH_SPILL_ST(q, tr_f_bits(bestc)); CSH_SPILL_ST(q + 256, tr_f_bits(Zi)); CSH_SPILL_ST(q + 512, P2); }
+            else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * CSH_TR_WGU; CSH_SPILL_ST(q, tr_f_bits(bestc)); CSH_SPILL_ST(q + CSH_TR_WG, tr_f_bits(Zi)); CSH_SPILL_ST(q + 2 * CSH_TR_WG, P2); }
         }
     }
 
@@ -217,7 +217,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
         float Ae, Ze; uint32_t Pe;
         if (e < CSH_TR_CAP) { Ae = L.A[e][tid]; Ze = L.Z[e][tid]; Pe = L.P[e][tid]; }
-        else { const uint32_t *q = sp + ((e - CSH_TR_CAP) * 3u) * 256u; Ae = tr_bits_f(CSH_SPILL_LD(q)); Ze = tr_bits_f(CSH_SPILL_LD(q + 256)); Pe = CSH_SPILL_LD(q + 512); }
+        else { const uint32_t *q = sp + ((e - CSH_TR_CAP) * 3u) * CSH_TR_WGU; Ae = tr_bits_f(CSH_SPILL_LD(q)); Ze = tr_bits_f(CSH_SPILL_LD(q + CSH_TR_WG)); Pe = CSH_SPILL_LD(q + 2 * CSH_TR_WG); }
         float cost = (Ae + Z63) - Ze;
         if (int((Pe >> 15) & 63u) < 63) cost = cost + lenEOBf;
         if (e < ne && cost < best) { best = cost; last = int(e); }
@@ -235,7 +235,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     for (int e = last; CSH_ANY(e >= 0);) {
         if (e >= 0) {
             uint32_t Pe;
-            if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + (uint32_t(e - CSH_TR_CAP) * 3u + 2u) * 256u);
+            if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + (uint32_t(e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
             const int pos = int((Pe >> 15) & 63u), level = int((Pe >> 21) & 1023u);
             dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
             e = int(Pe & 63u) - 1;
@@ -243,10 +243,10 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     }
 }
 
-__global__ void __launch_bounds__(256) k_trellis_ac(TrellisCtx c) {
-    CSH_SHARED float s_A[CSH_TR_CAP][256];
-    CSH_SHARED float s_Z[CSH_TR_CAP][256];
-    CSH_SHARED uint32_t s_P[CSH_TR_CAP][256];
+__global__ void __launch_bounds__(CSH_TR_WG) k_trellis_ac(TrellisCtx c) {
+    CSH_SHARED float s_A[CSH_TR_CAP][CSH_TR_WG];
+    CSH_SHARED float s_Z[CSH_TR_CAP][CSH_TR_WG];
+    CSH_SHARED uint32_t s_P[CSH_TR_CAP][CSH_TR_WG];
     CSH_SHARED float s_lenf[256 + 16];   // + 16: the candidate loop's reads behind symbol 0xFA of a lane that is not coding stay inside
     CSH_SHARED float s_runf[4];
     CSH_SHARED int s_eob;
@@ -407,9 +407,9 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
 void launch_trellis_ac(hipStream_t st, const TrellisCtx &c) {
     if (!c.nchunks) return;
 #ifdef CSH_EMUL
-    CSH_LAUNCH_PHASED(k_trellis_ac, 2, dim3(c.nchunks), dim3(256), st, c);
+    CSH_LAUNCH_PHASED(k_trellis_ac, 2, dim3(c.nchunks), dim3(CSH_TR_WG), st, c);
 #else
-    CSH_LAUNCH(k_trellis_ac, dim3(c.nchunks < CSH_TR_MAXWG ? c.nchunks : CSH_TR_MAXWG), dim3(256), st, c);
+    CSH_LAUNCH(k_trellis_ac, dim3(c.nchunks < CSH_TR_MAXWG ? c.nchunks : CSH_TR_MAXWG), dim3(CSH_TR_WG), st, c);
 #endif
 }
 void launch_trellis_dc(hipStream_t st, const TrellisCtx &c) {

@@ -107,6 +107,9 @@ void launch_pack(hipStream_t st, const EncCtx &c);
 
 // ---- mozjpeg's trellis quantiser (k_trellis.hip): re-quantise every block from the retained DCT with the statistics pass's code
 // lengths as rates -- AC coefficients per block (k_trellis_ac), DC coefficients along each row of blocks (k_trellis_dc)
+#ifndef CSH_TR_WG
+#define CSH_TR_WG 256   // blocks per workgroup (and per TrellisChunk) of k_trellis_ac (64 -- no wave waits for another's densest block, but the tables are staged four times as often -- measured 6 % slower)
+#endif
 struct TrellisCtx {
     const ImgDesc *imgs;
     const DevQuant *quant;

@@ -1041,7 +1041,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 tw.table_dc = progressive ? -1 : int32_t(sw.table_base);
                 tw.nunits = sw.nunits; tw.unit_base = b->t_units;
                 b->t_units += sw.nunits;
-                for (uint32_t j = 0; j < (sw.nunits + 255) / 256; j++) b->tchunks.push_back(TrellisChunk{uint32_t(b->twork.size()), j});
+                for (uint32_t j = 0; j < (sw.nunits + CSH_TR_WG - 1) / CSH_TR_WG; j++) b->tchunks.push_back(TrellisChunk{uint32_t(b->twork.size()), j});
                 b->t_max_rows = std::max<uint32_t>(b->t_max_rows, uint32_t((im.out[c].real_bh + im.out[c].v - 1) / im.out[c].v));
                 b->twork.push_back(tw);
             }
