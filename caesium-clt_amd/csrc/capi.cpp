@@ -94,9 +94,11 @@ static int jpeg_batch_compress(const CByteArray *inputs, size_t count, const CCS
         for (size_t k; (k = next++) < spans.size();)
             failed += jpeg_span_compress(inputs + spans[k].first, spans[k].second, p, device, outputs + spans[k].first, results ? results + spans[k].first : nullptr, span);
     };
-    std::thread second(worker);
+    const size_t nworkers = std::min<size_t>(spans.size(), getenv("CSH_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_WORKERS")))) : 2);
+    std::vector<std::thread> others;
+    for (size_t t = 1; t < nworkers; t++) others.emplace_back(worker);
     worker();
-    second.join();
+    for (auto &t : others) t.join();
     return failed.load();
 }
 static int jpeg_span_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results, size_t span) {

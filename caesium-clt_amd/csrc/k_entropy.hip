@@ -82,7 +82,7 @@ __device__ __forceinline__ static uint64_t wave_or64(uint64_t v) {
 __device__ __forceinline__ static uint32_t wave_incl_scan(const uint32_t *in, int lane) {
 #ifdef CSH_EMUL
     uint32_t s = 0;
-    for (int i = 0; i <= lane; i++) s += in[i];
+    for (int i = 0; i <= lane; i++) s += in[i] & 0xFFFFu;   // (k_tokens keeps another value in the high halves, written by the lanes that ran before this one)
     return s;
 #else
     return wave_incl_sum(in[lane]);
@@ -336,8 +336,8 @@ __device__ __forceinline__ static bool ac_scan_of(const EncScan &sc, int comp) {
 // in occupancy than the second load does.
 __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
     CSH_SHARED uint32_t hist[CSH_TK_MAXSLOT * 257];
-    CSH_SHARED uint32_t cnt[CSH_TK_MAXSLOT][256];   // tokens per (slot, lane)
-    CSH_SHARED uint32_t off[CSH_TK_MAXSLOT][256];   // exclusive scan of them inside the lane's wave
+    CSH_SHARED uint32_t cnt[CSH_TK_MAXSLOT][256];   // per (slot, lane): its tokens (low half: at most a few hundred) | the exclusive scan of them inside the lane's wave << 16
+                                                     // (one array instead of two: 12 KB of LDS less; the kernel stays at 3 waves per SIMD for its 167 VGPRs -- at 128 it spills 39)
     CSH_SHARED uint32_t s_wtot[4][CSH_TK_MAXSLOT];  // per wave: tokens of the slot
     CSH_SHARED unsigned long long s_wbase[4][CSH_TK_MAXSLOT];   // per wave: first token of its segment in the pool (~0: no room)
     CSH_SHARED uint32_t s_raw[CSH_TK_MAXSLOT];      // raw (non-Huffman) bits of the slot, EOBRUN bits excluded
@@ -460,8 +460,8 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             // ---------------------------------------------------------------- exclusive scan of the counts inside the wave, slot by slot
             const int nslot = ch.kind == 1 ? 1 : int(P.nslot);   // the slots above hold nothing (and are not read below)
             for (int slot = 0; slot < nslot; slot++) {
-                const uint32_t incl = wave_incl_scan(&cnt[slot][64 * wv], lane);
-                off[slot][tid] = incl - cnt[slot][tid];
+                const uint32_t incl = wave_incl_scan(&cnt[slot][64 * wv], lane);   // counts only: the high halves are still zero
+                cnt[slot][tid] |= (incl - cnt[slot][tid]) << 16;
                 if (lane == 63) s_wtot[wv][slot] = incl;
             }
             continue;
@@ -510,10 +510,10 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                 const ScanWork &w = s_w;
                 const EncScan &sc = s_sc;
                 if (u >= w.nunits) continue;
-                TokSink<true> s; s.begin(); s.out = out; s.out.pool = c.tokens + s_wbase[wv][0] + off[0][tid]; s.out.pos = 0; s.hist = hist; s.h0 = 0; s.rawbits = 0;
+                TokSink<true> s; s.begin(); s.out = out; s.out.pool = c.tokens + s_wbase[wv][0] + (cnt[0][tid] >> 16); s.out.pos = 0; s.hist = hist; s.h0 = 0; s.rawbits = 0;
                 if (sc.sequential) walk_seq(s, c, s_im, sc, u); else walk_dc(s, c, s_im, sc, u);
                 s.finish();
-                while (s.out.pos < cnt[0][tid]) s.out.put(TK_RAW);
+                while (s.out.pos < (cnt[0][tid] & 0xFFFFu)) s.out.put(TK_RAW);
                 if (s.rawbits) atomicAdd(&s_raw[0], s.rawbits);
                 continue;
             }
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                 const AcSlot &a = P.s[slot];
                 const uint64_t band = band_mask(a.Ss, a.Se);
                 const uint64_t lo = pick_sig(pl, a.Al);
-                out.pool = c.tokens + s_wbase[wv][slot] + off[slot][tid];
+                out.pool = c.tokens + s_wbase[wv][slot] + (cnt[slot][tid] >> 16);
                 out.pos = 0;
                 uint32_t rawbits = 0;
                 if (a.Ah == 0) {
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                 } else {
                     const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
                     if (c.debug & 8u) continue;
-                    emit_ac_refine(out, hist + slot * 257, uint32_t(tid), H, N, sgn, a.Ss, !((N >> a.Se) & 1), cnt[slot][tid]);
+                    emit_ac_refine(out, hist + slot * 257, uint32_t(tid), H, N, sgn, a.Ss, !((N >> a.Se) & 1), cnt[slot][tid] & 0xFFFFu);
                     rawbits = uint32_t(__popcll(N) + __popcll(H));   // a sign bit per new coefficient, a correction bit per old one
                 }
                 if (rawbits) atomicAdd(&s_raw[slot], rawbits);
