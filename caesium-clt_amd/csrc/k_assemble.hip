@@ -57,10 +57,7 @@ __device__ static uint32_t scan_header_bytes(const AsmCtx &a, const ScanWork &w,
     if (sc.ntables) { hdr += 4; for (int t = 0; t < sc.ntables; t++) hdr += 17 + a.tables[w.table_base + t].nsym; }
     return hdr + 2 + 2 + 1 + 2 * sc.ncomp + 3;
 }
-__device__ static uint64_t scan_stuffing(const AsmCtx &a, const ScanWork &w) {
-    uint64_t c0 = w.raw_off >> 6, c1 = (w.raw_off + ((uint64_t(w.raw_bytes) + 63) & ~uint64_t(63))) >> 6;
-    return c1 <= a.raw_chunks ? a.chunk_ffoff[c1] - a.chunk_ffoff[c0] : 0;
-}
+__device__ static uint64_t scan_stuffing(const AsmCtx &, const ScanWork &w) { return w.no_room ? 0u : w.ff_bytes; }
 __global__ void k_scan_cost(AsmCtx a) {
     int j = a.work0 + int(blockIdx.x * blockDim.x + threadIdx.x);
     if (j >= a.work0 + a.nwork_run) return;
@@ -92,19 +89,61 @@ __device__ static int owner_scan(const AsmCtx &a, uint64_t c) {
     return lo;
 }
 
+// 0xFF bytes of a word of the bit string whose first `nvalid` bytes (big-endian order) belong to the scan
+__device__ __forceinline__ static uint32_t ff_bytes_of(uint32_t w, uint32_t nvalid) {
+    const uint32_t x = ~w;                                   // a byte of x is zero where the scan has 0xFF
+    uint32_t y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    y = ~(y | x | 0x7F7F7F7Fu);                              // 0x80 in every zero byte of x, exactly
+    const uint32_t valid = nvalid >= 4 ? 0x80808080u : (~(0xFFFFFFFFu >> (8 * nvalid)) & 0x80808080u);
+    return uint32_t(__builtin_popcount(y & valid));
+}
+// the stuffing of the scans of one stage: one workgroup per scan, one 64-byte chunk per lane and step.  work[].ff_bytes gets the scan's
+// total (all that the scan search and k_layout ask for); the chunks' own counts stay in chunk_ff for k_ff_prefix.
 __global__ void __launch_bounds__(256) k_ff_count(AsmCtx a) {
-    uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c >= a.raw_chunks) return;
-    uint32_t n = 0;
-    uint64_t used = a.scan_raw_off[a.nwork];
-    if (c * 64 < used && used <= a.raw_chunks * 64) {
-        int j = owner_scan(a, c);
-        uint64_t rel = c * 64 - a.scan_raw_off[j];
-        uint64_t nbytes = a.work[j].raw_bytes;
-        for (int i = 0; i < 64; i++)
-            if (rel + i < nbytes && raw_byte(a.raw, c * 64 + i) == 0xFF) n++;
+    CSH_SHARED uint32_t s_total;
+    ScanWork &w = a.work[a.work0 + int(blockIdx.x)];
+    CSH_PHASE_LOOP(3) {
+        if (phase == 0) { if (threadIdx.x == 0) s_total = 0; continue; }
+        if (phase == 2) { if (threadIdx.x == 0) w.ff_bytes = s_total; continue; }
+        const uint32_t nbytes = w.no_room ? 0u : w.raw_bytes;
+        const uint64_t c0 = w.raw_off >> 6;
+        uint32_t mine = 0;
+        for (uint32_t c = threadIdx.x; uint64_t(c) * 64 < nbytes; c += blockDim.x) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.raw + (c0 + c) * 16);
+            const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            const uint32_t ws[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+            const uint32_t left = nbytes - c * 64;
+            uint32_t n = 0;
+            CSH_UNROLL
+            for (int j = 0; j < 16; j++) n += ff_bytes_of(ws[j], left > uint32_t(4 * j) ? left - uint32_t(4 * j) : 0u);
+            a.chunk_ff[c0 + c] = n;
+            mine += n;
+        }
+        if (mine) atomicAdd(&s_total, mine);
     }
-    a.chunk_ff[c] = n;
+}
+// the scans that made it into a file: chunk_ff becomes, in place, the number of stuffed bytes in front of each chunk within its scan
+// (what k_emit_data adds to a chunk's position).  One workgroup per scan; lane t owns a run of consecutive chunks.
+__global__ void __launch_bounds__(256) k_ff_prefix(AsmCtx a) {
+    CSH_SHARED uint32_t s_part[256];
+    const ScanWork &w = a.work[blockIdx.x];
+    const bool listed = w.out_off != 0xFFFFFFFFu && !w.no_room;
+    const uint32_t nchunks = listed ? (w.raw_bytes + 63u) >> 6 : 0u;
+    const uint32_t per = (nchunks + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = min(nchunks, threadIdx.x * per), hi = min(nchunks, lo + per);
+    uint32_t *cf = a.chunk_ff + (w.raw_off >> 6);
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) {
+            uint32_t n = 0;
+            for (uint32_t c = lo; c < hi; c++) n += cf[c];
+            s_part[threadIdx.x] = n;
+            continue;
+        }
+        if (lo == hi) continue;
+        uint32_t acc = 0;
+        for (uint32_t t = 0; t < threadIdx.x; t++) acc += s_part[t];
+        for (uint32_t c = lo; c < hi; c++) { const uint32_t n = cf[c]; cf[c] = acc; acc += n; }
+    }
 }
 
 // per image: where every scan lands in the file, and the file size
@@ -163,46 +202,49 @@ __global__ void k_emit_headers(AsmCtx a) {
 }
 
 // stuffed copy: one lane per 64-byte raw chunk
+// four workgroups per scan of a file (blockIdx.y), one 64-byte chunk per lane and step
 __global__ void __launch_bounds__(256) k_emit_data(AsmCtx a) {
-    uint64_t c = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (c >= a.raw_chunks || *a.overflow) return;
-    uint64_t used = a.scan_raw_off[a.nwork];
-    if (c * 64 >= used) return;
-    int j = owner_scan(a, c);
-    const ScanWork &w = a.work[j];
-    uint64_t rel = c * 64 - w.raw_off;
-    if (rel >= w.raw_bytes || w.out_off == 0xFFFFFFFFu) return;
-    uint64_t c0 = w.raw_off >> 6;
-    ByteRun o; o.begin(a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes + rel + (a.chunk_ffoff[c] - a.chunk_ffoff[c0]));
-    // the whole chunk first (four loads in flight at once), then the stores back to back: stores of one lane that are spread
-    // over several memory round trips reach HBM as separate 32-byte sector writes instead of merging in the L2
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.raw + c * 16);
-    const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-    const uint32_t ws[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-    const uint32_t nbytes = w.raw_bytes - rel < 64 ? uint32_t(w.raw_bytes - rel) : 64u;
-    CSH_UNROLL
-    for (int j = 0; j < 16; j++) {
+    if (*a.overflow) return;
+    const ScanWork &w = a.work[blockIdx.x];
+    if (w.out_off == 0xFFFFFFFFu || w.no_room) return;
+    const uint64_t c0 = w.raw_off >> 6;
+    uint8_t *dst = a.out + a.img_off[w.image] + w.out_off + w.hdr_bytes;
+    for (uint32_t c = blockIdx.y * blockDim.x + threadIdx.x; uint64_t(c) * 64 < w.raw_bytes; c += gridDim.y * blockDim.x) {
+        const uint32_t rel = c * 64;
+        ByteRun o; o.begin(dst + rel + a.chunk_ff[c0 + c]);
+        // the whole chunk first (four loads in flight at once), then the stores back to back: stores of one lane that are spread
+        // over several memory round trips reach HBM as separate 32-byte sector writes instead of merging in the L2
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.raw + (c0 + c) * 16);
+        const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        const uint32_t ws[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+        const uint32_t nbytes = w.raw_bytes - rel < 64 ? w.raw_bytes - rel : 64u;
         CSH_UNROLL
-        for (int i = 0; i < 4; i++) {
-            if (uint32_t(4 * j + i) < nbytes) {
-                uint32_t b = (ws[j] >> (24 - 8 * i)) & 255u;
-                o.push(b);
-                if (b == 0xFFu) o.push(0u);
+        for (int j = 0; j < 16; j++) {
+            CSH_UNROLL
+            for (int i = 0; i < 4; i++) {
+                if (uint32_t(4 * j + i) < nbytes) {
+                    uint32_t b = (ws[j] >> (24 - 8 * i)) & 255u;
+                    o.push(b);
+                    if (b == 0xFFu) o.push(0u);
+                }
             }
         }
+        o.finish();
     }
-    o.finish();
 }
 
 void launch_scan_sizes(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH(k_scan_sizes, dim3((a.nwork_run + 255) / 256), dim3(256), st, a); }
 void launch_scan_place(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH(k_scan_place, dim3((a.nwork_run + 255) / 256), dim3(256), st, a); }
 void launch_scan_cost(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH(k_scan_cost, dim3((a.nwork_run + 255) / 256), dim3(256), st, a); }
-void launch_ff_count(hipStream_t st, const AsmCtx &a) { if (a.raw_chunks) CSH_LAUNCH(k_ff_count, dim3(unsigned((a.raw_chunks + 255) / 256)), dim3(256), st, a); }
-void launch_layout(hipStream_t st, const AsmCtx &a) { if (a.nimg) CSH_LAUNCH(k_layout, dim3((a.nimg + 63) / 64), dim3(64), st, a); }
+void launch_ff_count(hipStream_t st, const AsmCtx &a) { if (a.nwork_run) CSH_LAUNCH_PHASED(k_ff_count, 3, dim3(unsigned(a.nwork_run)), dim3(256), st, a); }
+void launch_layout(hipStream_t st, const AsmCtx &a) {
+    if (a.nimg) CSH_LAUNCH(k_layout, dim3((a.nimg + 63) / 64), dim3(64), st, a);
+    if (a.nwork) CSH_LAUNCH_PHASED(k_ff_prefix, 2, dim3(unsigned(a.nwork)), dim3(256), st, a);
+}
 void launch_emit(hipStream_t st, const AsmCtx &a) {
     int n = a.nimg + a.nwork;
     if (n) CSH_LAUNCH(k_emit_headers, dim3((n + 63) / 64), dim3(64), st, a);
-    if (a.raw_chunks) CSH_LAUNCH(k_emit_data, dim3(unsigned((a.raw_chunks + 255) / 256)), dim3(256), st, a);
+    if (a.nwork) CSH_LAUNCH(k_emit_data, dim3(unsigned(a.nwork), 4), dim3(256), st, a);
 }
 
 }  // namespace csh

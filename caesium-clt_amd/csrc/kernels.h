@@ -151,8 +151,7 @@ struct AsmCtx {
     uint64_t *scan_raw_off;       // [nwork+1] exclusive scan of scan_pad_bytes
     const uint32_t *raw;          // packed bits, big-endian-logical u32 words
     uint64_t raw_chunks;          // capacity of raw in 64-byte chunks
-    uint32_t *chunk_ff;           // [raw_chunks] number of 0xFF bytes in the chunk
-    uint64_t *chunk_ffoff;        // [raw_chunks+1] exclusive scan of chunk_ff
+    uint32_t *chunk_ff;           // [raw_chunks] number of 0xFF bytes in the chunk (k_ff_count); after k_ff_prefix, for the scans of a file: of the chunks in front of it
     const uint8_t *hdr_pool;      // per-image frame headers (host-built: SOI .. SOFn)
     const uint32_t *hdr_off;      // [nimg+1]
     uint32_t *img_size_pad;       // [nimg] file size rounded up to 16
@@ -163,7 +162,7 @@ struct AsmCtx {
     uint32_t *status;             // per image
     uint32_t *overflow;           // [1] set when a pool is too small
 };
-void launch_scan_cost(hipStream_t st, const AsmCtx &a);      // scan_cost of the run's work items (after launch_ff_count + its scan)
+void launch_scan_cost(hipStream_t st, const AsmCtx &a);      // scan_cost of the run's work items (after launch_ff_count)
 void launch_scan_sizes(hipStream_t st, const AsmCtx &a);     // fills scan_pad_bytes + work[].raw_bytes
 void launch_scan_place(hipStream_t st, const AsmCtx &a);     // work[].raw_off from scan_raw_off
 void launch_ff_count(hipStream_t st, const AsmCtx &a);

@@ -182,7 +182,7 @@ struct csh_batch {
     DevBuf<uint8_t> d_wprobs, d_wupdate;
     uint32_t wmax_mbh = 0;
     DevBuf<int16_t> d_wlevels;
-    DevBuf<uint64_t> d_corr, d_symbits, d_eobbits, d_tok_off, d_chunk_off, d_scan_raw_off, d_chunk_ffoff, d_img_off;
+    DevBuf<uint64_t> d_corr, d_symbits, d_eobbits, d_tok_off, d_chunk_off, d_scan_raw_off, d_img_off;
     DevBuf<uint32_t> d_tok_cursor;
     DevBuf<TokRegion> d_regions;
     DevBuf<uint16_t> d_eobrun, d_slot_hist;
@@ -1180,7 +1180,7 @@ static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
     "k_idct_plane", "resize", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc", "k_tokens",
     "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack",
-    "k_ff_count", "scan_chunks", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", ""};
+    "k_ff_count", "-", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", ""};
 // a WebP batch (csh_batch_create_webp) leaves the JPEG path behind the resize slot: its next three slots are these
 static const char *const kWebpTailNames[3] = {"k_webp_yuv", "k_webp_mb", "k_webp_stats+probs+code+assemble"};
 
@@ -1403,10 +1403,10 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     const int nimg = b->nimg;
     uint64_t raw_chunks = (b->raw_bytes_cap + 63) / 64;
     if (b->d_raw.n != raw_chunks * 16) {
-        if (b->d_raw.alloc(raw_chunks * 16) || b->d_chunk_ff.alloc(raw_chunks + 1) || b->d_chunk_ffoff.alloc(raw_chunks + 2) || b->d_out.alloc(b->out_cap + 64))
+        if (b->d_raw.alloc(raw_chunks * 16) || b->d_chunk_ff.alloc(raw_chunks + 1) || b->d_out.alloc(b->out_cap + 64))
             return -1;
-        size_t tmp = std::max(std::max(exclusive_scan_tmp_bytes(b->slot_work.size() + 1), exclusive_scan_tmp_bytes(raw_chunks)),
-                              std::max(exclusive_scan_tmp_bytes(b->dc_total), exclusive_scan_tmp_bytes(b->bits_pool.size() / 64 + 1)));
+        const uint64_t longest = std::max({uint64_t(b->slot_work.size()), uint64_t(b->swork.size()), uint64_t(b->dc_total), uint64_t(b->total_sub), uint64_t(b->bits_pool.size() / 64), uint64_t(nimg)});
+        size_t tmp = exclusive_scan_tmp_bytes(longest + 1);   // the longest input any exclusive scan of a run gets
         if (b->d_scan_tmp.alloc(tmp)) return -1;
     }
     if (b->d_tokens.n < b->tok_cap && b->d_tokens.alloc(b->tok_cap)) return -1;
@@ -1549,7 +1549,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     a.imgs = b->d_imgs.p; a.script = b->d_script.p; a.work = b->d_swork.p; a.nimg = nimg;
     a.nwork = b->trellis ? int(b->tstage.work0) : c.nwork;   // the trellis stage's statistics scans (the last work items) put nothing into a file
     a.tables = b->d_tables.p; a.chunk_off = b->d_chunk_off.p; a.scan_pad_bytes = b->d_scan_pad.p; a.scan_raw_off = b->d_scan_raw_off.p;
-    a.raw = b->d_raw.p; a.raw_chunks = raw_chunks; a.chunk_ff = b->d_chunk_ff.p; a.chunk_ffoff = b->d_chunk_ffoff.p;
+    a.raw = b->d_raw.p; a.raw_chunks = raw_chunks; a.chunk_ff = b->d_chunk_ff.p;
     a.hdr_pool = b->d_hdr.p; a.hdr_off = b->d_hdr_off.p; a.img_size = b->d_img_size.p; a.img_size_pad = b->d_img_size_pad.p;
     a.img_off = b->d_img_off.p; a.out = b->d_out.p; a.out_cap = b->out_cap; a.status = b->d_status.p; a.overflow = b->d_overflow.p;
     a.img_list = b->d_img_list.p; a.img_nlist = b->d_img_nlist.p; a.scan_cost = b->d_scan_cost.p;
@@ -1580,8 +1580,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         SMARK();
         launch_ff_count(st, a);
         SMARK();
-        launch_exclusive_scan(st, b->d_chunk_ff.p, b->d_chunk_ffoff.p, raw_chunks, b->d_scan_tmp.p, b->d_scan_tmp.n);
-        SMARK();
+        SMARK();   // (the slot of the scan over every chunk's count that k_ff_count's per-scan totals replaced)
 #undef SMARK
         return 0;
     };

@@ -173,6 +173,7 @@ struct ScanWork {
     uint32_t first_chunk;  // first 256-unit chunk of this scan in the flat chunk list (EncCtx::chunk_work)
     uint32_t word_base;    // offset in the u64 bitmask arrays (AC scans), nwords = ceil(nunits/64)
     uint32_t table_base;   // first of this scan's Huffman tables in the table pool
+    uint32_t ff_bytes;     // 0xFF bytes among raw_bytes = bytes the stuffing adds (device-computed, k_ff_count)
     uint64_t raw_off;      // byte offset (multiple of 64) of the scan's unstuffed bytes in the raw pool (device-computed)
     uint32_t raw_bytes;    // unstuffed length in bytes (device-computed)
     uint32_t out_off;      // offset of this scan's DHT marker inside the image's output file (device-computed)
