@@ -266,19 +266,20 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
         limit = 512;
         std::vector<csp_pixels> px;
         std::vector<const uint8_t *> aplane;   // per picture: its alpha plane in device memory, or null (opaque)
+        std::vector<csp_pixels> rgb3;          // per picture: its RGB whatever its transparency ...
+        std::vector<const uint8_t *> rplane;   // ... and the plane of a picture the RGBA consumers (PNG, lossless WebP) get: what a resize works on
         std::vector<size_t> at;
         for (size_t k = 0; k < n && rc == 0; k++) {
             csp_pixels s; const char *msg = "";
             int code = cswd_batch_pixels(wb, k, &s.device_pixels, &s.width, &s.height, &s.channels, &msg);
             const uint8_t *rgba = nullptr, *plane = nullptr;
             if (!code) cswd_batch_alpha(wb, k, &rgba, &plane);
-            if (!code && plane && (p->width || p->height) && !(target == CS_TYPE_WEBP && !p->webp_lossless) && target != CS_TYPE_JPEG) {   // the RGBA consumers take no resize here
-                code = CS_ERR_UNSUPPORTED; msg = "resizing a WebP picture with transparency into a PNG / lossless WebP has no device path in this build";
-            }
             if (code) { if (results) results[g0 + k] = make_result(code, msg); failed_total++; continue; }
             // a picture with transparency: the PNG coder and the lossless WebP coder take its RGBA; the lossy WebP encoder its RGB, the plane becomes the
             // ALPH chunk afterwards; a JPEG drops the plane (as image-rs does)
-            if (plane && (target == CS_TYPE_PNG || (target == CS_TYPE_WEBP && p->webp_lossless))) { s.device_pixels = rgba; s.channels = 4; }
+            const bool wants_rgba = plane && (target == CS_TYPE_PNG || (target == CS_TYPE_WEBP && p->webp_lossless));
+            rgb3.push_back(s); rplane.push_back(wants_rgba ? plane : nullptr);
+            if (wants_rgba) { s.device_pixels = rgba; s.channels = 4; }
             px.push_back(s); aplane.push_back((plane && target == CS_TYPE_WEBP && !p->webp_lossless) ? plane : nullptr); at.push_back(g0 + k);
         }
         if (rc) { for (size_t k = 0; k < n; k++) if (results) results[g0 + k] = make_result(rc, csh_last_error()); failed_total += int(n); cswd_batch_destroy(wb); continue; }
@@ -286,25 +287,41 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
             std::vector<CByteArray> out(px.size());
             std::vector<CCSResult> res(px.size());
             int failed = -1;
-            csh_batch *jb = nullptr, *rb = nullptr;
+            csh_batch *jb = nullptr, *rb = nullptr, *rb2 = nullptr;
             csp_batch *pb = nullptr;
+            std::vector<cswd_rgba *> joined;
+            // the pictures at the size asked for, for the PNG / lossless WebP coders: every picture's RGB through the Lanczos branch, the alpha planes of the
+            // pictures with transparency through it as grey pictures (image-rs resamples the four channels alike), and the two halves joined again
+            auto resized = [&](std::vector<csp_pixels> &src) -> int {
+                int r = csh_batch_create_from_pixels_rgb(rgb3.data(), rgb3.size(), p, device, &rb);
+                if (r == 0) r = csh_batch_run(rb, nullptr);
+                for (size_t k = 0; k < rgb3.size() && r == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) r = CS_ERR_NO_DEVICE; }
+                std::vector<csp_pixels> planes;
+                std::vector<size_t> whose;
+                for (size_t k = 0; k < rgb3.size(); k++) if (rplane[k]) { planes.push_back(csp_pixels{rplane[k], rgb3[k].width, rgb3[k].height, 1}); whose.push_back(k); }
+                if (r || planes.empty()) return r;
+                r = csh_batch_create_from_pixels_rgb(planes.data(), planes.size(), p, device, &rb2);
+                if (r == 0) r = csh_batch_run(rb2, nullptr);
+                for (size_t j = 0; j < planes.size() && r == 0; j++) {
+                    const char *m = ""; csp_pixels a;
+                    if (csh_batch_pixels(rb2, j, &a.device_pixels, &a.width, &a.height, &a.channels, &m)) { r = CS_ERR_NO_DEVICE; break; }
+                    csp_pixels &c = src[whose[j]];
+                    if (a.width != c.width || a.height != c.height || a.channels != 1 || c.channels != 3) { r = CS_ERR_NO_DEVICE; break; }
+                    cswd_rgba *jn = nullptr;
+                    r = cswd_rgba_join(c.device_pixels, a.device_pixels, c.width, c.height, device, &jn, &c.device_pixels);
+                    if (r == 0) { joined.push_back(jn); c.channels = 4; } else r = CS_ERR_NO_DEVICE;
+                }
+                return r;
+            };
             if (target == CS_TYPE_PNG) {
                 std::vector<csp_pixels> src = px;
-                if (p->width || p->height) {   // resized pixels first: the JPEG row's resize branch, stopped behind its RGB
-                    rc = csh_batch_create_from_pixels_rgb(px.data(), px.size(), p, device, &rb);
-                    if (rc == 0) rc = csh_batch_run(rb, nullptr);
-                    for (size_t k = 0; k < px.size() && rc == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) rc = CS_ERR_NO_DEVICE; }
-                }
+                if (p->width || p->height) rc = resized(src);   // resized pixels first: the JPEG row's resize branch, stopped behind its RGB
                 if (rc == 0) rc = csp_batch_create_pixels(src.data(), src.size(), p, device, &pb);
                 if (rc == 0) rc = csp_batch_run(pb, nullptr);
                 if (rc == 0) failed = csp_batch_fetch(pb, out.data(), res.data());
             } else if (target == CS_TYPE_WEBP && p->webp_lossless) {   // webp.lossless: the VP8L coder over the (resized) pixels
                 std::vector<csp_pixels> src = px;
-                if (p->width || p->height) {
-                    rc = csh_batch_create_from_pixels_rgb(px.data(), px.size(), p, device, &rb);
-                    if (rc == 0) rc = csh_batch_run(rb, nullptr);
-                    for (size_t k = 0; k < px.size() && rc == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) rc = CS_ERR_NO_DEVICE; }
-                }
+                if (p->width || p->height) rc = resized(src);
                 if (rc == 0) failed = csl_encode_pixels(src.data(), src.size(), device, out.data(), res.data());
             } else {
                 rc = target == CS_TYPE_WEBP ? csh_batch_create_webp_from_pixels(px.data(), px.size(), p, device, &jb) : csh_batch_create_from_pixels(px.data(), px.size(), p, device, &jb);
@@ -342,7 +359,8 @@ static int webp_inputs(const CByteArray *inputs, size_t count, const CCSParamete
                     outputs[at[k]] = out[k]; if (results) results[at[k]] = res[k]; else cs_free_result(&res[k]);
                 }
             }
-            csp_batch_destroy(pb); csh_batch_destroy(jb); csh_batch_destroy(rb);
+            csp_batch_destroy(pb); csh_batch_destroy(jb); csh_batch_destroy(rb); csh_batch_destroy(rb2);
+            for (cswd_rgba *jn : joined) cswd_rgba_destroy(jn);
         }
         cswd_batch_destroy(wb);
     }

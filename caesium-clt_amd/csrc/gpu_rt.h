@@ -117,6 +117,8 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, h
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return 0; }
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
@@ -155,3 +157,12 @@ using std::min;
     } while (0)
 
 void csh_set_error(const char *fmt, ...);
+
+// A copy the host waits for, ordered on the batch's OWN stream.  A plain hipMemcpy goes through the legacy default stream: it waits for every
+// kernel of every other batch of the process (the second worker's, another file type's), and holds their next launches up until it is done.
+// The batches' streams are created hipStreamNonBlocking for the same reason; nothing in this library uses the default stream.
+template <class Kind>
+static inline hipError_t csh_copy_wait(void *dst, const void *src, size_t n, Kind kind, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst, src, n, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}

@@ -37,4 +37,15 @@ void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, 
     if (n) CSH_LAUNCH(k_vp8_decode, dim3(unsigned(n)), dim3(64), st, pool, imgs, n, work, rgb);
 }
 
+// RGB + alpha plane -> interleaved RGBA (the resized halves of a picture with transparency, joined for the PNG / lossless WebP coders): four pixels per lane
+__global__ void __launch_bounds__(256) k_rgba_join(const uint8_t *rgb, const uint8_t *alpha, uint8_t *rgba, uint64_t npx) {
+    const uint64_t p0 = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+    for (uint64_t p = p0; p < npx && p < p0 + 4; p++) {
+        rgba[4 * p] = rgb[3 * p]; rgba[4 * p + 1] = rgb[3 * p + 1]; rgba[4 * p + 2] = rgb[3 * p + 2]; rgba[4 * p + 3] = alpha[p];
+    }
+}
+void launch_rgba_join(hipStream_t st, const uint8_t *rgb, const uint8_t *alpha, uint8_t *rgba, uint64_t npx) {
+    if (npx) CSH_LAUNCH(k_rgba_join, dim3(unsigned((npx + 1023) / 1024)), dim3(256), st, rgb, alpha, rgba, npx);
+}
+
 }  // namespace csw

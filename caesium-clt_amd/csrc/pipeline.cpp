@@ -444,7 +444,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     b->lossless = p->jpeg_optimize && !webp && !rgb_out && !px;
     b->webp = webp; b->rgb_out = rgb_out;
     const bool progressive = p->jpeg_progressive;
-    if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     b->items.resize(count);
 
@@ -1677,9 +1677,9 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
     for (int attempt = 0; attempt < 4; attempt++) {
         if (run_once(b, t, requant_only)) return CS_ERR_NO_DEVICE;
         uint32_t ovf[4] = {0, 0, 0, 0};
-        if (hipMemcpy(ovf, b->d_overflow.p, sizeof ovf, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
+        if (csh_copy_wait(ovf, b->d_overflow.p, sizeof ovf, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
         b->h_status.resize(b->nimg);
-        if (hipMemcpy(b->h_status.data(), b->d_status.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
+        if (csh_copy_wait(b->h_status.data(), b->d_status.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return CS_ERR_NO_DEVICE;
         bool pool = ovf[0] != 0;
         if (ovf[1]) {   // token pool (k_tokens)
             pool = true; b->tok_scale *= 4;
@@ -1694,16 +1694,16 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
     }
     b->h_img_size.resize(b->nimg);
     b->h_img_off.resize(b->nimg + 1);
-    if (hipMemcpy(b->h_img_size.data(), b->d_img_size.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(b->h_img_off.data(), b->d_img_off.p, (b->nimg + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) {
+    if (csh_copy_wait(b->h_img_size.data(), b->d_img_size.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+        csh_copy_wait(b->h_img_off.data(), b->d_img_off.p, (b->nimg + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream) != hipSuccess) {
         csh_set_error("D2H of sizes failed"); return CS_ERR_NO_DEVICE;
     }
     if (t) {
         std::vector<uint32_t> ns(b->nimg);
-        if (hipMemcpy(ns.data(), b->d_need_seq.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return CS_ERR_NO_DEVICE;
+        if (csh_copy_wait(ns.data(), b->d_need_seq.p, b->nimg * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream) != hipSuccess) return CS_ERR_NO_DEVICE;
         if (getenv("CSH_TRACE") && b->d_relax_cnt.n) {   // sub-sequences re-listed after each relaxation round
             std::vector<uint32_t> rc(b->d_relax_cnt.n);
-            if (hipMemcpy(rc.data(), b->d_relax_cnt.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (csh_copy_wait(rc.data(), b->d_relax_cnt.p, rc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream) == hipSuccess) {
                 fprintf(stderr, "[csh] relax list sizes (of %u sub-sequences):", b->total_sub);
                 for (size_t i = 0; i < rc.size() && (i < 16 || rc[i]); i++) fprintf(stderr, " %u", rc[i]);
                 fprintf(stderr, "\n");
@@ -1756,7 +1756,7 @@ extern "C" int csh_batch_fetch(csh_batch *b, CByteArray *outputs, CCSResult *res
     if (b->nimg && b->h_img_off[b->nimg]) {
         host.p = static_cast<uint8_t *>(pinned_cache().get(b->h_img_off[b->nimg], host.cap));
         if (!host.p) { csh_set_error("out of pinned host memory"); return -1; }
-        if (hipMemcpy(host.p, b->d_out.p, b->h_img_off[b->nimg], hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H of output failed"); return -1; }
+        if (csh_copy_wait(host.p, b->d_out.p, b->h_img_off[b->nimg], hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("D2H of output failed"); return -1; }
     }
     std::atomic<int> failed{0};
     std::atomic<size_t> next{0};
@@ -1799,7 +1799,7 @@ extern "C" int csh_batch_read_coefs(csh_batch *b, size_t image, int comp, int wh
     const ImgDesc &im = b->imgs[b->items[image].image];
     const CompGeom &g = which ? im.out[comp] : im.in[comp];
     std::vector<int16_t> tiles(size_t(g.ntiles) * CSH_TILE_I16);
-    if (hipMemcpy(tiles.data(), b->d_coef.p + size_t(g.tile_base) * CSH_TILE_I16, tiles.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return -1; }
+    if (csh_copy_wait(tiles.data(), b->d_coef.p + size_t(g.tile_base) * CSH_TILE_I16, tiles.size() * 2, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("D2H failed"); return -1; }
     for (int blk = 0; blk < bw * bh; blk++)
         for (int k = 0; k < 64; k++) dst[size_t(blk) * 64 + k] = tiles[size_t(blk >> 6) * CSH_TILE_I16 + (blk & 63) * CSH_BLK_STRIDE + coef_off(k)];
     return 0;

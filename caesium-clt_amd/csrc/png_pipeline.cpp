@@ -329,7 +329,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     b->from_pixels = px != nullptr;
     b->decode_only = decode_only;
     b->to_webp = to_webp; b->webp_quality = int(p->webp_quality);
-    if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     for (auto &e : b->ev) if (hipEventCreate(&e) != hipSuccess) { csh_set_error("hipEventCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_events = true;
@@ -549,7 +549,7 @@ static int reduce_step(csp_batch *b) {
             std::vector<std::vector<QBin>> lists(gn);
             for (size_t k = 0; k < gn; k++) {
                 lists[k].resize(qn[k]);
-                if (qn[k] && hipMemcpy(lists[k].data(), b->d_qlist.p + part[k].list_off, sizeof(QBin) * qn[k], hipMemcpyDeviceToHost) != hipSuccess) return -1;
+                if (qn[k] && csh_copy_wait(lists[k].data(), b->d_qlist.p + part[k].list_off, sizeof(QBin) * qn[k], hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -1;
             }
             // the cuts of different images are independent: host threads (a 4K photograph has ~10^5 bins, tens of milliseconds each)
             std::vector<std::vector<uint32_t>> cut(gn);
@@ -586,7 +586,7 @@ static int reduce_step(csp_batch *b) {
         bool nearest = false;
         if (b->cand0[i] && !grey && nbps == 1 && (nk == 3 || nk == 4) && counts[i] <= 256) {
             tab.resize(CSP_PAL_SLOTS);
-            if (hipMemcpy(tab.data(), b->d_keys.p + size_t(i) * CSP_PAL_SLOTS, sizeof(unsigned long long) * CSP_PAL_SLOTS, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            if (csh_copy_wait(tab.data(), b->d_keys.p + size_t(i) * CSP_PAL_SLOTS, sizeof(unsigned long long) * CSP_PAL_SLOTS, hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -1;
             for (auto k : tab) if (k != ~0ull) pal.push_back(uint32_t(k));
             std::sort(pal.begin(), pal.end());
             const uint32_t n = uint32_t(pal.size());
@@ -771,8 +771,8 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
         for (int i = 0; i + 1 < k; i++) (void)hipEventElapsedTime(&t->kernel_ms[i], b->ev[i], b->ev[i + 1]);
         std::vector<uint32_t> status(size_t(nimg) + 1), flen(size_t(nimg) + 1);
         if (nimg) {
-            (void)hipMemcpy(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost);
+            (void)csh_copy_wait(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, b->stream);
+            (void)csh_copy_wait(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, b->stream);
         }
         for (auto &it : b->items) {
             if (it.image < 0) { t->n_failed++; continue; }
@@ -799,7 +799,7 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
     hipStream_t st = a->stream;
     const int nimg = int(a->imgs.size());
     std::vector<uint32_t> status(size_t(nimg) + 1, 0);
-    if (nimg && hipMemcpy(status.data(), a->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return CS_ERR_NO_DEVICE; }
+    if (nimg && csh_copy_wait(status.data(), a->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, a->stream) != hipSuccess) { csh_set_error("download failed"); return CS_ERR_NO_DEVICE; }
     std::vector<PreFail> pre(count);
     std::vector<csp_pixels> px(count);
     std::vector<PngResize> jobs;
@@ -896,7 +896,7 @@ static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSP
     hipStream_t st = a->stream;
     const int nimg = int(a->imgs.size());
     std::vector<uint32_t> status(size_t(nimg) + 1, 0);
-    if (nimg && hipMemcpy(status.data(), a->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return fail_all(CS_ERR_NO_DEVICE); }
+    if (nimg && csh_copy_wait(status.data(), a->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, a->stream) != hipSuccess) { csh_set_error("download failed"); return fail_all(CS_ERR_NO_DEVICE); }
     std::vector<RgbJob> ejobs;
     std::vector<uint8_t> tables(1, 0);
     std::vector<size_t> at;
@@ -912,7 +912,6 @@ static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSP
         if (!code && !lossless_webp && (it.width > 65535 || it.height > 65535)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a JPEG"; }
         if (!code && lossless_webp && (it.width > 16384 || it.height > 16384)) { code = CS_ERR_UNSUPPORTED; msg = "image too large for a WebP"; }
         const bool transparent = it.ctype == 4 || it.ctype == 6 || it.has_trns;
-        if (!code && lossless_webp && transparent && (p->width || p->height)) { code = CS_ERR_UNSUPPORTED; msg = "PNG -> lossless WebP: a transparent picture cannot be resized on this path in this build"; }
         if (code) { if (results) results[i] = png_result(code, msg); failed++; continue; }
         RgbJob e{};
         e.image = uint32_t(it.image); e.width = it.width; e.height = it.height; e.rowbytes = it.rowbytes; e.ctype = it.ctype; e.depth = it.depth;
@@ -938,10 +937,50 @@ static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSP
     if (lossless_webp) {
         std::vector<csp_pixels> src = px;
         csh_batch *rb = nullptr;
+        DevBuf<PngResize> d_jobs;
+        DevBuf<csh::ResizeTap> d_taps;
+        DevBuf<float> d_weights, d_tmp;
+        DevBuf<uint8_t> d_dst;
         if (p->width || p->height) {
-            rc = csh_batch_create_from_pixels_rgb(px.data(), px.size(), p, device, &rb);
-            if (rc == 0) rc = csh_batch_run(rb, nullptr);
-            for (size_t k = 0; k < px.size() && rc == 0; k++) { const char *m = ""; if (csh_batch_pixels(rb, k, &src[k].device_pixels, &src[k].width, &src[k].height, &src[k].channels, &m)) rc = CS_ERR_NO_DEVICE; }
+            // opaque pictures (grey, RGB): the JPEG row's resize branch, stopped behind its pixels; pictures with transparency (grey + alpha, RGBA): the PNG
+            // row's own two Lanczos passes over the interleaved samples (k_png_resize.hip, the same arithmetic; image-rs resamples the channels alike)
+            std::vector<csp_pixels> opaque;
+            std::vector<size_t> opaque_at, job_at;
+            std::vector<PngResize> jobs;
+            std::vector<csh::ResizeTap> taps;
+            std::vector<float> weights;
+            uint64_t tmp_floats = 0, dst_bytes = 0, max_tmp = 0, max_dst = 0;
+            for (size_t k = 0; k < px.size(); k++) {
+                if (px[k].channels == 1 || px[k].channels == 3) { opaque.push_back(px[k]); opaque_at.push_back(k); continue; }
+                int nw = 0, nh = 0;
+                csh_compute_dimensions(int(px[k].width), int(px[k].height), int(p->width), int(p->height), nw, nh);
+                const uint32_t nc = px[k].channels;
+                const uint64_t tmpn = uint64_t(nh) * px[k].width * nc, dstn = uint64_t(nw) * nh * nc;
+                if (uint64_t(nw) * nc > 0x7FFFFFF0u || tmpn > 0xFFFFFF00u || dstn > 0xFFFFFF00u) { csh_set_error("resized PNG too large for one device batch"); rc = CS_ERR_UNSUPPORTED; break; }
+                PngResize j{};
+                j.width = px[k].width; j.height = px[k].height; j.nc = nc; j.nw = uint32_t(nw); j.nh = uint32_t(nh); j.bps = 1;
+                j.src_off = ejobs[k].dst_off; j.tmp_off = tmp_floats; j.dst_off = dst_bytes;
+                const bool same = uint32_t(nw) == px[k].width && uint32_t(nh) == px[k].height;
+                j.vtap_base = uint32_t(taps.size()); csh_lanczos_axis(int(px[k].height), nh, same, taps, weights);
+                j.htap_base = uint32_t(taps.size()); csh_lanczos_axis(int(px[k].width), nw, same, taps, weights);
+                tmp_floats += (tmpn + 63) & ~uint64_t(63); dst_bytes += (dstn + 255) & ~uint64_t(255);
+                max_tmp = std::max(max_tmp, tmpn); max_dst = std::max(max_dst, dstn);
+                src[k].width = uint32_t(nw); src[k].height = uint32_t(nh);
+                jobs.push_back(j); job_at.push_back(k);
+            }
+            if (rc == 0 && !opaque.empty()) {
+                rc = csh_batch_create_from_pixels_rgb(opaque.data(), opaque.size(), p, device, &rb);
+                if (rc == 0) rc = csh_batch_run(rb, nullptr);
+                for (size_t j = 0; j < opaque.size() && rc == 0; j++) { const char *m = ""; csp_pixels &d = src[opaque_at[j]]; if (csh_batch_pixels(rb, j, &d.device_pixels, &d.width, &d.height, &d.channels, &m)) rc = CS_ERR_NO_DEVICE; }
+            }
+            if (rc == 0 && !jobs.empty()) {
+                if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256)) rc = CS_ERR_NO_DEVICE;
+                else {
+                    launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
+                    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG resize kernels failed"); rc = CS_ERR_NO_DEVICE; }
+                    for (size_t j = 0; j < jobs.size(); j++) src[job_at[j]].device_pixels = d_dst.p + jobs[j].dst_off;
+                }
+            }
         }
         std::vector<CByteArray> out(px.size());
         std::vector<CCSResult> res(px.size());
@@ -982,8 +1021,8 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
     const int nimg = int(b->imgs.size());
     std::vector<uint32_t> status(size_t(nimg) + 1), flen(size_t(nimg) + 1);
     if (nimg) {
-        if (hipMemcpy(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return -1; }
+        if (csh_copy_wait(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+            csh_copy_wait(flen.data(), b->d_file_len.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("download failed"); return -1; }
     }
     int failed = 0;
     // pictures with transparency going to WebP: their alpha plane through the VP8L coder now (the pixels are still in d_rgb), one call for all of them
@@ -1022,7 +1061,7 @@ extern "C" int csp_batch_fetch(csp_batch *b, CByteArray *outputs, CCSResult *res
             outputs[i].length = it.file_size;
         } else {
             outputs[i].data = (uint8_t *)malloc(n ? n : 1);
-            if (hipMemcpy(outputs[i].data, b->d_out.p + b->imgs[it.image].out_off, n, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("download failed"); return -1; }
+            if (csh_copy_wait(outputs[i].data, b->d_out.p + b->imgs[it.image].out_off, n, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("download failed"); return -1; }
             outputs[i].length = n;
         }
         if (alpha_at[i] >= 0) {
@@ -1053,20 +1092,20 @@ extern "C" int csp_batch_geometry(csp_batch *b, size_t image, uint32_t *width, u
 extern "C" int csp_batch_read_rows(csp_batch *b, size_t image, uint8_t *dst) {
     const PngImg *im = tap_image(b, image);
     if (!im) return -1;
-    return hipMemcpy(dst, b->d_work.p + im->pix_off, size_t(im->height) * im->rowbytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return csh_copy_wait(dst, b->d_work.p + im->pix_off, size_t(im->height) * im->rowbytes, hipMemcpyDeviceToHost, b->stream) == hipSuccess ? 0 : -1;
 }
 extern "C" int csp_batch_read_stream(csp_batch *b, size_t image, int strategy, uint8_t *dst) {
     const PngImg *im = tap_image(b, image);
     if (!im) return -1;
     if (strategy < 0 || strategy > 9 || b->slot_of_strategy[strategy] < 0) { csh_set_error("strategy %d is not part of this level's plan", strategy); return -1; }
-    return hipMemcpy(dst, b->d_streams.p + im->stream_off + uint64_t(b->slot_of_strategy[strategy]) * im->stream_stride, im->raw_len, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return csh_copy_wait(dst, b->d_streams.p + im->stream_off + uint64_t(b->slot_of_strategy[strategy]) * im->stream_stride, im->raw_len, hipMemcpyDeviceToHost, b->stream) == hipSuccess ? 0 : -1;
 }
 extern "C" int csp_batch_read_scores(csp_batch *b, size_t image, uint64_t *dst, int *have) {
     const PngImg *im = tap_image(b, image);
     if (!im) return -1;
     *have = 0;
     for (int a = 0; a < b->plan.nadaptive; a++) *have |= b->plan.adaptive_strategy[a] == 9 ? 16 : 15;
-    return hipMemcpy(dst, b->d_scores.p + size_t(im->row_base) * 25, sizeof(uint64_t) * 25 * im->height, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return csh_copy_wait(dst, b->d_scores.p + size_t(im->row_base) * 25, sizeof(uint64_t) * 25 * im->height, hipMemcpyDeviceToHost, b->stream) == hipSuccess ? 0 : -1;
 }
 extern "C" int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uint64_t *zlib_bytes, int *ntrials, int *winner) {
     const PngImg *im = tap_image(b, image);
@@ -1075,8 +1114,8 @@ extern "C" int csp_batch_trials(csp_batch *b, size_t image, int *strategies, uin
     *ntrials = b->plan.ntrials;
     for (int t = 0; t < b->plan.ntrials; t++) strategies[t] = b->plan.trial_strategy[t];
     int32_t w = 0;
-    if (hipMemcpy(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * b->plan.ntrials, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(&w, b->d_winner.p + idx, sizeof w, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (csh_copy_wait(zlib_bytes, b->d_trial_bytes.p + size_t(idx) * CSP_MAX_STREAMS, sizeof(uint64_t) * b->plan.ntrials, hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+        csh_copy_wait(&w, b->d_winner.p + idx, sizeof w, hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -1;
     *winner = w;
     return 0;
 }
@@ -1085,7 +1124,7 @@ extern "C" int csp_batch_chunk_bits(csp_batch *b, size_t image, int trial, uint6
     if (!im || trial < 0 || trial >= b->plan.ntrials) return -1;
     *nchunks = im->nchunks;
     std::vector<PngChunk> recs(im->nchunks);
-    if (hipMemcpy(recs.data(), b->d_chunks.p + size_t(im->chunk_base) + size_t(b->plan.trial_slot[trial]) * im->nchunks, sizeof(PngChunk) * im->nchunks, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (csh_copy_wait(recs.data(), b->d_chunks.p + size_t(im->chunk_base) + size_t(b->plan.trial_slot[trial]) * im->nchunks, sizeof(PngChunk) * im->nchunks, hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -1;
     for (size_t i = 0; i < im->nchunks && i < cap; i++) dst[i] = recs[i].bits;
     return 0;
 }

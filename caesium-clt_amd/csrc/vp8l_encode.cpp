@@ -52,7 +52,7 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
     DevBuf<uint32_t> d_work, d_hist, d_len, d_status;
     DevBuf<uint8_t> d_modes, d_out;
     std::vector<uint32_t> len(imgs.size()), status(imgs.size());
-    bool ok = hipStreamCreate(&st) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     have_st = ok;
     ok = ok && !d_imgs.upload(imgs, st) && !d_work.alloc(work + 64) && !d_hist.alloc(imgs.size() * 1024 + 8) && !d_hist.zero(st) && !d_len.alloc(imgs.size() + 1) && !d_status.alloc(imgs.size() + 1) &&
          !d_modes.alloc(modes + 64) && !d_out.alloc(out + 256);
@@ -66,7 +66,7 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
         if (!ok) { results[i] = make_res(CS_ERR_NO_DEVICE, "lossless WebP coding failed on the device"); failed++; continue; }
         if (status[k] || !len[k]) { results[i] = make_res(CS_ERR_POOL_OVERFLOW, "lossless WebP output larger than its region"); failed++; continue; }
         outputs[i].data = static_cast<uint8_t *>(malloc(len[k]));
-        if (!outputs[i].data || hipMemcpy(outputs[i].data, d_out.p + imgs[k].out_off, len[k], hipMemcpyDeviceToHost) != hipSuccess) {
+        if (!outputs[i].data || csh_copy_wait(outputs[i].data, d_out.p + imgs[k].out_off, len[k], hipMemcpyDeviceToHost, st) != hipSuccess) {
             free(outputs[i].data); outputs[i].data = nullptr; results[i] = make_res(CS_ERR_NO_DEVICE, "D2H failed"); failed++; continue;
         }
         outputs[i].length = len[k];

@@ -72,7 +72,7 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
     std::unique_ptr<cswd_batch> b(new cswd_batch);
     b->device = device;
-    if (hipStreamCreate(&b->stream) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
     b->have_stream = true;
     b->items.resize(count);
     for (size_t n = 0; n < count; n++) {
@@ -156,7 +156,7 @@ extern "C" int cswd_batch_read_pixels(cswd_batch *b, size_t image, uint8_t *dst)
     const uint8_t *p; uint32_t w, h, c; const char *m;
     int rc = cswd_batch_pixels(b, image, &p, &w, &h, &c, &m);
     if (rc) return rc;
-    if (hipMemcpy(dst, p, size_t(w) * h * c, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
+    if (csh_copy_wait(dst, p, size_t(w) * h * c, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
     return 0;
 }
 
@@ -166,8 +166,28 @@ extern "C" int cswd_batch_read_rgba(cswd_batch *b, size_t image, uint8_t *dst) {
     if (rc) return rc;
     if (!rgba) return 1;
     const csw::Vp8In &im = b->imgs[size_t(b->items[image].image)];
-    if (hipMemcpy(dst, rgba, size_t(im.width) * im.height * 4, hipMemcpyDeviceToHost) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
+    if (csh_copy_wait(dst, rgba, size_t(im.width) * im.height * 4, hipMemcpyDeviceToHost, b->stream) != hipSuccess) { csh_set_error("D2H failed"); return CS_ERR_NO_DEVICE; }
     return 0;
 }
 
 extern "C" void cswd_batch_destroy(cswd_batch *b) { delete b; }
+
+// RGB and an alpha plane of the same size, both in device memory (the two halves of a picture with transparency after their resize) -> one RGBA picture
+struct cswd_rgba { DevBuf<uint8_t> d; };
+extern "C" int cswd_rgba_join(const uint8_t *device_rgb, const uint8_t *device_alpha, uint32_t width, uint32_t height, int device, cswd_rgba **out, const uint8_t **device_rgba) {
+    *out = nullptr; *device_rgba = nullptr;
+    if (!device_rgb || !device_alpha || !width || !height) { csh_set_error("cswd_rgba_join: null pixels / empty picture"); return -1; }
+    if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
+    cswd_rgba *r = new cswd_rgba;
+    const uint64_t npx = uint64_t(width) * height;
+    if (r->d.alloc(size_t(npx) * 4)) { delete r; return CS_ERR_NO_DEVICE; }
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { delete r; csh_set_error("hipStreamCreate failed"); return CS_ERR_NO_DEVICE; }
+    csw::launch_rgba_join(st, device_rgb, device_alpha, r->d.p, npx);
+    const bool ok = hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+    (void)hipStreamDestroy(st);
+    if (!ok) { delete r; csh_set_error("k_rgba_join failed on the device"); return CS_ERR_NO_DEVICE; }
+    *out = r; *device_rgba = r->d.p;
+    return 0;
+}
+extern "C" void cswd_rgba_destroy(cswd_rgba *r) { delete r; }

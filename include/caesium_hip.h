@@ -247,6 +247,12 @@ int cswd_batch_read_pixels(cswd_batch *b, size_t image, uint8_t *dst /* width * 
 int cswd_batch_alpha(cswd_batch *b, size_t image, const uint8_t **device_rgba, const uint8_t **device_alpha);
 int cswd_batch_read_rgba(cswd_batch *b, size_t image, uint8_t *dst /* width * height * 4; returns 1 for an opaque picture */);
 void cswd_batch_destroy(cswd_batch *b);
+/* the two halves of a picture with transparency after their resize (RGB, 3 bytes per pixel, and the alpha plane, both in device memory) joined into one
+   RGBA picture in device memory of its own: what the PNG coder and the lossless WebP coder take (image-rs resamples the four channels alike,
+   /root/reference/src/compressor.rs:289-300 through libcaesium's resize).  0 ok. */
+typedef struct cswd_rgba cswd_rgba;
+int cswd_rgba_join(const uint8_t *device_rgb, const uint8_t *device_alpha, uint32_t width, uint32_t height, int device, cswd_rgba **out, const uint8_t **device_rgba);
+void cswd_rgba_destroy(cswd_rgba *r);
 /* pixels in, WebP out: the lossy WebP encoder behind the same stand-in as csh_batch_create_from_pixels */
 int csh_batch_create_webp_from_pixels(const struct csp_pixels_s *sources, size_t count, const CCSParameters *p, int device, csh_batch **out);
 /* pixels in, resized pixels out (csh_batch_pixels): the Lanczos branch alone */

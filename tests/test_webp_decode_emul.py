@@ -284,7 +284,7 @@ def test_emul_transparent_sources_keep_their_alpha(api):
         assert im.format == "PNG" and np.array_equal(np.asarray(im.convert("RGBA")), src_rgba), label
         out = api.convert_in_memory(src, pkg.default_parameters(jpeg_quality=90), 0)
         assert Image.open(io.BytesIO(out)).mode == "RGB"
-        # with a resize: colour and plane through the same Lanczos branch (the plane as a grey picture); the RGBA consumers refuse it, per file
+        # with a resize: colour and plane through the same Lanczos branch (the plane as a grey picture)
         outs = api.cs_batch_compress([src, opaque], pkg.default_parameters(webp_quality=70, width=40))
         small = Image.open(io.BytesIO(outs[0]))
         assert small.mode == "RGBA" and small.size == (40, 28) and isinstance(outs[1], bytes), label
@@ -292,8 +292,17 @@ def test_emul_transparent_sources_keep_their_alpha(api):
         Image.fromarray(np.repeat(src_rgba[:, :, 3:4], 3, axis=2), "RGB").save(plane, format="WEBP", lossless=True)   # the plane as a grey picture, resized the same way
         want = np.asarray(Image.open(io.BytesIO(api.compress_in_memory(plane.getvalue(), pkg.default_parameters(webp_lossless=True, width=40)))).convert("RGB"))[:, :, 0]
         assert np.array_equal(np.asarray(small)[:, :, 3], want), label
-        outs = api.cs_batch_compress([src, opaque], pkg.default_parameters(webp_lossless=True, width=40))
-        assert getattr(outs[0], "code", 0) == 10201 and isinstance(outs[1], bytes)
+        # the RGBA consumers (lossless WebP, PNG): the two resized halves joined again -- the colour of the opaque picture with the same RGB, the plane as above
+        colour = io.BytesIO()
+        Image.fromarray(src_rgba[:, :, :3], "RGB").save(colour, format="WEBP", lossless=True)
+        want_rgb = np.asarray(Image.open(io.BytesIO(api.compress_in_memory(colour.getvalue(), pkg.default_parameters(webp_lossless=True, width=40)))).convert("RGB"))
+        want_rgba = np.dstack([want_rgb, want])
+        outs = api.cs_batch_compress([src, opaque, src], pkg.default_parameters(webp_lossless=True, width=40))
+        assert outs[0] == outs[2] and outs[0][8:16] == b"WEBPVP8L" and isinstance(outs[1], bytes), label
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(outs[0])).convert("RGBA")), want_rgba), label
+        out = api.convert_in_memory(src, pkg.default_parameters(png_optimize=True, width=40), 1)
+        im = Image.open(io.BytesIO(out))
+        assert im.format == "PNG" and im.size == (40, 28) and np.array_equal(np.asarray(im.convert("RGBA")), want_rgba), label
     # metadata travels with the alpha: ICCP in front of ALPH, EXIF behind the frame
     meta = io.BytesIO()
     Image.fromarray(np.dstack([rgb, a]), "RGBA").save(meta, format="WEBP", quality=85, exif=b"Exif\0\0MM\0*\0\0\0\x08\0\0", icc_profile=b"fake profile bytes")
