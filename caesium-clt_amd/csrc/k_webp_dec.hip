@@ -1,4 +1,4 @@
-// k_webp_dec.hip -- WebP inputs: one VP8 key frame (lossy) or VP8L stream (lossless, vp8l_dec.h) per wave (lane 0 walks it; the pictures of a batch are the parallel axis),
+// k_webp_dec.hip -- WebP inputs: one VP8 key frame (lossy) or VP8L stream (lossless, vp8l_dec.h) per workgroup (the serial part on lane 0, the rest across the lanes; the pictures of a batch are the other parallel axis),
 // vp8_dec.h holds the decoder.  Replaces libwebp's decoder on libcaesium's WebP input paths (reference call sites
 // /root/reference/src/compressor.rs:289-305; file type sniffed as /root/reference/src/compressor.rs:589-598 does).
 #include "webp_kernels.h"
@@ -7,34 +7,65 @@
 
 namespace csw {
 
-__global__ void __launch_bounds__(64) k_vp8_decode(const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb) {
+// One workgroup per picture, in phases: (0) lane 0 walks the serial part -- a lossless picture altogether (vp8l_dec.h), a lossy frame's parse and
+// reconstruction (vp8_parse_frame) --; (1 .. nsteps) the loop filter as a wave front, macroblock row r at column t - 2 r in step t; then the RGB
+// conversion by row pairs across the lanes; then a lossy file's alpha plane (lane 0: a VP8L stream of its own) and its join with the colour (all lanes).
+// nsteps = the largest mbw + 2 mbh of the batch's lossy frames.
+__global__ void __launch_bounds__(256) k_vp8_decode(const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps) {
+    CSH_SHARED Vp8Hot hot;
+    CSH_SHARED uint32_t s_translucent;
     const int i = int(blockIdx.x);
-    if (i >= n || threadIdx.x != 0) return;
     Vp8In &im = imgs[i];
     const bool room = im.rgba_off != ~0ull;
     uint8_t *rgba = room ? rgb + im.rgba_off : nullptr, *aplane = room ? rgb + im.a_off : nullptr;
-    uint32_t has_alpha = 0;
-    if (im.lossless) im.status = uint32_t(vp8l_decode_frame(pool + im.data_off, im.data_len, im.width, im.height, work + im.work_off, rgb + im.rgb_off, im.data_len, false, rgba, aplane, &has_alpha));
-    else {
-        im.status = uint32_t(vp8_decode_frame(pool + im.data_off, im.data_len, im.width, im.height, work + im.work_off, rgb + im.rgb_off));
-        if (!im.status && im.alph_len) {   // the alpha plane of a lossy file (the frame's work area is free again)
-            if (!room) im.status = 3;
-            else {
-                im.status = uint32_t(alph_decode(pool + im.alph_off, im.alph_len, im.width, im.height, work + im.work_off, aplane));
-                if (!im.status) {
-                    const uint64_t npx = uint64_t(im.width) * im.height;
-                    const uint8_t *c = rgb + im.rgb_off;
-                    uint32_t amin = 255;
-                    for (uint64_t k = 0; k < npx; k++) { rgba[4 * k] = c[3 * k]; rgba[4 * k + 1] = c[3 * k + 1]; rgba[4 * k + 2] = c[3 * k + 2]; rgba[4 * k + 3] = aplane[k]; if (aplane[k] < amin) amin = aplane[k]; }
-                    has_alpha = amin < 255 ? 1u : 0u;
-                }
+    uint8_t *wk = work + im.work_off, *out = rgb + im.rgb_off;
+    const uint32_t W = im.width, H = im.height;
+    CSH_PHASE_LOOP(nsteps + 5) {
+        if (phase == 0) {
+            if (threadIdx.x == 0) {
+                uint32_t has_alpha = 0;
+                s_translucent = 0;
+                if (im.lossless) im.status = uint32_t(vp8l_decode_frame(pool + im.data_off, im.data_len, W, H, wk, out, im.data_len, false, rgba, aplane, &has_alpha));
+                else im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, W, H, wk, hot, im.debug));
+                im.has_alpha = has_alpha;
             }
+            continue;
         }
+        if (im.lossless || im.status) continue;
+        if (phase <= nsteps) {
+            if (im.debug & 3u) continue;
+            const int t = phase - 1;
+            for (uint32_t r = threadIdx.x; r < im.mbh; r += blockDim.x) {
+                const int mx = t - 2 * int(r);
+                if (mx >= 0 && mx < int(im.mbw)) vp8_filter_mb(wk, W, H, uint32_t(mx), r);
+            }
+            continue;
+        }
+        if (phase == nsteps + 1) {
+            if (im.debug & 5u) continue;
+            for (uint32_t k = threadIdx.x; k <= (H + 1) >> 1; k += blockDim.x) vp8_rgb_rows(wk, W, H, k, out);
+            continue;
+        }
+        if (!im.alph_len) continue;
+        if (phase == nsteps + 2) {   // the alpha plane of a lossy file (the frame's work area is free again)
+            if (threadIdx.x == 0) im.status = !room ? 3u : uint32_t(alph_decode(pool + im.alph_off, im.alph_len, W, H, wk, aplane));
+            continue;
+        }
+        if (phase == nsteps + 3) {
+            const uint64_t npx = uint64_t(W) * H;
+            bool translucent = false;
+            for (uint64_t k = threadIdx.x; k < npx; k += blockDim.x) {
+                rgba[4 * k] = out[3 * k]; rgba[4 * k + 1] = out[3 * k + 1]; rgba[4 * k + 2] = out[3 * k + 2]; rgba[4 * k + 3] = aplane[k];
+                translucent |= aplane[k] < 255;
+            }
+            if (translucent) s_translucent = 1;   // (several lanes may store the same 1)
+            continue;
+        }
+        if (threadIdx.x == 0) im.has_alpha = s_translucent;
     }
-    im.has_alpha = has_alpha;
 }
-void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb) {
-    if (n) CSH_LAUNCH(k_vp8_decode, dim3(unsigned(n)), dim3(64), st, pool, imgs, n, work, rgb);
+void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps) {
+    if (n) CSH_LAUNCH_PHASED(k_vp8_decode, nsteps + 5, dim3(unsigned(n)), dim3(256), st, pool, imgs, n, work, rgb, nsteps);
 }
 
 // RGB + alpha plane -> interleaved RGBA (the resized halves of a picture with transparency, joined for the PNG / lossless WebP coders): four pixels per lane

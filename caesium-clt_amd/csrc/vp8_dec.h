@@ -1,8 +1,9 @@
 // vp8_dec.h -- VP8 key-frame decoder (RFC 6386), the lossy WebP inputs of libcaesium's webp::compress / convert paths
-// (/root/reference/src/compressor.rs:289-305, 589-598 name WebP among the inputs; libcaesium decodes them with libwebp).  One image is
-// decoded by ONE lane, start to end (boolean decoder, intra prediction, inverse transforms, loop filter, then libwebp's "fancy"
-// chroma upsampling and its fixed-point YCbCr -> RGB): the format is a serial chain per partition and the pictures of a batch are the
-// parallel axis.  Pixel-exact against libwebp (through Pillow) in tests/test_webp_decode*.py.
+// (/root/reference/src/compressor.rs:289-305, 589-598 name WebP among the inputs; libcaesium decodes them with libwebp).  The frame's
+// boolean-coded data is a serial chain: ONE lane parses it and reconstructs the macroblocks as it goes (vp8_parse_frame, its working set in LDS);
+// the loop filter then runs as a wave front over the macroblock rows and libwebp's "fancy" chroma upsampling + fixed-point YCbCr -> RGB by
+// row pairs, both across the lanes of the picture's workgroup (k_webp_dec.hip).  Pixel-exact against libwebp (through Pillow) in
+// tests/test_webp_decode*.py.
 // Everything here is host + device code: the emulation build compiles it as plain C++.
 #pragma once
 #include <cstdint>
@@ -20,7 +21,7 @@ struct Vp8In {              // one input file, host-parsed container
     uint32_t lossless;      // 1: the payload is a VP8L stream (vp8l_dec.h), work area sized by vp8l_work_bytes
     uint32_t has_alpha;     // device: 1 when the picture is not opaque -- then rgba_off / a_off hold it as RGBA and its alpha plane as well
     uint64_t alph_off;      // lossy files: the ALPH chunk's payload in the input pool (alph_len 0: none)
-    uint32_t alph_len, pad_;
+    uint32_t alph_len, debug;   // debug: CSH_WEBP_DEBUG (timing probes: 1 parse only, 2 no loop filter, 4 no RGB)
     uint64_t rgba_off, a_off;   // width * height * 4 and width * height bytes in the pixel pool (~0: not reserved)
 };
 // work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts
@@ -29,27 +30,39 @@ __host__ __device__ static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t
     return ly + 2 * lc + uint64_t(mbw) * mbh * 4 + uint64_t(mbw) * 16 + 256;
 }
 
+// RFC 6386 section 7's boolean decoder with a wide window: `value` holds the decoder's 8-bit value and nbits bits of look-ahead below it, so
+// bytes come in four at a time and the renormalisation is one count-leading-zeros shift instead of a loop (the decisions depend on the top
+// eight bits only: value16 >= split << 8 is top8 >= split).  eof() answers what the byte-wise form's flag did: a byte past the end has been
+// shifted INTO the 16-bit window (the reference form loads its next byte after every eighth shift).
 struct BoolDec {
     const uint8_t *p, *end;
-    uint32_t value, range;
-    int bits;   // bits consumed of the current low byte
-    bool eof;
+    uint64_t value;
+    uint32_t range, loaded, len;
+    int nbits;
+    __host__ __device__ void refill() {
+        uint32_t w;
+        if (end - p >= 4) { w = (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); p += 4; }
+        else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (p < end ? uint32_t(*p++) : 0u); }
+        value = (value << 32) | w; nbits += 32; loaded += 4;
+    }
     __host__ __device__ void init(const uint8_t *d, size_t n) {
-        p = d; end = d + n; eof = false;
-        value = 0;
-        for (int i = 0; i < 2; i++) value = (value << 8) | (p < end ? *p++ : 0u);
-        range = 255; bits = 0;
+        p = d; end = d + n; len = uint32_t(n);
+        value = 0; nbits = -8; loaded = 0; range = 255;
+        refill();
     }
     __host__ __device__ int get(int prob) {
+        if (nbits < 8) refill();
         const uint32_t split = 1u + (((range - 1u) * uint32_t(prob)) >> 8);
-        const uint32_t big = split << 8;
+        const uint32_t top = uint32_t(value >> nbits);
         int r;
-        if (value >= big) { r = 1; range -= split; value -= big; } else { r = 0; range = split; }
-        while (range < 128u) {
-            value <<= 1; range <<= 1;
-            if (++bits == 8) { bits = 0; if (p < end) value |= *p++; else eof = true; }
-        }
+        if (top >= split) { r = 1; range -= split; value -= uint64_t(split) << nbits; } else { r = 0; range = split; }
+        const int shift = __builtin_clz(range) - 24;
+        range <<= shift; nbits -= shift;
         return r;
+    }
+    __host__ __device__ bool eof() const {
+        const int64_t groups = (int64_t(8) * loaded - 8 - nbits) >> 3;   // completed groups of eight shifts = bytes the byte-wise form has loaded behind its first two
+        return groups >= 1 && groups + 1 >= int64_t(len);
     }
     __host__ __device__ uint32_t lit(int n) { uint32_t v = 0; while (n-- > 0) v = (v << 1) | uint32_t(get(128)); return v; }
     __host__ __device__ int slit(int n) { const int v = int(lit(n)); return get(128) ? -v : v; }
@@ -203,9 +216,47 @@ __host__ __device__ static inline void yuv_rgb(int y, int u, int v, uint8_t *o) 
 
 struct Vp8Seg { int y1[2], y2[2], uv[2]; };
 struct Vp8FInfo { uint8_t limit, ilevel, inner, hev; };
+struct Vp8Frame { uint32_t filtering, simple; };   // what the stages behind the parse need of the frame header (kept behind the contexts in the work area)
 
-// the whole key frame.  Returns 0 or an error code (CS_ERR_* numbers are the caller's: 1 = malformed, 2 = unsupported feature)
-__host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *rgb) {
+// the work area of one picture (vp8_work_bytes)
+struct Vp8Planes {
+    uint8_t *Y, *U, *V;
+    Vp8FInfo *finfo;
+    uint8_t *ctx;        // per macroblock column: [0..3] sub-block modes above, [4..12] non-zero flags above (4 y, 2 u, 2 v, 1 y2)
+    Vp8Frame *frame;
+    int ys, cs;
+    uint32_t mbw, mbh;
+};
+__host__ __device__ static inline Vp8Planes vp8_planes(uint8_t *work, uint32_t W, uint32_t H) {
+    Vp8Planes p;
+    p.mbw = (W + 15) >> 4; p.mbh = (H + 15) >> 4;
+    p.ys = int(p.mbw * 16); p.cs = int(p.mbw * 8);
+    p.Y = work; p.U = p.Y + size_t(p.ys) * p.mbh * 16; p.V = p.U + size_t(p.cs) * p.mbh * 8;
+    p.finfo = reinterpret_cast<Vp8FInfo *>(p.V + size_t(p.cs) * p.mbh * 8);
+    p.ctx = reinterpret_cast<uint8_t *>(p.finfo + size_t(p.mbw) * p.mbh);
+    p.frame = reinterpret_cast<Vp8Frame *>(p.ctx + size_t(p.mbw) * 16);
+    return p;
+}
+
+// The parse's working set.  One lane walks a frame (a boolean-coded partition is one chain), and everything it touches per symbol -- the
+// probabilities, the small constant tables, the macroblock's coefficients, the prediction scratch -- would sit in private memory (scratch: a
+// round trip to the memory system per look-up) if it were local arrays; the kernel keeps this struct in LDS.
+struct Vp8Hot {
+    alignas(4) uint8_t sy[(16 + 1) * 32];   // prediction scratch: the block at row 1, column 4 (aligned words), its neighbours above and to the left
+    alignas(4) uint8_t su[(8 + 1) * 16], sv[(8 + 1) * 16];
+    int16_t coef[25 * 16];                  // zero between macroblocks
+    uint8_t probs[4 * 8 * 3 * 11];          // [4 types][8 bands][3 contexts][11 nodes]
+    uint8_t bmode[10 * 10 * 9];
+    uint8_t bands[17], zigzag[16], cat[4][12];
+    uint8_t bmodes[16], ctx[16];
+    uint8_t left_modes[4], lnz[9];          // to the left: sub-block modes; non-zero flags (4 y, 2 u, 2 v, y2)
+    int16_t dc[16];                         // the Y2 block of an i16 macroblock
+};
+
+// the parse: frame header, then macroblock by macroblock modes, coefficients and -- from UNFILTERED neighbours -- the reconstruction; leaves the
+// planes, the filter strengths and the frame info in the work area.  Returns 0 or an error code (CS_ERR_* numbers are the caller's: 1 = malformed,
+// 2 = unsupported feature)
+__host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, Vp8Hot &hot, uint32_t debug = 0) {
     if (n < 10) return 1;
     const uint32_t tag = data[0] | (data[1] << 8) | (data[2] << 16);
     if (tag & 1) return 2;                                   // not a key frame
@@ -214,11 +265,12 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
     const uint32_t fw = (data[6] | (data[7] << 8)) & 0x3FFF, fh = (data[8] | (data[9] << 8)) & 0x3FFF;
     if (fw != W || fh != H || !W || !H) return 1;
     if (10 + size_t(part0_len) > n) return 1;
-    const uint32_t mbw = (W + 15) >> 4, mbh = (H + 15) >> 4;
-    const int ys = int(mbw * 16), cs = int(mbw * 8);
-    uint8_t *Y = work, *U = Y + size_t(ys) * mbh * 16, *V = U + size_t(cs) * mbh * 8;
-    Vp8FInfo *finfo = reinterpret_cast<Vp8FInfo *>(V + size_t(cs) * mbh * 8);
-    uint8_t *ctx = reinterpret_cast<uint8_t *>(finfo + size_t(mbw) * mbh);   // per macroblock column: [0..3] sub-block modes above, [4..12] non-zero flags above (4 y, 2 u, 2 v, 1 y2)
+    const Vp8Planes pl = vp8_planes(work, W, H);
+    const uint32_t mbw = pl.mbw, mbh = pl.mbh;
+    const int ys = pl.ys, cs = pl.cs;
+    uint8_t *Y = pl.Y, *U = pl.U, *V = pl.V;
+    Vp8FInfo *finfo = pl.finfo;
+    uint8_t *ctx = pl.ctx;
     BoolDec br; br.init(data + 10, part0_len);
     br.get(128); br.get(128);                                // colour space, clamping type: no effect on decoding
     // segments
@@ -272,9 +324,13 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
         seg[i].uv[0] = kVp8DcQ[clipq(q + dq[3], 117)]; seg[i].uv[1] = kVp8AcQ[clipq(q + dq[4], 127)];
     }
     br.get(128);                                             // refresh_entropy_probs: a single frame
-    // coefficient probabilities
-    uint8_t probs_local[4 * 8 * 3 * 11];                     // [4 types][8 bands][3 contexts][11 nodes]
-    for (int i = 0; i < 4 * 8 * 3 * 11; i++) probs_local[i] = br.get(kVp8CoefUpdateProbs[i]) ? uint8_t(br.lit(8)) : kVp8CoefProbs[i];
+    // coefficient probabilities, and the constant tables of the hot loop next to them
+    for (int i = 0; i < 4 * 8 * 3 * 11; i++) hot.probs[i] = br.get(kVp8CoefUpdateProbs[i]) ? uint8_t(br.lit(8)) : kVp8CoefProbs[i];
+    for (int i = 0; i < 10 * 10 * 9; i++) hot.bmode[i] = kVp8BModeProbs[i];
+    for (int i = 0; i < 17; i++) hot.bands[i] = kVp8Bands[i];
+    for (int i = 0; i < 16; i++) hot.zigzag[i] = kVp8Zigzag[i];
+    for (int i = 0; i < 12; i++) { hot.cat[0][i] = i < 4 ? kVp8Cat3[i] : 0; hot.cat[1][i] = i < 5 ? kVp8Cat4[i] : 0; hot.cat[2][i] = i < 6 ? kVp8Cat5[i] : 0; hot.cat[3][i] = kVp8Cat6[i]; }
+    for (int k = 0; k < 25 * 16; k++) hot.coef[k] = 0;
     const bool use_skip = br.get(128) != 0;
     const int skip_p = use_skip ? int(br.lit(8)) : 0;
     // filter strengths per segment and block type
@@ -296,21 +352,27 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
             fstr[s][i4] = f;
         }
     const bool filtering = level != 0;   // libwebp: a frame-level 0 switches the filter off whatever the segments say
+    pl.frame->filtering = filtering ? 1u : 0u; pl.frame->simple = simple ? 1u : 0u;
 
     for (uint32_t i = 0; i < mbw * 16; i++) ctx[i] = 0;
+    int16_t *const coef = hot.coef;
+    const int S = 32, SC = 16;
+    uint8_t *const py = hot.sy + S + 4, *const pu = hot.su + SC + 4, *const pv = hot.sv + SC + 4;
     // ---- macroblocks
     for (uint32_t my = 0; my < mbh; my++) {
-        BoolDec &tb = tok[my & uint32_t(nparts - 1)];
-        uint8_t left_modes[4] = {0, 0, 0, 0};
-        uint8_t lnz[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // non-zero flags to the left: 4 y, 2 u, 2 v, y2
+        BoolDec tb = tok[my & uint32_t(nparts - 1)];   // the row's token reader in registers; handed back at the end of the row
+        uint8_t *const left_modes = hot.left_modes, *const lnz = hot.lnz;
+        for (int k = 0; k < 4; k++) left_modes[k] = 0;
+        for (int k = 0; k < 9; k++) lnz[k] = 0;
         for (uint32_t mx = 0; mx < mbw; mx++) {
-            uint8_t *top_modes = ctx + size_t(mx) * 16, *tnz = top_modes + 4;
+            uint8_t *top_modes = hot.ctx, *tnz = top_modes + 4;
+            for (int k = 0; k < 16; k++) hot.ctx[k] = ctx[size_t(mx) * 16 + k];
             // modes (first partition)
             int segment = 0;
             if (update_map) segment = !br.get(seg_prob[0]) ? br.get(seg_prob[1]) : br.get(seg_prob[2]) + 2;
             const bool skip_flag = use_skip ? br.get(skip_p) != 0 : false;
             const bool i4 = !br.get(145);
-            uint8_t bmodes[16];
+            uint8_t *bmodes = hot.bmodes;
             int ymode = 0;
             if (!i4) {
                 ymode = br.get(156) ? (br.get(128) ? 1 : 3) : (br.get(163) ? 2 : 0);   // B_ order: 0 DC, 1 TM, 2 V, 3 H
@@ -319,7 +381,7 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
                 for (int y = 0; y < 4; y++) {
                     int lm = left_modes[y];
                     for (int x = 0; x < 4; x++) {
-                        const uint8_t *pr = kVp8BModeProbs + (size_t(top_modes[x]) * 10 + size_t(lm)) * 9;
+                        const uint8_t *pr = hot.bmode + (size_t(top_modes[x]) * 10 + size_t(lm)) * 9;
                         int m;
                         if (!br.get(pr[0])) m = 0;
                         else if (!br.get(pr[1])) m = 1;
@@ -335,18 +397,17 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
             }
             const int uvmode = !br.get(142) ? 0 : !br.get(114) ? 2 : br.get(183) ? 1 : 3;
             // residuals (token partition of this macroblock row)
-            int16_t coef[25 * 16];
-            for (int k = 0; k < 25 * 16; k++) coef[k] = 0;
             uint32_t nzmask = 0;   // blocks with coefficients: bit b (0..15 y, 16..19 u, 20..23 v)
             const Vp8Seg &sq = seg[segment];
             auto get_coeffs = [&](int type, int ctx0, const int *q2, int first, int16_t *out) -> int {
-                const uint8_t *bp = probs_local + size_t(type) * 8 * 33;
+                const int q_dc = q2[0], q_ac = q2[1];
+                const uint8_t *bp = hot.probs + size_t(type) * 8 * 33;
                 int nn = first;
-                const uint8_t *p = bp + size_t(kVp8Bands[nn]) * 33 + size_t(ctx0) * 11;
+                const uint8_t *p = bp + size_t(hot.bands[nn]) * 33 + size_t(ctx0) * 11;
                 for (; nn < 16; nn++) {
                     if (!tb.get(p[0])) return nn;
-                    while (!tb.get(p[1])) { p = bp + size_t(kVp8Bands[++nn]) * 33; if (nn == 16) return 16; }
-                    const uint8_t *pn = bp + size_t(kVp8Bands[nn + 1]) * 33;
+                    while (!tb.get(p[1])) { p = bp + size_t(hot.bands[++nn]) * 33; if (nn == 16) return 16; }
+                    const uint8_t *pn = bp + size_t(hot.bands[nn + 1]) * 33;
                     int v;
                     if (!tb.get(p[2])) { v = 1; p = pn + 11; }
                     else {
@@ -356,21 +417,21 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
                             else { v = 7 + 2 * tb.get(165); v += tb.get(145); }
                         } else {
                             const int b1 = tb.get(p[8]), b0 = tb.get(p[9 + b1]), cat = 2 * b1 + b0;
-                            const uint8_t *tab = cat == 0 ? kVp8Cat3 : cat == 1 ? kVp8Cat4 : cat == 2 ? kVp8Cat5 : kVp8Cat6;
+                            const uint8_t *tab = hot.cat[cat];
                             v = 0;
                             for (; *tab; ++tab) v += v + tb.get(*tab);
                             v += 3 + (8 << cat);
                         }
                         p = pn + 22;
                     }
-                    out[kVp8Zigzag[nn]] = int16_t((tb.get(128) ? -v : v) * q2[nn > 0]);
+                    out[hot.zigzag[nn]] = int16_t((tb.get(128) ? -v : v) * (nn > 0 ? q_ac : q_dc));
                 }
                 return 16;
             };
             if (!skip_flag) {
                 int first = 0, ytype = 3;
                 if (!i4) {
-                    int16_t dc[16];
+                    int16_t *const dc = hot.dc;
                     for (int k = 0; k < 16; k++) dc[k] = 0;
                     const int nz = get_coeffs(1, tnz[8] + lnz[8], sq.y2, 0, dc);
                     tnz[8] = lnz[8] = uint8_t(nz > 0);
@@ -395,14 +456,13 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
                 for (int k = 0; k < 8; k++) { tnz[k] = 0; lnz[k] = 0; }
                 if (!i4) { tnz[8] = 0; lnz[8] = 0; }
             }
+            for (int k = 0; k < 16; k++) ctx[size_t(mx) * 16 + k] = hot.ctx[k];
             // libwebp: f_inner |= !skip with skip = !(non_zero_y | non_zero_uv), the bits AFTER the inverse WHT -- a Y2 block whose transform comes out all zero does not count
             if (filtering) { Vp8FInfo f = fstr[segment][i4 ? 1 : 0]; f.inner |= uint8_t((skip_flag || nzmask == 0) ? 0 : 1); finfo[size_t(my) * mbw + mx] = f; }
-            // ---- reconstruction (prediction from UNFILTERED neighbours: the loop filter runs over the finished frame below)
+            if (!(debug & 1u)) {   // (debug bit 0, CSH_WEBP_DEBUG: the parse alone -- a timing probe)
+            // ---- reconstruction (prediction from UNFILTERED neighbours: the loop filter runs over the finished frame afterwards)
             uint8_t *yd = Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = V + size_t(my) * 8 * cs + size_t(mx) * 8;
-            // borders live in small local arrays copied around the block: the planes have no margin, so predict into a 21 x 17 scratch
-            uint8_t sy[(16 + 1) * 32], su[(8 + 1) * 16], sv[(8 + 1) * 16];
-            const int S = 32, SC = 16;
-            uint8_t *py = sy + S + 1, *pu = su + SC + 1, *pv = sv + SC + 1;
+            // the planes have no margin: predict in the scratch, whose row above and column to the left get the neighbours (frame edges: 127 above, 129 to the left)
             for (int x = -1; x < 20; x++) {
                 int v = 127;
                 if (my > 0) {
@@ -447,63 +507,83 @@ __host__ __device__ static inline int vp8_decode_frame(const uint8_t *data, size
                 }
                 for (int k = 0; k < 4; k++) if (nzmask & (1u << (16 + 4 * ch + k))) vp8_idct_add(coef + (16 + 4 * ch + k) * 16, pc + (k >> 1) * 4 * SC + (k & 1) * 4, SC);
             }
-            for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) yd[y * ys + x] = py[y * S + x];
-            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) { ud[y * cs + x] = pu[y * SC + x]; vd[y * cs + x] = pv[y * SC + x]; }
-        }
-        if (br.eof) return 1;
-    }
-    // ---- loop filter, macroblock by macroblock in raster order
-    if (filtering)
-        for (uint32_t my = 0; my < mbh; my++)
-            for (uint32_t mx = 0; mx < mbw; mx++) {
-                const Vp8FInfo f = finfo[size_t(my) * mbw + mx];
-                if (!f.limit) continue;
-                uint8_t *yd = Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = V + size_t(my) * 8 * cs + size_t(mx) * 8;
-                if (simple) {
-                    if (mx > 0) lf_simple(yd, 1, ys, 16, f.limit + 4);
-                    if (f.inner) for (int k = 4; k < 16; k += 4) lf_simple(yd + k, 1, ys, 16, f.limit);
-                    if (my > 0) lf_simple(yd, ys, 1, 16, f.limit + 4);
-                    if (f.inner) for (int k = 4; k < 16; k += 4) lf_simple(yd + k * ys, ys, 1, 16, f.limit);
-                } else {
-                    if (mx > 0) { lf_edge(yd, 1, ys, 16, f.limit + 4, f.ilevel, f.hev, true); lf_edge(ud, 1, cs, 8, f.limit + 4, f.ilevel, f.hev, true); lf_edge(vd, 1, cs, 8, f.limit + 4, f.ilevel, f.hev, true); }
-                    if (f.inner) {
-                        for (int k = 4; k < 16; k += 4) lf_edge(yd + k, 1, ys, 16, f.limit, f.ilevel, f.hev, false);
-                        lf_edge(ud + 4, 1, cs, 8, f.limit, f.ilevel, f.hev, false); lf_edge(vd + 4, 1, cs, 8, f.limit, f.ilevel, f.hev, false);
-                    }
-                    if (my > 0) { lf_edge(yd, ys, 1, 16, f.limit + 4, f.ilevel, f.hev, true); lf_edge(ud, cs, 1, 8, f.limit + 4, f.ilevel, f.hev, true); lf_edge(vd, cs, 1, 8, f.limit + 4, f.ilevel, f.hev, true); }
-                    if (f.inner) {
-                        for (int k = 4; k < 16; k += 4) lf_edge(yd + k * ys, ys, 1, 16, f.limit, f.ilevel, f.hev, false);
-                        lf_edge(ud + 4 * cs, cs, 1, 8, f.limit, f.ilevel, f.hev, false); lf_edge(vd + 4 * cs, cs, 1, 8, f.limit, f.ilevel, f.hev, false);
-                    }
-                }
+            // whole words out (the block sits word-aligned in the scratch, the planes are 16 / 8 samples per macroblock wide)
+            for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x += 4) *reinterpret_cast<uint32_t *>(yd + y * ys + x) = *reinterpret_cast<const uint32_t *>(py + y * S + x);
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x += 4) {
+                *reinterpret_cast<uint32_t *>(ud + y * cs + x) = *reinterpret_cast<const uint32_t *>(pu + y * SC + x);
+                *reinterpret_cast<uint32_t *>(vd + y * cs + x) = *reinterpret_cast<const uint32_t *>(pv + y * SC + x);
             }
-    // ---- libwebp's fancy upsampler (chroma at 9:3:3:1 of the four nearest samples, computed on u | v << 16 pairs) + YCbCr -> RGB
-    const int cw = int((W + 1) >> 1), chh = int((H + 1) >> 1);
-    auto uvp = [&](int cx, int cy) -> uint32_t { return uint32_t(U[size_t(cy) * cs + cx]) | (uint32_t(V[size_t(cy) * cs + cx]) << 16); };
-    auto line_pair = [&](int ytop, int ybot, int ctop, int ccur) {   // ytop / ybot: luma rows (-1: none); chroma rows above / current
-        auto emit = [&](int yrow, int x, uint32_t uv) { yuv_rgb(Y[size_t(yrow) * ys + x], int(uv & 0xFF), int(uv >> 16), rgb + (size_t(yrow) * W + x) * 3); };
-        const int last_pair = (int(W) - 1) >> 1;
-        uint32_t tl = uvp(0, ctop), l = uvp(0, ccur);
-        if (ytop >= 0) emit(ytop, 0, (3 * tl + l + 0x00020002u) >> 2);
-        if (ybot >= 0) emit(ybot, 0, (3 * l + tl + 0x00020002u) >> 2);
-        for (int x = 1; x <= last_pair; x++) {
-            const uint32_t t = uvp(x, ctop), c = uvp(x, ccur);
-            const uint32_t avg = tl + t + l + c + 0x00080008u;
-            const uint32_t d12 = (avg + 2 * (t + l)) >> 3, d03 = (avg + 2 * (tl + c)) >> 3;
-            if (ytop >= 0) { emit(ytop, 2 * x - 1, (d12 + tl) >> 1); emit(ytop, 2 * x, (d03 + t) >> 1); }
-            if (ybot >= 0) { emit(ybot, 2 * x - 1, (d03 + l) >> 1); emit(ybot, 2 * x, (d12 + c) >> 1); }
-            tl = t; l = c;
+            }
+            // the coefficient store goes back to all zeros: only blocks in nzmask hold anything
+            for (int k = 0; k < 24; k++) if (nzmask & (1u << k)) for (int q = 0; q < 16; q++) coef[16 * k + q] = 0;
         }
-        if (!(W & 1)) {
-            if (ytop >= 0) emit(ytop, int(W) - 1, (3 * tl + l + 0x00020002u) >> 2);
-            if (ybot >= 0) emit(ybot, int(W) - 1, (3 * l + tl + 0x00020002u) >> 2);
-        }
-    };
-    (void)cw;
-    line_pair(0, -1, 0, 0);                                             // first row: its chroma row on both sides
-    for (int k = 1; k < chh; k++) line_pair(2 * k - 1, 2 * k, k - 1, k); // rows 2k-1 and 2k between chroma rows k-1 and k
-    if (!(H & 1)) line_pair(int(H) - 1, -1, chh - 1, chh - 1);          // even height: the last row again on its own
+        tok[my & uint32_t(nparts - 1)] = tb;
+        if (br.eof()) return 1;
+    }
     return 0;
+}
+
+// the loop filter of one macroblock (RFC 6386 section 15: macroblocks in raster order).  What a macroblock's filter reads and changes reaches three
+// samples into the macroblocks to its left and above, so (mx, my) only needs (mx - 1, my), (mx, my - 1) and (mx + 1, my - 1) done: the kernel runs the
+// frame as a wave front, macroblock row r at column t - 2 r in step t.
+__host__ __device__ static inline void vp8_filter_mb(uint8_t *work, uint32_t W, uint32_t H, uint32_t mx, uint32_t my) {
+    const Vp8Planes pl = vp8_planes(work, W, H);
+    if (!pl.frame->filtering) return;
+    const bool simple = pl.frame->simple != 0;
+    const int ys = pl.ys, cs = pl.cs;
+    const Vp8FInfo f = pl.finfo[size_t(my) * pl.mbw + mx];
+    if (!f.limit) return;
+    uint8_t *yd = pl.Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = pl.U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = pl.V + size_t(my) * 8 * cs + size_t(mx) * 8;
+    if (simple) {
+        if (mx > 0) lf_simple(yd, 1, ys, 16, f.limit + 4);
+        if (f.inner) for (int k = 4; k < 16; k += 4) lf_simple(yd + k, 1, ys, 16, f.limit);
+        if (my > 0) lf_simple(yd, ys, 1, 16, f.limit + 4);
+        if (f.inner) for (int k = 4; k < 16; k += 4) lf_simple(yd + k * ys, ys, 1, 16, f.limit);
+    } else {
+        if (mx > 0) { lf_edge(yd, 1, ys, 16, f.limit + 4, f.ilevel, f.hev, true); lf_edge(ud, 1, cs, 8, f.limit + 4, f.ilevel, f.hev, true); lf_edge(vd, 1, cs, 8, f.limit + 4, f.ilevel, f.hev, true); }
+        if (f.inner) {
+            for (int k = 4; k < 16; k += 4) lf_edge(yd + k, 1, ys, 16, f.limit, f.ilevel, f.hev, false);
+            lf_edge(ud + 4, 1, cs, 8, f.limit, f.ilevel, f.hev, false); lf_edge(vd + 4, 1, cs, 8, f.limit, f.ilevel, f.hev, false);
+        }
+        if (my > 0) { lf_edge(yd, ys, 1, 16, f.limit + 4, f.ilevel, f.hev, true); lf_edge(ud, cs, 1, 8, f.limit + 4, f.ilevel, f.hev, true); lf_edge(vd, cs, 1, 8, f.limit + 4, f.ilevel, f.hev, true); }
+        if (f.inner) {
+            for (int k = 4; k < 16; k += 4) lf_edge(yd + k * ys, ys, 1, 16, f.limit, f.ilevel, f.hev, false);
+            lf_edge(ud + 4 * cs, cs, 1, 8, f.limit, f.ilevel, f.hev, false); lf_edge(vd + 4 * cs, cs, 1, 8, f.limit, f.ilevel, f.hev, false);
+        }
+    }
+}
+
+// libwebp's fancy upsampler (chroma at 9:3:3:1 of the four nearest samples, computed on u | v << 16 pairs) + YCbCr -> RGB, one pair of luma rows
+// between two chroma rows per call: k = 0 the first row (its chroma row on both sides), k = 1 .. chh - 1 rows 2k-1 and 2k between chroma rows k-1 and k,
+// k = chh the last row of an even height on its own.  The calls are independent of one another.
+__host__ __device__ static inline void vp8_rgb_rows(uint8_t *work, uint32_t W, uint32_t H, uint32_t k, uint8_t *rgb) {
+    const Vp8Planes pl = vp8_planes(work, W, H);
+    const uint8_t *Y = pl.Y, *U = pl.U, *V = pl.V;
+    const int ys = pl.ys, cs = pl.cs;
+    const int chh = int((H + 1) >> 1);
+    int ytop, ybot, ctop, ccur;
+    if (k == 0) { ytop = 0; ybot = -1; ctop = 0; ccur = 0; }
+    else if (int(k) < chh) { ytop = 2 * int(k) - 1; ybot = 2 * int(k); ctop = int(k) - 1; ccur = int(k); }
+    else if (int(k) == chh && !(H & 1)) { ytop = int(H) - 1; ybot = -1; ctop = chh - 1; ccur = chh - 1; }
+    else return;
+    auto uvp = [&](int cx, int cy) -> uint32_t { return uint32_t(U[size_t(cy) * cs + cx]) | (uint32_t(V[size_t(cy) * cs + cx]) << 16); };
+    auto emit = [&](int yrow, int x, uint32_t uv) { yuv_rgb(Y[size_t(yrow) * ys + x], int(uv & 0xFF), int(uv >> 16), rgb + (size_t(yrow) * W + x) * 3); };
+    const int last_pair = (int(W) - 1) >> 1;
+    uint32_t tl = uvp(0, ctop), l = uvp(0, ccur);
+    if (ytop >= 0) emit(ytop, 0, (3 * tl + l + 0x00020002u) >> 2);
+    if (ybot >= 0) emit(ybot, 0, (3 * l + tl + 0x00020002u) >> 2);
+    for (int x = 1; x <= last_pair; x++) {
+        const uint32_t t = uvp(x, ctop), c = uvp(x, ccur);
+        const uint32_t avg = tl + t + l + c + 0x00080008u;
+        const uint32_t d12 = (avg + 2 * (t + l)) >> 3, d03 = (avg + 2 * (tl + c)) >> 3;
+        if (ytop >= 0) { emit(ytop, 2 * x - 1, (d12 + tl) >> 1); emit(ytop, 2 * x, (d03 + t) >> 1); }
+        if (ybot >= 0) { emit(ybot, 2 * x - 1, (d03 + l) >> 1); emit(ybot, 2 * x, (d12 + c) >> 1); }
+        tl = t; l = c;
+    }
+    if (!(W & 1)) {
+        if (ytop >= 0) emit(ytop, int(W) - 1, (3 * tl + l + 0x00020002u) >> 2);
+        if (ybot >= 0) emit(ybot, int(W) - 1, (3 * l + tl + 0x00020002u) >> 2);
+    }
 }
 
 }  // namespace csw

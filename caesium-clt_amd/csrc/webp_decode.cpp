@@ -90,6 +90,7 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
         b->pool.resize((b->pool.size() + 15) & ~size_t(15));
         im.width = w; im.height = h; im.mbw = (w + 15) / 16; im.mbh = (h + 15) / 16;
         im.lossless = lossless ? 1u : 0u;
+        im.debug = getenv("CSH_WEBP_DEBUG") ? uint32_t(atoi(getenv("CSH_WEBP_DEBUG"))) : 0u;
         uint64_t work = lossless ? csw::vp8l_work_bytes(w, h, len) : csw::vp8_work_bytes(im.mbw, im.mbh);
         if (alph_len) {
             im.alph_off = b->pool.size(); im.alph_len = uint32_t(alph_len);
@@ -118,7 +119,9 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
 extern "C" int cswd_batch_run(cswd_batch *b) {
     if (b->imgs.empty()) { b->ran = true; return 0; }
     if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
-    csw::launch_vp8_decode(b->stream, b->d_pool.p, b->d_imgs.p, int(b->imgs.size()), b->d_work.p, b->d_rgb.p);
+    int nsteps = 0;   // of the loop filter's wave front: the largest lossy frame's columns + 2 x rows of macroblocks
+    for (const csw::Vp8In &im : b->imgs) if (!im.lossless) nsteps = std::max(nsteps, int(im.mbw + 2 * im.mbh));
+    csw::launch_vp8_decode(b->stream, b->d_pool.p, b->d_imgs.p, int(b->imgs.size()), b->d_work.p, b->d_rgb.p, nsteps);
     if (hipMemcpyAsync(b->imgs.data(), b->d_imgs.p, b->imgs.size() * sizeof(csw::Vp8In), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
         hipStreamSynchronize(b->stream) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("VP8 decode failed on the device"); return CS_ERR_NO_DEVICE; }
     for (cswd_batch::Item &it : b->items)

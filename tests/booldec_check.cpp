@@ -1,0 +1,37 @@
+// The wide-window boolean decoder of vp8_dec.h against the byte-wise form of RFC 6386 section 7 (the statement it replaced): every decision and the
+// end-of-data flag, on random bytes and probabilities (tests/test_webp_decode_emul.py builds and runs this).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstddef>
+#define __host__
+#define __device__
+#include "../caesium-clt_amd/csrc/vp8_dec.h"
+struct Old {
+    const uint8_t *p, *end; uint32_t value, range; int bits; bool eof;
+    void init(const uint8_t *d, size_t n) { p = d; end = d + n; eof = false; value = 0; for (int i = 0; i < 2; i++) value = (value << 8) | (p < end ? *p++ : 0u); range = 255; bits = 0; }
+    int get(int prob) {
+        const uint32_t split = 1u + (((range - 1u) * uint32_t(prob)) >> 8); const uint32_t big = split << 8; int r;
+        if (value >= big) { r = 1; range -= split; value -= big; } else { r = 0; range = split; }
+        while (range < 128u) { value <<= 1; range <<= 1; if (++bits == 8) { bits = 0; if (p < end) value |= *p++; else eof = true; } }
+        return r;
+    }
+};
+int main() {
+    srand(7);
+    long checked = 0;
+    for (int it = 0; it < 20000; it++) {
+        int n = rand() % 40;
+        uint8_t buf[64];
+        for (int i = 0; i < n; i++) buf[i] = (it & 1) ? uint8_t(rand()) : uint8_t(rand() % 3 ? 0xFF : rand());
+        Old o; o.init(buf, n); csw::BoolDec b; b.init(buf, n);
+        for (int k = 0; k < 600; k++) {
+            int prob = 1 + rand() % 255; if (rand() % 8 == 0) prob = (rand() & 1) ? 1 : 255;
+            if (o.value >= (o.range << 8)) break;   /* outside the coder's invariant (no encoder writes this): the 32-bit byte-wise form wraps, the wide form is libwebp's arithmetic */
+            int r0 = o.get(prob), r1 = b.get(prob);
+            if (r0 != r1 || o.eof != b.eof()) { printf("MISMATCH it=%d k=%d n=%d r %d %d eof %d %d\n", it, k, n, r0, r1, o.eof, b.eof()); return 1; }
+            checked++;
+        }
+    }
+    printf("ok %ld decisions\n", checked);
+}

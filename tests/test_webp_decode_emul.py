@@ -311,6 +311,16 @@ def test_emul_transparent_sources_keep_their_alpha(api):
     assert im.mode == "RGBA" and im.info.get("icc_profile") == b"fake profile bytes" and out[20] & 0x38 == 0x38
 
 
+def test_boolean_decoder_equals_the_byte_wise_form(tmp_path):
+    """vp8_dec.h's BoolDec (32 bits of look-ahead, one shift per symbol) decides like RFC 6386's two-byte form, bit for bit, and reports the end of the data at the same symbol"""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "booldec_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(here, "..", "include"), os.path.join(here, "booldec_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, check=True)
+    assert r.stdout.decode().startswith("ok "), r.stdout
+
+
 def test_emul_damaged_transparent_files_fail_alone(api):
     """bit flips inside the ALPH chunk and in non-opaque VP8L streams, truncated chunks, a plane shorter than the picture: refused per file or decoded to a
     picture of the right shape, never past a buffer (tools/asan_emul.sh runs this under the sanitizers)"""

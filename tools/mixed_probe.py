@@ -26,7 +26,8 @@ def main():
                 with open(os.path.join(d, "tree", ext, f"m{k:04d}.{ext}"), "wb") as f:
                     f.write(blobs[k % 8])
         env = dict(os.environ, CSH_TRACE="1")
-        for what in ("jpg", "png", "webp", "", ""):
+        only = sys.argv[2:] or ("jpg", "png", "webp", "", "")
+        for what in only:
             out = os.path.join(d, "out_" + (what or "all"))
             secs, r = bench.run_cli(["-q", "80", "-R", "-S", "--quiet", "-o", out, os.path.join(d, "tree", what)], env=env)
             nout = sum(len(fs) for _, _, fs in os.walk(out))
