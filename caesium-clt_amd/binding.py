@@ -49,7 +49,7 @@ EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_siz
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_create_webp", "csp_batch_create_pixels", "csh_batch_create_pixels", "csh_batch_pixels", "csh_batch_create_from_pixels", "csp_png_to_jpeg", "csp_png_to_lossless_webp", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
            "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert",
-           "cswd_batch_create", "cswd_batch_run", "cswd_batch_pixels", "cswd_batch_read_pixels", "cswd_batch_alpha", "cswd_batch_read_rgba", "cswd_batch_destroy", "csh_batch_create_webp_from_pixels", "csh_batch_create_from_pixels_rgb", "csl_encode_pixels", "csl_attach_alpha"]
+           "cswd_batch_create", "cswd_batch_run", "cswd_batch_pixels", "cswd_batch_read_pixels", "cswd_batch_alpha", "cswd_batch_read_rgba", "cswd_batch_destroy", "cswd_rgba_join", "cswd_rgba_destroy", "csh_batch_create_webp_from_pixels", "csh_batch_create_from_pixels_rgb", "csl_encode_pixels", "csl_attach_alpha"]
 
 
 def _declare(L):
@@ -108,6 +108,10 @@ def _declare(L):
     L.cswd_batch_read_rgba.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     L.cswd_batch_destroy.argtypes = [C.c_void_p]
     L.cswd_batch_destroy.restype = None
+    L.cswd_rgba_join.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.cswd_rgba_join.restype = C.c_int
+    L.cswd_rgba_destroy.argtypes = [C.c_void_p]
+    L.cswd_rgba_destroy.restype = None
     return L
 
 
