@@ -592,7 +592,8 @@ int run(const Options &o) {
         int ndev = std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
         // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being
         // parsed and uploaded (separate streams; the boundary call is thread-safe)
-        const size_t nworkers = size_t(ndev) * 2;
+        const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 2;
+        const size_t nworkers = size_t(ndev) * per_dev;
         parallel_for(nworkers, nworkers, [&](size_t worker) {
             const size_t dev = worker % size_t(ndev);
             for (size_t bi = worker; bi < batches.size(); bi += nworkers) {
