@@ -401,7 +401,7 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
         (t == CS_TYPE_PNG ? png : t == CS_TYPE_WEBP ? webp : other).push_back(i);
     }
     if (png.empty() && webp.empty() && !any_pass) return jpeg_batch_compress(inputs, count, p, device, outputs, results);
-    int failed = 0;
+    std::atomic<int> failed{0};
     auto run = [&](const std::vector<size_t> &idx, int kind) {
         if (idx.empty()) return;
         std::vector<CByteArray> in(idx.size()), out(idx.size());
@@ -412,10 +412,13 @@ int cs_batch_compress(const CByteArray *inputs, size_t count, const CCSParameter
                                 : jpeg_batch_compress(in.data(), in.size(), p, device, out.data(), res.data());
         for (size_t k = 0; k < idx.size(); k++) { outputs[idx[k]] = out[k]; if (results) results[idx[k]] = res[k]; else cs_free_result(&res[k]); }
     };
-    run(png, 1);
-    run(webp, 2);
+    // the three rows side by side (each batch keeps to its own stream; their outputs are disjoint): a tree of all three kinds waits for its slowest row only
+    std::vector<std::thread> rows;
+    if (!png.empty() && (!webp.empty() || !other.empty())) rows.emplace_back(run, std::cref(png), 1); else run(png, 1);
+    if (!webp.empty() && !other.empty()) rows.emplace_back(run, std::cref(webp), 2); else run(webp, 2);
     run(other, 0);
-    return failed + passed_failed;
+    for (std::thread &t : rows) t.join();
+    return failed.load() + passed_failed;
 }
 CCSResult cs_compress_in_memory(const uint8_t *in, size_t n, const CCSParameters *p, CByteArray *out) {
     CByteArray input; input.data = const_cast<uint8_t *>(in); input.length = n;
