@@ -7,12 +7,16 @@
 
 namespace csw {
 
-// One workgroup per picture, in phases: (0) lane 0 walks the serial part -- a lossless picture altogether (vp8l_dec.h), a lossy frame's parse and
-// reconstruction (vp8_parse_frame) --; (1 .. nsteps) the loop filter as a wave front, macroblock row r at column t - 2 r in step t; then the RGB
-// conversion by row pairs across the lanes; then a lossy file's alpha plane (lane 0: a VP8L stream of its own) and its join with the colour (all lanes).
-// nsteps = the largest mbw + 2 mbh of the batch's lossy frames.
+// One workgroup per picture, in phases: (0) lane 0 walks the serial part -- a lossless picture altogether (vp8l_dec.h), a lossy frame's parse
+// (vp8_parse_frame: modes and coefficients into per-macroblock records) --; (1 .. nsteps) the reconstruction and (nsteps + 1 .. 2 nsteps) the loop filter,
+// each as a wave front over the macroblock rows: row r at column t - 2 r in step t (a macroblock needs its left, upper and upper-right neighbours); then
+// the RGB conversion by row pairs across the lanes; then a lossy file's alpha plane (lane 0: a VP8L stream of its own) and its join with the colour (all
+// lanes).  nsteps = the largest mbw + 2 mbh of the batch's lossy frames.  The reconstruction predicts in a scratch patch per lane: 64 of them (rows 64
+// apart are in flight together only in frames wider than 2048 samples; a lane then takes its rows one after the other), in the LDS the parse has left.
+#define CSW_RECON_LANES 64
+union Vp8Lds { Vp8Hot hot; Vp8Scratch scratch[CSW_RECON_LANES]; };
 __global__ void __launch_bounds__(256) k_vp8_decode(const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps) {
-    CSH_SHARED Vp8Hot hot;
+    CSH_SHARED Vp8Lds lds;
     CSH_SHARED uint32_t s_translucent;
     const int i = int(blockIdx.x);
     Vp8In &im = imgs[i];
@@ -20,38 +24,47 @@ __global__ void __launch_bounds__(256) k_vp8_decode(const uint8_t *pool, Vp8In *
     uint8_t *rgba = room ? rgb + im.rgba_off : nullptr, *aplane = room ? rgb + im.a_off : nullptr;
     uint8_t *wk = work + im.work_off, *out = rgb + im.rgb_off;
     const uint32_t W = im.width, H = im.height;
-    CSH_PHASE_LOOP(nsteps + 5) {
+    CSH_PHASE_LOOP(2 * nsteps + 5) {
         if (phase == 0) {
             if (threadIdx.x == 0) {
                 uint32_t has_alpha = 0;
                 s_translucent = 0;
                 if (im.lossless) im.status = uint32_t(vp8l_decode_frame(pool + im.data_off, im.data_len, W, H, wk, out, im.data_len, false, rgba, aplane, &has_alpha));
-                else im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, W, H, wk, hot, im.debug));
+                else im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, W, H, wk, lds.hot, im.debug));
                 im.has_alpha = has_alpha;
             }
             continue;
         }
         if (im.lossless || im.status) continue;
         if (phase <= nsteps) {
-            if (im.debug & 3u) continue;
+            if ((im.debug & 1u) || threadIdx.x >= CSW_RECON_LANES) continue;
             const int t = phase - 1;
+            for (uint32_t r = threadIdx.x; r < im.mbh; r += CSW_RECON_LANES) {
+                const int mx = t - 2 * int(r);
+                if (mx >= 0 && mx < int(im.mbw)) vp8_recon_mb(wk, W, H, uint32_t(mx), r, lds.scratch[threadIdx.x]);
+            }
+            continue;
+        }
+        if (phase <= 2 * nsteps) {
+            if (im.debug & 3u) continue;
+            const int t = phase - nsteps - 1;
             for (uint32_t r = threadIdx.x; r < im.mbh; r += blockDim.x) {
                 const int mx = t - 2 * int(r);
                 if (mx >= 0 && mx < int(im.mbw)) vp8_filter_mb(wk, W, H, uint32_t(mx), r);
             }
             continue;
         }
-        if (phase == nsteps + 1) {
+        if (phase == 2 * nsteps + 1) {
             if (im.debug & 5u) continue;
             for (uint32_t k = threadIdx.x; k <= (H + 1) >> 1; k += blockDim.x) vp8_rgb_rows(wk, W, H, k, out);
             continue;
         }
         if (!im.alph_len) continue;
-        if (phase == nsteps + 2) {   // the alpha plane of a lossy file (the frame's work area is free again)
+        if (phase == 2 * nsteps + 2) {   // the alpha plane of a lossy file (the frame's work area is free again)
             if (threadIdx.x == 0) im.status = !room ? 3u : uint32_t(alph_decode(pool + im.alph_off, im.alph_len, W, H, wk, aplane));
             continue;
         }
-        if (phase == nsteps + 3) {
+        if (phase == 2 * nsteps + 3) {
             const uint64_t npx = uint64_t(W) * H;
             bool translucent = false;
             for (uint64_t k = threadIdx.x; k < npx; k += blockDim.x) {
@@ -65,7 +78,7 @@ __global__ void __launch_bounds__(256) k_vp8_decode(const uint8_t *pool, Vp8In *
     }
 }
 void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps) {
-    if (n) CSH_LAUNCH_PHASED(k_vp8_decode, nsteps + 5, dim3(unsigned(n)), dim3(256), st, pool, imgs, n, work, rgb, nsteps);
+    if (n) CSH_LAUNCH_PHASED(k_vp8_decode, 2 * nsteps + 5, dim3(unsigned(n)), dim3(256), st, pool, imgs, n, work, rgb, nsteps);
 }
 
 // RGB + alpha plane -> interleaved RGBA (the resized halves of a picture with transparency, joined for the PNG / lossless WebP coders): four pixels per lane

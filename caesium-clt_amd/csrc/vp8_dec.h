@@ -21,13 +21,14 @@ struct Vp8In {              // one input file, host-parsed container
     uint32_t lossless;      // 1: the payload is a VP8L stream (vp8l_dec.h), work area sized by vp8l_work_bytes
     uint32_t has_alpha;     // device: 1 when the picture is not opaque -- then rgba_off / a_off hold it as RGBA and its alpha plane as well
     uint64_t alph_off;      // lossy files: the ALPH chunk's payload in the input pool (alph_len 0: none)
-    uint32_t alph_len, debug;   // debug: CSH_WEBP_DEBUG (timing probes: 1 parse only, 2 no loop filter, 4 no RGB)
+    uint32_t alph_len, debug;   // debug: CSH_WEBP_DEBUG (timing probes: 1 no reconstruction, 2 no loop filter, 4 no RGB)
     uint64_t rgba_off, a_off;   // width * height * 4 and width * height bytes in the pixel pool (~0: not reserved)
 };
-// work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts
+// work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts, the frame info, and what the
+// parse hands the reconstruction: per macroblock a record of its modes (24 bytes) and its 24 dequantised 4 x 4 blocks (768 bytes, only those in nzmask written)
 __host__ __device__ static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t mbh) {
     const uint64_t ly = uint64_t(mbw) * 16 * mbh * 16, lc = uint64_t(mbw) * 8 * mbh * 8;
-    return ly + 2 * lc + uint64_t(mbw) * mbh * 4 + uint64_t(mbw) * 16 + 256;
+    return ly + 2 * lc + uint64_t(mbw) * mbh * 4 + uint64_t(mbw) * 16 + 256 + uint64_t(mbw) * mbh * (24 + 768);
 }
 
 // RFC 6386 section 7's boolean decoder with a wide window: `value` holds the decoder's 8-bit value and nbits bits of look-ahead below it, so
@@ -72,7 +73,12 @@ __host__ __device__ static inline int clip8(int v) { return v < 0 ? 0 : v > 255 
 __host__ __device__ static inline int clipq(int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; }
 
 // inverse DCT of one 4x4 block, added to the prediction in dst (libwebp TransformOne: the two multipliers of RFC 6386 14.3)
-__host__ __device__ static inline void vp8_idct_add(const int16_t *in, uint8_t *dst, int stride) {
+__host__ __device__ static inline void vp8_idct_add(const int16_t *in16, uint8_t *dst, int stride) {
+    // the block comes out of the work area (16-byte aligned): two loads up front instead of thirty-two the compiler has to order against the stores below
+    const uint4 q0 = reinterpret_cast<const uint4 *>(in16)[0], q1 = reinterpret_cast<const uint4 *>(in16)[1];
+    const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    int in[16];
+    for (int i = 0; i < 8; i++) { in[2 * i] = int16_t(w[i] & 0xFFFFu); in[2 * i + 1] = int16_t(w[i] >> 16); }
     int tmp[16];
     for (int i = 0; i < 4; i++) {
         const int a = in[i] + in[8 + i], b = in[i] - in[8 + i];
@@ -217,6 +223,7 @@ __host__ __device__ static inline void yuv_rgb(int y, int u, int v, uint8_t *o) 
 struct Vp8Seg { int y1[2], y2[2], uv[2]; };
 struct Vp8FInfo { uint8_t limit, ilevel, inner, hev; };
 struct Vp8Frame { uint32_t filtering, simple; };   // what the stages behind the parse need of the frame header (kept behind the contexts in the work area)
+struct Vp8MbRec { uint32_t nzmask; uint8_t i4, ymode, uvmode, pad; uint8_t bmodes[16]; };   // a macroblock as the parse leaves it (nzmask: blocks with coefficients, 0..15 y, 16..19 u, 20..23 v)
 
 // the work area of one picture (vp8_work_bytes)
 struct Vp8Planes {
@@ -224,6 +231,8 @@ struct Vp8Planes {
     Vp8FInfo *finfo;
     uint8_t *ctx;        // per macroblock column: [0..3] sub-block modes above, [4..12] non-zero flags above (4 y, 2 u, 2 v, 1 y2)
     Vp8Frame *frame;
+    Vp8MbRec *rec;       // [mbw * mbh]
+    int16_t *mbcoef;     // [mbw * mbh][24][16]
     int ys, cs;
     uint32_t mbw, mbh;
 };
@@ -235,16 +244,16 @@ __host__ __device__ static inline Vp8Planes vp8_planes(uint8_t *work, uint32_t W
     p.finfo = reinterpret_cast<Vp8FInfo *>(p.V + size_t(p.cs) * p.mbh * 8);
     p.ctx = reinterpret_cast<uint8_t *>(p.finfo + size_t(p.mbw) * p.mbh);
     p.frame = reinterpret_cast<Vp8Frame *>(p.ctx + size_t(p.mbw) * 16);
+    p.rec = reinterpret_cast<Vp8MbRec *>(p.ctx + size_t(p.mbw) * 16 + 64);
+    p.mbcoef = reinterpret_cast<int16_t *>((reinterpret_cast<uintptr_t>(p.rec + size_t(p.mbw) * p.mbh) + 15) & ~uintptr_t(15));   // 16-byte blocks (the + 256 of vp8_work_bytes pays for the gaps)
     return p;
 }
 
 // The parse's working set.  One lane walks a frame (a boolean-coded partition is one chain), and everything it touches per symbol -- the
-// probabilities, the small constant tables, the macroblock's coefficients, the prediction scratch -- would sit in private memory (scratch: a
+// probabilities, the small constant tables, the macroblock's coefficients, the contexts -- would sit in private memory (scratch: a
 // round trip to the memory system per look-up) if it were local arrays; the kernel keeps this struct in LDS.
 struct Vp8Hot {
-    alignas(4) uint8_t sy[(16 + 1) * 32];   // prediction scratch: the block at row 1, column 4 (aligned words), its neighbours above and to the left
-    alignas(4) uint8_t su[(8 + 1) * 16], sv[(8 + 1) * 16];
-    int16_t coef[25 * 16];                  // zero between macroblocks
+    alignas(16) int16_t coef[25 * 16];      // zero between macroblocks
     uint8_t probs[4 * 8 * 3 * 11];          // [4 types][8 bands][3 contexts][11 nodes]
     uint8_t bmode[10 * 10 * 9];
     uint8_t bands[17], zigzag[16], cat[4][12];
@@ -253,10 +262,11 @@ struct Vp8Hot {
     int16_t dc[16];                         // the Y2 block of an i16 macroblock
 };
 
-// the parse: frame header, then macroblock by macroblock modes, coefficients and -- from UNFILTERED neighbours -- the reconstruction; leaves the
-// planes, the filter strengths and the frame info in the work area.  Returns 0 or an error code (CS_ERR_* numbers are the caller's: 1 = malformed,
+// the parse: frame header, then macroblock by macroblock the modes and the coefficients (dequantised, the Y2 block folded into the luma DCs); leaves the
+// macroblock records, their coefficient blocks, the filter strengths and the frame info in the work area.  Returns 0 or an error code (CS_ERR_* numbers are the caller's: 1 = malformed,
 // 2 = unsupported feature)
 __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, Vp8Hot &hot, uint32_t debug = 0) {
+    (void)debug;
     if (n < 10) return 1;
     const uint32_t tag = data[0] | (data[1] << 8) | (data[2] << 16);
     if (tag & 1) return 2;                                   // not a key frame
@@ -267,8 +277,6 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
     if (10 + size_t(part0_len) > n) return 1;
     const Vp8Planes pl = vp8_planes(work, W, H);
     const uint32_t mbw = pl.mbw, mbh = pl.mbh;
-    const int ys = pl.ys, cs = pl.cs;
-    uint8_t *Y = pl.Y, *U = pl.U, *V = pl.V;
     Vp8FInfo *finfo = pl.finfo;
     uint8_t *ctx = pl.ctx;
     BoolDec br; br.init(data + 10, part0_len);
@@ -356,8 +364,6 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
 
     for (uint32_t i = 0; i < mbw * 16; i++) ctx[i] = 0;
     int16_t *const coef = hot.coef;
-    const int S = 32, SC = 16;
-    uint8_t *const py = hot.sy + S + 4, *const pu = hot.su + SC + 4, *const pv = hot.sv + SC + 4;
     // ---- macroblocks
     for (uint32_t my = 0; my < mbh; my++) {
         BoolDec tb = tok[my & uint32_t(nparts - 1)];   // the row's token reader in registers; handed back at the end of the row
@@ -459,60 +465,16 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
             for (int k = 0; k < 16; k++) ctx[size_t(mx) * 16 + k] = hot.ctx[k];
             // libwebp: f_inner |= !skip with skip = !(non_zero_y | non_zero_uv), the bits AFTER the inverse WHT -- a Y2 block whose transform comes out all zero does not count
             if (filtering) { Vp8FInfo f = fstr[segment][i4 ? 1 : 0]; f.inner |= uint8_t((skip_flag || nzmask == 0) ? 0 : 1); finfo[size_t(my) * mbw + mx] = f; }
-            if (!(debug & 1u)) {   // (debug bit 0, CSH_WEBP_DEBUG: the parse alone -- a timing probe)
-            // ---- reconstruction (prediction from UNFILTERED neighbours: the loop filter runs over the finished frame afterwards)
-            uint8_t *yd = Y + size_t(my) * 16 * ys + size_t(mx) * 16, *ud = U + size_t(my) * 8 * cs + size_t(mx) * 8, *vd = V + size_t(my) * 8 * cs + size_t(mx) * 8;
-            // the planes have no margin: predict in the scratch, whose row above and column to the left get the neighbours (frame edges: 127 above, 129 to the left)
-            for (int x = -1; x < 20; x++) {
-                int v = 127;
-                if (my > 0) {
-                    if (x < 0) v = mx > 0 ? yd[-ys - 1] : 129;
-                    else if (x < 16) v = yd[-ys + x];
-                    else v = mx + 1 < mbw ? yd[-ys + x] : yd[-ys + 15];
-                }
-                py[-S + x] = uint8_t(v);
-            }
-            for (int y = 0; y < 16; y++) py[y * S - 1] = mx > 0 ? yd[y * ys - 1] : uint8_t(129);
-            for (int x = -1; x < 8; x++) {
-                int a = 127, b = 127;
-                if (my > 0) { if (x < 0) { a = mx > 0 ? ud[-cs - 1] : 129; b = mx > 0 ? vd[-cs - 1] : 129; } else { a = ud[-cs + x]; b = vd[-cs + x]; } }
-                pu[-SC + x] = uint8_t(a); pv[-SC + x] = uint8_t(b);
-            }
-            for (int y = 0; y < 8; y++) { pu[y * SC - 1] = mx > 0 ? ud[y * cs - 1] : uint8_t(129); pv[y * SC - 1] = mx > 0 ? vd[y * cs - 1] : uint8_t(129); }
-            if (!i4) {
-                switch (ymode) {
-                case 0: pred_dc(py, S, 16, my > 0, mx > 0); break;
-                case 1: pred_tm(py, S, 16); break;
-                case 2: pred_v(py, S, 16); break;
-                default: pred_h(py, S, 16); break;
-                }
-                for (int k = 0; k < 16; k++) if (nzmask & (1u << k)) vp8_idct_add(coef + 16 * k, py + (k >> 2) * 4 * S + (k & 3) * 4, S);
-            } else {
-                for (int k = 0; k < 16; k++) {
-                    uint8_t *d = py + (k >> 2) * 4 * S + (k & 3) * 4;
-                    uint8_t tr[4];
-                    if ((k & 3) == 3) { for (int q = 0; q < 4; q++) tr[q] = py[-S + 16 + q]; }    // right column: the four samples above and right of the MACROBLOCK, whatever the row
-                    else for (int q = 0; q < 4; q++) tr[q] = d[-S + 4 + q];
-                    pred4(d, S, bmodes[k], tr);
-                    if (nzmask & (1u << k)) vp8_idct_add(coef + 16 * k, d, S);
-                }
-            }
-            for (int ch = 0; ch < 2; ch++) {
-                uint8_t *pc = ch ? pv : pu;
-                switch (uvmode) {
-                case 0: pred_dc(pc, SC, 8, my > 0, mx > 0); break;
-                case 1: pred_tm(pc, SC, 8); break;
-                case 2: pred_v(pc, SC, 8); break;
-                default: pred_h(pc, SC, 8); break;
-                }
-                for (int k = 0; k < 4; k++) if (nzmask & (1u << (16 + 4 * ch + k))) vp8_idct_add(coef + (16 + 4 * ch + k) * 16, pc + (k >> 1) * 4 * SC + (k & 1) * 4, SC);
-            }
-            // whole words out (the block sits word-aligned in the scratch, the planes are 16 / 8 samples per macroblock wide)
-            for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x += 4) *reinterpret_cast<uint32_t *>(yd + y * ys + x) = *reinterpret_cast<const uint32_t *>(py + y * S + x);
-            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x += 4) {
-                *reinterpret_cast<uint32_t *>(ud + y * cs + x) = *reinterpret_cast<const uint32_t *>(pu + y * SC + x);
-                *reinterpret_cast<uint32_t *>(vd + y * cs + x) = *reinterpret_cast<const uint32_t *>(pv + y * SC + x);
-            }
+            // what the reconstruction needs of this macroblock: its record, and the blocks that hold something (two 16-byte stores each)
+            {
+                Vp8MbRec r;
+                r.nzmask = nzmask; r.i4 = i4 ? 1 : 0; r.ymode = uint8_t(ymode); r.uvmode = uint8_t(uvmode); r.pad = 0;
+                for (int k = 0; k < 16; k++) r.bmodes[k] = bmodes[k];
+                const size_t mb = size_t(my) * mbw + mx;
+                pl.rec[mb] = r;
+                uint4 *dst = reinterpret_cast<uint4 *>(pl.mbcoef + mb * 384);
+                const uint4 *src = reinterpret_cast<const uint4 *>(coef);
+                for (int k = 0; k < 24; k++) if (nzmask & (1u << k)) { dst[2 * k] = src[2 * k]; dst[2 * k + 1] = src[2 * k + 1]; }
             }
             // the coefficient store goes back to all zeros: only blocks in nzmask hold anything
             for (int k = 0; k < 24; k++) if (nzmask & (1u << k)) for (int q = 0; q < 16; q++) coef[16 * k + q] = 0;
@@ -521,6 +483,72 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
         if (br.eof()) return 1;
     }
     return 0;
+}
+
+// the reconstruction of one macroblock from its record: intra prediction from the UNFILTERED neighbours (the loop filter runs over the finished frame
+// afterwards) + the inverse transforms of the blocks in nzmask.  Needs (mx - 1, my), (mx, my - 1), (mx - 1, my - 1) and (mx + 1, my - 1) done: the same wave
+// front as the loop filter.  `sc` is scratch for one macroblock (LDS in the kernel: the planes have no margin, so the block is predicted in a 17 x 32 patch
+// whose row above and column to the left get the neighbours -- frame edges: 127 above, 129 to the left -- and sits word-aligned at row 1, column 4).
+struct Vp8Scratch { alignas(4) uint8_t s[(16 + 1) * 32]; };
+__host__ __device__ static inline void vp8_recon_mb(uint8_t *work, uint32_t W, uint32_t H, uint32_t mx, uint32_t my, Vp8Scratch &sc) {
+    const Vp8Planes pl = vp8_planes(work, W, H);
+    const uint32_t mbw = pl.mbw;
+    const int ys = pl.ys, cs = pl.cs;
+    const size_t mb = size_t(my) * mbw + mx;
+    const Vp8MbRec r = pl.rec[mb];
+    const int16_t *coef = pl.mbcoef + mb * 384;
+    const uint32_t nzmask = r.nzmask;
+    const int S = 32;
+    uint8_t *const py = sc.s + S + 4;
+    uint8_t *yd = pl.Y + size_t(my) * 16 * ys + size_t(mx) * 16;
+    for (int x = -1; x < 20; x++) {
+        int v = 127;
+        if (my > 0) {
+            if (x < 0) v = mx > 0 ? yd[-ys - 1] : 129;
+            else if (x < 16) v = yd[-ys + x];
+            else v = mx + 1 < mbw ? yd[-ys + x] : yd[-ys + 15];
+        }
+        py[-S + x] = uint8_t(v);
+    }
+    for (int y = 0; y < 16; y++) py[y * S - 1] = mx > 0 ? yd[y * ys - 1] : uint8_t(129);
+    if (!r.i4) {
+        switch (r.ymode) {
+        case 0: pred_dc(py, S, 16, my > 0, mx > 0); break;
+        case 1: pred_tm(py, S, 16); break;
+        case 2: pred_v(py, S, 16); break;
+        default: pred_h(py, S, 16); break;
+        }
+        for (int k = 0; k < 16; k++) if (nzmask & (1u << k)) vp8_idct_add(coef + 16 * k, py + (k >> 2) * 4 * S + (k & 3) * 4, S);
+    } else {
+        for (int k = 0; k < 16; k++) {
+            uint8_t *d = py + (k >> 2) * 4 * S + (k & 3) * 4;
+            uint8_t tr[4];
+            if ((k & 3) == 3) { for (int q = 0; q < 4; q++) tr[q] = py[-S + 16 + q]; }    // right column: the four samples above and right of the MACROBLOCK, whatever the row
+            else for (int q = 0; q < 4; q++) tr[q] = d[-S + 4 + q];
+            pred4(d, S, r.bmodes[k], tr);
+            if (nzmask & (1u << k)) vp8_idct_add(coef + 16 * k, d, S);
+        }
+    }
+    // whole words out (the block sits word-aligned in the scratch, the planes are 16 / 8 samples per macroblock wide)
+    for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x += 4) *reinterpret_cast<uint32_t *>(yd + y * ys + x) = *reinterpret_cast<const uint32_t *>(py + y * S + x);
+    for (int ch = 0; ch < 2; ch++) {   // the chroma planes, one after the other in the same scratch
+        uint8_t *cd = (ch ? pl.V : pl.U) + size_t(my) * 8 * cs + size_t(mx) * 8;
+        uint8_t *pc = py;
+        for (int x = -1; x < 8; x++) {
+            int a = 127;
+            if (my > 0) a = x < 0 ? (mx > 0 ? cd[-cs - 1] : 129) : cd[-cs + x];
+            pc[-S + x] = uint8_t(a);
+        }
+        for (int y = 0; y < 8; y++) pc[y * S - 1] = mx > 0 ? cd[y * cs - 1] : uint8_t(129);
+        switch (r.uvmode) {
+        case 0: pred_dc(pc, S, 8, my > 0, mx > 0); break;
+        case 1: pred_tm(pc, S, 8); break;
+        case 2: pred_v(pc, S, 8); break;
+        default: pred_h(pc, S, 8); break;
+        }
+        for (int k = 0; k < 4; k++) if (nzmask & (1u << (16 + 4 * ch + k))) vp8_idct_add(coef + (16 + 4 * ch + k) * 16, pc + (k >> 1) * 4 * S + (k & 1) * 4, S);
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x += 4) *reinterpret_cast<uint32_t *>(cd + y * cs + x) = *reinterpret_cast<const uint32_t *>(pc + y * S + x);
+    }
 }
 
 // the loop filter of one macroblock (RFC 6386 section 15: macroblocks in raster order).  What a macroblock's filter reads and changes reaches three

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstddef>
+struct uint4 { uint32_t x, y, z, w; };
 #define __host__
 #define __device__
 #include "../caesium-clt_amd/csrc/vp8_dec.h"
