@@ -1,4 +1,4 @@
-"""Lossless PNG row on the device: `python tools/png_bench.py [files] [distinct] [width] [height] [level]` -- a batch of synthetic
+"""The PNG row on the device: `python tools/png_bench.py [files] [distinct] [width] [height] [level] [quality]` (a quality selects the lossy form, `-q` on a PNG) -- a batch of synthetic
 RGB8 PNGs (configs[2] shape by default), per-kernel device times, sizes against the input (Pillow level 6) and zlib -9."""
 import os
 import sys
@@ -18,7 +18,8 @@ level = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 api, pkg = product_api(), package()
 src = [synth_png(100 + k, w, h, "RGB", texture=float(k % 4)) for k in range(distinct)]
 blobs = [src[k % distinct] for k in range(n)]
-p = pkg.default_parameters(png_optimize=True, png_optimization_level=level)
+quality = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+p = pkg.default_parameters(png_quality=quality) if quality else pkg.default_parameters(png_optimize=True, png_optimization_level=level)
 for rep in range(2):
     t0 = time.time()
     b = api.png_batch(blobs, p)
@@ -30,7 +31,7 @@ for rep in range(2):
     names = api.png_kernel_names()
     print(f"rep {rep}: {n} files {w}x{h} level {level}: create {t1 - t0:.2f}s run {t2 - t1:.2f}s (device {tm.total_ms:.1f} ms) fetch {t3 - t2:.2f}s; "
           f"{n * w * h / 1e6 / (tm.total_ms / 1e3):.0f} MP/s, {n / (tm.total_ms / 1e3):.1f} files/s")
-    print("   " + ", ".join(f"{names[i]} {tm.kernel_ms[i]:.1f}" for i in range(11)))
+    print("   " + ", ".join(f"{names[i]} {tm.kernel_ms[i]:.1f}" for i in range(len(names)) if names[i] and tm.kernel_ms[i] > 0.05))
     tr = b.trials(0)
     b.close()
 print("sizes: input", [len(s) for s in src], "output", [len(outs[k]) for k in range(distinct)], "trials of file 0", tr)
