@@ -197,17 +197,47 @@ __global__ void __launch_bounds__(256) k_png_rgb(const RgbJob *jobs, const uint8
     }
 }
 // ---- lossy PNG: colour bins
+// colour bins of an image: count and channel sums per bin.  A workgroup takes QH_ROWS rows and gathers them in an LDS table first (neighbouring pixels share
+// bins: a 1080p photograph's row touches a few hundred): five global atomics per DISTINCT bin of the rows instead of five per pixel (88 ms per 96
+// 1080p files before).  A pixel that finds no slot within QH_PROBES steps goes to the global bins directly; all sums are integers, so neither the slot a bin lands in
+// nor the order of the additions shows in the result.
+enum { QH_ROWS = 8, QH_SLOTS = 2048, QH_PROBES = 16 };
 __global__ void __launch_bounds__(256) k_png_qhist(const QuantJob *jobs, const uint8_t *work, uint32_t *bins) {
+    CSH_SHARED uint32_t s_key[QH_SLOTS];
+    CSH_SHARED uint32_t s_val[QH_SLOTS][5];
     const QuantJob j = jobs[blockIdx.y];
-    const uint32_t y = blockIdx.x;
-    if (y >= j.height) return;
-    const uint8_t *r = work + j.src_off + uint64_t(y) * j.rowbytes;
+    const uint32_t y0 = blockIdx.x * QH_ROWS;
     uint32_t *b = bins + j.bins_off;
-    for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
-        const uint32_t key = pixel_key(r + uint64_t(x) * j.channels * j.bps, j.channels, j.bps);
-        const uint32_t a = key >> 24, rr = (key >> 16) & 255u, g = (key >> 8) & 255u, bb = key & 255u;
-        uint32_t *q = b + uint64_t(((a >> 4) << 15) | ((rr >> 3) << 10) | ((g >> 3) << 5) | (bb >> 3)) * 5;
-        atomicAdd(&q[0], 1u); atomicAdd(&q[1], rr); atomicAdd(&q[2], g); atomicAdd(&q[3], bb); atomicAdd(&q[4], a);
+    CSH_PHASE_LOOP(3) {
+        if (y0 >= j.height) continue;
+        if (phase == 0) {
+            for (uint32_t k = threadIdx.x; k < QH_SLOTS; k += blockDim.x) { s_key[k] = 0xFFFFFFFFu; for (int c = 0; c < 5; c++) s_val[k][c] = 0; }
+            continue;
+        }
+        if (phase == 1) {
+            for (uint32_t y = y0; y < y0 + QH_ROWS && y < j.height; y++) {
+                const uint8_t *r = work + j.src_off + uint64_t(y) * j.rowbytes;
+                for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
+                    const uint32_t key = pixel_key(r + uint64_t(x) * j.channels * j.bps, j.channels, j.bps);
+                    const uint32_t a = key >> 24, rr = (key >> 16) & 255u, g = (key >> 8) & 255u, bb = key & 255u;
+                    const uint32_t id = ((a >> 4) << 15) | ((rr >> 3) << 10) | ((g >> 3) << 5) | (bb >> 3);
+                    uint32_t h = (id * 2654435761u) >> 21;
+                    int probes = 0;
+                    for (; probes < QH_PROBES; probes++, h = (h + 1u) & (QH_SLOTS - 1u)) {
+                        const uint32_t seen = atomicCAS(&s_key[h], 0xFFFFFFFFu, id);
+                        if (seen == 0xFFFFFFFFu || seen == id) break;
+                    }
+                    if (probes < QH_PROBES) { uint32_t *q = s_val[h]; atomicAdd(&q[0], 1u); atomicAdd(&q[1], rr); atomicAdd(&q[2], g); atomicAdd(&q[3], bb); atomicAdd(&q[4], a); }
+                    else { uint32_t *q = b + uint64_t(id) * 5; atomicAdd(&q[0], 1u); atomicAdd(&q[1], rr); atomicAdd(&q[2], g); atomicAdd(&q[3], bb); atomicAdd(&q[4], a); }
+                }
+            }
+            continue;
+        }
+        for (uint32_t k = threadIdx.x; k < QH_SLOTS; k += blockDim.x) {
+            if (s_key[k] == 0xFFFFFFFFu) continue;
+            uint32_t *q = b + uint64_t(s_key[k]) * 5;
+            for (int c = 0; c < 5; c++) atomicAdd(&q[c], s_val[k][c]);
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_png_qcompact(const QuantJob *jobs, const uint32_t *bins, QBin *list, uint32_t *nlist) {
@@ -219,6 +249,240 @@ __global__ void __launch_bounds__(256) k_png_qcompact(const QuantJob *jobs, cons
     const uint32_t slot = atomicAdd(&nlist[blockIdx.y], 1u);
     QBin o; o.id = i; o.cnt = q[0]; o.s[0] = q[1]; o.s[1] = q[2]; o.s[2] = q[3]; o.s[3] = q[4];
     list[j.list_off + slot] = o;
+}
+// ---- lossy PNG: the median cut over the colour bins of one image (oracle: median_cut), one workgroup per image.
+// A box is a set of bins: a contiguous range of an index array (the order inside does not matter).  A split = the most populous live box, its widest channel
+// (of the bin means), and the weighted median of the box's bins in the order (mean on that channel, bin id): the lower part ends with the bin at which it
+// first holds half the box's pixels (never with the box's last bin).  No sort: the 256-level histogram of the channel finds the level the median falls
+// in, a histogram over 1024 ranges of bin ids inside that level the range, and the range's 512 ids are slots of their own -- three counting passes; the
+// split then moves the box's indices into the other index array, lower part from the front, upper part from the back.  Every step is a pass of all
+// lanes over the BOX's bins (so the 255 splits together visit each bin about ten times, not 255 times) between decisions that a prefix per lane takes
+// (lane l sums the entries up to l; the one lane at which the sum crosses half the box writes the answer).  All sums are integers: the order of the
+// atomics does not matter, nor does the order of the bin list.  The cut stops at 256 boxes, when nothing can be split, or -- imagequant's
+// set_quality(0, q) -- when the squared error of the bin means against the rounded box means is within the bound of the quality.
+// Phases: 5 of set-up (0..4), then MC_STEP per iteration (a split, or the retirement of a box whose bins all share one mean), at most 255 + 256 iterations.
+enum { MC_LANES = 1024, MC_STEP = 14, MC_ITER = 511, MC_PHASES = 5 + MC_STEP * MC_ITER };
+static_assert(CSP_QBINS == 1024 * 512, "the id ranges of the median search");
+struct McRec { uint32_t mean, cnt, id, pad; };            // a bin as the passes read it: its four channel means in one word, its pixels, its id
+struct McLds {
+    unsigned long long cnt[256], err[256], sum[256][4];   // per box: pixels, error, channel sums
+    uint32_t lo[256], hi[256];                            // per box: its range of the index array ...
+    uint32_t buf[256];                                    // ... and which of the two arrays holds it
+    uint32_t dead[256];
+    unsigned long long lev[256];                          // pixels per level of the axis, in the picked box
+    unsigned long long rng[1024];                         // ... per range of 512 bin ids, inside the median's level
+    unsigned long long slot[512];                         // ... per bin id, inside the median's range
+    unsigned long long psum[2][4], pcnt[2], perr[2];      // the two parts of a split
+    uint32_t pnb[2], pmean[2][4];
+    uint32_t mn[4], mx[4];
+    unsigned long long total, total_err;
+    unsigned long long below;                             // pixels in front of the level / range being searched
+    unsigned long long best;                              // the picked box's pixels
+    int nbox, pick, axis, cut, done, skip;                // cut: the median's level
+    int range, cut_id, cut_incl, last_slot;               // the median's id range; the lower part ends with bin cut_id (cut_incl) or just in front of it
+};
+__global__ void __launch_bounds__(MC_LANES) k_png_mediancut(const QuantJob *jobs, const QBin *list, const uint32_t *nlist, uint4 *recs, uint32_t *order, uint64_t order_stride, int quality,
+                                                          unsigned long long bound, uint32_t *pal_out, uint32_t *npal_out) {
+    CSH_SHARED McLds L;
+    const QuantJob j = jobs[blockIdx.x];
+    const uint32_t n = nlist[blockIdx.x], tid = threadIdx.x;
+    const QBin *bins = list + j.list_off;
+    McRec *rec = reinterpret_cast<McRec *>(recs + j.list_off);
+    uint32_t *ord[2] = {order + j.list_off, order + order_stride + j.list_off};
+    auto mean_of = [&](uint32_t m, int c) -> uint32_t { return (m >> (8 * c)) & 255u; };
+    // a bin's error in a part: its mean against the part's rounded mean
+    auto error_of = [&](int part, const McRec &r) {
+        unsigned long long d2 = 0;
+        for (int c = 0; c < 4; c++) { const long long d = (long long)mean_of(r.mean, c) - (long long)L.pmean[part][c]; d2 += (unsigned long long)(d * d); }
+        return d2 * r.cnt;
+    };
+    CSH_PHASE_LOOP(MC_PHASES + 1) {
+        if (phase == 0) {
+            if (tid < 256) { L.cnt[tid] = 0; L.err[tid] = 0; L.lo[tid] = 0; L.hi[tid] = 0; L.buf[tid] = 0; L.dead[tid] = 0; for (int c = 0; c < 4; c++) L.sum[tid][c] = 0; }
+            if (tid == 0) { L.nbox = 1; L.done = n == 0 ? 1 : 0; L.skip = 0; L.perr[0] = L.perr[1] = 0; }
+            continue;
+        }
+        if (phase == 1) {   // the bins as records; box 0 = everything
+            unsigned long long c0 = 0, s0[4] = {0, 0, 0, 0};
+            for (uint32_t i = tid; i < n; i += MC_LANES) {
+                const QBin q = bins[i];
+                McRec r;
+                r.mean = (q.s[0] / q.cnt) | ((q.s[1] / q.cnt) << 8) | ((q.s[2] / q.cnt) << 16) | ((q.s[3] / q.cnt) << 24); r.cnt = q.cnt; r.id = q.id; r.pad = 0;
+                rec[i] = r;
+                ord[0][i] = i;
+                c0 += q.cnt; for (int c = 0; c < 4; c++) s0[c] += q.s[c];
+            }
+            if (c0) { atomicAdd(&L.cnt[0], c0); for (int c = 0; c < 4; c++) atomicAdd(&L.sum[0][c], s0[c]); }
+            continue;
+        }
+        if (phase == 2) {
+            if (tid == 0 && n) { L.hi[0] = n; L.total = L.cnt[0]; for (int c = 0; c < 4; c++) L.pmean[0][c] = uint32_t((2 * L.sum[0][c] + L.cnt[0]) / (2 * L.cnt[0])); }
+            continue;
+        }
+        if (phase == 3) {
+            unsigned long long e = 0;
+            for (uint32_t i = tid; i < n; i += MC_LANES) e += error_of(0, rec[i]);
+            if (e) atomicAdd(&L.perr[0], e);
+            continue;
+        }
+        if (phase == 4) { if (tid == 0) { L.err[0] = L.perr[0]; L.total_err = L.perr[0]; L.best = 0; L.pick = -1; } continue; }
+        if (phase == MC_PHASES) {   // palette entries (unsorted: the host sorts them and merges equal ones)
+            if (tid < 256) {
+                uint32_t v = 0;
+                if (int(tid) < L.nbox && n) {
+                    uint32_t m[4];
+                    for (int c = 0; c < 4; c++) m[c] = uint32_t((2 * L.sum[tid][c] + L.cnt[tid]) / (2 * L.cnt[tid]));
+                    v = (m[3] << 24) | (m[0] << 16) | (m[1] << 8) | m[2];
+                }
+                pal_out[blockIdx.x * 256 + tid] = v;
+            }
+            if (tid == 0) npal_out[blockIdx.x] = n ? uint32_t(L.nbox) : 0u;
+            continue;
+        }
+        if (L.done) continue;
+        const int sub = (phase - 5) % MC_STEP;
+        if (sub == 0) {          // good enough?  otherwise the most populous box that can be split (the first of equals): every box bids its pixels
+            if (tid < 256) L.lev[tid] = 0;
+            L.rng[tid] = 0;
+            if (tid < 512) L.slot[tid] = 0;
+            if (tid < 4) { L.mn[tid] = 255; L.mx[tid] = 0; }
+            const int q = quality < 0 ? 0 : quality > 100 ? 100 : quality;
+            const bool enough = L.nbox >= 256 || (L.nbox >= 2 && (q == 0 || L.total_err * 1024ull <= bound * L.total));
+            if (tid == 0) { L.skip = 0; L.pick = -1; L.best = 0; if (enough) L.done = 1; }
+            continue;
+        }
+        if (sub == 1) {          // (the bids: a box that can be split has pixels, so 0 means none)
+            if (int(tid) < L.nbox && !L.dead[tid] && L.hi[tid] - L.lo[tid] > 1) atomicMax(&L.best, L.cnt[tid]);
+            continue;
+        }
+        if (sub == 2) {          // the first box with that many pixels
+            if (int(tid) < L.nbox && !L.dead[tid] && L.hi[tid] - L.lo[tid] > 1 && L.cnt[tid] == L.best) {
+                bool first = true;
+                for (int k = 0; k < int(tid); k++) if (!L.dead[k] && L.hi[k] - L.lo[k] > 1 && L.cnt[k] == L.best) { first = false; break; }
+                if (first) L.pick = int(tid);
+            }
+            continue;
+        }
+        const int pick = L.pick;
+        if (pick < 0) { if (tid == 0) L.done = 1; continue; }
+        if (L.skip) continue;
+        const uint32_t lo = L.lo[pick], hi = L.hi[pick];
+        const uint32_t *src = ord[L.buf[pick]];
+        if (sub == 3) {          // the box's extent in every channel
+            uint32_t mn[4] = {255, 255, 255, 255}, mx[4] = {0, 0, 0, 0};
+            bool any = false;
+            for (uint32_t k = lo + tid; k < hi; k += MC_LANES) {
+                const uint32_t m = rec[src[k]].mean;
+                any = true;
+                for (int c = 0; c < 4; c++) { const uint32_t v = mean_of(m, c); mn[c] = min(mn[c], v); mx[c] = max(mx[c], v); }
+            }
+            if (any) for (int c = 0; c < 4; c++) { atomicMin(&L.mn[c], mn[c]); atomicMax(&L.mx[c], mx[c]); }
+            continue;
+        }
+        if (sub == 4) {          // the widest channel (the first of equals); a box of one colour is retired
+            if (tid == 0) {
+                int axis = 0, range = -1;
+                for (int c = 0; c < 4; c++) if (int(L.mx[c]) - int(L.mn[c]) > range) { range = int(L.mx[c]) - int(L.mn[c]); axis = c; }
+                L.axis = axis;
+                if (range == 0) { L.dead[pick] = 1; L.skip = 1; }
+            }
+            continue;
+        }
+        const int axis = L.axis;
+        if (sub == 5) {          // pixels per level of that channel
+            for (uint32_t k = lo + tid; k < hi; k += MC_LANES) { const McRec r = rec[src[k]]; atomicAdd(&L.lev[mean_of(r.mean, axis)], (unsigned long long)r.cnt); }
+            continue;
+        }
+        const unsigned long long half = L.cnt[pick];   // compared with twice a running sum
+        if (sub == 6) {          // the level the median falls in: the first at which the lower levels + this one hold half the box's pixels
+            if (tid < 256 && L.lev[tid]) {
+                unsigned long long run = 0;
+                for (uint32_t l = 0; l < tid; l++) run += L.lev[l];
+                if (2 * run < half && 2 * (run + L.lev[tid]) >= half) { L.cut = int(tid); L.below = run; }
+            }
+            continue;
+        }
+        const int cut = L.cut;
+        if (sub == 7) {          // inside that level: pixels per range of bin ids
+            for (uint32_t k = lo + tid; k < hi; k += MC_LANES) { const McRec r = rec[src[k]]; if (int(mean_of(r.mean, axis)) == cut) atomicAdd(&L.rng[r.id >> 9], (unsigned long long)r.cnt); }
+            continue;
+        }
+        if (sub == 8) {
+            if (L.rng[tid]) {
+                unsigned long long run = L.below;
+                for (uint32_t r = 0; r < tid; r++) run += L.rng[r];
+                if (2 * run < half && 2 * (run + L.rng[tid]) >= half) { L.range = int(tid); L.below = run; }
+            }
+            continue;
+        }
+        if (sub == 9) {          // inside that range: every bin id is a slot
+            const uint32_t rg = uint32_t(L.range);
+            for (uint32_t k = lo + tid; k < hi; k += MC_LANES) { const McRec r = rec[src[k]]; if (int(mean_of(r.mean, axis)) == cut && (r.id >> 9) == rg) L.slot[r.id & 511u] = r.cnt; }
+            if (tid == 0) L.last_slot = -1;
+            continue;
+        }
+        if (sub == 10) {         // the bin the lower part ends with -- or, if that is the box's last bin, ends in front of
+            if (tid < 512 && L.slot[tid]) {
+                unsigned long long run = L.below;
+                for (uint32_t k = 0; k < tid; k++) run += L.slot[k];
+                if (2 * run < half && 2 * (run + L.slot[tid]) >= half) {
+                    bool is_last = true;                       // of the range; of the box if nothing lies behind the range and the level either
+                    for (uint32_t k = tid + 1; k < 512 && is_last; k++) if (L.slot[k]) is_last = false;
+                    for (int r = L.range + 1; r < 1024 && is_last; r++) if (L.rng[r]) is_last = false;
+                    for (int l = cut + 1; l < 256 && is_last; l++) if (L.lev[l]) is_last = false;
+                    L.cut_id = L.range * 512 + int(tid); L.cut_incl = is_last ? 0 : 1;
+                }
+            }
+            if (tid == 0) for (int p = 0; p < 2; p++) { L.pcnt[p] = 0; L.perr[p] = 0; L.pnb[p] = 0; for (int c = 0; c < 4; c++) L.psum[p][c] = 0; }
+            continue;
+        }
+        uint32_t *dst = ord[L.buf[pick] ^ 1u];
+        if (sub == 11) {         // the split: indices into the other array (lower part from the front of the range, upper part from its back); both parts' sums
+            const uint32_t cut_id = uint32_t(L.cut_id), incl = uint32_t(L.cut_incl);
+            unsigned long long pc[2] = {0, 0}, ps[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            for (uint32_t k = lo + tid; k < hi; k += MC_LANES) {
+                const uint32_t i = src[k];
+                const McRec r = rec[i];
+                const int lv = int(mean_of(r.mean, axis));
+                const int part = (lv > cut || (lv == cut && (incl ? r.id > cut_id : r.id >= cut_id))) ? 1 : 0;
+                const uint32_t at = atomicAdd(&L.pnb[part], 1u);
+                dst[part ? hi - 1 - at : lo + at] = i;
+                const QBin q = bins[i];
+                pc[part] += q.cnt;
+                for (int c = 0; c < 4; c++) ps[part][c] += q.s[c];
+            }
+            for (int p = 0; p < 2; p++) if (pc[p]) { atomicAdd(&L.pcnt[p], pc[p]); for (int c = 0; c < 4; c++) atomicAdd(&L.psum[p][c], ps[p][c]); }
+            continue;
+        }
+        if (sub == 12) {         // both parts' errors (every lane works the parts' rounded means out for itself from the finished sums)
+            uint32_t pm[2][4];
+            for (int p = 0; p < 2; p++) for (int c = 0; c < 4; c++) pm[p][c] = uint32_t((2 * L.psum[p][c] + L.pcnt[p]) / (2 * L.pcnt[p]));
+            const uint32_t nl = L.pnb[0];
+            unsigned long long e[2] = {0, 0};
+            for (uint32_t k = lo + tid; k < hi; k += MC_LANES) {
+                const McRec r = rec[dst[k]];
+                const int part = k - lo < nl ? 0 : 1;
+                unsigned long long d2 = 0;
+                for (int c = 0; c < 4; c++) { const long long d = (long long)mean_of(r.mean, c) - (long long)pm[part][c]; d2 += (unsigned long long)(d * d); }
+                e[part] += d2 * r.cnt;
+            }
+            for (int p = 0; p < 2; p++) if (e[p]) atomicAdd(&L.perr[p], e[p]);
+            continue;
+        }
+        if (tid == 0) {          // sub == 13: the box table
+            const int nbox = L.nbox;
+            const uint32_t mid = lo + L.pnb[0], nb = L.buf[pick] ^ 1u;
+            L.total_err = L.total_err - L.err[pick] + L.perr[0] + L.perr[1];
+            L.cnt[pick] = L.pcnt[0]; L.err[pick] = L.perr[0]; L.hi[pick] = mid; L.buf[pick] = nb;
+            L.cnt[nbox] = L.pcnt[1]; L.err[nbox] = L.perr[1]; L.lo[nbox] = mid; L.hi[nbox] = hi; L.buf[nbox] = nb;
+            for (int c = 0; c < 4; c++) { L.sum[pick][c] = L.psum[0][c]; L.sum[nbox][c] = L.psum[1][c]; }
+            L.nbox = nbox + 1;
+        }
+    }
+}
+void launch_png_mediancut(hipStream_t st, const QuantJob *jobs, int njobs, const QBin *list, const uint32_t *nlist, uint4 *recs, uint32_t *order, uint64_t order_stride, int quality,
+                          unsigned long long bound, uint32_t *pal, uint32_t *npal) {
+    if (njobs) CSH_LAUNCH_PHASED(k_png_mediancut, MC_PHASES + 1, dim3(unsigned(njobs)), dim3(MC_LANES), st, jobs, list, nlist, recs, order, order_stride, quality, bound, pal, npal);
 }
 void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys,
                        uint32_t *counts, const uint32_t *status) {
@@ -232,7 +496,7 @@ void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_
     if (njobs) CSH_LAUNCH(k_png_rgb, dim3(max_height, njobs), dim3(256), st, jobs, plte, work, rgb, status);
 }
 void launch_png_qhist(hipStream_t st, const QuantJob *jobs, int njobs, uint32_t max_height, const uint8_t *work, uint32_t *bins) {
-    if (njobs) CSH_LAUNCH(k_png_qhist, dim3(max_height, njobs), dim3(256), st, jobs, work, bins);
+    if (njobs) CSH_LAUNCH_PHASED(k_png_qhist, 3, dim3((max_height + QH_ROWS - 1) / QH_ROWS, njobs), dim3(256), st, jobs, work, bins);
 }
 void launch_png_qcompact(hipStream_t st, const QuantJob *jobs, int njobs, const uint32_t *bins, QBin *list, uint32_t *nlist) {
     if (njobs) CSH_LAUNCH(k_png_qcompact, dim3(CSP_QBINS / 256, njobs), dim3(256), st, jobs, bins, list, nlist);

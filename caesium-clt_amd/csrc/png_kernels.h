@@ -54,6 +54,10 @@ struct QBin { uint32_t id, cnt, s[4]; };
 struct QuantJob { uint32_t image, channels, bps, rowbytes, width, height; uint64_t src_off, bins_off, list_off; };   // bins_off: in uint32 units (5 per bin); list_off: in QBin units
 void launch_png_qhist(hipStream_t st, const QuantJob *jobs, int njobs, uint32_t max_height, const uint8_t *work, uint32_t *bins);
 void launch_png_qcompact(hipStream_t st, const QuantJob *jobs, int njobs, const uint32_t *bins, QBin *list, uint32_t *nlist);
+// the median cut of every job's bin list: pal[job][256] (unsorted, equal entries possible), npal[job]; scratch: recs (one 16-byte entry per list
+// element), order (two arrays of one uint32 per list element, order_stride apart)
+void launch_png_mediancut(hipStream_t st, const QuantJob *jobs, int njobs, const QBin *list, const uint32_t *nlist, uint4 *recs, uint32_t *order, uint64_t order_stride, int quality,
+                          unsigned long long bound, uint32_t *pal, uint32_t *npal);
 
 // P3: row-filter search (k_png_filter.hip)
 struct FilterCtx {

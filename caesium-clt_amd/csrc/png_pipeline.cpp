@@ -203,70 +203,6 @@ struct csp_batch {
 extern "C" const char *csp_kernel_name(int i) { return (i >= 0 && i < CSP_NKERNELS) ? kPngKernelNames[i] : ""; }
 extern "C" void csp_batch_destroy(csp_batch *b) { delete b; }
 
-// lossy PNG: the median cut over the colour bins of one image (oracle: median_cut).  bins must be sorted by id.  Returns the palette
-// (keys a, r, g, b; sorted, duplicates merged).
-static std::vector<uint32_t> median_cut(const std::vector<QBin> &bins, int quality) {
-    const int nbins = int(bins.size());
-    std::vector<int> ord(nbins);
-    for (int i = 0; i < nbins; i++) ord[i] = i;
-    struct Box { int lo, hi; uint64_t cnt; bool dead; };
-    std::vector<Box> box;
-    uint64_t total = 0;
-    for (auto &q : bins) total += q.cnt;
-    box.push_back(Box{0, nbins, total, false});
-    auto mean = [&](int bin, int c) { return int(bins[bin].s[c] / bins[bin].cnt); };
-    // error of the palette entry a box would give: every bin mean against the rounded box mean (oracle: box_error)
-    auto box_error = [&](const Box &bx) {
-        uint64_t sum[4] = {0, 0, 0, 0}, cnt = 0, err = 0;
-        for (int i = bx.lo; i < bx.hi; i++) { const QBin &q = bins[ord[i]]; cnt += q.cnt; for (int c = 0; c < 4; c++) sum[c] += q.s[c]; }
-        for (int i = bx.lo; i < bx.hi; i++) {
-            uint64_t d2 = 0;
-            for (int c = 0; c < 4; c++) { const int64_t d = int64_t(mean(ord[i], c)) - int64_t((2 * sum[c] + cnt) / (2 * cnt)); d2 += uint64_t(d * d); }
-            err += d2 * bins[ord[i]].cnt;
-        }
-        return err;
-    };
-    std::vector<uint64_t> berr(1, nbins ? box_error(box[0]) : 0);
-    uint64_t total_err = berr[0];
-    quality = quality < 0 ? 0 : quality > 100 ? 100 : quality;
-    while (box.size() < 256) {
-        if (box.size() >= 2 && (quality == 0 || total_err * 1024 <= kQualityBound[quality] * total)) break;   // good enough for this -q
-        int pick = -1;
-        for (int k = 0; k < int(box.size()); k++) if (!box[k].dead && box[k].hi - box[k].lo > 1 && (pick < 0 || box[k].cnt > box[pick].cnt)) pick = k;
-        if (pick < 0) break;
-        int axis = 0, range = -1;
-        for (int c = 0; c < 4; c++) {
-            int mn = 255, mx = 0;
-            for (int i = box[pick].lo; i < box[pick].hi; i++) { const int m = mean(ord[i], c); mn = std::min(mn, m); mx = std::max(mx, m); }
-            if (mx - mn > range) { range = mx - mn; axis = c; }
-        }
-        if (range == 0) { box[pick].dead = true; continue; }
-        std::sort(ord.begin() + box[pick].lo, ord.begin() + box[pick].hi, [&](int x, int y) {
-            const int mx = mean(x, axis), my = mean(y, axis);
-            return mx != my ? mx < my : bins[x].id < bins[y].id;
-        });
-        uint64_t cum = 0;
-        int sp = box[pick].lo;
-        while (sp < box[pick].hi - 1) { cum += bins[ord[sp]].cnt; sp++; if (2 * cum >= box[pick].cnt) break; }
-        box.push_back(Box{sp, box[pick].hi, box[pick].cnt - cum, false});
-        box[pick].hi = sp; box[pick].cnt = cum;
-        total_err -= berr[pick];
-        berr[pick] = box_error(box[pick]); berr.push_back(box_error(box.back()));
-        total_err += berr[pick] + berr.back();
-    }
-    std::vector<uint32_t> pal;
-    for (auto &bx : box) {
-        uint64_t sum[4] = {0, 0, 0, 0}, cnt = 0;
-        for (int i = bx.lo; i < bx.hi; i++) { const QBin &q = bins[ord[i]]; cnt += q.cnt; for (int c = 0; c < 4; c++) sum[c] += q.s[c]; }
-        uint32_t v[4];
-        for (int c = 0; c < 4; c++) v[c] = uint32_t((2 * sum[c] + cnt) / (2 * cnt));
-        pal.push_back((v[3] << 24) | (v[0] << 16) | (v[1] << 8) | v[2]);
-    }
-    std::sort(pal.begin(), pal.end());
-    pal.erase(std::unique(pal.begin(), pal.end()), pal.end());
-    return pal;
-}
-
 // (re)build the per-chunk / per-group index arrays from the current geometry of the images
 static int upload_chunk_index(csp_batch *b) {
     const int nimg = int(b->imgs.size());
@@ -518,8 +454,8 @@ static int reduce_step(csp_batch *b) {
     }
     std::vector<size_t> item_of(nimg, 0);
     for (size_t n = 0; n < b->items.size(); n++) if (b->items[n].image >= 0) item_of[b->items[n].image] = n;
-    // lossy: truecolour images that keep more than 256 colours after the lossless reductions get their colour bins counted, and the
-    // host runs the median cut on the non-empty bins (a second round trip, only for such images)
+    // lossy: truecolour images that keep more than 256 colours after the lossless reductions get their colour bins counted and compacted, and a
+    // workgroup per image runs the median cut over the non-empty bins (a second round trip for the <= 256 palette entries, only for such images)
     std::map<int, std::vector<uint32_t>> qpal;
     if (b->lossy) {
         std::vector<QuantJob> qjobs;
@@ -544,26 +480,21 @@ static int reduce_step(csp_batch *b) {
             if (b->d_qbins.alloc(gn * size_t(CSP_QBINS) * 5) || b->d_qbins.zero(st) || b->d_qlist.alloc(lt + 1) || b->d_qn.alloc(gn + 1) || b->d_qn.zero(st) || b->d_qjobs.upload(part, st)) return -1;
             launch_png_qhist(st, b->d_qjobs.p, int(gn), qmax_h, b->d_work.p, b->d_qbins.p);
             launch_png_qcompact(st, b->d_qjobs.p, int(gn), b->d_qbins.p, b->d_qlist.p, b->d_qn.p);
-            std::vector<uint32_t> qn(gn);
-            if (hipMemcpyAsync(qn.data(), b->d_qn.p, sizeof(uint32_t) * gn, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-            std::vector<std::vector<QBin>> lists(gn);
-            for (size_t k = 0; k < gn; k++) {
-                lists[k].resize(qn[k]);
-                if (qn[k] && csh_copy_wait(lists[k].data(), b->d_qlist.p + part[k].list_off, sizeof(QBin) * qn[k], hipMemcpyDeviceToHost, b->stream) != hipSuccess) return -1;
-            }
-            // the cuts of different images are independent: host threads (a 4K photograph has ~10^5 bins, tens of milliseconds each)
+            // the median cut of every image's list, one workgroup each (k_png_mediancut); the host only sorts the <= 256 entries and merges equal ones
+            DevBuf<uint32_t> d_qord, d_cutpal, d_ncut;
+            DevBuf<uint4> d_qrec;
+            if (d_qrec.alloc(lt + 1) || d_qord.alloc(2 * (lt + 1)) || d_cutpal.alloc(gn * 256) || d_ncut.alloc(gn)) return -1;
+            const int q = b->png_quality < 0 ? 0 : b->png_quality > 100 ? 100 : b->png_quality;
+            launch_png_mediancut(st, b->d_qjobs.p, int(gn), b->d_qlist.p, b->d_qn.p, d_qrec.p, d_qord.p, lt + 1, q, kQualityBound[q], d_cutpal.p, d_ncut.p);
+            std::vector<uint32_t> cutpal(gn * 256), ncut(gn);
+            if (csh_copy_wait(cutpal.data(), d_cutpal.p, sizeof(uint32_t) * gn * 256, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                csh_copy_wait(ncut.data(), d_ncut.p, sizeof(uint32_t) * gn, hipMemcpyDeviceToHost, st) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
             std::vector<std::vector<uint32_t>> cut(gn);
-            std::atomic<size_t> next{0};
-            auto worker = [&]() {
-                for (size_t k; (k = next++) < gn;) {
-                    std::sort(lists[k].begin(), lists[k].end(), [](const QBin &x, const QBin &y) { return x.id < y.id; });
-                    cut[k] = median_cut(lists[k], b->png_quality);
-                }
-            };
-            std::vector<std::thread> pool;
-            for (size_t t = 1; t < std::min<size_t>(gn, std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()))); t++) pool.emplace_back(worker);
-            worker();
-            for (auto &t : pool) t.join();
+            for (size_t k = 0; k < gn; k++) {
+                cut[k].assign(cutpal.begin() + k * 256, cutpal.begin() + k * 256 + std::min<uint32_t>(ncut[k], 256));
+                std::sort(cut[k].begin(), cut[k].end());
+                cut[k].erase(std::unique(cut[k].begin(), cut[k].end()), cut[k].end());
+            }
             for (size_t k = 0; k < gn; k++) qpal[int(part[k].image)] = std::move(cut[k]);
         }
     }

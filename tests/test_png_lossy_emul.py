@@ -45,6 +45,35 @@ def test_lossy_equals_oracle(api):
     check_lossy(api, lossy_cases())
 
 
+def lattice_png(seed, w, h, alpha=False):
+    """pixels on a coarse lattice of colours with a little noise in the low bits: every colour bin of a lattice point has the same mean on every channel,
+    so each split of the median cut falls inside a run of bins with EQUAL keys (the order by bin id decides) -- and more than 256 distinct pixels"""
+    rng = np.random.default_rng(seed)
+    ch = 4 if alpha else 3
+    base = rng.choice(np.array([0, 64, 128, 192, 248], np.uint8), size=(h, w, ch))
+    if alpha:
+        base[:, :, 3] = rng.choice(np.array([0, 128, 255], np.uint8), size=(h, w))
+    px = base + rng.integers(0, 4, size=(h, w, ch), dtype=np.uint8) * (base < 250)
+    b = io.BytesIO()
+    PIL.fromarray(px.astype(np.uint8), "RGBA" if alpha else "RGB").save(b, format="PNG")
+    return b.getvalue()
+
+
+def test_median_falls_among_equal_keys(api):
+    """the weighted median inside runs of bins that tie on the cut channel (three counting passes on the device, a sort in the oracle), down to boxes of two
+    bins, at a quality that keeps splitting and at one that stops early"""
+    pkg = package()
+    cases = [("lattice_rgb", lattice_png(5, 96, 64)), ("lattice_rgba", lattice_png(6, 80, 50, alpha=True)), ("lattice_small", lattice_png(7, 24, 16))]
+    noise = io.BytesIO()   # white noise, 400 pixels wide: eight rows hold more distinct colour bins than the histogram kernel's LDS table has slots (its direct path)
+    PIL.fromarray(np.random.default_rng(8).integers(0, 256, size=(24, 400, 3), dtype=np.uint8), "RGB").save(noise, format="PNG")
+    cases.append(("noise", noise.getvalue()))
+    for quality in (100, 40):
+        outs = api.cs_batch_compress([c[1] for c in cases], pkg.default_parameters(png_optimize=False, png_optimization_level=2, png_quality=quality))
+        for (name, src), out in zip(cases, outs):
+            assert not isinstance(out, Exception), (name, out)
+            assert out == oracle_png_lossy(src, 2, quality=quality), (name, quality)
+
+
 def test_quality_sets_the_palette_size(api):
     """-q is imagequant's quality: the fewest colours whose error is within the bound of that quality; lower -q, fewer colours, smaller file"""
     cases = [c for c in lossy_cases() if c[0] in ("RGB_200x150_3chunks", "RGBA_soft_alpha", "RGB_97x61")]

@@ -17,7 +17,12 @@ def api():
 def test_lossy_equals_oracle(api):
     check_lossy(api, lossy_cases(big=True))
     check_lossy(api, lossy_cases()[:4], level=0)
-    check_lossy(api, lossy_cases()[:6], level=1, quality=30)   # fewer colours: the cut stops at the bound of that quality (host decision)
+    check_lossy(api, lossy_cases()[:6], level=1, quality=30)   # fewer colours: the cut stops at the bound of that quality (k_png_mediancut)
+
+
+def test_median_falls_among_equal_keys(api):
+    from test_png_lossy_emul import test_median_falls_among_equal_keys as body
+    body(api)
 
 
 def test_max_size_on_png_files(api):
