@@ -47,8 +47,8 @@ void launch_png_resize(hipStream_t st, const PngResize *jobs, int njobs, const c
 struct RgbJob { uint32_t image, width, height, rowbytes, ctype, depth, plte_off, npal, out_nc, trns_off, ntrns, pad_; uint64_t src_off, dst_off; };
 void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_height, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status);
 
-// lossy PNG (oracle: quantize): colour bins of 4 + 5 + 5 + 5 bits (a, r, g, b) with count and channel sums, compacted to a list the
-// host runs the median cut on
+// lossy PNG (oracle: quantize): colour bins of 4 + 5 + 5 + 5 bits (a, r, g, b) with count and channel sums, compacted to a list
+// k_png_mediancut works on
 enum { CSP_QBINS = 1 << 19 };
 struct QBin { uint32_t id, cnt, s[4]; };
 struct QuantJob { uint32_t image, channels, bps, rowbytes, width, height; uint64_t src_off, bins_off, list_off; };   // bins_off: in uint32 units (5 per bin); list_off: in QBin units
