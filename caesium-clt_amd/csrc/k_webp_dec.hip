@@ -7,65 +7,128 @@
 
 namespace csw {
 
-// One workgroup per picture, in phases: (0) lane 0 walks the serial part -- a lossless picture altogether (vp8l_dec.h), a lossy frame's parse
-// (vp8_parse_frame: modes and coefficients into per-macroblock records) --; (1 .. nsteps) the reconstruction and (nsteps + 1 .. 2 nsteps) the loop filter,
-// each as a wave front over the macroblock rows: row r at column t - 2 r in step t (a macroblock needs its left, upper and upper-right neighbours); then
-// the RGB conversion by row pairs across the lanes; then a lossy file's alpha plane (lane 0: a VP8L stream of its own) and its join with the colour (all
-// lanes).  nsteps = the largest mbw + 2 mbh of the batch's lossy frames.  The reconstruction predicts in a scratch patch per lane: 64 of them (rows 64
-// apart are in flight together only in frames wider than 2048 samples; a lane then takes its rows one after the other), in the LDS the parse has left.
+// The pictures of a batch are one parallel axis (a workgroup each); inside a picture:
+//   k_webp_parse    lane 0 walks the serial part, its working set in LDS.  mode 0: a lossy frame's parse (vp8_parse_frame: modes and coefficients into
+//                   per-macroblock records), a lossless picture's entropy layer (vp8l_entropy: the transformed ARGB frame); mode 1: the entropy layer of a
+//                   lossy file's alpha plane (a VP8L stream of its own, in the frame's work area, which is free again by then)
+//   k_vp8_pixels    lossy frames: (1 .. nsteps) the reconstruction and (nsteps + 1 .. 2 nsteps) the loop filter, each as a wave front over the macroblock
+//                   rows: row r at column t - 2 r in step t (a macroblock needs its left, upper and upper-right neighbours); then the RGB conversion by row
+//                   pairs across the lanes.  nsteps = the largest mbw + 2 mbh.  The reconstruction predicts in a scratch patch per lane: 64 of them (rows
+//                   64 apart are in flight together only in frames wider than 2048 samples; a lane then takes its rows one after the other)
+//   k_vp8l_pixels   VP8L frames: the inverse transforms (vp8l_transform_step: a pass each, the predictor a wave front over the rows), then mode 0 the
+//                   RGB / RGBA / alpha-plane output, mode 1 the alpha plane out of the green channel and its unfilter (another wave front)
+//   k_vp8_alpha_join  a lossy file's colour and alpha plane joined, across the lanes
+// (separate kernels: as one, the compiler had 900 registers to spill -- and got it wrong)
 #define CSW_RECON_LANES 64
-union Vp8Lds { Vp8Hot hot; Vp8Scratch scratch[CSW_RECON_LANES]; };
-__global__ void __launch_bounds__(256) k_vp8_decode(const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps) {
-    CSH_SHARED Vp8Lds lds;
-    CSH_SHARED uint32_t s_translucent;
-    const int i = int(blockIdx.x);
-    Vp8In &im = imgs[i];
-    const bool room = im.rgba_off != ~0ull;
-    uint8_t *rgba = room ? rgb + im.rgba_off : nullptr, *aplane = room ? rgb + im.a_off : nullptr;
+union ParseLds { Vp8Hot hot; LHot lossless; };
+__global__ void __launch_bounds__(64) k_webp_parse(const uint8_t *pool, Vp8In *imgs, uint8_t *work, int mode) {
+    CSH_SHARED ParseLds lds;
+    if (threadIdx.x != 0) return;
+    Vp8In &im = imgs[blockIdx.x];
+    uint8_t *wk = work + im.work_off;
+    if (mode == 0) {
+        im.has_alpha = 0;
+        if (!im.lossless) { im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, im.width, im.height, wk, lds.hot, im.debug)); return; }
+        im.status = uint32_t(vp8l_entropy(pool + im.data_off, im.data_len, im.width, im.height, wk, im.data_len, false, &lds.lossless));
+        return;
+    }
+    if (im.lossless || im.status || !im.alph_len) return;
+    im.status = im.rgba_off == ~0ull ? 3u : uint32_t(alph_entropy(pool + im.alph_off, im.alph_len, im.width, im.height, wk, &lds.lossless));
+}
+__global__ void __launch_bounds__(256) k_vp8_pixels(const Vp8In *imgs, uint8_t *work, uint8_t *rgb, int nsteps) {
+    CSH_SHARED Vp8Scratch scratch[CSW_RECON_LANES];
+    const Vp8In &im = imgs[blockIdx.x];
     uint8_t *wk = work + im.work_off, *out = rgb + im.rgb_off;
     const uint32_t W = im.width, H = im.height;
-    CSH_PHASE_LOOP(2 * nsteps + 5) {
-        if (phase == 0) {
-            if (threadIdx.x == 0) {
-                uint32_t has_alpha = 0;
-                s_translucent = 0;
-                if (im.lossless) im.status = uint32_t(vp8l_decode_frame(pool + im.data_off, im.data_len, W, H, wk, out, im.data_len, false, rgba, aplane, &has_alpha));
-                else im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, W, H, wk, lds.hot, im.debug));
-                im.has_alpha = has_alpha;
-            }
-            continue;
-        }
-        if (im.lossless || im.status) continue;
-        if (phase <= nsteps) {
+    const bool skip = im.lossless || im.status;
+    CSH_PHASE_LOOP(2 * nsteps + 1) {
+        if (skip) continue;
+        if (phase < nsteps) {
             if ((im.debug & 1u) || threadIdx.x >= CSW_RECON_LANES) continue;
-            const int t = phase - 1;
             for (uint32_t r = threadIdx.x; r < im.mbh; r += CSW_RECON_LANES) {
-                const int mx = t - 2 * int(r);
-                if (mx >= 0 && mx < int(im.mbw)) vp8_recon_mb(wk, W, H, uint32_t(mx), r, lds.scratch[threadIdx.x]);
+                const int mx = phase - 2 * int(r);
+                if (mx >= 0 && mx < int(im.mbw)) vp8_recon_mb(wk, W, H, uint32_t(mx), r, scratch[threadIdx.x]);
             }
             continue;
         }
-        if (phase <= 2 * nsteps) {
+        if (phase < 2 * nsteps) {
             if (im.debug & 3u) continue;
-            const int t = phase - nsteps - 1;
             for (uint32_t r = threadIdx.x; r < im.mbh; r += blockDim.x) {
-                const int mx = t - 2 * int(r);
+                const int mx = phase - nsteps - 2 * int(r);
                 if (mx >= 0 && mx < int(im.mbw)) vp8_filter_mb(wk, W, H, uint32_t(mx), r);
             }
             continue;
         }
-        if (phase == 2 * nsteps + 1) {
-            if (im.debug & 5u) continue;
-            for (uint32_t k = threadIdx.x; k <= (H + 1) >> 1; k += blockDim.x) vp8_rgb_rows(wk, W, H, k, out);
+        if (im.debug & 5u) continue;
+        for (uint32_t k = threadIdx.x; k <= (H + 1) >> 1; k += blockDim.x) vp8_rgb_rows(wk, W, H, k, out);
+    }
+}
+// phases: the undo slots one after the other (the predictor's takes psteps phases, the others one each: at most psteps + 3), then two of output (mode 0) or
+// 1 + psteps of the alpha plane (mode 1).  psteps = the batch's largest vp8l_pred_steps.
+__global__ void __launch_bounds__(256) k_vp8l_pixels(const uint8_t *pool, Vp8In *imgs, uint8_t *work, uint8_t *rgb, int psteps, int mode) {
+    CSH_SHARED uint32_t s_amin;
+    Vp8In &im = imgs[blockIdx.x];
+    const bool mine = mode == 0 ? im.lossless != 0 : (!im.lossless && im.alph_len != 0);
+    const uint32_t W = im.width, H = im.height;
+    const LWork lw = lwork(work + im.work_off, W, H);
+    const int tail = psteps + 3;
+    CSH_PHASE_LOOP(tail + (mode == 0 ? 2 : 1 + psteps)) {
+        if (!mine || im.status) continue;
+        if (im.debug & 8u) continue;   // (timing probe: the entropy layer alone)
+        const LFrame &f = *lw.info;
+        if (phase < tail) {
+            // which undo slot, which of its steps
+            int start = 0, slot = -1, step = 0;
+            for (int j = 0; j < int(f.ntr); j++) {
+                const int len = f.tr[f.ntr - 1 - uint32_t(j)].type == 0 ? psteps : 1;
+                if (phase >= start && phase < start + len) { slot = j; step = phase - start; }
+                start += len;
+            }
+            if (slot >= 0) vp8l_transform_step(lw, H, slot, uint32_t(step), threadIdx.x, blockDim.x);
+            if (phase == 0 && threadIdx.x == 0) s_amin = 255;
             continue;
         }
-        if (!im.alph_len) continue;
-        if (phase == 2 * nsteps + 2) {   // the alpha plane of a lossy file (the frame's work area is free again)
-            if (threadIdx.x == 0) im.status = !room ? 3u : uint32_t(alph_decode(pool + im.alph_off, im.alph_len, W, H, wk, aplane));
+        if (mode == 1) {
+            uint8_t *aplane = rgb + im.a_off;
+            if (phase == tail) alph_plane_step(lw, pool + im.alph_off, aplane, threadIdx.x, blockDim.x);
+            else alph_unfilter_step(lw, aplane, W, H, uint32_t(phase - tail - 1), threadIdx.x, blockDim.x);
             continue;
         }
-        if (phase == 2 * nsteps + 3) {
-            const uint64_t npx = uint64_t(W) * H;
+        if (im.debug & 16u) continue;   // (timing probe: no output)
+        const uint32_t *cur = vp8l_result(lw);
+        uint8_t *out = rgb + im.rgb_off;
+        if (phase == tail) {   // ARGB -> RGB for the three-channel encoders; is the picture opaque?
+            uint32_t amin = 255;
+            for (uint64_t i = threadIdx.x; i < lw.npx; i += blockDim.x) {
+                const uint32_t v = cur[i];
+                out[3 * i] = uint8_t(v >> 16); out[3 * i + 1] = uint8_t(v >> 8); out[3 * i + 2] = uint8_t(v);
+                if ((v >> 24) < amin) amin = v >> 24;
+            }
+            if (amin < 255) atomicMin(&s_amin, amin);
+            continue;
+        }
+        if (s_amin == 255) continue;   // a picture that is not opaque leaves RGBA and its alpha plane as well
+        if (im.rgba_off == ~0ull) { if (threadIdx.x == 0) im.status = 3; continue; }
+        uint8_t *rgba = rgb + im.rgba_off, *aplane = rgb + im.a_off;
+        for (uint64_t i = threadIdx.x; i < lw.npx; i += blockDim.x) {
+            const uint32_t v = cur[i];
+            rgba[4 * i] = uint8_t(v >> 16); rgba[4 * i + 1] = uint8_t(v >> 8); rgba[4 * i + 2] = uint8_t(v); rgba[4 * i + 3] = uint8_t(v >> 24);
+            aplane[i] = uint8_t(v >> 24);
+        }
+        if (threadIdx.x == 0) im.has_alpha = 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_vp8_alpha_join(Vp8In *imgs, uint8_t *rgb) {
+    CSH_SHARED uint32_t s_translucent;
+    Vp8In &im = imgs[blockIdx.x];
+    const bool skip = im.lossless || im.status || !im.alph_len;
+    CSH_PHASE_LOOP(3) {
+        if (skip) continue;
+        if (phase == 0) { if (threadIdx.x == 0) s_translucent = 0; continue; }
+        if (phase == 1) {
+            const uint8_t *out = rgb + im.rgb_off, *aplane = rgb + im.a_off;
+            uint8_t *rgba = rgb + im.rgba_off;
+            const uint64_t npx = uint64_t(im.width) * im.height;
             bool translucent = false;
             for (uint64_t k = threadIdx.x; k < npx; k += blockDim.x) {
                 rgba[4 * k] = out[3 * k]; rgba[4 * k + 1] = out[3 * k + 1]; rgba[4 * k + 2] = out[3 * k + 2]; rgba[4 * k + 3] = aplane[k];
@@ -77,8 +140,16 @@ __global__ void __launch_bounds__(256) k_vp8_decode(const uint8_t *pool, Vp8In *
         if (threadIdx.x == 0) im.has_alpha = s_translucent;
     }
 }
-void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps) {
-    if (n) CSH_LAUNCH_PHASED(k_vp8_decode, 2 * nsteps + 5, dim3(unsigned(n)), dim3(256), st, pool, imgs, n, work, rgb, nsteps);
+void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps, int psteps_lossless, int psteps_alpha) {
+    if (!n) return;
+    CSH_LAUNCH(k_webp_parse, dim3(unsigned(n)), dim3(64), st, pool, imgs, work, 0);
+    if (nsteps) CSH_LAUNCH_PHASED(k_vp8_pixels, 2 * nsteps + 1, dim3(unsigned(n)), dim3(256), st, imgs, work, rgb, nsteps);
+    if (psteps_lossless) CSH_LAUNCH_PHASED(k_vp8l_pixels, psteps_lossless + 3 + 2, dim3(unsigned(n)), dim3(256), st, pool, imgs, work, rgb, psteps_lossless, 0);
+    if (psteps_alpha) {
+        CSH_LAUNCH(k_webp_parse, dim3(unsigned(n)), dim3(64), st, pool, imgs, work, 1);
+        CSH_LAUNCH_PHASED(k_vp8l_pixels, psteps_alpha + 3 + 1 + psteps_alpha, dim3(unsigned(n)), dim3(256), st, pool, imgs, work, rgb, psteps_alpha, 1);
+        CSH_LAUNCH_PHASED(k_vp8_alpha_join, 3, dim3(unsigned(n)), dim3(256), st, imgs, rgb);
+    }
 }
 
 // RGB + alpha plane -> interleaved RGBA (the resized halves of a picture with transparency, joined for the PNG / lossless WebP coders): four pixels per lane

@@ -9,6 +9,14 @@
 #include <cstdint>
 #include "../../include/vp8_tables.h"
 
+// everything of the decoders is inlined into its kernel: only then does the compiler see which pointers are LDS (ds_read instead of flat_load)
+#ifdef CSH_EMUL
+#define CSW_INLINE
+#define CSW_NOUNROLL
+#else
+#define CSW_INLINE __attribute__((always_inline))
+#define CSW_NOUNROLL _Pragma("clang loop unroll(disable)")   // (the coefficient reader is inlined: one copy per call site, not per block)
+#endif
 namespace csw {
 
 struct Vp8In {              // one input file, host-parsed container
@@ -26,7 +34,7 @@ struct Vp8In {              // one input file, host-parsed container
 };
 // work area: Y plane (mbw*16 x mbh*16), U, V (mbw*8 x mbh*8), per-macroblock filter info (4 bytes), per-column contexts, the frame info, and what the
 // parse hands the reconstruction: per macroblock a record of its modes (24 bytes) and its 24 dequantised 4 x 4 blocks (768 bytes, only those in nzmask written)
-__host__ __device__ static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t mbh) {
+__host__ __device__ CSW_INLINE static inline uint64_t vp8_work_bytes(uint32_t mbw, uint32_t mbh) {
     const uint64_t ly = uint64_t(mbw) * 16 * mbh * 16, lc = uint64_t(mbw) * 8 * mbh * 8;
     return ly + 2 * lc + uint64_t(mbw) * mbh * 4 + uint64_t(mbw) * 16 + 256 + uint64_t(mbw) * mbh * (24 + 768);
 }
@@ -40,18 +48,19 @@ struct BoolDec {
     uint64_t value;
     uint32_t range, loaded, len;
     int nbits;
-    __host__ __device__ void refill() {
+    // (the bytes come straight from the memory system, four per 32 bits of look-ahead: a window of the stream in LDS was measured and bought nothing)
+    __host__ __device__ CSW_INLINE void refill() {
         uint32_t w;
         if (end - p >= 4) { w = (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); p += 4; }
         else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (p < end ? uint32_t(*p++) : 0u); }
         value = (value << 32) | w; nbits += 32; loaded += 4;
     }
-    __host__ __device__ void init(const uint8_t *d, size_t n) {
+    __host__ __device__ CSW_INLINE void init(const uint8_t *d, size_t n) {
         p = d; end = d + n; len = uint32_t(n);
         value = 0; nbits = -8; loaded = 0; range = 255;
         refill();
     }
-    __host__ __device__ int get(int prob) {
+    __host__ __device__ CSW_INLINE int get(int prob) {
         if (nbits < 8) refill();
         const uint32_t split = 1u + (((range - 1u) * uint32_t(prob)) >> 8);
         const uint32_t top = uint32_t(value >> nbits);
@@ -61,19 +70,19 @@ struct BoolDec {
         range <<= shift; nbits -= shift;
         return r;
     }
-    __host__ __device__ bool eof() const {
+    __host__ __device__ CSW_INLINE bool eof() const {
         const int64_t groups = (int64_t(8) * loaded - 8 - nbits) >> 3;   // completed groups of eight shifts = bytes the byte-wise form has loaded behind its first two
         return groups >= 1 && groups + 1 >= int64_t(len);
     }
-    __host__ __device__ uint32_t lit(int n) { uint32_t v = 0; while (n-- > 0) v = (v << 1) | uint32_t(get(128)); return v; }
-    __host__ __device__ int slit(int n) { const int v = int(lit(n)); return get(128) ? -v : v; }
+    __host__ __device__ CSW_INLINE uint32_t lit(int n) { uint32_t v = 0; while (n-- > 0) v = (v << 1) | uint32_t(get(128)); return v; }
+    __host__ __device__ CSW_INLINE int slit(int n) { const int v = int(lit(n)); return get(128) ? -v : v; }
 };
 
-__host__ __device__ static inline int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
-__host__ __device__ static inline int clipq(int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; }
+__host__ __device__ CSW_INLINE static inline int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+__host__ __device__ CSW_INLINE static inline int clipq(int v, int hi) { return v < 0 ? 0 : v > hi ? hi : v; }
 
 // inverse DCT of one 4x4 block, added to the prediction in dst (libwebp TransformOne: the two multipliers of RFC 6386 14.3)
-__host__ __device__ static inline void vp8_idct_add(const int16_t *in16, uint8_t *dst, int stride) {
+__host__ __device__ CSW_INLINE static inline void vp8_idct_add(const int16_t *in16, uint8_t *dst, int stride) {
     // the block comes out of the work area (16-byte aligned): two loads up front instead of thirty-two the compiler has to order against the stores below
     const uint4 q0 = reinterpret_cast<const uint4 *>(in16)[0], q1 = reinterpret_cast<const uint4 *>(in16)[1];
     const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -97,7 +106,7 @@ __host__ __device__ static inline void vp8_idct_add(const int16_t *in16, uint8_t
     }
 }
 // inverse Walsh-Hadamard of the 16 luma DCs (libwebp TransformWHT); out[k * 16] = DC of block k
-__host__ __device__ static inline void vp8_iwht(const int16_t *in, int16_t *out) {
+__host__ __device__ CSW_INLINE static inline void vp8_iwht(const int16_t *in, int16_t *out) {
     int tmp[16];
     for (int i = 0; i < 4; i++) {
         const int a0 = in[i] + in[12 + i], a1 = in[4 + i] + in[8 + i], a2 = in[4 + i] - in[8 + i], a3 = in[i] - in[12 + i];
@@ -113,15 +122,15 @@ __host__ __device__ static inline void vp8_iwht(const int16_t *in, int16_t *out)
 
 // ---- intra prediction.  `d` points at the block's top-left sample in a plane with `s` bytes per row whose row above and column to the
 // left hold the neighbours (frame edges: 127 above, 129 to the left, as libwebp initialises them)
-__host__ __device__ static inline void pred_fill(uint8_t *d, int s, int n, int v) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) d[y * s + x] = uint8_t(v); }
-__host__ __device__ static inline void pred_tm(uint8_t *d, int s, int n) {
+__host__ __device__ CSW_INLINE static inline void pred_fill(uint8_t *d, int s, int n, int v) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) d[y * s + x] = uint8_t(v); }
+__host__ __device__ CSW_INLINE static inline void pred_tm(uint8_t *d, int s, int n) {
     const int tl = d[-s - 1];
     for (int y = 0; y < n; y++) { const int l = d[y * s - 1]; for (int x = 0; x < n; x++) d[y * s + x] = uint8_t(clip8(l + d[-s + x] - tl)); }
 }
-__host__ __device__ static inline void pred_v(uint8_t *d, int s, int n) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) d[y * s + x] = d[-s + x]; }
-__host__ __device__ static inline void pred_h(uint8_t *d, int s, int n) { for (int y = 0; y < n; y++) { const uint8_t l = d[y * s - 1]; for (int x = 0; x < n; x++) d[y * s + x] = l; } }
+__host__ __device__ CSW_INLINE static inline void pred_v(uint8_t *d, int s, int n) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) d[y * s + x] = d[-s + x]; }
+__host__ __device__ CSW_INLINE static inline void pred_h(uint8_t *d, int s, int n) { for (int y = 0; y < n; y++) { const uint8_t l = d[y * s - 1]; for (int x = 0; x < n; x++) d[y * s + x] = l; } }
 // DC of an n x n block (n = 16 or 8): has_top / has_left say which neighbours exist
-__host__ __device__ static inline void pred_dc(uint8_t *d, int s, int n, bool has_top, bool has_left) {
+__host__ __device__ CSW_INLINE static inline void pred_dc(uint8_t *d, int s, int n, bool has_top, bool has_left) {
     int sum = 0, cnt = 0;
     if (has_top) { for (int x = 0; x < n; x++) sum += d[-s + x]; cnt += n; }
     if (has_left) { for (int y = 0; y < n; y++) sum += d[y * s - 1]; cnt += n; }
@@ -131,7 +140,7 @@ __host__ __device__ static inline void pred_dc(uint8_t *d, int s, int n, bool ha
 #define AVG3(a, b, c) uint8_t(((a) + 2 * (b) + (c) + 2) >> 2)
 #define AVG2(a, b) uint8_t(((a) + (b) + 1) >> 1)
 // the ten 4x4 modes (RFC 6386 12.3); tr = the four samples above and to the right
-__host__ __device__ static inline void pred4(uint8_t *d, int s, int mode, const uint8_t *tr) {
+__host__ __device__ CSW_INLINE static inline void pred4(uint8_t *d, int s, int mode, const uint8_t *tr) {
     const int A = d[-s], B = d[-s + 1], C = d[-s + 2], D = d[-s + 3], E = tr[0], F = tr[1], G = tr[2], H = tr[3];
     const int I = d[-1], J = d[s - 1], K = d[2 * s - 1], L = d[3 * s - 1], X = d[-s - 1];
 #define P(x, y) d[(y) * s + (x)]
@@ -171,49 +180,49 @@ __host__ __device__ static inline void pred4(uint8_t *d, int s, int mode, const 
 }
 
 // ---- loop filter (RFC 6386 section 15, libwebp's arithmetic)
-__host__ __device__ static inline int sclip1(int v) { return v < -128 ? -128 : v > 127 ? 127 : v; }
-__host__ __device__ static inline int sclip2(int v) { return v < -16 ? -16 : v > 15 ? 15 : v; }
-__host__ __device__ static inline int iabs(int v) { return v < 0 ? -v : v; }
-__host__ __device__ static inline void lf2(uint8_t *p, int st) {
+__host__ __device__ CSW_INLINE static inline int sclip1(int v) { return v < -128 ? -128 : v > 127 ? 127 : v; }
+__host__ __device__ CSW_INLINE static inline int sclip2(int v) { return v < -16 ? -16 : v > 15 ? 15 : v; }
+__host__ __device__ CSW_INLINE static inline int iabs(int v) { return v < 0 ? -v : v; }
+__host__ __device__ CSW_INLINE static inline void lf2(uint8_t *p, int st) {
     const int p1 = p[-2 * st], p0 = p[-st], q0 = p[0], q1 = p[st];
     const int a = 3 * (q0 - p0) + sclip1(p1 - q1);
     const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3);
     p[-st] = uint8_t(clip8(p0 + a2)); p[0] = uint8_t(clip8(q0 - a1));
 }
-__host__ __device__ static inline void lf4(uint8_t *p, int st) {
+__host__ __device__ CSW_INLINE static inline void lf4(uint8_t *p, int st) {
     const int p1 = p[-2 * st], p0 = p[-st], q0 = p[0], q1 = p[st];
     const int a = 3 * (q0 - p0);
     const int a1 = sclip2((a + 4) >> 3), a2 = sclip2((a + 3) >> 3), a3 = (a1 + 1) >> 1;
     p[-2 * st] = uint8_t(clip8(p1 + a3)); p[-st] = uint8_t(clip8(p0 + a2)); p[0] = uint8_t(clip8(q0 - a1)); p[st] = uint8_t(clip8(q1 - a3));
 }
-__host__ __device__ static inline void lf6(uint8_t *p, int st) {
+__host__ __device__ CSW_INLINE static inline void lf6(uint8_t *p, int st) {
     const int p2 = p[-3 * st], p1 = p[-2 * st], p0 = p[-st], q0 = p[0], q1 = p[st], q2 = p[2 * st];
     const int a = sclip1(3 * (q0 - p0) + sclip1(p1 - q1));
     const int a1 = (27 * a + 63) >> 7, a2 = (18 * a + 63) >> 7, a3 = (9 * a + 63) >> 7;
     p[-3 * st] = uint8_t(clip8(p2 + a3)); p[-2 * st] = uint8_t(clip8(p1 + a2)); p[-st] = uint8_t(clip8(p0 + a1));
     p[0] = uint8_t(clip8(q0 - a1)); p[st] = uint8_t(clip8(q1 - a2)); p[2 * st] = uint8_t(clip8(q2 - a3));
 }
-__host__ __device__ static inline bool lf_hev(const uint8_t *p, int st, int t) { return iabs(p[-2 * st] - p[-st]) > t || iabs(p[st] - p[0]) > t; }
-__host__ __device__ static inline bool lf_needs(const uint8_t *p, int st, int t) { return 4 * iabs(p[-st] - p[0]) + iabs(p[-2 * st] - p[st]) <= t; }
-__host__ __device__ static inline bool lf_needs2(const uint8_t *p, int st, int t, int it) {
+__host__ __device__ CSW_INLINE static inline bool lf_hev(const uint8_t *p, int st, int t) { return iabs(p[-2 * st] - p[-st]) > t || iabs(p[st] - p[0]) > t; }
+__host__ __device__ CSW_INLINE static inline bool lf_needs(const uint8_t *p, int st, int t) { return 4 * iabs(p[-st] - p[0]) + iabs(p[-2 * st] - p[st]) <= t; }
+__host__ __device__ CSW_INLINE static inline bool lf_needs2(const uint8_t *p, int st, int t, int it) {
     if (4 * iabs(p[-st] - p[0]) + iabs(p[-2 * st] - p[st]) > t) return false;
     return iabs(p[-4 * st] - p[-3 * st]) <= it && iabs(p[-3 * st] - p[-2 * st]) <= it && iabs(p[-2 * st] - p[-st]) <= it &&
            iabs(p[3 * st] - p[2 * st]) <= it && iabs(p[2 * st] - p[st]) <= it && iabs(p[st] - p[0]) <= it;
 }
 // an edge of `size` samples: hs = step across the edge, vs = step along it
-__host__ __device__ static inline void lf_simple(uint8_t *p, int hs, int vs, int size, int thresh) {
+__host__ __device__ CSW_INLINE static inline void lf_simple(uint8_t *p, int hs, int vs, int size, int thresh) {
     const int t2 = 2 * thresh + 1;
     for (int i = 0; i < size; i++, p += vs) if (lf_needs(p, hs, t2)) lf2(p, hs);
 }
-__host__ __device__ static inline void lf_edge(uint8_t *p, int hs, int vs, int size, int thresh, int ithresh, int hev, bool mb_edge) {
+__host__ __device__ CSW_INLINE static inline void lf_edge(uint8_t *p, int hs, int vs, int size, int thresh, int ithresh, int hev, bool mb_edge) {
     const int t2 = 2 * thresh + 1;
     for (int i = 0; i < size; i++, p += vs)
         if (lf_needs2(p, hs, t2, ithresh)) { if (lf_hev(p, hs, hev)) lf2(p, hs); else if (mb_edge) lf6(p, hs); else lf4(p, hs); }
 }
 
 // libwebp yuv.h: 14-bit fixed point with the rounding folded into the constants
-__host__ __device__ static inline int yuv_clip(int v) { return (v & ~16383) == 0 ? (v >> 6) : (v < 0 ? 0 : 255); }
-__host__ __device__ static inline void yuv_rgb(int y, int u, int v, uint8_t *o) {
+__host__ __device__ CSW_INLINE static inline int yuv_clip(int v) { return (v & ~16383) == 0 ? (v >> 6) : (v < 0 ? 0 : 255); }
+__host__ __device__ CSW_INLINE static inline void yuv_rgb(int y, int u, int v, uint8_t *o) {
     const int yy = (y * 19077) >> 8;
     o[0] = uint8_t(yuv_clip(yy + ((v * 26149) >> 8) - 14234));
     o[1] = uint8_t(yuv_clip(yy - ((u * 6419) >> 8) - ((v * 13320) >> 8) + 8708));
@@ -236,7 +245,7 @@ struct Vp8Planes {
     int ys, cs;
     uint32_t mbw, mbh;
 };
-__host__ __device__ static inline Vp8Planes vp8_planes(uint8_t *work, uint32_t W, uint32_t H) {
+__host__ __device__ CSW_INLINE static inline Vp8Planes vp8_planes(uint8_t *work, uint32_t W, uint32_t H) {
     Vp8Planes p;
     p.mbw = (W + 15) >> 4; p.mbh = (H + 15) >> 4;
     p.ys = int(p.mbw * 16); p.cs = int(p.mbw * 8);
@@ -245,7 +254,9 @@ __host__ __device__ static inline Vp8Planes vp8_planes(uint8_t *work, uint32_t W
     p.ctx = reinterpret_cast<uint8_t *>(p.finfo + size_t(p.mbw) * p.mbh);
     p.frame = reinterpret_cast<Vp8Frame *>(p.ctx + size_t(p.mbw) * 16);
     p.rec = reinterpret_cast<Vp8MbRec *>(p.ctx + size_t(p.mbw) * 16 + 64);
-    p.mbcoef = reinterpret_cast<int16_t *>((reinterpret_cast<uintptr_t>(p.rec + size_t(p.mbw) * p.mbh) + 15) & ~uintptr_t(15));   // 16-byte blocks (the + 256 of vp8_work_bytes pays for the gaps)
+    // 16-byte blocks: the offset rounded up (the work area itself starts at a multiple of 64 bytes; the + 256 of vp8_work_bytes pays for the gaps)
+    const size_t rec_end = size_t(reinterpret_cast<uint8_t *>(p.rec + size_t(p.mbw) * p.mbh) - work);
+    p.mbcoef = reinterpret_cast<int16_t *>(work + ((rec_end + 15) & ~size_t(15)));
     return p;
 }
 
@@ -265,7 +276,7 @@ struct Vp8Hot {
 // the parse: frame header, then macroblock by macroblock the modes and the coefficients (dequantised, the Y2 block folded into the luma DCs); leaves the
 // macroblock records, their coefficient blocks, the filter strengths and the frame info in the work area.  Returns 0 or an error code (CS_ERR_* numbers are the caller's: 1 = malformed,
 // 2 = unsupported feature)
-__host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, Vp8Hot &hot, uint32_t debug = 0) {
+__host__ __device__ CSW_INLINE static inline int vp8_parse_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, Vp8Hot &hot, uint32_t debug = 0) {
     (void)debug;
     if (n < 10) return 1;
     const uint32_t tag = data[0] | (data[1] << 8) | (data[2] << 16);
@@ -384,8 +395,10 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
                 ymode = br.get(156) ? (br.get(128) ? 1 : 3) : (br.get(163) ? 2 : 0);   // B_ order: 0 DC, 1 TM, 2 V, 3 H
                 for (int k = 0; k < 4; k++) { top_modes[k] = uint8_t(ymode); left_modes[k] = uint8_t(ymode); }
             } else {
+                CSW_NOUNROLL
                 for (int y = 0; y < 4; y++) {
                     int lm = left_modes[y];
+                    CSW_NOUNROLL
                     for (int x = 0; x < 4; x++) {
                         const uint8_t *pr = hot.bmode + (size_t(top_modes[x]) * 10 + size_t(lm)) * 9;
                         int m;
@@ -445,14 +458,19 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
                     for (int k = 0; k < 16; k++) if (coef[16 * k]) nzmask |= 1u << k;
                     first = 1; ytype = 0;
                 }
+                CSW_NOUNROLL
                 for (int y = 0; y < 4; y++)
+                    CSW_NOUNROLL
                     for (int x = 0; x < 4; x++) {
                         const int nz = get_coeffs(ytype, tnz[x] + lnz[y], sq.y1, first, coef + (4 * y + x) * 16);
                         tnz[x] = lnz[y] = uint8_t(nz > first);
                         if (nz > first) nzmask |= 1u << (4 * y + x);
                     }
+                CSW_NOUNROLL
                 for (int ch = 0; ch < 2; ch++)
+                    CSW_NOUNROLL
                     for (int y = 0; y < 2; y++)
+                        CSW_NOUNROLL
                         for (int x = 0; x < 2; x++) {
                             const int nz = get_coeffs(2, tnz[4 + 2 * ch + x] + lnz[4 + 2 * ch + y], sq.uv, 0, coef + (16 + 4 * ch + 2 * y + x) * 16);
                             tnz[4 + 2 * ch + x] = lnz[4 + 2 * ch + y] = uint8_t(nz > 0);
@@ -490,7 +508,7 @@ __host__ __device__ static inline int vp8_parse_frame(const uint8_t *data, size_
 // front as the loop filter.  `sc` is scratch for one macroblock (LDS in the kernel: the planes have no margin, so the block is predicted in a 17 x 32 patch
 // whose row above and column to the left get the neighbours -- frame edges: 127 above, 129 to the left -- and sits word-aligned at row 1, column 4).
 struct Vp8Scratch { alignas(4) uint8_t s[(16 + 1) * 32]; };
-__host__ __device__ static inline void vp8_recon_mb(uint8_t *work, uint32_t W, uint32_t H, uint32_t mx, uint32_t my, Vp8Scratch &sc) {
+__host__ __device__ CSW_INLINE static inline void vp8_recon_mb(uint8_t *work, uint32_t W, uint32_t H, uint32_t mx, uint32_t my, Vp8Scratch &sc) {
     const Vp8Planes pl = vp8_planes(work, W, H);
     const uint32_t mbw = pl.mbw;
     const int ys = pl.ys, cs = pl.cs;
@@ -554,7 +572,7 @@ __host__ __device__ static inline void vp8_recon_mb(uint8_t *work, uint32_t W, u
 // the loop filter of one macroblock (RFC 6386 section 15: macroblocks in raster order).  What a macroblock's filter reads and changes reaches three
 // samples into the macroblocks to its left and above, so (mx, my) only needs (mx - 1, my), (mx, my - 1) and (mx + 1, my - 1) done: the kernel runs the
 // frame as a wave front, macroblock row r at column t - 2 r in step t.
-__host__ __device__ static inline void vp8_filter_mb(uint8_t *work, uint32_t W, uint32_t H, uint32_t mx, uint32_t my) {
+__host__ __device__ CSW_INLINE static inline void vp8_filter_mb(uint8_t *work, uint32_t W, uint32_t H, uint32_t mx, uint32_t my) {
     const Vp8Planes pl = vp8_planes(work, W, H);
     if (!pl.frame->filtering) return;
     const bool simple = pl.frame->simple != 0;
@@ -584,7 +602,7 @@ __host__ __device__ static inline void vp8_filter_mb(uint8_t *work, uint32_t W, 
 // libwebp's fancy upsampler (chroma at 9:3:3:1 of the four nearest samples, computed on u | v << 16 pairs) + YCbCr -> RGB, one pair of luma rows
 // between two chroma rows per call: k = 0 the first row (its chroma row on both sides), k = 1 .. chh - 1 rows 2k-1 and 2k between chroma rows k-1 and k,
 // k = chh the last row of an even height on its own.  The calls are independent of one another.
-__host__ __device__ static inline void vp8_rgb_rows(uint8_t *work, uint32_t W, uint32_t H, uint32_t k, uint8_t *rgb) {
+__host__ __device__ CSW_INLINE static inline void vp8_rgb_rows(uint8_t *work, uint32_t W, uint32_t H, uint32_t k, uint8_t *rgb) {
     const Vp8Planes pl = vp8_planes(work, W, H);
     const uint8_t *Y = pl.Y, *U = pl.U, *V = pl.V;
     const int ys = pl.ys, cs = pl.cs;

@@ -10,27 +10,65 @@
 #pragma once
 #include <cstdint>
 
+// everything of the decoders is inlined into its kernel: only then does the compiler see which pointers are LDS (ds_read instead of flat_load)
+#ifdef CSH_EMUL
+#define CSW_INLINE
+#else
+#define CSW_INLINE __attribute__((always_inline))
+#endif
 namespace csw {
 
 // work area of one image (bytes): two ARGB frames (the decoded -- possibly pixel-packed -- picture and the one colour indexing expands
 // into), three sub-images (predictor modes, cross-colour elements, meta prefix groups: at most a quarter of the picture's side each,
 // as their block side is >= 4), the palette, the colour cache, and the prefix-code arena
-__host__ __device__ static inline uint64_t vp8l_arena_bytes(uint64_t file_bytes) { return 4ull * 1024 * 1024 + 16ull * file_bytes; }
-__host__ __device__ static inline uint64_t vp8l_sub_pixels(uint32_t w, uint32_t h) { return uint64_t((w + 3) / 4) * ((h + 3) / 4) + 16; }
-__host__ __device__ static inline uint64_t vp8l_work_bytes(uint32_t w, uint32_t h, uint64_t file_bytes) {
+__host__ __device__ CSW_INLINE static inline uint64_t vp8l_arena_bytes(uint64_t file_bytes) { return 4ull * 1024 * 1024 + 16ull * file_bytes; }
+__host__ __device__ CSW_INLINE static inline uint64_t vp8l_sub_pixels(uint32_t w, uint32_t h) { return uint64_t((w + 3) / 4) * ((h + 3) / 4) + 16; }
+__host__ __device__ CSW_INLINE static inline uint64_t vp8l_work_bytes(uint32_t w, uint32_t h, uint64_t file_bytes) {
     return 2ull * 4 * w * h + 3ull * 4 * vp8l_sub_pixels(w, h) + 4ull * 256 + 4ull * 2048 + vp8l_arena_bytes(file_bytes) + 256;
 }
 
-struct LBits {   // LSB-first bit reader
-    const uint8_t *p, *end;
+// LSB-first bit reader.  The stream is read through a window of L_WIN bytes kept close (LDS in the kernel): one lane walks the stream, and fetching
+// it from the memory system eight bytes at a time was a round trip every other pixel; the window is refilled 256 words at a stretch.
+enum { L_WIN = 1024 };
+struct LBits {
+    const uint8_t *data;
+    uint8_t *win;          // L_WIN + 64 bytes, 16-byte aligned
+    uint32_t len, pos;     // bytes of the stream; next byte to take
+    uint32_t wstart;       // stream position of win[0] (a multiple of 4)
     uint64_t val;
     int nbits;
     bool eos;
-    __host__ __device__ void init(const uint8_t *d, size_t n) { p = d; end = d + n; val = 0; nbits = 0; eos = false; }
-    __host__ __device__ void fill() { while (nbits <= 56 && p < end) { val |= uint64_t(*p++) << nbits; nbits += 8; } }
-    __host__ __device__ uint32_t peek(int n) { if (nbits < n) fill(); return uint32_t(val) & ((1u << n) - 1u); }   // n <= 16
-    __host__ __device__ void drop(int n) { if (nbits < n) { eos = true; val = 0; nbits = 0; return; } val >>= n; nbits -= n; }
-    __host__ __device__ uint32_t read(int n) { if (!n) return 0; const uint32_t v = peek(n); drop(n); return v; }
+    __host__ __device__ CSW_INLINE void load_window(uint32_t at) {
+        const uint32_t mis = uint32_t((reinterpret_cast<uintptr_t>(data) + at) & 15u);   // the window starts at a 16-byte boundary of memory at or in front of `at`
+        wstart = at >= mis ? at - mis : 0u;
+        const uint8_t *src = data + wstart;
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && wstart + L_WIN + 16 <= len) {   // 64 bytes per step, the four loads in flight together (the files' streams start at
+            for (uint32_t i = 0; i < L_WIN + 16; i += 64) {                                    // multiples of 16 in the pool); a load per word would be a memory round trip per word
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(src + i);
+                const uint4 a = s4[0], b = s4[1], c = s4[2], d = s4[3];
+                uint4 *d4 = reinterpret_cast<uint4 *>(win + i);
+                d4[0] = a; d4[1] = b; d4[2] = c; d4[3] = d;
+            }
+            return;
+        }
+        for (uint32_t i = 0; i < L_WIN + 16; i++) win[i] = wstart + i < len ? src[i] : uint8_t(0);   // the ragged end of a stream, or its very start
+    }
+    __host__ __device__ CSW_INLINE void init(const uint8_t *d, size_t n, uint8_t *window) { data = d; win = window; len = uint32_t(n); pos = 0; val = 0; nbits = 0; eos = false; load_window(0); }
+    __host__ __device__ CSW_INLINE void fill() {
+        if (pos >= len) return;
+        if (pos - wstart > L_WIN) load_window(pos);
+        const uint8_t *q = win + (pos - wstart);
+        uint64_t w = 0;
+        for (int i = 0; i < 8; i++) w |= uint64_t(q[i]) << (8 * i);
+        int k = (64 - nbits) >> 3;
+        if (uint32_t(k) > len - pos) k = int(len - pos);
+        if (k >= 8) { val = w; nbits = 64; pos += 8; return; }   // (nbits == 0: a shift by 64 is not a shift)
+        if (k <= 0) return;
+        val |= (w & ((1ull << (8 * k)) - 1ull)) << nbits; nbits += 8 * k; pos += uint32_t(k);
+    }
+    __host__ __device__ CSW_INLINE uint32_t peek(int n) { if (nbits < n) fill(); return uint32_t(val) & ((1u << n) - 1u); }   // n <= 16
+    __host__ __device__ CSW_INLINE void drop(int n) { if (nbits < n) { eos = true; val = 0; nbits = 0; return; } val >>= n; nbits -= n; }
+    __host__ __device__ CSW_INLINE uint32_t read(int n) { if (!n) return 0; const uint32_t v = peek(n); drop(n); return v; }
 };
 
 // one prefix code: canonical, decoded length by length; codes of up to 8 bits also through a 256-entry table (when the arena had room)
@@ -45,7 +83,7 @@ struct LGroup { LCode c[5]; };   // green + length prefixes + cache indices, red
 
 struct LArena { uint16_t *base; uint64_t cap, used; };   // in u16 units
 
-__host__ __device__ static inline int lsym(LBits &br, const LCode &c, const uint16_t *arena) {
+__host__ __device__ CSW_INLINE static inline int lsym(LBits &br, const LCode &c, const uint16_t *arena) {
     if (c.nsym <= 1) return c.single;
     if (c.lut != 0xFFFFFFFFu) {
         const uint16_t e = arena[c.lut + br.peek(8)];
@@ -62,7 +100,7 @@ __host__ __device__ static inline int lsym(LBits &br, const LCode &c, const uint
 }
 
 // lengths[0..n) -> code.  false: not a complete prefix code (or no room for its symbols)
-__host__ __device__ static inline bool lbuild(const uint8_t *lengths, int n, LCode &c, LArena &ar, bool want_lut) {
+__host__ __device__ CSW_INLINE static inline bool lbuild(const uint8_t *lengths, int n, LCode &c, LArena &ar, bool want_lut) {
     for (int l = 0; l < 16; l++) c.count[l] = 0;
     int used = 0, last = 0;
     for (int s = 0; s < n; s++) if (lengths[s]) { c.count[lengths[s]]++; used++; last = s; }
@@ -83,7 +121,8 @@ __host__ __device__ static inline bool lbuild(const uint8_t *lengths, int n, LCo
     uint16_t next[16];
     for (int l = 1; l <= 15; l++) next[l] = c.first_idx[l];
     for (int s = 0; s < n; s++) if (lengths[s]) ar.base[c.syms + next[lengths[s]]++] = uint16_t(s);
-    if (want_lut && ar.used + 256 <= ar.cap) {
+    if (want_lut && ar.used + 257 <= ar.cap) {
+        ar.used += ar.used & 1;   // at an even position: the tables are copied to the hot set as words
         c.lut = uint32_t(ar.used); ar.used += 256;
         uint16_t *t = ar.base + c.lut;
         for (int i = 0; i < 256; i++) t[i] = 0;
@@ -100,7 +139,7 @@ __host__ __device__ static inline bool lbuild(const uint8_t *lengths, int n, LCo
 }
 
 // reads one prefix code of `alphabet` symbols (lengths: scratch of >= alphabet bytes)
-__host__ __device__ static inline bool lread_code(LBits &br, int alphabet, LCode &c, LArena &ar, uint8_t *lengths, bool want_lut) {
+__host__ __device__ CSW_INLINE static inline bool lread_code(LBits &br, int alphabet, LCode &c, LArena &ar, uint8_t *lengths, bool want_lut) {
     for (int i = 0; i < alphabet; i++) lengths[i] = 0;
     if (br.read(1)) {   // simple code: one or two symbols
         const int nsym = int(br.read(1)) + 1;
@@ -144,7 +183,7 @@ __host__ __device__ static inline bool lread_code(LBits &br, int alphabet, LCode
 }
 
 // LZ77 prefix value (length or distance code): the prefix symbol, then its extra bits
-__host__ __device__ static inline uint32_t lprefix_value(LBits &br, int sym) {
+__host__ __device__ CSW_INLINE static inline uint32_t lprefix_value(LBits &br, int sym) {
     if (sym < 4) return uint32_t(sym) + 1;
     const int extra = (sym - 2) >> 1;
     const uint32_t off = uint32_t(2 + (sym & 1)) << extra;
@@ -153,7 +192,7 @@ __host__ __device__ static inline uint32_t lprefix_value(LBits &br, int sym) {
 // distance code 1..120 -> pixel distance through the neighbourhood map: the 120 positions (dx, dy), dy in 0..7, dx in -7..8 (dy = 0: dx > 0),
 // ordered by dx^2 + dy^2, then |dx|, then dx > 0 first (the specification's table, generated instead of spelled out); kept packed as
 // (dy << 4) | (8 - dx)
-__host__ __device__ static inline void lplane_table(uint8_t t[120]) {
+__host__ __device__ CSW_INLINE static inline void lplane_table(uint8_t t[120]) {
     int n = 0;
     for (int d2 = 1; d2 <= 113 && n < 120; d2++)
         for (int ax = 0; ax <= 8; ax++)
@@ -171,26 +210,26 @@ __host__ __device__ static inline void lplane_table(uint8_t t[120]) {
             }
 }
 
-__host__ __device__ static inline uint32_t ladd(uint32_t a, uint32_t b) { return (((a & 0xFF00FF00u) + (b & 0xFF00FF00u)) & 0xFF00FF00u) | (((a & 0x00FF00FFu) + (b & 0x00FF00FFu)) & 0x00FF00FFu); }
-__host__ __device__ static inline uint32_t lavg(uint32_t a, uint32_t b) { return (((a ^ b) & 0xFEFEFEFEu) >> 1) + (a & b); }
-__host__ __device__ static inline int labs(int v) { return v < 0 ? -v : v; }
-__host__ __device__ static inline uint32_t lclip(int v) { return v < 0 ? 0u : v > 255 ? 255u : uint32_t(v); }
-__host__ __device__ static inline uint32_t lselect(uint32_t L, uint32_t T, uint32_t TL) {
+__host__ __device__ CSW_INLINE static inline uint32_t ladd(uint32_t a, uint32_t b) { return (((a & 0xFF00FF00u) + (b & 0xFF00FF00u)) & 0xFF00FF00u) | (((a & 0x00FF00FFu) + (b & 0x00FF00FFu)) & 0x00FF00FFu); }
+__host__ __device__ CSW_INLINE static inline uint32_t lavg(uint32_t a, uint32_t b) { return (((a ^ b) & 0xFEFEFEFEu) >> 1) + (a & b); }
+__host__ __device__ CSW_INLINE static inline int labs(int v) { return v < 0 ? -v : v; }
+__host__ __device__ CSW_INLINE static inline uint32_t lclip(int v) { return v < 0 ? 0u : v > 255 ? 255u : uint32_t(v); }
+__host__ __device__ CSW_INLINE static inline uint32_t lselect(uint32_t L, uint32_t T, uint32_t TL) {
     int pl = 0, pt = 0;   // distance of the gradient estimate L + T - TL to L and to T
     for (int s = 0; s < 32; s += 8) { const int l = int((L >> s) & 255u), t = int((T >> s) & 255u), tl = int((TL >> s) & 255u); pl += labs(t - tl); pt += labs(l - tl); }
     return pl < pt ? L : T;
 }
-__host__ __device__ static inline uint32_t lclamp_full(uint32_t a, uint32_t b, uint32_t c) {
+__host__ __device__ CSW_INLINE static inline uint32_t lclamp_full(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r = 0;
     for (int s = 0; s < 32; s += 8) r |= lclip(int((a >> s) & 255u) + int((b >> s) & 255u) - int((c >> s) & 255u)) << s;
     return r;
 }
-__host__ __device__ static inline uint32_t lclamp_half(uint32_t a, uint32_t b) {
+__host__ __device__ CSW_INLINE static inline uint32_t lclamp_half(uint32_t a, uint32_t b) {
     uint32_t r = 0;
     for (int s = 0; s < 32; s += 8) { const int x = int((a >> s) & 255u), y = int((b >> s) & 255u); r |= lclip(x + (x - y) / 2) << s; }
     return r;
 }
-__host__ __device__ static inline uint32_t lpredict_vals(int mode, uint32_t L, uint32_t T, uint32_t TR, uint32_t TL) {
+__host__ __device__ CSW_INLINE static inline uint32_t lpredict_vals(int mode, uint32_t L, uint32_t T, uint32_t TR, uint32_t TL) {
     switch (mode) {
     case 0: return 0xFF000000u;
     case 1: return L;
@@ -209,23 +248,53 @@ __host__ __device__ static inline uint32_t lpredict_vals(int mode, uint32_t L, u
     default: return 0xFF000000u;   // modes 14, 15: libwebp treats them as "black"
     }
 }
-__host__ __device__ static inline uint32_t lpredict(int mode, const uint32_t *px, int w) {   // px: the pixel being decoded, in a frame of width w
+__host__ __device__ CSW_INLINE static inline uint32_t lpredict(int mode, const uint32_t *px, int w) {   // px: the pixel being decoded, in a frame of width w
     return lpredict_vals(mode, px[-1], px[-w], px[-w + 1], px[-w - 1]);
 }
 
 struct LTransform { int type, bits; uint32_t xsize; uint32_t *data; uint32_t ncolors; };
 
+// What the pixel loop touches per symbol, kept close (LDS in the kernel; one lane walks the stream, and a look-up in the arena is a round trip to the memory
+// system): the colour cache, the distance map, and the prefix-code groups in use -- a direct-mapped cache of L_SLOTS groups (their descriptions and their
+// 256-entry tables; the symbols of codes longer than 8 bits stay in the arena).
+enum { L_SLOTS = 8 };
+struct LHot {
+    uint32_t cache[2048];
+    uint16_t lut[L_SLOTS][5][256];
+    LCode code[L_SLOTS][5];
+    uint32_t tag[L_SLOTS];      // group index + 1 held by the slot (0: none)
+    uint8_t plane[120];
+    alignas(16) uint8_t win[L_WIN + 64];   // the bit reader's window of the stream
+};
 struct LDec {
     LBits br;
     LArena ar;
-    uint32_t *cache;      // 2048 entries
+    LHot *hot;
+    uint32_t *cache;      // 2048 entries (hot->cache)
     uint8_t *lengths;     // scratch: 2328 bytes
-    uint8_t plane[120];
+    uint8_t *plane;       // hot->plane
 };
+// a symbol of code k of the group in slot `sl`
+__host__ __device__ CSW_INLINE static inline int lsym_hot(LBits &br, const LHot &h, int sl, int k, const uint16_t *arena) {
+    const LCode &c = h.code[sl][k];
+    if (c.nsym <= 1) return c.single;
+    if (c.lut != 0xFFFFFFFFu) {
+        const uint16_t e = h.lut[sl][k][br.peek(8)];
+        if (e) { br.drop(e >> 12); return e & 0xFFF; }
+    }
+    uint32_t code = 0;
+    for (int len = 1; len <= 15; len++) {
+        code = (code << 1) | br.read(1);
+        const uint32_t d = code - c.first_code[len];
+        if (d < c.count[len]) return arena[c.syms + c.first_idx[len] + d];
+    }
+    br.eos = true;   // cannot happen with a complete code
+    return 0;
+}
 
 // entropy-coded ARGB image of xs x ys pixels into out.  level0: the meta prefix image may be present (meta_buf holds it).
 template <bool level0>
-__host__ __device__ static inline int ldecode_pixels(LDec &d, uint32_t xs, uint32_t ys, uint32_t *out, uint32_t *meta_buf, uint64_t meta_cap) {
+__host__ __device__ CSW_INLINE static inline int ldecode_pixels(LDec &d, uint32_t xs, uint32_t ys, uint32_t *out, uint32_t *meta_buf, uint64_t meta_cap) {
     LBits &br = d.br;
     int cache_bits = 0;
     if (br.read(1)) { cache_bits = int(br.read(4)); if (cache_bits < 1 || cache_bits > 11) return 1; }
@@ -263,22 +332,39 @@ __host__ __device__ static inline int ldecode_pixels(LDec &d, uint32_t xs, uint3
     uint64_t pos = 0;
     uint32_t x = 0, y = 0;
     const uint32_t pmask = prec ? (1u << prec) - 1 : 0xFFFFFFFFu;
-    const LGroup *grp = &groups[0];
-    auto pick = [&]() { if (prec) grp = &groups[meta_buf[uint64_t(y >> prec) * mw + (x >> prec)]]; };
-    auto put_cache = [&](uint32_t v) { if (cache_bits) d.cache[(0x1E35A7BDu * v) >> (32 - cache_bits)] = v; };
-    pick();
+    LHot &hot = *d.hot;
     const uint16_t *A = d.ar.base;
+    for (int i = 0; i < L_SLOTS; i++) hot.tag[i] = 0;
+    int sl = 0;
+    auto load_group = [&](uint32_t g) {   // group g into its slot, unless it is there
+        sl = int(g & uint32_t(L_SLOTS - 1));
+        if (hot.tag[sl] == g + 1) return;
+        hot.tag[sl] = g + 1;
+        for (int k = 0; k < 5; k++) {
+            const LCode c = groups[g].c[k];
+            hot.code[sl][k] = c;
+            if (c.nsym > 1 && c.lut != 0xFFFFFFFFu) {
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(A + c.lut);   // (tables start at even arena positions: see lbuild)
+                uint32_t *dst = reinterpret_cast<uint32_t *>(hot.lut[sl][k]);
+                for (int i = 0; i < 128; i++) dst[i] = src[i];
+            }
+        }
+    };
+    auto pick = [&]() { if (prec) load_group(meta_buf[uint64_t(y >> prec) * mw + (x >> prec)]); };
+    auto put_cache = [&](uint32_t v) { if (cache_bits) d.cache[(0x1E35A7BDu * v) >> (32 - cache_bits)] = v; };
+    load_group(0);
+    pick();
     while (pos < total) {
         if ((x & pmask) == 0) pick();
-        const int code = lsym(br, grp->c[0], A);
+        const int code = lsym_hot(br, hot, sl, 0, A);
         if (code < 256) {
-            const uint32_t r = uint32_t(lsym(br, grp->c[1], A)), b = uint32_t(lsym(br, grp->c[2], A)), a = uint32_t(lsym(br, grp->c[3], A));
+            const uint32_t r = uint32_t(lsym_hot(br, hot, sl, 1, A)), b = uint32_t(lsym_hot(br, hot, sl, 2, A)), a = uint32_t(lsym_hot(br, hot, sl, 3, A));
             const uint32_t v = (a << 24) | (r << 16) | (uint32_t(code) << 8) | b;
             out[pos++] = v; put_cache(v);
             if (++x == xs) { x = 0; y++; }
         } else if (code < 256 + 24) {
             const uint32_t len = lprefix_value(br, code - 256);
-            const int ds = lsym(br, grp->c[4], A);
+            const int ds = lsym_hot(br, hot, sl, 4, A);
             const uint32_t dcode = lprefix_value(br, ds);
             uint64_t dist;
             if (dcode > 120) dist = dcode - 120;
@@ -304,13 +390,25 @@ __host__ __device__ static inline int ldecode_pixels(LDec &d, uint32_t xs, uint3
     return 0;
 }
 
-// 0 ok, 1 malformed, 2 beyond this build (work area exhausted), 3 the picture is not opaque and the caller gave no room for its alpha.
-// headerless: the stream of an ALPH chunk -- no signature, no sizes (W x H are the picture's); its green channel is the alpha plane and goes to aplane.
-// Otherwise rgb gets the colour; a picture that is not opaque also fills rgba (interleaved) and aplane and sets *has_alpha.
-__host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *rgb, uint64_t file_bytes, bool headerless = false,
-                                                        uint8_t *rgba = nullptr, uint8_t *aplane = nullptr, uint32_t *has_alpha = nullptr) {
+// what the entropy layer leaves for the pixel stages (vp8l_transform_step, vp8l_output_*): the transforms in the order they were read, in the work area
+struct LTrRec { uint32_t type, bits, xsize, ncolors; };
+struct LFrame { uint32_t ntr, xs, alph_filter, alph_raw; LTrRec tr[4]; };
+struct LWork { uint32_t *frame0, *frame1, *subimg[3], *palette; LFrame *info; uint64_t npx, sub; };
+__host__ __device__ CSW_INLINE static inline LWork lwork(uint8_t *work, uint32_t W, uint32_t H) {
+    LWork w;
+    w.npx = uint64_t(W) * H; w.sub = vp8l_sub_pixels(W, H);
+    w.frame0 = reinterpret_cast<uint32_t *>(work); w.frame1 = w.frame0 + w.npx;
+    w.subimg[0] = w.frame1 + w.npx; w.subimg[1] = w.subimg[0] + w.sub; w.subimg[2] = w.subimg[1] + w.sub;
+    w.palette = w.subimg[2] + w.sub;
+    w.info = reinterpret_cast<LFrame *>(w.palette + 256);   // (8 KiB here were the colour cache's before it moved to the hot set)
+    return w;
+}
+// The entropy layer of one VP8L stream -- ONE lane: transforms' sub-images, palette, then the picture into frame0, all still transformed; leaves LFrame.
+// 0 ok, 1 malformed, 2 beyond this build (work area exhausted).  headerless: the stream of an ALPH chunk -- no signature, no sizes (W x H are the picture's).
+__host__ __device__ CSW_INLINE static inline int vp8l_entropy(const uint8_t *data, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint64_t file_bytes, bool headerless, LHot *hot) {
     LDec d;
-    d.br.init(data, n);
+    d.hot = hot;
+    d.br.init(data, n, hot->win);
     LBits &br = d.br;
     if (!headerless) {
         if (br.read(8) != 0x2F) return 1;
@@ -318,14 +416,14 @@ __host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, siz
         br.read(1);   // alpha_is_used: a hint; the pixels decide
         if (br.read(3) != 0 || w != W || h != H) return 1;
     }
-    const uint64_t npx = uint64_t(W) * H, sub = vp8l_sub_pixels(W, H);
-    uint32_t *frame0 = reinterpret_cast<uint32_t *>(work), *frame1 = frame0 + npx;
-    uint32_t *subimg[3] = {frame1 + npx, frame1 + npx + sub, frame1 + npx + 2 * sub};
-    uint32_t *palette = subimg[2] + sub;
-    d.cache = palette + 256;
-    d.ar.base = reinterpret_cast<uint16_t *>(d.cache + 2048);
+    const LWork lw = lwork(work, W, H);
+    const uint64_t sub = lw.sub;
+    uint32_t *frame0 = lw.frame0, *const *subimg = lw.subimg, *palette = lw.palette;
+    d.cache = hot->cache;
+    d.ar.base = reinterpret_cast<uint16_t *>(palette + 256 + 2048);   // (the 8 KiB in between were the colour cache's before it moved to the hot set)
     d.ar.cap = vp8l_arena_bytes(file_bytes) / 2 - 2328 / 2 - 8; d.ar.used = 0;
     d.lengths = reinterpret_cast<uint8_t *>(d.ar.base + d.ar.cap);
+    d.plane = hot->plane;
     lplane_table(d.plane);
     // ---- transforms, in the order they are undone LAST to FIRST
     LTransform tr[4];
@@ -365,112 +463,129 @@ __host__ __device__ static inline int vp8l_decode_frame(const uint8_t *data, siz
         const int rc = ldecode_pixels<true>(d, xs, H, frame0, subimg[2], sub);
         if (rc) return rc;
     }
-    // ---- inverse transforms
-    uint32_t *cur = frame0, *other = frame1;
-    for (int k = ntr - 1; k >= 0; k--) {
-        const LTransform &t = tr[k];
-        const uint32_t tw = t.xsize;
-        if (t.type == 2) {
-            const uint64_t cnt = uint64_t(tw) * H;
-            for (uint64_t i = 0; i < cnt; i++) { const uint32_t v = cur[i], g = (v >> 8) & 255u; cur[i] = (v & 0xFF00FF00u) | ((((v & 0x00FF00FFu) + ((g << 16) | g))) & 0x00FF00FFu); }
-        } else if (t.type == 1) {
-            const uint32_t bw = (tw + (1u << t.bits) - 1) >> t.bits;
-            for (uint32_t y = 0; y < H; y++)
-                for (uint32_t x = 0; x < tw; x++) {
-                    const uint32_t m = t.data[uint64_t(y >> t.bits) * bw + (x >> t.bits)];
-                    const int8_t g2r = int8_t(m & 255u), g2b = int8_t((m >> 8) & 255u), r2b = int8_t((m >> 16) & 255u);
-                    uint32_t &p = cur[uint64_t(y) * tw + x];
-                    const int8_t green = int8_t((p >> 8) & 255u);
-                    int nr = int((p >> 16) & 255u), nb = int(p & 255u);
-                    nr = (nr + ((int(g2r) * int(green)) >> 5)) & 255;
-                    nb = (nb + ((int(g2b) * int(green)) >> 5) + ((int(r2b) * int(int8_t(nr))) >> 5)) & 255;
-                    p = (p & 0xFF00FF00u) | (uint32_t(nr) << 16) | uint32_t(nb);
-                }
-        } else if (t.type == 0) {
-            const uint32_t bw = (tw + (1u << t.bits) - 1) >> t.bits;
-            cur[0] = ladd(cur[0], 0xFF000000u);
-            for (uint32_t x = 1; x < tw; x++) cur[x] = ladd(cur[x], cur[x - 1]);
-            for (uint32_t y = 1; y < H; y++) {
-                uint32_t *row = cur + uint64_t(y) * tw;
-                row[0] = ladd(row[0], row[-int64_t(tw)]);
-                for (uint32_t x = 1; x < tw; x++) {
-                    const int mode = int((t.data[uint64_t(y >> t.bits) * bw + (x >> t.bits)] >> 8) & 15u);
-                    row[x] = ladd(row[x], lpredict(mode, row + x, int(tw)));
-                }
-            }
-        } else {
-            // colour indexing: the frame holds 1 << bits indices per pixel (bits > 0), the low ones first
-            const uint32_t pw = (tw + (1u << t.bits) - 1) >> t.bits;
-            const int per = 1 << t.bits, nb = 8 >> t.bits;
-            for (uint32_t y = 0; y < H; y++)
-                for (uint32_t x = 0; x < tw; x++) {
-                    const uint32_t packed = (cur[uint64_t(y) * pw + (x >> t.bits)] >> 8) & 255u;
-                    const uint32_t idx = t.bits ? (packed >> (nb * int(x & uint32_t(per - 1)))) & ((1u << nb) - 1u) : packed;
-                    other[uint64_t(y) * tw + x] = idx < t.ncolors ? t.data[idx] : 0u;
-                }
-            uint32_t *sw = cur; cur = other; other = sw;
-            xs = tw;
-        }
-    }
-    if (headerless) {   // an alpha plane travelling in the green channel
-        for (uint64_t i = 0; i < npx; i++) aplane[i] = uint8_t(cur[i] >> 8);
-        return 0;
-    }
-    // ---- ARGB -> RGB for the three-channel encoders; a picture that is not opaque leaves RGBA and its alpha plane as well
-    uint32_t amin = 255;
-    for (uint64_t i = 0; i < npx; i++) {
-        const uint32_t v = cur[i];
-        rgb[3 * i] = uint8_t(v >> 16); rgb[3 * i + 1] = uint8_t(v >> 8); rgb[3 * i + 2] = uint8_t(v);
-        if ((v >> 24) < amin) amin = v >> 24;
-    }
-    if (amin == 255) return 0;
-    if (!rgba || !aplane) return 3;
-    for (uint64_t i = 0; i < npx; i++) {
-        const uint32_t v = cur[i];
-        rgba[4 * i] = uint8_t(v >> 16); rgba[4 * i + 1] = uint8_t(v >> 8); rgba[4 * i + 2] = uint8_t(v); rgba[4 * i + 3] = uint8_t(v >> 24);
-        aplane[i] = uint8_t(v >> 24);
-    }
-    if (has_alpha) *has_alpha = 1;
+    LFrame &f = *lw.info;
+    f.ntr = uint32_t(ntr); f.xs = xs; f.alph_filter = 0; f.alph_raw = 0;
+    for (int k = 0; k < ntr; k++) { f.tr[k].type = uint32_t(tr[k].type); f.tr[k].bits = uint32_t(tr[k].bits); f.tr[k].xsize = tr[k].xsize; f.tr[k].ncolors = tr[k].ncolors; }
     return 0;
 }
 
+// ---- the pixel stages: every lane of the picture's workgroup (k_vp8l_pixels).  The transforms are undone last to first; undo slot j is transform ntr - 1 - j.
+// Subtract-green, cross-colour and colour indexing are a pass over the pixels each (one step); the predictor is a wave front over the rows: a pixel needs its
+// left, upper, upper-left and upper-RIGHT neighbours, so row r takes the L_CHUNK pixels from L_CHUNK (t - r) - r in step t -- one pixel behind the row above
+// for every row, vp8l_pred_steps(W, H) steps in all.
+enum { L_CHUNK = 8 };
+__host__ __device__ CSW_INLINE static inline uint32_t vp8l_pred_steps(uint32_t W, uint32_t H) { return H + (W + H + L_CHUNK - 1) / L_CHUNK + 2; }
+// the frame the undo slot j reads (colour indexing, undone at most once, writes the other one)
+__host__ __device__ CSW_INLINE static inline bool vp8l_swapped_before(const LFrame &f, int j) {
+    for (int i = 0; i < j && i < int(f.ntr); i++) if (f.tr[f.ntr - 1 - uint32_t(i)].type == 3) return true;
+    return false;
+}
+__host__ __device__ CSW_INLINE static inline void vp8l_transform_step(const LWork &lw, uint32_t H, int j, uint32_t step, uint32_t tid, uint32_t nlanes) {
+    const LFrame &f = *lw.info;
+    const LTrRec t = f.tr[f.ntr - 1 - uint32_t(j)];
+    const bool sw = vp8l_swapped_before(f, j);
+    uint32_t *cur = sw ? lw.frame1 : lw.frame0, *other = sw ? lw.frame0 : lw.frame1;
+    const uint32_t tw = t.xsize;
+    if (t.type == 2) {
+        if (step) return;
+        const uint64_t cnt = uint64_t(tw) * H;
+        for (uint64_t i = tid; i < cnt; i += nlanes) { const uint32_t v = cur[i], g = (v >> 8) & 255u; cur[i] = (v & 0xFF00FF00u) | ((((v & 0x00FF00FFu) + ((g << 16) | g))) & 0x00FF00FFu); }
+    } else if (t.type == 1) {
+        if (step) return;
+        const uint32_t bw = (tw + (1u << t.bits) - 1) >> t.bits;
+        const uint32_t *data = lw.subimg[1];
+        const uint64_t cnt = uint64_t(tw) * H;
+        for (uint64_t i = tid; i < cnt; i += nlanes) {
+            const uint32_t y = uint32_t(i / tw), x = uint32_t(i - uint64_t(y) * tw);
+            const uint32_t m = data[uint64_t(y >> t.bits) * bw + (x >> t.bits)];
+            const int8_t g2r = int8_t(m & 255u), g2b = int8_t((m >> 8) & 255u), r2b = int8_t((m >> 16) & 255u);
+            const uint32_t p = cur[i];
+            const int8_t green = int8_t((p >> 8) & 255u);
+            int nr = int((p >> 16) & 255u), nb = int(p & 255u);
+            nr = (nr + ((int(g2r) * int(green)) >> 5)) & 255;
+            nb = (nb + ((int(g2b) * int(green)) >> 5) + ((int(r2b) * int(int8_t(nr))) >> 5)) & 255;
+            cur[i] = (p & 0xFF00FF00u) | (uint32_t(nr) << 16) | uint32_t(nb);
+        }
+    } else if (t.type == 0) {
+        const uint32_t bw = (tw + (1u << t.bits) - 1) >> t.bits;
+        const uint32_t *data = lw.subimg[0];
+        for (uint32_t r = tid; r < H; r += nlanes) {
+            const int64_t x0 = int64_t(L_CHUNK) * (int64_t(step) - int64_t(r)) - int64_t(r);
+            if (x0 + L_CHUNK <= 0 || x0 >= int64_t(tw)) continue;
+            const uint32_t xa = x0 < 0 ? 0u : uint32_t(x0), xb = x0 + L_CHUNK > int64_t(tw) ? tw : uint32_t(x0 + L_CHUNK);
+            uint32_t *row = cur + uint64_t(r) * tw;
+            for (uint32_t x = xa; x < xb; x++) {
+                uint32_t pred;
+                if (r == 0) pred = x == 0 ? 0xFF000000u : row[x - 1];
+                else if (x == 0) pred = row[-int64_t(tw)];
+                else pred = lpredict(int((data[uint64_t(r >> t.bits) * bw + (x >> t.bits)] >> 8) & 15u), row + x, int(tw));
+                row[x] = ladd(row[x], pred);
+            }
+        }
+    } else {
+        // colour indexing: the frame holds 1 << bits indices per pixel (bits > 0), the low ones first
+        if (step) return;
+        const uint32_t pw = (tw + (1u << t.bits) - 1) >> t.bits;
+        const int per = 1 << t.bits, nb = 8 >> t.bits;
+        const uint64_t cnt = uint64_t(tw) * H;
+        for (uint64_t i = tid; i < cnt; i += nlanes) {
+            const uint32_t y = uint32_t(i / tw), x = uint32_t(i - uint64_t(y) * tw);
+            const uint32_t packed = (cur[uint64_t(y) * pw + (x >> t.bits)] >> 8) & 255u;
+            const uint32_t idx = t.bits ? (packed >> (nb * int(x & uint32_t(per - 1)))) & ((1u << nb) - 1u) : packed;
+            other[i] = idx < t.ncolors ? lw.palette[idx] : 0u;
+        }
+    }
+}
+// the finished ARGB frame
+__host__ __device__ CSW_INLINE static inline const uint32_t *vp8l_result(const LWork &lw) { return vp8l_swapped_before(*lw.info, int(lw.info->ntr)) ? lw.frame1 : lw.frame0; }
+
 // The ALPH chunk of a lossy file (WebP container specification): a header byte -- compression in bits 0-1 (0 raw, 1 a headerless VP8L stream), filter in bits
 // 2-3 (none, horizontal, vertical, gradient), pre-processing in bits 4-5 (nothing to undo) -- then the plane; the filters predict a sample from its left /
-// upper neighbours as libwebp's unfilters do (first row: from the left, first sample 0; first sample of a later row: from the one above).  0 ok, else as above.
-__host__ __device__ static inline int alph_decode(const uint8_t *d, size_t n, uint32_t W, uint32_t H, uint8_t *work, uint8_t *aplane) {
+// upper neighbours as libwebp's unfilters do (first row: from the left, first sample 0; first sample of a later row: from the one above).
+// alph_entropy: ONE lane; 0 ok, else as vp8l_entropy.  The plane itself is made by the pixel stages: the transforms, then alph_plane_step (green channel or the
+// raw bytes into aplane), then alph_unfilter_step as a wave front like the predictor's (a sample needs its left, upper and upper-left neighbours).
+__host__ __device__ CSW_INLINE static inline int alph_entropy(const uint8_t *d, size_t n, uint32_t W, uint32_t H, uint8_t *work, LHot *hot) {
     if (n < 1) return 1;
     const int method = d[0] & 3, filter = (d[0] >> 2) & 3, pre = (d[0] >> 4) & 3, rsrv = (d[0] >> 6) & 3;
     const uint64_t npx = uint64_t(W) * H;
     if (method > 1 || pre > 1 || rsrv > 1) return 1;
+    LFrame &f = *lwork(work, W, H).info;
     if (method == 0) {
         if (uint64_t(n - 1) < npx) return 1;
-        for (uint64_t i = 0; i < npx; i++) aplane[i] = d[1 + i];
+        f.ntr = 0; f.xs = W; f.alph_raw = 1;
     } else {
-        const int rc = vp8l_decode_frame(d + 1, n - 1, W, H, work, nullptr, n - 1, true, nullptr, aplane, nullptr);
+        const int rc = vp8l_entropy(d + 1, n - 1, W, H, work, n - 1, true, hot);
         if (rc) return rc;
     }
-    if (filter == 0) return 0;
-    for (uint32_t y = 0; y < H; y++) {
-        uint8_t *row = aplane + uint64_t(y) * W;
-        const uint8_t *prev = y ? row - W : nullptr;
-        if (!prev || filter == 1) {   // horizontal (and every filter's first row)
-            uint32_t pred = prev ? prev[0] : 0u;
-            for (uint32_t x = 0; x < W; x++) { pred = (pred + row[x]) & 255u; row[x] = uint8_t(pred); }
-        } else if (filter == 2) {
-            for (uint32_t x = 0; x < W; x++) row[x] = uint8_t(row[x] + prev[x]);
-        } else {
-            int top = prev[0], top_left = top, left = top;
-            for (uint32_t x = 0; x < W; x++) {
-                top = prev[x];
-                int g = left + top - top_left;
-                g = g < 0 ? 0 : g > 255 ? 255 : g;
-                left = (int(row[x]) + g) & 255;
-                top_left = top;
-                row[x] = uint8_t(left);
+    f.alph_filter = uint32_t(filter);
+    return 0;
+}
+__host__ __device__ CSW_INLINE static inline void alph_plane_step(const LWork &lw, const uint8_t *chunk, uint8_t *aplane, uint32_t tid, uint32_t nlanes) {
+    if (lw.info->alph_raw) { for (uint64_t i = tid; i < lw.npx; i += nlanes) aplane[i] = chunk[1 + i]; return; }
+    const uint32_t *cur = vp8l_result(lw);
+    for (uint64_t i = tid; i < lw.npx; i += nlanes) aplane[i] = uint8_t(cur[i] >> 8);   // the plane travels in the green channel
+}
+__host__ __device__ CSW_INLINE static inline void alph_unfilter_step(const LWork &lw, uint8_t *aplane, uint32_t W, uint32_t H, uint32_t step, uint32_t tid, uint32_t nlanes) {
+    const uint32_t filter = lw.info->alph_filter;
+    if (!filter) return;
+    for (uint32_t r = tid; r < H; r += nlanes) {
+        const int64_t x0 = int64_t(L_CHUNK) * (int64_t(step) - int64_t(r)) - int64_t(r);
+        if (x0 + L_CHUNK <= 0 || x0 >= int64_t(W)) continue;
+        const uint32_t xa = x0 < 0 ? 0u : uint32_t(x0), xb = x0 + L_CHUNK > int64_t(W) ? W : uint32_t(x0 + L_CHUNK);
+        uint8_t *row = aplane + uint64_t(r) * W;
+        const uint8_t *prev = r ? row - W : nullptr;
+        for (uint32_t x = xa; x < xb; x++) {
+            int pred;
+            if (!prev || filter == 1) pred = x ? row[x - 1] : (prev ? prev[0] : 0);   // horizontal (and every filter's first row)
+            else if (filter == 2) pred = prev[x];
+            else {   // gradient; the first sample of a row from the one above
+                const int top = prev[x], left = x ? row[x - 1] : prev[0], top_left = x ? prev[x - 1] : prev[0];
+                const int g = left + top - top_left;
+                pred = g < 0 ? 0 : g > 255 ? 255 : g;
             }
+            row[x] = uint8_t((int(row[x]) + pred) & 255);
         }
     }
-    return 0;
 }
 
 }  // namespace csw

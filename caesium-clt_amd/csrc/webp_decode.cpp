@@ -119,9 +119,15 @@ extern "C" int cswd_batch_create(const CByteArray *inputs, size_t count, int dev
 extern "C" int cswd_batch_run(cswd_batch *b) {
     if (b->imgs.empty()) { b->ran = true; return 0; }
     if (hipSetDevice(b->device) != hipSuccess) { csh_set_error("hipSetDevice failed"); return CS_ERR_NO_DEVICE; }
-    int nsteps = 0;   // of the loop filter's wave front: the largest lossy frame's columns + 2 x rows of macroblocks
-    for (const csw::Vp8In &im : b->imgs) if (!im.lossless) nsteps = std::max(nsteps, int(im.mbw + 2 * im.mbh));
-    csw::launch_vp8_decode(b->stream, b->d_pool.p, b->d_imgs.p, int(b->imgs.size()), b->d_work.p, b->d_rgb.p, nsteps);
+    int nsteps = 0, psteps_lossless = 0, psteps_alpha = 0;   // of the wave fronts: the lossy frames' mbw + 2 mbh; the lossless pictures' and the alpha planes' predictor steps
+    for (const csw::Vp8In &im : b->imgs) {
+        if (im.lossless) psteps_lossless = std::max(psteps_lossless, int(csw::vp8l_pred_steps(im.width, im.height)));
+        else {
+            nsteps = std::max(nsteps, int(im.mbw + 2 * im.mbh));
+            if (im.alph_len) psteps_alpha = std::max(psteps_alpha, int(csw::vp8l_pred_steps(im.width, im.height)));
+        }
+    }
+    csw::launch_vp8_decode(b->stream, b->d_pool.p, b->d_imgs.p, int(b->imgs.size()), b->d_work.p, b->d_rgb.p, nsteps, psteps_lossless, psteps_alpha);
     if (hipMemcpyAsync(b->imgs.data(), b->d_imgs.p, b->imgs.size() * sizeof(csw::Vp8In), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
         hipStreamSynchronize(b->stream) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("VP8 decode failed on the device"); return CS_ERR_NO_DEVICE; }
     for (cswd_batch::Item &it : b->items)

@@ -41,7 +41,7 @@ void launch_vp8l_encode(hipStream_t st, const Vp8lImg *imgs, int nimg, uint32_t 
 
 struct Vp8In;
 // lossy WebP inputs (k_webp_dec.hip): every image's VP8 key frame -> RGB in the pixel pool; imgs[i].status = 0 or an error
-void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps);
+void launch_vp8_decode(hipStream_t st, const uint8_t *pool, Vp8In *imgs, int n, uint8_t *work, uint8_t *rgb, int nsteps, int psteps_lossless, int psteps_alpha);
 void launch_rgba_join(hipStream_t st, const uint8_t *rgb, const uint8_t *alpha, uint8_t *rgba, uint64_t npx);
 
 }  // namespace csw
