@@ -276,7 +276,7 @@ struct McLds {
     uint32_t pnb[2], pmean[2][4];
     uint32_t mn[4], mx[4];
     unsigned long long total, total_err;
-    unsigned long long below;                             // pixels in front of the level / range being searched
+    unsigned long long below, below_range;                // pixels in front of the median's level; ... and of its id range (two words: the lanes of the range search read the first while one of them writes the second)
     unsigned long long best;                              // the picked box's pixels
     int nbox, pick, axis, cut, done, skip;                // cut: the median's level
     int range, cut_id, cut_incl, last_slot;               // the median's id range; the lower part ends with bin cut_id (cut_incl) or just in front of it
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(MC_LANES) k_png_mediancut(const QuantJob *jobs
             if (L.rng[tid]) {
                 unsigned long long run = L.below;
                 for (uint32_t r = 0; r < tid; r++) run += L.rng[r];
-                if (2 * run < half && 2 * (run + L.rng[tid]) >= half) { L.range = int(tid); L.below = run; }
+                if (2 * run < half && 2 * (run + L.rng[tid]) >= half) { L.range = int(tid); L.below_range = run; }
             }
             continue;
         }
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(MC_LANES) k_png_mediancut(const QuantJob *jobs
         }
         if (sub == 10) {         // the bin the lower part ends with -- or, if that is the box's last bin, ends in front of
             if (tid < 512 && L.slot[tid]) {
-                unsigned long long run = L.below;
+                unsigned long long run = L.below_range;
                 for (uint32_t k = 0; k < tid; k++) run += L.slot[k];
                 if (2 * run < half && 2 * (run + L.slot[tid]) >= half) {
                     bool is_last = true;                       // of the range; of the box if nothing lies behind the range and the level either

@@ -34,3 +34,12 @@ def test_webp_and_conversions_back_to_front(api):
     assert PW.check(api, png_cases()[:8], 70) >= 4
     JP.check(api, W.webp_cases()[:3], True, level=2)
     JP.check(api, W.webp_cases()[:3], False)
+
+
+def test_webp_inputs_back_to_front(api):
+    """the decoders' wave fronts (reconstruction, loop filter, VP8L predictor, alpha unfilter) and the per-lane output stages"""
+    import test_webp_decode_emul as WD
+    WD.test_emul_synthetic_files_decode_like_libwebp(api)
+    WD.test_emul_lossless_files_decode_like_libwebp(api)
+    WD.test_emul_transparent_files_decode_like_libwebp(api)
+
