@@ -3,7 +3,7 @@
 # __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
-HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip"
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip"
 CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp vp8l_encode.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
     $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
