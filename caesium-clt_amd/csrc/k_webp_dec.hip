@@ -23,12 +23,19 @@ namespace csw {
 union ParseLds { Vp8Hot hot; LHot lossless; };
 __global__ void __launch_bounds__(64) k_webp_parse(const uint8_t *pool, Vp8In *imgs, uint8_t *work, int mode) {
     CSH_SHARED ParseLds lds;
+#ifdef CSH_EMUL
     if (threadIdx.x != 0) return;
+#endif
     Vp8In &im = imgs[blockIdx.x];
     uint8_t *wk = work + im.work_off;
+    if (mode == 0 && !im.lossless) {   // the whole wave walks the frame in step (vp8_dec.h, CSW_U): every lane the same values and the same stores
+        im.has_alpha = 0;
+        im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, im.width, im.height, wk, lds.hot, im.debug));
+        return;
+    }
+    if (threadIdx.x != 0) return;
     if (mode == 0) {
         im.has_alpha = 0;
-        if (!im.lossless) { im.status = uint32_t(vp8_parse_frame(pool + im.data_off, im.data_len, im.width, im.height, wk, lds.hot, im.debug)); return; }
         im.status = uint32_t(vp8l_entropy(pool + im.data_off, im.data_len, im.width, im.height, wk, im.data_len, false, &lds.lossless));
         return;
     }

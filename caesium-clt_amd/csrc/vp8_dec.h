@@ -13,7 +13,12 @@
 #ifdef CSH_EMUL
 #define CSW_INLINE
 #define CSW_NOUNROLL
+#define CSW_U(x) (x)
 #else
+// a value every lane of the wave holds alike, moved to a scalar register: what is computed from it then runs on the scalar unit.  The parse is ONE chain of
+// dependent operations; as vector instructions of a wave with one live lane each costs ~8 cycles, as scalar instructions a fraction of that -- so the
+// whole wave walks the chain in step (every lane the same values, the same stores) and the loaded values are declared uniform here.
+#define CSW_U(x) (static_cast<decltype(x)>(__builtin_amdgcn_readfirstlane(static_cast<int>(x))))
 #define CSW_INLINE __attribute__((always_inline))
 #define CSW_NOUNROLL _Pragma("clang loop unroll(disable)")   // (the coefficient reader is inlined: one copy per call site, not per block)
 #endif
@@ -53,6 +58,7 @@ struct BoolDec {
         uint32_t w;
         if (end - p >= 4) { w = (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); p += 4; }
         else { w = 0; for (int i = 0; i < 4; i++) w = (w << 8) | (p < end ? uint32_t(*p++) : 0u); }
+        w = CSW_U(w);
         value = (value << 32) | w; nbits += 32; loaded += 4;
     }
     __host__ __device__ CSW_INLINE void init(const uint8_t *d, size_t n) {
@@ -61,6 +67,7 @@ struct BoolDec {
         refill();
     }
     __host__ __device__ CSW_INLINE int get(int prob) {
+        prob = CSW_U(prob);
         if (nbits < 8) refill();
         const uint32_t split = 1u + (((range - 1u) * uint32_t(prob)) >> 8);
         const uint32_t top = uint32_t(value >> nbits);
@@ -344,11 +351,14 @@ __host__ __device__ CSW_INLINE static inline int vp8_parse_frame(const uint8_t *
     }
     br.get(128);                                             // refresh_entropy_probs: a single frame
     // coefficient probabilities, and the constant tables of the hot loop next to them
+    CSW_NOUNROLL
     for (int i = 0; i < 4 * 8 * 3 * 11; i++) hot.probs[i] = br.get(kVp8CoefUpdateProbs[i]) ? uint8_t(br.lit(8)) : kVp8CoefProbs[i];
+    CSW_NOUNROLL
     for (int i = 0; i < 10 * 10 * 9; i++) hot.bmode[i] = kVp8BModeProbs[i];
     for (int i = 0; i < 17; i++) hot.bands[i] = kVp8Bands[i];
     for (int i = 0; i < 16; i++) hot.zigzag[i] = kVp8Zigzag[i];
     for (int i = 0; i < 12; i++) { hot.cat[0][i] = i < 4 ? kVp8Cat3[i] : 0; hot.cat[1][i] = i < 5 ? kVp8Cat4[i] : 0; hot.cat[2][i] = i < 6 ? kVp8Cat5[i] : 0; hot.cat[3][i] = kVp8Cat6[i]; }
+    CSW_NOUNROLL
     for (int k = 0; k < 25 * 16; k++) hot.coef[k] = 0;
     const bool use_skip = br.get(128) != 0;
     const int skip_p = use_skip ? int(br.lit(8)) : 0;
@@ -492,9 +502,11 @@ __host__ __device__ CSW_INLINE static inline int vp8_parse_frame(const uint8_t *
                 pl.rec[mb] = r;
                 uint4 *dst = reinterpret_cast<uint4 *>(pl.mbcoef + mb * 384);
                 const uint4 *src = reinterpret_cast<const uint4 *>(coef);
+                CSW_NOUNROLL
                 for (int k = 0; k < 24; k++) if (nzmask & (1u << k)) { dst[2 * k] = src[2 * k]; dst[2 * k + 1] = src[2 * k + 1]; }
             }
             // the coefficient store goes back to all zeros: only blocks in nzmask hold anything
+            CSW_NOUNROLL
             for (int k = 0; k < 24; k++) if (nzmask & (1u << k)) for (int q = 0; q < 16; q++) coef[16 * k + q] = 0;
         }
         tok[my & uint32_t(nparts - 1)] = tb;

@@ -13,8 +13,16 @@
 // everything of the decoders is inlined into its kernel: only then does the compiler see which pointers are LDS (ds_read instead of flat_load)
 #ifdef CSH_EMUL
 #define CSW_INLINE
+#define CSW_NOINLINE
+#ifndef CSW_NOUNROLL
+#define CSW_NOUNROLL
+#endif
 #else
 #define CSW_INLINE __attribute__((always_inline))
+#ifndef CSW_NOUNROLL
+#define CSW_NOUNROLL _Pragma("clang loop unroll(disable)")
+#endif
+#define CSW_NOINLINE __attribute__((noinline))   // set-up paths: a copy per call site would push the hot loop out of the instruction cache
 #endif
 namespace csw {
 
@@ -29,7 +37,25 @@ __host__ __device__ CSW_INLINE static inline uint64_t vp8l_work_bytes(uint32_t w
 
 // LSB-first bit reader.  The stream is read through a window of L_WIN bytes kept close (LDS in the kernel): one lane walks the stream, and fetching
 // it from the memory system eight bytes at a time was a round trip every other pixel; the window is refilled 256 words at a stretch.
+// fills a bit reader's window (L_WIN + 64 bytes at `win`) from stream position `at` on; returns the stream position of win[0].  Not inlined -- a copy per
+// refill site would push the pixel loop out of the instruction cache -- and called with values, so that the reader itself stays in registers.
 enum { L_WIN = 1024 };
+__host__ __device__ CSW_NOINLINE static uint32_t lwin_load(const uint8_t *data, uint32_t len, uint8_t *win, uint32_t at) {
+    const uint32_t mis = uint32_t((reinterpret_cast<uintptr_t>(data) + at) & 15u);   // the window starts at a 16-byte boundary of memory at or in front of `at`
+    const uint32_t wstart = at >= mis ? at - mis : 0u;
+    const uint8_t *src = data + wstart;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && wstart + L_WIN + 16 <= len) {   // 64 bytes per step, the four loads in flight together (the files' streams start at
+        for (uint32_t i = 0; i < L_WIN + 16; i += 64) {                                    // multiples of 16 in the pool); a load per word would be a memory round trip per word
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src + i);
+            const uint4 a = s4[0], b = s4[1], c = s4[2], d = s4[3];
+            uint4 *d4 = reinterpret_cast<uint4 *>(win + i);
+            d4[0] = a; d4[1] = b; d4[2] = c; d4[3] = d;
+        }
+        return wstart;
+    }
+    for (uint32_t i = 0; i < L_WIN + 16; i++) win[i] = wstart + i < len ? src[i] : uint8_t(0);   // the ragged end of a stream, or its very start
+    return wstart;
+}
 struct LBits {
     const uint8_t *data;
     uint8_t *win;          // L_WIN + 64 bytes, 16-byte aligned
@@ -38,21 +64,7 @@ struct LBits {
     uint64_t val;
     int nbits;
     bool eos;
-    __host__ __device__ CSW_INLINE void load_window(uint32_t at) {
-        const uint32_t mis = uint32_t((reinterpret_cast<uintptr_t>(data) + at) & 15u);   // the window starts at a 16-byte boundary of memory at or in front of `at`
-        wstart = at >= mis ? at - mis : 0u;
-        const uint8_t *src = data + wstart;
-        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && wstart + L_WIN + 16 <= len) {   // 64 bytes per step, the four loads in flight together (the files' streams start at
-            for (uint32_t i = 0; i < L_WIN + 16; i += 64) {                                    // multiples of 16 in the pool); a load per word would be a memory round trip per word
-                const uint4 *s4 = reinterpret_cast<const uint4 *>(src + i);
-                const uint4 a = s4[0], b = s4[1], c = s4[2], d = s4[3];
-                uint4 *d4 = reinterpret_cast<uint4 *>(win + i);
-                d4[0] = a; d4[1] = b; d4[2] = c; d4[3] = d;
-            }
-            return;
-        }
-        for (uint32_t i = 0; i < L_WIN + 16; i++) win[i] = wstart + i < len ? src[i] : uint8_t(0);   // the ragged end of a stream, or its very start
-    }
+    __host__ __device__ CSW_INLINE void load_window(uint32_t at) { wstart = lwin_load(data, len, win, at); }
     __host__ __device__ CSW_INLINE void init(const uint8_t *d, size_t n, uint8_t *window) { data = d; win = window; len = uint32_t(n); pos = 0; val = 0; nbits = 0; eos = false; load_window(0); }
     __host__ __device__ CSW_INLINE void fill() {
         if (pos >= len) return;
@@ -100,7 +112,7 @@ __host__ __device__ CSW_INLINE static inline int lsym(LBits &br, const LCode &c,
 }
 
 // lengths[0..n) -> code.  false: not a complete prefix code (or no room for its symbols)
-__host__ __device__ CSW_INLINE static inline bool lbuild(const uint8_t *lengths, int n, LCode &c, LArena &ar, bool want_lut) {
+__host__ __device__ CSW_NOINLINE static bool lbuild(const uint8_t *lengths, int n, LCode &c, LArena &ar, bool want_lut) {
     for (int l = 0; l < 16; l++) c.count[l] = 0;
     int used = 0, last = 0;
     for (int s = 0; s < n; s++) if (lengths[s]) { c.count[lengths[s]]++; used++; last = s; }
@@ -139,7 +151,7 @@ __host__ __device__ CSW_INLINE static inline bool lbuild(const uint8_t *lengths,
 }
 
 // reads one prefix code of `alphabet` symbols (lengths: scratch of >= alphabet bytes)
-__host__ __device__ CSW_INLINE static inline bool lread_code(LBits &br, int alphabet, LCode &c, LArena &ar, uint8_t *lengths, bool want_lut) {
+__host__ __device__ CSW_NOINLINE static bool lread_code(LBits &br, int alphabet, LCode &c, LArena &ar, uint8_t *lengths, bool want_lut) {
     for (int i = 0; i < alphabet; i++) lengths[i] = 0;
     if (br.read(1)) {   // simple code: one or two symbols
         const int nsym = int(br.read(1)) + 1;
@@ -274,14 +286,15 @@ struct LDec {
     uint8_t *lengths;     // scratch: 2328 bytes
     uint8_t *plane;       // hot->plane
 };
-// a symbol of code k of the group in slot `sl`
-__host__ __device__ CSW_INLINE static inline int lsym_hot(LBits &br, const LHot &h, int sl, int k, const uint16_t *arena) {
-    const LCode &c = h.code[sl][k];
-    if (c.nsym <= 1) return c.single;
-    if (c.lut != 0xFFFFFFFFu) {
+// a symbol of code k of the group in slot `sl`.  `fl` = what the loop keeps of that code in a register (a symbol is a chain of dependent look-ups, and each
+// one in LDS costs a round trip): bit 31 the code has a single symbol (bits 0-15, costs no bits), bit 30 it has a 256-entry table
+__host__ __device__ CSW_INLINE static inline int lsym_hot(LBits &br, const LHot &h, int sl, int k, uint32_t fl, const uint16_t *arena) {
+    if (fl & 0x80000000u) return int(fl & 0xFFFFu);
+    if (fl & 0x40000000u) {
         const uint16_t e = h.lut[sl][k][br.peek(8)];
         if (e) { br.drop(e >> 12); return e & 0xFFF; }
     }
+    const LCode &c = h.code[sl][k];
     uint32_t code = 0;
     for (int len = 1; len <= 15; len++) {
         code = (code << 1) | br.read(1);
@@ -291,10 +304,14 @@ __host__ __device__ CSW_INLINE static inline int lsym_hot(LBits &br, const LHot 
     br.eos = true;   // cannot happen with a complete code
     return 0;
 }
-
-// entropy-coded ARGB image of xs x ys pixels into out.  level0: the meta prefix image may be present (meta_buf holds it).
+// An entropy-coded ARGB image of xs x ys pixels, in two halves.  lsetup_pixels (not inlined: set-up code, one copy) reads the colour-cache size, the meta prefix
+// image (level0: the picture itself may have one; meta_buf receives it) and the prefix codes of every group, into the arena.  lrun_pixels is the pixel loop;
+// it exists twice: inlined into the kernel for the picture (there the compiler knows that `hot` is LDS and that the bit reader -- a local copy nothing else
+// sees -- stays in registers), and once more inside ldecode_sub for the small images (meta prefix image, transform data, palette).
+struct LPix { int cache_bits, prec; uint32_t mw, ngroups; LGroup *groups; };
+__host__ __device__ static int ldecode_sub(LDec &d, uint32_t xs, uint32_t ys, uint32_t *out);
 template <bool level0>
-__host__ __device__ CSW_INLINE static inline int ldecode_pixels(LDec &d, uint32_t xs, uint32_t ys, uint32_t *out, uint32_t *meta_buf, uint64_t meta_cap) {
+__host__ __device__ CSW_NOINLINE static int lsetup_pixels(LDec &d, uint32_t xs, uint32_t ys, uint32_t *meta_buf, uint64_t meta_cap, LPix &px) {
     LBits &br = d.br;
     int cache_bits = 0;
     if (br.read(1)) { cache_bits = int(br.read(4)); if (cache_bits < 1 || cache_bits > 11) return 1; }
@@ -305,7 +322,7 @@ __host__ __device__ CSW_INLINE static inline int ldecode_pixels(LDec &d, uint32_
         mw = (xs + (1u << prec) - 1) >> prec;
         const uint32_t mh = (ys + (1u << prec) - 1) >> prec;
         if (uint64_t(mw) * mh > meta_cap) return 1;
-        const int rc = ldecode_pixels<false>(d, mw, mh, meta_buf, nullptr, 0);
+        const int rc = ldecode_sub(d, mw, mh, meta_buf);
         d.ar.used = arena_mark;   // the meta image's codes are done with
         if (rc) return rc;
         uint32_t mx = 0;
@@ -327,68 +344,95 @@ __host__ __device__ CSW_INLINE static inline int ldecode_pixels(LDec &d, uint32_
             if (!lread_code(br, alpha[k], groups[g].c[k], d.ar, d.lengths, want_lut)) return br.eos ? 1 : (d.ar.used + 4096 >= d.ar.cap ? 2 : 1);
         }
     }
-    if (cache_bits) for (int i = 0; i < cache_size; i++) d.cache[i] = 0;
+    px.cache_bits = cache_bits; px.prec = prec; px.mw = mw; px.ngroups = ngroups; px.groups = groups;
+    return 0;
+}
+__host__ __device__ CSW_INLINE static inline int lrun_pixels(LDec &d, LHot &hot, const LPix &px, uint32_t xs, uint32_t ys, uint32_t *out, const uint32_t *meta_buf) {
+    LBits br = d.br;        // the reader of the loop: a copy nothing else sees; handed back at the end
+    br.win = hot.win;
+    const int cache_bits = px.cache_bits, prec = px.prec;
+    const uint32_t mw = px.mw;
+    const LGroup *groups = px.groups;
+    const int cache_size = cache_bits ? 1 << cache_bits : 0;
+    uint32_t *const cache = hot.cache;
+    const uint8_t *const plane = hot.plane;
+    if (cache_bits) { CSW_NOUNROLL for (int i = 0; i < cache_size; i++) cache[i] = 0; }
     const uint64_t total = uint64_t(xs) * ys;
     uint64_t pos = 0;
     uint32_t x = 0, y = 0;
     const uint32_t pmask = prec ? (1u << prec) - 1 : 0xFFFFFFFFu;
-    LHot &hot = *d.hot;
     const uint16_t *A = d.ar.base;
     for (int i = 0; i < L_SLOTS; i++) hot.tag[i] = 0;
     int sl = 0;
+    uint32_t fl0 = 0, fl1 = 0, fl2 = 0, fl3 = 0, fl4 = 0;   // the five codes of the group in use (lsym_hot)
+    auto flags_of = [&](int k) -> uint32_t { const LCode &c = hot.code[sl][k]; return c.nsym <= 1 ? (0x80000000u | c.single) : (c.lut != 0xFFFFFFFFu ? 0x40000000u : 0u); };
+    auto take_flags = [&]() { fl0 = flags_of(0); fl1 = flags_of(1); fl2 = flags_of(2); fl3 = flags_of(3); fl4 = flags_of(4); };
     auto load_group = [&](uint32_t g) {   // group g into its slot, unless it is there
+        const int was = sl;
         sl = int(g & uint32_t(L_SLOTS - 1));
-        if (hot.tag[sl] == g + 1) return;
+        if (hot.tag[sl] == g + 1) { if (sl != was) take_flags(); return; }
         hot.tag[sl] = g + 1;
+        CSW_NOUNROLL
         for (int k = 0; k < 5; k++) {
             const LCode c = groups[g].c[k];
             hot.code[sl][k] = c;
             if (c.nsym > 1 && c.lut != 0xFFFFFFFFu) {
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(A + c.lut);   // (tables start at even arena positions: see lbuild)
                 uint32_t *dst = reinterpret_cast<uint32_t *>(hot.lut[sl][k]);
-                for (int i = 0; i < 128; i++) dst[i] = src[i];
+                CSW_NOUNROLL
+                for (int i = 0; i < 128; i += 4) { const uint32_t a = src[i], b = src[i + 1], c2 = src[i + 2], d2 = src[i + 3]; dst[i] = a; dst[i + 1] = b; dst[i + 2] = c2; dst[i + 3] = d2; }
             }
         }
+        take_flags();
     };
     auto pick = [&]() { if (prec) load_group(meta_buf[uint64_t(y >> prec) * mw + (x >> prec)]); };
-    auto put_cache = [&](uint32_t v) { if (cache_bits) d.cache[(0x1E35A7BDu * v) >> (32 - cache_bits)] = v; };
+    auto put_cache = [&](uint32_t v) { if (cache_bits) cache[(0x1E35A7BDu * v) >> (32 - cache_bits)] = v; };
     load_group(0);
     pick();
     while (pos < total) {
         if ((x & pmask) == 0) pick();
-        const int code = lsym_hot(br, hot, sl, 0, A);
+        const int code = lsym_hot(br, hot, sl, 0, fl0, A);
         if (code < 256) {
-            const uint32_t r = uint32_t(lsym_hot(br, hot, sl, 1, A)), b = uint32_t(lsym_hot(br, hot, sl, 2, A)), a = uint32_t(lsym_hot(br, hot, sl, 3, A));
+            const uint32_t r = uint32_t(lsym_hot(br, hot, sl, 1, fl1, A)), b = uint32_t(lsym_hot(br, hot, sl, 2, fl2, A)), a = uint32_t(lsym_hot(br, hot, sl, 3, fl3, A));
             const uint32_t v = (a << 24) | (r << 16) | (uint32_t(code) << 8) | b;
             out[pos++] = v; put_cache(v);
             if (++x == xs) { x = 0; y++; }
         } else if (code < 256 + 24) {
             const uint32_t len = lprefix_value(br, code - 256);
-            const int ds = lsym_hot(br, hot, sl, 4, A);
+            const int ds = lsym_hot(br, hot, sl, 4, fl4, A);
             const uint32_t dcode = lprefix_value(br, ds);
             uint64_t dist;
             if (dcode > 120) dist = dcode - 120;
             else {
-                const uint8_t e = d.plane[dcode - 1];
+                const uint8_t e = plane[dcode - 1];
                 const int64_t dd = int64_t(e >> 4) * xs + (8 - int(e & 15));
                 dist = dd < 1 ? 1 : uint64_t(dd);
             }
-            if (dist > pos || pos + len > total) return 1;
+            if (dist > pos || pos + len > total) { d.br = br; return 1; }
             for (uint32_t i = 0; i < len; i++) { const uint32_t v = out[pos - dist]; out[pos++] = v; put_cache(v); }
             x += len;
             while (x >= xs) { x -= xs; y++; }
             if (pos < total && prec) pick();
         } else {
             const int idx = code - (256 + 24);
-            if (idx >= cache_size) return 1;
-            const uint32_t v = d.cache[idx];
+            if (idx >= cache_size) { d.br = br; return 1; }
+            const uint32_t v = cache[idx];
             out[pos++] = v; put_cache(v);
             if (++x == xs) { x = 0; y++; }
         }
-        if (br.eos) return 1;
+        if (br.eos) { d.br = br; return 1; }
     }
+    d.br = br;
     return 0;
 }
+// a small image (meta prefix image, transform data, palette) from set-up to pixels; not inlined
+__host__ __device__ CSW_NOINLINE static int ldecode_sub(LDec &d, uint32_t xs, uint32_t ys, uint32_t *out) {
+    LPix px;
+    const int rc = lsetup_pixels<false>(d, xs, ys, nullptr, 0, px);
+    return rc ? rc : lrun_pixels(d, *d.hot, px, xs, ys, out, nullptr);
+}
+
+
 
 // what the entropy layer leaves for the pixel stages (vp8l_transform_step, vp8l_output_*): the transforms in the order they were read, in the work area
 struct LTrRec { uint32_t type, bits, xsize, ncolors; };
@@ -441,7 +485,7 @@ __host__ __device__ CSW_INLINE static inline int vp8l_entropy(const uint8_t *dat
             if (uint64_t(bw) * bh > sub) return 1;
             t.data = subimg[type];
             const uint64_t keep = d.ar.used;
-            const int rc = ldecode_pixels<false>(d, bw, bh, t.data, nullptr, 0);
+            const int rc = ldecode_sub(d, bw, bh, t.data);
             d.ar.used = keep;   // the sub-image's codes are done with
             if (rc) return rc;
         } else if (type == 3) {
@@ -449,7 +493,7 @@ __host__ __device__ CSW_INLINE static inline int vp8l_entropy(const uint8_t *dat
             t.bits = t.ncolors > 16 ? 0 : t.ncolors > 4 ? 1 : t.ncolors > 2 ? 2 : 3;
             t.data = palette;
             const uint64_t keep = d.ar.used;
-            const int rc = ldecode_pixels<false>(d, t.ncolors, 1, palette, nullptr, 0);
+            const int rc = ldecode_sub(d, t.ncolors, 1, palette);
             d.ar.used = keep;
             if (rc) return rc;
             for (uint32_t i = 1; i < t.ncolors; i++) palette[i] = ladd(palette[i], palette[i - 1]);
@@ -460,7 +504,9 @@ __host__ __device__ CSW_INLINE static inline int vp8l_entropy(const uint8_t *dat
     }
     // ---- the picture itself
     {
-        const int rc = ldecode_pixels<true>(d, xs, H, frame0, subimg[2], sub);
+        LPix px;
+        int rc = lsetup_pixels<true>(d, xs, H, subimg[2], sub, px);
+        if (!rc) rc = lrun_pixels(d, *hot, px, xs, H, frame0, subimg[2]);   // `hot`: the kernel's LDS, as the compiler can see here
         if (rc) return rc;
     }
     LFrame &f = *lw.info;
