@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstddef>
 struct uint4 { uint32_t x, y, z, w; };
+#define CSH_EMUL   // the header's plain-C++ side
 #define __host__
 #define __device__
 #include "../caesium-clt_amd/csrc/vp8_dec.h"
