@@ -50,17 +50,21 @@ __global__ void __launch_bounds__(256) k_vp8_pixels(const Vp8In *imgs, uint8_t *
     const bool skip = im.lossless || im.status;
     CSH_PHASE_LOOP(2 * nsteps + 1) {
         if (skip) continue;
+        // the rows of a step are dealt over the four waves (row r to wave r & 3): the macroblocks of a step differ in their modes, and a wave walks every
+        // path its lanes take -- sixteen rows per wave diverge a quarter as much as sixty-four
+        const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
         if (phase < nsteps) {
-            if ((im.debug & 1u) || threadIdx.x >= CSW_RECON_LANES) continue;
-            for (uint32_t r = threadIdx.x; r < im.mbh; r += CSW_RECON_LANES) {
+            if ((im.debug & 1u) || ln >= CSW_RECON_LANES / 4) continue;
+            const uint32_t slot = ln * 4 + wv;
+            for (uint32_t r = slot; r < im.mbh; r += CSW_RECON_LANES) {
                 const int mx = phase - 2 * int(r);
-                if (mx >= 0 && mx < int(im.mbw)) vp8_recon_mb(wk, W, H, uint32_t(mx), r, scratch[threadIdx.x]);
+                if (mx >= 0 && mx < int(im.mbw)) vp8_recon_mb(wk, W, H, uint32_t(mx), r, scratch[slot]);
             }
             continue;
         }
         if (phase < 2 * nsteps) {
             if (im.debug & 3u) continue;
-            for (uint32_t r = threadIdx.x; r < im.mbh; r += blockDim.x) {
+            for (uint32_t r = ln * 4 + wv; r < im.mbh; r += blockDim.x) {
                 const int mx = phase - nsteps - 2 * int(r);
                 if (mx >= 0 && mx < int(im.mbw)) vp8_filter_mb(wk, W, H, uint32_t(mx), r);
             }
