@@ -201,7 +201,8 @@ struct csh_batch {
     std::vector<uint32_t> h_status;
     bool ran = false;
 
-    ~csh_batch() { if (have_stream) (void)hipStreamDestroy(stream); }
+    // (wait for whatever is still queued -- a run that failed half-way leaves launches behind -- before the members hand their device blocks back to the cache)
+    ~csh_batch() { if (have_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } }
 };
 
 // ------------------------------------------------------------------------------------------------

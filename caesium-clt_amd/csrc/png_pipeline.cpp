@@ -196,7 +196,7 @@ struct csp_batch {
     bool have_events = false, ran = false;
     ~csp_batch() {
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
-        if (have_stream) (void)hipStreamDestroy(stream);
+        if (have_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }   // nothing queued may outlive the device blocks
     }
 };
 

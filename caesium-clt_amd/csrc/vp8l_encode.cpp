@@ -72,7 +72,7 @@ extern "C" int csl_encode_pixels(const csp_pixels *px, size_t count, int device,
         outputs[i].length = len[k];
         results[i] = make_res(0, nullptr);
     }
-    if (have_st) (void)hipStreamDestroy(st);
+    if (have_st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }   // nothing queued may outlive the device blocks
     return failed;
 }
 

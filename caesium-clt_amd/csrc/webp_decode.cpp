@@ -30,7 +30,7 @@ struct cswd_batch {
     DevBuf<csw::Vp8In> d_imgs;
     uint64_t work_bytes = 0, rgb_bytes = 0;
     bool ran = false;
-    ~cswd_batch() { if (have_stream) (void)hipStreamDestroy(stream); }
+    ~cswd_batch() { if (have_stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); } }   // nothing queued may outlive the device blocks
 };
 
 static uint32_t rd32le(const uint8_t *d) { return uint32_t(d[0]) | (uint32_t(d[1]) << 8) | (uint32_t(d[2]) << 16) | (uint32_t(d[3]) << 24); }
