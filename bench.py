@@ -61,7 +61,7 @@ ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2", "k_dec_spec": "k_dec_dense<0", "
                 "scan_search_stage2": "k_tokens"}
 
 
-def live_pmc(kernel, batch, profile, timeout=240):
+def live_pmc(kernel, batch, profile, inputs=None, timeout=180):
     """HBM bytes of ONE launch of `kernel`, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass,
     MI355X_MICROARCH.md "rocprofv3 PMC slots"; no trace domain next to them) over one step of this same workload in a child process
     (`--pmc-child`).  Counter unit KiB; FETCH_SIZE doubled (the gfx950 note of the same guide: wide coalesced reads are tallied at half their
@@ -74,9 +74,32 @@ def live_pmc(kernel, batch, profile, timeout=240):
     key = ROCPROF_NAME.get(kernel, kernel)
     detail = {"kernel_regex": key, "method": "rocprofv3 --pmc <counter> --kernel-include-regex, one step, child process of this run"}
     total = 0.0
+    # the child gets its input files from this process (a pickle): making them there means a fork pool inside a profiled process -- one such child hung
+    import pickle
+    handoff = None
+    if inputs:
+        fd, handoff = tempfile.mkstemp(prefix="csh_pmc_in_", suffix=".pkl", dir="/tmp")
+        with os.fdopen(fd, "wb") as f:
+            pickle.dump(list(inputs[:64]), f)
+    try:
+        return _live_pmc_passes(exe, key, detail, batch, profile, handoff, timeout)
+    finally:
+        if handoff:
+            try:
+                os.unlink(handoff)
+            except OSError:
+                pass
+
+
+def _live_pmc_passes(exe, key, detail, batch, profile, handoff, timeout):
+    import csv
+    import glob
+    total = 0.0
     for counter, scale in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="csh_pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
+        if handoff:
+            env["CSH_PMC_INPUTS"] = handoff
         if profile:
             env["CSH_PROFILE"] = profile
         else:
@@ -84,7 +107,13 @@ def live_pmc(kernel, batch, profile, timeout=240):
         cmd = [exe, "--pmc", counter, "--kernel-include-regex", key.replace("<", "."), "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(batch)]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            except subprocess.TimeoutExpired:   # once more: the passes are independent processes
+                detail.setdefault("retried", []).append(counter)
+                shutil.rmtree(d, ignore_errors=True)
+                os.makedirs(d, exist_ok=True)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
             if r.returncode != 0:
                 err = "\n".join(ln for ln in r.stderr.decode(errors="replace").splitlines() if not (ln[:1] in "WEI" and ln[1:5].isdigit()))   # the child's own words, not the profiler's log lines
                 return None, dict(detail, error=f"{counter}: rocprofv3 exited {r.returncode}: ...{err[-400:]}")
@@ -295,8 +324,13 @@ def main():
         from _util import package
         pkg = package()
         api = pkg.load()
-        uniq = make_inputs(0, 64)
-        b = api.batch([uniq[i % 64] for i in range(args.batch)], pkg.default_parameters(jpeg_quality=80))
+        if os.environ.get("CSH_PMC_INPUTS"):
+            import pickle
+            with open(os.environ["CSH_PMC_INPUTS"], "rb") as f:
+                uniq = pickle.load(f)
+        else:
+            uniq = [_one_input(i) for i in range(16)]   # (no process pool in here: this process runs under the profiler)
+        b = api.batch([uniq[i % len(uniq)] for i in range(args.batch)], pkg.default_parameters(jpeg_quality=80))
         b.run()
         b.close()
         return None
@@ -380,7 +414,7 @@ def main():
         extras = world == 1 and not args.no_extras
         if world == 1 and not args.no_pmc:
             api.release_cached_memory()   # the closed batch's pools sit in this process's block cache: the child needs the same 100 GB
-            traffic, detail = live_pmc(names[dom], args.batch, prof_env)
+            traffic, detail = live_pmc(names[dom], args.batch, prof_env, inputs=blobs)
             roof["traffic"] = traffic
             roof["traffic_detail"] = detail
             if traffic and ab:
