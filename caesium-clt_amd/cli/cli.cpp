@@ -541,8 +541,29 @@ int run(const Options &o) {
     std::vector<Job> jobs(files.size());
     const std::string suffix = o.suffix.value_or("");
 
+    // The files go through the three stages a WINDOW at a time (at most CSH_CLI_WINDOW files, default 4096, or 8 GiB of input): what is held in
+    // memory is a window's inputs and outputs, not the tree's -- the reference works file by file (compressor.rs:81-100) and takes trees of any size.
+    std::vector<std::pair<size_t, size_t>> windows;
+    {
+        const size_t max_files = getenv("CSH_CLI_WINDOW") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WINDOW")))) : 4096;
+        const uint64_t max_bytes = uint64_t(8) << 30;
+        size_t b0 = 0;
+        uint64_t bytes = 0;
+        for (size_t i = 0; i < files.size(); i++) {
+            struct stat st;
+            const uint64_t sz = stat(files[i].c_str(), &st) == 0 ? uint64_t(st.st_size) : 0;
+            if (i > b0 && (i - b0 >= max_files || bytes + sz > max_bytes)) { windows.emplace_back(b0, i); b0 = i; bytes = 0; }
+            bytes += sz;
+        }
+        windows.emplace_back(b0, files.size());
+    }
+    double ms_read = 0, ms_engine = 0, ms_write = 0;
+    for (const auto &win : windows) {
+    const size_t w0 = win.first, w1 = win.second;
+    const auto t_win = now();
     // ---- stage 1 (host, parallel): everything of perform_compression that precedes the engine call
-    parallel_for(files.size(), threads, [&](size_t i) {
+    parallel_for(w1 - w0, threads, [&](size_t k) {
+        const size_t i = w0 + k;
         Result &r = results[i];
         Job &j = jobs[i];
         j.input = files[i];
@@ -575,7 +596,7 @@ int run(const Options &o) {
     // batch per device; groups go round-robin over --gpus devices, one host thread per device.
     if (!o.dry_run) {
         std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;   // resize target -> job indices (the only per-file parameter)
-        for (size_t i = 0; i < jobs.size(); i++) if (jobs[i].engine) groups[{jobs[i].params.width, jobs[i].params.height}].push_back(i);
+        for (size_t i = w0; i < w1; i++) if (jobs[i].engine) groups[{jobs[i].params.width, jobs[i].params.height}].push_back(i);
         std::vector<std::vector<size_t>> batches;
         // files per device batch (and never more than one device batch takes by bytes / declared pixels: cs_batch_extent).  A cold process pays for the
         // device pools it allocates (~25 MB per 1080p file) before the first kernel runs, and later batches reuse the first ones' pools: smaller
@@ -639,7 +660,8 @@ int run(const Options &o) {
 
     const auto t_engine = now();
     // ---- stage 3 (host, parallel): the rest of perform_compression
-    parallel_for(files.size(), threads, [&](size_t i) {
+    parallel_for(w1 - w0, threads, [&](size_t k) {
+        const size_t i = w0 + k;
         Job &j = jobs[i];
         Result &r = results[i];
         if (!j.engine) return;
@@ -678,8 +700,11 @@ int run(const Options &o) {
         r.compressed_size = outsz;
     });
 
+    for (size_t i = w0; i < w1; i++) std::vector<uint8_t>().swap(jobs[i].data);   // the window's inputs (its outputs went in stage 3)
+    ms_read += ms(t_win, t_read); ms_engine += ms(t_read, t_engine); ms_write += ms(t_engine, now());
+    }
     if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms, engine %.0f ms, policy+write %.0f ms\n", files.size(), ms(t_start, t_scan),
-                       ms(t_scan, t_read), ms(t_read, t_engine), ms(t_engine, now()));
+                       ms_read, ms_engine, ms_write);
     if (o.json) printf("%s\n", build_json(results, o.dry_run, nullptr).c_str());
     else fputs(build_recap(results, verbose, isatty(1)).c_str(), stdout);
     return 0;

@@ -468,6 +468,23 @@ def png_to_jpeg_step(binary, tmp_path):
     assert [open(f["output_path"], "rb").read() for f in j["files"]] == want
 
 
+def test_tree_in_windows_equals_tree_in_one_piece(tree, tmp_path):
+    """the CLI takes a tree a window of files at a time (bounded memory); CSH_CLI_WINDOW=1 and =2 must give the files, the JSON and the order of the default run"""
+    root, _ = tree
+    runs = []
+    for label, window in (("whole", None), ("w1", "1"), ("w2", "2")):
+        out = tmp_path / ("out_" + label)
+        env = dict(os.environ)
+        if window:
+            env["CSH_CLI_WINDOW"] = window
+        r = subprocess.run([EMUL_CLI, "-q", "80", "-R", "-S", "--json", "-o", str(out), str(root)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        j = json.loads(r.stdout)
+        listing = {os.path.relpath(os.path.join(d, f), out): open(os.path.join(d, f), "rb").read() for d, _, fs in os.walk(out) for f in fs}
+        runs.append(([(os.path.relpath(f["original_path"], root), f["status"], f["compressed_size"]) for f in j["files"]], listing))
+    assert runs[0] == runs[1] == runs[2] and len(runs[0][0]) >= 3 and len(runs[0][1]) >= 3
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
