@@ -13,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <future>
 #include <map>
 #include <thread>
 
@@ -558,10 +559,11 @@ int run(const Options &o) {
         windows.emplace_back(b0, files.size());
     }
     double ms_read = 0, ms_engine = 0, ms_write = 0;
-    for (const auto &win : windows) {
-    const size_t w0 = win.first, w1 = win.second;
+    // ---- stage 1 (host, parallel): everything of perform_compression that precedes the engine call.  The next window is read while this one is in the
+    // engine and being written (two windows in memory at most)
+    std::atomic<long long> us_read{0};
+    auto read_window = [&](size_t w0, size_t w1) {
     const auto t_win = now();
-    // ---- stage 1 (host, parallel): everything of perform_compression that precedes the engine call
     parallel_for(w1 - w0, threads, [&](size_t k) {
         const size_t i = w0 + k;
         Result &r = results[i];
@@ -590,7 +592,13 @@ int run(const Options &o) {
         if (!build_parameters(o, j.data, j.params, perr)) { r.message = "Error building compression parameters: " + perr; return; }
         j.engine = true;
     });
-
+    us_read += (long long)(ms(t_win, now()) * 1000.0);
+    };
+    std::future<void> ahead = std::async(std::launch::async, read_window, windows[0].first, windows[0].second);
+    for (size_t wi = 0; wi < windows.size(); wi++) {
+    const size_t w0 = windows[wi].first, w1 = windows[wi].second;
+    ahead.get();
+    if (wi + 1 < windows.size()) ahead = std::async(std::launch::async, read_window, windows[wi + 1].first, windows[wi + 1].second);
     const auto t_read = now();
     // ---- stage 2 (device): the engine calls of compressor.rs:287-306, batched.  Files that share a parameter set form one
     // batch per device; groups go round-robin over --gpus devices, one host thread per device.
@@ -701,8 +709,9 @@ int run(const Options &o) {
     });
 
     for (size_t i = w0; i < w1; i++) std::vector<uint8_t>().swap(jobs[i].data);   // the window's inputs (its outputs went in stage 3)
-    ms_read += ms(t_win, t_read); ms_engine += ms(t_read, t_engine); ms_write += ms(t_engine, now());
+    ms_engine += ms(t_read, t_engine); ms_write += ms(t_engine, now());
     }
+    ms_read = double(us_read.load()) / 1000.0;
     if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms, engine %.0f ms, policy+write %.0f ms\n", files.size(), ms(t_start, t_scan),
                        ms_read, ms_engine, ms_write);
     if (o.json) printf("%s\n", build_json(results, o.dry_run, nullptr).c_str());
