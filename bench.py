@@ -386,7 +386,7 @@ def main():
     prof_env = os.environ.get("CSH_PROFILE", "")
     profile = {"plain": "plain (stock jpeg_simple_progression script)",
                "mozjpeg": "mozjpeg JCP_MAX_COMPRESSION (scan search + trellis quantisation + overshoot deringing; parity with the real crate unpinned)"}.get(
-        prof_env, "mozjpeg scan search (optimize_scans: 64 candidate scans coded per file, pinned by samples/j0.JPG) over the scalar quantiser")
+        prof_env, "mozjpeg scan search (optimize_scans in mozjpeg's own order: about 40 of its 64 candidate scans coded per file, the rest only where a file's search asks for them; pinned by samples/j0.JPG) over the scalar quantiser")
     mp_per_step = t.pixels / 1e6 * world
     value = mp_per_step * args.steps / dt
 
