@@ -25,11 +25,21 @@ __global__ void __launch_bounds__(256) k_png_analyze(const PngImg *imgs, const u
     if (status[image]) return;
     const PngImg &im = imgs[image];
     const uint32_t ch = im.channels, bps = im.bps;
-    if (!bps) return;
     uint32_t keep = flags[image];   // only ever cleared: a stale read costs work, not correctness
     if (!keep) return;
     const uint32_t start = keep;
     const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
+    if (keep & 448u) {   // an 8-bit indexed image (the only kind with these bits): do its pixels use the first 16 / 4 / 2 palette entries only?
+        for (uint32_t x = threadIdx.x; x < im.width && keep; x += blockDim.x) {
+            const uint32_t v = r[x];
+            if (v >= 16u) keep &= ~64u;
+            if (v >= 4u) keep &= ~128u;
+            if (v >= 2u) keep &= ~256u;
+        }
+        if (keep != start) atomicAnd(&flags[image], keep);
+        return;
+    }
+    if (!bps) return;
     for (uint32_t x = threadIdx.x; x < im.width && keep; x += blockDim.x) {
         const uint8_t *px = r + uint64_t(x) * ch * bps;
         if (keep & 1u) for (uint32_t k = 0; k < ch; k++) if (px[2 * k] != px[2 * k + 1]) keep &= ~1u;
@@ -52,13 +62,14 @@ __global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const Re
     const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
     uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
     if (j.gdepth) {   // an 8-bit grey result packed to 4, 2 or 1 bit: one lane per byte of the new row
-        const uint32_t per = 8u / j.gdepth, div = 255u / ((1u << j.gdepth) - 1u);
+        // (bit 8 of gdepth: the samples are palette indices -- packed as they are, not scaled)
+        const uint32_t gd = j.gdepth & 255u, per = 8u / gd, div = (j.gdepth & 256u) ? 1u : 255u / ((1u << gd) - 1u);
         for (uint32_t bx = threadIdx.x; bx < im.rowbytes; bx += blockDim.x) {
             uint32_t v = 0;
             for (uint32_t k = 0; k < per; k++) {
                 const uint32_t x = bx * per + k;
                 if (x >= im.width) break;
-                v |= (uint32_t(s[uint64_t(x) * j.old_channels * j.old_bps]) / div) << (8u - j.gdepth - k * j.gdepth);
+                v |= (uint32_t(s[uint64_t(x) * j.old_channels * j.old_bps]) / div) << (8u - gd - k * gd);
             }
             d[bx] = uint8_t(v);
         }

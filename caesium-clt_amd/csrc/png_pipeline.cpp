@@ -44,6 +44,7 @@ struct PngItem {
     size_t file_size = 0;
     uint32_t width = 0, height = 0, rowbytes = 0, bpp = 0, channels = 0, depth = 0, ctype = 0;
     bool no_reduce = false;   // a carried chunk is tied to the colour type (tRNS, bKGD, sBIT)
+    bool pal_tied = false;    // a carried chunk counts on the palette as it is (bKGD, sBIT, hIST): an indexed image keeps its depth
     bool interlace = false;   // Adam7 input (the output never is)
     bool has_plte = false, has_trns = false;
     std::vector<uint8_t> plte, trns;                // PLTE / tRNS payloads (conversion to WebP and the resize read them)
@@ -107,6 +108,7 @@ void parse_png(const uint8_t *in, size_t n, bool keep_metadata, PngItem &it) {
             const bool critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
                 if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) it.no_reduce = true;
+                if (!memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4) || !memcmp(type, "hIST", 4)) it.pal_tied = true;
                 std::vector<uint8_t> &dst = seen_idat ? it.suffix : it.prefix;
                 dst.insert(dst.end(), in + pos, in + pos + 12 + size_t(len));
             }
@@ -354,7 +356,9 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         im.chunk_stride = im.nchunks;
         im.channels = it.channels; im.bps = (it.ctype != 3 && it.depth >= 8) ? it.depth / 8 : 0;
         b->cand0.push_back((!it.no_reduce && !it.has_plte && im.bps && (im.channels == 3 || im.channels == 4)) ? im.channels : 0u);
-        b->flags0.push_back((it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u) | 56u));
+        // bits 1 / 2 / 4 / 8-32: 16 -> 8 bits, alpha away, colour -> grey, grey depth 4 / 2 / 1; bits 64-256: an 8-bit indexed image using its first 16 / 4 / 2 entries only
+        b->flags0.push_back((it.ctype == 3 && it.depth == 8 && !it.pal_tied && !px) ? 448u
+                            : (it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u) | 56u));
         if (nchunk_recs > 0x7FFFFFFFu) { csh_set_error("PNG batch too large"); return CS_ERR_POOL_OVERFLOW; }
         im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
         im.fix_off = fixed.size();
@@ -538,7 +542,9 @@ static int reduce_step(csp_batch *b) {
         // 8-bit grey -> 4 / 2 / 1 bit (oracle: grey_depth): the result is a single 8-bit channel whose every level fits
         uint32_t gdepth = 0;
         if (!depth && nk == 1 && nbps == 1) gdepth = (flags[i] & 32u) ? 1u : (flags[i] & 16u) ? 2u : (flags[i] & 8u) ? 4u : 0u;
-        if (!depth && !(flags[i] & 7u) && !gdepth) continue;
+        // an 8-bit indexed image whose pixels use the first 16 / 4 / 2 palette entries only -> 4 / 2 / 1 bit (oracle: index_depth)
+        const uint32_t idepth = (flags[i] & 256u) ? 1u : (flags[i] & 128u) ? 2u : (flags[i] & 64u) ? 4u : 0u;
+        if (!depth && !(flags[i] & 7u) && !gdepth && !idepth) continue;
         changed = true;
         uint8_t *ihdr = &it.prefix[8];   // the new IHDR: depth, colour type, checksum
         if (depth) {
@@ -565,6 +571,33 @@ static int reduce_step(csp_batch *b) {
                 it.prefix.insert(it.prefix.end(), tr.begin(), tr.end());
             }
             pjobs.push_back(j);
+        } else if (idepth) {
+            ReduceJob j{};
+            j.image = uint32_t(i); j.mask = 0; j.old_rowbytes = im.rowbytes; j.old_channels = 1; j.old_bps = 1;
+            j.src_off = im.pix_off; j.dst_off = im.raw_off;
+            j.gdepth = idepth | 256u;
+            im.bps = 0; im.bpp = 1; im.rowbytes = uint32_t((uint64_t(im.width) * idepth + 7) / 8);
+            ihdr[8 + 8] = uint8_t(idepth);
+            // PLTE cut to the entries the new depth can address, tRNS to the entries PLTE keeps: the carried chunks behind IHDR, written again
+            const uint32_t keep = std::min<uint32_t>(uint32_t(it.plte.size() / 3), 1u << idepth);
+            std::vector<uint8_t> np(it.prefix.begin(), it.prefix.begin() + 33);
+            for (size_t pos = 33; pos + 12 <= it.prefix.size();) {
+                const uint32_t len = be32(&it.prefix[pos]);
+                const uint8_t *type = &it.prefix[pos + 4];
+                uint32_t nlen = len;
+                if (!memcmp(type, "PLTE", 4)) nlen = 3 * keep;
+                else if (!memcmp(type, "tRNS", 4)) nlen = std::min(len, keep);
+                const size_t at = np.size();
+                np.resize(at + 12 + nlen);
+                put_be32(&np[at], nlen); memcpy(&np[at + 4], type, 4); memcpy(&np[at + 8], &it.prefix[pos + 8], nlen);
+                if (nlen != len) put_be32(&np[at + 8 + nlen], crc32_host(&np[at + 4], 4 + nlen)); else memcpy(&np[at + 8 + nlen], &it.prefix[pos + 8 + len], 4);
+                pos += 12 + size_t(len);
+            }
+            it.prefix.swap(np);
+            it.plte.resize(size_t(3) * keep);
+            if (it.trns.size() > keep) it.trns.resize(keep);
+            ihdr = &it.prefix[8];
+            jobs.push_back(j);
         } else {
             ReduceJob j{};
             j.image = uint32_t(i); j.mask = flags[i] & 7u; j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps;

@@ -48,7 +48,7 @@ class EncParams(C.Structure):
 class Png(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_int), ("ctype", C.c_int), ("interlace", C.c_int),
                 ("channels", C.c_int), ("bpp", C.c_int), ("nplte", C.c_int), ("rowbytes", C.c_size_t),
-                ("pix", C.POINTER(C.c_uint8)), ("chunks", C.POINTER(C.c_uint8)), ("chunks_len", C.c_size_t), ("idat_at", C.c_size_t), ("no_reduce", C.c_int)]
+                ("pix", C.POINTER(C.c_uint8)), ("chunks", C.POINTER(C.c_uint8)), ("chunks_len", C.c_size_t), ("idat_at", C.c_size_t), ("no_reduce", C.c_int), ("pal_tied", C.c_int)]
 
 
 def build(force=False):

@@ -248,6 +248,7 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
             int critical = !(type[0] & 0x20);
             if (critical || keep_metadata || kept_when_stripping(type)) {
                 if (!memcmp(type, "tRNS", 4) || !memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4)) P->no_reduce = 1;
+                if (!memcmp(type, "bKGD", 4) || !memcmp(type, "sBIT", 4) || !memcmp(type, "hIST", 4)) P->pal_tied = 1;
                 memcpy(P->chunks + P->chunks_len, in + pos, 12 + (size_t)len);
                 P->chunks_len += 12 + (size_t)len;
             }
@@ -321,7 +322,8 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
  * dropped when every pixel is opaque; colour -> grey when r == g == b everywhere.  Applied in that order, always (oxipng
  * evaluates both variants and keeps the smaller; for these three the reduced image practically always wins), and never
  * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Then colour -> palette (to_palette) and 8-bit grey -> 4 / 2 / 1 bit
- * (grey_depth).  Depth reductions of images that come in indexed: not built. */
+ * (grey_depth).  An 8-bit indexed image that uses only the head of its palette is packed at the depth the head needs (index_depth); palettes are not
+ * re-ordered. */
 /* colour -> palette: an 8-bit RGB / RGBA image with at most 256 distinct pixels becomes an indexed one (entries sorted by
    alpha, then red, green, blue, so that the translucent ones come first and tRNS stops at the last of them; index depth 1, 2, 4
    or 8 by their number) when the indexed rows plus the PLTE / tRNS chunks are smaller than the rows were.  Returns 8 or 0. */
@@ -402,7 +404,47 @@ static int grey_depth(cso_png *P) {
     P->pix = np; P->rowbytes = nrb; P->depth = d; P->bpp = 1;
     return 32;
 }
+/* an 8-bit indexed image whose pixels only use the first 16 / 4 / 2 palette entries: the indices packed at 4 / 2 / 1 bits, PLTE cut to the entries that depth
+   can address and tRNS to the entries PLTE keeps (the carried chunks are rewritten in place).  Not when a carried chunk counts on the palette as it is
+   (bKGD, sBIT, hIST).  Returns 64 or 0. */
+static int index_depth(cso_png *P) {
+    if (P->ctype != 3 || P->depth != 8 || P->pal_tied) return 0;
+    int mx = 0;
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) { const int v = P->pix[(size_t)y * P->rowbytes + x]; if (v > mx) mx = v; }
+    const int d = mx < 2 ? 1 : mx < 4 ? 2 : mx < 16 ? 4 : 8;
+    if (d == 8) return 0;
+    const size_t nrb = ((size_t)P->width * d + 7) / 8;
+    uint8_t *np = (uint8_t *)calloc(nrb, P->height);
+    for (uint32_t y = 0; y < P->height; y++)
+        for (uint32_t x = 0; x < P->width; x++) {
+            const size_t bit = (size_t)x * d;
+            np[(size_t)y * nrb + bit / 8] |= (uint8_t)(P->pix[(size_t)y * P->rowbytes + x] << (8 - d - (bit & 7)));
+        }
+    free(P->pix);
+    P->pix = np; P->rowbytes = nrb; P->depth = d; P->bpp = 1;
+    /* the carried chunks again, PLTE and tRNS shortened */
+    const int keep = P->nplte < (1 << d) ? P->nplte : (1 << d);
+    uint8_t *nc = (uint8_t *)malloc(P->chunks_len ? P->chunks_len : 1), *w = nc;
+    size_t new_idat_at = P->idat_at;
+    for (size_t pos = 0; pos + 12 <= P->chunks_len;) {
+        const uint32_t len = be32(P->chunks + pos);
+        const uint8_t *type = P->chunks + pos + 4;
+        uint32_t nlen = len;
+        if (!memcmp(type, "PLTE", 4)) nlen = (uint32_t)(3 * keep);
+        else if (!memcmp(type, "tRNS", 4)) nlen = len < (uint32_t)keep ? len : (uint32_t)keep;
+        put_be32(w, nlen); memcpy(w + 4, type, 4); memcpy(w + 8, P->chunks + pos + 8, nlen);
+        if (nlen != len) put_be32(w + 8 + nlen, cso_crc32(0, w + 4, 4 + (size_t)nlen)); else memcpy(w + 8 + nlen, P->chunks + pos + 8 + len, 4);
+        if (pos < P->idat_at) new_idat_at -= len - nlen;
+        w += 12 + nlen;
+        pos += 12 + (size_t)len;
+    }
+    free(P->chunks);
+    P->chunks = nc; P->chunks_len = (size_t)(w - nc); P->idat_at = new_idat_at; P->nplte = keep;
+    return 64;
+}
 int cso_png_reduce(cso_png *P) {
+    if (P->ctype == 3) return index_depth(P);
     if (P->no_reduce || P->ctype == 3 || P->depth < 8) return 0;
     const int bps = P->depth / 8, ch = P->channels;
     const size_t npx = (size_t)P->width * P->height;

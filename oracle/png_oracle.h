@@ -12,6 +12,7 @@ typedef struct {
     uint8_t *chunks;         /* the chunks that are carried over (whole: length, type, data, crc), in file order */
     size_t chunks_len, idat_at; /* idat_at: offset in `chunks` where the first IDAT stood */
     int no_reduce;           /* a carried chunk (tRNS, bKGD, sBIT) is tied to the colour type: the image keeps its format */
+    int pal_tied;            /* a carried chunk (bKGD, sBIT, hIST) counts on the palette as it is: an indexed image keeps its depth */
 } cso_png;
 uint32_t cso_crc32(uint32_t crc, const uint8_t *p, size_t n);
 uint32_t cso_adler32(const uint8_t *p, size_t n);
@@ -19,7 +20,7 @@ int cso_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size
 int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out);
 void cso_png_free(cso_png *p);
 int cso_png_scores(const cso_png *P, uint64_t *out);
-int cso_png_reduce(cso_png *P);   /* P2: returns a bit mask of what was applied (1: 16->8 bits, 2: alpha dropped, 4: colour->grey, 8: colour->palette, 32: grey depth) */
+int cso_png_reduce(cso_png *P);   /* P2: returns a bit mask of what was applied (1: 16->8 bits, 2: alpha dropped, 4: colour->grey, 8: colour->palette, 32: grey depth, 64: index depth) */
 int cso_png_quantize(cso_png *P, int quality);   /* lossy: truecolour with more than 256 colours -> indexed (median cut); returns 16 when applied */
 int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, int quality, uint8_t **out, size_t *out_len);
 int cso_png_to_rgb(const cso_png *P, uint8_t *rgb);   /* width * height * 3 bytes; CSO_PNG_UNSUPPORTED for an image with transparency */

@@ -1,5 +1,7 @@
 """Lossless PNG row: the kernel sources compiled for the CPU (emulation build, tests only) against the oracle, stage by
 stage and file bytes.  The same cases run on the device in test_png_gpu.py."""
+import io
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,47 @@ def test_emul_zopfli_is_refused_loudly(api):
         api.compress_in_memory(png, package().default_parameters(png_optimize=True, png_force_zopfli=True))
     assert e.value.code == 10201 and "zopfli" in str(e.value)
     assert isinstance(api.compress_in_memory(png, package().default_parameters(png_optimize=True)), bytes)
+
+
+def index_depth_cases():
+    """8-bit indexed files whose pixels use only the first 16 / 4 / 2 / 1 entries of a long palette, with and without tRNS, one whose pixels reach entry 16,
+    one with a chunk that counts on the palette (bKGD, carried under keep_metadata), and an interlaced one"""
+    from test_png_webp_emul import make_png
+    rng = np.random.default_rng(21)
+    plte = bytes(rng.integers(0, 256, 3 * 200, dtype=np.uint8))
+    out = []
+    for name, top, w, h, extra in (("idx16", 16, 61, 37, []), ("idx4", 4, 50, 20, []), ("idx2", 2, 33, 9, []), ("idx1", 1, 8, 5, []), ("idx17", 17, 40, 30, []),
+                                   ("idx4_trns", 4, 45, 31, [(b"tRNS", bytes([0, 128, 255, 7, 9, 200]))]), ("idx16_trns_short", 16, 30, 30, [(b"tRNS", bytes([10, 20]))]),
+                                   ("idx4_bkgd", 4, 24, 24, [(b"bKGD", bytes([1]))])):
+        px = rng.integers(0, top, size=(h, w), dtype=np.uint8)
+        px[h // 2, w // 2] = top - 1
+        out.append((name, make_png(w, h, 8, 3, px.tobytes(), extra=[(b"PLTE", plte)] + extra)))
+    b = io.BytesIO()
+    im = PIL.fromarray(rng.integers(0, 3, size=(19, 27), dtype=np.uint8), "P")
+    im.putpalette(list(plte[:3 * 64]))
+    im.save(b, format="PNG")
+    out.append(("idx3_pillow", b.getvalue()))
+    return out
+
+
+def test_indexed_images_lose_unused_depth(api):
+    """an indexed image that uses only the head of its palette is packed at the depth that head needs, PLTE / tRNS cut to match (oracle: index_depth) --
+    rows, trials, winner and file equal the oracle's; the result decodes to the source's pixels; a chunk tied to the palette blocks it"""
+    cases = index_depth_cases()
+    check_batch(api, cases, 2)
+    check_batch(api, cases, 1, keep_metadata=True)
+    pkg = package()
+    outs = api.cs_batch_compress([c[1] for c in cases], pkg.default_parameters(png_optimize=True, png_optimization_level=2))
+    depth = {}
+    for (name, src), out in zip(cases, outs):
+        assert not isinstance(out, Exception), (name, out)
+        a, b = PIL.open(io.BytesIO(src)), PIL.open(io.BytesIO(out))
+        assert np.array_equal(np.asarray(a.convert("RGBA")), np.asarray(b.convert("RGBA"))), name
+        depth[name] = out[24]
+    assert depth["idx16"] == 4 and depth["idx4"] == 2 and depth["idx2"] == 1 and depth["idx1"] == 1 and depth["idx17"] == 8 and depth["idx4_trns"] == 2 and depth["idx3_pillow"] in (2, 8), depth
+    kept = api.cs_batch_compress([dict(cases)["idx4_bkgd"]], pkg.default_parameters(png_optimize=True, png_optimization_level=2, keep_metadata=True))[0]
+    assert kept[24] == 8   # bKGD is an index into the palette as it stands
+    lossy = api.cs_batch_compress([dict(cases)["idx16"]], pkg.default_parameters(png_optimize=False, png_optimization_level=2, png_quality=80))[0]
+    from _util import oracle_png_lossy
+    assert lossy == oracle_png_lossy(dict(cases)["idx16"], 2, quality=80) and lossy[24] == 4
+

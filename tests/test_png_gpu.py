@@ -113,3 +113,9 @@ def test_damaged_files_are_refused_or_decoded_like_the_oracle(api):
 def test_reference_sample_pngs(api, reference_samples):
     import test_png_emul as E
     E.test_emul_reference_sample_pngs(api, reference_samples)
+
+
+def test_indexed_images_lose_unused_depth(api):
+    from test_png_emul import test_indexed_images_lose_unused_depth as body
+    body(api)
+
