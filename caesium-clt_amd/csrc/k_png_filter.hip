@@ -29,16 +29,7 @@ __global__ void __launch_bounds__(256) k_png_analyze(const PngImg *imgs, const u
     if (!keep) return;
     const uint32_t start = keep;
     const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
-    if (keep & 448u) {   // an 8-bit indexed image (the only kind with these bits): do its pixels use the first 16 / 4 / 2 palette entries only?
-        for (uint32_t x = threadIdx.x; x < im.width && keep; x += blockDim.x) {
-            const uint32_t v = r[x];
-            if (v >= 16u) keep &= ~64u;
-            if (v >= 4u) keep &= ~128u;
-            if (v >= 2u) keep &= ~256u;
-        }
-        if (keep != start) atomicAnd(&flags[image], keep);
-        return;
-    }
+    if (keep & 64u) return;   // an 8-bit indexed image: k_png_used looks at it
     if (!bps) return;
     for (uint32_t x = threadIdx.x; x < im.width && keep; x += blockDim.x) {
         const uint8_t *px = r + uint64_t(x) * ch * bps;
@@ -52,7 +43,25 @@ __global__ void __launch_bounds__(256) k_png_analyze(const PngImg *imgs, const u
     }
     if (keep != start) atomicAnd(&flags[image], keep);
 }
-__global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const ReduceJob *jobs, const uint8_t *src, uint8_t *dst) {
+// which palette entries do the pixels of an 8-bit indexed image point at?  One workgroup per row, the row's 256-bit answer gathered in LDS first.
+__global__ void __launch_bounds__(256) k_png_used(const PngImg *imgs, const uint32_t *row_image, const uint8_t *pix, const uint32_t *flags, uint32_t *used, const uint32_t *status) {
+    CSH_SHARED uint32_t s_used[8];
+    const uint32_t row = blockIdx.x, image = row_image[row];
+    const bool mine = !status[image] && (flags[image] & 64u);
+    CSH_PHASE_LOOP(3) {
+        if (!mine) continue;
+        if (phase == 0) { if (threadIdx.x < 8) s_used[threadIdx.x] = 0; continue; }
+        if (phase == 1) {
+            const PngImg &im = imgs[image];
+            const uint8_t *r = pix + im.pix_off + uint64_t(row - im.row_base) * im.rowbytes;
+            uint32_t last = 256;
+            for (uint32_t x = threadIdx.x; x < im.width; x += blockDim.x) { const uint32_t v = r[x]; if (v != last) { atomicOr(&s_used[v >> 5], 1u << (v & 31u)); last = v; } }
+            continue;
+        }
+        if (threadIdx.x < 8 && s_used[threadIdx.x]) atomicOr(&used[image * 8u + threadIdx.x], s_used[threadIdx.x]);
+    }
+}
+__global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const ReduceJob *jobs, const uint8_t *src, uint8_t *dst, const uint8_t *remaps) {
     const ReduceJob j = jobs[blockIdx.y];
     const PngImg &im = imgs[j.image];   // already the new geometry
     const uint32_t y = blockIdx.x;
@@ -62,14 +71,17 @@ __global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const Re
     const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
     uint8_t *d = dst + j.dst_off + uint64_t(y) * im.rowbytes;
     if (j.gdepth) {   // an 8-bit grey result packed to 4, 2 or 1 bit: one lane per byte of the new row
-        // (bit 8 of gdepth: the samples are palette indices -- packed as they are, not scaled)
-        const uint32_t gd = j.gdepth & 255u, per = 8u / gd, div = (j.gdepth & 256u) ? 1u : 255u / ((1u << gd) - 1u);
+        // (bit 8 of gdepth: the samples are palette indices -- renumbered by the job's table and packed at 1, 2, 4 or 8 bits, not scaled)
+        const bool index = (j.gdepth & 256u) != 0;
+        const uint32_t gd = j.gdepth & 255u, per = 8u / gd, div = index ? 1u : 255u / ((1u << gd) - 1u);
+        const uint8_t *map = remaps + uint64_t(j.remap) * 256u;
         for (uint32_t bx = threadIdx.x; bx < im.rowbytes; bx += blockDim.x) {
             uint32_t v = 0;
             for (uint32_t k = 0; k < per; k++) {
                 const uint32_t x = bx * per + k;
                 if (x >= im.width) break;
-                v |= (uint32_t(s[uint64_t(x) * j.old_channels * j.old_bps]) / div) << (8u - gd - k * gd);
+                const uint32_t sv = s[uint64_t(x) * j.old_channels * j.old_bps];
+                v |= (index ? uint32_t(map[sv]) : sv / div) << (8u - gd - k * gd);
             }
             d[bx] = uint8_t(v);
         }
@@ -87,8 +99,11 @@ __global__ void __launch_bounds__(256) k_png_repack(const PngImg *imgs, const Re
 void launch_png_analyze(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, uint32_t *flags, const uint32_t *status) {
     if (total_rows) CSH_LAUNCH(k_png_analyze, dim3(total_rows), dim3(256), st, imgs, row_image, pix, flags, status);
 }
-void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst) {
-    if (njobs) CSH_LAUNCH(k_png_repack, dim3(max_height, njobs), dim3(256), st, imgs, jobs, src, dst);
+void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst, const uint8_t *remaps) {
+    if (njobs) CSH_LAUNCH(k_png_repack, dim3(max_height, njobs), dim3(256), st, imgs, jobs, src, dst, remaps);
+}
+void launch_png_used(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *flags, uint32_t *used, const uint32_t *status) {
+    if (total_rows) CSH_LAUNCH_PHASED(k_png_used, 3, dim3(total_rows), dim3(256), st, imgs, row_image, pix, flags, used, status);
 }
 
 // ---- colour -> palette

@@ -15,9 +15,11 @@ void launch_png_deinterlace(hipStream_t st, const PngImg *imgs, const PngAdam7 *
 // opaque alpha channel, 4: colour -> grey; 8 / 16 / 32: the first sample of every pixel is a multiple of 17 / 85 / 255, i.e. a grey result
 // fits 4 / 2 / 1 bits); the analysis clears what a pixel contradicts; the host decides and rewrites the
 // descriptor; the repack moves the surviving bytes (from `src` at the old geometry to `dst` at the new one).
-struct ReduceJob { uint32_t image, mask, old_rowbytes, old_channels, old_bps, gdepth; uint64_t src_off, dst_off; };   // gdepth: 0, or the depth (1, 2, 4) an 8-bit grey result is packed to; | 256: an 8-bit indexed image's indices packed to that depth (no scaling)
+struct ReduceJob { uint32_t image, mask, old_rowbytes, old_channels, old_bps, gdepth, remap, pad_; uint64_t src_off, dst_off; };   // gdepth: 0, or the depth (1, 2, 4) an 8-bit grey result is packed to; | 256: an 8-bit indexed image's indices, renumbered by table `remap` (256 bytes each) and packed at that depth (1, 2, 4, 8)
 void launch_png_analyze(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, uint32_t *flags, const uint32_t *status);
-void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst);
+void launch_png_repack(hipStream_t st, const PngImg *imgs, const ReduceJob *jobs, int njobs, uint32_t max_height, const uint8_t *src, uint8_t *dst, const uint8_t *remaps);
+// 8-bit indexed images (flag bit 64): used[image * 8 + w] |= the palette entries their pixels point at
+void launch_png_used(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *flags, uint32_t *used, const uint32_t *status);
 
 // colour -> palette (oracle: to_palette).  cand[image] = channels (3 / 4) of an 8- or 16-bit truecolour image that may become indexed,
 // else 0.  The distinct pixels (alpha, red, green, blue of the high bytes in one 32-bit key) are collected in a 1024-slot open

@@ -356,8 +356,8 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         im.chunk_stride = im.nchunks;
         im.channels = it.channels; im.bps = (it.ctype != 3 && it.depth >= 8) ? it.depth / 8 : 0;
         b->cand0.push_back((!it.no_reduce && !it.has_plte && im.bps && (im.channels == 3 || im.channels == 4)) ? im.channels : 0u);
-        // bits 1 / 2 / 4 / 8-32: 16 -> 8 bits, alpha away, colour -> grey, grey depth 4 / 2 / 1; bits 64-256: an 8-bit indexed image using its first 16 / 4 / 2 entries only
-        b->flags0.push_back((it.ctype == 3 && it.depth == 8 && !it.pal_tied && !px) ? 448u
+        // bits 1 / 2 / 4 / 8-32: 16 -> 8 bits, alpha away, colour -> grey, grey depth 4 / 2 / 1; bit 64: an 8-bit indexed image (k_png_used finds the palette entries it uses)
+        b->flags0.push_back((it.ctype == 3 && it.depth == 8 && !it.pal_tied && !px) ? 64u
                             : (it.no_reduce || !im.bps) ? 0u : ((im.bps == 2 ? 1u : 0u) | ((im.channels == 2 || im.channels == 4) ? 2u : 0u) | (im.channels >= 3 ? 4u : 0u) | 56u));
         if (nchunk_recs > 0x7FFFFFFFu) { csh_set_error("PNG batch too large"); return CS_ERR_POOL_OVERFLOW; }
         im.prefix_len = uint32_t(it.prefix.size()); im.suffix_len = uint32_t(it.suffix.size());
@@ -449,7 +449,15 @@ static int reduce_step(csp_batch *b) {
         hipMemsetAsync(b->d_keys.p, 0xFF, sizeof(unsigned long long) * size_t(nimg) * CSP_PAL_SLOTS, st) != hipSuccess || b->d_counts.zero(st)) return -1;
     launch_png_analyze(st, b->d_imgs.p, b->total_rows, b->d_row_image.p, b->d_work.p, b->d_flags.p, b->d_status.p);
     launch_png_colors(st, b->d_imgs.p, b->total_rows, b->d_row_image.p, b->d_work.p, b->d_cand.p, b->d_keys.p, b->d_counts.p, b->d_status.p);
-    std::vector<uint32_t> flags(nimg), status(nimg), counts(nimg);
+    std::vector<uint32_t> flags(nimg), status(nimg), counts(nimg), used(size_t(nimg) * 8, 0);
+    bool any_indexed = false;
+    for (int i = 0; i < nimg; i++) any_indexed |= (b->flags0[i] & 64u) != 0;
+    DevBuf<uint32_t> d_used;
+    if (any_indexed) {
+        if (d_used.alloc(size_t(nimg) * 8) || d_used.zero(st)) return -1;
+        launch_png_used(st, b->d_imgs.p, b->total_rows, b->d_row_image.p, b->d_work.p, b->d_flags.p, d_used.p, b->d_status.p);
+        if (hipMemcpyAsync(used.data(), d_used.p, sizeof(uint32_t) * used.size(), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    }
     if (hipMemcpyAsync(flags.data(), b->d_flags.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(counts.data(), b->d_counts.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(status.data(), b->d_status.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -503,6 +511,7 @@ static int reduce_step(csp_batch *b) {
         }
     }
     std::vector<ReduceJob> jobs;
+    std::vector<uint8_t> remaps;   // 256 bytes per indexed job: old palette index -> new
     std::vector<PaletteJob> pjobs;
     std::vector<uint32_t> palettes;
     std::vector<uint16_t> slot_index(size_t(nimg) * CSP_PAL_SLOTS, 0);
@@ -542,8 +551,20 @@ static int reduce_step(csp_batch *b) {
         // 8-bit grey -> 4 / 2 / 1 bit (oracle: grey_depth): the result is a single 8-bit channel whose every level fits
         uint32_t gdepth = 0;
         if (!depth && nk == 1 && nbps == 1) gdepth = (flags[i] & 32u) ? 1u : (flags[i] & 16u) ? 2u : (flags[i] & 8u) ? 4u : 0u;
-        // an 8-bit indexed image whose pixels use the first 16 / 4 / 2 palette entries only -> 4 / 2 / 1 bit (oracle: index_depth)
-        const uint32_t idepth = (flags[i] & 256u) ? 1u : (flags[i] & 128u) ? 2u : (flags[i] & 64u) ? 4u : 0u;
+        // an 8-bit indexed image that does not use its whole palette: the unused entries go, the rest is renumbered and packed at the depth it needs (oracle: index_depth)
+        uint32_t idepth = 0, nused = 0;
+        uint8_t imap[256];
+        if (flags[i] & 64u) {
+            const uint32_t npl = uint32_t(it.plte.size() / 3);
+            bool ok = true;
+            for (uint32_t v = 0; v < 256; v++) {
+                const bool u = (used[size_t(i) * 8 + (v >> 5)] >> (v & 31u)) & 1u;
+                if (u && v >= npl) ok = false;
+                imap[v] = uint8_t(nused); nused += u ? 1u : 0u;
+            }
+            idepth = nused <= 2 ? 1u : nused <= 4 ? 2u : nused <= 16 ? 4u : 8u;
+            if (!ok || !nused || (idepth == 8 && nused == npl)) idepth = 0;
+        }
         if (!depth && !(flags[i] & 7u) && !gdepth && !idepth) continue;
         changed = true;
         uint8_t *ihdr = &it.prefix[8];   // the new IHDR: depth, colour type, checksum
@@ -575,27 +596,39 @@ static int reduce_step(csp_batch *b) {
             ReduceJob j{};
             j.image = uint32_t(i); j.mask = 0; j.old_rowbytes = im.rowbytes; j.old_channels = 1; j.old_bps = 1;
             j.src_off = im.pix_off; j.dst_off = im.raw_off;
-            j.gdepth = idepth | 256u;
+            j.gdepth = idepth | 256u; j.remap = uint32_t(remaps.size() / 256);
+            remaps.insert(remaps.end(), imap, imap + 256);
             im.bps = 0; im.bpp = 1; im.rowbytes = uint32_t((uint64_t(im.width) * idepth + 7) / 8);
             ihdr[8 + 8] = uint8_t(idepth);
-            // PLTE cut to the entries the new depth can address, tRNS to the entries PLTE keeps: the carried chunks behind IHDR, written again
-            const uint32_t keep = std::min<uint32_t>(uint32_t(it.plte.size() / 3), 1u << idepth);
+            // PLTE and tRNS of the entries that are left (a tRNS that ends up all opaque goes): the carried chunks behind IHDR, written again
+            std::vector<uint8_t> npl, ntr;
+            uint32_t nt = 0;
+            for (uint32_t v = 0, k = 0; v < 256; v++) if ((used[size_t(i) * 8 + (v >> 5)] >> (v & 31u)) & 1u) {
+                npl.insert(npl.end(), it.plte.begin() + 3 * v, it.plte.begin() + 3 * v + 3);
+                ntr.push_back(v < it.trns.size() ? it.trns[v] : uint8_t(255));
+                if (ntr.back() != 255) nt = k + 1;
+                k++;
+            }
+            ntr.resize(nt);
             std::vector<uint8_t> np(it.prefix.begin(), it.prefix.begin() + 33);
             for (size_t pos = 33; pos + 12 <= it.prefix.size();) {
                 const uint32_t len = be32(&it.prefix[pos]);
                 const uint8_t *type = &it.prefix[pos + 4];
+                const uint8_t *data = &it.prefix[pos + 8];
                 uint32_t nlen = len;
-                if (!memcmp(type, "PLTE", 4)) nlen = 3 * keep;
-                else if (!memcmp(type, "tRNS", 4)) nlen = std::min(len, keep);
-                const size_t at = np.size();
-                np.resize(at + 12 + nlen);
-                put_be32(&np[at], nlen); memcpy(&np[at + 4], type, 4); memcpy(&np[at + 8], &it.prefix[pos + 8], nlen);
-                if (nlen != len) put_be32(&np[at + 8 + nlen], crc32_host(&np[at + 4], 4 + nlen)); else memcpy(&np[at + 8 + nlen], &it.prefix[pos + 8 + len], 4);
+                bool drop = false;
+                if (!memcmp(type, "PLTE", 4)) { nlen = uint32_t(npl.size()); data = npl.data(); }
+                else if (!memcmp(type, "tRNS", 4)) { nlen = nt; data = ntr.data(); drop = nt == 0; }
+                if (!drop) {
+                    const size_t at = np.size();
+                    np.resize(at + 12 + nlen);
+                    put_be32(&np[at], nlen); memcpy(&np[at + 4], type, 4); if (nlen) memcpy(&np[at + 8], data, nlen);
+                    put_be32(&np[at + 8 + nlen], crc32_host(&np[at + 4], 4 + nlen));
+                }
                 pos += 12 + size_t(len);
             }
             it.prefix.swap(np);
-            it.plte.resize(size_t(3) * keep);
-            if (it.trns.size() > keep) it.trns.resize(keep);
+            it.plte = npl; it.trns = ntr;
             ihdr = &it.prefix[8];
             jobs.push_back(j);
         } else {
@@ -632,7 +665,10 @@ static int reduce_step(csp_batch *b) {
     if (b->d_fixed.upload(b->fixed, st) || b->d_pjobs.upload(pjobs, st) || b->d_slot_index.upload(slot_index, st) || b->d_qpal.upload(palettes, st) ||
         hipMemcpyAsync(b->d_imgs.p, b->imgs.data(), sizeof(PngImg) * nimg, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(b->d_jobs.p, jobs.data(), sizeof(ReduceJob) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess) { csh_set_error("PNG reduction upload failed"); return -1; }
-    launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()) - 1, max_height, b->d_work.p, b->d_work.p);
+    remaps.resize(remaps.size() + 256, 0);   // never an empty upload
+    DevBuf<uint8_t> d_remaps;
+    if (d_remaps.upload(remaps, st)) return -1;
+    launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()) - 1, max_height, b->d_work.p, b->d_work.p, d_remaps.p);
     launch_png_indexed(st, b->d_imgs.p, b->d_pjobs.p, int(pjobs.size()) - 1, max_height, b->d_keys.p, b->d_slot_index.p, b->d_qpal.p, b->d_work.p, b->d_work.p);
     return upload_chunk_index(b);   // synchronises: the job vectors may go out of scope
 }

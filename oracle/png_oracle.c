@@ -322,8 +322,8 @@ int cso_png_decode(const uint8_t *in, size_t n, int keep_metadata, cso_png **out
  * dropped when every pixel is opaque; colour -> grey when r == g == b everywhere.  Applied in that order, always (oxipng
  * evaluates both variants and keeps the smaller; for these three the reduced image practically always wins), and never
  * when a carried chunk is tied to the colour type (tRNS, bKGD, sBIT).  Then colour -> palette (to_palette) and 8-bit grey -> 4 / 2 / 1 bit
- * (grey_depth).  An 8-bit indexed image that uses only the head of its palette is packed at the depth the head needs (index_depth); palettes are not
- * re-ordered. */
+ * (grey_depth).  An 8-bit indexed image that does not use its whole palette loses the unused entries and the depth they cost (index_depth);
+ * palettes are not re-ordered, duplicate entries not merged. */
 /* colour -> palette: an 8-bit RGB / RGBA image with at most 256 distinct pixels becomes an indexed one (entries sorted by
    alpha, then red, green, blue, so that the translucent ones come first and tRNS stops at the last of them; index depth 1, 2, 4
    or 8 by their number) when the indexed rows plus the PLTE / tRNS chunks are smaller than the rows were.  Returns 8 or 0. */
@@ -404,43 +404,63 @@ static int grey_depth(cso_png *P) {
     P->pix = np; P->rowbytes = nrb; P->depth = d; P->bpp = 1;
     return 32;
 }
-/* an 8-bit indexed image whose pixels only use the first 16 / 4 / 2 palette entries: the indices packed at 4 / 2 / 1 bits, PLTE cut to the entries that depth
-   can address and tRNS to the entries PLTE keeps (the carried chunks are rewritten in place).  Not when a carried chunk counts on the palette as it is
-   (bKGD, sBIT, hIST).  Returns 64 or 0. */
+/* an 8-bit indexed image that does not use its whole palette: the entries no pixel points at are dropped (the others keep their order), the indices
+   renumbered and packed at the smallest depth that holds the entries left (1, 2, 4 or 8 bits), PLTE and tRNS written again for them (a tRNS that ends up
+   all opaque goes).  Not when a carried chunk counts on the palette as it is (bKGD, sBIT, hIST), nor when a pixel points past the palette.
+   Returns 64 or 0. */
 static int index_depth(cso_png *P) {
     if (P->ctype != 3 || P->depth != 8 || P->pal_tied) return 0;
-    int mx = 0;
+    int used[256], map[256], n = 0;
+    memset(used, 0, sizeof used);
     for (uint32_t y = 0; y < P->height; y++)
-        for (uint32_t x = 0; x < P->width; x++) { const int v = P->pix[(size_t)y * P->rowbytes + x]; if (v > mx) mx = v; }
-    const int d = mx < 2 ? 1 : mx < 4 ? 2 : mx < 16 ? 4 : 8;
-    if (d == 8) return 0;
+        for (uint32_t x = 0; x < P->width; x++) used[P->pix[(size_t)y * P->rowbytes + x]] = 1;
+    for (int i = 0; i < 256; i++) { if (used[i] && i >= P->nplte) return 0; map[i] = n; n += used[i]; }
+    const int d = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
+    if (d == 8 && n == P->nplte) return 0;
     const size_t nrb = ((size_t)P->width * d + 7) / 8;
     uint8_t *np = (uint8_t *)calloc(nrb, P->height);
     for (uint32_t y = 0; y < P->height; y++)
         for (uint32_t x = 0; x < P->width; x++) {
             const size_t bit = (size_t)x * d;
-            np[(size_t)y * nrb + bit / 8] |= (uint8_t)(P->pix[(size_t)y * P->rowbytes + x] << (8 - d - (bit & 7)));
+            np[(size_t)y * nrb + bit / 8] |= (uint8_t)(map[P->pix[(size_t)y * P->rowbytes + x]] << (8 - d - (bit & 7)));
         }
     free(P->pix);
     P->pix = np; P->rowbytes = nrb; P->depth = d; P->bpp = 1;
-    /* the carried chunks again, PLTE and tRNS shortened */
-    const int keep = P->nplte < (1 << d) ? P->nplte : (1 << d);
-    uint8_t *nc = (uint8_t *)malloc(P->chunks_len ? P->chunks_len : 1), *w = nc;
+    /* the carried chunks again: PLTE and tRNS of the entries that are left */
+    const uint8_t *plte = NULL, *trns = NULL;
+    uint32_t ntrns = 0;
+    for (size_t pos = 0; pos + 12 <= P->chunks_len; pos += 12 + (size_t)be32(P->chunks + pos)) {
+        if (!memcmp(P->chunks + pos + 4, "PLTE", 4)) plte = P->chunks + pos + 8;
+        if (!memcmp(P->chunks + pos + 4, "tRNS", 4)) { trns = P->chunks + pos + 8; ntrns = be32(P->chunks + pos); }
+    }
+    uint8_t npl[768], ntr[256];
+    int nt = 0;
+    for (int i = 0, k = 0; i < 256; i++) if (used[i]) {
+        memcpy(npl + 3 * k, plte + 3 * i, 3);
+        ntr[k] = (trns && (uint32_t)i < ntrns) ? trns[i] : 255;
+        if (ntr[k] != 255) nt = k + 1;
+        k++;
+    }
+    uint8_t *nc = (uint8_t *)malloc(P->chunks_len + 16), *w = nc;
     size_t new_idat_at = P->idat_at;
     for (size_t pos = 0; pos + 12 <= P->chunks_len;) {
         const uint32_t len = be32(P->chunks + pos);
         const uint8_t *type = P->chunks + pos + 4;
+        const uint8_t *data = P->chunks + pos + 8;
         uint32_t nlen = len;
-        if (!memcmp(type, "PLTE", 4)) nlen = (uint32_t)(3 * keep);
-        else if (!memcmp(type, "tRNS", 4)) nlen = len < (uint32_t)keep ? len : (uint32_t)keep;
-        put_be32(w, nlen); memcpy(w + 4, type, 4); memcpy(w + 8, P->chunks + pos + 8, nlen);
-        if (nlen != len) put_be32(w + 8 + nlen, cso_crc32(0, w + 4, 4 + (size_t)nlen)); else memcpy(w + 8 + nlen, P->chunks + pos + 8 + len, 4);
-        if (pos < P->idat_at) new_idat_at -= len - nlen;
-        w += 12 + nlen;
+        int drop = 0;
+        if (!memcmp(type, "PLTE", 4)) { nlen = (uint32_t)(3 * n); data = npl; }
+        else if (!memcmp(type, "tRNS", 4)) { nlen = (uint32_t)nt; data = ntr; drop = nt == 0; }
+        if (!drop) {
+            put_be32(w, nlen); memcpy(w + 4, type, 4); memcpy(w + 8, data, nlen);
+            put_be32(w + 8 + nlen, cso_crc32(0, w + 4, 4 + (size_t)nlen));
+            w += 12 + nlen;
+        }
+        if (pos < P->idat_at) new_idat_at -= (12 + (size_t)len) - (drop ? 0 : 12 + (size_t)nlen);
         pos += 12 + (size_t)len;
     }
     free(P->chunks);
-    P->chunks = nc; P->chunks_len = (size_t)(w - nc); P->idat_at = new_idat_at; P->nplte = keep;
+    P->chunks = nc; P->chunks_len = (size_t)(w - nc); P->idat_at = new_idat_at; P->nplte = n;
     return 64;
 }
 int cso_png_reduce(cso_png *P) {

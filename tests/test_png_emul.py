@@ -188,6 +188,13 @@ def index_depth_cases():
         px = rng.integers(0, top, size=(h, w), dtype=np.uint8)
         px[h // 2, w // 2] = top - 1
         out.append((name, make_png(w, h, 8, 3, px.tobytes(), extra=[(b"PLTE", plte)] + extra)))
+    # entries anywhere in the palette: the used ones are renumbered; a tRNS that only made unused entries transparent goes; a pixel past the palette blocks it
+    for name, values, w, h, extra in (("scattered3", [3, 77, 150], 40, 21, []), ("scattered20", list(range(5, 200, 10)), 64, 33, []),
+                                      ("scattered_trns", [1, 9, 130], 31, 17, [(b"tRNS", bytes([255, 0] + [255] * 7 + [40]))]),
+                                      ("trns_unused_only", [2, 3], 16, 16, [(b"tRNS", bytes([0, 0]))]), ("past_palette", [0, 1, 230], 20, 10, [])):
+        px = rng.choice(np.array(values, np.uint8), size=(h, w))
+        px.flat[:len(values)] = values
+        out.append((name, make_png(w, h, 8, 3, px.tobytes(), extra=[(b"PLTE", plte)] + extra)))
     b = io.BytesIO()
     im = PIL.fromarray(rng.integers(0, 3, size=(19, 27), dtype=np.uint8), "P")
     im.putpalette(list(plte[:3 * 64]))
@@ -197,7 +204,7 @@ def index_depth_cases():
 
 
 def test_indexed_images_lose_unused_depth(api):
-    """an indexed image that uses only the head of its palette is packed at the depth that head needs, PLTE / tRNS cut to match (oracle: index_depth) --
+    """an indexed image that does not use its whole palette loses the unused entries and is packed at the depth the rest needs, PLTE / tRNS written again (oracle: index_depth) --
     rows, trials, winner and file equal the oracle's; the result decodes to the source's pixels; a chunk tied to the palette blocks it"""
     cases = index_depth_cases()
     check_batch(api, cases, 2)
@@ -211,6 +218,11 @@ def test_indexed_images_lose_unused_depth(api):
         assert np.array_equal(np.asarray(a.convert("RGBA")), np.asarray(b.convert("RGBA"))), name
         depth[name] = out[24]
     assert depth["idx16"] == 4 and depth["idx4"] == 2 and depth["idx2"] == 1 and depth["idx1"] == 1 and depth["idx17"] == 8 and depth["idx4_trns"] == 2 and depth["idx3_pillow"] in (2, 8), depth
+    assert depth["scattered3"] == 2 and depth["scattered20"] == 8 and depth["scattered_trns"] == 2 and depth["trns_unused_only"] == 1 and depth["past_palette"] == 8, depth
+    outs = dict(zip([c[0] for c in cases], outs))
+    assert b"tRNS" not in outs["trns_unused_only"] and b"tRNS" in outs["scattered_trns"]
+    plte_len = lambda f: int.from_bytes(f[f.index(b"PLTE") - 4:f.index(b"PLTE")], "big") // 3
+    assert plte_len(outs["scattered20"]) == 20 and plte_len(outs["scattered3"]) == 3 and plte_len(outs["idx17"]) == 17 and plte_len(outs["past_palette"]) == 200
     kept = api.cs_batch_compress([dict(cases)["idx4_bkgd"]], pkg.default_parameters(png_optimize=True, png_optimization_level=2, keep_metadata=True))[0]
     assert kept[24] == 8   # bKGD is an index into the palette as it stands
     lossy = api.cs_batch_compress([dict(cases)["idx16"]], pkg.default_parameters(png_optimize=False, png_optimization_level=2, png_quality=80))[0]

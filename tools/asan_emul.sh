@@ -18,6 +18,9 @@ from gen_synth import synth_jpeg
 T.check_batch(api, _util.png_cases(), 3)
 T.check_batch(api, [c for c in _util.png_cases() if c[0] in ("RGB_97x61", "palette_rgba_translucent", "adam7_1_37x11", "reduce_i16_narrow")], 6)
 assert T.agree_with_oracle(api, T.damaged_pngs(1, 80)) == 0
+T.test_indexed_images_lose_unused_depth(api)
+import test_png_lossy_emul as PLY
+PLY.test_median_falls_among_equal_keys(api)
 W.check(api, W.webp_cases(), 85); W.check(api, W.webp_cases()[:2], 60, width=50)
 srcs = [synth_jpeg(1, 160, 96, texture=10), synth_jpeg(2, 97, 61, subsampling=0, texture=5), synth_jpeg(5, 104, 72, progressive=True, texture=6), synth_jpeg(6, 120, 88, restart_rows=1, texture=9)]
 for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_quality=80))): assert o == _util.oracle_lossy(s)
