@@ -61,7 +61,7 @@ ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2", "k_dec_spec": "k_dec_dense<0", "
                 "scan_search_stage2": "k_tokens"}
 
 
-def live_pmc(kernel, batch, profile, inputs=None, timeout=180):
+def live_pmc(kernel, batch, profile, inputs=None, timeout=120):
     """HBM bytes of ONE launch of `kernel`, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass,
     MI355X_MICROARCH.md "rocprofv3 PMC slots"; no trace domain next to them) over one step of this same workload in a child process
     (`--pmc-child`).  Counter unit KiB; FETCH_SIZE doubled (the gfx950 note of the same guide: wide coalesced reads are tallied at half their
@@ -109,7 +109,9 @@ def _live_pmc_passes(exe, key, detail, batch, profile, handoff, timeout):
         try:
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
-            except subprocess.TimeoutExpired:   # once more: the passes are independent processes
+            except subprocess.TimeoutExpired:   # once more (once per run): the passes are independent processes
+                if detail.get("retried"):
+                    raise
                 detail.setdefault("retried", []).append(counter)
                 shutil.rmtree(d, ignore_errors=True)
                 os.makedirs(d, exist_ok=True)
