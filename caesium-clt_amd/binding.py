@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NPHASES = 8
-NKERNELS = 32
+NKERNELS = 36
 PHASE_NAMES = ["decode", "pixel", "masks_flags_runs", "stats_tables", "sizes_scan", "pack", "stuff_assemble", "reserved"]
 
 

@@ -1194,8 +1194,8 @@ __device__ __forceinline__ static void pack_segments(const EncCtx &c, const Toke
 #endif
 __global__ void __launch_bounds__(256) k_pack(EncCtx c) {
     const int wv = int(threadIdx.x >> 6), lane = lane_id();
-    const uint32_t cs = c.slot0 + blockIdx.x * 4u + uint32_t(wv);
-    if (cs >= c.slot0 + c.nslots) return;
+    if (blockIdx.x * 4u + uint32_t(wv) >= c.ntok_slots) return;
+    const uint32_t cs = c.tok_slots[blockIdx.x * 4u + uint32_t(wv)];   // the run's slots that are packed from tokens (the others: k_aclist.hip)
     const SlotRec r = c.slots[cs];
     const ScanWork &w = c.work[r.work];
     if (c.work_active && !c.work_active[r.work]) return;
@@ -1285,6 +1285,6 @@ void launch_ac_runs(hipStream_t st, const EncCtx &c) {
 #endif
 }
 void launch_chunk_sizes(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH(k_chunk_sizes, dim3((c.nslots + 3) / 4), dim3(256), st, c); }
-void launch_pack(hipStream_t st, const EncCtx &c) { if (c.nslots) CSH_LAUNCH(k_pack, dim3((c.nslots + 3) / 4), dim3(256), st, c); }
+void launch_pack(hipStream_t st, const EncCtx &c) { if (c.ntok_slots) CSH_LAUNCH(k_pack, dim3((c.ntok_slots + 3) / 4), dim3(256), st, c); }
 
 }  // namespace csh

@@ -97,6 +97,19 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint32_t debug;            // CSH_DEBUG: performance experiments (parts of k_tokens switched off; output is then garbage)
     uint32_t stats_only;       // the trellis stage's statistics scans: histograms, flags and EOB runs only -- no token is written
     const uint8_t *work_active;// null: every work item of the run is coded; else per work item 1 = coded, 0 = skipped (conditional stages of the scan search)
+    // the compacted coefficient lists and the slots coded from them (k_aclist.hip, types.h NzList)
+    const NzList *nzlists;
+    const NzSet *nzsets;
+    const NzChunk *nzchunks;   // the builder's grid for this run
+    uint32_t nnzchunks;
+    uint32_t *nz_pool;         // the entries
+    uint32_t *nz_cursor;       // per list: entries handed out
+    uint32_t *nz_chunk_off;    // per (list, chunk): first entry, relative to the list's region
+    uint32_t *nz_chunk_cnt;    // per (list, chunk): entries (END entries included, padding excluded)
+    const uint32_t *list_slots;// the run's slots that are coded from a list (k_list_stats, k_list_pack) ...
+    uint32_t nlist_slots;
+    const uint32_t *tok_slots; // ... and those packed from tokens (k_pack); null: every slot of [slot0, slot0 + nslots)
+    uint32_t ntok_slots;
 };
 void launch_tokens(hipStream_t st, const EncCtx &c);
 void launch_ac_runs(hipStream_t st, const EncCtx &c);
@@ -104,6 +117,14 @@ void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables);
 void launch_chunk_sizes(hipStream_t st, const EncCtx &c);
 void launch_zero_edges(hipStream_t st, const EncCtx &c);   // between the scans' placement and the pack
 void launch_pack(hipStream_t st, const EncCtx &c);
+// progressive AC scans from the compacted lists (k_aclist.hip): build the lists of the run's NzChunks; statistics (histograms, raw-bit
+// counts, has-symbol / ends-with-EOB flags) of the run's list slots -- in launch_tokens' place --; their bits -- in launch_pack's place
+void launch_nzlist(hipStream_t st, const EncCtx &c);
+void launch_list_stats(hipStream_t st, const EncCtx &c);
+void launch_list_pack(hipStream_t st, const EncCtx &c);
+// marks every work item "in no file, no bits" at the start of a run (a conditional stage of the scan search that does not run this time
+// must not leave the placement of an earlier run behind)
+void launch_reset_works(hipStream_t st, ScanWork *work, int nwork);
 
 // ---- mozjpeg's trellis quantiser (k_trellis.hip): re-quantise every block from the retained DCT with the statistics pass's code
 // lengths as rates -- AC coefficients per block (k_trellis_ac), DC coefficients along each row of blocks (k_trellis_dc)

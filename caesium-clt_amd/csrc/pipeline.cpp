@@ -112,6 +112,17 @@ struct csh_batch {
     std::vector<TokRegion> regions;       // one per TokPlan, then one per DC / sequential work item
     std::vector<uint32_t> region_est;     // estimated tokens of each (x tok_scale = its capacity)
     uint32_t hist_rows = 0;               // rows of 256 symbol counts over all slots
+    // the compacted coefficient lists the progressive AC first-pass scans are coded from (k_aclist.hip; types.h NzList)
+    std::vector<NzList> nzlists;          // one per (image, component, Al) some scan of the batch needs
+    std::vector<NzSet> nzsets;            // one per (image, component)
+    std::vector<int> nzset_of;            // [image * CSH_MAX_COMPS + component] -> NzSet, -1
+    std::vector<uint32_t> nzset_built;    // per set: levels some stage's builder makes
+    std::vector<int> nzset_comp, nzset_image;
+    std::vector<NzChunk> nzchunks;        // the builder's grid, stage after stage
+    std::vector<uint32_t> nz_est, nz_worst; // per list: estimated / largest possible number of entries
+    uint32_t nz_nrec = 0;                 // per-(list, chunk) records
+    uint64_t nz_cap = 0;                  // pool capacity: the sum of the regions
+    std::vector<uint32_t> list_slots, tok_slots;   // per stage, contiguous: its slots coded from lists / packed from tokens
     // mozjpeg's scan search (the default profile; CSH_PROFILE=plain keeps the stock script): the candidate scans are coded in stages
     // -- work items, slots, token chunks and tables of one stage behind those of the stage before -- and the host replays
     // jcmaster.c select_scans on their sizes in between.  mozjpeg codes its candidates one after the other and skips ahead as soon as
@@ -120,7 +131,16 @@ struct csh_batch {
     // asks for them, and then only over the work items of those images (EncCtx::work_active).
     bool search = false;
     enum { ST_1 = 0, ST_1B = 1, ST_2 = 2, ST_2B = 3, ST_2C = 4, ST_N = 5 };
-    struct Stage { uint32_t work0 = 0, nwork = 0, slot0 = 0, nslots = 0, ech0 = 0, nech = 0, table0 = 0, ntables = 0, plan0 = 0, nplans = 0; } stage[ST_N];
+    struct Stage { uint32_t work0 = 0, nwork = 0, slot0 = 0, nslots = 0, ech0 = 0, nech = 0, table0 = 0, ntables = 0, plan0 = 0, nplans = 0, nzc0 = 0, nnzc = 0, ls0 = 0, nls = 0, ts0 = 0, nts = 0; } stage[ST_N];
+    void stage_begin(Stage &sg) {
+        sg.work0 = uint32_t(swork.size()); sg.slot0 = uint32_t(slot_work.size()); sg.ech0 = uint32_t(echunks.size()); sg.table0 = uint32_t(ntables); sg.plan0 = uint32_t(plans.size());
+        sg.nzc0 = uint32_t(nzchunks.size()); sg.ls0 = uint32_t(list_slots.size()); sg.ts0 = uint32_t(tok_slots.size());
+    }
+    void stage_end(Stage &sg) {
+        sg.nwork = uint32_t(swork.size()) - sg.work0; sg.nslots = uint32_t(slot_work.size()) - sg.slot0; sg.nech = uint32_t(echunks.size()) - sg.ech0;
+        sg.ntables = uint32_t(ntables) - sg.table0; sg.nplans = uint32_t(plans.size()) - sg.plan0;
+        sg.nnzc = uint32_t(nzchunks.size()) - sg.nzc0; sg.nls = uint32_t(list_slots.size()) - sg.ls0; sg.nts = uint32_t(tok_slots.size()) - sg.ts0;
+    }
     struct SearchImg {
         int cand_work[64]; int ncand;       // candidate number -> work item (-1: not coded by itself -- see search_work)
         int Al_luma = 0, Al_chroma = 0;
@@ -190,6 +210,10 @@ struct csh_batch {
     DevBuf<DevEncTable> d_tables;
     DevBuf<uint8_t> d_scan_tmp;
     DevBuf<uint8_t> d_work_active;
+    DevBuf<NzList> d_nzlists;
+    DevBuf<NzSet> d_nzsets;
+    DevBuf<NzChunk> d_nzchunks;
+    DevBuf<uint32_t> d_nz_pool, d_nz_cursor, d_nz_chunk_off, d_nz_chunk_cnt, d_list_slots, d_tok_slots;
     DevBuf<TrellisWork> d_twork;
     DevBuf<TrellisChunk> d_tchunks;
     DevBuf<uint64_t> d_tlambda;
@@ -433,6 +457,14 @@ static void layout_token_pool(csh_batch *b) {
         at += (cap + 3) & ~uint64_t(3);
     }
     b->tok_cap = at + 64;
+    // the list pool (k_aclist.hip): the same rule, capped by what a list can hold at most; regions start on 16-byte boundaries
+    at = 0;
+    for (size_t i = 0; i < b->nzlists.size(); i++) {
+        const uint64_t cap = std::min<uint64_t>(uint64_t(b->nz_est[i]) * b->tok_scale, b->nz_worst[i]);
+        b->nzlists[i].base = at; b->nzlists[i].cap = uint32_t(cap);
+        at += (cap + 3) & ~uint64_t(3);
+    }
+    b->nz_cap = at + 64;
 }
 static int batch_create(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, bool webp, csh_batch **out, bool rgb_out, const csp_pixels *px) {
     *out = nullptr;
@@ -500,15 +532,59 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         b->script.push_back(e);
         return b->cand_script[key] = int(b->script.size()) - 1;
     };
+    // the NzList of (image, component, Al), made on first use (k_aclist.hip): the list itself, level 0 (what the others are filtered from), the set
+    auto nz_list = [&](int img_index, int comp, int Al, const ImgDesc &im, size_t in_len) -> uint32_t {
+        if (b->nzset_of.size() < size_t(img_index + 1) * CSH_MAX_COMPS) b->nzset_of.resize(size_t(img_index + 1) * CSH_MAX_COMPS, -1);
+        int &si = b->nzset_of[size_t(img_index) * CSH_MAX_COMPS + size_t(comp)];
+        const uint32_t nu = uint32_t(im.out[comp].real_bw * im.out[comp].real_bh);
+        if (si < 0) {
+            NzSet S;
+            memset(&S, 0, sizeof S);
+            for (int L = 0; L < CSH_NZ_LEVELS; L++) S.list[L] = 0xFFFFFFFFu;
+            S.nunits = nu; S.real_bw = im.out[comp].real_bw; S.bw = im.out[comp].bw; S.tile_base = im.out[comp].tile_base;   // rebased with the plans below
+            si = int(b->nzsets.size());
+            b->nzsets.push_back(S); b->nzset_built.push_back(0u); b->nzset_comp.push_back(comp); b->nzset_image.push_back(img_index);
+        }
+        uint64_t blocks_all = 0;
+        for (int k = 0; k < im.ncomp; k++) blocks_all += uint64_t(im.out[k].real_bw) * im.out[k].real_bh;
+        // a non-zero coefficient costs a source file 3 bits at the very least and ~5 at ordinary qualities; one of magnitude >= 2^Al more
+        static const uint32_t kShare[CSH_NZ_LEVELS] = {20, 16, 12, 9};   // eighths of the file's bytes, per level
+        for (int L : {0, Al}) {
+            if (b->nzsets[size_t(si)].list[L] != 0xFFFFFFFFu) continue;
+            const uint32_t nch = (nu + 255) / 256;
+            NzList R;
+            memset(&R, 0, sizeof R);
+            R.chunk0 = b->nz_nrec; b->nz_nrec += nch;
+            b->nzsets[size_t(si)].list[L] = uint32_t(b->nzlists.size());
+            b->nzlists.push_back(R);
+            const uint64_t est = uint64_t(in_len) * kShare[L] / 8 * nu / std::max<uint64_t>(1, blocks_all) + nu + 4ull * nch + 256;
+            const uint64_t worst = uint64_t(nu) * 64 + 4ull * nch;
+            b->nz_est.push_back(uint32_t(std::min<uint64_t>(est, worst)));
+            b->nz_worst.push_back(uint32_t(std::min<uint64_t>(worst, 0xFFFFFFF0ull)));
+        }
+        return b->nzsets[size_t(si)].list[Al];
+    };
     // work items, slots, token chunks and plans of one image for a list of scans (EncScan indices), in list order
     auto add_works = [&](Item &it, ImgDesc &im, int img_index, const std::vector<int> &list, size_t in_len, const JpegInfo &o, bool stats_only = false) {
         const int w_first = int(b->swork.size());
+        uint32_t nz_need[CSH_MAX_COMPS] = {0, 0, 0}, nz_gate[CSH_MAX_COMPS] = {0, 0, 0};
         for (int sidx : list) {
             const EncScan &e = b->script[sidx];
             ScanWork w;
             memset(&w, 0, sizeof w);
             w.image = img_index; w.scan = sidx;
             w.out_off = 0xFFFFFFFFu;   // not part of a file until k_layout says so (a conditional stage of the scan search may never run)
+            // progressive AC first-pass scans are coded from the component's compacted list at their Al; everything else from tokens
+            const bool from_list = e.Ss > 0 && !e.sequential && e.Ah == 0;
+            w.list = 0xFFFFFFFFu;
+            if (from_list) {
+                if (e.Al >= CSH_NZ_LEVELS) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "internal: output scan script outside what the list coder carries"; }
+                else {
+                    w.list = nz_list(img_index, e.comp[0], e.Al, im, in_len);
+                    if (!nz_need[e.comp[0]]) nz_gate[e.comp[0]] = uint32_t(b->swork.size());
+                    nz_need[e.comp[0]] |= 1u << e.Al;
+                }
+            }
             if (e.Ss == 0 && e.ncomp > 1) w.nunits = uint32_t(im.omcus_x * im.omcus_y);
             else w.nunits = uint32_t(im.out[e.comp[0]].real_bw * im.out[e.comp[0]].real_bh);
             w.unit_base = uint32_t(b->total_units);
@@ -524,10 +600,11 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 SlotRec r;
                 r.work = uint32_t(b->swork.size()); r.j = j; r.nch = nch; r.first_chunk = w.first_chunk; r.unit0 = w.unit_base + 256 * j;
                 r.nun = std::min<uint32_t>(256, w.nunits - 256 * j); r.table_base = w.table_base; r.ntables = uint16_t(e.ntables);
-                r.flags = uint16_t((e.Ss > 0 && !e.sequential ? 1 : 0) | (e.Ss > 0 && !e.sequential && e.Ah ? 2 : 0));
+                r.flags = uint16_t((e.Ss > 0 && !e.sequential ? 1 : 0) | (e.Ss > 0 && !e.sequential && e.Ah ? 2 : 0) | (w.list != 0xFFFFFFFFu ? 4 : 0));
                 r.hist_row = b->hist_rows; b->hist_rows += uint32_t(e.ntables);
                 r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
                 r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                (w.list != 0xFFFFFFFFu ? b->list_slots : b->tok_slots).push_back(uint32_t(b->slots.size()));
                 b->slots.push_back(r);
             }
             if (e.Ss == 0 || e.sequential) {   // DC scans and sequential-mode scans: one token workgroup per (scan, 256 units)
@@ -540,10 +617,20 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             }
             b->swork.push_back(w);
         }
-        // the progressive AC scans of a component share one pass over its blocks
+        // the lists this call's scans need and no earlier stage makes: one builder wave per 256 blocks (the trellis stage's statistics
+        // scans are coded from the scalar-quantised coefficients, the other stages from the trellis's: that stage makes its level 0 anew)
+        for (int c = 0; c < im.ncomp; c++) {
+            if (!nz_need[c]) continue;
+            const int si = b->nzset_of[size_t(img_index) * CSH_MAX_COMPS + size_t(c)];
+            const uint32_t levels = stats_only ? (nz_need[c] | 1u) : ((nz_need[c] | 1u) & ~b->nzset_built[size_t(si)]);
+            b->nzset_built[size_t(si)] |= levels;
+            const uint32_t nu = b->nzsets[size_t(si)].nunits;
+            for (uint32_t j = 0; levels && j < (nu + 255) / 256; j++) b->nzchunks.push_back(NzChunk{uint32_t(si), j, levels, nz_gate[c]});
+        }
+        // the progressive AC refinement scans of a component share one pass over its blocks (k_tokens)
         for (int c = 0; c < im.ncomp; c++) {
             int nac = 0;
-            for (int sidx : list) { const EncScan &e = b->script[sidx]; if (e.Ss > 0 && !e.sequential && e.comp[0] == c) { nac++; if (e.Al > (e.Ah ? 3 : 4)) nac = 99; } }
+            for (int sidx : list) { const EncScan &e = b->script[sidx]; if (e.Ss > 0 && !e.sequential && e.Ah && e.comp[0] == c) { nac++; if (e.Al > 3) nac = 99; } }
             if (nac > CSH_TK_MAXSLOT) { it.code = CS_ERR_JPEG_FEATURE; it.msg = "internal: output scan script outside what the token kernel carries"; }
             const uint32_t nu = uint32_t(im.out[c].real_bw * im.out[c].real_bh);
             if (!nac || nac > CSH_TK_MAXSLOT) continue;
@@ -553,7 +640,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             P.work0 = 0xFFFFFFFFu;
             for (size_t k = 0; k < list.size(); k++) {
                 const EncScan &e = b->script[list[k]];
-                if (!(e.Ss > 0 && !e.sequential && e.comp[0] == c)) continue;
+                if (!(e.Ss > 0 && !e.sequential && e.Ah && e.comp[0] == c)) continue;
                 const ScanWork &w = b->swork[size_t(w_first) + k];
                 if (P.work0 == 0xFFFFFFFFu) P.work0 = uint32_t(w_first) + uint32_t(k);   // the plan's scans are coded or skipped together: the first stands for all
                 AcSlot &a = P.s[P.nslot++];
@@ -954,8 +1041,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     b->hdr_off.push_back(uint32_t(b->hdr_pool.size()));
     b->nimg = int(b->imgs.size());
     // stage boundary: everything made so far is stage 1 (without the search: all there is)
-    b->stage[0].nwork = uint32_t(b->swork.size()); b->stage[0].nslots = uint32_t(b->slot_work.size()); b->stage[0].nech = uint32_t(b->echunks.size());
-    b->stage[0].ntables = uint32_t(b->ntables); b->stage[0].nplans = uint32_t(b->plans.size());
+    b->stage_end(b->stage[0]);
     if (b->search) {
         static const int split[5] = {2, 8, 5, 12, 18};
         // the later stages, each contiguous: make(image, add) lists the stage's candidates of one image
@@ -963,8 +1049,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             // one unused slot between the stages: each stage's exclusive scan of chunk sizes writes one entry past its slots
             { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
             csh_batch::Stage &sg = b->stage[sid];
-            sg.work0 = uint32_t(b->swork.size()); sg.slot0 = uint32_t(b->slot_work.size()); sg.ech0 = uint32_t(b->echunks.size());
-            sg.table0 = uint32_t(b->ntables); sg.plan0 = uint32_t(b->plans.size());
+            b->stage_begin(sg);
             for (size_t n = 0; n < count; n++) {
                 Item &it = b->items[n];
                 if (it.image < 0) continue;
@@ -977,8 +1062,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 add_works(it, im, it.image, list, inputs[n].length, it.out);
                 for (size_t k = 0; k < cands.size(); k++) si.cand_work[cands[k]] = first + int(k);
             }
-            sg.nwork = uint32_t(b->swork.size()) - sg.work0; sg.nslots = uint32_t(b->slot_work.size()) - sg.slot0;
-            sg.nech = uint32_t(b->echunks.size()) - sg.ech0; sg.ntables = uint32_t(b->ntables) - sg.table0; sg.nplans = uint32_t(b->plans.size()) - sg.plan0;
+            b->stage_end(sg);
             return 0;
         };
         // ST_1B: luma at Al 3 -- the refinement that brings it back to 2 and the two band scans
@@ -1011,8 +1095,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         // histograms only (mozjpeg jcmaster.c: the huff_opt pass in front of every trellis pass; oracle: cso_trellis_tables)
         { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
         csh_batch::Stage &tg = b->tstage;
-        tg.work0 = uint32_t(b->swork.size()); tg.slot0 = uint32_t(b->slot_work.size()); tg.ech0 = uint32_t(b->echunks.size());
-        tg.table0 = uint32_t(b->ntables); tg.plan0 = uint32_t(b->plans.size());
+        b->stage_begin(tg);
         auto seq1_index = [&](int comp) -> int {
             const std::array<int, 5> key = {comp, 0, 63, -1, -1};
             auto f = b->cand_script.find(key);
@@ -1047,14 +1130,14 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 b->twork.push_back(tw);
             }
         }
-        tg.nwork = uint32_t(b->swork.size()) - tg.work0; tg.nslots = uint32_t(b->slot_work.size()) - tg.slot0;
-        tg.nech = uint32_t(b->echunks.size()) - tg.ech0; tg.ntables = uint32_t(b->ntables) - tg.table0; tg.nplans = uint32_t(b->plans.size()) - tg.plan0;
+        b->stage_end(tg);
         if (b->total_units > 0xFFFFFFF0ull) { csh_set_error("csh_batch_create: batch too large (fewer files per batch)"); return CS_ERR_POOL_OVERFLOW; }
     }
     // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
     if (!b->lossless)
         for (ImgDesc &im : b->imgs) for (int c = 0; c < im.ncomp; c++) im.out[c].tile_base += b->ntiles_in;
     for (size_t i = 0; i < b->plans.size(); i++) b->plans[i].tile_base = b->imgs[size_t(b->plan_image[i])].out[b->plan_comp[i]].tile_base;
+    for (size_t i = 0; i < b->nzsets.size(); i++) b->nzsets[i].tile_base = b->imgs[size_t(b->nzset_image[i])].out[b->nzset_comp[i]].tile_base;
     for (ParScan &ps : b->pscans)   // table selectors: slot numbers of the table-set form the batch uses
         for (int m = 0; m < ps.nb_mcu && m < 10; m++) {
             int dcs = ps.dct[m] & 3, acs = 4 + (ps.act[m] & 3);
@@ -1092,6 +1175,8 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->d_tok_off.alloc(4 * b->slot_work.size() + 4) || b->d_chunk_ntok.alloc(4 * b->slot_work.size() + 4) || b->d_slot_hist.alloc(size_t(b->hist_rows) * 256 + 256) ||
             b->d_slot_raw.alloc(b->slot_work.size() + 1) || b->d_img_list.upload(b->img_list, st) || b->d_img_nlist.upload(b->img_nlist, st) || b->d_scan_cost.alloc(b->swork.size() + 1) || b->d_slot_eobh.alloc(16 * b->slot_work.size() + 16) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
             b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
+            b->d_nzlists.upload(b->nzlists, st) || b->d_nzsets.upload(b->nzsets, st) || b->d_nzchunks.upload(b->nzchunks, st) || b->d_list_slots.upload(b->list_slots, st) || b->d_tok_slots.upload(b->tok_slots, st) ||
+            b->d_nz_cursor.alloc(b->nzlists.size() + 1) || b->d_nz_chunk_off.alloc(size_t(b->nz_nrec) + 1) || b->d_nz_chunk_cnt.alloc(size_t(b->nz_nrec) + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
             return CS_ERR_NO_DEVICE;
@@ -1179,15 +1264,15 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
     "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
-    "k_idct_plane", "resize", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc", "k_tokens",
-    "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack",
-    "k_ff_count", "-", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", ""};
+    "k_idct_plane", "resize", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc",
+    "k_nzlist", "k_tokens", "k_list_stats", "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack", "k_list_pack",
+    "k_ff_count", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", "", ""};
 // a WebP batch (csh_batch_create_webp) leaves the JPEG path behind the resize slot: its next three slots are these
 static const char *const kWebpTailNames[3] = {"k_webp_yuv", "k_webp_mb", "k_webp_stats+probs+code+assemble"};
 
 // the trellis slots (statistics scan = k_tokens without tokens + k_ac_runs + k_gen_tables; the two k_trellis kernels + k_fix_dummy) count
 // as phase 1: they are the quantiser; zero unless CSH_PROFILE=mozjpeg
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 3, 4, 4, 4, 5, 6, 6, 7, 6, 6, 6, 7, 7};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 2, 2, 3, 4, 4, 4, 5, 5, 6, 7, 6, 6, 6, 7, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
 extern "C" const char *csh_kernel_name_webp(int i) { return (i >= 10 && i < 13) ? kWebpTailNames[i - 10] : csh_kernel_name(i); }
 
@@ -1356,7 +1441,9 @@ static int search_decide(csh_batch *b, int stage) {
                 ScanWork &w = b->swork[wi];
                 const EncScan e = b->script[size_t(w.scan)];
                 const csh_batch::SearchImg &si = b->simg[size_t(w.image)];
-                w.scan = b->cand_script.at({e.comp[0], e.Ss, e.Se, 0, e.comp[0] == 0 ? si.Al_luma : si.Al_chroma});
+                const int Al = e.comp[0] == 0 ? si.Al_luma : si.Al_chroma;
+                w.scan = b->cand_script.at({e.comp[0], e.Ss, e.Se, 0, Al});
+                w.list = b->nzsets[size_t(b->nzset_of[size_t(w.image) * CSH_MAX_COMPS + size_t(e.comp[0])])].list[Al];   // made by ST_1 (Al 0..2) or ST_1B (luma Al 3)
             }
             for (uint32_t pi = sg.plan0; pi < sg.plan0 + sg.nplans; pi++) {
                 TokPlan &P = b->plans[pi];
@@ -1411,6 +1498,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         if (b->d_scan_tmp.alloc(tmp)) return -1;
     }
     if (b->d_tokens.n < b->tok_cap && b->d_tokens.alloc(b->tok_cap)) return -1;
+    if (b->d_nz_pool.n < b->nz_cap && b->d_nz_pool.alloc(b->nz_cap)) return -1;
     hipEvent_t ev[CSH_NKERNELS + 1];
     for (auto &e : ev) CSH_CHECK(hipEventCreate(&e));
     int slot = 0;
@@ -1514,7 +1602,10 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     c.tokens = b->d_tokens.p; c.regions = b->d_regions.p; c.tok_cursor = b->d_tok_cursor.p; c.tok_off = b->d_tok_off.p; c.chunk_ntok = b->d_chunk_ntok.p; c.slot_hist = b->d_slot_hist.p; c.slot_raw = b->d_slot_raw.p; c.slot_eobh = b->d_slot_eobh.p;
     c.chunk_bits = b->d_chunk_bits.p; c.chunk_off = b->d_chunk_off.p; c.tables = b->d_tables.p;
     c.raw = b->d_raw.p; c.raw_words = raw_chunks * 16; c.status = b->d_status.p; c.overflow = b->d_overflow.p;
+    c.nzlists = b->d_nzlists.p; c.nzsets = b->d_nzsets.p; c.nz_pool = b->d_nz_pool.p; c.nz_cursor = b->d_nz_cursor.p; c.nz_chunk_off = b->d_nz_chunk_off.p; c.nz_chunk_cnt = b->d_nz_chunk_cnt.p;
     c.debug = getenv("CSH_DEBUG") ? uint32_t(atoi(getenv("CSH_DEBUG"))) : 0u;
+    launch_reset_works(st, b->d_swork.p, c.nwork);
+    if (b->d_nz_cursor.zero(st) || b->d_nz_chunk_cnt.zero(st)) return -1;
     if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st) || b->d_scan_pad.zero(st)) return -1;
 #ifdef CSH_EMUL
     if (b->d_raw.zero(st)) return -1;   // the emulation's packer ORs every word into the pool (no LDS window there)
@@ -1524,14 +1615,23 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     MARK();
     // ---- mozjpeg's trellis quantiser (CSH_PROFILE=mozjpeg): per component a statistics scan over the scalar-quantised coefficients
     // (tokens without tokens: histograms, flags, EOB runs -> optimal tables), then every block re-quantised from the retained DCT
+    auto set_stage = [&](const csh_batch::Stage &sg) {
+        c.echunks = b->d_echunks.p + sg.ech0; c.nechunks = sg.nech; c.slot0 = sg.slot0; c.nslots = sg.nslots;
+        c.nzchunks = b->d_nzchunks.p + sg.nzc0; c.nnzchunks = sg.nnzc;
+        c.list_slots = b->d_list_slots.p + sg.ls0; c.nlist_slots = sg.nls; c.tok_slots = b->d_tok_slots.p + sg.ts0; c.ntok_slots = sg.nts;
+    };
     if (b->trellis) {
         const csh_batch::Stage &tg = b->tstage;
-        c.echunks = b->d_echunks.p + tg.ech0; c.nechunks = tg.nech; c.slot0 = tg.slot0; c.nslots = tg.nslots; c.stats_only = 1;
+        set_stage(tg);
+        c.stats_only = 1;
         if (b->d_long_cnt.zero(st)) return -1;
-        launch_tokens(st, c);
+        launch_nzlist(st, c);       // level 0 of the scalar-quantised coefficients (progressive output: the statistics scans are list slots)
+        launch_tokens(st, c);       // (sequential output: one-component sequential scans, histograms only)
+        launch_list_stats(st, c);
         launch_ac_runs(st, c);
         launch_gen_tables(st, b->d_tables.p + tg.table0, int(tg.ntables));
         c.stats_only = 0;
+        if (b->d_nz_cursor.zero(st)) return -1;   // the lists are made again from what the trellis leaves
         MARK();
         TrellisCtx tc;
         memset(&tc, 0, sizeof tc);
@@ -1558,11 +1658,15 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     // (without the scan search: one stage, everything).  mark: timing slots are recorded for stage 1 only, stage 2 gets one slot.
     auto run_stage = [&](const csh_batch::Stage &sg, bool mark, bool gate) -> int {
 #define SMARK() do { if (mark) MARK(); } while (0)
-        c.echunks = b->d_echunks.p + sg.ech0; c.nechunks = sg.nech; c.slot0 = sg.slot0; c.nslots = sg.nslots;
+        set_stage(sg);
         c.work_active = gate ? b->d_work_active.p : nullptr;
         a.work0 = int(sg.work0); a.nwork_run = int(sg.nwork);
         if (b->d_long_cnt.zero(st)) return -1;
-        launch_tokens(st, c);
+        launch_nzlist(st, c);       // the lists this stage's first-pass scans are coded from and no earlier stage made
+        SMARK();
+        launch_tokens(st, c);       // DC, sequential-mode and refinement scans
+        SMARK();
+        launch_list_stats(st, c);   // AC first-pass scans
         SMARK();
         launch_ac_runs(st, c);
         SMARK();
@@ -1579,9 +1683,10 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         SMARK();
         launch_pack(st, c);
         SMARK();
+        launch_list_pack(st, c);
+        SMARK();
         launch_ff_count(st, a);
         SMARK();
-        SMARK();   // (the slot of the scan over every chunk's count that k_ff_count's per-scan totals replaced)
 #undef SMARK
         return 0;
     };
@@ -1685,7 +1790,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
         if (ovf[1]) {   // token pool (k_tokens)
             pool = true; b->tok_scale *= 4;
             layout_token_pool(b);
-            if (b->d_regions.upload(b->regions, b->stream) || hipStreamSynchronize(b->stream) != hipSuccess) return CS_ERR_NO_DEVICE;
+            if (b->d_regions.upload(b->regions, b->stream) || b->d_nzlists.upload(b->nzlists, b->stream) || hipStreamSynchronize(b->stream) != hipSuccess) return CS_ERR_NO_DEVICE;
         }
         for (uint32_t s : b->h_status) if (s == CS_ERR_POOL_OVERFLOW) pool = true;
         if (!pool) break;

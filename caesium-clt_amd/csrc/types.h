@@ -179,6 +179,7 @@ struct ScanWork {
     uint32_t out_off;      // offset of this scan's DHT marker inside the image's output file (device-computed)
     uint32_t hdr_bytes;    // DHT + SOS bytes in front of the entropy-coded data (device-computed)
     uint32_t no_room;      // the raw pool cannot hold this scan (device-computed): the packer skips it, the batch is re-run with a larger pool
+    uint32_t list;         // progressive AC scans: the NzList (component, point transform) the scan is coded from (k_aclist.hip); 0xFFFFFFFF otherwise
 };
 
 // one workgroup of the token kernel (k_tokens): 256 consecutive units, [256 j, 256 j + 256)
@@ -201,13 +202,38 @@ struct TokPlan {
     uint32_t pad[2];
     AcSlot s[CSH_TK_MAXSLOT];
 };
+// ---- the compacted coefficient lists (k_aclist.hip): what every progressive AC scan is coded from.
+// One NzList per (image, component, point transform Al): for every real block, in scan order, one entry per coefficient k = 1..63 with
+// |c_k| >> Al != 0, then one END entry.  An entry is one u32:
+//   [6:0] k (1..63; 64 = END; 0 = padding, codes nothing)   [7] sign (1: negative)   [22:8] |c_k| >> Al   [30:23] block inside its 256-block chunk
+// The entries of a 256-block chunk are contiguous and start on a 16-byte boundary (chunk_off / chunk_cnt per (list, chunk)); chunks of a
+// list are placed with a bump cursor inside the list's region of the pool, like the token regions.
+#define CSH_NZ_END 64u
+#define CSH_NZ_LEVELS 4   // Al 0..3 (the scan search tries luma up to Al 3)
+struct NzList {
+    uint64_t base;         // first entry of the list's region in the pool
+    uint32_t cap;          // entries the region holds
+    uint32_t chunk0;       // first of the list's (nunits + 255) / 256 records in the per-chunk arrays
+};
+// the lists of one component of one image, and what the builder needs to read its blocks
+struct NzSet {
+    uint32_t list[CSH_NZ_LEVELS];   // NzList index per Al, 0xFFFFFFFF: not kept
+    uint32_t nunits;                // real blocks of the component
+    int32_t real_bw, bw;            // block grid: real and MCU-padded width
+    uint32_t tile_base;
+    uint32_t pad[4];
+};
+// one wave of the builder: chunk j of set `set`, the levels in `levels` (bit Al).  Level 0 is made from the coefficients; the others are
+// filtered from level 0 (which an earlier stage may have made)
+struct NzChunk { uint32_t set, j, levels, work0; };   // work0: a work item whose gate (EncCtx::work_active) stands for the chunk in a conditional stage
+
 // what the per-slot kernels need of (work item, chunk j), in one 32-byte load (host-built; slot = work.first_chunk + j)
 struct SlotRec {
     uint32_t work, j, nch;       // work item, chunk number, chunks of the work item
     uint32_t first_chunk;        // the work item's first slot
     uint32_t unit0, nun;         // first unit (index into the per-unit arrays) and number of units of the chunk
     uint32_t table_base;
-    uint16_t ntables, flags;     // flags: 1 progressive AC scan (EOB tokens), 2 refinement (correction words)
+    uint16_t ntables, flags;     // flags: 1 progressive AC scan (EOB tokens), 2 refinement (correction words), 4 coded from its NzList (k_aclist.hip), not from tokens
     uint32_t hist_row;           // first of the slot's ntables rows of 256 symbol counts (EncCtx::slot_hist)
     uint32_t word_base, unit_base, nunits_work;   // of the work item (k_ac_runs)
     uint8_t Ss, Se, Ah, Al; uint32_t pad[3];

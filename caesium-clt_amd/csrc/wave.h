@@ -1,0 +1,42 @@
+// wave.h -- wave-level helpers for kernels written once for both builds (png_wave.h holds the basic set: LV<T> per-lane values,
+// LFOR(l) "for every lane", lballot, lscan).  Product build: a 64-lane wave, cross-lane traffic on the VALU's DPP path.  Emulation build
+// (tests only): one host thread plays the whole wave, LV<T> is a 64-element array.  The kernel logic between the two is shared line for line.
+#pragma once
+#include "png_wave.h"
+
+namespace csh {
+
+using csp::LV;
+using csp::lballot;
+using csp::lanes_below;
+using csp::lscan;
+using csp::uni;
+
+// lane l gets the value of lane l - 1; lane 0 gets `carry`
+__device__ __forceinline__ static LV<uint32_t> lprev(const LV<uint32_t> &x, uint32_t carry) {
+    LV<uint32_t> r;
+#ifdef CSH_EMUL
+    r.v[0] = carry;
+    for (int j = 1; j < 64; j++) r.v[j] = x.v[j - 1];
+#else
+    r.v = uint32_t(__builtin_amdgcn_update_dpp(int(carry), int(x.v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+#endif
+    return r;
+}
+// the value of lane 63, in every lane (wave-uniform)
+__device__ __forceinline__ static uint32_t llast(const LV<uint32_t> &x) {
+#ifdef CSH_EMUL
+    return x.v[63];
+#else
+    return uint32_t(__builtin_amdgcn_readlane(int(x.v), 63));
+#endif
+}
+// sum over the lanes, in every lane (all 64 lanes active)
+__device__ __forceinline__ static uint32_t lsum32(const LV<uint32_t> &x) {
+    uint32_t s;
+    (void)lscan(x, s);
+    return s;
+}
+__device__ __forceinline__ static uint32_t popc64(uint64_t m) { return uint32_t(__popcll((unsigned long long)m)); }
+
+}  // namespace csh

@@ -116,7 +116,7 @@ void cs_free_result(CCSResult *r);
  */
 typedef struct csh_batch csh_batch;
 
-enum { CSH_NPHASES = 8, CSH_NKERNELS = 32 };
+enum { CSH_NPHASES = 8, CSH_NKERNELS = 36 };
 typedef struct {
     float total_ms;               /* hipEvent time around the whole run, on the batch's stream */
     float phase_ms[CSH_NPHASES];  /* 0 decode, 1 pixel transcode, 2 masks+flags+runs, 3 stats+tables,
