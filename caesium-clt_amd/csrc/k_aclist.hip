@@ -26,146 +26,179 @@ __device__ __forceinline__ static uint32_t lbitlen(uint32_t v) { return 32u - ui
 __device__ __forceinline__ static int lwave() { return int(threadIdx.x) / CSP_WAVE_THREADS; }
 
 // ------------------------------------------------------------------------------------------------ the builder
-// One wave per 256-block chunk of a component.  Lane (b, o) = (l >> 3, l & 7) holds octet o (coefficients 8 o .. 8 o + 7: one 16-byte
-// load) of block 8 s + b in step s, so the lanes of a step, in lane order, hold 8 blocks' coefficients in list order: a wave scan of the
-// per-lane counts places every lane's entries, and the lanes' stores land next to each other.  Two passes over the coefficients (the
-// second one out of the L2): the chunk's entry count, then -- behind one atomic add on the list's cursor -- the entries.
-// The lists of the other point transforms are filtered from level 0 (flat: entry -> |c| >> Al, dropped when that is zero).
-struct NzCoord { int bx, by; };
-__device__ __forceinline__ static uint4 nz_load(const EncCtx &c, const NzSet &S, uint32_t u, const NzCoord &xy, uint32_t oct) {
+// Level 0 (k_nzlist): one wave per 256-block chunk of a component.  Lane (b, o) = (l >> 3, l & 7) holds octet o (coefficients 8 o .. 8 o + 7:
+// one 16-byte load) of block 8 s + b in step s, so the lanes of a step, in lane order, hold 8 blocks' coefficients in list order: a wave
+// scan of the per-lane counts places every lane's entries, and the lanes' stores land next to each other.  Half a chunk (16 steps) is
+// loaded at once -- 16 loads in flight per lane, 64 registers -- so the two passes (the chunk's entry count, then, behind one atomic add
+// on the list's cursor, the entries) wait for memory three times in all, not once per step.
+// The other levels (k_nzfilter): flat over the level-0 chunk, entry -> |c| >> Al, dropped when that is zero.
+#define CSH_NZ_HALF 16   // steps of 8 blocks held in registers at a time: half a chunk
+__device__ __forceinline__ static uint4 nz_load(const EncCtx &c, const NzSet &S, uint32_t u, int bx, int by, uint32_t oct) {
     uint4 q; q.x = q.y = q.z = q.w = 0u;
     if (u < S.nunits) {
-        const int b = xy.by * S.bw + xy.bx;
+        const int b = by * S.bw + bx;
         q = *reinterpret_cast<const uint4 *>(c.coef + (size_t(S.tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE) + size_t(oct) * CSH_OCT_STRIDE);
     }
     return q;
 }
-__device__ __forceinline__ static void nz_advance(NzCoord &xy, int real_bw) {   // eight blocks on
-    xy.bx += 8;
-    while (xy.bx >= real_bw) { xy.bx -= real_bw; xy.by++; }
-}
 // bit i: coefficient i of the octet is a non-zero AC coefficient
-__device__ __forceinline__ static uint32_t nz_mask8(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t oct) {
+__device__ __forceinline__ static uint32_t nz_mask8(const uint4 &q, uint32_t oct) {
     uint32_t m = 0;
-    m |= (w0 & 0xFFFFu) ? 1u : 0u;   m |= (w0 >> 16) ? 2u : 0u;
-    m |= (w1 & 0xFFFFu) ? 4u : 0u;   m |= (w1 >> 16) ? 8u : 0u;
-    m |= (w2 & 0xFFFFu) ? 16u : 0u;  m |= (w2 >> 16) ? 32u : 0u;
-    m |= (w3 & 0xFFFFu) ? 64u : 0u;  m |= (w3 >> 16) ? 128u : 0u;
+    m |= (q.x & 0xFFFFu) ? 1u : 0u;   m |= (q.x >> 16) ? 2u : 0u;
+    m |= (q.y & 0xFFFFu) ? 4u : 0u;   m |= (q.y >> 16) ? 8u : 0u;
+    m |= (q.z & 0xFFFFu) ? 16u : 0u;  m |= (q.z >> 16) ? 32u : 0u;
+    m |= (q.w & 0xFFFFu) ? 64u : 0u;  m |= (q.w >> 16) ? 128u : 0u;
     return oct ? m : (m & ~1u);
+}
+// half `half` (128 blocks, 16 steps) of the chunk that starts at block u0: every lane's 16 octets, all loads in flight at once
+__device__ __forceinline__ static void nz_load_half(const EncCtx &c, const NzSet &S, uint32_t u0, int half, LV<uint4> (&q)[CSH_NZ_HALF]) {
+    LFOR(l) {
+        const uint32_t oct = uint32_t(l & 7);
+        uint32_t u = u0 + 128u * uint32_t(half) + uint32_t(l >> 3);
+        int by = int(u) / S.real_bw, bx = int(u) - by * S.real_bw;
+        CSH_UNROLL
+        for (int s = 0; s < CSH_NZ_HALF; s++) {
+            q[s][l] = nz_load(c, S, u, bx, by, oct);
+            u += 8u; bx += 8;
+            while (bx >= S.real_bw) { bx -= S.real_bw; by++; }   // eight blocks on
+        }
+    }
+}
+// entries of the half per lane: its non-zero AC coefficients; the lane of octet 7 adds the block's END
+__device__ __forceinline__ static void nz_count_half(const NzSet &S, uint32_t u0, int half, const LV<uint4> (&q)[CSH_NZ_HALF], LV<uint32_t> &cnt) {
+    LFOR(l) {
+        const uint32_t oct = uint32_t(l & 7);
+        uint32_t n = 0;
+        CSH_UNROLL
+        for (int s = 0; s < CSH_NZ_HALF; s++)
+            n += uint32_t(__popc(nz_mask8(q[s][l], oct))) + ((oct == 7u && u0 + 128u * uint32_t(half) + 8u * uint32_t(s) + uint32_t(l >> 3) < S.nunits) ? 1u : 0u);
+        cnt[l] += n;
+    }
+}
+__device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0, int half, const LV<uint4> (&q)[CSH_NZ_HALF], uint32_t *dst, uint32_t run) {
+    CSH_UNROLL
+    for (int s = 0; s < CSH_NZ_HALF; s++) {
+        LV<uint32_t> mk, cl;
+        LFOR(l) {
+            const uint32_t oct = uint32_t(l & 7);
+            mk[l] = nz_mask8(q[s][l], oct);
+            cl[l] = uint32_t(__popc(mk[l])) + ((oct == 7u && u0 + 128u * uint32_t(half) + 8u * uint32_t(s) + uint32_t(l >> 3) < S.nunits) ? 1u : 0u);
+        }
+        uint32_t tot;
+        const LV<uint32_t> ex = lscan(cl, tot);
+        LFOR(l) {
+            const uint32_t oct = uint32_t(l & 7);
+            const uint32_t blk = 16u * 8u * uint32_t(half) + 8u * uint32_t(s) + uint32_t(l >> 3);
+            const uint32_t base = (8u * oct) | (blk << 23);
+            const uint32_t w[4] = {q[s][l].x, q[s][l].y, q[s][l].z, q[s][l].w};
+            uint32_t o = run + ex[l];
+            CSH_UNROLL
+            for (int i = 0; i < 8; i++)
+                if ((mk[l] >> i) & 1u) {
+                    const int h = (i & 1) ? (int(w[i >> 1]) >> 16) : (int(w[i >> 1] << 16) >> 16);
+                    const uint32_t a = uint32_t(h < 0 ? -h : h);
+                    dst[o++] = (base + uint32_t(i)) | (h < 0 ? 128u : 0u) | (a << 8);
+                }
+            if (oct == 7u && u0 + blk < S.nunits) dst[o] = CSH_NZ_END | (base & 0x7F800000u);
+        }
+        run += tot;
+    }
 }
 __global__ void __launch_bounds__(64) k_nzlist(EncCtx c) {
     const NzChunk ch = c.nzchunks[blockIdx.x];
+    if (!(ch.levels & 1u)) return;
     const NzSet S = c.nzsets[ch.set];
     if (c.work_active && !c.work_active[ch.work0]) return;
     const uint32_t u0 = ch.j * 256u;
     const NzList L0 = c.nzlists[S.list[0]];
     const uint32_t rec0 = L0.chunk0 + ch.j;
-    uint32_t n0 = 0, off0 = 0;
-    bool ok0 = true;
-    LV<NzCoord> xy0;   // where every lane's first block lies
-    LFOR(l) { const uint32_t u = u0 + uint32_t(l >> 3); xy0[l].by = int(u) / S.real_bw; xy0[l].bx = int(u) - xy0[l].by * S.real_bw; }
-    if (ch.levels & 1u) {
-        // ---- pass 1: the chunk's entries
-        LV<uint32_t> cnt;
-        LV<NzCoord> xy = xy0;
-        LFOR(l) cnt[l] = 0;
-        for (uint32_t s = 0; s < 32; s++) {
-            LFOR(l) {
-                const uint32_t u = u0 + 8u * s + uint32_t(l >> 3), oct = uint32_t(l & 7);
-                const uint4 q = nz_load(c, S, u, xy[l], oct);
-                cnt[l] += uint32_t(__popc(nz_mask8(q.x, q.y, q.z, q.w, oct))) + ((oct == 7u && u < S.nunits) ? 1u : 0u);
-                nz_advance(xy[l], S.real_bw);
-            }
-        }
-        n0 = lsum32(cnt);
-        const uint32_t n0a = (n0 + 3u) & ~3u;
-        uint32_t rel = 0;
-        LFOR(l) if (l == 0) rel = atomicAdd(&c.nz_cursor[S.list[0]], n0a);
-        rel = uni(rel);
-        ok0 = uint64_t(rel) + n0a <= L0.cap;
-        LFOR(l) if (l == 0) { c.nz_chunk_off[rec0] = rel; c.nz_chunk_cnt[rec0] = ok0 ? n0 : 0u; if (!ok0) c.overflow[1] = 1; }
-        off0 = rel;
-        if (ok0) {
-            // ---- pass 2: the entries
-            uint32_t *dst = c.nz_pool + L0.base + rel;
-            uint32_t run = 0;
-            xy = xy0;
-            for (uint32_t s = 0; s < 32; s++) {
-                LV<uint32_t> w0, w1, w2, w3, mk, cl;
-                LFOR(l) {
-                    const uint32_t u = u0 + 8u * s + uint32_t(l >> 3), oct = uint32_t(l & 7);
-                    const uint4 q = nz_load(c, S, u, xy[l], oct);
-                    w0[l] = q.x; w1[l] = q.y; w2[l] = q.z; w3[l] = q.w;
-                    mk[l] = nz_mask8(q.x, q.y, q.z, q.w, oct);
-                    cl[l] = uint32_t(__popc(mk[l])) + ((oct == 7u && u < S.nunits) ? 1u : 0u);
-                    nz_advance(xy[l], S.real_bw);
-                }
-                uint32_t tot;
-                const LV<uint32_t> ex = lscan(cl, tot);
-                LFOR(l) {
-                    const uint32_t u = u0 + 8u * s + uint32_t(l >> 3), oct = uint32_t(l & 7);
-                    const uint32_t base = (8u * oct) | ((8u * s + uint32_t(l >> 3)) << 23);
-                    const uint32_t w[4] = {w0[l], w1[l], w2[l], w3[l]};
-                    uint32_t o = run + ex[l];
-                    CSH_UNROLL
-                    for (int i = 0; i < 8; i++)
-                        if ((mk[l] >> i) & 1u) {
-                            const int h = (i & 1) ? (int(w[i >> 1]) >> 16) : (int(w[i >> 1] << 16) >> 16);
-                            const uint32_t a = uint32_t(h < 0 ? -h : h);
-                            dst[o++] = (base + uint32_t(i)) | (h < 0 ? 128u : 0u) | (a << 8);
-                        }
-                    if (oct == 7u && u < S.nunits) dst[o] = CSH_NZ_END | (base & 0x7F800000u);
-                }
-                run += tot;
-            }
-            LFOR(l) if (n0 + uint32_t(l) < n0a) dst[n0 + uint32_t(l)] = 0u;   // padding to the next 16-byte boundary: entries that code nothing
-        }
-    } else { n0 = c.nz_chunk_cnt[rec0]; off0 = c.nz_chunk_off[rec0]; ok0 = n0 != 0; }
-    // ---- the other point transforms: filtered from level 0 (count, one atomic add per list, write)
+    // ---- pass 1: the chunk's entries, half after half; the second half stays in the registers
+    LV<uint4> q[CSH_NZ_HALF];
+    LV<uint32_t> cnt;
+    LFOR(l) cnt[l] = 0u;
+    nz_load_half(c, S, u0, 0, q);
+    nz_count_half(S, u0, 0, q, cnt);
+    const uint32_t nA = lsum32(cnt);
+    nz_load_half(c, S, u0, 1, q);
+    nz_count_half(S, u0, 1, q, cnt);
+    const uint32_t n0 = lsum32(cnt), n0a = (n0 + 3u) & ~3u;
+    uint32_t rel = 0;
+    LFOR(l) if (l == 0) rel = atomicAdd(&c.nz_cursor[S.list[0]], n0a);
+    rel = uni(rel);
+    const bool ok0 = uint64_t(rel) + n0a <= L0.cap;
+    LFOR(l) if (l == 0) { c.nz_chunk_off[rec0] = rel; c.nz_chunk_cnt[rec0] = ok0 ? n0 : 0u; if (!ok0) c.overflow[1] = 1; }
+    if (!ok0) return;
+    // ---- pass 2: the entries -- of the second half first (it is here), then of the first one (out of the L2)
+    uint32_t *dst = c.nz_pool + L0.base + rel;
+    nz_write_half(S, u0, 1, q, dst, nA);
+    nz_load_half(c, S, u0, 0, q);
+    nz_write_half(S, u0, 0, q, dst, 0u);
+    LFOR(l) if (n0 + uint32_t(l) < n0a) dst[n0 + uint32_t(l)] = 0u;   // padding to the next 16-byte boundary: entries that code nothing
+}
+// the other point transforms of a chunk, filtered from its level 0 (which this stage's k_nzlist or an earlier stage's made): count, one
+// atomic add per list, write.  Four entries per lane and step; the second pass reads the chunk out of the L2.
+__global__ void __launch_bounds__(64) k_nzfilter(EncCtx c) {
+    const NzChunk ch = c.nzchunks[blockIdx.x];
     const uint32_t others = ch.levels & ~1u;
     if (!others) return;
-    const uint32_t *src = c.nz_pool + L0.base + off0;
-    auto kept = [](uint32_t x, int L) { return (x & CSH_NZ_END) != 0u || (((x >> 8) & 0x7FFFu) >> L) != 0u; };   // an END entry, or a coefficient that is not zero at level L
-    uint32_t *dstL[CSH_NZ_LEVELS];
-    uint32_t runL[CSH_NZ_LEVELS], recL[CSH_NZ_LEVELS], cntL[CSH_NZ_LEVELS];
-    bool okL[CSH_NZ_LEVELS];
-    for (int L = 1; L < CSH_NZ_LEVELS; L++) { dstL[L] = nullptr; runL[L] = 0; recL[L] = 0; cntL[L] = 0; okL[L] = false; }
-    CSP_MEM_FENCE();   // this wave reads back, lane by lane, what other lanes of it have just stored
-    for (uint32_t g0 = 0; g0 < n0 && ok0; g0 += 64) {
-        LV<uint32_t> e;
-        LFOR(l) e[l] = g0 + uint32_t(l) < n0 ? csp::coherent_load(src + g0 + uint32_t(l)) : 0u;
-        for (int L = 1; L < CSH_NZ_LEVELS; L++)
-            if ((others >> L) & 1u) cntL[L] += popc64(lballot([&](int l) { return kept(e[l], L); }));
+    const NzSet S = c.nzsets[ch.set];
+    if (c.work_active && !c.work_active[ch.work0]) return;
+    const NzList L0 = c.nzlists[S.list[0]];
+    const uint32_t n0 = c.nz_chunk_cnt[L0.chunk0 + ch.j];
+    const uint32_t *src = c.nz_pool + L0.base + c.nz_chunk_off[L0.chunk0 + ch.j];
+    auto kept = [](uint32_t x, int L) { return ((x & CSH_NZ_END) != 0u || (((x >> 8) & 0x7FFFu) >> L) != 0u) ? 1u : 0u; };   // an END entry, or a coefficient that is not zero at level L
+    LV<uint32_t> cntL[CSH_NZ_LEVELS];
+    LFOR(l) for (int L = 1; L < CSH_NZ_LEVELS; L++) cntL[L][l] = 0u;
+    for (uint32_t g0 = 0; g0 < n0; g0 += 256) {
+        LFOR(l) {
+            const uint32_t g = g0 + 4u * uint32_t(l);
+            uint4 e; e.x = e.y = e.z = e.w = 0u;
+            if (g < n0) e = *reinterpret_cast<const uint4 *>(src + g);
+            CSH_UNROLL
+            for (int L = 1; L < CSH_NZ_LEVELS; L++) cntL[L][l] += kept(e.x, L) + kept(e.y, L) + kept(e.z, L) + kept(e.w, L);
+        }
     }
+    uint32_t *dstL[CSH_NZ_LEVELS];
+    uint32_t runL[CSH_NZ_LEVELS];
+    bool okL[CSH_NZ_LEVELS];
     for (int L = 1; L < CSH_NZ_LEVELS; L++) {
+        dstL[L] = nullptr; runL[L] = 0; okL[L] = false;
         if (!((others >> L) & 1u)) continue;
         const NzList LL = c.nzlists[S.list[L]];
-        const uint32_t na = (cntL[L] + 3u) & ~3u;
+        const uint32_t n = lsum32(cntL[L]), na = (n + 3u) & ~3u;
         uint32_t rel = 0;
         LFOR(l) if (l == 0) rel = atomicAdd(&c.nz_cursor[S.list[L]], na);
         rel = uni(rel);
-        okL[L] = ok0 && uint64_t(rel) + na <= LL.cap;
-        recL[L] = LL.chunk0 + ch.j;
+        okL[L] = n0 != 0u && uint64_t(rel) + na <= LL.cap;
         dstL[L] = c.nz_pool + LL.base + rel;
-        LFOR(l) if (l == 0) { c.nz_chunk_off[recL[L]] = rel; c.nz_chunk_cnt[recL[L]] = okL[L] ? cntL[L] : 0u; if (!okL[L]) c.overflow[1] = 1; }
-    }
-    for (uint32_t g0 = 0; g0 < n0 && ok0; g0 += 64) {
-        LV<uint32_t> e;
-        LFOR(l) e[l] = g0 + uint32_t(l) < n0 ? csp::coherent_load(src + g0 + uint32_t(l)) : 0u;
-        for (int L = 1; L < CSH_NZ_LEVELS; L++) {
-            if (!okL[L]) continue;
-            const uint64_t keep = lballot([&](int l) { return kept(e[l], L); });
-            LFOR(l) if ((keep >> l) & 1ull) {
-                const uint32_t x = e[l];
-                dstL[L][runL[L] + popc64(keep & lanes_below(l))] = (x & 0xFF8000FFu) | ((((x >> 8) & 0x7FFFu) >> L) << 8);
-            }
-            runL[L] += popc64(keep);
+        LFOR(l) {
+            if (l == 0) { c.nz_chunk_off[LL.chunk0 + ch.j] = rel; c.nz_chunk_cnt[LL.chunk0 + ch.j] = okL[L] ? n : 0u; if (!okL[L]) c.overflow[1] = 1; }
+            if (okL[L] && n + uint32_t(l) < na) dstL[L][n + uint32_t(l)] = 0u;   // padding
         }
     }
-    for (int L = 1; L < CSH_NZ_LEVELS; L++) {
-        if (!okL[L]) continue;
-        const uint32_t n = runL[L], na = (n + 3u) & ~3u;
-        LFOR(l) if (n + uint32_t(l) < na) dstL[L][n + uint32_t(l)] = 0u;
+    for (uint32_t g0 = 0; g0 < n0; g0 += 256) {
+        LV<uint32_t> e0, e1, e2, e3;
+        LFOR(l) {
+            const uint32_t g = g0 + 4u * uint32_t(l);
+            uint4 e; e.x = e.y = e.z = e.w = 0u;
+            if (g < n0) e = *reinterpret_cast<const uint4 *>(src + g);
+            e0[l] = e.x; e1[l] = e.y; e2[l] = e.z; e3[l] = e.w;
+        }
+        for (int L = 1; L < CSH_NZ_LEVELS; L++) {
+            if (!okL[L]) continue;
+            LV<uint32_t> k4;
+            LFOR(l) k4[l] = kept(e0[l], L) + kept(e1[l], L) + kept(e2[l], L) + kept(e3[l], L);
+            uint32_t tot;
+            const LV<uint32_t> ex = lscan(k4, tot);
+            LFOR(l) {
+                const uint32_t e[4] = {e0[l], e1[l], e2[l], e3[l]};
+                uint32_t o = runL[L] + ex[l];
+                CSH_UNROLL
+                for (int q = 0; q < 4; q++)
+                    if (kept(e[q], L)) dstL[L][o++] = (e[q] & 0xFF8000FFu) | ((((e[q] >> 8) & 0x7FFFu) >> L) << 8);
+            }
+            runL[L] += tot;
+        }
     }
 }
 
@@ -383,7 +416,11 @@ __global__ void k_reset_works(ScanWork *work, int nwork) {
     work[j].out_off = 0xFFFFFFFFu; work[j].raw_bytes = 0; work[j].hdr_bytes = 0; work[j].ff_bytes = 0; work[j].no_room = 0;
 }
 
-void launch_nzlist(hipStream_t st, const EncCtx &c) { if (c.nnzchunks) CSH_LAUNCH(k_nzlist, dim3(c.nnzchunks), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_nzlist(hipStream_t st, const EncCtx &c) {
+    if (!c.nnzchunks) return;
+    CSH_LAUNCH(k_nzlist, dim3(c.nnzchunks), dim3(CSP_WAVE_THREADS), st, c);
+    CSH_LAUNCH(k_nzfilter, dim3(c.nnzchunks), dim3(CSP_WAVE_THREADS), st, c);
+}
 void launch_list_stats(hipStream_t st, const EncCtx &c) { if (c.nlist_slots) CSH_LAUNCH(k_list_stats, dim3((c.nlist_slots + 3) / 4), dim3(4 * CSP_WAVE_THREADS), st, c); }
 void launch_list_pack(hipStream_t st, const EncCtx &c) { if (c.nlist_slots) CSH_LAUNCH(k_list_pack, dim3((c.nlist_slots + 3) / 4), dim3(4 * CSP_WAVE_THREADS), st, c); }
 void launch_reset_works(hipStream_t st, ScanWork *work, int nwork) { if (nwork) CSH_LAUNCH(k_reset_works, dim3((nwork + 255) / 256), dim3(256), st, work, nwork); }

@@ -430,18 +430,12 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                 const uint64_t lo = pick_sig(pl, a.Al);
                 bool has_sym = false, ends_eob = false;
                 uint32_t n = 0; int tail = 0;
-                if (valid) {
-                    if (a.Ah == 0) {
-                        const uint64_t NZ = lo & band;
-                        has_sym = NZ != 0; ends_eob = !((NZ >> a.Se) & 1);
-                        n = uint32_t(__popcll(NZ)) + (ends_eob ? 1u : 0u);
-                    } else {
-                        const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
-                        has_sym = N != 0; ends_eob = !((N >> a.Se) & 1);
-                        tail = N ? __popcll(H & ~((2ull << msb64(N)) - 1)) : __popcll(H);
-                        n = refine_room(H, N, a.Ss, ends_eob);
-                        if (!(c.debug & 256u)) c.corr[a.unit_base + u] = correction_word(H, pick_bit(pl + 5, a.Al));
-                    }
+                if (valid) {   // (a plan holds refinement scans only: the first-pass scans are coded from the compacted lists, k_aclist.hip)
+                    const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
+                    has_sym = N != 0; ends_eob = !((N >> a.Se) & 1);
+                    tail = N ? __popcll(H & ~((2ull << msb64(N)) - 1)) : __popcll(H);
+                    n = refine_room(H, N, a.Ss, ends_eob);
+                    if (!(c.debug & 256u)) c.corr[a.unit_base + u] = correction_word(H, pick_bit(pl + 5, a.Al));
                     c.tail[a.unit_base + u] = uint8_t(tail);
                 }
                 cnt[slot][tid] = n;
@@ -519,61 +513,16 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
             }
             if (u >= P.nunits) continue;
             const uint64_t sgn = pl[9];
-            uint32_t aw[32];   // |c_k|: k = 2 i in the low half of word i, k = 2 i + 1 in the high half
-            {
-                const int by = int(u) / P.real_bw, b = by * P.bw + (int(u) - by * P.real_bw);
-                const int16_t *p = c.coef + (size_t(P.tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE);
-                CSH_UNROLL
-                for (int j = 0; j < 8; j++) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(p + CSH_OCT_STRIDE * j);
-                    aw[4 * j] = pk_abs16(q.x); aw[4 * j + 1] = pk_abs16(q.y); aw[4 * j + 2] = pk_abs16(q.z); aw[4 * j + 3] = pk_abs16(q.w);
-                }
-                CSH_SCHED_FENCE();
-            }
             for (int slot = 0; slot < int(P.nslot); slot++) {
                 const AcSlot &a = P.s[slot];
                 const uint64_t band = band_mask(a.Ss, a.Se);
                 const uint64_t lo = pick_sig(pl, a.Al);
                 out.pool = c.tokens + s_wbase[wv][slot] + (cnt[slot][tid] >> 16);
                 out.pos = 0;
-                uint32_t rawbits = 0;
-                if (a.Ah == 0) {
-                    if (c.debug & 16u) continue;
-                    // first pass: one token per coded coefficient; the 63 positions are a static sweep, so that |c_k| is a register
-                    CSH_UNROLL
-                    for (int i = 0; i < 32; i++) CSH_PIN(aw[i]);   // what the steps derive from loop-invariant registers (the unpacked halves, the sign
-                    uint32_t sg_lo = uint32_t(sgn), sg_hi = uint32_t(sgn >> 32);   // bits) is not to be hoisted out of the loop over the scans: 64 + 63 live registers
-                    CSH_PIN(sg_lo); CSH_PIN(sg_hi);
-                    const uint64_t NZ = lo & band;
-                    const uint64_t any = wave_or64(NZ);   // positions no lane of the wave codes cost two scalar instructions
-                    uint32_t *h = hist + slot * 257;
-                    const int Al = CSH_UNIFORM(a.Al), Se = CSH_UNIFORM(a.Se);   // read from LDS here: the steps below then wait for nothing
-                    int prev = CSH_UNIFORM(a.Ss) - 1;
-                    CSH_UNROLL
-                    for (int k = 1; k < 64; k++) {
-                        CSH_SCHED_FENCE();
-                        if (!((any >> k) & 1)) continue;
-                        if ((NZ >> k) & 1) {
-                            const uint32_t av = ((k & 1) ? (aw[k >> 1] >> 16) : (aw[k >> 1] & 0xFFFFu)) >> Al;
-                            const int nb = bitlen32(av);
-                            const int r = k - prev - 1;
-                            prev = k;
-                            const uint32_t val = ((((k < 32 ? sg_lo >> (k & 31) : sg_hi >> (k & 31)) & 1u) ? ~av : av)) & ((1u << nb) - 1u);
-                            out.put(TK_ACF | (uint32_t(r) << 3) | (uint32_t(nb) << 9) | (val << 13));
-                            if (!(c.debug & 2u)) {
-                            if (r >> 4) atomicAdd(&h[0xF0], uint32_t(r >> 4));
-                            atomicAdd(&h[((r & 15) << 4) | nb], 1u);
-                            }
-                            rawbits += uint32_t(nb);
-                        }
-                    }
-                    if (!((NZ >> Se) & 1)) out.put(TK_EOB | (uint32_t(tid) << 3));
-                } else {
-                    const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
-                    if (c.debug & 8u) continue;
-                    emit_ac_refine(out, hist + slot * 257, uint32_t(tid), H, N, sgn, a.Ss, !((N >> a.Se) & 1), cnt[slot][tid] & 0xFFFFu);
-                    rawbits = uint32_t(__popcll(N) + __popcll(H));   // a sign bit per new coefficient, a correction bit per old one
-                }
+                const uint64_t hi = pick_sig(pl, a.Al + 1), H = hi & band, N = lo & ~hi & band;
+                if (c.debug & 8u) continue;
+                emit_ac_refine(out, hist + slot * 257, uint32_t(tid), H, N, sgn, a.Ss, !((N >> a.Se) & 1), cnt[slot][tid] & 0xFFFFu);
+                const uint32_t rawbits = uint32_t(__popcll(N) + __popcll(H));   // a sign bit per new coefficient, a correction bit per old one
                 if (rawbits) atomicAdd(&s_raw[slot], rawbits);
             }
             continue;
@@ -649,23 +598,26 @@ __device__ static bool eob_run_end(const uint64_t *sym, uint32_t nunits, uint32_
     return true;
 }
 #define CSH_LONG_RUN_WORDS 8   // a run whose end is not within 8 words (512 blocks) goes to k_ac_runs_long: one WAVE per run
-// Four slots (1024 blocks) per workgroup, one block per lane and slot.  The common case needs no loop and no further load: the block
+// One WAVE per slot (256 blocks: four per lane), four slots per workgroup -- the slots' chains of dependent loads (record, bit-vector
+// words, counters) run side by side instead of one after the other.  The common case needs no loop and no further load: the block
 // starts a run (it ends with an EOB and has symbols, or its predecessor does not end with one), the next block with a symbol lies in
 // this or the next word of the has-symbol vector, and the run is at most 14 blocks long -- then no correction-bit limit can cut it
 // (14 x 63 <= 937) and its EOBRUN is its length.  Everything else takes the general path (eob_run_end / eob_run_serial).
 __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
     const int lane = lane_id();
-    (void)lane;
+    const uint32_t cs = c.slot0 + blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (cs >= c.slot0 + c.nslots) return;
+    const SlotRec r = c.slots[cs];
+    if (!(r.flags & 1u)) return;
+    if (c.work_active && !c.work_active[r.work]) return;
+    const uint32_t nunits = r.nunits_work;
+    uint32_t *freq = c.tables[r.table_base].freq;
+    const uint64_t *sym = c.sym_bits + r.word_base, *eob = c.eob_bits + r.word_base;
+    uint32_t mine = 0;   // lane nb: EOBn symbols of ordinary runs counted so far
+    (void)mine; (void)lane;
     CSH_UNROLL
-    for (int q = 0; q < 4; q++) {
-        const uint32_t cs = c.slot0 + blockIdx.x * 4u + uint32_t(q);
-        if (cs >= c.slot0 + c.nslots) break;
-        const SlotRec r = c.slots[cs];
-        if (!(r.flags & 1u)) continue;
-        if (c.work_active && !c.work_active[r.work]) continue;
-        const uint32_t u = r.j * 256u + threadIdx.x, nunits = r.nunits_work;
-        uint32_t *freq = c.tables[r.table_base].freq;
-        const uint64_t *sym = c.sym_bits + r.word_base, *eob = c.eob_bits + r.word_base;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t u = r.j * 256u + uint32_t(i) * 64u + uint32_t(lane);
         int my_nb = -1;
         if (u < nunits) {
             const uint32_t w0 = u >> 6, nwords = (nunits + 63) >> 6;
@@ -705,16 +657,19 @@ __global__ void __launch_bounds__(256) k_ac_runs(EncCtx c) {
         CSH_UNROLL
         for (int nb = 0; nb < 4; nb++) {   // runs of up to 14 blocks: EOB0 .. EOB3; longer first-pass runs below
             const uint64_t m = __ballot(my_nb == nb);
-            if (m && lane == nb) { atomicAdd(&freq[nb << 4], uint32_t(__popcll(m))); atomicAdd(&c.slot_eobh[cs * 16u + uint32_t(nb)], uint32_t(__popcll(m))); }
+            if (lane == nb) mine += uint32_t(__popcll(m));
         }
         if (__ballot(my_nb >= 4)) {
             for (int nb = 4; nb < 15; nb++) {
                 const uint64_t m = __ballot(my_nb == nb);
-                if (m && lane == nb) { atomicAdd(&freq[nb << 4], uint32_t(__popcll(m))); atomicAdd(&c.slot_eobh[cs * 16u + uint32_t(nb)], uint32_t(__popcll(m))); }
+                if (lane == nb) mine += uint32_t(__popcll(m));
             }
         }
 #endif
     }
+#ifndef CSH_EMUL
+    if (mine && lane < 15) { atomicAdd(&freq[lane << 4], mine); atomicAdd(&c.slot_eobh[cs * 16u + uint32_t(lane)], mine); }
+#endif
 }
 // long runs (flat regions, low-quality sources: a run can span a whole scan of 32 k blocks, and a single lane walking it held
 // the kernel for a millisecond): the 64 lanes look for the end 4096 blocks at a time and cut the run 64 blocks at a time
