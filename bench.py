@@ -6,11 +6,13 @@ assembly) over one batch of synthetic 1080p JPEGs whose bytes are already reside
 GPU; files shard per rank with no collective on the data path (weak scaling: every rank gets --batch files).
 Prints ONE JSON line on rank 0.
 
-Beside the headline (`value`: the default profile = mozjpeg's scan search over the scalar quantiser, the profile whose pieces are pinned)
-the line carries, measured in the same run: `plain_profile` and `mozjpeg_profile` (CSH_PROFILE=mozjpeg: scan search + trellis quantisation
-+ overshoot deringing -- what libcaesium's -q runs; unpinned), `roofline` for the dominant kernel with `traffic` from two rocprofv3 --pmc
-passes this script starts itself (FETCH_SIZE, WRITE_SIZE; separate passes, no trace domain), `cpu_baseline` (the oracle on the host),
-`boundary` (cs_batch_compress from host buffers), `cli_end_to_end` (the caesiumclt binary, files in -> files out), `other_configs`
+The headline (`value`, `ms_per_step`, `roofline`, `phases`) is the library's DEFAULT profile = what libcaesium's `-q 80` runs
+(compressor.rs:415,427 -> mozjpeg JCP_MAX_COMPRESSION): scan search + trellis quantisation + overshoot deringing.  Measured in the same run
+and carried in the line: `scalar_profile` (CSH_PROFILE=scalar: the scan search over the scalar quantiser -- the pieces pinned by j0.JPG and
+libjpeg-turbo) and `plain_profile` (stock script, whole files equal libjpeg-turbo's); a `summary` object at the FRONT of the line repeats
+the three values; `roofline` for the dominant kernel with `traffic` from two rocprofv3 --pmc passes this script starts itself (FETCH_SIZE,
+WRITE_SIZE; separate passes, no trace domain); `cpu_baseline` (the oracle on the host, same profile), `boundary` (cs_batch_compress from
+host buffers), `cli_end_to_end` (the caesiumclt binary, files in -> files out), `other_configs`
 (configs[2], configs[3], configs[4]) each with its own roofline and CPU lines.
 """
 import argparse
@@ -45,6 +47,9 @@ def algorithmic_bytes(kernel, t, n):
         # phase E reads the planes ONCE (k_tokens: every AC scan of a component from one load of its blocks -- the scan search's 28 / 33
         # candidate scans of a stage included) and writes the files; tokens are this design's intermediate, not algorithmic bytes
         "k_tokens": coef, "k_pack": t.out_bytes, "scan_search_stage2": coef,
+        # the list builder reads the planes once (what k_tokens used to do per stage); the list passes read lists, not planes: their
+        # algorithmic input is still the component's coefficients (SURVEY 8d phase E), their output the files
+        "k_nzlist": coef, "k_list_stats": coef, "k_list_pack": t.out_bytes,
         "k_xform_direct": 2 * y,
         "k_idct_plane": c + planes,
         "k_resample+k_plane_fdct": 3 * planes + c,
@@ -57,8 +62,8 @@ def algorithmic_bytes(kernel, t, n):
 
 # hipEvent kernel slot -> substring of the rocprofv3 kernel name
 ROCPROF_NAME = {"k_dec_write": "k_dec_dense<2", "k_dec_spec": "k_dec_dense<0", "k_dec_relax0": "k_dec_dense<1", "k_dec_relax1_4": "k_dec_relax_list",
-                "k_resample+k_plane_fdct": "k_resample_fdct_420", "unstuff": "k_unstuff_copy", "k_emit": "k_emit_data", "trellis_stats": "k_tokens",
-                "scan_search_stage2": "k_tokens"}
+                "k_resample+k_plane_fdct": "k_resample_fdct_420", "unstuff": "k_unstuff_copy", "k_emit": "k_emit_data", "trellis_stats": "k_nzlist",
+                "scan_search_stage2": "k_list_pack"}
 
 
 def live_pmc(kernel, batch, profile, inputs=None, timeout=120):
@@ -270,9 +275,11 @@ def profile_record(api, pkg, blobs, params, local, profile, steps, names, note, 
         torch.cuda.synchronize()
         pdt = (time.perf_counter() - p0) / len(ptm)
         outs = pb.fetch()
-        parity = all(outs[i] == oracle_lossy(blobs[i]) for i in parity_idx)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(len(parity_idx), os.cpu_count() or 1)) as ex:
+            parity = all(ex.map(lambda i: outs[i] == oracle_lossy(blobs[i]), parity_idx))
         rec = {"value": round(ptm[-1].pixels / 1e6 / pdt, 1), "unit": "MP/s", "ms_per_step": round(pdt * 1e3, 3), "out_bytes": int(ptm[-1].out_bytes),
-               "parity_spot_check": bool(parity),
+               "parity_spot_check": bool(parity), "parity_files_checked": len(parity_idx),
                "kernel_ms": {names[i]: round(sum(x.kernel_ms[i] for x in ptm) / len(ptm), 3) for i in range(len(names)) if names[i] and ptm[-1].kernel_ms[i] > 0.05},
                "note": note}
         del outs
@@ -309,7 +316,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=2048, help="1080p files per rank per step (2048 x ~21 MB of device pools = 44 GB of the 288 GB)")
     ap.add_argument("--unique", type=int, default=1000, help="distinct synthetic images per rank (cycled to --batch): SURVEY 8d's 1 000 unique images; generated on all host cores")
-    ap.add_argument("--cpu-images", type=int, default=48, help="files timed through the single-thread CPU oracle (rank 0, N=1); the all-core and Pillow lines scale from it")
+    ap.add_argument("--cpu-images", type=int, default=6, help="files timed through the single-thread CPU oracle in the headline's profile (rank 0, N=1; ~4 s each with the trellis); the all-core and Pillow lines scale from it")
     ap.add_argument("--boundary-files", type=int, default=512, help="files of the cs_batch_compress (host buffers in, host buffers out) measurement; 0 = skip")
     ap.add_argument("--cli-files", type=int, default=2048, help="files of the caesiumclt end-to-end measurement (files in -> files out); 0 = skip")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / CPU / other-config records (profiling runs)")
@@ -385,18 +392,25 @@ def main():
 
     t = timings[-1]
     assert t.n_images == args.batch and t.n_failed == 0
-    prof_env = os.environ.get("CSH_PROFILE", "")
-    profile = {"plain": "plain (stock jpeg_simple_progression script)",
-               "mozjpeg": "mozjpeg JCP_MAX_COMPRESSION (scan search + trellis quantisation + overshoot deringing; parity with the real crate unpinned)"}.get(
-        prof_env, "mozjpeg scan search (optimize_scans in mozjpeg's own order: about 40 of its 64 candidate scans coded per file, the rest only where a file's search asks for them; pinned by samples/j0.JPG) over the scalar quantiser")
+    prof_env = os.environ.get("CSH_PROFILE") or "mozjpeg"
+    PROFILE_NOTES = {
+        "mozjpeg": "the library's default = what libcaesium's -q runs: mozjpeg JCP_MAX_COMPRESSION -- scan search (optimize_scans in mozjpeg's own order, pinned by samples/j0.JPG) + trellis "
+                   "quantisation + overshoot deringing (device == oracle byte for byte; the oracle's trellis / deringing restated from recall of mozjpeg 4.1: parity with the real crate UNPINNED, "
+                   "tests/golden/make_reference_goldens.sh is the recipe that pins it)",
+        "scalar": "CSH_PROFILE=scalar: mozjpeg's scan search over the scalar quantiser -- the pieces pinned by samples/j0.JPG and libjpeg-turbo",
+        "plain": "CSH_PROFILE=plain: jpeg_simple_progression, no scan search, scalar quantiser; whole files byte-identical to libjpeg-turbo (tests/test_oracle_jpeg.py)",
+    }
+    profile = PROFILE_NOTES.get(prof_env, prof_env)
     mp_per_step = t.pixels / 1e6 * world
     value = mp_per_step * args.steps / dt
 
-    # spot-check parity on this very batch (outside the timed region): files spread over the distinct images
+    # parity on this very batch (outside the timed region): 32 files spread over the distinct images, device output == oracle byte for byte
     outs = batch.fetch()
     from _util import oracle_lossy
-    parity_idx = sorted({0, nuniq // 3, (2 * nuniq) // 3, nuniq - 1})
-    parity = all(outs[i] == oracle_lossy(blobs[i]) for i in parity_idx)
+    parity_idx = sorted({(i * nuniq) // 32 for i in range(32)} | {nuniq - 1})
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(len(parity_idx), os.cpu_count() or 1)) as ex:   # (ctypes releases the GIL inside the oracle)
+        parity = all(ex.map(lambda i: outs[i] == oracle_lossy(blobs[i]), parity_idx))
     del outs
     batch.close()   # its pools go back to the block cache: the records below make batches of their own
 
@@ -421,7 +435,7 @@ def main():
             roof["traffic_detail"] = detail
             if traffic and ab:
                 roof["traffic_over_algorithmic"] = round(traffic / ab, 3)
-        cpu = cpu_all = cpu_pillow = cpu_moz = boundary = plain = moz = cli = None
+        cpu = cpu_all = cpu_pillow = boundary = plain = scalar = cli = None
         # the three phases of the path against SURVEY 8d's algorithmic bytes (D: stream in + planes out, X: planes in + out, E: planes in + files out)
         ph = [sum(tm.phase_ms[i] for tm in timings) / len(timings) for i in range(8)]
         coefb = t.coef_bytes
@@ -429,50 +443,37 @@ def main():
         def phase(ms, nbytes):
             return {"ms": round(ms, 3), "algorithmic_bytes": int(nbytes), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                     "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
-        phases = {"D_entropy_decode": phase(ph[0], t.in_bytes + coefb), "X_pixel_transcode": phase(ph[1], 2 * coefb),
-                  "X_read_only": phase(ph[1], coefb), "E_entropy_encode": phase(sum(ph[2:8]), coefb + t.out_bytes)}
+        # the quantiser's kernels (trellis statistics, k_trellis_ac, k_trellis_dc) are timed under phase 1 by the library (SURVEY 8a J7 sits inside
+        # phase X); listed apart here so that X stays the transform pair the north-star's read-roofline target names
+        i_q = [names.index(n) for n in ("trellis_stats", "k_trellis_ac", "k_trellis_dc")]
+        q_ms = sum(kms[i] for i in i_q)
+        phases = {"D_entropy_decode": phase(ph[0], t.in_bytes + coefb), "X_pixel_transcode": phase(ph[1] - q_ms, 2 * coefb),
+                  "X_read_only": phase(ph[1] - q_ms, coefb), "Q_trellis_quantiser": phase(q_ms, 2 * coefb), "E_entropy_encode": phase(sum(ph[2:8]), coefb + t.out_bytes)}
         sub_steps = max(2, args.steps // 2)
+        if extras and prof_env != "scalar":
+            scalar, _ = profile_record(api, pkg, blobs, params, local, "scalar", sub_steps, names, PROFILE_NOTES["scalar"], parity_idx)
         if extras and prof_env != "plain":
-            plain, _ = profile_record(api, pkg, blobs, params, local, "plain", sub_steps, names,
-                                      "CSH_PROFILE=plain: jpeg_simple_progression, no scan search; byte-identical to libjpeg-turbo (tests/test_oracle_jpeg.py)", parity_idx[:2])
-        if extras and prof_env != "mozjpeg":
-            moz, mtm = profile_record(api, pkg, blobs, params, local, "mozjpeg", sub_steps, names,
-                                      "CSH_PROFILE=mozjpeg: the whole JCP_MAX_COMPRESSION profile libcaesium's -q runs -- scan search + trellis quantisation (k_trellis_ac / k_trellis_dc "
-                                      "after a statistics scan) + overshoot deringing; device == oracle byte for byte, oracle restated from recall of mozjpeg 4.1 (UNPINNED: "
-                                      "tests/golden/make_reference_goldens.sh is the recipe that pins it)", parity_idx[:2])
-            i_tr = names.index("k_trellis_ac")
-            tr_ms = sum(x.kernel_ms[i_tr] for x in mtm) / len(mtm)
-            moz["roofline_k_trellis_ac"] = {"bound": "hbm", "avg_ms": round(tr_ms, 3), "algorithmic_bytes": int(2 * coefb), "achieved": round(2 * coefb / (tr_ms * 1e-3) / 1e9, 1),
-                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(2 * coefb / (tr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                            "note": "a per-block dynamic programme (float cost minimisation over list entries): bound by instruction issue and LDS latency, not by HBM"}
+            plain, _ = profile_record(api, pkg, blobs, params, local, "plain", sub_steps, names, PROFILE_NOTES["plain"], parity_idx)
         if extras and args.cpu_images > 0:
+            # the oracle in the headline's profile (what libcaesium's -q does: trellis + deringing + scan search) on one host thread: a bounded sample
             n = args.cpu_images
             c0 = time.perf_counter()
             for i in range(n):
                 oracle_lossy(blobs[i % len(blobs)])
             cdt = time.perf_counter() - c0
             cpu = {"value": round(n * MP_1080P / cdt, 2), "unit": "MP/s", "cores": 1, "kind": "port",
-                   "sample": f"{n} of the same 1080p files through oracle/jpeg_oracle.c (decode+IDCT+FDCT+quant+scan search+progressive optimal-Huffman: the default profile), 1 thread, {cdt:.1f} s"}
+                   "sample": f"{n} of the same 1080p files through oracle/jpeg_oracle.c in the headline's profile ({prof_env}: decode + IDCT + FDCT + deringing + trellis quantisation "
+                             f"+ scan search + progressive optimal-Huffman coding), 1 thread, {cdt:.1f} s"}
             # the same port on every host core (the reference's rayon par_iter shape), and the libjpeg-turbo proxy (Pillow: decode to YCbCr,
             # re-encode q80 4:2:0 progressive + optimised tables -- the plain profile the oracle is pinned to) on every core
             cores = os.cpu_count() or 1
-            m = min(max(cores * 6, n), 16 * n)
+            m = min(cores * 2, 64 * n)
             cdt = timed_threads(lambda i: len(oracle_lossy(blobs[i % len(blobs)])), range(m), cores)   # ctypes releases the GIL inside the oracle
-            cpu_all = {"value": round(m * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port", "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
+            cpu_all = {"value": round(m * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port", "sample": f"{m} files, {cores} threads, {cdt:.1f} s, profile {prof_env}"}
+            m = min(cores * 4, 128 * n)
             cdt = timed_threads(lambda i: len(pillow_proxy(blobs[i % len(blobs)])), range(m), cores)
             cpu_pillow = {"value": round(m * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "libjpeg-turbo proxy (Pillow), not libcaesium",
                           "sample": f"{m} files, {cores} threads, {cdt:.1f} s"}
-            # the oracle doing what libcaesium's -q does (trellis + deringing + scan search): what the mozjpeg_profile record is to be read against
-            set_profile("mozjpeg")
-            try:
-                mm = min(m, cores * 4)
-                cdt = timed_threads(lambda i: len(oracle_lossy(blobs[i % len(blobs)])), range(mm), cores)
-                cpu_moz = {"value": round(mm * MP_1080P / cdt, 2), "unit": "MP/s", "cores": cores, "kind": "port",
-                           "sample": f"{mm} files through the oracle with trellis + deringing + scan search, {cores} threads, {cdt:.1f} s"}
-            finally:
-                set_profile(prof_env)
-            if moz is not None:
-                moz["cpu_baseline_all_cores"] = cpu_moz
         other = None
         if extras:
             other = other_configs(api, pkg, blobs, local)
@@ -489,7 +490,13 @@ def main():
         if extras and args.cli_files > 0:
             api.release_cached_memory()   # another process is about to use the device
             cli = cli_end_to_end(blobs, min(args.cli_files, 4096))
+        def short(rec):
+            return None if rec is None else {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "parity": rec["parity_spot_check"]}
+        summary = {"unit": "MP/s", prof_env + " (headline)": {"value": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "parity": bool(parity)},
+                   "scalar": short(scalar), "plain": short(plain), "roofline_kernel": roof["kernel"], "roofline_frac": roof.get("frac"),
+                   "X_read_only_frac": phases["X_read_only"]["frac_of_8TBps"], "E_ms": phases["E_entropy_encode"]["ms"]}
         out = {
+            "summary": summary,
             "metric": "megapixels/sec JPEG q=80 1920x1080 batch", "value": round(value, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -498,8 +505,9 @@ def main():
                        "profile": profile},
             "parity_spot_check": bool(parity), "parity_files_checked": len(parity_idx),
             "device_ms_per_step": round(sum(tm.total_ms for tm in timings) / len(timings), 3),
+            "roofline": roof, "cpu_baseline": cpu, "phases": phases,
             "kernel_ms": {names[i]: round(kms[i], 4) for i in range(len(names)) if names[i]},
-            "roofline": roof, "phases": phases, "plain_profile": plain, "mozjpeg_profile": moz, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow,
+            "scalar_profile": scalar, "plain_profile": plain, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow,
             "boundary": boundary, "cli_end_to_end": cli, "other_configs": other,
             "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
             "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},

@@ -494,13 +494,16 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     add_script(b->script, 3, false);  // entry 16
     add_script(b->script, 1, false);  // entry 17
     const int script_base3 = progressive ? 0 : 16, script_base1 = progressive ? 10 : 17;
-    const char *profile = getenv("CSH_PROFILE");
-    b->search = progressive && !webp && !rgb_out && !(profile && !strcmp(profile, "plain"));
-    // CSH_PROFILE=mozjpeg: the whole JCP_MAX_COMPRESSION profile libcaesium's -q runs (scan search + trellis quantisation + overshoot
-    // deringing; UNPINNED); mozjpeg-trellis / mozjpeg-dering switch the two halves on separately (scan search kept)
+    // CSH_PROFILE names what stands in for libcaesium's JPEG engine.  Unset or "mozjpeg": the whole JCP_MAX_COMPRESSION profile libcaesium's
+    // -q runs (compressor.rs:415,427): scan search + trellis quantisation + overshoot deringing.  "scalar": the scan search over the scalar
+    // quantiser (the pieces pinned by samples/j0.JPG and libjpeg-turbo); "plain": the stock jpeg_simple_progression script over the
+    // scalar quantiser (whole files equal libjpeg-turbo's); "mozjpeg-trellis" / "mozjpeg-dering": one half of the quantiser each (scan search kept)
+    const char *penv = getenv("CSH_PROFILE");
+    const std::string profile = penv && *penv ? penv : "mozjpeg";
+    b->search = progressive && !webp && !rgb_out && profile != "plain";
     const bool lossy_jpeg = !b->lossless && !webp && !rgb_out;
-    b->trellis = lossy_jpeg && profile && (!strcmp(profile, "mozjpeg") || !strcmp(profile, "mozjpeg-trellis"));
-    b->dering = lossy_jpeg && profile && (!strcmp(profile, "mozjpeg") || !strcmp(profile, "mozjpeg-dering"));
+    b->trellis = lossy_jpeg && (profile == "mozjpeg" || profile == "mozjpeg-trellis");
+    b->dering = lossy_jpeg && (profile == "mozjpeg" || profile == "mozjpeg-dering");
     // EncScan entries of the search's candidates, made on first use
     auto cand_index = [&](int comp, int Ss, int Se, int Ah, int Al) -> int {
         const std::array<int, 5> key = {comp, Ss, Se, Ah, Al};

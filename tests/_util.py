@@ -32,16 +32,22 @@ def emul_api():
     return package().CaesiumHip(so)
 
 
+def device_profile():
+    """the JPEG profile the device library is in (pipeline.cpp batch_create): unset = "mozjpeg", what libcaesium's -q runs"""
+    return os.environ.get("CSH_PROFILE") or "mozjpeg"
+
+
 def device_scan_script():
-    """the oracle's scan_script for what the device library does by default: mozjpeg's scan search (2); the stock jpeg_simple_progression
+    """the oracle's scan_script for what the device library does: mozjpeg's scan search (2); the stock jpeg_simple_progression
     script (0) under CSH_PROFILE=plain"""
-    return 0 if os.environ.get("CSH_PROFILE") == "plain" else 2
+    return 0 if device_profile() == "plain" else 2
 
 
 def device_quantiser():
-    """the oracle's trellis / deringing switches for the profile the device library is in: both under CSH_PROFILE=mozjpeg (the whole
-    JCP_MAX_COMPRESSION profile libcaesium's -q runs), one each under mozjpeg-trellis / mozjpeg-dering, neither by default"""
-    prof = os.environ.get("CSH_PROFILE", "")
+    """the oracle's trellis / deringing switches for the profile the device library is in: both by default (CSH_PROFILE unset or "mozjpeg":
+    the whole JCP_MAX_COMPRESSION profile libcaesium's -q runs), one each under mozjpeg-trellis / mozjpeg-dering, neither under "scalar" (the
+    scan search over the scalar quantiser) and under "plain" """
+    prof = device_profile()
     return dict(trellis=int(prof in ("mozjpeg", "mozjpeg-trellis")), deringing=int(prof in ("mozjpeg", "mozjpeg-dering")))
 
 

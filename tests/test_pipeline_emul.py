@@ -387,8 +387,10 @@ def test_emul_plain_profile_keeps_the_stock_script(api, monkeypatch):
     out = api.compress_in_memory(src, params())
     assert out == O.jpeg_compress(src, O.params(quality=80, scan_script=0)) == oracle_lossy(src)
     assert O.decode(out).scans() == O.stock_script(3, 0)
-    monkeypatch.delenv("CSH_PROFILE")
-    assert api.compress_in_memory(src, params()) == O.jpeg_compress(src, O.params(quality=80, scan_script=2))
+    monkeypatch.setenv("CSH_PROFILE", "scalar")   # the scan search over the scalar quantiser: the pieces pinned by j0.JPG and libjpeg-turbo
+    assert api.compress_in_memory(src, params()) == O.jpeg_compress(src, O.params(quality=80, scan_script=2)) == oracle_lossy(src)
+    monkeypatch.delenv("CSH_PROFILE")             # the default: what libcaesium's -q runs -- scan search + trellis quantisation + deringing
+    assert api.compress_in_memory(src, params()) == O.jpeg_compress(src, O.params(quality=80, scan_script=2, trellis=1, deringing=1)) == oracle_lossy(src)
 
 
 def test_emul_long_eob_runs_and_flat_images(api):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 from PIL import Image
 
-from _util import device_scan_script, emul_api, package
+from _util import device_quantiser, device_scan_script, emul_api, package
 from gen_synth import synth_rgb
 
 
@@ -134,13 +134,13 @@ def test_emul_compress_and_convert_from_webp(api, reference_samples):
     for src in srcs:
         rgb = np.ascontiguousarray(libwebp_rgb(src))
         assert api.compress_in_memory(src, params(webp_quality=60)) == O.webp_encode_rgb(rgb, 60)
-        want_jpeg = O.pixels_to_jpeg(rgb, O.params(quality=75, progressive=1, subsampling=420, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), 0, 0)
+        want_jpeg = O.pixels_to_jpeg(rgb, O.params(quality=75, progressive=1, subsampling=420, qtable_profile=3, marker_style=1, scan_script=device_scan_script(), **device_quantiser()), 0, 0)
         assert api.convert_in_memory(src, params(jpeg_quality=75), 0) == want_jpeg
         got_png = api.convert_in_memory(src, params(png_optimize=True), 1)
         assert np.array_equal(np.asarray(Image.open(io.BytesIO(got_png)).convert("RGB")), rgb)
     # a size on the way: the JPEG row's Lanczos branch resamples the decoded pixels
     rgb = np.ascontiguousarray(libwebp_rgb(srcs[1]))
-    want = O.pixels_to_jpeg(rgb, O.params(quality=80, progressive=1, subsampling=420, qtable_profile=3, marker_style=1, scan_script=device_scan_script()), 48, 0)
+    want = O.pixels_to_jpeg(rgb, O.params(quality=80, progressive=1, subsampling=420, qtable_profile=3, marker_style=1, scan_script=device_scan_script(), **device_quantiser()), 48, 0)
     assert api.convert_in_memory(srcs[1], params(jpeg_quality=80, width=48), 0) == want
     got_png = api.convert_in_memory(srcs[1], params(png_optimize=True, width=48), 1)
     assert Image.open(io.BytesIO(got_png)).size[0] == 48

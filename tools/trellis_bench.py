@@ -1,4 +1,4 @@
-"""Device time of the JPEG path under each profile (plain / default scan search / mozjpeg = scan search + trellis + deringing), per kernel."""
+"""Device time of the JPEG path under each profile (plain / scalar = scan search over the scalar quantiser / mozjpeg = scan search + trellis + deringing, the default), per kernel."""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ from bench import make_inputs
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 uniq = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-profiles = sys.argv[3].split(",") if len(sys.argv) > 3 else ["", "mozjpeg"]
+profiles = sys.argv[3].split(",") if len(sys.argv) > 3 else ["scalar", "mozjpeg"]
 pkg = package()
 api = pkg.load()
 blobs = make_inputs(0, uniq)

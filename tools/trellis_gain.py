@@ -1,4 +1,4 @@
-"""Bytes at equal PSNR: mozjpeg's trellis quantiser (CSH_PROFILE=mozjpeg-trellis / mozjpeg) against the scalar quantiser (default profile),
+"""Bytes at equal PSNR: mozjpeg's trellis quantiser (CSH_PROFILE=mozjpeg-trellis / mozjpeg) against the scalar quantiser (CSH_PROFILE=scalar),
 on the bench's synthetic 1080p set, made on the device (the outputs are byte-identical to the oracle's: tests/test_trellis_gpu.py).
 
 For every image: the profile's file at -q 80 (bytes, PSNR against the decoded source), and the scalar quantiser's files at -q 60..80; the scalar
@@ -35,10 +35,7 @@ def psnr_all(outs):
 
 
 def run(profile, qualities):
-    if profile:
-        os.environ["CSH_PROFILE"] = profile
-    else:
-        os.environ.pop("CSH_PROFILE", None)
+    os.environ["CSH_PROFILE"] = profile or "scalar"   # (unset = the library's default = the whole mozjpeg profile)
     b = api.batch(srcs, pkg.default_parameters(jpeg_quality=80))
     b.retain_dct()
     b.run()
@@ -55,7 +52,7 @@ def run(profile, qualities):
 scalar = run("", list(range(60, 81, 2)))
 qs = sorted(scalar)
 print(f"# {n} synthetic 1080p images (SURVEY 8d recipe, q92 4:2:0 sources), PSNR of the decoded RGB against the decoded source; device outputs (== oracle)")
-print(f"# scalar quantiser (default profile) at -q 80: {scalar[80][0].mean() / 1e3:.1f} KB, {scalar[80][1].mean():.3f} dB")
+print(f"# scalar quantiser (CSH_PROFILE=scalar) at -q 80: {scalar[80][0].mean() / 1e3:.1f} KB, {scalar[80][1].mean():.3f} dB")
 print("profile              bytes@q80(KB)  PSNR(dB)  vs scalar@q80  scalar bytes at equal PSNR(KB)  gain at equal PSNR   (per-image gain: min / median / max)")
 for prof in ("mozjpeg-trellis", "mozjpeg-dering", "mozjpeg"):
     by, ps = run(prof, [80])[80]
