@@ -85,13 +85,15 @@ __device__ __forceinline__ static void fdct1d(int &d0, int &d1, int &d2, int &d3
 // load (8 x 16-byte octets) + dequantise + 2-D IDCT + level shift + range limit; samples (0..255) out, natural order
 template <int J, int... I>
 __device__ __forceinline__ static void dequant_octet(int x[64], const uint4 &v, const DevQuant &q, std::integer_sequence<int, I...>) {
-    ((x[kZ2N[8 * J + I]] = half_of<I>(v) * int(q.q[8 * J + I])), ...);
+    ((x[kZ2N[8 * J + I]] = MUL(half_of<I>(v), int(q.q[8 * J + I]))), ...);   // 16-bit coefficient x 16-bit table entry: the 24-bit multiplier is exact and full rate (v_mul_lo_u32 is quarter rate)
 }
 template <int... J>
 __device__ __forceinline__ static void load_dequant(const int16_t *__restrict__ blk, const DevQuant &q, int x[64], std::integer_sequence<int, J...>) {
     const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_OCT_STRIDE * J)...};  // all eight loads in flight before first use
     (dequant_octet<J>(x, v[J], q, Oct()), ...);
 }
+// CENTRED: samples come out level-shifted (-128..127: what the forward transform takes) -- one clamp instead of add + clamp, and no subtraction in front of the FDCT
+template <bool CENTRED = false>
 __device__ __forceinline__ static void load_idct(const int16_t *__restrict__ blk, const DevQuant &q, int x[64]) {
     load_dequant(blk, q, x, Oct());
     CSH_SCHED_FENCE();
@@ -102,7 +104,10 @@ __device__ __forceinline__ static void load_idct(const int16_t *__restrict__ blk
     for (int r = 0; r < 8; r++) {
         idct1d(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7], 18);
         CSH_UNROLL
-        for (int c = 0; c < 8; c++) { int v = x[8 * r + c] + 128; x[8 * r + c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+        for (int c = 0; c < 8; c++) {
+            if (CENTRED) { const int v = x[8 * r + c]; x[8 * r + c] = v < -128 ? -128 : (v > 127 ? 127 : v); }
+            else { const int v = x[8 * r + c] + 128; x[8 * r + c] = v < 0 ? 0 : (v > 255 ? 255 : v); }
+        }
     }
     CSH_SCHED_FENCE();
 }
@@ -126,16 +131,14 @@ __device__ __forceinline__ static void replicate_edges(int x[64], int vc, int vr
 }
 
 // samples (0..255, natural order) -> level shift -> 2-D FDCT -> scalar quantise -> store as 8 x 16-byte octets
+// high 32 bits of the 48-bit product of two 24-bit values: v_mul_hi_u32_u24, full rate
+__device__ __forceinline__ static uint32_t mulhi24(uint32_t a, uint32_t b) { return uint32_t((uint64_t(a & 0xFFFFFFu) * uint64_t(b & 0xFFFFFFu)) >> 32); }
 template <int K>
 __device__ __forceinline__ static uint32_t quant_one(const int x[64], const DevQuant &q) {
-    int d = q.div[K];
-    int t = x[kZ2N[K]], a = t < 0 ? -t : t;
-    a += d >> 1;
-    // exact a/d: float estimate (a < 2^24) with one correction step
-    int qv = int(float(a) * q.rcp[K]);
-    int r = a - qv * d;
-    qv += (r >= d) ? 1 : 0;
-    qv -= (r < 0) ? 1 : 0;
+    // (|t| + d / 2) / d, exactly, in two full-rate instructions (types.h DevQuant::mul): |t| <= 2^15 (a jfdctint output of 8-bit samples, or a
+    // retained one read back from its int16), d = 8 q <= 2040
+    const int t = x[kZ2N[K]], a = (t < 0 ? -t : t) + (q.div[K] >> 1);
+    const int qv = int(mulhi24(uint32_t(a) << q.sh[K], q.mul[K]));
     return uint32_t(t < 0 ? -qv : qv) & 0xFFFFu;
 }
 template <int J>
@@ -234,12 +237,18 @@ __device__ __forceinline__ static void dering_block(int x[64] /* level-shifted, 
         for (int i = 0; i < 64; i++) x[i] = col[i * 256];
     }
 }
-template <bool DERING>
+template <bool DERING, bool CENTRED = false>
 __device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw, CSH_DERING_LDS) {
     CSH_SCHED_FENCE();
-    CSH_UNROLL
-    for (int i = 0; i < 64; i++) x[i] -= 128;
+    if (!CENTRED) {
+        CSH_UNROLL
+        for (int i = 0; i < 64; i++) x[i] -= 128;
+    }
     if (DERING) { dering_block(x, int(q.q[0]), dr_col); CSH_SCHED_FENCE(); }
+    // the compiler knows these are 8-bit values and turns the row pass's 24-bit multiplies into plain 32-bit ones (v_mul_lo_u32 / v_mad_u64_u32:
+    // quarter rate, ~80 of them per block); behind an opaque register copy they stay v_mul_i32_i24 / v_mad_i32_i24
+    CSH_UNROLL
+    for (int i = 0; i < 64; i++) CSH_PIN(x[i]);
     CSH_UNROLL
     for (int r = 0; r < 8; r++) fdct1d<true>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
     CSH_SCHED_FENCE();
@@ -287,10 +296,10 @@ __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const
     int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
     if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); return; }
     int x[64];
-    load_idct(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
+    load_idct<true>(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
     int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
     if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
-    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
+    fdct_quant_store<DERING, true>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
 }
 
 // mode 1 producer: subsampled component, IDCT -> u8 plane (pitch real_bw*8, rows real_bh*8, edges replicated)

@@ -61,14 +61,10 @@ __device__ __forceinline__ static void tr_load(const int16_t *__restrict__ blk, 
     const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_OCT_STRIDE * J)...};
     (tr_unpack<J>(r, v[J], Oct8()), ...);
 }
-// exact (x + d / 2) / d for 0 <= x < 2^16, d = 8 q: float estimate + one correction (the pixel kernels' quantiser)
-__device__ __forceinline__ static int tr_level(int x, int d, float rcp) {
-    const int a = x + (d >> 1);
-    int qv = int(float(a) * rcp);
-    const int rem = a - qv * d;
-    qv += (rem >= d) ? 1 : 0;
-    qv -= (rem < 0) ? 1 : 0;
-    return qv;
+// exact (x + d / 2) / d for 0 <= x <= 2^15, d = 8 q: the pixel kernels' quantiser -- two full-rate instructions (types.h DevQuant::mul)
+__device__ __forceinline__ static int tr_level(int x, int d, uint32_t mul, uint32_t sh) {
+    const uint32_t a = uint32_t(x + (d >> 1)) << sh;
+    return int(uint32_t((uint64_t(a & 0xFFFFFFu) * uint64_t(mul & 0xFFFFFFu)) >> 32));   // v_mul_hi_u32_u24
 }
 __device__ __forceinline__ static int tr_bitlen(unsigned v) { return 32 - __clz(v); }
 __device__ __forceinline__ static float tr_bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -87,13 +83,13 @@ struct TrLds {
     const float *runf;    // [4] what 0..3 ZRLs in front of a symbol cost; 1e38 where ZRL has no code
     int lenEOB;           // plain code length of the end-of-block symbol
     const int32_t *q8;    // 8 q, zig-zag order
-    const float *rcp;     // 1 / (8 q)
+    const uint32_t *qmul, *qsh;   // the exact-division pair of 8 q
     const float *lt;      // 1 / q^2
 };
 
 // tables of the chunk's component -> LDS (all 256 lanes)
 // (the sweep reads the quantiser's three values per position from here: as loads from HBM they were 189 dependent round trips per wave)
-__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, float *s_lenf, float *s_runf, int *s_eob, int32_t *s_q8, float *s_rcp, float *s_lt) {
+__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, float *s_lenf, float *s_runf, int *s_eob, int32_t *s_q8, uint32_t *s_qmul, uint32_t *s_qsh, float *s_lt) {
     const TrellisWork &w = c.work[c.chunks[chi].work];
     const ImgDesc &im = c.imgs[w.image];
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
@@ -102,7 +98,7 @@ __device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32
     for (int i = tid; i < 256; i += CSH_TR_WG) { const int l = size[i]; s_lenf[i] = l ? float(l + (i & 15)) : 1e38f; }
     if (tid < 4) s_runf[tid] = tid == 0 ? 0.0f : (size[0xF0] ? float(tid * int(size[0xF0])) : 1e38f);
     if (tid == 0) *s_eob = size[0x00];
-    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_rcp[tid] = Q.rcp[tid]; s_lt[tid] = Q.lt[tid]; }
+    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_qmul[tid] = Q.mul[tid]; s_qsh[tid] = Q.sh[tid]; s_lt[tid] = Q.lt[tid]; }
 }
 
 __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32_t chi, uint32_t wg_slot, const TrLds &L) {
@@ -135,7 +131,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     CSH_UNROLL
     for (int k = 1; k < 64; k++) {
         const int v = r[k], x = v < 0 ? -v : v;
-        int qv = tr_level(x, L.q8[k], L.rcp[k]);
+        int qv = tr_level(x, L.q8[k], L.qmul[k], L.qsh[k]);
         qv = qv > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : qv;
         if (qv) {
             const uint32_t P = uint32_t(x) | (uint32_t(k) << 15) | (uint32_t(qv) << 21) | (v < 0 ? 0x80000000u : 0u);
@@ -146,7 +142,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         Zrun = (float(x * x) * lambda) * L.lt[k] + Zrun;
     }
     const float Z63 = Zrun;
-    const int dc_level = tr_level(r[0] < 0 ? -r[0] : r[0], L.q8[0], L.rcp[0]);   // scalar DC: k_trellis_dc replaces it
+    const int dc_level = tr_level(r[0] < 0 ? -r[0] : r[0], L.q8[0], L.qmul[0], L.qsh[0]);   // scalar DC: k_trellis_dc replaces it
     const int dc_signed = r[0] < 0 ? -dc_level : dc_level;
     CSH_SCHED_FENCE();
 
@@ -251,18 +247,19 @@ __global__ void __launch_bounds__(CSH_TR_WG) k_trellis_ac(TrellisCtx c) {
     CSH_SHARED float s_runf[4];
     CSH_SHARED int s_eob;
     CSH_SHARED int32_t s_q8[64];
-    CSH_SHARED float s_rcp[64];
+    CSH_SHARED uint32_t s_qmul[64];
+    CSH_SHARED uint32_t s_qsh[64];
     CSH_SHARED float s_lt[64];
-    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.lenf = s_lenf; L.runf = s_runf; L.q8 = s_q8; L.rcp = s_rcp; L.lt = s_lt;
+    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.lenf = s_lenf; L.runf = s_runf; L.q8 = s_q8; L.qmul = s_qmul; L.qsh = s_qsh; L.lt = s_lt;
 #ifdef CSH_EMUL
     CSH_PHASE_LOOP(2) {
-        if (phase == 0) { trellis_stage(c, blockIdx.x, s_lenf, s_runf, &s_eob, s_q8, s_rcp, s_lt); continue; }
+        if (phase == 0) { trellis_stage(c, blockIdx.x, s_lenf, s_runf, &s_eob, s_q8, s_qmul, s_qsh, s_lt); continue; }
         L.lenEOB = s_eob;
         trellis_block(c, blockIdx.x, 0u, L);
     }
 #else
     for (uint32_t chi = blockIdx.x; chi < c.nchunks; chi += gridDim.x) {
-        trellis_stage(c, chi, s_lenf, s_runf, &s_eob, s_q8, s_rcp, s_lt);
+        trellis_stage(c, chi, s_lenf, s_runf, &s_eob, s_q8, s_qmul, s_qsh, s_lt);
         __syncthreads();
         L.lenEOB = s_eob;
         trellis_block(c, chi, blockIdx.x, L);
@@ -290,7 +287,8 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
     CSH_SHARED float s_cost[16];
     for (int i = 0; i < 12; i++) s_cost[i] = float(i + int(w.table_dc < 0 ? kStdDcLen[w.comp ? 1 : 0][i] : c.tables[w.table_dc].size[i]));
     const int q = Q.div[0];
-    const float rcp = Q.rcp[0], lt0 = Q.lt[0];
+    const uint32_t qmul = Q.mul[0], qsh = Q.sh[0];
+    const float lt0 = Q.lt[0];
     const int half = ncand / 2;
     int last_dc = 0;   // compress_trellis_pass: 0 at the start of every iMCU row, then the last DC of the row before
     const int by1 = (row + 1) * g.v < g.real_bh ? (row + 1) * g.v : g.real_bh;
@@ -311,7 +309,7 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
             const int raw0 = int(int16_t(uint16_t(rec & 0xFFFFu)));
             const float lambda_dc = tr_bits_f(uint32_t(rec >> 32)) * lt0;
             const int x = raw0 < 0 ? -raw0 : raw0;
-            const int qval = tr_level(x, q, rcp);
+            const int qval = tr_level(x, q, qmul, qsh);
             const int sgn = raw0 < 0 ? 1 : 0;
             const bool clamped = qval + half > TRELLIS_MAX_LEVEL;   // a candidate is cut off at the largest level: the closed form below does not hold
             uint64_t bt = 0;

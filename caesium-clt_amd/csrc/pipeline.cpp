@@ -293,6 +293,14 @@ static void make_quant(const uint16_t nat[64], DevQuant &q) {
         q.div[k] = int32_t(q.q[k]) * 8;
         q.rcp[k] = 1.0f / float(q.div[k]);
         q.lt[k] = float(1.0 / double(int(q.q[k]) * int(q.q[k])));   // mozjpeg quantize_trellis, mode 1: lambda_table[i] = 1.0 / (q * q)
+        q.mul[k] = 0; q.sh[k] = 0;
+        if (q.div[k] > 0 && q.div[k] < (1 << 14)) {
+            int lg = 0;
+            while ((2 << lg) <= q.div[k]) lg++;   // floor(log2 div)
+            const int P = std::max(25, lg + 18);
+            q.mul[k] = uint32_t((1ull << P) / uint64_t(q.div[k])) + 1u;
+            q.sh[k] = uint32_t(32 - P);
+        }
     }
 }
 

@@ -135,6 +135,12 @@ struct DevQuant {
     int32_t div[64];     // q*8 (jfdctint output is scaled by 8)
     float rcp[64];       // 1.0f/div, host-computed
     float lt[64];        // 1 / q^2 as float(1.0 / double(q * q)): the distortion weight of mozjpeg's trellis (k_trellis.hip), host-computed
+    // exact a / div for 0 <= a < 2^17 on the full-rate 24-bit multiplier: (a << sh) * mul >> 32  (v_mul_hi_u32_u24).  With P = 32 - sh =
+    // max(25, floor(log2 div) + 18) and mul = floor(2^P / div) + 1: the estimate exceeds a / div by less than 1 / div (a * div < 2^P), so its
+    // floor is the quotient's; a << sh < 2^24 (sh <= 7) and mul < 2^24 (P - log2 div < 24).  Valid for div < 2^14 (8-bit tables: div <= 2040);
+    // mul = 0 marks a table the kernels must not quantise with (16-bit input tables: they only dequantise)
+    uint32_t mul[64];
+    uint32_t sh[64];
 };
 
 // work item of the pixel kernels: one component of one image
