@@ -75,7 +75,7 @@ __device__ __forceinline__ static void nz_count_half(const NzSet &S, uint32_t u0
         cnt[l] += n;
     }
 }
-__device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0, int half, const LV<uint4> (&q)[CSH_NZ_HALF], uint32_t *dst, uint32_t run) {
+__device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0, int half, const LV<uint4> (&q)[CSH_NZ_HALF], uint32_t *dst, uint32_t run, uint8_t *blk_cnt) {
     CSH_UNROLL
     for (int s = 0; s < CSH_NZ_HALF; s++) {
         LV<uint32_t> mk, cl;
@@ -86,6 +86,14 @@ __device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0
         }
         uint32_t tot;
         const LV<uint32_t> ex = lscan(cl, tot);
+        if (blk_cnt) {   // the block's entries = where its END lands - where its first octet starts (seven lanes down)
+            LV<uint32_t> first = ex;
+            for (int d = 0; d < 7; d++) first = lprev(first, 0u);
+            LFOR(l) {
+                const uint32_t blk = 16u * 8u * uint32_t(half) + 8u * uint32_t(s) + uint32_t(l >> 3);
+                if ((l & 7) == 7 && u0 + blk < S.nunits) blk_cnt[u0 + blk] = uint8_t(ex[l] + cl[l] - 1u - first[l]);
+            }
+        }
         LFOR(l) {
             const uint32_t oct = uint32_t(l & 7);
             const uint32_t blk = 16u * 8u * uint32_t(half) + 8u * uint32_t(s) + uint32_t(l >> 3);
@@ -130,9 +138,10 @@ __global__ void __launch_bounds__(64) k_nzlist(EncCtx c) {
     if (!ok0) return;
     // ---- pass 2: the entries -- of the second half first (it is here), then of the first one (out of the L2)
     uint32_t *dst = c.nz_pool + L0.base + rel;
-    nz_write_half(S, u0, 1, q, dst, nA);
+    uint8_t *blk_cnt = (c.nz_blk_cnt && S.cnt_base != 0xFFFFFFFFu) ? c.nz_blk_cnt + S.cnt_base : nullptr;
+    nz_write_half(S, u0, 1, q, dst, nA, blk_cnt);
     nz_load_half(c, S, u0, 0, q);
-    nz_write_half(S, u0, 0, q, dst, 0u);
+    nz_write_half(S, u0, 0, q, dst, 0u, blk_cnt);
     LFOR(l) if (n0 + uint32_t(l) < n0a) dst[n0 + uint32_t(l)] = 0u;   // padding to the next 16-byte boundary: entries that code nothing
 }
 // the other point transforms of a chunk, filtered from its level 0 (which this stage's k_nzlist or an earlier stage's made): count, one

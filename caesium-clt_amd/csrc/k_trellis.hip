@@ -95,7 +95,12 @@ __device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
     const int tid = int(threadIdx.x);
     const uint8_t *size = c.tables[w.table_ac].size;
-    for (int i = tid; i < 256; i += CSH_TR_WG) { const int l = size[i]; s_lenf[i] = l ? float(l + (i & 15)) : 1e38f; }
+    // s_lenf[11 r + s - 1] = what symbol r << 4 | s (s = 1..10) costs.  Rows of 11: the candidate loop reads row (zero run & 15) at every
+    // predecessor, and with rows of 16 the runs 0, 2, 4 .. met in one bank (42 % of the kernel's LDS cycles were bank conflicts)
+    for (int i = tid; i < 16 * 11; i += CSH_TR_WG) {
+        const int r = i / 11, sz = i % 11 + 1, l = sz <= 10 ? size[(r << 4) | sz] : 0;
+        s_lenf[i] = l ? float(l + sz) : 1e38f;
+    }
     if (tid < 4) s_runf[tid] = tid == 0 ? 0.0f : (size[0xF0] ? float(tid * int(size[0xF0])) : 1e38f);
     if (tid == 0) *s_eob = size[0x00];
     if (tid < 64) { s_q8[tid] = Q.div[tid]; s_qmul[tid] = Q.mul[tid]; s_qsh[tid] = Q.sh[tid]; s_lt[tid] = Q.lt[tid]; }
@@ -107,8 +112,9 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     const ImgDesc &im = c.imgs[w.image];
     const CompGeom g = im.out[w.comp];
     const int tid = int(threadIdx.x);
-    const uint32_t u = ch.j * CSH_TR_WGU + uint32_t(tid);
-    if (u >= w.nunits) return;
+    const uint32_t slot = ch.j * CSH_TR_WGU + uint32_t(tid);
+    if (slot >= w.nunits) return;
+    const uint32_t u = c.perm ? c.perm[w.unit_base + slot] : slot;   // the blocks of a chunk: neighbours in the order of list length (k_trellis_sort), or in raster order
     const int by = int(u) / g.real_bw, b = by * g.bw + (int(u) - by * g.real_bw);
     uint32_t *sp = c.spill + size_t(wg_slot) * (CSH_TR_SPILL * 3u * CSH_TR_WGU) + uint32_t(tid);   // entry e >= CAP: sp[((e - CAP) * 3 + {0 A, 1 Z, 2 P}) * WG]
 
@@ -178,7 +184,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         auto from = [&](int jj, int posj, float Aj, float Zj) {
             const int zr = kpos - 1 - posj;
             const float runf = L.runf[(zr >> 4) & 3];
-            const float *lf = L.lenf + (16 * (zr & 15) + 1);   // symbols (zr & 15) << 4 | 1 .. : in range whatever zr is (a lane that is not `on` reads valid, unused floats)
+            const float *lf = L.lenf + 11 * (zr & 15);   // symbols (zr & 15) << 4 | 1 .. : in range whatever zr is (a lane that is not `on` reads valid, unused floats)
             const float tj = (Zp - Zj) + Aj;
             const uint32_t sel0 = uint32_t(jj + 1) << 4;
             CSH_UNROLL
@@ -239,11 +245,30 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     }
 }
 
+// The blocks of a component in order of list length (counting sort over 64 keys, one workgroup per component; which of two equally long
+// blocks comes first is left to the atomics -- the order only decides which lanes run side by side, never a block's result).
+__global__ void __launch_bounds__(256) k_trellis_sort(TrellisCtx c) {
+    CSH_SHARED uint32_t s_cnt[64];
+    const TrellisWork w = c.work[blockIdx.x];
+    const uint8_t *cnt = c.blk_cnt + w.unit_base;
+    uint32_t *perm = c.perm + w.unit_base;
+    CSH_PHASE_LOOP(4) {
+        if (phase == 0) { if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0; continue; }
+        if (phase == 1) { for (uint32_t u = threadIdx.x; u < w.nunits; u += 256) atomicAdd(&s_cnt[cnt[u] & 63u], 1u); continue; }
+        if (phase == 2) {   // exclusive prefix, longest lists first: the chunks at the front are the long-running ones
+            if (threadIdx.x == 0) { uint32_t at = 0; for (int k = 63; k >= 0; k--) { const uint32_t n = s_cnt[k]; s_cnt[k] = at; at += n; } }
+            continue;
+        }
+        for (uint32_t u = threadIdx.x; u < w.nunits; u += 256) perm[atomicAdd(&s_cnt[cnt[u] & 63u], 1u)] = u;
+    }
+}
+void launch_trellis_sort(hipStream_t st, const TrellisCtx &c) { if (c.nwork && c.perm && c.blk_cnt) CSH_LAUNCH_PHASED(k_trellis_sort, 4, dim3(unsigned(c.nwork)), dim3(256), st, c); }
+
 __global__ void __launch_bounds__(CSH_TR_WG) k_trellis_ac(TrellisCtx c) {
     CSH_SHARED float s_A[CSH_TR_CAP][CSH_TR_WG];
     CSH_SHARED float s_Z[CSH_TR_CAP][CSH_TR_WG];
     CSH_SHARED uint32_t s_P[CSH_TR_CAP][CSH_TR_WG];
-    CSH_SHARED float s_lenf[256 + 16];   // + 16: the candidate loop's reads behind symbol 0xFA of a lane that is not coding stay inside
+    CSH_SHARED float s_lenf[16 * 11 + 16];   // + 16: the candidate loop's reads past a row's tenth entry stay inside
     CSH_SHARED float s_runf[4];
     CSH_SHARED int s_eob;
     CSH_SHARED int32_t s_q8[64];
@@ -274,17 +299,22 @@ __global__ void __launch_bounds__(CSH_TR_WG) k_trellis_ac(TrellisCtx c) {
 __device__ static const uint8_t kStdDcLen[2][12] = {{2, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9}, {2, 2, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}};
 
 __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
-    const TrellisWork w = c.work[blockIdx.y];
+    // one lane per iMCU row of any component of any image (TrellisCtx::rows: longest rows first, so that a wave's 64 walks are of a length:
+    // a grid of (rows of a component) x (components) left most waves a quarter full)
+    const uint32_t ri = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ri >= c.nrows) return;
+    const uint32_t rr = c.rows[ri];
+    const TrellisWork w = c.work[rr >> 16];
     const ImgDesc &im = c.imgs[w.image];
     const CompGeom g = im.out[w.comp];
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
-    const int row = int(blockIdx.x * blockDim.x + threadIdx.x);
-    if (row >= (g.real_bh + g.v - 1) / g.v) return;
+    const int row = int(rr & 0xFFFFu);
     int ncand = (2 + 60 / int(Q.q[0])) | 1;
     ncand = ncand > 9 ? 9 : ncand;
     // what a DC difference of category 0..11 costs: its code length + that many raw bits, as the float the C source converts it to.  Every
     // lane writes the (same) twelve values and reads them back itself: no barrier
-    CSH_SHARED float s_cost[16];
+    CSH_SHARED float s_costs[64][13];   // (a column per lane: the lanes of a wave belong to different components now)
+    float *s_cost = s_costs[threadIdx.x & 63u];
     for (int i = 0; i < 12; i++) s_cost[i] = float(i + int(w.table_dc < 0 ? kStdDcLen[w.comp ? 1 : 0][i] : c.tables[w.table_dc].size[i]));
     const int q = Q.div[0];
     const uint32_t qmul = Q.mul[0], qsh = Q.sh[0];
@@ -411,7 +441,7 @@ void launch_trellis_ac(hipStream_t st, const TrellisCtx &c) {
 #endif
 }
 void launch_trellis_dc(hipStream_t st, const TrellisCtx &c) {
-    if (c.nwork && c.max_rows) CSH_LAUNCH(k_trellis_dc, dim3((c.max_rows + 63) / 64, c.nwork), dim3(64), st, c);
+    if (c.nrows) CSH_LAUNCH(k_trellis_dc, dim3((c.nrows + 63) / 64), dim3(64), st, c);
 }
 
 }  // namespace csh

@@ -106,6 +106,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint32_t *nz_cursor;       // per list: entries handed out
     uint32_t *nz_chunk_off;    // per (list, chunk): first entry, relative to the list's region
     uint32_t *nz_chunk_cnt;    // per (list, chunk): entries (END entries included, padding excluded)
+    uint8_t *nz_blk_cnt;       // null, or (the trellis stage's statistics lists) per block: its non-zero AC coefficients (NzSet::cnt_base)
     const uint32_t *list_slots;// the run's slots that are coded from a list (k_list_stats, k_list_pack) ...
     uint32_t nlist_slots;
     const uint32_t *tok_slots; // ... and those packed from tokens (k_pack); null: every slot of [slot0, slot0 + nslots)
@@ -146,8 +147,13 @@ struct TrellisCtx {
     uint64_t *dcbt;            // per real block: back-pointers of the DC path (9 x 4 bits) | rounded DC level << 36 | sign << 47
     uint32_t *spill;           // per workgroup of the AC kernel: entries of the block lists that do not fit LDS
     uint32_t max_rows;         // DC kernel: most iMCU rows of a component
+    const uint8_t *blk_cnt;    // per real block (unit_base + u): non-zero scalar levels, the length of its list (the builder of the statistics lists counted them); null: no sorting
+    uint32_t *perm;            // per work item, unit_base + slot -> block: the blocks in order of list length (k_trellis_sort), so that the 256 blocks of a chunk -- the 64 of a wave -- run equally long programmes
+    const uint32_t *rows;      // DC kernel: every (work item << 16 | iMCU row) of the batch, longest rows first: one lane each
+    uint32_t nrows;
     uint32_t debug;            // CSH_TR_DEBUG: timing experiments (parts of k_trellis_ac switched off; the output is then garbage)
 };
+void launch_trellis_sort(hipStream_t st, const TrellisCtx &c);   // fills TrellisCtx::perm from ::blk_cnt
 void launch_trellis_ac(hipStream_t st, const TrellisCtx &c);
 void launch_trellis_dc(hipStream_t st, const TrellisCtx &c);
 size_t trellis_spill_words();   // size of TrellisCtx::spill in u32

@@ -160,6 +160,8 @@ struct csh_batch {
     std::vector<TrellisWork> twork;
     std::vector<TrellisChunk> tchunks;
     uint32_t t_units = 0, t_max_rows = 0;
+    std::vector<uint32_t> trows;          // k_trellis_dc: (work item << 16 | iMCU row), longest rows first
+    bool t_sort = false;                  // k_trellis_ac takes its blocks in order of list length (progressive output: the statistics lists count them)
     PinnedBytes bits_pool;
     std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
@@ -216,6 +218,8 @@ struct csh_batch {
     DevBuf<uint32_t> d_nz_pool, d_nz_cursor, d_nz_chunk_off, d_nz_chunk_cnt, d_list_slots, d_tok_slots;
     DevBuf<TrellisWork> d_twork;
     DevBuf<TrellisChunk> d_tchunks;
+    DevBuf<uint32_t> d_trows, d_tperm;
+    DevBuf<uint8_t> d_tblk_cnt;
     DevBuf<uint64_t> d_tlambda;
     DevBuf<uint64_t> d_tdcbt;
     DevBuf<uint32_t> d_tspill;
@@ -552,6 +556,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             NzSet S;
             memset(&S, 0, sizeof S);
             for (int L = 0; L < CSH_NZ_LEVELS; L++) S.list[L] = 0xFFFFFFFFu;
+            S.cnt_base = 0xFFFFFFFFu;
             S.nunits = nu; S.real_bw = im.out[comp].real_bw; S.bw = im.out[comp].bw; S.tile_base = im.out[comp].tile_base;   // rebased with the plans below
             si = int(b->nzsets.size());
             b->nzsets.push_back(S); b->nzset_built.push_back(0u); b->nzset_comp.push_back(comp); b->nzset_image.push_back(img_index);
@@ -1138,10 +1143,22 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 b->t_units += sw.nunits;
                 for (uint32_t j = 0; j < (sw.nunits + CSH_TR_WG - 1) / CSH_TR_WG; j++) b->tchunks.push_back(TrellisChunk{uint32_t(b->twork.size()), j});
                 b->t_max_rows = std::max<uint32_t>(b->t_max_rows, uint32_t((im.out[c].real_bh + im.out[c].v - 1) / im.out[c].v));
+                if (progressive) b->nzsets[size_t(b->nzset_of[size_t(it.image) * CSH_MAX_COMPS + size_t(c)])].cnt_base = tw.unit_base;   // the statistics list's builder counts every block's entries
                 b->twork.push_back(tw);
             }
         }
         b->stage_end(tg);
+        {   // the DC walks, longest first (a wave's 64 lanes then walk rows of a length)
+            const char *ts = getenv("CSH_TR_SORT");
+            b->t_sort = progressive && !(ts && !strcmp(ts, "0"));
+            std::vector<std::pair<uint32_t, uint32_t>> rows;
+            for (size_t wi = 0; wi < b->twork.size(); wi++) {
+                const CompGeom &g = b->imgs[size_t(b->twork[wi].image)].out[b->twork[wi].comp];
+                for (int r = 0; r < (g.real_bh + g.v - 1) / g.v; r++) rows.push_back({uint32_t(g.real_bw * g.v), uint32_t(wi << 16) | uint32_t(r)});
+            }
+            std::stable_sort(rows.begin(), rows.end(), [](const auto &a, const auto &b2) { return a.first > b2.first; });
+            for (const auto &r : rows) b->trows.push_back(r.second);
+        }
         if (b->total_units > 0xFFFFFFF0ull) { csh_set_error("csh_batch_create: batch too large (fewer files per batch)"); return CS_ERR_POOL_OVERFLOW; }
     }
     // pool layout: [all decoded tiles][all re-quantised tiles]; only the first part must start at zero for the decoder
@@ -1191,6 +1208,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
             return CS_ERR_NO_DEVICE;
+        if (b->trellis && (b->d_trows.upload(b->trows, st) || (b->t_sort && (b->d_tperm.alloc(size_t(b->t_units) + 1) || b->d_tblk_cnt.alloc(size_t(b->t_units) + 1))))) return CS_ERR_NO_DEVICE;
         if (b->trellis && (b->d_twork.upload(b->twork, st) || b->d_tchunks.upload(b->tchunks, st) || b->d_tlambda.alloc(size_t(b->t_units) + 1) || b->d_tdcbt.alloc(size_t(b->t_units) + 1) ||
                            b->d_tspill.alloc(trellis_spill_words()) || b->d_dct_raw.alloc(size_t(b->ntiles_out) * CSH_TILE_I16)))
             return CS_ERR_NO_DEVICE;
@@ -1636,7 +1654,9 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         set_stage(tg);
         c.stats_only = 1;
         if (b->d_long_cnt.zero(st)) return -1;
+        c.nz_blk_cnt = b->t_sort ? b->d_tblk_cnt.p : nullptr;
         launch_nzlist(st, c);       // level 0 of the scalar-quantised coefficients (progressive output: the statistics scans are list slots)
+        c.nz_blk_cnt = nullptr;
         launch_tokens(st, c);       // (sequential output: one-component sequential scans, histograms only)
         launch_list_stats(st, c);
         launch_ac_runs(st, c);
@@ -1649,6 +1669,8 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         tc.imgs = b->d_imgs.p; tc.quant = b->d_quants.p; tc.work = b->d_twork.p; tc.nwork = int(b->twork.size()); tc.chunks = b->d_tchunks.p; tc.nchunks = uint32_t(b->tchunks.size());
         tc.tables = b->d_tables.p; tc.raw = b->d_dct_raw.p; tc.raw_tile0 = b->ntiles_in; tc.coef = b->d_coef.p; tc.dcrec = b->d_tlambda.p; tc.dcbt = b->d_tdcbt.p;
         tc.spill = b->d_tspill.p; tc.max_rows = b->t_max_rows;
+        tc.rows = b->d_trows.p; tc.nrows = uint32_t(b->trows.size());
+        if (b->t_sort) { tc.blk_cnt = b->d_tblk_cnt.p; tc.perm = b->d_tperm.p; launch_trellis_sort(st, tc); }
         tc.debug = getenv("CSH_TR_DEBUG") ? uint32_t(atoi(getenv("CSH_TR_DEBUG"))) : 0u;
         launch_trellis_ac(st, tc);
         MARK();

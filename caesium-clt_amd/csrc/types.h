@@ -227,7 +227,8 @@ struct NzSet {
     uint32_t nunits;                // real blocks of the component
     int32_t real_bw, bw;            // block grid: real and MCU-padded width
     uint32_t tile_base;
-    uint32_t pad[4];
+    uint32_t cnt_base;              // where the builder leaves every block's number of non-zero AC coefficients (EncCtx::nz_blk_cnt: the trellis stage sorts its blocks by it); 0xFFFFFFFF: nowhere
+    uint32_t pad[3];
 };
 // one wave of the builder: chunk j of set `set`, the levels in `levels` (bit Al).  Level 0 is made from the coefficients; the others are
 // filtered from level 0 (which an earlier stage may have made)
