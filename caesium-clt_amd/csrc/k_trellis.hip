@@ -33,10 +33,18 @@ size_t trellis_spill_words() { return size_t(CSH_TR_MAXWG) * CSH_TR_SPILL * 3u *
 
 #ifdef CSH_EMUL
 #define CSH_ANY(p) (p)                     // a lane cannot see the others there: its own loop bounds
+#define CSH_WAVE_OR(v) (v)
 #define CSH_SPILL_LD(ptr) (*(ptr))
 #define CSH_SPILL_ST(ptr, v) (*(ptr) = (v))
 #else
 #define CSH_ANY(p) (__ballot(p) != 0ull)   // wave-uniform loop conditions
+__device__ __forceinline__ static unsigned tr_wave_or(unsigned v) {   // OR over the wave's active lanes, in a scalar register
+    unsigned r = 0;
+    CSH_UNROLL
+    for (int b = 0; b < 10; b++) r |= (__ballot((v >> b) & 1u) != 0ull) ? (1u << b) : 0u;   // levels have ten bits
+    return r;
+}
+#define CSH_WAVE_OR(v) tr_wave_or(v)
 // the spilled entries are read and written as streaming accesses: besides the hint, that keeps them from being merged with the LDS
 // accesses of the other branch into one generic-address (flat) access -- which is what the compiler made of `e < CAP ? lds : hbm`,
 // three flat loads with a full wait per predecessor
@@ -145,11 +153,9 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             else { CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 1u) * CSH_TR_WGU, tr_f_bits(Zrun)); CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU, P); }
             ne++;
         }
-        Zrun = (float(x * x) * lambda) * L.lt[k] + Zrun;
+        Zrun = (float(__mul24(x, x)) * lambda) * L.lt[k] + Zrun;
     }
     const float Z63 = Zrun;
-    const int dc_level = tr_level(r[0] < 0 ? -r[0] : r[0], L.q8[0], L.qmul[0], L.qsh[0]);   // scalar DC: k_trellis_dc replaces it
-    const int dc_signed = r[0] < 0 ? -dc_level : dc_level;
     CSH_SCHED_FENCE();
 
     // ---- the programme over list entries.  Every candidate's cost is the C source's float expression, operation for operation:
@@ -168,15 +174,16 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         const int q8 = L.q8[kpos];
         const float ltk = L.lt[kpos];
         const int ncand = on ? tr_bitlen(unsigned(qval)) : 0;
-        int ncmax = 0;   // most candidates any lane of the wave has at this step: the (uniform) bound of the candidate loops
-        CSH_UNROLL
-        for (int kc = 0; kc < 10; kc++) ncmax = CSH_ANY(kc < ncand) ? kc + 1 : ncmax;
+        // most candidates any lane of the wave has at this step -- the (uniform) bound of the candidate loops: the bit length of the OR of the levels
+        const int ncmax = tr_bitlen(CSH_WAVE_OR(on ? unsigned(qval) : 0u));
         float dist[10];
         CSH_UNROLL
         for (int kc = 0; kc < 10; kc++) {
+            dist[kc] = 1e38f;
+            if (kc >= ncmax) continue;   // (uniform)
             const int cand = kc < ncand - 1 ? (2 << kc) - 1 : qval;
-            const int delta = cand * q8 - x;
-            dist[kc] = kc < ncand ? (float(delta * delta) * lambda) * ltk : 1e38f;
+            const int delta = __mul24(cand, q8) - x;   // |delta| <= 2^15: the full-rate 24-bit multiplier is exact (v_mul_lo_u32 is quarter rate)
+            dist[kc] = kc < ncand ? (float(__mul24(delta, delta)) * lambda) * ltk : 1e38f;
         }
         float bestc = 1e38f;
         uint32_t bestsel = 0;   // (predecessor entry + 1) << 4 | candidate
@@ -198,7 +205,38 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         };
         from(-1, 0, 0.0f, 0.0f);
         const int t_lds = int(t) < CSH_TR_CAP ? int(t) : CSH_TR_CAP;
-        for (int jj = 0; jj < t_lds; jj++) from(jj, int((L.P[jj][tid] >> 15) & 63u), L.A[jj][tid], L.Z[jj][tid]);
+        // The predecessors in LDS.  One predecessor per round trip -- read its entry, then the table row its zero run selects, then compare -- is
+        // a chain of two LDS latencies per predecessor.  So, while no lane of the wave has more than four candidates (levels below 16), four
+        // predecessors at a time: their twelve values, then the sixteen table entries, then the compares -- in the order of the plain loop,
+        // predecessor by predecessor, candidate by candidate (ties go to the first).  A row at or above t is read and priced at 1e38; a candidate
+        // the level does not offer has dist 1e38: neither can win.
+        if (ncmax <= 4) {
+            for (int j0 = 0; j0 < t_lds; j0 += 4) {
+                uint32_t Pj[4]; float Aj[4], Zj[4];
+                CSH_UNROLL
+                for (int i = 0; i < 4; i++) { const int r = j0 + i < CSH_TR_CAP ? j0 + i : CSH_TR_CAP - 1; Pj[i] = L.P[r][tid]; Aj[i] = L.A[r][tid]; Zj[i] = L.Z[r][tid]; }
+                float cost[4][4];
+                CSH_UNROLL
+                for (int i = 0; i < 4; i++) {
+                    const int zr = kpos - 1 - int((Pj[i] >> 15) & 63u);
+                    const float runf = L.runf[(zr >> 4) & 3];
+                    const float *lf = L.lenf + 11 * (zr & 15);
+                    const float tj = j0 + i < t_lds ? (Zp - Zj[i]) + Aj[i] : 1e38f;
+                    CSH_UNROLL
+                    for (int kc = 0; kc < 4; kc++) cost[i][kc] = ((lf[kc] + runf) + dist[kc]) + tj;
+                }
+                CSH_UNROLL
+                for (int i = 0; i < 4; i++) {
+                    CSH_UNROLL
+                    for (int kc = 0; kc < 4; kc++) {
+                        const bool better = cost[i][kc] < bestc;
+                        bestc = better ? cost[i][kc] : bestc;
+                        bestsel = better ? ((uint32_t(j0 + i + 1) << 4) | uint32_t(kc)) : bestsel;
+                    }
+                }
+            }
+        } else
+            for (int jj = 0; jj < t_lds; jj++) from(jj, int((L.P[jj][tid] >> 15) & 63u), L.A[jj][tid], L.Z[jj][tid]);
         for (int jj = CSH_TR_CAP; jj < int(t); jj++) {
             const uint32_t *q = sp + (uint32_t(jj - CSH_TR_CAP) * 3u) * CSH_TR_WGU;
             from(jj, int((CSH_SPILL_LD(q + 2 * CSH_TR_WG) >> 15) & 63u), tr_bits_f(CSH_SPILL_LD(q)), tr_bits_f(CSH_SPILL_LD(q + CSH_TR_WG)));
@@ -206,7 +244,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         if (on) {
             const int bk = int(bestsel & 15u);
             const uint32_t level = uint32_t(bk < ncand - 1 ? (2 << bk) - 1 : qval);
-            const float Zi = (float(x * x) * lambda) * ltk + Zp;
+            const float Zi = (float(__mul24(x, x)) * lambda) * ltk + Zp;
             const uint32_t P2 = (bestsel >> 4) | (uint32_t(kpos) << 15) | (level << 21) | (P & 0x80000000u);
             if (t < CSH_TR_CAP) { L.A[t][tid] = bestc; L.Z[t][tid] = Zi; L.P[t][tid] = P2; }
             else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * CSH_TR_WGU; CSH_SPILL_ST(q, tr_f_bits(bestc)); CSH_SPILL_ST(q + CSH_TR_WG, tr_f_bits(Zi)); CSH_SPILL_ST(q + 2 * CSH_TR_WG, P2); }
@@ -226,21 +264,26 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     }
 
     if (c.debug & 4u) return;
-    // ---- the block: zeros, the scalar DC, the levels on the path back from the last coefficient
-    int16_t *dst = c.coef + coef_index(g.tile_base, b, 0);
-    {
-        uint4 z; z.x = z.y = z.z = z.w = 0;
-        CSH_UNROLL
-        for (int j = 0; j < 8; j++) *reinterpret_cast<uint4 *>(dst + CSH_OCT_STRIDE * j) = z;
-    }
-    dst[0] = int16_t(dc_signed);
+    // ---- the block.  It holds the scalar quantiser's output (the pixel kernels wrote it: zeros wherever the list has no entry, the scalar DC,
+    // which k_trellis_dc replaces): only the list's positions change -- the level chosen on the path back from the last coefficient, zero off
+    // the path.  (Writing the block anew -- zeros, DC, levels -- was 128 bytes a block and, with the blocks in order of list length, most of
+    // what that order cost: scattered 16-byte stores.)
+    uint64_t kept = 0;   // entries on the path
     for (int e = last; CSH_ANY(e >= 0);) {
         if (e >= 0) {
             uint32_t Pe;
             if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + (uint32_t(e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
-            const int pos = int((Pe >> 15) & 63u), level = int((Pe >> 21) & 1023u);
-            dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
+            kept |= 1ull << e;
             e = int(Pe & 63u) - 1;
+        }
+    }
+    int16_t *dst = c.coef + coef_index(g.tile_base, b, 0);
+    for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
+        if (e < ne) {
+            uint32_t Pe;
+            if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + ((e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
+            const int pos = int((Pe >> 15) & 63u), level = ((kept >> e) & 1ull) ? int((Pe >> 21) & 1023u) : 0;
+            dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
         }
     }
 }

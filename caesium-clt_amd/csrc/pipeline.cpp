@@ -1657,6 +1657,12 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         c.nz_blk_cnt = b->t_sort ? b->d_tblk_cnt.p : nullptr;
         launch_nzlist(st, c);       // level 0 of the scalar-quantised coefficients (progressive output: the statistics scans are list slots)
         c.nz_blk_cnt = nullptr;
+        if (b->t_sort) {   // the blocks of every component in order of list length (timed with the statistics)
+            TrellisCtx ts;
+            memset(&ts, 0, sizeof ts);
+            ts.work = b->d_twork.p; ts.nwork = int(b->twork.size()); ts.blk_cnt = b->d_tblk_cnt.p; ts.perm = b->d_tperm.p;
+            launch_trellis_sort(st, ts);
+        }
         launch_tokens(st, c);       // (sequential output: one-component sequential scans, histograms only)
         launch_list_stats(st, c);
         launch_ac_runs(st, c);
@@ -1670,7 +1676,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         tc.tables = b->d_tables.p; tc.raw = b->d_dct_raw.p; tc.raw_tile0 = b->ntiles_in; tc.coef = b->d_coef.p; tc.dcrec = b->d_tlambda.p; tc.dcbt = b->d_tdcbt.p;
         tc.spill = b->d_tspill.p; tc.max_rows = b->t_max_rows;
         tc.rows = b->d_trows.p; tc.nrows = uint32_t(b->trows.size());
-        if (b->t_sort) { tc.blk_cnt = b->d_tblk_cnt.p; tc.perm = b->d_tperm.p; launch_trellis_sort(st, tc); }
+        if (b->t_sort) { tc.blk_cnt = b->d_tblk_cnt.p; tc.perm = b->d_tperm.p; }
         tc.debug = getenv("CSH_TR_DEBUG") ? uint32_t(atoi(getenv("CSH_TR_DEBUG"))) : 0u;
         launch_trellis_ac(st, tc);
         MARK();

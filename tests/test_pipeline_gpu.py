@@ -25,9 +25,11 @@ def params(**kw):
     return package().default_parameters(**kw)
 
 
-def test_golden_vectors_through_c_abi(api):
-    """committed libjpeg-turbo vectors: same DQT..EOI as the golden file (marker style differs: merged DQT/DHT)"""
+def test_golden_vectors_through_c_abi(api, monkeypatch):
+    """committed libjpeg-turbo vectors: same DQT..EOI as the golden file (marker style differs: merged DQT/DHT).  The vectors pin the SCALAR
+    quantiser (libjpeg-turbo has no trellis): CSH_PROFILE=scalar; the library's default profile re-quantises and is checked against the oracle below."""
     from oracle import oracle as O
+    monkeypatch.setenv("CSH_PROFILE", "scalar")
     man = json.load(open(os.path.join(GOLD, "manifest.json")))
     for case in man["cases"]:
         src = open(os.path.join(GOLD, case["name"] + ".src.jpg"), "rb").read()
