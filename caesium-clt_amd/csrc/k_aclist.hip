@@ -28,9 +28,9 @@ __device__ __forceinline__ static int lwave() { return int(threadIdx.x) / CSP_WA
 // ------------------------------------------------------------------------------------------------ the builder
 // Level 0 (k_nzlist): one wave per 256-block chunk of a component.  Lane (b, o) = (l >> 3, l & 7) holds octet o (coefficients 8 o .. 8 o + 7:
 // one 16-byte load) of block 8 s + b in step s, so the lanes of a step, in lane order, hold 8 blocks' coefficients in list order: a wave
-// scan of the per-lane counts places every lane's entries, and the lanes' stores land next to each other.  Half a chunk (16 steps) is
-// loaded at once -- 16 loads in flight per lane, 64 registers -- so the two passes (the chunk's entry count, then, behind one atomic add
-// on the list's cursor, the entries) wait for memory three times in all, not once per step.
+// scan of the per-lane counts places every lane's entries, and the lanes' stores land next to each other.  A wave takes half a chunk (16
+// steps: 16 loads in flight per lane, 64 registers) and both passes -- the entry count, then, behind one atomic add on the list's cursor,
+// the entries -- run from those registers: the kernel waits for memory once.
 // The other levels (k_nzfilter): flat over the level-0 chunk, entry -> |c| >> Al, dropped when that is zero.
 #define CSH_NZ_HALF 16   // steps of 8 blocks held in registers at a time: half a chunk
 __device__ __forceinline__ static uint4 nz_load(const EncCtx &c, const NzSet &S, uint32_t u, int bx, int by, uint32_t oct) {
@@ -112,37 +112,49 @@ __device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0
         run += tot;
     }
 }
-__global__ void __launch_bounds__(64) k_nzlist(EncCtx c) {
+__global__ void __launch_bounds__(128, 3) k_nzlist(EncCtx c) {
+    // two waves per chunk, one half each: a wave loads its 128 blocks once, counts, and -- behind the barrier at which wave 0 reserves the
+    // chunk's room -- writes its entries from the same registers
+    CSH_SHARED uint32_t s_cnt[2];
+    CSH_SHARED uint32_t s_rel;      // the chunk's first entry, relative to the list's region; 0xFFFFFFFF: no room
+    CSH_WPERSIST(LV<uint4>, q, CSH_NZ_HALF, 2);
     const NzChunk ch = c.nzchunks[blockIdx.x];
-    if (!(ch.levels & 1u)) return;
-    const NzSet S = c.nzsets[ch.set];
-    if (c.work_active && !c.work_active[ch.work0]) return;
-    const uint32_t u0 = ch.j * 256u;
-    const NzList L0 = c.nzlists[S.list[0]];
-    const uint32_t rec0 = L0.chunk0 + ch.j;
-    // ---- pass 1: the chunk's entries, half after half; the second half stays in the registers
-    LV<uint4> q[CSH_NZ_HALF];
-    LV<uint32_t> cnt;
-    LFOR(l) cnt[l] = 0u;
-    nz_load_half(c, S, u0, 0, q);
-    nz_count_half(S, u0, 0, q, cnt);
-    const uint32_t nA = lsum32(cnt);
-    nz_load_half(c, S, u0, 1, q);
-    nz_count_half(S, u0, 1, q, cnt);
-    const uint32_t n0 = lsum32(cnt), n0a = (n0 + 3u) & ~3u;
-    uint32_t rel = 0;
-    LFOR(l) if (l == 0) rel = atomicAdd(&c.nz_cursor[S.list[0]], n0a);
-    rel = uni(rel);
-    const bool ok0 = uint64_t(rel) + n0a <= L0.cap;
-    LFOR(l) if (l == 0) { c.nz_chunk_off[rec0] = rel; c.nz_chunk_cnt[rec0] = ok0 ? n0 : 0u; if (!ok0) c.overflow[1] = 1; }
-    if (!ok0) return;
-    // ---- pass 2: the entries -- of the second half first (it is here), then of the first one (out of the L2)
-    uint32_t *dst = c.nz_pool + L0.base + rel;
-    uint8_t *blk_cnt = (c.nz_blk_cnt && S.cnt_base != 0xFFFFFFFFu) ? c.nz_blk_cnt + S.cnt_base : nullptr;
-    nz_write_half(S, u0, 1, q, dst, nA, blk_cnt);
-    nz_load_half(c, S, u0, 0, q);
-    nz_write_half(S, u0, 0, q, dst, 0u, blk_cnt);
-    LFOR(l) if (n0 + uint32_t(l) < n0a) dst[n0 + uint32_t(l)] = 0u;   // padding to the next 16-byte boundary: entries that code nothing
+    const int half = lwave();
+    const bool skip = !(ch.levels & 1u) || (c.work_active && !c.work_active[ch.work0]);
+    CSH_PHASE_LOOP(3) {
+        if (skip) continue;
+        const NzSet S = c.nzsets[ch.set];
+        const uint32_t u0 = ch.j * 256u;
+        const NzList L0 = c.nzlists[S.list[0]];
+        if (phase == 0) {
+            LV<uint32_t> cnt;
+            LFOR(l) cnt[l] = 0u;
+            nz_load_half(c, S, u0, half, q);
+            nz_count_half(S, u0, half, q, cnt);
+            const uint32_t n = lsum32(cnt);
+            LFOR(l) if (l == 0) s_cnt[half] = n;
+            continue;
+        }
+        if (phase == 1) {
+            if (half == 0) {
+                const uint32_t n0 = s_cnt[0] + s_cnt[1], n0a = (n0 + 3u) & ~3u, rec0 = L0.chunk0 + ch.j;
+                uint32_t rel = 0;
+                LFOR(l) if (l == 0) rel = atomicAdd(&c.nz_cursor[S.list[0]], n0a);
+                rel = uni(rel);
+                const bool ok0 = uint64_t(rel) + n0a <= L0.cap;
+                LFOR(l) if (l == 0) { c.nz_chunk_off[rec0] = rel; c.nz_chunk_cnt[rec0] = ok0 ? n0 : 0u; if (!ok0) c.overflow[1] = 1; s_rel = ok0 ? rel : 0xFFFFFFFFu; }
+            }
+            continue;
+        }
+        if (s_rel == 0xFFFFFFFFu) continue;
+        uint32_t *dst = c.nz_pool + L0.base + s_rel;
+        uint8_t *blk_cnt = (c.nz_blk_cnt && S.cnt_base != 0xFFFFFFFFu) ? c.nz_blk_cnt + S.cnt_base : nullptr;
+        nz_write_half(S, u0, half, q, dst, half ? s_cnt[0] : 0u, blk_cnt);
+        if (half == 1) {   // padding to the next 16-byte boundary: entries that code nothing
+            const uint32_t n0 = s_cnt[0] + s_cnt[1], n0a = (n0 + 3u) & ~3u;
+            LFOR(l) if (n0 + uint32_t(l) < n0a) dst[n0 + uint32_t(l)] = 0u;
+        }
+    }
 }
 // the other point transforms of a chunk, filtered from its level 0 (which this stage's k_nzlist or an earlier stage's made): count, one
 // atomic add per list, write.  Four entries per lane and step; the second pass reads the chunk out of the L2.
@@ -427,7 +439,7 @@ __global__ void k_reset_works(ScanWork *work, int nwork) {
 
 void launch_nzlist(hipStream_t st, const EncCtx &c) {
     if (!c.nnzchunks) return;
-    CSH_LAUNCH(k_nzlist, dim3(c.nnzchunks), dim3(CSP_WAVE_THREADS), st, c);
+    CSH_LAUNCH_PHASED(k_nzlist, 3, dim3(c.nnzchunks), dim3(2 * CSP_WAVE_THREADS), st, c);
     CSH_LAUNCH(k_nzfilter, dim3(c.nnzchunks), dim3(CSP_WAVE_THREADS), st, c);
 }
 void launch_list_stats(hipStream_t st, const EncCtx &c) { if (c.nlist_slots) CSH_LAUNCH(k_list_stats, dim3((c.nlist_slots + 3) / 4), dim3(4 * CSP_WAVE_THREADS), st, c); }

@@ -161,7 +161,7 @@ __device__ __forceinline__ static void raw_store_octet(const int x[64], int16_t 
     v.y = (uint32_t(x[kZ2N[8 * J + 2]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 3]]) << 16);
     v.z = (uint32_t(x[kZ2N[8 * J + 4]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 5]]) << 16);
     v.w = (uint32_t(x[kZ2N[8 * J + 6]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 7]]) << 16);
-    *reinterpret_cast<uint4 *>(raw + CSH_OCT_STRIDE * J) = v;
+    *reinterpret_cast<uint4 *>(raw + CSH_RAW_OCT * J) = v;
 }
 template <int... J>
 __device__ __forceinline__ static void raw_store_all(const int x[64], int16_t *__restrict__ raw, std::integer_sequence<int, J...>) {
@@ -266,7 +266,7 @@ __device__ __forceinline__ static void raw_to_nat(int x[64], const uint4 &v, std
 }
 template <int... J>
 __device__ __forceinline__ static void requant_block(const int16_t *__restrict__ raw, const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
-    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(raw + CSH_OCT_STRIDE * J)...};
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(raw + CSH_RAW_OCT * J)...};
     int x[64];
     (raw_to_nat<J>(x, v[J], Oct()), ...);
     quant_store_all(x, q, blk, Oct());
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const
     load_idct<true>(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
     int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
     if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
-    fdct_quant_store<DERING, true>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
+    fdct_quant_store<DERING, true>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
 }
 
 // mode 1 producer: subsampled component, IDCT -> u8 plane (pitch real_bw*8, rows real_bh*8, edges replicated)
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
         CSH_UNROLL
         for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
     }
-    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
+    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
 }
 
 // The camera case in one pass: 4:2:0 in, 4:2:0 out, no resize (PlaneWork.mode 10).  One lane per OUTPUT block: a 10 x 10 window of
@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, 
                 for (int cc = 0; cc < 8; cc++) x[8 * r + cc] = x[8 * (r - 1) + cc];
             }
     }
-    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + coef_index(go.tile_base - raw_tile0, b, 0) : nullptr, s_dr);
+    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
 }
 
 // size-targeting: re-quantise every retained DCT block with the image's CURRENT output table (one block per lane)
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(256) k_requant(const ImgDesc *imgs, const Plan
     if (b >= go.bw * go.bh) return;
     int by = b / go.bw, bx = b - by * go.bw;
     if (by >= go.real_bh || bx >= go.real_bw) return;   // dummy blocks: k_fix_dummy
-    requant_block(dct_raw + coef_index(go.tile_base - raw_tile0, b, 0), quant[im.qt_out[w.comp]], coef_out + coef_index(go.tile_base, b, 0), Oct());
+    requant_block(dct_raw + raw_index(go.tile_base - raw_tile0, b), quant[im.qt_out[w.comp]], coef_out + coef_index(go.tile_base, b, 0), Oct());
 }
 
 // dummy blocks (exist only to complete an MCU): zero AC, DC copied per libjpeg's jccoefct rule

@@ -66,7 +66,7 @@ template <int J, int... I>
 __device__ __forceinline__ static void tr_unpack(int r[64], const uint4 &v, std::integer_sequence<int, I...>) { ((r[8 * J + I] = tr_half<I>(v)), ...); }
 template <int... J>
 __device__ __forceinline__ static void tr_load(const int16_t *__restrict__ blk, int r[64], std::integer_sequence<int, J...>) {   // zig-zag order
-    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_OCT_STRIDE * J)...};
+    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_RAW_OCT * J)...};
     (tr_unpack<J>(r, v[J], Oct8()), ...);
 }
 // exact (x + d / 2) / d for 0 <= x <= 2^15, d = 8 q: the pixel kernels' quantiser -- two full-rate instructions (types.h DevQuant::mul)
@@ -127,7 +127,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     uint32_t *sp = c.spill + size_t(wg_slot) * (CSH_TR_SPILL * 3u * CSH_TR_WGU) + uint32_t(tid);   // entry e >= CAP: sp[((e - CAP) * 3 + {0 A, 1 Z, 2 P}) * WG]
 
     int r[64];
-    tr_load(c.raw + coef_index(g.tile_base - c.raw_tile0, b, 0), r, Oct8());
+    tr_load(c.raw + raw_index(g.tile_base - c.raw_tile0, b), r, Oct8());
     CSH_SCHED_FENCE();
     // lambda: the block's mean squared AC value (float accumulation in natural order), two roundings from double as in the C source
     float norm = 0.0f;

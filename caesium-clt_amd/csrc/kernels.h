@@ -11,6 +11,12 @@ __host__ __device__ static inline size_t coef_index(uint32_t tile_base, int b, i
     return (size_t(tile_base) + size_t(b >> 6)) * CSH_TILE_I16 + size_t((b & 63) * CSH_BLK_STRIDE) + size_t(coef_off(k));
 }
 
+// the retained unquantised DCT (size targeting, the trellis quantiser) is BLOCK-major -- int16 raw[block][64 k]: one block = one 128-byte line.
+// Its readers take whole blocks, and the trellis takes them in order of list length (k_trellis.hip): with the coefficient tiles' octet-major
+// layout a block is eight 16-byte pieces in eight lines, and such a gather moved eight lines per block.
+#define CSH_RAW_OCT 8   // int16 elements between a block's octets
+__host__ __device__ static inline size_t raw_index(uint32_t tile_base, int b) { return size_t(tile_base) * CSH_TILE_I16 + size_t(b) * 64; }
+
 // ---- phase 0: entropy decode (k_decode.hip)
 void launch_decode_seq(hipStream_t st, const uint8_t *bits, ImgDesc *imgs, const DecScan *scans, const DevHuffSet *huffs,
                        int16_t *coef, int nimg, const uint32_t *need_seq);

@@ -37,6 +37,13 @@ __device__ __forceinline__ static uint32_t lsum32(const LV<uint32_t> &x) {
     (void)lscan(x, s);
     return s;
 }
+// per-wave state that lives across the phases of a phased kernel (gpu_rt.h CSH_PHASE_LOOP): plain registers on the device; the emulation re-enters
+// the kernel once per phase and wave-thread, so there it is a per-thread array indexed by the wave.  Declare it in front of CSH_PHASE_LOOP.
+#ifdef CSH_EMUL
+#define CSH_WPERSIST(T, name, N, NWAVES) static thread_local T name##_w_[NWAVES][N]; T (&name)[N] = name##_w_[threadIdx.x / CSP_WAVE_THREADS]
+#else
+#define CSH_WPERSIST(T, name, N, NWAVES) T name[N]
+#endif
 __device__ __forceinline__ static uint32_t popc64(uint64_t m) { return uint32_t(__popcll((unsigned long long)m)); }
 
 }  // namespace csh
