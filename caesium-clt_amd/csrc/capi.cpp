@@ -29,7 +29,8 @@ static CCSResult make_result(int code, const char *msg) {
 }
 
 // one device batch = at most CS_GROUP files: launch grids index (image, scan) pairs in gridDim.y (<= 65535), and a group
-// of 2048 1080p files already occupies ~40 GB of HBM and tens of thousands of workgroups per launch
+// of 2048 1080p files already occupies ~40 GB of HBM and tens of thousands of workgroups per launch (cs_batch_extent's cap; the JPEG row
+// cuts its groups further into spans of CS_SPAN files -- CSH_GROUP overrides that span, see jpeg_batch_compress)
 enum { CS_GROUP = 2048 };
 // declared pixel count of a JPEG / PNG (0 when the header does not say): what a file will occupy on the device is known before
 // anything is decoded
@@ -502,8 +503,15 @@ int cs_batch_compress_to_size(const CByteArray *inputs, size_t count, CCSParamet
         if (t == CS_TYPE_GIF || t == CS_TYPE_TIFF) {   // passed through as it is (see passthrough()): there is no quality to walk
             CCSResult r = make_result(0, nullptr);
             passthrough(inputs[i], p, &outputs[i], &r);
+            // libcaesium's size walk returns its smallest try when asked to, and fails otherwise: a file that cannot be made smaller
+            // and is larger than the target is a failure unless return_smallest
+            if (r.success && outputs[i].length > max_output_size && !return_smallest) {
+                cs_free_result(&r);
+                free(outputs[i].data); outputs[i].data = nullptr; outputs[i].length = 0;
+                r = make_result(CS_ERR_TOO_BIG, "the file is passed through as it is (GIF / TIFF have no device path) and is larger than the target size");
+            }
             if (!r.success) failed++;
-            results[i] = r;
+            if (results) results[i] = r; else cs_free_result(&r);
             any_pass = true;
             continue;
         }

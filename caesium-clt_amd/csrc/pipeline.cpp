@@ -1534,11 +1534,20 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     // one event after every kernel, on the batch's own stream: kernel_ms[i] = ev[i+1] - ev[i]
 #define MARK() CSH_CHECK(hipEventRecord(ev[++slot], st))
     CSH_CHECK(hipEventRecord(ev[0], st));
-    if (requant_only) {
+    // a re-run at another quality (size targeting): from the retained DCT -- unless the batch derings: the overshoot mozjpeg's deringing allows
+    // depends on the DC quantiser (jcdctmgr.c preprocess_deringing), so the forward DCT's input changes with the table and the re-run starts
+    // at the pixel phase, from the decoded coefficients that are still in the pool
+    const bool from_pixels = requant_only && b->dering;
+    if (requant_only && !from_pixels) {
         if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
         launch_requant(st, b->d_imgs.p, b->d_pwork.p, int(b->pwork.size()), b->max_tiles, b->d_quants.p, b->d_dct_raw.p, b->ntiles_in, b->d_coef.p);
         launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
         slot = 13;   // kernel_ms slots of the decode + pixel phases: only the first carries time (k_requant + k_fix_dummy)
+        for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
+    } else {
+    if (from_pixels) {
+        if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
+        slot = 8;   // the decode phase's kernel_ms slots stay empty
         for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
     } else {
     // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
@@ -1602,6 +1611,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
                        b->d_coef.p, b->d_need_seq.p);
     launch_decode_seq(st, b->d_bits.p, b->d_imgs.p, b->d_dscans.p, b->d_hsets.p, b->d_coef.p, nimg, b->d_need_seq.p);
     MARK();
+    }  // !from_pixels
     // ---- phase 1: pixel-domain transcode
     int nw = b->lossless ? 0 : int(b->pwork.size());
     launch_idct_plane(st, b->d_imgs.p, b->d_pwork.p, nw, b->max_tiles, b->d_quants.p, b->d_coef.p, b->d_planes.p);

@@ -44,7 +44,7 @@ __host__ __device__ CSW_NOINLINE static uint32_t lwin_load(const uint8_t *data, 
     const uint32_t mis = uint32_t((reinterpret_cast<uintptr_t>(data) + at) & 15u);   // the window starts at a 16-byte boundary of memory at or in front of `at`
     const uint32_t wstart = at >= mis ? at - mis : 0u;
     const uint8_t *src = data + wstart;
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && wstart + L_WIN + 16 <= len) {   // 64 bytes per step, the four loads in flight together (the files' streams start at
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && wstart + L_WIN + 64 <= len) {   // the copy runs in 64-byte steps up to L_WIN + 64: all of it must lie inside the stream;   // 64 bytes per step, the four loads in flight together (the files' streams start at
         for (uint32_t i = 0; i < L_WIN + 16; i += 64) {                                    // multiples of 16 in the pool); a load per word would be a memory round trip per word
             const uint4 *s4 = reinterpret_cast<const uint4 *>(src + i);
             const uint4 a = s4[0], b = s4[1], c = s4[2], d = s4[3];

@@ -574,6 +574,26 @@ def test_emul_batch_size_targeting_and_requant_equivalence(api):
     del test_emul_batch_size_targeting_and_requant_equivalence._last
 
 
+def test_emul_rerun_after_a_run_that_took_the_conditional_stages(api):
+    """A re-quantised run of the same batch starts from "no work item is in a file": the conditional stages of the scan search (luma Al 3,
+    the splits at 12 / 18) that ran -- and placed their winners -- in one run and do not run in the next must leave nothing behind
+    (k_reset_works; ADVICE r03: stale ScanWork records of a skipped stage).  Runs at q 80 (all three extra stages, late splits win), then
+    q 30 (none), then q 80 again: every file equals a fresh encode at that quality."""
+    rich = [(0, 90), (0, 10), (4, 90), (1, 90)]
+    srcs = [synth_jpeg(sd, 160, 120, texture=tx) for sd, tx in rich] + [synth_jpeg(0, 160, 120, texture=0)]
+    b = api.batch(srcs, params(jpeg_quality=80))
+    b.retain_dct()
+    t = b.run()
+    assert t.n_search_extra == 3
+    for q, extra in ((30, None), (80, 3), (95, None), (30, None)):
+        b.set_quality([q] * len(srcs))
+        t = b.rerun_encode()
+        if extra is not None:
+            assert t.n_search_extra == extra
+        for src, out in zip(srcs, b.fetch()):
+            assert out == oracle_lossy(src, q), q
+
+
 # ---- the product library: loads and exports everything include/caesium_hip.h declares (no compute without a GPU)
 def test_product_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "caesium_hip.h")).read()

@@ -98,6 +98,10 @@ def test_scan_search_conditional_stages(api):
     E.test_emul_scan_search_conditional_stages(api)
 
 
+def test_rerun_after_a_run_that_took_the_conditional_stages(api):
+    E.test_emul_rerun_after_a_run_that_took_the_conditional_stages(api)
+
+
 def test_non_interleaved_sequential_scans(api):
     E.test_emul_non_interleaved_sequential_scans(api)
 
