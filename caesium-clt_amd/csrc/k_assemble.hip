@@ -5,34 +5,65 @@
 // Every offset is computed on the device (exclusive scans), so the whole batch needs no host round trip
 // between entropy coding and the final D2H copy.
 #include "kernels.h"
-#ifndef CSH_EMUL
-#include <rocprim/rocprim.hpp>
-#endif
 
 namespace csh {
 
 // ------------------------------------------------------------------------------------------------
-#ifdef CSH_EMUL
-size_t exclusive_scan_tmp_bytes(uint64_t) { return 16; }
-void launch_exclusive_scan(hipStream_t, const uint32_t *in, uint64_t *out, uint64_t n, void *, size_t) {
-    uint64_t acc = 0;
-    for (uint64_t i = 0; i < n; i++) { out[i] = acc; acc += in[i]; }
-    out[n] = acc;
+// out[i] = sum of in[0 .. i) for i = 0 .. n (n + 1 outputs of 64 bits, n inputs of 32): the one scan primitive of the pipeline (chunk
+// offsets, scan offsets, block ordinals, DC prefixes).  Three launches: sums of 4096-element stretches, an exclusive scan of those sums
+// by one workgroup, and the stretches again with their offsets.  (Inputs run from ~2 k image sizes to ~100 M DC differences.)
+#define CSH_SCAN_PER_LANE 16
+#define CSH_SCAN_STRETCH (256 * CSH_SCAN_PER_LANE)
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t *in, uint64_t n, uint64_t *sums) {
+    CSH_SHARED uint64_t s_part[256];
+    const uint64_t i0 = uint64_t(blockIdx.x) * CSH_SCAN_STRETCH;
+    CSH_PHASE_LOOP(2) {
+        if (phase == 0) {
+            uint64_t acc = 0;
+            for (int k = 0; k < CSH_SCAN_PER_LANE; k++) { const uint64_t i = i0 + uint64_t(k) * 256 + threadIdx.x; if (i < n) acc += in[i]; }   // (order is free in a sum: coalesced)
+            s_part[threadIdx.x] = acc;
+            continue;
+        }
+        if (threadIdx.x == 0) { uint64_t t = 0; for (int k = 0; k < 256; k++) t += s_part[k]; sums[blockIdx.x] = t; }
+    }
 }
-#else
-struct WidenU32 { __device__ uint64_t operator()(uint32_t v) const { return uint64_t(v); } };
-// in[] is allocated with one extra (zero) element so that an exclusive scan over n+1 inputs yields the total
-size_t exclusive_scan_tmp_bytes(uint64_t n) {
-    size_t bytes = 0;
-    auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, WidenU32());
-    (void)rocprim::exclusive_scan(nullptr, bytes, it, (uint64_t *)nullptr, uint64_t(0), size_t(n + 1), rocprim::plus<uint64_t>());
-    return bytes + 256;
+__global__ void __launch_bounds__(256) k_scan_spine(uint64_t *sums, uint32_t nb) {   // in place: sums[b] = sum of the stretches in front of b; sums[nb] = everything
+    CSH_SHARED uint64_t s_part[257];
+    const uint32_t per = (nb + 255) / 256, lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+    CSH_PHASE_LOOP(3) {
+        if (phase == 0) { uint64_t acc = 0; for (uint32_t b = lo; b < hi; b++) acc += sums[b]; s_part[threadIdx.x] = acc; continue; }
+        if (phase == 1) { if (threadIdx.x == 0) { uint64_t t = 0; for (int k = 0; k < 256; k++) { const uint64_t v = s_part[k]; s_part[k] = t; t += v; } s_part[256] = t; } continue; }
+        uint64_t acc = s_part[threadIdx.x];
+        for (uint32_t b = lo; b < hi; b++) { const uint64_t v = sums[b]; sums[b] = acc; acc += v; }
+        if (threadIdx.x == 0) sums[nb] = s_part[256];
+    }
 }
+__global__ void __launch_bounds__(256) k_scan_down(const uint32_t *in, uint64_t n, const uint64_t *sums, uint32_t nb, uint64_t *out) {
+    CSH_SHARED uint64_t s_part[256];
+    const uint64_t i0 = uint64_t(blockIdx.x) * CSH_SCAN_STRETCH + uint64_t(threadIdx.x) * CSH_SCAN_PER_LANE;   // a lane's sixteen consecutive elements
+    CSH_PHASE_LOOP(3) {
+        if (phase == 0) {
+            uint64_t acc = 0;
+            for (int k = 0; k < CSH_SCAN_PER_LANE; k++) if (i0 + uint64_t(k) < n) acc += in[i0 + uint64_t(k)];
+            s_part[threadIdx.x] = acc;
+            continue;
+        }
+        if (phase == 1) { if (threadIdx.x == 0) { uint64_t t = sums[blockIdx.x]; for (int k = 0; k < 256; k++) { const uint64_t v = s_part[k]; s_part[k] = t; t += v; } } continue; }
+        uint64_t acc = s_part[threadIdx.x];
+        for (int k = 0; k < CSH_SCAN_PER_LANE; k++) if (i0 + uint64_t(k) < n) { out[i0 + uint64_t(k)] = acc; acc += in[i0 + uint64_t(k)]; }
+        if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = sums[nb];
+    }
+}
+size_t exclusive_scan_tmp_bytes(uint64_t n) { return size_t((n + CSH_SCAN_STRETCH - 1) / CSH_SCAN_STRETCH + 2) * sizeof(uint64_t); }
 void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, size_t tmp_bytes) {
-    auto it = rocprim::make_transform_iterator(in, WidenU32());
-    (void)rocprim::exclusive_scan(tmp, tmp_bytes, it, out, uint64_t(0), size_t(n + 1), rocprim::plus<uint64_t>(), st);
+    uint64_t *sums = static_cast<uint64_t *>(tmp);
+    const uint32_t nb = uint32_t((n + CSH_SCAN_STRETCH - 1) / CSH_SCAN_STRETCH);
+    if (!nb) { (void)hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
+    if (size_t(nb + 2) * sizeof(uint64_t) > tmp_bytes) { csh_set_error("exclusive scan: temporary buffer too small"); return; }
+    CSH_LAUNCH_PHASED(k_scan_sums, 2, dim3(nb), dim3(256), st, in, n, sums);
+    CSH_LAUNCH_PHASED(k_scan_spine, 3, dim3(1), dim3(256), st, sums, nb);
+    CSH_LAUNCH_PHASED(k_scan_down, 3, dim3(nb), dim3(256), st, in, n, sums, nb, out);
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------
 __global__ void k_scan_sizes(AsmCtx a) {
