@@ -5,26 +5,36 @@
 // Every offset is computed on the device (exclusive scans), so the whole batch needs no host round trip
 // between entropy coding and the final D2H copy.
 #include "kernels.h"
+#include "wave.h"
 
 namespace csh {
 
 // ------------------------------------------------------------------------------------------------
 // out[i] = sum of in[0 .. i) for i = 0 .. n (n + 1 outputs of 64 bits, n inputs of 32): the one scan primitive of the pipeline (chunk
-// offsets, scan offsets, block ordinals, DC prefixes).  Three launches: sums of 4096-element stretches, an exclusive scan of those sums
-// by one workgroup, and the stretches again with their offsets.  (Inputs run from ~2 k image sizes to ~100 M DC differences.)
-#define CSH_SCAN_PER_LANE 16
-#define CSH_SCAN_STRETCH (256 * CSH_SCAN_PER_LANE)
+// offsets, scan offsets, block ordinals, DC prefixes: ~2 k image sizes up to ~100 M DC differences).  Three launches: sums of
+// 16384-element stretches (a wave sums a quarter, 64 lanes x 64 coalesced steps), an exclusive scan of those sums by one workgroup, and the
+// stretches again with their offsets -- a wave scan (DPP) per step, the running total carried in a scalar.
+#define CSH_SCAN_WAVE 4096                       // elements per wave
+#define CSH_SCAN_STRETCH (4 * CSH_SCAN_WAVE)     // per workgroup
+__device__ __forceinline__ static uint64_t scan_wave_sum(const uint32_t *in, uint64_t n, uint64_t w0) {
+    LV<uint64_t> acc;
+    LFOR(l) {
+        uint64_t a = 0;
+        for (uint32_t k = 0; k < CSH_SCAN_WAVE / 64; k++) { const uint64_t i = w0 + uint64_t(k) * 64 + uint64_t(l); if (i < n) a += in[i]; }
+        acc[l] = a;
+    }
+    return csp::lsum(acc);
+}
 __global__ void __launch_bounds__(256) k_scan_sums(const uint32_t *in, uint64_t n, uint64_t *sums) {
-    CSH_SHARED uint64_t s_part[256];
-    const uint64_t i0 = uint64_t(blockIdx.x) * CSH_SCAN_STRETCH;
+    CSH_SHARED uint64_t s_part[4];
+    const int wv = int(threadIdx.x) / CSP_WAVE_THREADS;
     CSH_PHASE_LOOP(2) {
         if (phase == 0) {
-            uint64_t acc = 0;
-            for (int k = 0; k < CSH_SCAN_PER_LANE; k++) { const uint64_t i = i0 + uint64_t(k) * 256 + threadIdx.x; if (i < n) acc += in[i]; }   // (order is free in a sum: coalesced)
-            s_part[threadIdx.x] = acc;
+            const uint64_t t = scan_wave_sum(in, n, uint64_t(blockIdx.x) * CSH_SCAN_STRETCH + uint64_t(wv) * CSH_SCAN_WAVE);
+            LFOR(l) if (l == 0) s_part[wv] = t;
             continue;
         }
-        if (threadIdx.x == 0) { uint64_t t = 0; for (int k = 0; k < 256; k++) t += s_part[k]; sums[blockIdx.x] = t; }
+        if (wv == 0) LFOR(l) if (l == 0) sums[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
     }
 }
 __global__ void __launch_bounds__(256) k_scan_spine(uint64_t *sums, uint32_t nb) {   // in place: sums[b] = sum of the stretches in front of b; sums[nb] = everything
@@ -39,19 +49,26 @@ __global__ void __launch_bounds__(256) k_scan_spine(uint64_t *sums, uint32_t nb)
     }
 }
 __global__ void __launch_bounds__(256) k_scan_down(const uint32_t *in, uint64_t n, const uint64_t *sums, uint32_t nb, uint64_t *out) {
-    CSH_SHARED uint64_t s_part[256];
-    const uint64_t i0 = uint64_t(blockIdx.x) * CSH_SCAN_STRETCH + uint64_t(threadIdx.x) * CSH_SCAN_PER_LANE;   // a lane's sixteen consecutive elements
-    CSH_PHASE_LOOP(3) {
+    CSH_SHARED uint64_t s_part[4];
+    const int wv = int(threadIdx.x) / CSP_WAVE_THREADS;
+    const uint64_t w0 = uint64_t(blockIdx.x) * CSH_SCAN_STRETCH + uint64_t(wv) * CSH_SCAN_WAVE;
+    CSH_PHASE_LOOP(2) {
         if (phase == 0) {
-            uint64_t acc = 0;
-            for (int k = 0; k < CSH_SCAN_PER_LANE; k++) if (i0 + uint64_t(k) < n) acc += in[i0 + uint64_t(k)];
-            s_part[threadIdx.x] = acc;
+            const uint64_t t = scan_wave_sum(in, n, w0);
+            LFOR(l) if (l == 0) s_part[wv] = t;
             continue;
         }
-        if (phase == 1) { if (threadIdx.x == 0) { uint64_t t = sums[blockIdx.x]; for (int k = 0; k < 256; k++) { const uint64_t v = s_part[k]; s_part[k] = t; t += v; } } continue; }
-        uint64_t acc = s_part[threadIdx.x];
-        for (int k = 0; k < CSH_SCAN_PER_LANE; k++) if (i0 + uint64_t(k) < n) { out[i0 + uint64_t(k)] = acc; acc += in[i0 + uint64_t(k)]; }
-        if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = sums[nb];
+        uint64_t carry = sums[blockIdx.x];
+        for (int q = 0; q < wv; q++) carry += s_part[q];
+        for (uint32_t k = 0; k < CSH_SCAN_WAVE / 64 && w0 + uint64_t(k) * 64 < n; k++) {
+            LV<uint32_t> v;
+            LFOR(l) { const uint64_t i = w0 + uint64_t(k) * 64 + uint64_t(l); v[l] = i < n ? in[i] : 0u; }
+            uint32_t tot;
+            const LV<uint32_t> ex = lscan(v, tot);   // (a step's 64 inputs sum below 2^32 wherever this scan is used: counts and sizes)
+            LFOR(l) { const uint64_t i = w0 + uint64_t(k) * 64 + uint64_t(l); if (i < n) out[i] = carry + ex[l]; }
+            carry += tot;
+        }
+        if (blockIdx.x == nb - 1 && wv == 3) LFOR(l) if (l == 0) out[n] = sums[nb];
     }
 }
 size_t exclusive_scan_tmp_bytes(uint64_t n) { return size_t((n + CSH_SCAN_STRETCH - 1) / CSH_SCAN_STRETCH + 2) * sizeof(uint64_t); }
@@ -60,9 +77,9 @@ void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, ui
     const uint32_t nb = uint32_t((n + CSH_SCAN_STRETCH - 1) / CSH_SCAN_STRETCH);
     if (!nb) { (void)hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
     if (size_t(nb + 2) * sizeof(uint64_t) > tmp_bytes) { csh_set_error("exclusive scan: temporary buffer too small"); return; }
-    CSH_LAUNCH_PHASED(k_scan_sums, 2, dim3(nb), dim3(256), st, in, n, sums);
+    CSH_LAUNCH_PHASED(k_scan_sums, 2, dim3(nb), dim3(4 * CSP_WAVE_THREADS), st, in, n, sums);
     CSH_LAUNCH_PHASED(k_scan_spine, 3, dim3(1), dim3(256), st, sums, nb);
-    CSH_LAUNCH_PHASED(k_scan_down, 3, dim3(nb), dim3(256), st, in, n, sums, nb, out);
+    CSH_LAUNCH_PHASED(k_scan_down, 2, dim3(nb), dim3(4 * CSP_WAVE_THREADS), st, in, n, sums, nb, out);
 }
 
 // ------------------------------------------------------------------------------------------------

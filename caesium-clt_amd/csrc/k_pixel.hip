@@ -167,6 +167,50 @@ template <int... J>
 __device__ __forceinline__ static void raw_store_all(const int x[64], int16_t *__restrict__ raw, std::integer_sequence<int, J...>) {
     (raw_store_octet<J>(x, raw), ...);
 }
+// The retained DCT is block-major (kernels.h raw_index): a lane's block is one 128-byte line, and eight 16-byte stores per lane at a 128-byte
+// stride are 512 partial-line requests per wave.  So the wave's 64 blocks go through LDS: every lane puts its eight pieces into its row of
+// the wave's 8 KiB (piece J in slot J ^ (lane & 7): the rows' equal slots would all meet in one bank group), then lane l stores piece l & 7
+// of blocks l >> 3, 8 + (l >> 3), ..: eight lanes write one whole line, a store instruction eight whole lines.  The 8 KiB are the wave's
+// columns of the deringing scratch (free again by the time the forward DCT is through).  The emulation stores the pieces directly.
+#ifdef CSH_EMUL
+#define CSH_RAW_VIA_LDS 0
+#else
+#define CSH_RAW_VIA_LDS 1
+#endif
+template <int J>
+__device__ __forceinline__ static void raw_put_octet(const int x[64], int16_t (*tr)[256], int tid) {
+    uint4 v;
+    v.x = (uint32_t(x[kZ2N[8 * J + 0]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 1]]) << 16);
+    v.y = (uint32_t(x[kZ2N[8 * J + 2]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 3]]) << 16);
+    v.z = (uint32_t(x[kZ2N[8 * J + 4]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 5]]) << 16);
+    v.w = (uint32_t(x[kZ2N[8 * J + 6]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 7]]) << 16);
+    const int l = tid & 63;
+    *reinterpret_cast<uint4 *>(&tr[l][(tid & ~63) + 8 * (J ^ (l & 7))]) = v;
+}
+template <int... J>
+__device__ __forceinline__ static void raw_put_all(const int x[64], int16_t (*tr)[256], int tid, std::integer_sequence<int, J...>) {
+    (raw_put_octet<J>(x, tr, tid), ...);
+}
+// every lane of the wave comes here (lanes without a block included): tile_raw = the retained DCT of the wave's first block
+__device__ __forceinline__ static void raw_copy_out(int16_t *__restrict__ tile_raw, bool has_raw, int16_t (*tr)[256], int tid) {
+#if CSH_RAW_VIA_LDS
+    const uint64_t mask = __ballot(has_raw);
+    if (!mask) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int l = tid & 63;
+    CSH_UNROLL
+    for (int j = 0; j < 8; j++) {
+        const int src = 8 * j + (l >> 3);
+        if ((mask >> src) & 1ull) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&tr[src][(tid & ~63) + 8 * ((l & 7) ^ (src & 7))]);
+            *reinterpret_cast<uint4 *>(tile_raw + src * 64 + (l & 7) * CSH_RAW_OCT) = v;
+        }
+    }
+#else
+    (void)tile_raw; (void)has_raw; (void)tr; (void)tid;
+#endif
+}
 // mozjpeg's overshoot deringing (jcdctmgr.c preprocess_deringing + catmull_rom; on in the JCP_MAX_COMPRESSION profile libcaesium's -q runs,
 // /root/reference/src/compressor.rs:415,427; [UPSTREAM-RECALL], the statement checked against: oracle/jpeg_oracle.c cso_dering_block).
 // On the level-shifted samples, walked in zig-zag order as one line: every run of samples at the top of the range (>= 127) becomes a
@@ -255,7 +299,9 @@ __device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuan
     CSH_UNROLL
     for (int c = 0; c < 8; c++) fdct1d<false>(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
     CSH_SCHED_FENCE();
-    if (raw) raw_store_all(x, raw, Oct());   // size-targeting keeps the unquantised DCT so later tries only re-quantise
+    if (raw) {   // size-targeting keeps the unquantised DCT so later tries only re-quantise; the trellis quantiser works from it
+        if (CSH_RAW_VIA_LDS) raw_put_all(x, dr_col, int(threadIdx.x), Oct()); else raw_store_all(x, raw, Oct());
+    }
     quant_store_all(x, q, blk, Oct());
 }
 
@@ -283,7 +329,7 @@ __device__ __forceinline__ static void store_zero_block(int16_t *__restrict__ bl
 template <bool DERING>
 __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant,
                                                        const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
-    CSH_SHARED int16_t s_dr[DERING ? 64 : 1][256];
+    CSH_SHARED int16_t s_dr[64][256];   // deringing: a column per lane; then the wave's columns carry its retained-DCT blocks to whole-line stores (raw_copy_out)
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 0) return;
     const ImgDesc &im = imgs[w.image];
@@ -291,15 +337,20 @@ __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const
     int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     int b = tile * 64 + lane;
-    if (b >= go.bw * go.bh) return;
-    int by = b / go.bw, bx = b - by * go.bw;
-    int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
-    if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); return; }
-    int x[64];
-    load_idct<true>(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
-    int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
-    if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
-    fdct_quant_store<DERING, true>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    bool has_raw = false;
+    do {
+        if (b >= go.bw * go.bh) break;
+        int by = b / go.bw, bx = b - by * go.bw;
+        int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
+        if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); break; }
+        int x[64];
+        load_idct<true>(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
+        int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
+        if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
+        fdct_quant_store<DERING, true>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+        has_raw = dct_raw != nullptr;
+    } while (0);
+    if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
 }
 
 // mode 1 producer: subsampled component, IDCT -> u8 plane (pitch real_bw*8, rows real_bh*8, edges replicated)
@@ -486,7 +537,7 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
 template <bool DERING>
 __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *oplanes,
                                                      int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
-    CSH_SHARED int16_t s_dr[DERING ? 64 : 1][256];
+    CSH_SHARED int16_t s_dr[64][256];   // deringing: a column per lane; then the wave's columns carry its retained-DCT blocks to whole-line stores (raw_copy_out)
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0 || w.mode == 10) return;
     const ImgDesc &im = imgs[w.image];
@@ -494,10 +545,12 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
     int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     int b = tile * 64 + lane;
-    if (b >= go.bw * go.bh) return;
+    bool has_raw = false;
+    do {
+    if (b >= go.bw * go.bh) break;
     int by = b / go.bw, bx = b - by * go.bw;
     int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
-    if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); return; }
+    if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); break; }
     const int pitch = go.real_bw * 8;
     const uint8_t *p = oplanes + im.oplane_off[w.comp] + size_t(by * 8) * pitch + bx * 8;
     int x[64];
@@ -508,6 +561,9 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
         for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
     }
     fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    has_raw = dct_raw != nullptr;
+    } while (0);
+    if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
 }
 
 // The camera case in one pass: 4:2:0 in, 4:2:0 out, no resize (PlaneWork.mode 10).  One lane per OUTPUT block: a 10 x 10 window of
@@ -520,7 +576,7 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
 template <bool DERING>
 __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *planes,
                                                             int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
-    CSH_SHARED int16_t s_dr[DERING ? 64 : 1][256];
+    CSH_SHARED int16_t s_dr[64][256];   // deringing: a column per lane; then the wave's columns carry its retained-DCT blocks to whole-line stores (raw_copy_out)
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 10) return;
     const ImgDesc &im = imgs[w.image];
@@ -528,10 +584,12 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, 
     int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int lane = threadIdx.x & 63;
     int b = tile * 64 + lane;
-    if (b >= go.bw * go.bh) return;
+    bool has_raw = false;
+    do {
+    if (b >= go.bw * go.bh) break;
     int by = b / go.bw, bx = b - by * go.bw;
     int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
-    if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); return; }
+    if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); break; }
     const int pitch = gi.real_bw * 8, rows_alloc = gi.real_bh * 8;
     const uint8_t *pl = planes + im.splane_off[w.comp];
     const int x0 = bx * 8, y0 = by * 8, W = im.enc_w, H = im.enc_h, och = go.comp_h;
@@ -601,6 +659,9 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, 
             }
     }
     fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    has_raw = dct_raw != nullptr;
+    } while (0);
+    if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
 }
 
 // size-targeting: re-quantise every retained DCT block with the image's CURRENT output table (one block per lane)
