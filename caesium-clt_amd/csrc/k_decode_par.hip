@@ -183,12 +183,14 @@ struct ParCtx {
     int mcus_x;            // MCUs per row (write pass)
     uint32_t first_mcu;    // where in the scan this segment starts (restart intervals)
     uint32_t real_bits;    // unstuffed length of the segment in bits
+    int Ss, Se, Al;        // progressive first scans: the band (AC) and the point transform
 };
 __device__ __forceinline__ static ParCtx make_ctx(const ParScan &ps, const ImgDesc *im) {
     ParCtx c; c.sel = ps.sel; c.nb_mcu = ps.nb_mcu; c.total_blocks = ps.total_blocks;
     c.mcus_x = im ? (ps.ncomp > 1 ? im->mcus_x : im->in[ps.comp_of[0]].real_bw) : 1;
     c.first_mcu = ps.first_mcu;
     c.real_bits = ps.clean_len * 8u;
+    c.Ss = ps.Ss; c.Se = ps.Se; c.Al = ps.Al;
     return c;
 }
 // per-m placement table of the write pass (LDS): a non-interleaved scan walks its component block by block (h = v = 1)
@@ -210,7 +212,14 @@ __device__ __forceinline__ static void make_block_info(const ParScan &ps, const 
 //     31 bits past its cut and a symbol is at most 31 bits), the next word is fetched one refill ahead;
 //   * table selectors for every block-in-MCU index sit in a register (ParCtx::sel); the write pass takes its per-block
 //     placement from a small LDS table (ParBlockInfo).
-template <bool WRITE, class R>
+// KIND (ParScan::kind, uniform per call): CSH_PS_SEQ a sequential-mode scan -- whole blocks, DC then AC; CSH_PS_DC_FIRST a progressive DC first
+// scan -- one DC symbol per block, the difference stored unshifted (k_dc_scatter shifts the prefix sums by Al); CSH_PS_AC_FIRST a progressive AC
+// first scan of one component -- per block the symbols of the band Ss..Se (T.81 G.1.2.2, libjpeg jdphuff.c decode_mcu_AC_first: a coefficient
+// at k + r with its value bits, stored << Al; ZRL; EOBn = the run of 2^n + n extra bits blocks, this one included, that have nothing more in the
+// band).  Its state at a cut is (bit position, zig-zag position): there is no block-in-MCU label to creep, so these scans settle in the first
+// list rounds; an EOB run simply adds to the count of blocks the sub-sequence completes.  A first scan only writes coefficients nobody else
+// writes (T.81 G.1.1.1.1: bands of later scans are disjoint or refine), but it shares their octets with other scans: 2-byte stores.
+template <bool WRITE, int KIND, class R>
 __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0, const uint8_t *hb, uint32_t sub_off, const ParCtx &cx, PState &st, uint32_t stop_bit,
                                                         uint32_t ordinal, const ParBlockInfo *bi, int16_t *coef, int32_t *dcdiff) {
     uint32_t nblk = 0;
@@ -241,6 +250,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     // coefficient cost the memory system a 32-byte sector write each (2.4x the planes in HBM write traffic).  An octet that
     // this lane may share with a neighbouring lane (the block it entered half-way: the octet of its entry position; the block
     // it leaves unfinished: the octet still pending at the exit) is written coefficient by coefficient instead.
+    const int k_first = KIND == CSH_PS_AC_FIRST ? cx.Ss : 0;   // where a block starts
     int cur_oct = -1, shared_oct = k > 0 ? (k >> 3) : -1;
     uint64_t olo = 0, ohi = 0;
     auto flush = [&](bool piecewise) {
@@ -266,7 +276,7 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     uint32_t nxt = word(wi);
     auto step = [&]() {
         const uint32_t w = uint32_t(acc >> 32), top16 = w >> 16;
-        const bool isdc = k == 0;
+        const bool isdc = KIND == CSH_PS_DC_FIRST ? true : (KIND == CSH_PS_AC_FIRST ? false : k == 0);
         uint32_t e = *reinterpret_cast<const uint16_t *>(hb + (isdc ? dco : aco) + ((top16 >> 7) << 1));
         if (e & 0x8000u) e = sub[(e & 0xFFFu) + ((top16 & 127u) >> (7u - ((e >> 12) & 7u)))];
         const int len = e ? int(e >> 8) : 16;      // no such code: consume 16 bits, symbol 0 (as the sequential path)
@@ -275,11 +285,16 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
         const int n = sym & 15, r = isdc ? 0 : (sym >> 4);
         const int kn = k + r;
         const bool val = n != 0 && kn <= 63;                           // kn > 63: corrupt run, block ends, no value bits consumed
-        int v = int((w << len) >> ((32 - n) & 31));
-        v = v < int(1u << ((n - 1) & 31)) ? v - (1 << n) + 1 : v;   // EXTEND (T.81 F.2.2.1); n == 0 is masked below
-        v = val ? v : 0;
+        // AC first scan: n == 0 and r < 15 is EOBr -- r more bits follow, the run's low bits
+        const bool eobrun = KIND == CSH_PS_AC_FIRST && n == 0 && r != 15;
+        const int nx = eobrun ? r : n;                                  // raw bits behind the symbol
+        int v = int((w << len) >> ((32 - nx) & 31));
+        uint32_t run = 1;                                               // blocks this symbol completes, if it completes one
+        if (eobrun) { run = (1u << r) + (r ? uint32_t(v) : 0u); v = 0; }
+        else { v = v < int(1u << ((n - 1) & 31)) ? v - (1 << n) + 1 : v; v = val ? v : 0; }   // EXTEND (T.81 F.2.2.1); n == 0 is masked
         if (WRITE && in_range) {
-            if (isdc) *dcp = v;
+            if (KIND == CSH_PS_AC_FIRST) { if (val) blk[coef_off(kn)] = int16_t(v * (1 << cx.Al)); }
+            else if (isdc) *dcp = v;
             else if (val) {
                 const int oct = kn >> 3;
                 if (oct != cur_oct) { if (cur_oct >= 0) flush(cur_oct == shared_oct); cur_oct = oct; }
@@ -287,24 +302,30 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
                 if (kn & 4) ohi |= piece; else olo |= piece;
             }
         }
-        const int used = len + (val ? n : 0);
-        const bool eob = !isdc && n == 0 && r != 15;
+        const int used = len + (eobrun ? r : (val ? n : 0));
+        const bool eob = KIND == CSH_PS_AC_FIRST ? eobrun : (!isdc && n == 0 && r != 15);
         const int kc = kn > 63 ? 63 : kn;
-        k = eob ? 64 : kc + 1;                                           // ZRL: k + 16; coefficient / DC: kn + 1
+        if (KIND == CSH_PS_DC_FIRST) k = 64;                             // a block of a DC scan is its one symbol
+        else if (KIND == CSH_PS_AC_FIRST) k = (eob || kn > 63 || kc + 1 > cx.Se) ? 64 : kc + 1;   // EOBr, a corrupt run, or the band's end (ZRL: n == 0, kn = k + 15)
+        else k = eob ? 64 : kc + 1;                                      // ZRL: k + 16; coefficient / DC: kn + 1
         pos += uint32_t(used);
         acc <<= used;
         nb -= used;
         if (nb < 32) { acc |= uint64_t(nxt) << (32 - nb); nb += 32; wi++; nxt = word(wi); }
         if (k >= 64) {
-            if (WRITE) { if (cur_oct >= 0) flush(cur_oct == shared_oct); shared_oct = -1; }
-            k = 0;
-            nblk++;
+            if (WRITE && KIND == CSH_PS_SEQ) { if (cur_oct >= 0) flush(cur_oct == shared_oct); shared_oct = -1; }
+            k = k_first;
+            nblk += run;
             if (WRITE) cut_mcu = (pos > cx.real_bits && mcu < cut_mcu) ? mcu : cut_mcu;
             const bool wrap = m + 1 == cx.nb_mcu;
             m = wrap ? 0 : m + 1;
             tables(m);
             if (WRITE) {
-                if (wrap) { mcu++; if (++mx == cx.mcus_x) { mx = 0; my++; } }
+                if (KIND == CSH_PS_AC_FIRST) {   // (nb_mcu = 1: a unit is a block) on by the run: the blocks inside an EOB run carry no bits
+                    mcu += run;
+                    if (run == 1) { if (++mx == cx.mcus_x) { mx = 0; my++; } }
+                    else { my = int(mcu + cx.first_mcu) / cx.mcus_x; mx = int(mcu + cx.first_mcu) - my * cx.mcus_x; }
+                } else if (wrap) { mcu++; if (++mx == cx.mcus_x) { mx = 0; my++; } }
                 locate(m);
             }
         }
@@ -313,12 +334,18 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
     // the lane in which the data ran out finishes that MCU (if the frame needs it) past its own cut: nobody else will, the
     // next lanes are beyond the data.  (A separate loop: this condition inside the hot loop doubled the kernel's time.)
     if (WRITE && !dead)
-        while (pos > cx.real_bits && (k != 0 || m != 0) && __umul24(mcu, uint32_t(cx.nb_mcu)) < cx.total_blocks) step();
-    if (WRITE && cur_oct >= 0) flush(true);   // unfinished block: the next lane may add to this octet
+        while (pos > cx.real_bits && (k != k_first || m != 0) && __umul24(mcu, uint32_t(cx.nb_mcu)) < cx.total_blocks) step();
+    if (WRITE && KIND == CSH_PS_SEQ && cur_oct >= 0) flush(true);   // unfinished block: the next lane may add to this octet
     st.pos = pos; st.k = k; st.m = m;
     // WRITE: first block ordinal (relative to the segment) that stays zero because the data ran out, or 0xFFFFFFFF
     return WRITE ? ((cut_mcu == 0xFFFFFFFFu || dead) ? 0xFFFFFFFFu : (cut_mcu + 1u) * uint32_t(cx.nb_mcu)) : nblk;
 }
+
+// the span decoder of a segment's kind (uniform wherever a workgroup serves one scan)
+#define CSH_SPAN(WR, KINDV, ...)                                                                        \
+    ((KINDV) == CSH_PS_AC_FIRST ? decode_span<WR, CSH_PS_AC_FIRST>(__VA_ARGS__)                          \
+                                : (KINDV) == CSH_PS_DC_FIRST ? decode_span<WR, CSH_PS_DC_FIRST>(__VA_ARGS__) : decode_span<WR, CSH_PS_SEQ>(__VA_ARGS__))
+__device__ __forceinline__ static bool par_decoded(int kind) { return kind == CSH_PS_SEQ || kind == CSH_PS_DC_FIRST || kind == CSH_PS_AC_FIRST; }
 
 // pass B: relaxation  s[t+1] = F_t(s[t]), in place.  Only the lane of sub-sequence t-1 ever writes s[t]; whenever it
 // changes s[t] it appends t to the next work list, so t is re-evaluated in a LATER launch with the newest s[t].  An empty
@@ -388,7 +415,7 @@ __global__ void __launch_bounds__(CSH_LIST_LANES) k_dec_relax_list(const uint8_t
         PReader g; g.base = clean + ps.bits_off; g.len = ps.clean_len;
         for (int step = 0;; step++) {
             const uint32_t w0 = t * (CSH_SUBSEQ_BYTES / 4), stop = (t + 1) * CSH_SUBSEQ_BYTES * 8;
-            const uint32_t n = decode_span<false>(rd, w0, hb, uint32_t(sizeof(SET::root)), cx, st, stop, 0, nullptr, nullptr, nullptr);
+            const uint32_t n = CSH_SPAN(false, ps.kind, rd, w0, hb, uint32_t(sizeof(SET::root)), cx, st, stop, 0, nullptr, nullptr, nullptr);
             nblk[ps.sub_base + t] = n;
             const uint64_t e = pack_state(st);
             if (e == state[base + t + 1]) break;                            // in step with what is recorded: nothing downstream changes
@@ -418,8 +445,9 @@ __global__ void __launch_bounds__(256) k_dec_mark_pending(const ParScan *pss, co
 }
 __global__ void k_dec_chain(const ParScan *pss, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq) {
     int si = blockIdx.x * blockDim.x + threadIdx.x;
-    if (si >= nps || !scan_pending[si] || pss[si].kind) return;
+    if (si >= nps || !scan_pending[si] || !par_decoded(pss[si].kind)) return;
     const ParScan &ps = pss[si];
+    if (ps.kind == CSH_PS_AC_FIRST) { need_seq[ps.image] = 2; return; }   // (no label to settle there: a scan still listed is not converging -- the sequential kernel takes the image)
     uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     size_t base = ps.sub_base + ps.par_index;
     int m = 0;
@@ -445,7 +473,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     CSH_SHARED SET lhs;
     CSH_SHARED ParBlockInfo lbi[10];   // write pass: where block m of an MCU goes
     const ParScan &ps = a.pss[blockIdx.y];
-    if (ps.kind) return;   // progressive scan: listed for the unstuffing pass only (uniform for the workgroup, before any barrier)
+    if (!par_decoded(ps.kind)) return;   // listed for the unstuffing pass only (uniform for the workgroup, before any barrier)
     const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
     const uint32_t t0 = blockIdx.x * 256, tid = threadIdx.x, t = t0 + tid;
     const bool wg_live = t0 < nsub && t0 * CSH_SUBSEQ_BYTES < ps.clean_len && !(MODE == 2 && a.need_seq[ps.image] == 1) &&
@@ -476,15 +504,15 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
         const uint32_t sub_off = uint32_t(sizeof(SET::root));
         const ParCtx cx = make_ctx(ps, MODE == 2 ? &a.imgs[ps.image] : nullptr);
         if (MODE == 0) {
-            PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = 0;
+            PState st; st.pos = t * CSH_SUBSEQ_BYTES * 8; st.m = 0; st.k = ps.kind == CSH_PS_AC_FIRST ? ps.Ss : 0;
             if (t == 0) a.state[base] = pack_state(st);
             if (!live) { a.state[base + t + 1] = 0; continue; }
-            decode_span<false>(rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
+            CSH_SPAN(false, ps.kind, rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
             a.state[base + t + 1] = pack_state(st);
         } else if (MODE == 1) {
             if (!live) continue;
             PState st = unpack_state(a.state[base + t]);
-            uint32_t n = decode_span<false>(rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
+            uint32_t n = CSH_SPAN(false, ps.kind, rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
             a.nblk[ps.sub_base + t] = n;
             uint64_t e = pack_state(st);
             if (e != a.state[base + t + 1]) {
@@ -499,18 +527,18 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             const bool last = (t + 1) * CSH_SUBSEQ_BYTES >= ps.clean_len;
             for (int m0 = 0; m0 < ps.nb_mcu && m0 < 10; m0++) {
                 PState st = s0; st.m = m0;
-                uint32_t n = decode_span<false>(rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
+                uint32_t n = CSH_SPAN(false, ps.kind, rd, w0, hb, sub_off, cx, st, stop, 0, nullptr, nullptr, nullptr);
                 const bool same = last || (st.pos == nx.pos && st.k == nx.k);
                 a.hyp[(size_t(ps.sub_base) + t) * 10 + m0] = same ? uint16_t((st.m << 12) | (n > 4095 ? 4095 : n)) : uint16_t(0xFFFF);
             }
         } else {
-            if (a.need_seq[ps.image]) continue;
+            { const uint32_t ns = a.need_seq[ps.image]; if (ns && ns != 4u) continue; }   // (4: a progressive image -- its first scans are decoded here, its AC refinements by k_decode_prog)
             uint32_t ordinal = uint32_t(a.blk_off[ps.sub_base + t] - a.blk_off[ps.sub_base]);
             // a segment that yields fewer blocks than the frame needs has run out of data: its remaining blocks stay zero
             // (cut_block, set by the lane that crossed the end; k_dc_scatter gives those blocks a zero DC as well)
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            const uint32_t cut = decode_span<true>(rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
+            const uint32_t cut = CSH_SPAN(true, ps.kind, rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
             if (cut != 0xFFFFFFFFu) atomicMin(&a.cut_block[ps.par_index], cut);
         }
     }
@@ -520,7 +548,8 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
 __global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef, const uint32_t *need_seq,
                                                      const uint32_t *cut_block) {
     const ParScan &ps = pss[blockIdx.y];
-    if (need_seq[ps.image]) return;
+    if (ps.kind != CSH_PS_SEQ && ps.kind != CSH_PS_DC_FIRST) return;
+    { const uint32_t ns = need_seq[ps.image]; if (ns && ns != 4u) return; }
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;  // block ordinal in scan order
     if (j >= ps.total_blocks) return;
     const ImgDesc &im = imgs[ps.image];
@@ -535,7 +564,25 @@ __global__ void __launch_bounds__(256) k_dc_scatter(const ParScan *pss, const Im
     // inclusive prefix over this component's differences (two's-complement wrap-around is harmless)
     uint32_t v = uint32_t(dc_off[idx + 1] - dc_off[ps.dc_base[m]]);
     if (j >= cut_block[blockIdx.y]) v = 0;   // MCUs after the one in which the data ran out hold zeros, DC included
-    coef[coef_index(g.tile_base, by * g.bw + bx, 0)] = int16_t(int32_t(v));
+    coef[coef_index(g.tile_base, by * g.bw + bx, 0)] = int16_t(int32_t(v) * (1 << (ps.kind == CSH_PS_DC_FIRST ? ps.Al : 0)));   // (a progressive DC first scan carries the values >> Al)
+}
+// progressive DC refinement (T.81 G.1.2.1.1, libjpeg jdphuff.c decode_mcu_DC_refine): one raw bit per block in scan order -- bit j of the
+// unstuffed segment is block j's; a set bit ORs 1 << Al into the DC value (k_dc_scatter wrote it: launched after).  Past the data: nothing.
+__global__ void __launch_bounds__(256) k_dc_refine(const uint8_t *clean, const ParScan *pss, const ImgDesc *imgs, int16_t *coef, const uint32_t *need_seq) {
+    const ParScan &ps = pss[blockIdx.y];
+    if (ps.kind != CSH_PS_DC_REFINE || need_seq[ps.image] != 4u) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ps.total_blocks || (j >> 3) >= ps.clean_len) return;
+    if (!((clean[ps.bits_off + (j >> 3)] >> (7u - (j & 7u))) & 1u)) return;
+    const ImgDesc &im = imgs[ps.image];
+    const uint32_t mcu = j / uint32_t(ps.nb_mcu);
+    const int m = int(j - mcu * uint32_t(ps.nb_mcu));
+    const CompGeom &g = im.in[ps.comp_of[m]];
+    int by, bx;
+    if (ps.ncomp > 1) { const int my = int(mcu) / im.mcus_x, mx = int(mcu) - my * im.mcus_x; by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
+    else { by = int(mcu) / g.real_bw; bx = int(mcu) - by * g.real_bw; }
+    int16_t *p = coef + coef_index(g.tile_base, by * g.bw + bx, 0);
+    *p = int16_t(*p | (1 << ps.Al));
 }
 
 void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt) {
@@ -583,6 +630,9 @@ void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_s
 }
 void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq) {
     if (nps) CSH_LAUNCH(k_dec_chain, dim3((nps + 63) / 64), dim3(64), st, ps, nps, state, nblk, hyp, scan_pending, need_seq);
+}
+void launch_dc_refine(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, int16_t *coef, const uint32_t *need_seq) {
+    if (nps && max_blocks) CSH_LAUNCH(k_dc_refine, dim3((max_blocks + 255) / 256, nps), dim3(256), st, clean, ps, imgs, coef, need_seq);
 }
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq, const uint32_t *cut_block) {

@@ -39,6 +39,7 @@ void launch_decode_prog(hipStream_t st, const uint8_t *clean, const ParScan *pss
                         const int *chain_scans, int nchains, const ImgDesc *imgs, int16_t *coef, uint32_t *need_seq);
 void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending);
 void launch_dec_chain(hipStream_t st, const ParScan *ps, int nps, uint64_t *state, uint32_t *nblk, const uint16_t *hyp, const uint32_t *scan_pending, uint32_t *need_seq);
+void launch_dc_refine(hipStream_t st, const uint8_t *clean, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, int16_t *coef, const uint32_t *need_seq);   // after launch_dc_scatter
 void launch_dc_scatter(hipStream_t st, const ParScan *ps, int nps, uint32_t max_blocks, const ImgDesc *imgs, const uint64_t *dc_off, int16_t *coef,
                        const uint32_t *need_seq, const uint32_t *cut_block);
 

@@ -902,22 +902,57 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             if (js.has_marker || js.data_len >= (1u << 28) || !b->phset_fits[b->dscans[im.first_scan + s].huff_set]) prog_ok = false;
         }
         if (prog_ok) {
+            // The scans of a progressive file, by what they are to the decoder (k_decode_par.hip, k_decode_prog.hip):
+            //   DC first / AC first scans  self-synchronising like sequential scans -- cut into sub-sequences, speculated, relaxed, written
+            //                              (CSH_PS_DC_FIRST / CSH_PS_AC_FIRST).  They carry most of a file's bits;
+            //   DC refinement              one bit per block: unstuffed, then scattered (CSH_PS_DC_REFINE);
+            //   AC refinement              a chain per component, one wave each (the bits between two symbols depend on the block's history:
+            //                              a decoder that does not know its block cannot find the next symbol) -- CSH_PS_UNSTUFF + ProgChain.
+            // CSH_PROG_PAR=0 (or a file beyond the parallel decoder's 24-bit block counts) leaves every scan to the chains, as before round 4.
+            const char *pp = getenv("CSH_PROG_PAR");
+            const bool par_first = !(pp && !strcmp(pp, "0")) && uint64_t(in.mcus_x) * uint64_t(in.mcus_y) * 10 < (1u << 24);
             for (size_t s = 0; s < in.scans.size(); s++) {
+                const JScan &js = in.scans[s];
                 DecScan &ds = b->dscans[im.first_scan + s];
                 ParScan ps;
                 memset(&ps, 0, sizeof ps);
-                ps.kind = 1;
                 ps.bits_off = ds.bits_off; ps.bits_len = ds.bits_len; ps.huff_set = ds.huff_set; ps.image = img_index; ps.ncomp = ds.ncomp; ps.nb_mcu = 1;
+                ps.Ss = js.Ss; ps.Se = js.Se; ps.Al = js.Al;
+                ps.kind = !par_first ? CSH_PS_UNSTUFF : js.Ss == 0 ? (js.Ah == 0 ? CSH_PS_DC_FIRST : CSH_PS_DC_REFINE) : (js.Ah == 0 ? CSH_PS_AC_FIRST : CSH_PS_UNSTUFF);
                 ps.sub_base = b->total_sub; ps.par_index = uint32_t(b->pscans.size());
+                if (ps.kind != CSH_PS_UNSTUFF) {   // where the blocks of the scan lie (as for a sequential-mode scan: units are MCUs, or the blocks of its one component)
+                    int m = 0;
+                    for (int k = 0; k < js.ncomp; k++) {
+                        const JComp &jc = in.comp[js.comp_idx[k]];
+                        const int nh = js.ncomp > 1 ? jc.h : 1, nv = js.ncomp > 1 ? jc.v : 1;
+                        const uint32_t units = js.ncomp > 1 ? uint32_t(in.mcus_x * in.mcus_y) : uint32_t(jc.real_bw * jc.real_bh);
+                        const uint32_t nblocks = units * uint32_t(nh * nv);
+                        for (int y = 0; y < nv; y++)
+                            for (int x = 0; x < nh; x++, m++) {
+                                if (m >= 10) break;
+                                ps.comp_of[m] = js.comp_idx[k]; ps.by_of[m] = y; ps.bx_of[m] = x; ps.dct[m] = js.td[k]; ps.act[m] = js.ta[k];
+                                ps.dc_base[m] = b->dc_total; ps.dc_per_mcu[m] = uint32_t(nh * nv); ps.dc_idx[m] = uint32_t(y * nh + x);
+                            }
+                        if (ps.kind == CSH_PS_DC_FIRST) b->dc_total += nblocks;
+                        ps.total_blocks += nblocks;
+                    }
+                    ps.nb_mcu = m;
+                    b->max_par_blocks = std::max(b->max_par_blocks, ps.total_blocks);
+                    if (ps.kind != CSH_PS_DC_REFINE) {
+                        const uint32_t nsub = (ps.bits_len + CSH_SUBSEQ_BYTES - 1) / CSH_SUBSEQ_BYTES;
+                        b->total_sub += nsub;
+                        b->max_sub = std::max(b->max_sub, nsub);
+                    }
+                }
                 ds.par_index = int(b->pscans.size());
                 b->pscans.push_back(ps);
             }
-            for (int chain = 0; chain <= in.ncomp; chain++) {   // 0: DC scans; c + 1: AC scans of component c
+            for (int chain = 0; chain <= in.ncomp; chain++) {   // 0: DC scans; c + 1: AC scans of component c -- those the parallel decoder does not take
                 ProgChain pc; pc.image = img_index; pc.first = int(b->chain_scans.size()); pc.count = 0;
                 for (size_t s = 0; s < in.scans.size(); s++) {
                     const JScan &js = in.scans[s];
-                    bool mine = chain == 0 ? js.Ss == 0 : (js.Ss != 0 && js.comp_idx[0] == chain - 1);
-                    if (mine) { b->chain_scans.push_back(im.first_scan + int(s)); pc.count++; }
+                    const bool mine = chain == 0 ? js.Ss == 0 : (js.Ss != 0 && js.comp_idx[0] == chain - 1);
+                    if (mine && b->pscans[size_t(b->dscans[im.first_scan + s].par_index)].kind == CSH_PS_UNSTUFF) { b->chain_scans.push_back(im.first_scan + int(s)); pc.count++; }
                 }
                 if (pc.count) b->chains.push_back(pc);
             }
@@ -1605,6 +1640,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         MARK();
         if (nps) launch_exclusive_scan(st, reinterpret_cast<uint32_t *>(b->d_dcdiff.p), b->d_dc_off.p, b->dc_total, b->d_scan_tmp.p, b->d_scan_tmp.n);
         launch_dc_scatter(st, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_dc_off.p, b->d_coef.p, b->d_need_seq.p, b->d_cut_block.p);
+        launch_dc_refine(st, b->d_clean.p, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_coef.p, b->d_need_seq.p);
         MARK();
     }
     launch_decode_prog(st, b->d_clean.p, b->d_pscans.p, b->d_phsets.p, b->d_dscans.p, b->d_chains.p, b->d_chain_scans.p, int(b->chains.size()), b->d_imgs.p,

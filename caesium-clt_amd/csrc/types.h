@@ -126,8 +126,13 @@ struct ParScan {
     uint32_t dc_base[10], dc_per_mcu[10], dc_idx[10];  // where block m's DC difference goes (scan order, per component)
     uint64_t sel;                 // table selectors, 6 bits per block-in-MCU index m: dct[m] | (4 + act[m]) << 3
     uint32_t first_mcu;           // restart interval: MCU (or block, non-interleaved) of the scan this segment starts at
-    int kind;                     // 0: sequential-mode scan for the self-synchronising decoder; 1: progressive scan, listed only to be unstuffed
+    int kind;                     // what the segment is to the self-synchronising decoder (k_decode_par.hip):
+                                  //   0 sequential-mode scan (whole blocks);  1 listed only to be unstuffed (progressive AC refinement: k_decode_prog.hip);
+                                  //   2 progressive DC first scan (one DC symbol per block);  3 progressive AC first scan (band Ss..Se of one component,
+                                  //   EOB runs);  4 progressive DC refinement (unstuffed, then one bit per block: k_dc_refine)
+    int Ss, Se, Al;               // kinds 2, 3, 4
 };
+enum { CSH_PS_SEQ = 0, CSH_PS_UNSTUFF = 1, CSH_PS_DC_FIRST = 2, CSH_PS_AC_FIRST = 3, CSH_PS_DC_REFINE = 4 };
 
 // quantisation table as the kernels want it: zig-zag order, with exact-division helpers
 struct DevQuant {
