@@ -15,6 +15,7 @@
 #include <functional>
 #include <future>
 #include <map>
+#include <unordered_set>
 #include <thread>
 
 #include "../../include/caesium_hip.h"
@@ -594,11 +595,32 @@ int run(const Options &o) {
     });
     us_read += (long long)(ms(t_win, now()) * 1000.0);
     };
-    std::future<void> ahead = std::async(std::launch::async, read_window, windows[0].first, windows[0].second);
+    // Ordering: the read-ahead stats, checks the overwrite policy of and reads window N + 1 while window N is written.  That is only sound when no output
+    // of one file is the input (or the overwrite-policy target) of another: `--format` or `--suffix` writing into the input tree can make a.png -> a.jpg land
+    // on the input a.jpg.  (The reference's par_iter has the same race between its threads; a sequential reader has not.)  With more than one window,
+    // every file's output path is computed up front; if one names another file's input the windows run strictly one after the other.
+    bool read_ahead = windows.size() > 1;
+    if (read_ahead) {
+        auto key = [](const fs::path &q) { std::error_code e; fs::path a = fs::absolute(q, e); return (e ? q : a).lexically_normal().string(); };
+        std::unordered_set<std::string> inputs;
+        for (auto &f : files) inputs.insert(key(f));
+        for (size_t i = 0; i < files.size() && read_ahead; i++) {
+            fs::path outdir_in = o.same_folder_as_input ? files[i].parent_path() : *o.output, dir;
+            std::string name;
+            const bool same = o.same_folder_as_input || outdir_in == *base;
+            if (!compute_output_full_path(outdir_in, files[i], *base, o.keep_structure, suffix, o.format, same, dir, name)) continue;
+            const std::string out = key(dir / name);
+            if (out != key(files[i]) && inputs.count(out)) read_ahead = false;
+        }
+    }
+    std::future<void> ahead;
+    if (read_ahead) ahead = std::async(std::launch::async, read_window, windows[0].first, windows[0].second);
     for (size_t wi = 0; wi < windows.size(); wi++) {
     const size_t w0 = windows[wi].first, w1 = windows[wi].second;
-    ahead.get();
-    if (wi + 1 < windows.size()) ahead = std::async(std::launch::async, read_window, windows[wi + 1].first, windows[wi + 1].second);
+    if (read_ahead) {
+        ahead.get();
+        if (wi + 1 < windows.size()) ahead = std::async(std::launch::async, read_window, windows[wi + 1].first, windows[wi + 1].second);
+    } else read_window(w0, w1);
     const auto t_read = now();
     // ---- stage 2 (device): the engine calls of compressor.rs:287-306, batched.  Files that share a parameter set form one
     // batch per device; groups go round-robin over --gpus devices, one host thread per device.

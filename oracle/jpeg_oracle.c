@@ -12,7 +12,15 @@
  * Profiles: "plain" = ISLOW integer DCTs, scalar quantiser, optimal Huffman tables, stock progression
  * (or a supplied script) -- byte-pinned to libjpeg-turbo; + mozjpeg's scan search (scan_script 2, pinned by
  * samples/j0.JPG); + mozjpeg's trellis quantiser and overshoot deringing (cso_enc_params.trellis /
- * .deringing: restated from recall of mozjpeg 4.1's jcdctmgr.c, PARITY UNPINNED -- DESIGN.md).
+ * .deringing: written down from memory of mozjpeg 4.1's jcdctmgr.c, PARITY UNPINNED -- DESIGN.md).
+ *
+ * Provenance of the trellis routine: quantize_trellis_row below is NOT an independent restatement of a published
+ * algorithm.  It follows mozjpeg's quantize_trellis (jcdctmgr.c, BSD-3-Clause / IJG licence) identifier for identifier
+ * (accumulated_zero_dist, accumulated_cost, run_start, dc_cost_backtrack, lambda_table, the candidate loops and the float
+ * evaluation order), because the product has to reproduce that routine's choices bit for bit and its behaviour is defined
+ * by nothing but its source.  mozjpeg is not under /root/reference; this file is test infrastructure only and nothing of it
+ * is compiled into, linked with or executed by the product (caesium-clt_amd/csrc/k_trellis.hip is a different programme: one
+ * wave per block, predecessor sets in registers -- DESIGN.md 4.6).
  */
 #include "jpeg_oracle.h"
 #include <math.h>

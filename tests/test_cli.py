@@ -485,6 +485,24 @@ def test_tree_in_windows_equals_tree_in_one_piece(tree, tmp_path):
     assert runs[0] == runs[1] == runs[2] and len(runs[0][0]) >= 3 and len(runs[0][1]) >= 3
 
 
+def test_read_ahead_stops_when_an_output_is_a_later_input(tmp_path):
+    """the window read-ahead must not read a later window's input while an earlier window is still writing that very file
+    (--suffix / --format into the input tree).  a.jpg -> a_z.jpg, and a_z.jpg is itself an input of the next window: the sequential reading is
+    a_z_z.jpg = compress(compress(a.jpg)); a reader running ahead would have compressed the old a_z.jpg."""
+    d = tmp_path / "ra"
+    d.mkdir()
+    a, stale = synth_jpeg(61, 96, 64, texture=30), synth_jpeg(62, 80, 48, texture=5)
+    (d / "a.jpg").write_bytes(a)
+    (d / "a_z.jpg").write_bytes(stale)
+    env = dict(os.environ, CSH_CLI_WINDOW="1")
+    r = subprocess.run([EMUL_CLI, "-q", "80", "--suffix", "_z", "--same-folder-as-input", "-O", "all", "--json", str(d / "a.jpg"), str(d / "a_z.jpg")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout)
+    assert [os.path.basename(f["output_path"]) for f in j["files"]] == ["a_z.jpg", "a_z_z.jpg"]
+    once = oracle_lossy(a)
+    assert (d / "a_z.jpg").read_bytes() == once and (d / "a_z_z.jpg").read_bytes() == oracle_lossy(once)
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
