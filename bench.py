@@ -41,7 +41,7 @@ def algorithmic_bytes(kernel, t, n):
     c = coef - y
     planes = c // 2                # u8 chroma planes (1 B/sample vs 2 B/coefficient)
     table = {
-        "k_decode_seq": t.in_bytes + coef,
+        "k_decode_prog+seq": t.in_bytes + coef, "k_refine_chains": t.in_bytes + coef,
         "k_dec_spec": t.in_bytes, "k_dec_relax0": t.in_bytes,
         "k_dec_write": t.in_bytes + coef,           # stream in, coefficient planes out (SURVEY 8d phase D)
         # phase E reads the planes ONCE (k_tokens: every AC scan of a component from one load of its blocks -- the scan search's 28 / 33
@@ -477,6 +477,9 @@ def main():
         other = None
         if extras:
             other = other_configs(api, pkg, blobs, local)
+        prog_inputs = None
+        if extras:
+            prog_inputs = progressive_inputs(api, pkg, local)
         if extras and args.boundary_files > 0:
             # the boundary itself: cs_batch_compress, host buffers in -> host buffers out (marker parse, pinned upload, kernels, download);
             # PCIe and the host side are inside this number and never inside `value`
@@ -508,7 +511,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "phases": phases,
             "kernel_ms": {names[i]: round(kms[i], 4) for i in range(len(names)) if names[i]},
             "scalar_profile": scalar, "plain_profile": plain, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow,
-            "boundary": boundary, "cli_end_to_end": cli, "other_configs": other,
+            "progressive_inputs": prog_inputs, "boundary": boundary, "cli_end_to_end": cli, "other_configs": other,
             "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
             "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},
         }
@@ -600,6 +603,33 @@ def cli_end_to_end(blobs, n):
         return {"error": str(e)[:200]}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def progressive_inputs(api, pkg, local, files=512):
+    """progressive JPEG inputs (caesium's own outputs are progressive): device time of the decode phase of 512 x 1080p files -- libjpeg's stock
+    script (Pillow progressive=True: four AC refinement scans) and this library's own -q 80 output (mozjpeg's script).  DC first / AC first scans go through
+    the self-synchronising decoder; AC refinement scans are parsed one wave per scan and applied one lane per block (k_decode_refine.hip).  Every file
+    == the oracle's lossless transcode on a spot check."""
+    try:
+        from _util import oracle_lossless
+        from gen_synth import synth_jpeg
+        names = api.kernel_names()
+        stock = [synth_jpeg(i, progressive=True) for i in range(8)]
+        own = api.batch_compress([synth_jpeg(i) for i in range(8)], pkg.default_parameters(jpeg_quality=80), device=local)
+        rec = {"files": files, "note": "lossless transcode (decode + re-encode), inputs resident in HBM; decode_ms = the kernel slots of phase D"}
+        for label, uniq in (("stock_script", stock), ("own_q80_output", own)):
+            b = api.batch([uniq[i % 8] for i in range(files)], pkg.default_parameters(jpeg_optimize=True), device=local)
+            b.run()
+            t = b.run()
+            outs = b.fetch()
+            nd = names.index("k_idct_plane")
+            rec[label] = {"decode_ms": round(sum(t.kernel_ms[:nd]), 2), "total_ms": round(t.total_ms, 2), "n_seq_decoded": int(t.n_seq_decoded), "n_refine_chains": int(t.n_refine_chains),
+                          "k_refine_chains_ms": round(t.kernel_ms[names.index("k_refine_chains")], 2), "in_bytes_per_file": int(t.in_bytes // files),
+                          "parity": bool(outs[0] == oracle_lossless(uniq[0]) and outs[7] == oracle_lossless(uniq[7]))}
+            b.close()
+        return rec
+    except Exception as e:   # a sub-record must not take the headline down
+        return {"error": repr(e)}
 
 
 def other_configs(api, pkg, blobs, local):

@@ -26,7 +26,7 @@ class CByteArray(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("phase_ms", C.c_float * NPHASES), ("kernel_ms", C.c_float * NKERNELS), ("in_bytes", C.c_uint64), ("out_bytes", C.c_uint64),
-                ("pixels", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32), ("n_seq_decoded", C.c_uint32), ("n_par_fallback", C.c_uint32), ("n_par_short", C.c_uint32), ("n_prog_decoded", C.c_uint32), ("n_search_extra", C.c_uint32)]
+                ("pixels", C.c_uint64), ("coef_bytes", C.c_uint64), ("n_images", C.c_uint32), ("n_failed", C.c_uint32), ("n_seq_decoded", C.c_uint32), ("n_par_fallback", C.c_uint32), ("n_par_short", C.c_uint32), ("n_prog_decoded", C.c_uint32), ("n_refine_chains", C.c_uint32), ("n_search_extra", C.c_uint32)]
 
 
 class PngTiming(C.Structure):

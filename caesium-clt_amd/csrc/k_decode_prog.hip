@@ -1,4 +1,5 @@
-// k_decode_prog.hip -- phase 0 for PROGRESSIVE inputs: one wave per chain of scans.
+// k_decode_prog.hip -- phase 0 for PROGRESSIVE inputs: one wave per chain of scans.  Since round 4 this is the path behind the switches (CSH_PROG_PAR=0 / 1)
+// and for files beyond the other paths' limits: DC first / AC first scans go through k_decode_par.hip, AC refinement chains through k_decode_refine.hip.
 //
 // A progressive scan cannot be cut into self-synchronising pieces the way a sequential scan can (k_decode_par.hip): in
 // a refinement scan the number of correction bits between two Huffman symbols depends on which coefficients of the
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(64) k_decode_prog(const uint8_t *clean, const 
     const int ch = blockIdx.x;
     if (ch >= nchains) return;
     const ProgChain pc = chains[ch];
-    if (need_seq[pc.image] != 4) return;
+    if (pc.refine || need_seq[pc.image] != 4) return;   // refinement chains: k_decode_refine.hip
     int cur_set = -1;
     for (int s = 0; s < pc.count; s++) {
         const DecScan &sc = scans[chain_scans[pc.first + s]];

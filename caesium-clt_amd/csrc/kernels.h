@@ -35,6 +35,10 @@ void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const void *huffs, int compact, uint64_t *state, uint32_t *nblk,
                            const uint64_t *list_in, const uint32_t *cnt_in, uint64_t *list_out, uint32_t *cnt_out, size_t nstate, uint32_t *claim, uint32_t epoch);
 // progressive inputs: one wave per chain of scans (k_decode_prog.hip); images with need_seq == 4
+// AC refinement chains of progressive inputs (k_decode_refine.hip): history masks, the serial parse (one wave per chain), the parallel apply
+void launch_refine_chains(hipStream_t st, const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,
+                          const int *chain_scans, int nchains, const RefineUnit *units, int nunits, uint32_t max_blocks, const ImgDesc *imgs, int16_t *coef,
+                          const uint32_t *need_seq, uint64_t *hist, uint32_t *posv, uint32_t *prog);
 void launch_decode_prog(hipStream_t st, const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,
                         const int *chain_scans, int nchains, const ImgDesc *imgs, int16_t *coef, uint32_t *need_seq);
 void launch_dec_mark_pending(hipStream_t st, const ParScan *ps, uint32_t total_sub, const uint64_t *list_in, const uint32_t *cnt_in, uint32_t *scan_pending);

@@ -99,6 +99,7 @@ struct csh_batch {
     std::vector<uint32_t> need_seq_init;
     std::vector<ProgChain> chains;        // progressive inputs (k_decode_prog.hip)
     std::vector<int> chain_scans;
+    uint32_t refine_hist = 0, refine_pos = 0, refine_max_blocks = 0;   // AC refinement chains (k_decode_refine.hip): history masks, block positions, largest chain
     uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
@@ -182,6 +183,10 @@ struct csh_batch {
     DevBuf<DecScan> d_dscans;
     DevBuf<ProgChain> d_chains;
     DevBuf<int> d_chain_scans;
+    DevBuf<uint64_t> d_refine_hist;
+    DevBuf<uint32_t> d_refine_pos, d_refine_prog;
+    DevBuf<RefineUnit> d_refine_units;
+    std::vector<RefineUnit> refine_units;
     DevBuf<DevHuffSet> d_hsets;
     DevBuf<ParHuffSet> d_phsets;
     DevBuf<ParHuffSet4> d_phsets4;
@@ -947,12 +952,30 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 ds.par_index = int(b->pscans.size());
                 b->pscans.push_back(ps);
             }
+            // CSH_PROG_PAR=1: the first scans in parallel, refinement chains in one wave each (k_decode_prog.hip) as before k_decode_refine.hip
+            const bool refine_split = par_first && !(pp && !strcmp(pp, "1"));
             for (int chain = 0; chain <= in.ncomp; chain++) {   // 0: DC scans; c + 1: AC scans of component c -- those the parallel decoder does not take
-                ProgChain pc; pc.image = img_index; pc.first = int(b->chain_scans.size()); pc.count = 0;
+                ProgChain pc;
+                memset(&pc, 0, sizeof pc);
+                pc.image = img_index; pc.first = int(b->chain_scans.size());
+                bool all_refine = chain != 0;
                 for (size_t s = 0; s < in.scans.size(); s++) {
                     const JScan &js = in.scans[s];
                     const bool mine = chain == 0 ? js.Ss == 0 : (js.Ss != 0 && js.comp_idx[0] == chain - 1);
-                    if (mine && b->pscans[size_t(b->dscans[im.first_scan + s].par_index)].kind == CSH_PS_UNSTUFF) { b->chain_scans.push_back(im.first_scan + int(s)); pc.count++; }
+                    if (mine && b->pscans[size_t(b->dscans[im.first_scan + s].par_index)].kind == CSH_PS_UNSTUFF) {
+                        b->chain_scans.push_back(im.first_scan + int(s)); pc.count++;
+                        if (js.Ah == 0 || js.data_len >= (1u << 27)) all_refine = false;
+                    }
+                }
+                if (pc.count && refine_split && all_refine) {   // parse + apply: room for a mask per block and a position per block and scan
+                    const JComp &jc = in.comp[chain - 1];
+                    const uint64_t nblocks = uint64_t(jc.real_bw) * uint64_t(jc.real_bh);
+                    if (nblocks && uint64_t(b->refine_pos) + nblocks * uint64_t(pc.count) < (1ull << 32)) {
+                        pc.refine = 1; pc.comp = chain - 1; pc.nblocks = uint32_t(nblocks);
+                        pc.hist_off = b->refine_hist; pc.pos_off = b->refine_pos;
+                        b->refine_hist += pc.nblocks; b->refine_pos += pc.nblocks * uint32_t(pc.count);
+                        b->refine_max_blocks = std::max(b->refine_max_blocks, pc.nblocks);
+                    }
                 }
                 if (pc.count) b->chains.push_back(pc);
             }
@@ -1207,6 +1230,20 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             if (b->use4) { dcs = std::max<int>(0, b->slot4[ps.huff_set][dcs]); acs = std::max<int>(0, b->slot4[ps.huff_set][acs]); }
             ps.sel |= uint64_t(dcs | (acs << 3)) << (6 * m);
         }
+    {   // the scans of the refinement chains as units of k_refine_parse, scan-major: a unit's predecessor has a smaller number
+        std::vector<int> last(b->chains.size(), -1);
+        for (int s = 0;; s++) {
+            bool any = false;
+            for (size_t c = 0; c < b->chains.size(); c++)
+                if (b->chains[c].refine && b->chains[c].count > s) {
+                    RefineUnit u; u.chain = int(c); u.s = s; u.prev = last[c];
+                    last[c] = int(b->refine_units.size());
+                    b->refine_units.push_back(u);
+                    any = true;
+                }
+            if (!any) break;
+        }
+    }
     b->ntiles = b->ntiles_in + b->ntiles_out;
     b->plane_bytes = plane_off;
     b->oplane_bytes = oplane_off;
@@ -1229,7 +1266,9 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             if (b->d_clean.alloc(b->bits_pool.size() + 64) || b->d_unstuff_cnt.alloc(nchunks + 1) || b->d_unstuff_off.alloc(nchunks + 2) ||
                 b->d_pstate.alloc(nst) || b->d_relax_list[0].alloc(nst) || b->d_relax_list[1].alloc(nst) || b->d_relax_cnt.alloc(512) || b->d_scan_pending.alloc(b->pscans.size() + 1) || b->d_cut_block.alloc(b->pscans.size() + 1) || b->d_claim.alloc(size_t(b->total_sub) + 1) || b->d_hyp.alloc((size_t(b->total_sub) + 1) * 10) ||
                 b->d_nblk.alloc(size_t(b->total_sub) + 1) || b->d_blk_off.alloc(size_t(b->total_sub) + 2) || b->d_need_seq.alloc(b->nimg + 1) ||
-                b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2))
+                b->d_dcdiff.alloc(size_t(b->dc_total) + 1) || b->d_dc_off.alloc(size_t(b->dc_total) + 2) ||
+                b->d_refine_hist.alloc(size_t(b->refine_hist) + 1) || b->d_refine_pos.alloc(size_t(b->refine_pos) + 1) || b->d_refine_units.upload(b->refine_units, st) ||
+                b->d_refine_prog.alloc(b->refine_units.size() + 1))
                 return CS_ERR_NO_DEVICE;
         }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
@@ -1327,18 +1366,18 @@ extern "C" void csh_batch_destroy(csh_batch *b) { delete b; }
 
 // kernel timing slots (csh_timing.kernel_ms); names via csh_kernel_name()
 static const char *const kKernelNames[CSH_NKERNELS] = {
-    "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_decode_seq",
+    "memset_coef", "unstuff", "k_dec_spec", "k_dec_relax0", "k_dec_relax1_4", "k_dec_write", "k_dc_scatter", "k_refine_chains", "k_decode_prog+seq",
     "k_idct_plane", "resize", "k_xform_direct", "k_resample+k_plane_fdct", "k_fix_dummy", "memset_enc", "trellis_stats", "k_trellis_ac", "k_trellis_dc",
     "k_nzlist", "k_tokens", "k_list_stats", "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack", "k_list_pack",
-    "k_ff_count", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", "", ""};
+    "k_ff_count", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", ""};
 // a WebP batch (csh_batch_create_webp) leaves the JPEG path behind the resize slot: its next three slots are these
 static const char *const kWebpTailNames[3] = {"k_webp_yuv", "k_webp_mb", "k_webp_stats+probs+code+assemble"};
 
 // the trellis slots (statistics scan = k_tokens without tokens + k_ac_runs + k_gen_tables; the two k_trellis kernels + k_fix_dummy) count
 // as phase 1: they are the quantiser; zero unless CSH_PROFILE=mozjpeg
-static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 2, 2, 3, 4, 4, 4, 5, 5, 6, 7, 6, 6, 6, 7, 7, 7, 7};
+static const int kKernelPhase[CSH_NKERNELS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2, 2, 2, 3, 4, 4, 4, 5, 5, 6, 7, 6, 6, 6, 7, 7, 7};
 extern "C" const char *csh_kernel_name(int i) { return (i >= 0 && i < CSH_NKERNELS) ? kKernelNames[i] : ""; }
-extern "C" const char *csh_kernel_name_webp(int i) { return (i >= 10 && i < 13) ? kWebpTailNames[i - 10] : csh_kernel_name(i); }
+extern "C" const char *csh_kernel_name_webp(int i) { return (i >= 11 && i < 14) ? kWebpTailNames[i - 11] : csh_kernel_name(i); }
 
 // the WebP tail of a run: RGB (resize branch) -> YUV 4:2:0 -> macroblocks -> tokens; files land in the batch's output pool at
 // fixed offsets (capacity per macroblock grows on overflow, like the JPEG pools)
@@ -1577,12 +1616,12 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
         launch_requant(st, b->d_imgs.p, b->d_pwork.p, int(b->pwork.size()), b->max_tiles, b->d_quants.p, b->d_dct_raw.p, b->ntiles_in, b->d_coef.p);
         launch_fix_dummy(st, b->d_imgs.p, nimg, b->max_dummy, b->d_coef.p);
-        slot = 13;   // kernel_ms slots of the decode + pixel phases: only the first carries time (k_requant + k_fix_dummy)
+        slot = 14;   // kernel_ms slots of the decode + pixel phases: only the first carries time (k_requant + k_fix_dummy)
         for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
     } else {
     if (from_pixels) {
         if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
-        slot = 8;   // the decode phase's kernel_ms slots stay empty
+        slot = 9;   // the decode phase's kernel_ms slots stay empty
         for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
     } else {
     // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
@@ -1643,6 +1682,9 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         launch_dc_refine(st, b->d_clean.p, b->d_pscans.p, nps, b->max_par_blocks, b->d_imgs.p, b->d_coef.p, b->d_need_seq.p);
         MARK();
     }
+    launch_refine_chains(st, b->d_clean.p, b->d_pscans.p, b->d_phsets.p, b->d_dscans.p, b->d_chains.p, b->d_chain_scans.p, int(b->chains.size()), b->d_refine_units.p,
+                         int(b->refine_units.size()), b->refine_max_blocks, b->d_imgs.p, b->d_coef.p, b->d_need_seq.p, b->d_refine_hist.p, b->d_refine_pos.p, b->d_refine_prog.p);
+    MARK();
     launch_decode_prog(st, b->d_clean.p, b->d_pscans.p, b->d_phsets.p, b->d_dscans.p, b->d_chains.p, b->d_chain_scans.p, int(b->chains.size()), b->d_imgs.p,
                        b->d_coef.p, b->d_need_seq.p);
     launch_decode_seq(st, b->d_bits.p, b->d_imgs.p, b->d_dscans.p, b->d_hsets.p, b->d_coef.p, nimg, b->d_need_seq.p);
@@ -1900,6 +1942,7 @@ static int batch_run(csh_batch *b, csh_timing *t, bool requant_only) {
                 fprintf(stderr, "\n");
             }
         }
+        for (const ProgChain &pc : b->chains) if (pc.refine && ns[size_t(pc.image)] == 4) t->n_refine_chains++;
         for (uint32_t v : ns) { if (v == 4) { t->n_prog_decoded++; continue; } if (v) t->n_seq_decoded++; if (v == 2 || v == 3) t->n_par_fallback++; if (v == 3) t->n_par_short++; }
         t->n_images = uint32_t(b->nimg);
         t->n_search_extra = b->search ? b->n_gated_runs : 0u;

@@ -15,6 +15,8 @@ __device__ __forceinline__ static uint32_t uni(uint32_t x) { return x; }
 #define CSP_WAVE_SYNC() ((void)0)
 #define CSP_MEM_FENCE() ((void)0)
 template <class T> __device__ __forceinline__ static T coherent_load(const T *p) { return *p; }
+template <class T> __device__ __forceinline__ static void coherent_store(T *p, T v) { *p = v; }
+#define CSP_ACQUIRE_FENCE() ((void)0)
 #else
 #define LFOR(j) for (int j = int(threadIdx.x & 63u), once_ = 1; once_; once_ = 0)
 template <class T> struct LV { T v; __device__ T &operator[](int) { return v; } __device__ const T &operator[](int) const { return v; } };
@@ -25,6 +27,9 @@ __device__ __forceinline__ static uint32_t uni(uint32_t x) { return uint32_t(__b
 // this wave's global stores are complete and visible to its own later (cache-bypassing) loads
 #define CSP_MEM_FENCE() __threadfence()
 template <class T> __device__ __forceinline__ static T coherent_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ static void coherent_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// later loads of this wave see what another wave published before the value just read with coherent_load
+#define CSP_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #endif
 
 template <class F>

@@ -88,7 +88,10 @@ struct DecScan {
 
 // progressive input: a chain = the scans of one image that must run in file order because they touch the same
 // coefficients -- all DC scans, or all AC scans of one component.  Chains of an image are independent of each other.
-struct ProgChain { int image, first, count; };   // chain_scans[first .. first+count) = DecScan indices
+// refine != 0: every scan of the chain is an AC refinement scan of component `comp` (k_decode_refine.hip: parse + apply); its nblocks history masks
+// start at hist_off, its count * nblocks block positions at pos_off.  Otherwise the chain runs in one wave of k_decode_prog.hip.
+struct RefineUnit { int chain, s, prev; };   // one scan of a refinement chain = one wave of k_refine_parse; prev = the unit of the chain's scan s - 1, or -1
+struct ProgChain { int image, first, count, refine, comp; uint32_t nblocks, hist_off, pos_off; };   // chain_scans[first .. first+count) = DecScan indices
 
 struct ImgDesc {
     int width, height, ncomp;

@@ -11,6 +11,8 @@ using csp::lballot;
 using csp::lanes_below;
 using csp::lscan;
 using csp::uni;
+using csp::coherent_load;
+using csp::coherent_store;
 
 // lane l gets the value of lane l - 1; lane 0 gets `carry`
 __device__ __forceinline__ static LV<uint32_t> lprev(const LV<uint32_t> &x, uint32_t carry) {
@@ -29,6 +31,21 @@ __device__ __forceinline__ static uint32_t llast(const LV<uint32_t> &x) {
     return x.v[63];
 #else
     return uint32_t(__builtin_amdgcn_readlane(int(x.v), 63));
+#endif
+}
+// the value of lane `lane` (wave-uniform), in every lane;  lset: the wave-uniform `val` into lane `lane` of x
+__device__ __forceinline__ static uint32_t lget(const LV<uint32_t> &x, uint32_t lane) {
+#ifdef CSH_EMUL
+    return x.v[lane & 63u];
+#else
+    return uint32_t(__builtin_amdgcn_readlane(int(x.v), int(lane)));
+#endif
+}
+__device__ __forceinline__ static void lset(LV<uint32_t> &x, uint32_t lane, uint32_t val) {
+#ifdef CSH_EMUL
+    x.v[lane & 63u] = val;
+#else
+    x.v = (threadIdx.x & 63u) == lane ? val : x.v;   // v_cmp + v_cndmask (v_writelane wants its lane select in m0: inline assembly for one instruction less)
 #endif
 }
 // sum over the lanes, in every lane (all 64 lanes active)

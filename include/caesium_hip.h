@@ -131,6 +131,7 @@ typedef struct {
     uint32_t n_par_fallback;      /* of those, images the parallel decoder started and gave up on */
     uint32_t n_par_short;         /* of those, because the scan produced fewer blocks than the frame needs (truncated data) */
     uint32_t n_prog_decoded;      /* progressive inputs decoded by the wave-per-chain kernel (not counted in n_seq_decoded) */
+    uint32_t n_refine_chains;     /* chains of AC refinement scans (progressive inputs) taken by the parse + apply kernels (k_decode_refine.hip) */
     uint32_t n_search_extra;      /* conditional stages of the scan search this run needed (0..3: luma at Al 3, the fourth and the fifth frequency split) */
 } csh_timing;
 

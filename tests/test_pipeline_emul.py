@@ -80,6 +80,45 @@ def test_emul_parallel_decoder_is_the_path_taken(api):
         assert out == oracle_lossy(src)
 
 
+def deep_refinement_file(seed=5, w=203, h=155, ss=2, texture=40):
+    """a progressive file whose script refines deeper and in more pieces than any encoder's stock script: three refinement passes over luma, chroma
+    bands refined apart from each other and in another order than they were first coded"""
+    from oracle import oracle as O
+    ci = O.decode(synth_jpeg(seed, w, h, subsampling=ss, texture=texture))
+    script = [((0, 1, 2), 0, 0, 0, 1),
+              ((0,), 1, 63, 0, 3), ((1,), 1, 5, 0, 1), ((1,), 6, 63, 0, 1), ((2,), 1, 63, 0, 2),
+              ((0,), 1, 63, 3, 2), ((2,), 21, 63, 2, 1), ((0,), 1, 63, 2, 1), ((2,), 1, 20, 2, 1), ((0, 1, 2), 0, 0, 1, 0),
+              ((1,), 6, 63, 1, 0), ((0,), 1, 63, 1, 0), ((1,), 1, 5, 1, 0), ((2,), 1, 63, 1, 0)]
+    return ci.encode(O.params(progressive=1, marker_style=0), script=script)
+
+
+def test_emul_refinement_scans_parse_and_apply(api, monkeypatch):
+    """AC refinement scans: the serial parse finds every block's bit position, the apply is one lane per block (k_decode_refine.hip).  Deep scripts, EOB
+    runs across many blocks (a flat picture), long correction-bit stretches, streams cut inside refinement scans; the same bytes from the one-wave-per-
+    chain kernel (CSH_PROG_PAR=1) and from everything on chains (CSH_PROG_PAR=0)"""
+    from PIL import Image
+    srcs = [deep_refinement_file(), deep_refinement_file(7, 64, 48, 0, 10), deep_refinement_file(8, 129, 67, 1, 80), crafted_corrbit_stream(),
+            synth_jpeg(2, 520, 390, progressive=True, texture=3)]
+    b = io.BytesIO(); Image.fromarray(np.full((256, 320, 3), 99, np.uint8)).save(b, format="JPEG", quality=90, progressive=True); srcs.append(b.getvalue())
+    deep = srcs[0]
+    first_refine = [i for i in range(len(deep) - 1) if deep[i] == 0xFF and deep[i + 1] == 0xDA][5]
+    for frac in (0.05, 0.4, 0.8, 0.99):
+        n = first_refine + int((len(deep) - first_refine) * frac)
+        srcs += [deep[:n] + b"\xff\xd9", deep[:n + 1]]
+    want = [oracle_lossless(s) for s in srcs]
+    for mode in (None, "1", "0"):
+        if mode is None: monkeypatch.delenv("CSH_PROG_PAR", raising=False)
+        else: monkeypatch.setenv("CSH_PROG_PAR", mode)
+        bt = api.batch(srcs, params(jpeg_optimize=True))
+        t = bt.run()
+        assert t.n_seq_decoded == 0 and t.n_par_fallback == 0
+        assert (t.n_refine_chains >= 18) if mode is None else (t.n_refine_chains == 0), mode   # files cut short lose chains
+        for i, (w_, out) in enumerate(zip(want, bt.fetch())):
+            assert out == w_, (mode, i)
+    monkeypatch.delenv("CSH_PROG_PAR", raising=False)
+    assert api.batch_compress(srcs[:4], params()) == [oracle_lossy(s) for s in srcs[:4]]
+
+
 def test_emul_non_interleaved_sequential_scans(api):
     """a sequential-mode file whose components come in three separate scans (legal, rare): each scan is its own segment of the
     parallel decoder, the block grid of a non-interleaved scan is the component's real one (no MCU padding blocks)"""
@@ -218,7 +257,7 @@ def test_emul_relaxation_is_order_independent(api):
     sweep; running every launch in DESCENDING order forces the work-list rounds a real GPU needs (and every atomics-based
     kernel to cope with another arrival order).  Bytes must not change."""
     import ctypes
-    blobs = [synth_jpeg(1, 640, 360, texture=25), synth_jpeg(4, 333, 222, subsampling=0, texture=50), synth_jpeg(2, 104, 72, progressive=True)]
+    blobs = [synth_jpeg(1, 640, 360, texture=25), synth_jpeg(4, 333, 222, subsampling=0, texture=50), synth_jpeg(2, 104, 72, progressive=True), deep_refinement_file()]
     api.L.csh_emul_set_reverse.argtypes = [ctypes.c_int]
     api.L.csh_emul_set_reverse(1)
     try:
@@ -227,7 +266,7 @@ def test_emul_relaxation_is_order_independent(api):
         outs = b.fetch()
     finally:
         api.L.csh_emul_set_reverse(0)
-    assert t.n_par_fallback == 0 and t.n_seq_decoded == 0 and t.n_prog_decoded == 1
+    assert t.n_par_fallback == 0 and t.n_seq_decoded == 0 and t.n_prog_decoded == 2 and t.n_refine_chains == 6   # the refinement scans' waves take tickets: a scan's predecessor has started
     for src, out in zip(blobs, outs):
         assert out == oracle_lossy(src)
 

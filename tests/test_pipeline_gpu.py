@@ -102,6 +102,10 @@ def test_rerun_after_a_run_that_took_the_conditional_stages(api):
     E.test_emul_rerun_after_a_run_that_took_the_conditional_stages(api)
 
 
+def test_refinement_scans_parse_and_apply(api, monkeypatch):
+    E.test_emul_refinement_scans_parse_and_apply(api, monkeypatch)
+
+
 def test_non_interleaved_sequential_scans(api):
     E.test_emul_non_interleaved_sequential_scans(api)
 

@@ -1,5 +1,6 @@
 """Device time of the decode phase by input class: baseline, progressive (Pillow's stock script; and this library's own -q 80 output -- the mozjpeg
-script with EOB runs, what caesium itself writes), restart intervals.  CSH_PROG_PAR=0 puts every progressive scan back on the chains.
+script with EOB runs, what caesium itself writes), restart intervals.  CSH_PROG_PAR=0 puts every progressive scan back on the chains, =1 only the
+refinement scans (one wave per chain, as before k_decode_refine.hip).
 usage: python tools/prog_bench.py [files=512]"""
 import os
 import sys
@@ -21,7 +22,7 @@ for name, uniq in classes:
         b = api.batch(blobs, pkg.default_parameters(jpeg_quality=80, jpeg_optimize=lossless), device=0)
         b.run()
         t = [b.run() for _ in range(3)][-1]
-        dec = sum(t.kernel_ms[i] for i in range(8))
+        dec = sum(t.kernel_ms[i] for i in range(9))
         print(f"{name:32s} files={n} lossless decode_ms={dec:.2f} total_ms={t.total_ms:.2f} seq={t.n_seq_decoded} prog={t.n_prog_decoded}",
-              {k: round(v, 2) for k, v in zip(names[:8], t.kernel_ms[:8]) if v > 0.5}, flush=True)
+              {k: round(v, 2) for k, v in zip(names[:9], t.kernel_ms[:9]) if v > 0.5}, flush=True)
         b.close()
