@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048, help="1080p files per rank per step (2048 x ~21 MB of device pools = 44 GB of the 288 GB)")
     ap.add_argument("--unique", type=int, default=1000, help="distinct synthetic images per rank (cycled to --batch): SURVEY 8d's 1 000 unique images; generated on all host cores")
     ap.add_argument("--cpu-images", type=int, default=96, help="files timed through the single-thread CPU oracle in the headline's profile (rank 0, N=1; ~0.15 s each: a 10-20 s sample); the all-core and Pillow lines scale from it")
-    ap.add_argument("--boundary-files", type=int, default=512, help="files of the cs_batch_compress (host buffers in, host buffers out) measurement; 0 = skip")
+    ap.add_argument("--boundary-files", type=int, default=2048, help="files of the cs_batch_compress (host buffers in, host buffers out) measurement; 0 = skip")
     ap.add_argument("--cli-files", type=int, default=2048, help="files of the caesiumclt end-to-end measurement (files in -> files out); 0 = skip")
     ap.add_argument("--no-extras", action="store_true", help="skip the boundary / CPU / other-config records (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes behind roofline.traffic")

@@ -45,7 +45,7 @@ def library_path():
 
 
 EXPORTS = ["cs_default_parameters", "cs_compress_in_memory", "cs_compress_to_size_in_memory", "cs_convert_in_memory",
-           "cs_batch_compress", "cs_batch_extent", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_kernel_name_webp", "csh_release_cached_memory", "csh_batch_create",
+           "cs_batch_compress", "cs_batch_extent", "cs_free_bytes", "cs_free_result", "csh_device_count", "csh_last_error", "csh_kernel_name", "csh_kernel_name_webp", "csh_release_cached_memory", "csh_warmup", "csh_batch_create",
            "csh_batch_run", "csh_batch_fetch", "csh_batch_destroy", "csh_batch_retain_dct", "csh_batch_set_quality", "csh_batch_rerun_encode", "cs_batch_compress_to_size", "csh_batch_geometry", "csh_batch_read_coefs",
            "csp_kernel_name", "csp_batch_create", "csp_batch_create_webp", "csp_batch_create_pixels", "csh_batch_create_pixels", "csh_batch_pixels", "csh_batch_create_from_pixels", "csp_png_to_jpeg", "csp_png_to_lossless_webp", "csp_batch_run", "csp_batch_fetch", "csp_batch_destroy", "csp_batch_geometry", "csp_batch_read_rows", "csp_batch_read_stream",
            "csp_batch_trials", "csp_batch_read_scores", "csp_batch_chunk_bits", "csh_batch_create_webp", "cs_batch_convert",

@@ -530,6 +530,10 @@ int run(const Options &o) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t_start = now();
+    // the runtime and the device context start while the tree is scanned and read (a cold process pays ~0.15 s for them in front of its first kernel)
+    std::vector<std::thread> warm;
+    if (!o.dry_run) for (int d = 0; d < std::max(1, o.gpus); d++) warm.emplace_back([d] { csh_warmup(d); });
+    struct JoinWarm { std::vector<std::thread> &t; ~JoinWarm() { for (auto &x : t) if (x.joinable()) x.join(); } } join_warm{warm};
     std::optional<fs::path> base;
     std::vector<fs::path> files;
     scan_files(o.files, o.recursive, o.check_extension_only, base, files);
@@ -595,6 +599,47 @@ int run(const Options &o) {
     });
     us_read += (long long)(ms(t_win, now()) * 1000.0);
     };
+    // ---- stage 3 (host): the rest of perform_compression for one file -- savings and overwrite policy, the write.  It runs per device batch, as soon as
+    // the batch comes back, on the batch's own worker (a few threads): the writes of one batch overlap the kernels of the next ones
+    std::atomic<long long> us_write{0};
+    auto finish_job = [&](size_t i) {
+        Job &j = jobs[i];
+        Result &r = results[i];
+        if (!j.engine) return;
+        if (!j.ok) { r.message = j.engine_msg; return; }
+        const uint64_t orig = r.original_size, outsz = j.result.length;
+        struct Release { CByteArray *b; ~Release() { cs_free_bytes(b); } } release{&j.result};
+        if (o.min_savings && orig != 0) {
+            uint64_t saved = orig > outsz ? orig - outsz : 0;
+            char b[160];
+            if (o.min_savings->percent) {
+                double sp = (double(saved) / double(orig)) * 100.0;
+                if (sp < o.min_savings->pct) { snprintf(b, sizeof b, "Insufficient savings: %.2f%% < %.2f%%, skipped", sp, o.min_savings->pct); r.status = Status::Skipped; r.compressed_size = orig; r.message = b; return; }
+            } else if (saved < o.min_savings->bytes) {
+                r.status = Status::Skipped; r.compressed_size = orig;
+                r.message = "Insufficient savings: " + format_bytesize(saved) + " < " + format_bytesize(o.min_savings->bytes) + ", skipped";
+                return;
+            }
+        }
+        std::error_code ec;
+        if (o.overwrite == Overwrite::Bigger && fs::exists(j.output, ec)) {
+            uint64_t existing = fs::file_size(j.output, ec);
+            if (ec) r.message = "Error reading existing file metadata";
+            else if (existing <= outsz) { r.status = Status::Skipped; r.compressed_size = orig; r.message = "File already exists, skipped due overwrite policy"; return; }
+        }
+        FILE *f = fopen(j.output.c_str(), "wb");
+        if (!f) { r.message = "Error creating output file"; return; }
+        bool wrote = fwrite(j.result.data, 1, j.result.length, f) == j.result.length;
+        if (wrote && o.keep_dates) {
+            fflush(f);
+            struct timespec ts[2] = {j.st.st_atim, j.st.st_mtim};
+            if (futimens(fileno(f), ts) != 0) { fclose(f); r.message = "Error preserving file times"; return; }
+        }
+        fclose(f);
+        if (!wrote) { r.message = "Error writing output file"; return; }
+        r.status = Status::Success;
+        r.compressed_size = outsz;
+    };
     // Ordering: the read-ahead stats, checks the overwrite policy of and reads window N + 1 while window N is written.  That is only sound when no output
     // of one file is the input (or the overwrite-policy target) of another: `--format` or `--suffix` writing into the input tree can make a.png -> a.jpg land
     // on the input a.jpg.  (The reference's par_iter has the same race between its threads; a sequential reader has not.)  With more than one window,
@@ -641,9 +686,9 @@ int run(const Options &o) {
             }
         }
         int ndev = std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
-        // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being
-        // parsed and uploaded (separate streams; the boundary call is thread-safe)
-        const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 2;
+        // three host threads per device, each with its own batches: while one batch is in its kernels another is being parsed and
+        // uploaded and a third fetched (separate streams; the boundary call is thread-safe)
+        const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 3;
         const size_t nworkers = size_t(ndev) * per_dev;
         parallel_for(nworkers, nworkers, [&](size_t worker) {
             const size_t dev = worker % size_t(ndev);
@@ -684,57 +729,20 @@ int run(const Options &o) {
                     }
                     cs_free_result(&res[k]);
                 }
+                const auto t_w = now();
+                parallel_for(idx.size(), std::min<size_t>(threads, 8), [&](size_t k) { finish_job(idx[k]); });
+                us_write += (long long)(ms(t_w, now()) * 1000.0);
             }
         });
     }
 
     const auto t_engine = now();
-    // ---- stage 3 (host, parallel): the rest of perform_compression
-    parallel_for(w1 - w0, threads, [&](size_t k) {
-        const size_t i = w0 + k;
-        Job &j = jobs[i];
-        Result &r = results[i];
-        if (!j.engine) return;
-        if (!j.ok) { r.message = j.engine_msg; return; }
-        const uint64_t orig = r.original_size, outsz = j.result.length;
-        struct Release { CByteArray *b; ~Release() { cs_free_bytes(b); } } release{&j.result};
-        if (o.min_savings && orig != 0) {
-            uint64_t saved = orig > outsz ? orig - outsz : 0;
-            char b[160];
-            if (o.min_savings->percent) {
-                double sp = (double(saved) / double(orig)) * 100.0;
-                if (sp < o.min_savings->pct) { snprintf(b, sizeof b, "Insufficient savings: %.2f%% < %.2f%%, skipped", sp, o.min_savings->pct); r.status = Status::Skipped; r.compressed_size = orig; r.message = b; return; }
-            } else if (saved < o.min_savings->bytes) {
-                r.status = Status::Skipped; r.compressed_size = orig;
-                r.message = "Insufficient savings: " + format_bytesize(saved) + " < " + format_bytesize(o.min_savings->bytes) + ", skipped";
-                return;
-            }
-        }
-        std::error_code ec;
-        if (o.overwrite == Overwrite::Bigger && fs::exists(j.output, ec)) {
-            uint64_t existing = fs::file_size(j.output, ec);
-            if (ec) r.message = "Error reading existing file metadata";
-            else if (existing <= outsz) { r.status = Status::Skipped; r.compressed_size = orig; r.message = "File already exists, skipped due overwrite policy"; return; }
-        }
-        FILE *f = fopen(j.output.c_str(), "wb");
-        if (!f) { r.message = "Error creating output file"; return; }
-        bool wrote = fwrite(j.result.data, 1, j.result.length, f) == j.result.length;
-        if (wrote && o.keep_dates) {
-            fflush(f);
-            struct timespec ts[2] = {j.st.st_atim, j.st.st_mtim};
-            if (futimens(fileno(f), ts) != 0) { fclose(f); r.message = "Error preserving file times"; return; }
-        }
-        fclose(f);
-        if (!wrote) { r.message = "Error writing output file"; return; }
-        r.status = Status::Success;
-        r.compressed_size = outsz;
-    });
 
     for (size_t i = w0; i < w1; i++) std::vector<uint8_t>().swap(jobs[i].data);   // the window's inputs (its outputs went in stage 3)
-    ms_engine += ms(t_read, t_engine); ms_write += ms(t_engine, now());
+    ms_engine += ms(t_read, t_engine); ms_write = double(us_write.load()) / 1000.0;
     }
     ms_read = double(us_read.load()) / 1000.0;
-    if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms, engine %.0f ms, policy+write %.0f ms\n", files.size(), ms(t_start, t_scan),
+    if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms, engine+write %.0f ms (of which policy+write, summed over the batch workers: %.0f ms)\n", files.size(), ms(t_start, t_scan),
                        ms_read, ms_engine, ms_write);
     if (o.json) printf("%s\n", build_json(results, o.dry_run, nullptr).c_str());
     else fputs(build_recap(results, verbose, isatty(1)).c_str(), stdout);

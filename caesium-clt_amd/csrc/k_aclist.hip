@@ -444,6 +444,36 @@ void launch_nzlist(hipStream_t st, const EncCtx &c) {
 }
 void launch_list_stats(hipStream_t st, const EncCtx &c) { if (c.nlist_slots) CSH_LAUNCH(k_list_stats, dim3((c.nlist_slots + 3) / 4), dim3(4 * CSP_WAVE_THREADS), st, c); }
 void launch_list_pack(hipStream_t st, const EncCtx &c) { if (c.nlist_slots) CSH_LAUNCH(k_list_pack, dim3((c.nlist_slots + 3) / 4), dim3(4 * CSP_WAVE_THREADS), st, c); }
+// ---- the slots of the work items: one workgroup per work item, one lane per 256-unit chunk.  Under the scan search a 1080p image has ~3.9 k slots in 58 work
+// items: built on the host they were 64 MB of records per 256 files to write and to upload in front of the first kernel (the boundary call paid ~15 ms of
+// every 50 for them); the host only counts them now (pipeline.cpp add_works).  Slots between the stages belong to no work item and stay zero.
+__global__ void __launch_bounds__(64) k_make_slots(const ScanWork *works, uint32_t nworks, const EncScan *script, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
+                                                   uint32_t *tok_slots) {
+    const uint32_t wi = blockIdx.x;
+    if (wi >= nworks) return;
+    const ScanWork &w = works[wi];
+    const EncScan &e = script[w.scan];
+    const uint32_t nch = (w.nunits + 255u) / 256u;
+    const bool prog_ac = e.Ss > 0 && !e.sequential, listed = w.list != 0xFFFFFFFFu;
+    for (uint32_t j = threadIdx.x; j < nch; j += blockDim.x) {
+        SlotRec r;
+        r.work = wi; r.j = j; r.nch = nch; r.first_chunk = w.first_chunk; r.unit0 = w.unit_base + 256u * j;
+        r.nun = w.nunits - 256u * j < 256u ? w.nunits - 256u * j : 256u; r.table_base = w.table_base; r.ntables = uint16_t(e.ntables);
+        r.flags = uint16_t((prog_ac ? 1 : 0) | (prog_ac && e.Ah ? 2 : 0) | (listed ? 4 : 0));
+        r.hist_row = w.hist_row0 + j * uint32_t(e.ntables);
+        r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
+        r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        slots[w.first_chunk + j] = r;
+        slot_work[w.first_chunk + j] = wi;
+        (listed ? list_slots : tok_slots)[w.ls_base + j] = w.first_chunk + j;
+    }
+}
+void launch_make_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const EncScan *script, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
+                       uint32_t *tok_slots) {
+    if (!nworks) return;
+    CSH_LAUNCH(k_make_slots, dim3(nworks), dim3(64), st, works, nworks, script, slots, slot_work, list_slots, tok_slots);
+}
+
 void launch_reset_works(hipStream_t st, ScanWork *work, int nwork) { if (nwork) CSH_LAUNCH(k_reset_works, dim3((nwork + 255) / 256), dim3(256), st, work, nwork); }
 
 }  // namespace csh

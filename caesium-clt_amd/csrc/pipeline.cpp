@@ -14,6 +14,7 @@
 #include <mutex>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -103,8 +104,9 @@ struct csh_batch {
     uint32_t total_sub = 0, max_sub = 0, max_par_blocks = 0, dc_total = 0;
     std::vector<EncScan> script;
     std::vector<ScanWork> swork;
-    std::vector<uint32_t> slot_work;      // per (work item, 256-unit chunk) slot: its work item
-    std::vector<SlotRec> slots;
+    // per (work item, 256-unit chunk) slot: its work item, its SlotRec, its place in the list-coded / token-coded slot lists -- ~3.9 k slots per 1080p image
+    // under the scan search (64 MB of records per 256 files): the host only counts them, k_make_slots writes them on the device from the work items
+    uint32_t nslots = 0, nlist_slots = 0, ntok_slots = 0;
     std::vector<TokPlan> plans;
     std::vector<int> plan_comp, plan_image;
     std::vector<EChunk> echunks;          // the token kernel's workgroups
@@ -123,7 +125,6 @@ struct csh_batch {
     std::vector<uint32_t> nz_est, nz_worst; // per list: estimated / largest possible number of entries
     uint32_t nz_nrec = 0;                 // per-(list, chunk) records
     uint64_t nz_cap = 0;                  // pool capacity: the sum of the regions
-    std::vector<uint32_t> list_slots, tok_slots;   // per stage, contiguous: its slots coded from lists / packed from tokens
     // mozjpeg's scan search (the default profile; CSH_PROFILE=plain keeps the stock script): the candidate scans are coded in stages
     // -- work items, slots, token chunks and tables of one stage behind those of the stage before -- and the host replays
     // jcmaster.c select_scans on their sizes in between.  mozjpeg codes its candidates one after the other and skips ahead as soon as
@@ -134,13 +135,13 @@ struct csh_batch {
     enum { ST_1 = 0, ST_1B = 1, ST_2 = 2, ST_2B = 3, ST_2C = 4, ST_N = 5 };
     struct Stage { uint32_t work0 = 0, nwork = 0, slot0 = 0, nslots = 0, ech0 = 0, nech = 0, table0 = 0, ntables = 0, plan0 = 0, nplans = 0, nzc0 = 0, nnzc = 0, ls0 = 0, nls = 0, ts0 = 0, nts = 0; } stage[ST_N];
     void stage_begin(Stage &sg) {
-        sg.work0 = uint32_t(swork.size()); sg.slot0 = uint32_t(slot_work.size()); sg.ech0 = uint32_t(echunks.size()); sg.table0 = uint32_t(ntables); sg.plan0 = uint32_t(plans.size());
-        sg.nzc0 = uint32_t(nzchunks.size()); sg.ls0 = uint32_t(list_slots.size()); sg.ts0 = uint32_t(tok_slots.size());
+        sg.work0 = uint32_t(swork.size()); sg.slot0 = nslots; sg.ech0 = uint32_t(echunks.size()); sg.table0 = uint32_t(ntables); sg.plan0 = uint32_t(plans.size());
+        sg.nzc0 = uint32_t(nzchunks.size()); sg.ls0 = nlist_slots; sg.ts0 = ntok_slots;
     }
     void stage_end(Stage &sg) {
-        sg.nwork = uint32_t(swork.size()) - sg.work0; sg.nslots = uint32_t(slot_work.size()) - sg.slot0; sg.nech = uint32_t(echunks.size()) - sg.ech0;
+        sg.nwork = uint32_t(swork.size()) - sg.work0; sg.nslots = nslots - sg.slot0; sg.nech = uint32_t(echunks.size()) - sg.ech0;
         sg.ntables = uint32_t(ntables) - sg.table0; sg.nplans = uint32_t(plans.size()) - sg.plan0;
-        sg.nnzc = uint32_t(nzchunks.size()) - sg.nzc0; sg.nls = uint32_t(list_slots.size()) - sg.ls0; sg.nts = uint32_t(tok_slots.size()) - sg.ts0;
+        sg.nnzc = uint32_t(nzchunks.size()) - sg.nzc0; sg.nls = nlist_slots - sg.ls0; sg.nts = ntok_slots - sg.ts0;
     }
     struct SearchImg {
         int cand_work[64]; int ncand;       // candidate number -> work item (-1: not coded by itself -- see search_work)
@@ -452,6 +453,18 @@ extern "C" void csh_release_cached_memory(void) {
     for (int d = 0; d < n && d < 64; d++) device_cache(d).trim(0);
     pinned_cache().trim(0);
 }
+// A process that knows it will use a device says so early, from a thread of its own: runtime start-up, the device's context and the library's code
+// objects (the first launch loads them) take ~0.15 s that can pass while the caller is still reading its files (the CLI does: cli.cpp)
+__global__ void k_warmup(uint32_t *p) { if (p && threadIdx.x == 1024) *p = 0; }
+extern "C" void csh_warmup(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || hipSetDevice(device) != hipSuccess) return;
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
+    CSH_LAUNCH(k_warmup, dim3(1), dim3(1), st, static_cast<uint32_t *>(nullptr));
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+}
 extern "C" int csh_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -488,6 +501,17 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     if (csh_device_count() <= device) { csh_set_error("no HIP device %d available (libcaesium_hip has no CPU path)", device); return CS_ERR_NO_DEVICE; }
     if (hipSetDevice(device) != hipSuccess) { csh_set_error("hipSetDevice(%d) failed", device); return CS_ERR_NO_DEVICE; }
     if (count > 6000) { csh_set_error("csh_batch_create: at most 6000 files per device batch (cs_batch_compress splits for you)"); return CS_ERR_POOL_OVERFLOW; }
+    // CSH_TRACE: host-side laps of this call on stderr (what the boundary pays in front of the first kernel)
+    const bool trace = getenv("CSH_TRACE") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    std::string laps;
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof buf, " %s %.1f", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+        laps += buf; lap_t = now;
+    };
     std::unique_ptr<csh_batch> b(new csh_batch);
     b->device = device;
     b->params = *p;
@@ -615,18 +639,12 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             w.table_base = uint32_t(b->ntables);
             b->ntables += e.ntables;
             b->max_units = std::max(b->max_units, w.nunits);
-            w.first_chunk = uint32_t(b->slot_work.size());
-            b->slot_work.insert(b->slot_work.end(), (w.nunits + 255) / 256, uint32_t(b->swork.size()));
-            for (uint32_t j = 0, nch = (w.nunits + 255) / 256; j < nch; j++) {
-                SlotRec r;
-                r.work = uint32_t(b->swork.size()); r.j = j; r.nch = nch; r.first_chunk = w.first_chunk; r.unit0 = w.unit_base + 256 * j;
-                r.nun = std::min<uint32_t>(256, w.nunits - 256 * j); r.table_base = w.table_base; r.ntables = uint16_t(e.ntables);
-                r.flags = uint16_t((e.Ss > 0 && !e.sequential ? 1 : 0) | (e.Ss > 0 && !e.sequential && e.Ah ? 2 : 0) | (w.list != 0xFFFFFFFFu ? 4 : 0));
-                r.hist_row = b->hist_rows; b->hist_rows += uint32_t(e.ntables);
-                r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
-                r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
-                (w.list != 0xFFFFFFFFu ? b->list_slots : b->tok_slots).push_back(uint32_t(b->slots.size()));
-                b->slots.push_back(r);
+            {   // its slots, one per 256 units: counted here, written by k_make_slots (k_aclist.hip) from this record
+                const uint32_t nch = (w.nunits + 255) / 256;
+                w.first_chunk = b->nslots; b->nslots += nch;
+                w.hist_row0 = b->hist_rows; b->hist_rows += nch * uint32_t(e.ntables);
+                uint32_t &cursor = w.list != 0xFFFFFFFFu ? b->nlist_slots : b->ntok_slots;
+                w.ls_base = cursor; cursor += nch;
             }
             if (e.Ss == 0 || e.sequential) {   // DC scans and sequential-mode scans: one token workgroup per (scan, 256 units)
                 // tokens of a DC scan are known exactly (one per block, or one per fifteen blocks' bits); a sequential-mode block has at most 64 + 3
@@ -703,6 +721,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         worker();
         for (auto &t : pool) t.join();
     }
+    lap("stream+parse");
     {
         size_t total = 0;
         for (size_t n = 0; n < count; n++) total += inputs[n].length;
@@ -711,6 +730,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         if (total + total / 16 + (64u << 10) >= 0xF0000000ull) { csh_set_error("csh_batch_create: more than 3.75 GiB of input in one device batch (cs_batch_extent sizes groups)"); return CS_ERR_POOL_OVERFLOW; }
         if (!b->bits_pool.reserve(total + total / 16 + (64u << 10))) { csh_set_error("out of pinned host memory"); return CS_ERR_NO_DEVICE; }
     }
+    lap("pinned");
     for (size_t n = 0; n < count; n++) {
         Item &it = b->items[n];
         const uint8_t *d = inputs[n].data;
@@ -1121,7 +1141,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         // the later stages, each contiguous: make(image, add) lists the stage's candidates of one image
         auto add_stage = [&](int sid, auto make) -> int {
             // one unused slot between the stages: each stage's exclusive scan of chunk sizes writes one entry past its slots
-            { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
+            b->nslots++;
             csh_batch::Stage &sg = b->stage[sid];
             b->stage_begin(sg);
             for (size_t n = 0; n < count; n++) {
@@ -1167,7 +1187,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         // the trellis stage: per component one statistics scan in the output mode's entropy coder -- progressive: the component alone,
         // 1-63 at Al 0 (EOBRUN symbols included); sequential: a one-component sequential scan (DC and AC tables) -- coded for its
         // histograms only (mozjpeg jcmaster.c: the huff_opt pass in front of every trellis pass; oracle: cso_trellis_tables)
-        { SlotRec r; memset(&r, 0, sizeof r); b->slots.push_back(r); b->slot_work.push_back(0u); }
+        b->nslots++;
         csh_batch::Stage &tg = b->tstage;
         b->stage_begin(tg);
         auto seq1_index = [&](int comp) -> int {
@@ -1250,14 +1270,16 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     b->out_cap = b->raw_bytes_cap;
     layout_token_pool(b.get());
 
+    lap("descriptors");
     // upload what never changes between runs
     hipStream_t st = b->stream;
     if (b->nimg) {
         b->bits_pool.flush_copies();
+        lap("copy_in");
         if (b->d_bits.alloc(b->bits_pool.size()) || (b->bits_pool.size() && hipMemcpyAsync(b->d_bits.p, b->bits_pool.p, b->bits_pool.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
             b->d_imgs.upload(b->imgs, st) || b->d_dscans.upload(b->dscans, st) || b->d_chains.upload(b->chains, st) || b->d_chain_scans.upload(b->chain_scans, st) ||
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || (b->use4 && b->d_phsets4.upload(b->phsets4, st)) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
-            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_slot_work.upload(b->slot_work, st) || b->d_slots.upload(b->slots, st) || b->d_plans.upload(b->plans, st) || b->d_echunks.upload(b->echunks, st) || b->d_hdr.upload(b->hdr_pool, st) ||
+            b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_slot_work.alloc(size_t(b->nslots) + 1) || b->d_slots.alloc(size_t(b->nslots) + 1) || b->d_plans.upload(b->plans, st) || b->d_echunks.upload(b->echunks, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
             b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
@@ -1274,14 +1296,18 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
             b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
             b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_corr.alloc(b->total_units + 1) ||
-            b->d_tok_off.alloc(4 * b->slot_work.size() + 4) || b->d_chunk_ntok.alloc(4 * b->slot_work.size() + 4) || b->d_slot_hist.alloc(size_t(b->hist_rows) * 256 + 256) ||
-            b->d_slot_raw.alloc(b->slot_work.size() + 1) || b->d_img_list.upload(b->img_list, st) || b->d_img_nlist.upload(b->img_nlist, st) || b->d_scan_cost.alloc(b->swork.size() + 1) || b->d_slot_eobh.alloc(16 * b->slot_work.size() + 16) || b->d_chunk_bits.alloc(b->slot_work.size() + 1) || b->d_chunk_off.alloc(b->slot_work.size() + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
+            b->d_tok_off.alloc(4 * size_t(b->nslots) + 4) || b->d_chunk_ntok.alloc(4 * size_t(b->nslots) + 4) || b->d_slot_hist.alloc(size_t(b->hist_rows) * 256 + 256) ||
+            b->d_slot_raw.alloc(size_t(b->nslots) + 1) || b->d_img_list.upload(b->img_list, st) || b->d_img_nlist.upload(b->img_nlist, st) || b->d_scan_cost.alloc(b->swork.size() + 1) || b->d_slot_eobh.alloc(16 * size_t(b->nslots) + 16) || b->d_chunk_bits.alloc(size_t(b->nslots) + 1) || b->d_chunk_off.alloc(size_t(b->nslots) + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
             b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||
-            b->d_nzlists.upload(b->nzlists, st) || b->d_nzsets.upload(b->nzsets, st) || b->d_nzchunks.upload(b->nzchunks, st) || b->d_list_slots.upload(b->list_slots, st) || b->d_tok_slots.upload(b->tok_slots, st) ||
+            b->d_nzlists.upload(b->nzlists, st) || b->d_nzsets.upload(b->nzsets, st) || b->d_nzchunks.upload(b->nzchunks, st) || b->d_list_slots.alloc(size_t(b->nlist_slots) + 1) || b->d_tok_slots.alloc(size_t(b->ntok_slots) + 1) ||
             b->d_nz_cursor.alloc(b->nzlists.size() + 1) || b->d_nz_chunk_off.alloc(size_t(b->nz_nrec) + 1) || b->d_nz_chunk_cnt.alloc(size_t(b->nz_nrec) + 1) ||
             b->d_scan_raw_off.alloc(b->swork.size() + 2) || b->d_img_size.alloc(b->nimg + 1) || b->d_img_size_pad.alloc(b->nimg + 1) ||
             b->d_img_off.alloc(b->nimg + 2) || b->d_status.alloc(b->nimg) || b->d_overflow.alloc(4))
             return CS_ERR_NO_DEVICE;
+        // the slots of every work item, written where they are used (the host counted them: add_works)
+        if (hipMemsetAsync(b->d_slots.p, 0, (size_t(b->nslots) + 1) * sizeof(SlotRec), st) != hipSuccess ||
+            hipMemsetAsync(b->d_slot_work.p, 0, (size_t(b->nslots) + 1) * sizeof(uint32_t), st) != hipSuccess) { csh_set_error("hipMemsetAsync failed"); return CS_ERR_NO_DEVICE; }
+        launch_make_slots(st, b->d_swork.p, uint32_t(b->swork.size()), b->d_script.p, b->d_slots.p, b->d_slot_work.p, b->d_list_slots.p, b->d_tok_slots.p);
         if (b->trellis && (b->d_trows.upload(b->trows, st) || (b->t_sort && (b->d_tperm.alloc(size_t(b->t_units) + 1) || b->d_tblk_cnt.alloc(size_t(b->t_units) + 1))))) return CS_ERR_NO_DEVICE;
         if (b->trellis && (b->d_twork.upload(b->twork, st) || b->d_tchunks.upload(b->tchunks, st) || b->d_tlambda.alloc(size_t(b->t_units) + 1) || b->d_tdcbt.alloc(size_t(b->t_units) + 1) ||
                            b->d_tspill.alloc(trellis_spill_words()) || b->d_dct_raw.alloc(size_t(b->ntiles_out) * CSH_TILE_I16)))
@@ -1293,8 +1319,11 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             if (rw.image != it.image) { csh_set_error("internal: resize work out of order"); return CS_ERR_NO_DEVICE; }
             if (hipMemcpyAsync(b->d_rgb.p + rw.rgb_src_off, px[n].device_pixels, size_t(px[n].width) * px[n].height * px[n].channels, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
         }
+        lap("alloc+enqueue");
         if (hipStreamSynchronize(st) != hipSuccess) { csh_set_error("upload failed"); return CS_ERR_NO_DEVICE; }
+        lap("upload_wait");
     }
+    if (trace) fprintf(stderr, "[csh] create %zu files:%s\n", count, laps.c_str());
     *out = b.release();
     return 0;
 }
@@ -1596,7 +1625,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     if (b->d_raw.n != raw_chunks * 16) {
         if (b->d_raw.alloc(raw_chunks * 16) || b->d_chunk_ff.alloc(raw_chunks + 1) || b->d_out.alloc(b->out_cap + 64))
             return -1;
-        const uint64_t longest = std::max({uint64_t(b->slot_work.size()), uint64_t(b->swork.size()), uint64_t(b->dc_total), uint64_t(b->total_sub), uint64_t(b->bits_pool.size() / 64), uint64_t(nimg)});
+        const uint64_t longest = std::max({uint64_t(size_t(b->nslots)), uint64_t(b->swork.size()), uint64_t(b->dc_total), uint64_t(b->total_sub), uint64_t(b->bits_pool.size() / 64), uint64_t(nimg)});
         size_t tmp = exclusive_scan_tmp_bytes(longest + 1);   // the longest input any exclusive scan of a run gets
         if (b->d_scan_tmp.alloc(tmp)) return -1;
     }
@@ -1713,7 +1742,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     EncCtx c;
     memset(&c, 0, sizeof c);
     c.imgs = b->d_imgs.p; c.script = b->d_script.p; c.work = b->d_swork.p; c.nwork = int(b->swork.size());
-    c.echunks = b->d_echunks.p; c.plans = b->d_plans.p; c.nechunks = uint32_t(b->echunks.size()); c.slot_work = b->d_slot_work.p; c.slots = b->d_slots.p; c.nslots = uint32_t(b->slot_work.size());
+    c.echunks = b->d_echunks.p; c.plans = b->d_plans.p; c.nechunks = uint32_t(b->echunks.size()); c.slot_work = b->d_slot_work.p; c.slots = b->d_slots.p; c.nslots = b->nslots;
     c.coef = b->d_coef.p; c.sym_bits = b->d_symbits.p; c.eob_bits = b->d_eobbits.p; c.tail = b->d_tail.p;
     c.eobrun = b->d_eobrun.p; c.long_runs = b->d_long_runs.p; c.long_cnt = b->d_long_cnt.p; c.corr = b->d_corr.p;
     c.tokens = b->d_tokens.p; c.regions = b->d_regions.p; c.tok_cursor = b->d_tok_cursor.p; c.tok_off = b->d_tok_off.p; c.chunk_ntok = b->d_chunk_ntok.p; c.slot_hist = b->d_slot_hist.p; c.slot_raw = b->d_slot_raw.p; c.slot_eobh = b->d_slot_eobh.p;

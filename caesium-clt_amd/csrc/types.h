@@ -194,6 +194,8 @@ struct ScanWork {
     uint32_t hdr_bytes;    // DHT + SOS bytes in front of the entropy-coded data (device-computed)
     uint32_t no_room;      // the raw pool cannot hold this scan (device-computed): the packer skips it, the batch is re-run with a larger pool
     uint32_t list;         // progressive AC scans: the NzList (component, point transform) the scan is coded from (k_aclist.hip); 0xFFFFFFFF otherwise
+    uint32_t hist_row0;    // first histogram row of its first slot (slot j: hist_row0 + j * ntables)
+    uint32_t ls_base;      // where its slots stand in the list of list-coded slots (list != 0xFFFFFFFF) or of token-coded slots
 };
 
 // one workgroup of the token kernel (k_tokens): 256 consecutive units, [256 j, 256 j + 256)
@@ -242,7 +244,7 @@ struct NzSet {
 // filtered from level 0 (which an earlier stage may have made)
 struct NzChunk { uint32_t set, j, levels, work0; };   // work0: a work item whose gate (EncCtx::work_active) stands for the chunk in a conditional stage
 
-// what the per-slot kernels need of (work item, chunk j), in one 32-byte load (host-built; slot = work.first_chunk + j)
+// what the per-slot kernels need of (work item, chunk j), in one load (written by k_make_slots from the work items; slot = work.first_chunk + j)
 struct SlotRec {
     uint32_t work, j, nch;       // work item, chunk number, chunks of the work item
     uint32_t first_chunk;        // the work item's first slot

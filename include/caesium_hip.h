@@ -137,6 +137,7 @@ typedef struct {
 
 int csh_device_count(void);
 const char *csh_last_error(void);
+void csh_warmup(int device);            /* optional: start the runtime, the device context and the code objects now (call it from a thread of its own while the files are being read) */
 void csh_release_cached_memory(void);   /* hand the cached device pools and pinned blocks of finished batches back to the driver (they are kept for the next batch otherwise) */
 const char *csh_kernel_name(int slot);
 const char *csh_kernel_name_webp(int slot);   /* the same for a csh_batch_create_webp batch: behind the resize slot come the VP8 tail's kernels */
