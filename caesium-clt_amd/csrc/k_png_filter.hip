@@ -197,6 +197,18 @@ __global__ void __launch_bounds__(256) k_png_rgb(const RgbJob *jobs, const uint8
     auto sample = [&](const uint8_t *p) { return bps == 2 ? uint32_t(((((uint32_t(p[0]) << 8) | p[1]) + 128u) / 257u)) : uint32_t(p[0]); };
     auto raw16 = [&](const uint8_t *p) { return bps == 2 ? ((uint32_t(p[0]) << 8) | p[1]) : uint32_t(p[0]); };
     auto key = [&](int c) { return (uint32_t(trns[2 * c]) << 8) | trns[2 * c + 1]; };
+    if (j.wide) {   // 16-bit grey / RGB + tRNS -> 16-bit grey + alpha / RGBA (what the png crate's EXPAND hands image-rs: La16 / Rgba16): samples as they are, alpha 0 at the key
+        const uint32_t colour = j.ctype == 2 ? 3u : 1u;
+        uint8_t *dw = rgb + j.dst_off + uint64_t(y) * j.width * nc * 2u;
+        for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
+            const uint8_t *p = r + uint64_t(x) * colour * 2u;
+            uint8_t *o = dw + uint64_t(x) * nc * 2u;
+            bool hit = j.ntrns != 0;
+            for (uint32_t c = 0; c < colour; c++) { o[2 * c] = p[2 * c]; o[2 * c + 1] = p[2 * c + 1]; hit = hit && raw16(p + 2 * c) == key(int(c)); }
+            o[2 * colour] = o[2 * colour + 1] = hit ? 0 : 255;
+        }
+        return;
+    }
     for (uint32_t x = threadIdx.x; x < j.width; x += blockDim.x) {
         uint8_t *o = d + uint64_t(x) * nc;
         if (j.ctype == 2 || j.ctype == 6 || j.ctype == 4 || (j.ctype == 0 && j.depth >= 8)) {

@@ -46,7 +46,8 @@ void launch_png_resize(hipStream_t st, const PngResize *jobs, int njobs, const c
 // k_webp_yuv (opaque sources).  out_nc 2 / 4 (or 1 / 3 with no tRNS): what the png crate's EXPAND transformation gives image-rs before
 // a resize -- palette entries looked up, sub-byte grey scaled, tRNS turned into an alpha channel (trns: per-index alpha for a palette,
 // else the transparent sample value(s) as 16-bit big-endian numbers)
-struct RgbJob { uint32_t image, width, height, rowbytes, ctype, depth, plte_off, npal, out_nc, trns_off, ntrns, pad_; uint64_t src_off, dst_off; };
+// wide != 0: a 16-bit grey / RGB image with a tRNS chunk -- its samples stay 16-bit (big-endian, as in the file) and the colour key becomes a 16-bit alpha sample
+struct RgbJob { uint32_t image, width, height, rowbytes, ctype, depth, plte_off, npal, out_nc, trns_off, ntrns, wide; uint64_t src_off, dst_off; };
 void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_height, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status);
 
 // lossy PNG (oracle: quantize): colour bins of 4 + 5 + 5 + 5 bits (a, r, g, b) with count and channel sums, compacted to a list

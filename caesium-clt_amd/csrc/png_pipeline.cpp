@@ -299,7 +299,6 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
         else parse_png(inputs[i].data, inputs[i].length, p->keep_metadata, it);
         if (it.code) continue;
         if (to_webp && uint64_t((it.width + 15) / 16) * ((it.height + 15) / 16) * 256 > 0x7FFFFFFFu) { it.code = CS_ERR_UNSUPPORTED; it.msg = "PNG too large for one device batch"; continue; }
-        if (mode == MODE_DECODE && it.depth == 16 && it.has_trns) { it.code = CS_ERR_UNSUPPORTED; it.msg = "resizing a 16-bit PNG with a tRNS chunk has no device path in this build"; continue; }
         if (decode_only && it.has_trns && it.trns.size() != (it.ctype == 3 ? it.trns.size() : it.ctype == 0 ? 2u : it.ctype == 2 ? 6u : ~size_t(0))) { it.code = CS_ERR_BAD_PNG; it.msg = "bad tRNS"; continue; }
         PngImg im{};
         im.width = it.width; im.height = it.height; im.rowbytes = it.rowbytes; im.bpp = it.bpp;
@@ -788,7 +787,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
 // batch, the two Lanczos passes over its pixels, then the coder -- or, on the way to WebP, the VP8 encoder -- over the resized pixels
 // (device to device, as for JPEG -> PNG).
 // The pixels are expanded first as the png crate does for image-rs (palette looked up, sub-byte grey scaled, tRNS as an alpha channel:
-// k_png_rgb); 16-bit sources keep their 16 bits (refused only with a tRNS chunk).
+// k_png_rgb); 16-bit sources keep their 16 bits (a tRNS chunk becomes a 16-bit alpha sample).
 static int png_create_resized(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, int mode, csp_batch **out) {
     *out = nullptr;
     csp_batch *raw = nullptr;
@@ -821,6 +820,7 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
         // what the png crate's EXPAND transformation hands image-rs: 8-bit samples, palette looked up, tRNS as an alpha channel
         // (16-bit images stay as they are: image-rs resamples L16 / La16 / Rgb16 / Rgba16 at 16 bits)
         const bool wide = it.depth == 16;
+        if (wide && it.has_trns && mode != MODE_PNG) { pre[i] = PreFail{CS_ERR_UNSUPPORTED, "resizing a 16-bit PNG with a tRNS chunk on the way to another format has no device path in this build"}; continue; }
         const uint32_t colour = (it.ctype == 2 || it.ctype == 6 || it.ctype == 3) ? 3u : 1u, nc = colour + ((it.ctype == 4 || it.ctype == 6 || it.has_trns) ? 1u : 0u), bps = wide ? 2u : 1u;
         int nw = 0, nh = 0;
         csh_compute_dimensions(int(it.width), int(it.height), int(p->width), int(p->height), nw, nh);
@@ -834,7 +834,8 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
         tables.insert(tables.end(), it.trns.begin(), it.trns.end());
         e.src_off = a->imgs[it.image].pix_off; e.dst_off = src_bytes;
         src_bytes += (uint64_t(it.width) * it.height * nc * bps + 255) & ~uint64_t(255);
-        if (wide) copies.push_back(RawCopy{e.dst_off, e.src_off, uint64_t(it.height) * it.rowbytes});   // nothing to expand
+        e.wide = wide && it.has_trns && (it.ctype == 0 || it.ctype == 2) ? 1u : 0u;   // the colour key becomes a 16-bit alpha sample
+        if (wide && !e.wide) copies.push_back(RawCopy{e.dst_off, e.src_off, uint64_t(it.height) * it.rowbytes});   // nothing to expand
         else { max_h = std::max(max_h, it.height); ejobs.push_back(e); }
         bits[i] = uint8_t(8 * bps);
         PngResize j{};

@@ -325,16 +325,25 @@ def png_resized_pixels(P, width, height):
     nw, nh = C.c_int(), C.c_int()
     O.lib().cso_compute_dimensions(im.width, im.height, width, height, C.byref(nw), C.byref(nh))
     if im.depth == 16:
-        chunks, pos = C.string_at(im.chunks, im.chunks_len), 0
+        chunks, pos, trns = C.string_at(im.chunks, im.chunks_len), 0, None
         while pos + 12 <= len(chunks):
+            ln = int.from_bytes(chunks[pos:pos + 4], "big")
             if chunks[pos + 4:pos + 8] == b"tRNS":
-                raise O.PngError(10201)
-            pos += 12 + int.from_bytes(chunks[pos:pos + 4], "big")
-        h, w, nc = im.height, im.width, im.channels
+                trns = chunks[pos + 8:pos + 8 + ln]
+            pos += 12 + ln
+        h, w, nc, ctype = im.height, im.width, im.channels, im.ctype
         pix = np.ascontiguousarray(P.rows().view(">u2").astype(np.uint16).reshape(h, w, nc))
+        if trns is not None and ctype in (0, 2):
+            # the png crate's EXPAND on a 16-bit image with a colour key: a 16-bit alpha sample, 0 at the key and 65535 elsewhere (La16 / Rgba16 for image-rs)
+            if len(trns) != 2 * nc:
+                raise O.PngError(30100)
+            key = np.array([int.from_bytes(trns[2 * c:2 * c + 2], "big") for c in range(nc)], dtype=np.uint16)
+            alpha = np.where((pix == key).all(axis=2), 0, 65535).astype(np.uint16)
+            pix = np.ascontiguousarray(np.concatenate([pix, alpha[:, :, None]], axis=2))
+            nc, ctype = nc + 1, {0: 4, 2: 6}[ctype]
         out = np.empty((nh.value, nw.value, nc), dtype=np.uint16)
         O.lib().cso_lanczos3_resize16(pix.ctypes.data, w, h, nc, nw.value, nh.value, out.ctypes.data)
-        return out, im.ctype, 16
+        return out, ctype, 16
     pix, ctype = png_expand8(P)
     pix = np.ascontiguousarray(pix)
     h, w, nc = pix.shape
@@ -345,8 +354,7 @@ def png_resized_pixels(P, width, height):
 
 def oracle_png_resized(src, lossless, level=3, width=0, height=0, quality=80):
     """the oracle's statement of compress_in_memory on a PNG with a size: decode (oracle), image-rs Lanczos3 over the decoded samples
-    (oracle; after png_expand8), a PNG file of the result, then the PNG path over that file.  16-bit images are resampled at 16 bits (with a tRNS chunk they raise: the
-    device refuses them)"""
+    (oracle; after png_expand8), a PNG file of the result, then the PNG path over that file.  16-bit images are resampled at 16 bits (a tRNS chunk as a 16-bit alpha sample)"""
     import ctypes as C
 
     import numpy as np

@@ -73,6 +73,27 @@ def test_sixteen_bit_images_stay_sixteen_bit(api):
     assert out[24] == 16   # IHDR bit depth
 
 
+def test_sixteen_bit_images_with_a_colour_key(api):
+    """16-bit grey / RGB with a tRNS chunk: the png crate's EXPAND hands image-rs La16 / Rgba16 -- the key becomes a 16-bit alpha sample (0 at the key, 65535
+    elsewhere), the picture is resampled at 16 bits with it and written as grey + alpha / RGBA"""
+    from test_png_webp_emul import make_png
+    rng = np.random.default_rng(9)
+    g = rng.integers(0, 4, (23, 31)).astype(">u2") * 21845            # four levels: the key hits a quarter of the pixels
+    rgb = rng.integers(0, 2, (19, 27, 3)).astype(">u2") * 65535       # eight colours
+    grey_key = make_png(31, 23, 16, 0, g.tobytes(), extra=[(b"tRNS", (21845).to_bytes(2, "big"))])
+    rgb_key = make_png(27, 19, 16, 2, rgb.tobytes(), extra=[(b"tRNS", b"\xff\xff\x00\x00\xff\xff")])
+    no_hit = make_png(31, 23, 16, 0, g.tobytes(), extra=[(b"tRNS", (7).to_bytes(2, "big"))])   # a key no pixel has: the alpha is opaque everywhere (and may be dropped again)
+    pick = [("grey16_key", grey_key), ("rgb16_key", rgb_key), ("grey16_key_unused", no_hit)]
+    assert check(api, pick, True, level=2, width=17) == 3
+    assert check(api, pick, True, level=1, width=40, height=30) == 3
+    out = api.cs_batch_compress([rgb_key], package().default_parameters(png_optimize=True, width=17))[0]
+    im = PIL.open(io.BytesIO(out))
+    assert im.size == (17, 12) and im.mode in ("RGBA", "RGBA;16B") and out[24] == 16 and out[25] == 6   # 16-bit RGBA in the file
+    bad = make_png(8, 8, 16, 2, bytes(8 * 8 * 6), extra=[(b"tRNS", b"\0\1")])   # a key of the wrong length
+    r = api.cs_batch_compress([bad], package().default_parameters(png_optimize=True, width=4))[0]
+    assert isinstance(r, Exception)
+
+
 def test_sizes_and_shapes(api):
     cases = dict(png_cases())
     pick = [(k, cases[k]) for k in ("RGB_97x61", "RGBA_97x61", "L_97x61", "LA_97x61", "RGB_200x150_3chunks")]
@@ -100,13 +121,13 @@ def test_mixed_batch_with_jpegs_and_damage(api):
     cases = dict(png_cases())
     jpg = synth_jpeg(3, 120, 90, texture=5)
     from test_png_webp_emul import make_png
-    wide_trns = make_png(20, 10, 16, 0, bytes(range(200)) * 2, extra=[(b"tRNS", b"\0\7")])   # 16-bit grey with a transparent level: refused
+    wide_trns = make_png(20, 10, 16, 0, bytes(range(200)) * 2, extra=[(b"tRNS", b"\0\7")])   # 16-bit grey with a transparent level: resized as La16
     blobs = [cases["RGB_97x61"], jpg, wide_trns, b"junk", cases["P_97x61"], cases["I;16_97x61"]] + damaged_pngs(5, 12)
     p = package().default_parameters(png_optimize=True, png_optimization_level=1, jpeg_quality=80, width=48)
     outs = api.cs_batch_compress(blobs, p)
     assert outs[0] == oracle_png_resized(blobs[0], True, 1, 48, 0)
     assert outs[1] == oracle_resized(jpg, 48, 0)
-    assert outs[2].code == 10201 and "16-bit" in str(outs[2]) and outs[3].code == 10200
+    assert outs[2] == oracle_png_resized(wide_trns, True, 1, 48, 0) and outs[3].code == 10200
     assert outs[4] == oracle_png_resized(blobs[4], True, 1, 48, 0) and outs[5] == oracle_png_resized(blobs[5], True, 1, 48, 0)
     from oracle import oracle as O
     for b, o in zip(blobs[6:], outs[6:]):

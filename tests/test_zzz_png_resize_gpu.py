@@ -19,6 +19,8 @@ def test_resized_pngs_equal_oracle(api):
     import test_png_resize_emul as T
     T.test_every_case_resizes_like_the_oracle_or_is_refused(api)
     T.test_sizes_and_shapes(api)
+    T.test_sixteen_bit_images_stay_sixteen_bit(api)
+    T.test_sixteen_bit_images_with_a_colour_key(api)
     T.test_result_is_close_to_pillows_lanczos(api)
     T.test_mixed_batch_with_jpegs_and_damage(api)
 
