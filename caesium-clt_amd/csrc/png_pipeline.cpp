@@ -552,15 +552,26 @@ static int reduce_step(csp_batch *b) {
         if (!depth && nk == 1 && nbps == 1) gdepth = (flags[i] & 32u) ? 1u : (flags[i] & 16u) ? 2u : (flags[i] & 8u) ? 4u : 0u;
         // an 8-bit indexed image that does not use its whole palette: the unused entries go, the rest is renumbered and packed at the depth it needs (oracle: index_depth)
         uint32_t idepth = 0, nused = 0;
-        uint8_t imap[256];
+        uint8_t imap[256], iorder[256];
         if (flags[i] & 64u) {
             const uint32_t npl = uint32_t(it.plte.size() / 3);
             bool ok = true;
+            // the entries that stay (oracle: index_depth): one per distinct colour among the used ones, those that are not opaque in front of the opaque ones
+            int first_of[256];
+            uint32_t col[256];
+            auto is_used = [&](uint32_t v) { return ((used[size_t(i) * 8 + (v >> 5)] >> (v & 31u)) & 1u) != 0; };
             for (uint32_t v = 0; v < 256; v++) {
-                const bool u = (used[size_t(i) * 8 + (v >> 5)] >> (v & 31u)) & 1u;
-                if (u && v >= npl) ok = false;
-                imap[v] = uint8_t(nused); nused += u ? 1u : 0u;
+                first_of[v] = -1; imap[v] = 0;
+                if (!is_used(v)) continue;
+                if (v >= npl) { ok = false; continue; }
+                col[v] = (uint32_t(v < it.trns.size() ? it.trns[v] : 255) << 24) | (uint32_t(it.plte[3 * v]) << 16) | (uint32_t(it.plte[3 * v + 1]) << 8) | it.plte[3 * v + 2];
+                first_of[v] = int(v);
+                for (uint32_t k = 0; k < v; k++) if (first_of[k] == int(k) && col[k] == col[v]) { first_of[v] = int(k); break; }
             }
+            for (int pass = 0; pass < 2 && ok; pass++)
+                for (uint32_t v = 0; v < 256; v++)
+                    if (first_of[v] == int(v) && ((col[v] >> 24) != 255) == (pass == 0)) { imap[v] = uint8_t(nused); iorder[nused++] = uint8_t(v); }
+            for (uint32_t v = 0; v < 256 && ok; v++) if (first_of[v] >= 0 && first_of[v] != int(v)) imap[v] = imap[first_of[v]];
             idepth = nused <= 2 ? 1u : nused <= 4 ? 2u : nused <= 16 ? 4u : 8u;
             if (!ok || !nused || (idepth == 8 && nused == npl)) idepth = 0;
         }
@@ -602,11 +613,11 @@ static int reduce_step(csp_batch *b) {
             // PLTE and tRNS of the entries that are left (a tRNS that ends up all opaque goes): the carried chunks behind IHDR, written again
             std::vector<uint8_t> npl, ntr;
             uint32_t nt = 0;
-            for (uint32_t v = 0, k = 0; v < 256; v++) if ((used[size_t(i) * 8 + (v >> 5)] >> (v & 31u)) & 1u) {
+            for (uint32_t k = 0; k < nused; k++) {
+                const uint32_t v = iorder[k];
                 npl.insert(npl.end(), it.plte.begin() + 3 * v, it.plte.begin() + 3 * v + 3);
                 ntr.push_back(v < it.trns.size() ? it.trns[v] : uint8_t(255));
                 if (ntr.back() != 255) nt = k + 1;
-                k++;
             }
             ntr.resize(nt);
             std::vector<uint8_t> np(it.prefix.begin(), it.prefix.begin() + 33);

@@ -404,8 +404,9 @@ static int grey_depth(cso_png *P) {
     P->pix = np; P->rowbytes = nrb; P->depth = d; P->bpp = 1;
     return 32;
 }
-/* an 8-bit indexed image that does not use its whole palette: the entries no pixel points at are dropped (the others keep their order), the indices
-   renumbered and packed at the smallest depth that holds the entries left (1, 2, 4 or 8 bits), PLTE and tRNS written again for them (a tRNS that ends up
+/* an 8-bit indexed image that does not use its whole palette, or lists a colour twice: the entries no pixel points at are dropped, duplicates (same red,
+   green, blue and alpha) merged into their first, the entries that are not opaque moved in front of the opaque ones (round 4; oxipng's reduced_palette /
+   alpha-first ordering in spirit, not its luma sort), the indices renumbered and packed at the smallest depth that holds the entries left (1, 2, 4 or 8 bits), PLTE and tRNS written again for them (a tRNS that ends up
    all opaque goes).  Not when a carried chunk counts on the palette as it is (bKGD, sBIT, hIST), nor when a pixel points past the palette.
    Returns 64 or 0. */
 static int index_depth(cso_png *P) {
@@ -414,7 +415,31 @@ static int index_depth(cso_png *P) {
     memset(used, 0, sizeof used);
     for (uint32_t y = 0; y < P->height; y++)
         for (uint32_t x = 0; x < P->width; x++) used[P->pix[(size_t)y * P->rowbytes + x]] = 1;
-    for (int i = 0; i < 256; i++) { if (used[i] && i >= P->nplte) return 0; map[i] = n; n += used[i]; }
+    for (int i = 0; i < 256; i++) if (used[i] && i >= P->nplte) return 0;
+    /* the entries that stay: one per distinct colour (red, green, blue, alpha) among the used ones -- a later duplicate points at the first --, those that are
+       not opaque in front of the opaque ones (each group in the old order), so that tRNS stops at the last of them */
+    const uint8_t *plte0 = NULL, *trns0 = NULL;
+    uint32_t ntrns0 = 0;
+    for (size_t pos = 0; pos + 12 <= P->chunks_len; pos += 12 + (size_t)be32(P->chunks + pos)) {
+        if (!memcmp(P->chunks + pos + 4, "PLTE", 4)) plte0 = P->chunks + pos + 8;
+        if (!memcmp(P->chunks + pos + 4, "tRNS", 4)) { trns0 = P->chunks + pos + 8; ntrns0 = be32(P->chunks + pos); }
+    }
+    if (!plte0) return 0;
+    int first_of[256], order[256], nuniq = 0;
+    uint32_t col[256];
+    for (int i = 0; i < 256; i++) {
+        first_of[i] = -1;
+        if (!used[i]) continue;
+        col[i] = ((uint32_t)((trns0 && (uint32_t)i < ntrns0) ? trns0[i] : 255) << 24) | ((uint32_t)plte0[3 * i] << 16) | ((uint32_t)plte0[3 * i + 1] << 8) | plte0[3 * i + 2];
+        first_of[i] = i;
+        for (int k = 0; k < i; k++) if (used[k] && first_of[k] == k && col[k] == col[i]) { first_of[i] = k; break; }
+        if (first_of[i] == i) nuniq++;
+    }
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < 256; i++)
+            if (used[i] && first_of[i] == i && ((col[i] >> 24) != 255) == (pass == 0)) { map[i] = n; order[n++] = i; }
+    for (int i = 0; i < 256; i++) if (used[i] && first_of[i] != i) map[i] = map[first_of[i]];
+    (void)nuniq;
     const int d = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
     if (d == 8 && n == P->nplte) return 0;
     const size_t nrb = ((size_t)P->width * d + 7) / 8;
@@ -435,11 +460,11 @@ static int index_depth(cso_png *P) {
     }
     uint8_t npl[768], ntr[256];
     int nt = 0;
-    for (int i = 0, k = 0; i < 256; i++) if (used[i]) {
+    for (int k = 0; k < n; k++) {
+        const int i = order[k];
         memcpy(npl + 3 * k, plte + 3 * i, 3);
         ntr[k] = (trns && (uint32_t)i < ntrns) ? trns[i] : 255;
         if (ntr[k] != 255) nt = k + 1;
-        k++;
     }
     uint8_t *nc = (uint8_t *)malloc(P->chunks_len + 16), *w = nc;
     size_t new_idat_at = P->idat_at;

@@ -136,6 +136,59 @@ def test_reductions_keep_what_the_pixels_mean():
             assert np.array_equal(np.asarray(a.convert("RGBA")), np.asarray(b.convert("RGBA"))), name
 
 
+def palette_with_duplicates():
+    """8-bit indexed files whose palettes list colours twice, carry translucent entries behind opaque ones, and have entries no pixel uses"""
+    from test_png_webp_emul import make_png
+    rng = np.random.default_rng(12)
+    cases = []
+    # 40 entries: 0-9 distinct, 10-19 repeat 0-9, 20-29 distinct again but unused, 30-39 distinct; alpha: entries 5, 15 (a duplicate pair) and 33 translucent
+    pal = [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(40)]
+    for k in range(10):
+        pal[10 + k] = pal[k]
+    trns = [255] * 40
+    trns[5] = trns[15] = 80
+    trns[33] = 0
+    idx = rng.choice(np.array([k for k in range(40) if not 20 <= k < 30]), size=(31, 45)).astype(np.uint8)
+    plte = b"".join(bytes(c) for c in pal)
+    cases.append(("dupes_translucent", make_png(45, 31, 8, 3, idx.tobytes(), extra=[(b"PLTE", plte), (b"tRNS", bytes(trns[:34]))])))
+    # same colour, different alpha: NOT duplicates
+    pal2 = [(10, 20, 30), (10, 20, 30), (200, 100, 50), (200, 100, 50)]
+    idx2 = rng.integers(0, 4, (9, 14)).astype(np.uint8)
+    cases.append(("same_rgb_other_alpha", make_png(14, 9, 8, 3, idx2.tobytes(), extra=[(b"PLTE", b"".join(bytes(c) for c in pal2)), (b"tRNS", bytes([255, 128, 7, 7]))])))
+    # all of a full-size palette used, but half of it twice over: 256 -> 128 entries
+    pal3 = [tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(128)] * 2
+    idx3 = rng.integers(0, 256, (40, 40)).astype(np.uint8)
+    cases.append(("full_palette_twice", make_png(40, 40, 8, 3, idx3.tobytes(), extra=[(b"PLTE", b"".join(bytes(c) for c in pal3))])))
+    return cases
+
+
+def test_indexed_palettes_lose_duplicates_and_put_translucent_entries_first():
+    """P2, round 4: among the entries an indexed image uses, one per distinct (red, green, blue, alpha); those that are not opaque in front, so that tRNS is as
+    short as it can be; the picture means what it meant"""
+    for name, data in palette_with_duplicates():
+        P = O.png_decode(data)
+        assert P.reduce() == 64, name
+        out, _ = O.png_optimize(data, 2)
+        a, b = PIL.open(io.BytesIO(data)), PIL.open(io.BytesIO(out))
+        assert b.mode == "P" and np.array_equal(np.asarray(a.convert("RGBA")), np.asarray(b.convert("RGBA"))), name
+        plte = out[out.index(b"PLTE") + 4:][:int.from_bytes(out[out.index(b"PLTE") - 4:out.index(b"PLTE")], "big")]
+        trns = b""
+        if b"tRNS" in out:
+            trns = out[out.index(b"tRNS") + 4:][:int.from_bytes(out[out.index(b"tRNS") - 4:out.index(b"tRNS")], "big")]
+        n = len(plte) // 3
+        cols = [(plte[3 * k], plte[3 * k + 1], plte[3 * k + 2], trns[k] if k < len(trns) else 255) for k in range(n)]
+        assert len(set(cols)) == n, name                                            # no colour twice
+        assert all(c[3] != 255 for c in cols[:len(trns)]) and all(c[3] == 255 for c in cols[len(trns):]), name   # tRNS holds the translucent entries and nothing else
+        used = set(np.asarray(b).ravel().tolist())
+        assert used == set(range(n)), name                                          # every entry is pointed at
+    want = {"dupes_translucent": (20, 2), "same_rgb_other_alpha": (3, 2), "full_palette_twice": (128, 0)}   # (entries, tRNS bytes)
+    for name, data in palette_with_duplicates():
+        out, _ = O.png_optimize(data, 2)
+        n = int.from_bytes(out[out.index(b"PLTE") - 4:out.index(b"PLTE")], "big") // 3
+        nt = int.from_bytes(out[out.index(b"tRNS") - 4:out.index(b"tRNS")], "big") if b"tRNS" in out else 0
+        assert (n, nt) == want[name], (name, n, nt)
+
+
 def test_refusals():
     data = synth_png(8, 40, 30, "RGB")
     with pytest.raises(O.PngError):

@@ -49,6 +49,13 @@ def check_batch(api, cases, level, keep_metadata=False, stages=True):
         b.close()
 
 
+def test_indexed_palettes_with_duplicates_and_translucent_entries(api):
+    """the index_depth reduction with its round-4 rules (duplicates merged, translucent entries first): the host decides, the device renumbers; file == oracle"""
+    from test_oracle_png import palette_with_duplicates
+    check_batch(api, palette_with_duplicates(), 2)
+    check_batch(api, palette_with_duplicates(), 1, keep_metadata=True)
+
+
 def test_level3_stage_by_stage(api):
     check_batch(api, png_cases(), 3)
 

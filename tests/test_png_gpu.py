@@ -119,3 +119,7 @@ def test_indexed_images_lose_unused_depth(api):
     from test_png_emul import test_indexed_images_lose_unused_depth as body
     body(api)
 
+
+def test_indexed_palettes_with_duplicates_and_translucent_entries(api):
+    import test_png_emul as E
+    E.test_indexed_palettes_with_duplicates_and_translucent_entries(api)
