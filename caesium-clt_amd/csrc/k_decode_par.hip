@@ -221,7 +221,7 @@ __device__ __forceinline__ static void make_block_info(const ParScan &ps, const 
 // writes (T.81 G.1.1.1.1: bands of later scans are disjoint or refine), but it shares their octets with other scans: 2-byte stores.
 template <bool WRITE, int KIND, class R>
 __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0, const uint8_t *hb, uint32_t sub_off, const ParCtx &cx, PState &st, uint32_t stop_bit,
-                                                        uint32_t ordinal, const ParBlockInfo *bi, int16_t *coef, int32_t *dcdiff) {
+                                                        uint32_t ordinal, const ParBlockInfo *bi, int16_t *coef, int32_t *dcdiff, uint32_t *hand_over = nullptr) {
     uint32_t nblk = 0;
     int16_t *blk = nullptr;
     int32_t *dcp = nullptr;
@@ -293,7 +293,12 @@ __device__ __forceinline__ static uint32_t decode_span(const R &rd, uint32_t w0,
         if (eobrun) { run = (1u << r) + (r ? uint32_t(v) : 0u); v = 0; }
         else { v = v < int(1u << ((n - 1) & 31)) ? v - (1 << n) + 1 : v; v = val ? v : 0; }   // EXTEND (T.81 F.2.2.1); n == 0 is masked
         if (WRITE && in_range) {
-            if (KIND == CSH_PS_AC_FIRST) { if (val) blk[coef_off(kn)] = int16_t(v * (1 << cx.Al)); }
+            if (KIND == CSH_PS_AC_FIRST) {
+                if (val) blk[coef_off(kn)] = int16_t(v * (1 << cx.Al));
+                // a run that leaves the scan's band (damaged data: libjpeg stores the coefficient all the same) lands in the band of ANOTHER scan, and the
+                // scans of a file are written side by side here: which of the two values stays is a matter of file order -- the sequential kernel's
+                if (val && kn > cx.Se) *hand_over = 2u;
+            }
             else if (isdc) *dcp = v;
             else if (val) {
                 const int oct = kn >> 3;
@@ -538,7 +543,7 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
             // (cut_block, set by the lane that crossed the end; k_dc_scatter gives those blocks a zero DC as well)
             if (!live || ordinal >= ps.total_blocks) continue;
             PState st = unpack_state(a.state[base + t]);
-            const uint32_t cut = CSH_SPAN(true, ps.kind, rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff);
+            const uint32_t cut = CSH_SPAN(true, ps.kind, rd, w0, hb, sub_off, cx, st, stop, ordinal, lbi, a.coef, a.dcdiff, a.need_seq + ps.image);
             if (cut != 0xFFFFFFFFu) atomicMin(&a.cut_block[ps.par_index], cut);
         }
     }

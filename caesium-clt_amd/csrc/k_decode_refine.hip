@@ -173,7 +173,7 @@ __device__ __forceinline__ static uint32_t rf_fast_symbols(uint32_t &pos, uint64
 // numbered scan-major (a chain's scan s before any chain's scan s + 1) and a wave takes its unit from a ticket counter, so the unit a wave waits for belongs
 // to a wave that started earlier: nothing waits for a wave that is not running yet, whatever order the workgroups are dispatched in.
 __global__ void __launch_bounds__(64) k_refine_parse(const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,
-                                                     const int *chain_scans, const RefineUnit *units, int nunits, const uint32_t *need_seq, uint64_t *hist, uint32_t *posv,
+                                                     const int *chain_scans, const RefineUnit *units, int nunits, uint32_t *need_seq, uint64_t *hist, uint32_t *posv,
                                                      uint32_t *prog) {
     LV<uint32_t> tv;
     LFOR(l) tv[l] = l == 0 ? atomicAdd(&prog[nunits], 1u) : 0u;
@@ -281,6 +281,9 @@ __global__ void __launch_bounds__(64) k_refine_parse(const uint8_t *clean, const
                         pos += (e & 31u) + rf_popc64(Hr);
                         Nb |= beyond;
                         Hr = 0;
+                        // ... which is a coefficient of ANOTHER scan's band, and this file's first scans all ran before its refinement scans: whether the
+                        // value stays is a matter of file order -- the sequential kernel's (damaged data only: an encoder's run ends inside the band)
+                        if (beyond) need_seq[pc.image] = 2u;
                         break;
                     }
                     // the next symbol the general way: outside the decoded positions, EOBn or ZRL
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(256) k_refine_apply(const uint8_t *clean, cons
 // ---------------------------------------------------------------------------------------------------------------- launch
 void launch_refine_chains(hipStream_t st, const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,
                           const int *chain_scans, int nchains, const RefineUnit *units, int nunits, uint32_t max_blocks, const ImgDesc *imgs, int16_t *coef,
-                          const uint32_t *need_seq, uint64_t *hist, uint32_t *posv, uint32_t *prog) {
+                          uint32_t *need_seq, uint64_t *hist, uint32_t *posv, uint32_t *prog) {
     if (!nunits || !max_blocks) return;
     const dim3 per_block((max_blocks + 255u) / 256u, unsigned(nchains));
     (void)hipMemsetAsync(prog, 0, (size_t(nunits) + 1) * sizeof(uint32_t), st);

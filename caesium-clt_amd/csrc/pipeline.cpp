@@ -935,7 +935,25 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             //                              a decoder that does not know its block cannot find the next symbol) -- CSH_PS_UNSTUFF + ProgChain.
             // CSH_PROG_PAR=0 (or a file beyond the parallel decoder's 24-bit block counts) leaves every scan to the chains, as before round 4.
             const char *pp = getenv("CSH_PROG_PAR");
-            const bool par_first = !(pp && !strcmp(pp, "0")) && uint64_t(in.mcus_x) * uint64_t(in.mcus_y) * 10 < (1u << 24);
+            // The parallel kinds run side by side and in front of the refinement chains: sound only for a REGULAR progression -- every coefficient of every
+            // component gets its first scan (Ah = 0) once and before any refinement, and each refinement takes over where the scan before it left the
+            // coefficient (Ah = that scan's Al, Al = Ah - 1).  A damaged header can say otherwise (two first scans over one band: the later one wins in file
+            // order, and two waves writing the same coefficient do not know which of them is later); libjpeg warns and decodes in file order: so do the chains.
+            bool regular = true;
+            {
+                int state[CSH_MAX_COMPS][64];
+                for (auto &row : state) for (int &v : row) v = -1;
+                for (const JScan &js : in.scans)
+                    for (int k = 0; k < js.ncomp && regular; k++) {
+                        const int c = js.comp_idx[k];
+                        if (c < 0 || c >= CSH_MAX_COMPS || js.Ss < 0 || js.Se > 63 || js.Ss > js.Se) { regular = false; break; }
+                        for (int z = js.Ss; z <= js.Se; z++) {
+                            if (js.Ah == 0 ? state[c][z] != -1 : (state[c][z] != js.Ah || js.Al != js.Ah - 1)) { regular = false; break; }
+                            state[c][z] = js.Al;
+                        }
+                    }
+            }
+            const bool par_first = regular && !(pp && !strcmp(pp, "0")) && uint64_t(in.mcus_x) * uint64_t(in.mcus_y) * 10 < (1u << 24);
             for (size_t s = 0; s < in.scans.size(); s++) {
                 const JScan &js = in.scans[s];
                 DecScan &ds = b->dscans[im.first_scan + s];

@@ -119,6 +119,49 @@ def test_emul_refinement_scans_parse_and_apply(api, monkeypatch):
     assert api.batch_compress(srcs[:4], params()) == [oracle_lossy(s) for s in srcs[:4]]
 
 
+def test_emul_irregular_progressions_decode_in_file_order(api):
+    """a damaged scan header can make two first scans cover one band, or a refinement scan come before the band's first scan: libjpeg warns and decodes in file
+    order (the later scan wins).  The parallel kinds of the progressive decoder run side by side, so such a file must stay on the ordered chains"""
+    src = bytearray(deep_refinement_file())
+    sos = [i for i in range(len(src) - 1) if src[i] == 0xFF and src[i + 1] == 0xDA]
+    def patched(scan, Ss=None, Se=None, AhAl=None):
+        b = bytearray(src)
+        at = sos[scan] + 4 + 1 + 2 * b[sos[scan] + 4]      # behind the component list: Ss, Se, Ah/Al
+        if Ss is not None: b[at] = Ss
+        if Se is not None: b[at + 1] = Se
+        if AhAl is not None: b[at + 2] = AhAl
+        return bytes(b)
+    files = [patched(3, Ss=1),            # chroma 6-63 first scan now covers 1-63: two first scans over 1-5
+             patched(5, AhAl=0x00),       # luma's first refinement claims to be a first scan
+             patched(1, AhAl=0x32),       # luma's first scan claims to be a refinement (nothing to refine yet)
+             patched(7, AhAl=0x10)]       # a refinement that skips a level
+    bt = api.batch(files, params(jpeg_optimize=True))
+    t = bt.run()
+    outs = bt.fetch()
+    assert t.n_refine_chains == 0
+    # a regular progression whose DATA leaves the band: luma's first refinement scan cut to 1-40 (its runs were coded for 1-63: one of them ends behind 40
+    # and libjpeg stores the coefficient there, in the band no scan of this file refines any more), and a first scan whose band was narrowed
+    from oracle import oracle as O
+    files += [patched(11, Se=40)]   # the last luma refinement: nothing behind it makes the progression irregular
+    plain = bytearray(O.decode(synth_jpeg(5, 120, 88, texture=40)).encode(O.params(progressive=1, marker_style=0), script=[((0, 1, 2), 0, 0, 0, 0), ((0,), 1, 63, 0, 0), ((1,), 1, 63, 0, 0), ((2,), 1, 63, 0, 0)]))
+    at = [i for i in range(len(plain) - 1) if plain[i] == 0xFF and plain[i + 1] == 0xDA][1]
+    plain[at + 4 + 1 + 2 * plain[at + 4] + 1] = 20   # luma's only AC scan narrowed to 1-20: its runs land behind 20
+    files += [bytes(plain)]
+    bt2 = api.batch(files[4:], params(jpeg_optimize=True))
+    t2 = bt2.run()
+    outs += bt2.fetch()
+    assert t2.n_seq_decoded == 2   # both handed to the kernel that decodes in file order
+    for i, (f, out) in enumerate(zip(files, outs)):
+        try:
+            want = oracle_lossless(f)
+        except Exception:
+            want = None
+        if want is None:
+            assert isinstance(out, Exception), i
+        else:
+            assert out == want, i
+
+
 def test_emul_non_interleaved_sequential_scans(api):
     """a sequential-mode file whose components come in three separate scans (legal, rare): each scan is its own segment of the
     parallel decoder, the block grid of a non-interleaved scan is the component's real one (no MCU padding blocks)"""
