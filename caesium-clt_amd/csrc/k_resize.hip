@@ -128,6 +128,73 @@ __global__ void __launch_bounds__(256) k_lanczos_h(const ImgDesc *imgs, const Re
     }
 }
 
+// Both passes in one kernel, the f32 row between them in LDS: a workgroup is ONE output row -- phase 0 is the vertical pass of that row (every source column,
+// the row's taps as scalars, four samples per lane: k_lanczos_v's arithmetic), phase 1 the horizontal pass over it (a lane per output pixel: k_lanczos_h's).
+// The values and the order of every multiplication and addition are the two kernels' own, so the bytes are too; what goes is the intermediate image
+// (1920 x 844 x 3 floats = 19.4 MB per picture written and read back through HBM, and 20 GB of pool per 1024 pictures).  CAP = floats of LDS: the launch
+// takes the smallest that holds the batch's widest source row; rows beyond the largest keep the two-kernel form.
+#define CSH_RZ_CAP_S 6144    // 2048 pixels of RGB: 24 KB, six workgroups per CU
+#define CSH_RZ_CAP_L 16128   // 5376 pixels of RGB: 63 KB
+template <int CAP>
+__global__ void __launch_bounds__(256) k_lanczos_fused(const ImgDesc *imgs, const ResizeWork *work, const ResizeTap *taps, const float *weights, const uint8_t *rgb_in,
+                                                        uint8_t *rgb_out) {
+    CSH_SHARED float s_row[CAP];
+    const ResizeWork w = work[blockIdx.y];
+    const ImgDesc &im = imgs[w.image];
+    const uint32_t nc = uint32_t(im.ncomp), rowlen = uint32_t(im.width) * nc, rowlen_out = uint32_t(w.nw) * nc;
+    const uint32_t oy = blockIdx.x;
+    CSH_PHASE_LOOP(2) {
+        if (oy >= uint32_t(w.nh) || rowlen > uint32_t(CAP)) continue;
+        if (phase == 0) {
+            const ResizeTap t = taps[w.vtap_base + oy];
+            const float *ws = weights + t.woff;
+            for (uint32_t xc = threadIdx.x * 4u; xc < rowlen; xc += blockDim.x * 4u) {
+                const uint8_t *s = rgb_in + w.rgb_src_off + size_t(t.left) * rowlen + xc;
+                if (xc + 4 <= rowlen) {
+                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                    for (int k = 0; k < t.n; k++) {
+                        uint32_t v;
+                        memcpy(&v, s + size_t(k) * rowlen, 4);   // a row need not start on a word
+                        const float wk = ws[k];
+                        a0 = __fadd_rn(a0, __fmul_rn(float(v & 255u), wk)); a1 = __fadd_rn(a1, __fmul_rn(float((v >> 8) & 255u), wk));
+                        a2 = __fadd_rn(a2, __fmul_rn(float((v >> 16) & 255u), wk)); a3 = __fadd_rn(a3, __fmul_rn(float(v >> 24), wk));
+                    }
+                    s_row[xc] = a0; s_row[xc + 1] = a1; s_row[xc + 2] = a2; s_row[xc + 3] = a3;
+                } else {
+                    for (uint32_t j = 0; xc + j < rowlen; j++) {
+                        float acc = 0.0f;
+                        for (int k = 0; k < t.n; k++) acc = __fadd_rn(acc, __fmul_rn(float(s[size_t(k) * rowlen + j]), ws[k]));
+                        s_row[xc + j] = acc;
+                    }
+                }
+            }
+            continue;
+        }
+        uint8_t *drow = rgb_out + w.rgb_dst_off + size_t(oy) * rowlen_out;
+        for (uint32_t ox = threadIdx.x; ox < uint32_t(w.nw); ox += blockDim.x) {
+            const ResizeTap t = taps[w.htap_base + ox];
+            const float *ws = weights + t.woff;
+            const float *s = s_row + size_t(t.left) * nc;
+            uint8_t *d = drow + size_t(ox) * nc;
+            if (nc == 3) {
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+                for (int k = 0; k < t.n; k++) {
+                    const float wk = ws[k], s0 = s[3 * k], s1 = s[3 * k + 1], s2 = s[3 * k + 2];
+                    a0 = __fadd_rn(a0, __fmul_rn(s0, wk)); a1 = __fadd_rn(a1, __fmul_rn(s1, wk)); a2 = __fadd_rn(a2, __fmul_rn(s2, wk));
+                }
+                d[0] = lanczos_round(a0); d[1] = lanczos_round(a1); d[2] = lanczos_round(a2);
+                continue;
+            }
+            for (uint32_t c = 0; c < nc; c++) {
+                float acc = 0.0f;
+                for (int k = 0; k < t.n; k++) acc = __fadd_rn(acc, __fmul_rn(s[size_t(k) * nc + c], ws[k]));
+                d[c] = lanczos_round(acc);
+            }
+        }
+    }
+}
+bool resize_is_fused(uint32_t max_row_in) { return max_row_in <= uint32_t(CSH_RZ_CAP_L) && !getenv("CSH_RESIZE_TWO_PASS"); }
+
 // RGB -> full-resolution component planes (jccolor.c rgb_ycc_convert); pitch = the luma plane's padded width
 __global__ void __launch_bounds__(256) k_rgb_to_planes(const ImgDesc *imgs, const ResizeWork *work, const uint8_t *rgb, uint8_t *planes) {
     const ResizeWork w = work[blockIdx.y];
@@ -149,8 +216,13 @@ void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, 
     (void)max_tmp;
     if (!nwork) return;
     CSH_LAUNCH(k_planes_to_rgb, dim3((max_src_px + 255) / 256, nwork), dim3(256), st, imgs, work, planes, rgb);
-    CSH_LAUNCH(k_lanczos_v, dim3((max_row_in + 1023) / 1024, max_nh, nwork), dim3(256), st, imgs, work, taps, weights, rgb, tmp);
-    CSH_LAUNCH(k_lanczos_h, dim3((max_out_w + 255) / 256, max_nh, nwork), dim3(256), st, imgs, work, taps, weights, tmp, rgb);
+    if (resize_is_fused(max_row_in)) {   // (source and result lie in different stretches of the RGB pool: rgb_src_off / rgb_dst_off)
+        if (max_row_in <= uint32_t(CSH_RZ_CAP_S)) CSH_LAUNCH_PHASED(k_lanczos_fused<CSH_RZ_CAP_S>, 2, dim3(max_nh, nwork), dim3(256), st, imgs, work, taps, weights, rgb, rgb);
+        else CSH_LAUNCH_PHASED(k_lanczos_fused<CSH_RZ_CAP_L>, 2, dim3(max_nh, nwork), dim3(256), st, imgs, work, taps, weights, rgb, rgb);
+    } else {
+        CSH_LAUNCH(k_lanczos_v, dim3((max_row_in + 1023) / 1024, max_nh, nwork), dim3(256), st, imgs, work, taps, weights, rgb, tmp);
+        CSH_LAUNCH(k_lanczos_h, dim3((max_out_w + 255) / 256, max_nh, nwork), dim3(256), st, imgs, work, taps, weights, tmp, rgb);
+    }
     if (to_planes) CSH_LAUNCH(k_rgb_to_planes, dim3(unsigned((max_dst + 255) / 256), nwork), dim3(256), st, imgs, work, rgb, planes);   // only the JPEG encoder reads planes; the WebP / PNG rows take the RGB
 }
 

@@ -69,6 +69,7 @@ void launch_resample_fdct_420(hipStream_t st, const ImgDesc *imgs, const PlaneWo
 void launch_fix_dummy(hipStream_t st, const ImgDesc *imgs, int nimg, int max_blocks, int16_t *coef_out);
 
 // resize branch (k_resize.hip): decoded planes -> RGB -> Lanczos3 (f32, image-rs order) -> full-resolution YCbCr planes
+bool resize_is_fused(uint32_t max_row_in);   // both Lanczos passes in one kernel, no f32 intermediate image (the batch's widest source row fits LDS)
 void launch_resize(hipStream_t st, const ImgDesc *imgs, const ResizeWork *work, int nwork, const ResizeTap *taps, const float *weights,
                    uint8_t *planes, uint8_t *rgb, float *tmp, uint32_t max_src_px, uint64_t max_tmp, uint64_t max_dst, uint32_t max_row_in, uint32_t max_out_w, uint32_t max_nh, bool to_planes);
 

@@ -1299,7 +1299,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             b->d_hsets.upload(b->hsets, st) || b->d_phsets.upload(b->phsets, st) || (b->use4 && b->d_phsets4.upload(b->phsets4, st)) || b->d_quants.upload(b->quants, st) || b->d_pwork.upload(b->pwork, st) ||
             b->d_script.upload(b->script, st) || b->d_swork.upload(b->swork, st) || b->d_slot_work.alloc(size_t(b->nslots) + 1) || b->d_slots.alloc(size_t(b->nslots) + 1) || b->d_plans.upload(b->plans, st) || b->d_echunks.upload(b->echunks, st) || b->d_hdr.upload(b->hdr_pool, st) ||
             b->d_hdr_off.upload(b->hdr_off, st) || b->d_pscans.upload(b->pscans, st) || b->d_rwork.upload(b->rwork, st) || b->d_rtaps.upload(b->rtaps, st) ||
-            b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc(b->tmp_floats + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
+            b->d_rweights.upload(b->rweights, st) || b->d_rgb.alloc(b->rgb_bytes + 64) || b->d_rtmp.alloc((resize_is_fused(b->max_row_in) ? 0 : b->tmp_floats) + 16) || b->d_need_seq_init.upload(b->need_seq_init, st))
             return CS_ERR_NO_DEVICE;
         {
             size_t nchunks = b->bits_pool.size() / 64 + 1, nst = size_t(b->total_sub) + b->pscans.size() + 1;

@@ -425,6 +425,13 @@ def test_emul_resize_lanczos3(api, ss):
     with pytest.raises(package().CaesiumError) as e:
         api.compress_in_memory(src, params(width=50, jpeg_optimize=True))
     assert e.value.code == 10201
+    # the two Lanczos passes as separate kernels with the f32 image between them (what rows too wide for LDS still take): the same bytes as the fused kernel
+    os.environ["CSH_RESIZE_TWO_PASS"] = "1"
+    try:
+        for (w, h) in [(150, 0), (97, 201), (333, 0)]:
+            assert api.compress_in_memory(src, params(width=w, height=h)) == oracle_resized(src, w, h), (w, h)
+    finally:
+        del os.environ["CSH_RESIZE_TWO_PASS"]
 
 
 def test_emul_sequential_output(api):
