@@ -532,7 +532,8 @@ int run(const Options &o) {
     const auto t_start = now();
     // the runtime and the device context start while the tree is scanned and read (a cold process pays ~0.15 s for them in front of its first kernel)
     std::vector<std::thread> warm;
-    if (!o.dry_run) for (int d = 0; d < std::max(1, o.gpus); d++) warm.emplace_back([d] { csh_warmup(d); });
+    const char *wu = getenv("CSH_CLI_WARMUP");
+    if (!o.dry_run && !(wu && !strcmp(wu, "0"))) for (int d = 0; d < std::max(1, o.gpus); d++) warm.emplace_back([d] { csh_warmup(d); });
     struct JoinWarm { std::vector<std::thread> &t; ~JoinWarm() { for (auto &x : t) if (x.joinable()) x.join(); } } join_warm{warm};
     std::optional<fs::path> base;
     std::vector<fs::path> files;
@@ -686,9 +687,10 @@ int run(const Options &o) {
             }
         }
         int ndev = std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
-        // three host threads per device, each with its own batches: while one batch is in its kernels another is being parsed and
-        // uploaded and a third fetched (separate streams; the boundary call is thread-safe)
-        const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 3;
+        // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being parsed and uploaded or
+        // fetched and written (separate streams; the boundary call is thread-safe).  A third in flight helps a warm caller of the library (capi.cpp: 3); a cold
+        // process pays for every batch's pools once, and the third set of them costs what it gains (2048 files: 0.88-0.98 s with 2, 0.94-0.98 s with 3)
+        const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 2;
         const size_t nworkers = size_t(ndev) * per_dev;
         parallel_for(nworkers, nworkers, [&](size_t worker) {
             const size_t dev = worker % size_t(ndev);

@@ -28,7 +28,10 @@ PY
   rm -rf gpurun_out/pmc_sq
 done
 python tools/prog_bench.py 512 > gpurun_out/r04_prog_bench.txt 2>&1
+CSH_PROG_PAR=1 python tools/prog_bench.py 512 2>&1 | grep progressive | sed 's/^/CSH_PROG_PAR=1  /' >> gpurun_out/r04_prog_bench.txt
 CSH_PROG_PAR=0 python tools/prog_bench.py 512 2>&1 | grep progressive | sed 's/^/CSH_PROG_PAR=0  /' >> gpurun_out/r04_prog_bench.txt
+python tools/prog_bench.py 2048 2>&1 | grep progressive >> gpurun_out/r04_prog_bench.txt
+python tools/boundary_probe.py 2048 > gpurun_out/r04_boundary_probe.txt 2>&1
 python tools/trellis_probe.py 1024 64 > gpurun_out/r04_trellis_probe.txt 2>&1
 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err
 head -c 1200 gpurun_out/r04_bench_default.json
