@@ -19,6 +19,7 @@
 // chunk, and k_pack turns a chunk's tokens into bits in LDS and moves them to their final place with one shifted copy.
 // Passes: tokens(+flags+stats) -> runs -> optimal tables -> chunk sizes -> exclusive scan -> pack.
 #include "kernels.h"
+#include "wave.h"
 
 namespace csh {
 
@@ -735,142 +736,90 @@ __global__ void __launch_bounds__(64) k_ac_runs_long(EncCtx c) {
 // ---- pass D: optimal Huffman tables (libjpeg jpeg_gen_optimal_table behaviour).
 // The merge loop runs over the COMPACTED list of used symbols (ascending symbol order, pseudo-symbol 256 last), which
 // preserves libjpeg's tie-breaking ("least frequency, ties to the larger symbol") while doing nnz^2 instead of 257*nnz work.
-#ifdef CSH_EMUL
-// emulation build: the plain serial form, one lane per table (the statement of the algorithm the wave kernel must match)
-__global__ void k_gen_tables(DevEncTable *tables, int ntables) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntables) return;
-    DevEncTable &T = tables[t];
-    uint32_t freq[257];
-    int16_t symof[257], codesize[257], others[257];
-    uint8_t bits[33];
-    int n = 0;
-    for (int i = 0; i < 256; i++) { uint32_t f = T.freq[i]; if (f) { freq[n] = f; symof[n] = int16_t(i); n++; } }
-    freq[n] = 1; symof[n] = 256; n++;   // reserved code point: guarantees no all-ones code
-    for (int i = 0; i < n; i++) { codesize[i] = 0; others[i] = -1; }
-    for (int i = 0; i < 33; i++) bits[i] = 0;
-    for (;;) {
-        int c1 = -1, c2 = -1;
-        uint32_t v = 0xFFFFFFFFu;
-        for (int i = 0; i < n; i++) if (freq[i] && freq[i] <= v) { v = freq[i]; c1 = i; }
-        v = 0xFFFFFFFFu;
-        for (int i = 0; i < n; i++) if (freq[i] && freq[i] <= v && i != c1) { v = freq[i]; c2 = i; }
-        if (c2 < 0) break;
-        freq[c1] += freq[c2]; freq[c2] = 0;
-        codesize[c1]++; while (others[c1] >= 0) { c1 = others[c1]; codesize[c1]++; }
-        others[c1] = int16_t(c2);
-        codesize[c2]++; while (others[c2] >= 0) { c2 = others[c2]; codesize[c2]++; }
-    }
-    for (int i = 0; i < n; i++) if (codesize[i]) bits[codesize[i] > 32 ? 32 : codesize[i]]++;
-    for (int i = 32; i > 16; i--)
-        while (bits[i] > 0) {
-            int j = i - 2; while (bits[j] == 0) j--;
-            bits[i] -= 2; bits[i - 1]++; bits[j + 1] += 2; bits[j]--;
-        }
-    int i = 16; while (i > 0 && bits[i] == 0) i--;
-    if (i > 0) bits[i]--;
-    for (int l = 0; l <= 16; l++) T.bits[l] = l ? bits[l] : 0;
-    int p = 0;
-    for (int l = 1; l <= 32; l++) for (int s = 0; s < n - 1; s++) if (codesize[s] == l) T.vals[p++] = uint8_t(symof[s]);
-    T.nsym = p;
-    for (int s = 0; s < 256; s++) { T.size[s] = 0; T.code[s] = 0; }
-    int code = 0; p = 0;
-    for (int l = 1; l <= 16; l++) { for (int k2 = 0; k2 < T.bits[l]; k2++, p++) { T.code[T.vals[p]] = uint16_t(code++); T.size[T.vals[p]] = uint8_t(l); } code <<= 1; }
-    for (int s = 0; s < 256; s++) T.lut[s] = (uint32_t(T.size[s]) << 16) | T.code[s];
-}
-#else
-// product build: one WAVE per table.  Entry e of the compacted list lives in lane e & 63, slot e >> 6 (registers).  A merge
-// is two wave-wide arg-min reductions (key = freq << 32 | ~index: least frequency, ties to the larger index) and one
-// data-parallel update: instead of walking libjpeg's `others` chain, every entry carries the id of the tree it belongs to
-// and all entries of the two merged trees bump their code size at once -- the same code sizes, without the serial chain.
-#define CSH_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-__device__ __forceinline__ static uint64_t wave_min_u64(uint64_t v) {
-    CSH_UNROLL
-    for (int o = 32; o >= 1; o >>= 1) {
-        uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(v)), o, 64)), hi = uint32_t(__shfl_xor(int(uint32_t(v >> 32)), o, 64));
-        uint64_t x = (uint64_t(hi) << 32) | lo;
-        v = x < v ? x : v;
-    }
-    return v;
-}
-__global__ void __launch_bounds__(256) k_gen_tables(DevEncTable *tables, int ntables) {
-    __shared__ uint32_t s_freq[4][260];
-    __shared__ uint16_t s_sym[4][260], s_grp[4][260], s_cs[4][260], s_code[4][256];
-    __shared__ uint8_t s_size[4][256], s_vals[4][256];
-    __shared__ uint32_t s_bits[4][34];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// One WAVE per table, written once for both builds (wave.h: LV<T> per-lane values, LFOR "for every lane"; the emulation plays the wave's lanes in a loop).
+// Entry e of the compacted list lives in lane e & 63, slot e >> 6 (registers).  A merge is two wave-wide arg-min reductions (key = freq << 32 | ~index:
+// least frequency, ties to the larger index) and one data-parallel update: instead of walking libjpeg's `others` chain, every entry carries the id of the
+// tree it belongs to and all entries of the two merged trees bump their code size at once -- the same code sizes, without the serial chain.
+__global__ void __launch_bounds__(4 * CSP_WAVE_THREADS) k_gen_tables(DevEncTable *tables, int ntables) {
+    CSH_SHARED uint32_t s_freq[4][260];
+    CSH_SHARED uint16_t s_sym[4][260], s_grp[4][260], s_cs[4][260], s_code[4][256];
+    CSH_SHARED uint8_t s_size[4][256], s_vals[4][256];
+    CSH_SHARED uint32_t s_bits[4][34];
+    const int wv = int(threadIdx.x) / CSP_WAVE_THREADS;
     const int t = blockIdx.x * 4 + wv;
     if (t >= ntables) return;   // whole wave: only wave-level synchronisation is used below
     DevEncTable &T = tables[t];
     uint32_t *freq0 = s_freq[wv]; uint16_t *symof = s_sym[wv], *grp = s_grp[wv], *csz = s_cs[wv], *ocode = s_code[wv];
     uint8_t *osize = s_size[wv], *ovals = s_vals[wv];
     uint32_t *bits = s_bits[wv];
-    const uint64_t lt = (1ull << lane) - 1ull;
     // compact the used symbols, ascending
     int n = 0;
-    CSH_UNROLL
     for (int j = 0; j < 4; j++) {
-        uint32_t f = T.freq[lane + 64 * j];
-        uint64_t m = __ballot(f != 0);
-        if (f) { int pos = n + __popcll(m & lt); freq0[pos] = f; symof[pos] = uint16_t(lane + 64 * j); }
-        n += __popcll(m);
+        LV<uint32_t> fj;
+        LFOR(l) fj[l] = T.freq[l + 64 * j];
+        const uint64_t m = lballot([&](int l) { return fj[l] != 0; });
+        LFOR(l) if (fj[l]) { const int pos = n + int(popc64(m & lanes_below(l))); freq0[pos] = fj[l]; symof[pos] = uint16_t(l + 64 * j); }
+        n += int(popc64(m));
     }
-    if (lane == 0) { freq0[n] = 1; symof[n] = 256; }   // reserved code point: guarantees no all-ones code
+    LFOR(l) if (l == 0) { freq0[n] = 1; symof[n] = 256; }   // reserved code point: guarantees no all-ones code
     n++;
-    if (lane < 34) bits[lane] = 0;
-    for (int i = lane; i < 256; i += 64) { ocode[i] = 0; osize[i] = 0; ovals[i] = 0; }
-    CSH_WAVE_SYNC();
-    uint32_t f[5]; int cs[5], g[5];
-    CSH_UNROLL
-    for (int j = 0; j < 5; j++) { int e = lane + 64 * j; f[j] = e < n ? freq0[e] : 0u; cs[j] = 0; g[j] = e; if (e < n) grp[e] = uint16_t(e); }
-    CSH_WAVE_SYNC();
+    LFOR(l) {
+        if (l < 34) bits[l] = 0;
+        for (int i = l; i < 256; i += 64) { ocode[i] = 0; osize[i] = 0; ovals[i] = 0; }
+    }
+    CSP_WAVE_SYNC();
+    LV<uint32_t> f[5], cs[5], g[5];
+    for (int j = 0; j < 5; j++) LFOR(l) { const int e = l + 64 * j; f[j][l] = e < n ? freq0[e] : 0u; cs[j][l] = 0; g[j][l] = uint32_t(e); if (e < n) grp[e] = uint16_t(e); }
+    CSP_WAVE_SYNC();
     for (;;) {
-        uint64_t k1 = ~0ull;
-        CSH_UNROLL
-        for (int j = 0; j < 5; j++) { uint64_t k = (uint64_t(f[j]) << 32) | uint32_t(~uint32_t(lane + 64 * j)); if (f[j] && k < k1) k1 = k; }
-        k1 = wave_min_u64(k1);
+        LV<uint64_t> key;
+        LFOR(l) {
+            uint64_t k1 = ~0ull;
+            for (int j = 0; j < 5; j++) { const uint64_t k = (uint64_t(f[j][l]) << 32) | uint32_t(~uint32_t(l + 64 * j)); if (f[j][l] && k < k1) k1 = k; }
+            key[l] = k1;
+        }
+        const uint64_t k1 = lmin64(key);
         const int c1 = int(~uint32_t(k1));
-        uint64_t k2 = ~0ull;
-        CSH_UNROLL
-        for (int j = 0; j < 5; j++) { uint64_t k = (uint64_t(f[j]) << 32) | uint32_t(~uint32_t(lane + 64 * j)); if (f[j] && lane + 64 * j != c1 && k < k2) k2 = k; }
-        k2 = wave_min_u64(k2);
+        LFOR(l) {
+            uint64_t k2 = ~0ull;
+            for (int j = 0; j < 5; j++) { const uint64_t k = (uint64_t(f[j][l]) << 32) | uint32_t(~uint32_t(l + 64 * j)); if (f[j][l] && l + 64 * j != c1 && k < k2) k2 = k; }
+            key[l] = k2;
+        }
+        const uint64_t k2 = lmin64(key);
         if (k2 == ~0ull) break;
         const int c2 = int(~uint32_t(k2));
         const uint32_t f2 = uint32_t(k2 >> 32);
-        const int g1 = grp[c1], g2 = grp[c2];
-        CSH_WAVE_SYNC();   // everyone has read the tree ids before they are rewritten
-        CSH_UNROLL
-        for (int j = 0; j < 5; j++) {
-            const int e = lane + 64 * j;
-            if (e == c1) f[j] += f2;
-            if (e == c2) f[j] = 0;
-            if (e < n && (g[j] == g1 || g[j] == g2)) { cs[j]++; if (g[j] != g1) { g[j] = g1; grp[e] = uint16_t(g1); } }
+        const uint32_t g1 = grp[c1], g2 = grp[c2];
+        CSP_WAVE_SYNC();   // everyone has read the tree ids before they are rewritten
+        for (int j = 0; j < 5; j++) LFOR(l) {
+            const int e = l + 64 * j;
+            if (e == c1) f[j][l] += f2;
+            if (e == c2) f[j][l] = 0;
+            if (e < n && (g[j][l] == g1 || g[j][l] == g2)) { cs[j][l]++; if (g[j][l] != g1) { g[j][l] = g1; grp[e] = uint16_t(g1); } }
         }
-        CSH_WAVE_SYNC();
+        CSP_WAVE_SYNC();
     }
     // code-length counts (of every entry, the reserved one included), then libjpeg's length limiting
-    CSH_UNROLL
-    for (int j = 0; j < 5; j++) {
-        const int e = lane + 64 * j;
+    for (int j = 0; j < 5; j++) LFOR(l) {
+        const int e = l + 64 * j;
         if (e < n) {
-            csz[e] = uint16_t(cs[j]);
-            if (cs[j]) atomicAdd(&bits[cs[j] > 32 ? 32 : cs[j]], 1u);
-            if (e < n - 1 && cs[j] >= 1 && cs[j] <= 32) atomicAdd(&bits[33], 1u);   // listed symbols
+            csz[e] = uint16_t(cs[j][l]);
+            if (cs[j][l]) atomicAdd(&bits[cs[j][l] > 32 ? 32 : cs[j][l]], 1u);
+            if (e < n - 1 && cs[j][l] >= 1 && cs[j][l] <= 32) atomicAdd(&bits[33], 1u);   // listed symbols
         }
     }
-    CSH_WAVE_SYNC();
+    CSP_WAVE_SYNC();
     // order of the symbols: by code size, then by symbol (the reserved entry n-1 is not listed); sizes above 32 are not coded
     {
-        int before[5] = {0, 0, 0, 0, 0};
+        LV<uint32_t> before[5];
+        for (int j = 0; j < 5; j++) LFOR(l) before[j][l] = 0;
         for (int q = 0; q < n - 1; q++) {
-            const int cq = csz[q];
-            CSH_UNROLL
-            for (int j = 0; j < 5; j++) before[j] += (cq >= 1 && cq <= 32 && (cq < cs[j] || (cq == cs[j] && q < lane + 64 * j))) ? 1 : 0;
+            const uint32_t cq = csz[q];
+            for (int j = 0; j < 5; j++) LFOR(l) before[j][l] += (cq >= 1 && cq <= 32 && (cq < cs[j][l] || (cq == cs[j][l] && q < l + 64 * j))) ? 1u : 0u;
         }
-        CSH_UNROLL
-        for (int j = 0; j < 5; j++) { const int e = lane + 64 * j; if (e < n - 1 && cs[j] >= 1 && cs[j] <= 32) ovals[before[j]] = uint8_t(symof[e]); }
+        for (int j = 0; j < 5; j++) LFOR(l) { const int e = l + 64 * j; if (e < n - 1 && cs[j][l] >= 1 && cs[j][l] <= 32) ovals[before[j][l]] = uint8_t(symof[e]); }
     }
-    if (lane == 0) {
+    LFOR(l) if (l == 0) {
         for (int i = 32; i > 16; i--)
             while (bits[i] > 0) {
                 int j = i - 2; while (bits[j] == 0) j--;
@@ -879,10 +828,10 @@ __global__ void __launch_bounds__(256) k_gen_tables(DevEncTable *tables, int nta
         int i = 16; while (i > 0 && bits[i] == 0) i--;
         if (i > 0) bits[i]--;
     }
-    CSH_WAVE_SYNC();
+    CSP_WAVE_SYNC();
     const int nsym = int(bits[33]);
     // canonical codes for the listed symbols: position p has the length l with start[l] <= p < start[l] + bits[l]
-    for (int p = lane; p < nsym; p += 64) {
+    LFOR(lane) for (int p = lane; p < nsym; p += 64) {
         int code = 0, st = 0, len = 0, mine = 0;
         for (int l = 1; l <= 16; l++) {
             const int bl = int(bits[l]);
@@ -891,18 +840,15 @@ __global__ void __launch_bounds__(256) k_gen_tables(DevEncTable *tables, int nta
         }
         if (len) { ocode[ovals[p]] = uint16_t(mine); osize[ovals[p]] = uint8_t(len); }
     }
-    CSH_WAVE_SYNC();
-    if (lane <= 16) T.bits[lane] = lane ? uint8_t(bits[lane]) : 0;
-    if (lane == 0) T.nsym = nsym;
-    for (int i = lane; i < 256; i += 64) { T.vals[i] = ovals[i]; T.code[i] = ocode[i]; T.size[i] = osize[i]; T.lut[i] = (uint32_t(osize[i]) << 16) | ocode[i]; }
+    CSP_WAVE_SYNC();
+    LFOR(lane) {
+        if (lane <= 16) T.bits[lane] = lane ? uint8_t(bits[lane]) : 0;
+        if (lane == 0) T.nsym = nsym;
+        for (int i = lane; i < 256; i += 64) { T.vals[i] = ovals[i]; T.code[i] = ocode[i]; T.size[i] = osize[i]; T.lut[i] = (uint32_t(osize[i]) << 16) | ocode[i]; }
+    }
 }
-#endif
 void launch_gen_tables(hipStream_t st, DevEncTable *tables, int ntables) {
-#ifdef CSH_EMUL
-    if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 63) / 64), dim3(64), st, tables, ntables);
-#else
-    if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 3) / 4), dim3(256), st, tables, ntables);
-#endif
+    if (ntables) CSH_LAUNCH(k_gen_tables, dim3((ntables + 3) / 4), dim3(4 * CSP_WAVE_THREADS), st, tables, ntables);
 }
 
 // ------------------------------------------------------------------------------------------------ tokens -> bits

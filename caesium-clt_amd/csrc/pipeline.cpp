@@ -1497,7 +1497,7 @@ static int run_rgb_only(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
 //   after ST_2B  split at 12, [stop unless it leads].  Not stopped: the split at 18 (ST_2C)
 //   after ST_2C  split at 18.  Then every file's list of scans.
 // Candidate numbering: cso_search_progression's.
-static const int kSplit[5] = {2, 8, 5, 12, 18};
+
 enum { kLumaSplit0 = 12, kNLuma = 23, kChromaBase = 26, kChromaSplit0 = 42 };
 // the work item that holds candidate `cand` of an image: its own, or -- the split at 8 -- stage 1's band scans at the chosen Al
 static int search_work(const csh_batch::SearchImg &si, int cand) {

@@ -62,5 +62,22 @@ __device__ __forceinline__ static uint32_t lsum32(const LV<uint32_t> &x) {
 #define CSH_WPERSIST(T, name, N, NWAVES) T name[N]
 #endif
 __device__ __forceinline__ static uint32_t popc64(uint64_t m) { return uint32_t(__popcll((unsigned long long)m)); }
+// minimum over the lanes, in every lane
+__device__ __forceinline__ static uint64_t lmin64(const LV<uint64_t> &x) {
+#ifdef CSH_EMUL
+    uint64_t m = x.v[0];
+    for (int j = 1; j < 64; j++) m = x.v[j] < m ? x.v[j] : m;
+    return m;
+#else
+    uint64_t v = x.v;
+    CSH_UNROLL
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(v)), o, 64)), hi = uint32_t(__shfl_xor(int(uint32_t(v >> 32)), o, 64));
+        const uint64_t y = (uint64_t(hi) << 32) | lo;
+        v = y < v ? y : v;
+    }
+    return v;
+#endif
+}
 
 }  // namespace csh
