@@ -533,7 +533,7 @@ int run(const Options &o) {
     // the runtime and the device context start while the tree is scanned and read (a cold process pays ~0.15 s for them in front of its first kernel)
     std::vector<std::thread> warm;
     const char *wu = getenv("CSH_CLI_WARMUP");
-    if (!o.dry_run && !(wu && !strcmp(wu, "0"))) for (int d = 0; d < std::max(1, o.gpus); d++) warm.emplace_back([d] { csh_warmup(d); });
+    if (!o.dry_run && !(wu && !strcmp(wu, "0"))) for (int d = 0; d < (getenv("CSH_CLI_SAME_DEVICE") ? 1 : std::max(1, o.gpus)); d++) warm.emplace_back([d] { csh_warmup(d); });
     struct JoinWarm { std::vector<std::thread> &t; ~JoinWarm() { for (auto &x : t) if (x.joinable()) x.join(); } } join_warm{warm};
     std::optional<fs::path> base;
     std::vector<fs::path> files;
@@ -686,14 +686,16 @@ int run(const Options &o) {
                 batches.emplace_back(g.second.begin() + k, g.second.begin() + k + n);
             }
         }
-        int ndev = std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
+        // CSH_CLI_SAME_DEVICE=1 (tests): --gpus N deals the batches over N device slots that are all device 0 -- the code path of N GPUs on a box that has one
+        const bool same_device = getenv("CSH_CLI_SAME_DEVICE") != nullptr;
+        int ndev = same_device ? std::max(1, o.gpus) : std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
         // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being parsed and uploaded or
         // fetched and written (separate streams; the boundary call is thread-safe).  A third in flight helps a warm caller of the library (capi.cpp: 3); a cold
         // process pays for every batch's pools once, and the third set of them costs what it gains (2048 files: 0.88-0.98 s with 2, 0.94-0.98 s with 3)
         const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 2;
         const size_t nworkers = size_t(ndev) * per_dev;
         parallel_for(nworkers, nworkers, [&](size_t worker) {
-            const size_t dev = worker % size_t(ndev);
+            const size_t dev = same_device ? 0 : worker % size_t(ndev);
             for (size_t bi = worker; bi < batches.size(); bi += nworkers) {
                 const std::vector<size_t> &idx = batches[bi];
                 std::vector<CByteArray> in(idx.size()), out(idx.size());

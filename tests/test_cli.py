@@ -503,6 +503,29 @@ def test_read_ahead_stops_when_an_output_is_a_later_input(tmp_path):
     assert (d / "a_z.jpg").read_bytes() == once and (d / "a_z_z.jpg").read_bytes() == oracle_lossy(once)
 
 
+def gpus_dealing(binary, tmp_path):
+    """--gpus 3 on a box with one device (CSH_CLI_SAME_DEVICE=1: three device slots, all device 0): the batches are dealt over 3 x CSH_CLI_WORKERS host threads,
+    small batches so that every slot gets several; files, JSON and order are those of the plain run"""
+    d = tmp_path / "gp_in"
+    d.mkdir()
+    srcs = [synth_jpeg(300 + i, 96 + 8 * (i % 3), 64, texture=10 + i) for i in range(23)]
+    for i, s in enumerate(srcs):
+        (d / f"g{i:02d}.jpg").write_bytes(s)
+    runs = []
+    for label, extra, env in (("one", [], {}), ("three", ["--gpus", "3"], {"CSH_CLI_SAME_DEVICE": "1", "CSH_CLI_BATCH": "2"})):
+        out = tmp_path / ("gp_" + label)
+        r = subprocess.run([binary, "-q", "75", "--json", "-o", str(out), *extra, str(d)], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        j = json.loads(r.stdout)
+        runs.append([(os.path.basename(f["original_path"]), f["status"], open(f["output_path"], "rb").read()) for f in j["files"]])
+    assert runs[0] == runs[1] and len(runs[0]) == 23
+    assert [x[2] for x in runs[0]] == [oracle_lossy(s, 75) for s in srcs]
+
+
+def test_gpus_flag_deals_batches_over_device_slots(tmp_path):
+    gpus_dealing(EMUL_CLI, tmp_path)
+
+
 def test_whole_program_emulated(tree, tmp_path):
     end_to_end(EMUL_CLI, tree, tmp_path)
     lossy_png_step(EMUL_CLI, tmp_path)
@@ -516,6 +539,7 @@ def test_whole_program_emulated(tree, tmp_path):
 def test_whole_program_on_device(tree, tmp_path):
     assert os.path.exists(PRODUCT_CLI), "caesium-clt_amd/bin/caesiumclt is not built (python -c 'import __graft_entry__ as g; g.build()')"
     end_to_end(PRODUCT_CLI, tree, tmp_path)
+    gpus_dealing(PRODUCT_CLI, tmp_path)
     # many small files across two parameter groups in one run, order preserved
     many = tmp_path / "many"
     many.mkdir()
