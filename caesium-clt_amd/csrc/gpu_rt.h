@@ -127,6 +127,7 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new csh_emul_event
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return 0;
 }

@@ -15,6 +15,8 @@
 #include "../../include/vp8_tables.h"
 #include "png_wave.h"
 #include "webp_kernels.h"
+#include "devmem.hpp"
+#include "kernels.h"
 
 namespace csw {
 using namespace csp;   // LFOR / LV / lsum / coherent_load (png_wave.h)
@@ -589,11 +591,23 @@ struct CodeSink {
 };
 struct StatSink {
     uint32_t *cnt;   // [1056][2] in LDS
+    uint32_t nd;     // decisions of this block (adaptive and fixed-probability ones): what its stretch of the decision stream will hold
     __device__ __forceinline__ void begin(const int16_t *) {}
     __device__ __forceinline__ int lev(const int16_t *lv, int i) const { return lv[i]; }   // lanes = blocks here: every lane reads its own block
     __device__ __forceinline__ int last_nonzero(const int16_t *lv, int first) const { int last = -1; for (int i = first; i < 16; i++) if (lv[i]) last = i; return last; }
-    __device__ __forceinline__ void ad(int bit, int idx) { atomicAdd(&cnt[2 * idx + (bit ? 1 : 0)], 1u); }
-    __device__ __forceinline__ void fx(int, int) {}
+    __device__ __forceinline__ void ad(int bit, int idx) { atomicAdd(&cnt[2 * idx + (bit ? 1 : 0)], 1u); nd++; }
+    __device__ __forceinline__ void fx(int, int) { nd++; }
+};
+// the same walk writing its decisions down: (bit, probability) pairs, two bytes each, in the order the coder takes them -- the probability is resolved here
+// (the frame's table is final by now), so the coder behind it needs neither the levels nor the tables (k_webp_bool)
+struct WriteSink {
+    const uint8_t *probs;   // LDS
+    uint16_t *out;
+    __device__ __forceinline__ void begin(const int16_t *) {}
+    __device__ __forceinline__ int lev(const int16_t *lv, int i) const { return lv[i]; }
+    __device__ __forceinline__ int last_nonzero(const int16_t *lv, int first) const { int last = -1; for (int i = first; i < 16; i++) if (lv[i]) last = i; return last; }
+    __device__ __forceinline__ void ad(int bit, int idx) { *out++ = uint16_t((bit ? 1u : 0u) | (uint32_t(probs[idx]) << 1)); }
+    __device__ __forceinline__ void fx(int bit, int prob) { *out++ = uint16_t((bit ? 1u : 0u) | (uint32_t(prob) << 1)); }
 };
 template <class S>
 __device__ static int put_coeffs(S &e, int type, int ctx, const int16_t *lv, int first) {
@@ -663,7 +677,15 @@ __device__ __forceinline__ static void block_info(int k, uint32_t cur, uint32_t 
 // at a time (the contexts come from the masks, so all blocks of all macroblocks are independent); LDS counters, then one
 // atomic per non-zero counter into the image's totals
 enum { WEBP_NPROB = 4 * 8 * 3 * 11 };
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *imgs, const int16_t *levels, uint32_t *stats) {
+// where macroblock (mx, my) stands among the macroblocks of its picture in CHAIN order: the rows of token partition 0 first (rows 0, P, 2P ..), then
+// partition 1's -- the order in which the decision stream holds them
+__device__ __forceinline__ static uint32_t webp_chain_index(int mbw, int mbh, int mx, int my) {
+    const int P = webp_parts(mbh), p = my % P;
+    int rows_before = 0;
+    for (int q = 0; q < p; q++) rows_before += (mbh - q + P - 1) / P;
+    return uint32_t((rows_before + my / P) * mbw + mx);
+}
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *imgs, const int16_t *levels, uint32_t *stats, const uint64_t *mb_base, uint32_t *mb_cnt, uint16_t *blk_cnt) {
     CSH_SHARED uint32_t cnt[2 * WEBP_NPROB];
     const WebpImg im = imgs[blockIdx.y];
     const int mbw = int(im.mbw), my = int(blockIdx.x);
@@ -675,12 +697,22 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *
         const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
         const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
         const bool i4 = L[MB_INFO + 2] == 4;
-        LFOR(l) if (l < 25 && !(i4 && l == 0)) {   // no Y2 block in an i4x4 macroblock
-            int type, first, ctx;
-            block_info(l, cur, top, left, i4, type, first, ctx);
-            StatSink sink{cnt};
-            put_coeffs(sink, type, ctx, L + l * 16, first);
+        LV<uint32_t> nd;
+        LFOR(l) {
+            nd[l] = 0;
+            if (l < 25 && !(i4 && l == 0)) {   // no Y2 block in an i4x4 macroblock
+                int type, first, ctx;
+                block_info(l, cur, top, left, i4, type, first, ctx);
+                StatSink sink{cnt, 0u};
+                put_coeffs(sink, type, ctx, L + l * 16, first);
+                nd[l] = sink.nd;
+            }
         }
+        // decisions per block and per macroblock, in chain order: the write pass (k_webp_decisions) places every block's stretch from them
+        const uint64_t at = mb_base[blockIdx.y] + webp_chain_index(mbw, int(im.mbh), mx, my);
+        uint32_t total;
+        (void)lscan(nd, total);
+        LFOR(l) { if (l < 32) blk_cnt[at * 32 + uint32_t(l)] = uint16_t(nd[l]); if (l == 0) mb_cnt[at] = total; }
     }
     CSP_WAVE_SYNC();
     uint32_t *dst = stats + size_t(im.image) * 2 * WEBP_NPROB;
@@ -852,6 +884,139 @@ __global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, cons
     }
 }
 
+// ---- the token partitions as decision streams (round 4).  The boolean coder is a serial chain per partition, and a wave that walks one chain on its
+// uniform side costs the chip's SCALAR issue rate: eight waves per picture, ~8 k scalar instructions per macroblock -- 137 ms per 1024 pictures, half of the
+// JPEG -> WebP path.  What is serial, though, is only the arithmetic coder; WHICH decisions it takes (the token tree over the levels, the contexts out of the
+// masks, the probabilities of the frame) is known for every block at once.  So:
+//   k_webp_stats      (the walk that counts the frame's statistics) also counts every block's decisions;
+//   an exclusive scan over the macroblocks in chain order gives every macroblock its place in the stream;
+//   k_webp_decisions  the same walk, lanes = the blocks of a macroblock, writes (bit, probability) pairs -- two bytes a decision;
+//   k_webp_bool       ONE LANE per partition runs the coder over its stretch of pairs: no tree, no table, no levels -- 64 chains to a wave on the vector unit.
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_decisions(const WebpImg *imgs, const int16_t *levels, const uint8_t *probs_all, const uint64_t *mb_base, const uint64_t *mb_off,
+                                                                      const uint16_t *blk_cnt, uint16_t *stream, const uint32_t *status) {
+    CSH_SHARED uint8_t s_probs[WEBP_NPROB];
+    const WebpImg im = imgs[blockIdx.y];
+    const int mbw = int(im.mbw), my = int(blockIdx.x);
+    if (my >= int(im.mbh) || status[im.image]) return;
+    const uint8_t *probs_g = probs_all + size_t(im.image) * WEBP_NPROB;
+    LFOR(l) for (int i = l; i < WEBP_NPROB; i += 64) s_probs[i] = probs_g[i];
+    CSP_WAVE_SYNC();
+    const int16_t *row = levels + im.lev_off + size_t(my) * mbw * WEBP_MB_REC;
+    for (int mx = 0; mx < mbw; mx++) {
+        const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
+        const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
+        const bool i4 = L[MB_INFO + 2] == 4;
+        const uint64_t at = mb_base[blockIdx.y] + webp_chain_index(mbw, int(im.mbh), mx, my);
+        LV<uint32_t> nd;
+        LFOR(l) nd[l] = l < 32 ? uint32_t(blk_cnt[at * 32 + uint32_t(l)]) : 0u;
+        uint32_t total;
+        const LV<uint32_t> ex = lscan(nd, total);
+        uint16_t *dst = stream + mb_off[at];
+        LFOR(l) if (l < 25 && !(i4 && l == 0)) {
+            int type, first, ctx;
+            block_info(l, cur, top, left, i4, type, first, ctx);
+            WriteSink sink{s_probs, dst + ex[l]};
+            put_coeffs(sink, type, ctx, L + l * 16, first);
+        }
+    }
+}
+// one lane = one chain (token partition `part` of picture `image`: the decisions of nmb macroblocks from chain-order macroblock `first` on)
+struct WebpChain { uint32_t image, part; uint64_t first, nmb; };
+struct BoolEncLane {   // the boolean coder (oracle: boolenc) with per-lane state.  Sixty-four of these run side by side in a wave, every lane at its own place in its own
+                       // chain, and whatever one lane branches into, the whole wave executes.  So: a decision is straight-line arithmetic (the renormalisation
+                       // shifts by 0 when none is due); the bits a decision completes stay in a 64-bit accumulator and leave on a FIXED schedule (flush() after
+                       // every fourth decision: every lane emits its zero to four complete bytes then -- the same digits the byte-at-a-time coder produces, a
+                       // carry that it would have patched into a written byte is simply added before the byte is written); and the output never READS (a carry
+                       // that does reach a written byte goes into the last one, which the lane still holds in a register)
+    uint8_t *buf;
+    uint32_t pos, cap;
+    int32_t range;
+    uint64_t value;
+    int run, nb_bits;
+    uint32_t last;
+    bool overflow;
+    __device__ __forceinline__ void init(uint8_t *b, uint32_t c) { buf = b; pos = 0; cap = c; run = 0; nb_bits = -8; overflow = false; range = 254; value = 0; last = 0; }
+    __device__ __forceinline__ void flush() {
+        while (nb_bits > 0) {
+            const int s = 8 + nb_bits;
+            const uint32_t bits = uint32_t(value >> s);   // eight bits and a carry
+            value -= uint64_t(bits) << s;
+            nb_bits -= 8;
+            if ((bits & 0xffu) != 0xffu) {
+                if (pos + uint32_t(run) + 1 > cap) { overflow = true; run = 0; nb_bits = -8; value = 0; return; }
+                if ((bits & 0x100u) && pos > 0) { last = (last + 1u) & 0xffu; buf[pos - 1] = uint8_t(last); }   // (the byte in front of a run of 0xff is never 0xff itself)
+                const uint8_t v = (bits & 0x100u) ? 0x00 : 0xff;
+                for (int k = 0; k < run; k++) buf[pos + uint32_t(k)] = v;
+                last = bits & 0xffu;
+                buf[pos + uint32_t(run)] = uint8_t(last);
+                pos += uint32_t(run) + 1; run = 0;
+            } else
+                run++;
+        }
+    }
+    __device__ __forceinline__ void put(int bit, int prob) {   // at most four of these between two flush(): 8 + 8 + 4 x 7 + 1 bits fit the accumulator many times over
+        const int32_t split = (range * prob) >> 8, m = -int32_t(bit != 0);
+        value += uint64_t(uint32_t((split + 1) & m));
+        range = split + ((range - 2 * split - 1) & m);               // bit ? range - split - 1 : split
+        const int shift = __clz(uint32_t(range + 1)) - 24;          // 0 for range >= 127: no renormalisation due
+        range = ((range + 1) << shift) - 1;
+        value <<= shift;
+        nb_bits += shift;
+    }
+    __device__ __forceinline__ void finish() {
+        flush();
+        for (int n = 9 - nb_bits; n > 0; n--) { put(0, 128); flush(); }
+        nb_bits = 0;
+        {   // the last byte, as the byte-at-a-time coder flushes it (nb_bits = 0: s = 8)
+            const int s = 8;
+            const uint32_t bits = uint32_t(value >> s);
+            value -= uint64_t(bits) << s;
+            nb_bits = -8;
+            if ((bits & 0xffu) != 0xffu) {
+                if (pos + uint32_t(run) + 1 > cap) { overflow = true; run = 0; return; }
+                if ((bits & 0x100u) && pos > 0) { last = (last + 1u) & 0xffu; buf[pos - 1] = uint8_t(last); }
+                const uint8_t v = (bits & 0x100u) ? 0x00 : 0xff;
+                for (int k = 0; k < run; k++) buf[pos + uint32_t(k)] = v;
+                last = bits & 0xffu;
+                buf[pos + uint32_t(run)] = uint8_t(last);
+                pos += uint32_t(run) + 1; run = 0;
+            } else
+                run++;
+        }
+    }
+};
+__global__ void __launch_bounds__(64) k_webp_bool(const WebpImg *imgs, const WebpChain *chains, uint32_t nchains, const uint64_t *mb_off, const uint16_t *stream, uint8_t *scratch,
+                                                  uint32_t *part_size, const uint32_t *status) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    const WebpChain ch = chains[c];
+    const WebpImg &im = imgs[ch.image];   // (chains are listed per WebpImg entry)
+    if (status[im.image]) return;
+    BoolEncLane e;
+    e.init(scratch + im.out_off + webp_hdr_cap(im) + ch.part * webp_part_cap(im), webp_part_cap(im));
+    const uint64_t d0 = mb_off[ch.first], d1 = mb_off[ch.first + ch.nmb];
+    // eight decisions to a 16-byte load, the next load in flight while these are coded (a lane's loads are its own: nothing hides their latency but this)
+    uint64_t d = d0;
+    for (; d < d1 && (d & 7u) && !e.overflow; d++) { const uint32_t v = stream[d]; e.put(int(v & 1u), int(v >> 1)); e.flush(); }
+    if (d + 8 <= d1 && !e.overflow) {
+        uint4 nxt = *reinterpret_cast<const uint4 *>(stream + d);
+        for (; d + 8 <= d1 && !e.overflow; d += 8) {
+            const uint4 cur = nxt;
+            if (d + 16 <= d1) nxt = *reinterpret_cast<const uint4 *>(stream + d + 8);
+            const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+            CSH_UNROLL
+            for (int k = 0; k < 4; k++) {
+                e.put(int(w[k] & 1u), int((w[k] >> 1) & 0x7FFFu));
+                e.put(int((w[k] >> 16) & 1u), int(w[k] >> 17));
+                if (k & 1) e.flush();
+            }
+        }
+    }
+    for (; d < d1 && !e.overflow; d++) { const uint32_t v = stream[d]; e.put(int(v & 1u), int(v >> 1)); e.flush(); }
+    e.finish();
+    part_size[size_t(im.image) * 9 + 1 + ch.part] = e.overflow ? 0xFFFFFFFFu : e.pos;
+}
+
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work) {
     if (nimg && max_luma) CSH_LAUNCH(k_webp_yuv, dim3((max_luma + 255) / 256, nimg), dim3(256), st, imgs, rgb, work);
 }
@@ -859,13 +1024,58 @@ void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_
     if (!nimg || !max_mbw || !max_mbh) return;
     for (uint32_t d = 0; d + 2 < max_mbw + 2 * max_mbh; d++) CSH_LAUNCH(k_webp_mb, dim3(max_mbh, unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, imgs, work, levels, int(d));
 }
-void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
-                      uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
+void launch_webp_code(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update,
+                      uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
     if (!nimg) return;
-    CSH_LAUNCH(k_webp_stats, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, stats);
+    const char *sw = getenv("CSH_WEBP_CHAINS");   // "1": every token partition on a wave of its own (k_webp_code), as before round 4
+    const bool streams = !(sw && !strcmp(sw, "1"));
+    // the macroblocks of the batch in chain order (picture by picture, inside a picture partition by partition) and the chains themselves
+    std::vector<uint64_t> base(size_t(nimg) + 1);
+    std::vector<WebpChain> chains;
+    uint64_t nmb = 0;
+    for (int i = 0; i < nimg; i++) {
+        const uint32_t mbw = himgs[i].mbw, mbh = himgs[i].mbh, P = uint32_t(mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1);   // webp_parts
+        base[size_t(i)] = nmb;
+        uint64_t first = nmb;
+        for (uint32_t p = 0; p < P; p++) { const uint64_t n = uint64_t((mbh - p + P - 1) / P) * mbw; chains.push_back(WebpChain{uint32_t(i), p, first, n}); first += n; }
+        nmb += uint64_t(mbw) * mbh;
+    }
+    base[size_t(nimg)] = nmb;
+    csh::DevBuf<uint64_t> d_base, d_off;
+    csh::DevBuf<uint32_t> d_cnt;
+    csh::DevBuf<uint16_t> d_blk, d_stream;
+    csh::DevBuf<WebpChain> d_chains;
+    csh::DevBuf<uint8_t> d_tmp;
+    const size_t tmp_bytes = csh::exclusive_scan_tmp_bytes(nmb);
+    if (d_base.upload(base, st) || d_chains.upload(chains, st) || d_cnt.alloc(nmb + 1) || d_off.alloc(nmb + 2) || d_blk.alloc((nmb + 1) * 32) || d_tmp.alloc(tmp_bytes + 64)) return;
+    CSH_LAUNCH(k_webp_stats, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, stats, d_base.p, d_cnt.p, d_blk.p);
     CSH_LAUNCH(k_webp_probs, dim3((WEBP_NPROB + 255) / 256, nimg), dim3(256), st, imgs, stats, probs, update);
-    CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
+    if (!streams) CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
+    else {
+        // the header partition (modes: one serial chain over the picture, still a wave's) beside the token path, on a stream of its own
+        hipStream_t side = st;
+        hipEvent_t fork = nullptr, join = nullptr;
+        const bool forked = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&fork) == hipSuccess && hipEventCreate(&join) == hipSuccess &&
+                            hipEventRecord(fork, st) == hipSuccess && hipStreamWaitEvent(side, fork, 0) == hipSuccess;
+        CSH_LAUNCH(k_webp_code, dim3(nimg, 1), dim3(CSP_WAVE_THREADS), forked ? side : st, imgs, levels, probs, update, scratch, part_size, status);
+        if (forked) (void)hipEventRecord(join, side);
+        csh::launch_exclusive_scan(st, d_cnt.p, d_off.p, nmb, d_tmp.p, tmp_bytes + 64);
+        uint64_t total = 0;
+        if (csh_copy_wait(&total, d_off.p + nmb, sizeof total, hipMemcpyDeviceToHost, st) == hipSuccess && !d_stream.alloc(size_t(total) + 64)) {
+            CSH_LAUNCH(k_webp_decisions, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, d_base.p, d_off.p, d_blk.p, d_stream.p, status);
+            const uint32_t nchains = uint32_t(chains.size());
+            CSH_LAUNCH(k_webp_bool, dim3((nchains + 63) / 64), dim3(64), st, imgs, d_chains.p, nchains, d_off.p, d_stream.p, scratch, part_size, status);
+        }
+        if (forked) (void)hipStreamWaitEvent(st, join, 0);
+        CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
+        (void)hipStreamSynchronize(st);   // the workspace goes back to the block cache when this returns: nothing may still read it
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (side != st) (void)hipStreamDestroy(side);
+        return;
+    }
     CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
+    (void)hipStreamSynchronize(st);
 }
 
 }  // namespace csw

@@ -1456,7 +1456,7 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     CSH_CHECK(hipEventRecord(ev[++slot], st));
     { uint32_t mw = 0, mh = 0; for (const csw::WebpImg &wi : b->wimgs) { mw = std::max(mw, wi.mbw); mh = std::max(mh, wi.mbh); } csw::launch_webp_mb(st, b->d_wimgs.p, nimg, mw, mh, b->d_wwork.p, b->d_wlevels.p); }
     CSH_CHECK(hipEventRecord(ev[++slot], st));
-    csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p,
+    csw::launch_webp_code(st, b->d_wimgs.p, b->wimgs.data(), nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p,
                           b->d_img_size.p, b->d_status.p);
     CSH_CHECK(hipEventRecord(ev[++slot], st));
     CSH_CHECK(hipStreamSynchronize(st));

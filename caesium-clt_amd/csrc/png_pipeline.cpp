@@ -703,7 +703,7 @@ static int run_to_webp(csp_batch *b) {
         if (b->d_out.alloc(out_bytes + 64) || b->d_wscratch.alloc(out_bytes + 64) || b->d_wimgs.upload(b->wimgs, st) || b->d_wstats.zero(st) || b->d_wstatus.zero(st) || b->d_file_len.zero(st)) return CS_ERR_NO_DEVICE;
         csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
         { uint32_t mw = 0, mh = 0; for (const csw::WebpImg &wi : b->wimgs) { mw = std::max(mw, wi.mbw); mh = std::max(mh, wi.mbh); } csw::launch_webp_mb(st, b->d_wimgs.p, nimg, mw, mh, b->d_wwork.p, b->d_wlevels.p); }
-        csw::launch_webp_code(st, b->d_wimgs.p, nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_file_len.p,
+        csw::launch_webp_code(st, b->d_wimgs.p, b->wimgs.data(), nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_file_len.p,
                               b->d_wstatus.p);
         if (hipMemcpyAsync(b->h_wstatus.data(), b->d_wstatus.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
             hipGetLastError() != hipSuccess) { csh_set_error("WebP kernels failed"); return CS_ERR_NO_DEVICE; }

@@ -23,8 +23,9 @@ void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max
 void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels);   // one launch per skewed diagonal of macroblocks
 // stats: nimg x 1056 x 2 counters (zeroed by the caller); probs / update: nimg x 1056 bytes; scratch: a second region laid out like the
 // output pool (every partition is coded into its own slice of it); part_size: nimg x 9
-void launch_webp_code(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update, uint8_t *scratch,
-                      uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
+// himgs: the host's copy of imgs (the launcher lays the token partitions' decision streams out from the pictures' sizes).  Returns with the stream idle.
+void launch_webp_code(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update,
+                      uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
 
 enum { VP8L_ALPHA_OF = 16 };   // Vp8lImg::channels = VP8L_ALPHA_OF + 2 / + 4: code the alpha sample of a grey + alpha / RGBA picture as a grey picture
 // lossless WebP output (k_vp8l_enc.hip): one picture of 8-bit grey (channels 1), grey + alpha (2), RGB (3) or RGBA (4) pixels in device memory
