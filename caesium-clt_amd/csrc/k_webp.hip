@@ -17,6 +17,7 @@
 #include "webp_kernels.h"
 #include "devmem.hpp"
 #include "kernels.h"
+#include "wave.h"
 
 namespace csw {
 using namespace csp;   // LFOR / LV / lsum / coherent_load (png_wave.h)
@@ -693,26 +694,36 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *
     LFOR(l) for (int i = l; i < 2 * WEBP_NPROB; i += 64) cnt[i] = 0;
     CSP_WAVE_SYNC();
     const int16_t *row = levels + im.lev_off + size_t(my) * mbw * WEBP_MB_REC;
-    for (int mx = 0; mx < mbw; mx++) {
-        const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
-        const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
-        const bool i4 = L[MB_INFO + 2] == 4;
+    for (int mx0 = 0; mx0 < mbw; mx0 += 2) {   // two macroblocks to a step: lanes 0..24 the blocks of one, lanes 32..56 those of the next
         LV<uint32_t> nd;
         LFOR(l) {
+            const int mx = mx0 + (l >> 5), k = l & 31;
             nd[l] = 0;
-            if (l < 25 && !(i4 && l == 0)) {   // no Y2 block in an i4x4 macroblock
-                int type, first, ctx;
-                block_info(l, cur, top, left, i4, type, first, ctx);
-                StatSink sink{cnt, 0u};
-                put_coeffs(sink, type, ctx, L + l * 16, first);
-                nd[l] = sink.nd;
+            if (mx < mbw && k < 25) {
+                const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
+                const bool i4 = L[MB_INFO + 2] == 4;
+                if (!(i4 && k == 0)) {   // no Y2 block in an i4x4 macroblock
+                    const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
+                    int type, first, ctx;
+                    block_info(k, cur, top, left, i4, type, first, ctx);
+                    StatSink sink{cnt, 0u};
+                    put_coeffs(sink, type, ctx, L + k * 16, first);
+                    nd[l] = sink.nd;
+                }
             }
         }
         // decisions per block and per macroblock, in chain order: the write pass (k_webp_decisions) places every block's stretch from them
-        const uint64_t at = mb_base[blockIdx.y] + webp_chain_index(mbw, int(im.mbh), mx, my);
         uint32_t total;
-        (void)lscan(nd, total);
-        LFOR(l) { if (l < 32) blk_cnt[at * 32 + uint32_t(l)] = uint16_t(nd[l]); if (l == 0) mb_cnt[at] = total; }
+        const LV<uint32_t> ex = lscan(nd, total);
+        const uint32_t lower = csh::lget(ex, 32);
+        LFOR(l) {
+            const int mx = mx0 + (l >> 5), k = l & 31;
+            if (mx < mbw) {
+                const uint64_t at = mb_base[blockIdx.y] + webp_chain_index(mbw, int(im.mbh), mx, my);
+                blk_cnt[at * 32 + uint32_t(k)] = uint16_t(nd[l]);
+                if (k == 0) mb_cnt[at] = (l >> 5) ? total - lower : lower;
+            }
+        }
     }
     CSP_WAVE_SYNC();
     uint32_t *dst = stats + size_t(im.image) * 2 * WEBP_NPROB;
@@ -902,21 +913,30 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_decisions(const WebpI
     LFOR(l) for (int i = l; i < WEBP_NPROB; i += 64) s_probs[i] = probs_g[i];
     CSP_WAVE_SYNC();
     const int16_t *row = levels + im.lev_off + size_t(my) * mbw * WEBP_MB_REC;
-    for (int mx = 0; mx < mbw; mx++) {
-        const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
-        const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
-        const bool i4 = L[MB_INFO + 2] == 4;
-        const uint64_t at = mb_base[blockIdx.y] + webp_chain_index(mbw, int(im.mbh), mx, my);
+    for (int mx0 = 0; mx0 < mbw; mx0 += 2) {   // two macroblocks to a step, as in k_webp_stats
         LV<uint32_t> nd;
-        LFOR(l) nd[l] = l < 32 ? uint32_t(blk_cnt[at * 32 + uint32_t(l)]) : 0u;
+        LV<uint64_t> at;
+        LFOR(l) {
+            const int mx = mx0 + (l >> 5), k = l & 31;
+            at[l] = mx < mbw ? mb_base[blockIdx.y] + webp_chain_index(mbw, int(im.mbh), mx, my) : 0ull;
+            nd[l] = mx < mbw ? uint32_t(blk_cnt[at[l] * 32 + uint32_t(k)]) : 0u;
+        }
         uint32_t total;
         const LV<uint32_t> ex = lscan(nd, total);
-        uint16_t *dst = stream + mb_off[at];
-        LFOR(l) if (l < 25 && !(i4 && l == 0)) {
-            int type, first, ctx;
-            block_info(l, cur, top, left, i4, type, first, ctx);
-            WriteSink sink{s_probs, dst + ex[l]};
-            put_coeffs(sink, type, ctx, L + l * 16, first);
+        const uint32_t lower = csh::lget(ex, 32);
+        LFOR(l) {
+            const int mx = mx0 + (l >> 5), k = l & 31;
+            if (mx < mbw && k < 25) {
+                const int16_t *L = row + size_t(mx) * WEBP_MB_REC;
+                const bool i4 = L[MB_INFO + 2] == 4;
+                if (!(i4 && k == 0)) {
+                    const uint32_t cur = nz_mask(L), top = my ? nz_mask(L - size_t(mbw) * WEBP_MB_REC) : 0u, left = mx ? nz_mask(L - WEBP_MB_REC) : 0u;
+                    int type, first, ctx;
+                    block_info(k, cur, top, left, i4, type, first, ctx);
+                    WriteSink sink{s_probs, stream + mb_off[at[l]] + (ex[l] - ((l >> 5) ? lower : 0u))};
+                    put_coeffs(sink, type, ctx, L + k * 16, first);
+                }
+            }
         }
     }
 }
