@@ -73,6 +73,7 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release() { if (p) device_cache(dev).put(p, cap); p = nullptr; n = 0; cap = 0; }
     int alloc(size_t count) {
+        if (getenv("CSH_TRACE_ALLOC") && count * sizeof(T) >= (32u << 20)) fprintf(stderr, "[alloc] %.1f MB (%zu x %zu)\n", double(count * sizeof(T)) / 1048576.0, count, sizeof(T));   // what a batch holds, buffer by buffer
         release();
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
         void *q = device_cache(dev).get((count ? count : 1) * sizeof(T), cap);

@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(64) k_make_slots(const ScanWork *works, uint32
         r.flags = uint16_t((prog_ac ? 1 : 0) | (prog_ac && e.Ah ? 2 : 0) | (listed ? 4 : 0));
         r.hist_row = w.hist_row0 + j * uint32_t(e.ntables);
         r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
-        r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.corr0 = w.corr_base == 0xFFFFFFFFu ? 0u : w.corr_base + 256u * j; r.pad[0] = r.pad[1] = 0;
         slots[w.first_chunk + j] = r;
         slot_work[w.first_chunk + j] = wi;
         (listed ? list_slots : tok_slots)[w.ls_base + j] = w.first_chunk + j;

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256, 3) k_tokens(EncCtx c) {
                     has_sym = N != 0; ends_eob = !((N >> a.Se) & 1);
                     tail = N ? __popcll(H & ~((2ull << msb64(N)) - 1)) : __popcll(H);
                     n = refine_room(H, N, a.Ss, ends_eob);
-                    if (!(c.debug & 256u)) c.corr[a.unit_base + u] = correction_word(H, pick_bit(pl + 5, a.Al));
+                    if (!(c.debug & 256u)) c.corr[a.corr_base + u] = correction_word(H, pick_bit(pl + 5, a.Al));
                     c.tail[a.unit_base + u] = uint8_t(tail);
                 }
                 cnt[slot][tid] = n;
@@ -913,7 +913,7 @@ __device__ __forceinline__ static TokenCtx token_ctx(const EncCtx &c, const Slot
     TokenCtx x;
     x.lut = c.tables[r.table_base].lut; x.lut_stride = CSH_LUT_STRIDE;
     x.eobrun = c.eobrun + r.unit0;
-    x.corr = c.corr + r.unit0;
+    x.corr = c.corr + r.corr0;   // (read by refinement scans only)
     return x;
 }
 // four consecutive tokens of the chunk, starting at i (one 16-byte load where all four exist: the pool is 16-byte aligned per chunk only

@@ -107,6 +107,7 @@ struct csh_batch {
     // per (work item, 256-unit chunk) slot: its work item, its SlotRec, its place in the list-coded / token-coded slot lists -- ~3.9 k slots per 1080p image
     // under the scan search (64 MB of records per 256 files): the host only counts them, k_make_slots writes them on the device from the work items
     uint32_t nslots = 0, nlist_slots = 0, ntok_slots = 0;
+    uint64_t total_corr = 0;              // correction words: one per unit of a refinement scan
     std::vector<TokPlan> plans;
     std::vector<int> plan_comp, plan_image;
     std::vector<EChunk> echunks;          // the token kernel's workgroups
@@ -634,6 +635,8 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
             else w.nunits = uint32_t(im.out[e.comp[0]].real_bw * im.out[e.comp[0]].real_bh);
             w.unit_base = uint32_t(b->total_units);
             b->total_units += w.nunits;
+            w.corr_base = 0xFFFFFFFFu;
+            if (e.Ss > 0 && !e.sequential && e.Ah) { w.corr_base = uint32_t(b->total_corr); b->total_corr += w.nunits; }
             w.word_base = uint32_t(b->total_words);
             if (e.Ss) b->total_words += (w.nunits + 63) / 64;
             w.table_base = uint32_t(b->ntables);
@@ -683,7 +686,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 const ScanWork &w = b->swork[size_t(w_first) + k];
                 if (P.work0 == 0xFFFFFFFFu) P.work0 = uint32_t(w_first) + uint32_t(k);   // the plan's scans are coded or skipped together: the first stands for all
                 AcSlot &a = P.s[P.nslot++];
-                a.unit_base = w.unit_base; a.word_base = w.word_base; a.first_chunk = w.first_chunk; a.table_base = w.table_base; a.nunits_work = w.nunits;
+                a.unit_base = w.unit_base; a.word_base = w.word_base; a.first_chunk = w.first_chunk; a.table_base = w.table_base; a.nunits_work = w.nunits; a.corr_base = w.corr_base;
                 a.Ss = uint8_t(e.Ss); a.Se = uint8_t(e.Se); a.Ah = uint8_t(e.Ah); a.Al = uint8_t(e.Al);
             }
             // every non-zero coefficient becomes a token in exactly one scan of a script (~5 bits of a source file each), plus an EOB per
@@ -1313,7 +1316,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         }
         if (b->d_coef.alloc(size_t(b->ntiles) * CSH_TILE_I16) || b->d_planes.alloc(b->plane_bytes + 64) || b->d_oplanes.alloc(b->oplane_bytes + 64) ||
             b->d_symbits.alloc(b->total_words + 1) || b->d_eobbits.alloc(b->total_words + 1) ||
-            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_corr.alloc(b->total_units + 1) ||
+            b->d_long_runs.alloc(2 * (b->total_units / 512 + b->swork.size() + 16)) || b->d_long_cnt.alloc(4) || b->d_tail.alloc(b->total_units + 1) || b->d_eobrun.alloc(b->total_units + 1) || b->d_corr.alloc(b->total_corr + 1) ||
             b->d_tok_off.alloc(4 * size_t(b->nslots) + 4) || b->d_chunk_ntok.alloc(4 * size_t(b->nslots) + 4) || b->d_slot_hist.alloc(size_t(b->hist_rows) * 256 + 256) ||
             b->d_slot_raw.alloc(size_t(b->nslots) + 1) || b->d_img_list.upload(b->img_list, st) || b->d_img_nlist.upload(b->img_nlist, st) || b->d_scan_cost.alloc(b->swork.size() + 1) || b->d_slot_eobh.alloc(16 * size_t(b->nslots) + 16) || b->d_chunk_bits.alloc(size_t(b->nslots) + 1) || b->d_chunk_off.alloc(size_t(b->nslots) + 2) || b->d_tok_cursor.alloc(b->region_est.size() + 1) || b->d_regions.upload(b->regions, st) ||
             b->d_tables.alloc(b->ntables) || b->d_scan_pad.alloc(b->swork.size() + 1) ||

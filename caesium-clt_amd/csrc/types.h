@@ -194,6 +194,8 @@ struct ScanWork {
     uint32_t hdr_bytes;    // DHT + SOS bytes in front of the entropy-coded data (device-computed)
     uint32_t no_room;      // the raw pool cannot hold this scan (device-computed): the packer skips it, the batch is re-run with a larger pool
     uint32_t list;         // progressive AC scans: the NzList (component, point transform) the scan is coded from (k_aclist.hip); 0xFFFFFFFF otherwise
+    uint32_t corr_base;    // refinement scans: the scan's first correction word in EncCtx::corr (one u64 per unit of a REFINEMENT scan only: 8 bytes for every unit of
+                           // every candidate scan were 7.5 MB of a 1080p picture's 37 MB of pools); 0xFFFFFFFF otherwise
     uint32_t hist_row0;    // first histogram row of its first slot (slot j: hist_row0 + j * ntables)
     uint32_t ls_base;      // where its slots stand in the list of list-coded slots (list != 0xFFFFFFFF) or of token-coded slots
 };
@@ -209,7 +211,7 @@ struct TokRegion { uint64_t base; uint32_t cap, pad; };
 #define CSH_TK_MAXSLOT 12  // AC scans of one component that a kind-0 chunk can carry (a stage of the scan search has 11)
 // what a kind-0 chunk needs of its image, component and scans, in one piece (host-built per (image, component); the workgroup copies it
 // to LDS with one coalesced load instead of chasing ImgDesc -> ScanWork -> EncScan through dependent scalar loads, scan after scan)
-struct AcSlot { uint32_t unit_base, word_base, first_chunk, table_base, nunits_work; uint8_t Ss, Se, Ah, Al; uint32_t pad[2]; };   // 32 bytes
+struct AcSlot { uint32_t unit_base, word_base, first_chunk, table_base, nunits_work; uint8_t Ss, Se, Ah, Al; uint32_t corr_base, pad; };   // 32 bytes; corr_base: the scan's first correction word (ScanWork)
 struct TokPlan {
     uint32_t nslot, nunits;        // AC scans of the component; its blocks
     int32_t real_bw, bw;           // block grid: real and MCU-padded width
@@ -253,7 +255,7 @@ struct SlotRec {
     uint16_t ntables, flags;     // flags: 1 progressive AC scan (EOB tokens), 2 refinement (correction words), 4 coded from its NzList (k_aclist.hip), not from tokens
     uint32_t hist_row;           // first of the slot's ntables rows of 256 symbol counts (EncCtx::slot_hist)
     uint32_t word_base, unit_base, nunits_work;   // of the work item (k_ac_runs)
-    uint8_t Ss, Se, Ah, Al; uint32_t pad[3];
+    uint8_t Ss, Se, Ah, Al; uint32_t corr0, pad[2];   // corr0: the chunk's first correction word (refinement scans)
 };
 
 // mozjpeg's trellis quantiser (k_trellis.hip; CSH_PROFILE=mozjpeg): one work item per (image, component) -- the component's statistics
