@@ -46,6 +46,24 @@ def test_convert_equals_oracle(api):
     check(api, webp_cases()[:3], 30)
 
 
+def test_token_partitions_as_decision_streams_and_as_chains(api, monkeypatch):
+    """round 4: the token partitions are coded one LANE per partition from (bit, probability) pairs written down ahead of the coder (k_webp_decisions /
+    k_webp_bool: a 64-bit accumulator flushed every fourth decision, carries added before the byte is written); CSH_WEBP_CHAINS=1 keeps the coder that walks
+    the token tree itself, one wave per partition.  The same files either way -- pictures with one, two, four and eight partitions, busy and empty ones, both
+    macroblock kinds, values of every size class (q 100 gives long extra-bit runs)"""
+    cases = webp_cases() + [("busy_200x150", synth_jpeg(9, 200, 150, texture=90)), ("tall_24x200", synth_jpeg(10, 24, 200, texture=40)), ("wide_333x17", synth_jpeg(11, 333, 17, texture=20))]
+    for q in (100, 75, 5):
+        assert check(api, cases, q) is None
+    pkg = package()
+    for q in (100, 40):
+        p = pkg.default_parameters(webp_quality=q, jpeg_quality=q)
+        streams = api.batch_convert([c[1] for c in cases], p, WEBP)
+        monkeypatch.setenv("CSH_WEBP_CHAINS", "1")
+        chains = api.batch_convert([c[1] for c in cases], p, WEBP)
+        monkeypatch.delenv("CSH_WEBP_CHAINS")
+        assert streams == chains
+
+
 def test_convert_with_resize(api):
     check(api, webp_cases()[:2], 85, width=60)
     check(api, webp_cases()[1:3], 75, height=40)

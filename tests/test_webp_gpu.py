@@ -25,6 +25,11 @@ def test_convert_equals_oracle(api):
     check(api, webp_cases()[:4], 100)
 
 
+def test_token_partitions_as_decision_streams_and_as_chains(api, monkeypatch):
+    import test_webp_emul as E
+    E.test_token_partitions_as_decision_streams_and_as_chains(api, monkeypatch)
+
+
 def test_convert_with_resize(api):
     check(api, webp_cases()[:3], 85, width=60)
     check(api, webp_cases()[1:4], 75, height=40)
