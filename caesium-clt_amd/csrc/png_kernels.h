@@ -39,7 +39,9 @@ void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jo
 // resize of a PNG source (k_png_resize.hip): interleaved samples of bps bytes (1, or 2 big-endian), nc per pixel; src / dst are byte
 // offsets, tmp a float offset
 struct PngResize { uint32_t width, height, nc, nw, nh, vtap_base, htap_base, bps; uint64_t src_off, tmp_off, dst_off; };
-void launch_png_resize(hipStream_t st, const PngResize *jobs, int njobs, const csh::ResizeTap *taps, const float *weights, const uint8_t *src, float *tmp, uint8_t *dst,
+// hjobs: the host's copy of jobs.  Fused (every source row fits LDS): one kernel, tmp is not touched and need not exist
+bool png_resize_is_fused(const PngResize *hjobs, int njobs);
+void launch_png_resize(hipStream_t st, const PngResize *jobs, const PngResize *hjobs, int njobs, const csh::ResizeTap *taps, const float *weights, const uint8_t *src, float *tmp, uint8_t *dst,
                        uint64_t max_tmp, uint64_t max_dst);
 
 // the decoded pixels of an 8-bit-or-less PNG format (16-bit: narrowed) as interleaved 8-bit samples.  out_nc 1 / 3: grey or RGB for

@@ -866,12 +866,12 @@ static int png_create_resized(const CByteArray *inputs, size_t count, const CCSP
     DevBuf<uint8_t> d_dst, d_src, d_tables;
     DevBuf<RgbJob> d_ejobs;
     if (!jobs.empty()) {
-        if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256) ||
+        if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc((png_resize_is_fused(jobs.data(), int(jobs.size())) ? 0 : tmp_floats) + 64) || d_dst.alloc(dst_bytes + 256) ||
             d_ejobs.upload(ejobs, st) || d_tables.upload(tables, st) || d_src.alloc(src_bytes + 256)) return CS_ERR_NO_DEVICE;
         launch_png_rgb(st, d_ejobs.p, int(ejobs.size()), max_h, d_tables.p, a->d_work.p, d_src.p, a->d_status.p);
         for (const RawCopy &c : copies)
             if (hipMemcpyAsync(d_src.p + c.dst, a->d_work.p + c.src, c.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { csh_set_error("pixel copy failed"); return CS_ERR_NO_DEVICE; }
-        launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
+        launch_png_resize(st, d_jobs.p, jobs.data(), int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG resize kernels failed"); return CS_ERR_NO_DEVICE; }
         for (size_t k = 0; k < jobs.size(); k++) px[job_item[k]].device_pixels = d_dst.p + jobs[k].dst_off;
     }
@@ -986,9 +986,9 @@ static int png_to_pixels_then(const CByteArray *inputs, size_t count, const CCSP
                 for (size_t j = 0; j < opaque.size() && rc == 0; j++) { const char *m = ""; csp_pixels &d = src[opaque_at[j]]; if (csh_batch_pixels(rb, j, &d.device_pixels, &d.width, &d.height, &d.channels, &m)) rc = CS_ERR_NO_DEVICE; }
             }
             if (rc == 0 && !jobs.empty()) {
-                if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc(tmp_floats + 64) || d_dst.alloc(dst_bytes + 256)) rc = CS_ERR_NO_DEVICE;
+                if (d_jobs.upload(jobs, st) || d_taps.upload(taps, st) || d_weights.upload(weights, st) || d_tmp.alloc((png_resize_is_fused(jobs.data(), int(jobs.size())) ? 0 : tmp_floats) + 64) || d_dst.alloc(dst_bytes + 256)) rc = CS_ERR_NO_DEVICE;
                 else {
-                    launch_png_resize(st, d_jobs.p, int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
+                    launch_png_resize(st, d_jobs.p, jobs.data(), int(jobs.size()), d_taps.p, d_weights.p, d_src.p, d_tmp.p, d_dst.p, max_tmp, max_dst);
                     if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { csh_set_error("PNG resize kernels failed"); rc = CS_ERR_NO_DEVICE; }
                     for (size_t j = 0; j < jobs.size(); j++) src[job_at[j]].device_pixels = d_dst.p + jobs[j].dst_off;
                 }
