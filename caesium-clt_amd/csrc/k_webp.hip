@@ -902,7 +902,8 @@ __global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, cons
 //   k_webp_stats      (the walk that counts the frame's statistics) also counts every block's decisions;
 //   an exclusive scan over the macroblocks in chain order gives every macroblock its place in the stream;
 //   k_webp_decisions  the same walk, lanes = the blocks of a macroblock, writes (bit, probability) pairs -- two bytes a decision;
-//   k_webp_bool       ONE LANE per partition runs the coder over its stretch of pairs: no tree, no table, no levels -- 64 chains to a wave on the vector unit.
+//   k_webp_bool       ONE LANE per partition runs the coder over its stretch of pairs: no tree, no table, no levels -- 64 chains to a wave on the vector unit;
+//   k_webp_hdr        the header partition the same way (fields, probability updates, every macroblock's modes): its chain is a ninth lane per picture.
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_decisions(const WebpImg *imgs, const int16_t *levels, const uint8_t *probs_all, const uint64_t *mb_base, const uint64_t *mb_off,
                                                                       const uint16_t *blk_cnt, uint16_t *stream, const uint32_t *status) {
     CSH_SHARED uint8_t s_probs[WEBP_NPROB];
@@ -940,8 +941,76 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_decisions(const WebpI
         }
     }
 }
+// ---- the header partition the same way: its chain is the frame header's fields, the frame's probability updates, then every macroblock's modes in raster
+// order.  One lane per ITEM (item 0: the fields and the updates; item 1 + i: macroblock i) counts its decisions or writes them: the modes' contexts are the
+// neighbours' modes, which k_webp_mb left with the levels.  (oracle: write_frame_header / the mode part of cso_webp_encode_yuv; the wave form: code_header)
+struct HdrSink {
+    uint16_t *out;   // nullptr: count only
+    uint32_t n;
+    __device__ __forceinline__ void put(int bit, int prob) { if (out) *out++ = uint16_t((bit ? 1u : 0u) | (uint32_t(prob) << 1)); n++; }
+    __device__ __forceinline__ void bits(uint32_t v, int nb) { while (nb--) put(int((v >> nb) & 1u), 128); }
+};
+__device__ static void hdr_item(HdrSink &e, const WebpImg &im, const int16_t *lev, const uint8_t *probs, const uint8_t *update, uint32_t item) {
+    const int mbw = int(im.mbw), mbh = int(im.mbh), nparts = webp_parts(mbh);
+    if (item == 0) {
+        e.bits(0, 1); e.bits(0, 1); e.bits(0, 1);           // colour space, clamping, no segmentation
+        e.bits(1, 1); e.bits(0, 6); e.bits(0, 3);           // simple filter at level 0 (off), sharpness
+        e.bits(0, 1);                                       // no filter deltas
+        e.bits(uint32_t(nparts == 8 ? 3 : nparts == 4 ? 2 : nparts == 2 ? 1 : 0), 2);
+        e.bits(uint32_t(im.qi), 7);
+        for (int i = 0; i < 5; i++) e.bits(0, 1);           // no quantiser deltas
+        e.bits(0, 1);                                       // refresh_entropy_probs
+        for (int i = 0; i < WEBP_NPROB; i++) { e.put(update[i], kVp8CoefUpdateProbs[i]); if (update[i]) e.bits(probs[i], 8); }   // the frame's coefficient probabilities
+        e.bits(0, 1);                                       // no skip flags
+        return;
+    }
+    const int i = int(item) - 1, my = i / mbw, mx = i - my * mbw;
+    const int16_t *I = lev + size_t(i) * WEBP_MB_REC + MB_INFO, *It = I - size_t(mbw) * WEBP_MB_REC, *Il = I - WEBP_MB_REC;
+    const int ym = I[2], cm = I[3];
+    if (ym == 4) {
+        e.put(0, 145);                                                                    // i4x4: sixteen sub-block modes, each after the modes above and to the left
+        for (int k = 0; k < 16; k++) {
+            const int bx = k & 3, by = k >> 2, m = I[4 + k];
+            const int tmode = by ? int(I[4 + k - 4]) : (my ? int(It[4 + 12 + bx]) : 0), lmode = bx ? int(I[4 + k - 1]) : (mx ? int(Il[4 + by * 4 + 3]) : 0);
+            const uint8_t *prv = kVp8BModeProbs + (tmode * 10 + lmode) * 9;
+            // the key-frame sub-block mode tree (RFC 6386 11.2; oracle: bmode_path)
+            if (m == 0) e.put(0, prv[0]);
+            else {
+                e.put(1, prv[0]);
+                if (m == 1) e.put(0, prv[1]);
+                else {
+                    e.put(1, prv[1]);
+                    if (m == 2) e.put(0, prv[2]);
+                    else {
+                        e.put(1, prv[2]);
+                        if (m <= 5) { e.put(0, prv[3]); if (m == 3) e.put(0, prv[4]); else { e.put(1, prv[4]); e.put(m == 5, prv[5]); } }
+                        else { e.put(1, prv[3]); if (m == 6) e.put(0, prv[6]); else { e.put(1, prv[6]); if (m == 7) e.put(0, prv[7]); else { e.put(1, prv[7]); e.put(m == 9, prv[8]); } } }
+                    }
+                }
+            }
+        }
+    } else {
+        e.put(1, 145);                                                                    // i16x16
+        if (ym >= 2) { e.put(1, 156); e.put(ym == 3, 128); } else { e.put(0, 156); e.put(ym == 1, 163); }   // (H | TM) : (DC | V)
+    }
+    if (!cm) e.put(0, 142); else { e.put(1, 142); if (cm == 1) e.put(0, 114); else { e.put(1, 114); e.put(cm == 3, 183); } }
+}
+// hdr_base[image]: the picture's first header item among all counted things (behind the macroblocks in chain order); WRITE: cnt is the scan's output
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_webp_hdr(const WebpImg *imgs, const int16_t *levels, const uint8_t *probs_all, const uint8_t *update_all, const uint64_t *hdr_base, uint32_t *cnt,
+                                                  const uint64_t *off, uint16_t *stream, const uint32_t *status) {
+    const WebpImg &im = imgs[blockIdx.y];
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item > im.mbw * im.mbh) return;
+    if (WRITE && status[im.image]) return;
+    const uint64_t at = hdr_base[blockIdx.y] + item;
+    HdrSink e{WRITE ? stream + off[at] : nullptr, 0u};
+    hdr_item(e, im, levels + im.lev_off, probs_all + size_t(im.image) * WEBP_NPROB, update_all + size_t(im.image) * WEBP_NPROB, item);
+    if (!WRITE) cnt[at] = e.n;
+}
+
 // one lane = one chain (token partition `part` of picture `image`: the decisions of nmb macroblocks from chain-order macroblock `first` on)
-struct WebpChain { uint32_t image, part; uint64_t first, nmb; };
+struct WebpChain { uint32_t image, part; uint64_t first, nmb; };   // part 0xFFFFFFFF: the header partition (first / nmb: its items)
 struct BoolEncLane {   // the boolean coder (oracle: boolenc) with per-lane state.  Sixty-four of these run side by side in a wave, every lane at its own place in its own
                        // chain, and whatever one lane branches into, the whole wave executes.  So: a decision is straight-line arithmetic (the renormalisation
                        // shifts by 0 when none is due); the bits a decision completes stay in a 64-bit accumulator and leave on a FIXED schedule (flush() after
@@ -1013,7 +1082,8 @@ __global__ void __launch_bounds__(64) k_webp_bool(const WebpImg *imgs, const Web
     const WebpImg &im = imgs[ch.image];   // (chains are listed per WebpImg entry)
     if (status[im.image]) return;
     BoolEncLane e;
-    e.init(scratch + im.out_off + webp_hdr_cap(im) + ch.part * webp_part_cap(im), webp_part_cap(im));
+    const bool header = ch.part == 0xFFFFFFFFu;
+    if (header) e.init(scratch + im.out_off, webp_hdr_cap(im)); else e.init(scratch + im.out_off + webp_hdr_cap(im) + ch.part * webp_part_cap(im), webp_part_cap(im));
     const uint64_t d0 = mb_off[ch.first], d1 = mb_off[ch.first + ch.nmb];
     // eight decisions to a 16-byte load, the next load in flight while these are coded (a lane's loads are its own: nothing hides their latency but this)
     uint64_t d = d0;
@@ -1034,7 +1104,7 @@ __global__ void __launch_bounds__(64) k_webp_bool(const WebpImg *imgs, const Web
     }
     for (; d < d1 && !e.overflow; d++) { const uint32_t v = stream[d]; e.put(int(v & 1u), int(v >> 1)); e.flush(); }
     e.finish();
-    part_size[size_t(im.image) * 9 + 1 + ch.part] = e.overflow ? 0xFFFFFFFFu : e.pos;
+    part_size[size_t(im.image) * 9 + (header ? 0u : 1u + ch.part)] = e.overflow ? 0xFFFFFFFFu : e.pos;
 }
 
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work) {
@@ -1050,49 +1120,49 @@ void launch_webp_code(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs,
     const char *sw = getenv("CSH_WEBP_CHAINS");   // "1": every token partition on a wave of its own (k_webp_code), as before round 4
     const bool streams = !(sw && !strcmp(sw, "1"));
     // the macroblocks of the batch in chain order (picture by picture, inside a picture partition by partition) and the chains themselves
-    std::vector<uint64_t> base(size_t(nimg) + 1);
+    std::vector<uint64_t> base(size_t(nimg) + 1), hbase(size_t(nimg) + 1);
     std::vector<WebpChain> chains;
     uint64_t nmb = 0;
+    uint32_t max_items = 0;
     for (int i = 0; i < nimg; i++) {
         const uint32_t mbw = himgs[i].mbw, mbh = himgs[i].mbh, P = uint32_t(mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1);   // webp_parts
         base[size_t(i)] = nmb;
         uint64_t first = nmb;
         for (uint32_t p = 0; p < P; p++) { const uint64_t n = uint64_t((mbh - p + P - 1) / P) * mbw; chains.push_back(WebpChain{uint32_t(i), p, first, n}); first += n; }
         nmb += uint64_t(mbw) * mbh;
+        max_items = std::max(max_items, mbw * mbh + 1u);
     }
     base[size_t(nimg)] = nmb;
-    csh::DevBuf<uint64_t> d_base, d_off;
+    // behind them the header partitions' items: per picture the fields + updates, then its macroblocks in raster order
+    uint64_t nall = nmb;
+    for (int i = 0; i < nimg; i++) {
+        const uint64_t n = uint64_t(himgs[i].mbw) * himgs[i].mbh + 1;
+        hbase[size_t(i)] = nall;
+        if (streams) chains.push_back(WebpChain{uint32_t(i), 0xFFFFFFFFu, nall, n});
+        nall += n;
+    }
+    hbase[size_t(nimg)] = nall;
+    csh::DevBuf<uint64_t> d_base, d_hbase, d_off;
     csh::DevBuf<uint32_t> d_cnt;
     csh::DevBuf<uint16_t> d_blk, d_stream;
     csh::DevBuf<WebpChain> d_chains;
     csh::DevBuf<uint8_t> d_tmp;
-    const size_t tmp_bytes = csh::exclusive_scan_tmp_bytes(nmb);
-    if (d_base.upload(base, st) || d_chains.upload(chains, st) || d_cnt.alloc(nmb + 1) || d_off.alloc(nmb + 2) || d_blk.alloc((nmb + 1) * 32) || d_tmp.alloc(tmp_bytes + 64)) return;
+    const size_t tmp_bytes = csh::exclusive_scan_tmp_bytes(nall);
+    if (d_base.upload(base, st) || d_hbase.upload(hbase, st) || d_chains.upload(chains, st) || d_cnt.alloc(nall + 1) || d_off.alloc(nall + 2) || d_blk.alloc((nmb + 1) * 32) || d_tmp.alloc(tmp_bytes + 64)) return;
     CSH_LAUNCH(k_webp_stats, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, stats, d_base.p, d_cnt.p, d_blk.p);
     CSH_LAUNCH(k_webp_probs, dim3((WEBP_NPROB + 255) / 256, nimg), dim3(256), st, imgs, stats, probs, update);
     if (!streams) CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
     else {
-        // the header partition (modes: one serial chain over the picture, still a wave's) beside the token path, on a stream of its own
-        hipStream_t side = st;
-        hipEvent_t fork = nullptr, join = nullptr;
-        const bool forked = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&fork) == hipSuccess && hipEventCreate(&join) == hipSuccess &&
-                            hipEventRecord(fork, st) == hipSuccess && hipStreamWaitEvent(side, fork, 0) == hipSuccess;
-        CSH_LAUNCH(k_webp_code, dim3(nimg, 1), dim3(CSP_WAVE_THREADS), forked ? side : st, imgs, levels, probs, update, scratch, part_size, status);
-        if (forked) (void)hipEventRecord(join, side);
-        csh::launch_exclusive_scan(st, d_cnt.p, d_off.p, nmb, d_tmp.p, tmp_bytes + 64);
+        const dim3 items((max_items + 255) / 256, unsigned(nimg));
+        CSH_LAUNCH(k_webp_hdr<false>, items, dim3(256), st, imgs, levels, probs, update, d_hbase.p, d_cnt.p, d_off.p, d_stream.p, status);
+        csh::launch_exclusive_scan(st, d_cnt.p, d_off.p, nall, d_tmp.p, tmp_bytes + 64);
         uint64_t total = 0;
-        if (csh_copy_wait(&total, d_off.p + nmb, sizeof total, hipMemcpyDeviceToHost, st) == hipSuccess && !d_stream.alloc(size_t(total) + 64)) {
+        if (csh_copy_wait(&total, d_off.p + nall, sizeof total, hipMemcpyDeviceToHost, st) == hipSuccess && !d_stream.alloc(size_t(total) + 64)) {
             CSH_LAUNCH(k_webp_decisions, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, d_base.p, d_off.p, d_blk.p, d_stream.p, status);
+            CSH_LAUNCH(k_webp_hdr<true>, items, dim3(256), st, imgs, levels, probs, update, d_hbase.p, d_cnt.p, d_off.p, d_stream.p, status);
             const uint32_t nchains = uint32_t(chains.size());
             CSH_LAUNCH(k_webp_bool, dim3((nchains + 63) / 64), dim3(64), st, imgs, d_chains.p, nchains, d_off.p, d_stream.p, scratch, part_size, status);
         }
-        if (forked) (void)hipStreamWaitEvent(st, join, 0);
-        CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
-        (void)hipStreamSynchronize(st);   // the workspace goes back to the block cache when this returns: nothing may still read it
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
-        if (side != st) (void)hipStreamDestroy(side);
-        return;
     }
     CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
     (void)hipStreamSynchronize(st);
