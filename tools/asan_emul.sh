@@ -3,7 +3,7 @@
 # __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
-HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip"
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_decode_refine.hip k_aclist.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip"
 CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp vp8l_encode.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
     $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
@@ -27,6 +27,12 @@ for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_quali
 for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_optimize=True))): assert o == _util.oracle_lossless(s)
 for s, o in zip(srcs, api.batch_compress(srcs[:2], pkg.default_parameters(jpeg_quality=70, width=60))): assert o == _util.oracle_resized(s, 60, 0, quality=70)
 api.batch_compress(PE.fuzzed_blobs(3, 24, True), pkg.default_parameters(jpeg_quality=80))
+class MP:
+    def setenv(self, k, v): import os; os.environ[k] = v
+    def delenv(self, k, raising=True): import os; os.environ.pop(k, None)
+PE.test_emul_refinement_scans_parse_and_apply(api, MP())
+PE.test_emul_irregular_progressions_decode_in_file_order(api)
+W.test_token_partitions_as_decision_streams_and_as_chains(api, MP())
 import test_png_webp_emul as PW, test_jpeg_png_emul as JP
 PW.check(api, _util.png_cases(), 85); PW.check(api, PW.extra_cases(), 60); PW.test_damaged_pngs_convert_like_the_oracle_or_fail(api)
 JP.check(api, W.webp_cases(), True); JP.check(api, W.webp_cases()[:3], False, width=50); JP.test_mixed_batch_and_failures(api); JP.test_damaged_jpegs_convert_like_the_oracle_or_fail(api)
