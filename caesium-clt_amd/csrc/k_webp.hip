@@ -1162,7 +1162,8 @@ void launch_webp_code(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs,
             CSH_LAUNCH(k_webp_hdr<true>, items, dim3(256), st, imgs, levels, probs, update, d_hbase.p, d_cnt.p, d_off.p, d_stream.p, status);
             const uint32_t nchains = uint32_t(chains.size());
             CSH_LAUNCH(k_webp_bool, dim3((nchains + 63) / 64), dim3(64), st, imgs, d_chains.p, nchains, d_off.p, d_stream.p, scratch, part_size, status);
-        }
+        } else   // no room for the pairs (two bytes a decision): the partitions as chains, a wave each -- the same files, later
+            CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
     }
     CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
     (void)hipStreamSynchronize(st);
