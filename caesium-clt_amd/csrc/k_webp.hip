@@ -713,6 +713,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_stats(const WebpImg *
             }
         }
         // decisions per block and per macroblock, in chain order: the write pass (k_webp_decisions) places every block's stretch from them
+        if (!mb_cnt) continue;   // (no room for the decision streams: the partitions will be coded as chains)
         uint32_t total;
         const LV<uint32_t> ex = lscan(nd, total);
         const uint32_t lower = csh::lget(ex, 32);
@@ -1148,10 +1149,11 @@ void launch_webp_code(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs,
     csh::DevBuf<WebpChain> d_chains;
     csh::DevBuf<uint8_t> d_tmp;
     const size_t tmp_bytes = csh::exclusive_scan_tmp_bytes(nall);
-    if (d_base.upload(base, st) || d_hbase.upload(hbase, st) || d_chains.upload(chains, st) || d_cnt.alloc(nall + 1) || d_off.alloc(nall + 2) || d_blk.alloc((nmb + 1) * 32) || d_tmp.alloc(tmp_bytes + 64)) return;
-    CSH_LAUNCH(k_webp_stats, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, stats, d_base.p, d_cnt.p, d_blk.p);
+    const bool room = streams && !(d_base.upload(base, st) || d_hbase.upload(hbase, st) || d_chains.upload(chains, st) || d_cnt.alloc(nall + 1) || d_off.alloc(nall + 2) || d_blk.alloc((nmb + 1) * 32) ||
+                                   d_tmp.alloc(tmp_bytes + 64));
+    CSH_LAUNCH(k_webp_stats, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, stats, room ? d_base.p : nullptr, room ? d_cnt.p : nullptr, room ? d_blk.p : nullptr);
     CSH_LAUNCH(k_webp_probs, dim3((WEBP_NPROB + 255) / 256, nimg), dim3(256), st, imgs, stats, probs, update);
-    if (!streams) CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
+    if (!room) CSH_LAUNCH(k_webp_code, dim3(nimg, 9), dim3(CSP_WAVE_THREADS), st, imgs, levels, probs, update, scratch, part_size, status);
     else {
         const dim3 items((max_items + 255) / 256, unsigned(nimg));
         CSH_LAUNCH(k_webp_hdr<false>, items, dim3(256), st, imgs, levels, probs, update, d_hbase.p, d_cnt.p, d_off.p, d_stream.p, status);
