@@ -104,7 +104,7 @@ __device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0
             for (int i = 0; i < 8; i++)
                 if ((mk[l] >> i) & 1u) {
                     const int h = (i & 1) ? (int(w[i >> 1]) >> 16) : (int(w[i >> 1] << 16) >> 16);
-                    const uint32_t a = uint32_t(h < 0 ? -h : h);
+                    const uint32_t a = h == -32768 ? 32767u : uint32_t(h < 0 ? -h : h);   // 15 bits of magnitude: -32768 (a crafted progressive input; no encoder's coefficient) must not reach the block field
                     dst[o++] = (base + uint32_t(i)) | (h < 0 ? 128u : 0u) | (a << 8);
                 }
             if (oct == 7u && u0 + blk < S.nunits) dst[o] = CSH_NZ_END | (base & 0x7F800000u);

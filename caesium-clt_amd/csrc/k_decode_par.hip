@@ -586,8 +586,12 @@ __global__ void __launch_bounds__(256) k_dc_refine(const uint8_t *clean, const P
     int by, bx;
     if (ps.ncomp > 1) { const int my = int(mcu) / im.mcus_x, mx = int(mcu) - my * im.mcus_x; by = my * g.v + ps.by_of[m]; bx = mx * g.h + ps.bx_of[m]; }
     else { by = int(mcu) / g.real_bw; bx = int(mcu) - by * g.real_bw; }
+    // every DC refinement scan of an image is in this one grid (blockIdx.y = scan): two scans (Al = 1 and Al = 0 behind a first scan at Al = 2)
+    // touch the same coefficient from different workgroups, so the OR is atomic, on the aligned word that holds the int16 (ORs of
+    // different bits commute: the scans need no order among themselves)
     int16_t *p = coef + coef_index(g.tile_base, by * g.bw + bx, 0);
-    *p = int16_t(*p | (1 << ps.Al));
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    atomicOr(reinterpret_cast<uint32_t *>(a & ~uintptr_t(3)), (1u << ps.Al) << ((a & 2u) ? 16 : 0));
 }
 
 void launch_unstuff_count(hipStream_t st, const uint8_t *raw, const ParScan *ps, int nps, uint32_t nchunks, uint32_t *cnt) {

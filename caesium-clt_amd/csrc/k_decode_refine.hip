@@ -181,7 +181,6 @@ __global__ void __launch_bounds__(64) k_refine_parse(const uint8_t *clean, const
     if (unit >= uint32_t(nunits)) return;
     const RefineUnit u = units[unit];
     const ProgChain pc = chains[u.chain];
-    if (need_seq[pc.image] != 4) return;   // so do all the units of this chain: nobody waits for this one
     uint64_t *H = hist + pc.hist_off;
     auto wait_for = [&](uint32_t upto) {   // the previous scan of the chain has rewritten the masks of blocks < upto
         if (u.prev < 0) return;
@@ -198,6 +197,10 @@ __global__ void __launch_bounds__(64) k_refine_parse(const uint8_t *clean, const
         CSP_MEM_FENCE();
         LFOR(l) if (l == 0) coherent_store(&prog[unit], upto);
     };
+    // need_seq changes INSIDE this kernel (a damaged run that leaves its band hands the image to the sequential decoder, below): a unit of the chain's
+    // next scan may have read 4 before that store landed and be waiting for this one -- so a unit that steps aside says "all blocks done" first
+    // (the image is decoded again by k_decode_seq, whatever the waiting unit then parses from the masks is thrown away)
+    if (coherent_load(&need_seq[pc.image]) != 4u) { publish(pc.nblocks); return; }
     {
         const int s = u.s;
         const DecScan &sc = scans[chain_scans[pc.first + s]];

@@ -119,6 +119,26 @@ def test_emul_refinement_scans_parse_and_apply(api, monkeypatch):
     assert api.batch_compress(srcs[:4], params()) == [oracle_lossy(s) for s in srcs[:4]]
 
 
+def two_dc_refinements_file(seed=6, w=211, h=157, ss=2, texture=30):
+    """a regular progression whose DC starts at Al = 2 and is refined twice (to Al = 1, then to Al = 0): both DC refinement scans of the image sit in
+    one launch of k_dc_refine and touch the same int16 (the OR into it is atomic)"""
+    from oracle import oracle as O
+    ci = O.decode(synth_jpeg(seed, w, h, subsampling=ss, texture=texture))
+    script = [((0, 1, 2), 0, 0, 0, 2), ((0,), 1, 63, 0, 1), ((1,), 1, 63, 0, 1), ((2,), 1, 63, 0, 1),
+              ((0, 1, 2), 0, 0, 2, 1), ((0,), 1, 63, 1, 0), ((0, 1, 2), 0, 0, 1, 0), ((1,), 1, 63, 1, 0), ((2,), 1, 63, 1, 0)]
+    return ci.encode(O.params(progressive=1, marker_style=0), script=script)
+
+
+def test_emul_two_dc_refinement_passes(api):
+    srcs = [two_dc_refinements_file(), two_dc_refinements_file(11, 640, 480, 2, 60), two_dc_refinements_file(12, 97, 75, 0, 15)]
+    want = [oracle_lossless(s) for s in srcs]
+    bt = api.batch(srcs, params(jpeg_optimize=True))
+    t = bt.run()
+    assert t.n_seq_decoded == 0 and t.n_par_fallback == 0
+    assert bt.fetch() == want
+    assert api.batch_compress(srcs, params()) == [oracle_lossy(s) for s in srcs]
+
+
 def test_emul_irregular_progressions_decode_in_file_order(api):
     """a damaged scan header can make two first scans cover one band, or a refinement scan come before the band's first scan: libjpeg warns and decodes in file
     order (the later scan wins).  The parallel kinds of the progressive decoder run side by side, so such a file must stay on the ordered chains"""
