@@ -45,42 +45,67 @@ using Oct = std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>;
 #define FIX_2_562 20995
 #define FIX_3_072 25172
 #define MUL(a, c) __mul24((a), (c))
-#define DESC(x, n) (((x) + (1 << ((n)-1))) >> (n))
+#define MAD(a, c, b) (__mul24((a), (c)) + (b))   // v_mad_i32_i24
 
-// one 1-D inverse transform of jidctint; in: frequency order, out: sample order
-__device__ __forceinline__ static void idct1d(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5, int &x6, int &x7, const int sh) {
-    int z1 = MUL(x2 + x6, FIX_0_541), tmp2 = z1 - MUL(x6, FIX_1_847), tmp3 = z1 + MUL(x2, FIX_0_765);
-    int tmp0 = (x0 + x4) * 8192, tmp1 = (x0 - x4) * 8192;
-    int t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
+// What an instruction costs on gfx950 (tools/ubench/valu_rates*.hip, profiles/r05_valu_rates.txt): a wave64 VALU instruction issues in 2 cycles if it
+// is a plain add / subtract / logic / right shift / move / f32 add, multiply or fma on VGPR or literal operands, and in 4 if it is anything else --
+// every integer multiply (24- or 32-bit, v_dot2 alike), v_mad, v_add3, v_med3, min / max, v_perm, the left shift, every SDWA / DPP form, every
+// packed 16-bit operation, every conversion, anything that reads an SGPR.  So the transforms below are written for FEW SLOW instructions, not for
+// few instructions: 14 multiplies per 1-D transform, the rounding term of a pass folded into the multiply-add that makes the even part's z1 /
+// tmp0 / tmp1 (or the odd part's z5) so that an output is one add and one right shift, and sums of three terms as two adds (v_add3 costs the
+// same as two adds).  A v_dot2_i32_i16 form (16 dot products per 1-D transform) would need its inputs packed in pairs by v_perm (4 cycles a
+// pair) and a 16-bit range check per pass: measured arithmetic, DESIGN.md 6 -- it does not pay.
+
+// one 1-D inverse transform of jidctint; in: frequency order, out: sample order; DESCALE(., SH) of every output
+template <int SH>
+__device__ __forceinline__ static void idct1d(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5, int &x6, int &x7) {
+    const int R = 1 << (SH - 1);
+    const int z1 = MUL(x2 + x6, FIX_0_541), tmp2 = MAD(x6, -FIX_1_847, z1), tmp3 = MAD(x2, FIX_0_765, z1);
+    const int tmp0 = MAD(x0 + x4, 8192, R), tmp1 = MAD(x0 - x4, 8192, R);   // carries the rounding term of all eight outputs
+    const int t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
     int a0 = x7, a1 = x5, a2 = x3, a3 = x1;
-    int y1 = a0 + a3, y2 = a1 + a2, y3 = a0 + a2, y4 = a1 + a3, y5 = MUL(y3 + y4, FIX_1_175);
-    a0 = MUL(a0, FIX_0_298); a1 = MUL(a1, FIX_2_053); a2 = MUL(a2, FIX_3_072); a3 = MUL(a3, FIX_1_501);
-    y1 = MUL(y1, -FIX_0_899); y2 = MUL(y2, -FIX_2_562); y3 = MUL(y3, -FIX_1_961) + y5; y4 = MUL(y4, -FIX_0_390) + y5;
-    a0 += y1 + y3; a1 += y2 + y4; a2 += y2 + y3; a3 += y1 + y4;
-    x0 = DESC(t10 + a3, sh); x7 = DESC(t10 - a3, sh);
-    x1 = DESC(t11 + a2, sh); x6 = DESC(t11 - a2, sh);
-    x2 = DESC(t12 + a1, sh); x5 = DESC(t12 - a1, sh);
-    x3 = DESC(t13 + a0, sh); x4 = DESC(t13 - a0, sh);
+    const int y1 = a0 + a3, y2 = a1 + a2;
+    int y3 = a0 + a2, y4 = a1 + a3;
+    const int y5 = MUL(y3 + y4, FIX_1_175);
+    y3 = MAD(y3, -FIX_1_961, y5); y4 = MAD(y4, -FIX_0_390, y5);
+    const int p1 = MUL(y1, -FIX_0_899), p2 = MUL(y2, -FIX_2_562);
+    a0 = MAD(a0, FIX_0_298, p1) + y3; a1 = MAD(a1, FIX_2_053, p2) + y4; a2 = MAD(a2, FIX_3_072, p2) + y3; a3 = MAD(a3, FIX_1_501, p1) + y4;
+    x0 = (t10 + a3) >> SH; x7 = (t10 - a3) >> SH;
+    x1 = (t11 + a2) >> SH; x6 = (t11 - a2) >> SH;
+    x2 = (t12 + a1) >> SH; x5 = (t12 - a1) >> SH;
+    x3 = (t13 + a0) >> SH; x4 = (t13 - a0) >> SH;
 }
 
 // one 1-D forward transform of jfdctint; FIRST: row pass (<<2, descale 11), else column pass (descale 2 / 15)
 template <bool FIRST>
 __device__ __forceinline__ static void fdct1d(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5, int &d6, int &d7) {
     int tmp0 = d0 + d7, tmp7 = d0 - d7, tmp1 = d1 + d6, tmp6 = d1 - d6, tmp2 = d2 + d5, tmp5 = d2 - d5, tmp3 = d3 + d4, tmp4 = d3 - d4;
-    int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-    const int SH = FIRST ? 11 : 15;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    const int SH = FIRST ? 11 : 15, R = 1 << (SH - 1);
     int o0, o4;
     if (FIRST) { o0 = (tmp10 + tmp11) * 4; o4 = (tmp10 - tmp11) * 4; }
-    else { o0 = DESC(tmp10 + tmp11, 2); o4 = DESC(tmp10 - tmp11, 2); }
-    int z1 = MUL(tmp12 + tmp13, FIX_0_541);
-    int o2 = DESC(z1 + MUL(tmp13, FIX_0_765), SH), o6 = DESC(z1 - MUL(tmp12, FIX_1_847), SH);
-    int y1 = tmp4 + tmp7, y2 = tmp5 + tmp6, y3 = tmp4 + tmp6, y4 = tmp5 + tmp7, y5 = MUL(y3 + y4, FIX_1_175);
-    tmp4 = MUL(tmp4, FIX_0_298); tmp5 = MUL(tmp5, FIX_2_053); tmp6 = MUL(tmp6, FIX_3_072); tmp7 = MUL(tmp7, FIX_1_501);
-    y1 = MUL(y1, -FIX_0_899); y2 = MUL(y2, -FIX_2_562); y3 = MUL(y3, -FIX_1_961) + y5; y4 = MUL(y4, -FIX_0_390) + y5;
+    else { o0 = (tmp10 + tmp11 + 2) >> 2; o4 = (tmp10 - tmp11 + 2) >> 2; }
+    const int z1 = MAD(tmp12 + tmp13, FIX_0_541, R);
+    const int o2 = MAD(tmp13, FIX_0_765, z1) >> SH, o6 = MAD(tmp12, -FIX_1_847, z1) >> SH;
+    const int y1 = tmp4 + tmp7, y2 = tmp5 + tmp6;
+    int y3 = tmp4 + tmp6, y4 = tmp5 + tmp7;
+    const int y5 = MAD(y3 + y4, FIX_1_175, R);   // every odd output holds exactly one of y3 / y4, so z5 carries their rounding term
+    y3 = MAD(y3, -FIX_1_961, y5); y4 = MAD(y4, -FIX_0_390, y5);
+    const int p1 = MUL(y1, -FIX_0_899), p2 = MUL(y2, -FIX_2_562);
     d0 = o0; d4 = o4; d2 = o2; d6 = o6;
-    d7 = DESC(tmp4 + y1 + y3, SH); d5 = DESC(tmp5 + y2 + y4, SH);
-    d3 = DESC(tmp6 + y2 + y3, SH); d1 = DESC(tmp7 + y1 + y4, SH);
+    d7 = (MAD(tmp4, FIX_0_298, p1) + y3) >> SH; d5 = (MAD(tmp5, FIX_2_053, p2) + y4) >> SH;
+    d3 = (MAD(tmp6, FIX_3_072, p2) + y3) >> SH; d1 = (MAD(tmp7, FIX_1_501, p1) + y4) >> SH;
 }
+
+// two 16-bit halves in one register: lo's low half | hi's low half << 16 (v_perm_b32: one instruction, nothing to mask)
+__device__ __forceinline__ static uint32_t pack_halves(uint32_t lo, uint32_t hi) {
+#ifdef CSH_EMUL
+    return (lo & 0xFFFFu) | (hi << 16);
+#else
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+#endif
+}
+__device__ __forceinline__ static uint32_t float_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
 // load (8 x 16-byte octets) + dequantise + 2-D IDCT + level shift + range limit; samples (0..255) out, natural order
 template <int J, int... I>
@@ -98,11 +123,11 @@ __device__ __forceinline__ static void load_idct(const int16_t *__restrict__ blk
     load_dequant(blk, q, x, Oct());
     CSH_SCHED_FENCE();
     CSH_UNROLL
-    for (int c = 0; c < 8; c++) idct1d(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c], 11);
+    for (int c = 0; c < 8; c++) idct1d<11>(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
     CSH_SCHED_FENCE();
     CSH_UNROLL
     for (int r = 0; r < 8; r++) {
-        idct1d(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7], 18);
+        idct1d<18>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
         CSH_UNROLL
         for (int c = 0; c < 8; c++) {
             if (CENTRED) { const int v = x[8 * r + c]; x[8 * r + c] = v < -128 ? -128 : (v > 127 ? 127 : v); }
@@ -131,23 +156,23 @@ __device__ __forceinline__ static void replicate_edges(int x[64], int vc, int vr
 }
 
 // samples (0..255, natural order) -> level shift -> 2-D FDCT -> scalar quantise -> store as 8 x 16-byte octets
-// high 32 bits of the 48-bit product of two 24-bit values: v_mul_hi_u32_u24, full rate
-__device__ __forceinline__ static uint32_t mulhi24(uint32_t a, uint32_t b) { return uint32_t((uint64_t(a & 0xFFFFFFu) * uint64_t(b & 0xFFFFFFu)) >> 32); }
+// The scalar quantiser sign(t) * ((|t| + d / 2) / d), d = 8 q, as ONE fused multiply-add in f32: t * rcp + 1.5 * 2^23, whose low
+// 16 bits are the two's-complement quotient.  rcp = fl((1 / d) (1 + 2^-19)) (types.h DevQuant::rcp): the product is formed exactly, the nudge
+// puts every tie t = d (k + 1/2) beyond its half (away from zero, as the integer form rounds) and moves nothing else across a half (|t| / d *
+// 2^-19 < 1 / (16 d), the next quotient down is 1 / d away), and the add's round-to-nearest at 2^23 (spacing 1) is the rounding itself.
+// Exhaustive over every d = 8 q, q < 65536, and |t| <= 2^15: tests/test_quant_reciprocal.py.  Three instructions a coefficient (convert,
+// fma, half of a v_perm) against eight for the integer reciprocal it replaces; any 16-bit table value (round 4's form stopped at q < 2048).
 template <int K>
 __device__ __forceinline__ static uint32_t quant_one(const int x[64], const DevQuant &q) {
-    // (|t| + d / 2) / d, exactly, in two full-rate instructions (types.h DevQuant::mul): |t| <= 2^15 (a jfdctint output of 8-bit samples, or a
-    // retained one read back from its int16), d = 8 q <= 2040
-    const int t = x[kZ2N[K]], a = (t < 0 ? -t : t) + (q.div[K] >> 1);
-    const int qv = int(mulhi24(uint32_t(a) << q.sh[K], q.mul[K]));
-    return uint32_t(t < 0 ? -qv : qv) & 0xFFFFu;
+    return float_bits(__builtin_fmaf(float(x[kZ2N[K]]), q.rcp[K], 12582912.0f));   // low half = the level
 }
 template <int J>
 __device__ __forceinline__ static void quant_store_octet(const int x[64], const DevQuant &q, int16_t *__restrict__ blk) {
     uint4 v;
-    v.x = quant_one<8 * J + 0>(x, q) | (quant_one<8 * J + 1>(x, q) << 16);
-    v.y = quant_one<8 * J + 2>(x, q) | (quant_one<8 * J + 3>(x, q) << 16);
-    v.z = quant_one<8 * J + 4>(x, q) | (quant_one<8 * J + 5>(x, q) << 16);
-    v.w = quant_one<8 * J + 6>(x, q) | (quant_one<8 * J + 7>(x, q) << 16);
+    v.x = pack_halves(quant_one<8 * J + 0>(x, q), quant_one<8 * J + 1>(x, q));
+    v.y = pack_halves(quant_one<8 * J + 2>(x, q), quant_one<8 * J + 3>(x, q));
+    v.z = pack_halves(quant_one<8 * J + 4>(x, q), quant_one<8 * J + 5>(x, q));
+    v.w = pack_halves(quant_one<8 * J + 6>(x, q), quant_one<8 * J + 7>(x, q));
     *reinterpret_cast<uint4 *>(blk + CSH_OCT_STRIDE * J) = v;
 }
 template <int... J>
@@ -157,10 +182,10 @@ __device__ __forceinline__ static void quant_store_all(const int x[64], const De
 template <int J>
 __device__ __forceinline__ static void raw_store_octet(const int x[64], int16_t *__restrict__ raw) {
     uint4 v;
-    v.x = (uint32_t(x[kZ2N[8 * J + 0]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 1]]) << 16);
-    v.y = (uint32_t(x[kZ2N[8 * J + 2]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 3]]) << 16);
-    v.z = (uint32_t(x[kZ2N[8 * J + 4]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 5]]) << 16);
-    v.w = (uint32_t(x[kZ2N[8 * J + 6]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 7]]) << 16);
+    v.x = pack_halves(uint32_t(x[kZ2N[8 * J + 0]]), uint32_t(x[kZ2N[8 * J + 1]]));
+    v.y = pack_halves(uint32_t(x[kZ2N[8 * J + 2]]), uint32_t(x[kZ2N[8 * J + 3]]));
+    v.z = pack_halves(uint32_t(x[kZ2N[8 * J + 4]]), uint32_t(x[kZ2N[8 * J + 5]]));
+    v.w = pack_halves(uint32_t(x[kZ2N[8 * J + 6]]), uint32_t(x[kZ2N[8 * J + 7]]));
     *reinterpret_cast<uint4 *>(raw + CSH_RAW_OCT * J) = v;
 }
 template <int... J>
@@ -180,10 +205,10 @@ __device__ __forceinline__ static void raw_store_all(const int x[64], int16_t *_
 template <int J>
 __device__ __forceinline__ static void raw_put_octet(const int x[64], int16_t (*tr)[256], int tid) {
     uint4 v;
-    v.x = (uint32_t(x[kZ2N[8 * J + 0]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 1]]) << 16);
-    v.y = (uint32_t(x[kZ2N[8 * J + 2]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 3]]) << 16);
-    v.z = (uint32_t(x[kZ2N[8 * J + 4]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 5]]) << 16);
-    v.w = (uint32_t(x[kZ2N[8 * J + 6]]) & 0xFFFFu) | (uint32_t(x[kZ2N[8 * J + 7]]) << 16);
+    v.x = pack_halves(uint32_t(x[kZ2N[8 * J + 0]]), uint32_t(x[kZ2N[8 * J + 1]]));
+    v.y = pack_halves(uint32_t(x[kZ2N[8 * J + 2]]), uint32_t(x[kZ2N[8 * J + 3]]));
+    v.z = pack_halves(uint32_t(x[kZ2N[8 * J + 4]]), uint32_t(x[kZ2N[8 * J + 5]]));
+    v.w = pack_halves(uint32_t(x[kZ2N[8 * J + 6]]), uint32_t(x[kZ2N[8 * J + 7]]));
     const int l = tid & 63;
     *reinterpret_cast<uint4 *>(&tr[l][(tid & ~63) + 8 * (J ^ (l & 7))]) = v;
 }
@@ -327,8 +352,8 @@ __device__ __forceinline__ static void store_zero_block(int16_t *__restrict__ bl
 // ------------------------------------------------------------------------------------------------
 // mode 0: full-resolution component, IDCT -> (crop + edge expand) -> FDCT -> quantise
 template <bool DERING>
-__global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant,
-                                                       const int16_t *coef_in, int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+__global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *__restrict__ imgs, const PlaneWork *__restrict__ work, const DevQuant *__restrict__ quant,
+                                                       const int16_t *__restrict__ coef_in, int16_t *__restrict__ coef_out, int16_t *__restrict__ dct_raw, uint32_t raw_tile0) {
     CSH_SHARED int16_t s_dr[64][256];   // deringing: a column per lane; then the wave's columns carry its retained-DCT blocks to whole-line stores (raw_copy_out)
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 0) return;
@@ -344,18 +369,18 @@ __global__ void __launch_bounds__(256) k_xform_direct(const ImgDesc *imgs, const
         int16_t *dst = coef_out + coef_index(go.tile_base, b, 0);
         if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); break; }
         int x[64];
-        load_idct<true>(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[im.qt_in[w.comp]], x);
+        load_idct<true>(coef_in + coef_index(gi.tile_base, by * gi.bw + bx, 0), quant[CSH_UNIFORM(im.qt_in[w.comp])], x);
         int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
         if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
-        fdct_quant_store<DERING, true>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+        fdct_quant_store<DERING, true>(x, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
         has_raw = dct_raw != nullptr;
     } while (0);
     if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
 }
 
 // mode 1 producer: subsampled component, IDCT -> u8 plane (pitch real_bw*8, rows real_bh*8, edges replicated)
-__global__ void __launch_bounds__(256) k_idct_plane(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant,
-                                                     const int16_t *coef_in, uint8_t *planes) {
+__global__ void __launch_bounds__(256) k_idct_plane(const ImgDesc *__restrict__ imgs, const PlaneWork *__restrict__ work, const DevQuant *__restrict__ quant,
+                                                     const int16_t *__restrict__ coef_in, uint8_t *__restrict__ planes) {
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0) return;
     const ImgDesc &im = imgs[w.image];
@@ -367,7 +392,7 @@ __global__ void __launch_bounds__(256) k_idct_plane(const ImgDesc *imgs, const P
     int by = b / gi.bw, bx = b - by * gi.bw;
     if (by >= gi.real_bh || bx >= gi.real_bw) return;
     int x[64];
-    load_idct(coef_in + coef_index(gi.tile_base, b, 0), quant[im.qt_in[w.comp]], x);
+    load_idct(coef_in + coef_index(gi.tile_base, b, 0), quant[CSH_UNIFORM(im.qt_in[w.comp])], x);
     int vc = gi.comp_w - bx * 8, vr = gi.comp_h - by * 8;
     if (vc < 8 || vr < 8) replicate_edges(x, vc, vr);
     int pitch = gi.real_bw * 8;
@@ -535,8 +560,8 @@ __global__ void __launch_bounds__(256) k_resample_plane(const ImgDesc *imgs, con
 
 // encoder-side plane -> FDCT -> quantise, one block per lane
 template <bool DERING>
-__global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *oplanes,
-                                                     int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+__global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *__restrict__ imgs, const PlaneWork *__restrict__ work, const DevQuant *__restrict__ quant, const uint8_t *__restrict__ oplanes,
+                                                     int16_t *__restrict__ coef_out, int16_t *__restrict__ dct_raw, uint32_t raw_tile0) {
     CSH_SHARED int16_t s_dr[64][256];   // deringing: a column per lane; then the wave's columns carry its retained-DCT blocks to whole-line stores (raw_copy_out)
     const PlaneWork w = work[blockIdx.y];
     if (w.mode == 0 || w.mode == 10) return;
@@ -560,7 +585,7 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
         CSH_UNROLL
         for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
     }
-    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    fdct_quant_store<DERING>(x, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
     has_raw = dct_raw != nullptr;
     } while (0);
     if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
@@ -574,8 +599,8 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *imgs, const P
 //   columns: full-resolution columns beyond W-1 replicate column W-1 -- the per-column sums are patched in the block that
 //            holds plane column (W-1)/2 (always the last block column).
 template <bool DERING>
-__global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const uint8_t *planes,
-                                                            int16_t *coef_out, int16_t *dct_raw, uint32_t raw_tile0) {
+__global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *__restrict__ imgs, const PlaneWork *__restrict__ work, const DevQuant *__restrict__ quant, const uint8_t *__restrict__ planes,
+                                                            int16_t *__restrict__ coef_out, int16_t *__restrict__ dct_raw, uint32_t raw_tile0) {
     CSH_SHARED int16_t s_dr[64][256];   // deringing: a column per lane; then the wave's columns carry its retained-DCT blocks to whole-line stores (raw_copy_out)
     const PlaneWork w = work[blockIdx.y];
     if (w.mode != 10) return;
@@ -658,15 +683,15 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *imgs, 
                 for (int cc = 0; cc < 8; cc++) x[8 * r + cc] = x[8 * (r - 1) + cc];
             }
     }
-    fdct_quant_store<DERING>(x, quant[im.qt_out[w.comp]], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    fdct_quant_store<DERING>(x, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
     has_raw = dct_raw != nullptr;
     } while (0);
     if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
 }
 
 // size-targeting: re-quantise every retained DCT block with the image's CURRENT output table (one block per lane)
-__global__ void __launch_bounds__(256) k_requant(const ImgDesc *imgs, const PlaneWork *work, const DevQuant *quant, const int16_t *dct_raw, uint32_t raw_tile0,
-                                                  int16_t *coef_out) {
+__global__ void __launch_bounds__(256) k_requant(const ImgDesc *__restrict__ imgs, const PlaneWork *__restrict__ work, const DevQuant *__restrict__ quant, const int16_t *__restrict__ dct_raw, uint32_t raw_tile0,
+                                                  int16_t *__restrict__ coef_out) {
     const PlaneWork w = work[blockIdx.y];
     const ImgDesc &im = imgs[w.image];
     const CompGeom go = im.out[w.comp];
@@ -676,7 +701,7 @@ __global__ void __launch_bounds__(256) k_requant(const ImgDesc *imgs, const Plan
     if (b >= go.bw * go.bh) return;
     int by = b / go.bw, bx = b - by * go.bw;
     if (by >= go.real_bh || bx >= go.real_bw) return;   // dummy blocks: k_fix_dummy
-    requant_block(dct_raw + raw_index(go.tile_base - raw_tile0, b), quant[im.qt_out[w.comp]], coef_out + coef_index(go.tile_base, b, 0), Oct());
+    requant_block(dct_raw + raw_index(go.tile_base - raw_tile0, b), quant[CSH_UNIFORM(im.qt_out[w.comp])], coef_out + coef_index(go.tile_base, b, 0), Oct());
 }
 
 // dummy blocks (exist only to complete an MCU): zero AC, DC copied per libjpeg's jccoefct rule

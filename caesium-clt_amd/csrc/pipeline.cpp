@@ -302,7 +302,7 @@ static void make_quant(const uint16_t nat[64], DevQuant &q) {
     for (int k = 0; k < 64; k++) {
         q.q[k] = nat[kZigZag[k]];
         q.div[k] = int32_t(q.q[k]) * 8;
-        q.rcp[k] = 1.0f / float(q.div[k]);
+        q.rcp[k] = float((1.0 / double(q.div[k])) * (1.0 + 1.0 / 524288.0));   // the pixel kernels' quantiser: one fma (k_pixel.hip quant_one); exact for every 16-bit q
         q.lt[k] = float(1.0 / double(int(q.q[k]) * int(q.q[k])));   // mozjpeg quantize_trellis, mode 1: lambda_table[i] = 1.0 / (q * q)
         q.mul[k] = 0; q.sh[k] = 0;
         if (q.div[k] > 0 && q.div[k] < (1 << 14)) {

@@ -141,7 +141,7 @@ enum { CSH_PS_SEQ = 0, CSH_PS_UNSTUFF = 1, CSH_PS_DC_FIRST = 2, CSH_PS_AC_FIRST 
 struct DevQuant {
     uint16_t q[64];      // table value, zig-zag order
     int32_t div[64];     // q*8 (jfdctint output is scaled by 8)
-    float rcp[64];       // 1.0f/div, host-computed
+    float rcp[64];       // fl((1 / div) (1 + 2^-19)), host-computed in double: the quantiser's one fma (k_pixel.hip quant_one)
     float lt[64];        // 1 / q^2 as float(1.0 / double(q * q)): the distortion weight of mozjpeg's trellis (k_trellis.hip), host-computed
     // exact a / div for 0 <= a < 2^17 on the full-rate 24-bit multiplier: (a << sh) * mul >> 32  (v_mul_hi_u32_u24).  With P = 32 - sh =
     // max(25, floor(log2 div) + 18) and mul = floor(2^P / div) + 1: the estimate exceeds a / div by less than 1 / div (a * div < 2^P), so its

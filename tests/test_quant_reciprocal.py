@@ -1,6 +1,20 @@
-"""The quantiser's exact division (types.h DevQuant::mul / ::sh, k_pixel.hip quant_one): (a << sh) * mul >> 32 on the 24-bit multiplier must be
-a / d for every dividend the kernels can meet (a = |coefficient| + d / 2 < 2^17) and every divisor d = 8 q of an 8-bit table."""
+"""Exact division in the quantisers.  (1) the trellis kernels' integer reciprocal (types.h DevQuant::mul / ::sh, k_trellis.hip): (a << sh) * mul >> 32
+on the 24-bit multiplier must be a / d for every dividend the kernels can meet (a = |coefficient| + d / 2 < 2^17) and every divisor d = 8 q of an
+8-bit table.  (2) the pixel kernels' scalar quantiser (k_pixel.hip quant_one): one f32 fused multiply-add, exhaustively (tests/quant_fma_check.c)."""
+import os
+import subprocess
+import tempfile
+
 import numpy as np
+
+
+def test_fma_quantiser_every_16_bit_table_value_and_every_coefficient():
+    src = os.path.join(os.path.dirname(__file__), "quant_fma_check.c")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "qcheck")
+        subprocess.check_call(["gcc", "-O2", "-o", exe, src, "-lm"])
+        out = subprocess.check_output([exe], timeout=600).decode()
+    assert out.strip().endswith("bad=0"), out
 
 
 def recip(d):
