@@ -591,6 +591,19 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *__restrict__ 
     if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
 }
 
+// sixteen bytes of a plane row from a 4-byte aligned address (x0 - 4): one global_load_dwordx4
+struct Row16 { uint32_t a, b, c, d; };
+__device__ __forceinline__ static Row16 load_row16(const uint8_t *p) {
+    Row16 r;
+#ifdef CSH_EMUL
+    __builtin_memcpy(&r, p, 16);
+#else
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p);
+    r.a = v.x; r.b = v.y; r.c = v.z; r.d = v.w;
+#endif
+    return r;
+}
 // The camera case in one pass: 4:2:0 in, 4:2:0 out, no resize (PlaneWork.mode 10).  One lane per OUTPUT block: a 10 x 10 window of
 // the decoded plane (4 dwords x 10 rows) -> fancy upsample o box downsample in packed registers -> FDCT -> quantise.  The
 // encoder-side plane is never written.  libjpeg's edge rules are applied where they bite:
@@ -632,30 +645,47 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *__rest
         mC[q] = even_gone(4 * q + 1) | (even_gone(4 * q + 3) << 16);
         mD[q] = odd_gone(4 * q + 1) | (odd_gone(4 * q + 3) << 16);
     }
-    int x[64];
-    Quad420 win[3][2];
-    auto load_row = [&](int j, Quad420 out[2]) {
+    // the whole 10 x 16-byte window first (one wait for memory, not ten): row j = plane row y0 - 1 + j, bytes x0 - 4 .. x0 + 11.  The first
+    // block of a row reads four bytes in front of its row and the last four bytes behind it (the neighbouring rows' ends; the plane pool has 64
+    // bytes of slack at either end, pipeline.cpp) and replaces them with its own edge sample.
+    Row16 rows[10];
+    CSH_UNROLL
+    for (int j = 0; j < 10; j++) {
         int yy = y0 - 1 + j;
         if (hodd && yy == och) yy = och - 2;
         yy = yy < 0 ? 0 : (yy > rows_alloc - 1 ? rows_alloc - 1 : yy);
-        const uint32_t *rp = reinterpret_cast<const uint32_t *>(pl + size_t(yy) * pitch + x0);
-        const uint32_t bq = rp[0], cq = rp[1];
-        const uint32_t aq = first ? bq << 24 : rp[-1];     // plane column -1 = column 0
-        const uint32_t dq = last ? cq >> 24 : rp[2];       // plane column `pitch` = column pitch-1
+        rows[j] = load_row16(pl + size_t(yy) * pitch + x0 - 4);
+    }
+    // does any lane of the wave sit on the picture's right edge with columns to replicate?  (1080p: none -- W is even and ends with its block)
+    const bool patch = kt < 8 && ((mA[0] | mB[0] | mC[0] | mD[0] | mA[1] | mB[1] | mC[1] | mD[1]) != 0u);
+#ifdef CSH_EMUL
+    const bool any_patch = patch;
+#else
+    const bool any_patch = __ballot(patch) != 0ull;
+#endif
+    int x[64];
+    Quad420 win[3][2];
+    auto row_fields = [&](int j, Quad420 out[2]) {
+        const uint32_t bq = rows[j].b, cq = rows[j].c;
+        const uint32_t aq = first ? bq << 24 : rows[j].a;     // plane column -1 = column 0
+        const uint32_t dq = last ? cq >> 24 : rows[j].d;      // plane column `pitch` = column pitch-1
         out[0] = quad420_fields(aq, bq, cq);
         out[1] = quad420_fields(bq, cq, dq);
     };
-    load_row(0, win[0]);
-    load_row(1, win[1]);
+    row_fields(0, win[0]);
+    row_fields(1, win[1]);
     CSH_UNROLL
     for (int r = 0; r < 8; r++) {
         Quad420 *p = win[r % 3], *c = win[(r + 1) % 3], *n = win[(r + 2) % 3];
-        load_row(r + 2, n);
+        row_fields(r + 2, n);
         Sums420 s[2] = {quad420_sums(p[0], c[0], n[0]), quad420_sums(p[1], c[1], n[1])};
-        if (kt < 8) {
+        if (any_patch && patch) {
             // the sum at full-resolution column W-1: plane column kt, the 2x+1 sample when W is even
-            const int q = kt >> 2, odd_col = kt & 1;
-            uint32_t sl = wodd ? (odd_col ? s[q].C : s[q].A) : (odd_col ? s[q].D : s[q].B);
+            const int odd_col = kt & 1;
+            const Sums420 &sq = (kt >> 2) ? s[1] : s[0];   // (selects, not a run-time index: that would put the sums in scratch memory)
+            const uint32_t sqA = (kt >> 2) ? s[1].A : s[0].A, sqB = (kt >> 2) ? s[1].B : s[0].B, sqC = (kt >> 2) ? s[1].C : s[0].C, sqD = (kt >> 2) ? s[1].D : s[0].D;
+            (void)sq;
+            uint32_t sl = wodd ? (odd_col ? sqC : sqA) : (odd_col ? sqD : sqB);
             sl = (kt & 2) ? sl >> 16 : sl & 0xFFFFu;
             sl |= sl << 16;
             CSH_UNROLL

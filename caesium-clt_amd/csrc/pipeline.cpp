@@ -704,7 +704,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
 
     std::vector<std::pair<std::vector<uint8_t>, int>> hset_keys;
     std::map<std::vector<uint16_t>, int> quant_index;
-    uint64_t plane_off = 0, oplane_off = 0;   // 64-bit: a resize batch of 1024 1080p files has 7 GB of planes
+    uint64_t plane_off = 64, oplane_off = 0;  // 64-bit: a resize batch of 1024 1080p files has 7 GB of planes; 64 bytes in front of the first plane: k_resample_fdct_420 reads a row's window from four bytes before it
 
     {   // marker parsing is per file and touches every byte of it once (the hunt for the end of each scan): all cores
         std::atomic<size_t> next{0};

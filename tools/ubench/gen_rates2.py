@@ -1,6 +1,16 @@
 #!/usr/bin/env python3
 """Writes valu_rates2.hip: issue cost of one VALU instruction form per kernel (16 independent registers, 64 instructions per loop trip)."""
+import re
 forms = [
+    ("add_u32", "v_add_u32 %0, %0, %1"), ("add3_u32", "v_add3_u32 %0, %0, %1, %2"), ("mul_i32_i24", "v_mul_i32_i24 %0, %0, %1"), ("mad_i32_i24", "v_mad_i32_i24 %0, %1, %2, %0"),
+    ("mul_hi_u32_u24", "v_mul_hi_u32_u24 %0, %0, %1"), ("mul_lo_u32", "v_mul_lo_u32 %0, %0, %1"), ("dot2_i32_i16", "v_dot2_i32_i16 %0, %1, %2, %0"),
+    ("pk_mul_lo_u16", "v_pk_mul_lo_u16 %0, %0, %1"), ("pk_add_i16", "v_pk_add_i16 %0, %0, %1"), ("perm_b32", "v_perm_b32 %0, %0, %1, %2"),
+    ("cvt_pk_i16_i32", "v_cvt_pk_i16_i32 %0, %0, %1"), ("med3_i32", "v_med3_i32 %0, %0, %1, %2"), ("ashrrev_i32", "v_ashrrev_i32 %0, 3, %0"),
+    ("lshl_add_u32", "v_lshl_add_u32 %0, %0, 2, %1"), ("lshl_or_b32", "v_lshl_or_b32 %0, %0, 16, %1"), ("and_or_b32", "v_and_or_b32 %0, %0, %1, %2"),
+    ("bitop3_b32", "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96"), ("bfi_b32", "v_bfi_b32 %0, %1, %0, %2"), ("cvt_f32_i32", "v_cvt_f32_i32 %0, %0"),
+    ("cvt_i32_f32", "v_cvt_i32_f32 %0, %0"), ("fma_f32", "v_fma_f32 %0, %1, %2, %0"), ("mul_f32", "v_mul_f32 %0, %0, %1"), ("fmaak_f32", "v_fmaak_f32 %0, %0, %1, 0x4b400000"),
+    ("max_i32", "v_max_i32 %0, %0, %1"), ("or3_b32", "v_or3_b32 %0, %0, %1, %2"),
+    ("mul24_sdwa", "v_mul_i32_i24_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"),
     # name, asm (%0 = accumulator register i, %1/%2 = loop-invariant VGPRs)
     ("sub_u32", "v_sub_u32 %0, %0, %1"), ("and_b32", "v_and_b32 %0, %0, %1"), ("or_b32", "v_or_b32 %0, %0, %1"), ("xor_b32", "v_xor_b32 %0, %0, %1"),
     ("lshlrev", "v_lshlrev_b32 %0, 1, %0"), ("lshrrev", "v_lshrrev_b32 %0, 1, %0"), ("mov_b32", "v_mov_b32 %0, %1"),
@@ -34,6 +44,11 @@ forms = [
 out = ['// generated by gen_rates2.py', '#include <hip/hip_runtime.h>', '#include <cstdio>', '#include <vector>']
 for name, asm in forms:
     k = "k_" + name.replace("+", "_")
+    lines = []
+    for i in range(16):
+        lines.append(asm.replace("%0", "%" + str(i)).replace("%1", "%16").replace("%2", "%17") if False else re.sub(r"%([012])", lambda m: "%" + str({0: i, 1: 16, 2: 17}[int(m.group(1))]), asm))
+    asm16 = " ".join('"' + l + '\\n"' for l in lines)
+    outs = ", ".join(f'"+v"(r[{i}])' for i in range(16))
     out.append(f'''__global__ void __launch_bounds__(256) {k}(uint32_t *out, int iters, uint32_t seed) {{
     uint32_t r[16];
     for (int i = 0; i < 16; i++) r[i] = seed * (threadIdx.x + 1) + i * 0x01010101u;
@@ -41,7 +56,7 @@ for name, asm in forms:
     asm volatile("s_mov_b64 s[12:13], 0x5555\\n s_mov_b32 s14, 0x3f800001\\n v_cmp_gt_u32 vcc, %0, %1" :: "v"(a), "v"(b) : "s12", "s13", "s14", "vcc", "s10", "s11");
     for (int it = 0; it < iters; it++) {{
         _Pragma("unroll") for (int u = 0; u < 4; u++) {{
-            _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile("{asm}" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc", "s10", "s11");
+            asm volatile({asm16} : {outs} : "v"(a), "v"(b) : "vcc", "s10", "s11");
         }}
     }}
     uint32_t s = 0;
