@@ -287,47 +287,150 @@ __device__ static void dering_walk(int16_t *col /* sample n (natural order) at c
         n++;
     } while (n < size);
 }
-__device__ __forceinline__ static void dering_block(int x[64] /* level-shifted, natural order */, int dc_quant, CSH_DERING_LDS) {
+// ---- the forward transform on PACKED samples.  jfdctint's inputs are 9-bit (level-shifted samples, up to 158 after deringing) and its first
+// pass's outputs 14-bit, so both passes take their inputs as pairs of int16 in one register: the first butterfly is a packed add and a packed
+// subtract (v_pk_add_i16 / v_pk_sub_i16: two butterflies each), and every output is two v_dot2_i32_i16 -- the even and odd parts of ISLOW written as
+// the exact integer dot products they are (the constants below are the sums of jfdctint's; the pre-shift sum of an output equals ISLOW's, so does
+// its DESCALE).  26 / 28 instructions per 1-D pass against 42 / 44 in the multiply-add form; every VALU instruction of a mixed integer stream
+// costs about four cycles on gfx950 (profiles/r05_valu_rates.txt), so the count is what matters.  No range check: the bounds hold for every input.
+// A block's row r is four registers: A = (d0, d1), B = (d7, d6), C = (d2, d3), D = (d5, d4).
+// UNCENTRED samples (0..255, +31 after deringing) may be transformed as they are: the level shift only moves the DC term -- + 8 * 128 * 4 behind
+// the row pass, which the column pass of column 0 turns into + 8192 on coefficient (0, 0); its rounding term takes that back (BIAS0).
+constexpr uint32_t PK(int lo, int hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
+#ifdef CSH_EMUL
+__device__ __forceinline__ static uint32_t pk_add(uint32_t a, uint32_t b) { return ((a + b) & 0xFFFFu) | ((a & 0xFFFF0000u) + (b & 0xFFFF0000u)); }
+__device__ __forceinline__ static uint32_t pk_sub(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | ((a & 0xFFFF0000u) - (b & 0xFFFF0000u)); }
+__device__ __forceinline__ static uint32_t pk_max(uint32_t a, uint32_t b) {
+    const int16_t al = int16_t(a), bl = int16_t(b), ah = int16_t(a >> 16), bh = int16_t(b >> 16);
+    return uint32_t(uint16_t(al > bl ? al : bl)) | (uint32_t(uint16_t(ah > bh ? ah : bh)) << 16);
+}
+__device__ __forceinline__ static int dot2(uint32_t a, uint32_t k, int acc) {
+    return int(uint32_t(acc) + uint32_t(int(int16_t(a)) * int(int16_t(k))) + uint32_t(int(int16_t(a >> 16)) * int(int16_t(k >> 16))));
+}
+__device__ __forceinline__ static uint32_t pack_hi_halves(uint32_t lo, uint32_t hi) { return (lo >> 16) | (hi & 0xFFFF0000u); }
+// bytes I0, I1 of w, zero-extended to two halves
+template <int I0, int I1> __device__ __forceinline__ static uint32_t bytes_to_halves(uint32_t w) { return ((w >> (8 * I0)) & 255u) | (((w >> (8 * I1)) & 255u) << 16); }
+#else
+typedef short pk16_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ static uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(pk16_t, a) + __builtin_bit_cast(pk16_t, b)); }
+__device__ __forceinline__ static uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(pk16_t, a) - __builtin_bit_cast(pk16_t, b)); }
+__device__ __forceinline__ static uint32_t pk_max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk16_t, a), __builtin_bit_cast(pk16_t, b))); }
+__device__ __forceinline__ static int dot2(uint32_t a, uint32_t k, int acc) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(pk16_t, a), __builtin_bit_cast(pk16_t, k), acc, false); }
+__device__ __forceinline__ static uint32_t pack_hi_halves(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+template <int I0, int I1> __device__ __forceinline__ static uint32_t bytes_to_halves(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c000c00u | uint32_t(I0) | (uint32_t(I1) << 16)); }
+#endif
+// the odd part as a 4 x 4 matrix on (tmp4, tmp5, tmp6, tmp7): what jfdctint's z1..z5 network sums up to, per output
+constexpr int kO7[4] = {FIX_0_298 - FIX_0_899 - FIX_1_961 + FIX_1_175, FIX_1_175, -FIX_1_961 + FIX_1_175, -FIX_0_899 + FIX_1_175};
+constexpr int kO5[4] = {FIX_1_175, FIX_2_053 - FIX_2_562 - FIX_0_390 + FIX_1_175, -FIX_2_562 + FIX_1_175, -FIX_0_390 + FIX_1_175};
+constexpr int kO3[4] = {-FIX_1_961 + FIX_1_175, -FIX_2_562 + FIX_1_175, FIX_3_072 - FIX_2_562 - FIX_1_961 + FIX_1_175, FIX_1_175};
+constexpr int kO1[4] = {-FIX_0_899 + FIX_1_175, -FIX_0_390 + FIX_1_175, FIX_1_175, FIX_1_501 - FIX_0_899 - FIX_0_390 + FIX_1_175};
+template <bool FIRST>
+__device__ __forceinline__ static void fdct1d_pk(uint32_t A, uint32_t B, uint32_t C, uint32_t D, int R, int R0, int R4, int &o0, int &o1, int &o2, int &o3, int &o4, int &o5, int &o6, int &o7) {
+    const uint32_t P = pk_add(A, B), M = pk_sub(A, B), Q = pk_add(C, D), N = pk_sub(C, D);   // (tmp0, tmp1), (tmp7, tmp6), (tmp2, tmp3), (tmp5, tmp4)
+    const int SH = FIRST ? 11 : 15;
+    // R: the rounding term of the outputs that are descaled by SH; R0 / R4: what out0 / out4 start from (row pass: 0; column pass: 2, and column 0 of an
+    // uncentred block 2 - 32768)
+    constexpr uint32_t KE0P = FIRST ? PK(4, 4) : PK(1, 1), KE0Q = KE0P, KE4P = FIRST ? PK(4, -4) : PK(1, -1), KE4Q = FIRST ? PK(-4, 4) : PK(-1, 1);
+    // z1 = (tmp12 + tmp13) c4433 with tmp13 = tmp0 - tmp3, tmp12 = tmp1 - tmp2: out2 = tmp13 (c4433 + c6270) + tmp12 c4433, out6 = tmp13 c4433 + tmp12 (c4433 - c15137)
+    constexpr uint32_t KE2P = PK(FIX_0_541 + FIX_0_765, FIX_0_541), KE2Q = PK(-FIX_0_541, -(FIX_0_541 + FIX_0_765));
+    constexpr uint32_t KE6P = PK(FIX_0_541, FIX_0_541 - FIX_1_847), KE6Q = PK(FIX_1_847 - FIX_0_541, -FIX_0_541);
+#ifdef CSH_EMUL
+    o0 = dot2(P, KE0P, dot2(Q, KE0Q, R0)); o4 = dot2(P, KE4P, dot2(Q, KE4Q, R4));
+    o2 = dot2(P, KE2P, dot2(Q, KE2Q, R)); o6 = dot2(P, KE6P, dot2(Q, KE6Q, R));
+    o7 = dot2(M, PK(kO7[3], kO7[2]), dot2(N, PK(kO7[1], kO7[0]), R));
+    o5 = dot2(M, PK(kO5[3], kO5[2]), dot2(N, PK(kO5[1], kO5[0]), R));
+    o3 = dot2(M, PK(kO3[3], kO3[2]), dot2(N, PK(kO3[1], kO3[0]), R));
+    o1 = dot2(M, PK(kO1[3], kO1[2]), dot2(N, PK(kO1[1], kO1[0]), R));
+#else
+    // the three-operand v_dot2_i32_i16 with its constants in scalar registers.  (Through the builtin the compiler picks the two-operand v_dot2c with a
+    // literal, which needs a v_mov of the rounding term in front of every output: 128 more instructions per block.  One asm statement per half
+    // transform: between separate statements it would put a wait state.)
+    asm("v_dot2_i32_i16 %0, %5, %8, %11\n\tv_dot2_i32_i16 %1, %5, %10, %12\n\tv_dot2_i32_i16 %2, %5, %14, %7\n\tv_dot2_i32_i16 %3, %5, %16, %7\n\t"
+        "v_dot2_i32_i16 %0, %4, %6, %0\n\tv_dot2_i32_i16 %1, %4, %9, %1\n\tv_dot2_i32_i16 %2, %4, %13, %2\n\tv_dot2_i32_i16 %3, %4, %15, %3"
+        : "=&v"(o0), "=&v"(o4), "=&v"(o2), "=&v"(o6)
+        : "v"(P), "v"(Q), "s"(KE0P), "v"(R), "s"(KE0Q), "s"(KE4P), "s"(KE4Q), "v"(R0), "v"(R4), "s"(KE2P), "s"(KE2Q), "s"(KE6P), "s"(KE6Q));
+    asm("v_dot2_i32_i16 %0, %5, %8, %6\n\tv_dot2_i32_i16 %1, %5, %10, %6\n\tv_dot2_i32_i16 %2, %5, %12, %6\n\tv_dot2_i32_i16 %3, %5, %14, %6\n\t"
+        "v_dot2_i32_i16 %0, %4, %7, %0\n\tv_dot2_i32_i16 %1, %4, %9, %1\n\tv_dot2_i32_i16 %2, %4, %11, %2\n\tv_dot2_i32_i16 %3, %4, %13, %3"
+        : "=&v"(o7), "=&v"(o5), "=&v"(o3), "=&v"(o1)
+        : "v"(M), "v"(N), "v"(R), "s"(PK(kO7[3], kO7[2])), "s"(PK(kO7[1], kO7[0])), "s"(PK(kO5[3], kO5[2])), "s"(PK(kO5[1], kO5[0])),
+          "s"(PK(kO3[3], kO3[2])), "s"(PK(kO3[1], kO3[0])), "s"(PK(kO1[3], kO1[2])), "s"(PK(kO1[1], kO1[0])));
+#endif
+    if (!FIRST) { o0 >>= 2; o4 >>= 2; }
+    o2 >>= SH; o6 >>= SH; o7 >>= SH; o5 >>= SH; o3 >>= SH; o1 >>= SH;
+}
+// deringing on the packed block: few blocks hold a sample at the top of the range -- a packed maximum finds them (31 instructions), the others pay nothing more
+template <bool CENTRED>
+__device__ __forceinline__ static void dering_block_pk(uint32_t pr[8][4], int dc_quant, CSH_DERING_LDS) {
+    uint32_t m = pr[0][0];
+    CSH_UNROLL
+    for (int i = 1; i < 32; i++) m = pk_max(m, pr[i >> 2][i & 3]);
+    const int top = CENTRED ? 127 : 255, off = CENTRED ? 0 : 128;
+    const bool any = int(int16_t(m)) >= top || int(int16_t(m >> 16)) >= top;
+#ifndef CSH_EMUL
+    if (!__ballot(any)) return;
+#endif
+    if (!any) return;
+    // natural order: row r = (A.lo, A.hi, C.lo, C.hi, D.hi, D.lo, B.hi, B.lo)
+    int x[64];
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++) {
+        const uint32_t A = pr[r][0], B = pr[r][1], C = pr[r][2], D = pr[r][3];
+        x[8 * r + 0] = int(int16_t(A)) - off; x[8 * r + 1] = int(int16_t(A >> 16)) - off; x[8 * r + 2] = int(int16_t(C)) - off; x[8 * r + 3] = int(int16_t(C >> 16)) - off;
+        x[8 * r + 4] = int(int16_t(D >> 16)) - off; x[8 * r + 5] = int(int16_t(D)) - off; x[8 * r + 6] = int(int16_t(B >> 16)) - off; x[8 * r + 7] = int(int16_t(B)) - off;
+    }
     int cnt = 0, sum = 0;
     CSH_UNROLL
     for (int i = 0; i < 64; i++) { sum += x[i]; cnt += x[i] >= 127 ? 1 : 0; }
-    const bool need = cnt != 0 && cnt != 64;
-#ifdef CSH_EMUL
-    if (!need) return;
-#else
-    if (!__ballot(need)) return;
-#endif
+    if (cnt == 64) return;
     int16_t *col = &dr_col[0][threadIdx.x];
-    if (need) {
-        CSH_UNROLL
-        for (int i = 0; i < 64; i++) col[i * 256] = int16_t(x[i]);
-        dering_walk(col, dc_quant, cnt, sum);
-        CSH_UNROLL
-        for (int i = 0; i < 64; i++) x[i] = col[i * 256];
+    CSH_UNROLL
+    for (int i = 0; i < 64; i++) col[i * 256] = int16_t(x[i]);
+    dering_walk(col, dc_quant, cnt, sum);
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++) {
+        auto at = [&](int c) { return uint32_t(int(col[(8 * r + c) * 256]) + off); };
+        pr[r][0] = pack_halves(at(0), at(1)); pr[r][1] = pack_halves(at(7), at(6)); pr[r][2] = pack_halves(at(2), at(3)); pr[r][3] = pack_halves(at(5), at(4));
     }
 }
-template <bool DERING, bool CENTRED = false>
-__device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw, CSH_DERING_LDS) {
+// packed rows -> [deringing] -> 2-D FDCT -> [retained DCT] -> quantise -> store
+template <bool DERING, bool CENTRED>
+__device__ __forceinline__ static void fdct_quant_store_pk(uint32_t pr[8][4], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw, CSH_DERING_LDS) {
     CSH_SCHED_FENCE();
-    if (!CENTRED) {
-        CSH_UNROLL
-        for (int i = 0; i < 64; i++) x[i] -= 128;
+    if (DERING) { dering_block_pk<CENTRED>(pr, int(q.q[0]), dr_col); CSH_SCHED_FENCE(); }
+    int x[64];
+    int R = 1 << 10, Z = 0;
+    CSH_PIN(R); CSH_PIN(Z);
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++)
+        fdct1d_pk<true>(pr[r][0], pr[r][1], pr[r][2], pr[r][3], R, Z, Z, x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
+    CSH_SCHED_FENCE();
+    int R2 = 1 << 14, TWO = 2, RDC = 2 - 32768;   // RDC: the level shift an uncentred block did not have, taken out of coefficient (0, 0)
+    CSH_PIN(R2); CSH_PIN(TWO); CSH_PIN(RDC);
+    CSH_UNROLL
+    for (int c = 0; c < 8; c++) {
+        const uint32_t A = pack_halves(uint32_t(x[c]), uint32_t(x[8 + c])), B = pack_halves(uint32_t(x[56 + c]), uint32_t(x[48 + c]));
+        const uint32_t C = pack_halves(uint32_t(x[16 + c]), uint32_t(x[24 + c])), D = pack_halves(uint32_t(x[40 + c]), uint32_t(x[32 + c]));
+        fdct1d_pk<false>(A, B, C, D, R2, (c == 0 && !CENTRED) ? RDC : TWO, TWO, x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
     }
-    if (DERING) { dering_block(x, int(q.q[0]), dr_col); CSH_SCHED_FENCE(); }
-    // the compiler knows these are 8-bit values and turns the row pass's 24-bit multiplies into plain 32-bit ones (v_mul_lo_u32 / v_mad_u64_u32:
-    // quarter rate, ~80 of them per block); behind an opaque register copy they stay v_mul_i32_i24 / v_mad_i32_i24
-    CSH_UNROLL
-    for (int i = 0; i < 64; i++) CSH_PIN(x[i]);
-    CSH_UNROLL
-    for (int r = 0; r < 8; r++) fdct1d<true>(x[8 * r], x[8 * r + 1], x[8 * r + 2], x[8 * r + 3], x[8 * r + 4], x[8 * r + 5], x[8 * r + 6], x[8 * r + 7]);
-    CSH_SCHED_FENCE();
-    CSH_UNROLL
-    for (int c = 0; c < 8; c++) fdct1d<false>(x[c], x[8 + c], x[16 + c], x[24 + c], x[32 + c], x[40 + c], x[48 + c], x[56 + c]);
     CSH_SCHED_FENCE();
     if (raw) {   // size-targeting keeps the unquantised DCT so later tries only re-quantise; the trellis quantiser works from it
         if (CSH_RAW_VIA_LDS) raw_put_all(x, dr_col, int(threadIdx.x), Oct()); else raw_store_all(x, raw, Oct());
     }
     quant_store_all(x, q, blk, Oct());
+}
+// centred samples in registers (natural order) -> the packed rows
+__device__ __forceinline__ static void pack_rows(const int x[64], uint32_t pr[8][4]) {
+    CSH_UNROLL
+    for (int r = 0; r < 8; r++) {
+        pr[r][0] = pack_halves(uint32_t(x[8 * r]), uint32_t(x[8 * r + 1])); pr[r][1] = pack_halves(uint32_t(x[8 * r + 7]), uint32_t(x[8 * r + 6]));
+        pr[r][2] = pack_halves(uint32_t(x[8 * r + 2]), uint32_t(x[8 * r + 3])); pr[r][3] = pack_halves(uint32_t(x[8 * r + 5]), uint32_t(x[8 * r + 4]));
+    }
+}
+template <bool DERING, bool CENTRED = false>
+__device__ __forceinline__ static void fdct_quant_store(int x[64], const DevQuant &q, int16_t *__restrict__ blk, int16_t *__restrict__ raw, CSH_DERING_LDS) {
+    uint32_t pr[8][4];
+    pack_rows(x, pr);
+    fdct_quant_store_pk<DERING, CENTRED>(pr, q, blk, raw, dr_col);
 }
 
 // re-quantise a retained DCT block with another table (k_requant)
