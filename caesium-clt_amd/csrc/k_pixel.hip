@@ -681,14 +681,13 @@ __global__ void __launch_bounds__(256) k_plane_fdct(const ImgDesc *__restrict__ 
     if (by >= go.real_bh || bx >= go.real_bw) { store_zero_block(dst); break; }
     const int pitch = go.real_bw * 8;
     const uint8_t *p = oplanes + im.oplane_off[w.comp] + size_t(by * 8) * pitch + bx * 8;
-    int x[64];
+    uint32_t pr[8][4];
     CSH_UNROLL
     for (int r = 0; r < 8; r++) {
         const uint2 v = *reinterpret_cast<const uint2 *>(p + size_t(r) * pitch);
-        CSH_UNROLL
-        for (int c = 0; c < 4; c++) { x[8 * r + c] = int((v.x >> (8 * c)) & 255u); x[8 * r + 4 + c] = int((v.y >> (8 * c)) & 255u); }
+        pr[r][0] = bytes_to_halves<0, 1>(v.x); pr[r][2] = bytes_to_halves<2, 3>(v.x); pr[r][1] = bytes_to_halves<3, 2>(v.y); pr[r][3] = bytes_to_halves<1, 0>(v.y);
     }
-    fdct_quant_store<DERING>(x, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    fdct_quant_store_pk<DERING, false>(pr, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
     has_raw = dct_raw != nullptr;
     } while (0);
     if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
@@ -766,7 +765,7 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *__rest
 #else
     const bool any_patch = __ballot(patch) != 0ull;
 #endif
-    int x[64];
+    uint32_t pr[8][4];
     Quad420 win[3][2];
     auto row_fields = [&](int j, Quad420 out[2]) {
         const uint32_t bq = rows[j].b, cq = rows[j].c;
@@ -799,13 +798,11 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *__rest
                 s[qq].D = (s[qq].D & ~mD[qq]) | (sl & mD[qq]);
             }
         }
-        CSH_UNROLL
-        for (int q = 0; q < 2; q++) {
-            uint32_t even, odd;
-            quad420_finish(s[q], even, odd);
-            x[8 * r + 4 * q] = int(even & 0xFFFFu); x[8 * r + 4 * q + 2] = int(even >> 16);
-            x[8 * r + 4 * q + 1] = int(odd & 0xFFFFu); x[8 * r + 4 * q + 3] = int(odd >> 16);
-        }
+        // the row as the forward transform takes it (fdct1d_pk): the fields (d0, d2) (d1, d3) (d4, d6) (d5, d7) re-paired, never unpacked
+        uint32_t e0, o0, e1, o1;
+        quad420_finish(s[0], e0, o0);
+        quad420_finish(s[1], e1, o1);
+        pr[r][0] = pack_halves(e0, o0); pr[r][2] = pack_hi_halves(e0, o0); pr[r][1] = pack_hi_halves(o1, e1); pr[r][3] = pack_halves(o1, e1);
     }
     const int ylast = och - 1 - y0;   // rows below the last downsampled row replicate it
     if (ylast < 7) {
@@ -813,10 +810,10 @@ __global__ void __launch_bounds__(256) k_resample_fdct_420(const ImgDesc *__rest
         for (int r = 1; r < 8; r++)
             if (r > ylast) {
                 CSH_UNROLL
-                for (int cc = 0; cc < 8; cc++) x[8 * r + cc] = x[8 * (r - 1) + cc];
+                for (int cc = 0; cc < 4; cc++) pr[r][cc] = pr[r - 1][cc];
             }
     }
-    fdct_quant_store<DERING>(x, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
+    fdct_quant_store_pk<DERING, false>(pr, quant[CSH_UNIFORM(im.qt_out[w.comp])], dst, dct_raw ? dct_raw + raw_index(go.tile_base - raw_tile0, b) : nullptr, s_dr);
     has_raw = dct_raw != nullptr;
     } while (0);
     if (dct_raw) raw_copy_out(dct_raw + raw_index(go.tile_base - raw_tile0, tile * 64), has_raw, s_dr, int(threadIdx.x));
