@@ -404,15 +404,37 @@ def main():
     mp_per_step = t.pixels / 1e6 * world
     value = mp_per_step * args.steps / dt
 
-    # parity on this very batch (outside the timed region): 32 files spread over the distinct images, device output == oracle byte for byte
+    # parity on this very batch (outside the timed region): EVERY distinct image of the batch, device output == oracle byte for byte (the all-core
+    # oracle does ~150 MP/s: 1000 files in ~14 s); the two side profiles check every 8th
     outs = batch.fetch()
     from _util import oracle_lossy
-    parity_idx = sorted({(i * nuniq) // 32 for i in range(32)} | {nuniq - 1})
+    all_idx = list(range(nuniq)) if (world == 1 and not args.no_extras) else sorted({(i * nuniq) // 32 for i in range(32)} | {nuniq - 1})
+    parity_idx = sorted(set(range(0, nuniq, 8)) | {nuniq - 1})
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(len(parity_idx), os.cpu_count() or 1)) as ex:   # (ctypes releases the GIL inside the oracle)
-        parity = all(ex.map(lambda i: outs[i] == oracle_lossy(blobs[i]), parity_idx))
+    with ThreadPoolExecutor(min(len(all_idx), os.cpu_count() or 1)) as ex:   # (ctypes releases the GIL inside the oracle)
+        parity = all(ex.map(lambda i: outs[i] == oracle_lossy(blobs[i]), all_idx))
     del outs
     batch.close()   # its pools go back to the block cache: the records below make batches of their own
+
+    # strong scaling at the boundary, in this same invocation (every rank takes part); then, N > 1 only, the drop-in binary over the same list on N devices
+    bstrong = cli_gpus = None
+    if not args.no_extras and args.boundary_total > 0:
+        def reduce_max_sum(mx, sums):
+            if world == 1:
+                return mx, sums
+            tmax = torch.tensor([mx], device="cuda", dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tsum = torch.tensor(sums, device="cuda", dtype=torch.float64); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            return float(tmax.item()), [float(x) for x in tsum.tolist()]
+        try:
+            bstrong = boundary_strong_leg(api, pkg, args, rank, world, local, barrier, reduce_max_sum)
+        except Exception as e:   # a sub-record must not take the headline down (nor leave the other ranks in a collective: they fail alike)
+            bstrong = {"error": repr(e)[:200]}
+        if world > 1:
+            api.release_cached_memory()   # rank 0's caesiumclt is about to use every device
+            barrier()
+            if rank == 0:
+                cli_gpus = cli_gpus_leg(blobs, min(args.boundary_total, 10000), world)
+            barrier()
 
     out = None
     if rank == 0:
@@ -435,7 +457,7 @@ def main():
             roof["traffic_detail"] = detail
             if traffic and ab:
                 roof["traffic_over_algorithmic"] = round(traffic / ab, 3)
-        cpu = cpu_all = cpu_pillow = boundary = plain = scalar = cli = None
+        cpu = cpu_all = cpu_pillow = boundary = plain = scalar = cli = cli10k = None
         # the three phases of the path against SURVEY 8d's algorithmic bytes (D: stream in + planes out, X: planes in + out, E: planes in + files out)
         ph = [sum(tm.phase_ms[i] for tm in timings) / len(timings) for i in range(8)]
         coefb = t.coef_bytes
@@ -493,32 +515,84 @@ def main():
         if extras and args.cli_files > 0:
             api.release_cached_memory()   # another process is about to use the device
             cli = cli_end_to_end(blobs, min(args.cli_files, 4096))
+            if args.cli_files >= 2048 and args.boundary_total >= 10000:
+                cli10k = cli_end_to_end(blobs, 10000)   # BASELINE configs[1]'s own count: the cold process amortises
         def short(rec):
             return None if rec is None else {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "parity": rec["parity_spot_check"]}
         summary = {"unit": "MP/s", prof_env + " (headline)": {"value": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "parity": bool(parity)},
                    "scalar": short(scalar), "plain": short(plain), "roofline_kernel": roof["kernel"], "roofline_frac": roof.get("frac"),
                    "X_read_only_frac": phases["X_read_only"]["frac_of_8TBps"], "E_ms": phases["E_entropy_encode"]["ms"]}
+        # ONE line; the bulky sub-records first, the contract's keys, roofline, cpu_baseline, phases and the summary at the END of the line (what a tail of it keeps)
         out = {
-            "summary": summary,
+            "kernel_ms": {names[i]: round(kms[i], 3) for i in range(len(names)) if names[i] and kms[i] > 0.02},
+            "other_configs": other, "progressive_inputs": prog_inputs,
+            "scalar_profile": scalar, "plain_profile": plain, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow,
+            "cli_end_to_end": cli, "cli_end_to_end_10k": cli10k, "cli_end_to_end_gpus": cli_gpus, "boundary": boundary, "boundary_strong": bstrong,
+            "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
+            "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},
             "metric": "megapixels/sec JPEG q=80 1920x1080 batch", "value": round(value, 1), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic 1920x1080 q92 4:2:0 baseline JPEGs -> -q 80 progressive, inputs resident in HBM",
                        "files_per_gpu_per_step": args.batch, "unique_images": nuniq, "sharding": f"files/{world} ranks, no collective",
                        "profile": profile},
-            "parity_spot_check": bool(parity), "parity_files_checked": len(parity_idx),
+            "parity_spot_check": bool(parity), "parity_files_checked": len(all_idx),
             "device_ms_per_step": round(sum(tm.total_ms for tm in timings) / len(timings), 3),
-            "roofline": roof, "cpu_baseline": cpu, "phases": phases,
-            "kernel_ms": {names[i]: round(kms[i], 4) for i in range(len(names)) if names[i]},
-            "scalar_profile": scalar, "plain_profile": plain, "cpu_baseline_all_cores": cpu_all, "cpu_proxy_pillow": cpu_pillow,
-            "progressive_inputs": prog_inputs, "boundary": boundary, "cli_end_to_end": cli, "other_configs": other,
-            "host": {"nproc": os.cpu_count(), "cpu": cpu_model()},
-            "bytes": {"in": int(t.in_bytes), "out": int(t.out_bytes), "coef_one_way": int(t.coef_bytes)},
+            "cpu_baseline": cpu, "roofline": roof, "phases": phases, "summary": summary,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     return out
+
+
+def boundary_strong_leg(api, pkg, args, rank, world, local, barrier, reduce_max_sum):
+    """the host-bound STRONG-scaling number inside the default invocation (so that a 1/2/4/8-GPU sweep of `bench.py --gpus N` carries it next to the
+    resident weak-scaling value): one shared list of --boundary-total 1080p files (every rank makes the same list), rank r takes files r, r + N, ...
+    (caesium-clt_amd/sharding.py) and calls cs_batch_compress on them from host buffers on its own device -- marker parse on the host's cores, pinned
+    upload, kernels, download all inside the time; value = all files / the slowest rank's seconds.  No collective on the data path."""
+    nuniq = max(1, min(args.unique, 256, args.boundary_total))
+    uniq = make_inputs(0, nuniq)
+    files = [uniq[i % nuniq] for i in range(args.boundary_total)]
+    mine = files[rank::world]
+    params = pkg.default_parameters(jpeg_quality=80)
+    api.cs_batch_compress(mine[:64], params, device=local)
+    barrier()
+    t0 = time.perf_counter()
+    res = api.cs_batch_compress(mine, params, device=local)
+    dt = time.perf_counter() - t0
+    ok = sum(1 for r in res if isinstance(r, bytes))
+    del res
+    dt_max, sums = reduce_max_sum(dt, [float(ok), float(len(mine))])
+    nfiles = int(sums[1])
+    return {"entry": "cs_batch_compress from host buffers, one shared list, file i -> rank i mod N", "files": nfiles, "ok": int(sums[0]), "seconds_slowest_rank": round(dt_max, 4),
+            "files_per_s": round(nfiles / dt_max, 1), "value": round(nfiles * MP_1080P / dt_max, 1), "unit": "MP/s", "scaling": "strong", "n_gpus": world,
+            "parse_threads_per_rank": min(16, os.cpu_count() or 1),
+            "note": "PCIe, host parsing and the download are inside this number (never inside `value`); N ranks use up to 16 N host cores and N upload streams"}
+
+
+def cli_gpus_leg(blobs, n, gpus):
+    """caesiumclt --gpus N over n 1080p files, files in -> files out, whole process (the reference tool's shape of a run on N devices of one node)"""
+    d = scratch_dir()
+    try:
+        os.makedirs(os.path.join(d, "in"))
+        for k in range(n):
+            with open(os.path.join(d, "in", f"f{k:05d}.jpg"), "wb") as f:
+                f.write(blobs[k % len(blobs)])
+        runs = []
+        for _ in range(2):
+            shutil.rmtree(os.path.join(d, "out"), ignore_errors=True)
+            secs, r = run_cli(["-q", "80", "--quiet", "--gpus", str(gpus), "-o", os.path.join(d, "out"), os.path.join(d, "in")])
+            if r.returncode != 0:
+                return {"error": f"caesiumclt exited {r.returncode}: {r.stderr.decode()[-200:]}"}
+            runs.append(round(secs, 3))
+        best = min(runs)
+        return {"command": f"caesiumclt -q 80 --quiet --gpus {gpus} -o out/ in/", "files": n, "files_written": len(os.listdir(os.path.join(d, "out"))), "seconds": best,
+                "seconds_each_run": runs, "files_per_s": round(n / best, 1), "value": round(n * MP_1080P / best, 1), "unit": "MP/s", "scaling": "strong", "n_gpus": gpus}
+    except Exception as e:
+        return {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def boundary_main(args):
