@@ -75,7 +75,7 @@ __device__ __forceinline__ static void nz_count_half(const NzSet &S, uint32_t u0
         cnt[l] += n;
     }
 }
-__device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0, int half, const LV<uint4> (&q)[CSH_NZ_HALF], uint32_t *dst, uint32_t run, uint8_t *blk_cnt) {
+__device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0, int half, const LV<uint4> (&q)[CSH_NZ_HALF], uint32_t *dst, uint32_t run, uint8_t *blk_cnt, uint16_t *blk_off) {
     CSH_UNROLL
     for (int s = 0; s < CSH_NZ_HALF; s++) {
         LV<uint32_t> mk, cl;
@@ -92,6 +92,7 @@ __device__ __forceinline__ static void nz_write_half(const NzSet &S, uint32_t u0
             LFOR(l) {
                 const uint32_t blk = 16u * 8u * uint32_t(half) + 8u * uint32_t(s) + uint32_t(l >> 3);
                 if ((l & 7) == 7 && u0 + blk < S.nunits) blk_cnt[u0 + blk] = uint8_t(ex[l] + cl[l] - 1u - first[l]);
+                if ((l & 7) == 7 && u0 + blk < S.nunits && blk_off) blk_off[u0 + blk] = uint16_t(run + first[l]);   // (a chunk holds at most 256 x 64 entries)
             }
         }
         LFOR(l) {
@@ -149,7 +150,8 @@ __global__ void __launch_bounds__(128, 3) k_nzlist(EncCtx c) {
         if (s_rel == 0xFFFFFFFFu) continue;
         uint32_t *dst = c.nz_pool + L0.base + s_rel;
         uint8_t *blk_cnt = (c.nz_blk_cnt && S.cnt_base != 0xFFFFFFFFu) ? c.nz_blk_cnt + S.cnt_base : nullptr;
-        nz_write_half(S, u0, half, q, dst, half ? s_cnt[0] : 0u, blk_cnt);
+        uint16_t *blk_off = (blk_cnt && c.nz_blk_off) ? c.nz_blk_off + S.cnt_base : nullptr;
+        nz_write_half(S, u0, half, q, dst, half ? s_cnt[0] : 0u, blk_cnt, blk_off);
         if (half == 1) {   // padding to the next 16-byte boundary: entries that code nothing
             const uint32_t n0 = s_cnt[0] + s_cnt[1], n0a = (n0 + 3u) & ~3u;
             LFOR(l) if (n0 + uint32_t(l) < n0a) dst[n0 + uint32_t(l)] = 0u;
@@ -160,28 +162,41 @@ __global__ void __launch_bounds__(128, 3) k_nzlist(EncCtx c) {
 // atomic add per list, write.  Four entries per lane and step; the second pass reads the chunk out of the L2.
 __global__ void __launch_bounds__(64) k_nzfilter(EncCtx c) {
     const NzChunk ch = c.nzchunks[blockIdx.x];
-    const uint32_t others = ch.levels & ~1u;
+    const uint32_t others = ch.levels & ~1u;   // levels 1..3 to filter, and CSH_NZ_COMPACT0
     if (!others) return;
+    const bool compact0 = (ch.levels & CSH_NZ_COMPACT0) != 0u;
     const NzSet S = c.nzsets[ch.set];
     if (c.work_active && !c.work_active[ch.work0]) return;
     const NzList L0 = c.nzlists[S.list[0]];
     const uint32_t n0 = c.nz_chunk_cnt[L0.chunk0 + ch.j];
     const uint32_t *src = c.nz_pool + L0.base + c.nz_chunk_off[L0.chunk0 + ch.j];
     auto kept = [](uint32_t x, int L) { return ((x & CSH_NZ_END) != 0u || (((x >> 8) & 0x7FFFu) >> L) != 0u) ? 1u : 0u; };   // an END entry, or a coefficient that is not zero at level L
+    // (level 0 here only under CSH_NZ_COMPACT0: the list k_trellis_ac wrote its levels into -- the coefficients it dropped have magnitude 0 -- is
+    // compacted IN PLACE: a step's 256 entries are in registers before any of them is written, and an entry never moves up)
+    const int Lfirst = compact0 ? 0 : 1;
     LV<uint32_t> cntL[CSH_NZ_LEVELS];
-    LFOR(l) for (int L = 1; L < CSH_NZ_LEVELS; L++) cntL[L][l] = 0u;
+    LFOR(l) for (int L = 0; L < CSH_NZ_LEVELS; L++) cntL[L][l] = 0u;
     for (uint32_t g0 = 0; g0 < n0; g0 += 256) {
         LFOR(l) {
             const uint32_t g = g0 + 4u * uint32_t(l);
             uint4 e; e.x = e.y = e.z = e.w = 0u;
             if (g < n0) e = *reinterpret_cast<const uint4 *>(src + g);
-            CSH_UNROLL
-            for (int L = 1; L < CSH_NZ_LEVELS; L++) cntL[L][l] += kept(e.x, L) + kept(e.y, L) + kept(e.z, L) + kept(e.w, L);
+            if (g < n0) {   // (the padding behind the chunk's last entry is not an entry: it must not count as a level-0 END)
+                CSH_UNROLL
+                for (int L = 0; L < CSH_NZ_LEVELS; L++) cntL[L][l] += kept(e.x, L) + kept(e.y, L) + kept(e.z, L) + kept(e.w, L);
+            }
         }
     }
     uint32_t *dstL[CSH_NZ_LEVELS];
     uint32_t runL[CSH_NZ_LEVELS];
     bool okL[CSH_NZ_LEVELS];
+    uint32_t n0new = n0;
+    dstL[0] = nullptr; runL[0] = 0; okL[0] = false;
+    if (compact0 && n0) {   // same place, same room: nothing to reserve; the count and the padding are written behind the last step
+        dstL[0] = c.nz_pool + L0.base + c.nz_chunk_off[L0.chunk0 + ch.j];
+        okL[0] = true;
+        n0new = lsum32(cntL[0]);
+    }
     for (int L = 1; L < CSH_NZ_LEVELS; L++) {
         dstL[L] = nullptr; runL[L] = 0; okL[L] = false;
         if (!((others >> L) & 1u)) continue;
@@ -205,7 +220,7 @@ __global__ void __launch_bounds__(64) k_nzfilter(EncCtx c) {
             if (g < n0) e = *reinterpret_cast<const uint4 *>(src + g);
             e0[l] = e.x; e1[l] = e.y; e2[l] = e.z; e3[l] = e.w;
         }
-        for (int L = 1; L < CSH_NZ_LEVELS; L++) {
+        for (int L = Lfirst; L < CSH_NZ_LEVELS; L++) {
             if (!okL[L]) continue;
             LV<uint32_t> k4;
             LFOR(l) k4[l] = kept(e0[l], L) + kept(e1[l], L) + kept(e2[l], L) + kept(e3[l], L);
@@ -219,6 +234,13 @@ __global__ void __launch_bounds__(64) k_nzfilter(EncCtx c) {
                     if (kept(e[q], L)) dstL[L][o++] = (e[q] & 0xFF8000FFu) | ((((e[q] >> 8) & 0x7FFFu) >> L) << 8);
             }
             runL[L] += tot;
+        }
+    }
+    if (okL[0]) {
+        const uint32_t na = (n0new + 3u) & ~3u;
+        LFOR(l) {
+            if (n0new + uint32_t(l) < na) dstL[0][n0new + uint32_t(l)] = 0u;   // padding to the 16-byte boundary: entries that code nothing
+            if (l == 0) c.nz_chunk_cnt[L0.chunk0 + ch.j] = n0new;
         }
     }
 }

@@ -278,12 +278,23 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         }
     }
     int16_t *dst = c.coef + coef_index(g.tile_base, b, 0);
+    // the block's entries in the statistics scan's level-0 list (the same coefficients in the same order: both are "scalar level not zero", in
+    // zig-zag order): they take the chosen levels, so that the coding stages' lists are filtered from this list (k_nzfilter) and the
+    // coefficient tiles are not swept a second time
+    uint32_t *lst = nullptr;
+    if (c.nz_pool && w.nzset != 0xFFFFFFFFu) {
+        const NzSet &S = c.nzsets[w.nzset];
+        const NzList &L0 = c.nzlists[S.list[0]];
+        const uint32_t rec = L0.chunk0 + (u >> 8);
+        if (c.nz_chunk_cnt[rec]) lst = c.nz_pool + L0.base + c.nz_chunk_off[rec] + c.blk_off[w.unit_base + u];   // (a chunk that found no room has no entries: the run is repeated with larger pools)
+    }
     for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
         if (e < ne) {
             uint32_t Pe;
             if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + ((e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
             const int pos = int((Pe >> 15) & 63u), level = ((kept >> e) & 1ull) ? int((Pe >> 21) & 1023u) : 0;
             dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
+            if (lst) lst[e] = uint32_t(pos) | ((Pe >> 31) ? 128u : 0u) | (uint32_t(level) << 8) | ((u & 255u) << 23);
         }
     }
 }

@@ -122,6 +122,7 @@ struct EncCtx {  // device pointers + sizes every entropy kernel needs
     uint32_t *nz_chunk_off;    // per (list, chunk): first entry, relative to the list's region
     uint32_t *nz_chunk_cnt;    // per (list, chunk): entries (END entries included, padding excluded)
     uint8_t *nz_blk_cnt;       // null, or (the trellis stage's statistics lists) per block: its non-zero AC coefficients (NzSet::cnt_base)
+    uint16_t *nz_blk_off;      // null, or (the same lists) per block: where its first entry stands in its chunk -- k_trellis_ac writes the levels it chose into the entries
     const uint32_t *list_slots;// the run's slots that are coded from a list (k_list_stats, k_list_pack) ...
     uint32_t nlist_slots;
     const uint32_t *tok_slots; // ... and those packed from tokens (k_pack); null: every slot of [slot0, slot0 + nslots)
@@ -167,6 +168,14 @@ struct TrellisCtx {
     const uint32_t *rows;      // DC kernel: every (work item << 16 | iMCU row) of the batch, longest rows first: one lane each
     uint32_t nrows;
     uint32_t debug;            // CSH_TR_DEBUG: timing experiments (parts of k_trellis_ac switched off; the output is then garbage)
+    // progressive output: the statistics scan's level-0 NzList holds exactly the coefficients the trellis decides about, block by block in the
+    // programme's own order -- k_trellis_ac writes its levels into those entries (a dropped coefficient: magnitude 0) and the coding stages'
+    // lists are FILTERED from that list (k_nzfilter, NZ_COMPACT0) instead of being built from the coefficient tiles a second time.  null: no lists
+    uint32_t *nz_pool;
+    const NzList *nzlists;
+    const NzSet *nzsets;
+    const uint32_t *nz_chunk_off, *nz_chunk_cnt;
+    const uint16_t *blk_off;   // EncCtx::nz_blk_off
 };
 void launch_trellis_sort(hipStream_t st, const TrellisCtx &c);   // fills TrellisCtx::perm from ::blk_cnt
 void launch_trellis_ac(hipStream_t st, const TrellisCtx &c);

@@ -165,6 +165,7 @@ struct csh_batch {
     uint32_t t_units = 0, t_max_rows = 0;
     std::vector<uint32_t> trows;          // k_trellis_dc: (work item << 16 | iMCU row), longest rows first
     bool t_sort = false;                  // k_trellis_ac takes its blocks in order of list length (progressive output: the statistics lists count them)
+    bool nz_once = false;                 // progressive output under the trellis quantiser: its levels go into the statistics scan's level-0 lists and the coding stages filter those (no second k_nzlist over the tiles)
     PinnedBytes bits_pool;
     std::vector<uint8_t> hdr_pool;
     std::vector<uint32_t> hdr_off;
@@ -227,6 +228,7 @@ struct csh_batch {
     DevBuf<TrellisChunk> d_tchunks;
     DevBuf<uint32_t> d_trows, d_tperm;
     DevBuf<uint8_t> d_tblk_cnt;
+    DevBuf<uint16_t> d_tblk_off;
     DevBuf<uint64_t> d_tlambda;
     DevBuf<uint64_t> d_tdcbt;
     DevBuf<uint32_t> d_tspill;
@@ -546,6 +548,10 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
     const bool lossy_jpeg = !b->lossless && !webp && !rgb_out;
     b->trellis = lossy_jpeg && (profile == "mozjpeg" || profile == "mozjpeg-trellis");
     b->dering = lossy_jpeg && (profile == "mozjpeg" || profile == "mozjpeg-dering");
+    {   // (CSH_NZ_ONCE=0: the coding stages build their level-0 lists from the coefficient tiles again, as before round 5; CSH_TR_SORT=0 implies it -- the per-block list offsets come with the sort's counts)
+        const char *once = getenv("CSH_NZ_ONCE"), *ts = getenv("CSH_TR_SORT");
+        b->nz_once = b->trellis && progressive && !(once && !strcmp(once, "0")) && !(ts && !strcmp(ts, "0"));
+    }
     // EncScan entries of the search's candidates, made on first use
     auto cand_index = [&](int comp, int Ss, int Se, int Ah, int Al) -> int {
         const std::array<int, 5> key = {comp, Ss, Se, Ah, Al};
@@ -664,8 +670,10 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         for (int c = 0; c < im.ncomp; c++) {
             if (!nz_need[c]) continue;
             const int si = b->nzset_of[size_t(img_index) * CSH_MAX_COMPS + size_t(c)];
-            const uint32_t levels = stats_only ? (nz_need[c] | 1u) : ((nz_need[c] | 1u) & ~b->nzset_built[size_t(si)]);
+            uint32_t levels = stats_only ? (nz_need[c] | 1u) : ((nz_need[c] | 1u) & ~b->nzset_built[size_t(si)]);
             b->nzset_built[size_t(si)] |= levels;
+            // the trellis stage's statistics list takes the trellis's levels (k_trellis_ac): a coding stage does not build level 0 from the tiles, it drops the list's zero entries
+            if (!stats_only && b->nz_once && (levels & 1u)) levels = (levels & ~1u) | CSH_NZ_COMPACT0;
             const uint32_t nu = b->nzsets[size_t(si)].nunits;
             for (uint32_t j = 0; levels && j < (nu + 255) / 256; j++) b->nzchunks.push_back(NzChunk{uint32_t(si), j, levels, nz_gate[c]});
         }
@@ -1242,7 +1250,12 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
                 b->t_units += sw.nunits;
                 for (uint32_t j = 0; j < (sw.nunits + CSH_TR_WG - 1) / CSH_TR_WG; j++) b->tchunks.push_back(TrellisChunk{uint32_t(b->twork.size()), j});
                 b->t_max_rows = std::max<uint32_t>(b->t_max_rows, uint32_t((im.out[c].real_bh + im.out[c].v - 1) / im.out[c].v));
-                if (progressive) b->nzsets[size_t(b->nzset_of[size_t(it.image) * CSH_MAX_COMPS + size_t(c)])].cnt_base = tw.unit_base;   // the statistics list's builder counts every block's entries
+                tw.nzset = 0xFFFFFFFFu;
+                if (progressive) {
+                    const int si = b->nzset_of[size_t(it.image) * CSH_MAX_COMPS + size_t(c)];
+                    b->nzsets[size_t(si)].cnt_base = tw.unit_base;   // the statistics list's builder counts every block's entries
+                    if (b->nz_once) tw.nzset = uint32_t(si);
+                }
                 b->twork.push_back(tw);
             }
         }
@@ -1329,7 +1342,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         if (hipMemsetAsync(b->d_slots.p, 0, (size_t(b->nslots) + 1) * sizeof(SlotRec), st) != hipSuccess ||
             hipMemsetAsync(b->d_slot_work.p, 0, (size_t(b->nslots) + 1) * sizeof(uint32_t), st) != hipSuccess) { csh_set_error("hipMemsetAsync failed"); return CS_ERR_NO_DEVICE; }
         launch_make_slots(st, b->d_swork.p, uint32_t(b->swork.size()), b->d_script.p, b->d_slots.p, b->d_slot_work.p, b->d_list_slots.p, b->d_tok_slots.p);
-        if (b->trellis && (b->d_trows.upload(b->trows, st) || (b->t_sort && (b->d_tperm.alloc(size_t(b->t_units) + 1) || b->d_tblk_cnt.alloc(size_t(b->t_units) + 1))))) return CS_ERR_NO_DEVICE;
+        if (b->trellis && (b->d_trows.upload(b->trows, st) || (b->t_sort && (b->d_tperm.alloc(size_t(b->t_units) + 1) || b->d_tblk_cnt.alloc(size_t(b->t_units) + 1) || (b->nz_once && b->d_tblk_off.alloc(size_t(b->t_units) + 1)))))) return CS_ERR_NO_DEVICE;
         if (b->trellis && (b->d_twork.upload(b->twork, st) || b->d_tchunks.upload(b->tchunks, st) || b->d_tlambda.alloc(size_t(b->t_units) + 1) || b->d_tdcbt.alloc(size_t(b->t_units) + 1) ||
                            b->d_tspill.alloc(trellis_spill_words()) || b->d_dct_raw.alloc(size_t(b->ntiles_out) * CSH_TILE_I16)))
             return CS_ERR_NO_DEVICE;
@@ -1793,8 +1806,9 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         c.stats_only = 1;
         if (b->d_long_cnt.zero(st)) return -1;
         c.nz_blk_cnt = b->t_sort ? b->d_tblk_cnt.p : nullptr;
+        c.nz_blk_off = (b->t_sort && b->nz_once) ? b->d_tblk_off.p : nullptr;
         launch_nzlist(st, c);       // level 0 of the scalar-quantised coefficients (progressive output: the statistics scans are list slots)
-        c.nz_blk_cnt = nullptr;
+        c.nz_blk_cnt = nullptr; c.nz_blk_off = nullptr;
         if (b->t_sort) {   // the blocks of every component in order of list length (timed with the statistics)
             TrellisCtx ts;
             memset(&ts, 0, sizeof ts);
@@ -1815,6 +1829,10 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         tc.spill = b->d_tspill.p; tc.max_rows = b->t_max_rows;
         tc.rows = b->d_trows.p; tc.nrows = uint32_t(b->trows.size());
         if (b->t_sort) { tc.blk_cnt = b->d_tblk_cnt.p; tc.perm = b->d_tperm.p; }
+        if (b->t_sort && b->nz_once) {
+            tc.nz_pool = b->d_nz_pool.p; tc.nzlists = b->d_nzlists.p; tc.nzsets = b->d_nzsets.p; tc.nz_chunk_off = b->d_nz_chunk_off.p; tc.nz_chunk_cnt = b->d_nz_chunk_cnt.p;
+            tc.blk_off = b->d_tblk_off.p;
+        }
         tc.debug = getenv("CSH_TR_DEBUG") ? uint32_t(atoi(getenv("CSH_TR_DEBUG"))) : 0u;
         launch_trellis_ac(st, tc);
         MARK();

@@ -244,6 +244,7 @@ struct NzSet {
 };
 // one wave of the builder: chunk j of set `set`, the levels in `levels` (bit Al).  Level 0 is made from the coefficients; the others are
 // filtered from level 0 (which an earlier stage may have made)
+#define CSH_NZ_COMPACT0 0x80000000u   // NzChunk::levels: level 0 exists (the trellis stage's statistics list, the trellis's levels written into it): drop its zero entries in place, filter the other levels from the result
 struct NzChunk { uint32_t set, j, levels, work0; };   // work0: a work item whose gate (EncCtx::work_active) stands for the chunk in a conditional stage
 
 // what the per-slot kernels need of (work item, chunk j), in one load (written by k_make_slots from the work items; slot = work.first_chunk + j)
@@ -266,7 +267,8 @@ struct TrellisWork {
     int32_t table_dc;        // sequential output: the optimal DC table of the same pass; -1: the Annex K table of the component (progressive)
     uint32_t nunits;         // real blocks of the component
     uint32_t unit_base;      // first entry of the component in the per-block side arrays (lambda, DC back-pointers)
-    uint32_t pad[2];
+    uint32_t nzset;          // the component's NzSet (its level-0 list takes the chosen levels: TrellisCtx::nz_pool), 0xFFFFFFFF: none
+    uint32_t pad[1];
 };
 struct TrellisChunk { uint32_t work, j; };
 
