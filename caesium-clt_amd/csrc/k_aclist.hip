@@ -269,10 +269,11 @@ __device__ __forceinline__ static NzEvent nz_event(uint32_t e, uint32_t p, uint3
 }
 struct ListSlot { const uint32_t *lst; uint32_t n; };
 __device__ __forceinline__ static ListSlot list_of_slot(const EncCtx &c, const SlotRec &r) {
-    const NzList L = c.nzlists[c.work[r.work].list];
+    // the slot record names its list and its chunk record (k_make_slots): three independent loads here, not a chain of four (work item -> list
+    // -> chunk record -> offset); the waves of these kernels are short, and what they wait for first is this
     ListSlot s;
-    s.n = c.nz_chunk_cnt[L.chunk0 + r.j];
-    s.lst = c.nz_pool + L.base + c.nz_chunk_off[L.chunk0 + r.j];
+    s.n = c.nz_chunk_cnt[r.nzrec];
+    s.lst = c.nz_pool + c.nzlists[r.nzlist].base + c.nz_chunk_off[r.nzrec];
     return s;
 }
 // four consecutive entries per lane (the chunk starts on a 16-byte boundary and is padded to one with entries that code nothing)
@@ -469,7 +470,7 @@ void launch_list_pack(hipStream_t st, const EncCtx &c) { if (c.nlist_slots) CSH_
 // ---- the slots of the work items: one workgroup per work item, one lane per 256-unit chunk.  Under the scan search a 1080p image has ~3.9 k slots in 58 work
 // items: built on the host they were 64 MB of records per 256 files to write and to upload in front of the first kernel (the boundary call paid ~15 ms of
 // every 50 for them); the host only counts them now (pipeline.cpp add_works).  Slots between the stages belong to no work item and stay zero.
-__global__ void __launch_bounds__(64) k_make_slots(const ScanWork *works, uint32_t nworks, const EncScan *script, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
+__global__ void __launch_bounds__(64) k_make_slots(const ScanWork *works, uint32_t nworks, const EncScan *script, const NzList *nzlists, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
                                                    uint32_t *tok_slots) {
     const uint32_t wi = blockIdx.x;
     if (wi >= nworks) return;
@@ -484,16 +485,29 @@ __global__ void __launch_bounds__(64) k_make_slots(const ScanWork *works, uint32
         r.flags = uint16_t((prog_ac ? 1 : 0) | (prog_ac && e.Ah ? 2 : 0) | (listed ? 4 : 0));
         r.hist_row = w.hist_row0 + j * uint32_t(e.ntables);
         r.word_base = w.word_base; r.unit_base = w.unit_base; r.nunits_work = w.nunits;
-        r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.corr0 = w.corr_base == 0xFFFFFFFFu ? 0u : w.corr_base + 256u * j; r.pad[0] = r.pad[1] = 0;
+        r.Ss = uint8_t(e.Ss); r.Se = uint8_t(e.Se); r.Ah = uint8_t(e.Ah); r.Al = uint8_t(e.Al); r.corr0 = w.corr_base == 0xFFFFFFFFu ? 0u : w.corr_base + 256u * j;
+        r.nzlist = listed ? w.list : 0u; r.nzrec = listed ? nzlists[w.list].chunk0 + j : 0u;
         slots[w.first_chunk + j] = r;
         slot_work[w.first_chunk + j] = wi;
         (listed ? list_slots : tok_slots)[w.ls_base + j] = w.first_chunk + j;
     }
 }
-void launch_make_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const EncScan *script, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
+// the scan search re-points work items to the lists of the point transform it chose (pipeline.cpp search_decide): their slots follow
+__global__ void __launch_bounds__(64) k_rebind_slots(const ScanWork *works, uint32_t nworks, const NzList *nzlists, SlotRec *slots) {
+    const uint32_t wi = blockIdx.x;
+    if (wi >= nworks) return;
+    const ScanWork &w = works[wi];
+    if (w.list == 0xFFFFFFFFu) return;
+    const uint32_t nch = (w.nunits + 255u) / 256u, chunk0 = nzlists[w.list].chunk0;
+    for (uint32_t j = threadIdx.x; j < nch; j += blockDim.x) { slots[w.first_chunk + j].nzlist = w.list; slots[w.first_chunk + j].nzrec = chunk0 + j; }
+}
+void launch_rebind_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const NzList *nzlists, SlotRec *slots) {
+    if (nworks) CSH_LAUNCH(k_rebind_slots, dim3(nworks), dim3(64), st, works, nworks, nzlists, slots);
+}
+void launch_make_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const EncScan *script, const NzList *nzlists, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
                        uint32_t *tok_slots) {
     if (!nworks) return;
-    CSH_LAUNCH(k_make_slots, dim3(nworks), dim3(64), st, works, nworks, script, slots, slot_work, list_slots, tok_slots);
+    CSH_LAUNCH(k_make_slots, dim3(nworks), dim3(64), st, works, nworks, script, nzlists, slots, slot_work, list_slots, tok_slots);
 }
 
 void launch_reset_works(hipStream_t st, ScanWork *work, int nwork) { if (nwork) CSH_LAUNCH(k_reset_works, dim3((nwork + 255) / 256), dim3(256), st, work, nwork); }

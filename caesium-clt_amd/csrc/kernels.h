@@ -40,7 +40,8 @@ void launch_refine_chains(hipStream_t st, const uint8_t *clean, const ParScan *p
                           const int *chain_scans, int nchains, const RefineUnit *units, int nunits, uint32_t max_blocks, const ImgDesc *imgs, int16_t *coef,
                           uint32_t *need_seq, uint64_t *hist, uint32_t *posv, uint32_t *prog);
 // per (work item, 256-unit chunk): SlotRec, slot -> work item, and the slot's entry in the list-coded / token-coded slot lists (k_aclist.hip)
-void launch_make_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const EncScan *script, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
+void launch_rebind_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const NzList *nzlists, SlotRec *slots);   // after the host re-points work items' lists
+void launch_make_slots(hipStream_t st, const ScanWork *works, uint32_t nworks, const EncScan *script, const NzList *nzlists, SlotRec *slots, uint32_t *slot_work, uint32_t *list_slots,
                        uint32_t *tok_slots);
 void launch_decode_prog(hipStream_t st, const uint8_t *clean, const ParScan *pss, const ParHuffSet *huffs, const DecScan *scans, const ProgChain *chains,
                         const int *chain_scans, int nchains, const ImgDesc *imgs, int16_t *coef, uint32_t *need_seq);

@@ -1341,7 +1341,7 @@ static int batch_create(const CByteArray *inputs, size_t count, const CCSParamet
         // the slots of every work item, written where they are used (the host counted them: add_works)
         if (hipMemsetAsync(b->d_slots.p, 0, (size_t(b->nslots) + 1) * sizeof(SlotRec), st) != hipSuccess ||
             hipMemsetAsync(b->d_slot_work.p, 0, (size_t(b->nslots) + 1) * sizeof(uint32_t), st) != hipSuccess) { csh_set_error("hipMemsetAsync failed"); return CS_ERR_NO_DEVICE; }
-        launch_make_slots(st, b->d_swork.p, uint32_t(b->swork.size()), b->d_script.p, b->d_slots.p, b->d_slot_work.p, b->d_list_slots.p, b->d_tok_slots.p);
+        launch_make_slots(st, b->d_swork.p, uint32_t(b->swork.size()), b->d_script.p, b->d_nzlists.p, b->d_slots.p, b->d_slot_work.p, b->d_list_slots.p, b->d_tok_slots.p);
         if (b->trellis && (b->d_trows.upload(b->trows, st) || (b->t_sort && (b->d_tperm.alloc(size_t(b->t_units) + 1) || b->d_tblk_cnt.alloc(size_t(b->t_units) + 1) || (b->nz_once && b->d_tblk_off.alloc(size_t(b->t_units) + 1)))))) return CS_ERR_NO_DEVICE;
         if (b->trellis && (b->d_twork.upload(b->twork, st) || b->d_tchunks.upload(b->tchunks, st) || b->d_tlambda.alloc(size_t(b->t_units) + 1) || b->d_tdcbt.alloc(size_t(b->t_units) + 1) ||
                            b->d_tspill.alloc(trellis_spill_words()) || b->d_dct_raw.alloc(size_t(b->ntiles_out) * CSH_TILE_I16)))
@@ -1617,6 +1617,7 @@ static int search_decide(csh_batch *b, int stage) {
                 for (uint32_t k = 0; k < P.nslot; k++) P.s[k].Al = uint8_t(b->plan_comp[pi] == 0 ? si.Al_luma : si.Al_chroma);
             }
             if (sg.nwork) CSH_CHECK(hipMemcpyAsync(b->d_swork.p + sg.work0, b->swork.data() + sg.work0, size_t(sg.nwork) * sizeof(ScanWork), hipMemcpyHostToDevice, st));
+            launch_rebind_slots(st, b->d_swork.p + sg.work0, sg.nwork, b->d_nzlists.p, b->d_slots.p);   // the slots name their list themselves (SlotRec::nzlist)
             if (sg.nplans) CSH_CHECK(hipMemcpyAsync(b->d_plans.p + sg.plan0, b->plans.data() + sg.plan0, size_t(sg.nplans) * sizeof(TokPlan), hipMemcpyHostToDevice, st));
         }
     }

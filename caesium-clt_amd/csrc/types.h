@@ -256,7 +256,8 @@ struct SlotRec {
     uint16_t ntables, flags;     // flags: 1 progressive AC scan (EOB tokens), 2 refinement (correction words), 4 coded from its NzList (k_aclist.hip), not from tokens
     uint32_t hist_row;           // first of the slot's ntables rows of 256 symbol counts (EncCtx::slot_hist)
     uint32_t word_base, unit_base, nunits_work;   // of the work item (k_ac_runs)
-    uint8_t Ss, Se, Ah, Al; uint32_t corr0, pad[2];   // corr0: the chunk's first correction word (refinement scans)
+    uint8_t Ss, Se, Ah, Al; uint32_t corr0;           // corr0: the chunk's first correction word (refinement scans)
+    uint32_t nzlist, nzrec;      // list-coded slots: the NzList and the chunk's record in the per-chunk arrays (nz_chunk_off / nz_chunk_cnt)
 };
 
 // mozjpeg's trellis quantiser (k_trellis.hip; CSH_PROFILE=mozjpeg): one work item per (image, component) -- the component's statistics
