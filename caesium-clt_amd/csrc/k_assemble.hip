@@ -72,11 +72,16 @@ __global__ void __launch_bounds__(256) k_scan_down(const uint32_t *in, uint64_t 
     }
 }
 size_t exclusive_scan_tmp_bytes(uint64_t n) { return size_t((n + CSH_SCAN_STRETCH - 1) / CSH_SCAN_STRETCH + 2) * sizeof(uint64_t); }
+// CONTRACT: out[i] is the true 64-bit prefix wherever every stretch of 64 consecutive inputs sums below 2^32 (sizes, counts: every caller but one).  The DC
+// differences (pipeline.cpp: dcdiff reinterpreted as uint32_t, negative values ~ 2^32) break that premise on purpose: their prefix is only right modulo
+// 2^32, and k_dc_scatter uses the low 32 bits of the DIFFERENCE of two prefixes only.
 void launch_exclusive_scan(hipStream_t st, const uint32_t *in, uint64_t *out, uint64_t n, void *tmp, size_t tmp_bytes) {
     uint64_t *sums = static_cast<uint64_t *>(tmp);
     const uint32_t nb = uint32_t((n + CSH_SCAN_STRETCH - 1) / CSH_SCAN_STRETCH);
     if (!nb) { (void)hipMemsetAsync(out, 0, sizeof(uint64_t), st); return; }
-    if (size_t(nb + 2) * sizeof(uint64_t) > tmp_bytes) { csh_set_error("exclusive scan: temporary buffer too small"); return; }
+    // (cannot happen: every caller sizes tmp with exclusive_scan_tmp_bytes for its largest n.  If it does: the offsets are all zero -- every consumer stays
+    // inside its pool -- and the error string says why the run's output is wrong)
+    if (size_t(nb + 2) * sizeof(uint64_t) > tmp_bytes) { csh_set_error("exclusive scan: temporary buffer too small"); (void)hipMemsetAsync(out, 0, size_t(n + 1) * sizeof(uint64_t), st); return; }
     CSH_LAUNCH_PHASED(k_scan_sums, 2, dim3(nb), dim3(4 * CSP_WAVE_THREADS), st, in, n, sums);
     CSH_LAUNCH_PHASED(k_scan_spine, 3, dim3(1), dim3(256), st, sums, nb);
     CSH_LAUNCH_PHASED(k_scan_down, 2, dim3(nb), dim3(4 * CSP_WAVE_THREADS), st, in, n, sums, nb, out);
