@@ -288,13 +288,33 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         const uint32_t rec = L0.chunk0 + (u >> 8);
         if (c.nz_chunk_cnt[rec]) lst = c.nz_pool + L0.base + c.nz_chunk_off[rec] + c.blk_off[w.unit_base + u];   // (a chunk that found no room has no entries: the run is repeated with larger pools)
     }
-    for (uint32_t e = 0; CSH_ANY(e < ne); e++) {
-        if (e < ne) {
-            uint32_t Pe;
-            if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + ((e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
-            const int pos = int((Pe >> 15) & 63u), level = ((kept >> e) & 1ull) ? int((Pe >> 21) & 1023u) : 0;
-            dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
-            if (lst) lst[e] = uint32_t(pos) | ((Pe >> 31) ? 128u : 0u) | (uint32_t(level) << 8) | ((u & 255u) << 23);
+    // (the list entries four at a time: one 16-byte store where the block has four more -- a 4-byte store per entry and lane was 0.9 ms per 1024 files)
+    for (uint32_t e0 = 0; CSH_ANY(e0 < ne); e0 += 4) {
+        uint32_t ent[4] = {0u, 0u, 0u, 0u};
+        CSH_UNROLL
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t e = e0 + i;
+            if (e < ne) {
+                uint32_t Pe;
+                if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + ((e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
+                const int pos = int((Pe >> 15) & 63u), level = ((kept >> e) & 1ull) ? int((Pe >> 21) & 1023u) : 0;
+                dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
+                ent[i] = uint32_t(pos) | ((Pe >> 31) ? 128u : 0u) | (uint32_t(level) << 8) | ((u & 255u) << 23);
+            }
+        }
+        if (lst && e0 < ne) {
+            if (e0 + 4 <= ne) {
+#ifdef CSH_EMUL
+                memcpy(lst + e0, ent, 16);
+#else
+                typedef uint32_t tr_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                tr_u32x4_a4 v; v.x = ent[0]; v.y = ent[1]; v.z = ent[2]; v.w = ent[3];
+                *reinterpret_cast<tr_u32x4_a4 *>(lst + e0) = v;
+#endif
+            } else {
+                CSH_UNROLL
+                for (uint32_t i = 0; i < 3; i++) if (e0 + i < ne) lst[e0 + i] = ent[i];
+            }
         }
     }
 }
