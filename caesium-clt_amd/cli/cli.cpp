@@ -548,11 +548,11 @@ int run(const Options &o) {
     std::vector<Job> jobs(files.size());
     const std::string suffix = o.suffix.value_or("");
 
-    // The files go through the three stages a WINDOW at a time (at most CSH_CLI_WINDOW files, default 4096, or 8 GiB of input): what is held in
+    // The files go through the three stages a WINDOW at a time (at most CSH_CLI_WINDOW files, default 1024, or 8 GiB of input): what is held in
     // memory is a window's inputs and outputs, not the tree's -- the reference works file by file (compressor.rs:81-100) and takes trees of any size.
     std::vector<std::pair<size_t, size_t>> windows;
     {
-        const size_t max_files = getenv("CSH_CLI_WINDOW") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WINDOW")))) : 4096;
+        const size_t max_files = getenv("CSH_CLI_WINDOW") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WINDOW")))) : 1024;   // (round 5, 10 000 x 1080p on /dev/shm: 2.1-2.4 s at 512-1024 files per window, 2.7-2.9 s at 4096: the first window is read before anything else happens, and a window's end is a join)
         const uint64_t max_bytes = uint64_t(8) << 30;
         size_t b0 = 0;
         uint64_t bytes = 0;
@@ -677,7 +677,7 @@ int run(const Options &o) {
         // files per device batch (and never more than one device batch takes by bytes / declared pixels: cs_batch_extent).  A cold process pays for the
         // device pools it allocates (~25 MB per 1080p file) before the first kernel runs, and later batches reuse the first ones' pools: smaller
         // batches start sooner -- 2048 x 1080p files end to end on one MI355X: 3.3-5.6 s at 1024 files per batch, 1.0 s at 256, 0.9 s at 128; CSH_CLI_BATCH overrides
-        const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : 256;
+        const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : 128;   // (round 5: 10 000 files 2.11-2.13 s at 128, 2.23-2.37 s at 256 -- half the pools a cold process has to map before its first kernel)
         for (auto &g : groups) {
             std::vector<CByteArray> gin(g.second.size());
             for (size_t k = 0; k < gin.size(); k++) { gin[k].data = jobs[g.second[k]].data.data(); gin[k].length = jobs[g.second[k]].data.size(); }
