@@ -143,8 +143,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8l_pack(const Vp8lImg *i
         LFOR(l) { val[l] = l == 0 ? v : 0ull; nb[l] = l == 0 ? n : 0u; }
         bo.put(val, nb);
     };
-    // a code with one or two symbols is written as such (8-bit symbol fields); any other the long way: all 19 code-length codes present,
-    // the lengths 0..15 coded with 4 bits each, no run lengths, cut behind the last symbol in use
+    // a code with one or two symbols is written as such (8-bit symbol fields); any other the long way: the code-length code gives the lengths
+    // 0..15 four bits each and the run-length symbols 16..18 none, the lengths are cut behind the last symbol in use
     auto put_code = [&](int t) __attribute__((always_inline)) {
         const uint32_t used = S.nused[t];
         if (used <= 2) {

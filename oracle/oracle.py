@@ -110,6 +110,7 @@ def lib():
         L.cso_webp_quality_to_qi.argtypes = [C.c_int]
         L.cso_webp_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p]
         L.cso_webp_encode_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_vp8l_encode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 
@@ -430,6 +431,18 @@ def webp_quality_to_qi(q):
 def png_to_webp(data, quality):
     out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
     rc = lib().cso_png_to_webp(data, len(data), quality, C.byref(out), C.byref(n))
+    if rc:
+        raise PngError(rc)
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res
+
+
+def vp8l_encode(pixels, width, height, channels):
+    """lossless WebP (VP8L) of `pixels` (bytes: width * height * channels; 1 grey, 2 grey + alpha, 3 RGB, 4 RGBA) as the device coder writes it
+    (oracle/png_oracle.c cso_vp8l_encode)"""
+    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+    rc = lib().cso_vp8l_encode(bytes(pixels), width, height, channels, C.byref(out), C.byref(n))
     if rc:
         raise PngError(rc)
     res = C.string_at(out, n.value)

@@ -1157,3 +1157,156 @@ int cso_png_to_webp(const uint8_t *in, size_t n, int quality, uint8_t **out, siz
     cso_png_free(P);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * Lossless WebP OUTPUT (VP8L), the statement the device coder (caesium-clt_amd/csrc/k_vp8l_enc.hip) is compared with byte for byte.
+ * Replaces, for webp.lossless, libwebp's lossless coder as libcaesium calls it (/root/reference/src/compressor.rs:427-429, call sites
+ * :289-305).  NOT libwebp's bytes -- "parity unpinned": the stream uses the format's data-parallel tools only (subtract-green, the
+ * spatial predictor with the best of the 14 modes per 16 x 16 block by the sum of absolute residuals, every mode predicting from ORIGINAL
+ * neighbours, one group of prefix codes limited to 15 bits); what is pinned is the format (WebP Lossless Bitstream Specification,
+ * sections 4.1 "predictor transform", 4.3 "subtract green", 6.2 "details of decoding prefix codes"): libwebp decodes the file to the
+ * source pixels (tests/test_webp_lossless_emul.py).  Lives in this file because it shares code_lengths() / canonical() with DEFLATE.
+ * px: `channels` (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA) bytes per pixel.  Returns 0, *out malloc'ed. */
+static uint32_t l_avg(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+    for (int s = 0; s < 32; s += 8) r |= ((((a >> s) & 255u) + ((b >> s) & 255u)) >> 1) << s;
+    return r;
+}
+static uint32_t l_clip(int v) { return v < 0 ? 0u : v > 255 ? 255u : (uint32_t)v; }
+static uint32_t l_predict(int mode, uint32_t L, uint32_t T, uint32_t TR, uint32_t TL) {
+    uint32_t r = 0;
+    switch (mode) {
+    case 0: return 0xFF000000u;
+    case 1: return L;
+    case 2: return T;
+    case 3: return TR;
+    case 4: return TL;
+    case 5: return l_avg(l_avg(L, TR), T);
+    case 6: return l_avg(L, TL);
+    case 7: return l_avg(L, T);
+    case 8: return l_avg(TL, T);
+    case 9: return l_avg(T, TR);
+    case 10: return l_avg(l_avg(L, TL), l_avg(T, TR));
+    case 11: {   /* Select: the neighbour nearer to the gradient estimate L + T - TL (Manhattan distance over the four channels) */
+        int pl = 0, pt = 0;
+        for (int s = 0; s < 32; s += 8) {
+            const int l = (int)((L >> s) & 255u), t = (int)((T >> s) & 255u), tl = (int)((TL >> s) & 255u);
+            pl += abs(t - tl);   /* |(l + t - tl) - l| */
+            pt += abs(l - tl);   /* |(l + t - tl) - t| */
+        }
+        return pl < pt ? L : T;
+    }
+    case 12:
+        for (int s = 0; s < 32; s += 8) r |= l_clip((int)((L >> s) & 255u) + (int)((T >> s) & 255u) - (int)((TL >> s) & 255u)) << s;
+        return r;
+    case 13: {
+        const uint32_t a = l_avg(L, T);
+        for (int s = 0; s < 32; s += 8) { const int x = (int)((a >> s) & 255u), y = (int)((TL >> s) & 255u); r |= l_clip(x + (x - y) / 2) << s; }
+        return r;
+    }
+    default: return 0xFF000000u;
+    }
+}
+static uint32_t l_sub(uint32_t a, uint32_t b) {   /* per channel, modulo 256 */
+    uint32_t r = 0;
+    for (int s = 0; s < 32; s += 8) r |= ((((a >> s) & 255u) - ((b >> s) & 255u)) & 255u) << s;
+    return r;
+}
+static uint32_t l_sg(const uint8_t *px, int w, int channels, int x, int y) {   /* ARGB after the subtract-green transform */
+    const uint8_t *p = px + ((size_t)y * (size_t)w + (size_t)x) * (size_t)channels;
+    if (channels <= 2) return (channels == 2 ? (uint32_t)p[1] << 24 : 0xFF000000u) | ((uint32_t)p[0] << 8);
+    const uint32_t r = p[0], g = p[1], b = p[2];
+    return (channels == 4 ? (uint32_t)p[3] << 24 : 0xFF000000u) | (((r - g) & 255u) << 16) | (g << 8) | ((b - g) & 255u);
+}
+static uint32_t l_pred_at(const uint8_t *px, int w, int channels, int x, int y, int mode) {   /* the frame's rules: first pixel black, first row left, first column top */
+    if (y == 0) return x == 0 ? 0xFF000000u : l_sg(px, w, channels, x - 1, 0);
+    if (x == 0) return l_sg(px, w, channels, 0, y - 1);
+    const uint32_t TR = x + 1 < w ? l_sg(px, w, channels, x + 1, y - 1) : l_sg(px, w, channels, 0, y);   /* one past the row above = the row's own first pixel */
+    return l_predict(mode, l_sg(px, w, channels, x - 1, y), l_sg(px, w, channels, x, y - 1), TR, l_sg(px, w, channels, x - 1, y - 1));
+}
+typedef struct { uint8_t len[288]; uint16_t code[288]; int used, s0, s1, last; } lcode;
+static void l_make_code(lcode *c, const uint32_t *f, int n) {
+    code_lengths(f, n, 15, c->len);
+    c->used = 0; c->s0 = c->s1 = c->last = 0;
+    for (int i = 0; i < n; i++) if (f[i]) { if (c->used == 0) c->s0 = i; else if (c->used == 1) c->s1 = i; c->used++; c->last = i; }
+    if (c->used <= 1) memset(c->len, 0, (size_t)n);   /* a code with one symbol costs no bits */
+    canonical(c->len, n, c->code);
+}
+static void l_put_code(obits *o, const lcode *c) {
+    if (c->used <= 2) {   /* a simple code: one or two symbols, the first in a 1-bit field when that is enough */
+        const int two = c->used == 2, wide = c->s0 > 1, w0 = wide ? 8 : 1;
+        put(o, 1, 1); put(o, (uint32_t)two, 1); put(o, (uint32_t)wide, 1); put(o, (uint32_t)c->s0, w0);
+        if (two) put(o, (uint32_t)c->s1, 8);
+        return;
+    }
+    /* a normal code the long way: the code-length code gives the sixteen lengths 0..15 four bits each (so length v is the 4-bit code v, written
+       MSB first as prefix codes are) and the run-length symbols 16, 17, 18 none; the lengths are cut behind the last symbol in use */
+    static const int kOrder[19] = {17, 18, 0, 1, 2, 3, 4, 5, 16, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};   /* the format's order of the code-length code lengths */
+    put(o, 0, 1);
+    put(o, 15, 4);                              /* 4 + 15 = 19 code-length code lengths follow */
+    for (int i = 0; i < 19; i++) put(o, kOrder[i] <= 15 ? 4u : 0u, 3);
+    const int n = c->last + 1;
+    put(o, 1, 1);                               /* max_symbol is given: */
+    put(o, 4, 3);                               /*   in a field of 2 + 2 * 4 = 10 bits */
+    put(o, (uint32_t)(n - 2), 10);
+    for (int i = 0; i < n; i++) { const int v = c->len[i]; put(o, (uint32_t)(((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3)), 4); }
+}
+static void l_put_single(obits *o) { put(o, 1, 1); put(o, 0, 1); put(o, 0, 1); put(o, 0, 1); }   /* simple code, one symbol, 1-bit field, symbol 0 */
+int cso_vp8l_encode(const uint8_t *px, int width, int height, int channels, uint8_t **out, size_t *out_len) {
+    if (width < 1 || height < 1 || width > 16384 || height > 16384 || channels < 1 || channels > 4) return CSO_PNG_UNSUPPORTED;
+    const int bw = (width + 15) / 16, bh = (height + 15) / 16;
+    uint8_t *modes = (uint8_t *)malloc((size_t)bw * (size_t)bh);
+    uint32_t *res = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)width * (size_t)height);
+    for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++) {
+            uint64_t cost[14] = {0};
+            for (int y = by * 16; y < by * 16 + 16 && y < height; y++)
+                for (int x = bx * 16; x < bx * 16 + 16 && x < width; x++) {
+                    if (!x || !y) continue;   /* the frame's first row and column are predicted the same way whatever the mode */
+                    const uint32_t me = l_sg(px, width, channels, x, y);
+                    for (int m = 0; m < 14; m++) {
+                        const uint32_t r = l_sub(me, l_pred_at(px, width, channels, x, y, m));
+                        for (int s = 0; s < 32; s += 8) { const uint32_t v = (r >> s) & 255u; cost[m] += v < 128u ? v : 256u - v; }
+                    }
+                }
+            int best = 0;
+            for (int m = 1; m < 14; m++) if (cost[m] < cost[best]) best = m;
+            modes[by * bw + bx] = (uint8_t)best;
+        }
+    uint32_t hist[4][288]; uint32_t mh[288];
+    memset(hist, 0, sizeof hist); memset(mh, 0, sizeof mh);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const uint32_t v = l_sub(l_sg(px, width, channels, x, y), l_pred_at(px, width, channels, x, y, modes[(y / 16) * bw + x / 16]));
+            res[(size_t)y * (size_t)width + (size_t)x] = v;
+            hist[0][(v >> 8) & 255u]++; hist[1][(v >> 16) & 255u]++; hist[2][v & 255u]++; hist[3][v >> 24]++;
+        }
+    for (int b = 0; b < bw * bh; b++) mh[modes[b]]++;
+    lcode cg, cr, cb, ca, cm;
+    l_make_code(&cg, hist[0], 280); l_make_code(&cr, hist[1], 256); l_make_code(&cb, hist[2], 256); l_make_code(&ca, hist[3], 256); l_make_code(&cm, mh, 280);
+    obits o; memset(&o, 0, sizeof o);
+    put(&o, 0x2F, 8);
+    put(&o, (uint32_t)(width - 1), 14); put(&o, (uint32_t)(height - 1), 14); put(&o, (channels == 2 || channels == 4) ? 1u : 0u, 1); put(&o, 0, 3);
+    put(&o, 1, 1); put(&o, 2, 2);                    /* a transform: subtract green */
+    put(&o, 1, 1); put(&o, 0, 2); put(&o, 2, 3);     /* a transform: predictor, blocks of 1 << (2 + 2) pixels */
+    put(&o, 0, 1);                                   /* its mode image (a sub-resolution image: no meta prefix bit): no colour cache */
+    l_put_code(&o, &cm); l_put_single(&o); l_put_single(&o); l_put_single(&o); l_put_single(&o);   /* the mode sits in the green channel */
+    for (int b = 0; b < bw * bh; b++) put(&o, cm.code[modes[b]], cm.len[modes[b]]);
+    put(&o, 0, 1);                                   /* no further transform */
+    put(&o, 0, 1);                                   /* the picture: no colour cache */
+    put(&o, 0, 1);                                   /* no meta prefix image */
+    l_put_code(&o, &cg); l_put_code(&o, &cr); l_put_code(&o, &cb); l_put_code(&o, &ca); l_put_single(&o);   /* green, red, blue, alpha, distance */
+    for (size_t i = 0; i < (size_t)width * (size_t)height; i++) {
+        const uint32_t v = res[i], g = (v >> 8) & 255u, r = (v >> 16) & 255u, b = v & 255u, a = v >> 24;
+        put(&o, cg.code[g], cg.len[g]); put(&o, cr.code[r], cr.len[r]); put(&o, cb.code[b], cb.len[b]); put(&o, ca.code[a], ca.len[a]);
+    }
+    align(&o);
+    const size_t payload = o.n, padded = payload + (payload & 1u), total = 20 + padded;
+    uint8_t *f = (uint8_t *)calloc(total, 1);
+    memcpy(f, "RIFF", 4); f[4] = (uint8_t)(total - 8); f[5] = (uint8_t)((total - 8) >> 8); f[6] = (uint8_t)((total - 8) >> 16); f[7] = (uint8_t)((total - 8) >> 24);
+    memcpy(f + 8, "WEBPVP8L", 8); f[16] = (uint8_t)payload; f[17] = (uint8_t)(payload >> 8); f[18] = (uint8_t)(payload >> 16); f[19] = (uint8_t)(payload >> 24);
+    memcpy(f + 20, o.p, payload);
+    free(o.p); free(modes); free(res);
+    *out = f; *out_len = total;
+    return 0;
+}

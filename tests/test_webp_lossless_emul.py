@@ -27,6 +27,17 @@ def check_vp8l(blob, want_rgb):
     im = Image.open(io.BytesIO(blob))
     got = np.asarray(im.convert("RGB"))
     assert got.shape == want_rgb.shape and np.array_equal(got, want_rgb)
+    assert blob == oracle_vp8l(blob)
+
+
+def oracle_vp8l(blob):
+    """the bytes the oracle's statement of the VP8L coder (oracle/png_oracle.c cso_vp8l_encode) makes of the pixels `blob` decodes to (libwebp's reading): the
+    device's / the emulation's file must BE that -- the coder is checked against a statement of its own, not against another build of its source.
+    (A grey picture coded from one channel and from three equal ones is the same stream: subtract-green leaves the same residuals.)"""
+    from oracle import oracle as O
+    alpha = (int.from_bytes(blob[21:25], "little") >> 28) & 1
+    px = np.asarray(Image.open(io.BytesIO(blob)).convert("RGBA" if alpha else "RGB"))
+    return O.vp8l_encode(px.tobytes(), px.shape[1], px.shape[0], 4 if alpha else 3)
 
 
 def sources():
@@ -100,6 +111,7 @@ def test_emul_png_to_lossless_webp(api):
         got = Image.open(io.BytesIO(out))
         assert got.mode == "RGBA", name
         assert np.array_equal(np.asarray(got), np.asarray(Image.open(io.BytesIO(cases[name])).convert("RGBA"))), name
+        assert out == oracle_vp8l(out), name
     for name, out in zip(["I;16_97x61", "rgb16_70x45"], outs[len(exact) + len(alpha):]):   # 16-bit samples are narrowed (the lossy PNG -> WebP path pins the rule)
         assert isinstance(out, bytes) and Image.open(io.BytesIO(out)).size == Image.open(io.BytesIO(cases[name])).size, name
     # the same pixels as the lossy conversion's source: a JPEG made from the PNG at 4:4:4 q100 is not exact, so compare with PNG -> PNG resize instead

@@ -30,13 +30,17 @@ def test_lossless_webp_failures_stay_per_file(api):
     E.test_emul_lossless_webp_failures_stay_per_file(api)
 
 
-def test_emulation_and_device_write_the_same_bytes(api):
+def test_device_writes_the_oracles_bytes(api):
+    """every case above already compares the device's file with the oracle's statement of the coder (check_vp8l -> oracle_vp8l: oracle/png_oracle.c
+    cso_vp8l_encode); here one larger picture, against the oracle and against the emulation build"""
     import test_webp_decode_emul as D
     from gen_synth import synth_rgb
     from _util import emul_api
     src = D.lossless_of(synth_rgb(9, 150, 90, texture=20.0))
     p = E.params(webp_lossless=True)
-    assert api.compress_in_memory(src, p) == emul_api().compress_in_memory(src, p)
+    out = api.compress_in_memory(src, p)
+    assert out == E.oracle_vp8l(out)
+    assert out == emul_api().compress_in_memory(src, p)
 
 
 def test_png_to_lossless_webp(api):
