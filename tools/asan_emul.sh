@@ -58,6 +58,12 @@ WD.test_emul_transparent_files_decode_like_libwebp(api); WD.test_emul_damaged_tr
 import test_webp_lossless_emul as WL
 WL.test_emul_lossless_webp_round_trips_through_libwebp(api, '$R/tests/golden/reference_samples'); WL.test_emul_jpeg_to_lossless_webp_and_resize(api); WL.test_emul_lossless_webp_failures_stay_per_file(api); WL.test_emul_png_to_lossless_webp(api)
 PW.test_transparency_becomes_an_alph_chunk(api)
+# round 5: the chroma window's 16-byte loads around a row's first / last block (odd and tiny sizes), the statistics list that takes the trellis's levels and is
+# compacted in place (several chunks per component), two DC refinement scans in one launch
+PE.test_emul_two_dc_refinement_passes(api)
+srcs5 = [synth_jpeg(30 + i, w, h, texture=t) for i, (w, h, t) in enumerate([(17, 9, 20), (33, 31, 60), (200, 8, 10), (8, 200, 10), (641, 363, 35), (1000, 520, 25)])]
+for s, o in zip(srcs5, api.batch_compress(srcs5, pkg.default_parameters(jpeg_quality=80))): assert o == _util.oracle_lossy(s)
+for s, o in zip(srcs5, api.batch_compress(srcs5, pkg.default_parameters(jpeg_quality=35))): assert o == _util.oracle_lossy(s, 35)
 print('asan run: all cases equal the oracle')
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 python $O/run.py 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|asan run|Traceback|Error" | sort | uniq -c
