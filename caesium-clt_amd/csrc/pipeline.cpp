@@ -483,9 +483,11 @@ extern "C" int csh_batch_create_webp(const CByteArray *inputs, size_t count, con
 // token pool (k_entropy.hip): every region gets its estimate x tok_scale (the scale grows on overflow, like the other pools)
 static void layout_token_pool(csh_batch *b) {
     b->regions.resize(b->region_est.size());
+    // CSH_TEST_POOL_SHIFT=n (tests): every estimate divided by 2^n, so that the first runs overflow and the batch goes through its retries with larger pools
+    const int shift = getenv("CSH_TEST_POOL_SHIFT") ? std::min(16, std::max(0, atoi(getenv("CSH_TEST_POOL_SHIFT")))) : 0;
     uint64_t at = 0;
     for (size_t i = 0; i < b->regions.size(); i++) {
-        const uint64_t cap = std::min<uint64_t>(uint64_t(b->region_est[i]) * b->tok_scale, 0xFFFFFFF0ull);
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>((uint64_t(b->region_est[i]) * b->tok_scale) >> shift, 64), 0xFFFFFFF0ull);
         b->regions[i].base = at; b->regions[i].cap = uint32_t(cap); b->regions[i].pad = 0;
         at += (cap + 3) & ~uint64_t(3);
     }
@@ -493,7 +495,7 @@ static void layout_token_pool(csh_batch *b) {
     // the list pool (k_aclist.hip): the same rule, capped by what a list can hold at most; regions start on 16-byte boundaries
     at = 0;
     for (size_t i = 0; i < b->nzlists.size(); i++) {
-        const uint64_t cap = std::min<uint64_t>(uint64_t(b->nz_est[i]) * b->tok_scale, b->nz_worst[i]);
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>((uint64_t(b->nz_est[i]) * b->tok_scale) >> shift, 64), b->nz_worst[i]);
         b->nzlists[i].base = at; b->nzlists[i].cap = uint32_t(cap);
         at += (cap + 3) & ~uint64_t(3);
     }

@@ -139,3 +139,18 @@ def test_trellis_saves_bytes_at_equal_quality():
     moz = O.jpeg_compress(src, O.params(quality=80, scan_script=2, trellis=1, deringing=1))
     assert len(moz) < 0.95 * len(plain)
     assert psnr(plain) - psnr(moz) < 0.6
+
+
+def test_emul_pools_that_overflow_are_grown_and_the_run_repeated(api, monkeypatch):
+    """CSH_TEST_POOL_SHIFT: every token / list pool estimate divided by 16 -- the statistics lists and the coding stages' lists overflow, the run is
+    repeated with pools four times the size until they fit (pipeline.cpp csh_batch_run).  The lists that take the trellis's levels (round 5) must
+    come out of the retries as they come out of a first run: the same bytes as the oracle's."""
+    monkeypatch.setenv("CSH_TEST_POOL_SHIFT", "4")
+    srcs = [synth_jpeg(41, 320, 240, texture=40), synth_jpeg(42, 200, 136, subsampling=0, texture=70), synth_jpeg(43, 97, 61, texture=10)]
+    for prof in (None, "scalar"):
+        if prof: monkeypatch.setenv("CSH_PROFILE", prof)
+        else: monkeypatch.delenv("CSH_PROFILE", raising=False)
+        outs = api.batch_compress(srcs, params(jpeg_quality=80))
+        for s_, o in zip(srcs, outs):
+            assert o == oracle_lossy(s_), prof
+

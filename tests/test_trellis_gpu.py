@@ -36,6 +36,10 @@ def test_size_targeting(api, monkeypatch):
     E.check_size_targeting(api, monkeypatch)
 
 
+def test_pools_that_overflow_are_grown_and_the_run_repeated(api, monkeypatch):
+    E.test_emul_pools_that_overflow_are_grown_and_the_run_repeated(api, monkeypatch)
+
+
 def test_1080p_full_size_and_a_wide_batch(api, monkeypatch):
     """BASELINE configs[1]'s size, and enough files that the AC kernel's workgroups loop over several chunks each"""
     monkeypatch.setenv("CSH_PROFILE", "mozjpeg")
