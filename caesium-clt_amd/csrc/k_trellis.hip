@@ -245,7 +245,9 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             const int bk = int(bestsel & 15u);
             const uint32_t level = uint32_t(bk < ncand - 1 ? (2 << bk) - 1 : qval);
             const float Zi = (float(__mul24(x, x)) * lambda) * ltk + Zp;
-            const uint32_t P2 = (bestsel >> 4) | (uint32_t(kpos) << 15) | (level << 21) | (P & 0x80000000u);
+            // (bit 14: the chosen level IS the scalar level -- what the coefficient tile already holds: the write-back leaves such a coefficient alone;
+            // not at the largest level, which the sweep may have cut the scalar level down to)
+            const uint32_t P2 = (bestsel >> 4) | ((level == uint32_t(qval) && qval < TRELLIS_MAX_LEVEL) ? 0x4000u : 0u) | (uint32_t(kpos) << 15) | (level << 21) | (P & 0x80000000u);
             if (t < CSH_TR_CAP) { L.A[t][tid] = bestc; L.Z[t][tid] = Zi; L.P[t][tid] = P2; }
             else { uint32_t *q = sp + ((t - CSH_TR_CAP) * 3u) * CSH_TR_WGU; CSH_SPILL_ST(q, tr_f_bits(bestc)); CSH_SPILL_ST(q + CSH_TR_WG, tr_f_bits(Zi)); CSH_SPILL_ST(q + 2 * CSH_TR_WG, P2); }
         }
@@ -298,7 +300,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
                 uint32_t Pe;
                 if (e < CSH_TR_CAP) Pe = L.P[e][tid]; else Pe = CSH_SPILL_LD(sp + ((e - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU);
                 const int pos = int((Pe >> 15) & 63u), level = ((kept >> e) & 1ull) ? int((Pe >> 21) & 1023u) : 0;
-                dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);
+                if (!(((kept >> e) & 1ull) && (Pe & 0x4000u))) dst[coef_off(pos)] = int16_t((Pe >> 31) ? -level : level);   // kept at the scalar level: the tile holds it
                 ent[i] = uint32_t(pos) | ((Pe >> 31) ? 128u : 0u) | (uint32_t(level) << 8) | ((u & 255u) << 23);
             }
         }
