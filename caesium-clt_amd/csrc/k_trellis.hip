@@ -38,11 +38,14 @@ size_t trellis_spill_words() { return size_t(CSH_TR_MAXWG) * CSH_TR_SPILL * 3u *
 #define CSH_SPILL_ST(ptr, v) (*(ptr) = (v))
 #else
 #define CSH_ANY(p) (__ballot(p) != 0ull)   // wave-uniform loop conditions
-__device__ __forceinline__ static unsigned tr_wave_or(unsigned v) {   // OR over the wave's active lanes, in a scalar register
+__device__ __forceinline__ static unsigned tr_wave_or(unsigned v) {   // a value with the bit length of the OR over the wave's active lanes (all its users take the bit length): the largest bit length, found in four ballots (ten, one per bit, before round 5)
+    const unsigned n = 32u - unsigned(__clz(v));   // 0..10: levels have ten bits
     unsigned r = 0;
-    CSH_UNROLL
-    for (int b = 0; b < 10; b++) r |= (__ballot((v >> b) & 1u) != 0ull) ? (1u << b) : 0u;   // levels have ten bits
-    return r;
+    if (__ballot(n >= 8u)) r = 8u;
+    if (__ballot(n >= r + 4u)) r += 4u;
+    if (__ballot(n >= r + 2u)) r += 2u;
+    if (__ballot(n >= r + 1u)) r += 1u;
+    return r ? 1u << (r - 1u) : 0u;
 }
 #define CSH_WAVE_OR(v) tr_wave_or(v)
 // the spilled entries are read and written as streaming accesses: besides the hint, that keeps them from being merged with the LDS
@@ -93,11 +96,12 @@ struct TrLds {
     const int32_t *q8;    // 8 q, zig-zag order
     const uint32_t *qmul, *qsh;   // the exact-division pair of 8 q
     const float *lt;      // 1 / q^2
+    const float *rcp;     // the one-fma quantiser's reciprocal of 8 q (DevQuant::rcp)
 };
 
 // tables of the chunk's component -> LDS (all 256 lanes)
 // (the sweep reads the quantiser's three values per position from here: as loads from HBM they were 189 dependent round trips per wave)
-__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, float *s_lenf, float *s_runf, int *s_eob, int32_t *s_q8, uint32_t *s_qmul, uint32_t *s_qsh, float *s_lt) {
+__device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32_t chi, float *s_lenf, float *s_runf, int *s_eob, int32_t *s_q8, uint32_t *s_qmul, uint32_t *s_qsh, float *s_lt, float *s_rcp) {
     const TrellisWork &w = c.work[c.chunks[chi].work];
     const ImgDesc &im = c.imgs[w.image];
     const DevQuant &Q = c.quant[im.qt_out[w.comp]];
@@ -111,7 +115,7 @@ __device__ __forceinline__ static void trellis_stage(const TrellisCtx &c, uint32
     }
     if (tid < 4) s_runf[tid] = tid == 0 ? 0.0f : (size[0xF0] ? float(tid * int(size[0xF0])) : 1e38f);
     if (tid == 0) *s_eob = size[0x00];
-    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_qmul[tid] = Q.mul[tid]; s_qsh[tid] = Q.sh[tid]; s_lt[tid] = Q.lt[tid]; }
+    if (tid < 64) { s_q8[tid] = Q.div[tid]; s_qmul[tid] = Q.mul[tid]; s_qsh[tid] = Q.sh[tid]; s_lt[tid] = Q.lt[tid]; s_rcp[tid] = Q.rcp[tid]; }
 }
 
 __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32_t chi, uint32_t wg_slot, const TrLds &L) {
@@ -132,7 +136,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     // lambda: the block's mean squared AC value (float accumulation in natural order), two roundings from double as in the C source
     float norm = 0.0f;
     CSH_UNROLL
-    for (int n = 1; n < 64; n++) { const int v = r[kN2Z[n]]; norm = norm + float(v * v); }
+    for (int n = 1; n < 64; n++) { const float vf = float(r[kN2Z[n]]); norm = norm + vf * vf; }   // (the float product of the converted value IS the converted integer square: both are the exact square rounded once)
     norm = float(double(norm) / 63.0);
     const float lambda = float(TRELLIS_LAMBDA_C1 / (TRELLIS_LAMBDA_C2 + double(norm)));
     c.dcrec[w.unit_base + u] = (uint64_t(tr_f_bits(lambda)) << 32) | (uint32_t(r[0]) & 0xFFFFu);   // what the DC kernel needs of this block, in one load
@@ -145,7 +149,8 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
     CSH_UNROLL
     for (int k = 1; k < 64; k++) {
         const int v = r[k], x = v < 0 ? -v : v;
-        int qv = tr_level(x, L.q8[k], L.qmul[k], L.qsh[k]);
+        const float xf = float(x);
+        int qv = int(tr_f_bits(__builtin_fmaf(xf, L.rcp[k], 12582912.0f)) & 0xFFFFu);   // (x + d / 2) / d exactly: the pixel kernels' one-fma quantiser (k_pixel.hip quant_one, DevQuant::rcp)
         qv = qv > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : qv;
         if (qv) {
             const uint32_t P = uint32_t(x) | (uint32_t(k) << 15) | (uint32_t(qv) << 21) | (v < 0 ? 0x80000000u : 0u);
@@ -153,7 +158,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
             else { CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 1u) * CSH_TR_WGU, tr_f_bits(Zrun)); CSH_SPILL_ST(sp + ((ne - CSH_TR_CAP) * 3u + 2u) * CSH_TR_WGU, P); }
             ne++;
         }
-        Zrun = (float(__mul24(x, x)) * lambda) * L.lt[k] + Zrun;
+        Zrun = ((xf * xf) * lambda) * L.lt[k] + Zrun;
     }
     const float Z63 = Zrun;
     CSH_SCHED_FENCE();
@@ -351,16 +356,17 @@ __global__ void __launch_bounds__(CSH_TR_WG) k_trellis_ac(TrellisCtx c) {
     CSH_SHARED uint32_t s_qmul[64];
     CSH_SHARED uint32_t s_qsh[64];
     CSH_SHARED float s_lt[64];
-    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.lenf = s_lenf; L.runf = s_runf; L.q8 = s_q8; L.qmul = s_qmul; L.qsh = s_qsh; L.lt = s_lt;
+    CSH_SHARED float s_rcp[64];
+    TrLds L; L.A = s_A; L.Z = s_Z; L.P = s_P; L.lenf = s_lenf; L.runf = s_runf; L.q8 = s_q8; L.qmul = s_qmul; L.qsh = s_qsh; L.lt = s_lt; L.rcp = s_rcp;
 #ifdef CSH_EMUL
     CSH_PHASE_LOOP(2) {
-        if (phase == 0) { trellis_stage(c, blockIdx.x, s_lenf, s_runf, &s_eob, s_q8, s_qmul, s_qsh, s_lt); continue; }
+        if (phase == 0) { trellis_stage(c, blockIdx.x, s_lenf, s_runf, &s_eob, s_q8, s_qmul, s_qsh, s_lt, s_rcp); continue; }
         L.lenEOB = s_eob;
         trellis_block(c, blockIdx.x, 0u, L);
     }
 #else
     for (uint32_t chi = blockIdx.x; chi < c.nchunks; chi += gridDim.x) {
-        trellis_stage(c, chi, s_lenf, s_runf, &s_eob, s_q8, s_qmul, s_qsh, s_lt);
+        trellis_stage(c, chi, s_lenf, s_runf, &s_eob, s_q8, s_qmul, s_qsh, s_lt, s_rcp);
         __syncthreads();
         L.lenEOB = s_eob;
         trellis_block(c, chi, blockIdx.x, L);
