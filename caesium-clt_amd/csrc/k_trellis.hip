@@ -216,30 +216,39 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         // predecessor by predecessor, candidate by candidate (ties go to the first).  A row at or above t is read and priced at 1e38; a candidate
         // the level does not offer has dist 1e38: neither can win.
         if (ncmax <= 4) {
-            for (int j0 = 0; j0 < t_lds; j0 += 4) {
-                uint32_t Pj[4]; float Aj[4], Zj[4];
-                CSH_UNROLL
-                for (int i = 0; i < 4; i++) { const int r = j0 + i < CSH_TR_CAP ? j0 + i : CSH_TR_CAP - 1; Pj[i] = L.P[r][tid]; Aj[i] = L.A[r][tid]; Zj[i] = L.Z[r][tid]; }
-                float cost[4][4];
-                CSH_UNROLL
-                for (int i = 0; i < 4; i++) {
-                    const int zr = kpos - 1 - int((Pj[i] >> 15) & 63u);
-                    const float runf = L.runf[(zr >> 4) & 3];
-                    const float *lf = L.lenf + 11 * (zr & 15);
-                    const float tj = j0 + i < t_lds ? (Zp - Zj[i]) + Aj[i] : 1e38f;
+            // (one instantiation per candidate count of the step, 1..4: with levels 1 and 2..3 -- most steps -- half of the four-candidate form's adds and compares
+            // priced candidates no lane has)
+            auto batch = [&](auto KCV) {
+                constexpr int KC = decltype(KCV)::value;
+                for (int j0 = 0; j0 < t_lds; j0 += 4) {
+                    uint32_t Pj[4]; float Aj[4], Zj[4];
                     CSH_UNROLL
-                    for (int kc = 0; kc < 4; kc++) cost[i][kc] = ((lf[kc] + runf) + dist[kc]) + tj;
-                }
-                CSH_UNROLL
-                for (int i = 0; i < 4; i++) {
+                    for (int i = 0; i < 4; i++) { const int r = j0 + i < CSH_TR_CAP ? j0 + i : CSH_TR_CAP - 1; Pj[i] = L.P[r][tid]; Aj[i] = L.A[r][tid]; Zj[i] = L.Z[r][tid]; }
+                    float cost[4][KC];
                     CSH_UNROLL
-                    for (int kc = 0; kc < 4; kc++) {
-                        const bool better = cost[i][kc] < bestc;
-                        bestc = better ? cost[i][kc] : bestc;
-                        bestsel = better ? ((uint32_t(j0 + i + 1) << 4) | uint32_t(kc)) : bestsel;
+                    for (int i = 0; i < 4; i++) {
+                        const int zr = kpos - 1 - int((Pj[i] >> 15) & 63u);
+                        const float runf = L.runf[(zr >> 4) & 3];
+                        const float *lf = L.lenf + 11 * (zr & 15);
+                        const float tj = j0 + i < t_lds ? (Zp - Zj[i]) + Aj[i] : 1e38f;
+                        CSH_UNROLL
+                        for (int kc = 0; kc < KC; kc++) cost[i][kc] = ((lf[kc] + runf) + dist[kc]) + tj;
+                    }
+                    CSH_UNROLL
+                    for (int i = 0; i < 4; i++) {
+                        CSH_UNROLL
+                        for (int kc = 0; kc < KC; kc++) {
+                            const bool better = cost[i][kc] < bestc;
+                            bestc = better ? cost[i][kc] : bestc;
+                            bestsel = better ? ((uint32_t(j0 + i + 1) << 4) | uint32_t(kc)) : bestsel;
+                        }
                     }
                 }
-            }
+            };
+            if (ncmax <= 1) batch(std::integral_constant<int, 1>());
+            else if (ncmax == 2) batch(std::integral_constant<int, 2>());
+            else if (ncmax == 3) batch(std::integral_constant<int, 3>());
+            else batch(std::integral_constant<int, 4>());
         } else
             for (int jj = 0; jj < t_lds; jj++) from(jj, int((L.P[jj][tid] >> 15) & 63u), L.A[jj][tid], L.Z[jj][tid]);
         for (int jj = CSH_TR_CAP; jj < int(t); jj++) {
