@@ -302,9 +302,12 @@ __global__ void __launch_bounds__(256) k_list_stats(EncCtx c) {
     uint32_t carry = CSH_NZ_END;
     LV<uint32_t> raw;
     LFOR(l) raw[l] = 0u;
+    // (the next step's entries are asked for before this step's are looked at: a step is short, and what it waited for was its own load)
+    LV<uint32_t> x0, x1, x2, x3;
+    LFOR(l) list_load4(ls, 4u * uint32_t(l), x0[l], x1[l], x2[l], x3[l]);
     for (uint32_t g0 = 0; g0 < ls.n; g0 += 256) {
-        LV<uint32_t> e0, e1, e2, e3;
-        LFOR(l) list_load4(ls, g0 + 4u * uint32_t(l), e0[l], e1[l], e2[l], e3[l]);
+        const LV<uint32_t> e0 = x0, e1 = x1, e2 = x2, e3 = x3;
+        if (g0 + 256u < ls.n) LFOR(l) list_load4(ls, g0 + 256u + 4u * uint32_t(l), x0[l], x1[l], x2[l], x3[l]);
         const LV<uint32_t> p0 = lprev(e3, carry);
         carry = llast(e3);
         LFOR(l) {
@@ -387,9 +390,11 @@ __global__ void __launch_bounds__(256) k_list_pack(EncCtx c) {
     const uint32_t zrl = lut[0xF0], zc = zrl & 0xFFFFu, zl = zrl >> 16;
     uint32_t carry = CSH_NZ_END;
     const uint32_t n_ext = ls.n + (pad ? 1u : 0u);   // the byte fill rides as one more entry
+    LV<uint32_t> x0, x1, x2, x3;   // the next step's entries, asked for a step ahead
+    LFOR(l) list_load4(ls, 4u * uint32_t(l), x0[l], x1[l], x2[l], x3[l]);
     for (uint32_t g0 = 0; g0 < n_ext; g0 += 256) {
-        LV<uint32_t> e0, e1, e2, e3;
-        LFOR(l) list_load4(ls, g0 + 4u * uint32_t(l), e0[l], e1[l], e2[l], e3[l]);
+        const LV<uint32_t> e0 = x0, e1 = x1, e2 = x2, e3 = x3;
+        if (g0 + 256u < n_ext) LFOR(l) list_load4(ls, g0 + 256u + 4u * uint32_t(l), x0[l], x1[l], x2[l], x3[l]);
         const LV<uint32_t> p0 = lprev(e3, carry);
         carry = llast(e3);
         // what every entry emits: nz[q] ZRLs, then the n[q] low bits of v[q]
