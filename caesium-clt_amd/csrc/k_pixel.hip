@@ -31,6 +31,17 @@ __device__ __forceinline__ static int half_of(const uint4 &v) {  // sign-extende
     return (I & 1) ? (int(w) >> 16) : (int(w << 16) >> 16);
 }
 using Oct = std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7>;
+// coefficient tiles and the retained DCT are streamed: read once here, written once for kernels that run many milliseconds (and 12.8 GB) later.  As
+// non-temporal accesses they leave the L2 / MALL to the data that is reused (round 5: k_xform_direct 2.07 -> 1.95 ms per 1024 files, 5.9 -> 6.3 TB/s)
+#ifndef CSH_EMUL
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ static void nt_store16(void *p, const uint4 &v) { nt_u32x4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w; __builtin_nontemporal_store(x, reinterpret_cast<nt_u32x4 *>(p)); }
+__device__ __forceinline__ static uint4 nt_load16(const void *p) { const nt_u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(p)); uint4 v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w; return v; }
+#else
+__device__ __forceinline__ static void nt_store16(void *p, const uint4 &v) { *reinterpret_cast<uint4 *>(p) = v; }
+__device__ __forceinline__ static uint4 nt_load16(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+#endif
+
 
 #define FIX_0_298 2446
 #define FIX_0_390 3196
@@ -114,7 +125,7 @@ __device__ __forceinline__ static void dequant_octet(int x[64], const uint4 &v, 
 }
 template <int... J>
 __device__ __forceinline__ static void load_dequant(const int16_t *__restrict__ blk, const DevQuant &q, int x[64], std::integer_sequence<int, J...>) {
-    const uint4 v[8] = {*reinterpret_cast<const uint4 *>(blk + CSH_OCT_STRIDE * J)...};  // all eight loads in flight before first use
+    const uint4 v[8] = {nt_load16(blk + CSH_OCT_STRIDE * J)...};  // all eight loads in flight before first use
     (dequant_octet<J>(x, v[J], q, Oct()), ...);
 }
 // CENTRED: samples come out level-shifted (-128..127: what the forward transform takes) -- one clamp instead of add + clamp, and no subtraction in front of the FDCT
@@ -173,7 +184,7 @@ __device__ __forceinline__ static void quant_store_octet(const int x[64], const 
     v.y = pack_halves(quant_one<8 * J + 2>(x, q), quant_one<8 * J + 3>(x, q));
     v.z = pack_halves(quant_one<8 * J + 4>(x, q), quant_one<8 * J + 5>(x, q));
     v.w = pack_halves(quant_one<8 * J + 6>(x, q), quant_one<8 * J + 7>(x, q));
-    *reinterpret_cast<uint4 *>(blk + CSH_OCT_STRIDE * J) = v;
+    nt_store16(blk + CSH_OCT_STRIDE * J, v);
 }
 template <int... J>
 __device__ __forceinline__ static void quant_store_all(const int x[64], const DevQuant &q, int16_t *__restrict__ blk, std::integer_sequence<int, J...>) {
@@ -229,7 +240,7 @@ __device__ __forceinline__ static void raw_copy_out(int16_t *__restrict__ tile_r
         const int src = 8 * j + (l >> 3);
         if ((mask >> src) & 1ull) {
             const uint4 v = *reinterpret_cast<const uint4 *>(&tr[src][(tid & ~63) + 8 * ((l & 7) ^ (src & 7))]);
-            *reinterpret_cast<uint4 *>(tile_raw + src * 64 + (l & 7) * CSH_RAW_OCT) = v;
+            nt_store16(tile_raw + src * 64 + (l & 7) * CSH_RAW_OCT, v);
         }
     }
 #else
