@@ -87,7 +87,9 @@ __device__ __forceinline__ static void idct1d(int &x0, int &x1, int &x2, int &x3
     x3 = (t13 + a0) >> SH; x4 = (t13 - a0) >> SH;
 }
 
-// one 1-D forward transform of jfdctint; FIRST: row pass (<<2, descale 11), else column pass (descale 2 / 15)
+// one 1-D forward transform of jfdctint; FIRST: row pass (<<2, descale 11), else column pass (descale 2 / 15).
+// The multiply-add statement of the pass: the kernels run the packed form below (fdct1d_pk); this one is what tests/xform_block_check.cpp compares it with
+// (and, through it, with the oracle), so it stays next to it.
 template <bool FIRST>
 __device__ __forceinline__ static void fdct1d(int &d0, int &d1, int &d2, int &d3, int &d4, int &d5, int &d6, int &d7) {
     int tmp0 = d0 + d7, tmp7 = d0 - d7, tmp1 = d1 + d6, tmp6 = d1 - d6, tmp2 = d2 + d5, tmp5 = d2 - d5, tmp3 = d3 + d4, tmp4 = d3 - d4;
