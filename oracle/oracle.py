@@ -45,6 +45,25 @@ class EncParams(C.Structure):
                 ("trellis", C.c_int), ("deringing", C.c_int)]
 
 
+class Vp8Mb(C.Structure):
+    _fields_ = [("segment", C.c_uint8), ("is_i4", C.c_uint8), ("ymode", C.c_uint8), ("uvmode", C.c_uint8), ("bmodes", C.c_uint8 * 16),
+                ("skip", C.c_uint8), ("alpha", C.c_uint8), ("pad", C.c_uint8 * 2), ("levels", (C.c_int16 * 16) * 25)]
+
+
+class Vp8Frame(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("mbw", C.c_int), ("mbh", C.c_int),
+                ("num_segments", C.c_int), ("update_map", C.c_int), ("seg_quant", C.c_int * 4), ("seg_filter", C.c_int * 4), ("seg_probs", C.c_int * 3),
+                ("filter_simple", C.c_int), ("filter_level", C.c_int), ("filter_sharpness", C.c_int),
+                ("num_parts_log2", C.c_int), ("base_quant", C.c_int), ("dq", C.c_int * 5), ("use_skip", C.c_int), ("skip_proba", C.c_int),
+                ("probas", C.c_uint8 * 1056), ("part0_size", C.c_size_t), ("vp8_size", C.c_size_t),
+                ("alpha_avg", C.c_int), ("uv_alpha_avg", C.c_int), ("seg_alpha", C.c_int * 4), ("seg_beta", C.c_int * 4), ("seg_max_edge", C.c_int * 4)]
+
+    def header(self):
+        return dict(size=(self.width, self.height), nseg=self.num_segments, update_map=self.update_map, quant=list(self.seg_quant), filt=list(self.seg_filter),
+                    seg_probs=list(self.seg_probs), filter=(self.filter_simple, self.filter_level, self.filter_sharpness), parts=self.num_parts_log2,
+                    base_quant=self.base_quant, dq=list(self.dq), skip=(self.use_skip, self.skip_proba))
+
+
 class Png(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("depth", C.c_int), ("ctype", C.c_int), ("interlace", C.c_int),
                 ("channels", C.c_int), ("bpp", C.c_int), ("nplte", C.c_int), ("rowbytes", C.c_size_t),
@@ -52,7 +71,7 @@ class Png(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h", "webp_oracle.c", "webp_oracle.h")] + [os.path.join(_HERE, "..", "include", f) for f in ("png_quality_table.h", "vp8_tables.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("jpeg_oracle.c", "jpeg_oracle.h", "png_oracle.c", "png_oracle.h", "webp_oracle.c", "webp_oracle.h", "vp8enc_oracle.c", "vp8enc_oracle.h")] + [os.path.join(_HERE, "..", "include", f) for f in ("png_quality_table.h", "vp8_tables.h", "vp8_cost_tables.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
@@ -106,6 +125,9 @@ def lib():
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_trials.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.cso_png_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.cso_vp8enc_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
+        L.cso_vp8enc_encode_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_vp8_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.cso_webp_rgb_to_yuv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cso_webp_quality_to_qi.argtypes = [C.c_int]
         L.cso_webp_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p]
@@ -422,6 +444,47 @@ def webp_encode_rgb(rgb, quality):
     data = C.string_at(out, n.value)
     lib().cso_free(out)
     return data
+
+
+# ---------------------------------------------------------------- libwebp's lossy encoder restated (vp8enc_oracle.c; pinned to libwebp itself)
+def _mbs_array(mbs, n):
+    a = np.frombuffer(mbs, dtype=np.dtype([("segment", "u1"), ("is_i4", "u1"), ("ymode", "u1"), ("uvmode", "u1"), ("bmodes", "u1", 16), ("skip", "u1"), ("alpha", "u1"), ("pad", "u1", 2), ("levels", "<i2", (25, 16))]), count=n)
+    return a.copy()
+
+
+def vp8enc_encode_yuv(y, u, v, width, height, quality, trace=False):
+    """-> bytes [, Vp8Frame, per-macroblock structured array] for padded planes (webp_rgb_to_yuv)"""
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    nmb = ((width + 15) // 16) * ((height + 15) // 16)
+    frame, mbs = Vp8Frame(), (Vp8Mb * nmb)()
+    rc = lib().cso_vp8enc_encode_yuv(y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, float(quality), C.byref(out), C.byref(n), C.byref(frame), C.byref(mbs))
+    if rc:
+        raise OracleError("vp8enc oracle: %d" % rc)
+    data = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return (data, frame, _mbs_array(mbs, nmb)) if trace else data
+
+
+def vp8enc_encode_rgb(rgb, quality, trace=False):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    y, u, v = webp_rgb_to_yuv(rgb)
+    return vp8enc_encode_yuv(y, u, v, w, h, quality, trace)
+
+
+def vp8_parse(data):
+    """-> Vp8Frame, per-macroblock structured array of any lossy WebP / VP8 key frame"""
+    frame = Vp8Frame()
+    cap = 1 << 20
+    w = h = 0
+    off = 20 if data[:4] == b"RIFF" else 0
+    w, h = int.from_bytes(data[off + 6:off + 8], "little") & 0x3fff, int.from_bytes(data[off + 8:off + 10], "little") & 0x3fff
+    cap = ((w + 15) // 16) * ((h + 15) // 16)
+    mbs = (Vp8Mb * cap)()
+    rc = lib().cso_vp8_parse(data, len(data), C.byref(frame), C.byref(mbs), cap)
+    if rc:
+        raise OracleError("vp8 parse: %d" % rc)
+    return frame, _mbs_array(mbs, cap)
 
 
 def webp_quality_to_qi(q):
