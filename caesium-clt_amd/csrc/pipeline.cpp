@@ -1457,7 +1457,7 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
         off[wi.image] = out_bytes;
         out_bytes += (wi.out_cap + 63) & ~uint64_t(63);
         const int q = int(b->params.webp_quality);
-        wi.qi = kVp8QualityToQi[q < 0 ? 0 : q > 100 ? 100 : q];   // libwebp's quality -> quantiser curve for one segment, no SNS (vp8_tables.h; oracle: cso_webp_quality_to_qi)
+        wi.quality = q < 0 ? 0 : q > 100 ? 100 : q;
     }
     off[b->nimg] = out_bytes;
     if (b->d_out.n < out_bytes + 64 && b->d_out.alloc(out_bytes + 64)) return -1;
@@ -1472,10 +1472,8 @@ static int run_webp(csh_batch *b, csh_timing *t, hipEvent_t *ev, int slot) {
     if (b->d_img_size.zero(st)) return -1;
     csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
     CSH_CHECK(hipEventRecord(ev[++slot], st));
-    { uint32_t mw = 0, mh = 0; for (const csw::WebpImg &wi : b->wimgs) { mw = std::max(mw, wi.mbw); mh = std::max(mh, wi.mbh); } csw::launch_webp_mb(st, b->d_wimgs.p, nimg, mw, mh, b->d_wwork.p, b->d_wlevels.p); }
-    CSH_CHECK(hipEventRecord(ev[++slot], st));
-    csw::launch_webp_code(st, b->d_wimgs.p, b->wimgs.data(), nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p,
-                          b->d_img_size.p, b->d_status.p);
+    const int mid = ++slot;
+    if (csw::launch_webp_encode(st, b->wimgs.data(), nimg, b->d_wimgs.p, b->d_wwork.p, b->d_wlevels.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_img_size.p, b->d_status.p, ev[mid])) return -1;
     CSH_CHECK(hipEventRecord(ev[++slot], st));
     CSH_CHECK(hipStreamSynchronize(st));
     CSH_CHECK(hipGetLastError());

@@ -690,21 +690,19 @@ static int run_to_webp(csp_batch *b) {
     const int nimg = int(b->wimgs.size());
     if (!nimg) return 0;
     launch_png_rgb(st, b->d_rgbjobs.p, nimg, b->rgb_max_h, b->d_plte.p, b->d_work.p, b->d_rgb.p, b->d_status.p);
-    const int q = b->webp_quality, qi = kVp8QualityToQi[q < 0 ? 0 : q > 100 ? 100 : q];   // libwebp's quality -> quantiser curve for one segment, no SNS (vp8_tables.h)
+    const int q = b->webp_quality, quality = q < 0 ? 0 : q > 100 ? 100 : q;
     b->h_wstatus.assign(size_t(nimg), 0);
     for (int attempt = 0; attempt < 4; attempt++) {
         uint64_t out_bytes = 0;
         for (auto &wi : b->wimgs) {
             const uint64_t cap = 4096 + uint64_t(wi.mbw) * wi.mbh * (b->webp_mb_bytes + 2);
-            wi.out_cap = uint32_t(std::min<uint64_t>(cap, 0xFFFFFF00u)); wi.out_off = out_bytes; wi.qi = qi;
+            wi.out_cap = uint32_t(std::min<uint64_t>(cap, 0xFFFFFF00u)); wi.out_off = out_bytes; wi.quality = quality;
             b->imgs[wi.image].out_off = out_bytes;
             out_bytes += (wi.out_cap + 63) & ~uint64_t(63);
         }
         if (b->d_out.alloc(out_bytes + 64) || b->d_wscratch.alloc(out_bytes + 64) || b->d_wimgs.upload(b->wimgs, st) || b->d_wstats.zero(st) || b->d_wstatus.zero(st) || b->d_file_len.zero(st)) return CS_ERR_NO_DEVICE;
         csw::launch_webp_yuv(st, b->d_wimgs.p, nimg, b->wmax_luma, b->d_rgb.p, b->d_wwork.p);
-        { uint32_t mw = 0, mh = 0; for (const csw::WebpImg &wi : b->wimgs) { mw = std::max(mw, wi.mbw); mh = std::max(mh, wi.mbh); } csw::launch_webp_mb(st, b->d_wimgs.p, nimg, mw, mh, b->d_wwork.p, b->d_wlevels.p); }
-        csw::launch_webp_code(st, b->d_wimgs.p, b->wimgs.data(), nimg, b->wmax_mbh, b->d_wlevels.p, b->d_wstats.p, b->d_wprobs.p, b->d_wupdate.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_file_len.p,
-                              b->d_wstatus.p);
+        if (csw::launch_webp_encode(st, b->wimgs.data(), nimg, b->d_wimgs.p, b->d_wwork.p, b->d_wlevels.p, b->d_wscratch.p, b->d_wpart.p, b->d_out.p, b->d_file_len.p, b->d_wstatus.p, nullptr)) return CS_ERR_NO_DEVICE;
         if (hipMemcpyAsync(b->h_wstatus.data(), b->d_wstatus.p, sizeof(uint32_t) * nimg, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
             hipGetLastError() != hipSuccess) { csh_set_error("WebP kernels failed"); return CS_ERR_NO_DEVICE; }
         bool pool = false;

@@ -1,7 +1,11 @@
-// webp_kernels.h -- the lossy WebP row on the device: descriptors and launchers (k_webp.hip).
-// Statement: oracle/webp_oracle.c (a minimal conformant VP8 key-frame encoder; see its header for what is and is not pinned).
+// webp_kernels.h -- the lossy WebP row on the device: descriptors and launchers (k_webp.hip: import and coder back end; k_vp8enc.hip:
+// libwebp's encoder).  Statement: oracle/vp8enc_oracle.c (pinned to libwebp's WebPEncode byte for byte) and oracle/webp_oracle.c (the import).
 #pragma once
+#include <vector>
+
 #include "gpu_rt.h"
+
+namespace csh { template <class T> struct DevBuf; }
 
 namespace csw {
 
@@ -9,7 +13,8 @@ enum { WEBP_MB_REC = 432 };   // int16 per macroblock in the level pool: 25 bloc
 
 struct WebpImg {
     uint32_t width, height, mbw, mbh, ncomp;   // ncomp: samples per input pixel: 3 = interleaved RGB, 1 = grey, 4 / 2 = the same with an alpha sample behind (skipped here)
-    int32_t qi;                                // quantiser index 0..127
+    int32_t quality;                           // libwebp's quality 0..100
+    uint32_t cls, qtab;                        // set by launch_webp_encode: the picture's size class (its plan of steps) and its quality table
     uint64_t rgb_off;                          // input pixels in the RGB pool
     uint64_t y_off, u_off, v_off;              // source planes, padded to whole macroblocks (work pool)
     uint64_t ry_off, ru_off, rv_off;           // the encoder's reconstruction (what a decoder will see)
@@ -20,12 +25,15 @@ struct WebpImg {
 };
 
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work);
-void launch_webp_mb(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_mbw, uint32_t max_mbh, uint8_t *work, int16_t *levels);   // one launch per skewed diagonal of macroblocks
-// stats: nimg x 1056 x 2 counters (zeroed by the caller); probs / update: nimg x 1056 bytes; scratch: a second region laid out like the
-// output pool (every partition is coded into its own slice of it); part_size: nimg x 9
-// himgs: the host's copy of imgs (the launcher lays the token partitions' decision streams out from the pictures' sizes).  Returns with the stream idle.
-void launch_webp_code(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs, int nimg, uint32_t max_mbh, const int16_t *levels, uint32_t *stats, uint8_t *probs, uint8_t *update,
-                      uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
+// the encoder behind the import: analysis, segments, the macroblock loop step by step, statistics, then the two partitions and the file.  himgs: the host's
+// pictures (cls / qtab are filled in here and the array copied over d_imgs, which the caller uploaded for launch_webp_yuv);
+// scratch: a second region laid out like the output pool; part_size: nimg x 2.  `mid` (optional) is recorded between the macroblock loop and the coder.
+// Returns with the stream idle; != 0 on an allocation / launch failure.
+int launch_webp_encode(hipStream_t st, WebpImg *himgs, int nimg, WebpImg *d_imgs, uint8_t *work, int16_t *levels, uint8_t *scratch, uint32_t *part_size, uint8_t *out,
+                       uint32_t *img_size, uint32_t *status, hipEvent_t mid);
+struct Vp8FrameDev;
+int launch_webp_backend(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs, int nimg, const int16_t *levels, const Vp8FrameDev *frames, const std::vector<uint64_t> &base,
+                        const uint64_t *d_base, csh::DevBuf<uint32_t> &d_cnt, const uint16_t *d_blk, uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status);
 
 enum { VP8L_ALPHA_OF = 16 };   // Vp8lImg::channels = VP8L_ALPHA_OF + 2 / + 4: code the alpha sample of a grey + alpha / RGBA picture as a grey picture
 // lossless WebP output (k_vp8l_enc.hip): one picture of 8-bit grey (channels 1), grey + alpha (2), RGB (3) or RGBA (4) pixels in device memory

@@ -532,11 +532,8 @@ int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp,
     *out = o; *out_len = total;
     return 0;
 }
+/* the row's encoder is libwebp's, restated in vp8enc_oracle.c (pinned to WebPEncode); this is the entry point the conversion oracles call */
+int cso_vp8enc_encode_rgb(const uint8_t *rgb, int width, int height, float quality, uint8_t **out, size_t *out_len);
 int cso_webp_encode_rgb(const uint8_t *rgb, int width, int height, int quality, uint8_t **out, size_t *out_len) {
-    const int mbw = (width + 15) >> 4, mbh = (height + 15) >> 4;
-    uint8_t *yp = (uint8_t *)malloc((size_t)mbw * mbh * 256), *up = (uint8_t *)malloc((size_t)mbw * mbh * 64), *vp = (uint8_t *)malloc((size_t)mbw * mbh * 64);
-    cso_webp_rgb_to_yuv(rgb, width, height, yp, up, vp);
-    int rc = cso_webp_encode_yuv(yp, up, vp, width, height, cso_webp_quality_to_qi(quality), out, out_len, NULL, NULL, NULL);
-    free(yp); free(up); free(vp);
-    return rc;
+    return cso_vp8enc_encode_rgb(rgb, width, height, (float)quality, out, out_len);
 }
