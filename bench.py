@@ -762,14 +762,14 @@ def other_configs(api, pkg, blobs, local):
     except Exception as e:   # a sub-record must not take the headline down
         other["configs[2] 4K PNG --lossless -o3"] = {"error": str(e)[:200]}
     try:
-        nweb = 1024   # the macroblock and boolean-coder kernels are one wave per (picture, partition): 256 files leave the chip half empty
+        nweb = 1024   # a step of the macroblock loop holds at most seven macroblocks of a picture: the batch is what fills the chip
         wb = api.webp_batch([blobs[k % len(blobs)] for k in range(nweb)], pkg.default_parameters(webp_quality=85, width=1500), device=local)
         wb.run()
         wtm = wb.run()
         wn = api.webp_kernel_names()
         wdom = max(range(len(wn)), key=lambda i: wtm.kernel_ms[i])
         # Lanczos R 6 220 800 / W 3 798 000 per file; the VP8 tail reads the 1500 x 844 YUV 4:2:0 (1 899 000 B) and writes levels + the file
-        per_file = {"resize": 6_220_800 + 3_798_000, "k_webp_yuv": 3_798_000 + 1_899_000, "k_webp_mb": 2 * 1_899_000, "k_webp_stats+probs+code+assemble": 1_899_000 + int(wtm.out_bytes) // nweb}
+        per_file = {"resize": 6_220_800 + 3_798_000, "k_webp_yuv": 3_798_000 + 1_899_000, "k_vp8_analyse+segments+mb+chunk": 2 * 1_899_000 + 4_304_448, "k_webp_hdr+decisions+bool+assemble": 4_304_448 + int(wtm.out_bytes) // nweb}   # 4 304 448 B: the level records of 4 982 macroblocks
         abw = per_file.get(wn[wdom], 1_899_000) * nweb
         rec = {"files": nweb, "value": round(nweb * MP_1080P / (wtm.total_ms / 1e3), 1), "unit": "source MP/s", "device_ms": round(wtm.total_ms, 1), "out_bytes": int(wtm.out_bytes),
                "dominant_kernel": wn[wdom], "dominant_ms": round(wtm.kernel_ms[wdom], 1),
@@ -788,7 +788,7 @@ def other_configs(api, pkg, blobs, local):
             oracle_jpeg_to_webp(blobs[i], 85, 1500, 0)
         cdt = time.perf_counter() - c0
         rec["cpu_baseline"] = {"value": round(2 * MP_1080P / cdt, 2), "unit": "source MP/s", "cores": 1, "kind": "port",
-                               "sample": f"2 of the same files through the oracle (libjpeg decode, Lanczos3, oracle/webp_oracle.c), 1 thread, {cdt:.1f} s"}
+                               "sample": f"2 of the same files through the oracle (libjpeg decode, Lanczos3, oracle/vp8enc_oracle.c = libwebp's encoder restated), 1 thread, {cdt:.1f} s"}
         other["configs[3] JPEG -> WebP q85 long edge 1500"] = rec
     except Exception as e:
         other["configs[3] JPEG -> WebP q85 long edge 1500"] = {"error": str(e)[:200]}

@@ -295,6 +295,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_analyse(const WebpImg 
         }
     }
     const LV<int> csum = halfsum(edge);
+    LV<int> usum, vsum;   // the U / V sums of the row, taken while every lane is active (a cross-lane read of an inactive lane returns 0)
+    LFOR(l) {
+#ifdef CSH_EMUL
+        usum[l] = csum.v[l & 48]; vsum[l] = csum.v[(l & 48) + 8];
+#else
+        usum[l] = __shfl(csum.v, l & 48, 64); vsum[l] = __shfl(csum.v, (l & 48) + 8, 64);
+#endif
+    }
     LFOR(l) {
         const int g = l >> 4, n = int(blockIdx.x) * 4 + g, i = l & 15;
         if (n < nmb) {
@@ -310,16 +318,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_analyse(const WebpImg 
                 CSH_UNROLL
                 for (int k = 0; k < 4; k++) { top[k] = ht ? int(mb[bx * 4 + k - stride]) : 127; left[k] = hl ? int(mb[size_t(by * 4 + k) * stride - 1]) : 129; }
                 const int tl = (hl && ht) ? int(mb[-stride - 1]) : 0;
-                // the chroma DC of the V plane: lanes 4..7 sit in the second half-row only when i >= 8; the sums were taken per half-row (U lanes 0..7, V lanes 8..15)
-                int dcv;
-                if (!pass) dcv = dc_value(ysum[l], hl, ht, 16);
-                else {
-#ifdef CSH_EMUL
-                    dcv = dc_value(csum.v[(l & 48) + (i < 4 ? 0 : 8)], hl, ht, 8);
-#else
-                    dcv = dc_value(__shfl(csum.v, (l & 48) + (i < 4 ? 0 : 8), 64), hl, ht, 8);
-#endif
-                }
+                const int dcv = !pass ? dc_value(ysum[l], hl, ht, 16) : dc_value(i < 4 ? usum[l] : vsum[l], hl, ht, 8);
                 for (int mode = 0; mode < 2; mode++) {
                     int pred[16], d[16], c[16];
                     pred_block(mode, top, left, tl, dcv, hl, ht, pred);
@@ -564,6 +563,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
         }
     }
     const LV<int> ydc_sum = rowsum(t1), cdc_sum = halfsum(t2);   // cdc_sum: lanes 0..7 the U sum, 8..15 the V sum
+    LV<int> usum, vsum;
+    LFOR(l) {
+#ifdef CSH_EMUL
+        usum[l] = cdc_sum.v[l & 48]; vsum[l] = cdc_sum.v[(l & 48) + 8];
+#else
+        usum[l] = __shfl(cdc_sum.v, l & 48, 64); vsum[l] = __shfl(cdc_sum.v, (l & 48) + 8, 64);
+#endif
+    }
 
     // =========================================================================================== i16: four modes, lane = luma block
     LVA<int, 16> coef, best_lv, best_rec, best_lv2;
@@ -779,11 +786,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 int top[4], left[4], d[16];
                 CSH_UNROLL
                 for (int k = 0; k < 4; k++) { top[k] = s[g].ce[pl][bx * 4 + k]; left[k] = s[g].ce[pl][8 + by * 4 + k]; }
-#ifdef CSH_EMUL
-                const int csum = cdc_sum.v[(l & 48) + pl * 8];
-#else
-                const int csum = __shfl(cdc_sum.v, (l & 48) + pl * 8, 64);
-#endif
+                const int csum = pl ? vsum[l] : usum[l];
                 pred_block(mode, top, left, s[g].ce[pl][16], dc_value(csum, hl, ht, 8), hl, ht, pred[l]);
                 CSH_UNROLL
                 for (int k = 0; k < 16; k++) { src[l][k] = cs8[(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)]; d[k] = src[l][k] - pred[l][k]; }
@@ -1021,15 +1024,15 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *i
             for (int i = l; i < VP8_NSLOT; i += 64) {
                 const uint32_t cn = s_cnt[i];
                 if (!cn) continue;
-                const uint32_t p = F->stats[i];
-                if ((p >> 16) + cn <= 0xfffeu) F->stats[i] = p + (cn << 16) + s_ones[i];
+                const uint32_t p = coherent_load(&F->stats[i]);
+                if ((p >> 16) + cn <= 0xfffeu) coherent_store(&F->stats[i], p + (cn << 16) + s_ones[i]);
                 else s_list[atomicAdd(&s_nlist, 1u) & 63u] = uint32_t(i);
             }
         CSP_WAVE_SYNC();
         const uint32_t nlist = uni(s_nlist);
         for (uint32_t q = 0; q < nlist && q < 64; q++) {   // (more than 64 slots overflowing inside one group of 64 macroblocks cannot happen: 64 x 400 events in all)
             const int slot = int(uni(s_list[q]));
-            const uint32_t p = F->stats[slot], k = 0xfffeu - (p >> 16);   // the halving comes after k more events
+            const uint32_t p = coherent_load(&F->stats[slot]), k = 0xfffeu - (p >> 16);   // the halving comes after k more events
             LV<uint32_t> tl, ol;
             LFOR(l) {
                 tl[l] = 0; ol[l] = 0;
@@ -1059,7 +1062,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *i
             (void)lscan(part, before);
             LFOR(l) if (l == 0) {
                 const uint32_t nk = (p & 0xffffu) + before, halved = ((nk + 1u) >> 1) & 0x7fffu;
-                F->stats[slot] = ((0x7fffu + (tsum - k)) << 16) | (halved + (osum - before));
+                coherent_store(&F->stats[slot], ((0x7fffu + (tsum - k)) << 16) | (halved + (osum - before)));
             }
         }
         CSP_WAVE_SYNC();
@@ -1069,7 +1072,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *i
     LFOR(l) {
         chg[l] = 0;
         for (int i = l; i < VP8_NSLOT; i += 64) {
-            const uint32_t st = F->stats[i];
+            const uint32_t st = coherent_load(&F->stats[i]);
             const int nb = int(st & 0xffffu), total = int(st >> 16), up = kVp8CoefUpdateProbs[i], oldp = kVp8CoefProbs[i];
             const int newp = nb ? 255 - nb * 255 / total : 255;
             const int old_cost = nb * vp8_bitcost(1, oldp) + (total - nb) * vp8_bitcost(0, oldp) + vp8_bitcost(0, up);

@@ -129,8 +129,6 @@ def lib():
         L.cso_vp8enc_encode_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_vp8_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.cso_webp_rgb_to_yuv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.cso_webp_quality_to_qi.argtypes = [C.c_int]
-        L.cso_webp_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p, C.c_void_p]
         L.cso_webp_encode_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_vp8l_encode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         _lib = L
@@ -412,7 +410,7 @@ def png_optimize(data, level=3, keep_metadata=False):
     return res, chosen.value
 
 
-# ---------------------------------------------------------------- lossy WebP row (webp_oracle.c; a minimal VP8 encoder, parity unpinned)
+# ---------------------------------------------------------------- lossy WebP row (webp_oracle.c: libwebp's import; the encoder is vp8enc_oracle.c below)
 def webp_rgb_to_yuv(rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     h, w, _ = rgb.shape
@@ -420,18 +418,6 @@ def webp_rgb_to_yuv(rgb):
     y = np.empty((mbh * 16, mbw * 16), np.uint8); u = np.empty((mbh * 8, mbw * 8), np.uint8); v = np.empty_like(u)
     lib().cso_webp_rgb_to_yuv(rgb.ctypes.data, w, h, y.ctypes.data, u.ctypes.data, v.ctypes.data)
     return y, u, v
-
-
-def webp_encode_yuv(y, u, v, width, height, qi):
-    """-> (file bytes, the encoder's own reconstruction (y, u, v))"""
-    ry, ru, rv = np.zeros_like(y), np.zeros_like(u), np.zeros_like(v)
-    out = C.POINTER(C.c_uint8)(); n = C.c_size_t()
-    rc = lib().cso_webp_encode_yuv(y.ctypes.data, u.ctypes.data, v.ctypes.data, width, height, qi, C.byref(out), C.byref(n), ry.ctypes.data, ru.ctypes.data, rv.ctypes.data)
-    if rc:
-        raise OracleError("webp oracle: %d" % rc)
-    data = C.string_at(out, n.value)
-    lib().cso_free(out)
-    return data, (ry, ru, rv)
 
 
 def webp_encode_rgb(rgb, quality):
@@ -485,10 +471,6 @@ def vp8_parse(data):
     if rc:
         raise OracleError("vp8 parse: %d" % rc)
     return frame, _mbs_array(mbs, cap)
-
-
-def webp_quality_to_qi(q):
-    return lib().cso_webp_quality_to_qi(q)
 
 
 def png_to_webp(data, quality):

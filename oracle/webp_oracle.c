@@ -1,23 +1,12 @@
 /*
- * webp_oracle.c -- CPU ORACLE of the lossy WebP row: RGB -> YUV 4:2:0 -> VP8 key frame -> RIFF.
+ * webp_oracle.c -- CPU ORACLE of the lossy WebP row's import: RGB -> YUV 4:2:0 as libwebp does it.
  *
  * TEST INFRASTRUCTURE ONLY (tests/, tools/): nothing under caesium-clt_amd/ links or calls this.
  *
- * PARITY UNPINNED, AND THE ENCODER IS NOT libwebp's.  The reference reaches this path through
- * `caesium::convert_in_memory(.., SupportedFileTypes::WebP)` (/root/reference/src/compressor.rs:289, :300), i.e. libwebp
- * (libwebp-sys 0.9.5, Cargo.lock:956) at its default method 4: analysis, segments, intra-mode RD search (i16 / i4 / uv),
- * trellis, loop-filter strength search.  None of that source is available.  This file is a conformant VP8 encoder laid out
- * for the GPU: a macroblock is coded i16x16 (DC / V / H / TM by least transformed residual) when that leaves no luma AC level, and
- * i4x4 otherwise (sixteen sub-blocks, ten modes each, chosen by transformed residual + the mode's cost in the key-frame mode
- * tree); one chroma mode chosen like the i16 one, one quantiser index, no segments, no trellis, no loop filter, coefficient
- * probabilities chosen from the frame's own token counts, up to eight token partitions (rows interleaved).  What is pinned:
- *   - the bitstream is valid: libwebp (through Pillow) decodes every output;
- *   - the decoder-side arithmetic (dequantisation, inverse WHT / DCT, the 16x16 / 8x8 / 4x4 predictors with the decoder's
- *     frame-edge rules, RFC 6386) is restated exactly, which the tests check by comparing this file's own reconstruction with
- *     libwebp's decoded YUV -> the encoder and any decoder stay in step;
- *   - quality: PSNR against the source is asserted in the tests; bytes at equal PSNR are 0.91-1.02 x libwebp's on the 1500 px
- *     set (tools/webp_rd_eval.py) -- measured, not pinned.
- * The device path (k_webp.hip) must equal this file byte for byte.
+ * The reference reaches this path through `caesium::convert_in_memory(.., SupportedFileTypes::WebP)` and the WebP recompression
+ * (/root/reference/src/compressor.rs:289, :300, :417, :429), i.e. libwebp (libwebp-sys 0.9.5, Cargo.lock:956).  The import is PINNED bit for bit
+ * against WebPPictureImportRGB of the libwebp in this container (tests/test_oracle_webp.py); the encoder behind it (W2, W3) is vp8enc_oracle.c,
+ * pinned byte for byte against WebPEncode.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -59,479 +48,6 @@ void cso_webp_rgb_to_yuv(const uint8_t *rgb, int w, int h, uint8_t *yp, uint8_t 
         }
 }
 
-/* ------------------------------------------------------------------------------------------------ transforms */
-/* forward 4x4 DCT of (src - pred), libwebp's integer form; forward transforms are the encoder's choice */
-static void fdct4(const uint8_t *src, int sstride, const uint8_t *ref, int rstride, int16_t *out) {
-    int tmp[16];
-    for (int i = 0; i < 4; i++, src += sstride, ref += rstride) {
-        int d0 = src[0] - ref[0], d1 = src[1] - ref[1], d2 = src[2] - ref[2], d3 = src[3] - ref[3];
-        int a0 = d0 + d3, a1 = d1 + d2, a2 = d1 - d2, a3 = d0 - d3;
-        tmp[0 + i * 4] = (a0 + a1) * 8;
-        tmp[1 + i * 4] = (a2 * 2217 + a3 * 5352 + 1812) >> 9;
-        tmp[2 + i * 4] = (a0 - a1) * 8;
-        tmp[3 + i * 4] = (a3 * 2217 - a2 * 5352 + 937) >> 9;
-    }
-    for (int i = 0; i < 4; i++) {
-        int a0 = tmp[0 + i] + tmp[12 + i], a1 = tmp[4 + i] + tmp[8 + i], a2 = tmp[4 + i] - tmp[8 + i], a3 = tmp[0 + i] - tmp[12 + i];
-        out[0 + i] = (int16_t)((a0 + a1 + 7) >> 4);
-        out[4 + i] = (int16_t)(((a2 * 2217 + a3 * 5352 + 12000) >> 16) + (a3 != 0));
-        out[8 + i] = (int16_t)((a0 - a1 + 7) >> 4);
-        out[12 + i] = (int16_t)((a3 * 2217 - a2 * 5352 + 51000) >> 16);
-    }
-}
-static void fwht(const int16_t *dc16, int16_t *out) {   /* the 16 luma DCs (raster order of the 4x4 blocks) */
-    int tmp[16];
-    for (int i = 0; i < 4; i++) {
-        int a0 = dc16[i * 4 + 0] + dc16[i * 4 + 2], a1 = dc16[i * 4 + 1] + dc16[i * 4 + 3], a2 = dc16[i * 4 + 1] - dc16[i * 4 + 3], a3 = dc16[i * 4 + 0] - dc16[i * 4 + 2];
-        tmp[0 + i * 4] = a0 + a1; tmp[1 + i * 4] = a3 + a2; tmp[2 + i * 4] = a3 - a2; tmp[3 + i * 4] = a0 - a1;
-    }
-    for (int i = 0; i < 4; i++) {
-        int a0 = tmp[0 + i] + tmp[8 + i], a1 = tmp[4 + i] + tmp[12 + i], a2 = tmp[4 + i] - tmp[12 + i], a3 = tmp[0 + i] - tmp[8 + i];
-        out[0 + i] = (int16_t)((a0 + a1) >> 1); out[4 + i] = (int16_t)((a3 + a2) >> 1); out[8 + i] = (int16_t)((a3 - a2) >> 1); out[12 + i] = (int16_t)((a0 - a1) >> 1);
-    }
-}
-/* inverse transforms: RFC 6386 section 14.3 / 14.4, what every decoder does */
-static void iwht(const int16_t *in, int16_t *dc16) {
-    int tmp[16];
-    for (int i = 0; i < 4; i++) {
-        int a0 = in[0 + i] + in[12 + i], a1 = in[4 + i] + in[8 + i], a2 = in[4 + i] - in[8 + i], a3 = in[0 + i] - in[12 + i];
-        tmp[0 + i] = a0 + a1; tmp[8 + i] = a0 - a1; tmp[4 + i] = a3 + a2; tmp[12 + i] = a3 - a2;
-    }
-    for (int i = 0; i < 4; i++) {
-        int dc = tmp[0 + i * 4] + 3, a0 = dc + tmp[3 + i * 4], a1 = tmp[1 + i * 4] + tmp[2 + i * 4], a2 = tmp[1 + i * 4] - tmp[2 + i * 4], a3 = dc - tmp[3 + i * 4];
-        dc16[i * 4 + 0] = (int16_t)((a0 + a1) >> 3); dc16[i * 4 + 1] = (int16_t)((a3 + a2) >> 3); dc16[i * 4 + 2] = (int16_t)((a0 - a1) >> 3); dc16[i * 4 + 3] = (int16_t)((a3 - a2) >> 3);
-    }
-}
-#define MUL1(a) ((((a) * 20091) >> 16) + (a))
-#define MUL2(a) (((a) * 35468) >> 16)
-static void idct4_add(const int16_t *in, const uint8_t *pred, int pstride, uint8_t *dst, int dstride) {
-    int tmp[16];
-    for (int i = 0; i < 4; i++) {   /* vertical pass */
-        int a = in[0 + i] + in[8 + i], b = in[0 + i] - in[8 + i];
-        int c = MUL2(in[4 + i]) - MUL1(in[12 + i]), d = MUL1(in[4 + i]) + MUL2(in[12 + i]);
-        tmp[0 + i * 4] = a + d; tmp[1 + i * 4] = b + c; tmp[2 + i * 4] = b - c; tmp[3 + i * 4] = a - d;
-    }
-    for (int i = 0; i < 4; i++) {   /* horizontal pass: output row i... the transposed walk of libwebp's TransformOne */
-        int dc = tmp[0 + i] + 4, a = dc + tmp[8 + i], b = dc - tmp[8 + i];
-        int c = MUL2(tmp[4 + i]) - MUL1(tmp[12 + i]), d = MUL1(tmp[4 + i]) + MUL2(tmp[12 + i]);
-        dst[i * dstride + 0] = (uint8_t)clip8(pred[i * pstride + 0] + ((a + d) >> 3));
-        dst[i * dstride + 1] = (uint8_t)clip8(pred[i * pstride + 1] + ((b + c) >> 3));
-        dst[i * dstride + 2] = (uint8_t)clip8(pred[i * pstride + 2] + ((b - c) >> 3));
-        dst[i * dstride + 3] = (uint8_t)clip8(pred[i * pstride + 3] + ((a - d) >> 3));
-    }
-}
-
-/* ------------------------------------------------------------------------------------------------ boolean entropy coder
- * RFC 6386 section 7 arithmetic in the carry-deferring form (a run counter for 0xFF bytes instead of walking back over the
- * output), so that a writer never reads what it wrote except the one byte in front of it. */
-typedef struct { uint8_t *buf; size_t pos, cap; int32_t range, value; int run, nb_bits; } boolenc;
-static void be_init(boolenc *e) { e->buf = NULL; e->pos = 0; e->cap = 0; e->range = 255 - 1; e->value = 0; e->run = 0; e->nb_bits = -8; }
-static void be_room(boolenc *e, size_t n) { if (e->pos + n > e->cap) { e->cap = (e->pos + n) * 2 + 256; e->buf = (uint8_t *)realloc(e->buf, e->cap); } }
-static void be_flush_bits(boolenc *e) {
-    const int s = 8 + e->nb_bits;
-    const int32_t bits = e->value >> s;
-    e->value -= bits << s;
-    e->nb_bits -= 8;
-    if ((bits & 0xff) != 0xff) {
-        be_room(e, (size_t)e->run + 1);
-        if ((bits & 0x100) && e->pos > 0) e->buf[e->pos - 1]++;   /* the carry; the byte in front is never 0xff */
-        if (e->run > 0) { const uint8_t v = (bits & 0x100) ? 0x00 : 0xff; for (; e->run > 0; --e->run) e->buf[e->pos++] = v; }
-        e->buf[e->pos++] = (uint8_t)(bits & 0xff);
-    } else
-        e->run++;
-}
-static void be_put(boolenc *e, int bit, int prob) {
-    const int32_t split = (e->range * prob) >> 8;
-    if (bit) { e->value += split + 1; e->range -= split + 1; } else e->range = split;
-    if (e->range < 127) {
-        const int shift = __builtin_clz((unsigned)(e->range + 1)) - 24;   /* (range + 1) << shift lands in [128, 255] */
-        e->range = ((e->range + 1) << shift) - 1;
-        e->value <<= shift;
-        e->nb_bits += shift;
-        if (e->nb_bits > 0) be_flush_bits(e);
-    }
-}
-static void be_bits(boolenc *e, uint32_t v, int n) { while (n--) be_put(e, (v >> n) & 1, 128); }
-static void be_flush(boolenc *e) {
-    be_bits(e, 0, 9 - e->nb_bits);
-    e->nb_bits = 0;
-    be_flush_bits(e);
-}
-
-/* ------------------------------------------------------------------------------------------------ tokens (RFC 6386 section 13) */
-/* one block: coefficient levels in scan order, first = 1 for i16 luma blocks (their DC travels in the Y2 block).  The walk
-   either codes (e != NULL, with the frame's probabilities) or only counts what it would code (stats[2 * index + bit]), which is
-   how the frame's probabilities are chosen. */
-typedef struct { boolenc *e; const uint8_t *probs; uint32_t *stats; } tsink;
-static void ad(tsink *s, int bit, int idx) { if (s->stats) s->stats[2 * idx + (bit ? 1 : 0)]++; else be_put(s->e, bit, s->probs[idx]); }
-static void fx(tsink *s, int bit, int prob) { if (!s->stats) be_put(s->e, bit, prob); }
-static int put_coeffs(tsink *e, int type, int ctx, const int16_t *lv, int first) {
-    int last = -1;
-    for (int i = first; i < 16; i++) if (lv[i]) last = i;
-    int n = first;
-    int p = ((type * 8 + kVp8Bands[n]) * 3 + ctx) * 11;
-    if (last < 0) { ad(e, 0, p + 0); return 0; }
-    ad(e, 1, p + 0);
-    while (n < 16) {
-        const int c = lv[n++];
-        const int sign = c < 0;
-        int v = sign ? -c : c;
-        if (!v) { ad(e, 0, p + 1); p = ((type * 8 + kVp8Bands[n]) * 3 + 0) * 11; continue; }
-        ad(e, 1, p + 1);
-        if (v == 1) { ad(e, 0, p + 2); p = ((type * 8 + kVp8Bands[n]) * 3 + 1) * 11; }
-        else {
-            ad(e, 1, p + 2);
-            if (v <= 4) { ad(e, 0, p + 3); if (v == 2) ad(e, 0, p + 4); else { ad(e, 1, p + 4); ad(e, v == 4, p + 5); } }
-            else if (v <= 10) {
-                ad(e, 1, p + 3); ad(e, 0, p + 6);
-                if (v <= 6) { ad(e, 0, p + 7); fx(e, v == 6, 159); }
-                else { ad(e, 1, p + 7); fx(e, v >= 9, 165); fx(e, !(v & 1), 145); }
-            } else {
-                int mask; const uint8_t *tab;
-                ad(e, 1, p + 3); ad(e, 1, p + 6);
-                if (v < 3 + (8 << 1)) { ad(e, 0, p + 8); ad(e, 0, p + 9); v -= 3 + (8 << 0); mask = 1 << 2; tab = kVp8Cat3; }
-                else if (v < 3 + (8 << 2)) { ad(e, 0, p + 8); ad(e, 1, p + 9); v -= 3 + (8 << 1); mask = 1 << 3; tab = kVp8Cat4; }
-                else if (v < 3 + (8 << 3)) { ad(e, 1, p + 8); ad(e, 0, p + 10); v -= 3 + (8 << 2); mask = 1 << 4; tab = kVp8Cat5; }
-                else { ad(e, 1, p + 8); ad(e, 1, p + 10); v -= 3 + (8 << 3); mask = 1 << 10; tab = kVp8Cat6; }
-                while (mask) { fx(e, !!(v & mask), *tab++); mask >>= 1; }
-            }
-            p = ((type * 8 + kVp8Bands[n]) * 3 + 2) * 11;
-        }
-        fx(e, sign, 128);
-        if (n == 16) return 1;
-        if (n > last) { ad(e, 0, p + 0); return 1; }
-        ad(e, 1, p + 0);
-    }
-    return 1;
-}
-/* cost of a boolean with probability p / 256 in 1/256 bit: 256 * (8 - log2 p), log2 by its integer part and a linear
-   fraction -- integers only, so that every build decides alike */
-static uint32_t bool_cost(int p) {
-    int l = 31 - __builtin_clz((unsigned)p);
-    return (uint32_t)(256 * (8 - l) - ((((unsigned)p << 8) >> l) - 256));
-}
-/* the frame's coefficient probabilities: for each of the 1056 entries the probability the counts ask for, taken when coding
-   with it (plus the 8 bits and the flag that announce it) is cheaper than keeping the default */
-static void choose_probs(const uint32_t *stats, uint8_t *probs, uint8_t *update) {
-    for (int i = 0; i < 4 * 8 * 3 * 11; i++) {
-        const uint64_t n0 = stats[2 * i], n1 = stats[2 * i + 1], total = n0 + n1;
-        const int oldp = kVp8CoefProbs[i], up = kVp8CoefUpdateProbs[i];
-        int np = total ? (int)(255 - n1 * 255 / total) : 255;
-        if (np < 1) np = 1;
-        const uint64_t old_cost = n0 * bool_cost(oldp) + n1 * bool_cost(256 - oldp) + bool_cost(up);
-        const uint64_t new_cost = n0 * bool_cost(np) + n1 * bool_cost(256 - np) + bool_cost(256 - up) + 8 * 256;
-        update[i] = (uint8_t)(new_cost < old_cost);
-        probs[i] = (uint8_t)(update[i] ? np : oldp);
-    }
-}
-
-/* ------------------------------------------------------------------------------------------------ the frame */
-/* quality 0..100 -> quantiser index 0..127: libwebp's curve for one segment without SNS modulation (vp8_tables.h; pinned to streams libwebp made) */
-int cso_webp_quality_to_qi(int quality) { return kVp8QualityToQi[quality < 0 ? 0 : quality > 100 ? 100 : quality]; }
-/* scalar quantiser with libwebp's rounding offsets (bias / 256 of a step instead of one half: luma AC 110, Y2 DC 96 / AC 108,
-   chroma DC 110 / AC 115 -- its kBiasMatrices), levels capped at 2047 */
-static int quant(int c, int q, int bias) { int a = c < 0 ? -c : c; a = (a + ((q * bias) >> 8)) / q; if (a > 2047) a = 2047; return c < 0 ? -a : a; }
-
-enum { MODE_REC = 18 };   /* per macroblock: luma mode (0 DC, 1 V, 2 H, 3 TM; 4 = i4x4), chroma mode, the sixteen sub-block modes */
-/* every macroblock's blocks in coding order; row r goes to sink[r mod nsinks] (one = a single sink for all rows) */
-static void token_walk(tsink *one, tsink *sinks, int nsinks, const int16_t *levels, const uint8_t *modes, int mbw, int mbh) {
-    uint8_t *top = (uint8_t *)calloc((size_t)mbw * 9, 1);   /* per column: 4 luma, 2 U, 2 V, Y2 */
-    for (int my = 0; my < mbh; my++) {
-        uint8_t left[9]; memset(left, 0, 9);
-        tsink *e = one ? one : &sinks[my & (nsinks - 1)];
-        for (int mx = 0; mx < mbw; mx++) {
-            const int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
-            uint8_t *tp = top + (size_t)mx * 9;
-            const int i4 = modes[((size_t)my * mbw + mx) * MODE_REC] == 4;
-            /* an i4x4 macroblock has no Y2 block (its luma blocks are of type 3 and carry their own DC); the Y2 context flags pass through it untouched */
-            if (!i4) tp[8] = left[8] = (uint8_t)put_coeffs(e, 1, tp[8] + left[8], L, 0);
-            for (int by = 0; by < 4; by++)
-                for (int bx = 0; bx < 4; bx++) tp[bx] = left[by] = (uint8_t)put_coeffs(e, i4 ? 3 : 0, tp[bx] + left[by], L + (1 + by * 4 + bx) * 16, i4 ? 0 : 1);
-            for (int pl = 0; pl < 2; pl++)
-                for (int by = 0; by < 2; by++)
-                    for (int bx = 0; bx < 2; bx++)
-                        tp[4 + pl * 2 + bx] = left[4 + pl * 2 + by] = (uint8_t)put_coeffs(e, 2, tp[4 + pl * 2 + bx] + left[4 + pl * 2 + by], L + (17 + pl * 4 + by * 2 + bx) * 16, 0);
-        }
-    }
-    free(top);
-}
-
-/* One N x N intra prediction (N = 16 luma, 8 chroma) from the reconstruction around it (RFC 6386 section 12.2).  Modes: 0 DC,
-   1 V (the row above), 2 H (the column to the left), 3 TM (above + left - corner, clipped).  Returns the chosen mode and its
-   prediction in pred (stride N); for chroma the two planes share one mode and pred holds U then V (64 samples each). */
-static void fill_pred(int mode, const uint8_t *r, int rs, int N, int mx, int my, uint8_t *pred) {
-    if (mode == 0) {
-        int dc = 128;
-        if (mx || my) {
-            int sum = 0, n = 0;
-            if (my) { for (int i = 0; i < N; i++) sum += r[i - rs]; n += N; }
-            if (mx) { for (int i = 0; i < N; i++) sum += r[i * rs - 1]; n += N; }
-            dc = n == 2 * N ? (sum + N) / (2 * N) : (sum + N / 2) / N;
-        }
-        memset(pred, dc, (size_t)N * N);
-        return;
-    }
-    for (int y = 0; y < N; y++)
-        for (int x = 0; x < N; x++)
-            pred[y * N + x] = (uint8_t)(mode == 1 ? r[x - rs] : mode == 2 ? r[y * rs - 1] : clip8(r[x - rs] + r[y * rs - 1] - r[-rs - 1]));
-}
-static int predict(const uint8_t *r, int rs, int N, const uint8_t *s, int ss, int mx, int my, const uint8_t *r2, const uint8_t *s2, int two, uint8_t *pred, int pstride) {
-    (void)pstride;
-    int best = 0;
-    uint64_t best_err = ~0ull;
-    const int nmodes = (mx && my) ? 4 : 1;
-    uint8_t tmp[2][256];
-    for (int m = 0; m < nmodes; m++) {
-        uint64_t err = 0;
-        for (int pl = 0; pl <= two; pl++) {
-            fill_pred(m, pl ? r2 : r, rs, N, mx, my, tmp[pl]);
-            const uint8_t *src = pl ? s2 : s;
-            /* cost of a mode: the sum of the magnitudes of the transformed residual (what the entropy coder will have to
-               spend bits on), not the squared error -- on noisy texture the flat DC prediction is the cheaper one */
-            for (int by = 0; by < N / 4; by++)
-                for (int bx = 0; bx < N / 4; bx++) {
-                    int16_t c[16];
-                    fdct4(src + by * 4 * ss + bx * 4, ss, tmp[pl] + by * 4 * N + bx * 4, N, c);
-                    for (int k = 0; k < 16; k++) err += (uint64_t)(c[k] < 0 ? -c[k] : c[k]);
-                }
-        }
-        if (err < best_err) { best_err = err; best = m; }
-    }
-    for (int pl = 0; pl <= two; pl++) fill_pred(best, pl ? r2 : r, rs, N, mx, my, pred + pl * N * N);
-    return best;
-}
-
-/* ---- i4x4: the ten sub-block predictors from the thirteen edge samples e[] = L K J I X A B C D E F G H (vp8_tables.h) */
-static void pred4(int mode, const uint8_t *e, uint8_t *out) {
-    if (mode == 0) { const int v = (e[5] + e[6] + e[7] + e[8] + e[3] + e[2] + e[1] + e[0] + 4) >> 3; memset(out, v, 16); return; }
-    for (int k = 0; k < 16; k++) {
-        if (mode == 1) out[k] = (uint8_t)clip8(e[3 - (k >> 2)] + e[5 + (k & 3)] - e[4]);
-        else { const unsigned t = kVp8Pred4Taps[(mode - 2) * 16 + k]; out[k] = (uint8_t)((e[t & 15] + e[(t >> 4) & 15] + e[(t >> 8) & 15] + e[t >> 12] + 2) >> 2); }
-    }
-}
-/* cost (1/256 bit) of coding sub-block mode m after the modes above and to the left (the fixed key-frame tree, RFC 6386 11.2) */
-static void bmode_path(int m, int *node, int *bit, int *n) {
-    static const signed char path[10][4][2] = {   /* (node, bit) steps of the tree, -1 ends */
-        {{0, 0}, {-1, 0}, {-1, 0}, {-1, 0}}, {{0, 1}, {1, 0}, {-1, 0}, {-1, 0}}, {{0, 1}, {1, 1}, {2, 0}, {-1, 0}},
-        {{3, 0}, {4, 0}, {-1, 0}, {-1, 0}}, {{3, 0}, {4, 1}, {5, 0}, {-1, 0}}, {{3, 0}, {4, 1}, {5, 1}, {-1, 0}},
-        {{3, 1}, {6, 0}, {-1, 0}, {-1, 0}}, {{3, 1}, {6, 1}, {7, 0}, {-1, 0}}, {{3, 1}, {6, 1}, {7, 1}, {8, 0}}, {{3, 1}, {6, 1}, {7, 1}, {8, 1}}};
-    *n = 0;
-    if (m >= 3) { node[0] = 0; bit[0] = 1; node[1] = 1; bit[1] = 1; node[2] = 2; bit[2] = 1; *n = 3; }   /* modes 3..9 sit behind three 1-branches */
-    for (int k = 0; k < 4 && path[m][k][0] >= 0; k++) { node[*n] = path[m][k][0]; bit[*n] = path[m][k][1]; (*n)++; }
-}
-static uint32_t bmode_cost(int m, int top, int left) {
-    const uint8_t *pr = kVp8BModeProbs + (top * 10 + left) * 9;
-    int node[8], bit[8], n;
-    uint32_t c = 0;
-    bmode_path(m, node, bit, &n);
-    for (int k = 0; k < n; k++) c += bool_cost(bit[k] ? 256 - pr[node[k]] : pr[node[k]]);
-    return c;
-}
-/* for the tests: the formula above against the table the device reads (vp8_tables.h) */
-int cso_webp_bmode_cost(int m, int top, int left, int from_table) { return from_table ? kVp8BModeCost[(top * 10 + left) * 10 + m] : (int)bmode_cost(m, top, left); }
-static void put_bmode(boolenc *e, int m, int top, int left) {
-    const uint8_t *pr = kVp8BModeProbs + (top * 10 + left) * 9;
-    int node[8], bit[8], n;
-    bmode_path(m, node, bit, &n);
-    for (int k = 0; k < n; k++) be_put(e, bit[k], pr[node[k]]);
-}
-static const uint8_t kI16AsBMode[4] = {0, 2, 3, 1};   /* what an i16 macroblock (DC, V, H, TM) counts as in its neighbours' sub-block mode contexts */
-/* the sub-block mode choice weighs the transformed residual against the mode's cost: BM_SATD * sum|DCT| + (BM_LAMBDA * q * cost in 1/256 bit) >> BM_SHIFT,
-   q = the luma AC step (weights found on the 1500 px set; tools/webp_rd_eval.py) */
-enum { BM_SATD = 16, BM_LAMBDA = 4, BM_SHIFT = 8 };
-
-/* levels: per macroblock 25 blocks x 16 (Y2, 16 luma, 4 U, 4 V), scan order.  recon planes come back for the tests. */
-int cso_webp_encode_yuv(const uint8_t *yp, const uint8_t *up, const uint8_t *vp, int width, int height, int qi, uint8_t **out, size_t *out_len,
-                        uint8_t *ry, uint8_t *ru, uint8_t *rv) {
-    const int mbw = (width + 15) >> 4, mbh = (height + 15) >> 4, ys = mbw * 16, cs = mbw * 8;
-    if (width < 1 || height < 1 || width > 16383 || height > 16383) return -1;
-    const int y1dc = kVp8DcQ[qi], y1ac = kVp8AcQ[qi], y2dc = kVp8DcQ[qi] * 2;
-    int y2ac = kVp8AcQ[qi] * 155 / 100; if (y2ac < 8) y2ac = 8;
-    int uvdc = kVp8DcQ[qi]; if (uvdc > 132) uvdc = 132;
-    const int uvac = kVp8AcQ[qi];
-    int own = 0;
-    if (!ry) { own = 1; ry = (uint8_t *)malloc((size_t)ys * mbh * 16); ru = (uint8_t *)malloc((size_t)cs * mbh * 8); rv = (uint8_t *)malloc((size_t)cs * mbh * 8); }
-    int16_t *levels = (int16_t *)calloc((size_t)mbw * mbh * 400, sizeof(int16_t));
-    uint8_t *modes = (uint8_t *)calloc((size_t)mbw * mbh, MODE_REC);
-    uint8_t *tmodes = (uint8_t *)calloc((size_t)mbw, 4);       /* sub-block modes of the row above, per column */
-    for (int my = 0; my < mbh; my++) {
-        uint8_t lmodes[4] = {0, 0, 0, 0};
-        for (int mx = 0; mx < mbw; mx++) {
-            int16_t *L = levels + ((size_t)my * mbw + mx) * 400;
-            uint8_t *M = modes + ((size_t)my * mbw + mx) * MODE_REC;
-            uint8_t *tm = tmodes + (size_t)mx * 4;
-            {
-                uint8_t *r = ry + (size_t)my * 16 * ys + mx * 16;
-                const uint8_t *s = yp + (size_t)my * 16 * ys + mx * 16;
-                /* --- i16x16 first: DC_PRED, or -- where both the row above and the column to the left exist -- V / H / TM when that leaves
-                   the smaller transformed residual (sum of |DCT coefficients|; ties: the earlier in this order) */
-                uint8_t pred[256];
-                int16_t L16[17 * 16];
-                const int ym = predict(r, ys, 16, s, ys, mx, my, NULL, NULL, 0, pred, 16);
-                int16_t coef[16][16], dcs[16], y2[16], dq[16];
-                for (int b = 0; b < 16; b++) { fdct4(s + (b >> 2) * 4 * ys + (b & 3) * 4, ys, pred + (b >> 2) * 64 + (b & 3) * 4, 16, coef[b]); dcs[b] = coef[b][0]; }
-                fwht(dcs, y2);
-                for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; L16[n] = (int16_t)quant(y2[k], k ? y2ac : y2dc, k ? 108 : 96); dq[k] = (int16_t)(L16[n] * (k ? y2ac : y2dc)); }
-                iwht(dq, dcs);
-                int any16 = 0;
-                for (int b = 0; b < 16; b++) {
-                    L16[16 + b * 16] = 0;
-                    for (int n = 1; n < 16; n++) { L16[16 + b * 16 + n] = (int16_t)quant(coef[b][kVp8Zigzag[n]], y1ac, 110); any16 |= L16[16 + b * 16 + n]; }
-                }
-                if (!any16) {
-                    /* nothing but the sixteen DCs (the Y2 block) to code: the macroblock stays i16x16 */
-                    M[0] = (uint8_t)ym;
-                    memcpy(L, L16, sizeof L16);
-                    for (int b = 0; b < 16; b++) {
-                        int16_t c[16];
-                        memset(c, 0, sizeof c);
-                        c[0] = dcs[b];
-                        idct4_add(c, pred + (b >> 2) * 64 + (b & 3) * 4, 16, r + (b >> 2) * 4 * ys + (b & 3) * 4, ys);
-                    }
-                    for (int k = 0; k < 4; k++) tm[k] = lmodes[k] = kI16AsBMode[ym];
-                } else {
-                    /* --- otherwise i4x4 (on the 1500 px set a rate-distortion comparison of the two codings picked i4x4 for all but a few
-                       of these macroblocks and bought 0.25 %: not worth a second reconstruction on the device).  Sub-blocks in raster order,
-                       each predicted from the reconstruction so far with the decoder's frame-edge rules (127 above the frame, 129 to its
-                       left; the four samples above-right of the MACROBLOCK serve the whole right column of sub-blocks); its mode is the one
-                       with the least BM_SATD * sum|DCT of the residual| + (BM_LAMBDA * q * mode cost) >> BM_SHIFT, ties to the lower mode */
-                    enum { CB = 32 };
-                    uint8_t cbuf[17 * CB], *cb = cbuf + CB + 1;
-                    for (int x = -1; x < 20; x++) {
-                        int v = 127;
-                        if (my > 0) {
-                            if (x < 0) v = mx > 0 ? r[-ys - 1] : 129;
-                            else if (x < 16) v = r[-ys + x];
-                            else v = mx + 1 < mbw ? r[-ys + x] : r[-ys + 15];
-                        }
-                        cb[-CB + x] = (uint8_t)v;
-                    }
-                    for (int y = 0; y < 16; y++) cb[y * CB - 1] = mx > 0 ? r[y * ys - 1] : (uint8_t)129;
-                    M[0] = 4;
-                    memset(L, 0, 16 * sizeof(int16_t));
-                    for (int k = 0; k < 16; k++) {
-                        const int bx = k & 3, by = k >> 2;
-                        uint8_t *d = cb + by * 4 * CB + bx * 4, e[13], best_pred[16];
-                        for (int i = 0; i < 4; i++) { e[i] = d[(3 - i) * CB - 1]; e[5 + i] = d[-CB + i]; e[9 + i] = bx == 3 ? cb[-CB + 16 + i] : d[-CB + 4 + i]; }
-                        e[4] = d[-CB - 1];
-                        uint64_t best = ~0ull;
-                        int bmode = 0;
-                        int16_t bc[16], c[16];
-                        for (int m = 0; m < 10; m++) {
-                            uint8_t p4[16];
-                            pred4(m, e, p4);
-                            fdct4(s + by * 4 * ys + bx * 4, ys, p4, 4, c);
-                            uint64_t sc = 0;
-                            for (int i = 0; i < 16; i++) sc += (uint64_t)(c[i] < 0 ? -c[i] : c[i]);
-                            sc = sc * BM_SATD + (((uint64_t)BM_LAMBDA * y1ac * bmode_cost(m, tm[bx], lmodes[by])) >> BM_SHIFT);
-                            if (sc < best) { best = sc; bmode = m; memcpy(bc, c, sizeof bc); memcpy(best_pred, p4, 16); }
-                        }
-                        M[2 + k] = tm[bx] = lmodes[by] = (uint8_t)bmode;
-                        int16_t *lv = L + 16 + k * 16;
-                        for (int n = 0; n < 16; n++) { const int z = kVp8Zigzag[n], q = z ? y1ac : y1dc; lv[n] = (int16_t)quant(bc[z], q, z ? 110 : 96); c[z] = (int16_t)(lv[n] * q); }
-                        idct4_add(c, best_pred, 4, d, CB);
-                    }
-                    for (int y = 0; y < 16; y++) memcpy(r + (size_t)y * ys, cb + y * CB, 16);
-                }
-            }
-            {
-                uint8_t *r0 = ru + (size_t)my * 8 * cs + mx * 8, *r1 = rv + (size_t)my * 8 * cs + mx * 8;
-                const uint8_t *s0 = up + (size_t)my * 8 * cs + mx * 8, *s1 = vp + (size_t)my * 8 * cs + mx * 8;
-                uint8_t pred[2][64];
-                M[1] = (uint8_t)predict(r0, cs, 8, s0, cs, mx, my, r1, s1, 1, pred[0], 8);
-                for (int pl = 0; pl < 2; pl++) {
-                    uint8_t *r = pl ? r1 : r0;
-                    const uint8_t *s = pl ? s1 : s0;
-                    for (int b = 0; b < 4; b++) {
-                        int16_t coef[16], c[16], *lv = L + (17 + pl * 4 + b) * 16;
-                        fdct4(s + (b >> 1) * 4 * cs + (b & 1) * 4, cs, pred[pl] + (b >> 1) * 32 + (b & 1) * 4, 8, coef);
-                        for (int n = 0; n < 16; n++) { const int k = kVp8Zigzag[n]; lv[n] = (int16_t)quant(coef[k], k ? uvac : uvdc, k ? 115 : 110); c[k] = (int16_t)(lv[n] * (k ? uvac : uvdc)); }
-                        idct4_add(c, pred[pl] + (b >> 1) * 32 + (b & 1) * 4, 8, r + (b >> 1) * 4 * cs + (b & 1) * 4, cs);
-                    }
-                }
-            }
-        }
-    }
-    free(tmodes);
-    /* what the token walk will code, counted first: the frame's coefficient probabilities come from it */
-    uint8_t probs[4 * 8 * 3 * 11], update[4 * 8 * 3 * 11];
-    {
-        uint32_t *stats = (uint32_t *)calloc(2 * 4 * 8 * 3 * 11, sizeof(uint32_t));
-        tsink cnt = {NULL, NULL, stats};
-        token_walk(&cnt, NULL, 1, levels, modes, mbw, mbh);
-        choose_probs(stats, probs, update);
-        free(stats);
-    }
-    /* partition 0: frame header + per-macroblock modes; partition 1: tokens */
-    boolenc h;
-    be_init(&h);
-    be_bits(&h, 0, 1);            /* colour space */
-    be_bits(&h, 0, 1);            /* clamping required */
-    be_bits(&h, 0, 1);            /* no segmentation */
-    be_bits(&h, 1, 1);            /* simple filter ... */
-    be_bits(&h, 0, 6);            /* ... at level 0: off */
-    be_bits(&h, 0, 3);            /* sharpness */
-    be_bits(&h, 0, 1);            /* no filter deltas */
-    be_bits(&h, (uint32_t)(mbh >= 8 ? 3 : mbh >= 4 ? 2 : mbh >= 2 ? 1 : 0), 2);   /* log2 of the number of token partitions */
-    be_bits(&h, (uint32_t)qi, 7);
-    for (int i = 0; i < 5; i++) be_bits(&h, 0, 1);   /* no quantiser deltas */
-    be_bits(&h, 0, 1);            /* refresh_entropy_probs */
-    for (int i = 0; i < 4 * 8 * 3 * 11; i++) { be_put(&h, update[i], kVp8CoefUpdateProbs[i]); if (update[i]) be_bits(&h, probs[i], 8); }   /* the frame's coefficient probabilities */
-    be_bits(&h, 0, 1);            /* no skip flags */
-    {
-        uint8_t *tmo = (uint8_t *)calloc((size_t)mbw, 4);
-        for (int my = 0; my < mbh; my++) {
-            uint8_t lmo[4] = {0, 0, 0, 0};
-            for (int mx = 0; mx < mbw; mx++) {
-                const uint8_t *M = modes + ((size_t)my * mbw + mx) * MODE_REC;
-                const int ym = M[0], cm = M[1];
-                uint8_t *tm = tmo + (size_t)mx * 4;
-                if (ym == 4) {
-                    be_put(&h, 0, 145);                                                       /* i4x4: sixteen sub-block modes, each after its neighbours' */
-                    for (int k = 0; k < 16; k++) { put_bmode(&h, M[2 + k], tm[k & 3], lmo[k >> 2]); tm[k & 3] = lmo[k >> 2] = M[2 + k]; }
-                } else {
-                    be_put(&h, 1, 145);                                                       /* i16x16 */
-                    if (ym >= 2) { be_put(&h, 1, 156); be_put(&h, ym == 3, 128); } else { be_put(&h, 0, 156); be_put(&h, ym == 1, 163); }   /* (H | TM) : (DC | V) */
-                    for (int k = 0; k < 4; k++) tm[k] = lmo[k] = kI16AsBMode[ym];
-                }
-                if (!cm) be_put(&h, 0, 142); else { be_put(&h, 1, 142); if (cm == 1) be_put(&h, 0, 114); else { be_put(&h, 1, 114); be_put(&h, cm == 3, 183); } }
-            }
-        }
-        free(tmo);
-    }
-    be_flush(&h);
-    /* token partitions: macroblock row r goes to partition r mod P, P = 8 / 4 / 2 / 1 by the number of rows.  The contexts
-       (is the block above / to the left non-zero?) carry over from row to row whatever the partition, and depend on the
-       levels only -- so the partitions are independent chains once the levels exist. */
-    const int nparts = mbh >= 8 ? 8 : mbh >= 4 ? 4 : mbh >= 2 ? 2 : 1;
-    boolenc t[8];
-    for (int p = 0; p < nparts; p++) be_init(&t[p]);
-    {
-        tsink code[8];
-        for (int p = 0; p < nparts; p++) { code[p].e = &t[p]; code[p].probs = probs; code[p].stats = NULL; }
-        token_walk(NULL, code, nparts, levels, modes, mbw, mbh);
-    }
-    size_t tok = 0;
-    for (int p = 0; p < nparts; p++) { be_flush(&t[p]); tok += t[p].pos; }
-    free(levels); free(modes);
-    if (own) { free(ry); free(ru); free(rv); }
-    /* RIFF / WEBP / "VP8 " : frame tag, start code, dimensions, partition 0, the sizes of all token partitions but the last, the partitions */
-    const size_t vp8 = 10 + h.pos + 3 * (size_t)(nparts - 1) + tok, padded = vp8 + (vp8 & 1), total = 12 + 8 + padded;
-    uint8_t *o = (uint8_t *)calloc(total, 1), *w = o;
-    memcpy(w, "RIFF", 4); w[4] = (uint8_t)(total - 8); w[5] = (uint8_t)((total - 8) >> 8); w[6] = (uint8_t)((total - 8) >> 16); w[7] = (uint8_t)((total - 8) >> 24);
-    memcpy(w + 8, "WEBPVP8 ", 8); w[16] = (uint8_t)vp8; w[17] = (uint8_t)(vp8 >> 8); w[18] = (uint8_t)(vp8 >> 16); w[19] = (uint8_t)(vp8 >> 24);
-    w += 20;
-    const uint32_t tag = ((uint32_t)h.pos << 5) | (1u << 4) | (0u << 1) | 0u;   /* key frame, version 0, shown */
-    w[0] = (uint8_t)tag; w[1] = (uint8_t)(tag >> 8); w[2] = (uint8_t)(tag >> 16);
-    w[3] = 0x9D; w[4] = 0x01; w[5] = 0x2A;
-    w[6] = (uint8_t)width; w[7] = (uint8_t)(width >> 8); w[8] = (uint8_t)height; w[9] = (uint8_t)(height >> 8);
-    memcpy(w + 10, h.buf, h.pos); w += 10 + h.pos;
-    for (int p = 0; p + 1 < nparts; p++) { w[0] = (uint8_t)t[p].pos; w[1] = (uint8_t)(t[p].pos >> 8); w[2] = (uint8_t)(t[p].pos >> 16); w += 3; }
-    for (int p = 0; p < nparts; p++) { memcpy(w, t[p].buf, t[p].pos); w += t[p].pos; free(t[p].buf); }
-    free(h.buf);
-    *out = o; *out_len = total;
-    return 0;
-}
 /* the row's encoder is libwebp's, restated in vp8enc_oracle.c (pinned to WebPEncode); this is the entry point the conversion oracles call */
 int cso_vp8enc_encode_rgb(const uint8_t *rgb, int width, int height, float quality, uint8_t **out, size_t *out_len);
 int cso_webp_encode_rgb(const uint8_t *rgb, int width, int height, int quality, uint8_t **out, size_t *out_len) {

@@ -191,7 +191,7 @@ def oracle_png(src, level=3, keep_metadata=False):
 # ---------------------------------------------------------------- lossy WebP row (JPEG in, WebP out)
 def oracle_jpeg_to_webp(src, quality=80, width=0, height=0):
     """the oracle's statement of convert_in_memory(JPEG -> WebP): libjpeg decode to RGB (oracle), image-rs Lanczos3 when a size
-    is given (oracle), then the minimal VP8 encoder (oracle/webp_oracle.c)"""
+    is given (oracle), then libwebp's encoder as restated in oracle/vp8enc_oracle.c (pinned to WebPEncode byte for byte)"""
     import ctypes as C
 
     import numpy as np

@@ -1,184 +1,124 @@
-"""Pins the CPU oracle of the lossy WebP row (oracle/webp_oracle.c) to what exists here: libwebp's DECODER.  Every stream
-must decode, and the encoder's own reconstruction must equal what libwebp decodes (so the prediction chain of the encoder and
-of any decoder stay in step).  Byte parity with libwebp's ENCODER is neither possible nor claimed: see the oracle's header."""
+"""Pins the CPU oracle of the lossy WebP row to libwebp itself, which is executable in this container:
+  W1  oracle/webp_oracle.c cso_webp_rgb_to_yuv   == WebPPictureImportRGB, bit for bit;
+  W2 / W3  oracle/vp8enc_oracle.c                == WebPEncode with a default WebPConfig at the quality (the reference's call), BYTE FOR BYTE, for every
+           libwebp here (1.2.0, 1.2.2, 1.6.0 agree with each other, so does what libwebp-sys 0.9.5 vendors in between), live when a libwebp is present
+           and against the committed digests of libwebp's files otherwise (tests/golden/libwebp_vp8enc.json, made by tests/golden/make_libwebp_goldens.py)."""
 import ctypes as C
 import ctypes.util
-import io
+import hashlib
+import json
+import os
 
 import numpy as np
 import pytest
 
 from gen_synth import synth_rgb
+from libwebp_pin import compare, libwebp_encode, libwebps
 from oracle import oracle as O
 
 PIL = pytest.importorskip("PIL.Image")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "libwebp_vp8enc.json")
+SAMPLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_samples")
 
 
 def crop(seed, w, h, texture=4.0):
     return np.ascontiguousarray(synth_rgb(seed, w + 400, h + 300, texture=texture)[150:150 + h, 200:200 + w])
 
 
-def libwebp_decode_yuv(data):
-    name = ctypes.util.find_library("webp")
-    if not name:
-        pytest.skip("no system libwebp for the YUV-level comparison")
-    W = C.CDLL(name)
-    W.WebPDecodeYUV.restype = C.POINTER(C.c_uint8)
-    w, h, s, us = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    u, v = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)()
-    y = W.WebPDecodeYUV(data, len(data), C.byref(w), C.byref(h), C.byref(u), C.byref(v), C.byref(s), C.byref(us))
-    assert y, "libwebp refuses the stream"
-    cw, ch = (w.value + 1) // 2, (h.value + 1) // 2
-    Y = np.ctypeslib.as_array(y, shape=(h.value, s.value))[:, :w.value].copy()
-    U = np.ctypeslib.as_array(u, shape=(ch, us.value))[:, :cw].copy()
-    V = np.ctypeslib.as_array(v, shape=(ch, us.value))[:, :cw].copy()
-    return Y, U, V
+def pictures(big=False):
+    """(name, rgb, quality): every quality class (error diffusion on / off above 98, the two branches of the quality curve), frame-edge shapes (one macroblock wide /
+    high, 1 x 1, partial macroblocks), flat and noisy content (the i16 / i4 balance, flat-source and flatness penalties, skip-everything macroblocks), pictures
+    of more than one statistics chunk, the reference's own sample pictures; big: configs[3]-sized ones and a noisy large one whose token books overflow 16 bits"""
+    out = []
+    for q in (0, 1, 10, 30, 50, 74, 75, 76, 80, 90, 95, 98, 99, 100):
+        out.append(("q%d_200x120" % q, crop(0, 200, 120), q))
+    for k, (w, h) in enumerate(((1, 1), (3, 5), (16, 16), (17, 17), (15, 33), (97, 61), (250, 16), (16, 200), (129, 130), (333, 251))):
+        out.append(("s%dx%d_q85" % (w, h), crop(20 + k, w, h, texture=6.0), 85))
+        out.append(("s%dx%d_q40_noisy" % (w, h), crop(40 + k, w, h, texture=30.0), 40))
+    out.append(("flat_grey_96x64", np.full((64, 96, 3), 119, np.uint8), 85))
+    g = np.zeros((80, 112, 3), np.uint8); g[:, :, 0] = np.arange(112)[None, :] * 2; g[:, :, 1] = np.arange(80)[:, None] * 3; g[:, :, 2] = 60
+    out.append(("gradient_112x80", g, 75))
+    out.append(("chunks_640x481_q85", crop(7, 640, 481, texture=10.0), 85))
+    for name in ("w0.webp", "level_1_1/w1.webp", "p0.png"):
+        path = os.path.join(SAMPLES, name)
+        if os.path.exists(path):
+            out.append(("sample_" + os.path.basename(name), np.ascontiguousarray(np.asarray(PIL.open(path).convert("RGB"))), 80))
+    if big:
+        for seed in range(3):
+            out.append(("synth%d_1500x844_q85" % seed, np.ascontiguousarray(synth_rgb(seed, 1500, 844)), 85))
+        rng = np.random.default_rng(5)
+        noisy = (synth_rgb(3, 1920, 1080).astype(int) + rng.integers(-40, 40, (1080, 1920, 3))).clip(0, 255).astype(np.uint8)
+        out.append(("noisy_1920x1080_q85", np.ascontiguousarray(noisy), 85))
+    return out
 
 
-CASES = [(64, 48, 85), (100, 75, 85), (161, 97, 50), (320, 240, 95), (17, 9, 75), (300, 200, 10), (1, 1, 50), (16, 16, 100), (33, 250, 0)]
+def test_bytes_equal_libwebp_live():
+    """every libwebp in the container, default configuration: the oracle's file IS libwebp's file"""
+    libs = libwebps()
+    if not libs:
+        pytest.skip("no libwebp with the encoder API")
+    for name, rgb, q in pictures():
+        mine = O.vp8enc_encode_rgb(rgb, q)
+        for ver, W in libs:
+            ref = libwebp_encode(W, rgb, q)
+            assert mine == ref, (name, ver, compare(ref, mine, verbose=False))
 
 
-@pytest.mark.parametrize("w,h,q", CASES)
-def test_reconstruction_equals_libwebp_decoder(w, h, q):
-    rgb = crop(3, w, h)
-    y, u, v = O.webp_rgb_to_yuv(rgb)
-    data, (ry, ru, rv) = O.webp_encode_yuv(y, u, v, w, h, O.webp_quality_to_qi(q))
-    assert data[:4] == b"RIFF" and data[8:16] == b"WEBPVP8 " and int.from_bytes(data[4:8], "little") == len(data) - 8
-    Y, U, V = libwebp_decode_yuv(data)
-    assert np.array_equal(Y, ry[:h, :w]) and np.array_equal(U, ru[:(h + 1) // 2, :(w + 1) // 2]) and np.array_equal(V, rv[:(h + 1) // 2, :(w + 1) // 2])
+def test_bytes_equal_committed_libwebp_digests():
+    gold = json.load(open(GOLDEN))["cases"]
+    seen = 0
+    for name, rgb, q in pictures():
+        if name not in gold:
+            continue
+        mine = O.vp8enc_encode_rgb(rgb, q)
+        assert len(mine) == gold[name]["bytes"] and hashlib.sha256(mine).hexdigest() == gold[name]["sha256"], name
+        seen += 1
+    assert seen >= 35
 
 
-def test_quality_against_libwebp_at_the_same_setting():
-    rgb = crop(5, 320, 240, texture=6.0)
-    for q in (50, 85):
-        ours = O.webp_encode_rgb(rgb, q)
-        b = io.BytesIO()
-        PIL.fromarray(rgb).save(b, "WEBP", quality=q)
-
-        def psnr(data):
-            a = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(np.float64)
-            return 10 * np.log10(255.0 ** 2 / ((a - rgb) ** 2).mean())
-        # no mode search: about the same fidelity as libwebp at this quality, more bytes
-        assert psnr(ours) > psnr(b.getvalue()) - 1.0
-        assert len(ours) < 4 * len(b.getvalue())
+def test_big_pictures_equal_committed_libwebp_digests():
+    """configs[3]'s size, and a noisy 1080p picture whose per-slot token counts pass 65534 (libwebp halves its 16-bit books on the way: order-dependent)"""
+    gold = json.load(open(GOLDEN))["cases"]
+    for name, rgb, q in pictures(big=True):
+        if not (name.startswith("synth") or name.startswith("noisy")):
+            continue
+        mine = O.vp8enc_encode_rgb(rgb, q)
+        assert hashlib.sha256(mine).hexdigest() == gold[name]["sha256"], name
 
 
-def test_quality_curve():
-    assert [O.webp_quality_to_qi(q) for q in (0, 50, 75, 85, 100)] == [127, 38, 26, 14, 0]
+def test_the_webp_crate_s_picture_set_up_imports_alike():
+    """crate webp 0.3.1 sets use_argb = 1 before WebPPictureImportRGB; WebPEncode then converts ARGB -> YUV itself: the same file"""
+    libs = libwebps()
+    if not libs:
+        pytest.skip("no libwebp with the encoder API")
+    rgb = crop(5, 150, 90, texture=8.0)
+    for _, W in libs:
+        assert libwebp_encode(W, rgb, 85, use_argb=True) == libwebp_encode(W, rgb, 85)
 
 
-class _BoolDecoder:
-    """RFC 6386 section 7, enough of it to read a frame header"""
-    def __init__(self, d):
-        self.d, self.pos, self.value, self.range, self.bits = d, 2, (d[0] << 8) | d[1], 255, 0
-
-    def get(self, p):
-        split = 1 + (((self.range - 1) * p) >> 8)
-        big = split << 8
-        if self.value >= big:
-            bit, self.range, self.value = 1, self.range - split, self.value - big
-        else:
-            bit, self.range = 0, split
-        while self.range < 128:
-            self.value <<= 1
-            self.range <<= 1
-            self.bits += 1
-            if self.bits == 8:
-                self.bits = 0
-                self.value |= self.d[self.pos] if self.pos < len(self.d) else 0
-                self.pos += 1
-        return bit
-
-    def lit(self, n):
-        v = 0
-        for _ in range(n):
-            v = (v << 1) | self.get(128)
-        return v
+def test_parser_reads_back_what_the_encoder_decided():
+    """the stream parser (the tool the pin was built with) against the encoder's own trace: header fields, segment map, modes, every level"""
+    for name, rgb, q in pictures()[12:30:3]:
+        data, frame, mbs = O.vp8enc_encode_rgb(rgb, q, trace=True)
+        f2, m2 = O.vp8_parse(data)
+        assert f2.header() == frame.header() | {"quant": f2.header()["quant"], "filt": f2.header()["filt"], "nseg": f2.header()["nseg"]}, name
+        if frame.num_segments > 1:
+            assert list(f2.seg_quant) == list(frame.seg_quant) and list(f2.seg_filter) == list(frame.seg_filter)
+        for k in ("is_i4", "uvmode", "bmodes", "levels"):
+            assert np.array_equal(mbs[k], m2[k]), (name, k)
+        if frame.update_map:
+            assert np.array_equal(mbs["segment"], m2["segment"]), name
+        assert bytes(f2.probas) == bytes(frame.probas)
 
 
-def frame_quantiser_index(webp):
-    assert webp[12:16] == b"VP8 "
-    b = _BoolDecoder(webp[30:])
-    b.lit(2)
-    assert b.lit(1) == 0, "segments"
-    b.lit(10)
-    if b.lit(1) and b.lit(1):
-        for _ in range(8):
-            if b.lit(1):
-                b.lit(7)
-    b.lit(2)
-    return b.lit(7)
+def test_every_stream_decodes():
+    for name, rgb, q in pictures()[::5]:
+        im = PIL.open(__import__("io").BytesIO(O.vp8enc_encode_rgb(rgb, q)))
+        im.load()
+        assert im.size == (rgb.shape[1], rgb.shape[0]), name
 
 
-def libwebp_encode(rgb, quality, segments=1, sns=0, filt=0, method=4):
-    """libwebp's own encoder through ctypes (WebPConfig: 4-byte fields, [2] method, [6] segments, [7] sns_strength, [8] filter_strength; WebPPicture: writer and
-    custom_ptr at bytes 96 / 104) -- here with everything this repo's encoder does not have switched off"""
-    name = ctypes.util.find_library("webp")
-    if not name:
-        pytest.skip("no system libwebp")
-    W = C.CDLL(name)
-    if not hasattr(W, "WebPEncode"):
-        pytest.skip("libwebp without the encoder API")
-    h, w, _ = rgb.shape
-    cfg = (C.c_int32 * 64)()
-    W.WebPConfigInitInternal.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int]
-    assert W.WebPConfigInitInternal(cfg, 0, float(quality), 0x020f)
-    cfg[2], cfg[6], cfg[7], cfg[8] = method, segments, sns, filt
-    pic = (C.c_uint8 * 1024)()
-    assert W.WebPPictureInitInternal(pic, 0x020f)
-    ints = C.cast(pic, C.POINTER(C.c_int32))
-    ints[2], ints[3] = w, h
-    rgb = np.ascontiguousarray(rgb)
-    W.WebPPictureImportRGB.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    assert W.WebPPictureImportRGB(pic, rgb.ctypes.data, w * 3)
-    wr = (C.c_uint8 * 64)()
-    W.WebPMemoryWriterInit.argtypes = [C.c_void_p]
-    W.WebPMemoryWriterInit(wr)
-    ptrs = C.cast(pic, C.POINTER(C.c_void_p))
-    ptrs[12] = C.cast(W.WebPMemoryWrite, C.c_void_p).value
-    ptrs[13] = C.addressof(wr)
-    W.WebPEncode.argtypes = [C.c_void_p, C.c_void_p]
-    assert W.WebPEncode(cfg, pic)
-    data = C.string_at(C.cast(wr, C.POINTER(C.c_void_p))[0], C.cast(wr, C.POINTER(C.c_size_t))[1])
-    W.WebPPictureFree(pic)
-    return data
-
-
-def test_quality_to_quantiser_index_is_libwebp_s():
-    """the base quantiser index libwebp itself writes into its frame header (one segment, no SNS) for every quality 0..100, and the one this repo's streams carry"""
-    rgb = np.random.default_rng(0).integers(0, 256, (32, 48, 3), dtype=np.uint8)
-    for q in range(101):
-        want = frame_quantiser_index(libwebp_encode(rgb, q))
-        assert O.webp_quality_to_qi(q) == want, q
-        if q % 10 == 0:
-            assert frame_quantiser_index(O.webp_encode_rgb(rgb, q)) == want
-
-
-
-def test_sub_block_mode_cost_table_is_the_formula():
-    L = O.lib()
-    for top in range(10):
-        for left in range(10):
-            for m in range(10):
-                assert L.cso_webp_bmode_cost(m, top, left, 1) == L.cso_webp_bmode_cost(m, top, left, 0)
-
-
-@pytest.mark.parametrize("w,h,q,texture", [(97, 61, 85, 8.0), (48, 48, 92, 12.0), (200, 120, 60, 6.0), (16, 200, 85, 9.0), (250, 16, 85, 9.0), (129, 130, 100, 10.0)])
-def test_i4x4_macroblocks_reconstruct_like_libwebp(w, h, q, texture):
-    """Textured pictures make most macroblocks i4x4 (sub-block modes at the frame edges, along the right column where the samples above-right
-    come from the next macroblock, on one-macroblock-wide and -high pictures): the encoder's reconstruction must be the decoder's."""
-    rgb = crop(11, w, h, texture=texture)
-    y, u, v = O.webp_rgb_to_yuv(rgb)
-    data, (ry, ru, rv) = O.webp_encode_yuv(y, u, v, w, h, O.webp_quality_to_qi(q))
-    Y, U, V = libwebp_decode_yuv(data)
-    assert np.array_equal(Y, ry[:h, :w]) and np.array_equal(U, ru[:(h + 1) // 2, :(w + 1) // 2]) and np.array_equal(V, rv[:(h + 1) // 2, :(w + 1) // 2])
-    # the i4x4 flag of the first macroblock's header is not visible from here; what is: such pictures must now be smaller than libwebp's
-    # i16-only coding would allow -- checked loosely against libwebp itself at the same quality
-    b = io.BytesIO()
-    PIL.fromarray(rgb).save(b, "WEBP", quality=q)
-    assert len(data) < 1.35 * len(b.getvalue()) + 200
-
-
+# ------------------------------------------------------------------------------------------------ W1: the import
 def libwebp_import_rgb(rgb):
     """libwebp's own RGB -> YUV 4:2:0 (WebPPictureImportRGB on a picture with use_argb = 0), read out of its WebPPicture: use_argb, colorspace, width, height
     (4 x int32), y / u / v pointers, y_stride, uv_stride -- the head of the struct in webp/encode.h since libwebp 0.5"""
@@ -225,32 +165,3 @@ def test_gamma_tables_cover_every_sample_value():
     y, u, vv = O.webp_rgb_to_yuv(rgb)
     Y, U, V = libwebp_import_rgb(rgb)
     assert np.array_equal(y[:2, :512], Y) and np.array_equal(u[:1, :256], U) and np.array_equal(vv[:1, :256], V)
-
-
-def test_bytes_and_fidelity_against_libwebp_at_the_same_quantiser():
-    """W2 measured where it can be: libwebp method 4 with one segment, no SNS and no loop filter uses the same quantiser index as this encoder.  Its trellis and RD
-    search buy it some fidelity; this encoder must stay within 4 % of its bytes and 0.6 dB of its PSNR (tools/webp_vs_libwebp.py prints the table) and far
-    ahead of libwebp's method 0, which is what it was in round 1 (no 4x4 modes)."""
-    rgb = crop(9, 320, 240, texture=6.0)
-
-    def psnr(data):
-        a = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(np.float64)
-        return 10 * np.log10(255.0 ** 2 / ((a - rgb) ** 2).mean())
-    for q in (60, 85):
-        ours, lib4, lib0 = O.webp_encode_rgb(rgb, q), libwebp_encode(rgb, q), libwebp_encode(rgb, q, method=0)
-        assert frame_quantiser_index(ours) == frame_quantiser_index(lib4)
-        assert len(ours) <= 1.04 * len(lib4) and psnr(ours) >= psnr(lib4) - 0.6, (q, len(ours), len(lib4), psnr(ours), psnr(lib4))
-        assert len(ours) < 0.9 * len(lib0), (q, len(ours), len(lib0))
-
-
-def test_random_sizes_and_qualities_reconstruct_like_libwebp():
-    """forty random pictures (1 .. 70 pixels a side, any quality, flat to very noisy): every combination of frame-edge rule, sub-block mode and macroblock
-    type the encoder can reach must leave exactly the picture libwebp's decoder makes of the stream"""
-    rng = np.random.default_rng(2024)
-    for k in range(40):
-        w, h, q = int(rng.integers(1, 71)), int(rng.integers(1, 71)), int(rng.integers(0, 101))
-        rgb = crop(100 + k, w, h, texture=float(rng.choice([0.0, 1.0, 4.0, 12.0, 40.0])))
-        y, u, v = O.webp_rgb_to_yuv(rgb)
-        data, (ry, ru, rv) = O.webp_encode_yuv(y, u, v, w, h, O.webp_quality_to_qi(q))
-        Y, U, V = libwebp_decode_yuv(data)
-        assert np.array_equal(Y, ry[:h, :w]) and np.array_equal(U, ru[:(h + 1) // 2, :(w + 1) // 2]) and np.array_equal(V, rv[:(h + 1) // 2, :(w + 1) // 2]), (k, w, h, q)

@@ -1,4 +1,4 @@
-"""JPEG in, WebP out (convert_in_memory to WebP): the kernel sources compiled for the CPU against the oracle; the same cases
+"""JPEG in, WebP out (convert_in_memory to WebP): the kernel sources compiled for the CPU against the oracle (= libwebp's bytes: tests/test_oracle_webp.py); the same cases
 run on the device in test_webp_gpu.py."""
 import io
 
@@ -46,22 +46,20 @@ def test_convert_equals_oracle(api):
     check(api, webp_cases()[:3], 30)
 
 
-def test_token_partitions_as_decision_streams_and_as_chains(api, monkeypatch):
-    """round 4: the token partitions are coded one LANE per partition from (bit, probability) pairs written down ahead of the coder (k_webp_decisions /
-    k_webp_bool: a 64-bit accumulator flushed every fourth decision, carries added before the byte is written); CSH_WEBP_CHAINS=1 keeps the coder that walks
-    the token tree itself, one wave per partition.  The same files either way -- pictures with one, two, four and eight partitions, busy and empty ones, both
-    macroblock kinds, values of every size class (q 100 gives long extra-bit runs)"""
+def test_every_quality_class_and_shape(api):
+    """the coder back end takes its decisions from (bit, probability) pairs written down ahead of it (k_webp_decisions / k_webp_hdr / k_webp_bool: a 64-bit
+    accumulator flushed every fourth decision, carries added before the byte is written); the encoder in front of it is libwebp's (k_vp8enc.hip).  Busy and
+    empty pictures, both macroblock kinds, one-macroblock-wide and -high ones, values of every size class (q 100 gives long extra-bit runs and switches the
+    chroma error diffusion off), several statistics chunks (200 x 150 = 130 macroblocks: the cost tables are rebuilt after 96)"""
     cases = webp_cases() + [("busy_200x150", synth_jpeg(9, 200, 150, texture=90)), ("tall_24x200", synth_jpeg(10, 24, 200, texture=40)), ("wide_333x17", synth_jpeg(11, 333, 17, texture=20))]
-    for q in (100, 75, 5):
+    for q in (100, 99, 75, 5):
         assert check(api, cases, q) is None
-    pkg = package()
-    for q in (100, 40):
-        p = pkg.default_parameters(webp_quality=q, jpeg_quality=q)
-        streams = api.batch_convert([c[1] for c in cases], p, WEBP)
-        monkeypatch.setenv("CSH_WEBP_CHAINS", "1")
-        chains = api.batch_convert([c[1] for c in cases], p, WEBP)
-        monkeypatch.delenv("CSH_WEBP_CHAINS")
-        assert streams == chains
+
+
+def test_statistics_books_overflow_in_order(api):
+    """libwebp keeps its token statistics in 16 + 16 bits and halves a slot when 65534 events are reached: WHICH events came before matters.  A noisy picture
+    makes several slots pass that point (and k_vp8_chunk recount them in macroblock order); the file must still be the oracle's = libwebp's"""
+    check(api, [("noisy_640x400", synth_jpeg(12, 640, 400, texture=120))], 95)
 
 
 def test_convert_with_resize(api):
