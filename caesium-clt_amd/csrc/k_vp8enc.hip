@@ -217,27 +217,6 @@ __device__ __forceinline__ static int quant_single(int &v, const QM &m) {   // c
     return (sign ? -V : V) >> 1;
 }
 
-// ---- costs (oracle: residual_cost)
-__device__ __forceinline__ static int level_cost1(const uint16_t *tab, int v) { return int(kVp8LevelFixedCosts[v]) + int(tab[v > VP8_MAXLV ? VP8_MAXLV : v]); }
-__device__ static int residual_cost(const Vp8FrameDev *F, int type, int first, int ctx0, const int (&lv)[16]) {
-    int last = -1;
-    CSH_UNROLL
-    for (int i = 0; i < 16; i++) if (lv[i]) last = i;
-    const int p0 = F->coeffs[vp8_slot(type, kVp8Bands[first], ctx0)];
-    if (last < 0) return vp8_bitcost(0, p0);
-    int cost = ctx0 == 0 ? vp8_bitcost(1, p0) : 0, ctx = ctx0, vlast = 0;
-    CSH_UNROLL
-    for (int n = 0; n < 16; n++)
-        if (n >= first && n <= last) {
-            const int v = iabs(lv[n]);
-            cost += level_cost1(F->level_cost + ((type * 8 + kVp8Bands[n]) * 3 + ctx) * (VP8_MAXLV + 1), v);
-            ctx = v >= 2 ? 2 : v;
-            vlast = v;
-        }
-    if (last < 15) cost += vp8_bitcost(0, F->coeffs[vp8_slot(type, kVp8Bands[last + 1], vlast == 1 ? 1 : 2)]);
-    return cost;
-}
-
 // =================================================================================================== A: analysis
 // grid (ceil(nmb / 4), images); a row of sixteen lanes per macroblock: lane = luma block, then lanes 0..7 = the U and V blocks.  DC and TM predictions from
 // SOURCE samples around the macroblock (oracle: analyse_mb); per prediction the histogram of |coefficient| >> 3 over its blocks; alpha = 510 * last / max
@@ -349,7 +328,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_analyse(const WebpImg 
 
 // =================================================================================================== B: segments, quantisers, cost tables
 // level_cost tables from the current probabilities (oracle: level_costs): lanes share the 96 x 68 entries
-__device__ static void make_level_costs(Vp8FrameDev *F, const uint8_t *coeffs) {
+__device__ static void make_level_costs(uint16_t *lc, const uint8_t *coeffs) {
     LFOR(l)
         for (int e = l; e < 96 * (VP8_MAXLV + 1); e += 64) {
             const int tbc = e / (VP8_MAXLV + 1), v = e - tbc * (VP8_MAXLV + 1), c = tbc % 3;
@@ -362,7 +341,7 @@ __device__ static void make_level_costs(Vp8FrameDev *F, const uint8_t *coeffs) {
                 cost = vp8_bitcost(1, p[1]) + cost0;
                 for (int i = 2; pattern; i++, bits >>= 1, pattern >>= 1) if (pattern & 1) cost += vp8_bitcost(bits & 1, p[i]);
             }
-            F->level_cost[e] = uint16_t(cost);
+            lc[e] = uint16_t(cost);
         }
 }
 __device__ static void expand_matrix(Vp8SegDev &S, int t, int type_bias) {
@@ -469,7 +448,6 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_segments(const WebpImg
         }
         for (int i = l; i < VP8_NSLOT; i += 64) { F->coeffs[i] = kVp8CoefProbs[i]; F->stats[i] = 0; }
     }
-    make_level_costs(F, kVp8CoefProbs);
 }
 
 // =================================================================================================== C: the macroblock loop
@@ -483,44 +461,68 @@ struct MbLds {
     uint32_t csrcw[2][16];         // chroma source 8 x 8 x 2
     uint8_t ce[2][20];             // chroma edges: [0..7] above, [8..15] left, [16] corner
     int32_t dcs[16];               // i16: the sixteen block DCs
+    int32_t hsrc[16];              // the weighted Hadamard spectrum of each luma source block
+    int16_t y2best[16];            // i16: the best mode's Y2 levels
     int16_t lv4[16][16];           // i4: the chosen levels
     int16_t lvuv[8][16];           // chroma: the best mode's levels
     uint32_t recuv[2][16];         // chroma: its reconstruction
     int32_t cdc[4][4];             // chroma: the four DCs of one (mode & 1, plane) for the error diffusion
     int32_t cerr[4][4];            // and the three errors it hands on
     uint8_t e[16];                 // i4: the edge line L K J I X A B C D E F G H of the current sub-block
-    int32_t win[6];                // i4: the winning candidate's D, SD, R, H, nz, mode
+    int32_t win[4];                // i4: the winning candidate's D, SD, R, H
     uint8_t bm[16], nz4[16];
-    int8_t derr[2][3];
+    int8_t derr[2][4];
 };
+// the picture's tables, one copy per wave (all four macroblocks of a wave belong to one picture): level costs, probabilities, the fixed tables, the segments
+struct MbTables {
+    uint16_t lc[96 * (VP8_MAXLV + 1)];
+    uint16_t fixed[256];             // kVp8LevelFixedCosts for levels below 256 (larger ones are read from the constant table)
+    uint16_t ent[256];
+    uint8_t coeffs[VP8_NSLOT];
+    Vp8SegDev seg[4];
+};
+__device__ __forceinline__ static int tb_bitcost(const MbTables &T, int bit, int p) { return T.ent[bit ? 255 - p : p]; }
+// bits (1/256) of one block's levels given the context of its first coefficient (oracle: residual_cost).  Every table look-up is addressed from the levels
+// alone, so the sixteen steps are independent loads
+__device__ __forceinline__ static int block_cost(const MbTables &T, int type, int first, int ctx0, const int (&lv)[16]) {
+    int last = -1;
+    CSH_UNROLL
+    for (int i = 0; i < 16; i++) if (lv[i]) last = i;
+    const int p0 = T.coeffs[vp8_slot(type, first, ctx0)];   // (band of position 0 / 1 = 0 / 1)
+    int cost = ctx0 == 0 ? tb_bitcost(T, 1, p0) : 0, ctx = ctx0;
+    CSH_UNROLL
+    for (int n = 0; n < 16; n++) {
+        const int v = iabs(lv[n]), on = (n >= first && n <= last) ? 1 : 0;
+        const int c = int(v < 256 ? T.fixed[v] : kVp8LevelFixedCosts[v]) + int(T.lc[((type * 8 + kVp8Bands[n]) * 3 + ctx) * (VP8_MAXLV + 1) + (v > VP8_MAXLV ? VP8_MAXLV : v)]);
+        cost += on ? c : 0;
+        ctx = n >= first ? (v >= 2 ? 2 : v) : ctx;
+    }
+    int vl = 0;
+    CSH_UNROLL
+    for (int n = 0; n < 16; n++) vl = n == last ? iabs(lv[n]) : vl;
+    const int tail = last < 15 ? tb_bitcost(T, 0, T.coeffs[vp8_slot(type, kVp8Bands[(last < 0 ? 0 : last) + 1], vl == 1 ? 1 : 2)]) : 0;
+    return last < 0 ? tb_bitcost(T, 0, p0) : cost + tail;
+}
+__device__ __forceinline__ static uint32_t pack4(const int (&p)[16], int r) { return uint32_t(p[r * 4]) | (uint32_t(p[r * 4 + 1]) << 8) | (uint32_t(p[r * 4 + 2]) << 16) | (uint32_t(p[r * 4 + 3]) << 24); }
 
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs, int nimg, const Vp8Class *classes, const uint32_t *steps, const uint32_t *items, uint8_t *work,
-                                                              int16_t *levels, Vp8FrameDev *frames, int step) {
-    CSH_SHARED MbLds s[4];
+// the macroblocks items[lo .. min(lo + 4, hi)) of one picture, a row of sixteen lanes each
+__device__ __attribute__((noinline)) static void mb_batch(MbLds (&s)[4], const MbTables &T, const WebpImg &im, Vp8FrameDev *F, const uint32_t *items, uint32_t lo, uint32_t hi, uint8_t *work, int16_t *levels) {
+    const int mbw = int(im.mbw), ys = mbw * 16, cs = mbw * 8;
     // ---- which macroblock each row of sixteen lanes works on
     LV<int> ok, vmx, vmy;
     LFOR(l) {
-        const int g = l >> 4, img = int(blockIdx.y) * 4 + g;
-        ok[l] = 0; vmx[l] = 0; vmy[l] = 0;
-        if (img < nimg) {
-            const Vp8Class c = classes[imgs[img].cls];
-            if (uint32_t(step) < c.nsteps) {
-                const uint32_t lo = steps[c.step_off + uint32_t(step)], hi = steps[c.step_off + uint32_t(step) + 1];
-                if (lo + blockIdx.x < hi) { const uint32_t it = items[c.item_off + lo + blockIdx.x]; ok[l] = 1; vmx[l] = int(it & 0xFFFFu); vmy[l] = int(it >> 16); }
-            }
-        }
+        const uint32_t it = lo + uint32_t(l >> 4);
+        ok[l] = it < hi;
+        const uint32_t xy = ok[l] ? items[it] : 0u;
+        vmx[l] = int(xy & 0xFFFFu); vmy[l] = int(xy >> 16);
     }
-    if (lballot([&](int l) { return ok[l] != 0; }) == 0) return;
 
 #define MB_PROLOGUE                                                                                                                             \
-    const int g = l >> 4, i = l & 15;                                                                                                           \
-    const WebpImg &im = imgs[int(blockIdx.y) * 4 + g < nimg ? int(blockIdx.y) * 4 + g : 0];                                                   \
-    const int mbw = int(im.mbw), ys = mbw * 16, cs = mbw * 8, mx = vmx[l], my = vmy[l];                                                          \
+    const int g = l >> 4, i = l & 15, mx = vmx[l], my = vmy[l];                                                                                 \
     const bool hl = mx > 0, ht = my > 0;                                                                                                        \
-    Vp8FrameDev *F = frames + (int(blockIdx.y) * 4 + g < nimg ? int(blockIdx.y) * 4 + g : 0);                                                   \
     int16_t *L = levels + im.lev_off + (size_t(my) * mbw + mx) * WEBP_MB_REC;                                                                    \
     uint8_t *cb = reinterpret_cast<uint8_t *>(s[g].cbw), *srcb = reinterpret_cast<uint8_t *>(s[g].srcw);                                        \
-    (void)i; (void)ys; (void)cs; (void)hl; (void)ht; (void)F; (void)L; (void)cb; (void)srcb
+    (void)i; (void)hl; (void)ht; (void)L; (void)cb; (void)srcb
 
     // ---- source samples, the edges of the reconstruction, the neighbours' contexts
     LV<int> segv;
@@ -530,13 +532,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
         if (ok[l]) {
             MB_PROLOGUE;
             const uint8_t *sy = work + im.y_off + size_t(my * 16) * ys + mx * 16, *ry = work + im.ry_off + size_t(my * 16) * ys + mx * 16;
-            CSH_UNROLL
-            for (int k = 0; k < 4; k++) s[g].srcw[i * 4 + k] = *reinterpret_cast<const uint32_t *>(sy + size_t(i) * ys + k * 4);
+            const uint4 row = *reinterpret_cast<const uint4 *>(sy + size_t(i) * ys);
+            s[g].srcw[i * 4] = row.x; s[g].srcw[i * 4 + 1] = row.y; s[g].srcw[i * 4 + 2] = row.z; s[g].srcw[i * 4 + 3] = row.w;
             {
                 const int pl = i >> 3, r = i & 7;
                 const uint8_t *sc = work + (pl ? im.v_off : im.u_off) + size_t(my * 8 + r) * cs + mx * 8, *rc = work + (pl ? im.rv_off : im.ru_off) + size_t(my * 8) * cs + mx * 8;
-                s[g].csrcw[pl][r * 2] = *reinterpret_cast<const uint32_t *>(sc);
-                s[g].csrcw[pl][r * 2 + 1] = *reinterpret_cast<const uint32_t *>(sc + 4);
+                const uint2 crow = *reinterpret_cast<const uint2 *>(sc);
+                s[g].csrcw[pl][r * 2] = crow.x;
+                s[g].csrcw[pl][r * 2 + 1] = crow.y;
                 s[g].ce[pl][r] = ht ? rc[r - cs] : uint8_t(127);
                 s[g].ce[pl][8 + r] = hl ? rc[size_t(r) * cs - 1] : uint8_t(129);
                 if (r == 0) s[g].ce[pl][16] = (hl && ht) ? rc[-cs - 1] : uint8_t(0);
@@ -552,7 +555,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
     }
     CSP_WAVE_SYNC();
 
-    // ---- DC values
+    // ---- DC values; the Hadamard spectrum of every luma source block (the texture term compares it with the reconstruction's)
     LV<int> t1, t2;
     LFOR(l) {
         t1[l] = 0; t2[l] = 0;
@@ -560,6 +563,10 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
             MB_PROLOGUE;
             t1[l] = (ht ? int(cb[4 + i]) : 0) + (hl ? int(cb[(i + 1) * 32 + 3]) : 0);
             t2[l] = (ht ? int(s[g].ce[i >> 3][i & 7]) : 0) + (hl ? int(s[g].ce[i >> 3][8 + (i & 7)]) : 0);
+            int src[16];
+            CSH_UNROLL
+            for (int k = 0; k < 16; k++) src[k] = srcb[((i >> 2) * 4 + (k >> 2)) * 16 + (i & 3) * 4 + (k & 3)];
+            s[g].hsrc[i] = hadamard_w(src);
         }
     }
     const LV<int> ydc_sum = rowsum(t1), cdc_sum = halfsum(t2);   // cdc_sum: lanes 0..7 the U sum, 8..15 the V sum
@@ -571,9 +578,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
         usum[l] = __shfl(cdc_sum.v, l & 48, 64); vsum[l] = __shfl(cdc_sum.v, (l & 48) + 8, 64);
 #endif
     }
+    CSP_WAVE_SYNC();
 
     // =========================================================================================== i16: four modes, lane = luma block
-    LVA<int, 16> coef, best_lv, best_rec, best_lv2;
+    LVA<int, 8> best_lv;         // the best mode's levels of this lane's block, two to a register
+    LVA<uint32_t, 4> best_rec;   // and its reconstruction, a row to a register
     LV<int64_t> sc16;            // the best i16 candidate's score for the i16 / i4 decision (lambda_mode)
     LV<int> best16, nz16, srcflat, D16;
     {
@@ -581,7 +590,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
             best16[l] = -1; nz16[l] = 0; D16[l] = 0; sc16[l] = 0; t1[l] = 1;
             if (ok[l]) {
                 MB_PROLOGUE;
-                const uint32_t first = s[g].srcw[0] & 255u, rep = first * 0x01010101u;
+                const uint32_t rep = (s[g].srcw[0] & 255u) * 0x01010101u;
                 int same = 1;
                 CSH_UNROLL
                 for (int k = 0; k < 4; k++) same &= s[g].srcw[(((i >> 2) * 4 + k) * 4) + (i & 3)] == rep;
@@ -593,6 +602,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
         LV<int64_t> best_score;
         LFOR(l) best_score[l] = 0;
         for (int mode = 0; mode < 4; mode++) {
+            LVA<int, 16> coef;
             LFOR(l) if (ok[l]) {
                 MB_PROLOGUE;
                 const int bx = i & 3, by = i >> 2;
@@ -606,15 +616,17 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 s[g].dcs[i] = coef[l][0];
             }
             CSP_WAVE_SYNC();
-            LVA<int, 16> lv, rec, lv2;
+            LVA<int, 16> lv;
+            LVA<uint32_t, 4> rec4;
+            LVA<int, 16> lv2;
             LV<int> vD, vSD, vnz, vnz2;
             LFOR(l) {
                 vD[l] = 0; vSD[l] = 0; vnz[l] = 0; vnz2[l] = 0;
                 if (ok[l]) {
                     MB_PROLOGUE;
                     const int bx = i & 3, by = i >> 2;
-                    const Vp8SegDev &S = F->seg[segv[l]];
-                    int dcs[16], y2[16], top[4], left[4], pred[16], src[16];
+                    const Vp8SegDev &S = T.seg[segv[l]];
+                    int dcs[16], y2[16], top[4], left[4], pred[16], src[16], rec[16];
                     CSH_UNROLL
                     for (int k = 0; k < 16; k++) dcs[k] = s[g].dcs[k];
                     fwht(dcs, y2);
@@ -629,14 +641,15 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                     CSH_UNROLL
                     for (int k = 0; k < 4; k++) { top[k] = cb[4 + bx * 4 + k]; left[k] = cb[(by * 4 + k + 1) * 32 + 3]; }
                     pred_block(mode, top, left, cb[3], dc_value(ydc_sum[l], hl, ht, 16), hl, ht, pred);
-                    idct4_add(coef[l], pred, rec[l]);
+                    idct4_add(coef[l], pred, rec);
                     CSH_UNROLL
                     for (int k = 0; k < 16; k++) src[k] = srcb[(by * 4 + (k >> 2)) * 16 + bx * 4 + (k & 3)];
-                    vD[l] = sse16(src, rec[l]);
-                    vSD[l] = iabs(hadamard_w(rec[l]) - hadamard_w(src)) >> 5;
+                    vD[l] = sse16(src, rec);
+                    vSD[l] = iabs(hadamard_w(rec) - s[g].hsrc[i]) >> 5;
+                    CSH_UNROLL
+                    for (int r = 0; r < 4; r++) rec4[l][r] = pack4(rec, r);
                 }
             }
-            CSP_WAVE_SYNC();
             const uint64_t nzb = lballot([&](int l) { return vnz[l] != 0; });
             LV<int> vR;
             LFOR(l) {
@@ -646,14 +659,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                     const uint32_t cur = (uint32_t((nzb >> (l & 48)) & 0xFFFFu) << 1);
                     int type, first, ctx;
                     block_info(1 + i, cur, topm[l], leftm[l], false, type, first, ctx);
-                    vR[l] = residual_cost(F, type, first, ctx, lv[l]);
-                    if (i == 0) { block_info(0, cur, topm[l], leftm[l], false, type, first, ctx); vR[l] += residual_cost(F, type, first, ctx, lv2[l]); }
+                    vR[l] = block_cost(T, type, first, ctx, lv[l]);
+                    if (i == 0) { block_info(0, cur, topm[l], leftm[l], false, type, first, ctx); vR[l] += block_cost(T, type, first, ctx, lv2[l]); }
                 }
             }
             const LV<int> sD = rowsum(vD), sSD = rowsum(vSD), sR = rowsum(vR);
             LFOR(l) if (ok[l]) {
                 MB_PROLOGUE;
-                const Vp8SegDev &S = F->seg[segv[l]];
+                const Vp8SegDev &S = T.seg[segv[l]];
                 const uint32_t acnz = uint32_t((nzb >> (l & 48)) & 0xFFFFu);
                 int64_t D = sD[l], SD = S.tlambda ? (int64_t(S.tlambda) * sSD[l] + 128) >> 8 : 0;
                 if (srcflat[l]) { srcflat[l] = acnz == 0; if (srcflat[l]) { D *= 2; SD *= 2; } }   // a flat source whose levels are flat too: distortion counts double
@@ -664,39 +677,44 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                     D16[l] = int(D);
                     sc16[l] = RH * S.lambda_mode + 256 * (D + SD);
                     CSH_UNROLL
-                    for (int k = 0; k < 16; k++) { best_lv[l][k] = lv[l][k]; best_rec[l][k] = rec[l][k]; best_lv2[l][k] = lv2[l][k]; }
+                    for (int k = 0; k < 8; k++) best_lv[l][k] = (lv[l][2 * k] & 0xFFFF) | (lv[l][2 * k + 1] << 16);
+                    CSH_UNROLL
+                    for (int r = 0; r < 4; r++) best_rec[l][r] = rec4[l][r];
+                    int mine = 0;
+                    CSH_UNROLL
+                    for (int k = 0; k < 16; k++) mine = i == k ? lv2[l][k] : mine;
+                    s[g].y2best[i] = int16_t(mine);
                 }
             }
+            CSP_WAVE_SYNC();
         }
         // only DCs, yet distorted: blocky -> remember the step for the loop filter (oracle: max_edge)
         LFOR(l) if (ok[l] && (l & 15) == 0) {
             MB_PROLOGUE;
-            Vp8SegDev &S = F->seg[segv[l]];
+            const Vp8SegDev &S = T.seg[segv[l]];
             if ((uint32_t(nz16[l]) & 0x100ffffu) == 0x1000000u && D16[l] > S.min_disto) {
-                const int v0 = iabs(best_lv2[l][1]), v1 = iabs(best_lv2[l][2]), v2 = iabs(best_lv2[l][4]);
+                const int v0 = iabs(s[g].y2best[1]), v1 = iabs(s[g].y2best[2]), v2 = iabs(s[g].y2best[4]);
                 int m = v1 > v0 ? v1 : v0;
                 if (v2 > m) m = v2;
-                atomicMax(&S.max_edge, m);
+                atomicMax(&F->seg[segv[l]].max_edge, m);
             }
         }
     }
 
     // =========================================================================================== i4: sixteen sub-blocks in order, lane = mode
     LV<int> use4, live4, hbits;
-    LV<int64_t> sc4, D4;     // running i4 score (lambda_mode) and its parts are only needed as the score
+    LV<int64_t> sc4;     // running i4 score (lambda_mode)
     {
         LFOR(l) {
-            use4[l] = 0; live4[l] = ok[l]; hbits[l] = 0; sc4[l] = 0; D4[l] = 0;
-            if (ok[l]) {
-                MB_PROLOGUE;
-                const Vp8SegDev &S = F->seg[segv[l]];
-                sc4[l] = int64_t(211) * S.lambda_mode;   // the cost of the "not i16" flag
-            }
+            use4[l] = 0; live4[l] = ok[l]; hbits[l] = 0; sc4[l] = 0;
+            if (ok[l]) sc4[l] = int64_t(211) * T.seg[segv[l]].lambda_mode;   // the cost of the "not i16" flag
         }
         for (int k = 0; k < 16; k++) {
             const int bx = k & 3, by = k >> 2;
+            if (lballot([&](int l) { return live4[l] != 0; }) == 0) break;
             LV<uint64_t> key;
-            LVA<int, 16> lv, rec;
+            LVA<int, 16> lv;
+            LVA<uint32_t, 4> rec4;
             LV<int> vD, vSD, vR, vH, vnz;
             LFOR(l) if (live4[l] && (l & 15) < 13) {
                 MB_PROLOGUE;
@@ -709,9 +727,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 if (live4[l] && (l & 15) < 10) {
                     MB_PROLOGUE;
                     const int mode = i;
-                    const Vp8SegDev &S = F->seg[segv[l]];
+                    const Vp8SegDev &S = T.seg[segv[l]];
                     const uint8_t *e = s[g].e;
-                    int pred[16], dd[16], c[16], src[16];
+                    int pred[16], dd[16], c[16], src[16], rec[16];
                     if (mode == 0) {
                         const int v = (int(e[5]) + e[6] + e[7] + e[8] + e[3] + e[2] + e[1] + e[0] + 4) >> 3;
                         CSH_UNROLL
@@ -730,9 +748,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                     for (int t = 0; t < 16; t++) { src[t] = srcb[(by * 4 + (t >> 2)) * 16 + bx * 4 + (t & 3)]; dd[t] = src[t] - pred[t]; }
                     fdct4(dd, c);
                     vnz[l] = quant_block<true>(c, lv[l], load_qm(S, 0));
-                    idct4_add(c, pred, rec[l]);
-                    vD[l] = sse16(src, rec[l]);
-                    vSD[l] = S.tlambda ? (S.tlambda * (iabs(hadamard_w(rec[l]) - hadamard_w(src)) >> 5) + 128) >> 8 : 0;
+                    idct4_add(c, pred, rec);
+                    vD[l] = sse16(src, rec);
+                    vSD[l] = S.tlambda ? (S.tlambda * (iabs(hadamard_w(rec) - s[g].hsrc[k]) >> 5) + 128) >> 8 : 0;
+                    CSH_UNROLL
+                    for (int r = 0; r < 4; r++) rec4[l][r] = pack4(rec, r);
                     const int tmode = by ? int(s[g].bm[k - 4]) : (ht ? int((L - size_t(mbw) * WEBP_MB_REC)[MB_INFO + 4 + 12 + bx]) : 0);
                     const int lmode = bx ? int(s[g].bm[k - 1]) : (hl ? int((L - WEBP_MB_REC)[MB_INFO + 4 + by * 4 + 3]) : 0);
                     vH[l] = kVp8FixedCostsI4[(tmode * 10 + lmode) * 10 + mode];
@@ -741,7 +761,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                     for (int t = 1; t < 16; t++) nzac += lv[l][t] != 0;
                     int R = (mode > 0 && nzac <= 3) ? 140 : 0;   // flatness penalty: a flat block should not be predicted by a complex mode
                     const int tctx = by ? int(s[g].nz4[k - 4]) : int((topm[l] >> (13 + bx)) & 1u), lctx = bx ? int(s[g].nz4[k - 1]) : int((leftm[l] >> (4 + by * 4)) & 1u);
-                    R += residual_cost(F, 3, 0, tctx + lctx, lv[l]);
+                    R += block_cost(T, 3, 0, tctx + lctx, lv[l]);
                     vR[l] = R;
                     const int64_t score = int64_t(R + vH[l]) * S.lambda_i4 + 256 * int64_t(vD[l] + vSD[l]);
                     key[l] = (uint64_t(score) << 4) | uint64_t(mode);
@@ -751,8 +771,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
             LFOR(l) if (live4[l] && key[l] == best[l] && key[l] != ~0ull) {
                 MB_PROLOGUE;
                 CSH_UNROLL
-                for (int r = 0; r < 4; r++)
-                    s[g].cbw[(by * 4 + r + 1) * 8 + 1 + bx] = uint32_t(rec[l][r * 4]) | (uint32_t(rec[l][r * 4 + 1]) << 8) | (uint32_t(rec[l][r * 4 + 2]) << 16) | (uint32_t(rec[l][r * 4 + 3]) << 24);
+                for (int r = 0; r < 4; r++) s[g].cbw[(by * 4 + r + 1) * 8 + 1 + bx] = rec4[l][r];
                 CSH_UNROLL
                 for (int t = 0; t < 16; t++) s[g].lv4[k][t] = int16_t(lv[l][t]);
                 s[g].bm[k] = uint8_t(i);
@@ -761,8 +780,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
             }
             CSP_WAVE_SYNC();
             LFOR(l) if (live4[l]) {
-                MB_PROLOGUE;
-                const Vp8SegDev &S = F->seg[segv[l]];
+                const int g = l >> 4;
+                const Vp8SegDev &S = T.seg[segv[l]];
                 sc4[l] += int64_t(s[g].win[2] + s[g].win[3]) * S.lambda_mode + 256 * int64_t(s[g].win[0] + s[g].win[1]);
                 hbits[l] += s[g].win[3];
                 if (sc4[l] >= sc16[l] || hbits[l] > 256 * 16 * 16) live4[l] = 0;
@@ -778,7 +797,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
         LV<int64_t> best_score;
         LFOR(l) { bestuv[l] = -1; nzuv[l] = 0; best_score[l] = 0; }
         for (int pass = 0; pass < 2; pass++) {
-            LVA<int, 16> c, pred, src;
+            LVA<int, 16> c, pred;
             LFOR(l) if (ok[l]) {
                 MB_PROLOGUE;
                 const int mode = pass * 2 + (i >> 3), b = i & 7, pl = b >> 2, bx = b & 1, by = (b >> 1) & 1;
@@ -786,10 +805,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 int top[4], left[4], d[16];
                 CSH_UNROLL
                 for (int k = 0; k < 4; k++) { top[k] = s[g].ce[pl][bx * 4 + k]; left[k] = s[g].ce[pl][8 + by * 4 + k]; }
-                const int csum = pl ? vsum[l] : usum[l];
-                pred_block(mode, top, left, s[g].ce[pl][16], dc_value(csum, hl, ht, 8), hl, ht, pred[l]);
+                pred_block(mode, top, left, s[g].ce[pl][16], dc_value(pl ? vsum[l] : usum[l], hl, ht, 8), hl, ht, pred[l]);
                 CSH_UNROLL
-                for (int k = 0; k < 16; k++) { src[l][k] = cs8[(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)]; d[k] = src[l][k] - pred[l][k]; }
+                for (int k = 0; k < 16; k++) d[k] = int(cs8[(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)]) - pred[l][k];
                 fdct4(d, c[l]);
                 s[g].cdc[(i >> 3) * 2 + pl][b & 3] = c[l][0];
             }
@@ -799,8 +817,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 MB_PROLOGUE;
                 const int slot4 = i >> 2, pl = slot4 & 1;    // slot4 = (mode & 1) * 2 + plane
                 if (F->diffuse) {
-                    const Vp8SegDev &S = F->seg[segv[l]];
-                    const QM m = load_qm(S, 2);
+                    const QM m = load_qm(T.seg[segv[l]], 2);
                     const int16_t *Lt = L - size_t(mbw) * WEBP_MB_REC, *Ll = L - WEBP_MB_REC;
                     const int tp0 = ht ? int(int8_t(uint16_t(Lt[MB_DERR_TOP + pl]) & 255u)) : 0, tp1 = ht ? int(int8_t(uint16_t(Lt[MB_DERR_TOP + pl]) >> 8)) : 0;
                     const int lf0 = hl ? int(int8_t(uint16_t(Ll[MB_DERR_LEFT + pl]) & 255u)) : 0, lf1 = hl ? int(int8_t(uint16_t(Ll[MB_DERR_LEFT + pl]) >> 8)) : 0;
@@ -818,18 +835,24 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 } else { s[g].cerr[slot4][0] = 0; s[g].cerr[slot4][1] = 0; s[g].cerr[slot4][2] = 0; }
             }
             CSP_WAVE_SYNC();
-            LVA<int, 16> lv, rec;
+            LVA<int, 16> lv;
+            LVA<uint32_t, 4> rec4;
             LV<int> vD, vnz, vac;
             LFOR(l) {
                 vD[l] = 0; vnz[l] = 0; vac[l] = 0;
                 if (ok[l]) {
                     MB_PROLOGUE;
-                    const Vp8SegDev &S = F->seg[segv[l]];
-                    const int b = i & 7, pl = b >> 2;
+                    const int b = i & 7, pl = b >> 2, bx = b & 1, by = (b >> 1) & 1;
+                    const uint8_t *cs8 = reinterpret_cast<const uint8_t *>(s[g].csrcw[pl]);
+                    int rec[16], src[16];
                     c[l][0] = s[g].cdc[(i >> 3) * 2 + pl][b & 3];
-                    vnz[l] = quant_block<false>(c[l], lv[l], load_qm(S, 2));
-                    idct4_add(c[l], pred[l], rec[l]);
-                    vD[l] = sse16(src[l], rec[l]);
+                    vnz[l] = quant_block<false>(c[l], lv[l], load_qm(T.seg[segv[l]], 2));
+                    idct4_add(c[l], pred[l], rec);
+                    CSH_UNROLL
+                    for (int k = 0; k < 16; k++) src[k] = cs8[(by * 4 + (k >> 2)) * 8 + bx * 4 + (k & 3)];
+                    vD[l] = sse16(src, rec);
+                    CSH_UNROLL
+                    for (int r = 0; r < 4; r++) rec4[l][r] = pack4(rec, r);
                     int nzac = 0;
                     CSH_UNROLL
                     for (int t = 1; t < 16; t++) nzac += lv[l][t] != 0;
@@ -841,12 +864,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
             LFOR(l) {
                 vR[l] = 0;
                 if (ok[l]) {
-                    MB_PROLOGUE;
-                    const int b = i & 7;
+                    const int i = l & 15, b = i & 7;
                     const uint32_t cur = uint32_t((nzb >> ((l & 48) + (i & 8))) & 0xFFu) << 17;
                     int type, first, ctx;
                     block_info(17 + b, cur, topm[l], leftm[l], false, type, first, ctx);
-                    vR[l] = residual_cost(F, type, first, ctx, lv[l]);
+                    vR[l] = block_cost(T, type, first, ctx, lv[l]);
                 }
             }
             const LV<int> sD = halfsum(vD), sR = halfsum(vR), sAC = halfsum(vac);
@@ -854,12 +876,10 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
             LFOR(l) {
                 sc[l] = 0;
                 if (ok[l]) {
-                    MB_PROLOGUE;
-                    const Vp8SegDev &S = F->seg[segv[l]];
-                    const int mode = pass * 2 + (i >> 3);
+                    const int i = l & 15, mode = pass * 2 + (i >> 3);
                     int R = sR[l];
                     if (mode > 0 && sAC[l] <= 2) R += 140 * 8;
-                    sc[l] = int64_t(R + kVp8FixedCostsUV[mode]) * S.lambda_uv + 256 * int64_t(sD[l]);
+                    sc[l] = int64_t(R + kVp8FixedCostsUV[mode]) * T.seg[segv[l]].lambda_uv + 256 * int64_t(sD[l]);
                 }
             }
             // the better of the pass's two modes (the lower mode on a tie), then against the best so far
@@ -868,7 +888,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
 #ifdef CSH_EMUL
                 other[l] = sc.v[l ^ 8];
 #else
-                other[l] = (int64_t(__shfl(int(uint32_t(uint64_t(sc.v) >> 32)), l ^ 8, 64)) << 32) | uint32_t(__shfl(int(uint32_t(uint64_t(sc.v))), l ^ 8, 64));
+                other[l] = int64_t((uint64_t(uint32_t(__shfl(int(uint32_t(uint64_t(sc.v) >> 32)), l ^ 8, 64))) << 32) | uint32_t(__shfl(int(uint32_t(uint64_t(sc.v))), l ^ 8, 64)));
 #endif
             }
             LV<int> take;
@@ -876,9 +896,9 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                 take[l] = 0;
                 if (ok[l]) {
                     const int i = l & 15, mode = pass * 2 + (i >> 3);
-                    const int64_t lo = (i & 8) ? other[l] : sc[l], hi = (i & 8) ? sc[l] : other[l];   // scores of modes 2 pass and 2 pass + 1
-                    const int pick = hi < lo ? 1 : 0;
-                    const int64_t psc = pick ? hi : lo;
+                    const int64_t lo2 = (i & 8) ? other[l] : sc[l], hi2 = (i & 8) ? sc[l] : other[l];   // scores of modes 2 pass and 2 pass + 1
+                    const int pick = hi2 < lo2 ? 1 : 0;
+                    const int64_t psc = pick ? hi2 : lo2;
                     const int pmode = pass * 2 + pick;
                     if (bestuv[l] < 0 || psc < best_score[l]) {
                         const uint32_t rownz = uint32_t((nzb >> (l & 48)) & 0xFFFFu);
@@ -887,17 +907,13 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
                     }
                 }
             }
-            LFOR(l) if (ok[l]) {
-                MB_PROLOGUE;
-                if (take[l]) {
-                    const int b = i & 7, pl = b >> 2, bx = b & 1, by = (b >> 1) & 1;
-                    CSH_UNROLL
-                    for (int t = 0; t < 16; t++) s[g].lvuv[b][t] = int16_t(lv[l][t]);
-                    CSH_UNROLL
-                    for (int r = 0; r < 4; r++)
-                        s[g].recuv[pl][(by * 4 + r) * 2 + bx] = uint32_t(rec[l][r * 4]) | (uint32_t(rec[l][r * 4 + 1]) << 8) | (uint32_t(rec[l][r * 4 + 2]) << 16) | (uint32_t(rec[l][r * 4 + 3]) << 24);
-                    if ((b & 3) == 0) { const int slot4 = (i >> 3) * 2 + pl; s[g].derr[pl][0] = int8_t(s[g].cerr[slot4][0]); s[g].derr[pl][1] = int8_t(s[g].cerr[slot4][1]); s[g].derr[pl][2] = int8_t(s[g].cerr[slot4][2]); }
-                }
+            LFOR(l) if (ok[l] && take[l]) {
+                const int g = l >> 4, i = l & 15, b = i & 7, pl = b >> 2, bx = b & 1, by = (b >> 1) & 1;
+                CSH_UNROLL
+                for (int t = 0; t < 16; t++) s[g].lvuv[b][t] = int16_t(lv[l][t]);
+                CSH_UNROLL
+                for (int r = 0; r < 4; r++) s[g].recuv[pl][(by * 4 + r) * 2 + bx] = rec4[l][r];
+                if ((b & 3) == 0) { const int slot4 = (i >> 3) * 2 + pl; s[g].derr[pl][0] = int8_t(s[g].cerr[slot4][0]); s[g].derr[pl][1] = int8_t(s[g].cerr[slot4][1]); s[g].derr[pl][2] = int8_t(s[g].cerr[slot4][2]); }
             }
             CSP_WAVE_SYNC();
         }
@@ -908,27 +924,23 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
         MB_PROLOGUE;
         const bool i4 = use4[l] != 0;
         uint8_t *ry = work + im.ry_off + size_t(my * 16) * ys + mx * 16;
-        // luma reconstruction: lane = block (i16) / the sub-blocks' buffer (i4)
+        // luma reconstruction and levels: lane = block (i16) / the sub-blocks' buffer (i4)
         {
             const int bx = i & 3, by = i >> 2;
             CSH_UNROLL
-            for (int r = 0; r < 4; r++) {
-                const uint32_t w16 = uint32_t(best_rec[l][r * 4]) | (uint32_t(best_rec[l][r * 4 + 1]) << 8) | (uint32_t(best_rec[l][r * 4 + 2]) << 16) | (uint32_t(best_rec[l][r * 4 + 3]) << 24);
-                *reinterpret_cast<uint32_t *>(ry + size_t(by * 4 + r) * ys + bx * 4) = i4 ? s[g].cbw[(by * 4 + r + 1) * 8 + 1 + bx] : w16;
-            }
-            int16_t *o = L + (1 + i) * 16;
+            for (int r = 0; r < 4; r++) *reinterpret_cast<uint32_t *>(ry + size_t(by * 4 + r) * ys + bx * 4) = i4 ? s[g].cbw[(by * 4 + r + 1) * 8 + 1 + bx] : best_rec[l][r];
+            uint32_t *o = reinterpret_cast<uint32_t *>(L + (1 + i) * 16);
+            const uint32_t *o4 = reinterpret_cast<const uint32_t *>(s[g].lv4[i]);
             CSH_UNROLL
-            for (int t = 0; t < 16; t++) o[t] = i4 ? s[g].lv4[i][t] : int16_t(best_lv[l][t]);
-            int y2v = 0;
-            CSH_UNROLL
-            for (int t = 0; t < 16; t++) y2v = i == t ? best_lv2[l][t] : y2v;
-            L[i] = i4 ? int16_t(0) : int16_t(y2v);
+            for (int t = 0; t < 8; t++) o[t] = i4 ? o4[t] : uint32_t(best_lv[l][t]);
+            L[i] = i4 ? int16_t(0) : s[g].y2best[i];
         }
         // chroma: lanes 0..7 a block's levels; every lane two words of the reconstruction
         if (i < 8) {
-            int16_t *o = L + (17 + i) * 16;
+            uint32_t *o = reinterpret_cast<uint32_t *>(L + (17 + i) * 16);
+            const uint32_t *ouv = reinterpret_cast<const uint32_t *>(s[g].lvuv[i]);
             CSH_UNROLL
-            for (int t = 0; t < 16; t++) o[t] = s[g].lvuv[i][t];
+            for (int t = 0; t < 8; t++) o[t] = ouv[t];
         }
         {
             const int pl = i >> 3, r = i & 7;
@@ -956,7 +968,6 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_mb(const WebpImg *imgs
     }
 #undef MB_PROLOGUE
 }
-
 
 // =================================================================================================== C': statistics between chunks
 // the statistics walk of one block: every adaptive decision counted in the group's LDS counters (events and ones), and the block's number of decisions
@@ -992,20 +1003,14 @@ __device__ static void walk_mb(S &sink, const int16_t *L, int mbw, int mx, int m
     if (blk_cnt && i4) blk_cnt[0] = 0;
 }
 
-// one wave per picture.  mb_base[image]: the picture's first macroblock among the batch's; mb_cnt / blk_cnt: decisions per macroblock / block (32 slots a macroblock)
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *imgs, const Vp8Class *classes, const uint32_t *chunk_step, const uint32_t *chunk_end, const int16_t *levels,
-                                                                 Vp8FrameDev *frames, const uint64_t *mb_base, uint32_t *mb_cnt, uint16_t *blk_cnt, int step) {
-    CSH_SHARED uint32_t s_cnt[VP8_NSLOT], s_ones[VP8_NSLOT], s_list[64], s_nlist;
-    CSH_SHARED uint8_t s_coeffs[VP8_NSLOT];
-    const WebpImg im = imgs[blockIdx.x];
-    const Vp8Class c = classes[im.cls];
-    int j = -1;
-    for (uint32_t q = 0; q < c.nchunks; q++) if (chunk_step[c.chunk_off + q] == uint32_t(step)) j = int(q);
-    if (j < 0) return;
-    const int n0 = j ? int(chunk_end[c.chunk_off + uint32_t(j) - 1]) : 0, n1 = int(chunk_end[c.chunk_off + uint32_t(j)]), mbw = int(im.mbw);
-    const bool final_chunk = uint32_t(j) + 1 == c.nchunks;
-    Vp8FrameDev *F = frames + blockIdx.x;
-    const int16_t *lev = levels + im.lev_off;
+struct StatLds { uint32_t cnt[VP8_NSLOT], ones[VP8_NSLOT], list[64], nlist; };
+// macroblocks n0 .. n1 of one picture (a chunk), one wave.  mb_cnt / blk_cnt (already offset to the picture's first macroblock): decisions per macroblock / block (32 slots
+// a macroblock).  Leaves the frame's probabilities so far in T.coeffs and, when any differs from the defaults, the level-cost tables made from them in T.lc
+__device__ __attribute__((noinline)) static void chunk_stats(StatLds &A, MbTables &T, const WebpImg &im, Vp8FrameDev *F, const int16_t *lev, int n0, int n1, bool final_chunk, uint32_t *mb_cnt, uint16_t *blk_cnt) {
+    uint32_t *s_cnt = A.cnt, *s_ones = A.ones, *s_list = A.list;
+    uint32_t &s_nlist = A.nlist;
+    uint8_t *s_coeffs = T.coeffs;
+    const int mbw = int(im.mbw);
     for (int base = n0; base < n1; base += 64) {
         LFOR(l) { for (int i = l; i < VP8_NSLOT; i += 64) { s_cnt[i] = 0; s_ones[i] = 0; } if (l == 0) s_nlist = 0; }
         CSP_WAVE_SYNC();
@@ -1014,8 +1019,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *i
             if (n < n1) {
                 const int my = n / mbw, mx = n - my * mbw;
                 StatSink sink{s_cnt, s_ones, 0u};
-                walk_mb(sink, lev + size_t(n) * WEBP_MB_REC, mbw, mx, my, blk_cnt + (mb_base[blockIdx.x] + uint64_t(n)) * 32);
-                mb_cnt[mb_base[blockIdx.x] + uint64_t(n)] = sink.nd;
+                walk_mb(sink, lev + size_t(n) * WEBP_MB_REC, mbw, mx, my, blk_cnt + size_t(n) * 32);
+                mb_cnt[n] = sink.nd;
             }
         }
         CSP_WAVE_SYNC();
@@ -1085,7 +1090,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *i
     }
     CSP_WAVE_SYNC();
     const bool dirty = lballot([&](int l) { return chg[l] != 0; }) != 0;
-    if (!final_chunk) { if (dirty) make_level_costs(F, s_coeffs); return; }
+    if (dirty) make_level_costs(T.lc, s_coeffs);
+    if (!final_chunk) return;
     // after the last macroblock: blocky DC-only macroblocks ask for at least this much filtering (oracle: the max_edge loop)
     LFOR(l) if (l == 0) {
         int m = 0;
@@ -1096,6 +1102,49 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_chunk(const WebpImg *i
             if (m < S.fstrength) m = S.fstrength;
         }
         F->filter_level = m;
+    }
+}
+
+// =================================================================================================== C + C': one workgroup walks one picture
+// Two waves per picture; phase p of the loop is step p - 1 of the picture's plan (phase 0 sets the tables up): in a macroblock step wave w takes the macroblocks 4w .. 4w + 3
+// (then 8 + 4w .., for steps wider than eight), in a statistics step wave 0 brings the books, the probabilities and the level-cost tables up to date.  The tables live in
+// LDS for the whole walk; what a step leaves for the next (levels, modes, flags, reconstruction) goes through global memory, fenced at the barrier between the phases.
+// Pictures walk independently of each other: no launch per step, no lock-step between the pictures of a batch.
+union WaveLds { MbLds mb[4]; StatLds st; };
+__global__ void __launch_bounds__(2 * CSP_WAVE_THREADS, 2) k_vp8_loop(const WebpImg *imgs, const Vp8Class *classes, const uint32_t *steps, const uint32_t *items, const uint32_t *chunk_step,
+                                                                    const uint32_t *chunk_end, uint8_t *work, int16_t *levels, Vp8FrameDev *frames, const uint64_t *mb_base, uint32_t *mb_cnt,
+                                                                    uint16_t *blk_cnt, int nph) {
+    CSH_SHARED MbTables T;
+    CSH_SHARED WaveLds s[2];
+    const WebpImg im = imgs[blockIdx.x];
+    const Vp8Class cls = classes[im.cls];
+    Vp8FrameDev *F = frames + blockIdx.x;
+    const int wave = int(threadIdx.x / CSP_WAVE_THREADS);
+    CSH_PHASE_LOOP(nph) {
+        CSP_ACQUIRE_FENCE();
+        if (phase == 0) {
+            if (wave == 0) {
+                LFOR(l) {
+                    for (int i = l; i < VP8_NSLOT; i += 64) T.coeffs[i] = kVp8CoefProbs[i];
+                    for (int i = l; i < 256; i += 64) { T.fixed[i] = kVp8LevelFixedCosts[i]; T.ent[i] = kVp8EntropyCost[i]; }
+                    for (int i = l; i < int(sizeof(T.seg) / 4); i += 64) reinterpret_cast<uint32_t *>(T.seg)[i] = reinterpret_cast<const uint32_t *>(F->seg)[i];
+                }
+                make_level_costs(T.lc, kVp8CoefProbs);
+            }
+        } else if (uint32_t(phase - 1) < cls.nsteps) {
+            const uint32_t step = uint32_t(phase - 1), lo = steps[cls.step_off + step], hi = steps[cls.step_off + step + 1];
+            if (lo < hi) {
+                for (uint32_t at = lo + uint32_t(wave) * 4u; at < hi; at += 8u) mb_batch(s[wave].mb, T, im, F, items + cls.item_off, at, hi, work, levels);
+            } else if (wave == 0) {
+                int j = -1;
+                for (uint32_t q = 0; q < cls.nchunks; q++) if (chunk_step[cls.chunk_off + q] == step) j = int(q);
+                if (j >= 0) {
+                    const int n0 = j ? int(chunk_end[cls.chunk_off + uint32_t(j) - 1]) : 0, n1 = int(chunk_end[cls.chunk_off + uint32_t(j)]);
+                    chunk_stats(s[1].st, T, im, F, levels + im.lev_off, n0, n1, uint32_t(j) + 1 == cls.nchunks, mb_cnt + mb_base[blockIdx.x], blk_cnt + mb_base[blockIdx.x] * 32);
+                }
+            }
+        }
+        CSP_MEM_FENCE();
     }
 }
 
@@ -1184,10 +1233,8 @@ int launch_webp_encode(hipStream_t st, WebpImg *himgs, int nimg, WebpImg *d_imgs
         return -1;
     CSH_LAUNCH(k_vp8_analyse, dim3((max_nmb + 3) / 4, unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, d_imgs, work, levels, d_frames.p);
     CSH_LAUNCH(k_vp8_segments, dim3(unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, d_imgs, d_frames.p, d_qtabs.p);
-    for (uint32_t s = 0; s < P.nsteps; s++) {
-        if (P.width_at[s]) CSH_LAUNCH(k_vp8_mb, dim3(P.width_at[s], unsigned(nimg + 3) / 4), dim3(CSP_WAVE_THREADS), st, d_imgs, nimg, d_classes.p, d_steps.p, d_items.p, work, levels, d_frames.p, int(s));
-        if (P.stats_at[s]) CSH_LAUNCH(k_vp8_chunk, dim3(unsigned(nimg)), dim3(CSP_WAVE_THREADS), st, d_imgs, d_classes.p, d_cstep.p, d_cend.p, levels, d_frames.p, d_base.p, d_cnt.p, d_blk.p, int(s));
-    }
+    CSH_LAUNCH_PHASED(k_vp8_loop, int(P.nsteps) + 1, dim3(unsigned(nimg)), dim3(2 * CSP_WAVE_THREADS), st, d_imgs, d_classes.p, d_steps.p, d_items.p, d_cstep.p, d_cend.p, work, levels, d_frames.p,
+                      d_base.p, d_cnt.p, d_blk.p, int(P.nsteps) + 1);
     if (mid) CSH_CHECK(hipEventRecord(mid, st));
     return launch_webp_backend(st, d_imgs, himgs, nimg, levels, d_frames.p, base, d_base.p, d_cnt, d_blk.p, scratch, part_size, out, img_size, status);
 }

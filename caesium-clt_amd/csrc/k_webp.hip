@@ -166,26 +166,148 @@ __global__ void __launch_bounds__(256) k_webp_hdr(const WebpImg *imgs, const int
     if (!WRITE) cnt[at] = e.n;
 }
 
-// one lane = one chain (the token partition of picture `image`: the decisions of nmb macroblocks from macroblock `first` on; part 0xFFFFFFFF: partition 0, first / nmb its items)
+// ---- the boolean coder, a partition in many pieces.  One chain = one partition of one picture: d1 - d0 decisions.  What makes the coder serial is its range (one of
+// 128 values after every renormalisation); the low end of the interval only ADDS up.  So:
+//   k_bool_scan   per piece of BOOL_SEG decisions and for each of the 128 ranges it could start from: the range it ends with and the bits it shifts out (lanes = start ranges);
+//   k_bool_chain  per chain, piece after piece: the range and the bit position every piece really starts with (a walk through the maps);
+//   k_bool_code   ONE LANE per piece runs the coder (oracle: boolenc) from its true range, aligned to its true bit position, with a low end of 0: the bytes it
+//                 completes are its own places in the partition; what it still holds at its end, and a carry out of its first byte, go to
+//   k_bool_merge  per chain, piece after piece: the held bits of a piece are added into the first bytes of the next (the sum of the pieces' numbers IS the coder's
+//                 number), carries ripple back through the bytes already there; then the coder's closing bits.
 struct WebpChain { uint32_t image, part; uint64_t first, nmb; };
-struct BoolEncLane {   // the boolean coder (oracle: boolenc) with per-lane state.  Sixty-four of these run side by side in a wave, every lane at its own place in its own
-                       // chain, and whatever one lane branches into, the whole wave executes.  So: a decision is straight-line arithmetic (the renormalisation
-                       // shifts by 0 when none is due); the bits a decision completes stay in a 64-bit accumulator and leave on a FIXED schedule (flush() after
-                       // every fourth decision: every lane emits its zero to four complete bytes then -- the same digits the byte-at-a-time coder produces, a
-                       // carry that it would have patched into a written byte is simply added before the byte is written); and the output never READS (a carry
-                       // that does reach a written byte goes into the last one, which the lane still holds in a register)
+struct LVA4 {   // four values per lane (emulation: per lane)
+#ifdef CSH_EMUL
+    int v[64][4];
+    __device__ int (&operator[](int l))[4] { return v[l]; }
+#else
+    int v[4];
+    __device__ __forceinline__ int (&operator[](int))[4] { return v; }
+#endif
+};   // part 0: the token partition (first / nmb: macroblocks); part 0xFFFFFFFF: partition 0 (first / nmb: its items)
+enum { BOOL_SEG = 2048 };   // decisions per piece (the launcher passes it on: tests shorten it to make pieces that complete no byte at all)
+struct BoolPiece { uint32_t range, carry_front, pend; uint32_t pad; uint64_t bits0; };   // what k_bool_chain / k_bool_code leave per piece
+__device__ __forceinline__ static uint32_t bytes_after(uint64_t S) { return S ? uint32_t((S - 1) >> 3) : 0u; }   // bytes the coder has completed after S shifted bits
+__device__ __forceinline__ static int nb_after(uint64_t S) { return -8 + int(S - 8ull * bytes_after(S)); }        // and its bit count then (-7 .. 0; -8 before the first bit)
+// chain of piece `seg` (seg_start: pieces before each chain, nchains + 1 entries)
+__device__ __forceinline__ static uint32_t chain_of(const uint32_t *seg_start, uint32_t nchains, uint32_t seg) {
+    uint32_t lo = 0, hi = nchains;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_start[mid] <= seg) lo = mid; else hi = mid; }
+    return lo;
+}
+// one decision for one range: the range after it and the bits it shifts out
+__device__ __forceinline__ static void range_step(int &r, int &n, uint32_t v) {
+    const int sp = (r * int(v >> 1)) >> 8, q = (v & 1u) ? r - sp - 1 : sp, sh = __clz(uint32_t(q + 1)) - 24;
+    r = ((q + 1) << sh) - 1; n += sh;
+}
+// A wave takes FOUR pieces.  All 128 start ranges are followed through the first BOOL_WARM decisions of a piece only (two to a lane): by then they have run together into
+// a handful of distinct ranges (16 or fewer for 99 pieces in 100; measured on the configs[3] pictures), and a row of sixteen lanes carries those through the rest of the
+// piece, the four pieces side by side.  A piece with more than sixteen survivors is followed with all 128 to its end, as before.
+enum { BOOL_WARM = 128, BOOL_SLOTS = 16 };
+__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_bool_scan(const WebpChain *chains, uint32_t nchains, const uint32_t *seg_start, const uint64_t *mb_off, const uint16_t *stream, uint32_t *maps, uint32_t seglen) {
+    CSH_SHARED uint32_t s_owner[4][256];        // per piece: the first start range (0..127) that arrived at each range
+    CSH_SHARED uint32_t s_slot[4][256];         // per piece: range -> slot
+    CSH_SHARED uint32_t s_res[4][BOOL_SLOTS];   // per piece and slot: range | bits << 8 after the rest of the piece
+    CSH_SHARED uint32_t s_rng[4][BOOL_SLOTS];   // per piece and slot: the range it stands for after the warm-up
+    const uint32_t nseg = seg_start[nchains], seg0 = blockIdx.x * 4u;
+    if (seg0 >= nseg) return;
+    LVA4 r0, r1, n0, n1;
+    uint64_t dbeg[4], dend[4];
+    uint32_t nslots[4];
+    CSH_UNROLL
+    for (int g = 0; g < 4; g++) {
+        const uint32_t seg = seg0 + uint32_t(g);
+        dbeg[g] = 0; dend[g] = 0; nslots[g] = 0;
+        LFOR(l) { r0[l][g] = 127 + l; r1[l][g] = 191 + l; n0[l][g] = 0; n1[l][g] = 0; }
+        if (seg >= nseg) continue;
+        const uint32_t c = chain_of(seg_start, nchains, seg);
+        const WebpChain ch = chains[c];
+        const uint64_t d0 = mb_off[ch.first] + uint64_t(seg - seg_start[c]) * seglen, de = mb_off[ch.first + ch.nmb], d1 = d0 + seglen < de ? d0 + seglen : de;
+        const uint64_t dw = d0 + BOOL_WARM < d1 ? d0 + BOOL_WARM : d1;
+        for (uint64_t d = d0; d < dw; d++) {
+            const uint32_t v = stream[d];
+            LFOR(l) { range_step(r0[l][g], n0[l][g], v); range_step(r1[l][g], n1[l][g], v); }
+        }
+        dbeg[g] = dw; dend[g] = d1;
+        // the distinct ranges among the 128: the lowest start range that reached each one owns it
+        LFOR(l) for (int i = l; i < 256; i += 64) s_owner[g][i] = 0xFFFFFFFFu;
+        CSP_WAVE_SYNC();
+        LFOR(l) { atomicMin(&s_owner[g][r0[l][g]], uint32_t(l)); atomicMin(&s_owner[g][r1[l][g]], uint32_t(64 + l)); }
+        CSP_WAVE_SYNC();
+        const uint64_t own0 = lballot([&](int l) { return s_owner[g][r0[l][g]] == uint32_t(l); }), own1 = lballot([&](int l) { return s_owner[g][r1[l][g]] == uint32_t(64 + l); });
+        nslots[g] = csh::popc64(own0) + csh::popc64(own1);
+        LFOR(l) {
+            if ((own0 >> l) & 1u) { const uint32_t k = csh::popc64(own0 & lanes_below(l)); s_slot[g][r0[l][g]] = k; if (k < BOOL_SLOTS) s_rng[g][k] = uint32_t(r0[l][g]); }
+            if ((own1 >> l) & 1u) { const uint32_t k = csh::popc64(own0) + csh::popc64(own1 & lanes_below(l)); s_slot[g][r1[l][g]] = k; if (k < BOOL_SLOTS) s_rng[g][k] = uint32_t(r1[l][g]); }
+        }
+        CSP_WAVE_SYNC();
+    }
+    // the rest of the four pieces side by side: lane (g, k) carries the range of slot k of piece g
+    {
+        LV<int> r, n;
+        LV<uint64_t> d, de;
+        LFOR(l) {
+            const int g = l >> 4, k = l & 15;
+            r[l] = 127; n[l] = 0; d[l] = 0; de[l] = 0;
+            if (uint32_t(k) < nslots[g] && nslots[g] <= BOOL_SLOTS) {
+                r[l] = int(s_rng[g][k]);
+                d[l] = dbeg[g]; de[l] = dend[g];
+            }
+        }
+        for (;;) {
+            if (lballot([&](int l) { return d[l] < de[l]; }) == 0) break;
+            LFOR(l) if (d[l] < de[l]) { range_step(r[l], n[l], stream[d[l]]); d[l]++; }
+        }
+        LFOR(l) { const int g = l >> 4, k = l & 15; s_res[g][k] = uint32_t(r[l]) | (uint32_t(n[l]) << 8); }
+        CSP_WAVE_SYNC();
+    }
+    CSH_UNROLL
+    for (int g = 0; g < 4; g++) {
+        const uint32_t seg = seg0 + uint32_t(g);
+        if (seg >= nseg) continue;
+        if (nslots[g] > BOOL_SLOTS) {   // too many survivors: all 128 to the end
+            for (uint64_t d = dbeg[g]; d < dend[g]; d++) {
+                const uint32_t v = stream[d];
+                LFOR(l) { range_step(r0[l][g], n0[l][g], v); range_step(r1[l][g], n1[l][g], v); }
+            }
+            LFOR(l) { maps[size_t(seg) * 128 + l] = uint32_t(r0[l][g]) | (uint32_t(n0[l][g]) << 8); maps[size_t(seg) * 128 + 64 + l] = uint32_t(r1[l][g]) | (uint32_t(n1[l][g]) << 8); }
+        } else
+            LFOR(l) {
+                const uint32_t a = s_res[g][s_slot[g][r0[l][g]]], b2 = s_res[g][s_slot[g][r1[l][g]]];
+                maps[size_t(seg) * 128 + l] = (a & 255u) | (((a >> 8) + uint32_t(n0[l][g])) << 8);
+                maps[size_t(seg) * 128 + 64 + l] = (b2 & 255u) | (((b2 >> 8) + uint32_t(n1[l][g])) << 8);
+            }
+    }
+}
+__global__ void __launch_bounds__(64) k_bool_chain(uint32_t nchains, const uint32_t *seg_start, const uint32_t *maps, BoolPiece *pieces, uint64_t *chain_bits) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    uint32_t r = 254;
+    uint64_t bits = 0;
+    for (uint32_t seg = seg_start[c]; seg < seg_start[c + 1]; seg++) {
+        pieces[seg].range = r; pieces[seg].bits0 = bits;
+        const uint32_t m = maps[size_t(seg) * 128 + (r - 127)];
+        r = m & 255u; bits += m >> 8;
+    }
+    chain_bits[2 * c] = bits; chain_bits[2 * c + 1] = r;
+}
+struct BoolEncLane {   // the boolean coder (oracle: boolenc) with per-lane state.  Sixty-four of these run side by side in a wave, every lane at its own place, and whatever one lane
+                       // branches into, the whole wave executes.  So: a decision is straight-line arithmetic (the renormalisation shifts by 0 when none is due); the bits a
+                       // decision completes stay in a 64-bit accumulator and leave on a FIXED schedule (flush() after every fourth decision: every lane emits its zero to
+                       // four complete bytes then -- the same digits the byte-at-a-time coder produces, a carry that it would have patched into a written byte is simply
+                       // added before the byte is written); and the output never READS (a carry that does reach a written byte goes into the last one, which the lane
+                       // still holds in a register; one that would reach in front of the piece's first byte is left to k_bool_merge)
     uint8_t *buf;
-    uint32_t pos, cap;
+    uint32_t pos, first, cap;
     int32_t range;
     uint64_t value;
     int run, nb_bits;
-    uint32_t last;
+    uint32_t last, carry_front;
     bool overflow;
-    __device__ __forceinline__ void init(uint8_t *b, uint32_t c) { buf = b; pos = 0; cap = c; run = 0; nb_bits = -8; overflow = false; range = 254; value = 0; last = 0; }
+    __device__ __forceinline__ void init(uint8_t *b, uint32_t c, int r, int nb, uint32_t at) { buf = b; pos = at; first = at; cap = c; run = 0; nb_bits = nb; overflow = false; range = r; value = 0; last = 0; carry_front = 0; }
     __device__ __forceinline__ void emit(uint32_t bits) {   // eight bits and a carry
         if ((bits & 0xffu) != 0xffu) {
             if (pos + uint32_t(run) + 1 > cap) { overflow = true; run = 0; nb_bits = -8; value = 0; return; }
-            if ((bits & 0x100u) && pos > 0) { last = (last + 1u) & 0xffu; buf[pos - 1] = uint8_t(last); }   // (the byte in front of a run of 0xff is never 0xff itself)
+            if (bits & 0x100u) { if (pos > first) { last = (last + 1u) & 0xffu; buf[pos - 1] = uint8_t(last); } else carry_front = 1; }   // (the byte in front of a run of 0xff is never 0xff itself)
             const uint8_t v = (bits & 0x100u) ? 0x00 : 0xff;
             for (int k = 0; k < run; k++) buf[pos + uint32_t(k)] = v;
             last = bits & 0xffu;
@@ -212,28 +334,27 @@ struct BoolEncLane {   // the boolean coder (oracle: boolenc) with per-lane stat
         value <<= shift;
         nb_bits += shift;
     }
-    __device__ __forceinline__ void finish() {
-        flush();
-        for (int n = 9 - nb_bits; n > 0 && !overflow; n--) { put(0, 128); flush(); }
-        if (overflow) return;
-        nb_bits = 0;
-        const uint32_t bits = uint32_t(value >> 8);   // the last byte, as the byte-at-a-time coder flushes it (nb_bits = 0: s = 8)
-        value -= uint64_t(bits) << 8;
-        nb_bits = -8;
-        emit(bits);
+    __device__ __forceinline__ void settle() {   // the 0xff bytes held back for a carry that did not come inside this piece: written as they are
+        if (pos + uint32_t(run) > cap) { overflow = true; run = 0; return; }
+        for (int k = 0; k < run; k++) buf[pos + uint32_t(k)] = 0xff;
+        pos += uint32_t(run); run = 0;
     }
 };
-__global__ void __launch_bounds__(64) k_webp_bool(const WebpImg *imgs, const WebpChain *chains, uint32_t nchains, const uint64_t *mb_off, const uint16_t *stream, uint8_t *scratch,
-                                                  uint32_t *part_size, const uint32_t *status) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchains) return;
+__global__ void __launch_bounds__(64) k_bool_code(const WebpImg *imgs, const WebpChain *chains, uint32_t nchains, const uint32_t *seg_start, const uint64_t *mb_off, const uint16_t *stream,
+                                                  uint8_t *scratch, BoolPiece *pieces, uint32_t *part_size, const uint32_t *status, uint32_t seglen) {
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= seg_start[nchains]) return;
+    const uint32_t c = chain_of(seg_start, nchains, seg);
     const WebpChain ch = chains[c];
-    const WebpImg &im = imgs[ch.image];   // (chains are listed per WebpImg entry)
+    const WebpImg &im = imgs[ch.image];
     if (status[im.image]) return;
-    BoolEncLane e;
     const bool header = ch.part == 0xFFFFFFFFu;
-    if (header) e.init(scratch + im.out_off, webp_hdr_cap(im)); else e.init(scratch + im.out_off + webp_hdr_cap(im), webp_part_cap(im));
-    const uint64_t d0 = mb_off[ch.first], d1 = mb_off[ch.first + ch.nmb];
+    uint8_t *base = header ? scratch + im.out_off : scratch + im.out_off + webp_hdr_cap(im);
+    const uint32_t cap = header ? webp_hdr_cap(im) : webp_part_cap(im);
+    const uint64_t B0 = pieces[seg].bits0;
+    BoolEncLane e;
+    e.init(base, cap, int(pieces[seg].range), B0 ? nb_after(B0) : -8, bytes_after(B0));
+    const uint64_t d0 = mb_off[ch.first] + uint64_t(seg - seg_start[c]) * seglen, dend = mb_off[ch.first + ch.nmb], d1 = d0 + seglen < dend ? d0 + seglen : dend;
     // eight decisions to a 16-byte load, the next load in flight while these are coded (a lane's loads are its own: nothing hides their latency but this)
     uint64_t d = d0;
     for (; d < d1 && (d & 7u) && !e.overflow; d++) { const uint32_t v = stream[d]; e.put(int(v & 1u), int(v >> 1)); e.flush(); }
@@ -252,8 +373,83 @@ __global__ void __launch_bounds__(64) k_webp_bool(const WebpImg *imgs, const Web
         }
     }
     for (; d < d1 && !e.overflow; d++) { const uint32_t v = stream[d]; e.put(int(v & 1u), int(v >> 1)); e.flush(); }
-    e.finish();
-    part_size[size_t(im.image) * 2 + (header ? 0u : 1u)] = e.overflow ? 0xFFFFFFFFu : e.pos;
+    e.flush();
+    e.settle();
+    pieces[seg].carry_front = e.carry_front;
+    pieces[seg].pend = uint32_t(e.value);
+    if (e.overflow) part_size[size_t(im.image) * 2 + (header ? 0u : 1u)] = 0xFFFFFFFFu;
+}
+// one lane per chain.  Piece p held `pend` at its end: had piece p + 1 started with it instead of 0, its number would be larger by pend << (bits it shifts): that lands in the
+// first two bytes piece p + 1 completed (it shifts at least 16 + nb bits when it completes two), or -- a piece that completed fewer -- partly in what it holds itself
+__global__ void __launch_bounds__(64) k_bool_merge(const WebpImg *imgs, const WebpChain *chains, uint32_t nchains, const uint32_t *seg_start, const BoolPiece *pieces, const uint64_t *chain_bits,
+                                                   uint8_t *scratch, uint32_t *part_size, const uint32_t *status) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchains) return;
+    const WebpChain ch = chains[c];
+    const WebpImg &im = imgs[ch.image];
+    if (status[im.image]) return;
+    const bool header = ch.part == 0xFFFFFFFFu;
+    uint32_t *size_out = part_size + size_t(im.image) * 2 + (header ? 0u : 1u);
+    if (*size_out == 0xFFFFFFFFu) return;   // a piece ran out of room
+    uint8_t *buf = header ? scratch + im.out_off : scratch + im.out_off + webp_hdr_cap(im);
+    const uint32_t cap = header ? webp_hdr_cap(im) : webp_part_cap(im);
+    auto ripple = [&](uint32_t at_plus_1, uint32_t cy) {   // add cy to the byte in front of at_plus_1 and carry on backwards
+        for (uint32_t q = at_plus_1; cy && q > 0; q--) { const uint32_t t = uint32_t(buf[q - 1]) + cy; buf[q - 1] = uint8_t(t); cy = t >> 8; }
+    };
+    uint64_t v = 0;
+    const uint32_t s0 = seg_start[c], s1 = seg_start[c + 1];
+    for (uint32_t seg = s0; seg < s1; seg++) {
+        const uint64_t B0 = pieces[seg].bits0, B1 = seg + 1 < s1 ? pieces[seg + 1].bits0 : chain_bits[2 * c];
+        const uint32_t E0 = bytes_after(B0), k = bytes_after(B1) - E0;
+        const int nb0 = B0 ? nb_after(B0) : -8, w_end = 16 + (B1 ? nb_after(B1) : -8);
+        if (pieces[seg].carry_front) ripple(E0, 1);
+        const uint64_t pend = pieces[seg].pend;
+        if (!v) { v = pend; continue; }
+        if (k >= 2) {
+            const uint64_t add = v << (-nb0);   // at most 17 bits: two bytes and a carry
+            uint32_t t = uint32_t(buf[E0 + 1]) + uint32_t(add & 0xffu);
+            buf[E0 + 1] = uint8_t(t);
+            t = uint32_t(buf[E0]) + uint32_t((add >> 8) & 0xffu) + (t >> 8);
+            buf[E0] = uint8_t(t);
+            ripple(E0, (t >> 8) + uint32_t(add >> 16));
+            v = pend;
+        } else {
+            const uint64_t total = (v << (B1 - B0)) + pend;
+            if (k == 1) {
+                const uint64_t em = total >> w_end;
+                const uint32_t t = uint32_t(buf[E0]) + uint32_t(em & 0xffu);
+                buf[E0] = uint8_t(t);
+                ripple(E0, (t >> 8) + uint32_t(em >> 8));
+                v = total & ((1ull << w_end) - 1ull);
+            } else
+                v = total;
+        }
+    }
+    // the coder's closing bits from its real state (oracle: be_finish): 9 - nb_bits zero bits at even odds, then the last byte
+    const uint64_t S = chain_bits[2 * c];
+    uint32_t pos = bytes_after(S);
+    int32_t range = int32_t(chain_bits[2 * c + 1]), nb_bits = S ? nb_after(S) : -8;
+    uint64_t value = v;
+    bool overflow = false;
+    auto out_byte = [&](uint32_t bits) {
+        if (pos + 1 > cap) { overflow = true; return; }
+        buf[pos] = uint8_t(bits);
+        ripple(pos, bits >> 8);
+        pos++;
+    };
+    for (int n = 9 - nb_bits; n > 0; n--) {
+        const int32_t split = range >> 1;
+        range = split;
+        if (range < 127) { const int shift = __clz(uint32_t(range + 1)) - 24; range = ((range + 1) << shift) - 1; value <<= shift; nb_bits += shift; }
+        if (nb_bits > 0) { const int s = 8 + nb_bits; const uint32_t bits = uint32_t(value >> s); value -= uint64_t(bits) << s; nb_bits -= 8; out_byte(bits); }
+    }
+    { const uint32_t bits = uint32_t(value >> 8); out_byte(bits); }
+    *size_out = overflow ? 0xFFFFFFFFu : pos;
+}
+// where every chain's decisions begin and end (for the host: it lays the pieces out)
+__global__ void k_chain_bounds(const WebpChain *chains, uint32_t nchains, const uint64_t *mb_off, uint64_t *bounds) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nchains) { bounds[2 * c] = mb_off[chains[c].first]; bounds[2 * c + 1] = mb_off[chains[c].first + chains[c].nmb]; }
 }
 // the file: RIFF / WEBP / "VP8 " headers (the chunk size counts the padding byte, as libwebp writes it), frame tag, start code, dimensions, the two partitions
 __global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, const uint8_t *scratch, const uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {
@@ -313,12 +509,34 @@ int launch_webp_backend(hipStream_t st, const WebpImg *imgs, const WebpImg *himg
     const dim3 items((max_items + 255) / 256, unsigned(nimg));
     CSH_LAUNCH(k_webp_hdr<false>, items, dim3(256), st, imgs, levels, frames, d_hbase.p, d_cnt.p, d_off.p, d_stream.p, status);
     csh::launch_exclusive_scan(st, d_cnt.p, d_off.p, nall, d_tmp.p, tmp_bytes + 64);
+    const uint32_t nchains = uint32_t(chains.size());
+    csh::DevBuf<uint64_t> d_bounds, d_cbits;
+    if (d_bounds.alloc(2 * size_t(nchains) + 2) || d_cbits.alloc(2 * size_t(nchains) + 2)) return -1;
+    CSH_LAUNCH(k_chain_bounds, dim3((nchains + 255) / 256), dim3(256), st, d_chains.p, nchains, d_off.p, d_bounds.p);
+    std::vector<uint64_t> bounds(2 * size_t(nchains));
+    if (csh_copy_wait(bounds.data(), d_bounds.p, bounds.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    const char *sl = getenv("CSH_TEST_BOOL_SEG");   // test hook: shorter pieces
+    const uint32_t seglen = sl && atoi(sl) > 0 ? uint32_t(atoi(sl)) : uint32_t(BOOL_SEG);
     uint64_t total = 0;
-    if (csh_copy_wait(&total, d_off.p + nall, sizeof total, hipMemcpyDeviceToHost, st) != hipSuccess || d_stream.alloc(size_t(total) + 64)) return -1;
+    std::vector<uint32_t> seg_start(size_t(nchains) + 1, 0);
+    for (uint32_t c = 0; c < nchains; c++) {
+        total = std::max(total, bounds[2 * c + 1]);
+        seg_start[c + 1] = seg_start[c] + uint32_t((bounds[2 * c + 1] - bounds[2 * c] + seglen - 1) / seglen);
+    }
+    const uint32_t nseg = seg_start[nchains];
+    csh::DevBuf<uint32_t> d_seg_start, d_maps;
+    csh::DevBuf<BoolPiece> d_pieces;
+    if (d_stream.alloc(size_t(total) + 64) || d_seg_start.upload(seg_start, st) || d_maps.alloc(size_t(nseg) * 128 + 128) || d_pieces.alloc(size_t(nseg) + 1)) return -1;
+    CSH_CHECK(hipMemsetAsync(part_size, 0, size_t(nimg) * 2 * sizeof(uint32_t), st));
     CSH_LAUNCH(k_webp_decisions, dim3(max_mbh, nimg), dim3(CSP_WAVE_THREADS), st, imgs, levels, frames, d_base, d_off.p, d_blk, d_stream.p, status);
     CSH_LAUNCH(k_webp_hdr<true>, items, dim3(256), st, imgs, levels, frames, d_hbase.p, d_cnt.p, d_off.p, d_stream.p, status);
-    const uint32_t nchains = uint32_t(chains.size());
-    CSH_LAUNCH(k_webp_bool, dim3((nchains + 63) / 64), dim3(64), st, imgs, d_chains.p, nchains, d_off.p, d_stream.p, scratch, part_size, status);
+    if (!nseg) { csh_set_error("webp: empty decision streams"); return -1; }
+    {
+        CSH_LAUNCH(k_bool_scan, dim3((nseg + 3) / 4), dim3(CSP_WAVE_THREADS), st, d_chains.p, nchains, d_seg_start.p, d_off.p, d_stream.p, d_maps.p, seglen);
+        CSH_LAUNCH(k_bool_chain, dim3((nchains + 63) / 64), dim3(64), st, nchains, d_seg_start.p, d_maps.p, d_pieces.p, d_cbits.p);
+        CSH_LAUNCH(k_bool_code, dim3((nseg + 63) / 64), dim3(64), st, imgs, d_chains.p, nchains, d_seg_start.p, d_off.p, d_stream.p, scratch, d_pieces.p, part_size, status, seglen);
+    }
+    CSH_LAUNCH(k_bool_merge, dim3((nchains + 63) / 64), dim3(64), st, imgs, d_chains.p, nchains, d_seg_start.p, d_pieces.p, d_cbits.p, scratch, part_size, status);
     CSH_LAUNCH(k_webp_assemble, dim3(nimg), dim3(256), st, imgs, scratch, part_size, out, img_size, status);
     CSH_CHECK(hipStreamSynchronize(st));
     return 0;

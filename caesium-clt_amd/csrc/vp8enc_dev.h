@@ -35,8 +35,7 @@ struct Vp8FrameDev {
     uint8_t alpha_seg[256];             // susceptibility -> segment
     Vp8SegDev seg[4];
     uint32_t stats[VP8_NSLOT];          // hi 16: events, lo 16: ones -- libwebp's proba_t with its halving
-    uint8_t coeffs[VP8_NSLOT];          // the probabilities the cost tables were made from; at the end: the frame's
-    uint16_t level_cost[4 * 8 * 3 * (VP8_MAXLV + 1)];
+    uint8_t coeffs[VP8_NSLOT];          // at the end of the walk: the frame's probabilities
 };
 __device__ __forceinline__ static int vp8_slot(int t, int b, int c) { return ((t * 8 + b) * 3 + c) * 11; }
 __device__ __forceinline__ static int vp8_bitcost(int bit, int p) { return kVp8EntropyCost[bit ? 255 - p : p]; }

@@ -62,6 +62,17 @@ def test_statistics_books_overflow_in_order(api):
     check(api, [("noisy_640x400", synth_jpeg(12, 640, 400, texture=120))], 95)
 
 
+def test_boolean_coder_in_pieces(api, monkeypatch):
+    """a partition is coded in pieces of 2048 decisions from the ranges a scan over all 128 possible ones finds (k_bool_scan / _chain / _code / _merge); with pieces of
+    1, 3 and 61 decisions most pieces complete fewer than two bytes, some none: what they hold travels through them into later pieces, carries ripple back"""
+    cases = webp_cases()[:4] + [("busy_200x150", synth_jpeg(9, 200, 150, texture=90))]
+    for seg in ("1", "3", "61"):
+        monkeypatch.setenv("CSH_TEST_BOOL_SEG", seg)
+        check(api, cases, 85)
+        check(api, cases[:2], 100)
+    monkeypatch.delenv("CSH_TEST_BOOL_SEG")
+
+
 def test_convert_with_resize(api):
     check(api, webp_cases()[:2], 85, width=60)
     check(api, webp_cases()[1:3], 75, height=40)
