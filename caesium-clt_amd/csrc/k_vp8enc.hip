@@ -192,12 +192,10 @@ __device__ __forceinline__ static int quant_block(int (&c)[16], int (&lv)[16], c
         const int q = j ? m.q1 : m.q0, iq = j ? m.iq1 : m.iq0, b = j ? m.b1 : m.b0, z = j ? m.z1 : m.z0;
         const int sign = c[j] < 0;
         const uint32_t coeff = uint32_t(iabs(c[j]) + (SHARP ? (int(kVp8FreqSharpening[j]) * q) >> 11 : 0));
-        int level = 0;
-        if (coeff > uint32_t(z)) {
-            level = int((coeff * uint32_t(iq) + uint32_t(b)) >> 17);
-            if (level > 2047) level = 2047;
-            if (sign) level = -level;
-        }
+        (void)z;   // (coeff <= zthresh <=> the division below gives 0: that is how zthresh is defined)
+        int level = int((coeff * uint32_t(iq) + uint32_t(b)) >> 17);
+        if (level > 2047) level = 2047;
+        if (sign) level = -level;
         c[j] = level * q;
         lv[n] = level;
         any |= level;
@@ -476,7 +474,7 @@ struct MbLds {
 // the picture's tables, one copy per wave (all four macroblocks of a wave belong to one picture): level costs, probabilities, the fixed tables, the segments
 struct MbTables {
     uint16_t lc[96 * (VP8_MAXLV + 1)];
-    uint16_t fixed[256];             // kVp8LevelFixedCosts for levels below 256 (larger ones are read from the constant table)
+    uint16_t fixed[2048];            // kVp8LevelFixedCosts
     uint16_t ent[256];
     uint8_t coeffs[VP8_NSLOT];
     Vp8SegDev seg[4];
@@ -493,7 +491,7 @@ __device__ __forceinline__ static int block_cost(const MbTables &T, int type, in
     CSH_UNROLL
     for (int n = 0; n < 16; n++) {
         const int v = iabs(lv[n]), on = (n >= first && n <= last) ? 1 : 0;
-        const int c = int(v < 256 ? T.fixed[v] : kVp8LevelFixedCosts[v]) + int(T.lc[((type * 8 + kVp8Bands[n]) * 3 + ctx) * (VP8_MAXLV + 1) + (v > VP8_MAXLV ? VP8_MAXLV : v)]);
+        const int c = int(T.fixed[v]) + int(T.lc[((type * 8 + kVp8Bands[n]) * 3 + ctx) * (VP8_MAXLV + 1) + (v > VP8_MAXLV ? VP8_MAXLV : v)]);
         cost += on ? c : 0;
         ctx = n >= first ? (v >= 2 ? 2 : v) : ctx;
     }
@@ -1126,7 +1124,8 @@ __global__ void __launch_bounds__(2 * CSP_WAVE_THREADS, 2) k_vp8_loop(const Webp
             if (wave == 0) {
                 LFOR(l) {
                     for (int i = l; i < VP8_NSLOT; i += 64) T.coeffs[i] = kVp8CoefProbs[i];
-                    for (int i = l; i < 256; i += 64) { T.fixed[i] = kVp8LevelFixedCosts[i]; T.ent[i] = kVp8EntropyCost[i]; }
+                    for (int i = l; i < 256; i += 64) T.ent[i] = kVp8EntropyCost[i];
+                    for (int i = l; i < 2048; i += 64) T.fixed[i] = kVp8LevelFixedCosts[i];
                     for (int i = l; i < int(sizeof(T.seg) / 4); i += 64) reinterpret_cast<uint32_t *>(T.seg)[i] = reinterpret_cast<const uint32_t *>(F->seg)[i];
                 }
                 make_level_costs(T.lc, kVp8CoefProbs);
