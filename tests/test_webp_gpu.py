@@ -1,11 +1,12 @@
-"""JPEG in, WebP out on the device, through the C ABI, against the oracle (oracle/webp_oracle.c + the JPEG / resize oracle in
-front of it): file bytes; configs[3] shape (1080p JPEG, --long-edge 1500, -q 85) included."""
+"""JPEG in, WebP out on the device, through the C ABI, against the oracle (oracle/vp8enc_oracle.c = libwebp's encoder, pinned to WebPEncode byte for byte, + the
+JPEG / resize oracle in front of it): file bytes; configs[3] shape (1080p JPEG, --long-edge 1500, -q 85) included; and against libwebp itself where the box has one."""
 import io
 
 import numpy as np
 import pytest
 
 from _util import oracle_jpeg_to_webp, package, product_api
+from gen_synth import synth_jpeg
 from test_webp_emul import check, webp_cases
 
 pytestmark = pytest.mark.gpu
@@ -25,9 +26,37 @@ def test_convert_equals_oracle(api):
     check(api, webp_cases()[:4], 100)
 
 
-def test_token_partitions_as_decision_streams_and_as_chains(api, monkeypatch):
+def test_every_quality_class_and_shape(api):
     import test_webp_emul as E
-    E.test_token_partitions_as_decision_streams_and_as_chains(api, monkeypatch)
+    E.test_every_quality_class_and_shape(api)
+
+
+def test_statistics_books_overflow_in_order(api):
+    import test_webp_emul as E
+    E.test_statistics_books_overflow_in_order(api)
+    check(api, [("noisy_1280x720", synth_jpeg(13, 1280, 720, texture=100))], 90)
+
+
+def test_boolean_coder_in_pieces(api, monkeypatch):
+    import test_webp_emul as E
+    E.test_boolean_coder_in_pieces(api, monkeypatch)
+
+
+def test_device_file_is_libwebp_s_file(api):
+    """the whole claim in one place: RGB pixels -> this library's PNG -> WebP conversion on the device == WebPEncode of the libwebp on this box on the same pixels"""
+    from libwebp_pin import libwebp_encode, libwebps
+    from gen_synth import synth_rgb
+    libs = libwebps()
+    if not libs:
+        pytest.skip("no libwebp with the encoder API on this box")
+    pkg = package()
+    for seed, (w, h), q in ((0, (1500, 844), 85), (1, (640, 481), 60), (2, (97, 61), 100)):
+        rgb = np.ascontiguousarray(synth_rgb(seed, w, h))
+        b = io.BytesIO()
+        PIL.fromarray(rgb).save(b, "PNG")
+        out = api.convert_in_memory(b.getvalue(), pkg.default_parameters(webp_quality=q), 3)
+        for ver, W in libs:
+            assert out == libwebp_encode(W, rgb, q), (seed, w, h, q, ver)
 
 
 def test_convert_with_resize(api):
