@@ -72,7 +72,7 @@ template <int SH>
 __device__ __forceinline__ static void idct1d(int &x0, int &x1, int &x2, int &x3, int &x4, int &x5, int &x6, int &x7) {
     const int R = 1 << (SH - 1);
     const int z1 = MUL(x2 + x6, FIX_0_541), tmp2 = MAD(x6, -FIX_1_847, z1), tmp3 = MAD(x2, FIX_0_765, z1);
-    const int tmp0 = MAD(x0 + x4, 8192, R), tmp1 = MAD(x0 - x4, 8192, R);   // carries the rounding term of all eight outputs
+    const int tmp0 = ((x0 + x4) << 13) + R, tmp1 = ((x0 - x4) << 13) + R;   // carries the rounding term of all eight outputs; a shift, not the 24-bit multiplier: the DC term of a 16-bit-table stream can pass 2^23
     const int t10 = tmp0 + tmp3, t13 = tmp0 - tmp3, t11 = tmp1 + tmp2, t12 = tmp1 - tmp2;
     int a0 = x7, a1 = x5, a2 = x3, a3 = x1;
     const int y1 = a0 + a3, y2 = a1 + a2;
@@ -357,13 +357,15 @@ __device__ __forceinline__ static void fdct1d_pk(uint32_t A, uint32_t B, uint32_
 #else
     // the three-operand v_dot2_i32_i16 with its constants in scalar registers.  (Through the builtin the compiler picks the two-operand v_dot2c with a
     // literal, which needs a v_mov of the rounding term in front of every output: 128 more instructions per block.  One asm statement per half
-    // transform: between separate statements it would put a wait state.)
+    // transform: between separate statements it would put a wait state.)  The compiler's hazard recogniser does not see inside an asm statement: a DOT write
+    // needs three wait states before a non-DOT VALU instruction reads it, and the shifts behind the statement read o*; `s_nop 2` at its end makes that
+    // structural instead of an accident of scheduling.
     asm("v_dot2_i32_i16 %0, %5, %8, %11\n\tv_dot2_i32_i16 %1, %5, %10, %12\n\tv_dot2_i32_i16 %2, %5, %14, %7\n\tv_dot2_i32_i16 %3, %5, %16, %7\n\t"
-        "v_dot2_i32_i16 %0, %4, %6, %0\n\tv_dot2_i32_i16 %1, %4, %9, %1\n\tv_dot2_i32_i16 %2, %4, %13, %2\n\tv_dot2_i32_i16 %3, %4, %15, %3"
+        "v_dot2_i32_i16 %0, %4, %6, %0\n\tv_dot2_i32_i16 %1, %4, %9, %1\n\tv_dot2_i32_i16 %2, %4, %13, %2\n\tv_dot2_i32_i16 %3, %4, %15, %3\n\ts_nop 2"
         : "=&v"(o0), "=&v"(o4), "=&v"(o2), "=&v"(o6)
         : "v"(P), "v"(Q), "s"(KE0P), "v"(R), "s"(KE0Q), "s"(KE4P), "s"(KE4Q), "v"(R0), "v"(R4), "s"(KE2P), "s"(KE2Q), "s"(KE6P), "s"(KE6Q));
     asm("v_dot2_i32_i16 %0, %5, %8, %6\n\tv_dot2_i32_i16 %1, %5, %10, %6\n\tv_dot2_i32_i16 %2, %5, %12, %6\n\tv_dot2_i32_i16 %3, %5, %14, %6\n\t"
-        "v_dot2_i32_i16 %0, %4, %7, %0\n\tv_dot2_i32_i16 %1, %4, %9, %1\n\tv_dot2_i32_i16 %2, %4, %11, %2\n\tv_dot2_i32_i16 %3, %4, %13, %3"
+        "v_dot2_i32_i16 %0, %4, %7, %0\n\tv_dot2_i32_i16 %1, %4, %9, %1\n\tv_dot2_i32_i16 %2, %4, %11, %2\n\tv_dot2_i32_i16 %3, %4, %13, %3\n\ts_nop 2"
         : "=&v"(o7), "=&v"(o5), "=&v"(o3), "=&v"(o1)
         : "v"(M), "v"(N), "v"(R), "s"(PK(kO7[3], kO7[2])), "s"(PK(kO7[1], kO7[0])), "s"(PK(kO5[3], kO5[2])), "s"(PK(kO5[1], kO5[0])),
           "s"(PK(kO3[3], kO3[2])), "s"(PK(kO3[1], kO3[0])), "s"(PK(kO1[3], kO1[2])), "s"(PK(kO1[1], kO1[0])));

@@ -304,6 +304,16 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
         const uint32_t rec = L0.chunk0 + (u >> 8);
         if (c.nz_chunk_cnt[rec]) lst = c.nz_pool + L0.base + c.nz_chunk_off[rec] + c.blk_off[w.unit_base + u];   // (a chunk that found no room has no entries: the run is repeated with larger pools)
     }
+    // the list was laid out from the statistics scan's count of this block's non-zero scalar levels; the programme's own count must be that number (the same
+    // quantiser on the same coefficients).  Should the two ever part -- a change to either quantiser -- the entries are not written past the block's room
+    // (ADVICE r05); the emulation build stops on it
+    uint32_t room = ne;
+    if (lst && c.blk_cnt) {
+        room = c.blk_cnt[w.unit_base + u];
+#ifdef CSH_EMUL
+        if (room != ne) { fprintf(stderr, "k_trellis_ac: block %u of unit %u has %u list entries but %u levels\n", u, w.unit_base, room, ne); abort(); }
+#endif
+    }
     // (the list entries four at a time: one 16-byte store where the block has four more -- a 4-byte store per entry and lane was 0.9 ms per 1024 files)
     for (uint32_t e0 = 0; CSH_ANY(e0 < ne); e0 += 4) {
         uint32_t ent[4] = {0u, 0u, 0u, 0u};
@@ -318,8 +328,8 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
                 ent[i] = uint32_t(pos) | ((Pe >> 31) ? 128u : 0u) | (uint32_t(level) << 8) | ((u & 255u) << 23);
             }
         }
-        if (lst && e0 < ne) {
-            if (e0 + 4 <= ne) {
+        if (lst && e0 < ne && e0 < room) {
+            if (e0 + 4 <= ne && e0 + 4 <= room) {
 #ifdef CSH_EMUL
                 memcpy(lst + e0, ent, 16);
 #else
@@ -329,7 +339,7 @@ __device__ __forceinline__ static void trellis_block(const TrellisCtx &c, uint32
 #endif
             } else {
                 CSH_UNROLL
-                for (uint32_t i = 0; i < 3; i++) if (e0 + i < ne) lst[e0 + i] = ent[i];
+                for (uint32_t i = 0; i < 4; i++) if (e0 + i < ne && e0 + i < room) lst[e0 + i] = ent[i];
             }
         }
     }

@@ -108,17 +108,17 @@ __device__ __forceinline__ static void fdct4(const int (&d)[16], int (&out)[16])
     for (int i = 0; i < 4; i++) {
         const int a0 = d[4 * i] + d[4 * i + 3], a1 = d[4 * i + 1] + d[4 * i + 2], a2 = d[4 * i + 1] - d[4 * i + 2], a3 = d[4 * i] - d[4 * i + 3];
         t[0 + i * 4] = (a0 + a1) * 8;
-        t[1 + i * 4] = (a2 * 2217 + a3 * 5352 + 1812) >> 9;
+        t[1 + i * 4] = (__mul24(a2, 2217) + __mul24(a3, 5352) + 1812) >> 9;
         t[2 + i * 4] = (a0 - a1) * 8;
-        t[3 + i * 4] = (a3 * 2217 - a2 * 5352 + 937) >> 9;
+        t[3 + i * 4] = (__mul24(a3, 2217) - __mul24(a2, 5352) + 937) >> 9;
     }
     CSH_UNROLL
     for (int i = 0; i < 4; i++) {
         const int a0 = t[0 + i] + t[12 + i], a1 = t[4 + i] + t[8 + i], a2 = t[4 + i] - t[8 + i], a3 = t[0 + i] - t[12 + i];
         out[0 + i] = (a0 + a1 + 7) >> 4;
-        out[4 + i] = ((a2 * 2217 + a3 * 5352 + 12000) >> 16) + (a3 != 0);
+        out[4 + i] = ((__mul24(a2, 2217) + __mul24(a3, 5352) + 12000) >> 16) + (a3 != 0);
         out[8 + i] = (a0 - a1 + 7) >> 4;
-        out[12 + i] = (a3 * 2217 - a2 * 5352 + 51000) >> 16;
+        out[12 + i] = (__mul24(a3, 2217) - __mul24(a2, 5352) + 51000) >> 16;
     }
 }
 __device__ __forceinline__ static void fwht(const int (&dc)[16], int (&out)[16]) {
@@ -147,8 +147,9 @@ __device__ __forceinline__ static void iwht(const int (&in)[16], int (&dc)[16]) 
         dc[i * 4 + 0] = (a0 + a1) >> 3; dc[i * 4 + 1] = (a3 + a2) >> 3; dc[i * 4 + 2] = (a0 - a1) >> 3; dc[i * 4 + 3] = (a3 - a2) >> 3;
     }
 }
-__device__ __forceinline__ static int mul1(int a) { return ((a * 20091) >> 16) + a; }
-__device__ __forceinline__ static int mul2(int a) { return (a * 35468) >> 16; }
+// (the 24-bit multiplier runs at full rate, the 32-bit one at a quarter; every operand here is far inside 24 bits and the low 32 bits of the product are the same)
+__device__ __forceinline__ static int mul1(int a) { return (__mul24(a, 20091) >> 16) + a; }
+__device__ __forceinline__ static int mul2(int a) { return __mul24(a, 35468) >> 16; }
 __device__ __forceinline__ static void idct4_add(const int (&in)[16], const int (&pred)[16], int (&px)[16]) {
     int t[16];
     CSH_UNROLL
@@ -173,11 +174,11 @@ __device__ __forceinline__ static int hadamard_w(const int (&p)[16]) {   // weig
     CSH_UNROLL
     for (int i = 0; i < 4; i++) {
         const int a0 = t[0 + i] + t[8 + i], a1 = t[4 + i] + t[12 + i], a2 = t[4 + i] - t[12 + i], a3 = t[0 + i] - t[8 + i];
-        sum += int(kVp8WeightY[0 + i]) * iabs(a0 + a1) + int(kVp8WeightY[4 + i]) * iabs(a3 + a2) + int(kVp8WeightY[8 + i]) * iabs(a3 - a2) + int(kVp8WeightY[12 + i]) * iabs(a0 - a1);
+        sum += __mul24(int(kVp8WeightY[0 + i]), iabs(a0 + a1)) + __mul24(int(kVp8WeightY[4 + i]), iabs(a3 + a2)) + __mul24(int(kVp8WeightY[8 + i]), iabs(a3 - a2)) + __mul24(int(kVp8WeightY[12 + i]), iabs(a0 - a1));
     }
     return sum;
 }
-__device__ __forceinline__ static int sse16(const int (&a)[16], const int (&b)[16]) { int s = 0; CSH_UNROLL for (int k = 0; k < 16; k++) { const int d = a[k] - b[k]; s += d * d; } return s; }
+__device__ __forceinline__ static int sse16(const int (&a)[16], const int (&b)[16]) { int s = 0; CSH_UNROLL for (int k = 0; k < 16; k++) { const int d = a[k] - b[k]; s += __mul24(d, d); } return s; }
 
 // ---- quantiser (oracle: quantize_block / quantize_single)
 struct QM { int q0, q1, iq0, iq1, b0, b1, z0, z1; };
@@ -191,12 +192,12 @@ __device__ __forceinline__ static int quant_block(int (&c)[16], int (&lv)[16], c
         const int j = kVp8Zigzag[n];
         const int q = j ? m.q1 : m.q0, iq = j ? m.iq1 : m.iq0, b = j ? m.b1 : m.b0, z = j ? m.z1 : m.z0;
         const int sign = c[j] < 0;
-        const uint32_t coeff = uint32_t(iabs(c[j]) + (SHARP ? (int(kVp8FreqSharpening[j]) * q) >> 11 : 0));
+        const uint32_t coeff = uint32_t(iabs(c[j]) + (SHARP ? __mul24(int(kVp8FreqSharpening[j]), q) >> 11 : 0));
         (void)z;   // (coeff <= zthresh <=> the division below gives 0: that is how zthresh is defined)
-        int level = int((coeff * uint32_t(iq) + uint32_t(b)) >> 17);
+        int level = int((__umul24(coeff, uint32_t(iq)) + uint32_t(b)) >> 17);   // coeff < 2^16, iq <= 2^15
         if (level > 2047) level = 2047;
         if (sign) level = -level;
-        c[j] = level * q;
+        c[j] = __mul24(level, q);
         lv[n] = level;
         any |= level;
     }
@@ -504,7 +505,7 @@ __device__ __forceinline__ static int block_cost(const MbTables &T, int type, in
 __device__ __forceinline__ static uint32_t pack4(const int (&p)[16], int r) { return uint32_t(p[r * 4]) | (uint32_t(p[r * 4 + 1]) << 8) | (uint32_t(p[r * 4 + 2]) << 16) | (uint32_t(p[r * 4 + 3]) << 24); }
 
 // the macroblocks items[lo .. min(lo + 4, hi)) of one picture, a row of sixteen lanes each
-__device__ __attribute__((noinline)) static void mb_batch(MbLds (&s)[4], const MbTables &T, const WebpImg &im, Vp8FrameDev *F, const uint32_t *items, uint32_t lo, uint32_t hi, uint8_t *work, int16_t *levels) {
+__device__ __forceinline__ static void mb_batch(MbLds (&s)[4], const MbTables &T, const WebpImg &im, Vp8FrameDev *F, const uint32_t *items, uint32_t lo, uint32_t hi, uint8_t *work, int16_t *levels) {
     const int mbw = int(im.mbw), ys = mbw * 16, cs = mbw * 8;
     // ---- which macroblock each row of sixteen lanes works on
     LV<int> ok, vmx, vmy;
@@ -1004,7 +1005,7 @@ __device__ static void walk_mb(S &sink, const int16_t *L, int mbw, int mx, int m
 struct StatLds { uint32_t cnt[VP8_NSLOT], ones[VP8_NSLOT], list[64], nlist; };
 // macroblocks n0 .. n1 of one picture (a chunk), one wave.  mb_cnt / blk_cnt (already offset to the picture's first macroblock): decisions per macroblock / block (32 slots
 // a macroblock).  Leaves the frame's probabilities so far in T.coeffs and, when any differs from the defaults, the level-cost tables made from them in T.lc
-__device__ __attribute__((noinline)) static void chunk_stats(StatLds &A, MbTables &T, const WebpImg &im, Vp8FrameDev *F, const int16_t *lev, int n0, int n1, bool final_chunk, uint32_t *mb_cnt, uint16_t *blk_cnt) {
+__device__ __forceinline__ static void chunk_stats(StatLds &A, MbTables &T, const WebpImg &im, Vp8FrameDev *F, const int16_t *lev, int n0, int n1, bool final_chunk, uint32_t *mb_cnt, uint16_t *blk_cnt) {
     uint32_t *s_cnt = A.cnt, *s_ones = A.ones, *s_list = A.list;
     uint32_t &s_nlist = A.nlist;
     uint8_t *s_coeffs = T.coeffs;

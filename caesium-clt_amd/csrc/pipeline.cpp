@@ -71,6 +71,7 @@ struct csh_batch {
     bool rgb_out = false;          // csh_batch_create_pixels: stop after the resize branch's RGB
     bool webp = false;             // target container: the decoded (and resized) RGB goes to the VP8 encoder instead of the JPEG one
     uint32_t webp_mb_bytes = 768;  // output bytes reserved per macroblock (grows on overflow)
+    int test_pool_shift = -1;      // CSH_TEST_POOL_SHIFT as read at the first pool layout of this batch (-1: not read yet)
     std::vector<csw::WebpImg> wimgs;
     uint64_t wwork_bytes = 0, wlevels = 0;
     uint32_t wmax_luma = 0;
@@ -484,7 +485,9 @@ extern "C" int csh_batch_create_webp(const CByteArray *inputs, size_t count, con
 static void layout_token_pool(csh_batch *b) {
     b->regions.resize(b->region_est.size());
     // CSH_TEST_POOL_SHIFT=n (tests): every estimate divided by 2^n, so that the first runs overflow and the batch goes through its retries with larger pools
-    const int shift = getenv("CSH_TEST_POOL_SHIFT") ? std::min(16, std::max(0, atoi(getenv("CSH_TEST_POOL_SHIFT")))) : 0;
+    // (read once per batch object, at its first layout: the retries of a run keep what the run started with -- ADVICE r05; an unsupported test hook)
+    if (b->test_pool_shift < 0) b->test_pool_shift = getenv("CSH_TEST_POOL_SHIFT") ? std::min(16, std::max(0, atoi(getenv("CSH_TEST_POOL_SHIFT")))) : 0;
+    const int shift = b->test_pool_shift;
     uint64_t at = 0;
     for (size_t i = 0; i < b->regions.size(); i++) {
         const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>((uint64_t(b->region_est[i]) * b->tok_scale) >> shift, 64), 0xFFFFFFF0ull);

@@ -154,3 +154,17 @@ def test_emul_pools_that_overflow_are_grown_and_the_run_repeated(api, monkeypatc
         for s_, o in zip(srcs, outs):
             assert o == oracle_lossy(s_), prof
 
+
+
+def test_emul_trellis_levels_through_the_lists_or_through_the_tiles(api, monkeypatch):
+    """the coding stages' lists are filtered from the list k_trellis_ac wrote its levels into (the default), or built from the coefficient tiles again
+    (CSH_NZ_ONCE=0): the same bytes either way, and the emulation build stops if a block's list room and its programme's entry count ever part"""
+    monkeypatch.delenv("CSH_PROFILE", raising=False)
+    srcs = [synth_jpeg(51, 200, 136, texture=60), synth_jpeg(52, 97, 61, subsampling=0, texture=25), saturated_jpeg()]
+    for q in (80, 30, 97):
+        monkeypatch.delenv("CSH_NZ_ONCE", raising=False)
+        once = api.batch_compress(srcs, params(jpeg_quality=q))
+        monkeypatch.setenv("CSH_NZ_ONCE", "0")
+        twice = api.batch_compress(srcs, params(jpeg_quality=q))
+        assert once == twice and all(isinstance(o, bytes) for o in once), q
+        assert once[0] == oracle_lossy(srcs[0], q)
