@@ -303,8 +303,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_vp8_analyse(const WebpImg 
                     CSH_UNROLL
                     for (int k = 0; k < 16; k++) d[k] = src[k] - pred[k];
                     fdct4(d, c);
+                    // (most coefficients land in bin 0: counted in a register and added once per block, or every lane of the row would queue at one LDS word)
+                    uint32_t zeros = 0;
                     CSH_UNROLL
-                    for (int k = 0; k < 16; k++) { const int v = iabs(c[k]) >> 3; atomicAdd(&s[g].hist[pass * 2 + mode][v > 31 ? 31 : v], 1u); }
+                    for (int k = 0; k < 16; k++) { const int v = iabs(c[k]) >> 3; if (v == 0) zeros++; else atomicAdd(&s[g].hist[pass * 2 + mode][v > 31 ? 31 : v], 1u); }
+                    if (zeros) atomicAdd(&s[g].hist[pass * 2 + mode][0], zeros);
                 }
             }
         }
