@@ -784,7 +784,7 @@ def other_configs(api, pkg, blobs, local):
         wn = api.webp_kernel_names()
         wdom = max(range(len(wn)), key=lambda i: wtm.kernel_ms[i])
         # Lanczos R 6 220 800 / W 3 798 000 per file; the VP8 tail reads the 1500 x 844 YUV 4:2:0 (1 899 000 B) and writes levels + the file
-        per_file = {"resize": 6_220_800 + 3_798_000, "k_webp_yuv": 3_798_000 + 1_899_000, "k_vp8_analyse+segments+mb+chunk": 2 * 1_899_000 + 4_304_448, "k_webp_hdr+decisions+bool+assemble": 4_304_448 + int(wtm.out_bytes) // nweb}   # 4 304 448 B: the level records of 4 982 macroblocks
+        per_file = {"resize": 6_220_800 + 3_798_000, "k_webp_yuv": 3_798_000 + 1_899_000, "k_vp8_analyse+segments+loop": 2 * 1_899_000 + 4_304_448, "k_webp_hdr+decisions+bool+assemble": 4_304_448 + int(wtm.out_bytes) // nweb}   # 4 304 448 B: the level records of 4 982 macroblocks
         abw = per_file.get(wn[wdom], 1_899_000) * nweb
         rec = {"files": nweb, "value": round(nweb * MP_1080P / (wtm.total_ms / 1e3), 1), "unit": "source MP/s", "device_ms": round(wtm.total_ms, 1), "out_bytes": int(wtm.out_bytes),
                "dominant_kernel": wn[wdom], "dominant_ms": round(wtm.kernel_ms[wdom], 1),

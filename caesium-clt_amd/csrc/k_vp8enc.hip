@@ -1,15 +1,15 @@
 // k_vp8enc.hip -- SURVEY.md 8a row W2 on the device: libwebp's lossy encoder at its defaults (method 4, 4 segments, SNS 50, filter strength 60),
 // byte for byte.  Statement: oracle/vp8enc_oracle.c (pinned to libwebp itself); the phases are the oracle's:
 //   k_vp8_analyse    A  one 16-lane row per macroblock: the susceptibility (alpha) of its DC / TM residual spectra, from source samples only
-//   k_vp8_segments   B  one wave per picture: 4-means over the alpha histogram, segment quantisers (SNS), matrices, lambdas, filter strengths, the default cost tables
-//   k_vp8_mb         C  the rate-distortion mode decision.  A macroblock needs the reconstruction and the modes / non-zero flags of its left, upper and upper-right
-//                       neighbours, and the level-cost tables of its CHUNK (libwebp refreshes them from the token statistics every max(96, mbs / 8) (+1)
-//                       macroblocks): the host lays the macroblocks of a picture out in steps (launch_webp_encode), one launch per step, a step's macroblocks --
-//                       of every picture of the batch -- being independent.  Four macroblocks to a wave, sixteen lanes each: the sixteen luma blocks of an i16
-//                       candidate, the ten modes of an i4 sub-block, two chroma modes x eight blocks
-//   k_vp8_chunk      C' between two chunks, one wave per picture: the chunk's token statistics in libwebp's 16-bit form (its halving on overflow depends on the
-//                       ORDER of the events: counted in groups of 64 macroblocks, a group that straddles a halving point is recounted in order), the frame's
-//                       probabilities so far and the level-cost tables of the next chunk; after the last chunk: the final probabilities and the filter level
+//   k_vp8_segments   B  one wave per picture: 4-means over the alpha histogram, segment quantisers (SNS), matrices, lambdas, filter strengths
+//   k_vp8_loop       C  ONE WORKGROUP (two waves) WALKS ONE PICTURE through the rate-distortion mode decision.  A macroblock needs the reconstruction and the modes /
+//                       non-zero flags of its left, upper and upper-right neighbours, and the level-cost tables of its CHUNK (libwebp rebuilds them from the token
+//                       statistics every max(96, mbs / 8) (+1) macroblocks): the host lays the macroblocks of a picture size out in steps (plan_class) and the kernel is
+//                       a phased loop over them with a workgroup barrier between steps.  mb_batch: four macroblocks to a wave, sixteen lanes each -- the sixteen luma
+//                       blocks of an i16 candidate, the ten modes of an i4 sub-block, two chroma modes x eight blocks.  chunk_stats (wave 0, between two chunks): the
+//                       chunk's token statistics in libwebp's 16-bit form (its halving on overflow depends on the ORDER of the events: counted in groups of 64
+//                       macroblocks, a group that straddles a halving point is recounted in order), the frame's probabilities so far and the level-cost tables of the
+//                       next chunk, all in LDS; after the last chunk the final probabilities and the filter level
 // The coder back end (decision streams, boolean coder, RIFF) is k_webp.hip.
 #include "vp8enc_dev.h"
 #include "devmem.hpp"

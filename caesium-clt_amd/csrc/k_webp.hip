@@ -3,7 +3,7 @@
 //   k_webp_yuv        W1: RGB -> YUV 4:2:0 planes padded to whole macroblocks, one lane per sample; libwebp's import (chroma averaged in gamma-0.80 linear light)
 //   W3: the boolean entropy coder is a serial chain per partition; WHICH decisions it takes (the token tree over the levels, the contexts out of the
 //   non-zero masks, the frame's probabilities) is known for every block at once.  So:
-//   k_vp8_chunk       (k_vp8enc.hip: the walk that keeps the frame's statistics) also counts every block's decisions;
+//   chunk_stats       (k_vp8enc.hip, inside k_vp8_loop: the walk that keeps the frame's statistics) also counts every block's decisions;
 //   an exclusive scan over the macroblocks in raster order gives every macroblock its place in the stream;
 //   k_webp_decisions  the same walk, lanes = the blocks of a macroblock, writes (bit, probability) pairs -- two bytes a decision;
 //   k_webp_hdr        partition 0 the same way (segment / filter / quantiser fields, probability updates, every macroblock's segment and modes);
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_webp_decisions(const WebpI
 }
 // ---- partition 0 the same way: its chain is the frame header's fields, the frame's probability updates, then every macroblock's segment and modes in raster
 // order.  One lane per ITEM (item 0: the fields and the updates; item 1 + i: macroblock i) counts its decisions or writes them: the modes' contexts are the
-// neighbours' modes, which k_vp8_mb left with the levels.  (oracle: part D of cso_vp8enc_encode_yuv)
+// neighbours' modes, which k_vp8_loop left with the levels.  (oracle: part D of cso_vp8enc_encode_yuv)
 struct HdrSink {
     uint16_t *out;   // nullptr: count only
     uint32_t n;
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256) k_webp_assemble(const WebpImg *imgs, cons
 void launch_webp_yuv(hipStream_t st, const WebpImg *imgs, int nimg, uint32_t max_luma, const uint8_t *rgb, uint8_t *work) {
     if (nimg && max_luma) CSH_LAUNCH(k_webp_yuv, dim3((max_luma + 255) / 256, nimg), dim3(256), st, imgs, rgb, work);
 }
-// base[i]: picture i's first macroblock among the batch's (host copy of d_base); d_cnt holds the macroblocks' decision counts (k_vp8_chunk) and has room for
+// base[i]: picture i's first macroblock among the batch's (host copy of d_base); d_cnt holds the macroblocks' decision counts (k_vp8_loop: chunk_stats) and has room for
 // the header items behind them
 int launch_webp_backend(hipStream_t st, const WebpImg *imgs, const WebpImg *himgs, int nimg, const int16_t *levels, const Vp8FrameDev *frames, const std::vector<uint64_t> &base,
                         const uint64_t *d_base, csh::DevBuf<uint32_t> &d_cnt, const uint16_t *d_blk, uint8_t *scratch, uint32_t *part_size, uint8_t *out, uint32_t *img_size, uint32_t *status) {

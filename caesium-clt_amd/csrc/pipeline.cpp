@@ -1439,7 +1439,7 @@ static const char *const kKernelNames[CSH_NKERNELS] = {
     "k_nzlist", "k_tokens", "k_list_stats", "k_ac_runs", "k_gen_tables", "k_chunk_sizes", "scan_chunk_bits", "scan_layout", "k_pack", "k_list_pack",
     "k_ff_count", "scan_search_stage2", "k_layout", "scan_images", "k_emit", "", "", ""};
 // a WebP batch (csh_batch_create_webp) leaves the JPEG path behind the resize slot: its next three slots are these
-static const char *const kWebpTailNames[3] = {"k_webp_yuv", "k_vp8_analyse+segments+mb+chunk", "k_webp_hdr+decisions+bool+assemble"};
+static const char *const kWebpTailNames[3] = {"k_webp_yuv", "k_vp8_analyse+segments+loop", "k_webp_hdr+decisions+bool+assemble"};
 
 // the trellis slots (statistics scan = k_tokens without tokens + k_ac_runs + k_gen_tables; the two k_trellis kernels + k_fix_dummy) count
 // as phase 1: they are the quantiser; zero unless CSH_PROFILE=mozjpeg

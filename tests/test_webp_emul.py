@@ -58,7 +58,7 @@ def test_every_quality_class_and_shape(api):
 
 def test_statistics_books_overflow_in_order(api):
     """libwebp keeps its token statistics in 16 + 16 bits and halves a slot when 65534 events are reached: WHICH events came before matters.  A noisy picture
-    makes several slots pass that point (and k_vp8_chunk recount them in macroblock order); the file must still be the oracle's = libwebp's"""
+    makes several slots pass that point (and k_vp8_loop's chunk_stats recount them in macroblock order); the file must still be the oracle's = libwebp's"""
     check(api, [("noisy_640x400", synth_jpeg(12, 640, 400, texture=120))], 95)
 
 
