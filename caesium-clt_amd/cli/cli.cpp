@@ -677,7 +677,9 @@ int run(const Options &o) {
         // files per device batch (and never more than one device batch takes by bytes / declared pixels: cs_batch_extent).  A cold process pays for the
         // device pools it allocates (~25 MB per 1080p file) before the first kernel runs, and later batches reuse the first ones' pools: smaller
         // batches start sooner -- 2048 x 1080p files end to end on one MI355X: 3.3-5.6 s at 1024 files per batch, 1.0 s at 256, 0.9 s at 128; CSH_CLI_BATCH overrides
-        const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : 128;   // (round 5: 10 000 files 2.11-2.13 s at 128, 2.23-2.37 s at 256 -- half the pools a cold process has to map before its first kernel)
+        // (a WebP output walks every picture macroblock step by step -- libwebp's encoder, one workgroup per picture: ~0.1 s for a 1500 x 844 picture however few
+        // pictures share the device; its batches are as large as the window allows)
+        const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : (o.format == Format::Webp ? 1024 : 128);   // (round 5: 10 000 files 2.11-2.13 s at 128, 2.23-2.37 s at 256 -- half the pools a cold process has to map before its first kernel)
         for (auto &g : groups) {
             std::vector<CByteArray> gin(g.second.size());
             for (size_t k = 0; k < gin.size(); k++) { gin[k].data = jobs[g.second[k]].data.data(); gin[k].length = jobs[g.second[k]].data.size(); }
