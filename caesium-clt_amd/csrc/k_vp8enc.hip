@@ -1005,16 +1005,15 @@ __device__ static void walk_mb(S &sink, const int16_t *L, int mbw, int mx, int m
     if (blk_cnt && i4) blk_cnt[0] = 0;
 }
 
-struct StatLds { uint32_t cnt[VP8_NSLOT], ones[VP8_NSLOT], list[64], nlist; };
+struct StatLds { uint32_t cnt[VP8_NSLOT], ones[VP8_NSLOT]; };
 // macroblocks n0 .. n1 of one picture (a chunk), one wave.  mb_cnt / blk_cnt (already offset to the picture's first macroblock): decisions per macroblock / block (32 slots
 // a macroblock).  Leaves the frame's probabilities so far in T.coeffs and, when any differs from the defaults, the level-cost tables made from them in T.lc
 __device__ __forceinline__ static void chunk_stats(StatLds &A, MbTables &T, const WebpImg &im, Vp8FrameDev *F, const int16_t *lev, int n0, int n1, bool final_chunk, uint32_t *mb_cnt, uint16_t *blk_cnt) {
-    uint32_t *s_cnt = A.cnt, *s_ones = A.ones, *s_list = A.list;
-    uint32_t &s_nlist = A.nlist;
+    uint32_t *s_cnt = A.cnt, *s_ones = A.ones;
     uint8_t *s_coeffs = T.coeffs;
     const int mbw = int(im.mbw);
     for (int base = n0; base < n1; base += 64) {
-        LFOR(l) { for (int i = l; i < VP8_NSLOT; i += 64) { s_cnt[i] = 0; s_ones[i] = 0; } if (l == 0) s_nlist = 0; }
+        LFOR(l) for (int i = l; i < VP8_NSLOT; i += 64) { s_cnt[i] = 0; s_ones[i] = 0; }
         CSP_WAVE_SYNC();
         LFOR(l) {
             const int n = base + l;
@@ -1026,19 +1025,25 @@ __device__ __forceinline__ static void chunk_stats(StatLds &A, MbTables &T, cons
             }
         }
         CSP_WAVE_SYNC();
-        // into libwebp's 16-bit books; a slot that would pass 0xfffe events inside this group is recounted in order below
-        LFOR(l)
-            for (int i = l; i < VP8_NSLOT; i += 64) {
+        // into libwebp's 16-bit books; a slot that would pass 0xfffe events inside this group is recounted in order below (lane l looks after the slots
+        // l, l + 64, ..: bit k of `pend` = its k-th slot is waiting for that)
+        LV<uint32_t> pend;
+        LFOR(l) {
+            pend[l] = 0;
+            for (int i = l, k = 0; i < VP8_NSLOT; i += 64, k++) {
                 const uint32_t cn = s_cnt[i];
                 if (!cn) continue;
                 const uint32_t p = coherent_load(&F->stats[i]);
                 if ((p >> 16) + cn <= 0xfffeu) coherent_store(&F->stats[i], p + (cn << 16) + s_ones[i]);
-                else s_list[atomicAdd(&s_nlist, 1u) & 63u] = uint32_t(i);
+                else pend[l] |= 1u << k;
             }
-        CSP_WAVE_SYNC();
-        const uint32_t nlist = uni(s_nlist);
-        for (uint32_t q = 0; q < nlist && q < 64; q++) {   // (more than 64 slots overflowing inside one group of 64 macroblocks cannot happen: 64 x 400 events in all)
-            const int slot = int(uni(s_list[q]));
+        }
+        for (;;) {
+            const uint64_t waiting = lballot([&](int l) { return pend[l] != 0; });
+            if (!waiting) break;
+            const uint32_t lane = uint32_t(__builtin_ctzll(waiting)), bits = csh::lget(pend, lane), kbit = uint32_t(__builtin_ctz(bits));
+            csh::lset(pend, lane, bits & (bits - 1u));
+            const int slot = int(lane + 64u * kbit);
             const uint32_t p = coherent_load(&F->stats[slot]), k = 0xfffeu - (p >> 16);   // the halving comes after k more events
             LV<uint32_t> tl, ol;
             LFOR(l) {
