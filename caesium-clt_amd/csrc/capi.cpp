@@ -143,13 +143,8 @@ static int sniff(const uint8_t *d, size_t n);
 // filtered stream per trial slot (up to 10) and the output region, ~13 x the raw size
 static int png_batch_compress(const CByteArray *inputs, size_t count, const CCSParameters *p, int device, CByteArray *outputs, CCSResult *results, bool to_webp = false) {
     int failed_total = 0;
-    if (p->png_force_zopfli && p->png_optimize && !to_webp) {   // --zopfli: libcaesium hands the streams to zopfli; nothing of that kind is built, and a
-        for (size_t i = 0; i < count; i++) {                    // silently weaker file would pass for it: refused per file
-            outputs[i].data = nullptr; outputs[i].length = 0;
-            if (results) results[i] = make_result(CS_ERR_UNSUPPORTED, "png.force_zopfli (--zopfli) has no device path in this build: run without it for the device's own DEFLATE coder");
-        }
-        return int(count);
-    }
+    // png.force_zopfli (--zopfli): libcaesium hands the streams to zopfli; here the same coder runs CSP_DEEP_ITERS_ZOPFLI passes of its cost model
+    // over the chunks that take the min-cost-path parse (png_pipeline.cpp, png_parse.h)
     const uint64_t budget = uint64_t(96) << 30;
     for (size_t g0 = 0; g0 < count;) {
         uint64_t bytes = 0;

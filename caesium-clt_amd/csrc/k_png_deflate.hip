@@ -9,17 +9,10 @@
 //   emit   one wave per chunk of the winner: tokenizer again, bits through an LDS window straight to their final place
 //   finish Adler-32, CRC-32, IDAT framing, carried chunks
 // Only sizes decide the winner, so the losing trials are never packed.
-#include "png_kernels.h"
-#include "png_lz.h"
-#include "png_codes.h"
+#include "png_emit.h"
+#include "png_parse.h"
 
 namespace csp {
-
-__device__ static const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-__device__ __forceinline__ static PngChunk &chunk_rec(const DeflateCtx &c, const PngImg &im, int slot, uint32_t ci) {
-    return c.chunks[uint64_t(im.chunk_base) + uint64_t(slot) * im.chunk_stride + ci];
-}
 
 // ------------------------------------------------------------------------------------------------ hist
 struct HistLds { LzLds lz; uint32_t hist[CSP_NSYM]; };
@@ -59,7 +52,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_hist(DeflateCtx c) {
         LV<uint64_t> e;
         LFOR(l) e[l] = sink.extra[l];
         const uint64_t extra = lsum(e);
-        LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+        // a chunk with enough matches in it gets the min-cost-path parse (k_png_deep_hist replaces these counts; oracle: deflate_chunk)
+        LV<uint64_t> nm, nt;
+        LFOR(l) { nm[l] = 0; nt[l] = 0; for (uint32_t i = uint32_t(l); i < CSP_NLIT; i += 64) { nt[l] += S.hist[i]; if (i > 256) nm[l] += S.hist[i]; } }
+        const uint64_t matches = lsum(nm), tokens = lsum(nt);
+        LFOR(l) if (l == 0) { rec.extra_bits = uint32_t(extra); rec.deep = (c.deep_iters > 0 && matches * CSP_DEEP_DIV >= tokens) ? 1u : 0u; }
         CSP_WAVE_SYNC();
     }
 }
@@ -136,30 +133,8 @@ __global__ void __launch_bounds__(64) k_png_choose(DeflateCtx c) {
 }
 
 // ------------------------------------------------------------------------------------------------ emit
-// bits are OR-ed into a window of LDS words; complete words leave for HBM after every tile
+// bits are OR-ed into a window of LDS words; complete words leave for HBM after every tile (png_emit.h)
 struct EmitLds { LzLds lz; uint32_t code[CSP_NSYM]; uint32_t win[160]; };
-struct EmitSink {
-    const uint32_t *code;   // code | length << 16, litlen then distance
-    BitOut *bo;
-    __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t taken, const LV<uint32_t> &mlen, const LV<uint32_t> &mdist, const LV<uint32_t> &lit) {
-        LV<uint64_t> val; LV<uint32_t> nb;
-        LFOR(l) {
-            val[l] = 0; nb[l] = 0;
-            if ((taken >> l) & 1) {
-                if (mlen[l]) {
-                    const uint32_t lc = len_code_of(mlen[l]), dc = dist_code_of(mdist[l]);
-                    const uint32_t cl = code[257 + lc], cd = code[CSP_NLIT + dc];
-                    uint64_t v = cl & 0xFFFFu; uint32_t n = cl >> 16;
-                    v |= uint64_t(mlen[l] - len_base_of(lc)) << n; n += len_extra_of(lc);
-                    v |= uint64_t(cd & 0xFFFFu) << n; n += cd >> 16;
-                    v |= uint64_t(mdist[l] - dist_base_of(dc)) << n; n += dist_extra_of(dc);
-                    val[l] = v; nb[l] = n;
-                } else { const uint32_t cl = code[lit[l]]; val[l] = cl & 0xFFFFu; nb[l] = cl >> 16; }
-            }
-        }
-        bo->put(val, nb);
-    }
-};
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_emit(DeflateCtx c) {
     CSH_SHARED EmitLds S;
     const uint32_t bg = blockIdx.x;
@@ -180,50 +155,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_emit(DeflateCtx c) {
     for (uint32_t ci = c0; ci < c1; ci++) {
         const PngChunk &rec = chunk_rec(c, im, slot, ci);
         const bool last = ci + 1 == im.nchunks;
-        LFOR(l) {
-            for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.code[i] = uint32_t(rec.code[i]) | (uint32_t(rec.len[i]) << 16);
-            for (uint32_t i = uint32_t(l); i < 160; i += 64) S.win[i] = 0;
+        if (!rec.deep) {   // (the others: k_png_deep_emit)
+            BitOut bo;
+            emit_block_begin(rec, last, S.code, S.win, c.out + im.out_off + at, bo);
+            EmitSink sink; sink.code = S.code; sink.bo = &bo;
+            const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
+            lz_chunk(data, im.raw_len, start, end, S.lz, sink);
+            if (!emit_block_end(rec, last, S.code, bo)) ok = false;   // the size pass and the emit pass disagree: never ship it
         }
-        CSP_WAVE_SYNC();
-        BitOut bo; bo.win = S.win; bo.out = c.out + im.out_off + at; bo.bitpos = 0; bo.wbase = 0;
-        LV<uint64_t> val; LV<uint32_t> nb;
-        // block header: BFINAL, BTYPE=2, HLIT, HDIST, HCLEN (lane 0), the code-length code's lengths (lanes 1..)
-        LFOR(l) {
-            val[l] = 0; nb[l] = 0;
-            if (l == 0) { val[l] = (last ? 1u : 0u) | (2u << 1) | (uint64_t(rec.hlit - 257) << 3) | (uint64_t(rec.hdist - 1) << 8) | (uint64_t(rec.hclen - 4) << 13); nb[l] = 17; }
-            else if (l <= int(rec.hclen)) { val[l] = rec.cl_len[kClOrder[l - 1]]; nb[l] = 3; }
-        }
-        bo.put(val, nb);
-        for (uint32_t h0 = 0; h0 < rec.nhdr; h0 += 64) {
-            LFOR(l) {
-                val[l] = 0; nb[l] = 0;
-                const uint32_t h = h0 + uint32_t(l);
-                if (h < rec.nhdr) {
-                    const uint32_t s = rec.hdr_sym[h], n = rec.cl_len[s];
-                    val[l] = uint64_t(rec.cl_code[s]) | (uint64_t(rec.hdr_extra[h]) << n);
-                    nb[l] = n + (s == 16 ? 2u : s == 17 ? 3u : s == 18 ? 7u : 0u);
-                }
-            }
-            bo.put(val, nb);
-        }
-        EmitSink sink; sink.code = S.code; sink.bo = &bo;
-        const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
-        lz_chunk(data, im.raw_len, start, end, S.lz, sink);
-        // end of block; then the sync marker (empty stored block) that byte-aligns every chunk but the last
-        LFOR(l) {
-            val[l] = 0; nb[l] = 0;
-            if (l == 0) { val[l] = S.code[256] & 0xFFFFu; nb[l] = S.code[256] >> 16; }
-            if (l == 1 && !last) nb[l] = 3;
-        }
-        bo.put(val, nb);
-        if (!last) {
-            const uint32_t pad = uint32_t((8 - (bo.bitpos & 7)) & 7);
-            LFOR(l) { val[l] = 0; nb[l] = 0; if (l == 0) nb[l] = pad; if (l == 1) nb[l] = 16; if (l == 2) { val[l] = 0xFFFF; nb[l] = 16; } }
-            bo.put(val, nb);
-        }
-        CSP_WAVE_SYNC();
-        bo.finish();
-        if (bo.bitpos != (last ? rec.bits : ((rec.bits + 3 + 7) & ~7ull) + 32)) ok = false;   // the size pass and the emit pass disagree: never ship it
         at += rec.bytes;
         CSP_WAVE_SYNC();
     }
@@ -348,10 +287,10 @@ __global__ void __launch_bounds__(64) k_png_crc_fold2(DeflateCtx c, uint32_t max
     t[0] = uint8_t(crc >> 24); t[1] = uint8_t(crc >> 16); t[2] = uint8_t(crc >> 8); t[3] = uint8_t(crc);
 }
 
-void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) CSH_LAUNCH(k_png_hist, dim3(c.total_groups, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) { CSH_LAUNCH(k_png_hist, dim3(c.total_groups, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); launch_png_deep_hist(st, c); } }
 void launch_png_codes(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_codes, dim3((c.total_chunks + 63) / 64, c.plan.ntrials), dim3(64), st, c); }
 void launch_png_choose(hipStream_t st, const DeflateCtx &c) { if (c.nimg) CSH_LAUNCH(k_png_choose, dim3((c.nimg + 63) / 64), dim3(64), st, c); }
-void launch_png_emit(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) CSH_LAUNCH(k_png_emit, dim3(c.total_groups), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_emit(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) { CSH_LAUNCH(k_png_emit, dim3(c.total_groups), dim3(CSP_WAVE_THREADS), st, c); launch_png_deep_emit(st, c); } }
 void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces) {
     if (!c.nimg) return;
     CSH_LAUNCH_PHASED(k_png_adler, 3, dim3(c.total_chunks), dim3(256), st, c);

@@ -103,11 +103,16 @@ struct DeflateCtx {
     uint32_t *file_len;           // [nimg]
     uint32_t *crc_parts;          // per KiB piece of the IDAT chunk
     uint32_t *status;
+    uint8_t *deep_scratch;        // [deep_slots][CSP_DEEP_SCRATCH]: one area per workgroup of the min-cost-path kernels (png_parse.h)
+    uint32_t deep_slots;
+    int deep_iters;               // passes of that parse over the chunks that qualify: CSP_DEEP_ITERS, CSP_DEEP_ITERS_ZOPFLI with png.force_zopfli
 };
 void launch_png_hist(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 1: symbol counts of every (trial, chunk)
 void launch_png_codes(hipStream_t st, const DeflateCtx &c);    // code lengths, codes, header, block size
 void launch_png_choose(hipStream_t st, const DeflateCtx &c);   // per image: stream sizes, the winner, chunk byte offsets
 void launch_png_emit(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 2 on the winner: the blocks, in place
+void launch_png_deep_hist(hipStream_t st, const DeflateCtx &c);   // (inside launch_png_hist) the marked chunks' counts from the min-cost-path parse
+void launch_png_deep_emit(hipStream_t st, const DeflateCtx &c);   // (inside launch_png_emit) the winner's marked chunks
 void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces);   // max_pieces: KiB pieces of the largest IDAT chunk; crc_parts holds nimg * max_pieces   // zlib header + Adler-32, IDAT framing + CRC-32, carried chunks
 
 }  // namespace csp

@@ -1,0 +1,305 @@
+// png_parse.h -- the min-cost-path parse of a deflate chunk, one wave per chunk (statement: oracle/png_oracle.c deep_parse()).
+// What libdeflate's levels 10-12 (oxipng -o3 / -o4) and zopfli do in their own ways -- candidate matches per position, symbol costs from the
+// previous parse's statistics, the cheapest path, again -- laid out for a 64-lane wave:
+//   M  candidates, tile by tile as png_lz.h does it (a tile = 64 consecutive positions, one per lane): the six fixed distances, the four entries of the
+//      4-byte-hash table, the eight of a second table keyed by 8 bytes (the long matches far back).  Kept per position, in ONE 64-bit word in the wave's
+//      scratch area: c0 = the nearest candidate with >= 3 bytes, c1 = the longest, and the byte itself.
+//   C  costs (1/16 bit) of every literal, length and distance code from the counts of the parse before.
+//   D  the path: the chunk is 64 SEGMENTS of 512 bytes, one per lane; every lane walks its segment backwards with the costs of the next sixteen
+//      positions in registers (lengths above sixteen are tried only at a candidate's full length and look their cost up in the scratch area).  No lane
+//      waits for another; the scratch arrays are laid out [position in segment][lane], so a step's loads and stores are one line per array.
+//   F  every lane follows its segment's choices forwards and counts the symbols (LDS atomics).
+// C-D-F repeat `iters` times; the caller's sink then sees the tokens tile by tile, as from lz_chunk.
+#pragma once
+#include "png_lz.h"
+
+namespace csp {
+
+enum : uint32_t {
+    CSP_DEEP_DIV = 512,        // a chunk qualifies when matches * DIV >= tokens in its greedy parse
+    CSP_HASH8_BITS = 11, CSP_WAYS8 = 8,
+    CSP_DEEP_SEG = 512, CSP_DEEP_CAP = 16, CSP_DEEP_START = 64,
+    CSP_DEEP_ITERS = 3, CSP_DEEP_ITERS_ZOPFLI = 15,
+    // the wave's scratch area in HBM: candidates (8 B), choices (2 B), costs (4 B, one row more), visit marks (1 B) per position
+    CSP_DEEP_CAND_OFF = 0, CSP_DEEP_CHOICE_OFF = 262144, CSP_DEEP_COST_OFF = 327680, CSP_DEEP_TAKEN_OFF = 327680 + 131584, CSP_DEEP_SCRATCH = 524288,
+};
+static_assert(uint32_t(CSP_HASH8_BITS) == uint32_t(CSP_HASH_BITS), "one last-lane map serves both tables");
+static_assert(CSP_DEEP_TAKEN_OFF + 32768 <= CSP_DEEP_SCRATCH, "scratch layout");
+
+struct DeepLds {
+    uint64_t bucket[1u << CSP_HASH_BITS];        // 4-byte table: four 16-bit positions, most recent in the low bits (png_lz.h)
+    uint64_t bucket8[2][1u << CSP_HASH8_BITS];   // 8-byte table: ways 0..3 in [0], 4..7 in [1]
+    uint8_t lastlane[1u << CSP_HASH_BITS];
+    uint32_t hist[CSP_NSYM];
+    uint16_t lit_cost[256], len_cost[260], dist_cost[32];
+};
+
+__device__ __forceinline__ static uint32_t lz_hash8(uint64_t v) { return ((uint32_t(v) * 0x9E3779B1u) ^ (uint32_t(v >> 32) * 0x85EBCA6Bu)) >> (32 - CSP_HASH8_BITS); }
+__device__ __forceinline__ static uint32_t cost16_of(uint32_t c, uint32_t total) {   // 16 log2(total / c), 1 .. 240 (oracle: cost16_of)
+    const uint32_t q = (total << 8) / c;
+    const uint32_t e = 31u - uint32_t(__clz(q));
+    const uint32_t v = 16u * (e - 8u) + (((q << 4) >> e) & 15u);
+    return v < 1u ? 1u : v > 240u ? 240u : v;
+}
+// per-lane small arrays (registers on the device: every index is a constant after unrolling)
+#ifdef CSH_EMUL
+template <class T, int N> struct LVArr { T v[64][N]; __device__ T *operator[](int j) { return v[j]; } };
+#else
+template <class T, int N> struct LVArr { T v[N]; __device__ T *operator[](int) { return v; } };
+#endif
+
+// which lane of the tile is the last with each hash
+__device__ __forceinline__ static void deep_last_lanes(DeepLds &S, const LV<uint32_t> &hash, const LV<uint32_t> &hashable) {
+    LFOR(l) if (hashable[l]) S.lastlane[hash[l]] = uint8_t(l);
+    CSP_WAVE_SYNC();
+    for (;;) {
+        const uint64_t lose = lballot([&](int l) { return hashable[l] && int(S.lastlane[hash[l]]) < l; });
+        if (!lose) break;
+        LFOR(l) if ((lose >> l) & 1) S.lastlane[hash[l]] = uint8_t(l);
+        CSP_WAVE_SYNC();
+    }
+}
+__device__ __forceinline__ static void deep_insert(DeepLds &S, const LV<uint32_t> &h4, const LV<uint32_t> &ok4, const LV<uint32_t> &h8, const LV<uint32_t> &ok8, const LV<uint32_t> &rel) {
+    deep_last_lanes(S, h4, ok4);
+    LFOR(l) if (ok4[l] && int(S.lastlane[h4[l]]) == l && rel[l] != 0xFFFFu) S.bucket[h4[l]] = (S.bucket[h4[l]] << 16) | rel[l];
+    CSP_WAVE_SYNC();
+    deep_last_lanes(S, h8, ok8);
+    LFOR(l) if (ok8[l] && int(S.lastlane[h8[l]]) == l && rel[l] != 0xFFFFu) {
+        const uint64_t b0 = S.bucket8[0][h8[l]], b1 = S.bucket8[1][h8[l]];
+        S.bucket8[0][h8[l]] = (b0 << 16) | rel[l];
+        S.bucket8[1][h8[l]] = (b1 << 16) | (b0 >> 48);
+    }
+    CSP_WAVE_SYNC();
+}
+
+struct NoSink { __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t, const LV<uint32_t> &, const LV<uint32_t> &, const LV<uint32_t> &) {} };
+
+// data[start, end): a chunk of a stream of `total` bytes.  S.hist holds the last pass's counts on exit.  want_tokens: the sink sees the final parse.
+template <class Sink>
+__device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, DeepLds &S, uint8_t *scratch, int iters, bool want_tokens, Sink &sink) {
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(scratch + CSP_DEEP_CAND_OFF);   // [i][lane]: len0 | d0 << 9 | len1 << 25 | d1 << 34 | byte << 50
+    uint16_t *choice = reinterpret_cast<uint16_t *>(scratch + CSP_DEEP_CHOICE_OFF);
+    uint32_t *costs = reinterpret_cast<uint32_t *>(scratch + CSP_DEEP_COST_OFF);
+    uint8_t *tk = scratch + CSP_DEEP_TAKEN_OFF;
+    const uint32_t n = uint32_t(end - start);
+    // ---------------------------------------------------------------------------------------------------------------- M
+    LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH_BITS); i += 64) { S.bucket[i] = ~0ull; S.bucket8[0][i] = ~0ull; S.bucket8[1][i] = ~0ull; }
+    CSP_WAVE_SYNC();
+    {
+        const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
+        for (uint64_t t0 = seed0; t0 < start; t0 += 64) {
+            LV<uint32_t> h4, ok4, h8, ok8, rel;
+            LFOR(l) {
+                const uint64_t p = t0 + uint32_t(l);
+                const uint64_t v = load64u(data + p);
+                ok4[l] = p + 4 <= total ? 1u : 0u; ok8[l] = p + 8 <= total ? 1u : 0u;
+                h4[l] = ok4[l] ? lz_hash(uint32_t(v)) : 0u; h8[l] = ok8[l] ? lz_hash8(v) : 0u;
+                rel[l] = uint32_t(p + 32768 - start);
+            }
+            deep_insert(S, h4, ok4, h8, ok8, rel);
+        }
+    }
+    for (uint64_t t0 = start; t0 < end; t0 += 64) {
+        const uint32_t count = end - t0 < 64 ? uint32_t(end - t0) : 64u;
+        LV<uint32_t> h4, ok4, h8, ok8, rel;
+        LFOR(l) {
+            const uint64_t p = t0 + uint32_t(l);
+            h4[l] = 0; ok4[l] = 0; h8[l] = 0; ok8[l] = 0; rel[l] = uint32_t(p + 32768 - start);
+            if (uint32_t(l) < count) {
+                const uint32_t maxlen = end - p < 258 ? uint32_t(end - p) : 258u;
+                const uint64_t hi = load64u(data + p);
+                uint32_t len0 = 0, d0 = 0, len1 = 0, d1 = 0;   // c0: the nearest with >= 3 bytes; c1: the longest (ties: the nearer)
+                auto offer = [&](uint32_t L, uint32_t D) {
+                    if (L >= 3 && (!d0 || D < d0)) { len0 = L; d0 = D; }
+                    if (L > len1 || (L == len1 && L && D < d1)) { len1 = L; d1 = D; }
+                };
+                {   // the fixed distances against the 8 bytes in front of p
+                    const uint64_t lo = load64u(data + p - 8);   // (p < 8: whatever the pool holds there; guarded by d <= p)
+                    const uint32_t cap8 = maxlen < 8 ? maxlen : 8u;
+                    uint32_t l8best = 0, dbest = 0, f0l = 0, f0d = 0;
+                    CSH_UNROLL
+                    for (int k = 0; k < 6; k++) {
+                        const uint32_t d = k < 4 ? uint32_t(k + 1) : (k == 4 ? 6u : 8u);
+                        if (uint64_t(d) > p) continue;
+                        const uint64_t shifted = d == 8 ? lo : ((hi << (8 * d)) | (lo >> (64 - 8 * d)));
+                        const uint64_t x = hi ^ shifted;
+                        uint32_t l8 = x ? ctz64(x) >> 3 : 8u;
+                        if (l8 > cap8) l8 = cap8;
+                        if (l8 > l8best) { l8best = l8; dbest = d; }
+                        if (l8 >= 3 && !f0d) { f0l = l8; f0d = d; }
+                    }
+                    if (l8best) {
+                        uint32_t ln = l8best;
+                        if (l8best == 8 && maxlen > 8) ln = lz_lcp(data, p, dbest, maxlen, 8);
+                        if (f0d && f0d != dbest) offer(f0l, f0d);
+                        offer(ln, dbest);
+                    }
+                }
+                // both tables' candidates: their first eight bytes fetched together, then judged in any order (the rule above does not depend on it)
+                uint32_t dw[CSP_WAYS + CSP_WAYS8];
+                uint64_t xw[CSP_WAYS + CSP_WAYS8];
+                int nw = 0;
+                if (p + 4 <= total) {
+                    ok4[l] = 1; h4[l] = lz_hash(uint32_t(hi));
+                    const uint64_t b = S.bucket[h4[l]];
+                    for (int w = 0; w < int(CSP_WAYS); w++) {
+                        const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;
+                        if (r == 0xFFFFu) break;
+                        const uint32_t d = rel[l] - r;
+                        if (d > 32768u) break;
+                        dw[nw++] = d;
+                    }
+                }
+                if (p + 8 <= total) {
+                    ok8[l] = 1; h8[l] = lz_hash8(hi);
+                    const uint64_t b0 = S.bucket8[0][h8[l]], b1 = S.bucket8[1][h8[l]];
+                    for (int w = 0; w < int(CSP_WAYS8); w++) {
+                        const uint32_t r = uint32_t((w < 4 ? b0 : b1) >> (16 * (w & 3))) & 0xFFFFu;
+                        if (r == 0xFFFFu) break;
+                        const uint32_t d = rel[l] - r;
+                        if (d > 32768u) break;
+                        dw[nw++] = d;
+                    }
+                }
+                CSH_UNROLL
+                for (int w = 0; w < int(CSP_WAYS + CSP_WAYS8); w++) xw[w] = w < nw ? hi ^ load64u(data + p - dw[w]) : 0ull;
+                CSH_UNROLL
+                for (int w = 0; w < int(CSP_WAYS + CSP_WAYS8); w++) if (w < nw) {
+                    uint32_t ln;
+                    if (xw[w]) { ln = ctz64(xw[w]) >> 3; if (ln > maxlen) ln = maxlen; }
+                    else ln = maxlen > 8 ? lz_lcp(data, p, dw[w], maxlen, 8) : maxlen;
+                    offer(ln, dw[w]);
+                }
+                if (len1 <= len0) { len1 = 0; d1 = 0; }
+                const uint32_t off = uint32_t(p - start);
+                cand[uint64_t(off & (CSP_DEEP_SEG - 1)) * 64 + (off / CSP_DEEP_SEG)] =
+                    uint64_t(len0) | (uint64_t(d0) << 9) | (uint64_t(len1) << 25) | (uint64_t(d1) << 34) | ((hi & 255ull) << 50);
+            }
+        }
+        CSP_WAVE_SYNC();
+        deep_insert(S, h4, ok4, h8, ok8, rel);
+    }
+    CSP_MEM_FENCE();
+    // ---------------------------------------------------------------------------------------------------------------- C, D, F
+    LV<uint32_t> ns;   // lane = segment: how many positions it holds
+    LFOR(l) { const uint32_t s0 = uint32_t(l) * CSP_DEEP_SEG; ns[l] = s0 >= n ? 0u : (n - s0 < CSP_DEEP_SEG ? n - s0 : uint32_t(CSP_DEEP_SEG)); }
+    // the first pass's counts: every byte of the chunk a literal
+    LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.hist[i] = 0;
+    CSP_WAVE_SYNC();
+    for (uint64_t p0 = start; p0 < end; p0 += 512) LFOR(l) {   // eight bytes per lane and step
+        const uint64_t p = p0 + uint32_t(l) * 8u;
+        if (p + 8 <= end) { const uint64_t v = load64u(data + p); CSH_UNROLL for (int k = 0; k < 8; k++) atomicAdd(&S.hist[uint32_t(v >> (8 * k)) & 255u], 1u); }
+        else for (uint64_t q = p; q < end; q++) atomicAdd(&S.hist[data[q]], 1u);
+    }
+    CSP_WAVE_SYNC();
+    for (int it = 0; it < iters; it++) {
+        const bool final_pass = it + 1 == iters;
+        {
+            LV<uint64_t> a, b;
+            LFOR(l) { a[l] = 0; b[l] = 0; for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) { if (i < CSP_NLIT) a[l] += S.hist[i]; else b[l] += S.hist[i]; } }
+            const uint32_t tl = uint32_t(lsum(a)), td = uint32_t(lsum(b));
+            LFOR(l) {
+                for (uint32_t i = uint32_t(l); i < 256; i += 64) S.lit_cost[i] = uint16_t(S.hist[i] ? cost16_of(S.hist[i], tl) : cost16_of(1, 2 * tl));
+                for (uint32_t ln = 3 + uint32_t(l); ln <= 258; ln += 64) {
+                    const uint32_t c = len_code_of(ln), f = S.hist[257 + c];
+                    S.len_cost[ln] = uint16_t((it == 0 ? uint32_t(CSP_DEEP_START) : f ? cost16_of(f, tl) : cost16_of(1, 2 * tl)) + 16u * len_extra_of(c));
+                }
+                if (l < 30) {
+                    const uint32_t f = S.hist[CSP_NLIT + l];
+                    S.dist_cost[l] = uint16_t((it == 0 ? uint32_t(CSP_DEEP_START) : td == 0 ? 80u : f ? cost16_of(f, td) : cost16_of(1, 2 * td)) + 16u * dist_extra_of(uint32_t(l)));
+                }
+            }
+            CSP_WAVE_SYNC();
+            LFOR(l) for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) S.hist[i] = i == 256 ? 1u : 0u;
+            if (final_pass && want_tokens) LFOR(l) for (uint32_t i = uint32_t(l) * 8u; i < 32768u; i += 512u) *reinterpret_cast<unsigned long long *>(tk + i) = 0ull;
+            CSP_WAVE_SYNC();
+        }
+        // D: backwards through the segments; W[l][k] = cost of position i + 1 + k
+        LVArr<uint32_t, CSP_DEEP_CAP> W;
+        LFOR(l) { uint32_t *w = W[l]; CSH_UNROLL for (int k = 0; k < int(CSP_DEEP_CAP); k++) w[k] = 0; costs[uint64_t(ns[l]) * 64 + uint32_t(l)] = 0; }   // (the end of a segment costs nothing)
+        uint32_t lenc[CSP_DEEP_CAP + 1];
+        CSH_UNROLL
+        for (int k = 3; k <= int(CSP_DEEP_CAP); k++) lenc[k] = S.len_cost[k];
+        for (uint32_t i = CSP_DEEP_SEG; i-- > 0;) {
+            LFOR(l) if (i < ns[l]) {
+                uint32_t *w = W[l];
+                const uint64_t c = coherent_load(&cand[uint64_t(i) * 64 + uint32_t(l)]);
+                const uint32_t avail = ns[l] - i;
+                uint32_t l0 = uint32_t(c) & 511u, l1 = uint32_t(c >> 25) & 511u;
+                const uint32_t d0 = uint32_t(c >> 9) & 0xFFFFu, d1 = uint32_t(c >> 34) & 0xFFFFu;
+                if (l0 > avail) l0 = avail;
+                if (l1 > avail) l1 = avail;
+                uint32_t best = ((w[0] + S.lit_cost[uint32_t(c >> 50) & 255u]) << 9) | 1u;
+                if (l0 >= 3) {
+                    const uint32_t dc0 = S.dist_cost[dist_code_of(d0)];
+                    const uint32_t dc1 = l1 > l0 ? uint32_t(S.dist_cost[dist_code_of(d1)]) : 0u;
+                    const uint32_t top = l1 > l0 ? l1 : l0;
+                    CSH_UNROLL
+                    for (int k = 3; k <= int(CSP_DEEP_CAP); k++) {
+                        const uint32_t key = ((w[k - 1] + lenc[k] + (uint32_t(k) <= l0 ? dc0 : dc1)) << 9) | uint32_t(k);
+                        if (uint32_t(k) <= top && key < best) best = key;
+                    }
+                    if (l0 > CSP_DEEP_CAP) { const uint32_t key = ((costs[uint64_t(i + l0) * 64 + uint32_t(l)] + S.len_cost[l0] + dc0) << 9) | l0; if (key < best) best = key; }
+                    if (l1 > l0 && l1 > CSP_DEEP_CAP) { const uint32_t key = ((costs[uint64_t(i + l1) * 64 + uint32_t(l)] + S.len_cost[l1] + dc1) << 9) | l1; if (key < best) best = key; }
+                }
+                const uint32_t cst = best >> 9;
+                choice[uint64_t(i) * 64 + uint32_t(l)] = uint16_t(best & 511u);
+                costs[uint64_t(i) * 64 + uint32_t(l)] = cst;
+                CSH_UNROLL
+                for (int k = int(CSP_DEEP_CAP) - 1; k > 0; k--) w[k] = w[k - 1];
+                w[0] = cst;
+            }
+        }
+        // F: forwards; every lane counts its segment's symbols (final pass: and marks the positions the parse visits)
+        LV<uint32_t> at;
+        LFOR(l) at[l] = 0;
+        for (;;) {
+            if (!lballot([&](int l) { return at[l] < ns[l]; })) break;
+            LFOR(l) if (at[l] < ns[l]) {
+                const uint32_t i = at[l];
+                const uint32_t ch = choice[uint64_t(i) * 64 + uint32_t(l)];
+                const uint64_t c = coherent_load(&cand[uint64_t(i) * 64 + uint32_t(l)]);
+                if (final_pass && want_tokens) tk[uint32_t(l) * CSP_DEEP_SEG + i] = 1;
+                if (ch == 1) { atomicAdd(&S.hist[uint32_t(c >> 50) & 255u], 1u); at[l] = i + 1; }
+                else {
+                    const uint32_t avail = ns[l] - i;
+                    uint32_t l0 = uint32_t(c) & 511u;
+                    if (l0 > avail) l0 = avail;
+                    const uint32_t d = ch <= l0 ? uint32_t(c >> 9) & 0xFFFFu : uint32_t(c >> 34) & 0xFFFFu;
+                    atomicAdd(&S.hist[257 + len_code_of(ch)], 1u); atomicAdd(&S.hist[CSP_NLIT + dist_code_of(d)], 1u);
+                    at[l] = i + ch;
+                }
+            }
+        }
+        CSP_WAVE_SYNC();
+    }
+    if (!want_tokens) return;
+    // ---------------------------------------------------------------------------------------------------------------- the tokens, tile by tile
+    CSP_MEM_FENCE();
+    for (uint64_t t0 = start; t0 < end; t0 += 64) {
+        const uint32_t count = end - t0 < 64 ? uint32_t(end - t0) : 64u;
+        LV<uint32_t> mlen, mdist, lit, visited;
+        LFOR(l) {
+            mlen[l] = 0; mdist[l] = 0; lit[l] = 0; visited[l] = 0;
+            if (uint32_t(l) < count) {
+                const uint32_t off = uint32_t(t0 - start) + uint32_t(l), seg = off / CSP_DEEP_SEG, i = off & (CSP_DEEP_SEG - 1);
+                const uint64_t c = coherent_load(&cand[uint64_t(i) * 64 + seg]);
+                lit[l] = uint32_t(c >> 50) & 255u;
+                visited[l] = coherent_load(&tk[off]);
+                if (visited[l]) {
+                    const uint32_t ch = coherent_load(&choice[uint64_t(i) * 64 + seg]);
+                    if (ch != 1) {
+                        const uint32_t nseg = n - seg * CSP_DEEP_SEG < CSP_DEEP_SEG ? n - seg * CSP_DEEP_SEG : uint32_t(CSP_DEEP_SEG), avail = nseg - i;
+                        uint32_t l0 = uint32_t(c) & 511u;
+                        if (l0 > avail) l0 = avail;
+                        mlen[l] = ch; mdist[l] = ch <= l0 ? uint32_t(c >> 9) & 0xFFFFu : uint32_t(c >> 34) & 0xFFFFu;
+                    }
+                }
+            }
+        }
+        const uint64_t taken = lballot([&](int l) { return visited[l] != 0; });
+        sink.tile(t0, count, taken, mlen, mdist, lit);
+    }
+}
+
+}  // namespace csp

@@ -13,6 +13,7 @@
 #include "../../include/png_quality_table.h"
 #include "devmem.hpp"
 #include "png_kernels.h"
+#include "png_parse.h"
 #include "webp_kernels.h"
 #include "../../include/vp8_tables.h"
 #include "resize_host.h"
@@ -194,6 +195,9 @@ struct csp_batch {
     DevBuf<uint64_t> d_scores, d_trial_bytes;
     DevBuf<int32_t> d_winner;
     DevBuf<PngChunk> d_chunks;
+    DevBuf<uint8_t> d_deep;         // the min-cost-path kernels' scratch areas (png_parse.h)
+    uint32_t deep_slots = 0;
+    int deep_iters = CSP_DEEP_ITERS;   // png.force_zopfli: CSP_DEEP_ITERS_ZOPFLI
     hipEvent_t ev[CSP_NKERNELS + 1]{};
     bool have_events = false, ran = false;
     ~csp_batch() {
@@ -264,6 +268,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     std::unique_ptr<csp_batch> b(new csp_batch);
     b->device = device;
     b->lossy = !p->png_optimize; b->png_quality = int(p->png_quality);
+    b->deep_iters = (p->png_optimize && p->png_force_zopfli) ? int(CSP_DEEP_ITERS_ZOPFLI) : int(CSP_DEEP_ITERS);
     b->from_pixels = px != nullptr;
     b->decode_only = decode_only;
     b->to_webp = to_webp; b->webp_quality = int(p->webp_quality);
@@ -765,6 +770,12 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     mark(); if (need_scores) launch_png_scores(st, f);
     mark(); if (b->plan.need_brute) launch_png_brute(st, f);
     mark(); launch_png_pick(st, f);
+    {   // one scratch area per workgroup the device holds at the parse kernels' LDS footprint (three per CU), no more than there are items
+        const uint64_t items = uint64_t(b->total_chunks) * uint32_t(b->plan.ntrials);
+        b->deep_slots = uint32_t(std::min<uint64_t>(items, 768));
+        if (b->deep_slots && b->d_deep.alloc(size_t(b->deep_slots) * CSP_DEEP_SCRATCH)) return CS_ERR_NO_DEVICE;
+        d.deep_scratch = b->d_deep.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters;
+    }
     mark(); launch_png_hist(st, d);
     mark(); launch_png_codes(st, d);
     mark(); launch_png_choose(st, d);

@@ -70,7 +70,7 @@ struct PngChunk {
     uint8_t hdr_sym[CSP_NSYM], hdr_extra[CSP_NSYM];
     uint64_t bits;                // size of the block in bits (header + data + end-of-block)
     uint32_t bytes;               // bytes this chunk contributes to the zlib stream (block + sync marker / final padding)
-    uint32_t pad_;
+    uint32_t deep;                // 1: the chunk takes the min-cost-path parse (k_png_hist decides, png_parse.h)
 };
 
 // trial plan of a batch (the same for every image: one --png-opt-level per call)

@@ -125,6 +125,10 @@ def lib():
         L.cso_deflate_zlib.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_trials.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.cso_png_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.cso_png_optimize_zopfli.argtypes = L.cso_png_optimize.argtypes
+        L.cso_png_optimize_iters.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_png_deep_div.argtypes = [C.c_int]
+        L.cso_png_deep_div.restype = None
         L.cso_vp8enc_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
         L.cso_vp8enc_encode_rgb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_vp8_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -397,17 +401,32 @@ def png_trials(level):
     return [arr[i] for i in range(n)]
 
 
-def png_optimize(data, level=3, keep_metadata=False):
-    """-> (file bytes, winning strategy or -1 when the input is returned unchanged)"""
+def png_optimize(data, level=3, keep_metadata=False, zopfli=False):
+    """-> (file bytes, winning strategy or -1 when the input is returned unchanged); zopfli: png.force_zopfli (more passes of the cost model)"""
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t()
     chosen = C.c_int()
-    rc = lib().cso_png_optimize(data, len(data), level, 1 if keep_metadata else 0, C.byref(out), C.byref(n), C.byref(chosen))
+    fn = lib().cso_png_optimize_zopfli if zopfli else lib().cso_png_optimize
+    rc = fn(data, len(data), level, 1 if keep_metadata else 0, C.byref(out), C.byref(n), C.byref(chosen))
     if rc:
         raise PngError(rc)
     res = C.string_at(out, n.value)
     lib().cso_free(out)
     return res, chosen.value
+
+
+def png_optimize_iters(data, level, iters, deep_div=0):
+    """tools: the lossless recode with `iters` passes of the min-cost-path parse (0: the greedy parse everywhere); deep_div overrides which chunks qualify"""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    lib().cso_png_deep_div(deep_div)
+    rc = lib().cso_png_optimize_iters(data, len(data), level, iters, C.byref(out), C.byref(n))
+    lib().cso_png_deep_div(0)
+    if rc:
+        raise PngError(rc)
+    res = C.string_at(out, n.value)
+    lib().cso_free(out)
+    return res
 
 
 # ---------------------------------------------------------------- lossy WebP row (webp_oracle.c: libwebp's import; the encoder is vp8enc_oracle.c below)

@@ -886,6 +886,190 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
         }
     }
 }
+/* ------------------------------------------------------------------------------------------------ the min-cost-path parse
+ * What libdeflate's levels 10-12 (oxipng -o3 / -o4 call 11 / 12) and zopfli do in their own ways: find, per position, a few candidate
+ * matches, give every symbol a cost from the statistics of the previous parse, take the cheapest path through the chunk, and repeat.
+ * Restated for the GPU's shape (k_png_parse.hip runs the same steps; every rule below is order-independent or tie-broken explicitly):
+ *   WHICH CHUNKS: a chunk whose greedy parse (tokenize) made at least one token in DEEP_DIV (512) a match.  Photographic chunks have next to
+ *   no matches and nothing to choose between: they keep the greedy parse (and its speed).
+ *   CANDIDATES of position p: distances from (a) the fixed set 1,2,3,4,6,8 -- of these f0 = the nearest whose first 8 bytes agree in
+ *   >= 3, f1 = the one that agrees longest inside 8 bytes (ties: the nearer; extended when all 8 agree); (b) the four 4-byte-hash
+ *   entries of tokenize's table; (c) the DEEP_WAYS8 entries of a second table keyed by 8 bytes (2048 buckets, refreshed tile by tile
+ *   in the same way), which is where the long matches far back come from.  Kept per position: c0 = the nearest candidate that matches
+ *   >= 3 bytes, c1 = the longest (ties: the nearer), if longer than c0.  Lengths up to c0's use c0's distance, longer ones c1's.
+ *   COSTS in 1/16 bit: 16 log2(total / count) (literal_costs' integer log2) per literal / length / distance symbol from the
+ *   previous parse's counts, a symbol that did not occur costs as if it had occurred half a time; plus the extra bits.
+ *   PATH: the chunk is cut into DEEP_SEG-byte segments (one per GPU lane); per segment, backwards, cost[i] = min over: the literal,
+ *   c0 at lengths 3..min(len0, DEEP_CAP) and len0, c1 at lengths len0+1..min(len1, DEEP_CAP) and len1 (lengths above DEEP_CAP only in
+ *   full: the cost window of a lane is DEEP_CAP wide).  Ties: the literal, then the shorter length (key = cost << 9 | length).
+ *   Matches end at their segment's end.
+ *   ITERATIONS: DEEP_ITERS passes, each from the counts of the one before; the first prices literals by the chunk's byte counts and both symbols of
+ *   a match at DEEP_START / 16 bits (+ extra bits); --zopfli: DEEP_ITERS_ZOPFLI. */
+#define DEEP_DIV 512
+#define DEEP_HASH8_BITS 11
+#define DEEP_WAYS8 8
+#define DEEP_SEG 512
+#define DEEP_CAP 16
+#define DEEP_ITERS 3
+#define DEEP_START 64   /* 1/16 bit */
+#define DEEP_ITERS_ZOPFLI 15
+static int deep_div_override = 0;   /* tools only (tools/png_parse_gap.py sweeps it): 0 = DEEP_DIV */
+void cso_png_deep_div(int v) { deep_div_override = v; }
+static uint32_t hash8(const uint8_t *d) {
+    uint32_t lo = d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24);
+    uint32_t hi = d[4] | ((uint32_t)d[5] << 8) | ((uint32_t)d[6] << 16) | ((uint32_t)d[7] << 24);
+    return ((lo * 0x9E3779B1u) ^ (hi * 0x85EBCA6Bu)) >> (32 - DEEP_HASH8_BITS);
+}
+static void insert_tile8(uint16_t (*table)[DEEP_WAYS8], const uint8_t *data, size_t total, size_t base_rel, size_t t0, size_t t1) {
+    size_t lastpos[1 << DEEP_HASH8_BITS];
+    for (size_t p = t0; p < t1 && p + 8 <= total; p++) lastpos[hash8(data + p)] = p;
+    for (size_t p = t0; p < t1 && p + 8 <= total; p++) {
+        uint32_t h = hash8(data + p);
+        size_t rel = p + base_rel;
+        if (lastpos[h] != p || rel == 0xFFFF) continue;
+        for (int w = DEEP_WAYS8 - 1; w > 0; w--) table[h][w] = table[h][w - 1];
+        table[h][0] = (uint16_t)rel;
+    }
+}
+static uint32_t cost16_of(uint32_t c, uint32_t total) {   /* 16 log2(total / c), 1 .. 240; c >= 1, total >= c, total < 2^23 */
+    const uint32_t q = (total << 8) / c;
+    int e = 31; while (!((q >> e) & 1)) e--;
+    uint32_t v = 16u * (uint32_t)(e - 8) + (((q << 4) >> e) & 15u);
+    return v < 1 ? 1 : v > 240 ? 240 : v;
+}
+typedef struct { uint16_t len0, d0, len1, d1; } deep_cand;
+static void deep_costs(const uint32_t *lf, const uint32_t *df, uint32_t *lit_cost, uint32_t *len_cost, uint32_t *dist_cost) {
+    uint32_t tl = 0, td = 0;
+    for (int i = 0; i < 286; i++) tl += lf[i];
+    for (int i = 0; i < 30; i++) td += df[i];
+    for (int i = 0; i < 256; i++) lit_cost[i] = lf[i] ? cost16_of(lf[i], tl) : cost16_of(1, 2 * tl);
+    for (int l = 3; l <= 258; l++) { int c = len_code(l); len_cost[l] = (lf[257 + c] ? cost16_of(lf[257 + c], tl) : cost16_of(1, 2 * tl)) + 16u * (uint32_t)LEN_EXTRA[c]; }
+    for (int c = 0; c < 30; c++) dist_cost[c] = (td == 0 ? 80u : df[c] ? cost16_of(df[c], td) : cost16_of(1, 2 * td)) + 16u * (uint32_t)DIST_EXTRA[c];
+}
+/* tok / taken: out, as tokenize() */
+static void deep_parse(const uint8_t *data, size_t total, size_t start, size_t end, int iters, token *tok, uint8_t *taken) {
+    const size_t n = end - start;
+    deep_cand *cand = (deep_cand *)malloc(sizeof(deep_cand) * n);
+    {
+        uint16_t table[1 << HASH_BITS][WAYS];
+        static uint16_t table8[1 << DEEP_HASH8_BITS][DEEP_WAYS8];
+        memset(table, 0xFF, sizeof table);
+        memset(table8, 0xFF, sizeof table8);
+        const size_t seed0 = start > 32768 ? start - 32768 : 0;
+        const size_t base_rel = 32768 - start;
+        for (size_t t0 = seed0; t0 < start; t0 += 64) { insert_tile(table, data, total, base_rel, t0, t0 + 64); insert_tile8(table8, data, total, base_rel, t0, t0 + 64); }
+        for (size_t t0 = start; t0 < end; t0 += 64) {
+            size_t t1 = t0 + 64 < end ? t0 + 64 : end;
+            for (size_t p = t0; p < t1; p++) {
+                const size_t maxlen = end - p < 258 ? end - p : 258;
+                size_t len0 = 0, d0 = 0, len1 = 0, d1 = 0;   /* c0: nearest with >= 3; c1: longest, ties nearer */
+#define DEEP_OFFER(L_, D_) do { size_t L__ = (L_), D__ = (D_); if (L__ >= 3 && (!d0 || D__ < d0)) { len0 = L__; d0 = D__; } if (L__ > len1 || (L__ == len1 && L__ && D__ < d1)) { len1 = L__; d1 = D__; } } while (0)
+                {
+                    size_t l8best = 0, dbest = 0, f0l = 0, f0d = 0;
+                    for (int k = 0; k < 6; k++) {
+                        size_t d = (size_t)FIXED_DIST[k];
+                        if (d > p) continue;
+                        size_t l8 = lcp(data + p, data + p - d, maxlen < 8 ? maxlen : 8);
+                        if (l8 > l8best) { l8best = l8; dbest = d; }
+                        if (l8 >= 3 && !f0d) { f0l = l8; f0d = d; }
+                    }
+                    if (l8best) {
+                        size_t l = l8best;
+                        if (l8best == 8 && maxlen > 8) l = lcp(data + p, data + p - dbest, maxlen);
+                        if (f0d && f0d != dbest) DEEP_OFFER(f0l, f0d);
+                        DEEP_OFFER(l, dbest);
+                    }
+                }
+                if (p + 4 <= total) {
+                    uint32_t h = hash4(data + p);
+                    for (int w = 0; w < WAYS; w++) {
+                        if (table[h][w] == 0xFFFF) break;
+                        size_t d = (p + base_rel) - table[h][w];
+                        if (d > 32768) break;
+                        DEEP_OFFER(lcp(data + p, data + p - d, maxlen), d);
+                    }
+                }
+                if (p + 8 <= total) {
+                    uint32_t h = hash8(data + p);
+                    for (int w = 0; w < DEEP_WAYS8; w++) {
+                        if (table8[h][w] == 0xFFFF) break;
+                        size_t d = (p + base_rel) - table8[h][w];
+                        if (d > 32768) break;
+                        DEEP_OFFER(lcp(data + p, data + p - d, maxlen), d);
+                    }
+                }
+#undef DEEP_OFFER
+                if (len1 <= len0) { len1 = 0; d1 = 0; }
+                deep_cand *c = &cand[p - start];
+                c->len0 = (uint16_t)len0; c->d0 = (uint16_t)(d0 & 0xFFFF); c->len1 = (uint16_t)len1; c->d1 = (uint16_t)(d1 & 0xFFFF);   /* 32768 is kept as 32768 */
+            }
+            insert_tile(table, data, total, base_rel, t0, t1);
+            insert_tile8(table8, data, total, base_rel, t0, t1);
+        }
+    }
+    uint32_t lf[286], df[30];   /* the first pass's counts: every byte of the chunk a literal (its matches: DEEP_START) */
+    memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
+    for (size_t p = start; p < end; p++) lf[data[p]]++;
+    uint32_t *cost = (uint32_t *)malloc(sizeof(uint32_t) * (DEEP_SEG + 1));
+    uint16_t *choice = (uint16_t *)malloc(sizeof(uint16_t) * n);
+    for (int it = 0; it < iters; it++) {
+        uint32_t lit_cost[256], len_cost[259], dist_cost[30];
+        deep_costs(lf, df, lit_cost, len_cost, dist_cost);
+        if (it == 0) {   /* no parse yet: start as if a match's two symbols cost DEEP_START / 16 bits each */
+            for (int l = 3; l <= 258; l++) len_cost[l] = DEEP_START + 16u * (uint32_t)LEN_EXTRA[len_code(l)];
+            for (int c = 0; c < 30; c++) dist_cost[c] = DEEP_START + 16u * (uint32_t)DIST_EXTRA[c];
+        }
+        memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
+        for (size_t s0 = 0; s0 < n; s0 += DEEP_SEG) {
+            const size_t ns = n - s0 < DEEP_SEG ? n - s0 : DEEP_SEG;
+            cost[ns] = 0;
+            for (size_t i = ns; i-- > 0;) {
+                const deep_cand *c = &cand[s0 + i];
+                const size_t avail = ns - i;
+                const size_t l0 = c->len0 < avail ? c->len0 : avail, l1 = c->len1 < avail ? c->len1 : avail;
+                uint32_t best = ((cost[i + 1] + lit_cost[data[start + s0 + i]]) << 9) | 1u;
+                if (l0 >= 3) {
+                    const uint32_t dc0 = dist_cost[dist_code(c->d0 ? c->d0 : 1)];
+                    const size_t top = l0 < DEEP_CAP ? l0 : DEEP_CAP;
+                    for (size_t l = 3; l <= top; l++) { uint32_t k = ((cost[i + l] + len_cost[l] + dc0) << 9) | (uint32_t)l; if (k < best) best = k; }
+                    if (l0 > DEEP_CAP) { uint32_t k = ((cost[i + l0] + len_cost[l0] + dc0) << 9) | (uint32_t)l0; if (k < best) best = k; }
+                    if (l1 > l0) {
+                        const uint32_t dc1 = dist_cost[dist_code(c->d1)];
+                        const size_t top1 = l1 < DEEP_CAP ? l1 : DEEP_CAP;
+                        for (size_t l = l0 + 1; l <= top1; l++) { uint32_t k = ((cost[i + l] + len_cost[l] + dc1) << 9) | (uint32_t)l; if (k < best) best = k; }
+                        if (l1 > DEEP_CAP) { uint32_t k = ((cost[i + l1] + len_cost[l1] + dc1) << 9) | (uint32_t)l1; if (k < best) best = k; }
+                    }
+                }
+                cost[i] = best >> 9;
+                choice[s0 + i] = (uint16_t)(best & 511u);
+            }
+            for (size_t i = 0; i < ns;) {
+                const deep_cand *c = &cand[s0 + i];
+                const size_t avail = ns - i, l = choice[s0 + i];
+                if (l == 1) { lf[data[start + s0 + i]]++; i++; continue; }
+                const size_t l0 = c->len0 < avail ? c->len0 : avail;
+                const size_t d = l <= l0 ? c->d0 : c->d1;
+                lf[257 + len_code((int)l)]++; df[dist_code((int)d)]++;
+                i += l;
+            }
+        }
+        lf[256] = 1;
+    }
+    memset(taken, 0, n);
+    for (size_t s0 = 0; s0 < n; s0 += DEEP_SEG) {
+        const size_t ns = n - s0 < DEEP_SEG ? n - s0 : DEEP_SEG;
+        for (size_t i = 0; i < ns;) {
+            const deep_cand *c = &cand[s0 + i];
+            const size_t avail = ns - i, l = choice[s0 + i];
+            taken[s0 + i] = 1;
+            if (l == 1) { tok[s0 + i].len = 0; tok[s0 + i].dist = 0; i++; continue; }
+            const size_t l0 = c->len0 < avail ? c->len0 : avail;
+            tok[s0 + i].len = (uint16_t)l; tok[s0 + i].dist = (uint16_t)(l <= l0 ? c->d0 : c->d1);
+            i += l;
+        }
+    }
+    free(cand); free(cost); free(choice);
+}
 /* code lengths for freq[0..n): Huffman, then limited to `limit` bits */
 static void code_lengths(const uint32_t *freq_in, int n, int limit, uint8_t *len_out) {
     uint32_t freq[288]; int codesize[288], others[288], idx[288], m = 0;
@@ -963,7 +1147,7 @@ static int header_symbols(const uint8_t *seq, int n, uint8_t *sym, uint8_t *extr
     }
     return m;
 }
-static void deflate_chunk(const uint8_t *data, size_t total, size_t start, size_t end, int last, obits *o) {
+static void deflate_chunk(const uint8_t *data, size_t total, size_t start, size_t end, int last, int iters, obits *o) {
     size_t n = end - start;
     token *tok = (token *)malloc(sizeof(token) * n);
     uint8_t *taken = (uint8_t *)malloc(n);
@@ -975,6 +1159,30 @@ static void deflate_chunk(const uint8_t *data, size_t total, size_t start, size_
         if (tok[i].len) { lf[257 + len_code(tok[i].len)]++; df[dist_code(tok[i].dist)]++; } else lf[data[start + i]]++;
     }
     lf[256] = 1;
+    {
+        uint32_t nm = 0, nt = 0;
+        for (int i = 0; i < 286; i++) if (i != 256) nt += lf[i];
+        for (int i = 257; i < 286; i++) nm += lf[i];
+        if (iters > 0 && nm * (uint32_t)(deep_div_override ? deep_div_override : DEEP_DIV) >= nt) {
+            double ent0 = 0; uint64_t avgl = 0;
+            if (getenv("CSO_DEEP_REPORT")) { uint16_t c16[256]; literal_costs(data, start, end, c16); for (size_t i = start; i < end; i++) avgl += c16[data[i]]; avgl /= n;
+                uint32_t T = 0, TD = 0; for (int i = 0; i < 286; i++) T += lf[i]; for (int i = 0; i < 30; i++) TD += df[i];
+                for (int i = 0; i < 286; i++) if (lf[i]) ent0 += lf[i] * (double)cost16_of(lf[i], T) / 16 + (i > 256 ? lf[i] * LEN_EXTRA[i - 257] : 0);
+                for (int i = 0; i < 30; i++) if (df[i]) ent0 += df[i] * (double)cost16_of(df[i], TD) / 16 + df[i] * DIST_EXTRA[i]; }
+            deep_parse(data, total, start, end, iters, tok, taken);
+            memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
+            for (size_t i = 0; i < n; i++) {
+                if (!taken[i]) continue;
+                if (tok[i].len) { lf[257 + len_code(tok[i].len)]++; df[dist_code(tok[i].dist)]++; } else lf[data[start + i]]++;
+            }
+            lf[256] = 1;
+            if (getenv("CSO_DEEP_REPORT")) { double ent1 = 0;
+                uint32_t T = 0, TD = 0; for (int i = 0; i < 286; i++) T += lf[i]; for (int i = 0; i < 30; i++) TD += df[i];
+                for (int i = 0; i < 286; i++) if (lf[i]) ent1 += lf[i] * (double)cost16_of(lf[i], T) / 16 + (i > 256 ? lf[i] * LEN_EXTRA[i - 257] : 0);
+                for (int i = 0; i < 30; i++) if (df[i]) ent1 += df[i] * (double)cost16_of(df[i], TD) / 16 + df[i] * DIST_EXTRA[i];
+                fprintf(stderr, "chunk %zu avglit16 %llu nm %u nt %u greedy %.0f deep %.0f gain %.2f%%\n", start / CHUNK, (unsigned long long)avgl, nm, nt, ent0 / 8, ent1 / 8, 100 * (ent0 - ent1) / ent0); }
+        }
+    }
     uint8_t ll[286], dl[30];
     uint16_t lc[286], dc[30];
     code_lengths(lf, 286, 15, ll);
@@ -1038,13 +1246,16 @@ static uint64_t fixed_cost_row(const uint8_t *row, size_t n, int bpp) {
     free(tok); free(taken);
     return bits - sub;
 }
-int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len) {
+int cso_deflate_zlib_iters(const uint8_t *data, size_t n, int iters, uint8_t **out, size_t *out_len);
+int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len) { return cso_deflate_zlib_iters(data, n, DEEP_ITERS, out, out_len); }
+/* iters: passes of the min-cost-path parse over the chunks that qualify (0: greedy parse everywhere; DEEP_ITERS; --zopfli: DEEP_ITERS_ZOPFLI) */
+int cso_deflate_zlib_iters(const uint8_t *data, size_t n, int iters, uint8_t **out, size_t *out_len) {
     obits o; memset(&o, 0, sizeof o);
     put(&o, 0x78, 8); put(&o, 0xDA, 8);
     if (n == 0) { put(&o, 1, 1); put(&o, 1, 2); put(&o, 0, 7); align(&o); }
     for (size_t s = 0; s < n; s += CHUNK) {
         size_t e = s + CHUNK < n ? s + CHUNK : n;
-        deflate_chunk(data, n, s, e, e == n, &o);
+        deflate_chunk(data, n, s, e, e == n, iters, &o);
     }
     uint32_t ad = cso_adler32(data, n);
     put(&o, ad >> 24, 8); put(&o, (ad >> 16) & 255, 8); put(&o, (ad >> 8) & 255, 8); put(&o, ad & 255, 8);
@@ -1064,7 +1275,7 @@ int cso_png_trials(int level, int *set) {
     memcpy(set, s, sizeof(int) * (size_t)n);
     return n;
 }
-static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata, int lossy, int quality, uint8_t **out, size_t *out_len, int *chosen) {
+static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata, int lossy, int quality, int iters, uint8_t **out, size_t *out_len, int *chosen) {
     cso_png *P = NULL;
     int rc = cso_png_decode(in, n, keep_metadata, &P);
     if (rc) return rc;
@@ -1077,7 +1288,7 @@ static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata,
     for (int t = 0; t < ns; t++) {
         uint8_t *z; size_t zl;
         cso_png_filter(P, set[t], filt, NULL);
-        cso_deflate_zlib(filt, raw_len, &z, &zl);
+        cso_deflate_zlib_iters(filt, raw_len, iters, &z, &zl);
         if (!best || zl < best_len) { free(best); best = z; best_len = zl; best_s = set[t]; } else free(z);
     }
     free(filt);
@@ -1102,11 +1313,19 @@ static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata,
     return 0;
 }
 int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen) {
-    return png_recode(in, n, level, keep_metadata, 0, 0, out, out_len, chosen);
+    return png_recode(in, n, level, keep_metadata, 0, 0, DEEP_ITERS, out, out_len, chosen);
+}
+/* png.force_zopfli (--zopfli): the same coder with DEEP_ITERS_ZOPFLI passes of the cost model */
+int cso_png_optimize_zopfli(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen) {
+    return png_recode(in, n, level, keep_metadata, 0, 0, DEEP_ITERS_ZOPFLI, out, out_len, chosen);
+}
+/* tools: any number of passes (0 = the greedy parse everywhere) */
+int cso_png_optimize_iters(const uint8_t *in, size_t n, int level, int iters, uint8_t **out, size_t *out_len) {
+    return png_recode(in, n, level, 0, 0, 0, iters, out, out_len, NULL);
 }
 /* `-q` on a PNG: the reductions, the quantiser, then the same filter trials and coder; the result is returned whatever its size */
 int cso_png_lossy(const uint8_t *in, size_t n, int level, int keep_metadata, int quality, uint8_t **out, size_t *out_len) {
-    return png_recode(in, n, level, keep_metadata, 1, quality, out, out_len, NULL);
+    return png_recode(in, n, level, keep_metadata, 1, quality, DEEP_ITERS, out, out_len, NULL);
 }
 
 /* ---- PNG -> WebP (caesium::convert_in_memory with a PNG source, /root/reference/src/compressor.rs:289-299): the decoded pixels as the

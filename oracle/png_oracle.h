@@ -27,6 +27,10 @@ int cso_png_to_rgb(const cso_png *P, uint8_t *rgb);   /* width * height * 3 byte
 int cso_png_to_webp(const uint8_t *in, size_t n, int quality, uint8_t **out, size_t *out_len);
 int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice);
 int cso_deflate_zlib(const uint8_t *data, size_t n, uint8_t **out, size_t *out_len);
+int cso_deflate_zlib_iters(const uint8_t *data, size_t n, int iters, uint8_t **out, size_t *out_len);
+int cso_png_optimize_zopfli(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen);
+int cso_png_optimize_iters(const uint8_t *in, size_t n, int level, int iters, uint8_t **out, size_t *out_len);
+void cso_png_deep_div(int v);
 int cso_png_trials(int level, int *set);
 int cso_png_optimize(const uint8_t *in, size_t n, int level, int keep_metadata, uint8_t **out, size_t *out_len, int *chosen);
 /* lossless WebP output (VP8L) as the device coder writes it (k_vp8l_enc.hip): px = width * height * channels bytes (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA) */

@@ -173,13 +173,31 @@ def test_emul_reference_sample_pngs(api, reference_samples):
         assert np.array_equal(np.asarray(Image.open(io.BytesIO(out)).convert("RGB")), np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
 
 
-def test_emul_zopfli_is_refused_loudly(api):
-    from _util import package, png_cases
-    png = dict(png_cases())["RGB_97x61"]
-    with pytest.raises(Exception) as e:
-        api.compress_in_memory(png, package().default_parameters(png_optimize=True, png_force_zopfli=True))
-    assert e.value.code == 10201 and "zopfli" in str(e.value)
-    assert isinstance(api.compress_in_memory(png, package().default_parameters(png_optimize=True)), bytes)
+def deep_parse_cases():
+    """pictures whose chunks take the min-cost-path parse (matches in at least one token of 512): smooth, flat, indexed, one whose last chunk is short"""
+    from gen_synth import synth_png
+    return [("smooth_rgb_200x150", synth_png(51, 200, 150, "RGB", texture=0.4)), ("smooth_l_300x220", synth_png(52, 300, 220, "L", texture=0.3)),
+            ("indexed_160x120", synth_png(53, 160, 120, "P", texture=1.0)), ("smooth_rgba_130x70", synth_png(54, 130, 70, "RGBA", texture=0.5))]
+
+
+def test_emul_min_cost_path_parse(api):
+    """chunks with enough matches: candidates from both hash tables, costs from the previous pass, the per-segment path -- file == oracle"""
+    check_batch(api, deep_parse_cases(), 3)
+    check_batch(api, deep_parse_cases()[:2], 1, stages=False)
+
+
+def test_emul_zopfli_means_more_passes(api):
+    """png.force_zopfli (--zopfli): the same coder with CSP_DEEP_ITERS_ZOPFLI passes of the cost model; == the oracle's statement of it, never larger than
+    a plain run by more than a block header's noise, and the pixels are the input's"""
+    import io
+    from PIL import Image
+    from _util import package
+    for name, png in deep_parse_cases()[:3]:
+        z = api.compress_in_memory(png, package().default_parameters(png_optimize=True, png_force_zopfli=True))
+        plain = api.compress_in_memory(png, package().default_parameters(png_optimize=True))
+        assert z == O.png_optimize(png, 3, zopfli=True)[0], name
+        assert len(z) <= len(plain) + 16, (name, len(z), len(plain))
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(z)).convert("RGBA")), np.asarray(Image.open(io.BytesIO(png)).convert("RGBA"))), name
 
 
 def index_depth_cases():
