@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_hist(DeflateCtx c) {
 }
 
 // ------------------------------------------------------------------------------------------------ codes
-__global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c) {
+__global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c, int only_deep) {   // only_deep: the records k_png_deep_hist has rewritten
     const uint32_t bc = blockIdx.x * blockDim.x + threadIdx.x, trial = blockIdx.y;
     if (bc >= c.total_chunks) return;
     const uint32_t image = c.chunk_image[bc];
@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c) {
     const PngImg &im = c.imgs[image];
     const uint32_t ci = bc - c.chunk_first[image];
     PngChunk &rec = chunk_rec(c, im, c.plan.trial_slot[trial], ci);
+    if (only_deep && !rec.deep) return;
     code_lengths(rec.freq, CSP_NLIT, 15, rec.len);
     code_lengths(rec.freq + CSP_NLIT, CSP_NDIST, 15, rec.len + CSP_NLIT);
     canonical(rec.len, CSP_NLIT, rec.code);
@@ -126,6 +127,9 @@ __global__ void __launch_bounds__(64) k_png_choose(DeflateCtx c) {
         c.trial_bytes[uint64_t(image) * CSP_MAX_STREAMS + t] = bytes;
         if (bytes < best_bytes) { best_bytes = bytes; best = t; }
     }
+    // which trials take the min-cost-path parse (read by k_png_deep_hist behind the first of the two calls; oracle: png_recode)
+    for (int t = 0; t < c.plan.ntrials; t++)
+        c.trial_live[uint64_t(image) * CSP_MAX_STREAMS + t] = c.trial_bytes[uint64_t(image) * CSP_MAX_STREAMS + t] * CSP_DEEP_LIVE_DEN <= best_bytes * CSP_DEEP_LIVE_NUM ? 1 : 0;
     c.winner[image] = best;
     const uint64_t file_len = uint64_t(im.prefix_len) + 12 + best_bytes + im.suffix_len;
     if (file_len > im.out_cap) { c.status[image] = CSP_ERR_POOL; return; }
@@ -287,8 +291,8 @@ __global__ void __launch_bounds__(64) k_png_crc_fold2(DeflateCtx c, uint32_t max
     t[0] = uint8_t(crc >> 24); t[1] = uint8_t(crc >> 16); t[2] = uint8_t(crc >> 8); t[3] = uint8_t(crc);
 }
 
-void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) { CSH_LAUNCH(k_png_hist, dim3(c.total_groups, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); launch_png_deep_hist(st, c); } }
-void launch_png_codes(hipStream_t st, const DeflateCtx &c) { if (c.total_chunks) CSH_LAUNCH(k_png_codes, dim3((c.total_chunks + 63) / 64, c.plan.ntrials), dim3(64), st, c); }
+void launch_png_hist(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) CSH_LAUNCH(k_png_hist, dim3(c.total_groups, c.plan.ntrials), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_codes(hipStream_t st, const DeflateCtx &c, int only_deep) { if (c.total_chunks) CSH_LAUNCH(k_png_codes, dim3((c.total_chunks + 63) / 64, c.plan.ntrials), dim3(64), st, c, only_deep); }
 void launch_png_choose(hipStream_t st, const DeflateCtx &c) { if (c.nimg) CSH_LAUNCH(k_png_choose, dim3((c.nimg + 63) / 64), dim3(64), st, c); }
 void launch_png_emit(hipStream_t st, const DeflateCtx &c) { if (c.total_groups) { CSH_LAUNCH(k_png_emit, dim3(c.total_groups), dim3(CSP_WAVE_THREADS), st, c); launch_png_deep_emit(st, c); } }
 void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces) {

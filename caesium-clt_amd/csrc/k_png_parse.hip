@@ -9,12 +9,25 @@
 
 namespace csp {
 
+// the next item of a launch-wide queue (one counter, zeroed before the launch), the same in every lane
+__device__ __forceinline__ static uint32_t next_item(uint32_t *counter) {
+    LV<uint32_t> v;
+    LFOR(l) v[l] = l == 0 ? atomicAdd(counter, 1u) : 0u;
+#ifdef CSH_EMUL
+    return v.v[0];
+#else
+    return uint32_t(__builtin_amdgcn_readfirstlane(int(v.v)));
+#endif
+}
+
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_hist(DeflateCtx c) {
     CSH_SHARED DeepLds S;
     uint8_t *scratch = c.deep_scratch + uint64_t(blockIdx.x) * CSP_DEEP_SCRATCH;
-    const uint64_t nitems = uint64_t(c.total_chunks) * uint32_t(c.plan.ntrials);
-    for (uint64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const uint32_t trial = uint32_t(item / c.total_chunks), bc = uint32_t(item % c.total_chunks);
+    const uint32_t nitems = c.total_chunks * uint32_t(c.plan.ntrials);
+    for (;;) {
+        const uint32_t item = next_item(&c.deep_queue[0]);   // a queue, not a stride: the marked items cluster, and the workgroups past the device's residency start late
+        if (item >= nitems) break;
+        const uint32_t trial = item / c.total_chunks, bc = item % c.total_chunks;
         const uint32_t image = c.chunk_image[bc];
         if (c.status[image]) continue;
         const PngImg &im = c.imgs[image];
@@ -22,6 +35,11 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_hist(DeflateCtx c
         const int slot = c.plan.trial_slot[trial];
         PngChunk &rec = chunk_rec(c, im, slot, ci);
         if (!rec.deep) continue;
+        if (!c.trial_live[uint64_t(image) * CSP_MAX_STREAMS + trial]) {   // a trial too far behind to win keeps its greedy parse
+            LFOR(l) if (l == 0) rec.deep = 0;
+            CSP_WAVE_SYNC();
+            continue;
+        }
         const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
         const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
         NoSink none;
@@ -46,7 +64,9 @@ struct DeepEmitLds { DeepLds deep; uint32_t code[CSP_NSYM]; uint32_t win[160]; }
 __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_emit(DeflateCtx c) {
     CSH_SHARED DeepEmitLds S;
     uint8_t *scratch = c.deep_scratch + uint64_t(blockIdx.x) * CSP_DEEP_SCRATCH;
-    for (uint32_t bc = blockIdx.x; bc < c.total_chunks; bc += gridDim.x) {
+    for (;;) {
+        const uint32_t bc = next_item(&c.deep_queue[1]);
+        if (bc >= c.total_chunks) break;
         const uint32_t image = c.chunk_image[bc];
         if (c.status[image]) continue;
         const PngImg &im = c.imgs[image];
@@ -73,7 +93,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_emit(DeflateCtx c
     }
 }
 
-void launch_png_deep_hist(hipStream_t st, const DeflateCtx &c) { if (c.deep_iters > 0 && c.deep_slots) CSH_LAUNCH(k_png_deep_hist, dim3(c.deep_slots), dim3(CSP_WAVE_THREADS), st, c); }
+// behind the greedy parse's hist / codes / choose: the parse over the live trials' marked chunks, their codes again, the winner again
+void launch_png_deep(hipStream_t st, const DeflateCtx &c) {
+    if (c.deep_iters <= 0 || !c.deep_slots) return;
+    (void)hipMemsetAsync(c.deep_queue, 0, 2 * sizeof(uint32_t), st);
+    CSH_LAUNCH(k_png_deep_hist, dim3(c.deep_slots), dim3(CSP_WAVE_THREADS), st, c);
+    launch_png_codes(st, c, 1);
+    launch_png_choose(st, c);
+}
 void launch_png_deep_emit(hipStream_t st, const DeflateCtx &c) { if (c.deep_iters > 0 && c.deep_slots) CSH_LAUNCH(k_png_deep_emit, dim3(c.deep_slots), dim3(CSP_WAVE_THREADS), st, c); }
 
 }  // namespace csp

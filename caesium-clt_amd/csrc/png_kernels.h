@@ -97,6 +97,7 @@ struct DeflateCtx {
     PngPlan plan;
     uint64_t *trial_bytes;        // [nimg][CSP_MAX_STREAMS] zlib stream size per trial
     int32_t *winner;              // [nimg] winning trial
+    uint8_t *trial_live;          // [nimg][CSP_MAX_STREAMS] 1: the trial's greedy stream is close enough to the smallest for the min-cost-path parse to matter
     uint32_t *adler_parts;        // [total_chunks][2]
     uint8_t *out;
     const uint8_t *fixed;         // prefix/suffix bytes
@@ -105,13 +106,14 @@ struct DeflateCtx {
     uint32_t *status;
     uint8_t *deep_scratch;        // [deep_slots][CSP_DEEP_SCRATCH]: one area per workgroup of the min-cost-path kernels (png_parse.h)
     uint32_t deep_slots;
+    uint32_t *deep_queue;         // [2] work counters of the two kernels (zeroed by launch_png_deep_hist)
     int deep_iters;               // passes of that parse over the chunks that qualify: CSP_DEEP_ITERS, CSP_DEEP_ITERS_ZOPFLI with png.force_zopfli
 };
 void launch_png_hist(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 1: symbol counts of every (trial, chunk)
-void launch_png_codes(hipStream_t st, const DeflateCtx &c);    // code lengths, codes, header, block size
+void launch_png_codes(hipStream_t st, const DeflateCtx &c, int only_deep = 0);    // code lengths, codes, header, block size
 void launch_png_choose(hipStream_t st, const DeflateCtx &c);   // per image: stream sizes, the winner, chunk byte offsets
 void launch_png_emit(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 2 on the winner: the blocks, in place
-void launch_png_deep_hist(hipStream_t st, const DeflateCtx &c);   // (inside launch_png_hist) the marked chunks' counts from the min-cost-path parse
+void launch_png_deep(hipStream_t st, const DeflateCtx &c);        // behind choose: the marked chunks of the live trials through the min-cost-path parse, codes and choose again
 void launch_png_deep_emit(hipStream_t st, const DeflateCtx &c);   // (inside launch_png_emit) the winner's marked chunks
 void launch_png_finish(hipStream_t st, const DeflateCtx &c, uint32_t max_pieces);   // max_pieces: KiB pieces of the largest IDAT chunk; crc_parts holds nimg * max_pieces   // zlib header + Adler-32, IDAT framing + CRC-32, carried chunks
 

@@ -15,7 +15,7 @@ namespace csp {
 struct LzLds {
     uint64_t bucket[1u << CSP_HASH_BITS];   // four 16-bit positions, most recent in the low bits; position = offset from (chunk start - 32768)
     uint8_t lastlane[1u << CSP_HASH_BITS];
-    uint32_t cnt[256];      // byte counts of the chunk
+    uint32_t cnt[256];      // byte counts of the chunk; lz_insert borrows the first 64 words (the counts are made and used between the seeding and the tiles)      // byte counts of the chunk
     uint16_t cost16[256];   // what a literal costs in this chunk, in 1/16 bit (oracle/png_oracle.c literal_costs)
 };
 enum { CSP_MATCH_BASE16 = 320, CSP_MATCH_RULE_MAXLEN = 8 };
@@ -29,13 +29,18 @@ __device__ __forceinline__ static uint64_t load64u(const uint8_t *p) {
 }
 __device__ __forceinline__ static uint32_t lz_hash(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - CSP_HASH_BITS); }
 __device__ __forceinline__ static uint32_t ctz64(uint64_t x) { return uint32_t(__ffsll((unsigned long long)x) - 1); }
-// common prefix of data[p..] and data[p-d..], at most maxlen, given that the first `from` bytes are known to agree
+// common prefix of data[p..] and data[p-d..], at most maxlen, given that the first `from` bytes are known to agree.  32 bytes per round trip (eight loads
+// in flight; a wave that follows a 258-byte match waits eight times, not thirty-two); the bytes past maxlen it may fetch lie inside the pool's slack
 __device__ __forceinline__ static uint32_t lz_lcp(const uint8_t *data, uint64_t p, uint32_t d, uint32_t maxlen, uint32_t from) {
     uint32_t k = from;
     while (k < maxlen) {
-        const uint64_t x = load64u(data + p + k) ^ load64u(data + p - d + k);
-        if (x) { k += ctz64(x) >> 3; break; }
-        k += 8;
+        const uint8_t *a = data + p + k, *b = a - d;
+        const uint64_t x0 = load64u(a) ^ load64u(b), x1 = load64u(a + 8) ^ load64u(b + 8), x2 = load64u(a + 16) ^ load64u(b + 16), x3 = load64u(a + 24) ^ load64u(b + 24);
+        if (x0) { k += ctz64(x0) >> 3; break; }
+        if (x1) { k += 8 + (ctz64(x1) >> 3); break; }
+        if (x2) { k += 16 + (ctz64(x2) >> 3); break; }
+        if (x3) { k += 24 + (ctz64(x3) >> 3); break; }
+        k += 32;
     }
     return k < maxlen ? k : maxlen;
 }
@@ -55,17 +60,15 @@ __device__ __forceinline__ static uint32_t dist_code_of(uint32_t dist) {   // 0.
 __device__ __forceinline__ static uint32_t dist_extra_of(uint32_t code) { return code < 4 ? 0u : (code >> 1) - 1u; }
 __device__ __forceinline__ static uint32_t dist_base_of(uint32_t code) { return code < 4 ? code + 1u : ((2u | (code & 1u)) << ((code >> 1) - 1u)) + 1u; }
 
-// insert the tile [t0, t1) into the table: per hash its last position
+// insert the tile [t0, t1) into the table: per hash its last position.  Which lane that is: a byte per hash names SOME lane that has it (whichever write the
+// LDS kept), and the lanes that share it take the maximum of their numbers in that lane's slot -- two LDS round trips whatever the tile holds
 __device__ __forceinline__ static void lz_insert(LzLds &L, const LV<uint32_t> &hash, const LV<uint32_t> &hashable, const LV<uint32_t> &rel) {
-    LFOR(l) if (hashable[l]) L.lastlane[hash[l]] = uint8_t(l);
+    LFOR(l) { L.cnt[l] = 0; if (hashable[l]) L.lastlane[hash[l]] = uint8_t(l); }
     CSP_WAVE_SYNC();
-    for (;;) {
-        const uint64_t lose = lballot([&](int l) { return hashable[l] && int(L.lastlane[hash[l]]) < l; });
-        if (!lose) break;
-        LFOR(l) if ((lose >> l) & 1) L.lastlane[hash[l]] = uint8_t(l);
-        CSP_WAVE_SYNC();
-    }
-    LFOR(l) if (hashable[l] && int(L.lastlane[hash[l]]) == l && rel[l] != 0xFFFFu) L.bucket[hash[l]] = (L.bucket[hash[l]] << 16) | rel[l];
+    LV<uint32_t> rep;
+    LFOR(l) { rep[l] = hashable[l] ? uint32_t(L.lastlane[hash[l]]) : 0u; if (hashable[l]) atomicMax(&L.cnt[rep[l]], uint32_t(l)); }
+    CSP_WAVE_SYNC();
+    LFOR(l) if (hashable[l] && L.cnt[rep[l]] == uint32_t(l) && rel[l] != 0xFFFFu) L.bucket[hash[l]] = (L.bucket[hash[l]] << 16) | rel[l];
     CSP_WAVE_SYNC();
 }
 

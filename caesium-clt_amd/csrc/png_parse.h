@@ -19,7 +19,8 @@ enum : uint32_t {
     CSP_DEEP_DIV = 512,        // a chunk qualifies when matches * DIV >= tokens in its greedy parse
     CSP_HASH8_BITS = 11, CSP_WAYS8 = 8,
     CSP_DEEP_SEG = 512, CSP_DEEP_CAP = 16, CSP_DEEP_START = 64,
-    CSP_DEEP_ITERS = 3, CSP_DEEP_ITERS_ZOPFLI = 15,
+    CSP_DEEP_ITERS = 5, CSP_DEEP_ITERS_ZOPFLI = 15,
+    CSP_DEEP_LIVE_NUM = 9, CSP_DEEP_LIVE_DEN = 8,   // a trial takes the parse when its greedy stream is within NUM / DEN of the picture's smallest
     // the wave's scratch area in HBM: candidates (8 B), choices (2 B), costs (4 B, one row more), visit marks (1 B) per position
     CSP_DEEP_CAND_OFF = 0, CSP_DEEP_CHOICE_OFF = 262144, CSP_DEEP_COST_OFF = 327680, CSP_DEEP_TAKEN_OFF = 327680 + 131584, CSP_DEEP_SCRATCH = 524288,
 };
@@ -30,7 +31,7 @@ struct DeepLds {
     uint64_t bucket[1u << CSP_HASH_BITS];        // 4-byte table: four 16-bit positions, most recent in the low bits (png_lz.h)
     uint64_t bucket8[2][1u << CSP_HASH8_BITS];   // 8-byte table: ways 0..3 in [0], 4..7 in [1]
     uint8_t lastlane[1u << CSP_HASH_BITS];
-    uint32_t hist[CSP_NSYM];
+    uint32_t hist[CSP_NSYM];                     // (its first 64 words serve deep_last_lanes while the candidates are made: the counts start after that)
     uint16_t lit_cost[256], len_cost[260], dist_cost[32];
 };
 
@@ -48,23 +49,25 @@ template <class T, int N> struct LVArr { T v[64][N]; __device__ T *operator[](in
 template <class T, int N> struct LVArr { T v[N]; __device__ T *operator[](int) { return v; } };
 #endif
 
-// which lane of the tile is the last with each hash
-__device__ __forceinline__ static void deep_last_lanes(DeepLds &S, const LV<uint32_t> &hash, const LV<uint32_t> &hashable) {
-    LFOR(l) if (hashable[l]) S.lastlane[hash[l]] = uint8_t(l);
+// which lane of the tile is the last with each hash: a byte per hash names SOME lane that has it (whichever write the LDS kept), and the lanes that share it
+// take the maximum of their numbers in that lane's slot -- two LDS round trips whatever the tile holds (a retry loop until the highest lane's write has stuck
+// took one round per lane in a run of equal bytes: 64 rounds a tile in front of every flat area)
+__device__ __forceinline__ static void deep_last_lanes(DeepLds &S, const LV<uint32_t> &hash, const LV<uint32_t> &hashable, LV<uint32_t> &is_last) {
+    LFOR(l) { S.hist[l] = 0; if (hashable[l]) S.lastlane[hash[l]] = uint8_t(l); }
     CSP_WAVE_SYNC();
-    for (;;) {
-        const uint64_t lose = lballot([&](int l) { return hashable[l] && int(S.lastlane[hash[l]]) < l; });
-        if (!lose) break;
-        LFOR(l) if ((lose >> l) & 1) S.lastlane[hash[l]] = uint8_t(l);
-        CSP_WAVE_SYNC();
-    }
+    LV<uint32_t> rep;
+    LFOR(l) { rep[l] = hashable[l] ? uint32_t(S.lastlane[hash[l]]) : 0u; if (hashable[l]) atomicMax(&S.hist[rep[l]], uint32_t(l)); }
+    CSP_WAVE_SYNC();
+    LFOR(l) is_last[l] = hashable[l] && S.hist[rep[l]] == uint32_t(l) ? 1u : 0u;
+    CSP_WAVE_SYNC();
 }
 __device__ __forceinline__ static void deep_insert(DeepLds &S, const LV<uint32_t> &h4, const LV<uint32_t> &ok4, const LV<uint32_t> &h8, const LV<uint32_t> &ok8, const LV<uint32_t> &rel) {
-    deep_last_lanes(S, h4, ok4);
-    LFOR(l) if (ok4[l] && int(S.lastlane[h4[l]]) == l && rel[l] != 0xFFFFu) S.bucket[h4[l]] = (S.bucket[h4[l]] << 16) | rel[l];
+    LV<uint32_t> last;
+    deep_last_lanes(S, h4, ok4, last);
+    LFOR(l) if (last[l] && rel[l] != 0xFFFFu) S.bucket[h4[l]] = (S.bucket[h4[l]] << 16) | rel[l];
     CSP_WAVE_SYNC();
-    deep_last_lanes(S, h8, ok8);
-    LFOR(l) if (ok8[l] && int(S.lastlane[h8[l]]) == l && rel[l] != 0xFFFFu) {
+    deep_last_lanes(S, h8, ok8, last);
+    LFOR(l) if (last[l] && rel[l] != 0xFFFFu) {
         const uint64_t b0 = S.bucket8[0][h8[l]], b1 = S.bucket8[1][h8[l]];
         S.bucket8[0][h8[l]] = (b0 << 16) | rel[l];
         S.bucket8[1][h8[l]] = (b1 << 16) | (b0 >> 48);
@@ -166,9 +169,21 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                 CSH_UNROLL
                 for (int w = 0; w < int(CSP_WAYS + CSP_WAYS8); w++) if (w < nw) {
                     uint32_t ln;
+                    const uint32_t d = dw[w];
                     if (xw[w]) { ln = ctz64(xw[w]) >> 3; if (ln > maxlen) ln = maxlen; }
-                    else ln = maxlen > 8 ? lz_lcp(data, p, dw[w], maxlen, 8) : maxlen;
-                    offer(ln, dw[w]);
+                    else if (maxlen <= 8) ln = maxlen;
+                    else {
+                        // all eight agree.  How far it goes matters only if it can become c0 (nearer than c0) or c1 (longer than c1, or as long and nearer):
+                        // a candidate that differs inside the `need` bytes it would have to match changes nothing, whatever else is offered later (c0 only
+                        // gets nearer, c1 only better) -- in a run of equal bytes every candidate but the first leaves here
+                        if (d0 && d > d0) {
+                            const uint32_t need = d < d1 ? len1 : len1 + 1u;
+                            if (need > maxlen) continue;
+                            if (need > 8 && load64u(data + p + need - 8) != load64u(data + p - d + need - 8)) continue;
+                        }
+                        ln = lz_lcp(data, p, d, maxlen, 8);
+                    }
+                    offer(ln, d);
                 }
                 if (len1 <= len0) { len1 = 0; d1 = 0; }
                 const uint32_t off = uint32_t(p - start);
@@ -220,10 +235,14 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
         uint32_t lenc[CSP_DEEP_CAP + 1];
         CSH_UNROLL
         for (int k = 3; k <= int(CSP_DEEP_CAP); k++) lenc[k] = S.len_cost[k];
+        LV<uint64_t> cnext;   // the candidate word of the step to come: asked for a step ahead (the addresses do not depend on the path)
+        LFOR(l) cnext[l] = coherent_load(&cand[uint64_t(CSP_DEEP_SEG - 1) * 64 + uint32_t(l)]);
         for (uint32_t i = CSP_DEEP_SEG; i-- > 0;) {
-            LFOR(l) if (i < ns[l]) {
+            LFOR(l) {
+                const uint64_t c = cnext[l];
+                if (i) cnext[l] = coherent_load(&cand[uint64_t(i - 1) * 64 + uint32_t(l)]);
+                if (i >= ns[l]) continue;
                 uint32_t *w = W[l];
-                const uint64_t c = coherent_load(&cand[uint64_t(i) * 64 + uint32_t(l)]);
                 const uint32_t avail = ns[l] - i;
                 uint32_t l0 = uint32_t(c) & 511u, l1 = uint32_t(c >> 25) & 511u;
                 const uint32_t d0 = uint32_t(c >> 9) & 0xFFFFu, d1 = uint32_t(c >> 34) & 0xFFFFu;
@@ -250,24 +269,36 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                 w[0] = cst;
             }
         }
-        // F: forwards; every lane counts its segment's symbols (final pass: and marks the positions the parse visits)
-        LV<uint32_t> at;
-        LFOR(l) at[l] = 0;
-        for (;;) {
-            if (!lballot([&](int l) { return at[l] < ns[l]; })) break;
-            LFOR(l) if (at[l] < ns[l]) {
-                const uint32_t i = at[l];
-                const uint32_t ch = choice[uint64_t(i) * 64 + uint32_t(l)];
-                const uint64_t c = coherent_load(&cand[uint64_t(i) * 64 + uint32_t(l)]);
-                if (final_pass && want_tokens) tk[uint32_t(l) * CSP_DEEP_SEG + i] = 1;
-                if (ch == 1) { atomicAdd(&S.hist[uint32_t(c >> 50) & 255u], 1u); at[l] = i + 1; }
-                else {
-                    const uint32_t avail = ns[l] - i;
-                    uint32_t l0 = uint32_t(c) & 511u;
-                    if (l0 > avail) l0 = avail;
-                    const uint32_t d = ch <= l0 ? uint32_t(c >> 9) & 0xFFFFu : uint32_t(c >> 34) & 0xFFFFu;
-                    atomicAdd(&S.hist[257 + len_code_of(ch)], 1u); atomicAdd(&S.hist[CSP_NLIT + dist_code_of(d)], 1u);
-                    at[l] = i + ch;
+        // F: forwards over all positions; a lane acts at the positions its path visits (nxt) -- no load waits for the path -- and counts their symbols
+        // (final pass: and marks them)
+        LV<uint32_t> nxt;
+        LFOR(l) nxt[l] = 0;
+        for (uint32_t i0 = 0; i0 < CSP_DEEP_SEG; i0 += 8) {
+            LVArr<uint64_t, 8> cw;
+            LVArr<uint32_t, 8> chw;
+            LFOR(l) {
+                uint64_t *cc = cw[l]; uint32_t *hh = chw[l];
+                CSH_UNROLL
+                for (int k = 0; k < 8; k++) { cc[k] = coherent_load(&cand[uint64_t(i0 + k) * 64 + uint32_t(l)]); hh[k] = choice[uint64_t(i0 + k) * 64 + uint32_t(l)]; }
+            }
+            LFOR(l) {
+                const uint64_t *cc = cw[l]; const uint32_t *hh = chw[l];
+                CSH_UNROLL
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t i = i0 + uint32_t(k);
+                    if (i != nxt[l] || i >= ns[l]) continue;
+                    const uint64_t c = cc[k];
+                    const uint32_t ch = hh[k];
+                    if (final_pass && want_tokens) tk[uint32_t(l) * CSP_DEEP_SEG + i] = 1;
+                    if (ch == 1) { atomicAdd(&S.hist[uint32_t(c >> 50) & 255u], 1u); nxt[l] = i + 1; }
+                    else {
+                        const uint32_t avail = ns[l] - i;
+                        uint32_t l0 = uint32_t(c) & 511u;
+                        if (l0 > avail) l0 = avail;
+                        const uint32_t d = ch <= l0 ? uint32_t(c >> 9) & 0xFFFFu : uint32_t(c >> 34) & 0xFFFFu;
+                        atomicAdd(&S.hist[257 + len_code_of(ch)], 1u); atomicAdd(&S.hist[CSP_NLIT + dist_code_of(d)], 1u);
+                        nxt[l] = i + ch;
+                    }
                 }
             }
         }

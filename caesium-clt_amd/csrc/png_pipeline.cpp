@@ -137,7 +137,7 @@ int trial_set(int level, int *set) {
 }
 
 const char *kPngKernelNames[CSP_NKERNELS] = {"k_png_inflate", "k_png_unfilter", "k_png_reduce", "k_png_filter5", "k_png_scores", "k_png_brute", "k_png_pick",
-                                             "k_png_hist", "k_png_codes", "k_png_choose", "k_png_emit", "k_png_finish", "", "", "", ""};
+                                             "k_png_hist", "k_png_codes", "k_png_choose", "k_png_deep", "k_png_emit", "k_png_finish", "", "", ""};
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -194,9 +194,11 @@ struct csp_batch {
     DevBuf<uint32_t> d_row_image, d_chunk_image, d_chunk_first, d_group_image, d_group_first, d_status, d_nmatch, d_file_len, d_adler, d_crc;
     DevBuf<uint64_t> d_scores, d_trial_bytes;
     DevBuf<int32_t> d_winner;
+    DevBuf<uint8_t> d_trial_live;
     DevBuf<PngChunk> d_chunks;
     DevBuf<uint8_t> d_deep;         // the min-cost-path kernels' scratch areas (png_parse.h)
     uint32_t deep_slots = 0;
+    DevBuf<uint32_t> d_deep_queue;
     int deep_iters = CSP_DEEP_ITERS;   // png.force_zopfli: CSP_DEEP_ITERS_ZOPFLI
     hipEvent_t ev[CSP_NKERNELS + 1]{};
     bool have_events = false, ran = false;
@@ -420,7 +422,7 @@ static int png_create(const CByteArray *inputs, const csp_pixels *px, size_t cou
     if (b->d_idat.alloc(idat_pool.size() + 256) || b->d_work.alloc(work_bytes + 256) || b->d_passes.upload(b->passes, st) || b->d_adam7.upload(b->adam7, st) || b->d_streams.alloc(stream_bytes + 256) ||
         b->d_out.alloc(out_bytes + 256) || b->d_choice.alloc(size_t(5) * b->total_rows + 1) || b->d_status.alloc(size_t(nimg) + 1) || b->d_file_len.alloc(size_t(nimg) + 1) ||
         b->d_adler.alloc(2 * size_t(b->total_chunks) + 2) || b->d_crc.alloc(size_t(nimg) * b->max_pieces + 1) || b->d_scores.alloc(size_t(b->total_rows) * 25 + 1) ||
-        b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_nmatch.alloc(size_t(nimg) + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
+        b->d_trial_bytes.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_nmatch.alloc(size_t(nimg) + 1) || b->d_winner.alloc(size_t(nimg) + 1) || b->d_trial_live.alloc(size_t(nimg) * CSP_MAX_STREAMS + 1) || b->d_chunks.alloc(size_t(nchunk_recs) + 1))
         return CS_ERR_NO_DEVICE;
     if (to_webp && (b->d_rgbjobs.upload(b->rgbjobs, st) || b->d_plte.upload(b->plte, st) || b->d_rgb.alloc(b->rgb_bytes + 256) || b->d_wwork.alloc(b->wwork_bytes + 64) ||
                     b->d_wlevels.alloc(b->wlevels + 64) || b->d_wstats.alloc(size_t(nimg) * 2112 + 8) || b->d_wprobs.alloc(size_t(nimg) * 1056 + 8) || b->d_wupdate.alloc(size_t(nimg) * 1056 + 8) ||
@@ -731,7 +733,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     DeflateCtx d{};
     d.imgs = b->d_imgs.p; d.nimg = nimg; d.total_chunks = b->total_chunks; d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p;
     d.total_groups = b->total_groups; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;
-    d.streams = b->d_streams.p; d.chunks = b->d_chunks.p; d.plan = b->plan; d.trial_bytes = b->d_trial_bytes.p; d.winner = b->d_winner.p;
+    d.streams = b->d_streams.p; d.chunks = b->d_chunks.p; d.plan = b->plan; d.trial_bytes = b->d_trial_bytes.p; d.winner = b->d_winner.p; d.trial_live = b->d_trial_live.p;
     d.adler_parts = b->d_adler.p; d.out = b->d_out.p; d.fixed = b->d_fixed.p; d.file_len = b->d_file_len.p; d.crc_parts = b->d_crc.p; d.status = b->d_status.p;
     bool need_scores = false;
     for (int a = 0; a < b->plan.nadaptive; a++) if (b->plan.adaptive_strategy[a] != 9) need_scores = true;
@@ -773,12 +775,13 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     {   // one scratch area per workgroup the device holds at the parse kernels' LDS footprint (three per CU), no more than there are items
         const uint64_t items = uint64_t(b->total_chunks) * uint32_t(b->plan.ntrials);
         b->deep_slots = uint32_t(std::min<uint64_t>(items, 768));
-        if (b->deep_slots && b->d_deep.alloc(size_t(b->deep_slots) * CSP_DEEP_SCRATCH)) return CS_ERR_NO_DEVICE;
-        d.deep_scratch = b->d_deep.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters;
+        if (b->deep_slots && (b->d_deep.alloc(size_t(b->deep_slots) * CSP_DEEP_SCRATCH) || b->d_deep_queue.alloc(2))) return CS_ERR_NO_DEVICE;
+        d.deep_scratch = b->d_deep.p; d.deep_queue = b->d_deep_queue.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters;
     }
     mark(); launch_png_hist(st, d);
     mark(); launch_png_codes(st, d);
     mark(); launch_png_choose(st, d);
+    mark(); launch_png_deep(st, d);
     mark(); launch_png_emit(st, d);
     mark(); launch_png_finish(st, d, b->max_pieces);
     mark();

@@ -127,6 +127,7 @@ def lib():
         L.cso_png_optimize.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.cso_png_optimize_zopfli.argtypes = L.cso_png_optimize.argtypes
         L.cso_png_optimize_iters.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+        L.cso_deflate_zlib_iters.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
         L.cso_png_deep_div.argtypes = [C.c_int]
         L.cso_png_deep_div.restype = None
         L.cso_vp8enc_encode_yuv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.c_void_p, C.c_void_p]
@@ -376,11 +377,15 @@ def png_decode(data, keep_metadata=False):
     return PngImage(ptr)
 
 
-def deflate_zlib(data):
+def deflate_zlib(data, iters=None):
+    """the coder over one stream; iters: passes of the min-cost-path parse over the chunks that qualify (None: the default, 0: the greedy parse everywhere)"""
     data = bytes(data)
     out = C.POINTER(C.c_uint8)()
     n = C.c_size_t()
-    lib().cso_deflate_zlib(data, len(data), C.byref(out), C.byref(n))
+    if iters is None:
+        lib().cso_deflate_zlib(data, len(data), C.byref(out), C.byref(n))
+    else:
+        lib().cso_deflate_zlib_iters(data, len(data), int(iters), C.byref(out), C.byref(n))
     res = C.string_at(out, n.value)
     lib().cso_free(out)
     return res

@@ -910,8 +910,10 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
 #define DEEP_WAYS8 8
 #define DEEP_SEG 512
 #define DEEP_CAP 16
-#define DEEP_ITERS 3
+#define DEEP_ITERS 5
 #define DEEP_START 64   /* 1/16 bit */
+#define DEEP_LIVE_NUM 9   /* a trial takes the parse when its greedy stream is within NUM / DEN of the smallest greedy stream of the picture */
+#define DEEP_LIVE_DEN 8
 #define DEEP_ITERS_ZOPFLI 15
 static int deep_div_override = 0;   /* tools only (tools/png_parse_gap.py sweeps it): 0 = DEEP_DIV */
 void cso_png_deep_div(int v) { deep_div_override = v; }
@@ -1285,10 +1287,21 @@ static int png_recode(const uint8_t *in, size_t n, int level, int keep_metadata,
     uint8_t *filt = (uint8_t *)malloc(raw_len), *best = NULL;
     size_t best_len = 0;
     int set[10], ns = cso_png_trials(level, set), best_s = -1;
+    /* every trial with the greedy parse first; the min-cost-path parse then only for the trials within an eighth of the smallest (it gains a few
+       percent: a trial further behind cannot win -- on photographs that is filter None, the one stream full of matches) */
+    uint8_t *zt[10]; size_t zn[10], smallest = 0;
     for (int t = 0; t < ns; t++) {
-        uint8_t *z; size_t zl;
         cso_png_filter(P, set[t], filt, NULL);
-        cso_deflate_zlib_iters(filt, raw_len, iters, &z, &zl);
+        cso_deflate_zlib_iters(filt, raw_len, 0, &zt[t], &zn[t]);
+        if (t == 0 || zn[t] < smallest) smallest = zn[t];
+    }
+    for (int t = 0; t < ns; t++) {
+        uint8_t *z = zt[t]; size_t zl = zn[t];
+        if (iters > 0 && (uint64_t)zn[t] * DEEP_LIVE_DEN <= (uint64_t)smallest * DEEP_LIVE_NUM) {
+            free(z);
+            cso_png_filter(P, set[t], filt, NULL);
+            cso_deflate_zlib_iters(filt, raw_len, iters, &z, &zl);
+        }
         if (!best || zl < best_len) { free(best); best = z; best_len = zl; best_s = set[t]; } else free(z);
     }
     free(filt);

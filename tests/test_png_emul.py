@@ -38,10 +38,11 @@ def check_batch(api, cases, level, keep_metadata=False, stages=True):
                         bad = np.argwhere(got[:, :, k] != want[:, :, k])
                         assert not len(bad), (name, "score", k, "row/filter", bad[0].tolist(), int(got[tuple(bad[0])][k]), int(want[tuple(bad[0])][k]))
                 trials, winner = b.trials(i)
+                greedy = {s: len(O.deflate_zlib(P.filtered(s)[0], 0)) for s, _ in trials}   # the min-cost-path parse only for trials within 9/8 of the smallest greedy stream
                 for s, zbytes in trials:
                     f, _ = P.filtered(s)
                     assert np.array_equal(b.stream(i, s), f), (name, s)
-                    assert zbytes == len(O.deflate_zlib(f)), (name, s)
+                    assert zbytes == (len(O.deflate_zlib(f)) if greedy[s] * 8 <= min(greedy.values()) * 9 else greedy[s]), (name, s)
                 if chosen >= 0:
                     assert trials[winner][0] == chosen, name
             assert outs[i] == ref, name

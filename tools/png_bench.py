@@ -10,6 +10,9 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")]
 from _util import package, product_api   # noqa: E402
 from gen_synth import synth_png           # noqa: E402
 
+zopfli = "--zopfli" in sys.argv   # png.force_zopfli: more passes of the cost model
+if zopfli:
+    sys.argv.remove("--zopfli")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 distinct = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 3840
@@ -19,7 +22,7 @@ api, pkg = product_api(), package()
 src = [synth_png(100 + k, w, h, "RGB", texture=float(k % 4)) for k in range(distinct)]
 blobs = [src[k % distinct] for k in range(n)]
 quality = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-p = pkg.default_parameters(png_quality=quality) if quality else pkg.default_parameters(png_optimize=True, png_optimization_level=level)
+p = pkg.default_parameters(png_quality=quality) if quality else pkg.default_parameters(png_optimize=True, png_optimization_level=level, png_force_zopfli=zopfli)
 for rep in range(2):
     t0 = time.time()
     b = api.png_batch(blobs, p)
