@@ -9,23 +9,21 @@
 
 namespace csp {
 
-// the next item of a launch-wide queue (one counter, zeroed before the launch), the same in every lane
-__device__ __forceinline__ static uint32_t next_item(uint32_t *counter) {
-    LV<uint32_t> v;
-    LFOR(l) v[l] = l == 0 ? atomicAdd(counter, 1u) : 0u;
-#ifdef CSH_EMUL
-    return v.v[0];
-#else
-    return uint32_t(__builtin_amdgcn_readfirstlane(int(v.v)));
-#endif
+// the next item of a launch-wide queue (one counter, zeroed before the launch), the same in every lane of the workgroup
+__device__ __forceinline__ static uint32_t next_item(uint32_t *counter, uint32_t *slot) {
+    LFOR(l) if (CSP_WAVE0 && l == 0) *slot = atomicAdd(counter, 1u);
+    CSP_WG_SYNC();
+    const uint32_t v = *slot;
+    CSP_WG_SYNC();
+    return v;
 }
 
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_hist(DeflateCtx c) {
+__global__ void __launch_bounds__(CSP_DEEP_THREADS) k_png_deep_hist(DeflateCtx c) {
     CSH_SHARED DeepLds S;
     uint8_t *scratch = c.deep_scratch + uint64_t(blockIdx.x) * CSP_DEEP_SCRATCH;
     const uint32_t nitems = c.total_chunks * uint32_t(c.plan.ntrials);
     for (;;) {
-        const uint32_t item = next_item(&c.deep_queue[0]);   // a queue, not a stride: the marked items cluster, and the workgroups past the device's residency start late
+        const uint32_t item = next_item(&c.deep_queue[0], &S.item);   // a queue, not a stride: the marked items cluster, and the workgroups past the device's residency start late
         if (item >= nitems) break;
         const uint32_t trial = item / c.total_chunks, bc = item % c.total_chunks;
         const uint32_t image = c.chunk_image[bc];
@@ -36,14 +34,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_hist(DeflateCtx c
         PngChunk &rec = chunk_rec(c, im, slot, ci);
         if (!rec.deep) continue;
         if (!c.trial_live[uint64_t(image) * CSP_MAX_STREAMS + trial]) {   // a trial too far behind to win keeps its greedy parse
-            LFOR(l) if (l == 0) rec.deep = 0;
-            CSP_WAVE_SYNC();
+            LFOR(l) if (CSP_WAVE0 && l == 0) rec.deep = 0;
             continue;
         }
         const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
         const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
         NoSink none;
-        deep_chunk(data, im.raw_len, start, end, S, scratch, c.deep_iters, false, none);
+        deep_chunk(data, im.raw_len, start, end, S, scratch, c.deep_iters, false, none, c.deep_debug);
+        if (CSP_WAVE0) {
         LV<uint64_t> e;
         LFOR(l) {
             e[l] = 0;
@@ -56,16 +54,17 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_hist(DeflateCtx c
         }
         const uint64_t extra = lsum(e);
         LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
-        CSP_WAVE_SYNC();
+        }
+        CSP_WG_SYNC();
     }
 }
 
 struct DeepEmitLds { DeepLds deep; uint32_t code[CSP_NSYM]; uint32_t win[160]; };
-__global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_emit(DeflateCtx c) {
+__global__ void __launch_bounds__(CSP_DEEP_THREADS) k_png_deep_emit(DeflateCtx c) {
     CSH_SHARED DeepEmitLds S;
     uint8_t *scratch = c.deep_scratch + uint64_t(blockIdx.x) * CSP_DEEP_SCRATCH;
     for (;;) {
-        const uint32_t bc = next_item(&c.deep_queue[1]);
+        const uint32_t bc = next_item(&c.deep_queue[1], &S.deep.item);
         if (bc >= c.total_chunks) break;
         const uint32_t image = c.chunk_image[bc];
         if (c.status[image]) continue;
@@ -84,12 +83,12 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_emit(DeflateCtx c
         }
         const bool last = ci + 1 == im.nchunks;
         BitOut bo;
-        emit_block_begin(rec, last, S.code, S.win, c.out + im.out_off + at, bo);
+        if (CSP_WAVE0) emit_block_begin(rec, last, S.code, S.win, c.out + im.out_off + at, bo);
         EmitSink sink; sink.code = S.code; sink.bo = &bo;
         const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
-        deep_chunk(data, im.raw_len, start, end, S.deep, scratch, c.deep_iters, true, sink);
-        if (!emit_block_end(rec, last, S.code, bo)) LFOR(l) if (l == 0) c.status[image] = CSP_ERR_POOL;   // the size pass and this pass disagree: never ship it
-        CSP_WAVE_SYNC();
+        deep_chunk(data, im.raw_len, start, end, S.deep, scratch, c.deep_iters, true, sink);   // (the sink sees the tokens on the first wave)
+        if (CSP_WAVE0 && !emit_block_end(rec, last, S.code, bo)) LFOR(l) if (l == 0) c.status[image] = CSP_ERR_POOL;   // the size pass and this pass disagree: never ship it
+        CSP_WG_SYNC();
     }
 }
 
@@ -97,10 +96,10 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_deep_emit(DeflateCtx c
 void launch_png_deep(hipStream_t st, const DeflateCtx &c) {
     if (c.deep_iters <= 0 || !c.deep_slots) return;
     (void)hipMemsetAsync(c.deep_queue, 0, 2 * sizeof(uint32_t), st);
-    CSH_LAUNCH(k_png_deep_hist, dim3(c.deep_slots), dim3(CSP_WAVE_THREADS), st, c);
+    CSH_LAUNCH(k_png_deep_hist, dim3(c.deep_slots), dim3(CSP_DEEP_THREADS), st, c);
     launch_png_codes(st, c, 1);
     launch_png_choose(st, c);
 }
-void launch_png_deep_emit(hipStream_t st, const DeflateCtx &c) { if (c.deep_iters > 0 && c.deep_slots) CSH_LAUNCH(k_png_deep_emit, dim3(c.deep_slots), dim3(CSP_WAVE_THREADS), st, c); }
+void launch_png_deep_emit(hipStream_t st, const DeflateCtx &c) { if (c.deep_iters > 0 && c.deep_slots) CSH_LAUNCH(k_png_deep_emit, dim3(c.deep_slots), dim3(CSP_DEEP_THREADS), st, c); }
 
 }  // namespace csp

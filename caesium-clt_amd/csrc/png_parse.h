@@ -1,7 +1,7 @@
 // png_parse.h -- the min-cost-path parse of a deflate chunk, one wave per chunk (statement: oracle/png_oracle.c deep_parse()).
 // What libdeflate's levels 10-12 (oxipng -o3 / -o4) and zopfli do in their own ways -- candidate matches per position, symbol costs from the
 // previous parse's statistics, the cheapest path, again -- laid out for a 64-lane wave:
-//   M  candidates, tile by tile as png_lz.h does it (a tile = 64 consecutive positions, one per lane): the six fixed distances, the four entries of the
+//   M  candidates, tile by tile as png_lz.h does it (here a tile = 256 consecutive positions, four per lane): the six fixed distances, the four entries of the
 //      4-byte-hash table, the eight of a second table keyed by 8 bytes (the long matches far back).  Kept per position, in ONE 64-bit word in the wave's
 //      scratch area: c0 = the nearest candidate with >= 3 bytes, c1 = the longest, and the byte itself.
 //   C  costs (1/16 bit) of every literal, length and distance code from the counts of the parse before.
@@ -18,6 +18,7 @@ namespace csp {
 enum : uint32_t {
     CSP_DEEP_DIV = 512,        // a chunk qualifies when matches * DIV >= tokens in its greedy parse
     CSP_HASH8_BITS = 11, CSP_WAYS8 = 8,
+    CSP_DEEP_TILE = 256,       // positions whose candidates come out of one state of the tables (four per lane)
     CSP_DEEP_SEG = 512, CSP_DEEP_CAP = 16, CSP_DEEP_START = 64,
     CSP_DEEP_ITERS = 5, CSP_DEEP_ITERS_ZOPFLI = 15,
     CSP_DEEP_LIVE_NUM = 9, CSP_DEEP_LIVE_DEN = 8,   // a trial takes the parse when its greedy stream is within NUM / DEN of the picture's smallest
@@ -31,7 +32,8 @@ struct DeepLds {
     uint64_t bucket[1u << CSP_HASH_BITS];        // 4-byte table: four 16-bit positions, most recent in the low bits (png_lz.h)
     uint64_t bucket8[2][1u << CSP_HASH8_BITS];   // 8-byte table: ways 0..3 in [0], 4..7 in [1]
     uint8_t lastlane[1u << CSP_HASH_BITS];
-    uint32_t hist[CSP_NSYM];                     // (its first 64 words serve deep_last_lanes while the candidates are made: the counts start after that)
+    uint32_t hist[CSP_NSYM];                     // (its first 256 words serve deep_last_lanes while the candidates are made: the counts start after that)
+    uint32_t item;                               // the workgroup's current work item (next_item)
     uint16_t lit_cost[256], len_cost[260], dist_cost[32];
 };
 
@@ -42,6 +44,21 @@ __device__ __forceinline__ static uint32_t cost16_of(uint32_t c, uint32_t total)
     const uint32_t v = 16u * (e - 8u) + (((q << 4) >> e) & 15u);
     return v < 1u ? 1u : v > 240u ? 240u : v;
 }
+// The candidate search runs on a WORKGROUP of four waves that share the tables: wave u takes positions t0 + 64 u + lane of a 256-position tile, and the
+// steps that read and write the tables are separated by workgroup barriers.  The emulation plays the four waves one after the other inside UFOR.
+#ifdef CSH_EMUL
+#define UFOR(u) for (int u = 0; u < 4; u++)
+#define UIX(u) (u)
+#define CSP_WG_SYNC() ((void)0)
+#define CSP_WAVE0 true
+enum { CSP_DEEP_THREADS = 1, CSP_UN = 4 };
+#else
+#define UFOR(u) for (int u [[maybe_unused]] = int(threadIdx.x >> 6), once_u_ = 1; once_u_; once_u_ = 0)
+#define UIX(u) 0
+#define CSP_WG_SYNC() __syncthreads()
+#define CSP_WAVE0 (threadIdx.x < 64u)
+enum { CSP_DEEP_THREADS = 256, CSP_UN = 1 };
+#endif
 // per-lane small arrays (registers on the device: every index is a constant after unrolling)
 #ifdef CSH_EMUL
 template <class T, int N> struct LVArr { T v[64][N]; __device__ T *operator[](int j) { return v[j]; } };
@@ -49,37 +66,50 @@ template <class T, int N> struct LVArr { T v[64][N]; __device__ T *operator[](in
 template <class T, int N> struct LVArr { T v[N]; __device__ T *operator[](int) { return v; } };
 #endif
 
-// which lane of the tile is the last with each hash: a byte per hash names SOME lane that has it (whichever write the LDS kept), and the lanes that share it
-// take the maximum of their numbers in that lane's slot -- two LDS round trips whatever the tile holds (a retry loop until the highest lane's write has stuck
-// took one round per lane in a run of equal bytes: 64 rounds a tile in front of every flat area)
-__device__ __forceinline__ static void deep_last_lanes(DeepLds &S, const LV<uint32_t> &hash, const LV<uint32_t> &hashable, LV<uint32_t> &is_last) {
-    LFOR(l) { S.hist[l] = 0; if (hashable[l]) S.lastlane[hash[l]] = uint8_t(l); }
-    CSP_WAVE_SYNC();
-    LV<uint32_t> rep;
-    LFOR(l) { rep[l] = hashable[l] ? uint32_t(S.lastlane[hash[l]]) : 0u; if (hashable[l]) atomicMax(&S.hist[rep[l]], uint32_t(l)); }
-    CSP_WAVE_SYNC();
-    LFOR(l) is_last[l] = hashable[l] && S.hist[rep[l]] == uint32_t(l) ? 1u : 0u;
-    CSP_WAVE_SYNC();
-}
-__device__ __forceinline__ static void deep_insert(DeepLds &S, const LV<uint32_t> &h4, const LV<uint32_t> &ok4, const LV<uint32_t> &h8, const LV<uint32_t> &ok8, const LV<uint32_t> &rel) {
-    LV<uint32_t> last;
-    deep_last_lanes(S, h4, ok4, last);
-    LFOR(l) if (last[l] && rel[l] != 0xFFFFu) S.bucket[h4[l]] = (S.bucket[h4[l]] << 16) | rel[l];
-    CSP_WAVE_SYNC();
-    deep_last_lanes(S, h8, ok8, last);
-    LFOR(l) if (last[l] && rel[l] != 0xFFFFu) {
-        const uint64_t b0 = S.bucket8[0][h8[l]], b1 = S.bucket8[1][h8[l]];
-        S.bucket8[0][h8[l]] = (b0 << 16) | rel[l];
-        S.bucket8[1][h8[l]] = (b1 << 16) | (b0 >> 48);
+// A TILE of the candidate search is 256 consecutive positions, four per lane (position t0 + 64 u + lane): the four are independent work -- their loads are in
+// flight together, which is what a wave that has its SIMD to itself (the tables leave room for three waves per CU) needs instead of neighbours.
+// Which position of the tile is the last with each hash: a byte per hash names SOME position that has it (whichever write the LDS kept), and the positions that
+// share it take the maximum of their numbers in that position's slot -- two LDS round trips whatever the tile holds (a retry loop until the highest write has
+// stuck took one round per position in a run of equal bytes)
+typedef LVArr<uint32_t, CSP_UN> LV4;
+__device__ __forceinline__ static void deep_last_lanes(DeepLds &S, LV4 &hash, LV4 &hashable, LV4 &is_last) {
+    LFOR(l) {
+        UFOR(u) { S.hist[u * 64 + l] = 0; if (hashable[l][UIX(u)]) S.lastlane[hash[l][UIX(u)]] = uint8_t(u * 64 + l); }
     }
-    CSP_WAVE_SYNC();
+    CSP_WG_SYNC();
+    LV4 rep;
+    LFOR(l) {
+        UFOR(u) { rep[l][UIX(u)] = hashable[l][UIX(u)] ? uint32_t(S.lastlane[hash[l][UIX(u)]]) : 0u; if (hashable[l][UIX(u)]) atomicMax(&S.hist[rep[l][UIX(u)]], uint32_t(u * 64 + l)); }
+    }
+    CSP_WG_SYNC();
+    LFOR(l) {
+        UFOR(u) is_last[l][UIX(u)] = hashable[l][UIX(u)] && S.hist[rep[l][UIX(u)]] == uint32_t(u * 64 + l) ? 1u : 0u;
+    }
+    CSP_WG_SYNC();
+}
+__device__ __forceinline__ static void deep_insert(DeepLds &S, LV4 &h4, LV4 &ok4, LV4 &h8, LV4 &ok8, LV4 &rel) {
+    LV4 last;
+    deep_last_lanes(S, h4, ok4, last);
+    LFOR(l) {
+        UFOR(u) if (last[l][UIX(u)] && rel[l][UIX(u)] != 0xFFFFu) S.bucket[h4[l][UIX(u)]] = (S.bucket[h4[l][UIX(u)]] << 16) | rel[l][UIX(u)];
+    }
+    CSP_WG_SYNC();
+    deep_last_lanes(S, h8, ok8, last);
+    LFOR(l) {
+        UFOR(u) if (last[l][UIX(u)] && rel[l][UIX(u)] != 0xFFFFu) {
+            const uint64_t b0 = S.bucket8[0][h8[l][UIX(u)]], b1 = S.bucket8[1][h8[l][UIX(u)]];
+            S.bucket8[0][h8[l][UIX(u)]] = (b0 << 16) | rel[l][UIX(u)];
+            S.bucket8[1][h8[l][UIX(u)]] = (b1 << 16) | (b0 >> 48);
+        }
+    }
+    CSP_WG_SYNC();
 }
 
 struct NoSink { __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t, const LV<uint32_t> &, const LV<uint32_t> &, const LV<uint32_t> &) {} };
 
 // data[start, end): a chunk of a stream of `total` bytes.  S.hist holds the last pass's counts on exit.  want_tokens: the sink sees the final parse.
 template <class Sink>
-__device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, DeepLds &S, uint8_t *scratch, int iters, bool want_tokens, Sink &sink) {
+__device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, DeepLds &S, uint8_t *scratch, int iters, bool want_tokens, Sink &sink, int dbg = 0) {
     unsigned long long *cand = reinterpret_cast<unsigned long long *>(scratch + CSP_DEEP_CAND_OFF);   // [i][lane]: len0 | d0 << 9 | len1 << 25 | d1 << 34 | byte << 50
     uint16_t *choice = reinterpret_cast<uint16_t *>(scratch + CSP_DEEP_CHOICE_OFF);
     uint32_t *costs = reinterpret_cast<uint32_t *>(scratch + CSP_DEEP_COST_OFF);
@@ -87,45 +117,91 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
     const uint32_t n = uint32_t(end - start);
     // ---------------------------------------------------------------------------------------------------------------- M
     LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH_BITS); i += 64) { S.bucket[i] = ~0ull; S.bucket8[0][i] = ~0ull; S.bucket8[1][i] = ~0ull; }
-    CSP_WAVE_SYNC();
+    CSP_WG_SYNC();
     {
         const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
-        for (uint64_t t0 = seed0; t0 < start; t0 += 64) {
-            LV<uint32_t> h4, ok4, h8, ok8, rel;
+        for (uint64_t t0 = seed0; t0 < start && !(dbg & 1); t0 += CSP_DEEP_TILE) {
+            LV4 h4, ok4, h8, ok8, rel;
             LFOR(l) {
-                const uint64_t p = t0 + uint32_t(l);
-                const uint64_t v = load64u(data + p);
-                ok4[l] = p + 4 <= total ? 1u : 0u; ok8[l] = p + 8 <= total ? 1u : 0u;
-                h4[l] = ok4[l] ? lz_hash(uint32_t(v)) : 0u; h8[l] = ok8[l] ? lz_hash8(v) : 0u;
-                rel[l] = uint32_t(p + 32768 - start);
+                UFOR(u) {
+                    const uint64_t p = t0 + uint32_t(u * 64 + l);
+                    const uint64_t v = load64u(data + p);
+                    ok4[l][UIX(u)] = p + 4 <= total ? 1u : 0u; ok8[l][UIX(u)] = p + 8 <= total ? 1u : 0u;
+                    h4[l][UIX(u)] = ok4[l][UIX(u)] ? lz_hash(uint32_t(v)) : 0u; h8[l][UIX(u)] = ok8[l][UIX(u)] ? lz_hash8(v) : 0u;
+                    rel[l][UIX(u)] = uint32_t(p + 32768 - start);
+                }
             }
             deep_insert(S, h4, ok4, h8, ok8, rel);
         }
     }
-    for (uint64_t t0 = start; t0 < end; t0 += 64) {
-        const uint32_t count = end - t0 < 64 ? uint32_t(end - t0) : 64u;
-        LV<uint32_t> h4, ok4, h8, ok8, rel;
+    for (uint64_t t0 = start; t0 < end; t0 += CSP_DEEP_TILE) {
+        LV4 h4, ok4, h8, ok8, rel;
         LFOR(l) {
-            const uint64_t p = t0 + uint32_t(l);
-            h4[l] = 0; ok4[l] = 0; h8[l] = 0; ok8[l] = 0; rel[l] = uint32_t(p + 32768 - start);
-            if (uint32_t(l) < count) {
-                const uint32_t maxlen = end - p < 258 ? uint32_t(end - p) : 258u;
-                const uint64_t hi = load64u(data + p);
-                uint32_t len0 = 0, d0 = 0, len1 = 0, d1 = 0;   // c0: the nearest with >= 3 bytes; c1: the longest (ties: the nearer)
+            enum { NW = CSP_WAYS + CSP_WAYS8 };
+            uint64_t hi[CSP_UN], lo[CSP_UN], xw[CSP_UN][NW];
+            uint32_t dw[CSP_UN][NW], maxlen[CSP_UN];
+            int nw[CSP_UN];
+            bool in[CSP_UN];
+            // stage 1: the positions' own bytes
+            UFOR(u) {
+                const uint64_t p = t0 + uint32_t(u * 64 + l);
+                in[UIX(u)] = p < end;
+                h4[l][UIX(u)] = 0; ok4[l][UIX(u)] = 0; h8[l][UIX(u)] = 0; ok8[l][UIX(u)] = 0; rel[l][UIX(u)] = uint32_t(p + 32768 - start);
+                hi[UIX(u)] = in[UIX(u)] ? load64u(data + p) : 0ull;
+                lo[UIX(u)] = in[UIX(u)] ? load64u(data + p - 8) : 0ull;   // (p < 8: whatever the pool holds there; guarded by d <= p)
+                maxlen[UIX(u)] = in[UIX(u)] ? (end - p < 258 ? uint32_t(end - p) : 258u) : 0u;
+            }
+            // stage 2: both tables' entries, and their first eight bytes asked for -- all four positions' at once
+            UFOR(u) {
+                const uint64_t p = t0 + uint32_t(u * 64 + l);
+                nw[UIX(u)] = 0;
+                if (in[UIX(u)] && p + 4 <= total && !(dbg & 8)) {
+                    ok4[l][UIX(u)] = 1; h4[l][UIX(u)] = lz_hash(uint32_t(hi[UIX(u)]));
+                    const uint64_t b = S.bucket[h4[l][UIX(u)]];
+                    for (int w = 0; w < int(CSP_WAYS); w++) {
+                        const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;
+                        if (r == 0xFFFFu) break;
+                        const uint32_t d = rel[l][UIX(u)] - r;
+                        if (d > 32768u) break;
+                        dw[UIX(u)][nw[UIX(u)]++] = d;
+                    }
+                }
+                if (in[UIX(u)] && p + 8 <= total && !(dbg & 8)) {
+                    ok8[l][UIX(u)] = 1; h8[l][UIX(u)] = lz_hash8(hi[UIX(u)]);
+                    const uint64_t b0 = S.bucket8[0][h8[l][UIX(u)]], b1 = S.bucket8[1][h8[l][UIX(u)]];
+                    for (int w = 0; w < int(CSP_WAYS8); w++) {
+                        const uint32_t r = uint32_t((w < 4 ? b0 : b1) >> (16 * (w & 3))) & 0xFFFFu;
+                        if (r == 0xFFFFu) break;
+                        const uint32_t d = rel[l][UIX(u)] - r;
+                        if (d > 32768u) break;
+                        dw[UIX(u)][nw[UIX(u)]++] = d;
+                    }
+                }
+            }
+            UFOR(u) {
+                const uint64_t p = t0 + uint32_t(u * 64 + l);
+                CSH_UNROLL
+                for (int w = 0; w < NW; w++) xw[UIX(u)][w] = w < nw[UIX(u)] ? hi[UIX(u)] ^ load64u(data + p - dw[UIX(u)][w]) : 0ull;
+            }
+            if (dbg & 2) { UFOR(u) nw[UIX(u)] = 0; }
+            // stage 3: judge them.  c0: the nearest with >= 3 bytes; c1: the longest (ties: the nearer) -- whatever the order of the offers
+            UFOR(u) if (in[UIX(u)]) {
+                const uint64_t p = t0 + uint32_t(u * 64 + l);
+                const uint32_t ml = maxlen[UIX(u)];
+                uint32_t len0 = 0, d0 = 0, len1 = 0, d1 = 0;
                 auto offer = [&](uint32_t L, uint32_t D) {
                     if (L >= 3 && (!d0 || D < d0)) { len0 = L; d0 = D; }
                     if (L > len1 || (L == len1 && L && D < d1)) { len1 = L; d1 = D; }
                 };
                 {   // the fixed distances against the 8 bytes in front of p
-                    const uint64_t lo = load64u(data + p - 8);   // (p < 8: whatever the pool holds there; guarded by d <= p)
-                    const uint32_t cap8 = maxlen < 8 ? maxlen : 8u;
+                    const uint32_t cap8 = ml < 8 ? ml : 8u;
                     uint32_t l8best = 0, dbest = 0, f0l = 0, f0d = 0;
                     CSH_UNROLL
                     for (int k = 0; k < 6; k++) {
                         const uint32_t d = k < 4 ? uint32_t(k + 1) : (k == 4 ? 6u : 8u);
                         if (uint64_t(d) > p) continue;
-                        const uint64_t shifted = d == 8 ? lo : ((hi << (8 * d)) | (lo >> (64 - 8 * d)));
-                        const uint64_t x = hi ^ shifted;
+                        const uint64_t shifted = d == 8 ? lo[UIX(u)] : ((hi[UIX(u)] << (8 * d)) | (lo[UIX(u)] >> (64 - 8 * d)));
+                        const uint64_t x = hi[UIX(u)] ^ shifted;
                         uint32_t l8 = x ? ctz64(x) >> 3 : 8u;
                         if (l8 > cap8) l8 = cap8;
                         if (l8 > l8best) { l8best = l8; dbest = d; }
@@ -133,69 +209,43 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                     }
                     if (l8best) {
                         uint32_t ln = l8best;
-                        if (l8best == 8 && maxlen > 8) ln = lz_lcp(data, p, dbest, maxlen, 8);
+                        if (l8best == 8 && ml > 8) ln = lz_lcp(data, p, dbest, ml, 8);
                         if (f0d && f0d != dbest) offer(f0l, f0d);
                         offer(ln, dbest);
                     }
                 }
-                // both tables' candidates: their first eight bytes fetched together, then judged in any order (the rule above does not depend on it)
-                uint32_t dw[CSP_WAYS + CSP_WAYS8];
-                uint64_t xw[CSP_WAYS + CSP_WAYS8];
-                int nw = 0;
-                if (p + 4 <= total) {
-                    ok4[l] = 1; h4[l] = lz_hash(uint32_t(hi));
-                    const uint64_t b = S.bucket[h4[l]];
-                    for (int w = 0; w < int(CSP_WAYS); w++) {
-                        const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;
-                        if (r == 0xFFFFu) break;
-                        const uint32_t d = rel[l] - r;
-                        if (d > 32768u) break;
-                        dw[nw++] = d;
-                    }
-                }
-                if (p + 8 <= total) {
-                    ok8[l] = 1; h8[l] = lz_hash8(hi);
-                    const uint64_t b0 = S.bucket8[0][h8[l]], b1 = S.bucket8[1][h8[l]];
-                    for (int w = 0; w < int(CSP_WAYS8); w++) {
-                        const uint32_t r = uint32_t((w < 4 ? b0 : b1) >> (16 * (w & 3))) & 0xFFFFu;
-                        if (r == 0xFFFFu) break;
-                        const uint32_t d = rel[l] - r;
-                        if (d > 32768u) break;
-                        dw[nw++] = d;
-                    }
-                }
                 CSH_UNROLL
-                for (int w = 0; w < int(CSP_WAYS + CSP_WAYS8); w++) xw[w] = w < nw ? hi ^ load64u(data + p - dw[w]) : 0ull;
-                CSH_UNROLL
-                for (int w = 0; w < int(CSP_WAYS + CSP_WAYS8); w++) if (w < nw) {
+                for (int w = 0; w < NW; w++) if (w < nw[UIX(u)]) {
                     uint32_t ln;
-                    const uint32_t d = dw[w];
-                    if (xw[w]) { ln = ctz64(xw[w]) >> 3; if (ln > maxlen) ln = maxlen; }
-                    else if (maxlen <= 8) ln = maxlen;
+                    const uint32_t d = dw[UIX(u)][w];
+                    if (xw[UIX(u)][w]) { ln = ctz64(xw[UIX(u)][w]) >> 3; if (ln > ml) ln = ml; }
+                    else if (ml <= 8) ln = ml;
                     else {
                         // all eight agree.  How far it goes matters only if it can become c0 (nearer than c0) or c1 (longer than c1, or as long and nearer):
                         // a candidate that differs inside the `need` bytes it would have to match changes nothing, whatever else is offered later (c0 only
                         // gets nearer, c1 only better) -- in a run of equal bytes every candidate but the first leaves here
                         if (d0 && d > d0) {
                             const uint32_t need = d < d1 ? len1 : len1 + 1u;
-                            if (need > maxlen) continue;
+                            if (need > ml) continue;
                             if (need > 8 && load64u(data + p + need - 8) != load64u(data + p - d + need - 8)) continue;
                         }
-                        ln = lz_lcp(data, p, d, maxlen, 8);
+                        ln = lz_lcp(data, p, d, ml, 8);
                     }
                     offer(ln, d);
                 }
                 if (len1 <= len0) { len1 = 0; d1 = 0; }
                 const uint32_t off = uint32_t(p - start);
                 cand[uint64_t(off & (CSP_DEEP_SEG - 1)) * 64 + (off / CSP_DEEP_SEG)] =
-                    uint64_t(len0) | (uint64_t(d0) << 9) | (uint64_t(len1) << 25) | (uint64_t(d1) << 34) | ((hi & 255ull) << 50);
+                    uint64_t(len0) | (uint64_t(d0) << 9) | (uint64_t(len1) << 25) | (uint64_t(d1) << 34) | ((hi[UIX(u)] & 255ull) << 50);
             }
         }
-        CSP_WAVE_SYNC();
+        CSP_WG_SYNC();
         deep_insert(S, h4, ok4, h8, ok8, rel);
     }
     CSP_MEM_FENCE();
-    // ---------------------------------------------------------------------------------------------------------------- C, D, F
+    CSP_WG_SYNC();
+    if (!CSP_WAVE0) return;   // (the caller's barrier behind deep_chunk is where the other waves wait)
+    // ---------------------------------------------------------------------------------------------------------------- C, D, F  (one wave)
     LV<uint32_t> ns;   // lane = segment: how many positions it holds
     LFOR(l) { const uint32_t s0 = uint32_t(l) * CSP_DEEP_SEG; ns[l] = s0 >= n ? 0u : (n - s0 < CSP_DEEP_SEG ? n - s0 : uint32_t(CSP_DEEP_SEG)); }
     // the first pass's counts: every byte of the chunk a literal
@@ -207,6 +257,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
         else for (uint64_t q = p; q < end; q++) atomicAdd(&S.hist[data[q]], 1u);
     }
     CSP_WAVE_SYNC();
+    if (dbg & 4) iters = 0;
     for (int it = 0; it < iters; it++) {
         const bool final_pass = it + 1 == iters;
         {

@@ -894,8 +894,8 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
  *   no matches and nothing to choose between: they keep the greedy parse (and its speed).
  *   CANDIDATES of position p: distances from (a) the fixed set 1,2,3,4,6,8 -- of these f0 = the nearest whose first 8 bytes agree in
  *   >= 3, f1 = the one that agrees longest inside 8 bytes (ties: the nearer; extended when all 8 agree); (b) the four 4-byte-hash
- *   entries of tokenize's table; (c) the DEEP_WAYS8 entries of a second table keyed by 8 bytes (2048 buckets, refreshed tile by tile
- *   in the same way), which is where the long matches far back come from.  Kept per position: c0 = the nearest candidate that matches
+ *   entries of tokenize's table; (c) the DEEP_WAYS8 entries of a second table keyed by 8 bytes (2048 buckets), which is where the long matches far back
+ *   come from.  Both tables are refreshed in tokenize's way but every DEEP_TILE positions: of a tile's positions with one hash the last enters.  Kept per position: c0 = the nearest candidate that matches
  *   >= 3 bytes, c1 = the longest (ties: the nearer), if longer than c0.  Lengths up to c0's use c0's distance, longer ones c1's.
  *   COSTS in 1/16 bit: 16 log2(total / count) (literal_costs' integer log2) per literal / length / distance symbol from the
  *   previous parse's counts, a symbol that did not occur costs as if it had occurred half a time; plus the extra bits.
@@ -908,6 +908,7 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
 #define DEEP_DIV 512
 #define DEEP_HASH8_BITS 11
 #define DEEP_WAYS8 8
+#define DEEP_TILE 256   /* positions whose candidates come out of one state of the tables (the GPU wave takes four per lane: independent work in flight together) */
 #define DEEP_SEG 512
 #define DEEP_CAP 16
 #define DEEP_ITERS 5
@@ -959,9 +960,9 @@ static void deep_parse(const uint8_t *data, size_t total, size_t start, size_t e
         memset(table8, 0xFF, sizeof table8);
         const size_t seed0 = start > 32768 ? start - 32768 : 0;
         const size_t base_rel = 32768 - start;
-        for (size_t t0 = seed0; t0 < start; t0 += 64) { insert_tile(table, data, total, base_rel, t0, t0 + 64); insert_tile8(table8, data, total, base_rel, t0, t0 + 64); }
-        for (size_t t0 = start; t0 < end; t0 += 64) {
-            size_t t1 = t0 + 64 < end ? t0 + 64 : end;
+        for (size_t t0 = seed0; t0 < start; t0 += DEEP_TILE) { insert_tile(table, data, total, base_rel, t0, t0 + DEEP_TILE); insert_tile8(table8, data, total, base_rel, t0, t0 + DEEP_TILE); }
+        for (size_t t0 = start; t0 < end; t0 += DEEP_TILE) {
+            size_t t1 = t0 + DEEP_TILE < end ? t0 + DEEP_TILE : end;
             for (size_t p = t0; p < t1; p++) {
                 const size_t maxlen = end - p < 258 ? end - p : 258;
                 size_t len0 = 0, d0 = 0, len1 = 0, d1 = 0;   /* c0: nearest with >= 3; c1: longest, ties nearer */
