@@ -42,18 +42,23 @@ __global__ void __launch_bounds__(CSP_DEEP_THREADS) k_png_deep_hist(DeflateCtx c
         NoSink none;
         deep_chunk(data, im.raw_len, start, end, S, scratch, c.deep_iters, false, none, c.deep_debug);
         if (CSP_WAVE0) {
-        LV<uint64_t> e;
-        LFOR(l) {
-            e[l] = 0;
-            for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) {
-                const uint32_t f = i == 256 ? 1u : S.hist[i];
-                rec.freq[i] = f;
-                if (i > 256 && i < CSP_NLIT) e[l] += uint64_t(f) * len_extra_of(i - 257);
-                if (i >= CSP_NLIT) e[l] += uint64_t(f) * dist_extra_of(i - CSP_NLIT);
-            }
-        }
-        const uint64_t extra = lsum(e);
-        LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+            // the parse's counts replace the greedy ones only where they promise a smaller block (segment ends cut long runs: a flat chunk can lose)
+            const uint64_t est_greedy = deep_estimate([&](uint32_t i) { return rec.freq[i]; }), est_deep = deep_estimate([&](uint32_t i) { return i == 256 ? 1u : S.hist[i]; });
+            if (est_deep < est_greedy) {
+                LV<uint64_t> e;
+                LFOR(l) {
+                    e[l] = 0;
+                    for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) {
+                        const uint32_t f = i == 256 ? 1u : S.hist[i];
+                        rec.freq[i] = f;
+                        if (i > 256 && i < CSP_NLIT) e[l] += uint64_t(f) * len_extra_of(i - 257);
+                        if (i >= CSP_NLIT) e[l] += uint64_t(f) * dist_extra_of(i - CSP_NLIT);
+                    }
+                }
+                const uint64_t extra = lsum(e);
+                LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+            } else
+                LFOR(l) if (l == 0) rec.deep = 0;
         }
         CSP_WG_SYNC();
     }

@@ -17,6 +17,7 @@ namespace csp {
 
 enum : uint32_t {
     CSP_DEEP_DIV = 512,        // a chunk qualifies when matches * DIV >= tokens in its greedy parse
+    CSP_HASH4_BITS = 11,       // the parse's own 4-byte table: 2048 buckets x 4 (the greedy tokenizer's has 512)
     CSP_HASH8_BITS = 11, CSP_WAYS8 = 8,
     CSP_DEEP_TILE = 256,       // positions whose candidates come out of one state of the tables (four per lane)
     CSP_DEEP_SEG = 512, CSP_DEEP_CAP = 16, CSP_DEEP_START = 64,
@@ -25,18 +26,19 @@ enum : uint32_t {
     // the wave's scratch area in HBM: candidates (8 B), choices (2 B), costs (4 B, one row more), visit marks (1 B) per position
     CSP_DEEP_CAND_OFF = 0, CSP_DEEP_CHOICE_OFF = 262144, CSP_DEEP_COST_OFF = 327680, CSP_DEEP_TAKEN_OFF = 327680 + 131584, CSP_DEEP_SCRATCH = 524288,
 };
-static_assert(uint32_t(CSP_HASH8_BITS) == uint32_t(CSP_HASH_BITS), "one last-lane map serves both tables");
+static_assert(uint32_t(CSP_HASH8_BITS) == uint32_t(CSP_HASH4_BITS), "one last-lane map serves both tables");
 static_assert(CSP_DEEP_TAKEN_OFF + 32768 <= CSP_DEEP_SCRATCH, "scratch layout");
 
 struct DeepLds {
-    uint64_t bucket[1u << CSP_HASH_BITS];        // 4-byte table: four 16-bit positions, most recent in the low bits (png_lz.h)
+    uint64_t bucket[1u << CSP_HASH4_BITS];        // 4-byte table: four 16-bit positions, most recent in the low bits (png_lz.h)
     uint64_t bucket8[2][1u << CSP_HASH8_BITS];   // 8-byte table: ways 0..3 in [0], 4..7 in [1]
-    uint8_t lastlane[1u << CSP_HASH_BITS];
+    uint8_t lastlane[1u << CSP_HASH4_BITS];
     uint32_t hist[CSP_NSYM];                     // (its first 256 words serve deep_last_lanes while the candidates are made: the counts start after that)
     uint32_t item;                               // the workgroup's current work item (next_item)
     uint16_t lit_cost[256], len_cost[260], dist_cost[32];
 };
 
+__device__ __forceinline__ static uint32_t lz_hash4(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - CSP_HASH4_BITS); }
 __device__ __forceinline__ static uint32_t lz_hash8(uint64_t v) { return ((uint32_t(v) * 0x9E3779B1u) ^ (uint32_t(v >> 32) * 0x85EBCA6Bu)) >> (32 - CSP_HASH8_BITS); }
 __device__ __forceinline__ static uint32_t cost16_of(uint32_t c, uint32_t total) {   // 16 log2(total / c), 1 .. 240 (oracle: cost16_of)
     const uint32_t q = (total << 8) / c;
@@ -105,6 +107,25 @@ __device__ __forceinline__ static void deep_insert(DeepLds &S, LV4 &h4, LV4 &ok4
     CSP_WG_SYNC();
 }
 
+// what a block with these counts takes, in 1/16 bit, by the entropy of its two alphabets (+ the extra bits): the parse replaces the greedy one only if this
+// says it is smaller (oracle: deep_estimate).  freq: CSP_NSYM counts, end-of-block included
+template <class F>
+__device__ __forceinline__ static uint64_t deep_estimate(F freq) {
+    LV<uint64_t> a, b;
+    LFOR(l) { a[l] = 0; b[l] = 0; for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) { if (i < CSP_NLIT) a[l] += freq(i); else b[l] += freq(i); } }
+    const uint32_t tl = uint32_t(lsum(a)), td = uint32_t(lsum(b));
+    LV<uint64_t> e;
+    LFOR(l) {
+        e[l] = 0;
+        for (uint32_t i = uint32_t(l); i < CSP_NSYM; i += 64) {
+            const uint32_t f = freq(i);
+            if (!f) continue;
+            e[l] += uint64_t(f) * (cost16_of(f, i < CSP_NLIT ? tl : td) + 16u * (i > 256 && i < CSP_NLIT ? len_extra_of(i - 257) : i >= CSP_NLIT ? dist_extra_of(i - CSP_NLIT) : 0u));
+        }
+    }
+    return lsum(e);
+}
+
 struct NoSink { __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_t, const LV<uint32_t> &, const LV<uint32_t> &, const LV<uint32_t> &) {} };
 
 // data[start, end): a chunk of a stream of `total` bytes.  S.hist holds the last pass's counts on exit.  want_tokens: the sink sees the final parse.
@@ -116,7 +137,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
     uint8_t *tk = scratch + CSP_DEEP_TAKEN_OFF;
     const uint32_t n = uint32_t(end - start);
     // ---------------------------------------------------------------------------------------------------------------- M
-    LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH_BITS); i += 64) { S.bucket[i] = ~0ull; S.bucket8[0][i] = ~0ull; S.bucket8[1][i] = ~0ull; }
+    LFOR(l) for (uint32_t i = uint32_t(l); i < (1u << CSP_HASH4_BITS); i += 64) { S.bucket[i] = ~0ull; S.bucket8[0][i] = ~0ull; S.bucket8[1][i] = ~0ull; }
     CSP_WG_SYNC();
     {
         const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
@@ -127,7 +148,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                     const uint64_t p = t0 + uint32_t(u * 64 + l);
                     const uint64_t v = load64u(data + p);
                     ok4[l][UIX(u)] = p + 4 <= total ? 1u : 0u; ok8[l][UIX(u)] = p + 8 <= total ? 1u : 0u;
-                    h4[l][UIX(u)] = ok4[l][UIX(u)] ? lz_hash(uint32_t(v)) : 0u; h8[l][UIX(u)] = ok8[l][UIX(u)] ? lz_hash8(v) : 0u;
+                    h4[l][UIX(u)] = ok4[l][UIX(u)] ? lz_hash4(uint32_t(v)) : 0u; h8[l][UIX(u)] = ok8[l][UIX(u)] ? lz_hash8(v) : 0u;
                     rel[l][UIX(u)] = uint32_t(p + 32768 - start);
                 }
             }
@@ -156,7 +177,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                 const uint64_t p = t0 + uint32_t(u * 64 + l);
                 nw[UIX(u)] = 0;
                 if (in[UIX(u)] && p + 4 <= total && !(dbg & 8)) {
-                    ok4[l][UIX(u)] = 1; h4[l][UIX(u)] = lz_hash(uint32_t(hi[UIX(u)]));
+                    ok4[l][UIX(u)] = 1; h4[l][UIX(u)] = lz_hash4(uint32_t(hi[UIX(u)]));
                     const uint64_t b = S.bucket[h4[l][UIX(u)]];
                     for (int w = 0; w < int(CSP_WAYS); w++) {
                         const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;

@@ -8,7 +8,9 @@ namespace csp {
 
 enum : uint32_t {
     CSP_CHUNK = 32768,        // bytes of filtered stream per deflate block (one wave codes one chunk)
-    CSP_HASH_BITS = 11,       // match finder: 2048 buckets x 4 positions (16 KiB of LDS per wave)
+    CSP_HASH_BITS = 9,        // the greedy match finder: 512 buckets x 4 positions (4 KiB of LDS per wave).  What it is for is telling the chunks with matches in
+                              // them from the ones without -- the former get the min-cost-path parse and its own, larger tables (png_parse.h); the latter lose
+                              // nothing to a small table (measured on the synthetic set at 2048 / 1024 / 512 / 256 buckets), and its waves fit a CU four times over
     CSP_WAYS = 4,
     CSP_GROUP = 1,            // consecutive chunks one wave codes in a row (every chunk seeds its own match finder: carrying the
                               // table from chunk to chunk was measured at -3 % on the tokenizer passes, not worth its complexity)

@@ -784,23 +784,23 @@ int cso_png_filter(const cso_png *P, int strategy, uint8_t *out, uint8_t *choice
  * alphabet (zlib's rule, which keeps every code complete).
  */
 #define CHUNK 32768u
-#define HASH_BITS 11
+#define HASH_BITS 9   /* the greedy table: 512 buckets (what it has to tell apart is chunks with matches from chunks without; the parse has its own tables) */
 #define WAYS 4
 static int len_code(int len) { int c = 28; while (LEN_BASE[c] > len) c--; return c; }
 static int dist_code(int d) { int c = 29; while (DIST_BASE[c] > d) c--; return c; }
 static size_t lcp(const uint8_t *a, const uint8_t *b, size_t max) { size_t l = 0; while (l < max && a[l] == b[l]) l++; return l; }
 static const int FIXED_DIST[6] = {1, 2, 3, 4, 6, 8};
-static uint32_t hash4(const uint8_t *d) {
+static uint32_t hash4(const uint8_t *d, int bits) {
     uint32_t v = d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24);
-    return (v * 0x9E3779B1u) >> (32 - HASH_BITS);
+    return (v * 0x9E3779B1u) >> (32 - bits);
 }
 /* after a tile: of the tile's positions with one hash only the LAST enters the bucket, pushing the older entries back */
-static void insert_tile(uint16_t (*table)[WAYS], const uint8_t *data, size_t total, size_t base_rel, size_t t0, size_t t1) {
+static void insert_tile(uint16_t (*table)[WAYS], int bits, const uint8_t *data, size_t total, size_t base_rel, size_t t0, size_t t1) {
     /* positions are stored as 16-bit offsets from (chunk start - 32768): rel = p + base_rel */
-    size_t lastpos[1 << HASH_BITS];   /* only the slots of this tile's hashes are read */
-    for (size_t p = t0; p < t1 && p + 4 <= total; p++) lastpos[hash4(data + p)] = p;
+    size_t lastpos[1 << 11];   /* only the slots of this tile's hashes are read (bits <= 11) */
+    for (size_t p = t0; p < t1 && p + 4 <= total; p++) lastpos[hash4(data + p, bits)] = p;
     for (size_t p = t0; p < t1 && p + 4 <= total; p++) {
-        uint32_t h = hash4(data + p);
+        uint32_t h = hash4(data + p, bits);
         size_t rel = p + base_rel;
         if (lastpos[h] != p || rel == 0xFFFF) continue;
         for (int w = WAYS - 1; w > 0; w--) table[h][w] = table[h][w - 1];
@@ -839,7 +839,7 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
     memset(table, 0xFF, sizeof table);
     const size_t seed0 = start > 32768 ? start - 32768 : 0;
     const size_t base_rel = 32768 - start;   /* modulo 2^64: rel = p - start + 32768 */
-    for (size_t t0 = seed0; t0 < start; t0 += 64) insert_tile(table, data, total, base_rel, t0, t0 + 64);
+    for (size_t t0 = seed0; t0 < start; t0 += 64) insert_tile(table, HASH_BITS, data, total, base_rel, t0, t0 + 64);
     size_t carry = start;   /* next position the parse visits */
     uint16_t cost16[256];
     literal_costs(data, start, end, cost16);
@@ -857,7 +857,7 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
             }
             if (l8best) { bl = l8best; bd = dbest; if (l8best == 8 && maxlen > 8) bl = lcp(data + p, data + p - dbest, maxlen); }
             if (p + 4 <= total) {
-                uint32_t h = hash4(data + p);
+                uint32_t h = hash4(data + p, HASH_BITS);
                 for (int w = 0; w < WAYS; w++) {   /* most recent first; a longer match wins, a tie keeps the nearer */
                     if (table[h][w] == 0xFFFF) break;
                     size_t d = (p + base_rel) - table[h][w];
@@ -874,7 +874,7 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
             }
             tok[p - start].len = (uint16_t)bl; tok[p - start].dist = (uint16_t)bd;
         }
-        insert_tile(table, data, total, base_rel, t0, t1);
+        insert_tile(table, HASH_BITS, data, total, base_rel, t0, t1);
         for (size_t p = t0; p < t1; p++) {
             size_t i = p - start;
             taken[i] = 0;
@@ -906,6 +906,7 @@ static void tokenize(const uint8_t *data, size_t total, size_t start, size_t end
  *   ITERATIONS: DEEP_ITERS passes, each from the counts of the one before; the first prices literals by the chunk's byte counts and both symbols of
  *   a match at DEEP_START / 16 bits (+ extra bits); --zopfli: DEEP_ITERS_ZOPFLI. */
 #define DEEP_DIV 512
+#define DEEP_HASH4_BITS 11
 #define DEEP_HASH8_BITS 11
 #define DEEP_WAYS8 8
 #define DEEP_TILE 256   /* positions whose candidates come out of one state of the tables (the GPU wave takes four per lane: independent work in flight together) */
@@ -949,18 +950,28 @@ static void deep_costs(const uint32_t *lf, const uint32_t *df, uint32_t *lit_cos
     for (int l = 3; l <= 258; l++) { int c = len_code(l); len_cost[l] = (lf[257 + c] ? cost16_of(lf[257 + c], tl) : cost16_of(1, 2 * tl)) + 16u * (uint32_t)LEN_EXTRA[c]; }
     for (int c = 0; c < 30; c++) dist_cost[c] = (td == 0 ? 80u : df[c] ? cost16_of(df[c], td) : cost16_of(1, 2 * td)) + 16u * (uint32_t)DIST_EXTRA[c];
 }
+/* what a block with these counts takes, in 1/16 bit: the entropy of its two alphabets + the extra bits */
+static uint64_t deep_estimate(const uint32_t *lf, const uint32_t *df) {
+    uint32_t tl = 0, td = 0;
+    uint64_t e = 0;
+    for (int i = 0; i < 286; i++) tl += lf[i];
+    for (int i = 0; i < 30; i++) td += df[i];
+    for (int i = 0; i < 286; i++) if (lf[i]) e += (uint64_t)lf[i] * (cost16_of(lf[i], tl) + 16u * (uint32_t)(i > 256 ? LEN_EXTRA[i - 257] : 0));
+    for (int i = 0; i < 30; i++) if (df[i]) e += (uint64_t)df[i] * (cost16_of(df[i], td) + 16u * (uint32_t)DIST_EXTRA[i]);
+    return e;
+}
 /* tok / taken: out, as tokenize() */
 static void deep_parse(const uint8_t *data, size_t total, size_t start, size_t end, int iters, token *tok, uint8_t *taken) {
     const size_t n = end - start;
     deep_cand *cand = (deep_cand *)malloc(sizeof(deep_cand) * n);
     {
-        uint16_t table[1 << HASH_BITS][WAYS];
+        uint16_t table[1 << DEEP_HASH4_BITS][WAYS];
         static uint16_t table8[1 << DEEP_HASH8_BITS][DEEP_WAYS8];
         memset(table, 0xFF, sizeof table);
         memset(table8, 0xFF, sizeof table8);
         const size_t seed0 = start > 32768 ? start - 32768 : 0;
         const size_t base_rel = 32768 - start;
-        for (size_t t0 = seed0; t0 < start; t0 += DEEP_TILE) { insert_tile(table, data, total, base_rel, t0, t0 + DEEP_TILE); insert_tile8(table8, data, total, base_rel, t0, t0 + DEEP_TILE); }
+        for (size_t t0 = seed0; t0 < start; t0 += DEEP_TILE) { insert_tile(table, DEEP_HASH4_BITS, data, total, base_rel, t0, t0 + DEEP_TILE); insert_tile8(table8, data, total, base_rel, t0, t0 + DEEP_TILE); }
         for (size_t t0 = start; t0 < end; t0 += DEEP_TILE) {
             size_t t1 = t0 + DEEP_TILE < end ? t0 + DEEP_TILE : end;
             for (size_t p = t0; p < t1; p++) {
@@ -984,7 +995,7 @@ static void deep_parse(const uint8_t *data, size_t total, size_t start, size_t e
                     }
                 }
                 if (p + 4 <= total) {
-                    uint32_t h = hash4(data + p);
+                    uint32_t h = hash4(data + p, DEEP_HASH4_BITS);
                     for (int w = 0; w < WAYS; w++) {
                         if (table[h][w] == 0xFFFF) break;
                         size_t d = (p + base_rel) - table[h][w];
@@ -1006,7 +1017,7 @@ static void deep_parse(const uint8_t *data, size_t total, size_t start, size_t e
                 deep_cand *c = &cand[p - start];
                 c->len0 = (uint16_t)len0; c->d0 = (uint16_t)(d0 & 0xFFFF); c->len1 = (uint16_t)len1; c->d1 = (uint16_t)(d1 & 0xFFFF);   /* 32768 is kept as 32768 */
             }
-            insert_tile(table, data, total, base_rel, t0, t1);
+            insert_tile(table, DEEP_HASH4_BITS, data, total, base_rel, t0, t1);
             insert_tile8(table8, data, total, base_rel, t0, t1);
         }
     }
@@ -1167,6 +1178,9 @@ static void deflate_chunk(const uint8_t *data, size_t total, size_t start, size_
         for (int i = 0; i < 286; i++) if (i != 256) nt += lf[i];
         for (int i = 257; i < 286; i++) nm += lf[i];
         if (iters > 0 && nm * (uint32_t)(deep_div_override ? deep_div_override : DEEP_DIV) >= nt) {
+            const uint64_t est_greedy = deep_estimate(lf, df);
+            token *gtok = (token *)malloc(sizeof(token) * n); uint8_t *gtaken = (uint8_t *)malloc(n);
+            memcpy(gtok, tok, sizeof(token) * n); memcpy(gtaken, taken, n);
             double ent0 = 0; uint64_t avgl = 0;
             if (getenv("CSO_DEEP_REPORT")) { uint16_t c16[256]; literal_costs(data, start, end, c16); for (size_t i = start; i < end; i++) avgl += c16[data[i]]; avgl /= n;
                 uint32_t T = 0, TD = 0; for (int i = 0; i < 286; i++) T += lf[i]; for (int i = 0; i < 30; i++) TD += df[i];
@@ -1179,6 +1193,16 @@ static void deflate_chunk(const uint8_t *data, size_t total, size_t start, size_
                 if (tok[i].len) { lf[257 + len_code(tok[i].len)]++; df[dist_code(tok[i].dist)]++; } else lf[data[start + i]]++;
             }
             lf[256] = 1;
+            if (deep_estimate(lf, df) >= est_greedy) {   /* the parse must promise a smaller block (segment ends cut long runs: a flat chunk can lose) */
+                memcpy(tok, gtok, sizeof(token) * n); memcpy(taken, gtaken, n);
+                memset(lf, 0, sizeof lf); memset(df, 0, sizeof df);
+                for (size_t i = 0; i < n; i++) {
+                    if (!taken[i]) continue;
+                    if (tok[i].len) { lf[257 + len_code(tok[i].len)]++; df[dist_code(tok[i].dist)]++; } else lf[data[start + i]]++;
+                }
+                lf[256] = 1;
+            }
+            free(gtok); free(gtaken);
             if (getenv("CSO_DEEP_REPORT")) { double ent1 = 0;
                 uint32_t T = 0, TD = 0; for (int i = 0; i < 286; i++) T += lf[i]; for (int i = 0; i < 30; i++) TD += df[i];
                 for (int i = 0; i < 286; i++) if (lf[i]) ent1 += lf[i] * (double)cost16_of(lf[i], T) / 16 + (i > 256 ? lf[i] * LEN_EXTRA[i - 257] : 0);

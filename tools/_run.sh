@@ -1,13 +1,12 @@
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests/test_png_gpu.py -x -q 2>&1 | tail -3
 R=$(pwd); cd /tmp; export TMPDIR=/tmp
-for N in 64; do
+for N in 64 256; do
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_png -- python $R/tools/png_bench.py $N 4 > $R/gpurun_out/r06_png_bench_batch$N.txt 2> $R/gpurun_out/prof_png.err
 f=$(find $R/gpurun_out/prof_png -name "*kernel_stats.csv"); cp $f $R/gpurun_out/r06_png_kernel_stats_batch$N.csv
 rm -rf $R/gpurun_out/prof_png; grep "rep 1" -A1 $R/gpurun_out/r06_png_bench_batch$N.txt
 python3 - $R/gpurun_out/r06_png_kernel_stats_batch$N.csv <<'PY'
 import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:6]: print("%-40s calls %s avg ms %.1f"%(r['Name'][:40],r['Calls'],float(r['AverageNs'])/1e6))
+for r in list(csv.DictReader(open(sys.argv[1])))[:9]: print("%-40s calls %s avg ms %.1f"%(r['Name'][:40],r['Calls'],float(r['AverageNs'])/1e6))
 PY
 done
-cd $R; for D in 1 4 8; do echo "debug $D: $(CSH_DEEP_DEBUG=$D python tools/png_bench.py 64 4 2>&1 | grep -A1 'rep 1' | tail -1 | grep -o 'k_png_deep [0-9.]*')"; done
