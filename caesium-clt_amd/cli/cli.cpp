@@ -14,7 +14,10 @@
 #include <fstream>
 #include <functional>
 #include <future>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <unordered_set>
 #include <thread>
 
@@ -647,7 +650,9 @@ int run(const Options &o) {
     // every file's output path is computed up front; if one names another file's input the windows run strictly one after the other.
     bool read_ahead = windows.size() > 1;
     if (read_ahead) {
-        auto key = [](const fs::path &q) { std::error_code e; fs::path a = fs::absolute(q, e); return (e ? q : a).lexically_normal().string(); };
+        std::error_code cwd_ec;
+        const fs::path cwd = fs::current_path(cwd_ec);   // once: fs::absolute asks the kernel for it on every call (20 000 calls for 10 000 files)
+        auto key = [&](const fs::path &q) { return (q.is_absolute() || cwd_ec ? q : cwd / q).lexically_normal().string(); };
         std::unordered_set<std::string> inputs;
         for (auto &f : files) inputs.insert(key(f));
         for (size_t i = 0; i < files.size() && read_ahead; i++) {
@@ -659,99 +664,134 @@ int run(const Options &o) {
             if (out != key(files[i]) && inputs.count(out)) read_ahead = false;
         }
     }
+    const auto t_plan = now();
+    // ---- stage 2 (device): the engine calls of compressor.rs:287-306, batched.  Files that share a parameter set form one batch per device; the batches of
+    // all windows go through ONE queue that a few host threads per device drain (round 6; before, every window ended in a join with the device idle while its
+    // last batches were written): a window's batches are queued as soon as it is read, while the window before it is still finishing.  What is held in
+    // memory stays two windows: window N + 1 is read only when window N - 1 is done.
+    // CSH_CLI_SAME_DEVICE=1 (tests): --gpus N deals the batches over N device slots that are all device 0 -- the code path of N GPUs on a box that has one
+    const bool same_device = getenv("CSH_CLI_SAME_DEVICE") != nullptr;
+    const int ndev = o.dry_run ? 1 : (same_device ? std::max(1, o.gpus) : std::max(1, std::min(o.gpus, std::max(1, csh_device_count()))));
+    // host threads per device, each with its own batches: while one batch is in its kernels the others are being parsed and uploaded or fetched and
+    // written (separate streams; the boundary call is thread-safe).  A cold process pays for every thread's pools once (~55 ms): two for a short run
+    // (2048 x 1080p: 0.75-0.83 s with 2, 0.81-0.85 s with 4), four for a long one (10 000 files: 1.86-2.05 s with 2, 1.64-1.67 s with 4)
+    const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : (files.size() >= 4096 ? 4 : 2);
+    const size_t nworkers = size_t(ndev) * per_dev;
+    struct QueuedBatch { size_t window; std::vector<size_t> idx; };
+    std::mutex qmu;
+    std::condition_variable qcv, donecv;
+    std::deque<QueuedBatch> queue;
+    std::vector<size_t> pending(windows.size(), 0);   // batches of a window still in the queue or in a worker's hands
+    bool closing = false;
+    auto run_batch = [&](size_t dev, const std::vector<size_t> &idx) {
+        std::vector<CByteArray> in(idx.size()), out(idx.size());
+        std::vector<CCSResult> res(idx.size());
+        std::vector<char> silent(idx.size(), 0);
+        for (size_t k = 0; k < idx.size(); k++) { in[k].data = jobs[idx[k]].data.data(); in[k].length = jobs[idx[k]].data.size(); }
+        CCSParameters p = jobs[idx[0]].params;
+        if (o.format != Format::Original && !o.max_size) {
+            cs_batch_convert(in.data(), in.size(), &p, map_format(o.format), int(dev), out.data(), res.data());   // the whole group in one device batch
+        } else if (o.format != Format::Original) {
+            // convert + size targeting: one engine call per file, as the reference does
+            for (size_t k = 0; k < idx.size(); k++) {
+                // convert, then walk the quality over the converted file (a WebP made here is decoded again on the device, as the reference does with libwebp)
+                res[k] = cs_convert_in_memory(in[k].data, in[k].length, &p, map_format(o.format), &out[k]);
+                if (o.max_size && res[k].success) {
+                    CByteArray conv = out[k];
+                    CCSParameters pk = p;
+                    cs_free_result(&res[k]);
+                    res[k] = cs_compress_to_size_in_memory(conv.data, conv.length, &pk, *o.max_size, true, &out[k]);
+                    cs_free_bytes(&conv);
+                } else if (o.max_size) {   // `.ok()?` in the reference: the error text is dropped
+                    cs_free_result(&res[k]);
+                    res[k].success = false; res[k].error_message = nullptr; silent[k] = 1;
+                }
+            }
+        } else if (o.max_size) cs_batch_compress_to_size(in.data(), in.size(), &p, *o.max_size, true, int(dev), out.data(), res.data());
+        else cs_batch_compress(in.data(), in.size(), &p, int(dev), out.data(), res.data());
+        for (size_t k = 0; k < idx.size(); k++) {
+            Job &j = jobs[idx[k]];
+            j.ok = res[k].success;
+            if (j.ok) j.result = out[k];
+            else {
+                if (!silent[k]) j.engine_msg = std::string("Error compressing file: ") + (res[k].error_message ? res[k].error_message : "");
+                cs_free_bytes(&out[k]);
+            }
+            cs_free_result(&res[k]);
+        }
+        const auto t_w = now();
+        // (the batch's inputs go here, on the worker: a window's 1024 buffers released in one go at its end were 25 ms of munmap with the device idle)
+        parallel_for(idx.size(), std::min<size_t>(threads, 8), [&](size_t k) { std::vector<uint8_t>().swap(jobs[idx[k]].data); finish_job(idx[k]); });
+        us_write += (long long)(ms(t_w, now()) * 1000.0);
+    };
+    std::vector<std::thread> workers;
+    if (!o.dry_run) for (size_t w = 0; w < nworkers; w++) workers.emplace_back([&, w] {
+        const size_t dev = same_device ? 0 : w % size_t(ndev);
+        for (;;) {
+            QueuedBatch qb;
+            {
+                std::unique_lock<std::mutex> lk(qmu);
+                qcv.wait(lk, [&] { return closing || !queue.empty(); });
+                if (queue.empty()) return;
+                qb = std::move(queue.front()); queue.pop_front();
+            }
+            run_batch(dev, qb.idx);
+            { std::lock_guard<std::mutex> lk(qmu); pending[qb.window]--; }
+            donecv.notify_all();
+        }
+    });
+    auto wait_window = [&](size_t wi) { std::unique_lock<std::mutex> lk(qmu); donecv.wait(lk, [&] { return pending[wi] == 0; }); };
+    const auto t_engine0 = now();
     std::future<void> ahead;
     if (read_ahead) ahead = std::async(std::launch::async, read_window, windows[0].first, windows[0].second);
     for (size_t wi = 0; wi < windows.size(); wi++) {
-    const size_t w0 = windows[wi].first, w1 = windows[wi].second;
-    if (read_ahead) {
-        ahead.get();
-        if (wi + 1 < windows.size()) ahead = std::async(std::launch::async, read_window, windows[wi + 1].first, windows[wi + 1].second);
-    } else read_window(w0, w1);
-    const auto t_read = now();
-    // ---- stage 2 (device): the engine calls of compressor.rs:287-306, batched.  Files that share a parameter set form one
-    // batch per device; groups go round-robin over --gpus devices, one host thread per device.
-    if (!o.dry_run) {
-        std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;   // resize target -> job indices (the only per-file parameter)
-        for (size_t i = w0; i < w1; i++) if (jobs[i].engine) groups[{jobs[i].params.width, jobs[i].params.height}].push_back(i);
-        std::vector<std::vector<size_t>> batches;
-        // files per device batch (and never more than one device batch takes by bytes / declared pixels: cs_batch_extent).  A cold process pays for the
-        // device pools it allocates (~25 MB per 1080p file) before the first kernel runs, and later batches reuse the first ones' pools: smaller
-        // batches start sooner -- 2048 x 1080p files end to end on one MI355X: 3.3-5.6 s at 1024 files per batch, 1.0 s at 256, 0.9 s at 128; CSH_CLI_BATCH overrides
-        // (a WebP output walks every picture macroblock step by step -- libwebp's encoder, one workgroup per picture: ~0.1 s for a 1500 x 844 picture however few
-        // pictures share the device; its batches are as large as the window allows)
-        const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : (o.format == Format::Webp ? 1024 : 128);   // (round 5: 10 000 files 2.11-2.13 s at 128, 2.23-2.37 s at 256 -- half the pools a cold process has to map before its first kernel)
-        for (auto &g : groups) {
-            std::vector<CByteArray> gin(g.second.size());
-            for (size_t k = 0; k < gin.size(); k++) { gin[k].data = jobs[g.second[k]].data.data(); gin[k].length = jobs[g.second[k]].data.size(); }
-            for (size_t k = 0, n = 0; k < g.second.size(); k += n) {
-                n = std::max<size_t>(1, cs_batch_extent(gin.data() + k, std::min(kBatch, g.second.size() - k)));
-                batches.emplace_back(g.second.begin() + k, g.second.begin() + k + n);
-            }
-        }
-        // CSH_CLI_SAME_DEVICE=1 (tests): --gpus N deals the batches over N device slots that are all device 0 -- the code path of N GPUs on a box that has one
-        const bool same_device = getenv("CSH_CLI_SAME_DEVICE") != nullptr;
-        int ndev = same_device ? std::max(1, o.gpus) : std::max(1, std::min(o.gpus, std::max(1, csh_device_count())));
-        // two host threads per device, each with its own batches: while one batch is in its kernels the other one is being parsed and uploaded or
-        // fetched and written (separate streams; the boundary call is thread-safe).  A third in flight helps a warm caller of the library (capi.cpp: 3); a cold
-        // process pays for every batch's pools once, and the third set of them costs what it gains (2048 files: 0.88-0.98 s with 2, 0.94-0.98 s with 3)
-        const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : 2;
-        const size_t nworkers = size_t(ndev) * per_dev;
-        parallel_for(nworkers, nworkers, [&](size_t worker) {
-            const size_t dev = same_device ? 0 : worker % size_t(ndev);
-            for (size_t bi = worker; bi < batches.size(); bi += nworkers) {
-                const std::vector<size_t> &idx = batches[bi];
-                std::vector<CByteArray> in(idx.size()), out(idx.size());
-                std::vector<CCSResult> res(idx.size());
-                std::vector<char> silent(idx.size(), 0);
-                for (size_t k = 0; k < idx.size(); k++) { in[k].data = jobs[idx[k]].data.data(); in[k].length = jobs[idx[k]].data.size(); }
-                CCSParameters p = jobs[idx[0]].params;
-                if (o.format != Format::Original && !o.max_size) {
-                    cs_batch_convert(in.data(), in.size(), &p, map_format(o.format), int(dev), out.data(), res.data());   // the whole group in one device batch
-                } else if (o.format != Format::Original) {
-                    // convert + size targeting: one engine call per file, as the reference does
-                    for (size_t k = 0; k < idx.size(); k++) {
-                        // convert, then walk the quality over the converted file (a WebP made here is decoded again on the device, as the reference does with libwebp)
-                        res[k] = cs_convert_in_memory(in[k].data, in[k].length, &p, map_format(o.format), &out[k]);
-                        if (o.max_size && res[k].success) {
-                            CByteArray conv = out[k];
-                            CCSParameters pk = p;
-                            cs_free_result(&res[k]);
-                            res[k] = cs_compress_to_size_in_memory(conv.data, conv.length, &pk, *o.max_size, true, &out[k]);
-                            cs_free_bytes(&conv);
-                        } else if (o.max_size) {   // `.ok()?` in the reference: the error text is dropped
-                            cs_free_result(&res[k]);
-                            res[k].success = false; res[k].error_message = nullptr; silent[k] = 1;
-                        }
-                    }
-                } else if (o.max_size) cs_batch_compress_to_size(in.data(), in.size(), &p, *o.max_size, true, int(dev), out.data(), res.data());
-                else cs_batch_compress(in.data(), in.size(), &p, int(dev), out.data(), res.data());
-                for (size_t k = 0; k < idx.size(); k++) {
-                    Job &j = jobs[idx[k]];
-                    j.ok = res[k].success;
-                    if (j.ok) j.result = out[k];
-                    else {
-                        if (!silent[k]) j.engine_msg = std::string("Error compressing file: ") + (res[k].error_message ? res[k].error_message : "");
-                        cs_free_bytes(&out[k]);
-                    }
-                    cs_free_result(&res[k]);
+        const size_t w0 = windows[wi].first, w1 = windows[wi].second;
+        if (read_ahead) ahead.get(); else read_window(w0, w1);
+        if (!o.dry_run) {
+            std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;   // resize target -> job indices (the only per-file parameter)
+            for (size_t i = w0; i < w1; i++) if (jobs[i].engine) groups[{jobs[i].params.width, jobs[i].params.height}].push_back(i);
+            std::vector<QueuedBatch> batches;
+            // files per device batch (and never more than one device batch takes by bytes / declared pixels: cs_batch_extent).  A cold process pays for the
+            // device pools it allocates (~25 MB per 1080p file) before the first kernel runs, and later batches reuse the first ones' pools: smaller
+            // batches start sooner -- 2048 x 1080p files end to end on one MI355X: 3.3-5.6 s at 1024 files per batch, 1.0 s at 256, 0.9 s at 128; CSH_CLI_BATCH overrides
+            // (a WebP output walks every picture macroblock step by step -- libwebp's encoder, one workgroup per picture: ~0.1 s for a 1500 x 844 picture however few
+            // pictures share the device; its batches are as large as the window allows)
+            const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : (o.format == Format::Webp ? 1024 : 128);   // (round 5: 10 000 files 2.11-2.13 s at 128, 2.23-2.37 s at 256 -- half the pools a cold process has to map before its first kernel)
+            for (auto &g : groups) {
+                std::vector<CByteArray> gin(g.second.size());
+                for (size_t k = 0; k < gin.size(); k++) { gin[k].data = jobs[g.second[k]].data.data(); gin[k].length = jobs[g.second[k]].data.size(); }
+                for (size_t k = 0, n = 0; k < g.second.size(); k += n) {
+                    n = std::max<size_t>(1, cs_batch_extent(gin.data() + k, std::min(kBatch, g.second.size() - k)));
+                    batches.push_back(QueuedBatch{wi, std::vector<size_t>(g.second.begin() + k, g.second.begin() + k + n)});
                 }
-                const auto t_w = now();
-                parallel_for(idx.size(), std::min<size_t>(threads, 8), [&](size_t k) { finish_job(idx[k]); });
-                us_write += (long long)(ms(t_w, now()) * 1000.0);
             }
-        });
+            {
+                std::lock_guard<std::mutex> lk(qmu);
+                pending[wi] = batches.size();
+                for (auto &qb : batches) queue.push_back(std::move(qb));
+            }
+            qcv.notify_all();
+            // two windows in memory: the one just queued and the one before it (still finishing).  The window before must be done before the next is read;
+            // without read-ahead (an output of one file may be another's input) the windows run strictly one after the other
+            if (!read_ahead) wait_window(wi);
+            else if (wi > 0) wait_window(wi - 1);
+        }
+        if (read_ahead && wi + 1 < windows.size()) ahead = std::async(std::launch::async, read_window, windows[wi + 1].first, windows[wi + 1].second);
     }
-
-    const auto t_engine = now();
-
-    for (size_t i = w0; i < w1; i++) std::vector<uint8_t>().swap(jobs[i].data);   // the window's inputs (its outputs went in stage 3)
-    ms_engine += ms(t_read, t_engine); ms_write = double(us_write.load()) / 1000.0;
+    if (!o.dry_run) {
+        for (size_t wi = 0; wi < windows.size(); wi++) wait_window(wi);
+        { std::lock_guard<std::mutex> lk(qmu); closing = true; }
+        qcv.notify_all();
+        for (auto &t : workers) t.join();
     }
+    ms_engine = ms(t_engine0, now()); ms_write = double(us_write.load()) / 1000.0;
     ms_read = double(us_read.load()) / 1000.0;
-    if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms, engine+write %.0f ms (of which policy+write, summed over the batch workers: %.0f ms)\n", files.size(), ms(t_start, t_scan),
+    const auto t_done = now();
+    if (trace) fprintf(stderr, "[cli] %zu files: scan %.0f ms, read+prepare %.0f ms (summed over the windows; all but the first behind the engine), first read + engine + write %.0f ms (of which policy+write, summed over the batch workers: %.0f ms)\n", files.size(), ms(t_start, t_scan),
                        ms_read, ms_engine, ms_write);
     if (o.json) printf("%s\n", build_json(results, o.dry_run, nullptr).c_str());
     else fputs(build_recap(results, verbose, isatty(1)).c_str(), stdout);
+    if (trace) fprintf(stderr, "[cli] run() took %.0f ms (windows planned at %.0f, last window done at %.0f)\n", ms(t_start, now()), ms(t_start, t_plan), ms(t_start, t_done));
     return 0;
 }
 

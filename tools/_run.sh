@@ -1,12 +1,19 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_png_gpu.py -x -q 2>&1 | tail -3
-R=$(pwd); cd /tmp; export TMPDIR=/tmp
-for N in 64 256; do
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_png -- python $R/tools/png_bench.py $N 4 > $R/gpurun_out/r06_png_bench_batch$N.txt 2> $R/gpurun_out/prof_png.err
-f=$(find $R/gpurun_out/prof_png -name "*kernel_stats.csv"); cp $f $R/gpurun_out/r06_png_kernel_stats_batch$N.csv
-rm -rf $R/gpurun_out/prof_png; grep "rep 1" -A1 $R/gpurun_out/r06_png_bench_batch$N.txt
-python3 - $R/gpurun_out/r06_png_kernel_stats_batch$N.csv <<'PY'
-import csv,sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:9]: print("%-40s calls %s avg ms %.1f"%(r['Name'][:40],r['Calls'],float(r['AverageNs'])/1e6))
+for N in 2048 10000; do
+D=/dev/shm/cli_e2e; rm -rf $D; mkdir -p $D/in
+python - <<PY
+import sys; sys.path.insert(0,'tools')
+from gen_synth import synth_jpeg
+u=[synth_jpeg(i) for i in range(16)]
+for k in range($N): open('$D/in/f%05d.jpg'%k,'wb').write(u[k%16])
 PY
+r=""
+for t in 1 2 3; do
+rm -rf $D/out; s=$(date +%s.%N)
+CSH_TRACE=1 caesium-clt_amd/bin/caesiumclt -q 80 -o $D/out --quiet $D/in 2>&1 | grep "^\[cli\]" | cut -c1-200 > /tmp/t.txt
+e=$(date +%s.%N); r="$r $(python -c "print('%.3f' % ($e - $s))")"
 done
+cat /tmp/t.txt; echo "N $N default:$r  written $(ls $D/out | wc -l)"
+rm -rf $D
+done
+timeout 600 python -m pytest tests/test_pipeline_gpu.py -x -q -k "cli or batch_order" 2>&1 | tail -2
