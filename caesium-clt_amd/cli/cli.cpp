@@ -260,6 +260,7 @@ std::optional<fs::path> compute_base_folder(const std::optional<fs::path> &bf, c
     return folder;
 }
 
+namespace { void parallel_for(size_t n, size_t threads, const std::function<void(size_t)> &fn); }
 void scan_files(const std::vector<std::string> &args, bool recursive, bool ext_only, std::optional<fs::path> &base, std::vector<fs::path> &files) {
     base.reset();
     auto valid = [&](const fs::path &p) { return ext_only ? has_supported_extension(p) : is_filetype_supported(p); };
@@ -281,7 +282,10 @@ void scan_files(const std::vector<std::string> &args, bool recursive, bool ext_o
             if (recursive) { for (auto it = fs::recursive_directory_iterator(in, fs::directory_options::skip_permission_denied, ec); it != fs::recursive_directory_iterator(); it.increment(ec)) if (it->is_regular_file(ec) && !it->is_symlink(ec)) found.push_back(it->path()); }
             else { for (auto it = fs::directory_iterator(in, fs::directory_options::skip_permission_denied, ec); it != fs::directory_iterator(); it.increment(ec)) if (it->is_regular_file(ec) && !it->is_symlink(ec)) found.push_back(it->path()); }
             std::sort(found.begin(), found.end());
-            for (const fs::path &p : found) if (valid(p)) add(p);
+            // (the type check opens every file: on a few threads -- 10 000 files took 80 ms one after the other -- the order stays the sorted one)
+            std::vector<char> ok(found.size(), 0);
+            parallel_for(found.size(), std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), [&](size_t k) { ok[k] = valid(found[k]) ? 1 : 0; });
+            for (size_t k = 0; k < found.size(); k++) if (ok[k]) add(found[k]);
         } else if (fs::is_regular_file(in, ec) && valid(in)) add(in);
     }
 }
