@@ -561,30 +561,38 @@ __global__ void __launch_bounds__(256) k_png_filter5(FilterCtx c) {
     }
 }
 
-// one workgroup per batch row; per filter seven barrier-separated steps (byte histogram, entropy, pair counts in two halves
-// of the key space: 32768 32-bit counters fill 128 KiB of LDS).  An exchange-with-zero pass reads every distinct pair
-// once and leaves the table clean for the next use.
-enum { SCORE_STEPS = 7, SCORE_THREADS = 1024 };
+// one workgroup per batch row; per filter three barrier-separated steps: the byte histogram (+ MinSum); the histogram's entropy (256 lanes) together
+// with the pair counts; the pairs read back.  The 65536 pair counters are 16 bits wide (a row has at most 2^16 - 1 pairs: rows longer than that take the
+// two-halves path below), two to a 32-bit LDS word -- 128 KiB, the whole key space in one pass -- and are read back by exchanging the WORD with zero: whoever
+// gets there first accounts for both of its counters and leaves the table clean for the next filter.  Every filter has accumulators of its own, written
+// out in one last step.  (Round 6: 17 steps a row instead of 36 -- the steps are short, eleven bytes per lane for a 4K row, and a step is a barrier.)
+enum { SCORE_THREADS = 1024 };
 struct ScoreLds {
     uint32_t pair[32768];
     uint32_t hist[256];
-    unsigned long long minsum, entropy, distinct, bigent;
+    unsigned long long acc[5][4];   // per filter: minsum, entropy, distinct, bigent
 };
+template <bool WIDE>   // WIDE: some row of the batch has more than 65536 bytes -- counts may pass 16 bits: 32-bit counters, the key space in two halves, six steps per filter
 __global__ void __launch_bounds__(SCORE_THREADS) k_png_scores(FilterCtx c) {
+    constexpr int SCORE_STEPS = WIDE ? 6 : 3;
     CSH_SHARED ScoreLds S;
     const uint32_t row = blockIdx.x;
     const uint32_t image = c.row_image[row];
     const PngImg &im = c.imgs[image];
     const uint32_t y = row - im.row_base, W = im.rowbytes, n = W + 1;   // n bytes: type byte + data
     const bool dead = c.status[image] != 0;
-    CSH_PHASE_LOOP(1 + 5 * SCORE_STEPS) {
+    CSH_PHASE_LOOP(2 + 5 * SCORE_STEPS) {
         if (phase == 0) {
             for (uint32_t i = threadIdx.x; i < 32768; i += blockDim.x) S.pair[i] = 0;
             if (threadIdx.x < 256) S.hist[threadIdx.x] = 0;
-            if (threadIdx.x == 0) { S.minsum = 0; S.entropy = 0; S.distinct = 0; S.bigent = 0; }
+            if (threadIdx.x < 20) S.acc[threadIdx.x >> 2][threadIdx.x & 3] = 0;
             continue;
         }
         if (dead) continue;
+        if (phase == 1 + 5 * SCORE_STEPS) {
+            if (threadIdx.x < 20) c.scores[(uint64_t(row) * 5 + (threadIdx.x >> 2)) * 5 + (threadIdx.x & 3)] = S.acc[threadIdx.x >> 2][threadIdx.x & 3];
+            continue;
+        }
         const int f = (phase - 1) / SCORE_STEPS, step = (phase - 1) % SCORE_STEPS;
         const uint8_t *r = c.streams + im.stream_off + uint64_t(f) * im.stream_stride + uint64_t(y) * n;
         if (step == 0) {
@@ -594,27 +602,37 @@ __global__ void __launch_bounds__(SCORE_THREADS) k_png_scores(FilterCtx c) {
                 atomicAdd(&S.hist[b], 1u);
                 if (i) ms += b < 128 ? b : 256 - b;
             }
-            if (ms) atomicAdd(&S.minsum, ms);
+            if (ms) atomicAdd(&S.acc[f][0], ms);
         } else if (step == 1) {
-            if (threadIdx.x < 256) { const uint32_t h = S.hist[threadIdx.x]; S.hist[threadIdx.x] = 0; if (h) atomicAdd(&S.entropy, (unsigned long long)ilog2i(h)); }
+            if (threadIdx.x < 256) { const uint32_t h = S.hist[threadIdx.x]; S.hist[threadIdx.x] = 0; if (h) atomicAdd(&S.acc[f][1], (unsigned long long)ilog2i(h)); }
+            if (!WIDE)
+                for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) {
+                    const uint32_t k = (uint32_t(r[i]) << 8) | r[i + 1];
+                    atomicAdd(&S.pair[k >> 1], (k & 1u) ? 65536u : 1u);
+                }
+        } else if (!WIDE) {
+            unsigned long long d = 0, e = 0;
+            for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) {
+                const uint32_t k = (uint32_t(r[i]) << 8) | r[i + 1];
+                const uint32_t both = atomicExch(&S.pair[k >> 1], 0u);
+                if (both & 0xFFFFu) { d++; e += ilog2i(both & 0xFFFFu); }
+                if (both >> 16) { d++; e += ilog2i(both >> 16); }
+            }
+            if (d) { atomicAdd(&S.acc[f][2], d); atomicAdd(&S.acc[f][3], e); }
         } else if (step == 2 || step == 4) {
             const uint32_t half = step == 2 ? 0u : 1u;
             for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) {
                 const uint32_t k = (uint32_t(r[i]) << 8) | r[i + 1];
                 if ((k >> 15) == half) atomicAdd(&S.pair[k & 32767u], 1u);
             }
-        } else if (step == 3 || step == 5) {
+        } else {
             const uint32_t half = step == 3 ? 0u : 1u;
             unsigned long long d = 0, e = 0;
             for (uint32_t i = threadIdx.x; i + 1 < n; i += blockDim.x) {
                 const uint32_t k = (uint32_t(r[i]) << 8) | r[i + 1];
                 if ((k >> 15) == half) { const uint32_t cnt = atomicExch(&S.pair[k & 32767u], 0u); if (cnt) { d++; e += ilog2i(cnt); } }
             }
-            if (d) { atomicAdd(&S.distinct, d); atomicAdd(&S.bigent, e); }
-        } else if (threadIdx.x == 0) {
-            uint64_t *sc = c.scores + (uint64_t(row) * 5 + uint32_t(f)) * 5;
-            sc[0] = S.minsum; sc[1] = S.entropy; sc[2] = S.distinct; sc[3] = S.bigent;
-            S.minsum = 0; S.entropy = 0; S.distinct = 0; S.bigent = 0;
+            if (d) { atomicAdd(&S.acc[f][2], d); atomicAdd(&S.acc[f][3], e); }
         }
     }
 }
@@ -688,7 +706,9 @@ __global__ void __launch_bounds__(256) k_png_pick(FilterCtx c) {
 
 void launch_png_filter5(hipStream_t st, const FilterCtx &c) { if (c.total_rows) CSH_LAUNCH(k_png_filter5, dim3(c.total_rows), dim3(256), st, c); }
 void launch_png_scores(hipStream_t st, const FilterCtx &c) {
-    if (c.total_rows) CSH_LAUNCH_PHASED(k_png_scores, 1 + 5 * SCORE_STEPS, dim3(c.total_rows), dim3(SCORE_THREADS), st, c);
+    if (!c.total_rows) return;
+    if (c.max_rowbytes + 1 > 65536u) CSH_LAUNCH_PHASED(k_png_scores<true>, 2 + 5 * 6, dim3(c.total_rows), dim3(SCORE_THREADS), st, c);
+    else CSH_LAUNCH_PHASED(k_png_scores<false>, 2 + 5 * 3, dim3(c.total_rows), dim3(SCORE_THREADS), st, c);
 }
 void launch_png_brute(hipStream_t st, const FilterCtx &c) { if (c.total_rows) CSH_LAUNCH(k_png_brute, dim3(c.total_rows, 5), dim3(CSP_WAVE_THREADS), st, c); }
 void launch_png_pick(hipStream_t st, const FilterCtx &c) { if (c.total_rows && c.plan.nadaptive) CSH_LAUNCH(k_png_pick, dim3(c.total_rows), dim3(256), st, c); }

@@ -69,6 +69,7 @@ struct FilterCtx {
     const PngImg *imgs;
     int nimg;
     uint32_t total_rows;          // rows of the whole batch
+    uint32_t max_rowbytes;        // the longest row of the batch (k_png_scores: 16-bit pair counters while a row has fewer than 65536 pairs)
     const uint32_t *row_image;    // [total_rows] image of a batch row
     const uint8_t *pix;
     uint8_t *streams;

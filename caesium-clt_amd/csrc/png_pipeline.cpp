@@ -730,6 +730,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     FilterCtx f{};
     f.imgs = b->d_imgs.p; f.nimg = nimg; f.total_rows = b->total_rows; f.row_image = b->d_row_image.p; f.pix = b->d_work.p; f.streams = b->d_streams.p;
     f.scores = b->d_scores.p; f.choice = b->d_choice.p; f.plan = b->plan; f.status = b->d_status.p;
+    for (const PngImg &im : b->imgs) f.max_rowbytes = std::max(f.max_rowbytes, im.rowbytes);
     DeflateCtx d{};
     d.imgs = b->d_imgs.p; d.nimg = nimg; d.total_chunks = b->total_chunks; d.chunk_image = b->d_chunk_image.p; d.chunk_first = b->d_chunk_first.p;
     d.total_groups = b->total_groups; d.group_image = b->d_group_image.p; d.group_first = b->d_group_first.p;

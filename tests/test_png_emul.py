@@ -187,6 +187,12 @@ def test_emul_min_cost_path_parse(api):
     check_batch(api, deep_parse_cases()[:2], 1, stages=False)
 
 
+def test_emul_rows_longer_than_65536_bytes(api):
+    """a row of more than 65536 bytes: the pair counters of the Bigrams / BigEnt scores no longer fit 16 bits (k_png_scores<true>: the key space in two halves)"""
+    from gen_synth import synth_png
+    check_batch(api, [("wide_rgb_22000x2", synth_png(61, 22000, 2, "RGB", texture=1.0)), ("narrow_next_to_it", synth_png(62, 40, 3, "RGB"))], 3)
+
+
 def test_emul_zopfli_means_more_passes(api):
     """png.force_zopfli (--zopfli): the same coder with CSP_DEEP_ITERS_ZOPFLI passes of the cost model; == the oracle's statement of it, never larger than
     a plain run by more than a block header's noise, and the pixels are the input's"""

@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout 900 python bench.py > gpurun_out/r06_bench_default_v2.json 2> gpurun_out/r06_bench_default_v2.err; echo "bench rc $?"
-tail -c 1500 gpurun_out/r06_bench_default_v2.json
+timeout 1500 python -m pytest tests/test_png_gpu.py -x -q 2>&1 | tail -3
+for N in 64 256; do python tools/png_bench.py $N 4 2>&1 | grep -A1 "rep 1"; done
