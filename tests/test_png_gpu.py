@@ -33,6 +33,20 @@ def test_other_levels(api, level):
     check_batch(api, cases, level)
 
 
+def test_min_cost_path_parse_zopfli_and_wide_rows(api):
+    """round 6's paths on the device: chunks that take the min-cost-path parse (four-wave workgroups, 256-position tiles, the work queue), png.force_zopfli
+    (fifteen passes), a row of more than 65536 bytes (k_png_scores<true>), a larger smooth picture (several chunks per trial, live and dead trials)"""
+    from test_png_emul import deep_parse_cases
+    check_batch(api, deep_parse_cases() + [("smooth_rgb_640x360", synth_png(41, 640, 360, "RGB", texture=0.5))], 3)
+    check_batch(api, [("wide_rgb_22000x2", synth_png(61, 22000, 2, "RGB", texture=1.0)), ("narrow_next_to_it", synth_png(62, 40, 3, "RGB"))], 3)
+    pkg = package()
+    for name, png in deep_parse_cases()[:3]:
+        z = api.compress_in_memory(png, pkg.default_parameters(png_optimize=True, png_force_zopfli=True))
+        assert z == O.png_optimize(png, 3, zopfli=True)[0], name
+    # the same batch again: the queue counters and the scratch areas are the previous run's
+    check_batch(api, deep_parse_cases(), 3, stages=False)
+
+
 def test_keep_metadata(api):
     cases = [c for c in png_cases() if c[0] == "RGB_with_text_and_phys"]
     check_batch(api, cases, 3, keep_metadata=True, stages=False)
