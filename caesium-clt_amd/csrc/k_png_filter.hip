@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const P
     const uint32_t y = blockIdx.x;
     CSH_PHASE_LOOP(2) {
         if (phase == 0) { if (j.nearest && threadIdx.x < j.npal) pal[threadIdx.x] = palettes[j.pal_off + threadIdx.x]; continue; }
-        if (y >= im.height) continue;
+        if (y >= im.height || j.nearest == 2u) continue;   // (2: the quantiser's jobs go to k_png_dither)
         const unsigned long long *tab = keys + uint64_t(j.table) * CSP_PAL_SLOTS;
         const uint16_t *idx = slot_index + uint64_t(j.table) * CSP_PAL_SLOTS;
         const uint8_t *s = src + j.src_off + uint64_t(y) * j.old_rowbytes;
@@ -181,6 +181,74 @@ __global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const P
             }
             d[bx] = uint8_t(v);
         }
+    }
+}
+// ---- the lossy row's pixels to palette entries with Floyd-Steinberg error diffusion (oracle: quantize).  One workgroup per picture, a lane per ROW: row r is
+// two pixels behind row r - 1 (the error it needs from above -- 3 / 5 / 1 sixteenths of the upper row's pixels x + 1, x, x - 1 -- was made one, two and three
+// steps ago and sits in a four-deep ring in LDS), so DITHER_ROWS rows advance together, a barrier a step.  A picture taller than that goes in bands: the last row
+// of a band leaves what it hands down in a line buffer in HBM (two of them, taken in turns).  The nearest entry is a search over the whole palette (256 x 4
+// channels) per pixel: ~2.5 k instructions a step, which is what a step costs; a 1080p picture takes (1080 / 256 + 1) x (1920 + 512) steps.
+enum { DITHER_ROWS = 256 };
+struct DitherLds { uint32_t pal[256]; int16_t ring[DITHER_ROWS][4][4]; };   // ring[row][step & 3][r g b a]
+__global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, const PaletteJob *jobs, const uint32_t *palettes, const uint8_t *src, uint8_t *dst, int16_t *lines, int nsteps) {
+    CSH_SHARED DitherLds S;
+    CSH_PERSIST(int, left, 4);      // what this row's last pixel left for the next one
+    CSH_PERSIST(int, prev, 8);      // the errors of this row's last two pixels (the band's last row: what goes into the line buffer)
+    CSH_PERSIST(uint32_t, acc, 1);  // the byte of indices being filled
+    const PaletteJob j = jobs[blockIdx.x];
+    const PngImg &im = imgs[j.image];   // already the new geometry
+    const uint32_t W = im.width, H = im.height, r = threadIdx.x;
+    const uint32_t per_band = W + 2u * DITHER_ROWS;
+    int16_t *line0 = lines + uint64_t(j.line_off) * 4u, *line1 = line0 + uint64_t(W) * 4u;
+    CSH_PHASE_LOOP(nsteps + 1) {
+        if (phase == 0) { S.pal[r] = r < j.npal ? palettes[j.pal_off + r] : 0u; CSH_UNROLL for (int k = 0; k < 4; k++) CSH_UNROLL for (int c = 0; c < 4; c++) S.ring[r][k][c] = 0; continue; }
+        if (j.nearest != 2u) continue;
+        const uint32_t t_all = uint32_t(phase - 1), band = t_all / per_band, t = t_all % per_band;
+        const uint32_t y = band * DITHER_ROWS + r;
+        const int x = int(t) - 2 * int(r);
+        int e[4] = {0, 0, 0, 0};
+        if (y < H && x >= 0 && x < int(W)) {
+            if (x == 0) { CSH_UNROLL for (int c = 0; c < 4; c++) { left[c] = 0; prev[c] = 0; prev[4 + c] = 0; } acc[0] = 0; }
+            int below[4];
+            if (r == 0) {   // from the band above, through the line buffer it wrote (nothing above the first band)
+                const int16_t *in = (band & 1u) ? line1 : line0;
+                CSH_UNROLL
+                for (int c = 0; c < 4; c++) below[c] = band ? int(coherent_load(&in[uint64_t(x) * 4u + c])) : 0;
+            } else {
+                const int16_t (*up)[4] = S.ring[r - 1];
+                CSH_UNROLL
+                for (int c = 0; c < 4; c++) below[c] = 3 * up[(t + 3u) & 3u][c] + 5 * up[(t + 2u) & 3u][c] + up[(t + 1u) & 3u][c];   // steps t - 1, t - 2, t - 3
+            }
+            const uint32_t key = pixel_key(src + j.src_off + uint64_t(y) * j.old_rowbytes + uint64_t(x) * j.old_channels * j.old_bps, j.old_channels, j.old_bps);
+            const int px[4] = {int((key >> 16) & 255u), int((key >> 8) & 255u), int(key & 255u), int(key >> 24)};   // r g b a
+            int want[4];
+            CSH_UNROLL
+            for (int c = 0; c < 4; c++) { const int v = px[c] + ((7 * left[c] + below[c] + 8) >> 4); want[c] = v < 0 ? 0 : v > 255 ? 255 : v; }
+            uint32_t bd = ~0u, index = 0;
+            for (uint32_t q = 0; q < j.npal; q++) {   // squared distance over a, r, g, b; ties: the lower index
+                const uint32_t pq = S.pal[q];
+                const int dr = want[0] - int((pq >> 16) & 255u), dg = want[1] - int((pq >> 8) & 255u), db = want[2] - int(pq & 255u), da = want[3] - int(pq >> 24);
+                const uint32_t dist = uint32_t(dr * dr + dg * dg + db * db + da * da);
+                if (dist < bd) { bd = dist; index = q; }
+            }
+            const uint32_t pq = S.pal[index];
+            e[0] = want[0] - int((pq >> 16) & 255u); e[1] = want[1] - int((pq >> 8) & 255u); e[2] = want[2] - int(pq & 255u); e[3] = want[3] - int(pq >> 24);
+            // the band's last row (when rows follow below it): what pixel x - 1 of the row below gets is complete now
+            if (r == DITHER_ROWS - 1 && y + 1 < H) {
+                int16_t *out = (band & 1u) ? line0 : line1;
+                if (x >= 1) { CSH_UNROLL for (int c = 0; c < 4; c++) out[uint64_t(x - 1) * 4u + c] = int16_t(prev[4 + c] + 5 * prev[c] + 3 * e[c]); }
+                if (x == int(W) - 1) { CSH_UNROLL for (int c = 0; c < 4; c++) out[uint64_t(x) * 4u + c] = int16_t(prev[c] + 5 * e[c]); }
+            }
+            CSH_UNROLL
+            for (int c = 0; c < 4; c++) { prev[4 + c] = prev[c]; prev[c] = e[c]; left[c] = e[c]; }
+            // the index into its byte
+            const uint32_t d = j.depth, bit = uint32_t(x) * d;
+            acc[0] |= index << (8u - d - (bit & 7u));
+            if (((bit + d) & 7u) == 0 || x == int(W) - 1) { dst[j.dst_off + uint64_t(y) * im.rowbytes + (bit >> 3)] = uint8_t(acc[0]); acc[0] = 0; }
+        }
+        CSH_UNROLL
+        for (int c = 0; c < 4; c++) S.ring[r][t & 3u][c] = int16_t(e[c]);
+        if (t + 1 == per_band) CSP_MEM_FENCE();   // the band's line buffer is complete before the next band's first row reads it (the barrier follows)
     }
 }
 // ---- one lane per pixel: any PNG format to interleaved 8-bit samples (RgbJob).  16-bit samples round as image-rs converts them
@@ -529,6 +597,10 @@ void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, 
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
                         const uint32_t *palettes, const uint8_t *src, uint8_t *dst) {
     if (njobs) CSH_LAUNCH_PHASED(k_png_indexed, 2, dim3(max_height, njobs), dim3(256), st, imgs, jobs, keys, slot_index, palettes, src, dst);
+}
+// nsteps: the largest (bands x steps per band) of the jobs that dither; lines: two rows of width x 4 int16 per such job (PaletteJob::line_off, in pixels)
+void launch_png_dither(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, int nsteps, const uint32_t *palettes, const uint8_t *src, uint8_t *dst, int16_t *lines) {
+    if (njobs && nsteps) CSH_LAUNCH_PHASED(k_png_dither, nsteps + 1, dim3(unsigned(njobs)), dim3(DITHER_ROWS), st, imgs, jobs, palettes, src, dst, lines, nsteps);
 }
 void launch_png_rgb(hipStream_t st, const RgbJob *jobs, int njobs, uint32_t max_height, const uint8_t *plte, const uint8_t *work, uint8_t *rgb, const uint32_t *status) {
     if (njobs) CSH_LAUNCH(k_png_rgb, dim3(max_height, njobs), dim3(256), st, jobs, plte, work, rgb, status);

@@ -28,13 +28,16 @@ void launch_png_used(hipStream_t st, const PngImg *imgs, uint32_t total_rows, co
 enum { CSP_PAL_SLOTS = 1024 };
 struct PaletteJob {
     uint32_t image, old_rowbytes, old_channels, old_bps, depth, table;   // table: the image's slot in the hash tables (exact) ...
-    uint32_t nearest, npal, pal_off;                                      // ... or, lossy: nearest entry of palette[pal_off, pal_off + npal)
+    uint32_t nearest, npal, pal_off;                                      // ... or, lossy (nearest 2): palette[pal_off, pal_off + npal), Floyd-Steinberg error diffusion (k_png_dither)
+    uint32_t line_off, pad_;                                              // k_png_dither: the job's two hand-down lines start at this pixel of the line buffer
     uint64_t src_off, dst_off;
 };
 void launch_png_colors(hipStream_t st, const PngImg *imgs, uint32_t total_rows, const uint32_t *row_image, const uint8_t *pix, const uint32_t *cand, unsigned long long *keys,
                        uint32_t *counts, const uint32_t *status);
 void launch_png_indexed(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, uint32_t max_height, const unsigned long long *keys, const uint16_t *slot_index,
                         const uint32_t *palettes, const uint8_t *src, uint8_t *dst);
+enum { CSP_DITHER_ROWS = 256 };   // rows of a picture that advance together in k_png_dither
+void launch_png_dither(hipStream_t st, const PngImg *imgs, const PaletteJob *jobs, int njobs, int nsteps, const uint32_t *palettes, const uint8_t *src, uint8_t *dst, int16_t *lines);
 
 // resize of a PNG source (k_png_resize.hip): interleaved samples of bps bytes (1, or 2 big-endian), nc per pixel; src / dst are byte
 // offsets, tmp a float offset

@@ -519,6 +519,7 @@ static int reduce_step(csp_batch *b) {
     std::vector<ReduceJob> jobs;
     std::vector<uint8_t> remaps;   // 256 bytes per indexed job: old palette index -> new
     std::vector<PaletteJob> pjobs;
+    uint64_t dither_pixels = 0, dither_steps = 0;   // k_png_dither: line-buffer pixels of the quantised images, the longest image's steps
     std::vector<uint32_t> palettes;
     std::vector<uint16_t> slot_index(size_t(nimg) * CSP_PAL_SLOTS, 0);
     uint32_t max_height = 0;
@@ -589,7 +590,12 @@ static int reduce_step(csp_batch *b) {
             PaletteJob j{};
             j.image = uint32_t(i); j.old_rowbytes = im.rowbytes; j.old_channels = im.channels; j.old_bps = im.bps; j.depth = depth; j.table = uint32_t(i);
             j.src_off = im.pix_off; j.dst_off = im.raw_off;
-            j.nearest = nearest ? 1u : 0u; j.npal = uint32_t(pal.size()); j.pal_off = uint32_t(palettes.size());
+            j.nearest = nearest ? 2u : 0u; j.npal = uint32_t(pal.size()); j.pal_off = uint32_t(palettes.size());   // (2: with error diffusion, k_png_dither)
+            if (nearest) {
+                j.line_off = uint32_t(dither_pixels); dither_pixels += 2 * uint64_t(im.width);
+                const uint64_t steps = uint64_t((im.height + CSP_DITHER_ROWS - 1) / CSP_DITHER_ROWS) * (uint64_t(im.width) + 2 * CSP_DITHER_ROWS);
+                dither_steps = std::max(dither_steps, steps);
+            }
             if (nearest) palettes.insert(palettes.end(), pal.begin(), pal.end());
             for (uint32_t sl = 0; sl < CSP_PAL_SLOTS && !nearest; sl++)
                 if (tab[sl] != ~0ull) slot_index[size_t(i) * CSP_PAL_SLOTS + sl] = uint16_t(std::lower_bound(pal.begin(), pal.end(), uint32_t(tab[sl])) - pal.begin());
@@ -687,6 +693,11 @@ static int reduce_step(csp_batch *b) {
     if (d_remaps.upload(remaps, st)) return -1;
     launch_png_repack(st, b->d_imgs.p, b->d_jobs.p, int(jobs.size()) - 1, max_height, b->d_work.p, b->d_work.p, d_remaps.p);
     launch_png_indexed(st, b->d_imgs.p, b->d_pjobs.p, int(pjobs.size()) - 1, max_height, b->d_keys.p, b->d_slot_index.p, b->d_qpal.p, b->d_work.p, b->d_work.p);
+    DevBuf<int16_t> d_lines;   // the error rows the bands of k_png_dither hand down (freed behind the synchronisation below)
+    if (dither_steps) {
+        if (dither_steps > 0x3FFFFFFFull || d_lines.alloc(size_t(dither_pixels) * 4 + 4)) { csh_set_error("PNG dither buffers failed"); return -1; }
+        launch_png_dither(st, b->d_imgs.p, b->d_pjobs.p, int(pjobs.size()) - 1, int(dither_steps), b->d_qpal.p, b->d_work.p, b->d_work.p, d_lines.p);
+    }
     return upload_chunk_index(b);   // synchronises: the job vectors may go out of scope
 }
 

@@ -651,19 +651,37 @@ static int quantize(cso_png *P, int quality) {
     const int d = n <= 2 ? 1 : n <= 4 ? 2 : n <= 16 ? 4 : 8;
     const size_t nrb = ((size_t)P->width * d + 7) / 8;
     uint8_t *np = (uint8_t *)calloc(nrb, P->height);
-    for (uint32_t y = 0; y < P->height; y++)
+    /* every pixel its palette entry, with Floyd-Steinberg error diffusion (libcaesium runs imagequant at dithering level 1.0; this is the plain
+       integer form, every row left to right -- so that on the GPU a row can follow the one above it two pixels behind --, not imagequant's): the pixel plus
+       the error that reached it (sixteenths: 7 from the left, 3 / 5 / 1 from the row above's x+1 / x / x-1), clamped to 0..255 per channel, goes to
+       its nearest entry (squared distance over a, r, g, b; ties: the lower index); what is left goes on */
+    int (*below)[4] = (int (*)[4])calloc((size_t)P->width + 2, sizeof(int[4])), (*next)[4] = (int (*)[4])calloc((size_t)P->width + 2, sizeof(int[4]));   /* index x + 1 */
+    for (uint32_t y = 0; y < P->height; y++) {
+        int left[4] = {0, 0, 0, 0};
+        memset(next, 0, ((size_t)P->width + 2) * sizeof(int[4]));
         for (uint32_t x = 0; x < P->width; x++) {
             const uint8_t *px = P->pix + (size_t)y * P->rowbytes + (size_t)x * ch * bps;
-            const int r = px[0], g = px[bps], b = px[2 * bps], a = ch == 4 ? px[3 * bps] : 255;
+            const int src[4] = {px[0], px[bps], px[2 * bps], ch == 4 ? px[3 * bps] : 255};   /* r g b a */
+            int want[4];
+            for (int c = 0; c < 4; c++) { int v = src[c] + ((7 * left[c] + below[x + 1][c] + 8) >> 4); want[c] = v < 0 ? 0 : v > 255 ? 255 : v; }
             int best = 0; uint32_t bd = ~0u;
             for (int k = 0; k < n; k++) {
-                const int dr = r - (int)((pal[k] >> 16) & 255), dg = g - (int)((pal[k] >> 8) & 255), db = b - (int)(pal[k] & 255), da = a - (int)(pal[k] >> 24);
+                const int dr = want[0] - (int)((pal[k] >> 16) & 255), dg = want[1] - (int)((pal[k] >> 8) & 255), db = want[2] - (int)(pal[k] & 255), da = want[3] - (int)(pal[k] >> 24);
                 const uint32_t dist = (uint32_t)(dr * dr + dg * dg + db * db + da * da);
                 if (dist < bd) { bd = dist; best = k; }
+            }
+            const int got[4] = {(int)((pal[best] >> 16) & 255), (int)((pal[best] >> 8) & 255), (int)(pal[best] & 255), (int)(pal[best] >> 24)};
+            for (int c = 0; c < 4; c++) {
+                const int e = want[c] - got[c];
+                left[c] = e;
+                next[x][c] += 3 * e; next[x + 1][c] += 5 * e; next[x + 2][c] += e;   /* (x - 1, x, x + 1 of the row below) */
             }
             const size_t bit = (size_t)x * d;
             np[(size_t)y * nrb + bit / 8] |= (uint8_t)(best << (8 - d - (bit & 7)));
         }
+        int (*t)[4] = below; below = next; next = t;
+    }
+    free(below); free(next);
     free(P->pix);
     P->pix = np; P->rowbytes = nrb; P->channels = 1; P->depth = d; P->bpp = 1; P->ctype = 3; P->nplte = n;
     const size_t extra = 12 + 3 * (size_t)n + (ntr ? 12 + (size_t)ntr : 0);
