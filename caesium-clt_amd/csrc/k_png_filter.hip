@@ -189,7 +189,19 @@ __global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const P
 // of a band leaves what it hands down in a line buffer in HBM (two of them, taken in turns).  The nearest entry is a search over the whole palette (256 x 4
 // channels) per pixel: ~2.5 k instructions a step, which is what a step costs; a 1080p picture takes (1080 / 256 + 1) x (1920 + 512) steps.
 enum { DITHER_ROWS = 256 };
-struct DitherLds { uint32_t pal[256]; int16_t ring[DITHER_ROWS][4][4]; };   // ring[row][step & 3][r g b a]
+struct DitherLds { uint32_t pal[256]; uint32_t pal_rg[256], pal_ba[256]; int16_t ring[DITHER_ROWS][4][4]; };   // pal_rg / pal_ba: the entries as halves (r, g) and (b, a); ring[row][step & 3][r g b a]
+// two 16-bit halves subtracted / multiplied and summed in one instruction each (v_pk_sub_i16, v_dot2_i32_i16): a palette entry's squared distance is four
+// instructions, and four entries at a time keep four chains going -- the search is what a step of k_png_dither costs
+#ifdef CSH_EMUL
+__device__ __forceinline__ static uint32_t dpk_sub(uint32_t a, uint32_t b) { return ((a - b) & 0xFFFFu) | ((a & 0xFFFF0000u) - (b & 0xFFFF0000u)); }
+__device__ __forceinline__ static int ddot2(uint32_t a, uint32_t k, int acc) {
+    return int(uint32_t(acc) + uint32_t(int(int16_t(a)) * int(int16_t(k))) + uint32_t(int(int16_t(a >> 16)) * int(int16_t(k >> 16))));
+}
+#else
+typedef short dpk16_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ static uint32_t dpk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(dpk16_t, a) - __builtin_bit_cast(dpk16_t, b)); }
+__device__ __forceinline__ static int ddot2(uint32_t a, uint32_t k, int acc) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(dpk16_t, a), __builtin_bit_cast(dpk16_t, k), acc, false); }
+#endif
 __global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, const PaletteJob *jobs, const uint32_t *palettes, const uint8_t *src, uint8_t *dst, int16_t *lines, int nsteps) {
     CSH_SHARED DitherLds S;
     CSH_PERSIST(int, left, 4);      // what this row's last pixel left for the next one
@@ -201,7 +213,15 @@ __global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, 
     const uint32_t per_band = W + 2u * DITHER_ROWS;
     int16_t *line0 = lines + uint64_t(j.line_off) * 4u, *line1 = line0 + uint64_t(W) * 4u;
     CSH_PHASE_LOOP(nsteps + 1) {
-        if (phase == 0) { S.pal[r] = r < j.npal ? palettes[j.pal_off + r] : 0u; CSH_UNROLL for (int k = 0; k < 4; k++) CSH_UNROLL for (int c = 0; c < 4; c++) S.ring[r][k][c] = 0; continue; }
+        if (phase == 0) {
+            const uint32_t pq = r < j.npal ? palettes[j.pal_off + r] : 0u;
+            S.pal[r] = pq;
+            // (an entry past the palette: 0x4000 in every half -- farther than any colour, its squares still inside 32 bits)
+            S.pal_rg[r] = r < j.npal ? ((pq >> 16) & 255u) | (((pq >> 8) & 255u) << 16) : 0x40004000u;
+            S.pal_ba[r] = r < j.npal ? (pq & 255u) | ((pq >> 24) << 16) : 0x40004000u;
+            CSH_UNROLL for (int k = 0; k < 4; k++) CSH_UNROLL for (int c = 0; c < 4; c++) S.ring[r][k][c] = 0;
+            continue;
+        }
         if (j.nearest != 2u) continue;
         const uint32_t t_all = uint32_t(phase - 1), band = t_all / per_band, t = t_all % per_band;
         const uint32_t y = band * DITHER_ROWS + r;
@@ -224,13 +244,20 @@ __global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, 
             int want[4];
             CSH_UNROLL
             for (int c = 0; c < 4; c++) { const int v = px[c] + ((7 * left[c] + below[c] + 8) >> 4); want[c] = v < 0 ? 0 : v > 255 ? 255 : v; }
-            uint32_t bd = ~0u, index = 0;
-            for (uint32_t q = 0; q < j.npal; q++) {   // squared distance over a, r, g, b; ties: the lower index
-                const uint32_t pq = S.pal[q];
-                const int dr = want[0] - int((pq >> 16) & 255u), dg = want[1] - int((pq >> 8) & 255u), db = want[2] - int(pq & 255u), da = want[3] - int(pq >> 24);
-                const uint32_t dist = uint32_t(dr * dr + dg * dg + db * db + da * da);
-                if (dist < bd) { bd = dist; index = q; }
+            // squared distance over a, r, g, b; ties: the lower index.  Four entries a round, each with its own running minimum (entry q in chain q & 3)
+            const uint32_t wrg = uint32_t(want[0]) | (uint32_t(want[1]) << 16), wba = uint32_t(want[2]) | (uint32_t(want[3]) << 16);
+            uint32_t bdk[4] = {~0u, ~0u, ~0u, ~0u}, ixk[4] = {0, 1, 2, 3};
+            for (uint32_t q0 = 0; q0 < j.npal; q0 += 4) {
+                CSH_UNROLL
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t drg = dpk_sub(wrg, S.pal_rg[q0 + k]), dba = dpk_sub(wba, S.pal_ba[q0 + k]);
+                    const uint32_t dist = uint32_t(ddot2(drg, drg, ddot2(dba, dba, 0)));
+                    if (dist < bdk[k]) { bdk[k] = dist; ixk[k] = q0 + uint32_t(k); }
+                }
             }
+            uint32_t bd = bdk[0], index = ixk[0];
+            CSH_UNROLL
+            for (int k = 1; k < 4; k++) if (bdk[k] < bd || (bdk[k] == bd && ixk[k] < index)) { bd = bdk[k]; index = ixk[k]; }
             const uint32_t pq = S.pal[index];
             e[0] = want[0] - int((pq >> 16) & 255u); e[1] = want[1] - int((pq >> 8) & 255u); e[2] = want[2] - int(pq & 255u); e[3] = want[3] - int(pq >> 24);
             // the band's last row (when rows follow below it): what pixel x - 1 of the row below gets is complete now

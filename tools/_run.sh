@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_png_gpu.py -x -q 2>&1 | tail -3
-for N in 64 256; do python tools/png_bench.py $N 4 2>&1 | grep -A1 "rep 1"; done
+timeout 1500 python -m pytest tests/test_zz_png_lossy_gpu.py -x -q 2>&1 | tail -3
+python tools/png_bench.py 96 4 1920 1080 3 80 2>&1 | tail -3
