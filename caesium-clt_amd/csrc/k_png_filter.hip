@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, 
     CSH_PERSIST(int, left, 4);      // what this row's last pixel left for the next one
     CSH_PERSIST(int, prev, 8);      // the errors of this row's last two pixels (the band's last row: what goes into the line buffer)
     CSH_PERSIST(uint32_t, acc, 1);  // the byte of indices being filled
+    CSH_PERSIST(uint32_t, nextkey, 1);   // the row's next pixel, asked for a step ahead (the lanes of a wave read 64 different rows: the load is a step's longest wait)
     const PaletteJob j = jobs[blockIdx.x];
     const PngImg &im = imgs[j.image];   // already the new geometry
     const uint32_t W = im.width, H = im.height, r = threadIdx.x;
@@ -239,7 +240,9 @@ __global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, 
                 CSH_UNROLL
                 for (int c = 0; c < 4; c++) below[c] = 3 * up[(t + 3u) & 3u][c] + 5 * up[(t + 2u) & 3u][c] + up[(t + 1u) & 3u][c];   // steps t - 1, t - 2, t - 3
             }
-            const uint32_t key = pixel_key(src + j.src_off + uint64_t(y) * j.old_rowbytes + uint64_t(x) * j.old_channels * j.old_bps, j.old_channels, j.old_bps);
+            const uint8_t *rowp = src + j.src_off + uint64_t(y) * j.old_rowbytes;
+            const uint32_t key = x == 0 ? pixel_key(rowp, j.old_channels, j.old_bps) : nextkey[0];
+            if (x + 1 < int(W)) nextkey[0] = pixel_key(rowp + uint64_t(x + 1) * j.old_channels * j.old_bps, j.old_channels, j.old_bps);
             const int px[4] = {int((key >> 16) & 255u), int((key >> 8) & 255u), int(key & 255u), int(key >> 24)};   // r g b a
             int want[4];
             CSH_UNROLL
