@@ -185,10 +185,10 @@ __global__ void __launch_bounds__(256) k_png_indexed(const PngImg *imgs, const P
 }
 // ---- the lossy row's pixels to palette entries with Floyd-Steinberg error diffusion (oracle: quantize).  One workgroup per picture, a lane per ROW: row r is
 // two pixels behind row r - 1 (the error it needs from above -- 3 / 5 / 1 sixteenths of the upper row's pixels x + 1, x, x - 1 -- was made one, two and three
-// steps ago and sits in a four-deep ring in LDS), so DITHER_ROWS rows advance together, a barrier a step.  A picture taller than that goes in bands: the last row
+// steps ago and sits in a four-deep ring in LDS), so DITHER_ROWS (512) rows advance together, a barrier a step.  A picture taller than that goes in bands: the last row
 // of a band leaves what it hands down in a line buffer in HBM (two of them, taken in turns).  The nearest entry is a search over the whole palette (256 x 4
-// channels) per pixel: ~2.5 k instructions a step, which is what a step costs; a 1080p picture takes (1080 / 256 + 1) x (1920 + 512) steps.
-enum { DITHER_ROWS = 256 };
+// channels) per pixel: ~2.5 k instructions a step, which is what a step costs; a 1080p picture takes three bands of 1920 + 1024 steps.
+enum { DITHER_ROWS = CSP_DITHER_ROWS };
 struct DitherLds { uint32_t pal[256]; uint32_t pal_rg[256], pal_ba[256]; int16_t ring[DITHER_ROWS][4][4]; };   // pal_rg / pal_ba: the entries as halves (r, g) and (b, a); ring[row][step & 3][r g b a]
 // two 16-bit halves subtracted / multiplied and summed in one instruction each (v_pk_sub_i16, v_dot2_i32_i16): a palette entry's squared distance is four
 // instructions, and four entries at a time keep four chains going -- the search is what a step of k_png_dither costs
@@ -215,11 +215,13 @@ __global__ void __launch_bounds__(DITHER_ROWS) k_png_dither(const PngImg *imgs, 
     int16_t *line0 = lines + uint64_t(j.line_off) * 4u, *line1 = line0 + uint64_t(W) * 4u;
     CSH_PHASE_LOOP(nsteps + 1) {
         if (phase == 0) {
-            const uint32_t pq = r < j.npal ? palettes[j.pal_off + r] : 0u;
-            S.pal[r] = pq;
-            // (an entry past the palette: 0x4000 in every half -- farther than any colour, its squares still inside 32 bits)
-            S.pal_rg[r] = r < j.npal ? ((pq >> 16) & 255u) | (((pq >> 8) & 255u) << 16) : 0x40004000u;
-            S.pal_ba[r] = r < j.npal ? (pq & 255u) | ((pq >> 24) << 16) : 0x40004000u;
+            if (r < 256u) {
+                const uint32_t pq = r < j.npal ? palettes[j.pal_off + r] : 0u;
+                S.pal[r] = pq;
+                // (an entry past the palette: 0x4000 in every half -- farther than any colour, its squares still inside 32 bits)
+                S.pal_rg[r] = r < j.npal ? ((pq >> 16) & 255u) | (((pq >> 8) & 255u) << 16) : 0x40004000u;
+                S.pal_ba[r] = r < j.npal ? (pq & 255u) | ((pq >> 24) << 16) : 0x40004000u;
+            }
             CSH_UNROLL for (int k = 0; k < 4; k++) CSH_UNROLL for (int c = 0; c < 4; c++) S.ring[r][k][c] = 0;
             continue;
         }
