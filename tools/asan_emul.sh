@@ -3,7 +3,7 @@
 # __mul24 shim shifts negative ints), driven through the C ABI by the same cases the parity tests use.  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_asan; mkdir -p $O
-HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_decode_refine.hip k_aclist.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip"
+HIP="k_decode.hip k_decode_par.hip k_decode_prog.hip k_decode_refine.hip k_aclist.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_png_parse.hip k_webp.hip k_vp8enc.hip k_webp_dec.hip k_vp8l_enc.hip"
 CPP="pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp vp8l_encode.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=address,undefined -fno-sanitize=shift -fno-omit-frame-pointer -Wno-unknown-pragmas -Wno-attributes \
     $(for f in $HIP $CPP; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
@@ -19,8 +19,10 @@ T.check_batch(api, _util.png_cases(), 3)
 T.check_batch(api, [c for c in _util.png_cases() if c[0] in ("RGB_97x61", "palette_rgba_translucent", "adam7_1_37x11", "reduce_i16_narrow")], 6)
 assert T.agree_with_oracle(api, T.damaged_pngs(1, 80)) == 0
 T.test_indexed_images_lose_unused_depth(api)
+T.test_emul_min_cost_path_parse(api); T.test_emul_zopfli_means_more_passes(api); T.test_emul_rows_longer_than_65536_bytes(api)   # round 6: the parse's workgroup form, scratch areas, k_png_scores<true>
 import test_png_lossy_emul as PLY
 PLY.test_median_falls_among_equal_keys(api)
+PLY.check_lossy(api, [c for c in PLY.lossy_cases() if c[0] in ('RGB_97x61', 'RGBA_soft_alpha', 'RGB_tall_24x600', 'RGB_513_rows')])   # round 6: k_png_dither's bands and line buffers
 W.check(api, W.webp_cases(), 85); W.check(api, W.webp_cases()[:2], 60, width=50)
 srcs = [synth_jpeg(1, 160, 96, texture=10), synth_jpeg(2, 97, 61, subsampling=0, texture=5), synth_jpeg(5, 104, 72, progressive=True, texture=6), synth_jpeg(6, 120, 88, restart_rows=1, texture=9)]
 for s, o in zip(srcs, api.batch_compress(srcs, pkg.default_parameters(jpeg_quality=80))): assert o == _util.oracle_lossy(s)
@@ -32,7 +34,7 @@ class MP:
     def delenv(self, k, raising=True): import os; os.environ.pop(k, None)
 PE.test_emul_refinement_scans_parse_and_apply(api, MP())
 PE.test_emul_irregular_progressions_decode_in_file_order(api)
-W.test_token_partitions_as_decision_streams_and_as_chains(api, MP())
+W.test_boolean_coder_in_pieces(api, MP()); W.test_statistics_books_overflow_in_order(api)
 import test_png_webp_emul as PW, test_jpeg_png_emul as JP
 PW.check(api, _util.png_cases(), 85); PW.check(api, PW.extra_cases(), 60); PW.test_damaged_pngs_convert_like_the_oracle_or_fail(api)
 JP.check(api, W.webp_cases(), True); JP.check(api, W.webp_cases()[:3], False, width=50); JP.test_mixed_batch_and_failures(api); JP.test_damaged_jpegs_convert_like_the_oracle_or_fail(api)
