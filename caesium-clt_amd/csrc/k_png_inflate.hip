@@ -642,7 +642,23 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
         LFOR(l) { const uint32_t y = y0 + uint32_t(l); ft[l] = y < ye ? src[uint64_t(y) * (W + 1)] : 0u; a[l] = 0; c[l] = 0; mine[l] = 0; }
         if (lballot([&](int l) { return ft[l] > 4u; })) { bad = true; break; }
         if (y0 > ys) CSP_MEM_FENCE();   // the band above was written by this wave
+        LV<uint64_t> upper;   // the last row of the band above, 64 pixels at a time (lane l: pixel t0 + l): lane 0's upper neighbour comes out of it by a lane
+        LFOR(l) upper[l] = 0;   // read -- one coalesced, cache-bypassing fetch per 64 steps instead of one per step, which was what a step waited for
         for (uint32_t t = 0; t < npx + 63; t++) {
+            if (y0 > ys && (t & 63u) == 0) LFOR(l) {
+                const uint32_t i = t + uint32_t(l);
+                uint64_t b = 0;
+                if (i < npx) for (uint32_t k = 0; k < bpp; k++) b |= uint64_t(coherent_load(dst + uint64_t(y0 - 1) * W + uint64_t(i) * bpp + k)) << (8 * k);
+                upper[l] = b;
+            }
+            uint64_t up0 = 0;
+            if (y0 > ys) {
+#ifdef CSH_EMUL
+                up0 = upper.v[t & 63u];
+#else
+                up0 = uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(upper.v)), int(t & 63u)))) | (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(upper.v >> 32)), int(t & 63u)))) << 32);
+#endif
+            }
             // what the row above produced one step ago is the pixel above this lane's current pixel
             LV<uint64_t> up;
 #ifdef CSH_EMUL
@@ -658,7 +674,7 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
                 const uint32_t y = y0 + uint32_t(l), i = t - uint32_t(l);
                 if (y < ye && t >= uint32_t(l) && i < npx) {
                     uint64_t b = up[l];
-                    if (l == 0 && y0 > ys) { b = 0; for (uint32_t k = 0; k < bpp; k++) b |= uint64_t(coherent_load(dst + uint64_t(y - 1) * W + uint64_t(i) * bpp + k)) << (8 * k); }
+                    if (l == 0 && y0 > ys) b = up0;   // (lane 0 is at pixel t)
                     const uint8_t *f = src + uint64_t(y) * (W + 1) + 1 + uint64_t(i) * bpp;
                     uint64_t o = 0;
                     for (uint32_t k = 0; k < bpp; k++) {

@@ -27,6 +27,21 @@ __device__ __forceinline__ static uint64_t load64u(const uint8_t *p) {
     return *reinterpret_cast<const uint64_t *>(p);   // unaligned global loads are legal on gfx9
 #endif
 }
+__device__ __forceinline__ static uint32_t load32u(const uint8_t *p) {
+#ifdef CSH_EMUL
+    uint32_t v; memcpy(&v, p, 4); return v;
+#else
+    return *reinterpret_cast<const uint32_t *>(p);
+#endif
+}
+// bytes `shift` .. `shift` + 3 of the eight bytes lo, hi (v_alignbyte_b32)
+__device__ __forceinline__ static uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t shift) {
+#ifdef CSH_EMUL
+    return uint32_t(((uint64_t(hi) << 32) | lo) >> (8u * shift));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, shift);
+#endif
+}
 __device__ __forceinline__ static uint32_t lz_hash(uint32_t v) { return (v * 0x9E3779B1u) >> (32 - CSP_HASH_BITS); }
 __device__ __forceinline__ static uint32_t ctz64(uint64_t x) { return uint32_t(__ffsll((unsigned long long)x) - 1); }
 // common prefix of data[p..] and data[p-d..], at most maxlen, given that the first `from` bytes are known to agree.  32 bytes per round trip (eight loads
@@ -128,33 +143,26 @@ __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t st
                 const uint32_t maxlen = end - p < 258 ? uint32_t(end - p) : 258u;
                 const uint64_t hi = load64u(data + p);
                 lit[l] = uint32_t(hi & 255u);
-                // the six fixed distances against the 8 bytes in front of p
+                // First, cheaply: does ANY candidate -- the six fixed distances, the bucket's entries -- agree with p in its first three bytes?  Nothing shorter is a
+                // match, and on photographic data hardly a position has one (the bucket's entries are mostly other strings with the same hash): 32-bit compares on
+                // the bytes at hand decide it, and the judging below -- 64-bit compares, lengths, the longest-wins rules -- runs for the lanes that need it only
                 uint32_t bl = 0, bd = 0;
-                {
-                    const uint64_t lo = load64u(data + p - 8);   // bytes p-8..p-1; in front of the data (p < 8) whatever the pool holds there: guarded by d <= p
-                    const uint32_t cap8 = maxlen < 8 ? maxlen : 8u;
-                    uint32_t l8best = 0, dbest = 0;
-                    CSH_UNROLL
-                    for (int k = 0; k < 6; k++) {
-                        const uint32_t d = k < 4 ? uint32_t(k + 1) : (k == 4 ? 6u : 8u);
-                        if (uint64_t(d) > p) continue;
-                        const uint64_t shifted = d == 8 ? lo : ((hi << (8 * d)) | (lo >> (64 - 8 * d)));   // bytes p-d .. p-d+7
-                        const uint64_t x = hi ^ shifted;
-                        uint32_t l8 = x ? ctz64(x) >> 3 : 8u;
-                        if (l8 > cap8) l8 = cap8;
-                        if (l8 > l8best) { l8best = l8; dbest = d; }
-                    }
-                    if (l8best) { bl = l8best; bd = dbest; if (l8best == 8 && maxlen > 8) bl = lz_lcp(data, p, dbest, maxlen, 8); }
+                const uint64_t lo = load64u(data + p - 8);   // bytes p-8..p-1; in front of the data (p < 8) whatever the pool holds there: guarded by d <= p
+                const uint32_t h0 = uint32_t(hi), l0 = uint32_t(lo), l1 = uint32_t(lo >> 32);
+                bool any3 = false;
+                CSH_UNROLL
+                for (int k = 0; k < 6; k++) {
+                    const uint32_t d = k < 4 ? uint32_t(k + 1) : (k == 4 ? 6u : 8u);
+                    if (uint64_t(d) > p) continue;
+                    const uint32_t s4 = d == 8 ? l0 : d == 4 ? l1 : d == 6 ? align_bytes(l1, l0, 2) : align_bytes(h0, l1, 4u - d);   // bytes p-d .. p-d+3
+                    any3 |= ((h0 ^ s4) & 0xFFFFFFu) == 0u;
                 }
+                uint32_t dw[CSP_WAYS];
+                int nw = 0;
                 if (p + 4 <= total) {
                     hashable[l] = 1;
-                    hash[l] = lz_hash(uint32_t(hi));
+                    hash[l] = lz_hash(h0);
                     const uint64_t b = L.bucket[hash[l]];
-                    // the candidates' first eight bytes are fetched together (independent loads, one round trip to the L2 instead of one
-                    // per candidate); the order of evaluation, and with it every tie, stays the serial statement's
-                    uint32_t dw[CSP_WAYS];
-                    uint64_t xw[CSP_WAYS];
-                    int nw = 0;
                     for (int w = 0; w < int(CSP_WAYS); w++) {
                         const uint32_t r = uint32_t(b >> (16 * w)) & 0xFFFFu;
                         if (r == 0xFFFFu) break;
@@ -162,6 +170,31 @@ __device__ static void lz_chunk(const uint8_t *data, uint64_t total, uint64_t st
                         if (d > 32768u) break;
                         dw[nw++] = d;
                     }
+                    uint32_t cw[CSP_WAYS];
+                    CSH_UNROLL
+                    for (int w = 0; w < int(CSP_WAYS); w++) cw[w] = w < nw ? load32u(data + p - dw[w]) : ~h0;   // (fetched together: one round trip)
+                    CSH_UNROLL
+                    for (int w = 0; w < int(CSP_WAYS); w++) any3 |= ((h0 ^ cw[w]) & 0xFFFFFFu) == 0u;
+                }
+                if (any3 && maxlen >= 3) {
+                    // the six fixed distances against the 8 bytes in front of p
+                    {
+                        const uint32_t cap8 = maxlen < 8 ? maxlen : 8u;
+                        uint32_t l8best = 0, dbest = 0;
+                        CSH_UNROLL
+                        for (int k = 0; k < 6; k++) {
+                            const uint32_t d = k < 4 ? uint32_t(k + 1) : (k == 4 ? 6u : 8u);
+                            if (uint64_t(d) > p) continue;
+                            const uint64_t shifted = d == 8 ? lo : ((hi << (8 * d)) | (lo >> (64 - 8 * d)));   // bytes p-d .. p-d+7
+                            const uint64_t x = hi ^ shifted;
+                            uint32_t l8 = x ? ctz64(x) >> 3 : 8u;
+                            if (l8 > cap8) l8 = cap8;
+                            if (l8 > l8best) { l8best = l8; dbest = d; }
+                        }
+                        if (l8best) { bl = l8best; bd = dbest; if (l8best == 8 && maxlen > 8) bl = lz_lcp(data, p, dbest, maxlen, 8); }
+                    }
+                    // the bucket's candidates: their first eight bytes fetched together; the order of evaluation, and with it every tie, stays the serial statement's
+                    uint64_t xw[CSP_WAYS];
                     CSH_UNROLL
                     for (int w = 0; w < int(CSP_WAYS); w++) xw[w] = w < nw ? hi ^ load64u(data + p - dw[w]) : 0ull;
                     CSH_UNROLL
