@@ -608,6 +608,13 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS * HUFF_WAVES) k_png_lz77(cons
 // ---- reconstruction filters: pixel (i, y) needs (i-1, y), (i, y-1), (i-1, y-1) -> an anti-diagonal front.  One wave per
 // image; its lanes are 64 consecutive rows, lane l one pixel behind lane l-1, so the pixel above arrives by a lane
 // shift from the row's upper neighbour (only lane 0 reads the band above from memory).
+__device__ __forceinline__ static uint64_t load64u_(const uint8_t *p) {
+#ifdef CSH_EMUL
+    uint64_t v; memcpy(&v, p, 8); return v;
+#else
+    return *reinterpret_cast<const uint64_t *>(p);   // unaligned global loads are legal on gfx9
+#endif
+}
 __device__ __forceinline__ static int paeth(int a, int b, int c) {
     const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
@@ -638,8 +645,8 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
     bool bad = false;
     for (uint32_t y0 = ys; y0 < ye; y0 += 64) {
         LV<uint32_t> ft;
-        LV<uint64_t> a, c, mine;   // left, upper-left, this row's latest pixel (bytes packed little-endian)
-        LFOR(l) { const uint32_t y = y0 + uint32_t(l); ft[l] = y < ye ? src[uint64_t(y) * (W + 1)] : 0u; a[l] = 0; c[l] = 0; mine[l] = 0; }
+        LV<uint64_t> a, c, mine, ahead;   // left, upper-left, this row's latest pixel (bytes packed little-endian); the next pixel's filtered bytes
+        LFOR(l) { const uint32_t y = y0 + uint32_t(l); ft[l] = y < ye ? src[uint64_t(y) * (W + 1)] : 0u; a[l] = 0; c[l] = 0; mine[l] = 0; ahead[l] = 0; }
         if (lballot([&](int l) { return ft[l] > 4u; })) { bad = true; break; }
         if (y0 > ys) CSP_MEM_FENCE();   // the band above was written by this wave
         LV<uint64_t> upper;   // the last row of the band above, 64 pixels at a time (lane l: pixel t0 + l): lane 0's upper neighbour comes out of it by a lane
@@ -675,11 +682,15 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_unfilter(const PngPass
                 if (y < ye && t >= uint32_t(l) && i < npx) {
                     uint64_t b = up[l];
                     if (l == 0 && y0 > ys) b = up0;   // (lane 0 is at pixel t)
+                    // the pixel's filtered bytes: one unaligned 8-byte load (bpp <= 8; what it takes past the row lies inside the buffer's slack), asked for a step
+                    // ahead -- the lanes of a wave read 64 different rows, a line each, and a step used to wait for three such byte loads
                     const uint8_t *f = src + uint64_t(y) * (W + 1) + 1 + uint64_t(i) * bpp;
+                    const uint64_t f8 = i == 0 ? load64u_(f) : ahead[l];
+                    if (i + 1 < npx) ahead[l] = load64u_(f + bpp);
                     uint64_t o = 0;
                     for (uint32_t k = 0; k < bpp; k++) {
                         const int av = int((a[l] >> (8 * k)) & 255u), bv = int((b >> (8 * k)) & 255u), cv = int((c[l] >> (8 * k)) & 255u);
-                        int v = f[k];
+                        int v = int((f8 >> (8 * k)) & 255u);
                         switch (ft[l]) {
                         case 1: v += av; break;
                         case 2: v += bv; break;
