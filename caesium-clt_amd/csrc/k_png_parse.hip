@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(CSP_DEEP_THREADS) k_png_deep_hist(DeflateCtx c
         const uint8_t *data = c.streams + im.stream_off + uint64_t(slot) * im.stream_stride;
         const uint64_t start = uint64_t(ci) * CSP_CHUNK, end = start + CSP_CHUNK < im.raw_len ? start + CSP_CHUNK : im.raw_len;
         NoSink none;
-        deep_chunk(data, im.raw_len, start, end, S, scratch, c.deep_iters, false, none, c.deep_debug);
+        deep_chunk(data, im.raw_len, start, end, S, scratch, c.deep_iters, false, none);
         if (CSP_WAVE0) {
             // the parse's counts replace the greedy ones only where they promise a smaller block (segment ends cut long runs: a flat chunk can lose)
             const uint64_t est_greedy = deep_estimate([&](uint32_t i) { return rec.freq[i]; }), est_deep = deep_estimate([&](uint32_t i) { return i == 256 ? 1u : S.hist[i]; });

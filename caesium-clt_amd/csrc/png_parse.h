@@ -130,7 +130,7 @@ struct NoSink { __device__ __forceinline__ void tile(uint64_t, uint32_t, uint64_
 
 // data[start, end): a chunk of a stream of `total` bytes.  S.hist holds the last pass's counts on exit.  want_tokens: the sink sees the final parse.
 template <class Sink>
-__device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, DeepLds &S, uint8_t *scratch, int iters, bool want_tokens, Sink &sink, int dbg = 0) {
+__device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t start, uint64_t end, DeepLds &S, uint8_t *scratch, int iters, bool want_tokens, Sink &sink) {
     unsigned long long *cand = reinterpret_cast<unsigned long long *>(scratch + CSP_DEEP_CAND_OFF);   // [i][lane]: len0 | d0 << 9 | len1 << 25 | d1 << 34 | byte << 50
     uint16_t *choice = reinterpret_cast<uint16_t *>(scratch + CSP_DEEP_CHOICE_OFF);
     uint32_t *costs = reinterpret_cast<uint32_t *>(scratch + CSP_DEEP_COST_OFF);
@@ -141,7 +141,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
     CSP_WG_SYNC();
     {
         const uint64_t seed0 = start > 32768 ? start - 32768 : 0;
-        for (uint64_t t0 = seed0; t0 < start && !(dbg & 1); t0 += CSP_DEEP_TILE) {
+        for (uint64_t t0 = seed0; t0 < start; t0 += CSP_DEEP_TILE) {
             LV4 h4, ok4, h8, ok8, rel;
             LFOR(l) {
                 UFOR(u) {
@@ -176,7 +176,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
             UFOR(u) {
                 const uint64_t p = t0 + uint32_t(u * 64 + l);
                 nw[UIX(u)] = 0;
-                if (in[UIX(u)] && p + 4 <= total && !(dbg & 8)) {
+                if (in[UIX(u)] && p + 4 <= total) {
                     ok4[l][UIX(u)] = 1; h4[l][UIX(u)] = lz_hash4(uint32_t(hi[UIX(u)]));
                     const uint64_t b = S.bucket[h4[l][UIX(u)]];
                     for (int w = 0; w < int(CSP_WAYS); w++) {
@@ -187,7 +187,7 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                         dw[UIX(u)][nw[UIX(u)]++] = d;
                     }
                 }
-                if (in[UIX(u)] && p + 8 <= total && !(dbg & 8)) {
+                if (in[UIX(u)] && p + 8 <= total) {
                     ok8[l][UIX(u)] = 1; h8[l][UIX(u)] = lz_hash8(hi[UIX(u)]);
                     const uint64_t b0 = S.bucket8[0][h8[l][UIX(u)]], b1 = S.bucket8[1][h8[l][UIX(u)]];
                     for (int w = 0; w < int(CSP_WAYS8); w++) {
@@ -204,7 +204,6 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
                 CSH_UNROLL
                 for (int w = 0; w < NW; w++) xw[UIX(u)][w] = w < nw[UIX(u)] ? hi[UIX(u)] ^ load64u(data + p - dw[UIX(u)][w]) : 0ull;
             }
-            if (dbg & 2) { UFOR(u) nw[UIX(u)] = 0; }
             // stage 3: judge them.  c0: the nearest with >= 3 bytes; c1: the longest (ties: the nearer) -- whatever the order of the offers
             UFOR(u) if (in[UIX(u)]) {
                 const uint64_t p = t0 + uint32_t(u * 64 + l);
@@ -278,7 +277,6 @@ __device__ static void deep_chunk(const uint8_t *data, uint64_t total, uint64_t 
         else for (uint64_t q = p; q < end; q++) atomicAdd(&S.hist[data[q]], 1u);
     }
     CSP_WAVE_SYNC();
-    if (dbg & 4) iters = 0;
     for (int it = 0; it < iters; it++) {
         const bool final_pass = it + 1 == iters;
         {

@@ -788,7 +788,7 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
         const uint64_t items = uint64_t(b->total_chunks) * uint32_t(b->plan.ntrials);
         b->deep_slots = uint32_t(std::min<uint64_t>(items, 768));
         if (b->deep_slots && (b->d_deep.alloc(size_t(b->deep_slots) * CSP_DEEP_SCRATCH) || b->d_deep_queue.alloc(2))) return CS_ERR_NO_DEVICE;
-        d.deep_scratch = b->d_deep.p; d.deep_queue = b->d_deep_queue.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters; d.deep_debug = getenv("CSH_DEEP_DEBUG") ? atoi(getenv("CSH_DEEP_DEBUG")) : 0;
+        d.deep_scratch = b->d_deep.p; d.deep_queue = b->d_deep_queue.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters;
     }
     mark(); launch_png_hist(st, d);
     mark(); launch_png_codes(st, d);
