@@ -54,7 +54,7 @@ typedef struct {
     bool jpeg_preserve_icc;
     uint32_t png_quality;
     uint32_t png_optimization_level;
-    bool png_force_zopfli;
+    bool png_force_zopfli;            /* --zopfli (with png_optimize): fifteen passes of the DEFLATE coder's cost model instead of five; refused until round 6 */
     bool png_optimize;
     uint32_t gif_quality;
     uint32_t webp_quality;
