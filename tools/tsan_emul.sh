@@ -3,7 +3,7 @@
 # at once (the boundary is called from several threads: the reference's rayon workers, the CLI's two workers per device).  CPU only.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/caesium-clt_amd/csrc; O=${TMPDIR:-/tmp}/csh_tsan; mkdir -p $O
-SRC="k_decode.hip k_decode_par.hip k_decode_prog.hip k_decode_refine.hip k_aclist.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_webp.hip k_webp_dec.hip k_vp8l_enc.hip pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp vp8l_encode.cpp"
+SRC="k_decode.hip k_decode_par.hip k_decode_prog.hip k_decode_refine.hip k_aclist.hip k_pixel.hip k_resize.hip k_png_resize.hip k_entropy.hip k_trellis.hip k_assemble.hip k_png_inflate.hip k_png_filter.hip k_png_deflate.hip k_png_parse.hip k_webp.hip k_vp8enc.hip k_webp_dec.hip k_vp8l_enc.hip pipeline.cpp jpeg_host.cpp capi.cpp png_pipeline.cpp webp_decode.cpp vp8l_encode.cpp"
 (cd $C && g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -DCSH_EMUL -fsanitize=thread -Wno-unknown-pragmas -Wno-attributes $(for f in $SRC; do echo -x c++ $f; done) -o $O/libcaesium_emul.so -lpthread)
 cat > $O/run.py <<PY
 import sys, threading
