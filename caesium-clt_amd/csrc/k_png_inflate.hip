@@ -5,7 +5,7 @@
 // stream).  Two things make a stream slow when it is walked token by token: waiting for every match copy before the next symbol, and
 // the walk itself being one dependent chain.  Both are taken apart:
 //   k_png_huff   walks the codes and nothing else, speculatively: where a prefix-coded stream is entered matters only for a few tokens,
-//                so every lane of the workgroup's four waves walks its own 288-bit stretch of the block from a guessed entry, then from
+//                so every lane of the workgroup's four waves walks its own 352-bit stretch of the block from a guessed entry, then from
 //                where its left neighbour's walk really left off, until no entry moves; prefix sums of what the walks produce place
 //                every literal (stored directly: its position is known) and every match (an 8-byte record: position, length,
 //                distance).  The first wave also parses the block headers and builds the tables (every lane decodes its own root
@@ -16,7 +16,7 @@
 //                not 258 steps -- then gathered.  No step waits for a single copy.
 // Adam7 inputs: the stream holds seven reduced images; each is reconstructed as a job of its own, then k_png_deinterlace
 // gathers the pixels into place (the output is never interlaced).
-// Codes longer than the root tables (13 / 10 bits) resume the canonical walk behind the root width (rare symbols by construction).
+// Codes longer than the root tables (11 / 10 bits) resume the canonical walk behind the root width (rare symbols by construction).
 #include "png_kernels.h"
 #include "png_wave.h"
 
@@ -26,10 +26,25 @@ namespace csp {
 enum { HUFF_WAVES = 1 };   // the emulation plays one wave: the same code, the hand-overs between waves degenerate
 #define HUFF_BARRIER() ((void)0)
 #else
-enum { HUFF_WAVES = 4 };
+#ifndef CSP_HUFF_WAVES
+#define CSP_HUFF_WAVES 4
+#endif
+enum { HUFF_WAVES = CSP_HUFF_WAVES };
 #define HUFF_BARRIER() __syncthreads()
 #endif
-enum { LROOT = 13, DROOT = 10, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = 288, HUFF_PRE = 192, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
+#ifndef CSP_HUFF_SUB
+#define CSP_HUFF_SUB 352   // bits of the block a lane walks per round.  Swept on the MI355X in round 6 (64 4K files, k_png_huff + k_png_lz77): 224: 458 ms, 288: 416, 320: 401, 352: 361, 384: ~360, 416: 377, 480: 409, 544: 441
+#endif
+#ifndef CSP_HUFF_PRE
+#define CSP_HUFF_PRE 192
+#endif
+#ifndef CSP_LROOT
+#define CSP_LROOT 11      // root table of the literal / length code: 13 bits 361 ms, 12: 330, 11: 315, 10: 312, 9: 318 (at 352 bits a lane) -- a smaller table is built faster for every block, longer codes resume the canonical walk
+#endif
+#ifndef CSP_DROOT
+#define CSP_DROOT 10
+#endif
+enum { LROOT = CSP_LROOT, DROOT = CSP_DROOT, LZ_RING = 65536, LZ_PIECE = 16384, HUFF_SUB = CSP_HUFF_SUB, HUFF_PRE = CSP_HUFF_PRE, HUFF_LANES = 64 * HUFF_WAVES, HUFF_STAGE_WORDS = HUFF_SUB * HUFF_LANES / 32 + 8 };   // k_png_lz77: 64 KiB ring = the piece being resolved + 48 KiB behind it (a match reaches back 32 KiB)
 
 struct InflateLds {
     uint32_t lcount[16], dcount[16], ccount[16], offs[16];
