@@ -670,7 +670,10 @@ __global__ void __launch_bounds__(256) k_png_filter5(FilterCtx c) {
 // two-halves path below), two to a 32-bit LDS word -- 128 KiB, the whole key space in one pass -- and are read back by exchanging the WORD with zero: whoever
 // gets there first accounts for both of its counters and leaves the table clean for the next filter.  Every filter has accumulators of its own, written
 // out in one last step.  (Round 6: 17 steps a row instead of 36 -- the steps are short, eleven bytes per lane for a 4K row, and a step is a barrier.)
-enum { SCORE_THREADS = 1024 };
+#ifndef CSP_SCORE_THREADS
+#define CSP_SCORE_THREADS 1024
+#endif
+enum { SCORE_THREADS = CSP_SCORE_THREADS };
 struct ScoreLds {
     uint32_t pair[32768];
     uint32_t hist[256];
