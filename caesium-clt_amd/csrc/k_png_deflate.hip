@@ -62,8 +62,14 @@ __global__ void __launch_bounds__(CSP_WAVE_THREADS) k_png_hist(DeflateCtx c) {
 }
 
 // ------------------------------------------------------------------------------------------------ codes
-__global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c, int only_deep) {   // only_deep: the records k_png_deep_hist has rewritten
-    const uint32_t bc = blockIdx.x * blockDim.x + threadIdx.x, trial = blockIdx.y;
+__global__ void __launch_bounds__(64) k_png_codes(DeflateCtx c, int only_deep) {   // only_deep: the records k_png_deep_hist has rewritten, from the list it left
+    uint32_t bc = blockIdx.x * blockDim.x + threadIdx.x, trial = blockIdx.y;
+    if (only_deep) {   // (a lane per LISTED record: lanes that skipped unlisted records wave by wave paid for the listed ones' code construction all the same)
+        const uint32_t i = bc + trial * gridDim.x * blockDim.x;
+        if (i >= c.deep_queue[2]) return;
+        const uint32_t item = c.deep_list[i];
+        trial = item / c.total_chunks; bc = item % c.total_chunks;
+    }
     if (bc >= c.total_chunks) return;
     const uint32_t image = c.chunk_image[bc];
     if (c.status[image]) return;

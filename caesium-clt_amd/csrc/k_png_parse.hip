@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(CSP_DEEP_THREADS) k_png_deep_hist(DeflateCtx c
                     }
                 }
                 const uint64_t extra = lsum(e);
-                LFOR(l) if (l == 0) rec.extra_bits = uint32_t(extra);
+                LFOR(l) if (l == 0) { rec.extra_bits = uint32_t(extra); c.deep_list[atomicAdd(&c.deep_queue[2], 1u)] = item; }   // (its codes are made again: k_png_codes over this list)
             } else
                 LFOR(l) if (l == 0) rec.deep = 0;
         }
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(CSP_DEEP_THREADS) k_png_deep_emit(DeflateCtx c
 // behind the greedy parse's hist / codes / choose: the parse over the live trials' marked chunks, their codes again, the winner again
 void launch_png_deep(hipStream_t st, const DeflateCtx &c) {
     if (c.deep_iters <= 0 || !c.deep_slots) return;
-    (void)hipMemsetAsync(c.deep_queue, 0, 2 * sizeof(uint32_t), st);
+    (void)hipMemsetAsync(c.deep_queue, 0, 4 * sizeof(uint32_t), st);
     CSH_LAUNCH(k_png_deep_hist, dim3(c.deep_slots), dim3(CSP_DEEP_THREADS), st, c);
     launch_png_codes(st, c, 1);
     launch_png_choose(st, c);

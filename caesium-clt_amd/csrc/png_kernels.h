@@ -110,7 +110,8 @@ struct DeflateCtx {
     uint32_t *status;
     uint8_t *deep_scratch;        // [deep_slots][CSP_DEEP_SCRATCH]: one area per workgroup of the min-cost-path kernels (png_parse.h)
     uint32_t deep_slots;
-    uint32_t *deep_queue;         // [2] work counters of the two kernels (zeroed by launch_png_deep_hist)
+    uint32_t *deep_queue;         // [4] work counters of the two kernels, the length of deep_list (zeroed by launch_png_deep)
+    uint32_t *deep_list;          // [total_chunks * ntrials] the (trial, chunk) items whose counts the parse replaced
     int deep_iters;               // passes of that parse over the chunks that qualify: CSP_DEEP_ITERS, CSP_DEEP_ITERS_ZOPFLI with png.force_zopfli
 };
 void launch_png_hist(hipStream_t st, const DeflateCtx &c);     // tokenizer pass 1: symbol counts of every (trial, chunk)

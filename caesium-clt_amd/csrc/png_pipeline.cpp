@@ -198,7 +198,7 @@ struct csp_batch {
     DevBuf<PngChunk> d_chunks;
     DevBuf<uint8_t> d_deep;         // the min-cost-path kernels' scratch areas (png_parse.h)
     uint32_t deep_slots = 0;
-    DevBuf<uint32_t> d_deep_queue;
+    DevBuf<uint32_t> d_deep_queue, d_deep_list;
     int deep_iters = CSP_DEEP_ITERS;   // png.force_zopfli: CSP_DEEP_ITERS_ZOPFLI
     hipEvent_t ev[CSP_NKERNELS + 1]{};
     bool have_events = false, ran = false;
@@ -787,8 +787,8 @@ extern "C" int csp_batch_run(csp_batch *b, csp_timing *t) {
     {   // one scratch area per workgroup the device holds at the parse kernels' LDS footprint (three per CU), no more than there are items
         const uint64_t items = uint64_t(b->total_chunks) * uint32_t(b->plan.ntrials);
         b->deep_slots = uint32_t(std::min<uint64_t>(items, 768));
-        if (b->deep_slots && (b->d_deep.alloc(size_t(b->deep_slots) * CSP_DEEP_SCRATCH) || b->d_deep_queue.alloc(2))) return CS_ERR_NO_DEVICE;
-        d.deep_scratch = b->d_deep.p; d.deep_queue = b->d_deep_queue.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters;
+        if (b->deep_slots && (b->d_deep.alloc(size_t(b->deep_slots) * CSP_DEEP_SCRATCH) || b->d_deep_queue.alloc(4) || b->d_deep_list.alloc(size_t(items) + 1))) return CS_ERR_NO_DEVICE;
+        d.deep_scratch = b->d_deep.p; d.deep_queue = b->d_deep_queue.p; d.deep_list = b->d_deep_list.p; d.deep_slots = b->deep_slots; d.deep_iters = b->deep_iters;
     }
     mark(); launch_png_hist(st, d);
     mark(); launch_png_codes(st, d);
