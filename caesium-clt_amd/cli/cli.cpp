@@ -20,6 +20,7 @@
 #include <mutex>
 #include <unordered_set>
 #include <thread>
+#include <tuple>
 
 #include "../../include/caesium_hip.h"
 
@@ -677,9 +678,9 @@ int run(const Options &o) {
     const bool same_device = getenv("CSH_CLI_SAME_DEVICE") != nullptr;
     const int ndev = o.dry_run ? 1 : (same_device ? std::max(1, o.gpus) : std::max(1, std::min(o.gpus, std::max(1, csh_device_count()))));
     // host threads per device, each with its own batches: while one batch is in its kernels the others are being parsed and uploaded or fetched and
-    // written (separate streams; the boundary call is thread-safe).  A cold process pays for every thread's pools once (~55 ms): two for a short run
-    // (2048 x 1080p: 0.75-0.83 s with 2, 0.81-0.85 s with 4), four for a long one (10 000 files: 1.86-2.05 s with 2, 1.64-1.67 s with 4)
-    const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : (files.size() >= 4096 ? 4 : 2);
+    // written (separate streams; the boundary call is thread-safe).  A cold process pays for every thread's pools once (~55 ms): three for a short run
+    // (2048 x 1080p: 0.75-0.83 s with 2, 0.78-0.84 with 3, 0.81-0.85 s with 4), four for a long one (10 000 files: 1.86-2.05 s with 2, 1.64-1.67 s with 4)
+    const size_t per_dev = getenv("CSH_CLI_WORKERS") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_WORKERS")))) : (files.size() >= 4096 ? 4 : 3);   // (three: a tree of JPEG, PNG and WebP files is three batches of different kinds, the PNG and WebP ones latency-bound -- configs[4]: 2.1 s with two workers)
     const size_t nworkers = size_t(ndev) * per_dev;
     struct QueuedBatch { size_t window; std::vector<size_t> idx; };
     std::mutex qmu;
@@ -752,8 +753,17 @@ int run(const Options &o) {
         const size_t w0 = windows[wi].first, w1 = windows[wi].second;
         if (read_ahead) ahead.get(); else read_window(w0, w1);
         if (!o.dry_run) {
-            std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> groups;   // resize target -> job indices (the only per-file parameter)
-            for (size_t i = w0; i < w1; i++) if (jobs[i].engine) groups[{jobs[i].params.width, jobs[i].params.height}].push_back(i);
+            // resize target (the only per-file parameter) and file type -> job indices.  The type is part of the key since round 6: a PNG or WebP batch pays a
+            // latency that does not depend on its size (one workgroup per zlib stream / per VP8 frame: 0.3 / 0.8 s), so a tree's PNG and WebP files go to
+            // the device in as few batches as the window allows instead of being cut wherever 128 files of the sorted tree end (configs[4]'s 96 + 96 + 96
+            // files were three mixed batches, the WebP latency paid twice)
+            auto kind_of = [](const std::vector<uint8_t> &d) -> uint32_t {
+                if (d.size() >= 12 && !memcmp(d.data(), "RIFF", 4) && !memcmp(d.data() + 8, "WEBP", 4)) return 2;
+                if (d.size() >= 8 && !memcmp(d.data(), "\x89PNG", 4)) return 1;
+                return 0;
+            };
+            std::map<std::tuple<uint32_t, uint32_t, uint32_t>, std::vector<size_t>> groups;
+            for (size_t i = w0; i < w1; i++) if (jobs[i].engine) groups[{kind_of(jobs[i].data), jobs[i].params.width, jobs[i].params.height}].push_back(i);
             std::vector<QueuedBatch> batches;
             // files per device batch (and never more than one device batch takes by bytes / declared pixels: cs_batch_extent).  A cold process pays for the
             // device pools it allocates (~25 MB per 1080p file) before the first kernel runs, and later batches reuse the first ones' pools: smaller
@@ -762,10 +772,11 @@ int run(const Options &o) {
             // pictures share the device; its batches are as large as the window allows)
             const size_t kBatch = getenv("CSH_CLI_BATCH") ? std::max<size_t>(1, size_t(atol(getenv("CSH_CLI_BATCH")))) : (o.format == Format::Webp ? 1024 : 128);   // (round 5: 10 000 files 2.11-2.13 s at 128, 2.23-2.37 s at 256 -- half the pools a cold process has to map before its first kernel)
             for (auto &g : groups) {
+                const size_t kGroupBatch = (std::get<0>(g.first) != 0 && !getenv("CSH_CLI_BATCH")) ? 1024 : kBatch;   // PNG / WebP inputs: latency-bound rows, the library cuts by memory itself
                 std::vector<CByteArray> gin(g.second.size());
                 for (size_t k = 0; k < gin.size(); k++) { gin[k].data = jobs[g.second[k]].data.data(); gin[k].length = jobs[g.second[k]].data.size(); }
                 for (size_t k = 0, n = 0; k < g.second.size(); k += n) {
-                    n = std::max<size_t>(1, cs_batch_extent(gin.data() + k, std::min(kBatch, g.second.size() - k)));
+                    n = std::max<size_t>(1, cs_batch_extent(gin.data() + k, std::min(kGroupBatch, g.second.size() - k)));
                     batches.push_back(QueuedBatch{wi, std::vector<size_t>(g.second.begin() + k, g.second.begin() + k + n)});
                 }
             }
