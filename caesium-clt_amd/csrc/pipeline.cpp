@@ -1691,8 +1691,10 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         slot = 9;   // the decode phase's kernel_ms slots stay empty
         for (int s = 1; s <= slot; s++) CSH_CHECK(hipEventRecord(ev[s], st));
     } else {
-    // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients)
-    CSH_CHECK(hipMemsetAsync(b->d_coef.p, 0, size_t(b->ntiles_in) * CSH_TILE_I16 * sizeof(int16_t), st));
+    // ---- phase 0: entropy decode (tiles must start at zero: the decoder only writes non-zero coefficients).  Where the speculation pass runs, its workgroups
+    // clear the tiles on the side (k_dec_dense<0>); a memset in front of the phase otherwise (only progressive / irregular scans listed)
+    const bool zero_in_spec = !b->pscans.empty() && b->max_sub != 0;
+    if (!zero_in_spec) CSH_CHECK(hipMemsetAsync(b->d_coef.p, 0, size_t(b->ntiles_in) * CSH_TILE_I16 * sizeof(int16_t), st));
     if (b->d_status.zero(st) || b->d_overflow.zero(st)) return -1;
     CSH_CHECK(hipMemcpyAsync(b->d_need_seq.p, b->d_need_seq_init.p, size_t(nimg) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     MARK();
@@ -1711,11 +1713,16 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         da.list_out = b->d_relax_list[0].p; da.cnt_out = b->d_relax_cnt.p; da.blk_off = b->d_blk_off.p; da.imgs = b->d_imgs.p;
         da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p; da.cut_block = b->d_cut_block.p;
         CSH_CHECK(hipMemsetAsync(b->d_cut_block.p, 0xFF, b->d_cut_block.n * sizeof(uint32_t), st));
+        const uint64_t zero_all = uint64_t(b->ntiles_in) * CSH_TILE_I16 * sizeof(int16_t), zero_half = (zero_all / 2) & ~uint64_t(15);
+        if (zero_in_spec) { da.zero_ptr = reinterpret_cast<uint8_t *>(b->d_coef.p); da.zero_bytes = zero_half; }
         launch_dec_dense(st, 0, nps, b->max_sub, da);
+        da.zero_bytes = 0;
         MARK();
         if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
         if (nps && b->d_claim.zero(st)) return -1;
+        if (zero_in_spec) { da.zero_ptr = reinterpret_cast<uint8_t *>(b->d_coef.p) + zero_half; da.zero_bytes = zero_all - zero_half; }   // (the other half: k_dec_dense<1>)
         launch_dec_dense(st, 1, nps, b->max_sub, da);
+        da.zero_bytes = 0;
         MARK();
         // list rounds until the list is empty.  How many that takes depends on the data: stock tables at ordinary quality settle
         // in ~8 (the list shrinks by 60 % a round), 50 bytes per block in ~30, 85 bytes per block in more than a hundred (a
