@@ -481,18 +481,23 @@ __global__ void __launch_bounds__(256) k_dec_dense(DenseArgs a) {
     // their instructions, so their workgroups clear the tiles (half each) between them on the side, each BEHIND its own work (the stores of the early finishers run under the others' decoding) -- 12.85 GB
     // per 2048 files that a memset in front of the phase took 2.1 ms of HBM time for (round 6).  Every workgroup takes part, also those of scans that leave below.
     // (The emulation enters here once per phase: clearing twice is clearing.)
-    auto clear_share = [&]() __attribute__((always_inline)) {
-        if ((MODE != 0 && MODE != 1) || !a.zero_bytes) return;
+    auto clear_region = [&](uint8_t *ptr, uint64_t bytes) __attribute__((always_inline)) {
+        if (!bytes) return;
         const uint64_t nwg = uint64_t(gridDim.x) * gridDim.y, wg = uint64_t(blockIdx.y) * gridDim.x + blockIdx.x;
-        const uint64_t share = ((a.zero_bytes / 16 + nwg - 1) / nwg) * 16, z0 = wg * share, z1 = z0 + share < a.zero_bytes ? z0 + share : a.zero_bytes;
+        const uint64_t share = ((bytes / 16 + nwg - 1) / nwg) * 16, z0 = wg * share, z1 = z0 + share < bytes ? z0 + share : bytes;
         for (uint64_t off = z0 + uint64_t(threadIdx.x) * 16; off < z1; off += 256 * 16) {
 #ifdef CSH_EMUL
-            memset(a.zero_ptr + off, 0, 16);
+            memset(ptr + off, 0, 16);
 #else
-            __builtin_nontemporal_store(0ull, reinterpret_cast<unsigned long long *>(a.zero_ptr + off));
-            __builtin_nontemporal_store(0ull, reinterpret_cast<unsigned long long *>(a.zero_ptr + off + 8));
+            __builtin_nontemporal_store(0ull, reinterpret_cast<unsigned long long *>(ptr + off));
+            __builtin_nontemporal_store(0ull, reinterpret_cast<unsigned long long *>(ptr + off + 8));
 #endif
         }
+    };
+    auto clear_share = [&]() __attribute__((always_inline)) {
+        if (MODE != 0 && MODE != 1) return;
+        clear_region(a.zero_ptr, a.zero_bytes);
+        clear_region(a.zero2_ptr, a.zero2_bytes);
     };
     const ParScan &ps = a.pss[blockIdx.y];
     if (!par_decoded(ps.kind)) { clear_share(); return; }   // listed for the unstuffing pass only (uniform for the workgroup, before any barrier)

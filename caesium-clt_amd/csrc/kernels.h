@@ -30,7 +30,8 @@ struct DenseArgs {
     uint16_t *hyp; const uint32_t *scan_pending;                                       // label hypotheses (mode 3)
     const uint64_t *blk_off; const ImgDesc *imgs; int16_t *coef; int32_t *dcdiff; uint32_t *need_seq;  // write
     uint32_t *cut_block;   // per segment: first block that stays zero because the data ran out (0xFFFFFFFF: none), write pass -> k_dc_scatter
-    uint8_t *zero_ptr; uint64_t zero_bytes;   // speculation pass (mode 0): a region its workgroups clear between them -- the coefficient tiles, which the write pass needs at zero (a multiple of 16 bytes)
+    uint8_t *zero_ptr; uint64_t zero_bytes;   // the store-less passes (modes 0, 1): a region their workgroups clear between them -- the coefficient tiles, which the write pass needs at zero (a multiple of 16 bytes)
+    uint8_t *zero2_ptr; uint64_t zero2_bytes; // a second one: the encoder's EOBRUN array (4 GB per 2048 files, cleared for every run)
 };
 void launch_dec_dense(hipStream_t st, int mode /*0 speculate, 1 relax, 2 write*/, int nps, uint32_t max_sub, const DenseArgs &a);
 void launch_dec_relax_list(hipStream_t st, const uint8_t *clean, const ParScan *ps, uint32_t total_sub, const void *huffs, int compact, uint64_t *state, uint32_t *nblk,

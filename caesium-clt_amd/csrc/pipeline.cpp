@@ -1658,6 +1658,7 @@ static int search_lists(csh_batch *b) {
 
 static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     hipStream_t st = b->stream;
+    bool eobrun_cleared = false;   // the decode phase's store-less passes have cleared the encoder's EOBRUN array on the side (k_dec_dense clear_share)
     const int nimg = b->nimg;
     uint64_t raw_chunks = (b->raw_bytes_cap + 63) / 64;
     if (b->d_raw.n != raw_chunks * 16) {
@@ -1714,15 +1715,21 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
         da.coef = b->d_coef.p; da.dcdiff = b->d_dcdiff.p; da.need_seq = b->d_need_seq.p; da.cut_block = b->d_cut_block.p;
         CSH_CHECK(hipMemsetAsync(b->d_cut_block.p, 0xFF, b->d_cut_block.n * sizeof(uint32_t), st));
         const uint64_t zero_all = uint64_t(b->ntiles_in) * CSH_TILE_I16 * sizeof(int16_t), zero_half = (zero_all / 2) & ~uint64_t(15);
-        if (zero_in_spec) { da.zero_ptr = reinterpret_cast<uint8_t *>(b->d_coef.p); da.zero_bytes = zero_half; }
+        const uint64_t eob_all = (uint64_t(b->d_eobrun.n) * sizeof(uint16_t)) & ~uint64_t(15), eob_half = (eob_all / 2) & ~uint64_t(15);   // (the last < 16 bytes: a memset below)
+        if (zero_in_spec) { da.zero_ptr = reinterpret_cast<uint8_t *>(b->d_coef.p); da.zero_bytes = zero_half; da.zero2_ptr = reinterpret_cast<uint8_t *>(b->d_eobrun.p); da.zero2_bytes = eob_half; }
         launch_dec_dense(st, 0, nps, b->max_sub, da);
-        da.zero_bytes = 0;
+        da.zero_bytes = 0; da.zero2_bytes = 0;
         MARK();
         if (nps) CSH_CHECK(hipMemsetAsync(b->d_relax_cnt.p, 0, b->d_relax_cnt.n * sizeof(uint32_t), st));
         if (nps && b->d_claim.zero(st)) return -1;
-        if (zero_in_spec) { da.zero_ptr = reinterpret_cast<uint8_t *>(b->d_coef.p) + zero_half; da.zero_bytes = zero_all - zero_half; }   // (the other half: k_dec_dense<1>)
+        if (zero_in_spec) {   // (the other halves: k_dec_dense<1>)
+            da.zero_ptr = reinterpret_cast<uint8_t *>(b->d_coef.p) + zero_half; da.zero_bytes = zero_all - zero_half;
+            da.zero2_ptr = reinterpret_cast<uint8_t *>(b->d_eobrun.p) + eob_half; da.zero2_bytes = eob_all - eob_half;
+            if (uint64_t(b->d_eobrun.n) * sizeof(uint16_t) > eob_all) CSH_CHECK(hipMemsetAsync(reinterpret_cast<uint8_t *>(b->d_eobrun.p) + eob_all, 0, uint64_t(b->d_eobrun.n) * sizeof(uint16_t) - eob_all, st));
+            eobrun_cleared = b->d_eobrun.n != 0;
+        }
         launch_dec_dense(st, 1, nps, b->max_sub, da);
-        da.zero_bytes = 0;
+        da.zero_bytes = 0; da.zero2_bytes = 0;
         MARK();
         // list rounds until the list is empty.  How many that takes depends on the data: stock tables at ordinary quality settle
         // in ~8 (the list shrinks by 60 % a round), 50 bytes per block in ~30, 85 bytes per block in more than a hundred (a
@@ -1797,7 +1804,7 @@ static int run_once(csh_batch *b, csh_timing *t, bool requant_only) {
     c.debug = getenv("CSH_DEBUG") ? uint32_t(atoi(getenv("CSH_DEBUG"))) : 0u;
     launch_reset_works(st, b->d_swork.p, c.nwork);
     if (b->d_nz_cursor.zero(st) || b->d_nz_chunk_cnt.zero(st)) return -1;
-    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || b->d_eobrun.zero(st) || b->d_tables.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st) || b->d_scan_pad.zero(st)) return -1;
+    if (b->d_symbits.zero(st) || b->d_eobbits.zero(st) || (!eobrun_cleared && b->d_eobrun.zero(st)) || b->d_tables.zero(st) || b->d_tok_cursor.zero(st) || b->d_slot_eobh.zero(st) || b->d_scan_pad.zero(st)) return -1;
 #ifdef CSH_EMUL
     if (b->d_raw.zero(st)) return -1;   // the emulation's packer ORs every word into the pool (no LDS window there)
 #else
