@@ -413,7 +413,8 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
     int ncand = (2 + 60 / int(Q.q[0])) | 1;
     ncand = ncand > 9 ? 9 : ncand;
     // what a DC difference of category 0..11 costs: its code length + that many raw bits, as the float the C source converts it to.  Every
-    // lane writes the (same) twelve values and reads them back itself: no barrier
+    // lane writes the (same) twelve values and reads them back itself: no barrier (the twelve as five-bit fields of a register pair, shifted
+    // out where they are needed: measured, no faster)
     CSH_SHARED float s_costs[64][13];   // (a column per lane: the lanes of a wave belong to different components now)
     float *s_cost = s_costs[threadIdx.x & 63u];
     for (int i = 0; i < 12; i++) s_cost[i] = float(i + int(w.table_dc < 0 ? kStdDcLen[w.comp ? 1 : 0][i] : c.tables[w.table_dc].size[i]));
@@ -447,40 +448,34 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
             float nacc[9];
             int ccur[9];
             float dist[9];
+            // levels past the ncand-th cost infinity: they never win a comparison (strict <, the first level of a block always stands), so the
+            // loops below run over all nine without a test per level (the tests were 200 branches on the lanes' masks)
             CSH_UNROLL
             for (int k = 0; k < 9; k++) {
-                nacc[k] = 0.0f; ccur[k] = 0; dist[k] = 0.0f;
-                if (k < ncand) {
-                    int cand = qval - half + k;
-                    cand = cand > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : cand;
-                    cand = cand < -TRELLIS_MAX_LEVEL ? -TRELLIS_MAX_LEVEL : cand;
-                    const int delta = cand * q - x;
-                    dist[k] = float(delta * delta) * lambda_dc;
-                    ccur[k] = sgn ? -cand : cand;
-                }
+                int cand = qval - half + k;
+                cand = cand > TRELLIS_MAX_LEVEL ? TRELLIS_MAX_LEVEL : cand;
+                cand = cand < -TRELLIS_MAX_LEVEL ? -TRELLIS_MAX_LEVEL : cand;
+                const int delta = cand * q - x;
+                dist[k] = k < ncand ? float(delta * delta) * lambda_dc : __builtin_inff();
+                ccur[k] = sgn ? -cand : cand;
             }
             if (bi == 0) {
                 CSH_UNROLL
-                for (int k = 0; k < 9; k++)
-                    if (k < ncand) { const int d = ccur[k] - last_dc, bits = tr_bitlen(unsigned(d < 0 ? -d : d)); nacc[k] = s_cost[bits] + dist[k]; }
+                for (int k = 0; k < 9; k++) { const int d = ccur[k] - last_dc, bits = tr_bitlen(unsigned(d < 0 ? -d : d)); nacc[k] = s_cost[bits] + dist[k]; }
             } else if (clamped || cprev_clamped) {
                 // the general statement: every pair of levels by itself
                 CSH_UNROLL
                 for (int k = 0; k < 9; k++) {
-                    if (k < ncand) {
-                        float bc = 0.0f;
-                        uint32_t bl = 0;
-                        CSH_UNROLL
-                        for (int l = 0; l < 9; l++) {
-                            if (l < ncand) {
-                                const int d = ccur[k] - cprev[l], bits = tr_bitlen(unsigned(d < 0 ? -d : d));
-                                const float cost = (s_cost[bits] + dist[k]) + acc[l];
-                                if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
-                            }
-                        }
-                        nacc[k] = bc;
-                        bt |= uint64_t(bl) << (4 * k);
+                    float bc = 0.0f;
+                    uint32_t bl = 0;
+                    CSH_UNROLL
+                    for (int l = 0; l < 9; l++) {
+                        const int d = ccur[k] - cprev[l], bits = tr_bitlen(unsigned(d < 0 ? -d : d));
+                        const float cost = (s_cost[bits] + dist[k]) + acc[l];
+                        if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
                     }
+                    nacc[k] = bc;
+                    bt |= uint64_t(bl) << (4 * k);
                 }
             } else {
                 // the levels of a block are consecutive integers, so the difference of level k to the previous block's level l depends on
@@ -493,20 +488,16 @@ __global__ void __launch_bounds__(64) k_trellis_dc(TrellisCtx c) {
                 for (int i = 0; i < 17; i++) { const int d = base + (i - 8); const int dd = same ? d : d + 8; cd[i] = s_cost[tr_bitlen(unsigned(dd < 0 ? -dd : dd))]; }   // same: index k - l + 8; opposite: index k + l
                 CSH_UNROLL
                 for (int k = 0; k < 9; k++) {
-                    if (k < ncand) {
-                        float bc = 0.0f;
-                        uint32_t bl = 0;
-                        CSH_UNROLL
-                        for (int l = 0; l < 9; l++) {
-                            if (l < ncand) {
-                                const float cbits = same ? cd[k - l + 8] : cd[k + l];
-                                const float cost = (cbits + dist[k]) + acc[l];
-                                if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
-                            }
-                        }
-                        nacc[k] = bc;
-                        bt |= uint64_t(bl) << (4 * k);
+                    float bc = 0.0f;
+                    uint32_t bl = 0;
+                    CSH_UNROLL
+                    for (int l = 0; l < 9; l++) {
+                        const float cbits = same ? cd[k - l + 8] : cd[k + l];
+                        const float cost = (cbits + dist[k]) + acc[l];
+                        if (l == 0 || cost < bc) { bc = cost; bl = uint32_t(l); }
                     }
+                    nacc[k] = bc;
+                    bt |= uint64_t(bl) << (4 * k);
                 }
             }
             CSH_UNROLL
